@@ -1,0 +1,103 @@
+"""Build libgraphtools_amd.so (HIP, gfx950 only) in-tree with hipcc.
+
+``python -m graphtools_amd._build`` or ``graphtools_amd._build.build()``.  Objects are
+compiled in parallel (one hipcc process per translation unit; the MFMA candidate kernel is
+compiled once per padded feature count) and linked into ``graphtools_amd/libgraphtools_amd.so``.
+Only out-of-date objects are rebuilt.
+"""
+import concurrent.futures
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "build")
+LIB = os.path.join(HERE, "libgraphtools_amd.so")
+ARCH = "gfx950"
+SELECT_DPS = (16, 32, 56, 64, 104, 128)  # keep in sync with GT_SEL_DP_LIST in gt_knn_select_dispatch.cpp
+
+COMMON_FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+                "-ffp-contract=off"]
+
+
+def _hipcc():
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found - the HIP toolchain is required to build graphtools_amd")
+    return exe
+
+
+def _units():
+    units = []
+    for name in ("gt_api.cpp", "gt_knn.cpp", "gt_knn_select_dispatch.cpp"):
+        units.append((name, name.replace(".cpp", ".o"), ["-x", "hip"]))
+    for name in ("gt_prep.hip", "gt_rerank.hip", "gt_sparse.hip", "gt_dense.hip", "gt_landmark.hip", "gt_debug.hip"):
+        if os.path.exists(os.path.join(CSRC, name)):
+            units.append((name, name.replace(".hip", ".o"), []))
+    for dp in SELECT_DPS:
+        units.append(("gt_knn_select.hip", "gt_knn_select_dp%d.o" % dp, ["-DGT_SEL_DP=%d" % dp]))
+    return units
+
+
+def _deps_digest(extra):
+    h = hashlib.sha256()
+    for root in (CSRC, os.path.join(os.path.dirname(HERE), "include")):
+        for fn in sorted(os.listdir(root)):
+            if fn.endswith((".h", ".hip", ".cpp")):
+                with open(os.path.join(root, fn), "rb") as f:
+                    h.update(fn.encode())
+                    h.update(f.read())
+    h.update(" ".join(extra).encode())
+    return h.hexdigest()
+
+
+def _compile(unit):
+    src, obj, extra = unit
+    obj_path = os.path.join(OBJ, obj)
+    stamp = obj_path + ".stamp"
+    # every unit depends on all headers; hash headers + its own source + flags
+    h = hashlib.sha256()
+    for fn in sorted(os.listdir(CSRC)):
+        if fn.endswith(".h") or fn == src:
+            with open(os.path.join(CSRC, fn), "rb") as f:
+                h.update(fn.encode())
+                h.update(f.read())
+    with open(os.path.join(os.path.dirname(HERE), "include", "graphtools_amd.h"), "rb") as f:
+        h.update(f.read())
+    h.update(" ".join(COMMON_FLAGS + extra).encode())
+    digest = h.hexdigest()
+    if os.path.exists(obj_path) and os.path.exists(stamp) and open(stamp).read() == digest:
+        return obj_path, False, ""
+    cmd = [_hipcc()] + COMMON_FLAGS + extra + ["-c", os.path.join(CSRC, src), "-o", obj_path]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, " ".join(cmd), res.stderr[-8000:]))
+    with open(stamp, "w") as f:
+        f.write(digest)
+    return obj_path, True, res.stderr
+
+
+def build(verbose=False, jobs=None):
+    os.makedirs(OBJ, exist_ok=True)
+    units = _units()
+    jobs = jobs or min(8, os.cpu_count() or 1)
+    objs, rebuilt = [], False
+    with concurrent.futures.ThreadPoolExecutor(max_workers=jobs) as ex:
+        for obj_path, did, log in ex.map(_compile, units):
+            objs.append(obj_path)
+            rebuilt |= did
+            if verbose and log.strip():
+                print(log, file=sys.stderr)
+    if rebuilt or not os.path.exists(LIB):
+        cmd = [_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode != 0:
+            raise RuntimeError("link failed:\n%s\n%s" % (" ".join(cmd), res.stderr[-8000:]))
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(verbose=True))

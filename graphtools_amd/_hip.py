@@ -1,0 +1,294 @@
+"""ctypes binding of libgraphtools_amd.so (the C ABI declared in include/graphtools_amd.h).
+
+The product path fails loudly when the HIP library is missing or no MI355X is visible:
+there is no CPU fallback (``HipUnavailableError``).
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgraphtools_amd.so")
+
+GT_F32, GT_F64 = 0, 1
+SYMM = {None: 0, "none": 0, "+": 1, "*": 2, "mnn": 3}
+FLAG_DUPLICATES, FLAG_ZERO_DIAGONAL, FLAG_FALLBACK_ROWS, FLAG_RADIUS_ROWS = 1, 2, 4, 8
+CSR_K, CSR_P = 0, 1
+VEC_BANDWIDTH, VEC_DEGREE = 0, 1
+
+
+class HipUnavailableError(RuntimeError):
+    """The HIP extension (or a GPU) is not available; graphtools_amd has no CPU path."""
+
+
+class HipError(RuntimeError):
+    pass
+
+
+class KnnParams(ctypes.Structure):
+    """mirror of gt_knn_params"""
+
+    _fields_ = [
+        ("knn", ctypes.c_int32),
+        ("kernel_symm", ctypes.c_int32),
+        ("decay", ctypes.c_double),
+        ("thresh", ctypes.c_double),
+        ("bandwidth_scale", ctypes.c_double),
+        ("theta", ctypes.c_double),
+        ("anisotropy", ctypes.c_double),
+        ("bandwidth", ctypes.c_void_p),
+        ("bandwidth_len", ctypes.c_int64),
+        ("knn_max", ctypes.c_int64),
+    ]
+
+
+_lib = None
+
+_c = ctypes
+_SIGNATURES = {
+    "gt_abi_version": (_c.c_int, []),
+    "gt_ctx_create": (_c.c_int, [_c.c_int, _c.POINTER(_c.c_void_p)]),
+    "gt_ctx_destroy": (None, [_c.c_void_p]),
+    "gt_last_error": (_c.c_char_p, [_c.c_void_p]),
+    "gt_device_count": (_c.c_int, []),
+    "gt_stage_ms": (_c.c_double, [_c.c_void_p, _c.c_char_p]),
+    "gt_stage_launches": (_c.c_int, [_c.c_void_p, _c.c_char_p]),
+    "gt_set_points": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_int32]),
+    "gt_knn_search": (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_int64, _c.c_void_p, _c.c_int64, _c.c_int32, _c.c_int32,
+                                 _c.c_void_p, _c.c_void_p, _c.c_int32, _c.POINTER(_c.c_uint32)]),
+    "gt_graph_begin": (_c.c_int, [_c.c_void_p, _c.POINTER(KnnParams), _c.c_int32, _c.c_int32, _c.c_void_p, _c.c_void_p]),
+    "gt_graph_emit": (_c.c_int, [_c.c_void_p, _c.c_void_p]),
+    "gt_graph_finish": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64, _c.POINTER(_c.c_int64), _c.POINTER(_c.c_uint32)]),
+    "gt_graph_anisotropy": (_c.c_int, [_c.c_void_p, _c.c_void_p]),
+    "gt_graph_build": (_c.c_int, [_c.c_void_p, _c.POINTER(KnnParams), _c.POINTER(_c.c_int64), _c.POINTER(_c.c_uint32)]),
+    "gt_graph_rows": (_c.c_int, [_c.c_void_p, _c.POINTER(_c.c_int64), _c.POINTER(_c.c_int64), _c.POINTER(_c.c_int64)]),
+    "gt_graph_fetch_csr": (_c.c_int, [_c.c_void_p, _c.c_int32, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int32]),
+    "gt_graph_fetch_vec": (_c.c_int, [_c.c_void_p, _c.c_int32, _c.c_void_p, _c.c_int32]),
+    "gt_graph_stats": (_c.c_int, [_c.c_void_p, _c.c_void_p]),
+    "gt_dense_graph_build": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_int32,
+                                        _c.c_int32, _c.c_int32, _c.c_double, _c.c_double, _c.c_void_p, _c.c_int64,
+                                        _c.c_double, _c.c_int32, _c.c_double, _c.c_double, _c.c_int32, _c.c_void_p,
+                                        _c.c_void_p, _c.c_int32, _c.POINTER(_c.c_uint32)]),
+    "gt_landmark_partial": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int32, _c.c_void_p, _c.c_void_p, _c.c_int32]),
+    "gt_landmark_transitions_nnz": (_c.c_int, [_c.c_void_p, _c.POINTER(_c.c_int64)]),
+    "gt_landmark_fetch_transitions": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int32]),
+    "gt_nearest_landmark": (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_int64, _c.c_void_p, _c.c_int32, _c.c_int32, _c.c_void_p]),
+    "gt_dev_alloc": (_c.c_int, [_c.c_void_p, _c.c_size_t, _c.POINTER(_c.c_void_p)]),
+    "gt_dev_free": (_c.c_int, [_c.c_void_p, _c.c_void_p]),
+    "gt_dev_upload": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_size_t]),
+    "gt_dev_download": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_size_t]),
+    "gt_dev_sync": (_c.c_int, [_c.c_void_p]),
+}
+
+
+def load_library():
+    """dlopen the in-tree library and declare every prototype (no GPU needed for this)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipUnavailableError(
+            "%s not found: build it with `python -m graphtools_amd._build` (needs hipcc). "
+            "graphtools_amd has no CPU fallback." % LIB_PATH
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _ptr(a):
+    return None if a is None else ctypes.c_void_p(a.ctypes.data)
+
+
+class Context:
+    """One gt_ctx (one HIP device, one stream, all device workspace)."""
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        if self.lib.gt_device_count() <= 0:
+            raise HipUnavailableError("no HIP device visible; graphtools_amd has no CPU fallback")
+        h = ctypes.c_void_p()
+        rc = self.lib.gt_ctx_create(int(device), ctypes.byref(h))
+        if rc != 0:
+            raise HipUnavailableError("gt_ctx_create failed: %s" % self.lib.gt_last_error(None).decode())
+        self.h = h
+        self.device = int(device)
+        self._points = None
+        self.n = 0
+        self.d = 0
+        self.dtype = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.gt_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise HipError("%s failed (%d): %s" % (what, rc, self.lib.gt_last_error(self.h).decode()))
+
+    def stage_ms(self, stage):
+        return float(self.lib.gt_stage_ms(self.h, stage.encode()))
+
+    def stage_launches(self, stage):
+        return int(self.lib.gt_stage_launches(self.h, stage.encode()))
+
+    # ---- points -----------------------------------------------------------------------------
+    def set_points(self, X):
+        """Bind host data (numpy float32/float64, C order).  The array is copied to the device."""
+        X = np.ascontiguousarray(X)
+        if X.dtype not in (np.float32, np.float64):
+            X = X.astype(np.float64)
+        self._points = X
+        self.n, self.d = X.shape
+        self.dtype = X.dtype
+        self._check(
+            self.lib.gt_set_points(self.h, _ptr(X), self.n, self.d, GT_F32 if X.dtype == np.float32 else GT_F64, 0),
+            "gt_set_points",
+        )
+
+    def set_points_device(self, dev_ptr, n, d, dtype):
+        """Bind a device-resident n x d matrix (pointer must stay valid while bound)."""
+        self._points = None
+        self.n, self.d = int(n), int(d)
+        self.dtype = np.dtype(dtype)
+        self._check(
+            self.lib.gt_set_points(self.h, ctypes.c_void_p(int(dev_ptr)), self.n, self.d,
+                                   GT_F32 if self.dtype == np.float32 else GT_F64, 1),
+            "gt_set_points",
+        )
+
+    # ---- kNN --------------------------------------------------------------------------------
+    def knn_search(self, k, rows=None, Y=None):
+        """(distances float64 [m,k], indices int64 [m,k], flags)"""
+        if Y is not None:
+            Y = np.ascontiguousarray(Y, dtype=self.dtype)
+            m = Y.shape[0]
+            r0, r1 = 0, 0
+        else:
+            r0, r1 = rows if rows is not None else (0, self.n)
+            m = r1 - r0
+        idx = np.empty((m, k), dtype=np.int64)
+        dist = np.empty((m, k), dtype=np.float64)
+        flags = ctypes.c_uint32(0)
+        self._check(
+            self.lib.gt_knn_search(self.h, r0, r1, _ptr(Y), m, 0, int(k), _ptr(idx), _ptr(dist), 0, ctypes.byref(flags)),
+            "gt_knn_search",
+        )
+        return dist, idx, flags.value
+
+    # ---- graph ------------------------------------------------------------------------------
+    @staticmethod
+    def make_params(knn, decay, thresh, bandwidth, bandwidth_scale, knn_max, kernel_symm, theta, anisotropy):
+        p = KnnParams()
+        p.knn = int(knn)
+        p.kernel_symm = SYMM[kernel_symm]
+        p.decay = float("nan") if decay is None else float(decay)
+        p.thresh = float(thresh)
+        p.bandwidth_scale = float(bandwidth_scale)
+        p.theta = 1.0 if theta is None else float(theta)
+        p.anisotropy = float(anisotropy)
+        keep = None
+        if bandwidth is None:
+            p.bandwidth = None
+            p.bandwidth_len = 0
+        else:
+            keep = np.ascontiguousarray(np.atleast_1d(np.asarray(bandwidth, dtype=np.float64)))
+            p.bandwidth = keep.ctypes.data
+            p.bandwidth_len = keep.shape[0]
+        p.knn_max = -1 if knn_max is None else int(knn_max)
+        return p, keep
+
+    def graph_build(self, params):
+        nnz = ctypes.c_int64(0)
+        flags = ctypes.c_uint32(0)
+        self._check(self.lib.gt_graph_build(self.h, ctypes.byref(params), ctypes.byref(nnz), ctypes.byref(flags)),
+                    "gt_graph_build")
+        return nnz.value, flags.value
+
+    def graph_begin(self, params, world, rank, row_splits):
+        splits = np.ascontiguousarray(row_splits, dtype=np.int64)
+        counts = np.zeros(world, dtype=np.int64)
+        self._check(self.lib.gt_graph_begin(self.h, ctypes.byref(params), world, rank, _ptr(splits), _ptr(counts)),
+                    "gt_graph_begin")
+        return counts
+
+    def graph_emit(self, send_ptr):
+        self._check(self.lib.gt_graph_emit(self.h, ctypes.c_void_p(int(send_ptr)) if send_ptr else None), "gt_graph_emit")
+
+    def graph_finish(self, recv_ptr, n_recv):
+        nnz = ctypes.c_int64(0)
+        flags = ctypes.c_uint32(0)
+        self._check(
+            self.lib.gt_graph_finish(self.h, ctypes.c_void_p(int(recv_ptr)) if recv_ptr else None, int(n_recv),
+                                     ctypes.byref(nnz), ctypes.byref(flags)),
+            "gt_graph_finish",
+        )
+        return nnz.value, flags.value
+
+    def graph_anisotropy(self, degree_all_ptr):
+        self._check(self.lib.gt_graph_anisotropy(self.h, ctypes.c_void_p(int(degree_all_ptr))), "gt_graph_anisotropy")
+
+    def graph_rows(self):
+        r0, r1, nnz = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+        self._check(self.lib.gt_graph_rows(self.h, ctypes.byref(r0), ctypes.byref(r1), ctypes.byref(nnz)), "gt_graph_rows")
+        return r0.value, r1.value, nnz.value
+
+    def graph_fetch_csr(self, which):
+        """host copies: (data float64, indices int32, indptr int64) for the owned rows"""
+        r0, r1, nnz = self.graph_rows()
+        data = np.empty(nnz, dtype=np.float64)
+        indices = np.empty(nnz, dtype=np.int32)
+        indptr = np.empty(r1 - r0 + 1, dtype=np.int64)
+        self._check(self.lib.gt_graph_fetch_csr(self.h, which, _ptr(data), _ptr(indices), _ptr(indptr), 0),
+                    "gt_graph_fetch_csr")
+        return data, indices, indptr
+
+    def graph_fetch_vec(self, which):
+        r0, r1, _ = self.graph_rows() if which == VEC_DEGREE else (0, self.n, 0)
+        if which == VEC_BANDWIDTH:
+            st = np.zeros(4, dtype=np.int64)
+            # bandwidth is available after begin; owned rows only
+            try:
+                r0, r1, _ = self.graph_rows()
+            except HipError:
+                pass
+        out = np.empty(r1 - r0, dtype=np.float64)
+        self._check(self.lib.gt_graph_fetch_vec(self.h, which, _ptr(out), 0), "gt_graph_fetch_vec")
+        return out
+
+    def graph_stats(self):
+        st = np.zeros(4, dtype=np.int64)
+        self._check(self.lib.gt_graph_stats(self.h, _ptr(st)), "gt_graph_stats")
+        return {"fallback_rows": int(st[0]), "radius_rows": int(st[1]), "nnz_unsymmetrised": int(st[2]),
+                "radius_retries": int(st[3])}
+
+    # ---- raw device memory --------------------------------------------------------------------
+    def dev_alloc(self, nbytes):
+        p = ctypes.c_void_p()
+        self._check(self.lib.gt_dev_alloc(self.h, int(nbytes), ctypes.byref(p)), "gt_dev_alloc")
+        return p.value
+
+    def dev_free(self, p):
+        self._check(self.lib.gt_dev_free(self.h, ctypes.c_void_p(int(p))), "gt_dev_free")
+
+    def dev_upload(self, dst, arr):
+        arr = np.ascontiguousarray(arr)
+        self._check(self.lib.gt_dev_upload(self.h, ctypes.c_void_p(int(dst)), _ptr(arr), arr.nbytes), "gt_dev_upload")
+
+    def dev_download(self, arr, src):
+        self._check(self.lib.gt_dev_download(self.h, _ptr(arr), ctypes.c_void_p(int(src)), arr.nbytes), "gt_dev_download")
+
+    def sync(self):
+        self._check(self.lib.gt_dev_sync(self.h), "gt_dev_sync")

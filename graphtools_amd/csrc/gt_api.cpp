@@ -1,0 +1,168 @@
+// Context management, point binding and the small device-memory helpers of the C ABI.
+#include "gt_common.h"
+#include "gt_knn.h"
+
+static thread_local std::string g_create_error;
+
+void gt_free_knn_work(gt_ctx* ctx);     // gt_knn.hip
+void gt_free_graph_state(gt_ctx* ctx);  // gt_sparse.hip
+
+extern "C" {
+
+int gt_abi_version(void) { return GT_ABI_VERSION; }
+
+int gt_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int gt_ctx_create(int device, gt_ctx** out) {
+    if (!out) return GT_E_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        g_create_error = std::string("no HIP device available: ") + hipGetErrorString(e);
+        return GT_E_HIP;
+    }
+    if (device < 0 || device >= ndev) {
+        g_create_error = "device ordinal out of range";
+        return GT_E_ARG;
+    }
+    e = hipSetDevice(device);
+    if (e != hipSuccess) {
+        g_create_error = std::string("hipSetDevice: ") + hipGetErrorString(e);
+        return GT_E_HIP;
+    }
+    gt_ctx* ctx = new gt_ctx();
+    ctx->device = device;
+    e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        g_create_error = std::string("hipStreamCreate: ") + hipGetErrorString(e);
+        delete ctx;
+        return GT_E_HIP;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->n_cu = prop.multiProcessorCount;
+    *out = ctx;
+    return GT_OK;
+}
+
+void gt_ctx_destroy(gt_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    gt_free_knn_work(ctx);
+    gt_free_graph_state(ctx);
+    ctx->reset_stages();
+    for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
+    ctx->X_own.release();
+    ctx->Yp.release();
+    ctx->xn.release();
+    ctx->hneg.release();
+    ctx->ymax.release();
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char* gt_last_error(const gt_ctx* ctx) {
+    if (!ctx) return g_create_error.c_str();
+    return ctx->err.c_str();
+}
+
+double gt_stage_ms(const gt_ctx* ctx, const char* stage) {
+    if (!ctx || !stage) return -1.0;
+    auto it = ctx->stages.find(stage);
+    if (it == ctx->stages.end()) return -1.0;
+    (void)hipStreamSynchronize(ctx->stream);
+    double total = 0.0;
+    for (auto& s : it->second.spans) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, s.first, s.second) == hipSuccess) total += ms;
+    }
+    return total;
+}
+
+int gt_stage_launches(const gt_ctx* ctx, const char* stage) {
+    if (!ctx || !stage) return -1;
+    auto it = ctx->stages.find(stage);
+    if (it == ctx->stages.end()) return -1;
+    return it->second.launches;
+}
+
+int gt_set_points(gt_ctx* ctx, const void* X, int64_t n, int32_t d, int32_t dtype, int32_t on_device) {
+    if (!ctx) return GT_E_ARG;
+    if (!X || n <= 0 || d <= 0) GT_FAIL(ctx, GT_E_ARG, "gt_set_points: empty input");
+    if (dtype != GT_F32 && dtype != GT_F64) GT_FAIL(ctx, GT_E_ARG, "gt_set_points: dtype must be GT_F32 or GT_F64");
+    if (n >= (int64_t(1) << 31) - 1) GT_FAIL(ctx, GT_E_LIMIT, "gt_set_points: n must be < 2^31 - 1");
+    GT_HIP(ctx, hipSetDevice(ctx->device));
+    ctx->reset_stages();
+    const size_t esz = dtype == GT_F32 ? 4 : 8;
+    if (on_device) {
+        ctx->X = X;
+    } else {
+        GT_HIP(ctx, ctx->X_own.reserve(size_t(n) * d * esz));
+        GT_HIP(ctx, hipMemcpyAsync(ctx->X_own.p, X, size_t(n) * d * esz, hipMemcpyHostToDevice, ctx->stream));
+        ctx->X = ctx->X_own.p;
+    }
+    ctx->n = n;
+    ctx->d = d;
+    ctx->dtype = dtype;
+    ctx->DP = gt_choose_dp(d);
+    if (ctx->DP == 0) {
+        // exact dense path and landmark assignment still work on the raw points; kNN needs d <= 128 for now
+        ctx->n_pad = 0;
+        GT_HIP(ctx, ctx->xn.reserve(size_t(n) * sizeof(double)));
+        GT_HIP(ctx, ctx->ymax.reserve(sizeof(double)));
+        GT_TRY(gt_prep_matrix(ctx, ctx->X, n, d, dtype, 0, 0, nullptr, ctx->xn.as<double>(), nullptr,
+                              ctx->ymax.as<double>()));
+    } else {
+        GT_TRY(gt_prep_points(ctx));
+    }
+    GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return GT_OK;
+}
+
+int gt_dev_alloc(gt_ctx* ctx, size_t bytes, void** out) {
+    if (!ctx || !out) return GT_E_ARG;
+    GT_HIP(ctx, hipSetDevice(ctx->device));
+    hipError_t e = hipMalloc(out, bytes ? bytes : 16);
+    if (e != hipSuccess) {
+        ctx->set_error(std::string("hipMalloc: ") + hipGetErrorString(e));
+        return GT_E_ALLOC;
+    }
+    return GT_OK;
+}
+
+int gt_dev_free(gt_ctx* ctx, void* p) {
+    if (!ctx) return GT_E_ARG;
+    GT_HIP(ctx, hipSetDevice(ctx->device));
+    GT_HIP(ctx, hipFree(p));
+    return GT_OK;
+}
+
+int gt_dev_upload(gt_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes) {
+    if (!ctx) return GT_E_ARG;
+    GT_HIP(ctx, hipSetDevice(ctx->device));
+    GT_HIP(ctx, hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return GT_OK;
+}
+
+int gt_dev_download(gt_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes) {
+    if (!ctx) return GT_E_ARG;
+    GT_HIP(ctx, hipSetDevice(ctx->device));
+    GT_HIP(ctx, hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return GT_OK;
+}
+
+int gt_dev_sync(gt_ctx* ctx) {
+    if (!ctx) return GT_E_ARG;
+    GT_HIP(ctx, hipSetDevice(ctx->device));
+    GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return GT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,153 @@
+// Host-side plumbing shared by the translation units of libgraphtools_amd.so:
+// context object, device buffers, error reporting, per-stage hipEvent timing.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/graphtools_amd.h"
+
+// ---- error helpers ---------------------------------------------------------------------------
+#define GT_HIP(ctx, expr)                                                                       \
+    do {                                                                                        \
+        hipError_t _e = (expr);                                                                 \
+        if (_e != hipSuccess) {                                                                 \
+            (ctx)->set_error(std::string(#expr) + ": " + hipGetErrorString(_e) + " (" __FILE__ ":" + \
+                             std::to_string(__LINE__) + ")");                                   \
+            return GT_E_HIP;                                                                    \
+        }                                                                                       \
+    } while (0)
+
+#define GT_TRY(expr)                 \
+    do {                             \
+        int _rc = (expr);            \
+        if (_rc != GT_OK) return _rc; \
+    } while (0)
+
+#define GT_FAIL(ctx, code, msg)   \
+    do {                          \
+        (ctx)->set_error(msg);    \
+        return (code);            \
+    } while (0)
+
+// grow-only device buffer
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    template <class T>
+    T* as() const {
+        return reinterpret_cast<T*>(p);
+    }
+    hipError_t reserve(size_t bytes) {
+        if (bytes <= cap && p) return hipSuccess;
+        if (p) {
+            hipError_t e = hipFree(p);
+            p = nullptr;
+            cap = 0;
+            if (e != hipSuccess) return e;
+        }
+        if (bytes == 0) bytes = 16;
+        size_t want = (bytes + 255) & ~size_t(255);
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) {
+            p = nullptr;
+            cap = 0;
+            return e;
+        }
+        cap = want;
+        return hipSuccess;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+struct StageAcc {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> spans;
+    int launches = 0;
+};
+
+struct GraphState;  // gt_sparse.hip
+struct KnnWork;     // gt_knn.hip
+
+struct gt_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    std::map<std::string, StageAcc> stages;
+    std::vector<hipEvent_t> event_pool;
+    int n_cu = 256;
+
+    // ---- bound points (gt_set_points) ----
+    const void* X = nullptr;  // device pointer, original dtype, n x d row-major
+    DevBuf X_own;             // owned copy when the caller passed host memory
+    int64_t n = 0;
+    int32_t d = 0;
+    int32_t dtype = GT_F32;
+    int32_t DP = 0;      // padded feature count of the float32 working copy
+    int64_t n_pad = 0;   // rows of the working copy (multiple of the db tile)
+    DevBuf Yp;           // float [n_pad][DP]
+    DevBuf xn;           // double [n]    squared row norms
+    DevBuf hneg;         // float [n_pad] -|y|^2/2 (-inf on pad rows)
+    DevBuf ymax;         // float [1]     max row norm (as float bits, atomicMax on uint)
+    float ymax_host = 0.f;
+
+    KnnWork* knn = nullptr;
+    GraphState* graph = nullptr;
+
+    void set_error(const std::string& m) { err = m; }
+
+    hipEvent_t get_event() {
+        if (!event_pool.empty()) {
+            hipEvent_t e = event_pool.back();
+            event_pool.pop_back();
+            return e;
+        }
+        hipEvent_t e;
+        (void)hipEventCreate(&e);
+        return e;
+    }
+    void reset_stages() {
+        for (auto& kv : stages) {
+            for (auto& s : kv.second.spans) {
+                event_pool.push_back(s.first);
+                event_pool.push_back(s.second);
+            }
+        }
+        stages.clear();
+    }
+};
+
+// RAII span: records a hipEvent pair on the ctx stream around the launches of one stage
+struct StageSpan {
+    gt_ctx* ctx;
+    StageAcc* acc;
+    hipEvent_t e0, e1;
+    StageSpan(gt_ctx* c, const char* name, int launches = 1) : ctx(c) {
+        acc = &c->stages[name];
+        e0 = c->get_event();
+        e1 = c->get_event();
+        acc->launches += launches;
+        (void)hipEventRecord(e0, c->stream);
+    }
+    ~StageSpan() {
+        (void)hipEventRecord(e1, ctx->stream);
+        acc->spans.emplace_back(e0, e1);
+    }
+};
+
+static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// gt_prep.hip
+int gt_prep_points(gt_ctx* ctx);
+// choose the padded feature count for d (0 if unsupported)
+int gt_choose_dp(int d);

@@ -1,0 +1,149 @@
+// Development / unit-test hooks (not part of the public ABI in include/graphtools_amd.h): they expose
+// the device primitives so that tests on the GPU box can check them in isolation.
+#include "gt_common.h"
+#include "gt_device.h"
+#include "gt_knn.h"
+
+namespace {
+
+template <int NT>
+__global__ void dbg_sort_desc_kernel(const uint64_t* in, int n, uint64_t* out) {
+    const int lane = threadIdx.x;
+    uint64_t key[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int e = t * 64 + lane;
+        key[t] = e < n ? in[e] : 0ull;
+    }
+    wave_bitonic_desc<NT>(key, lane);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) out[t * 64 + lane] = key[t];
+}
+
+template <int NT>
+__global__ void dbg_sort_pair_kernel(const uint64_t* in_hi, const uint64_t* in_lo, int n, uint64_t* out_hi,
+                                     uint64_t* out_lo) {
+    const int lane = threadIdx.x;
+    uint64_t hi[NT], lo[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int e = t * 64 + lane;
+        hi[t] = e < n ? in_hi[e] : ~0ull;
+        lo[t] = e < n ? in_lo[e] : ~0ull;
+    }
+    wave_bitonic_asc_pair<NT>(hi, lo, lane);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        out_hi[t * 64 + lane] = hi[t];
+        out_lo[t * 64 + lane] = lo[t];
+    }
+}
+
+// C[i][j] of one 32x32x2 MFMA chain: A = a[32][K], B = b[K][32] (b given as bt[32][K], i.e. B^T)
+__global__ void dbg_mfma_kernel(const float* a, const float* bt, int K, float* c) {
+    const int lane = threadIdx.x;
+    const int li = lane & 31, h = lane >> 5;
+    f32x16 acc;
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int s = 0; s < K / 2; ++s) {
+        const float av = a[li * K + h * (K / 2) + s];
+        const float bv = bt[li * K + h * (K / 2) + s];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+    }
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+        c[row * 32 + li] = acc[r];
+    }
+}
+
+}  // namespace
+
+extern "C" int gt_dbg_sort_desc(gt_ctx* ctx, const uint64_t* keys_host, int n, int nt, uint64_t* out_host) {
+    if (!ctx) return GT_E_ARG;
+    GT_HIP(ctx, hipSetDevice(ctx->device));
+    DevBuf in, out;
+    GT_HIP(ctx, in.reserve(size_t(64) * nt * 8));
+    GT_HIP(ctx, out.reserve(size_t(64) * nt * 8));
+    GT_HIP(ctx, hipMemcpy(in.p, keys_host, size_t(n) * 8, hipMemcpyHostToDevice));
+    switch (nt) {
+        case 1: hipLaunchKernelGGL(dbg_sort_desc_kernel<1>, dim3(1), dim3(64), 0, ctx->stream, in.as<uint64_t>(), n, out.as<uint64_t>()); break;
+        case 2: hipLaunchKernelGGL(dbg_sort_desc_kernel<2>, dim3(1), dim3(64), 0, ctx->stream, in.as<uint64_t>(), n, out.as<uint64_t>()); break;
+        case 8: hipLaunchKernelGGL(dbg_sort_desc_kernel<8>, dim3(1), dim3(64), 0, ctx->stream, in.as<uint64_t>(), n, out.as<uint64_t>()); break;
+        case 32: hipLaunchKernelGGL(dbg_sort_desc_kernel<32>, dim3(1), dim3(64), 0, ctx->stream, in.as<uint64_t>(), n, out.as<uint64_t>()); break;
+        default: GT_FAIL(ctx, GT_E_ARG, "nt");
+    }
+    GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    GT_HIP(ctx, hipMemcpy(out_host, out.p, size_t(64) * nt * 8, hipMemcpyDeviceToHost));
+    in.release();
+    out.release();
+    return GT_OK;
+}
+
+extern "C" int gt_dbg_sort_pair(gt_ctx* ctx, const uint64_t* hi_host, const uint64_t* lo_host, int n, int nt,
+                                uint64_t* out_hi, uint64_t* out_lo) {
+    if (!ctx) return GT_E_ARG;
+    GT_HIP(ctx, hipSetDevice(ctx->device));
+    DevBuf ih, il, oh, ol;
+    const size_t bytes = size_t(64) * nt * 8;
+    GT_HIP(ctx, ih.reserve(bytes));
+    GT_HIP(ctx, il.reserve(bytes));
+    GT_HIP(ctx, oh.reserve(bytes));
+    GT_HIP(ctx, ol.reserve(bytes));
+    GT_HIP(ctx, hipMemcpy(ih.p, hi_host, size_t(n) * 8, hipMemcpyHostToDevice));
+    GT_HIP(ctx, hipMemcpy(il.p, lo_host, size_t(n) * 8, hipMemcpyHostToDevice));
+    switch (nt) {
+        case 1: hipLaunchKernelGGL(dbg_sort_pair_kernel<1>, dim3(1), dim3(64), 0, ctx->stream, ih.as<uint64_t>(), il.as<uint64_t>(), n, oh.as<uint64_t>(), ol.as<uint64_t>()); break;
+        case 2: hipLaunchKernelGGL(dbg_sort_pair_kernel<2>, dim3(1), dim3(64), 0, ctx->stream, ih.as<uint64_t>(), il.as<uint64_t>(), n, oh.as<uint64_t>(), ol.as<uint64_t>()); break;
+        case 4: hipLaunchKernelGGL(dbg_sort_pair_kernel<4>, dim3(1), dim3(64), 0, ctx->stream, ih.as<uint64_t>(), il.as<uint64_t>(), n, oh.as<uint64_t>(), ol.as<uint64_t>()); break;
+        case 8: hipLaunchKernelGGL(dbg_sort_pair_kernel<8>, dim3(1), dim3(64), 0, ctx->stream, ih.as<uint64_t>(), il.as<uint64_t>(), n, oh.as<uint64_t>(), ol.as<uint64_t>()); break;
+        default: GT_FAIL(ctx, GT_E_ARG, "nt");
+    }
+    GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    GT_HIP(ctx, hipMemcpy(out_hi, oh.p, bytes, hipMemcpyDeviceToHost));
+    GT_HIP(ctx, hipMemcpy(out_lo, ol.p, bytes, hipMemcpyDeviceToHost));
+    ih.release();
+    il.release();
+    oh.release();
+    ol.release();
+    return GT_OK;
+}
+
+extern "C" int gt_dbg_mfma(gt_ctx* ctx, const float* a_host, const float* bt_host, int K, float* c_host) {
+    if (!ctx) return GT_E_ARG;
+    GT_HIP(ctx, hipSetDevice(ctx->device));
+    DevBuf a, b, c;
+    GT_HIP(ctx, a.reserve(size_t(32) * K * 4));
+    GT_HIP(ctx, b.reserve(size_t(32) * K * 4));
+    GT_HIP(ctx, c.reserve(size_t(32) * 32 * 4));
+    GT_HIP(ctx, hipMemcpy(a.p, a_host, size_t(32) * K * 4, hipMemcpyHostToDevice));
+    GT_HIP(ctx, hipMemcpy(b.p, bt_host, size_t(32) * K * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(dbg_mfma_kernel, dim3(1), dim3(64), 0, ctx->stream, a.as<float>(), b.as<float>(), K, c.as<float>());
+    GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    GT_HIP(ctx, hipMemcpy(c_host, c.p, size_t(32) * 32 * 4, hipMemcpyDeviceToHost));
+    a.release();
+    b.release();
+    c.release();
+    return GT_OK;
+}
+
+// raw candidate lists of the most recent kNN call: counts [nq] and the first `width` keys of each list
+extern "C" int gt_dbg_fetch_lists(gt_ctx* ctx, int64_t nq, int width, uint32_t* counts_host, uint64_t* keys_host) {
+    if (!ctx || !ctx->knn) return GT_E_STATE;
+    GT_HIP(ctx, hipSetDevice(ctx->device));
+    KnnWork* k = ctx->knn;
+    const size_t lcap = size_t(64) * k->nt;
+    GT_HIP(ctx, hipMemcpy(counts_host, k->counts.p, size_t(nq) * 4, hipMemcpyDeviceToHost));
+    GT_HIP(ctx, hipMemcpy2D(keys_host, size_t(width) * 8, k->lists.p, lcap * 8, size_t(width) * 8, size_t(nq),
+                            hipMemcpyDeviceToHost));
+    return GT_OK;
+}
+
+extern "C" int gt_dbg_fetch_cand(gt_ctx* ctx, int64_t nq, double* d2_host, uint32_t* j_host, double* lb_host) {
+    if (!ctx || !ctx->knn) return GT_E_STATE;
+    GT_HIP(ctx, hipSetDevice(ctx->device));
+    KnnWork* k = ctx->knn;
+    GT_HIP(ctx, hipMemcpy(d2_host, k->cand_d2.p, size_t(nq) * k->MP * 8, hipMemcpyDeviceToHost));
+    GT_HIP(ctx, hipMemcpy(j_host, k->cand_j.p, size_t(nq) * k->MP * 4, hipMemcpyDeviceToHost));
+    GT_HIP(ctx, hipMemcpy(lb_host, k->d2_lb.p, size_t(nq) * 8, hipMemcpyDeviceToHost));
+    return GT_OK;
+}

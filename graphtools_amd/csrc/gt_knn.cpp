@@ -1,0 +1,194 @@
+// Host orchestration of the kNN search: candidate pass (MFMA) -> exact re-rank (fp64) -> exhaustive
+// fallback for the rows whose candidate table could not be proven complete.
+#include "gt_knn.h"
+#include "gt_knn_select.h"
+
+#include <algorithm>
+
+int gt_select_bn_for(int dp) { return gt_select_bn(dp); }
+
+void gt_free_knn_work(gt_ctx* ctx) {
+    if (!ctx->knn) return;
+    KnnWork* k = ctx->knn;
+    for (DevBuf* b : {&k->Qraw, &k->Qp, &k->qn, &k->lists, &k->counts, &k->cand_d2, &k->cand_j, &k->cand_n,
+                      &k->d2_lb, &k->fb_rows, &k->fb_count, &k->fb_scratch, &k->gflags})
+        b->release();
+    delete k;
+    ctx->knn = nullptr;
+}
+
+// fp32 accumulation error coefficient: |s~ - s| <= err_coef * (|y|^2/2 + |x||y|), see gt_rerank.hip.
+// The MFMA chain performs DP fused multiply-adds on top of the rounded seed -|y|^2/2 (any summation order of
+// DP+1 terms obeys gamma_{DP+1}); float64 inputs add 2u from the float32 conversion of both operands.
+// A factor 2 of head-room is applied on top.
+static double err_coefficient(int dp) {
+    const double u = 5.9604644775390625e-08;  // 2^-24
+    return 2.0 * double(dp + 6) * u;
+}
+
+int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int need_m) {
+    if (ctx->n <= 0 || !ctx->X) GT_FAIL(ctx, GT_E_STATE, "no points bound (call gt_set_points first)");
+    if (ctx->DP == 0) GT_FAIL(ctx, GT_E_LIMIT, "kNN on the HIP path needs n_features <= 128 (reduce with n_pca)");
+    if (need_m < 1 || int64_t(need_m) > ctx->n) GT_FAIL(ctx, GT_E_ARG, "k must be in [1, n_samples]");
+    if (nq <= 0) GT_FAIL(ctx, GT_E_ARG, "no query rows");
+    if (!ctx->knn) ctx->knn = new KnnWork();
+    KnnWork* k = ctx->knn;
+    int nt;
+    if (need_m <= 112)
+        nt = 8;
+    else if (need_m <= 448)
+        nt = 32;
+    else
+        GT_FAIL(ctx, GT_E_LIMIT, "k > 448 neighbours is not supported by the HIP path yet");
+    const int MP = 16 * nt;
+    const int bq = gt_select_bq(ctx->DP);
+    k->MP = MP;
+    k->nt = nt;
+    k->nq = nq;
+    k->nq_pad = ceil_div64(nq, bq) * bq;
+    k->q0 = q0;
+    k->external = external;
+    k->n_fallback = 0;
+    const size_t lcap = size_t(64) * nt;
+    GT_HIP(ctx, k->lists.reserve(size_t(k->nq_pad) * lcap * sizeof(uint64_t)));
+    GT_HIP(ctx, k->counts.reserve(size_t(k->nq_pad) * sizeof(uint32_t)));
+    GT_HIP(ctx, k->cand_d2.reserve(size_t(nq) * MP * sizeof(double)));
+    GT_HIP(ctx, k->cand_j.reserve(size_t(nq) * MP * sizeof(uint32_t)));
+    GT_HIP(ctx, k->cand_n.reserve(size_t(nq) * sizeof(uint32_t)));
+    GT_HIP(ctx, k->d2_lb.reserve(size_t(nq) * sizeof(double)));
+    GT_HIP(ctx, k->fb_rows.reserve(size_t(nq) * sizeof(int32_t)));
+    GT_HIP(ctx, k->fb_count.reserve(sizeof(uint32_t)));
+    GT_HIP(ctx, k->gflags.reserve(sizeof(uint32_t)));
+    GT_HIP(ctx, hipMemsetAsync(k->fb_count.p, 0, sizeof(uint32_t), ctx->stream));
+    GT_HIP(ctx, hipMemsetAsync(k->gflags.p, 0, sizeof(uint32_t), ctx->stream));
+
+    SelectArgs sa;
+    sa.dp = ctx->DP;
+    sa.mode = 0;
+    sa.nt = nt;
+    sa.Yp = ctx->Yp.as<float>();
+    sa.hneg = ctx->hneg.as<float>();
+    sa.n_pad = ctx->n_pad;
+    sa.Qp = external ? k->Qp.as<float>() : ctx->Yp.as<float>();
+    sa.qrows = nullptr;
+    sa.q0 = external ? 0 : q0;
+    sa.nq = int32_t(nq);
+    sa.lists = k->lists.as<uint64_t>();
+    sa.counts = k->counts.as<uint32_t>();
+    {
+        StageSpan span(ctx, "knn_select");
+        GT_TRY(gt_launch_select(ctx, sa));
+    }
+    RerankArgs ra;
+    ra.X = ctx->X;
+    ra.dtype = ctx->dtype;
+    ra.n = ctx->n;
+    ra.d = ctx->d;
+    ra.xn = ctx->xn.as<double>();
+    ra.Q = external ? k->Qraw.p : ctx->X;
+    ra.qn = external ? k->qn.as<double>() : ctx->xn.as<double>();
+    ra.q0 = external ? 0 : q0;
+    ra.nq = nq;
+    ra.lists = k->lists.as<uint64_t>();
+    ra.lstride = int(lcap);
+    ra.counts = k->counts.as<uint32_t>();
+    ra.ymax2 = ctx->ymax.as<double>();
+    ra.err_coef = err_coefficient(ctx->DP);
+    ra.need_m = need_m;
+    ra.MP = MP;
+    ra.cand_d2 = k->cand_d2.as<double>();
+    ra.cand_j = k->cand_j.as<uint32_t>();
+    ra.cand_n = k->cand_n.as<uint32_t>();
+    ra.d2_lb = k->d2_lb.as<double>();
+    ra.fb_count = k->fb_count.as<uint32_t>();
+    ra.fb_rows = k->fb_rows.as<int32_t>();
+    ra.gflags = k->gflags.as<uint32_t>();
+    {
+        StageSpan span(ctx, "rerank");
+        GT_TRY(gt_launch_rerank(ctx, ra));
+    }
+    uint32_t n_fb = 0;
+    GT_HIP(ctx, hipMemcpyAsync(&n_fb, k->fb_count.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    k->n_fallback = n_fb;
+    if (n_fb > 0) {
+        // batches sized so that the float64 distance scratch stays <= 2 GiB
+        int64_t batch = std::max<int64_t>(1, (int64_t(2) << 30) / (ctx->n * int64_t(sizeof(double))));
+        batch = std::min<int64_t>(batch, n_fb);
+        GT_HIP(ctx, k->fb_scratch.reserve(size_t(batch) * size_t(ctx->n) * sizeof(double)));
+        StageSpan span(ctx, "fallback", int(ceil_div64(n_fb, batch)));
+        for (int64_t off = 0; off < n_fb; off += batch) {
+            const int64_t rows = std::min<int64_t>(batch, n_fb - off);
+            GT_TRY(gt_launch_fallback(ctx, ra, rows, off, k->fb_scratch.as<double>()));
+        }
+    }
+    return GT_OK;
+}
+
+extern "C" int gt_knn_search(gt_ctx* ctx, int64_t row0, int64_t row1, const void* Y, int64_t m, int32_t y_on_device,
+                             int32_t k, int64_t* out_idx, double* out_dist, int32_t out_on_device, uint32_t* flags) {
+    if (!ctx) return GT_E_ARG;
+    GT_HIP(ctx, hipSetDevice(ctx->device));
+    ctx->reset_stages();
+    if (!out_idx || !out_dist) GT_FAIL(ctx, GT_E_ARG, "gt_knn_search: output pointers are required");
+    int64_t nq;
+    bool external = (Y != nullptr);
+    if (!ctx->knn) ctx->knn = new KnnWork();
+    KnnWork* kw = ctx->knn;
+    if (external) {
+        if (m <= 0) GT_FAIL(ctx, GT_E_ARG, "gt_knn_search: m must be positive");
+        if (ctx->DP == 0) GT_FAIL(ctx, GT_E_LIMIT, "kNN on the HIP path needs n_features <= 128");
+        nq = m;
+        const size_t esz = ctx->dtype == GT_F32 ? 4 : 8;
+        const int bq = gt_select_bq(ctx->DP);
+        const int64_t mpad = ceil_div64(m, bq) * bq;
+        GT_HIP(ctx, kw->Qraw.reserve(size_t(m) * ctx->d * esz));
+        GT_HIP(ctx, hipMemcpyAsync(kw->Qraw.p, Y, size_t(m) * ctx->d * esz,
+                                   y_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
+        GT_HIP(ctx, kw->Qp.reserve(size_t(mpad) * ctx->DP * sizeof(float)));
+        GT_HIP(ctx, kw->qn.reserve(size_t(m) * sizeof(double)));
+        GT_TRY(gt_prep_matrix(ctx, kw->Qraw.p, m, ctx->d, ctx->dtype, ctx->DP, mpad, kw->Qp.as<float>(),
+                              kw->qn.as<double>(), nullptr, nullptr));
+        row0 = 0;
+    } else {
+        if (row0 < 0 || row1 > ctx->n || row1 <= row0) GT_FAIL(ctx, GT_E_ARG, "gt_knn_search: bad row range");
+        nq = row1 - row0;
+    }
+    GT_TRY(gt_knn_candidates(ctx, row0, nq, external, k));
+    int64_t* d_idx = out_idx;
+    double* d_dist = out_dist;
+    DevBuf tmp_i, tmp_d;
+    if (!out_on_device) {
+        GT_HIP(ctx, tmp_i.reserve(size_t(nq) * k * sizeof(int64_t)));
+        GT_HIP(ctx, tmp_d.reserve(size_t(nq) * k * sizeof(double)));
+        d_idx = tmp_i.as<int64_t>();
+        d_dist = tmp_d.as<double>();
+    }
+    int rc = gt_launch_emit_knn(ctx, kw->cand_d2.as<double>(), kw->cand_j.as<uint32_t>(), kw->MP, nq, k, ctx->dtype,
+                                d_idx, d_dist);
+    if (rc == GT_OK && !out_on_device) {
+        hipError_t e = hipMemcpyAsync(out_idx, d_idx, size_t(nq) * k * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(out_dist, d_dist, size_t(nq) * k * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+        if (e != hipSuccess) {
+            ctx->set_error(std::string("copy-out: ") + hipGetErrorString(e));
+            rc = GT_E_HIP;
+        }
+    }
+    uint32_t fl = 0;
+    if (rc == GT_OK) {
+        hipError_t e = hipMemcpyAsync(&fl, kw->gflags.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream);
+        if (e != hipSuccess) rc = GT_E_HIP;
+    }
+    hipError_t es = hipStreamSynchronize(ctx->stream);
+    tmp_i.release();
+    tmp_d.release();
+    if (rc != GT_OK) return rc;
+    if (es != hipSuccess) {
+        ctx->set_error(std::string("stream sync: ") + hipGetErrorString(es));
+        return GT_E_HIP;
+    }
+    if (kw->n_fallback > 0) fl |= GT_FLAG_FALLBACK_ROWS;
+    if (flags) *flags = fl;
+    return GT_OK;
+}

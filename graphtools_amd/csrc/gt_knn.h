@@ -1,0 +1,64 @@
+// kNN driver state shared between gt_knn.hip (host orchestration), gt_rerank.hip (exact fp64 kernels)
+// and gt_sparse.hip (affinity stage reads the candidate tables).
+#pragma once
+#include "gt_common.h"
+
+// Exact candidate tables for a block of queries, produced by gt_knn_candidates():
+//   cand_d2[q][p], cand_j[q][p]  p < MP : float64 squared distance (scikit-learn GEMM form) and database
+//                                 index, ascending by (d2, j); unused slots hold +inf / 0xFFFFFFFF
+//   cand_n[q]                     number of valid slots
+//   d2_lb[q]                      completeness bound: EVERY database row with d2 < d2_lb[q] is in the table
+struct KnnWork {
+    int MP = 0;          // table width (128 or 512)
+    int nt = 0;          // MP / 16
+    int64_t nq = 0;      // queries in the tables
+    int64_t nq_pad = 0;  // rounded up to the select kernel's query block
+    int64_t q0 = 0;      // first query row (self queries) - queries are rows [q0, q0+nq) of the bound points
+    bool external = false;
+    // external queries (gt_knn_search with Y)
+    DevBuf Qraw, Qp, qn;
+    DevBuf lists, counts;
+    DevBuf cand_d2, cand_j, cand_n, d2_lb;
+    DevBuf fb_rows, fb_count, fb_scratch, gflags;
+    int64_t n_fallback = 0;
+};
+
+int gt_select_bn_for(int dp);
+int gt_prep_matrix(gt_ctx* ctx, const void* Xdev, int64_t n, int d, int dtype, int DP, int64_t n_pad, float* Yp,
+                   double* xn, float* hneg, double* ymax2);
+
+// Build exact candidate tables with the first `need_m` entries of every row guaranteed to be the true
+// need_m nearest neighbours.  Queries: rows [q0, q0+nq) of the bound points, or (external) the matrix in
+// ctx->knn->Qraw prepared by the caller.
+int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int need_m);
+
+// gt_rerank.hip
+struct RerankArgs {
+    const void* X;          // database, original dtype, n x d
+    int dtype;
+    int64_t n;
+    int d;
+    const double* xn;       // database squared norms
+    const void* Q;          // query matrix (original dtype); rows addressed as q0 + q
+    const double* qn;       // squared norms of the query matrix rows (indexed like Q)
+    int64_t q0;
+    int64_t nq;
+    const uint64_t* lists;
+    int lstride;
+    const uint32_t* counts;
+    const double* ymax2;
+    double err_coef;
+    int need_m;
+    int MP;
+    double* cand_d2;
+    uint32_t* cand_j;
+    uint32_t* cand_n;
+    double* d2_lb;
+    uint32_t* fb_count;
+    int32_t* fb_rows;
+    uint32_t* gflags;
+};
+int gt_launch_rerank(gt_ctx* ctx, const RerankArgs& a);
+int gt_launch_fallback(gt_ctx* ctx, const RerankArgs& a, int64_t n_rows, int64_t row_off, double* scratch);
+int gt_launch_emit_knn(gt_ctx* ctx, const double* cand_d2, const uint32_t* cand_j, int MP, int64_t nq, int k,
+                       int dtype, int64_t* out_idx, double* out_dist);

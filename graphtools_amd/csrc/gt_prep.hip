@@ -1,0 +1,94 @@
+// Point preprocessing: the padded float32 working copy consumed by the MFMA candidate kernels, the
+// float64 squared row norms used by the exact re-rank (scikit-learn computes them in float64 as well,
+// sklearn:metrics/_pairwise_distances_reduction/_base.pyx.tp:45-83) and the -|y|^2/2 accumulator seeds.
+// HBM-bound, one pass over the data.
+#include "gt_common.h"
+#include "gt_device.h"
+#include "gt_knn.h"
+
+namespace {
+
+template <typename T>
+__global__ __launch_bounds__(256) void pad_convert_kernel(const T* __restrict__ X, int64_t n, int d, int DP,
+                                                          int64_t n_pad, float* __restrict__ Yp) {
+    const int64_t total4 = n_pad * DP / 4;
+    const int dp4 = DP / 4;
+    for (int64_t f = int64_t(blockIdx.x) * 256 + threadIdx.x; f < total4; f += int64_t(gridDim.x) * 256) {
+        const int64_t r = f / dp4;
+        const int c = int(f % dp4) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < n) {
+            const T* src = X + r * int64_t(d);
+            if (c + 0 < d) v.x = float(src[c + 0]);
+            if (c + 1 < d) v.y = float(src[c + 1]);
+            if (c + 2 < d) v.z = float(src[c + 2]);
+            if (c + 3 < d) v.w = float(src[c + 3]);
+        }
+        reinterpret_cast<float4*>(Yp)[f] = v;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void row_norm_kernel(const T* __restrict__ X, int64_t n, int d, int64_t n_pad,
+                                                       double* __restrict__ xn, float* __restrict__ hneg,
+                                                       unsigned long long* __restrict__ ymax2_bits) {
+    const int64_t r = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    double acc = 0.0;
+    if (r < n) {
+        const T* src = X + r * int64_t(d);
+        for (int k = 0; k < d; ++k) {
+            const double v = double(src[k]);
+            acc = fma(v, v, acc);
+        }
+        xn[r] = acc;
+        if (hneg) hneg[r] = float(-0.5 * acc);
+    } else if (r < n_pad) {
+        if (hneg) hneg[r] = -INFINITY;
+    }
+    // block max -> one atomic per wave
+    double m = (r < n) ? acc : 0.0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0 && ymax2_bits) atomicMax(ymax2_bits, (unsigned long long)__double_as_longlong(m));
+}
+
+}  // namespace
+
+int gt_prep_matrix(gt_ctx* ctx, const void* Xdev, int64_t n, int d, int dtype, int DP, int64_t n_pad, float* Yp,
+                   double* xn, float* hneg, double* ymax2) {
+    if (ymax2) GT_HIP(ctx, hipMemsetAsync(ymax2, 0, sizeof(double), ctx->stream));
+    if (Yp) {
+        const int64_t total4 = n_pad * DP / 4;
+        int64_t blocks = ceil_div64(total4, 256);
+        if (blocks > 8192) blocks = 8192;
+        if (dtype == GT_F32)
+            hipLaunchKernelGGL(pad_convert_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream,
+                               (const float*)Xdev, n, d, DP, n_pad, Yp);
+        else
+            hipLaunchKernelGGL(pad_convert_kernel<double>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream,
+                               (const double*)Xdev, n, d, DP, n_pad, Yp);
+        GT_HIP(ctx, hipGetLastError());
+    }
+    const int64_t rows = hneg ? n_pad : n;
+    const int64_t nb = ceil_div64(rows, 256);
+    if (dtype == GT_F32)
+        hipLaunchKernelGGL(row_norm_kernel<float>, dim3((unsigned)nb), dim3(256), 0, ctx->stream, (const float*)Xdev, n,
+                           d, n_pad, xn, hneg, (unsigned long long*)ymax2);
+    else
+        hipLaunchKernelGGL(row_norm_kernel<double>, dim3((unsigned)nb), dim3(256), 0, ctx->stream, (const double*)Xdev,
+                           n, d, n_pad, xn, hneg, (unsigned long long*)ymax2);
+    GT_HIP(ctx, hipGetLastError());
+    return GT_OK;
+}
+
+int gt_prep_points(gt_ctx* ctx) {
+    StageSpan span(ctx, "prep", 2);
+    const int bn = gt_select_bn_for(ctx->DP);
+    ctx->n_pad = ceil_div64(ctx->n, bn) * bn;
+    GT_HIP(ctx, ctx->Yp.reserve(size_t(ctx->n_pad) * ctx->DP * sizeof(float)));
+    GT_HIP(ctx, ctx->xn.reserve(size_t(ctx->n) * sizeof(double)));
+    GT_HIP(ctx, ctx->hneg.reserve(size_t(ctx->n_pad) * sizeof(float)));
+    GT_HIP(ctx, ctx->ymax.reserve(sizeof(double)));
+    return gt_prep_matrix(ctx, ctx->X, ctx->n, ctx->d, ctx->dtype, ctx->DP, ctx->n_pad, ctx->Yp.as<float>(),
+                          ctx->xn.as<double>(), ctx->hneg.as<float>(), ctx->ymax.as<double>());
+}

@@ -1,0 +1,304 @@
+// Exact fp64 stage of the kNN search.
+//
+// rerank_kernel: for every query, recompute the squared distance of each candidate exactly the way
+//   scikit-learn's EuclideanArgKmin does - d2 = (|x|^2 + (-2 x.y)) + |y|^2 in float64 with float32 inputs
+//   upcast (sklearn:_argkmin.pyx.tp:497-505) - sort the candidates by (d2, index), and derive the
+//   completeness bound d2_lb: the candidate kernel rejected a database row only when its float32 score
+//   s~ = x.y - |y|^2/2 was <= thr, and |s~ - s| <= e (e from the fp32 accumulation bound), hence every
+//   rejected row has d2 = |x|^2 - 2 s >= |x|^2 - 2 (thr + e) =: d2_lb.  The first m table entries are
+//   the exact m nearest neighbours iff d2[m-1] < d2_lb; rows that fail go to
+// fallback_kernel: exhaustive float64 distances to every database row + an exact selection of the m
+//   smallest (d2, index) pairs (64-step bitwise search for the m-th key, ordered collection, sort).
+//
+// One wave per query; candidates are spread over lanes (MP/64 per lane), the query row sits in LDS as
+// float64.  Work is O(nq * MP * d) fp64 FMAs + a random gather of MP database rows per query - small
+// next to the O(nq * n * d) candidate pass.
+#include "gt_common.h"
+#include "gt_device.h"
+#include "gt_knn.h"
+
+namespace {
+
+constexpr unsigned long long kInfBits = 0x7FF0000000000000ull;
+
+template <typename T>
+__device__ __forceinline__ double dot_row(const double* __restrict__ xs, const T* __restrict__ y, int d) {
+    double acc = 0.0;
+    for (int k = 0; k < d; ++k) acc = fma(xs[k], double(y[k]), acc);
+    return acc;
+}
+template <>
+__device__ __forceinline__ double dot_row<float>(const double* __restrict__ xs, const float* __restrict__ y, int d) {
+    double acc = 0.0;
+    if ((d & 3) == 0 && ((reinterpret_cast<uintptr_t>(y) & 15) == 0)) {
+        const float4* y4 = reinterpret_cast<const float4*>(y);
+        for (int k = 0; k < d / 4; ++k) {
+            const float4 v = y4[k];
+            acc = fma(xs[4 * k + 0], double(v.x), acc);
+            acc = fma(xs[4 * k + 1], double(v.y), acc);
+            acc = fma(xs[4 * k + 2], double(v.z), acc);
+            acc = fma(xs[4 * k + 3], double(v.w), acc);
+        }
+    } else {
+        for (int k = 0; k < d; ++k) acc = fma(xs[k], double(y[k]), acc);
+    }
+    return acc;
+}
+
+// scikit-learn association: (|x|^2 + middle) + |y|^2, middle = -2 * x.y, clamped at 0
+__device__ __forceinline__ double sq_dist(double qn, double dot, double yn) {
+    double t = qn + (-2.0 * dot);
+    t = t + yn;
+    return t > 0.0 ? t : 0.0;
+}
+
+template <typename T, int NT2>
+__global__ __launch_bounds__(256) void rerank_kernel(const T* __restrict__ X, const int d, const double* __restrict__ xn,
+                                                     const T* __restrict__ Q, const double* __restrict__ qn,
+                                                     const int64_t q0, const int64_t nq,
+                                                     const uint64_t* __restrict__ lists, const int lstride,
+                                                     const uint32_t* __restrict__ counts,
+                                                     const double* __restrict__ ymax2p, const double err_coef,
+                                                     const int need_m, double* __restrict__ cand_d2,
+                                                     uint32_t* __restrict__ cand_j, uint32_t* __restrict__ cand_n,
+                                                     double* __restrict__ d2_lb, uint32_t* __restrict__ fb_count,
+                                                     int32_t* __restrict__ fb_rows, uint32_t* __restrict__ gflags) {
+    constexpr int MP = NT2 * 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int lane = threadIdx.x & 63;
+    const int w = threadIdx.x >> 6;
+    double* xs = reinterpret_cast<double*>(smem_raw) + size_t(w) * d;
+    const int64_t q = int64_t(blockIdx.x) * 4 + w;
+    if (q >= nq) return;   // whole wave exits together (q is wave-uniform); no block-level sync below
+
+    const T* xrow = Q + (q0 + q) * int64_t(d);
+    for (int k = lane; k < d; k += 64) xs[k] = double(xrow[k]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const double qnq = qn[q0 + q];
+    const uint32_t cnt = counts[q];
+    const uint32_t n = cnt < uint32_t(MP) ? cnt : uint32_t(MP);
+    const uint64_t* lp = lists + size_t(q) * lstride;
+
+    uint64_t hi[NT2], lo[NT2];
+#pragma unroll
+    for (int u = 0; u < NT2; ++u) {
+        const uint32_t c = uint32_t(u * 64 + lane);
+        hi[u] = kInfBits;
+        lo[u] = 0xFFFFFFFFull;
+        if (c < n) {
+            const uint32_t j = cand_index(lp[c]);
+            const double dot = dot_row<T>(xs, X + int64_t(j) * d, d);
+            hi[u] = (uint64_t)__double_as_longlong(sq_dist(qnq, dot, xn[j]));
+            lo[u] = j;
+        }
+    }
+    wave_bitonic_asc_pair<NT2>(hi, lo, lane);
+#pragma unroll
+    for (int u = 0; u < NT2; ++u) {
+        cand_d2[size_t(q) * MP + u * 64 + lane] = __longlong_as_double((long long)hi[u]);
+        cand_j[size_t(q) * MP + u * 64 + lane] = uint32_t(lo[u]);
+    }
+    // completeness bound
+    double lb = INFINITY;
+    if (cnt >= uint32_t(MP)) {
+        const double thr = double(cand_score(lp[MP - 1]));
+        const double y2 = *ymax2p;
+        const double e = err_coef * (0.5 * y2 + sqrt(qnq * y2));
+        lb = qnq - 2.0 * (thr + e);
+        lb -= 1e-9 * (qnq + y2);   // float64 rounding of the quantities above, with a wide margin
+    }
+    // d2 of the need_m-th neighbour (position need_m - 1)
+    const int pos = need_m - 1;
+    uint64_t sel = 0;
+#pragma unroll
+    for (int u = 0; u < NT2; ++u)
+        if ((pos >> 6) == u) sel = hi[u];
+    const double d2_need = __longlong_as_double((long long)__shfl((unsigned long long)sel, pos & 63));
+    const uint64_t second = __shfl((unsigned long long)hi[0], 1);
+    if (lane == 0) {
+        cand_n[q] = n;
+        d2_lb[q] = lb;
+        if (!(d2_need < lb)) {
+            const uint32_t slot = atomicAdd(fb_count, 1u);
+            fb_rows[slot] = int32_t(q);
+        }
+        if (n > 1 && second == 0ull) atomicOr(gflags, GT_FLAG_DUPLICATES);
+    }
+}
+
+// ---- exhaustive exact fallback: one workgroup per flagged query ---------------------------------
+template <typename T, int NT2>
+__global__ __launch_bounds__(256) void fallback_kernel(const T* __restrict__ X, const int64_t n, const int d,
+                                                       const double* __restrict__ xn, const T* __restrict__ Q,
+                                                       const double* __restrict__ qn, const int64_t q0,
+                                                       const int32_t* __restrict__ fb_rows, const int64_t row_off,
+                                                       const int need_m, double* __restrict__ scratch,
+                                                       double* __restrict__ cand_d2, uint32_t* __restrict__ cand_j,
+                                                       uint32_t* __restrict__ cand_n, double* __restrict__ d2_lb) {
+    constexpr int MP = NT2 * 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    double* xs = reinterpret_cast<double*>(smem_raw);                         // [d]
+    unsigned long long* out_hi = reinterpret_cast<unsigned long long*>(xs + d);   // [MP]
+    uint32_t* out_lo = reinterpret_cast<uint32_t*>(out_hi + MP);              // [MP]
+    int* red = reinterpret_cast<int*>(out_lo + MP);                           // [4]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = tid >> 6;
+    const int64_t q = fb_rows[row_off + blockIdx.x];
+    double* sc = scratch + size_t(blockIdx.x) * size_t(n);
+    const T* xrow = Q + (q0 + q) * int64_t(d);
+    for (int k = tid; k < d; k += 256) xs[k] = double(xrow[k]);
+    __syncthreads();
+    const double qnq = qn[q0 + q];
+    for (int64_t j = tid; j < n; j += 256) {
+        const double dot = dot_row<T>(xs, X + j * d, d);
+        sc[j] = sq_dist(qnq, dot, xn[j]);
+    }
+    __syncthreads();
+    // bitwise search for the need_m-th smallest key (float64 >= 0: bit pattern is order preserving)
+    unsigned long long v = 0ull;
+    for (int b = 63; b >= 0; --b) {
+        const unsigned long long trial = v | ((1ull << b) - 1ull);
+        int c = 0;
+        for (int64_t j = tid; j < n; j += 256)
+            c += ((unsigned long long)__double_as_longlong(sc[j]) <= trial) ? 1 : 0;
+        c = wave_sum_i32(c);
+        __syncthreads();
+        if (lane == 0) red[w] = c;
+        __syncthreads();
+        const int total = red[0] + red[1] + red[2] + red[3];
+        if (total < need_m) v |= (1ull << b);
+    }
+    __syncthreads();
+    // ordered collection by wave 0: all keys < v, then the lowest-index keys == v
+    if (w == 0) {
+        for (int p = lane; p < MP; p += 64) {
+            out_hi[p] = kInfBits;
+            out_lo[p] = 0xFFFFFFFFu;
+        }
+        int c_less_local = 0;
+        for (int64_t j = lane; j < n; j += 64)
+            c_less_local += ((unsigned long long)__double_as_longlong(sc[j]) < v) ? 1 : 0;
+        const int c_less = wave_sum_i32(c_less_local);
+        int base_less = 0, base_eq = 0;
+        const int eq_quota = need_m - c_less;
+        for (int64_t j0 = 0; j0 < n; j0 += 64) {
+            const int64_t j = j0 + lane;
+            unsigned long long key = ~0ull;
+            if (j < n) key = (unsigned long long)__double_as_longlong(sc[j]);
+            const bool is_less = (j < n) && key < v;
+            const bool is_eq = (j < n) && key == v;
+            int tl, te;
+            const int pl = wave_prefix_count(is_less, lane, tl);
+            const int pe = wave_prefix_count(is_eq, lane, te);
+            if (is_less) {
+                out_hi[base_less + pl] = key;
+                out_lo[base_less + pl] = uint32_t(j);
+            }
+            if (is_eq && base_eq + pe < eq_quota) {
+                out_hi[c_less + base_eq + pe] = key;
+                out_lo[c_less + base_eq + pe] = uint32_t(j);
+            }
+            base_less += tl;
+            base_eq += te;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        uint64_t hi[NT2], lo[NT2];
+#pragma unroll
+        for (int u = 0; u < NT2; ++u) {
+            hi[u] = out_hi[u * 64 + lane];
+            lo[u] = out_lo[u * 64 + lane];
+        }
+        wave_bitonic_asc_pair<NT2>(hi, lo, lane);
+#pragma unroll
+        for (int u = 0; u < NT2; ++u) {
+            cand_d2[size_t(q) * MP + u * 64 + lane] = __longlong_as_double((long long)hi[u]);
+            cand_j[size_t(q) * MP + u * 64 + lane] = uint32_t(lo[u]);
+        }
+        if (lane == 0) {
+            cand_n[q] = uint32_t(need_m);
+            d2_lb[q] = __longlong_as_double((long long)v);   // everything strictly closer is in the table
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void emit_knn_kernel(const double* __restrict__ cand_d2,
+                                                       const uint32_t* __restrict__ cand_j, const int MP,
+                                                       const int64_t nq, const int k, const int dtype,
+                                                       int64_t* __restrict__ out_idx, double* __restrict__ out_dist) {
+    const int64_t total = nq * k;
+    for (int64_t e = int64_t(blockIdx.x) * 256 + threadIdx.x; e < total; e += int64_t(gridDim.x) * 256) {
+        const int64_t q = e / k;
+        const int p = int(e % k);
+        const double d2 = cand_d2[q * MP + p];
+        // _rdist_to_dist in the input dtype (sklearn:_dist_metrics.pyx.tp:1018-1019)
+        const double dist = (dtype == GT_F32) ? double(sqrtf(float(d2))) : sqrt(d2);
+        out_idx[e] = int64_t(cand_j[q * MP + p]);
+        out_dist[e] = dist;
+    }
+}
+
+template <typename T>
+int rerank_t(gt_ctx* ctx, const RerankArgs& a) {
+    const int64_t blocks = ceil_div64(a.nq, 4);
+    const size_t lds = size_t(4) * a.d * sizeof(double);
+    if (a.MP == 128) {
+        hipLaunchKernelGGL((rerank_kernel<T, 2>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, (const T*)a.X,
+                           a.d, a.xn, (const T*)a.Q, a.qn, a.q0, a.nq, a.lists, a.lstride, a.counts, a.ymax2,
+                           a.err_coef, a.need_m, a.cand_d2, a.cand_j, a.cand_n, a.d2_lb, a.fb_count, a.fb_rows,
+                           a.gflags);
+    } else if (a.MP == 512) {
+        hipLaunchKernelGGL((rerank_kernel<T, 8>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, (const T*)a.X,
+                           a.d, a.xn, (const T*)a.Q, a.qn, a.q0, a.nq, a.lists, a.lstride, a.counts, a.ymax2,
+                           a.err_coef, a.need_m, a.cand_d2, a.cand_j, a.cand_n, a.d2_lb, a.fb_count, a.fb_rows,
+                           a.gflags);
+    } else {
+        GT_FAIL(ctx, GT_E_ARG, "rerank: unsupported table width");
+    }
+    GT_HIP(ctx, hipGetLastError());
+    return GT_OK;
+}
+
+template <typename T>
+int fallback_t(gt_ctx* ctx, const RerankArgs& a, int64_t n_rows, int64_t row_off, double* scratch) {
+    if (a.MP == 128) {
+        const size_t lds = size_t(a.d) * 8 + size_t(128) * 12 + 16;
+        hipLaunchKernelGGL((fallback_kernel<T, 2>), dim3((unsigned)n_rows), dim3(256), lds, ctx->stream, (const T*)a.X,
+                           a.n, a.d, a.xn, (const T*)a.Q, a.qn, a.q0, a.fb_rows, row_off, a.need_m, scratch, a.cand_d2,
+                           a.cand_j, a.cand_n, a.d2_lb);
+    } else if (a.MP == 512) {
+        const size_t lds = size_t(a.d) * 8 + size_t(512) * 12 + 16;
+        hipLaunchKernelGGL((fallback_kernel<T, 8>), dim3((unsigned)n_rows), dim3(256), lds, ctx->stream, (const T*)a.X,
+                           a.n, a.d, a.xn, (const T*)a.Q, a.qn, a.q0, a.fb_rows, row_off, a.need_m, scratch, a.cand_d2,
+                           a.cand_j, a.cand_n, a.d2_lb);
+    } else {
+        GT_FAIL(ctx, GT_E_ARG, "fallback: unsupported table width");
+    }
+    GT_HIP(ctx, hipGetLastError());
+    return GT_OK;
+}
+
+}  // namespace
+
+int gt_launch_rerank(gt_ctx* ctx, const RerankArgs& a) {
+    if (a.dtype == GT_F32) return rerank_t<float>(ctx, a);
+    return rerank_t<double>(ctx, a);
+}
+
+int gt_launch_fallback(gt_ctx* ctx, const RerankArgs& a, int64_t n_rows, int64_t row_off, double* scratch) {
+    if (a.dtype == GT_F32) return fallback_t<float>(ctx, a, n_rows, row_off, scratch);
+    return fallback_t<double>(ctx, a, n_rows, row_off, scratch);
+}
+
+int gt_launch_emit_knn(gt_ctx* ctx, const double* cand_d2, const uint32_t* cand_j, int MP, int64_t nq, int k,
+                       int dtype, int64_t* out_idx, double* out_dist) {
+    int64_t blocks = ceil_div64(nq * k, 256);
+    if (blocks > 16384) blocks = 16384;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(emit_knn_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, cand_d2, cand_j, MP, nq, k,
+                       dtype, out_idx, out_dist);
+    GT_HIP(ctx, hipGetLastError());
+    return GT_OK;
+}

@@ -1,0 +1,1103 @@
+// Sparse tail of the kNN graph build: bandwidths, radius pass bookkeeping, alpha-decay affinities with
+// thresholding, symmetrisation (transpose by triplet exchange + per-row sort/merge), anisotropy and the
+// row-stochastic diffusion operator.  All HBM-bound streaming kernels; one wave per matrix row.
+//
+// Reference semantics (graphtools/graphs.py:886-911, 450-559; base.py:557-592, 629-666):
+//   bw_i  = max(D[i, knn] * scale, eps)            (or the user bandwidth * scale)
+//   r_i   = bw_i * (-ln thresh)^(1/decay)
+//   K0_ij = exp(-(D_ij / bw_i)^decay), NaN -> 1, kept iff >= thresh, for every j with D_ij <= r_i
+//   K     = sym(K0);  K_ij /= (q_i q_j)^alpha;  P = diag(1/sum_j|K_ij|) K;  degree = K 1
+#include <cfloat>
+
+#include "gt_common.h"
+#include "gt_device.h"
+#include "gt_knn.h"
+#include "gt_knn_select.h"
+
+struct Triplet {
+    uint32_t row;   // destination (global) row
+    uint32_t col;   // global column
+    double val;
+};
+static_assert(sizeof(Triplet) == 16, "triplet layout");
+
+struct GraphState {
+    gt_knn_params p{};
+    std::vector<double> bw_host;
+    int world = 1, rank = 0;
+    std::vector<int64_t> splits;
+    int64_t r0 = 0, r1 = 0, nloc = 0;
+    bool begun = false, finished = false;
+    int need_m = 0;
+    int limit = 0;          // eligible table entries per row
+    double radius_factor = 0.0;
+    // per-row
+    DevBuf bw, bw_user, rowsrc, lenN, lenT, cursor, off, outlen, indptr, degree;
+    // radius pass
+    DevBuf over_rows, over_count, rthr, rlists, rcounts, rK, rmax;
+    int64_t n_over = 0;
+    int32_t rcap = 0;
+    int64_t radius_retries = 0;
+    // exchange
+    DevBuf sendcnt, sendcur, selfbuf, splits_dev;
+    std::vector<int64_t> send_counts_host;
+    // merge
+    DevBuf Ukey, Uval, Vkey, Vval, bigrows, bigcount, bigscratch_k, bigscratch_v;
+    DevBuf indices, Kdata, Pdata, flags;
+    int64_t nnz0 = 0, nnz = 0;
+};
+
+void gt_free_graph_state(gt_ctx* ctx) {
+    if (!ctx->graph) return;
+    GraphState* g = ctx->graph;
+    for (DevBuf* b : {&g->bw, &g->bw_user, &g->rowsrc, &g->lenN, &g->lenT, &g->cursor, &g->off, &g->outlen, &g->indptr,
+                      &g->degree, &g->over_rows, &g->over_count, &g->rthr, &g->rlists, &g->rcounts, &g->rK, &g->rmax,
+                      &g->sendcnt, &g->sendcur, &g->selfbuf, &g->splits_dev, &g->Ukey, &g->Uval, &g->Vkey, &g->Vval,
+                      &g->bigrows, &g->bigcount, &g->bigscratch_k, &g->bigscratch_v, &g->indices, &g->Kdata, &g->Pdata,
+                      &g->flags})
+        b->release();
+    delete g;
+    ctx->graph = nullptr;
+}
+
+namespace {
+
+constexpr int kMaxWorld = 64;
+
+struct Splits {
+    int64_t s[kMaxWorld + 1];
+    int world;
+};
+
+__device__ __forceinline__ int owner_of(const Splits& sp, int64_t row) {
+    int o = 0;
+    for (int r = 1; r < sp.world; ++r) o += (row >= sp.s[r]) ? 1 : 0;
+    return o;
+}
+
+__device__ __forceinline__ double dist_from_d2(double d2, int dtype) {
+    return (dtype == GT_F32) ? double(sqrtf(float(d2))) : sqrt(d2);
+}
+
+__device__ __forceinline__ double affinity(double dist, double bw, double decay) {
+    double w = exp(-pow(dist / bw, decay));
+    return (w != w) ? 1.0 : w;   // NaN -> 1 (graphs.py:505-506)
+}
+
+// ---- A0: bandwidth, radius, classification ------------------------------------------------------
+__global__ __launch_bounds__(256) void bandwidth_kernel(
+    const int64_t nloc, const int64_t r0, const int MP, const int kprime, const int dtype, const double* __restrict__ cand_d2,
+    const double* __restrict__ d2_lb, const double* __restrict__ xn, const double* __restrict__ ymax2p,
+    const double err_coef, const double* __restrict__ bw_user, const int64_t bw_len, const double bw_scale,
+    const int use_radius, const double radius_factor, double* __restrict__ bw_out, int32_t* __restrict__ rowsrc,
+    int32_t* __restrict__ over_rows, uint32_t* __restrict__ over_count, float* __restrict__ rthr) {
+    const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= nloc) return;
+    double bw;
+    if (bw_len == 0)
+        bw = dist_from_d2(cand_d2[i * MP + (kprime - 1)], dtype) * bw_scale;
+    else
+        bw = (bw_len == 1 ? bw_user[0] : bw_user[r0 + i]) * bw_scale;
+    bw = fmax(bw, DBL_EPSILON);
+    bw_out[i] = bw;
+    int32_t src = -1;
+    if (use_radius) {
+        const double r = bw * radius_factor * (1.0 + 1e-6);
+        const double r2 = r * r;
+        if (!(r2 < d2_lb[i])) {
+            const uint32_t slot = atomicAdd(over_count, 1u);
+            over_rows[slot] = int32_t(r0 + i);
+            src = int32_t(slot);
+            const double qn = xn[r0 + i];
+            const double y2 = *ymax2p;
+            const double e = err_coef * (0.5 * y2 + sqrt(qn * y2));
+            const double x = 0.5 * (qn - r2) - e - 1e-9 * (qn + y2);
+            float f = float(x);
+            if (double(f) >= x) f = nextafterf(f, -INFINITY);
+            rthr[slot] = f;
+        }
+    }
+    rowsrc[i] = src;
+}
+
+__global__ void max_u32_kernel(const uint32_t* __restrict__ v, const int64_t n, uint32_t* __restrict__ out) {
+    uint32_t m = 0;
+    for (int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += int64_t(gridDim.x) * 256) m = max(m, v[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, m);
+}
+
+// ---- A1: affinities + counts ----------------------------------------------------------------------
+// One wave per local row.  Table rows: K overwrites cand_d2 in place (-1 marks a dropped slot).
+// Radius rows: exact float64 distance for every collected candidate, K into rK.
+template <typename T>
+__global__ __launch_bounds__(256) void affinity_kernel(
+    const int64_t nloc, const int64_t r0, const T* __restrict__ X, const int d, const double* __restrict__ xn,
+    const int dtype, const int MP, const int limit, double* __restrict__ cand_d2, const uint32_t* __restrict__ cand_j,
+    const uint32_t* __restrict__ cand_n, const int32_t* __restrict__ rowsrc, const uint64_t* __restrict__ rlists,
+    const uint32_t* __restrict__ rcounts, const int32_t rcap, double* __restrict__ rK, const double* __restrict__ bw,
+    const double decay, const int binary, const double thresh, const int count_owners, const Splits sp,
+    int32_t* __restrict__ lenN, unsigned long long* __restrict__ sendcnt) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int lane = threadIdx.x & 63;
+    const int w = threadIdx.x >> 6;
+    double* xs = reinterpret_cast<double*>(smem_raw) + size_t(w) * d;
+    const int64_t i = int64_t(blockIdx.x) * 4 + w;
+    if (i >= nloc) return;
+    const int32_t src = rowsrc[i];
+    const double bwi = bw[i];
+    int kept = 0;
+    int owner_cnt = 0;   // lane o accumulates the count for owner o (world <= 64)
+    if (src < 0) {
+        uint32_t n = cand_n[i];
+        if (n > uint32_t(limit)) n = uint32_t(limit);
+        for (uint32_t e0 = 0; e0 < n; e0 += 64) {
+            const uint32_t e = e0 + lane;
+            bool keep = false;
+            uint32_t j = 0;
+            if (e < n) {
+                const double d2 = cand_d2[i * MP + e];
+                j = cand_j[i * MP + e];
+                double kv = 1.0;
+                if (!binary) kv = affinity(dist_from_d2(d2, dtype), bwi, decay);
+                keep = binary || (kv >= thresh);
+                cand_d2[i * MP + e] = keep ? kv : -1.0;
+            }
+            kept += __popcll(__ballot(keep));
+            if (count_owners) {
+                const int o = keep ? owner_of(sp, j) : -1;
+                for (int r = 0; r < sp.world; ++r) {
+                    const int c = __popcll(__ballot(o == r));
+                    if (lane == r) owner_cnt += c;
+                }
+            }
+        }
+        // slots beyond the eligible range are dropped
+        for (uint32_t e = n + lane; e < uint32_t(MP); e += 64) cand_d2[i * MP + e] = -1.0;
+    } else {
+        const T* xrow = X + (r0 + i) * int64_t(d);
+        for (int k = lane; k < d; k += 64) xs[k] = double(xrow[k]);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const double qn = xn[r0 + i];
+        uint32_t n = rcounts[src];
+        if (n > uint32_t(rcap)) n = uint32_t(rcap);
+        const uint64_t* lp = rlists + size_t(src) * rcap;
+        double* kp = rK + size_t(src) * rcap;
+        for (uint32_t e0 = 0; e0 < n; e0 += 64) {
+            const uint32_t e = e0 + lane;
+            bool keep = false;
+            uint32_t j = 0;
+            if (e < n) {
+                j = cand_index(lp[e]);
+                const T* y = X + int64_t(j) * d;
+                double dot = 0.0;
+                for (int k = 0; k < d; ++k) dot = fma(xs[k], double(y[k]), dot);
+                double t = qn + (-2.0 * dot);
+                t = t + xn[j];
+                t = t > 0.0 ? t : 0.0;
+                const double kv = affinity(dist_from_d2(t, dtype), bwi, decay);
+                keep = kv >= thresh;
+                kp[e] = keep ? kv : -1.0;
+            }
+            kept += __popcll(__ballot(keep));
+            if (count_owners) {
+                const int o = keep ? owner_of(sp, j) : -1;
+                for (int r = 0; r < sp.world; ++r) {
+                    const int c = __popcll(__ballot(o == r));
+                    if (lane == r) owner_cnt += c;
+                }
+            }
+        }
+    }
+    if (lane == 0) lenN[i] = kept;
+    if (count_owners && lane < sp.world && owner_cnt > 0) atomicAdd(&sendcnt[lane], (unsigned long long)owner_cnt);
+}
+
+// ---- A2t: transposed triplets, bucketed by destination rank --------------------------------------
+struct Buckets {
+    int64_t base[kMaxWorld];
+};
+
+__global__ __launch_bounds__(256) void emit_triplets_kernel(
+    const int64_t nloc, const int64_t r0, const int MP, const double* __restrict__ cand_k,
+    const uint32_t* __restrict__ cand_j, const int32_t* __restrict__ rowsrc, const uint64_t* __restrict__ rlists,
+    const uint32_t* __restrict__ rcounts, const int32_t rcap, const double* __restrict__ rK, const Splits sp,
+    const Buckets bk, unsigned long long* __restrict__ sendcur, Triplet* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int w = threadIdx.x >> 6;
+    const int64_t i = int64_t(blockIdx.x) * 4 + w;
+    if (i >= nloc) return;
+    const int32_t src = rowsrc[i];
+    uint32_t n;
+    const double* kv;
+    if (src < 0) {
+        n = uint32_t(MP);
+        kv = cand_k + i * MP;
+    } else {
+        n = rcounts[src];
+        if (n > uint32_t(rcap)) n = uint32_t(rcap);
+        kv = rK + size_t(src) * rcap;
+    }
+    for (uint32_t e0 = 0; e0 < n; e0 += 64) {
+        const uint32_t e = e0 + lane;
+        double v = -1.0;
+        uint32_t j = 0;
+        if (e < n) {
+            v = kv[e];
+            j = (src < 0) ? cand_j[i * MP + e] : cand_index(rlists[size_t(src) * rcap + e]);
+        }
+        const bool keep = v >= 0.0;
+        const int o = keep ? owner_of(sp, j) : -1;
+        for (int r = 0; r < sp.world; ++r) {
+            const unsigned long long m = __ballot(o == r);
+            if (m == 0ull) continue;
+            unsigned long long base = 0;
+            if (lane == 0) base = atomicAdd(&sendcur[r], (unsigned long long)__popcll(m));
+            base = __shfl(base, 0);
+            if (o == r) {
+                const int64_t pos = bk.base[r] + int64_t(base) + __popcll(m & ((1ull << lane) - 1ull));
+                Triplet t;
+                t.row = j;
+                t.col = uint32_t(r0 + i);
+                t.val = v;
+                out[pos] = t;
+            }
+        }
+    }
+}
+
+// ---- R1: count received triplets per local row ---------------------------------------------------
+__global__ __launch_bounds__(256) void count_recv_kernel(const Triplet* __restrict__ recv, const int64_t n_recv,
+                                                         const int64_t r0, int32_t* __restrict__ lenT) {
+    for (int64_t t = int64_t(blockIdx.x) * 256 + threadIdx.x; t < n_recv; t += int64_t(gridDim.x) * 256)
+        atomicAdd(&lenT[int64_t(recv[t].row) - r0], 1);
+}
+
+// ---- scans (int32 in -> int64 exclusive out, with total in out[n]) --------------------------------
+__global__ __launch_bounds__(256) void scan_block_kernel(const int32_t* __restrict__ a, const int32_t* __restrict__ b,
+                                                         const int64_t n, int64_t* __restrict__ out,
+                                                         int64_t* __restrict__ block_sums) {
+    __shared__ int64_t wsum[4];
+    const int64_t base = int64_t(blockIdx.x) * 1024;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int64_t v[4];
+    int64_t tsum = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int64_t idx = base + int64_t(threadIdx.x) * 4 + u;
+        v[u] = idx < n ? int64_t(a[idx]) + (b ? int64_t(b[idx]) : 0) : 0;
+        tsum += v[u];
+    }
+    // inclusive scan of tsum across the wave
+    int64_t inc = tsum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int64_t up = __shfl_up(inc, o);
+        if (lane >= o) inc += up;
+    }
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    int64_t woff = 0;
+    for (int r = 0; r < w; ++r) woff += wsum[r];
+    int64_t run = woff + inc - tsum;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int64_t idx = base + int64_t(threadIdx.x) * 4 + u;
+        if (idx < n) out[idx] = run;
+        run += v[u];
+    }
+    if (threadIdx.x == 255) block_sums[blockIdx.x] = woff + inc;
+}
+
+__global__ void scan_sums_kernel(int64_t* __restrict__ block_sums, const int64_t nb) {
+    // single thread: nb <= a few thousand
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        int64_t run = 0;
+        for (int64_t i = 0; i < nb; ++i) {
+            const int64_t v = block_sums[i];
+            block_sums[i] = run;
+            run += v;
+        }
+        block_sums[nb] = run;
+    }
+}
+
+__global__ __launch_bounds__(256) void scan_add_kernel(int64_t* __restrict__ out, const int64_t n,
+                                                       const int64_t* __restrict__ block_sums, const int64_t nb) {
+    const int64_t base = int64_t(blockIdx.x) * 1024;
+    const int64_t add = block_sums[blockIdx.x];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int64_t idx = base + int64_t(threadIdx.x) * 4 + u;
+        if (idx < n) out[idx] += add;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = block_sums[nb];
+}
+
+// ---- A2n: N part of the union rows ---------------------------------------------------------------
+__global__ __launch_bounds__(256) void fill_rows_kernel(
+    const int64_t nloc, const int MP, const double* __restrict__ cand_k, const uint32_t* __restrict__ cand_j,
+    const int32_t* __restrict__ rowsrc, const uint64_t* __restrict__ rlists, const uint32_t* __restrict__ rcounts,
+    const int32_t rcap, const double* __restrict__ rK, const int64_t* __restrict__ off, uint32_t* __restrict__ Ukey,
+    double* __restrict__ Uval) {
+    const int lane = threadIdx.x & 63;
+    const int w = threadIdx.x >> 6;
+    const int64_t i = int64_t(blockIdx.x) * 4 + w;
+    if (i >= nloc) return;
+    const int32_t src = rowsrc[i];
+    uint32_t n;
+    const double* kv;
+    if (src < 0) {
+        n = uint32_t(MP);
+        kv = cand_k + i * MP;
+    } else {
+        n = rcounts[src];
+        if (n > uint32_t(rcap)) n = uint32_t(rcap);
+        kv = rK + size_t(src) * rcap;
+    }
+    int64_t pos = off[i];
+    for (uint32_t e0 = 0; e0 < n; e0 += 64) {
+        const uint32_t e = e0 + lane;
+        double v = -1.0;
+        uint32_t j = 0;
+        if (e < n) {
+            v = kv[e];
+            j = (src < 0) ? cand_j[i * MP + e] : cand_index(rlists[size_t(src) * rcap + e]);
+        }
+        const bool keep = v >= 0.0;
+        int total;
+        const int p = wave_prefix_count(keep, lane, total);
+        if (keep) {
+            Ukey[pos + p] = (j << 1);
+            Uval[pos + p] = v;
+        }
+        pos += total;
+    }
+}
+
+// ---- R2: T part of the union rows ----------------------------------------------------------------
+__global__ __launch_bounds__(256) void fill_recv_kernel(const Triplet* __restrict__ recv, const int64_t n_recv,
+                                                        const int64_t r0, const int64_t* __restrict__ off,
+                                                        const int32_t* __restrict__ lenN, int32_t* __restrict__ cursor,
+                                                        uint32_t* __restrict__ Ukey, double* __restrict__ Uval) {
+    for (int64_t t = int64_t(blockIdx.x) * 256 + threadIdx.x; t < n_recv; t += int64_t(gridDim.x) * 256) {
+        const Triplet tr = recv[t];
+        const int64_t il = int64_t(tr.row) - r0;
+        const int slot = atomicAdd(&cursor[il], 1);
+        const int64_t pos = off[il] + lenN[il] + slot;
+        Ukey[pos] = (tr.col << 1) | 1u;
+        Uval[pos] = tr.val;
+    }
+}
+
+// ---- S5: per-row sort by column + merge of (K0, K0^T) pairs ---------------------------------------
+__device__ __forceinline__ double merge_values(double a, double b, int symm, double theta) {
+    switch (symm) {
+        case GT_SYMM_ADD: return (a + b) / 2;
+        case GT_SYMM_MUL: return a * b;
+        case GT_SYMM_MNN: return theta * fmin(a, b) + (1 - theta) * fmax(a, b);
+        default: return a;
+    }
+}
+
+// merge a sorted key/value sequence held in registers (position p = t*64 + lane); returns the number of
+// merged entries written to (Vk, Vv).
+template <int NT>
+__device__ __forceinline__ int merge_sorted_regs(const uint64_t (&hi)[NT], const uint64_t (&lo)[NT], const int lane,
+                                                 const int symm, const double theta, uint32_t* __restrict__ Vk,
+                                                 double* __restrict__ Vv) {
+    constexpr uint64_t SENT = ~0ull;
+    int count = 0;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const uint64_t key = hi[t];
+        const uint64_t val = lo[t];
+        uint64_t pk = __shfl_up((unsigned long long)key, 1);
+        const uint64_t pk_edge = (t > 0) ? __shfl((unsigned long long)hi[t > 0 ? t - 1 : 0], 63) : SENT;
+        if (lane == 0) pk = pk_edge;
+        uint64_t nk = __shfl_down((unsigned long long)key, 1);
+        uint64_t nv = __shfl_down((unsigned long long)val, 1);
+        const uint64_t nk_edge = (t < NT - 1) ? __shfl((unsigned long long)hi[t < NT - 1 ? t + 1 : t], 0) : SENT;
+        const uint64_t nv_edge = (t < NT - 1) ? __shfl((unsigned long long)lo[t < NT - 1 ? t + 1 : t], 0) : 0ull;
+        if (lane == 63) {
+            nk = nk_edge;
+            nv = nv_edge;
+        }
+        const bool valid = key != SENT;
+        const uint64_t col = key >> 1;
+        const bool first = valid && (pk == SENT || (pk >> 1) != col);
+        const bool pair = first && nk != SENT && (nk >> 1) == col;
+        const int tag = int(key & 1ull);
+        const double v = __longlong_as_double((long long)val);
+        const double a = tag == 0 ? v : 0.0;
+        const double b = tag == 1 ? v : (pair ? __longlong_as_double((long long)nv) : 0.0);
+        const double m = merge_values(a, b, symm, theta);
+        const bool emit = first && m != 0.0;
+        int total;
+        const int p = wave_prefix_count(emit, lane, total);
+        if (emit) {
+            Vk[count + p] = uint32_t(col);
+            Vv[count + p] = m;
+        }
+        count += total;
+    }
+    return count;
+}
+
+template <int NT>
+__device__ __forceinline__ int sort_merge_row(const uint32_t* __restrict__ Uk, const double* __restrict__ Uv,
+                                              const int L, const int lane, const int symm, const double theta,
+                                              uint32_t* __restrict__ Vk, double* __restrict__ Vv) {
+    uint64_t hi[NT], lo[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int p = t * 64 + lane;
+        hi[t] = ~0ull;
+        lo[t] = 0ull;
+        if (p < L) {
+            hi[t] = uint64_t(Uk[p]);
+            lo[t] = (uint64_t)__double_as_longlong(Uv[p]);
+        }
+    }
+    wave_bitonic_asc_pair<NT>(hi, lo, lane);
+    return merge_sorted_regs<NT>(hi, lo, lane, symm, theta, Vk, Vv);
+}
+
+constexpr int kBigRow = 512;   // longer rows take the global-memory sort (big_sort_kernel)
+
+__global__ __launch_bounds__(256) void sort_merge_kernel(const int64_t nloc, const int64_t* __restrict__ off,
+                                                         const uint32_t* __restrict__ Ukey, const double* __restrict__ Uval,
+                                                         const int symm, const double theta, uint32_t* __restrict__ Vkey,
+                                                         double* __restrict__ Vval, int32_t* __restrict__ outlen,
+                                                         int32_t* __restrict__ bigrows, uint32_t* __restrict__ bigcount) {
+    const int lane = threadIdx.x & 63;
+    const int w = threadIdx.x >> 6;
+    const int64_t i = int64_t(blockIdx.x) * 4 + w;
+    if (i >= nloc) return;
+    const int64_t o0 = off[i];
+    const int64_t L64 = off[i + 1] - o0;
+    if (L64 > kBigRow) {
+        if (lane == 0) {
+            const uint32_t slot = atomicAdd(bigcount, 1u);
+            bigrows[slot] = int32_t(i);
+        }
+        return;
+    }
+    const int L = int(L64);
+    const uint32_t* Uk = Ukey + o0;
+    const double* Uv = Uval + o0;
+    uint32_t* Vk = Vkey + o0;
+    double* Vv = Vval + o0;
+    int c;
+    if (L <= 64)
+        c = sort_merge_row<1>(Uk, Uv, L, lane, symm, theta, Vk, Vv);
+    else if (L <= 128)
+        c = sort_merge_row<2>(Uk, Uv, L, lane, symm, theta, Vk, Vv);
+    else if (L <= 256)
+        c = sort_merge_row<4>(Uk, Uv, L, lane, symm, theta, Vk, Vv);
+    else
+        c = sort_merge_row<8>(Uk, Uv, L, lane, symm, theta, Vk, Vv);
+    if (lane == 0) outlen[i] = c;
+}
+
+// big rows: bitonic sort in global scratch (one workgroup per row), then a separate merge kernel
+__global__ __launch_bounds__(1024) void big_sort_kernel(const int32_t* __restrict__ bigrows, const int64_t* __restrict__ off,
+                                                        const uint32_t* __restrict__ Ukey, const double* __restrict__ Uval,
+                                                        const int64_t* __restrict__ scratch_off,
+                                                        uint32_t* __restrict__ Sk, double* __restrict__ Sv) {
+    const int64_t i = bigrows[blockIdx.x];
+    const int64_t o0 = off[i];
+    const int64_t L = off[i + 1] - o0;
+    const int64_t s0 = scratch_off[blockIdx.x];
+    const int64_t P = scratch_off[blockIdx.x + 1] - s0;   // power of two >= L
+    uint32_t* k = Sk + s0;
+    double* v = Sv + s0;
+    for (int64_t p = threadIdx.x; p < P; p += 1024) {
+        k[p] = p < L ? Ukey[o0 + p] : 0xFFFFFFFFu;
+        v[p] = p < L ? Uval[o0 + p] : 0.0;
+    }
+    __syncthreads();
+    for (int64_t kk = 2; kk <= P; kk <<= 1) {
+        for (int64_t j = kk >> 1; j > 0; j >>= 1) {
+            for (int64_t p = threadIdx.x; p < P; p += 1024) {
+                const int64_t q = p ^ j;
+                if (q > p) {
+                    const bool asc = ((p & kk) == 0);
+                    const uint32_t a = k[p], b = k[q];
+                    if ((a > b) == asc) {
+                        k[p] = b;
+                        k[q] = a;
+                        const double t = v[p];
+                        v[p] = v[q];
+                        v[q] = t;
+                    }
+                }
+            }
+            __threadfence_block();
+            __syncthreads();
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void big_merge_kernel(const int32_t* __restrict__ bigrows, const int64_t* __restrict__ off,
+                                                       const int64_t* __restrict__ scratch_off,
+                                                       const uint32_t* __restrict__ Sk, const double* __restrict__ Sv,
+                                                       const int symm, const double theta, uint32_t* __restrict__ Vkey,
+                                                       double* __restrict__ Vval, int32_t* __restrict__ outlen) {
+    const int lane = threadIdx.x;
+    const int64_t i = bigrows[blockIdx.x];
+    const int64_t o0 = off[i];
+    const int64_t L = off[i + 1] - o0;
+    const uint32_t* k = Sk + scratch_off[blockIdx.x];
+    const double* v = Sv + scratch_off[blockIdx.x];
+    int count = 0;
+    for (int64_t p0 = 0; p0 < L; p0 += 64) {
+        const int64_t p = p0 + lane;
+        bool emit = false;
+        uint32_t col = 0;
+        double m = 0.0;
+        if (p < L) {
+            const uint32_t key = k[p];
+            col = key >> 1;
+            const bool first = (p == 0) || ((k[p - 1] >> 1) != col);
+            const bool pair = first && (p + 1 < L) && ((k[p + 1] >> 1) == col);
+            const int tag = int(key & 1u);
+            const double a = tag == 0 ? v[p] : 0.0;
+            const double b = tag == 1 ? v[p] : (pair ? v[p + 1] : 0.0);
+            m = merge_values(a, b, symm, theta);
+            emit = first && m != 0.0;
+        }
+        int total;
+        const int pp = wave_prefix_count(emit, lane, total);
+        if (emit) {
+            Vkey[o0 + count + pp] = col;
+            Vval[o0 + count + pp] = m;
+        }
+        count += total;
+    }
+    if (lane == 0) outlen[i] = count;
+}
+
+// ---- S6: compaction to CSR, degrees, anisotropy, P -----------------------------------------------
+__global__ __launch_bounds__(256) void compact_kernel(const int64_t nloc, const int64_t r0, const int64_t* __restrict__ off,
+                                                      const int32_t* __restrict__ outlen, const int64_t* __restrict__ indptr,
+                                                      const uint32_t* __restrict__ Vkey, const double* __restrict__ Vval,
+                                                      int32_t* __restrict__ indices, double* __restrict__ Kdata,
+                                                      double* __restrict__ degree, uint32_t* __restrict__ flags) {
+    const int lane = threadIdx.x & 63;
+    const int w = threadIdx.x >> 6;
+    const int64_t i = int64_t(blockIdx.x) * 4 + w;
+    if (i >= nloc) return;
+    const int64_t s = off[i];
+    const int64_t dst = indptr[i];
+    const int n = outlen[i];
+    double sum = 0.0;
+    bool has_diag = false;
+    for (int e = lane; e < n; e += 64) {
+        const uint32_t c = Vkey[s + e];
+        const double v = Vval[s + e];
+        indices[dst + e] = int32_t(c);
+        Kdata[dst + e] = v;
+        sum += v;
+        has_diag |= (int64_t(c) == r0 + i) && (v != 0.0);
+    }
+    sum = wave_sum_f64(sum);
+    const bool any_diag = __ballot(has_diag) != 0ull;
+    if (lane == 0) {
+        degree[i] = sum;
+        if (!any_diag) atomicOr(flags, GT_FLAG_ZERO_DIAGONAL);
+    }
+}
+
+__global__ __launch_bounds__(256) void anisotropy_kernel(const int64_t nloc, const int64_t r0,
+                                                         const int64_t* __restrict__ indptr,
+                                                         const int32_t* __restrict__ indices, double* __restrict__ Kdata,
+                                                         const double* __restrict__ degree_all, const double alpha,
+                                                         double* __restrict__ degree_out) {
+    const int lane = threadIdx.x & 63;
+    const int w = threadIdx.x >> 6;
+    const int64_t i = int64_t(blockIdx.x) * 4 + w;
+    if (i >= nloc) return;
+    const int64_t s = indptr[i], e1 = indptr[i + 1];
+    const double qi = degree_all[r0 + i];
+    double sum = 0.0;
+    for (int64_t e = s + lane; e < e1; e += 64) {
+        const double v = Kdata[e] / pow(qi * degree_all[indices[e]], alpha);
+        Kdata[e] = v;
+        sum += v;
+    }
+    sum = wave_sum_f64(sum);
+    if (lane == 0) degree_out[i] = sum;
+}
+
+__global__ __launch_bounds__(256) void normalize_kernel(const int64_t nloc, const int64_t* __restrict__ indptr,
+                                                        const double* __restrict__ Kdata, double* __restrict__ Pdata) {
+    const int lane = threadIdx.x & 63;
+    const int w = threadIdx.x >> 6;
+    const int64_t i = int64_t(blockIdx.x) * 4 + w;
+    if (i >= nloc) return;
+    const int64_t s = indptr[i], e1 = indptr[i + 1];
+    double sum = 0.0;
+    for (int64_t e = s + lane; e < e1; e += 64) sum += fabs(Kdata[e]);
+    sum = wave_sum_f64(sum);
+    // sklearn inplace_csr_row_normalize_l1: rows with zero sum are left untouched
+    for (int64_t e = s + lane; e < e1; e += 64) Pdata[e] = (sum != 0.0) ? Kdata[e] / sum : Kdata[e];
+}
+
+int exclusive_scan(gt_ctx* ctx, const int32_t* a, const int32_t* b, int64_t n, int64_t* out, DevBuf& tmp) {
+    const int64_t nb = ceil_div64(n, 1024);
+    GT_HIP(ctx, tmp.reserve(size_t(nb + 1) * sizeof(int64_t)));
+    hipLaunchKernelGGL(scan_block_kernel, dim3((unsigned)nb), dim3(256), 0, ctx->stream, a, b, n, out, tmp.as<int64_t>());
+    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(64), 0, ctx->stream, tmp.as<int64_t>(), nb);
+    hipLaunchKernelGGL(scan_add_kernel, dim3((unsigned)nb), dim3(256), 0, ctx->stream, out, n, tmp.as<int64_t>(), nb);
+    GT_HIP(ctx, hipGetLastError());
+    return GT_OK;
+}
+
+Splits make_splits(const GraphState* g) {
+    Splits sp;
+    sp.world = g->world;
+    for (int r = 0; r <= g->world; ++r) sp.s[r] = g->splits[r];
+    return sp;
+}
+
+template <typename T>
+void launch_affinity(gt_ctx* ctx, GraphState* g, KnnWork* k, int binary, double decay, double thresh, int count_owners) {
+    const int64_t blocks = ceil_div64(g->nloc, 4);
+    const size_t lds = size_t(4) * ctx->d * sizeof(double);
+    hipLaunchKernelGGL((affinity_kernel<T>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, g->nloc, g->r0,
+                       (const T*)ctx->X, ctx->d, ctx->xn.as<double>(), ctx->dtype, k->MP, g->limit, k->cand_d2.as<double>(),
+                       k->cand_j.as<uint32_t>(), k->cand_n.as<uint32_t>(), g->rowsrc.as<int32_t>(),
+                       g->rlists.as<uint64_t>(), g->rcounts.as<uint32_t>(), g->rcap, g->rK.as<double>(),
+                       g->bw.as<double>(), decay, binary, thresh, count_owners, make_splits(g), g->lenN.as<int32_t>(),
+                       g->sendcnt.as<unsigned long long>());
+}
+
+}  // namespace
+
+// ================================================================================================
+extern "C" int gt_graph_begin(gt_ctx* ctx, const gt_knn_params* params, int32_t world, int32_t rank,
+                              const int64_t* row_splits, int64_t* send_counts) {
+    if (!ctx || !params) return GT_E_ARG;
+    GT_HIP(ctx, hipSetDevice(ctx->device));
+    ctx->reset_stages();
+    if (ctx->n <= 0) GT_FAIL(ctx, GT_E_STATE, "gt_graph_begin: no points bound");
+    if (world < 1 || world > kMaxWorld || rank < 0 || rank >= world || !row_splits || !send_counts)
+        GT_FAIL(ctx, GT_E_ARG, "gt_graph_begin: bad world/rank/row_splits");
+    if (row_splits[0] != 0 || row_splits[world] != ctx->n) GT_FAIL(ctx, GT_E_ARG, "row_splits must cover [0, n]");
+    for (int r = 0; r < world; ++r)
+        if (row_splits[r + 1] < row_splits[r]) GT_FAIL(ctx, GT_E_ARG, "row_splits must be ascending");
+    if (params->knn < 1) GT_FAIL(ctx, GT_E_ARG, "knn must be >= 1");
+    if (!ctx->graph) ctx->graph = new GraphState();
+    GraphState* g = ctx->graph;
+    g->p = *params;
+    g->world = world;
+    g->rank = rank;
+    g->splits.assign(row_splits, row_splits + world + 1);
+    g->r0 = row_splits[rank];
+    g->r1 = row_splits[rank + 1];
+    g->nloc = g->r1 - g->r0;
+    g->begun = false;
+    g->finished = false;
+    g->n_over = 0;
+    g->radius_retries = 0;
+    g->rcap = 0;
+    if (g->nloc <= 0) GT_FAIL(ctx, GT_E_ARG, "gt_graph_begin: this rank owns no rows");
+    const bool binary = std::isnan(params->decay) || params->thresh == 1.0;
+    double thresh = params->thresh;
+    if (!binary) {
+        if (thresh <= 0 && params->knn_max <= 0)
+            GT_FAIL(ctx, GT_E_ARG, "thresh <= 0 needs knn_max (use the exact dense graph instead)");
+        if (thresh < DBL_EPSILON) thresh = DBL_EPSILON;   // graphs.py:628-629
+    }
+    g->p.thresh = thresh;
+    const int kprime = params->knn + 1;
+    if (int64_t(kprime) > ctx->n) GT_FAIL(ctx, GT_E_ARG, "knn + 1 exceeds n_samples");
+    int need = kprime;
+    bool use_radius = !binary;
+    if (!binary && params->knn_max > 0) {
+        const int64_t km = std::min<int64_t>(params->knn_max + 1, ctx->n);
+        need = int(std::max<int64_t>(kprime, km));
+        use_radius = false;
+    }
+    g->need_m = need;
+    if (params->bandwidth_len != 0 && params->bandwidth_len != 1 && params->bandwidth_len != ctx->n)
+        GT_FAIL(ctx, GT_E_ARG, "bandwidth must have 1 or n_samples entries");
+    if (params->bandwidth_len > 0 && !params->bandwidth) GT_FAIL(ctx, GT_E_ARG, "bandwidth pointer is NULL");
+
+    // ---- kNN candidates for the owned rows ----
+    GT_TRY(gt_knn_candidates(ctx, g->r0, g->nloc, false, need));
+    KnnWork* k = ctx->knn;
+    g->limit = binary ? kprime : (params->knn_max > 0 ? need : k->MP);
+
+    GT_HIP(ctx, g->bw.reserve(size_t(g->nloc) * sizeof(double)));
+    GT_HIP(ctx, g->rowsrc.reserve(size_t(g->nloc) * sizeof(int32_t)));
+    GT_HIP(ctx, g->lenN.reserve(size_t(g->nloc) * sizeof(int32_t)));
+    GT_HIP(ctx, g->lenT.reserve(size_t(g->nloc) * sizeof(int32_t)));
+    GT_HIP(ctx, g->cursor.reserve(size_t(g->nloc) * sizeof(int32_t)));
+    GT_HIP(ctx, g->over_rows.reserve(size_t(g->nloc) * sizeof(int32_t)));
+    GT_HIP(ctx, g->rthr.reserve(size_t(g->nloc) * sizeof(float)));
+    GT_HIP(ctx, g->over_count.reserve(sizeof(uint32_t)));
+    GT_HIP(ctx, g->rmax.reserve(sizeof(uint32_t)));
+    GT_HIP(ctx, g->sendcnt.reserve(size_t(kMaxWorld) * sizeof(unsigned long long)));
+    GT_HIP(ctx, g->sendcur.reserve(size_t(kMaxWorld) * sizeof(unsigned long long)));
+    GT_HIP(ctx, g->flags.reserve(sizeof(uint32_t)));
+    GT_HIP(ctx, hipMemsetAsync(g->over_count.p, 0, sizeof(uint32_t), ctx->stream));
+    GT_HIP(ctx, hipMemsetAsync(g->sendcnt.p, 0, size_t(kMaxWorld) * sizeof(unsigned long long), ctx->stream));
+    GT_HIP(ctx, hipMemsetAsync(g->sendcur.p, 0, size_t(kMaxWorld) * sizeof(unsigned long long), ctx->stream));
+    GT_HIP(ctx, hipMemsetAsync(g->flags.p, 0, sizeof(uint32_t), ctx->stream));
+    if (params->bandwidth_len > 0) {
+        GT_HIP(ctx, g->bw_user.reserve(size_t(params->bandwidth_len) * sizeof(double)));
+        GT_HIP(ctx, hipMemcpyAsync(g->bw_user.p, params->bandwidth, size_t(params->bandwidth_len) * sizeof(double),
+                                   hipMemcpyHostToDevice, ctx->stream));
+    }
+    g->radius_factor = binary ? 0.0 : std::pow(-1.0 * std::log(thresh), 1.0 / params->decay);   // graphs.py:902-904
+    const double err_coef = 2.0 * double(ctx->DP + 6) * 5.9604644775390625e-08;
+    {
+        StageSpan span(ctx, "affinity");
+        hipLaunchKernelGGL(bandwidth_kernel, dim3((unsigned)ceil_div64(g->nloc, 256)), dim3(256), 0, ctx->stream, g->nloc,
+                           g->r0, k->MP, kprime, ctx->dtype, k->cand_d2.as<double>(), k->d2_lb.as<double>(),
+                           ctx->xn.as<double>(), ctx->ymax.as<double>(), err_coef, g->bw_user.as<double>(),
+                           params->bandwidth_len, params->bandwidth_scale, use_radius ? 1 : 0, g->radius_factor,
+                           g->bw.as<double>(), g->rowsrc.as<int32_t>(), g->over_rows.as<int32_t>(),
+                           g->over_count.as<uint32_t>(), g->rthr.as<float>());
+        GT_HIP(ctx, hipGetLastError());
+    }
+    uint32_t n_over = 0;
+    GT_HIP(ctx, hipMemcpyAsync(&n_over, g->over_count.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    g->n_over = n_over;
+    if (n_over > 0) {
+        // ---- radius pass over the rows whose table is not provably complete out to their radius ----
+        const int bq = gt_select_bq(ctx->DP);
+        const int64_t nover_pad = ceil_div64(n_over, bq) * bq;
+        int64_t cap = 1024;
+        GT_HIP(ctx, g->rcounts.reserve(size_t(nover_pad) * sizeof(uint32_t)));
+        for (;;) {
+            if (cap > ctx->n_pad) cap = ctx->n_pad;
+            GT_HIP(ctx, g->rlists.reserve(size_t(nover_pad) * size_t(cap) * sizeof(uint64_t)));
+            SelectArgs sa;
+            sa.dp = ctx->DP;
+            sa.mode = 1;
+            sa.Yp = ctx->Yp.as<float>();
+            sa.hneg = ctx->hneg.as<float>();
+            sa.n_pad = ctx->n_pad;
+            sa.Qp = ctx->Yp.as<float>();
+            sa.qrows = g->over_rows.as<int32_t>();
+            sa.q0 = 0;
+            sa.nq = int32_t(n_over);
+            sa.lists = g->rlists.as<uint64_t>();
+            sa.counts = g->rcounts.as<uint32_t>();
+            sa.thr_in = g->rthr.as<float>();
+            sa.cap = int32_t(cap);
+            {
+                StageSpan span(ctx, "radius");
+                GT_TRY(gt_launch_select(ctx, sa));
+            }
+            GT_HIP(ctx, hipMemsetAsync(g->rmax.p, 0, sizeof(uint32_t), ctx->stream));
+            hipLaunchKernelGGL(max_u32_kernel, dim3(64), dim3(256), 0, ctx->stream, g->rcounts.as<uint32_t>(),
+                               int64_t(n_over), g->rmax.as<uint32_t>());
+            uint32_t rmax = 0;
+            GT_HIP(ctx, hipMemcpyAsync(&rmax, g->rmax.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+            GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (int64_t(rmax) <= cap) break;
+            if (cap >= ctx->n_pad) GT_FAIL(ctx, GT_E_STATE, "radius pass: inconsistent candidate count");
+            cap = std::max<int64_t>(cap * 8, int64_t(rmax) + 64);
+            g->radius_retries++;
+        }
+        g->rcap = int32_t(cap);
+        GT_HIP(ctx, g->rK.reserve(size_t(n_over) * size_t(cap) * sizeof(double)));
+    }
+    // ---- affinities + per-row / per-destination counts ----
+    const int count_owners = (params->kernel_symm != GT_SYMM_NONE) ? 1 : 0;
+    {
+        StageSpan span(ctx, "affinity");
+        if (ctx->dtype == GT_F32)
+            launch_affinity<float>(ctx, g, k, binary ? 1 : 0, params->decay, thresh, count_owners);
+        else
+            launch_affinity<double>(ctx, g, k, binary ? 1 : 0, params->decay, thresh, count_owners);
+        GT_HIP(ctx, hipGetLastError());
+    }
+    unsigned long long sc[kMaxWorld];
+    GT_HIP(ctx, hipMemcpyAsync(sc, g->sendcnt.p, sizeof(sc), hipMemcpyDeviceToHost, ctx->stream));
+    GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    g->send_counts_host.assign(world, 0);
+    for (int r = 0; r < world; ++r) {
+        g->send_counts_host[r] = int64_t(sc[r]);
+        send_counts[r] = int64_t(sc[r]);
+    }
+    g->begun = true;
+    return GT_OK;
+}
+
+extern "C" int gt_graph_emit(gt_ctx* ctx, void* send_buf_dev) {
+    if (!ctx) return GT_E_ARG;
+    GT_HIP(ctx, hipSetDevice(ctx->device));
+    GraphState* g = ctx->graph;
+    if (!g || !g->begun) GT_FAIL(ctx, GT_E_STATE, "gt_graph_emit: call gt_graph_begin first");
+    int64_t total = 0;
+    Buckets bk;
+    for (int r = 0; r < g->world; ++r) {
+        bk.base[r] = total;
+        total += g->send_counts_host[r];
+    }
+    if (total == 0) return GT_OK;
+    if (!send_buf_dev) GT_FAIL(ctx, GT_E_ARG, "gt_graph_emit: send buffer is NULL");
+    KnnWork* k = ctx->knn;
+    GT_HIP(ctx, hipMemsetAsync(g->sendcur.p, 0, size_t(kMaxWorld) * sizeof(unsigned long long), ctx->stream));
+    StageSpan span(ctx, "symmetrize");
+    hipLaunchKernelGGL(emit_triplets_kernel, dim3((unsigned)ceil_div64(g->nloc, 4)), dim3(256), 0, ctx->stream, g->nloc,
+                       g->r0, k->MP, k->cand_d2.as<double>(), k->cand_j.as<uint32_t>(), g->rowsrc.as<int32_t>(),
+                       g->rlists.as<uint64_t>(), g->rcounts.as<uint32_t>(), g->rcap, g->rK.as<double>(), make_splits(g),
+                       bk, g->sendcur.as<unsigned long long>(), (Triplet*)send_buf_dev);
+    GT_HIP(ctx, hipGetLastError());
+    GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return GT_OK;
+}
+
+static int finish_normalize(gt_ctx* ctx, GraphState* g, const double* degree_all_dev);
+
+extern "C" int gt_graph_finish(gt_ctx* ctx, const void* recv_buf_dev, int64_t n_recv, int64_t* out_nnz, uint32_t* flags) {
+    if (!ctx) return GT_E_ARG;
+    GT_HIP(ctx, hipSetDevice(ctx->device));
+    GraphState* g = ctx->graph;
+    if (!g || !g->begun) GT_FAIL(ctx, GT_E_STATE, "gt_graph_finish: call gt_graph_begin first");
+    if (n_recv < 0 || (n_recv > 0 && !recv_buf_dev)) GT_FAIL(ctx, GT_E_ARG, "gt_graph_finish: bad receive buffer");
+    KnnWork* k = ctx->knn;
+    const Triplet* recv = (const Triplet*)recv_buf_dev;
+    const int64_t nloc = g->nloc;
+    {
+        StageSpan span(ctx, "symmetrize");
+        GT_HIP(ctx, hipMemsetAsync(g->lenT.p, 0, size_t(nloc) * sizeof(int32_t), ctx->stream));
+        GT_HIP(ctx, hipMemsetAsync(g->cursor.p, 0, size_t(nloc) * sizeof(int32_t), ctx->stream));
+        if (n_recv > 0) {
+            int64_t blocks = std::min<int64_t>(ceil_div64(n_recv, 256), 16384);
+            hipLaunchKernelGGL(count_recv_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, recv, n_recv, g->r0,
+                               g->lenT.as<int32_t>());
+        }
+        GT_HIP(ctx, g->off.reserve(size_t(nloc + 1) * sizeof(int64_t)));
+        DevBuf tmp;
+        int rc = exclusive_scan(ctx, g->lenN.as<int32_t>(), g->lenT.as<int32_t>(), nloc, g->off.as<int64_t>(), tmp);
+        int64_t total_u = 0;
+        if (rc == GT_OK) {
+            hipError_t e = hipMemcpyAsync(&total_u, g->off.as<int64_t>() + nloc, sizeof(int64_t), hipMemcpyDeviceToHost,
+                                          ctx->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            if (e != hipSuccess) {
+                ctx->set_error(std::string("scan: ") + hipGetErrorString(e));
+                rc = GT_E_HIP;
+            }
+        }
+        tmp.release();
+        GT_TRY(rc);
+        g->nnz0 = total_u - n_recv;
+        GT_HIP(ctx, g->Ukey.reserve(size_t(total_u) * sizeof(uint32_t)));
+        GT_HIP(ctx, g->Uval.reserve(size_t(total_u) * sizeof(double)));
+        GT_HIP(ctx, g->Vkey.reserve(size_t(total_u) * sizeof(uint32_t)));
+        GT_HIP(ctx, g->Vval.reserve(size_t(total_u) * sizeof(double)));
+        GT_HIP(ctx, g->outlen.reserve(size_t(nloc) * sizeof(int32_t)));
+        GT_HIP(ctx, g->bigrows.reserve(size_t(nloc) * sizeof(int32_t)));
+        GT_HIP(ctx, g->bigcount.reserve(sizeof(uint32_t)));
+        GT_HIP(ctx, hipMemsetAsync(g->bigcount.p, 0, sizeof(uint32_t), ctx->stream));
+        hipLaunchKernelGGL(fill_rows_kernel, dim3((unsigned)ceil_div64(nloc, 4)), dim3(256), 0, ctx->stream, nloc, k->MP,
+                           k->cand_d2.as<double>(), k->cand_j.as<uint32_t>(), g->rowsrc.as<int32_t>(),
+                           g->rlists.as<uint64_t>(), g->rcounts.as<uint32_t>(), g->rcap, g->rK.as<double>(),
+                           g->off.as<int64_t>(), g->Ukey.as<uint32_t>(), g->Uval.as<double>());
+        if (n_recv > 0) {
+            int64_t blocks = std::min<int64_t>(ceil_div64(n_recv, 256), 16384);
+            hipLaunchKernelGGL(fill_recv_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, recv, n_recv, g->r0,
+                               g->off.as<int64_t>(), g->lenN.as<int32_t>(), g->cursor.as<int32_t>(), g->Ukey.as<uint32_t>(),
+                               g->Uval.as<double>());
+        }
+        hipLaunchKernelGGL(sort_merge_kernel, dim3((unsigned)ceil_div64(nloc, 4)), dim3(256), 0, ctx->stream, nloc,
+                           g->off.as<int64_t>(), g->Ukey.as<uint32_t>(), g->Uval.as<double>(), g->p.kernel_symm, g->p.theta,
+                           g->Vkey.as<uint32_t>(), g->Vval.as<double>(), g->outlen.as<int32_t>(), g->bigrows.as<int32_t>(),
+                           g->bigcount.as<uint32_t>());
+        GT_HIP(ctx, hipGetLastError());
+        uint32_t nbig = 0;
+        GT_HIP(ctx, hipMemcpyAsync(&nbig, g->bigcount.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (nbig > 0) {
+            // rows longer than kBigRow: global-memory bitonic sort, one workgroup per row
+            std::vector<int32_t> rows(nbig);
+            GT_HIP(ctx, hipMemcpy(rows.data(), g->bigrows.p, size_t(nbig) * sizeof(int32_t), hipMemcpyDeviceToHost));
+            std::vector<int64_t> offh(nloc + 1);
+            GT_HIP(ctx, hipMemcpy(offh.data(), g->off.p, size_t(nloc + 1) * sizeof(int64_t), hipMemcpyDeviceToHost));
+            std::vector<int64_t> soff(nbig + 1, 0);
+            for (uint32_t b = 0; b < nbig; ++b) {
+                const int64_t L = offh[rows[b] + 1] - offh[rows[b]];
+                int64_t P = 1;
+                while (P < L) P <<= 1;
+                soff[b + 1] = soff[b] + P;
+            }
+            DevBuf soff_dev;
+            GT_HIP(ctx, soff_dev.reserve(size_t(nbig + 1) * sizeof(int64_t)));
+            GT_HIP(ctx, hipMemcpy(soff_dev.p, soff.data(), size_t(nbig + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+            GT_HIP(ctx, g->bigscratch_k.reserve(size_t(soff[nbig]) * sizeof(uint32_t)));
+            GT_HIP(ctx, g->bigscratch_v.reserve(size_t(soff[nbig]) * sizeof(double)));
+            hipLaunchKernelGGL(big_sort_kernel, dim3(nbig), dim3(1024), 0, ctx->stream, g->bigrows.as<int32_t>(),
+                               g->off.as<int64_t>(), g->Ukey.as<uint32_t>(), g->Uval.as<double>(), soff_dev.as<int64_t>(),
+                               g->bigscratch_k.as<uint32_t>(), g->bigscratch_v.as<double>());
+            hipLaunchKernelGGL(big_merge_kernel, dim3(nbig), dim3(64), 0, ctx->stream, g->bigrows.as<int32_t>(),
+                               g->off.as<int64_t>(), soff_dev.as<int64_t>(), g->bigscratch_k.as<uint32_t>(),
+                               g->bigscratch_v.as<double>(), g->p.kernel_symm, g->p.theta, g->Vkey.as<uint32_t>(),
+                               g->Vval.as<double>(), g->outlen.as<int32_t>());
+            hipError_t e = hipGetLastError();
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            soff_dev.release();
+            if (e != hipSuccess) {
+                ctx->set_error(std::string("big-row sort: ") + hipGetErrorString(e));
+                return GT_E_HIP;
+            }
+        }
+        // ---- compact to CSR ----
+        GT_HIP(ctx, g->indptr.reserve(size_t(nloc + 1) * sizeof(int64_t)));
+        DevBuf tmp2;
+        rc = exclusive_scan(ctx, g->outlen.as<int32_t>(), nullptr, nloc, g->indptr.as<int64_t>(), tmp2);
+        int64_t nnz = 0;
+        if (rc == GT_OK) {
+            hipError_t e = hipMemcpyAsync(&nnz, g->indptr.as<int64_t>() + nloc, sizeof(int64_t), hipMemcpyDeviceToHost,
+                                          ctx->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            if (e != hipSuccess) {
+                ctx->set_error(std::string("scan: ") + hipGetErrorString(e));
+                rc = GT_E_HIP;
+            }
+        }
+        tmp2.release();
+        GT_TRY(rc);
+        g->nnz = nnz;
+        GT_HIP(ctx, g->indices.reserve(size_t(nnz) * sizeof(int32_t)));
+        GT_HIP(ctx, g->Kdata.reserve(size_t(nnz) * sizeof(double)));
+        GT_HIP(ctx, g->Pdata.reserve(size_t(nnz) * sizeof(double)));
+        GT_HIP(ctx, g->degree.reserve(size_t(nloc) * sizeof(double)));
+        hipLaunchKernelGGL(compact_kernel, dim3((unsigned)ceil_div64(nloc, 4)), dim3(256), 0, ctx->stream, nloc, g->r0,
+                           g->off.as<int64_t>(), g->outlen.as<int32_t>(), g->indptr.as<int64_t>(), g->Vkey.as<uint32_t>(),
+                           g->Vval.as<double>(), g->indices.as<int32_t>(), g->Kdata.as<double>(), g->degree.as<double>(),
+                           g->flags.as<uint32_t>());
+        GT_HIP(ctx, hipGetLastError());
+    }
+    g->finished = true;
+    if (g->p.anisotropy != 0.0) {
+        if (g->world > 1) {
+            // the caller must all-gather the degrees and call gt_graph_anisotropy
+            if (out_nnz) *out_nnz = g->nnz;
+            if (flags) *flags = 0;
+            GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            return GT_OK;
+        }
+        GT_TRY(finish_normalize(ctx, g, g->degree.as<double>()));
+    } else {
+        GT_TRY(finish_normalize(ctx, g, nullptr));
+    }
+    uint32_t fl = 0, kfl = 0;
+    GT_HIP(ctx, hipMemcpyAsync(&fl, g->flags.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    GT_HIP(ctx, hipMemcpyAsync(&kfl, k->gflags.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    fl |= kfl;
+    if (k->n_fallback > 0) fl |= GT_FLAG_FALLBACK_ROWS;
+    if (g->n_over > 0) fl |= GT_FLAG_RADIUS_ROWS;
+    if (out_nnz) *out_nnz = g->nnz;
+    if (flags) *flags = fl;
+    return GT_OK;
+}
+
+static int finish_normalize(gt_ctx* ctx, GraphState* g, const double* degree_all_dev) {
+    StageSpan span(ctx, "normalize");
+    const int64_t nloc = g->nloc;
+    if (degree_all_dev && g->p.anisotropy != 0.0) {
+        // degree_all_dev is indexed by GLOBAL row; for world == 1 the local degree vector is global
+        DevBuf tmp;
+        GT_HIP(ctx, tmp.reserve(size_t(nloc) * sizeof(double)));
+        hipLaunchKernelGGL(anisotropy_kernel, dim3((unsigned)ceil_div64(nloc, 4)), dim3(256), 0, ctx->stream, nloc, g->r0,
+                           g->indptr.as<int64_t>(), g->indices.as<int32_t>(), g->Kdata.as<double>(), degree_all_dev,
+                           g->p.anisotropy, tmp.as<double>());
+        hipError_t e = hipMemcpyAsync(g->degree.p, tmp.p, size_t(nloc) * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        tmp.release();
+        if (e != hipSuccess) {
+            ctx->set_error(std::string("anisotropy: ") + hipGetErrorString(e));
+            return GT_E_HIP;
+        }
+    }
+    hipLaunchKernelGGL(normalize_kernel, dim3((unsigned)ceil_div64(nloc, 4)), dim3(256), 0, ctx->stream, nloc,
+                       g->indptr.as<int64_t>(), g->Kdata.as<double>(), g->Pdata.as<double>());
+    GT_HIP(ctx, hipGetLastError());
+    return GT_OK;
+}
+
+extern "C" int gt_graph_anisotropy(gt_ctx* ctx, const double* degree_all_dev) {
+    if (!ctx) return GT_E_ARG;
+    GT_HIP(ctx, hipSetDevice(ctx->device));
+    GraphState* g = ctx->graph;
+    if (!g || !g->finished) GT_FAIL(ctx, GT_E_STATE, "gt_graph_anisotropy: call gt_graph_finish first");
+    if (!degree_all_dev) GT_FAIL(ctx, GT_E_ARG, "gt_graph_anisotropy: degree vector is NULL");
+    GT_TRY(finish_normalize(ctx, g, degree_all_dev));
+    GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return GT_OK;
+}
+
+extern "C" int gt_graph_build(gt_ctx* ctx, const gt_knn_params* params, int64_t* out_nnz, uint32_t* flags) {
+    if (!ctx) return GT_E_ARG;
+    int64_t splits[2] = {0, ctx->n};
+    int64_t sendc[1] = {0};
+    GT_TRY(gt_graph_begin(ctx, params, 1, 0, splits, sendc));
+    GraphState* g = ctx->graph;
+    if (sendc[0] > 0) {
+        GT_HIP(ctx, g->selfbuf.reserve(size_t(sendc[0]) * sizeof(Triplet)));
+        GT_TRY(gt_graph_emit(ctx, g->selfbuf.p));
+    }
+    return gt_graph_finish(ctx, sendc[0] > 0 ? g->selfbuf.p : nullptr, sendc[0], out_nnz, flags);
+}
+
+extern "C" int gt_graph_rows(const gt_ctx* ctx, int64_t* row0, int64_t* row1, int64_t* nnz) {
+    if (!ctx || !ctx->graph || !ctx->graph->finished) return GT_E_STATE;
+    if (row0) *row0 = ctx->graph->r0;
+    if (row1) *row1 = ctx->graph->r1;
+    if (nnz) *nnz = ctx->graph->nnz;
+    return GT_OK;
+}
+
+extern "C" int gt_graph_fetch_csr(gt_ctx* ctx, int32_t which, double* data, int32_t* indices, int64_t* indptr,
+                                  int32_t on_device) {
+    if (!ctx) return GT_E_ARG;
+    GT_HIP(ctx, hipSetDevice(ctx->device));
+    GraphState* g = ctx->graph;
+    if (!g || !g->finished) GT_FAIL(ctx, GT_E_STATE, "gt_graph_fetch_csr: no finished graph");
+    const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    const double* src = which == GT_CSR_P ? g->Pdata.as<double>() : g->Kdata.as<double>();
+    if (data && g->nnz > 0) GT_HIP(ctx, hipMemcpyAsync(data, src, size_t(g->nnz) * sizeof(double), kind, ctx->stream));
+    if (indices && g->nnz > 0)
+        GT_HIP(ctx, hipMemcpyAsync(indices, g->indices.p, size_t(g->nnz) * sizeof(int32_t), kind, ctx->stream));
+    if (indptr) GT_HIP(ctx, hipMemcpyAsync(indptr, g->indptr.p, size_t(g->nloc + 1) * sizeof(int64_t), kind, ctx->stream));
+    GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return GT_OK;
+}
+
+extern "C" int gt_graph_fetch_vec(gt_ctx* ctx, int32_t which, double* out, int32_t on_device) {
+    if (!ctx || !out) return GT_E_ARG;
+    GT_HIP(ctx, hipSetDevice(ctx->device));
+    GraphState* g = ctx->graph;
+    if (!g || !g->begun) GT_FAIL(ctx, GT_E_STATE, "gt_graph_fetch_vec: no graph");
+    const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    const void* src = nullptr;
+    if (which == GT_VEC_BANDWIDTH)
+        src = g->bw.p;
+    else if (which == GT_VEC_DEGREE && g->finished)
+        src = g->degree.p;
+    if (!src) GT_FAIL(ctx, GT_E_ARG, "gt_graph_fetch_vec: unknown or unavailable vector");
+    GT_HIP(ctx, hipMemcpyAsync(out, src, size_t(g->nloc) * sizeof(double), kind, ctx->stream));
+    GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return GT_OK;
+}
+
+extern "C" int gt_graph_stats(const gt_ctx* ctx, int64_t* out4) {
+    if (!ctx || !out4 || !ctx->graph) return GT_E_STATE;
+    out4[0] = ctx->knn ? ctx->knn->n_fallback : 0;
+    out4[1] = ctx->graph->n_over;
+    out4[2] = ctx->graph->nnz0;
+    out4[3] = ctx->graph->radius_retries;
+    return GT_OK;
+}

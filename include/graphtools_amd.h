@@ -1,0 +1,200 @@
+/*
+ * graphtools_amd.h - C ABI of the MI355X (gfx950) implementation of the graphtools
+ * kNN -> affinity kernel -> diffusion operator hot path.
+ *
+ * The reference (KrishnaswamyLab/graphtools v2.1.0) is pure Python; its "FFI" for
+ * this path is the set of numpy-level calls it makes into scikit-learn / scipy.
+ * Every entry point below names the reference interface (file:line) it replaces.
+ * The library is plain `extern "C"`: pointers + sizes, no C++/torch types.  It is
+ * loaded with ctypes by graphtools_amd/_hip.py; INTEGRATION.md shows the stub a
+ * reference maintainer would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success, <0 on error (GT_E_*); the message is
+ *     available from gt_last_error(ctx) (or gt_last_error(NULL) for ctx creation).
+ *   - one gt_ctx per thread of control; a ctx is bound to one HIP device and owns
+ *     one HIP stream plus all device workspace.  Calls are blocking.
+ *   - "dev" pointers are HIP device pointers on the ctx's device; "host" pointers
+ *     are ordinary process memory.  Functions that accept either take an explicit
+ *     `on_device` flag.
+ *   - matrices are row-major and C-contiguous.  dtype: GT_F32 / GT_F64.
+ *   - the C side never owns caller memory and never frees caller pointers.
+ */
+#ifndef GRAPHTOOLS_AMD_H
+#define GRAPHTOOLS_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GT_ABI_VERSION 1
+
+/* status codes */
+#define GT_OK 0
+#define GT_E_ARG (-1)     /* invalid argument / unsupported configuration */
+#define GT_E_HIP (-2)     /* HIP runtime error */
+#define GT_E_ALLOC (-3)   /* device allocation failed */
+#define GT_E_STATE (-4)   /* call sequence error */
+#define GT_E_LIMIT (-5)   /* size outside what the HIP path supports */
+
+/* dtypes */
+#define GT_F32 0
+#define GT_F64 1
+
+/* kernel symmetrisation (graphtools/base.py:557-577) */
+#define GT_SYMM_NONE 0
+#define GT_SYMM_ADD 1   /* (K + K^T) / 2 */
+#define GT_SYMM_MUL 2   /* K o K^T */
+#define GT_SYMM_MNN 3   /* theta*min(K,K^T) + (1-theta)*max(K,K^T) */
+
+/* result flags (bit set in *flags outputs) */
+#define GT_FLAG_DUPLICATES 1u      /* some distances[:,1] == 0  (graphs.py:787-817 -> RuntimeWarning on host) */
+#define GT_FLAG_ZERO_DIAGONAL 2u   /* K has a zero on the diagonal (base.py:553-554) */
+#define GT_FLAG_FALLBACK_ROWS 4u   /* informational: some rows took the exact fp64 fallback */
+#define GT_FLAG_RADIUS_ROWS 8u     /* informational: some rows needed the radius pass */
+
+/* which-selectors for gt_graph_fetch_* */
+#define GT_CSR_K 0
+#define GT_CSR_P 1
+#define GT_VEC_BANDWIDTH 0
+#define GT_VEC_DEGREE 1
+
+typedef struct gt_ctx gt_ctx;
+
+/* Parameters of kNNGraph(...)  (graphtools/graphs.py:608-672; api.Graph graphtools/api.py:14-42). */
+typedef struct gt_knn_params {
+    int32_t knn;               /* user knn (self excluded); internal k' = knn + 1 (graphs.py:783-784) */
+    int32_t kernel_symm;       /* GT_SYMM_* */
+    double decay;              /* alpha-decay exponent; NaN = None -> binary connectivity kernel (graphs.py:872-877) */
+    double thresh;             /* affinity threshold (clamped to >= DBL_EPSILON when decay is set, graphs.py:628-629) */
+    double bandwidth_scale;    /* graphs.py:892 */
+    double theta;              /* mnn symmetrisation constant */
+    double anisotropy;         /* base.py:579-592 */
+    const double* bandwidth;   /* host pointer: NULL, 1 value (fixed) or n values (per row)   (graphs.py:886-897) */
+    int64_t bandwidth_len;     /* 0, 1 or n */
+    int64_t knn_max;           /* <= 0: None.  >0: at most knn_max+1 nearest columns per row (graphs.py:783, 869) */
+} gt_knn_params;
+
+/* ---- context ----------------------------------------------------------------------------- */
+int gt_abi_version(void);
+int gt_ctx_create(int device, gt_ctx** out);
+void gt_ctx_destroy(gt_ctx* ctx);
+const char* gt_last_error(const gt_ctx* ctx);
+int gt_device_count(void);
+/* per-stage GPU time (ms, hipEvent on the ctx stream) of the most recent call that ran `stage`;
+ * stages: "prep" "knn_select" "rerank" "fallback" "radius" "affinity" "symmetrize" "normalize"
+ *         "dense_bandwidth" "dense_kernel" "dense_normalize" "landmark".  Returns <0 if never run. */
+double gt_stage_ms(const gt_ctx* ctx, const char* stage);
+/* number of launches accumulated for `stage` in the most recent call (for roofline: ms / launches) */
+int gt_stage_launches(const gt_ctx* ctx, const char* stage);
+
+/* ---- points ------------------------------------------------------------------------------ */
+/* Bind the data matrix (n x d).  Replaces NearestNeighbors(...).fit(data_nu) (graphs.py:763-768):
+ * builds the padded float32 working copy, float64 row norms and -|y|^2/2 terms on the device.
+ * X may be a host or a device pointer; it must stay valid until the next gt_set_points / destroy
+ * when it is a device pointer of dtype F32/F64 (the exact re-rank reads it). */
+int gt_set_points(gt_ctx* ctx, const void* X, int64_t n, int32_t d, int32_t dtype, int32_t on_device);
+
+/* ---- kNN search -------------------------------------------------------------------------- */
+/* Replaces knn_tree.kneighbors(Y, n_neighbors=k) (graphs.py:883 / sklearn EuclideanArgKmin{32,64}):
+ * queries are rows [row0,row1) of the bound points when Y == NULL, else the m x d matrix Y
+ * (same dtype as the points, host or device per y_on_device).  Outputs (host or device per
+ * out_on_device): out_idx int64 [m*k], out_dist float64 [m*k], ascending by (distance, index);
+ * distances carry scikit-learn's rounding: float32 points -> (double)sqrtf((float)d2), float64 -> sqrt(d2).
+ * Indices are bit-exact w.r.t. the fp64 GEMM-form ordering (ties broken by index). */
+int gt_knn_search(gt_ctx* ctx, int64_t row0, int64_t row1, const void* Y, int64_t m, int32_t y_on_device,
+                  int32_t k, int64_t* out_idx, double* out_dist, int32_t out_on_device, uint32_t* flags);
+
+/* ---- kNN graph: kernel + diffusion operator ------------------------------------------------ */
+/* The three calls replace, for rows [row0,row1) of the graph,
+ *   kNNGraph.build_kernel            graphs.py:771-785, 819-982 (+ _build_csr_from_neighbors :450-559)
+ *   BaseGraph.symmetrize_kernel      base.py:557-577
+ *   BaseGraph.apply_anisotropy       base.py:579-592
+ *   BaseGraph.P (normalize l1)       base.py:629-646
+ *   BaseGraph.kernel_degree          base.py:648-666
+ * Row sharding: `row_splits` (world+1 ascending int64, host) gives the owner of every row; this
+ * process is `rank` and builds rows [row_splits[rank], row_splits[rank+1]).  world == 1 is the
+ * single-GPU case.
+ *
+ *   gt_graph_begin : kNN search, bandwidths, radius pass, affinities for the owned rows; counts the
+ *                    transposed entries each peer will receive.  send_counts[world] (host, out) is in
+ *                    units of 16-byte triplets {uint32 row, uint32 col, double value}.
+ *   gt_graph_emit  : writes the transposed triplets, bucketed by destination rank in rank order, into
+ *                    the caller's device buffer (sum(send_counts) * 16 bytes).  The caller moves them
+ *                    (RCCL all-to-all over xGMI through torch.distributed; a no-op when world == 1).
+ *   gt_graph_finish: merges the owned rows with the received triplets (n_recv of them, device pointer),
+ *                    symmetrises, applies anisotropy, row-normalises.  Results stay on the device. */
+int gt_graph_begin(gt_ctx* ctx, const gt_knn_params* params, int32_t world, int32_t rank,
+                   const int64_t* row_splits, int64_t* send_counts);
+int gt_graph_emit(gt_ctx* ctx, void* send_buf_dev);
+int gt_graph_finish(gt_ctx* ctx, const void* recv_buf_dev, int64_t n_recv, int64_t* out_nnz, uint32_t* flags);
+/* Anisotropy needs the degree (row sum) of EVERY column.  With world == 1 gt_graph_finish applies it
+ * itself.  With world > 1 and anisotropy != 0 gt_graph_finish stops after the symmetrised kernel and its
+ * degrees; the caller all-gathers the degree vectors (GT_VEC_DEGREE) into one n-vector on the device and
+ * calls gt_graph_anisotropy, which rescales K (base.py:579-592) and then forms P. */
+int gt_graph_anisotropy(gt_ctx* ctx, const double* degree_all_dev);
+/* single-GPU convenience: begin + emit + finish with an internal buffer */
+int gt_graph_build(gt_ctx* ctx, const gt_knn_params* params, int64_t* out_nnz, uint32_t* flags);
+
+/* Results of the most recent gt_graph_finish, for the owned rows.
+ * CSR is canonical (sorted columns, no duplicates): data float64 [nnz], indices int32 [nnz] (global
+ * column ids), indptr int64 [rows+1].  Any of the three pointers may be NULL.  on_device selects
+ * host or device destination memory. */
+int gt_graph_rows(const gt_ctx* ctx, int64_t* row0, int64_t* row1, int64_t* nnz);
+int gt_graph_fetch_csr(gt_ctx* ctx, int32_t which, double* data, int32_t* indices, int64_t* indptr,
+                       int32_t on_device);
+int gt_graph_fetch_vec(gt_ctx* ctx, int32_t which, double* out, int32_t on_device);
+/* statistics of the last build: out[0]=rows that took the exact fallback, out[1]=rows that took the
+ * radius pass, out[2]=nnz of the unsymmetrised kernel, out[3]=radius-pass capacity retries */
+int gt_graph_stats(const gt_ctx* ctx, int64_t* out4);
+
+/* ---- exact dense graph (TraditionalGraph) -------------------------------------------------- */
+/* Replaces TraditionalGraph.build_kernel (graphs.py:1514-1610) + symmetrise + P for a dense n x n
+ * problem on one GPU.
+ *   from data       : X_or_D = n x d points (dtype F32/F64), precomputed = 0; distances are float64
+ *                     difference form like scipy pdist; K, P are float64.
+ *   from distances  : X_or_D = n x n matrix, precomputed = 1; dtype is preserved (float32 D -> float32 K, P).
+ * bandwidth: NULL -> (knn+1)-th smallest entry of each row (graphs.py:1583-1587), else 1 or n values.
+ * Outputs (device or host per out_on_device, any may be NULL): K [n*n], P [n*n] in the result dtype.
+ * When `inplace` != 0 and precomputed == 1 and X_or_D is a device pointer, K overwrites D (for
+ * problems where D alone fills most of HBM) and out_K is ignored. */
+int gt_dense_graph_build(gt_ctx* ctx, const void* X_or_D, int64_t n, int32_t d, int32_t dtype, int32_t on_device,
+                         int32_t precomputed, int32_t knn, double decay, double thresh,
+                         const double* bandwidth, int64_t bandwidth_len, double bandwidth_scale,
+                         int32_t kernel_symm, double theta, double anisotropy, int32_t inplace,
+                         void* out_K, void* out_P, int32_t out_on_device, uint32_t* flags);
+
+/* ---- landmark operator (LandmarkGraph) ------------------------------------------------------ */
+/* Replaces LandmarkGraph._landmarks_to_data + the products of build_landmark_op
+ * (graphs.py:1169-1182, 1232-1246) on the kernel of the most recent gt_graph_finish.
+ * clusters: int32 [rows] labels in [0, n_landmark) for the OWNED rows (host); labels must be dense
+ * (np.unique-compressed by the caller).  Outputs:
+ *   partial_op     float64 [L*L]  sum over owned rows n of  pmn[:, n] (x) pnm_hat[n, :] partial products,
+ *                  to be summed over ranks (RCCL all-reduce) and then row-scaled by 1/col_sums;
+ *   partial_colsum float64 [L]    partial row sums of pmn (sum over owned columns), same all-reduce;
+ *   transitions    CSR over owned rows x L (row-normalised pnm): counts via gt_landmark_transitions_*.
+ * See graphtools_amd/graphs.py for the host algebra that finishes the operator. */
+int gt_landmark_partial(gt_ctx* ctx, const int32_t* clusters, int32_t n_landmark,
+                        double* partial_op, double* partial_colsum, int32_t out_on_device);
+int gt_landmark_transitions_nnz(const gt_ctx* ctx, int64_t* nnz);
+int gt_landmark_fetch_transitions(gt_ctx* ctx, double* data, int32_t* indices, int64_t* indptr, int32_t on_device);
+/* Random-landmark assignment (graphs.py:1200-1213): clusters[i] = argmin_j |x_i - x_{landmarks[j]}| over the
+ * bound points, rows [row0,row1); ties -> lowest j.  mode 0: scipy cdist arithmetic (float64 difference
+ * form), mode 1: sklearn euclidean_distances arithmetic (float64 GEMM form rounded to the input dtype). */
+int gt_nearest_landmark(gt_ctx* ctx, int64_t row0, int64_t row1, const int64_t* landmarks, int32_t n_landmark,
+                        int32_t mode, int32_t* out_clusters);
+
+/* ---- device memory helpers (so a host language without a HIP binding can keep data resident) -- */
+int gt_dev_alloc(gt_ctx* ctx, size_t bytes, void** out);
+int gt_dev_free(gt_ctx* ctx, void* p);
+int gt_dev_upload(gt_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
+int gt_dev_download(gt_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+int gt_dev_sync(gt_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GRAPHTOOLS_AMD_H */
