@@ -70,8 +70,10 @@ _SIGNATURES = {
                                         _c.c_int32, _c.c_int32, _c.c_double, _c.c_double, _c.c_void_p, _c.c_int64,
                                         _c.c_double, _c.c_int32, _c.c_double, _c.c_double, _c.c_int32, _c.c_void_p,
                                         _c.c_void_p, _c.c_int32, _c.POINTER(_c.c_uint32)]),
-    "gt_landmark_partial": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int32, _c.c_void_p, _c.c_void_p, _c.c_int32]),
-    "gt_landmark_transitions_nnz": (_c.c_int, [_c.c_void_p, _c.POINTER(_c.c_int64)]),
+    "gt_dense_fetch_vec": (_c.c_int, [_c.c_void_p, _c.c_int32, _c.c_void_p]),
+    "gt_landmark_build": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int32, _c.c_void_p, _c.c_void_p, _c.c_int32,
+                                     _c.POINTER(_c.c_int64)]),
+    "gt_landmark_scale": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int32, _c.c_int32]),
     "gt_landmark_fetch_transitions": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int32]),
     "gt_nearest_landmark": (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_int64, _c.c_void_p, _c.c_int32, _c.c_int32, _c.c_void_p]),
     "gt_dev_alloc": (_c.c_int, [_c.c_void_p, _c.c_size_t, _c.POINTER(_c.c_void_p)]),
@@ -256,14 +258,7 @@ class Context:
         return data, indices, indptr
 
     def graph_fetch_vec(self, which):
-        r0, r1, _ = self.graph_rows() if which == VEC_DEGREE else (0, self.n, 0)
-        if which == VEC_BANDWIDTH:
-            st = np.zeros(4, dtype=np.int64)
-            # bandwidth is available after begin; owned rows only
-            try:
-                r0, r1, _ = self.graph_rows()
-            except HipError:
-                pass
+        r0, r1, _ = self.graph_rows()
         out = np.empty(r1 - r0, dtype=np.float64)
         self._check(self.lib.gt_graph_fetch_vec(self.h, which, _ptr(out), 0), "gt_graph_fetch_vec")
         return out
@@ -273,6 +268,76 @@ class Context:
         self._check(self.lib.gt_graph_stats(self.h, _ptr(st)), "gt_graph_stats")
         return {"fallback_rows": int(st[0]), "radius_rows": int(st[1]), "nnz_unsymmetrised": int(st[2]),
                 "radius_retries": int(st[3])}
+
+    # ---- exact dense graph -------------------------------------------------------------------
+    def dense_graph_build(self, data, precomputed, knn, decay, thresh, bandwidth, bandwidth_scale, kernel_symm, theta,
+                          anisotropy, want_P=True):
+        """(K ndarray, P ndarray or None, flags).  Result dtype follows numpy's rules in the reference."""
+        data = np.ascontiguousarray(data)
+        if data.dtype not in (np.float32, np.float64):
+            data = data.astype(np.float64)
+        n = data.shape[0]
+        d = 0 if precomputed else data.shape[1]
+        bw = None
+        bw_len = 0
+        if bandwidth is not None:
+            bw = np.ascontiguousarray(np.atleast_1d(np.asarray(bandwidth, dtype=np.float64)))
+            bw_len = bw.shape[0]
+        out_f64 = (not precomputed) or data.dtype == np.float64 or bw_len > 1
+        odt = np.float64 if out_f64 else np.float32
+        K = np.empty((n, n), dtype=odt)
+        P = np.empty((n, n), dtype=odt) if want_P else None
+        flags = ctypes.c_uint32(0)
+        self._check(
+            self.lib.gt_dense_graph_build(
+                self.h, _ptr(data), n, d, GT_F32 if data.dtype == np.float32 else GT_F64, 0, 1 if precomputed else 0,
+                int(knn) if knn is not None else 0, float(decay), float(thresh), _ptr(bw), bw_len, float(bandwidth_scale),
+                SYMM[kernel_symm], 1.0 if theta is None else float(theta), float(anisotropy), 0, _ptr(K), _ptr(P), 0,
+                ctypes.byref(flags)),
+            "gt_dense_graph_build",
+        )
+        if not precomputed:
+            self.n, self.d, self.dtype = n, data.shape[1], data.dtype
+        return K, P, flags.value
+
+    def dense_fetch_vec(self, which, n):
+        out = np.empty(n, dtype=np.float64)
+        self._check(self.lib.gt_dense_fetch_vec(self.h, which, _ptr(out)), "gt_dense_fetch_vec")
+        return out
+
+    # ---- landmarks ----------------------------------------------------------------------------
+    def nearest_landmark(self, landmarks, mode, rows=None):
+        r0, r1 = rows if rows is not None else (0, self.n)
+        lm = np.ascontiguousarray(landmarks, dtype=np.int64)
+        out = np.empty(r1 - r0, dtype=np.int32)
+        self._check(self.lib.gt_nearest_landmark(self.h, r0, r1, _ptr(lm), lm.shape[0], int(mode), _ptr(out)),
+                    "gt_nearest_landmark")
+        return out
+
+    def landmark_build(self, clusters, n_landmark):
+        """(M [L,L], R [L], transitions nnz): unscaled partial operator of the owned rows (host copies)"""
+        cl = np.ascontiguousarray(clusters, dtype=np.int32)
+        M = np.empty((n_landmark, n_landmark), dtype=np.float64)
+        R = np.empty(n_landmark, dtype=np.float64)
+        tnnz = ctypes.c_int64(0)
+        self._check(self.lib.gt_landmark_build(self.h, _ptr(cl), int(n_landmark), _ptr(M), _ptr(R), 0, ctypes.byref(tnnz)),
+                    "gt_landmark_build")
+        return M, R, tnnz.value
+
+    def landmark_scale(self, M, R):
+        M = np.ascontiguousarray(M, dtype=np.float64)
+        R = np.ascontiguousarray(R, dtype=np.float64)
+        self._check(self.lib.gt_landmark_scale(self.h, _ptr(M), _ptr(R), M.shape[0], 0), "gt_landmark_scale")
+        return M
+
+    def landmark_fetch_transitions(self, tnnz):
+        r0, r1, _ = self.graph_rows()
+        data = np.empty(tnnz, dtype=np.float64)
+        indices = np.empty(tnnz, dtype=np.int32)
+        indptr = np.empty(r1 - r0 + 1, dtype=np.int64)
+        self._check(self.lib.gt_landmark_fetch_transitions(self.h, _ptr(data), _ptr(indices), _ptr(indptr), 0),
+                    "gt_landmark_fetch_transitions")
+        return data, indices, indptr
 
     # ---- raw device memory --------------------------------------------------------------------
     def dev_alloc(self, nbytes):

@@ -1,0 +1,221 @@
+"""Host-side mirror of the reference's abstract graph layer (graphtools/base.py).
+
+Only what the hot path needs: parameter handling and validation with the reference's
+messages, the lazy cached properties ``K``/``kernel``, ``P``/``diff_op``, ``kernel_degree``,
+``diff_aff`` and the post-build sanity warnings.  All numerics run in the HIP library
+(:mod:`graphtools_amd._hip`); there is no CPU implementation behind these classes.
+"""
+import numbers
+import warnings
+
+import numpy as np
+from scipy import sparse
+
+from . import _hip
+
+
+class BaseGraph(object):
+    """Parent graph class (reference: graphtools/base.py:427-724).
+
+    Parameters
+    ----------
+    kernel_symm : {'+', '*', 'mnn', None}
+    theta : float, mnn symmetrisation constant
+    anisotropy : float in [0, 1]
+    initialize : bool, build the kernel on construction
+    """
+
+    def __init__(self, kernel_symm="+", theta=None, anisotropy=0, gamma=None, initialize=True, **kwargs):
+        if gamma is not None:
+            warnings.warn("gamma is deprecated. Setting theta={}".format(gamma), FutureWarning)
+            theta = gamma
+        if kernel_symm in ("gamma", "theta"):
+            warnings.warn(
+                "kernel_symm='{}' is deprecated. Setting kernel_symm='mnn'".format(kernel_symm), FutureWarning
+            )
+            kernel_symm = "mnn"
+        self.kernel_symm = kernel_symm
+        self.theta = theta
+        self._check_symmetrization(kernel_symm, theta)
+        if not (isinstance(anisotropy, numbers.Real) and 0 <= anisotropy <= 1):
+            raise ValueError("Expected 0 <= anisotropy <= 1. Got {}".format(anisotropy))
+        self.anisotropy = anisotropy
+        if kwargs:
+            # reference: Base.__init__ is object.__init__ -> unexpected keyword TypeError (test_api.py:161-165)
+            raise TypeError("__init__() got an unexpected keyword argument '{}'".format(sorted(kwargs)[0]))
+        if initialize:
+            self.K
+
+    def _check_symmetrization(self, kernel_symm, theta):
+        # reference: base.py:508-532
+        if kernel_symm not in ["+", "*", "mnn", None]:
+            raise ValueError(
+                "kernel_symm '{}' not recognized. Choose from '+', '*', 'mnn', or 'none'.".format(kernel_symm)
+            )
+        elif kernel_symm != "mnn" and theta is not None:
+            warnings.warn("kernel_symm='{}' but theta is not None. Setting kernel_symm='mnn'.".format(kernel_symm))
+            self.kernel_symm = kernel_symm = "mnn"
+        if kernel_symm == "mnn":
+            if theta is None:
+                self.theta = theta = 1
+                warnings.warn("kernel_symm='mnn' but theta not given. Defaulting to theta={}.".format(self.theta))
+            elif not isinstance(theta, numbers.Number) or theta < 0 or theta > 1:
+                raise ValueError("theta {} not recognized. Expected a float between 0 and 1".format(theta))
+
+    # ---- parameters -------------------------------------------------------------------------
+    def get_params(self):
+        return {"kernel_symm": self.kernel_symm, "theta": self.theta, "anisotropy": self.anisotropy}
+
+    def set_params(self, **params):
+        # reference: base.py:602-627
+        if "theta" in params and params["theta"] != self.theta:
+            raise ValueError("Cannot update theta. Please create a new graph")
+        if "anisotropy" in params and params["anisotropy"] != self.anisotropy:
+            raise ValueError("Cannot update anisotropy. Please create a new graph")
+        if "kernel_symm" in params and params["kernel_symm"] != self.kernel_symm:
+            raise ValueError("Cannot update kernel_symm. Please create a new graph")
+        return self
+
+    # ---- device plumbing --------------------------------------------------------------------
+    @property
+    def hip(self):
+        """The :class:`graphtools_amd._hip.Context` that owns this graph's device state."""
+        try:
+            return self._hip_ctx
+        except AttributeError:
+            self._hip_ctx = _hip.Context(getattr(self, "device", 0) or 0)
+            return self._hip_ctx
+
+    def _emit_build_warnings(self, flags):
+        # reference: base.py:551-554 (symmetry holds by construction of the merge kernel)
+        if flags & _hip.FLAG_ZERO_DIAGONAL:
+            warnings.warn("K should have a non-zero diagonal", RuntimeWarning)
+
+    # ---- abstract ---------------------------------------------------------------------------
+    def _build_kernel(self):
+        """Build kernel + diffusion operator on the device; returns K (scipy CSR or ndarray)."""
+        raise NotImplementedError
+
+    def _fetch_diff_op(self):
+        raise NotImplementedError
+
+    def _fetch_degree(self):
+        raise NotImplementedError
+
+    # ---- cached properties (reference: base.py:629-724) ---------------------------------------
+    @property
+    def K(self):
+        try:
+            return self._kernel
+        except AttributeError:
+            self._kernel = self._build_kernel()
+            return self._kernel
+
+    @property
+    def kernel(self):
+        return self.K
+
+    @property
+    def P(self):
+        try:
+            return self._diff_op
+        except AttributeError:
+            self.K
+            self._diff_op = self._fetch_diff_op()
+            return self._diff_op
+
+    @property
+    def diff_op(self):
+        return self.P
+
+    @property
+    def kernel_degree(self):
+        try:
+            return self._kernel_degree
+        except AttributeError:
+            self.K
+            self._kernel_degree = np.asarray(self._fetch_degree(), dtype=np.float64).reshape(-1, 1)
+            return self._kernel_degree
+
+    @property
+    def diff_aff(self):
+        """Symmetric diffusion affinity D^-1/2 K D^-1/2 (reference: base.py:668-698).
+
+        A diagonal rescaling of the cached kernel by the cached degrees (both device results)."""
+        deg = self.kernel_degree
+        if sparse.issparse(self.kernel):
+            n = len(deg)
+            dm = sparse.csr_matrix((1 / np.sqrt(deg.flatten()), np.arange(n), np.arange(n + 1)))
+            return dm @ self.kernel @ dm
+        return (self.kernel / np.sqrt(deg)) / np.sqrt(deg.T)
+
+    # convenience used by downstream packages
+    @property
+    def N(self):
+        return self.K.shape[0]
+
+
+class Data(object):
+    """Input coercion and optional PCA pre-reduction (reference: graphtools/base.py:72-424).
+
+    The reduction is pre-processing in front of the hot path and stays on host scikit-learn,
+    exactly as in the reference; ``data_nu`` is what the device sees.
+    """
+
+    def __init__(self, data, n_pca=None, rank_threshold=None, random_state=None):
+        if hasattr(data, "sparse") and hasattr(data, "columns"):  # pandas sparse frame
+            data = data.sparse.to_coo()
+        elif hasattr(data, "columns") and hasattr(data, "values"):  # pandas DataFrame
+            data = np.array(data)
+        elif hasattr(data, "X") and hasattr(data, "obs"):  # anndata
+            data = data.X
+        if not sparse.issparse(data):
+            data = np.asarray(data)
+            if data.ndim != 2:
+                raise ValueError("Expected 2D array, got {}D array instead".format(data.ndim))
+        if min(data.shape) == 0:
+            raise ValueError("Found array with 0 sample(s) or feature(s): {}".format(data.shape))
+        if n_pca in (None, 0, False):
+            n_pca = None
+        elif n_pca is True or isinstance(n_pca, str):
+            raise NotImplementedError("n_pca='auto' (rank estimation) is not supported by graphtools_amd")
+        elif not isinstance(n_pca, numbers.Integral) or n_pca < 0:
+            raise ValueError("n_pca was not an instance of numbers.Number, could not be cast to False, and not None. "
+                             "Please supply an integer 0 <= n_pca < min(n_samples,n_features) or None")
+        elif n_pca >= min(data.shape):
+            warnings.warn(
+                "Cannot perform PCA to {} dimensions on data with min(n_samples, n_features) = {}".format(
+                    n_pca, min(data.shape)),
+                RuntimeWarning,
+            )
+            n_pca = None
+        self.data = data
+        self.n_pca = n_pca
+        self.rank_threshold = rank_threshold
+        self.random_state = random_state
+        self.data_nu = self._reduce_data()
+
+    def _reduce_data(self):
+        if self.n_pca is None:
+            d = self.data
+            if sparse.issparse(d):
+                d = d.toarray()
+            return d
+        from sklearn.decomposition import PCA, TruncatedSVD
+
+        if sparse.issparse(self.data):
+            self.data_pca = TruncatedSVD(self.n_pca, random_state=self.random_state)
+        else:
+            self.data_pca = PCA(self.n_pca, svd_solver="randomized", random_state=self.random_state)
+        self.data_pca.fit(self.data)
+        return self.data_pca.transform(self.data)
+
+    def get_params(self):
+        return {"n_pca": self.n_pca, "random_state": self.random_state}
+
+    def set_params(self, **params):
+        if "n_pca" in params and params["n_pca"] != self.n_pca:
+            raise ValueError("Cannot update n_pca. Please create a new graph")
+        if "random_state" in params:
+            self.random_state = params["random_state"]
+        return self

@@ -6,6 +6,7 @@ static thread_local std::string g_create_error;
 
 void gt_free_knn_work(gt_ctx* ctx);     // gt_knn.hip
 void gt_free_graph_state(gt_ctx* ctx);  // gt_sparse.hip
+void gt_free_landmark_state(gt_ctx* ctx);  // gt_landmark.hip
 
 extern "C" {
 
@@ -55,6 +56,7 @@ void gt_ctx_destroy(gt_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     gt_free_knn_work(ctx);
     gt_free_graph_state(ctx);
+    gt_free_landmark_state(ctx);
     ctx->reset_stages();
     for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
     ctx->X_own.release();
@@ -62,6 +64,8 @@ void gt_ctx_destroy(gt_ctx* ctx) {
     ctx->xn.release();
     ctx->hneg.release();
     ctx->ymax.release();
+    ctx->dense_degree.release();
+    ctx->dense_bw.release();
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

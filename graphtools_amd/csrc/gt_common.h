@@ -101,8 +101,13 @@ struct gt_ctx {
     DevBuf ymax;         // float [1]     max row norm (as float bits, atomicMax on uint)
     float ymax_host = 0.f;
 
+    // last dense build (gt_dense_graph_build): degree = row sums of K, bandwidth
+    DevBuf dense_degree, dense_bw;
+    int64_t dense_n = 0;
+
     KnnWork* knn = nullptr;
     GraphState* graph = nullptr;
+    void* landmark = nullptr;   // LandmarkState (gt_landmark.hip)
 
     void set_error(const std::string& m) { err = m; }
 

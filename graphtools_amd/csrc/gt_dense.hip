@@ -1,0 +1,551 @@
+// Exact dense graph (TraditionalGraph.build_kernel, graphtools/graphs.py:1514-1610, + symmetrise,
+// anisotropy and P from graphtools/base.py:557-592, 629-646) for one GPU.
+//
+//   D      : from data  -> float64 difference form sqrt(sum_k (x_ik - x_jk)^2), sequential in k (scipy pdist)
+//            precomputed -> the caller's n x n matrix, dtype preserved
+//   bw_i   : (knn+1)-th smallest entry of row i (self's 0 included) * scale, or the user bandwidth * scale
+//   K0_ij  : exp(-(D_ij / bw_i)^decay), NaN -> 1, < thresh -> 0      (arithmetic in D's dtype, like numpy)
+//   K      : symmetrised tile pair by tile pair (both (I,J) and (J,I) are produced by one workgroup, so the
+//            update can be done IN PLACE on D), then anisotropy, then P = K / rowsum.
+//
+// HBM-bound: per element 1 read + 1 write for K, 1-2 reads + 1 write for P (row sums re-read the row while
+// it is L2 resident).  The from-data variant adds 3*d float64 flops per element on the vector pipe.
+#include <cfloat>
+
+#include "gt_common.h"
+#include "gt_device.h"
+#include "gt_knn.h"
+
+namespace {
+
+constexpr int TS = 64;        // tile side
+constexpr int TSP = TS + 1;   // padded LDS row
+
+template <typename T>
+__device__ __forceinline__ T affinity_t(T dist, T bw, T decay) {
+    T w;
+    if constexpr (sizeof(T) == 4) {
+        w = expf(-powf(dist / bw, decay));
+    } else {
+        w = exp(-pow(dist / bw, decay));
+    }
+    return (w != w) ? T(1) : w;
+}
+
+template <typename T>
+__device__ __forceinline__ T merge_t(T a, T b, int symm, T theta) {
+    switch (symm) {
+        case GT_SYMM_ADD: return (a + b) / T(2);
+        case GT_SYMM_MUL: return a * b;
+        case GT_SYMM_MNN: return theta * (a < b ? a : b) + (T(1) - theta) * (a < b ? b : a);
+        default: return a;
+    }
+}
+
+// ---- bandwidth from a precomputed distance matrix: (knn+1)-th smallest of every row --------------
+template <typename T, int KL>
+__global__ __launch_bounds__(256) void dense_bandwidth_kernel(const T* __restrict__ D, const int64_t n, const int kth,
+                                                              const double scale, double* __restrict__ bw) {
+    __shared__ double cand[256 * KL];
+    __shared__ int red[4];
+    const int64_t i = blockIdx.x;
+    const int tid = threadIdx.x;
+    const T* row = D + i * n;
+    double best[KL];
+#pragma unroll
+    for (int t = 0; t < KL; ++t) best[t] = INFINITY;
+    for (int64_t j = tid; j < n; j += 256) {
+        const double v = double(row[j]);
+        if (v < best[KL - 1]) {
+            best[KL - 1] = v;
+#pragma unroll
+            for (int t = KL - 1; t > 0; --t) {
+                if (best[t] < best[t - 1]) {
+                    const double tmp = best[t];
+                    best[t] = best[t - 1];
+                    best[t - 1] = tmp;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < KL; ++t) cand[tid * KL + t] = best[t];
+    __syncthreads();
+    // kth smallest (1-based) of the 256*KL candidates by bitwise search on the float64 pattern (values >= 0)
+    unsigned long long v = 0ull;
+    for (int b = 63; b >= 0; --b) {
+        const unsigned long long trial = v | ((1ull << b) - 1ull);
+        int c = 0;
+        for (int e = tid; e < 256 * KL; e += 256) {
+            const double x = cand[e];
+            const unsigned long long key = (x > 0.0) ? (unsigned long long)__double_as_longlong(x) : 0ull;
+            c += (key <= trial) ? 1 : 0;
+        }
+        c = wave_sum_i32(c);
+        __syncthreads();
+        if ((tid & 63) == 0) red[tid >> 6] = c;
+        __syncthreads();
+        const int total = red[0] + red[1] + red[2] + red[3];
+        if (total < kth) v |= (1ull << b);
+    }
+    if (tid == 0) bw[i] = __longlong_as_double((long long)v) * scale;
+}
+
+// generic (any kth): bitwise search straight over the row (64 passes; the row stays L2 resident)
+template <typename T>
+__global__ __launch_bounds__(256) void dense_bandwidth_generic_kernel(const T* __restrict__ D, const int64_t n,
+                                                                      const int kth, const double scale,
+                                                                      double* __restrict__ bw) {
+    __shared__ int red[4];
+    const int64_t i = blockIdx.x;
+    const int tid = threadIdx.x;
+    const T* row = D + i * n;
+    unsigned long long v = 0ull;
+    for (int b = 63; b >= 0; --b) {
+        const unsigned long long trial = v | ((1ull << b) - 1ull);
+        int c = 0;
+        for (int64_t j = tid; j < n; j += 256) {
+            const double x = double(row[j]);
+            const unsigned long long key = (x > 0.0) ? (unsigned long long)__double_as_longlong(x) : 0ull;
+            c += (key <= trial) ? 1 : 0;
+        }
+        c = wave_sum_i32(c);
+        __syncthreads();
+        if ((tid & 63) == 0) red[tid >> 6] = c;
+        __syncthreads();
+        const int total = red[0] + red[1] + red[2] + red[3];
+        if (total < kth) v |= (1ull << b);
+    }
+    if (tid == 0) bw[i] = __longlong_as_double((long long)v) * scale;
+}
+
+// ---- bandwidth from data: exact difference-form distance of the (knn+1) nearest candidates ---------
+template <typename T>
+__global__ __launch_bounds__(256) void dense_bandwidth_from_knn_kernel(const T* __restrict__ X, const int64_t n,
+                                                                       const int d, const uint32_t* __restrict__ cand_j,
+                                                                       const int MP, const int kth, const double scale,
+                                                                       double* __restrict__ bw) {
+    const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= n) return;
+    const T* xi = X + i * d;
+    double m = 0.0;
+    for (int c = 0; c < kth; ++c) {
+        const T* xj = X + int64_t(cand_j[i * MP + c]) * d;
+        double s = 0.0;
+        for (int k = 0; k < d; ++k) {
+            const double diff = double(xi[k]) - double(xj[k]);
+            s += diff * diff;
+        }
+        const double dist = sqrt(s);
+        m = dist > m ? dist : m;
+    }
+    bw[i] = m * scale;
+}
+
+__global__ void dense_user_bandwidth_kernel(const double* __restrict__ user, const int64_t len, const int64_t n,
+                                            const double scale, double* __restrict__ bw) {
+    const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i < n) bw[i] = (len == 1 ? user[0] : user[i]) * scale;
+}
+
+// ---- tile-pair kernel ------------------------------------------------------------------------------
+// grid.x enumerates tile pairs (bi <= bj).  TC = compute/output dtype, TD = dtype of the stored distances.
+template <typename TD, typename TC, typename TX, bool FROM_DATA>
+__global__ __launch_bounds__(256) void dense_kernel_tiles(const TD* __restrict__ D, const TX* __restrict__ X, const int d,
+                                                          const int64_t n, const int nb, const double* __restrict__ bw,
+                                                          const double decay_d, const double thresh_d, const int symm,
+                                                          const double theta_d, TC* __restrict__ Kout,
+                                                          uint32_t* __restrict__ flags) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    TC* sA = reinterpret_cast<TC*>(smem_raw);      // [TS][TSP]  K0 of tile (I,J): sA[i][j]
+    TC* sB = sA + TS * TSP;                        // [TS][TSP]  K0 of tile (J,I): sB[j][i]
+    double* xI = reinterpret_cast<double*>(sB + TS * TSP);   // FROM_DATA: [TS][KC] chunks
+    // decode (bi, bj) with bi <= bj from the linear pair index
+    int64_t p = blockIdx.x;
+    int bi = 0;
+    {
+        // row bi of the upper triangle holds nb - bi pairs
+        int64_t rem = p;
+        int lo = 0, hi = nb;   // find bi such that offset(bi) <= p < offset(bi+1), offset(b) = b*nb - b(b-1)/2
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) / 2;
+            const int64_t off = int64_t(mid) * nb - int64_t(mid) * (mid - 1) / 2;
+            if (off <= p) lo = mid; else hi = mid;
+        }
+        bi = lo;
+        rem = p - (int64_t(bi) * nb - int64_t(bi) * (bi - 1) / 2);
+        p = rem;
+    }
+    const int bj = bi + int(p);
+    const int64_t I0 = int64_t(bi) * TS, J0 = int64_t(bj) * TS;
+    const int tx = threadIdx.x & 63;
+    const int ty = threadIdx.x >> 6;
+    const TC decay = TC(decay_d), thresh = TC(thresh_d), theta = TC(theta_d);
+    const bool diag = (bi == bj);
+
+    if (FROM_DATA) {
+        constexpr int KC = 32, KCP = 33;   // padded stride: conflict-free per-lane rows
+        double* xJ = xI + TS * KCP;
+        double acc[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0;
+        for (int k0 = 0; k0 < d; k0 += KC) {
+            __syncthreads();
+            for (int e = threadIdx.x; e < TS * KC; e += 256) {
+                const int r = e / KC, k = e % KC;
+                const int64_t gi = I0 + r, gj = J0 + r;
+                xI[r * KCP + k] = (gi < n && k0 + k < d) ? double(X[gi * d + k0 + k]) : 0.0;
+                xJ[r * KCP + k] = (gj < n && k0 + k < d) ? double(X[gj * d + k0 + k]) : 0.0;
+            }
+            __syncthreads();
+            const int kc = (d - k0) < KC ? (d - k0) : KC;
+            for (int k = 0; k < kc; ++k) {
+                const double xj = xJ[tx * KCP + k];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const double diff = xI[(ty + 4 * r) * KCP + k] - xj;
+                    acc[r] += diff * diff;
+                }
+            }
+        }
+        // D is symmetric here: K0_ij uses bw_i, K0_ji uses bw_j
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = ty + 4 * r, j = tx;
+            const int64_t gi = I0 + i, gj = J0 + j;
+            TC ka = TC(0), kb = TC(0);
+            if (gi < n && gj < n) {
+                const TC dist = TC(sqrt(acc[r]));
+                ka = affinity_t<TC>(dist, TC(bw[gi]), decay);
+                kb = affinity_t<TC>(dist, TC(bw[gj]), decay);
+                if (ka < thresh) ka = TC(0);
+                if (kb < thresh) kb = TC(0);
+                if (dist == TC(0) && gi != gj) atomicOr(flags, GT_FLAG_DUPLICATES);
+            }
+            sA[i * TSP + j] = ka;
+            sB[j * TSP + i] = kb;
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = ty + 4 * r;
+            {   // tile (I,J): row I0+i, column J0+tx
+                const int64_t gi = I0 + i, gj = J0 + tx;
+                TC ka = TC(0);
+                if (gi < n && gj < n) {
+                    ka = affinity_t<TC>(TC(D[gi * n + gj]), TC(bw[gi]), decay);
+                    if (ka < thresh) ka = TC(0);
+                }
+                sA[i * TSP + tx] = ka;
+            }
+            if (!diag) {   // tile (J,I): row J0+i, column I0+tx
+                const int64_t gj = J0 + i, gi = I0 + tx;
+                TC kb = TC(0);
+                if (gi < n && gj < n) {
+                    kb = affinity_t<TC>(TC(D[gj * n + gi]), TC(bw[gj]), decay);
+                    if (kb < thresh) kb = TC(0);
+                }
+                sB[i * TSP + tx] = kb;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- symmetrise + write (both tiles are fully consumed above: safe to overwrite D in place) ----
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int i = ty + 4 * r;
+        {   // output tile (I,J): element (i, tx)
+            const int64_t gi = I0 + i, gj = J0 + tx;
+            if (gi < n && gj < n) {
+                const TC a = sA[i * TSP + tx];
+                const TC b = diag ? sA[tx * TSP + i] : sB[tx * TSP + i];
+                Kout[gi * n + gj] = merge_t<TC>(a, b, symm, theta);
+            }
+        }
+        if (!diag) {   // output tile (J,I): element (row j = i-th row of J block, column tx of I block)
+            const int64_t gj = J0 + i, gi = I0 + tx;
+            if (gi < n && gj < n) {
+                const TC b = sB[i * TSP + tx];
+                const TC a = sA[tx * TSP + i];
+                Kout[gj * n + gi] = merge_t<TC>(b, a, symm, theta);
+            }
+        }
+    }
+}
+
+// ---- row sums / anisotropy / normalisation ---------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void dense_rowsum_kernel(const T* __restrict__ K, const int64_t n, const int use_abs,
+                                                           double* __restrict__ out, uint32_t* __restrict__ flags) {
+    __shared__ double red[4];
+    const int64_t i = blockIdx.x;
+    const T* row = K + i * n;
+    double s = 0.0;
+    for (int64_t j = threadIdx.x; j < n; j += 256) {
+        const double v = double(row[j]);
+        s += use_abs ? fabs(v) : v;
+    }
+    s = wave_sum_f64(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out[i] = red[0] + red[1] + red[2] + red[3];
+        if (flags && row[i] == T(0)) atomicOr(flags, GT_FLAG_ZERO_DIAGONAL);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void dense_anisotropy_kernel(T* __restrict__ K, const int64_t n,
+                                                               const double* __restrict__ deg, const double alpha) {
+    const int64_t i = blockIdx.y;
+    const int64_t j = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (j >= n) return;
+    if constexpr (sizeof(T) == 4) {
+        // numpy: float32 K / (outer(d, d) ** alpha) with d float32
+        const float q = powf(float(deg[i]) * float(deg[j]), float(alpha));
+        K[i * n + j] = K[i * n + j] / q;
+    } else {
+        K[i * n + j] = K[i * n + j] / pow(deg[i] * deg[j], alpha);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void dense_normalize_kernel(const T* __restrict__ K, const int64_t n,
+                                                              const double* __restrict__ rowsum, T* __restrict__ P) {
+    const int64_t i = blockIdx.y;
+    const int64_t j = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (j >= n) return;
+    double s = rowsum[i];
+    if (s == 0.0) s = 1.0;   // sklearn _handle_zeros_in_scale
+    P[i * n + j] = T(K[i * n + j] / T(s));
+}
+
+struct DenseState {
+    DevBuf bw, bw_user, rowsum, deg, work_in, work_k, work_p, flags;
+};
+
+template <typename TD, typename TC, typename TX, bool FROM_DATA>
+int launch_tiles(gt_ctx* ctx, const TD* D, const TX* X, int d, int64_t n, const double* bw, double decay, double thresh,
+                 int symm, double theta, TC* Kout, uint32_t* flags) {
+    const int nb = int(ceil_div64(n, TS));
+    const int64_t pairs = int64_t(nb) * (nb + 1) / 2;
+    size_t lds = size_t(2) * TS * TSP * sizeof(TC);
+    if (FROM_DATA) lds += size_t(2) * TS * 33 * sizeof(double);
+    auto kern = dense_kernel_tiles<TD, TC, TX, FROM_DATA>;
+    GT_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    int(lds)));
+    hipLaunchKernelGGL(kern, dim3((unsigned)pairs), dim3(256), lds, ctx->stream, D, X, d, n, nb, bw, decay, thresh, symm,
+                       theta, Kout, flags);
+    GT_HIP(ctx, hipGetLastError());
+    return GT_OK;
+}
+
+template <typename T>
+int finish_dense(gt_ctx* ctx, DenseState& st, T* K, T* P, int64_t n, double anisotropy) {
+    GT_HIP(ctx, st.rowsum.reserve(size_t(n) * sizeof(double)));
+    {
+        StageSpan span(ctx, "dense_normalize");
+        if (anisotropy != 0.0) {
+            GT_HIP(ctx, st.deg.reserve(size_t(n) * sizeof(double)));
+            hipLaunchKernelGGL(dense_rowsum_kernel<T>, dim3((unsigned)n), dim3(256), 0, ctx->stream, K, n, 0,
+                               st.deg.as<double>(), (uint32_t*)nullptr);
+            hipLaunchKernelGGL(dense_anisotropy_kernel<T>, dim3((unsigned)ceil_div64(n, 256), (unsigned)n), dim3(256), 0,
+                               ctx->stream, K, n, st.deg.as<double>(), anisotropy);
+        }
+        hipLaunchKernelGGL(dense_rowsum_kernel<T>, dim3((unsigned)n), dim3(256), 0, ctx->stream, K, n, 1,
+                           st.rowsum.as<double>(), st.flags.as<uint32_t>());
+        if (P)
+            hipLaunchKernelGGL(dense_normalize_kernel<T>, dim3((unsigned)ceil_div64(n, 256), (unsigned)n), dim3(256), 0,
+                               ctx->stream, K, n, st.rowsum.as<double>(), P);
+        GT_HIP(ctx, hipGetLastError());
+    }
+    return GT_OK;
+}
+
+}  // namespace
+
+extern "C" int gt_dense_graph_build(gt_ctx* ctx, const void* X_or_D, int64_t n, int32_t d, int32_t dtype,
+                                    int32_t on_device, int32_t precomputed, int32_t knn, double decay, double thresh,
+                                    const double* bandwidth, int64_t bandwidth_len, double bandwidth_scale,
+                                    int32_t kernel_symm, double theta, double anisotropy, int32_t inplace, void* out_K,
+                                    void* out_P, int32_t out_on_device, uint32_t* flags) {
+    if (!ctx) return GT_E_ARG;
+    GT_HIP(ctx, hipSetDevice(ctx->device));
+    ctx->reset_stages();
+    if (!X_or_D || n <= 0) GT_FAIL(ctx, GT_E_ARG, "gt_dense_graph_build: empty input");
+    if (dtype != GT_F32 && dtype != GT_F64) GT_FAIL(ctx, GT_E_ARG, "dtype must be GT_F32 or GT_F64");
+    if (std::isnan(decay)) GT_FAIL(ctx, GT_E_ARG, "`decay` must be provided for a TraditionalGraph");
+    if (bandwidth_len != 0 && bandwidth_len != 1 && bandwidth_len != n)
+        GT_FAIL(ctx, GT_E_ARG, "bandwidth must have 1 or n entries");
+    if (bandwidth_len == 0 && (knn < 0 || int64_t(knn) + 1 > n)) GT_FAIL(ctx, GT_E_ARG, "knn + 1 exceeds n_samples");
+    if (inplace && !(precomputed && on_device)) GT_FAIL(ctx, GT_E_ARG, "inplace needs a device-resident distance matrix");
+    DenseState st;
+    int rc = GT_OK;
+    // result dtype: float64 from data, D's dtype from distances (a float64 bandwidth VECTOR promotes to float64)
+    const bool out_f64 = (!precomputed) || dtype == GT_F64 || bandwidth_len > 1;
+    if (inplace && out_f64 != (dtype == GT_F64)) GT_FAIL(ctx, GT_E_ARG, "inplace needs equal input and output dtypes");
+    const size_t out_esz = out_f64 ? 8 : 4;
+    const size_t in_esz = dtype == GT_F64 ? 8 : 4;
+    auto cleanup = [&]() {
+        for (DevBuf* b : {&st.bw, &st.bw_user, &st.rowsum, &st.deg, &st.work_in, &st.work_k, &st.work_p, &st.flags})
+            b->release();
+    };
+#define DENSE_TRY(expr)            \
+    do {                           \
+        rc = (expr);               \
+        if (rc != GT_OK) {         \
+            cleanup();             \
+            return rc;             \
+        }                          \
+    } while (0)
+#define DENSE_HIP(expr)                                                                   \
+    do {                                                                                  \
+        hipError_t _e = (expr);                                                           \
+        if (_e != hipSuccess) {                                                           \
+            ctx->set_error(std::string(#expr) + ": " + hipGetErrorString(_e));            \
+            cleanup();                                                                    \
+            return GT_E_HIP;                                                              \
+        }                                                                                 \
+    } while (0)
+
+    DENSE_HIP(st.bw.reserve(size_t(n) * sizeof(double)));
+    DENSE_HIP(st.flags.reserve(sizeof(uint32_t)));
+    DENSE_HIP(hipMemsetAsync(st.flags.p, 0, sizeof(uint32_t), ctx->stream));
+    const void* in_dev = X_or_D;
+    if (!precomputed) {
+        // binds the points (device copy + norms + padded working copy for the kNN bandwidth search)
+        DENSE_TRY(gt_set_points(ctx, X_or_D, n, d, dtype, on_device));
+        in_dev = ctx->X;
+    } else if (!on_device) {
+        DENSE_HIP(st.work_in.reserve(size_t(n) * n * in_esz));
+        DENSE_HIP(hipMemcpyAsync(st.work_in.p, X_or_D, size_t(n) * n * in_esz, hipMemcpyHostToDevice, ctx->stream));
+        in_dev = st.work_in.p;
+    }
+    // ---- bandwidth ----
+    {
+        StageSpan span(ctx, "dense_bandwidth");
+        if (bandwidth_len > 0) {
+            DENSE_HIP(st.bw_user.reserve(size_t(bandwidth_len) * sizeof(double)));
+            DENSE_HIP(hipMemcpyAsync(st.bw_user.p, bandwidth, size_t(bandwidth_len) * sizeof(double),
+                                     hipMemcpyHostToDevice, ctx->stream));
+            hipLaunchKernelGGL(dense_user_bandwidth_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, ctx->stream,
+                               st.bw_user.as<double>(), bandwidth_len, n, bandwidth_scale, st.bw.as<double>());
+        } else if (!precomputed) {
+            if (ctx->DP == 0) {
+                ctx->set_error("exact graph from data needs n_features <= 128 on the HIP path (reduce with n_pca)");
+                cleanup();
+                return GT_E_LIMIT;
+            }
+            DENSE_TRY(gt_knn_candidates(ctx, 0, n, false, knn + 1));
+            KnnWork* k = ctx->knn;
+            if (dtype == GT_F32)
+                hipLaunchKernelGGL(dense_bandwidth_from_knn_kernel<float>, dim3((unsigned)ceil_div64(n, 256)), dim3(256),
+                                   0, ctx->stream, (const float*)in_dev, n, d, k->cand_j.as<uint32_t>(), k->MP, knn + 1,
+                                   bandwidth_scale, st.bw.as<double>());
+            else
+                hipLaunchKernelGGL(dense_bandwidth_from_knn_kernel<double>, dim3((unsigned)ceil_div64(n, 256)), dim3(256),
+                                   0, ctx->stream, (const double*)in_dev, n, d, k->cand_j.as<uint32_t>(), k->MP, knn + 1,
+                                   bandwidth_scale, st.bw.as<double>());
+        } else {
+            const int kth = knn + 1;
+#define LAUNCH_BW(T, KL)                                                                                               \
+    hipLaunchKernelGGL((dense_bandwidth_kernel<T, KL>), dim3((unsigned)n), dim3(256), 0, ctx->stream, (const T*)in_dev, n, \
+                       kth, bandwidth_scale, st.bw.as<double>())
+            if (dtype == GT_F32) {
+                if (kth <= 8) LAUNCH_BW(float, 8);
+                else if (kth <= 16) LAUNCH_BW(float, 16);
+                else hipLaunchKernelGGL(dense_bandwidth_generic_kernel<float>, dim3((unsigned)n), dim3(256), 0, ctx->stream,
+                                        (const float*)in_dev, n, kth, bandwidth_scale, st.bw.as<double>());
+            } else {
+                if (kth <= 8) LAUNCH_BW(double, 8);
+                else if (kth <= 16) LAUNCH_BW(double, 16);
+                else hipLaunchKernelGGL(dense_bandwidth_generic_kernel<double>, dim3((unsigned)n), dim3(256), 0, ctx->stream,
+                                        (const double*)in_dev, n, kth, bandwidth_scale, st.bw.as<double>());
+            }
+#undef LAUNCH_BW
+        }
+        DENSE_HIP(hipGetLastError());
+    }
+    // ---- kernel tiles ----
+    void* K_dev = nullptr;
+    if (inplace) {
+        K_dev = const_cast<void*>(in_dev);
+    } else if (out_K && out_on_device) {
+        K_dev = out_K;
+    } else {
+        DENSE_HIP(st.work_k.reserve(size_t(n) * n * out_esz));
+        K_dev = st.work_k.p;
+    }
+    {
+        StageSpan span(ctx, "dense_kernel");
+        uint32_t* fl = st.flags.as<uint32_t>();
+        const double* bw = st.bw.as<double>();
+        if (!precomputed) {
+            if (dtype == GT_F32)
+                DENSE_TRY((launch_tiles<double, double, float, true>(ctx, nullptr, (const float*)in_dev, d, n, bw, decay,
+                                                                     thresh, kernel_symm, theta, (double*)K_dev, fl)));
+            else
+                DENSE_TRY((launch_tiles<double, double, double, true>(ctx, nullptr, (const double*)in_dev, d, n, bw, decay,
+                                                                      thresh, kernel_symm, theta, (double*)K_dev, fl)));
+        } else if (dtype == GT_F64) {
+            DENSE_TRY((launch_tiles<double, double, double, false>(ctx, (const double*)in_dev, nullptr, 0, n, bw, decay,
+                                                                   thresh, kernel_symm, theta, (double*)K_dev, fl)));
+        } else if (out_f64) {
+            DENSE_TRY((launch_tiles<float, double, double, false>(ctx, (const float*)in_dev, nullptr, 0, n, bw, decay,
+                                                                  thresh, kernel_symm, theta, (double*)K_dev, fl)));
+        } else {
+            DENSE_TRY((launch_tiles<float, float, double, false>(ctx, (const float*)in_dev, nullptr, 0, n, bw, decay,
+                                                                 thresh, kernel_symm, theta, (float*)K_dev, fl)));
+        }
+    }
+    // ---- anisotropy + P ----
+    void* P_dev = nullptr;
+    if (out_P) {
+        if (out_on_device) {
+            P_dev = out_P;
+        } else {
+            DENSE_HIP(st.work_p.reserve(size_t(n) * n * out_esz));
+            P_dev = st.work_p.p;
+        }
+    }
+    if (out_f64)
+        DENSE_TRY(finish_dense<double>(ctx, st, (double*)K_dev, (double*)P_dev, n, anisotropy));
+    else
+        DENSE_TRY(finish_dense<float>(ctx, st, (float*)K_dev, (float*)P_dev, n, anisotropy));
+    if (out_K && !out_on_device)
+        DENSE_HIP(hipMemcpyAsync(out_K, K_dev, size_t(n) * n * out_esz, hipMemcpyDeviceToHost, ctx->stream));
+    if (out_P && !out_on_device)
+        DENSE_HIP(hipMemcpyAsync(out_P, P_dev, size_t(n) * n * out_esz, hipMemcpyDeviceToHost, ctx->stream));
+    uint32_t fl = 0;
+    DENSE_HIP(hipMemcpyAsync(&fl, st.flags.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    DENSE_HIP(hipStreamSynchronize(ctx->stream));
+    if (!precomputed && ctx->knn) {
+        uint32_t kfl = 0;
+        DENSE_HIP(hipMemcpy(&kfl, ctx->knn->gflags.p, sizeof(uint32_t), hipMemcpyDeviceToHost));
+        fl |= (kfl & GT_FLAG_DUPLICATES);
+    }
+    if (flags) *flags = fl;
+    // keep degree (row sums of K) and bandwidth for gt_dense_fetch_vec
+    ctx->dense_n = n;
+    {
+        hipError_t e1 = ctx->dense_degree.reserve(size_t(n) * sizeof(double));
+        hipError_t e2 = ctx->dense_bw.reserve(size_t(n) * sizeof(double));
+        if (e1 == hipSuccess && e2 == hipSuccess) {
+            (void)hipMemcpy(ctx->dense_degree.p, st.rowsum.p, size_t(n) * sizeof(double), hipMemcpyDeviceToDevice);
+            (void)hipMemcpy(ctx->dense_bw.p, st.bw.p, size_t(n) * sizeof(double), hipMemcpyDeviceToDevice);
+        }
+    }
+    cleanup();
+    return GT_OK;
+#undef DENSE_TRY
+#undef DENSE_HIP
+}
+
+extern "C" int gt_dense_fetch_vec(gt_ctx* ctx, int32_t which, double* out_host) {
+    if (!ctx || !out_host) return GT_E_ARG;
+    GT_HIP(ctx, hipSetDevice(ctx->device));
+    if (ctx->dense_n <= 0) GT_FAIL(ctx, GT_E_STATE, "gt_dense_fetch_vec: no dense graph built");
+    const void* src = which == GT_VEC_BANDWIDTH ? ctx->dense_bw.p : ctx->dense_degree.p;
+    GT_HIP(ctx, hipMemcpy(out_host, src, size_t(ctx->dense_n) * sizeof(double), hipMemcpyDeviceToHost));
+    return GT_OK;
+}

@@ -1,0 +1,39 @@
+// Device-resident state of a kNN graph build (gt_sparse.hip), shared with the landmark kernels.
+#pragma once
+#include <vector>
+
+#include "gt_common.h"
+
+struct Triplet {
+    uint32_t row;   // destination (global) row
+    uint32_t col;   // global column
+    double val;
+};
+static_assert(sizeof(Triplet) == 16, "triplet layout");
+
+struct GraphState {
+    gt_knn_params p{};
+    std::vector<double> bw_host;
+    int world = 1, rank = 0;
+    std::vector<int64_t> splits;
+    int64_t r0 = 0, r1 = 0, nloc = 0;
+    bool begun = false, finished = false;
+    int need_m = 0;
+    int limit = 0;          // eligible table entries per row
+    double radius_factor = 0.0;
+    // per-row
+    DevBuf bw, bw_user, rowsrc, lenN, lenT, cursor, off, outlen, indptr, degree;
+    // radius pass
+    DevBuf over_rows, over_count, rthr, rlists, rcounts, rK, rmax;
+    int64_t n_over = 0;
+    int32_t rcap = 0;
+    int64_t radius_retries = 0;
+    // exchange
+    DevBuf sendcnt, sendcur, selfbuf, splits_dev;
+    std::vector<int64_t> send_counts_host;
+    // merge
+    DevBuf Ukey, Uval, Vkey, Vval, bigrows, bigcount, bigscratch_k, bigscratch_v;
+    DevBuf indices, Kdata, Pdata, flags;
+    int64_t nnz0 = 0, nnz = 0;
+};
+

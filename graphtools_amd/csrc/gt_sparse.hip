@@ -13,39 +13,7 @@
 #include "gt_device.h"
 #include "gt_knn.h"
 #include "gt_knn_select.h"
-
-struct Triplet {
-    uint32_t row;   // destination (global) row
-    uint32_t col;   // global column
-    double val;
-};
-static_assert(sizeof(Triplet) == 16, "triplet layout");
-
-struct GraphState {
-    gt_knn_params p{};
-    std::vector<double> bw_host;
-    int world = 1, rank = 0;
-    std::vector<int64_t> splits;
-    int64_t r0 = 0, r1 = 0, nloc = 0;
-    bool begun = false, finished = false;
-    int need_m = 0;
-    int limit = 0;          // eligible table entries per row
-    double radius_factor = 0.0;
-    // per-row
-    DevBuf bw, bw_user, rowsrc, lenN, lenT, cursor, off, outlen, indptr, degree;
-    // radius pass
-    DevBuf over_rows, over_count, rthr, rlists, rcounts, rK, rmax;
-    int64_t n_over = 0;
-    int32_t rcap = 0;
-    int64_t radius_retries = 0;
-    // exchange
-    DevBuf sendcnt, sendcur, selfbuf, splits_dev;
-    std::vector<int64_t> send_counts_host;
-    // merge
-    DevBuf Ukey, Uval, Vkey, Vval, bigrows, bigcount, bigscratch_k, bigscratch_v;
-    DevBuf indices, Kdata, Pdata, flags;
-    int64_t nnz0 = 0, nnz = 0;
-};
+#include "gt_graph_state.h"
 
 void gt_free_graph_state(gt_ctx* ctx) {
     if (!ctx->graph) return;
@@ -676,6 +644,20 @@ void launch_affinity(gt_ctx* ctx, GraphState* g, KnnWork* k, int binary, double 
 }
 
 }  // namespace
+
+int gt_exclusive_scan_i32(gt_ctx* ctx, const int32_t* a, int64_t n, int64_t* out) {
+    DevBuf tmp;
+    int rc = exclusive_scan(ctx, a, nullptr, n, out, tmp);
+    if (rc == GT_OK) {
+        hipError_t e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) {
+            ctx->set_error(std::string("scan: ") + hipGetErrorString(e));
+            rc = GT_E_HIP;
+        }
+    }
+    tmp.release();
+    return rc;
+}
 
 // ================================================================================================
 extern "C" int gt_graph_begin(gt_ctx* ctx, const gt_knn_params* params, int32_t world, int32_t rank,

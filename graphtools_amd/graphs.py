@@ -1,0 +1,507 @@
+"""Concrete graph classes backed by the HIP library (reference: graphtools/graphs.py).
+
+``kNNGraph``          graphtools/graphs.py:562-982   -> gt_set_points + gt_graph_build
+``TraditionalGraph``  graphtools/graphs.py:1320-1704 -> gt_dense_graph_build
+``LandmarkGraph``     graphtools/graphs.py:985-1317  -> gt_nearest_landmark / gt_landmark_partial
+
+Same constructor arguments, attribute names, warnings and errors as the reference for this
+path; the numerics run on the MI355X.  No CPU implementation exists behind these classes.
+"""
+import numbers
+import warnings
+
+import numpy as np
+from scipy import sparse
+
+from . import _hip
+from .base import BaseGraph, Data
+
+
+class DataGraph(Data, BaseGraph):
+    """Graphs built from a data matrix (reference: graphtools/base.py:1046-1254)."""
+
+    def __init__(self, data, n_pca=None, rank_threshold=None, random_state=None, verbose=True, n_jobs=1,
+                 device=None, **kwargs):
+        self.n_jobs = n_jobs
+        self.verbose = verbose
+        self.device = device
+        Data.__init__(self, data, n_pca=n_pca, rank_threshold=rank_threshold, random_state=random_state)
+        BaseGraph.__init__(self, **kwargs)
+
+    def get_params(self):
+        params = Data.get_params(self)
+        params.update(BaseGraph.get_params(self))
+        return params
+
+    def set_params(self, **params):
+        if "n_jobs" in params:
+            self.n_jobs = params["n_jobs"]
+        if "verbose" in params:
+            self.verbose = params["verbose"]
+        Data.set_params(self, **params)
+        BaseGraph.set_params(self, **params)
+        return self
+
+    def _check_extension_shape(self, Y):
+        Y = np.asarray(Y)
+        if Y.ndim != 2:
+            raise ValueError("Expected a 2D matrix. Y has shape {}".format(Y.shape))
+        if Y.shape[1] != self.data_nu.shape[1]:
+            if Y.shape[1] == self.data.shape[1] and self.n_pca is not None:
+                Y = self.data_pca.transform(Y)
+            else:
+                raise ValueError(
+                    "Y must be of shape either (n, {}) or (n, {})".format(self.data.shape[1], self.data_nu.shape[1])
+                )
+        return Y
+
+
+class _KnnTree(object):
+    """Stand-in for the reference's ``knn_tree`` attribute (a fitted sklearn NearestNeighbors,
+    graphs.py:748-769): ``kneighbors`` runs the brute-force search on the device."""
+
+    def __init__(self, graph):
+        self._graph = graph
+        self._fit_method = "brute"
+
+    def kneighbors(self, X=None, n_neighbors=None, return_distance=True):
+        g = self._graph
+        if n_neighbors is None:
+            n_neighbors = g.knn + 1
+        g._bind_points()
+        if X is None or X is g.data_nu:
+            dist, idx, _ = g.hip.knn_search(int(n_neighbors))
+        else:
+            dist, idx, _ = g.hip.knn_search(int(n_neighbors), Y=np.asarray(X))
+        return (dist, idx) if return_distance else idx
+
+
+class kNNGraph(DataGraph):
+    """K nearest neighbours graph with optional alpha-decay kernel (reference: graphs.py:562-982)."""
+
+    def __init__(self, data, knn=5, decay=None, knn_max=None, search_multiplier=6, bandwidth=None,
+                 bandwidth_scale=1.0, distance="euclidean", thresh=1e-4, n_pca=None, **kwargs):
+        # reference: graphs.py:621-661
+        if decay is not None:
+            if thresh <= 0 and knn_max is None:
+                raise ValueError(
+                    "Cannot instantiate a kNNGraph with `decay=None`, "
+                    "`thresh=0` and `knn_max=None`. Use a TraditionalGraph instead."
+                )
+            elif thresh < np.finfo(float).eps:
+                thresh = np.finfo(float).eps
+        if callable(bandwidth):
+            raise NotImplementedError(
+                "Callable bandwidth is only supported by graphtools.graphs.TraditionalGraph."
+            )
+        if knn is None and bandwidth is None:
+            raise ValueError("Either `knn` or `bandwidth` must be provided.")
+        elif knn is None and bandwidth is not None:
+            knn = 5
+        if decay is None and bandwidth is not None:
+            warnings.warn("`bandwidth` is not used when `decay=None`.", UserWarning)
+        n_samples = data.shape[0]
+        if knn > n_samples - 2:
+            warnings.warn(
+                "Cannot set knn ({k}) to be greater than "
+                "n_samples - 2 ({n}). Setting knn={n}".format(k=knn, n=n_samples - 2)
+            )
+            knn = n_samples - 2
+        if knn_max is not None and knn_max < knn:
+            warnings.warn(
+                "Cannot set knn_max ({knn_max}) to be less than "
+                "knn ({knn}). Setting knn_max={knn}".format(knn=knn, knn_max=knn_max)
+            )
+            knn_max = knn
+        if n_pca in [None, 0, False] and data.shape[1] > 500:
+            warnings.warn(
+                "Building a kNNGraph on data of shape {} is expensive. Consider setting n_pca.".format(data.shape),
+                UserWarning,
+            )
+        if distance != "euclidean":
+            raise NotImplementedError(
+                "graphtools_amd.kNNGraph: distance='{}' is not available on the HIP path yet "
+                "(euclidean only)".format(distance)
+            )
+        self.knn = knn
+        self.knn_max = knn_max
+        self.search_multiplier = search_multiplier
+        self.decay = decay
+        self.bandwidth = bandwidth
+        self.bandwidth_scale = bandwidth_scale
+        self.distance = distance
+        self.thresh = thresh
+        super().__init__(data, n_pca=n_pca, **kwargs)
+
+    def get_params(self):
+        params = super().get_params()
+        params.update({
+            "knn": self.knn, "decay": self.decay, "bandwidth": self.bandwidth,
+            "bandwidth_scale": self.bandwidth_scale, "knn_max": self.knn_max, "distance": self.distance,
+            "thresh": self.thresh, "n_jobs": self.n_jobs, "random_state": self.random_state, "verbose": self.verbose,
+        })
+        return params
+
+    def set_params(self, **params):
+        # reference: graphs.py:693-746
+        if "knn" in params and params["knn"] != self.knn:
+            raise ValueError("Cannot update knn. Please create a new graph")
+        if "knn_max" in params and params["knn_max"] != self.knn:
+            raise ValueError("Cannot update knn_max. Please create a new graph")
+        if "decay" in params and params["decay"] != self.decay:
+            raise ValueError("Cannot update decay. Please create a new graph")
+        if "bandwidth" in params and params["bandwidth"] != self.bandwidth:
+            raise ValueError("Cannot update bandwidth. Please create a new graph")
+        if "bandwidth_scale" in params and params["bandwidth_scale"] != self.bandwidth_scale:
+            raise ValueError("Cannot update bandwidth_scale. Please create a new graph")
+        if "distance" in params and params["distance"] != self.distance:
+            raise ValueError("Cannot update distance. Please create a new graph")
+        if "thresh" in params and params["thresh"] != self.thresh and self.decay != 0:
+            raise ValueError("Cannot update thresh. Please create a new graph")
+        super().set_params(**params)
+        return self
+
+    # ---- device -------------------------------------------------------------------------------
+    def _bind_points(self):
+        if getattr(self, "_points_bound", False):
+            return
+        X = np.ascontiguousarray(self.data_nu)
+        if X.dtype not in (np.float32, np.float64):
+            X = X.astype(np.float64)
+        self.hip.set_points(X)
+        self._points_bound = True
+
+    @property
+    def knn_tree(self):
+        try:
+            return self._knn_tree
+        except AttributeError:
+            self._knn_tree = _KnnTree(self)
+            return self._knn_tree
+
+    def _check_duplicates(self):
+        # reference: graphs.py:787-817; only reached when the device flagged a zero distance
+        search_knn = min((self.knn + 1) * self.search_multiplier, self.data_nu.shape[0])
+        if self.knn_max:
+            search_knn = min(search_knn, self.knn_max + 1)
+        distances, indices = self.knn_tree.kneighbors(None, n_neighbors=min(search_knn, 96))
+        if np.any(distances[:, 1] == 0):
+            has_duplicates = distances[:, 1] == 0
+            if np.sum(distances[:, 1:] == 0) < 20:
+                idx = np.argwhere((distances == 0) & has_duplicates[:, None])
+                duplicate_ids = np.array(
+                    [[indices[i[0], i[1]], i[0]] for i in idx if indices[i[0], i[1]] < i[0]]
+                )
+                duplicate_ids = duplicate_ids[np.argsort(duplicate_ids[:, 0])]
+                duplicate_names = ", ".join(["{} and {}".format(i[0], i[1]) for i in duplicate_ids])
+                warnings.warn(
+                    "Detected zero distance between samples {}. Consider removing duplicates to avoid errors in "
+                    "downstream processing.".format(duplicate_names),
+                    RuntimeWarning,
+                )
+            else:
+                warnings.warn(
+                    "Detected zero distance between {} pairs of samples. Consider removing duplicates to avoid "
+                    "errors in downstream processing.".format(np.sum(np.sum(distances[:, 1:] == 0)) // 2),
+                    RuntimeWarning,
+                )
+
+    def _params_struct(self):
+        bw = self.bandwidth
+        if bw is not None and not isinstance(bw, numbers.Number):
+            bw = np.asarray(bw, dtype=np.float64)
+            if bw.shape != (self.data_nu.shape[0],):
+                raise ValueError("bandwidth must be a scalar or have one entry per sample")
+        return _hip.Context.make_params(self.knn, self.decay, self.thresh, bw, self.bandwidth_scale, self.knn_max,
+                                        self.kernel_symm, self.theta, self.anisotropy)
+
+    def _device_build(self, kernel_symm, theta, anisotropy):
+        self._bind_points()
+        params, keep = self._params_struct()
+        params.kernel_symm = _hip.SYMM[kernel_symm]
+        params.theta = 1.0 if theta is None else float(theta)
+        params.anisotropy = float(anisotropy)
+        nnz, flags = self.hip.graph_build(params)
+        del keep
+        self._device_state = (kernel_symm, theta, anisotropy)
+        return nnz, flags
+
+    def _ensure_device_graph(self):
+        """(Re)build on the device if another build (e.g. build_kernel()) replaced the cached state."""
+        want = (self.kernel_symm, self.theta, self.anisotropy)
+        if getattr(self, "_device_state", None) != want:
+            self._device_build(*want)
+
+    def _build_kernel(self):
+        nnz, flags = self._device_build(self.kernel_symm, self.theta, self.anisotropy)
+        self._build_flags = flags
+        data, indices, indptr = self.hip.graph_fetch_csr(_hip.CSR_K)
+        n = self.data_nu.shape[0]
+        if nnz < 2**31:
+            indptr = indptr.astype(np.int32)
+        K = sparse.csr_matrix((data, indices, indptr), shape=(n, n))
+        if flags & _hip.FLAG_DUPLICATES:
+            self._check_duplicates()
+        self._emit_build_warnings(flags)
+        return K
+
+    def build_kernel(self):
+        """The unsymmetrised kernel K0 (reference: graphs.py:771-785), as a scipy CSR matrix."""
+        nnz, flags = self._device_build(None, None, 0)
+        data, indices, indptr = self.hip.graph_fetch_csr(_hip.CSR_K)
+        n = self.data_nu.shape[0]
+        if nnz < 2**31:
+            indptr = indptr.astype(np.int32)
+        return sparse.csr_matrix((data, indices, indptr), shape=(n, n))
+
+    def _fetch_diff_op(self):
+        self._ensure_device_graph()
+        data, _, _ = self.hip.graph_fetch_csr(_hip.CSR_P)
+        K = self._kernel
+        return sparse.csr_matrix((data, K.indices, K.indptr), shape=K.shape)
+
+    def _fetch_degree(self):
+        self._ensure_device_graph()
+        return self.hip.graph_fetch_vec(_hip.VEC_DEGREE)
+
+    @property
+    def build_stats(self):
+        """Device-side statistics of the last build (fallback / radius rows, stage timings in ms)."""
+        self.K
+        st = self.hip.graph_stats()
+        st["stage_ms"] = {s: self.hip.stage_ms(s) for s in
+                          ("knn_select", "rerank", "fallback", "radius", "affinity", "symmetrize", "normalize")}
+        return st
+
+    def build_kernel_to_data(self, Y, knn=None, knn_max=None, bandwidth=None, bandwidth_scale=None):
+        raise NotImplementedError(
+            "graphtools_amd: out-of-sample extension (build_kernel_to_data / extend_to_data) is the next "
+            "row of the build plan and is not on the HIP path yet"
+        )
+
+
+class LandmarkGraph(DataGraph):
+    """Landmark graph mixin (reference: graphtools/graphs.py:985-1317).
+
+    The cluster assignment for ``random_landmarking=True`` and the operator algebra
+    (``pmn``/``pnm`` aggregation, both normalisations, the L x L product) run on the device.  The spectral
+    front end of the default mode (randomized SVD of ``diff_aff`` + MiniBatchKMeans, graphs.py:1215-1230)
+    is RNG/iteration-order dependent pre-processing and stays on host scikit-learn exactly as in the
+    reference; its labels are an input to the device step.
+    """
+
+    def __init__(self, data, n_landmark=2000, n_svd=100, random_landmarking=False, **kwargs):
+        if n_landmark >= data.shape[0]:
+            raise ValueError(
+                "n_landmark ({}) >= n_samples ({}). Use kNNGraph instead".format(n_landmark, data.shape[0])
+            )
+        if (n_svd >= data.shape[0]) and (not random_landmarking):
+            warnings.warn(
+                "n_svd ({}) >= n_samples ({}) Consider using kNNGraph or lower n_svd".format(n_svd, data.shape[0]),
+                RuntimeWarning,
+            )
+        self.random_landmarking = random_landmarking
+        self.n_landmark = n_landmark
+        self.n_svd = n_svd
+        super().__init__(data, **kwargs)
+
+    def get_params(self):
+        params = super().get_params()
+        params.update({"n_landmark": self.n_landmark, "n_pca": self.n_pca,
+                       "random_landmarking": self.random_landmarking})
+        return params
+
+    def set_params(self, **params):
+        reset_landmarks = False
+        if "n_landmark" in params and params["n_landmark"] != self.n_landmark:
+            self.n_landmark = params["n_landmark"]
+            reset_landmarks = True
+        if "n_svd" in params and params["n_svd"] != self.n_svd:
+            self.n_svd = params["n_svd"]
+            reset_landmarks = True
+        if "random_landmarking" in params and params["random_landmarking"] != self.random_landmarking:
+            self.random_landmarking = params["random_landmarking"]
+            reset_landmarks = True
+        super().set_params(**params)
+        if reset_landmarks:
+            self._reset_landmarks()
+        return self
+
+    def _reset_landmarks(self):
+        for attr in ("_landmark_op", "_transitions", "_clusters"):
+            if hasattr(self, attr):
+                delattr(self, attr)
+
+    @property
+    def landmark_op(self):
+        try:
+            return self._landmark_op
+        except AttributeError:
+            self.build_landmark_op()
+            return self._landmark_op
+
+    @property
+    def clusters(self):
+        try:
+            return self._clusters
+        except AttributeError:
+            self.build_landmark_op()
+            return self._clusters
+
+    @property
+    def transitions(self):
+        try:
+            return self._transitions
+        except AttributeError:
+            self.build_landmark_op()
+            return self._transitions
+
+    def _assign_clusters(self):
+        n_samples = self.data.shape[0]
+        if self.random_landmarking:
+            # reference: graphs.py:1200-1213
+            rng = np.random.default_rng(self.random_state)
+            landmark_indices = rng.choice(n_samples, self.n_landmark, replace=False)
+            self._bind_points()
+            mode = 1 if (n_samples > 5000 and self.distance == "euclidean") else 0
+            return self.hip.nearest_landmark(landmark_indices, mode).astype(np.int64)
+        # spectral front end on host scikit-learn, as in the reference (graphs.py:1215-1230)
+        from sklearn.cluster import MiniBatchKMeans
+        from sklearn.utils.extmath import randomized_svd
+
+        _, _, VT = randomized_svd(self.diff_aff, n_components=self.n_svd, random_state=self.random_state)
+        kmeans = MiniBatchKMeans(self.n_landmark, init_size=3 * self.n_landmark, n_init=1, batch_size=10000,
+                                 random_state=self.random_state)
+        return kmeans.fit_predict(self.diff_op.dot(VT.T))
+
+    def build_landmark_op(self):
+        """Landmark operator and sample-to-landmark transitions (reference: graphs.py:1187-1246)."""
+        self.K
+        if not sparse.issparse(self._kernel):
+            raise NotImplementedError(
+                "graphtools_amd: the landmark operator is accelerated for kNN (sparse) kernels only"
+            )
+        if not hasattr(self, "_clusters"):
+            self._clusters = self._assign_clusters()
+        landmarks, inverse = np.unique(self._clusters, return_inverse=True)
+        L = len(landmarks)
+        self._ensure_device_graph()
+        M, R, tnnz = self.hip.landmark_build(inverse.astype(np.int32), L)
+        self._landmark_op = self.hip.landmark_scale(M, R)
+        data, indices, indptr = self.hip.landmark_fetch_transitions(tnnz)
+        self._transitions = sparse.csr_matrix((data, indices, indptr), shape=(self.data.shape[0], L))
+
+
+class TraditionalGraph(DataGraph):
+    """Exact dense alpha-decay graph (reference: graphtools/graphs.py:1320-1704)."""
+
+    def __init__(self, data, knn=5, decay=40, bandwidth=None, bandwidth_scale=1.0, distance="euclidean", n_pca=None,
+                 thresh=1e-4, precomputed=None, **kwargs):
+        # reference: graphs.py:1397-1436
+        if decay is None and precomputed not in ["affinity", "adjacency"]:
+            raise ValueError("`decay` must be provided for a TraditionalGraph. For kNN kernel, use kNNGraph.")
+        if precomputed is not None and n_pca not in [None, 0, False]:
+            n_pca = None
+            warnings.warn("n_pca cannot be given on a precomputed graph. Setting n_pca=None", RuntimeWarning)
+        if knn is None and bandwidth is None:
+            raise ValueError("Either `knn` or `bandwidth` must be provided.")
+        if knn is not None and knn > data.shape[0] - 2:
+            warnings.warn(
+                "Cannot set knn ({k}) to be greater than "
+                " n_samples - 2 ({n}). Setting knn={n}".format(k=knn, n=data.shape[0] - 2)
+            )
+            knn = data.shape[0] - 2
+        if precomputed is not None:
+            if precomputed not in ["distance", "affinity", "adjacency"]:
+                raise ValueError(
+                    "Precomputed value {} not recognized. "
+                    "Choose from ['distance', 'affinity', 'adjacency']".format(precomputed)
+                )
+            elif data.shape[0] != data.shape[1]:
+                raise ValueError("Precomputed {} must be a square matrix. {} was given".format(precomputed, data.shape))
+            elif (data < 0).sum() > 0:
+                raise ValueError("Precomputed {} should be non-negative".format(precomputed))
+        if distance != "euclidean" and precomputed is None:
+            raise NotImplementedError(
+                "graphtools_amd.TraditionalGraph: distance='{}' is not available on the HIP path yet".format(distance)
+            )
+        self.knn = knn
+        self.decay = decay
+        self.bandwidth = bandwidth
+        self.bandwidth_scale = bandwidth_scale
+        self.distance = distance
+        self.thresh = thresh
+        self.precomputed = precomputed
+        super().__init__(data, n_pca=n_pca, **kwargs)
+
+    def get_params(self):
+        params = super().get_params()
+        params.update({
+            "knn": self.knn, "decay": self.decay, "bandwidth": self.bandwidth,
+            "bandwidth_scale": self.bandwidth_scale, "distance": self.distance, "precomputed": self.precomputed,
+        })
+        return params
+
+    def set_params(self, **params):
+        # reference: graphs.py:1462-1512
+        if "precomputed" in params and params["precomputed"] != self.precomputed:
+            raise ValueError("Cannot update precomputed. Please create a new graph")
+        if "distance" in params and params["distance"] != self.distance and self.precomputed is None:
+            raise ValueError("Cannot update distance. Please create a new graph")
+        if "knn" in params and params["knn"] != self.knn and self.precomputed is None:
+            raise ValueError("Cannot update knn. Please create a new graph")
+        if "decay" in params and params["decay"] != self.decay and self.precomputed is None:
+            raise ValueError("Cannot update decay. Please create a new graph")
+        if "bandwidth" in params and params["bandwidth"] != self.bandwidth and self.precomputed is None:
+            raise ValueError("Cannot update bandwidth. Please create a new graph")
+        if "bandwidth_scale" in params and params["bandwidth_scale"] != self.bandwidth_scale:
+            raise ValueError("Cannot update bandwidth_scale. Please create a new graph")
+        super().set_params(**params)
+        return self
+
+    def _build_kernel(self):
+        data = self.data_nu
+        if sparse.issparse(data):
+            data = data.toarray()
+        data = np.asarray(data)
+        if self.precomputed in ("affinity", "adjacency"):
+            raise NotImplementedError(
+                "graphtools_amd: precomputed='{}' is a pass-through of the caller's matrix and is not routed "
+                "through the device".format(self.precomputed)
+            )
+        bandwidth = self.bandwidth
+        if callable(bandwidth):
+            if self.precomputed != "distance":
+                raise NotImplementedError(
+                    "graphtools_amd: a callable bandwidth needs the distance matrix on the host; pass "
+                    "precomputed='distance'"
+                )
+            bandwidth = np.asarray(bandwidth(data), dtype=np.float64)
+        K, P, flags = self.hip.dense_graph_build(
+            data, self.precomputed == "distance", self.knn, self.decay, self.thresh, bandwidth, self.bandwidth_scale,
+            self.kernel_symm, self.theta, self.anisotropy, want_P=True)
+        self._diff_op = P
+        self._kernel_degree = self.hip.dense_fetch_vec(_hip.VEC_DEGREE, K.shape[0]).reshape(-1, 1).astype(K.dtype)
+        if flags & _hip.FLAG_DUPLICATES and self.precomputed is None:
+            warnings.warn(
+                "Detected zero distance between samples. Consider removing duplicates to avoid errors in "
+                "downstream processing.", RuntimeWarning)
+        self._emit_build_warnings(flags)
+        return K
+
+    def _fetch_diff_op(self):
+        return self._diff_op
+
+    def _fetch_degree(self):
+        return self._kernel_degree
+
+    def build_kernel_to_data(self, Y, knn=None, bandwidth=None, bandwidth_scale=None):
+        raise NotImplementedError("graphtools_amd: out-of-sample extension is not on the HIP path yet")
+
+
+class kNNLandmarkGraph(kNNGraph, LandmarkGraph):
+    pass
+
+
+class TraditionalLandmarkGraph(TraditionalGraph, LandmarkGraph):
+    pass

@@ -167,23 +167,29 @@ int gt_dense_graph_build(gt_ctx* ctx, const void* X_or_D, int64_t n, int32_t d, 
                          int32_t kernel_symm, double theta, double anisotropy, int32_t inplace,
                          void* out_K, void* out_P, int32_t out_on_device, uint32_t* flags);
 
+/* degree (row sums of K, GT_VEC_DEGREE) or bandwidth (GT_VEC_BANDWIDTH) of the last dense build, n float64 to host */
+int gt_dense_fetch_vec(gt_ctx* ctx, int32_t which, double* out_host);
+
 /* ---- landmark operator (LandmarkGraph) ------------------------------------------------------ */
 /* Replaces LandmarkGraph._landmarks_to_data + the products of build_landmark_op
- * (graphs.py:1169-1182, 1232-1246) on the kernel of the most recent gt_graph_finish.
- * clusters: int32 [rows] labels in [0, n_landmark) for the OWNED rows (host); labels must be dense
- * (np.unique-compressed by the caller).  Outputs:
- *   partial_op     float64 [L*L]  sum over owned rows n of  pmn[:, n] (x) pnm_hat[n, :] partial products,
- *                  to be summed over ranks (RCCL all-reduce) and then row-scaled by 1/col_sums;
- *   partial_colsum float64 [L]    partial row sums of pmn (sum over owned columns), same all-reduce;
- *   transitions    CSR over owned rows x L (row-normalised pnm): counts via gt_landmark_transitions_*.
- * See graphtools_amd/graphs.py for the host algebra that finishes the operator. */
-int gt_landmark_partial(gt_ctx* ctx, const int32_t* clusters, int32_t n_landmark,
-                        double* partial_op, double* partial_colsum, int32_t out_on_device);
-int gt_landmark_transitions_nnz(const gt_ctx* ctx, int64_t* nnz);
+ * (graphs.py:1169-1182, 1232-1246) on the kernel of the most recent gt_graph_finish (owned rows).
+ *   clusters : int32 [n] (host) dense labels in [0, n_landmark) for ALL n points (the caller applies
+ *              np.unique(..., return_inverse=True), graphs.py:1170).
+ * gt_landmark_build forms, for the owned rows n,
+ *   pnm[n, c]  = sum_{j in cluster c} K[n, j]          (= pmn[c, n]; K is symmetric)
+ *   transitions[n, :] = pnm[n, :] / sum_c pnm[n, c]     (CSR over owned rows x n_landmark, fetched separately)
+ *   M[c, c']   = sum_n pnm[n, c] * transitions[n, c']   R[c] = sum_n pnm[n, c]      (float64 [L*L], [L])
+ * M and R are partial sums over the owned rows; with world > 1 the caller sums them over ranks (RCCL
+ * all-reduce) before gt_landmark_scale, which finishes landmark_op[c, :] = M[c, :] / R[c] in place. */
+int gt_landmark_build(gt_ctx* ctx, const int32_t* clusters, int32_t n_landmark, double* out_M, double* out_R,
+                      int32_t out_on_device, int64_t* out_transitions_nnz);
+int gt_landmark_scale(gt_ctx* ctx, double* M_inout, const double* R, int32_t n_landmark, int32_t on_device);
+/* transitions of the last gt_landmark_build: data float64 [nnz], indices int32 [nnz], indptr int64 [rows+1] */
 int gt_landmark_fetch_transitions(gt_ctx* ctx, double* data, int32_t* indices, int64_t* indptr, int32_t on_device);
 /* Random-landmark assignment (graphs.py:1200-1213): clusters[i] = argmin_j |x_i - x_{landmarks[j]}| over the
  * bound points, rows [row0,row1); ties -> lowest j.  mode 0: scipy cdist arithmetic (float64 difference
- * form), mode 1: sklearn euclidean_distances arithmetic (float64 GEMM form rounded to the input dtype). */
+ * form), mode 1: sklearn euclidean_distances arithmetic (float64 GEMM form rounded to the input dtype).
+ * landmarks: int64 [n_landmark] (host), out_clusters: int32 [row1-row0] (host). */
 int gt_nearest_landmark(gt_ctx* ctx, int64_t row0, int64_t row1, const int64_t* landmarks, int32_t n_landmark,
                         int32_t mode, int32_t* out_clusters);
 

@@ -1,0 +1,69 @@
+"""CPU: the C-ABI library loads, exports every symbol declared in include/graphtools_amd.h, its structs
+have the declared layout, and the product path fails loudly (no CPU fallback) when no GPU is present."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from graphtools_amd import _hip
+
+HEADER = os.path.join(ROOT, "include", "graphtools_amd.h")
+
+
+def _declared_functions():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(gt_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = ctypes.CDLL(_hip.LIB_PATH)
+    names = _declared_functions()
+    assert len(names) >= 25
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+
+
+def test_python_binding_covers_header():
+    assert set(_declared_functions()) == set(_hip._SIGNATURES)
+
+
+def test_abi_version_and_struct_layout():
+    lib = _hip.load_library()
+    assert lib.gt_abi_version() == 1
+    # gt_knn_params: 2 x int32, 5 x double, pointer, 2 x int64 = 72 bytes on LP64
+    assert ctypes.sizeof(_hip.KnnParams) == 72
+    assert _hip.KnnParams.decay.offset == 8 and _hip.KnnParams.bandwidth.offset == 48
+
+
+def test_make_params_roundtrip():
+    p, keep = _hip.Context.make_params(15, 40, 1e-4, None, 1.0, None, "+", None, 0)
+    assert (p.knn, p.kernel_symm, p.bandwidth_len, p.knn_max) == (15, 1, 0, -1)
+    p, keep = _hip.Context.make_params(5, None, 1e-4, np.arange(3.0), 2.0, 7, "mnn", 0.3, 0.5)
+    assert np.isnan(p.decay) and p.kernel_symm == 3 and p.bandwidth_len == 3 and p.knn_max == 7
+    assert p.theta == 0.3 and p.anisotropy == 0.5
+
+
+def test_no_gpu_fails_loudly():
+    lib = _hip.load_library()
+    if lib.gt_device_count() > 0:
+        pytest.skip("a GPU is visible here")
+    with pytest.raises(_hip.HipUnavailableError):
+        _hip.Context(0)
+    import graphtools_amd
+
+    X = np.random.default_rng(0).standard_normal((50, 8)).astype(np.float32)
+    with pytest.raises(_hip.HipUnavailableError):
+        graphtools_amd.Graph(X, knn=3, decay=10)
+
+
+def test_product_never_imports_oracle():
+    """the shipped package must not reference the oracle (tests/bench/smoke only)"""
+    pkg = os.path.join(ROOT, "graphtools_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert "import oracle" not in src and "from oracle" not in src, fn

@@ -1,0 +1,98 @@
+"""GPU: exact dense graph (TraditionalGraph) and landmark operator vs golden vectors / oracle."""
+import warnings
+
+import numpy as np
+import pytest
+from scipy import sparse
+
+import graphtools_amd
+import oracle
+from conftest import golden_csr, load_golden, make_mix
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("tag,src,kw,rtol", [
+    ("data_t1e-4", "X", dict(thresh=1e-4), 1e-9),
+    ("data_t0", "X", dict(thresh=0), 1e-9),
+    ("d64_t1e-4", "D64", dict(thresh=1e-4, precomputed="distance"), 1e-9),
+    ("d32_t1e-4", "D32", dict(thresh=1e-4, precomputed="distance"), 1e-5),
+    ("d32_t0", "D32", dict(thresh=0, precomputed="distance"), 1e-5),
+])
+def test_exact_graph_matches_reference_vectors(tag, src, kw, rtol):
+    z = load_golden("g6_exact")
+    G = graphtools_amd.Graph(z[src], knn=int(z["knn"]), decay=float(z["decay"]), n_pca=None, graphtype="exact", **kw)
+    assert type(G).__name__ == "TraditionalGraph"
+    Kg, Pg = z["K_" + tag], z["P_" + tag]
+    assert G.K.dtype == Kg.dtype and G.P.dtype == Pg.dtype
+    # same sparsity pattern except entries within tolerance of the threshold
+    thresh = kw["thresh"]
+    flip = (G.K == 0) != (Kg == 0)
+    assert np.all(np.abs(np.where(flip, np.maximum(G.K, Kg), thresh) - thresh) <= 4 * rtol * max(thresh, 1e-30) + 1e-30)
+    m = ~flip
+    np.testing.assert_allclose(G.K[m], Kg[m], rtol=rtol, atol=1e-300)
+    np.testing.assert_allclose(G.P[m], Pg[m], rtol=max(rtol, 1e-6), atol=1e-300)
+    np.testing.assert_allclose(G.kernel_degree.ravel(), Kg.sum(axis=1), rtol=max(rtol, 1e-6))
+
+
+@pytest.mark.parametrize("kw", [
+    dict(kernel_symm="*"), dict(kernel_symm="mnn", theta=0.4), dict(kernel_symm=None), dict(anisotropy=0.5),
+    dict(bandwidth=9.0, bandwidth_scale=1.2), dict(knn=3, decay=5),
+])
+def test_exact_graph_variants_vs_oracle(kw):
+    X = make_mix(333, 30, 21)     # not a multiple of the tile size
+    args = dict(knn=8, decay=12, thresh=1e-4)
+    args.update(kw)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        G = graphtools_amd.Graph(X, n_pca=None, graphtype="exact", **args)
+    K0, P0 = oracle.exact_graph(X, **args)
+    np.testing.assert_allclose(G.K, K0, rtol=1e-9, atol=1e-300)
+    np.testing.assert_allclose(G.P, P0, rtol=1e-9, atol=1e-300)
+
+
+def test_exact_graph_vector_bandwidth_precomputed():
+    z = load_golden("g6_exact")
+    D = z["D64"]
+    bw = np.random.default_rng(5).uniform(8, 12, size=D.shape[0])
+    G = graphtools_amd.Graph(D, precomputed="distance", bandwidth=bw, decay=10, knn=5, n_pca=None)
+    K0, P0 = oracle.exact_graph(D, knn=5, decay=10, bandwidth=bw, precomputed="distance")
+    np.testing.assert_allclose(G.K, K0, rtol=1e-9, atol=1e-300)
+    np.testing.assert_allclose(G.P, P0, rtol=1e-9, atol=1e-300)
+
+
+def test_landmark_operator_matches_reference_vectors():
+    z = load_golden("g7_landmark")
+    X = z["X"]
+    G = graphtools_amd.Graph(X, knn=15, decay=40, n_pca=None, n_landmark=int(z["n_landmark"]), random_landmarking=True,
+                             random_state=int(z["random_state"]))
+    assert type(G).__name__ == "kNNLandmarkGraph"
+    assert np.array_equal(G.clusters, z["clusters"])
+    np.testing.assert_allclose(G.landmark_op, z["landmark_op"], rtol=1e-9, atol=1e-15)
+    T = golden_csr(z, "transitions")
+    Tg = sparse.csr_matrix(G.transitions)
+    Tg.sort_indices()
+    assert np.array_equal(Tg.indptr, T.indptr) and np.array_equal(Tg.indices, T.indices)
+    np.testing.assert_allclose(Tg.data, T.data, rtol=1e-9)
+    np.testing.assert_allclose(G.landmark_op.sum(axis=1), 1.0, rtol=0, atol=1e-12)
+
+
+def test_landmark_operator_given_spectral_labels():
+    """the spectral front end is out of scope: its labels are an input to the device algebra"""
+    z = load_golden("g7_landmark")
+    G = graphtools_amd.Graph(z["X"], knn=15, decay=40, n_pca=None, n_landmark=int(z["n_landmark"]), random_state=42)
+    G._clusters = z["spectral_clusters"].astype(np.int64)
+    np.testing.assert_allclose(G.landmark_op, z["spectral_landmark_op"], rtol=1e-9, atol=1e-15)
+    T = golden_csr(z, "spectral_transitions")
+    assert abs(sparse.csr_matrix(G.transitions) - T).max() < 1e-12
+
+
+def test_random_landmark_assignment_large_n_path():
+    """n > 5000: scikit-learn euclidean_distances arithmetic (float32 rounding of the float64 GEMM form)"""
+    z = load_golden("g7_landmark")
+    X = z["big_X"]
+    G = graphtools_amd.Graph(X, knn=5, decay=None, n_pca=None, n_landmark=64, random_landmarking=True, random_state=7)
+    assert np.array_equal(G.clusters, z["big_clusters"])
+    K = sparse.csr_matrix(G.K)
+    op, tr = oracle.landmark_operator(K, z["big_clusters"])
+    np.testing.assert_allclose(G.landmark_op, op, rtol=1e-9, atol=1e-15)

@@ -1,0 +1,132 @@
+"""GPU: brute-force kNN through the C ABI vs the oracle / golden vectors.
+
+Bar: neighbour indices bit-exact (row argsort order); distances exact for float32 data (they carry
+scikit-learn's float32 rounding) and within a few float64 ulps for float64 data."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import oracle
+from conftest import load_golden, make_gauss, make_manifold, make_mix
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(ctx, X, k, Y=None):
+    ctx.set_points(X)
+    d, i, flags = ctx.knn_search(k, Y=Y)
+    d0, i0 = oracle.kneighbors(X, Y, k)
+    assert np.array_equal(i, i0), "kNN indices differ in %d rows" % int((i != i0).any(axis=1).sum())
+    if X.dtype == np.float32:
+        first = 1 if Y is None else 0   # column 0 of a self query is the self distance (rounding noise in sklearn)
+        assert np.array_equal(d[:, first:], d0[:, first:])
+        if Y is None:
+            assert np.all(d[:, 0] <= 1e-5 * (1 + np.abs(X).max()))
+    else:
+        np.testing.assert_allclose(d, d0, rtol=1e-12, atol=1e-9)
+    return flags
+
+
+@pytest.mark.parametrize("name", ["g3_mix_f32", "g4_gauss_f32", "g5_manifold_f32", "g2b_mix_binary"])
+def test_knn_matches_reference_vectors(hip_ctx, name):
+    z = load_golden(name)
+    X, k = z["X"], int(z["search_k"])
+    hip_ctx.set_points(X)
+    d, i, _ = hip_ctx.knn_search(k)
+    assert np.array_equal(i, z["knn_idx"])
+    assert np.array_equal(d[:, 1:], z["knn_dist"].astype(np.float64)[:, 1:])
+
+
+def test_knn_digits_float64_with_ties(hip_ctx):
+    z = load_golden("g1_digits_decay40")
+    X, k = z["X"], int(z["search_k"])
+    hip_ctx.set_points(X)
+    d, i, _ = hip_ctx.knn_search(k)
+    assert np.array_equal(d, z["knn_dist"])          # integer data: float64 arithmetic is exact
+    d0, i0 = oracle.kneighbors(X, None, k)
+    assert np.array_equal(i, i0)                     # ties broken by index, like the oracle
+    gi = z["knn_idx"]
+    for r in range(0, X.shape[0], 13):               # vs scikit-learn: equal as sets below the last tie group
+        keep = d[r] < d[r, -1]
+        assert set(i[r, keep]) == set(gi[r, keep])
+
+
+@pytest.mark.parametrize("n,d,k,maker,seed", [
+    (1024, 50, 96, make_mix, 0), (5000, 64, 96, make_mix, 1), (3000, 64, 96, make_gauss, 1),
+    (3000, 100, 96, make_mix, 2), (2000, 20, 30, make_mix, 3), (2500, 8, 16, make_gauss, 4),
+    (4000, 64, 300, make_mix, 6), (3000, 128, 50, make_manifold, 7), (1000, 3, 10, make_gauss, 8),
+])
+def test_knn_random_inputs(hip_ctx, n, d, k, maker, seed):
+    _check(hip_ctx, maker(n, d, seed), k)
+
+
+def test_knn_float64_input(hip_ctx):
+    _check(hip_ctx, make_mix(777, 50, 4, np.float64), 66)
+
+
+def test_knn_external_queries(hip_ctx):
+    X = make_mix(3000, 40, 9)
+    Y = make_mix(500, 40, 10)
+    _check(hip_ctx, X, 25, Y=Y)
+
+
+def test_knn_small_and_ragged_sizes(hip_ctx):
+    for n in (2, 5, 63, 64, 65, 127, 129, 257, 300):
+        X = make_gauss(n, 7, n)
+        _check(hip_ctx, X, min(n, 20))
+    # k == n: every point is a neighbour
+    X = make_gauss(50, 5, 1)
+    _check(hip_ctx, X, 50)
+
+
+def test_knn_row_block(hip_ctx):
+    X = make_mix(4000, 32, 11)
+    hip_ctx.set_points(X)
+    d, i, _ = hip_ctx.knn_search(20, rows=(1000, 1700))
+    d0, i0 = oracle.kneighbors(X, X[1000:1700], 20)
+    assert np.array_equal(i, i0)
+
+
+def test_knn_duplicates_flag(hip_ctx):
+    X = make_mix(600, 16, 12)
+    X[17] = X[400]
+    hip_ctx.set_points(X)
+    d, i, flags = hip_ctx.knn_search(10)
+    assert flags & 1
+    assert d[17, 1] == 0 and d[400, 1] == 0
+
+
+def test_forced_exact_fallback(hip_ctx):
+    """Massive exact ties (points on a tiny integer lattice): the candidate table cannot be proven complete,
+    the exhaustive float64 fallback must take over and still return the exact (d2, index) order."""
+    rng = np.random.default_rng(3)
+    X = rng.integers(0, 2, size=(1500, 10)).astype(np.float32)   # 1024 distinct points, many duplicates
+    hip_ctx.set_points(X)
+    d, i, flags = hip_ctx.knn_search(96)
+    assert flags & 4, "expected the exact fallback to trigger"
+    d0, i0 = oracle.kneighbors(X, None, 96)
+    assert np.array_equal(d, d0)
+    assert np.array_equal(i, i0)
+
+
+def test_device_primitives(hip_ctx):
+    """wave-level sorting networks and the MFMA result layout, in isolation"""
+    lib = hip_ctx.lib
+    rng = np.random.default_rng(0)
+    a = rng.standard_normal((32, 8)).astype(np.float32)
+    bt = rng.standard_normal((32, 8)).astype(np.float32)   # asymmetric on purpose (transpose-detecting)
+    c = np.zeros((32, 32), dtype=np.float32)
+    lib.gt_dbg_mfma.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int, ctypes.c_void_p]
+    assert lib.gt_dbg_mfma(hip_ctx.h, a.ctypes.data, bt.ctypes.data, 8, c.ctypes.data) == 0
+    np.testing.assert_allclose(c, a @ bt.T, rtol=0, atol=1e-5)
+    lib.gt_dbg_sort_desc.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    for nt in (1, 2, 8, 32):
+        for n in (1, 63, 64 * nt - 5, 64 * nt):
+            n = max(1, min(n, 64 * nt))
+            keys = rng.integers(1, 2**63, size=n, dtype=np.uint64)
+            out = np.zeros(64 * nt, dtype=np.uint64)
+            assert lib.gt_dbg_sort_desc(hip_ctx.h, keys.ctypes.data, n, nt, out.ctypes.data) == 0
+            exp = np.zeros(64 * nt, dtype=np.uint64)
+            exp[:n] = np.sort(keys)[::-1]
+            assert np.array_equal(out, exp)

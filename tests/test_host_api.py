@@ -1,0 +1,87 @@
+"""CPU: host-side mirror of the reference interface - class selection, argument validation, warnings and
+parameter guards (reference behaviours listed in SURVEY.md Appendix D).  No kernel is built here
+(initialize=False), so no GPU is needed."""
+import warnings
+
+import numpy as np
+import pytest
+
+import graphtools_amd
+from graphtools_amd import graphs
+
+X = np.random.default_rng(0).standard_normal((60, 10)).astype(np.float32)
+
+
+def test_class_selection_rules():
+    assert type(graphtools_amd.Graph(X, knn=3, decay=10, initialize=False)).__name__ == "kNNGraph"
+    assert type(graphtools_amd.Graph(X, knn=3, decay=None, initialize=False)).__name__ == "kNNGraph"
+    assert type(graphtools_amd.Graph(X, knn=3, decay=10, thresh=0, initialize=False)).__name__ == "TraditionalGraph"
+    D = np.abs(np.random.default_rng(1).standard_normal((20, 20)))
+    g = graphtools_amd.Graph(D, precomputed="distance", knn=3, decay=10, initialize=False)
+    assert type(g).__name__ == "TraditionalGraph"
+    g = graphtools_amd.Graph(X, knn=3, decay=10, n_landmark=10, initialize=False)
+    assert type(g).__name__ == "kNNLandmarkGraph"
+
+
+def test_initialize_false_is_lazy():
+    g = graphtools_amd.Graph(X, knn=3, decay=10, initialize=False)
+    assert not hasattr(g, "_kernel")
+
+
+def test_reference_error_messages():
+    with pytest.raises(ValueError, match="kNNGraph does not support precomputed"):
+        graphtools_amd.Graph(X, graphtype="knn", precomputed="distance", initialize=False)
+    with pytest.raises(ValueError, match="graphtype 'hello' not recognized"):
+        graphtools_amd.Graph(X, graphtype="hello", initialize=False)
+    with pytest.raises(ValueError, match="Cannot instantiate a kNNGraph with `decay=None`, `thresh=0`"):
+        graphs.kNNGraph(X, knn=3, decay=10, thresh=0, initialize=False)
+    with pytest.raises(ValueError, match="Expected 0 <= anisotropy <= 1"):
+        graphtools_amd.Graph(X, knn=3, decay=10, anisotropy=2, initialize=False)
+    with pytest.raises(ValueError, match="kernel_symm 'x' not recognized"):
+        graphtools_amd.Graph(X, knn=3, decay=10, kernel_symm="x", initialize=False)
+    with pytest.raises(TypeError, match="unexpected keyword argument"):
+        graphtools_amd.Graph(X, knn=3, decay=10, hello=1, initialize=False)
+    with pytest.raises(NotImplementedError):
+        graphs.kNNGraph(X, knn=3, decay=10, bandwidth=lambda d: d, initialize=False)
+
+
+def test_reference_warnings():
+    with pytest.warns(UserWarning, match=r"Cannot set knn \(100\) to be greater than n_samples - 2 \(58\)"):
+        g = graphs.kNNGraph(X, knn=100, decay=10, initialize=False)
+    assert g.knn == 58
+    with pytest.warns(UserWarning, match=r"Cannot set knn_max \(2\) to be less than knn \(5\)"):
+        g = graphs.kNNGraph(X, knn=5, knn_max=2, decay=10, initialize=False)
+    assert g.knn_max == 5
+    with pytest.warns(UserWarning, match="`bandwidth` is not used when `decay=None`"):
+        graphs.kNNGraph(X, knn=5, decay=None, bandwidth=2.0, initialize=False)
+    with pytest.warns(UserWarning, match="kernel_symm='\\+' but theta is not None"):
+        g = graphtools_amd.Graph(X, knn=3, decay=10, theta=0.5, initialize=False)
+    assert g.kernel_symm == "mnn"
+    with pytest.warns(UserWarning, match="kernel_symm='mnn' but theta not given"):
+        g = graphtools_amd.Graph(X, knn=3, decay=10, kernel_symm="mnn", initialize=False)
+    assert g.theta == 1
+
+
+def test_thresh_clamped_to_eps():
+    g = graphs.kNNGraph(X, knn=3, decay=10, thresh=1e-30, initialize=False)
+    assert g.thresh == np.finfo(float).eps
+
+
+def test_get_set_params_guards():
+    g = graphtools_amd.Graph(X, knn=3, decay=10, initialize=False, random_state=4)
+    p = g.get_params()
+    assert set(p) == {"n_pca", "random_state", "kernel_symm", "theta", "anisotropy", "knn", "decay", "bandwidth",
+                      "bandwidth_scale", "knn_max", "distance", "thresh", "n_jobs", "verbose"}
+    for key, val in [("knn", 4), ("decay", 11), ("thresh", 1e-3), ("kernel_symm", "*"), ("anisotropy", 0.5),
+                     ("bandwidth", 3), ("bandwidth_scale", 2), ("distance", "cosine"), ("theta", 0.3), ("n_pca", 3)]:
+        with pytest.raises(ValueError, match="Cannot update {}".format(key)):
+            g.set_params(**{key: val})
+    g.set_params(n_jobs=4, random_state=13, verbose=2)
+    assert (g.n_jobs, g.random_state, g.verbose) == (4, 13, 2)
+
+
+def test_mnn_and_pygsp_are_out_of_scope():
+    with pytest.raises(NotImplementedError):
+        graphtools_amd.Graph(X, sample_idx=np.arange(60) % 2, initialize=False)
+    with pytest.raises(NotImplementedError):
+        graphtools_amd.Graph(X, use_pygsp=True, initialize=False)

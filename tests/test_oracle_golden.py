@@ -1,0 +1,134 @@
+"""CPU: the numpy oracle (oracle/) reproduces every golden vector generated from the reference."""
+import numpy as np
+import pytest
+from scipy import sparse
+
+import oracle
+from conftest import golden_csr, golden_params, load_golden
+
+KNN_FIXTURES = [
+    "g1_digits_decay40", "g2b_mix_binary", "g3_mix_f32", "g4_gauss_f32", "g5_manifold_f32",
+    "g3b_mix_symm_mul", "g3c_mix_symm_mnn", "g3d_mix_symm_none", "g3e_mix_aniso", "g3f_mix_bwscalar",
+    "g3g_mix_knnmax", "g3h_mix_thresh", "g3i_mix_bwvector",
+]
+
+
+def _decay(z):
+    return None if np.isnan(z["decay"]) else float(z["decay"])
+
+
+@pytest.mark.parametrize("name", KNN_FIXTURES)
+def test_knn_graph_matches_reference(name):
+    z = load_golden(name)
+    K, P = oracle.knn_graph(z["X"], knn=int(z["knn"]), decay=_decay(z), **golden_params(z))
+    Kg = golden_csr(z, "K")
+    K = sparse.csr_matrix(K)
+    K.sort_indices()
+    assert (K != Kg).nnz == 0  # identical structure and values (same float64 arithmetic)
+    P = sparse.csr_matrix(P)
+    P.sort_indices()
+    np.testing.assert_allclose(P.data, z["P_data"], rtol=0, atol=1e-15)
+
+
+@pytest.mark.parametrize("name", ["g1_digits_decay40", "g3_mix_f32", "g4_gauss_f32", "g5_manifold_f32", "g2b_mix_binary"])
+def test_unsymmetrised_kernel_matches_reference(name):
+    z = load_golden(name)
+    K0 = oracle.knn_kernel(z["X"], knn=int(z["knn"]), decay=_decay(z))
+    K0 = sparse.csr_matrix(K0)
+    K0.sort_indices()
+    assert (K0 != golden_csr(z, "K0")).nnz == 0
+
+
+@pytest.mark.parametrize("name", ["g3_mix_f32", "g4_gauss_f32", "g5_manifold_f32", "g2b_mix_binary"])
+def test_kneighbors_matches_sklearn_vectors(name):
+    z = load_golden(name)
+    d, i = oracle.kneighbors(z["X"], None, int(z["search_k"]))
+    assert np.array_equal(i, z["knn_idx"])  # bit-exact neighbour order (no exact ties in these inputs)
+    # distances: float64(float32) rounding of scikit-learn; column 0 is self (rounding noise in sklearn)
+    assert np.array_equal(d[:, 1:], z["knn_dist"].astype(np.float64)[:, 1:])
+
+
+def test_kneighbors_digits_ties():
+    """integer-valued data: exact distance ties; neighbour order within a tie group is unspecified in
+    scikit-learn, distances must still agree exactly and indices as sets per distinct distance."""
+    z = load_golden("g1_digits_decay40")
+    d, i = oracle.kneighbors(z["X"], None, int(z["search_k"]))
+    assert np.array_equal(d, z["knn_dist"])
+    gi = z["knn_idx"]
+    for r in range(0, d.shape[0], 37):
+        # all but the last tie group (which may be cut by k) must hold the same members
+        last = d[r, -1]
+        keep = d[r] < last
+        assert set(i[r, keep]) == set(gi[r, keep])
+
+
+def test_digits_binary_kernel_ties():
+    z = load_golden("g2_digits_binary")
+    K, _ = oracle.knn_graph(z["X"], knn=int(z["knn"]), decay=None)
+    Kg = golden_csr(z, "K")
+    # tie-breaking at the k-th neighbour may swap equidistant members: only a handful of entries differ
+    assert (sparse.csr_matrix(K) != Kg).nnz <= 64
+    assert abs(K.sum() - Kg.sum()) < 1e-9
+
+
+def test_radius_neighbors_rounding():
+    z = load_golden("g3_mix_f32")
+    X = z["X"]
+    from sklearn.neighbors import NearestNeighbors
+
+    nn = NearestNeighbors(algorithm="brute").fit(X)
+    d_ref, i_ref = nn.radius_neighbors(X[:64], radius=9.3)
+    d, i = oracle.radius_neighbors(X, X[:64], 9.3)
+    for r in range(64):
+        o_ref, o = np.argsort(i_ref[r]), np.argsort(i[r])
+        assert np.array_equal(i_ref[r][o_ref], i[r][o])
+        keep = i[r][o] != r
+        assert np.array_equal(d_ref[r][o_ref][keep], d[r][o][keep])
+
+
+def test_kneighbors_matches_live_sklearn():
+    from sklearn.neighbors import NearestNeighbors
+
+    rng = np.random.default_rng(11)
+    X = rng.standard_normal((700, 33)).astype(np.float32)
+    Y = rng.standard_normal((50, 33)).astype(np.float32)
+    nn = NearestNeighbors(algorithm="brute").fit(X)
+    d_ref, i_ref = nn.kneighbors(Y, 40)
+    d, i = oracle.kneighbors(X, Y, 40)
+    assert np.array_equal(i, i_ref)
+    assert np.array_equal(d, d_ref)
+
+
+@pytest.mark.parametrize("tag,src,kw", [
+    ("data_t1e-4", "X", dict(thresh=1e-4)),
+    ("data_t0", "X", dict(thresh=0)),
+    ("d64_t1e-4", "D64", dict(thresh=1e-4, precomputed="distance")),
+    ("d32_t1e-4", "D32", dict(thresh=1e-4, precomputed="distance")),
+    ("d32_t0", "D32", dict(thresh=0, precomputed="distance")),
+])
+def test_exact_graph_matches_reference(tag, src, kw):
+    z = load_golden("g6_exact")
+    K, P = oracle.exact_graph(z[src], knn=int(z["knn"]), decay=float(z["decay"]), **kw)
+    assert K.dtype == z["K_" + tag].dtype
+    assert np.array_equal(K, z["K_" + tag])
+    assert np.array_equal(P, z["P_" + tag])
+
+
+def test_pairwise_distances_match_scipy_vector():
+    z = load_golden("g6_exact")
+    assert np.array_equal(oracle.pairwise_distances_exact(z["X"]), z["D64"])
+
+
+def test_landmark_operator_matches_reference():
+    z = load_golden("g7_landmark")
+    K = golden_csr(z, "K")
+    cl, _ = oracle.random_landmark_clusters(z["X"], int(z["n_landmark"]), int(z["random_state"]))
+    assert np.array_equal(cl, z["clusters"])
+    op, tr = oracle.landmark_operator(K, z["clusters"])
+    np.testing.assert_allclose(op, z["landmark_op"], rtol=0, atol=1e-14)
+    T = golden_csr(z, "transitions")
+    assert abs(sparse.csr_matrix(tr) - T).max() < 1e-14
+    op2, tr2 = oracle.landmark_operator(K, z["spectral_clusters"])
+    np.testing.assert_allclose(op2, z["spectral_landmark_op"], rtol=0, atol=1e-14)
+    cl_big, _ = oracle.random_landmark_clusters(z["big_X"], 64, 7)
+    assert np.array_equal(cl_big, z["big_clusters"])
