@@ -18,13 +18,13 @@ def _check(ctx, X, k, Y=None):
     d, i, flags = ctx.knn_search(k, Y=Y)
     d0, i0 = oracle.kneighbors(X, Y, k)
     assert np.array_equal(i, i0), "kNN indices differ in %d rows" % int((i != i0).any(axis=1).sum())
+    first = 1 if Y is None else 0   # column 0 of a self query is the self distance (rounding noise in sklearn)
     if X.dtype == np.float32:
-        first = 1 if Y is None else 0   # column 0 of a self query is the self distance (rounding noise in sklearn)
         assert np.array_equal(d[:, first:], d0[:, first:])
-        if Y is None:
-            assert np.all(d[:, 0] <= 1e-5 * (1 + np.abs(X).max()))
     else:
-        np.testing.assert_allclose(d, d0, rtol=1e-12, atol=1e-9)
+        np.testing.assert_allclose(d[:, first:], d0[:, first:], rtol=1e-12, atol=0)
+    if Y is None:
+        assert np.all(d[:, 0] <= 1e-5 * (1 + np.abs(X).max()))
     return flags
 
 
