@@ -1,0 +1,160 @@
+"""Row-sharded multi-GPU build: one process per GPU, ``torch.distributed`` over RCCL/xGMI.
+
+The N x N affinity build shards by row blocks: rank g owns rows
+``[splits[g], splits[g+1])`` and every rank needs all N points as the database side.
+
+  1. all-gather of the points        (each rank contributes its row slice; RCCL all-gather)
+  2. local work                      gt_graph_begin: kNN -> bandwidth -> radius pass -> affinities
+  3. all-to-all of transposed triplets {row, col, value} (16 B each) bucketed by the owner of ``row``
+                                      gt_graph_emit fills the send buffer, RCCL all-to-all moves it
+  4. local merge + normalisation     gt_graph_finish  (anisotropy: + one all-gather of the degrees)
+  landmark operator: all-reduce(sum) of the L x L partial products and the L partial row sums.
+
+torch is used for device buffers and collectives only; all numerics are in libgraphtools_amd.so.
+The communication helpers work on CPU tensors with the gloo backend too (tests/test_dist_cpu.py).
+"""
+import numpy as np
+
+WORDS_PER_TRIPLET = 2  # a triplet {uint32 row, uint32 col, float64 value} travels as two int64 words
+
+
+def even_row_splits(n, world):
+    """world+1 ascending row boundaries covering [0, n] as evenly as possible."""
+    base, rem = divmod(int(n), int(world))
+    sizes = [base + (1 if r < rem else 0) for r in range(world)]
+    return np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+
+
+def _dist():
+    import torch.distributed as dist
+
+    return dist
+
+
+def exchange_counts(send_counts, device, group=None):
+    """all-to-all of one int64 per peer: how many triplets each peer will send us."""
+    import torch
+
+    dist = _dist()
+    world = dist.get_world_size(group)
+    send = torch.as_tensor(np.asarray(send_counts, dtype=np.int64), device=device)
+    recv = torch.empty(world, dtype=torch.int64, device=device)
+    dist.all_to_all_single(recv, send, group=group)
+    return recv.cpu().numpy()
+
+
+def exchange_triplets(send_words, send_counts, group=None):
+    """all-to-all of the bucketed triplet buffer.
+
+    send_words : int64 tensor of 2 * sum(send_counts) words, buckets in rank order
+    returns (recv_words int64 tensor, recv_counts numpy int64[world])
+    """
+    import torch
+
+    dist = _dist()
+    send_counts = np.asarray(send_counts, dtype=np.int64)
+    recv_counts = exchange_counts(send_counts, send_words.device, group)
+    recv = torch.empty(int(recv_counts.sum()) * WORDS_PER_TRIPLET, dtype=torch.int64, device=send_words.device)
+    dist.all_to_all_single(
+        recv, send_words,
+        output_split_sizes=[int(c) * WORDS_PER_TRIPLET for c in recv_counts],
+        input_split_sizes=[int(c) * WORDS_PER_TRIPLET for c in send_counts],
+        group=group,
+    )
+    return recv, recv_counts
+
+
+def allgather_rows(x_local, splits, group=None):
+    """all-gather of row slices of unequal length into the full [n, d] matrix (every rank gets all rows)."""
+    import torch
+
+    dist = _dist()
+    world = dist.get_world_size(group)
+    splits = np.asarray(splits, dtype=np.int64)
+    sizes = np.diff(splits)
+    d = x_local.shape[1]
+    maxrows = int(sizes.max())
+    if int(sizes.min()) == maxrows:
+        full = torch.empty((int(splits[-1]), d), dtype=x_local.dtype, device=x_local.device)
+        dist.all_gather_into_tensor(full, x_local.contiguous(), group=group)
+        return full
+    pad = torch.zeros((maxrows, d), dtype=x_local.dtype, device=x_local.device)
+    pad[: x_local.shape[0]] = x_local
+    gathered = torch.empty((world * maxrows, d), dtype=x_local.dtype, device=x_local.device)
+    dist.all_gather_into_tensor(gathered, pad, group=group)
+    return torch.cat([gathered[r * maxrows: r * maxrows + int(sizes[r])] for r in range(world)], dim=0)
+
+
+def allgather_vector(v_local, splits, group=None):
+    return allgather_rows(v_local.reshape(-1, 1), splits, group).reshape(-1)
+
+
+class ShardedKnnGraph(object):
+    """One rank's share of a row-sharded kNN graph build.
+
+    ``ctx`` is a :class:`graphtools_amd._hip.Context` on this rank's GPU; ``x_local`` a CUDA tensor with
+    this rank's rows of the data (float32/float64, C order).  After :meth:`build`, the owned CSR row block
+    of K and P is resident on the device (``ctx.graph_fetch_csr`` copies it to the host).
+    """
+
+    def __init__(self, ctx, n_total, group=None):
+        dist = _dist()
+        self.ctx = ctx
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.n = int(n_total)
+        self.splits = even_row_splits(self.n, self.world)
+
+    def gather_points(self, x_local):
+        """RCCL all-gather of the row slices; binds the full matrix (kept alive on self) to the context."""
+        import torch
+
+        full = allgather_rows(x_local, self.splits, self.group)
+        if full.is_cuda:
+            torch.cuda.synchronize(full.device)
+        self._points = full
+        self.ctx.set_points_device(full.data_ptr(), full.shape[0], full.shape[1],
+                                   np.float32 if full.dtype == torch.float32 else np.float64)
+        return full
+
+    def build(self, params):
+        """kernel + diffusion operator for the owned rows; returns (nnz_local, flags)."""
+        import torch
+
+        dist = _dist()
+        ctx = self.ctx
+        device = self._points.device
+        send_counts = ctx.graph_begin(params, self.world, self.rank, self.splits)
+        total = int(send_counts.sum())
+        send = torch.empty(max(total, 1) * WORDS_PER_TRIPLET, dtype=torch.int64, device=device)
+        if total > 0:
+            ctx.graph_emit(send.data_ptr())
+        recv, recv_counts = exchange_triplets(send[: total * WORDS_PER_TRIPLET], send_counts, self.group)
+        if recv.is_cuda:
+            torch.cuda.synchronize(device)
+        n_recv = int(recv_counts.sum())
+        nnz, flags = ctx.graph_finish(recv.data_ptr() if n_recv > 0 else 0, n_recv)
+        if params.anisotropy != 0.0 and self.world > 1:
+            nloc = int(self.splits[self.rank + 1] - self.splits[self.rank])
+            deg = torch.empty(nloc, dtype=torch.float64, device=device)
+            ctx._check(ctx.lib.gt_graph_fetch_vec(ctx.h, 1, deg.data_ptr(), 1), "gt_graph_fetch_vec")
+            deg_all = allgather_vector(deg, self.splits, self.group).contiguous()
+            if deg_all.is_cuda:
+                torch.cuda.synchronize(device)
+            ctx.graph_anisotropy(deg_all.data_ptr())
+        self._keep = (send, recv)
+        return nnz, flags
+
+    def landmark_operator(self, clusters, n_landmark):
+        """all-reduce of the partial L x L products; returns the finished landmark operator (host array)."""
+        import torch
+
+        dist = _dist()
+        M, R, tnnz = self.ctx.landmark_build(clusters, n_landmark)
+        device = self._points.device
+        Mt = torch.as_tensor(M, device=device)
+        Rt = torch.as_tensor(R, device=device)
+        dist.all_reduce(Mt, group=self.group)
+        dist.all_reduce(Rt, group=self.group)
+        return self.ctx.landmark_scale(Mt.cpu().numpy(), Rt.cpu().numpy()), tnnz

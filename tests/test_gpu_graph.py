@@ -139,3 +139,70 @@ def test_api_warnings_from_device_flags():
     X[17] = X[400]
     with pytest.warns(RuntimeWarning, match="Detected zero distance between samples 17 and 400"):
         graphtools_amd.Graph(X, knn=5, decay=10, n_pca=None)
+
+
+@pytest.mark.parametrize("symm,aniso", [("+", 0.0), ("*", 0.0), ("mnn", 0.0), (None, 0.0), ("+", 0.5)])
+def test_two_rank_sharding_on_one_gpu(symm, aniso):
+    """The multi-rank device path (owner bucketing, row offsets, received-triplet merge, degree exchange for
+    anisotropy) with two contexts on one GPU and the exchange done by hand: the stacked row blocks must be
+    identical to the single-rank build."""
+    X = make_mix(3000, 32, 31)
+    n = X.shape[0]
+    splits = np.array([0, 1400, n], dtype=np.int64)
+    theta = 0.3 if symm == "mnn" else None
+    ref = _hip.Context(0)
+    ref.set_points(X)
+    p, keep = ref.make_params(12, 30, 1e-4, None, 1.0, None, symm, theta, aniso)
+    ref.graph_build(p)
+    Kd, Ki, Kp = ref.graph_fetch_csr(_hip.CSR_K)
+    Pd, _, _ = ref.graph_fetch_csr(_hip.CSR_P)
+    ctxs = [_hip.Context(0), _hip.Context(0)]
+    sends, counts = [], []
+    trip = np.dtype([("row", np.uint32), ("col", np.uint32), ("val", np.float64)])
+    for r, c in enumerate(ctxs):
+        c.set_points(X)
+        cnt = c.graph_begin(p, 2, r, splits)
+        total = int(cnt.sum())
+        host = np.zeros(total, dtype=trip)
+        if total:
+            buf = c.dev_alloc(total * 16)
+            c.graph_emit(buf)
+            c.dev_download(host, buf)
+            c.dev_free(buf)
+        sends.append(host)
+        counts.append(cnt)
+    blocks = []
+    for r, c in enumerate(ctxs):
+        parts = []
+        for s in range(2):
+            off = int(counts[s][:r].sum())
+            parts.append(sends[s][off: off + int(counts[s][r])])
+        recv = np.concatenate(parts)
+        assert np.all((recv["row"] >= splits[r]) & (recv["row"] < splits[r + 1]))
+        buf = c.dev_alloc(max(len(recv), 1) * 16)
+        if len(recv):
+            c.dev_upload(buf, recv)
+        c.graph_finish(buf if len(recv) else 0, len(recv))
+        c.dev_free(buf)
+    if aniso != 0.0:
+        deg = np.concatenate([c.graph_fetch_vec(_hip.VEC_DEGREE) for c in ctxs])
+        for c in ctxs:
+            buf = c.dev_alloc(n * 8)
+            c.dev_upload(buf, deg)
+            c.graph_anisotropy(buf)
+            c.dev_free(buf)
+    datas, inds, ptrs, pdatas = [], [], [], []
+    base = 0
+    for c in ctxs:
+        d_, i_, p_ = c.graph_fetch_csr(_hip.CSR_K)
+        pd_, _, _ = c.graph_fetch_csr(_hip.CSR_P)
+        datas.append(d_); inds.append(i_); pdatas.append(pd_)
+        ptrs.append(p_[:-1] + base)
+        base += p_[-1]
+    ptr = np.concatenate(ptrs + [[base]])
+    assert np.array_equal(ptr, Kp)
+    assert np.array_equal(np.concatenate(inds), Ki)
+    assert np.array_equal(np.concatenate(datas), Kd)      # bit-identical to the single-rank build
+    np.testing.assert_allclose(np.concatenate(pdatas), Pd, rtol=1e-14)
+    for c in ctxs + [ref]:
+        c.close()
