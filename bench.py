@@ -28,7 +28,9 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FP32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
+# MI355X_MICROARCH.md dense matrix peaks (256 CUs @ 2.4 GHz)
+MFMA_PEAK_TFLOPS = {"f16": 2500.0,    # v_mfma_f32_32x32x16_f16 (split-float16 candidate pass, 3 MFMA chains per product)
+                    "f32": 157.3}     # v_mfma_f32_32x32x2_f32
 
 
 def make_mix(n, d, seed, dtype=np.float32):
@@ -106,6 +108,8 @@ def main():
     ap.add_argument("--knn", type=int, default=15)
     ap.add_argument("--decay", type=float, default=40.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--knn-precision", choices=["f16", "f32"], default=os.environ.get("GT_KNN_PRECISION", "f16"),
+                    help="arithmetic of the candidate pass (results are identical; see DESIGN.md)")
     args = ap.parse_args()
 
     import torch
@@ -130,6 +134,7 @@ def main():
     thresh = 1e-4
     X = make_mix(n, d, 1)
     ctx = _hip.Context(local_rank)
+    ctx.set_option("knn_precision", args.knn_precision)
 
     def params_factory(symm="+"):
         return ctx.make_params(args.knn, args.decay, thresh, None, 1.0, None, symm, None, 0)
@@ -181,6 +186,8 @@ def main():
         flops = 2.0 * nloc * n * d                      # algorithmic: 2*d flop per (query, database row) pair
         avg_ms = float(np.mean(select_ms))
         achieved = flops / (avg_ms * 1e-3) / 1e12
+        peak = MFMA_PEAK_TFLOPS[args.knn_precision]
+        executed = flops * (3.0 if args.knn_precision == "f16" else 1.0)   # hi.hi + hi.lo + lo.hi chains
         stats = ctx.graph_stats()
         out = {
             "metric": "graphs/sec (kernel+diff_op) at N=1e6 d=64 k=15",
@@ -193,16 +200,17 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "f32 candidates (MFMA) + f64 re-rank/affinities",
+            "dtype": ("f16x2-split" if args.knn_precision == "f16" else "f32") + " MFMA candidates + f64 re-rank/affinities",
             "data": "synthetic",
             "config": {"workload": "C3: mix N=%d d=%d float32 seed=1, kNNGraph knn=%d decay=%g thresh=1e-4, "
                                    "kernel_symm='+', device-complete K and P" % (n, d, args.knn, args.decay),
                        "row_sharding": "%d rank(s) x %d rows" % (world, nloc), "nnz_K": nnz_total,
                        "radius_rows_rank0": stats["radius_rows"], "fallback_rows_rank0": stats["fallback_rows"]},
-            "roofline": {"kernel": "knn_select_kernel (fp32 MFMA 32x32x2 candidate pass)", "bound": "mfma",
-                         "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
-                         "avg_launch_ms": avg_ms, "algorithmic_flop_per_launch": flops},
+            "roofline": {"kernel": "knn_select_kernel (%s MFMA candidate pass)" % args.knn_precision, "bound": "mfma",
+                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                         "traffic": None, "avg_launch_ms": avg_ms, "algorithmic_flop_per_launch": flops,
+                         "executed_mfma_flop_per_launch": executed,
+                         "executed_mfma_frac": executed / (avg_ms * 1e-3) / 1e12 / peak},
             "stage_ms_last_step": {s: round(ctx.stage_ms(s), 3) for s in
                                    ("prep", "knn_select", "rerank", "fallback", "radius", "affinity", "symmetrize",
                                     "normalize")},

@@ -17,7 +17,8 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libgraphtools_amd.so")
 ARCH = "gfx950"
-SELECT_DPS = (16, 32, 56, 64, 104, 128)  # keep in sync with GT_SEL_DP_LIST in gt_knn_select_dispatch.cpp
+# (precision, padded feature count) instantiations; keep in sync with gt_knn_select_dispatch.cpp
+SELECT_UNITS = [(0, dp) for dp in (16, 32, 56, 64, 104, 128)] + [(1, dp) for dp in (16, 32, 48, 64, 80, 96, 112, 128)]
 
 COMMON_FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
                 "-ffp-contract=off"]
@@ -37,21 +38,10 @@ def _units():
     for name in ("gt_prep.hip", "gt_rerank.hip", "gt_sparse.hip", "gt_dense.hip", "gt_landmark.hip", "gt_debug.hip"):
         if os.path.exists(os.path.join(CSRC, name)):
             units.append((name, name.replace(".hip", ".o"), []))
-    for dp in SELECT_DPS:
-        units.append(("gt_knn_select.hip", "gt_knn_select_dp%d.o" % dp, ["-DGT_SEL_DP=%d" % dp]))
+    for prec, dp in SELECT_UNITS:
+        units.append(("gt_knn_select.hip", "gt_knn_select_p%d_dp%d.o" % (prec, dp),
+                      ["-DGT_SEL_PREC=%d" % prec, "-DGT_SEL_DP=%d" % dp]))
     return units
-
-
-def _deps_digest(extra):
-    h = hashlib.sha256()
-    for root in (CSRC, os.path.join(os.path.dirname(HERE), "include")):
-        for fn in sorted(os.listdir(root)):
-            if fn.endswith((".h", ".hip", ".cpp")):
-                with open(os.path.join(root, fn), "rb") as f:
-                    h.update(fn.encode())
-                    h.update(f.read())
-    h.update(" ".join(extra).encode())
-    return h.hexdigest()
 
 
 def _compile(unit):

@@ -54,6 +54,7 @@ _SIGNATURES = {
     "gt_device_count": (_c.c_int, []),
     "gt_stage_ms": (_c.c_double, [_c.c_void_p, _c.c_char_p]),
     "gt_stage_launches": (_c.c_int, [_c.c_void_p, _c.c_char_p]),
+    "gt_set_option": (_c.c_int, [_c.c_void_p, _c.c_char_p, _c.c_char_p]),
     "gt_set_points": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_int32]),
     "gt_knn_search": (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_int64, _c.c_void_p, _c.c_int64, _c.c_int32, _c.c_int32,
                                  _c.c_void_p, _c.c_void_p, _c.c_int32, _c.POINTER(_c.c_uint32)]),
@@ -145,6 +146,9 @@ class Context:
 
     def stage_launches(self, stage):
         return int(self.lib.gt_stage_launches(self.h, stage.encode()))
+
+    def set_option(self, name, value):
+        self._check(self.lib.gt_set_option(self.h, name.encode(), str(value).encode()), "gt_set_option")
 
     # ---- points -----------------------------------------------------------------------------
     def set_points(self, X):

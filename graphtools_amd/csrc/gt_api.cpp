@@ -1,6 +1,9 @@
 // Context management, point binding and the small device-memory helpers of the C ABI.
 #include "gt_common.h"
 #include "gt_knn.h"
+#include "gt_knn_select.h"
+
+#include <cstdlib>
 
 static thread_local std::string g_create_error;
 
@@ -46,6 +49,10 @@ int gt_ctx_create(int device, gt_ctx** out) {
     }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->n_cu = prop.multiProcessorCount;
+    if (const char* pr = std::getenv("GT_KNN_PRECISION")) {
+        if (std::string(pr) == "f32") ctx->prec = 0;
+        if (std::string(pr) == "f16") ctx->prec = 1;
+    }
     *out = ctx;
     return GT_OK;
 }
@@ -113,19 +120,39 @@ int gt_set_points(gt_ctx* ctx, const void* X, int64_t n, int32_t d, int32_t dtyp
     ctx->n = n;
     ctx->d = d;
     ctx->dtype = dtype;
-    ctx->DP = gt_choose_dp(d);
+    ctx->DP = gt_choose_dp_prec(d, ctx->prec);
     if (ctx->DP == 0) {
         // exact dense path and landmark assignment still work on the raw points; kNN needs d <= 128 for now
         ctx->n_pad = 0;
         GT_HIP(ctx, ctx->xn.reserve(size_t(n) * sizeof(double)));
         GT_HIP(ctx, ctx->ymax.reserve(sizeof(double)));
         GT_TRY(gt_prep_matrix(ctx, ctx->X, n, d, dtype, 0, 0, nullptr, ctx->xn.as<double>(), nullptr,
-                              ctx->ymax.as<double>()));
+                              ctx->ymax.as<double>(), 0, 1.0));
     } else {
         GT_TRY(gt_prep_points(ctx));
     }
     GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return GT_OK;
+}
+
+int gt_set_option(gt_ctx* ctx, const char* name, const char* value) {
+    if (!ctx || !name || !value) return GT_E_ARG;
+    const std::string k(name), v(value);
+    if (k == "knn_precision") {
+        if (v == "f32")
+            ctx->prec = 0;
+        else if (v == "f16")
+            ctx->prec = 1;
+        else
+            GT_FAIL(ctx, GT_E_ARG, "knn_precision must be 'f32' or 'f16'");
+        ctx->n = 0;   // the working copy depends on the precision: points must be bound again
+        return GT_OK;
+    }
+    if (k == "dbg_select") {
+        ctx->dbg_select = std::atoi(value);
+        return GT_OK;
+    }
+    GT_FAIL(ctx, GT_E_ARG, "unknown option");
 }
 
 int gt_dev_alloc(gt_ctx* ctx, size_t bytes, void** out) {

@@ -93,11 +93,15 @@ struct gt_ctx {
     int64_t n = 0;
     int32_t d = 0;
     int32_t dtype = GT_F32;
-    int32_t DP = 0;      // padded feature count of the float32 working copy
+    int32_t DP = 0;      // padded feature count of the working copy
+    int32_t prec = 1;    // candidate arithmetic: 0 = float32 MFMA, 1 = split-float16 MFMA (default)
+    double sc = 1.0;     // power-of-two scale applied to the working copy (prec 1: max|x|*sc in [2^13, 2^14))
+    double maxabs = 0.0; // max |x_ij| of the bound points
+    int32_t dbg_select = 0;   // experiment switches forwarded to the candidate kernel (results invalid when set)
     int64_t n_pad = 0;   // rows of the working copy (multiple of the db tile)
-    DevBuf Yp;           // float [n_pad][DP]
+    DevBuf Yp;           // working copy: [n_pad] rows of 4*DP bytes (float32, or float16 hi plane | lo plane)
     DevBuf xn;           // double [n]    squared row norms
-    DevBuf hneg;         // float [n_pad] -|y|^2/2 (-inf on pad rows)
+    DevBuf hneg;         // float [n_pad] -sc^2 |y|^2/2 (-inf on pad rows)
     DevBuf ymax;         // float [1]     max row norm (as float bits, atomicMax on uint)
     float ymax_host = 0.f;
 

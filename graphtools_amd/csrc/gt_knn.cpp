@@ -10,20 +10,29 @@ int gt_select_bn_for(int dp) { return gt_select_bn(dp); }
 void gt_free_knn_work(gt_ctx* ctx) {
     if (!ctx->knn) return;
     KnnWork* k = ctx->knn;
-    for (DevBuf* b : {&k->Qraw, &k->Qp, &k->qn, &k->lists, &k->counts, &k->cand_d2, &k->cand_j, &k->cand_n,
+    for (DevBuf* b : {&k->Qraw, &k->Qp, &k->qn, &k->lists, &k->counts, &k->thr_final, &k->cand_d2, &k->cand_j, &k->cand_n,
                       &k->d2_lb, &k->fb_rows, &k->fb_count, &k->fb_scratch, &k->gflags})
         b->release();
     delete k;
     ctx->knn = nullptr;
 }
 
-// fp32 accumulation error coefficient: |s~ - s| <= err_coef * (|y|^2/2 + |x||y|), see gt_rerank.hip.
-// The MFMA chain performs DP fused multiply-adds on top of the rounded seed -|y|^2/2 (any summation order of
-// DP+1 terms obeys gamma_{DP+1}); float64 inputs add 2u from the float32 conversion of both operands.
-// A factor 2 of head-room is applied on top.
-static double err_coefficient(int dp) {
+ErrModel gt_err_model(const gt_ctx* ctx) {
     const double u = 5.9604644775390625e-08;  // 2^-24
-    return 2.0 * double(dp + 6) * u;
+    ErrModel m;
+    if (ctx->prec == 1) {
+        // 3*DP + 1 summands in fp32 (factor 2 head-room, also covers truncating alignment inside the MFMA),
+        // + 3 * 2^-22 for the two residuals and the dropped lo.lo products (x1.01 for second-order terms)
+        m.rel = 2.0 * double(3 * ctx->DP + 4) * u + 1.01 * 3.0 * 4.0 * u;
+        // float16 underflow of a lo part: absolute 2^-25 per element in scaled units
+        m.abs = std::sqrt(double(ctx->DP)) * 2.0 * u / ctx->sc;
+    } else {
+        // DP fused multiply-adds on top of the rounded seed; float64 inputs add 2u from the float32 conversion
+        m.rel = 2.0 * double(ctx->DP + 6) * u;
+        m.abs = 0.0;
+    }
+    m.inv_sc2 = 1.0 / (ctx->sc * ctx->sc);
+    return m;
 }
 
 int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int need_m) {
@@ -52,6 +61,7 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
     const size_t lcap = size_t(64) * nt;
     GT_HIP(ctx, k->lists.reserve(size_t(k->nq_pad) * lcap * sizeof(uint64_t)));
     GT_HIP(ctx, k->counts.reserve(size_t(k->nq_pad) * sizeof(uint32_t)));
+    GT_HIP(ctx, k->thr_final.reserve(size_t(k->nq_pad) * sizeof(float)));
     GT_HIP(ctx, k->cand_d2.reserve(size_t(nq) * MP * sizeof(double)));
     GT_HIP(ctx, k->cand_j.reserve(size_t(nq) * MP * sizeof(uint32_t)));
     GT_HIP(ctx, k->cand_n.reserve(size_t(nq) * sizeof(uint32_t)));
@@ -64,6 +74,7 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
 
     SelectArgs sa;
     sa.dp = ctx->DP;
+    sa.prec = ctx->prec;
     sa.mode = 0;
     sa.nt = nt;
     sa.Yp = ctx->Yp.as<float>();
@@ -75,6 +86,8 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
     sa.nq = int32_t(nq);
     sa.lists = k->lists.as<uint64_t>();
     sa.counts = k->counts.as<uint32_t>();
+    sa.thr_out = k->thr_final.as<float>();
+    sa.dbg = ctx->dbg_select;
     {
         StageSpan span(ctx, "knn_select");
         GT_TRY(gt_launch_select(ctx, sa));
@@ -92,8 +105,9 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
     ra.lists = k->lists.as<uint64_t>();
     ra.lstride = int(lcap);
     ra.counts = k->counts.as<uint32_t>();
+    ra.thr_final = k->thr_final.as<float>();
     ra.ymax2 = ctx->ymax.as<double>();
-    ra.err_coef = err_coefficient(ctx->DP);
+    ra.err = gt_err_model(ctx);
     ra.need_m = need_m;
     ra.MP = MP;
     ra.cand_d2 = k->cand_d2.as<double>();
@@ -147,8 +161,19 @@ extern "C" int gt_knn_search(gt_ctx* ctx, int64_t row0, int64_t row1, const void
                                    y_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
         GT_HIP(ctx, kw->Qp.reserve(size_t(mpad) * ctx->DP * sizeof(float)));
         GT_HIP(ctx, kw->qn.reserve(size_t(m) * sizeof(double)));
+        if (ctx->prec == 1) {
+            // the query matrix shares the database's power-of-two scale; re-scale both if it would overflow float16
+            double qmax = 0.0;
+            GT_TRY(gt_max_abs(ctx, kw->Qraw.p, m * int64_t(ctx->d), ctx->dtype, &qmax));
+            if (qmax * ctx->sc >= 32768.0) {
+                const double keep = ctx->maxabs;
+                ctx->sc = gt_f16_scale(std::max(qmax, keep));
+                GT_TRY(gt_prep_matrix(ctx, ctx->X, ctx->n, ctx->d, ctx->dtype, ctx->DP, ctx->n_pad, ctx->Yp.as<float>(),
+                                      ctx->xn.as<double>(), ctx->hneg.as<float>(), ctx->ymax.as<double>(), 1, ctx->sc));
+            }
+        }
         GT_TRY(gt_prep_matrix(ctx, kw->Qraw.p, m, ctx->d, ctx->dtype, ctx->DP, mpad, kw->Qp.as<float>(),
-                              kw->qn.as<double>(), nullptr, nullptr));
+                              kw->qn.as<double>(), nullptr, nullptr, ctx->prec, ctx->sc));
         row0 = 0;
     } else {
         if (row0 < 0 || row1 > ctx->n || row1 <= row0) GT_FAIL(ctx, GT_E_ARG, "gt_knn_search: bad row range");

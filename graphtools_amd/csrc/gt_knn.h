@@ -17,7 +17,7 @@ struct KnnWork {
     bool external = false;
     // external queries (gt_knn_search with Y)
     DevBuf Qraw, Qp, qn;
-    DevBuf lists, counts;
+    DevBuf lists, counts, thr_final;
     DevBuf cand_d2, cand_j, cand_n, d2_lb;
     DevBuf fb_rows, fb_count, fb_scratch, gflags;
     int64_t n_fallback = 0;
@@ -25,7 +25,20 @@ struct KnnWork {
 
 int gt_select_bn_for(int dp);
 int gt_prep_matrix(gt_ctx* ctx, const void* Xdev, int64_t n, int d, int dtype, int DP, int64_t n_pad, float* Yp,
-                   double* xn, float* hneg, double* ymax2);
+                   double* xn, float* hneg, double* ymax2, int prec, double sc);
+int gt_max_abs(gt_ctx* ctx, const void* Xdev, int64_t total, int dtype, double* out_host);
+double gt_f16_scale(double maxabs);
+
+// Error model of the candidate scores (scaled units s~ = sc^2 (x.y - |y|^2/2) + error):
+//   |s~/sc^2 - s| <= rel * (|y|^2/2 + |x||y|) + abs * (|x| + |y|)
+// rel covers the accumulation (any summation order of the MFMA chain, with head-room) and, for the split-float16
+// back end, the 2^-22 representation residual and the dropped lo.lo term; abs covers float16 underflow of lo parts.
+struct ErrModel {
+    double rel;
+    double abs;
+    double inv_sc2;
+};
+ErrModel gt_err_model(const gt_ctx* ctx);
 
 // Build exact candidate tables with the first `need_m` entries of every row guaranteed to be the true
 // need_m nearest neighbours.  Queries: rows [q0, q0+nq) of the bound points, or (external) the matrix in
@@ -46,8 +59,9 @@ struct RerankArgs {
     const uint64_t* lists;
     int lstride;
     const uint32_t* counts;
+    const float* thr_final;   // last admission threshold of the candidate pass (scaled score units)
     const double* ymax2;
-    double err_coef;
+    ErrModel err;
     int need_m;
     int MP;
     double* cand_d2;

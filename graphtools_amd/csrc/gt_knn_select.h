@@ -4,9 +4,10 @@
 
 struct SelectArgs {
     int dp = 0;            // padded feature count (gt_choose_dp)
+    int prec = 0;          // 0: float32 operands, 1: split float16 planes (hi + lo)
     int mode = 0;          // 0: top-M' selection, 1: radius collect
     int nt = 8;            // selection: keys per lane in the compaction sort; list capacity 64*nt, M' = 16*nt
-    const float* Yp = nullptr;    // database, [n_pad][dp]
+    const float* Yp = nullptr;    // database working copy, [n_pad] rows of 4*dp bytes
     const float* hneg = nullptr;  // [n_pad]
     int64_t n_pad = 0;
     const float* Qp = nullptr;    // query matrix, [*][dp]
@@ -16,9 +17,12 @@ struct SelectArgs {
     uint64_t* lists = nullptr;    // [nq_pad][64*nt] (selection) or [nq_pad][cap] (radius)
     uint32_t* counts = nullptr;   // [nq_pad]
     const float* thr_in = nullptr;  // radius mode: per-query score threshold [nq]
+    float* thr_out = nullptr;       // selection mode: final admission threshold per query [nq_pad]
     int32_t cap = 0;                // radius mode: list capacity per query
+    int32_t dbg = 0;                // experiment switches (bit 0: no survivors, bit 1: no compaction sort)
 };
 
 int gt_launch_select(gt_ctx* ctx, const SelectArgs& a);
+int gt_choose_dp_prec(int d, int prec);  // padded feature count for a precision (0 if unsupported)
 int gt_select_bq(int dp);  // query rows per workgroup
 int gt_select_bn(int dp);  // database rows per tile

@@ -1,51 +1,180 @@
 // Candidate generation for brute-force kNN / radius search on gfx950.
 //
-// One workgroup (4 waves) owns BQ = 128*QT query rows and streams the whole padded float32 database
-// through LDS in tiles of BN rows.  Each wave keeps its 32*QT query rows as the B operand of
-// v_mfma_f32_32x32x2_f32 in registers for the whole kernel; the database tile is the A operand, so the
-// 32x32 result block lands with ONE QUERY PER LANE (column = lane & 31) and 16 database rows per lane
-// (row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)).  The accumulator is pre-loaded with -|y|^2/2, so after the
-// K loop it holds the score  s = x.y - |y|^2/2  (d^2 = |x|^2 - 2 s: larger score = closer), and the
-// per-query running threshold is a single VGPR compare per lane.
+// One workgroup (4 waves) owns BQ = 128*QT query rows and streams the padded working copy of the database
+// through LDS in tiles of BN rows.  Each wave keeps its 32*QT query rows as the B operand of a 32x32 MFMA in
+// registers for the whole kernel; the database tile is the A operand, so the 32x32 result block lands with
+// ONE QUERY PER LANE (column = lane & 31) and 16 database rows per lane
+// (row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)).  The accumulator is pre-loaded with -|y|^2/2, so after the K
+// loop it holds the score  s = x.y - |y|^2/2  (d^2 = |x|^2 - 2 s: larger score = closer), and the per-query
+// running threshold is a single VGPR compare per lane.
+//
+// Two arithmetic back ends produce the scores (PREC):
+//   PREC 0  float32 operands, v_mfma_f32_32x32x2_f32 (157 TF peak): exact products, fp32 accumulation.
+//   PREC 1  every (power-of-two scaled) value is split into two float16 planes x = hi + lo (22 significant
+//           bits); x.y ~ hi.hi + hi.lo + lo.hi with three v_mfma_f32_32x32x16_f16 chains (2.5 PF peak, fp32
+//           accumulation).  5.3x fewer matrix-pipe cycles than PREC 0 at fp32-class accuracy.
+// Either way the scores only have to be within a KNOWN error bound of the true ones: exact ordering is
+// established afterwards in float64 (gt_rerank.hip), which also proves the candidate table complete or sends
+// the row to an exhaustive fallback.
 //
 // MODE 0 (top-M' selection): survivors (s > thr) are appended to the query's candidate list in global
 //   memory (slot from an LDS counter; the wave owns its queries, so no cross-wave traffic).  When a list
-//   passes its trigger level the owning wave sorts it in registers (bitonic, 64*NT keys), keeps the best
-//   M' = 16*NT and raises thr to the M'-th score.  At the end every list is sorted; list[0..M') are the
-//   candidates in descending score order.  Exact ordering is established afterwards in fp64 (gt_rerank.hip);
-//   the scores here only have to be within a known error bound of the true ones.
+//   passes its trigger level the owning wave selects the best M' = 16*NT of its 64*NT keys (bitwise search for
+//   the M'-th largest score with wave ballots, then an order-free filter) and raises thr to the M'-th score.
+//   At the end list[0..count) holds the candidates (unordered) and thr_out the last admission threshold.
 // MODE 1 (radius collect): thr is a fixed per-query score bound; every survivor is appended (up to `cap`
-//   entries per query, the true count is always reported).
+//   entries per query, the true count is always reported).  Slots come from a global counter so the
+//   database can be split over gridDim.y workgroups when there are few query rows.
 //
-// Roofline: MFMA-bound (fp32 matrix, 157.3 TF peak): 2*DP flop per (query, database row) pair.
+// Roofline: MFMA-bound.  Algorithmic work 2*d flop per (query, database row) pair.
 #include "gt_common.h"
 #include "gt_device.h"
 #include "gt_knn_select.h"
 
 namespace {
 
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
 template <int DP>
 struct SelCfg {
-    static constexpr int KS = DP / 2;                   // k-steps (2 k per MFMA), per-lane fragment length
     static constexpr int QT = (DP <= 64) ? 2 : 1;       // 32-row query tiles per wave
     static constexpr int BQ = 4 * QT * 32;              // query rows per workgroup
     static constexpr int BN = (DP <= 64) ? 128 : 64;    // database rows per LDS tile
-    static constexpr int LDP = DP + 4;                  // LDS row stride (floats): conflict-free ds_read_b128
-    static constexpr int NF4 = BN * DP / 4;             // float4 per tile
+    static constexpr int LDP = DP + 4;                  // LDS row stride (dwords): conflict-free ds_read_b128
+    static constexpr int NF4 = BN * DP / 4;             // 16-byte units per tile (a row is 4*DP bytes in both layouts)
     static constexpr int F4_PER_THREAD = (NF4 + 255) / 256;
     static constexpr int TILE_FLOATS = BN * LDP;
     static constexpr size_t LDS_BYTES =
         size_t(2) * TILE_FLOATS * 4 + size_t(2) * BN * 4 + size_t(BQ) * 4 * 2;
 };
 
-template <int DP, int NT, int MODE>
+// ---- operand fragments -------------------------------------------------------------------------
+// PREC 0: row = DP floats; lane (li, h) holds features [h*DP/2, (h+1)*DP/2)  (one per MFMA k-step)
+// PREC 1: row = hi plane (DP halves) | lo plane (DP halves); per k-step s of 16 features lane (li, h) holds
+//         features [16 s + 8 h, 16 s + 8 h + 8) of a plane as one f16x8
+template <int DP, int PREC>
+struct Frag;
+
+template <int DP>
+struct Frag<DP, 0> {
+    static constexpr int KS = DP / 2;
+    float v[KS];
+    __device__ __forceinline__ void load(const float* row, int h) {
+        const float4* p = reinterpret_cast<const float4*>(row + h * KS);
+#pragma unroll
+        for (int c = 0; c < KS / 4; ++c) {
+            const float4 q = p[c];
+            v[4 * c + 0] = q.x;
+            v[4 * c + 1] = q.y;
+            v[4 * c + 2] = q.z;
+            v[4 * c + 3] = q.w;
+        }
+    }
+};
+
+template <int DP>
+struct Frag<DP, 1> {
+    static constexpr int NS = DP / 16;
+    f16x8 hi[NS], lo[NS];
+    __device__ __forceinline__ void load(const float* row, int h) {
+        const f16x8* p = reinterpret_cast<const f16x8*>(row);   // 16-byte units: hi plane = units [0, DP/8)
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            hi[s] = p[2 * s + h];
+            lo[s] = p[DP / 8 + 2 * s + h];
+        }
+    }
+};
+
+template <int DP, int QT>
+__device__ __forceinline__ void mma_block(const Frag<DP, 0>& a, const Frag<DP, 0> (&b)[QT], f32x16 (&acc)[QT]) {
+#pragma unroll
+    for (int s = 0; s < DP / 2; ++s) {
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt)
+            acc[qt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[s], b[qt].v[s], acc[qt], 0, 0, 0);
+    }
+}
+
+template <int DP, int QT>
+__device__ __forceinline__ void mma_block(const Frag<DP, 1>& a, const Frag<DP, 1> (&b)[QT], f32x16 (&acc)[QT]) {
+    // small cross terms first, the dominant hi.hi chain last
+#pragma unroll
+    for (int s = 0; s < DP / 16; ++s) {
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt)
+            acc[qt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.lo[s], b[qt].hi[s], acc[qt], 0, 0, 0);
+    }
+#pragma unroll
+    for (int s = 0; s < DP / 16; ++s) {
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt)
+            acc[qt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.hi[s], b[qt].lo[s], acc[qt], 0, 0, 0);
+    }
+#pragma unroll
+    for (int s = 0; s < DP / 16; ++s) {
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt)
+            acc[qt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.hi[s], b[qt].hi[s], acc[qt], 0, 0, 0);
+    }
+}
+
+// ---- candidate-list compaction: keep the MKEEP best scores of a list of n <= 64*NT keys ---------------
+// The list does not have to be ordered while streaming (the float64 re-rank sorts the final table), so this
+// is a selection, not a sort: a 32-step bitwise search for the MKEEP-th largest score (wave ballots + scalar
+// popcounts, no cross-lane shuffles), then an order-free filter.  Entries tied with the threshold are kept
+// only up to the quota; dropping the rest is consistent with the strict `score > thr` admission test.
+// Returns the new threshold (the MKEEP-th largest score) and the new count via `new_n`.
+template <int NT>
+__device__ __forceinline__ float compact_list(uint64_t* __restrict__ lp, const uint32_t n, const int lane,
+                                              uint32_t& new_n) {
+    constexpr uint32_t MKEEP = 16 * NT;
+    uint64_t key[NT];
+    uint32_t ord[NT];
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+        const uint32_t e = uint32_t(u * 64 + lane);
+        key[u] = e < n ? ld_agent_u64(lp + e) : 0ull;
+        ord[u] = uint32_t(key[u] >> 32);
+    }
+    uint32_t T = 0u;
+#pragma unroll 1
+    for (int b = 31; b >= 0; --b) {
+        const uint32_t trial = T | (1u << b);
+        uint32_t c = 0;
+#pragma unroll
+        for (int u = 0; u < NT; ++u) c += uint32_t(__popcll(__ballot(ord[u] >= trial)));
+        if (c >= MKEEP) T = trial;
+    }
+    uint32_t c_gt = 0;
+#pragma unroll
+    for (int u = 0; u < NT; ++u) c_gt += uint32_t(__popcll(__ballot(ord[u] > T)));
+    const uint32_t quota_eq = MKEEP - c_gt;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    uint32_t base_gt = 0, base_eq = 0;
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+        const bool gt = ord[u] > T;
+        const bool eq = ord[u] == T;
+        const unsigned long long mg = __ballot(gt), me = __ballot(eq);
+        if (gt) st_agent_u64(lp + base_gt + uint32_t(__popcll(mg & lt_mask)), key[u]);
+        const uint32_t pe = base_eq + uint32_t(__popcll(me & lt_mask));
+        if (eq && pe < quota_eq) st_agent_u64(lp + c_gt + pe, key[u]);
+        base_gt += uint32_t(__popcll(mg));
+        base_eq += uint32_t(__popcll(me));
+    }
+    new_n = MKEEP;
+    return ord_f32(T);
+}
+
+template <int DP, int NT, int MODE, int PREC>
 __global__ __launch_bounds__(256, 2) void knn_select_kernel(
     const float* __restrict__ Yp, const float* __restrict__ hneg, const float* __restrict__ Qp,
     const int32_t* __restrict__ qrows, const int64_t q0, const int32_t nq, const int32_t ntiles,
     uint64_t* __restrict__ lists, uint32_t* __restrict__ counts, const float* __restrict__ thr_in,
-    const int32_t cap) {
+    float* __restrict__ thr_out, const int32_t cap, const int32_t dbg) {
     using C = SelCfg<DP>;
-    constexpr int KS = C::KS, QT = C::QT, BQ = C::BQ, BN = C::BN, LDP = C::LDP;
+    constexpr int QT = C::QT, BQ = C::BQ, BN = C::BN, LDP = C::LDP;
     constexpr int LCAP = 64 * NT;        // list capacity in selection mode
     constexpr int MKEEP = 16 * NT;       // M'
     constexpr int TRIG = LCAP - BN;      // compaction trigger (a tile can add at most BN entries per query)
@@ -64,9 +193,17 @@ __global__ __launch_bounds__(256, 2) void knn_select_kernel(
     const int h = lane >> 5;
     const int64_t qblock = int64_t(blockIdx.x) * BQ;
     const size_t lstride = (MODE == 0) ? size_t(LCAP) : size_t(cap);
+    // database tile range of this workgroup (MODE 1 may split the database over gridDim.y)
+    int t_begin = 0, t_end = ntiles;
+    if (MODE == 1) {
+        const int per = (ntiles + int(gridDim.y) - 1) / int(gridDim.y);
+        t_begin = int(blockIdx.y) * per;
+        t_end = t_begin + per < ntiles ? t_begin + per : ntiles;
+        if (t_begin >= t_end) return;
+    }
 
-    // ---- query fragments: lane (li, h) holds query (w*QT + qt)*32 + li, features [h*KS, h*KS + KS) ----
-    float bq[QT][KS];
+    // ---- query fragments (B operand), resident for the whole kernel ----
+    Frag<DP, PREC> bq[QT];
     float thr[QT];
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
@@ -74,16 +211,8 @@ __global__ __launch_bounds__(256, 2) void knn_select_kernel(
         const int64_t qg = qblock + ql;
         const int64_t qc = qg < nq ? qg : int64_t(nq) - 1;   // clamp pad queries onto a real row
         const int64_t row = qrows ? int64_t(qrows[qc]) : q0 + qc;
-        const float4* src = reinterpret_cast<const float4*>(Qp + row * DP + h * KS);
-#pragma unroll
-        for (int c = 0; c < KS / 4; ++c) {
-            const float4 v = src[c];
-            bq[qt][4 * c + 0] = v.x;
-            bq[qt][4 * c + 1] = v.y;
-            bq[qt][4 * c + 2] = v.z;
-            bq[qt][4 * c + 3] = v.w;
-        }
-        thr[qt] = (MODE == 0) ? -INFINITY : thr_in[qc];
+        bq[qt].load(Qp + row * DP, h);
+        thr[qt] = (MODE == 0) ? ((dbg & 1) ? INFINITY : -INFINITY) : ((qg < nq) ? thr_in[qc] : INFINITY);
     }
     if (tid < BQ) {
         cnt[tid] = 0u;
@@ -116,30 +245,22 @@ __global__ __launch_bounds__(256, 2) void knn_select_kernel(
         if (tid < BN) hn[(BUF_) * BN + tid] = stage_h;                                        \
     }
 
-    GT_STAGE_LOAD(0);
+    GT_STAGE_LOAD(t_begin);
     GT_STAGE_STORE(0);
     __syncthreads();
 
-    for (int t = 0; t < ntiles; ++t) {
-        const int buf = t & 1;
-        if (t + 1 < ntiles) GT_STAGE_LOAD(t + 1);
+    for (int t = t_begin; t < t_end; ++t) {
+        const int buf = (t - t_begin) & 1;
+        if (t + 1 < t_end) GT_STAGE_LOAD(t + 1);
         const float* tb = tile + buf * C::TILE_FLOATS;
         const float* hb = hn + buf * BN;
         const uint32_t tbase = uint32_t(t) * BN;
 
 #pragma unroll 1
         for (int sb = 0; sb < BN / 32; ++sb) {
-            // A fragment: database row sb*32 + li, features [h*KS, h*KS+KS)
-            float a[KS];
-            const float4* ap = reinterpret_cast<const float4*>(tb + (sb * 32 + li) * LDP + h * KS);
-#pragma unroll
-            for (int c = 0; c < KS / 4; ++c) {
-                const float4 v = ap[c];
-                a[4 * c + 0] = v.x;
-                a[4 * c + 1] = v.y;
-                a[4 * c + 2] = v.z;
-                a[4 * c + 3] = v.w;
-            }
+            // A fragment: database row sb*32 + li
+            Frag<DP, PREC> a;
+            a.load(tb + (sb * 32 + li) * LDP, h);
             // accumulator init: acc[4g+e] <-> database row 8g + 4h + e  => -|y|^2/2 of that row
             f32x16 acc[QT];
 #pragma unroll
@@ -153,12 +274,7 @@ __global__ __launch_bounds__(256, 2) void knn_select_kernel(
                     acc[qt][4 * g + 3] = hv.w;
                 }
             }
-#pragma unroll
-            for (int s = 0; s < KS; ++s) {
-#pragma unroll
-                for (int qt = 0; qt < QT; ++qt)
-                    acc[qt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], bq[qt][s], acc[qt], 0, 0, 0);
-            }
+            mma_block<DP, QT>(a, bq, acc);
             // ---- epilogue: one query per lane, 16 database rows in registers ----
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt) {
@@ -172,9 +288,14 @@ __global__ __launch_bounds__(256, 2) void knn_select_kernel(
                     for (int r = 0; r < 16; ++r) {
                         const float v = acc[qt][r];
                         if (v > thr[qt]) {
-                            const uint32_t slot = atomicAdd(&cnt[ql], 1u);
                             const uint32_t j = tbase + uint32_t(sb * 32 + 8 * (r >> 2) + 4 * h + (r & 3));
-                            if (MODE == 0 || slot < uint32_t(cap)) st_agent_u64(lp + slot, cand_pack(v, j));
+                            if (MODE == 0) {
+                                const uint32_t slot = atomicAdd(&cnt[ql], 1u);
+                                st_agent_u64(lp + slot, cand_pack(v, j));
+                            } else {
+                                const uint32_t slot = atomicAdd(&counts[qblock + ql], 1u);
+                                if (slot < uint32_t(cap)) st_agent_u64(lp + slot, cand_pack(v, j));
+                            }
                         }
                     }
                 }
@@ -185,6 +306,10 @@ __global__ __launch_bounds__(256, 2) void knn_select_kernel(
             // ---- list maintenance: lane L <-> query w*QT*32 + L of this wave ----
             const uint32_t c = (lane < QT * 32) ? cnt[w * QT * 32 + lane] : 0u;
             unsigned long long need = __ballot(c > uint32_t(TRIG));
+            if ((dbg & 2) && need) {   // experiment: no selection, just pretend the list was compacted
+                if (c > uint32_t(TRIG)) cnt[w * QT * 32 + lane] = uint32_t(MKEEP);
+                need = 0;
+            }
             if (need) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's list stores have reached L2
                 while (need) {
@@ -193,20 +318,11 @@ __global__ __launch_bounds__(256, 2) void knn_select_kernel(
                     const int ql = w * QT * 32 + L;
                     const uint32_t n = cnt[ql];
                     uint64_t* lp = lists + size_t(qblock + ql) * lstride;
-                    uint64_t key[NT];
-#pragma unroll
-                    for (int u = 0; u < NT; ++u) {
-                        const uint32_t e = uint32_t(u * 64 + lane);
-                        key[u] = e < n ? ld_agent_u64(lp + e) : 0ull;
-                    }
-                    wave_bitonic_desc<NT>(key, lane);
-                    // survivors: positions [0, MKEEP) = registers [0, NT/4)
-#pragma unroll
-                    for (int u = 0; u < NT / 4; ++u) st_agent_u64(lp + u * 64 + lane, key[u]);
-                    const uint64_t last = __shfl((unsigned long long)key[NT / 4 - 1], 63);
+                    uint32_t new_n;
+                    const float t = compact_list<NT>(lp, n, lane, new_n);
                     if (lane == 0) {
-                        cnt[ql] = n < uint32_t(MKEEP) ? n : uint32_t(MKEEP);
-                        thr_lds[ql] = n >= uint32_t(MKEEP) ? cand_score(last) : -INFINITY;
+                        cnt[ql] = new_n;
+                        thr_lds[ql] = t;
                     }
                 }
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -215,64 +331,70 @@ __global__ __launch_bounds__(256, 2) void knn_select_kernel(
             }
         }
 
-        if (t + 1 < ntiles) GT_STAGE_STORE(buf ^ 1);
+        if (t + 1 < t_end) GT_STAGE_STORE(buf ^ 1);
         __syncthreads();
     }
 
-    // ---- finalisation ----
+    // ---- finalisation: trim every list to MKEEP entries, publish count and the last admission threshold ----
     if (MODE == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll 1
         for (int L = 0; L < QT * 32; ++L) {
             const int ql = w * QT * 32 + L;
-            const uint32_t n = cnt[ql];
-            uint64_t* lp = lists + size_t(qblock + ql) * lstride;
-            uint64_t key[NT];
-#pragma unroll
-            for (int u = 0; u < NT; ++u) {
-                const uint32_t e = uint32_t(u * 64 + lane);
-                key[u] = e < n ? ld_agent_u64(lp + e) : 0ull;
+            uint32_t n = cnt[ql];
+            float t = thr_lds[ql];
+            if (n > uint32_t(MKEEP)) {
+                uint64_t* lp = lists + size_t(qblock + ql) * lstride;
+                t = compact_list<NT>(lp, n, lane, n);
             }
-            wave_bitonic_desc<NT>(key, lane);
-#pragma unroll
-            for (int u = 0; u < NT / 4; ++u) st_agent_u64(lp + u * 64 + lane, key[u]);
-            if (lane == 0) counts[qblock + ql] = n;   // >= MKEEP means "list was truncated to MKEEP"
+            if (lane == 0) {
+                counts[qblock + ql] = n;
+                thr_out[qblock + ql] = t;   // every rejected database row scored <= t (-inf: nothing was rejected)
+            }
         }
-    } else {
-        if (tid < BQ) counts[qblock + tid] = cnt[tid];
     }
 }
 
-template <int DP, int NT, int MODE>
+template <int DP, int NT, int MODE, int PREC>
 int launch_one(gt_ctx* ctx, const SelectArgs& a) {
     using C = SelCfg<DP>;
     const int64_t nblocks = ceil_div64(a.nq, C::BQ);
-    auto kern = knn_select_kernel<DP, NT, MODE>;
+    const int ntiles = int(a.n_pad / C::BN);
+    int nsplit = 1;
+    if (MODE == 1) {
+        // few query blocks: split the database so that ~4 workgroups per CU are in flight
+        const int64_t want = int64_t(ctx->n_cu) * 4;
+        nsplit = int(std::min<int64_t>(std::max<int64_t>(1, want / nblocks), std::max(1, ntiles / 8)));
+        GT_HIP(ctx, hipMemsetAsync(a.counts, 0, size_t(nblocks) * C::BQ * sizeof(uint32_t), ctx->stream));
+    }
+    auto kern = knn_select_kernel<DP, NT, MODE, PREC>;
     GT_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     int(C::LDS_BYTES)));
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(256), C::LDS_BYTES, ctx->stream, a.Yp, a.hneg, a.Qp,
-                       a.qrows, a.q0, a.nq, int32_t(a.n_pad / C::BN), a.lists, a.counts, a.thr_in, a.cap);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks, (unsigned)nsplit), dim3(256), C::LDS_BYTES, ctx->stream, a.Yp,
+                       a.hneg, a.Qp, a.qrows, a.q0, a.nq, ntiles, a.lists, a.counts, a.thr_in, a.thr_out, a.cap, a.dbg);
     GT_HIP(ctx, hipGetLastError());
     return GT_OK;
 }
 
-template <int DP>
+template <int DP, int PREC>
 int launch_dp(gt_ctx* ctx, const SelectArgs& a) {
-    if (a.mode == 1) return launch_one<DP, 8, 1>(ctx, a);
+    if (a.mode == 1) return launch_one<DP, 8, 1, PREC>(ctx, a);
     switch (a.nt) {
-        case 8: return launch_one<DP, 8, 0>(ctx, a);
-        case 32: return launch_one<DP, 32, 0>(ctx, a);
+        case 8: return launch_one<DP, 8, 0, PREC>(ctx, a);
+        case 32: return launch_one<DP, 32, 0, PREC>(ctx, a);
     }
     GT_FAIL(ctx, GT_E_ARG, "knn_select: unsupported list size");
 }
 
 }  // namespace
 
-// This file is compiled once per padded feature count (-DGT_SEL_DP=<dp>) so the instantiations build in
-// parallel; gt_knn_select_dispatch.cpp routes to the right one.
-#ifndef GT_SEL_DP
-#error "compile with -DGT_SEL_DP=<dp>"
+// This file is compiled once per (precision, padded feature count): -DGT_SEL_PREC=<0|1> -DGT_SEL_DP=<dp>, so the
+// instantiations build in parallel; gt_knn_select_dispatch.cpp routes to the right one.
+#if !defined(GT_SEL_DP) || !defined(GT_SEL_PREC)
+#error "compile with -DGT_SEL_PREC=<0|1> -DGT_SEL_DP=<dp>"
 #endif
-#define GT_CAT2(a, b) a##b
-#define GT_CAT(a, b) GT_CAT2(a, b)
-int GT_CAT(gt_launch_select_dp, GT_SEL_DP)(gt_ctx* ctx, const SelectArgs& a) { return launch_dp<GT_SEL_DP>(ctx, a); }
+#define GT_CAT3_(a, b, c, d) a##b##c##d
+#define GT_CAT3(a, b, c, d) GT_CAT3_(a, b, c, d)
+int GT_CAT3(gt_launch_select_p, GT_SEL_PREC, _dp, GT_SEL_DP)(gt_ctx* ctx, const SelectArgs& a) {
+    return launch_dp<GT_SEL_DP, GT_SEL_PREC>(ctx, a);
+}

@@ -1,23 +1,30 @@
-// Routes a candidate-kernel launch to the translation unit compiled for its padded feature count.
+// Routes a candidate-kernel launch to the translation unit compiled for its precision / padded feature count.
 #include "gt_knn_select.h"
 
-#define GT_SEL_DP_LIST(X) X(16) X(32) X(56) X(64) X(104) X(128)
-#define GT_DECL(dp) int gt_launch_select_dp##dp(gt_ctx*, const SelectArgs&);
-GT_SEL_DP_LIST(GT_DECL)
+// keep in sync with SELECT_UNITS in graphtools_amd/_build.py
+#define GT_SEL_P0_LIST(X) X(0, 16) X(0, 32) X(0, 56) X(0, 64) X(0, 104) X(0, 128)
+#define GT_SEL_P1_LIST(X) X(1, 16) X(1, 32) X(1, 48) X(1, 64) X(1, 80) X(1, 96) X(1, 112) X(1, 128)
+#define GT_DECL(PR_, DP_) int gt_launch_select_p##PR_##_dp##DP_(gt_ctx*, const SelectArgs&);
+GT_SEL_P0_LIST(GT_DECL)
+GT_SEL_P1_LIST(GT_DECL)
 
-int gt_choose_dp(int d) {
-#define GT_PICK(dp) if (d <= dp) return dp;
-    GT_SEL_DP_LIST(GT_PICK)
+int gt_choose_dp_prec(int d, int prec) {
+#define GT_PICK(PR_, DP_) if (d <= DP_) return DP_;
+    if (prec == 0) {
+        GT_SEL_P0_LIST(GT_PICK)
+    } else {
+        GT_SEL_P1_LIST(GT_PICK)
+    }
     return 0;
 }
 
+int gt_choose_dp(int d) { return gt_choose_dp_prec(d, 0); }
 int gt_select_bq(int dp) { return dp <= 64 ? 256 : 128; }
 int gt_select_bn(int dp) { return dp <= 64 ? 128 : 64; }
 
 int gt_launch_select(gt_ctx* ctx, const SelectArgs& a) {
-    switch (a.dp) {
-#define GT_CASE(dp) case dp: return gt_launch_select_dp##dp(ctx, a);
-        GT_SEL_DP_LIST(GT_CASE)
-    }
+#define GT_CASE(PR_, DP_) if (a.prec == PR_ && a.dp == DP_) return gt_launch_select_p##PR_##_dp##DP_(ctx, a);
+    GT_SEL_P0_LIST(GT_CASE)
+    GT_SEL_P1_LIST(GT_CASE)
     GT_FAIL(ctx, GT_E_LIMIT, "knn_select: feature dimension > 128 is not supported by the HIP path yet");
 }

@@ -6,6 +6,8 @@
 #include "gt_device.h"
 #include "gt_knn.h"
 
+#include <algorithm>
+
 namespace {
 
 template <typename T>
@@ -28,10 +30,41 @@ __global__ __launch_bounds__(256) void pad_convert_kernel(const T* __restrict__ 
     }
 }
 
+// max |x| over the matrix (for the power-of-two scale of the split-float16 working copy)
+template <typename T>
+__global__ __launch_bounds__(256) void max_abs_kernel(const T* __restrict__ X, const int64_t total,
+                                                      unsigned long long* __restrict__ out_bits) {
+    double m = 0.0;
+    for (int64_t f = int64_t(blockIdx.x) * 256 + threadIdx.x; f < total; f += int64_t(gridDim.x) * 256) {
+        const double v = fabs(double(X[f]));
+        m = v > m ? v : m;   // NaN never wins
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(out_bits, (unsigned long long)__double_as_longlong(m));
+}
+
+// split-float16 working copy: row = hi plane (DP halves) | lo plane (DP halves), x*sc = hi + lo + O(2^-22 |x*sc|)
+template <typename T>
+__global__ __launch_bounds__(256) void pad_split_f16_kernel(const T* __restrict__ X, int64_t n, int d, int DP,
+                                                            int64_t n_pad, double sc, _Float16* __restrict__ Yh) {
+    const int64_t total = n_pad * DP;
+    for (int64_t f = int64_t(blockIdx.x) * 256 + threadIdx.x; f < total; f += int64_t(gridDim.x) * 256) {
+        const int64_t r = f / DP;
+        const int c = int(f % DP);
+        double v = 0.0;
+        if (r < n && c < d) v = double(X[r * int64_t(d) + c]) * sc;   // exact: sc is a power of two
+        const _Float16 hi = _Float16(v);
+        const _Float16 lo = _Float16(v - double(hi));
+        Yh[r * int64_t(2 * DP) + c] = hi;
+        Yh[r * int64_t(2 * DP) + DP + c] = lo;
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void row_norm_kernel(const T* __restrict__ X, int64_t n, int d, int64_t n_pad,
                                                        double* __restrict__ xn, float* __restrict__ hneg,
-                                                       unsigned long long* __restrict__ ymax2_bits) {
+                                                       const double sc2, unsigned long long* __restrict__ ymax2_bits) {
     const int64_t r = int64_t(blockIdx.x) * 256 + threadIdx.x;
     double acc = 0.0;
     if (r < n) {
@@ -41,7 +74,7 @@ __global__ __launch_bounds__(256) void row_norm_kernel(const T* __restrict__ X, 
             acc = fma(v, v, acc);
         }
         xn[r] = acc;
-        if (hneg) hneg[r] = float(-0.5 * acc);
+        if (hneg) hneg[r] = float(-0.5 * acc * sc2);
     } else if (r < n_pad) {
         if (hneg) hneg[r] = -INFINITY;
     }
@@ -54,10 +87,50 @@ __global__ __launch_bounds__(256) void row_norm_kernel(const T* __restrict__ X, 
 
 }  // namespace
 
+int gt_max_abs(gt_ctx* ctx, const void* Xdev, int64_t total, int dtype, double* out_host) {
+    DevBuf tmp;
+    GT_HIP(ctx, tmp.reserve(sizeof(double)));
+    GT_HIP(ctx, hipMemsetAsync(tmp.p, 0, sizeof(double), ctx->stream));
+    int64_t blocks = std::min<int64_t>(ceil_div64(total, 256), 4096);
+    if (dtype == GT_F32)
+        hipLaunchKernelGGL(max_abs_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (const float*)Xdev,
+                           total, (unsigned long long*)tmp.p);
+    else
+        hipLaunchKernelGGL(max_abs_kernel<double>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (const double*)Xdev,
+                           total, (unsigned long long*)tmp.p);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(out_host, tmp.p, sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    tmp.release();
+    if (e != hipSuccess) {
+        ctx->set_error(std::string("max_abs: ") + hipGetErrorString(e));
+        return GT_E_HIP;
+    }
+    return GT_OK;
+}
+
+// power-of-two scale that puts max|x| * sc into [2^13, 2^14): float16 hi parts stay far from overflow
+double gt_f16_scale(double maxabs) {
+    if (!(maxabs > 0.0) || !std::isfinite(maxabs)) return 1.0;
+    int e = 0;
+    (void)std::frexp(maxabs, &e);   // maxabs = m * 2^e, m in [0.5, 1)
+    return std::ldexp(1.0, 14 - e);
+}
+
 int gt_prep_matrix(gt_ctx* ctx, const void* Xdev, int64_t n, int d, int dtype, int DP, int64_t n_pad, float* Yp,
-                   double* xn, float* hneg, double* ymax2) {
+                   double* xn, float* hneg, double* ymax2, int prec, double sc) {
     if (ymax2) GT_HIP(ctx, hipMemsetAsync(ymax2, 0, sizeof(double), ctx->stream));
-    if (Yp) {
+    if (Yp && prec == 1) {
+        const int64_t total = n_pad * DP;
+        int64_t blocks = std::min<int64_t>(ceil_div64(total, 256), 16384);
+        if (dtype == GT_F32)
+            hipLaunchKernelGGL(pad_split_f16_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream,
+                               (const float*)Xdev, n, d, DP, n_pad, sc, (_Float16*)Yp);
+        else
+            hipLaunchKernelGGL(pad_split_f16_kernel<double>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream,
+                               (const double*)Xdev, n, d, DP, n_pad, sc, (_Float16*)Yp);
+        GT_HIP(ctx, hipGetLastError());
+    } else if (Yp) {
         const int64_t total4 = n_pad * DP / 4;
         int64_t blocks = ceil_div64(total4, 256);
         if (blocks > 8192) blocks = 8192;
@@ -73,15 +146,20 @@ int gt_prep_matrix(gt_ctx* ctx, const void* Xdev, int64_t n, int d, int dtype, i
     const int64_t nb = ceil_div64(rows, 256);
     if (dtype == GT_F32)
         hipLaunchKernelGGL(row_norm_kernel<float>, dim3((unsigned)nb), dim3(256), 0, ctx->stream, (const float*)Xdev, n,
-                           d, n_pad, xn, hneg, (unsigned long long*)ymax2);
+                           d, n_pad, xn, hneg, sc * sc, (unsigned long long*)ymax2);
     else
         hipLaunchKernelGGL(row_norm_kernel<double>, dim3((unsigned)nb), dim3(256), 0, ctx->stream, (const double*)Xdev,
-                           n, d, n_pad, xn, hneg, (unsigned long long*)ymax2);
+                           n, d, n_pad, xn, hneg, sc * sc, (unsigned long long*)ymax2);
     GT_HIP(ctx, hipGetLastError());
     return GT_OK;
 }
 
 int gt_prep_points(gt_ctx* ctx) {
+    ctx->sc = 1.0;
+    if (ctx->prec == 1) {
+        GT_TRY(gt_max_abs(ctx, ctx->X, ctx->n * int64_t(ctx->d), ctx->dtype, &ctx->maxabs));
+        ctx->sc = gt_f16_scale(ctx->maxabs);
+    }
     StageSpan span(ctx, "prep", 2);
     const int bn = gt_select_bn_for(ctx->DP);
     ctx->n_pad = ceil_div64(ctx->n, bn) * bn;
@@ -90,5 +168,5 @@ int gt_prep_points(gt_ctx* ctx) {
     GT_HIP(ctx, ctx->hneg.reserve(size_t(ctx->n_pad) * sizeof(float)));
     GT_HIP(ctx, ctx->ymax.reserve(sizeof(double)));
     return gt_prep_matrix(ctx, ctx->X, ctx->n, ctx->d, ctx->dtype, ctx->DP, ctx->n_pad, ctx->Yp.as<float>(),
-                          ctx->xn.as<double>(), ctx->hneg.as<float>(), ctx->ymax.as<double>());
+                          ctx->xn.as<double>(), ctx->hneg.as<float>(), ctx->ymax.as<double>(), ctx->prec, ctx->sc);
 }

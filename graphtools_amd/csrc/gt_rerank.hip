@@ -58,7 +58,8 @@ __global__ __launch_bounds__(256) void rerank_kernel(const T* __restrict__ X, co
                                                      const int64_t q0, const int64_t nq,
                                                      const uint64_t* __restrict__ lists, const int lstride,
                                                      const uint32_t* __restrict__ counts,
-                                                     const double* __restrict__ ymax2p, const double err_coef,
+                                                     const float* __restrict__ thr_final,
+                                                     const double* __restrict__ ymax2p, const ErrModel err,
                                                      const int need_m, double* __restrict__ cand_d2,
                                                      uint32_t* __restrict__ cand_j, uint32_t* __restrict__ cand_n,
                                                      double* __restrict__ d2_lb, uint32_t* __restrict__ fb_count,
@@ -101,10 +102,11 @@ __global__ __launch_bounds__(256) void rerank_kernel(const T* __restrict__ X, co
     }
     // completeness bound
     double lb = INFINITY;
-    if (cnt >= uint32_t(MP)) {
-        const double thr = double(cand_score(lp[MP - 1]));
+    const float thr_f = thr_final[q];
+    if (thr_f > -INFINITY) {   // -inf: the candidate pass rejected nothing for this query
+        const double thr = double(thr_f) * err.inv_sc2;
         const double y2 = *ymax2p;
-        const double e = err_coef * (0.5 * y2 + sqrt(qnq * y2));
+        const double e = err.rel * (0.5 * y2 + sqrt(qnq * y2)) + err.abs * (sqrt(qnq) + sqrt(y2));
         lb = qnq - 2.0 * (thr + e);
         lb -= 1e-9 * (qnq + y2);   // float64 rounding of the quantities above, with a wide margin
     }
@@ -246,13 +248,13 @@ int rerank_t(gt_ctx* ctx, const RerankArgs& a) {
     const size_t lds = size_t(4) * a.d * sizeof(double);
     if (a.MP == 128) {
         hipLaunchKernelGGL((rerank_kernel<T, 2>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, (const T*)a.X,
-                           a.d, a.xn, (const T*)a.Q, a.qn, a.q0, a.nq, a.lists, a.lstride, a.counts, a.ymax2,
-                           a.err_coef, a.need_m, a.cand_d2, a.cand_j, a.cand_n, a.d2_lb, a.fb_count, a.fb_rows,
+                           a.d, a.xn, (const T*)a.Q, a.qn, a.q0, a.nq, a.lists, a.lstride, a.counts, a.thr_final, a.ymax2,
+                           a.err, a.need_m, a.cand_d2, a.cand_j, a.cand_n, a.d2_lb, a.fb_count, a.fb_rows,
                            a.gflags);
     } else if (a.MP == 512) {
         hipLaunchKernelGGL((rerank_kernel<T, 8>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, (const T*)a.X,
-                           a.d, a.xn, (const T*)a.Q, a.qn, a.q0, a.nq, a.lists, a.lstride, a.counts, a.ymax2,
-                           a.err_coef, a.need_m, a.cand_d2, a.cand_j, a.cand_n, a.d2_lb, a.fb_count, a.fb_rows,
+                           a.d, a.xn, (const T*)a.Q, a.qn, a.q0, a.nq, a.lists, a.lstride, a.counts, a.thr_final, a.ymax2,
+                           a.err, a.need_m, a.cand_d2, a.cand_j, a.cand_n, a.d2_lb, a.fb_count, a.fb_rows,
                            a.gflags);
     } else {
         GT_FAIL(ctx, GT_E_ARG, "rerank: unsupported table width");

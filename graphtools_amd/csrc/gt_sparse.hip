@@ -56,7 +56,7 @@ __device__ __forceinline__ double affinity(double dist, double bw, double decay)
 __global__ __launch_bounds__(256) void bandwidth_kernel(
     const int64_t nloc, const int64_t r0, const int MP, const int kprime, const int dtype, const double* __restrict__ cand_d2,
     const double* __restrict__ d2_lb, const double* __restrict__ xn, const double* __restrict__ ymax2p,
-    const double err_coef, const double* __restrict__ bw_user, const int64_t bw_len, const double bw_scale,
+    const ErrModel err, const double* __restrict__ bw_user, const int64_t bw_len, const double bw_scale,
     const int use_radius, const double radius_factor, double* __restrict__ bw_out, int32_t* __restrict__ rowsrc,
     int32_t* __restrict__ over_rows, uint32_t* __restrict__ over_count, float* __restrict__ rthr) {
     const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
@@ -78,8 +78,8 @@ __global__ __launch_bounds__(256) void bandwidth_kernel(
             src = int32_t(slot);
             const double qn = xn[r0 + i];
             const double y2 = *ymax2p;
-            const double e = err_coef * (0.5 * y2 + sqrt(qn * y2));
-            const double x = 0.5 * (qn - r2) - e - 1e-9 * (qn + y2);
+            const double e = err.rel * (0.5 * y2 + sqrt(qn * y2)) + err.abs * (sqrt(qn) + sqrt(y2));
+            const double x = (0.5 * (qn - r2) - e - 1e-9 * (qn + y2)) / err.inv_sc2;   // scaled score units
             float f = float(x);
             if (double(f) >= x) f = nextafterf(f, -INFINITY);
             rthr[slot] = f;
@@ -736,12 +736,12 @@ extern "C" int gt_graph_begin(gt_ctx* ctx, const gt_knn_params* params, int32_t 
                                    hipMemcpyHostToDevice, ctx->stream));
     }
     g->radius_factor = binary ? 0.0 : std::pow(-1.0 * std::log(thresh), 1.0 / params->decay);   // graphs.py:902-904
-    const double err_coef = 2.0 * double(ctx->DP + 6) * 5.9604644775390625e-08;
+    const ErrModel err_model = gt_err_model(ctx);
     {
         StageSpan span(ctx, "affinity");
         hipLaunchKernelGGL(bandwidth_kernel, dim3((unsigned)ceil_div64(g->nloc, 256)), dim3(256), 0, ctx->stream, g->nloc,
                            g->r0, k->MP, kprime, ctx->dtype, k->cand_d2.as<double>(), k->d2_lb.as<double>(),
-                           ctx->xn.as<double>(), ctx->ymax.as<double>(), err_coef, g->bw_user.as<double>(),
+                           ctx->xn.as<double>(), ctx->ymax.as<double>(), err_model, g->bw_user.as<double>(),
                            params->bandwidth_len, params->bandwidth_scale, use_radius ? 1 : 0, g->radius_factor,
                            g->bw.as<double>(), g->rowsrc.as<int32_t>(), g->over_rows.as<int32_t>(),
                            g->over_count.as<uint32_t>(), g->rthr.as<float>());
@@ -762,6 +762,7 @@ extern "C" int gt_graph_begin(gt_ctx* ctx, const gt_knn_params* params, int32_t 
             GT_HIP(ctx, g->rlists.reserve(size_t(nover_pad) * size_t(cap) * sizeof(uint64_t)));
             SelectArgs sa;
             sa.dp = ctx->DP;
+            sa.prec = ctx->prec;
             sa.mode = 1;
             sa.Yp = ctx->Yp.as<float>();
             sa.hneg = ctx->hneg.as<float>();

@@ -91,6 +91,12 @@ double gt_stage_ms(const gt_ctx* ctx, const char* stage);
 /* number of launches accumulated for `stage` in the most recent call (for roofline: ms / launches) */
 int gt_stage_launches(const gt_ctx* ctx, const char* stage);
 
+/* Options (call before gt_set_points).  "knn_precision": arithmetic of the candidate pass, "f16" (default:
+ * two float16 planes per value on the 2.5 PF f16 MFMA path) or "f32" (float32 MFMA).  Results do not depend
+ * on it - exact ordering and values always come from the float64 stage - only speed and how often rows take
+ * the exhaustive fallback.  The environment variable GT_KNN_PRECISION sets the default. */
+int gt_set_option(gt_ctx* ctx, const char* name, const char* value);
+
 /* ---- points ------------------------------------------------------------------------------ */
 /* Bind the data matrix (n x d).  Replaces NearestNeighbors(...).fit(data_nu) (graphs.py:763-768):
  * builds the padded float32 working copy, float64 row norms and -|y|^2/2 terms on the device.

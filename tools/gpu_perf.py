@@ -42,11 +42,16 @@ def run(ctx, n, d, seed, reps=2, **kw):
 
 if __name__ == "__main__":
     sizes = [int(s) for s in sys.argv[1:]] or [100000, 1000000]
-    ctx = _hip.Context(0)
     reps = []
-    for n in sizes:
-        d = 50 if n == 100000 else 64
-        reps.append(run(ctx, n, d, 0 if n == 100000 else 1))
+    for prec in ("f16", "f32"):
+        ctx = _hip.Context(0)
+        ctx.set_option("knn_precision", prec)
+        for n in sizes:
+            d = 50 if n == 100000 else 64
+            r = run(ctx, n, d, 0 if n == 100000 else 1)
+            r["precision"] = prec
+            reps.append(r)
+        ctx.close()
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "gpu_perf.json"), "w") as f:
         json.dump(reps, f, indent=1)
