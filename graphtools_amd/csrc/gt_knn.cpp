@@ -92,6 +92,7 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
         StageSpan span(ctx, "knn_select");
         GT_TRY(gt_launch_select(ctx, sa));
     }
+    if (ctx->dbg_select & 4) return GT_OK;   // experiment: candidate pass only (tables are NOT valid)
     RerankArgs ra;
     ra.X = ctx->X;
     ra.dtype = ctx->dtype;

@@ -18,8 +18,8 @@
 // the row to an exhaustive fallback.
 //
 // MODE 0 (top-M' selection): survivors (s > thr) are appended to the query's candidate list in global
-//   memory (slot from an LDS counter; the wave owns its queries, so no cross-wave traffic).  When a list
-//   passes its trigger level the owning wave selects the best M' = 16*NT of its 64*NT keys (bitwise search for
+//   memory (each half-wave owns one half of the list and keeps its fill count in a register: no atomics, no
+//   cross-wave traffic).  When a half passes its trigger level the owning wave selects the best M' = 16*NT of its 64*NT keys (bitwise search for
 //   the M'-th largest score with wave ballots, then an order-free filter) and raises thr to the M'-th score.
 //   At the end list[0..count) holds the candidates (unordered) and thr_out the last admission threshold.
 // MODE 1 (radius collect): thr is a fixed per-query score bound; every survivor is appended (up to `cap`
@@ -30,6 +30,10 @@
 #include "gt_common.h"
 #include "gt_device.h"
 #include "gt_knn_select.h"
+
+#ifndef GT_SEL_SETPRIO
+#define GT_SEL_SETPRIO 1
+#endif
 
 namespace {
 
@@ -45,7 +49,7 @@ struct SelCfg {
     static constexpr int F4_PER_THREAD = (NF4 + 255) / 256;
     static constexpr int TILE_FLOATS = BN * LDP;
     static constexpr size_t LDS_BYTES =
-        size_t(2) * TILE_FLOATS * 4 + size_t(2) * BN * 4 + size_t(BQ) * 4 * 2;
+        size_t(2) * TILE_FLOATS * 4 + size_t(2) * BN * 4;
 };
 
 // ---- operand fragments -------------------------------------------------------------------------
@@ -86,85 +90,84 @@ struct Frag<DP, 1> {
     }
 };
 
-template <int DP, int QT>
-__device__ __forceinline__ void mma_block(const Frag<DP, 0>& a, const Frag<DP, 0> (&b)[QT], f32x16 (&acc)[QT]) {
+// one query tile's K chain (the two query tiles of a wave are issued back to back so that the epilogue of the
+// first can overlap the matrix work of the second)
+template <int DP>
+__device__ __forceinline__ void mma_chain(const Frag<DP, 0>& a, const Frag<DP, 0>& b, f32x16& acc) {
 #pragma unroll
-    for (int s = 0; s < DP / 2; ++s) {
-#pragma unroll
-        for (int qt = 0; qt < QT; ++qt)
-            acc[qt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[s], b[qt].v[s], acc[qt], 0, 0, 0);
-    }
+    for (int s = 0; s < DP / 2; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[s], b.v[s], acc, 0, 0, 0);
 }
 
-template <int DP, int QT>
-__device__ __forceinline__ void mma_block(const Frag<DP, 1>& a, const Frag<DP, 1> (&b)[QT], f32x16 (&acc)[QT]) {
+template <int DP>
+__device__ __forceinline__ void mma_chain(const Frag<DP, 1>& a, const Frag<DP, 1>& b, f32x16& acc) {
     // small cross terms first, the dominant hi.hi chain last
 #pragma unroll
-    for (int s = 0; s < DP / 16; ++s) {
+    for (int s = 0; s < DP / 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.lo[s], b.hi[s], acc, 0, 0, 0);
 #pragma unroll
-        for (int qt = 0; qt < QT; ++qt)
-            acc[qt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.lo[s], b[qt].hi[s], acc[qt], 0, 0, 0);
-    }
+    for (int s = 0; s < DP / 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.hi[s], b.lo[s], acc, 0, 0, 0);
 #pragma unroll
-    for (int s = 0; s < DP / 16; ++s) {
-#pragma unroll
-        for (int qt = 0; qt < QT; ++qt)
-            acc[qt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.hi[s], b[qt].lo[s], acc[qt], 0, 0, 0);
-    }
-#pragma unroll
-    for (int s = 0; s < DP / 16; ++s) {
-#pragma unroll
-        for (int qt = 0; qt < QT; ++qt)
-            acc[qt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.hi[s], b[qt].hi[s], acc[qt], 0, 0, 0);
-    }
+    for (int s = 0; s < DP / 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.hi[s], b.hi[s], acc, 0, 0, 0);
 }
 
-// ---- candidate-list compaction: keep the MKEEP best scores of a list of n <= 64*NT keys ---------------
-// The list does not have to be ordered while streaming (the float64 re-rank sorts the final table), so this
-// is a selection, not a sort: a 32-step bitwise search for the MKEEP-th largest score (wave ballots + scalar
+// ---- candidate-list compaction ----------------------------------------------------------------------
+// A query's list has two halves of HALF = 32*NT slots, one per half-wave (lanes li and li+32 see disjoint
+// database rows of every tile), each with its own fill count kept in a REGISTER of the owning lane - the hot
+// path needs no atomics.  Compaction keeps the MKEEP = 16*NT best scores of both halves together.  The list
+// does not have to be ordered while streaming (the float64 re-rank sorts the final table), so this is a
+// selection, not a sort: a 32-step bitwise search for the MKEEP-th largest score (wave ballots + scalar
 // popcounts, no cross-lane shuffles), then an order-free filter.  Entries tied with the threshold are kept
 // only up to the quota; dropping the rest is consistent with the strict `score > thr` admission test.
-// Returns the new threshold (the MKEEP-th largest score) and the new count via `new_n`.
-template <int NT>
-__device__ __forceinline__ float compact_list(uint64_t* __restrict__ lp, const uint32_t n, const int lane,
-                                              uint32_t& new_n) {
+// CONTIG: survivors go to slots [0, kept) (final table); else they are dealt evenly to the two halves.
+// Returns the threshold implied by the selection (-inf when nothing had to be dropped).
+template <int NT, bool CONTIG>
+__device__ __forceinline__ float compact_list(uint64_t* __restrict__ lp, const uint32_t n0, const uint32_t n1,
+                                              const int lane, uint32_t& kept) {
     constexpr uint32_t MKEEP = 16 * NT;
+    constexpr uint32_t HALF = 32 * NT;
     uint64_t key[NT];
     uint32_t ord[NT];
 #pragma unroll
     for (int u = 0; u < NT; ++u) {
-        const uint32_t e = uint32_t(u * 64 + lane);
-        key[u] = e < n ? ld_agent_u64(lp + e) : 0ull;
-        ord[u] = uint32_t(key[u] >> 32);
+        const bool second = u >= NT / 2;
+        const uint32_t e = uint32_t((second ? u - NT / 2 : u) * 64 + lane);
+        const bool valid = e < (second ? n1 : n0);
+        key[u] = valid ? ld_agent_u64(lp + (second ? HALF : 0u) + e) : 0ull;
+        ord[u] = uint32_t(key[u] >> 32);   // a valid key has ord > 0 (ord(-inf) = 0x007fffff)
     }
-    uint32_t T = 0u;
+    const uint32_t n = n0 + n1;
+    uint32_t T = 0u, c_gt = n, quota_eq = 0u;
+    if (n > MKEEP) {
 #pragma unroll 1
-    for (int b = 31; b >= 0; --b) {
-        const uint32_t trial = T | (1u << b);
-        uint32_t c = 0;
+        for (int b = 31; b >= 0; --b) {
+            const uint32_t trial = T | (1u << b);
+            uint32_t c = 0;
 #pragma unroll
-        for (int u = 0; u < NT; ++u) c += uint32_t(__popcll(__ballot(ord[u] >= trial)));
-        if (c >= MKEEP) T = trial;
+            for (int u = 0; u < NT; ++u) c += uint32_t(__popcll(__ballot(ord[u] >= trial)));
+            if (c >= MKEEP) T = trial;
+        }
+        c_gt = 0;
+#pragma unroll
+        for (int u = 0; u < NT; ++u) c_gt += uint32_t(__popcll(__ballot(ord[u] > T)));
+        quota_eq = MKEEP - c_gt;
     }
-    uint32_t c_gt = 0;
-#pragma unroll
-    for (int u = 0; u < NT; ++u) c_gt += uint32_t(__popcll(__ballot(ord[u] > T)));
-    const uint32_t quota_eq = MKEEP - c_gt;
+    kept = n > MKEEP ? MKEEP : n;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     uint32_t base_gt = 0, base_eq = 0;
 #pragma unroll
     for (int u = 0; u < NT; ++u) {
         const bool gt = ord[u] > T;
-        const bool eq = ord[u] == T;
+        const bool eq = (ord[u] == T) && (T != 0u);
         const unsigned long long mg = __ballot(gt), me = __ballot(eq);
-        if (gt) st_agent_u64(lp + base_gt + uint32_t(__popcll(mg & lt_mask)), key[u]);
-        const uint32_t pe = base_eq + uint32_t(__popcll(me & lt_mask));
-        if (eq && pe < quota_eq) st_agent_u64(lp + c_gt + pe, key[u]);
+        const uint32_t kg = base_gt + uint32_t(__popcll(mg & lt_mask));
+        const uint32_t ke = base_eq + uint32_t(__popcll(me & lt_mask));
+        const bool take = gt || (eq && ke < quota_eq);
+        const uint32_t k = gt ? kg : c_gt + ke;
+        const uint32_t slot = CONTIG ? k : ((k < MKEEP / 2) ? k : HALF + (k - MKEEP / 2));
+        if (take) st_agent_u64(lp + slot, key[u]);
         base_gt += uint32_t(__popcll(mg));
         base_eq += uint32_t(__popcll(me));
     }
-    new_n = MKEEP;
-    return ord_f32(T);
+    return n > MKEEP ? ord_f32(T) : -INFINITY;
 }
 
 template <int DP, int NT, int MODE, int PREC>
@@ -175,16 +178,15 @@ __global__ __launch_bounds__(256, 2) void knn_select_kernel(
     float* __restrict__ thr_out, const int32_t cap, const int32_t dbg) {
     using C = SelCfg<DP>;
     constexpr int QT = C::QT, BQ = C::BQ, BN = C::BN, LDP = C::LDP;
-    constexpr int LCAP = 64 * NT;        // list capacity in selection mode
+    constexpr int LCAP = 64 * NT;        // list capacity in selection mode (two halves of HALF slots)
+    constexpr int HALF = 32 * NT;
     constexpr int MKEEP = 16 * NT;       // M'
-    constexpr int TRIG = LCAP - BN;      // compaction trigger (a tile can add at most BN entries per query)
-    static_assert(TRIG >= MKEEP, "list too small for the tile");
+    constexpr int TRIGH = HALF - BN / 2; // per-half trigger: a tile adds at most BN/2 entries to one half
+    static_assert(TRIGH >= MKEEP / 2, "list too small for the tile");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* tile = reinterpret_cast<float*>(smem_raw);                    // [2][BN][LDP]
     float* hn = tile + 2 * C::TILE_FLOATS;                               // [2][BN]
-    uint32_t* cnt = reinterpret_cast<uint32_t*>(hn + 2 * BN);            // [BQ]
-    float* thr_lds = reinterpret_cast<float*>(cnt + BQ);                 // [BQ]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -205,18 +207,16 @@ __global__ __launch_bounds__(256, 2) void knn_select_kernel(
     // ---- query fragments (B operand), resident for the whole kernel ----
     Frag<DP, PREC> bq[QT];
     float thr[QT];
+    uint32_t fill[QT];   // MODE 0: entries in this lane's half of the query's list
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
+        fill[qt] = 0u;
         const int ql = (w * QT + qt) * 32 + li;
         const int64_t qg = qblock + ql;
         const int64_t qc = qg < nq ? qg : int64_t(nq) - 1;   // clamp pad queries onto a real row
         const int64_t row = qrows ? int64_t(qrows[qc]) : q0 + qc;
         bq[qt].load(Qp + row * DP, h);
         thr[qt] = (MODE == 0) ? ((dbg & 1) ? INFINITY : -INFINITY) : ((qg < nq) ? thr_in[qc] : INFINITY);
-    }
-    if (tid < BQ) {
-        cnt[tid] = 0u;
-        thr_lds[tid] = -INFINITY;
     }
 
     // ---- tile staging (global -> registers -> LDS, padded rows) ----
@@ -256,11 +256,14 @@ __global__ __launch_bounds__(256, 2) void knn_select_kernel(
         const float* hb = hn + buf * BN;
         const uint32_t tbase = uint32_t(t) * BN;
 
-#pragma unroll 1
+        // A fragments are prefetched one sub-tile ahead (ping-pong registers) so the LDS latency hides under the
+        // matrix work; the loop is fully unrolled to keep the ping-pong index static.
+        Frag<DP, PREC> afr[2];
+        afr[0].load(tb + li * LDP, h);
+#pragma unroll
         for (int sb = 0; sb < BN / 32; ++sb) {
-            // A fragment: database row sb*32 + li
-            Frag<DP, PREC> a;
-            a.load(tb + (sb * 32 + li) * LDP, h);
+            if (sb + 1 < BN / 32) afr[(sb + 1) & 1].load(tb + ((sb + 1) * 32 + li) * LDP, h);
+            const Frag<DP, PREC>& a = afr[sb & 1];
             // accumulator init: acc[4g+e] <-> database row 8g + 4h + e  => -|y|^2/2 of that row
             f32x16 acc[QT];
 #pragma unroll
@@ -274,27 +277,48 @@ __global__ __launch_bounds__(256, 2) void knn_select_kernel(
                     acc[qt][4 * g + 3] = hv.w;
                 }
             }
-            mma_block<DP, QT>(a, bq, acc);
-            // ---- epilogue: one query per lane, 16 database rows in registers ----
+#if GT_SEL_SETPRIO
+            __builtin_amdgcn_s_setprio(1);   // let this wave's matrix burst win the pipe over its co-resident wave
+#endif
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) mma_chain<DP>(a, bq[qt], acc[qt]);
+#if GT_SEL_SETPRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
+            // ---- epilogue: one query per lane, 16 database rows in registers (4 groups of 4) ----
+            // predicates come from plain compares (no fmax: it would canonicalise every MFMA output); the
+            // admission path is entered wave-uniformly, per group, and issues its LDS slot atomics back to back
+            // before any of the stores that consume them
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt) {
-                float m = acc[qt][0];
+                const float tq = thr[qt];
+                bool hg[4];
 #pragma unroll
-                for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[qt][r]);
-                if (m > thr[qt]) {
+                for (int g = 0; g < 4; ++g)
+                    hg[g] = (acc[qt][4 * g] > tq) | (acc[qt][4 * g + 1] > tq) | (acc[qt][4 * g + 2] > tq) |
+                            (acc[qt][4 * g + 3] > tq);
+                if (__ballot(hg[0] | hg[1] | hg[2] | hg[3])) {   // wave-uniform: most sub-tiles admit nothing
                     const int ql = (w * QT + qt) * 32 + li;
-                    uint64_t* lp = lists + size_t(qblock + ql) * lstride;
+                    uint64_t* lp = lists + size_t(qblock + ql) * lstride + (MODE == 0 ? size_t(h) * HALF : size_t(0));
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float v = acc[qt][r];
-                        if (v > thr[qt]) {
-                            const uint32_t j = tbase + uint32_t(sb * 32 + 8 * (r >> 2) + 4 * h + (r & 3));
-                            if (MODE == 0) {
-                                const uint32_t slot = atomicAdd(&cnt[ql], 1u);
-                                st_agent_u64(lp + slot, cand_pack(v, j));
-                            } else {
-                                const uint32_t slot = atomicAdd(&counts[qblock + ql], 1u);
-                                if (slot < uint32_t(cap)) st_agent_u64(lp + slot, cand_pack(v, j));
+                    for (int g = 0; g < 4; ++g) {
+                        if (__ballot(hg[g])) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float v = acc[qt][4 * g + e];
+                                if (v > tq) {
+                                    const uint32_t j = tbase + uint32_t(sb * 32 + 8 * g + 4 * h + e);
+                                    if (MODE == 0) {
+                                        // plain store: it only has to reach this XCD's L2 (compaction re-reads with
+                                        // L2-scope loads from the same CU; the next kernel sees it after the
+                                        // end-of-kernel release)
+                                        if (!(dbg & 8)) lp[fill[qt]] = cand_pack(v, j);
+                                        fill[qt] += 1u;
+                                    } else {
+                                        const uint32_t slot = atomicAdd(&counts[qblock + ql], 1u);
+                                        if (slot < uint32_t(cap)) lp[slot] = cand_pack(v, j);
+                                    }
+                                }
                             }
                         }
                     }
@@ -303,31 +327,33 @@ __global__ __launch_bounds__(256, 2) void knn_select_kernel(
         }
 
         if (MODE == 0) {
-            // ---- list maintenance: lane L <-> query w*QT*32 + L of this wave ----
-            const uint32_t c = (lane < QT * 32) ? cnt[w * QT * 32 + lane] : 0u;
-            unsigned long long need = __ballot(c > uint32_t(TRIG));
-            if ((dbg & 2) && need) {   // experiment: no selection, just pretend the list was compacted
-                if (c > uint32_t(TRIG)) cnt[w * QT * 32 + lane] = uint32_t(MKEEP);
-                need = 0;
-            }
-            if (need) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's list stores have reached L2
-                while (need) {
-                    const int L = __ffsll((long long)need) - 1;
-                    need &= need - 1;
-                    const int ql = w * QT * 32 + L;
-                    const uint32_t n = cnt[ql];
-                    uint64_t* lp = lists + size_t(qblock + ql) * lstride;
-                    uint32_t new_n;
-                    const float t = compact_list<NT>(lp, n, lane, new_n);
-                    if (lane == 0) {
-                        cnt[ql] = new_n;
-                        thr_lds[ql] = t;
-                    }
-                }
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            // ---- list maintenance: lane (li, h) owns half h of query (qt, li) ----
 #pragma unroll
-                for (int qt = 0; qt < QT; ++qt) thr[qt] = thr_lds[(w * QT + qt) * 32 + li];
+            for (int qt = 0; qt < QT; ++qt) {
+                const unsigned long long full = __ballot(fill[qt] > uint32_t(TRIGH));
+                uint32_t need = uint32_t(full) | uint32_t(full >> 32);
+                if ((dbg & 18) && need) {   // experiment: no selection, just pretend the lists were compacted
+                    if (need & (1u << li)) fill[qt] = uint32_t(MKEEP / 2);
+                    need = 0;
+                }
+                if (need) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's list stores have reached L2
+                    while (need) {
+                        const int L = __ffs(int(need)) - 1;
+                        need &= need - 1;
+                        const uint32_t n0 = __shfl(fill[qt], L);
+                        const uint32_t n1 = __shfl(fill[qt], L + 32);
+                        uint64_t* lp = lists + size_t(qblock + (w * QT + qt) * 32 + L) * lstride;
+                        uint32_t kept;
+                        const float t = compact_list<NT, false>(lp, n0, n1, lane, kept);
+                        if (li == L) {
+                            const uint32_t k0 = kept < uint32_t(MKEEP / 2) ? kept : uint32_t(MKEEP / 2);
+                            fill[qt] = h ? kept - k0 : k0;
+                            thr[qt] = fmaxf(thr[qt], t);
+                        }
+                    }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
             }
         }
 
@@ -335,21 +361,25 @@ __global__ __launch_bounds__(256, 2) void knn_select_kernel(
         __syncthreads();
     }
 
-    // ---- finalisation: trim every list to MKEEP entries, publish count and the last admission threshold ----
+    // ---- finalisation: gather every list into slots [0, count), publish count and the last admission threshold ----
     if (MODE == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
 #pragma unroll 1
-        for (int L = 0; L < QT * 32; ++L) {
-            const int ql = w * QT * 32 + L;
-            uint32_t n = cnt[ql];
-            float t = thr_lds[ql];
-            if (n > uint32_t(MKEEP)) {
+            for (int L = 0; L < 32; ++L) {
+                const uint32_t n0 = __shfl(fill[qt], L);
+                const uint32_t n1 = __shfl(fill[qt], L + 32);
+                const float t_prev = __shfl(thr[qt], L);
+                const int ql = (w * QT + qt) * 32 + L;
                 uint64_t* lp = lists + size_t(qblock + ql) * lstride;
-                t = compact_list<NT>(lp, n, lane, n);
-            }
-            if (lane == 0) {
-                counts[qblock + ql] = n;
-                thr_out[qblock + ql] = t;   // every rejected database row scored <= t (-inf: nothing was rejected)
+                uint32_t kept;
+                const float t = compact_list<NT, true>(lp, n0, n1, lane, kept);
+                if (lane == 0) {
+                    counts[qblock + ql] = kept;
+                    // every rejected database row scored <= thr_out (-inf: nothing was ever rejected)
+                    thr_out[qblock + ql] = (dbg & 1) ? -INFINITY : fmaxf(t_prev, t);
+                }
             }
         }
     }
