@@ -46,6 +46,20 @@ def make_mix(n, d, seed, dtype=np.float32):
     return out
 
 
+def measured_traffic(n, d, precision, world):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE doubled per
+    MI355X_MICROARCH.md + WRITE_SIZE, profiles/r1_pmc_fetch_write_per_kernel.json).  PMC counters cannot be read
+    from inside this process, so the number is only reported for the exact workload that was profiled."""
+    if not (n == 1000000 and d == 64 and precision == "f16" and world == 1):
+        return None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r1_pmc_fetch_write_per_kernel.json")) as f:
+            k = json.load(f)["kernels"]["knn_select_kernel<64, 8, 0, 1>"]
+        return (k["hbm_read_GB_per_launch_corrected_x2"] + k["hbm_write_GB_per_launch"]) * 1e9
+    except Exception:
+        return None
+
+
 def cpu_baseline(X, knn, decay, thresh, ctx, params_factory, budget_s=25.0):
     """Oracle port (numpy/scipy + the reference's scikit-learn call sites) on this host's cores.
 
@@ -103,8 +117,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=1000000)
-    ap.add_argument("--d", type=int, default=64)
+    ap.add_argument("--npoints", type=int, default=1000000)
+    ap.add_argument("--dim", type=int, default=64)
     ap.add_argument("--knn", type=int, default=15)
     ap.add_argument("--decay", type=float, default=40.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -120,7 +134,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
+    # GT_BENCH_FORCE_DIST=1 exercises the RCCL path with a single rank (development aid)
+    distributed = world > 1 or os.environ.get("GT_BENCH_FORCE_DIST") == "1"
     if args.gpus != world:
         if rank == 0 and world > 1:
             print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
@@ -130,7 +145,7 @@ def main():
         import torch.distributed as dist
 
         dist.init_process_group("nccl")
-    n, d = args.n, args.d
+    n, d = args.npoints, args.dim
     thresh = 1e-4
     X = make_mix(n, d, 1)
     ctx = _hip.Context(local_rank)
@@ -208,7 +223,8 @@ def main():
                        "radius_rows_rank0": stats["radius_rows"], "fallback_rows_rank0": stats["fallback_rows"]},
             "roofline": {"kernel": "knn_select_kernel (%s MFMA candidate pass)" % args.knn_precision, "bound": "mfma",
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "traffic": None, "avg_launch_ms": avg_ms, "algorithmic_flop_per_launch": flops,
+                         "traffic": measured_traffic(n, d, args.knn_precision, world), "traffic_unit": "bytes/launch",
+                         "avg_launch_ms": avg_ms, "algorithmic_flop_per_launch": flops,
                          "executed_mfma_flop_per_launch": executed,
                          "executed_mfma_frac": executed / (avg_ms * 1e-3) / 1e12 / peak},
             "stage_ms_last_step": {s: round(ctx.stage_ms(s), 3) for s in

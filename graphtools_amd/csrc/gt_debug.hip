@@ -147,3 +147,10 @@ extern "C" int gt_dbg_fetch_cand(gt_ctx* ctx, int64_t nq, double* d2_host, uint3
     GT_HIP(ctx, hipMemcpy(lb_host, k->d2_lb.p, size_t(nq) * 8, hipMemcpyDeviceToHost));
     return GT_OK;
 }
+
+extern "C" int gt_dbg_fetch_prof(gt_ctx* ctx, int64_t nwaves, unsigned long long* out_host) {
+    if (!ctx || !ctx->knn || !ctx->knn->prof.p) return GT_E_STATE;
+    GT_HIP(ctx, hipSetDevice(ctx->device));
+    GT_HIP(ctx, hipMemcpy(out_host, ctx->knn->prof.p, size_t(nwaves) * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return GT_OK;
+}

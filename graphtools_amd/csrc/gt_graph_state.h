@@ -29,7 +29,7 @@ struct GraphState {
     int32_t rcap = 0;
     int64_t radius_retries = 0;
     // exchange
-    DevBuf sendcnt, sendcur, selfbuf, splits_dev;
+    DevBuf ownercnt, ownerpos, scan_tmp, selfbuf, splits_dev;
     std::vector<int64_t> send_counts_host;
     // merge
     DevBuf Ukey, Uval, Vkey, Vval, bigrows, bigcount, bigscratch_k, bigscratch_v;

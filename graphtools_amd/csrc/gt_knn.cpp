@@ -11,7 +11,7 @@ void gt_free_knn_work(gt_ctx* ctx) {
     if (!ctx->knn) return;
     KnnWork* k = ctx->knn;
     for (DevBuf* b : {&k->Qraw, &k->Qp, &k->qn, &k->lists, &k->counts, &k->thr_final, &k->cand_d2, &k->cand_j, &k->cand_n,
-                      &k->d2_lb, &k->fb_rows, &k->fb_count, &k->fb_scratch, &k->gflags})
+                      &k->d2_lb, &k->fb_rows, &k->fb_count, &k->fb_scratch, &k->gflags, &k->prof})
         b->release();
     delete k;
     ctx->knn = nullptr;
@@ -88,6 +88,11 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
     sa.counts = k->counts.as<uint32_t>();
     sa.thr_out = k->thr_final.as<float>();
     sa.dbg = ctx->dbg_select;
+    if (ctx->dbg_select & 64) {
+        GT_HIP(ctx, k->prof.reserve(size_t(k->nq_pad / bq) * 4 * 8 * sizeof(unsigned long long)));
+        GT_HIP(ctx, hipMemsetAsync(k->prof.p, 0, size_t(k->nq_pad / bq) * 4 * 8 * sizeof(unsigned long long), ctx->stream));
+        sa.prof = k->prof.as<unsigned long long>();
+    }
     {
         StageSpan span(ctx, "knn_select");
         GT_TRY(gt_launch_select(ctx, sa));

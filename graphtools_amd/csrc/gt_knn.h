@@ -19,7 +19,7 @@ struct KnnWork {
     DevBuf Qraw, Qp, qn;
     DevBuf lists, counts, thr_final;
     DevBuf cand_d2, cand_j, cand_n, d2_lb;
-    DevBuf fb_rows, fb_count, fb_scratch, gflags;
+    DevBuf fb_rows, fb_count, fb_scratch, gflags, prof;
     int64_t n_fallback = 0;
 };
 

@@ -19,6 +19,7 @@ struct SelectArgs {
     const float* thr_in = nullptr;  // radius mode: per-query score threshold [nq]
     float* thr_out = nullptr;       // selection mode: final admission threshold per query [nq_pad]
     int32_t cap = 0;                // radius mode: list capacity per query
+    unsigned long long* prof = nullptr;   // optional per-wave cycle counters [nblocks*4][8] (development)
     int32_t dbg = 0;                // experiment switches (bit 0: no survivors, bit 1: no compaction sort)
 };
 

@@ -32,7 +32,7 @@
 #include "gt_knn_select.h"
 
 #ifndef GT_SEL_SETPRIO
-#define GT_SEL_SETPRIO 1
+#define GT_SEL_SETPRIO 0
 #endif
 
 namespace {
@@ -109,6 +109,15 @@ __device__ __forceinline__ void mma_chain(const Frag<DP, 1>& a, const Frag<DP, 1
     for (int s = 0; s < DP / 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.hi[s], b.hi[s], acc, 0, 0, 0);
 }
 
+// Append store that hipcc does not track: a compiler-visible store makes hipcc park the wave on
+// `s_waitcnt vmcnt(0)` at the top of every tile (it guards the reuse of the store's registers), i.e. on the full
+// L2 write-acknowledge latency.  The data registers are protected by the s_nop inside the string; the untracked
+// entries in the VMEM queue can only make hipcc's own counted waits stricter (cdna_hip_programming.md 5.7);
+// readers of the list wait with an explicit `s_waitcnt vmcnt(0)` first.
+__device__ __forceinline__ void list_store(uint64_t* p, uint64_t v) {
+    asm volatile("global_store_dwordx2 %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+
 // ---- candidate-list compaction ----------------------------------------------------------------------
 // A query's list has two halves of HALF = 32*NT slots, one per half-wave (lanes li and li+32 see disjoint
 // database rows of every tile), each with its own fill count kept in a REGISTER of the owning lane - the hot
@@ -175,8 +184,9 @@ __global__ __launch_bounds__(256, 2) void knn_select_kernel(
     const float* __restrict__ Yp, const float* __restrict__ hneg, const float* __restrict__ Qp,
     const int32_t* __restrict__ qrows, const int64_t q0, const int32_t nq, const int32_t ntiles,
     uint64_t* __restrict__ lists, uint32_t* __restrict__ counts, const float* __restrict__ thr_in,
-    float* __restrict__ thr_out, const int32_t cap, const int32_t dbg) {
+    float* __restrict__ thr_out, const int32_t cap, const int32_t dbg, unsigned long long* __restrict__ prof) {
     using C = SelCfg<DP>;
+    unsigned long long t_adm = 0, t_cmp = 0, t_bar = 0, n_cmp = 0, n_adm = 0;
     constexpr int QT = C::QT, BQ = C::BQ, BN = C::BN, LDP = C::LDP;
     constexpr int LCAP = 64 * NT;        // list capacity in selection mode (two halves of HALF slots)
     constexpr int HALF = 32 * NT;
@@ -298,6 +308,7 @@ __global__ __launch_bounds__(256, 2) void knn_select_kernel(
                     hg[g] = (acc[qt][4 * g] > tq) | (acc[qt][4 * g + 1] > tq) | (acc[qt][4 * g + 2] > tq) |
                             (acc[qt][4 * g + 3] > tq);
                 if (__ballot(hg[0] | hg[1] | hg[2] | hg[3])) {   // wave-uniform: most sub-tiles admit nothing
+                    const unsigned long long ts_ = prof ? __builtin_readcyclecounter() : 0ull;
                     const int ql = (w * QT + qt) * 32 + li;
                     uint64_t* lp = lists + size_t(qblock + ql) * lstride + (MODE == 0 ? size_t(h) * HALF : size_t(0));
 #pragma unroll
@@ -312,7 +323,7 @@ __global__ __launch_bounds__(256, 2) void knn_select_kernel(
                                         // plain store: it only has to reach this XCD's L2 (compaction re-reads with
                                         // L2-scope loads from the same CU; the next kernel sees it after the
                                         // end-of-kernel release)
-                                        if (!(dbg & 8)) lp[fill[qt]] = cand_pack(v, j);
+                                        list_store(lp + fill[qt], cand_pack(v, j));
                                         fill[qt] += 1u;
                                     } else {
                                         const uint32_t slot = atomicAdd(&counts[qblock + ql], 1u);
@@ -322,6 +333,7 @@ __global__ __launch_bounds__(256, 2) void knn_select_kernel(
                             }
                         }
                     }
+                    if (prof) { t_adm += __builtin_readcyclecounter() - ts_; n_adm += 1; }
                 }
             }
         }
@@ -337,8 +349,10 @@ __global__ __launch_bounds__(256, 2) void knn_select_kernel(
                     need = 0;
                 }
                 if (need) {
+                    const unsigned long long ts_ = prof ? __builtin_readcyclecounter() : 0ull;
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's list stores have reached L2
                     while (need) {
+                        n_cmp += 1;
                         const int L = __ffs(int(need)) - 1;
                         need &= need - 1;
                         const uint32_t n0 = __shfl(fill[qt], L);
@@ -353,12 +367,21 @@ __global__ __launch_bounds__(256, 2) void knn_select_kernel(
                         }
                     }
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (prof) t_cmp += __builtin_readcyclecounter() - ts_;
                 }
             }
         }
 
         if (t + 1 < t_end) GT_STAGE_STORE(buf ^ 1);
-        __syncthreads();
+        {
+            const unsigned long long ts_ = prof ? __builtin_readcyclecounter() : 0ull;
+            __syncthreads();
+            if (prof) t_bar += __builtin_readcyclecounter() - ts_;
+        }
+    }
+    if (prof && lane == 0) {
+        unsigned long long* o = prof + (size_t(blockIdx.x) * 4 + w) * 8;
+        o[0] = t_adm; o[1] = t_cmp; o[2] = t_bar; o[3] = n_cmp; o[4] = n_adm;
     }
 
     // ---- finalisation: gather every list into slots [0, count), publish count and the last admission threshold ----
@@ -401,7 +424,7 @@ int launch_one(gt_ctx* ctx, const SelectArgs& a) {
     GT_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     int(C::LDS_BYTES)));
     hipLaunchKernelGGL(kern, dim3((unsigned)nblocks, (unsigned)nsplit), dim3(256), C::LDS_BYTES, ctx->stream, a.Yp,
-                       a.hneg, a.Qp, a.qrows, a.q0, a.nq, ntiles, a.lists, a.counts, a.thr_in, a.thr_out, a.cap, a.dbg);
+                       a.hneg, a.Qp, a.qrows, a.q0, a.nq, ntiles, a.lists, a.counts, a.thr_in, a.thr_out, a.cap, a.dbg, a.prof);
     GT_HIP(ctx, hipGetLastError());
     return GT_OK;
 }

@@ -20,7 +20,7 @@ void gt_free_graph_state(gt_ctx* ctx) {
     GraphState* g = ctx->graph;
     for (DevBuf* b : {&g->bw, &g->bw_user, &g->rowsrc, &g->lenN, &g->lenT, &g->cursor, &g->off, &g->outlen, &g->indptr,
                       &g->degree, &g->over_rows, &g->over_count, &g->rthr, &g->rlists, &g->rcounts, &g->rK, &g->rmax,
-                      &g->sendcnt, &g->sendcur, &g->selfbuf, &g->splits_dev, &g->Ukey, &g->Uval, &g->Vkey, &g->Vval,
+                      &g->ownercnt, &g->ownerpos, &g->scan_tmp, &g->selfbuf, &g->splits_dev, &g->Ukey, &g->Uval, &g->Vkey, &g->Vval,
                       &g->bigrows, &g->bigcount, &g->bigscratch_k, &g->bigscratch_v, &g->indices, &g->Kdata, &g->Pdata,
                       &g->flags})
         b->release();
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void affinity_kernel(
     const uint32_t* __restrict__ cand_n, const int32_t* __restrict__ rowsrc, const uint64_t* __restrict__ rlists,
     const uint32_t* __restrict__ rcounts, const int32_t rcap, double* __restrict__ rK, const double* __restrict__ bw,
     const double decay, const int binary, const double thresh, const int count_owners, const Splits sp,
-    int32_t* __restrict__ lenN, unsigned long long* __restrict__ sendcnt) {
+    int32_t* __restrict__ lenN, int32_t* __restrict__ ownercnt) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int lane = threadIdx.x & 63;
     const int w = threadIdx.x >> 6;
@@ -180,19 +180,15 @@ __global__ __launch_bounds__(256) void affinity_kernel(
         }
     }
     if (lane == 0) lenN[i] = kept;
-    if (count_owners && lane < sp.world && owner_cnt > 0) atomicAdd(&sendcnt[lane], (unsigned long long)owner_cnt);
+    if (count_owners && lane < sp.world) ownercnt[int64_t(lane) * nloc + i] = owner_cnt;   // owner-major layout
 }
 
 // ---- A2t: transposed triplets, bucketed by destination rank --------------------------------------
-struct Buckets {
-    int64_t base[kMaxWorld];
-};
-
 __global__ __launch_bounds__(256) void emit_triplets_kernel(
     const int64_t nloc, const int64_t r0, const int MP, const double* __restrict__ cand_k,
     const uint32_t* __restrict__ cand_j, const int32_t* __restrict__ rowsrc, const uint64_t* __restrict__ rlists,
     const uint32_t* __restrict__ rcounts, const int32_t rcap, const double* __restrict__ rK, const Splits sp,
-    const Buckets bk, unsigned long long* __restrict__ sendcur, Triplet* __restrict__ out) {
+    const int64_t* __restrict__ ownerpos, Triplet* __restrict__ out) {
     const int lane = threadIdx.x & 63;
     const int w = threadIdx.x >> 6;
     const int64_t i = int64_t(blockIdx.x) * 4 + w;
@@ -208,6 +204,9 @@ __global__ __launch_bounds__(256) void emit_triplets_kernel(
         if (n > uint32_t(rcap)) n = uint32_t(rcap);
         kv = rK + size_t(src) * rcap;
     }
+    // lane r tracks how many triplets of this row already went to owner r; the row's first slot in bucket r is
+    // ownerpos[r * nloc + i] (exclusive scan of the owner-major count array: deterministic, no atomics)
+    int64_t my_base = (lane < sp.world) ? ownerpos[int64_t(lane) * nloc + i] : 0;
     for (uint32_t e0 = 0; e0 < n; e0 += 64) {
         const uint32_t e = e0 + lane;
         double v = -1.0;
@@ -221,11 +220,10 @@ __global__ __launch_bounds__(256) void emit_triplets_kernel(
         for (int r = 0; r < sp.world; ++r) {
             const unsigned long long m = __ballot(o == r);
             if (m == 0ull) continue;
-            unsigned long long base = 0;
-            if (lane == 0) base = atomicAdd(&sendcur[r], (unsigned long long)__popcll(m));
-            base = __shfl(base, 0);
+            const int64_t base = __shfl(my_base, r);
+            if (lane == r) my_base += __popcll(m);
             if (o == r) {
-                const int64_t pos = bk.base[r] + int64_t(base) + __popcll(m & ((1ull << lane) - 1ull));
+                const int64_t pos = base + __popcll(m & ((1ull << lane) - 1ull));
                 Triplet t;
                 t.row = j;
                 t.col = uint32_t(r0 + i);
@@ -640,7 +638,7 @@ void launch_affinity(gt_ctx* ctx, GraphState* g, KnnWork* k, int binary, double 
                        k->cand_j.as<uint32_t>(), k->cand_n.as<uint32_t>(), g->rowsrc.as<int32_t>(),
                        g->rlists.as<uint64_t>(), g->rcounts.as<uint32_t>(), g->rcap, g->rK.as<double>(),
                        g->bw.as<double>(), decay, binary, thresh, count_owners, make_splits(g), g->lenN.as<int32_t>(),
-                       g->sendcnt.as<unsigned long long>());
+                       g->ownercnt.as<int32_t>());
 }
 
 }  // namespace
@@ -723,12 +721,9 @@ extern "C" int gt_graph_begin(gt_ctx* ctx, const gt_knn_params* params, int32_t 
     GT_HIP(ctx, g->rthr.reserve(size_t(g->nloc) * sizeof(float)));
     GT_HIP(ctx, g->over_count.reserve(sizeof(uint32_t)));
     GT_HIP(ctx, g->rmax.reserve(sizeof(uint32_t)));
-    GT_HIP(ctx, g->sendcnt.reserve(size_t(kMaxWorld) * sizeof(unsigned long long)));
-    GT_HIP(ctx, g->sendcur.reserve(size_t(kMaxWorld) * sizeof(unsigned long long)));
+    GT_HIP(ctx, g->ownercnt.reserve(size_t(int64_t(world) * g->nloc) * sizeof(int32_t)));
     GT_HIP(ctx, g->flags.reserve(sizeof(uint32_t)));
     GT_HIP(ctx, hipMemsetAsync(g->over_count.p, 0, sizeof(uint32_t), ctx->stream));
-    GT_HIP(ctx, hipMemsetAsync(g->sendcnt.p, 0, size_t(kMaxWorld) * sizeof(unsigned long long), ctx->stream));
-    GT_HIP(ctx, hipMemsetAsync(g->sendcur.p, 0, size_t(kMaxWorld) * sizeof(unsigned long long), ctx->stream));
     GT_HIP(ctx, hipMemsetAsync(g->flags.p, 0, sizeof(uint32_t), ctx->stream));
     if (params->bandwidth_len > 0) {
         GT_HIP(ctx, g->bw_user.reserve(size_t(params->bandwidth_len) * sizeof(double)));
@@ -803,14 +798,20 @@ extern "C" int gt_graph_begin(gt_ctx* ctx, const gt_knn_params* params, int32_t 
             launch_affinity<double>(ctx, g, k, binary ? 1 : 0, params->decay, thresh, count_owners);
         GT_HIP(ctx, hipGetLastError());
     }
-    unsigned long long sc[kMaxWorld];
-    GT_HIP(ctx, hipMemcpyAsync(sc, g->sendcnt.p, sizeof(sc), hipMemcpyDeviceToHost, ctx->stream));
-    GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     g->send_counts_host.assign(world, 0);
-    for (int r = 0; r < world; ++r) {
-        g->send_counts_host[r] = int64_t(sc[r]);
-        send_counts[r] = int64_t(sc[r]);
+    if (count_owners) {
+        // exclusive scan of the owner-major counts: slot of every (row, owner) pair inside the bucketed send buffer
+        GT_HIP(ctx, g->ownerpos.reserve(size_t(int64_t(world) * g->nloc + 1) * sizeof(int64_t)));
+        GT_TRY(exclusive_scan(ctx, g->ownercnt.as<int32_t>(), nullptr, int64_t(world) * g->nloc, g->ownerpos.as<int64_t>(),
+                              g->scan_tmp));
+        std::vector<int64_t> edge(world + 1);
+        for (int r = 0; r <= world; ++r)
+            GT_HIP(ctx, hipMemcpyAsync(&edge[r], g->ownerpos.as<int64_t>() + int64_t(r) * g->nloc, sizeof(int64_t),
+                                       hipMemcpyDeviceToHost, ctx->stream));
+        GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (int r = 0; r < world; ++r) g->send_counts_host[r] = edge[r + 1] - edge[r];
     }
+    for (int r = 0; r < world; ++r) send_counts[r] = g->send_counts_host[r];
     g->begun = true;
     return GT_OK;
 }
@@ -821,20 +822,15 @@ extern "C" int gt_graph_emit(gt_ctx* ctx, void* send_buf_dev) {
     GraphState* g = ctx->graph;
     if (!g || !g->begun) GT_FAIL(ctx, GT_E_STATE, "gt_graph_emit: call gt_graph_begin first");
     int64_t total = 0;
-    Buckets bk;
-    for (int r = 0; r < g->world; ++r) {
-        bk.base[r] = total;
-        total += g->send_counts_host[r];
-    }
+    for (int r = 0; r < g->world; ++r) total += g->send_counts_host[r];
     if (total == 0) return GT_OK;
     if (!send_buf_dev) GT_FAIL(ctx, GT_E_ARG, "gt_graph_emit: send buffer is NULL");
     KnnWork* k = ctx->knn;
-    GT_HIP(ctx, hipMemsetAsync(g->sendcur.p, 0, size_t(kMaxWorld) * sizeof(unsigned long long), ctx->stream));
     StageSpan span(ctx, "symmetrize");
     hipLaunchKernelGGL(emit_triplets_kernel, dim3((unsigned)ceil_div64(g->nloc, 4)), dim3(256), 0, ctx->stream, g->nloc,
                        g->r0, k->MP, k->cand_d2.as<double>(), k->cand_j.as<uint32_t>(), g->rowsrc.as<int32_t>(),
                        g->rlists.as<uint64_t>(), g->rcounts.as<uint32_t>(), g->rcap, g->rK.as<double>(), make_splits(g),
-                       bk, g->sendcur.as<unsigned long long>(), (Triplet*)send_buf_dev);
+                       g->ownerpos.as<int64_t>(), (Triplet*)send_buf_dev);
     GT_HIP(ctx, hipGetLastError());
     GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return GT_OK;
@@ -861,8 +857,7 @@ extern "C" int gt_graph_finish(gt_ctx* ctx, const void* recv_buf_dev, int64_t n_
                                g->lenT.as<int32_t>());
         }
         GT_HIP(ctx, g->off.reserve(size_t(nloc + 1) * sizeof(int64_t)));
-        DevBuf tmp;
-        int rc = exclusive_scan(ctx, g->lenN.as<int32_t>(), g->lenT.as<int32_t>(), nloc, g->off.as<int64_t>(), tmp);
+        int rc = exclusive_scan(ctx, g->lenN.as<int32_t>(), g->lenT.as<int32_t>(), nloc, g->off.as<int64_t>(), g->scan_tmp);
         int64_t total_u = 0;
         if (rc == GT_OK) {
             hipError_t e = hipMemcpyAsync(&total_u, g->off.as<int64_t>() + nloc, sizeof(int64_t), hipMemcpyDeviceToHost,
@@ -873,7 +868,6 @@ extern "C" int gt_graph_finish(gt_ctx* ctx, const void* recv_buf_dev, int64_t n_
                 rc = GT_E_HIP;
             }
         }
-        tmp.release();
         GT_TRY(rc);
         g->nnz0 = total_u - n_recv;
         GT_HIP(ctx, g->Ukey.reserve(size_t(total_u) * sizeof(uint32_t)));
@@ -937,8 +931,7 @@ extern "C" int gt_graph_finish(gt_ctx* ctx, const void* recv_buf_dev, int64_t n_
         }
         // ---- compact to CSR ----
         GT_HIP(ctx, g->indptr.reserve(size_t(nloc + 1) * sizeof(int64_t)));
-        DevBuf tmp2;
-        rc = exclusive_scan(ctx, g->outlen.as<int32_t>(), nullptr, nloc, g->indptr.as<int64_t>(), tmp2);
+        rc = exclusive_scan(ctx, g->outlen.as<int32_t>(), nullptr, nloc, g->indptr.as<int64_t>(), g->scan_tmp);
         int64_t nnz = 0;
         if (rc == GT_OK) {
             hipError_t e = hipMemcpyAsync(&nnz, g->indptr.as<int64_t>() + nloc, sizeof(int64_t), hipMemcpyDeviceToHost,
@@ -949,7 +942,6 @@ extern "C" int gt_graph_finish(gt_ctx* ctx, const void* recv_buf_dev, int64_t n_
                 rc = GT_E_HIP;
             }
         }
-        tmp2.release();
         GT_TRY(rc);
         g->nnz = nnz;
         GT_HIP(ctx, g->indices.reserve(size_t(nnz) * sizeof(int32_t)));

@@ -27,4 +27,15 @@ for prec, dbg in [(p_, d_) for p_ in precs for d_ in dbgs]:
     print(json.dumps({"prec": prec, "dbg": dbg, "nq": nq, "select_ms": round(best, 2), "TF_alg": round(flops / best / 1e9, 1),
                       "rerank_ms": round(ctx.stage_ms("rerank"), 2), "fallback_ms": round(ctx.stage_ms("fallback"), 2),
                       "flags": fl, "idx_ok_256": bool(np.array_equal(i[:256], i0))}))
+    if dbg & 64:
+        import ctypes
+        nw = (nq // 256) * 4
+        buf = np.zeros((nw, 8), dtype=np.uint64)
+        ctx.lib.gt_dbg_fetch_prof.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]
+        rc = ctx.lib.gt_dbg_fetch_prof(ctx.h, nw, buf.ctypes.data)
+        tot = best * 1e-3
+        m = buf.mean(axis=0)
+        print(json.dumps({"rc": rc, "mean_cycles_per_wave": {"admission": float(m[0]), "compaction": float(m[1]), "barrier": float(m[2])},
+                          "n_compactions_per_wave": float(m[3]), "n_admission_entries_per_wave": float(m[4]),
+                          "max_barrier": float(buf[:, 2].max()), "kernel_ms": best}))
     ctx.close()
