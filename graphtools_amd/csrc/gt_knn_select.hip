@@ -31,6 +31,9 @@
 #include "gt_device.h"
 #include "gt_knn_select.h"
 
+#ifndef GT_SEL_PIPE
+#define GT_SEL_PIPE 1
+#endif
 #ifndef GT_SEL_SETPRIO
 #define GT_SEL_SETPRIO 0
 #endif
@@ -229,102 +232,123 @@ __global__ __launch_bounds__(256, 2) void knn_select_kernel(
         thr[qt] = (MODE == 0) ? ((dbg & 1) ? INFINITY : -INFINITY) : ((qg < nq) ? thr_in[qc] : INFINITY);
     }
 
-    // ---- tile staging (global -> registers -> LDS, padded rows) ----
-    float4 stage[C::F4_PER_THREAD];
+    // ---- tile staging (global -> registers -> LDS, padded rows), in two halves to halve the staging registers ----
+    constexpr int HF4 = C::NF4 / 2;                      // 16-byte units per half tile
+    constexpr int HF4_PER_THREAD = (HF4 + 255) / 256;
+    float4 stage[HF4_PER_THREAD];
     float stage_h = 0.f;
-#define GT_STAGE_LOAD(T_)                                                                     \
-    {                                                                                         \
-        const float4* src_ = reinterpret_cast<const float4*>(Yp + size_t(T_) * BN * DP);      \
-        _Pragma("unroll") for (int u = 0; u < C::F4_PER_THREAD; ++u) {                        \
-            const int f = tid + u * 256;                                                      \
-            stage[u] = (f < C::NF4) ? src_[f] : make_float4(0.f, 0.f, 0.f, 0.f);              \
-        }                                                                                     \
-        stage_h = (tid < BN) ? hneg[size_t(T_) * BN + tid] : 0.f;                             \
+#define GT_STAGE_LOAD(T_, HALF_)                                                                          \
+    {                                                                                                     \
+        const float4* src_ = reinterpret_cast<const float4*>(Yp + size_t(T_) * BN * DP) + (HALF_) * HF4;   \
+        _Pragma("unroll") for (int u_ = 0; u_ < HF4_PER_THREAD; ++u_) {                                    \
+            const int f = tid + u_ * 256;                                                                 \
+            stage[u_] = (f < HF4) ? src_[f] : make_float4(0.f, 0.f, 0.f, 0.f);                            \
+        }                                                                                                 \
+        if ((HALF_) == 0) stage_h = (tid < BN) ? hneg[size_t(T_) * BN + tid] : 0.f;                       \
     }
-#define GT_STAGE_STORE(BUF_)                                                                  \
-    {                                                                                         \
-        float* tb_ = tile + (BUF_) * C::TILE_FLOATS;                                          \
-        _Pragma("unroll") for (int u = 0; u < C::F4_PER_THREAD; ++u) {                        \
-            const int f = tid + u * 256;                                                      \
-            if (f < C::NF4) {                                                                 \
-                const int r = (f * 4) / DP;                                                   \
-                const int c = (f * 4) % DP;                                                   \
-                *reinterpret_cast<float4*>(tb_ + r * LDP + c) = stage[u];                     \
-            }                                                                                 \
-        }                                                                                     \
-        if (tid < BN) hn[(BUF_) * BN + tid] = stage_h;                                        \
+#define GT_STAGE_STORE(BUF_, HALF_)                                                                       \
+    {                                                                                                     \
+        float* tb_ = tile + (BUF_) * C::TILE_FLOATS;                                                      \
+        _Pragma("unroll") for (int u_ = 0; u_ < HF4_PER_THREAD; ++u_) {                                    \
+            const int f = tid + u_ * 256;                                                                 \
+            if (f < HF4) {                                                                                \
+                const int g_ = f + (HALF_) * HF4;                                                         \
+                const int r = (g_ * 4) / DP;                                                              \
+                const int c = (g_ * 4) % DP;                                                              \
+                *reinterpret_cast<float4*>(tb_ + r * LDP + c) = stage[u_];                                \
+            }                                                                                             \
+        }                                                                                                 \
+        if ((HALF_) == 0 && tid < BN) hn[(BUF_) * BN + tid] = stage_h;                                    \
     }
 
-    GT_STAGE_LOAD(t_begin);
-    GT_STAGE_STORE(0);
+    GT_STAGE_LOAD(t_begin, 0);
+    GT_STAGE_STORE(0, 0);
+    GT_STAGE_LOAD(t_begin, 1);
+    GT_STAGE_STORE(0, 1);
     __syncthreads();
 
     for (int t = t_begin; t < t_end; ++t) {
         const int buf = (t - t_begin) & 1;
-        if (t + 1 < t_end) GT_STAGE_LOAD(t + 1);
+        if (t + 1 < t_end) GT_STAGE_LOAD(t + 1, 0);
         const float* tb = tile + buf * C::TILE_FLOATS;
         const float* hb = hn + buf * BN;
         const uint32_t tbase = uint32_t(t) * BN;
 
-        // A fragments are prefetched one sub-tile ahead (ping-pong registers) so the LDS latency hides under the
-        // matrix work; the loop is fully unrolled to keep the ping-pong index static.
+        // Software pipeline over the NU = (BN/32)*QT units (sub-tile, query tile) of this tile, fully unrolled:
+        //   unit u:  [ MFMA chain of u   ||   admission predicates of u-1 (VALU/SALU in the MFMA issue gaps) ]
+        //            admission path of u-1 (taken only when a lane beat its threshold)
+        // Two accumulator sets alternate, A fragments are prefetched one sub-tile ahead (ping-pong registers),
+        // so neither the LDS latency nor the epilogue sits between two matrix bursts of the wave.
+        constexpr int NSUB = BN / 32;
+        constexpr int NU = NSUB * QT;
         Frag<DP, PREC> afr[2];
         afr[0].load(tb + li * LDP, h);
+        // three accumulator sets rotate: unit u accumulates into accp[u%3] while the predicates of u-1 read
+        // accp[(u-1)%3] and the seeds (-|y|^2/2) of u+1 are fetched from LDS into accp[(u+1)%3]
+        f32x16 accp[3];
+        bool hg[4];
+#define GT_SEED(U_)                                                                                        \
+    {                                                                                                      \
+        _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) {                                                 \
+            const float4 hv_ = *reinterpret_cast<const float4*>(hb + ((U_) / QT) * 32 + 8 * g_ + 4 * h);   \
+            accp[(U_) % 3][4 * g_ + 0] = hv_.x;                                                            \
+            accp[(U_) % 3][4 * g_ + 1] = hv_.y;                                                            \
+            accp[(U_) % 3][4 * g_ + 2] = hv_.z;                                                            \
+            accp[(U_) % 3][4 * g_ + 3] = hv_.w;                                                            \
+        }                                                                                                  \
+    }
+        GT_SEED(0);
 #pragma unroll
-        for (int sb = 0; sb < BN / 32; ++sb) {
-            if (sb + 1 < BN / 32) afr[(sb + 1) & 1].load(tb + ((sb + 1) * 32 + li) * LDP, h);
-            const Frag<DP, PREC>& a = afr[sb & 1];
-            // accumulator init: acc[4g+e] <-> database row 8g + 4h + e  => -|y|^2/2 of that row
-            f32x16 acc[QT];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float4 hv = *reinterpret_cast<const float4*>(hb + sb * 32 + 8 * g + 4 * h);
-#pragma unroll
-                for (int qt = 0; qt < QT; ++qt) {
-                    acc[qt][4 * g + 0] = hv.x;
-                    acc[qt][4 * g + 1] = hv.y;
-                    acc[qt][4 * g + 2] = hv.z;
-                    acc[qt][4 * g + 3] = hv.w;
-                }
+        for (int u = 0; u <= NU; ++u) {
+            const int sb = u / QT, qt = u % QT;              // the unit whose chain is issued now (u < NU)
+            const int psb = (u - 1) / QT, pqt = (u - 1) % QT;   // the unit whose results are examined now (u > 0)
+            if (u == NU / 2 && t + 1 < t_end) {
+                // first half of the next tile has landed: park it in the other LDS buffer, fetch the second half
+                GT_STAGE_STORE(buf ^ 1, 0);
+                GT_STAGE_LOAD(t + 1, 1);
             }
-#if GT_SEL_SETPRIO
-            __builtin_amdgcn_s_setprio(1);   // let this wave's matrix burst win the pipe over its co-resident wave
-#endif
-#pragma unroll
-            for (int qt = 0; qt < QT; ++qt) mma_chain<DP>(a, bq[qt], acc[qt]);
-#if GT_SEL_SETPRIO
-            __builtin_amdgcn_s_setprio(0);
-#endif
-            // ---- epilogue: one query per lane, 16 database rows in registers (4 groups of 4) ----
-            // predicates come from plain compares (no fmax: it would canonicalise every MFMA output); the
-            // admission path is entered wave-uniformly, per group, and issues its LDS slot atomics back to back
-            // before any of the stores that consume them
-#pragma unroll
-            for (int qt = 0; qt < QT; ++qt) {
-                const float tq = thr[qt];
-                bool hg[4];
+            if (u < NU) {
+                if (qt == 0 && sb + 1 < NSUB) afr[(sb + 1) & 1].load(tb + ((sb + 1) * 32 + li) * LDP, h);
+                if (u + 1 < NU) GT_SEED(u + 1);
+                mma_chain<DP>(afr[sb & 1], bq[qt], accp[u % 3]);
+            }
+            if (u > 0) {
+                // predicates from plain compares (no fmax: it would canonicalise every MFMA output)
+                const float tq = thr[pqt];
+                const f32x16& pa = accp[(u - 1) % 3];
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
-                    hg[g] = (acc[qt][4 * g] > tq) | (acc[qt][4 * g + 1] > tq) | (acc[qt][4 * g + 2] > tq) |
-                            (acc[qt][4 * g + 3] > tq);
-                if (__ballot(hg[0] | hg[1] | hg[2] | hg[3])) {   // wave-uniform: most sub-tiles admit nothing
+                    hg[g] = (pa[4 * g] > tq) | (pa[4 * g + 1] > tq) | (pa[4 * g + 2] > tq) | (pa[4 * g + 3] > tq);
+            }
+#if GT_SEL_PIPE
+            if (u > 0 && u < NU) {
+                // interleave: one MFMA, then a few of the compare / mask instructions of the previous unit
+#pragma unroll
+                for (int i = 0; i < (PREC == 1 ? 3 * DP / 16 : DP / 2); ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x002, PREC == 1 ? 2 : 1, 0);   // VALU
+                    __builtin_amdgcn_sched_group_barrier(0x004, PREC == 1 ? 2 : 1, 0);   // SALU
+                }
+            }
+#endif
+            if (u > 0) {
+                const float tq = thr[pqt];
+                const f32x16& pa = accp[(u - 1) % 3];
+                if (__ballot(hg[0] | hg[1] | hg[2] | hg[3])) {   // wave-uniform: most units admit nothing
                     const unsigned long long ts_ = prof ? __builtin_readcyclecounter() : 0ull;
-                    const int ql = (w * QT + qt) * 32 + li;
+                    const int ql = (w * QT + pqt) * 32 + li;
                     uint64_t* lp = lists + size_t(qblock + ql) * lstride + (MODE == 0 ? size_t(h) * HALF : size_t(0));
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         if (__ballot(hg[g])) {
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
-                                const float v = acc[qt][4 * g + e];
+                                const float v = pa[4 * g + e];
                                 if (v > tq) {
-                                    const uint32_t j = tbase + uint32_t(sb * 32 + 8 * g + 4 * h + e);
+                                    const uint32_t j = tbase + uint32_t(psb * 32 + 8 * g + 4 * h + e);
                                     if (MODE == 0) {
-                                        // plain store: it only has to reach this XCD's L2 (compaction re-reads with
-                                        // L2-scope loads from the same CU; the next kernel sees it after the
-                                        // end-of-kernel release)
-                                        list_store(lp + fill[qt], cand_pack(v, j));
-                                        fill[qt] += 1u;
+                                        list_store(lp + fill[pqt], cand_pack(v, j));
+                                        fill[pqt] += 1u;
                                     } else {
                                         const uint32_t slot = atomicAdd(&counts[qblock + ql], 1u);
                                         if (slot < uint32_t(cap)) lp[slot] = cand_pack(v, j);
@@ -372,7 +396,7 @@ __global__ __launch_bounds__(256, 2) void knn_select_kernel(
             }
         }
 
-        if (t + 1 < t_end) GT_STAGE_STORE(buf ^ 1);
+        if (t + 1 < t_end) GT_STAGE_STORE(buf ^ 1, 1);
         {
             const unsigned long long ts_ = prof ? __builtin_readcyclecounter() : 0ull;
             __syncthreads();
@@ -423,7 +447,13 @@ int launch_one(gt_ctx* ctx, const SelectArgs& a) {
     auto kern = knn_select_kernel<DP, NT, MODE, PREC>;
     GT_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     int(C::LDS_BYTES)));
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks, (unsigned)nsplit), dim3(256), C::LDS_BYTES, ctx->stream, a.Yp,
+    size_t lds_bytes = C::LDS_BYTES;
+    if (a.dbg & 128) {   // experiment: one workgroup per CU
+        lds_bytes += 24 * 1024;
+        GT_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        int(lds_bytes)));
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks, (unsigned)nsplit), dim3(256), lds_bytes, ctx->stream, a.Yp,
                        a.hneg, a.Qp, a.qrows, a.q0, a.nq, ntiles, a.lists, a.counts, a.thr_in, a.thr_out, a.cap, a.dbg, a.prof);
     GT_HIP(ctx, hipGetLastError());
     return GT_OK;
