@@ -73,6 +73,7 @@ void gt_ctx_destroy(gt_ctx* ctx) {
     ctx->ymax.release();
     ctx->dense_degree.release();
     ctx->dense_bw.release();
+    ctx->X_norm.release();
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -117,6 +118,12 @@ int gt_set_points(gt_ctx* ctx, const void* X, int64_t n, int32_t d, int32_t dtyp
         GT_HIP(ctx, hipMemcpyAsync(ctx->X_own.p, X, size_t(n) * d * esz, hipMemcpyHostToDevice, ctx->stream));
         ctx->X = ctx->X_own.p;
     }
+    if (ctx->metric == 1) {
+        // cosine: every later stage works on the row-normalised points (distance = 1 - xhat.yhat)
+        GT_HIP(ctx, ctx->X_norm.reserve(size_t(n) * d * esz));
+        GT_TRY(gt_normalize_rows(ctx, ctx->X, ctx->X_norm.p, n, d, dtype));
+        ctx->X = ctx->X_norm.p;
+    }
     ctx->n = n;
     ctx->d = d;
     ctx->dtype = dtype;
@@ -146,6 +153,16 @@ int gt_set_option(gt_ctx* ctx, const char* name, const char* value) {
         else
             GT_FAIL(ctx, GT_E_ARG, "knn_precision must be 'f32' or 'f16'");
         ctx->n = 0;   // the working copy depends on the precision: points must be bound again
+        return GT_OK;
+    }
+    if (k == "metric") {
+        if (v == "euclidean")
+            ctx->metric = 0;
+        else if (v == "cosine")
+            ctx->metric = 1;
+        else
+            GT_FAIL(ctx, GT_E_ARG, "metric must be 'euclidean' or 'cosine'");
+        ctx->n = 0;   // points must be bound again
         return GT_OK;
     }
     if (k == "dbg_select") {

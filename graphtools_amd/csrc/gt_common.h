@@ -97,6 +97,8 @@ struct gt_ctx {
     int32_t prec = 1;    // candidate arithmetic: 0 = float32 MFMA, 1 = split-float16 MFMA (default)
     double sc = 1.0;     // power-of-two scale applied to the working copy (prec 1: max|x|*sc in [2^13, 2^14))
     double maxabs = 0.0; // max |x_ij| of the bound points
+    int32_t metric = 0;  // 0 euclidean, 1 cosine (points are row-normalised copies; distance = 1 - x.y)
+    DevBuf X_norm;       // cosine: normalised points in the input dtype
     int32_t dbg_select = 0;   // experiment switches forwarded to the candidate kernel (results invalid when set)
     int64_t n_pad = 0;   // rows of the working copy (multiple of the db tile)
     DevBuf Yp;           // working copy: [n_pad] rows of 4*DP bytes (float32, or float16 hi plane | lo plane)

@@ -114,6 +114,7 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
     ra.thr_final = k->thr_final.as<float>();
     ra.ymax2 = ctx->ymax.as<double>();
     ra.err = gt_err_model(ctx);
+    ra.metric = ctx->metric;
     ra.need_m = need_m;
     ra.MP = MP;
     ra.cand_d2 = k->cand_d2.as<double>();
@@ -165,6 +166,7 @@ extern "C" int gt_knn_search(gt_ctx* ctx, int64_t row0, int64_t row1, const void
         GT_HIP(ctx, kw->Qraw.reserve(size_t(m) * ctx->d * esz));
         GT_HIP(ctx, hipMemcpyAsync(kw->Qraw.p, Y, size_t(m) * ctx->d * esz,
                                    y_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
+        if (ctx->metric == 1) GT_TRY(gt_normalize_rows(ctx, kw->Qraw.p, kw->Qraw.p, m, ctx->d, ctx->dtype));
         GT_HIP(ctx, kw->Qp.reserve(size_t(mpad) * ctx->DP * sizeof(float)));
         GT_HIP(ctx, kw->qn.reserve(size_t(m) * sizeof(double)));
         if (ctx->prec == 1) {
@@ -196,7 +198,7 @@ extern "C" int gt_knn_search(gt_ctx* ctx, int64_t row0, int64_t row1, const void
         d_dist = tmp_d.as<double>();
     }
     int rc = gt_launch_emit_knn(ctx, kw->cand_d2.as<double>(), kw->cand_j.as<uint32_t>(), kw->MP, nq, k, ctx->dtype,
-                                d_idx, d_dist);
+                                ctx->metric, d_idx, d_dist);
     if (rc == GT_OK && !out_on_device) {
         hipError_t e = hipMemcpyAsync(out_idx, d_idx, size_t(nq) * k * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess)

@@ -28,6 +28,8 @@ int gt_prep_matrix(gt_ctx* ctx, const void* Xdev, int64_t n, int d, int dtype, i
                    double* xn, float* hneg, double* ymax2, int prec, double sc);
 int gt_max_abs(gt_ctx* ctx, const void* Xdev, int64_t total, int dtype, double* out_host);
 double gt_f16_scale(double maxabs);
+// row-wise l2 normalisation in the input dtype (sklearn normalize: zero rows untouched); in place allowed
+int gt_normalize_rows(gt_ctx* ctx, const void* X, void* out, int64_t n, int d, int dtype);
 
 // Error model of the candidate scores (scaled units s~ = sc^2 (x.y - |y|^2/2) + error):
 //   |s~/sc^2 - s| <= rel * (|y|^2/2 + |x||y|) + abs * (|x| + |y|)
@@ -44,6 +46,29 @@ ErrModel gt_err_model(const gt_ctx* ctx);
 // need_m nearest neighbours.  Queries: rows [q0, q0+nq) of the bound points, or (external) the matrix in
 // ctx->knn->Qraw prepared by the caller.
 int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int need_m);
+
+// ---- metric helpers shared by the float64 stages ---------------------------------------------------------
+// The sortable non-negative "key" of a (query, database row) pair is the squared euclidean distance in
+// scikit-learn's association (|x|^2 + (-2 x.y)) + |y|^2 clamped at 0 (sklearn:_argkmin.pyx.tp:497-505), or, for
+// the cosine metric, clip(1 - xhat.yhat, 0, 2) (sklearn:metrics/pairwise.py:1169-1184) on the normalised points.
+#ifdef __HIPCC__
+__device__ __forceinline__ double gt_pair_key(double qn, double dot, double yn, int metric) {
+    if (metric == 1) {
+        double t = 1.0 - dot;
+        t = t > 0.0 ? t : 0.0;
+        return t < 2.0 ? t : 2.0;
+    }
+    double t = qn + (-2.0 * dot);
+    t = t + yn;
+    return t > 0.0 ? t : 0.0;
+}
+// distance as the reference sees it: _rdist_to_dist in the input dtype (euclidean), the input dtype's rounding
+// of the float64 value (cosine)
+__device__ __forceinline__ double gt_key_to_dist(double key, int dtype, int metric) {
+    if (metric == 1) return (dtype == GT_F32) ? double(float(key)) : key;
+    return (dtype == GT_F32) ? double(sqrtf(float(key))) : sqrt(key);
+}
+#endif
 
 // gt_rerank.hip
 struct RerankArgs {
@@ -62,6 +87,7 @@ struct RerankArgs {
     const float* thr_final;   // last admission threshold of the candidate pass (scaled score units)
     const double* ymax2;
     ErrModel err;
+    int metric;
     int need_m;
     int MP;
     double* cand_d2;
@@ -75,4 +101,4 @@ struct RerankArgs {
 int gt_launch_rerank(gt_ctx* ctx, const RerankArgs& a);
 int gt_launch_fallback(gt_ctx* ctx, const RerankArgs& a, int64_t n_rows, int64_t row_off, double* scratch);
 int gt_launch_emit_knn(gt_ctx* ctx, const double* cand_d2, const uint32_t* cand_j, int MP, int64_t nq, int k,
-                       int dtype, int64_t* out_idx, double* out_dist);
+                       int dtype, int metric, int64_t* out_idx, double* out_dist);

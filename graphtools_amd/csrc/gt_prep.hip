@@ -61,6 +61,23 @@ __global__ __launch_bounds__(256) void pad_split_f16_kernel(const T* __restrict_
     }
 }
 
+// sklearn.preprocessing.normalize(X, "l2"): x / sqrt(sum x^2), rows with zero norm untouched
+template <typename T>
+__global__ __launch_bounds__(256) void normalize_rows_kernel(const T* __restrict__ X, T* __restrict__ out, int64_t n, int d) {
+    const int64_t r = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (r >= n) return;
+    const T* src = X + r * int64_t(d);
+    double acc = 0.0;
+    for (int k = 0; k < d; ++k) {
+        const double v = double(src[k]);
+        acc = fma(v, v, acc);
+    }
+    T nrm = T(sqrt(acc));
+    if (nrm == T(0)) nrm = T(1);
+    T* dst = out + r * int64_t(d);
+    for (int k = 0; k < d; ++k) dst[k] = src[k] / nrm;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void row_norm_kernel(const T* __restrict__ X, int64_t n, int d, int64_t n_pad,
                                                        double* __restrict__ xn, float* __restrict__ hneg,
@@ -86,6 +103,18 @@ __global__ __launch_bounds__(256) void row_norm_kernel(const T* __restrict__ X, 
 }
 
 }  // namespace
+
+int gt_normalize_rows(gt_ctx* ctx, const void* X, void* out, int64_t n, int d, int dtype) {
+    const int64_t nb = ceil_div64(n, 256);
+    if (dtype == GT_F32)
+        hipLaunchKernelGGL(normalize_rows_kernel<float>, dim3((unsigned)nb), dim3(256), 0, ctx->stream, (const float*)X,
+                           (float*)out, n, d);
+    else
+        hipLaunchKernelGGL(normalize_rows_kernel<double>, dim3((unsigned)nb), dim3(256), 0, ctx->stream, (const double*)X,
+                           (double*)out, n, d);
+    GT_HIP(ctx, hipGetLastError());
+    return GT_OK;
+}
 
 int gt_max_abs(gt_ctx* ctx, const void* Xdev, int64_t total, int dtype, double* out_host) {
     DevBuf tmp;

@@ -45,13 +45,6 @@ __device__ __forceinline__ double dot_row<float>(const double* __restrict__ xs, 
     return acc;
 }
 
-// scikit-learn association: (|x|^2 + middle) + |y|^2, middle = -2 * x.y, clamped at 0
-__device__ __forceinline__ double sq_dist(double qn, double dot, double yn) {
-    double t = qn + (-2.0 * dot);
-    t = t + yn;
-    return t > 0.0 ? t : 0.0;
-}
-
 template <typename T, int NT2>
 __global__ __launch_bounds__(256) void rerank_kernel(const T* __restrict__ X, const int d, const double* __restrict__ xn,
                                                      const T* __restrict__ Q, const double* __restrict__ qn,
@@ -60,7 +53,7 @@ __global__ __launch_bounds__(256) void rerank_kernel(const T* __restrict__ X, co
                                                      const uint32_t* __restrict__ counts,
                                                      const float* __restrict__ thr_final,
                                                      const double* __restrict__ ymax2p, const ErrModel err,
-                                                     const int need_m, double* __restrict__ cand_d2,
+                                                     const int metric, const int need_m, double* __restrict__ cand_d2,
                                                      uint32_t* __restrict__ cand_j, uint32_t* __restrict__ cand_n,
                                                      double* __restrict__ d2_lb, uint32_t* __restrict__ fb_count,
                                                      int32_t* __restrict__ fb_rows, uint32_t* __restrict__ gflags) {
@@ -90,7 +83,7 @@ __global__ __launch_bounds__(256) void rerank_kernel(const T* __restrict__ X, co
         if (c < n) {
             const uint32_t j = cand_index(lp[c]);
             const double dot = dot_row<T>(xs, X + int64_t(j) * d, d);
-            hi[u] = (uint64_t)__double_as_longlong(sq_dist(qnq, dot, xn[j]));
+            hi[u] = (uint64_t)__double_as_longlong(gt_pair_key(qnq, dot, xn[j], metric));
             lo[u] = j;
         }
     }
@@ -107,7 +100,8 @@ __global__ __launch_bounds__(256) void rerank_kernel(const T* __restrict__ X, co
         const double thr = double(thr_f) * err.inv_sc2;
         const double y2 = *ymax2p;
         const double e = err.rel * (0.5 * y2 + sqrt(qnq * y2)) + err.abs * (sqrt(qnq) + sqrt(y2));
-        lb = qnq - 2.0 * (thr + e);
+        // euclidean: d2 = |x|^2 - 2 s ; cosine: D = 1 - x.y = 1 - s - |y|^2/2 >= 1 - s - ymax^2/2
+        lb = (metric == 1) ? (1.0 - (thr + e) - 0.5 * y2) : (qnq - 2.0 * (thr + e));
         lb -= 1e-9 * (qnq + y2);   // float64 rounding of the quantities above, with a wide margin
     }
     // d2 of the need_m-th neighbour (position need_m - 1)
@@ -135,7 +129,7 @@ __global__ __launch_bounds__(256) void fallback_kernel(const T* __restrict__ X, 
                                                        const double* __restrict__ xn, const T* __restrict__ Q,
                                                        const double* __restrict__ qn, const int64_t q0,
                                                        const int32_t* __restrict__ fb_rows, const int64_t row_off,
-                                                       const int need_m, double* __restrict__ scratch,
+                                                       const int metric, const int need_m, double* __restrict__ scratch,
                                                        double* __restrict__ cand_d2, uint32_t* __restrict__ cand_j,
                                                        uint32_t* __restrict__ cand_n, double* __restrict__ d2_lb) {
     constexpr int MP = NT2 * 64;
@@ -155,7 +149,7 @@ __global__ __launch_bounds__(256) void fallback_kernel(const T* __restrict__ X, 
     const double qnq = qn[q0 + q];
     for (int64_t j = tid; j < n; j += 256) {
         const double dot = dot_row<T>(xs, X + j * d, d);
-        sc[j] = sq_dist(qnq, dot, xn[j]);
+        sc[j] = gt_pair_key(qnq, dot, xn[j], metric);
     }
     __syncthreads();
     // bitwise search for the need_m-th smallest key (float64 >= 0: bit pattern is order preserving)
@@ -228,15 +222,14 @@ __global__ __launch_bounds__(256) void fallback_kernel(const T* __restrict__ X, 
 
 __global__ __launch_bounds__(256) void emit_knn_kernel(const double* __restrict__ cand_d2,
                                                        const uint32_t* __restrict__ cand_j, const int MP,
-                                                       const int64_t nq, const int k, const int dtype,
+                                                       const int64_t nq, const int k, const int dtype, const int metric,
                                                        int64_t* __restrict__ out_idx, double* __restrict__ out_dist) {
     const int64_t total = nq * k;
     for (int64_t e = int64_t(blockIdx.x) * 256 + threadIdx.x; e < total; e += int64_t(gridDim.x) * 256) {
         const int64_t q = e / k;
         const int p = int(e % k);
         const double d2 = cand_d2[q * MP + p];
-        // _rdist_to_dist in the input dtype (sklearn:_dist_metrics.pyx.tp:1018-1019)
-        const double dist = (dtype == GT_F32) ? double(sqrtf(float(d2))) : sqrt(d2);
+        const double dist = gt_key_to_dist(d2, dtype, metric);
         out_idx[e] = int64_t(cand_j[q * MP + p]);
         out_dist[e] = dist;
     }
@@ -249,12 +242,12 @@ int rerank_t(gt_ctx* ctx, const RerankArgs& a) {
     if (a.MP == 128) {
         hipLaunchKernelGGL((rerank_kernel<T, 2>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, (const T*)a.X,
                            a.d, a.xn, (const T*)a.Q, a.qn, a.q0, a.nq, a.lists, a.lstride, a.counts, a.thr_final, a.ymax2,
-                           a.err, a.need_m, a.cand_d2, a.cand_j, a.cand_n, a.d2_lb, a.fb_count, a.fb_rows,
+                           a.err, a.metric, a.need_m, a.cand_d2, a.cand_j, a.cand_n, a.d2_lb, a.fb_count, a.fb_rows,
                            a.gflags);
     } else if (a.MP == 512) {
         hipLaunchKernelGGL((rerank_kernel<T, 8>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, (const T*)a.X,
                            a.d, a.xn, (const T*)a.Q, a.qn, a.q0, a.nq, a.lists, a.lstride, a.counts, a.thr_final, a.ymax2,
-                           a.err, a.need_m, a.cand_d2, a.cand_j, a.cand_n, a.d2_lb, a.fb_count, a.fb_rows,
+                           a.err, a.metric, a.need_m, a.cand_d2, a.cand_j, a.cand_n, a.d2_lb, a.fb_count, a.fb_rows,
                            a.gflags);
     } else {
         GT_FAIL(ctx, GT_E_ARG, "rerank: unsupported table width");
@@ -268,12 +261,12 @@ int fallback_t(gt_ctx* ctx, const RerankArgs& a, int64_t n_rows, int64_t row_off
     if (a.MP == 128) {
         const size_t lds = size_t(a.d) * 8 + size_t(128) * 12 + 16;
         hipLaunchKernelGGL((fallback_kernel<T, 2>), dim3((unsigned)n_rows), dim3(256), lds, ctx->stream, (const T*)a.X,
-                           a.n, a.d, a.xn, (const T*)a.Q, a.qn, a.q0, a.fb_rows, row_off, a.need_m, scratch, a.cand_d2,
+                           a.n, a.d, a.xn, (const T*)a.Q, a.qn, a.q0, a.fb_rows, row_off, a.metric, a.need_m, scratch, a.cand_d2,
                            a.cand_j, a.cand_n, a.d2_lb);
     } else if (a.MP == 512) {
         const size_t lds = size_t(a.d) * 8 + size_t(512) * 12 + 16;
         hipLaunchKernelGGL((fallback_kernel<T, 8>), dim3((unsigned)n_rows), dim3(256), lds, ctx->stream, (const T*)a.X,
-                           a.n, a.d, a.xn, (const T*)a.Q, a.qn, a.q0, a.fb_rows, row_off, a.need_m, scratch, a.cand_d2,
+                           a.n, a.d, a.xn, (const T*)a.Q, a.qn, a.q0, a.fb_rows, row_off, a.metric, a.need_m, scratch, a.cand_d2,
                            a.cand_j, a.cand_n, a.d2_lb);
     } else {
         GT_FAIL(ctx, GT_E_ARG, "fallback: unsupported table width");
@@ -295,12 +288,12 @@ int gt_launch_fallback(gt_ctx* ctx, const RerankArgs& a, int64_t n_rows, int64_t
 }
 
 int gt_launch_emit_knn(gt_ctx* ctx, const double* cand_d2, const uint32_t* cand_j, int MP, int64_t nq, int k,
-                       int dtype, int64_t* out_idx, double* out_dist) {
+                       int dtype, int metric, int64_t* out_idx, double* out_dist) {
     int64_t blocks = ceil_div64(nq * k, 256);
     if (blocks > 16384) blocks = 16384;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(emit_knn_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, cand_d2, cand_j, MP, nq, k,
-                       dtype, out_idx, out_dist);
+                       dtype, metric, out_idx, out_dist);
     GT_HIP(ctx, hipGetLastError());
     return GT_OK;
 }

@@ -43,10 +43,6 @@ __device__ __forceinline__ int owner_of(const Splits& sp, int64_t row) {
     return o;
 }
 
-__device__ __forceinline__ double dist_from_d2(double d2, int dtype) {
-    return (dtype == GT_F32) ? double(sqrtf(float(d2))) : sqrt(d2);
-}
-
 __device__ __forceinline__ double affinity(double dist, double bw, double decay) {
     double w = exp(-pow(dist / bw, decay));
     return (w != w) ? 1.0 : w;   // NaN -> 1 (graphs.py:505-506)
@@ -54,7 +50,8 @@ __device__ __forceinline__ double affinity(double dist, double bw, double decay)
 
 // ---- A0: bandwidth, radius, classification ------------------------------------------------------
 __global__ __launch_bounds__(256) void bandwidth_kernel(
-    const int64_t nloc, const int64_t r0, const int MP, const int kprime, const int dtype, const double* __restrict__ cand_d2,
+    const int64_t nloc, const int64_t r0, const int MP, const int kprime, const int dtype, const int metric,
+    const double* __restrict__ cand_d2,
     const double* __restrict__ d2_lb, const double* __restrict__ xn, const double* __restrict__ ymax2p,
     const ErrModel err, const double* __restrict__ bw_user, const int64_t bw_len, const double bw_scale,
     const int use_radius, const double radius_factor, double* __restrict__ bw_out, int32_t* __restrict__ rowsrc,
@@ -63,7 +60,7 @@ __global__ __launch_bounds__(256) void bandwidth_kernel(
     if (i >= nloc) return;
     double bw;
     if (bw_len == 0)
-        bw = dist_from_d2(cand_d2[i * MP + (kprime - 1)], dtype) * bw_scale;
+        bw = gt_key_to_dist(cand_d2[i * MP + (kprime - 1)], dtype, metric) * bw_scale;
     else
         bw = (bw_len == 1 ? bw_user[0] : bw_user[r0 + i]) * bw_scale;
     bw = fmax(bw, DBL_EPSILON);
@@ -71,7 +68,7 @@ __global__ __launch_bounds__(256) void bandwidth_kernel(
     int32_t src = -1;
     if (use_radius) {
         const double r = bw * radius_factor * (1.0 + 1e-6);
-        const double r2 = r * r;
+        const double r2 = (metric == 1) ? r : r * r;   // key space: squared distance / cosine distance
         if (!(r2 < d2_lb[i])) {
             const uint32_t slot = atomicAdd(over_count, 1u);
             over_rows[slot] = int32_t(r0 + i);
@@ -79,7 +76,9 @@ __global__ __launch_bounds__(256) void bandwidth_kernel(
             const double qn = xn[r0 + i];
             const double y2 = *ymax2p;
             const double e = err.rel * (0.5 * y2 + sqrt(qn * y2)) + err.abs * (sqrt(qn) + sqrt(y2));
-            const double x = (0.5 * (qn - r2) - e - 1e-9 * (qn + y2)) / err.inv_sc2;   // scaled score units
+            // every row within the radius scores at least this much (scaled score units)
+            const double smin = (metric == 1) ? (1.0 - r2 - 0.5 * y2) : 0.5 * (qn - r2);
+            const double x = (smin - e - 1e-9 * (qn + y2)) / err.inv_sc2;
             float f = float(x);
             if (double(f) >= x) f = nextafterf(f, -INFINITY);
             rthr[slot] = f;
@@ -102,7 +101,7 @@ __global__ void max_u32_kernel(const uint32_t* __restrict__ v, const int64_t n, 
 template <typename T>
 __global__ __launch_bounds__(256) void affinity_kernel(
     const int64_t nloc, const int64_t r0, const T* __restrict__ X, const int d, const double* __restrict__ xn,
-    const int dtype, const int MP, const int limit, double* __restrict__ cand_d2, const uint32_t* __restrict__ cand_j,
+    const int dtype, const int metric, const int MP, const int limit, double* __restrict__ cand_d2, const uint32_t* __restrict__ cand_j,
     const uint32_t* __restrict__ cand_n, const int32_t* __restrict__ rowsrc, const uint64_t* __restrict__ rlists,
     const uint32_t* __restrict__ rcounts, const int32_t rcap, double* __restrict__ rK, const double* __restrict__ bw,
     const double decay, const int binary, const double thresh, const int count_owners, const Splits sp,
@@ -128,7 +127,7 @@ __global__ __launch_bounds__(256) void affinity_kernel(
                 const double d2 = cand_d2[i * MP + e];
                 j = cand_j[i * MP + e];
                 double kv = 1.0;
-                if (!binary) kv = affinity(dist_from_d2(d2, dtype), bwi, decay);
+                if (!binary) kv = affinity(gt_key_to_dist(d2, dtype, metric), bwi, decay);
                 keep = binary || (kv >= thresh);
                 cand_d2[i * MP + e] = keep ? kv : -1.0;
             }
@@ -162,10 +161,8 @@ __global__ __launch_bounds__(256) void affinity_kernel(
                 const T* y = X + int64_t(j) * d;
                 double dot = 0.0;
                 for (int k = 0; k < d; ++k) dot = fma(xs[k], double(y[k]), dot);
-                double t = qn + (-2.0 * dot);
-                t = t + xn[j];
-                t = t > 0.0 ? t : 0.0;
-                const double kv = affinity(dist_from_d2(t, dtype), bwi, decay);
+                const double t = gt_pair_key(qn, dot, xn[j], metric);
+                const double kv = affinity(gt_key_to_dist(t, dtype, metric), bwi, decay);
                 keep = kv >= thresh;
                 kp[e] = keep ? kv : -1.0;
             }
@@ -634,7 +631,7 @@ void launch_affinity(gt_ctx* ctx, GraphState* g, KnnWork* k, int binary, double 
     const int64_t blocks = ceil_div64(g->nloc, 4);
     const size_t lds = size_t(4) * ctx->d * sizeof(double);
     hipLaunchKernelGGL((affinity_kernel<T>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, g->nloc, g->r0,
-                       (const T*)ctx->X, ctx->d, ctx->xn.as<double>(), ctx->dtype, k->MP, g->limit, k->cand_d2.as<double>(),
+                       (const T*)ctx->X, ctx->d, ctx->xn.as<double>(), ctx->dtype, ctx->metric, k->MP, g->limit, k->cand_d2.as<double>(),
                        k->cand_j.as<uint32_t>(), k->cand_n.as<uint32_t>(), g->rowsrc.as<int32_t>(),
                        g->rlists.as<uint64_t>(), g->rcounts.as<uint32_t>(), g->rcap, g->rK.as<double>(),
                        g->bw.as<double>(), decay, binary, thresh, count_owners, make_splits(g), g->lenN.as<int32_t>(),
@@ -735,7 +732,7 @@ extern "C" int gt_graph_begin(gt_ctx* ctx, const gt_knn_params* params, int32_t 
     {
         StageSpan span(ctx, "affinity");
         hipLaunchKernelGGL(bandwidth_kernel, dim3((unsigned)ceil_div64(g->nloc, 256)), dim3(256), 0, ctx->stream, g->nloc,
-                           g->r0, k->MP, kprime, ctx->dtype, k->cand_d2.as<double>(), k->d2_lb.as<double>(),
+                           g->r0, k->MP, kprime, ctx->dtype, ctx->metric, k->cand_d2.as<double>(), k->d2_lb.as<double>(),
                            ctx->xn.as<double>(), ctx->ymax.as<double>(), err_model, g->bw_user.as<double>(),
                            params->bandwidth_len, params->bandwidth_scale, use_radius ? 1 : 0, g->radius_factor,
                            g->bw.as<double>(), g->rowsrc.as<int32_t>(), g->over_rows.as<int32_t>(),

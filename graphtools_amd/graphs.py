@@ -118,10 +118,10 @@ class kNNGraph(DataGraph):
                 "Building a kNNGraph on data of shape {} is expensive. Consider setting n_pca.".format(data.shape),
                 UserWarning,
             )
-        if distance != "euclidean":
+        if distance not in ("euclidean", "cosine"):
             raise NotImplementedError(
-                "graphtools_amd.kNNGraph: distance='{}' is not available on the HIP path yet "
-                "(euclidean only)".format(distance)
+                "graphtools_amd.kNNGraph: distance='{}' is not available on the HIP path "
+                "(euclidean and cosine are)".format(distance)
             )
         self.knn = knn
         self.knn_max = knn_max
@@ -168,6 +168,7 @@ class kNNGraph(DataGraph):
         X = np.ascontiguousarray(self.data_nu)
         if X.dtype not in (np.float32, np.float64):
             X = X.astype(np.float64)
+        self.hip.set_option("metric", self.distance)
         self.hip.set_points(X)
         self._points_bound = True
 
@@ -360,6 +361,8 @@ class LandmarkGraph(DataGraph):
         n_samples = self.data.shape[0]
         if self.random_landmarking:
             # reference: graphs.py:1200-1213
+            if self.distance != "euclidean":
+                raise NotImplementedError("graphtools_amd: random landmarking supports the euclidean metric only")
             rng = np.random.default_rng(self.random_state)
             landmark_indices = rng.choice(n_samples, self.n_landmark, replace=False)
             self._bind_points()

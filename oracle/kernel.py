@@ -33,23 +33,28 @@ __all__ = [
 class _NumpyEngine:
     """kneighbors / radius_neighbors through the numpy restatement (oracle/knn.py)."""
 
-    def __init__(self, data):
+    def __init__(self, data, distance="euclidean"):
         self.data = data
+        self.distance = distance
 
     def kneighbors(self, Y, k):
+        if self.distance == "cosine":
+            return _knn.cosine_kneighbors(self.data, Y, k)
         return _knn.kneighbors(self.data, Y, k)
 
     def radius_neighbors(self, Y, radius):
+        if self.distance == "cosine":
+            return _knn.cosine_radius_neighbors(self.data, Y, radius)
         return _knn.radius_neighbors(self.data, Y, radius)
 
 
 class _SklearnEngine:
     """The reference's own third-party call sites (graphtools/graphs.py:763-768)."""
 
-    def __init__(self, data, knn):
+    def __init__(self, data, knn, distance="euclidean"):
         from sklearn.neighbors import NearestNeighbors
 
-        self.tree = NearestNeighbors(n_neighbors=knn, algorithm="auto", metric="euclidean").fit(data)
+        self.tree = NearestNeighbors(n_neighbors=knn, algorithm="auto", metric=distance).fit(data)
 
     def kneighbors(self, Y, k):
         return self.tree.kneighbors(Y, n_neighbors=k)
@@ -104,6 +109,7 @@ def knn_kernel(
     Y=None,
     engine="numpy",
     return_search=False,
+    distance="euclidean",
 ):
     """Unsymmetrised kernel of ``kNNGraph`` (graphtools/graphs.py:771-785, 819-982).
 
@@ -127,7 +133,7 @@ def knn_kernel(
         k_eff = n
     if knn_max_eff is None:
         knn_max_eff = n
-    eng = _SklearnEngine(data, knn + 1) if engine == "sklearn" else _NumpyEngine(data)
+    eng = _SklearnEngine(data, knn + 1, distance) if engine == "sklearn" else _NumpyEngine(data, distance)
     m = Y.shape[0]
 
     if decay is None or thresh == 1:
@@ -272,12 +278,13 @@ def knn_graph(
     theta=None,
     anisotropy=0,
     engine="numpy",
+    distance="euclidean",
 ):
     """Kernel K and diffusion operator P of ``graphtools.Graph(data, ...)`` when it
     resolves to ``kNNGraph`` (graphtools/base.py:534-555 ``_build_kernel``, :629-646 ``P``)."""
     K0 = knn_kernel(
         data, knn=knn, decay=decay, thresh=thresh, bandwidth=bandwidth,
-        bandwidth_scale=bandwidth_scale, knn_max=knn_max, engine=engine,
+        bandwidth_scale=bandwidth_scale, knn_max=knn_max, engine=engine, distance=distance,
     )
     K = symmetrize_kernel(K0, kernel_symm, theta)
     K = apply_anisotropy(K, anisotropy)

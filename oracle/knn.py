@@ -35,7 +35,8 @@ ulp on a ~1e-7 fraction of entries (float32 data) or by a few float64 ulps
 """
 import numpy as np
 
-__all__ = ["row_norms_sq", "kneighbors", "radius_neighbors", "rdist_to_dist"]
+__all__ = ["row_norms_sq", "kneighbors", "radius_neighbors", "rdist_to_dist", "cosine_kneighbors",
+           "cosine_radius_neighbors"]
 
 
 def row_norms_sq(X):
@@ -61,6 +62,60 @@ def _sq_dists_block(Q64, qn, Y64, yn):
     mid += yn[None, :]
     np.maximum(mid, 0.0, out=mid)
     return mid
+
+
+def _normalize_rows(X):
+    """sklearn.preprocessing.normalize(X, "l2") as used by cosine_distances
+    (sklearn:metrics/pairwise.py:1169-1172, preprocessing/_data.py:1985-2014): rows / sqrt(einsum(x, x)),
+    zero rows untouched."""
+    X = np.array(X, dtype=np.float64 if X.dtype != np.float32 else np.float32, copy=True)
+    norms = np.sqrt(np.einsum("ij,ij->i", X, X))
+    norms[norms == 0.0] = 1.0
+    X /= norms[:, None]
+    return X
+
+
+def cosine_kneighbors(data, queries=None, n_neighbors=5, q_chunk=1024):
+    """kNN under sklearn's cosine distance: D = clip(1 - xhat . yhat, 0, 2) in the input dtype
+    (NearestNeighbors(metric="cosine") -> brute -> pairwise_distances_chunked -> cosine_distances,
+    sklearn:metrics/pairwise.py:1130-1184; reduce sklearn:neighbors/_base.py:703-741).  Ties by index."""
+    data = np.ascontiguousarray(data)
+    qn = _normalize_rows(data if queries is None else np.ascontiguousarray(queries))
+    yn = _normalize_rows(data)
+    k = int(n_neighbors)
+    m = qn.shape[0]
+    out_d = np.empty((m, k), dtype=np.float64)
+    out_i = np.empty((m, k), dtype=np.int64)
+    for q0 in range(0, m, q_chunk):
+        q1 = min(m, q0 + q_chunk)
+        S = qn[q0:q1] @ yn.T
+        S *= -1
+        S += 1
+        np.clip(S, 0, 2, out=S)
+        order = np.lexsort((np.broadcast_to(np.arange(S.shape[1]), S.shape), S), axis=1)[:, :k]
+        out_i[q0:q1] = order
+        out_d[q0:q1] = np.take_along_axis(S, order, axis=1).astype(np.float64)
+    return out_d, out_i
+
+
+def cosine_radius_neighbors(data, queries, radius, q_chunk=512):
+    data = np.ascontiguousarray(data)
+    qn = _normalize_rows(np.ascontiguousarray(queries))
+    yn = _normalize_rows(data)
+    m = qn.shape[0]
+    dist_out = np.empty(m, dtype=object)
+    ind_out = np.empty(m, dtype=object)
+    for q0 in range(0, m, q_chunk):
+        q1 = min(m, q0 + q_chunk)
+        S = qn[q0:q1] @ yn.T
+        S *= -1
+        S += 1
+        np.clip(S, 0, 2, out=S)
+        for r in range(q1 - q0):
+            keep = np.nonzero(S[r] <= radius)[0]
+            ind_out[q0 + r] = keep.astype(np.int64)
+            dist_out[q0 + r] = S[r, keep].astype(np.float64)
+    return dist_out, ind_out
 
 
 def kneighbors(data, queries=None, n_neighbors=5, q_chunk=512, y_chunk=65536):

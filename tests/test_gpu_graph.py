@@ -206,3 +206,34 @@ def test_two_rank_sharding_on_one_gpu(symm, aniso):
     np.testing.assert_allclose(np.concatenate(pdatas), Pd, rtol=1e-14)
     for c in ctxs + [ref]:
         c.close()
+
+
+def test_cosine_metric_matches_reference_vectors(hip_ctx):
+    """G8: cosine distance, float64 input (scikit-learn's float32 cosine path runs an sgemm whose summation
+    order is not reproducible, so the bit-level fixture uses float64)"""
+    z = load_golden("g8_cosine")
+    X = z["X"]
+    G = graphtools_amd.Graph(X, knn=int(z["knn"]), decay=float(z["decay"]), n_pca=None, distance="cosine")
+    d, i = G.knn_tree.kneighbors(None, 66)
+    assert np.array_equal(i, z["knn_idx"])
+    np.testing.assert_allclose(d, z["knn_dist"], rtol=0, atol=5e-15)   # 1 - x.y cancels: absolute float64 noise
+    Kg = golden_csr(z, "K")
+    assert_csr_close(G.K, Kg)
+    assert_csr_close(G.P, sparse.csr_matrix((z["P_data"], Kg.indices, Kg.indptr), shape=Kg.shape))
+
+
+@pytest.mark.parametrize("dtype,rtol", [(np.float64, 1e-9), (np.float32, 2e-3)])
+def test_cosine_metric_vs_oracle(dtype, rtol):
+    X = make_mix(2500, 40, 17, dtype)
+    X += 3.0   # off-centre so that the angular structure is not trivial
+    G = graphtools_amd.Graph(X, knn=12, decay=15, n_pca=None, distance="cosine")
+    K0, P0 = oracle.knn_graph(X, knn=12, decay=15, distance="cosine")
+    if dtype == np.float64:
+        assert_csr_close(G.K, K0, rtol=rtol)
+        assert_csr_close(G.P, P0, rtol=rtol)
+    else:
+        # float32: scikit-learn's (and the oracle's) distances come from a float32 GEMM; values agree to float32
+        # rounding amplified by the decay exponent, entries at the threshold may flip
+        D = abs(sparse.csr_matrix(G.K) - sparse.csr_matrix(K0))
+        assert D.max() < 5e-3
+        assert abs(G.K.nnz - K0.nnz) <= 0.01 * K0.nnz

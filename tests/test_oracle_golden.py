@@ -132,3 +132,13 @@ def test_landmark_operator_matches_reference():
     np.testing.assert_allclose(op2, z["spectral_landmark_op"], rtol=0, atol=1e-14)
     cl_big, _ = oracle.random_landmark_clusters(z["big_X"], 64, 7)
     assert np.array_equal(cl_big, z["big_clusters"])
+
+
+def test_cosine_matches_reference():
+    z = load_golden("g8_cosine")
+    d, i = oracle.knn.cosine_kneighbors(z["X"], None, 66)
+    assert np.array_equal(i, z["knn_idx"])
+    assert np.array_equal(d, z["knn_dist"])
+    K, P = oracle.knn_graph(z["X"], knn=int(z["knn"]), decay=float(z["decay"]), distance="cosine")
+    Kg = golden_csr(z, "K")
+    assert (sparse.csr_matrix(K) != Kg).nnz == 0
