@@ -63,6 +63,8 @@ _SIGNATURES = {
     "gt_graph_finish": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64, _c.POINTER(_c.c_int64), _c.POINTER(_c.c_uint32)]),
     "gt_graph_anisotropy": (_c.c_int, [_c.c_void_p, _c.c_void_p]),
     "gt_graph_build": (_c.c_int, [_c.c_void_p, _c.POINTER(KnnParams), _c.POINTER(_c.c_int64), _c.POINTER(_c.c_uint32)]),
+    "gt_graph_extend": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int32, _c.POINTER(KnnParams),
+                                   _c.POINTER(_c.c_int64), _c.POINTER(_c.c_uint32)]),
     "gt_graph_rows": (_c.c_int, [_c.c_void_p, _c.POINTER(_c.c_int64), _c.POINTER(_c.c_int64), _c.POINTER(_c.c_int64)]),
     "gt_graph_fetch_csr": (_c.c_int, [_c.c_void_p, _c.c_int32, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int32]),
     "gt_graph_fetch_vec": (_c.c_int, [_c.c_void_p, _c.c_int32, _c.c_void_p, _c.c_int32]),
@@ -221,6 +223,15 @@ class Context:
         flags = ctypes.c_uint32(0)
         self._check(self.lib.gt_graph_build(self.h, ctypes.byref(params), ctypes.byref(nnz), ctypes.byref(flags)),
                     "gt_graph_build")
+        return nnz.value, flags.value
+
+    def graph_extend(self, Y, params):
+        """K_yx / transitions for new points Y against the bound points; returns (nnz, flags)"""
+        Y = np.ascontiguousarray(Y, dtype=self.dtype)
+        nnz = ctypes.c_int64(0)
+        flags = ctypes.c_uint32(0)
+        self._check(self.lib.gt_graph_extend(self.h, _ptr(Y), Y.shape[0], 0, ctypes.byref(params), ctypes.byref(nnz),
+                                             ctypes.byref(flags)), "gt_graph_extend")
         return nnz.value, flags.value
 
     def graph_begin(self, params, world, rank, row_splits):

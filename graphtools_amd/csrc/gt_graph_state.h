@@ -18,6 +18,12 @@ struct GraphState {
     std::vector<int64_t> splits;
     int64_t r0 = 0, r1 = 0, nloc = 0;
     bool begun = false, finished = false;
+    // query side: rows of the graph are rows [qoff, qoff + nloc) of Qmat (= the bound points unless `external`,
+    // i.e. build_kernel_to_data(Y), graphs.py:819-982)
+    bool external = false;
+    const void* Qmat = nullptr;
+    const double* qnorm = nullptr;
+    int64_t qoff = 0;
     int need_m = 0;
     int limit = 0;          // eligible table entries per row
     double radius_factor = 0.0;

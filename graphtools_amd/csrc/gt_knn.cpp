@@ -146,6 +146,37 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
     return GT_OK;
 }
 
+int gt_prepare_queries(gt_ctx* ctx, const void* Y, int64_t m, int32_t y_on_device) {
+    if (!Y || m <= 0) GT_FAIL(ctx, GT_E_ARG, "query matrix is empty");
+    if (ctx->n <= 0 || !ctx->X) GT_FAIL(ctx, GT_E_STATE, "no points bound (call gt_set_points first)");
+    if (ctx->DP == 0) GT_FAIL(ctx, GT_E_LIMIT, "kNN on the HIP path needs n_features <= 128");
+    if (!ctx->knn) ctx->knn = new KnnWork();
+    KnnWork* kw = ctx->knn;
+    const size_t esz = ctx->dtype == GT_F32 ? 4 : 8;
+    const int bq = gt_select_bq(ctx->DP);
+    const int64_t mpad = ceil_div64(m, bq) * bq;
+    GT_HIP(ctx, kw->Qraw.reserve(size_t(m) * ctx->d * esz));
+    GT_HIP(ctx, hipMemcpyAsync(kw->Qraw.p, Y, size_t(m) * ctx->d * esz,
+                               y_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
+    if (ctx->metric == 1) GT_TRY(gt_normalize_rows(ctx, kw->Qraw.p, kw->Qraw.p, m, ctx->d, ctx->dtype));
+    GT_HIP(ctx, kw->Qp.reserve(size_t(mpad) * ctx->DP * sizeof(float)));
+    GT_HIP(ctx, kw->qn.reserve(size_t(m) * sizeof(double)));
+    if (ctx->prec == 1) {
+        // the query matrix shares the database's power-of-two scale; re-scale both if it would overflow float16
+        double qmax = 0.0;
+        GT_TRY(gt_max_abs(ctx, kw->Qraw.p, m * int64_t(ctx->d), ctx->dtype, &qmax));
+        if (qmax * ctx->sc >= 32768.0) {
+            const double keep = ctx->maxabs;
+            ctx->sc = gt_f16_scale(std::max(qmax, keep));
+            GT_TRY(gt_prep_matrix(ctx, ctx->X, ctx->n, ctx->d, ctx->dtype, ctx->DP, ctx->n_pad, ctx->Yp.as<float>(),
+                                  ctx->xn.as<double>(), ctx->hneg.as<float>(), ctx->ymax.as<double>(), 1, ctx->sc));
+        }
+    }
+    GT_TRY(gt_prep_matrix(ctx, kw->Qraw.p, m, ctx->d, ctx->dtype, ctx->DP, mpad, kw->Qp.as<float>(), kw->qn.as<double>(),
+                          nullptr, nullptr, ctx->prec, ctx->sc));
+    return GT_OK;
+}
+
 extern "C" int gt_knn_search(gt_ctx* ctx, int64_t row0, int64_t row1, const void* Y, int64_t m, int32_t y_on_device,
                              int32_t k, int64_t* out_idx, double* out_dist, int32_t out_on_device, uint32_t* flags) {
     if (!ctx) return GT_E_ARG;
@@ -157,31 +188,9 @@ extern "C" int gt_knn_search(gt_ctx* ctx, int64_t row0, int64_t row1, const void
     if (!ctx->knn) ctx->knn = new KnnWork();
     KnnWork* kw = ctx->knn;
     if (external) {
-        if (m <= 0) GT_FAIL(ctx, GT_E_ARG, "gt_knn_search: m must be positive");
-        if (ctx->DP == 0) GT_FAIL(ctx, GT_E_LIMIT, "kNN on the HIP path needs n_features <= 128");
+        GT_TRY(gt_prepare_queries(ctx, Y, m, y_on_device));
+        kw = ctx->knn;
         nq = m;
-        const size_t esz = ctx->dtype == GT_F32 ? 4 : 8;
-        const int bq = gt_select_bq(ctx->DP);
-        const int64_t mpad = ceil_div64(m, bq) * bq;
-        GT_HIP(ctx, kw->Qraw.reserve(size_t(m) * ctx->d * esz));
-        GT_HIP(ctx, hipMemcpyAsync(kw->Qraw.p, Y, size_t(m) * ctx->d * esz,
-                                   y_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
-        if (ctx->metric == 1) GT_TRY(gt_normalize_rows(ctx, kw->Qraw.p, kw->Qraw.p, m, ctx->d, ctx->dtype));
-        GT_HIP(ctx, kw->Qp.reserve(size_t(mpad) * ctx->DP * sizeof(float)));
-        GT_HIP(ctx, kw->qn.reserve(size_t(m) * sizeof(double)));
-        if (ctx->prec == 1) {
-            // the query matrix shares the database's power-of-two scale; re-scale both if it would overflow float16
-            double qmax = 0.0;
-            GT_TRY(gt_max_abs(ctx, kw->Qraw.p, m * int64_t(ctx->d), ctx->dtype, &qmax));
-            if (qmax * ctx->sc >= 32768.0) {
-                const double keep = ctx->maxabs;
-                ctx->sc = gt_f16_scale(std::max(qmax, keep));
-                GT_TRY(gt_prep_matrix(ctx, ctx->X, ctx->n, ctx->d, ctx->dtype, ctx->DP, ctx->n_pad, ctx->Yp.as<float>(),
-                                      ctx->xn.as<double>(), ctx->hneg.as<float>(), ctx->ymax.as<double>(), 1, ctx->sc));
-            }
-        }
-        GT_TRY(gt_prep_matrix(ctx, kw->Qraw.p, m, ctx->d, ctx->dtype, ctx->DP, mpad, kw->Qp.as<float>(),
-                              kw->qn.as<double>(), nullptr, nullptr, ctx->prec, ctx->sc));
         row0 = 0;
     } else {
         if (row0 < 0 || row1 > ctx->n || row1 <= row0) GT_FAIL(ctx, GT_E_ARG, "gt_knn_search: bad row range");

@@ -46,6 +46,9 @@ ErrModel gt_err_model(const gt_ctx* ctx);
 // need_m nearest neighbours.  Queries: rows [q0, q0+nq) of the bound points, or (external) the matrix in
 // ctx->knn->Qraw prepared by the caller.
 int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int need_m);
+// Upload / convert an external query matrix (same dtype and width as the bound points) into ctx->knn->Qraw
+// (original dtype, normalised for the cosine metric), Qp (working copy) and qn (float64 squared norms).
+int gt_prepare_queries(gt_ctx* ctx, const void* Y, int64_t m, int32_t y_on_device);
 
 // ---- metric helpers shared by the float64 stages ---------------------------------------------------------
 // The sortable non-negative "key" of a (query, database row) pair is the squared euclidean distance in

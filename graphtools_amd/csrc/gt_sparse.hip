@@ -52,7 +52,8 @@ __device__ __forceinline__ double affinity(double dist, double bw, double decay)
 __global__ __launch_bounds__(256) void bandwidth_kernel(
     const int64_t nloc, const int64_t r0, const int MP, const int kprime, const int dtype, const int metric,
     const double* __restrict__ cand_d2,
-    const double* __restrict__ d2_lb, const double* __restrict__ xn, const double* __restrict__ ymax2p,
+    const double* __restrict__ d2_lb, const double* __restrict__ qnorm, const int64_t qoff,
+    const double* __restrict__ ymax2p,
     const ErrModel err, const double* __restrict__ bw_user, const int64_t bw_len, const double bw_scale,
     const int use_radius, const double radius_factor, double* __restrict__ bw_out, int32_t* __restrict__ rowsrc,
     int32_t* __restrict__ over_rows, uint32_t* __restrict__ over_count, float* __restrict__ rthr) {
@@ -71,9 +72,9 @@ __global__ __launch_bounds__(256) void bandwidth_kernel(
         const double r2 = (metric == 1) ? r : r * r;   // key space: squared distance / cosine distance
         if (!(r2 < d2_lb[i])) {
             const uint32_t slot = atomicAdd(over_count, 1u);
-            over_rows[slot] = int32_t(r0 + i);
+            over_rows[slot] = int32_t(qoff + i);
             src = int32_t(slot);
-            const double qn = xn[r0 + i];
+            const double qn = qnorm[qoff + i];
             const double y2 = *ymax2p;
             const double e = err.rel * (0.5 * y2 + sqrt(qn * y2)) + err.abs * (sqrt(qn) + sqrt(y2));
             // every row within the radius scores at least this much (scaled score units)
@@ -101,7 +102,7 @@ __global__ void max_u32_kernel(const uint32_t* __restrict__ v, const int64_t n, 
 template <typename T>
 __global__ __launch_bounds__(256) void affinity_kernel(
     const int64_t nloc, const int64_t r0, const T* __restrict__ X, const int d, const double* __restrict__ xn,
-    const int dtype, const int metric, const int MP, const int limit, double* __restrict__ cand_d2, const uint32_t* __restrict__ cand_j,
+    const T* __restrict__ Qm, const double* __restrict__ qnorm, const int64_t qoff, const int dtype, const int metric, const int MP, const int limit, double* __restrict__ cand_d2, const uint32_t* __restrict__ cand_j,
     const uint32_t* __restrict__ cand_n, const int32_t* __restrict__ rowsrc, const uint64_t* __restrict__ rlists,
     const uint32_t* __restrict__ rcounts, const int32_t rcap, double* __restrict__ rK, const double* __restrict__ bw,
     const double decay, const int binary, const double thresh, const int count_owners, const Splits sp,
@@ -143,11 +144,11 @@ __global__ __launch_bounds__(256) void affinity_kernel(
         // slots beyond the eligible range are dropped
         for (uint32_t e = n + lane; e < uint32_t(MP); e += 64) cand_d2[i * MP + e] = -1.0;
     } else {
-        const T* xrow = X + (r0 + i) * int64_t(d);
+        const T* xrow = Qm + (qoff + i) * int64_t(d);
         for (int k = lane; k < d; k += 64) xs[k] = double(xrow[k]);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        const double qn = xn[r0 + i];
+        const double qn = qnorm[qoff + i];
         uint32_t n = rcounts[src];
         if (n > uint32_t(rcap)) n = uint32_t(rcap);
         const uint64_t* lp = rlists + size_t(src) * rcap;
@@ -631,7 +632,8 @@ void launch_affinity(gt_ctx* ctx, GraphState* g, KnnWork* k, int binary, double 
     const int64_t blocks = ceil_div64(g->nloc, 4);
     const size_t lds = size_t(4) * ctx->d * sizeof(double);
     hipLaunchKernelGGL((affinity_kernel<T>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, g->nloc, g->r0,
-                       (const T*)ctx->X, ctx->d, ctx->xn.as<double>(), ctx->dtype, ctx->metric, k->MP, g->limit, k->cand_d2.as<double>(),
+                       (const T*)ctx->X, ctx->d, ctx->xn.as<double>(), (const T*)g->Qmat, g->qnorm, g->qoff, ctx->dtype, ctx->metric,
+                       k->MP, g->limit, k->cand_d2.as<double>(),
                        k->cand_j.as<uint32_t>(), k->cand_n.as<uint32_t>(), g->rowsrc.as<int32_t>(),
                        g->rlists.as<uint64_t>(), g->rcounts.as<uint32_t>(), g->rcap, g->rK.as<double>(),
                        g->bw.as<double>(), decay, binary, thresh, count_owners, make_splits(g), g->lenN.as<int32_t>(),
@@ -655,15 +657,15 @@ int gt_exclusive_scan_i32(gt_ctx* ctx, const int32_t* a, int64_t n, int64_t* out
 }
 
 // ================================================================================================
-extern "C" int gt_graph_begin(gt_ctx* ctx, const gt_knn_params* params, int32_t world, int32_t rank,
-                              const int64_t* row_splits, int64_t* send_counts) {
+static int graph_begin_impl(gt_ctx* ctx, const gt_knn_params* params, int32_t world, int32_t rank,
+                            const int64_t* row_splits, int64_t* send_counts, bool external, int64_t m_ext) {
     if (!ctx || !params) return GT_E_ARG;
     GT_HIP(ctx, hipSetDevice(ctx->device));
-    ctx->reset_stages();
     if (ctx->n <= 0) GT_FAIL(ctx, GT_E_STATE, "gt_graph_begin: no points bound");
     if (world < 1 || world > kMaxWorld || rank < 0 || rank >= world || !row_splits || !send_counts)
         GT_FAIL(ctx, GT_E_ARG, "gt_graph_begin: bad world/rank/row_splits");
-    if (row_splits[0] != 0 || row_splits[world] != ctx->n) GT_FAIL(ctx, GT_E_ARG, "row_splits must cover [0, n]");
+    if (row_splits[0] != 0 || row_splits[world] != (external ? m_ext : ctx->n))
+        GT_FAIL(ctx, GT_E_ARG, "row_splits must cover [0, n]");
     for (int r = 0; r < world; ++r)
         if (row_splits[r + 1] < row_splits[r]) GT_FAIL(ctx, GT_E_ARG, "row_splits must be ascending");
     if (params->knn < 1) GT_FAIL(ctx, GT_E_ARG, "knn must be >= 1");
@@ -678,6 +680,7 @@ extern "C" int gt_graph_begin(gt_ctx* ctx, const gt_knn_params* params, int32_t 
     g->nloc = g->r1 - g->r0;
     g->begun = false;
     g->finished = false;
+    g->external = external;
     g->n_over = 0;
     g->radius_retries = 0;
     g->rcap = 0;
@@ -690,23 +693,27 @@ extern "C" int gt_graph_begin(gt_ctx* ctx, const gt_knn_params* params, int32_t 
         if (thresh < DBL_EPSILON) thresh = DBL_EPSILON;   // graphs.py:628-629
     }
     g->p.thresh = thresh;
-    const int kprime = params->knn + 1;
+    // build_kernel: knn + 1 neighbours (self included, graphs.py:783-784); build_kernel_to_data(Y): knn (:854-855)
+    const int kprime = external ? params->knn : params->knn + 1;
     if (int64_t(kprime) > ctx->n) GT_FAIL(ctx, GT_E_ARG, "knn + 1 exceeds n_samples");
     int need = kprime;
     bool use_radius = !binary;
     if (!binary && params->knn_max > 0) {
-        const int64_t km = std::min<int64_t>(params->knn_max + 1, ctx->n);
+        const int64_t km = std::min<int64_t>(external ? params->knn_max : params->knn_max + 1, ctx->n);
         need = int(std::max<int64_t>(kprime, km));
         use_radius = false;
     }
     g->need_m = need;
-    if (params->bandwidth_len != 0 && params->bandwidth_len != 1 && params->bandwidth_len != ctx->n)
+    if (params->bandwidth_len != 0 && params->bandwidth_len != 1 && params->bandwidth_len != (external ? m_ext : ctx->n))
         GT_FAIL(ctx, GT_E_ARG, "bandwidth must have 1 or n_samples entries");
     if (params->bandwidth_len > 0 && !params->bandwidth) GT_FAIL(ctx, GT_E_ARG, "bandwidth pointer is NULL");
 
     // ---- kNN candidates for the owned rows ----
-    GT_TRY(gt_knn_candidates(ctx, g->r0, g->nloc, false, need));
+    GT_TRY(gt_knn_candidates(ctx, g->r0, g->nloc, external, need));
     KnnWork* k = ctx->knn;
+    g->Qmat = external ? k->Qraw.p : ctx->X;
+    g->qnorm = external ? k->qn.as<double>() : ctx->xn.as<double>();
+    g->qoff = g->r0;
     g->limit = binary ? kprime : (params->knn_max > 0 ? need : k->MP);
 
     GT_HIP(ctx, g->bw.reserve(size_t(g->nloc) * sizeof(double)));
@@ -733,7 +740,7 @@ extern "C" int gt_graph_begin(gt_ctx* ctx, const gt_knn_params* params, int32_t 
         StageSpan span(ctx, "affinity");
         hipLaunchKernelGGL(bandwidth_kernel, dim3((unsigned)ceil_div64(g->nloc, 256)), dim3(256), 0, ctx->stream, g->nloc,
                            g->r0, k->MP, kprime, ctx->dtype, ctx->metric, k->cand_d2.as<double>(), k->d2_lb.as<double>(),
-                           ctx->xn.as<double>(), ctx->ymax.as<double>(), err_model, g->bw_user.as<double>(),
+                           g->qnorm, g->qoff, ctx->ymax.as<double>(), err_model, g->bw_user.as<double>(),
                            params->bandwidth_len, params->bandwidth_scale, use_radius ? 1 : 0, g->radius_factor,
                            g->bw.as<double>(), g->rowsrc.as<int32_t>(), g->over_rows.as<int32_t>(),
                            g->over_count.as<uint32_t>(), g->rthr.as<float>());
@@ -759,7 +766,7 @@ extern "C" int gt_graph_begin(gt_ctx* ctx, const gt_knn_params* params, int32_t 
             sa.Yp = ctx->Yp.as<float>();
             sa.hneg = ctx->hneg.as<float>();
             sa.n_pad = ctx->n_pad;
-            sa.Qp = ctx->Yp.as<float>();
+            sa.Qp = g->external ? k->Qp.as<float>() : ctx->Yp.as<float>();
             sa.qrows = g->over_rows.as<int32_t>();
             sa.q0 = 0;
             sa.nq = int32_t(n_over);
@@ -810,6 +817,31 @@ extern "C" int gt_graph_begin(gt_ctx* ctx, const gt_knn_params* params, int32_t 
     }
     for (int r = 0; r < world; ++r) send_counts[r] = g->send_counts_host[r];
     g->begun = true;
+    return GT_OK;
+}
+
+extern "C" int gt_graph_begin(gt_ctx* ctx, const gt_knn_params* params, int32_t world, int32_t rank,
+                              const int64_t* row_splits, int64_t* send_counts) {
+    if (!ctx) return GT_E_ARG;
+    ctx->reset_stages();
+    return graph_begin_impl(ctx, params, world, rank, row_splits, send_counts, false, 0);
+}
+
+extern "C" int gt_graph_extend(gt_ctx* ctx, const void* Y, int64_t m, int32_t y_on_device, const gt_knn_params* params,
+                               int64_t* out_nnz, uint32_t* flags) {
+    if (!ctx || !params) return GT_E_ARG;
+    GT_HIP(ctx, hipSetDevice(ctx->device));
+    ctx->reset_stages();
+    GT_TRY(gt_prepare_queries(ctx, Y, m, y_on_device));
+    gt_knn_params p = *params;
+    p.kernel_symm = GT_SYMM_NONE;   // K_yx is rectangular: no symmetrisation, no anisotropy (graphs.py:819-982)
+    p.anisotropy = 0.0;
+    int64_t splits[2] = {0, m};
+    int64_t sendc[1] = {0};
+    GT_TRY(graph_begin_impl(ctx, &p, 1, 0, splits, sendc, true, m));
+    uint32_t fl = 0;
+    GT_TRY(gt_graph_finish(ctx, nullptr, 0, out_nnz, &fl));
+    if (flags) *flags = fl & ~uint32_t(GT_FLAG_ZERO_DIAGONAL | GT_FLAG_DUPLICATES);
     return GT_OK;
 }
 

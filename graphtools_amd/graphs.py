@@ -274,11 +274,53 @@ class kNNGraph(DataGraph):
                           ("knn_select", "rerank", "fallback", "radius", "affinity", "symmetrize", "normalize")}
         return st
 
+    def _extend_on_device(self, Y, knn=None, knn_max=None, bandwidth=None, bandwidth_scale=None):
+        if knn is None:
+            knn = self.knn
+        if bandwidth is None:
+            bandwidth = self.bandwidth
+        if bandwidth_scale is None:
+            bandwidth_scale = self.bandwidth_scale
+        if knn > self.data.shape[0]:
+            warnings.warn(
+                "Cannot set knn ({k}) to be greater than "
+                "n_samples ({n}). Setting knn={n}".format(k=knn, n=self.data_nu.shape[0])
+            )
+            knn = self.data_nu.shape[0]
+        Y = self._check_extension_shape(Y)
+        if bandwidth is not None and not isinstance(bandwidth, numbers.Number):
+            raise NotImplementedError("graphtools_amd: out-of-sample extension supports a scalar bandwidth only")
+        self._bind_points()
+        params, keep = _hip.Context.make_params(knn, self.decay, self.thresh, bandwidth, bandwidth_scale, knn_max,
+                                                None, None, 0)
+        nnz, flags = self.hip.graph_extend(np.asarray(Y), params)
+        del keep
+        self._device_state = None   # the device now holds the rectangular kernel, not this graph's K
+        return nnz
+
+    def _fetch_rect(self, which, m, nnz):
+        data, indices, indptr = self.hip.graph_fetch_csr(which)
+        if nnz < 2**31:
+            indptr = indptr.astype(np.int32)
+        return sparse.csr_matrix((data, indices, indptr), shape=(m, self.data_nu.shape[0]))
+
     def build_kernel_to_data(self, Y, knn=None, knn_max=None, bandwidth=None, bandwidth_scale=None):
-        raise NotImplementedError(
-            "graphtools_amd: out-of-sample extension (build_kernel_to_data / extend_to_data) is the next "
-            "row of the build plan and is not on the HIP path yet"
-        )
+        """Kernel from new points ``Y`` to the graph's data (reference: graphs.py:819-982)."""
+        nnz = self._extend_on_device(Y, knn, knn_max, bandwidth, bandwidth_scale)
+        return self._fetch_rect(_hip.CSR_K, np.asarray(Y).shape[0], nnz)
+
+    def extend_to_data(self, Y):
+        """Row-stochastic transitions from new points to the graph's data (reference: base.py:1166-1193)."""
+        nnz = self._extend_on_device(Y)
+        return self._fetch_rect(_hip.CSR_P, np.asarray(Y).shape[0], nnz)
+
+    def interpolate(self, transform, transitions=None, Y=None):
+        """reference: base.py:1195-1229"""
+        if transitions is None:
+            if Y is None:
+                raise ValueError("Either `transitions` or `Y` must be provided.")
+            transitions = self.extend_to_data(Y)
+        return transitions.dot(transform)
 
 
 class LandmarkGraph(DataGraph):

@@ -145,6 +145,13 @@ int gt_graph_anisotropy(gt_ctx* ctx, const double* degree_all_dev);
 /* single-GPU convenience: begin + emit + finish with an internal buffer */
 int gt_graph_build(gt_ctx* ctx, const gt_knn_params* params, int64_t* out_nnz, uint32_t* flags);
 
+/* Out-of-sample kernel, replaces kNNGraph.build_kernel_to_data(Y) + the normalize() of DataGraph.extend_to_data
+ * (graphs.py:819-982, base.py:1166-1193): rows = the m query points Y (same dtype / width as the bound points,
+ * host or device), columns = the n bound points; `knn` neighbours (no +1), no symmetrisation.  K_yx and its
+ * row-normalised form (the transition matrix) are fetched with gt_graph_fetch_csr(GT_CSR_K / GT_CSR_P). */
+int gt_graph_extend(gt_ctx* ctx, const void* Y, int64_t m, int32_t y_on_device, const gt_knn_params* params,
+                    int64_t* out_nnz, uint32_t* flags);
+
 /* Results of the most recent gt_graph_finish, for the owned rows.
  * CSR is canonical (sorted columns, no duplicates): data float64 [nnz], indices int32 [nnz] (global
  * column ids), indptr int64 [rows+1].  Any of the three pointers may be NULL.  on_device selects

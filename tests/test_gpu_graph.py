@@ -237,3 +237,24 @@ def test_cosine_metric_vs_oracle(dtype, rtol):
         D = abs(sparse.csr_matrix(G.K) - sparse.csr_matrix(K0))
         assert D.max() < 5e-3
         assert abs(G.K.nnz - K0.nnz) <= 0.01 * K0.nnz
+
+
+@pytest.mark.parametrize("maker,kw", [(make_mix, {}), (make_gauss, {"knn": 8, "decay": 10}), (make_mix, {"decay": None})])
+def test_out_of_sample_extension(maker, kw):
+    """build_kernel_to_data / extend_to_data / interpolate vs the oracle's restatement"""
+    X = maker(3000, 32, 41)
+    Y = maker(700, 32, 42)
+    knn = kw.get("knn", 12)
+    decay = kw.get("decay", 30)
+    G = graphtools_amd.Graph(X, knn=knn, decay=decay, n_pca=None)
+    K_ref = oracle.knn_kernel(X, knn=knn, decay=decay, Y=Y)
+    K_yx = G.build_kernel_to_data(Y)
+    assert K_yx.shape == (700, 3000)
+    assert_csr_close(K_yx, K_ref)
+    T = G.extend_to_data(Y)
+    assert_csr_close(T, oracle.kernel.diff_op_fast(sparse.csr_matrix(K_ref)))
+    emb = np.random.default_rng(0).standard_normal((3000, 3))
+    np.testing.assert_allclose(G.interpolate(emb, Y=Y), oracle.kernel.diff_op_fast(sparse.csr_matrix(K_ref)).dot(emb), rtol=1e-9)
+    # the graph's own kernel / operator are still served correctly afterwards
+    K0, P0 = oracle.knn_graph(X, knn=knn, decay=decay)
+    assert_csr_close(G.P, P0)
