@@ -479,7 +479,7 @@ extern "C" int gt_nearest_landmark(gt_ctx* ctx, int64_t row0, int64_t row1, cons
     GT_HIP(ctx, hipMemcpyAsync(lmk.p, landmarks, size_t(n_landmark) * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
     const size_t lds = (size_t(32) * ctx->d + 32) * sizeof(double);
     {
-        StageSpan span(ctx, "landmark");
+        StageSpan span(ctx, "landmark_assign");
         if (ctx->dtype == GT_F32) {
             auto kern = nearest_landmark_kernel<float>;
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));

@@ -407,9 +407,26 @@ class LandmarkGraph(DataGraph):
                 raise NotImplementedError("graphtools_amd: random landmarking supports the euclidean metric only")
             rng = np.random.default_rng(self.random_state)
             landmark_indices = rng.choice(n_samples, self.n_landmark, replace=False)
+            if n_samples > 5000:
+                # sklearn euclidean_distances arithmetic: float64 GEMM form rounded to the input dtype, then sqrt -
+                # the same rounding the device kNN search emits.  Nearest landmark = 1-NN against the L landmark
+                # rows on the MFMA path; argmin's first-index rule is applied among the (few) nearest that tie
+                # after the float32 rounding.
+                X = np.ascontiguousarray(self.data_nu)
+                if X.dtype not in (np.float32, np.float64):
+                    X = X.astype(np.float64)
+                lm_ctx = _hip.Context(getattr(self, "device", 0) or 0)
+                try:
+                    lm_ctx.set_points(X[landmark_indices])
+                    k = int(min(4, self.n_landmark))
+                    dist, idx, _ = lm_ctx.knn_search(k, Y=X)
+                finally:
+                    lm_ctx.close()
+                tie = dist == dist[:, :1]
+                cand = np.where(tie, idx, np.iinfo(np.int64).max)
+                return cand.min(axis=1).astype(np.int64)
             self._bind_points()
-            mode = 1 if (n_samples > 5000 and self.distance == "euclidean") else 0
-            return self.hip.nearest_landmark(landmark_indices, mode).astype(np.int64)
+            return self.hip.nearest_landmark(landmark_indices, 0).astype(np.int64)
         # spectral front end on host scikit-learn, as in the reference (graphs.py:1215-1230)
         from sklearn.cluster import MiniBatchKMeans
         from sklearn.utils.extmath import randomized_svd
