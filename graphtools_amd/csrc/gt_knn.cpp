@@ -11,7 +11,8 @@ void gt_free_knn_work(gt_ctx* ctx) {
     if (!ctx->knn) return;
     KnnWork* k = ctx->knn;
     for (DevBuf* b : {&k->Qraw, &k->Qp, &k->qn, &k->lists, &k->counts, &k->thr_final, &k->cand_d2, &k->cand_j, &k->cand_n,
-                      &k->d2_lb, &k->fb_rows, &k->fb_count, &k->fb_scratch, &k->gflags, &k->prof})
+                      &k->d2_lb, &k->fb_rows, &k->fb_count, &k->fb_scratch, &k->gflags, &k->prof, &k->fb_qrows, &k->fb_thr, &k->fb_lists,
+                      &k->fb_counts, &k->fb_max})
         b->release();
     delete k;
     ctx->knn = nullptr;
@@ -58,6 +59,7 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
     k->q0 = q0;
     k->external = external;
     k->n_fallback = 0;
+    k->n_fallback_exhaustive = 0;
     const size_t lcap = size_t(64) * nt;
     GT_HIP(ctx, k->lists.reserve(size_t(k->nq_pad) * lcap * sizeof(uint64_t)));
     GT_HIP(ctx, k->counts.reserve(size_t(k->nq_pad) * sizeof(uint32_t)));
@@ -133,14 +135,72 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
     GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     k->n_fallback = n_fb;
     if (n_fb > 0) {
-        // batches sized so that the float64 distance scratch stays <= 2 GiB
-        int64_t batch = std::max<int64_t>(1, (int64_t(2) << 30) / (ctx->n * int64_t(sizeof(double))));
-        batch = std::min<int64_t>(batch, n_fb);
-        GT_HIP(ctx, k->fb_scratch.reserve(size_t(batch) * size_t(ctx->n) * sizeof(double)));
-        StageSpan span(ctx, "fallback", int(ceil_div64(n_fb, batch)));
-        for (int64_t off = 0; off < n_fb; off += batch) {
-            const int64_t rows = std::min<int64_t>(batch, n_fb - off);
-            GT_TRY(gt_launch_fallback(ctx, ra, rows, off, k->fb_scratch.as<double>()));
+        // Repair at MFMA speed: radius-mode candidate pass around each flagged query's need_m-th candidate key, exact
+        // keys + (key, index) selection on what it collected (gt_rerank.hip).  The exhaustive kernel is the last
+        // resort (a collected list that would need every database row).
+        GT_HIP(ctx, k->fb_max.reserve(2 * sizeof(uint32_t)));
+        const float* Qp_sel = external ? k->Qp.as<float>() : ctx->Yp.as<float>();
+        int64_t cap = 1024;
+        int64_t off = 0;
+        while (off < int64_t(n_fb)) {
+            // batch rows so that lists (8 B) + float64 scratch (8 B) stay within ~4 GiB
+            int64_t rows = std::min<int64_t>(int64_t(n_fb) - off, std::max<int64_t>(1, (int64_t(4) << 30) / (cap * 16)));
+            const int64_t rows_pad = ceil_div64(rows, bq) * bq;
+            GT_HIP(ctx, k->fb_qrows.reserve(size_t(rows) * sizeof(int32_t)));
+            GT_HIP(ctx, k->fb_thr.reserve(size_t(rows) * sizeof(float)));
+            GT_HIP(ctx, k->fb_counts.reserve(size_t(rows_pad) * sizeof(uint32_t)));
+            GT_HIP(ctx, k->fb_lists.reserve(size_t(rows_pad) * size_t(cap) * sizeof(uint64_t)));
+            uint32_t host_max[2] = {0, 0};
+            {
+                StageSpan span(ctx, "fallback", 3);
+                GT_TRY(gt_launch_fallback_thr(ctx, ra, rows, off, k->fb_qrows.as<int32_t>(), k->fb_thr.as<float>()));
+                SelectArgs fa;
+                fa.dp = ctx->DP;
+                fa.prec = ctx->prec;
+                fa.mode = 1;
+                fa.Yp = ctx->Yp.as<float>();
+                fa.hneg = ctx->hneg.as<float>();
+                fa.n_pad = ctx->n_pad;
+                fa.Qp = Qp_sel;
+                fa.qrows = k->fb_qrows.as<int32_t>();
+                fa.q0 = 0;
+                fa.nq = int32_t(rows);
+                fa.lists = k->fb_lists.as<uint64_t>();
+                fa.counts = k->fb_counts.as<uint32_t>();
+                fa.thr_in = k->fb_thr.as<float>();
+                fa.cap = int32_t(cap);
+                GT_TRY(gt_launch_select(ctx, fa));
+                GT_HIP(ctx, hipMemsetAsync(k->fb_max.p, 0, 2 * sizeof(uint32_t), ctx->stream));
+                GT_TRY(gt_launch_max_u32(ctx, k->fb_counts.as<uint32_t>(), rows, k->fb_max.as<uint32_t>()));
+                GT_HIP(ctx, hipMemcpyAsync(host_max, k->fb_max.p, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+                GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            }
+            if (int64_t(host_max[0]) > cap) {
+                if (cap >= ctx->n_pad) GT_FAIL(ctx, GT_E_STATE, "fallback: inconsistent collected count");
+                cap = std::min<int64_t>(ctx->n_pad, std::max<int64_t>(cap * 8, int64_t(host_max[0]) + 64));
+                continue;   // retry this batch with the larger capacity
+            }
+            if (cap >= ctx->n_pad / 2) {
+                // degenerate (nearly every row ties): the exhaustive kernel is as good as anything
+                GT_HIP(ctx, k->fb_scratch.reserve(size_t(rows) * size_t(ctx->n) * sizeof(double)));
+                StageSpan span(ctx, "fallback");
+                GT_TRY(gt_launch_fallback(ctx, ra, rows, off, k->fb_scratch.as<double>()));
+                k->n_fallback_exhaustive += rows;
+            } else {
+                GT_HIP(ctx, k->fb_scratch.reserve(size_t(rows) * size_t(cap) * sizeof(double)));
+                StageSpan span(ctx, "fallback");
+                GT_TRY(gt_launch_collected_select(ctx, ra, rows, off, k->fb_lists.as<uint64_t>(), k->fb_counts.as<uint32_t>(),
+                                                  int(cap), k->fb_scratch.as<double>(), k->fb_max.as<uint32_t>() + 1));
+                GT_HIP(ctx, hipMemcpyAsync(host_max, k->fb_max.p, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+                GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                if (host_max[1] > 0) {
+                    // never expected: fall back to the exhaustive kernel for the whole batch rather than trust it
+                    GT_HIP(ctx, k->fb_scratch.reserve(size_t(rows) * size_t(ctx->n) * sizeof(double)));
+                    GT_TRY(gt_launch_fallback(ctx, ra, rows, off, k->fb_scratch.as<double>()));
+                    k->n_fallback_exhaustive += rows;
+                }
+            }
+            off += rows;
         }
     }
     return GT_OK;

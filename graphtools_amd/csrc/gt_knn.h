@@ -20,6 +20,8 @@ struct KnnWork {
     DevBuf lists, counts, thr_final;
     DevBuf cand_d2, cand_j, cand_n, d2_lb;
     DevBuf fb_rows, fb_count, fb_scratch, gflags, prof;
+    DevBuf fb_qrows, fb_thr, fb_lists, fb_counts, fb_max;   // collected fallback
+    int64_t n_fallback_exhaustive = 0;
     int64_t n_fallback = 0;
 };
 
@@ -103,5 +105,9 @@ struct RerankArgs {
 };
 int gt_launch_rerank(gt_ctx* ctx, const RerankArgs& a);
 int gt_launch_fallback(gt_ctx* ctx, const RerankArgs& a, int64_t n_rows, int64_t row_off, double* scratch);
+int gt_launch_fallback_thr(gt_ctx* ctx, const RerankArgs& a, int64_t n_rows, int64_t row_off, int32_t* qrows, float* thr);
+int gt_launch_collected_select(gt_ctx* ctx, const RerankArgs& a, int64_t n_rows, int64_t row_off, const uint64_t* clists,
+                               const uint32_t* ccounts, int cap, double* scratch, uint32_t* fail);
+int gt_launch_max_u32(gt_ctx* ctx, const uint32_t* v, int64_t n, uint32_t* out);   // gt_sparse.hip (out pre-zeroed)
 int gt_launch_emit_knn(gt_ctx* ctx, const double* cand_d2, const uint32_t* cand_j, int MP, int64_t nq, int k,
                        int dtype, int metric, int64_t* out_idx, double* out_dist);

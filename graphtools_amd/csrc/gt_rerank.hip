@@ -220,6 +220,136 @@ __global__ __launch_bounds__(256) void fallback_kernel(const T* __restrict__ X, 
     }
 }
 
+// ---- collected fallback ---------------------------------------------------------------------------------
+// A flagged query (its table could not be proven complete - typically exact distance ties) is repaired without
+// touching all n rows: every database row with key <= K_M (the exact need_m-th candidate key, an upper bound of the
+// true need_m-th key) scores at least smin(K_M) - e, so one radius-mode candidate pass with that threshold collects
+// a superset of the answer at MFMA speed.  fallback_thr_kernel derives the thresholds, collected_select_kernel
+// (one workgroup per flagged query) evaluates the exact keys of the collected rows and selects the need_m smallest
+// (key, index) pairs with two bitwise searches (key, then index among the ties).
+__global__ __launch_bounds__(256) void fallback_thr_kernel(const int32_t* __restrict__ fb_rows, const int64_t n_rows,
+                                                           const int64_t row_off, const int64_t q0, const int MP,
+                                                           const int need_m, const int metric,
+                                                           const double* __restrict__ cand_d2,
+                                                           const double* __restrict__ qn,
+                                                           const double* __restrict__ ymax2p, const ErrModel err,
+                                                           int32_t* __restrict__ qrows, float* __restrict__ thr) {
+    const int64_t f = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (f >= n_rows) return;
+    const int64_t q = fb_rows[row_off + f];
+    const double key = cand_d2[q * MP + (need_m - 1)] * (1.0 + 1e-12);
+    const double qnq = qn[q0 + q];
+    const double y2 = *ymax2p;
+    const double e = err.rel * (0.5 * y2 + sqrt(qnq * y2)) + err.abs * (sqrt(qnq) + sqrt(y2));
+    const double smin = (metric == 1) ? (1.0 - key - 0.5 * y2) : 0.5 * (qnq - key);
+    const double x = (smin - e - 1e-9 * (qnq + y2)) / err.inv_sc2;
+    float t = float(x);
+    if (double(t) >= x) t = nextafterf(t, -INFINITY);
+    qrows[f] = int32_t(q0 + q);
+    thr[f] = t;
+}
+
+template <typename T, int NT2>
+__global__ __launch_bounds__(256) void collected_select_kernel(
+    const T* __restrict__ X, const int d, const double* __restrict__ xn, const T* __restrict__ Q,
+    const double* __restrict__ qn, const int64_t q0, const int32_t* __restrict__ fb_rows, const int64_t row_off,
+    const int metric, const int need_m, const uint64_t* __restrict__ clists, const uint32_t* __restrict__ ccounts,
+    const int cap, double* __restrict__ scratch, double* __restrict__ cand_d2, uint32_t* __restrict__ cand_j,
+    uint32_t* __restrict__ cand_n, double* __restrict__ d2_lb, uint32_t* __restrict__ fail) {
+    constexpr int MP = NT2 * 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    double* xs = reinterpret_cast<double*>(smem_raw);                             // [d]
+    unsigned long long* out_hi = reinterpret_cast<unsigned long long*>(xs + d);   // [MP]
+    uint32_t* out_lo = reinterpret_cast<uint32_t*>(out_hi + MP);                  // [MP]
+    int* red = reinterpret_cast<int*>(out_lo + MP);                               // [4]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int64_t f = blockIdx.x;
+    const int64_t q = fb_rows[row_off + f];
+    const int c = int(ccounts[f] < uint32_t(cap) ? ccounts[f] : uint32_t(cap));
+    if (c < need_m) {   // cannot happen if the threshold logic holds; reported, never silently accepted
+        if (tid == 0) atomicAdd(fail, 1u);
+        return;
+    }
+    const uint64_t* cl = clists + size_t(f) * cap;
+    double* sc = scratch + size_t(f) * cap;
+    const T* xrow = Q + (q0 + q) * int64_t(d);
+    for (int k = tid; k < d; k += 256) xs[k] = double(xrow[k]);
+    __syncthreads();
+    const double qnq = qn[q0 + q];
+    for (int e = tid; e < c; e += 256) {
+        const uint32_t j = cand_index(cl[e]);
+        const double dot = dot_row<T>(xs, X + int64_t(j) * d, d);
+        sc[e] = gt_pair_key(qnq, dot, xn[j], metric);
+    }
+    __syncthreads();
+    auto block_count = [&](int local) {
+        local = wave_sum_i32(local);
+        __syncthreads();
+        if (lane == 0) red[w] = local;
+        __syncthreads();
+        return red[0] + red[1] + red[2] + red[3];
+    };
+    // need_m-th smallest key
+    unsigned long long v = 0ull;
+    for (int b = 63; b >= 0; --b) {
+        const unsigned long long trial = v | ((1ull << b) - 1ull);
+        int cnt = 0;
+        for (int e = tid; e < c; e += 256) cnt += ((unsigned long long)__double_as_longlong(sc[e]) <= trial) ? 1 : 0;
+        if (block_count(cnt) < need_m) v |= (1ull << b);
+    }
+    int cl_local = 0;
+    for (int e = tid; e < c; e += 256) cl_local += ((unsigned long long)__double_as_longlong(sc[e]) < v) ? 1 : 0;
+    const int c_less = block_count(cl_local);
+    const int quota = need_m - c_less;
+    // quota-th smallest index among the ties at v
+    uint32_t jv = 0u;
+    for (int b = 31; b >= 0; --b) {
+        const uint32_t trial = jv | ((1u << b) - 1u);
+        int cnt = 0;
+        for (int e = tid; e < c; e += 256)
+            cnt += ((unsigned long long)__double_as_longlong(sc[e]) == v && cand_index(cl[e]) <= trial) ? 1 : 0;
+        if (block_count(cnt) < quota) jv |= (1u << b);
+    }
+    // collect the need_m winners (unordered), then sort them in wave 0
+    __shared__ int slot_sh;
+    if (tid == 0) slot_sh = 0;
+    for (int p = tid; p < MP; p += 256) {
+        out_hi[p] = kInfBits;
+        out_lo[p] = 0xFFFFFFFFu;
+    }
+    __syncthreads();
+    for (int e = tid; e < c; e += 256) {
+        const unsigned long long key = (unsigned long long)__double_as_longlong(sc[e]);
+        const uint32_t j = cand_index(cl[e]);
+        if (key < v || (key == v && j <= jv)) {
+            const int s = atomicAdd(&slot_sh, 1);
+            if (s < MP) {
+                out_hi[s] = key;
+                out_lo[s] = j;
+            }
+        }
+    }
+    __syncthreads();
+    if (w == 0) {
+        uint64_t hi[NT2], lo[NT2];
+#pragma unroll
+        for (int u = 0; u < NT2; ++u) {
+            hi[u] = out_hi[u * 64 + lane];
+            lo[u] = out_lo[u * 64 + lane];
+        }
+        wave_bitonic_asc_pair<NT2>(hi, lo, lane);
+#pragma unroll
+        for (int u = 0; u < NT2; ++u) {
+            cand_d2[size_t(q) * MP + u * 64 + lane] = __longlong_as_double((long long)hi[u]);
+            cand_j[size_t(q) * MP + u * 64 + lane] = uint32_t(lo[u]);
+        }
+        if (lane == 0) {
+            cand_n[q] = uint32_t(need_m);
+            d2_lb[q] = __longlong_as_double((long long)v);   // everything strictly closer is in the table
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void emit_knn_kernel(const double* __restrict__ cand_d2,
                                                        const uint32_t* __restrict__ cand_j, const int MP,
                                                        const int64_t nq, const int k, const int dtype, const int metric,
@@ -296,4 +426,33 @@ int gt_launch_emit_knn(gt_ctx* ctx, const double* cand_d2, const uint32_t* cand_
                        dtype, metric, out_idx, out_dist);
     GT_HIP(ctx, hipGetLastError());
     return GT_OK;
+}
+
+int gt_launch_fallback_thr(gt_ctx* ctx, const RerankArgs& a, int64_t n_rows, int64_t row_off, int32_t* qrows, float* thr) {
+    hipLaunchKernelGGL(fallback_thr_kernel, dim3((unsigned)ceil_div64(n_rows, 256)), dim3(256), 0, ctx->stream, a.fb_rows,
+                       n_rows, row_off, a.q0, a.MP, a.need_m, a.metric, a.cand_d2, a.qn, a.ymax2, a.err, qrows, thr);
+    GT_HIP(ctx, hipGetLastError());
+    return GT_OK;
+}
+
+template <typename T>
+static int collected_t(gt_ctx* ctx, const RerankArgs& a, int64_t n_rows, int64_t row_off, const uint64_t* clists,
+                       const uint32_t* ccounts, int cap, double* scratch, uint32_t* fail) {
+    const size_t lds = size_t(a.d) * 8 + size_t(a.MP) * 12 + 16;
+    if (a.MP == 128)
+        hipLaunchKernelGGL((collected_select_kernel<T, 2>), dim3((unsigned)n_rows), dim3(256), lds, ctx->stream, (const T*)a.X,
+                           a.d, a.xn, (const T*)a.Q, a.qn, a.q0, a.fb_rows, row_off, a.metric, a.need_m, clists, ccounts, cap,
+                           scratch, a.cand_d2, a.cand_j, a.cand_n, a.d2_lb, fail);
+    else
+        hipLaunchKernelGGL((collected_select_kernel<T, 8>), dim3((unsigned)n_rows), dim3(256), lds, ctx->stream, (const T*)a.X,
+                           a.d, a.xn, (const T*)a.Q, a.qn, a.q0, a.fb_rows, row_off, a.metric, a.need_m, clists, ccounts, cap,
+                           scratch, a.cand_d2, a.cand_j, a.cand_n, a.d2_lb, fail);
+    GT_HIP(ctx, hipGetLastError());
+    return GT_OK;
+}
+
+int gt_launch_collected_select(gt_ctx* ctx, const RerankArgs& a, int64_t n_rows, int64_t row_off, const uint64_t* clists,
+                               const uint32_t* ccounts, int cap, double* scratch, uint32_t* fail) {
+    if (a.dtype == GT_F32) return collected_t<float>(ctx, a, n_rows, row_off, clists, ccounts, cap, scratch, fail);
+    return collected_t<double>(ctx, a, n_rows, row_off, clists, ccounts, cap, scratch, fail);
 }

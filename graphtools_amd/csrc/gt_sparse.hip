@@ -642,6 +642,12 @@ void launch_affinity(gt_ctx* ctx, GraphState* g, KnnWork* k, int binary, double 
 
 }  // namespace
 
+int gt_launch_max_u32(gt_ctx* ctx, const uint32_t* v, int64_t n, uint32_t* out) {
+    hipLaunchKernelGGL(max_u32_kernel, dim3(64), dim3(256), 0, ctx->stream, v, n, out);
+    GT_HIP(ctx, hipGetLastError());
+    return GT_OK;
+}
+
 int gt_exclusive_scan_i32(gt_ctx* ctx, const int32_t* a, int64_t n, int64_t* out) {
     DevBuf tmp;
     int rc = exclusive_scan(ctx, a, nullptr, n, out, tmp);

@@ -130,3 +130,29 @@ def test_device_primitives(hip_ctx):
             exp = np.zeros(64 * nt, dtype=np.uint64)
             exp[:n] = np.sort(keys)[::-1]
             assert np.array_equal(out, exp)
+
+
+def test_tie_heavy_lattice_collected_fallback(hip_ctx):
+    """Integer lattice: squared distances are small integers, so the k-th neighbour ties with many others and
+    the candidate table cannot be proven complete for most rows.  They are repaired by the radius-mode
+    collection + exact (key, index) selection at MFMA speed; results must equal the oracle's (index order on ties)."""
+    rng = np.random.default_rng(5)
+    X = rng.integers(0, 4, size=(12000, 12)).astype(np.float32)
+    hip_ctx.set_points(X)
+    d, i, flags = hip_ctx.knn_search(100)
+    assert flags & 4
+    d0, i0 = oracle.kneighbors(X, None, 100)
+    assert np.array_equal(d, d0)
+    assert np.array_equal(i, i0)
+    # and the graph on top of it
+    p, keep = hip_ctx.make_params(60, 10, 1e-4, None, 1.0, None, "+", None, 0)
+    import warnings
+    from scipy import sparse
+    nnz, fl = hip_ctx.graph_build(p)
+    Kd, Ki, Kp = hip_ctx.graph_fetch_csr(0)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        K0, P0 = oracle.knn_graph(X, knn=60, decay=10)
+    K0 = sparse.csr_matrix(K0); K0.sort_indices()
+    assert np.array_equal(Kp, K0.indptr) and np.array_equal(Ki, K0.indices)
+    np.testing.assert_allclose(Kd, K0.data, rtol=1e-9)
