@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgraphtools_amd.so")
+# GRAPHTOOLS_AMD_LIB: development override (kernel-variant experiments, tools/build_variant.py)
+LIB_PATH = os.environ.get("GRAPHTOOLS_AMD_LIB") or os.path.join(_HERE, "libgraphtools_amd.so")
 
 GT_F32, GT_F64 = 0, 1
 SYMM = {None: 0, "none": 0, "+": 1, "*": 2, "mnn": 3}

@@ -165,6 +165,18 @@ int gt_set_option(gt_ctx* ctx, const char* name, const char* value) {
         ctx->n = 0;   // points must be bound again
         return GT_OK;
     }
+    if (k == "select_samp_stride") {
+        ctx->samp_stride = std::atoi(value);
+        return GT_OK;
+    }
+    if (k == "select_samp_end") {
+        ctx->samp_end = std::atoi(value);
+        return GT_OK;
+    }
+    if (k == "select_samp_keep") {
+        ctx->samp_keep = std::atoi(value);
+        return GT_OK;
+    }
     if (k == "dbg_select") {
         ctx->dbg_select = std::atoi(value);
         return GT_OK;

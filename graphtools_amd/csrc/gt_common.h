@@ -99,6 +99,9 @@ struct gt_ctx {
     double maxabs = 0.0; // max |x_ij| of the bound points
     int32_t metric = 0;  // 0 euclidean, 1 cosine (points are row-normalised copies; distance = 1 - x.y)
     DevBuf X_norm;       // cosine: normalised points in the input dtype
+    int32_t samp_stride = 16; // candidate pass: threshold-seeding phase over every samp_stride-th tile (<= 1: off)
+    int32_t samp_keep = 0;    //   list budget of that phase (0: the number of neighbours wanted, at least 16)
+    int32_t samp_end = -1;    //   list budget at the end of that phase (0: none, -1: same as samp_keep)
     int32_t dbg_select = 0;   // experiment switches forwarded to the candidate kernel (results invalid when set)
     int64_t n_pad = 0;   // rows of the working copy (multiple of the db tile)
     DevBuf Yp;           // working copy: [n_pad] rows of 4*DP bytes (float32, or float16 hi plane | lo plane)

@@ -90,6 +90,19 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
     sa.counts = k->counts.as<uint32_t>();
     sa.thr_out = k->thr_final.as<float>();
     sa.dbg = ctx->dbg_select;
+    {
+        // threshold-seeding phase: worthwhile when the stream is long and the wanted count is well below M'
+        int keep = std::max(ctx->samp_keep > 0 ? ctx->samp_keep : 16, need_m);
+        keep += keep & 1;
+        const int64_t ntiles = ctx->n_pad / gt_select_bn(ctx->DP);
+        if (ctx->samp_stride > 1 && keep <= MP / 2 && ntiles >= int64_t(8) * ctx->samp_stride) {
+            sa.samp_stride = ctx->samp_stride;
+            sa.samp_keep = keep;
+            int end = ctx->samp_end < 0 ? keep : std::max(ctx->samp_end > 0 ? ctx->samp_end : 0, ctx->samp_end > 0 ? need_m : 0);
+            end += end & 1;
+            sa.samp_end = end <= MP / 2 ? end : 0;
+        }
+    }
     if (ctx->dbg_select & 64) {
         GT_HIP(ctx, k->prof.reserve(size_t(k->nq_pad / bq) * 4 * 8 * sizeof(unsigned long long)));
         GT_HIP(ctx, hipMemsetAsync(k->prof.p, 0, size_t(k->nq_pad / bq) * 4 * 8 * sizeof(unsigned long long), ctx->stream));

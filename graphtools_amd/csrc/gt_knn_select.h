@@ -20,6 +20,9 @@ struct SelectArgs {
     float* thr_out = nullptr;       // selection mode: final admission threshold per query [nq_pad]
     int32_t cap = 0;                // radius mode: list capacity per query
     unsigned long long* prof = nullptr;   // optional per-wave cycle counters [nblocks*4][8] (development)
+    int32_t samp_stride = 0;        // selection: > 1 = visit every samp_stride-th tile first with a keep-samp_keep budget
+    int32_t samp_keep = 0;          //   (must be >= the number of neighbours wanted, even, <= 8*nt)
+    int32_t samp_end = 0;           //   > 0: after the last sampled tile every list is cut to its samp_end best
     int32_t dbg = 0;                // experiment switches (bit 0: no survivors, bit 1: no compaction sort)
 };
 

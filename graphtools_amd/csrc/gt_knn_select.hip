@@ -37,6 +37,13 @@
 #ifndef GT_SEL_SETPRIO
 #define GT_SEL_SETPRIO 0
 #endif
+// development ablations (tools/build_variant.py; results are invalid when set):
+//   1 seeds not read from LDS   2 A fragments read once per tile   4 no staging / barrier after the first tile
+//   8 no admission test   16 staging but no barrier   32 barrier but no staging   64 stream 16 L2-resident tiles
+#ifndef GT_SEL_EXP
+#define GT_SEL_EXP 0
+#endif
+
 
 namespace {
 
@@ -133,8 +140,7 @@ __device__ __forceinline__ void list_store(uint64_t* p, uint64_t v) {
 // Returns the threshold implied by the selection (-inf when nothing had to be dropped).
 template <int NT, bool CONTIG>
 __device__ __forceinline__ float compact_list(uint64_t* __restrict__ lp, const uint32_t n0, const uint32_t n1,
-                                              const int lane, uint32_t& kept) {
-    constexpr uint32_t MKEEP = 16 * NT;
+                                              const int lane, uint32_t& kept, const uint32_t MKEEP = 16 * NT) {
     constexpr uint32_t HALF = 32 * NT;
     uint64_t key[NT];
     uint32_t ord[NT];
@@ -187,7 +193,8 @@ __global__ __launch_bounds__(256, 2) void knn_select_kernel(
     const float* __restrict__ Yp, const float* __restrict__ hneg, const float* __restrict__ Qp,
     const int32_t* __restrict__ qrows, const int64_t q0, const int32_t nq, const int32_t ntiles,
     uint64_t* __restrict__ lists, uint32_t* __restrict__ counts, const float* __restrict__ thr_in,
-    float* __restrict__ thr_out, const int32_t cap, const int32_t dbg, unsigned long long* __restrict__ prof) {
+    float* __restrict__ thr_out, const int32_t cap, const int32_t dbg, unsigned long long* __restrict__ prof,
+    const int32_t samp_stride, const int32_t samp_keep, const int32_t samp_end) {
     using C = SelCfg<DP>;
     unsigned long long t_adm = 0, t_cmp = 0, t_bar = 0, n_cmp = 0, n_adm = 0;
     constexpr int QT = C::QT, BQ = C::BQ, BN = C::BN, LDP = C::LDP;
@@ -239,7 +246,7 @@ __global__ __launch_bounds__(256, 2) void knn_select_kernel(
     float stage_h = 0.f;
 #define GT_STAGE_LOAD(T_, HALF_)                                                                          \
     {                                                                                                     \
-        const float4* src_ = reinterpret_cast<const float4*>(Yp + size_t(T_) * BN * DP) + (HALF_) * HF4;   \
+        const float4* src_ = reinterpret_cast<const float4*>(Yp + size_t((GT_SEL_EXP & 64) ? ((T_) & 15) : (T_)) * BN * DP) + (HALF_) * HF4;   \
         _Pragma("unroll") for (int u_ = 0; u_ < HF4_PER_THREAD; ++u_) {                                    \
             const int f = tid + u_ * 256;                                                                 \
             stage[u_] = (f < HF4) ? src_[f] : make_float4(0.f, 0.f, 0.f, 0.f);                            \
@@ -261,15 +268,26 @@ __global__ __launch_bounds__(256, 2) void knn_select_kernel(
         if ((HALF_) == 0 && tid < BN) hn[(BUF_) * BN + tid] = stage_h;                                    \
     }
 
-    GT_STAGE_LOAD(t_begin, 0);
+    // Tile order (MODE 0 with samp_stride > 1): phase A visits every samp_stride-th tile with a small list
+    // budget (keep the samp_keep best), which gives every query a tight admission threshold after 1/samp_stride
+    // of the stream; phase B streams the remaining tiles with the normal budget.  Any order and any
+    // keep >= the number of neighbours wanted is correct - thresholds only ever rise, and every entry dropped
+    // or rejected scored <= the final threshold - the split only cuts the number of admissions (~3x).
+    const int n_a = (MODE == 0 && samp_stride > 1) ? (ntiles + samp_stride - 1) / samp_stride : 0;
+#define GT_TILE_OF(IT_) \
+    ((IT_) < n_a ? (IT_) * samp_stride : (n_a ? ((IT_) - n_a) + ((IT_) - n_a) / (samp_stride - 1) + 1 : (IT_)))
+
+    GT_STAGE_LOAD(GT_TILE_OF(t_begin), 0);
     GT_STAGE_STORE(0, 0);
-    GT_STAGE_LOAD(t_begin, 1);
+    GT_STAGE_LOAD(GT_TILE_OF(t_begin), 1);
     GT_STAGE_STORE(0, 1);
     __syncthreads();
 
-    for (int t = t_begin; t < t_end; ++t) {
-        const int buf = (t - t_begin) & 1;
-        if (t + 1 < t_end) GT_STAGE_LOAD(t + 1, 0);
+    for (int it = t_begin; it < t_end; ++it) {
+        const int buf = (GT_SEL_EXP & (4 | 32)) ? 0 : ((it - t_begin) & 1);
+        const int t = GT_TILE_OF(it);
+        const int t_next = GT_TILE_OF(it + 1);
+        if (!(GT_SEL_EXP & (4 | 32)) && it + 1 < t_end) GT_STAGE_LOAD(t_next, 0);
         const float* tb = tile + buf * C::TILE_FLOATS;
         const float* hb = hn + buf * BN;
         const uint32_t tbase = uint32_t(t) * BN;
@@ -290,7 +308,8 @@ __global__ __launch_bounds__(256, 2) void knn_select_kernel(
 #define GT_SEED(U_)                                                                                        \
     {                                                                                                      \
         _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) {                                                 \
-            const float4 hv_ = *reinterpret_cast<const float4*>(hb + ((U_) / QT) * 32 + 8 * g_ + 4 * h);   \
+            const float4 hv_ = (GT_SEL_EXP & 1) ? make_float4(0.f, 0.f, 0.f, 0.f) :                        \
+                *reinterpret_cast<const float4*>(hb + ((U_) / QT) * 32 + 8 * g_ + 4 * h);                  \
             accp[(U_) % 3][4 * g_ + 0] = hv_.x;                                                            \
             accp[(U_) % 3][4 * g_ + 1] = hv_.y;                                                            \
             accp[(U_) % 3][4 * g_ + 2] = hv_.z;                                                            \
@@ -302,20 +321,21 @@ __global__ __launch_bounds__(256, 2) void knn_select_kernel(
         for (int u = 0; u <= NU; ++u) {
             const int sb = u / QT, qt = u % QT;              // the unit whose chain is issued now (u < NU)
             const int psb = (u - 1) / QT, pqt = (u - 1) % QT;   // the unit whose results are examined now (u > 0)
-            if (u == NU / 2 && t + 1 < t_end) {
+            if (!(GT_SEL_EXP & (4 | 32)) && u == NU / 2 && it + 1 < t_end) {
                 // first half of the next tile has landed: park it in the other LDS buffer, fetch the second half
                 GT_STAGE_STORE(buf ^ 1, 0);
-                GT_STAGE_LOAD(t + 1, 1);
+                GT_STAGE_LOAD(t_next, 1);
             }
             if (u < NU) {
-                if (qt == 0 && sb + 1 < NSUB) afr[(sb + 1) & 1].load(tb + ((sb + 1) * 32 + li) * LDP, h);
+                if (!(GT_SEL_EXP & 2) && qt == 0 && sb + 1 < NSUB) afr[(sb + 1) & 1].load(tb + ((sb + 1) * 32 + li) * LDP, h);
                 if (u + 1 < NU) GT_SEED(u + 1);
-                mma_chain<DP>(afr[sb & 1], bq[qt], accp[u % 3]);
+                mma_chain<DP>(afr[(GT_SEL_EXP & 2) ? 0 : (sb & 1)], bq[qt], accp[u % 3]);
             }
             if (u > 0) {
                 // predicates from plain compares (no fmax: it would canonicalise every MFMA output)
-                const float tq = thr[pqt];
+                const float tq = (GT_SEL_EXP & 8) ? INFINITY : thr[pqt];
                 const f32x16& pa = accp[(u - 1) % 3];
+                if (GT_SEL_EXP & 8) asm volatile("" ::"v"(pa));   // keep the matrix work alive
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
                     hg[g] = (pa[4 * g] > tq) | (pa[4 * g + 1] > tq) | (pa[4 * g + 2] > tq) | (pa[4 * g + 3] > tq);
@@ -364,12 +384,17 @@ __global__ __launch_bounds__(256, 2) void knn_select_kernel(
 
         if (MODE == 0) {
             // ---- list maintenance: lane (li, h) owns half h of query (qt, li) ----
+            const bool phase_a = it < n_a;
+            const bool end_a = samp_end > 0 && it + 1 == n_a;   // last sampled tile: settle the seed threshold
+            const uint32_t mkeep = end_a ? uint32_t(samp_end) : phase_a ? uint32_t(samp_keep) : uint32_t(MKEEP);
+            const uint32_t trig = phase_a ? uint32_t(samp_keep) / 2u + 24u : uint32_t(TRIGH);
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt) {
-                const unsigned long long full = __ballot(fill[qt] > uint32_t(TRIGH));
+                const unsigned long long full =
+                    end_a ? __ballot(fill[qt] + __shfl_xor(fill[qt], 32) > mkeep) : __ballot(fill[qt] > trig);
                 uint32_t need = uint32_t(full) | uint32_t(full >> 32);
                 if ((dbg & 18) && need) {   // experiment: no selection, just pretend the lists were compacted
-                    if (need & (1u << li)) fill[qt] = uint32_t(MKEEP / 2);
+                    if (need & (1u << li)) fill[qt] = mkeep / 2u;
                     need = 0;
                 }
                 if (need) {
@@ -383,11 +408,11 @@ __global__ __launch_bounds__(256, 2) void knn_select_kernel(
                         const uint32_t n1 = __shfl(fill[qt], L + 32);
                         uint64_t* lp = lists + size_t(qblock + (w * QT + qt) * 32 + L) * lstride;
                         uint32_t kept;
-                        const float t = compact_list<NT, false>(lp, n0, n1, lane, kept);
+                        const float tc = compact_list<NT, false>(lp, n0, n1, lane, kept, mkeep);
                         if (li == L) {
-                            const uint32_t k0 = kept < uint32_t(MKEEP / 2) ? kept : uint32_t(MKEEP / 2);
+                            const uint32_t k0 = kept < mkeep / 2u ? kept : mkeep / 2u;
                             fill[qt] = h ? kept - k0 : k0;
-                            thr[qt] = fmaxf(thr[qt], t);
+                            thr[qt] = fmaxf(thr[qt], tc);
                         }
                     }
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -396,8 +421,8 @@ __global__ __launch_bounds__(256, 2) void knn_select_kernel(
             }
         }
 
-        if (t + 1 < t_end) GT_STAGE_STORE(buf ^ 1, 1);
-        {
+        if (!(GT_SEL_EXP & (4 | 32)) && it + 1 < t_end) GT_STAGE_STORE(buf ^ 1, 1);
+        if (!(GT_SEL_EXP & (4 | 16))) {
             const unsigned long long ts_ = prof ? __builtin_readcyclecounter() : 0ull;
             __syncthreads();
             if (prof) t_bar += __builtin_readcyclecounter() - ts_;
@@ -454,7 +479,8 @@ int launch_one(gt_ctx* ctx, const SelectArgs& a) {
                                         int(lds_bytes)));
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)nblocks, (unsigned)nsplit), dim3(256), lds_bytes, ctx->stream, a.Yp,
-                       a.hneg, a.Qp, a.qrows, a.q0, a.nq, ntiles, a.lists, a.counts, a.thr_in, a.thr_out, a.cap, a.dbg, a.prof);
+                       a.hneg, a.Qp, a.qrows, a.q0, a.nq, ntiles, a.lists, a.counts, a.thr_in, a.thr_out, a.cap, a.dbg, a.prof,
+                       a.samp_stride, a.samp_keep, a.samp_end);
     GT_HIP(ctx, hipGetLastError());
     return GT_OK;
 }

@@ -1,0 +1,28 @@
+#!/usr/bin/env python
+"""Development: link a variant of libgraphtools_amd.so whose (precision 1, DP 64) candidate kernel is compiled
+with extra -D flags, for ablation runs (GRAPHTOOLS_AMD_LIB=<path> python tools/...).
+usage: build_variant.py NAME -DGT_SEL_EXP=1 [...]   ->  graphtools_amd/_variants/libgt_NAME.so"""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from graphtools_amd import _build  # noqa: E402
+
+if __name__ == "__main__":
+    name, flags = sys.argv[1], sys.argv[2:]
+    _build.build()
+    out_dir = os.path.join(_build.HERE, "_variants")
+    os.makedirs(out_dir, exist_ok=True)
+    prec, dp = 1, 64
+    obj = os.path.join(out_dir, "sel_%s.o" % name)
+    cmd = [_build._hipcc()] + _build.COMMON_FLAGS + ["-DGT_SEL_PREC=%d" % prec, "-DGT_SEL_DP=%d" % dp] + flags + [
+        "-c", os.path.join(_build.CSRC, "gt_knn_select.hip"), "-o", obj]
+    subprocess.run(cmd, check=True)
+    objs = []
+    for src, o, extra in _build._units():
+        objs.append(obj if o == "gt_knn_select_p%d_dp%d.o" % (prec, dp) else os.path.join(_build.OBJ, o))
+    lib = os.path.join(out_dir, "libgt_%s.so" % name)
+    subprocess.run([_build._hipcc(), "--offload-arch=" + _build.ARCH, "-shared", "-fPIC", "-o", lib] + objs, check=True)
+    print(lib)

@@ -1,0 +1,45 @@
+#!/usr/bin/env python
+"""Development probe: effect of the threshold-seeding phase (select_samp_stride / select_samp_keep) on the
+candidate pass at benchmark size.  usage: gpu_samp_ablate.py N "stride:keep,stride:keep,..." [dbg]"""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from graphtools_amd import _hip  # noqa: E402
+from tools.gpu_perf import make_mix  # noqa: E402
+
+if __name__ == "__main__":
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
+    combos = [tuple(int(v) for v in c.split(":")) for c in (sys.argv[2] if len(sys.argv) > 2 else "0:0,16:16").split(",")]
+    dbg = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+    d = 64
+    X = make_mix(n, d, 1)
+    out = []
+    for combo in combos:
+        stride, keep = combo[0], combo[1]
+        end = combo[2] if len(combo) > 2 else 0
+        ctx = _hip.Context(0)
+        ctx.set_option("select_samp_stride", str(stride))
+        ctx.set_option("select_samp_keep", str(keep))
+        ctx.set_option("select_samp_end", str(end))
+        if dbg:
+            ctx.set_option("dbg_select", str(dbg))
+        ctx.set_points(X)
+        p, hold = ctx.make_params(15, 40, 1e-4, None, 1.0, None, "+", None, 0)
+        best = None
+        for r in range(2):
+            nnz, fl = ctx.graph_build(p)
+            st = {s: round(ctx.stage_ms(s), 3) for s in ("knn_select", "rerank", "fallback", "radius", "affinity", "symmetrize", "normalize")}
+            if best is None or st["knn_select"] < best["knn_select"]:
+                best = st
+        rec = {"n": n, "stride": stride, "keep": keep, "end": end, "nnz": nnz, "flags": fl, "stage_ms": best, "stats": ctx.graph_stats()}
+        print(json.dumps(rec), flush=True)
+        out.append(rec)
+        ctx.close()
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "gpu_samp_ablate.json"), "w") as f:
+        json.dump(out, f, indent=1)

@@ -17,6 +17,11 @@ for prec, dbg in [(p_, d_) for p_ in precs for d_ in dbgs]:
     ctx = _hip.Context(0)
     ctx.set_option("knn_precision", prec)
     ctx.set_option("dbg_select", dbg)
+    if os.environ.get("GT_SAMP"):   # "stride:keep"
+        st_, kp_, en_ = (os.environ["GT_SAMP"].split(":") + ["0"])[:3]
+        ctx.set_option("select_samp_end", en_)
+        ctx.set_option("select_samp_stride", st_)
+        ctx.set_option("select_samp_keep", kp_)
     ctx.set_points(X)
     best = 1e9
     for rep in range(3):
