@@ -34,6 +34,10 @@
 #ifndef GT_SEL_PIPE
 #define GT_SEL_PIPE 1
 #endif
+// the admission path is laid out of line (cold): the common case - no lane beat its threshold - falls through
+#ifndef GT_SEL_LIKELY
+#define GT_SEL_LIKELY 0
+#endif
 #ifndef GT_SEL_SETPRIO
 #define GT_SEL_SETPRIO 0
 #endif
@@ -49,18 +53,35 @@ namespace {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-template <int DP>
+// GLDS: the database tile goes global -> LDS directly (global_load_lds_dwordx4, 1 KiB per wave instruction, no
+// staging registers, no ds_write pass).  The LDS image is then lane-linear, so rows cannot be padded; bank
+// conflicts are avoided by an XOR swizzle of the 16-byte chunk index with a function of the row, applied to the
+// per-lane SOURCE address of the load and to the ds_read address alike (power-of-two row sizes only).
+#ifndef GT_SEL_GLDS
+#define GT_SEL_GLDS 1
+#endif
+template <int DP, int PREC>
 struct SelCfg {
     static constexpr int QT = (DP <= 64) ? 2 : 1;       // 32-row query tiles per wave
     static constexpr int BQ = 4 * QT * 32;              // query rows per workgroup
     static constexpr int BN = (DP <= 64) ? 128 : 64;    // database rows per LDS tile
-    static constexpr int LDP = DP + 4;                  // LDS row stride (dwords): conflict-free ds_read_b128
+    static constexpr bool GLDS = GT_SEL_GLDS && PREC == 1 && (DP == 16 || DP == 32 || DP == 64 || DP == 128);
+    static constexpr int LDP = GLDS ? DP : DP + 4;      // LDS row stride (dwords); padded: conflict-free ds_read_b128
     static constexpr int NF4 = BN * DP / 4;             // 16-byte units per tile (a row is 4*DP bytes in both layouts)
     static constexpr int F4_PER_THREAD = (NF4 + 255) / 256;
     static constexpr int TILE_FLOATS = BN * LDP;
     static constexpr size_t LDS_BYTES =
         size_t(2) * TILE_FLOATS * 4 + size_t(2) * BN * 4;
+    // swizzle geometry (GLDS)
+    static constexpr int RB = 4 * DP;                   // row bytes
+    static constexpr int CPR = RB / 16;                 // 16-byte chunks per row
+    static constexpr int RDIV = (RB >= 256) ? 1 : 256 / RB;   // rows sharing one 256-byte bank row
+    static constexpr int SMASK = (CPR < 16 ? CPR : 16) - 1;
+    static constexpr int RPP = 1024 / RB > 0 ? 1024 / RB : 1; // rows per 1 KiB piece (RB <= 512)
+    static constexpr int NPW = (BN * RB / 1024) / 4;    // pieces per wave and tile
+    static_assert(!GLDS || (BN * RB) % 4096 == 0, "tile must split into 1 KiB pieces over 4 waves");
 };
+__device__ __forceinline__ int swz_of_row(int row, int rdiv, int smask) { return (row / rdiv) & smask; }
 
 // ---- operand fragments -------------------------------------------------------------------------
 // PREC 0: row = DP floats; lane (li, h) holds features [h*DP/2, (h+1)*DP/2)  (one per MFMA k-step)
@@ -73,7 +94,7 @@ template <int DP>
 struct Frag<DP, 0> {
     static constexpr int KS = DP / 2;
     float v[KS];
-    __device__ __forceinline__ void load(const float* row, int h) {
+    __device__ __forceinline__ void load(const float* row, int h, int = 0) {
         const float4* p = reinterpret_cast<const float4*>(row + h * KS);
 #pragma unroll
         for (int c = 0; c < KS / 4; ++c) {
@@ -90,12 +111,12 @@ template <int DP>
 struct Frag<DP, 1> {
     static constexpr int NS = DP / 16;
     f16x8 hi[NS], lo[NS];
-    __device__ __forceinline__ void load(const float* row, int h) {
+    __device__ __forceinline__ void load(const float* row, int h, int swz = 0) {
         const f16x8* p = reinterpret_cast<const f16x8*>(row);   // 16-byte units: hi plane = units [0, DP/8)
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
-            hi[s] = p[2 * s + h];
-            lo[s] = p[DP / 8 + 2 * s + h];
+            hi[s] = p[(2 * s + h) ^ swz];
+            lo[s] = p[(DP / 8 + 2 * s + h) ^ swz];
         }
     }
 };
@@ -195,7 +216,7 @@ __global__ __launch_bounds__(256, 2) void knn_select_kernel(
     uint64_t* __restrict__ lists, uint32_t* __restrict__ counts, const float* __restrict__ thr_in,
     float* __restrict__ thr_out, const int32_t cap, const int32_t dbg, unsigned long long* __restrict__ prof,
     const int32_t samp_stride, const int32_t samp_keep, const int32_t samp_end) {
-    using C = SelCfg<DP>;
+    using C = SelCfg<DP, PREC>;
     unsigned long long t_adm = 0, t_cmp = 0, t_bar = 0, n_cmp = 0, n_adm = 0;
     constexpr int QT = C::QT, BQ = C::BQ, BN = C::BN, LDP = C::LDP;
     constexpr int LCAP = 64 * NT;        // list capacity in selection mode (two halves of HALF slots)
@@ -268,6 +289,30 @@ __global__ __launch_bounds__(256, 2) void knn_select_kernel(
         if ((HALF_) == 0 && tid < BN) hn[(BUF_) * BN + tid] = stage_h;                                    \
     }
 
+    // direct global -> LDS staging of one tile (GLDS): wave wu copies pieces [wu*NPW, (wu+1)*NPW) of 1 KiB; lane L of
+    // piece p fills LDS bytes [p*1024 + 16 L, +16) = (row p*RPP + L/CPR, physical chunk L%CPR), i.e. it fetches
+    // the logical chunk (L%CPR) ^ swz(row) of that row.  Seeds: waves [0, BN/64) copy 64 floats each.
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef const __attribute__((address_space(1))) void glb_void;
+    const int wu = __builtin_amdgcn_readfirstlane(w);
+#define GT_GLDS_ISSUE(T_, BUF_)                                                                            \
+    {                                                                                                      \
+        const char* gt_ = reinterpret_cast<const char*>(Yp) + size_t((GT_SEL_EXP & 64) ? ((T_) & 15) : (T_)) * BN * C::RB; \
+        char* lt_ = reinterpret_cast<char*>(tile + (BUF_) * C::TILE_FLOATS);                               \
+        uint32_t lv_ = uint32_t(lane);                                                                     \
+        asm volatile("" : "+v"(lv_));   /* recompute the lane offsets per tile instead of pinning 8 registers */ \
+        _Pragma("unroll") for (int i_ = 0; i_ < C::NPW; ++i_) {                                            \
+            const uint32_t p_ = uint32_t(wu * C::NPW + i_);                                                \
+            const uint32_t r_ = p_ * C::RPP + lv_ / C::CPR;                                                \
+            const uint32_t c_ = (lv_ % C::CPR) ^ ((r_ / C::RDIV) & C::SMASK);                              \
+            __builtin_amdgcn_global_load_lds((glb_void*)(gt_ + (r_ * C::RB + c_ * 16u)),                   \
+                                             (lds_void*)(lt_ + p_ * 1024u), 16, 0, 0);                     \
+        }                                                                                                  \
+        if (wu < BN / 64)                                                                                  \
+            __builtin_amdgcn_global_load_lds((glb_void*)(hneg + size_t(T_) * BN + uint32_t(wu * 64) + lv_), \
+                                             (lds_void*)(hn + (BUF_) * BN + wu * 64), 4, 0, 0);            \
+    }
+
     // Tile order (MODE 0 with samp_stride > 1): phase A visits every samp_stride-th tile with a small list
     // budget (keep the samp_keep best), which gives every query a tight admission threshold after 1/samp_stride
     // of the stream; phase B streams the remaining tiles with the normal budget.  Any order and any
@@ -277,17 +322,29 @@ __global__ __launch_bounds__(256, 2) void knn_select_kernel(
 #define GT_TILE_OF(IT_) \
     ((IT_) < n_a ? (IT_) * samp_stride : (n_a ? ((IT_) - n_a) + ((IT_) - n_a) / (samp_stride - 1) + 1 : (IT_)))
 
-    GT_STAGE_LOAD(GT_TILE_OF(t_begin), 0);
-    GT_STAGE_STORE(0, 0);
-    GT_STAGE_LOAD(GT_TILE_OF(t_begin), 1);
-    GT_STAGE_STORE(0, 1);
+    if constexpr (C::GLDS) {
+        GT_GLDS_ISSUE(GT_TILE_OF(t_begin), 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        GT_STAGE_LOAD(GT_TILE_OF(t_begin), 0);
+        GT_STAGE_STORE(0, 0);
+        GT_STAGE_LOAD(GT_TILE_OF(t_begin), 1);
+        GT_STAGE_STORE(0, 1);
+    }
     __syncthreads();
+    const int aswz = C::GLDS ? swz_of_row(li, C::RDIV, C::SMASK) : 0;   // sub-tiles start at multiples of 32 rows
 
     for (int it = t_begin; it < t_end; ++it) {
         const int buf = (GT_SEL_EXP & (4 | 32)) ? 0 : ((it - t_begin) & 1);
         const int t = GT_TILE_OF(it);
         const int t_next = GT_TILE_OF(it + 1);
-        if (!(GT_SEL_EXP & (4 | 32)) && it + 1 < t_end) GT_STAGE_LOAD(t_next, 0);
+        if (!(GT_SEL_EXP & (4 | 32)) && it + 1 < t_end) {
+            if constexpr (C::GLDS) {
+                GT_GLDS_ISSUE(t_next, buf ^ 1);   // every wave left buf^1 at the barrier that ended the previous tile
+            } else {
+                GT_STAGE_LOAD(t_next, 0);
+            }
+        }
         const float* tb = tile + buf * C::TILE_FLOATS;
         const float* hb = hn + buf * BN;
         const uint32_t tbase = uint32_t(t) * BN;
@@ -300,7 +357,7 @@ __global__ __launch_bounds__(256, 2) void knn_select_kernel(
         constexpr int NSUB = BN / 32;
         constexpr int NU = NSUB * QT;
         Frag<DP, PREC> afr[2];
-        afr[0].load(tb + li * LDP, h);
+        afr[0].load(tb + li * LDP, h, aswz);
         // three accumulator sets rotate: unit u accumulates into accp[u%3] while the predicates of u-1 read
         // accp[(u-1)%3] and the seeds (-|y|^2/2) of u+1 are fetched from LDS into accp[(u+1)%3]
         f32x16 accp[3];
@@ -316,18 +373,43 @@ __global__ __launch_bounds__(256, 2) void knn_select_kernel(
             accp[(U_) % 3][4 * g_ + 3] = hv_.w;                                                            \
         }                                                                                                  \
     }
+#define GT_ADMIT(PA_, HG_, PSB_, PQT_)                                                                     \
+    if (__builtin_expect(__ballot((HG_)[0] | (HG_)[1] | (HG_)[2] | (HG_)[3]) != 0ull, GT_SEL_LIKELY)) {   /* wave-uniform */ \
+        const float tq_ = thr[PQT_];                                                                       \
+        const unsigned long long ts_ = prof ? __builtin_readcyclecounter() : 0ull;                         \
+        const int ql = (w * QT + (PQT_)) * 32 + li;                                                        \
+        uint64_t* lp = lists + size_t(qblock + ql) * lstride + (MODE == 0 ? size_t(h) * HALF : size_t(0)); \
+        _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                    \
+            if (__ballot((HG_)[g])) {                                                                      \
+                _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                            \
+                    const float v = (PA_)[4 * g + e];                                                      \
+                    if (v > tq_) {                                                                         \
+                        const uint32_t j = tbase + uint32_t((PSB_) * 32 + 8 * g + 4 * h + e);              \
+                        if (MODE == 0) {                                                                   \
+                            list_store(lp + fill[PQT_], cand_pack(v, j));                                  \
+                            fill[PQT_] += 1u;                                                              \
+                        } else {                                                                           \
+                            const uint32_t slot = atomicAdd(&counts[qblock + ql], 1u);                     \
+                            if (slot < uint32_t(cap)) lp[slot] = cand_pack(v, j);                          \
+                        }                                                                                  \
+                    }                                                                                      \
+                }                                                                                          \
+            }                                                                                              \
+        }                                                                                                  \
+        if (prof) { t_adm += __builtin_readcyclecounter() - ts_; n_adm += 1; }                             \
+    }
         GT_SEED(0);
 #pragma unroll
         for (int u = 0; u <= NU; ++u) {
             const int sb = u / QT, qt = u % QT;              // the unit whose chain is issued now (u < NU)
             const int psb = (u - 1) / QT, pqt = (u - 1) % QT;   // the unit whose results are examined now (u > 0)
-            if (!(GT_SEL_EXP & (4 | 32)) && u == NU / 2 && it + 1 < t_end) {
+            if (!C::GLDS && !(GT_SEL_EXP & (4 | 32)) && u == NU / 2 && it + 1 < t_end) {
                 // first half of the next tile has landed: park it in the other LDS buffer, fetch the second half
                 GT_STAGE_STORE(buf ^ 1, 0);
                 GT_STAGE_LOAD(t_next, 1);
             }
             if (u < NU) {
-                if (!(GT_SEL_EXP & 2) && qt == 0 && sb + 1 < NSUB) afr[(sb + 1) & 1].load(tb + ((sb + 1) * 32 + li) * LDP, h);
+                if (!(GT_SEL_EXP & 2) && qt == 0 && sb + 1 < NSUB) afr[(sb + 1) & 1].load(tb + ((sb + 1) * 32 + li) * LDP, h, aswz);
                 if (u + 1 < NU) GT_SEED(u + 1);
                 mma_chain<DP>(afr[(GT_SEL_EXP & 2) ? 0 : (sb & 1)], bq[qt], accp[u % 3]);
             }
@@ -351,37 +433,8 @@ __global__ __launch_bounds__(256, 2) void knn_select_kernel(
                 }
             }
 #endif
-            if (u > 0) {
-                const float tq = thr[pqt];
-                const f32x16& pa = accp[(u - 1) % 3];
-                if (__ballot(hg[0] | hg[1] | hg[2] | hg[3])) {   // wave-uniform: most units admit nothing
-                    const unsigned long long ts_ = prof ? __builtin_readcyclecounter() : 0ull;
-                    const int ql = (w * QT + pqt) * 32 + li;
-                    uint64_t* lp = lists + size_t(qblock + ql) * lstride + (MODE == 0 ? size_t(h) * HALF : size_t(0));
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        if (__ballot(hg[g])) {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                const float v = pa[4 * g + e];
-                                if (v > tq) {
-                                    const uint32_t j = tbase + uint32_t(psb * 32 + 8 * g + 4 * h + e);
-                                    if (MODE == 0) {
-                                        list_store(lp + fill[pqt], cand_pack(v, j));
-                                        fill[pqt] += 1u;
-                                    } else {
-                                        const uint32_t slot = atomicAdd(&counts[qblock + ql], 1u);
-                                        if (slot < uint32_t(cap)) lp[slot] = cand_pack(v, j);
-                                    }
-                                }
-                            }
-                        }
-                    }
-                    if (prof) { t_adm += __builtin_readcyclecounter() - ts_; n_adm += 1; }
-                }
-            }
+            if (u > 0) GT_ADMIT(accp[(u - 1) % 3], hg, psb, pqt);
         }
-
         if (MODE == 0) {
             // ---- list maintenance: lane (li, h) owns half h of query (qt, li) ----
             const bool phase_a = it < n_a;
@@ -421,7 +474,11 @@ __global__ __launch_bounds__(256, 2) void knn_select_kernel(
             }
         }
 
-        if (!(GT_SEL_EXP & (4 | 32)) && it + 1 < t_end) GT_STAGE_STORE(buf ^ 1, 1);
+        if constexpr (C::GLDS) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the next tile are in LDS
+        } else {
+            if (!(GT_SEL_EXP & (4 | 32)) && it + 1 < t_end) GT_STAGE_STORE(buf ^ 1, 1);
+        }
         if (!(GT_SEL_EXP & (4 | 16))) {
             const unsigned long long ts_ = prof ? __builtin_readcyclecounter() : 0ull;
             __syncthreads();
@@ -459,7 +516,7 @@ __global__ __launch_bounds__(256, 2) void knn_select_kernel(
 
 template <int DP, int NT, int MODE, int PREC>
 int launch_one(gt_ctx* ctx, const SelectArgs& a) {
-    using C = SelCfg<DP>;
+    using C = SelCfg<DP, PREC>;
     const int64_t nblocks = ceil_div64(a.nq, C::BQ);
     const int ntiles = int(a.n_pad / C::BN);
     int nsplit = 1;
