@@ -66,6 +66,8 @@ _SIGNATURES = {
     "gt_graph_build": (_c.c_int, [_c.c_void_p, _c.POINTER(KnnParams), _c.POINTER(_c.c_int64), _c.POINTER(_c.c_uint32)]),
     "gt_graph_extend": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int32, _c.POINTER(KnnParams),
                                    _c.POINTER(_c.c_int64), _c.POINTER(_c.c_uint32)]),
+    "gt_csr_graph_build": (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int32,
+                                      _c.c_double, _c.c_double, _c.POINTER(_c.c_int64), _c.POINTER(_c.c_uint32)]),
     "gt_graph_rows": (_c.c_int, [_c.c_void_p, _c.POINTER(_c.c_int64), _c.POINTER(_c.c_int64), _c.POINTER(_c.c_int64)]),
     "gt_graph_fetch_csr": (_c.c_int, [_c.c_void_p, _c.c_int32, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int32]),
     "gt_graph_fetch_vec": (_c.c_int, [_c.c_void_p, _c.c_int32, _c.c_void_p, _c.c_int32]),
@@ -233,6 +235,21 @@ class Context:
         flags = ctypes.c_uint32(0)
         self._check(self.lib.gt_graph_extend(self.h, _ptr(Y), Y.shape[0], 0, ctypes.byref(params), ctypes.byref(nnz),
                                              ctypes.byref(flags)), "gt_graph_extend")
+        return nnz.value, flags.value
+
+    def csr_graph_build(self, K0, kernel_symm, theta, anisotropy):
+        """symmetrise + anisotropy + row-normalise a host CSR kernel on the device; returns (nnz, flags)"""
+        K0 = K0.tocsr()
+        K0.sort_indices()
+        indptr = np.ascontiguousarray(K0.indptr, dtype=np.int64)
+        indices = np.ascontiguousarray(K0.indices, dtype=np.int32)
+        data = np.ascontiguousarray(K0.data, dtype=np.float64)
+        nnz = ctypes.c_int64(0)
+        flags = ctypes.c_uint32(0)
+        self._check(self.lib.gt_csr_graph_build(self.h, K0.shape[0], _ptr(indptr), _ptr(indices), _ptr(data),
+                                                SYMM[kernel_symm], float(theta if theta is not None else 1.0),
+                                                float(anisotropy), ctypes.byref(nnz), ctypes.byref(flags)),
+                    "gt_csr_graph_build")
         return nnz.value, flags.value
 
     def graph_begin(self, params, world, rank, row_splits):

@@ -1,7 +1,7 @@
 """``graphtools_amd.Graph`` - the reference's factory (graphtools/api.py:14-295) over the HIP classes.
 
 Same signature and class-selection rules; combinations that are outside the hot path
-(batch-corrected MNN graphs, PyGSP inheritance) raise ``NotImplementedError``.
+(PyGSP inheritance, MNN landmark graphs) raise ``NotImplementedError``.
 """
 import warnings
 
@@ -74,7 +74,9 @@ def Graph(
                 "MNNGraph does not support precomputed values. Use `graphtype='exact'` and `sample_idx=None` or "
                 "`precomputed=None`"
             )
-        raise NotImplementedError("graphtools_amd: MNNGraph (batch correction) is outside the accelerated hot path")
+        if n_landmark is not None:
+            raise NotImplementedError("graphtools_amd: MNNLandmarkGraph is not on the HIP path")
+        base = "MNN"
     elif graphtype == "exact":
         if sample_idx is not None:
             raise ValueError(
@@ -103,6 +105,10 @@ def Graph(
     )
     if base == "kNN":
         params["knn_max"] = knn_max
+    elif base == "MNN":
+        # reference: api.py:253-283 passes only what MNNGraph.__init__ and its parents accept
+        del params["bandwidth_scale"]
+        params.update(sample_idx=sample_idx, beta=beta, adaptive_k=adaptive_k)
     else:
         params["precomputed"] = precomputed
     if n_landmark is not None:

@@ -620,6 +620,31 @@ int exclusive_scan(gt_ctx* ctx, const int32_t* a, const int32_t* b, int64_t n, i
     return GT_OK;
 }
 
+// ---- C0: ingest an arbitrary CSR kernel (gt_csr_graph_build) into the radius-list layout the pipeline reads ----
+__global__ __launch_bounds__(256) void csr_ingest_kernel(const int64_t n, const int64_t* __restrict__ indptr,
+                                                         const int32_t* __restrict__ indices,
+                                                         const double* __restrict__ data, const int32_t rcap,
+                                                         const int count_owners, uint64_t* __restrict__ rlists,
+                                                         double* __restrict__ rK, uint32_t* __restrict__ rcounts,
+                                                         int32_t* __restrict__ rowsrc, int32_t* __restrict__ lenN,
+                                                         int32_t* __restrict__ ownercnt) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const int64_t s0 = indptr[i];
+    const int32_t len = int32_t(indptr[i + 1] - s0);
+    for (int32_t e = lane; e < len; e += 64) {
+        rlists[size_t(i) * rcap + e] = cand_pack(0.f, uint32_t(indices[s0 + e]));
+        rK[size_t(i) * rcap + e] = data[s0 + e];
+    }
+    if (lane == 0) {
+        rcounts[i] = uint32_t(len);
+        rowsrc[i] = int32_t(i);
+        lenN[i] = len;
+        if (count_owners) ownercnt[i] = len;
+    }
+}
+
 Splits make_splits(const GraphState* g) {
     Splits sp;
     sp.world = g->world;
@@ -1060,6 +1085,109 @@ extern "C" int gt_graph_build(gt_ctx* ctx, const gt_knn_params* params, int64_t*
         GT_TRY(gt_graph_emit(ctx, g->selfbuf.p));
     }
     return gt_graph_finish(ctx, sendc[0] > 0 ? g->selfbuf.p : nullptr, sendc[0], out_nnz, flags);
+}
+
+/* Symmetrisation, anisotropy and row normalisation of a caller-assembled square kernel (CSR, unique ascending or
+ * unordered columns per row, non-negative values): the tail of BaseGraph._build_kernel + BaseGraph.P for graphs whose
+ * unsymmetrised kernel is a composition of kNN kernels (MNNGraph.build_kernel, graphs.py:1857-1936). */
+extern "C" int gt_csr_graph_build(gt_ctx* ctx, int64_t n, const int64_t* indptr, const int32_t* indices,
+                                  const double* data, int32_t kernel_symm, double theta, double anisotropy,
+                                  int64_t* out_nnz, uint32_t* flags) {
+    if (!ctx || !indptr || n <= 0) return GT_E_ARG;
+    GT_HIP(ctx, hipSetDevice(ctx->device));
+    ctx->reset_stages();
+    if (n >= (int64_t(1) << 31)) GT_FAIL(ctx, GT_E_LIMIT, "gt_csr_graph_build: too many rows");
+    if (indptr[0] != 0) GT_FAIL(ctx, GT_E_ARG, "gt_csr_graph_build: indptr[0] must be 0");
+    const int64_t nnz0 = indptr[n];
+    int64_t maxlen = 1;
+    for (int64_t i = 0; i < n; ++i) {
+        const int64_t len = indptr[i + 1] - indptr[i];
+        if (len < 0) GT_FAIL(ctx, GT_E_ARG, "gt_csr_graph_build: indptr must be ascending");
+        maxlen = std::max(maxlen, len);
+    }
+    if (nnz0 > 0 && (!indices || !data)) GT_FAIL(ctx, GT_E_ARG, "gt_csr_graph_build: indices / data are NULL");
+    if (double(n) * double(maxlen) * 16.0 > 128e9)
+        GT_FAIL(ctx, GT_E_LIMIT, "gt_csr_graph_build: padded row layout would exceed 128 GB");
+    if (!ctx->knn) ctx->knn = new KnnWork();
+    KnnWork* k = ctx->knn;
+    k->n_fallback = 0;
+    k->n_fallback_exhaustive = 0;
+    GT_HIP(ctx, k->gflags.reserve(sizeof(uint32_t)));
+    GT_HIP(ctx, hipMemsetAsync(k->gflags.p, 0, sizeof(uint32_t), ctx->stream));
+    if (!ctx->graph) ctx->graph = new GraphState();
+    GraphState* g = ctx->graph;
+    g->p = gt_knn_params{};
+    g->p.knn = 1;
+    g->p.kernel_symm = kernel_symm;
+    g->p.theta = theta;
+    g->p.anisotropy = anisotropy;
+    g->world = 1;
+    g->rank = 0;
+    g->splits = {0, n};
+    g->r0 = 0;
+    g->r1 = n;
+    g->nloc = n;
+    g->begun = false;
+    g->finished = false;
+    g->external = true;   // rows are not tied to bound points
+    g->n_over = 0;
+    g->radius_retries = 0;
+    g->rcap = int32_t(maxlen);
+    const int count_owners = (kernel_symm != GT_SYMM_NONE) ? 1 : 0;
+    DevBuf d_indptr, d_indices, d_data;
+    int rc = GT_OK;
+    do {
+        hipError_t e = d_indptr.reserve(size_t(n + 1) * sizeof(int64_t));
+        if (e == hipSuccess) e = d_indices.reserve(size_t(std::max<int64_t>(nnz0, 1)) * sizeof(int32_t));
+        if (e == hipSuccess) e = d_data.reserve(size_t(std::max<int64_t>(nnz0, 1)) * sizeof(double));
+        if (e == hipSuccess) e = g->rlists.reserve(size_t(n) * size_t(maxlen) * sizeof(uint64_t));
+        if (e == hipSuccess) e = g->rK.reserve(size_t(n) * size_t(maxlen) * sizeof(double));
+        if (e == hipSuccess) e = g->rcounts.reserve(size_t(n) * sizeof(uint32_t));
+        if (e == hipSuccess) e = g->rowsrc.reserve(size_t(n) * sizeof(int32_t));
+        if (e == hipSuccess) e = g->lenN.reserve(size_t(n) * sizeof(int32_t));
+        if (e == hipSuccess) e = g->lenT.reserve(size_t(n) * sizeof(int32_t));
+        if (e == hipSuccess) e = g->cursor.reserve(size_t(n) * sizeof(int32_t));
+        if (e == hipSuccess) e = g->ownercnt.reserve(size_t(n) * sizeof(int32_t));
+        if (e == hipSuccess) e = g->bw.reserve(size_t(n) * sizeof(double));
+        if (e == hipSuccess) e = g->flags.reserve(sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMemsetAsync(g->flags.p, 0, sizeof(uint32_t), ctx->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(g->bw.p, 0, size_t(n) * sizeof(double), ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_indptr.p, indptr, size_t(n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess && nnz0 > 0)
+            e = hipMemcpyAsync(d_indices.p, indices, size_t(nnz0) * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess && nnz0 > 0)
+            e = hipMemcpyAsync(d_data.p, data, size_t(nnz0) * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) {
+            StageSpan span(ctx, "symmetrize");
+            hipLaunchKernelGGL(csr_ingest_kernel, dim3((unsigned)ceil_div64(n, 4)), dim3(256), 0, ctx->stream, n,
+                               d_indptr.as<int64_t>(), d_indices.as<int32_t>(), d_data.as<double>(), g->rcap, count_owners,
+                               g->rlists.as<uint64_t>(), g->rK.as<double>(), g->rcounts.as<uint32_t>(),
+                               g->rowsrc.as<int32_t>(), g->lenN.as<int32_t>(), g->ownercnt.as<int32_t>());
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) {
+            ctx->set_error(std::string("gt_csr_graph_build: ") + hipGetErrorString(e));
+            rc = GT_E_HIP;
+        }
+    } while (0);
+    d_indptr.release();
+    d_indices.release();
+    d_data.release();
+    GT_TRY(rc);
+    g->send_counts_host.assign(1, 0);
+    if (count_owners) {
+        GT_HIP(ctx, g->ownerpos.reserve(size_t(n + 1) * sizeof(int64_t)));
+        GT_TRY(exclusive_scan(ctx, g->ownercnt.as<int32_t>(), nullptr, n, g->ownerpos.as<int64_t>(), g->scan_tmp));
+        g->send_counts_host[0] = nnz0;
+    }
+    g->begun = true;
+    const int64_t sendc = g->send_counts_host[0];
+    if (sendc > 0) {
+        GT_HIP(ctx, g->selfbuf.reserve(size_t(sendc) * sizeof(Triplet)));
+        GT_TRY(gt_graph_emit(ctx, g->selfbuf.p));
+    }
+    return gt_graph_finish(ctx, sendc > 0 ? g->selfbuf.p : nullptr, sendc, out_nnz, flags);
 }
 
 extern "C" int gt_graph_rows(const gt_ctx* ctx, int64_t* row0, int64_t* row1, int64_t* nnz) {

@@ -3,6 +3,7 @@
 ``kNNGraph``          graphtools/graphs.py:562-982   -> gt_set_points + gt_graph_build
 ``TraditionalGraph``  graphtools/graphs.py:1320-1704 -> gt_dense_graph_build
 ``LandmarkGraph``     graphtools/graphs.py:985-1317  -> gt_nearest_landmark / gt_landmark_partial
+``MNNGraph``          graphtools/graphs.py:1707-1966 -> per-batch gt_graph_build + gt_graph_extend blocks + gt_csr_graph_build
 
 Same constructor arguments, attribute names, warnings and errors as the reference for this
 path; the numerics run on the MI355X.  No CPU implementation exists behind these classes.
@@ -559,6 +560,129 @@ class TraditionalGraph(DataGraph):
 
     def build_kernel_to_data(self, Y, knn=None, bandwidth=None, bandwidth_scale=None):
         raise NotImplementedError("graphtools_amd: out-of-sample extension is not on the HIP path yet")
+
+
+class MNNGraph(DataGraph):
+    """Mutual nearest neighbours graph for batch correction (reference: graphs.py:1707-1966).
+
+    A composition of the accelerated path: every batch gets a ``kNNGraph`` (kernel_symm='+') on the device, every
+    ordered pair of batches a ``build_kernel_to_data`` block, each block row is scaled by
+    ``min(1, within / between) * beta`` and the assembled kernel goes back to the device for symmetrisation,
+    anisotropy and the diffusion operator (``gt_csr_graph_build``).
+    """
+
+    def __init__(self, data, sample_idx, knn=5, beta=1, n_pca=None, decay=None, adaptive_k=None, bandwidth=None,
+                 distance="euclidean", thresh=1e-4, n_jobs=1, **kwargs):
+        # reference: graphs.py:1743-1790
+        self.beta = beta
+        self.sample_idx = sample_idx
+        self.samples, self.n_cells = np.unique(self.sample_idx, return_counts=True)
+        self.knn = knn
+        self.decay = decay
+        self.distance = distance
+        self.bandwidth = bandwidth
+        self.thresh = thresh
+        self.n_jobs = n_jobs
+        if sample_idx is None:
+            raise ValueError("sample_idx must be given. For a graph without batch correction, use kNNGraph.")
+        elif len(sample_idx) != data.shape[0]:
+            raise ValueError(
+                "sample_idx ({}) must be the same length as data ({})".format(len(sample_idx), data.shape[0])
+            )
+        elif len(self.samples) == 1:
+            raise ValueError("sample_idx must contain more than one unique value")
+        if adaptive_k is not None:
+            warnings.warn("`adaptive_k` has been deprecated. Using fixed knn.", DeprecationWarning)
+        if decay is not None and thresh <= 0:
+            raise NotImplementedError(
+                "graphtools_amd.MNNGraph: thresh=0 with a decaying kernel makes every block an exact dense graph; "
+                "only the sparse (kNN) composition is on the HIP path"
+            )
+        super().__init__(data, n_pca=n_pca, n_jobs=n_jobs, **kwargs)
+
+    def _check_symmetrization(self, kernel_symm, theta):
+        # reference: graphs.py:1792-1803
+        if (kernel_symm == "theta" or kernel_symm == "mnn") and theta is not None and \
+                not isinstance(theta, numbers.Number):
+            raise TypeError("Expected `theta` as a float. Got {}.".format(type(theta)))
+        else:
+            super()._check_symmetrization(kernel_symm, theta)
+
+    def get_params(self):
+        params = super().get_params()
+        params.update({"beta": self.beta, "knn": self.knn, "decay": self.decay, "bandwidth": self.bandwidth,
+                       "distance": self.distance, "thresh": self.thresh, "n_jobs": self.n_jobs})
+        return params
+
+    def set_params(self, **params):
+        # reference: graphs.py:1822-1868
+        if "beta" in params and params["beta"] != self.beta:
+            raise ValueError("Cannot update beta. Please create a new graph")
+        for arg in ["knn", "decay", "distance", "thresh", "bandwidth"]:
+            if arg in params and params[arg] != getattr(self, arg):
+                raise ValueError("Cannot update {}. Please create a new graph".format(arg))
+        for arg in ["n_jobs", "random_state", "verbose"]:
+            if arg in params:
+                self.__setattr__(arg, params[arg])
+                for g in getattr(self, "subgraphs", []):
+                    g.set_params(**{arg: params[arg]})
+        super().set_params(**params)
+        return self
+
+    def build_kernel(self):
+        """The unsymmetrised MNN kernel (reference: graphs.py:1870-1946) as a scipy CSR matrix."""
+        n = self.data_nu.shape[0]
+        masks = [np.asarray(self.sample_idx) == s for s in self.samples]
+        index = [np.nonzero(m)[0] for m in masks]
+        self.subgraphs = []
+        for m in masks:
+            self.subgraphs.append(kNNGraph(
+                self.data_nu[m], n_pca=None, knn=self.knn, decay=self.decay, bandwidth=self.bandwidth,
+                distance=self.distance, thresh=self.thresh, verbose=self.verbose, random_state=self.random_state,
+                n_jobs=self.n_jobs, kernel_symm="+", initialize=True, device=self.device,
+            ))
+            self.subgraphs[-1].kernel_degree   # cache the row sums before the context is reused for cross kernels
+        rows, cols, vals = [], [], []
+        for i, X in enumerate(self.subgraphs):
+            Kii = X.K.tocoo()
+            rows.append(index[i][Kii.row])
+            cols.append(index[i][Kii.col])
+            vals.append(Kii.data)
+            within_batch_norm = np.asarray(X.kernel_degree).flatten()
+            for j, Y in enumerate(self.subgraphs):
+                if i == j:
+                    continue
+                Kij = Y.build_kernel_to_data(X.data_nu, knn=self.knn)
+                between_batch_norm = np.array(np.sum(Kij, 1)).flatten()
+                scale = np.minimum(1, within_batch_norm / between_batch_norm) * self.beta
+                Kij = Kij.multiply(scale[:, None]).tocoo()
+                rows.append(index[i][Kij.row])
+                cols.append(index[j][Kij.col])
+                vals.append(Kij.data)
+        K = sparse.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(n, n))
+        return K
+
+    def _build_kernel(self):
+        K0 = self.build_kernel()
+        nnz, flags = self.hip.csr_graph_build(K0, self.kernel_symm, self.theta, self.anisotropy)
+        data, indices, indptr = self.hip.graph_fetch_csr(_hip.CSR_K)
+        n = K0.shape[0]
+        if nnz < 2**31:
+            indptr = indptr.astype(np.int32)
+        self._emit_build_warnings(flags)
+        return sparse.csr_matrix((data, indices, indptr), shape=(n, n))
+
+    def _fetch_diff_op(self):
+        data, _, _ = self.hip.graph_fetch_csr(_hip.CSR_P)
+        K = self._kernel
+        return sparse.csr_matrix((data, K.indices, K.indptr), shape=K.shape)
+
+    def _fetch_degree(self):
+        return self.hip.graph_fetch_vec(_hip.VEC_DEGREE)
+
+    def build_kernel_to_data(self, Y, theta=None):
+        # reference: graphs.py:1948-1966
+        raise NotImplementedError
 
 
 class kNNLandmarkGraph(kNNGraph, LandmarkGraph):

@@ -145,6 +145,14 @@ int gt_graph_anisotropy(gt_ctx* ctx, const double* degree_all_dev);
 /* single-GPU convenience: begin + emit + finish with an internal buffer */
 int gt_graph_build(gt_ctx* ctx, const gt_knn_params* params, int64_t* out_nnz, uint32_t* flags);
 
+/* Tail of BaseGraph._build_kernel + BaseGraph.P (base.py:534-555, 557-592, 629-646) for a kernel the caller assembled
+ * from device-built blocks - MNNGraph.build_kernel (graphs.py:1857-1936) composes per-batch kNN kernels and
+ * cross-batch build_kernel_to_data blocks: host CSR (int64 indptr, int32 indices, float64 data, n x n, unique columns
+ * per row, values >= 0) -> symmetrisation (kernel_symm, theta), anisotropy, row normalisation on the device.  Results
+ * are fetched like those of gt_graph_build. */
+int gt_csr_graph_build(gt_ctx* ctx, int64_t n, const int64_t* indptr, const int32_t* indices, const double* data,
+                       int32_t kernel_symm, double theta, double anisotropy, int64_t* out_nnz, uint32_t* flags);
+
 /* Out-of-sample kernel, replaces kNNGraph.build_kernel_to_data(Y) + the normalize() of DataGraph.extend_to_data
  * (graphs.py:819-982, base.py:1166-1193): rows = the m query points Y (same dtype / width as the bound points,
  * host or device), columns = the n bound points; `knn` neighbours (no +1), no symmetrisation.  K_yx and its

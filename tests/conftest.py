@@ -66,3 +66,14 @@ def hip_ctx():
     ctx = _hip.Context(0)
     yield ctx
     ctx.close()
+
+
+def mnn_params(z):
+    """keyword arguments of the MNN fixtures (tools/make_golden_mnn.py); NaN encodes None"""
+    def val(k):
+        v = z["param_" + k]
+        return None if np.isnan(v) else v.item()
+    kw = {k: val(k) for k in ("knn", "decay", "thresh", "beta", "theta", "anisotropy")}
+    kw["knn"] = int(kw["knn"])
+    kw["kernel_symm"] = str(z["param_kernel_symm"])
+    return kw

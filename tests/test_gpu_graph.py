@@ -10,7 +10,7 @@ from scipy import sparse
 
 import graphtools_amd
 import oracle
-from conftest import golden_csr, golden_params, load_golden, make_gauss, make_manifold, make_mix
+from conftest import golden_csr, golden_params, load_golden, make_gauss, make_manifold, make_mix, mnn_params
 from graphtools_amd import _hip
 
 pytestmark = pytest.mark.gpu
@@ -258,3 +258,50 @@ def test_out_of_sample_extension(maker, kw):
     # the graph's own kernel / operator are still served correctly afterwards
     K0, P0 = oracle.knn_graph(X, knn=knn, decay=decay)
     assert_csr_close(G.P, P0)
+
+
+# ---- MNNGraph: composition of device kernels + gt_csr_graph_build ---------------------------------------------
+@pytest.mark.parametrize("name", ["g9_mnn_decay", "g9b_mnn_binary_theta", "g9c_mnn_aniso"])
+def test_mnn_graph_matches_reference(name):
+    z = load_golden(name)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        G = graphtools_amd.Graph(z["X"], sample_idx=z["sample_idx"], n_pca=None, verbose=0, **mnn_params(z))
+    assert type(G).__name__ == "MNNGraph" and len(G.subgraphs) == 3
+    assert_csr_close(G.K, golden_csr(z, "K"))
+    np.testing.assert_allclose(G.P.data, z["P_data"], rtol=RTOL, atol=0)
+    K0 = G.build_kernel()
+    K0.sort_indices()
+    assert_csr_close(K0, golden_csr(z, "K0"))
+    np.testing.assert_allclose(np.asarray(G.P.sum(axis=1)).ravel(), 1.0, rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("symm,theta,aniso", [("+", None, 0.0), ("*", None, 0.0), ("mnn", 0.25, 0.0), ("+", None, 1.0),
+                                              (None, None, 0.0)])
+def test_csr_graph_build_vs_oracle(symm, theta, aniso):
+    """gt_csr_graph_build on an arbitrary non-negative CSR (ragged rows, some empty, some longer than the
+    register-sort limit of 512 after the union with the transpose)."""
+    rng = np.random.default_rng(5)
+    n = 1500
+    A = sparse.random(n, n, density=0.01, random_state=7, format="lil", data_rvs=lambda k: rng.uniform(0.1, 1.0, k))
+    A[3, :] = 0                                   # an empty row
+    A[10, rng.choice(n, 700, replace=False)] = rng.uniform(0.1, 1.0, 700)    # a long row
+    A[:, 11] = 0
+    A[rng.choice(n, 650, replace=False), 11] = 0.5                            # a long column (long row of A^T)
+    A.setdiag(1.0)
+    A = sparse.csr_matrix(A)
+    A.eliminate_zeros()
+    ctx = _hip.Context(0)
+    nnz, flags = ctx.csr_graph_build(A, symm, theta, aniso)
+    Kd, Ki, Kp = ctx.graph_fetch_csr(_hip.CSR_K)
+    Pd, _, _ = ctx.graph_fetch_csr(_hip.CSR_P)
+    K = sparse.csr_matrix((Kd, Ki, Kp), shape=(n, n))
+    Ko = sparse.csr_matrix(oracle.apply_anisotropy(oracle.symmetrize_kernel(A, symm, theta), aniso))
+    Ko.sort_indices()
+    if symm == "*":
+        Ko.eliminate_zeros()
+    assert nnz == Ko.nnz
+    assert_csr_close(K, Ko, rtol=1e-12)
+    Po = oracle.diff_op(Ko)
+    np.testing.assert_allclose(Pd, Po.data, rtol=1e-12, atol=0)
+    ctx.close()

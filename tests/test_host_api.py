@@ -80,8 +80,36 @@ def test_get_set_params_guards():
     assert (g.n_jobs, g.random_state, g.verbose) == (4, 13, 2)
 
 
-def test_mnn_and_pygsp_are_out_of_scope():
-    with pytest.raises(NotImplementedError):
-        graphtools_amd.Graph(X, sample_idx=np.arange(60) % 2, initialize=False)
+def test_pygsp_and_mnn_landmarks_are_out_of_scope():
     with pytest.raises(NotImplementedError):
         graphtools_amd.Graph(X, use_pygsp=True, initialize=False)
+    with pytest.raises(NotImplementedError):
+        graphtools_amd.Graph(X, sample_idx=np.arange(60) % 2, n_landmark=10, initialize=False)
+
+
+def test_mnn_graph_selection_and_validation():
+    # reference: api.py:196-236, graphs.py:1743-1790, test/test_mnn.py
+    idx = np.arange(60) % 3
+    g = graphtools_amd.Graph(X, sample_idx=idx, knn=4, initialize=False)
+    assert type(g).__name__ == "MNNGraph" and not hasattr(g, "_kernel")
+    assert list(g.samples) == [0, 1, 2] and list(g.n_cells) == [20, 20, 20]
+    assert g.get_params()["beta"] == 1 and g.get_params()["knn"] == 4
+    with pytest.raises(ValueError, match="Cannot update beta"):
+        g.set_params(beta=0.5)
+    with pytest.raises(ValueError, match="Cannot update knn"):
+        g.set_params(knn=7)
+    with pytest.raises(ValueError, match="must be the same length as data"):
+        graphtools_amd.graphs.MNNGraph(X, sample_idx=idx[:-1], initialize=False)
+    with pytest.raises(ValueError, match="more than one unique value"):
+        graphtools_amd.graphs.MNNGraph(X, sample_idx=np.zeros(60), initialize=False)
+    with pytest.raises(TypeError, match="Expected `theta` as a float"):
+        graphtools_amd.graphs.MNNGraph(X, sample_idx=idx, kernel_symm="mnn", theta="a", initialize=False)
+    with pytest.warns(DeprecationWarning, match="adaptive_k"):
+        graphtools_amd.graphs.MNNGraph(X, sample_idx=idx, adaptive_k="sqrt", initialize=False)
+    with pytest.warns(UserWarning, match="Only one unique sample"):
+        g1 = graphtools_amd.Graph(X, sample_idx=np.zeros(60), initialize=False)
+    assert type(g1).__name__ == "kNNGraph"
+    with pytest.raises(ValueError, match="MNNGraph does not support precomputed"):
+        graphtools_amd.Graph(X, sample_idx=idx, precomputed="distance", graphtype="mnn", initialize=False)
+    with pytest.raises(NotImplementedError):
+        g.build_kernel_to_data(X)

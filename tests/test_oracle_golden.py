@@ -4,7 +4,7 @@ import pytest
 from scipy import sparse
 
 import oracle
-from conftest import golden_csr, golden_params, load_golden
+from conftest import golden_csr, golden_params, load_golden, mnn_params
 
 KNN_FIXTURES = [
     "g1_digits_decay40", "g2b_mix_binary", "g3_mix_f32", "g4_gauss_f32", "g5_manifold_f32",
@@ -142,3 +142,17 @@ def test_cosine_matches_reference():
     K, P = oracle.knn_graph(z["X"], knn=int(z["knn"]), decay=float(z["decay"]), distance="cosine")
     Kg = golden_csr(z, "K")
     assert (sparse.csr_matrix(K) != Kg).nnz == 0
+
+
+MNN_FIXTURES = ["g9_mnn_decay", "g9b_mnn_binary_theta", "g9c_mnn_aniso"]
+
+
+@pytest.mark.parametrize("name", MNN_FIXTURES)
+def test_mnn_graph_matches_reference(name):
+    """MNNGraph.build_kernel (graphs.py:1870-1946) + symmetrisation + P, bit-identical to the reference."""
+    z = load_golden(name)
+    K0, K, P = oracle.mnn_graph(z["X"], z["sample_idx"], **mnn_params(z))
+    K0.sort_indices()
+    assert (K0 != golden_csr(z, "K0")).nnz == 0
+    assert (K != golden_csr(z, "K")).nnz == 0
+    np.testing.assert_allclose(P.data, z["P_data"], rtol=0, atol=1e-15)
