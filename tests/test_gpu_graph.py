@@ -305,3 +305,44 @@ def test_csr_graph_build_vs_oracle(symm, theta, aniso):
     Po = oracle.diff_op(Ko)
     np.testing.assert_allclose(Pd, Po.data, rtol=1e-12, atol=0)
     ctx.close()
+
+
+def test_full_size_properties_n1e6():
+    """BASELINE.json's headline configuration (mix N = 1e6, d = 64, knn = 15, decay = 40) end to end through
+    graphtools_amd.Graph: size-independent properties of K and P, bit-exact symmetry, determinism, and a
+    sample of rows of the unsymmetrised kernel against the brute-force oracle."""
+    n = 1000000
+    X = make_mix(n, 64, 1)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        G = graphtools_amd.Graph(X, knn=15, decay=40, n_pca=None, verbose=0)
+    K, P = G.K, G.P
+    assert K.shape == (n, n) and K.has_canonical_format and K.dtype == np.float64
+    assert np.all(K.diagonal() == 1.0)
+    assert K.data.min() >= 1e-4 / 2 and K.data.max() <= 1.0          # (k + k') / 2 with k, k' in {0} U [thresh, 1]
+    KT = sparse.csr_matrix(K.T)
+    KT.sort_indices()
+    assert np.array_equal(KT.indptr, K.indptr) and np.array_equal(KT.indices, K.indices)
+    assert np.array_equal(KT.data, K.data)                             # symmetric to the last bit
+    del KT
+    deg = np.asarray(K.sum(axis=1)).ravel()
+    np.testing.assert_allclose(np.asarray(G.kernel_degree).ravel(), deg, rtol=1e-13, atol=0)
+    np.testing.assert_allclose(P.data, K.data / np.repeat(deg, np.diff(K.indptr)), rtol=1e-13, atol=0)
+    np.testing.assert_allclose(np.asarray(P.sum(axis=1)).ravel(), 1.0, rtol=0, atol=1e-12)
+    st = G.build_stats
+    assert st["fallback_rows"] == 0
+    # sampled rows of the unsymmetrised kernel vs the oracle (exact float64 brute force over all 1e6 points)
+    K0 = G.build_kernel()
+    rows = np.concatenate([np.arange(64), np.random.default_rng(0).choice(n, 192, replace=False)])
+    Ko = sparse.csr_matrix(oracle.knn_kernel(X, knn=16, decay=40, Y=X[rows]))   # knn=16 to_data == knn=15 self build
+    Ko.sort_indices()
+    Ks = sparse.csr_matrix(K0[rows])
+    Ks.sort_indices()
+    assert np.array_equal(Ks.indptr, Ko.indptr) and np.array_equal(Ks.indices, Ko.indices)
+    np.testing.assert_allclose(Ks.data, Ko.data, rtol=RTOL, atol=1e-37)
+    # determinism: a second build gives the same bits
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        G2 = graphtools_amd.Graph(X, knn=15, decay=40, n_pca=None, verbose=0)
+    assert np.array_equal(G2.K.indices, K.indices) and np.array_equal(G2.K.data, K.data)
+    assert np.array_equal(G2.P.data, P.data)

@@ -9,7 +9,8 @@ from tools.gpu_perf import make_mix
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
 precs = sys.argv[2].split(",") if len(sys.argv) > 2 else ["f16", "f32"]
-X = make_mix(n, 64, 1)
+D = int(os.environ.get("GT_DIM", "64"))
+X = make_mix(n, D, 1)
 nq = min(n, 131072)
 import oracle
 dbgs = [int(v) for v in sys.argv[3].split(",")] if len(sys.argv) > 3 else [0]
@@ -27,7 +28,7 @@ for prec, dbg in [(p_, d_) for p_ in precs for d_ in dbgs]:
     for rep in range(3):
         d, i, fl = ctx.knn_search(16, rows=(0, nq))
         best = min(best, ctx.stage_ms("knn_select"))
-    flops = 2.0 * nq * n * 64
+    flops = 2.0 * nq * n * D
     d0, i0 = oracle.kneighbors(X, X[:256], 16)
     print(json.dumps({"prec": prec, "dbg": dbg, "nq": nq, "select_ms": round(best, 2), "TF_alg": round(flops / best / 1e9, 1),
                       "rerank_ms": round(ctx.stage_ms("rerank"), 2), "fallback_ms": round(ctx.stage_ms("fallback"), 2),
