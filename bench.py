@@ -29,8 +29,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 # MI355X_MICROARCH.md dense matrix peaks (256 CUs @ 2.4 GHz)
-MFMA_PEAK_TFLOPS = {"f16": 2500.0,    # v_mfma_f32_32x32x16_f16 (split-float16 candidate pass, 3 MFMA chains per product)
+MFMA_PEAK_TFLOPS = {"f16x1": 2500.0,  # v_mfma_f32_32x32x16_f16, one chain per product (high float16 plane)
+                    "f16": 2500.0,    # same instruction, split float16: 3 chains per product
                     "f32": 157.3}     # v_mfma_f32_32x32x2_f32
+MFMA_CHAINS = {"f16x1": 1.0, "f16": 3.0, "f32": 1.0}
+SELECT_KERNEL = {"f16x1": "knn_select_kernel<64, 8, 0, 2>", "f16": "knn_select_kernel<64, 8, 0, 1>",
+                 "f32": "knn_select_kernel<64, 8, 0, 0>"}
 
 
 def make_mix(n, d, seed, dtype=np.float32):
@@ -48,13 +52,14 @@ def make_mix(n, d, seed, dtype=np.float32):
 
 def measured_traffic(n, d, precision, world):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE doubled per
-    MI355X_MICROARCH.md + WRITE_SIZE, profiles/r1_pmc_fetch_write_per_kernel.json).  PMC counters cannot be read
+    MI355X_MICROARCH.md + WRITE_SIZE, profiles/r1_pmc_fetch_write_per_kernel_<precision>.json).  PMC counters cannot be read
     from inside this process, so the number is only reported for the exact workload that was profiled."""
-    if not (n == 1000000 and d == 64 and precision == "f16" and world == 1):
+    if not (n == 1000000 and d == 64 and world == 1):
         return None
     try:
-        with open(os.path.join(ROOT, "profiles", "r1_pmc_fetch_write_per_kernel.json")) as f:
-            k = json.load(f)["kernels"]["knn_select_kernel<64, 8, 0, 1>"]
+        name = {"f16x1": "f16x1", "f16": "f16split"}[precision]
+        with open(os.path.join(ROOT, "profiles", "r1_pmc_fetch_write_per_kernel_%s.json" % name)) as f:
+            k = json.load(f)["kernels"][SELECT_KERNEL[precision]]
         return (k["hbm_read_GB_per_launch_corrected_x2"] + k["hbm_write_GB_per_launch"]) * 1e9
     except Exception:
         return None
@@ -122,8 +127,10 @@ def main():
     ap.add_argument("--knn", type=int, default=15)
     ap.add_argument("--decay", type=float, default=40.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--knn-precision", choices=["f16", "f32"], default=os.environ.get("GT_KNN_PRECISION", "f16"),
-                    help="arithmetic of the candidate pass (results are identical; see DESIGN.md)")
+    ap.add_argument("--knn-precision", choices=["auto", "f16x1", "f16", "f32"],
+                    default=os.environ.get("GT_KNN_PRECISION", "auto"),
+                    help="arithmetic of the candidate pass (results are identical; see DESIGN.md); auto = the library "
+                         "default: single float16 chain when the data tolerate it, else split float16")
     args = ap.parse_args()
 
     import torch
@@ -201,8 +208,9 @@ def main():
         flops = 2.0 * nloc * n * d                      # algorithmic: 2*d flop per (query, database row) pair
         avg_ms = float(np.mean(select_ms))
         achieved = flops / (avg_ms * 1e-3) / 1e12
-        peak = MFMA_PEAK_TFLOPS[args.knn_precision]
-        executed = flops * (3.0 if args.knn_precision == "f16" else 1.0)   # hi.hi + hi.lo + lo.hi chains
+        main = ctx.last_knn_precision()                 # what the main candidate pass actually ran on
+        peak = MFMA_PEAK_TFLOPS[main]
+        executed = flops * MFMA_CHAINS[main]
         stats = ctx.graph_stats()
         out = {
             "metric": "graphs/sec (kernel+diff_op) at N=1e6 d=64 k=15",
@@ -215,15 +223,17 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": ("f16x2-split" if args.knn_precision == "f16" else "f32") + " MFMA candidates + f64 re-rank/affinities",
+            "dtype": {"f16x1": "f16", "f16": "f16x2-split", "f32": "f32"}[main] + " MFMA candidates + f64 re-rank/affinities",
             "data": "synthetic",
             "config": {"workload": "C3: mix N=%d d=%d float32 seed=1, kNNGraph knn=%d decay=%g thresh=1e-4, "
                                    "kernel_symm='+', device-complete K and P" % (n, d, args.knn, args.decay),
                        "row_sharding": "%d rank(s) x %d rows" % (world, nloc), "nnz_K": nnz_total,
                        "radius_rows_rank0": stats["radius_rows"], "fallback_rows_rank0": stats["fallback_rows"]},
-            "roofline": {"kernel": "knn_select_kernel (%s MFMA candidate pass)" % args.knn_precision, "bound": "mfma",
+            "roofline": {"kernel": "%s (%s MFMA candidate pass, knn_precision=%s)" % (SELECT_KERNEL[main], main,
+                                                                                       args.knn_precision),
+                         "bound": "mfma",
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "traffic": measured_traffic(n, d, args.knn_precision, world), "traffic_unit": "bytes/launch",
+                         "traffic": measured_traffic(n, d, main, world), "traffic_unit": "bytes/launch",
                          "avg_launch_ms": avg_ms, "algorithmic_flop_per_launch": flops,
                          "executed_mfma_flop_per_launch": executed,
                          "executed_mfma_frac": executed / (avg_ms * 1e-3) / 1e12 / peak},

@@ -18,7 +18,8 @@ OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libgraphtools_amd.so")
 ARCH = "gfx950"
 # (precision, padded feature count) instantiations; keep in sync with gt_knn_select_dispatch.cpp
-SELECT_UNITS = [(0, dp) for dp in (16, 32, 56, 64, 104, 128)] + [(1, dp) for dp in (16, 32, 48, 64, 80, 96, 112, 128)]
+SELECT_UNITS = ([(0, dp) for dp in (16, 32, 56, 64, 104, 128)] + [(1, dp) for dp in (16, 32, 48, 64, 80, 96, 112, 128)] +
+                [(2, dp) for dp in (16, 32, 48, 64, 80, 96, 112, 128)])
 
 COMMON_FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
                 "-ffp-contract=off"]

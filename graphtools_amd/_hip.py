@@ -59,6 +59,7 @@ _SIGNATURES = {
     "gt_set_points": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_int32]),
     "gt_knn_search": (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_int64, _c.c_void_p, _c.c_int64, _c.c_int32, _c.c_int32,
                                  _c.c_void_p, _c.c_void_p, _c.c_int32, _c.POINTER(_c.c_uint32)]),
+    "gt_last_knn_precision": (_c.c_int, [_c.c_void_p]),
     "gt_graph_begin": (_c.c_int, [_c.c_void_p, _c.POINTER(KnnParams), _c.c_int32, _c.c_int32, _c.c_void_p, _c.c_void_p]),
     "gt_graph_emit": (_c.c_int, [_c.c_void_p, _c.c_void_p]),
     "gt_graph_finish": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64, _c.POINTER(_c.c_int64), _c.POINTER(_c.c_uint32)]),
@@ -236,6 +237,10 @@ class Context:
         self._check(self.lib.gt_graph_extend(self.h, _ptr(Y), Y.shape[0], 0, ctypes.byref(params), ctypes.byref(nnz),
                                              ctypes.byref(flags)), "gt_graph_extend")
         return nnz.value, flags.value
+
+    def last_knn_precision(self):
+        """arithmetic of the last main candidate pass: 'f32', 'f16' (split, 3 chains) or 'f16x1' (single chain)"""
+        return {0: "f32", 1: "f16", 2: "f16x1"}[self.lib.gt_last_knn_precision(self.h)]
 
     def csr_graph_build(self, K0, kernel_symm, theta, anisotropy):
         """symmetrise + anisotropy + row-normalise a host CSR kernel on the device; returns (nnz, flags)"""

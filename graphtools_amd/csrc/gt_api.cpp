@@ -51,7 +51,9 @@ int gt_ctx_create(int device, gt_ctx** out) {
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->n_cu = prop.multiProcessorCount;
     if (const char* pr = std::getenv("GT_KNN_PRECISION")) {
         if (std::string(pr) == "f32") ctx->prec = 0;
-        if (std::string(pr) == "f16") ctx->prec = 1;
+        if (std::string(pr) == "f16") { ctx->prec = 1; ctx->fast_mode = 0; }
+        if (std::string(pr) == "f16x1") { ctx->prec = 1; ctx->fast_mode = 2; }
+        if (std::string(pr) == "auto") { ctx->prec = 1; ctx->fast_mode = 1; }
     }
     *out = ctx;
     return GT_OK;
@@ -68,6 +70,7 @@ void gt_ctx_destroy(gt_ctx* ctx) {
     for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
     ctx->X_own.release();
     ctx->Yp.release();
+    ctx->Yc.release();
     ctx->xn.release();
     ctx->hneg.release();
     ctx->ymax.release();
@@ -125,6 +128,7 @@ int gt_set_points(gt_ctx* ctx, const void* X, int64_t n, int32_t d, int32_t dtyp
         ctx->X = ctx->X_norm.p;
     }
     ctx->n = n;
+    ctx->fast_ok = -1;
     ctx->d = d;
     ctx->dtype = dtype;
     ctx->DP = gt_choose_dp_prec(d, ctx->prec);
@@ -142,16 +146,26 @@ int gt_set_points(gt_ctx* ctx, const void* X, int64_t n, int32_t d, int32_t dtyp
     return GT_OK;
 }
 
+int gt_last_knn_precision(const gt_ctx* ctx) { return ctx ? ctx->last_main_prec : GT_E_ARG; }
+
 int gt_set_option(gt_ctx* ctx, const char* name, const char* value) {
     if (!ctx || !name || !value) return GT_E_ARG;
     const std::string k(name), v(value);
     if (k == "knn_precision") {
-        if (v == "f32")
+        if (v == "f32") {
             ctx->prec = 0;
-        else if (v == "f16")
+        } else if (v == "f16") {          // split float16 (3 chains) only
             ctx->prec = 1;
-        else
-            GT_FAIL(ctx, GT_E_ARG, "knn_precision must be 'f32' or 'f16'");
+            ctx->fast_mode = 0;
+        } else if (v == "f16x1") {        // single float16 chain for the main pass, always
+            ctx->prec = 1;
+            ctx->fast_mode = 2;
+        } else if (v == "auto") {         // single chain when the data tolerate it (default)
+            ctx->prec = 1;
+            ctx->fast_mode = 1;
+        } else {
+            GT_FAIL(ctx, GT_E_ARG, "knn_precision must be 'auto', 'f16x1', 'f16' or 'f32'");
+        }
         ctx->n = 0;   // the working copy depends on the precision: points must be bound again
         return GT_OK;
     }

@@ -94,9 +94,18 @@ struct gt_ctx {
     int32_t d = 0;
     int32_t dtype = GT_F32;
     int32_t DP = 0;      // padded feature count of the working copy
-    int32_t prec = 1;    // candidate arithmetic: 0 = float32 MFMA, 1 = split-float16 MFMA (default)
+    int32_t prec = 1;    // working copy / candidate arithmetic: 0 = float32 MFMA, 1 = split-float16 MFMA (default)
+    // prec 1 only - single-chain float16 main pass (hi planes, score error 2^-10 |x||y|) instead of the three
+    // split chains: 0 never, 1 auto (try it, fall back to the split chains for this point set when more than
+    // kFastFailFrac of the rows cannot be proven complete), 2 always.  Repairs always run on the split chains.
+    int32_t fast_mode = 1;
+    int32_t fast_ok = -1;        // auto: verdict for the bound points (-1 unknown, 0 no, 1 yes); reset by gt_set_points
+    int32_t last_main_prec = 1;  // arithmetic of the last main candidate pass (0 f32, 1 split f16, 2 single f16)
     double sc = 1.0;     // power-of-two scale applied to the working copy (prec 1: max|x|*sc in [2^13, 2^14))
     double maxabs = 0.0; // max |x_ij| of the bound points
+    double lomax = 0.0;  // prec 1: max over rows of |x - hi(x)|_2 (true units), the float16 rounding residual norm
+    double qlomax = 0.0; //         same for the external query matrix of the current call
+    DevBuf lomax_dev;
     int32_t metric = 0;  // 0 euclidean, 1 cosine (points are row-normalised copies; distance = 1 - x.y)
     DevBuf X_norm;       // cosine: normalised points in the input dtype
     int32_t samp_stride = 16; // candidate pass: threshold-seeding phase over every samp_stride-th tile (<= 1: off)
@@ -105,6 +114,7 @@ struct gt_ctx {
     int32_t dbg_select = 0;   // experiment switches forwarded to the candidate kernel (results invalid when set)
     int64_t n_pad = 0;   // rows of the working copy (multiple of the db tile)
     DevBuf Yp;           // working copy: [n_pad] rows of 4*DP bytes (float32, or float16 hi plane | lo plane)
+    DevBuf Yc;           // prec 1 with fast_mode: compact copy of the hi plane, [n_pad] rows of 2*DP bytes
     DevBuf xn;           // double [n]    squared row norms
     DevBuf hneg;         // float [n_pad] -sc^2 |y|^2/2 (-inf on pad rows)
     DevBuf ymax;         // float [1]     max row norm (as float bits, atomicMax on uint)

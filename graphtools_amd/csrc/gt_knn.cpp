@@ -10,23 +10,34 @@ int gt_select_bn_for(int dp) { return gt_select_bn(dp); }
 void gt_free_knn_work(gt_ctx* ctx) {
     if (!ctx->knn) return;
     KnnWork* k = ctx->knn;
-    for (DevBuf* b : {&k->Qraw, &k->Qp, &k->qn, &k->lists, &k->counts, &k->thr_final, &k->cand_d2, &k->cand_j, &k->cand_n,
+    for (DevBuf* b : {&k->Qraw, &k->Qp, &k->Qc, &k->qn, &k->lists, &k->counts, &k->thr_final, &k->cand_d2, &k->cand_j, &k->cand_n,
                       &k->d2_lb, &k->fb_rows, &k->fb_count, &k->fb_scratch, &k->gflags, &k->prof, &k->fb_qrows, &k->fb_thr, &k->fb_lists,
-                      &k->fb_counts, &k->fb_max})
+                      &k->fb_counts, &k->fb_max, &k->unproven, &k->qlomax_dev})
         b->release();
     delete k;
     ctx->knn = nullptr;
 }
 
-ErrModel gt_err_model(const gt_ctx* ctx) {
+ErrModel gt_err_model(const gt_ctx* ctx, int prec) {
     const double u = 5.9604644775390625e-08;  // 2^-24
     ErrModel m;
-    if (ctx->prec == 1) {
+    m.rel_dot = 0.0;
+    m.cst = 0.0;
+    if (prec == 1) {
         // 3*DP + 1 summands in fp32 (factor 2 head-room, also covers truncating alignment inside the MFMA),
         // + 3 * 2^-22 for the two residuals and the dropped lo.lo products (x1.01 for second-order terms)
         m.rel = 2.0 * double(3 * ctx->DP + 4) * u + 1.01 * 3.0 * 4.0 * u;
         // float16 underflow of a lo part: absolute 2^-25 per element in scaled units
         m.abs = std::sqrt(double(ctx->DP)) * 2.0 * u / ctx->sc;
+    } else if (prec == 2) {
+        // hi planes only: with x sc = xh + xl (xl the exact float16 rounding residual), the chain computes xh.yh and
+        // drops xh.yl + xl.yh + xl.yl, bounded by |x| Ly + Lx |y| + Lx Ly with L = max residual row norm (measured on
+        // the bound points and the query matrix, gt_prep.hip) - far tighter than the worst case 2^-10 |x||y|;
+        // on top of it the fp32 accumulation of DP + 1 summands
+        const double L = std::max(ctx->lomax, ctx->qlomax);
+        m.rel = 2.0 * double(ctx->DP + 4) * u;
+        m.abs = 1.001 * L;
+        m.cst = L * L;
     } else {
         // DP fused multiply-adds on top of the rounded seed; float64 inputs add 2u from the float32 conversion
         m.rel = 2.0 * double(ctx->DP + 6) * u;
@@ -36,7 +47,10 @@ ErrModel gt_err_model(const gt_ctx* ctx) {
     return m;
 }
 
-int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int need_m) {
+// fraction of rows the single-chain pass may leave unproven before the split chains take over for this point set
+static const double kFastFailFrac = 0.05;
+
+int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int need_m, double radius_key_factor) {
     if (ctx->n <= 0 || !ctx->X) GT_FAIL(ctx, GT_E_STATE, "no points bound (call gt_set_points first)");
     if (ctx->DP == 0) GT_FAIL(ctx, GT_E_LIMIT, "kNN on the HIP path needs n_features <= 128 (reduce with n_pca)");
     if (need_m < 1 || int64_t(need_m) > ctx->n) GT_FAIL(ctx, GT_E_ARG, "k must be in [1, n_samples]");
@@ -50,7 +64,14 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
         nt = 32;
     else
         GT_FAIL(ctx, GT_E_LIMIT, "k > 448 neighbours is not supported by the HIP path yet");
-    const int MP = 16 * nt;
+    // arithmetic of the main pass (see gt_common.h fast_mode): single-chain float16 when allowed and not yet refuted
+    int main_prec = ctx->prec;
+    const bool fast_auto = ctx->prec == 1 && ctx->fast_mode == 1;
+    if (ctx->prec == 1 && (ctx->fast_mode == 2 || (fast_auto && ctx->fast_ok != 0 && nq >= 4096))) main_prec = 2;
+    const int mkeep = 16 * nt;   // list budget of the streaming selection
+    // exact table width M' = entries kept at the end of the stream: the wider error bound of the single chain is paid
+    // for with a deeper table (the completeness bound moves out with it), the lists have room for 64*nt anyway
+    const int MP = (main_prec == 2 && nt == 8) ? 256 : mkeep;
     const int bq = gt_select_bq(ctx->DP);
     k->MP = MP;
     k->nt = nt;
@@ -58,6 +79,7 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
     k->nq_pad = ceil_div64(nq, bq) * bq;
     k->q0 = q0;
     k->external = external;
+    if (!external) ctx->qlomax = 0.0;   // the residual bound of a previous external query matrix does not apply
     k->n_fallback = 0;
     k->n_fallback_exhaustive = 0;
     const size_t lcap = size_t(64) * nt;
@@ -76,7 +98,8 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
 
     SelectArgs sa;
     sa.dp = ctx->DP;
-    sa.prec = ctx->prec;
+    sa.prec = main_prec;
+    sa.final_keep = MP;
     sa.mode = 0;
     sa.nt = nt;
     sa.Yp = ctx->Yp.as<float>();
@@ -94,13 +117,13 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
         // threshold-seeding phase: worthwhile when the stream is long and the wanted count is well below M'
         int keep = std::max(ctx->samp_keep > 0 ? ctx->samp_keep : 16, need_m);
         keep += keep & 1;
-        const int64_t ntiles = ctx->n_pad / gt_select_bn(ctx->DP);
-        if (ctx->samp_stride > 1 && keep <= MP / 2 && ntiles >= int64_t(8) * ctx->samp_stride) {
+        const int64_t ntiles = ctx->n_pad / (ctx->DP <= 64 ? 128 : 64);   // tiles of the candidate kernels
+        if (ctx->samp_stride > 1 && keep <= mkeep / 2 && ntiles >= int64_t(8) * ctx->samp_stride) {
             sa.samp_stride = ctx->samp_stride;
             sa.samp_keep = keep;
             int end = ctx->samp_end < 0 ? keep : std::max(ctx->samp_end > 0 ? ctx->samp_end : 0, ctx->samp_end > 0 ? need_m : 0);
             end += end & 1;
-            sa.samp_end = end <= MP / 2 ? end : 0;
+            sa.samp_end = end <= mkeep / 2 ? end : 0;
         }
     }
     if (ctx->dbg_select & 64) {
@@ -108,11 +131,7 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
         GT_HIP(ctx, hipMemsetAsync(k->prof.p, 0, size_t(k->nq_pad / bq) * 4 * 8 * sizeof(unsigned long long), ctx->stream));
         sa.prof = k->prof.as<unsigned long long>();
     }
-    {
-        StageSpan span(ctx, "knn_select");
-        GT_TRY(gt_launch_select(ctx, sa));
-    }
-    if (ctx->dbg_select & 4) return GT_OK;   // experiment: candidate pass only (tables are NOT valid)
+    GT_HIP(ctx, k->unproven.reserve(sizeof(uint32_t)));
     RerankArgs ra;
     ra.X = ctx->X;
     ra.dtype = ctx->dtype;
@@ -128,7 +147,6 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
     ra.counts = k->counts.as<uint32_t>();
     ra.thr_final = k->thr_final.as<float>();
     ra.ymax2 = ctx->ymax.as<double>();
-    ra.err = gt_err_model(ctx);
     ra.metric = ctx->metric;
     ra.need_m = need_m;
     ra.MP = MP;
@@ -139,14 +157,49 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
     ra.fb_count = k->fb_count.as<uint32_t>();
     ra.fb_rows = k->fb_rows.as<int32_t>();
     ra.gflags = k->gflags.as<uint32_t>();
-    {
-        StageSpan span(ctx, "rerank");
-        GT_TRY(gt_launch_rerank(ctx, ra));
-    }
+    ra.radius_key_factor = radius_key_factor;
+    ra.unproven = k->unproven.as<uint32_t>();
     uint32_t n_fb = 0;
-    GT_HIP(ctx, hipMemcpyAsync(&n_fb, k->fb_count.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-    GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (;;) {
+        sa.prec = main_prec;
+        // the single chain streams the compact hi-plane copies (rows of 2*DP bytes), the others the full working copy
+        sa.Yp = main_prec == 2 ? ctx->Yc.as<float>() : ctx->Yp.as<float>();
+        sa.Qp = main_prec == 2 ? (external ? k->Qc.as<float>() : ctx->Yc.as<float>())
+                               : (external ? k->Qp.as<float>() : ctx->Yp.as<float>());
+        ra.err = gt_err_model(ctx, main_prec);
+        {
+            StageSpan span(ctx, "knn_select");
+            GT_TRY(gt_launch_select(ctx, sa));
+        }
+        ctx->last_main_prec = main_prec;
+        if (ctx->dbg_select & 4) return GT_OK;   // experiment: candidate pass only (tables are NOT valid)
+        GT_HIP(ctx, hipMemsetAsync(k->unproven.p, 0, sizeof(uint32_t), ctx->stream));
+        {
+            StageSpan span(ctx, "rerank");
+            GT_TRY(gt_launch_rerank(ctx, ra));
+        }
+        uint32_t n_unproven = 0;
+        GT_HIP(ctx, hipMemcpyAsync(&n_fb, k->fb_count.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        GT_HIP(ctx, hipMemcpyAsync(&n_unproven, k->unproven.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (main_prec == 2 && fast_auto) {
+            // verdict for this point set: the wide error bound of the single chain must leave (almost) every row
+            // provably complete, otherwise the repairs would cost more than the split chains
+            const bool ok = double(n_unproven) <= kFastFailFrac * double(nq);
+            if (nq >= 4096) ctx->fast_ok = ok ? 1 : 0;
+            if (!ok) {
+                main_prec = 1;
+                GT_HIP(ctx, hipMemsetAsync(k->fb_count.p, 0, sizeof(uint32_t), ctx->stream));
+                GT_HIP(ctx, hipMemsetAsync(k->gflags.p, 0, sizeof(uint32_t), ctx->stream));
+                continue;
+            }
+        }
+        break;
+    }
     k->n_fallback = n_fb;
+    // repairs run on the accurate arithmetic of the working copy
+    ra.err = gt_err_model(ctx, ctx->prec);
+    ra.unproven = nullptr;
     if (n_fb > 0) {
         // Repair at MFMA speed: radius-mode candidate pass around each flagged query's need_m-th candidate key, exact
         // keys + (key, index) selection on what it collected (gt_rerank.hip).  The exhaustive kernel is the last
@@ -169,7 +222,7 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
                 GT_TRY(gt_launch_fallback_thr(ctx, ra, rows, off, k->fb_qrows.as<int32_t>(), k->fb_thr.as<float>()));
                 SelectArgs fa;
                 fa.dp = ctx->DP;
-                fa.prec = ctx->prec;
+                fa.prec = ctx->prec;   // accurate arithmetic (thresholds from ra.err above)
                 fa.mode = 1;
                 fa.Yp = ctx->Yp.as<float>();
                 fa.hneg = ctx->hneg.as<float>();
@@ -242,11 +295,28 @@ int gt_prepare_queries(gt_ctx* ctx, const void* Y, int64_t m, int32_t y_on_devic
             const double keep = ctx->maxabs;
             ctx->sc = gt_f16_scale(std::max(qmax, keep));
             GT_TRY(gt_prep_matrix(ctx, ctx->X, ctx->n, ctx->d, ctx->dtype, ctx->DP, ctx->n_pad, ctx->Yp.as<float>(),
-                                  ctx->xn.as<double>(), ctx->hneg.as<float>(), ctx->ymax.as<double>(), 1, ctx->sc));
+                                  ctx->xn.as<double>(), ctx->hneg.as<float>(), ctx->ymax.as<double>(), 1, ctx->sc,
+                                  ctx->lomax_dev.as<double>(), ctx->fast_mode != 0 ? ctx->Yc.p : nullptr));
+            double lo2 = 0.0;
+            GT_HIP(ctx, hipMemcpyAsync(&lo2, ctx->lomax_dev.p, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+            GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            ctx->lomax = std::sqrt(lo2) / ctx->sc;
+            ctx->fast_ok = -1;
         }
     }
+    GT_HIP(ctx, kw->qlomax_dev.reserve(sizeof(double)));
+    const bool want_hi = ctx->prec == 1 && ctx->fast_mode != 0;
+    if (want_hi) GT_HIP(ctx, kw->Qc.reserve(size_t(mpad) * ctx->DP * sizeof(_Float16)));
     GT_TRY(gt_prep_matrix(ctx, kw->Qraw.p, m, ctx->d, ctx->dtype, ctx->DP, mpad, kw->Qp.as<float>(), kw->qn.as<double>(),
-                          nullptr, nullptr, ctx->prec, ctx->sc));
+                          nullptr, nullptr, ctx->prec, ctx->sc, ctx->prec == 1 ? kw->qlomax_dev.as<double>() : nullptr,
+                          want_hi ? kw->Qc.p : nullptr));
+    ctx->qlomax = 0.0;
+    if (ctx->prec == 1) {
+        double lo2 = 0.0;
+        GT_HIP(ctx, hipMemcpyAsync(&lo2, kw->qlomax_dev.p, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->qlomax = std::sqrt(lo2) / ctx->sc;
+    }
     return GT_OK;
 }
 

@@ -16,9 +16,10 @@ struct KnnWork {
     int64_t q0 = 0;      // first query row (self queries) - queries are rows [q0, q0+nq) of the bound points
     bool external = false;
     // external queries (gt_knn_search with Y)
-    DevBuf Qraw, Qp, qn;
+    DevBuf Qraw, Qp, Qc, qn;   // Qc: compact hi-plane copy of the query matrix (single-chain pass)
     DevBuf lists, counts, thr_final;
     DevBuf cand_d2, cand_j, cand_n, d2_lb;
+    DevBuf unproven, qlomax_dev;
     DevBuf fb_rows, fb_count, fb_scratch, gflags, prof;
     DevBuf fb_qrows, fb_thr, fb_lists, fb_counts, fb_max;   // collected fallback
     int64_t n_fallback_exhaustive = 0;
@@ -27,7 +28,7 @@ struct KnnWork {
 
 int gt_select_bn_for(int dp);
 int gt_prep_matrix(gt_ctx* ctx, const void* Xdev, int64_t n, int d, int dtype, int DP, int64_t n_pad, float* Yp,
-                   double* xn, float* hneg, double* ymax2, int prec, double sc);
+                   double* xn, float* hneg, double* ymax2, int prec, double sc, double* lomax2 = nullptr, void* Yc = nullptr);
 int gt_max_abs(gt_ctx* ctx, const void* Xdev, int64_t total, int dtype, double* out_host);
 double gt_f16_scale(double maxabs);
 // row-wise l2 normalisation in the input dtype (sklearn normalize: zero rows untouched); in place allowed
@@ -37,17 +38,26 @@ int gt_normalize_rows(gt_ctx* ctx, const void* X, void* out, int64_t n, int d, i
 //   |s~/sc^2 - s| <= rel * (|y|^2/2 + |x||y|) + abs * (|x| + |y|)
 // rel covers the accumulation (any summation order of the MFMA chain, with head-room) and, for the split-float16
 // back end, the 2^-22 representation residual and the dropped lo.lo term; abs covers float16 underflow of lo parts.
+// |score/sc^2 - (x.y - |y|^2/2)| <= rel (|y|^2/2 + |x||y|) + rel_dot |x||y| + abs (|x| + |y|) + cst
 struct ErrModel {
     double rel;
+    double rel_dot;
     double abs;
+    double cst;
     double inv_sc2;
 };
-ErrModel gt_err_model(const gt_ctx* ctx);
+__host__ __device__ inline double gt_err_bound(const ErrModel& m, double x2, double y2) {
+    const double xy = sqrt(x2 * y2);
+    return m.rel * (0.5 * y2 + xy) + m.rel_dot * xy + m.abs * (sqrt(x2) + sqrt(y2)) + m.cst;
+}
+ErrModel gt_err_model(const gt_ctx* ctx, int prec);   // prec: arithmetic of the pass (0 f32, 1 split f16, 2 single f16)
 
 // Build exact candidate tables with the first `need_m` entries of every row guaranteed to be the true
 // need_m nearest neighbours.  Queries: rows [q0, q0+nq) of the bound points, or (external) the matrix in
 // ctx->knn->Qraw prepared by the caller.
-int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int need_m);
+// `radius_key_factor` (optional): the caller will need every row within factor x key(need_m-th neighbour) - only used to
+// judge whether the single-chain float16 main pass is adequate for this point set (speed, never correctness).
+int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int need_m, double radius_key_factor = 1.0);
 // Upload / convert an external query matrix (same dtype and width as the bound points) into ctx->knn->Qraw
 // (original dtype, normalised for the cosine metric), Qp (working copy) and qn (float64 squared norms).
 int gt_prepare_queries(gt_ctx* ctx, const void* Y, int64_t m, int32_t y_on_device);
@@ -102,6 +112,8 @@ struct RerankArgs {
     uint32_t* fb_count;
     int32_t* fb_rows;
     uint32_t* gflags;
+    double radius_key_factor = 1.0;   // see gt_knn_candidates
+    uint32_t* unproven = nullptr;     // optional counter: rows with key(need_m-th) * radius_key_factor >= bound
 };
 int gt_launch_rerank(gt_ctx* ctx, const RerankArgs& a);
 int gt_launch_fallback(gt_ctx* ctx, const RerankArgs& a, int64_t n_rows, int64_t row_off, double* scratch);

@@ -4,7 +4,7 @@
 
 struct SelectArgs {
     int dp = 0;            // padded feature count (gt_choose_dp)
-    int prec = 0;          // 0: float32 operands, 1: split float16 planes (hi + lo)
+    int prec = 0;          // 0: float32 operands, 1: split float16 planes (hi + lo), 2: hi planes of the split copy only
     int mode = 0;          // 0: top-M' selection, 1: radius collect
     int nt = 8;            // selection: keys per lane in the compaction sort; list capacity 64*nt, M' = 16*nt
     const float* Yp = nullptr;    // database working copy, [n_pad] rows of 4*dp bytes
@@ -23,6 +23,7 @@ struct SelectArgs {
     int32_t samp_stride = 0;        // selection: > 1 = visit every samp_stride-th tile first with a keep-samp_keep budget
     int32_t samp_keep = 0;          //   (must be >= the number of neighbours wanted, even, <= 8*nt)
     int32_t samp_end = 0;           //   > 0: after the last sampled tile every list is cut to its samp_end best
+    int32_t final_keep = 0;         // selection: entries kept per query at the end (0: M' = 16*nt; at most 64*nt)
     int32_t dbg = 0;                // experiment switches (bit 0: no survivors, bit 1: no compaction sort)
 };
 

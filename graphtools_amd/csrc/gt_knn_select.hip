@@ -13,6 +13,9 @@
 //   PREC 1  every (power-of-two scaled) value is split into two float16 planes x = hi + lo (22 significant
 //           bits); x.y ~ hi.hi + hi.lo + lo.hi with three v_mfma_f32_32x32x16_f16 chains (2.5 PF peak, fp32
 //           accumulation).  5.3x fewer matrix-pipe cycles than PREC 0 at fp32-class accuracy.
+//   PREC 2  the same working copy as PREC 1, hi planes only: one MFMA chain per product (11 significant bits,
+//           score error <= 2^-10 |x||y|).  3x fewer matrix-pipe cycles again; the host uses it for the main pass
+//           when the data tolerate the wider error bound (gt_knn.cpp) - repairs always run in PREC 1.
 // Either way the scores only have to be within a KNOWN error bound of the true ones: exact ordering is
 // established afterwards in float64 (gt_rerank.hip), which also proves the candidate table complete or sends
 // the row to an exhaustive fallback.
@@ -57,6 +60,9 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 // staging registers, no ds_write pass).  The LDS image is then lane-linear, so rows cannot be padded; bank
 // conflicts are avoided by an XOR swizzle of the 16-byte chunk index with a function of the row, applied to the
 // per-lane SOURCE address of the load and to the ds_read address alike (power-of-two row sizes only).
+#ifndef GT_SEL_P2_BN
+#define GT_SEL_P2_BN 128
+#endif
 #ifndef GT_SEL_GLDS
 #define GT_SEL_GLDS 1
 #endif
@@ -64,22 +70,24 @@ template <int DP, int PREC>
 struct SelCfg {
     static constexpr int QT = (DP <= 64) ? 2 : 1;       // 32-row query tiles per wave
     static constexpr int BQ = 4 * QT * 32;              // query rows per workgroup
-    static constexpr int BN = (DP <= 64) ? 128 : 64;    // database rows per LDS tile
-    static constexpr bool GLDS = GT_SEL_GLDS && PREC == 1 && (DP == 16 || DP == 32 || DP == 64 || DP == 128);
-    static constexpr int LDP = GLDS ? DP : DP + 4;      // LDS row stride (dwords); padded: conflict-free ds_read_b128
-    static constexpr int NF4 = BN * DP / 4;             // 16-byte units per tile (a row is 4*DP bytes in both layouts)
+    static constexpr int BN = (DP <= 64) ? ((PREC == 2) ? GT_SEL_P2_BN : 128) : 64;    // database rows per LDS tile
+    static constexpr int RW = (PREC == 2) ? DP / 2 : DP;   // row width in dwords: float32 | hi,lo float16 planes | hi plane
+    static constexpr int RB = 4 * RW;                   // row bytes
+    static constexpr bool GLDS = GT_SEL_GLDS && PREC >= 1 && (RB & (RB - 1)) == 0 && RB <= 512 && (BN * RB) % 4096 == 0;
+    static constexpr int LDP = GLDS ? RW : RW + 4;      // LDS row stride (dwords); padded: conflict-free ds_read_b128
+    static constexpr int NF4 = BN * RW / 4;             // 16-byte units per tile
     static constexpr int F4_PER_THREAD = (NF4 + 255) / 256;
     static constexpr int TILE_FLOATS = BN * LDP;
     static constexpr size_t LDS_BYTES =
         size_t(2) * TILE_FLOATS * 4 + size_t(2) * BN * 4;
     // swizzle geometry (GLDS)
-    static constexpr int RB = 4 * DP;                   // row bytes
     static constexpr int CPR = RB / 16;                 // 16-byte chunks per row
     static constexpr int RDIV = (RB >= 256) ? 1 : 256 / RB;   // rows sharing one 256-byte bank row
     static constexpr int SMASK = (CPR < 16 ? CPR : 16) - 1;
     static constexpr int RPP = 1024 / RB > 0 ? 1024 / RB : 1; // rows per 1 KiB piece (RB <= 512)
     static constexpr int NPW = (BN * RB / 1024) / 4;    // pieces per wave and tile
-    static_assert(!GLDS || (BN * RB) % 4096 == 0, "tile must split into 1 KiB pieces over 4 waves");
+    // waves per SIMD the register budget is cut for: the single-chain kernel needs < 128 VGPRs and half the LDS
+    static constexpr int WAVES = (PREC == 2) ? 4 : 2;
 };
 __device__ __forceinline__ int swz_of_row(int row, int rdiv, int smask) { return (row / rdiv) & smask; }
 
@@ -121,6 +129,17 @@ struct Frag<DP, 1> {
     }
 };
 
+template <int DP>
+struct Frag<DP, 2> {
+    static constexpr int NS = DP / 16;
+    f16x8 hi[NS];
+    __device__ __forceinline__ void load(const float* row, int h, int swz = 0) {
+        const f16x8* p = reinterpret_cast<const f16x8*>(row);   // hi plane of the split layout
+#pragma unroll
+        for (int s = 0; s < NS; ++s) hi[s] = p[(2 * s + h) ^ swz];
+    }
+};
+
 // one query tile's K chain (the two query tiles of a wave are issued back to back so that the epilogue of the
 // first can overlap the matrix work of the second)
 template <int DP>
@@ -136,6 +155,12 @@ __device__ __forceinline__ void mma_chain(const Frag<DP, 1>& a, const Frag<DP, 1
     for (int s = 0; s < DP / 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.lo[s], b.hi[s], acc, 0, 0, 0);
 #pragma unroll
     for (int s = 0; s < DP / 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.hi[s], b.lo[s], acc, 0, 0, 0);
+#pragma unroll
+    for (int s = 0; s < DP / 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.hi[s], b.hi[s], acc, 0, 0, 0);
+}
+
+template <int DP>
+__device__ __forceinline__ void mma_chain(const Frag<DP, 2>& a, const Frag<DP, 2>& b, f32x16& acc) {
 #pragma unroll
     for (int s = 0; s < DP / 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.hi[s], b.hi[s], acc, 0, 0, 0);
 }
@@ -209,13 +234,16 @@ __device__ __forceinline__ float compact_list(uint64_t* __restrict__ lp, const u
     return n > MKEEP ? ord_f32(T) : -INFINITY;
 }
 
+#ifndef GT_SEL_P2_WAVES
+#define GT_SEL_P2_WAVES 3
+#endif
 template <int DP, int NT, int MODE, int PREC>
-__global__ __launch_bounds__(256, 2) void knn_select_kernel(
+__global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) void knn_select_kernel(
     const float* __restrict__ Yp, const float* __restrict__ hneg, const float* __restrict__ Qp,
     const int32_t* __restrict__ qrows, const int64_t q0, const int32_t nq, const int32_t ntiles,
     uint64_t* __restrict__ lists, uint32_t* __restrict__ counts, const float* __restrict__ thr_in,
     float* __restrict__ thr_out, const int32_t cap, const int32_t dbg, unsigned long long* __restrict__ prof,
-    const int32_t samp_stride, const int32_t samp_keep, const int32_t samp_end) {
+    const int32_t samp_stride, const int32_t samp_keep, const int32_t samp_end, const int32_t final_keep) {
     using C = SelCfg<DP, PREC>;
     unsigned long long t_adm = 0, t_cmp = 0, t_bar = 0, n_cmp = 0, n_adm = 0;
     constexpr int QT = C::QT, BQ = C::BQ, BN = C::BN, LDP = C::LDP;
@@ -256,7 +284,7 @@ __global__ __launch_bounds__(256, 2) void knn_select_kernel(
         const int64_t qg = qblock + ql;
         const int64_t qc = qg < nq ? qg : int64_t(nq) - 1;   // clamp pad queries onto a real row
         const int64_t row = qrows ? int64_t(qrows[qc]) : q0 + qc;
-        bq[qt].load(Qp + row * DP, h);
+        bq[qt].load(Qp + row * C::RW, h);
         thr[qt] = (MODE == 0) ? ((dbg & 1) ? INFINITY : -INFINITY) : ((qg < nq) ? thr_in[qc] : INFINITY);
     }
 
@@ -267,7 +295,7 @@ __global__ __launch_bounds__(256, 2) void knn_select_kernel(
     float stage_h = 0.f;
 #define GT_STAGE_LOAD(T_, HALF_)                                                                          \
     {                                                                                                     \
-        const float4* src_ = reinterpret_cast<const float4*>(Yp + size_t((GT_SEL_EXP & 64) ? ((T_) & 15) : (T_)) * BN * DP) + (HALF_) * HF4;   \
+        const float4* src_ = reinterpret_cast<const float4*>(Yp + size_t((GT_SEL_EXP & 64) ? ((T_) & 15) : (T_)) * BN * C::RW) + (HALF_) * HF4;   \
         _Pragma("unroll") for (int u_ = 0; u_ < HF4_PER_THREAD; ++u_) {                                    \
             const int f = tid + u_ * 256;                                                                 \
             stage[u_] = (f < HF4) ? src_[f] : make_float4(0.f, 0.f, 0.f, 0.f);                            \
@@ -281,8 +309,8 @@ __global__ __launch_bounds__(256, 2) void knn_select_kernel(
             const int f = tid + u_ * 256;                                                                 \
             if (f < HF4) {                                                                                \
                 const int g_ = f + (HALF_) * HF4;                                                         \
-                const int r = (g_ * 4) / DP;                                                              \
-                const int c = (g_ * 4) % DP;                                                              \
+                const int r = (g_ * 4) / C::RW;                                                           \
+                const int c = (g_ * 4) % C::RW;                                                           \
                 *reinterpret_cast<float4*>(tb_ + r * LDP + c) = stage[u_];                                \
             }                                                                                             \
         }                                                                                                 \
@@ -426,10 +454,10 @@ __global__ __launch_bounds__(256, 2) void knn_select_kernel(
             if (u > 0 && u < NU) {
                 // interleave: one MFMA, then a few of the compare / mask instructions of the previous unit
 #pragma unroll
-                for (int i = 0; i < (PREC == 1 ? 3 * DP / 16 : DP / 2); ++i) {
+                for (int i = 0; i < (PREC == 1 ? 3 * DP / 16 : PREC == 2 ? DP / 16 : DP / 2); ++i) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x002, PREC == 1 ? 2 : 1, 0);   // VALU
-                    __builtin_amdgcn_sched_group_barrier(0x004, PREC == 1 ? 2 : 1, 0);   // SALU
+                    __builtin_amdgcn_sched_group_barrier(0x002, PREC == 1 ? 2 : PREC == 2 ? 6 : 1, 0);   // VALU
+                    __builtin_amdgcn_sched_group_barrier(0x004, PREC == 1 ? 2 : PREC == 2 ? 6 : 1, 0);   // SALU
                 }
             }
 #endif
@@ -503,7 +531,7 @@ __global__ __launch_bounds__(256, 2) void knn_select_kernel(
                 const int ql = (w * QT + qt) * 32 + L;
                 uint64_t* lp = lists + size_t(qblock + ql) * lstride;
                 uint32_t kept;
-                const float t = compact_list<NT, true>(lp, n0, n1, lane, kept);
+                const float t = compact_list<NT, true>(lp, n0, n1, lane, kept, uint32_t(final_keep));
                 if (lane == 0) {
                     counts[qblock + ql] = kept;
                     // every rejected database row scored <= thr_out (-inf: nothing was ever rejected)
@@ -537,7 +565,8 @@ int launch_one(gt_ctx* ctx, const SelectArgs& a) {
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)nblocks, (unsigned)nsplit), dim3(256), lds_bytes, ctx->stream, a.Yp,
                        a.hneg, a.Qp, a.qrows, a.q0, a.nq, ntiles, a.lists, a.counts, a.thr_in, a.thr_out, a.cap, a.dbg, a.prof,
-                       a.samp_stride, a.samp_keep, a.samp_end);
+                       a.samp_stride, a.samp_keep, a.samp_end,
+                       (a.final_keep > 0 && a.final_keep <= 64 * NT) ? a.final_keep : 16 * NT);
     GT_HIP(ctx, hipGetLastError());
     return GT_OK;
 }
@@ -557,7 +586,7 @@ int launch_dp(gt_ctx* ctx, const SelectArgs& a) {
 // This file is compiled once per (precision, padded feature count): -DGT_SEL_PREC=<0|1> -DGT_SEL_DP=<dp>, so the
 // instantiations build in parallel; gt_knn_select_dispatch.cpp routes to the right one.
 #if !defined(GT_SEL_DP) || !defined(GT_SEL_PREC)
-#error "compile with -DGT_SEL_PREC=<0|1> -DGT_SEL_DP=<dp>"
+#error "compile with -DGT_SEL_PREC=<0|1|2> -DGT_SEL_DP=<dp>"
 #endif
 #define GT_CAT3_(a, b, c, d) a##b##c##d
 #define GT_CAT3(a, b, c, d) GT_CAT3_(a, b, c, d)

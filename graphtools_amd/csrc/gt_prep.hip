@@ -47,7 +47,8 @@ __global__ __launch_bounds__(256) void max_abs_kernel(const T* __restrict__ X, c
 // split-float16 working copy: row = hi plane (DP halves) | lo plane (DP halves), x*sc = hi + lo + O(2^-22 |x*sc|)
 template <typename T>
 __global__ __launch_bounds__(256) void pad_split_f16_kernel(const T* __restrict__ X, int64_t n, int d, int DP,
-                                                            int64_t n_pad, double sc, _Float16* __restrict__ Yh) {
+                                                            int64_t n_pad, double sc, _Float16* __restrict__ Yh,
+                                                            _Float16* __restrict__ Yc) {
     const int64_t total = n_pad * DP;
     for (int64_t f = int64_t(blockIdx.x) * 256 + threadIdx.x; f < total; f += int64_t(gridDim.x) * 256) {
         const int64_t r = f / DP;
@@ -58,6 +59,7 @@ __global__ __launch_bounds__(256) void pad_split_f16_kernel(const T* __restrict_
         const _Float16 lo = _Float16(v - double(hi));
         Yh[r * int64_t(2 * DP) + c] = hi;
         Yh[r * int64_t(2 * DP) + DP + c] = lo;
+        if (Yc) Yc[f] = hi;   // compact copy of the hi plane (rows of 2*DP bytes) for the single-chain pass
     }
 }
 
@@ -81,14 +83,21 @@ __global__ __launch_bounds__(256) void normalize_rows_kernel(const T* __restrict
 template <typename T>
 __global__ __launch_bounds__(256) void row_norm_kernel(const T* __restrict__ X, int64_t n, int d, int64_t n_pad,
                                                        double* __restrict__ xn, float* __restrict__ hneg,
-                                                       const double sc2, unsigned long long* __restrict__ ymax2_bits) {
+                                                       const double sc2, unsigned long long* __restrict__ ymax2_bits,
+                                                       const double sc, unsigned long long* __restrict__ lomax2_bits) {
     const int64_t r = int64_t(blockIdx.x) * 256 + threadIdx.x;
-    double acc = 0.0;
+    double acc = 0.0, lo2 = 0.0;
     if (r < n) {
         const T* src = X + r * int64_t(d);
         for (int k = 0; k < d; ++k) {
             const double v = double(src[k]);
             acc = fma(v, v, acc);
+            if (lomax2_bits) {
+                // exact residual of the float16 rounding of the scaled value (what the hi-plane-only pass drops)
+                const double vs = v * sc;
+                const double res = vs - double(_Float16(vs));
+                lo2 = fma(res, res, lo2);
+            }
         }
         xn[r] = acc;
         if (hneg) hneg[r] = float(-0.5 * acc * sc2);
@@ -100,6 +109,12 @@ __global__ __launch_bounds__(256) void row_norm_kernel(const T* __restrict__ X, 
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
     if ((threadIdx.x & 63) == 0 && ymax2_bits) atomicMax(ymax2_bits, (unsigned long long)__double_as_longlong(m));
+    if (lomax2_bits) {
+        double l = (r < n) ? lo2 : 0.0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) l = fmax(l, __shfl_xor(l, o));
+        if ((threadIdx.x & 63) == 0) atomicMax(lomax2_bits, (unsigned long long)__double_as_longlong(l));
+    }
 }
 
 }  // namespace
@@ -147,17 +162,18 @@ double gt_f16_scale(double maxabs) {
 }
 
 int gt_prep_matrix(gt_ctx* ctx, const void* Xdev, int64_t n, int d, int dtype, int DP, int64_t n_pad, float* Yp,
-                   double* xn, float* hneg, double* ymax2, int prec, double sc) {
+                   double* xn, float* hneg, double* ymax2, int prec, double sc, double* lomax2, void* Yc) {
     if (ymax2) GT_HIP(ctx, hipMemsetAsync(ymax2, 0, sizeof(double), ctx->stream));
+    if (lomax2) GT_HIP(ctx, hipMemsetAsync(lomax2, 0, sizeof(double), ctx->stream));
     if (Yp && prec == 1) {
         const int64_t total = n_pad * DP;
         int64_t blocks = std::min<int64_t>(ceil_div64(total, 256), 16384);
         if (dtype == GT_F32)
             hipLaunchKernelGGL(pad_split_f16_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream,
-                               (const float*)Xdev, n, d, DP, n_pad, sc, (_Float16*)Yp);
+                               (const float*)Xdev, n, d, DP, n_pad, sc, (_Float16*)Yp, (_Float16*)Yc);
         else
             hipLaunchKernelGGL(pad_split_f16_kernel<double>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream,
-                               (const double*)Xdev, n, d, DP, n_pad, sc, (_Float16*)Yp);
+                               (const double*)Xdev, n, d, DP, n_pad, sc, (_Float16*)Yp, (_Float16*)Yc);
         GT_HIP(ctx, hipGetLastError());
     } else if (Yp) {
         const int64_t total4 = n_pad * DP / 4;
@@ -175,10 +191,10 @@ int gt_prep_matrix(gt_ctx* ctx, const void* Xdev, int64_t n, int d, int dtype, i
     const int64_t nb = ceil_div64(rows, 256);
     if (dtype == GT_F32)
         hipLaunchKernelGGL(row_norm_kernel<float>, dim3((unsigned)nb), dim3(256), 0, ctx->stream, (const float*)Xdev, n,
-                           d, n_pad, xn, hneg, sc * sc, (unsigned long long*)ymax2);
+                           d, n_pad, xn, hneg, sc * sc, (unsigned long long*)ymax2, sc, (unsigned long long*)lomax2);
     else
         hipLaunchKernelGGL(row_norm_kernel<double>, dim3((unsigned)nb), dim3(256), 0, ctx->stream, (const double*)Xdev,
-                           n, d, n_pad, xn, hneg, sc * sc, (unsigned long long*)ymax2);
+                           n, d, n_pad, xn, hneg, sc * sc, (unsigned long long*)ymax2, sc, (unsigned long long*)lomax2);
     GT_HIP(ctx, hipGetLastError());
     return GT_OK;
 }
@@ -196,6 +212,18 @@ int gt_prep_points(gt_ctx* ctx) {
     GT_HIP(ctx, ctx->xn.reserve(size_t(ctx->n) * sizeof(double)));
     GT_HIP(ctx, ctx->hneg.reserve(size_t(ctx->n_pad) * sizeof(float)));
     GT_HIP(ctx, ctx->ymax.reserve(sizeof(double)));
-    return gt_prep_matrix(ctx, ctx->X, ctx->n, ctx->d, ctx->dtype, ctx->DP, ctx->n_pad, ctx->Yp.as<float>(),
-                          ctx->xn.as<double>(), ctx->hneg.as<float>(), ctx->ymax.as<double>(), ctx->prec, ctx->sc);
+    GT_HIP(ctx, ctx->lomax_dev.reserve(sizeof(double)));
+    const bool want_hi = ctx->prec == 1 && ctx->fast_mode != 0;
+    if (want_hi) GT_HIP(ctx, ctx->Yc.reserve(size_t(ctx->n_pad) * ctx->DP * sizeof(_Float16)));
+    GT_TRY(gt_prep_matrix(ctx, ctx->X, ctx->n, ctx->d, ctx->dtype, ctx->DP, ctx->n_pad, ctx->Yp.as<float>(),
+                          ctx->xn.as<double>(), ctx->hneg.as<float>(), ctx->ymax.as<double>(), ctx->prec, ctx->sc,
+                          ctx->prec == 1 ? ctx->lomax_dev.as<double>() : nullptr, want_hi ? ctx->Yc.p : nullptr));
+    ctx->lomax = 0.0;
+    if (ctx->prec == 1) {
+        double lo2 = 0.0;
+        GT_HIP(ctx, hipMemcpyAsync(&lo2, ctx->lomax_dev.p, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->lomax = std::sqrt(lo2) / ctx->sc;
+    }
+    return GT_OK;
 }

@@ -56,7 +56,8 @@ __global__ __launch_bounds__(256) void rerank_kernel(const T* __restrict__ X, co
                                                      const int metric, const int need_m, double* __restrict__ cand_d2,
                                                      uint32_t* __restrict__ cand_j, uint32_t* __restrict__ cand_n,
                                                      double* __restrict__ d2_lb, uint32_t* __restrict__ fb_count,
-                                                     int32_t* __restrict__ fb_rows, uint32_t* __restrict__ gflags) {
+                                                     int32_t* __restrict__ fb_rows, uint32_t* __restrict__ gflags,
+                                                     const double radius_key_factor, uint32_t* __restrict__ unproven) {
     constexpr int MP = NT2 * 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int lane = threadIdx.x & 63;
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(256) void rerank_kernel(const T* __restrict__ X, co
     if (thr_f > -INFINITY) {   // -inf: the candidate pass rejected nothing for this query
         const double thr = double(thr_f) * err.inv_sc2;
         const double y2 = *ymax2p;
-        const double e = err.rel * (0.5 * y2 + sqrt(qnq * y2)) + err.abs * (sqrt(qnq) + sqrt(y2));
+        const double e = gt_err_bound(err, qnq, y2);
         // euclidean: d2 = |x|^2 - 2 s ; cosine: D = 1 - x.y = 1 - s - |y|^2/2 >= 1 - s - ymax^2/2
         lb = (metric == 1) ? (1.0 - (thr + e) - 0.5 * y2) : (qnq - 2.0 * (thr + e));
         lb -= 1e-9 * (qnq + y2);   // float64 rounding of the quantities above, with a wide margin
@@ -119,6 +120,7 @@ __global__ __launch_bounds__(256) void rerank_kernel(const T* __restrict__ X, co
             const uint32_t slot = atomicAdd(fb_count, 1u);
             fb_rows[slot] = int32_t(q);
         }
+        if (unproven && !(d2_need * radius_key_factor < lb)) atomicAdd(unproven, 1u);
         if (n > 1 && second == 0ull) atomicOr(gflags, GT_FLAG_DUPLICATES);
     }
 }
@@ -240,7 +242,7 @@ __global__ __launch_bounds__(256) void fallback_thr_kernel(const int32_t* __rest
     const double key = cand_d2[q * MP + (need_m - 1)] * (1.0 + 1e-12);
     const double qnq = qn[q0 + q];
     const double y2 = *ymax2p;
-    const double e = err.rel * (0.5 * y2 + sqrt(qnq * y2)) + err.abs * (sqrt(qnq) + sqrt(y2));
+    const double e = gt_err_bound(err, qnq, y2);
     const double smin = (metric == 1) ? (1.0 - key - 0.5 * y2) : 0.5 * (qnq - key);
     const double x = (smin - e - 1e-9 * (qnq + y2)) / err.inv_sc2;
     float t = float(x);
@@ -373,12 +375,17 @@ int rerank_t(gt_ctx* ctx, const RerankArgs& a) {
         hipLaunchKernelGGL((rerank_kernel<T, 2>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, (const T*)a.X,
                            a.d, a.xn, (const T*)a.Q, a.qn, a.q0, a.nq, a.lists, a.lstride, a.counts, a.thr_final, a.ymax2,
                            a.err, a.metric, a.need_m, a.cand_d2, a.cand_j, a.cand_n, a.d2_lb, a.fb_count, a.fb_rows,
-                           a.gflags);
+                           a.gflags, a.radius_key_factor, a.unproven);
+    } else if (a.MP == 256) {
+        hipLaunchKernelGGL((rerank_kernel<T, 4>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, (const T*)a.X,
+                           a.d, a.xn, (const T*)a.Q, a.qn, a.q0, a.nq, a.lists, a.lstride, a.counts, a.thr_final, a.ymax2,
+                           a.err, a.metric, a.need_m, a.cand_d2, a.cand_j, a.cand_n, a.d2_lb, a.fb_count, a.fb_rows,
+                           a.gflags, a.radius_key_factor, a.unproven);
     } else if (a.MP == 512) {
         hipLaunchKernelGGL((rerank_kernel<T, 8>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, (const T*)a.X,
                            a.d, a.xn, (const T*)a.Q, a.qn, a.q0, a.nq, a.lists, a.lstride, a.counts, a.thr_final, a.ymax2,
                            a.err, a.metric, a.need_m, a.cand_d2, a.cand_j, a.cand_n, a.d2_lb, a.fb_count, a.fb_rows,
-                           a.gflags);
+                           a.gflags, a.radius_key_factor, a.unproven);
     } else {
         GT_FAIL(ctx, GT_E_ARG, "rerank: unsupported table width");
     }
@@ -391,6 +398,11 @@ int fallback_t(gt_ctx* ctx, const RerankArgs& a, int64_t n_rows, int64_t row_off
     if (a.MP == 128) {
         const size_t lds = size_t(a.d) * 8 + size_t(128) * 12 + 16;
         hipLaunchKernelGGL((fallback_kernel<T, 2>), dim3((unsigned)n_rows), dim3(256), lds, ctx->stream, (const T*)a.X,
+                           a.n, a.d, a.xn, (const T*)a.Q, a.qn, a.q0, a.fb_rows, row_off, a.metric, a.need_m, scratch, a.cand_d2,
+                           a.cand_j, a.cand_n, a.d2_lb);
+    } else if (a.MP == 256) {
+        const size_t lds = size_t(a.d) * 8 + size_t(256) * 12 + 16;
+        hipLaunchKernelGGL((fallback_kernel<T, 4>), dim3((unsigned)n_rows), dim3(256), lds, ctx->stream, (const T*)a.X,
                            a.n, a.d, a.xn, (const T*)a.Q, a.qn, a.q0, a.fb_rows, row_off, a.metric, a.need_m, scratch, a.cand_d2,
                            a.cand_j, a.cand_n, a.d2_lb);
     } else if (a.MP == 512) {
@@ -441,6 +453,10 @@ static int collected_t(gt_ctx* ctx, const RerankArgs& a, int64_t n_rows, int64_t
     const size_t lds = size_t(a.d) * 8 + size_t(a.MP) * 12 + 16;
     if (a.MP == 128)
         hipLaunchKernelGGL((collected_select_kernel<T, 2>), dim3((unsigned)n_rows), dim3(256), lds, ctx->stream, (const T*)a.X,
+                           a.d, a.xn, (const T*)a.Q, a.qn, a.q0, a.fb_rows, row_off, a.metric, a.need_m, clists, ccounts, cap,
+                           scratch, a.cand_d2, a.cand_j, a.cand_n, a.d2_lb, fail);
+    else if (a.MP == 256)
+        hipLaunchKernelGGL((collected_select_kernel<T, 4>), dim3((unsigned)n_rows), dim3(256), lds, ctx->stream, (const T*)a.X,
                            a.d, a.xn, (const T*)a.Q, a.qn, a.q0, a.fb_rows, row_off, a.metric, a.need_m, clists, ccounts, cap,
                            scratch, a.cand_d2, a.cand_j, a.cand_n, a.d2_lb, fail);
     else

@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void bandwidth_kernel(
             src = int32_t(slot);
             const double qn = qnorm[qoff + i];
             const double y2 = *ymax2p;
-            const double e = err.rel * (0.5 * y2 + sqrt(qn * y2)) + err.abs * (sqrt(qn) + sqrt(y2));
+            const double e = gt_err_bound(err, qn, y2);
             // every row within the radius scores at least this much (scaled score units)
             const double smin = (metric == 1) ? (1.0 - r2 - 0.5 * y2) : 0.5 * (qn - r2);
             const double x = (smin - e - 1e-9 * (qn + y2)) / err.inv_sc2;
@@ -740,7 +740,15 @@ static int graph_begin_impl(gt_ctx* ctx, const gt_knn_params* params, int32_t wo
     if (params->bandwidth_len > 0 && !params->bandwidth) GT_FAIL(ctx, GT_E_ARG, "bandwidth pointer is NULL");
 
     // ---- kNN candidates for the owned rows ----
-    GT_TRY(gt_knn_candidates(ctx, g->r0, g->nloc, external, need));
+    {
+        // hint for the arithmetic choice of the main pass: rows out to radius_factor x bandwidth will be needed
+        double hint = 1.0;
+        if (use_radius && params->bandwidth_len == 0) {
+            const double rf = std::pow(-1.0 * std::log(thresh), 1.0 / params->decay) * params->bandwidth_scale;
+            hint = (ctx->metric == 1) ? rf : rf * rf;
+        }
+        GT_TRY(gt_knn_candidates(ctx, g->r0, g->nloc, external, need, hint));
+    }
     KnnWork* k = ctx->knn;
     g->Qmat = external ? k->Qraw.p : ctx->X;
     g->qnorm = external ? k->qn.as<double>() : ctx->xn.as<double>();
@@ -766,7 +774,8 @@ static int graph_begin_impl(gt_ctx* ctx, const gt_knn_params* params, int32_t wo
                                    hipMemcpyHostToDevice, ctx->stream));
     }
     g->radius_factor = binary ? 0.0 : std::pow(-1.0 * std::log(thresh), 1.0 / params->decay);   // graphs.py:902-904
-    const ErrModel err_model = gt_err_model(ctx);
+    // repairs (radius pass) run on the accurate arithmetic of the working copy, whatever the main pass used
+    const ErrModel err_model = gt_err_model(ctx, ctx->prec);
     {
         StageSpan span(ctx, "affinity");
         hipLaunchKernelGGL(bandwidth_kernel, dim3((unsigned)ceil_div64(g->nloc, 256)), dim3(256), 0, ctx->stream, g->nloc,

@@ -91,11 +91,17 @@ double gt_stage_ms(const gt_ctx* ctx, const char* stage);
 /* number of launches accumulated for `stage` in the most recent call (for roofline: ms / launches) */
 int gt_stage_launches(const gt_ctx* ctx, const char* stage);
 
-/* Options (call before gt_set_points).  "knn_precision": arithmetic of the candidate pass, "f16" (default:
- * two float16 planes per value on the 2.5 PF f16 MFMA path) or "f32" (float32 MFMA).  Results do not depend
- * on it - exact ordering and values always come from the float64 stage - only speed and how often rows take
- * the exhaustive fallback.  The environment variable GT_KNN_PRECISION sets the default. */
+/* Options (call before gt_set_points).  "knn_precision": arithmetic of the candidate pass -
+ *   "auto"  (default) float16 MFMA: one chain on the high float16 plane of every value when the bound data tolerate
+ *           its 2^-10 |x||y| score error (judged after the first pass: at most 5 % of the rows unproven), otherwise
+ *   "f16"   three chains on two float16 planes per value (2^-22), "f16x1" forces the single chain,
+ *   "f32"   float32 MFMA.
+ * Results never depend on it - exact ordering and values always come from the float64 stage, rows whose candidate
+ * table cannot be proven complete are repaired on the accurate arithmetic - only speed does.  The environment
+ * variable GT_KNN_PRECISION sets the default.  Also: "metric" ("euclidean" | "cosine"). */
 int gt_set_option(gt_ctx* ctx, const char* name, const char* value);
+/* arithmetic the most recent main candidate pass ran on: 0 float32, 1 split float16 (3 chains), 2 single float16 chain */
+int gt_last_knn_precision(const gt_ctx* ctx);
 
 /* ---- points ------------------------------------------------------------------------------ */
 /* Bind the data matrix (n x d).  Replaces NearestNeighbors(...).fit(data_nu) (graphs.py:763-768):

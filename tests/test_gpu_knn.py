@@ -156,3 +156,54 @@ def test_tie_heavy_lattice_collected_fallback(hip_ctx):
     K0 = sparse.csr_matrix(K0); K0.sort_indices()
     assert np.array_equal(Kp, K0.indptr) and np.array_equal(Ki, K0.indices)
     np.testing.assert_allclose(Kd, K0.data, rtol=1e-9)
+
+
+@pytest.mark.parametrize("prec", ["f16x1", "f16", "f32", "auto"])
+@pytest.mark.parametrize("maker,n,d,k", [(make_mix, 20000, 64, 16), (make_manifold, 12000, 50, 30), (make_gauss, 9000, 24, 96)])
+def test_knn_every_candidate_arithmetic_is_exact(prec, maker, n, d, k):
+    """The arithmetic of the candidate pass only changes speed: single-chain float16 (wide error bound, rows it cannot
+    prove complete are repaired on the split chains), split float16, float32 - identical neighbours and distances."""
+    from graphtools_amd import _hip
+
+    X = maker(n, d, 21)
+    ctx = _hip.Context(0)
+    ctx.set_option("knn_precision", prec)
+    Y = X[::7]                                   # external queries exercise the query-side residual bound too
+    ctx.set_points(X)
+    dd, ii, _ = ctx.knn_search(k, Y=Y)
+    d0, i0 = oracle.kneighbors(X, Y, k)
+    assert np.array_equal(ii, i0)
+    assert np.array_equal(dd[:, 1:], d0[:, 1:])   # column 0: a point's distance to itself is rounding noise
+    dd, ii, _ = ctx.knn_search(k, rows=(0, 6000))
+    d0, i0 = oracle.kneighbors(X, X[:6000], k)
+    assert np.array_equal(ii, i0)
+    assert np.array_equal(dd[:, 1:], d0[:, 1:])
+    want = {"f16x1": "f16x1", "f16": "f16", "f32": "f32"}.get(prec)
+    if want:
+        assert ctx.last_knn_precision() == want
+    ctx.close()
+
+
+def test_auto_precision_verdict_follows_the_data():
+    """'auto' keeps the single float16 chain where its error bound leaves the rows provable (well separated
+    neighbour shells: mixture data) and settles on the split chains where it does not (a low-dimensional manifold
+    far from the origin: neighbour gaps far below 2^-11 |x|^2) - with identical graphs either way."""
+    import graphtools_amd
+    from graphtools_amd import _hip
+
+    for maker, shift, expect in ((make_mix, 0.0, "f16x1"), (make_manifold, 60.0, "f16")):
+        X = (maker(30000, 64, 5) + np.float32(shift)).astype(np.float32)
+        ctx = _hip.Context(0)
+        ctx.set_points(X)
+        p, keep = ctx.make_params(15, 40, 1e-4, None, 1.0, None, "+", None, 0)
+        nnz, _ = ctx.graph_build(p)
+        assert ctx.last_knn_precision() == expect
+        Kd, Ki, Kp = ctx.graph_fetch_csr(_hip.CSR_K)
+        ref = _hip.Context(0)
+        ref.set_option("knn_precision", "f32")
+        ref.set_points(X)
+        ref.graph_build(p)
+        Rd, Ri, Rp = ref.graph_fetch_csr(_hip.CSR_K)
+        assert np.array_equal(Kp, Rp) and np.array_equal(Ki, Ri) and np.array_equal(Kd, Rd)
+        ctx.close()
+        ref.close()

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
-"""Development: link a variant of libgraphtools_amd.so whose (precision 1, DP 64) candidate kernel is compiled
-with extra -D flags, for ablation runs (GRAPHTOOLS_AMD_LIB=<path> python tools/...).
+"""Development: link a variant of libgraphtools_amd.so whose (precision, DP) candidate kernel (GT_VARIANT_UNIT="p:dp",
+default 1:64) is compiled with extra -D flags, for ablation runs (GRAPHTOOLS_AMD_LIB=<path> python tools/...).
 usage: build_variant.py NAME -DGT_SEL_EXP=1 [...]   ->  graphtools_amd/_variants/libgt_NAME.so"""
 import os
 import subprocess
@@ -15,7 +15,7 @@ if __name__ == "__main__":
     _build.build()
     out_dir = os.path.join(_build.HERE, "_variants")
     os.makedirs(out_dir, exist_ok=True)
-    prec, dp = 1, 64
+    prec, dp = [int(v) for v in os.environ.get("GT_VARIANT_UNIT", "1:64").split(":")]
     obj = os.path.join(out_dir, "sel_%s.o" % name)
     cmd = [_build._hipcc()] + _build.COMMON_FLAGS + ["-DGT_SEL_PREC=%d" % prec, "-DGT_SEL_DP=%d" % dp] + flags + [
         "-c", os.path.join(_build.CSRC, "gt_knn_select.hip"), "-o", obj]

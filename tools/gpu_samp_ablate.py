@@ -26,6 +26,8 @@ if __name__ == "__main__":
         ctx.set_option("select_samp_stride", str(stride))
         ctx.set_option("select_samp_keep", str(keep))
         ctx.set_option("select_samp_end", str(end))
+        if os.environ.get("GT_PREC"):
+            ctx.set_option("knn_precision", os.environ["GT_PREC"])
         if dbg:
             ctx.set_option("dbg_select", str(dbg))
         ctx.set_points(X)
@@ -36,7 +38,7 @@ if __name__ == "__main__":
             st = {s: round(ctx.stage_ms(s), 3) for s in ("knn_select", "rerank", "fallback", "radius", "affinity", "symmetrize", "normalize")}
             if best is None or st["knn_select"] < best["knn_select"]:
                 best = st
-        rec = {"n": n, "stride": stride, "keep": keep, "end": end, "nnz": nnz, "flags": fl, "stage_ms": best, "stats": ctx.graph_stats()}
+        rec = {"n": n, "stride": stride, "keep": keep, "end": end, "nnz": nnz, "flags": fl, "stage_ms": best, "stats": ctx.graph_stats(), "main": ctx.last_knn_precision()}
         print(json.dumps(rec), flush=True)
         out.append(rec)
         ctx.close()

@@ -32,7 +32,7 @@ for prec, dbg in [(p_, d_) for p_ in precs for d_ in dbgs]:
     d0, i0 = oracle.kneighbors(X, X[:256], 16)
     print(json.dumps({"prec": prec, "dbg": dbg, "nq": nq, "select_ms": round(best, 2), "TF_alg": round(flops / best / 1e9, 1),
                       "rerank_ms": round(ctx.stage_ms("rerank"), 2), "fallback_ms": round(ctx.stage_ms("fallback"), 2),
-                      "flags": fl, "idx_ok_256": bool(np.array_equal(i[:256], i0))}))
+                      "flags": fl, "idx_ok_256": bool(np.array_equal(i[:256], i0)), "main": ctx.last_knn_precision()}))
     if dbg & 64:
         import ctypes
         nw = (nq // 256) * 4
