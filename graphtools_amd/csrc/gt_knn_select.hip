@@ -41,6 +41,9 @@
 #ifndef GT_SEL_LIKELY
 #define GT_SEL_LIKELY 0
 #endif
+#ifndef GT_SEL_DSFIRST
+#define GT_SEL_DSFIRST 1
+#endif
 #ifndef GT_SEL_SETPRIO
 #define GT_SEL_SETPRIO 0
 #endif
@@ -389,7 +392,7 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
         // three accumulator sets rotate: unit u accumulates into accp[u%3] while the predicates of u-1 read
         // accp[(u-1)%3] and the seeds (-|y|^2/2) of u+1 are fetched from LDS into accp[(u+1)%3]
         f32x16 accp[3];
-        bool hg[4];
+        bool any_hit = false;
 #define GT_SEED(U_)                                                                                        \
     {                                                                                                      \
         _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) {                                                 \
@@ -401,14 +404,16 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
             accp[(U_) % 3][4 * g_ + 3] = hv_.w;                                                            \
         }                                                                                                  \
     }
-#define GT_ADMIT(PA_, HG_, PSB_, PQT_)                                                                     \
-    if (__builtin_expect(__ballot((HG_)[0] | (HG_)[1] | (HG_)[2] | (HG_)[3]) != 0ull, GT_SEL_LIKELY)) {   /* wave-uniform */ \
+#define GT_ADMIT(PA_, ANY_, PSB_, PQT_)                                                                    \
+    if (__builtin_expect(__ballot(ANY_) != 0ull, GT_SEL_LIKELY)) {   /* wave-uniform: most units admit nothing */ \
         const float tq_ = thr[PQT_];                                                                       \
         const unsigned long long ts_ = prof ? __builtin_readcyclecounter() : 0ull;                         \
         const int ql = (w * QT + (PQT_)) * 32 + li;                                                        \
         uint64_t* lp = lists + size_t(qblock + ql) * lstride + (MODE == 0 ? size_t(h) * HALF : size_t(0)); \
         _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                    \
-            if (__ballot((HG_)[g])) {                                                                      \
+            const bool hg_ = ((PA_)[4 * g] > tq_) | ((PA_)[4 * g + 1] > tq_) | ((PA_)[4 * g + 2] > tq_) |  \
+                             ((PA_)[4 * g + 3] > tq_);                                                     \
+            if (__ballot(hg_)) {                                                                           \
                 _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                            \
                     const float v = (PA_)[4 * g + e];                                                      \
                     if (v > tq_) {                                                                         \
@@ -442,26 +447,38 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
                 mma_chain<DP>(afr[(GT_SEL_EXP & 2) ? 0 : (sb & 1)], bq[qt], accp[u % 3]);
             }
             if (u > 0) {
-                // predicates from plain compares (no fmax: it would canonicalise every MFMA output)
+                // one predicate per lane: the largest of its 16 scores against the query's threshold (a v_max3 tree
+                // and one compare in the MFMA issue gaps; the per-element compares are redone on the cold admission path)
                 const float tq = (GT_SEL_EXP & 8) ? INFINITY : thr[pqt];
                 const f32x16& pa = accp[(u - 1) % 3];
                 if (GT_SEL_EXP & 8) asm volatile("" ::"v"(pa));   // keep the matrix work alive
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    hg[g] = (pa[4 * g] > tq) | (pa[4 * g + 1] > tq) | (pa[4 * g + 2] > tq) | (pa[4 * g + 3] > tq);
+                const float m0 = fmaxf(fmaxf(pa[0], pa[1]), pa[2]);
+                const float m1 = fmaxf(fmaxf(pa[3], pa[4]), pa[5]);
+                const float m2 = fmaxf(fmaxf(pa[6], pa[7]), pa[8]);
+                const float m3 = fmaxf(fmaxf(pa[9], pa[10]), pa[11]);
+                const float m4 = fmaxf(fmaxf(pa[12], pa[13]), pa[14]);
+                const float m5 = fmaxf(fmaxf(m0, m1), m2);
+                const float m6 = fmaxf(fmaxf(m3, m4), pa[15]);
+                any_hit = fmaxf(m5, m6) > tq;
             }
 #if GT_SEL_PIPE
             if (u > 0 && u < NU) {
-                // interleave: one MFMA, then a few of the compare / mask instructions of the previous unit
+                // The LDS reads of this step (seeds of unit u+1, A fragments of the next sub-tile) go right behind the
+                // first MFMA: the wait that MFMA needs (its seeds, read one unit ago) then has nothing young in front
+                // of it, and the new reads have the rest of the chain to land.
+                // Then: one MFMA, a few of the max / compare instructions of the previous unit, ...
 #pragma unroll
                 for (int i = 0; i < (PREC == 1 ? 3 * DP / 16 : PREC == 2 ? DP / 16 : DP / 2); ++i) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x002, PREC == 1 ? 2 : PREC == 2 ? 6 : 1, 0);   // VALU
-                    __builtin_amdgcn_sched_group_barrier(0x004, PREC == 1 ? 2 : PREC == 2 ? 6 : 1, 0);   // SALU
+#if GT_SEL_DSFIRST
+                    if (i == 0) __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);   // DS read (as many as there are)
+#endif
+                    __builtin_amdgcn_sched_group_barrier(0x002, PREC == 1 ? 1 : PREC == 2 ? 3 : 1, 0);   // VALU
+                    __builtin_amdgcn_sched_group_barrier(0x004, 1, 0);   // SALU
                 }
             }
 #endif
-            if (u > 0) GT_ADMIT(accp[(u - 1) % 3], hg, psb, pqt);
+            if (u > 0) GT_ADMIT(accp[(u - 1) % 3], any_hit, psb, pqt);
         }
         if (MODE == 0) {
             // ---- list maintenance: lane (li, h) owns half h of query (qt, li) ----

@@ -17,7 +17,7 @@ if __name__ == "__main__":
     os.makedirs(out_dir, exist_ok=True)
     prec, dp = [int(v) for v in os.environ.get("GT_VARIANT_UNIT", "1:64").split(":")]
     obj = os.path.join(out_dir, "sel_%s.o" % name)
-    cmd = [_build._hipcc()] + _build.COMMON_FLAGS + ["-DGT_SEL_PREC=%d" % prec, "-DGT_SEL_DP=%d" % dp] + flags + [
+    cmd = [_build._hipcc()] + _build.COMMON_FLAGS + ["-DGT_SEL_PREC=%d" % prec, "-DGT_SEL_DP=%d" % dp] + _build.SELECT_FLAGS + flags + [
         "-c", os.path.join(_build.CSRC, "gt_knn_select.hip"), "-o", obj]
     subprocess.run(cmd, check=True)
     objs = []

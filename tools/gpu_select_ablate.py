@@ -11,7 +11,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
 precs = sys.argv[2].split(",") if len(sys.argv) > 2 else ["f16", "f32"]
 D = int(os.environ.get("GT_DIM", "64"))
 X = make_mix(n, D, 1)
-nq = min(n, 131072)
+nq = min(n, int(os.environ.get("GT_NQ", "131072")))
 import oracle
 dbgs = [int(v) for v in sys.argv[3].split(",")] if len(sys.argv) > 3 else [0]
 for prec, dbg in [(p_, d_) for p_ in precs for d_ in dbgs]:
