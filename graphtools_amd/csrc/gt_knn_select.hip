@@ -8,22 +8,24 @@
 // loop it holds the score  s = x.y - |y|^2/2  (d^2 = |x|^2 - 2 s: larger score = closer), and the per-query
 // running threshold is a single VGPR compare per lane.
 //
-// Two arithmetic back ends produce the scores (PREC):
+// Three arithmetic back ends produce the scores (PREC):
 //   PREC 0  float32 operands, v_mfma_f32_32x32x2_f32 (157 TF peak): exact products, fp32 accumulation.
 //   PREC 1  every (power-of-two scaled) value is split into two float16 planes x = hi + lo (22 significant
 //           bits); x.y ~ hi.hi + hi.lo + lo.hi with three v_mfma_f32_32x32x16_f16 chains (2.5 PF peak, fp32
 //           accumulation).  5.3x fewer matrix-pipe cycles than PREC 0 at fp32-class accuracy.
-//   PREC 2  the same working copy as PREC 1, hi planes only: one MFMA chain per product (11 significant bits,
-//           score error <= 2^-10 |x||y|).  3x fewer matrix-pipe cycles again; the host uses it for the main pass
-//           when the data tolerate the wider error bound (gt_knn.cpp) - repairs always run in PREC 1.
+//   PREC 2  a compact copy of the hi planes alone (rows of 2*DP bytes): one MFMA chain per product (11 significant
+//           bits; the score error is bounded with the measured float16 residual norms, gt_knn.cpp).  3x fewer
+//           matrix-pipe cycles again, half the LDS and fabric traffic, 3 workgroups per CU; the host uses it for the
+//           main pass when the data tolerate the wider error bound - repairs always run in PREC 1.
 // Either way the scores only have to be within a KNOWN error bound of the true ones: exact ordering is
 // established afterwards in float64 (gt_rerank.hip), which also proves the candidate table complete or sends
 // the row to an exhaustive fallback.
 //
 // MODE 0 (top-M' selection): survivors (s > thr) are appended to the query's candidate list in global
 //   memory (each half-wave owns one half of the list and keeps its fill count in a register: no atomics, no
-//   cross-wave traffic).  When a half passes its trigger level the owning wave selects the best M' = 16*NT of its 64*NT keys (bitwise search for
-//   the M'-th largest score with wave ballots, then an order-free filter) and raises thr to the M'-th score.
+//   cross-wave traffic).  When a half passes its trigger level the owning wave selects the best 16*NT of its
+//   64*NT keys (bitwise search for the 16*NT-th largest score with wave ballots, then an order-free filter) and
+//   raises thr to that score.
 //   At the end list[0..count) holds the candidates (unordered) and thr_out the last admission threshold.
 // MODE 1 (radius collect): thr is a fixed per-query score bound; every survivor is appended (up to `cap`
 //   entries per query, the true count is always reported).  Slots come from a global counter so the
@@ -37,15 +39,8 @@
 #ifndef GT_SEL_PIPE
 #define GT_SEL_PIPE 1
 #endif
-// the admission path is laid out of line (cold): the common case - no lane beat its threshold - falls through
-#ifndef GT_SEL_LIKELY
-#define GT_SEL_LIKELY 0
-#endif
 #ifndef GT_SEL_DSFIRST
 #define GT_SEL_DSFIRST 1
-#endif
-#ifndef GT_SEL_SETPRIO
-#define GT_SEL_SETPRIO 0
 #endif
 // development ablations (tools/build_variant.py; results are invalid when set):
 //   1 seeds not read from LDS   2 A fragments read once per tile   4 no staging / barrier after the first tile
@@ -63,9 +58,6 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 // staging registers, no ds_write pass).  The LDS image is then lane-linear, so rows cannot be padded; bank
 // conflicts are avoided by an XOR swizzle of the 16-byte chunk index with a function of the row, applied to the
 // per-lane SOURCE address of the load and to the ds_read address alike (power-of-two row sizes only).
-#ifndef GT_SEL_P2_BN
-#define GT_SEL_P2_BN 128
-#endif
 #ifndef GT_SEL_GLDS
 #define GT_SEL_GLDS 1
 #endif
@@ -73,7 +65,7 @@ template <int DP, int PREC>
 struct SelCfg {
     static constexpr int QT = (DP <= 64) ? 2 : 1;       // 32-row query tiles per wave
     static constexpr int BQ = 4 * QT * 32;              // query rows per workgroup
-    static constexpr int BN = (DP <= 64) ? ((PREC == 2) ? GT_SEL_P2_BN : 128) : 64;    // database rows per LDS tile
+    static constexpr int BN = (DP <= 64) ? 128 : 64;    // database rows per LDS tile
     static constexpr int RW = (PREC == 2) ? DP / 2 : DP;   // row width in dwords: float32 | hi,lo float16 planes | hi plane
     static constexpr int RB = 4 * RW;                   // row bytes
     static constexpr bool GLDS = GT_SEL_GLDS && PREC >= 1 && (RB & (RB - 1)) == 0 && RB <= 512 && (BN * RB) % 4096 == 0;
@@ -405,7 +397,7 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
         }                                                                                                  \
     }
 #define GT_ADMIT(PA_, ANY_, PSB_, PQT_)                                                                    \
-    if (__builtin_expect(__ballot(ANY_) != 0ull, GT_SEL_LIKELY)) {   /* wave-uniform: most units admit nothing */ \
+    if (__builtin_expect(__ballot(ANY_) != 0ull, 0)) {   /* wave-uniform and cold: most units admit nothing */  \
         const float tq_ = thr[PQT_];                                                                       \
         const unsigned long long ts_ = prof ? __builtin_readcyclecounter() : 0ull;                         \
         const int ql = (w * QT + (PQT_)) * 32 + li;                                                        \

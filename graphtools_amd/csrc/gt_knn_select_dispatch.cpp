@@ -22,9 +22,8 @@ int gt_choose_dp_prec(int d, int prec) {
 
 int gt_choose_dp(int d) { return gt_choose_dp_prec(d, 0); }
 int gt_select_bq(int dp) { return dp <= 64 ? 256 : 128; }
-// row padding granule of the working copies: a multiple of every kernel's tile (128 / 64 rows; 256 for the compact
-// single-chain tiles when built with GT_SEL_P2_BN=256)
-int gt_select_bn(int dp) { return dp <= 64 ? 256 : 64; }
+// row padding granule of the working copies: a multiple of every kernel's tile (128 / 64 rows)
+int gt_select_bn(int dp) { return dp <= 64 ? 128 : 64; }
 
 int gt_launch_select(gt_ctx* ctx, const SelectArgs& a) {
 #define GT_CASE(PR_, DP_) if (a.prec == PR_ && a.dp == DP_) return gt_launch_select_p##PR_##_dp##DP_(ctx, a);
