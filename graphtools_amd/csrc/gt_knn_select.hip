@@ -179,16 +179,18 @@ __device__ __forceinline__ void list_store(uint64_t* p, uint64_t v) {
 // only up to the quota; dropping the rest is consistent with the strict `score > thr` admission test.
 // CONTIG: survivors go to slots [0, kept) (final table); else they are dealt evenly to the two halves.
 // Returns the threshold implied by the selection (-inf when nothing had to be dropped).
-template <int NT, bool CONTIG>
-__device__ __forceinline__ float compact_list(uint64_t* __restrict__ lp, const uint32_t n0, const uint32_t n1,
-                                              const int lane, uint32_t& kept, const uint32_t MKEEP = 16 * NT) {
+// NTE = key slots per lane actually populated (entries per half <= 32*NTE): the ballots of the bitwise search scale
+// with it, and most compactions (threshold-seeding phase, final tables) see short lists.
+template <int NT, int NTE, bool CONTIG>
+__device__ __forceinline__ float compact_impl(uint64_t* __restrict__ lp, const uint32_t n0, const uint32_t n1,
+                                              const int lane, uint32_t& kept, const uint32_t MKEEP) {
     constexpr uint32_t HALF = 32 * NT;
-    uint64_t key[NT];
-    uint32_t ord[NT];
+    uint64_t key[NTE];
+    uint32_t ord[NTE];
 #pragma unroll
-    for (int u = 0; u < NT; ++u) {
-        const bool second = u >= NT / 2;
-        const uint32_t e = uint32_t((second ? u - NT / 2 : u) * 64 + lane);
+    for (int u = 0; u < NTE; ++u) {
+        const bool second = u >= NTE / 2;
+        const uint32_t e = uint32_t((second ? u - NTE / 2 : u) * 64 + lane);
         const bool valid = e < (second ? n1 : n0);
         key[u] = valid ? ld_agent_u64(lp + (second ? HALF : 0u) + e) : 0ull;
         ord[u] = uint32_t(key[u] >> 32);   // a valid key has ord > 0 (ord(-inf) = 0x007fffff)
@@ -201,19 +203,19 @@ __device__ __forceinline__ float compact_list(uint64_t* __restrict__ lp, const u
             const uint32_t trial = T | (1u << b);
             uint32_t c = 0;
 #pragma unroll
-            for (int u = 0; u < NT; ++u) c += uint32_t(__popcll(__ballot(ord[u] >= trial)));
+            for (int u = 0; u < NTE; ++u) c += uint32_t(__popcll(__ballot(ord[u] >= trial)));
             if (c >= MKEEP) T = trial;
         }
         c_gt = 0;
 #pragma unroll
-        for (int u = 0; u < NT; ++u) c_gt += uint32_t(__popcll(__ballot(ord[u] > T)));
+        for (int u = 0; u < NTE; ++u) c_gt += uint32_t(__popcll(__ballot(ord[u] > T)));
         quota_eq = MKEEP - c_gt;
     }
     kept = n > MKEEP ? MKEEP : n;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     uint32_t base_gt = 0, base_eq = 0;
 #pragma unroll
-    for (int u = 0; u < NT; ++u) {
+    for (int u = 0; u < NTE; ++u) {
         const bool gt = ord[u] > T;
         const bool eq = (ord[u] == T) && (T != 0u);
         const unsigned long long mg = __ballot(gt), me = __ballot(eq);
@@ -227,6 +229,19 @@ __device__ __forceinline__ float compact_list(uint64_t* __restrict__ lp, const u
         base_eq += uint32_t(__popcll(me));
     }
     return n > MKEEP ? ord_f32(T) : -INFINITY;
+}
+
+template <int NT, bool CONTIG>
+__device__ __forceinline__ float compact_list(uint64_t* __restrict__ lp, const uint32_t n0, const uint32_t n1,
+                                              const int lane, uint32_t& kept, const uint32_t MKEEP = 16 * NT) {
+    const uint32_t nm = n0 > n1 ? n0 : n1;   // wave-uniform
+    if (nm <= 64u) return compact_impl<NT, 2, CONTIG>(lp, n0, n1, lane, kept, MKEEP);
+    if (nm <= 128u) return compact_impl<NT, 4, CONTIG>(lp, n0, n1, lane, kept, MKEEP);
+    if constexpr (NT > 8) {
+        if (nm <= 256u) return compact_impl<NT, 8, CONTIG>(lp, n0, n1, lane, kept, MKEEP);
+        if (nm <= 512u) return compact_impl<NT, 16, CONTIG>(lp, n0, n1, lane, kept, MKEEP);
+    }
+    return compact_impl<NT, NT, CONTIG>(lp, n0, n1, lane, kept, MKEEP);
 }
 
 #ifndef GT_SEL_P2_WAVES
