@@ -338,7 +338,8 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
         const char* gt_ = reinterpret_cast<const char*>(Yp) + size_t((GT_SEL_EXP & 64) ? ((T_) & 15) : (T_)) * BN * C::RB; \
         char* lt_ = reinterpret_cast<char*>(tile + (BUF_) * C::TILE_FLOATS);                               \
         uint32_t lv_ = uint32_t(lane);                                                                     \
-        asm volatile("" : "+v"(lv_));   /* recompute the lane offsets per tile instead of pinning 8 registers */ \
+        /* many pieces: recompute the lane offsets per tile instead of pinning a register each */          \
+        if (C::NPW > 2) asm volatile("" : "+v"(lv_));                                                      \
         _Pragma("unroll") for (int i_ = 0; i_ < C::NPW; ++i_) {                                            \
             const uint32_t p_ = uint32_t(wu * C::NPW + i_);                                                \
             const uint32_t r_ = p_ * C::RPP + lv_ / C::CPR;                                                \
@@ -357,16 +358,17 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
     // keep >= the number of neighbours wanted is correct - thresholds only ever rise, and every entry dropped
     // or rejected scored <= the final threshold - the split only cuts the number of admissions (~3x).
     const int n_a = (MODE == 0 && samp_stride > 1) ? (ntiles + samp_stride - 1) / samp_stride : 0;
-#define GT_TILE_OF(IT_) \
-    ((IT_) < n_a ? (IT_) * samp_stride : (n_a ? ((IT_) - n_a) + ((IT_) - n_a) / (samp_stride - 1) + 1 : (IT_)))
+    // running tile index (no divisions in the loop): phase A steps by samp_stride, phase B by one and hops over the
+    // multiples of samp_stride (t_mod tracks t mod samp_stride there)
+    int t = t_begin, t_mod = 0;
 
     if constexpr (C::GLDS) {
-        GT_GLDS_ISSUE(GT_TILE_OF(t_begin), 0);
+        GT_GLDS_ISSUE(t, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
-        GT_STAGE_LOAD(GT_TILE_OF(t_begin), 0);
+        GT_STAGE_LOAD(t, 0);
         GT_STAGE_STORE(0, 0);
-        GT_STAGE_LOAD(GT_TILE_OF(t_begin), 1);
+        GT_STAGE_LOAD(t, 1);
         GT_STAGE_STORE(0, 1);
     }
     __syncthreads();
@@ -374,8 +376,19 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
 
     for (int it = t_begin; it < t_end; ++it) {
         const int buf = (GT_SEL_EXP & (4 | 32)) ? 0 : ((it - t_begin) & 1);
-        const int t = GT_TILE_OF(it);
-        const int t_next = GT_TILE_OF(it + 1);
+        int t_next, t_mod_next = t_mod;
+        if (it + 1 < n_a) {
+            t_next = t + samp_stride;
+        } else if (n_a && it + 1 == n_a) {
+            t_next = 1;                      // first tile that is not a multiple of samp_stride
+            t_mod_next = 1;
+        } else {
+            t_next = t + 1;
+            if (n_a && ++t_mod_next == samp_stride) {
+                t_next += 1;
+                t_mod_next = 1;
+            }
+        }
         if (!(GT_SEL_EXP & (4 | 32)) && it + 1 < t_end) {
             if constexpr (C::GLDS) {
                 GT_GLDS_ISSUE(t_next, buf ^ 1);   // every wave left buf^1 at the barrier that ended the previous tile
@@ -400,6 +413,7 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
         // accp[(u-1)%3] and the seeds (-|y|^2/2) of u+1 are fetched from LDS into accp[(u+1)%3]
         f32x16 accp[3];
         bool any_hit = false;
+        float mx[5];
 #define GT_SEED(U_)                                                                                        \
     {                                                                                                      \
         _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) {                                                 \
@@ -411,31 +425,36 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
             accp[(U_) % 3][4 * g_ + 3] = hv_.w;                                                            \
         }                                                                                                  \
     }
-#define GT_ADMIT(PA_, ANY_, PSB_, PQT_)                                                                    \
+// cold path: the partial maxima of the hot path's v_max3 tree (MX_[t] covers elements 3t .. 3t+2, element 15 stands
+// alone) say which triples hold a hit, only those are looked at element by element
+#define GT_ADMIT_ONE(PA_, E_, PSB_, PQT_)                                                                  \
+    {                                                                                                      \
+        const float v = (PA_)[E_];                                                                         \
+        if (v > tq_) {                                                                                     \
+            const uint32_t j = tbase + uint32_t((PSB_) * 32 + 8 * ((E_) >> 2) + 4 * h + ((E_) & 3));       \
+            if (MODE == 0) {                                                                               \
+                list_store(lp + fill[PQT_], cand_pack(v, j));                                              \
+                fill[PQT_] += 1u;                                                                          \
+            } else {                                                                                       \
+                const uint32_t slot = atomicAdd(&counts[qblock + ql], 1u);                                 \
+                if (slot < uint32_t(cap)) lp[slot] = cand_pack(v, j);                                      \
+            }                                                                                              \
+        }                                                                                                  \
+    }
+#define GT_ADMIT(PA_, ANY_, MX_, PSB_, PQT_)                                                               \
     if (__builtin_expect(__ballot(ANY_) != 0ull, 0)) {   /* wave-uniform and cold: most units admit nothing */  \
         const float tq_ = thr[PQT_];                                                                       \
         const unsigned long long ts_ = prof ? __builtin_readcyclecounter() : 0ull;                         \
         const int ql = (w * QT + (PQT_)) * 32 + li;                                                        \
         uint64_t* lp = lists + size_t(qblock + ql) * lstride + (MODE == 0 ? size_t(h) * HALF : size_t(0)); \
-        _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                    \
-            const bool hg_ = ((PA_)[4 * g] > tq_) | ((PA_)[4 * g + 1] > tq_) | ((PA_)[4 * g + 2] > tq_) |  \
-                             ((PA_)[4 * g + 3] > tq_);                                                     \
-            if (__ballot(hg_)) {                                                                           \
-                _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                            \
-                    const float v = (PA_)[4 * g + e];                                                      \
-                    if (v > tq_) {                                                                         \
-                        const uint32_t j = tbase + uint32_t((PSB_) * 32 + 8 * g + 4 * h + e);              \
-                        if (MODE == 0) {                                                                   \
-                            list_store(lp + fill[PQT_], cand_pack(v, j));                                  \
-                            fill[PQT_] += 1u;                                                              \
-                        } else {                                                                           \
-                            const uint32_t slot = atomicAdd(&counts[qblock + ql], 1u);                     \
-                            if (slot < uint32_t(cap)) lp[slot] = cand_pack(v, j);                          \
-                        }                                                                                  \
-                    }                                                                                      \
-                }                                                                                          \
+        _Pragma("unroll") for (int t_ = 0; t_ < 5; ++t_) {                                                 \
+            if (__ballot((MX_)[t_] > tq_)) {                                                               \
+                GT_ADMIT_ONE(PA_, 3 * t_ + 0, PSB_, PQT_);                                                 \
+                GT_ADMIT_ONE(PA_, 3 * t_ + 1, PSB_, PQT_);                                                 \
+                GT_ADMIT_ONE(PA_, 3 * t_ + 2, PSB_, PQT_);                                                 \
             }                                                                                              \
         }                                                                                                  \
+        if (__ballot((PA_)[15] > tq_)) GT_ADMIT_ONE(PA_, 15, PSB_, PQT_);                                  \
         if (prof) { t_adm += __builtin_readcyclecounter() - ts_; n_adm += 1; }                             \
     }
         GT_SEED(0);
@@ -459,13 +478,10 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
                 const float tq = (GT_SEL_EXP & 8) ? INFINITY : thr[pqt];
                 const f32x16& pa = accp[(u - 1) % 3];
                 if (GT_SEL_EXP & 8) asm volatile("" ::"v"(pa));   // keep the matrix work alive
-                const float m0 = fmaxf(fmaxf(pa[0], pa[1]), pa[2]);
-                const float m1 = fmaxf(fmaxf(pa[3], pa[4]), pa[5]);
-                const float m2 = fmaxf(fmaxf(pa[6], pa[7]), pa[8]);
-                const float m3 = fmaxf(fmaxf(pa[9], pa[10]), pa[11]);
-                const float m4 = fmaxf(fmaxf(pa[12], pa[13]), pa[14]);
-                const float m5 = fmaxf(fmaxf(m0, m1), m2);
-                const float m6 = fmaxf(fmaxf(m3, m4), pa[15]);
+#pragma unroll
+                for (int t3 = 0; t3 < 5; ++t3) mx[t3] = fmaxf(fmaxf(pa[3 * t3], pa[3 * t3 + 1]), pa[3 * t3 + 2]);
+                const float m5 = fmaxf(fmaxf(mx[0], mx[1]), mx[2]);
+                const float m6 = fmaxf(fmaxf(mx[3], mx[4]), pa[15]);
                 any_hit = fmaxf(m5, m6) > tq;
             }
 #if GT_SEL_PIPE
@@ -485,7 +501,7 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
                 }
             }
 #endif
-            if (u > 0) GT_ADMIT(accp[(u - 1) % 3], any_hit, psb, pqt);
+            if (u > 0) GT_ADMIT(accp[(u - 1) % 3], any_hit, mx, psb, pqt);
         }
         if (MODE == 0) {
             // ---- list maintenance: lane (li, h) owns half h of query (qt, li) ----
@@ -536,6 +552,8 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
             __syncthreads();
             if (prof) t_bar += __builtin_readcyclecounter() - ts_;
         }
+        t = t_next;
+        t_mod = t_mod_next;
     }
     if (prof && lane == 0) {
         unsigned long long* o = prof + (size_t(blockIdx.x) * 4 + w) * 8;
