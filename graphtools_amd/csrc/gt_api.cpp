@@ -71,6 +71,8 @@ void gt_ctx_destroy(gt_ctx* ctx) {
     ctx->X_own.release();
     ctx->Yp.release();
     ctx->Yc.release();
+    ctx->small_tmp.release();
+    ctx->lomax_dev.release();
     ctx->xn.release();
     ctx->hneg.release();
     ctx->ymax.release();

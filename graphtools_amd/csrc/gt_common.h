@@ -8,6 +8,8 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <chrono>
+#include <cstdlib>
 #include <string>
 #include <utility>
 #include <vector>
@@ -106,6 +108,8 @@ struct gt_ctx {
     double lomax = 0.0;  // prec 1: max over rows of |x - hi(x)|_2 (true units), the float16 rounding residual norm
     double qlomax = 0.0; //         same for the external query matrix of the current call
     DevBuf lomax_dev;
+    DevBuf small_tmp;    // a few persistent bytes for scalar reductions (no hipMalloc / hipFree on the per-call paths:
+                         // both can stall for seconds in a process that also runs RCCL)
     int32_t metric = 0;  // 0 euclidean, 1 cosine (points are row-normalised copies; distance = 1 - x.y)
     DevBuf X_norm;       // cosine: normalised points in the input dtype
     int32_t samp_stride = 16; // candidate pass: threshold-seeding phase over every samp_stride-th tile (<= 1: off)
@@ -170,6 +174,29 @@ struct StageSpan {
 };
 
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// GT_TRACE=1: host wall-clock trace of the coarse steps of a call (development aid; synchronises the stream)
+struct HostTrace {
+    gt_ctx* ctx;
+    const char* what;
+    bool on;
+    std::chrono::steady_clock::time_point t0;
+    HostTrace(gt_ctx* c, const char* w) : ctx(c), what(w) {
+        static const bool enabled = std::getenv("GT_TRACE") != nullptr;
+        on = enabled;
+        if (on) {
+            (void)hipStreamSynchronize(c->stream);
+            t0 = std::chrono::steady_clock::now();
+        }
+    }
+    ~HostTrace() {
+        if (on) {
+            (void)hipStreamSynchronize(ctx->stream);
+            const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            std::fprintf(stderr, "[gt_trace] %-28s %10.3f ms\n", what, ms);
+        }
+    }
+};
 
 // gt_prep.hip
 int gt_prep_points(gt_ctx* ctx);

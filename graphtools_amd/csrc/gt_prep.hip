@@ -132,8 +132,8 @@ int gt_normalize_rows(gt_ctx* ctx, const void* X, void* out, int64_t n, int d, i
 }
 
 int gt_max_abs(gt_ctx* ctx, const void* Xdev, int64_t total, int dtype, double* out_host) {
-    DevBuf tmp;
-    GT_HIP(ctx, tmp.reserve(sizeof(double)));
+    DevBuf& tmp = ctx->small_tmp;
+    GT_HIP(ctx, tmp.reserve(64));
     GT_HIP(ctx, hipMemsetAsync(tmp.p, 0, sizeof(double), ctx->stream));
     int64_t blocks = std::min<int64_t>(ceil_div64(total, 256), 4096);
     if (dtype == GT_F32)
@@ -145,7 +145,6 @@ int gt_max_abs(gt_ctx* ctx, const void* Xdev, int64_t total, int dtype, double* 
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(out_host, tmp.p, sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    tmp.release();
     if (e != hipSuccess) {
         ctx->set_error(std::string("max_abs: ") + hipGetErrorString(e));
         return GT_E_HIP;

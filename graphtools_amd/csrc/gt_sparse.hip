@@ -21,8 +21,8 @@ void gt_free_graph_state(gt_ctx* ctx) {
     for (DevBuf* b : {&g->bw, &g->bw_user, &g->rowsrc, &g->lenN, &g->lenT, &g->cursor, &g->off, &g->outlen, &g->indptr,
                       &g->degree, &g->over_rows, &g->over_count, &g->rthr, &g->rlists, &g->rcounts, &g->rK, &g->rmax,
                       &g->ownercnt, &g->ownerpos, &g->scan_tmp, &g->selfbuf, &g->splits_dev, &g->Ukey, &g->Uval, &g->Vkey, &g->Vval,
-                      &g->bigrows, &g->bigcount, &g->bigscratch_k, &g->bigscratch_v, &g->indices, &g->Kdata, &g->Pdata,
-                      &g->flags})
+                      &g->bigrows, &g->bigcount, &g->bigscratch_k, &g->bigscratch_v, &g->bigsoff, &g->aniso_tmp, &g->scan_own,
+                      &g->indices, &g->Kdata, &g->Pdata, &g->flags})
         b->release();
     delete g;
     ctx->graph = nullptr;
@@ -918,6 +918,7 @@ extern "C" int gt_graph_finish(gt_ctx* ctx, const void* recv_buf_dev, int64_t n_
     const int64_t nloc = g->nloc;
     {
         StageSpan span(ctx, "symmetrize");
+        HostTrace tr_all(ctx, "finish: symmetrize");
         GT_HIP(ctx, hipMemsetAsync(g->lenT.p, 0, size_t(nloc) * sizeof(int32_t), ctx->stream));
         GT_HIP(ctx, hipMemsetAsync(g->cursor.p, 0, size_t(nloc) * sizeof(int32_t), ctx->stream));
         if (n_recv > 0) {
@@ -939,6 +940,7 @@ extern "C" int gt_graph_finish(gt_ctx* ctx, const void* recv_buf_dev, int64_t n_
         }
         GT_TRY(rc);
         g->nnz0 = total_u - n_recv;
+        HostTrace tr_u(ctx, "finish: fill + merge");
         GT_HIP(ctx, g->Ukey.reserve(size_t(total_u) * sizeof(uint32_t)));
         GT_HIP(ctx, g->Uval.reserve(size_t(total_u) * sizeof(double)));
         GT_HIP(ctx, g->Vkey.reserve(size_t(total_u) * sizeof(uint32_t)));
@@ -965,12 +967,19 @@ extern "C" int gt_graph_finish(gt_ctx* ctx, const void* recv_buf_dev, int64_t n_
         uint32_t nbig = 0;
         GT_HIP(ctx, hipMemcpyAsync(&nbig, g->bigcount.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
         GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        HostTrace tr_b(ctx, "finish: long rows + compact");
         if (nbig > 0) {
             // rows longer than kBigRow: global-memory bitonic sort, one workgroup per row
             std::vector<int32_t> rows(nbig);
-            GT_HIP(ctx, hipMemcpy(rows.data(), g->bigrows.p, size_t(nbig) * sizeof(int32_t), hipMemcpyDeviceToHost));
             std::vector<int64_t> offh(nloc + 1);
-            GT_HIP(ctx, hipMemcpy(offh.data(), g->off.p, size_t(nloc + 1) * sizeof(int64_t), hipMemcpyDeviceToHost));
+            {
+                // copies on the library's stream (the null stream would synchronise with every other stream of the process)
+                GT_HIP(ctx, hipMemcpyAsync(rows.data(), g->bigrows.p, size_t(nbig) * sizeof(int32_t), hipMemcpyDeviceToHost,
+                                           ctx->stream));
+                GT_HIP(ctx, hipMemcpyAsync(offh.data(), g->off.p, size_t(nloc + 1) * sizeof(int64_t), hipMemcpyDeviceToHost,
+                                           ctx->stream));
+                GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            }
             std::vector<int64_t> soff(nbig + 1, 0);
             for (uint32_t b = 0; b < nbig; ++b) {
                 const int64_t L = offh[rows[b] + 1] - offh[rows[b]];
@@ -978,9 +987,16 @@ extern "C" int gt_graph_finish(gt_ctx* ctx, const void* recv_buf_dev, int64_t n_
                 while (P < L) P <<= 1;
                 soff[b + 1] = soff[b] + P;
             }
-            DevBuf soff_dev;
+            if (std::getenv("GT_TRACE")) {
+                int64_t lmax = 0;
+                for (uint32_t b = 0; b < nbig; ++b) lmax = std::max<int64_t>(lmax, offh[rows[b] + 1] - offh[rows[b]]);
+                std::fprintf(stderr, "[gt_trace] long rows: %u, longest %lld entries (received %lld triplets)\n", nbig,
+                             (long long)lmax, (long long)n_recv);
+            }
+            DevBuf& soff_dev = g->bigsoff;   // persistent: no hipMalloc / hipFree per call
             GT_HIP(ctx, soff_dev.reserve(size_t(nbig + 1) * sizeof(int64_t)));
-            GT_HIP(ctx, hipMemcpy(soff_dev.p, soff.data(), size_t(nbig + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+            GT_HIP(ctx, hipMemcpyAsync(soff_dev.p, soff.data(), size_t(nbig + 1) * sizeof(int64_t), hipMemcpyHostToDevice,
+                                       ctx->stream));
             GT_HIP(ctx, g->bigscratch_k.reserve(size_t(soff[nbig]) * sizeof(uint32_t)));
             GT_HIP(ctx, g->bigscratch_v.reserve(size_t(soff[nbig]) * sizeof(double)));
             hipLaunchKernelGGL(big_sort_kernel, dim3(nbig), dim3(1024), 0, ctx->stream, g->bigrows.as<int32_t>(),
@@ -992,7 +1008,6 @@ extern "C" int gt_graph_finish(gt_ctx* ctx, const void* recv_buf_dev, int64_t n_
                                g->Vval.as<double>(), g->outlen.as<int32_t>());
             hipError_t e = hipGetLastError();
             if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-            soff_dev.release();
             if (e != hipSuccess) {
                 ctx->set_error(std::string("big-row sort: ") + hipGetErrorString(e));
                 return GT_E_HIP;
@@ -1053,14 +1068,13 @@ static int finish_normalize(gt_ctx* ctx, GraphState* g, const double* degree_all
     const int64_t nloc = g->nloc;
     if (degree_all_dev && g->p.anisotropy != 0.0) {
         // degree_all_dev is indexed by GLOBAL row; for world == 1 the local degree vector is global
-        DevBuf tmp;
+        DevBuf& tmp = g->aniso_tmp;
         GT_HIP(ctx, tmp.reserve(size_t(nloc) * sizeof(double)));
         hipLaunchKernelGGL(anisotropy_kernel, dim3((unsigned)ceil_div64(nloc, 4)), dim3(256), 0, ctx->stream, nloc, g->r0,
                            g->indptr.as<int64_t>(), g->indices.as<int32_t>(), g->Kdata.as<double>(), degree_all_dev,
                            g->p.anisotropy, tmp.as<double>());
         hipError_t e = hipMemcpyAsync(g->degree.p, tmp.p, size_t(nloc) * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-        tmp.release();
         if (e != hipSuccess) {
             ctx->set_error(std::string("anisotropy: ") + hipGetErrorString(e));
             return GT_E_HIP;

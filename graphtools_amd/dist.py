@@ -43,7 +43,13 @@ def exchange_counts(send_counts, device, group=None):
     return recv.cpu().numpy()
 
 
-def exchange_triplets(send_words, send_counts, group=None):
+# Largest per-peer message handed to one collective call.  RCCL 2.26 as shipped with torch 2.10+rocm7.0 delivers only
+# half of a send/recv pair once it exceeds 1 GiB (tools/gpu_a2a_probe.py: 1024 MB intact, 1150 MB half zeros), so
+# bigger segments are moved in rounds.
+MAX_PEER_BYTES = 512 << 20
+
+
+def exchange_triplets(send_words, send_counts, group=None, max_peer_bytes=None):
     """all-to-all of the bucketed triplet buffer.
 
     send_words : int64 tensor of 2 * sum(send_counts) words, buckets in rank order
@@ -52,15 +58,43 @@ def exchange_triplets(send_words, send_counts, group=None):
     import torch
 
     dist = _dist()
+    world = dist.get_world_size(group)
     send_counts = np.asarray(send_counts, dtype=np.int64)
     recv_counts = exchange_counts(send_counts, send_words.device, group)
     recv = torch.empty(int(recv_counts.sum()) * WORDS_PER_TRIPLET, dtype=torch.int64, device=send_words.device)
-    dist.all_to_all_single(
-        recv, send_words,
-        output_split_sizes=[int(c) * WORDS_PER_TRIPLET for c in recv_counts],
-        input_split_sizes=[int(c) * WORDS_PER_TRIPLET for c in send_counts],
-        group=group,
-    )
+    limit = int(max_peer_bytes or MAX_PEER_BYTES) // (8 * WORDS_PER_TRIPLET)      # triplets per peer and round
+    biggest = int(max(send_counts.max(initial=0), recv_counts.max(initial=0)))
+    if biggest <= limit:
+        dist.all_to_all_single(
+            recv, send_words,
+            output_split_sizes=[int(c) * WORDS_PER_TRIPLET for c in recv_counts],
+            input_split_sizes=[int(c) * WORDS_PER_TRIPLET for c in send_counts],
+            group=group,
+        )
+        return recv, recv_counts
+    # rounds of at most `limit` triplets per ordered pair; every rank derives the same number of rounds
+    rounds = torch.tensor([-(-biggest // limit)], dtype=torch.int64, device=send_words.device)
+    dist.all_reduce(rounds, op=dist.ReduceOp.MAX, group=group)
+    send_off = np.concatenate([[0], np.cumsum(send_counts)])
+    recv_off = np.concatenate([[0], np.cumsum(recv_counts)])
+    for k in range(int(rounds.item())):
+        s_len = np.clip(send_counts - k * limit, 0, limit)
+        r_len = np.clip(recv_counts - k * limit, 0, limit)
+        s_in = torch.cat([send_words[(send_off[p] + k * limit) * WORDS_PER_TRIPLET:
+                                     (send_off[p] + k * limit + s_len[p]) * WORDS_PER_TRIPLET] for p in range(world)])
+        r_out = torch.empty(int(r_len.sum()) * WORDS_PER_TRIPLET, dtype=torch.int64, device=send_words.device)
+        dist.all_to_all_single(
+            r_out, s_in,
+            output_split_sizes=[int(c) * WORDS_PER_TRIPLET for c in r_len],
+            input_split_sizes=[int(c) * WORDS_PER_TRIPLET for c in s_len],
+            group=group,
+        )
+        pos = 0
+        for p in range(world):
+            n = int(r_len[p]) * WORDS_PER_TRIPLET
+            a = (int(recv_off[p]) + k * limit) * WORDS_PER_TRIPLET
+            recv[a: a + n] = r_out[pos: pos + n]
+            pos += n
     return recv, recv_counts
 
 

@@ -118,6 +118,10 @@ def main():
     tot = torch.tensor([float(trip["val"].sum()), float(got["val"].sum()), float(m), float(len(got))], dtype=torch.float64)
     dist.all_reduce(tot)
     assert abs(tot[0] - tot[1]) < 1e-9 and tot[2] == tot[3]
+    # the same exchange in rounds of at most 100 triplets per ordered pair (the path that keeps every message
+    # below RCCL's 1 GiB limit) delivers the identical buffer
+    recv2, rc2 = gdist.exchange_triplets(send, counts, max_peer_bytes=100 * 16)
+    assert np.array_equal(rc2, rc) and torch.equal(recv2, recv)
 
     # 4. end-to-end sharded build through ShardedKnnGraph with the numpy stand-in context
     from tests_helpers_mix import make_mix  # noqa: E402  (injected by the launcher)
