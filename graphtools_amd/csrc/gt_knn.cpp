@@ -69,9 +69,11 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
     const bool fast_auto = ctx->prec == 1 && ctx->fast_mode == 1;
     if (ctx->prec == 1 && (ctx->fast_mode == 2 || (fast_auto && ctx->fast_ok != 0 && nq >= 4096))) main_prec = 2;
     const int mkeep = 16 * nt;   // list budget of the streaming selection
-    // exact table width M' = entries kept at the end of the stream: the wider error bound of the single chain is paid
-    // for with a deeper table (the completeness bound moves out with it), the lists have room for 64*nt anyway
-    const int MP = (main_prec == 2 && nt == 8) ? 256 : mkeep;
+    // exact table width M' = entries kept at the end of the stream.  The lists have room for 64*nt, and after the
+    // threshold-seeding phase they typically end with ~16x the seed budget anyway: keeping 256 instead of 128 moves the
+    // completeness bound out (it pays for the wider error bound of the single chain, and rows with more than 128
+    // neighbours inside their radius stay out of the radius pass) for one more re-rank batch per row.
+    const int MP = (nt == 8) ? 256 : mkeep;
     const int bq = gt_select_bq(ctx->DP);
     k->MP = MP;
     k->nt = nt;
