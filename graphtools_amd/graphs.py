@@ -18,6 +18,17 @@ from . import _hip
 from .base import BaseGraph, Data
 
 
+def _assert_all_finite(X):
+    """The reference's kNN front end rejects non-finite input (sklearn check_array inside NearestNeighbors.fit,
+    graphs.py:763-768); same errors here, with sklearn's one-pass sum test first."""
+    if np.isfinite(np.sum(X, dtype=np.float64)):
+        return
+    if np.isnan(X).any():
+        raise ValueError("Input X contains NaN.")
+    if np.isinf(X).any():
+        raise ValueError("Input X contains infinity or a value too large for dtype('{}').".format(X.dtype))
+
+
 class DataGraph(Data, BaseGraph):
     """Graphs built from a data matrix (reference: graphtools/base.py:1046-1254)."""
 
@@ -169,6 +180,7 @@ class kNNGraph(DataGraph):
         X = np.ascontiguousarray(self.data_nu)
         if X.dtype not in (np.float32, np.float64):
             X = X.astype(np.float64)
+        _assert_all_finite(X)
         self.hip.set_option("metric", self.distance)
         self.hip.set_points(X)
         self._points_bound = True

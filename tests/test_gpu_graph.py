@@ -346,3 +346,15 @@ def test_full_size_properties_n1e6():
         G2 = graphtools_amd.Graph(X, knn=15, decay=40, n_pca=None, verbose=0)
     assert np.array_equal(G2.K.indices, K.indices) and np.array_equal(G2.K.data, K.data)
     assert np.array_equal(G2.P.data, P.data)
+
+
+def test_non_finite_input_is_rejected_like_sklearn():
+    X = make_mix(500, 8, 3)
+    Xn = X.copy()
+    Xn[7, 2] = np.nan
+    with pytest.raises(ValueError, match="contains NaN"):
+        graphtools_amd.Graph(Xn, knn=5, decay=10, verbose=0)
+    Xi = X.copy()
+    Xi[9, 1] = np.inf
+    with pytest.raises(ValueError, match="contains infinity"):
+        graphtools_amd.Graph(Xi, knn=5, decay=10, verbose=0)
