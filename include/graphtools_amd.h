@@ -105,7 +105,8 @@ int gt_last_knn_precision(const gt_ctx* ctx);
 
 /* ---- points ------------------------------------------------------------------------------ */
 /* Bind the data matrix (n x d).  Replaces NearestNeighbors(...).fit(data_nu) (graphs.py:763-768):
- * builds the padded float32 working copy, float64 row norms and -|y|^2/2 terms on the device.
+ * builds the padded working copies of the candidate pass (float16 planes or float32, see "knn_precision"),
+ * float64 row norms and the -|y|^2/2 accumulator seeds on the device.
  * X may be a host or a device pointer; it must stay valid until the next gt_set_points / destroy
  * when it is a device pointer of dtype F32/F64 (the exact re-rank reads it). */
 int gt_set_points(gt_ctx* ctx, const void* X, int64_t n, int32_t d, int32_t dtype, int32_t on_device);
