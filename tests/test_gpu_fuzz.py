@@ -1,0 +1,18 @@
+"""GPU: randomised parity sweep (tools/gpu_fuzz.py) - random shapes, dtypes, metrics, kernels and symmetrisations of
+graphtools_amd.Graph against the oracle; CSR structure identical, values within 1e-5 relative."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_random_configurations_match_the_oracle():
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gpu_fuzz.py"), "30", "11"], capture_output=True,
+                         text=True, timeout=1500)
+    tail = "\n".join(res.stdout.strip().splitlines()[-6:])
+    assert res.returncode == 0, tail + "\n" + res.stderr[-2000:]
