@@ -16,3 +16,10 @@ def test_random_configurations_match_the_oracle():
                          text=True, timeout=1500)
     tail = "\n".join(res.stdout.strip().splitlines()[-6:])
     assert res.returncode == 0, tail + "\n" + res.stderr[-2000:]
+
+
+def test_random_exact_extension_and_mnn_graphs_match_the_oracle():
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gpu_fuzz_more.py"), "30", "5"], capture_output=True,
+                         text=True, timeout=1500)
+    tail = "\n".join(res.stdout.strip().splitlines()[-6:])
+    assert res.returncode == 0, tail + "\n" + res.stderr[-2000:]
