@@ -72,6 +72,9 @@ void gt_ctx_destroy(gt_ctx* ctx) {
     ctx->Yp.release();
     ctx->Yc.release();
     ctx->small_tmp.release();
+    ctx->sel_idx.release();
+    ctx->xn_sel.release();
+    ctx->colstat.release();
     ctx->lomax_dev.release();
     ctx->xn.release();
     ctx->hneg.release();
@@ -134,8 +137,16 @@ int gt_set_points(gt_ctx* ctx, const void* X, int64_t n, int32_t d, int32_t dtyp
     ctx->d = d;
     ctx->dtype = dtype;
     ctx->DP = gt_choose_dp_prec(d, ctx->prec);
+    ctx->wide = false;
+    ctx->dsel = 0;
+    if (ctx->DP == 0 && ctx->metric == 0 && d <= 2048) {   // the float64 stages keep one row per wave in LDS (64 KB)
+        // more features than the candidate kernels hold: filter on the 128 columns of largest variance (gt_common.h)
+        ctx->wide = true;
+        ctx->DP = 128;
+        GT_TRY(gt_select_columns(ctx, 128));
+    }
     if (ctx->DP == 0) {
-        // exact dense path and landmark assignment still work on the raw points; kNN needs d <= 128 for now
+        // cosine metric on wide data: the exact dense path and landmark assignment still work on the raw points
         ctx->n_pad = 0;
         GT_HIP(ctx, ctx->xn.reserve(size_t(n) * sizeof(double)));
         GT_HIP(ctx, ctx->ymax.reserve(sizeof(double)));

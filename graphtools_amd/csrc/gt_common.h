@@ -108,6 +108,15 @@ struct gt_ctx {
     double lomax = 0.0;  // prec 1: max over rows of |x - hi(x)|_2 (true units), the float16 rounding residual norm
     double qlomax = 0.0; //         same for the external query matrix of the current call
     DevBuf lomax_dev;
+    // Wide data (more features than the candidate kernels hold in registers, euclidean metric): the candidate pass
+    // runs on the `dsel` coordinates of largest variance.  The squared distance over a coordinate subset is a LOWER
+    // bound of the full one, so every bound of the completeness proof holds with the partial norms (xn_sel) while the
+    // float64 stages use the full vectors; how much survives the filter only decides how many rows need repairs.
+    bool wide = false;
+    int32_t dsel = 0;
+    DevBuf sel_idx;      // int32 [dsel] selected columns
+    DevBuf xn_sel;       // float64 [n] squared norms over the selected columns (== xn when !wide)
+    DevBuf colstat;      // float64 [2 d] column sums / sums of squares
     DevBuf small_tmp;    // a few persistent bytes for scalar reductions (no hipMalloc / hipFree on the per-call paths:
                          // both can stall for seconds in a process that also runs RCCL)
     int32_t metric = 0;  // 0 euclidean, 1 cosine (points are row-normalised copies; distance = 1 - x.y)

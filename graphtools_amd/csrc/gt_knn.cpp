@@ -10,7 +10,7 @@ int gt_select_bn_for(int dp) { return gt_select_bn(dp); }
 void gt_free_knn_work(gt_ctx* ctx) {
     if (!ctx->knn) return;
     KnnWork* k = ctx->knn;
-    for (DevBuf* b : {&k->Qraw, &k->Qp, &k->Qc, &k->qn, &k->lists, &k->counts, &k->thr_final, &k->cand_d2, &k->cand_j, &k->cand_n,
+    for (DevBuf* b : {&k->Qraw, &k->Qp, &k->Qc, &k->qn, &k->qn_sel, &k->lists, &k->counts, &k->thr_final, &k->cand_d2, &k->cand_j, &k->cand_n,
                       &k->d2_lb, &k->fb_rows, &k->fb_count, &k->fb_scratch, &k->gflags, &k->prof, &k->fb_qrows, &k->fb_thr, &k->fb_lists,
                       &k->fb_counts, &k->fb_max, &k->unproven, &k->qlomax_dev})
         b->release();
@@ -52,7 +52,9 @@ static const double kFastFailFrac = 0.05;
 
 int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int need_m, double radius_key_factor) {
     if (ctx->n <= 0 || !ctx->X) GT_FAIL(ctx, GT_E_STATE, "no points bound (call gt_set_points first)");
-    if (ctx->DP == 0) GT_FAIL(ctx, GT_E_LIMIT, "kNN on the HIP path needs n_features <= 128 (reduce with n_pca)");
+    if (ctx->DP == 0)
+        GT_FAIL(ctx, GT_E_LIMIT, "kNN on the HIP path: n_features > 128 is supported for the euclidean metric up to 2048 "
+                                 "features (reduce with n_pca)");
     if (need_m < 1 || int64_t(need_m) > ctx->n) GT_FAIL(ctx, GT_E_ARG, "k must be in [1, n_samples]");
     if (nq <= 0) GT_FAIL(ctx, GT_E_ARG, "no query rows");
     if (!ctx->knn) ctx->knn = new KnnWork();
@@ -142,6 +144,7 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
     ra.xn = ctx->xn.as<double>();
     ra.Q = external ? k->Qraw.p : ctx->X;
     ra.qn = external ? k->qn.as<double>() : ctx->xn.as<double>();
+    ra.qn_sel = !ctx->wide ? ra.qn : (external ? k->qn_sel.as<double>() : ctx->xn_sel.as<double>());
     ra.q0 = external ? 0 : q0;
     ra.nq = nq;
     ra.lists = k->lists.as<uint64_t>();
@@ -277,7 +280,7 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
 int gt_prepare_queries(gt_ctx* ctx, const void* Y, int64_t m, int32_t y_on_device) {
     if (!Y || m <= 0) GT_FAIL(ctx, GT_E_ARG, "query matrix is empty");
     if (ctx->n <= 0 || !ctx->X) GT_FAIL(ctx, GT_E_STATE, "no points bound (call gt_set_points first)");
-    if (ctx->DP == 0) GT_FAIL(ctx, GT_E_LIMIT, "kNN on the HIP path needs n_features <= 128");
+    if (ctx->DP == 0) GT_FAIL(ctx, GT_E_LIMIT, "kNN on the HIP path: n_features > 128 needs the euclidean metric and <= 2048 features");
     if (!ctx->knn) ctx->knn = new KnnWork();
     KnnWork* kw = ctx->knn;
     const size_t esz = ctx->dtype == GT_F32 ? 4 : 8;
@@ -298,7 +301,9 @@ int gt_prepare_queries(gt_ctx* ctx, const void* Y, int64_t m, int32_t y_on_devic
             ctx->sc = gt_f16_scale(std::max(qmax, keep));
             GT_TRY(gt_prep_matrix(ctx, ctx->X, ctx->n, ctx->d, ctx->dtype, ctx->DP, ctx->n_pad, ctx->Yp.as<float>(),
                                   ctx->xn.as<double>(), ctx->hneg.as<float>(), ctx->ymax.as<double>(), 1, ctx->sc,
-                                  ctx->lomax_dev.as<double>(), ctx->fast_mode != 0 ? ctx->Yc.p : nullptr));
+                                  ctx->lomax_dev.as<double>(), ctx->fast_mode != 0 ? ctx->Yc.p : nullptr,
+                                  ctx->wide ? ctx->sel_idx.as<int32_t>() : nullptr, ctx->dsel,
+                                  ctx->wide ? ctx->xn_sel.as<double>() : nullptr));
             double lo2 = 0.0;
             GT_HIP(ctx, hipMemcpyAsync(&lo2, ctx->lomax_dev.p, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
             GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -309,9 +314,11 @@ int gt_prepare_queries(gt_ctx* ctx, const void* Y, int64_t m, int32_t y_on_devic
     GT_HIP(ctx, kw->qlomax_dev.reserve(sizeof(double)));
     const bool want_hi = ctx->prec == 1 && ctx->fast_mode != 0;
     if (want_hi) GT_HIP(ctx, kw->Qc.reserve(size_t(mpad) * ctx->DP * sizeof(_Float16)));
+    if (ctx->wide) GT_HIP(ctx, kw->qn_sel.reserve(size_t(m) * sizeof(double)));
     GT_TRY(gt_prep_matrix(ctx, kw->Qraw.p, m, ctx->d, ctx->dtype, ctx->DP, mpad, kw->Qp.as<float>(), kw->qn.as<double>(),
                           nullptr, nullptr, ctx->prec, ctx->sc, ctx->prec == 1 ? kw->qlomax_dev.as<double>() : nullptr,
-                          want_hi ? kw->Qc.p : nullptr));
+                          want_hi ? kw->Qc.p : nullptr, ctx->wide ? ctx->sel_idx.as<int32_t>() : nullptr, ctx->dsel,
+                          ctx->wide ? kw->qn_sel.as<double>() : nullptr));
     ctx->qlomax = 0.0;
     if (ctx->prec == 1) {
         double lo2 = 0.0;

@@ -17,6 +17,7 @@ struct KnnWork {
     bool external = false;
     // external queries (gt_knn_search with Y)
     DevBuf Qraw, Qp, Qc, qn;   // Qc: compact hi-plane copy of the query matrix (single-chain pass)
+    DevBuf qn_sel;             // wide data: partial squared norms of the query matrix
     DevBuf lists, counts, thr_final;
     DevBuf cand_d2, cand_j, cand_n, d2_lb;
     DevBuf unproven, qlomax_dev;
@@ -27,8 +28,10 @@ struct KnnWork {
 };
 
 int gt_select_bn_for(int dp);
+int gt_select_columns(gt_ctx* ctx, int want);   // gt_prep.hip: wide data, columns of largest variance
 int gt_prep_matrix(gt_ctx* ctx, const void* Xdev, int64_t n, int d, int dtype, int DP, int64_t n_pad, float* Yp,
-                   double* xn, float* hneg, double* ymax2, int prec, double sc, double* lomax2 = nullptr, void* Yc = nullptr);
+                   double* xn, float* hneg, double* ymax2, int prec, double sc, double* lomax2 = nullptr, void* Yc = nullptr,
+                   const int32_t* sel = nullptr, int dsel = 0, double* xn_sel = nullptr);
 int gt_max_abs(gt_ctx* ctx, const void* Xdev, int64_t total, int dtype, double* out_host);
 double gt_f16_scale(double maxabs);
 // row-wise l2 normalisation in the input dtype (sklearn normalize: zero rows untouched); in place allowed
@@ -94,6 +97,7 @@ struct RerankArgs {
     const double* xn;       // database squared norms
     const void* Q;          // query matrix (original dtype); rows addressed as q0 + q
     const double* qn;       // squared norms of the query matrix rows (indexed like Q)
+    const double* qn_sel;   // the norms the candidate pass saw (== qn unless wide data: partial norms), for the bounds
     int64_t q0;
     int64_t nq;
     const uint64_t* lists;

@@ -7,12 +7,16 @@
 #include "gt_knn.h"
 
 #include <algorithm>
+#include <utility>
+#include <vector>
 
 namespace {
 
+// `sel` (optional): the working copy holds columns sel[0 .. dw) of X instead of its first dw = min(d, DP) columns
 template <typename T>
 __global__ __launch_bounds__(256) void pad_convert_kernel(const T* __restrict__ X, int64_t n, int d, int DP,
-                                                          int64_t n_pad, float* __restrict__ Yp) {
+                                                          int64_t n_pad, float* __restrict__ Yp,
+                                                          const int32_t* __restrict__ sel, int dw) {
     const int64_t total4 = n_pad * DP / 4;
     const int dp4 = DP / 4;
     for (int64_t f = int64_t(blockIdx.x) * 256 + threadIdx.x; f < total4; f += int64_t(gridDim.x) * 256) {
@@ -21,13 +25,31 @@ __global__ __launch_bounds__(256) void pad_convert_kernel(const T* __restrict__ 
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (r < n) {
             const T* src = X + r * int64_t(d);
-            if (c + 0 < d) v.x = float(src[c + 0]);
-            if (c + 1 < d) v.y = float(src[c + 1]);
-            if (c + 2 < d) v.z = float(src[c + 2]);
-            if (c + 3 < d) v.w = float(src[c + 3]);
+            if (c + 0 < dw) v.x = float(src[sel ? sel[c + 0] : c + 0]);
+            if (c + 1 < dw) v.y = float(src[sel ? sel[c + 1] : c + 1]);
+            if (c + 2 < dw) v.z = float(src[sel ? sel[c + 2] : c + 2]);
+            if (c + 3 < dw) v.w = float(src[sel ? sel[c + 3] : c + 3]);
         }
         reinterpret_cast<float4*>(Yp)[f] = v;
     }
+}
+
+// per-column sums and sums of squares (float64): thread = one column of a 256-column slab, block = a chunk of rows
+template <typename T>
+__global__ __launch_bounds__(256) void col_stats_kernel(const T* __restrict__ X, int64_t n, int d, int64_t rows_per_block,
+                                                        double* __restrict__ stat) {
+    const int c = int(blockIdx.x) * 256 + threadIdx.x;
+    const int64_t r0 = int64_t(blockIdx.y) * rows_per_block;
+    const int64_t r1 = r0 + rows_per_block < n ? r0 + rows_per_block : n;
+    if (c >= d) return;
+    double s = 0.0, q = 0.0;
+    for (int64_t r = r0; r < r1; ++r) {
+        const double v = double(X[r * int64_t(d) + c]);
+        s += v;
+        q = fma(v, v, q);
+    }
+    atomicAdd(&stat[c], s);
+    atomicAdd(&stat[d + c], q);
 }
 
 // max |x| over the matrix (for the power-of-two scale of the split-float16 working copy)
@@ -48,13 +70,14 @@ __global__ __launch_bounds__(256) void max_abs_kernel(const T* __restrict__ X, c
 template <typename T>
 __global__ __launch_bounds__(256) void pad_split_f16_kernel(const T* __restrict__ X, int64_t n, int d, int DP,
                                                             int64_t n_pad, double sc, _Float16* __restrict__ Yh,
-                                                            _Float16* __restrict__ Yc) {
+                                                            _Float16* __restrict__ Yc, const int32_t* __restrict__ sel,
+                                                            int dw) {
     const int64_t total = n_pad * DP;
     for (int64_t f = int64_t(blockIdx.x) * 256 + threadIdx.x; f < total; f += int64_t(gridDim.x) * 256) {
         const int64_t r = f / DP;
         const int c = int(f % DP);
         double v = 0.0;
-        if (r < n && c < d) v = double(X[r * int64_t(d) + c]) * sc;   // exact: sc is a power of two
+        if (r < n && c < dw) v = double(X[r * int64_t(d) + (sel ? sel[c] : c)]) * sc;   // exact: sc is a power of two
         const _Float16 hi = _Float16(v);
         const _Float16 lo = _Float16(v - double(hi));
         Yh[r * int64_t(2 * DP) + c] = hi;
@@ -84,28 +107,46 @@ template <typename T>
 __global__ __launch_bounds__(256) void row_norm_kernel(const T* __restrict__ X, int64_t n, int d, int64_t n_pad,
                                                        double* __restrict__ xn, float* __restrict__ hneg,
                                                        const double sc2, unsigned long long* __restrict__ ymax2_bits,
-                                                       const double sc, unsigned long long* __restrict__ lomax2_bits) {
+                                                       const double sc, unsigned long long* __restrict__ lomax2_bits,
+                                                       const int32_t* __restrict__ sel, const int dw,
+                                                       double* __restrict__ xn_sel) {
+    // xn: squared norm over all d columns (exact stages).  With `sel` the candidate pass sees only columns sel[0..dw):
+    // its seeds, the norm bound and the residual bound come from the partial norm (xn_sel).
     const int64_t r = int64_t(blockIdx.x) * 256 + threadIdx.x;
-    double acc = 0.0, lo2 = 0.0;
+    double acc = 0.0, accs = 0.0, lo2 = 0.0;
     if (r < n) {
         const T* src = X + r * int64_t(d);
         for (int k = 0; k < d; ++k) {
             const double v = double(src[k]);
             acc = fma(v, v, acc);
-            if (lomax2_bits) {
+            if (lomax2_bits && !sel) {
                 // exact residual of the float16 rounding of the scaled value (what the hi-plane-only pass drops)
                 const double vs = v * sc;
                 const double res = vs - double(_Float16(vs));
                 lo2 = fma(res, res, lo2);
             }
         }
+        accs = acc;
+        if (sel) {
+            accs = 0.0;
+            for (int k = 0; k < dw; ++k) {
+                const double v = double(src[sel[k]]);
+                accs = fma(v, v, accs);
+                if (lomax2_bits) {
+                    const double vs = v * sc;
+                    const double res = vs - double(_Float16(vs));
+                    lo2 = fma(res, res, lo2);
+                }
+            }
+            xn_sel[r] = accs;
+        }
         xn[r] = acc;
-        if (hneg) hneg[r] = float(-0.5 * acc * sc2);
+        if (hneg) hneg[r] = float(-0.5 * accs * sc2);
     } else if (r < n_pad) {
         if (hneg) hneg[r] = -INFINITY;
     }
     // block max -> one atomic per wave
-    double m = (r < n) ? acc : 0.0;
+    double m = (r < n) ? accs : 0.0;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
     if ((threadIdx.x & 63) == 0 && ymax2_bits) atomicMax(ymax2_bits, (unsigned long long)__double_as_longlong(m));
@@ -161,7 +202,9 @@ double gt_f16_scale(double maxabs) {
 }
 
 int gt_prep_matrix(gt_ctx* ctx, const void* Xdev, int64_t n, int d, int dtype, int DP, int64_t n_pad, float* Yp,
-                   double* xn, float* hneg, double* ymax2, int prec, double sc, double* lomax2, void* Yc) {
+                   double* xn, float* hneg, double* ymax2, int prec, double sc, double* lomax2, void* Yc,
+                   const int32_t* sel, int dsel, double* xn_sel) {
+    const int dw = sel ? dsel : (d < DP || DP == 0 ? d : DP);
     if (ymax2) GT_HIP(ctx, hipMemsetAsync(ymax2, 0, sizeof(double), ctx->stream));
     if (lomax2) GT_HIP(ctx, hipMemsetAsync(lomax2, 0, sizeof(double), ctx->stream));
     if (Yp && prec == 1) {
@@ -169,10 +212,10 @@ int gt_prep_matrix(gt_ctx* ctx, const void* Xdev, int64_t n, int d, int dtype, i
         int64_t blocks = std::min<int64_t>(ceil_div64(total, 256), 16384);
         if (dtype == GT_F32)
             hipLaunchKernelGGL(pad_split_f16_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream,
-                               (const float*)Xdev, n, d, DP, n_pad, sc, (_Float16*)Yp, (_Float16*)Yc);
+                               (const float*)Xdev, n, d, DP, n_pad, sc, (_Float16*)Yp, (_Float16*)Yc, sel, dw);
         else
             hipLaunchKernelGGL(pad_split_f16_kernel<double>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream,
-                               (const double*)Xdev, n, d, DP, n_pad, sc, (_Float16*)Yp, (_Float16*)Yc);
+                               (const double*)Xdev, n, d, DP, n_pad, sc, (_Float16*)Yp, (_Float16*)Yc, sel, dw);
         GT_HIP(ctx, hipGetLastError());
     } else if (Yp) {
         const int64_t total4 = n_pad * DP / 4;
@@ -180,21 +223,56 @@ int gt_prep_matrix(gt_ctx* ctx, const void* Xdev, int64_t n, int d, int dtype, i
         if (blocks > 8192) blocks = 8192;
         if (dtype == GT_F32)
             hipLaunchKernelGGL(pad_convert_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream,
-                               (const float*)Xdev, n, d, DP, n_pad, Yp);
+                               (const float*)Xdev, n, d, DP, n_pad, Yp, sel, dw);
         else
             hipLaunchKernelGGL(pad_convert_kernel<double>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream,
-                               (const double*)Xdev, n, d, DP, n_pad, Yp);
+                               (const double*)Xdev, n, d, DP, n_pad, Yp, sel, dw);
         GT_HIP(ctx, hipGetLastError());
     }
     const int64_t rows = hneg ? n_pad : n;
     const int64_t nb = ceil_div64(rows, 256);
     if (dtype == GT_F32)
         hipLaunchKernelGGL(row_norm_kernel<float>, dim3((unsigned)nb), dim3(256), 0, ctx->stream, (const float*)Xdev, n,
-                           d, n_pad, xn, hneg, sc * sc, (unsigned long long*)ymax2, sc, (unsigned long long*)lomax2);
+                           d, n_pad, xn, hneg, sc * sc, (unsigned long long*)ymax2, sc, (unsigned long long*)lomax2, sel, dw, xn_sel);
     else
         hipLaunchKernelGGL(row_norm_kernel<double>, dim3((unsigned)nb), dim3(256), 0, ctx->stream, (const double*)Xdev,
-                           n, d, n_pad, xn, hneg, sc * sc, (unsigned long long*)ymax2, sc, (unsigned long long*)lomax2);
+                           n, d, n_pad, xn, hneg, sc * sc, (unsigned long long*)ymax2, sc, (unsigned long long*)lomax2, sel, dw, xn_sel);
     GT_HIP(ctx, hipGetLastError());
+    return GT_OK;
+}
+
+// Wide data: pick the `want` columns of largest variance (ties by index) and upload their indices.
+int gt_select_columns(gt_ctx* ctx, int want) {
+    const int d = ctx->d;
+    GT_HIP(ctx, ctx->colstat.reserve(size_t(2) * d * sizeof(double)));
+    GT_HIP(ctx, hipMemsetAsync(ctx->colstat.p, 0, size_t(2) * d * sizeof(double), ctx->stream));
+    const int64_t rows_per_block = 2048;
+    dim3 grid((unsigned)ceil_div64(d, 256), (unsigned)ceil_div64(ctx->n, rows_per_block));
+    if (ctx->dtype == GT_F32)
+        hipLaunchKernelGGL(col_stats_kernel<float>, grid, dim3(256), 0, ctx->stream, (const float*)ctx->X, ctx->n, d,
+                           rows_per_block, ctx->colstat.as<double>());
+    else
+        hipLaunchKernelGGL(col_stats_kernel<double>, grid, dim3(256), 0, ctx->stream, (const double*)ctx->X, ctx->n, d,
+                           rows_per_block, ctx->colstat.as<double>());
+    GT_HIP(ctx, hipGetLastError());
+    std::vector<double> st(size_t(2) * d);
+    GT_HIP(ctx, hipMemcpyAsync(st.data(), ctx->colstat.p, st.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<std::pair<double, int>> var(d);
+    for (int c = 0; c < d; ++c) {
+        const double mean = st[c] / double(ctx->n);
+        double v = st[d + c] / double(ctx->n) - mean * mean;
+        if (!(v > 0.0)) v = 0.0;   // also NaN
+        var[c] = {-v, c};
+    }
+    std::sort(var.begin(), var.end());
+    std::vector<int32_t> sel(want);
+    for (int k = 0; k < want; ++k) sel[k] = var[k].second;
+    std::sort(sel.begin(), sel.end());   // ascending columns: friendlier gathers
+    GT_HIP(ctx, ctx->sel_idx.reserve(size_t(want) * sizeof(int32_t)));
+    GT_HIP(ctx, hipMemcpyAsync(ctx->sel_idx.p, sel.data(), size_t(want) * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->dsel = want;
     return GT_OK;
 }
 
@@ -214,9 +292,12 @@ int gt_prep_points(gt_ctx* ctx) {
     GT_HIP(ctx, ctx->lomax_dev.reserve(sizeof(double)));
     const bool want_hi = ctx->prec == 1 && ctx->fast_mode != 0;
     if (want_hi) GT_HIP(ctx, ctx->Yc.reserve(size_t(ctx->n_pad) * ctx->DP * sizeof(_Float16)));
+    if (ctx->wide) GT_HIP(ctx, ctx->xn_sel.reserve(size_t(ctx->n) * sizeof(double)));
     GT_TRY(gt_prep_matrix(ctx, ctx->X, ctx->n, ctx->d, ctx->dtype, ctx->DP, ctx->n_pad, ctx->Yp.as<float>(),
                           ctx->xn.as<double>(), ctx->hneg.as<float>(), ctx->ymax.as<double>(), ctx->prec, ctx->sc,
-                          ctx->prec == 1 ? ctx->lomax_dev.as<double>() : nullptr, want_hi ? ctx->Yc.p : nullptr));
+                          ctx->prec == 1 ? ctx->lomax_dev.as<double>() : nullptr, want_hi ? ctx->Yc.p : nullptr,
+                          ctx->wide ? ctx->sel_idx.as<int32_t>() : nullptr, ctx->dsel,
+                          ctx->wide ? ctx->xn_sel.as<double>() : nullptr));
     ctx->lomax = 0.0;
     if (ctx->prec == 1) {
         double lo2 = 0.0;

@@ -48,7 +48,7 @@ __device__ __forceinline__ double dot_row<float>(const double* __restrict__ xs, 
 template <typename T, int NT2>
 __global__ __launch_bounds__(256) void rerank_kernel(const T* __restrict__ X, const int d, const double* __restrict__ xn,
                                                      const T* __restrict__ Q, const double* __restrict__ qn,
-                                                     const int64_t q0, const int64_t nq,
+                                                     const double* __restrict__ qn_sel, const int64_t q0, const int64_t nq,
                                                      const uint64_t* __restrict__ lists, const int lstride,
                                                      const uint32_t* __restrict__ counts,
                                                      const float* __restrict__ thr_final,
@@ -98,12 +98,15 @@ __global__ __launch_bounds__(256) void rerank_kernel(const T* __restrict__ X, co
     double lb = INFINITY;
     const float thr_f = thr_final[q];
     if (thr_f > -INFINITY) {   // -inf: the candidate pass rejected nothing for this query
+        // qs, y2: the norms of what the candidate pass scored (a coordinate subset for wide data: its squared distance
+        // is a lower bound of the full one, so the bound below holds for the full distance as well)
+        const double qs = qn_sel[q0 + q];
         const double thr = double(thr_f) * err.inv_sc2;
         const double y2 = *ymax2p;
-        const double e = gt_err_bound(err, qnq, y2);
+        const double e = gt_err_bound(err, qs, y2);
         // euclidean: d2 = |x|^2 - 2 s ; cosine: D = 1 - x.y = 1 - s - |y|^2/2 >= 1 - s - ymax^2/2
-        lb = (metric == 1) ? (1.0 - (thr + e) - 0.5 * y2) : (qnq - 2.0 * (thr + e));
-        lb -= 1e-9 * (qnq + y2);   // float64 rounding of the quantities above, with a wide margin
+        lb = (metric == 1) ? (1.0 - (thr + e) - 0.5 * y2) : (qs - 2.0 * (thr + e));
+        lb -= 1e-9 * (qs + y2);   // float64 rounding of the quantities above, with a wide margin
     }
     // d2 of the need_m-th neighbour (position need_m - 1)
     const int pos = need_m - 1;
@@ -373,17 +376,17 @@ int rerank_t(gt_ctx* ctx, const RerankArgs& a) {
     const size_t lds = size_t(4) * a.d * sizeof(double);
     if (a.MP == 128) {
         hipLaunchKernelGGL((rerank_kernel<T, 2>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, (const T*)a.X,
-                           a.d, a.xn, (const T*)a.Q, a.qn, a.q0, a.nq, a.lists, a.lstride, a.counts, a.thr_final, a.ymax2,
+                           a.d, a.xn, (const T*)a.Q, a.qn, a.qn_sel, a.q0, a.nq, a.lists, a.lstride, a.counts, a.thr_final, a.ymax2,
                            a.err, a.metric, a.need_m, a.cand_d2, a.cand_j, a.cand_n, a.d2_lb, a.fb_count, a.fb_rows,
                            a.gflags, a.radius_key_factor, a.unproven);
     } else if (a.MP == 256) {
         hipLaunchKernelGGL((rerank_kernel<T, 4>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, (const T*)a.X,
-                           a.d, a.xn, (const T*)a.Q, a.qn, a.q0, a.nq, a.lists, a.lstride, a.counts, a.thr_final, a.ymax2,
+                           a.d, a.xn, (const T*)a.Q, a.qn, a.qn_sel, a.q0, a.nq, a.lists, a.lstride, a.counts, a.thr_final, a.ymax2,
                            a.err, a.metric, a.need_m, a.cand_d2, a.cand_j, a.cand_n, a.d2_lb, a.fb_count, a.fb_rows,
                            a.gflags, a.radius_key_factor, a.unproven);
     } else if (a.MP == 512) {
         hipLaunchKernelGGL((rerank_kernel<T, 8>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, (const T*)a.X,
-                           a.d, a.xn, (const T*)a.Q, a.qn, a.q0, a.nq, a.lists, a.lstride, a.counts, a.thr_final, a.ymax2,
+                           a.d, a.xn, (const T*)a.Q, a.qn, a.qn_sel, a.q0, a.nq, a.lists, a.lstride, a.counts, a.thr_final, a.ymax2,
                            a.err, a.metric, a.need_m, a.cand_d2, a.cand_j, a.cand_n, a.d2_lb, a.fb_count, a.fb_rows,
                            a.gflags, a.radius_key_factor, a.unproven);
     } else {
@@ -442,7 +445,7 @@ int gt_launch_emit_knn(gt_ctx* ctx, const double* cand_d2, const uint32_t* cand_
 
 int gt_launch_fallback_thr(gt_ctx* ctx, const RerankArgs& a, int64_t n_rows, int64_t row_off, int32_t* qrows, float* thr) {
     hipLaunchKernelGGL(fallback_thr_kernel, dim3((unsigned)ceil_div64(n_rows, 256)), dim3(256), 0, ctx->stream, a.fb_rows,
-                       n_rows, row_off, a.q0, a.MP, a.need_m, a.metric, a.cand_d2, a.qn, a.ymax2, a.err, qrows, thr);
+                       n_rows, row_off, a.q0, a.MP, a.need_m, a.metric, a.cand_d2, a.qn_sel, a.ymax2, a.err, qrows, thr);
     GT_HIP(ctx, hipGetLastError());
     return GT_OK;
 }

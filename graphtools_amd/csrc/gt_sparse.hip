@@ -776,11 +776,13 @@ static int graph_begin_impl(gt_ctx* ctx, const gt_knn_params* params, int32_t wo
     g->radius_factor = binary ? 0.0 : std::pow(-1.0 * std::log(thresh), 1.0 / params->decay);   // graphs.py:902-904
     // repairs (radius pass) run on the accurate arithmetic of the working copy, whatever the main pass used
     const ErrModel err_model = gt_err_model(ctx, ctx->prec);
+    // norms the candidate pass saw (partial norms for wide data): they bound the scores of everything inside a radius
+    const double* qn_bound = !ctx->wide ? g->qnorm : (external ? k->qn_sel.as<double>() : ctx->xn_sel.as<double>());
     {
         StageSpan span(ctx, "affinity");
         hipLaunchKernelGGL(bandwidth_kernel, dim3((unsigned)ceil_div64(g->nloc, 256)), dim3(256), 0, ctx->stream, g->nloc,
                            g->r0, k->MP, kprime, ctx->dtype, ctx->metric, k->cand_d2.as<double>(), k->d2_lb.as<double>(),
-                           g->qnorm, g->qoff, ctx->ymax.as<double>(), err_model, g->bw_user.as<double>(),
+                           qn_bound, g->qoff, ctx->ymax.as<double>(), err_model, g->bw_user.as<double>(),
                            params->bandwidth_len, params->bandwidth_scale, use_radius ? 1 : 0, g->radius_factor,
                            g->bw.as<double>(), g->rowsrc.as<int32_t>(), g->over_rows.as<int32_t>(),
                            g->over_count.as<uint32_t>(), g->rthr.as<float>());

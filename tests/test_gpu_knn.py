@@ -207,3 +207,40 @@ def test_auto_precision_verdict_follows_the_data():
         assert np.array_equal(Kp, Rp) and np.array_equal(Ki, Ri) and np.array_equal(Kd, Rd)
         ctx.close()
         ref.close()
+
+
+def _pca_like(n, d, seed, decay=0.93):
+    """anisotropic data: column scales fall off geometrically (what a few hundred principal components look like),
+    columns shuffled so that the informative ones are not the leading ones"""
+    rng = np.random.default_rng(seed)
+    scales = decay ** np.arange(d)
+    X = rng.standard_normal((n, d)) * scales
+    centres = rng.standard_normal((8, d)) * scales * 3
+    X += centres[rng.integers(8, size=n)]
+    return np.ascontiguousarray(X[:, rng.permutation(d)].astype(np.float32))
+
+
+@pytest.mark.parametrize("n,d,k,maker", [
+    (3000, 200, 20, _pca_like), (6000, 300, 16, _pca_like), (2500, 129, 30, _pca_like),
+    (1200, 400, 10, lambda n, d, s: make_gauss(n, d, s)),      # isotropic: the 128-column filter is weak, repairs carry it
+])
+def test_knn_wide_data_is_exact(hip_ctx, n, d, k, maker):
+    """More than 128 features: candidates come from the 128 columns of largest variance (a lower bound of the distance),
+    the float64 stages see all columns - same neighbours and distances as the brute-force oracle."""
+    X = maker(n, d, 17)
+    _check(hip_ctx, X, k)
+    _check(hip_ctx, X, k, Y=maker(300, d, 18))
+
+
+def test_wide_graph_matches_oracle():
+    import graphtools_amd
+    from scipy import sparse
+
+    X = _pca_like(4500, 250, 3)
+    G = graphtools_amd.Graph(X, knn=10, decay=20, n_pca=None, verbose=0)
+    Ko, Po = oracle.knn_graph(X, knn=10, decay=20)
+    Ko = sparse.csr_matrix(Ko)
+    Ko.sort_indices()
+    assert np.array_equal(G.K.indptr, Ko.indptr) and np.array_equal(G.K.indices, Ko.indices)
+    np.testing.assert_allclose(G.K.data, Ko.data, rtol=1e-5, atol=0)
+    np.testing.assert_allclose(G.P.data, sparse.csr_matrix(Po).data, rtol=1e-5, atol=0)

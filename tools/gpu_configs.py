@@ -43,6 +43,8 @@ def run(name, X, knn=15, decay=40.0, metric="euclidean", reps=2):
 
 if __name__ == "__main__":
     out = []
+    if os.environ.get("GT_WIDE") == "only":
+        sys.argv.append("wide-only")
     out.append(run("C2 mix 100k d50", make_mix(100000, 50, 0)))
     out.append(run("mix 300k d64", make_mix(300000, 64, 1)))
     out.append(run("mix 200k d100", make_mix(200000, 100, 2)))
@@ -54,5 +56,12 @@ if __name__ == "__main__":
     out.append(run("mix 200k d50 cosine", make_mix(200000, 50, 6), metric="cosine"))
     out.append(run("mix 100k d64 float64", make_mix(100000, 64, 7).astype(np.float64)))
     out.append(run("mix 100k d64 binary", make_mix(100000, 64, 8), decay=None))
+    if os.environ.get("GT_WIDE"):
+        rng = np.random.default_rng(9)
+        scales = 0.97 ** np.arange(300)
+        Xw = (rng.standard_normal((100000, 300)) * scales + (rng.standard_normal((20, 300)) * scales * 3)[rng.integers(20, size=100000)])
+        out.append(run("wide pca-like 100k d300", np.ascontiguousarray(Xw[:, rng.permutation(300)].astype(np.float32))))
+        out.append(run("wide mix 100k d300", make_mix(100000, 300, 10)))
+        out.append(run("wide gauss 30k d300 (isotropic)", rng.standard_normal((30000, 300)).astype(np.float32)))
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     json.dump(out, open(os.path.join(ROOT, "gpurun_out", "gpu_configs.json"), "w"), indent=1)
