@@ -42,7 +42,7 @@ def main():
     for case in range(n_cases):
         kind = rng.choice(["mix", "manifold", "gauss", "shifted", "lattice"], p=[0.35, 0.2, 0.2, 0.15, 0.1])
         n = int(rng.choice([int(rng.integers(200, 3000)), int(rng.integers(4096, 9000))]))
-        d = int(rng.choice([2, 3, 7, 16, 20, 33, 50, 64, 65, 100, 128]))
+        d = int(rng.choice([2, 3, 7, 16, 20, 33, 50, 64, 65, 100, 128, 150, 260]))
         dtype = rng.choice([np.float32, np.float64])
         knn = int(rng.integers(2, 25))
         decay = rng.choice([None, 2.0, 10.0, 40.0])
@@ -52,7 +52,7 @@ def main():
         theta = float(rng.uniform(0, 1)) if symm == "mnn" else None
         aniso = float(rng.choice([0.0, 0.0, 0.5, 1.0]))
         distance = str(rng.choice(["euclidean", "euclidean", "cosine"]))
-        if distance == "cosine" and (kind == "lattice" or dtype == np.float32 or d < 3):
+        if distance == "cosine" and (kind == "lattice" or dtype == np.float32 or d < 3 or d > 128):
             # float32 cosine distances are float32 GEMM results in scikit-learn (summation order of the BLAS decides
             # near ties), the device orders by the float64 value: parity is only defined for float64 input (fixture G8)
             distance = "euclidean"
