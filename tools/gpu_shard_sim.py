@@ -84,6 +84,21 @@ if __name__ == "__main__":
         fin_ms.append((t1 - t0) * 1e3)
     fin = {"finish_ms": fin_ms, "recv": int(len(recv)), "nnz_rank0": int(nnz),
            "stage_ms": {s: round(ctx.stage_ms(s), 3) for s in ("symmetrize", "normalize")}}
+    if os.environ.get("GT_SIM_VERIFY"):
+        # rank 0's row block must be bit-identical to the same rows of the single-rank build
+        d0, i0, p0 = ctx.graph_fetch_csr(_hip.CSR_K)
+        pd0, _, _ = ctx.graph_fetch_csr(_hip.CSR_P)
+        ref = _hip.Context(0)
+        ref.set_points_device(xbuf, n, 64, np.float32)
+        ref.graph_build(p)
+        d1, i1, p1 = ref.graph_fetch_csr(_hip.CSR_K)
+        pd1, _, _ = ref.graph_fetch_csr(_hip.CSR_P)
+        nl = int(splits[1])
+        e = int(p1[nl])
+        fin["identical_to_single_rank"] = bool(np.array_equal(p0, p1[: nl + 1]) and np.array_equal(i0, i1[:e]) and
+                                               np.array_equal(d0, d1[:e]) and np.array_equal(pd0, pd1[:e]))
+        fin["precision"] = ctx.last_knn_precision()
+        ref.close()
     out = {"n": n, "world": world, "ranks": recs, "finish_rank0": fin}
     print(json.dumps({"rank0": recs[0], "finish_rank0": fin}))
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
