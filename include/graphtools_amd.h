@@ -93,7 +93,7 @@ int gt_stage_launches(const gt_ctx* ctx, const char* stage);
 
 /* Options (call before gt_set_points).  "knn_precision": arithmetic of the candidate pass -
  *   "auto"  (default) float16 MFMA: one chain on the high float16 plane of every value when the bound data tolerate
- *           its 2^-10 |x||y| score error (judged after the first pass: at most 5 % of the rows unproven), otherwise
+ *           its wider score error bound (judged after the first pass: at most 20 % of the rows left to the repair passes), otherwise
  *   "f16"   three chains on two float16 planes per value (2^-22), "f16x1" forces the single chain,
  *   "f32"   float32 MFMA.
  * Results never depend on it - exact ordering and values always come from the float64 stage, rows whose candidate
