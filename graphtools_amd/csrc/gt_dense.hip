@@ -21,13 +21,18 @@ namespace {
 constexpr int TS = 64;        // tile side
 constexpr int TSP = TS + 1;   // padded LDS row
 
+// xcut: beyond this scaled distance the reference's result is exactly 0 - below `thresh` (then zeroed), or an
+// underflow of exp in T - so the transcendental work (the compute bound of this otherwise HBM-bound kernel) is
+// skipped for almost every entry of a dense matrix.  The host leaves a 1 % margin in the exponent (dense_xcut).
 template <typename T>
-__device__ __forceinline__ T affinity_t(T dist, T bw, T decay) {
+__device__ __forceinline__ T affinity_t(T dist, T bw, T decay, T xcut) {
+    const T x = dist / bw;
+    if (x > xcut) return T(0);
     T w;
     if constexpr (sizeof(T) == 4) {
-        w = expf(-powf(dist / bw, decay));
+        w = expf(-powf(x, decay));
     } else {
-        w = exp(-pow(dist / bw, decay));
+        w = exp(-pow(x, decay));
     }
     return (w != w) ? T(1) : w;
 }
@@ -54,20 +59,49 @@ __global__ __launch_bounds__(256) void dense_bandwidth_kernel(const T* __restric
     double best[KL];
 #pragma unroll
     for (int t = 0; t < KL; ++t) best[t] = INFINITY;
-    for (int64_t j = tid; j < n; j += 256) {
-        const double v = double(row[j]);
-        if (v < best[KL - 1]) {
-            best[KL - 1] = v;
+#define GT_BW_INSERT(V_)                                                                          \
+    {                                                                                             \
+        const double v_ = double(V_);                                                             \
+        if (v_ < best[KL - 1]) {                                                                  \
+            best[KL - 1] = v_;                                                                    \
+            _Pragma("unroll") for (int t = KL - 1; t > 0; --t) {                                  \
+                if (best[t] < best[t - 1]) {                                                      \
+                    const double tmp = best[t];                                                   \
+                    best[t] = best[t - 1];                                                        \
+                    best[t - 1] = tmp;                                                            \
+                }                                                                                 \
+            }                                                                                     \
+        }                                                                                         \
+    }
+    // The scan is a pure HBM stream: 16-byte loads, four of them in flight per thread (one load at a time leaves the
+    // kernel latency-bound at a tenth of the bandwidth).  Rows are 16-byte aligned when n is a multiple of the vector.
+    constexpr int VW = 16 / int(sizeof(T));
+    typedef T vecT __attribute__((ext_vector_type(VW)));
+    if ((n % VW) == 0) {
+        const vecT* rv = reinterpret_cast<const vecT*>(row);
+        const int64_t nv = n / VW;
+        for (int64_t j0 = 0; j0 < nv; j0 += 256 * 4) {
+            vecT v[4];
 #pragma unroll
-            for (int t = KL - 1; t > 0; --t) {
-                if (best[t] < best[t - 1]) {
-                    const double tmp = best[t];
-                    best[t] = best[t - 1];
-                    best[t - 1] = tmp;
+            for (int u = 0; u < 4; ++u) {
+                const int64_t j = j0 + u * 256 + tid;
+                if (j < nv) {
+                    v[u] = rv[j];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < VW; ++e) v[u][e] = T(INFINITY);
                 }
             }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                for (int e = 0; e < VW; ++e) GT_BW_INSERT(v[u][e]);
+            }
         }
+    } else {
+        for (int64_t j = tid; j < n; j += 256) GT_BW_INSERT(row[j]);
     }
+#undef GT_BW_INSERT
 #pragma unroll
     for (int t = 0; t < KL; ++t) cand[tid * KL + t] = best[t];
     __syncthreads();
@@ -91,14 +125,132 @@ __global__ __launch_bounds__(256) void dense_bandwidth_kernel(const T* __restric
     if (tid == 0) bw[i] = __longlong_as_double((long long)v) * scale;
 }
 
+// kth smallest of a row in two streaming passes (kth <= 256): the kth smallest of the 256 per-thread minima is an
+// upper bound of the answer with at least kth entries at or below it; the second pass collects everything at or
+// below that bound (a few dozen values) and the answer is selected among them.  Per element: one convert and one
+// min / compare - the kernel runs at the speed of the two HBM reads instead of maintaining per-thread sorted lists.
+// Returns through bw[i]; rows that collect more than CAP values are redone by the generic kernel (flagged in `redo`).
+template <typename T>
+__global__ __launch_bounds__(256) void dense_bandwidth_2pass_kernel(const T* __restrict__ D, const int64_t n, const int kth,
+                                                                    const double scale, double* __restrict__ bw,
+                                                                    uint32_t* __restrict__ redo) {
+    constexpr int CAP = 1024;
+    __shared__ double vals[CAP];
+    __shared__ int red[4];
+    __shared__ int cnt;
+    const int64_t i = blockIdx.x;
+    const int tid = threadIdx.x;
+    const T* row = D + i * n;
+    constexpr int VW = 16 / int(sizeof(T));
+    typedef T vecT __attribute__((ext_vector_type(VW)));
+    const bool vec = (n % VW) == 0;
+    const vecT* rv = reinterpret_cast<const vecT*>(row);
+    const int64_t nv = n / VW;
+    // ---- pass 1: per-thread minimum ----
+    double mn = INFINITY;
+    if (vec) {
+        for (int64_t j0 = 0; j0 < nv; j0 += 256 * 4) {
+            vecT v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t j = j0 + u * 256 + tid;
+                if (j < nv) {
+                    v[u] = rv[j];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < VW; ++e) v[u][e] = T(INFINITY);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int e = 0; e < VW; ++e) mn = fmin(mn, double(v[u][e]));
+        }
+    } else {
+        for (int64_t j = tid; j < n; j += 256) mn = fmin(mn, double(row[j]));
+    }
+    // ---- kth smallest of the 256 minima (bitwise search on the float64 pattern; values >= 0) ----
+    const unsigned long long mykey = (mn > 0.0) ? (unsigned long long)__double_as_longlong(mn) : 0ull;
+    unsigned long long bound = 0ull;
+    for (int b = 63; b >= 0; --b) {
+        const unsigned long long trial = bound | ((1ull << b) - 1ull);
+        int c = wave_sum_i32((mykey <= trial) ? 1 : 0);
+        __syncthreads();
+        if ((tid & 63) == 0) red[tid >> 6] = c;
+        __syncthreads();
+        if (red[0] + red[1] + red[2] + red[3] < kth) bound |= (1ull << b);
+    }
+    const double ub = __longlong_as_double((long long)bound);
+    if (tid == 0) cnt = 0;
+    __syncthreads();
+    // ---- pass 2: collect everything <= ub ----
+#define GT_BW_TAKE(V_)                                             \
+    {                                                              \
+        const double v_ = double(V_);                              \
+        if (v_ <= ub) {                                            \
+            const int pos = atomicAdd(&cnt, 1);                    \
+            if (pos < CAP) vals[pos] = v_;                         \
+        }                                                          \
+    }
+    if (vec) {
+        for (int64_t j0 = 0; j0 < nv; j0 += 256 * 4) {
+            vecT v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t j = j0 + u * 256 + tid;
+                if (j < nv) {
+                    v[u] = rv[j];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < VW; ++e) v[u][e] = T(INFINITY);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int e = 0; e < VW; ++e) GT_BW_TAKE(v[u][e]);
+        }
+    } else {
+        for (int64_t j = tid; j < n; j += 256) GT_BW_TAKE(row[j]);
+    }
+#undef GT_BW_TAKE
+    __syncthreads();
+    const int m = cnt;
+    if (m > CAP) {   // pathological row (mass ties at the bound): leave it to the generic kernel
+        if (tid == 0) {
+            bw[i] = -1.0;
+            atomicAdd(redo, 1u);
+        }
+        return;
+    }
+    // ---- kth smallest of the m collected values ----
+    unsigned long long v = 0ull;
+    for (int b = 63; b >= 0; --b) {
+        const unsigned long long trial = v | ((1ull << b) - 1ull);
+        int c = 0;
+        for (int e = tid; e < m; e += 256) {
+            const double x = vals[e];
+            const unsigned long long key = (x > 0.0) ? (unsigned long long)__double_as_longlong(x) : 0ull;
+            c += (key <= trial) ? 1 : 0;
+        }
+        c = wave_sum_i32(c);
+        __syncthreads();
+        if ((tid & 63) == 0) red[tid >> 6] = c;
+        __syncthreads();
+        if (red[0] + red[1] + red[2] + red[3] < kth) v |= (1ull << b);
+    }
+    if (tid == 0) bw[i] = __longlong_as_double((long long)v) * scale;
+}
+
 // generic (any kth): bitwise search straight over the row (64 passes; the row stays L2 resident)
 template <typename T>
 __global__ __launch_bounds__(256) void dense_bandwidth_generic_kernel(const T* __restrict__ D, const int64_t n,
                                                                       const int kth, const double scale,
-                                                                      double* __restrict__ bw) {
+                                                                      double* __restrict__ bw, const int only_flagged) {
     __shared__ int red[4];
     const int64_t i = blockIdx.x;
     const int tid = threadIdx.x;
+    if (only_flagged && !(bw[i] < 0.0)) return;   // block-uniform: redo pass after the two-pass kernel
     const T* row = D + i * n;
     unsigned long long v = 0ull;
     for (int b = 63; b >= 0; --b) {
@@ -155,7 +307,7 @@ __global__ __launch_bounds__(256) void dense_kernel_tiles(const TD* __restrict__
                                                           const int64_t n, const int nb, const double* __restrict__ bw,
                                                           const double decay_d, const double thresh_d, const int symm,
                                                           const double theta_d, TC* __restrict__ Kout,
-                                                          uint32_t* __restrict__ flags) {
+                                                          uint32_t* __restrict__ flags, const double xcut_d) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     TC* sA = reinterpret_cast<TC*>(smem_raw);      // [TS][TSP]  K0 of tile (I,J): sA[i][j]
     TC* sB = sA + TS * TSP;                        // [TS][TSP]  K0 of tile (J,I): sB[j][i]
@@ -180,7 +332,7 @@ __global__ __launch_bounds__(256) void dense_kernel_tiles(const TD* __restrict__
     const int64_t I0 = int64_t(bi) * TS, J0 = int64_t(bj) * TS;
     const int tx = threadIdx.x & 63;
     const int ty = threadIdx.x >> 6;
-    const TC decay = TC(decay_d), thresh = TC(thresh_d), theta = TC(theta_d);
+    const TC decay = TC(decay_d), thresh = TC(thresh_d), theta = TC(theta_d), xcut = TC(xcut_d);
     const bool diag = (bi == bj);
 
     if (FROM_DATA) {
@@ -216,8 +368,8 @@ __global__ __launch_bounds__(256) void dense_kernel_tiles(const TD* __restrict__
             TC ka = TC(0), kb = TC(0);
             if (gi < n && gj < n) {
                 const TC dist = TC(sqrt(acc[r]));
-                ka = affinity_t<TC>(dist, TC(bw[gi]), decay);
-                kb = affinity_t<TC>(dist, TC(bw[gj]), decay);
+                ka = affinity_t<TC>(dist, TC(bw[gi]), decay, xcut);
+                kb = affinity_t<TC>(dist, TC(bw[gj]), decay, xcut);
                 if (ka < thresh) ka = TC(0);
                 if (kb < thresh) kb = TC(0);
                 if (dist == TC(0) && gi != gj) atomicOr(flags, GT_FLAG_DUPLICATES);
@@ -233,7 +385,7 @@ __global__ __launch_bounds__(256) void dense_kernel_tiles(const TD* __restrict__
                 const int64_t gi = I0 + i, gj = J0 + tx;
                 TC ka = TC(0);
                 if (gi < n && gj < n) {
-                    ka = affinity_t<TC>(TC(D[gi * n + gj]), TC(bw[gi]), decay);
+                    ka = affinity_t<TC>(TC(D[gi * n + gj]), TC(bw[gi]), decay, xcut);
                     if (ka < thresh) ka = TC(0);
                 }
                 sA[i * TSP + tx] = ka;
@@ -242,7 +394,7 @@ __global__ __launch_bounds__(256) void dense_kernel_tiles(const TD* __restrict__
                 const int64_t gj = J0 + i, gi = I0 + tx;
                 TC kb = TC(0);
                 if (gi < n && gj < n) {
-                    kb = affinity_t<TC>(TC(D[gj * n + gi]), TC(bw[gj]), decay);
+                    kb = affinity_t<TC>(TC(D[gj * n + gi]), TC(bw[gj]), decay, xcut);
                     if (kb < thresh) kb = TC(0);
                 }
                 sB[i * TSP + tx] = kb;
@@ -321,8 +473,20 @@ __global__ __launch_bounds__(256) void dense_normalize_kernel(const T* __restric
 }
 
 struct DenseState {
-    DevBuf bw, bw_user, rowsum, deg, work_in, work_k, work_p, flags;
+    DevBuf bw, bw_user, rowsum, deg, work_in, work_k, work_p, flags, redo;
 };
+
+// Scaled distance beyond which exp(-x^decay) is exactly 0 in the reference: it falls below `thresh` (zeroed,
+// graphs.py:1598-1600) or, with thresh == 0, exp underflows to 0 in the result dtype.  1 % margin in the exponent:
+// the value at the cut is >= 8 % (thresh = 1e-4) away from the decision, rounding errors are ~1e-6.
+static double dense_xcut(double decay, double thresh, bool f32) {
+    if (!(decay > 0.0)) return INFINITY;
+    const double p_under = f32 ? 104.5 : 746.0;
+    double p_cut = p_under;
+    if (thresh > 0.0 && thresh < 1.0) p_cut = std::min(p_under, -std::log(thresh));
+    if (thresh >= 1.0) return INFINITY;
+    return std::pow(p_cut * 1.01, 1.0 / decay);
+}
 
 template <typename TD, typename TC, typename TX, bool FROM_DATA>
 int launch_tiles(gt_ctx* ctx, const TD* D, const TX* X, int d, int64_t n, const double* bw, double decay, double thresh,
@@ -335,7 +499,7 @@ int launch_tiles(gt_ctx* ctx, const TD* D, const TX* X, int d, int64_t n, const 
     GT_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     int(lds)));
     hipLaunchKernelGGL(kern, dim3((unsigned)pairs), dim3(256), lds, ctx->stream, D, X, d, n, nb, bw, decay, thresh, symm,
-                       theta, Kout, flags);
+                       theta, Kout, flags, dense_xcut(decay, thresh, sizeof(TC) == 4));
     GT_HIP(ctx, hipGetLastError());
     return GT_OK;
 }
@@ -387,7 +551,7 @@ extern "C" int gt_dense_graph_build(gt_ctx* ctx, const void* X_or_D, int64_t n, 
     const size_t out_esz = out_f64 ? 8 : 4;
     const size_t in_esz = dtype == GT_F64 ? 8 : 4;
     auto cleanup = [&]() {
-        for (DevBuf* b : {&st.bw, &st.bw_user, &st.rowsum, &st.deg, &st.work_in, &st.work_k, &st.work_p, &st.flags})
+        for (DevBuf* b : {&st.bw, &st.bw_user, &st.rowsum, &st.deg, &st.work_in, &st.work_k, &st.work_p, &st.flags, &st.redo})
             b->release();
     };
 #define DENSE_TRY(expr)            \
@@ -432,7 +596,7 @@ extern "C" int gt_dense_graph_build(gt_ctx* ctx, const void* X_or_D, int64_t n, 
                                st.bw_user.as<double>(), bandwidth_len, n, bandwidth_scale, st.bw.as<double>());
         } else if (!precomputed) {
             if (ctx->DP == 0) {
-                ctx->set_error("exact graph from data needs n_features <= 128 on the HIP path (reduce with n_pca)");
+                ctx->set_error("exact graph from data: this feature count is not supported on the HIP path (reduce with n_pca)");
                 cleanup();
                 return GT_E_LIMIT;
             }
@@ -448,21 +612,29 @@ extern "C" int gt_dense_graph_build(gt_ctx* ctx, const void* X_or_D, int64_t n, 
                                    bandwidth_scale, st.bw.as<double>());
         } else {
             const int kth = knn + 1;
-#define LAUNCH_BW(T, KL)                                                                                               \
-    hipLaunchKernelGGL((dense_bandwidth_kernel<T, KL>), dim3((unsigned)n), dim3(256), 0, ctx->stream, (const T*)in_dev, n, \
-                       kth, bandwidth_scale, st.bw.as<double>())
-            if (dtype == GT_F32) {
-                if (kth <= 8) LAUNCH_BW(float, 8);
-                else if (kth <= 16) LAUNCH_BW(float, 16);
-                else hipLaunchKernelGGL(dense_bandwidth_generic_kernel<float>, dim3((unsigned)n), dim3(256), 0, ctx->stream,
-                                        (const float*)in_dev, n, kth, bandwidth_scale, st.bw.as<double>());
-            } else {
-                if (kth <= 8) LAUNCH_BW(double, 8);
-                else if (kth <= 16) LAUNCH_BW(double, 16);
-                else hipLaunchKernelGGL(dense_bandwidth_generic_kernel<double>, dim3((unsigned)n), dim3(256), 0, ctx->stream,
-                                        (const double*)in_dev, n, kth, bandwidth_scale, st.bw.as<double>());
+            DENSE_HIP(st.redo.reserve(sizeof(uint32_t)));
+            DENSE_HIP(hipMemsetAsync(st.redo.p, 0, sizeof(uint32_t), ctx->stream));
+            uint32_t n_redo = (kth > 256) ? 1u : 0u;
+            if (kth <= 256) {
+                if (dtype == GT_F32)
+                    hipLaunchKernelGGL(dense_bandwidth_2pass_kernel<float>, dim3((unsigned)n), dim3(256), 0, ctx->stream,
+                                       (const float*)in_dev, n, kth, bandwidth_scale, st.bw.as<double>(), st.redo.as<uint32_t>());
+                else
+                    hipLaunchKernelGGL(dense_bandwidth_2pass_kernel<double>, dim3((unsigned)n), dim3(256), 0, ctx->stream,
+                                       (const double*)in_dev, n, kth, bandwidth_scale, st.bw.as<double>(), st.redo.as<uint32_t>());
+                DENSE_HIP(hipGetLastError());
+                DENSE_HIP(hipMemcpyAsync(&n_redo, st.redo.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+                DENSE_HIP(hipStreamSynchronize(ctx->stream));
             }
-#undef LAUNCH_BW
+            if (n_redo > 0) {
+                const int only = (kth <= 256) ? 1 : 0;
+                if (dtype == GT_F32)
+                    hipLaunchKernelGGL(dense_bandwidth_generic_kernel<float>, dim3((unsigned)n), dim3(256), 0, ctx->stream,
+                                       (const float*)in_dev, n, kth, bandwidth_scale, st.bw.as<double>(), only);
+                else
+                    hipLaunchKernelGGL(dense_bandwidth_generic_kernel<double>, dim3((unsigned)n), dim3(256), 0, ctx->stream,
+                                       (const double*)in_dev, n, kth, bandwidth_scale, st.bw.as<double>(), only);
+            }
         }
         DENSE_HIP(hipGetLastError());
     }
