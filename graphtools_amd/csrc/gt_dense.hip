@@ -433,9 +433,37 @@ __global__ __launch_bounds__(256) void dense_rowsum_kernel(const T* __restrict__
     const int64_t i = blockIdx.x;
     const T* row = K + i * n;
     double s = 0.0;
-    for (int64_t j = threadIdx.x; j < n; j += 256) {
-        const double v = double(row[j]);
-        s += use_abs ? fabs(v) : v;
+    constexpr int VW = 16 / int(sizeof(T));
+    typedef T vecT __attribute__((ext_vector_type(VW)));
+    if ((n % VW) == 0) {
+        // 16-byte loads, four in flight per thread (a pure HBM stream)
+        const vecT* rv = reinterpret_cast<const vecT*>(row);
+        const int64_t nv = n / VW;
+        for (int64_t j0 = 0; j0 < nv; j0 += 256 * 4) {
+            vecT v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t j = j0 + u * 256 + threadIdx.x;
+                if (j < nv) {
+                    v[u] = rv[j];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < VW; ++e) v[u][e] = T(0);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int e = 0; e < VW; ++e) {
+                    const double x = double(v[u][e]);
+                    s += use_abs ? fabs(x) : x;
+                }
+        }
+    } else {
+        for (int64_t j = threadIdx.x; j < n; j += 256) {
+            const double v = double(row[j]);
+            s += use_abs ? fabs(v) : v;
+        }
     }
     s = wave_sum_f64(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
