@@ -96,11 +96,26 @@ def main():
             if not ok_struct and kind == "lattice":
                 # exact distance ties at a neighbourhood boundary: scikit-learn's pick is unspecified; compare sets loosely
                 status = "tie-structure"
+            elif not ok_struct and cfg["decay"] is not None:
+                # An affinity within rounding of `thresh` may land on either side of the cut: the float64 squared
+                # distance depends on the summation order at the 1e-16 level, which flips its float32 rounding on a
+                # ~1e-7 fraction of entries (oracle/knn.py header) and moves the affinity by ~decay * 1e-7 relative.
+                # Accept a structural difference only if every differing entry of the UNSYMMETRISED kernel is such a
+                # threshold tie (within the 1e-5 relative bar of the values).
+                K0 = sparse.csr_matrix(G.build_kernel())
+                K0o = sparse.csr_matrix(oracle.knn_kernel(X, knn=knn, decay=cfg["decay"], thresh=thresh, bandwidth=bandwidth,
+                                                          bandwidth_scale=bw_scale, knn_max=knn_max, distance=distance))
+                A = (K0 != 0).astype(np.int8)
+                B = (K0o != 0).astype(np.int8)
+                diff = (A - B).tocoo()
+                vals = np.asarray((K0.maximum(K0o))[diff.row, diff.col]).ravel()
+                if len(vals) and len(vals) <= 1e-5 * max(K0o.nnz, 1) + 8 and np.all(np.abs(vals - thresh) <= 1e-5 * thresh):
+                    status = "threshold-tie"
         except Exception as e:   # noqa: BLE001
             status, err, ok_struct = "ERROR: %s: %s" % (type(e).__name__, str(e)[:200]), -1.0, False
         rec = dict(case=case, status=status, err=err, main=G.hip.last_knn_precision() if "G" in dir() else None, **cfg)
         print(json.dumps(rec), flush=True)
-        if status not in ("ok", "tie-structure"):
+        if status not in ("ok", "tie-structure", "threshold-tie"):
             fails.append(rec)
     print(json.dumps({"cases": n_cases, "failures": len(fails), "seconds": round(time.time() - t_start, 1)}))
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
