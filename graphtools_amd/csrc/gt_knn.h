@@ -58,8 +58,10 @@ ErrModel gt_err_model(const gt_ctx* ctx, int prec);   // prec: arithmetic of the
 // Build exact candidate tables with the first `need_m` entries of every row guaranteed to be the true
 // need_m nearest neighbours.  Queries: rows [q0, q0+nq) of the bound points, or (external) the matrix in
 // ctx->knn->Qraw prepared by the caller.
-// `radius_key_factor` (optional): the caller will need every row within factor x key(need_m-th neighbour) - only used to
-// judge whether the single-chain float16 main pass is adequate for this point set (speed, never correctness).
+// `radius_key_factor` (optional): the caller will need every row within factor x key(need_m-th neighbour).  Used to
+// judge whether the single-chain float16 main pass is adequate for this point set and to let the re-rank stop after its
+// first batch of candidates (speed, never correctness).  Negative: the extent is not tied to the need_m-th neighbour
+// (caller-given bandwidth) - the re-rank evaluates every candidate, |factor| serves the judgement.
 int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int need_m, double radius_key_factor = 1.0);
 // Upload / convert an external query matrix (same dtype and width as the bound points) into ctx->knn->Qraw
 // (original dtype, normalised for the cosine metric), Qp (working copy) and qn (float64 squared norms).

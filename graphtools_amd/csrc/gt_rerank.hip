@@ -75,41 +75,99 @@ __global__ __launch_bounds__(256) void rerank_kernel(const T* __restrict__ X, co
     const uint32_t n = cnt < uint32_t(MP) ? cnt : uint32_t(MP);
     const uint64_t* lp = lists + size_t(q) * lstride;
 
+    // completeness bound of the candidate pass: every row it rejected or dropped scored <= thr_final
+    // qs, y2: the norms of what the candidate pass scored (a coordinate subset for wide data: its squared distance
+    // is a lower bound of the full one, so the bounds below hold for the full distance as well)
+    const double qs = qn_sel[q0 + q];
+    const double y2 = *ymax2p;
+    const double e = gt_err_bound(err, qs, y2);
+    // euclidean: d2 = |x|^2 - 2 s ; cosine: D = 1 - x.y = 1 - s - |y|^2/2 >= 1 - s - ymax^2/2
+    auto bound_of_score = [&](float score) {
+        const double sv = double(score) * err.inv_sc2;
+        const double b = (metric == 1) ? (1.0 - (sv + e) - 0.5 * y2) : (qs - 2.0 * (sv + e));
+        return b - 1e-9 * (qs + y2);   // float64 rounding of the quantities above, with a wide margin
+    };
+    double lb = INFINITY;
+    const float thr_f = thr_final[q];
+    if (thr_f > -INFINITY) lb = bound_of_score(thr_f);   // -inf: the candidate pass rejected nothing for this query
+
     uint64_t hi[NT2], lo[NT2];
+    uint32_t n_tab = n;
+    const int pos = need_m - 1;
+    bool settled = false;
+    const bool may_stop = radius_key_factor > 0.0;
+    const double rkf = fabs(radius_key_factor);
+    if constexpr (NT2 == 4) {
+        // Two batches: the 128 candidates with the best approximate scores are evaluated exactly first.  Every other
+        // candidate scored at most s_129, i.e. lies beyond bound_of_score(s_129); if that bound (and the pass bound)
+        // clears what the caller needs - the need_m-th key times radius_key_factor - the second batch of row gathers
+        // (half of this kernel's HBM traffic) is skipped and the table ends at 128 entries.
+        uint64_t ks[4];
 #pragma unroll
-    for (int u = 0; u < NT2; ++u) {
-        const uint32_t c = uint32_t(u * 64 + lane);
-        hi[u] = kInfBits;
-        lo[u] = 0xFFFFFFFFull;
-        if (c < n) {
-            const uint32_t j = cand_index(lp[c]);
-            const double dot = dot_row<T>(xs, X + int64_t(j) * d, d);
-            hi[u] = (uint64_t)__double_as_longlong(gt_pair_key(qnq, dot, xn[j], metric));
-            lo[u] = j;
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t c = uint32_t(u * 64 + lane);
+            ks[u] = (c < n) ? lp[c] : 0ull;   // a valid key is never 0
+        }
+        wave_bitonic_desc<4>(ks, lane);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            hi[u] = kInfBits;
+            lo[u] = 0xFFFFFFFFull;
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (ks[u] != 0ull) {
+                const uint32_t j = cand_index(ks[u]);
+                const double dot = dot_row<T>(xs, X + int64_t(j) * d, d);
+                hi[u] = (uint64_t)__double_as_longlong(gt_pair_key(qnq, dot, xn[j], metric));
+                lo[u] = j;
+            }
+        }
+        const uint64_t k129 = __shfl((unsigned long long)ks[2], 0);
+        const double lb_rest = (k129 != 0ull) ? bound_of_score(cand_score(k129)) : INFINITY;
+        uint64_t h2[2] = {hi[0], hi[1]}, l2[2] = {lo[0], lo[1]};
+        wave_bitonic_asc_pair<2>(h2, l2, lane);
+        const uint64_t sel2 = (pos >> 6) == 0 ? h2[0] : h2[1];
+        const double need2 = __longlong_as_double((long long)__shfl((unsigned long long)sel2, pos & 63));
+        const double lbm = fmin(lb, lb_rest);
+        if (may_stop && pos < 128 && need2 * rkf < lbm) {   // wave-uniform
+            hi[0] = h2[0]; hi[1] = h2[1];
+            lo[0] = l2[0]; lo[1] = l2[1];
+            lb = lbm;
+            n_tab = n < 128u ? n : 128u;
+            settled = true;
+        } else {
+#pragma unroll
+            for (int u = 2; u < 4; ++u) {
+                if (ks[u] != 0ull) {
+                    const uint32_t j = cand_index(ks[u]);
+                    const double dot = dot_row<T>(xs, X + int64_t(j) * d, d);
+                    hi[u] = (uint64_t)__double_as_longlong(gt_pair_key(qnq, dot, xn[j], metric));
+                    lo[u] = j;
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < NT2; ++u) {
+            const uint32_t c = uint32_t(u * 64 + lane);
+            hi[u] = kInfBits;
+            lo[u] = 0xFFFFFFFFull;
+            if (c < n) {
+                const uint32_t j = cand_index(lp[c]);
+                const double dot = dot_row<T>(xs, X + int64_t(j) * d, d);
+                hi[u] = (uint64_t)__double_as_longlong(gt_pair_key(qnq, dot, xn[j], metric));
+                lo[u] = j;
+            }
         }
     }
-    wave_bitonic_asc_pair<NT2>(hi, lo, lane);
+    if (!settled) wave_bitonic_asc_pair<NT2>(hi, lo, lane);
 #pragma unroll
     for (int u = 0; u < NT2; ++u) {
         cand_d2[size_t(q) * MP + u * 64 + lane] = __longlong_as_double((long long)hi[u]);
         cand_j[size_t(q) * MP + u * 64 + lane] = uint32_t(lo[u]);
     }
-    // completeness bound
-    double lb = INFINITY;
-    const float thr_f = thr_final[q];
-    if (thr_f > -INFINITY) {   // -inf: the candidate pass rejected nothing for this query
-        // qs, y2: the norms of what the candidate pass scored (a coordinate subset for wide data: its squared distance
-        // is a lower bound of the full one, so the bound below holds for the full distance as well)
-        const double qs = qn_sel[q0 + q];
-        const double thr = double(thr_f) * err.inv_sc2;
-        const double y2 = *ymax2p;
-        const double e = gt_err_bound(err, qs, y2);
-        // euclidean: d2 = |x|^2 - 2 s ; cosine: D = 1 - x.y = 1 - s - |y|^2/2 >= 1 - s - ymax^2/2
-        lb = (metric == 1) ? (1.0 - (thr + e) - 0.5 * y2) : (qs - 2.0 * (thr + e));
-        lb -= 1e-9 * (qs + y2);   // float64 rounding of the quantities above, with a wide margin
-    }
     // d2 of the need_m-th neighbour (position need_m - 1)
-    const int pos = need_m - 1;
     uint64_t sel = 0;
 #pragma unroll
     for (int u = 0; u < NT2; ++u)
@@ -117,13 +175,13 @@ __global__ __launch_bounds__(256) void rerank_kernel(const T* __restrict__ X, co
     const double d2_need = __longlong_as_double((long long)__shfl((unsigned long long)sel, pos & 63));
     const uint64_t second = __shfl((unsigned long long)hi[0], 1);
     if (lane == 0) {
-        cand_n[q] = n;
+        cand_n[q] = n_tab;
         d2_lb[q] = lb;
         if (!(d2_need < lb)) {
             const uint32_t slot = atomicAdd(fb_count, 1u);
             fb_rows[slot] = int32_t(q);
         }
-        if (unproven && !(d2_need * radius_key_factor < lb)) atomicAdd(unproven, 1u);
+        if (unproven && !(d2_need * rkf < lb)) atomicAdd(unproven, 1u);
         if (n > 1 && second == 0ull) atomicOr(gflags, GT_FLAG_DUPLICATES);
     }
 }

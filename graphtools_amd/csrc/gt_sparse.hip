@@ -742,10 +742,14 @@ static int graph_begin_impl(gt_ctx* ctx, const gt_knn_params* params, int32_t wo
     // ---- kNN candidates for the owned rows ----
     {
         // hint for the arithmetic choice of the main pass: rows out to radius_factor x bandwidth will be needed
+        // (it also lets the re-rank stop after its first batch of candidates); a caller-given bandwidth is not tied to
+        // the k-th neighbour: no hint, every candidate is evaluated
         double hint = 1.0;
         if (use_radius && params->bandwidth_len == 0) {
             const double rf = std::pow(-1.0 * std::log(thresh), 1.0 / params->decay) * params->bandwidth_scale;
             hint = (ctx->metric == 1) ? rf : rf * rf;
+        } else if (use_radius) {
+            hint = -1.0;   // negative: no early stop in the re-rank (gt_knn.h)
         }
         GT_TRY(gt_knn_candidates(ctx, g->r0, g->nloc, external, need, hint));
     }
