@@ -20,12 +20,15 @@ namespace {
 
 constexpr int TS = 64;        // tile side
 constexpr int TSP = TS + 1;   // padded LDS row
+constexpr int SG = 8;         // super-tile side (tiles)
 
 // xcut: beyond this scaled distance the reference's result is exactly 0 - below `thresh` (then zeroed), or an
 // underflow of exp in T - so the transcendental work (the compute bound of this otherwise HBM-bound kernel) is
 // skipped for almost every entry of a dense matrix.  The host leaves a 1 % margin in the exponent (dense_xcut).
 template <typename T>
 __device__ __forceinline__ T affinity_t(T dist, T bw, T decay, T xcut) {
+    // cheap pre-test without the division (xcut carries a 1 % margin in the exponent, the factor below costs 1e-5 of it)
+    if (dist > bw * (xcut * T(1.00001))) return T(0);
     const T x = dist / bw;
     if (x > xcut) return T(0);
     T w;
@@ -312,28 +315,25 @@ __global__ __launch_bounds__(256) void dense_kernel_tiles(const TD* __restrict__
     TC* sA = reinterpret_cast<TC*>(smem_raw);      // [TS][TSP]  K0 of tile (I,J): sA[i][j]
     TC* sB = sA + TS * TSP;                        // [TS][TSP]  K0 of tile (J,I): sB[j][i]
     double* xI = reinterpret_cast<double*>(sB + TS * TSP);   // FROM_DATA: [TS][KC] chunks
-    // decode (bi, bj) with bi <= bj from the linear pair index
-    int64_t p = blockIdx.x;
-    int bi = 0;
-    {
-        // row bi of the upper triangle holds nb - bi pairs
-        int64_t rem = p;
-        int lo = 0, hi = nb;   // find bi such that offset(bi) <= p < offset(bi+1), offset(b) = b*nb - b(b-1)/2
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) / 2;
-            const int64_t off = int64_t(mid) * nb - int64_t(mid) * (mid - 1) / 2;
-            if (off <= p) lo = mid; else hi = mid;
-        }
-        bi = lo;
-        rem = p - (int64_t(bi) * nb - int64_t(bi) * (bi - 1) / 2);
-        p = rem;
-    }
-    const int bj = bi + int(p);
+    // Tile pairs are visited in super-tiles of SG x SG tiles: the workgroups in flight together then cover SG adjacent
+    // 256-byte segments of every row they touch - for the (I,J) tiles AND for the transposed (J,I) tiles, whose rows
+    // would otherwise be hit one isolated segment at a time (DRAM page misses on half of the traffic).  Positions
+    // below the diagonal exit at once.
+    const int nbs = (nb + SG - 1) / SG;
+    const int64_t st = int64_t(blockIdx.x) / (SG * SG);
+    const int within = int(int64_t(blockIdx.x) % (SG * SG));
+    const int sbi = int(st / nbs), sbj = int(st % nbs);
+    if (sbi > sbj) return;
+    const int bi = sbi * SG + within / SG;
+    const int bj = sbj * SG + within % SG;
+    if (bi > bj || bj >= nb) return;
     const int64_t I0 = int64_t(bi) * TS, J0 = int64_t(bj) * TS;
     const int tx = threadIdx.x & 63;
     const int ty = threadIdx.x >> 6;
     const TC decay = TC(decay_d), thresh = TC(thresh_d), theta = TC(theta_d), xcut = TC(xcut_d);
     const bool diag = (bi == bj);
+    constexpr bool kVecOK = !FROM_DATA && sizeof(TD) == 4 && sizeof(TC) == 4;
+    const bool vec4 = kVecOK && (n % 4) == 0;
 
     if (FROM_DATA) {
         constexpr int KC = 32, KCP = 33;   // padded stride: conflict-free per-lane rows
@@ -377,6 +377,82 @@ __global__ __launch_bounds__(256) void dense_kernel_tiles(const TD* __restrict__
             sA[i * TSP + j] = ka;
             sB[j * TSP + i] = kb;
         }
+    } else if (vec4) {
+        // float32 distances, n a multiple of 4: 16-byte loads and stores, one address computation per four elements
+        // (the scalar form below spends ~90 instructions per element, most of them on addressing)
+        if constexpr (kVecOK) {
+            const int tx4 = threadIdx.x & 15, ty16 = threadIdx.x >> 4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = ty16 + 16 * r;
+                {   // tile (I,J): row I0+i, columns J0 + 4 tx4 ..
+                    const int64_t gi = I0 + i, gj0 = J0 + 4 * tx4;
+                    float ka[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (gi < n && gj0 < n) {
+                        const float4 v = *reinterpret_cast<const float4*>(D + gi * n + gj0);
+                        const float bwi = float(bw[gi]);
+                        ka[0] = affinity_t<float>(v.x, bwi, decay, xcut);
+                        ka[1] = affinity_t<float>(v.y, bwi, decay, xcut);
+                        ka[2] = affinity_t<float>(v.z, bwi, decay, xcut);
+                        ka[3] = affinity_t<float>(v.w, bwi, decay, xcut);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (ka[e] < thresh) ka[e] = 0.f;
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) sA[i * TSP + 4 * tx4 + e] = ka[e];
+                }
+                if (!diag) {   // tile (J,I): row J0+i, columns I0 + 4 tx4 ..
+                    const int64_t gj = J0 + i, gi0 = I0 + 4 * tx4;
+                    float kb[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (gj < n && gi0 < n) {
+                        const float4 v = *reinterpret_cast<const float4*>(D + gj * n + gi0);
+                        const float bwj = float(bw[gj]);
+                        kb[0] = affinity_t<float>(v.x, bwj, decay, xcut);
+                        kb[1] = affinity_t<float>(v.y, bwj, decay, xcut);
+                        kb[2] = affinity_t<float>(v.z, bwj, decay, xcut);
+                        kb[3] = affinity_t<float>(v.w, bwj, decay, xcut);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (kb[e] < thresh) kb[e] = 0.f;
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) sB[i * TSP + 4 * tx4 + e] = kb[e];
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = ty16 + 16 * r;
+                {   // output tile (I,J)
+                    const int64_t gi = I0 + i, gj0 = J0 + 4 * tx4;
+                    if (gi < n && gj0 < n) {
+                        float o[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float a = sA[i * TSP + 4 * tx4 + e];
+                            const float b = diag ? sA[(4 * tx4 + e) * TSP + i] : sB[(4 * tx4 + e) * TSP + i];
+                            o[e] = merge_t<float>(a, b, symm, theta);
+                        }
+                        *reinterpret_cast<float4*>(Kout + gi * n + gj0) = make_float4(o[0], o[1], o[2], o[3]);
+                    }
+                }
+                if (!diag) {   // output tile (J,I)
+                    const int64_t gj = J0 + i, gi0 = I0 + 4 * tx4;
+                    if (gj < n && gi0 < n) {
+                        float o[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float b = sB[i * TSP + 4 * tx4 + e];
+                            const float a = sA[(4 * tx4 + e) * TSP + i];
+                            o[e] = merge_t<float>(b, a, symm, theta);
+                        }
+                        *reinterpret_cast<float4*>(Kout + gj * n + gi0) = make_float4(o[0], o[1], o[2], o[3]);
+                    }
+                }
+            }
+        }
+        return;
     } else {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -520,7 +596,9 @@ template <typename TD, typename TC, typename TX, bool FROM_DATA>
 int launch_tiles(gt_ctx* ctx, const TD* D, const TX* X, int d, int64_t n, const double* bw, double decay, double thresh,
                  int symm, double theta, TC* Kout, uint32_t* flags) {
     const int nb = int(ceil_div64(n, TS));
-    const int64_t pairs = int64_t(nb) * (nb + 1) / 2;
+    const int64_t nbs = ceil_div64(nb, SG);
+    const int64_t pairs = nbs * nbs * SG * SG;   // grid positions (super-tile order, lower triangle exits)
+    if (pairs >= (int64_t(1) << 31)) GT_FAIL(ctx, GT_E_LIMIT, "dense graph: too many tiles for one launch");
     size_t lds = size_t(2) * TS * TSP * sizeof(TC);
     if (FROM_DATA) lds += size_t(2) * TS * 33 * sizeof(double);
     auto kern = dense_kernel_tiles<TD, TC, TX, FROM_DATA>;

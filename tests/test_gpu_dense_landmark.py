@@ -98,3 +98,29 @@ def test_random_landmark_assignment_large_n_path():
     K = sparse.csr_matrix(G.K)
     op, tr = oracle.landmark_operator(K, z["big_clusters"])
     np.testing.assert_allclose(G.landmark_op, op, rtol=1e-9, atol=1e-15)
+
+
+@pytest.mark.parametrize("n", [1022, 1024, 257])
+@pytest.mark.parametrize("kw", [dict(kernel_symm="+"), dict(kernel_symm="*"), dict(kernel_symm="mnn", theta=0.3),
+                                dict(kernel_symm="+", thresh=0)])
+def test_exact_graph_from_float32_distances_vs_oracle(n, kw):
+    """float32 precomputed distances: results stay float32 like numpy's; n % 4 == 0 takes the 16-byte-vector tile path,
+    the other sizes the scalar one; thresh = 0 exercises the exp-underflow cut."""
+    X = make_mix(n, 12, 9)
+    D = np.sqrt(((X[:, None, :].astype(np.float64) - X[None, :, :]) ** 2).sum(-1)).astype(np.float32)
+    args = dict(knn=6, decay=8, thresh=1e-4)
+    args.update(kw)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        G = graphtools_amd.Graph(D, precomputed="distance", n_pca=None, **args)
+        K0, P0 = oracle.exact_graph(D, precomputed="distance", **args)
+    assert G.K.dtype == np.float32
+    thresh = args["thresh"]
+    # entries within float32 rounding of the threshold may fall either way; with thresh = 0 the "threshold" is the
+    # float32 underflow of exp: subnormal results (< 1.2e-38) carry no precision and may be flushed to zero
+    flip = (G.K == 0) != (K0 == 0)
+    assert np.all(np.abs(np.maximum(G.K, K0)[flip] - thresh) <= 1e-5 * max(thresh, 1e-30) + 1e-37)
+    assert flip.sum() <= (4 if thresh > 0 else 1e-4 * n * n)
+    m = ~flip
+    np.testing.assert_allclose(G.K[m], K0[m], rtol=1e-5, atol=1e-37)
+    np.testing.assert_allclose(G.P[m], P0[m], rtol=2e-5, atol=1e-37)
