@@ -21,6 +21,9 @@ ARCH = "gfx950"
 SELECT_UNITS = ([(0, dp) for dp in (16, 32, 56, 64, 104, 128)] + [(1, dp) for dp in (16, 32, 48, 64, 80, 96, 112, 128)] +
                 [(2, dp) for dp in (16, 32, 48, 64, 80, 96, 112, 128)])
 
+# 128-row-workgroup variants (single-chain float16, DP <= 64) for launches with few query rows (multi-GPU shards)
+SELECT_NARROW_UNITS = [(2, dp) for dp in (16, 32, 48, 64)]
+
 # candidate kernels: scores are never NaN (finite data, -inf seeds only on pad rows), so the v_max3 reduction of the
 # admission test needs no canonicalising moves
 SELECT_FLAGS = ["-fno-honor-nans"]
@@ -46,6 +49,9 @@ def _units():
     for prec, dp in SELECT_UNITS:
         units.append(("gt_knn_select.hip", "gt_knn_select_p%d_dp%d.o" % (prec, dp),
                       ["-DGT_SEL_PREC=%d" % prec, "-DGT_SEL_DP=%d" % dp] + SELECT_FLAGS))
+    for prec, dp in SELECT_NARROW_UNITS:
+        units.append(("gt_knn_select.hip", "gt_knn_select_narrow_p%d_dp%d.o" % (prec, dp),
+                      ["-DGT_SEL_PREC=%d" % prec, "-DGT_SEL_DP=%d" % dp, "-DGT_SEL_QT1=1"] + SELECT_FLAGS))
     return units
 
 

@@ -39,6 +39,10 @@
 #ifndef GT_SEL_PIPE
 #define GT_SEL_PIPE 1
 #endif
+// -DGT_SEL_QT1=1 builds the narrow variant of a (precision, DP <= 64) unit: one query tile per wave
+#ifndef GT_SEL_QT1
+#define GT_SEL_QT1 0
+#endif
 #ifndef GT_SEL_DSFIRST
 #define GT_SEL_DSFIRST 1
 #endif
@@ -63,7 +67,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #endif
 template <int DP, int PREC>
 struct SelCfg {
-    static constexpr int QT = (DP <= 64) ? 2 : 1;       // 32-row query tiles per wave
+    static constexpr int QT = (DP <= 64 && !GT_SEL_QT1) ? 2 : 1;       // 32-row query tiles per wave
     static constexpr int BQ = 4 * QT * 32;              // query rows per workgroup
     static constexpr int BN = (DP <= 64) ? 128 : 64;    // database rows per LDS tile
     static constexpr int RW = (PREC == 2) ? DP / 2 : DP;   // row width in dwords: float32 | hi,lo float16 planes | hi plane
@@ -632,6 +636,13 @@ int launch_dp(gt_ctx* ctx, const SelectArgs& a) {
 #endif
 #define GT_CAT3_(a, b, c, d) a##b##c##d
 #define GT_CAT3(a, b, c, d) GT_CAT3_(a, b, c, d)
+#if GT_SEL_QT1
+// narrow variant: one 32-row query tile per wave (128-row workgroups) - twice the workgroups for launches with few rows
+int GT_CAT3(gt_launch_select_narrow_p, GT_SEL_PREC, _dp, GT_SEL_DP)(gt_ctx* ctx, const SelectArgs& a) {
+    return launch_dp<GT_SEL_DP, GT_SEL_PREC>(ctx, a);
+}
+#else
 int GT_CAT3(gt_launch_select_p, GT_SEL_PREC, _dp, GT_SEL_DP)(gt_ctx* ctx, const SelectArgs& a) {
     return launch_dp<GT_SEL_DP, GT_SEL_PREC>(ctx, a);
 }
+#endif
