@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GRAPHTOOLS_AMD_LIB") or os.path.join(_HERE, "libgraphtools_amd.so")
 
 GT_F32, GT_F64 = 0, 1
+GT_E_NONFINITE = -6  # include/graphtools_amd.h
 SYMM = {None: 0, "none": 0, "+": 1, "*": 2, "mnn": 3}
 FLAG_DUPLICATES, FLAG_ZERO_DIAGONAL, FLAG_FALLBACK_ROWS, FLAG_RADIUS_ROWS = 1, 2, 4, 8
 CSR_K, CSR_P = 0, 1
@@ -144,6 +145,8 @@ class Context:
             pass
 
     def _check(self, rc, what):
+        if rc == GT_E_NONFINITE:   # the reference raises sklearn's ValueError here (NearestNeighbors.fit / kneighbors)
+            raise ValueError(self.lib.gt_last_error(self.h).decode())
         if rc != 0:
             raise HipError("%s failed (%d): %s" % (what, rc, self.lib.gt_last_error(self.h).decode()))
 
@@ -285,14 +288,15 @@ class Context:
         self._check(self.lib.gt_graph_rows(self.h, ctypes.byref(r0), ctypes.byref(r1), ctypes.byref(nnz)), "gt_graph_rows")
         return r0.value, r1.value, nnz.value
 
-    def graph_fetch_csr(self, which):
-        """host copies: (data float64, indices int32, indptr int64) for the owned rows"""
+    def graph_fetch_csr(self, which, structure=True):
+        """host copies: (data float64, indices int32, indptr int64) for the owned rows; ``structure=False`` copies
+        the values only (K and P share indices / indptr) and returns (data, None, None)"""
         r0, r1, nnz = self.graph_rows()
         data = np.empty(nnz, dtype=np.float64)
-        indices = np.empty(nnz, dtype=np.int32)
-        indptr = np.empty(r1 - r0 + 1, dtype=np.int64)
-        self._check(self.lib.gt_graph_fetch_csr(self.h, which, _ptr(data), _ptr(indices), _ptr(indptr), 0),
-                    "gt_graph_fetch_csr")
+        indices = np.empty(nnz, dtype=np.int32) if structure else None
+        indptr = np.empty(r1 - r0 + 1, dtype=np.int64) if structure else None
+        self._check(self.lib.gt_graph_fetch_csr(self.h, which, _ptr(data), _ptr(indices) if structure else None,
+                                                _ptr(indptr) if structure else None, 0), "gt_graph_fetch_csr")
         return data, indices, indptr
 
     def graph_fetch_vec(self, which):

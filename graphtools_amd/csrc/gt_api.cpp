@@ -1,5 +1,6 @@
 // Context management, point binding and the small device-memory helpers of the C ABI.
 #include "gt_common.h"
+#include "gt_hostcopy.h"
 #include "gt_knn.h"
 #include "gt_knn_select.h"
 
@@ -123,8 +124,18 @@ int gt_set_points(gt_ctx* ctx, const void* X, int64_t n, int32_t d, int32_t dtyp
         ctx->X = X;
     } else {
         GT_HIP(ctx, ctx->X_own.reserve(size_t(n) * d * esz));
-        GT_HIP(ctx, hipMemcpyAsync(ctx->X_own.p, X, size_t(n) * d * esz, hipMemcpyHostToDevice, ctx->stream));
+        GT_TRY(gt_copy_from_host(ctx, ctx->X_own.p, X, size_t(n) * d * esz));
         ctx->X = ctx->X_own.p;
+    }
+    {
+        // finiteness (the reference's NearestNeighbors.fit runs sklearn's check_array) + max |x| for the float16 scale
+        uint32_t nonfinite = 0;
+        GT_TRY(gt_max_abs(ctx, ctx->X, n * int64_t(d), dtype, &ctx->maxabs, &nonfinite));
+        if (nonfinite) {
+            ctx->n = 0;
+            ctx->X = nullptr;
+            return gt_fail_nonfinite(ctx, nonfinite, dtype);
+        }
     }
     if (ctx->metric == 1) {
         // cosine: every later stage works on the row-normalised points (distance = 1 - xhat.yhat)
@@ -232,17 +243,13 @@ int gt_dev_free(gt_ctx* ctx, void* p) {
 int gt_dev_upload(gt_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes) {
     if (!ctx) return GT_E_ARG;
     GT_HIP(ctx, hipSetDevice(ctx->device));
-    GT_HIP(ctx, hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
-    GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return GT_OK;
+    return gt_copy_from_host(ctx, dst_dev, src_host, bytes);
 }
 
 int gt_dev_download(gt_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes) {
     if (!ctx) return GT_E_ARG;
     GT_HIP(ctx, hipSetDevice(ctx->device));
-    GT_HIP(ctx, hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return GT_OK;
+    return gt_copy_to_host(ctx, dst_host, src_dev, bytes);
 }
 
 int gt_dev_sync(gt_ctx* ctx) {

@@ -13,6 +13,7 @@
 #include <cfloat>
 
 #include "gt_common.h"
+#include "gt_hostcopy.h"
 #include "gt_device.h"
 #include "gt_knn.h"
 
@@ -688,7 +689,7 @@ extern "C" int gt_dense_graph_build(gt_ctx* ctx, const void* X_or_D, int64_t n, 
         in_dev = ctx->X;
     } else if (!on_device) {
         DENSE_HIP(st.work_in.reserve(size_t(n) * n * in_esz));
-        DENSE_HIP(hipMemcpyAsync(st.work_in.p, X_or_D, size_t(n) * n * in_esz, hipMemcpyHostToDevice, ctx->stream));
+        DENSE_TRY(gt_copy_from_host(ctx, st.work_in.p, X_or_D, size_t(n) * n * in_esz));
         in_dev = st.work_in.p;
     }
     // ---- bandwidth ----
@@ -790,10 +791,8 @@ extern "C" int gt_dense_graph_build(gt_ctx* ctx, const void* X_or_D, int64_t n, 
         DENSE_TRY(finish_dense<double>(ctx, st, (double*)K_dev, (double*)P_dev, n, anisotropy));
     else
         DENSE_TRY(finish_dense<float>(ctx, st, (float*)K_dev, (float*)P_dev, n, anisotropy));
-    if (out_K && !out_on_device)
-        DENSE_HIP(hipMemcpyAsync(out_K, K_dev, size_t(n) * n * out_esz, hipMemcpyDeviceToHost, ctx->stream));
-    if (out_P && !out_on_device)
-        DENSE_HIP(hipMemcpyAsync(out_P, P_dev, size_t(n) * n * out_esz, hipMemcpyDeviceToHost, ctx->stream));
+    if (out_K && !out_on_device) DENSE_TRY(gt_copy_to_host(ctx, out_K, K_dev, size_t(n) * n * out_esz));
+    if (out_P && !out_on_device) DENSE_TRY(gt_copy_to_host(ctx, out_P, P_dev, size_t(n) * n * out_esz));
     uint32_t fl = 0;
     DENSE_HIP(hipMemcpyAsync(&fl, st.flags.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     DENSE_HIP(hipStreamSynchronize(ctx->stream));

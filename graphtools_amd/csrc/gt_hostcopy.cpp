@@ -1,0 +1,132 @@
+// Copies between PAGEABLE host memory (numpy arrays of the caller) and the device.
+//
+// hipMemcpy into a FRESH host array (np.empty: no page touched yet) moves 15-25 GB/s on the MI355X host - the
+// runtime pins the destination page by page, single-threaded, taking the first-touch faults on the way - against
+// 56 GB/s into resident memory (tools/gpu_copy_probe.py).  The results of a graph build at N = 1e6 are 2.3 GB (CSR K
+// and P), always copied into fresh arrays.  Here large device-to-host copies are cut into 8 MiB chunks and dealt to
+// kLanes host threads; every lane owns a HIP stream and two pinned slots and overlaps the DMA of its next chunk
+// with the memcpy of the current one from the slot into the caller's memory, where the page faults are then taken
+// in parallel: 50 GB/s into fresh memory.  Small copies and host-to-device copies take the plain runtime path.
+//
+// The pinned slots and streams are created once per process and device (128 MiB pinned) and never freed: the HIP
+// runtime may already be gone when static destructors run.
+#include <algorithm>
+#include <atomic>
+#include <mutex>
+#include <thread>
+
+#include "gt_common.h"
+#include "gt_hostcopy.h"
+
+namespace {
+
+constexpr int kMaxLanes = 32;
+// development overrides: GT_COPY_LANES (0 = plain hipMemcpy for every size), GT_COPY_SLOT_MB
+int env_int(const char* name, int dflt, int lo, int hi) {
+    const char* v = std::getenv(name);
+    if (!v) return dflt;
+    const int x = std::atoi(v);
+    return x < lo ? lo : x > hi ? hi : x;
+}
+const int kLanes = env_int("GT_COPY_LANES", 8, 0, kMaxLanes);
+const size_t kSlotBytes = size_t(env_int("GT_COPY_SLOT_MB", 8, 1, 64)) << 20;
+constexpr size_t kMinPipelined = size_t(32) << 20;
+constexpr int kMaxDevices = 64;
+
+struct Lane {
+    void* slot[2] = {nullptr, nullptr};
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+};
+
+struct Pipe {
+    Lane lanes[kMaxLanes];
+    std::mutex busy;   // one pipelined copy at a time per device
+};
+
+std::mutex g_create;
+Pipe* g_pipes[kMaxDevices];
+
+hipError_t pipe_for(int device, Pipe** out) {
+    std::lock_guard<std::mutex> lock(g_create);
+    if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+    if (!g_pipes[device]) {
+        Pipe* p = new Pipe();
+        for (int l = 0; l < kLanes; ++l) {
+            Lane& ln = p->lanes[l];
+            hipError_t e = hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking);
+            for (int s = 0; s < 2 && e == hipSuccess; ++s) {
+                e = hipHostMalloc(&ln.slot[s], kSlotBytes, hipHostMallocDefault);
+                if (e == hipSuccess) e = hipEventCreateWithFlags(&ln.ev[s], hipEventDisableTiming);
+            }
+            if (e != hipSuccess) return e;   // leaks the partial pipe; the caller reports the error
+        }
+        g_pipes[device] = p;
+    }
+    *out = g_pipes[device];
+    return hipSuccess;
+}
+
+// chunk c of the copy covers bytes [c * kSlotBytes, min(bytes, (c+1) * kSlotBytes)); lane l takes c = l, l + kLanes, ...
+void lane_d2h(int device, Lane* ln, int lane, char* dst, const char* src, size_t bytes, std::atomic<int>* err) {
+    hipError_t e = hipSetDevice(device);
+    const size_t nchunks = (bytes + kSlotBytes - 1) / kSlotBytes;
+    auto issue = [&](size_t c, int s) {
+        const size_t off = c * kSlotBytes, len = std::min(kSlotBytes, bytes - off);
+        hipError_t r = hipMemcpyAsync(ln->slot[s], src + off, len, hipMemcpyDeviceToHost, ln->stream);
+        if (r == hipSuccess) r = hipEventRecord(ln->ev[s], ln->stream);
+        return r;
+    };
+    int s = 0;
+    if (e == hipSuccess && size_t(lane) < nchunks) e = issue(size_t(lane), 0);
+    for (size_t c = size_t(lane); c < nchunks && e == hipSuccess; c += kLanes, s ^= 1) {
+        if (c + kLanes < nchunks) e = issue(c + kLanes, s ^ 1);   // its previous content was consumed one step ago
+        if (e == hipSuccess) e = hipEventSynchronize(ln->ev[s]);
+        if (e != hipSuccess) break;
+        const size_t off = c * kSlotBytes, len = std::min(kSlotBytes, bytes - off);
+        std::memcpy(dst + off, ln->slot[s], len);
+    }
+    if (e != hipSuccess) {
+        (void)hipStreamSynchronize(ln->stream);
+        err->store(int(e));
+    }
+}
+
+int pipelined_d2h(gt_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    Pipe* p = nullptr;
+    GT_HIP(ctx, pipe_for(ctx->device, &p));
+    std::lock_guard<std::mutex> lock(p->busy);
+    std::atomic<int> err(0);
+    std::thread th[kMaxLanes];
+    const int nl = int(std::min<size_t>(size_t(kLanes), (bytes + kSlotBytes - 1) / kSlotBytes));
+    for (int l = 0; l < nl; ++l)
+        th[l] = std::thread(lane_d2h, ctx->device, &p->lanes[l], l, static_cast<char*>(dst),
+                            static_cast<const char*>(src), bytes, &err);
+    for (int l = 0; l < nl; ++l) th[l].join();
+    if (err.load() != 0) {
+        ctx->set_error(std::string("pipelined host copy: ") + hipGetErrorString(hipError_t(err.load())));
+        return GT_E_HIP;
+    }
+    return GT_OK;
+}
+
+}  // namespace
+
+int gt_copy_to_host(gt_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes) {
+    if (bytes == 0) return GT_OK;
+    if (bytes < kMinPipelined || kLanes == 0) {
+        GT_HIP(ctx, hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return GT_OK;
+    }
+    GT_HIP(ctx, hipStreamSynchronize(ctx->stream));   // the producer kernels of src_dev
+    return pipelined_d2h(ctx, dst_host, src_dev, bytes);
+}
+
+int gt_copy_from_host(gt_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes) {
+    // the caller's array is resident: the runtime pins it in place and reaches the link rate (56 GB/s measured)
+    if (bytes == 0) return GT_OK;
+    GT_HIP(ctx, hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return GT_OK;
+}

@@ -1,6 +1,7 @@
 // Host orchestration of the kNN search: candidate pass (MFMA) -> exact re-rank (fp64) -> exhaustive
 // fallback for the rows whose candidate table could not be proven complete.
 #include "gt_knn.h"
+#include "gt_hostcopy.h"
 #include "gt_knn_select.h"
 
 #include <algorithm>
@@ -301,7 +302,9 @@ int gt_prepare_queries(gt_ctx* ctx, const void* Y, int64_t m, int32_t y_on_devic
     if (ctx->prec == 1) {
         // the query matrix shares the database's power-of-two scale; re-scale both if it would overflow float16
         double qmax = 0.0;
-        GT_TRY(gt_max_abs(ctx, kw->Qraw.p, m * int64_t(ctx->d), ctx->dtype, &qmax));
+        uint32_t nonfinite = 0;
+        GT_TRY(gt_max_abs(ctx, kw->Qraw.p, m * int64_t(ctx->d), ctx->dtype, &qmax, &nonfinite));
+        if (nonfinite) return gt_fail_nonfinite(ctx, nonfinite, ctx->dtype);
         if (qmax * ctx->sc >= 32768.0) {
             const double keep = ctx->maxabs;
             ctx->sc = gt_f16_scale(std::max(qmax, keep));
@@ -367,13 +370,8 @@ extern "C" int gt_knn_search(gt_ctx* ctx, int64_t row0, int64_t row1, const void
     int rc = gt_launch_emit_knn(ctx, kw->cand_d2.as<double>(), kw->cand_j.as<uint32_t>(), kw->MP, nq, k, ctx->dtype,
                                 ctx->metric, d_idx, d_dist);
     if (rc == GT_OK && !out_on_device) {
-        hipError_t e = hipMemcpyAsync(out_idx, d_idx, size_t(nq) * k * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream);
-        if (e == hipSuccess)
-            e = hipMemcpyAsync(out_dist, d_dist, size_t(nq) * k * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
-        if (e != hipSuccess) {
-            ctx->set_error(std::string("copy-out: ") + hipGetErrorString(e));
-            rc = GT_E_HIP;
-        }
+        rc = gt_copy_to_host(ctx, out_idx, d_idx, size_t(nq) * k * sizeof(int64_t));
+        if (rc == GT_OK) rc = gt_copy_to_host(ctx, out_dist, d_dist, size_t(nq) * k * sizeof(double));
     }
     uint32_t fl = 0;
     if (rc == GT_OK) {

@@ -32,7 +32,10 @@ int gt_select_columns(gt_ctx* ctx, int want);   // gt_prep.hip: wide data, colum
 int gt_prep_matrix(gt_ctx* ctx, const void* Xdev, int64_t n, int d, int dtype, int DP, int64_t n_pad, float* Yp,
                    double* xn, float* hneg, double* ymax2, int prec, double sc, double* lomax2 = nullptr, void* Yc = nullptr,
                    const int32_t* sel = nullptr, int dsel = 0, double* xn_sel = nullptr);
-int gt_max_abs(gt_ctx* ctx, const void* Xdev, int64_t total, int dtype, double* out_host);
+// max |x|; nonfinite (optional): bit 0 = NaN present, bit 1 = infinity present
+int gt_max_abs(gt_ctx* ctx, const void* Xdev, int64_t total, int dtype, double* out_host, uint32_t* nonfinite);
+// GT_E_NONFINITE with the message of sklearn's check_array when flags != 0
+int gt_fail_nonfinite(gt_ctx* ctx, uint32_t flags, int dtype);
 double gt_f16_scale(double maxabs);
 // row-wise l2 normalisation in the input dtype (sklearn normalize: zero rows untouched); in place allowed
 int gt_normalize_rows(gt_ctx* ctx, const void* X, void* out, int64_t n, int d, int dtype);

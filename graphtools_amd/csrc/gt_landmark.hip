@@ -12,6 +12,7 @@
 // M is accumulated per landmark row in LDS (one workgroup per landmark, ds_add_f64), so the only global
 // atomics are the counting-sort cursors that build the transposed structure.
 #include "gt_common.h"
+#include "gt_hostcopy.h"
 #include "gt_device.h"
 #include "gt_graph_state.h"
 
@@ -454,7 +455,13 @@ extern "C" int gt_landmark_fetch_transitions(gt_ctx* ctx, double* data, int32_t*
     GT_HIP(ctx, hipSetDevice(ctx->device));
     LandmarkState* l = reinterpret_cast<LandmarkState*>(ctx->landmark);
     if (!l || l->nloc == 0) GT_FAIL(ctx, GT_E_STATE, "gt_landmark_fetch_transitions: call gt_landmark_build first");
-    const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    if (!on_device) {
+        if (data) GT_TRY(gt_copy_to_host(ctx, data, l->tnorm.p, size_t(l->tnnz) * sizeof(double)));
+        if (indices) GT_TRY(gt_copy_to_host(ctx, indices, l->tcol.p, size_t(l->tnnz) * sizeof(int32_t)));
+        if (indptr) GT_TRY(gt_copy_to_host(ctx, indptr, l->tptr.p, size_t(l->nloc + 1) * sizeof(int64_t)));
+        return GT_OK;
+    }
+    const hipMemcpyKind kind = hipMemcpyDeviceToDevice;
     if (data && l->tnnz > 0) GT_HIP(ctx, hipMemcpyAsync(data, l->tnorm.p, size_t(l->tnnz) * sizeof(double), kind, ctx->stream));
     if (indices && l->tnnz > 0)
         GT_HIP(ctx, hipMemcpyAsync(indices, l->tcol.p, size_t(l->tnnz) * sizeof(int32_t), kind, ctx->stream));

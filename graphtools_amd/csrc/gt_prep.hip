@@ -52,18 +52,22 @@ __global__ __launch_bounds__(256) void col_stats_kernel(const T* __restrict__ X,
     atomicAdd(&stat[d + c], q);
 }
 
-// max |x| over the matrix (for the power-of-two scale of the split-float16 working copy)
+// max |x| over the matrix (for the power-of-two scale of the split-float16 working copy) and non-finite flags
+// (out_bits[1]: bit 0 = a NaN was seen, bit 1 = an infinity)
 template <typename T>
 __global__ __launch_bounds__(256) void max_abs_kernel(const T* __restrict__ X, const int64_t total,
                                                       unsigned long long* __restrict__ out_bits) {
     double m = 0.0;
+    bool nan = false;
     for (int64_t f = int64_t(blockIdx.x) * 256 + threadIdx.x; f < total; f += int64_t(gridDim.x) * 256) {
         const double v = fabs(double(X[f]));
-        m = v > m ? v : m;   // NaN never wins
+        nan |= v != v;
+        m = v > m ? v : m;   // NaN never wins, infinity does
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
     if ((threadIdx.x & 63) == 0) atomicMax(out_bits, (unsigned long long)__double_as_longlong(m));
+    if (__ballot(nan) != 0ull && (threadIdx.x & 63) == 0) atomicOr(out_bits + 1, 1ull);
 }
 
 // split-float16 working copy: row = hi plane (DP halves) | lo plane (DP halves), x*sc = hi + lo + O(2^-22 |x*sc|)
@@ -172,10 +176,10 @@ int gt_normalize_rows(gt_ctx* ctx, const void* X, void* out, int64_t n, int d, i
     return GT_OK;
 }
 
-int gt_max_abs(gt_ctx* ctx, const void* Xdev, int64_t total, int dtype, double* out_host) {
+int gt_max_abs(gt_ctx* ctx, const void* Xdev, int64_t total, int dtype, double* out_host, uint32_t* nonfinite) {
     DevBuf& tmp = ctx->small_tmp;
     GT_HIP(ctx, tmp.reserve(64));
-    GT_HIP(ctx, hipMemsetAsync(tmp.p, 0, sizeof(double), ctx->stream));
+    GT_HIP(ctx, hipMemsetAsync(tmp.p, 0, 2 * sizeof(double), ctx->stream));
     int64_t blocks = std::min<int64_t>(ceil_div64(total, 256), 4096);
     if (dtype == GT_F32)
         hipLaunchKernelGGL(max_abs_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (const float*)Xdev,
@@ -183,14 +187,26 @@ int gt_max_abs(gt_ctx* ctx, const void* Xdev, int64_t total, int dtype, double* 
     else
         hipLaunchKernelGGL(max_abs_kernel<double>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (const double*)Xdev,
                            total, (unsigned long long*)tmp.p);
+    unsigned long long host[2] = {0ull, 0ull};
     hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipMemcpyAsync(out_host, tmp.p, sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(host, tmp.p, sizeof(host), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) {
         ctx->set_error(std::string("max_abs: ") + hipGetErrorString(e));
         return GT_E_HIP;
     }
+    std::memcpy(out_host, &host[0], sizeof(double));
+    if (nonfinite) *nonfinite = uint32_t(host[1] & 1ull) | (std::isinf(*out_host) ? 2u : 0u);
     return GT_OK;
+}
+
+int gt_fail_nonfinite(gt_ctx* ctx, uint32_t flags, int dtype) {
+    if (flags & 1u)
+        ctx->set_error("Input X contains NaN.");
+    else
+        ctx->set_error(std::string("Input X contains infinity or a value too large for dtype('") +
+                       (dtype == GT_F32 ? "float32" : "float64") + "').");
+    return GT_E_NONFINITE;
 }
 
 // power-of-two scale that puts max|x| * sc into [2^13, 2^14): float16 hi parts stay far from overflow
@@ -279,7 +295,8 @@ int gt_select_columns(gt_ctx* ctx, int want) {
 int gt_prep_points(gt_ctx* ctx) {
     ctx->sc = 1.0;
     if (ctx->prec == 1) {
-        GT_TRY(gt_max_abs(ctx, ctx->X, ctx->n * int64_t(ctx->d), ctx->dtype, &ctx->maxabs));
+        // euclidean: gt_set_points has just measured max|x| together with its finiteness check
+        if (ctx->metric == 1) GT_TRY(gt_max_abs(ctx, ctx->X, ctx->n * int64_t(ctx->d), ctx->dtype, &ctx->maxabs, nullptr));
         ctx->sc = gt_f16_scale(ctx->maxabs);
     }
     StageSpan span(ctx, "prep", 2);

@@ -10,6 +10,7 @@
 #include <cfloat>
 
 #include "gt_common.h"
+#include "gt_hostcopy.h"
 #include "gt_device.h"
 #include "gt_knn.h"
 #include "gt_knn_select.h"
@@ -1233,8 +1234,15 @@ extern "C" int gt_graph_fetch_csr(gt_ctx* ctx, int32_t which, double* data, int3
     GT_HIP(ctx, hipSetDevice(ctx->device));
     GraphState* g = ctx->graph;
     if (!g || !g->finished) GT_FAIL(ctx, GT_E_STATE, "gt_graph_fetch_csr: no finished graph");
-    const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
     const double* src = which == GT_CSR_P ? g->Pdata.as<double>() : g->Kdata.as<double>();
+    if (!on_device) {
+        // caller's numpy arrays: pipelined through pinned slots (gt_hostcopy.cpp)
+        if (data) GT_TRY(gt_copy_to_host(ctx, data, src, size_t(g->nnz) * sizeof(double)));
+        if (indices) GT_TRY(gt_copy_to_host(ctx, indices, g->indices.p, size_t(g->nnz) * sizeof(int32_t)));
+        if (indptr) GT_TRY(gt_copy_to_host(ctx, indptr, g->indptr.p, size_t(g->nloc + 1) * sizeof(int64_t)));
+        return GT_OK;
+    }
+    const hipMemcpyKind kind = hipMemcpyDeviceToDevice;
     if (data && g->nnz > 0) GT_HIP(ctx, hipMemcpyAsync(data, src, size_t(g->nnz) * sizeof(double), kind, ctx->stream));
     if (indices && g->nnz > 0)
         GT_HIP(ctx, hipMemcpyAsync(indices, g->indices.p, size_t(g->nnz) * sizeof(int32_t), kind, ctx->stream));

@@ -18,17 +18,6 @@ from . import _hip
 from .base import BaseGraph, Data
 
 
-def _assert_all_finite(X):
-    """The reference's kNN front end rejects non-finite input (sklearn check_array inside NearestNeighbors.fit,
-    graphs.py:763-768); same errors here, with sklearn's one-pass sum test first."""
-    if np.isfinite(np.sum(X, dtype=np.float64)):
-        return
-    if np.isnan(X).any():
-        raise ValueError("Input X contains NaN.")
-    if np.isinf(X).any():
-        raise ValueError("Input X contains infinity or a value too large for dtype('{}').".format(X.dtype))
-
-
 class DataGraph(Data, BaseGraph):
     """Graphs built from a data matrix (reference: graphtools/base.py:1046-1254)."""
 
@@ -180,7 +169,8 @@ class kNNGraph(DataGraph):
         X = np.ascontiguousarray(self.data_nu)
         if X.dtype not in (np.float32, np.float64):
             X = X.astype(np.float64)
-        _assert_all_finite(X)
+        # non-finite input: gt_set_points reports it with sklearn's messages (ValueError, as NearestNeighbors.fit in
+        # the reference, graphs.py:763-768)
         self.hip.set_option("metric", self.distance)
         self.hip.set_points(X)
         self._points_bound = True
@@ -270,7 +260,7 @@ class kNNGraph(DataGraph):
 
     def _fetch_diff_op(self):
         self._ensure_device_graph()
-        data, _, _ = self.hip.graph_fetch_csr(_hip.CSR_P)
+        data, _, _ = self.hip.graph_fetch_csr(_hip.CSR_P, structure=False)
         K = self._kernel
         return sparse.csr_matrix((data, K.indices, K.indptr), shape=K.shape)
 
@@ -685,7 +675,7 @@ class MNNGraph(DataGraph):
         return sparse.csr_matrix((data, indices, indptr), shape=(n, n))
 
     def _fetch_diff_op(self):
-        data, _, _ = self.hip.graph_fetch_csr(_hip.CSR_P)
+        data, _, _ = self.hip.graph_fetch_csr(_hip.CSR_P, structure=False)
         K = self._kernel
         return sparse.csr_matrix((data, K.indices, K.indptr), shape=K.shape)
 

@@ -39,6 +39,8 @@ extern "C" {
 #define GT_E_ALLOC (-3)   /* device allocation failed */
 #define GT_E_STATE (-4)   /* call sequence error */
 #define GT_E_LIMIT (-5)   /* size outside what the HIP path supports */
+#define GT_E_NONFINITE (-6) /* gt_set_points: the data contain NaN or infinity; gt_last_error carries the message of
+                             * sklearn's check_array (raised by NearestNeighbors.fit in the reference, graphs.py:763-768) */
 
 /* dtypes */
 #define GT_F32 0

@@ -356,5 +356,16 @@ def test_non_finite_input_is_rejected_like_sklearn():
         graphtools_amd.Graph(Xn, knn=5, decay=10, verbose=0)
     Xi = X.copy()
     Xi[9, 1] = np.inf
-    with pytest.raises(ValueError, match="contains infinity"):
+    with pytest.raises(ValueError, match=r"contains infinity or a value too large for dtype\('float32'\)"):
         graphtools_amd.Graph(Xi, knn=5, decay=10, verbose=0)
+    with pytest.raises(ValueError, match=r"dtype\('float64'\)"):
+        graphtools_amd.Graph(Xi.astype(np.float64), knn=5, decay=10, verbose=0)
+    # NaN wins over infinity, as in check_array; query matrices are checked too (kneighbors in the reference)
+    Xb = Xi.copy()
+    Xb[400, 0] = np.nan
+    with pytest.raises(ValueError, match="contains NaN"):
+        graphtools_amd.Graph(Xb, knn=5, decay=10, verbose=0)
+    G = graphtools_amd.Graph(X, knn=5, decay=10, verbose=0)
+    with pytest.raises(ValueError, match="contains NaN"):
+        G.build_kernel_to_data(Xn[:20])
+    assert G.build_kernel_to_data(X[:20]).shape == (20, 500)   # the context is still usable afterwards
