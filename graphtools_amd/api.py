@@ -74,8 +74,6 @@ def Graph(
                 "MNNGraph does not support precomputed values. Use `graphtype='exact'` and `sample_idx=None` or "
                 "`precomputed=None`"
             )
-        if n_landmark is not None:
-            raise NotImplementedError("graphtools_amd: MNNLandmarkGraph is not on the HIP path")
         base = "MNN"
     elif graphtype == "exact":
         if sample_idx is not None:

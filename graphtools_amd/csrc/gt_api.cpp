@@ -211,6 +211,14 @@ int gt_set_option(gt_ctx* ctx, const char* name, const char* value) {
         ctx->samp_end = std::atoi(value);
         return GT_OK;
     }
+    if (k == "select_samp2_level") {
+        ctx->samp2_level = std::atoi(value);
+        return GT_OK;
+    }
+    if (k == "select_samp2_keep") {
+        ctx->samp2_keep = std::atoi(value);
+        return GT_OK;
+    }
     if (k == "select_samp_keep") {
         ctx->samp_keep = std::atoi(value);
         return GT_OK;

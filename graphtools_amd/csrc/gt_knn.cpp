@@ -125,9 +125,18 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
         int keep = std::max(ctx->samp_keep > 0 ? ctx->samp_keep : 16, need_m);
         keep += keep & 1;
         const int64_t ntiles = ctx->n_pad / (ctx->DP <= 64 ? 128 : 64);   // tiles of the candidate kernels
-        if (ctx->samp_stride > 1 && keep <= mkeep / 2 && ntiles >= int64_t(8) * ctx->samp_stride) {
-            sa.samp_stride = ctx->samp_stride;
+        int stride = 1, levels = 0;   // largest power of two <= the option
+        while (stride * 2 <= ctx->samp_stride) stride *= 2, ++levels;
+        if (stride > 1 && keep <= mkeep / 2 && ntiles >= int64_t(8) * stride) {
+            sa.samp_stride = stride;
             sa.samp_keep = keep;
+            // second cut once 2^samp2_level / stride of the tiles are seen
+            int keep2 = std::max(ctx->samp2_keep, 3 * keep);
+            keep2 += keep2 & 1;
+            if (ctx->samp2_level > 0 && ctx->samp2_level < levels && keep2 <= mkeep / 2) {
+                sa.samp2_level = ctx->samp2_level;
+                sa.samp2_keep = keep2;
+            }
             int end = ctx->samp_end < 0 ? keep : std::max(ctx->samp_end > 0 ? ctx->samp_end : 0, ctx->samp_end > 0 ? need_m : 0);
             end += end & 1;
             sa.samp_end = end <= mkeep / 2 ? end : 0;

@@ -20,9 +20,11 @@ struct SelectArgs {
     float* thr_out = nullptr;       // selection mode: final admission threshold per query [nq_pad]
     int32_t cap = 0;                // radius mode: list capacity per query
     unsigned long long* prof = nullptr;   // optional per-wave cycle counters [nblocks*4][8] (development)
-    int32_t samp_stride = 0;        // selection: > 1 = visit every samp_stride-th tile first with a keep-samp_keep budget
+    int32_t samp_stride = 0;        // selection: > 1 (power of two) = visit every samp_stride-th tile first with a keep-samp_keep budget
     int32_t samp_keep = 0;          //   (must be >= the number of neighbours wanted, even, <= 8*nt)
     int32_t samp_end = 0;           //   > 0: after the last sampled tile every list is cut to its samp_end best
+    int32_t samp2_level = 0;        //   > 0: second cut, to the samp2_keep best, once 2^samp2_level / samp_stride of the tiles are seen
+    int32_t samp2_keep = 0;
     int32_t narrow = 0;             // selection, prec 2, dp <= 64: 128-row workgroups (launches with few query rows)
     int32_t final_keep = 0;         // selection: entries kept per query at the end (0: M' = 16*nt; at most 64*nt)
     int32_t dbg = 0;                // experiment switches (bit 0: no survivors, bit 1: no compaction sort)

@@ -257,9 +257,11 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
     const int32_t* __restrict__ qrows, const int64_t q0, const int32_t nq, const int32_t ntiles,
     uint64_t* __restrict__ lists, uint32_t* __restrict__ counts, const float* __restrict__ thr_in,
     float* __restrict__ thr_out, const int32_t cap, const int32_t dbg, unsigned long long* __restrict__ prof,
-    const int32_t samp_stride, const int32_t samp_keep, const int32_t samp_end, const int32_t final_keep) {
+    const int32_t samp_stride, const int32_t samp_keep, const int32_t samp_end, const int32_t samp2_level,
+    const int32_t samp2_keep, const int32_t final_keep) {
     using C = SelCfg<DP, PREC>;
-    unsigned long long t_adm = 0, t_cmp = 0, t_bar = 0, n_cmp = 0, n_adm = 0;
+    unsigned long long t_adm = 0, t_cmp = 0, t_bar = 0, n_cmp = 0, n_adm = 0, t_lvl0 = 0, n_adm_lvl0 = 0;
+    const unsigned long long t_start = prof ? __builtin_readcyclecounter() : 0ull;
     constexpr int QT = C::QT, BQ = C::BQ, BN = C::BN, LDP = C::LDP;
     constexpr int LCAP = 64 * NT;        // list capacity in selection mode (two halves of HALF slots)
     constexpr int HALF = 32 * NT;
@@ -356,16 +358,16 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
                                              (lds_void*)(hn + (BUF_) * BN + wu * 64), 4, 0, 0);            \
     }
 
-    // Tile order (MODE 0 with samp_stride > 1): phase A visits every samp_stride-th tile with a small list
-    // budget (keep the samp_keep best), which gives every query a tight admission threshold after 1/samp_stride
-    // of the stream; phase B streams the remaining tiles with the normal budget.  Any order and any
-    // keep >= the number of neighbours wanted is correct - thresholds only ever rise, and every entry dropped
-    // or rejected scored <= the final threshold - the split only cuts the number of admissions (~3x).
+    // Tile order (MODE 0 with samp_stride = S > 1, a power of two): level 0 visits the tiles 0, S, 2S, ... with a small
+    // list budget (keep the samp_keep best), which gives every query a tight admission threshold after 1/S of the
+    // stream; level l >= 1 visits the odd multiples of S >> l, so that the tiles seen at the end of any level are an
+    // evenly strided sample of the database whatever order its rows are stored in.  At the end of level samp2_level
+    // (2^samp2_level / S of the stream seen) every list is cut once more, to its samp2_keep best.  Any order and
+    // any budget is correct - thresholds only ever rise, and every entry dropped or rejected scored <= the final
+    // threshold, which the float64 stage turns into a distance bound per row - the levels only cut the number of
+    // admissions.
     const int n_a = (MODE == 0 && samp_stride > 1) ? (ntiles + samp_stride - 1) / samp_stride : 0;
-    // running tile index (no divisions in the loop): phase A steps by samp_stride, phase B by one and hops over the
-    // multiples of samp_stride (t_mod tracks t mod samp_stride there)
-    int t = t_begin, t_mod = 0;
-
+    int t = t_begin, t_step = n_a ? samp_stride : 1, level = 0;
     if constexpr (C::GLDS) {
         GT_GLDS_ISSUE(t, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -380,18 +382,12 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
 
     for (int it = t_begin; it < t_end; ++it) {
         const int buf = (GT_SEL_EXP & (4 | 32)) ? 0 : ((it - t_begin) & 1);
-        int t_next, t_mod_next = t_mod;
-        if (it + 1 < n_a) {
-            t_next = t + samp_stride;
-        } else if (n_a && it + 1 == n_a) {
-            t_next = 1;                      // first tile that is not a multiple of samp_stride
-            t_mod_next = 1;
-        } else {
-            t_next = t + 1;
-            if (n_a && ++t_mod_next == samp_stride) {
-                t_next += 1;
-                t_mod_next = 1;
-            }
+        int t_next = t + t_step, level_next = level, t_step_next = t_step;
+        const bool level_end = n_a && t_next >= ntiles;
+        if (level_end) {   // next level: the odd multiples of samp_stride >> level_next
+            level_next = level + 1;
+            t_step_next = samp_stride >> level;
+            t_next = samp_stride >> level_next;
         }
         if (!(GT_SEL_EXP & (4 | 32)) && it + 1 < t_end) {
             if constexpr (C::GLDS) {
@@ -509,9 +505,11 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
         }
         if (MODE == 0) {
             // ---- list maintenance: lane (li, h) owns half h of query (qt, li) ----
-            const bool phase_a = it < n_a;
-            const bool end_a = samp_end > 0 && it + 1 == n_a;   // last sampled tile: settle the seed threshold
-            const uint32_t mkeep = end_a ? uint32_t(samp_end) : phase_a ? uint32_t(samp_keep) : uint32_t(MKEEP);
+            const bool phase_a = n_a && level == 0;
+            // forced cuts: after the last tile of level 0 (settles the seed threshold) and of level samp2_level
+            const bool end_a = level_end && ((level == 0 && samp_end > 0) || (level > 0 && level == samp2_level));
+            const uint32_t mkeep = end_a ? uint32_t(level == 0 ? samp_end : samp2_keep)
+                                         : phase_a ? uint32_t(samp_keep) : uint32_t(MKEEP);
             const uint32_t trig = phase_a ? uint32_t(samp_keep) / 2u + 24u : uint32_t(TRIGH);
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt) {
@@ -556,12 +554,18 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
             __syncthreads();
             if (prof) t_bar += __builtin_readcyclecounter() - ts_;
         }
+        if (prof && level_end && level == 0) {
+            t_lvl0 = __builtin_readcyclecounter() - t_start;
+            n_adm_lvl0 = n_adm;
+        }
         t = t_next;
-        t_mod = t_mod_next;
+        t_step = t_step_next;
+        level = level_next;
     }
     if (prof && lane == 0) {
         unsigned long long* o = prof + (size_t(blockIdx.x) * 4 + w) * 8;
         o[0] = t_adm; o[1] = t_cmp; o[2] = t_bar; o[3] = n_cmp; o[4] = n_adm;
+        o[5] = t_lvl0; o[6] = n_adm_lvl0; o[7] = __builtin_readcyclecounter() - t_start;
     }
 
     // ---- finalisation: gather every list into slots [0, count), publish count and the last admission threshold ----
@@ -611,7 +615,7 @@ int launch_one(gt_ctx* ctx, const SelectArgs& a) {
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)nblocks, (unsigned)nsplit), dim3(256), lds_bytes, ctx->stream, a.Yp,
                        a.hneg, a.Qp, a.qrows, a.q0, a.nq, ntiles, a.lists, a.counts, a.thr_in, a.thr_out, a.cap, a.dbg, a.prof,
-                       a.samp_stride, a.samp_keep, a.samp_end,
+                       a.samp_stride, a.samp_keep, a.samp_end, a.samp2_level, a.samp2_keep,
                        (a.final_keep > 0 && a.final_keep <= 64 * NT) ? a.final_keep : 16 * NT);
     GT_HIP(ctx, hipGetLastError());
     return GT_OK;

@@ -664,9 +664,26 @@ class MNNGraph(DataGraph):
         K = sparse.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(n, n))
         return K
 
+    def _device_build_from_k0(self):
+        nnz, flags = self.hip.csr_graph_build(self._kernel0, self.kernel_symm, self.theta, self.anisotropy)
+        self._device_state = (self.kernel_symm, self.theta, self.anisotropy)
+        return nnz, flags
+
+    def _ensure_device_graph(self):
+        """(Re)build K and P on the device from the assembled kernel if the context lost or changed them."""
+        if getattr(self, "_device_state", None) != (self.kernel_symm, self.theta, self.anisotropy):
+            if not hasattr(self, "_kernel0"):
+                self._kernel0 = self.build_kernel()
+            self._device_build_from_k0()
+
+    def _bind_points(self):
+        # binding the points (random landmark assignment) reuses this context's workspace
+        self._device_state = None
+        kNNGraph._bind_points(self)
+
     def _build_kernel(self):
-        K0 = self.build_kernel()
-        nnz, flags = self.hip.csr_graph_build(K0, self.kernel_symm, self.theta, self.anisotropy)
+        K0 = self._kernel0 = self.build_kernel()
+        nnz, flags = self._device_build_from_k0()
         data, indices, indptr = self.hip.graph_fetch_csr(_hip.CSR_K)
         n = K0.shape[0]
         if nnz < 2**31:
@@ -675,11 +692,13 @@ class MNNGraph(DataGraph):
         return sparse.csr_matrix((data, indices, indptr), shape=(n, n))
 
     def _fetch_diff_op(self):
+        self._ensure_device_graph()
         data, _, _ = self.hip.graph_fetch_csr(_hip.CSR_P, structure=False)
         K = self._kernel
         return sparse.csr_matrix((data, K.indices, K.indptr), shape=K.shape)
 
     def _fetch_degree(self):
+        self._ensure_device_graph()
         return self.hip.graph_fetch_vec(_hip.VEC_DEGREE)
 
     def build_kernel_to_data(self, Y, theta=None):
@@ -688,6 +707,11 @@ class MNNGraph(DataGraph):
 
 
 class kNNLandmarkGraph(kNNGraph, LandmarkGraph):
+    pass
+
+
+class MNNLandmarkGraph(MNNGraph, LandmarkGraph):
+    """reference: graphs.py:1973-1974 - the landmark algebra on the batch-corrected kernel"""
     pass
 
 

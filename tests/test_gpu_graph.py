@@ -276,6 +276,23 @@ def test_mnn_graph_matches_reference(name):
     np.testing.assert_allclose(np.asarray(G.P.sum(axis=1)).ravel(), 1.0, rtol=0, atol=1e-12)
 
 
+def test_mnn_landmark_graph_matches_reference():
+    """MNNLandmarkGraph: the landmark algebra on the batch-corrected kernel (reference graphs.py:1973-1974)"""
+    z = load_golden("g9d_mnn_landmark")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        G = graphtools_amd.Graph(z["X"], sample_idx=z["sample_idx"], n_pca=None, verbose=0,
+                                 n_landmark=int(z["n_landmark"]), random_landmarking=True,
+                                 random_state=int(z["random_state"]), **mnn_params(z))
+        assert type(G).__name__ == "MNNLandmarkGraph"
+        assert np.array_equal(G.clusters, z["clusters"])
+        np.testing.assert_allclose(G.landmark_op, z["landmark_op"], rtol=1e-9, atol=1e-15)
+        assert abs(sparse.csr_matrix(G.transitions) - golden_csr(z, "transitions")).max() < 1e-12
+        # the device graph is rebuilt from the assembled kernel when asked for after the landmark step
+        np.testing.assert_allclose(np.asarray(G.P.sum(axis=1)).ravel(), 1.0, rtol=0, atol=1e-12)
+        assert G.landmark_op.shape == (len(np.unique(z["clusters"])),) * 2
+
+
 @pytest.mark.parametrize("symm,theta,aniso", [("+", None, 0.0), ("*", None, 0.0), ("mnn", 0.25, 0.0), ("+", None, 1.0),
                                               (None, None, 0.0)])
 def test_csr_graph_build_vs_oracle(symm, theta, aniso):

@@ -80,11 +80,12 @@ def test_get_set_params_guards():
     assert (g.n_jobs, g.random_state, g.verbose) == (4, 13, 2)
 
 
-def test_pygsp_and_mnn_landmarks_are_out_of_scope():
+def test_pygsp_is_out_of_scope_and_mnn_landmark_selection():
     with pytest.raises(NotImplementedError):
         graphtools_amd.Graph(X, use_pygsp=True, initialize=False)
-    with pytest.raises(NotImplementedError):
-        graphtools_amd.Graph(X, sample_idx=np.arange(60) % 2, n_landmark=10, initialize=False)
+    g = graphtools_amd.Graph(X, sample_idx=np.arange(60) % 2, n_landmark=10, initialize=False)
+    assert type(g).__name__ == "MNNLandmarkGraph" and g.n_landmark == 10 and not hasattr(g, "_kernel")
+    assert [c.__name__ for c in type(g).__mro__[:3]] == ["MNNLandmarkGraph", "MNNGraph", "LandmarkGraph"]
 
 
 def test_mnn_graph_selection_and_validation():

@@ -156,3 +156,14 @@ def test_mnn_graph_matches_reference(name):
     assert (K0 != golden_csr(z, "K0")).nnz == 0
     assert (K != golden_csr(z, "K")).nnz == 0
     np.testing.assert_allclose(P.data, z["P_data"], rtol=0, atol=1e-15)
+
+
+def test_mnn_landmark_graph_matches_reference():
+    """MNNLandmarkGraph (graphs.py:1973-1974): random landmark clusters, landmark operator and transitions."""
+    z = load_golden("g9d_mnn_landmark")
+    _, K, _ = oracle.mnn_graph(z["X"], z["sample_idx"], **mnn_params(z))
+    clusters, _ = oracle.random_landmark_clusters(z["X"], int(z["n_landmark"]), int(z["random_state"]))
+    assert np.array_equal(clusters, z["clusters"])
+    op, tr = oracle.landmark_operator(K, clusters)
+    np.testing.assert_allclose(op, z["landmark_op"], rtol=0, atol=1e-15)
+    assert abs(sparse.csr_matrix(tr) - golden_csr(z, "transitions")).max() < 1e-15

@@ -1,6 +1,8 @@
 #!/usr/bin/env python
 """Development probe: effect of the threshold-seeding phase (select_samp_stride / select_samp_keep) on the
-candidate pass at benchmark size.  usage: gpu_samp_ablate.py N "stride:keep,stride:keep,..." [dbg]"""
+candidate pass at benchmark size.  usage: gpu_samp_ablate.py N "stride:keep[:end[:level2:keep2]],..." [dbg]
+GT_SORTED=1: rows ordered by mixture component (every neighbourhood contiguous in memory - the adversarial order for
+prefix-based thresholds)."""
 import json
 import os
 import sys
@@ -18,14 +20,24 @@ if __name__ == "__main__":
     dbg = int(sys.argv[3]) if len(sys.argv) > 3 else 0
     d = 64
     X = make_mix(n, d, 1)
+    if os.environ.get("GT_SORTED"):
+        rng = np.random.default_rng(1)
+        c = max(n // 2000, 1)
+        rng.uniform(-10, 10, (c, d))
+        labels = rng.integers(c, size=n)   # the label stream of make_mix(n, d, 1)
+        X = np.ascontiguousarray(X[np.argsort(labels, kind="stable")])
     out = []
     for combo in combos:
         stride, keep = combo[0], combo[1]
-        end = combo[2] if len(combo) > 2 else 0
+        end = combo[2] if len(combo) > 2 else -1
+        level2 = combo[3] if len(combo) > 3 else 0
+        keep2 = combo[4] if len(combo) > 4 else 40
         ctx = _hip.Context(0)
         ctx.set_option("select_samp_stride", str(stride))
         ctx.set_option("select_samp_keep", str(keep))
         ctx.set_option("select_samp_end", str(end))
+        ctx.set_option("select_samp2_level", str(level2))
+        ctx.set_option("select_samp2_keep", str(keep2))
         if os.environ.get("GT_PREC"):
             ctx.set_option("knn_precision", os.environ["GT_PREC"])
         if dbg:
@@ -38,7 +50,7 @@ if __name__ == "__main__":
             st = {s: round(ctx.stage_ms(s), 3) for s in ("knn_select", "rerank", "fallback", "radius", "affinity", "symmetrize", "normalize")}
             if best is None or st["knn_select"] < best["knn_select"]:
                 best = st
-        rec = {"n": n, "stride": stride, "keep": keep, "end": end, "nnz": nnz, "flags": fl, "stage_ms": best, "stats": ctx.graph_stats(), "main": ctx.last_knn_precision()}
+        rec = {"n": n, "stride": stride, "keep": keep, "end": end, "level2": level2, "keep2": keep2, "nnz": nnz, "flags": fl, "stage_ms": best, "stats": ctx.graph_stats(), "main": ctx.last_knn_precision()}
         print(json.dumps(rec), flush=True)
         out.append(rec)
         ctx.close()

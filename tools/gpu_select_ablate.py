@@ -19,10 +19,14 @@ for prec, dbg in [(p_, d_) for p_ in precs for d_ in dbgs]:
     ctx.set_option("knn_precision", prec)
     ctx.set_option("dbg_select", dbg)
     if os.environ.get("GT_SAMP"):   # "stride:keep"
-        st_, kp_, en_ = (os.environ["GT_SAMP"].split(":") + ["0"])[:3]
+        st_, kp_, en_ = (os.environ["GT_SAMP"].split(":") + ["-1"])[:3]
         ctx.set_option("select_samp_end", en_)
         ctx.set_option("select_samp_stride", st_)
         ctx.set_option("select_samp_keep", kp_)
+    if os.environ.get("GT_SAMP2"):  # "level:keep"
+        lv_, k2_ = os.environ["GT_SAMP2"].split(":")
+        ctx.set_option("select_samp2_level", lv_)
+        ctx.set_option("select_samp2_keep", k2_)
     ctx.set_points(X)
     best = 1e9
     for rep in range(3):
@@ -43,5 +47,7 @@ for prec, dbg in [(p_, d_) for p_ in precs for d_ in dbgs]:
         m = buf.mean(axis=0)
         print(json.dumps({"rc": rc, "mean_cycles_per_wave": {"admission": float(m[0]), "compaction": float(m[1]), "barrier": float(m[2])},
                           "n_compactions_per_wave": float(m[3]), "n_admission_entries_per_wave": float(m[4]),
-                          "max_barrier": float(buf[:, 2].max()), "kernel_ms": best}))
+                          "max_barrier": float(buf[:, 2].max()), "kernel_ms": best,
+                          "level0_cycles_per_wave": float(m[5]), "level0_admission_entries": float(m[6]),
+                          "total_cycles_per_wave": float(m[7])}))
     ctx.close()

@@ -64,6 +64,34 @@ def main():
         same = np.array_equal(OK.indices, csr_sorted(K).indices) and np.array_equal(OK.indptr, K.indptr)
         print("%-24s %6.2f MB  oracle: |dK0| %.2e |dK| %.2e |dP| %.2e structure %s" % (
             name, os.path.getsize(path) / 1e6, d0, dK, dP, same))
+    landmark_case(gt, oracle, X, idx)
+
+
+def landmark_case(gt, oracle, X, idx):
+    """MNNLandmarkGraph (graphs.py:1973-1974), random landmarking: clusters, landmark operator, transitions."""
+    kw = dict(knn=5, decay=20, thresh=1e-4, beta=1, kernel_symm="+", theta=None, anisotropy=0)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        G = gt.Graph(X, sample_idx=idx, n_pca=None, verbose=0, n_landmark=60, random_landmarking=True, random_state=42,
+                     **kw)
+        assert type(G).__name__ == "MNNLandmarkGraph"
+        op = np.asarray(G.landmark_op)
+        T = sparse.csr_matrix(G.transitions)
+        clusters = np.asarray(G.clusters)
+    out = {"X": X, "sample_idx": idx, "n_landmark": np.array(60), "random_state": np.array(42), "clusters": clusters,
+           "landmark_op": op}
+    for k, v in kw.items():
+        out["param_" + k] = np.array(np.nan if v is None else v)
+    T.sort_indices()
+    out.update(csr_parts("transitions", T))
+    path = os.path.join(OUT, "g9d_mnn_landmark.npz")
+    np.savez_compressed(path, **out)
+    _, OK, _ = oracle.mnn_graph(X, idx, engine="sklearn", **kw)
+    oc, _ = oracle.random_landmark_clusters(X, 60, 42)
+    oop, otr = oracle.landmark_operator(OK, oc)
+    print("%-24s %6.2f MB  oracle: clusters equal %s |dop| %.2e |dT| %.2e" % (
+        "g9d_mnn_landmark", os.path.getsize(path) / 1e6, np.array_equal(oc, clusters), abs(oop - op).max(),
+        abs(sparse.csr_matrix(otr) - T).max()))
 
 
 def csr_sorted(M):
