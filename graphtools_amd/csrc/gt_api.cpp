@@ -83,6 +83,7 @@ void gt_ctx_destroy(gt_ctx* ctx) {
     ctx->dense_degree.release();
     ctx->dense_bw.release();
     ctx->X_norm.release();
+    for (DevBuf* b : {&ctx->land_Y, &ctx->land_h, &ctx->order_cell, &ctx->order_rows, &ctx->order_tmp}) b->release();
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -209,6 +210,15 @@ int gt_set_option(gt_ctx* ctx, const char* name, const char* value) {
     }
     if (k == "select_samp_end") {
         ctx->samp_end = std::atoi(value);
+        return GT_OK;
+    }
+    if (k == "query_order") {
+        if (v == "auto" || v == "on" || v == "1")
+            ctx->query_order = 1;
+        else if (v == "off" || v == "0")
+            ctx->query_order = 0;
+        else
+            GT_FAIL(ctx, GT_E_ARG, "query_order must be 'auto' or 'off'");
         return GT_OK;
     }
     if (k == "select_samp2_level") {

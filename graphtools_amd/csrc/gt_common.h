@@ -124,6 +124,8 @@ struct gt_ctx {
     int32_t samp_stride = 16; // candidate pass: threshold-seeding phase over every samp_stride-th tile (<= 1: off)
     int32_t samp_keep = 0;    //   list budget of that phase (0: the number of neighbours wanted, at least 16)
     int32_t samp_end = -1;    //   list budget at the end of that phase (0: none, -1: same as samp_keep)
+    int32_t query_order = 1;  // candidate pass: deal the query rows to workgroups grouped by nearest landmark (gt_order.hip)
+    DevBuf land_Y, land_h, order_cell, order_rows, order_tmp;
     int32_t samp2_level = 2;  //   second cut of the lists once 2^samp2_level / samp_stride of the tiles are seen (0: none)
     int32_t samp2_keep = 48;  //   to this many entries (at least 3 * samp_keep)
     int32_t dbg_select = 0;   // experiment switches forwarded to the candidate kernel (results invalid when set)

@@ -21,6 +21,7 @@ struct KnnWork {
     DevBuf lists, counts, thr_final;
     DevBuf cand_d2, cand_j, cand_n, d2_lb;
     DevBuf unproven, qlomax_dev;
+    DevBuf qorder;             // self queries: the rows of the launch grouped by nearest landmark (gt_order.hip)
     DevBuf fb_rows, fb_count, fb_scratch, gflags, prof;
     DevBuf fb_qrows, fb_thr, fb_lists, fb_counts, fb_max;   // collected fallback
     int64_t n_fallback_exhaustive = 0;
@@ -123,6 +124,7 @@ struct RerankArgs {
     uint32_t* gflags;
     double radius_key_factor = 1.0;   // see gt_knn_candidates
     uint32_t* unproven = nullptr;     // optional counter: rows with key(need_m-th) * radius_key_factor >= bound
+    const int32_t* qrows = nullptr;   // list i of the candidate pass belongs to row qrows[i] (else q0 + i)
 };
 int gt_launch_rerank(gt_ctx* ctx, const RerankArgs& a);
 int gt_launch_fallback(gt_ctx* ctx, const RerankArgs& a, int64_t n_rows, int64_t row_off, double* scratch);

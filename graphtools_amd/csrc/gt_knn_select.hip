@@ -592,6 +592,52 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
     }
 }
 
+// ---- query ordering: nearest of L landmark rows (single float16 chain, approximate by design) --------------------
+// The candidate pass is fastest when the 32 queries of a wave share their neighbourhood: a database row that beats
+// one query's threshold then beats many of them in the same unit, and the (wave-wide) admission path is entered
+// once instead of once per query.  gt_query_order (gt_order.hip) therefore processes the queries grouped by the
+// nearest of L sample rows.  This kernel finds that row: Yl = the L landmark rows of the compact hi-plane copy, hl
+// their score seeds; one query per lane exactly as in the candidate kernel, no LDS (the landmarks stay in L1/L2).
+template <int DP>
+__global__ __launch_bounds__(256) void assign_cells_kernel(const float* __restrict__ Yc, const float* __restrict__ Yl,
+                                                           const float* __restrict__ hl, const int64_t q0,
+                                                           const int32_t nq, const int32_t L,
+                                                           uint32_t* __restrict__ cell) {
+    constexpr int RW = DP / 2;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, li = lane & 31, h = lane >> 5;
+    const int64_t q = int64_t(blockIdx.x) * 128 + w * 32 + li;
+    const int64_t qc = q < nq ? q : int64_t(nq) - 1;
+    Frag<DP, 2> bq;
+    bq.load(Yc + (q0 + qc) * RW, h);
+    float best = -INFINITY;
+    uint32_t bidx = 0;
+#pragma unroll 2
+    for (int l0 = 0; l0 < L; l0 += 32) {
+        Frag<DP, 2> a;
+        a.load(Yl + size_t(l0 + li) * RW, h);
+        f32x16 acc;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 hv = *reinterpret_cast<const float4*>(hl + l0 + 8 * g + 4 * h);
+            acc[4 * g + 0] = hv.x;
+            acc[4 * g + 1] = hv.y;
+            acc[4 * g + 2] = hv.z;
+            acc[4 * g + 3] = hv.w;
+        }
+        mma_chain<DP>(a, bq, acc);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const bool better = acc[e] > best;
+            best = better ? acc[e] : best;
+            bidx = better ? uint32_t(l0 + 8 * (e >> 2) + 4 * h + (e & 3)) : bidx;
+        }
+    }
+    const float ob = __shfl_xor(best, 32);
+    const uint32_t oi = __shfl_xor(bidx, 32);
+    if (ob > best || (ob == best && oi < bidx)) bidx = oi;
+    if (h == 0 && q < nq) cell[q] = bidx;
+}
+
 template <int DP, int NT, int MODE, int PREC>
 int launch_one(gt_ctx* ctx, const SelectArgs& a) {
     using C = SelCfg<DP, PREC>;
@@ -640,6 +686,16 @@ int launch_dp(gt_ctx* ctx, const SelectArgs& a) {
 #endif
 #define GT_CAT3_(a, b, c, d) a##b##c##d
 #define GT_CAT3(a, b, c, d) GT_CAT3_(a, b, c, d)
+#if GT_SEL_PREC == 2 && !GT_SEL_QT1
+int GT_CAT3(gt_launch_assign_cells_p, GT_SEL_PREC, _dp, GT_SEL_DP)(gt_ctx* ctx, const float* Yc, const float* Yl,
+                                                                  const float* hl, int64_t q0, int32_t nq, int32_t L,
+                                                                  uint32_t* cell) {
+    hipLaunchKernelGGL(assign_cells_kernel<GT_SEL_DP>, dim3((unsigned)ceil_div64(nq, 128)), dim3(256), 0, ctx->stream, Yc,
+                       Yl, hl, q0, nq, L, cell);
+    GT_HIP(ctx, hipGetLastError());
+    return GT_OK;
+}
+#endif
 #if GT_SEL_QT1
 // narrow variant: one 32-row query tile per wave (128-row workgroups) - twice the workgroups for launches with few rows
 int GT_CAT3(gt_launch_select_narrow_p, GT_SEL_PREC, _dp, GT_SEL_DP)(gt_ctx* ctx, const SelectArgs& a) {

@@ -1,0 +1,71 @@
+// Query ordering for the candidate pass: the rows of a launch grouped by the nearest of L landmark rows.
+//
+// Measured at N = 1e6 (mix, d = 64): with the 32 queries of a wave drawn from one neighbourhood the candidate kernel
+// enters its admission path in 6 % of the units instead of 23 % (a database row that beats one query's threshold
+// beats most of them in the same unit), -11 % kernel time.  The database side keeps the caller's row order - the
+// entries of the candidate lists stay original row ids - only the order in which query rows are dealt to workgroups
+// changes; list i then belongs to row out_rows[i], which the re-rank maps back (RerankArgs::qrows).
+// Landmarks: L = n/512 (64 ... 4096) evenly strided rows.  Assignment: one float16 MFMA chain against the landmark
+// rows (assign_cells_kernel, gt_knn_select.hip) - approximate by design, any grouping is correct.  Grouping: a
+// stable radix sort of (cell, row) pairs (rocPRIM), so the order is deterministic.
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include "gt_common.h"
+#include "gt_knn_select.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void gather_landmarks_kernel(const uint32_t* __restrict__ Yc, const float* __restrict__ hneg,
+                                                               const int64_t step, const int L, const int rw,
+                                                               uint32_t* __restrict__ Yl, float* __restrict__ hl) {
+    const int64_t f = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (f >= int64_t(L) * rw) return;
+    const int64_t l = f / rw;
+    const int c = int(f % rw);
+    Yl[f] = Yc[l * step * rw + c];
+    if (c == 0) hl[l] = hneg[l * step];
+}
+
+__global__ __launch_bounds__(256) void iota_rows_kernel(const int64_t q0, const int64_t nq, int32_t* __restrict__ rows) {
+    const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i < nq) rows[i] = int32_t(q0 + i);
+}
+
+}  // namespace
+
+int gt_query_order(gt_ctx* ctx, int64_t q0, int64_t nq, int32_t* out_rows, int* active) {
+    *active = 0;
+    constexpr int64_t kMinRows = 32768;   // below this the whole launch is a few workgroup rounds
+    if (!ctx->query_order || ctx->prec != 1 || ctx->fast_mode == 0 || !ctx->Yc.p || nq < kMinRows || ctx->n < kMinRows)
+        return GT_OK;
+    const int rw = ctx->DP / 2;   // dwords per row of the compact copy
+    int L = int(std::min<int64_t>(4096, std::max<int64_t>(64, (ctx->n / 512) / 32 * 32)));
+    const int64_t step = ctx->n / L;
+    GT_HIP(ctx, ctx->land_Y.reserve(size_t(L) * rw * sizeof(uint32_t)));
+    GT_HIP(ctx, ctx->land_h.reserve(size_t(L) * sizeof(float)));
+    GT_HIP(ctx, ctx->order_cell.reserve(size_t(nq) * sizeof(uint32_t) * 2));
+    GT_HIP(ctx, ctx->order_rows.reserve(size_t(nq) * sizeof(int32_t)));
+    hipLaunchKernelGGL(gather_landmarks_kernel, dim3((unsigned)ceil_div64(int64_t(L) * rw, 256)), dim3(256), 0, ctx->stream,
+                       ctx->Yc.as<uint32_t>(), ctx->hneg.as<float>(), step, L, rw, ctx->land_Y.as<uint32_t>(),
+                       ctx->land_h.as<float>());
+    GT_HIP(ctx, hipGetLastError());
+    uint32_t* cell = ctx->order_cell.as<uint32_t>();
+    uint32_t* cell_sorted = cell + nq;
+    GT_TRY(gt_launch_assign_cells(ctx, ctx->DP, ctx->Yc.as<float>(), ctx->land_Y.as<float>(), ctx->land_h.as<float>(), q0,
+                                  int32_t(nq), L, cell));
+    hipLaunchKernelGGL(iota_rows_kernel, dim3((unsigned)ceil_div64(nq, 256)), dim3(256), 0, ctx->stream, q0, nq,
+                       ctx->order_rows.as<int32_t>());
+    GT_HIP(ctx, hipGetLastError());
+    int bits = 1;
+    while ((1 << bits) < L) ++bits;
+    size_t tmp_bytes = 0;
+    GT_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tmp_bytes, cell, cell_sorted, ctx->order_rows.as<int32_t>(), out_rows,
+                                          size_t(nq), 0u, unsigned(bits), ctx->stream));
+    GT_HIP(ctx, ctx->order_tmp.reserve(tmp_bytes));
+    GT_HIP(ctx, rocprim::radix_sort_pairs(ctx->order_tmp.p, tmp_bytes, cell, cell_sorted, ctx->order_rows.as<int32_t>(),
+                                          out_rows, size_t(nq), 0u, unsigned(bits), ctx->stream));
+    *active = 1;
+    return GT_OK;
+}

@@ -57,23 +57,25 @@ __global__ __launch_bounds__(256) void rerank_kernel(const T* __restrict__ X, co
                                                      uint32_t* __restrict__ cand_j, uint32_t* __restrict__ cand_n,
                                                      double* __restrict__ d2_lb, uint32_t* __restrict__ fb_count,
                                                      int32_t* __restrict__ fb_rows, uint32_t* __restrict__ gflags,
-                                                     const double radius_key_factor, uint32_t* __restrict__ unproven) {
+                                                     const double radius_key_factor, uint32_t* __restrict__ unproven,
+                                                     const int32_t* __restrict__ qrows) {
     constexpr int MP = NT2 * 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int lane = threadIdx.x & 63;
     const int w = threadIdx.x >> 6;
     double* xs = reinterpret_cast<double*>(smem_raw) + size_t(w) * d;
-    const int64_t q = int64_t(blockIdx.x) * 4 + w;
-    if (q >= nq) return;   // whole wave exits together (q is wave-uniform); no block-level sync below
+    const int64_t ql = int64_t(blockIdx.x) * 4 + w;   // list index: the order the candidate pass dealt the queries in
+    if (ql >= nq) return;   // whole wave exits together (ql is wave-uniform); no block-level sync below
+    const int64_t q = qrows ? int64_t(qrows[ql]) - q0 : ql;   // row of the tables (rows [q0, q0 + nq) in their own order)
 
     const T* xrow = Q + (q0 + q) * int64_t(d);
     for (int k = lane; k < d; k += 64) xs[k] = double(xrow[k]);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     const double qnq = qn[q0 + q];
-    const uint32_t cnt = counts[q];
+    const uint32_t cnt = counts[ql];
     const uint32_t n = cnt < uint32_t(MP) ? cnt : uint32_t(MP);
-    const uint64_t* lp = lists + size_t(q) * lstride;
+    const uint64_t* lp = lists + size_t(ql) * lstride;
 
     // completeness bound of the candidate pass: every row it rejected or dropped scored <= thr_final
     // qs, y2: the norms of what the candidate pass scored (a coordinate subset for wide data: its squared distance
@@ -88,7 +90,7 @@ __global__ __launch_bounds__(256) void rerank_kernel(const T* __restrict__ X, co
         return b - 1e-9 * (qs + y2);   // float64 rounding of the quantities above, with a wide margin
     };
     double lb = INFINITY;
-    const float thr_f = thr_final[q];
+    const float thr_f = thr_final[ql];
     if (thr_f > -INFINITY) lb = bound_of_score(thr_f);   // -inf: the candidate pass rejected nothing for this query
 
     uint64_t hi[NT2], lo[NT2];
@@ -436,17 +438,17 @@ int rerank_t(gt_ctx* ctx, const RerankArgs& a) {
         hipLaunchKernelGGL((rerank_kernel<T, 2>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, (const T*)a.X,
                            a.d, a.xn, (const T*)a.Q, a.qn, a.qn_sel, a.q0, a.nq, a.lists, a.lstride, a.counts, a.thr_final, a.ymax2,
                            a.err, a.metric, a.need_m, a.cand_d2, a.cand_j, a.cand_n, a.d2_lb, a.fb_count, a.fb_rows,
-                           a.gflags, a.radius_key_factor, a.unproven);
+                           a.gflags, a.radius_key_factor, a.unproven, a.qrows);
     } else if (a.MP == 256) {
         hipLaunchKernelGGL((rerank_kernel<T, 4>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, (const T*)a.X,
                            a.d, a.xn, (const T*)a.Q, a.qn, a.qn_sel, a.q0, a.nq, a.lists, a.lstride, a.counts, a.thr_final, a.ymax2,
                            a.err, a.metric, a.need_m, a.cand_d2, a.cand_j, a.cand_n, a.d2_lb, a.fb_count, a.fb_rows,
-                           a.gflags, a.radius_key_factor, a.unproven);
+                           a.gflags, a.radius_key_factor, a.unproven, a.qrows);
     } else if (a.MP == 512) {
         hipLaunchKernelGGL((rerank_kernel<T, 8>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, (const T*)a.X,
                            a.d, a.xn, (const T*)a.Q, a.qn, a.qn_sel, a.q0, a.nq, a.lists, a.lstride, a.counts, a.thr_final, a.ymax2,
                            a.err, a.metric, a.need_m, a.cand_d2, a.cand_j, a.cand_n, a.d2_lb, a.fb_count, a.fb_rows,
-                           a.gflags, a.radius_key_factor, a.unproven);
+                           a.gflags, a.radius_key_factor, a.unproven, a.qrows);
     } else {
         GT_FAIL(ctx, GT_E_ARG, "rerank: unsupported table width");
     }

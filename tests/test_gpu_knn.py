@@ -265,3 +265,33 @@ def test_host_copies_round_trip(hip_ctx, nbytes):
         assert np.array_equal(out, src2)
     finally:
         hip_ctx.dev_free(p)
+
+
+def _hip_ctx_with(**options):
+    from graphtools_amd import _hip
+
+    ctx = _hip.Context(0)
+    for name, value in options.items():
+        ctx.set_option(name, value)
+    return ctx
+
+
+def test_query_order_does_not_change_results():
+    """Launches of >= 32768 rows deal the queries to workgroups grouped by nearest landmark (gt_order.hip); tables,
+    distances and graphs are those of the plain row order, and a row block of a larger point set (the multi-GPU
+    shard shape) maps back to the right rows."""
+    X = make_mix(40000, 24, 21)
+    res = {}
+    for mode in ("off", "auto"):
+        ctx = _hip_ctx_with(query_order=mode)
+        ctx.set_points(X)
+        res[mode] = ctx.knn_search(20)
+        res[mode + "_block"] = ctx.knn_search(20, rows=(3000, 3000 + 33000))
+        ctx.close()
+    for key in ("", "_block"):
+        d0, i0, _ = res["off" + key]
+        d1, i1, _ = res["auto" + key]
+        assert np.array_equal(i0, i1) and np.array_equal(d0, d1)
+    d_or, i_or = oracle.kneighbors(X, X[3000:3256], 20)
+    assert np.array_equal(res["auto_block"][1][:256], i_or)
+    assert np.array_equal(res["auto"][1][3000:3256], i_or)

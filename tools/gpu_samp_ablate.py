@@ -20,7 +20,16 @@ if __name__ == "__main__":
     dbg = int(sys.argv[3]) if len(sys.argv) > 3 else 0
     d = 64
     X = make_mix(n, d, 1)
-    if os.environ.get("GT_SORTED"):
+    if os.environ.get("GT_SORTED", "").startswith("voronoi:"):
+        # rows ordered by the nearest of L strided sample rows (what a device-side pre-ordering could do)
+        L = int(os.environ["GT_SORTED"].split(":")[1])
+        lm = X[:: max(n // L, 1)][:L].astype(np.float32)
+        ln = (lm * lm).sum(1) * 0.5
+        cell = np.empty(n, dtype=np.int32)
+        for a in range(0, n, 65536):
+            cell[a:a + 65536] = np.argmax(X[a:a + 65536] @ lm.T - ln[None, :], axis=1)
+        X = np.ascontiguousarray(X[np.argsort(cell, kind="stable")])
+    elif os.environ.get("GT_SORTED"):
         rng = np.random.default_rng(1)
         c = max(n // 2000, 1)
         rng.uniform(-10, 10, (c, d))
