@@ -121,13 +121,14 @@ struct gt_ctx {
                          // both can stall for seconds in a process that also runs RCCL)
     int32_t metric = 0;  // 0 euclidean, 1 cosine (points are row-normalised copies; distance = 1 - x.y)
     DevBuf X_norm;       // cosine: normalised points in the input dtype
-    int32_t samp_stride = 16; // candidate pass: threshold-seeding phase over every samp_stride-th tile (<= 1: off)
+    int32_t samp_stride = 32; // candidate pass: threshold-seeding phase over every samp_stride-th tile (<= 1: off)
     int32_t samp_keep = 0;    //   list budget of that phase (0: the number of neighbours wanted, at least 16)
     int32_t samp_end = -1;    //   list budget at the end of that phase (0: none, -1: same as samp_keep)
     int32_t query_order = 1;  // candidate pass: deal the query rows to workgroups grouped by nearest landmark (gt_order.hip)
+    int32_t order_cell_rows = 512;   //   rows per landmark cell (L = n / order_cell_rows landmarks, 64 ... 4096)
     DevBuf land_Y, land_h, order_cell, order_rows, order_tmp;
-    int32_t samp2_level = 2;  //   second cut of the lists once 2^samp2_level / samp_stride of the tiles are seen (0: none)
-    int32_t samp2_keep = 48;  //   to this many entries (at least 3 * samp_keep)
+    int32_t samp2_level = 3;  //   second cut of the lists once 2^samp2_level / samp_stride of the tiles are seen (0: none)
+    int32_t samp2_keep = 64;  //   to this many entries (at least 3 * samp_keep)
     int32_t dbg_select = 0;   // experiment switches forwarded to the candidate kernel (results invalid when set)
     int64_t n_pad = 0;   // rows of the working copy (multiple of the db tile)
     DevBuf Yp;           // working copy: [n_pad] rows of 4*DP bytes (float32, or float16 hi plane | lo plane)

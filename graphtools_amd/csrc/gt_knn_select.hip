@@ -611,7 +611,6 @@ __global__ __launch_bounds__(256) void assign_cells_kernel(const float* __restri
     bq.load(Yc + (q0 + qc) * RW, h);
     float best = -INFINITY;
     uint32_t bidx = 0;
-#pragma unroll 2
     for (int l0 = 0; l0 < L; l0 += 32) {
         Frag<DP, 2> a;
         a.load(Yl + size_t(l0 + li) * RW, h);

@@ -41,7 +41,7 @@ int gt_query_order(gt_ctx* ctx, int64_t q0, int64_t nq, int32_t* out_rows, int* 
     if (!ctx->query_order || ctx->prec != 1 || ctx->fast_mode == 0 || !ctx->Yc.p || nq < kMinRows || ctx->n < kMinRows)
         return GT_OK;
     const int rw = ctx->DP / 2;   // dwords per row of the compact copy
-    int L = int(std::min<int64_t>(4096, std::max<int64_t>(64, (ctx->n / 512) / 32 * 32)));
+    int L = int(std::min<int64_t>(4096, std::max<int64_t>(64, (ctx->n / std::max(ctx->order_cell_rows, 32)) / 32 * 32)));
     const int64_t step = ctx->n / L;
     GT_HIP(ctx, ctx->land_Y.reserve(size_t(L) * rw * sizeof(uint32_t)));
     GT_HIP(ctx, ctx->land_h.reserve(size_t(L) * sizeof(float)));

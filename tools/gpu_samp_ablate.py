@@ -18,7 +18,7 @@ if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
     combos = [tuple(int(v) for v in c.split(":")) for c in (sys.argv[2] if len(sys.argv) > 2 else "0:0,16:16").split(",")]
     dbg = int(sys.argv[3]) if len(sys.argv) > 3 else 0
-    d = 64
+    d = int(os.environ.get("GT_DIM", "64"))
     X = make_mix(n, d, 1)
     if os.environ.get("GT_SORTED", "").startswith("voronoi:"):
         # rows ordered by the nearest of L strided sample rows (what a device-side pre-ordering could do)
@@ -47,6 +47,10 @@ if __name__ == "__main__":
         ctx.set_option("select_samp_end", str(end))
         ctx.set_option("select_samp2_level", str(level2))
         ctx.set_option("select_samp2_keep", str(keep2))
+        if os.environ.get("GT_CELL_ROWS"):
+            ctx.set_option("query_order_cell_rows", os.environ["GT_CELL_ROWS"])
+        if os.environ.get("GT_QORDER"):
+            ctx.set_option("query_order", os.environ["GT_QORDER"])
         if os.environ.get("GT_PREC"):
             ctx.set_option("knn_precision", os.environ["GT_PREC"])
         if dbg:
@@ -56,7 +60,7 @@ if __name__ == "__main__":
         best = None
         for r in range(2):
             nnz, fl = ctx.graph_build(p)
-            st = {s: round(ctx.stage_ms(s), 3) for s in ("knn_select", "rerank", "fallback", "radius", "affinity", "symmetrize", "normalize")}
+            st = {s: round(ctx.stage_ms(s), 3) for s in ("query_order", "knn_select", "rerank", "fallback", "radius", "affinity", "symmetrize", "normalize")}
             if best is None or st["knn_select"] < best["knn_select"]:
                 best = st
         rec = {"n": n, "stride": stride, "keep": keep, "end": end, "level2": level2, "keep2": keep2, "nnz": nnz, "flags": fl, "stage_ms": best, "stats": ctx.graph_stats(), "main": ctx.last_knn_precision()}
