@@ -129,6 +129,7 @@ struct gt_ctx {
     DevBuf land_Y, land_h, order_cell, order_rows, order_tmp;
     int32_t samp2_level = 3;  //   second cut of the lists once 2^samp2_level / samp_stride of the tiles are seen (0: none)
     int32_t samp2_keep = 64;  //   to this many entries (at least 3 * samp_keep)
+    int32_t narrow_mode = -1; // 128-row-workgroup candidate kernels: -1 auto (few query rows), 0 never, 1 whenever available
     int32_t dbg_select = 0;   // experiment switches forwarded to the candidate kernel (results invalid when set)
     int64_t n_pad = 0;   // rows of the working copy (multiple of the db tile)
     DevBuf Yp;           // working copy: [n_pad] rows of 4*DP bytes (float32, or float16 hi plane | lo plane)

@@ -23,6 +23,10 @@ for prec, dbg in [(p_, d_) for p_ in precs for d_ in dbgs]:
         ctx.set_option("select_samp_end", en_)
         ctx.set_option("select_samp_stride", st_)
         ctx.set_option("select_samp_keep", kp_)
+    if os.environ.get("GT_NARROW"):
+        ctx.set_option("select_narrow", os.environ["GT_NARROW"])
+    if os.environ.get("GT_QORDER"):
+        ctx.set_option("query_order", os.environ["GT_QORDER"])
     if os.environ.get("GT_SAMP2"):  # "level:keep"
         lv_, k2_ = os.environ["GT_SAMP2"].split(":")
         ctx.set_option("select_samp2_level", lv_)
