@@ -13,7 +13,7 @@ void gt_free_knn_work(gt_ctx* ctx) {
     KnnWork* k = ctx->knn;
     for (DevBuf* b : {&k->Qraw, &k->Qp, &k->Qc, &k->qn, &k->qn_sel, &k->lists, &k->counts, &k->thr_final, &k->cand_d2, &k->cand_j, &k->cand_n,
                       &k->d2_lb, &k->fb_rows, &k->fb_count, &k->fb_scratch, &k->gflags, &k->prof, &k->fb_qrows, &k->fb_thr, &k->fb_lists,
-                      &k->fb_counts, &k->fb_max, &k->unproven, &k->qorder, &k->qlomax_dev})
+                      &k->fb_counts, &k->fb_max, &k->unproven, &k->qorder, &k->qthr0, &k->qlomax_dev})
         b->release();
     delete k;
     ctx->knn = nullptr;
@@ -176,15 +176,18 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
     ra.gflags = k->gflags.as<uint32_t>();
     ra.radius_key_factor = radius_key_factor;
     ra.unproven = k->unproven.as<uint32_t>();
+    bool have_thr0 = false;
     if (!external) {
         // deal the query rows to workgroups grouped by nearest landmark (list i <-> row qorder[i]; gt_order.hip)
         int ordered = 0;
         GT_HIP(ctx, k->qorder.reserve(size_t(nq) * sizeof(int32_t)));
+        GT_HIP(ctx, k->qthr0.reserve(size_t(nq) * sizeof(float)));
         {
             StageSpan span(ctx, "query_order");
-            GT_TRY(gt_query_order(ctx, q0, nq, k->qorder.as<int32_t>(), &ordered));
+            GT_TRY(gt_query_order(ctx, q0, nq, k->qorder.as<int32_t>(), k->qthr0.as<float>(), &ordered));
         }
         if (ordered) sa.qrows = ra.qrows = k->qorder.as<int32_t>();
+        have_thr0 = ordered != 0 && need_m <= 16 && ctx->thr0_mode != 0;
     }
     uint32_t n_fb = 0;
     for (;;) {
@@ -199,6 +202,8 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
         sa.Qp = main_prec == 2 ? (external ? k->Qc.as<float>() : ctx->Yc.as<float>())
                                : (external ? k->Qp.as<float>() : ctx->Yp.as<float>());
         ra.err = gt_err_model(ctx, main_prec);
+        // the assignment pass scored in the single-chain arithmetic: its bound holds for that arithmetic only
+        sa.thr_in = (have_thr0 && main_prec == 2) ? k->qthr0.as<float>() : nullptr;
         {
             StageSpan span(ctx, "knn_select");
             GT_TRY(gt_launch_select(ctx, sa));

@@ -21,6 +21,7 @@ struct KnnWork {
     DevBuf lists, counts, thr_final;
     DevBuf cand_d2, cand_j, cand_n, d2_lb;
     DevBuf unproven, qlomax_dev;
+    DevBuf qthr0;              //   and the starting thresholds that pass proves (single-chain arithmetic only)
     DevBuf qorder;             // self queries: the rows of the launch grouped by nearest landmark (gt_order.hip)
     DevBuf fb_rows, fb_count, fb_scratch, gflags, prof;
     DevBuf fb_qrows, fb_thr, fb_lists, fb_counts, fb_max;   // collected fallback

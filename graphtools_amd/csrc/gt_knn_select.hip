@@ -301,7 +301,9 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
         const int64_t qc = qg < nq ? qg : int64_t(nq) - 1;   // clamp pad queries onto a real row
         const int64_t row = qrows ? int64_t(qrows[qc]) : q0 + qc;
         bq[qt].load(Qp + row * C::RW, h);
-        thr[qt] = (MODE == 0) ? ((dbg & 1) ? INFINITY : -INFINITY) : ((qg < nq) ? thr_in[qc] : INFINITY);
+        // MODE 0: -inf, or a proven lower bound of the wanted scores indexed by row (gt_query_order); MODE 1: the radius
+        thr[qt] = (MODE == 0) ? ((dbg & 1) ? INFINITY : (thr_in ? thr_in[row - q0] : -INFINITY))
+                              : ((qg < nq) ? thr_in[qc] : INFINITY);
     }
 
     // ---- tile staging (global -> registers -> LDS, padded rows), in two halves to halve the staging registers ----
@@ -602,7 +604,7 @@ template <int DP>
 __global__ __launch_bounds__(256) void assign_cells_kernel(const float* __restrict__ Yc, const float* __restrict__ Yl,
                                                            const float* __restrict__ hl, const int64_t q0,
                                                            const int32_t nq, const int32_t L,
-                                                           uint32_t* __restrict__ cell) {
+                                                           uint32_t* __restrict__ cell, float* __restrict__ thr0) {
     constexpr int RW = DP / 2;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, li = lane & 31, h = lane >> 5;
     const int64_t q = int64_t(blockIdx.x) * 128 + w * 32 + li;
@@ -611,6 +613,12 @@ __global__ __launch_bounds__(256) void assign_cells_kernel(const float* __restri
     bq.load(Yc + (q0 + qc) * RW, h);
     float best = -INFINITY;
     uint32_t bidx = 0;
+    // gm[e]: best score among the landmarks that land in accumulator slot e of this lane - 16 disjoint sets of
+    // database rows, so at least 16 rows score >= min(gm): a valid (if loose, ~rank n/100) starting threshold for a
+    // top-16-or-more selection over the same scores (single-chain arithmetic, same seeds, same chain order)
+    float gm[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) gm[e] = -INFINITY;
     for (int l0 = 0; l0 < L; l0 += 32) {
         Frag<DP, 2> a;
         a.load(Yl + size_t(l0 + li) * RW, h);
@@ -629,12 +637,20 @@ __global__ __launch_bounds__(256) void assign_cells_kernel(const float* __restri
             const bool better = acc[e] > best;
             best = better ? acc[e] : best;
             bidx = better ? uint32_t(l0 + 8 * (e >> 2) + 4 * h + (e & 3)) : bidx;
+            gm[e] = fmaxf(gm[e], acc[e]);
         }
     }
+    float gmin = gm[0];
+#pragma unroll
+    for (int e = 1; e < 16; ++e) gmin = fminf(gmin, gm[e]);
+    gmin = fmaxf(gmin, __shfl_xor(gmin, 32));   // either half-wave's 16 sets will do
     const float ob = __shfl_xor(best, 32);
     const uint32_t oi = __shfl_xor(bidx, 32);
     if (ob > best || (ob == best && oi < bidx)) bidx = oi;
-    if (h == 0 && q < nq) cell[q] = bidx;
+    if (h == 0 && q < nq) {
+        cell[q] = bidx;
+        thr0[q] = gmin;
+    }
 }
 
 template <int DP, int NT, int MODE, int PREC>
@@ -688,9 +704,9 @@ int launch_dp(gt_ctx* ctx, const SelectArgs& a) {
 #if GT_SEL_PREC == 2 && !GT_SEL_QT1
 int GT_CAT3(gt_launch_assign_cells_p, GT_SEL_PREC, _dp, GT_SEL_DP)(gt_ctx* ctx, const float* Yc, const float* Yl,
                                                                   const float* hl, int64_t q0, int32_t nq, int32_t L,
-                                                                  uint32_t* cell) {
+                                                                  uint32_t* cell, float* thr0) {
     hipLaunchKernelGGL(assign_cells_kernel<GT_SEL_DP>, dim3((unsigned)ceil_div64(nq, 128)), dim3(256), 0, ctx->stream, Yc,
-                       Yl, hl, q0, nq, L, cell);
+                       Yl, hl, q0, nq, L, cell, thr0);
     GT_HIP(ctx, hipGetLastError());
     return GT_OK;
 }

@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void iota_rows_kernel(const int64_t q0, const 
 
 }  // namespace
 
-int gt_query_order(gt_ctx* ctx, int64_t q0, int64_t nq, int32_t* out_rows, int* active) {
+int gt_query_order(gt_ctx* ctx, int64_t q0, int64_t nq, int32_t* out_rows, float* out_thr0, int* active) {
     *active = 0;
     constexpr int64_t kMinRows = 32768;   // below this the whole launch is a few workgroup rounds
     if (!ctx->query_order || ctx->prec != 1 || ctx->fast_mode == 0 || !ctx->Yc.p || nq < kMinRows || ctx->n < kMinRows)
@@ -54,7 +54,7 @@ int gt_query_order(gt_ctx* ctx, int64_t q0, int64_t nq, int32_t* out_rows, int* 
     uint32_t* cell = ctx->order_cell.as<uint32_t>();
     uint32_t* cell_sorted = cell + nq;
     GT_TRY(gt_launch_assign_cells(ctx, ctx->DP, ctx->Yc.as<float>(), ctx->land_Y.as<float>(), ctx->land_h.as<float>(), q0,
-                                  int32_t(nq), L, cell));
+                                  int32_t(nq), L, cell, out_thr0));
     hipLaunchKernelGGL(iota_rows_kernel, dim3((unsigned)ceil_div64(nq, 256)), dim3(256), 0, ctx->stream, q0, nq,
                        ctx->order_rows.as<int32_t>());
     GT_HIP(ctx, hipGetLastError());

@@ -116,20 +116,36 @@ __global__ __launch_bounds__(256) void row_norm_kernel(const T* __restrict__ X, 
                                                        double* __restrict__ xn_sel) {
     // xn: squared norm over all d columns (exact stages).  With `sel` the candidate pass sees only columns sel[0..dw):
     // its seeds, the norm bound and the residual bound come from the partial norm (xn_sel).
-    const int64_t r = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    // One thread per row, columns accumulated in index order (the float64 stages depend on these exact sums); the
+    // block's 256 rows are staged through LDS in chunks of 32 columns so that the global reads are coalesced.
+    constexpr int CH = 32;
+    __shared__ T chunk[256][CH + 1];
+    const int64_t r0 = int64_t(blockIdx.x) * 256;
+    const int64_t r = r0 + threadIdx.x;
     double acc = 0.0, accs = 0.0, lo2 = 0.0;
-    if (r < n) {
-        const T* src = X + r * int64_t(d);
-        for (int k = 0; k < d; ++k) {
-            const double v = double(src[k]);
-            acc = fma(v, v, acc);
-            if (lomax2_bits && !sel) {
-                // exact residual of the float16 rounding of the scaled value (what the hi-plane-only pass drops)
-                const double vs = v * sc;
-                const double res = vs - double(_Float16(vs));
-                lo2 = fma(res, res, lo2);
+    for (int c0 = 0; c0 < d; c0 += CH) {
+        const int cw = d - c0 < CH ? d - c0 : CH;
+        __syncthreads();
+        for (int f = threadIdx.x; f < 256 * cw; f += 256) {
+            const int rr = f / cw, cc = f % cw;
+            chunk[rr][cc] = (r0 + rr < n) ? X[(r0 + rr) * int64_t(d) + c0 + cc] : T(0);
+        }
+        __syncthreads();
+        if (r < n) {
+            for (int k = 0; k < cw; ++k) {
+                const double v = double(chunk[threadIdx.x][k]);
+                acc = fma(v, v, acc);
+                if (lomax2_bits && !sel) {
+                    // exact residual of the float16 rounding of the scaled value (what the hi-plane-only pass drops)
+                    const double vs = v * sc;
+                    const double res = vs - double(_Float16(vs));
+                    lo2 = fma(res, res, lo2);
+                }
             }
         }
+    }
+    if (r < n) {
+        const T* src = X + r * int64_t(d);
         accs = acc;
         if (sel) {
             accs = 0.0;
