@@ -221,6 +221,10 @@ int gt_set_option(gt_ctx* ctx, const char* name, const char* value) {
             GT_FAIL(ctx, GT_E_ARG, "query_order must be 'auto' or 'off'");
         return GT_OK;
     }
+    if (k == "select_samp_trig") {
+        ctx->samp_trig = std::atoi(value);
+        return GT_OK;
+    }
     if (k == "select_thr0") {
         ctx->thr0_mode = std::atoi(value);
         return GT_OK;

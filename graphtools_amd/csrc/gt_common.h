@@ -128,6 +128,7 @@ struct gt_ctx {
     int32_t thr0_mode = 1;           //   start the candidate lists from the threshold the assignment pass proves (0: from -inf)
     int32_t order_cell_rows = 512;   //   rows per landmark cell (L = n / order_cell_rows landmarks, 64 ... 4096)
     DevBuf land_Y, land_h, order_cell, order_rows, order_tmp;
+    int32_t samp_trig = 0;    //   level 0: entries per half-list that trigger a cut (0: samp_keep / 2 + 24)
     int32_t samp2_level = 3;  //   second cut of the lists once 2^samp2_level / samp_stride of the tiles are seen (0: none)
     int32_t samp2_keep = 64;  //   to this many entries (at least 3 * samp_keep)
     int32_t narrow_mode = -1; // 128-row-workgroup candidate kernels: -1 auto (few query rows), 0 never, 1 whenever available

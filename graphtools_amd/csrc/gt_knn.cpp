@@ -130,6 +130,7 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
         if (stride > 1 && keep <= mkeep / 2 && ntiles >= int64_t(8) * stride) {
             sa.samp_stride = stride;
             sa.samp_keep = keep;
+            sa.samp_trig = ctx->samp_trig;
             // second cut once 2^samp2_level / stride of the tiles are seen
             int keep2 = std::max(ctx->samp2_keep, 3 * keep);
             keep2 += keep2 & 1;

@@ -26,6 +26,7 @@ struct SelectArgs {
     int32_t samp_end = 0;           //   > 0: after the last sampled tile every list is cut to its samp_end best
     int32_t samp2_level = 0;        //   > 0: second cut, to the samp2_keep best, once 2^samp2_level / samp_stride of the tiles are seen
     int32_t samp2_keep = 0;
+    int32_t samp_trig = 0;          //   level 0: a half-list is cut when it holds more than this (0: samp_keep / 2 + 24)
     int32_t narrow = 0;             // selection, prec 2, dp <= 64: 128-row workgroups (launches with few query rows)
     int32_t final_keep = 0;         // selection: entries kept per query at the end (0: M' = 16*nt; at most 64*nt)
     int32_t dbg = 0;                // experiment switches (bit 0: no survivors, bit 1: no compaction sort)

@@ -258,7 +258,7 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
     uint64_t* __restrict__ lists, uint32_t* __restrict__ counts, const float* __restrict__ thr_in,
     float* __restrict__ thr_out, const int32_t cap, const int32_t dbg, unsigned long long* __restrict__ prof,
     const int32_t samp_stride, const int32_t samp_keep, const int32_t samp_end, const int32_t samp2_level,
-    const int32_t samp2_keep, const int32_t final_keep) {
+    const int32_t samp2_keep, const int32_t samp_trig, const int32_t final_keep) {
     using C = SelCfg<DP, PREC>;
     unsigned long long t_adm = 0, t_cmp = 0, t_bar = 0, n_cmp = 0, n_adm = 0, t_lvl0 = 0, n_adm_lvl0 = 0;
     const unsigned long long t_start = prof ? __builtin_readcyclecounter() : 0ull;
@@ -512,7 +512,7 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
             const bool end_a = level_end && ((level == 0 && samp_end > 0) || (level > 0 && level == samp2_level));
             const uint32_t mkeep = end_a ? uint32_t(level == 0 ? samp_end : samp2_keep)
                                          : phase_a ? uint32_t(samp_keep) : uint32_t(MKEEP);
-            const uint32_t trig = phase_a ? uint32_t(samp_keep) / 2u + 24u : uint32_t(TRIGH);
+            const uint32_t trig = phase_a ? uint32_t(samp_trig) : uint32_t(TRIGH);
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt) {
                 const unsigned long long full =
@@ -677,6 +677,7 @@ int launch_one(gt_ctx* ctx, const SelectArgs& a) {
     hipLaunchKernelGGL(kern, dim3((unsigned)nblocks, (unsigned)nsplit), dim3(256), lds_bytes, ctx->stream, a.Yp,
                        a.hneg, a.Qp, a.qrows, a.q0, a.nq, ntiles, a.lists, a.counts, a.thr_in, a.thr_out, a.cap, a.dbg, a.prof,
                        a.samp_stride, a.samp_keep, a.samp_end, a.samp2_level, a.samp2_keep,
+                       (a.samp_trig > 0 && a.samp_trig <= 32 * NT - C::BN / 2) ? a.samp_trig : a.samp_keep / 2 + 24,
                        (a.final_keep > 0 && a.final_keep <= 64 * NT) ? a.final_keep : 16 * NT);
     GT_HIP(ctx, hipGetLastError());
     return GT_OK;

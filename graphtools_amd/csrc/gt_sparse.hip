@@ -235,9 +235,12 @@ __global__ __launch_bounds__(256) void emit_triplets_kernel(
 
 // ---- R1: count received triplets per local row ---------------------------------------------------
 __global__ __launch_bounds__(256) void count_recv_kernel(const Triplet* __restrict__ recv, const int64_t n_recv,
-                                                         const int64_t r0, int32_t* __restrict__ lenT) {
+                                                         const int64_t r0, int32_t* __restrict__ lenT,
+                                                         int32_t* __restrict__ slot) {
+    // the value the counter held is this triplet's place among the row's received entries: the fill pass needs no
+    // second round of atomics (the order within a row is arbitrary either way - the merge sorts by column)
     for (int64_t t = int64_t(blockIdx.x) * 256 + threadIdx.x; t < n_recv; t += int64_t(gridDim.x) * 256)
-        atomicAdd(&lenT[int64_t(recv[t].row) - r0], 1);
+        slot[t] = atomicAdd(&lenT[int64_t(recv[t].row) - r0], 1);
 }
 
 // ---- scans (int32 in -> int64 exclusive out, with total in out[n]) --------------------------------
@@ -345,13 +348,13 @@ __global__ __launch_bounds__(256) void fill_rows_kernel(
 // ---- R2: T part of the union rows ----------------------------------------------------------------
 __global__ __launch_bounds__(256) void fill_recv_kernel(const Triplet* __restrict__ recv, const int64_t n_recv,
                                                         const int64_t r0, const int64_t* __restrict__ off,
-                                                        const int32_t* __restrict__ lenN, int32_t* __restrict__ cursor,
+                                                        const int32_t* __restrict__ lenN,
+                                                        const int32_t* __restrict__ slot,
                                                         uint32_t* __restrict__ Ukey, double* __restrict__ Uval) {
     for (int64_t t = int64_t(blockIdx.x) * 256 + threadIdx.x; t < n_recv; t += int64_t(gridDim.x) * 256) {
         const Triplet tr = recv[t];
         const int64_t il = int64_t(tr.row) - r0;
-        const int slot = atomicAdd(&cursor[il], 1);
-        const int64_t pos = off[il] + lenN[il] + slot;
+        const int64_t pos = off[il] + lenN[il] + slot[t];
         Ukey[pos] = (tr.col << 1) | 1u;
         Uval[pos] = tr.val;
     }
@@ -927,11 +930,11 @@ extern "C" int gt_graph_finish(gt_ctx* ctx, const void* recv_buf_dev, int64_t n_
         StageSpan span(ctx, "symmetrize");
         HostTrace tr_all(ctx, "finish: symmetrize");
         GT_HIP(ctx, hipMemsetAsync(g->lenT.p, 0, size_t(nloc) * sizeof(int32_t), ctx->stream));
-        GT_HIP(ctx, hipMemsetAsync(g->cursor.p, 0, size_t(nloc) * sizeof(int32_t), ctx->stream));
+        GT_HIP(ctx, g->cursor.reserve(size_t(std::max<int64_t>(n_recv, 1)) * sizeof(int32_t)));   // slot of every received triplet
         if (n_recv > 0) {
             int64_t blocks = std::min<int64_t>(ceil_div64(n_recv, 256), 16384);
             hipLaunchKernelGGL(count_recv_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, recv, n_recv, g->r0,
-                               g->lenT.as<int32_t>());
+                               g->lenT.as<int32_t>(), g->cursor.as<int32_t>());
         }
         GT_HIP(ctx, g->off.reserve(size_t(nloc + 1) * sizeof(int64_t)));
         int rc = exclusive_scan(ctx, g->lenN.as<int32_t>(), g->lenT.as<int32_t>(), nloc, g->off.as<int64_t>(), g->scan_tmp);

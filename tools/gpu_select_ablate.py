@@ -23,6 +23,8 @@ for prec, dbg in [(p_, d_) for p_ in precs for d_ in dbgs]:
         ctx.set_option("select_samp_end", en_)
         ctx.set_option("select_samp_stride", st_)
         ctx.set_option("select_samp_keep", kp_)
+    if os.environ.get("GT_TRIG"):
+        ctx.set_option("select_samp_trig", os.environ["GT_TRIG"])
     if os.environ.get("GT_THR0"):
         ctx.set_option("select_thr0", os.environ["GT_THR0"])
     if os.environ.get("GT_NARROW"):
