@@ -299,6 +299,32 @@ class Context:
                                                 _ptr(indptr) if structure else None, 0), "gt_graph_fetch_csr")
         return data, indices, indptr
 
+    def graph_csr_torch(self, which):
+        """Device-resident hand-off: the owned rows of K or P as a ``torch.sparse_csr_tensor`` on this context's GPU
+        (device-to-device copies into torch-owned memory; nothing crosses PCIe).  For consumers that keep working
+        on the device - diffusion powers ``P^t X``, spectral front ends.  torch ships its own copy of the HIP
+        runtime: initialise it (``torch.cuda.init()``) before the first graphtools_amd call of the process."""
+        import torch
+
+        if not torch.cuda.is_initialized():
+            try:
+                torch.cuda.init()
+            except RuntimeError as e:
+                raise RuntimeError("torch could not initialise its HIP runtime after libgraphtools_amd.so had been "
+                                   "used in this process; call torch.cuda.init() first") from e
+
+        r0, r1, nnz = self.graph_rows()
+        dev = torch.device("cuda", self.device)
+        data = torch.empty(nnz, dtype=torch.float64, device=dev)
+        indices = torch.empty(nnz, dtype=torch.int32, device=dev)
+        indptr = torch.empty(r1 - r0 + 1, dtype=torch.int64, device=dev)
+        torch.cuda.synchronize(dev)   # torch's allocator may hand out memory with work pending on its own streams
+        self._check(self.lib.gt_graph_fetch_csr(self.h, which, ctypes.c_void_p(data.data_ptr()),
+                                                ctypes.c_void_p(indices.data_ptr()), ctypes.c_void_p(indptr.data_ptr()), 1),
+                    "gt_graph_fetch_csr")
+        n_cols = self.n
+        return torch.sparse_csr_tensor(indptr, indices.to(torch.int64), data, size=(r1 - r0, n_cols))
+
     def graph_fetch_vec(self, which):
         r0, r1, _ = self.graph_rows()
         out = np.empty(r1 - r0, dtype=np.float64)

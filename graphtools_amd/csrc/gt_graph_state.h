@@ -38,7 +38,7 @@ struct GraphState {
     DevBuf ownercnt, ownerpos, scan_tmp, selfbuf, splits_dev;
     std::vector<int64_t> send_counts_host;
     // merge
-    DevBuf Ukey, Uval, Vkey, Vval, bigrows, bigcount, bigscratch_k, bigscratch_v, bigsoff, aniso_tmp, scan_own;
+    DevBuf Ukey, Uval, Vkey, Vval, bigrows, hugerows, bigcount, bigscratch_k, bigscratch_v, bigsoff, aniso_tmp, scan_own;
     DevBuf indices, Kdata, Pdata, flags;
     int64_t nnz0 = 0, nnz = 0;
 };

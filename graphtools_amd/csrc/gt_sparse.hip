@@ -19,7 +19,7 @@
 void gt_free_graph_state(gt_ctx* ctx) {
     if (!ctx->graph) return;
     GraphState* g = ctx->graph;
-    for (DevBuf* b : {&g->bw, &g->bw_user, &g->rowsrc, &g->lenN, &g->lenT, &g->cursor, &g->off, &g->outlen, &g->indptr,
+    for (DevBuf* b : {&g->bw, &g->bw_user, &g->rowsrc, &g->hugerows, &g->lenN, &g->lenT, &g->cursor, &g->off, &g->outlen, &g->indptr,
                       &g->degree, &g->over_rows, &g->over_count, &g->rthr, &g->rlists, &g->rcounts, &g->rK, &g->rmax,
                       &g->ownercnt, &g->ownerpos, &g->scan_tmp, &g->selfbuf, &g->splits_dev, &g->Ukey, &g->Uval, &g->Vkey, &g->Vval,
                       &g->bigrows, &g->bigcount, &g->bigscratch_k, &g->bigscratch_v, &g->bigsoff, &g->aniso_tmp, &g->scan_own,
@@ -414,26 +414,37 @@ __device__ __forceinline__ int merge_sorted_regs(const uint64_t (&hi)[NT], const
     return count;
 }
 
+// One wave sorts a union row of L <= 64 NT entries by (column, tag) and merges the pairs.  Sort keys are packed into
+// one 64-bit word - (column, tag) above the entry's position in the row - so the bitonic network moves half the
+// registers of a key/value sort; the values are fetched by position afterwards (the row was read a moment ago).
 template <int NT>
 __device__ __forceinline__ int sort_merge_row(const uint32_t* __restrict__ Uk, const double* __restrict__ Uv,
                                               const int L, const int lane, const int symm, const double theta,
                                               uint32_t* __restrict__ Vk, double* __restrict__ Vv) {
-    uint64_t hi[NT], lo[NT];
+    uint64_t pk[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int p = t * 64 + lane;
+        // descending sort of the complement = ascending sort of the key; 0 (no entry) sorts last
+        pk[t] = (p < L) ? ~((uint64_t(Uk[p]) << 16) | uint64_t(p)) : 0ull;
+    }
+    wave_bitonic_desc<NT>(pk, lane);
+    uint64_t hi[NT], lo[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
         hi[t] = ~0ull;
         lo[t] = 0ull;
-        if (p < L) {
-            hi[t] = uint64_t(Uk[p]);
-            lo[t] = (uint64_t)__double_as_longlong(Uv[p]);
+        if (pk[t] != 0ull) {
+            const uint64_t x = ~pk[t];
+            hi[t] = x >> 16;
+            lo[t] = (uint64_t)__double_as_longlong(Uv[x & 0xFFFFull]);
         }
     }
-    wave_bitonic_asc_pair<NT>(hi, lo, lane);
     return merge_sorted_regs<NT>(hi, lo, lane, symm, theta, Vk, Vv);
 }
 
-constexpr int kBigRow = 512;   // longer rows take the global-memory sort (big_sort_kernel)
+constexpr int kBigRow = 512;    // longer rows go to sort_merge_long_kernel
+constexpr int kHugeRow = 2048;  // and beyond that to the global-memory sort (big_sort_kernel)
 
 __global__ __launch_bounds__(256) void sort_merge_kernel(const int64_t nloc, const int64_t* __restrict__ off,
                                                          const uint32_t* __restrict__ Ukey, const double* __restrict__ Uval,
@@ -470,7 +481,34 @@ __global__ __launch_bounds__(256) void sort_merge_kernel(const int64_t nloc, con
     if (lane == 0) outlen[i] = c;
 }
 
-// big rows: bitonic sort in global scratch (one workgroup per row), then a separate merge kernel
+// Rows of kBigRow < L <= kHugeRow entries (hub rows of the transpose): same register sort with 16 / 32 keys per lane in
+// a kernel of its own, so that its register budget does not cut the occupancy of the common case.  Persistent waves
+// walk the list sort_merge_kernel left in bigrows; what is longer still is compacted to the front of hugerows.
+__global__ __launch_bounds__(64) void sort_merge_long_kernel(const int64_t* __restrict__ off, const uint32_t* __restrict__ Ukey,
+                                                             const double* __restrict__ Uval, const int symm,
+                                                             const double theta, uint32_t* __restrict__ Vkey,
+                                                             double* __restrict__ Vval, int32_t* __restrict__ outlen,
+                                                             const int32_t* __restrict__ bigrows,
+                                                             const uint32_t* __restrict__ bigcount,
+                                                             int32_t* __restrict__ hugerows, uint32_t* __restrict__ hugecount) {
+    const int lane = threadIdx.x;
+    const uint32_t nbig = *bigcount;
+    for (uint32_t b = blockIdx.x; b < nbig; b += gridDim.x) {
+        const int64_t i = bigrows[b];
+        const int64_t o0 = off[i];
+        const int64_t L64 = off[i + 1] - o0;
+        if (L64 > kHugeRow) {
+            if (lane == 0) hugerows[atomicAdd(hugecount, 1u)] = int32_t(i);
+            continue;
+        }
+        const int L = int(L64);
+        const int c = (L <= 1024) ? sort_merge_row<16>(Ukey + o0, Uval + o0, L, lane, symm, theta, Vkey + o0, Vval + o0)
+                                  : sort_merge_row<32>(Ukey + o0, Uval + o0, L, lane, symm, theta, Vkey + o0, Vval + o0);
+        if (lane == 0) outlen[i] = c;
+    }
+}
+
+// huge rows: bitonic sort in global scratch (one workgroup per row), then a separate merge kernel
 __global__ __launch_bounds__(1024) void big_sort_kernel(const int32_t* __restrict__ bigrows, const int64_t* __restrict__ off,
                                                         const uint32_t* __restrict__ Ukey, const double* __restrict__ Uval,
                                                         const int64_t* __restrict__ scratch_off,
@@ -957,8 +995,9 @@ extern "C" int gt_graph_finish(gt_ctx* ctx, const void* recv_buf_dev, int64_t n_
         GT_HIP(ctx, g->Vval.reserve(size_t(total_u) * sizeof(double)));
         GT_HIP(ctx, g->outlen.reserve(size_t(nloc) * sizeof(int32_t)));
         GT_HIP(ctx, g->bigrows.reserve(size_t(nloc) * sizeof(int32_t)));
-        GT_HIP(ctx, g->bigcount.reserve(sizeof(uint32_t)));
-        GT_HIP(ctx, hipMemsetAsync(g->bigcount.p, 0, sizeof(uint32_t), ctx->stream));
+        GT_HIP(ctx, g->hugerows.reserve(size_t(nloc) * sizeof(int32_t)));
+        GT_HIP(ctx, g->bigcount.reserve(2 * sizeof(uint32_t)));   // [0] rows > kBigRow, [1] rows > kHugeRow
+        GT_HIP(ctx, hipMemsetAsync(g->bigcount.p, 0, 2 * sizeof(uint32_t), ctx->stream));
         hipLaunchKernelGGL(fill_rows_kernel, dim3((unsigned)ceil_div64(nloc, 4)), dim3(256), 0, ctx->stream, nloc, k->MP,
                            k->cand_d2.as<double>(), k->cand_j.as<uint32_t>(), g->rowsrc.as<int32_t>(),
                            g->rlists.as<uint64_t>(), g->rcounts.as<uint32_t>(), g->rcap, g->rK.as<double>(),
@@ -973,18 +1012,22 @@ extern "C" int gt_graph_finish(gt_ctx* ctx, const void* recv_buf_dev, int64_t n_
                            g->off.as<int64_t>(), g->Ukey.as<uint32_t>(), g->Uval.as<double>(), g->p.kernel_symm, g->p.theta,
                            g->Vkey.as<uint32_t>(), g->Vval.as<double>(), g->outlen.as<int32_t>(), g->bigrows.as<int32_t>(),
                            g->bigcount.as<uint32_t>());
+        hipLaunchKernelGGL(sort_merge_long_kernel, dim3(4096), dim3(64), 0, ctx->stream, g->off.as<int64_t>(),
+                           g->Ukey.as<uint32_t>(), g->Uval.as<double>(), g->p.kernel_symm, g->p.theta, g->Vkey.as<uint32_t>(),
+                           g->Vval.as<double>(), g->outlen.as<int32_t>(), g->bigrows.as<int32_t>(), g->bigcount.as<uint32_t>(),
+                           g->hugerows.as<int32_t>(), g->bigcount.as<uint32_t>() + 1);
         GT_HIP(ctx, hipGetLastError());
-        uint32_t nbig = 0;
-        GT_HIP(ctx, hipMemcpyAsync(&nbig, g->bigcount.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        uint32_t nbig = 0;   // rows beyond the register sorts
+        GT_HIP(ctx, hipMemcpyAsync(&nbig, g->bigcount.as<uint32_t>() + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
         GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
         HostTrace tr_b(ctx, "finish: long rows + compact");
         if (nbig > 0) {
-            // rows longer than kBigRow: global-memory bitonic sort, one workgroup per row
+            // rows longer than kHugeRow: global-memory bitonic sort, one workgroup per row
             std::vector<int32_t> rows(nbig);
             std::vector<int64_t> offh(nloc + 1);
             {
                 // copies on the library's stream (the null stream would synchronise with every other stream of the process)
-                GT_HIP(ctx, hipMemcpyAsync(rows.data(), g->bigrows.p, size_t(nbig) * sizeof(int32_t), hipMemcpyDeviceToHost,
+                GT_HIP(ctx, hipMemcpyAsync(rows.data(), g->hugerows.p, size_t(nbig) * sizeof(int32_t), hipMemcpyDeviceToHost,
                                            ctx->stream));
                 GT_HIP(ctx, hipMemcpyAsync(offh.data(), g->off.p, size_t(nloc + 1) * sizeof(int64_t), hipMemcpyDeviceToHost,
                                            ctx->stream));
@@ -1009,10 +1052,10 @@ extern "C" int gt_graph_finish(gt_ctx* ctx, const void* recv_buf_dev, int64_t n_
                                        ctx->stream));
             GT_HIP(ctx, g->bigscratch_k.reserve(size_t(soff[nbig]) * sizeof(uint32_t)));
             GT_HIP(ctx, g->bigscratch_v.reserve(size_t(soff[nbig]) * sizeof(double)));
-            hipLaunchKernelGGL(big_sort_kernel, dim3(nbig), dim3(1024), 0, ctx->stream, g->bigrows.as<int32_t>(),
+            hipLaunchKernelGGL(big_sort_kernel, dim3(nbig), dim3(1024), 0, ctx->stream, g->hugerows.as<int32_t>(),
                                g->off.as<int64_t>(), g->Ukey.as<uint32_t>(), g->Uval.as<double>(), soff_dev.as<int64_t>(),
                                g->bigscratch_k.as<uint32_t>(), g->bigscratch_v.as<double>());
-            hipLaunchKernelGGL(big_merge_kernel, dim3(nbig), dim3(64), 0, ctx->stream, g->bigrows.as<int32_t>(),
+            hipLaunchKernelGGL(big_merge_kernel, dim3(nbig), dim3(64), 0, ctx->stream, g->hugerows.as<int32_t>(),
                                g->off.as<int64_t>(), soff_dev.as<int64_t>(), g->bigscratch_k.as<uint32_t>(),
                                g->bigscratch_v.as<double>(), g->p.kernel_symm, g->p.theta, g->Vkey.as<uint32_t>(),
                                g->Vval.as<double>(), g->outlen.as<int32_t>());

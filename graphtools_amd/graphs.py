@@ -268,6 +268,19 @@ class kNNGraph(DataGraph):
         self._ensure_device_graph()
         return self.hip.graph_fetch_vec(_hip.VEC_DEGREE)
 
+    def diff_op_torch(self):
+        """The diffusion operator as a CUDA ``torch.sparse_csr_tensor`` (no host round trip): the hand-off to
+        consumers that continue on the device, e.g. ``P @ X`` diffusion steps."""
+        self.K
+        self._ensure_device_graph()
+        return self.hip.graph_csr_torch(_hip.CSR_P)
+
+    def kernel_torch(self):
+        """The kernel matrix K as a CUDA ``torch.sparse_csr_tensor``."""
+        self.K
+        self._ensure_device_graph()
+        return self.hip.graph_csr_torch(_hip.CSR_K)
+
     @property
     def build_stats(self):
         """Device-side statistics of the last build (fallback / radius rows, stage timings in ms)."""

@@ -16,6 +16,19 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    # torch bundles its own copy of the HIP runtime; when it initialises AFTER libgraphtools_amd.so has been working in
+    # the process for a while it can fail to see the GPU ("No HIP GPUs are available").  The tests that hand device
+    # memory to torch (diff_op_torch) therefore bring torch's context up first, as bench.py and the sharded path do.
+    try:
+        import torch
+
+        if torch.cuda.device_count() > 0:
+            torch.cuda.init()
+    except Exception:   # CPU-only box: nothing to initialise
+        pass
+
+
 def load_golden(name):
     return np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
 

@@ -295,16 +295,17 @@ def test_mnn_landmark_graph_matches_reference():
 
 @pytest.mark.parametrize("symm,theta,aniso", [("+", None, 0.0), ("*", None, 0.0), ("mnn", 0.25, 0.0), ("+", None, 1.0),
                                               (None, None, 0.0)])
-def test_csr_graph_build_vs_oracle(symm, theta, aniso):
-    """gt_csr_graph_build on an arbitrary non-negative CSR (ragged rows, some empty, some longer than the
-    register-sort limit of 512 after the union with the transpose)."""
+@pytest.mark.parametrize("n,long_row,long_col", [(1500, 700, 650), (4000, 1500, 900), (4000, 2600, 3000)])
+def test_csr_graph_build_vs_oracle(symm, theta, aniso, n, long_row, long_col):
+    """gt_csr_graph_build on an arbitrary non-negative CSR: ragged rows, some empty, some longer after the union with
+    the transpose than the 512-entry register sort of the common kernel (-> 1024 / 2048-entry register sorts of
+    sort_merge_long_kernel) and than 2048 entries (-> global-memory sort)."""
     rng = np.random.default_rng(5)
-    n = 1500
     A = sparse.random(n, n, density=0.01, random_state=7, format="lil", data_rvs=lambda k: rng.uniform(0.1, 1.0, k))
     A[3, :] = 0                                   # an empty row
-    A[10, rng.choice(n, 700, replace=False)] = rng.uniform(0.1, 1.0, 700)    # a long row
+    A[10, rng.choice(n, long_row, replace=False)] = rng.uniform(0.1, 1.0, long_row)    # a long row
     A[:, 11] = 0
-    A[rng.choice(n, 650, replace=False), 11] = 0.5                            # a long column (long row of A^T)
+    A[rng.choice(n, long_col, replace=False), 11] = 0.5                      # a long column (long row of A^T)
     A.setdiag(1.0)
     A = sparse.csr_matrix(A)
     A.eliminate_zeros()
@@ -386,3 +387,22 @@ def test_non_finite_input_is_rejected_like_sklearn():
     with pytest.raises(ValueError, match="contains NaN"):
         G.build_kernel_to_data(Xn[:20])
     assert G.build_kernel_to_data(X[:20]).shape == (20, 500)   # the context is still usable afterwards
+
+
+def test_device_resident_hand_off_matches_host_matrices():
+    """diff_op_torch / kernel_torch: K and P stay on the GPU as torch sparse CSR tensors; a diffusion step P @ X on the
+    device equals the host product."""
+    import torch
+
+    X = make_mix(3000, 10, 4)
+    G = graphtools_amd.Graph(X, knn=7, decay=20, n_pca=None, verbose=0)
+    Pt = G.diff_op_torch()
+    Kt = G.kernel_torch()
+    assert Pt.is_cuda and Pt.layout == torch.sparse_csr and tuple(Pt.shape) == (3000, 3000)
+    P = G.P
+    assert np.array_equal(Pt.values().cpu().numpy(), P.data)
+    assert np.array_equal(Pt.col_indices().cpu().numpy(), P.indices)
+    assert np.array_equal(Pt.crow_indices().cpu().numpy(), P.indptr)
+    assert np.array_equal(Kt.values().cpu().numpy(), G.K.data)
+    Z = torch.as_tensor(X.astype(np.float64), device=Pt.device)
+    np.testing.assert_allclose((Pt @ Z).cpu().numpy(), P @ X.astype(np.float64), rtol=1e-12, atol=1e-12)
