@@ -100,7 +100,11 @@ int gt_stage_launches(const gt_ctx* ctx, const char* stage);
  *   "f32"   float32 MFMA.
  * Results never depend on it - exact ordering and values always come from the float64 stage, rows whose candidate
  * table cannot be proven complete are repaired on the accurate arithmetic - only speed does.  The environment
- * variable GT_KNN_PRECISION sets the default.  Also: "metric" ("euclidean" | "cosine"). */
+ * variable GT_KNN_PRECISION sets the default.  Also: "metric" ("euclidean" | "cosine"); "query_order" ("auto" | "off":
+ * deal the query rows of large launches to workgroups grouped by nearest landmark - speed only).  Tuning switches of
+ * the candidate pass (development; results never depend on them): "select_samp_stride", "select_samp_keep",
+ * "select_samp_end", "select_samp2_level", "select_samp2_keep", "select_samp_trig", "select_thr0", "select_narrow",
+ * "query_order_cell_rows"; "dbg_select" switches invalidate the results. */
 int gt_set_option(gt_ctx* ctx, const char* name, const char* value);
 /* arithmetic the most recent main candidate pass ran on: 0 float32, 1 split float16 (3 chains), 2 single float16 chain */
 int gt_last_knn_precision(const gt_ctx* ctx);
