@@ -56,6 +56,8 @@ int gt_ctx_create(int device, gt_ctx** out) {
         if (std::string(pr) == "f16x1") { ctx->prec = 1; ctx->fast_mode = 2; }
         if (std::string(pr) == "auto") { ctx->prec = 1; ctx->fast_mode = 1; }
     }
+    // test hook: group the query rows of launches of at least this many rows (default 32768)
+    if (const char* mr = std::getenv("GT_QUERY_ORDER_MIN_ROWS")) ctx->order_min_rows = std::max(1, std::atoi(mr));
     *out = ctx;
     return GT_OK;
 }

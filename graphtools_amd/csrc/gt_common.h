@@ -125,6 +125,7 @@ struct gt_ctx {
     int32_t samp_keep = 0;    //   list budget of that phase (0: the number of neighbours wanted, at least 16)
     int32_t samp_end = -1;    //   list budget at the end of that phase (0: none, -1: same as samp_keep)
     int32_t query_order = 1;  // candidate pass: deal the query rows to workgroups grouped by nearest landmark (gt_order.hip)
+    int32_t order_min_rows = 32768;  //   launches with fewer query rows (or fewer points) are not grouped
     int32_t thr0_mode = 1;           //   start the candidate lists from the threshold the assignment pass proves (0: from -inf)
     int32_t order_cell_rows = 512;   //   rows per landmark cell (L = n / order_cell_rows landmarks, 64 ... 4096)
     DevBuf land_Y, land_h, order_cell, order_rows, order_tmp;

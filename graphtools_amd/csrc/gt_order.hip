@@ -37,11 +37,11 @@ __global__ __launch_bounds__(256) void iota_rows_kernel(const int64_t q0, const 
 
 int gt_query_order(gt_ctx* ctx, int64_t q0, int64_t nq, int32_t* out_rows, float* out_thr0, int* active) {
     *active = 0;
-    constexpr int64_t kMinRows = 32768;   // below this the whole launch is a few workgroup rounds
-    if (!ctx->query_order || ctx->prec != 1 || ctx->fast_mode == 0 || !ctx->Yc.p || nq < kMinRows || ctx->n < kMinRows)
+    const int64_t kMinRows = ctx->order_min_rows;   // below this the whole launch is a few workgroup rounds
+    if (!ctx->query_order || ctx->prec != 1 || ctx->fast_mode == 0 || !ctx->Yc.p || nq < kMinRows || ctx->n < std::max<int64_t>(kMinRows, 64))
         return GT_OK;
     const int rw = ctx->DP / 2;   // dwords per row of the compact copy
-    int L = int(std::min<int64_t>(4096, std::max<int64_t>(64, (ctx->n / std::max(ctx->order_cell_rows, 32)) / 32 * 32)));
+    int L = int(std::min<int64_t>(std::min<int64_t>(4096, ctx->n / 32 * 32), std::max<int64_t>(64, (ctx->n / std::max(ctx->order_cell_rows, 32)) / 32 * 32)));
     const int64_t step = ctx->n / L;
     GT_HIP(ctx, ctx->land_Y.reserve(size_t(L) * rw * sizeof(uint32_t)));
     GT_HIP(ctx, ctx->land_h.reserve(size_t(L) * sizeof(float)));

@@ -23,3 +23,13 @@ def test_random_exact_extension_and_mnn_graphs_match_the_oracle():
                          text=True, timeout=1500)
     tail = "\n".join(res.stdout.strip().splitlines()[-6:])
     assert res.returncode == 0, tail + "\n" + res.stderr[-2000:]
+
+
+def test_random_configurations_with_grouped_queries():
+    """the same sweep with the query ordering and the landmark starting thresholds forced on for small problems
+    (GT_QUERY_ORDER_MIN_ROWS=1; by default they only engage from 32768 rows)"""
+    env = dict(os.environ, GT_QUERY_ORDER_MIN_ROWS="1")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gpu_fuzz.py"), "30", "23"], capture_output=True,
+                         text=True, timeout=1500, env=env)
+    tail = "\n".join(res.stdout.strip().splitlines()[-6:])
+    assert res.returncode == 0, tail + "\n" + res.stderr[-2000:]
