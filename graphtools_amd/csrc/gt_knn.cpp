@@ -178,17 +178,19 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
     ra.radius_key_factor = radius_key_factor;
     ra.unproven = k->unproven.as<uint32_t>();
     bool have_thr0 = false;
-    if (!external) {
+    {
         // deal the query rows to workgroups grouped by nearest landmark (list i <-> row qorder[i]; gt_order.hip)
         int ordered = 0;
+        const float* Qc = external ? k->Qc.as<float>() : ctx->Yc.as<float>();
         GT_HIP(ctx, k->qorder.reserve(size_t(nq) * sizeof(int32_t)));
         GT_HIP(ctx, k->qthr0.reserve(size_t(nq) * sizeof(float)));
         {
             StageSpan span(ctx, "query_order");
-            GT_TRY(gt_query_order(ctx, q0, nq, k->qorder.as<int32_t>(), k->qthr0.as<float>(), &ordered));
+            GT_TRY(gt_query_order(ctx, Qc, external ? 0 : q0, nq, need_m, k->qorder.as<int32_t>(), k->qthr0.as<float>(),
+                                  &ordered));
         }
         if (ordered) sa.qrows = ra.qrows = k->qorder.as<int32_t>();
-        have_thr0 = ordered != 0 && need_m <= 16 && ctx->thr0_mode != 0;
+        have_thr0 = ordered != 0 && need_m <= 32 && ctx->thr0_mode != 0;
     }
     uint32_t n_fb = 0;
     for (;;) {

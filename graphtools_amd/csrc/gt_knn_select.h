@@ -35,12 +35,15 @@ struct SelectArgs {
 int gt_launch_select(gt_ctx* ctx, const SelectArgs& a);
 // nearest of the L landmark rows Yl (compact hi-plane rows, seeds hl) for the rows [q0, q0 + nq) of Yc (approximate)
 int gt_launch_assign_cells(gt_ctx* ctx, int dp, const float* Yc, const float* Yl, const float* hl, int64_t q0, int32_t nq,
-                           int32_t L, uint32_t* cell, float* thr0);
+                           int32_t L, int32_t need, uint32_t* cell, float* thr0);
 // gt_order.hip: the rows [q0, q0 + nq) grouped by nearest landmark -> out_rows (device, int32 [nq]); *active = 0 when
 // the launch is too small to bother or the compact copy is not available (out_rows untouched)
-// out_thr0 (device, float [nq], indexed by row - q0): a score at least 16 database rows reach in the single-chain
-// arithmetic - a valid starting threshold of a MODE 0 launch in that arithmetic (SelectArgs::thr_in)
-int gt_query_order(gt_ctx* ctx, int64_t q0, int64_t nq, int32_t* out_rows, float* out_thr0, int* active);
+// out_thr0 (device, float [nq], indexed by row - q0): a score at least `need` (<= 32) database rows reach in the
+// single-chain arithmetic - a valid starting threshold of a MODE 0 launch in that arithmetic (SelectArgs::thr_in)
+// Qc: compact hi-plane copy of the query matrix (the bound points themselves, or an external matrix prepared with the
+// same scale); rows [q0, q0 + nq) of it are ordered
+int gt_query_order(gt_ctx* ctx, const float* Qc, int64_t q0, int64_t nq, int need, int32_t* out_rows, float* out_thr0,
+                   int* active);
 int gt_choose_dp_prec(int d, int prec);  // padded feature count for a precision (0 if unsupported)
 int gt_select_bq(int dp);  // query rows per workgroup
 int gt_select_bn(int dp);  // database rows per tile

@@ -603,7 +603,7 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
 template <int DP>
 __global__ __launch_bounds__(256) void assign_cells_kernel(const float* __restrict__ Yc, const float* __restrict__ Yl,
                                                            const float* __restrict__ hl, const int64_t q0,
-                                                           const int32_t nq, const int32_t L,
+                                                           const int32_t nq, const int32_t L, const int32_t need,
                                                            uint32_t* __restrict__ cell, float* __restrict__ thr0) {
     constexpr int RW = DP / 2;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, li = lane & 31, h = lane >> 5;
@@ -614,8 +614,8 @@ __global__ __launch_bounds__(256) void assign_cells_kernel(const float* __restri
     float best = -INFINITY;
     uint32_t bidx = 0;
     // gm[e]: best score among the landmarks that land in accumulator slot e of this lane - 16 disjoint sets of
-    // database rows, so at least 16 rows score >= min(gm): a valid (if loose, ~rank n/100) starting threshold for a
-    // top-16-or-more selection over the same scores (single-chain arithmetic, same seeds, same chain order)
+    // database rows, so at least 16 rows score >= min(gm) (32 with the other half-wave's sets): a valid (if loose,
+    // ~rank n/100) starting threshold for a selection of the `need` <= 32 best over the same scores (single-chain arithmetic, same seeds, same chain order)
     float gm[16];
 #pragma unroll
     for (int e = 0; e < 16; ++e) gm[e] = -INFINITY;
@@ -643,7 +643,9 @@ __global__ __launch_bounds__(256) void assign_cells_kernel(const float* __restri
     float gmin = gm[0];
 #pragma unroll
     for (int e = 1; e < 16; ++e) gmin = fminf(gmin, gm[e]);
-    gmin = fmaxf(gmin, __shfl_xor(gmin, 32));   // either half-wave's 16 sets will do
+    // need <= 16: either half-wave's 16 sets will do (take the tighter); need <= 32: all 32 sets of the two halves
+    const float gother = __shfl_xor(gmin, 32);
+    gmin = need <= 16 ? fmaxf(gmin, gother) : fminf(gmin, gother);
     const float ob = __shfl_xor(best, 32);
     const uint32_t oi = __shfl_xor(bidx, 32);
     if (ob > best || (ob == best && oi < bidx)) bidx = oi;
@@ -705,9 +707,9 @@ int launch_dp(gt_ctx* ctx, const SelectArgs& a) {
 #if GT_SEL_PREC == 2 && !GT_SEL_QT1
 int GT_CAT3(gt_launch_assign_cells_p, GT_SEL_PREC, _dp, GT_SEL_DP)(gt_ctx* ctx, const float* Yc, const float* Yl,
                                                                   const float* hl, int64_t q0, int32_t nq, int32_t L,
-                                                                  uint32_t* cell, float* thr0) {
+                                                                  int32_t need, uint32_t* cell, float* thr0) {
     hipLaunchKernelGGL(assign_cells_kernel<GT_SEL_DP>, dim3((unsigned)ceil_div64(nq, 128)), dim3(256), 0, ctx->stream, Yc,
-                       Yl, hl, q0, nq, L, cell, thr0);
+                       Yl, hl, q0, nq, L, need, cell, thr0);
     GT_HIP(ctx, hipGetLastError());
     return GT_OK;
 }

@@ -35,10 +35,11 @@ __global__ __launch_bounds__(256) void iota_rows_kernel(const int64_t q0, const 
 
 }  // namespace
 
-int gt_query_order(gt_ctx* ctx, int64_t q0, int64_t nq, int32_t* out_rows, float* out_thr0, int* active) {
+int gt_query_order(gt_ctx* ctx, const float* Qc, int64_t q0, int64_t nq, int need, int32_t* out_rows, float* out_thr0,
+                   int* active) {
     *active = 0;
     const int64_t kMinRows = ctx->order_min_rows;   // below this the whole launch is a few workgroup rounds
-    if (!ctx->query_order || ctx->prec != 1 || ctx->fast_mode == 0 || !ctx->Yc.p || nq < kMinRows || ctx->n < std::max<int64_t>(kMinRows, 64))
+    if (!ctx->query_order || ctx->prec != 1 || ctx->fast_mode == 0 || !ctx->Yc.p || !Qc || nq < kMinRows || ctx->n < std::max<int64_t>(kMinRows, 64))
         return GT_OK;
     const int rw = ctx->DP / 2;   // dwords per row of the compact copy
     int L = int(std::min<int64_t>(std::min<int64_t>(4096, ctx->n / 32 * 32), std::max<int64_t>(64, (ctx->n / std::max(ctx->order_cell_rows, 32)) / 32 * 32)));
@@ -53,8 +54,8 @@ int gt_query_order(gt_ctx* ctx, int64_t q0, int64_t nq, int32_t* out_rows, float
     GT_HIP(ctx, hipGetLastError());
     uint32_t* cell = ctx->order_cell.as<uint32_t>();
     uint32_t* cell_sorted = cell + nq;
-    GT_TRY(gt_launch_assign_cells(ctx, ctx->DP, ctx->Yc.as<float>(), ctx->land_Y.as<float>(), ctx->land_h.as<float>(), q0,
-                                  int32_t(nq), L, cell, out_thr0));
+    GT_TRY(gt_launch_assign_cells(ctx, ctx->DP, Qc, ctx->land_Y.as<float>(), ctx->land_h.as<float>(), q0,
+                                  int32_t(nq), L, need, cell, out_thr0));
     hipLaunchKernelGGL(iota_rows_kernel, dim3((unsigned)ceil_div64(nq, 256)), dim3(256), 0, ctx->stream, q0, nq,
                        ctx->order_rows.as<int32_t>());
     GT_HIP(ctx, hipGetLastError());

@@ -295,3 +295,20 @@ def test_query_order_does_not_change_results():
     d_or, i_or = oracle.kneighbors(X, X[3000:3256], 20)
     assert np.array_equal(res["auto_block"][1][:256], i_or)
     assert np.array_equal(res["auto"][1][3000:3256], i_or)
+
+
+def test_query_order_for_external_queries_and_deeper_tables():
+    """external query matrices are grouped the same way (cells of the bound points); tables of up to 32 neighbours
+    start from the landmark bound, deeper ones from -inf - results identical either way"""
+    X = make_mix(36000, 20, 5)
+    Y = make_mix(34000, 20, 6)
+    res = {}
+    for mode in ("off", "auto"):
+        ctx = _hip_ctx_with(query_order=mode)
+        ctx.set_points(X)
+        res[mode] = [ctx.knn_search(k, Y=Y) for k in (10, 30, 50)] + [ctx.knn_search(30)]
+        ctx.close()
+    for (d0, i0, _), (d1, i1, _) in zip(res["off"], res["auto"]):
+        assert np.array_equal(i0, i1) and np.array_equal(d0, d1)
+    d_or, i_or = oracle.kneighbors(X, Y[:200], 30)
+    assert np.array_equal(res["auto"][1][1][:200], i_or)
