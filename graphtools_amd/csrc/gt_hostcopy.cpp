@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <atomic>
 #include <mutex>
+#include <system_error>
 #include <thread>
 
 #include "gt_common.h"
@@ -99,10 +100,17 @@ int pipelined_d2h(gt_ctx* ctx, void* dst, const void* src, size_t bytes) {
     std::atomic<int> err(0);
     std::thread th[kMaxLanes];
     const int nl = int(std::min<size_t>(size_t(kLanes), (bytes + kSlotBytes - 1) / kSlotBytes));
-    for (int l = 0; l < nl; ++l)
-        th[l] = std::thread(lane_d2h, ctx->device, &p->lanes[l], l, static_cast<char*>(dst),
-                            static_cast<const char*>(src), bytes, &err);
-    for (int l = 0; l < nl; ++l) th[l].join();
+    int started = 0;
+    try {
+        for (; started < nl; ++started)
+            th[started] = std::thread(lane_d2h, ctx->device, &p->lanes[started], started, static_cast<char*>(dst),
+                                      static_cast<const char*>(src), bytes, &err);
+    } catch (const std::system_error&) {
+        // the process cannot start another thread: this thread takes over the lanes that did not get one
+        for (int l = started; l < nl; ++l)
+            lane_d2h(ctx->device, &p->lanes[l], l, static_cast<char*>(dst), static_cast<const char*>(src), bytes, &err);
+    }
+    for (int l = 0; l < started; ++l) th[l].join();
     if (err.load() != 0) {
         ctx->set_error(std::string("pipelined host copy: ") + hipGetErrorString(hipError_t(err.load())));
         return GT_E_HIP;
