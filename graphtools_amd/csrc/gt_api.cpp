@@ -153,14 +153,14 @@ int gt_set_points(gt_ctx* ctx, const void* X, int64_t n, int32_t d, int32_t dtyp
     ctx->DP = gt_choose_dp_prec(d, ctx->prec);
     ctx->wide = false;
     ctx->dsel = 0;
-    if (ctx->DP == 0 && ctx->metric == 0 && d <= 2048) {   // the float64 stages keep one row per wave in LDS (64 KB)
+    if (ctx->DP == 0 && d <= 2048) {   // the float64 stages keep one row per wave in LDS (64 KB)
         // more features than the candidate kernels hold: filter on the 128 columns of largest variance (gt_common.h)
         ctx->wide = true;
         ctx->DP = 128;
         GT_TRY(gt_select_columns(ctx, 128));
     }
     if (ctx->DP == 0) {
-        // cosine metric on wide data: the exact dense path and landmark assignment still work on the raw points
+        // more than 2048 features: the exact dense path and landmark assignment still work on the raw points
         ctx->n_pad = 0;
         GT_HIP(ctx, ctx->xn.reserve(size_t(n) * sizeof(double)));
         GT_HIP(ctx, ctx->ymax.reserve(sizeof(double)));

@@ -170,6 +170,13 @@ __global__ __launch_bounds__(256) void row_norm_kernel(const T* __restrict__ X, 
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
     if ((threadIdx.x & 63) == 0 && ymax2_bits) atomicMax(ymax2_bits, (unsigned long long)__double_as_longlong(m));
+    if (ymax2_bits) {
+        // [1]: the largest FULL squared norm (differs from [0] for wide data; the cosine bounds need it)
+        double mf = (r < n) ? acc : 0.0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mf = fmax(mf, __shfl_xor(mf, o));
+        if ((threadIdx.x & 63) == 0) atomicMax(ymax2_bits + 1, (unsigned long long)__double_as_longlong(mf));
+    }
     if (lomax2_bits) {
         double l = (r < n) ? lo2 : 0.0;
 #pragma unroll
@@ -237,7 +244,7 @@ int gt_prep_matrix(gt_ctx* ctx, const void* Xdev, int64_t n, int d, int dtype, i
                    double* xn, float* hneg, double* ymax2, int prec, double sc, double* lomax2, void* Yc,
                    const int32_t* sel, int dsel, double* xn_sel) {
     const int dw = sel ? dsel : (d < DP || DP == 0 ? d : DP);
-    if (ymax2) GT_HIP(ctx, hipMemsetAsync(ymax2, 0, sizeof(double), ctx->stream));
+    if (ymax2) GT_HIP(ctx, hipMemsetAsync(ymax2, 0, 2 * sizeof(double), ctx->stream));   // [0] scored norms, [1] full norms
     if (lomax2) GT_HIP(ctx, hipMemsetAsync(lomax2, 0, sizeof(double), ctx->stream));
     if (Yp && prec == 1) {
         const int64_t total = n_pad * DP;

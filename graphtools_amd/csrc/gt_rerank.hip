@@ -81,12 +81,14 @@ __global__ __launch_bounds__(256) void rerank_kernel(const T* __restrict__ X, co
     // qs, y2: the norms of what the candidate pass scored (a coordinate subset for wide data: its squared distance
     // is a lower bound of the full one, so the bounds below hold for the full distance as well)
     const double qs = qn_sel[q0 + q];
-    const double y2 = *ymax2p;
+    const double y2 = ymax2p[0];    // largest squared norm over the scored columns
+    const double y2f = ymax2p[1];   // and over all columns
     const double e = gt_err_bound(err, qs, y2);
     // euclidean: d2 = |x|^2 - 2 s ; cosine: D = 1 - x.y = 1 - s - |y|^2/2 >= 1 - s - ymax^2/2
     auto bound_of_score = [&](float score) {
         const double sv = double(score) * err.inv_sc2;
-        const double b = (metric == 1) ? (1.0 - (sv + e) - 0.5 * y2) : (qs - 2.0 * (sv + e));
+        // cosine: D = 1 - x.y, x.y = x_S.y_S + x_R.y_R <= (s + |y_S|^2/2) + (|x_R|^2 + |y_R|^2)/2  (S: scored columns)
+        const double b = (metric == 1) ? (1.0 - (sv + e) - 0.5 * (qnq - qs) - 0.5 * y2f) : (qs - 2.0 * (sv + e));
         return b - 1e-9 * (qs + y2);   // float64 rounding of the quantities above, with a wide margin
     };
     double lb = INFINITY;
@@ -297,16 +299,18 @@ __global__ __launch_bounds__(256) void fallback_thr_kernel(const int32_t* __rest
                                                            const int need_m, const int metric,
                                                            const double* __restrict__ cand_d2,
                                                            const double* __restrict__ qn,
+                                                           const double* __restrict__ qn_full,
                                                            const double* __restrict__ ymax2p, const ErrModel err,
                                                            int32_t* __restrict__ qrows, float* __restrict__ thr) {
     const int64_t f = int64_t(blockIdx.x) * 256 + threadIdx.x;
     if (f >= n_rows) return;
     const int64_t q = fb_rows[row_off + f];
     const double key = cand_d2[q * MP + (need_m - 1)] * (1.0 + 1e-12);
-    const double qnq = qn[q0 + q];
-    const double y2 = *ymax2p;
+    const double qnq = qn[q0 + q];   // norm over the scored columns
+    const double y2 = ymax2p[0];
     const double e = gt_err_bound(err, qnq, y2);
-    const double smin = (metric == 1) ? (1.0 - key - 0.5 * y2) : 0.5 * (qnq - key);
+    // every row with key' <= key scores at least smin (see bound_of_score in rerank_kernel)
+    const double smin = (metric == 1) ? (1.0 - key - 0.5 * (qn_full[q0 + q] - qnq) - 0.5 * ymax2p[1]) : 0.5 * (qnq - key);
     const double x = (smin - e - 1e-9 * (qnq + y2)) / err.inv_sc2;
     float t = float(x);
     if (double(t) >= x) t = nextafterf(t, -INFINITY);
@@ -505,7 +509,7 @@ int gt_launch_emit_knn(gt_ctx* ctx, const double* cand_d2, const uint32_t* cand_
 
 int gt_launch_fallback_thr(gt_ctx* ctx, const RerankArgs& a, int64_t n_rows, int64_t row_off, int32_t* qrows, float* thr) {
     hipLaunchKernelGGL(fallback_thr_kernel, dim3((unsigned)ceil_div64(n_rows, 256)), dim3(256), 0, ctx->stream, a.fb_rows,
-                       n_rows, row_off, a.q0, a.MP, a.need_m, a.metric, a.cand_d2, a.qn_sel, a.ymax2, a.err, qrows, thr);
+                       n_rows, row_off, a.q0, a.MP, a.need_m, a.metric, a.cand_d2, a.qn_sel, a.qn, a.ymax2, a.err, qrows, thr);
     GT_HIP(ctx, hipGetLastError());
     return GT_OK;
 }

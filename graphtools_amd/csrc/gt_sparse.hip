@@ -53,8 +53,8 @@ __device__ __forceinline__ double affinity(double dist, double bw, double decay)
 __global__ __launch_bounds__(256) void bandwidth_kernel(
     const int64_t nloc, const int64_t r0, const int MP, const int kprime, const int dtype, const int metric,
     const double* __restrict__ cand_d2,
-    const double* __restrict__ d2_lb, const double* __restrict__ qnorm, const int64_t qoff,
-    const double* __restrict__ ymax2p,
+    const double* __restrict__ d2_lb, const double* __restrict__ qnorm, const double* __restrict__ qnorm_full,
+    const int64_t qoff, const double* __restrict__ ymax2p,
     const ErrModel err, const double* __restrict__ bw_user, const int64_t bw_len, const double bw_scale,
     const int use_radius, const double radius_factor, double* __restrict__ bw_out, int32_t* __restrict__ rowsrc,
     int32_t* __restrict__ over_rows, uint32_t* __restrict__ over_count, float* __restrict__ rthr) {
@@ -76,10 +76,12 @@ __global__ __launch_bounds__(256) void bandwidth_kernel(
             over_rows[slot] = int32_t(qoff + i);
             src = int32_t(slot);
             const double qn = qnorm[qoff + i];
-            const double y2 = *ymax2p;
+            const double y2 = ymax2p[0];
             const double e = gt_err_bound(err, qn, y2);
-            // every row within the radius scores at least this much (scaled score units)
-            const double smin = (metric == 1) ? (1.0 - r2 - 0.5 * y2) : 0.5 * (qn - r2);
+            // every row within the radius scores at least this much (scaled score units; qn, y2: norms over the
+            // scored columns, the cosine bound also needs the full ones - see bound_of_score in rerank_kernel)
+            const double smin = (metric == 1) ? (1.0 - r2 - 0.5 * (qnorm_full[qoff + i] - qn) - 0.5 * ymax2p[1])
+                                              : 0.5 * (qn - r2);
             const double x = (smin - e - 1e-9 * (qn + y2)) / err.inv_sc2;
             float f = float(x);
             if (double(f) >= x) f = nextafterf(f, -INFINITY);
@@ -828,7 +830,7 @@ static int graph_begin_impl(gt_ctx* ctx, const gt_knn_params* params, int32_t wo
         StageSpan span(ctx, "affinity");
         hipLaunchKernelGGL(bandwidth_kernel, dim3((unsigned)ceil_div64(g->nloc, 256)), dim3(256), 0, ctx->stream, g->nloc,
                            g->r0, k->MP, kprime, ctx->dtype, ctx->metric, k->cand_d2.as<double>(), k->d2_lb.as<double>(),
-                           qn_bound, g->qoff, ctx->ymax.as<double>(), err_model, g->bw_user.as<double>(),
+                           qn_bound, g->qnorm, g->qoff, ctx->ymax.as<double>(), err_model, g->bw_user.as<double>(),
                            params->bandwidth_len, params->bandwidth_scale, use_radius ? 1 : 0, g->radius_factor,
                            g->bw.as<double>(), g->rowsrc.as<int32_t>(), g->over_rows.as<int32_t>(),
                            g->over_count.as<uint32_t>(), g->rthr.as<float>());

@@ -239,6 +239,30 @@ def test_cosine_metric_vs_oracle(dtype, rtol):
         assert abs(G.K.nnz - K0.nnz) <= 0.01 * K0.nnz
 
 
+@pytest.mark.parametrize("d,concentrated", [(200, True), (300, False)])
+def test_cosine_metric_on_wide_data_vs_oracle(d, concentrated):
+    """cosine distance with more than 128 features: candidates from the 128 columns of largest variance of the
+    normalised points (the bound pays for the norm mass outside them; repairs carry what it cannot prove)"""
+    rng = np.random.default_rng(31)
+    n = 3000
+    scales = (0.93 ** np.arange(d)) if concentrated else np.ones(d)
+    centres = rng.standard_normal((6, d)) * scales * 3
+    X = rng.standard_normal((n, d)) * scales + centres[rng.integers(6, size=n)] + 1.0
+    X = np.ascontiguousarray(X[:, rng.permutation(d)])
+    G = graphtools_amd.Graph(X, knn=9, decay=15, n_pca=None, distance="cosine", verbose=0)
+    K0, P0 = oracle.knn_graph(X, knn=9, decay=15, distance="cosine")
+    assert_csr_close(G.K, K0, rtol=1e-9)
+    assert_csr_close(G.P, P0, rtol=1e-9)
+    # kNN table and out-of-sample queries through the same bounds
+    Y = X[:200] * 1.5 + 0.01 * rng.standard_normal((200, d))
+    from sklearn.neighbors import NearestNeighbors   # the reference's engine (graphs.py:763-768), float64 brute force
+
+    d_or, i_or = NearestNeighbors(n_neighbors=12, metric="cosine", algorithm="brute").fit(X).kneighbors(Y)
+    dist, idx = G.knn_tree.kneighbors(Y, n_neighbors=12)
+    assert np.array_equal(idx, i_or)
+    np.testing.assert_allclose(dist, d_or, rtol=1e-9, atol=1e-14)
+
+
 @pytest.mark.parametrize("maker,kw", [(make_mix, {}), (make_gauss, {"knn": 8, "decay": 10}), (make_mix, {"decay": None})])
 def test_out_of_sample_extension(maker, kw):
     """build_kernel_to_data / extend_to_data / interpolate vs the oracle's restatement"""
