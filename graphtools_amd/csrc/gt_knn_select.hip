@@ -46,6 +46,11 @@
 #ifndef GT_SEL_DSFIRST
 #define GT_SEL_DSFIRST 1
 #endif
+// 1: (single chain, two query tiles per wave) the -|y|^2/2 seeds of a sub-tile are read from LDS once, into registers
+// that enter the first MFMA of both query tiles' chains as the C operand, instead of once per accumulator
+#ifndef GT_SEL_SEEDREG
+#define GT_SEL_SEEDREG 1
+#endif
 // development ablations (tools/build_variant.py; results are invalid when set):
 //   1 seeds not read from LDS   2 A fragments read once per tile   4 no staging / barrier after the first tile
 //   8 no admission test   16 staging but no barrier   32 barrier but no staging   64 stream 16 L2-resident tiles
@@ -162,6 +167,15 @@ template <int DP>
 __device__ __forceinline__ void mma_chain(const Frag<DP, 2>& a, const Frag<DP, 2>& b, f32x16& acc) {
 #pragma unroll
     for (int s = 0; s < DP / 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.hi[s], b.hi[s], acc, 0, 0, 0);
+}
+
+// same chain, started from a seed that stays intact (D != C on the first instruction)
+template <int DP>
+__device__ __forceinline__ void mma_chain_seeded(const Frag<DP, 2>& a, const Frag<DP, 2>& b, const f32x16& seed,
+                                                 f32x16& acc) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.hi[0], b.hi[0], seed, 0, 0, 0);
+#pragma unroll
+    for (int s = 1; s < DP / 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.hi[s], b.hi[s], acc, 0, 0, 0);
 }
 
 // Append store that hipcc does not track: a compiler-visible store makes hipcc park the wave on
@@ -459,7 +473,24 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
         if (__ballot((PA_)[15] > tq_)) GT_ADMIT_ONE(PA_, 15, PSB_, PQT_);                                  \
         if (prof) { t_adm += __builtin_readcyclecounter() - ts_; n_adm += 1; }                             \
     }
-        GT_SEED(0);
+        constexpr bool SEEDREG = GT_SEL_SEEDREG && PREC == 2 && QT == 2;
+        constexpr int NACC = SEEDREG ? 2 : 3;
+        f32x16 seedr;
+#define GT_SEEDR(SB_)                                                                                      \
+    {                                                                                                      \
+        _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) {                                                 \
+            const float4 hv_ = *reinterpret_cast<const float4*>(hb + (SB_) * 32 + 8 * g_ + 4 * h);         \
+            seedr[4 * g_ + 0] = hv_.x;                                                                     \
+            seedr[4 * g_ + 1] = hv_.y;                                                                     \
+            seedr[4 * g_ + 2] = hv_.z;                                                                     \
+            seedr[4 * g_ + 3] = hv_.w;                                                                     \
+        }                                                                                                  \
+    }
+        if constexpr (SEEDREG) {
+            GT_SEEDR(0);
+        } else {
+            GT_SEED(0);
+        }
 #pragma unroll
         for (int u = 0; u <= NU; ++u) {
             const int sb = u / QT, qt = u % QT;              // the unit whose chain is issued now (u < NU)
@@ -471,14 +502,19 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
             }
             if (u < NU) {
                 if (!(GT_SEL_EXP & 2) && qt == 0 && sb + 1 < NSUB) afr[(sb + 1) & 1].load(tb + ((sb + 1) * 32 + li) * LDP, h, aswz);
-                if (u + 1 < NU) GT_SEED(u + 1);
-                mma_chain<DP>(afr[(GT_SEL_EXP & 2) ? 0 : (sb & 1)], bq[qt], accp[u % 3]);
+                if constexpr (SEEDREG) {
+                    mma_chain_seeded<DP>(afr[sb & 1], bq[qt], seedr, accp[u % NACC]);
+                    if (qt == QT - 1 && sb + 1 < NSUB) GT_SEEDR(sb + 1);   // behind the last reader of this sub-tile's seeds
+                } else {
+                    if (u + 1 < NU) GT_SEED(u + 1);
+                    mma_chain<DP>(afr[(GT_SEL_EXP & 2) ? 0 : (sb & 1)], bq[qt], accp[u % 3]);
+                }
             }
             if (u > 0) {
                 // one predicate per lane: the largest of its 16 scores against the query's threshold (a v_max3 tree
                 // and one compare in the MFMA issue gaps; the per-element compares are redone on the cold admission path)
                 const float tq = (GT_SEL_EXP & 8) ? INFINITY : thr[pqt];
-                const f32x16& pa = accp[(u - 1) % 3];
+                const f32x16& pa = accp[(u - 1) % NACC];
                 if (GT_SEL_EXP & 8) asm volatile("" ::"v"(pa));   // keep the matrix work alive
 #pragma unroll
                 for (int t3 = 0; t3 < 5; ++t3) mx[t3] = fmaxf(fmaxf(pa[3 * t3], pa[3 * t3 + 1]), pa[3 * t3 + 2]);
@@ -503,7 +539,7 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
                 }
             }
 #endif
-            if (u > 0) GT_ADMIT(accp[(u - 1) % 3], any_hit, mx, psb, pqt);
+            if (u > 0) GT_ADMIT(accp[(u - 1) % NACC], any_hit, mx, psb, pqt);
         }
         if (MODE == 0) {
             // ---- list maintenance: lane (li, h) owns half h of query (qt, li) ----
