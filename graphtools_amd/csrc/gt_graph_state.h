@@ -11,6 +11,15 @@ struct Triplet {
 };
 static_assert(sizeof(Triplet) == 16, "triplet layout");
 
+// entry of a union row (own entries tagged 0, received ones tagged 1): one 16-byte record, so that the scattered
+// writes of the received part touch one cache line per entry
+struct UEntry {
+    uint32_t key;   // (column << 1) | tag
+    uint32_t pad;
+    double val;
+};
+static_assert(sizeof(UEntry) == 16, "union entry layout");
+
 struct GraphState {
     gt_knn_params p{};
     std::vector<double> bw_host;

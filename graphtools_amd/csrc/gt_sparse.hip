@@ -310,8 +310,7 @@ __global__ __launch_bounds__(256) void scan_add_kernel(int64_t* __restrict__ out
 __global__ __launch_bounds__(256) void fill_rows_kernel(
     const int64_t nloc, const int MP, const double* __restrict__ cand_k, const uint32_t* __restrict__ cand_j,
     const int32_t* __restrict__ rowsrc, const uint64_t* __restrict__ rlists, const uint32_t* __restrict__ rcounts,
-    const int32_t rcap, const double* __restrict__ rK, const int64_t* __restrict__ off, uint32_t* __restrict__ Ukey,
-    double* __restrict__ Uval) {
+    const int32_t rcap, const double* __restrict__ rK, const int64_t* __restrict__ off, UEntry* __restrict__ U) {
     const int lane = threadIdx.x & 63;
     const int w = threadIdx.x >> 6;
     const int64_t i = int64_t(blockIdx.x) * 4 + w;
@@ -339,10 +338,7 @@ __global__ __launch_bounds__(256) void fill_rows_kernel(
         const bool keep = v >= 0.0;
         int total;
         const int p = wave_prefix_count(keep, lane, total);
-        if (keep) {
-            Ukey[pos + p] = (j << 1);
-            Uval[pos + p] = v;
-        }
+        if (keep) U[pos + p] = UEntry{j << 1, 0u, v};
         pos += total;
     }
 }
@@ -352,13 +348,12 @@ __global__ __launch_bounds__(256) void fill_recv_kernel(const Triplet* __restric
                                                         const int64_t r0, const int64_t* __restrict__ off,
                                                         const int32_t* __restrict__ lenN,
                                                         const int32_t* __restrict__ slot,
-                                                        uint32_t* __restrict__ Ukey, double* __restrict__ Uval) {
+                                                        UEntry* __restrict__ U) {
     for (int64_t t = int64_t(blockIdx.x) * 256 + threadIdx.x; t < n_recv; t += int64_t(gridDim.x) * 256) {
         const Triplet tr = recv[t];
         const int64_t il = int64_t(tr.row) - r0;
         const int64_t pos = off[il] + lenN[il] + slot[t];
-        Ukey[pos] = (tr.col << 1) | 1u;
-        Uval[pos] = tr.val;
+        U[pos] = UEntry{(tr.col << 1) | 1u, 0u, tr.val};
     }
 }
 
@@ -420,15 +415,15 @@ __device__ __forceinline__ int merge_sorted_regs(const uint64_t (&hi)[NT], const
 // one 64-bit word - (column, tag) above the entry's position in the row - so the bitonic network moves half the
 // registers of a key/value sort; the values are fetched by position afterwards (the row was read a moment ago).
 template <int NT>
-__device__ __forceinline__ int sort_merge_row(const uint32_t* __restrict__ Uk, const double* __restrict__ Uv,
-                                              const int L, const int lane, const int symm, const double theta,
+__device__ __forceinline__ int sort_merge_row(const UEntry* __restrict__ U, const int L, const int lane, const int symm,
+                                              const double theta,
                                               uint32_t* __restrict__ Vk, double* __restrict__ Vv) {
     uint64_t pk[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int p = t * 64 + lane;
         // descending sort of the complement = ascending sort of the key; 0 (no entry) sorts last
-        pk[t] = (p < L) ? ~((uint64_t(Uk[p]) << 16) | uint64_t(p)) : 0ull;
+        pk[t] = (p < L) ? ~((uint64_t(U[p].key) << 16) | uint64_t(p)) : 0ull;
     }
     wave_bitonic_desc<NT>(pk, lane);
     uint64_t hi[NT], lo[NT];
@@ -439,7 +434,7 @@ __device__ __forceinline__ int sort_merge_row(const uint32_t* __restrict__ Uk, c
         if (pk[t] != 0ull) {
             const uint64_t x = ~pk[t];
             hi[t] = x >> 16;
-            lo[t] = (uint64_t)__double_as_longlong(Uv[x & 0xFFFFull]);
+            lo[t] = (uint64_t)__double_as_longlong(U[x & 0xFFFFull].val);
         }
     }
     return merge_sorted_regs<NT>(hi, lo, lane, symm, theta, Vk, Vv);
@@ -449,7 +444,7 @@ constexpr int kBigRow = 512;    // longer rows go to sort_merge_long_kernel
 constexpr int kHugeRow = 2048;  // and beyond that to the global-memory sort (big_sort_kernel)
 
 __global__ __launch_bounds__(256) void sort_merge_kernel(const int64_t nloc, const int64_t* __restrict__ off,
-                                                         const uint32_t* __restrict__ Ukey, const double* __restrict__ Uval,
+                                                         const UEntry* __restrict__ Uall,
                                                          const int symm, const double theta, uint32_t* __restrict__ Vkey,
                                                          double* __restrict__ Vval, int32_t* __restrict__ outlen,
                                                          int32_t* __restrict__ bigrows, uint32_t* __restrict__ bigcount) {
@@ -467,27 +462,26 @@ __global__ __launch_bounds__(256) void sort_merge_kernel(const int64_t nloc, con
         return;
     }
     const int L = int(L64);
-    const uint32_t* Uk = Ukey + o0;
-    const double* Uv = Uval + o0;
+    const UEntry* U = Uall + o0;
     uint32_t* Vk = Vkey + o0;
     double* Vv = Vval + o0;
     int c;
     if (L <= 64)
-        c = sort_merge_row<1>(Uk, Uv, L, lane, symm, theta, Vk, Vv);
+        c = sort_merge_row<1>(U, L, lane, symm, theta, Vk, Vv);
     else if (L <= 128)
-        c = sort_merge_row<2>(Uk, Uv, L, lane, symm, theta, Vk, Vv);
+        c = sort_merge_row<2>(U, L, lane, symm, theta, Vk, Vv);
     else if (L <= 256)
-        c = sort_merge_row<4>(Uk, Uv, L, lane, symm, theta, Vk, Vv);
+        c = sort_merge_row<4>(U, L, lane, symm, theta, Vk, Vv);
     else
-        c = sort_merge_row<8>(Uk, Uv, L, lane, symm, theta, Vk, Vv);
+        c = sort_merge_row<8>(U, L, lane, symm, theta, Vk, Vv);
     if (lane == 0) outlen[i] = c;
 }
 
 // Rows of kBigRow < L <= kHugeRow entries (hub rows of the transpose): same register sort with 16 / 32 keys per lane in
 // a kernel of its own, so that its register budget does not cut the occupancy of the common case.  Persistent waves
 // walk the list sort_merge_kernel left in bigrows; what is longer still is compacted to the front of hugerows.
-__global__ __launch_bounds__(64) void sort_merge_long_kernel(const int64_t* __restrict__ off, const uint32_t* __restrict__ Ukey,
-                                                             const double* __restrict__ Uval, const int symm,
+__global__ __launch_bounds__(64) void sort_merge_long_kernel(const int64_t* __restrict__ off, const UEntry* __restrict__ U,
+                                                             const int symm,
                                                              const double theta, uint32_t* __restrict__ Vkey,
                                                              double* __restrict__ Vval, int32_t* __restrict__ outlen,
                                                              const int32_t* __restrict__ bigrows,
@@ -504,15 +498,15 @@ __global__ __launch_bounds__(64) void sort_merge_long_kernel(const int64_t* __re
             continue;
         }
         const int L = int(L64);
-        const int c = (L <= 1024) ? sort_merge_row<16>(Ukey + o0, Uval + o0, L, lane, symm, theta, Vkey + o0, Vval + o0)
-                                  : sort_merge_row<32>(Ukey + o0, Uval + o0, L, lane, symm, theta, Vkey + o0, Vval + o0);
+        const int c = (L <= 1024) ? sort_merge_row<16>(U + o0, L, lane, symm, theta, Vkey + o0, Vval + o0)
+                                  : sort_merge_row<32>(U + o0, L, lane, symm, theta, Vkey + o0, Vval + o0);
         if (lane == 0) outlen[i] = c;
     }
 }
 
 // huge rows: bitonic sort in global scratch (one workgroup per row), then a separate merge kernel
 __global__ __launch_bounds__(1024) void big_sort_kernel(const int32_t* __restrict__ bigrows, const int64_t* __restrict__ off,
-                                                        const uint32_t* __restrict__ Ukey, const double* __restrict__ Uval,
+                                                        const UEntry* __restrict__ U,
                                                         const int64_t* __restrict__ scratch_off,
                                                         uint32_t* __restrict__ Sk, double* __restrict__ Sv) {
     const int64_t i = bigrows[blockIdx.x];
@@ -523,8 +517,8 @@ __global__ __launch_bounds__(1024) void big_sort_kernel(const int32_t* __restric
     uint32_t* k = Sk + s0;
     double* v = Sv + s0;
     for (int64_t p = threadIdx.x; p < P; p += 1024) {
-        k[p] = p < L ? Ukey[o0 + p] : 0xFFFFFFFFu;
-        v[p] = p < L ? Uval[o0 + p] : 0.0;
+        k[p] = p < L ? U[o0 + p].key : 0xFFFFFFFFu;
+        v[p] = p < L ? U[o0 + p].val : 0.0;
     }
     __syncthreads();
     for (int64_t kk = 2; kk <= P; kk <<= 1) {
@@ -991,8 +985,7 @@ extern "C" int gt_graph_finish(gt_ctx* ctx, const void* recv_buf_dev, int64_t n_
         GT_TRY(rc);
         g->nnz0 = total_u - n_recv;
         HostTrace tr_u(ctx, "finish: fill + merge");
-        GT_HIP(ctx, g->Ukey.reserve(size_t(total_u) * sizeof(uint32_t)));
-        GT_HIP(ctx, g->Uval.reserve(size_t(total_u) * sizeof(double)));
+        GT_HIP(ctx, g->Ukey.reserve(size_t(total_u) * sizeof(UEntry)));   // union rows
         GT_HIP(ctx, g->Vkey.reserve(size_t(total_u) * sizeof(uint32_t)));
         GT_HIP(ctx, g->Vval.reserve(size_t(total_u) * sizeof(double)));
         GT_HIP(ctx, g->outlen.reserve(size_t(nloc) * sizeof(int32_t)));
@@ -1003,19 +996,18 @@ extern "C" int gt_graph_finish(gt_ctx* ctx, const void* recv_buf_dev, int64_t n_
         hipLaunchKernelGGL(fill_rows_kernel, dim3((unsigned)ceil_div64(nloc, 4)), dim3(256), 0, ctx->stream, nloc, k->MP,
                            k->cand_d2.as<double>(), k->cand_j.as<uint32_t>(), g->rowsrc.as<int32_t>(),
                            g->rlists.as<uint64_t>(), g->rcounts.as<uint32_t>(), g->rcap, g->rK.as<double>(),
-                           g->off.as<int64_t>(), g->Ukey.as<uint32_t>(), g->Uval.as<double>());
+                           g->off.as<int64_t>(), g->Ukey.as<UEntry>());
         if (n_recv > 0) {
             int64_t blocks = std::min<int64_t>(ceil_div64(n_recv, 256), 16384);
             hipLaunchKernelGGL(fill_recv_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, recv, n_recv, g->r0,
-                               g->off.as<int64_t>(), g->lenN.as<int32_t>(), g->cursor.as<int32_t>(), g->Ukey.as<uint32_t>(),
-                               g->Uval.as<double>());
+                               g->off.as<int64_t>(), g->lenN.as<int32_t>(), g->cursor.as<int32_t>(), g->Ukey.as<UEntry>());
         }
         hipLaunchKernelGGL(sort_merge_kernel, dim3((unsigned)ceil_div64(nloc, 4)), dim3(256), 0, ctx->stream, nloc,
-                           g->off.as<int64_t>(), g->Ukey.as<uint32_t>(), g->Uval.as<double>(), g->p.kernel_symm, g->p.theta,
+                           g->off.as<int64_t>(), g->Ukey.as<UEntry>(), g->p.kernel_symm, g->p.theta,
                            g->Vkey.as<uint32_t>(), g->Vval.as<double>(), g->outlen.as<int32_t>(), g->bigrows.as<int32_t>(),
                            g->bigcount.as<uint32_t>());
         hipLaunchKernelGGL(sort_merge_long_kernel, dim3(4096), dim3(64), 0, ctx->stream, g->off.as<int64_t>(),
-                           g->Ukey.as<uint32_t>(), g->Uval.as<double>(), g->p.kernel_symm, g->p.theta, g->Vkey.as<uint32_t>(),
+                           g->Ukey.as<UEntry>(), g->p.kernel_symm, g->p.theta, g->Vkey.as<uint32_t>(),
                            g->Vval.as<double>(), g->outlen.as<int32_t>(), g->bigrows.as<int32_t>(), g->bigcount.as<uint32_t>(),
                            g->hugerows.as<int32_t>(), g->bigcount.as<uint32_t>() + 1);
         GT_HIP(ctx, hipGetLastError());
@@ -1055,7 +1047,7 @@ extern "C" int gt_graph_finish(gt_ctx* ctx, const void* recv_buf_dev, int64_t n_
             GT_HIP(ctx, g->bigscratch_k.reserve(size_t(soff[nbig]) * sizeof(uint32_t)));
             GT_HIP(ctx, g->bigscratch_v.reserve(size_t(soff[nbig]) * sizeof(double)));
             hipLaunchKernelGGL(big_sort_kernel, dim3(nbig), dim3(1024), 0, ctx->stream, g->hugerows.as<int32_t>(),
-                               g->off.as<int64_t>(), g->Ukey.as<uint32_t>(), g->Uval.as<double>(), soff_dev.as<int64_t>(),
+                               g->off.as<int64_t>(), g->Ukey.as<UEntry>(), soff_dev.as<int64_t>(),
                                g->bigscratch_k.as<uint32_t>(), g->bigscratch_v.as<double>());
             hipLaunchKernelGGL(big_merge_kernel, dim3(nbig), dim3(64), 0, ctx->stream, g->hugerows.as<int32_t>(),
                                g->off.as<int64_t>(), soff_dev.as<int64_t>(), g->bigscratch_k.as<uint32_t>(),
