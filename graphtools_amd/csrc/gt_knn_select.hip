@@ -46,7 +46,7 @@
 #ifndef GT_SEL_DSFIRST
 #define GT_SEL_DSFIRST 1
 #endif
-// 1: (single chain, two query tiles per wave) the -|y|^2/2 seeds of a sub-tile are read from LDS once, into registers
+// 1: (float16 back ends, two query tiles per wave) the -|y|^2/2 seeds of a sub-tile are read from LDS once, into registers
 // that enter the first MFMA of both query tiles' chains as the C operand, instead of once per accumulator
 #ifndef GT_SEL_SEEDREG
 #define GT_SEL_SEEDREG 1
@@ -165,6 +165,19 @@ __device__ __forceinline__ void mma_chain(const Frag<DP, 1>& a, const Frag<DP, 1
 
 template <int DP>
 __device__ __forceinline__ void mma_chain(const Frag<DP, 2>& a, const Frag<DP, 2>& b, f32x16& acc) {
+#pragma unroll
+    for (int s = 0; s < DP / 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.hi[s], b.hi[s], acc, 0, 0, 0);
+}
+
+// split-float16 chain started from a seed that stays intact (D != C on the first instruction)
+template <int DP>
+__device__ __forceinline__ void mma_chain_seeded(const Frag<DP, 1>& a, const Frag<DP, 1>& b, const f32x16& seed,
+                                                 f32x16& acc) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.lo[0], b.hi[0], seed, 0, 0, 0);
+#pragma unroll
+    for (int s = 1; s < DP / 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.lo[s], b.hi[s], acc, 0, 0, 0);
+#pragma unroll
+    for (int s = 0; s < DP / 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.hi[s], b.lo[s], acc, 0, 0, 0);
 #pragma unroll
     for (int s = 0; s < DP / 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.hi[s], b.hi[s], acc, 0, 0, 0);
 }
@@ -473,7 +486,7 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
         if (__ballot((PA_)[15] > tq_)) GT_ADMIT_ONE(PA_, 15, PSB_, PQT_);                                  \
         if (prof) { t_adm += __builtin_readcyclecounter() - ts_; n_adm += 1; }                             \
     }
-        constexpr bool SEEDREG = GT_SEL_SEEDREG && PREC == 2 && QT == 2;
+        constexpr bool SEEDREG = GT_SEL_SEEDREG && PREC >= 1 && QT == 2;
         constexpr int NACC = SEEDREG ? 2 : 3;
         f32x16 seedr;
 #define GT_SEEDR(SB_)                                                                                      \
