@@ -231,6 +231,10 @@ int gt_set_option(gt_ctx* ctx, const char* name, const char* value) {
         ctx->thr0_mode = std::atoi(value);
         return GT_OK;
     }
+    if (k == "select_nt8_max_need") {
+        ctx->nt8_max_need = std::min(112, std::max(1, std::atoi(value)));
+        return GT_OK;
+    }
     if (k == "select_narrow") {
         ctx->narrow_mode = v == "auto" ? -1 : std::atoi(value);
         return GT_OK;

@@ -132,6 +132,7 @@ struct gt_ctx {
     int32_t samp_trig = 0;    //   level 0: entries per half-list that trigger a cut (0: samp_keep / 2 + 24)
     int32_t samp2_level = 3;  //   second cut of the lists once 2^samp2_level / samp_stride of the tiles are seen (0: none)
     int32_t samp2_keep = 64;  //   to this many entries (at least 3 * samp_keep)
+    int32_t nt8_max_need = 88;  // tables of up to this many neighbours use the 128-entry list budget (else 512)
     int32_t narrow_mode = -1; // 128-row-workgroup candidate kernels: -1 auto (few query rows), 0 never, 1 whenever available
     int32_t dbg_select = 0;   // experiment switches forwarded to the candidate kernel (results invalid when set)
     int64_t n_pad = 0;   // rows of the working copy (multiple of the db tile)

@@ -56,14 +56,13 @@ static const double kFastFailFrac = 0.20;
 int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int need_m, double radius_key_factor) {
     if (ctx->n <= 0 || !ctx->X) GT_FAIL(ctx, GT_E_STATE, "no points bound (call gt_set_points first)");
     if (ctx->DP == 0)
-        GT_FAIL(ctx, GT_E_LIMIT, "kNN on the HIP path: n_features > 128 is supported for the euclidean metric up to 2048 "
-                                 "features (reduce with n_pca)");
+        GT_FAIL(ctx, GT_E_LIMIT, "kNN on the HIP path: more than 2048 features are not supported (reduce with n_pca)");
     if (need_m < 1 || int64_t(need_m) > ctx->n) GT_FAIL(ctx, GT_E_ARG, "k must be in [1, n_samples]");
     if (nq <= 0) GT_FAIL(ctx, GT_E_ARG, "no query rows");
     if (!ctx->knn) ctx->knn = new KnnWork();
     KnnWork* k = ctx->knn;
     int nt;
-    if (need_m <= 112)
+    if (need_m <= ctx->nt8_max_need)
         nt = 8;
     else if (need_m <= 448)
         nt = 32;

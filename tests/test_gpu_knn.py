@@ -102,6 +102,7 @@ def test_forced_exact_fallback(hip_ctx):
     the exhaustive float64 fallback must take over and still return the exact (d2, index) order."""
     rng = np.random.default_rng(3)
     X = rng.integers(0, 2, size=(1500, 10)).astype(np.float32)   # 1024 distinct points, many duplicates
+    hip_ctx.set_option("select_nt8_max_need", 112)   # the 128-entry list budget (512 entries would prove this table)
     hip_ctx.set_points(X)
     d, i, flags = hip_ctx.knn_search(96)
     assert flags & 4, "expected the exact fallback to trigger"
