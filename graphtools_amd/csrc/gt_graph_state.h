@@ -38,6 +38,7 @@ struct GraphState {
     double radius_factor = 0.0;
     // per-row
     DevBuf bw, bw_user, rowsrc, lenN, lenT, cursor, off, outlen, indptr, degree;
+    DevBuf tablen;   // int32 [nloc]: entries of the candidate-table row the affinity pass looked at
     // radius pass
     DevBuf over_rows, over_count, rthr, rlists, rcounts, rK, rmax;
     int64_t n_over = 0;

@@ -19,7 +19,7 @@
 void gt_free_graph_state(gt_ctx* ctx) {
     if (!ctx->graph) return;
     GraphState* g = ctx->graph;
-    for (DevBuf* b : {&g->bw, &g->bw_user, &g->rowsrc, &g->hugerows, &g->lenN, &g->lenT, &g->cursor, &g->off, &g->outlen, &g->indptr,
+    for (DevBuf* b : {&g->bw, &g->bw_user, &g->rowsrc, &g->hugerows, &g->tablen, &g->lenN, &g->lenT, &g->cursor, &g->off, &g->outlen, &g->indptr,
                       &g->degree, &g->over_rows, &g->over_count, &g->rthr, &g->rlists, &g->rcounts, &g->rK, &g->rmax,
                       &g->ownercnt, &g->ownerpos, &g->scan_tmp, &g->selfbuf, &g->splits_dev, &g->Ukey, &g->Uval, &g->Vkey, &g->Vval,
                       &g->bigrows, &g->bigcount, &g->bigscratch_k, &g->bigscratch_v, &g->bigsoff, &g->aniso_tmp, &g->scan_own,
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void affinity_kernel(
     const uint32_t* __restrict__ cand_n, const int32_t* __restrict__ rowsrc, const uint64_t* __restrict__ rlists,
     const uint32_t* __restrict__ rcounts, const int32_t rcap, double* __restrict__ rK, const double* __restrict__ bw,
     const double decay, const int binary, const double thresh, const int count_owners, const Splits sp,
-    int32_t* __restrict__ lenN, int32_t* __restrict__ ownercnt) {
+    int32_t* __restrict__ lenN, int32_t* __restrict__ ownercnt, int32_t* __restrict__ tablen) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int lane = threadIdx.x & 63;
     const int w = threadIdx.x >> 6;
@@ -144,8 +144,7 @@ __global__ __launch_bounds__(256) void affinity_kernel(
                 }
             }
         }
-        // slots beyond the eligible range are dropped
-        for (uint32_t e = n + lane; e < uint32_t(MP); e += 64) cand_d2[i * MP + e] = -1.0;
+        if (lane == 0) tablen[i] = int32_t(n);   // the consumers stop here: slots beyond the eligible range are not theirs
     } else {
         const T* xrow = Qm + (qoff + i) * int64_t(d);
         for (int k = lane; k < d; k += 64) xs[k] = double(xrow[k]);
@@ -189,7 +188,7 @@ __global__ __launch_bounds__(256) void emit_triplets_kernel(
     const int64_t nloc, const int64_t r0, const int MP, const double* __restrict__ cand_k,
     const uint32_t* __restrict__ cand_j, const int32_t* __restrict__ rowsrc, const uint64_t* __restrict__ rlists,
     const uint32_t* __restrict__ rcounts, const int32_t rcap, const double* __restrict__ rK, const Splits sp,
-    const int64_t* __restrict__ ownerpos, Triplet* __restrict__ out) {
+    const int64_t* __restrict__ ownerpos, const int32_t* __restrict__ tablen, Triplet* __restrict__ out) {
     const int lane = threadIdx.x & 63;
     const int w = threadIdx.x >> 6;
     const int64_t i = int64_t(blockIdx.x) * 4 + w;
@@ -198,7 +197,7 @@ __global__ __launch_bounds__(256) void emit_triplets_kernel(
     uint32_t n;
     const double* kv;
     if (src < 0) {
-        n = uint32_t(MP);
+        n = uint32_t(tablen[i]);
         kv = cand_k + i * MP;
     } else {
         n = rcounts[src];
@@ -310,7 +309,8 @@ __global__ __launch_bounds__(256) void scan_add_kernel(int64_t* __restrict__ out
 __global__ __launch_bounds__(256) void fill_rows_kernel(
     const int64_t nloc, const int MP, const double* __restrict__ cand_k, const uint32_t* __restrict__ cand_j,
     const int32_t* __restrict__ rowsrc, const uint64_t* __restrict__ rlists, const uint32_t* __restrict__ rcounts,
-    const int32_t rcap, const double* __restrict__ rK, const int64_t* __restrict__ off, UEntry* __restrict__ U) {
+    const int32_t rcap, const double* __restrict__ rK, const int64_t* __restrict__ off,
+    const int32_t* __restrict__ tablen, UEntry* __restrict__ U) {
     const int lane = threadIdx.x & 63;
     const int w = threadIdx.x >> 6;
     const int64_t i = int64_t(blockIdx.x) * 4 + w;
@@ -319,7 +319,7 @@ __global__ __launch_bounds__(256) void fill_rows_kernel(
     uint32_t n;
     const double* kv;
     if (src < 0) {
-        n = uint32_t(MP);
+        n = uint32_t(tablen[i]);
         kv = cand_k + i * MP;
     } else {
         n = rcounts[src];
@@ -700,7 +700,7 @@ void launch_affinity(gt_ctx* ctx, GraphState* g, KnnWork* k, int binary, double 
                        k->cand_j.as<uint32_t>(), k->cand_n.as<uint32_t>(), g->rowsrc.as<int32_t>(),
                        g->rlists.as<uint64_t>(), g->rcounts.as<uint32_t>(), g->rcap, g->rK.as<double>(),
                        g->bw.as<double>(), decay, binary, thresh, count_owners, make_splits(g), g->lenN.as<int32_t>(),
-                       g->ownercnt.as<int32_t>());
+                       g->ownercnt.as<int32_t>(), g->tablen.as<int32_t>());
 }
 
 }  // namespace
@@ -800,6 +800,7 @@ static int graph_begin_impl(gt_ctx* ctx, const gt_knn_params* params, int32_t wo
     GT_HIP(ctx, g->bw.reserve(size_t(g->nloc) * sizeof(double)));
     GT_HIP(ctx, g->rowsrc.reserve(size_t(g->nloc) * sizeof(int32_t)));
     GT_HIP(ctx, g->lenN.reserve(size_t(g->nloc) * sizeof(int32_t)));
+    GT_HIP(ctx, g->tablen.reserve(size_t(g->nloc) * sizeof(int32_t)));
     GT_HIP(ctx, g->lenT.reserve(size_t(g->nloc) * sizeof(int32_t)));
     GT_HIP(ctx, g->cursor.reserve(size_t(g->nloc) * sizeof(int32_t)));
     GT_HIP(ctx, g->over_rows.reserve(size_t(g->nloc) * sizeof(int32_t)));
@@ -943,7 +944,7 @@ extern "C" int gt_graph_emit(gt_ctx* ctx, void* send_buf_dev) {
     hipLaunchKernelGGL(emit_triplets_kernel, dim3((unsigned)ceil_div64(g->nloc, 4)), dim3(256), 0, ctx->stream, g->nloc,
                        g->r0, k->MP, k->cand_d2.as<double>(), k->cand_j.as<uint32_t>(), g->rowsrc.as<int32_t>(),
                        g->rlists.as<uint64_t>(), g->rcounts.as<uint32_t>(), g->rcap, g->rK.as<double>(), make_splits(g),
-                       g->ownerpos.as<int64_t>(), (Triplet*)send_buf_dev);
+                       g->ownerpos.as<int64_t>(), g->tablen.as<int32_t>(), (Triplet*)send_buf_dev);
     GT_HIP(ctx, hipGetLastError());
     GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return GT_OK;
@@ -996,7 +997,7 @@ extern "C" int gt_graph_finish(gt_ctx* ctx, const void* recv_buf_dev, int64_t n_
         hipLaunchKernelGGL(fill_rows_kernel, dim3((unsigned)ceil_div64(nloc, 4)), dim3(256), 0, ctx->stream, nloc, k->MP,
                            k->cand_d2.as<double>(), k->cand_j.as<uint32_t>(), g->rowsrc.as<int32_t>(),
                            g->rlists.as<uint64_t>(), g->rcounts.as<uint32_t>(), g->rcap, g->rK.as<double>(),
-                           g->off.as<int64_t>(), g->Ukey.as<UEntry>());
+                           g->off.as<int64_t>(), g->tablen.as<int32_t>(), g->Ukey.as<UEntry>());
         if (n_recv > 0) {
             int64_t blocks = std::min<int64_t>(ceil_div64(n_recv, 256), 16384);
             hipLaunchKernelGGL(fill_recv_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, recv, n_recv, g->r0,
@@ -1215,6 +1216,7 @@ extern "C" int gt_csr_graph_build(gt_ctx* ctx, int64_t n, const int64_t* indptr,
         if (e == hipSuccess) e = g->rcounts.reserve(size_t(n) * sizeof(uint32_t));
         if (e == hipSuccess) e = g->rowsrc.reserve(size_t(n) * sizeof(int32_t));
         if (e == hipSuccess) e = g->lenN.reserve(size_t(n) * sizeof(int32_t));
+        if (e == hipSuccess) e = g->tablen.reserve(size_t(n) * sizeof(int32_t));
         if (e == hipSuccess) e = g->lenT.reserve(size_t(n) * sizeof(int32_t));
         if (e == hipSuccess) e = g->cursor.reserve(size_t(n) * sizeof(int32_t));
         if (e == hipSuccess) e = g->ownercnt.reserve(size_t(n) * sizeof(int32_t));
