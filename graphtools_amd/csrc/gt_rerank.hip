@@ -166,10 +166,14 @@ __global__ __launch_bounds__(256) void rerank_kernel(const T* __restrict__ X, co
         }
     }
     if (!settled) wave_bitonic_asc_pair<NT2>(hi, lo, lane);
+    // slots [0, max(n_tab, need_m)) are defined (+inf keys past the last candidate); nobody reads further
+    const uint32_t n_def = n_tab > uint32_t(need_m) ? n_tab : uint32_t(need_m);
 #pragma unroll
     for (int u = 0; u < NT2; ++u) {
-        cand_d2[size_t(q) * MP + u * 64 + lane] = __longlong_as_double((long long)hi[u]);
-        cand_j[size_t(q) * MP + u * 64 + lane] = uint32_t(lo[u]);
+        if (uint32_t(u * 64) < n_def) {   // wave-uniform
+            cand_d2[size_t(q) * MP + u * 64 + lane] = __longlong_as_double((long long)hi[u]);
+            cand_j[size_t(q) * MP + u * 64 + lane] = uint32_t(lo[u]);
+        }
     }
     // d2 of the need_m-th neighbour (position need_m - 1)
     uint64_t sel = 0;
