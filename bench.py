@@ -86,7 +86,7 @@ def cpu_baseline(X, knn, decay, thresh, ctx, params_factory, budget_s=25.0):
         t0 = time.perf_counter()
         oracle.knn_kernel(X, knn=knn + 1, decay=decay, thresh=thresh, Y=X[:m], engine=engine)
         t_rows = time.perf_counter() - t0
-        if t_rows >= 0.4 * budget_s or m >= n or m >= 32768:
+        if t_rows >= 0.4 * budget_s or m >= n or m >= 65536:
             break
         m = min(n, m * (4 if t_rows < 0.1 * budget_s else 2))
     t_knn_full = t_rows * (n / m)
