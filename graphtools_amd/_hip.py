@@ -323,7 +323,12 @@ class Context:
                                                 ctypes.c_void_p(indices.data_ptr()), ctypes.c_void_p(indptr.data_ptr()), 1),
                     "gt_graph_fetch_csr")
         n_cols = self.n
-        return torch.sparse_csr_tensor(indptr, indices.to(torch.int64), data, size=(r1 - r0, n_cols))
+        # torch wants one index dtype for both arrays: narrow the short one (row pointers) when the counts allow it
+        if nnz < 2**31:
+            indptr = indptr.to(torch.int32)
+        else:
+            indices = indices.to(torch.int64)
+        return torch.sparse_csr_tensor(indptr, indices, data, size=(r1 - r0, n_cols))
 
     def graph_fetch_vec(self, which):
         r0, r1, _ = self.graph_rows()
