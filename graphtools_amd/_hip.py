@@ -72,6 +72,7 @@ _SIGNATURES = {
                                       _c.c_double, _c.c_double, _c.POINTER(_c.c_int64), _c.POINTER(_c.c_uint32)]),
     "gt_graph_rows": (_c.c_int, [_c.c_void_p, _c.POINTER(_c.c_int64), _c.POINTER(_c.c_int64), _c.POINTER(_c.c_int64)]),
     "gt_graph_fetch_csr": (_c.c_int, [_c.c_void_p, _c.c_int32, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int32]),
+    "gt_graph_spmm": (_c.c_int, [_c.c_void_p, _c.c_int32, _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int32]),
     "gt_graph_fetch_vec": (_c.c_int, [_c.c_void_p, _c.c_int32, _c.c_void_p, _c.c_int32]),
     "gt_graph_stats": (_c.c_int, [_c.c_void_p, _c.c_void_p]),
     "gt_dense_graph_build": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_int32,
@@ -329,6 +330,18 @@ class Context:
         else:
             indices = indices.to(torch.int64)
         return torch.sparse_csr_tensor(indptr, indices, data, size=(r1 - r0, n_cols))
+
+    def graph_spmm(self, which, X):
+        """(K or P)[owned rows] @ X on the device; X: host array [n_columns, c] (any float dtype, converted to
+        float64 like scipy would) -> host float64 array [owned rows, c]"""
+        r0, r1, _ = self.graph_rows()
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        squeeze = X.ndim == 1
+        if squeeze:
+            X = X[:, None]
+        out = np.empty((r1 - r0, X.shape[1]), dtype=np.float64)
+        self._check(self.lib.gt_graph_spmm(self.h, which, _ptr(X), X.shape[1], _ptr(out), 0), "gt_graph_spmm")
+        return out[:, 0] if squeeze else out
 
     def graph_fetch_vec(self, which):
         r0, r1, _ = self.graph_rows()

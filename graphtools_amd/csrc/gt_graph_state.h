@@ -26,6 +26,7 @@ struct GraphState {
     int world = 1, rank = 0;
     std::vector<int64_t> splits;
     int64_t r0 = 0, r1 = 0, nloc = 0;
+    int64_t n_total = 0;   // number of columns of K / P
     bool begun = false, finished = false;
     // query side: rows of the graph are rows [qoff, qoff + nloc) of Qmat (= the bound points unless `external`,
     // i.e. build_kernel_to_data(Y), graphs.py:819-982)
@@ -38,6 +39,7 @@ struct GraphState {
     double radius_factor = 0.0;
     // per-row
     DevBuf bw, bw_user, rowsrc, lenN, lenT, cursor, off, outlen, indptr, degree;
+    DevBuf spmm_in, spmm_out;   // staging of gt_graph_spmm for host operands
     DevBuf tablen;   // int32 [nloc]: entries of the candidate-table row the affinity pass looked at
     // radius pass
     DevBuf over_rows, over_count, rthr, rlists, rcounts, rK, rmax;

@@ -19,7 +19,7 @@
 void gt_free_graph_state(gt_ctx* ctx) {
     if (!ctx->graph) return;
     GraphState* g = ctx->graph;
-    for (DevBuf* b : {&g->bw, &g->bw_user, &g->rowsrc, &g->hugerows, &g->tablen, &g->lenN, &g->lenT, &g->cursor, &g->off, &g->outlen, &g->indptr,
+    for (DevBuf* b : {&g->bw, &g->bw_user, &g->rowsrc, &g->hugerows, &g->tablen, &g->spmm_in, &g->spmm_out, &g->lenN, &g->lenT, &g->cursor, &g->off, &g->outlen, &g->indptr,
                       &g->degree, &g->over_rows, &g->over_count, &g->rthr, &g->rlists, &g->rcounts, &g->rK, &g->rmax,
                       &g->ownercnt, &g->ownerpos, &g->scan_tmp, &g->selfbuf, &g->splits_dev, &g->Ukey, &g->Uval, &g->Vkey, &g->Vval,
                       &g->bigrows, &g->bigcount, &g->bigscratch_k, &g->bigscratch_v, &g->bigsoff, &g->aniso_tmp, &g->scan_own,
@@ -747,6 +747,7 @@ static int graph_begin_impl(gt_ctx* ctx, const gt_knn_params* params, int32_t wo
     g->r0 = row_splits[rank];
     g->r1 = row_splits[rank + 1];
     g->nloc = g->r1 - g->r0;
+    g->n_total = ctx->n;   // columns: the bound points
     g->begun = false;
     g->finished = false;
     g->external = external;
@@ -1198,6 +1199,7 @@ extern "C" int gt_csr_graph_build(gt_ctx* ctx, int64_t n, const int64_t* indptr,
     g->r0 = 0;
     g->r1 = n;
     g->nloc = n;
+    g->n_total = n;
     g->begun = false;
     g->finished = false;
     g->external = true;   // rows are not tied to bound points
@@ -1289,6 +1291,60 @@ extern "C" int gt_graph_fetch_csr(gt_ctx* ctx, int32_t which, double* data, int3
     if (indices && g->nnz > 0)
         GT_HIP(ctx, hipMemcpyAsync(indices, g->indices.p, size_t(g->nnz) * sizeof(int32_t), kind, ctx->stream));
     if (indptr) GT_HIP(ctx, hipMemcpyAsync(indptr, g->indptr.p, size_t(g->nloc + 1) * sizeof(int64_t), kind, ctx->stream));
+    GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return GT_OK;
+}
+
+// ---- SpMM: rows of K / P times a dense matrix -----------------------------------------------------
+// One wave per row, one lane per output column (chunks of 64 columns): the entries of the row are walked in order,
+// (value, column) are wave-uniform loads, the gathered row of X is read coalesced.  HBM/L2-bound: nnz * ncols * 8 bytes
+// of gathers.
+__global__ __launch_bounds__(256) void spmm_rows_kernel(const int64_t nloc, const int64_t* __restrict__ indptr,
+                                                        const int32_t* __restrict__ indices, const double* __restrict__ data,
+                                                        const double* __restrict__ X, const int64_t ncols,
+                                                        double* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int w = threadIdx.x >> 6;
+    const int64_t i = int64_t(blockIdx.x) * 4 + w;
+    if (i >= nloc) return;
+    const int64_t e0 = indptr[i], e1 = indptr[i + 1];
+    for (int64_t c0 = 0; c0 < ncols; c0 += 64) {
+        const int64_t c = c0 + lane;
+        double acc = 0.0;
+        if (c < ncols) {
+            for (int64_t e = e0; e < e1; ++e) {
+                const double a = data[e];
+                const double x = X[int64_t(indices[e]) * ncols + c];
+                acc = acc + a * x;   // -ffp-contract=off: multiply, then add (scipy's csr_matvecs)
+            }
+            out[i * ncols + c] = acc;
+        }
+    }
+}
+
+extern "C" int gt_graph_spmm(gt_ctx* ctx, int32_t which, const double* X, int64_t ncols, double* out, int32_t on_device) {
+    if (!ctx || !X || !out || ncols <= 0) return GT_E_ARG;
+    GT_HIP(ctx, hipSetDevice(ctx->device));
+    GraphState* g = ctx->graph;
+    if (!g || !g->finished) GT_FAIL(ctx, GT_E_STATE, "gt_graph_spmm: no finished graph");
+    const int64_t n = g->n_total;
+    const double* Xd = X;
+    double* od = out;
+    if (!on_device) {
+        GT_HIP(ctx, g->spmm_in.reserve(size_t(n) * ncols * sizeof(double)));
+        GT_HIP(ctx, g->spmm_out.reserve(size_t(g->nloc) * ncols * sizeof(double)));
+        GT_TRY(gt_copy_from_host(ctx, g->spmm_in.p, X, size_t(n) * ncols * sizeof(double)));
+        Xd = g->spmm_in.as<double>();
+        od = g->spmm_out.as<double>();
+    }
+    const double* vals = which == GT_CSR_P ? g->Pdata.as<double>() : g->Kdata.as<double>();
+    {
+        StageSpan span(ctx, "spmm");
+        hipLaunchKernelGGL(spmm_rows_kernel, dim3((unsigned)ceil_div64(g->nloc, 4)), dim3(256), 0, ctx->stream, g->nloc,
+                           g->indptr.as<int64_t>(), g->indices.as<int32_t>(), vals, Xd, ncols, od);
+        GT_HIP(ctx, hipGetLastError());
+    }
+    if (!on_device) GT_TRY(gt_copy_to_host(ctx, out, od, size_t(g->nloc) * ncols * sizeof(double)));
     GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return GT_OK;
 }

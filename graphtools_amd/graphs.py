@@ -275,6 +275,18 @@ class kNNGraph(DataGraph):
         self._ensure_device_graph()
         return self.hip.graph_csr_torch(_hip.CSR_P)
 
+    def diffuse(self, X, t=1):
+        """``P^t X`` with the diffusion operator left on the device (``gt_graph_spmm``; the reference's consumers do
+        ``graph.diff_op.dot(X)`` on the host CSR).  X: [n_samples] or [n_samples, c]."""
+        self.K
+        self._ensure_device_graph()
+        X = np.asarray(X)
+        if X.shape[0] != self.data_nu.shape[0]:
+            raise ValueError("X must have one row per sample ({}), got {}".format(self.data_nu.shape[0], X.shape[0]))
+        for _ in range(int(t)):
+            X = self.hip.graph_spmm(_hip.CSR_P, X)
+        return X
+
     def kernel_torch(self):
         """The kernel matrix K as a CUDA ``torch.sparse_csr_tensor``."""
         self.K

@@ -181,6 +181,11 @@ int gt_graph_rows(const gt_ctx* ctx, int64_t* row0, int64_t* row1, int64_t* nnz)
 int gt_graph_fetch_csr(gt_ctx* ctx, int32_t which, double* data, int32_t* indices, int64_t* indptr,
                        int32_t on_device);
 int gt_graph_fetch_vec(gt_ctx* ctx, int32_t which, double* out, int32_t on_device);
+/* out[owned rows][ncols] = (K or P)[owned rows, :] @ X[n][ncols]  (float64, row-major) with the operator left on the
+ * device: the building block of the diffusion steps P^t X that consume `diff_op` downstream of the reference
+ * (`graph.diff_op.dot(data)` in PHATE / MAGIC).  Entries of a row are accumulated in column
+ * order with separate multiply and add, like scipy's csr @ dense.  on_device: X and out are device pointers. */
+int gt_graph_spmm(gt_ctx* ctx, int32_t which, const double* X, int64_t ncols, double* out, int32_t on_device);
 /* statistics of the last build: out[0]=rows that took the exact fallback, out[1]=rows that took the
  * radius pass, out[2]=nnz of the unsymmetrised kernel, out[3]=radius-pass capacity retries */
 int gt_graph_stats(const gt_ctx* ctx, int64_t* out4);

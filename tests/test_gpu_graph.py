@@ -430,3 +430,23 @@ def test_device_resident_hand_off_matches_host_matrices():
     assert np.array_equal(Kt.values().cpu().numpy(), G.K.data)
     Z = torch.as_tensor(X.astype(np.float64), device=Pt.device)
     np.testing.assert_allclose((Pt @ Z).cpu().numpy(), P @ X.astype(np.float64), rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("c", [1, 7, 64, 100])
+def test_diffusion_steps_on_the_device_match_scipy(c):
+    """gt_graph_spmm / Graph.diffuse: P @ X and P^3 @ X against scipy on the host CSR - same accumulation order, so
+    the products agree to the last bit."""
+    X = make_mix(4000, 12, 8)
+    G = graphtools_amd.Graph(X, knn=6, decay=15, n_pca=None, verbose=0)
+    rng = np.random.default_rng(c)
+    Z = rng.standard_normal((4000, c)) if c > 1 else rng.standard_normal(4000)
+    P = G.P
+    one = G.diffuse(Z)
+    assert np.array_equal(one, P @ Z)
+    three = G.diffuse(Z.astype(np.float32), t=3)
+    ref = Z.astype(np.float32).astype(np.float64)
+    for _ in range(3):
+        ref = P @ ref
+    assert np.array_equal(three, ref)
+    Kz = G.hip.graph_spmm(_hip.CSR_K, Z)
+    assert np.array_equal(Kz, G.K @ Z)
