@@ -64,7 +64,12 @@ __global__ __launch_bounds__(256) void rerank_kernel(const T* __restrict__ X, co
     const int lane = threadIdx.x & 63;
     const int w = threadIdx.x >> 6;
     double* xs = reinterpret_cast<double*>(smem_raw) + size_t(w) * d;
-    const int64_t ql = int64_t(blockIdx.x) * 4 + w;   // list index: the order the candidate pass dealt the queries in
+    // Workgroups are dealt to the 8 XCDs round robin; consecutive lists belong to neighbouring queries (same landmark
+    // cell) and re-rank largely the same database rows, so each XCD takes one contiguous eighth of the lists and finds
+    // those rows in its own L2.
+    const int64_t nb = gridDim.x, xcd = blockIdx.x & 7, base = nb >> 3, rem = nb & 7;
+    const int64_t bid = xcd * base + (xcd < rem ? xcd : rem) + (blockIdx.x >> 3);
+    const int64_t ql = bid * 4 + w;   // list index: the order the candidate pass dealt the queries in
     if (ql >= nq) return;   // whole wave exits together (ql is wave-uniform); no block-level sync below
     const int64_t q = qrows ? int64_t(qrows[ql]) - q0 : ql;   // row of the tables (rows [q0, q0 + nq) in their own order)
 
