@@ -648,7 +648,7 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
 // one query's threshold then beats many of them in the same unit, and the (wave-wide) admission path is entered
 // once instead of once per query.  gt_query_order (gt_order.hip) therefore processes the queries grouped by the
 // nearest of L sample rows.  This kernel finds that row: Yl = the L landmark rows of the compact hi-plane copy, hl
-// their score seeds; one query per lane exactly as in the candidate kernel, no LDS (the landmarks stay in L1/L2).
+// their score seeds; one query per lane exactly as in the candidate kernel, the landmark stream shared through LDS.
 template <int DP>
 __global__ __launch_bounds__(256) void assign_cells_kernel(const float* __restrict__ Yc, const float* __restrict__ Yl,
                                                            const float* __restrict__ hl, const int64_t q0,
@@ -660,21 +660,39 @@ __global__ __launch_bounds__(256) void assign_cells_kernel(const float* __restri
     const int64_t qc = q < nq ? q : int64_t(nq) - 1;
     Frag<DP, 2> bq;
     bq.load(Yc + (q0 + qc) * RW, h);
-    float best = -INFINITY;
-    uint32_t bidx = 0;
-    // gm[e]: best score among the landmarks that land in accumulator slot e of this lane - 16 disjoint sets of
-    // database rows, so at least 16 rows score >= min(gm) (32 with the other half-wave's sets): a valid (if loose,
-    // ~rank n/100) starting threshold for a selection of the `need` <= 32 best over the same scores (single-chain arithmetic, same seeds, same chain order)
+    // gm[e] / gl[e]: best score among the landmarks that land in accumulator slot e of this lane, and the unit that
+    // held it - 16 disjoint sets of database rows, so at least 16 rows score >= min(gm) (32 with the other half-wave's
+    // sets): a valid (if loose, ~rank n/100) starting threshold for a selection of the `need` <= 32 best over the same
+    // scores (single-chain arithmetic, same seeds, same chain order).  Independent per slot: no serial max chain.
     float gm[16];
+    int gl[16];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) gm[e] = -INFINITY;
-    for (int l0 = 0; l0 < L; l0 += 32) {
+    for (int e = 0; e < 16; ++e) {
+        gm[e] = -INFINITY;
+        gl[e] = 0;
+    }
+    // the four waves share the landmark stream through LDS: chunks of 32 landmarks (padded rows, two buffers)
+    constexpr int LDPA = RW + 4;
+    __shared__ __attribute__((aligned(16))) float lmk[2][32 * LDPA];
+    __shared__ __attribute__((aligned(16))) float lsd[2][32];
+    auto stage = [&](int l0, int buf) {
+        for (int f = threadIdx.x; f < 32 * (RW / 4); f += 256) {
+            const int r = f / (RW / 4), c4 = f % (RW / 4);
+            *reinterpret_cast<float4*>(&lmk[buf][r * LDPA + 4 * c4]) =
+                *reinterpret_cast<const float4*>(Yl + size_t(l0 + r) * RW + 4 * c4);
+        }
+        if (threadIdx.x < 32) lsd[buf][threadIdx.x] = hl[l0 + threadIdx.x];
+    };
+    stage(0, 0);
+    __syncthreads();
+    for (int l0 = 0, buf = 0; l0 < L; l0 += 32, buf ^= 1) {
+        if (l0 + 32 < L) stage(l0 + 32, buf ^ 1);   // the other buffer was released by the barrier that ended the last step
         Frag<DP, 2> a;
-        a.load(Yl + size_t(l0 + li) * RW, h);
+        a.load(&lmk[buf][li * LDPA], h);
         f32x16 acc;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const float4 hv = *reinterpret_cast<const float4*>(hl + l0 + 8 * g + 4 * h);
+            const float4 hv = *reinterpret_cast<const float4*>(&lsd[buf][8 * g + 4 * h]);
             acc[4 * g + 0] = hv.x;
             acc[4 * g + 1] = hv.y;
             acc[4 * g + 2] = hv.z;
@@ -683,11 +701,20 @@ __global__ __launch_bounds__(256) void assign_cells_kernel(const float* __restri
         mma_chain<DP>(a, bq, acc);
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            const bool better = acc[e] > best;
-            best = better ? acc[e] : best;
-            bidx = better ? uint32_t(l0 + 8 * (e >> 2) + 4 * h + (e & 3)) : bidx;
-            gm[e] = fmaxf(gm[e], acc[e]);
+            const bool better = acc[e] > gm[e];
+            gm[e] = better ? acc[e] : gm[e];
+            gl[e] = better ? l0 : gl[e];
         }
+        __syncthreads();
+    }
+    float best = gm[0];
+    uint32_t bidx = uint32_t(gl[0] + 4 * h);
+#pragma unroll
+    for (int e = 1; e < 16; ++e) {
+        const uint32_t idx = uint32_t(gl[e] + 8 * (e >> 2) + 4 * h + (e & 3));
+        const bool better = gm[e] > best || (gm[e] == best && idx < bidx);
+        best = better ? gm[e] : best;
+        bidx = better ? idx : bidx;
     }
     float gmin = gm[0];
 #pragma unroll
