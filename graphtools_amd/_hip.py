@@ -72,6 +72,7 @@ _SIGNATURES = {
                                       _c.c_double, _c.c_double, _c.POINTER(_c.c_int64), _c.POINTER(_c.c_uint32)]),
     "gt_graph_rows": (_c.c_int, [_c.c_void_p, _c.POINTER(_c.c_int64), _c.POINTER(_c.c_int64), _c.POINTER(_c.c_int64)]),
     "gt_graph_fetch_csr": (_c.c_int, [_c.c_void_p, _c.c_int32, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int32]),
+    "gt_release_cached_memory": (_c.c_int, []),
     "gt_graph_spmm": (_c.c_int, [_c.c_void_p, _c.c_int32, _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int32]),
     "gt_graph_fetch_vec": (_c.c_int, [_c.c_void_p, _c.c_int32, _c.c_void_p, _c.c_int32]),
     "gt_graph_stats": (_c.c_int, [_c.c_void_p, _c.c_void_p]),
@@ -110,6 +111,11 @@ def load_library():
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+def release_cached_memory():
+    """Hand the device memory parked by closed contexts (see gt_release_cached_memory) back to the driver."""
+    load_library().gt_release_cached_memory()
 
 
 def _ptr(a):

@@ -39,6 +39,14 @@
         return (code);            \
     } while (0)
 
+// Device memory of the library goes through a small process-wide cache (gt_devpool.cpp): a graph build holds ~15 GB
+// of workspace at N = 1e6, and handing that back to the driver with hipFree only to hipMalloc it again for the next
+// graph of the process costs hundreds of milliseconds.  Blocks of at least 1 MiB are parked per device when a
+// context lets go of them (up to GT_POOL_MAX_GB, default 64) and reused for requests they fit within a factor of two;
+// gt_release_cached_memory() / an allocation failure empties the cache.
+hipError_t gt_pool_alloc(void** p, size_t bytes, size_t* got);
+void gt_pool_free(void* p, size_t bytes);
+
 // grow-only device buffer
 struct DevBuf {
     void* p = nullptr;
@@ -49,25 +57,21 @@ struct DevBuf {
     }
     hipError_t reserve(size_t bytes) {
         if (bytes <= cap && p) return hipSuccess;
-        if (p) {
-            hipError_t e = hipFree(p);
-            p = nullptr;
-            cap = 0;
-            if (e != hipSuccess) return e;
-        }
+        release();
         if (bytes == 0) bytes = 16;
         size_t want = (bytes + 255) & ~size_t(255);
-        hipError_t e = hipMalloc(&p, want);
+        size_t got = 0;
+        hipError_t e = gt_pool_alloc(&p, want, &got);
         if (e != hipSuccess) {
             p = nullptr;
             cap = 0;
             return e;
         }
-        cap = want;
+        cap = got;
         return hipSuccess;
     }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p) gt_pool_free(p, cap);
         p = nullptr;
         cap = 0;
     }

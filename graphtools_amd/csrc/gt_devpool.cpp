@@ -1,0 +1,100 @@
+// Process-wide cache of large device allocations (see gt_common.h, DevBuf).
+#include <map>
+#include <mutex>
+
+#include "gt_common.h"
+
+namespace {
+
+constexpr size_t kMinPooled = size_t(1) << 20;
+constexpr int kMaxDevices = 64;
+
+struct Pool {
+    std::mutex mu;
+    std::multimap<size_t, void*> blocks[kMaxDevices];   // by size
+    size_t cached[kMaxDevices] = {};
+    size_t limit() {
+        static const size_t v = [] {
+            const char* s = std::getenv("GT_POOL_MAX_GB");
+            const double gb = s ? std::atof(s) : 64.0;
+            return gb <= 0 ? size_t(0) : size_t(gb * double(size_t(1) << 30));
+        }();
+        return v;
+    }
+};
+
+Pool& pool() {
+    static Pool* p = new Pool();   // never destroyed: the HIP runtime may be gone when static destructors run
+    return *p;
+}
+
+int current_device() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= kMaxDevices) return -1;
+    return d;
+}
+
+void flush_device(Pool& P, int d) {
+    for (auto& kv : P.blocks[d]) (void)hipFree(kv.second);
+    P.blocks[d].clear();
+    P.cached[d] = 0;
+}
+
+}  // namespace
+
+hipError_t gt_pool_alloc(void** p, size_t bytes, size_t* got) {
+    Pool& P = pool();
+    const int d = current_device();
+    if (d >= 0 && bytes >= kMinPooled) {
+        std::lock_guard<std::mutex> lock(P.mu);
+        auto it = P.blocks[d].lower_bound(bytes);
+        if (it != P.blocks[d].end() && it->first <= 2 * bytes) {
+            *p = it->second;
+            *got = it->first;
+            P.cached[d] -= it->first;
+            P.blocks[d].erase(it);
+            return hipSuccess;
+        }
+    }
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess && d >= 0) {
+        // out of memory with blocks parked: give them back and try once more
+        (void)hipGetLastError();
+        {
+            std::lock_guard<std::mutex> lock(P.mu);
+            flush_device(P, d);
+        }
+        e = hipMalloc(p, bytes);
+    }
+    *got = bytes;
+    return e;
+}
+
+void gt_pool_free(void* p, size_t bytes) {
+    if (!p) return;
+    Pool& P = pool();
+    const int d = current_device();
+    if (d >= 0 && bytes >= kMinPooled) {
+        std::lock_guard<std::mutex> lock(P.mu);
+        if (P.cached[d] + bytes <= P.limit()) {
+            P.blocks[d].emplace(bytes, p);
+            P.cached[d] += bytes;
+            return;
+        }
+    }
+    (void)hipFree(p);
+}
+
+extern "C" int gt_release_cached_memory(void) {
+    Pool& P = pool();
+    int prev = 0;
+    const bool have_prev = hipGetDevice(&prev) == hipSuccess;
+    std::lock_guard<std::mutex> lock(P.mu);
+    for (int d = 0; d < kMaxDevices; ++d) {
+        if (P.blocks[d].empty()) continue;
+        if (hipSetDevice(d) != hipSuccess) continue;
+        flush_device(P, d);
+    }
+    if (have_prev) (void)hipSetDevice(prev);
+    return GT_OK;
+}

@@ -86,6 +86,10 @@ int gt_ctx_create(int device, gt_ctx** out);
 void gt_ctx_destroy(gt_ctx* ctx);
 const char* gt_last_error(const gt_ctx* ctx);
 int gt_device_count(void);
+/* Device memory released by contexts is parked in a process-wide cache (blocks >= 1 MiB, up to GT_POOL_MAX_GB = 64 GB
+ * per device) so that the next context of the process does not pay hipMalloc for its workspace again; this hands
+ * the parked blocks back to the driver. */
+int gt_release_cached_memory(void);
 /* per-stage GPU time (ms, hipEvent on the ctx stream) of the most recent call that ran `stage`;
  * stages: "prep" "knn_select" "rerank" "fallback" "radius" "affinity" "symmetrize" "normalize"
  *         "dense_bandwidth" "dense_kernel" "dense_normalize" "landmark".  Returns <0 if never run. */

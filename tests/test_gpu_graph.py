@@ -450,3 +450,26 @@ def test_diffusion_steps_on_the_device_match_scipy(c):
     assert np.array_equal(three, ref)
     Kz = G.hip.graph_spmm(_hip.CSR_K, Z)
     assert np.array_equal(Kz, G.K @ Z)
+
+
+def test_device_memory_cache_is_reused_and_released():
+    """workspace of a closed context is parked and taken over by the next context of the process;
+    release_cached_memory() hands it back to the driver (free device memory returns to where it was)"""
+    import torch
+
+    def free_bytes():
+        return torch.cuda.mem_get_info(0)[0]
+
+    graphtools_amd.release_cached_memory()
+    X = make_mix(60000, 16, 2)
+    base = free_bytes()
+    G = graphtools_amd.Graph(X, knn=10, decay=20, n_pca=None, verbose=0)
+    nnz1 = G.K.nnz
+    del G
+    parked = base - free_bytes()
+    assert parked > (64 << 20)          # the workspace is still held by the cache
+    G = graphtools_amd.Graph(X, knn=10, decay=20, n_pca=None, verbose=0)
+    assert G.K.nnz == nnz1
+    del G
+    graphtools_amd.release_cached_memory()
+    assert base - free_bytes() < (64 << 20)
