@@ -252,10 +252,13 @@ class Context:
         """arithmetic of the last main candidate pass: 'f32', 'f16' (split, 3 chains) or 'f16x1' (single chain)"""
         return {0: "f32", 1: "f16", 2: "f16x1"}[self.lib.gt_last_knn_precision(self.h)]
 
-    def csr_graph_build(self, K0, kernel_symm, theta, anisotropy):
-        """symmetrise + anisotropy + row-normalise a host CSR kernel on the device; returns (nnz, flags)"""
+    def csr_graph_build(self, K0, kernel_symm, theta, anisotropy, assume_unique=False):
+        """symmetrise + anisotropy + row-normalise a host CSR kernel on the device; returns (nnz, flags).  The device
+        merge sorts every row itself; the columns of a row only have to be unique (``assume_unique``: the caller
+        vouches for that, else duplicates are summed here first)."""
         K0 = K0.tocsr()
-        K0.sort_indices()
+        if not assume_unique:
+            K0.sum_duplicates()
         indptr = np.ascontiguousarray(K0.indptr, dtype=np.int64)
         indices = np.ascontiguousarray(K0.indices, dtype=np.int32)
         data = np.ascontiguousarray(K0.data, dtype=np.float64)

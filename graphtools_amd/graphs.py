@@ -656,8 +656,11 @@ class MNNGraph(DataGraph):
         super().set_params(**params)
         return self
 
-    def build_kernel(self):
-        """The unsymmetrised MNN kernel (reference: graphs.py:1870-1946) as a scipy CSR matrix."""
+    def _assemble_kernel0(self):
+        """The unsymmetrised MNN kernel (reference: graphs.py:1870-1946) as CSR arrays with UNSORTED columns inside a
+        row: the blocks (one device kNN kernel per batch, one device ``build_kernel_to_data`` block per ordered batch
+        pair, rows scaled by ``min(1, within / between) * beta``) are written straight into their rows - O(nnz)
+        copies, no COO round trip and no host sort (the device merge sorts every row anyway)."""
         n = self.data_nu.shape[0]
         masks = [np.asarray(self.sample_idx) == s for s in self.samples]
         index = [np.nonzero(m)[0] for m in masks]
@@ -669,28 +672,49 @@ class MNNGraph(DataGraph):
                 n_jobs=self.n_jobs, kernel_symm="+", initialize=True, device=self.device,
             ))
             self.subgraphs[-1].kernel_degree   # cache the row sums before the context is reused for cross kernels
-        rows, cols, vals = [], [], []
+        blocks = []   # (batch of the rows, batch of the columns, CSR block in batch-local ids, per-row scale or None)
         for i, X in enumerate(self.subgraphs):
-            Kii = X.K.tocoo()
-            rows.append(index[i][Kii.row])
-            cols.append(index[i][Kii.col])
-            vals.append(Kii.data)
+            blocks.append((i, i, sparse.csr_matrix(X.K), None))
             within_batch_norm = np.asarray(X.kernel_degree).flatten()
             for j, Y in enumerate(self.subgraphs):
                 if i == j:
                     continue
-                Kij = Y.build_kernel_to_data(X.data_nu, knn=self.knn)
+                Kij = sparse.csr_matrix(Y.build_kernel_to_data(X.data_nu, knn=self.knn))
                 between_batch_norm = np.array(np.sum(Kij, 1)).flatten()
                 scale = np.minimum(1, within_batch_norm / between_batch_norm) * self.beta
-                Kij = Kij.multiply(scale[:, None]).tocoo()
-                rows.append(index[i][Kij.row])
-                cols.append(index[j][Kij.col])
-                vals.append(Kij.data)
-        K = sparse.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(n, n))
+                blocks.append((i, j, Kij, scale))
+        row_len = np.zeros(n, dtype=np.int64)
+        for i, _, M, _ in blocks:
+            row_len[index[i]] += np.diff(M.indptr)
+        indptr = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum(row_len, out=indptr[1:])
+        nnz = int(indptr[-1])
+        data = np.empty(nnz, dtype=np.float64)
+        indices = np.empty(nnz, dtype=np.int32)
+        cursor = indptr[:-1].copy()
+        for i, j, M, scale in blocks:
+            cnt = np.diff(M.indptr).astype(np.int64)
+            rows_g = index[i]
+            # entry e of local row r goes to cursor[row] + (e - M.indptr[r])
+            pos = np.repeat(cursor[rows_g] - M.indptr[:-1], cnt) + np.arange(M.nnz, dtype=np.int64)
+            data[pos] = M.data if scale is None else M.data * np.repeat(scale, cnt)
+            indices[pos] = index[j][M.indices]
+            cursor[rows_g] += cnt
+        if nnz < 2**31:
+            indptr = indptr.astype(np.int32)
+        K = sparse.csr_matrix((data, indices, indptr), shape=(n, n))
+        K.has_sorted_indices = False
+        return K
+
+    def build_kernel(self):
+        """The unsymmetrised MNN kernel (reference: graphs.py:1870-1946) as a canonical scipy CSR matrix."""
+        K = self._assemble_kernel0().copy()
+        K.sort_indices()
         return K
 
     def _device_build_from_k0(self):
-        nnz, flags = self.hip.csr_graph_build(self._kernel0, self.kernel_symm, self.theta, self.anisotropy)
+        nnz, flags = self.hip.csr_graph_build(self._kernel0, self.kernel_symm, self.theta, self.anisotropy,
+                                              assume_unique=True)
         self._device_state = (self.kernel_symm, self.theta, self.anisotropy)
         return nnz, flags
 
@@ -698,7 +722,7 @@ class MNNGraph(DataGraph):
         """(Re)build K and P on the device from the assembled kernel if the context lost or changed them."""
         if getattr(self, "_device_state", None) != (self.kernel_symm, self.theta, self.anisotropy):
             if not hasattr(self, "_kernel0"):
-                self._kernel0 = self.build_kernel()
+                self._kernel0 = self._assemble_kernel0()
             self._device_build_from_k0()
 
     def _bind_points(self):
@@ -707,7 +731,7 @@ class MNNGraph(DataGraph):
         kNNGraph._bind_points(self)
 
     def _build_kernel(self):
-        K0 = self._kernel0 = self.build_kernel()
+        K0 = self._kernel0 = self._assemble_kernel0()
         nnz, flags = self._device_build_from_k0()
         data, indices, indptr = self.hip.graph_fetch_csr(_hip.CSR_K)
         n = K0.shape[0]
