@@ -73,6 +73,7 @@ _SIGNATURES = {
     "gt_graph_rows": (_c.c_int, [_c.c_void_p, _c.POINTER(_c.c_int64), _c.POINTER(_c.c_int64), _c.POINTER(_c.c_int64)]),
     "gt_graph_fetch_csr": (_c.c_int, [_c.c_void_p, _c.c_int32, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int32]),
     "gt_release_cached_memory": (_c.c_int, []),
+    "gt_host_place_block": (_c.c_int, [_c.c_int64] + [_c.c_void_p] * 9),
     "gt_graph_spmm": (_c.c_int, [_c.c_void_p, _c.c_int32, _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int32]),
     "gt_graph_fetch_vec": (_c.c_int, [_c.c_void_p, _c.c_int32, _c.c_void_p, _c.c_int32]),
     "gt_graph_stats": (_c.c_int, [_c.c_void_p, _c.c_void_p]),
@@ -116,6 +117,21 @@ def load_library():
 def release_cached_memory():
     """Hand the device memory parked by closed contexts (see gt_release_cached_memory) back to the driver."""
     load_library().gt_release_cached_memory()
+
+
+def host_place_block(M, rows_global, cols_global, scale, cursor, out_indices, out_data):
+    """rows of the CSR block ``M`` (batch-local ids) -> their rows of the assembled kernel (gt_host_place_block)"""
+    indptr = np.ascontiguousarray(M.indptr, dtype=np.int64)
+    indices = np.ascontiguousarray(M.indices, dtype=np.int32)
+    data = np.ascontiguousarray(M.data, dtype=np.float64)
+    rows_global = np.ascontiguousarray(rows_global, dtype=np.int64)
+    cols_global = np.ascontiguousarray(cols_global, dtype=np.int64)
+    if scale is not None:
+        scale = np.ascontiguousarray(scale, dtype=np.float64)
+    rc = load_library().gt_host_place_block(M.shape[0], _ptr(indptr), _ptr(indices), _ptr(data), _ptr(rows_global),
+                                            _ptr(cols_global), _ptr(scale), _ptr(cursor), _ptr(out_indices), _ptr(out_data))
+    if rc != 0:
+        raise HipError("gt_host_place_block failed (%d)" % rc)
 
 
 def _ptr(a):

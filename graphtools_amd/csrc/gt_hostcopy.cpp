@@ -138,3 +138,41 @@ int gt_copy_from_host(gt_ctx* ctx, void* dst_dev, const void* src_host, size_t b
     GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return GT_OK;
 }
+
+// ---- host helper of the MNN composition (graphs.py MNNGraph._assemble_kernel0) --------------------------------------
+// Copies the rows of one CSR block (batch-local ids) into their rows of the assembled kernel: entry e of local row r
+// goes to cursor[rows_global[r]] + (e - indptr[r]), its column becomes cols_global[indices[e]], its value is scaled
+// by scale[r] when given.  cursor[] is advanced by the row lengths.  Rows are independent: split over host threads.
+extern "C" int gt_host_place_block(int64_t nrows, const int64_t* indptr, const int32_t* indices, const double* data,
+                                   const int64_t* rows_global, const int64_t* cols_global, const double* scale,
+                                   int64_t* cursor, int32_t* out_indices, double* out_data) {
+    if (nrows < 0 || !indptr || !rows_global || !cols_global || !cursor || !out_indices || !out_data) return GT_E_ARG;
+    auto work = [&](int64_t r0, int64_t r1) {
+        for (int64_t r = r0; r < r1; ++r) {
+            const int64_t g = rows_global[r];
+            int64_t dst = cursor[g];
+            const double s = scale ? scale[r] : 1.0;
+            for (int64_t e = indptr[r]; e < indptr[r + 1]; ++e, ++dst) {
+                out_indices[dst] = int32_t(cols_global[indices[e]]);
+                out_data[dst] = scale ? data[e] * s : data[e];
+            }
+            cursor[g] = dst;
+        }
+    };
+    const int64_t nnz = indptr[nrows] - indptr[0];
+    int nt = int(std::min<int64_t>(16, std::max<int64_t>(1, nnz / (int64_t(1) << 20))));
+    if (nt <= 1) {
+        work(0, nrows);
+        return GT_OK;
+    }
+    std::thread th[16];
+    int started = 0;
+    try {
+        for (; started < nt; ++started)
+            th[started] = std::thread(work, nrows * started / nt, nrows * (started + 1) / nt);
+    } catch (const std::system_error&) {
+        work(nrows * started / nt, nrows);
+    }
+    for (int t = 0; t < started; ++t) th[t].join();
+    return GT_OK;
+}

@@ -693,13 +693,8 @@ class MNNGraph(DataGraph):
         indices = np.empty(nnz, dtype=np.int32)
         cursor = indptr[:-1].copy()
         for i, j, M, scale in blocks:
-            cnt = np.diff(M.indptr).astype(np.int64)
-            rows_g = index[i]
-            # entry e of local row r goes to cursor[row] + (e - M.indptr[r])
-            pos = np.repeat(cursor[rows_g] - M.indptr[:-1], cnt) + np.arange(M.nnz, dtype=np.int64)
-            data[pos] = M.data if scale is None else M.data * np.repeat(scale, cnt)
-            indices[pos] = index[j][M.indices]
-            cursor[rows_g] += cnt
+            # entry e of local row r goes to cursor[row] + (e - M.indptr[r]); threaded copy in the library
+            _hip.host_place_block(M, index[i], index[j], scale, cursor, indices, data)
         if nnz < 2**31:
             indptr = indptr.astype(np.int32)
         K = sparse.csr_matrix((data, indices, indptr), shape=(n, n))

@@ -167,6 +167,13 @@ int gt_graph_build(gt_ctx* ctx, const gt_knn_params* params, int64_t* out_nnz, u
  * cross-batch build_kernel_to_data blocks: host CSR (int64 indptr, int32 indices, float64 data, n x n, unique columns
  * per row, values >= 0) -> symmetrisation (kernel_symm, theta), anisotropy, row normalisation on the device.  Results
  * are fetched like those of gt_graph_build. */
+/* Host helper of that composition (no device work): copies the rows of one CSR block given in batch-local ids into
+ * their rows of the assembled kernel - entry e of local row r lands at cursor[rows_global[r]] + (e - indptr[r]) with
+ * column cols_global[indices[e]] and value data[e] * scale[r] (scale may be NULL); cursor[] advances by the row
+ * lengths.  Replaces the scipy COO concatenation + sort of the reference's assembly (graphs.py:1905-1936). */
+int gt_host_place_block(int64_t nrows, const int64_t* indptr, const int32_t* indices, const double* data,
+                        const int64_t* rows_global, const int64_t* cols_global, const double* scale, int64_t* cursor,
+                        int32_t* out_indices, double* out_data);
 int gt_csr_graph_build(gt_ctx* ctx, int64_t n, const int64_t* indptr, const int32_t* indices, const double* data,
                        int32_t kernel_symm, double theta, double anisotropy, int64_t* out_nnz, uint32_t* flags);
 

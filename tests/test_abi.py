@@ -67,3 +67,43 @@ def test_product_never_imports_oracle():
         if fn.endswith(".py"):
             src = open(os.path.join(pkg, fn)).read()
             assert "import oracle" not in src and "from oracle" not in src, fn
+
+
+def test_host_place_block_matches_scipy_assembly():
+    """gt_host_place_block (host-only helper of the MNN composition): blocks in batch-local ids land in their rows
+    of the assembled CSR exactly like the reference's COO concatenation (compared after sorting the rows)."""
+    import numpy as np
+    from scipy import sparse
+
+    from graphtools_amd import _hip
+
+    rng = np.random.default_rng(0)
+    n = 500
+    owner = rng.integers(0, 3, size=n)
+    index = [np.nonzero(owner == b)[0] for b in range(3)]
+    blocks, rows, cols, vals = [], [], [], []
+    for i in range(3):
+        for j in range(3):
+            M = sparse.random(len(index[i]), len(index[j]), density=0.05, random_state=10 * i + j, format="csr")
+            scale = rng.uniform(0.2, 1.0, size=len(index[i])) if i != j else None
+            blocks.append((i, j, M, scale))
+            C = (M if scale is None else sparse.csr_matrix(M.multiply(scale[:, None]))).tocoo()
+            rows.append(index[i][C.row])
+            cols.append(index[j][C.col])
+            vals.append(C.data)
+    ref = sparse.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(n, n))
+    row_len = np.zeros(n, dtype=np.int64)
+    for i, _, M, _ in blocks:
+        row_len[index[i]] += np.diff(M.indptr)
+    indptr = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(row_len, out=indptr[1:])
+    data = np.empty(indptr[-1])
+    indices = np.empty(indptr[-1], dtype=np.int32)
+    cursor = indptr[:-1].copy()
+    for i, j, M, scale in blocks:
+        _hip.host_place_block(M, index[i], index[j], scale, cursor, indices, data)
+    assert np.array_equal(cursor, indptr[1:])
+    out = sparse.csr_matrix((data, indices, indptr), shape=(n, n))
+    out.sort_indices()
+    assert np.array_equal(out.indptr, ref.indptr) and np.array_equal(out.indices, ref.indices)
+    assert np.array_equal(out.data, ref.data)
