@@ -77,6 +77,7 @@ _SIGNATURES = {
     "gt_graph_spmm": (_c.c_int, [_c.c_void_p, _c.c_int32, _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int32]),
     "gt_graph_fetch_vec": (_c.c_int, [_c.c_void_p, _c.c_int32, _c.c_void_p, _c.c_int32]),
     "gt_graph_stats": (_c.c_int, [_c.c_void_p, _c.c_void_p]),
+    "gt_knn_stats": (_c.c_int, [_c.c_void_p, _c.c_void_p]),
     "gt_dense_graph_build": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_int32,
                                         _c.c_int32, _c.c_int32, _c.c_double, _c.c_double, _c.c_void_p, _c.c_int64,
                                         _c.c_double, _c.c_int32, _c.c_double, _c.c_double, _c.c_int32, _c.c_void_p,
@@ -372,6 +373,17 @@ class Context:
         r0, r1, _ = self.graph_rows()
         out = np.empty(r1 - r0, dtype=np.float64)
         self._check(self.lib.gt_graph_fetch_vec(self.h, which, _ptr(out), 0), "gt_graph_fetch_vec")
+        return out
+
+    def knn_stats(self):
+        st = np.zeros(12, dtype=np.int64)
+        self._check(self.lib.gt_knn_stats(self.h, _ptr(st)), "gt_knn_stats")
+        out = {"symmetric": bool(st[0]), "sym_overflow_rows": int(st[1]), "repaired_rows": int(st[2]),
+               "exhaustive_rows": int(st[3])}
+        if st[0]:
+            out.update(sym_forward_entries=int(st[5]), sym_transposed_entries=int(st[6]), sym_longest=int(st[7]),
+                       sym_rows_over_256=int(st[8]), sym_rows_forward_full=int(st[9]), sym_rows_transposed_full=int(st[10]),
+                       sym_rows_over_128=int(st[11]))
         return out
 
     def graph_stats(self):

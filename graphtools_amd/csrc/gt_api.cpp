@@ -58,6 +58,10 @@ int gt_ctx_create(int device, gt_ctx** out) {
     }
     // test hook: group the query rows of launches of at least this many rows (default 32768)
     if (const char* mr = std::getenv("GT_QUERY_ORDER_MIN_ROWS")) ctx->order_min_rows = std::max(1, std::atoi(mr));
+    // test hooks of the symmetric candidate pass (gt_sym.hip): force it on (1) / off (0), smallest launch, sample stride
+    if (const char* v = std::getenv("GT_SYMMETRIC")) ctx->sym_mode = std::atoi(v);
+    if (const char* v = std::getenv("GT_SYM_MIN_ROWS")) ctx->sym_min_rows = std::max(1, std::atoi(v));
+    if (const char* v = std::getenv("GT_SYM_STRIDE")) ctx->sym_stride = std::max(0, std::atoi(v));
     *out = ctx;
     return GT_OK;
 }
@@ -253,6 +257,34 @@ int gt_set_option(gt_ctx* ctx, const char* name, const char* value) {
     }
     if (k == "select_samp_keep") {
         ctx->samp_keep = std::atoi(value);
+        return GT_OK;
+    }
+    if (k == "query_order_min_rows") {
+        ctx->order_min_rows = std::max(1, std::atoi(value));
+        return GT_OK;
+    }
+    if (k == "select_symmetric") {
+        ctx->sym_mode = v == "auto" ? -1 : std::atoi(value);
+        return GT_OK;
+    }
+    if (k == "select_sym_stride") {
+        ctx->sym_stride = std::max(0, std::atoi(value));
+        return GT_OK;
+    }
+    if (k == "select_sym_cells") {
+        ctx->sym_cells = std::min(32, std::max(1, std::atoi(value)));
+        return GT_OK;
+    }
+    if (k == "select_sym_max_nb") {
+        ctx->sym_max_nb = std::max(8, std::atoi(value));
+        return GT_OK;
+    }
+    if (k == "select_sym_min_rows") {
+        ctx->sym_min_rows = std::atoll(value);
+        return GT_OK;
+    }
+    if (k == "select_sym_tcap") {
+        ctx->sym_tcap = std::min(4096, std::max(64, std::atoi(value)));
         return GT_OK;
     }
     if (k == "dbg_select") {

@@ -139,6 +139,14 @@ struct gt_ctx {
     int32_t nt8_max_need = 88;  // tables of up to this many neighbours use the 128-entry list budget (else 512)
     int32_t narrow_mode = -1; // 128-row-workgroup candidate kernels: -1 auto (few query rows), 0 never, 1 whenever available
     int32_t dbg_select = 0;   // experiment switches forwarded to the candidate kernel (results invalid when set)
+    // symmetric candidate pass for self queries over the whole point set (gt_sym.hip): -1 auto (large launches), 0 off, 1 on
+    int32_t sym_mode = -1;
+    int64_t sym_min_rows = 65536;
+    int32_t sym_stride = 32;    //   threshold-seeding launch: every sym_stride-th tile besides the row's own neighbourhood (0: none)
+    int32_t sym_cells = 12;     //   ... which is the rows of this many nearest cells (landmarks) of the block's own cells,
+    int32_t sym_max_nb = 384;   //   at most this many tiles
+    int32_t sym_tcap = 512;     //   capacity of a row's transposed list
+    int32_t order_L = 0;        // landmark cells of the last query order (gt_order.hip)
     int64_t n_pad = 0;   // rows of the working copy (multiple of the db tile)
     DevBuf Yp;           // working copy: [n_pad] rows of 4*DP bytes (float32, or float16 hi plane | lo plane)
     DevBuf Yc;           // prec 1 with fast_mode: compact copy of the hi plane, [n_pad] rows of 2*DP bytes

@@ -154,3 +154,26 @@ extern "C" int gt_dbg_fetch_prof(gt_ctx* ctx, int64_t nwaves, unsigned long long
     GT_HIP(ctx, hipMemcpy(out_host, ctx->knn->prof.p, size_t(nwaves) * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return GT_OK;
 }
+
+// development: raw buffers of the symmetric candidate pass (gt_sym.hip) of the most recent kNN call
+//   which: 0 thr (float [n]) 1 perm (int32 [n]) 2 forward counts (uint32 [n][2]) 3 transposed counts (uint32 [n])
+//          4 tile counts of launch A (int32 [blocks]) 5 sorted cell ids (uint32 [n])
+extern "C" int gt_dbg_fetch_sym(gt_ctx* ctx, int32_t which, int64_t count, void* out_host) {
+    if (!ctx || !ctx->knn) return GT_E_STATE;
+    GT_HIP(ctx, hipSetDevice(ctx->device));
+    KnnWork* k = ctx->knn;
+    const void* src = nullptr;
+    size_t esz = 4;
+    switch (which) {
+        case 0: src = k->thr_final.p; break;
+        case 1: src = k->qorder.p; break;
+        case 2: src = k->counts2.p; esz = 8; break;
+        case 3: src = k->tcounts.p; break;
+        case 4: src = k->sym_tile_cnt.p; break;
+        case 5: src = ctx->order_cell.as<uint32_t>() + ctx->n; break;
+        default: return GT_E_ARG;
+    }
+    if (!src) return GT_E_STATE;
+    GT_HIP(ctx, hipMemcpy(out_host, src, size_t(count) * esz, hipMemcpyDeviceToHost));
+    return GT_OK;
+}

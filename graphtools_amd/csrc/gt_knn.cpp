@@ -13,7 +13,9 @@ void gt_free_knn_work(gt_ctx* ctx) {
     KnnWork* k = ctx->knn;
     for (DevBuf* b : {&k->Qraw, &k->Qp, &k->Qc, &k->qn, &k->qn_sel, &k->lists, &k->counts, &k->thr_final, &k->cand_d2, &k->cand_j, &k->cand_n,
                       &k->d2_lb, &k->fb_rows, &k->fb_count, &k->fb_scratch, &k->gflags, &k->prof, &k->fb_qrows, &k->fb_thr, &k->fb_lists,
-                      &k->fb_counts, &k->fb_max, &k->unproven, &k->qorder, &k->qthr0, &k->qlomax_dev})
+                      &k->fb_counts, &k->fb_max, &k->unproven, &k->qorder, &k->qthr0, &k->qlomax_dev, &k->Ycs, &k->hnegs,
+                      &k->sym_g, &k->sym_gmin, &k->tlists, &k->tcounts, &k->counts2, &k->sym_stat, &k->sym_work, &k->sym_tiles,
+                      &k->sym_tile_cnt})
         b->release();
     delete k;
     ctx->knn = nullptr;
@@ -191,8 +193,126 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
         if (ordered) sa.qrows = ra.qrows = k->qorder.as<int32_t>();
         have_thr0 = ordered != 0 && need_m <= 32 && ctx->thr0_mode != 0;
     }
+    // Symmetric pass (gt_sym.hip): self queries over the whole point set, euclidean, single-chain arithmetic, grouped
+    // query order available (its permutation is the cell-sorted order both sides of the pass share)
+    const int bq_sym = gt_select_bq(ctx->DP);
+    const bool use_sym = ctx->sym_mode != 0 && !external && q0 == 0 && nq == ctx->n && sa.qrows != nullptr &&
+                         ctx->metric == 0 && !ctx->wide && nt == 8 && need_m <= 64 && ctx->Yc.p != nullptr &&
+                         (ctx->sym_mode > 0 || nq >= ctx->sym_min_rows) &&
+                         ctx->order_L > 0 && nq >= int64_t(8) * bq_sym;
+    k->sym_used = false;
     uint32_t n_fb = 0;
     for (;;) {
+        if (use_sym && main_prec == 2) {
+            const int64_t n_pad_s = ceil_div64(nq, bq_sym) * bq_sym;
+            const int hcap = 256, tcap = ctx->sym_tcap;
+            const int32_t* perm = k->qorder.as<int32_t>();
+            GT_HIP(ctx, k->Ycs.reserve(size_t(n_pad_s) * ctx->DP * sizeof(_Float16)));
+            GT_HIP(ctx, k->hnegs.reserve(size_t(n_pad_s) * sizeof(float)));
+            GT_HIP(ctx, k->sym_g.reserve(size_t(n_pad_s) * sizeof(float)));
+            GT_HIP(ctx, k->sym_gmin.reserve(size_t(n_pad_s / 32) * sizeof(float)));
+            GT_HIP(ctx, k->tlists.reserve(size_t(n_pad_s) * size_t(tcap) * sizeof(uint64_t)));
+            GT_HIP(ctx, k->tcounts.reserve(size_t(n_pad_s) * sizeof(uint32_t)));
+            GT_HIP(ctx, k->counts2.reserve(size_t(n_pad_s) * 2 * sizeof(uint32_t)));
+            GT_HIP(ctx, k->sym_stat.reserve(8 * sizeof(unsigned long long)));
+            ErrModel em = gt_err_model(ctx, 2);
+            em.rel += 8.0 * 5.9604644775390625e-08;   // the transposed test adds two float32 roundings to a score
+            ra.err = em;
+            const double rkf = std::max(1.0, std::fabs(radius_key_factor));
+            const int bn_sym = gt_select_bn(ctx->DP);
+            const int n_tiles_s = int(n_pad_s / bn_sym);
+            const int stride_a = ctx->sym_stride > 0 && n_tiles_s >= 8 * ctx->sym_stride ? ctx->sym_stride : 0;
+            const int tile_stride = ((stride_a ? n_tiles_s / stride_a + 1 : 0) + ctx->sym_max_nb + bq_sym / bn_sym + 63) / 64 * 64;
+            GT_HIP(ctx, k->sym_tiles.reserve(size_t(n_pad_s / bq_sym) * tile_stride * sizeof(int32_t)));
+            GT_HIP(ctx, k->sym_tile_cnt.reserve(size_t(n_pad_s / bq_sym) * sizeof(int32_t)));
+            {
+                StageSpan span(ctx, "sym_prepare");
+                GT_TRY(gt_sym_gather(ctx, perm, n_pad_s, k->Ycs.p, k->hnegs.as<float>()));
+                GT_TRY(gt_sym_schedule(ctx, n_pad_s, bq_sym, bn_sym, ctx->sym_cells, stride_a, ctx->sym_max_nb, tile_stride,
+                                       k->sym_work, k->sym_tiles.as<int32_t>(), k->sym_tile_cnt.as<int32_t>()));
+            }
+            SelectArgs a = sa;
+            a.prec = 2;
+            a.narrow = 0;
+            a.Yp = a.Qp = k->Ycs.as<float>();
+            a.hneg = k->hnegs.as<float>();
+            a.n_pad = n_pad_s;
+            a.qrows = nullptr;
+            a.q0 = 0;
+            a.thr_in = nullptr;
+            a.mode = 0;
+            a.sym.sched = 1;
+            a.sym.tile_list = k->sym_tiles.as<int32_t>();
+            a.sym.tile_cnt = k->sym_tile_cnt.as<int32_t>();
+            a.sym.tile_stride = tile_stride;
+            a.samp_stride = 0;
+            int keep = std::max(ctx->samp_keep > 0 ? ctx->samp_keep : 16, need_m);
+            keep += keep & 1;
+            a.samp_keep = keep;
+            a.samp_trig = ctx->samp_trig;
+            a.samp_end = 0;
+            a.samp2_level = 0;
+            a.final_keep = need_m;
+            {
+                StageSpan span(ctx, "sym_seed");
+                GT_TRY(gt_launch_select(ctx, a));
+            }
+            {
+                StageSpan span(ctx, "sym_prepare");
+                GT_TRY(gt_sym_thresholds(ctx, perm, n_pad_s, k->hnegs.as<float>(), k->lists.as<uint64_t>(), int(lcap),
+                                         k->counts.as<uint32_t>(), need_m, em, rkf, k->thr_final.as<float>(),
+                                         k->sym_g.as<float>(), k->sym_gmin.as<float>()));
+                GT_HIP(ctx, hipMemsetAsync(k->tcounts.p, 0, size_t(n_pad_s) * sizeof(uint32_t), ctx->stream));
+            }
+            a.mode = 2;
+            a.sym.sched = 0;
+            a.sym.g = k->sym_g.as<float>();
+            a.sym.gmin = k->sym_gmin.as<float>();
+            a.sym.tlists = k->tlists.as<uint64_t>();
+            a.sym.tcounts = k->tcounts.as<uint32_t>();
+            a.sym.tcap = tcap;
+            a.sym.hcap = hcap;
+            a.counts = k->counts2.as<uint32_t>();
+            a.thr_in = k->thr_final.as<float>();
+            {
+                StageSpan span(ctx, "knn_select");
+                GT_TRY(gt_launch_select(ctx, a));
+            }
+            ctx->last_main_prec = 2;
+            k->sym_used = true;
+            if (ctx->dbg_select & 4) return GT_OK;   // experiment: candidate pass only (tables are NOT valid)
+            GT_HIP(ctx, hipMemsetAsync(k->unproven.p, 0, sizeof(uint32_t), ctx->stream));
+            GT_HIP(ctx, hipMemsetAsync(k->sym_stat.p, 0, 8 * sizeof(unsigned long long), ctx->stream));
+            SymRerank sr;
+            sr.counts2 = k->counts2.as<uint32_t>();
+            sr.hcap = hcap;
+            sr.tlists = k->tlists.as<uint64_t>();
+            sr.tcounts = k->tcounts.as<uint32_t>();
+            sr.tcap = tcap;
+            sr.perm = perm;
+            sr.stat = k->sym_stat.as<unsigned long long>();
+            {
+                StageSpan span(ctx, "rerank");
+                GT_TRY(gt_launch_rerank_sym(ctx, ra, sr));
+            }
+            uint32_t n_unproven = 0;
+            GT_HIP(ctx, hipMemcpyAsync(&n_fb, k->fb_count.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+            GT_HIP(ctx, hipMemcpyAsync(&n_unproven, k->unproven.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+            GT_HIP(ctx, hipMemcpyAsync(k->sym_stat_host, k->sym_stat.p, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+            GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            k->sym_overflow = int64_t(k->sym_stat_host[0]);
+            if (fast_auto) {
+                const bool ok = double(n_unproven) <= kFastFailFrac * double(nq);
+                ctx->fast_ok = ok ? 1 : 0;
+                if (!ok) {
+                    main_prec = 1;
+                    GT_HIP(ctx, hipMemsetAsync(k->fb_count.p, 0, sizeof(uint32_t), ctx->stream));
+                    GT_HIP(ctx, hipMemsetAsync(k->gflags.p, 0, sizeof(uint32_t), ctx->stream));
+                    continue;
+                }
+            }
+            break;
+        }
         sa.prec = main_prec;
         // Few query rows (a shard of a multi-GPU build): 128-row workgroups double the number of workgroups, which fills
         // the machine better than it costs in shared-operand reuse (measured: -6 % at 125 k rows, -8 % at 250 k, +6 %
@@ -362,6 +482,17 @@ int gt_prepare_queries(gt_ctx* ctx, const void* Y, int64_t m, int32_t y_on_devic
         GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
         ctx->qlomax = std::sqrt(lo2) / ctx->sc;
     }
+    return GT_OK;
+}
+
+extern "C" int gt_knn_stats(const gt_ctx* ctx, int64_t* out12) {
+    if (!ctx || !out12) return GT_E_ARG;
+    const KnnWork* k = ctx->knn;
+    out12[0] = k && k->sym_used ? 1 : 0;
+    out12[1] = k ? k->sym_overflow : 0;
+    out12[2] = k ? k->n_fallback : 0;
+    out12[3] = k ? k->n_fallback_exhaustive : 0;
+    for (int i = 0; i < 8; ++i) out12[4 + i] = (k && k->sym_used) ? int64_t(k->sym_stat_host[i]) : 0;
     return GT_OK;
 }
 

@@ -25,6 +25,12 @@ struct KnnWork {
     DevBuf qorder;             // self queries: the rows of the launch grouped by nearest landmark (gt_order.hip)
     DevBuf fb_rows, fb_count, fb_scratch, gflags, prof;
     DevBuf fb_qrows, fb_thr, fb_lists, fb_counts, fb_max;   // collected fallback
+    // symmetric candidate pass (gt_sym.hip): cell-sorted compact copy + seeds, per-row thresholds in the transposed
+    // form and their sub-tile minima, transposed lists, forward fill counts
+    DevBuf Ycs, hnegs, sym_g, sym_gmin, tlists, tcounts, counts2, sym_stat, sym_work, sym_tiles, sym_tile_cnt;
+    bool sym_used = false;
+    int64_t sym_overflow = 0;
+    unsigned long long sym_stat_host[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int64_t n_fallback_exhaustive = 0;
     int64_t n_fallback = 0;
 };
@@ -128,6 +134,23 @@ struct RerankArgs {
     const int32_t* qrows = nullptr;   // list i of the candidate pass belongs to row qrows[i] (else q0 + i)
 };
 int gt_launch_rerank(gt_ctx* ctx, const RerankArgs& a);
+// symmetric candidate pass (gt_sym.hip): segments of list ql = cell-sorted position ql, row perm[ql]
+struct SymRerank {
+    const uint32_t* counts2;   // [n][2] forward fill counts (true counts)
+    int hcap;
+    const uint64_t* tlists;    // [n_pad][tcap]
+    const uint32_t* tcounts;
+    int tcap;
+    const int32_t* perm;       // sorted position -> row
+    unsigned long long* stat;  // optional counters [8] (rerank_sym_kernel)
+};
+int gt_launch_rerank_sym(gt_ctx* ctx, const RerankArgs& a, const SymRerank& sr);
+// gt_sym.hip
+int gt_sym_gather(gt_ctx* ctx, const int32_t* perm, int64_t n_pad_s, void* Ys, float* hs);
+int gt_sym_thresholds(gt_ctx* ctx, const int32_t* perm, int64_t n_pad_s, const float* hs, const uint64_t* lists, int lstride,
+                      const uint32_t* counts, int need_m, const ErrModel& err, double rkf, float* thr, float* g, float* gmin);
+int gt_sym_schedule(gt_ctx* ctx, int64_t n_pad_s, int bq, int bn, int cells, int stride, int max_nb, int tile_stride,
+                    DevBuf& work, int32_t* tile_list, int32_t* tile_cnt);
 int gt_launch_fallback(gt_ctx* ctx, const RerankArgs& a, int64_t n_rows, int64_t row_off, double* scratch);
 int gt_launch_fallback_thr(gt_ctx* ctx, const RerankArgs& a, int64_t n_rows, int64_t row_off, int32_t* qrows, float* thr);
 int gt_launch_collected_select(gt_ctx* ctx, const RerankArgs& a, int64_t n_rows, int64_t row_off, const uint64_t* clists,

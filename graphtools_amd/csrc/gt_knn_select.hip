@@ -31,6 +31,16 @@
 //   entries per query, the true count is always reported).  Slots come from a global counter so the
 //   database can be split over gridDim.y workgroups when there are few query rows.
 //
+// MODE 2 (symmetric collect, self queries over the whole point set in cell-sorted order, gt_knn.cpp): thr is a fixed
+//   per-row score bound (from a MODE 0 launch with sched = 1 over the row's own neighbourhood + a strided sample).  The
+//   score matrix is symmetric up to the seeds - x_i.x_j is the same MFMA chain whichever of the two is the query - so
+//   workgroup I (query block I) streams only the blocks I .. I + (NB-1)/2 (mod NB) and tests every result twice: once
+//   for its query (the lane's own threshold) and once for the database row as a query of its own (per-row thresholds
+//   staged with the tile; a per-sub-tile minimum keeps the hot path at one compare).  Forward survivors go to the
+//   query's list as in MODE 0 (register fill counts, no atomics), transposed ones to the database row's second list
+//   through a global slot counter.  Every unordered pair of rows is scored exactly once: N^2 d executed flop for
+//   the 2 N^2 d the problem asks for.
+//
 // Roofline: MFMA-bound.  Algorithmic work 2*d flop per (query, database row) pair.
 #include "gt_common.h"
 #include "gt_device.h"
@@ -84,6 +94,9 @@ struct SelCfg {
     static constexpr int TILE_FLOATS = BN * LDP;
     static constexpr size_t LDS_BYTES =
         size_t(2) * TILE_FLOATS * 4 + size_t(2) * BN * 4;
+    // MODE 2 also stages the database rows' own thresholds [2][BN] and their per-sub-tile minima [2][8]
+    static constexpr size_t LDS_BYTES_SYM = LDS_BYTES + size_t(2) * BN * 4 + size_t(2) * 8 * 4;
+    static constexpr int TPB = BQ / BN;                 // database tiles per query block
     // swizzle geometry (GLDS)
     static constexpr int CPR = RB / 16;                 // 16-byte chunks per row
     static constexpr int RDIV = (RB >= 256) ? 1 : 256 / RB;   // rows sharing one 256-byte bank row
@@ -285,7 +298,7 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
     uint64_t* __restrict__ lists, uint32_t* __restrict__ counts, const float* __restrict__ thr_in,
     float* __restrict__ thr_out, const int32_t cap, const int32_t dbg, unsigned long long* __restrict__ prof,
     const int32_t samp_stride, const int32_t samp_keep, const int32_t samp_end, const int32_t samp2_level,
-    const int32_t samp2_keep, const int32_t samp_trig, const int32_t final_keep) {
+    const int32_t samp2_keep, const int32_t samp_trig, const int32_t final_keep, const SymDev sy) {
     using C = SelCfg<DP, PREC>;
     unsigned long long t_adm = 0, t_cmp = 0, t_bar = 0, n_cmp = 0, n_adm = 0, t_lvl0 = 0, n_adm_lvl0 = 0;
     const unsigned long long t_start = prof ? __builtin_readcyclecounter() : 0ull;
@@ -299,14 +312,25 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* tile = reinterpret_cast<float*>(smem_raw);                    // [2][BN][LDP]
     float* hn = tile + 2 * C::TILE_FLOATS;                               // [2][BN]
+    float* gb = hn + 2 * BN;                                             // MODE 2: [2][BN] row thresholds, [2][8] sub-tile minima
+    float* gm = gb + 2 * BN;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = tid >> 6;
     const int li = lane & 31;
     const int h = lane >> 5;
-    const int64_t qblock = int64_t(blockIdx.x) * BQ;
-    const size_t lstride = (MODE == 0) ? size_t(LCAP) : size_t(cap);
+    // MODE 2 / sched 1: the queries ARE the database rows (cell-sorted order), query block I = rows [I*BQ, (I+1)*BQ).
+    // Workgroups are dealt to the 8 XCDs round robin: each XCD takes a contiguous eighth of the blocks, so that the
+    // workgroups sharing an L2 walk overlapping windows of the database.
+    const bool own_sched = (MODE == 2) || (MODE == 0 && sy.sched == 1);
+    int64_t bidx = blockIdx.x;
+    if (own_sched) {
+        const int64_t nb = gridDim.x, xcd = bidx & 7, base = nb >> 3, rem = nb & 7;
+        bidx = xcd * base + (xcd < rem ? xcd : rem) + (bidx >> 3);
+    }
+    const int64_t qblock = bidx * BQ;
+    const size_t lstride = (MODE == 0) ? size_t(LCAP) : (MODE == 2) ? size_t(2 * sy.hcap) : size_t(cap);
     // database tile range of this workgroup (MODE 1 may split the database over gridDim.y)
     int t_begin = 0, t_end = ntiles;
     if (MODE == 1) {
@@ -315,11 +339,33 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
         t_end = t_begin + per < ntiles ? t_begin + per : ntiles;
         if (t_begin >= t_end) return;
     }
+    // own_sched tile walks (T tiles = NB blocks of TPB tiles):
+    //   MODE 2:   the own block, then H = (NB-1)/2 blocks (mod NB) with both directions tested, then (NB even) the
+    //             antipodal block forward only - its owner does the same for the other direction
+    //   sched 1:  the explicit tile list of the query block (gt_sym.hip: the tiles of the cells nearest to the block's
+    //             own cells, then a strided sample of the rest; every tile at most once)
+    int n_tr_end = 0;
+    const int32_t* tl_base = nullptr;
+    int32_t tl_cache = 0;
+    if (own_sched) {
+        const int T = ntiles, NB = T / C::TPB;
+        t_begin = 0;
+        if (MODE == 2) {
+            const int H = (NB - 1) / 2;
+            n_tr_end = C::TPB * (1 + H);
+            t_end = n_tr_end + ((NB & 1) ? 0 : (NB > 1 ? C::TPB : 0));
+        } else {
+            t_end = sy.tile_cnt[bidx];
+            tl_base = sy.tile_list + size_t(bidx) * size_t(sy.tile_stride);
+            tl_cache = tl_base[lane < t_end ? lane : 0];
+        }
+    }
 
     // ---- query fragments (B operand), resident for the whole kernel ----
     Frag<DP, PREC> bq[QT];
     float thr[QT];
-    uint32_t fill[QT];   // MODE 0: entries in this lane's half of the query's list
+    float hnq[QT];       // MODE 2: the query's own seed (-inf on pad queries: never admitted anywhere)
+    uint32_t fill[QT];   // MODE 0 / 2: entries in this lane's half of the query's list
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
         fill[qt] = 0u;
@@ -331,13 +377,14 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
         // MODE 0: -inf, or a proven lower bound of the wanted scores indexed by row (gt_query_order); MODE 1: the radius
         thr[qt] = (MODE == 0) ? ((dbg & 1) ? INFINITY : (thr_in ? thr_in[row - q0] : -INFINITY))
                               : ((qg < nq) ? thr_in[qc] : INFINITY);
+        hnq[qt] = (MODE == 2) ? ((qg < nq) ? hneg[row] : -INFINITY) : 0.f;
     }
 
     // ---- tile staging (global -> registers -> LDS, padded rows), in two halves to halve the staging registers ----
     constexpr int HF4 = C::NF4 / 2;                      // 16-byte units per half tile
     constexpr int HF4_PER_THREAD = (HF4 + 255) / 256;
     float4 stage[HF4_PER_THREAD];
-    float stage_h = 0.f;
+    float stage_h = 0.f, stage_g = 0.f, stage_gm = 0.f;
 #define GT_STAGE_LOAD(T_, HALF_)                                                                          \
     {                                                                                                     \
         const float4* src_ = reinterpret_cast<const float4*>(Yp + size_t((GT_SEL_EXP & 64) ? ((T_) & 15) : (T_)) * BN * C::RW) + (HALF_) * HF4;   \
@@ -346,6 +393,10 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
             stage[u_] = (f < HF4) ? src_[f] : make_float4(0.f, 0.f, 0.f, 0.f);                            \
         }                                                                                                 \
         if ((HALF_) == 0) stage_h = (tid < BN) ? hneg[size_t(T_) * BN + tid] : 0.f;                       \
+        if (MODE == 2 && (HALF_) == 0) {                                                                  \
+            stage_g = (tid < BN) ? sy.g[size_t(T_) * BN + tid] : 0.f;                                     \
+            stage_gm = (tid < BN / 32) ? sy.gmin[size_t(T_) * (BN / 32) + tid] : 0.f;                     \
+        }                                                                                                 \
     }
 #define GT_STAGE_STORE(BUF_, HALF_)                                                                       \
     {                                                                                                     \
@@ -360,6 +411,8 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
             }                                                                                             \
         }                                                                                                 \
         if ((HALF_) == 0 && tid < BN) hn[(BUF_) * BN + tid] = stage_h;                                    \
+        if (MODE == 2 && (HALF_) == 0 && tid < BN) gb[(BUF_) * BN + tid] = stage_g;                       \
+        if (MODE == 2 && (HALF_) == 0 && tid < BN / 32) gm[(BUF_) * 8 + tid] = stage_gm;                  \
     }
 
     // direct global -> LDS staging of one tile (GLDS): wave wu copies pieces [wu*NPW, (wu+1)*NPW) of 1 KiB; lane L of
@@ -385,6 +438,12 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
         if (wu < BN / 64)                                                                                  \
             __builtin_amdgcn_global_load_lds((glb_void*)(hneg + size_t(T_) * BN + uint32_t(wu * 64) + lv_), \
                                              (lds_void*)(hn + (BUF_) * BN + wu * 64), 4, 0, 0);            \
+        if (MODE == 2 && wu >= BN / 64 && wu < 2 * (BN / 64))                                              \
+            __builtin_amdgcn_global_load_lds((glb_void*)(sy.g + size_t(T_) * BN + uint32_t((wu - BN / 64) * 64) + lv_), \
+                                             (lds_void*)(gb + (BUF_) * BN + (wu - BN / 64) * 64), 4, 0, 0); \
+        if (MODE == 2 && wu == 3 && lv_ < BN / 32)                                                         \
+            __builtin_amdgcn_global_load_lds((glb_void*)(sy.gmin + size_t(T_) * (BN / 32) + lv_),          \
+                                             (lds_void*)(gm + (BUF_) * 8), 4, 0, 0);                       \
     }
 
     // Tile order (MODE 0 with samp_stride = S > 1, a power of two): level 0 visits the tiles 0, S, 2S, ... with a small
@@ -395,8 +454,12 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
     // any budget is correct - thresholds only ever rise, and every entry dropped or rejected scored <= the final
     // threshold, which the float64 stage turns into a distance bound per row - the levels only cut the number of
     // admissions.
-    const int n_a = (MODE == 0 && samp_stride > 1) ? (ntiles + samp_stride - 1) / samp_stride : 0;
+    const int n_a = (MODE == 0 && samp_stride > 1 && !own_sched) ? (ntiles + samp_stride - 1) / samp_stride : 0;
     int t = t_begin, t_step = n_a ? samp_stride : 1, level = 0;
+    if (own_sched) {
+        t = int(bidx) * C::TPB;                                            // MODE 2: the own block first
+        if (MODE == 0) t = __builtin_amdgcn_readlane(tl_cache, 0);         // sched 1: first entry of the list
+    }
     if constexpr (C::GLDS) {
         GT_GLDS_ISSUE(t, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -412,6 +475,17 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
     for (int it = t_begin; it < t_end; ++it) {
         const int buf = (GT_SEL_EXP & (4 | 32)) ? 0 : ((it - t_begin) & 1);
         int t_next = t + t_step, level_next = level, t_step_next = t_step;
+        if (own_sched) {
+            if (MODE == 2) {
+                t_next = t + 1;
+                if (t_next >= ntiles) t_next -= ntiles;
+            } else if (it + 1 < t_end) {
+                // the list is read 64 entries at a time (one per lane), entries come out with a readlane
+                const int nx = it + 1;
+                if ((nx & 63) == 0) tl_cache = tl_base[nx + lane < t_end ? nx + lane : nx];
+                t_next = __builtin_amdgcn_readlane(tl_cache, nx & 63);
+            }
+        }
         const bool level_end = n_a && t_next >= ntiles;
         if (level_end) {   // next level: the odd multiples of samp_stride >> level_next
             level_next = level + 1;
@@ -428,6 +502,13 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
         const float* tb = tile + buf * C::TILE_FLOATS;
         const float* hb = hn + buf * BN;
         const uint32_t tbase = uint32_t(t) * BN;
+        // MODE 2: does this tile's block also take the results as ITS queries?  (wave-uniform; +inf switches the test off)
+        const bool tr_on = MODE == 2 && it >= C::TPB && it < n_tr_end;
+        const float* gbuf = gb + buf * BN;
+        float gms[BN / 32];
+#pragma unroll
+        for (int sb_ = 0; sb_ < BN / 32; ++sb_)
+            gms[sb_] = tr_on ? __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(gm[buf * 8 + sb_]))) : INFINITY;
 
         // Software pipeline over the NU = (BN/32)*QT units (sub-tile, query tile) of this tile, fully unrolled:
         //   unit u:  [ MFMA chain of u   ||   admission predicates of u-1 (VALU/SALU in the MFMA issue gaps) ]
@@ -464,10 +545,26 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
             if (MODE == 0) {                                                                               \
                 list_store(lp + fill[PQT_], cand_pack(v, j));                                              \
                 fill[PQT_] += 1u;                                                                          \
+            } else if (MODE == 2) {                                                                        \
+                if (fill[PQT_] < uint32_t(sy.hcap)) list_store(lp + fill[PQT_], cand_pack(v, j));          \
+                fill[PQT_] += 1u;   /* the true count: an overflowing row is repaired later */             \
             } else {                                                                                       \
                 const uint32_t slot = atomicAdd(&counts[qblock + ql], 1u);                                 \
                 if (slot < uint32_t(cap)) lp[slot] = cand_pack(v, j);                                      \
             }                                                                                              \
+        }                                                                                                  \
+    }
+// MODE 2, transposed direction: database row r_ of the tile takes query (PQT_, li) into its second list when the
+// score seen from its side, (x.y - |y_j|^2/2) + |y_j|^2/2 - |x_q|^2/2, beats its own threshold: (acc + hneg_q) > g_j
+#define GT_ADMIT_TR_ONE(PA_, E_, PSB_, PQT_)                                                               \
+    {                                                                                                      \
+        const int r_ = (PSB_) * 32 + 8 * ((E_) >> 2) + 4 * h + ((E_) & 3);                                 \
+        const float v = (PA_)[E_] + hq_;                                                                   \
+        if (v > gbuf[r_]) {                                                                                \
+            const uint32_t j = tbase + uint32_t(r_);                                                       \
+            const uint32_t slot = atomicAdd(&sy.tcounts[j], 1u);                                           \
+            if (slot < uint32_t(sy.tcap))                                                                  \
+                list_store(sy.tlists + size_t(j) * size_t(sy.tcap) + slot, cand_pack(v - hb[r_], uint32_t(qblock + ql))); \
         }                                                                                                  \
     }
 #define GT_ADMIT(PA_, ANY_, MX_, PSB_, PQT_)                                                               \
@@ -475,7 +572,8 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
         const float tq_ = thr[PQT_];                                                                       \
         const unsigned long long ts_ = prof ? __builtin_readcyclecounter() : 0ull;                         \
         const int ql = (w * QT + (PQT_)) * 32 + li;                                                        \
-        uint64_t* lp = lists + size_t(qblock + ql) * lstride + (MODE == 0 ? size_t(h) * HALF : size_t(0)); \
+        uint64_t* lp = lists + size_t(qblock + ql) * lstride +                                             \
+                       (MODE == 0 ? size_t(h) * HALF : MODE == 2 ? size_t(h) * size_t(sy.hcap) : size_t(0)); \
         _Pragma("unroll") for (int t_ = 0; t_ < 5; ++t_) {                                                 \
             if (__ballot((MX_)[t_] > tq_)) {                                                               \
                 GT_ADMIT_ONE(PA_, 3 * t_ + 0, PSB_, PQT_);                                                 \
@@ -484,6 +582,18 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
             }                                                                                              \
         }                                                                                                  \
         if (__ballot((PA_)[15] > tq_)) GT_ADMIT_ONE(PA_, 15, PSB_, PQT_);                                  \
+        if (MODE == 2 && tr_on) {                                                                          \
+            const float hq_ = hnq[PQT_];                                                                   \
+            const float gm_ = gms[PSB_];                                                                   \
+            _Pragma("unroll") for (int t_ = 0; t_ < 5; ++t_) {                                             \
+                if (__ballot((MX_)[t_] + hq_ > gm_)) {                                                     \
+                    GT_ADMIT_TR_ONE(PA_, 3 * t_ + 0, PSB_, PQT_);                                          \
+                    GT_ADMIT_TR_ONE(PA_, 3 * t_ + 1, PSB_, PQT_);                                          \
+                    GT_ADMIT_TR_ONE(PA_, 3 * t_ + 2, PSB_, PQT_);                                          \
+                }                                                                                          \
+            }                                                                                              \
+            if (__ballot((PA_)[15] + hq_ > gm_)) GT_ADMIT_TR_ONE(PA_, 15, PSB_, PQT_);                     \
+        }                                                                                                  \
         if (prof) { t_adm += __builtin_readcyclecounter() - ts_; n_adm += 1; }                             \
     }
         constexpr bool SEEDREG = GT_SEL_SEEDREG && PREC >= 1 && QT == 2;
@@ -533,7 +643,11 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
                 for (int t3 = 0; t3 < 5; ++t3) mx[t3] = fmaxf(fmaxf(pa[3 * t3], pa[3 * t3 + 1]), pa[3 * t3 + 2]);
                 const float m5 = fmaxf(fmaxf(mx[0], mx[1]), mx[2]);
                 const float m6 = fmaxf(fmaxf(mx[3], mx[4]), pa[15]);
-                any_hit = fmaxf(m5, m6) > tq;
+                const float m16 = fmaxf(m5, m6);
+                any_hit = m16 > tq;
+                // MODE 2: ... or some row of the sub-tile may want this query (same arithmetic as the cold path:
+                // rounding is monotone, so max(acc) + hq > min(g) whenever one acc_i + hq > g_i)
+                if (MODE == 2) any_hit = any_hit || (m16 + hnq[pqt] > gms[psb]);
             }
 #if GT_SEL_PIPE
             if (u > 0 && u < NU) {
@@ -556,7 +670,7 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
         }
         if (MODE == 0) {
             // ---- list maintenance: lane (li, h) owns half h of query (qt, li) ----
-            const bool phase_a = n_a && level == 0;
+            const bool phase_a = (n_a && level == 0) || own_sched;
             // forced cuts: after the last tile of level 0 (settles the seed threshold) and of level samp2_level
             const bool end_a = level_end && ((level == 0 && samp_end > 0) || (level > 0 && level == samp2_level));
             const uint32_t mkeep = end_a ? uint32_t(level == 0 ? samp_end : samp2_keep)
@@ -619,6 +733,11 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
         o[5] = t_lvl0; o[6] = n_adm_lvl0; o[7] = __builtin_readcyclecounter() - t_start;
     }
 
+    if (MODE == 2) {
+        // lane (li, h) owns half h of query (qt, li): publish its (true) entry count
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) counts[size_t(qblock + (w * QT + qt) * 32 + li) * 2 + h] = fill[qt];
+    }
     // ---- finalisation: gather every list into slots [0, count), publish count and the last admission threshold ----
     if (MODE == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -746,7 +865,15 @@ int launch_one(gt_ctx* ctx, const SelectArgs& a) {
     auto kern = knn_select_kernel<DP, NT, MODE, PREC>;
     GT_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     int(C::LDS_BYTES)));
-    size_t lds_bytes = C::LDS_BYTES;
+    size_t lds_bytes = MODE == 2 ? C::LDS_BYTES_SYM : C::LDS_BYTES;
+    if (MODE == 2) {
+        GT_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        int(lds_bytes)));
+        if (a.n_pad % C::BQ != 0 || a.nq > a.n_pad || a.sym.hcap <= 0 || a.sym.tcap <= 0)
+            GT_FAIL(ctx, GT_E_ARG, "knn_select: symmetric collect needs the padded point set as queries and database");
+    }
+    if (MODE == 0 && a.sym.sched == 1 && a.n_pad % C::BQ != 0)
+        GT_FAIL(ctx, GT_E_ARG, "knn_select: the own-neighbourhood schedule needs whole query blocks");
     if (a.dbg & 128) {   // experiment: one workgroup per CU
         lds_bytes += 24 * 1024;
         GT_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -756,7 +883,7 @@ int launch_one(gt_ctx* ctx, const SelectArgs& a) {
                        a.hneg, a.Qp, a.qrows, a.q0, a.nq, ntiles, a.lists, a.counts, a.thr_in, a.thr_out, a.cap, a.dbg, a.prof,
                        a.samp_stride, a.samp_keep, a.samp_end, a.samp2_level, a.samp2_keep,
                        (a.samp_trig > 0 && a.samp_trig <= 32 * NT - C::BN / 2) ? a.samp_trig : a.samp_keep / 2 + 24,
-                       (a.final_keep > 0 && a.final_keep <= 64 * NT) ? a.final_keep : 16 * NT);
+                       (a.final_keep > 0 && a.final_keep <= 64 * NT) ? a.final_keep : 16 * NT, a.sym);
     GT_HIP(ctx, hipGetLastError());
     return GT_OK;
 }
@@ -764,6 +891,10 @@ int launch_one(gt_ctx* ctx, const SelectArgs& a) {
 template <int DP, int PREC>
 int launch_dp(gt_ctx* ctx, const SelectArgs& a) {
     if (a.mode == 1) return launch_one<DP, 8, 1, PREC>(ctx, a);
+    if (a.mode == 2) {
+        if constexpr (PREC == 2) return launch_one<DP, 8, 2, PREC>(ctx, a);
+        GT_FAIL(ctx, GT_E_ARG, "knn_select: symmetric collect runs on the single-chain arithmetic only");
+    }
     switch (a.nt) {
         case 8: return launch_one<DP, 8, 0, PREC>(ctx, a);
         case 32: return launch_one<DP, 32, 0, PREC>(ctx, a);

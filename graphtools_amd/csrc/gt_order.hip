@@ -38,6 +38,7 @@ __global__ __launch_bounds__(256) void iota_rows_kernel(const int64_t q0, const 
 int gt_query_order(gt_ctx* ctx, const float* Qc, int64_t q0, int64_t nq, int need, int32_t* out_rows, float* out_thr0,
                    int* active) {
     *active = 0;
+    ctx->order_L = 0;
     const int64_t kMinRows = ctx->order_min_rows;   // below this the whole launch is a few workgroup rounds
     if (!ctx->query_order || ctx->prec != 1 || ctx->fast_mode == 0 || !ctx->Yc.p || !Qc || nq < kMinRows || ctx->n < std::max<int64_t>(kMinRows, 64))
         return GT_OK;
@@ -67,6 +68,7 @@ int gt_query_order(gt_ctx* ctx, const float* Qc, int64_t q0, int64_t nq, int nee
     GT_HIP(ctx, ctx->order_tmp.reserve(tmp_bytes));
     GT_HIP(ctx, rocprim::radix_sort_pairs(ctx->order_tmp.p, tmp_bytes, cell, cell_sorted, ctx->order_rows.as<int32_t>(),
                                           out_rows, size_t(nq), 0u, unsigned(bits), ctx->stream));
+    ctx->order_L = L;   // cells of the order just built (cell ids of the sorted rows: order_cell + nq)
     *active = 1;
     return GT_OK;
 }

@@ -199,6 +199,153 @@ __global__ __launch_bounds__(256) void rerank_kernel(const T* __restrict__ X, co
     }
 }
 
+// ---- re-rank of the symmetric candidate pass (knn_select_kernel MODE 2) ---------------------------------------
+// List ql belongs to the row at cell-sorted position ql (row perm[ql]); its candidates sit in three segments - the two
+// half-wave halves of the forward list and the transposed list other workgroups appended to - as (score, sorted
+// position) keys collected against the FIXED threshold thr[ql]: every row that is not in them scored <= thr[ql].
+// The 256 best approximate scores are evaluated exactly in two batches of 128 like above; a row whose segments
+// overflowed (or hold more than 512 keys together) is handed to the repair path (bound = -inf).
+template <typename T>
+__global__ __launch_bounds__(256) void rerank_sym_kernel(
+    const T* __restrict__ X, const int d, const double* __restrict__ xn, const int64_t nq,
+    const uint64_t* __restrict__ lists, const int hcap, const uint32_t* __restrict__ counts2,
+    const uint64_t* __restrict__ tlists, const int tcap, const uint32_t* __restrict__ tcounts,
+    const float* __restrict__ thr, const double* __restrict__ ymax2p, const ErrModel err, const int need_m,
+    const int32_t* __restrict__ perm, double* __restrict__ cand_d2, uint32_t* __restrict__ cand_j,
+    uint32_t* __restrict__ cand_n, double* __restrict__ d2_lb, uint32_t* __restrict__ fb_count,
+    int32_t* __restrict__ fb_rows, uint32_t* __restrict__ gflags, const double radius_key_factor,
+    uint32_t* __restrict__ unproven, unsigned long long* __restrict__ stat, const int want_stats) {
+    constexpr int MP = 256;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int lane = threadIdx.x & 63;
+    const int w = threadIdx.x >> 6;
+    double* xs = reinterpret_cast<double*>(smem_raw) + size_t(w) * d;
+    const int64_t nb = gridDim.x, xcd = blockIdx.x & 7, base = nb >> 3, rem = nb & 7;
+    const int64_t bid = xcd * base + (xcd < rem ? xcd : rem) + (blockIdx.x >> 3);
+    const int64_t ql = bid * 4 + w;
+    if (ql >= nq) return;
+    const int64_t q = perm[ql];
+    const T* xrow = X + q * int64_t(d);
+    for (int k = lane; k < d; k += 64) xs[k] = double(xrow[k]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const double qnq = xn[q];
+    const uint32_t c0 = counts2[2 * ql], c1 = counts2[2 * ql + 1], ct = tcounts[ql];
+    const uint32_t n0 = c0 < uint32_t(hcap) ? c0 : uint32_t(hcap);
+    const uint32_t n1 = c1 < uint32_t(hcap) ? c1 : uint32_t(hcap);
+    const uint32_t nt = ct < uint32_t(tcap) ? ct : uint32_t(tcap);
+    const bool overflow = c0 > uint32_t(hcap) || c1 > uint32_t(hcap) || ct > uint32_t(tcap) || n0 + n1 + nt > 512u;
+    const uint32_t n = overflow ? (n0 + n1 + nt < 512u ? n0 + n1 + nt : 512u) : n0 + n1 + nt;
+    const uint64_t* lp = lists + size_t(ql) * size_t(2 * hcap);
+    const uint64_t* tp = tlists + size_t(ql) * size_t(tcap);
+
+    const double y2 = ymax2p[0];
+    const double e = gt_err_bound(err, qnq, y2);
+    auto bound_of_score = [&](float score) {
+        const double sv = double(score) * err.inv_sc2;
+        return (qnq - 2.0 * (sv + e)) - 1e-9 * (qnq + y2);
+    };
+    double lb = overflow ? -INFINITY : bound_of_score(thr[ql]);
+
+    uint64_t ks[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const uint32_t c = uint32_t(u * 64 + lane);
+        uint64_t kv = 0ull;   // a valid key is never 0
+        if (c < n0)
+            kv = lp[c];
+        else if (c < n0 + n1)
+            kv = lp[size_t(hcap) + (c - n0)];
+        else if (c < n)
+            kv = tp[c - n0 - n1];
+        ks[u] = kv;
+    }
+    wave_bitonic_desc<8>(ks, lane);
+    const uint32_t n_eval = n < uint32_t(MP) ? n : uint32_t(MP);
+    uint64_t hi[4], lo[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        hi[u] = kInfBits;
+        lo[u] = 0xFFFFFFFFull;
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        if (ks[u] != 0ull) {
+            const uint32_t j = uint32_t(perm[cand_index(ks[u])]);
+            const double dot = dot_row<T>(xs, X + int64_t(j) * d, d);
+            hi[u] = (uint64_t)__double_as_longlong(gt_pair_key(qnq, dot, xn[j], 0));
+            lo[u] = j;
+        }
+    }
+    const int pos = need_m - 1;
+    const bool may_stop = radius_key_factor > 0.0;
+    const double rkf = fabs(radius_key_factor);
+    const uint64_t k129 = __shfl((unsigned long long)ks[2], 0);
+    const uint64_t k257 = __shfl((unsigned long long)ks[4], 0);
+    const double lb_rest = (k129 != 0ull) ? bound_of_score(cand_score(k129)) : INFINITY;
+    uint64_t h2[2] = {hi[0], hi[1]}, l2[2] = {lo[0], lo[1]};
+    wave_bitonic_asc_pair<2>(h2, l2, lane);
+    const uint64_t sel2 = (pos >> 6) == 0 ? h2[0] : h2[1];
+    const double need2 = __longlong_as_double((long long)__shfl((unsigned long long)sel2, pos & 63));
+    const double lbm = fmin(lb, lb_rest);
+    uint32_t n_tab = n_eval;
+    if (may_stop && pos < 128 && need2 * rkf < lbm) {   // wave-uniform
+        hi[0] = h2[0]; hi[1] = h2[1];
+        lo[0] = l2[0]; lo[1] = l2[1];
+        lb = lbm;
+        n_tab = n_eval < 128u ? n_eval : 128u;
+    } else {
+#pragma unroll
+        for (int u = 2; u < 4; ++u) {
+            if (ks[u] != 0ull) {
+                const uint32_t j = uint32_t(perm[cand_index(ks[u])]);
+                const double dot = dot_row<T>(xs, X + int64_t(j) * d, d);
+                hi[u] = (uint64_t)__double_as_longlong(gt_pair_key(qnq, dot, xn[j], 0));
+                lo[u] = j;
+            }
+        }
+        if (k257 != 0ull) lb = fmin(lb, bound_of_score(cand_score(k257)));   // candidates beyond the table
+        wave_bitonic_asc_pair<4>(hi, lo, lane);
+    }
+    const uint32_t n_def = n_tab > uint32_t(need_m) ? n_tab : uint32_t(need_m);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        if (uint32_t(u * 64) < n_def) {   // wave-uniform
+            cand_d2[size_t(q) * MP + u * 64 + lane] = __longlong_as_double((long long)hi[u]);
+            cand_j[size_t(q) * MP + u * 64 + lane] = uint32_t(lo[u]);
+        }
+    }
+    uint64_t sel = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        if ((pos >> 6) == u) sel = hi[u];
+    const double d2_need = __longlong_as_double((long long)__shfl((unsigned long long)sel, pos & 63));
+    const uint64_t second = __shfl((unsigned long long)hi[0], 1);
+    if (lane == 0) {
+        cand_n[q] = n_tab;
+        d2_lb[q] = lb;
+        if (!(d2_need < lb)) {
+            const uint32_t slot = atomicAdd(fb_count, 1u);
+            fb_rows[slot] = int32_t(q);
+        }
+        if (unproven && !(d2_need * rkf < lb)) atomicAdd(unproven, 1u);
+        if (stat && overflow) atomicAdd(stat + 0, 1ull);
+        if (stat && want_stats) {
+            // [1] sum of forward counts [2] sum of transposed counts [3] largest total [4] rows with more than 256 keys
+            // [5] rows with a forward half over capacity [6] transposed list over capacity [7] rows with more than 128 keys
+            const unsigned long long tot = (unsigned long long)c0 + c1 + ct;
+            atomicAdd(stat + 1, (unsigned long long)c0 + c1);
+            atomicAdd(stat + 2, (unsigned long long)ct);
+            atomicMax(stat + 3, tot);
+            if (tot > 256ull) atomicAdd(stat + 4, 1ull);
+            if (c0 > uint32_t(hcap) || c1 > uint32_t(hcap)) atomicAdd(stat + 5, 1ull);
+            if (ct > uint32_t(tcap)) atomicAdd(stat + 6, 1ull);
+            if (tot > 128ull) atomicAdd(stat + 7, 1ull);
+        }
+        if (n_tab > 1 && second == 0ull) atomicOr(gflags, GT_FLAG_DUPLICATES);
+    }
+}
+
 // ---- exhaustive exact fallback: one workgroup per flagged query ---------------------------------
 template <typename T, int NT2>
 __global__ __launch_bounds__(256) void fallback_kernel(const T* __restrict__ X, const int64_t n, const int d,
@@ -547,4 +694,22 @@ int gt_launch_collected_select(gt_ctx* ctx, const RerankArgs& a, int64_t n_rows,
                                const uint32_t* ccounts, int cap, double* scratch, uint32_t* fail) {
     if (a.dtype == GT_F32) return collected_t<float>(ctx, a, n_rows, row_off, clists, ccounts, cap, scratch, fail);
     return collected_t<double>(ctx, a, n_rows, row_off, clists, ccounts, cap, scratch, fail);
+}
+
+int gt_launch_rerank_sym(gt_ctx* ctx, const RerankArgs& a, const SymRerank& sr) {
+    const int64_t blocks = ceil_div64(a.nq, 4);
+    const size_t lds = size_t(4) * a.d * sizeof(double);
+    if (a.MP != 256 || a.metric != 0) GT_FAIL(ctx, GT_E_ARG, "rerank_sym: table width 256, euclidean metric only");
+    if (a.dtype == GT_F32)
+        hipLaunchKernelGGL((rerank_sym_kernel<float>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, (const float*)a.X,
+                           a.d, a.xn, a.nq, a.lists, sr.hcap, sr.counts2, sr.tlists, sr.tcap, sr.tcounts, a.thr_final, a.ymax2,
+                           a.err, a.need_m, sr.perm, a.cand_d2, a.cand_j, a.cand_n, a.d2_lb, a.fb_count, a.fb_rows, a.gflags,
+                           a.radius_key_factor, a.unproven, sr.stat, (ctx->dbg_select & 256) ? 1 : 0);
+    else
+        hipLaunchKernelGGL((rerank_sym_kernel<double>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, (const double*)a.X,
+                           a.d, a.xn, a.nq, a.lists, sr.hcap, sr.counts2, sr.tlists, sr.tcap, sr.tcounts, a.thr_final, a.ymax2,
+                           a.err, a.need_m, sr.perm, a.cand_d2, a.cand_j, a.cand_n, a.d2_lb, a.fb_count, a.fb_rows, a.gflags,
+                           a.radius_key_factor, a.unproven, sr.stat, (ctx->dbg_select & 256) ? 1 : 0);
+    GT_HIP(ctx, hipGetLastError());
+    return GT_OK;
 }

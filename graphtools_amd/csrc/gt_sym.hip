@@ -1,0 +1,324 @@
+// Symmetric candidate pass for self queries over the whole point set (euclidean, single-chain float16 arithmetic).
+//
+// The candidate kernel scores query x against database row y as x.y - |y|^2/2; the dot product is the same MFMA chain
+// whichever of the two rows is the query, so one 32 x 32 result block can serve both directions.  That only works
+// against FIXED per-row thresholds (a row's list is then fed by many workgroups and nobody can compact it), so the pass
+// runs in two launches over the points in CELL-SORTED order (gt_order.hip: rows grouped by nearest landmark, position
+// p <-> row perm[p]; queries and database share the order, a query block's neighbours sit next to it):
+//   A  knn_select_kernel<MODE 0, sched 1>: every row against its own neighbourhood - the rows of the sym_cells cells
+//      whose landmarks are nearest to the landmarks of the query block's own cells (contiguous ranges in the sorted
+//      order) - plus every sym_stride-th tile of the rest, keeping the need_m best rows seen.  sym_thresholds_kernel
+//      evaluates those need_m rows exactly (float64): the largest of their keys, D_K, bounds the need_m-th neighbour's,
+//      and every row the caller needs - within radius_key_factor x that - provably scores above the fixed threshold
+//      thr[p] it derives.
+//   B  knn_select_kernel<MODE 2>: query block I streams blocks I .. I + (NB-1)/2 only; each result is tested against
+//      the lane's threshold (forward) and the database row's (transposed).  N^2 d MFMA flop instead of 2 N^2 d, no
+//      list compaction, no threshold updates; on clustered data almost every unit leaves through the one compare.
+//   C  rerank_sym_kernel (gt_rerank.hip): exact float64 keys of the (up to 256) best candidates per row, completeness
+//      bound from thr[p]; rows whose lists overflowed go to the usual repair path.
+// The roofline line of bench.py prices this pass at the algorithmic 2 N^2 d and reports the executed
+// matrix work next to it.
+#include "gt_common.h"
+#include "gt_device.h"
+#include "gt_knn.h"
+#include "gt_knn_select.h"
+
+#include <algorithm>
+
+namespace {
+
+// rows of the compact hi-plane copy (2*DP bytes = c16 16-byte chunks) and their seeds in cell-sorted order; pad rows:
+// zeros / -inf
+__global__ __launch_bounds__(256) void gather_sorted_kernel(const uint4* __restrict__ Yc, const float* __restrict__ hneg,
+                                                            const int32_t* __restrict__ perm, const int64_t n,
+                                                            const int64_t n_pad, const int c16, uint4* __restrict__ Ys,
+                                                            float* __restrict__ hs) {
+    const int64_t f = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (f >= n_pad * c16) return;
+    const int64_t p = f / c16;
+    const int c = int(f % c16);
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (p < n) {
+        const int64_t r = perm[p];
+        v = Yc[r * c16 + c];
+        if (c == 0) hs[p] = hneg[r];
+    } else if (c == 0) {
+        hs[p] = -INFINITY;
+    }
+    Ys[f] = v;
+}
+
+// Fixed thresholds of launch B from the need_m rows launch A kept for sorted position p (list slots [0, kept)):
+//   D_K = the largest exact key (float64 squared distance, scikit-learn's association) among them: need_m distinct rows
+//   lie within D_K, so the need_m-th neighbour does.  The caller needs every row with d^2 <= rkf * d^2(need_m-th) <=
+//   R2 := rkf * D_K (1 + 1e-5); such a row has true score >= (|x|^2 - R2)/2 and scaled candidate score
+//   >= sc^2 ((|x|^2 - R2)/2 - e) =: thr (rounded down).
+// g[p] = thr[p] + hneg[p] (rounded down): the form the transposed test of launch B compares against;
+// gmin[p/32] = min of g over the 32 rows of a sub-tile.
+// 16 lanes per row (one candidate each, need_m <= 64 in turns), 16 rows per 256-thread block.
+template <typename T>
+__global__ __launch_bounds__(256) void sym_thresholds_kernel(const int64_t n, const int64_t n_pad,
+                                                             const int32_t* __restrict__ perm, const T* __restrict__ X,
+                                                             const int d, const double* __restrict__ xn,
+                                                             const float* __restrict__ hs,
+                                                             const uint64_t* __restrict__ lists, const int lstride,
+                                                             const uint32_t* __restrict__ counts, const int need_m,
+                                                             const double* __restrict__ ymax2p, const ErrModel err,
+                                                             const double rkf, float* __restrict__ thr,
+                                                             float* __restrict__ g) {
+    const int sub = threadIdx.x & 15;
+    const int64_t p = int64_t(blockIdx.x) * 16 + (threadIdx.x >> 4);
+    if (p >= n_pad) return;   // whole 16-lane group
+    float t = INFINITY, gv = INFINITY;
+    if (p < n) {
+        const int64_t q = perm[p];
+        const T* xq = X + q * int64_t(d);
+        const double qs = xn[q];
+        const uint32_t kept = counts[p];
+        double dk = 0.0;
+        for (uint32_t c = uint32_t(sub); c < kept; c += 16u) {
+            const int64_t j = perm[cand_index(lists[size_t(p) * lstride + c])];
+            const T* yj = X + j * int64_t(d);
+            double acc = 0.0;
+            for (int k = 0; k < d; ++k) acc = fma(double(xq[k]), double(yj[k]), acc);
+            dk = fmax(dk, gt_pair_key(qs, acc, xn[j], 0));
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) dk = fmax(dk, __shfl_xor(dk, o));
+        const double y2 = ymax2p[0];
+        const double e = gt_err_bound(err, qs, y2);
+        t = -3.0e38f;
+        if (kept >= uint32_t(need_m)) {
+            const double R2 = rkf * dk * (1.0 + 1e-5) + 1e-9 * (qs + y2);
+            const double smin = 0.5 * (qs - R2);
+            const double x = (smin - e - 1e-9 * (qs + y2)) / err.inv_sc2;
+            t = float(x);
+            if (double(t) >= x) t = nextafterf(t, -INFINITY);
+            if (!(t > -3.0e38f)) t = -3.0e38f;
+        }
+        gv = nextafterf(t + hs[p], -INFINITY);
+    }
+    if (sub == 0) {
+        thr[p] = t;
+        g[p] = gv;
+    }
+}
+
+__global__ __launch_bounds__(256) void sym_gmin_kernel(const int64_t n_pad, const float* __restrict__ g,
+                                                       float* __restrict__ gmin) {
+    const int64_t p = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    float m = p < n_pad ? g[p] : INFINITY;
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) m = fminf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 31) == 0 && p < n_pad) gmin[p >> 5] = m;
+}
+
+// ---- neighbourhood schedule of launch A -------------------------------------------------------------------------
+// M nearest landmarks of every landmark (itself first): one wave per landmark, float32 squared differences of the
+// float16 landmark rows (approximate by design: any tile list is correct)
+__global__ __launch_bounds__(64) void landmark_neighbours_kernel(const _Float16* __restrict__ Yl, const int L, const int DP,
+                                                                 const int M, int32_t* __restrict__ nbr) {
+    extern __shared__ float dist[];   // [L]
+    const int a = blockIdx.x, lane = threadIdx.x;
+    const _Float16* ra = Yl + size_t(a) * DP;
+    for (int b = lane; b < L; b += 64) {
+        const _Float16* rb = Yl + size_t(b) * DP;
+        float acc = 0.f;
+        for (int k = 0; k < DP; ++k) {
+            const float df = float(ra[k]) - float(rb[k]);
+            acc = fmaf(df, df, acc);
+        }
+        dist[b] = acc;
+    }
+    __syncthreads();
+    for (int m = 0; m < M; ++m) {
+        float best = INFINITY;
+        int bi = 0x7fffffff;
+        for (int b = lane; b < L; b += 64) {
+            const float v = dist[b];
+            if (v < best) {
+                best = v;
+                bi = b;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(best, o);
+            const int oi = __shfl_xor(bi, o);
+            if (ov < best || (ov == best && oi < bi)) {
+                best = ov;
+                bi = oi;
+            }
+        }
+        if (lane == 0) {
+            nbr[size_t(a) * M + m] = (bi < L) ? bi : a;
+            if (bi < L) dist[bi] = INFINITY;
+        }
+        __syncthreads();
+    }
+}
+
+// rows of every cell in the sorted order: cell_sorted is non-decreasing, cell c = positions [start[c], start[c] + cnt[c])
+__global__ __launch_bounds__(256) void cell_ranges_kernel(const uint32_t* __restrict__ cell_sorted, const int64_t n,
+                                                          int32_t* __restrict__ start, int32_t* __restrict__ cnt) {
+    const int64_t p = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (p >= n) return;
+    const uint32_t c = cell_sorted[p];
+    if (p == 0 || cell_sorted[p - 1] != c) start[c] = int32_t(p);
+    if (p + 1 == n || cell_sorted[p + 1] != c) cnt[c] = int32_t(p + 1);   // end position for now (fixed up by the reader)
+}
+
+// Tile list of every query block (one wave each): its own tiles, then the tiles of the M cells nearest to each of the
+// (up to 8) cells its rows belong to - nearest first, round robin over the block's cells, until max_nb tiles are
+// spoken for - in ascending order, then every stride-th tile that is not among them.  The neighbourhood is collected
+// as a bitmap over the T tiles in LDS, so every tile appears at most once.
+__global__ __launch_bounds__(64) void sym_schedule_kernel(const uint32_t* __restrict__ cell_sorted, const int64_t n,
+                                                          const int32_t* __restrict__ start, const int32_t* __restrict__ endp,
+                                                          const int32_t* __restrict__ nbr, const int M, const int NB,
+                                                          const int BQ, const int BN, const int T, const int stride,
+                                                          const int max_nb, const int tile_stride,
+                                                          int32_t* __restrict__ tile_list, int32_t* __restrict__ tile_cnt) {
+    extern __shared__ uint32_t bm[];   // [ceil(T / 32)]
+    const int I = blockIdx.x, lane = threadIdx.x;
+    const int nw = (T + 31) / 32;
+    for (int w = lane; w < nw; w += 64) bm[w] = 0u;
+    __syncthreads();
+    const int tpb = BQ / BN;
+    const int own_a = I * tpb, own_b = I * tpb + tpb - 1;
+    // distinct cells of the block's rows (sampled every BQ/8 rows; the cell ids are non-decreasing)
+    const int64_t r0 = int64_t(I) * BQ;
+    uint32_t mycell = 0xFFFFFFFFu;
+    if (lane < 8) {
+        int64_t r = r0 + int64_t(lane) * (BQ / 8) + BQ / 16;
+        r = r < n ? r : n - 1;
+        if (r0 < n) mycell = cell_sorted[r];
+    }
+    const uint32_t prev = __shfl_up(mycell, 1);
+    const bool first = lane < 8 && mycell != 0xFFFFFFFFu && (lane == 0 || prev != mycell);
+    const unsigned long long fm = __ballot(first);
+    const int nu = __popcll(fm);
+    // candidate intervals in priority order idx = m * nu + which
+    int carry = tpb;   // tiles spoken for so far (the own ones)
+    for (int base = 0; base < nu * M; base += 64) {
+        const int idx = base + lane;
+        int a = 0, b = -1;
+        if (idx < nu * M) {
+            const int m = idx / nu, which = idx % nu;
+            // which-th set bit of fm -> the lane that holds that cell
+            unsigned long long f = fm;
+            for (int i = 0; i < which; ++i) f &= f - 1;
+            const int src = __ffsll((long long)f) - 1;
+            const uint32_t c = __shfl(mycell, src);
+            const int cb = nbr[size_t(c) * M + m];
+            const int s = start[cb], e = endp[cb];
+            if (s >= 0 && e > s) {
+                a = s / BN;
+                b = (e - 1) / BN;
+            }
+        }
+        int len = b - a + 1;
+        int incl = len;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(incl, o);
+            if (lane >= o) incl += v;
+        }
+        const bool take = len > 0 && carry + incl <= max_nb;
+        if (take)
+            for (int t = a; t <= b; ++t) atomicOr(&bm[t >> 5], 1u << (t & 31));
+        carry += __shfl(incl, 63);
+    }
+    __syncthreads();
+    if (lane == 0)   // the own tiles are emitted first, by hand
+        for (int t = own_a; t <= own_b; ++t) bm[t >> 5] &= ~(1u << (t & 31));
+    __syncthreads();
+    int32_t* out = tile_list + size_t(I) * tile_stride;
+    int cnt = 0;
+    if (lane < tpb) out[lane] = own_a + lane;
+    cnt = tpb;
+    for (int w0 = 0; w0 < nw; w0 += 64) {
+        const int w = w0 + lane;
+        uint32_t word = w < nw ? bm[w] : 0u;
+        const int c = __popc(word);
+        int incl = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(incl, o);
+            if (lane >= o) incl += v;
+        }
+        int pos = cnt + incl - c;
+        while (word) {
+            const int bit = __ffs(int(word)) - 1;
+            word &= word - 1;
+            if (pos < tile_stride) out[pos] = w * 32 + bit;
+            ++pos;
+        }
+        cnt += __shfl(incl, 63);
+    }
+    if (stride > 0) {
+        for (int k0 = 0; k0 * stride < T; k0 += 64) {
+            const int t = (k0 + lane) * stride;
+            const bool want = t < T && !((bm[t >> 5] >> (t & 31)) & 1u) && (t < own_a || t > own_b);
+            const unsigned long long wm = __ballot(want);
+            const int pos = cnt + __popcll(wm & ((1ull << lane) - 1ull));
+            if (want && pos < tile_stride) out[pos] = t;
+            cnt += __popcll(wm);
+        }
+    }
+    if (lane == 0) tile_cnt[I] = cnt < tile_stride ? cnt : tile_stride;
+}
+
+}  // namespace
+
+int gt_sym_gather(gt_ctx* ctx, const int32_t* perm, int64_t n_pad_s, void* Ys, float* hs) {
+    const int c16 = ctx->DP / 8;   // 2*DP bytes per row
+    const int64_t total = n_pad_s * c16;
+    hipLaunchKernelGGL(gather_sorted_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, ctx->stream,
+                       ctx->Yc.as<uint4>(), ctx->hneg.as<float>(), perm, ctx->n, n_pad_s, c16, reinterpret_cast<uint4*>(Ys), hs);
+    GT_HIP(ctx, hipGetLastError());
+    return GT_OK;
+}
+
+int gt_sym_thresholds(gt_ctx* ctx, const int32_t* perm, int64_t n_pad_s, const float* hs, const uint64_t* lists, int lstride,
+                      const uint32_t* counts, int need_m, const ErrModel& err, double rkf, float* thr, float* g, float* gmin) {
+    const dim3 grid((unsigned)ceil_div64(n_pad_s, 16));
+    if (ctx->dtype == GT_F32)
+        hipLaunchKernelGGL(sym_thresholds_kernel<float>, grid, dim3(256), 0, ctx->stream, ctx->n, n_pad_s, perm,
+                           (const float*)ctx->X, ctx->d, ctx->xn.as<double>(), hs, lists, lstride, counts, need_m,
+                           ctx->ymax.as<double>(), err, rkf, thr, g);
+    else
+        hipLaunchKernelGGL(sym_thresholds_kernel<double>, grid, dim3(256), 0, ctx->stream, ctx->n, n_pad_s, perm,
+                           (const double*)ctx->X, ctx->d, ctx->xn.as<double>(), hs, lists, lstride, counts, need_m,
+                           ctx->ymax.as<double>(), err, rkf, thr, g);
+    GT_HIP(ctx, hipGetLastError());
+    hipLaunchKernelGGL(sym_gmin_kernel, dim3((unsigned)ceil_div64(n_pad_s, 256)), dim3(256), 0, ctx->stream, n_pad_s, g, gmin);
+    GT_HIP(ctx, hipGetLastError());
+    return GT_OK;
+}
+
+// Tile lists of launch A for the NB query blocks of the sorted order (tile_list [NB][tile_stride], tile_cnt [NB]).
+// Uses the landmark rows and the sorted cell ids the query ordering left in the context (gt_order.hip).
+int gt_sym_schedule(gt_ctx* ctx, int64_t n_pad_s, int bq, int bn, int cells, int stride, int max_nb, int tile_stride,
+                    DevBuf& work, int32_t* tile_list, int32_t* tile_cnt) {
+    const int L = ctx->order_L;
+    if (L <= 0 || !ctx->land_Y.p) GT_FAIL(ctx, GT_E_STATE, "sym schedule: no landmark cells");
+    const int M = std::min(std::min(cells, 32), L);
+    // work: nbr [L][M] | start [L] | end [L]
+    GT_HIP(ctx, work.reserve((size_t(L) * M + 2 * size_t(L)) * sizeof(int32_t)));
+    int32_t* nbr = work.as<int32_t>();
+    int32_t* start = nbr + size_t(L) * M;
+    int32_t* endp = start + L;
+    GT_HIP(ctx, hipMemsetAsync(start, 0xFF, 2 * size_t(L) * sizeof(int32_t), ctx->stream));   // -1: empty cell
+    hipLaunchKernelGGL(landmark_neighbours_kernel, dim3((unsigned)L), dim3(64), size_t(L) * sizeof(float), ctx->stream,
+                       ctx->land_Y.as<_Float16>(), L, ctx->DP, M, nbr);
+    GT_HIP(ctx, hipGetLastError());
+    const uint32_t* cell_sorted = ctx->order_cell.as<uint32_t>() + ctx->n;
+    hipLaunchKernelGGL(cell_ranges_kernel, dim3((unsigned)ceil_div64(ctx->n, 256)), dim3(256), 0, ctx->stream, cell_sorted,
+                       ctx->n, start, endp);
+    GT_HIP(ctx, hipGetLastError());
+    const int NB = int(n_pad_s / bq), T = int(n_pad_s / bn);
+    hipLaunchKernelGGL(sym_schedule_kernel, dim3((unsigned)NB), dim3(64), size_t((T + 31) / 32) * sizeof(uint32_t), ctx->stream,
+                       cell_sorted, ctx->n, start, endp, nbr, M, NB, bq, bn, T, stride, max_nb, tile_stride, tile_list, tile_cnt);
+    GT_HIP(ctx, hipGetLastError());
+    return GT_OK;
+}

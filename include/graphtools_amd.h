@@ -108,10 +108,16 @@ int gt_stage_launches(const gt_ctx* ctx, const char* stage);
  * deal the query rows of large launches to workgroups grouped by nearest landmark - speed only).  Tuning switches of
  * the candidate pass (development; results never depend on them): "select_samp_stride", "select_samp_keep",
  * "select_samp_end", "select_samp2_level", "select_samp2_keep", "select_samp_trig", "select_thr0", "select_narrow",
- * "query_order_cell_rows"; "dbg_select" switches invalidate the results. */
+ * "query_order_cell_rows", "query_order_min_rows"; "select_symmetric" ("auto" | 0 | 1: self queries over the whole point set score every
+ * unordered pair of rows once and test the result for both rows - gt_sym.hip), "select_sym_stride",
+ * "select_sym_min_rows", "select_sym_tcap", "select_sym_cells", "select_sym_max_nb"; "dbg_select" switches invalidate the results. */
 int gt_set_option(gt_ctx* ctx, const char* name, const char* value);
 /* arithmetic the most recent main candidate pass ran on: 0 float32, 1 split float16 (3 chains), 2 single float16 chain */
 int gt_last_knn_precision(const gt_ctx* ctx);
+/* statistics of the most recent kNN candidate search: out[0] = 1 if the symmetric pass ran, out[1] = rows whose
+ * symmetric lists overflowed (repaired), out[2] = rows repaired in all, out[3] = of those by the exhaustive kernel,
+ * out[4..11] = list-length counters of the symmetric pass (rerank_sym_kernel) */
+int gt_knn_stats(const gt_ctx* ctx, int64_t* out12);
 
 /* ---- points ------------------------------------------------------------------------------ */
 /* Bind the data matrix (n x d).  Replaces NearestNeighbors(...).fit(data_nu) (graphs.py:763-768):

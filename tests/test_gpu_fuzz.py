@@ -33,3 +33,13 @@ def test_random_configurations_with_grouped_queries():
                          text=True, timeout=1500, env=env)
     tail = "\n".join(res.stdout.strip().splitlines()[-6:])
     assert res.returncode == 0, tail + "\n" + res.stderr[-2000:]
+
+
+def test_random_configurations_with_the_symmetric_pass():
+    """the same sweep with the symmetric candidate pass (gt_sym.hip) forced on wherever it applies (euclidean self
+    queries of at least 2048 rows; by default it only engages from 65536 rows)"""
+    env = dict(os.environ, GT_QUERY_ORDER_MIN_ROWS="1", GT_SYMMETRIC="1", GT_SYM_STRIDE="4")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gpu_fuzz.py"), "30", "37"], capture_output=True,
+                         text=True, timeout=1500, env=env)
+    tail = "\n".join(res.stdout.strip().splitlines()[-6:])
+    assert res.returncode == 0, tail + "\n" + res.stderr[-2000:]

@@ -1,0 +1,131 @@
+"""GPU: the symmetric candidate pass (gt_sym.hip: every unordered pair of rows scored once, tested for both rows) against
+the oracle and against the classic pass.  The pass engages by itself from 65536 rows; here it is forced on for small
+point sets through the library's options.  Bar: kNN indices bit-exact, float32 distances exact, kernels identical to
+the classic pass bit for bit."""
+import numpy as np
+import pytest
+from scipy import sparse
+
+import oracle
+from conftest import make_gauss, make_manifold, make_mix
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def sym_ctx():
+    from graphtools_amd import _hip
+
+    ctx = _hip.Context(0)
+    ctx.set_option("query_order_min_rows", "1")
+    ctx.set_option("select_symmetric", "1")
+    ctx.set_option("select_sym_stride", "4")
+    yield ctx
+    ctx.close()
+
+
+def _knn(ctx, X, k):
+    ctx.set_points(X)
+    d, i, flags = ctx.knn_search(k)
+    assert ctx.knn_stats()["symmetric"], "the symmetric pass did not run"
+    d0, i0 = oracle.kneighbors(X, None, k)
+    assert np.array_equal(i, i0), "kNN indices differ in %d rows" % int((i != i0).any(axis=1).sum())
+    if X.dtype == np.float32:
+        assert np.array_equal(d[:, 1:], d0[:, 1:])
+    else:
+        np.testing.assert_allclose(d[:, 1:], d0[:, 1:], rtol=1e-12, atol=0)
+    return ctx.knn_stats()
+
+
+@pytest.mark.parametrize("n,d,k,maker,seed,dtype", [
+    (6000, 64, 16, make_mix, 0, np.float32),      # 256-row query blocks, 128-row tiles
+    (5003, 64, 31, make_mix, 1, np.float32),      # ragged last block
+    (4096, 20, 16, make_gauss, 2, np.float32),    # unclustered: the strided sample sets the thresholds
+    (7000, 100, 16, make_mix, 3, np.float32),     # 112 padded features: 128-row query blocks, 64-row tiles
+    (4500, 50, 20, make_mix, 4, np.float64),      # float64 points
+    (4100, 64, 60, make_manifold, 5, np.float32),
+    (9000, 33, 8, make_mix, 6, np.float32),
+])
+def test_symmetric_knn_matches_oracle(sym_ctx, n, d, k, maker, seed, dtype):
+    _knn(sym_ctx, maker(n, d, seed, dtype), k)
+
+
+def test_symmetric_knn_on_a_lattice_goes_through_the_repairs(sym_ctx):
+    """exact distance ties straddle every threshold: rows that cannot be proven complete are repaired"""
+    X = np.random.default_rng(0).integers(0, 4, size=(4500, 6)).astype(np.float32)
+    sym_ctx.set_points(X)
+    d, i, flags = sym_ctx.knn_search(12)
+    assert sym_ctx.knn_stats()["symmetric"]
+    d0, i0 = oracle.kneighbors(X, None, 12)
+    assert np.array_equal(d, d0)
+    assert np.array_equal(i, i0)
+
+
+def test_symmetric_knn_with_duplicate_rows(sym_ctx):
+    X = make_mix(5000, 32, 7)
+    X[100:140] = X[50]          # 41 copies of one point: more exact ties than neighbours asked for
+    X[4000] = X[3999]
+    sym_ctx.set_points(X)
+    d, i, flags = sym_ctx.knn_search(10)
+    d0, i0 = oracle.kneighbors(X, None, 10)
+    assert flags & 1                      # duplicates reported
+    assert np.array_equal(i, i0)
+    # distances between identical rows are rounding noise of the float64 GEMM form in scikit-learn (~1e-7), exactly 0 here
+    far = d0 > 1e-5
+    assert np.array_equal(d[far], d0[far]) and np.all(d[~far] <= 1e-5)
+
+
+def test_symmetric_lists_overflow_is_repaired(sym_ctx):
+    """tiny transposed lists: most rows overflow and must come back through the repair path unchanged"""
+    sym_ctx.set_option("select_sym_tcap", "64")
+    X = make_mix(6000, 64, 8)
+    st = _knn(sym_ctx, X, 40)
+    assert st["sym_overflow_rows"] > 0 and st["repaired_rows"] >= st["sym_overflow_rows"]
+
+
+@pytest.mark.parametrize("kw", [
+    dict(knn=15, decay=40.0), dict(knn=5, decay=10.0, kernel_symm="*"), dict(knn=10, decay=None),
+    dict(knn=8, decay=20.0, kernel_symm="mnn", theta=0.3, anisotropy=0.5), dict(knn=12, decay=40.0, bandwidth=3.0),
+])
+def test_symmetric_graph_matches_oracle(sym_ctx, kw):
+    X = make_mix(6000, 48, 11)
+    symm = kw.get("kernel_symm", "+")
+    sym_ctx.set_points(X)
+    p, keep = sym_ctx.make_params(kw["knn"], kw["decay"], 1e-4, kw.get("bandwidth"), 1.0, None, symm, kw.get("theta"),
+                                  kw.get("anisotropy", 0))
+    nnz, flags = sym_ctx.graph_build(p)
+    assert sym_ctx.knn_stats()["symmetric"]
+    from graphtools_amd import _hip
+
+    data, indices, indptr = sym_ctx.graph_fetch_csr(_hip.CSR_K)
+    pdata, _, _ = sym_ctx.graph_fetch_csr(_hip.CSR_P)
+    Ko, Po = oracle.knn_graph(X, knn=kw["knn"], decay=kw["decay"], bandwidth=kw.get("bandwidth"), kernel_symm=symm,
+                              theta=kw.get("theta"), anisotropy=kw.get("anisotropy", 0))
+    Ko = sparse.csr_matrix(Ko)
+    Ko.sort_indices()
+    if symm == "*":
+        Ko.eliminate_zeros()
+    assert np.array_equal(indptr, Ko.indptr) and np.array_equal(indices, Ko.indices)
+    np.testing.assert_allclose(data, Ko.data, rtol=2e-5 if symm == "*" else 1e-5, atol=0)
+    Po = sparse.csr_matrix(Po)
+    Po.sort_indices()
+    np.testing.assert_allclose(pdata, Po.data, rtol=2e-5 if symm == "*" else 1e-5, atol=0)
+
+
+def test_symmetric_and_classic_pass_build_identical_kernels():
+    """N = 150 000 (the pass engages by itself): K and P equal the classic pass bit for bit"""
+    from graphtools_amd import _hip
+
+    X = make_mix(150000, 64, 12)
+    out = {}
+    for mode in ("auto", "0"):
+        ctx = _hip.Context(0)
+        ctx.set_option("select_symmetric", mode)
+        ctx.set_points(X)
+        p, keep = ctx.make_params(15, 40.0, 1e-4, None, 1.0, None, "+", None, 0)
+        ctx.graph_build(p)
+        assert ctx.knn_stats()["symmetric"] == (mode == "auto")
+        out[mode] = ctx.graph_fetch_csr(_hip.CSR_K) + ctx.graph_fetch_csr(_hip.CSR_P)[:1]
+        ctx.close()
+    for a, b in zip(out["auto"], out["0"]):
+        assert np.array_equal(a, b)
