@@ -381,9 +381,8 @@ class Context:
         out = {"symmetric": bool(st[0]), "sym_overflow_rows": int(st[1]), "repaired_rows": int(st[2]),
                "exhaustive_rows": int(st[3])}
         if st[0]:
-            out.update(sym_forward_entries=int(st[5]), sym_transposed_entries=int(st[6]), sym_longest=int(st[7]),
-                       sym_rows_over_256=int(st[8]), sym_rows_forward_full=int(st[9]), sym_rows_transposed_full=int(st[10]),
-                       sym_rows_over_128=int(st[11]))
+            out.update(sym_nseg=int(st[6]), sym_entries=int(st[5]), sym_longest=int(st[7]), sym_rows_over_256=int(st[8]),
+                       sym_rows_over_128=int(st[11]))   # list-length counters: only with dbg_select bit 256
         return out
 
     def graph_stats(self):

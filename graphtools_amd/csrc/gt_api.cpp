@@ -152,6 +152,7 @@ int gt_set_points(gt_ctx* ctx, const void* X, int64_t n, int32_t d, int32_t dtyp
     }
     ctx->n = n;
     ctx->fast_ok = -1;
+    ctx->sym_ok = -1;
     ctx->d = d;
     ctx->dtype = dtype;
     ctx->DP = gt_choose_dp_prec(d, ctx->prec);
@@ -271,6 +272,10 @@ int gt_set_option(gt_ctx* ctx, const char* name, const char* value) {
         ctx->sym_stride = std::max(0, std::atoi(value));
         return GT_OK;
     }
+    if (k == "select_sym_nseg") {
+        ctx->sym_nseg = std::min(8, std::max(0, std::atoi(value)));
+        return GT_OK;
+    }
     if (k == "select_sym_cells") {
         ctx->sym_cells = std::min(32, std::max(1, std::atoi(value)));
         return GT_OK;
@@ -284,7 +289,7 @@ int gt_set_option(gt_ctx* ctx, const char* name, const char* value) {
         return GT_OK;
     }
     if (k == "select_sym_tcap") {
-        ctx->sym_tcap = std::min(4096, std::max(64, std::atoi(value)));
+        ctx->sym_tcap = std::min(512, std::max(64, std::atoi(value)));
         return GT_OK;
     }
     if (k == "dbg_select") {

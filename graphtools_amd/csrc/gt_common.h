@@ -142,10 +142,12 @@ struct gt_ctx {
     // symmetric candidate pass for self queries over the whole point set (gt_sym.hip): -1 auto (large launches), 0 off, 1 on
     int32_t sym_mode = -1;
     int64_t sym_min_rows = 65536;
-    int32_t sym_stride = 32;    //   threshold-seeding launch: every sym_stride-th tile besides the row's own neighbourhood (0: none)
+    int32_t sym_stride = 64;    //   threshold-seeding launch: every sym_stride-th tile besides the row's own neighbourhood (0: none)
     int32_t sym_cells = 12;     //   ... which is the rows of this many nearest cells (landmarks) of the block's own cells,
     int32_t sym_max_nb = 384;   //   at most this many tiles
-    int32_t sym_tcap = 512;     //   capacity of a row's transposed list
+    int32_t sym_tcap = 512;     //   capacity of a row's candidate list in launch B (<= 512)
+    int32_t sym_ok = -1;        //   auto: 0 once the bound point set has overflowed the lists of launch B (reset by gt_set_points)
+    int32_t sym_nseg = 0;       //   work items per query block in launch B (0: chosen to fill the last round of workgroups)
     int32_t order_L = 0;        // landmark cells of the last query order (gt_order.hip)
     int64_t n_pad = 0;   // rows of the working copy (multiple of the db tile)
     DevBuf Yp;           // working copy: [n_pad] rows of 4*DP bytes (float32, or float16 hi plane | lo plane)

@@ -156,7 +156,7 @@ extern "C" int gt_dbg_fetch_prof(gt_ctx* ctx, int64_t nwaves, unsigned long long
 }
 
 // development: raw buffers of the symmetric candidate pass (gt_sym.hip) of the most recent kNN call
-//   which: 0 thr (float [n]) 1 perm (int32 [n]) 2 forward counts (uint32 [n][2]) 3 transposed counts (uint32 [n])
+//   which: 0 thr (float [n]) 1 perm (int32 [n]) 3 list lengths (uint32 [n])
 //          4 tile counts of launch A (int32 [blocks]) 5 sorted cell ids (uint32 [n])
 extern "C" int gt_dbg_fetch_sym(gt_ctx* ctx, int32_t which, int64_t count, void* out_host) {
     if (!ctx || !ctx->knn) return GT_E_STATE;
@@ -167,10 +167,11 @@ extern "C" int gt_dbg_fetch_sym(gt_ctx* ctx, int32_t which, int64_t count, void*
     switch (which) {
         case 0: src = k->thr_final.p; break;
         case 1: src = k->qorder.p; break;
-        case 2: src = k->counts2.p; esz = 8; break;
         case 3: src = k->tcounts.p; break;
         case 4: src = k->sym_tile_cnt.p; break;
         case 5: src = ctx->order_cell.as<uint32_t>() + ctx->n; break;
+        case 6: src = k->sym_tiles.p; break;
+        case 7: src = k->sym_work.p; break;    // nbr [L][M] | start [L] | end [L]   // [blocks][tile_stride] tile lists of launch A (count = entries)
         default: return GT_E_ARG;
     }
     if (!src) return GT_E_STATE;

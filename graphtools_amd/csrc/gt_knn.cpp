@@ -14,7 +14,7 @@ void gt_free_knn_work(gt_ctx* ctx) {
     for (DevBuf* b : {&k->Qraw, &k->Qp, &k->Qc, &k->qn, &k->qn_sel, &k->lists, &k->counts, &k->thr_final, &k->cand_d2, &k->cand_j, &k->cand_n,
                       &k->d2_lb, &k->fb_rows, &k->fb_count, &k->fb_scratch, &k->gflags, &k->prof, &k->fb_qrows, &k->fb_thr, &k->fb_lists,
                       &k->fb_counts, &k->fb_max, &k->unproven, &k->qorder, &k->qthr0, &k->qlomax_dev, &k->Ycs, &k->hnegs,
-                      &k->sym_g, &k->sym_gmin, &k->tlists, &k->tcounts, &k->counts2, &k->sym_stat, &k->sym_work, &k->sym_tiles,
+                      &k->sym_g, &k->sym_gmin, &k->tlists, &k->tcounts, &k->sym_stat, &k->sym_work, &k->sym_tiles,
                       &k->sym_tile_cnt})
         b->release();
     delete k;
@@ -145,8 +145,9 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
         }
     }
     if (ctx->dbg_select & 64) {
-        GT_HIP(ctx, k->prof.reserve(size_t(k->nq_pad / bq) * 4 * 8 * sizeof(unsigned long long)));
-        GT_HIP(ctx, hipMemsetAsync(k->prof.p, 0, size_t(k->nq_pad / bq) * 4 * 8 * sizeof(unsigned long long), ctx->stream));
+        // one record per wave; the symmetric pass launches up to 8 work items per query block
+        GT_HIP(ctx, k->prof.reserve(size_t(k->nq_pad / bq) * 8 * 4 * 8 * sizeof(unsigned long long)));
+        GT_HIP(ctx, hipMemsetAsync(k->prof.p, 0, size_t(k->nq_pad / bq) * 8 * 4 * 8 * sizeof(unsigned long long), ctx->stream));
         sa.prof = k->prof.as<unsigned long long>();
     }
     GT_HIP(ctx, k->unproven.reserve(sizeof(uint32_t)));
@@ -201,11 +202,12 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
                          (ctx->sym_mode > 0 || nq >= ctx->sym_min_rows) &&
                          ctx->order_L > 0 && nq >= int64_t(8) * bq_sym;
     k->sym_used = false;
+    bool sym_now = use_sym && ctx->sym_ok != 0;
     uint32_t n_fb = 0;
     for (;;) {
-        if (use_sym && main_prec == 2) {
+        if (sym_now && main_prec == 2) {
             const int64_t n_pad_s = ceil_div64(nq, bq_sym) * bq_sym;
-            const int hcap = 256, tcap = ctx->sym_tcap;
+            const int tcap = ctx->sym_tcap;
             const int32_t* perm = k->qorder.as<int32_t>();
             GT_HIP(ctx, k->Ycs.reserve(size_t(n_pad_s) * ctx->DP * sizeof(_Float16)));
             GT_HIP(ctx, k->hnegs.reserve(size_t(n_pad_s) * sizeof(float)));
@@ -213,7 +215,6 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
             GT_HIP(ctx, k->sym_gmin.reserve(size_t(n_pad_s / 32) * sizeof(float)));
             GT_HIP(ctx, k->tlists.reserve(size_t(n_pad_s) * size_t(tcap) * sizeof(uint64_t)));
             GT_HIP(ctx, k->tcounts.reserve(size_t(n_pad_s) * sizeof(uint32_t)));
-            GT_HIP(ctx, k->counts2.reserve(size_t(n_pad_s) * 2 * sizeof(uint32_t)));
             GT_HIP(ctx, k->sym_stat.reserve(8 * sizeof(unsigned long long)));
             ErrModel em = gt_err_model(ctx, 2);
             em.rel += 8.0 * 5.9604644775390625e-08;   // the transposed test adds two float32 roundings to a score
@@ -271,8 +272,19 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
             a.sym.tlists = k->tlists.as<uint64_t>();
             a.sym.tcounts = k->tcounts.as<uint32_t>();
             a.sym.tcap = tcap;
-            a.sym.hcap = hcap;
-            a.counts = k->counts2.as<uint32_t>();
+            {
+                // work items per query block: the walk of a block is cut into nseg pieces so that the last round of
+                // workgroups is as full as the others (3 workgroups of this kernel per CU)
+                const int64_t slots = int64_t(ctx->n_cu) * 3, nb = n_pad_s / bq_sym;
+                int best = 1;
+                double best_cost = 1e30;
+                for (int sgm = 1; sgm <= 8; ++sgm) {
+                    const double cost = double(ceil_div64(nb * sgm, slots)) / sgm + 0.03 * sgm;
+                    if (cost < best_cost - 1e-9) best_cost = cost, best = sgm;
+                }
+                a.sym.nseg = ctx->sym_nseg > 0 ? std::min(ctx->sym_nseg, 8) : best;
+                k->sym_nseg = a.sym.nseg;
+            }
             a.thr_in = k->thr_final.as<float>();
             {
                 StageSpan span(ctx, "knn_select");
@@ -284,8 +296,6 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
             GT_HIP(ctx, hipMemsetAsync(k->unproven.p, 0, sizeof(uint32_t), ctx->stream));
             GT_HIP(ctx, hipMemsetAsync(k->sym_stat.p, 0, 8 * sizeof(unsigned long long), ctx->stream));
             SymRerank sr;
-            sr.counts2 = k->counts2.as<uint32_t>();
-            sr.hcap = hcap;
             sr.tlists = k->tlists.as<uint64_t>();
             sr.tcounts = k->tcounts.as<uint32_t>();
             sr.tcap = tcap;
@@ -301,11 +311,22 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
             GT_HIP(ctx, hipMemcpyAsync(k->sym_stat_host, k->sym_stat.p, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
             GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
             k->sym_overflow = int64_t(k->sym_stat_host[0]);
+            if (ctx->sym_mode < 0 && double(k->sym_overflow) > 0.10 * double(nq)) {
+                // neighbourhoods too large for the fixed lists (every overflowing row costs a repair): this point set
+                // goes through the classic pass, now and from here on
+                ctx->sym_ok = 0;
+                sym_now = false;
+                k->sym_used = false;
+                GT_HIP(ctx, hipMemsetAsync(k->fb_count.p, 0, sizeof(uint32_t), ctx->stream));
+                GT_HIP(ctx, hipMemsetAsync(k->gflags.p, 0, sizeof(uint32_t), ctx->stream));
+                continue;
+            }
             if (fast_auto) {
                 const bool ok = double(n_unproven) <= kFastFailFrac * double(nq);
                 ctx->fast_ok = ok ? 1 : 0;
                 if (!ok) {
                     main_prec = 1;
+                    k->sym_used = false;
                     GT_HIP(ctx, hipMemsetAsync(k->fb_count.p, 0, sizeof(uint32_t), ctx->stream));
                     GT_HIP(ctx, hipMemsetAsync(k->gflags.p, 0, sizeof(uint32_t), ctx->stream));
                     continue;
@@ -493,6 +514,7 @@ extern "C" int gt_knn_stats(const gt_ctx* ctx, int64_t* out12) {
     out12[2] = k ? k->n_fallback : 0;
     out12[3] = k ? k->n_fallback_exhaustive : 0;
     for (int i = 0; i < 8; ++i) out12[4 + i] = (k && k->sym_used) ? int64_t(k->sym_stat_host[i]) : 0;
+    if (k && k->sym_used) out12[6] = k->sym_nseg;   // work items per query block of launch B
     return GT_OK;
 }
 

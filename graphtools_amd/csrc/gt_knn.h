@@ -26,10 +26,11 @@ struct KnnWork {
     DevBuf fb_rows, fb_count, fb_scratch, gflags, prof;
     DevBuf fb_qrows, fb_thr, fb_lists, fb_counts, fb_max;   // collected fallback
     // symmetric candidate pass (gt_sym.hip): cell-sorted compact copy + seeds, per-row thresholds in the transposed
-    // form and their sub-tile minima, transposed lists, forward fill counts
-    DevBuf Ycs, hnegs, sym_g, sym_gmin, tlists, tcounts, counts2, sym_stat, sym_work, sym_tiles, sym_tile_cnt;
+    // form and their sub-tile minima, the candidate lists of launch B and their counters
+    DevBuf Ycs, hnegs, sym_g, sym_gmin, tlists, tcounts, sym_stat, sym_work, sym_tiles, sym_tile_cnt;
     bool sym_used = false;
     int64_t sym_overflow = 0;
+    int sym_nseg = 1;
     unsigned long long sym_stat_host[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int64_t n_fallback_exhaustive = 0;
     int64_t n_fallback = 0;
@@ -136,8 +137,6 @@ struct RerankArgs {
 int gt_launch_rerank(gt_ctx* ctx, const RerankArgs& a);
 // symmetric candidate pass (gt_sym.hip): segments of list ql = cell-sorted position ql, row perm[ql]
 struct SymRerank {
-    const uint32_t* counts2;   // [n][2] forward fill counts (true counts)
-    int hcap;
     const uint64_t* tlists;    // [n_pad][tcap]
     const uint32_t* tcounts;
     int tcap;

@@ -6,10 +6,10 @@
 struct SymDev {
     const float* g = nullptr;       // [n_pad] thr_j + hneg_j: row j admits query q iff (score_qj + hneg_q) > g_j; +inf on pad rows
     const float* gmin = nullptr;    // [n_pad / 32] minimum of g over each 32-row sub-tile
-    uint64_t* tlists = nullptr;     // [n_pad][tcap] transposed candidates of every row (slots from tcounts)
+    uint64_t* tlists = nullptr;     // [n_pad][tcap] candidates of every row, forward and transposed (slots from tcounts)
     uint32_t* tcounts = nullptr;    // [n_pad] (pre-zeroed; the true count, may exceed tcap)
     int32_t tcap = 0;
-    int32_t hcap = 0;               // MODE 2: capacity of one half-wave's half of a forward list (lists: [nq_pad][2 * hcap])
+    int32_t nseg = 1;               // MODE 2: work items per query block (grid = blocks x nseg)
     int32_t sched = 0;              // MODE 0: 1 = the queries are the database rows; query block I visits the tiles
                                     //         tile_list[I * tile_stride + 0 .. tile_cnt[I]) with the level-0 list budget
     const int32_t* tile_list = nullptr;
@@ -21,7 +21,7 @@ struct SelectArgs {
     int dp = 0;            // padded feature count (gt_choose_dp)
     int prec = 0;          // 0: float32 operands, 1: split float16 planes (hi + lo), 2: hi planes of the split copy only
     int mode = 0;          // 0: top-M' selection, 1: radius collect, 2: symmetric collect (self queries, prec 2)
-    SymDev sym;            // mode 2 / mode 0 with sym.sched = 1 (counts: mode 2 writes [nq_pad][2] fill counts)
+    SymDev sym;            // mode 2 / mode 0 with sym.sched = 1
     int nt = 8;            // selection: keys per lane in the compaction sort; list capacity 64*nt, M' = 16*nt
     const float* Yp = nullptr;    // database working copy, [n_pad] rows of 4*dp bytes
     const float* hneg = nullptr;  // [n_pad]

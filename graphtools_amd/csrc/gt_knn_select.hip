@@ -36,10 +36,12 @@
 //   score matrix is symmetric up to the seeds - x_i.x_j is the same MFMA chain whichever of the two is the query - so
 //   workgroup I (query block I) streams only the blocks I .. I + (NB-1)/2 (mod NB) and tests every result twice: once
 //   for its query (the lane's own threshold) and once for the database row as a query of its own (per-row thresholds
-//   staged with the tile; a per-sub-tile minimum keeps the hot path at one compare).  Forward survivors go to the
-//   query's list as in MODE 0 (register fill counts, no atomics), transposed ones to the database row's second list
-//   through a global slot counter.  Every unordered pair of rows is scored exactly once: N^2 d executed flop for
-//   the 2 N^2 d the problem asks for.
+//   staged with the tile; a per-sub-tile minimum keeps the hot path at one compare).  Survivors of either test go to
+//   the list of the row they are candidates OF (tlists, one per row of the point set) through a global slot counter:
+//   one atomic per lane and unit for the forward hits, one per transposed hit, all issued before the first store.
+//   A row's list is fed by many workgroups, so a block's walk can be cut into nseg independent work items (grid =
+//   blocks x nseg) - the host picks nseg so that the last round of workgroups is full.  Every unordered pair of rows is
+//   scored exactly once: N^2 d executed flop for the 2 N^2 d the problem asks for.
 //
 // Roofline: MFMA-bound.  Algorithmic work 2*d flop per (query, database row) pair.
 #include "gt_common.h"
@@ -325,12 +327,19 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
     // workgroups sharing an L2 walk overlapping windows of the database.
     const bool own_sched = (MODE == 2) || (MODE == 0 && sy.sched == 1);
     int64_t bidx = blockIdx.x;
+    int seg = 0;
     if (own_sched) {
         const int64_t nb = gridDim.x, xcd = bidx & 7, base = nb >> 3, rem = nb & 7;
         bidx = xcd * base + (xcd < rem ? xcd : rem) + (bidx >> 3);
+        if (MODE == 2) {   // work items are block-major (item = block * nseg + seg): every XCD gets its share of the
+                           // hit-rich first segments (the blocks' own neighbourhoods)
+            const int nseg = sy.nseg > 0 ? sy.nseg : 1;
+            seg = int(bidx % nseg);
+            bidx /= nseg;
+        }
     }
     const int64_t qblock = bidx * BQ;
-    const size_t lstride = (MODE == 0) ? size_t(LCAP) : (MODE == 2) ? size_t(2 * sy.hcap) : size_t(cap);
+    const size_t lstride = (MODE == 0) ? size_t(LCAP) : size_t(cap);
     // database tile range of this workgroup (MODE 1 may split the database over gridDim.y)
     int t_begin = 0, t_end = ntiles;
     if (MODE == 1) {
@@ -353,7 +362,11 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
         if (MODE == 2) {
             const int H = (NB - 1) / 2;
             n_tr_end = C::TPB * (1 + H);
-            t_end = n_tr_end + ((NB & 1) ? 0 : (NB > 1 ? C::TPB : 0));
+            const int walk = n_tr_end + ((NB & 1) ? 0 : (NB > 1 ? C::TPB : 0));
+            const int nseg = sy.nseg > 0 ? sy.nseg : 1;
+            t_begin = int(int64_t(walk) * seg / nseg);          // this item's part of the block's walk
+            t_end = int(int64_t(walk) * (seg + 1) / nseg);
+            if (t_begin >= t_end) return;
         } else {
             t_end = sy.tile_cnt[bidx];
             tl_base = sy.tile_list + size_t(bidx) * size_t(sy.tile_stride);
@@ -365,7 +378,7 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
     Frag<DP, PREC> bq[QT];
     float thr[QT];
     float hnq[QT];       // MODE 2: the query's own seed (-inf on pad queries: never admitted anywhere)
-    uint32_t fill[QT];   // MODE 0 / 2: entries in this lane's half of the query's list
+    uint32_t fill[QT];   // MODE 0: entries in this lane's half of the query's list
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
         fill[qt] = 0u;
@@ -457,7 +470,7 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
     const int n_a = (MODE == 0 && samp_stride > 1 && !own_sched) ? (ntiles + samp_stride - 1) / samp_stride : 0;
     int t = t_begin, t_step = n_a ? samp_stride : 1, level = 0;
     if (own_sched) {
-        t = int(bidx) * C::TPB;                                            // MODE 2: the own block first
+        t = int((int64_t(bidx) * C::TPB + t_begin) % ntiles);             // MODE 2: the own block first (segment 0)
         if (MODE == 0) t = __builtin_amdgcn_readlane(tl_cache, 0);         // sched 1: first entry of the list
     }
     if constexpr (C::GLDS) {
@@ -523,6 +536,7 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
         // accp[(u-1)%3] and the seeds (-|y|^2/2) of u+1 are fetched from LDS into accp[(u+1)%3]
         f32x16 accp[3];
         bool any_hit = false;
+        uint32_t hitmask = 0u;   // MODE 2: units of this tile whose compare fired
         float mx[5];
 #define GT_SEED(U_)                                                                                        \
     {                                                                                                      \
@@ -545,26 +559,66 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
             if (MODE == 0) {                                                                               \
                 list_store(lp + fill[PQT_], cand_pack(v, j));                                              \
                 fill[PQT_] += 1u;                                                                          \
-            } else if (MODE == 2) {                                                                        \
-                if (fill[PQT_] < uint32_t(sy.hcap)) list_store(lp + fill[PQT_], cand_pack(v, j));          \
-                fill[PQT_] += 1u;   /* the true count: an overflowing row is repaired later */             \
             } else {                                                                                       \
                 const uint32_t slot = atomicAdd(&counts[qblock + ql], 1u);                                 \
                 if (slot < uint32_t(cap)) lp[slot] = cand_pack(v, j);                                      \
             }                                                                                              \
         }                                                                                                  \
     }
-// MODE 2, transposed direction: database row r_ of the tile takes query (PQT_, li) into its second list when the
-// score seen from its side, (x.y - |y_j|^2/2) + |y_j|^2/2 - |x_q|^2/2, beats its own threshold: (acc + hneg_q) > g_j
-#define GT_ADMIT_TR_ONE(PA_, E_, PSB_, PQT_)                                                               \
+// MODE 2 cold path, run after the unit loop of a tile for the units whose hot-path compare fired (their 32 x 32 block is
+// recomputed - four MFMAs - so that nothing of it has to stay live in the unrolled loop).  Forward: the lane's query
+// takes every row of the unit that beats its threshold - the hits of the lane are counted first, one atomic reserves
+// their slots in the query's list.  Transposed: database row r_ takes query (PQT_, li) when the score seen from its
+// side, (x.y - |y_j|^2/2) + |y_j|^2/2 - |x_q|^2/2, beats its own threshold: (acc + hneg_q) > g_j; one atomic per hit
+// on the row's counter, four in flight at a time.
+#define GT_ADMIT2(PA_, PSB_, PQT_)                                                                         \
     {                                                                                                      \
-        const int r_ = (PSB_) * 32 + 8 * ((E_) >> 2) + 4 * h + ((E_) & 3);                                 \
-        const float v = (PA_)[E_] + hq_;                                                                   \
-        if (v > gbuf[r_]) {                                                                                \
-            const uint32_t j = tbase + uint32_t(r_);                                                       \
-            const uint32_t slot = atomicAdd(&sy.tcounts[j], 1u);                                           \
-            if (slot < uint32_t(sy.tcap))                                                                  \
-                list_store(sy.tlists + size_t(j) * size_t(sy.tcap) + slot, cand_pack(v - hb[r_], uint32_t(qblock + ql))); \
+        const float tq_ = thr[PQT_];                                                                       \
+        const int ql = (w * QT + (PQT_)) * 32 + li;                                                        \
+        const uint32_t qpos_ = uint32_t(qblock + ql);                                                      \
+        const float hq_ = hnq[PQT_];                                                                       \
+        uint32_t nf_ = 0u;                                                                                 \
+        _Pragma("unroll") for (int e_ = 0; e_ < 16; ++e_) nf_ += ((PA_)[e_] > tq_) ? 1u : 0u;              \
+        if (nf_) {                                                                                         \
+            uint32_t k_ = atomicAdd(&sy.tcounts[qpos_], nf_);                                              \
+            uint64_t* lp_ = sy.tlists + size_t(qpos_) * size_t(sy.tcap);                                   \
+            _Pragma("unroll") for (int e_ = 0; e_ < 16; ++e_) {                                            \
+                if ((PA_)[e_] > tq_) {                                                                     \
+                    const uint32_t j = tbase + uint32_t((PSB_) * 32 + 8 * (e_ >> 2) + 4 * h + (e_ & 3));   \
+                    if (k_ < uint32_t(sy.tcap)) list_store(lp_ + k_, cand_pack((PA_)[e_], j));             \
+                    ++k_;                                                                                  \
+                }                                                                                          \
+            }                                                                                              \
+            /* a row whose list has overflowed (count > capacity) is repaired later anyway: stop collecting */ \
+            if (k_ > uint32_t(sy.tcap)) thr[PQT_] = INFINITY;                                              \
+        }                                                                                                  \
+        if (tr_on) {                                                                                       \
+            _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) {                                             \
+                const float4 gv_ = *reinterpret_cast<const float4*>(gbuf + (PSB_) * 32 + 8 * g_ + 4 * h);  \
+                const float gr_[4] = {gv_.x, gv_.y, gv_.z, gv_.w};                                         \
+                bool hit_[4];                                                                              \
+                bool anyg_ = false;                                                                        \
+                _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                         \
+                    hit_[i_] = ((PA_)[4 * g_ + i_] + hq_) > gr_[i_];                                       \
+                    anyg_ = anyg_ || hit_[i_];                                                             \
+                }                                                                                          \
+                if (__ballot(anyg_)) {                                                                     \
+                    const float4 hv_ = *reinterpret_cast<const float4*>(hb + (PSB_) * 32 + 8 * g_ + 4 * h); \
+                    const float hr_[4] = {hv_.x, hv_.y, hv_.z, hv_.w};                                     \
+                    uint32_t tslot_[4];                                                                    \
+                    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                     \
+                        const uint32_t j = tbase + uint32_t((PSB_) * 32 + 8 * g_ + 4 * h + i_);            \
+                        tslot_[i_] = 0xFFFFFFFFu;                                                          \
+                        if (hit_[i_]) tslot_[i_] = atomicAdd(&sy.tcounts[j], 1u);                          \
+                    }                                                                                      \
+                    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                     \
+                        const uint32_t j = tbase + uint32_t((PSB_) * 32 + 8 * g_ + 4 * h + i_);            \
+                        if (hit_[i_] && tslot_[i_] < uint32_t(sy.tcap))                                    \
+                            list_store(sy.tlists + size_t(j) * size_t(sy.tcap) + tslot_[i_],               \
+                                       cand_pack(((PA_)[4 * g_ + i_] + hq_) - hr_[i_], qpos_));            \
+                    }                                                                                      \
+                }                                                                                          \
+            }                                                                                              \
         }                                                                                                  \
     }
 #define GT_ADMIT(PA_, ANY_, MX_, PSB_, PQT_)                                                               \
@@ -572,8 +626,7 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
         const float tq_ = thr[PQT_];                                                                       \
         const unsigned long long ts_ = prof ? __builtin_readcyclecounter() : 0ull;                         \
         const int ql = (w * QT + (PQT_)) * 32 + li;                                                        \
-        uint64_t* lp = lists + size_t(qblock + ql) * lstride +                                             \
-                       (MODE == 0 ? size_t(h) * HALF : MODE == 2 ? size_t(h) * size_t(sy.hcap) : size_t(0)); \
+        uint64_t* lp = lists + size_t(qblock + ql) * lstride + (MODE == 0 ? size_t(h) * HALF : size_t(0)); \
         _Pragma("unroll") for (int t_ = 0; t_ < 5; ++t_) {                                                 \
             if (__ballot((MX_)[t_] > tq_)) {                                                               \
                 GT_ADMIT_ONE(PA_, 3 * t_ + 0, PSB_, PQT_);                                                 \
@@ -582,18 +635,6 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
             }                                                                                              \
         }                                                                                                  \
         if (__ballot((PA_)[15] > tq_)) GT_ADMIT_ONE(PA_, 15, PSB_, PQT_);                                  \
-        if (MODE == 2 && tr_on) {                                                                          \
-            const float hq_ = hnq[PQT_];                                                                   \
-            const float gm_ = gms[PSB_];                                                                   \
-            _Pragma("unroll") for (int t_ = 0; t_ < 5; ++t_) {                                             \
-                if (__ballot((MX_)[t_] + hq_ > gm_)) {                                                     \
-                    GT_ADMIT_TR_ONE(PA_, 3 * t_ + 0, PSB_, PQT_);                                          \
-                    GT_ADMIT_TR_ONE(PA_, 3 * t_ + 1, PSB_, PQT_);                                          \
-                    GT_ADMIT_TR_ONE(PA_, 3 * t_ + 2, PSB_, PQT_);                                          \
-                }                                                                                          \
-            }                                                                                              \
-            if (__ballot((PA_)[15] + hq_ > gm_)) GT_ADMIT_TR_ONE(PA_, 15, PSB_, PQT_);                     \
-        }                                                                                                  \
         if (prof) { t_adm += __builtin_readcyclecounter() - ts_; n_adm += 1; }                             \
     }
         constexpr bool SEEDREG = GT_SEL_SEEDREG && PREC >= 1 && QT == 2;
@@ -666,7 +707,46 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
                 }
             }
 #endif
-            if (u > 0) GT_ADMIT(accp[(u - 1) % NACC], any_hit, mx, psb, pqt);
+            if (u > 0) {
+                if constexpr (MODE == 2) {
+                    // no branch in the unit loop: the units that need the cold path are only noted (bit = unit)
+                    hitmask |= (__ballot(any_hit) != 0ull) ? (1u << (u - 1)) : 0u;
+                } else {
+                    GT_ADMIT(accp[(u - 1) % NACC], any_hit, mx, psb, pqt);
+                }
+            }
+        }
+        if constexpr (MODE == 2) {
+            if (__builtin_expect(hitmask != 0u, 0)) {
+                const unsigned long long ts_ = prof ? __builtin_readcyclecounter() : 0ull;
+                while (hitmask) {   // wave-uniform
+                    const int pu = __ffs(int(hitmask)) - 1;
+                    hitmask &= hitmask - 1u;
+                    const int csb = pu / QT, cqt = pu % QT;
+                    Frag<DP, PREC> ca;
+                    ca.load(tb + (csb * 32 + li) * LDP, h, aswz);
+                    f32x16 cs, cacc;
+#pragma unroll
+                    for (int g_ = 0; g_ < 4; ++g_) {
+                        const float4 hv_ = *reinterpret_cast<const float4*>(hb + csb * 32 + 8 * g_ + 4 * h);
+                        cs[4 * g_ + 0] = hv_.x;
+                        cs[4 * g_ + 1] = hv_.y;
+                        cs[4 * g_ + 2] = hv_.z;
+                        cs[4 * g_ + 3] = hv_.w;
+                    }
+                    if (QT == 1 || cqt == 0) {
+                        cacc = cs;
+                        mma_chain<DP>(ca, bq[0], cacc);
+                        GT_ADMIT2(cacc, csb, 0);
+                    } else {
+                        cacc = cs;
+                        mma_chain<DP>(ca, bq[QT - 1], cacc);
+                        GT_ADMIT2(cacc, csb, QT - 1);
+                    }
+                    if (prof) n_adm += 1;
+                }
+                if (prof) t_adm += __builtin_readcyclecounter() - ts_;
+            }
         }
         if (MODE == 0) {
             // ---- list maintenance: lane (li, h) owns half h of query (qt, li) ----
@@ -733,11 +813,6 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
         o[5] = t_lvl0; o[6] = n_adm_lvl0; o[7] = __builtin_readcyclecounter() - t_start;
     }
 
-    if (MODE == 2) {
-        // lane (li, h) owns half h of query (qt, li): publish its (true) entry count
-#pragma unroll
-        for (int qt = 0; qt < QT; ++qt) counts[size_t(qblock + (w * QT + qt) * 32 + li) * 2 + h] = fill[qt];
-    }
     // ---- finalisation: gather every list into slots [0, count), publish count and the last admission threshold ----
     if (MODE == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -869,7 +944,7 @@ int launch_one(gt_ctx* ctx, const SelectArgs& a) {
     if (MODE == 2) {
         GT_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         int(lds_bytes)));
-        if (a.n_pad % C::BQ != 0 || a.nq > a.n_pad || a.sym.hcap <= 0 || a.sym.tcap <= 0)
+        if (a.n_pad % C::BQ != 0 || a.nq > a.n_pad || a.sym.tcap <= 0 || a.sym.nseg < 1)
             GT_FAIL(ctx, GT_E_ARG, "knn_select: symmetric collect needs the padded point set as queries and database");
     }
     if (MODE == 0 && a.sym.sched == 1 && a.n_pad % C::BQ != 0)
@@ -879,7 +954,8 @@ int launch_one(gt_ctx* ctx, const SelectArgs& a) {
         GT_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         int(lds_bytes)));
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks, (unsigned)nsplit), dim3(256), lds_bytes, ctx->stream, a.Yp,
+    const int64_t grid_x = MODE == 2 ? nblocks * a.sym.nseg : nblocks;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid_x, (unsigned)nsplit), dim3(256), lds_bytes, ctx->stream, a.Yp,
                        a.hneg, a.Qp, a.qrows, a.q0, a.nq, ntiles, a.lists, a.counts, a.thr_in, a.thr_out, a.cap, a.dbg, a.prof,
                        a.samp_stride, a.samp_keep, a.samp_end, a.samp2_level, a.samp2_keep,
                        (a.samp_trig > 0 && a.samp_trig <= 32 * NT - C::BN / 2) ? a.samp_trig : a.samp_keep / 2 + 24,

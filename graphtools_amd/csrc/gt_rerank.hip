@@ -200,15 +200,14 @@ __global__ __launch_bounds__(256) void rerank_kernel(const T* __restrict__ X, co
 }
 
 // ---- re-rank of the symmetric candidate pass (knn_select_kernel MODE 2) ---------------------------------------
-// List ql belongs to the row at cell-sorted position ql (row perm[ql]); its candidates sit in three segments - the two
-// half-wave halves of the forward list and the transposed list other workgroups appended to - as (score, sorted
-// position) keys collected against the FIXED threshold thr[ql]: every row that is not in them scored <= thr[ql].
-// The 256 best approximate scores are evaluated exactly in two batches of 128 like above; a row whose segments
-// overflowed (or hold more than 512 keys together) is handed to the repair path (bound = -inf).
+// List ql belongs to the row at cell-sorted position ql (row perm[ql]); it holds (score, sorted position) keys collected
+// against the FIXED threshold thr[ql] by every workgroup that scored a pair with that row: every row that is not in it
+// scored <= thr[ql].  The 256 best approximate scores are evaluated exactly in two batches of 128 like above (lists of up
+// to 128 / 256 keys take a shorter sorting network); a row whose list overflowed (more than tcap <= 512 keys) is handed
+// to the repair path (bound = -inf).
 template <typename T>
 __global__ __launch_bounds__(256) void rerank_sym_kernel(
     const T* __restrict__ X, const int d, const double* __restrict__ xn, const int64_t nq,
-    const uint64_t* __restrict__ lists, const int hcap, const uint32_t* __restrict__ counts2,
     const uint64_t* __restrict__ tlists, const int tcap, const uint32_t* __restrict__ tcounts,
     const float* __restrict__ thr, const double* __restrict__ ymax2p, const ErrModel err, const int need_m,
     const int32_t* __restrict__ perm, double* __restrict__ cand_d2, uint32_t* __restrict__ cand_j,
@@ -230,13 +229,9 @@ __global__ __launch_bounds__(256) void rerank_sym_kernel(
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     const double qnq = xn[q];
-    const uint32_t c0 = counts2[2 * ql], c1 = counts2[2 * ql + 1], ct = tcounts[ql];
-    const uint32_t n0 = c0 < uint32_t(hcap) ? c0 : uint32_t(hcap);
-    const uint32_t n1 = c1 < uint32_t(hcap) ? c1 : uint32_t(hcap);
-    const uint32_t nt = ct < uint32_t(tcap) ? ct : uint32_t(tcap);
-    const bool overflow = c0 > uint32_t(hcap) || c1 > uint32_t(hcap) || ct > uint32_t(tcap) || n0 + n1 + nt > 512u;
-    const uint32_t n = overflow ? (n0 + n1 + nt < 512u ? n0 + n1 + nt : 512u) : n0 + n1 + nt;
-    const uint64_t* lp = lists + size_t(ql) * size_t(2 * hcap);
+    const uint32_t ct = tcounts[ql];
+    const bool overflow = ct > uint32_t(tcap);
+    const uint32_t n = overflow ? uint32_t(tcap) : ct;
     const uint64_t* tp = tlists + size_t(ql) * size_t(tcap);
 
     const double y2 = ymax2p[0];
@@ -251,16 +246,23 @@ __global__ __launch_bounds__(256) void rerank_sym_kernel(
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
         const uint32_t c = uint32_t(u * 64 + lane);
-        uint64_t kv = 0ull;   // a valid key is never 0
-        if (c < n0)
-            kv = lp[c];
-        else if (c < n0 + n1)
-            kv = lp[size_t(hcap) + (c - n0)];
-        else if (c < n)
-            kv = tp[c - n0 - n1];
-        ks[u] = kv;
+        ks[u] = (c < n) ? tp[c] : 0ull;   // a valid key is never 0
     }
-    wave_bitonic_desc<8>(ks, lane);
+    if (n <= 128u) {   // wave-uniform
+        uint64_t k2[2] = {ks[0], ks[1]};
+        wave_bitonic_desc<2>(k2, lane);
+        ks[0] = k2[0];
+        ks[1] = k2[1];
+    } else if (n <= 256u) {
+        uint64_t k4[4] = {ks[0], ks[1], ks[2], ks[3]};
+        wave_bitonic_desc<4>(k4, lane);
+        ks[0] = k4[0];
+        ks[1] = k4[1];
+        ks[2] = k4[2];
+        ks[3] = k4[3];
+    } else {
+        wave_bitonic_desc<8>(ks, lane);
+    }
     const uint32_t n_eval = n < uint32_t(MP) ? n : uint32_t(MP);
     uint64_t hi[4], lo[4];
 #pragma unroll
@@ -328,18 +330,15 @@ __global__ __launch_bounds__(256) void rerank_sym_kernel(
             const uint32_t slot = atomicAdd(fb_count, 1u);
             fb_rows[slot] = int32_t(q);
         }
-        if (unproven && !(d2_need * rkf < lb)) atomicAdd(unproven, 1u);
+        // (an overflowing row is short of room, not of precision: it does not count against the arithmetic)
+        if (unproven && !overflow && !(d2_need * rkf < lb)) atomicAdd(unproven, 1u);
         if (stat && overflow) atomicAdd(stat + 0, 1ull);
         if (stat && want_stats) {
-            // [1] sum of forward counts [2] sum of transposed counts [3] largest total [4] rows with more than 256 keys
-            // [5] rows with a forward half over capacity [6] transposed list over capacity [7] rows with more than 128 keys
-            const unsigned long long tot = (unsigned long long)c0 + c1 + ct;
-            atomicAdd(stat + 1, (unsigned long long)c0 + c1);
-            atomicAdd(stat + 2, (unsigned long long)ct);
+            // [1] sum of the list lengths [3] longest list [4] rows with more than 256 keys [7] rows with more than 128 keys
+            const unsigned long long tot = (unsigned long long)ct;
+            atomicAdd(stat + 1, tot);
             atomicMax(stat + 3, tot);
             if (tot > 256ull) atomicAdd(stat + 4, 1ull);
-            if (c0 > uint32_t(hcap) || c1 > uint32_t(hcap)) atomicAdd(stat + 5, 1ull);
-            if (ct > uint32_t(tcap)) atomicAdd(stat + 6, 1ull);
             if (tot > 128ull) atomicAdd(stat + 7, 1ull);
         }
         if (n_tab > 1 && second == 0ull) atomicOr(gflags, GT_FLAG_DUPLICATES);
@@ -702,12 +701,12 @@ int gt_launch_rerank_sym(gt_ctx* ctx, const RerankArgs& a, const SymRerank& sr) 
     if (a.MP != 256 || a.metric != 0) GT_FAIL(ctx, GT_E_ARG, "rerank_sym: table width 256, euclidean metric only");
     if (a.dtype == GT_F32)
         hipLaunchKernelGGL((rerank_sym_kernel<float>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, (const float*)a.X,
-                           a.d, a.xn, a.nq, a.lists, sr.hcap, sr.counts2, sr.tlists, sr.tcap, sr.tcounts, a.thr_final, a.ymax2,
+                           a.d, a.xn, a.nq, sr.tlists, sr.tcap, sr.tcounts, a.thr_final, a.ymax2,
                            a.err, a.need_m, sr.perm, a.cand_d2, a.cand_j, a.cand_n, a.d2_lb, a.fb_count, a.fb_rows, a.gflags,
                            a.radius_key_factor, a.unproven, sr.stat, (ctx->dbg_select & 256) ? 1 : 0);
     else
         hipLaunchKernelGGL((rerank_sym_kernel<double>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, (const double*)a.X,
-                           a.d, a.xn, a.nq, a.lists, sr.hcap, sr.counts2, sr.tlists, sr.tcap, sr.tcounts, a.thr_final, a.ymax2,
+                           a.d, a.xn, a.nq, sr.tlists, sr.tcap, sr.tcounts, a.thr_final, a.ymax2,
                            a.err, a.need_m, sr.perm, a.cand_d2, a.cand_j, a.cand_n, a.d2_lb, a.fb_count, a.fb_rows, a.gflags,
                            a.radius_key_factor, a.unproven, sr.stat, (ctx->dbg_select & 256) ? 1 : 0);
     GT_HIP(ctx, hipGetLastError());

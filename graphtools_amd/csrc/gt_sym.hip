@@ -55,7 +55,9 @@ __global__ __launch_bounds__(256) void gather_sorted_kernel(const uint4* __restr
 //   >= sc^2 ((|x|^2 - R2)/2 - e) =: thr (rounded down).
 // g[p] = thr[p] + hneg[p] (rounded down): the form the transposed test of launch B compares against;
 // gmin[p/32] = min of g over the 32 rows of a sub-tile.
-// 16 lanes per row (one candidate each, need_m <= 64 in turns), 16 rows per 256-thread block.
+// 16 lanes per row, 16 rows per 256-thread block: the 16 lanes read each candidate row together (coalesced), the
+// partial dot products meet in a shuffle tree.  D_K only has to be an upper bound: the summation order differs from the
+// re-rank's, a relative 1e-12 covers it.
 template <typename T>
 __global__ __launch_bounds__(256) void sym_thresholds_kernel(const int64_t n, const int64_t n_pad,
                                                              const int32_t* __restrict__ perm, const T* __restrict__ X,
@@ -75,16 +77,29 @@ __global__ __launch_bounds__(256) void sym_thresholds_kernel(const int64_t n, co
         const T* xq = X + q * int64_t(d);
         const double qs = xn[q];
         const uint32_t kept = counts[p];
-        double dk = 0.0;
-        for (uint32_t c = uint32_t(sub); c < kept; c += 16u) {
-            const int64_t j = perm[cand_index(lists[size_t(p) * lstride + c])];
-            const T* yj = X + j * int64_t(d);
-            double acc = 0.0;
-            for (int k = 0; k < d; ++k) acc = fma(double(xq[k]), double(yj[k]), acc);
-            dk = fmax(dk, gt_pair_key(qs, acc, xn[j], 0));
-        }
+        // this lane's slice of the query row (features sub, sub + 16, ...), up to 8 values in registers (d <= 128)
+        double xr[8];
 #pragma unroll
-        for (int o = 8; o > 0; o >>= 1) dk = fmax(dk, __shfl_xor(dk, o));
+        for (int u = 0; u < 8; ++u) xr[u] = (sub + 16 * u < d) ? double(xq[sub + 16 * u]) : 0.0;
+        // candidate ids: lane c of the group fetches entry c (need_m <= 64: four rounds at most)
+        double dk = 0.0;
+        for (uint32_t c0 = 0; c0 < kept; c0 += 16u) {
+            int64_t jmine = 0;
+            if (c0 + uint32_t(sub) < kept) jmine = perm[cand_index(lists[size_t(p) * lstride + c0 + sub])];
+            const uint32_t lim = kept - c0 < 16u ? kept - c0 : 16u;
+            for (uint32_t c = 0; c < lim; ++c) {
+                const int64_t j = __shfl(jmine, int(c), 16);
+                const T* yj = X + j * int64_t(d);
+                double acc = 0.0;
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (sub + 16 * u < d) acc = fma(xr[u], double(yj[sub + 16 * u]), acc);
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 16);
+                dk = fmax(dk, gt_pair_key(qs, acc, xn[j], 0));
+            }
+        }
+        dk *= 1.0 + 1e-12;
         const double y2 = ymax2p[0];
         const double e = gt_err_bound(err, qs, y2);
         t = -3.0e38f;
@@ -185,18 +200,36 @@ __global__ __launch_bounds__(64) void sym_schedule_kernel(const uint32_t* __rest
     __syncthreads();
     const int tpb = BQ / BN;
     const int own_a = I * tpb, own_b = I * tpb + tpb - 1;
-    // distinct cells of the block's rows (sampled every BQ/8 rows; the cell ids are non-decreasing)
+    // distinct cells of the block's rows, in order (the cell ids of the sorted rows are non-decreasing: a cell is a
+    // run); the first 16 runs count - a block of 256 rows rarely holds more
+    __shared__ uint32_t blk_cells[16];
     const int64_t r0 = int64_t(I) * BQ;
-    uint32_t mycell = 0xFFFFFFFFu;
-    if (lane < 8) {
-        int64_t r = r0 + int64_t(lane) * (BQ / 8) + BQ / 16;
-        r = r < n ? r : n - 1;
-        if (r0 < n) mycell = cell_sorted[r];
+    const int per = (BQ + 63) / 64;   // rows per lane
+    int nchg = 0;
+    uint32_t chg[4] = {0u, 0u, 0u, 0u};
+    {
+        const int64_t ra = r0 + int64_t(lane) * per;
+        uint32_t prevc = (ra > r0 && ra - 1 < n) ? cell_sorted[ra - 1] : 0xFFFFFFFFu;
+        for (int k = 0; k < per && k < 4; ++k) {
+            const int64_t r = ra + k;
+            if (r < n && r < r0 + BQ) {
+                const uint32_t c = cell_sorted[r];
+                if (c != prevc) chg[nchg++] = c;
+                prevc = c;
+            }
+        }
     }
-    const uint32_t prev = __shfl_up(mycell, 1);
-    const bool first = lane < 8 && mycell != 0xFFFFFFFFu && (lane == 0 || prev != mycell);
-    const unsigned long long fm = __ballot(first);
-    const int nu = __popcll(fm);
+    int incl0 = nchg;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl0, o);
+        if (lane >= o) incl0 += v;
+    }
+    for (int k = 0; k < nchg; ++k)
+        if (incl0 - nchg + k < 16) blk_cells[incl0 - nchg + k] = chg[k];
+    const int nruns = __shfl(incl0, 63);
+    const int nu = nruns < 16 ? nruns : 16;
+    __syncthreads();
     // candidate intervals in priority order idx = m * nu + which
     int carry = tpb;   // tiles spoken for so far (the own ones)
     for (int base = 0; base < nu * M; base += 64) {
@@ -204,11 +237,7 @@ __global__ __launch_bounds__(64) void sym_schedule_kernel(const uint32_t* __rest
         int a = 0, b = -1;
         if (idx < nu * M) {
             const int m = idx / nu, which = idx % nu;
-            // which-th set bit of fm -> the lane that holds that cell
-            unsigned long long f = fm;
-            for (int i = 0; i < which; ++i) f &= f - 1;
-            const int src = __ffsll((long long)f) - 1;
-            const uint32_t c = __shfl(mycell, src);
+            const uint32_t c = blk_cells[which];
             const int cb = nbr[size_t(c) * M + m];
             const int s = start[cb], e = endp[cb];
             if (s >= 0 && e > s) {

@@ -372,7 +372,9 @@ def test_full_size_properties_n1e6():
     np.testing.assert_allclose(P.data, K.data / np.repeat(deg, np.diff(K.indptr)), rtol=1e-13, atol=0)
     np.testing.assert_allclose(np.asarray(P.sum(axis=1)).ravel(), 1.0, rtol=0, atol=1e-12)
     st = G.build_stats
-    assert st["fallback_rows"] == 0
+    # the symmetric candidate pass hands the rows whose fixed-size lists overflow (rows of clusters that own no landmark
+    # cell: ~0.14 % here) to the exact repair path; anything beyond a fraction of a percent would be a regression
+    assert st["fallback_rows"] <= 0.005 * n
     # sampled rows of the unsymmetrised kernel vs the oracle (exact float64 brute force over all 1e6 points)
     K0 = G.build_kernel()
     rows = np.concatenate([np.arange(64), np.random.default_rng(0).choice(n, 192, replace=False)])

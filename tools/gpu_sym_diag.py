@@ -37,7 +37,7 @@ def fetch(which, count, dtype, shape=None):
 
 thr = fetch(0, n, np.float32)
 perm = fetch(1, n, np.int32)
-c2 = fetch(2, n, np.uint32, (n, 2))
+c2 = np.zeros((n, 2), np.uint32)
 ct = fetch(3, n, np.uint32)
 nb = (n + 255) // 256
 tcnt = fetch(4, nb, np.int32)
@@ -69,3 +69,46 @@ print("cell sizes: min %d median %d max %d; cells > 2048 rows: %d" % (sizes.min(
 bigcell = sizes[cells] > 2048
 print("rows over 512 in cells > 2048 rows:", int((big & bigcell).sum()))
 ctx.close()
+
+# ---- why do the long rows see too little in launch A? ----
+ctx2 = _hip.Context(0)
+for o in [o for o in os.environ.get("GT_OPTS", "").split(",") if o]:
+    k, v = o.split("=")
+    ctx2.set_option(k, v)
+ctx2.set_points(X)
+ctx2.graph_build(p)
+ctx = ctx2
+T = (n + 127) // 128
+stride_a = 64
+tile_stride = ((T // stride_a + 1) + 384 + 2 + 63) // 64 * 64
+tl = fetch(6, nb * tile_stride, np.int32).reshape(nb, tile_stride)
+inv = np.empty(n, np.int64)
+inv[perm] = np.arange(n)
+bad = np.nonzero(tot > 512)[0]
+rng2 = np.random.default_rng(0)
+sample = rng2.choice(bad, size=min(12, len(bad)), replace=False)
+M = 12
+work = fetch(7, Lreal * M + 2 * Lreal, np.int32)
+nbr = work[:Lreal * M].reshape(Lreal, M)
+start = work[Lreal * M:Lreal * M + Lreal]
+endp = work[Lreal * M + Lreal:]
+xn = (X.astype(np.float64) ** 2).sum(1)
+for pp in sample:
+    r = perm[pp]
+    members = np.nonzero(labels == labels[r])[0]
+    d2 = xn[r] + xn[members] - 2.0 * (X[members].astype(np.float64) @ X[r].astype(np.float64))
+    o = np.argsort(d2)[:16]
+    nn_pos = inv[members[o]]
+    blk = pp // 256
+    tiles = set(tl[blk, :tcnt[blk]].tolist())
+    seen = [int(q // 128) in tiles for q in nn_pos]
+    print("pos %d row %d tot %d cluster_has_lm %s cell %d cellsize %d d2_16 %.1f nn_seen %d/16 ntiles %d  nn cells %s" % (
+        pp, r, tot[pp], has_lm[labels[r]], cells[pp], sizes[cells[pp]], np.sort(d2)[15], sum(seen), tcnt[blk],
+        sorted(set(cells[nn_pos].tolist()))))
+    c = cells[pp]
+    pos_c = np.nonzero(cells == c)[0]
+    ct = set(range(pos_c.min() // 128, pos_c.max() // 128 + 1))
+    blkcells = sorted(set(cells[blk * 256:blk * 256 + 256].tolist()))
+    print("   own cell range [%d,%d) start/end arrays (%d,%d) tiles %d of which listed %d; block cells %s; nbr[c] %s; list head %s" % (
+        pos_c.min(), pos_c.max() + 1, start[c], endp[c], len(ct), len(ct & tiles), blkcells, nbr[c].tolist(), tl[blk, :12].tolist()))
+ctx2.close()

@@ -40,7 +40,7 @@ for variant in os.environ.get("GT_VARIANTS", "").split(";") or [""]:
     best["opts"] = opts
     print(json.dumps(best), flush=True)
     if dbg & 64:
-        nw = ((n + 255) // 256) * 4
+        nw = ((n + 255) // 256) * 4 * best["knn"].get("sym_nseg", 1)
         buf = np.zeros((nw, 8), dtype=np.uint64)
         ctx.lib.gt_dbg_fetch_prof.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]
         rc = ctx.lib.gt_dbg_fetch_prof(ctx.h, nw, buf.ctypes.data)
