@@ -9,12 +9,16 @@ Workload (BASELINE.json configs[2], SURVEY.md 8d "C3"): synthetic `mix` data, N 
 float32, seed 1; graphtools.Graph(X, knn=15, decay=40, thresh=1e-4) -> kernel K and diff_op P.
 One step = one complete build of K and P (row norms / padded copy, kNN candidate pass, fp64 re-rank, radius
 pass, affinities, symmetrisation, row normalisation) with the points already resident in HBM; results stay on
-the device ("device-complete").  With N > 1 GPUs the rows are sharded over the ranks: every step additionally
+the device ("device-complete").  On one GPU the candidate pass is the symmetric one (graphtools_amd/csrc/gt_sym.hip):
+a threshold-seeding launch over every row's neighbourhood, then one launch that scores every unordered pair of rows
+once and tests the result for both rows.  With N > 1 GPUs the rows are sharded over the ranks: every step additionally
 contains the RCCL all-gather of the point slices and the all-to-all of the transposed triplets (strong
 scaling: the graph is the same size on any number of GPUs).
 
 Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` (dominant kernel =
-knn_select, MFMA-bound, timed with HIP events on the library's stream) and, at N = 1, `cpu_baseline`
+knn_select, MFMA-bound, timed with HIP events on the library's stream; `achieved` = the algorithmic 2 N^2 d flop of the
+pairwise-distance problem over the time of BOTH candidate launches, the matrix work actually executed is reported next
+to it) and, at N = 1, `cpu_baseline`
 (the numpy/scipy/scikit-learn oracle port timed on this host on a bounded sample).
 """
 import argparse
@@ -50,16 +54,23 @@ def make_mix(n, d, seed, dtype=np.float32):
     return out
 
 
-def measured_traffic(n, d, precision, world):
+SYM_KERNEL = "knn_select_kernel<64, 8, 2, 2>"   # symmetric collect (single GPU, single float16 chain)
+
+
+def measured_traffic(n, d, precision, world, symmetric):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE doubled per
-    MI355X_MICROARCH.md + WRITE_SIZE, profiles/r1_pmc_fetch_write_per_kernel_<precision>.json).  PMC counters cannot be read
+    MI355X_MICROARCH.md + WRITE_SIZE, profiles/r*_pmc_fetch_write_per_kernel*.json).  PMC counters cannot be read
     from inside this process, so the number is only reported for the exact workload that was profiled."""
     if not (n == 1000000 and d == 64 and world == 1):
         return None
     try:
-        name = {"f16x1": "f16x1", "f16": "f16split"}[precision]
-        with open(os.path.join(ROOT, "profiles", "r1_pmc_fetch_write_per_kernel_%s.json" % name)) as f:
-            k = json.load(f)["kernels"][SELECT_KERNEL[precision]]
+        if symmetric:
+            with open(os.path.join(ROOT, "profiles", "r2_pmc_fetch_write_per_kernel.json")) as f:
+                k = json.load(f)["kernels"][SYM_KERNEL]
+        else:
+            name = {"f16x1": "f16x1", "f16": "f16split"}[precision]
+            with open(os.path.join(ROOT, "profiles", "r1_pmc_fetch_write_per_kernel_%s.json" % name)) as f:
+                k = json.load(f)["kernels"][SELECT_KERNEL[precision]]
         return (k["hbm_read_GB_per_launch_corrected_x2"] + k["hbm_write_GB_per_launch"]) * 1e9
     except Exception:
         return None
@@ -184,12 +195,13 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    select_ms = []
+    select_ms, seed_ms = [], []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         nnz, flags = step()
         # stage timers were recorded with hipEvents on the library's own stream during the step
         select_ms.append(ctx.stage_ms("knn_select"))
+        seed_ms.append(max(ctx.stage_ms("sym_seed"), 0.0))
     fence()
     elapsed = time.perf_counter() - t0
     if distributed:
@@ -206,11 +218,25 @@ def main():
         ms_per_step = 1e3 * elapsed / args.steps
         nloc = int(splits[1] - splits[0])
         flops = 2.0 * nloc * n * d                      # algorithmic: 2*d flop per (query, database row) pair
-        avg_ms = float(np.mean(select_ms))
-        achieved = flops / (avg_ms * 1e-3) / 1e12
         main = ctx.last_knn_precision()                 # what the main candidate pass actually ran on
         peak = MFMA_PEAK_TFLOPS[main]
-        executed = flops * MFMA_CHAINS[main]
+        kst = ctx.knn_stats()
+        symmetric = bool(kst["symmetric"])
+        main_ms, seeding_ms = float(np.mean(select_ms)), float(np.mean(seed_ms))
+        avg_ms = main_ms + (seeding_ms if symmetric else 0.0)   # the candidate pass = both launches
+        achieved = flops / (avg_ms * 1e-3) / 1e12
+        if symmetric:
+            # executed matrix work: every unordered pair of (padded) rows once - 256-row query blocks against half of
+            # the 128-row tiles - plus the tiles of the seeding launch
+            n_pad = -(-n // 256) * 256
+            nb = n_pad // 256
+            walk_tiles = 2 * (1 + (nb - 1) // 2) + (0 if nb % 2 else 2)
+            executed = 2.0 * d * 256 * 128 * (nb * walk_tiles + kst.get("sym_seed_tiles", 0))
+            kernel_name = "%s + its threshold-seeding launch knn_select_kernel<64, 8, 0, 2> (symmetric f16x1 MFMA candidate " \
+                          "pass, knn_precision=%s): every unordered pair of rows scored once" % (SYM_KERNEL, args.knn_precision)
+        else:
+            executed = flops * MFMA_CHAINS[main]
+            kernel_name = "%s (%s MFMA candidate pass, knn_precision=%s)" % (SELECT_KERNEL[main], main, args.knn_precision)
         stats = ctx.graph_stats()
         out = {
             "metric": "graphs/sec (kernel+diff_op) at N=1e6 d=64 k=15",
@@ -228,18 +254,19 @@ def main():
             "config": {"workload": "C3: mix N=%d d=%d float32 seed=1, kNNGraph knn=%d decay=%g thresh=1e-4, "
                                    "kernel_symm='+', device-complete K and P" % (n, d, args.knn, args.decay),
                        "row_sharding": "%d rank(s) x %d rows" % (world, nloc), "nnz_K": nnz_total,
-                       "radius_rows_rank0": stats["radius_rows"], "fallback_rows_rank0": stats["fallback_rows"]},
-            "roofline": {"kernel": "%s (%s MFMA candidate pass, knn_precision=%s)" % (SELECT_KERNEL[main], main,
-                                                                                       args.knn_precision),
+                       "radius_rows_rank0": stats["radius_rows"], "fallback_rows_rank0": stats["fallback_rows"],
+                       "symmetric_candidate_pass": symmetric},
+            "roofline": {"kernel": kernel_name,
                          "bound": "mfma",
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "traffic": measured_traffic(n, d, main, world), "traffic_unit": "bytes/launch",
-                         "avg_launch_ms": avg_ms, "algorithmic_flop_per_launch": flops,
+                         "traffic": measured_traffic(n, d, main, world, symmetric), "traffic_unit": "bytes/launch",
+                         "avg_launch_ms": avg_ms, "main_launch_ms": main_ms, "seeding_launch_ms": seeding_ms if symmetric else 0.0,
+                         "algorithmic_flop_per_launch": flops,
                          "executed_mfma_flop_per_launch": executed,
                          "executed_mfma_frac": executed / (avg_ms * 1e-3) / 1e12 / peak},
             "stage_ms_last_step": {s: round(ctx.stage_ms(s), 3) for s in
-                                   ("prep", "knn_select", "rerank", "fallback", "radius", "affinity", "symmetrize",
-                                    "normalize")},
+                                   ("prep", "query_order", "sym_prepare", "sym_seed", "knn_select", "rerank", "fallback",
+                                    "radius", "affinity", "symmetrize", "normalize")},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(X, args.knn, args.decay, thresh, ctx, params_factory)

@@ -381,7 +381,7 @@ class Context:
         out = {"symmetric": bool(st[0]), "sym_overflow_rows": int(st[1]), "repaired_rows": int(st[2]),
                "exhaustive_rows": int(st[3])}
         if st[0]:
-            out.update(sym_nseg=int(st[6]), sym_entries=int(st[5]), sym_longest=int(st[7]), sym_rows_over_256=int(st[8]),
+            out.update(sym_nseg=int(st[6]), sym_seed_tiles=int(st[9]), sym_entries=int(st[5]), sym_longest=int(st[7]), sym_rows_over_256=int(st[8]),
                        sym_rows_over_128=int(st[11]))   # list-length counters: only with dbg_select bit 256
         return out
 

@@ -226,11 +226,13 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
             const int tile_stride = ((stride_a ? n_tiles_s / stride_a + 1 : 0) + ctx->sym_max_nb + bq_sym / bn_sym + 63) / 64 * 64;
             GT_HIP(ctx, k->sym_tiles.reserve(size_t(n_pad_s / bq_sym) * tile_stride * sizeof(int32_t)));
             GT_HIP(ctx, k->sym_tile_cnt.reserve(size_t(n_pad_s / bq_sym) * sizeof(int32_t)));
+            GT_HIP(ctx, hipMemsetAsync(k->sym_stat.p, 0, 8 * sizeof(unsigned long long), ctx->stream));
             {
                 StageSpan span(ctx, "sym_prepare");
                 GT_TRY(gt_sym_gather(ctx, perm, n_pad_s, k->Ycs.p, k->hnegs.as<float>()));
                 GT_TRY(gt_sym_schedule(ctx, n_pad_s, bq_sym, bn_sym, ctx->sym_cells, stride_a, ctx->sym_max_nb, tile_stride,
-                                       k->sym_work, k->sym_tiles.as<int32_t>(), k->sym_tile_cnt.as<int32_t>()));
+                                       k->sym_work, k->sym_tiles.as<int32_t>(), k->sym_tile_cnt.as<int32_t>(),
+                                       k->sym_stat.as<unsigned long long>() + 5));
             }
             SelectArgs a = sa;
             a.prec = 2;
@@ -294,7 +296,6 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
             k->sym_used = true;
             if (ctx->dbg_select & 4) return GT_OK;   // experiment: candidate pass only (tables are NOT valid)
             GT_HIP(ctx, hipMemsetAsync(k->unproven.p, 0, sizeof(uint32_t), ctx->stream));
-            GT_HIP(ctx, hipMemsetAsync(k->sym_stat.p, 0, 8 * sizeof(unsigned long long), ctx->stream));
             SymRerank sr;
             sr.tlists = k->tlists.as<uint64_t>();
             sr.tcounts = k->tcounts.as<uint32_t>();

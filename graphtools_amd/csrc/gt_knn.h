@@ -149,7 +149,7 @@ int gt_sym_gather(gt_ctx* ctx, const int32_t* perm, int64_t n_pad_s, void* Ys, f
 int gt_sym_thresholds(gt_ctx* ctx, const int32_t* perm, int64_t n_pad_s, const float* hs, const uint64_t* lists, int lstride,
                       const uint32_t* counts, int need_m, const ErrModel& err, double rkf, float* thr, float* g, float* gmin);
 int gt_sym_schedule(gt_ctx* ctx, int64_t n_pad_s, int bq, int bn, int cells, int stride, int max_nb, int tile_stride,
-                    DevBuf& work, int32_t* tile_list, int32_t* tile_cnt);
+                    DevBuf& work, int32_t* tile_list, int32_t* tile_cnt, unsigned long long* tiles_total = nullptr);
 int gt_launch_fallback(gt_ctx* ctx, const RerankArgs& a, int64_t n_rows, int64_t row_off, double* scratch);
 int gt_launch_fallback_thr(gt_ctx* ctx, const RerankArgs& a, int64_t n_rows, int64_t row_off, int32_t* qrows, float* thr);
 int gt_launch_collected_select(gt_ctx* ctx, const RerankArgs& a, int64_t n_rows, int64_t row_off, const uint64_t* clists,

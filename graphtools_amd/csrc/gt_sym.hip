@@ -297,6 +297,15 @@ __global__ __launch_bounds__(64) void sym_schedule_kernel(const uint32_t* __rest
     if (lane == 0) tile_cnt[I] = cnt < tile_stride ? cnt : tile_stride;
 }
 
+__global__ __launch_bounds__(256) void sum_i32_kernel(const int32_t* __restrict__ v, const int64_t n,
+                                                      unsigned long long* __restrict__ out) {
+    long long acc = 0;
+    for (int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += int64_t(gridDim.x) * 256) acc += v[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, (unsigned long long)acc);
+}
+
 }  // namespace
 
 int gt_sym_gather(gt_ctx* ctx, const int32_t* perm, int64_t n_pad_s, void* Ys, float* hs) {
@@ -328,7 +337,7 @@ int gt_sym_thresholds(gt_ctx* ctx, const int32_t* perm, int64_t n_pad_s, const f
 // Tile lists of launch A for the NB query blocks of the sorted order (tile_list [NB][tile_stride], tile_cnt [NB]).
 // Uses the landmark rows and the sorted cell ids the query ordering left in the context (gt_order.hip).
 int gt_sym_schedule(gt_ctx* ctx, int64_t n_pad_s, int bq, int bn, int cells, int stride, int max_nb, int tile_stride,
-                    DevBuf& work, int32_t* tile_list, int32_t* tile_cnt) {
+                    DevBuf& work, int32_t* tile_list, int32_t* tile_cnt, unsigned long long* tiles_total) {
     const int L = ctx->order_L;
     if (L <= 0 || !ctx->land_Y.p) GT_FAIL(ctx, GT_E_STATE, "sym schedule: no landmark cells");
     const int M = std::min(std::min(cells, 32), L);
@@ -349,5 +358,9 @@ int gt_sym_schedule(gt_ctx* ctx, int64_t n_pad_s, int bq, int bn, int cells, int
     hipLaunchKernelGGL(sym_schedule_kernel, dim3((unsigned)NB), dim3(64), size_t((T + 31) / 32) * sizeof(uint32_t), ctx->stream,
                        cell_sorted, ctx->n, start, endp, nbr, M, NB, bq, bn, T, stride, max_nb, tile_stride, tile_list, tile_cnt);
     GT_HIP(ctx, hipGetLastError());
+    if (tiles_total) {   // statistics: tiles launch A visits in all (device counter, pre-zeroed by the caller)
+        hipLaunchKernelGGL(sum_i32_kernel, dim3(16), dim3(256), 0, ctx->stream, tile_cnt, int64_t(NB), tiles_total);
+        GT_HIP(ctx, hipGetLastError());
+    }
     return GT_OK;
 }
