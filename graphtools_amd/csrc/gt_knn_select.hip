@@ -69,6 +69,12 @@
 #ifndef GT_SEL_EXP
 #define GT_SEL_EXP 0
 #endif
+// -DGT_SEL_EXP_MODE=<m>: the ablation applies to the kernels of that MODE only (e.g. 2: the symmetric collect keeps a
+// valid threshold-seeding launch in front of it)
+#ifndef GT_SEL_EXP_MODE
+#define GT_SEL_EXP_MODE -1
+#endif
+#define GT_EXP ((GT_SEL_EXP_MODE < 0 || MODE == GT_SEL_EXP_MODE) ? GT_SEL_EXP : 0)
 
 
 namespace {
@@ -400,7 +406,7 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
     float stage_h = 0.f, stage_g = 0.f, stage_gm = 0.f;
 #define GT_STAGE_LOAD(T_, HALF_)                                                                          \
     {                                                                                                     \
-        const float4* src_ = reinterpret_cast<const float4*>(Yp + size_t((GT_SEL_EXP & 64) ? ((T_) & 15) : (T_)) * BN * C::RW) + (HALF_) * HF4;   \
+        const float4* src_ = reinterpret_cast<const float4*>(Yp + size_t((GT_EXP & 64) ? ((T_) & 15) : (T_)) * BN * C::RW) + (HALF_) * HF4;   \
         _Pragma("unroll") for (int u_ = 0; u_ < HF4_PER_THREAD; ++u_) {                                    \
             const int f = tid + u_ * 256;                                                                 \
             stage[u_] = (f < HF4) ? src_[f] : make_float4(0.f, 0.f, 0.f, 0.f);                            \
@@ -436,7 +442,7 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
     const int wu = __builtin_amdgcn_readfirstlane(w);
 #define GT_GLDS_ISSUE(T_, BUF_)                                                                            \
     {                                                                                                      \
-        const char* gt_ = reinterpret_cast<const char*>(Yp) + size_t((GT_SEL_EXP & 64) ? ((T_) & 15) : (T_)) * BN * C::RB; \
+        const char* gt_ = reinterpret_cast<const char*>(Yp) + size_t((GT_EXP & 64) ? ((T_) & 15) : (T_)) * BN * C::RB; \
         char* lt_ = reinterpret_cast<char*>(tile + (BUF_) * C::TILE_FLOATS);                               \
         uint32_t lv_ = uint32_t(lane);                                                                     \
         /* many pieces: recompute the lane offsets per tile instead of pinning a register each */          \
@@ -486,7 +492,7 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
     const int aswz = C::GLDS ? swz_of_row(li, C::RDIV, C::SMASK) : 0;   // sub-tiles start at multiples of 32 rows
 
     for (int it = t_begin; it < t_end; ++it) {
-        const int buf = (GT_SEL_EXP & (4 | 32)) ? 0 : ((it - t_begin) & 1);
+        const int buf = (GT_EXP & (4 | 32)) ? 0 : ((it - t_begin) & 1);
         int t_next = t + t_step, level_next = level, t_step_next = t_step;
         if (own_sched) {
             if (MODE == 2) {
@@ -505,7 +511,7 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
             t_step_next = samp_stride >> level;
             t_next = samp_stride >> level_next;
         }
-        if (!(GT_SEL_EXP & (4 | 32)) && it + 1 < t_end) {
+        if (!(GT_EXP & (4 | 32)) && it + 1 < t_end) {
             if constexpr (C::GLDS) {
                 GT_GLDS_ISSUE(t_next, buf ^ 1);   // every wave left buf^1 at the barrier that ended the previous tile
             } else {
@@ -541,7 +547,7 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
 #define GT_SEED(U_)                                                                                        \
     {                                                                                                      \
         _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) {                                                 \
-            const float4 hv_ = (GT_SEL_EXP & 1) ? make_float4(0.f, 0.f, 0.f, 0.f) :                        \
+            const float4 hv_ = (GT_EXP & 1) ? make_float4(0.f, 0.f, 0.f, 0.f) :                        \
                 *reinterpret_cast<const float4*>(hb + ((U_) / QT) * 32 + 8 * g_ + 4 * h);                  \
             accp[(U_) % 3][4 * g_ + 0] = hv_.x;                                                            \
             accp[(U_) % 3][4 * g_ + 1] = hv_.y;                                                            \
@@ -570,20 +576,43 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
 // takes every row of the unit that beats its threshold - the hits of the lane are counted first, one atomic reserves
 // their slots in the query's list.  Transposed: database row r_ takes query (PQT_, li) when the score seen from its
 // side, (x.y - |y_j|^2/2) + |y_j|^2/2 - |x_q|^2/2, beats its own threshold: (acc + hneg_q) > g_j; one atomic per hit
-// on the row's counter, four in flight at a time.
-#define GT_ADMIT2(PA_, PSB_, PQT_)                                                                         \
+// on the row's counter.  All atomics of a unit are in flight together (one memory round trip per unit).
+#define GT_ADMIT2(PA_, SD_, PSB_, PQT_)                                                                    \
     {                                                                                                      \
         const float tq_ = thr[PQT_];                                                                       \
         const int ql = (w * QT + (PQT_)) * 32 + li;                                                        \
         const uint32_t qpos_ = uint32_t(qblock + ql);                                                      \
         const float hq_ = hnq[PQT_];                                                                       \
-        uint32_t nf_ = 0u;                                                                                 \
-        _Pragma("unroll") for (int e_ = 0; e_ < 16; ++e_) nf_ += ((PA_)[e_] > tq_) ? 1u : 0u;              \
+        uint32_t fmask_ = 0u, tmask_ = 0u;                                                                 \
+        _Pragma("unroll") for (int e_ = 0; e_ < 16; ++e_) fmask_ |= ((PA_)[e_] > tq_) ? (1u << e_) : 0u;   \
+        if (tr_on) {                                                                                       \
+            _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) {                                             \
+                const float4 gv_ = *reinterpret_cast<const float4*>(gbuf + (PSB_) * 32 + 8 * g_ + 4 * h);  \
+                tmask_ |= (((PA_)[4 * g_ + 0] + hq_) > gv_.x) ? (1u << (4 * g_ + 0)) : 0u;                 \
+                tmask_ |= (((PA_)[4 * g_ + 1] + hq_) > gv_.y) ? (1u << (4 * g_ + 1)) : 0u;                 \
+                tmask_ |= (((PA_)[4 * g_ + 2] + hq_) > gv_.z) ? (1u << (4 * g_ + 2)) : 0u;                 \
+                tmask_ |= (((PA_)[4 * g_ + 3] + hq_) > gv_.w) ? (1u << (4 * g_ + 3)) : 0u;                 \
+            }                                                                                              \
+        }                                                                                                  \
+        /* every atomic of the unit is issued before the first result is looked at: one round trip */      \
+        const uint32_t nf_ = uint32_t(__popc(fmask_));                                                     \
+        uint32_t k_ = 0u;                                                                                  \
+        if (nf_) k_ = atomicAdd(&sy.tcounts[qpos_], nf_);                                                  \
+        /* transposed: the 32 lanes of a half-wave (32 queries) aim at the SAME row's counter - the first hitting lane  \
+           of the half reserves the slots of all of them (same-address atomics of one instruction would serialise) */ \
+        uint32_t tslot_[16];                                                                               \
+        _Pragma("unroll") for (int e_ = 0; e_ < 16; ++e_) {                                                \
+            const uint32_t j = tbase + uint32_t((PSB_) * 32 + 8 * (e_ >> 2) + 4 * h + (e_ & 3));           \
+            const unsigned long long bm_ = __ballot((tmask_ >> e_) & 1u);                                  \
+            const uint32_t mh_ = h ? uint32_t(bm_ >> 32) : uint32_t(bm_);                                  \
+            tslot_[e_] = 0u;                                                                               \
+            if (mh_ != 0u && uint32_t(li) == uint32_t(__ffs(int(mh_)) - 1))                                \
+                tslot_[e_] = atomicAdd(&sy.tcounts[j], uint32_t(__popc(mh_)));                             \
+        }                                                                                                  \
         if (nf_) {                                                                                         \
-            uint32_t k_ = atomicAdd(&sy.tcounts[qpos_], nf_);                                              \
             uint64_t* lp_ = sy.tlists + size_t(qpos_) * size_t(sy.tcap);                                   \
             _Pragma("unroll") for (int e_ = 0; e_ < 16; ++e_) {                                            \
-                if ((PA_)[e_] > tq_) {                                                                     \
+                if (fmask_ & (1u << e_)) {                                                                 \
                     const uint32_t j = tbase + uint32_t((PSB_) * 32 + 8 * (e_ >> 2) + 4 * h + (e_ & 3));   \
                     if (k_ < uint32_t(sy.tcap)) list_store(lp_ + k_, cand_pack((PA_)[e_], j));             \
                     ++k_;                                                                                  \
@@ -592,30 +621,18 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
             /* a row whose list has overflowed (count > capacity) is repaired later anyway: stop collecting */ \
             if (k_ > uint32_t(sy.tcap)) thr[PQT_] = INFINITY;                                              \
         }                                                                                                  \
-        if (tr_on) {                                                                                       \
-            _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) {                                             \
-                const float4 gv_ = *reinterpret_cast<const float4*>(gbuf + (PSB_) * 32 + 8 * g_ + 4 * h);  \
-                const float gr_[4] = {gv_.x, gv_.y, gv_.z, gv_.w};                                         \
-                bool hit_[4];                                                                              \
-                bool anyg_ = false;                                                                        \
-                _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                         \
-                    hit_[i_] = ((PA_)[4 * g_ + i_] + hq_) > gr_[i_];                                       \
-                    anyg_ = anyg_ || hit_[i_];                                                             \
-                }                                                                                          \
-                if (__ballot(anyg_)) {                                                                     \
-                    const float4 hv_ = *reinterpret_cast<const float4*>(hb + (PSB_) * 32 + 8 * g_ + 4 * h); \
-                    const float hr_[4] = {hv_.x, hv_.y, hv_.z, hv_.w};                                     \
-                    uint32_t tslot_[4];                                                                    \
-                    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                     \
-                        const uint32_t j = tbase + uint32_t((PSB_) * 32 + 8 * g_ + 4 * h + i_);            \
-                        tslot_[i_] = 0xFFFFFFFFu;                                                          \
-                        if (hit_[i_]) tslot_[i_] = atomicAdd(&sy.tcounts[j], 1u);                          \
-                    }                                                                                      \
-                    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                     \
-                        const uint32_t j = tbase + uint32_t((PSB_) * 32 + 8 * g_ + 4 * h + i_);            \
-                        if (hit_[i_] && tslot_[i_] < uint32_t(sy.tcap))                                    \
-                            list_store(sy.tlists + size_t(j) * size_t(sy.tcap) + tslot_[i_],               \
-                                       cand_pack(((PA_)[4 * g_ + i_] + hq_) - hr_[i_], qpos_));            \
+        if (__ballot(tmask_ != 0u)) {                                                                      \
+            _Pragma("unroll") for (int e_ = 0; e_ < 16; ++e_) {                                            \
+                const unsigned long long bm_ = __ballot((tmask_ >> e_) & 1u);                              \
+                if (bm_) {   /* wave-uniform */                                                            \
+                    const uint32_t mh_ = h ? uint32_t(bm_ >> 32) : uint32_t(bm_);                          \
+                    const int lead_ = (mh_ ? __ffs(int(mh_)) - 1 : 0) + 32 * h;                            \
+                    const uint32_t slot_ = uint32_t(__shfl(int(tslot_[e_]), lead_)) +                      \
+                                           uint32_t(__popc(mh_ & ((1u << li) - 1u)));                      \
+                    if (((tmask_ >> e_) & 1u) && slot_ < uint32_t(sy.tcap)) {                              \
+                        const uint32_t j = tbase + uint32_t((PSB_) * 32 + 8 * (e_ >> 2) + 4 * h + (e_ & 3)); \
+                        list_store(sy.tlists + size_t(j) * size_t(sy.tcap) + slot_,                        \
+                                   cand_pack(((PA_)[e_] + hq_) - (SD_)[e_], qpos_));                       \
                     }                                                                                      \
                 }                                                                                          \
             }                                                                                              \
@@ -659,27 +676,27 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
         for (int u = 0; u <= NU; ++u) {
             const int sb = u / QT, qt = u % QT;              // the unit whose chain is issued now (u < NU)
             const int psb = (u - 1) / QT, pqt = (u - 1) % QT;   // the unit whose results are examined now (u > 0)
-            if (!C::GLDS && !(GT_SEL_EXP & (4 | 32)) && u == NU / 2 && it + 1 < t_end) {
+            if (!C::GLDS && !(GT_EXP & (4 | 32)) && u == NU / 2 && it + 1 < t_end) {
                 // first half of the next tile has landed: park it in the other LDS buffer, fetch the second half
                 GT_STAGE_STORE(buf ^ 1, 0);
                 GT_STAGE_LOAD(t_next, 1);
             }
             if (u < NU) {
-                if (!(GT_SEL_EXP & 2) && qt == 0 && sb + 1 < NSUB) afr[(sb + 1) & 1].load(tb + ((sb + 1) * 32 + li) * LDP, h, aswz);
+                if (!(GT_EXP & 2) && qt == 0 && sb + 1 < NSUB) afr[(sb + 1) & 1].load(tb + ((sb + 1) * 32 + li) * LDP, h, aswz);
                 if constexpr (SEEDREG) {
                     mma_chain_seeded<DP>(afr[sb & 1], bq[qt], seedr, accp[u % NACC]);
                     if (qt == QT - 1 && sb + 1 < NSUB) GT_SEEDR(sb + 1);   // behind the last reader of this sub-tile's seeds
                 } else {
                     if (u + 1 < NU) GT_SEED(u + 1);
-                    mma_chain<DP>(afr[(GT_SEL_EXP & 2) ? 0 : (sb & 1)], bq[qt], accp[u % 3]);
+                    mma_chain<DP>(afr[(GT_EXP & 2) ? 0 : (sb & 1)], bq[qt], accp[u % 3]);
                 }
             }
             if (u > 0) {
                 // one predicate per lane: the largest of its 16 scores against the query's threshold (a v_max3 tree
                 // and one compare in the MFMA issue gaps; the per-element compares are redone on the cold admission path)
-                const float tq = (GT_SEL_EXP & 8) ? INFINITY : thr[pqt];
+                const float tq = (GT_EXP & 8) ? INFINITY : thr[pqt];
                 const f32x16& pa = accp[(u - 1) % NACC];
-                if (GT_SEL_EXP & 8) asm volatile("" ::"v"(pa));   // keep the matrix work alive
+                if (GT_EXP & 8) asm volatile("" ::"v"(pa));   // keep the matrix work alive
 #pragma unroll
                 for (int t3 = 0; t3 < 5; ++t3) mx[t3] = fmaxf(fmaxf(pa[3 * t3], pa[3 * t3 + 1]), pa[3 * t3 + 2]);
                 const float m5 = fmaxf(fmaxf(mx[0], mx[1]), mx[2]);
@@ -688,7 +705,7 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
                 any_hit = m16 > tq;
                 // MODE 2: ... or some row of the sub-tile may want this query (same arithmetic as the cold path:
                 // rounding is monotone, so max(acc) + hq > min(g) whenever one acc_i + hq > g_i)
-                if (MODE == 2) any_hit = any_hit || (m16 + hnq[pqt] > gms[psb]);
+                if (MODE == 2 && !(GT_EXP & 8)) any_hit = any_hit || (m16 + hnq[pqt] > gms[psb]);
             }
 #if GT_SEL_PIPE
             if (u > 0 && u < NU) {
@@ -737,11 +754,11 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
                     if (QT == 1 || cqt == 0) {
                         cacc = cs;
                         mma_chain<DP>(ca, bq[0], cacc);
-                        GT_ADMIT2(cacc, csb, 0);
+                        GT_ADMIT2(cacc, cs, csb, 0);
                     } else {
                         cacc = cs;
                         mma_chain<DP>(ca, bq[QT - 1], cacc);
-                        GT_ADMIT2(cacc, csb, QT - 1);
+                        GT_ADMIT2(cacc, cs, csb, QT - 1);
                     }
                     if (prof) n_adm += 1;
                 }
@@ -792,9 +809,9 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
         if constexpr (C::GLDS) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the next tile are in LDS
         } else {
-            if (!(GT_SEL_EXP & (4 | 32)) && it + 1 < t_end) GT_STAGE_STORE(buf ^ 1, 1);
+            if (!(GT_EXP & (4 | 32)) && it + 1 < t_end) GT_STAGE_STORE(buf ^ 1, 1);
         }
-        if (!(GT_SEL_EXP & (4 | 16))) {
+        if (!(GT_EXP & (4 | 16))) {
             const unsigned long long ts_ = prof ? __builtin_readcyclecounter() : 0ull;
             __syncthreads();
             if (prof) t_bar += __builtin_readcyclecounter() - ts_;
