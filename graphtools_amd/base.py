@@ -86,8 +86,15 @@ class BaseGraph(object):
             self._hip_ctx = _hip.Context(getattr(self, "device", 0) or 0)
             return self._hip_ctx
 
-    def _emit_build_warnings(self, flags):
-        # reference: base.py:551-554 (symmetry holds by construction of the merge kernel)
+    def _emit_build_warnings(self, flags, K=None):
+        """The sanity warnings of BaseGraph._build_kernel (reference: base.py:551-554).  Every symmetrisation of the
+        merge kernel is symmetric by construction; without one (kernel_symm=None) the reference's own test
+        ``(K - K.T).max() > 1e-5`` is evaluated on the fetched matrix."""
+        if K is not None and getattr(self, "kernel_symm", "+") is None:
+            diff = K - K.T
+            asym = diff.max() if diff.shape[0] else 0.0
+            if asym > 1e-5:
+                warnings.warn("K should be symmetric", RuntimeWarning)
         if flags & _hip.FLAG_ZERO_DIAGONAL:
             warnings.warn("K should have a non-zero diagonal", RuntimeWarning)
 

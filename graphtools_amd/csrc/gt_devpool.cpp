@@ -1,4 +1,5 @@
 // Process-wide cache of large device allocations (see gt_common.h, DevBuf).
+#include <algorithm>
 #include <map>
 #include <mutex>
 
@@ -13,11 +14,19 @@ struct Pool {
     std::mutex mu;
     std::multimap<size_t, void*> blocks[kMaxDevices];   // by size
     size_t cached[kMaxDevices] = {};
+    // bytes that may stay parked per device: GT_POOL_MAX_GB, else a quarter of the device's memory (at most 64 GB) -
+    // the rest of the process (torch, RCCL) cannot see what sits here
     size_t limit() {
         static const size_t v = [] {
             const char* s = std::getenv("GT_POOL_MAX_GB");
-            const double gb = s ? std::atof(s) : 64.0;
-            return gb <= 0 ? size_t(0) : size_t(gb * double(size_t(1) << 30));
+            if (s) {
+                const double gb = std::atof(s);
+                return gb <= 0 ? size_t(0) : size_t(gb * double(size_t(1) << 30));
+            }
+            size_t free_b = 0, total_b = 0;
+            size_t cap = size_t(64) << 30;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b > 0) cap = std::min(cap, total_b / 4);
+            return cap;
         }();
         return v;
     }
@@ -75,6 +84,10 @@ void gt_pool_free(void* p, size_t bytes) {
     Pool& P = pool();
     const int d = current_device();
     if (d >= 0 && bytes >= kMinPooled) {
+        // hipFree would have waited for the device; a parked block can be handed to another context (another stream,
+        // another thread) at once, so work still queued on it must be finished first.  Blocks are let go when a buffer
+        // grows or a context closes - never inside the steady state of a build.
+        (void)hipDeviceSynchronize();
         std::lock_guard<std::mutex> lock(P.mu);
         if (P.cached[d] + bytes <= P.limit()) {
             P.blocks[d].emplace(bytes, p);

@@ -28,6 +28,7 @@ struct GraphState {
     int64_t r0 = 0, r1 = 0, nloc = 0;
     int64_t n_total = 0;   // number of columns of K / P
     bool begun = false, finished = false;
+    bool aniso_applied = false;   // finish_normalize has rescaled K by the degrees (not idempotent)
     // query side: rows of the graph are rows [qoff, qoff + nloc) of Qmat (= the bound points unless `external`,
     // i.e. build_kernel_to_data(Y), graphs.py:819-982)
     bool external = false;

@@ -99,6 +99,26 @@ __global__ void max_u32_kernel(const uint32_t* __restrict__ v, const int64_t n, 
     if ((threadIdx.x & 63) == 0) atomicMax(out, m);
 }
 
+// knn_max: rows whose s-th nearest neighbour still lies inside their radius, for the (up to 4) table sizes s the
+// reference's search-expansion loop would try (graphs.py:916-940: "update_idx" after a search with search_knn = s).
+// Distances and radii are compared as the reference holds them (float64 images of the input-dtype distances).
+__global__ __launch_bounds__(256) void stage_count_kernel(const int64_t nloc, const int MP, const int dtype, const int metric,
+                                                          const double* __restrict__ cand_d2, const double* __restrict__ bw,
+                                                          const double radius_factor, const int4 stages, const int nstage,
+                                                          uint32_t* __restrict__ counts) {
+    const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    const int st[4] = {stages.x, stages.y, stages.z, stages.w};
+    bool un[4] = {false, false, false, false};
+    if (i < nloc) {
+        const double r = bw[i] * radius_factor;
+        for (int t = 0; t < nstage; ++t) un[t] = gt_key_to_dist(cand_d2[i * MP + (st[t] - 1)], dtype, metric) < r;
+    }
+    for (int t = 0; t < nstage; ++t) {
+        const unsigned long long m = __ballot(un[t]);
+        if ((threadIdx.x & 63) == 0 && m) atomicAdd(&counts[t], uint32_t(__popcll(m)));
+    }
+}
+
 // ---- A1: affinities + counts ----------------------------------------------------------------------
 // One wave per local row.  Table rows: K overwrites cand_d2 in place (-1 marks a dropped slot).
 // Radius rows: exact float64 distance for every collected candidate, K into rK.
@@ -750,6 +770,7 @@ static int graph_begin_impl(gt_ctx* ctx, const gt_knn_params* params, int32_t wo
     g->n_total = ctx->n;   // columns: the bound points
     g->begun = false;
     g->finished = false;
+    g->aniso_applied = false;
     g->external = external;
     g->n_over = 0;
     g->radius_retries = 0;
@@ -768,9 +789,32 @@ static int graph_begin_impl(gt_ctx* ctx, const gt_knn_params* params, int32_t wo
     if (int64_t(kprime) > ctx->n) GT_FAIL(ctx, GT_E_ARG, "knn + 1 exceeds n_samples");
     int need = kprime;
     bool use_radius = !binary;
+    // knn_max: table sizes the reference's search-expansion loop tries (graphs.py:882, 916-940): 6 k', 36 k', ... capped
+    // at knn_max' = knn_max (+1 with self).  The exact tables are built as deep as knn_max' when the kernels can hold
+    // it (447 neighbours), else as deep as the largest step below - enough whenever the loop ends in its radius branch.
+    int64_t km = 0;
+    int kst[4] = {0, 0, 0, 0};
+    int n_kst = 0;
+    const int kMaxTable = 448;
     if (!binary && params->knn_max > 0) {
-        const int64_t km = std::min<int64_t>(external ? params->knn_max : params->knn_max + 1, ctx->n);
-        need = int(std::max<int64_t>(kprime, km));
+        km = std::max<int64_t>(kprime, std::min<int64_t>(external ? params->knn_max : params->knn_max + 1, ctx->n));
+        for (int64_t sv = std::min<int64_t>(int64_t(kprime) * 6, km); n_kst < 4; sv = std::min<int64_t>(sv * 6, km)) {
+            kst[n_kst++] = int(std::min<int64_t>(sv, 1 << 30));
+            if (sv >= km) break;
+        }
+        need = int(km);
+        if (km > kMaxTable || world > 1) {
+            // (sharded builds cannot replay the loop - it needs the row counts of every rank - and always cap)
+            if (world > 1 && km <= kMaxTable) {
+                n_kst = 0;
+            } else {
+                need = 0;
+                for (int t = 0; t < n_kst; ++t)
+                    if (kst[t] <= kMaxTable && kst[t] < km) need = kst[t];
+                if (need < kprime || world > 1)
+                    GT_FAIL(ctx, GT_E_LIMIT, "knn_max beyond 447 neighbours is only supported when the search ends in its radius branch");
+            }
+        }
         use_radius = false;
     }
     g->need_m = need;
@@ -831,6 +875,58 @@ static int graph_begin_impl(gt_ctx* ctx, const gt_knn_params* params, int32_t wo
                            g->bw.as<double>(), g->rowsrc.as<int32_t>(), g->over_rows.as<int32_t>(),
                            g->over_count.as<uint32_t>(), g->rthr.as<float>());
         GT_HIP(ctx, hipGetLastError());
+    }
+    if (n_kst > 0) {
+        // knn_max does not always cap (graphs.py:916-976): the reference escalates search_knn = 6 k', 36 k', ... <= knn_max'
+        // while more than a tenth of the rows still have their whole table inside their radius, and what is left over at
+        // the end is searched out to knn_max' only if the escalation got there - otherwise by RADIUS, without a cap.
+        // The exact tables answer every step of that loop they are deep enough for; in the radius case the build
+        // continues like one without knn_max (rows whose radius reaches past their table take the radius pass).
+        int n_avail = 0;
+        while (n_avail < n_kst && kst[n_avail] <= need) ++n_avail;
+        GT_HIP(ctx, g->rmax.reserve(4 * sizeof(uint32_t)));
+        GT_HIP(ctx, hipMemsetAsync(g->rmax.p, 0, 4 * sizeof(uint32_t), ctx->stream));
+        hipLaunchKernelGGL(stage_count_kernel, dim3((unsigned)ceil_div64(g->nloc, 256)), dim3(256), 0, ctx->stream, g->nloc,
+                           k->MP, ctx->dtype, ctx->metric, k->cand_d2.as<double>(), g->bw.as<double>(), g->radius_factor,
+                           make_int4(kst[0], kst[1], kst[2], kst[3]), n_avail, g->rmax.as<uint32_t>());
+        GT_HIP(ctx, hipGetLastError());
+        uint32_t un[4] = {0, 0, 0, 0};
+        GT_HIP(ctx, hipMemcpyAsync(un, g->rmax.p, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        // replay of the loop: t = step the remaining rows were last searched with, `next` = the table size tried next
+        int t = 0;
+        int64_t next = std::min<int64_t>(int64_t(kst[0]) * 6, km);
+        uint32_t remaining = un[0];
+        bool blind = n_avail < 1;
+        while (!blind && int64_t(remaining) > g->nloc / 10 && double(next) < double(ctx->n) / 2.0 && next < km) {
+            ++t;
+            if (t >= n_avail) {
+                blind = true;
+                break;
+            }
+            remaining = un[t];
+            next = std::min<int64_t>(next * 6, km);
+        }
+        const bool capped = !blind && remaining > 0 && next == km;
+        if (blind || (capped && need != km))
+            GT_FAIL(ctx, GT_E_LIMIT, "knn_max beyond 447 neighbours is only supported when the search ends in its radius branch");
+        if (remaining > 0 && !capped) {
+            // the reference gives up by radius search: no cap
+            use_radius = true;
+            g->limit = k->MP;
+            GT_HIP(ctx, hipMemsetAsync(g->over_count.p, 0, sizeof(uint32_t), ctx->stream));
+            StageSpan span(ctx, "affinity");
+            hipLaunchKernelGGL(bandwidth_kernel, dim3((unsigned)ceil_div64(g->nloc, 256)), dim3(256), 0, ctx->stream, g->nloc,
+                               g->r0, k->MP, kprime, ctx->dtype, ctx->metric, k->cand_d2.as<double>(), k->d2_lb.as<double>(),
+                               qn_bound, g->qnorm, g->qoff, ctx->ymax.as<double>(), err_model, g->bw_user.as<double>(),
+                               params->bandwidth_len, params->bandwidth_scale, 1, g->radius_factor,
+                               g->bw.as<double>(), g->rowsrc.as<int32_t>(), g->over_rows.as<int32_t>(),
+                               g->over_count.as<uint32_t>(), g->rthr.as<float>());
+            GT_HIP(ctx, hipGetLastError());
+        } else if (need != km) {
+            // every row finished inside the tables: nothing is capped, nothing is missing
+            g->limit = need;
+        }
     }
     uint32_t n_over = 0;
     GT_HIP(ctx, hipMemcpyAsync(&n_over, g->over_count.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -1089,14 +1185,9 @@ extern "C" int gt_graph_finish(gt_ctx* ctx, const void* recv_buf_dev, int64_t n_
     }
     g->finished = true;
     if (g->p.anisotropy != 0.0) {
-        if (g->world > 1) {
-            // the caller must all-gather the degrees and call gt_graph_anisotropy
-            if (out_nnz) *out_nnz = g->nnz;
-            if (flags) *flags = 0;
-            GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            return GT_OK;
-        }
-        GT_TRY(finish_normalize(ctx, g, g->degree.as<double>()));
+        // sharded build: the caller must all-gather the degrees and call gt_graph_anisotropy (K and every flag of the
+        // build are final here, only the anisotropic rescaling and P are still to come)
+        if (g->world == 1) GT_TRY(finish_normalize(ctx, g, g->degree.as<double>()));
     } else {
         GT_TRY(finish_normalize(ctx, g, nullptr));
     }
@@ -1116,6 +1207,7 @@ static int finish_normalize(gt_ctx* ctx, GraphState* g, const double* degree_all
     StageSpan span(ctx, "normalize");
     const int64_t nloc = g->nloc;
     if (degree_all_dev && g->p.anisotropy != 0.0) {
+        g->aniso_applied = true;
         // degree_all_dev is indexed by GLOBAL row; for world == 1 the local degree vector is global
         DevBuf& tmp = g->aniso_tmp;
         GT_HIP(ctx, tmp.reserve(size_t(nloc) * sizeof(double)));
@@ -1141,6 +1233,8 @@ extern "C" int gt_graph_anisotropy(gt_ctx* ctx, const double* degree_all_dev) {
     GraphState* g = ctx->graph;
     if (!g || !g->finished) GT_FAIL(ctx, GT_E_STATE, "gt_graph_anisotropy: call gt_graph_finish first");
     if (!degree_all_dev) GT_FAIL(ctx, GT_E_ARG, "gt_graph_anisotropy: degree vector is NULL");
+    // the rescaling overwrites K in place: a second call would apply it twice
+    if (g->aniso_applied) GT_FAIL(ctx, GT_E_STATE, "gt_graph_anisotropy: the anisotropy of this build has been applied already");
     GT_TRY(finish_normalize(ctx, g, degree_all_dev));
     GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return GT_OK;
@@ -1202,6 +1296,7 @@ extern "C" int gt_csr_graph_build(gt_ctx* ctx, int64_t n, const int64_t* indptr,
     g->n_total = n;
     g->begun = false;
     g->finished = false;
+    g->aniso_applied = false;
     g->external = true;   // rows are not tied to bound points
     g->n_over = 0;
     g->radius_retries = 0;

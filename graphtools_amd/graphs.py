@@ -246,7 +246,7 @@ class kNNGraph(DataGraph):
         K = sparse.csr_matrix((data, indices, indptr), shape=(n, n))
         if flags & _hip.FLAG_DUPLICATES:
             self._check_duplicates()
-        self._emit_build_warnings(flags)
+        self._emit_build_warnings(flags, K)
         return K
 
     def build_kernel(self):
@@ -427,6 +427,48 @@ class LandmarkGraph(DataGraph):
             self.build_landmark_op()
             return self._transitions
 
+    def extend_to_data(self, data, **kwargs):
+        """Transitions from new points to the LANDMARKS (reference: graphs.py:1247-1289): the kernel to the data
+        (``build_kernel_to_data`` - the device path for kNN graphs), its columns summed per cluster in the order of
+        ``np.unique(clusters)``, rows l1-normalised.  Returns [n_samples_y, n_landmark]."""
+        kernel = self.build_kernel_to_data(data, **kwargs)
+        landmarks, inverse = np.unique(np.asarray(self.clusters), return_inverse=True)
+        n = inverse.shape[0]
+        if sparse.issparse(kernel):
+            # one-hot cluster membership [n, L]; csr @ csr adds the entries of a row in ascending column order, which is
+            # the order the reference's boolean column mask + row sum sees them in
+            S = sparse.csr_matrix((np.ones(n), (np.arange(n), inverse)), shape=(n, len(landmarks)))
+            pnm = sparse.csr_matrix(sparse.csr_matrix(kernel).dot(S))
+            pnm.eliminate_zeros()
+            pnm.sort_indices()
+        else:
+            kernel = np.asarray(kernel)
+            pnm = np.array([np.sum(kernel[:, inverse == i], axis=1).T for i in range(len(landmarks))]).transpose()
+        return self._l1_rows(pnm)
+
+    @staticmethod
+    def _l1_rows(M):
+        # sklearn.preprocessing.normalize(M, "l1", axis=1): rows divided by the sum of their absolute values, zero rows kept
+        if sparse.issparse(M):
+            M = sparse.csr_matrix(M, dtype=np.float64, copy=True)
+            sums = np.asarray(abs(M).sum(axis=1)).ravel()
+            sums[sums == 0.0] = 1.0
+            M.data /= np.repeat(sums, np.diff(M.indptr))
+            return M
+        M = np.asarray(M, dtype=np.float64)
+        sums = np.abs(M).sum(axis=1)
+        sums[sums == 0.0] = 1.0
+        return M / sums[:, None]
+
+    def interpolate(self, transform, transitions=None, Y=None):
+        """reference: graphs.py:1291-1317 - without ``transitions`` and ``Y`` the landmark transitions of the graph's own
+        data are used (a landmark embedding is mapped back to every sample)."""
+        if transitions is None and Y is None:
+            transitions = self.transitions
+        if transitions is None:
+            transitions = self.extend_to_data(Y)
+        return transitions.dot(transform)
+
     def _assign_clusters(self):
         n_samples = self.data.shape[0]
         if self.random_landmarking:
@@ -573,10 +615,24 @@ class TraditionalGraph(DataGraph):
         self._diff_op = P
         self._kernel_degree = self.hip.dense_fetch_vec(_hip.VEC_DEGREE, K.shape[0]).reshape(-1, 1).astype(K.dtype)
         if flags & _hip.FLAG_DUPLICATES and self.precomputed is None:
-            warnings.warn(
-                "Detected zero distance between samples. Consider removing duplicates to avoid errors in "
-                "downstream processing.", RuntimeWarning)
-        self._emit_build_warnings(flags)
+            # reference: graphs.py:1553-1574 - the pairs (i < j) at pdist distance 0, i.e. identical rows, named when
+            # there are fewer than 20 of them
+            _, inverse = np.unique(data, axis=0, return_inverse=True)
+            inverse = np.asarray(inverse).ravel()
+            order = np.argsort(inverse, kind="stable")
+            groups = np.split(order, np.flatnonzero(np.diff(inverse[order])) + 1)
+            pairs = sorted((int(g[a]), int(g[b])) for g in groups if len(g) > 1
+                           for a in range(len(g)) for b in range(a + 1, len(g)))
+            if len(pairs) < 20:
+                warnings.warn(
+                    "Detected zero distance between samples {}. Consider removing duplicates to avoid errors in "
+                    "downstream processing.".format(", ".join("{} and {}".format(i, j) for i, j in pairs)),
+                    RuntimeWarning)
+            else:
+                warnings.warn(
+                    "Detected zero distance between {} pairs of samples. Consider removing duplicates to avoid errors "
+                    "in downstream processing.".format(len(pairs)), RuntimeWarning)
+        self._emit_build_warnings(flags, K)
         return K
 
     def _fetch_diff_op(self):
@@ -732,8 +788,9 @@ class MNNGraph(DataGraph):
         n = K0.shape[0]
         if nnz < 2**31:
             indptr = indptr.astype(np.int32)
-        self._emit_build_warnings(flags)
-        return sparse.csr_matrix((data, indices, indptr), shape=(n, n))
+        K = sparse.csr_matrix((data, indices, indptr), shape=(n, n))
+        self._emit_build_warnings(flags, K)
+        return K
 
     def _fetch_diff_op(self):
         self._ensure_device_graph()
@@ -751,13 +808,18 @@ class MNNGraph(DataGraph):
 
 
 class kNNLandmarkGraph(kNNGraph, LandmarkGraph):
-    pass
+    # kNNGraph carries its own (device) extend_to_data / interpolate; on a landmark graph the landmark versions apply, as
+    # in the reference, where only DataGraph and LandmarkGraph define them (graphs.py:1247-1317)
+    extend_to_data = LandmarkGraph.extend_to_data
+    interpolate = LandmarkGraph.interpolate
 
 
 class MNNLandmarkGraph(MNNGraph, LandmarkGraph):
     """reference: graphs.py:1973-1974 - the landmark algebra on the batch-corrected kernel"""
-    pass
+    extend_to_data = LandmarkGraph.extend_to_data
+    interpolate = LandmarkGraph.interpolate
 
 
 class TraditionalLandmarkGraph(TraditionalGraph, LandmarkGraph):
-    pass
+    extend_to_data = LandmarkGraph.extend_to_data
+    interpolate = LandmarkGraph.interpolate

@@ -30,5 +30,5 @@ from .kernel import (  # noqa: F401
     symmetrize_kernel,
 )
 from .exact import exact_kernel, exact_graph, pairwise_distances_exact  # noqa: F401
-from .landmark import landmark_operator, random_landmark_clusters  # noqa: F401
+from .landmark import landmark_extend, landmark_operator, random_landmark_clusters  # noqa: F401
 from .mnn import mnn_graph, mnn_kernel  # noqa: F401

@@ -13,7 +13,7 @@ labels are an input.
 import numpy as np
 from scipy import sparse
 
-__all__ = ["landmark_operator", "random_landmark_clusters"]
+__all__ = ["landmark_operator", "random_landmark_clusters", "landmark_extend"]
 
 
 def _normalize_l1(M):
@@ -46,6 +46,19 @@ def landmark_operator(K, clusters):
     if sparse.issparse(op):
         op = op.toarray()
     return np.asarray(op), pnm
+
+
+def landmark_extend(kernel_to_data, clusters):
+    """LandmarkGraph.extend_to_data (graphtools/graphs.py:1247-1289): the columns of the kernel from new points to the
+    data summed per cluster (``np.unique`` order), rows l1-normalised.  Returns a dense [m, L] array."""
+    clusters = np.asarray(clusters)
+    if sparse.issparse(kernel_to_data):
+        K = sparse.csr_matrix(kernel_to_data)
+        pnm = sparse.hstack([sparse.csr_matrix(K[:, clusters == i].sum(axis=1)) for i in np.unique(clusters)])
+        return np.asarray(_normalize_l1(sparse.csr_matrix(pnm)).toarray())
+    K = np.asarray(kernel_to_data)
+    pnm = np.array([np.sum(K[:, clusters == i], axis=1).T for i in np.unique(clusters)]).transpose()
+    return _normalize_l1(pnm)
 
 
 def random_landmark_clusters(data, n_landmark, random_state):

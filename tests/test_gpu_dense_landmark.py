@@ -124,3 +124,35 @@ def test_exact_graph_from_float32_distances_vs_oracle(n, kw):
     m = ~flip
     np.testing.assert_allclose(G.K[m], K0[m], rtol=1e-5, atol=1e-37)
     np.testing.assert_allclose(G.P[m], P0[m], rtol=2e-5, atol=1e-37)
+
+
+def test_landmark_graph_extend_and_interpolate_match_reference():
+    """kNNLandmarkGraph.extend_to_data(Y) -> [m, n_landmark] cluster-aggregated, l1-normalised transitions and
+    interpolate(transform) with no Y -> the graph's own landmark transitions (reference graphs.py:1247-1317; the
+    landmark versions must win over kNNGraph's in the MRO)."""
+    import warnings
+
+    z = load_golden("g7b_landmark_extend")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        G = graphtools_amd.Graph(z["X"], knn=15, decay=40, n_pca=None, n_landmark=int(z["n_landmark"]),
+                                 random_landmarking=True, random_state=int(z["random_state"]), verbose=0)
+    assert type(G).__name__ == "kNNLandmarkGraph"
+    assert np.array_equal(np.asarray(G.clusters), z["clusters"])
+    pnm = G.extend_to_data(z["Y"])
+    assert pnm.shape == (z["Y"].shape[0], int(z["n_landmark"]))
+    np.testing.assert_allclose(np.asarray(pnm.todense()), z["extend_pnm"], rtol=1e-9, atol=1e-15)
+    np.testing.assert_allclose(G.interpolate(z["transform"]), z["interp_self"], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(G.interpolate(z["transform"], Y=z["Y"]), z["interp_Y"], rtol=1e-9, atol=1e-12)
+    with pytest.raises(Exception):
+        G.interpolate(z["transform"][:5], Y=z["Y"])       # shape mismatch surfaces like in the reference (dot fails)
+
+
+def test_exact_graph_names_the_duplicate_pairs():
+    """TraditionalGraph from data: identical rows are reported pair by pair like the reference (graphs.py:1553-1574)"""
+    X = make_mix(300, 12, 3).astype(np.float64)
+    X[17] = X[250]
+    X[40] = X[5]
+    X[41] = X[5]
+    with pytest.warns(RuntimeWarning, match="Detected zero distance between samples 5 and 40, 5 and 41, 17 and 250, 40 and 41. Consider"):
+        graphtools_amd.Graph(X, knn=5, decay=10, graphtype="exact", n_pca=None, verbose=0).K

@@ -56,6 +56,39 @@ def test_graph_matches_reference_vectors(name):
         assert_csr_close(G.P, Pg)
 
 
+def test_unsymmetrised_kernel_warns_like_the_reference():
+    """kernel_symm=None: BaseGraph._build_kernel warns "K should be symmetric" when (K - K.T).max() > 1e-5
+    (reference base.py:551-552); a symmetrised kernel does not"""
+    z = load_golden("g3d_mix_symm_none")
+    with pytest.warns(RuntimeWarning, match="K should be symmetric"):
+        G = graphtools_amd.Graph(z["X"], knn=int(z["knn"]), decay=_decay(z), n_pca=None, **golden_params(z))
+        G.K
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        G = graphtools_amd.Graph(z["X"], knn=int(z["knn"]), decay=_decay(z), n_pca=None)
+        G.K
+
+
+@pytest.mark.parametrize("n,d,maker,seed,knn,decay,knn_max", [
+    (3000, 20, make_mix, 21, 5, 40.0, 300),     # 6 k' = 36 leaves < 10 % of the rows short, 216 < knn_max': radius branch, no cap
+    (3000, 20, make_mix, 21, 5, 40.0, 1000),    # the same beyond the kernels' table depth: only the radius branch is reachable
+    (2500, 8, make_gauss, 22, 5, 3.0, 250),     # wide kernel: most rows short at 36 -> escalates to knn_max' = 216 < 251 ... cap or radius
+    (2000, 16, make_mix, 23, 4, 10.0, 40),      # 6 k' = 30, next step = knn_max' = 41: capped branch
+    (2000, 16, make_mix, 23, 7, 10.0, 447),
+])
+def test_knn_max_follows_the_reference_branches(n, d, maker, seed, knn, decay, knn_max):
+    """knn_max caps a row only when the reference's escalation (6 k', 36 k', ... while > 10 % of the rows are short)
+    reaches knn_max'; otherwise the rows left over are searched by radius, uncapped (graphs.py:916-976)"""
+    X = maker(n, d, seed)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        G = graphtools_amd.Graph(X, knn=knn, decay=decay, knn_max=knn_max, n_pca=None, verbose=0)
+        K = G.K
+    Ko, Po = oracle.knn_graph(X, knn=knn, decay=decay, knn_max=knn_max)
+    assert_csr_close(K, Ko)
+    assert_csr_close(G.P, Po)
+
+
 def test_digits_binary_with_ties():
     z = load_golden("g2_digits_binary")
     G = graphtools_amd.Graph(z["X"], knn=int(z["knn"]), decay=None, n_pca=None)

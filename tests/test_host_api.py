@@ -114,3 +114,14 @@ def test_mnn_graph_selection_and_validation():
         graphtools_amd.Graph(X, sample_idx=idx, precomputed="distance", graphtype="mnn", initialize=False)
     with pytest.raises(NotImplementedError):
         g.build_kernel_to_data(X)
+
+
+def test_landmark_graphs_use_the_landmark_out_of_sample_methods():
+    """reference MRO: only DataGraph and LandmarkGraph define extend_to_data / interpolate, so on every landmark graph the
+    landmark versions (cluster-aggregated transitions, default to self.transitions) apply (graphs.py:1247-1317)"""
+    from graphtools_amd import graphs
+
+    for cls in (graphs.kNNLandmarkGraph, graphs.MNNLandmarkGraph, graphs.TraditionalLandmarkGraph):
+        assert cls.extend_to_data is graphs.LandmarkGraph.extend_to_data, cls
+        assert cls.interpolate is graphs.LandmarkGraph.interpolate, cls
+    assert graphs.kNNGraph.extend_to_data is not graphs.LandmarkGraph.extend_to_data

@@ -134,6 +134,22 @@ def test_landmark_operator_matches_reference():
     assert np.array_equal(cl_big, z["big_clusters"])
 
 
+def test_landmark_extend_and_interpolate_match_reference():
+    """LandmarkGraph.extend_to_data / interpolate (graphs.py:1247-1317) on the G7 configuration"""
+    z = load_golden("g7b_landmark_extend")
+    X, Y = z["X"], z["Y"]
+    cl, _ = oracle.random_landmark_clusters(X, int(z["n_landmark"]), int(z["random_state"]))
+    assert np.array_equal(cl, z["clusters"])
+    # build_kernel_to_data(Y) of a kNN graph built with knn=15: knn neighbours (no self), bandwidth from them
+    Ky = oracle.knn_kernel(X, knn=15, decay=40, Y=Y)
+    pnm = oracle.landmark_extend(Ky, cl)
+    np.testing.assert_allclose(pnm, z["extend_pnm"], rtol=0, atol=1e-15)
+    np.testing.assert_allclose(pnm.dot(z["transform"]), z["interp_Y"], rtol=0, atol=1e-13)
+    K, _ = oracle.knn_graph(X, knn=15, decay=40)
+    _, tr = oracle.landmark_operator(sparse.csr_matrix(K), cl)
+    np.testing.assert_allclose(tr.dot(z["transform"]), z["interp_self"], rtol=0, atol=1e-13)
+
+
 def test_cosine_matches_reference():
     z = load_golden("g8_cosine")
     d, i = oracle.knn.cosine_kneighbors(z["X"], None, 66)
