@@ -380,6 +380,7 @@ class Context:
         self._check(self.lib.gt_knn_stats(self.h, _ptr(st)), "gt_knn_stats")
         out = {"symmetric": bool(st[0]), "sym_overflow_rows": int(st[1]), "repaired_rows": int(st[2]),
                "exhaustive_rows": int(st[3])}
+        out["sym_far_kept"] = int(st[10])
         if st[0]:
             out.update(sym_nseg=int(st[6]), sym_seed_tiles=int(st[9]), sym_entries=int(st[5]), sym_longest=int(st[7]), sym_rows_over_256=int(st[8]),
                        sym_rows_over_128=int(st[11]))   # list-length counters: only with dbg_select bit 256

@@ -264,8 +264,28 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
                 StageSpan span(ctx, "sym_prepare");
                 GT_TRY(gt_sym_thresholds(ctx, perm, n_pad_s, k->hnegs.as<float>(), k->lists.as<uint64_t>(), int(lcap),
                                          k->counts.as<uint32_t>(), need_m, em, rkf, k->thr_final.as<float>(),
-                                         k->sym_g.as<float>(), k->sym_gmin.as<float>()));
+                                         k->sym_g.as<float>(), k->sym_gmin.as<float>(), k->sym_work, ctx->sym_cells,
+                                         k->sym_stat.as<unsigned long long>() + 2));
                 GT_HIP(ctx, hipMemsetAsync(k->tcounts.p, 0, size_t(n_pad_s) * sizeof(uint32_t), ctx->stream));
+            }
+            if (ctx->sym_mode < 0) {
+                // launch A kept need_m rows per point: when most of them came from the strided sample instead of the cells
+                // around the point, the cells say nothing about this point set (no cluster structure at their scale), the
+                // thresholds are loose and launch B would drown in candidates - the classic pass is the right tool
+                unsigned long long far_total = 0;
+                GT_HIP(ctx, hipMemcpyAsync(&far_total, k->sym_stat.as<unsigned long long>() + 2, sizeof(far_total),
+                                           hipMemcpyDeviceToHost, ctx->stream));
+                GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                k->sym_far = int64_t(far_total);
+                // the strided sample shows 1 / stride of the rows outside the neighbourhood: every kept row from it stands
+                // for `stride` rows at least as close.  An estimated need_m + stride * far rows inside D_K per point, times
+                // the growth out to the collection radius (x 5 ... 10), has to stay well inside the lists.
+                const double est = double(need_m) + double(std::max(stride_a, 1)) * double(far_total) / double(nq);
+                if (stride_a > 0 && est > double(tcap) / 8.0) {
+                    ctx->sym_ok = 0;
+                    sym_now = false;
+                    continue;
+                }
             }
             a.mode = 2;
             a.sym.sched = 0;
@@ -516,6 +536,7 @@ extern "C" int gt_knn_stats(const gt_ctx* ctx, int64_t* out12) {
     out12[3] = k ? k->n_fallback_exhaustive : 0;
     for (int i = 0; i < 8; ++i) out12[4 + i] = (k && k->sym_used) ? int64_t(k->sym_stat_host[i]) : 0;
     if (k && k->sym_used) out12[6] = k->sym_nseg;   // work items per query block of launch B
+    out12[10] = k ? k->sym_far : 0;                 // kept rows of launch A outside the neighbourhood cells (all points)
     return GT_OK;
 }
 

@@ -31,6 +31,7 @@ struct KnnWork {
     bool sym_used = false;
     int64_t sym_overflow = 0;
     int sym_nseg = 1;
+    int64_t sym_far = 0;
     unsigned long long sym_stat_host[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int64_t n_fallback_exhaustive = 0;
     int64_t n_fallback = 0;
@@ -147,7 +148,8 @@ int gt_launch_rerank_sym(gt_ctx* ctx, const RerankArgs& a, const SymRerank& sr);
 // gt_sym.hip
 int gt_sym_gather(gt_ctx* ctx, const int32_t* perm, int64_t n_pad_s, void* Ys, float* hs);
 int gt_sym_thresholds(gt_ctx* ctx, const int32_t* perm, int64_t n_pad_s, const float* hs, const uint64_t* lists, int lstride,
-                      const uint32_t* counts, int need_m, const ErrModel& err, double rkf, float* thr, float* g, float* gmin);
+                      const uint32_t* counts, int need_m, const ErrModel& err, double rkf, float* thr, float* g, float* gmin,
+                      const DevBuf& work, int cells, unsigned long long* far_total);
 int gt_sym_schedule(gt_ctx* ctx, int64_t n_pad_s, int bq, int bn, int cells, int stride, int max_nb, int tile_stride,
                     DevBuf& work, int32_t* tile_list, int32_t* tile_cnt, unsigned long long* tiles_total = nullptr);
 int gt_launch_fallback(gt_ctx* ctx, const RerankArgs& a, int64_t n_rows, int64_t row_off, double* scratch);

@@ -67,13 +67,31 @@ __global__ __launch_bounds__(256) void sym_thresholds_kernel(const int64_t n, co
                                                              const uint32_t* __restrict__ counts, const int need_m,
                                                              const double* __restrict__ ymax2p, const ErrModel err,
                                                              const double rkf, float* __restrict__ thr,
-                                                             float* __restrict__ g) {
+                                                             float* __restrict__ g, const uint32_t* __restrict__ cell_sorted,
+                                                             const int32_t* __restrict__ nbr, const int M,
+                                                             unsigned long long* __restrict__ far_total) {
     const int sub = threadIdx.x & 15;
     const int64_t p = int64_t(blockIdx.x) * 16 + (threadIdx.x >> 4);
     if (p >= n_pad) return;   // whole 16-lane group
     float t = INFINITY, gv = INFINITY;
     if (p < n) {
         const int64_t q = perm[p];
+        // how many of the kept rows lie outside the M cells around the row's own: when that is most of them the cells say
+        // nothing about this point set (launch A found its neighbours in the strided sample) and the thresholds are loose
+        if (far_total) {
+            const uint32_t kept0 = counts[p];
+            const uint32_t cme = cell_sorted[p];
+            uint32_t far = 0;
+            for (uint32_t c = uint32_t(sub); c < kept0; c += 16u) {
+                const uint32_t cc = cell_sorted[cand_index(lists[size_t(p) * lstride + c])];
+                bool near = false;
+                for (int m = 0; m < M; ++m) near = near || (uint32_t(nbr[size_t(cme) * M + m]) == cc);
+                far += near ? 0u : 1u;
+            }
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) far += __shfl_xor(far, o, 16);
+            if (sub == 0 && far) atomicAdd(far_total, (unsigned long long)far);
+        }
         const T* xq = X + q * int64_t(d);
         const double qs = xn[q];
         const uint32_t kept = counts[p];
@@ -318,16 +336,21 @@ int gt_sym_gather(gt_ctx* ctx, const int32_t* perm, int64_t n_pad_s, void* Ys, f
 }
 
 int gt_sym_thresholds(gt_ctx* ctx, const int32_t* perm, int64_t n_pad_s, const float* hs, const uint64_t* lists, int lstride,
-                      const uint32_t* counts, int need_m, const ErrModel& err, double rkf, float* thr, float* g, float* gmin) {
+                      const uint32_t* counts, int need_m, const ErrModel& err, double rkf, float* thr, float* g, float* gmin,
+                      const DevBuf& work, int cells, unsigned long long* far_total) {
     const dim3 grid((unsigned)ceil_div64(n_pad_s, 16));
+    // landmark adjacency the schedule of launch A was built from (gt_sym_schedule: nbr [L][M] at the head of `work`)
+    const int M = std::min(std::min(cells, 32), ctx->order_L);
+    const int32_t* nbr = work.as<int32_t>();
+    const uint32_t* cell_sorted = ctx->order_cell.as<uint32_t>() + ctx->n;
     if (ctx->dtype == GT_F32)
         hipLaunchKernelGGL(sym_thresholds_kernel<float>, grid, dim3(256), 0, ctx->stream, ctx->n, n_pad_s, perm,
                            (const float*)ctx->X, ctx->d, ctx->xn.as<double>(), hs, lists, lstride, counts, need_m,
-                           ctx->ymax.as<double>(), err, rkf, thr, g);
+                           ctx->ymax.as<double>(), err, rkf, thr, g, cell_sorted, nbr, M, far_total);
     else
         hipLaunchKernelGGL(sym_thresholds_kernel<double>, grid, dim3(256), 0, ctx->stream, ctx->n, n_pad_s, perm,
                            (const double*)ctx->X, ctx->d, ctx->xn.as<double>(), hs, lists, lstride, counts, need_m,
-                           ctx->ymax.as<double>(), err, rkf, thr, g);
+                           ctx->ymax.as<double>(), err, rkf, thr, g, cell_sorted, nbr, M, far_total);
     GT_HIP(ctx, hipGetLastError());
     hipLaunchKernelGGL(sym_gmin_kernel, dim3((unsigned)ceil_div64(n_pad_s, 256)), dim3(256), 0, ctx->stream, n_pad_s, g, gmin);
     GT_HIP(ctx, hipGetLastError());

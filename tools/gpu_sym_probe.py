@@ -17,7 +17,16 @@ from tools.gpu_sym_check import STAGES, make_mix  # noqa: E402
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
 d = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 kind = sys.argv[3] if len(sys.argv) > 3 else "mix"
-X = make_mix(n, d, 1) if kind == "mix" else np.random.default_rng(1).standard_normal((n, d)).astype(np.float32)
+if kind == "mix":
+    X = make_mix(n, d, 1)
+elif kind == "manifold":
+    _r = np.random.default_rng(1)
+    X = (_r.standard_normal((n, 5)) @ _r.standard_normal((5, d)) + 0.01 * _r.standard_normal((n, d))).astype(np.float32)
+elif kind == "sorted":      # mix with the rows stored cluster by cluster
+    X = make_mix(n, d, 1)
+    X = X[np.argsort(np.random.default_rng(1).integers(max(n // 2000, 1), size=n), kind="stable")]
+else:
+    X = np.random.default_rng(1).standard_normal((n, d)).astype(np.float32)
 for variant in os.environ.get("GT_VARIANTS", "").split(";") or [""]:
     ctx = _hip.Context(0)
     opts = [o for o in (os.environ.get("GT_OPTS", "") + "," + variant).split(",") if o]
