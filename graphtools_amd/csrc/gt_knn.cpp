@@ -260,6 +260,7 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
                 StageSpan span(ctx, "sym_seed");
                 GT_TRY(gt_launch_select(ctx, a));
             }
+            if (ctx->dbg_select & 1024) return GT_OK;   // experiment: stop behind the seeding launch (tables are NOT valid)
             {
                 StageSpan span(ctx, "sym_prepare");
                 GT_TRY(gt_sym_thresholds(ctx, perm, n_pad_s, k->hnegs.as<float>(), k->lists.as<uint64_t>(), int(lcap),

@@ -28,4 +28,14 @@ for _ in range(3):
         v = ctx.stage_ms(s)
         best[s] = min(best.get(s, 1e9), v)
 print(json.dumps({"lib": os.path.basename(_hip.LIB_PATH), "opts": os.environ.get("GT_OPTS", ""), **{k: round(v, 3) for k, v in best.items()}}))
+if int(os.environ.get("GT_DBG", "0")) & 64:
+    import ctypes
+    nw = ((n + 255) // 256) * 4
+    buf = np.zeros((nw, 8), dtype=np.uint64)
+    ctx.lib.gt_dbg_fetch_prof.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]
+    rc = ctx.lib.gt_dbg_fetch_prof(ctx.h, nw, buf.ctypes.data)
+    m = buf.mean(axis=0)
+    print(json.dumps({"rc": rc, "cycles_per_wave": {"admission": float(m[0]), "compaction": float(m[1]), "barrier": float(m[2]),
+                                                    "total": float(m[7])}, "admission_entries_per_wave": float(m[4]),
+                      "compactions_per_wave": float(m[3])}))
 ctx.close()
