@@ -88,6 +88,12 @@ _SIGNATURES = {
     "gt_landmark_scale": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int32, _c.c_int32]),
     "gt_landmark_fetch_transitions": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int32]),
     "gt_nearest_landmark": (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_int64, _c.c_void_p, _c.c_int32, _c.c_int32, _c.c_void_p]),
+    "gt_pca_begin": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_void_p, _c.c_void_p]),
+    "gt_pca_matmul": (_c.c_int, [_c.c_void_p, _c.c_int32, _c.c_void_p, _c.c_int32, _c.c_int32, _c.c_void_p, _c.c_int32]),
+    "gt_pca_tmatmul": (_c.c_int, [_c.c_void_p, _c.c_int32, _c.c_int32, _c.c_void_p, _c.c_void_p]),
+    "gt_pca_gram": (_c.c_int, [_c.c_void_p, _c.c_int32, _c.c_int32, _c.c_void_p]),
+    "gt_pca_fetch": (_c.c_int, [_c.c_void_p, _c.c_int32, _c.c_int32, _c.c_void_p, _c.c_int32]),
+    "gt_pca_end": (_c.c_int, [_c.c_void_p]),
     "gt_dev_alloc": (_c.c_int, [_c.c_void_p, _c.c_size_t, _c.POINTER(_c.c_void_p)]),
     "gt_dev_free": (_c.c_int, [_c.c_void_p, _c.c_void_p]),
     "gt_dev_upload": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_size_t]),
@@ -374,6 +380,42 @@ class Context:
         out = np.empty(r1 - r0, dtype=np.float64)
         self._check(self.lib.gt_graph_fetch_vec(self.h, which, _ptr(out), 0), "gt_graph_fetch_vec")
         return out
+
+    # ---- tall-matrix products of the PCA pre-reduction (gt_pca.hip; algorithm in graphtools_amd/_pca.py) ----------
+    def pca_begin(self, X):
+        """bind the float32 matrix; returns (column means, centred sums of squares) as float64"""
+        X = np.ascontiguousarray(X, dtype=np.float32)
+        n, d = X.shape
+        mean = np.empty(d, dtype=np.float64)
+        ssq = np.empty(d, dtype=np.float64)
+        self._check(self.lib.gt_pca_begin(self.h, _ptr(X), n, d, 0, _ptr(mean), _ptr(ssq)), "gt_pca_begin")
+        self._pca_shape = (n, d)
+        return mean, ssq
+
+    def pca_matmul(self, src, W, sub, dst):
+        W = np.ascontiguousarray(W, dtype=np.float64)
+        sub = None if sub is None else np.ascontiguousarray(sub, dtype=np.float64)
+        self._check(self.lib.gt_pca_matmul(self.h, int(src), _ptr(W), W.shape[0], W.shape[1], _ptr(sub), int(dst)),
+                    "gt_pca_matmul")
+
+    def pca_tmatmul(self, ybuf, k):
+        out = np.empty((self._pca_shape[1], k), dtype=np.float64)
+        colsum = np.empty(k, dtype=np.float64)
+        self._check(self.lib.gt_pca_tmatmul(self.h, int(ybuf), int(k), _ptr(out), _ptr(colsum)), "gt_pca_tmatmul")
+        return out, colsum
+
+    def pca_gram(self, ybuf, k):
+        out = np.empty((k, k), dtype=np.float64)
+        self._check(self.lib.gt_pca_gram(self.h, int(ybuf), int(k), _ptr(out)), "gt_pca_gram")
+        return out
+
+    def pca_fetch(self, ybuf, k):
+        out = np.empty((self._pca_shape[0], k), dtype=np.float32)
+        self._check(self.lib.gt_pca_fetch(self.h, int(ybuf), int(k), _ptr(out), 0), "gt_pca_fetch")
+        return out
+
+    def pca_end(self):
+        self._check(self.lib.gt_pca_end(self.h), "gt_pca_end")
 
     def knn_stats(self):
         st = np.zeros(12, dtype=np.int64)

@@ -6,6 +6,7 @@ messages, the lazy cached properties ``K``/``kernel``, ``P``/``diff_op``, ``kern
 (:mod:`graphtools_amd._hip`); there is no CPU implementation behind these classes.
 """
 import numbers
+import os
 import warnings
 
 import numpy as np
@@ -162,11 +163,18 @@ class BaseGraph(object):
         return self.K.shape[0]
 
 
+# PCA pre-reduction backend: "auto" (device for large dense float32 inputs the device solver applies to), "device"
+# (whenever it applies), "sklearn" (the reference's call, always).  GRAPHTOOLS_AMD_PCA sets the default.
+PCA_BACKEND = os.environ.get("GRAPHTOOLS_AMD_PCA", "auto")
+_PCA_DEVICE_MIN_ELEMENTS = 1 << 24
+
+
 class Data(object):
     """Input coercion and optional PCA pre-reduction (reference: graphtools/base.py:72-424).
 
-    The reduction is pre-processing in front of the hot path and stays on host scikit-learn,
-    exactly as in the reference; ``data_nu`` is what the device sees.
+    Dense float32 inputs are reduced by ``graphtools_amd._pca.DevicePCA`` - sklearn's randomized solver with its tall
+    matrix products on the device (statistical parity, see that module); sparse, float64, wide or small inputs go
+    through scikit-learn exactly as in the reference.  ``data_nu`` is what the graph kernels see.
     """
 
     def __init__(self, data, n_pca=None, rank_threshold=None, random_state=None):
@@ -213,6 +221,13 @@ class Data(object):
         if sparse.issparse(self.data):
             self.data_pca = TruncatedSVD(self.n_pca, random_state=self.random_state)
         else:
+            from ._pca import DevicePCA, device_pca_applies
+
+            backend = PCA_BACKEND
+            if backend != "sklearn" and device_pca_applies(self.data, self.n_pca) and (
+                    backend == "device" or self.data.size >= _PCA_DEVICE_MIN_ELEMENTS):
+                self.data_pca = DevicePCA(self.n_pca, random_state=self.random_state, device=getattr(self, "device", 0) or 0)
+                return self.data_pca.fit_transform(self.data)
             self.data_pca = PCA(self.n_pca, svd_solver="randomized", random_state=self.random_state)
         self.data_pca.fit(self.data)
         return self.data_pca.transform(self.data)

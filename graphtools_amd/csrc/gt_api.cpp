@@ -11,6 +11,7 @@ static thread_local std::string g_create_error;
 void gt_free_knn_work(gt_ctx* ctx);     // gt_knn.hip
 void gt_free_graph_state(gt_ctx* ctx);  // gt_sparse.hip
 void gt_free_landmark_state(gt_ctx* ctx);  // gt_landmark.hip
+void gt_free_pca_state(gt_ctx* ctx);       // gt_pca.hip
 
 extern "C" {
 
@@ -73,6 +74,7 @@ void gt_ctx_destroy(gt_ctx* ctx) {
     gt_free_knn_work(ctx);
     gt_free_graph_state(ctx);
     gt_free_landmark_state(ctx);
+    gt_free_pca_state(ctx);
     ctx->reset_stages();
     for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
     ctx->X_own.release();

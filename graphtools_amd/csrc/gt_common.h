@@ -164,6 +164,7 @@ struct gt_ctx {
     KnnWork* knn = nullptr;
     GraphState* graph = nullptr;
     void* landmark = nullptr;   // LandmarkState (gt_landmark.hip)
+    void* pca = nullptr;        // PcaState (gt_pca.hip)
 
     void set_error(const std::string& m) { err = m; }
 

@@ -243,6 +243,26 @@ int gt_landmark_build(gt_ctx* ctx, const int32_t* clusters, int32_t n_landmark, 
 int gt_landmark_scale(gt_ctx* ctx, double* M_inout, const double* R, int32_t n_landmark, int32_t on_device);
 /* transitions of the last gt_landmark_build: data float64 [nnz], indices int32 [nnz], indptr int64 [rows+1] */
 int gt_landmark_fetch_transitions(gt_ctx* ctx, double* data, int32_t* indices, int64_t* indptr, int32_t on_device);
+/* ---- PCA pre-reduction (Data._reduce_data) ------------------------------------------------ */
+/* Replaces the dense products of sklearn PCA(n_pca, svd_solver="randomized").fit(data) / .transform(data)
+ * (base.py:227-294 -> sklearn.utils.extmath.randomized_svd: M @ Q, M.T @ Q on the centred n x d matrix).  The matrix
+ * stays on the device; the thin factors (at most 128 columns) travel to the host, where the caller runs the reference's
+ * own small LAPACK steps (graphtools_amd/_pca.py).  float32 data only (float64 data keeps sklearn's float64 path).
+ *   gt_pca_begin    bind X (n x d float32; host memory is uploaded), column means and centred sums of squares (float64)
+ *   gt_pca_matmul   thin[dst] = S W - 1 sub^T;  src 0: S = X (W is d x k), src 1/2: S = thin[src] (W is wrows x k);
+ *                   W float64 row-major on the host, sub (k values, may be NULL) the centring term mean^T W
+ *   gt_pca_tmatmul  out (d x k float64, host) = X^T thin[ybuf][:, :k];  colsum (k, may be NULL) = column sums of thin
+ *   gt_pca_gram     out (k x k float64, host) = thin^T thin, accumulated in float64
+ *   gt_pca_fetch    thin[ybuf][:, :k] as float32 [n][k] (host or device memory)
+ *   gt_pca_end      release the workspace */
+int gt_pca_begin(gt_ctx* ctx, const float* X, int64_t n, int32_t d, int32_t x_on_device, double* mean_out,
+                 double* sumsq_centered_out);
+int gt_pca_matmul(gt_ctx* ctx, int32_t src, const double* W, int32_t wrows, int32_t k, const double* sub, int32_t dst);
+int gt_pca_tmatmul(gt_ctx* ctx, int32_t ybuf, int32_t k, double* out, double* colsum);
+int gt_pca_gram(gt_ctx* ctx, int32_t ybuf, int32_t k, double* out);
+int gt_pca_fetch(gt_ctx* ctx, int32_t ybuf, int32_t k, float* out, int32_t on_device);
+int gt_pca_end(gt_ctx* ctx);
+
 /* Random-landmark assignment (graphs.py:1200-1213): clusters[i] = argmin_j |x_i - x_{landmarks[j]}| over the
  * bound points, rows [row0,row1); ties -> lowest j.  mode 0: scipy cdist arithmetic (float64 difference
  * form), mode 1: sklearn euclidean_distances arithmetic (float64 GEMM form rounded to the input dtype).
