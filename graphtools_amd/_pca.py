@@ -71,15 +71,30 @@ class DevicePCA(object):
         rs = check_random_state(self.random_state)
         # sklearn draws float64 normals and casts them to the data's float32
         Q = rs.normal(size=(d, kp)).astype(np.float32).astype(np.float64)
+        import time
+
+        t0 = time.perf_counter()
+        phase = {}
+
+        def mark(name):
+            nonlocal t0
+            t1 = time.perf_counter()
+            phase[name] = round(phase.get(name, 0.0) + t1 - t0, 4)
+            t0 = t1
+
         ctx = _hip.Context(self.device)
         try:
+            mark("context")
             mean, ssq = ctx.pca_begin(X)
+            mark("upload+moments")
 
             def half_steps(Q):
                 ctx.pca_matmul(0, Q, mean @ Q, 1)                 # Y = (X - 1 mean^T) Q
                 Z, colsum = ctx.pca_tmatmul(1, Q.shape[1])        # X^T Y, 1^T Y
+                mark("products")
                 Z -= np.outer(mean, colsum)                       # (X - 1 mean^T)^T Y
                 Qn, _ = linalg.qr(Z, mode="economic", check_finite=False)
+                mark("host qr")
                 return Qn
 
             for _ in range(int(n_iter)):
@@ -87,6 +102,7 @@ class DevicePCA(object):
             Q = half_steps(Q)                                     # row space of sklearn's projected matrix Q^T A
             ctx.pca_matmul(0, Q, mean @ Q, 1)                     # Y = A Q
             C = ctx.pca_gram(1, kp)                               # Q^T A^T A Q
+            mark("products")
             w, V = np.linalg.eigh(0.5 * (C + C.T))
             order = np.argsort(w)[::-1][:k]
             w = np.maximum(w[order], 0.0)
@@ -97,10 +113,14 @@ class DevicePCA(object):
             signs[signs == 0] = 1.0
             comps *= signs[:, None]
             ctx.pca_matmul(1, V * signs[None, :], None, 2)        # transformed = Y V  (= A components^T)
+            mark("host eigh")
             T = ctx.pca_fetch(2, k)
+            mark("fetch")
             ctx.pca_end()
         finally:
             ctx.close()
+        mark("release")
+        self.phase_s_ = phase
         S = np.sqrt(w)
         self.n_samples_, self.n_features_in_ = n, d
         self.n_components_ = k

@@ -25,21 +25,23 @@ for s in range(0, n, 100000):
     e = min(n, s + 100000)
     X[s:e] = (rng.standard_normal((e - s, r), dtype=np.float32) * sv) @ V.T + 0.05 * rng.standard_normal((e - s, d), dtype=np.float32)
 out = {"n": n, "d": d, "k": k}
-for rep in range(2):
+for rep in range(0 if os.environ.get('GT_DBG') else 2):
     t = time.perf_counter()
     dev = DevicePCA(k, random_state=0)
     T = dev.fit_transform(X)
     out["device_fit_transform_s"] = round(time.perf_counter() - t, 3)
+    out["phases_s"] = getattr(dev, "phase_s_", None)
 # stage times of the products alone (one context, X resident)
 ctx = _hip.Context(0)
+if os.environ.get('GT_DBG'):
+    ctx.set_option('dbg_select', os.environ['GT_DBG'])
 t = time.perf_counter()
 mean, ssq = ctx.pca_begin(X)
 out["upload_and_moments_s"] = round(time.perf_counter() - t, 3)
 W = rng.standard_normal((d, k + 10))
-for _ in range(2):
-    ctx.pca_matmul(0, W, mean @ W, 1)
-    Z, cs = ctx.pca_tmatmul(1, k + 10)
-    C = ctx.pca_gram(1, k + 10)
+ctx.pca_matmul(0, W, mean @ W, 1)
+Z, cs = ctx.pca_tmatmul(1, k + 10)
+C = ctx.pca_gram(1, k + 10)
 out["matmul_ms"] = round(ctx.stage_ms("pca_matmul"), 3)
 out["tmatmul_ms"] = round(ctx.stage_ms("pca_tmatmul"), 3)
 out["gram_ms"] = round(ctx.stage_ms("pca_gram"), 3)
