@@ -94,6 +94,9 @@ _SIGNATURES = {
     "gt_pca_gram": (_c.c_int, [_c.c_void_p, _c.c_int32, _c.c_int32, _c.c_void_p]),
     "gt_pca_fetch": (_c.c_int, [_c.c_void_p, _c.c_int32, _c.c_int32, _c.c_void_p, _c.c_int32]),
     "gt_pca_end": (_c.c_int, [_c.c_void_p]),
+    "gt_thin_scale_rows": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int32, _c.c_void_p, _c.c_double]),
+    "gt_thin_gram": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int32, _c.c_void_p]),
+    "gt_thin_rmul": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int32, _c.c_void_p, _c.c_int32, _c.c_void_p]),
     "gt_dev_alloc": (_c.c_int, [_c.c_void_p, _c.c_size_t, _c.POINTER(_c.c_void_p)]),
     "gt_dev_free": (_c.c_int, [_c.c_void_p, _c.c_void_p]),
     "gt_dev_upload": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_size_t]),
@@ -503,6 +506,30 @@ class Context:
         self._check(self.lib.gt_landmark_fetch_transitions(self.h, _ptr(data), _ptr(indices), _ptr(indptr), 0),
                     "gt_landmark_fetch_transitions")
         return data, indices, indptr
+
+    # ---- tall thin float64 matrices on the device (gt_thin.hip; driver: graphtools_amd/_spectral.py) -------------
+    def thin_scale_rows(self, A, n, k, v, power):
+        self._check(self.lib.gt_thin_scale_rows(self.h, ctypes.c_void_p(int(A)), int(n), int(k), ctypes.c_void_p(int(v)),
+                                                float(power)), "gt_thin_scale_rows")
+
+    def thin_gram(self, A, n, k):
+        out = np.empty((k, k), dtype=np.float64)
+        self._check(self.lib.gt_thin_gram(self.h, ctypes.c_void_p(int(A)), int(n), int(k), _ptr(out)), "gt_thin_gram")
+        return out
+
+    def thin_rmul(self, A, n, k, R, B):
+        R = np.ascontiguousarray(R, dtype=np.float64)
+        assert R.shape[0] == k
+        self._check(self.lib.gt_thin_rmul(self.h, ctypes.c_void_p(int(A)), int(n), int(k), _ptr(R), R.shape[1],
+                                          ctypes.c_void_p(int(B))), "gt_thin_rmul")
+
+    def graph_spmm_device(self, which, X_dev, ncols, out_dev):
+        """(K or P) @ X with X and the result in device memory (row-major float64 [n, ncols])"""
+        self._check(self.lib.gt_graph_spmm(self.h, which, ctypes.c_void_p(int(X_dev)), int(ncols),
+                                           ctypes.c_void_p(int(out_dev)), 1), "gt_graph_spmm")
+
+    def graph_fetch_vec_device(self, which, out_dev):
+        self._check(self.lib.gt_graph_fetch_vec(self.h, which, ctypes.c_void_p(int(out_dev)), 1), "gt_graph_fetch_vec")
 
     # ---- raw device memory --------------------------------------------------------------------
     def dev_alloc(self, nbytes):

@@ -167,6 +167,9 @@ class BaseGraph(object):
 # (whenever it applies), "sklearn" (the reference's call, always).  GRAPHTOOLS_AMD_PCA sets the default.
 PCA_BACKEND = os.environ.get("GRAPHTOOLS_AMD_PCA", "auto")
 _PCA_DEVICE_MIN_ELEMENTS = 1 << 24
+# spectral landmark front end (LandmarkGraph, random_landmarking=False): "auto" = device from 20 000 samples on
+SPECTRAL_BACKEND = os.environ.get("GRAPHTOOLS_AMD_SPECTRAL", "auto")
+_SPECTRAL_DEVICE_MIN_ROWS = 20000
 
 
 class Data(object):

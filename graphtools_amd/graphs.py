@@ -497,7 +497,18 @@ class LandmarkGraph(DataGraph):
                 return cand.min(axis=1).astype(np.int64)
             self._bind_points()
             return self.hip.nearest_landmark(landmark_indices, 0).astype(np.int64)
-        # spectral front end on host scikit-learn, as in the reference (graphs.py:1215-1230)
+        # spectral front end (graphs.py:1215-1230).  Sparse kNN kernels that live on the device: randomized SVD of
+        # diff_aff, the embedding product and the labelling pass on the device (graphtools_amd/_spectral.py; statistical
+        # parity - the k-means in the middle is scikit-learn's own and RNG-dependent); otherwise host scikit-learn as in
+        # the reference.
+        from . import base as _base
+        if (_base.SPECTRAL_BACKEND != "sklearn" and isinstance(self, kNNGraph) and self.n_svd + 10 <= 128
+                and (_base.SPECTRAL_BACKEND == "device" or n_samples >= _base._SPECTRAL_DEVICE_MIN_ROWS)):
+            from ._spectral import spectral_clusters
+
+            self.K
+            self._ensure_device_graph()
+            return spectral_clusters(self, self.hip)
         from sklearn.cluster import MiniBatchKMeans
         from sklearn.utils.extmath import randomized_svd
 

@@ -243,6 +243,16 @@ int gt_landmark_build(gt_ctx* ctx, const int32_t* clusters, int32_t n_landmark, 
 int gt_landmark_scale(gt_ctx* ctx, double* M_inout, const double* R, int32_t n_landmark, int32_t on_device);
 /* transitions of the last gt_landmark_build: data float64 [nnz], indices int32 [nnz], indptr int64 [rows+1] */
 int gt_landmark_fetch_transitions(gt_ctx* ctx, double* data, int32_t* indices, int64_t* indptr, int32_t on_device);
+/* ---- tall thin float64 matrices on the device (spectral landmark front end) ------------------ */
+/* The dense steps of sklearn.utils.extmath.randomized_svd(diff_aff, n_svd) (graphs.py:1215-1219) next to gt_graph_spmm,
+ * on row-major n x k device matrices of at most 128 columns (allocate with gt_dev_alloc):
+ *   gt_thin_scale_rows  A[r][:] *= v[r]^power            (v: device vector, e.g. the degrees with power -1/2)
+ *   gt_thin_gram        out (k x k, host) = A^T A         (Cholesky-QR of a power-iteration block)
+ *   gt_thin_rmul        B = A R, R (k x m) on the host, B a different device matrix */
+int gt_thin_scale_rows(gt_ctx* ctx, double* A_dev, int64_t n, int32_t k, const double* v_dev, double power);
+int gt_thin_gram(gt_ctx* ctx, const double* A_dev, int64_t n, int32_t k, double* out_host);
+int gt_thin_rmul(gt_ctx* ctx, const double* A_dev, int64_t n, int32_t k, const double* R_host, int32_t m, double* B_dev);
+
 /* ---- PCA pre-reduction (Data._reduce_data) ------------------------------------------------ */
 /* Replaces the dense products of sklearn PCA(n_pca, svd_solver="randomized").fit(data) / .transform(data)
  * (base.py:227-294 -> sklearn.utils.extmath.randomized_svd: M @ Q, M.T @ Q on the centred n x d matrix).  The matrix
