@@ -403,7 +403,7 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
     constexpr int HF4 = C::NF4 / 2;                      // 16-byte units per half tile
     constexpr int HF4_PER_THREAD = (HF4 + 255) / 256;
     float4 stage[HF4_PER_THREAD];
-    float stage_h = 0.f, stage_g = 0.f, stage_gm = 0.f;
+    float stage_h = 0.f, stage_gm = 0.f;
 #define GT_STAGE_LOAD(T_, HALF_)                                                                          \
     {                                                                                                     \
         const float4* src_ = reinterpret_cast<const float4*>(Yp + size_t((GT_EXP & 64) ? ((T_) & 15) : (T_)) * BN * C::RW) + (HALF_) * HF4;   \
@@ -413,7 +413,6 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
         }                                                                                                 \
         if ((HALF_) == 0) stage_h = (tid < BN) ? hneg[size_t(T_) * BN + tid] : 0.f;                       \
         if (MODE == 2 && (HALF_) == 0) {                                                                  \
-            stage_g = (tid < BN) ? sy.g[size_t(T_) * BN + tid] : 0.f;                                     \
             stage_gm = (tid < BN / 32) ? sy.gmin[size_t(T_) * (BN / 32) + tid] : 0.f;                     \
         }                                                                                                 \
     }
@@ -430,7 +429,6 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
             }                                                                                             \
         }                                                                                                 \
         if ((HALF_) == 0 && tid < BN) hn[(BUF_) * BN + tid] = stage_h;                                    \
-        if (MODE == 2 && (HALF_) == 0 && tid < BN) gb[(BUF_) * BN + tid] = stage_g;                       \
         if (MODE == 2 && (HALF_) == 0 && tid < BN / 32) gm[(BUF_) * 8 + tid] = stage_gm;                  \
     }
 
@@ -457,9 +455,8 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
         if (wu < BN / 64)                                                                                  \
             __builtin_amdgcn_global_load_lds((glb_void*)(hneg + size_t(T_) * BN + uint32_t(wu * 64) + lv_), \
                                              (lds_void*)(hn + (BUF_) * BN + wu * 64), 4, 0, 0);            \
-        if (MODE == 2 && wu >= BN / 64 && wu < 2 * (BN / 64))                                              \
-            __builtin_amdgcn_global_load_lds((glb_void*)(sy.g + size_t(T_) * BN + uint32_t((wu - BN / 64) * 64) + lv_), \
-                                             (lds_void*)(gb + (BUF_) * BN + (wu - BN / 64) * 64), 4, 0, 0); \
+        /* MODE 2: only the sub-tile minima of the row thresholds are staged (the cold path reads the rows' own values  \
+           from global memory), by a wave that carries no seed piece */                                    \
         if (MODE == 2 && wu == 3 && lv_ < BN / 32)                                                         \
             __builtin_amdgcn_global_load_lds((glb_void*)(sy.gmin + size_t(T_) * (BN / 32) + lv_),          \
                                              (lds_void*)(gm + (BUF_) * 8), 4, 0, 0);                       \
@@ -523,7 +520,7 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
         const uint32_t tbase = uint32_t(t) * BN;
         // MODE 2: does this tile's block also take the results as ITS queries?  (wave-uniform; +inf switches the test off)
         const bool tr_on = MODE == 2 && it >= C::TPB && it < n_tr_end;
-        const float* gbuf = gb + buf * BN;
+        const float* gglob = (MODE == 2) ? sy.g + size_t(tbase) : nullptr;   // row thresholds of this tile (cold path only)
         float gms[BN / 32];
 #pragma unroll
         for (int sb_ = 0; sb_ < BN / 32; ++sb_)
@@ -587,7 +584,7 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
         _Pragma("unroll") for (int e_ = 0; e_ < 16; ++e_) fmask_ |= ((PA_)[e_] > tq_) ? (1u << e_) : 0u;   \
         if (tr_on) {                                                                                       \
             _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) {                                             \
-                const float4 gv_ = *reinterpret_cast<const float4*>(gbuf + (PSB_) * 32 + 8 * g_ + 4 * h);  \
+                const float4 gv_ = *reinterpret_cast<const float4*>(gglob + (PSB_) * 32 + 8 * g_ + 4 * h); \
                 tmask_ |= (((PA_)[4 * g_ + 0] + hq_) > gv_.x) ? (1u << (4 * g_ + 0)) : 0u;                 \
                 tmask_ |= (((PA_)[4 * g_ + 1] + hq_) > gv_.y) ? (1u << (4 * g_ + 1)) : 0u;                 \
                 tmask_ |= (((PA_)[4 * g_ + 2] + hq_) > gv_.z) ? (1u << (4 * g_ + 2)) : 0u;                 \

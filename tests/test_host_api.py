@@ -125,3 +125,23 @@ def test_landmark_graphs_use_the_landmark_out_of_sample_methods():
         assert cls.extend_to_data is graphs.LandmarkGraph.extend_to_data, cls
         assert cls.interpolate is graphs.LandmarkGraph.interpolate, cls
     assert graphs.kNNGraph.extend_to_data is not graphs.LandmarkGraph.extend_to_data
+
+
+def test_pca_backend_selection_is_host_logic():
+    """Data._reduce_data: the device solver applies to dense float32 inputs with n >= d and at most 118 components, from
+    2^24 elements on in auto mode; everything else is scikit-learn's randomized PCA as in the reference"""
+    import numpy as np
+
+    from graphtools_amd import _pca, base
+
+    X32 = np.zeros((300, 40), dtype=np.float32)
+    assert _pca.device_pca_applies(X32, 10)
+    assert not _pca.device_pca_applies(X32.astype(np.float64), 10)      # float64 keeps sklearn's float64 solver
+    assert not _pca.device_pca_applies(X32.T.copy(), 10)                # wide data (n < d): sklearn transposes
+    assert not _pca.device_pca_applies(np.zeros((5000, 400), np.float32), 119)   # 119 + 10 oversamples > 128 columns
+    assert not _pca.device_pca_applies(X32, 40)                         # no reduction at all
+    assert base.PCA_BACKEND in ("auto", "device", "sklearn")
+    # small inputs stay on the host in auto mode: no GPU is touched here
+    rng = np.random.default_rng(0)
+    D = base.Data(rng.standard_normal((200, 30)).astype(np.float32), n_pca=5, random_state=0)
+    assert type(D.data_pca).__name__ == "PCA" and D.data_nu.shape == (200, 5)
