@@ -192,6 +192,7 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
                                   &ordered));
         }
         if (ordered) sa.qrows = ra.qrows = k->qorder.as<int32_t>();
+        k->ordered = ordered != 0 && !external && q0 == 0 && nq == ctx->n;
         have_thr0 = ordered != 0 && need_m <= 32 && ctx->thr0_mode != 0;
     }
     // Symmetric pass (gt_sym.hip): self queries over the whole point set, euclidean, single-chain arithmetic, grouped

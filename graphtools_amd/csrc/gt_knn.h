@@ -23,6 +23,7 @@ struct KnnWork {
     DevBuf unproven, qlomax_dev;
     DevBuf qthr0;              //   and the starting thresholds that pass proves (single-chain arithmetic only)
     DevBuf qorder;             // self queries: the rows of the launch grouped by nearest landmark (gt_order.hip)
+    bool ordered = false;      //   valid for the current tables (all rows of the bound points, position -> row)
     DevBuf fb_rows, fb_count, fb_scratch, gflags, prof;
     DevBuf fb_qrows, fb_thr, fb_lists, fb_counts, fb_max;   // collected fallback
     // symmetric candidate pass (gt_sym.hip): cell-sorted compact copy + seeds, per-row thresholds in the transposed

@@ -21,7 +21,7 @@ void gt_free_graph_state(gt_ctx* ctx) {
     GraphState* g = ctx->graph;
     for (DevBuf* b : {&g->bw, &g->bw_user, &g->rowsrc, &g->hugerows, &g->tablen, &g->spmm_in, &g->spmm_out, &g->lenN, &g->lenT, &g->cursor, &g->off, &g->outlen, &g->indptr,
                       &g->degree, &g->over_rows, &g->over_count, &g->rthr, &g->rlists, &g->rcounts, &g->rK, &g->rmax,
-                      &g->ownercnt, &g->ownerpos, &g->scan_tmp, &g->selfbuf, &g->splits_dev, &g->Ukey, &g->Uval, &g->Vkey, &g->Vval,
+                      &g->ownercnt, &g->ownerpos, &g->cnt_sorted, &g->pos_sorted, &g->scan_tmp, &g->selfbuf, &g->splits_dev, &g->Ukey, &g->Uval, &g->Vkey, &g->Vval,
                       &g->bigrows, &g->bigcount, &g->bigscratch_k, &g->bigscratch_v, &g->bigsoff, &g->aniso_tmp, &g->scan_own,
                       &g->indices, &g->Kdata, &g->Pdata, &g->flags})
         b->release();
@@ -252,6 +252,22 @@ __global__ __launch_bounds__(256) void emit_triplets_kernel(
             }
         }
     }
+}
+
+// Single rank, cell-sorted row order available (gt_order.hip): the send buffer is laid out in THAT order - row perm[p]'s
+// triplets follow row perm[p-1]'s - so that the passes over the received triplets touch the union rows of one
+// neighbourhood while they are still in the L2 (a row's targets are its neighbours, i.e. rows of the same cells).
+__global__ __launch_bounds__(256) void gather_counts_kernel(const int32_t* __restrict__ cnt, const int32_t* __restrict__ perm,
+                                                            const int64_t n, int32_t* __restrict__ out) {
+    const int64_t p = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (p < n) out[p] = cnt[perm[p]];
+}
+__global__ __launch_bounds__(256) void scatter_positions_kernel(const int64_t* __restrict__ pos_sorted,
+                                                                const int32_t* __restrict__ perm, const int64_t n,
+                                                                int64_t* __restrict__ pos) {
+    const int64_t p = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (p < n) pos[perm[p]] = pos_sorted[p];
+    if (p == n) pos[n] = pos_sorted[n];
 }
 
 // ---- R1: count received triplets per local row ---------------------------------------------------
@@ -988,8 +1004,22 @@ static int graph_begin_impl(gt_ctx* ctx, const gt_knn_params* params, int32_t wo
     if (count_owners) {
         // exclusive scan of the owner-major counts: slot of every (row, owner) pair inside the bucketed send buffer
         GT_HIP(ctx, g->ownerpos.reserve(size_t(int64_t(world) * g->nloc + 1) * sizeof(int64_t)));
-        GT_TRY(exclusive_scan(ctx, g->ownercnt.as<int32_t>(), nullptr, int64_t(world) * g->nloc, g->ownerpos.as<int64_t>(),
-                              g->scan_tmp));
+        if (world == 1 && !external && k->ordered && k->nq == g->nloc && g->r0 == 0) {
+            // buffer in cell-sorted row order (see gather_counts_kernel)
+            const int32_t* perm = k->qorder.as<int32_t>();
+            GT_HIP(ctx, g->cnt_sorted.reserve(size_t(g->nloc) * sizeof(int32_t)));
+            GT_HIP(ctx, g->pos_sorted.reserve(size_t(g->nloc + 1) * sizeof(int64_t)));
+            hipLaunchKernelGGL(gather_counts_kernel, dim3((unsigned)ceil_div64(g->nloc, 256)), dim3(256), 0, ctx->stream,
+                               g->ownercnt.as<int32_t>(), perm, g->nloc, g->cnt_sorted.as<int32_t>());
+            GT_HIP(ctx, hipGetLastError());
+            GT_TRY(exclusive_scan(ctx, g->cnt_sorted.as<int32_t>(), nullptr, g->nloc, g->pos_sorted.as<int64_t>(), g->scan_tmp));
+            hipLaunchKernelGGL(scatter_positions_kernel, dim3((unsigned)ceil_div64(g->nloc + 1, 256)), dim3(256), 0, ctx->stream,
+                               g->pos_sorted.as<int64_t>(), perm, g->nloc, g->ownerpos.as<int64_t>());
+            GT_HIP(ctx, hipGetLastError());
+        } else {
+            GT_TRY(exclusive_scan(ctx, g->ownercnt.as<int32_t>(), nullptr, int64_t(world) * g->nloc, g->ownerpos.as<int64_t>(),
+                                  g->scan_tmp));
+        }
         std::vector<int64_t> edge(world + 1);
         for (int r = 0; r <= world; ++r)
             GT_HIP(ctx, hipMemcpyAsync(&edge[r], g->ownerpos.as<int64_t>() + int64_t(r) * g->nloc, sizeof(int64_t),
