@@ -41,7 +41,7 @@ def _hipcc():
 
 def _units():
     units = []
-    for name in ("gt_api.cpp", "gt_knn.cpp", "gt_knn_select_dispatch.cpp", "gt_hostcopy.cpp", "gt_devpool.cpp"):
+    for name in ("gt_api.cpp", "gt_knn.cpp", "gt_knn_shard.cpp", "gt_knn_select_dispatch.cpp", "gt_hostcopy.cpp", "gt_devpool.cpp"):
         units.append((name, name.replace(".cpp", ".o"), ["-x", "hip"]))
     for name in ("gt_prep.hip", "gt_rerank.hip", "gt_sparse.hip", "gt_dense.hip", "gt_landmark.hip", "gt_debug.hip", "gt_order.hip", "gt_sym.hip", "gt_pca.hip", "gt_thin.hip"):
         if os.path.exists(os.path.join(CSRC, name)):

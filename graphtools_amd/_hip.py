@@ -63,6 +63,12 @@ _SIGNATURES = {
     "gt_last_knn_precision": (_c.c_int, [_c.c_void_p]),
     "gt_graph_begin": (_c.c_int, [_c.c_void_p, _c.POINTER(KnnParams), _c.c_int32, _c.c_int32, _c.c_void_p, _c.c_void_p]),
     "gt_graph_emit": (_c.c_int, [_c.c_void_p, _c.c_void_p]),
+    "gt_graph_sym_plan": (_c.c_int, [_c.c_void_p, _c.POINTER(KnnParams), _c.c_int32, _c.c_int32, _c.c_void_p,
+                                     _c.POINTER(_c.c_int32), _c.POINTER(_c.c_int64), _c.c_void_p]),
+    "gt_graph_sym_seed": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.POINTER(_c.c_int64)]),
+    "gt_graph_sym_collect": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64, _c.POINTER(_c.c_int32), _c.c_void_p]),
+    "gt_graph_sym_emit": (_c.c_int, [_c.c_void_p, _c.c_void_p]),
+    "gt_graph_sym_finish": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64]),
     "gt_graph_finish": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64, _c.POINTER(_c.c_int64), _c.POINTER(_c.c_uint32)]),
     "gt_graph_anisotropy": (_c.c_int, [_c.c_void_p, _c.c_void_p]),
     "gt_graph_build": (_c.c_int, [_c.c_void_p, _c.POINTER(KnnParams), _c.POINTER(_c.c_int64), _c.POINTER(_c.c_uint32)]),
@@ -302,6 +308,42 @@ class Context:
         self._check(self.lib.gt_graph_begin(self.h, ctypes.byref(params), world, rank, _ptr(splits), _ptr(counts)),
                     "gt_graph_begin")
         return counts
+
+    # ---- row-sharded symmetric candidate pass (gt_knn_shard.cpp); dist.ShardedKnnGraph drives the stages ----
+    def graph_sym_plan(self, params, world, rank, row_splits):
+        """-> (applies, n_pad_sorted, sorted_splits): whether this context can run the sharded symmetric pass for these
+        parameters, and the split of the cell-sorted positions whose thresholds each rank seeds"""
+        splits = np.ascontiguousarray(row_splits, dtype=np.int64)
+        applies = ctypes.c_int32(0)
+        n_pad = ctypes.c_int64(0)
+        sorted_splits = np.zeros(world + 1, dtype=np.int64)
+        self._check(self.lib.gt_graph_sym_plan(self.h, ctypes.byref(params), world, rank, _ptr(splits), ctypes.byref(applies),
+                                               ctypes.byref(n_pad), _ptr(sorted_splits)), "gt_graph_sym_plan")
+        return bool(applies.value), n_pad.value, sorted_splits
+
+    def graph_sym_seed(self, thr_local_ptr):
+        """launch A for the planned share; float32 thresholds of it to thr_local_ptr (device); -> far-kept count"""
+        far = ctypes.c_int64(0)
+        self._check(self.lib.gt_graph_sym_seed(self.h, ctypes.c_void_p(int(thr_local_ptr)) if thr_local_ptr else None,
+                                               ctypes.byref(far)), "gt_graph_sym_seed")
+        return far.value
+
+    def graph_sym_collect(self, thr_all_ptr, far_total, world):
+        """launch B for this rank's pieces against the thresholds of all rows (device, float32 [n_pad_sorted]);
+        -> (applies, send_counts): records per destination rank, or applies False when the predictor refuses"""
+        applies = ctypes.c_int32(0)
+        counts = np.zeros(world, dtype=np.int64)
+        self._check(self.lib.gt_graph_sym_collect(self.h, ctypes.c_void_p(int(thr_all_ptr)), int(far_total),
+                                                  ctypes.byref(applies), _ptr(counts)), "gt_graph_sym_collect")
+        return bool(applies.value), counts
+
+    def graph_sym_emit(self, send_ptr):
+        self._check(self.lib.gt_graph_sym_emit(self.h, ctypes.c_void_p(int(send_ptr)) if send_ptr else None),
+                    "gt_graph_sym_emit")
+
+    def graph_sym_finish(self, recv_ptr, n_recv):
+        self._check(self.lib.gt_graph_sym_finish(self.h, ctypes.c_void_p(int(recv_ptr)) if recv_ptr else None, int(n_recv)),
+                    "gt_graph_sym_finish")
 
     def graph_emit(self, send_ptr):
         self._check(self.lib.gt_graph_emit(self.h, ctypes.c_void_p(int(send_ptr)) if send_ptr else None), "gt_graph_emit")

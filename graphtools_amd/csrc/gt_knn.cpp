@@ -5,6 +5,7 @@
 #include "gt_knn_select.h"
 
 #include <algorithm>
+#include <cstdio>
 
 int gt_select_bn_for(int dp) { return gt_select_bn(dp); }
 
@@ -15,7 +16,7 @@ void gt_free_knn_work(gt_ctx* ctx) {
                       &k->d2_lb, &k->fb_rows, &k->fb_count, &k->fb_scratch, &k->gflags, &k->prof, &k->fb_qrows, &k->fb_thr, &k->fb_lists,
                       &k->fb_counts, &k->fb_max, &k->unproven, &k->qorder, &k->qthr0, &k->qlomax_dev, &k->Ycs, &k->hnegs,
                       &k->sym_g, &k->sym_gmin, &k->tlists, &k->tcounts, &k->sym_stat, &k->sym_work, &k->sym_tiles,
-                      &k->sym_tile_cnt})
+                      &k->sym_tile_cnt, &k->sh_invperm, &k->sh_lists, &k->sh_counts, &k->sh_cnt, &k->sh_own, &k->sh_tmp})
         b->release();
     delete k;
     ctx->knn = nullptr;
@@ -180,7 +181,13 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
     ra.radius_key_factor = radius_key_factor;
     ra.unproven = k->unproven.as<uint32_t>();
     bool have_thr0 = false;
-    {
+    // row-sharded symmetric pass (gt_knn_shard.cpp): the candidate lists of exactly these rows are waiting
+    bool sh_ready = k->sh_stage == 5 && !external && q0 == k->sh_r0 && nq == k->sh_nloc && need_m == k->sh_need &&
+                    radius_key_factor == k->sh_rkf && MP == 256;
+    k->sh_stage = 0;
+    if (sh_ready) {
+        k->ordered = false;   // k->qorder holds the sorted order of ALL rows (candidate ids are positions in it)
+    } else {
         // deal the query rows to workgroups grouped by nearest landmark (list i <-> row qorder[i]; gt_order.hip)
         int ordered = 0;
         const float* Qc = external ? k->Qc.as<float>() : ctx->Yc.as<float>();
@@ -206,6 +213,53 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
     bool sym_now = use_sym && ctx->sym_ok != 0;
     uint32_t n_fb = 0;
     for (;;) {
+        if (sh_ready) {
+            sh_ready = false;
+            ErrModel em = gt_err_model(ctx, 2);
+            em.rel += 8.0 * 5.9604644775390625e-08;
+            ra.err = em;
+            GT_HIP(ctx, k->sym_stat.reserve(8 * sizeof(unsigned long long)));
+            GT_HIP(ctx, hipMemsetAsync(k->sym_stat.p, 0, 8 * sizeof(unsigned long long), ctx->stream));
+            GT_HIP(ctx, hipMemsetAsync(k->unproven.p, 0, sizeof(uint32_t), ctx->stream));
+            SymRerank sr;
+            sr.tlists = k->sh_lists.as<uint64_t>();
+            sr.tcounts = k->sh_counts.as<uint32_t>();
+            sr.tcap = ctx->sym_tcap;
+            sr.perm = k->qorder.as<int32_t>();
+            sr.stat = k->sym_stat.as<unsigned long long>();
+            sr.invperm = k->sh_invperm.as<int32_t>();
+            sr.own_rows = k->sh_own.as<int32_t>();
+            sr.own_r0 = q0;
+            {
+                StageSpan span(ctx, "rerank");
+                GT_TRY(gt_launch_rerank_sym(ctx, ra, sr));
+            }
+            uint32_t n_unproven = 0;
+            GT_HIP(ctx, hipMemcpyAsync(&n_fb, k->fb_count.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+            GT_HIP(ctx, hipMemcpyAsync(&n_unproven, k->unproven.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+            GT_HIP(ctx, hipMemcpyAsync(k->sym_stat_host, k->sym_stat.p, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+            GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            k->sym_overflow = int64_t(k->sym_stat_host[0]);
+            k->sym_used = true;
+            ctx->last_main_prec = 2;
+            // (the verdicts of the single-rank pass stay local: a rank whose share went badly redoes ITS rows with the
+            //  classic pass - its own rows against all points need nobody else)
+            if (ctx->dbg_select & 2048)
+                fprintf(stderr, "[gt] shard rerank: rows %lld unproven %u repairs %u overflow %lld\n", (long long)nq, n_unproven,
+                        n_fb, (long long)k->sym_overflow);
+            const bool too_many = ctx->sym_mode < 0 && double(k->sym_overflow) > 0.10 * double(nq);
+            const bool unproved = fast_auto && double(n_unproven) > kFastFailFrac * double(nq);
+            if (too_many || unproved) {
+                if (too_many) ctx->sym_ok = 0;
+                if (unproved) ctx->fast_ok = 0, main_prec = 1;
+                k->sym_used = false;
+                n_fb = 0;
+                GT_HIP(ctx, hipMemsetAsync(k->fb_count.p, 0, sizeof(uint32_t), ctx->stream));
+                GT_HIP(ctx, hipMemsetAsync(k->gflags.p, 0, sizeof(uint32_t), ctx->stream));
+                continue;
+            }
+            break;
+        }
         if (sym_now && main_prec == 2) {
             const int64_t n_pad_s = ceil_div64(nq, bq_sym) * bq_sym;
             const int tcap = ctx->sym_tcap;

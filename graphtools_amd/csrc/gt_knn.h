@@ -36,6 +36,18 @@ struct KnnWork {
     unsigned long long sym_stat_host[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int64_t n_fallback_exhaustive = 0;
     int64_t n_fallback = 0;
+    // row-sharded symmetric pass (gt_knn_shard.cpp): 0 idle, 1 planned, 2 seeded (own thresholds known), 3 collected
+    // (send counts known), 4 emitted, 5 the candidate lists of the owned rows are in sh_lists - the next
+    // gt_knn_candidates for exactly these rows re-ranks them instead of running a candidate pass
+    int sh_stage = 0;
+    int sh_world = 1, sh_rank = 0;
+    int64_t sh_r0 = 0, sh_nloc = 0, sh_n_pad_s = 0, sh_p0 = 0, sh_p1 = 0;
+    int sh_need = 0;
+    double sh_rkf = 1.0;
+    int sh_stride = 0, sh_tile_stride = 0;
+    int64_t sh_splits[65] = {0};
+    int64_t sh_send[64] = {0};
+    DevBuf sh_invperm, sh_lists, sh_counts, sh_cnt, sh_own, sh_tmp;
 };
 
 int gt_select_bn_for(int dp);
@@ -144,13 +156,31 @@ struct SymRerank {
     int tcap;
     const int32_t* perm;       // sorted position -> row
     unsigned long long* stat;  // optional counters [8] (rerank_sym_kernel)
+    // row-sharded builds: the lists belong to the owned rows own_r0 + ql (tables indexed by ql), thresholds are found
+    // through the inverse permutation (row -> sorted position)
+    const int32_t* invperm = nullptr;
+    const int32_t* own_rows = nullptr;   // the owned rows in the order of their sorted positions
+    int64_t own_r0 = 0;
 };
 int gt_launch_rerank_sym(gt_ctx* ctx, const RerankArgs& a, const SymRerank& sr);
 // gt_sym.hip
 int gt_sym_gather(gt_ctx* ctx, const int32_t* perm, int64_t n_pad_s, void* Ys, float* hs);
+// rows [p_first, p_last) of the sorted order only (p_last < 0: all); gmin = nullptr: sub-tile minima not formed
 int gt_sym_thresholds(gt_ctx* ctx, const int32_t* perm, int64_t n_pad_s, const float* hs, const uint64_t* lists, int lstride,
                       const uint32_t* counts, int need_m, const ErrModel& err, double rkf, float* thr, float* g, float* gmin,
-                      const DevBuf& work, int cells, unsigned long long* far_total);
+                      const DevBuf& work, int cells, unsigned long long* far_total, int64_t p_first = 0, int64_t p_last = -1);
+// row-sharded symmetric pass (gt_knn_shard.cpp)
+#define GT_SYM_MAX_WORLD 64
+int gt_sym_g_from_thr(gt_ctx* ctx, int64_t n_pad_s, const float* thr, const float* hs, float* g, float* gmin);
+int gt_sym_invperm(gt_ctx* ctx, const int32_t* perm, int32_t* inv);
+// the rows [r0, r1) in the order they have in perm -> own (device int32 [r1 - r0]); tmp: scratch
+int gt_sym_own_rows(gt_ctx* ctx, const int32_t* perm, int64_t r0, int64_t r1, int32_t* own, DevBuf& tmp);
+int gt_sym_shard_count(gt_ctx* ctx, const int32_t* perm, const uint32_t* tcounts, int tcap, int world, const int64_t* splits,
+                       unsigned long long* cnt);
+int gt_sym_shard_emit(gt_ctx* ctx, const int32_t* perm, const uint64_t* tlists, const uint32_t* tcounts, int tcap, int world,
+                      const int64_t* splits, unsigned long long* cursor, void* out);
+int gt_sym_shard_scatter(gt_ctx* ctx, const void* recs, int64_t n_recs, int64_t nloc, int tcap, uint64_t* lists,
+                         uint32_t* counts, uint32_t* bad);
 int gt_sym_schedule(gt_ctx* ctx, int64_t n_pad_s, int bq, int bn, int cells, int stride, int max_nb, int tile_stride,
                     DevBuf& work, int32_t* tile_list, int32_t* tile_cnt, unsigned long long* tiles_total = nullptr);
 int gt_launch_fallback(gt_ctx* ctx, const RerankArgs& a, int64_t n_rows, int64_t row_off, double* scratch);

@@ -60,6 +60,9 @@
 #endif
 // 1: (float16 back ends, two query tiles per wave) the -|y|^2/2 seeds of a sub-tile are read from LDS once, into registers
 // that enter the first MFMA of both query tiles' chains as the C operand, instead of once per accumulator
+#ifndef GT_SEL_PAIRCOLD
+#define GT_SEL_PAIRCOLD 1
+#endif
 #ifndef GT_SEL_SEEDREG
 #define GT_SEL_SEEDREG 1
 #endif
@@ -342,6 +345,9 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
             const int nseg = sy.nseg > 0 ? sy.nseg : 1;
             seg = int(bidx % nseg);
             bidx /= nseg;
+            if (sy.shard_world > 1) seg += int((int64_t(sy.shard_rank) + bidx) % sy.shard_world) * nseg;
+        } else {
+            bidx += sy.block0;
         }
     }
     const int64_t qblock = bidx * BQ;
@@ -369,7 +375,7 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
             const int H = (NB - 1) / 2;
             n_tr_end = C::TPB * (1 + H);
             const int walk = n_tr_end + ((NB & 1) ? 0 : (NB > 1 ? C::TPB : 0));
-            const int nseg = sy.nseg > 0 ? sy.nseg : 1;
+            const int nseg = (sy.nseg > 0 ? sy.nseg : 1) * (sy.shard_world > 1 ? sy.shard_world : 1);
             t_begin = int(int64_t(walk) * seg / nseg);          // this item's part of the block's walk
             t_end = int(int64_t(walk) * (seg + 1) / nseg);
             if (t_begin >= t_end) return;
@@ -635,6 +641,88 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
             }                                                                                              \
         }                                                                                                  \
     }
+// Both query tiles of a wave against one sub-tile in ONE memory round trip (QT == 2): the forward atomics of the two
+// queries a lane owns and the transposed atomics - aggregated per database row over the 64 queries of the two half-wave
+// tiles - are all issued before the first result is looked at.
+#define GT_ADMIT2P(A0_, A1_, SD_, PSB_)                                                                    \
+    {                                                                                                      \
+        const float tq0_ = thr[0], tq1_ = thr[QT - 1];                                                     \
+        const uint32_t qpos0_ = uint32_t(qblock + (w * QT) * 32 + li);                                     \
+        const uint32_t qpos1_ = uint32_t(qblock + (w * QT + QT - 1) * 32 + li);                            \
+        const float hq0_ = hnq[0], hq1_ = hnq[QT - 1];                                                     \
+        uint32_t f0_ = 0u, f1_ = 0u, t0_ = 0u, t1_ = 0u;                                                   \
+        _Pragma("unroll") for (int e_ = 0; e_ < 16; ++e_) {                                                \
+            f0_ |= ((A0_)[e_] > tq0_) ? (1u << e_) : 0u;                                                   \
+            f1_ |= ((A1_)[e_] > tq1_) ? (1u << e_) : 0u;                                                   \
+        }                                                                                                  \
+        if (tr_on) {                                                                                       \
+            _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) {                                             \
+                const float4 gv_ = *reinterpret_cast<const float4*>(gglob + (PSB_) * 32 + 8 * g_ + 4 * h); \
+                const float ge_[4] = {gv_.x, gv_.y, gv_.z, gv_.w};                                         \
+                _Pragma("unroll") for (int c_ = 0; c_ < 4; ++c_) {                                         \
+                    t0_ |= (((A0_)[4 * g_ + c_] + hq0_) > ge_[c_]) ? (1u << (4 * g_ + c_)) : 0u;           \
+                    t1_ |= (((A1_)[4 * g_ + c_] + hq1_) > ge_[c_]) ? (1u << (4 * g_ + c_)) : 0u;           \
+                }                                                                                          \
+            }                                                                                              \
+        }                                                                                                  \
+        const uint32_t nf0_ = uint32_t(__popc(f0_)), nf1_ = uint32_t(__popc(f1_));                         \
+        uint32_t k0_ = 0u, k1_ = 0u;                                                                       \
+        if (nf0_) k0_ = atomicAdd(&sy.tcounts[qpos0_], nf0_);                                              \
+        if (nf1_) k1_ = atomicAdd(&sy.tcounts[qpos1_], nf1_);                                              \
+        uint32_t tslot_[16];                                                                               \
+        _Pragma("unroll") for (int e_ = 0; e_ < 16; ++e_) {                                                \
+            const uint32_t j = tbase + uint32_t((PSB_) * 32 + 8 * (e_ >> 2) + 4 * h + (e_ & 3));           \
+            const unsigned long long b0_ = __ballot((t0_ >> e_) & 1u), b1_ = __ballot((t1_ >> e_) & 1u);   \
+            const uint32_t m0_ = h ? uint32_t(b0_ >> 32) : uint32_t(b0_);                                  \
+            const uint32_t m1_ = h ? uint32_t(b1_ >> 32) : uint32_t(b1_);                                  \
+            tslot_[e_] = 0u;                                                                               \
+            if ((m0_ | m1_) != 0u && uint32_t(li) == uint32_t(__ffs(int(m0_ ? m0_ : m1_)) - 1))            \
+                tslot_[e_] = atomicAdd(&sy.tcounts[j], uint32_t(__popc(m0_) + __popc(m1_)));               \
+        }                                                                                                  \
+        if (nf0_) {                                                                                        \
+            uint64_t* lp_ = sy.tlists + size_t(qpos0_) * size_t(sy.tcap);                                  \
+            _Pragma("unroll") for (int e_ = 0; e_ < 16; ++e_) {                                            \
+                if (f0_ & (1u << e_)) {                                                                    \
+                    const uint32_t j = tbase + uint32_t((PSB_) * 32 + 8 * (e_ >> 2) + 4 * h + (e_ & 3));   \
+                    if (k0_ < uint32_t(sy.tcap)) list_store(lp_ + k0_, cand_pack((A0_)[e_], j));           \
+                    ++k0_;                                                                                 \
+                }                                                                                          \
+            }                                                                                              \
+            if (k0_ > uint32_t(sy.tcap)) thr[0] = INFINITY;                                                \
+        }                                                                                                  \
+        if (nf1_) {                                                                                        \
+            uint64_t* lp_ = sy.tlists + size_t(qpos1_) * size_t(sy.tcap);                                  \
+            _Pragma("unroll") for (int e_ = 0; e_ < 16; ++e_) {                                            \
+                if (f1_ & (1u << e_)) {                                                                    \
+                    const uint32_t j = tbase + uint32_t((PSB_) * 32 + 8 * (e_ >> 2) + 4 * h + (e_ & 3));   \
+                    if (k1_ < uint32_t(sy.tcap)) list_store(lp_ + k1_, cand_pack((A1_)[e_], j));           \
+                    ++k1_;                                                                                 \
+                }                                                                                          \
+            }                                                                                              \
+            if (k1_ > uint32_t(sy.tcap)) thr[QT - 1] = INFINITY;                                           \
+        }                                                                                                  \
+        if (__ballot((t0_ | t1_) != 0u)) {                                                                 \
+            _Pragma("unroll") for (int e_ = 0; e_ < 16; ++e_) {                                            \
+                const unsigned long long b0_ = __ballot((t0_ >> e_) & 1u), b1_ = __ballot((t1_ >> e_) & 1u); \
+                if (b0_ | b1_) {   /* wave-uniform */                                                      \
+                    const uint32_t m0_ = h ? uint32_t(b0_ >> 32) : uint32_t(b0_);                          \
+                    const uint32_t m1_ = h ? uint32_t(b1_ >> 32) : uint32_t(b1_);                          \
+                    const uint32_t mm_ = m0_ ? m0_ : m1_;                                                  \
+                    const int lead_ = (mm_ ? __ffs(int(mm_)) - 1 : 0) + 32 * h;                            \
+                    const uint32_t base_ = uint32_t(__shfl(int(tslot_[e_]), lead_));                       \
+                    const uint32_t below_ = (1u << li) - 1u;                                               \
+                    const uint32_t j = tbase + uint32_t((PSB_) * 32 + 8 * (e_ >> 2) + 4 * h + (e_ & 3));   \
+                    uint64_t* lj_ = sy.tlists + size_t(j) * size_t(sy.tcap);                               \
+                    const uint32_t s0_ = base_ + uint32_t(__popc(m0_ & below_));                           \
+                    const uint32_t s1_ = base_ + uint32_t(__popc(m0_)) + uint32_t(__popc(m1_ & below_));   \
+                    if (((t0_ >> e_) & 1u) && s0_ < uint32_t(sy.tcap))                                     \
+                        list_store(lj_ + s0_, cand_pack(((A0_)[e_] + hq0_) - (SD_)[e_], qpos0_));          \
+                    if (((t1_ >> e_) & 1u) && s1_ < uint32_t(sy.tcap))                                     \
+                        list_store(lj_ + s1_, cand_pack(((A1_)[e_] + hq1_) - (SD_)[e_], qpos1_));          \
+                }                                                                                          \
+            }                                                                                              \
+        }                                                                                                  \
+    }
 #define GT_ADMIT(PA_, ANY_, MX_, PSB_, PQT_)                                                               \
     if (__builtin_expect(__ballot(ANY_) != 0ull, 0)) {   /* wave-uniform and cold: most units admit nothing */  \
         const float tq_ = thr[PQT_];                                                                       \
@@ -735,8 +823,9 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
                 const unsigned long long ts_ = prof ? __builtin_readcyclecounter() : 0ull;
                 while (hitmask) {   // wave-uniform
                     const int pu = __ffs(int(hitmask)) - 1;
-                    hitmask &= hitmask - 1u;
                     const int csb = pu / QT, cqt = pu % QT;
+                    if constexpr (QT == 2 && GT_SEL_PAIRCOLD) hitmask &= ~(3u << (csb * QT));
+                    else hitmask &= hitmask - 1u;
                     Frag<DP, PREC> ca;
                     ca.load(tb + (csb * 32 + li) * LDP, h, aswz);
                     f32x16 cs, cacc;
@@ -748,7 +837,15 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
                         cs[4 * g_ + 2] = hv_.z;
                         cs[4 * g_ + 3] = hv_.w;
                     }
-                    if (QT == 1 || cqt == 0) {
+                    if constexpr (QT == 2 && GT_SEL_PAIRCOLD) {
+                        // an unflagged tile of the pair has no passing element (its unit test is implied by every
+                        // element test), so scoring both unconditionally adds nothing but four MFMAs
+                        f32x16 cacc1 = cs;
+                        cacc = cs;
+                        mma_chain<DP>(ca, bq[0], cacc);
+                        mma_chain<DP>(ca, bq[QT - 1], cacc1);
+                        GT_ADMIT2P(cacc, cacc1, cs, csb);
+                    } else if (QT == 1 || cqt == 0) {
                         cacc = cs;
                         mma_chain<DP>(ca, bq[0], cacc);
                         GT_ADMIT2(cacc, cs, csb, 0);
@@ -968,7 +1065,9 @@ int launch_one(gt_ctx* ctx, const SelectArgs& a) {
         GT_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         int(lds_bytes)));
     }
-    const int64_t grid_x = MODE == 2 ? nblocks * a.sym.nseg : nblocks;
+    if (a.sym.nblk > 0 && (MODE != 0 || a.sym.sched != 1 || a.sym.block0 < 0 || a.sym.block0 + a.sym.nblk > nblocks))
+        GT_FAIL(ctx, GT_E_ARG, "knn_select: a block range needs the own-neighbourhood schedule");
+    const int64_t grid_x = MODE == 2 ? nblocks * a.sym.nseg : (a.sym.nblk > 0 ? a.sym.nblk : nblocks);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid_x, (unsigned)nsplit), dim3(256), lds_bytes, ctx->stream, a.Yp,
                        a.hneg, a.Qp, a.qrows, a.q0, a.nq, ntiles, a.lists, a.counts, a.thr_in, a.thr_out, a.cap, a.dbg, a.prof,
                        a.samp_stride, a.samp_keep, a.samp_end, a.samp2_level, a.samp2_keep,

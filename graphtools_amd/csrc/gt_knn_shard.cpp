@@ -1,0 +1,295 @@
+// Row-sharded symmetric candidate pass (one process per GPU; the collectives are the host language's, dist.py).
+//
+// Single rank (gt_knn.cpp, gt_sym.hip): launch A seeds a fixed threshold per row, launch B scores every unordered pair
+// of rows once and files the survivors in the lists of BOTH rows, the re-rank turns each list into an exact table.
+// Sharded over `world` ranks that all hold the full point set (the all-gather of the d-dim points comes first anyway):
+//   plan      every rank builds the same cell-sorted order (deterministic: MFMA assignment + stable radix sort)
+//   seed      launch A for the rank's share of the query blocks of that order only (1/world of the work);
+//             -> the host all-gathers the thresholds (4 bytes per row)
+//   collect   launch B with every block's walk cut into world x nseg pieces: this rank takes the pieces
+//             ((rank + block) mod world) x nseg ... - 1/world of the pair scores, the hit-rich pieces next to the
+//             diagonal spread round robin; the survivors land in this rank's own partial lists of ALL rows
+//   emit      partial lists -> 16-byte records {row local to its owner, key}, bucketed by the owner of the ROW in the
+//             caller's row split (the rank that builds that row of the kernel matrix)
+//             -> the host moves them with the same all-to-all the triplets use
+//   finish    received records -> lists of the owned rows; gt_knn_candidates() for exactly these rows then re-ranks
+//             them (rerank_sym_kernel, thresholds found through the inverse permutation) and runs the usual repairs.
+// The union of the ranks' partial lists is exactly the list the single-rank pass builds (same thresholds, same scores),
+// so the tables - and the graph - are those of the single-rank symmetric build.
+#include "gt_knn.h"
+#include "gt_knn_select.h"
+
+#include <algorithm>
+#include <cmath>
+
+namespace {
+
+bool shard_applicable(const gt_ctx* ctx, int need_m) {
+    const int bq = gt_select_bq(ctx->DP);
+    const bool fast = ctx->prec == 1 && (ctx->fast_mode == 2 || (ctx->fast_mode == 1 && ctx->fast_ok != 0));
+    return ctx->sym_mode != 0 && ctx->sym_ok != 0 && fast && ctx->metric == 0 && !ctx->wide && ctx->DP != 0 &&
+           need_m >= 1 && need_m <= ctx->nt8_max_need && need_m <= 64 && ctx->Yc.p != nullptr &&
+           (ctx->sym_mode > 0 || ctx->n >= ctx->sym_min_rows) && ctx->n >= int64_t(8) * bq && ctx->n >= 4096;
+}
+
+}  // namespace
+
+int gt_knn_shard_plan(gt_ctx* ctx, int world, int rank, const int64_t* splits, int need_m, double rkf, int32_t* applies,
+                      int64_t* n_pad_sorted, int64_t* sorted_splits) {
+    *applies = 0;
+    if (ctx->n <= 0 || !ctx->X) GT_FAIL(ctx, GT_E_STATE, "no points bound (call gt_set_points first)");
+    if (world < 1 || world > GT_SYM_MAX_WORLD || rank < 0 || rank >= world || !splits)
+        GT_FAIL(ctx, GT_E_ARG, "sym shard: bad world/rank/row_splits");
+    if (!ctx->knn) ctx->knn = new KnnWork();
+    KnnWork* k = ctx->knn;
+    k->sh_stage = 0;
+    if (!shard_applicable(ctx, need_m) || splits[rank + 1] <= splits[rank]) return GT_OK;
+    const int bq = gt_select_bq(ctx->DP);
+    const int64_t n_pad_s = ceil_div64(ctx->n, bq) * bq;
+    const int64_t NB = n_pad_s / bq;
+    if (NB < world) return GT_OK;
+    // the cell-sorted order of ALL rows (position -> row in k->qorder)
+    int ordered = 0;
+    GT_HIP(ctx, k->qorder.reserve(size_t(ctx->n) * sizeof(int32_t)));
+    GT_HIP(ctx, k->qthr0.reserve(size_t(ctx->n) * sizeof(float)));
+    {
+        StageSpan span(ctx, "query_order");
+        GT_TRY(gt_query_order(ctx, ctx->Yc.as<float>(), 0, ctx->n, need_m, k->qorder.as<int32_t>(), k->qthr0.as<float>(),
+                              &ordered));
+    }
+    k->ordered = false;
+    if (!ordered || ctx->order_L <= 0) return GT_OK;
+    k->sh_world = world;
+    k->sh_rank = rank;
+    for (int r = 0; r <= world; ++r) k->sh_splits[r] = splits[r];
+    k->sh_r0 = splits[rank];
+    k->sh_nloc = splits[rank + 1] - splits[rank];
+    k->sh_n_pad_s = n_pad_s;
+    k->sh_need = need_m;
+    k->sh_rkf = rkf;
+    for (int r = 0; r <= world; ++r) sorted_splits[r] = (NB * r / world) * bq;
+    k->sh_p0 = sorted_splits[rank];
+    k->sh_p1 = sorted_splits[rank + 1];
+    *n_pad_sorted = n_pad_s;
+    *applies = 1;
+    k->sh_stage = 1;
+    return GT_OK;
+}
+
+int gt_knn_shard_seed(gt_ctx* ctx, float* thr_local, int64_t* far_local) {
+    KnnWork* k = ctx->knn;
+    if (!k || k->sh_stage != 1) GT_FAIL(ctx, GT_E_STATE, "sym shard: seed without a plan");
+    k->sh_stage = 0;
+    const int bq = gt_select_bq(ctx->DP), bn = gt_select_bn(ctx->DP);
+    const int64_t n_pad_s = k->sh_n_pad_s, p0 = k->sh_p0, p1 = k->sh_p1;
+    const int need_m = k->sh_need;
+    const int tcap = ctx->sym_tcap;
+    const size_t lcap = size_t(64) * 8;
+    const int32_t* perm = k->qorder.as<int32_t>();
+    GT_HIP(ctx, k->Ycs.reserve(size_t(n_pad_s) * ctx->DP * sizeof(_Float16)));
+    GT_HIP(ctx, k->hnegs.reserve(size_t(n_pad_s) * sizeof(float)));
+    GT_HIP(ctx, k->sym_g.reserve(size_t(n_pad_s) * sizeof(float)));
+    GT_HIP(ctx, k->sym_gmin.reserve(size_t(n_pad_s / 32) * sizeof(float)));
+    GT_HIP(ctx, k->tlists.reserve(size_t(n_pad_s) * size_t(tcap) * sizeof(uint64_t)));
+    GT_HIP(ctx, k->tcounts.reserve(size_t(n_pad_s) * sizeof(uint32_t)));
+    GT_HIP(ctx, k->sym_stat.reserve(8 * sizeof(unsigned long long)));
+    GT_HIP(ctx, k->lists.reserve(size_t(std::max<int64_t>(p1 - p0, bq)) * lcap * sizeof(uint64_t)));   // own blocks only
+    GT_HIP(ctx, k->counts.reserve(size_t(n_pad_s) * sizeof(uint32_t)));
+    GT_HIP(ctx, k->thr_final.reserve(size_t(n_pad_s) * sizeof(float)));
+    GT_HIP(ctx, hipMemsetAsync(k->sym_stat.p, 0, 8 * sizeof(unsigned long long), ctx->stream));
+    const int n_tiles_s = int(n_pad_s / bn);
+    const int stride_a = ctx->sym_stride > 0 && n_tiles_s >= 8 * ctx->sym_stride ? ctx->sym_stride : 0;
+    const int tile_stride = ((stride_a ? n_tiles_s / stride_a + 1 : 0) + ctx->sym_max_nb + bq / bn + 63) / 64 * 64;
+    k->sh_stride = stride_a;
+    k->sh_tile_stride = tile_stride;
+    GT_HIP(ctx, k->sym_tiles.reserve(size_t(n_pad_s / bq) * tile_stride * sizeof(int32_t)));
+    GT_HIP(ctx, k->sym_tile_cnt.reserve(size_t(n_pad_s / bq) * sizeof(int32_t)));
+    {
+        StageSpan span(ctx, "sym_prepare");
+        GT_TRY(gt_sym_gather(ctx, perm, n_pad_s, k->Ycs.p, k->hnegs.as<float>()));
+        GT_TRY(gt_sym_schedule(ctx, n_pad_s, bq, bn, ctx->sym_cells, stride_a, ctx->sym_max_nb, tile_stride, k->sym_work,
+                               k->sym_tiles.as<int32_t>(), k->sym_tile_cnt.as<int32_t>(), nullptr));
+    }
+    // the lists of launch A are addressed by sorted position: a base pointer p0 rows before the buffer keeps the
+    // kernels' indexing (only positions [p0, p1) are touched)
+    uint64_t* lists0 = k->lists.as<uint64_t>() - size_t(p0) * lcap;
+    ErrModel em = gt_err_model(ctx, 2);
+    em.rel += 8.0 * 5.9604644775390625e-08;   // as in the single-rank pass (gt_knn.cpp)
+    if (p1 > p0) {
+        SelectArgs a;
+        a.dp = ctx->DP;
+        a.prec = 2;
+        a.mode = 0;
+        a.nt = 8;
+        a.narrow = 0;
+        a.Yp = a.Qp = k->Ycs.as<float>();
+        a.hneg = k->hnegs.as<float>();
+        a.n_pad = n_pad_s;
+        a.qrows = nullptr;
+        a.q0 = 0;
+        a.nq = int32_t(ctx->n);
+        a.lists = lists0;
+        a.counts = k->counts.as<uint32_t>();
+        a.thr_in = nullptr;
+        a.thr_out = k->thr_final.as<float>();
+        a.dbg = 0;
+        a.sym.sched = 1;
+        a.sym.tile_list = k->sym_tiles.as<int32_t>();
+        a.sym.tile_cnt = k->sym_tile_cnt.as<int32_t>();
+        a.sym.tile_stride = tile_stride;
+        a.sym.block0 = int32_t(p0 / bq);
+        a.sym.nblk = int32_t((p1 - p0) / bq);
+        int keep = std::max(ctx->samp_keep > 0 ? ctx->samp_keep : 16, need_m);
+        keep += keep & 1;
+        a.samp_stride = 0;
+        a.samp_keep = keep;
+        a.samp_trig = ctx->samp_trig;
+        a.samp_end = 0;
+        a.samp2_level = 0;
+        a.final_keep = need_m;
+        {
+            StageSpan span(ctx, "sym_seed");
+            GT_TRY(gt_launch_select(ctx, a));
+        }
+        StageSpan span(ctx, "sym_prepare");
+        GT_TRY(gt_sym_thresholds(ctx, perm, n_pad_s, k->hnegs.as<float>(), lists0, int(lcap), k->counts.as<uint32_t>(), need_m,
+                                 em, std::max(1.0, std::fabs(k->sh_rkf)), k->thr_final.as<float>(), k->sym_g.as<float>(),
+                                 nullptr, k->sym_work, ctx->sym_cells, k->sym_stat.as<unsigned long long>() + 2, p0, p1));
+        GT_HIP(ctx, hipMemcpyAsync(thr_local, k->thr_final.as<float>() + p0, size_t(p1 - p0) * sizeof(float),
+                                   hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    unsigned long long far = 0;
+    GT_HIP(ctx, hipMemcpyAsync(&far, k->sym_stat.as<unsigned long long>() + 2, sizeof(far), hipMemcpyDeviceToHost, ctx->stream));
+    GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *far_local = int64_t(far);
+    k->sh_stage = 2;
+    return GT_OK;
+}
+
+int gt_knn_shard_collect(gt_ctx* ctx, const float* thr_all, int64_t far_total, int32_t* applies, int64_t* send_counts) {
+    KnnWork* k = ctx->knn;
+    *applies = 0;
+    if (!k || k->sh_stage != 2) GT_FAIL(ctx, GT_E_STATE, "sym shard: collect without seeds");
+    k->sh_stage = 0;
+    const int bq = gt_select_bq(ctx->DP);
+    const int64_t n_pad_s = k->sh_n_pad_s;
+    const int tcap = ctx->sym_tcap;
+    k->sym_far = far_total;
+    if (ctx->sym_mode < 0) {
+        // the predictor of the single-rank pass on the far-kept count of ALL ranks (every rank sees the same number)
+        const double est = double(k->sh_need) + double(std::max(k->sh_stride, 1)) * double(far_total) / double(ctx->n);
+        if (k->sh_stride > 0 && est > double(tcap) / 8.0) {
+            ctx->sym_ok = 0;
+            return GT_OK;
+        }
+    }
+    GT_HIP(ctx, hipMemcpyAsync(k->thr_final.p, thr_all, size_t(n_pad_s) * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+    {
+        StageSpan span(ctx, "sym_prepare");
+        GT_TRY(gt_sym_g_from_thr(ctx, n_pad_s, k->thr_final.as<float>(), k->hnegs.as<float>(), k->sym_g.as<float>(),
+                                 k->sym_gmin.as<float>()));
+        GT_HIP(ctx, hipMemsetAsync(k->tcounts.p, 0, size_t(n_pad_s) * sizeof(uint32_t), ctx->stream));
+    }
+    SelectArgs a;
+    a.dp = ctx->DP;
+    a.prec = 2;
+    a.mode = 2;
+    a.nt = 8;
+    a.Yp = a.Qp = k->Ycs.as<float>();
+    a.hneg = k->hnegs.as<float>();
+    a.n_pad = n_pad_s;
+    a.q0 = 0;
+    a.nq = int32_t(ctx->n);
+    a.lists = nullptr;
+    a.counts = k->counts.as<uint32_t>();
+    a.thr_in = k->thr_final.as<float>();
+    a.thr_out = nullptr;
+    a.dbg = 0;
+    a.sym.g = k->sym_g.as<float>();
+    a.sym.gmin = k->sym_gmin.as<float>();
+    a.sym.tlists = k->tlists.as<uint64_t>();
+    a.sym.tcounts = k->tcounts.as<uint32_t>();
+    a.sym.tcap = tcap;
+    a.sym.shard_world = k->sh_world;
+    a.sym.shard_rank = k->sh_rank;
+    {
+        const int64_t slots = int64_t(ctx->n_cu) * 3, nb = n_pad_s / bq;
+        int best = 1;
+        double best_cost = 1e30;
+        for (int sgm = 1; sgm <= 8; ++sgm) {
+            const double cost = double(ceil_div64(nb * sgm, slots)) / sgm + 0.03 * sgm;
+            if (cost < best_cost - 1e-9) best_cost = cost, best = sgm;
+        }
+        a.sym.nseg = ctx->sym_nseg > 0 ? std::min(ctx->sym_nseg, 8) : best;
+        k->sym_nseg = a.sym.nseg;
+    }
+    {
+        StageSpan span(ctx, "knn_select");
+        GT_TRY(gt_launch_select(ctx, a));
+    }
+    ctx->last_main_prec = 2;
+    GT_HIP(ctx, k->sh_cnt.reserve(size_t(2 * GT_SYM_MAX_WORLD) * sizeof(unsigned long long)));
+    unsigned long long host_cnt[GT_SYM_MAX_WORLD];
+    {
+        StageSpan span(ctx, "sym_exchange");
+        GT_TRY(gt_sym_shard_count(ctx, k->qorder.as<int32_t>(), k->tcounts.as<uint32_t>(), tcap, k->sh_world, k->sh_splits,
+                                  k->sh_cnt.as<unsigned long long>()));
+    }
+    GT_HIP(ctx, hipMemcpyAsync(host_cnt, k->sh_cnt.p, size_t(k->sh_world) * sizeof(unsigned long long), hipMemcpyDeviceToHost,
+                               ctx->stream));
+    GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int r = 0; r < k->sh_world; ++r) send_counts[r] = k->sh_send[r] = int64_t(host_cnt[r]);
+    *applies = 1;
+    k->sh_stage = 3;
+    return GT_OK;
+}
+
+int gt_knn_shard_emit(gt_ctx* ctx, void* send_buf) {
+    KnnWork* k = ctx->knn;
+    if (!k || k->sh_stage != 3) GT_FAIL(ctx, GT_E_STATE, "sym shard: emit without collected lists");
+    unsigned long long off[GT_SYM_MAX_WORLD];
+    unsigned long long acc = 0;
+    for (int r = 0; r < k->sh_world; ++r) {
+        off[r] = acc;
+        acc += (unsigned long long)k->sh_send[r];
+    }
+    unsigned long long* cursor = k->sh_cnt.as<unsigned long long>() + GT_SYM_MAX_WORLD;
+    GT_HIP(ctx, hipMemcpyAsync(cursor, off, size_t(k->sh_world) * sizeof(unsigned long long), hipMemcpyHostToDevice, ctx->stream));
+    if (acc > 0) {
+        if (!send_buf) GT_FAIL(ctx, GT_E_ARG, "sym shard: send buffer is NULL");
+        StageSpan span(ctx, "sym_exchange");
+        GT_TRY(gt_sym_shard_emit(ctx, k->qorder.as<int32_t>(), k->tlists.as<uint64_t>(), k->tcounts.as<uint32_t>(), ctx->sym_tcap,
+                                 k->sh_world, k->sh_splits, cursor, send_buf));
+    }
+    GT_HIP(ctx, hipStreamSynchronize(ctx->stream));   // `off` is read by the copy; the caller's stream takes over the buffer
+    k->sh_stage = 4;
+    return GT_OK;
+}
+
+int gt_knn_shard_finish(gt_ctx* ctx, const void* recv, int64_t n_recv) {
+    KnnWork* k = ctx->knn;
+    if (!k || k->sh_stage != 4) GT_FAIL(ctx, GT_E_STATE, "sym shard: finish without an exchange");
+    k->sh_stage = 0;
+    if (n_recv < 0 || (n_recv > 0 && !recv)) GT_FAIL(ctx, GT_E_ARG, "sym shard: bad receive buffer");
+    const int tcap = ctx->sym_tcap;
+    GT_HIP(ctx, k->sh_lists.reserve(size_t(k->sh_nloc) * size_t(tcap) * sizeof(uint64_t)));
+    GT_HIP(ctx, k->sh_counts.reserve(size_t(k->sh_nloc) * sizeof(uint32_t)));
+    GT_HIP(ctx, k->sh_invperm.reserve(size_t(ctx->n) * sizeof(int32_t)));
+    GT_HIP(ctx, k->sh_own.reserve(size_t(k->sh_nloc + 1) * sizeof(int32_t)));
+    GT_HIP(ctx, k->unproven.reserve(sizeof(uint32_t)));
+    GT_HIP(ctx, hipMemsetAsync(k->sh_counts.p, 0, size_t(k->sh_nloc) * sizeof(uint32_t), ctx->stream));
+    GT_HIP(ctx, hipMemsetAsync(k->unproven.p, 0, sizeof(uint32_t), ctx->stream));
+    uint32_t bad = 0;
+    {
+        StageSpan span(ctx, "sym_exchange");
+        GT_TRY(gt_sym_shard_scatter(ctx, recv, n_recv, k->sh_nloc, tcap, k->sh_lists.as<uint64_t>(), k->sh_counts.as<uint32_t>(),
+                                    k->unproven.as<uint32_t>()));
+        GT_TRY(gt_sym_invperm(ctx, k->qorder.as<int32_t>(), k->sh_invperm.as<int32_t>()));
+        GT_TRY(gt_sym_own_rows(ctx, k->qorder.as<int32_t>(), k->sh_r0, k->sh_r0 + k->sh_nloc, k->sh_own.as<int32_t>(), k->sh_tmp));
+    }
+    GT_HIP(ctx, hipMemcpyAsync(&bad, k->unproven.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (bad) GT_FAIL(ctx, GT_E_ARG, "sym shard: received records for rows this rank does not own");
+    k->sh_stage = 5;
+    return GT_OK;
+}

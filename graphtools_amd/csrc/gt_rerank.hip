@@ -213,7 +213,8 @@ __global__ __launch_bounds__(256) void rerank_sym_kernel(
     const int32_t* __restrict__ perm, double* __restrict__ cand_d2, uint32_t* __restrict__ cand_j,
     uint32_t* __restrict__ cand_n, double* __restrict__ d2_lb, uint32_t* __restrict__ fb_count,
     int32_t* __restrict__ fb_rows, uint32_t* __restrict__ gflags, const double radius_key_factor,
-    uint32_t* __restrict__ unproven, unsigned long long* __restrict__ stat, const int want_stats) {
+    uint32_t* __restrict__ unproven, unsigned long long* __restrict__ stat, const int want_stats,
+    const int32_t* __restrict__ invperm, const int32_t* __restrict__ own_rows, const int64_t own_r0) {
     constexpr int MP = 256;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int lane = threadIdx.x & 63;
@@ -223,16 +224,24 @@ __global__ __launch_bounds__(256) void rerank_sym_kernel(
     const int64_t bid = xcd * base + (xcd < rem ? xcd : rem) + (blockIdx.x >> 3);
     const int64_t ql = bid * 4 + w;
     if (ql >= nq) return;
-    const int64_t q = perm[ql];
-    const T* xrow = X + q * int64_t(d);
+    // single rank: list ql = sorted position ql, tables indexed by the row perm[ql].  Row-sharded (invperm given): the
+    // ql-th owned row in the sorted order is own_rows[ql] (neighbouring waves then evaluate overlapping candidate rows),
+    // its list and table sit at its local index, its threshold at its sorted position
+    const int64_t qo = invperm ? int64_t(own_rows[ql]) : int64_t(perm[ql]);   // row of the bound points
+    const int64_t q = invperm ? qo - own_r0 : qo;                             // row of the tables
+    const int64_t qt = invperm ? int64_t(invperm[qo]) : ql;                   // index of the threshold
+    const int64_t ls = invperm ? q : ql;                                      // index of the list
+    const T* xrow = X + qo * int64_t(d);
     for (int k = lane; k < d; k += 64) xs[k] = double(xrow[k]);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    const double qnq = xn[q];
-    const uint32_t ct = tcounts[ql];
-    const bool overflow = ct > uint32_t(tcap);
+    const double qnq = xn[qo];
+    // (row-sharded builds: bit 31 = some rank's partial list of this row overflowed, gt_sym.hip shard_scatter_kernel)
+    const uint32_t ct_raw = tcounts[ls];
+    const uint32_t ct = ct_raw & 0x7FFFFFFFu;
+    const bool overflow = ct > uint32_t(tcap) || (ct_raw >> 31) != 0u;
     const uint32_t n = overflow ? uint32_t(tcap) : ct;
-    const uint64_t* tp = tlists + size_t(ql) * size_t(tcap);
+    const uint64_t* tp = tlists + size_t(ls) * size_t(tcap);
 
     const double y2 = ymax2p[0];
     const double e = gt_err_bound(err, qnq, y2);
@@ -240,7 +249,7 @@ __global__ __launch_bounds__(256) void rerank_sym_kernel(
         const double sv = double(score) * err.inv_sc2;
         return (qnq - 2.0 * (sv + e)) - 1e-9 * (qnq + y2);
     };
-    double lb = overflow ? -INFINITY : bound_of_score(thr[ql]);
+    double lb = overflow ? -INFINITY : bound_of_score(thr[qt]);
 
     uint64_t ks[8];
 #pragma unroll
@@ -703,12 +712,12 @@ int gt_launch_rerank_sym(gt_ctx* ctx, const RerankArgs& a, const SymRerank& sr) 
         hipLaunchKernelGGL((rerank_sym_kernel<float>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, (const float*)a.X,
                            a.d, a.xn, a.nq, sr.tlists, sr.tcap, sr.tcounts, a.thr_final, a.ymax2,
                            a.err, a.need_m, sr.perm, a.cand_d2, a.cand_j, a.cand_n, a.d2_lb, a.fb_count, a.fb_rows, a.gflags,
-                           a.radius_key_factor, a.unproven, sr.stat, (ctx->dbg_select & 256) ? 1 : 0);
+                           a.radius_key_factor, a.unproven, sr.stat, (ctx->dbg_select & 256) ? 1 : 0, sr.invperm, sr.own_rows, sr.own_r0);
     else
         hipLaunchKernelGGL((rerank_sym_kernel<double>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, (const double*)a.X,
                            a.d, a.xn, a.nq, sr.tlists, sr.tcap, sr.tcounts, a.thr_final, a.ymax2,
                            a.err, a.need_m, sr.perm, a.cand_d2, a.cand_j, a.cand_n, a.d2_lb, a.fb_count, a.fb_rows, a.gflags,
-                           a.radius_key_factor, a.unproven, sr.stat, (ctx->dbg_select & 256) ? 1 : 0);
+                           a.radius_key_factor, a.unproven, sr.stat, (ctx->dbg_select & 256) ? 1 : 0, sr.invperm, sr.own_rows, sr.own_r0);
     GT_HIP(ctx, hipGetLastError());
     return GT_OK;
 }

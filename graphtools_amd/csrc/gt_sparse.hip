@@ -762,6 +762,66 @@ int gt_exclusive_scan_i32(gt_ctx* ctx, const int32_t* a, int64_t n, int64_t* out
 }
 
 // ================================================================================================
+static double candidate_hint(const gt_ctx* ctx, const gt_knn_params* params, double thresh, bool use_radius) {
+    double hint = 1.0;
+    if (use_radius && params->bandwidth_len == 0) {
+        const double rf = std::pow(-1.0 * std::log(thresh), 1.0 / params->decay) * params->bandwidth_scale;
+        hint = (ctx->metric == 1) ? rf : rf * rf;
+    } else if (use_radius) {
+        hint = -1.0;   // negative: no early stop in the re-rank (gt_knn.h)
+    }
+    return hint;
+}
+
+// ---- row-sharded symmetric candidate pass: the stages around the host's collectives (gt_knn_shard.cpp) -------------
+int gt_knn_shard_plan(gt_ctx* ctx, int world, int rank, const int64_t* splits, int need_m, double rkf, int32_t* applies,
+                      int64_t* n_pad_sorted, int64_t* sorted_splits);
+int gt_knn_shard_seed(gt_ctx* ctx, float* thr_local, int64_t* far_local);
+int gt_knn_shard_collect(gt_ctx* ctx, const float* thr_all, int64_t far_total, int32_t* applies, int64_t* send_counts);
+int gt_knn_shard_emit(gt_ctx* ctx, void* send_buf);
+int gt_knn_shard_finish(gt_ctx* ctx, const void* recv, int64_t n_recv);
+
+extern "C" int gt_graph_sym_plan(gt_ctx* ctx, const gt_knn_params* params, int32_t world, int32_t rank,
+                                 const int64_t* row_splits, int32_t* applies, int64_t* n_pad_sorted, int64_t* sorted_splits) {
+    if (!ctx || !params || !applies || !n_pad_sorted || !sorted_splits || !row_splits) return GT_E_ARG;
+    GT_HIP(ctx, hipSetDevice(ctx->device));
+    ctx->reset_stages();
+    *applies = 0;
+    if (world < 1 || world > kMaxWorld || rank < 0 || rank >= world) GT_FAIL(ctx, GT_E_ARG, "gt_graph_sym_plan: bad world/rank");
+    if (row_splits[0] != 0 || row_splits[world] != ctx->n) GT_FAIL(ctx, GT_E_ARG, "row_splits must cover [0, n]");
+    // the cases whose table depth and re-rank hint graph_begin_impl derives without further state
+    if (params->knn < 1 || params->knn_max > 0 || int64_t(params->knn) + 1 > ctx->n) return GT_OK;
+    const bool binary = std::isnan(params->decay) || params->thresh == 1.0;
+    double thresh = params->thresh;
+    if (!binary) {
+        if (thresh <= 0) return GT_OK;
+        if (thresh < DBL_EPSILON) thresh = DBL_EPSILON;
+    }
+    const double hint = candidate_hint(ctx, params, thresh, !binary);
+    return gt_knn_shard_plan(ctx, world, rank, row_splits, params->knn + 1, hint, applies, n_pad_sorted, sorted_splits);
+}
+extern "C" int gt_graph_sym_seed(gt_ctx* ctx, void* thr_local, int64_t* far_local) {
+    if (!ctx || !far_local) return GT_E_ARG;
+    GT_HIP(ctx, hipSetDevice(ctx->device));
+    return gt_knn_shard_seed(ctx, static_cast<float*>(thr_local), far_local);
+}
+extern "C" int gt_graph_sym_collect(gt_ctx* ctx, const void* thr_all, int64_t far_total, int32_t* applies,
+                                    int64_t* send_counts) {
+    if (!ctx || !thr_all || !applies || !send_counts) return GT_E_ARG;
+    GT_HIP(ctx, hipSetDevice(ctx->device));
+    return gt_knn_shard_collect(ctx, static_cast<const float*>(thr_all), far_total, applies, send_counts);
+}
+extern "C" int gt_graph_sym_emit(gt_ctx* ctx, void* send_buf) {
+    if (!ctx) return GT_E_ARG;
+    GT_HIP(ctx, hipSetDevice(ctx->device));
+    return gt_knn_shard_emit(ctx, send_buf);
+}
+extern "C" int gt_graph_sym_finish(gt_ctx* ctx, const void* recv, int64_t n_recv) {
+    if (!ctx) return GT_E_ARG;
+    GT_HIP(ctx, hipSetDevice(ctx->device));
+    return gt_knn_shard_finish(ctx, recv, n_recv);
+}
+
 static int graph_begin_impl(gt_ctx* ctx, const gt_knn_params* params, int32_t world, int32_t rank,
                             const int64_t* row_splits, int64_t* send_counts, bool external, int64_t m_ext) {
     if (!ctx || !params) return GT_E_ARG;
@@ -843,13 +903,7 @@ static int graph_begin_impl(gt_ctx* ctx, const gt_knn_params* params, int32_t wo
         // hint for the arithmetic choice of the main pass: rows out to radius_factor x bandwidth will be needed
         // (it also lets the re-rank stop after its first batch of candidates); a caller-given bandwidth is not tied to
         // the k-th neighbour: no hint, every candidate is evaluated
-        double hint = 1.0;
-        if (use_radius && params->bandwidth_len == 0) {
-            const double rf = std::pow(-1.0 * std::log(thresh), 1.0 / params->decay) * params->bandwidth_scale;
-            hint = (ctx->metric == 1) ? rf : rf * rf;
-        } else if (use_radius) {
-            hint = -1.0;   // negative: no early stop in the re-rank (gt_knn.h)
-        }
+        const double hint = candidate_hint(ctx, params, thresh, use_radius);
         GT_TRY(gt_knn_candidates(ctx, g->r0, g->nloc, external, need, hint));
     }
     KnnWork* k = ctx->knn;
@@ -1035,7 +1089,8 @@ static int graph_begin_impl(gt_ctx* ctx, const gt_knn_params* params, int32_t wo
 extern "C" int gt_graph_begin(gt_ctx* ctx, const gt_knn_params* params, int32_t world, int32_t rank,
                               const int64_t* row_splits, int64_t* send_counts) {
     if (!ctx) return GT_E_ARG;
-    ctx->reset_stages();
+    // (the stages of a sharded symmetric pass that is about to be consumed belong to this build)
+    if (!(ctx->knn && ctx->knn->sh_stage == 5)) ctx->reset_stages();
     return graph_begin_impl(ctx, params, world, rank, row_splits, send_counts, false, 0);
 }
 

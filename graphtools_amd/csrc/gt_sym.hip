@@ -18,6 +18,8 @@
 //      bound from thr[p]; rows whose lists overflowed go to the usual repair path.
 // The roofline line of bench.py prices this pass at the algorithmic 2 N^2 d and reports the executed
 // matrix work next to it.
+#include <rocprim/device/device_select.hpp>
+
 #include "gt_common.h"
 #include "gt_device.h"
 #include "gt_knn.h"
@@ -59,7 +61,7 @@ __global__ __launch_bounds__(256) void gather_sorted_kernel(const uint4* __restr
 // partial dot products meet in a shuffle tree.  D_K only has to be an upper bound: the summation order differs from the
 // re-rank's, a relative 1e-12 covers it.
 template <typename T>
-__global__ __launch_bounds__(256) void sym_thresholds_kernel(const int64_t n, const int64_t n_pad,
+__global__ __launch_bounds__(256) void sym_thresholds_kernel(const int64_t n, const int64_t p_first, const int64_t p_last,
                                                              const int32_t* __restrict__ perm, const T* __restrict__ X,
                                                              const int d, const double* __restrict__ xn,
                                                              const float* __restrict__ hs,
@@ -71,8 +73,8 @@ __global__ __launch_bounds__(256) void sym_thresholds_kernel(const int64_t n, co
                                                              const int32_t* __restrict__ nbr, const int M,
                                                              unsigned long long* __restrict__ far_total) {
     const int sub = threadIdx.x & 15;
-    const int64_t p = int64_t(blockIdx.x) * 16 + (threadIdx.x >> 4);
-    if (p >= n_pad) return;   // whole 16-lane group
+    const int64_t p = p_first + int64_t(blockIdx.x) * 16 + (threadIdx.x >> 4);
+    if (p >= p_last) return;   // whole 16-lane group
     float t = INFINITY, gv = INFINITY;
     if (p < n) {
         const int64_t q = perm[p];
@@ -324,6 +326,126 @@ __global__ __launch_bounds__(256) void sum_i32_kernel(const int32_t* __restrict_
     if ((threadIdx.x & 63) == 0) atomicAdd(out, (unsigned long long)acc);
 }
 
+
+// ---- row-sharded builds (gt_knn_shard.cpp) -----------------------------------------------------------------------
+struct ShardSplits {
+    int64_t s[GT_SYM_MAX_WORLD + 1];
+    int world;
+};
+__device__ __forceinline__ int shard_owner(const ShardSplits& sp, int64_t row) {
+    int o = 0;
+    for (int r = 1; r < sp.world; ++r) o += (row >= sp.s[r]) ? 1 : 0;
+    return o;
+}
+
+__global__ __launch_bounds__(256) void sym_g_kernel(const int64_t n, const int64_t n_pad, const float* __restrict__ thr,
+                                                    const float* __restrict__ hs, float* __restrict__ g) {
+    const int64_t p = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (p >= n_pad) return;
+    g[p] = p < n ? nextafterf(thr[p] + hs[p], -INFINITY) : INFINITY;   // as sym_thresholds_kernel forms it
+}
+
+__global__ __launch_bounds__(256) void invperm_kernel(const int32_t* __restrict__ perm, const int64_t n,
+                                                      int32_t* __restrict__ inv) {
+    const int64_t p = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (p < n) inv[perm[p]] = int32_t(p);
+}
+
+// Candidate records a rank sends to the owners of the rows: {uint32 row (local to the owner), 0, uint64 key}; the
+// candidates this rank collected for sorted position p go to the owner of row perm[p].  A list that overflowed here
+// (count > tcap) sends its tcap entries and one marker record (key = all ones): the owner hands the row to the repairs.
+__global__ __launch_bounds__(256) void shard_count_kernel(const int64_t n, const int32_t* __restrict__ perm,
+                                                          const uint32_t* __restrict__ tcounts, const int tcap,
+                                                          const ShardSplits sp, unsigned long long* __restrict__ cnt) {
+    __shared__ unsigned int hist[GT_SYM_MAX_WORLD];
+    if (threadIdx.x < GT_SYM_MAX_WORLD) hist[threadIdx.x] = 0u;
+    __syncthreads();
+    const int64_t p = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (p < n) {
+        const uint32_t c = tcounts[p];
+        const uint32_t rec = c > uint32_t(tcap) ? uint32_t(tcap) + 1u : c;
+        if (rec) atomicAdd(&hist[shard_owner(sp, perm[p])], rec);
+    }
+    __syncthreads();
+    if (threadIdx.x < sp.world && hist[threadIdx.x]) atomicAdd(cnt + threadIdx.x, (unsigned long long)hist[threadIdx.x]);
+}
+
+// 256 sorted positions per workgroup; cursor[dest] starts at the bucket offset of dest in `out`.  The slots of a
+// workgroup's rows are reserved with ONE global atomic per destination (a million same-address atomics would
+// serialise); each wave then writes the records of 64 of the rows, lanes across the entries of a row.
+__global__ __launch_bounds__(256) void shard_emit_kernel(const int64_t n, const int32_t* __restrict__ perm,
+                                                         const uint64_t* __restrict__ tlists,
+                                                         const uint32_t* __restrict__ tcounts, const int tcap,
+                                                         const ShardSplits sp, unsigned long long* __restrict__ cursor,
+                                                         uint4* __restrict__ out) {
+    __shared__ unsigned int lcnt[GT_SYM_MAX_WORLD];
+    __shared__ unsigned long long lbase[GT_SYM_MAX_WORLD];
+    __shared__ unsigned int r_off[256], r_m[256], r_rl[256];
+    __shared__ unsigned char r_dest[256];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (tid < GT_SYM_MAX_WORLD) lcnt[tid] = 0u;
+    __syncthreads();
+    const int64_t p = int64_t(blockIdx.x) * 256 + tid;
+    uint32_t c = p < n ? tcounts[p] : 0u;
+    const bool over = c > uint32_t(tcap);
+    const uint32_t m = over ? uint32_t(tcap) : c;
+    int dest = 0;
+    uint32_t rl = 0u, off = 0u;
+    if (c) {
+        const int64_t row = perm[p];
+        dest = shard_owner(sp, row);
+        rl = uint32_t(row - sp.s[dest]);
+        off = atomicAdd(&lcnt[dest], m + (over ? 1u : 0u));
+    }
+    r_off[tid] = off;
+    r_m[tid] = m | (over ? 0x80000000u : 0u);
+    r_rl[tid] = rl;
+    r_dest[tid] = (unsigned char)dest;
+    __syncthreads();
+    if (tid < sp.world) lbase[tid] = lcnt[tid] ? atomicAdd(cursor + tid, (unsigned long long)lcnt[tid]) : 0ull;
+    __syncthreads();
+    for (int r = 0; r < 64; ++r) {
+        const int t = w * 64 + r;
+        const uint32_t mm = r_m[t];
+        const uint32_t mr = mm & 0x7FFFFFFFu;
+        if (mm == 0u) continue;   // wave-uniform
+        const unsigned long long base = lbase[r_dest[t]] + r_off[t];
+        const uint32_t rlr = r_rl[t];
+        const uint64_t* tp = tlists + size_t(int64_t(blockIdx.x) * 256 + t) * size_t(tcap);
+        for (uint32_t i = uint32_t(lane); i < mr; i += 64u) {
+            const uint64_t key = tp[i];
+            out[base + i] = make_uint4(rlr, 0u, uint32_t(key), uint32_t(key >> 32));
+        }
+        if ((mm >> 31) && lane == 0) out[base + mr] = make_uint4(rlr, 0u, 0xFFFFFFFFu, 0xFFFFFFFFu);
+    }
+}
+
+struct OwnedRow {
+    int32_t r0, r1;
+    __device__ bool operator()(const int32_t& row) const { return row >= r0 && row < r1; }
+};
+
+// the owner's side: records from every rank into the lists of the owned rows (slots from the row counters; a count
+// beyond tcap marks the row as overflowed, as in the single-rank pass, and so does bit 31, set by a marker record)
+__global__ __launch_bounds__(256) void shard_scatter_kernel(const uint4* __restrict__ recs, const int64_t n_recs,
+                                                            const int64_t nloc, const int tcap,
+                                                            uint64_t* __restrict__ lists, uint32_t* __restrict__ counts,
+                                                            uint32_t* __restrict__ bad) {
+    const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= n_recs) return;
+    const uint4 r = recs[i];
+    if (int64_t(r.x) >= nloc) {
+        atomicAdd(bad, 1u);
+        return;
+    }
+    if (r.z == 0xFFFFFFFFu && r.w == 0xFFFFFFFFu) {
+        atomicOr(&counts[r.x], 0x80000000u);   // the marker takes no slot: every slot below the count holds a key
+        return;
+    }
+    const uint32_t slot = atomicAdd(&counts[r.x], 1u) & 0x7FFFFFFFu;
+    if (slot < uint32_t(tcap)) lists[size_t(r.x) * size_t(tcap) + slot] = (uint64_t(r.w) << 32) | uint64_t(r.z);
+}
+
 }  // namespace
 
 int gt_sym_gather(gt_ctx* ctx, const int32_t* perm, int64_t n_pad_s, void* Ys, float* hs) {
@@ -337,22 +459,86 @@ int gt_sym_gather(gt_ctx* ctx, const int32_t* perm, int64_t n_pad_s, void* Ys, f
 
 int gt_sym_thresholds(gt_ctx* ctx, const int32_t* perm, int64_t n_pad_s, const float* hs, const uint64_t* lists, int lstride,
                       const uint32_t* counts, int need_m, const ErrModel& err, double rkf, float* thr, float* g, float* gmin,
-                      const DevBuf& work, int cells, unsigned long long* far_total) {
-    const dim3 grid((unsigned)ceil_div64(n_pad_s, 16));
+                      const DevBuf& work, int cells, unsigned long long* far_total, int64_t p_first, int64_t p_last) {
+    if (p_last < 0) p_last = n_pad_s;
+    const dim3 grid((unsigned)ceil_div64(p_last - p_first, 16));
     // landmark adjacency the schedule of launch A was built from (gt_sym_schedule: nbr [L][M] at the head of `work`)
     const int M = std::min(std::min(cells, 32), ctx->order_L);
     const int32_t* nbr = work.as<int32_t>();
     const uint32_t* cell_sorted = ctx->order_cell.as<uint32_t>() + ctx->n;
     if (ctx->dtype == GT_F32)
-        hipLaunchKernelGGL(sym_thresholds_kernel<float>, grid, dim3(256), 0, ctx->stream, ctx->n, n_pad_s, perm,
+        hipLaunchKernelGGL(sym_thresholds_kernel<float>, grid, dim3(256), 0, ctx->stream, ctx->n, p_first, p_last, perm,
                            (const float*)ctx->X, ctx->d, ctx->xn.as<double>(), hs, lists, lstride, counts, need_m,
                            ctx->ymax.as<double>(), err, rkf, thr, g, cell_sorted, nbr, M, far_total);
     else
-        hipLaunchKernelGGL(sym_thresholds_kernel<double>, grid, dim3(256), 0, ctx->stream, ctx->n, n_pad_s, perm,
+        hipLaunchKernelGGL(sym_thresholds_kernel<double>, grid, dim3(256), 0, ctx->stream, ctx->n, p_first, p_last, perm,
                            (const double*)ctx->X, ctx->d, ctx->xn.as<double>(), hs, lists, lstride, counts, need_m,
                            ctx->ymax.as<double>(), err, rkf, thr, g, cell_sorted, nbr, M, far_total);
     GT_HIP(ctx, hipGetLastError());
+    if (gmin) {
+        hipLaunchKernelGGL(sym_gmin_kernel, dim3((unsigned)ceil_div64(n_pad_s, 256)), dim3(256), 0, ctx->stream, n_pad_s, g, gmin);
+        GT_HIP(ctx, hipGetLastError());
+    }
+    return GT_OK;
+}
+
+// thresholds of all rows (gathered from the ranks that seeded them) -> transposed form g and its sub-tile minima
+int gt_sym_g_from_thr(gt_ctx* ctx, int64_t n_pad_s, const float* thr, const float* hs, float* g, float* gmin) {
+    hipLaunchKernelGGL(sym_g_kernel, dim3((unsigned)ceil_div64(n_pad_s, 256)), dim3(256), 0, ctx->stream, ctx->n, n_pad_s, thr,
+                       hs, g);
+    GT_HIP(ctx, hipGetLastError());
     hipLaunchKernelGGL(sym_gmin_kernel, dim3((unsigned)ceil_div64(n_pad_s, 256)), dim3(256), 0, ctx->stream, n_pad_s, g, gmin);
+    GT_HIP(ctx, hipGetLastError());
+    return GT_OK;
+}
+
+int gt_sym_invperm(gt_ctx* ctx, const int32_t* perm, int32_t* inv) {
+    hipLaunchKernelGGL(invperm_kernel, dim3((unsigned)ceil_div64(ctx->n, 256)), dim3(256), 0, ctx->stream, perm, ctx->n, inv);
+    GT_HIP(ctx, hipGetLastError());
+    return GT_OK;
+}
+
+int gt_sym_own_rows(gt_ctx* ctx, const int32_t* perm, int64_t r0, int64_t r1, int32_t* own, DevBuf& tmp) {
+    // stream compaction of perm by ownership (order kept): rocPRIM select; the count lands behind the rows
+    OwnedRow pred{int32_t(r0), int32_t(r1)};
+    size_t bytes = 0;
+    unsigned int* count = reinterpret_cast<unsigned int*>(own + (r1 - r0));
+    GT_HIP(ctx, rocprim::select(nullptr, bytes, perm, own, count, size_t(ctx->n), pred, ctx->stream));
+    GT_HIP(ctx, tmp.reserve(bytes));
+    GT_HIP(ctx, rocprim::select(tmp.p, bytes, perm, own, count, size_t(ctx->n), pred, ctx->stream));
+    return GT_OK;
+}
+
+static ShardSplits make_splits(int world, const int64_t* splits) {
+    ShardSplits sp;
+    sp.world = world;
+    for (int r = 0; r <= world; ++r) sp.s[r] = splits[r];
+    return sp;
+}
+
+int gt_sym_shard_count(gt_ctx* ctx, const int32_t* perm, const uint32_t* tcounts, int tcap, int world, const int64_t* splits,
+                       unsigned long long* cnt) {
+    if (world < 1 || world > GT_SYM_MAX_WORLD) GT_FAIL(ctx, GT_E_ARG, "sym shard: bad world size");
+    GT_HIP(ctx, hipMemsetAsync(cnt, 0, size_t(world) * sizeof(unsigned long long), ctx->stream));
+    hipLaunchKernelGGL(shard_count_kernel, dim3((unsigned)ceil_div64(ctx->n, 256)), dim3(256), 0, ctx->stream, ctx->n, perm,
+                       tcounts, tcap, make_splits(world, splits), cnt);
+    GT_HIP(ctx, hipGetLastError());
+    return GT_OK;
+}
+
+int gt_sym_shard_emit(gt_ctx* ctx, const int32_t* perm, const uint64_t* tlists, const uint32_t* tcounts, int tcap, int world,
+                      const int64_t* splits, unsigned long long* cursor, void* out) {
+    hipLaunchKernelGGL(shard_emit_kernel, dim3((unsigned)ceil_div64(ctx->n, 256)), dim3(256), 0, ctx->stream, ctx->n, perm, tlists,
+                       tcounts, tcap, make_splits(world, splits), cursor, reinterpret_cast<uint4*>(out));
+    GT_HIP(ctx, hipGetLastError());
+    return GT_OK;
+}
+
+int gt_sym_shard_scatter(gt_ctx* ctx, const void* recs, int64_t n_recs, int64_t nloc, int tcap, uint64_t* lists,
+                         uint32_t* counts, uint32_t* bad) {
+    if (n_recs <= 0) return GT_OK;
+    hipLaunchKernelGGL(shard_scatter_kernel, dim3((unsigned)ceil_div64(n_recs, 256)), dim3(256), 0, ctx->stream,
+                       reinterpret_cast<const uint4*>(recs), n_recs, nloc, tcap, lists, counts, bad);
     GT_HIP(ctx, hipGetLastError());
     return GT_OK;
 }

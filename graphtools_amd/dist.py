@@ -4,6 +4,9 @@ The N x N affinity build shards by row blocks: rank g own
 ``[splits[g], splits[g+1])`` and every rank needs all N points as the database side.
 
   1. all-gather of the points        (each rank contributes its row slice; RCCL all-gather)
+  1b. symmetric candidate pass       gt_graph_sym_*: every unordered row pair scored once, 1/world of them per rank;
+                                      all-gather of per-row thresholds (4 B per row), all-to-all of candidate records
+                                      (skipped, on all ranks alike, where the pass does not apply)
   2. local work                      gt_graph_begin: kNN -> bandwidth -> radius pass -> affinities
   3. all-to-all of transposed triplets {row, col, value} (16 B each) bucketed by the owner of ``row``
                                       gt_graph_emit fills the send buffer, RCCL all-to-all moves it
@@ -13,6 +16,8 @@ The N x N affinity build shards by row blocks: rank g own
 torch is used for device buffers and collectives only; all numerics are in libgraphtools_amd.so.
 The communication helpers work on CPU tensors with the gloo backend too (tests/test_dist_cpu.py).
 """
+import os
+
 import numpy as np
 
 WORDS_PER_TRIPLET = 2  # a triplet {uint32 row, uint32 col, float64 value} travels as two int64 words
@@ -152,13 +157,54 @@ class ShardedKnnGraph(object):
                                    np.float32 if full.dtype == torch.float32 else np.float64)
         return full
 
-    def build(self, params):
+    def symmetric_candidates(self, params):
+        """The symmetric candidate pass split over the ranks (gt_knn_shard.cpp): each rank scores 1/world of the
+        unordered row pairs; two small collectives (thresholds, far-kept count) and one all-to-all of candidate
+        records.  Returns True when the owned rows' candidate lists are ready for ``graph_begin``, False when the
+        pass does not apply (every rank agrees) and ``graph_begin`` will run the classic pass."""
+        import torch
+
+        dist = _dist()
+        ctx = self.ctx
+        device = self._points.device
+        if not hasattr(ctx, "graph_sym_plan"):
+            return False
+        ok, n_pad, sorted_splits = ctx.graph_sym_plan(params, self.world, self.rank, self.splits)
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int64, device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        if int(flag.item()) == 0:
+            return False
+        rows = int(sorted_splits[self.rank + 1] - sorted_splits[self.rank])
+        thr_local = torch.empty(max(rows, 1), dtype=torch.float32, device=device)
+        far = ctx.graph_sym_seed(thr_local.data_ptr())
+        thr_all = allgather_vector(thr_local[:rows], sorted_splits, self.group).contiguous()
+        far_t = torch.tensor([far], dtype=torch.int64, device=device)
+        dist.all_reduce(far_t, group=self.group)
+        if thr_all.is_cuda:
+            torch.cuda.synchronize(device)
+        ok, send_counts = ctx.graph_sym_collect(thr_all.data_ptr(), int(far_t.item()), self.world)
+        if not ok:      # the predictor saw the summed count: the same verdict on every rank
+            return False
+        total = int(send_counts.sum())
+        send = torch.empty(max(total, 1) * WORDS_PER_TRIPLET, dtype=torch.int64, device=device)
+        ctx.graph_sym_emit(send.data_ptr() if total > 0 else 0)
+        recv, recv_counts = exchange_triplets(send[: total * WORDS_PER_TRIPLET], send_counts, self.group)
+        if recv.is_cuda:
+            torch.cuda.synchronize(device)
+        n_recv = int(recv_counts.sum())
+        ctx.graph_sym_finish(recv.data_ptr() if n_recv > 0 else 0, n_recv)
+        return True
+
+    def build(self, params, symmetric="auto"):
         """kernel + diffusion operator for the owned rows; returns (nnz_local, flags)."""
         import torch
 
         dist = _dist()
         ctx = self.ctx
         device = self._points.device
+        # (a single rank has the whole pass in gt_graph_begin; GT_SHARD_SYM_FORCE=1 runs the staged form anyway - development)
+        staged = self.world > 1 or os.environ.get("GT_SHARD_SYM_FORCE") == "1"
+        self.symmetric_used = bool(symmetric) and staged and self.symmetric_candidates(params)
         send_counts = ctx.graph_begin(params, self.world, self.rank, self.splits)
         total = int(send_counts.sum())
         send = torch.empty(max(total, 1) * WORDS_PER_TRIPLET, dtype=torch.int64, device=device)

@@ -166,6 +166,27 @@ int gt_graph_finish(gt_ctx* ctx, const void* recv_buf_dev, int64_t n_recv, int64
  * degrees; the caller all-gathers the degree vectors (GT_VEC_DEGREE) into one n-vector on the device and
  * calls gt_graph_anisotropy, which rescales K (base.py:579-592) and then forms P. */
 int gt_graph_anisotropy(gt_ctx* ctx, const double* degree_all_dev);
+/* Row-sharded builds, optional first phase: the symmetric candidate pass (every unordered pair of rows scored once,
+ * DESIGN.md 3.6) split over the ranks - each rank scores 1/world of the pairs instead of its rows against everything.
+ * Every rank holds all points and calls, in order (a rank may stop after any call whose `applies` comes back 0, as long
+ * as ALL ranks stop - the host all-reduces the flag - and gt_graph_begin then runs the classic candidate pass):
+ *   gt_graph_sym_plan    applies (out): this context can run it for these parameters; n_pad_sorted, sorted_splits
+ *                        [world + 1] (out): positions of the shared cell-sorted row order whose thresholds each rank seeds
+ *   gt_graph_sym_seed    thr_local (device, float32 [sorted_splits[rank+1] - sorted_splits[rank]], out), far_local (out)
+ *                        -> the host all-gathers thr_local into float32 [n_pad_sorted] and sums far_local over the ranks
+ *   gt_graph_sym_collect thr_all (device), far_total; applies (out), send_counts [world] (out, 16-byte records
+ *                        {uint32 row local to its owner, uint32 0, uint64 candidate key})
+ *   gt_graph_sym_emit    records bucketed by destination rank into the caller's device buffer
+ *                        -> the host moves them with the all-to-all it uses for the triplets
+ *   gt_graph_sym_finish  received records (device, n_recv of them) -> candidate lists of the owned rows
+ * and then gt_graph_begin with the same params / world / rank / row_splits, which consumes the lists.  No reference
+ * counterpart: the reference is single-process (its search is sklearn's kneighbors, graphs.py:883). */
+int gt_graph_sym_plan(gt_ctx* ctx, const gt_knn_params* params, int32_t world, int32_t rank, const int64_t* row_splits,
+                      int32_t* applies, int64_t* n_pad_sorted, int64_t* sorted_splits);
+int gt_graph_sym_seed(gt_ctx* ctx, void* thr_local_dev, int64_t* far_local);
+int gt_graph_sym_collect(gt_ctx* ctx, const void* thr_all_dev, int64_t far_total, int32_t* applies, int64_t* send_counts);
+int gt_graph_sym_emit(gt_ctx* ctx, void* send_buf_dev);
+int gt_graph_sym_finish(gt_ctx* ctx, const void* recv_buf_dev, int64_t n_recv);
 /* single-GPU convenience: begin + emit + finish with an internal buffer */
 int gt_graph_build(gt_ctx* ctx, const gt_knn_params* params, int64_t* out_nnz, uint32_t* flags);
 

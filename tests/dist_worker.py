@@ -20,6 +20,7 @@ import oracle  # noqa: E402
 from graphtools_amd import dist as gdist  # noqa: E402
 
 TRIPLET = np.dtype([("row", np.uint32), ("col", np.uint32), ("val", np.float64)])
+SYMREC = np.dtype([("row", np.uint32), ("pad", np.uint32), ("key", np.uint64)])
 
 
 def _view(ptr, count):
@@ -40,7 +41,77 @@ class FakeCtx(object):
         self.X = np.frombuffer((ctypes.c_char * (n * d * np.dtype(dtype).itemsize)).from_address(ptr),
                                dtype=dtype).reshape(n, d).copy()
 
+    # ---- the sharded symmetric candidate pass (gt_graph_sym_*): a miniature with the same call sequence and buffer
+    # contracts - thresholds are position numbers, every rank contributes a known set of records per row - so that the
+    # host side (flag agreement, threshold all-gather, far-count all-reduce, record all-to-all) is checked end to end
+    sym_applies = True      # what this rank's plan answers
+    sym_refuse_at_collect = False
+    sym_ready = False
+    sym_consumed = False
+    calls = ()
+
+    @staticmethod
+    def _sym_records(sender, n, world):
+        """(row, key) pairs rank `sender` collected: row j gets (sender + j) % 3 of them"""
+        rows = np.repeat(np.arange(n), (sender + np.arange(n)) % 3)
+        keys = (np.uint64(sender) << np.uint64(40)) | (rows.astype(np.uint64) << np.uint64(8)) | \
+            (np.arange(len(rows), dtype=np.uint64) & np.uint64(0xFF))
+        return rows, keys
+
+    def graph_sym_plan(self, params, world, rank, splits):
+        self.calls = self.calls + ("plan",)
+        self.world, self.rank, self.splits = world, rank, np.asarray(splits)
+        n = self.X.shape[0]
+        self.n_pad = -(-n // 8) * 8
+        nb = self.n_pad // 8
+        self.sorted_splits = np.array([(nb * r // world) * 8 for r in range(world + 1)], dtype=np.int64)
+        return self.sym_applies, self.n_pad, self.sorted_splits
+
+    def graph_sym_seed(self, ptr):
+        self.calls = self.calls + ("seed",)
+        p0, p1 = int(self.sorted_splits[self.rank]), int(self.sorted_splits[self.rank + 1])
+        out = np.frombuffer((ctypes.c_char * ((p1 - p0) * 4)).from_address(ptr), dtype=np.float32)
+        out[:] = 0.5 * np.arange(p0, p1)
+        return 10 + self.rank
+
+    def graph_sym_collect(self, ptr, far_total, world):
+        self.calls = self.calls + ("collect",)
+        thr = np.frombuffer((ctypes.c_char * (self.n_pad * 4)).from_address(ptr), dtype=np.float32)
+        assert np.array_equal(thr, 0.5 * np.arange(self.n_pad, dtype=np.float32)), "thresholds were not gathered in order"
+        assert far_total == sum(10 + r for r in range(world)), far_total
+        if self.sym_refuse_at_collect:
+            return False, np.zeros(world, dtype=np.int64)
+        rows, keys = self._sym_records(self.rank, self.X.shape[0], world)
+        owner = np.searchsorted(self.splits, rows, side="right") - 1
+        order = np.argsort(owner, kind="stable")
+        self._sym_send = (rows[order] - self.splits[owner[order]], keys[order])
+        return True, np.bincount(owner, minlength=world).astype(np.int64)
+
+    def graph_sym_emit(self, ptr):
+        self.calls = self.calls + ("emit",)
+        rl, keys = self._sym_send
+        out = np.frombuffer((ctypes.c_char * (len(rl) * 16)).from_address(ptr), dtype=SYMREC) if len(rl) else np.zeros(0, SYMREC)
+        out["row"][:] = rl
+        out["pad"][:] = 0
+        out["key"][:] = keys
+
+    def graph_sym_finish(self, ptr, n_recv):
+        self.calls = self.calls + ("finish",)
+        got = np.frombuffer((ctypes.c_char * (n_recv * 16)).from_address(ptr), dtype=SYMREC) if n_recv else np.zeros(0, SYMREC)
+        r0, r1 = int(self.splits[self.rank]), int(self.splits[self.rank + 1])
+        assert np.all(got["row"] < r1 - r0), "received a record for a foreign row"
+        want = []
+        for s in range(self.world):
+            rows, keys = self._sym_records(s, self.X.shape[0], self.world)
+            sel = (rows >= r0) & (rows < r1)
+            want.append(np.stack([(rows[sel] - r0).astype(np.uint64), keys[sel]], axis=1))
+        want = np.concatenate(want)
+        have = np.stack([got["row"].astype(np.uint64), got["key"]], axis=1)
+        assert np.array_equal(want[np.lexsort(want.T[::-1])], have[np.lexsort(have.T[::-1])]), "records lost or duplicated"
+        self.sym_ready = True
+
     def graph_begin(self, params, world, rank, splits):
+        self.sym_consumed, self.sym_ready = self.sym_ready, False
         self.p, self.world, self.rank, self.splits = params, world, rank, np.asarray(splits)
         r0, r1 = int(splits[rank]), int(splits[rank + 1])
         self.r0, self.r1 = r0, r1
@@ -137,6 +208,23 @@ def main():
         K_full.sort_indices()
         block = K_full[g.splits[rank]:g.splits[rank + 1]]
         assert (g.ctx.K != block).nnz == 0, "sharded rows differ from the single-process oracle (%s)" % symm
+        assert g.symmetric_used and g.ctx.sym_consumed, "the symmetric candidate stages did not run"
+        assert g.ctx.calls == ("plan", "seed", "collect", "emit", "finish"), g.ctx.calls
+
+    # 5. the symmetric stages are all-or-nothing: one rank's plan declines -> nobody seeds; the predictor refuses at the
+    #    collect stage (same summed count everywhere) -> nobody exchanges; the build itself is unaffected
+    for scenario in ("plan", "collect", "off"):
+        c = FakeCtx()
+        c.sym_applies = not (scenario == "plan" and rank == 1)
+        c.sym_refuse_at_collect = scenario == "collect"
+        g = gdist.ShardedKnnGraph(c, Xg.shape[0])
+        g.gather_points(torch.from_numpy(Xg[g.splits[rank]:g.splits[rank + 1]].copy()))
+        g.build(FakeParams(10, 20, 1e-4, "+"), symmetric=False if scenario == "off" else "auto")
+        assert not g.symmetric_used and not c.sym_consumed
+        assert c.calls == {"plan": ("plan",), "collect": ("plan", "seed", "collect"), "off": ()}[scenario], (scenario, c.calls)
+        K_full = sparse.csr_matrix(oracle.knn_graph(Xg, knn=10, decay=20, kernel_symm="+")[0])
+        K_full.sort_indices()
+        assert (c.K != K_full[g.splits[rank]:g.splits[rank + 1]]).nnz == 0
     dist.barrier()
     dist.destroy_process_group()
     print("rank %d ok" % rank)
