@@ -275,6 +275,10 @@ int gt_set_option(gt_ctx* ctx, const char* name, const char* value) {
         ctx->sym_stride = std::max(0, std::atoi(value));
         return GT_OK;
     }
+    if (k == "select_sym_shard_group") {
+        ctx->sym_shard_group = std::max(1, std::atoi(value));
+        return GT_OK;
+    }
     if (k == "select_sym_nseg") {
         ctx->sym_nseg = std::min(8, std::max(0, std::atoi(value)));
         return GT_OK;

@@ -17,12 +17,16 @@ struct SymDev {
     int32_t tile_stride = 0;
     // row-sharded builds (gt_knn_shard.cpp): the sched 1 launch covers the query blocks [block0, block0 + nblk) only
     // (nblk = 0: all of them); a MODE 2 launch walks, for every query block I, the nseg pieces
-    // ((shard_rank + I) % shard_world) * nseg + 0 .. nseg-1 of the block's walk cut into shard_world * nseg pieces -
-    // the ranks together cover every piece once, and the hit-rich first pieces go round
+    // ((shard_rank + I / shard_group) % shard_world) * nseg + 0 .. nseg-1 of the block's walk cut into shard_world * nseg
+    // pieces - the ranks together cover every piece once, the hit-rich first pieces go round, and the blocks of a
+    // group (neighbours on an XCD) stream the same window of the database
     int32_t block0 = 0;
     int32_t nblk = 0;
     int32_t shard_world = 1;
     int32_t shard_rank = 0;
+    int32_t shard_group = 1;
+    int32_t list_shift = 0;    // sched 1: the tile list of query block b is list b >> list_shift (narrow 128-row
+                               // workgroups on lists made for 256-row blocks)
 };
 
 struct SelectArgs {

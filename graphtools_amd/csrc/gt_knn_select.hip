@@ -345,7 +345,7 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
             const int nseg = sy.nseg > 0 ? sy.nseg : 1;
             seg = int(bidx % nseg);
             bidx /= nseg;
-            if (sy.shard_world > 1) seg += int((int64_t(sy.shard_rank) + bidx) % sy.shard_world) * nseg;
+            if (sy.shard_world > 1) seg += int((int64_t(sy.shard_rank) + bidx / sy.shard_group) % sy.shard_world) * nseg;
         } else {
             bidx += sy.block0;
         }
@@ -380,8 +380,8 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
             t_end = int(int64_t(walk) * (seg + 1) / nseg);
             if (t_begin >= t_end) return;
         } else {
-            t_end = sy.tile_cnt[bidx];
-            tl_base = sy.tile_list + size_t(bidx) * size_t(sy.tile_stride);
+            t_end = sy.tile_cnt[bidx >> sy.list_shift];
+            tl_base = sy.tile_list + size_t(bidx >> sy.list_shift) * size_t(sy.tile_stride);
             tl_cache = tl_base[lane < t_end ? lane : 0];
         }
     }
@@ -1065,7 +1065,7 @@ int launch_one(gt_ctx* ctx, const SelectArgs& a) {
         GT_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         int(lds_bytes)));
     }
-    if (a.sym.nblk > 0 && (MODE != 0 || a.sym.sched != 1 || a.sym.block0 < 0 || a.sym.block0 + a.sym.nblk > nblocks))
+    if (a.sym.nblk > 0 && (MODE != 0 || a.sym.sched != 1 || a.sym.block0 < 0 || int64_t(a.sym.block0) + a.sym.nblk > a.n_pad / C::BQ))
         GT_FAIL(ctx, GT_E_ARG, "knn_select: a block range needs the own-neighbourhood schedule");
     const int64_t grid_x = MODE == 2 ? nblocks * a.sym.nseg : (a.sym.nblk > 0 ? a.sym.nblk : nblocks);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid_x, (unsigned)nsplit), dim3(256), lds_bytes, ctx->stream, a.Yp,

@@ -139,6 +139,14 @@ int gt_knn_shard_seed(gt_ctx* ctx, float* thr_local, int64_t* far_local) {
         a.sym.tile_stride = tile_stride;
         a.sym.block0 = int32_t(p0 / bq);
         a.sym.nblk = int32_t((p1 - p0) / bq);
+        if (ctx->DP <= 64 && bq == 256 && ctx->narrow_mode != 0) {
+            // a rank's share is a fraction of a round of 256-row workgroups and every workgroup walks its whole tile
+            // list: 128-row workgroups (one query tile per wave) double the waves that hide each other's latencies
+            a.narrow = 1;
+            a.sym.list_shift = 1;
+            a.sym.block0 *= 2;
+            a.sym.nblk *= 2;
+        }
         int keep = std::max(ctx->samp_keep > 0 ? ctx->samp_keep : 16, need_m);
         keep += keep & 1;
         a.samp_stride = 0;
@@ -212,12 +220,14 @@ int gt_knn_shard_collect(gt_ctx* ctx, const float* thr_all, int64_t far_total, i
     a.sym.tcap = tcap;
     a.sym.shard_world = k->sh_world;
     a.sym.shard_rank = k->sh_rank;
+    a.sym.shard_group = std::max(1, ctx->sym_shard_group);
     {
         const int64_t slots = int64_t(ctx->n_cu) * 3, nb = n_pad_s / bq;
         int best = 1;
         double best_cost = 1e30;
         for (int sgm = 1; sgm <= 8; ++sgm) {
-            const double cost = double(ceil_div64(nb * sgm, slots)) / sgm + 0.03 * sgm;
+            // (a work item is 1/world as long as a single rank's: its fixed costs weigh more)
+            const double cost = double(ceil_div64(nb * sgm, slots)) / sgm + 0.1 * sgm;
             if (cost < best_cost - 1e-9) best_cost = cost, best = sgm;
         }
         a.sym.nseg = ctx->sym_nseg > 0 ? std::min(ctx->sym_nseg, 8) : best;

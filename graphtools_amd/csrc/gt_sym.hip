@@ -155,13 +155,20 @@ __global__ __launch_bounds__(64) void landmark_neighbours_kernel(const _Float16*
                                                                  const int M, int32_t* __restrict__ nbr) {
     extern __shared__ float dist[];   // [L]
     const int a = blockIdx.x, lane = threadIdx.x;
-    const _Float16* ra = Yl + size_t(a) * DP;
+    // rows are DP halves = DP/8 16-byte chunks (DP is a multiple of 16): one vector load per 8 features
+    typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+    const half8* ra = reinterpret_cast<const half8*>(Yl + size_t(a) * DP);
+    const int c8 = DP / 8;
     for (int b = lane; b < L; b += 64) {
-        const _Float16* rb = Yl + size_t(b) * DP;
+        const half8* rb = reinterpret_cast<const half8*>(Yl + size_t(b) * DP);
         float acc = 0.f;
-        for (int k = 0; k < DP; ++k) {
-            const float df = float(ra[k]) - float(rb[k]);
-            acc = fmaf(df, df, acc);
+        for (int c = 0; c < c8; ++c) {
+            const half8 va = ra[c], vb = rb[c];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float df = float(va[e]) - float(vb[e]);
+                acc = fmaf(df, df, acc);
+            }
         }
         dist[b] = acc;
     }
