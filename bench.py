@@ -231,7 +231,8 @@ def main():
             n_pad = -(-n // 256) * 256
             nb = n_pad // 256
             walk_tiles = 2 * (1 + (nb - 1) // 2) + (0 if nb % 2 else 2)
-            executed = 2.0 * d * 256 * 128 * (nb * walk_tiles + kst.get("sym_seed_tiles", 0))
+            # (row-sharded: every rank walks 1/world of the pieces and seeds 1/world of the blocks)
+            executed = 2.0 * d * 256 * 128 * (nb * walk_tiles + kst.get("sym_seed_tiles", 0)) / world
             kernel_name = "%s + its threshold-seeding launch knn_select_kernel<64, 8, 0, 2> (symmetric f16x1 MFMA candidate " \
                           "pass, knn_precision=%s): every unordered pair of rows scored once" % (SYM_KERNEL, args.knn_precision)
         else:

@@ -218,8 +218,8 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
             ErrModel em = gt_err_model(ctx, 2);
             em.rel += 8.0 * 5.9604644775390625e-08;
             ra.err = em;
-            GT_HIP(ctx, k->sym_stat.reserve(8 * sizeof(unsigned long long)));
-            GT_HIP(ctx, hipMemsetAsync(k->sym_stat.p, 0, 8 * sizeof(unsigned long long), ctx->stream));
+            // (the counters of the seeding stage - far-kept rows [2], tiles [5] - stay; only the re-rank's own start at 0)
+            GT_HIP(ctx, hipMemsetAsync(k->sym_stat.p, 0, 2 * sizeof(unsigned long long), ctx->stream));
             GT_HIP(ctx, hipMemsetAsync(k->unproven.p, 0, sizeof(uint32_t), ctx->stream));
             SymRerank sr;
             sr.tlists = k->sh_lists.as<uint64_t>();

@@ -108,7 +108,8 @@ int gt_knn_shard_seed(gt_ctx* ctx, float* thr_local, int64_t* far_local) {
         StageSpan span(ctx, "sym_prepare");
         GT_TRY(gt_sym_gather(ctx, perm, n_pad_s, k->Ycs.p, k->hnegs.as<float>()));
         GT_TRY(gt_sym_schedule(ctx, n_pad_s, bq, bn, ctx->sym_cells, stride_a, ctx->sym_max_nb, tile_stride, k->sym_work,
-                               k->sym_tiles.as<int32_t>(), k->sym_tile_cnt.as<int32_t>(), nullptr));
+                               k->sym_tiles.as<int32_t>(), k->sym_tile_cnt.as<int32_t>(),
+                               k->sym_stat.as<unsigned long long>() + 5));   // (tiles of ALL blocks; this rank walks 1/world)
     }
     // the lists of launch A are addressed by sorted position: a base pointer p0 rows before the buffer keeps the
     // kernels' indexing (only positions [p0, p1) are touched)
