@@ -1058,7 +1058,8 @@ static int graph_begin_impl(gt_ctx* ctx, const gt_knn_params* params, int32_t wo
     if (count_owners) {
         // exclusive scan of the owner-major counts: slot of every (row, owner) pair inside the bucketed send buffer
         GT_HIP(ctx, g->ownerpos.reserve(size_t(int64_t(world) * g->nloc + 1) * sizeof(int64_t)));
-        if (world == 1 && !external && k->ordered && k->nq == g->nloc && g->r0 == 0) {
+        const bool sorted_buf = world == 1 && !external && k->ordered && k->nq == g->nloc && g->r0 == 0;
+        if (sorted_buf) {
             // buffer in cell-sorted row order (see gather_counts_kernel)
             const int32_t* perm = k->qorder.as<int32_t>();
             GT_HIP(ctx, g->cnt_sorted.reserve(size_t(g->nloc) * sizeof(int32_t)));
@@ -1074,8 +1075,9 @@ static int graph_begin_impl(gt_ctx* ctx, const gt_knn_params* params, int32_t wo
             GT_TRY(exclusive_scan(ctx, g->ownercnt.as<int32_t>(), nullptr, int64_t(world) * g->nloc, g->ownerpos.as<int64_t>(),
                                   g->scan_tmp));
         }
-        std::vector<int64_t> edge(world + 1);
-        for (int r = 0; r <= world; ++r)
+        std::vector<int64_t> edge(world + 1, 0);
+        // (sorted buffer, one rank: row 0 does not sit at slot 0 - only the total, behind the last row, is an edge)
+        for (int r = sorted_buf ? world : 0; r <= world; ++r)
             GT_HIP(ctx, hipMemcpyAsync(&edge[r], g->ownerpos.as<int64_t>() + int64_t(r) * g->nloc, sizeof(int64_t),
                                        hipMemcpyDeviceToHost, ctx->stream));
         GT_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -126,6 +126,20 @@ def test_graph_float64_input():
     assert_csr_close(G.P, P0)
 
 
+def test_grouped_queries_whose_first_row_is_not_first_in_the_order(hip_ctx):
+    """points far from the origin: the float16 cell assignment cannot tell them apart, so row 0 need not lead the
+    cell-sorted order the triplet buffer of a single-rank build is laid out in (its size is the scan's total, not the
+    distance between two rows' slots)"""
+    X = (np.random.default_rng(23).standard_normal((803, 7)) * 0.3 + 25.0).astype(np.float32)
+    hip_ctx.set_option("query_order_min_rows", "1")
+    hip_ctx.set_points(X)
+    p, keep = hip_ctx.make_params(24, 40, 1e-3, None, 1.5, None, "+", None, 0)
+    nnz, flags = hip_ctx.graph_build(p)
+    Kd, Ki, Kp = hip_ctx.graph_fetch_csr(_hip.CSR_K)
+    K0, P0 = oracle.knn_graph(X, knn=24, decay=40, thresh=1e-3, bandwidth_scale=1.5)
+    assert_csr_close(sparse.csr_matrix((Kd, Ki, Kp), shape=(803, 803)), K0)
+
+
 def test_all_rows_through_radius_pass(hip_ctx):
     """huge bandwidth: every row's radius exceeds the candidate table -> radius pass with capacity retries
     and rows longer than the in-register merge (global bitonic path)"""

@@ -70,6 +70,10 @@ def main():
         cfg = dict(kind=str(kind), n=n, d=d, dtype=np.dtype(dtype).name, knn=knn, decay=None if decay is None else float(decay),
                    thresh=thresh, symm=symm, theta=theta, aniso=aniso, distance=distance, bw=str(bw_mode), knn_max=knn_max,
                    bw_scale=bw_scale)
+        if case < int(os.environ.get("GT_FUZZ_FIRST", "0")):
+            continue    # (the random stream is drawn all the same: later cases keep their configuration)
+        if os.environ.get("GT_FUZZ_ECHO"):
+            print("case %d: %s" % (case, json.dumps(cfg)), file=sys.stderr, flush=True)
         try:
             with warnings.catch_warnings():
                 warnings.simplefilter("ignore")
