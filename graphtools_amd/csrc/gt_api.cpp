@@ -156,6 +156,7 @@ int gt_set_points(gt_ctx* ctx, const void* X, int64_t n, int32_t d, int32_t dtyp
     ctx->n = n;
     ctx->fast_ok = -1;
     ctx->sym_ok = -1;
+    ctx->sym_two_ok = -1;
     ctx->d = d;
     ctx->dtype = dtype;
     ctx->DP = gt_choose_dp_prec(d, ctx->prec);
@@ -273,6 +274,10 @@ int gt_set_option(gt_ctx* ctx, const char* name, const char* value) {
     }
     if (k == "select_sym_stride") {
         ctx->sym_stride = std::max(0, std::atoi(value));
+        return GT_OK;
+    }
+    if (k == "select_sym_two_stage") {
+        ctx->sym_two_stage = v == "auto" ? -1 : std::atoi(value);
         return GT_OK;
     }
     if (k == "select_sym_shard_group") {

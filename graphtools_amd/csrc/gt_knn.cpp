@@ -16,7 +16,7 @@ void gt_free_knn_work(gt_ctx* ctx) {
                       &k->d2_lb, &k->fb_rows, &k->fb_count, &k->fb_scratch, &k->gflags, &k->prof, &k->fb_qrows, &k->fb_thr, &k->fb_lists,
                       &k->fb_counts, &k->fb_max, &k->unproven, &k->qorder, &k->qthr0, &k->qlomax_dev, &k->Ycs, &k->hnegs,
                       &k->sym_g, &k->sym_gmin, &k->tlists, &k->tcounts, &k->sym_stat, &k->sym_work, &k->sym_tiles,
-                      &k->sym_tile_cnt, &k->sh_invperm, &k->sh_lists, &k->sh_counts, &k->sh_cnt, &k->sh_own, &k->sh_tmp})
+                      &k->sym_tile_cnt, &k->sh_invperm, &k->sh_lists, &k->sh_counts, &k->sh_cnt, &k->sh_own, &k->sh_tmp, &k->sym_hh, &k->sym_thrh, &k->sym_gh, &k->sym_gminh})
         b->release();
     delete k;
     ctx->knn = nullptr;
@@ -364,6 +364,24 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
                 k->sym_nseg = a.sym.nseg;
             }
             a.thr_in = k->thr_final.as<float>();
+            // two-stage scoring: half the features first, against partial-distance thresholds (gt_sym.hip sym_half_*)
+            const bool two_stage = ctx->DP % 32 == 0 && bq_sym == 256 &&
+                                   (ctx->sym_two_stage > 0 || (ctx->sym_two_stage < 0 && ctx->sym_two_ok != 0));
+            if (two_stage) {
+                const int hd = ctx->DP / 2;
+                GT_HIP(ctx, k->sym_hh.reserve(size_t(n_pad_s) * sizeof(float)));
+                GT_HIP(ctx, k->sym_thrh.reserve(size_t(n_pad_s) * sizeof(float)));
+                GT_HIP(ctx, k->sym_gh.reserve(size_t(n_pad_s) * sizeof(float)));
+                GT_HIP(ctx, k->sym_gminh.reserve(size_t(n_pad_s / 32) * sizeof(float)));
+                StageSpan span(ctx, "sym_prepare");
+                GT_TRY(gt_sym_half_seeds(ctx, k->Ycs.p, n_pad_s, hd, k->sym_hh.as<float>()));
+                GT_TRY(gt_sym_half_thresholds(ctx, perm, n_pad_s, k->thr_final.as<float>(), k->sym_hh.as<float>(), em, hd,
+                                              k->sym_thrh.as<float>(), k->sym_gh.as<float>(), k->sym_gminh.as<float>()));
+                a.sym.half_steps = hd / 16;
+                a.sym.hh = k->sym_hh.as<float>();
+                a.sym.thrh = k->sym_thrh.as<float>();
+                a.sym.gminh = k->sym_gminh.as<float>();
+            }
             {
                 StageSpan span(ctx, "knn_select");
                 GT_TRY(gt_launch_select(ctx, a));

@@ -29,6 +29,7 @@ struct KnnWork {
     // symmetric candidate pass (gt_sym.hip): cell-sorted compact copy + seeds, per-row thresholds in the transposed
     // form and their sub-tile minima, the candidate lists of launch B and their counters
     DevBuf Ycs, hnegs, sym_g, sym_gmin, tlists, tcounts, sym_stat, sym_work, sym_tiles, sym_tile_cnt;
+    DevBuf sym_hh, sym_thrh, sym_gh, sym_gminh;   // two-stage scoring (gt_sym.hip sym_half_*)
     bool sym_used = false;
     int64_t sym_overflow = 0;
     int sym_nseg = 1;
@@ -169,6 +170,10 @@ int gt_sym_gather(gt_ctx* ctx, const int32_t* perm, int64_t n_pad_s, void* Ys, f
 int gt_sym_thresholds(gt_ctx* ctx, const int32_t* perm, int64_t n_pad_s, const float* hs, const uint64_t* lists, int lstride,
                       const uint32_t* counts, int need_m, const ErrModel& err, double rkf, float* thr, float* g, float* gmin,
                       const DevBuf& work, int cells, unsigned long long* far_total, int64_t p_first = 0, int64_t p_last = -1);
+// two-stage scoring of launch B: half seeds of the sorted rows, partial-distance thresholds from the full ones
+int gt_sym_half_seeds(gt_ctx* ctx, const void* Ys, int64_t n_pad_s, int hd, float* hh);
+int gt_sym_half_thresholds(gt_ctx* ctx, const int32_t* perm, int64_t n_pad_s, const float* thr, const float* hh,
+                           const ErrModel& err, int hd, float* thrh, float* gh, float* gminh);
 // row-sharded symmetric pass (gt_knn_shard.cpp)
 #define GT_SYM_MAX_WORLD 64
 int gt_sym_g_from_thr(gt_ctx* ctx, int64_t n_pad_s, const float* thr, const float* hs, float* g, float* gmin);

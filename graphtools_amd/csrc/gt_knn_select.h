@@ -25,6 +25,15 @@ struct SymDev {
     int32_t shard_world = 1;
     int32_t shard_rank = 0;
     int32_t shard_group = 1;
+    // MODE 2, two-stage scoring (partial distances): the unit loop runs only the first `half_steps` k-steps of the chain,
+    // seeded with hh = -|y_h|^2/2 over those features: the result is |x_h|^2/2 - |x_h - y_h|^2/2, and a pair whose PARTIAL
+    // distance already exceeds the row's radius can be dropped; thrh / gminh are the thresholds of that test in the
+    // forward / transposed form (gt_sym.hip sym_half_thresholds_kernel).  Units that pass are recomputed in full on the
+    // cold path and tested as before.  half_steps = 0: off (the unit loop scores all features).
+    int32_t half_steps = 0;
+    const float* hh = nullptr;      // [n_pad]
+    const float* thrh = nullptr;    // [n_pad]
+    const float* gminh = nullptr;   // [n_pad / 32]
     int32_t list_shift = 0;    // sched 1: the tile list of query block b is list b >> list_shift (narrow 128-row
                                // workgroups on lists made for 256-row blocks)
 };

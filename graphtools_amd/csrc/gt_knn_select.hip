@@ -215,6 +215,30 @@ __device__ __forceinline__ void mma_chain_seeded(const Frag<DP, 2>& a, const Fra
     for (int s = 1; s < DP / 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.hi[s], b.hi[s], acc, 0, 0, 0);
 }
 
+// first NS1 k-steps only (MODE 2, two-stage scoring)
+template <int DP, int NS1>
+__device__ __forceinline__ void frag_load_part(Frag<DP, 2>& a, const float* row, int h, int swz) {
+    const f16x8* p = reinterpret_cast<const f16x8*>(row);
+#pragma unroll
+    for (int s = 0; s < NS1; ++s) a.hi[s] = p[(2 * s + h) ^ swz];
+}
+template <int DP, int NS1, int PR>
+__device__ __forceinline__ void frag_load_part(Frag<DP, PR>& a, const float* row, int h, int swz) {
+    a.load(row, h, swz);
+}
+template <int DP, int NS1>
+__device__ __forceinline__ void mma_chain_seeded_part(const Frag<DP, 2>& a, const Frag<DP, 2>& b, const f32x16& seed,
+                                                      f32x16& acc) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.hi[0], b.hi[0], seed, 0, 0, 0);
+#pragma unroll
+    for (int s = 1; s < NS1; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.hi[s], b.hi[s], acc, 0, 0, 0);
+}
+template <int DP, int NS1, int PR>
+__device__ __forceinline__ void mma_chain_seeded_part(const Frag<DP, PR>& a, const Frag<DP, PR>& b, const f32x16& seed,
+                                                      f32x16& acc) {
+    mma_chain_seeded<DP>(a, b, seed, acc);
+}
+
 // Append store that hipcc does not track: a compiler-visible store makes hipcc park the wave on
 // `s_waitcnt vmcnt(0)` at the top of every tile (it guards the reuse of the store's registers), i.e. on the full
 // L2 write-acknowledge latency.  The data registers are protected by the s_nop inside the string; the untracked
@@ -302,7 +326,7 @@ __device__ __forceinline__ float compact_list(uint64_t* __restrict__ lp, const u
 #ifndef GT_SEL_P2_WAVES
 #define GT_SEL_P2_WAVES 3
 #endif
-template <int DP, int NT, int MODE, int PREC>
+template <int DP, int NT, int MODEX, int PREC>
 __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) void knn_select_kernel(
     const float* __restrict__ Yp, const float* __restrict__ hneg, const float* __restrict__ Qp,
     const int32_t* __restrict__ qrows, const int64_t q0, const int32_t nq, const int32_t ntiles,
@@ -311,6 +335,11 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
     const int32_t samp_stride, const int32_t samp_keep, const int32_t samp_end, const int32_t samp2_level,
     const int32_t samp2_keep, const int32_t samp_trig, const int32_t final_keep, const SymDev sy) {
     using C = SelCfg<DP, PREC>;
+    // MODEX 3 = MODE 2 with two-stage scoring: the unit loop runs the first NS1 k-steps against partial-distance
+    // thresholds, the cold path recomputes the survivors in full (SymDev::half_steps)
+    constexpr int MODE = MODEX == 3 ? 2 : MODEX;
+    constexpr bool TWO = MODEX == 3;
+    constexpr int NS1 = TWO ? DP / 32 : DP / 16;   // k-steps of the unit loop (PREC 2)
     unsigned long long t_adm = 0, t_cmp = 0, t_bar = 0, n_cmp = 0, n_adm = 0, t_lvl0 = 0, n_adm_lvl0 = 0;
     const unsigned long long t_start = prof ? __builtin_readcyclecounter() : 0ull;
     constexpr int QT = C::QT, BQ = C::BQ, BN = C::BN, LDP = C::LDP;
@@ -403,6 +432,12 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
         thr[qt] = (MODE == 0) ? ((dbg & 1) ? INFINITY : (thr_in ? thr_in[row - q0] : -INFINITY))
                               : ((qg < nq) ? thr_in[qc] : INFINITY);
         hnq[qt] = (MODE == 2) ? ((qg < nq) ? hneg[row] : -INFINITY) : 0.f;
+        if constexpr (TWO) {
+            // the unit loop tests partial scores: half thresholds / half seeds here, the full ones come back from
+            // memory on the cold path
+            thr[qt] = (qg < nq) ? sy.thrh[qc] : INFINITY;
+            hnq[qt] = (qg < nq) ? sy.hh[row] : -INFINITY;
+        }
     }
 
     // ---- tile staging (global -> registers -> LDS, padded rows), in two halves to halve the staging registers ----
@@ -417,9 +452,9 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
             const int f = tid + u_ * 256;                                                                 \
             stage[u_] = (f < HF4) ? src_[f] : make_float4(0.f, 0.f, 0.f, 0.f);                            \
         }                                                                                                 \
-        if ((HALF_) == 0) stage_h = (tid < BN) ? hneg[size_t(T_) * BN + tid] : 0.f;                       \
+        if ((HALF_) == 0) stage_h = (tid < BN) ? (TWO ? sy.hh : hneg)[size_t(T_) * BN + tid] : 0.f;       \
         if (MODE == 2 && (HALF_) == 0) {                                                                  \
-            stage_gm = (tid < BN / 32) ? sy.gmin[size_t(T_) * (BN / 32) + tid] : 0.f;                     \
+            stage_gm = (tid < BN / 32) ? (TWO ? sy.gminh : sy.gmin)[size_t(T_) * (BN / 32) + tid] : 0.f;  \
         }                                                                                                 \
     }
 #define GT_STAGE_STORE(BUF_, HALF_)                                                                       \
@@ -459,12 +494,12 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
                                              (lds_void*)(lt_ + p_ * 1024u), 16, 0, 0);                     \
         }                                                                                                  \
         if (wu < BN / 64)                                                                                  \
-            __builtin_amdgcn_global_load_lds((glb_void*)(hneg + size_t(T_) * BN + uint32_t(wu * 64) + lv_), \
+            __builtin_amdgcn_global_load_lds((glb_void*)((TWO ? sy.hh : hneg) + size_t(T_) * BN + uint32_t(wu * 64) + lv_), \
                                              (lds_void*)(hn + (BUF_) * BN + wu * 64), 4, 0, 0);            \
         /* MODE 2: only the sub-tile minima of the row thresholds are staged (the cold path reads the rows' own values  \
            from global memory), by a wave that carries no seed piece */                                    \
         if (MODE == 2 && wu == 3 && lv_ < BN / 32)                                                         \
-            __builtin_amdgcn_global_load_lds((glb_void*)(sy.gmin + size_t(T_) * (BN / 32) + lv_),          \
+            __builtin_amdgcn_global_load_lds((glb_void*)((TWO ? sy.gminh : sy.gmin) + size_t(T_) * (BN / 32) + lv_), \
                                              (lds_void*)(gm + (BUF_) * 8), 4, 0, 0);                       \
     }
 
@@ -540,7 +575,7 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
         constexpr int NSUB = BN / 32;
         constexpr int NU = NSUB * QT;
         Frag<DP, PREC> afr[2];
-        afr[0].load(tb + li * LDP, h, aswz);
+        frag_load_part<DP, NS1>(afr[0], tb + li * LDP, h, aswz);
         // three accumulator sets rotate: unit u accumulates into accp[u%3] while the predicates of u-1 read
         // accp[(u-1)%3] and the seeds (-|y|^2/2) of u+1 are fetched from LDS into accp[(u+1)%3]
         f32x16 accp[3];
@@ -582,10 +617,10 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
 // on the row's counter.  All atomics of a unit are in flight together (one memory round trip per unit).
 #define GT_ADMIT2(PA_, SD_, PSB_, PQT_)                                                                    \
     {                                                                                                      \
-        const float tq_ = thr[PQT_];                                                                       \
+        const float tq_ = thrF[PQT_];                                                                      \
         const int ql = (w * QT + (PQT_)) * 32 + li;                                                        \
         const uint32_t qpos_ = uint32_t(qblock + ql);                                                      \
-        const float hq_ = hnq[PQT_];                                                                       \
+        const float hq_ = hnqF[PQT_];                                                                      \
         uint32_t fmask_ = 0u, tmask_ = 0u;                                                                 \
         _Pragma("unroll") for (int e_ = 0; e_ < 16; ++e_) fmask_ |= ((PA_)[e_] > tq_) ? (1u << e_) : 0u;   \
         if (tr_on) {                                                                                       \
@@ -646,10 +681,10 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
 // tiles - are all issued before the first result is looked at.
 #define GT_ADMIT2P(A0_, A1_, SD_, PSB_)                                                                    \
     {                                                                                                      \
-        const float tq0_ = thr[0], tq1_ = thr[QT - 1];                                                     \
+        const float tq0_ = thrF[0], tq1_ = thrF[QT - 1];                                                   \
         const uint32_t qpos0_ = uint32_t(qblock + (w * QT) * 32 + li);                                     \
         const uint32_t qpos1_ = uint32_t(qblock + (w * QT + QT - 1) * 32 + li);                            \
-        const float hq0_ = hnq[0], hq1_ = hnq[QT - 1];                                                     \
+        const float hq0_ = hnqF[0], hq1_ = hnqF[QT - 1];                                                   \
         uint32_t f0_ = 0u, f1_ = 0u, t0_ = 0u, t1_ = 0u;                                                   \
         _Pragma("unroll") for (int e_ = 0; e_ < 16; ++e_) {                                                \
             f0_ |= ((A0_)[e_] > tq0_) ? (1u << e_) : 0u;                                                   \
@@ -767,9 +802,10 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
                 GT_STAGE_LOAD(t_next, 1);
             }
             if (u < NU) {
-                if (!(GT_EXP & 2) && qt == 0 && sb + 1 < NSUB) afr[(sb + 1) & 1].load(tb + ((sb + 1) * 32 + li) * LDP, h, aswz);
+                if (!(GT_EXP & 2) && qt == 0 && sb + 1 < NSUB)
+                    frag_load_part<DP, NS1>(afr[(sb + 1) & 1], tb + ((sb + 1) * 32 + li) * LDP, h, aswz);
                 if constexpr (SEEDREG) {
-                    mma_chain_seeded<DP>(afr[sb & 1], bq[qt], seedr, accp[u % NACC]);
+                    mma_chain_seeded_part<DP, NS1>(afr[sb & 1], bq[qt], seedr, accp[u % NACC]);
                     if (qt == QT - 1 && sb + 1 < NSUB) GT_SEEDR(sb + 1);   // behind the last reader of this sub-tile's seeds
                 } else {
                     if (u + 1 < NU) GT_SEED(u + 1);
@@ -799,7 +835,7 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
                 // of it, and the new reads have the rest of the chain to land.
                 // Then: one MFMA, a few of the max / compare instructions of the previous unit, ...
 #pragma unroll
-                for (int i = 0; i < (PREC == 1 ? 3 * DP / 16 : PREC == 2 ? DP / 16 : DP / 2); ++i) {
+                for (int i = 0; i < (PREC == 1 ? 3 * DP / 16 : PREC == 2 ? NS1 : DP / 2); ++i) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
 #if GT_SEL_DSFIRST
                     if (i == 0) __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);   // DS read (as many as there are)
@@ -821,6 +857,20 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
         if constexpr (MODE == 2) {
             if (__builtin_expect(hitmask != 0u, 0)) {
                 const unsigned long long ts_ = prof ? __builtin_readcyclecounter() : 0ull;
+                // the full thresholds / seeds of the lane's queries (two-stage scoring keeps the half ones in registers)
+                float thrF[QT], hnqF[QT];
+#pragma unroll
+                for (int qt_ = 0; qt_ < QT; ++qt_) {
+                    if constexpr (TWO) {
+                        const int64_t qp_ = qblock + (w * QT + qt_) * 32 + li;
+                        const bool live_ = qp_ < nq && thr[qt_] != INFINITY;   // (INFINITY: pad query, or list overflowed)
+                        thrF[qt_] = live_ ? thr_in[qp_] : INFINITY;
+                        hnqF[qt_] = qp_ < nq ? hneg[qp_] : -INFINITY;
+                    } else {
+                        thrF[qt_] = thr[qt_];
+                        hnqF[qt_] = hnq[qt_];
+                    }
+                }
                 while (hitmask) {   // wave-uniform
                     const int pu = __ffs(int(hitmask)) - 1;
                     const int csb = pu / QT, cqt = pu % QT;
@@ -831,7 +881,9 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
                     f32x16 cs, cacc;
 #pragma unroll
                     for (int g_ = 0; g_ < 4; ++g_) {
-                        const float4 hv_ = *reinterpret_cast<const float4*>(hb + csb * 32 + 8 * g_ + 4 * h);
+                        // (two-stage scoring staged the half seeds: the full ones come from memory)
+                        const float4 hv_ = TWO ? *reinterpret_cast<const float4*>(hneg + size_t(tbase) + csb * 32 + 8 * g_ + 4 * h)
+                                               : *reinterpret_cast<const float4*>(hb + csb * 32 + 8 * g_ + 4 * h);
                         cs[4 * g_ + 0] = hv_.x;
                         cs[4 * g_ + 1] = hv_.y;
                         cs[4 * g_ + 2] = hv_.z;
@@ -1036,9 +1088,10 @@ __global__ __launch_bounds__(256) void assign_cells_kernel(const float* __restri
     }
 }
 
-template <int DP, int NT, int MODE, int PREC>
+template <int DP, int NT, int MODEX, int PREC>
 int launch_one(gt_ctx* ctx, const SelectArgs& a) {
     using C = SelCfg<DP, PREC>;
+    constexpr int MODE = MODEX == 3 ? 2 : MODEX;   // 3: MODE 2 with two-stage scoring
     const int64_t nblocks = ceil_div64(a.nq, C::BQ);
     const int ntiles = int(a.n_pad / C::BN);
     int nsplit = 1;
@@ -1048,7 +1101,7 @@ int launch_one(gt_ctx* ctx, const SelectArgs& a) {
         nsplit = int(std::min<int64_t>(std::max<int64_t>(1, want / nblocks), std::max(1, ntiles / 8)));
         GT_HIP(ctx, hipMemsetAsync(a.counts, 0, size_t(nblocks) * C::BQ * sizeof(uint32_t), ctx->stream));
     }
-    auto kern = knn_select_kernel<DP, NT, MODE, PREC>;
+    auto kern = knn_select_kernel<DP, NT, MODEX, PREC>;
     GT_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     int(C::LDS_BYTES)));
     size_t lds_bytes = MODE == 2 ? C::LDS_BYTES_SYM : C::LDS_BYTES;
@@ -1081,7 +1134,17 @@ template <int DP, int PREC>
 int launch_dp(gt_ctx* ctx, const SelectArgs& a) {
     if (a.mode == 1) return launch_one<DP, 8, 1, PREC>(ctx, a);
     if (a.mode == 2) {
-        if constexpr (PREC == 2) return launch_one<DP, 8, 2, PREC>(ctx, a);
+        if constexpr (PREC == 2) {
+            if (a.sym.half_steps > 0) {
+                if constexpr (DP % 32 == 0 && SelCfg<DP, PREC>::QT == 2) {
+                    if (a.sym.half_steps != DP / 32 || !a.sym.hh || !a.sym.thrh || !a.sym.gminh)
+                        GT_FAIL(ctx, GT_E_ARG, "knn_select: two-stage scoring needs the half seeds and thresholds");
+                    return launch_one<DP, 8, 3, PREC>(ctx, a);
+                }
+                GT_FAIL(ctx, GT_E_ARG, "knn_select: two-stage scoring is built for 32 | DP, 256-row blocks");
+            }
+            return launch_one<DP, 8, 2, PREC>(ctx, a);
+        }
         GT_FAIL(ctx, GT_E_ARG, "knn_select: symmetric collect runs on the single-chain arithmetic only");
     }
     switch (a.nt) {

@@ -222,6 +222,24 @@ int gt_knn_shard_collect(gt_ctx* ctx, const float* thr_all, int64_t far_total, i
     a.sym.shard_world = k->sh_world;
     a.sym.shard_rank = k->sh_rank;
     a.sym.shard_group = std::max(1, ctx->sym_shard_group);
+    if (ctx->DP % 32 == 0 && bq == 256 && (ctx->sym_two_stage > 0 || (ctx->sym_two_stage < 0 && ctx->sym_two_ok != 0))) {
+        // two-stage scoring, as in the single-rank pass (gt_knn.cpp)
+        const int hd = ctx->DP / 2;
+        ErrModel em = gt_err_model(ctx, 2);
+        em.rel += 8.0 * 5.9604644775390625e-08;
+        GT_HIP(ctx, k->sym_hh.reserve(size_t(n_pad_s) * sizeof(float)));
+        GT_HIP(ctx, k->sym_thrh.reserve(size_t(n_pad_s) * sizeof(float)));
+        GT_HIP(ctx, k->sym_gh.reserve(size_t(n_pad_s) * sizeof(float)));
+        GT_HIP(ctx, k->sym_gminh.reserve(size_t(n_pad_s / 32) * sizeof(float)));
+        StageSpan span(ctx, "sym_prepare");
+        GT_TRY(gt_sym_half_seeds(ctx, k->Ycs.p, n_pad_s, hd, k->sym_hh.as<float>()));
+        GT_TRY(gt_sym_half_thresholds(ctx, k->qorder.as<int32_t>(), n_pad_s, k->thr_final.as<float>(), k->sym_hh.as<float>(), em,
+                                      hd, k->sym_thrh.as<float>(), k->sym_gh.as<float>(), k->sym_gminh.as<float>()));
+        a.sym.half_steps = hd / 16;
+        a.sym.hh = k->sym_hh.as<float>();
+        a.sym.thrh = k->sym_thrh.as<float>();
+        a.sym.gminh = k->sym_gminh.as<float>();
+    }
     {
         const int64_t slots = int64_t(ctx->n_cu) * 3, nb = n_pad_s / bq;
         int best = 1;

@@ -334,6 +334,80 @@ __global__ __launch_bounds__(256) void sum_i32_kernel(const int32_t* __restrict_
 }
 
 
+// ---- two-stage scoring of launch B (partial distances) -----------------------------------------------------------
+// hh[p] = -1/2 sum_{k < HD} yc_k^2 over the first HD features of the sorted compact row p (float32, the float16 values
+// as they enter the MFMA): seeded with it, the first HD/16 k-steps of the chain give, for query row x,
+//     A = x_h.y_h - |y_h|^2/2 = |x_h|^2/2 - |x_h - y_h|^2/2        (x_h, y_h: the scaled float16 rows cut at HD)
+// i.e. the PARTIAL squared distance of the pair, which never exceeds the full one.
+__global__ __launch_bounds__(256) void sym_half_seeds_kernel(const _Float16* __restrict__ Ys, const int64_t n,
+                                                             const int64_t n_pad, const int DP, const int HD,
+                                                             float* __restrict__ hh) {
+    const int64_t p = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (p >= n_pad) return;
+    if (p >= n) {
+        hh[p] = -INFINITY;
+        return;
+    }
+    typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+    const half8* r = reinterpret_cast<const half8*>(Ys + size_t(p) * DP);
+    float acc = 0.f;
+    for (int c = 0; c < HD / 8; ++c) {
+        const half8 v = r[c];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc = fmaf(float(v[e]), float(v[e]), acc);
+    }
+    hh[p] = -0.5f * acc;
+}
+
+// Thresholds of the partial test from the full thresholds thr[p] (sorted positions).  The re-rank will claim for row p
+// "every row closer than lb_p is in the list", lb_p = |x|^2 - 2 (thr_p / sc^2 + e) - 1e-9 (...) (rerank_sym_kernel,
+// bound_of_score) - so stage one must let through every pair with |x - y|^2 < lb_p, seen from either side.  Such a pair
+// has scaled float16 rows at most sc sqrt(lb) + 2 Ls apart (Ls: largest rounding residual of a row), on any subset of
+// the features, so A >= |x_h|^2/2 - rho_p - (rounding of A), rho_p = (sc sqrt(lb_p) + 2 Ls)^2 / 2:
+//   forward     A > thrh[p]            thrh[p] = -hh[p] - rho_p - dmax      (rounded down)
+//   transposed  A + hh[x] > gh[p]      gh[p]   = -rho_p - dmax              (rounded down; gminh = its sub-tile minima)
+// dmax bounds the float32 accumulation of HD + 1 terms and the roundings of hh and of the sum A + hh[x] for any pair.
+__global__ __launch_bounds__(256) void sym_half_thresholds_kernel(const int64_t n, const int64_t n_pad,
+                                                                  const int32_t* __restrict__ perm,
+                                                                  const double* __restrict__ xn,
+                                                                  const float* __restrict__ thr,
+                                                                  const float* __restrict__ hh,
+                                                                  const double* __restrict__ ymax2p, const ErrModel err,
+                                                                  const int HD, float* __restrict__ thrh,
+                                                                  float* __restrict__ gh) {
+    const int64_t p = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (p >= n_pad) return;
+    float th = INFINITY, g = INFINITY;
+    if (p < n) {
+        const float t = thr[p];
+        if (!(t > -3.0e38f)) {
+            th = -3.0e38f;   // no threshold was seeded for this row: everything passes, as in the full test
+            g = -3.0e38f;
+        } else {
+            const double u = 5.9604644775390625e-08;
+            const double qs = xn[perm[p]], y2 = ymax2p[0];
+            const double e = gt_err_bound(err, qs, y2);
+            double lb = (qs - 2.0 * (double(t) * err.inv_sc2 + e)) - 1e-9 * (qs + y2);
+            lb = (lb > 0.0 ? lb : 0.0) * (1.0 + 1e-6) + 1e-9 * (qs + y2);
+            const double sc = 1.0 / sqrt(err.inv_sc2);
+            const double Ls = sc * err.abs;                       // (err.abs = 1.001 x the largest residual norm)
+            const double X2 = (sc * sqrt(y2) + Ls) * (sc * sqrt(y2) + Ls);
+            const double dmax = (2.0 * double(HD + 8) * 1.5 + 4.0) * u * X2;
+            const double r = sc * sqrt(lb) + 2.0 * Ls;
+            const double rho = 0.5 * r * r + dmax;
+            const double a = -double(hh[p]) - rho, b = -rho;
+            th = float(a);
+            if (double(th) >= a) th = nextafterf(th, -INFINITY);
+            g = float(b);
+            if (double(g) >= b) g = nextafterf(g, -INFINITY);
+            if (!(th > -3.0e38f)) th = -3.0e38f;
+            if (!(g > -3.0e38f)) g = -3.0e38f;
+        }
+    }
+    thrh[p] = th;
+    gh[p] = g;
+}
+
 // ---- row-sharded builds (gt_knn_shard.cpp) -----------------------------------------------------------------------
 struct ShardSplits {
     int64_t s[GT_SYM_MAX_WORLD + 1];
@@ -495,6 +569,23 @@ int gt_sym_g_from_thr(gt_ctx* ctx, int64_t n_pad_s, const float* thr, const floa
                        hs, g);
     GT_HIP(ctx, hipGetLastError());
     hipLaunchKernelGGL(sym_gmin_kernel, dim3((unsigned)ceil_div64(n_pad_s, 256)), dim3(256), 0, ctx->stream, n_pad_s, g, gmin);
+    GT_HIP(ctx, hipGetLastError());
+    return GT_OK;
+}
+
+int gt_sym_half_seeds(gt_ctx* ctx, const void* Ys, int64_t n_pad_s, int hd, float* hh) {
+    hipLaunchKernelGGL(sym_half_seeds_kernel, dim3((unsigned)ceil_div64(n_pad_s, 256)), dim3(256), 0, ctx->stream,
+                       reinterpret_cast<const _Float16*>(Ys), ctx->n, n_pad_s, ctx->DP, hd, hh);
+    GT_HIP(ctx, hipGetLastError());
+    return GT_OK;
+}
+
+int gt_sym_half_thresholds(gt_ctx* ctx, const int32_t* perm, int64_t n_pad_s, const float* thr, const float* hh,
+                           const ErrModel& err, int hd, float* thrh, float* gh, float* gminh) {
+    hipLaunchKernelGGL(sym_half_thresholds_kernel, dim3((unsigned)ceil_div64(n_pad_s, 256)), dim3(256), 0, ctx->stream, ctx->n,
+                       n_pad_s, perm, ctx->xn.as<double>(), thr, hh, ctx->ymax.as<double>(), err, hd, thrh, gh);
+    GT_HIP(ctx, hipGetLastError());
+    hipLaunchKernelGGL(sym_gmin_kernel, dim3((unsigned)ceil_div64(n_pad_s, 256)), dim3(256), 0, ctx->stream, n_pad_s, gh, gminh);
     GT_HIP(ctx, hipGetLastError());
     return GT_OK;
 }
