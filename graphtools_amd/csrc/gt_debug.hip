@@ -171,6 +171,11 @@ extern "C" int gt_dbg_fetch_sym(gt_ctx* ctx, int32_t which, int64_t count, void*
         case 4: src = k->sym_tile_cnt.p; break;
         case 5: src = ctx->order_cell.as<uint32_t>() + ctx->n; break;
         case 6: src = k->sym_tiles.p; break;
+        case 8: src = k->sym_qcount.p; break;  // entries noted per wave region of the two-stage collect
+        case 9: src = k->counts.p; break;      // rows launch A kept per sorted position
+        case 10: src = k->sym_thrh.p; break;   // two-stage collect: partial-distance thresholds, half seeds, row radii term
+        case 11: src = k->sym_hh.p; break;
+        case 12: src = k->sym_gh.p; break;
         case 7: src = k->sym_work.p; break;    // nbr [L][M] | start [L] | end [L]   // [blocks][tile_stride] tile lists of launch A (count = entries)
         default: return GT_E_ARG;
     }

@@ -16,7 +16,7 @@ void gt_free_knn_work(gt_ctx* ctx) {
                       &k->d2_lb, &k->fb_rows, &k->fb_count, &k->fb_scratch, &k->gflags, &k->prof, &k->fb_qrows, &k->fb_thr, &k->fb_lists,
                       &k->fb_counts, &k->fb_max, &k->unproven, &k->qorder, &k->qthr0, &k->qlomax_dev, &k->Ycs, &k->hnegs,
                       &k->sym_g, &k->sym_gmin, &k->tlists, &k->tcounts, &k->sym_stat, &k->sym_work, &k->sym_tiles,
-                      &k->sym_tile_cnt, &k->sh_invperm, &k->sh_lists, &k->sh_counts, &k->sh_cnt, &k->sh_own, &k->sh_tmp, &k->sym_hh, &k->sym_thrh, &k->sym_gh, &k->sym_gminh})
+                      &k->sym_tile_cnt, &k->sh_invperm, &k->sh_lists, &k->sh_counts, &k->sh_cnt, &k->sh_own, &k->sh_tmp, &k->sym_hh, &k->sym_thrh, &k->sym_gh, &k->sym_gminh, &k->sym_queue, &k->sym_qcount, &k->sym_qdense, &k->sym_qtot, &k->sym_racc})
         b->release();
     delete k;
     ctx->knn = nullptr;
@@ -261,7 +261,12 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
             break;
         }
         if (sym_now && main_prec == 2) {
-            const int64_t n_pad_s = ceil_div64(nq, bq_sym) * bq_sym;
+            // two-stage scoring: half the features first, against partial-distance thresholds (gt_sym.hip sym_half_*);
+            // its collect kernel works on query blocks of up to 1024 rows
+            const bool two_stage = ctx->DP % 32 == 0 && bq_sym == 256 &&
+                                   (ctx->sym_two_stage > 0 || (ctx->sym_two_stage < 0 && ctx->sym_two_ok != 0));
+            const int64_t pad_s = two_stage ? 1024 : bq_sym;
+            const int64_t n_pad_s = ceil_div64(nq, pad_s) * pad_s;
             const int tcap = ctx->sym_tcap;
             const int32_t* perm = k->qorder.as<int32_t>();
             GT_HIP(ctx, k->Ycs.reserve(size_t(n_pad_s) * ctx->DP * sizeof(_Float16)));
@@ -320,9 +325,18 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
                 StageSpan span(ctx, "sym_prepare");
                 GT_TRY(gt_sym_thresholds(ctx, perm, n_pad_s, k->hnegs.as<float>(), k->lists.as<uint64_t>(), int(lcap),
                                          k->counts.as<uint32_t>(), need_m, em, rkf, k->thr_final.as<float>(),
-                                         k->sym_g.as<float>(), k->sym_gmin.as<float>(), k->sym_work, ctx->sym_cells,
+                                         k->sym_g.as<float>(), nullptr, k->sym_work, ctx->sym_cells,
                                          k->sym_stat.as<unsigned long long>() + 2));
+                // rows with a radius far beyond the typical one are orphans as well (gt_sym.hip sym_radius_cut_kernel)
+                GT_HIP(ctx, k->sym_racc.reserve(2 * sizeof(double)));
+                GT_HIP(ctx, hipMemsetAsync(k->sym_racc.p, 0, 2 * sizeof(double), ctx->stream));
+                GT_TRY(gt_sym_radius_sum(ctx, perm, 0, n_pad_s, k->thr_final.as<float>(), em, k->sym_racc.as<double>()));
+                GT_TRY(gt_sym_radius_cut(ctx, perm, k->thr_final.as<float>(), em, k->sym_racc.as<double>(), ctx->sym_radius_cut));
+                GT_TRY(gt_sym_g_from_thr(ctx, n_pad_s, k->thr_final.as<float>(), k->hnegs.as<float>(), k->sym_g.as<float>(),
+                                         k->sym_gmin.as<float>()));
                 GT_HIP(ctx, hipMemsetAsync(k->tcounts.p, 0, size_t(n_pad_s) * sizeof(uint32_t), ctx->stream));
+                GT_TRY(gt_sym_inject_orphans(ctx, 0, n_pad_s, k->thr_final.as<float>(), k->lists.as<uint64_t>(), int(lcap),
+                                             k->counts.as<uint32_t>(), k->tlists.as<uint64_t>(), tcap, k->tcounts.as<uint32_t>()));
             }
             if (ctx->sym_mode < 0) {
                 // launch A kept need_m rows per point: when most of them came from the strided sample instead of the cells
@@ -364,11 +378,8 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
                 k->sym_nseg = a.sym.nseg;
             }
             a.thr_in = k->thr_final.as<float>();
-            // two-stage scoring: half the features first, against partial-distance thresholds (gt_sym.hip sym_half_*)
-            const bool two_stage = ctx->DP % 32 == 0 && bq_sym == 256 &&
-                                   (ctx->sym_two_stage > 0 || (ctx->sym_two_stage < 0 && ctx->sym_two_ok != 0));
             if (two_stage) {
-                const int hd = ctx->DP / 2;
+                const int hd = ctx->sym_two_steps > 0 ? 16 * ctx->sym_two_steps : ctx->DP / 2;
                 GT_HIP(ctx, k->sym_hh.reserve(size_t(n_pad_s) * sizeof(float)));
                 GT_HIP(ctx, k->sym_thrh.reserve(size_t(n_pad_s) * sizeof(float)));
                 GT_HIP(ctx, k->sym_gh.reserve(size_t(n_pad_s) * sizeof(float)));
@@ -381,10 +392,33 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
                 a.sym.hh = k->sym_hh.as<float>();
                 a.sym.thrh = k->sym_thrh.as<float>();
                 a.sym.gminh = k->sym_gminh.as<float>();
+                if (ctx->sym_nseg <= 0) {
+                    // (the collect workgroups of this kernel take 512 rows: NB x nseg items must fill the rounds)
+                    const int64_t slots = int64_t(ctx->n_cu) * 3, nb = ceil_div64(n_pad_s, 512);
+                    int best = 1;
+                    double best_cost = 1e30;
+                    for (int sgm = 1; sgm <= 8; ++sgm) {
+                        const double cost = double(ceil_div64(nb * sgm, slots)) / sgm + 0.01 * sgm;
+                        if (cost < best_cost - 1e-9) best_cost = cost, best = sgm;
+                    }
+                    a.sym.nseg = k->sym_nseg = best;
+                }
+                GT_TRY(gt_sym_queue_prepare(ctx, n_pad_s, a));
             }
             {
                 StageSpan span(ctx, "knn_select");
                 GT_TRY(gt_launch_select(ctx, a));
+            }
+            if (two_stage) {
+                int ok = 0;
+                GT_TRY(gt_sym_queue_finish(ctx, a, &k->sym_cold_entries, &ok));
+                if (!ok) {
+                    // stage one let (nearly) everything through: partial distances say nothing on this point set.  Start
+                    // launch B over with the one-stage kernel, now and for the later builds on these points.
+                    ctx->sym_two_ok = 0;
+                    continue;
+                }
+                if (ctx->sym_two_ok < 0) ctx->sym_two_ok = 1;
             }
             ctx->last_main_prec = 2;
             k->sym_used = true;
@@ -544,6 +578,56 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
             off += rows;
         }
     }
+    return GT_OK;
+}
+
+int gt_sym_queue_prepare(gt_ctx* ctx, int64_t n_pad_s, SelectArgs& a) {
+    KnnWork* k = ctx->knn;
+    // one region per wave of the collect launch (its workgroups take at least 512 rows), sized so that all of them
+    // together hold about one pair in 16 - beyond that stage one is not doing its job
+    const int64_t nwaves = (n_pad_s / 512) * a.sym.nseg * 4;
+    const int64_t units = (n_pad_s / 64) * (n_pad_s / 32) / 2 / std::max(1, a.sym.shard_world);
+    int64_t rcap = 256;
+    while (rcap < 8192 && rcap * nwaves < units / 16) rcap *= 2;
+    GT_HIP(ctx, k->sym_queue.reserve(size_t(nwaves) * size_t(rcap) * sizeof(uint2)));
+    GT_HIP(ctx, k->sym_qcount.reserve(size_t(nwaves) * sizeof(uint32_t)));
+    GT_HIP(ctx, hipMemsetAsync(k->sym_qcount.p, 0, size_t(nwaves) * sizeof(uint32_t), ctx->stream));
+    a.sym.queue = k->sym_queue.as<uint2>();
+    a.sym.qcount = k->sym_qcount.as<uint32_t>();
+    a.sym.qcap = int32_t(rcap);
+    return GT_OK;
+}
+
+int gt_sym_queue_finish(gt_ctx* ctx, const SelectArgs& a, int64_t* entries, int* ok) {
+    KnnWork* k = ctx->knn;
+    *ok = 0;
+    const int64_t nwaves = (a.n_pad / 512) * a.sym.nseg * 4;
+    const int64_t dense_cap = std::min<int64_t>(nwaves * int64_t(a.sym.qcap), int64_t(1) << 25);
+    GT_HIP(ctx, k->sym_qdense.reserve(size_t(dense_cap) * sizeof(uint2)));
+    GT_HIP(ctx, k->sym_qtot.reserve(2 * sizeof(uint32_t)));
+    GT_HIP(ctx, hipMemsetAsync(k->sym_qtot.p, 0, 2 * sizeof(uint32_t), ctx->stream));
+    StageSpan span(ctx, "sym_cold");
+    SelectArgs c = a;
+    c.mode = 5;
+    c.nq = int32_t(nwaves);
+    c.lists = k->sym_qdense.as<uint64_t>();
+    c.cap = int32_t(dense_cap);
+    c.counts = k->sym_qtot.as<uint32_t>();
+    GT_TRY(gt_launch_select(ctx, c));
+    uint32_t tot[2] = {0, 0};
+    GT_HIP(ctx, hipMemcpyAsync(tot, k->sym_qtot.p, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *entries = int64_t(tot[0]);
+    if (ctx->dbg_select & 2048)
+        fprintf(stderr, "[gt] two-stage queue: %u entries, fullest region %u, %lld regions of %d, dense capacity %lld\n", tot[0], tot[1],
+                (long long)nwaves, a.sym.qcap, (long long)dense_cap);
+    if (int64_t(tot[1]) > int64_t(a.sym.qcap) || int64_t(tot[0]) > dense_cap) return GT_OK;
+    SelectArgs d = a;
+    d.mode = 4;
+    d.sym.queue = k->sym_qdense.as<uint2>();
+    d.sym.qn = int32_t(tot[0]);
+    GT_TRY(gt_launch_select(ctx, d));
+    *ok = 1;
     return GT_OK;
 }
 

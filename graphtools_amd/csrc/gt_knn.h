@@ -29,7 +29,11 @@ struct KnnWork {
     // symmetric candidate pass (gt_sym.hip): cell-sorted compact copy + seeds, per-row thresholds in the transposed
     // form and their sub-tile minima, the candidate lists of launch B and their counters
     DevBuf Ycs, hnegs, sym_g, sym_gmin, tlists, tcounts, sym_stat, sym_work, sym_tiles, sym_tile_cnt;
+    DevBuf sym_racc;                              // {sum, count} of the rows' radii (orphan cut)
     DevBuf sym_hh, sym_thrh, sym_gh, sym_gminh;   // two-stage scoring (gt_sym.hip sym_half_*)
+    DevBuf sym_queue, sym_qcount, sym_qdense, sym_qtot;   //   and the queue of its deferred cold pass (wave regions,
+                                                          //   their counts, the compacted queue, {total, overflow})
+    int64_t sym_cold_entries = 0;
     bool sym_used = false;
     int64_t sym_overflow = 0;
     int sym_nseg = 1;
@@ -172,11 +176,25 @@ int gt_sym_thresholds(gt_ctx* ctx, const int32_t* perm, int64_t n_pad_s, const f
                       const DevBuf& work, int cells, unsigned long long* far_total, int64_t p_first = 0, int64_t p_last = -1);
 // two-stage scoring of launch B: half seeds of the sorted rows, partial-distance thresholds from the full ones
 int gt_sym_half_seeds(gt_ctx* ctx, const void* Ys, int64_t n_pad_s, int hd, float* hh);
+struct SelectArgs;
+// queue of the two-stage collect launch `a` (mode 2 with sym.half_steps): sizes and binds the wave regions
+int gt_sym_queue_prepare(gt_ctx* ctx, int64_t n_pad_s, SelectArgs& a);
+// after that launch: compacts the queue and runs the cold pass; *entries = pairs scored, *ok = 0 when the queue
+// overflowed (nothing was filed: the caller runs the one-stage kernel instead)
+int gt_sym_queue_finish(gt_ctx* ctx, const SelectArgs& a, int64_t* entries, int* ok);
 int gt_sym_half_thresholds(gt_ctx* ctx, const int32_t* perm, int64_t n_pad_s, const float* thr, const float* hh,
                            const ErrModel& err, int hd, float* thrh, float* gh, float* gminh);
 // row-sharded symmetric pass (gt_knn_shard.cpp)
 #define GT_SYM_MAX_WORLD 64
 int gt_sym_g_from_thr(gt_ctx* ctx, int64_t n_pad_s, const float* thr, const float* hs, float* g, float* gmin);
+// radii of the thresholds: {sum, count} over the rows [p_first, p_last) added into acc (device, 2 doubles); rows whose
+// radius exceeds cut x the mean of acc lose their threshold (+inf: orphans, repaired directly)
+int gt_sym_radius_sum(gt_ctx* ctx, const int32_t* perm, int64_t p_first, int64_t p_last, const float* thr, const ErrModel& err,
+                      double* acc);
+int gt_sym_radius_cut(gt_ctx* ctx, const int32_t* perm, float* thr, const ErrModel& err, const double* acc, double cut);
+// orphans of the sorted positions [p_first, p_last) (thr = +inf on a real row): the rows launch A kept -> head of tlists
+int gt_sym_inject_orphans(gt_ctx* ctx, int64_t p_first, int64_t p_last, const float* thr, const uint64_t* lists, int lstride,
+                          const uint32_t* counts, uint64_t* tlists, int tcap, uint32_t* tcounts);
 int gt_sym_invperm(gt_ctx* ctx, const int32_t* perm, int32_t* inv);
 // the rows [r0, r1) in the order they have in perm -> own (device int32 [r1 - r0]); tmp: scratch
 int gt_sym_own_rows(gt_ctx* ctx, const int32_t* perm, int64_t r0, int64_t r1, int32_t* own, DevBuf& tmp);

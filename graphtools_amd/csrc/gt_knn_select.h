@@ -34,6 +34,15 @@ struct SymDev {
     const float* hh = nullptr;      // [n_pad]
     const float* thrh = nullptr;    // [n_pad]
     const float* gminh = nullptr;   // [n_pad / 32]
+    // two-stage scoring defers the cold path: the unit loop only notes the (64-query group, 32-row sub-tile) pairs that
+    // passed stage one - plain stores into a region of the queue that belongs to the wave alone, nothing to wait for -
+    // and a second launch (mode 4, one wave per entry of the compacted queue) scores them in full and files the
+    // survivors.  The streaming workgroups never stall on list traffic.
+    uint2* queue = nullptr;         // collect launch: [waves][qcap] regions; mode 4: the compacted entries
+    uint32_t* qcount = nullptr;     // collect launch: [waves] entries noted by each wave (beyond qcap: dropped, the
+                                    // caller falls back)
+    int32_t qcap = 0;               // entries per wave region
+    int32_t qn = 0;                 // mode 4: entries to process
     int32_t list_shift = 0;    // sched 1: the tile list of query block b is list b >> list_shift (narrow 128-row
                                // workgroups on lists made for 256-row blocks)
 };
@@ -41,7 +50,10 @@ struct SymDev {
 struct SelectArgs {
     int dp = 0;            // padded feature count (gt_choose_dp)
     int prec = 0;          // 0: float32 operands, 1: split float16 planes (hi + lo), 2: hi planes of the split copy only
-    int mode = 0;          // 0: top-M' selection, 1: radius collect, 2: symmetric collect (self queries, prec 2)
+    int mode = 0;          // 0: top-M' selection, 1: radius collect, 2: symmetric collect (self queries, prec 2),
+                           // 4: the deferred cold pass of a two-stage symmetric collect (sym.queue, sym.qn),
+                           // 5: compaction of the wave regions of that collect's queue (lists = dense queue of `cap`
+                           //    entries, counts = {total, overflow flag}, nq = wave regions)
     SymDev sym;            // mode 2 / mode 0 with sym.sched = 1
     int nt = 8;            // selection: keys per lane in the compaction sort; list capacity 64*nt, M' = 16*nt
     const float* Yp = nullptr;    // database working copy, [n_pad] rows of 4*dp bytes

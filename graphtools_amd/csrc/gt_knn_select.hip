@@ -60,6 +60,18 @@
 #endif
 // 1: (float16 back ends, two query tiles per wave) the -|y|^2/2 seeds of a sub-tile are read from LDS once, into registers
 // that enter the first MFMA of both query tiles' chains as the C operand, instead of once per accumulator
+#ifndef GT_SEL_NBUF3
+#define GT_SEL_NBUF3 1   // symmetric collect: three tile buffers (two tiles in flight) instead of two
+#endif
+#ifndef GT_SEL_TWO_VPM
+#define GT_SEL_TWO_VPM 5   // two-stage collect: VALU instructions scheduled behind each MFMA of the unit loop
+#endif
+#ifndef GT_SEL_TWO_QT
+#define GT_SEL_TWO_QT 4   // query tiles per wave of the two-stage collect kernel (query block = 128 x this many rows)
+#endif
+#ifndef GT_SEL_TWO_NS1
+#define GT_SEL_TWO_NS1(DP_) ((DP_) / 32)   // k-steps (16 features each) of stage one of the two-stage symmetric collect
+#endif
 #ifndef GT_SEL_PAIRCOLD
 #define GT_SEL_PAIRCOLD 1
 #endif
@@ -105,8 +117,12 @@ struct SelCfg {
     static constexpr int TILE_FLOATS = BN * LDP;
     static constexpr size_t LDS_BYTES =
         size_t(2) * TILE_FLOATS * 4 + size_t(2) * BN * 4;
-    // MODE 2 also stages the database rows' own thresholds [2][BN] and their per-sub-tile minima [2][8]
-    static constexpr size_t LDS_BYTES_SYM = LDS_BYTES + size_t(2) * BN * 4 + size_t(2) * 8 * 4;
+    // MODE 2 streams the tiles through NBUF_SYM buffers (two tiles in flight per workgroup: the collect launch is bound
+    // by the bytes in flight, cdna_hip_programming.md "latency x bandwidth") and also stages the per-sub-tile minima
+    // of the row thresholds [NBUF][8]
+    static constexpr int NBUF_SYM = (GLDS && GT_SEL_NBUF3) ? 3 : 2;
+    static constexpr size_t LDS_BYTES_SYM =
+        size_t(NBUF_SYM) * TILE_FLOATS * 4 + size_t(NBUF_SYM) * BN * 4 + size_t(NBUF_SYM) * 8 * 4;
     static constexpr int TPB = BQ / BN;                 // database tiles per query block
     // swizzle geometry (GLDS)
     static constexpr int CPR = RB / 16;                 // 16-byte chunks per row
@@ -339,10 +355,13 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
     // thresholds, the cold path recomputes the survivors in full (SymDev::half_steps)
     constexpr int MODE = MODEX == 3 ? 2 : MODEX;
     constexpr bool TWO = MODEX == 3;
-    constexpr int NS1 = TWO ? DP / 32 : DP / 16;   // k-steps of the unit loop (PREC 2)
+    constexpr int NS1 = TWO ? GT_SEL_TWO_NS1(DP) : DP / 16;   // k-steps of the unit loop (PREC 2)
     unsigned long long t_adm = 0, t_cmp = 0, t_bar = 0, n_cmp = 0, n_adm = 0, t_lvl0 = 0, n_adm_lvl0 = 0;
     const unsigned long long t_start = prof ? __builtin_readcyclecounter() : 0ull;
-    constexpr int QT = C::QT, BQ = C::BQ, BN = C::BN, LDP = C::LDP;
+    // (two-stage collect: the unit loop keeps only the first NS1 k-steps of the query fragments in registers, which buys
+    //  more query tiles per wave - every streamed tile then meets 128 x QT rows, the stream shrinks accordingly)
+    constexpr int QT = TWO ? GT_SEL_TWO_QT : C::QT, BQ = 128 * QT, BN = C::BN, LDP = C::LDP, TPB = BQ / BN;
+    static_assert(TWO || BQ == C::BQ, "query block size");
     constexpr int LCAP = 64 * NT;        // list capacity in selection mode (two halves of HALF slots)
     constexpr int HALF = 32 * NT;
     constexpr int MKEEP = 16 * NT;       // M'
@@ -350,10 +369,10 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
     static_assert(TRIGH >= MKEEP / 2, "list too small for the tile");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    float* tile = reinterpret_cast<float*>(smem_raw);                    // [2][BN][LDP]
-    float* hn = tile + 2 * C::TILE_FLOATS;                               // [2][BN]
-    float* gb = hn + 2 * BN;                                             // MODE 2: [2][BN] row thresholds, [2][8] sub-tile minima
-    float* gm = gb + 2 * BN;
+    constexpr int NBUF = (MODE == 2) ? C::NBUF_SYM : 2;                  // tile buffers (MODE 2: two tiles in flight)
+    float* tile = reinterpret_cast<float*>(smem_raw);                    // [NBUF][BN][LDP]
+    float* hn = tile + NBUF * C::TILE_FLOATS;                            // [NBUF][BN]
+    float* gm = hn + NBUF * BN;                                          // MODE 2: [NBUF][8] sub-tile minima of the row thresholds
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -398,12 +417,12 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
     const int32_t* tl_base = nullptr;
     int32_t tl_cache = 0;
     if (own_sched) {
-        const int T = ntiles, NB = T / C::TPB;
+        const int T = ntiles, NB = T / TPB;
         t_begin = 0;
         if (MODE == 2) {
             const int H = (NB - 1) / 2;
-            n_tr_end = C::TPB * (1 + H);
-            const int walk = n_tr_end + ((NB & 1) ? 0 : (NB > 1 ? C::TPB : 0));
+            n_tr_end = TPB * (1 + H);
+            const int walk = n_tr_end + ((NB & 1) ? 0 : (NB > 1 ? TPB : 0));
             const int nseg = (sy.nseg > 0 ? sy.nseg : 1) * (sy.shard_world > 1 ? sy.shard_world : 1);
             t_begin = int(int64_t(walk) * seg / nseg);          // this item's part of the block's walk
             t_end = int(int64_t(walk) * (seg + 1) / nseg);
@@ -427,7 +446,8 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
         const int64_t qg = qblock + ql;
         const int64_t qc = qg < nq ? qg : int64_t(nq) - 1;   // clamp pad queries onto a real row
         const int64_t row = qrows ? int64_t(qrows[qc]) : q0 + qc;
-        bq[qt].load(Qp + row * C::RW, h);
+        if constexpr (TWO) frag_load_part<DP, NS1>(bq[qt], Qp + row * C::RW, h, 0);
+        else bq[qt].load(Qp + row * C::RW, h);
         // MODE 0: -inf, or a proven lower bound of the wanted scores indexed by row (gt_query_order); MODE 1: the radius
         thr[qt] = (MODE == 0) ? ((dbg & 1) ? INFINITY : (thr_in ? thr_in[row - q0] : -INFINITY))
                               : ((qg < nq) ? thr_in[qc] : INFINITY);
@@ -514,11 +534,17 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
     const int n_a = (MODE == 0 && samp_stride > 1 && !own_sched) ? (ntiles + samp_stride - 1) / samp_stride : 0;
     int t = t_begin, t_step = n_a ? samp_stride : 1, level = 0;
     if (own_sched) {
-        t = int((int64_t(bidx) * C::TPB + t_begin) % ntiles);             // MODE 2: the own block first (segment 0)
+        t = int((int64_t(bidx) * TPB + t_begin) % ntiles);                // MODE 2: the own block first (segment 0)
         if (MODE == 0) t = __builtin_amdgcn_readlane(tl_cache, 0);         // sched 1: first entry of the list
     }
     if constexpr (C::GLDS) {
         GT_GLDS_ISSUE(t, 0);
+        if constexpr (NBUF == 3) {
+            if (t_begin + 1 < t_end) {
+                const int t1_ = (t + 1 >= ntiles) ? t + 1 - ntiles : t + 1;
+                GT_GLDS_ISSUE(t1_, 1);
+            }
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
         GT_STAGE_LOAD(t, 0);
@@ -528,9 +554,31 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
     }
     __syncthreads();
     const int aswz = C::GLDS ? swz_of_row(li, C::RDIV, C::SMASK) : 0;   // sub-tiles start at multiples of 32 rows
+    uint32_t qfill = 0u;                                                  // two-stage collect: entries this wave has queued
+    uint32_t pend_pm = 0u, pend_t = 0u;                                   //   pairs of the previous tile not yet written
+// The wave owns its region of the queue: the slots come from a register, the entries leave as stores nobody waits for.
+// They must sit in the memory queue BEHIND the loads of the tile that is waited for next and IN FRONT of the loads issued
+// after them: a counted wait then passes them on the way to the loads it is about, and never has to drain younger loads
+// to reach them (loads return in order among themselves, stores only ever make a counted wait stricter).
+#define GT_QUEUE_FLUSH()                                                                                   \
+    if (TWO && pend_pm != 0u) {   /* wave-uniform */                                                       \
+        const uint32_t n_ = uint32_t(__popc(pend_pm));                                                     \
+        if (uint32_t(lane) < n_ && qfill + n_ <= uint32_t(sy.qcap)) {                                      \
+            uint32_t m_ = pend_pm;                                                                         \
+            for (int i_ = 0; i_ < lane; ++i_) m_ &= m_ - 1u;   /* the lane-th set bit (lane < 16) */       \
+            const uint32_t p_ = uint32_t(__ffs(int(m_)) - 1);                                              \
+            const uint32_t sb_ = p_ / uint32_t(QT / 2), pr_ = p_ % uint32_t(QT / 2);                       \
+            const uint64_t ent_ = uint64_t(uint32_t((qblock + (w * QT + 2 * pr_) * 32) / 64)) |            \
+                                  (uint64_t(pend_t * (BN / 32) + sb_) << 32);                              \
+            list_store(reinterpret_cast<uint64_t*>(qreg + qfill + uint32_t(lane)), ent_);                  \
+        }                                                                                                  \
+        qfill += n_;   /* (beyond the capacity: the count says so, the caller starts over) */              \
+        pend_pm = 0u;                                                                                      \
+    }
+    uint2* qreg = TWO ? sy.queue + (size_t(blockIdx.x) * 4 + w) * size_t(sy.qcap) : nullptr;
 
     for (int it = t_begin; it < t_end; ++it) {
-        const int buf = (GT_EXP & (4 | 32)) ? 0 : ((it - t_begin) & 1);
+        const int buf = (GT_EXP & (4 | 32)) ? 0 : (NBUF == 3 ? (it - t_begin) % 3 : ((it - t_begin) & 1));
         int t_next = t + t_step, level_next = level, t_step_next = t_step;
         if (own_sched) {
             if (MODE == 2) {
@@ -549,7 +597,16 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
             t_step_next = samp_stride >> level;
             t_next = samp_stride >> level_next;
         }
-        if (!(GT_EXP & (4 | 32)) && it + 1 < t_end) {
+        GT_QUEUE_FLUSH();
+        if (NBUF == 3 && !(GT_EXP & (4 | 32))) {
+            // three buffers: the tile after the next goes into the buffer every wave left at the barrier that ended the
+            // previous tile; the next tile has been on its way since the previous iteration
+            if (it + 2 < t_end) {
+                int t2_ = t_next + 1;
+                if (t2_ >= ntiles) t2_ -= ntiles;
+                GT_GLDS_ISSUE(t2_, (it + 2 - t_begin) % 3);
+            }
+        } else if (!(GT_EXP & (4 | 32)) && it + 1 < t_end) {
             if constexpr (C::GLDS) {
                 GT_GLDS_ISSUE(t_next, buf ^ 1);   // every wave left buf^1 at the barrier that ended the previous tile
             } else {
@@ -560,7 +617,7 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
         const float* hb = hn + buf * BN;
         const uint32_t tbase = uint32_t(t) * BN;
         // MODE 2: does this tile's block also take the results as ITS queries?  (wave-uniform; +inf switches the test off)
-        const bool tr_on = MODE == 2 && it >= C::TPB && it < n_tr_end;
+        const bool tr_on = MODE == 2 && it >= TPB && it < n_tr_end;
         const float* gglob = (MODE == 2) ? sy.g + size_t(tbase) : nullptr;   // row thresholds of this tile (cold path only)
         float gms[BN / 32];
 #pragma unroll
@@ -580,7 +637,9 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
         // accp[(u-1)%3] and the seeds (-|y|^2/2) of u+1 are fetched from LDS into accp[(u+1)%3]
         f32x16 accp[3];
         bool any_hit = false;
+        bool hit_now = false;    // MODE 2: the compare of the unit just examined fired in some lane (wave-uniform)
         uint32_t hitmask = 0u;   // MODE 2: units of this tile whose compare fired
+        bool cold_tile = false;  // MODE 2: this wave ran the cold path in this tile
         float mx[5];
 #define GT_SEED(U_)                                                                                        \
     {                                                                                                      \
@@ -774,7 +833,7 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
         if (__ballot((PA_)[15] > tq_)) GT_ADMIT_ONE(PA_, 15, PSB_, PQT_);                                  \
         if (prof) { t_adm += __builtin_readcyclecounter() - ts_; n_adm += 1; }                             \
     }
-        constexpr bool SEEDREG = GT_SEL_SEEDREG && PREC >= 1 && QT == 2;
+        constexpr bool SEEDREG = GT_SEL_SEEDREG && PREC >= 1 && QT >= 2;
         constexpr int NACC = SEEDREG ? 2 : 3;
         f32x16 seedr;
 #define GT_SEEDR(SB_)                                                                                      \
@@ -826,7 +885,12 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
                 any_hit = m16 > tq;
                 // MODE 2: ... or some row of the sub-tile may want this query (same arithmetic as the cold path:
                 // rounding is monotone, so max(acc) + hq > min(g) whenever one acc_i + hq > g_i)
-                if (MODE == 2 && !(GT_EXP & 8)) any_hit = any_hit || (m16 + hnq[pqt] > gms[psb]);
+                if constexpr (MODE == 2) {
+                    // the two compares write lane masks: their union is tested on the scalar side, no per-lane flag
+                    unsigned long long hm_ = __ballot(m16 > tq);
+                    if (!(GT_EXP & 8)) hm_ |= __ballot(m16 + hnq[pqt] > gms[psb]);
+                    hit_now = hm_ != 0ull;
+                }
             }
 #if GT_SEL_PIPE
             if (u > 0 && u < NU) {
@@ -840,7 +904,7 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
 #if GT_SEL_DSFIRST
                     if (i == 0) __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);   // DS read (as many as there are)
 #endif
-                    __builtin_amdgcn_sched_group_barrier(0x002, PREC == 1 ? 1 : PREC == 2 ? 3 : 1, 0);   // VALU
+                    __builtin_amdgcn_sched_group_barrier(0x002, PREC == 1 ? 1 : PREC == 2 ? (TWO ? GT_SEL_TWO_VPM : 3) : 1, 0);   // VALU
                     __builtin_amdgcn_sched_group_barrier(0x004, 1, 0);   // SALU
                 }
             }
@@ -848,13 +912,26 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
             if (u > 0) {
                 if constexpr (MODE == 2) {
                     // no branch in the unit loop: the units that need the cold path are only noted (bit = unit)
-                    hitmask |= (__ballot(any_hit) != 0ull) ? (1u << (u - 1)) : 0u;
+                    hitmask |= hit_now ? (1u << (u - 1)) : 0u;
                 } else {
                     GT_ADMIT(accp[(u - 1) % NACC], any_hit, mx, psb, pqt);
                 }
             }
         }
-        if constexpr (MODE == 2) {
+        if constexpr (TWO) {
+            // two-stage scoring: the pairs that passed stage one go to the queue of the cold launch (sym_cold_kernel)
+            if (GT_EXP & 256) hitmask = 0u;
+            cold_tile = hitmask != 0u;
+            if (__builtin_expect(hitmask != 0u, 0)) {   // wave-uniform
+                // one entry per (sub-tile, PAIR of query tiles): bit sb * QT/2 + pair.  They are written at the top of the
+                // next iteration, in front of the tile loads issued there (GT_QUEUE_FLUSH)
+#pragma unroll
+                for (int p_ = 0; p_ < (BN / 32) * (QT / 2); ++p_) pend_pm |= ((hitmask >> (2 * p_)) & 3u) ? (1u << p_) : 0u;
+                pend_t = uint32_t(t);
+            }
+        } else if constexpr (MODE == 2) {
+            if (GT_EXP & 256) hitmask = 0u;   // experiment: the unit loop with its compares, no cold path
+            cold_tile = hitmask != 0u;
             if (__builtin_expect(hitmask != 0u, 0)) {
                 const unsigned long long ts_ = prof ? __builtin_readcyclecounter() : 0ull;
                 // the full thresholds / seeds of the lane's queries (two-stage scoring keeps the half ones in registers)
@@ -952,14 +1029,31 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
             }
         }
 
-        if constexpr (C::GLDS) {
+        if constexpr (C::GLDS && NBUF == 3) {
+            // the next tile must have landed, the one after it may stay in flight: a wave issued NPW (+1) loads for it,
+            // all younger than the next tile's.  A tile that went through the cold path has younger memory operations
+            // of other kinds in the queue - it simply drains everything.
+            // (the two-stage kernel only issues stores nobody reads back: they can make a counted wait stricter, never
+            //  let it pass early - loads return in order among themselves)
+            if (it + 2 < t_end && (TWO || !cold_tile))
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::NPW) : "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else if constexpr (C::GLDS) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the next tile are in LDS
         } else {
             if (!(GT_EXP & (4 | 32)) && it + 1 < t_end) GT_STAGE_STORE(buf ^ 1, 1);
         }
         if (!(GT_EXP & (4 | 16))) {
             const unsigned long long ts_ = prof ? __builtin_readcyclecounter() : 0ull;
-            __syncthreads();
+            if constexpr (C::GLDS && NBUF == 3) {
+                // a tile is still in flight: __syncthreads() would drain it (its fence waits vmcnt(0) while an LDS-DMA is
+                // pending) - the LDS reads of this tile have to be back, nothing else
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            } else {
+                __syncthreads();
+            }
             if (prof) t_bar += __builtin_readcyclecounter() - ts_;
         }
         if (prof && level_end && level == 0) {
@@ -976,6 +1070,8 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
         o[5] = t_lvl0; o[6] = n_adm_lvl0; o[7] = __builtin_readcyclecounter() - t_start;
     }
 
+    GT_QUEUE_FLUSH();
+    if (TWO && lane == 0) sy.qcount[size_t(blockIdx.x) * 4 + w] = qfill;
     // ---- finalisation: gather every list into slots [0, count), publish count and the last admission threshold ----
     if (MODE == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1088,11 +1184,109 @@ __global__ __launch_bounds__(256) void assign_cells_kernel(const float* __restri
     }
 }
 
+// The wave regions of the collect launch -> one dense queue (order does not matter): one wave per region, its slots in
+// the dense queue from one atomic.  total (pre-zeroed): entries copied; flag (pre-zeroed): the largest region count.
+__global__ __launch_bounds__(256) void sym_queue_compact_kernel(const uint2* __restrict__ regions,
+                                                                const uint32_t* __restrict__ cnts, const int64_t nwaves,
+                                                                const int rcap, uint2* __restrict__ dense,
+                                                                const uint32_t dense_cap, uint32_t* __restrict__ total,
+                                                                uint32_t* __restrict__ flag) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    if (r >= nwaves) return;
+    uint32_t c = cnts[r];
+    if (c == 0u) return;
+    if (lane == 0) atomicMax(flag, c);   // the largest count of a region (beyond rcap: that region overflowed)
+    if (c > uint32_t(rcap)) c = uint32_t(rcap);
+    uint32_t base = 0u;
+    if (lane == 0) base = atomicAdd(total, c);
+    base = __shfl(base, 0);
+    const uint2* src = regions + size_t(r) * size_t(rcap);
+    for (uint32_t i = uint32_t(lane); i < c; i += 64u)
+        if (base + i < dense_cap) dense[base + i] = src[i];
+}
+
+// ---- deferred cold pass of the two-stage symmetric collect: one wave per queue entry -------------------------------
+// Entry {q64, d32}: the 64 queries [64 q64, 64 q64 + 64) (the two query tiles a wave of the collect launch owns)
+// against the 32 database rows [32 d32, 32 d32 + 32).  Operands come straight from the sorted compact copy; the block
+// is scored exactly as the collect kernel's own cold path scores it (same chain, same seeds), then tested and filed
+// by the same code (GT_ADMIT2P).
+template <int DP>
+__global__ __launch_bounds__(256, 3) void sym_cold_kernel(const float* __restrict__ Yp, const float* __restrict__ hneg,
+                                                       const float* __restrict__ thr_in, const int32_t nq,
+                                                       const int32_t ntiles, const SymDev sy) {
+    using C = SelCfg<DP, 2>;
+    constexpr int QT = 2;
+    const int lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
+    const int64_t en_ = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    if (en_ >= int64_t(sy.qn)) return;
+    const uint2 ent = sy.queue[en_];
+    const int64_t qblock = int64_t(ent.x) * (QT * 32);
+    const int w = 0;
+    const uint32_t tbase = ent.y * 32u;
+    // does the sub-tile's block take these queries as ITS candidates too?  (position of its tile in the walk of the
+    // queries' block, as in the collect kernel)
+    constexpr int BQ = 128 * GT_SEL_TWO_QT, TPB = BQ / C::BN;   // query blocks of the collect launch
+    const int T = ntiles, NB = T / TPB, H = (NB - 1) / 2;
+    int rel = int(ent.y / uint32_t(C::BN / 32)) - int(qblock / BQ) * TPB;
+    if (rel < 0) rel += T;
+    const bool tr_on = rel >= TPB && rel < TPB * (1 + H);
+    Frag<DP, 2> bq[QT], ca;
+    float thrF[QT], hnqF[QT], thr[QT];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        const int64_t qg = qblock + qt * 32 + li;
+        const int64_t qc = qg < nq ? qg : int64_t(nq) - 1;
+        bq[qt].load(Yp + qc * C::RW, h);
+        thrF[qt] = qg < nq ? thr_in[qc] : INFINITY;
+        hnqF[qt] = qg < nq ? hneg[qc] : -INFINITY;
+        thr[qt] = thrF[qt];
+    }
+    ca.load(Yp + (size_t(tbase) + li) * C::RW, h);
+    f32x16 cs;
+#pragma unroll
+    for (int g_ = 0; g_ < 4; ++g_) {
+        const float4 hv_ = *reinterpret_cast<const float4*>(hneg + size_t(tbase) + 8 * g_ + 4 * h);
+        cs[4 * g_ + 0] = hv_.x;
+        cs[4 * g_ + 1] = hv_.y;
+        cs[4 * g_ + 2] = hv_.z;
+        cs[4 * g_ + 3] = hv_.w;
+    }
+    const float* gglob = sy.g + size_t(tbase);
+    f32x16 cacc = cs, cacc1 = cs;
+    mma_chain<DP>(ca, bq[0], cacc);
+    mma_chain<DP>(ca, bq[QT - 1], cacc1);
+    GT_ADMIT2P(cacc, cacc1, cs, 0);
+    (void)thr;
+}
+
+int launch_queue_compact(gt_ctx* ctx, const SelectArgs& a) {
+    // a.lists: the dense queue (capacity a.cap entries); a.counts: [0] total, [1] overflow flag (both pre-zeroed);
+    // a.sym.queue / qcount / qcap: the regions; a.nq: number of wave regions
+    hipLaunchKernelGGL(sym_queue_compact_kernel, dim3((unsigned)ceil_div64(a.nq, 4)), dim3(256), 0, ctx->stream, a.sym.queue,
+                       a.sym.qcount, int64_t(a.nq), a.sym.qcap, reinterpret_cast<uint2*>(a.lists), uint32_t(a.cap), a.counts,
+                       a.counts + 1);
+    GT_HIP(ctx, hipGetLastError());
+    return GT_OK;
+}
+
+template <int DP>
+int launch_sym_cold(gt_ctx* ctx, const SelectArgs& a) {
+    if (a.sym.qn <= 0) return GT_OK;
+    if (!a.sym.queue || !a.sym.g || !a.sym.tlists || !a.sym.tcounts || a.sym.tcap <= 0)
+        GT_FAIL(ctx, GT_E_ARG, "knn_select: the cold pass needs the queue and the lists of the collect launch");
+    hipLaunchKernelGGL(sym_cold_kernel<DP>, dim3((unsigned)ceil_div64(a.sym.qn, 4)), dim3(256), 0, ctx->stream, a.Yp, a.hneg,
+                       a.thr_in, a.nq, int(a.n_pad / SelCfg<DP, 2>::BN), a.sym);
+    GT_HIP(ctx, hipGetLastError());
+    return GT_OK;
+}
+
 template <int DP, int NT, int MODEX, int PREC>
 int launch_one(gt_ctx* ctx, const SelectArgs& a) {
     using C = SelCfg<DP, PREC>;
     constexpr int MODE = MODEX == 3 ? 2 : MODEX;   // 3: MODE 2 with two-stage scoring
-    const int64_t nblocks = ceil_div64(a.nq, C::BQ);
+    constexpr int BQL = MODEX == 3 ? 128 * GT_SEL_TWO_QT : C::BQ;   // query rows per workgroup
+    const int64_t nblocks = ceil_div64(a.nq, BQL);
     const int ntiles = int(a.n_pad / C::BN);
     int nsplit = 1;
     if (MODE == 1) {
@@ -1108,7 +1302,7 @@ int launch_one(gt_ctx* ctx, const SelectArgs& a) {
     if (MODE == 2) {
         GT_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         int(lds_bytes)));
-        if (a.n_pad % C::BQ != 0 || a.nq > a.n_pad || a.sym.tcap <= 0 || a.sym.nseg < 1)
+        if (a.n_pad % BQL != 0 || a.nq > a.n_pad || a.sym.tcap <= 0 || a.sym.nseg < 1)
             GT_FAIL(ctx, GT_E_ARG, "knn_select: symmetric collect needs the padded point set as queries and database");
     }
     if (MODE == 0 && a.sym.sched == 1 && a.n_pad % C::BQ != 0)
@@ -1133,11 +1327,17 @@ int launch_one(gt_ctx* ctx, const SelectArgs& a) {
 template <int DP, int PREC>
 int launch_dp(gt_ctx* ctx, const SelectArgs& a) {
     if (a.mode == 1) return launch_one<DP, 8, 1, PREC>(ctx, a);
+    if (a.mode == 5) return launch_queue_compact(ctx, a);
+    if (a.mode == 4) {
+        if constexpr (PREC == 2 && DP % 32 == 0 && SelCfg<DP, PREC>::QT == 2) return launch_sym_cold<DP>(ctx, a);
+        GT_FAIL(ctx, GT_E_ARG, "knn_select: no cold pass for this kernel shape");
+    }
     if (a.mode == 2) {
         if constexpr (PREC == 2) {
             if (a.sym.half_steps > 0) {
                 if constexpr (DP % 32 == 0 && SelCfg<DP, PREC>::QT == 2) {
-                    if (a.sym.half_steps != DP / 32 || !a.sym.hh || !a.sym.thrh || !a.sym.gminh)
+                    if (a.sym.half_steps != GT_SEL_TWO_NS1(DP) || !a.sym.hh || !a.sym.thrh || !a.sym.gminh || !a.sym.queue ||
+                        !a.sym.qcount || a.sym.qcap <= 0)
                         GT_FAIL(ctx, GT_E_ARG, "knn_select: two-stage scoring needs the half seeds and thresholds");
                     return launch_one<DP, 8, 3, PREC>(ctx, a);
                 }

@@ -45,7 +45,10 @@ int gt_knn_shard_plan(gt_ctx* ctx, int world, int rank, const int64_t* splits, i
     k->sh_stage = 0;
     if (!shard_applicable(ctx, need_m) || splits[rank + 1] <= splits[rank]) return GT_OK;
     const int bq = gt_select_bq(ctx->DP);
-    const int64_t n_pad_s = ceil_div64(ctx->n, bq) * bq;
+    // (the two-stage collect kernel works on query blocks of up to 1024 rows; the seeding shares stay 256-row blocks)
+    const bool two = ctx->DP % 32 == 0 && bq == 256 && (ctx->sym_two_stage > 0 || (ctx->sym_two_stage < 0 && ctx->sym_two_ok != 0));
+    const int64_t pad_s = two ? 1024 : bq;
+    const int64_t n_pad_s = ceil_div64(ctx->n, pad_s) * pad_s;
     const int64_t NB = n_pad_s / bq;
     if (NB < world) return GT_OK;
     // the cell-sorted order of ALL rows (position -> row in k->qorder)
@@ -76,7 +79,7 @@ int gt_knn_shard_plan(gt_ctx* ctx, int world, int rank, const int64_t* splits, i
     return GT_OK;
 }
 
-int gt_knn_shard_seed(gt_ctx* ctx, float* thr_local, int64_t* far_local) {
+int gt_knn_shard_seed(gt_ctx* ctx, float* thr_local, int64_t* far_local, double* racc_local) {
     KnnWork* k = ctx->knn;
     if (!k || k->sh_stage != 1) GT_FAIL(ctx, GT_E_STATE, "sym shard: seed without a plan");
     k->sh_stage = 0;
@@ -167,6 +170,11 @@ int gt_knn_shard_seed(gt_ctx* ctx, float* thr_local, int64_t* far_local) {
         GT_HIP(ctx, hipMemcpyAsync(thr_local, k->thr_final.as<float>() + p0, size_t(p1 - p0) * sizeof(float),
                                    hipMemcpyDeviceToDevice, ctx->stream));
     }
+    // this rank's share of the radius statistics behind the orphan cut (summed over the ranks by the host)
+    GT_HIP(ctx, k->sym_racc.reserve(2 * sizeof(double)));
+    GT_HIP(ctx, hipMemsetAsync(k->sym_racc.p, 0, 2 * sizeof(double), ctx->stream));
+    GT_TRY(gt_sym_radius_sum(ctx, perm, p0, p1, k->thr_final.as<float>(), em, k->sym_racc.as<double>()));
+    GT_HIP(ctx, hipMemcpyAsync(racc_local, k->sym_racc.p, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     unsigned long long far = 0;
     GT_HIP(ctx, hipMemcpyAsync(&far, k->sym_stat.as<unsigned long long>() + 2, sizeof(far), hipMemcpyDeviceToHost, ctx->stream));
     GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -175,7 +183,8 @@ int gt_knn_shard_seed(gt_ctx* ctx, float* thr_local, int64_t* far_local) {
     return GT_OK;
 }
 
-int gt_knn_shard_collect(gt_ctx* ctx, const float* thr_all, int64_t far_total, int32_t* applies, int64_t* send_counts) {
+int gt_knn_shard_collect(gt_ctx* ctx, const float* thr_all, int64_t far_total, const double* racc_total, int32_t* applies,
+                         int64_t* send_counts) {
     KnnWork* k = ctx->knn;
     *applies = 0;
     if (!k || k->sh_stage != 2) GT_FAIL(ctx, GT_E_STATE, "sym shard: collect without seeds");
@@ -195,9 +204,20 @@ int gt_knn_shard_collect(gt_ctx* ctx, const float* thr_all, int64_t far_total, i
     GT_HIP(ctx, hipMemcpyAsync(k->thr_final.p, thr_all, size_t(n_pad_s) * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
     {
         StageSpan span(ctx, "sym_prepare");
+        // the orphan cut on the radius statistics of ALL rows: every rank applies the same cut to the same thresholds
+        ErrModel emc = gt_err_model(ctx, 2);
+        emc.rel += 8.0 * 5.9604644775390625e-08;
+        GT_HIP(ctx, hipMemcpyAsync(k->sym_racc.p, racc_total, 2 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        GT_TRY(gt_sym_radius_cut(ctx, k->qorder.as<int32_t>(), k->thr_final.as<float>(), emc, k->sym_racc.as<double>(),
+                                 ctx->sym_radius_cut));
         GT_TRY(gt_sym_g_from_thr(ctx, n_pad_s, k->thr_final.as<float>(), k->hnegs.as<float>(), k->sym_g.as<float>(),
                                  k->sym_gmin.as<float>()));
         GT_HIP(ctx, hipMemsetAsync(k->tcounts.p, 0, size_t(n_pad_s) * sizeof(uint32_t), ctx->stream));
+        // (the orphans among the rows THIS rank seeded: their kept rows travel to the owners with the other records)
+        const size_t lcap = size_t(64) * 8;
+        GT_TRY(gt_sym_inject_orphans(ctx, k->sh_p0, k->sh_p1, k->thr_final.as<float>(),
+                                     k->lists.as<uint64_t>() - size_t(k->sh_p0) * lcap, int(lcap), k->counts.as<uint32_t>(),
+                                     k->tlists.as<uint64_t>(), tcap, k->tcounts.as<uint32_t>()));
     }
     SelectArgs a;
     a.dp = ctx->DP;
@@ -222,9 +242,10 @@ int gt_knn_shard_collect(gt_ctx* ctx, const float* thr_all, int64_t far_total, i
     a.sym.shard_world = k->sh_world;
     a.sym.shard_rank = k->sh_rank;
     a.sym.shard_group = std::max(1, ctx->sym_shard_group);
-    if (ctx->DP % 32 == 0 && bq == 256 && (ctx->sym_two_stage > 0 || (ctx->sym_two_stage < 0 && ctx->sym_two_ok != 0))) {
+    if (n_pad_s % 1024 == 0 && ctx->DP % 32 == 0 && bq == 256 &&
+        (ctx->sym_two_stage > 0 || (ctx->sym_two_stage < 0 && ctx->sym_two_ok != 0))) {
         // two-stage scoring, as in the single-rank pass (gt_knn.cpp)
-        const int hd = ctx->DP / 2;
+        const int hd = ctx->sym_two_steps > 0 ? 16 * ctx->sym_two_steps : ctx->DP / 2;
         ErrModel em = gt_err_model(ctx, 2);
         em.rel += 8.0 * 5.9604644775390625e-08;
         GT_HIP(ctx, k->sym_hh.reserve(size_t(n_pad_s) * sizeof(float)));
@@ -240,6 +261,7 @@ int gt_knn_shard_collect(gt_ctx* ctx, const float* thr_all, int64_t far_total, i
         a.sym.thrh = k->sym_thrh.as<float>();
         a.sym.gminh = k->sym_gminh.as<float>();
     }
+    const bool two_stage = a.sym.half_steps > 0;
     {
         const int64_t slots = int64_t(ctx->n_cu) * 3, nb = n_pad_s / bq;
         int best = 1;
@@ -249,12 +271,26 @@ int gt_knn_shard_collect(gt_ctx* ctx, const float* thr_all, int64_t far_total, i
             const double cost = double(ceil_div64(nb * sgm, slots)) / sgm + 0.1 * sgm;
             if (cost < best_cost - 1e-9) best_cost = cost, best = sgm;
         }
-        a.sym.nseg = ctx->sym_nseg > 0 ? std::min(ctx->sym_nseg, 8) : best;
+        a.sym.nseg = ctx->sym_nseg > 0 ? std::min(ctx->sym_nseg, 8) : (two_stage ? std::max(1, best / 2) : best);
         k->sym_nseg = a.sym.nseg;
     }
-    {
-        StageSpan span(ctx, "knn_select");
-        GT_TRY(gt_launch_select(ctx, a));
+    if (two_stage) GT_TRY(gt_sym_queue_prepare(ctx, n_pad_s, a));
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        {
+            StageSpan span(ctx, "knn_select");
+            GT_TRY(gt_launch_select(ctx, a));
+        }
+        if (a.sym.half_steps <= 0) break;
+        // the deferred cold pass of the two-stage collect (gt_knn.cpp has the single-rank twin)
+        int ok = 0;
+        GT_TRY(gt_sym_queue_finish(ctx, a, &k->sym_cold_entries, &ok));
+        if (ok) {
+            if (ctx->sym_two_ok < 0) ctx->sym_two_ok = 1;
+            break;
+        }
+        ctx->sym_two_ok = 0;     // stage one is no filter on these points: the one-stage kernel, now and later
+        a.sym.half_steps = 0;
+        a.sym.nseg = k->sym_nseg = ctx->sym_nseg > 0 ? std::min(ctx->sym_nseg, 8) : 3;
     }
     ctx->last_main_prec = 2;
     GT_HIP(ctx, k->sh_cnt.reserve(size_t(2 * GT_SYM_MAX_WORLD) * sizeof(unsigned long long)));

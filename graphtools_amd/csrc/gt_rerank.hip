@@ -339,8 +339,9 @@ __global__ __launch_bounds__(256) void rerank_sym_kernel(
             const uint32_t slot = atomicAdd(fb_count, 1u);
             fb_rows[slot] = int32_t(q);
         }
-        // (an overflowing row is short of room, not of precision: it does not count against the arithmetic)
-        if (unproven && !overflow && !(d2_need * rkf < lb)) atomicAdd(unproven, 1u);
+        // (an overflowing row is short of room, an orphan - threshold +inf - of seeds, neither of precision: they do not
+        //  count against the arithmetic)
+        if (unproven && !overflow && thr[qt] != INFINITY && !(d2_need * rkf < lb)) atomicAdd(unproven, 1u);
         if (stat && overflow) atomicAdd(stat + 0, 1ull);
         if (stat && want_stats) {
             // [1] sum of the list lengths [3] longest list [4] rows with more than 256 keys [7] rows with more than 128 keys

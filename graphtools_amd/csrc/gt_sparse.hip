@@ -776,8 +776,9 @@ static double candidate_hint(const gt_ctx* ctx, const gt_knn_params* params, dou
 // ---- row-sharded symmetric candidate pass: the stages around the host's collectives (gt_knn_shard.cpp) -------------
 int gt_knn_shard_plan(gt_ctx* ctx, int world, int rank, const int64_t* splits, int need_m, double rkf, int32_t* applies,
                       int64_t* n_pad_sorted, int64_t* sorted_splits);
-int gt_knn_shard_seed(gt_ctx* ctx, float* thr_local, int64_t* far_local);
-int gt_knn_shard_collect(gt_ctx* ctx, const float* thr_all, int64_t far_total, int32_t* applies, int64_t* send_counts);
+int gt_knn_shard_seed(gt_ctx* ctx, float* thr_local, int64_t* far_local, double* racc_local);
+int gt_knn_shard_collect(gt_ctx* ctx, const float* thr_all, int64_t far_total, const double* racc_total, int32_t* applies,
+                         int64_t* send_counts);
 int gt_knn_shard_emit(gt_ctx* ctx, void* send_buf);
 int gt_knn_shard_finish(gt_ctx* ctx, const void* recv, int64_t n_recv);
 
@@ -800,16 +801,16 @@ extern "C" int gt_graph_sym_plan(gt_ctx* ctx, const gt_knn_params* params, int32
     const double hint = candidate_hint(ctx, params, thresh, !binary);
     return gt_knn_shard_plan(ctx, world, rank, row_splits, params->knn + 1, hint, applies, n_pad_sorted, sorted_splits);
 }
-extern "C" int gt_graph_sym_seed(gt_ctx* ctx, void* thr_local, int64_t* far_local) {
-    if (!ctx || !far_local) return GT_E_ARG;
+extern "C" int gt_graph_sym_seed(gt_ctx* ctx, void* thr_local, int64_t* far_local, double* radius_local) {
+    if (!ctx || !far_local || !radius_local) return GT_E_ARG;
     GT_HIP(ctx, hipSetDevice(ctx->device));
-    return gt_knn_shard_seed(ctx, static_cast<float*>(thr_local), far_local);
+    return gt_knn_shard_seed(ctx, static_cast<float*>(thr_local), far_local, radius_local);
 }
-extern "C" int gt_graph_sym_collect(gt_ctx* ctx, const void* thr_all, int64_t far_total, int32_t* applies,
-                                    int64_t* send_counts) {
-    if (!ctx || !thr_all || !applies || !send_counts) return GT_E_ARG;
+extern "C" int gt_graph_sym_collect(gt_ctx* ctx, const void* thr_all, int64_t far_total, const double* radius_total,
+                                    int32_t* applies, int64_t* send_counts) {
+    if (!ctx || !thr_all || !radius_total || !applies || !send_counts) return GT_E_ARG;
     GT_HIP(ctx, hipSetDevice(ctx->device));
-    return gt_knn_shard_collect(ctx, static_cast<const float*>(thr_all), far_total, applies, send_counts);
+    return gt_knn_shard_collect(ctx, static_cast<const float*>(thr_all), far_total, radius_total, applies, send_counts);
 }
 extern "C" int gt_graph_sym_emit(gt_ctx* ctx, void* send_buf) {
     if (!ctx) return GT_E_ARG;

@@ -80,10 +80,10 @@ __global__ __launch_bounds__(256) void sym_thresholds_kernel(const int64_t n, co
         const int64_t q = perm[p];
         // how many of the kept rows lie outside the M cells around the row's own: when that is most of them the cells say
         // nothing about this point set (launch A found its neighbours in the strided sample) and the thresholds are loose
+        uint32_t far = 0;
         if (far_total) {
             const uint32_t kept0 = counts[p];
             const uint32_t cme = cell_sorted[p];
-            uint32_t far = 0;
             for (uint32_t c = uint32_t(sub); c < kept0; c += 16u) {
                 const uint32_t cc = cell_sorted[cand_index(lists[size_t(p) * lstride + c])];
                 bool near = false;
@@ -131,7 +131,13 @@ __global__ __launch_bounds__(256) void sym_thresholds_kernel(const int64_t n, co
             if (double(t) >= x) t = nextafterf(t, -INFINITY);
             if (!(t > -3.0e38f)) t = -3.0e38f;
         }
-        gv = nextafterf(t + hs[p], -INFINITY);
+        // An orphan: a quarter or more of the rows launch A kept for it came from the strided sample, not from the cells
+        // around it - its cell says little about where its neighbours are, D_K is loose, and a threshold from it would
+        // pull in (and queue, and score) candidates by the thousand only to overflow the list.  It collects nothing
+        // (+inf), keeps the rows launch A found (sym_inject_orphans_kernel) and goes to the repair pass, which starts
+        // from their exact distances.
+        if (far * 4u >= uint32_t(need_m) && kept >= uint32_t(need_m)) t = INFINITY;
+        gv = t == INFINITY ? INFINITY : nextafterf(t + hs[p], -INFINITY);
     }
     if (sub == 0) {
         thr[p] = t;
@@ -334,6 +340,73 @@ __global__ __launch_bounds__(256) void sum_i32_kernel(const int32_t* __restrict_
 }
 
 
+// Completeness radius a threshold stands for: the re-rank will claim "every row closer than lb is in the list"
+// (rerank_sym_kernel, bound_of_score) - the same expression here
+__device__ __forceinline__ double sym_row_lb(float t, double qs, double y2, const ErrModel& err) {
+    const double e = gt_err_bound(err, qs, y2);
+    return (qs - 2.0 * (double(t) * err.inv_sc2 + e)) - 1e-9 * (qs + y2);
+}
+
+// sum and number of the radii lb of the rows [p_first, p_last) that have a threshold -> acc[0], acc[1] (pre-zeroed)
+__global__ __launch_bounds__(256) void sym_radius_sum_kernel(const int64_t n, const int64_t p_first, const int64_t p_last,
+                                                             const int32_t* __restrict__ perm,
+                                                             const double* __restrict__ xn, const float* __restrict__ thr,
+                                                             const double* __restrict__ ymax2p, const ErrModel err,
+                                                             double* __restrict__ acc) {
+    double s = 0.0, c = 0.0;
+    const int64_t hi = p_last < n ? p_last : n;
+    for (int64_t p = p_first + int64_t(blockIdx.x) * 256 + threadIdx.x; p < hi; p += int64_t(gridDim.x) * 256) {
+        const float t = thr[p];
+        if (t != INFINITY && t > -3.0e38f) {
+            const double lb = sym_row_lb(t, xn[perm[p]], ymax2p[0], err);
+            s += lb > 0.0 ? lb : 0.0;
+            c += 1.0;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s += __shfl_xor(s, o);
+        c += __shfl_xor(c, o);
+    }
+    if ((threadIdx.x & 63) == 0 && c > 0.0) {
+        atomicAdd(acc, s);
+        atomicAdd(acc + 1, c);
+    }
+}
+
+// Rows whose radius is far beyond the typical one (cut x the mean over all rows) are orphans too: launch A found them
+// SOME need_m rows nearby, but none of their real neighbours - their threshold would pass most of the point set.
+// They collect nothing (+inf) and go to the repair pass (see sym_thresholds_kernel).  acc = {sum, count} over ALL rows.
+__global__ __launch_bounds__(256) void sym_radius_cut_kernel(const int64_t n, const int32_t* __restrict__ perm,
+                                                             const double* __restrict__ xn, float* __restrict__ thr,
+                                                             const double* __restrict__ ymax2p, const ErrModel err,
+                                                             const double* __restrict__ acc, const double cut) {
+    const int64_t p = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (p >= n) return;
+    const float t = thr[p];
+    if (t == INFINITY || !(t > -3.0e38f) || !(acc[1] > 0.0)) return;
+    const double lb = sym_row_lb(t, xn[perm[p]], ymax2p[0], err);
+    if (lb > cut * (acc[0] / acc[1])) thr[p] = INFINITY;
+}
+
+// the rows launch A kept for an orphan (thr = +inf on a real row, see sym_thresholds_kernel) become the head of its list
+__global__ __launch_bounds__(256) void sym_inject_orphans_kernel(const int64_t n, const int64_t p_first, const int64_t p_last,
+                                                                 const float* __restrict__ thr,
+                                                                 const uint64_t* __restrict__ lists, const int lstride,
+                                                                 const uint32_t* __restrict__ counts,
+                                                                 uint64_t* __restrict__ tlists, const int tcap,
+                                                                 uint32_t* __restrict__ tcounts) {
+    const int sub = threadIdx.x & 15;
+    const int64_t p = p_first + int64_t(blockIdx.x) * 16 + (threadIdx.x >> 4);
+    if (p >= p_last || p >= n || thr[p] != INFINITY) return;
+    const uint32_t kept = counts[p] < uint32_t(tcap) ? counts[p] : uint32_t(tcap);
+    uint32_t base = 0u;
+    if (sub == 0) base = atomicAdd(&tcounts[p], kept);
+    base = __shfl(base, 0, 16);
+    for (uint32_t c = uint32_t(sub); c < kept; c += 16u)
+        if (base + c < uint32_t(tcap)) tlists[size_t(p) * size_t(tcap) + base + c] = lists[size_t(p) * lstride + c];
+}
+
 // ---- two-stage scoring of launch B (partial distances) -----------------------------------------------------------
 // hh[p] = -1/2 sum_{k < HD} yc_k^2 over the first HD features of the sorted compact row p (float32, the float16 values
 // as they enter the MFMA): seeded with it, the first HD/16 k-steps of the chain give, for query row x,
@@ -380,7 +453,9 @@ __global__ __launch_bounds__(256) void sym_half_thresholds_kernel(const int64_t 
     float th = INFINITY, g = INFINITY;
     if (p < n) {
         const float t = thr[p];
-        if (!(t > -3.0e38f)) {
+        if (t == INFINITY) {
+            // an orphan collects nothing (sym_thresholds_kernel): th = g = +inf
+        } else if (!(t > -3.0e38f)) {
             th = -3.0e38f;   // no threshold was seeded for this row: everything passes, as in the full test
             g = -3.0e38f;
         } else {
@@ -423,7 +498,7 @@ __global__ __launch_bounds__(256) void sym_g_kernel(const int64_t n, const int64
                                                     const float* __restrict__ hs, float* __restrict__ g) {
     const int64_t p = int64_t(blockIdx.x) * 256 + threadIdx.x;
     if (p >= n_pad) return;
-    g[p] = p < n ? nextafterf(thr[p] + hs[p], -INFINITY) : INFINITY;   // as sym_thresholds_kernel forms it
+    g[p] = (p < n && thr[p] != INFINITY) ? nextafterf(thr[p] + hs[p], -INFINITY) : INFINITY;   // as sym_thresholds_kernel forms it
 }
 
 __global__ __launch_bounds__(256) void invperm_kernel(const int32_t* __restrict__ perm, const int64_t n,
@@ -560,6 +635,31 @@ int gt_sym_thresholds(gt_ctx* ctx, const int32_t* perm, int64_t n_pad_s, const f
         hipLaunchKernelGGL(sym_gmin_kernel, dim3((unsigned)ceil_div64(n_pad_s, 256)), dim3(256), 0, ctx->stream, n_pad_s, g, gmin);
         GT_HIP(ctx, hipGetLastError());
     }
+    return GT_OK;
+}
+
+int gt_sym_radius_sum(gt_ctx* ctx, const int32_t* perm, int64_t p_first, int64_t p_last, const float* thr, const ErrModel& err,
+                      double* acc) {
+    if (p_last <= p_first) return GT_OK;
+    hipLaunchKernelGGL(sym_radius_sum_kernel, dim3(256), dim3(256), 0, ctx->stream, ctx->n, p_first, p_last, perm,
+                       ctx->xn.as<double>(), thr, ctx->ymax.as<double>(), err, acc);
+    GT_HIP(ctx, hipGetLastError());
+    return GT_OK;
+}
+
+int gt_sym_radius_cut(gt_ctx* ctx, const int32_t* perm, float* thr, const ErrModel& err, const double* acc, double cut) {
+    hipLaunchKernelGGL(sym_radius_cut_kernel, dim3((unsigned)ceil_div64(ctx->n, 256)), dim3(256), 0, ctx->stream, ctx->n, perm,
+                       ctx->xn.as<double>(), thr, ctx->ymax.as<double>(), err, acc, cut);
+    GT_HIP(ctx, hipGetLastError());
+    return GT_OK;
+}
+
+int gt_sym_inject_orphans(gt_ctx* ctx, int64_t p_first, int64_t p_last, const float* thr, const uint64_t* lists, int lstride,
+                          const uint32_t* counts, uint64_t* tlists, int tcap, uint32_t* tcounts) {
+    if (p_last <= p_first) return GT_OK;
+    hipLaunchKernelGGL(sym_inject_orphans_kernel, dim3((unsigned)ceil_div64(p_last - p_first, 16)), dim3(256), 0, ctx->stream,
+                       ctx->n, p_first, p_last, thr, lists, lstride, counts, tlists, tcap, tcounts);
+    GT_HIP(ctx, hipGetLastError());
     return GT_OK;
 }
 

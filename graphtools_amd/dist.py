@@ -176,13 +176,13 @@ class ShardedKnnGraph(object):
             return False
         rows = int(sorted_splits[self.rank + 1] - sorted_splits[self.rank])
         thr_local = torch.empty(max(rows, 1), dtype=torch.float32, device=device)
-        far = ctx.graph_sym_seed(thr_local.data_ptr())
+        stats = ctx.graph_sym_seed(thr_local.data_ptr())      # [far-kept rows, sum of radii, rows with a radius]
         thr_all = allgather_vector(thr_local[:rows], sorted_splits, self.group).contiguous()
-        far_t = torch.tensor([far], dtype=torch.int64, device=device)
-        dist.all_reduce(far_t, group=self.group)
+        stats_t = torch.as_tensor(np.asarray(stats, dtype=np.float64), device=device)
+        dist.all_reduce(stats_t, group=self.group)            # every rank receives the same sums
         if thr_all.is_cuda:
             torch.cuda.synchronize(device)
-        ok, send_counts = ctx.graph_sym_collect(thr_all.data_ptr(), int(far_t.item()), self.world)
+        ok, send_counts = ctx.graph_sym_collect(thr_all.data_ptr(), stats_t.cpu().numpy(), self.world)
         if not ok:      # the predictor saw the summed count: the same verdict on every rank
             return False
         total = int(send_counts.sum())

@@ -172,9 +172,11 @@ int gt_graph_anisotropy(gt_ctx* ctx, const double* degree_all_dev);
  * as ALL ranks stop - the host all-reduces the flag - and gt_graph_begin then runs the classic candidate pass):
  *   gt_graph_sym_plan    applies (out): this context can run it for these parameters; n_pad_sorted, sorted_splits
  *                        [world + 1] (out): positions of the shared cell-sorted row order whose thresholds each rank seeds
- *   gt_graph_sym_seed    thr_local (device, float32 [sorted_splits[rank+1] - sorted_splits[rank]], out), far_local (out)
- *                        -> the host all-gathers thr_local into float32 [n_pad_sorted] and sums far_local over the ranks
- *   gt_graph_sym_collect thr_all (device), far_total; applies (out), send_counts [world] (out, 16-byte records
+ *   gt_graph_sym_seed    thr_local (device, float32 [sorted_splits[rank+1] - sorted_splits[rank]], out), far_local (out),
+ *                        radius_local [2] (out: sum and count of the rows' completeness radii)
+ *                        -> the host all-gathers thr_local into float32 [n_pad_sorted] and sums far_local and
+ *                           radius_local over the ranks
+ *   gt_graph_sym_collect thr_all (device), far_total, radius_total [2]; applies (out), send_counts [world] (out, 16-byte records
  *                        {uint32 row local to its owner, uint32 0, uint64 candidate key})
  *   gt_graph_sym_emit    records bucketed by destination rank into the caller's device buffer
  *                        -> the host moves them with the all-to-all it uses for the triplets
@@ -183,8 +185,9 @@ int gt_graph_anisotropy(gt_ctx* ctx, const double* degree_all_dev);
  * counterpart: the reference is single-process (its search is sklearn's kneighbors, graphs.py:883). */
 int gt_graph_sym_plan(gt_ctx* ctx, const gt_knn_params* params, int32_t world, int32_t rank, const int64_t* row_splits,
                       int32_t* applies, int64_t* n_pad_sorted, int64_t* sorted_splits);
-int gt_graph_sym_seed(gt_ctx* ctx, void* thr_local_dev, int64_t* far_local);
-int gt_graph_sym_collect(gt_ctx* ctx, const void* thr_all_dev, int64_t far_total, int32_t* applies, int64_t* send_counts);
+int gt_graph_sym_seed(gt_ctx* ctx, void* thr_local_dev, int64_t* far_local, double* radius_local);
+int gt_graph_sym_collect(gt_ctx* ctx, const void* thr_all_dev, int64_t far_total, const double* radius_total, int32_t* applies,
+                         int64_t* send_counts);
 int gt_graph_sym_emit(gt_ctx* ctx, void* send_buf_dev);
 int gt_graph_sym_finish(gt_ctx* ctx, const void* recv_buf_dev, int64_t n_recv);
 /* single-GPU convenience: begin + emit + finish with an internal buffer */

@@ -72,9 +72,11 @@ class FakeCtx(object):
         p0, p1 = int(self.sorted_splits[self.rank]), int(self.sorted_splits[self.rank + 1])
         out = np.frombuffer((ctypes.c_char * ((p1 - p0) * 4)).from_address(ptr), dtype=np.float32)
         out[:] = 0.5 * np.arange(p0, p1)
-        return 10 + self.rank
+        return np.array([10.0 + self.rank, 1.5 * (self.rank + 1), 2.0], dtype=np.float64)
 
-    def graph_sym_collect(self, ptr, far_total, world):
+    def graph_sym_collect(self, ptr, stats_total, world):
+        far_total = int(round(stats_total[0]))
+        assert abs(stats_total[1] - sum(1.5 * (r + 1) for r in range(world))) < 1e-12 and stats_total[2] == 2.0 * world
         self.calls = self.calls + ("collect",)
         thr = np.frombuffer((ctypes.c_char * (self.n_pad * 4)).from_address(ptr), dtype=np.float32)
         assert np.array_equal(thr, 0.5 * np.arange(self.n_pad, dtype=np.float32)), "thresholds were not gathered in order"

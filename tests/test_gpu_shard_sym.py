@@ -53,7 +53,7 @@ def sharded_build(X, splits, pargs, opts=None):
         ss = plans[0][2]
         assert all(np.array_equal(pl[2], ss) and pl[1] == n_pad for pl in plans)
         assert ss[0] == 0 and ss[-1] == n_pad
-        parts, far = [], 0
+        parts, far = [], np.zeros(3)
         for r, c in enumerate(ctxs):
             rows = int(ss[r + 1] - ss[r])
             buf = c.dev_alloc(max(rows, 1) * 4)

@@ -33,7 +33,7 @@ if os.environ.get("GT_DBG"):
 ctx.set_points(X)
 p, keep = ctx.make_params(15, 40.0, 1e-4, None, 1.0, None, "+", None, 0)
 # phase 1: every rank's seeds (the thresholds do not depend on who computes them)
-parts, far, seed_ms = [], 0, []
+parts, far, seed_ms = [], np.zeros(3), []
 for r in range(world):
     ok, n_pad, ss = ctx.graph_sym_plan(p, world, r, splits)
     assert ok, "plan refused"
@@ -46,7 +46,7 @@ for r in range(world):
     parts.append(host)
     seed_ms.append({s: round(ctx.stage_ms(s), 3) for s in ("query_order", "sym_prepare", "sym_seed")})
 thr_all = np.concatenate(parts)
-print(json.dumps({"seed_stage_ms_rank0": seed_ms[0], "seed_stage_ms_last": seed_ms[-1], "far": far}), flush=True)
+print(json.dumps({"seed_stage_ms_rank0": seed_ms[0], "seed_stage_ms_last": seed_ms[-1], "far": [float(v) for v in far]}), flush=True)
 if os.environ.get("GT_COLLECT_ONLY"):
     tb = ctx.dev_alloc(n_pad * 4)
     ctx.dev_upload(tb, thr_all)
