@@ -322,22 +322,23 @@ class Context:
         return bool(applies.value), n_pad.value, sorted_splits
 
     def graph_sym_seed(self, thr_local_ptr):
-        """launch A for the planned share; float32 thresholds of it to thr_local_ptr (device); -> statistics of the
-        share the host sums over the ranks: numpy float64 [far-kept rows, sum of radii, rows with a radius]"""
+        """launch A for the planned share; float32 {threshold, far-kept seeds} pairs of its positions to thr_local_ptr
+        (device, [rows][2]); -> statistics of the
+        share the host sums over the ranks: numpy float64 [far-kept rows, then the four sums behind the orphan cut]"""
         far = ctypes.c_int64(0)
-        rad = np.zeros(2, dtype=np.float64)
+        rad = np.zeros(4, dtype=np.float64)
         self._check(self.lib.gt_graph_sym_seed(self.h, ctypes.c_void_p(int(thr_local_ptr)) if thr_local_ptr else None,
                                                ctypes.byref(far), _ptr(rad)), "gt_graph_sym_seed")
-        return np.array([float(far.value), rad[0], rad[1]], dtype=np.float64)
+        return np.concatenate([[float(far.value)], rad])
 
     def graph_sym_collect(self, thr_all_ptr, stats_total, world):
-        """launch B for this rank's pieces against the thresholds of all rows (device, float32 [n_pad_sorted]) and the
+        """launch B for this rank's pieces against the gathered pairs of all rows (device, float32 [n_pad_sorted][2]) and the
         summed statistics of graph_sym_seed; -> (applies, send_counts): records per destination rank, or applies False
         when the predictor refuses"""
         applies = ctypes.c_int32(0)
         counts = np.zeros(world, dtype=np.int64)
         st = np.ascontiguousarray(stats_total, dtype=np.float64)
-        rad = np.ascontiguousarray(st[1:3])
+        rad = np.ascontiguousarray(st[1:5])
         self._check(self.lib.gt_graph_sym_collect(self.h, ctypes.c_void_p(int(thr_all_ptr)), int(round(st[0])), _ptr(rad),
                                                   ctypes.byref(applies), _ptr(counts)), "gt_graph_sym_collect")
         return bool(applies.value), counts

@@ -276,6 +276,14 @@ int gt_set_option(gt_ctx* ctx, const char* name, const char* value) {
         ctx->sym_stride = std::max(0, std::atoi(value));
         return GT_OK;
     }
+    if (k == "select_sym_radius_cut") {
+        ctx->sym_radius_cut = std::atof(value);
+        return GT_OK;
+    }
+    if (k == "select_sym_orphan_far") {
+        ctx->sym_orphan_far = std::max(0, std::atoi(value));
+        return GT_OK;
+    }
     if (k == "select_sym_two_stage") {
         ctx->sym_two_stage = v == "auto" ? -1 : std::atoi(value);
         return GT_OK;

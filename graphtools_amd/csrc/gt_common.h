@@ -148,6 +148,7 @@ struct gt_ctx {
     int32_t sym_tcap = 512;     //   capacity of a row's candidate list in launch B (<= 512)
     int32_t sym_ok = -1;        //   auto: 0 once the bound point set has overflowed the lists of launch B (reset by gt_set_points)
     int32_t sym_nseg = 0;       //   work items per query block in launch B (0: chosen to fill the last round of workgroups)
+    int32_t sym_orphan_far = 4;  //  a row is an orphan when this many times its far-kept seeds reach the seeds wanted (0: off)
     double sym_radius_cut = 4.0; //  rows whose completeness radius (squared) exceeds this many times the mean are repaired directly
     int32_t sym_two_stage = -1; //   launch B scores half the features first (partial distances): -1 auto, 0 off, 1 on
     int32_t sym_two_steps = 0;  //   k-steps of stage one (0: half of them; development, must match the kernel build)

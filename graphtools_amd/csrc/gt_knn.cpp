@@ -16,7 +16,7 @@ void gt_free_knn_work(gt_ctx* ctx) {
                       &k->d2_lb, &k->fb_rows, &k->fb_count, &k->fb_scratch, &k->gflags, &k->prof, &k->fb_qrows, &k->fb_thr, &k->fb_lists,
                       &k->fb_counts, &k->fb_max, &k->unproven, &k->qorder, &k->qthr0, &k->qlomax_dev, &k->Ycs, &k->hnegs,
                       &k->sym_g, &k->sym_gmin, &k->tlists, &k->tcounts, &k->sym_stat, &k->sym_work, &k->sym_tiles,
-                      &k->sym_tile_cnt, &k->sh_invperm, &k->sh_lists, &k->sh_counts, &k->sh_cnt, &k->sh_own, &k->sh_tmp, &k->sym_hh, &k->sym_thrh, &k->sym_gh, &k->sym_gminh, &k->sym_queue, &k->sym_qcount, &k->sym_qdense, &k->sym_qtot, &k->sym_racc})
+                      &k->sym_tile_cnt, &k->sh_invperm, &k->sh_lists, &k->sh_counts, &k->sh_cnt, &k->sh_own, &k->sh_tmp, &k->sym_hh, &k->sym_thrh, &k->sym_gh, &k->sym_gminh, &k->sym_queue, &k->sym_qcount, &k->sym_qdense, &k->sym_qtot, &k->sym_racc, &k->sym_farcnt})
         b->release();
     delete k;
     ctx->knn = nullptr;
@@ -263,7 +263,7 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
         if (sym_now && main_prec == 2) {
             // two-stage scoring: half the features first, against partial-distance thresholds (gt_sym.hip sym_half_*);
             // its collect kernel works on query blocks of up to 1024 rows
-            const bool two_stage = ctx->DP % 32 == 0 && bq_sym == 256 &&
+            const bool two_stage = ctx->DP >= 32 && bq_sym == 256 &&
                                    (ctx->sym_two_stage > 0 || (ctx->sym_two_stage < 0 && ctx->sym_two_ok != 0));
             const int64_t pad_s = two_stage ? 1024 : bq_sym;
             const int64_t n_pad_s = ceil_div64(nq, pad_s) * pad_s;
@@ -323,20 +323,16 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
             if (ctx->dbg_select & 1024) return GT_OK;   // experiment: stop behind the seeding launch (tables are NOT valid)
             {
                 StageSpan span(ctx, "sym_prepare");
+                GT_HIP(ctx, k->sym_farcnt.reserve(size_t(n_pad_s) * sizeof(float)));
+                GT_HIP(ctx, k->sym_racc.reserve(4 * sizeof(double)));
+                GT_HIP(ctx, hipMemsetAsync(k->sym_racc.p, 0, 4 * sizeof(double), ctx->stream));
                 GT_TRY(gt_sym_thresholds(ctx, perm, n_pad_s, k->hnegs.as<float>(), k->lists.as<uint64_t>(), int(lcap),
                                          k->counts.as<uint32_t>(), need_m, em, rkf, k->thr_final.as<float>(),
-                                         k->sym_g.as<float>(), nullptr, k->sym_work, ctx->sym_cells,
-                                         k->sym_stat.as<unsigned long long>() + 2));
-                // rows with a radius far beyond the typical one are orphans as well (gt_sym.hip sym_radius_cut_kernel)
-                GT_HIP(ctx, k->sym_racc.reserve(2 * sizeof(double)));
-                GT_HIP(ctx, hipMemsetAsync(k->sym_racc.p, 0, 2 * sizeof(double), ctx->stream));
+                                         k->sym_g.as<float>(), k->sym_gmin.as<float>(), k->sym_work, ctx->sym_cells,
+                                         k->sym_stat.as<unsigned long long>() + 2, k->sym_farcnt.as<float>()));
+                // statistics for the orphan cut of the two-stage collect (gt_sym_two_stage_prepare)
                 GT_TRY(gt_sym_radius_sum(ctx, perm, 0, n_pad_s, k->thr_final.as<float>(), em, k->sym_racc.as<double>()));
-                GT_TRY(gt_sym_radius_cut(ctx, perm, k->thr_final.as<float>(), em, k->sym_racc.as<double>(), ctx->sym_radius_cut));
-                GT_TRY(gt_sym_g_from_thr(ctx, n_pad_s, k->thr_final.as<float>(), k->hnegs.as<float>(), k->sym_g.as<float>(),
-                                         k->sym_gmin.as<float>()));
                 GT_HIP(ctx, hipMemsetAsync(k->tcounts.p, 0, size_t(n_pad_s) * sizeof(uint32_t), ctx->stream));
-                GT_TRY(gt_sym_inject_orphans(ctx, 0, n_pad_s, k->thr_final.as<float>(), k->lists.as<uint64_t>(), int(lcap),
-                                             k->counts.as<uint32_t>(), k->tlists.as<uint64_t>(), tcap, k->tcounts.as<uint32_t>()));
             }
             if (ctx->sym_mode < 0) {
                 // launch A kept need_m rows per point: when most of them came from the strided sample instead of the cells
@@ -378,23 +374,16 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
                 k->sym_nseg = a.sym.nseg;
             }
             a.thr_in = k->thr_final.as<float>();
-            if (two_stage) {
-                const int hd = ctx->sym_two_steps > 0 ? 16 * ctx->sym_two_steps : ctx->DP / 2;
-                GT_HIP(ctx, k->sym_hh.reserve(size_t(n_pad_s) * sizeof(float)));
-                GT_HIP(ctx, k->sym_thrh.reserve(size_t(n_pad_s) * sizeof(float)));
-                GT_HIP(ctx, k->sym_gh.reserve(size_t(n_pad_s) * sizeof(float)));
-                GT_HIP(ctx, k->sym_gminh.reserve(size_t(n_pad_s / 32) * sizeof(float)));
-                StageSpan span(ctx, "sym_prepare");
-                GT_TRY(gt_sym_half_seeds(ctx, k->Ycs.p, n_pad_s, hd, k->sym_hh.as<float>()));
-                GT_TRY(gt_sym_half_thresholds(ctx, perm, n_pad_s, k->thr_final.as<float>(), k->sym_hh.as<float>(), em, hd,
-                                              k->sym_thrh.as<float>(), k->sym_gh.as<float>(), k->sym_gminh.as<float>()));
-                a.sym.half_steps = hd / 16;
-                a.sym.hh = k->sym_hh.as<float>();
-                a.sym.thrh = k->sym_thrh.as<float>();
-                a.sym.gminh = k->sym_gminh.as<float>();
+            if (two_stage) GT_TRY(gt_sym_two_stage_prepare(ctx, perm, n_pad_s, em, need_m, a));
+            const bool two_now = a.sym.half_steps > 0;
+            // (the orphans it declared start their lists with the rows launch A kept for them)
+            if (two_now)
+                GT_TRY(gt_sym_inject_orphans(ctx, 0, n_pad_s, k->thr_final.as<float>(), k->lists.as<uint64_t>(), int(lcap),
+                                             k->counts.as<uint32_t>(), k->tlists.as<uint64_t>(), tcap, k->tcounts.as<uint32_t>()));
+            if (two_now) {
                 if (ctx->sym_nseg <= 0) {
-                    // (the collect workgroups of this kernel take 512 rows: NB x nseg items must fill the rounds)
-                    const int64_t slots = int64_t(ctx->n_cu) * 3, nb = ceil_div64(n_pad_s, 512);
+                    // (the collect workgroups of this kernel take 1024 rows: NB x nseg items must fill the rounds)
+                    const int64_t slots = int64_t(ctx->n_cu) * 3, nb = ceil_div64(n_pad_s, 1024);
                     int best = 1;
                     double best_cost = 1e30;
                     for (int sgm = 1; sgm <= 8; ++sgm) {
@@ -409,7 +398,7 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
                 StageSpan span(ctx, "knn_select");
                 GT_TRY(gt_launch_select(ctx, a));
             }
-            if (two_stage) {
+            if (two_now) {
                 int ok = 0;
                 GT_TRY(gt_sym_queue_finish(ctx, a, &k->sym_cold_entries, &ok));
                 if (!ok) {
@@ -550,6 +539,9 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
                 GT_HIP(ctx, hipMemcpyAsync(host_max, k->fb_max.p, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
                 GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
             }
+            if (ctx->dbg_select & 2048)
+                fprintf(stderr, "[gt] repair batch: %lld rows, capacity %lld, longest collected list %u\n", (long long)rows,
+                        (long long)cap, host_max[0]);
             if (int64_t(host_max[0]) > cap) {
                 if (cap >= ctx->n_pad) GT_FAIL(ctx, GT_E_STATE, "fallback: inconsistent collected count");
                 cap = std::min<int64_t>(ctx->n_pad, std::max<int64_t>(cap * 8, int64_t(host_max[0]) + 64));
@@ -581,14 +573,61 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
     return GT_OK;
 }
 
+int gt_sym_two_stage_prepare(gt_ctx* ctx, const int32_t* perm, int64_t n_pad_s, const ErrModel& em, int need_m, SelectArgs& a,
+                             bool cut_done) {
+    KnnWork* k = ctx->knn;
+    const int hd = ctx->sym_two_steps > 0 ? 16 * ctx->sym_two_steps : 16;
+    GT_HIP(ctx, k->sym_hh.reserve(size_t(n_pad_s) * sizeof(float)));
+    GT_HIP(ctx, k->sym_thrh.reserve(size_t(n_pad_s) * sizeof(float)));
+    GT_HIP(ctx, k->sym_gh.reserve(size_t(n_pad_s) * sizeof(float)));
+    GT_HIP(ctx, k->sym_gminh.reserve(size_t(n_pad_s / 32) * sizeof(float)));
+    GT_HIP(ctx, k->sym_qtot.reserve(2 * sizeof(uint32_t)));
+    uint32_t flagged = 0;
+    const int64_t samples = 8192;
+    {
+        StageSpan span(ctx, "sym_prepare");
+        GT_TRY(gt_sym_half_seeds(ctx, k->Ycs.p, n_pad_s, hd, k->sym_hh.as<float>()));
+        GT_TRY(gt_sym_half_thresholds(ctx, perm, n_pad_s, k->thr_final.as<float>(), k->sym_hh.as<float>(), em, hd,
+                                      k->sym_thrh.as<float>(), k->sym_gh.as<float>(), k->sym_gminh.as<float>()));
+        if (ctx->sym_two_stage < 0)
+            GT_TRY(gt_sym_two_probe(ctx, k->Ycs.p, hd, k->sym_hh.as<float>(), k->sym_thrh.as<float>(), k->sym_gh.as<float>(),
+                                    samples, k->sym_qtot.as<uint32_t>()));
+    }
+    if (ctx->sym_two_stage < 0) {
+        GT_HIP(ctx, hipMemcpyAsync(&flagged, k->sym_qtot.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->dbg_select & 2048) fprintf(stderr, "[gt] two-stage forecast: %u of %lld sampled pairs pass stage one\n", flagged, (long long)samples);
+        // the queue holds one pair in 8; forecast beyond one in 24: partial distances are a poor filter on this point set
+        if (int64_t(flagged) * 24 > samples) {
+            ctx->sym_two_ok = 0;
+            return GT_OK;
+        }
+    }
+    if (!cut_done) {
+        // going ahead: the orphans lose their thresholds (a handful of rows; the forecast above was made with them), the
+        // forms derived from the thresholds are made again
+        StageSpan span(ctx, "sym_prepare");
+        GT_TRY(gt_sym_orphan_cut(ctx, perm, k->thr_final.as<float>(), k->sym_farcnt.as<float>(), em, k->sym_racc.as<double>(), need_m));
+        GT_TRY(gt_sym_g_from_thr(ctx, n_pad_s, k->thr_final.as<float>(), k->hnegs.as<float>(), k->sym_g.as<float>(),
+                                 k->sym_gmin.as<float>()));
+        GT_TRY(gt_sym_half_thresholds(ctx, perm, n_pad_s, k->thr_final.as<float>(), k->sym_hh.as<float>(), em, hd,
+                                      k->sym_thrh.as<float>(), k->sym_gh.as<float>(), k->sym_gminh.as<float>()));
+    }
+    a.sym.half_steps = hd / 16;
+    a.sym.hh = k->sym_hh.as<float>();
+    a.sym.thrh = k->sym_thrh.as<float>();
+    a.sym.gminh = k->sym_gminh.as<float>();
+    return GT_OK;
+}
+
 int gt_sym_queue_prepare(gt_ctx* ctx, int64_t n_pad_s, SelectArgs& a) {
     KnnWork* k = ctx->knn;
     // one region per wave of the collect launch (its workgroups take at least 512 rows), sized so that all of them
-    // together hold about one pair in 16 - beyond that stage one is not doing its job
+    // together hold about one pair in 8 - beyond that stage one is not doing its job
     const int64_t nwaves = (n_pad_s / 512) * a.sym.nseg * 4;
     const int64_t units = (n_pad_s / 64) * (n_pad_s / 32) / 2 / std::max(1, a.sym.shard_world);
-    int64_t rcap = 256;
-    while (rcap < 8192 && rcap * nwaves < units / 16) rcap *= 2;
+    int64_t rcap = 1024;   // (a wave next to the diagonal of a clustered set notes several hundred pairs)
+    while (rcap < 8192 && rcap * nwaves < units / 8) rcap *= 2;
     GT_HIP(ctx, k->sym_queue.reserve(size_t(nwaves) * size_t(rcap) * sizeof(uint2)));
     GT_HIP(ctx, k->sym_qcount.reserve(size_t(nwaves) * sizeof(uint32_t)));
     GT_HIP(ctx, hipMemsetAsync(k->sym_qcount.p, 0, size_t(nwaves) * sizeof(uint32_t), ctx->stream));

@@ -29,7 +29,8 @@ struct KnnWork {
     // symmetric candidate pass (gt_sym.hip): cell-sorted compact copy + seeds, per-row thresholds in the transposed
     // form and their sub-tile minima, the candidate lists of launch B and their counters
     DevBuf Ycs, hnegs, sym_g, sym_gmin, tlists, tcounts, sym_stat, sym_work, sym_tiles, sym_tile_cnt;
-    DevBuf sym_racc;                              // {sum, count} of the rows' radii (orphan cut)
+    DevBuf sym_racc, sym_farcnt;                     // radius / spread statistics of the orphan cut (4 doubles), far-kept
+                                                  // seeds per sorted position
     DevBuf sym_hh, sym_thrh, sym_gh, sym_gminh;   // two-stage scoring (gt_sym.hip sym_half_*)
     DevBuf sym_queue, sym_qcount, sym_qdense, sym_qtot;   //   and the queue of its deferred cold pass (wave regions,
                                                           //   their counts, the compacted queue, {total, overflow})
@@ -173,12 +174,22 @@ int gt_sym_gather(gt_ctx* ctx, const int32_t* perm, int64_t n_pad_s, void* Ys, f
 // rows [p_first, p_last) of the sorted order only (p_last < 0: all); gmin = nullptr: sub-tile minima not formed
 int gt_sym_thresholds(gt_ctx* ctx, const int32_t* perm, int64_t n_pad_s, const float* hs, const uint64_t* lists, int lstride,
                       const uint32_t* counts, int need_m, const ErrModel& err, double rkf, float* thr, float* g, float* gmin,
-                      const DevBuf& work, int cells, unsigned long long* far_total, int64_t p_first = 0, int64_t p_last = -1);
+                      const DevBuf& work, int cells, unsigned long long* far_total, float* farcnt = nullptr,
+                      int64_t p_first = 0, int64_t p_last = -1);
 // two-stage scoring of launch B: half seeds of the sorted rows, partial-distance thresholds from the full ones
 int gt_sym_half_seeds(gt_ctx* ctx, const void* Ys, int64_t n_pad_s, int hd, float* hh);
+// forecast of stage one: of `samples` pseudo-random (64 queries, 32 rows) pairs, how many pass (flagged: device counter)
+int gt_sym_two_probe(gt_ctx* ctx, const void* Ys, int hd, const float* hh, const float* thrh, const float* gh, int64_t samples,
+                     uint32_t* flagged);
 struct SelectArgs;
 // queue of the two-stage collect launch `a` (mode 2 with sym.half_steps): sizes and binds the wave regions
 int gt_sym_queue_prepare(gt_ctx* ctx, int64_t n_pad_s, SelectArgs& a);
+// half seeds + partial-distance thresholds + forecast: binds them to `a` (sym.half_steps > 0) when stage one is expected to
+// pass few enough pairs for the queue, leaves `a` a one-stage launch otherwise
+// (declares the orphans first - thr, g, gmin are updated - when it goes ahead)
+// cut_done: the orphans were already declared (row-sharded builds do it on every rank alike, whatever each rank decides here)
+int gt_sym_two_stage_prepare(gt_ctx* ctx, const int32_t* perm, int64_t n_pad_s, const ErrModel& em, int need_m, SelectArgs& a,
+                             bool cut_done = false);
 // after that launch: compacts the queue and runs the cold pass; *entries = pairs scored, *ok = 0 when the queue
 // overflowed (nothing was filed: the caller runs the one-stage kernel instead)
 int gt_sym_queue_finish(gt_ctx* ctx, const SelectArgs& a, int64_t* entries, int* ok);
@@ -187,11 +198,14 @@ int gt_sym_half_thresholds(gt_ctx* ctx, const int32_t* perm, int64_t n_pad_s, co
 // row-sharded symmetric pass (gt_knn_shard.cpp)
 #define GT_SYM_MAX_WORLD 64
 int gt_sym_g_from_thr(gt_ctx* ctx, int64_t n_pad_s, const float* thr, const float* hs, float* g, float* gmin);
-// radii of the thresholds: {sum, count} over the rows [p_first, p_last) added into acc (device, 2 doubles); rows whose
-// radius exceeds cut x the mean of acc lose their threshold (+inf: orphans, repaired directly)
+// statistics of the thresholds' radii and of the point set's spread over the rows [p_first, p_last), added into acc
+// (device, 4 doubles: gt_sym.hip sym_radius_sum_kernel); the orphans of the two-stage collect - by their far-kept seeds
+// (farcnt, from gt_sym_thresholds) or by a radius that is an outlier against those statistics - lose their threshold
+// (+inf: repaired directly)
 int gt_sym_radius_sum(gt_ctx* ctx, const int32_t* perm, int64_t p_first, int64_t p_last, const float* thr, const ErrModel& err,
                       double* acc);
-int gt_sym_radius_cut(gt_ctx* ctx, const int32_t* perm, float* thr, const ErrModel& err, const double* acc, double cut);
+int gt_sym_orphan_cut(gt_ctx* ctx, const int32_t* perm, float* thr, const float* farcnt, const ErrModel& err, const double* acc,
+                      int need_m);
 // orphans of the sorted positions [p_first, p_last) (thr = +inf on a real row): the rows launch A kept -> head of tlists
 int gt_sym_inject_orphans(gt_ctx* ctx, int64_t p_first, int64_t p_last, const float* thr, const uint64_t* lists, int lstride,
                           const uint32_t* counts, uint64_t* tlists, int tcap, uint32_t* tcounts);

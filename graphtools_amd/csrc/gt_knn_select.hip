@@ -67,10 +67,10 @@
 #define GT_SEL_TWO_VPM 5   // two-stage collect: VALU instructions scheduled behind each MFMA of the unit loop
 #endif
 #ifndef GT_SEL_TWO_QT
-#define GT_SEL_TWO_QT 4   // query tiles per wave of the two-stage collect kernel (query block = 128 x this many rows)
+#define GT_SEL_TWO_QT 8   // query tiles per wave of the two-stage collect kernel (query block = 128 x this many rows)
 #endif
 #ifndef GT_SEL_TWO_NS1
-#define GT_SEL_TWO_NS1(DP_) ((DP_) / 32)   // k-steps (16 features each) of stage one of the two-stage symmetric collect
+#define GT_SEL_TWO_NS1(DP_) 1   // k-steps (16 features each) of stage one of the two-stage symmetric collect
 #endif
 #ifndef GT_SEL_PAIRCOLD
 #define GT_SEL_PAIRCOLD 1
@@ -1329,19 +1329,19 @@ int launch_dp(gt_ctx* ctx, const SelectArgs& a) {
     if (a.mode == 1) return launch_one<DP, 8, 1, PREC>(ctx, a);
     if (a.mode == 5) return launch_queue_compact(ctx, a);
     if (a.mode == 4) {
-        if constexpr (PREC == 2 && DP % 32 == 0 && SelCfg<DP, PREC>::QT == 2) return launch_sym_cold<DP>(ctx, a);
+        if constexpr (PREC == 2 && DP >= 32 && SelCfg<DP, PREC>::QT == 2) return launch_sym_cold<DP>(ctx, a);
         GT_FAIL(ctx, GT_E_ARG, "knn_select: no cold pass for this kernel shape");
     }
     if (a.mode == 2) {
         if constexpr (PREC == 2) {
             if (a.sym.half_steps > 0) {
-                if constexpr (DP % 32 == 0 && SelCfg<DP, PREC>::QT == 2) {
+                if constexpr (DP >= 32 && SelCfg<DP, PREC>::QT == 2) {
                     if (a.sym.half_steps != GT_SEL_TWO_NS1(DP) || !a.sym.hh || !a.sym.thrh || !a.sym.gminh || !a.sym.queue ||
                         !a.sym.qcount || a.sym.qcap <= 0)
                         GT_FAIL(ctx, GT_E_ARG, "knn_select: two-stage scoring needs the half seeds and thresholds");
                     return launch_one<DP, 8, 3, PREC>(ctx, a);
                 }
-                GT_FAIL(ctx, GT_E_ARG, "knn_select: two-stage scoring is built for 32 | DP, 256-row blocks");
+                GT_FAIL(ctx, GT_E_ARG, "knn_select: two-stage scoring is built for 32 ... 64 padded features");
             }
             return launch_one<DP, 8, 2, PREC>(ctx, a);
         }

@@ -46,7 +46,7 @@ int gt_knn_shard_plan(gt_ctx* ctx, int world, int rank, const int64_t* splits, i
     if (!shard_applicable(ctx, need_m) || splits[rank + 1] <= splits[rank]) return GT_OK;
     const int bq = gt_select_bq(ctx->DP);
     // (the two-stage collect kernel works on query blocks of up to 1024 rows; the seeding shares stay 256-row blocks)
-    const bool two = ctx->DP % 32 == 0 && bq == 256 && (ctx->sym_two_stage > 0 || (ctx->sym_two_stage < 0 && ctx->sym_two_ok != 0));
+    const bool two = ctx->DP >= 32 && bq == 256 && (ctx->sym_two_stage > 0 || (ctx->sym_two_stage < 0 && ctx->sym_two_ok != 0));
     const int64_t pad_s = two ? 1024 : bq;
     const int64_t n_pad_s = ceil_div64(ctx->n, pad_s) * pad_s;
     const int64_t NB = n_pad_s / bq;
@@ -99,6 +99,8 @@ int gt_knn_shard_seed(gt_ctx* ctx, float* thr_local, int64_t* far_local, double*
     GT_HIP(ctx, k->lists.reserve(size_t(std::max<int64_t>(p1 - p0, bq)) * lcap * sizeof(uint64_t)));   // own blocks only
     GT_HIP(ctx, k->counts.reserve(size_t(n_pad_s) * sizeof(uint32_t)));
     GT_HIP(ctx, k->thr_final.reserve(size_t(n_pad_s) * sizeof(float)));
+    GT_HIP(ctx, k->sym_farcnt.reserve(size_t(n_pad_s) * sizeof(float)));
+    GT_HIP(ctx, hipMemsetAsync(k->sym_farcnt.p, 0, size_t(n_pad_s) * sizeof(float), ctx->stream));
     GT_HIP(ctx, hipMemsetAsync(k->sym_stat.p, 0, 8 * sizeof(unsigned long long), ctx->stream));
     const int n_tiles_s = int(n_pad_s / bn);
     const int stride_a = ctx->sym_stride > 0 && n_tiles_s >= 8 * ctx->sym_stride ? ctx->sym_stride : 0;
@@ -166,15 +168,19 @@ int gt_knn_shard_seed(gt_ctx* ctx, float* thr_local, int64_t* far_local, double*
         StageSpan span(ctx, "sym_prepare");
         GT_TRY(gt_sym_thresholds(ctx, perm, n_pad_s, k->hnegs.as<float>(), lists0, int(lcap), k->counts.as<uint32_t>(), need_m,
                                  em, std::max(1.0, std::fabs(k->sh_rkf)), k->thr_final.as<float>(), k->sym_g.as<float>(),
-                                 nullptr, k->sym_work, ctx->sym_cells, k->sym_stat.as<unsigned long long>() + 2, p0, p1));
-        GT_HIP(ctx, hipMemcpyAsync(thr_local, k->thr_final.as<float>() + p0, size_t(p1 - p0) * sizeof(float),
-                                   hipMemcpyDeviceToDevice, ctx->stream));
+                                 nullptr, k->sym_work, ctx->sym_cells, k->sym_stat.as<unsigned long long>() + 2,
+                                 k->sym_farcnt.as<float>(), p0, p1));
+        // {threshold, far-kept seeds} of every position of the share, interleaved, to the caller
+        GT_HIP(ctx, hipMemcpy2DAsync(thr_local, 2 * sizeof(float), k->thr_final.as<float>() + p0, sizeof(float), sizeof(float),
+                                     size_t(p1 - p0), hipMemcpyDeviceToDevice, ctx->stream));
+        GT_HIP(ctx, hipMemcpy2DAsync(thr_local + 1, 2 * sizeof(float), k->sym_farcnt.as<float>() + p0, sizeof(float), sizeof(float),
+                                     size_t(p1 - p0), hipMemcpyDeviceToDevice, ctx->stream));
     }
     // this rank's share of the radius statistics behind the orphan cut (summed over the ranks by the host)
-    GT_HIP(ctx, k->sym_racc.reserve(2 * sizeof(double)));
-    GT_HIP(ctx, hipMemsetAsync(k->sym_racc.p, 0, 2 * sizeof(double), ctx->stream));
+    GT_HIP(ctx, k->sym_racc.reserve(4 * sizeof(double)));
+    GT_HIP(ctx, hipMemsetAsync(k->sym_racc.p, 0, 4 * sizeof(double), ctx->stream));
     GT_TRY(gt_sym_radius_sum(ctx, perm, p0, p1, k->thr_final.as<float>(), em, k->sym_racc.as<double>()));
-    GT_HIP(ctx, hipMemcpyAsync(racc_local, k->sym_racc.p, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    GT_HIP(ctx, hipMemcpyAsync(racc_local, k->sym_racc.p, 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     unsigned long long far = 0;
     GT_HIP(ctx, hipMemcpyAsync(&far, k->sym_stat.as<unsigned long long>() + 2, sizeof(far), hipMemcpyDeviceToHost, ctx->stream));
     GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -201,23 +207,36 @@ int gt_knn_shard_collect(gt_ctx* ctx, const float* thr_all, int64_t far_total, c
             return GT_OK;
         }
     }
-    GT_HIP(ctx, hipMemcpyAsync(k->thr_final.p, thr_all, size_t(n_pad_s) * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+    // thr_all: {threshold, far-kept seeds} of every sorted position, interleaved
+    GT_HIP(ctx, hipMemcpy2DAsync(k->thr_final.p, sizeof(float), thr_all, 2 * sizeof(float), sizeof(float), size_t(n_pad_s),
+                                 hipMemcpyDeviceToDevice, ctx->stream));
+    GT_HIP(ctx, hipMemcpy2DAsync(k->sym_farcnt.p, sizeof(float), thr_all + 1, 2 * sizeof(float), sizeof(float), size_t(n_pad_s),
+                                 hipMemcpyDeviceToDevice, ctx->stream));
+    // the statistics of ALL rows behind the orphan cut (every rank holds the same sums, applies the same cut)
+    GT_HIP(ctx, hipMemcpyAsync(k->sym_racc.p, racc_total, 4 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    // The orphans (gt_sym.hip sym_orphan_cut_kernel) are declared on every rank alike wherever the two-stage collect is
+    // configured at all - whether a rank then runs it, or its forecast or its queue say no, is that rank's business, but
+    // which rows collect nothing must not differ between ranks (a row's list is the union of what the ranks collected)
+    const bool cut = n_pad_s % 1024 == 0 && ctx->DP >= 32 && bq == 256 && ctx->sym_two_stage != 0;
     {
         StageSpan span(ctx, "sym_prepare");
-        // the orphan cut on the radius statistics of ALL rows: every rank applies the same cut to the same thresholds
-        ErrModel emc = gt_err_model(ctx, 2);
-        emc.rel += 8.0 * 5.9604644775390625e-08;
-        GT_HIP(ctx, hipMemcpyAsync(k->sym_racc.p, racc_total, 2 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-        GT_TRY(gt_sym_radius_cut(ctx, k->qorder.as<int32_t>(), k->thr_final.as<float>(), emc, k->sym_racc.as<double>(),
-                                 ctx->sym_radius_cut));
+        if (cut) {
+            ErrModel emc = gt_err_model(ctx, 2);
+            emc.rel += 8.0 * 5.9604644775390625e-08;
+            GT_TRY(gt_sym_orphan_cut(ctx, k->qorder.as<int32_t>(), k->thr_final.as<float>(), k->sym_farcnt.as<float>(), emc,
+                                     k->sym_racc.as<double>(), k->sh_need));
+        }
         GT_TRY(gt_sym_g_from_thr(ctx, n_pad_s, k->thr_final.as<float>(), k->hnegs.as<float>(), k->sym_g.as<float>(),
                                  k->sym_gmin.as<float>()));
         GT_HIP(ctx, hipMemsetAsync(k->tcounts.p, 0, size_t(n_pad_s) * sizeof(uint32_t), ctx->stream));
-        // (the orphans among the rows THIS rank seeded: their kept rows travel to the owners with the other records)
-        const size_t lcap = size_t(64) * 8;
-        GT_TRY(gt_sym_inject_orphans(ctx, k->sh_p0, k->sh_p1, k->thr_final.as<float>(),
-                                     k->lists.as<uint64_t>() - size_t(k->sh_p0) * lcap, int(lcap), k->counts.as<uint32_t>(),
-                                     k->tlists.as<uint64_t>(), tcap, k->tcounts.as<uint32_t>()));
+        if (cut) {
+            // the orphans among the rows THIS rank seeded start their lists with the rows launch A kept for them; they
+            // travel to the owners with the other records
+            const size_t lcap = size_t(64) * 8;
+            GT_TRY(gt_sym_inject_orphans(ctx, k->sh_p0, k->sh_p1, k->thr_final.as<float>(),
+                                         k->lists.as<uint64_t>() - size_t(k->sh_p0) * lcap, int(lcap), k->counts.as<uint32_t>(),
+                                         k->tlists.as<uint64_t>(), tcap, k->tcounts.as<uint32_t>()));
+        }
     }
     SelectArgs a;
     a.dp = ctx->DP;
@@ -242,24 +261,12 @@ int gt_knn_shard_collect(gt_ctx* ctx, const float* thr_all, int64_t far_total, c
     a.sym.shard_world = k->sh_world;
     a.sym.shard_rank = k->sh_rank;
     a.sym.shard_group = std::max(1, ctx->sym_shard_group);
-    if (n_pad_s % 1024 == 0 && ctx->DP % 32 == 0 && bq == 256 &&
+    if (n_pad_s % 1024 == 0 && ctx->DP >= 32 && bq == 256 &&
         (ctx->sym_two_stage > 0 || (ctx->sym_two_stage < 0 && ctx->sym_two_ok != 0))) {
-        // two-stage scoring, as in the single-rank pass (gt_knn.cpp)
-        const int hd = ctx->sym_two_steps > 0 ? 16 * ctx->sym_two_steps : ctx->DP / 2;
+        // two-stage scoring, as in the single-rank pass (gt_knn.cpp); the forecast runs on the same data on every rank
         ErrModel em = gt_err_model(ctx, 2);
         em.rel += 8.0 * 5.9604644775390625e-08;
-        GT_HIP(ctx, k->sym_hh.reserve(size_t(n_pad_s) * sizeof(float)));
-        GT_HIP(ctx, k->sym_thrh.reserve(size_t(n_pad_s) * sizeof(float)));
-        GT_HIP(ctx, k->sym_gh.reserve(size_t(n_pad_s) * sizeof(float)));
-        GT_HIP(ctx, k->sym_gminh.reserve(size_t(n_pad_s / 32) * sizeof(float)));
-        StageSpan span(ctx, "sym_prepare");
-        GT_TRY(gt_sym_half_seeds(ctx, k->Ycs.p, n_pad_s, hd, k->sym_hh.as<float>()));
-        GT_TRY(gt_sym_half_thresholds(ctx, k->qorder.as<int32_t>(), n_pad_s, k->thr_final.as<float>(), k->sym_hh.as<float>(), em,
-                                      hd, k->sym_thrh.as<float>(), k->sym_gh.as<float>(), k->sym_gminh.as<float>()));
-        a.sym.half_steps = hd / 16;
-        a.sym.hh = k->sym_hh.as<float>();
-        a.sym.thrh = k->sym_thrh.as<float>();
-        a.sym.gminh = k->sym_gminh.as<float>();
+        GT_TRY(gt_sym_two_stage_prepare(ctx, k->qorder.as<int32_t>(), n_pad_s, em, k->sh_need, a, true));
     }
     const bool two_stage = a.sym.half_steps > 0;
     {

@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256) void rerank_sym_kernel(
     const uint32_t ct_raw = tcounts[ls];
     const uint32_t ct = ct_raw & 0x7FFFFFFFu;
     const bool overflow = ct > uint32_t(tcap) || (ct_raw >> 31) != 0u;
-    const uint32_t n = overflow ? uint32_t(tcap) : ct;
+    const uint32_t n = ct < uint32_t(tcap) ? ct : uint32_t(tcap);   // (a marked row may hold fewer than tcap keys)
     const uint64_t* tp = tlists + size_t(ls) * size_t(tcap);
 
     const double y2 = ymax2p[0];

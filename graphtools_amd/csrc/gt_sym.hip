@@ -71,7 +71,8 @@ __global__ __launch_bounds__(256) void sym_thresholds_kernel(const int64_t n, co
                                                              const double rkf, float* __restrict__ thr,
                                                              float* __restrict__ g, const uint32_t* __restrict__ cell_sorted,
                                                              const int32_t* __restrict__ nbr, const int M,
-                                                             unsigned long long* __restrict__ far_total) {
+                                                             unsigned long long* __restrict__ far_total,
+                                                             float* __restrict__ farcnt) {
     const int sub = threadIdx.x & 15;
     const int64_t p = p_first + int64_t(blockIdx.x) * 16 + (threadIdx.x >> 4);
     if (p >= p_last) return;   // whole 16-lane group
@@ -131,13 +132,9 @@ __global__ __launch_bounds__(256) void sym_thresholds_kernel(const int64_t n, co
             if (double(t) >= x) t = nextafterf(t, -INFINITY);
             if (!(t > -3.0e38f)) t = -3.0e38f;
         }
-        // An orphan: a quarter or more of the rows launch A kept for it came from the strided sample, not from the cells
-        // around it - its cell says little about where its neighbours are, D_K is loose, and a threshold from it would
-        // pull in (and queue, and score) candidates by the thousand only to overflow the list.  It collects nothing
-        // (+inf), keeps the rows launch A found (sym_inject_orphans_kernel) and goes to the repair pass, which starts
-        // from their exact distances.
-        if (far * 4u >= uint32_t(need_m) && kept >= uint32_t(need_m)) t = INFINITY;
-        gv = t == INFINITY ? INFINITY : nextafterf(t + hs[p], -INFINITY);
+        // (how many of the kept rows were far is handed on: sym_orphan_cut_kernel may declare the row an orphan)
+        if (farcnt && sub == 0) farcnt[p] = kept >= uint32_t(need_m) ? float(far) : 0.f;
+        gv = nextafterf(t + hs[p], -INFINITY);
     }
     if (sub == 0) {
         thr[p] = t;
@@ -347,46 +344,85 @@ __device__ __forceinline__ double sym_row_lb(float t, double qs, double y2, cons
     return (qs - 2.0 * (double(t) * err.inv_sc2 + e)) - 1e-9 * (qs + y2);
 }
 
-// sum and number of the radii lb of the rows [p_first, p_last) that have a threshold -> acc[0], acc[1] (pre-zeroed)
+// Statistics behind the orphan cut, over the rows [p_first, p_last), added into acc (4 doubles, pre-zeroed):
+//   acc[0], acc[1]  sum and number of the radii lb of the rows that have a threshold
+//   acc[2], acc[3]  sum and number of squared distances between every 64th row and a pseudo-random partner row - an
+//                   estimate of the typical squared distance between two unrelated points of the set (2 x its variance)
+template <typename T>
 __global__ __launch_bounds__(256) void sym_radius_sum_kernel(const int64_t n, const int64_t p_first, const int64_t p_last,
-                                                             const int32_t* __restrict__ perm,
-                                                             const double* __restrict__ xn, const float* __restrict__ thr,
+                                                             const int32_t* __restrict__ perm, const T* __restrict__ X,
+                                                             const int d, const double* __restrict__ xn,
+                                                             const float* __restrict__ thr,
                                                              const double* __restrict__ ymax2p, const ErrModel err,
                                                              double* __restrict__ acc) {
-    double s = 0.0, c = 0.0;
+    double s = 0.0, c = 0.0, ps = 0.0, pc = 0.0;
     const int64_t hi = p_last < n ? p_last : n;
     for (int64_t p = p_first + int64_t(blockIdx.x) * 256 + threadIdx.x; p < hi; p += int64_t(gridDim.x) * 256) {
         const float t = thr[p];
+        const int64_t row = perm[p];
         if (t != INFINITY && t > -3.0e38f) {
-            const double lb = sym_row_lb(t, xn[perm[p]], ymax2p[0], err);
+            const double lb = sym_row_lb(t, xn[row], ymax2p[0], err);
             s += lb > 0.0 ? lb : 0.0;
             c += 1.0;
+        }
+        if ((p & 63) == 0) {
+            const int64_t other = int64_t((uint64_t(p) * 0x9E3779B97F4A7C15ull >> 20) % uint64_t(n));
+            const T* a = X + row * int64_t(d);
+            const T* b = X + other * int64_t(d);
+            double dd = 0.0;
+            for (int k = 0; k < d; ++k) {
+                const double df = double(a[k]) - double(b[k]);
+                dd = fma(df, df, dd);
+            }
+            ps += dd;
+            pc += 1.0;
         }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         s += __shfl_xor(s, o);
         c += __shfl_xor(c, o);
+        ps += __shfl_xor(ps, o);
+        pc += __shfl_xor(pc, o);
     }
-    if ((threadIdx.x & 63) == 0 && c > 0.0) {
-        atomicAdd(acc, s);
-        atomicAdd(acc + 1, c);
+    if ((threadIdx.x & 63) == 0) {
+        if (c > 0.0) {
+            atomicAdd(acc, s);
+            atomicAdd(acc + 1, c);
+        }
+        if (pc > 0.0) {
+            atomicAdd(acc + 2, ps);
+            atomicAdd(acc + 3, pc);
+        }
     }
 }
 
-// Rows whose radius is far beyond the typical one (cut x the mean over all rows) are orphans too: launch A found them
-// SOME need_m rows nearby, but none of their real neighbours - their threshold would pass most of the point set.
-// They collect nothing (+inf) and go to the repair pass (see sym_thresholds_kernel).  acc = {sum, count} over ALL rows.
-__global__ __launch_bounds__(256) void sym_radius_cut_kernel(const int64_t n, const int32_t* __restrict__ perm,
+// Orphans of the two-stage collect: rows whose threshold would pass a good part of the point set through stage one, queue
+// it and score it, only to overflow the list.  Two signs:
+//   * orphan_far x (rows launch A kept for it from the strided sample, not from the cells around it) >= need_m: its
+//     cell says little about where its neighbours are, D_K is loose;
+//   * a radius far beyond the typical one (cut x the mean over all rows) that is no longer small against the typical
+//     distance between two unrelated points (1/16 of it: the 16-feature partial distances of stage one are a quarter of
+//     the full ones on isotropic data): launch A found it SOME need_m rows nearby, none of its real neighbours.
+// They collect nothing (+inf), keep the rows launch A found (sym_inject_orphans_kernel) and go to the repair pass, which
+// starts from those rows' exact distances.  acc = the statistics of sym_radius_sum_kernel over ALL rows.
+__global__ __launch_bounds__(256) void sym_orphan_cut_kernel(const int64_t n, const int32_t* __restrict__ perm,
                                                              const double* __restrict__ xn, float* __restrict__ thr,
+                                                             const float* __restrict__ farcnt,
                                                              const double* __restrict__ ymax2p, const ErrModel err,
-                                                             const double* __restrict__ acc, const double cut) {
+                                                             const double* __restrict__ acc, const double cut,
+                                                             const int orphan_far, const int need_m) {
     const int64_t p = int64_t(blockIdx.x) * 256 + threadIdx.x;
     if (p >= n) return;
     const float t = thr[p];
-    if (t == INFINITY || !(t > -3.0e38f) || !(acc[1] > 0.0)) return;
-    const double lb = sym_row_lb(t, xn[perm[p]], ymax2p[0], err);
-    if (lb > cut * (acc[0] / acc[1])) thr[p] = INFINITY;
+    if (t == INFINITY || !(t > -3.0e38f)) return;
+    bool orphan = orphan_far > 0 && farcnt && farcnt[p] * float(orphan_far) >= float(need_m);
+    if (!orphan && cut > 0.0 && acc[1] > 0.0) {
+        const double lb = sym_row_lb(t, xn[perm[p]], ymax2p[0], err);
+        const double typical_pair = acc[3] > 0.0 ? acc[2] / acc[3] : 0.0;
+        orphan = lb > cut * (acc[0] / acc[1]) && lb > typical_pair / 16.0;
+    }
+    if (orphan) thr[p] = INFINITY;
 }
 
 // the rows launch A kept for an orphan (thr = +inf on a real row, see sym_thresholds_kernel) become the head of its list
@@ -481,6 +517,37 @@ __global__ __launch_bounds__(256) void sym_half_thresholds_kernel(const int64_t 
     }
     thrh[p] = th;
     gh[p] = g;
+}
+
+// How many (64-query group, 32-row sub-tile) pairs would pass stage one?  One wave per pseudo-randomly drawn pair (lane =
+// query, the 32 rows in turn), the same partial scores and the same two tests as the collect kernel's unit loop (float32
+// FMA instead of the MFMA: a forecast, not a proof).  flagged (pre-zeroed): pairs in which some score passed.
+__global__ __launch_bounds__(256) void sym_two_probe_kernel(const _Float16* __restrict__ Ys, const int64_t n, const int DP,
+                                                            const int HD, const float* __restrict__ hh,
+                                                            const float* __restrict__ thrh, const float* __restrict__ gh,
+                                                            const int64_t samples, uint32_t* __restrict__ flagged) {
+    const int lane = threadIdx.x & 63;
+    const int64_t sidx = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    if (sidx >= samples) return;
+    const uint64_t h1 = (uint64_t(sidx) + 1) * 0x9E3779B97F4A7C15ull, h2 = (uint64_t(sidx) + 1) * 0xC2B2AE3D27D4EB4Full;
+    const int64_t q0 = int64_t((h1 >> 17) % uint64_t(n / 64)) * 64, d0 = int64_t((h2 >> 17) % uint64_t(n / 32)) * 32;
+    float xq[32];
+    const _Float16* xr = Ys + size_t(q0 + lane) * DP;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) xq[k] = k < HD ? float(xr[k]) : 0.f;
+    const float tq = thrh[q0 + lane], hq = hh[q0 + lane];
+    float gmin = INFINITY;
+    for (int j = 0; j < 32; ++j) gmin = fminf(gmin, gh[d0 + j]);
+    bool hit = false;
+    for (int j = 0; j < 32; ++j) {
+        const _Float16* yr = Ys + size_t(d0 + j) * DP;
+        float a = hh[d0 + j];
+#pragma unroll
+        for (int k = 0; k < 32; ++k)
+            if (k < HD) a = fmaf(xq[k], float(yr[k]), a);
+        hit = hit || a > tq || (a + hq > gmin);
+    }
+    if (__ballot(hit) != 0ull && lane == 0) atomicAdd(flagged, 1u);
 }
 
 // ---- row-sharded builds (gt_knn_shard.cpp) -----------------------------------------------------------------------
@@ -615,7 +682,8 @@ int gt_sym_gather(gt_ctx* ctx, const int32_t* perm, int64_t n_pad_s, void* Ys, f
 
 int gt_sym_thresholds(gt_ctx* ctx, const int32_t* perm, int64_t n_pad_s, const float* hs, const uint64_t* lists, int lstride,
                       const uint32_t* counts, int need_m, const ErrModel& err, double rkf, float* thr, float* g, float* gmin,
-                      const DevBuf& work, int cells, unsigned long long* far_total, int64_t p_first, int64_t p_last) {
+                      const DevBuf& work, int cells, unsigned long long* far_total, float* farcnt, int64_t p_first,
+                      int64_t p_last) {
     if (p_last < 0) p_last = n_pad_s;
     const dim3 grid((unsigned)ceil_div64(p_last - p_first, 16));
     // landmark adjacency the schedule of launch A was built from (gt_sym_schedule: nbr [L][M] at the head of `work`)
@@ -625,11 +693,11 @@ int gt_sym_thresholds(gt_ctx* ctx, const int32_t* perm, int64_t n_pad_s, const f
     if (ctx->dtype == GT_F32)
         hipLaunchKernelGGL(sym_thresholds_kernel<float>, grid, dim3(256), 0, ctx->stream, ctx->n, p_first, p_last, perm,
                            (const float*)ctx->X, ctx->d, ctx->xn.as<double>(), hs, lists, lstride, counts, need_m,
-                           ctx->ymax.as<double>(), err, rkf, thr, g, cell_sorted, nbr, M, far_total);
+                           ctx->ymax.as<double>(), err, rkf, thr, g, cell_sorted, nbr, M, far_total, farcnt);
     else
         hipLaunchKernelGGL(sym_thresholds_kernel<double>, grid, dim3(256), 0, ctx->stream, ctx->n, p_first, p_last, perm,
                            (const double*)ctx->X, ctx->d, ctx->xn.as<double>(), hs, lists, lstride, counts, need_m,
-                           ctx->ymax.as<double>(), err, rkf, thr, g, cell_sorted, nbr, M, far_total);
+                           ctx->ymax.as<double>(), err, rkf, thr, g, cell_sorted, nbr, M, far_total, farcnt);
     GT_HIP(ctx, hipGetLastError());
     if (gmin) {
         hipLaunchKernelGGL(sym_gmin_kernel, dim3((unsigned)ceil_div64(n_pad_s, 256)), dim3(256), 0, ctx->stream, n_pad_s, g, gmin);
@@ -641,15 +709,21 @@ int gt_sym_thresholds(gt_ctx* ctx, const int32_t* perm, int64_t n_pad_s, const f
 int gt_sym_radius_sum(gt_ctx* ctx, const int32_t* perm, int64_t p_first, int64_t p_last, const float* thr, const ErrModel& err,
                       double* acc) {
     if (p_last <= p_first) return GT_OK;
-    hipLaunchKernelGGL(sym_radius_sum_kernel, dim3(256), dim3(256), 0, ctx->stream, ctx->n, p_first, p_last, perm,
-                       ctx->xn.as<double>(), thr, ctx->ymax.as<double>(), err, acc);
+    if (ctx->dtype == GT_F32)
+        hipLaunchKernelGGL(sym_radius_sum_kernel<float>, dim3(256), dim3(256), 0, ctx->stream, ctx->n, p_first, p_last, perm,
+                           (const float*)ctx->X, ctx->d, ctx->xn.as<double>(), thr, ctx->ymax.as<double>(), err, acc);
+    else
+        hipLaunchKernelGGL(sym_radius_sum_kernel<double>, dim3(256), dim3(256), 0, ctx->stream, ctx->n, p_first, p_last, perm,
+                           (const double*)ctx->X, ctx->d, ctx->xn.as<double>(), thr, ctx->ymax.as<double>(), err, acc);
     GT_HIP(ctx, hipGetLastError());
     return GT_OK;
 }
 
-int gt_sym_radius_cut(gt_ctx* ctx, const int32_t* perm, float* thr, const ErrModel& err, const double* acc, double cut) {
-    hipLaunchKernelGGL(sym_radius_cut_kernel, dim3((unsigned)ceil_div64(ctx->n, 256)), dim3(256), 0, ctx->stream, ctx->n, perm,
-                       ctx->xn.as<double>(), thr, ctx->ymax.as<double>(), err, acc, cut);
+int gt_sym_orphan_cut(gt_ctx* ctx, const int32_t* perm, float* thr, const float* farcnt, const ErrModel& err, const double* acc,
+                      int need_m) {
+    hipLaunchKernelGGL(sym_orphan_cut_kernel, dim3((unsigned)ceil_div64(ctx->n, 256)), dim3(256), 0, ctx->stream, ctx->n, perm,
+                       ctx->xn.as<double>(), thr, farcnt, ctx->ymax.as<double>(), err, acc, ctx->sym_radius_cut,
+                       ctx->sym_orphan_far, need_m);
     GT_HIP(ctx, hipGetLastError());
     return GT_OK;
 }
@@ -686,6 +760,16 @@ int gt_sym_half_thresholds(gt_ctx* ctx, const int32_t* perm, int64_t n_pad_s, co
                        n_pad_s, perm, ctx->xn.as<double>(), thr, hh, ctx->ymax.as<double>(), err, hd, thrh, gh);
     GT_HIP(ctx, hipGetLastError());
     hipLaunchKernelGGL(sym_gmin_kernel, dim3((unsigned)ceil_div64(n_pad_s, 256)), dim3(256), 0, ctx->stream, n_pad_s, gh, gminh);
+    GT_HIP(ctx, hipGetLastError());
+    return GT_OK;
+}
+
+int gt_sym_two_probe(gt_ctx* ctx, const void* Ys, int hd, const float* hh, const float* thrh, const float* gh, int64_t samples,
+                     uint32_t* flagged) {
+    if (ctx->n < 64 || hd > 32) GT_FAIL(ctx, GT_E_ARG, "sym probe: bad shape");
+    GT_HIP(ctx, hipMemsetAsync(flagged, 0, sizeof(uint32_t), ctx->stream));
+    hipLaunchKernelGGL(sym_two_probe_kernel, dim3((unsigned)ceil_div64(samples, 4)), dim3(256), 0, ctx->stream,
+                       reinterpret_cast<const _Float16*>(Ys), ctx->n, ctx->DP, hd, hh, thrh, gh, samples, flagged);
     GT_HIP(ctx, hipGetLastError());
     return GT_OK;
 }

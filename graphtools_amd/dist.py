@@ -175,9 +175,9 @@ class ShardedKnnGraph(object):
         if int(flag.item()) == 0:
             return False
         rows = int(sorted_splits[self.rank + 1] - sorted_splits[self.rank])
-        thr_local = torch.empty(max(rows, 1), dtype=torch.float32, device=device)
-        stats = ctx.graph_sym_seed(thr_local.data_ptr())      # [far-kept rows, sum of radii, rows with a radius]
-        thr_all = allgather_vector(thr_local[:rows], sorted_splits, self.group).contiguous()
+        thr_local = torch.empty((max(rows, 1), 2), dtype=torch.float32, device=device)   # {threshold, far-kept seeds}
+        stats = ctx.graph_sym_seed(thr_local.data_ptr())      # [far-kept rows, four sums behind the orphan cut]
+        thr_all = allgather_rows(thr_local[:rows], sorted_splits, self.group).contiguous()
         stats_t = torch.as_tensor(np.asarray(stats, dtype=np.float64), device=device)
         dist.all_reduce(stats_t, group=self.group)            # every rank receives the same sums
         if thr_all.is_cuda:

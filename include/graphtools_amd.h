@@ -110,7 +110,7 @@ int gt_stage_launches(const gt_ctx* ctx, const char* stage);
  * "select_samp_end", "select_samp2_level", "select_samp2_keep", "select_samp_trig", "select_thr0", "select_narrow",
  * "query_order_cell_rows", "query_order_min_rows"; "select_symmetric" ("auto" | 0 | 1: self queries over the whole point set score every
  * unordered pair of rows once and test the result for both rows - gt_sym.hip), "select_sym_stride",
- * "select_sym_min_rows", "select_sym_tcap", "select_sym_cells", "select_sym_max_nb", "select_sym_nseg", "select_sym_shard_group", "select_sym_two_stage"; "dbg_select" switches invalidate the results. */
+ * "select_sym_min_rows", "select_sym_tcap", "select_sym_cells", "select_sym_max_nb", "select_sym_nseg", "select_sym_shard_group", "select_sym_two_stage", "select_sym_radius_cut", "select_sym_orphan_far"; "dbg_select" switches invalidate the results. */
 int gt_set_option(gt_ctx* ctx, const char* name, const char* value);
 /* arithmetic the most recent main candidate pass ran on: 0 float32, 1 split float16 (3 chains), 2 single float16 chain */
 int gt_last_knn_precision(const gt_ctx* ctx);
@@ -172,11 +172,13 @@ int gt_graph_anisotropy(gt_ctx* ctx, const double* degree_all_dev);
  * as ALL ranks stop - the host all-reduces the flag - and gt_graph_begin then runs the classic candidate pass):
  *   gt_graph_sym_plan    applies (out): this context can run it for these parameters; n_pad_sorted, sorted_splits
  *                        [world + 1] (out): positions of the shared cell-sorted row order whose thresholds each rank seeds
- *   gt_graph_sym_seed    thr_local (device, float32 [sorted_splits[rank+1] - sorted_splits[rank]], out), far_local (out),
- *                        radius_local [2] (out: sum and count of the rows' completeness radii)
- *                        -> the host all-gathers thr_local into float32 [n_pad_sorted] and sums far_local and
+ *   gt_graph_sym_seed    thr_local (device, float32 [sorted_splits[rank+1] - sorted_splits[rank]][2], out: the threshold
+ *                        and the far-kept seed count of every position of the share), far_local (out),
+ *                        radius_local [4] (out: sums and counts behind the orphan cut - the rows' completeness radii
+ *                        and a sample of squared distances between unrelated rows)
+ *                        -> the host all-gathers thr_local into float32 [n_pad_sorted][2] and sums far_local and
  *                           radius_local over the ranks
- *   gt_graph_sym_collect thr_all (device), far_total, radius_total [2]; applies (out), send_counts [world] (out, 16-byte records
+ *   gt_graph_sym_collect thr_all (device), far_total, radius_total [4]; applies (out), send_counts [world] (out, 16-byte records
  *                        {uint32 row local to its owner, uint32 0, uint64 candidate key})
  *   gt_graph_sym_emit    records bucketed by destination rank into the caller's device buffer
  *                        -> the host moves them with the all-to-all it uses for the triplets

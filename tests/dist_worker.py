@@ -70,16 +70,19 @@ class FakeCtx(object):
     def graph_sym_seed(self, ptr):
         self.calls = self.calls + ("seed",)
         p0, p1 = int(self.sorted_splits[self.rank]), int(self.sorted_splits[self.rank + 1])
-        out = np.frombuffer((ctypes.c_char * ((p1 - p0) * 4)).from_address(ptr), dtype=np.float32)
-        out[:] = 0.5 * np.arange(p0, p1)
-        return np.array([10.0 + self.rank, 1.5 * (self.rank + 1), 2.0], dtype=np.float64)
+        out = np.frombuffer((ctypes.c_char * ((p1 - p0) * 8)).from_address(ptr), dtype=np.float32).reshape(-1, 2)
+        out[:, 0] = 0.5 * np.arange(p0, p1)
+        out[:, 1] = np.arange(p0, p1) % 5
+        return np.array([10.0 + self.rank, 1.5 * (self.rank + 1), 2.0, 0.25, 1.0], dtype=np.float64)
 
     def graph_sym_collect(self, ptr, stats_total, world):
         far_total = int(round(stats_total[0]))
         assert abs(stats_total[1] - sum(1.5 * (r + 1) for r in range(world))) < 1e-12 and stats_total[2] == 2.0 * world
+        assert stats_total[3] == 0.25 * world and stats_total[4] == 1.0 * world
         self.calls = self.calls + ("collect",)
-        thr = np.frombuffer((ctypes.c_char * (self.n_pad * 4)).from_address(ptr), dtype=np.float32)
-        assert np.array_equal(thr, 0.5 * np.arange(self.n_pad, dtype=np.float32)), "thresholds were not gathered in order"
+        thr = np.frombuffer((ctypes.c_char * (self.n_pad * 8)).from_address(ptr), dtype=np.float32).reshape(-1, 2)
+        assert np.array_equal(thr[:, 0], 0.5 * np.arange(self.n_pad, dtype=np.float32)), "thresholds were not gathered in order"
+        assert np.array_equal(thr[:, 1], np.arange(self.n_pad) % 5)
         assert far_total == sum(10 + r for r in range(world)), far_total
         if self.sym_refuse_at_collect:
             return False, np.zeros(world, dtype=np.int64)

@@ -53,21 +53,21 @@ def sharded_build(X, splits, pargs, opts=None):
         ss = plans[0][2]
         assert all(np.array_equal(pl[2], ss) and pl[1] == n_pad for pl in plans)
         assert ss[0] == 0 and ss[-1] == n_pad
-        parts, far = [], np.zeros(3)
+        parts, far = [], np.zeros(5)
         for r, c in enumerate(ctxs):
             rows = int(ss[r + 1] - ss[r])
-            buf = c.dev_alloc(max(rows, 1) * 4)
+            buf = c.dev_alloc(max(rows, 1) * 8)
             far += c.graph_sym_seed(buf)
-            host = np.zeros(rows, dtype=np.float32)
+            host = np.zeros((rows, 2), dtype=np.float32)     # {threshold, far-kept seeds} per position
             if rows:
                 c.dev_download(host, buf)
             c.dev_free(buf)
             parts.append(host)
         thr_all = np.concatenate(parts)
-        assert len(thr_all) == n_pad
+        assert thr_all.shape == (n_pad, 2)
         sends, counts = [], []
         for r, c in enumerate(ctxs):
-            buf = c.dev_alloc(n_pad * 4)
+            buf = c.dev_alloc(n_pad * 8)
             c.dev_upload(buf, thr_all)
             ok, cnt = c.graph_sym_collect(buf, far, world)
             c.dev_free(buf)

@@ -33,14 +33,14 @@ if os.environ.get("GT_DBG"):
 ctx.set_points(X)
 p, keep = ctx.make_params(15, 40.0, 1e-4, None, 1.0, None, "+", None, 0)
 # phase 1: every rank's seeds (the thresholds do not depend on who computes them)
-parts, far, seed_ms = [], np.zeros(3), []
+parts, far, seed_ms = [], np.zeros(5), []
 for r in range(world):
     ok, n_pad, ss = ctx.graph_sym_plan(p, world, r, splits)
     assert ok, "plan refused"
     rows = int(ss[r + 1] - ss[r])
-    buf = ctx.dev_alloc(max(rows, 1) * 4)
+    buf = ctx.dev_alloc(max(rows, 1) * 8)
     far += ctx.graph_sym_seed(buf)
-    host = np.zeros(rows, dtype=np.float32)
+    host = np.zeros((rows, 2), dtype=np.float32)
     ctx.dev_download(host, buf)
     ctx.dev_free(buf)
     parts.append(host)
@@ -48,7 +48,7 @@ for r in range(world):
 thr_all = np.concatenate(parts)
 print(json.dumps({"seed_stage_ms_rank0": seed_ms[0], "seed_stage_ms_last": seed_ms[-1], "far": [float(v) for v in far]}), flush=True)
 if os.environ.get("GT_COLLECT_ONLY"):
-    tb = ctx.dev_alloc(n_pad * 4)
+    tb = ctx.dev_alloc(n_pad * 8)
     ctx.dev_upload(tb, thr_all)
     for variant in os.environ.get("GT_VARIANTS", "").split(";"):
         for o in [o for o in variant.split(",") if o]:
@@ -56,7 +56,7 @@ if os.environ.get("GT_COLLECT_ONLY"):
             ctx.set_option(k, v)
         for r in [int(x) for x in os.environ.get("GT_RANKS", "0,3").split(",")]:
             ok, n_pad, ss = ctx.graph_sym_plan(p, world, r, splits)
-            buf = ctx.dev_alloc(max(int(ss[r + 1] - ss[r]), 1) * 4)
+            buf = ctx.dev_alloc(max(int(ss[r + 1] - ss[r]), 1) * 8)
             ctx.graph_sym_seed(buf)
             ctx.dev_free(buf)
             ok, cnt = ctx.graph_sym_collect(tb, far, world)
@@ -66,11 +66,11 @@ if os.environ.get("GT_COLLECT_ONLY"):
 # phase 2: every rank's collect + emit; keep only what rank `who` will receive
 who = int(os.environ.get("GT_WHO", "0"))
 recv_parts, col_ms, counts_all = [], [], []
-tb = ctx.dev_alloc(n_pad * 4)
+tb = ctx.dev_alloc(n_pad * 8)
 ctx.dev_upload(tb, thr_all)
 for r in range(world):
     ok, n_pad, ss = ctx.graph_sym_plan(p, world, r, splits)
-    buf = ctx.dev_alloc(max(int(ss[r + 1] - ss[r]), 1) * 4)
+    buf = ctx.dev_alloc(max(int(ss[r + 1] - ss[r]), 1) * 8)
     ctx.graph_sym_seed(buf)
     ctx.dev_free(buf)
     t = time.time()
@@ -96,7 +96,7 @@ recv = np.concatenate(recv_parts)
 rb = ctx.dev_alloc(max(len(recv), 1) * 16)
 ctx.dev_upload(rb, recv)
 ss0 = ctx.graph_sym_plan(p, world, who, splits)[2]
-lb = ctx.dev_alloc(max(int(ss0[who + 1] - ss0[who]), 1) * 4)
+lb = ctx.dev_alloc(max(int(ss0[who + 1] - ss0[who]), 1) * 8)
 sb = ctx.dev_alloc(max(int(max(c.sum() for c in counts_all)), 1) * 16)
 for rep in range(int(os.environ.get("GT_REPS", "3"))):
     ctx.sync()
