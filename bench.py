@@ -54,7 +54,9 @@ def make_mix(n, d, seed, dtype=np.float32):
     return out
 
 
-SYM_KERNEL = "knn_select_kernel<64, 8, 2, 2>"   # symmetric collect (single GPU, single float16 chain)
+SYM_KERNEL = "knn_select_kernel<64, 8, 2, 2>"   # symmetric collect (single float16 chain), one-stage
+SYM2_KERNEL = "knn_select_kernel<64, 8, 3, 2>"  # symmetric collect, two-stage: 16 features in the unit loop ...
+SYM_COLD_KERNEL = "sym_cold_kernel<64>"         # ... survivors scored in full by the cold launch
 
 
 def measured_traffic(n, d, precision, world, symmetric):
@@ -66,7 +68,8 @@ def measured_traffic(n, d, precision, world, symmetric):
     try:
         if symmetric:
             with open(os.path.join(ROOT, "profiles", "r2_pmc_fetch_write_per_kernel.json")) as f:
-                k = json.load(f)["kernels"][SYM_KERNEL]
+                ks = json.load(f)["kernels"]
+                k = ks[SYM2_KERNEL] if SYM2_KERNEL in ks else ks[SYM_KERNEL]
         else:
             name = {"f16x1": "f16x1", "f16": "f16split"}[precision]
             with open(os.path.join(ROOT, "profiles", "r1_pmc_fetch_write_per_kernel_%s.json" % name)) as f:
@@ -195,13 +198,14 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    select_ms, seed_ms = [], []
+    select_ms, seed_ms, cold_ms = [], [], []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         nnz, flags = step()
         # stage timers were recorded with hipEvents on the library's own stream during the step
         select_ms.append(ctx.stage_ms("knn_select"))
         seed_ms.append(max(ctx.stage_ms("sym_seed"), 0.0))
+        cold_ms.append(max(ctx.stage_ms("sym_cold"), 0.0))
     fence()
     elapsed = time.perf_counter() - t0
     if distributed:
@@ -222,19 +226,32 @@ def main():
         peak = MFMA_PEAK_TFLOPS[main]
         kst = ctx.knn_stats()
         symmetric = bool(kst["symmetric"])
-        main_ms, seeding_ms = float(np.mean(select_ms)), float(np.mean(seed_ms))
-        avg_ms = main_ms + (seeding_ms if symmetric else 0.0)   # the candidate pass = both launches
+        main_ms, seeding_ms, cold_launch_ms = float(np.mean(select_ms)), float(np.mean(seed_ms)), float(np.mean(cold_ms))
+        two_stage = symmetric and bool(kst.get("sym_two_stage", False))
+        # the candidate pass = all of its launches (seeding + collect [+ cold launch of the two-stage collect])
+        avg_ms = main_ms + (seeding_ms if symmetric else 0.0) + (cold_launch_ms if two_stage else 0.0)
         achieved = flops / (avg_ms * 1e-3) / 1e12
         if symmetric:
-            # executed matrix work: every unordered pair of (padded) rows once - 256-row query blocks against half of
-            # the 128-row tiles - plus the tiles of the seeding launch
-            n_pad = -(-n // 256) * 256
-            nb = n_pad // 256
-            walk_tiles = 2 * (1 + (nb - 1) // 2) + (0 if nb % 2 else 2)
-            # (row-sharded: every rank walks 1/world of the pieces and seeds 1/world of the blocks)
-            executed = 2.0 * d * 256 * 128 * (nb * walk_tiles + kst.get("sym_seed_tiles", 0)) / world
-            kernel_name = "%s + its threshold-seeding launch knn_select_kernel<64, 8, 0, 2> (symmetric f16x1 MFMA candidate " \
-                          "pass, knn_precision=%s): every unordered pair of rows scored once" % (SYM_KERNEL, args.knn_precision)
+            # executed matrix work: every unordered pair of (padded) rows once, plus the tiles of the seeding launch
+            # (256-row blocks x 128-row tiles, all d features).  One-stage collect: all d features of every pair;
+            # two-stage: 16 features of every pair (1024-row query blocks) + all d of the pairs the cold launch scores
+            # (64 queries x 32 rows each).  Row-sharded: every rank walks 1/world of the pieces, seeds 1/world of the blocks.
+            seed_flop = 2.0 * d * 256 * 128 * kst.get("sym_seed_tiles", 0)
+            if two_stage:
+                n_pad = -(-n // 1024) * 1024
+                nb = n_pad // 1024
+                walk_tiles = 8 * (1 + (nb - 1) // 2) + (0 if nb % 2 else 8)
+                collect_flop = 2.0 * 16 * 1024 * 128 * nb * walk_tiles + 2.0 * d * 64 * 32 * kst.get("sym_cold_pairs", 0) * world
+                kname = SYM2_KERNEL + " + " + SYM_COLD_KERNEL
+            else:
+                n_pad = -(-n // 256) * 256
+                nb = n_pad // 256
+                walk_tiles = 2 * (1 + (nb - 1) // 2) + (0 if nb % 2 else 2)
+                collect_flop = 2.0 * d * 256 * 128 * nb * walk_tiles
+                kname = SYM_KERNEL
+            executed = (collect_flop + seed_flop) / world
+            kernel_name = "%s + the threshold-seeding launch knn_select_kernel<64, 8, 0, 2> (symmetric f16x1 MFMA candidate " \
+                          "pass, knn_precision=%s): every unordered pair of rows scored once" % (kname, args.knn_precision)
         else:
             executed = flops * MFMA_CHAINS[main]
             kernel_name = "%s (%s MFMA candidate pass, knn_precision=%s)" % (SELECT_KERNEL[main], main, args.knn_precision)
@@ -256,17 +273,18 @@ def main():
                                    "kernel_symm='+', device-complete K and P" % (n, d, args.knn, args.decay),
                        "row_sharding": "%d rank(s) x %d rows" % (world, nloc), "nnz_K": nnz_total,
                        "radius_rows_rank0": stats["radius_rows"], "fallback_rows_rank0": stats["fallback_rows"],
-                       "symmetric_candidate_pass": symmetric},
+                       "symmetric_candidate_pass": symmetric, "two_stage_collect": two_stage},
             "roofline": {"kernel": kernel_name,
                          "bound": "mfma",
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "traffic": measured_traffic(n, d, main, world, symmetric), "traffic_unit": "bytes/launch",
                          "avg_launch_ms": avg_ms, "main_launch_ms": main_ms, "seeding_launch_ms": seeding_ms if symmetric else 0.0,
+                         "cold_launch_ms": cold_launch_ms if two_stage else 0.0,
                          "algorithmic_flop_per_launch": flops,
                          "executed_mfma_flop_per_launch": executed,
                          "executed_mfma_frac": executed / (avg_ms * 1e-3) / 1e12 / peak},
             "stage_ms_last_step": {s: round(ctx.stage_ms(s), 3) for s in
-                                   ("prep", "query_order", "sym_prepare", "sym_seed", "knn_select", "rerank", "fallback",
+                                   ("prep", "query_order", "sym_prepare", "sym_seed", "knn_select", "sym_cold", "rerank", "fallback",
                                     "radius", "affinity", "symmetrize", "normalize")},
         }
         if world == 1 and not args.no_cpu_baseline:

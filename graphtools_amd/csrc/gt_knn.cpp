@@ -409,6 +409,7 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
                 }
                 if (ctx->sym_two_ok < 0) ctx->sym_two_ok = 1;
             }
+            k->sym_two_used = two_now;
             ctx->last_main_prec = 2;
             k->sym_used = true;
             if (ctx->dbg_select & 4) return GT_OK;   // experiment: candidate pass only (tables are NOT valid)
@@ -733,6 +734,8 @@ extern "C" int gt_knn_stats(const gt_ctx* ctx, int64_t* out12) {
     out12[3] = k ? k->n_fallback_exhaustive : 0;
     for (int i = 0; i < 8; ++i) out12[4 + i] = (k && k->sym_used) ? int64_t(k->sym_stat_host[i]) : 0;
     if (k && k->sym_used) out12[6] = k->sym_nseg;   // work items per query block of launch B
+    if (k && k->sym_used) out12[5] = k->sym_two_used ? k->sym_cold_entries : 0;   // pairs the cold launch scored in full
+    if (k && k->sym_used) out12[7] = k->sym_two_used ? 1 : 0;                     // two-stage collect ran
     out12[10] = k ? k->sym_far : 0;                 // kept rows of launch A outside the neighbourhood cells (all points)
     return GT_OK;
 }

@@ -35,6 +35,7 @@ struct KnnWork {
     DevBuf sym_queue, sym_qcount, sym_qdense, sym_qtot;   //   and the queue of its deferred cold pass (wave regions,
                                                           //   their counts, the compacted queue, {total, overflow})
     int64_t sym_cold_entries = 0;
+    bool sym_two_used = false;                    //   the last symmetric pass ran the two-stage collect
     bool sym_used = false;
     int64_t sym_overflow = 0;
     int sym_nseg = 1;

@@ -269,6 +269,7 @@ int gt_knn_shard_collect(gt_ctx* ctx, const float* thr_all, int64_t far_total, c
         GT_TRY(gt_sym_two_stage_prepare(ctx, k->qorder.as<int32_t>(), n_pad_s, em, k->sh_need, a, true));
     }
     const bool two_stage = a.sym.half_steps > 0;
+    k->sym_two_used = false;
     {
         const int64_t slots = int64_t(ctx->n_cu) * 3, nb = n_pad_s / bq;
         int best = 1;
@@ -293,6 +294,7 @@ int gt_knn_shard_collect(gt_ctx* ctx, const float* thr_all, int64_t far_total, c
         GT_TRY(gt_sym_queue_finish(ctx, a, &k->sym_cold_entries, &ok));
         if (ok) {
             if (ctx->sym_two_ok < 0) ctx->sym_two_ok = 1;
+            k->sym_two_used = true;
             break;
         }
         ctx->sym_two_ok = 0;     // stage one is no filter on these points: the one-stage kernel, now and later
