@@ -288,6 +288,10 @@ int gt_set_option(gt_ctx* ctx, const char* name, const char* value) {
         ctx->sym_two_stage = v == "auto" ? -1 : std::atoi(value);
         return GT_OK;
     }
+    if (k == "select_sym_queue_cap") {
+        ctx->sym_queue_cap = std::max(0, std::atoi(value));
+        return GT_OK;
+    }
     if (k == "select_sym_two_steps") {
         ctx->sym_two_steps = std::max(0, std::atoi(value));
         return GT_OK;

@@ -151,6 +151,7 @@ struct gt_ctx {
     int32_t sym_orphan_far = 4;  //  a row is an orphan when this many times its far-kept seeds reach the seeds wanted (0: off)
     double sym_radius_cut = 4.0; //  rows whose completeness radius (squared) exceeds this many times the mean are repaired directly
     int32_t sym_two_stage = -1; //   launch B scores half the features first (partial distances): -1 auto, 0 off, 1 on
+    int32_t sym_queue_cap = 0;  //   entries per wave region of the two-stage queue (0: sized from the problem; development / tests)
     int32_t sym_two_steps = 0;  //   k-steps of stage one (0: half of them; development, must match the kernel build)
     int32_t sym_two_ok = -1;    //   verdict of the last launch for the bound point set (cold-path share), -1 unknown
     int32_t sym_shard_group = 32;   //   row-sharded launch B: query blocks per rotation step of the walk pieces

@@ -211,6 +211,7 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
                          ctx->order_L > 0 && nq >= int64_t(8) * bq_sym;
     k->sym_used = false;
     bool sym_now = use_sym && ctx->sym_ok != 0;
+    bool two_failed = false;   // the two-stage collect of this call overflowed its queue
     uint32_t n_fb = 0;
     for (;;) {
         if (sh_ready) {
@@ -263,7 +264,7 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
         if (sym_now && main_prec == 2) {
             // two-stage scoring: half the features first, against partial-distance thresholds (gt_sym.hip sym_half_*);
             // its collect kernel works on query blocks of up to 1024 rows
-            const bool two_stage = ctx->DP >= 32 && bq_sym == 256 &&
+            const bool two_stage = !two_failed && ctx->DP >= 32 && bq_sym == 256 &&
                                    (ctx->sym_two_stage > 0 || (ctx->sym_two_stage < 0 && ctx->sym_two_ok != 0));
             const int64_t pad_s = two_stage ? 1024 : bq_sym;
             const int64_t n_pad_s = ceil_div64(nq, pad_s) * pad_s;
@@ -405,6 +406,7 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
                     // stage one let (nearly) everything through: partial distances say nothing on this point set.  Start
                     // launch B over with the one-stage kernel, now and for the later builds on these points.
                     ctx->sym_two_ok = 0;
+                    two_failed = true;   // (also when the option forces the two-stage collect: not a second time)
                     continue;
                 }
                 if (ctx->sym_two_ok < 0) ctx->sym_two_ok = 1;
@@ -629,6 +631,7 @@ int gt_sym_queue_prepare(gt_ctx* ctx, int64_t n_pad_s, SelectArgs& a) {
     const int64_t units = (n_pad_s / 64) * (n_pad_s / 32) / 2 / std::max(1, a.sym.shard_world);
     int64_t rcap = 1024;   // (a wave next to the diagonal of a clustered set notes several hundred pairs)
     while (rcap < 8192 && rcap * nwaves < units / 8) rcap *= 2;
+    if (ctx->sym_queue_cap > 0) rcap = ctx->sym_queue_cap;
     GT_HIP(ctx, k->sym_queue.reserve(size_t(nwaves) * size_t(rcap) * sizeof(uint2)));
     GT_HIP(ctx, k->sym_qcount.reserve(size_t(nwaves) * sizeof(uint32_t)));
     GT_HIP(ctx, hipMemsetAsync(k->sym_qcount.p, 0, size_t(nwaves) * sizeof(uint32_t), ctx->stream));

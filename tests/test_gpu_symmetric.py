@@ -129,3 +129,73 @@ def test_symmetric_and_classic_pass_build_identical_kernels():
         ctx.close()
     for a, b in zip(out["auto"], out["0"]):
         assert np.array_equal(a, b)
+
+
+# ---- two-stage collect (partial distances first, deferred cold pass) ---------------------------------------------------
+def _build(X, opts, knn=15, decay=40.0):
+    from graphtools_amd import _hip
+
+    c = _hip.Context(0)
+    for k, v in opts.items():
+        c.set_option(k, str(v))
+    c.set_points(X)
+    p, keep = c.make_params(knn, decay, 1e-4, None, 1.0, None, "+", None, 0)
+    c.graph_build(p)
+    Kd, Ki, Kp = c.graph_fetch_csr(_hip.CSR_K)
+    st, gs = c.knn_stats(), c.graph_stats()
+    c.close()
+    return (Kd, Ki, Kp), st, gs
+
+
+def _same_csr(a, b):
+    assert np.array_equal(a[2], b[2]) and np.array_equal(a[1], b[1]) and np.array_equal(a[0], b[0])
+
+
+def test_two_stage_collect_equals_the_one_stage_collect_and_the_classic_pass():
+    X = make_mix(150000, 64, 11)
+    two, st2, _ = _build(X, {"select_sym_two_stage": 1})
+    one, st1, _ = _build(X, {"select_sym_two_stage": 0})
+    classic, st0, _ = _build(X, {"select_symmetric": 0})
+    assert st2["symmetric"] and st2["sym_two_stage"] and st2["sym_cold_pairs"] > 0
+    assert st1["symmetric"] and not st1["sym_two_stage"]
+    assert not st0["symmetric"]
+    _same_csr(two, one)
+    _same_csr(two, classic)
+
+
+@pytest.mark.parametrize("d", [32, 40, 64])
+def test_two_stage_collect_on_forced_small_cases(sym_ctx, d):
+    """32 / 48 / 64 padded features, ragged last 1024-row block; kNN against the oracle"""
+    sym_ctx.set_option("select_sym_two_stage", "1")
+    st = _knn(sym_ctx, make_mix(5003, d, 12), 15)
+    assert st["sym_two_stage"] and st["sym_cold_pairs"] > 0
+
+
+def test_two_stage_forecast_declines_where_partial_distances_do_not_separate():
+    """a 5-dimensional manifold under a random projection: 16 of 64 features carry a quarter of every distance, a fifth of
+    the sampled pairs would pass stage one - the one-stage kernel runs, no pass is wasted, the graph is the classic one"""
+    X = make_manifold(100000, 64, 13)
+    auto, st, _ = _build(X, {"select_sym_min_rows": 1})
+    classic, _, _ = _build(X, {"select_symmetric": 0})
+    assert st["symmetric"] and not st["sym_two_stage"]
+    _same_csr(auto, classic)
+
+
+def test_two_stage_queue_overflow_starts_over_with_the_one_stage_kernel():
+    X = make_mix(70000, 64, 14)
+    small, st, _ = _build(X, {"select_sym_two_stage": 1, "select_sym_queue_cap": 2})
+    ref, _, _ = _build(X, {"select_symmetric": 0})
+    assert st["symmetric"] and not st["sym_two_stage"]
+    _same_csr(small, ref)
+
+
+def test_orphan_rows_are_repaired_from_their_seeds():
+    """every row with a far-kept seed is declared an orphan (select_sym_orphan_far large): it collects nothing, starts its
+    list with the rows launch A kept, and must come back through the repair pass with the exact neighbours"""
+    X = make_mix(70000, 64, 15)
+    orph, st, gs = _build(X, {"select_sym_two_stage": 1, "select_sym_orphan_far": 1000, "select_sym_stride": 16,
+                              "select_sym_cells": 3})
+    ref, _, _ = _build(X, {"select_symmetric": 0})
+    assert st["symmetric"] and st["sym_two_stage"]
+    assert st["repaired_rows"] > 5
+    _same_csr(orph, ref)
