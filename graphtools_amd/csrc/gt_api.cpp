@@ -62,6 +62,7 @@ int gt_ctx_create(int device, gt_ctx** out) {
     // test hooks of the symmetric candidate pass (gt_sym.hip): force it on (1) / off (0), smallest launch, sample stride
     if (const char* v = std::getenv("GT_DBG_SELECT")) ctx->dbg_select = std::atoi(v);   // development switches
     if (const char* v = std::getenv("GT_SYMMETRIC")) ctx->sym_mode = std::atoi(v);
+    if (const char* v = std::getenv("GT_SYM_TWO_STAGE")) ctx->sym_two_stage = std::atoi(v);
     if (const char* v = std::getenv("GT_SYM_MIN_ROWS")) ctx->sym_min_rows = std::max(1, std::atoi(v));
     if (const char* v = std::getenv("GT_SYM_STRIDE")) ctx->sym_stride = std::max(0, std::atoi(v));
     *out = ctx;

@@ -43,3 +43,13 @@ def test_random_configurations_with_the_symmetric_pass():
                          text=True, timeout=1500, env=env)
     tail = "\n".join(res.stdout.strip().splitlines()[-6:])
     assert res.returncode == 0, tail + "\n" + res.stderr[-2000:]
+
+
+def test_random_configurations_with_the_two_stage_symmetric_collect():
+    """the symmetric sweep with the two-stage collect forced on wherever it is built (32 ... 64 padded features): partial
+    distances first, deferred cold pass, orphans - whatever the data look like (a queue that overflows starts over)"""
+    env = dict(os.environ, GT_QUERY_ORDER_MIN_ROWS="1", GT_SYMMETRIC="1", GT_SYM_STRIDE="4", GT_SYM_TWO_STAGE="1")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gpu_fuzz.py"), "40", "53"], capture_output=True,
+                         text=True, timeout=1500, env=env)
+    tail = "\n".join(res.stdout.strip().splitlines()[-6:])
+    assert res.returncode == 0, tail + "\n" + res.stderr[-2000:]
