@@ -289,6 +289,24 @@ int gt_set_option(gt_ctx* ctx, const char* name, const char* value) {
         ctx->sym_two_stage = v == "auto" ? -1 : std::atoi(value);
         return GT_OK;
     }
+    if (k == "symmetrize_bins") {
+        ctx->symm_bins = v == "auto" ? -1 : std::atoi(value);
+        return GT_OK;
+    }
+    if (k == "symmetrize_bin_shift") {
+        const int sh = std::atoi(value);
+        if (sh != 0 && (sh < 8 || sh > 12)) return GT_E_ARG;
+        ctx->symm_bin_shift = sh;
+        return GT_OK;
+    }
+    if (k == "select_sym_pca") {
+        ctx->sym_pca = std::atoi(value);
+        return GT_OK;
+    }
+    if (k == "select_sym_spill_cap") {
+        ctx->sym_spill_cap = std::max(0, std::atoi(value));
+        return GT_OK;
+    }
     if (k == "select_sym_queue_cap") {
         ctx->sym_queue_cap = std::max(0, std::atoi(value));
         return GT_OK;

@@ -142,8 +142,8 @@ struct gt_ctx {
     // symmetric candidate pass for self queries over the whole point set (gt_sym.hip): -1 auto (large launches), 0 off, 1 on
     int32_t sym_mode = -1;
     int64_t sym_min_rows = 65536;
-    int32_t sym_stride = 64;    //   threshold-seeding launch: every sym_stride-th tile besides the row's own neighbourhood (0: none)
-    int32_t sym_cells = 12;     //   ... which is the rows of this many nearest cells (landmarks) of the block's own cells,
+    int32_t sym_stride = 96;    //   threshold-seeding launch: every sym_stride-th tile besides the row's own neighbourhood (0: none)
+    int32_t sym_cells = 8;     //   ... which is the rows of this many nearest cells (landmarks) of the block's own cells,
     int32_t sym_max_nb = 384;   //   at most this many tiles
     int32_t sym_tcap = 512;     //   capacity of a row's candidate list in launch B (<= 512)
     int32_t sym_ok = -1;        //   auto: 0 once the bound point set has overflowed the lists of launch B (reset by gt_set_points)
@@ -151,7 +151,11 @@ struct gt_ctx {
     int32_t sym_orphan_far = 4;  //  a row is an orphan when this many times its far-kept seeds reach the seeds wanted (0: off)
     double sym_radius_cut = 4.0; //  rows whose completeness radius (squared) exceeds this many times the mean are repaired directly
     int32_t sym_two_stage = -1; //   launch B scores half the features first (partial distances): -1 auto, 0 off, 1 on
+    int32_t symm_bins = -1;     // single-rank symmetrisation through destination bins (gt_sparse.hip): -1 auto, 0 off, 1 on
+    int32_t symm_bin_shift = 0; //   log2 of the rows per bin (0: 9, more from 2 M rows; development / tests: 8 ... 12)
+    int32_t sym_pca = 1;        //   stage one scores the 16 leading principal directions (0: the first 16 features)
     int32_t sym_queue_cap = 0;  //   entries per wave region of the two-stage queue (0: sized from the problem; development / tests)
+    int32_t sym_spill_cap = 0;  //   entries of the shared spill area behind the regions (0: 4 M; development / tests)
     int32_t sym_two_steps = 0;  //   k-steps of stage one (0: half of them; development, must match the kernel build)
     int32_t sym_two_ok = -1;    //   verdict of the last launch for the bound point set (cold-path share), -1 unknown
     int32_t sym_shard_group = 32;   //   row-sharded launch B: query blocks per rotation step of the walk pieces

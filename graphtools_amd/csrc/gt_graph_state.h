@@ -53,6 +53,8 @@ struct GraphState {
     // merge
     DevBuf Ukey, Uval, Vkey, Vval, bigrows, hugerows, bigcount, bigscratch_k, bigscratch_v, bigsoff, aniso_tmp, scan_own;
     DevBuf indices, Kdata, Pdata, flags;
+    DevBuf bincnt, binoff;   // destination bins of the single-rank transpose: triplets per bin (+ the emit cursors), scan
+    bool bins_used = false;
     int64_t nnz0 = 0, nnz = 0;
 };
 

@@ -5,6 +5,7 @@
 #include "gt_knn_select.h"
 
 #include <algorithm>
+#include <vector>
 #include <cstdio>
 
 int gt_select_bn_for(int dp) { return gt_select_bn(dp); }
@@ -16,7 +17,7 @@ void gt_free_knn_work(gt_ctx* ctx) {
                       &k->d2_lb, &k->fb_rows, &k->fb_count, &k->fb_scratch, &k->gflags, &k->prof, &k->fb_qrows, &k->fb_thr, &k->fb_lists,
                       &k->fb_counts, &k->fb_max, &k->unproven, &k->qorder, &k->qthr0, &k->qlomax_dev, &k->Ycs, &k->hnegs,
                       &k->sym_g, &k->sym_gmin, &k->tlists, &k->tcounts, &k->sym_stat, &k->sym_work, &k->sym_tiles,
-                      &k->sym_tile_cnt, &k->sh_invperm, &k->sh_lists, &k->sh_counts, &k->sh_cnt, &k->sh_own, &k->sh_tmp, &k->sym_hh, &k->sym_thrh, &k->sym_gh, &k->sym_gminh, &k->sym_queue, &k->sym_qcount, &k->sym_qdense, &k->sym_qtot, &k->sym_racc, &k->sym_farcnt})
+                      &k->sym_tile_cnt, &k->sh_invperm, &k->sh_lists, &k->sh_counts, &k->sh_cnt, &k->sh_own, &k->sh_tmp, &k->sym_hh, &k->sym_thrh, &k->sym_gh, &k->sym_gminh, &k->sym_queue, &k->sym_qcount, &k->sym_qdense, &k->sym_qtot, &k->sym_racc, &k->sym_farcnt, &k->sym_z, &k->sym_p, &k->sym_cov, &k->sym_qspill})
         b->release();
     delete k;
     ctx->knn = nullptr;
@@ -397,7 +398,7 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
             }
             {
                 StageSpan span(ctx, "knn_select");
-                GT_TRY(gt_launch_select(ctx, a));
+                GT_TRY(gt_sym_launch_collect(ctx, a));
             }
             if (two_now) {
                 int ok = 0;
@@ -576,58 +577,166 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
     return GT_OK;
 }
 
+// Symmetric eigenproblem of a small matrix (cyclic Jacobi, float64): A [m][m] row-major is destroyed, V gets the
+// eigenvectors in its COLUMNS, the eigenvalues end on A's diagonal.
+static void jacobi_eigen(std::vector<double>& A, std::vector<double>& V, int m) {
+    V.assign(size_t(m) * m, 0.0);
+    for (int i = 0; i < m; ++i) V[size_t(i) * m + i] = 1.0;
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        double off = 0.0, diag = 0.0;
+        for (int i = 0; i < m; ++i)
+            for (int j = 0; j < m; ++j) (i == j ? diag : off) += A[size_t(i) * m + j] * A[size_t(i) * m + j];
+        if (off <= 1e-28 * diag) break;
+        for (int p = 0; p < m - 1; ++p)
+            for (int q = p + 1; q < m; ++q) {
+                const double apq = A[size_t(p) * m + q];
+                if (std::fabs(apq) < 1e-300) continue;
+                const double theta = (A[size_t(q) * m + q] - A[size_t(p) * m + p]) / (2.0 * apq);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+                const double c = 1.0 / std::sqrt(t * t + 1.0), sn = t * c;
+                for (int r = 0; r < m; ++r) {   // columns p, q
+                    const double arp = A[size_t(r) * m + p], arq = A[size_t(r) * m + q];
+                    A[size_t(r) * m + p] = c * arp - sn * arq;
+                    A[size_t(r) * m + q] = sn * arp + c * arq;
+                }
+                for (int r = 0; r < m; ++r) {   // rows p, q
+                    const double apr = A[size_t(p) * m + r], aqr = A[size_t(q) * m + r];
+                    A[size_t(p) * m + r] = c * apr - sn * aqr;
+                    A[size_t(q) * m + r] = sn * apr + c * aqr;
+                }
+                for (int r = 0; r < m; ++r) {
+                    const double vrp = V[size_t(r) * m + p], vrq = V[size_t(r) * m + q];
+                    V[size_t(r) * m + p] = c * vrp - sn * vrq;
+                    V[size_t(r) * m + q] = sn * vrp + c * vrq;
+                }
+            }
+    }
+}
+
+// The frame of stage one (gt_sym.hip "stage-one subspace"): the 16 leading principal directions of a row sample, or - the
+// option off, or no more features than columns - the first 16 coordinate axes.  P_host: [16][64] floats, rows orthonormal.
+static int stage_one_frame(gt_ctx* ctx, float* P_host, bool principal) {
+    KnnWork* k = ctx->knn;
+    const int d = ctx->d;
+    std::fill(P_host, P_host + 16 * 64, 0.f);
+    if (!principal || d <= 16 || d > 64) {
+        for (int c = 0; c < 16 && c < d; ++c) P_host[c * 64 + c] = 1.f;
+        return GT_OK;
+    }
+    const int64_t ns = std::min<int64_t>(ctx->n, 32768), step = std::max<int64_t>(1, ctx->n / ns);
+    GT_HIP(ctx, k->sym_cov.reserve((64 * 64 + 64) * sizeof(double)));
+    double* C_dev = k->sym_cov.as<double>();
+    GT_TRY(gt_sym_sample_cov(ctx, step, ns, C_dev + 64 * 64, C_dev));
+    std::vector<double> C64(64 * 64);
+    GT_HIP(ctx, hipMemcpyAsync(C64.data(), C_dev, 64 * 64 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<double> A(size_t(d) * d), V;
+    for (int i = 0; i < d; ++i)
+        for (int j = 0; j < d; ++j) A[size_t(i) * d + j] = 0.5 * (C64[i * 64 + j] + C64[j * 64 + i]);
+    jacobi_eigen(A, V, d);
+    std::vector<int> order(d);
+    for (int i = 0; i < d; ++i) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](int x, int y) { return A[size_t(x) * d + x] > A[size_t(y) * d + y]; });
+    for (int c = 0; c < 16; ++c)
+        for (int m = 0; m < d; ++m) P_host[c * 64 + m] = float(V[size_t(m) * d + order[c]]);
+    return GT_OK;
+}
+
 int gt_sym_two_stage_prepare(gt_ctx* ctx, const int32_t* perm, int64_t n_pad_s, const ErrModel& em, int need_m, SelectArgs& a,
                              bool cut_done) {
     KnnWork* k = ctx->knn;
-    const int hd = ctx->sym_two_steps > 0 ? 16 * ctx->sym_two_steps : 16;
+    const int hd = 16;
     GT_HIP(ctx, k->sym_hh.reserve(size_t(n_pad_s) * sizeof(float)));
     GT_HIP(ctx, k->sym_thrh.reserve(size_t(n_pad_s) * sizeof(float)));
     GT_HIP(ctx, k->sym_gh.reserve(size_t(n_pad_s) * sizeof(float)));
     GT_HIP(ctx, k->sym_gminh.reserve(size_t(n_pad_s / 32) * sizeof(float)));
-    GT_HIP(ctx, k->sym_qtot.reserve(2 * sizeof(uint32_t)));
-    uint32_t flagged = 0;
+    GT_HIP(ctx, k->sym_qtot.reserve(4 * sizeof(uint32_t)));
+    GT_HIP(ctx, k->sym_z.reserve(size_t(n_pad_s) * 16 * sizeof(_Float16)));
+    GT_HIP(ctx, k->sym_p.reserve(16 * 64 * sizeof(float)));
+    // the stage-one copy Z = scz * P x: |P x| <= |x| <= sqrt(ymax2), the scale keeps that inside float16's normal range;
+    // its rounding residual per row: float16 (2^-11 relative per column) + the float32 projection
+    double y2 = 0.0;
+    GT_HIP(ctx, hipMemcpyAsync(&y2, ctx->ymax.p, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const double ymax = std::sqrt(std::max(y2, 1e-300));
+    const double scz = gt_f16_scale(ymax);
+    const double Lz = 1.01 * (4.8828125e-4 + double(ctx->d + 8) * 1.1920928955078125e-7) * scz * ymax;
     const int64_t samples = 8192;
-    {
-        StageSpan span(ctx, "sym_prepare");
-        GT_TRY(gt_sym_half_seeds(ctx, k->Ycs.p, n_pad_s, hd, k->sym_hh.as<float>()));
-        GT_TRY(gt_sym_half_thresholds(ctx, perm, n_pad_s, k->thr_final.as<float>(), k->sym_hh.as<float>(), em, hd,
-                                      k->sym_thrh.as<float>(), k->sym_gh.as<float>(), k->sym_gminh.as<float>()));
-        if (ctx->sym_two_stage < 0)
-            GT_TRY(gt_sym_two_probe(ctx, k->Ycs.p, hd, k->sym_hh.as<float>(), k->sym_thrh.as<float>(), k->sym_gh.as<float>(),
-                                    samples, k->sym_qtot.as<uint32_t>()));
-    }
-    if (ctx->sym_two_stage < 0) {
-        GT_HIP(ctx, hipMemcpyAsync(&flagged, k->sym_qtot.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-        GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (ctx->dbg_select & 2048) fprintf(stderr, "[gt] two-stage forecast: %u of %lld sampled pairs pass stage one\n", flagged, (long long)samples);
-        // the queue holds one pair in 8; forecast beyond one in 24: partial distances are a poor filter on this point set
-        if (int64_t(flagged) * 24 > samples) {
-            ctx->sym_two_ok = 0;
-            return GT_OK;
+    // Frames in turn: the first 16 coordinate axes (free), then the 16 leading principal directions of a row sample
+    // (a covariance pass and a 64 x 64 eigenproblem on the host: only when the axes do not separate).  The forecast
+    // decides; with the two-stage collect forced on, the first frame offered is taken (select_sym_pca = 2: the
+    // principal one).
+    const bool can_pca = ctx->sym_pca != 0 && ctx->d > 16 && ctx->d <= 64;
+    bool accepted = false;
+    for (int frame = (ctx->sym_pca == 2 && can_pca) ? 1 : 0; frame < 2 && !accepted; ++frame) {
+        if (frame == 1 && !can_pca) break;
+        float P_host[16 * 64];
+        {
+            StageSpan span(ctx, "sym_prepare");
+            GT_TRY(stage_one_frame(ctx, P_host, frame == 1));   // (synchronises when it runs the PCA)
         }
+        uint32_t flagged = 0;
+        {
+            StageSpan span(ctx, "sym_prepare");
+            GT_HIP(ctx, hipMemcpyAsync(k->sym_p.p, P_host, sizeof(P_host), hipMemcpyHostToDevice, ctx->stream));
+            GT_TRY(gt_sym_project(ctx, perm, n_pad_s, k->sym_p.as<float>(), scz, k->sym_z.p, k->sym_hh.as<float>()));
+            GT_TRY(gt_sym_half_thresholds(ctx, perm, n_pad_s, k->thr_final.as<float>(), k->sym_hh.as<float>(), em, hd, scz, Lz,
+                                          k->sym_thrh.as<float>(), k->sym_gh.as<float>(), k->sym_gminh.as<float>()));
+            if (ctx->sym_two_stage < 0)
+                GT_TRY(gt_sym_two_probe(ctx, k->sym_z.p, hd, k->sym_hh.as<float>(), k->sym_thrh.as<float>(),
+                                        k->sym_gh.as<float>(), samples, k->sym_qtot.as<uint32_t>()));
+            GT_HIP(ctx, hipMemcpyAsync(&flagged, k->sym_qtot.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        }
+        GT_HIP(ctx, hipStreamSynchronize(ctx->stream));   // (P_host is on the stack: its upload is done too)
+        if (ctx->sym_two_stage > 0) {
+            accepted = true;
+        } else {
+            if (ctx->dbg_select & 2048)
+                fprintf(stderr, "[gt] two-stage forecast (%s frame): %u of %lld sampled pairs pass stage one\n",
+                        frame ? "principal" : "coordinate", flagged, (long long)samples);
+            // the queue holds one pair in 8; forecast beyond one in 24: this frame is a poor filter on this point set
+            accepted = int64_t(flagged) * 24 <= samples;
+        }
+        k->sym_frame = frame;
+    }
+    if (!accepted) {
+        ctx->sym_two_ok = 0;
+        return GT_OK;
     }
     if (!cut_done) {
         // going ahead: the orphans lose their thresholds (a handful of rows; the forecast above was made with them), the
         // forms derived from the thresholds are made again
         StageSpan span(ctx, "sym_prepare");
-        GT_TRY(gt_sym_orphan_cut(ctx, perm, k->thr_final.as<float>(), k->sym_farcnt.as<float>(), em, k->sym_racc.as<double>(), need_m));
+        // (a radius is "no longer small" from 1/16 of the typical distance between unrelated rows when stage one sees 16
+        //  coordinates - a quarter of every distance on isotropic data -, from 1/4 in the principal frame)
+        GT_TRY(gt_sym_orphan_cut(ctx, perm, k->thr_final.as<float>(), k->sym_farcnt.as<float>(), em, k->sym_racc.as<double>(), need_m,
+                                 k->sym_frame == 1 ? 0.25 : 0.0625));
         GT_TRY(gt_sym_g_from_thr(ctx, n_pad_s, k->thr_final.as<float>(), k->hnegs.as<float>(), k->sym_g.as<float>(),
                                  k->sym_gmin.as<float>()));
-        GT_TRY(gt_sym_half_thresholds(ctx, perm, n_pad_s, k->thr_final.as<float>(), k->sym_hh.as<float>(), em, hd,
+        GT_TRY(gt_sym_half_thresholds(ctx, perm, n_pad_s, k->thr_final.as<float>(), k->sym_hh.as<float>(), em, hd, scz, Lz,
                                       k->sym_thrh.as<float>(), k->sym_gh.as<float>(), k->sym_gminh.as<float>()));
     }
-    a.sym.half_steps = hd / 16;
+    a.sym.half_steps = 1;
     a.sym.hh = k->sym_hh.as<float>();
     a.sym.thrh = k->sym_thrh.as<float>();
     a.sym.gminh = k->sym_gminh.as<float>();
+    a.sym.zrows = k->sym_z.as<float>();
     return GT_OK;
+}
+
+int gt_sym_launch_collect(gt_ctx* ctx, const SelectArgs& a) {
+    if (a.sym.half_steps <= 0) return gt_launch_select(ctx, a);
+    SelectArgs h = a;
+    h.dp = 16;
+    h.Yp = h.Qp = a.sym.zrows;
+    return gt_launch_select(ctx, h);
 }
 
 int gt_sym_queue_prepare(gt_ctx* ctx, int64_t n_pad_s, SelectArgs& a) {
     KnnWork* k = ctx->knn;
-    // one region per wave of the collect launch (its workgroups take at least 512 rows), sized so that all of them
-    // together hold about one pair in 8 - beyond that stage one is not doing its job
-    const int64_t nwaves = (n_pad_s / 512) * a.sym.nseg * 4;
+    // one region per wave of the collect launch, sized so that all of them together hold about one pair in 8 - beyond
+    // that stage one is not doing its job; a wave whose region is full spills into a shared area (4 M pairs)
+    const int64_t nwaves = ceil_div64(n_pad_s, 128 * GT_SEL_TWO_QT) * a.sym.nseg * 4;
     const int64_t units = (n_pad_s / 64) * (n_pad_s / 32) / 2 / std::max(1, a.sym.shard_world);
     int64_t rcap = 1024;   // (a wave next to the diagonal of a clustered set notes several hundred pairs)
     while (rcap < 8192 && rcap * nwaves < units / 8) rcap *= 2;
@@ -635,20 +744,27 @@ int gt_sym_queue_prepare(gt_ctx* ctx, int64_t n_pad_s, SelectArgs& a) {
     GT_HIP(ctx, k->sym_queue.reserve(size_t(nwaves) * size_t(rcap) * sizeof(uint2)));
     GT_HIP(ctx, k->sym_qcount.reserve(size_t(nwaves) * sizeof(uint32_t)));
     GT_HIP(ctx, hipMemsetAsync(k->sym_qcount.p, 0, size_t(nwaves) * sizeof(uint32_t), ctx->stream));
+    const int64_t spill_cap = ctx->sym_spill_cap > 0 ? ctx->sym_spill_cap : int64_t(1) << 22;
+    GT_HIP(ctx, k->sym_qspill.reserve(size_t(spill_cap) * sizeof(uint2) + 16));
     a.sym.queue = k->sym_queue.as<uint2>();
     a.sym.qcount = k->sym_qcount.as<uint32_t>();
     a.sym.qcap = int32_t(rcap);
+    // (the spill counter sits behind the spill entries)
+    a.sym.qspill = k->sym_qspill.as<uint2>();
+    a.sym.qspill_count = reinterpret_cast<uint32_t*>(k->sym_qspill.as<uint2>() + spill_cap);
+    a.sym.qspill_cap = int32_t(spill_cap);
+    GT_HIP(ctx, hipMemsetAsync(a.sym.qspill_count, 0, sizeof(uint32_t), ctx->stream));
     return GT_OK;
 }
 
 int gt_sym_queue_finish(gt_ctx* ctx, const SelectArgs& a, int64_t* entries, int* ok) {
     KnnWork* k = ctx->knn;
     *ok = 0;
-    const int64_t nwaves = (a.n_pad / 512) * a.sym.nseg * 4;
-    const int64_t dense_cap = std::min<int64_t>(nwaves * int64_t(a.sym.qcap), int64_t(1) << 25);
+    const int64_t nwaves = ceil_div64(a.n_pad, 128 * GT_SEL_TWO_QT) * a.sym.nseg * 4;
+    const int64_t dense_cap = std::min<int64_t>(nwaves * int64_t(a.sym.qcap) + a.sym.qspill_cap, int64_t(1) << 25);
     GT_HIP(ctx, k->sym_qdense.reserve(size_t(dense_cap) * sizeof(uint2)));
-    GT_HIP(ctx, k->sym_qtot.reserve(2 * sizeof(uint32_t)));
-    GT_HIP(ctx, hipMemsetAsync(k->sym_qtot.p, 0, 2 * sizeof(uint32_t), ctx->stream));
+    GT_HIP(ctx, k->sym_qtot.reserve(4 * sizeof(uint32_t)));
+    GT_HIP(ctx, hipMemsetAsync(k->sym_qtot.p, 0, 4 * sizeof(uint32_t), ctx->stream));
     StageSpan span(ctx, "sym_cold");
     SelectArgs c = a;
     c.mode = 5;
@@ -657,14 +773,14 @@ int gt_sym_queue_finish(gt_ctx* ctx, const SelectArgs& a, int64_t* entries, int*
     c.cap = int32_t(dense_cap);
     c.counts = k->sym_qtot.as<uint32_t>();
     GT_TRY(gt_launch_select(ctx, c));
-    uint32_t tot[2] = {0, 0};
-    GT_HIP(ctx, hipMemcpyAsync(tot, k->sym_qtot.p, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    uint32_t tot[3] = {0, 0, 0};   // entries, fullest region, spill overflow
+    GT_HIP(ctx, hipMemcpyAsync(tot, k->sym_qtot.p, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     *entries = int64_t(tot[0]);
     if (ctx->dbg_select & 2048)
         fprintf(stderr, "[gt] two-stage queue: %u entries, fullest region %u, %lld regions of %d, dense capacity %lld\n", tot[0], tot[1],
                 (long long)nwaves, a.sym.qcap, (long long)dense_cap);
-    if (int64_t(tot[1]) > int64_t(a.sym.qcap) || int64_t(tot[0]) > dense_cap) return GT_OK;
+    if (tot[2] != 0 || int64_t(tot[0]) > dense_cap) return GT_OK;   // entries were dropped: nothing was filed
     SelectArgs d = a;
     d.mode = 4;
     d.sym.queue = k->sym_qdense.as<uint2>();

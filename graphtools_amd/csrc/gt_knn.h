@@ -32,9 +32,12 @@ struct KnnWork {
     DevBuf sym_racc, sym_farcnt;                     // radius / spread statistics of the orphan cut (4 doubles), far-kept
                                                   // seeds per sorted position
     DevBuf sym_hh, sym_thrh, sym_gh, sym_gminh;   // two-stage scoring (gt_sym.hip sym_half_*)
+    DevBuf sym_z, sym_p, sym_cov;                 //   the stage-one copy Z = P x, its frame P, sample covariance scratch
+    DevBuf sym_qspill;                            //   spill area of the queue (+ its counter)
     DevBuf sym_queue, sym_qcount, sym_qdense, sym_qtot;   //   and the queue of its deferred cold pass (wave regions,
                                                           //   their counts, the compacted queue, {total, overflow})
     int64_t sym_cold_entries = 0;
+    int sym_frame = 0;                            //   frame of stage one: 0 coordinate axes, 1 principal directions
     bool sym_two_used = false;                    //   the last symmetric pass ran the two-stage collect
     bool sym_used = false;
     int64_t sym_overflow = 0;
@@ -178,11 +181,16 @@ int gt_sym_thresholds(gt_ctx* ctx, const int32_t* perm, int64_t n_pad_s, const f
                       const DevBuf& work, int cells, unsigned long long* far_total, float* farcnt = nullptr,
                       int64_t p_first = 0, int64_t p_last = -1);
 // two-stage scoring of launch B: half seeds of the sorted rows, partial-distance thresholds from the full ones
-int gt_sym_half_seeds(gt_ctx* ctx, const void* Ys, int64_t n_pad_s, int hd, float* hh);
+// stage-one copy of the two-stage collect: Z [n_pad][16] float16 = scz x P x (P_dev [16][64], orthonormal rows) in sorted
+// order, hh = its half seeds; sample covariance for the principal frame
+int gt_sym_project(gt_ctx* ctx, const int32_t* perm, int64_t n_pad_s, const float* P_dev, double scz, void* Z, float* hh);
+int gt_sym_sample_cov(gt_ctx* ctx, int64_t step, int64_t ns, double* sums_dev, double* C_dev);
 // forecast of stage one: of `samples` pseudo-random (64 queries, 32 rows) pairs, how many pass (flagged: device counter)
 int gt_sym_two_probe(gt_ctx* ctx, const void* Ys, int hd, const float* hh, const float* thrh, const float* gh, int64_t samples,
                      uint32_t* flagged);
 struct SelectArgs;
+// launch B: the one-stage kernel on the full copy, or (sym.half_steps > 0) the two-stage unit loop on the stage-one copy
+int gt_sym_launch_collect(gt_ctx* ctx, const SelectArgs& a);
 // queue of the two-stage collect launch `a` (mode 2 with sym.half_steps): sizes and binds the wave regions
 int gt_sym_queue_prepare(gt_ctx* ctx, int64_t n_pad_s, SelectArgs& a);
 // half seeds + partial-distance thresholds + forecast: binds them to `a` (sym.half_steps > 0) when stage one is expected to
@@ -195,7 +203,7 @@ int gt_sym_two_stage_prepare(gt_ctx* ctx, const int32_t* perm, int64_t n_pad_s, 
 // overflowed (nothing was filed: the caller runs the one-stage kernel instead)
 int gt_sym_queue_finish(gt_ctx* ctx, const SelectArgs& a, int64_t* entries, int* ok);
 int gt_sym_half_thresholds(gt_ctx* ctx, const int32_t* perm, int64_t n_pad_s, const float* thr, const float* hh,
-                           const ErrModel& err, int hd, float* thrh, float* gh, float* gminh);
+                           const ErrModel& err, int hd, double scz, double Lz, float* thrh, float* gh, float* gminh);
 // row-sharded symmetric pass (gt_knn_shard.cpp)
 #define GT_SYM_MAX_WORLD 64
 int gt_sym_g_from_thr(gt_ctx* ctx, int64_t n_pad_s, const float* thr, const float* hs, float* g, float* gmin);
@@ -206,7 +214,7 @@ int gt_sym_g_from_thr(gt_ctx* ctx, int64_t n_pad_s, const float* thr, const floa
 int gt_sym_radius_sum(gt_ctx* ctx, const int32_t* perm, int64_t p_first, int64_t p_last, const float* thr, const ErrModel& err,
                       double* acc);
 int gt_sym_orphan_cut(gt_ctx* ctx, const int32_t* perm, float* thr, const float* farcnt, const ErrModel& err, const double* acc,
-                      int need_m);
+                      int need_m, double pair_frac = 0.0625);
 // orphans of the sorted positions [p_first, p_last) (thr = +inf on a real row): the rows launch A kept -> head of tlists
 int gt_sym_inject_orphans(gt_ctx* ctx, int64_t p_first, int64_t p_last, const float* thr, const uint64_t* lists, int lstride,
                           const uint32_t* counts, uint64_t* tlists, int tcap, uint32_t* tcounts);

@@ -2,6 +2,10 @@
 #pragma once
 #include "gt_common.h"
 
+// query tiles per wave of the two-stage collect kernel: its workgroups take 128 x this many rows (host and kernels agree)
+#ifndef GT_SEL_TWO_QT
+#define GT_SEL_TWO_QT 8
+#endif
 // Device-side extras of the symmetric self-query path (MODE 2) and of the MODE 0 launch that seeds its thresholds
 struct SymDev {
     const float* g = nullptr;       // [n_pad] thr_j + hneg_j: row j admits query q iff (score_qj + hneg_q) > g_j; +inf on pad rows
@@ -31,6 +35,7 @@ struct SymDev {
     // forward / transposed form (gt_sym.hip sym_half_thresholds_kernel).  Units that pass are recomputed in full on the
     // cold path and tested as before.  half_steps = 0: off (the unit loop scores all features).
     int32_t half_steps = 0;
+    const float* zrows = nullptr;   // [n_pad][16] float16: the stage-one copy of the points (rows of the unit loop)
     const float* hh = nullptr;      // [n_pad]
     const float* thrh = nullptr;    // [n_pad]
     const float* gminh = nullptr;   // [n_pad / 32]
@@ -42,6 +47,9 @@ struct SymDev {
     uint32_t* qcount = nullptr;     // collect launch: [waves] entries noted by each wave (beyond qcap: dropped, the
                                     // caller falls back)
     int32_t qcap = 0;               // entries per wave region
+    uint2* qspill = nullptr;        // shared spill area for the waves whose region is full (slots from an atomic: rare)
+    uint32_t* qspill_count = nullptr;
+    int32_t qspill_cap = 0;
     int32_t qn = 0;                 // mode 4: entries to process
     int32_t list_shift = 0;    // sched 1: the tile list of query block b is list b >> list_shift (narrow 128-row
                                // workgroups on lists made for 256-row blocks)

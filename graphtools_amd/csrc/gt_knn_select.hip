@@ -66,9 +66,6 @@
 #ifndef GT_SEL_TWO_VPM
 #define GT_SEL_TWO_VPM 5   // two-stage collect: VALU instructions scheduled behind each MFMA of the unit loop
 #endif
-#ifndef GT_SEL_TWO_QT
-#define GT_SEL_TWO_QT 8   // query tiles per wave of the two-stage collect kernel (query block = 128 x this many rows)
-#endif
 #ifndef GT_SEL_TWO_NS1
 #define GT_SEL_TWO_NS1(DP_) 1   // k-steps (16 features each) of stage one of the two-stage symmetric collect
 #endif
@@ -563,16 +560,26 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
 #define GT_QUEUE_FLUSH()                                                                                   \
     if (TWO && pend_pm != 0u) {   /* wave-uniform */                                                       \
         const uint32_t n_ = uint32_t(__popc(pend_pm));                                                     \
-        if (uint32_t(lane) < n_ && qfill + n_ <= uint32_t(sy.qcap)) {                                      \
+        uint2* dst_ = qreg + qfill;                                                                        \
+        bool room_ = qfill + n_ <= uint32_t(sy.qcap);                                                      \
+        if (!room_) {   /* region full (wave-uniform, rare): slots in the shared spill area, from an atomic */ \
+            uint32_t sb0_ = 0u;                                                                            \
+            if (lane == 0) sb0_ = atomicAdd(sy.qspill_count, n_);                                          \
+            sb0_ = uint32_t(__builtin_amdgcn_readfirstlane(int(sb0_)));                                    \
+            room_ = sb0_ + n_ <= uint32_t(sy.qspill_cap);   /* (beyond it: the count says so, the caller starts over) */ \
+            dst_ = sy.qspill + sb0_;                                                                       \
+        } else {                                                                                           \
+            qfill += n_;                                                                                   \
+        }                                                                                                  \
+        if (uint32_t(lane) < n_ && room_) {                                                                \
             uint32_t m_ = pend_pm;                                                                         \
             for (int i_ = 0; i_ < lane; ++i_) m_ &= m_ - 1u;   /* the lane-th set bit (lane < 16) */       \
             const uint32_t p_ = uint32_t(__ffs(int(m_)) - 1);                                              \
             const uint32_t sb_ = p_ / uint32_t(QT / 2), pr_ = p_ % uint32_t(QT / 2);                       \
             const uint64_t ent_ = uint64_t(uint32_t((qblock + (w * QT + 2 * pr_) * 32) / 64)) |            \
                                   (uint64_t(pend_t * (BN / 32) + sb_) << 32);                              \
-            list_store(reinterpret_cast<uint64_t*>(qreg + qfill + uint32_t(lane)), ent_);                  \
+            list_store(reinterpret_cast<uint64_t*>(dst_ + uint32_t(lane)), ent_);                          \
         }                                                                                                  \
-        qfill += n_;   /* (beyond the capacity: the count says so, the caller starts over) */              \
         pend_pm = 0u;                                                                                      \
     }
     uint2* qreg = TWO ? sy.queue + (size_t(blockIdx.x) * 4 + w) * size_t(sy.qcap) : nullptr;
@@ -1196,14 +1203,32 @@ __global__ __launch_bounds__(256) void sym_queue_compact_kernel(const uint2* __r
     if (r >= nwaves) return;
     uint32_t c = cnts[r];
     if (c == 0u) return;
-    if (lane == 0) atomicMax(flag, c);   // the largest count of a region (beyond rcap: that region overflowed)
-    if (c > uint32_t(rcap)) c = uint32_t(rcap);
+    if (lane == 0) atomicMax(flag, c);   // the fullest region (statistics)
     uint32_t base = 0u;
     if (lane == 0) base = atomicAdd(total, c);
     base = __shfl(base, 0);
     const uint2* src = regions + size_t(r) * size_t(rcap);
     for (uint32_t i = uint32_t(lane); i < c; i += 64u)
         if (base + i < dense_cap) dense[base + i] = src[i];
+}
+
+// ... and the spill area behind them (spill_n entries, already dense): appended with one atomic per workgroup
+__global__ __launch_bounds__(256) void sym_queue_spill_kernel(const uint2* __restrict__ spill, const uint32_t* __restrict__ spill_count,
+                                                              const uint32_t spill_cap, uint2* __restrict__ dense,
+                                                              const uint32_t dense_cap, uint32_t* __restrict__ total,
+                                                              uint32_t* __restrict__ flag) {
+    __shared__ uint32_t base_s;
+    const uint32_t n = *spill_count;
+    if (n > spill_cap) {   // the spill area overflowed: entries are missing - the caller must start over
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(flag + 1, 1u);
+        return;
+    }
+    const uint32_t i0 = blockIdx.x * 256u;
+    if (i0 >= n) return;
+    const uint32_t c = n - i0 < 256u ? n - i0 : 256u;
+    if (threadIdx.x == 0) base_s = atomicAdd(total, c);
+    __syncthreads();
+    if (threadIdx.x < c && base_s + threadIdx.x < dense_cap) dense[base_s + threadIdx.x] = spill[i0 + threadIdx.x];
 }
 
 // ---- deferred cold pass of the two-stage symmetric collect: one wave per queue entry -------------------------------
@@ -1261,11 +1286,16 @@ __global__ __launch_bounds__(256, 3) void sym_cold_kernel(const float* __restric
 }
 
 int launch_queue_compact(gt_ctx* ctx, const SelectArgs& a) {
-    // a.lists: the dense queue (capacity a.cap entries); a.counts: [0] total, [1] overflow flag (both pre-zeroed);
+    // a.lists: the dense queue (capacity a.cap entries); a.counts: [0] total, [1] fullest region, [2] spill overflow
+    // flag (all pre-zeroed);
     // a.sym.queue / qcount / qcap: the regions; a.nq: number of wave regions
     hipLaunchKernelGGL(sym_queue_compact_kernel, dim3((unsigned)ceil_div64(a.nq, 4)), dim3(256), 0, ctx->stream, a.sym.queue,
                        a.sym.qcount, int64_t(a.nq), a.sym.qcap, reinterpret_cast<uint2*>(a.lists), uint32_t(a.cap), a.counts,
                        a.counts + 1);
+    GT_HIP(ctx, hipGetLastError());
+    hipLaunchKernelGGL(sym_queue_spill_kernel, dim3((unsigned)ceil_div64(a.sym.qspill_cap, 256)), dim3(256), 0, ctx->stream,
+                       a.sym.qspill, a.sym.qspill_count, uint32_t(a.sym.qspill_cap), reinterpret_cast<uint2*>(a.lists),
+                       uint32_t(a.cap), a.counts, a.counts + 1);
     GT_HIP(ctx, hipGetLastError());
     return GT_OK;
 }
@@ -1335,13 +1365,14 @@ int launch_dp(gt_ctx* ctx, const SelectArgs& a) {
     if (a.mode == 2) {
         if constexpr (PREC == 2) {
             if (a.sym.half_steps > 0) {
-                if constexpr (DP >= 32 && SelCfg<DP, PREC>::QT == 2) {
+                // (the unit loop of the two-stage collect scores the 16-column stage-one copy: the DP = 16 unit's kernel)
+                if constexpr (DP == 16 && SelCfg<DP, PREC>::QT == 2) {
                     if (a.sym.half_steps != GT_SEL_TWO_NS1(DP) || !a.sym.hh || !a.sym.thrh || !a.sym.gminh || !a.sym.queue ||
-                        !a.sym.qcount || a.sym.qcap <= 0)
+                        !a.sym.qcount || a.sym.qcap <= 0 || !a.sym.qspill || !a.sym.qspill_count || a.sym.qspill_cap <= 0)
                         GT_FAIL(ctx, GT_E_ARG, "knn_select: two-stage scoring needs the half seeds and thresholds");
                     return launch_one<DP, 8, 3, PREC>(ctx, a);
                 }
-                GT_FAIL(ctx, GT_E_ARG, "knn_select: two-stage scoring is built for 32 ... 64 padded features");
+                GT_FAIL(ctx, GT_E_ARG, "knn_select: the two-stage unit loop runs on the 16-column stage-one copy");
             }
             return launch_one<DP, 8, 2, PREC>(ctx, a);
         }

@@ -286,7 +286,7 @@ int gt_knn_shard_collect(gt_ctx* ctx, const float* thr_all, int64_t far_total, c
     for (int attempt = 0; attempt < 2; ++attempt) {
         {
             StageSpan span(ctx, "knn_select");
-            GT_TRY(gt_launch_select(ctx, a));
+            GT_TRY(gt_sym_launch_collect(ctx, a));
         }
         if (a.sym.half_steps <= 0) break;
         // the deferred cold pass of the two-stage collect (gt_knn.cpp has the single-rank twin)

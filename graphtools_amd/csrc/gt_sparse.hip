@@ -22,7 +22,7 @@ void gt_free_graph_state(gt_ctx* ctx) {
     for (DevBuf* b : {&g->bw, &g->bw_user, &g->rowsrc, &g->hugerows, &g->tablen, &g->spmm_in, &g->spmm_out, &g->lenN, &g->lenT, &g->cursor, &g->off, &g->outlen, &g->indptr,
                       &g->degree, &g->over_rows, &g->over_count, &g->rthr, &g->rlists, &g->rcounts, &g->rK, &g->rmax,
                       &g->ownercnt, &g->ownerpos, &g->cnt_sorted, &g->pos_sorted, &g->scan_tmp, &g->selfbuf, &g->splits_dev, &g->Ukey, &g->Uval, &g->Vkey, &g->Vval,
-                      &g->bigrows, &g->bigcount, &g->bigscratch_k, &g->bigscratch_v, &g->bigsoff, &g->aniso_tmp, &g->scan_own,
+                      &g->bincnt, &g->binoff, &g->bigrows, &g->bigcount, &g->bigscratch_k, &g->bigscratch_v, &g->bigsoff, &g->aniso_tmp, &g->scan_own,
                       &g->indices, &g->Kdata, &g->Pdata, &g->flags})
         b->release();
     delete g;
@@ -393,6 +393,200 @@ __global__ __launch_bounds__(256) void fill_recv_kernel(const Triplet* __restric
     }
 }
 
+// ---- single rank, cell-sorted order available: the transpose goes through DESTINATION BINS -------------------------
+// count_recv / fill_recv pay one device-scope atomic and one scattered 16-byte write per received triplet (58 M of each
+// at N = 10^6: 2.9 + 2.7 ms, both fabric-bound - a device-scope atomic is executed at the memory side, the union rows of
+// unrelated destinations share no cache line).  With every row of the graph on this device the exchange is a local
+// permutation, and the cell-sorted order of the points (gt_order.hip) makes it a NEARLY local one: the targets of a row
+// are its neighbours, i.e. rows of the same few cells.  So
+//   * the union rows are laid out in sorted order (row at sorted position p = point perm[p]); positions are cut into bins
+//     of 2^shift rows (512: the triplets of a bin are a few hundred KB, its union rows under a MB - L2-resident);
+//   * bin_count_kernel:  triplets per destination bin (histogram in the LDS, one global atomic per workgroup and bin);
+//   * bin_emit_kernel:   the triplets, written bin by bin (a workgroup reserves its run inside each bin with ONE returning
+//                        atomic per bin it touches, places its triplets through LDS cursors);
+//   * bin_fill_kernel:   one workgroup per bin counts its triplets per row, scans, and writes both halves of its union
+//                        rows - every counter and cursor lives in the LDS, the writes land in the bin's own window;
+//   * sort / merge / long rows run unchanged on the sorted row space; compact_kernel maps position -> row on the way out.
+// Entry order inside a union row depends on the atomics' arrival order; the per-row sort keys (column, tag) are unique,
+// so K does not.
+template <typename F>
+__device__ __forceinline__ void for_kept_entries(const int64_t i, const int lane, const int MP, const double* __restrict__ cand_k,
+                                                 const uint32_t* __restrict__ cand_j, const int32_t* __restrict__ rowsrc,
+                                                 const uint64_t* __restrict__ rlists, const uint32_t* __restrict__ rcounts,
+                                                 const int32_t rcap, const double* __restrict__ rK,
+                                                 const int32_t* __restrict__ tablen, F&& f) {
+    const int32_t src = rowsrc[i];
+    uint32_t n;
+    const double* kv;
+    if (src < 0) {
+        n = uint32_t(tablen[i]);
+        kv = cand_k + i * MP;
+    } else {
+        n = rcounts[src];
+        if (n > uint32_t(rcap)) n = uint32_t(rcap);
+        kv = rK + size_t(src) * rcap;
+    }
+    for (uint32_t e0 = 0; e0 < n; e0 += 64) {   // (wave-uniform trip count: f may use wave-wide operations)
+        const uint32_t e = e0 + lane;
+        double v = -1.0;
+        uint32_t j = 0;
+        if (e < n) {
+            v = kv[e];
+            j = (src < 0) ? cand_j[i * MP + e] : cand_index(rlists[size_t(src) * rcap + e]);
+        }
+        f(v >= 0.0, j, v);
+    }
+}
+
+constexpr int kEmitRows = 128;   // sorted rows per workgroup of bin_emit_kernel
+
+__global__ __launch_bounds__(256) void bin_count_kernel(const int64_t nloc, const int MP, const double* __restrict__ cand_k,
+                                                        const uint32_t* __restrict__ cand_j, const int32_t* __restrict__ rowsrc,
+                                                        const uint64_t* __restrict__ rlists, const uint32_t* __restrict__ rcounts,
+                                                        const int32_t rcap, const double* __restrict__ rK,
+                                                        const int32_t* __restrict__ tablen, const int32_t* __restrict__ perm,
+                                                        const int32_t* __restrict__ pos, const int shift, const int nbins,
+                                                        int32_t* __restrict__ bincnt) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    int32_t* hist = reinterpret_cast<int32_t*>(smem_raw);
+    for (int b = threadIdx.x; b < nbins; b += 256) hist[b] = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int64_t p = int64_t(blockIdx.x) * 4 + w; p < nloc; p += int64_t(gridDim.x) * 4)
+        for_kept_entries(perm[p], lane, MP, cand_k, cand_j, rowsrc, rlists, rcounts, rcap, rK, tablen,
+                         [&](bool keep, uint32_t j, double) {
+                             if (keep) atomicAdd(&hist[pos[j] >> shift], 1);
+                         });
+    __syncthreads();
+    for (int b = threadIdx.x; b < nbins; b += 256)
+        if (hist[b] != 0) atomicAdd(&bincnt[b], hist[b]);
+}
+
+__global__ __launch_bounds__(256) void bin_emit_kernel(const int64_t nloc, const int MP, const double* __restrict__ cand_k,
+                                                       const uint32_t* __restrict__ cand_j, const int32_t* __restrict__ rowsrc,
+                                                       const uint64_t* __restrict__ rlists, const uint32_t* __restrict__ rcounts,
+                                                       const int32_t rcap, const double* __restrict__ rK,
+                                                       const int32_t* __restrict__ tablen, const int32_t* __restrict__ perm,
+                                                       const int32_t* __restrict__ pos, const int shift, const int nbins,
+                                                       const int64_t* __restrict__ binoff, int32_t* __restrict__ bincur,
+                                                       Triplet* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    int32_t* hist = reinterpret_cast<int32_t*>(smem_raw);   // entries of this workgroup per bin, then its cursor there
+    int32_t* base = hist + nbins;                           // first slot of this workgroup's run inside the bin
+    for (int b = threadIdx.x; b < nbins; b += 256) hist[b] = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t p0 = int64_t(blockIdx.x) * kEmitRows;
+    const int64_t p1 = p0 + kEmitRows < nloc ? p0 + kEmitRows : nloc;
+    for (int64_t p = p0 + w; p < p1; p += 4)
+        for_kept_entries(perm[p], lane, MP, cand_k, cand_j, rowsrc, rlists, rcounts, rcap, rK, tablen,
+                         [&](bool keep, uint32_t j, double) {
+                             if (keep) atomicAdd(&hist[pos[j] >> shift], 1);
+                         });
+    __syncthreads();
+    for (int b = threadIdx.x; b < nbins; b += 256)
+        if (hist[b] != 0) {
+            base[b] = atomicAdd(&bincur[b], hist[b]);
+            hist[b] = 0;
+        }
+    __syncthreads();
+    for (int64_t p = p0 + w; p < p1; p += 4) {
+        const uint32_t i = uint32_t(perm[p]);
+        for_kept_entries(int64_t(i), lane, MP, cand_k, cand_j, rowsrc, rlists, rcounts, rcap, rK, tablen,
+                         [&](bool keep, uint32_t j, double v) {
+                             if (keep) {
+                                 const uint32_t pj = uint32_t(pos[j]);
+                                 const int b = int(pj >> shift);
+                                 const int slot = base[b] + atomicAdd(&hist[b], 1);
+                                 Triplet t;
+                                 t.row = pj;   // destination: the SORTED POSITION of point j
+                                 t.col = i;    // column: the point itself
+                                 t.val = v;
+                                 out[binoff[b] + slot] = t;
+                             }
+                         });
+    }
+}
+
+// One workgroup per bin.  sN: exclusive scan of the own-entry counts in sorted order (lenNs), binoff: of the bins'
+// triplet counts - the bin's union rows start at sN[first row] + binoff[bin].
+__global__ __launch_bounds__(256) void bin_fill_kernel(const int64_t nloc, const int MP, const double* __restrict__ cand_k,
+                                                       const uint32_t* __restrict__ cand_j, const int32_t* __restrict__ rowsrc,
+                                                       const uint64_t* __restrict__ rlists, const uint32_t* __restrict__ rcounts,
+                                                       const int32_t rcap, const double* __restrict__ rK,
+                                                       const int32_t* __restrict__ tablen, const int32_t* __restrict__ perm,
+                                                       const int shift, const int nbins, const int64_t* __restrict__ binoff,
+                                                       const Triplet* __restrict__ trip, const int32_t* __restrict__ lenNs,
+                                                       const int64_t* __restrict__ sN, int64_t* __restrict__ off,
+                                                       UEntry* __restrict__ U) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int R = 1 << shift;
+    int32_t* cnt = reinterpret_cast<int32_t*>(smem_raw);   // [R] received entries per row, then the cursor of its T part
+    int32_t* excl = cnt + R;                               // [R] start of the row inside the bin's window
+    __shared__ int32_t wsum[4];
+    const int b = blockIdx.x;
+    const int64_t p0 = int64_t(b) << shift;
+    const int nr = int(nloc - p0 < R ? nloc - p0 : R);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int r = threadIdx.x; r < R; r += 256) cnt[r] = 0;
+    __syncthreads();
+    const int64_t t0 = binoff[b], t1 = binoff[b + 1];
+    for (int64_t t = t0 + threadIdx.x; t < t1; t += 256) atomicAdd(&cnt[int64_t(trip[t].row) - p0], 1);
+    __syncthreads();
+    // exclusive scan of lenNs + cnt over the bin's rows: thread x owns the R / 256 consecutive rows from x R / 256
+    const int per = R / 256;
+    const int r_first = threadIdx.x * per;
+    int32_t mine = 0;
+    for (int u = 0; u < per; ++u) {
+        const int r = r_first + u;
+        if (r < nr) mine += lenNs[p0 + r] + cnt[r];
+    }
+    int32_t inc = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int32_t up = __shfl_up(inc, o);
+        if (lane >= o) inc += up;
+    }
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    int32_t run = inc - mine;
+    for (int q = 0; q < w; ++q) run += wsum[q];
+    const int64_t ubase = sN[p0] + t0;
+    for (int u = 0; u < per; ++u) {
+        const int r = r_first + u;
+        if (r < nr) {
+            const int32_t ln = lenNs[p0 + r], lt = cnt[r];
+            excl[r] = run;
+            cnt[r] = run + ln;
+            off[p0 + r] = ubase + run;
+            run += ln + lt;
+        }
+    }
+    if (b == nbins - 1 && threadIdx.x == 255) off[nloc] = ubase + run;
+    __syncthreads();
+    for (int64_t t = t0 + threadIdx.x; t < t1; t += 256) {
+        const Triplet tr = trip[t];
+        const int slot = atomicAdd(&cnt[int64_t(tr.row) - p0], 1);
+        U[ubase + slot] = UEntry{(tr.col << 1) | 1u, 0u, tr.val};
+    }
+    for (int r = w; r < nr; r += 4) {
+        int64_t at = ubase + excl[r];
+        for_kept_entries(perm[p0 + r], lane, MP, cand_k, cand_j, rowsrc, rlists, rcounts, rcap, rK, tablen,
+                         [&](bool keep, uint32_t j, double v) {
+                             int total;
+                             const int q = wave_prefix_count(keep, lane, total);
+                             if (keep) U[at + q] = UEntry{j << 1, 0u, v};
+                             at += total;
+                         });
+    }
+}
+
+__global__ __launch_bounds__(256) void scatter_i32_kernel(const int32_t* __restrict__ in, const int32_t* __restrict__ perm,
+                                                          const int64_t n, int32_t* __restrict__ out) {
+    const int64_t p = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (p < n) out[perm[p]] = in[p];
+}
+
 // ---- S5: per-row sort by column + merge of (K0, K0^T) pairs ---------------------------------------
 __device__ __forceinline__ double merge_values(double a, double b, int symm, double theta) {
     switch (symm) {
@@ -623,14 +817,17 @@ __global__ __launch_bounds__(256) void compact_kernel(const int64_t nloc, const 
                                                       const int32_t* __restrict__ outlen, const int64_t* __restrict__ indptr,
                                                       const uint32_t* __restrict__ Vkey, const double* __restrict__ Vval,
                                                       int32_t* __restrict__ indices, double* __restrict__ Kdata,
-                                                      double* __restrict__ degree, uint32_t* __restrict__ flags) {
+                                                      double* __restrict__ degree, uint32_t* __restrict__ flags,
+                                                      const int32_t* __restrict__ perm) {
+    // perm: the merged rows are in sorted order (bin path: merged row p is row perm[p] of K); nullptr: in row order
     const int lane = threadIdx.x & 63;
     const int w = threadIdx.x >> 6;
-    const int64_t i = int64_t(blockIdx.x) * 4 + w;
-    if (i >= nloc) return;
-    const int64_t s = off[i];
+    const int64_t p = int64_t(blockIdx.x) * 4 + w;
+    if (p >= nloc) return;
+    const int64_t i = perm ? int64_t(perm[p]) : p;
+    const int64_t s = off[p];
     const int64_t dst = indptr[i];
-    const int n = outlen[i];
+    const int n = outlen[p];
     double sum = 0.0;
     bool has_diag = false;
     for (int e = lane; e < n; e += 64) {
@@ -1137,7 +1334,9 @@ extern "C" int gt_graph_emit(gt_ctx* ctx, void* send_buf_dev) {
 
 static int finish_normalize(gt_ctx* ctx, GraphState* g, const double* degree_all_dev);
 
-extern "C" int gt_graph_finish(gt_ctx* ctx, const void* recv_buf_dev, int64_t n_recv, int64_t* out_nnz, uint32_t* flags) {
+// bins: single rank, every row local, cell-sorted order available - the transpose is built from the tables through
+// destination bins (see bin_count_kernel) and recv_buf_dev is not read
+static int graph_finish_impl(gt_ctx* ctx, const void* recv_buf_dev, int64_t n_recv, bool bins, int64_t* out_nnz, uint32_t* flags) {
     if (!ctx) return GT_E_ARG;
     GT_HIP(ctx, hipSetDevice(ctx->device));
     GraphState* g = ctx->graph;
@@ -1149,26 +1348,66 @@ extern "C" int gt_graph_finish(gt_ctx* ctx, const void* recv_buf_dev, int64_t n_
     {
         StageSpan span(ctx, "symmetrize");
         HostTrace tr_all(ctx, "finish: symmetrize");
-        GT_HIP(ctx, hipMemsetAsync(g->lenT.p, 0, size_t(nloc) * sizeof(int32_t), ctx->stream));
-        GT_HIP(ctx, g->cursor.reserve(size_t(std::max<int64_t>(n_recv, 1)) * sizeof(int32_t)));   // slot of every received triplet
-        if (n_recv > 0) {
-            int64_t blocks = std::min<int64_t>(ceil_div64(n_recv, 256), 16384);
-            hipLaunchKernelGGL(count_recv_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, recv, n_recv, g->r0,
-                               g->lenT.as<int32_t>(), g->cursor.as<int32_t>());
-        }
         GT_HIP(ctx, g->off.reserve(size_t(nloc + 1) * sizeof(int64_t)));
-        int rc = exclusive_scan(ctx, g->lenN.as<int32_t>(), g->lenT.as<int32_t>(), nloc, g->off.as<int64_t>(), g->scan_tmp);
+        int rc = GT_OK;
         int64_t total_u = 0;
-        if (rc == GT_OK) {
-            hipError_t e = hipMemcpyAsync(&total_u, g->off.as<int64_t>() + nloc, sizeof(int64_t), hipMemcpyDeviceToHost,
-                                          ctx->stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-            if (e != hipSuccess) {
-                ctx->set_error(std::string("scan: ") + hipGetErrorString(e));
-                rc = GT_E_HIP;
+        const int32_t* perm = bins ? k->qorder.as<int32_t>() : nullptr;
+        int shift = 9, nbins = 0;
+        if (bins) {
+            // rows per bin: 512, more only where the two histograms of an emitting workgroup would outgrow 32 KB of LDS
+            if (ctx->symm_bin_shift > 0) shift = ctx->symm_bin_shift;
+            while (ceil_div64(nloc, int64_t(1) << shift) > 4096) ++shift;
+            nbins = int(ceil_div64(nloc, int64_t(1) << shift));
+            StageSpan span_bins(ctx, "symm_bins");   // (nested in "symmetrize": its share, and the sign that this path ran)
+            GT_HIP(ctx, k->sh_invperm.reserve(size_t(nloc) * sizeof(int32_t)));
+            GT_TRY(gt_sym_invperm(ctx, perm, k->sh_invperm.as<int32_t>()));
+            // own entries in sorted order and their scan; triplets per bin and their scan
+            GT_HIP(ctx, g->cnt_sorted.reserve(size_t(nloc) * sizeof(int32_t)));
+            GT_HIP(ctx, g->pos_sorted.reserve(size_t(nloc + 1) * sizeof(int64_t)));
+            GT_HIP(ctx, g->bincnt.reserve(size_t(2 * nbins) * sizeof(int32_t)));
+            GT_HIP(ctx, g->binoff.reserve(size_t(nbins + 1) * sizeof(int64_t)));
+            GT_HIP(ctx, hipMemsetAsync(g->bincnt.p, 0, size_t(2 * nbins) * sizeof(int32_t), ctx->stream));
+            hipLaunchKernelGGL(gather_counts_kernel, dim3((unsigned)ceil_div64(nloc, 256)), dim3(256), 0, ctx->stream,
+                               g->lenN.as<int32_t>(), perm, nloc, g->cnt_sorted.as<int32_t>());
+            GT_TRY(exclusive_scan(ctx, g->cnt_sorted.as<int32_t>(), nullptr, nloc, g->pos_sorted.as<int64_t>(), g->scan_tmp));
+            hipLaunchKernelGGL(bin_count_kernel, dim3((unsigned)std::min<int64_t>(ceil_div64(nloc, 64), 2048)), dim3(256),
+                               size_t(nbins) * sizeof(int32_t), ctx->stream, nloc, k->MP, k->cand_d2.as<double>(),
+                               k->cand_j.as<uint32_t>(), g->rowsrc.as<int32_t>(), g->rlists.as<uint64_t>(),
+                               g->rcounts.as<uint32_t>(), g->rcap, g->rK.as<double>(), g->tablen.as<int32_t>(), perm,
+                               k->sh_invperm.as<int32_t>(), shift, nbins, g->bincnt.as<int32_t>());
+            GT_HIP(ctx, hipGetLastError());
+            rc = exclusive_scan(ctx, g->bincnt.as<int32_t>(), nullptr, nbins, g->binoff.as<int64_t>(), g->scan_tmp);
+            if (rc == GT_OK) {
+                hipError_t e = hipMemcpyAsync(&n_recv, g->binoff.as<int64_t>() + nbins, sizeof(int64_t), hipMemcpyDeviceToHost,
+                                              ctx->stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+                if (e != hipSuccess) {
+                    ctx->set_error(std::string("scan: ") + hipGetErrorString(e));
+                    rc = GT_E_HIP;
+                }
             }
+            GT_TRY(rc);
+            total_u = 2 * n_recv;   // every kept entry once in its own row, once in its column's
+        } else {
+            GT_HIP(ctx, hipMemsetAsync(g->lenT.p, 0, size_t(nloc) * sizeof(int32_t), ctx->stream));
+            GT_HIP(ctx, g->cursor.reserve(size_t(std::max<int64_t>(n_recv, 1)) * sizeof(int32_t)));   // slot of every received triplet
+            if (n_recv > 0) {
+                int64_t blocks = std::min<int64_t>(ceil_div64(n_recv, 256), 16384);
+                hipLaunchKernelGGL(count_recv_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, recv, n_recv, g->r0,
+                                   g->lenT.as<int32_t>(), g->cursor.as<int32_t>());
+            }
+            rc = exclusive_scan(ctx, g->lenN.as<int32_t>(), g->lenT.as<int32_t>(), nloc, g->off.as<int64_t>(), g->scan_tmp);
+            if (rc == GT_OK) {
+                hipError_t e = hipMemcpyAsync(&total_u, g->off.as<int64_t>() + nloc, sizeof(int64_t), hipMemcpyDeviceToHost,
+                                              ctx->stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+                if (e != hipSuccess) {
+                    ctx->set_error(std::string("scan: ") + hipGetErrorString(e));
+                    rc = GT_E_HIP;
+                }
+            }
+            GT_TRY(rc);
         }
-        GT_TRY(rc);
         g->nnz0 = total_u - n_recv;
         HostTrace tr_u(ctx, "finish: fill + merge");
         GT_HIP(ctx, g->Ukey.reserve(size_t(total_u) * sizeof(UEntry)));   // union rows
@@ -1179,14 +1418,33 @@ extern "C" int gt_graph_finish(gt_ctx* ctx, const void* recv_buf_dev, int64_t n_
         GT_HIP(ctx, g->hugerows.reserve(size_t(nloc) * sizeof(int32_t)));
         GT_HIP(ctx, g->bigcount.reserve(2 * sizeof(uint32_t)));   // [0] rows > kBigRow, [1] rows > kHugeRow
         GT_HIP(ctx, hipMemsetAsync(g->bigcount.p, 0, 2 * sizeof(uint32_t), ctx->stream));
-        hipLaunchKernelGGL(fill_rows_kernel, dim3((unsigned)ceil_div64(nloc, 4)), dim3(256), 0, ctx->stream, nloc, k->MP,
-                           k->cand_d2.as<double>(), k->cand_j.as<uint32_t>(), g->rowsrc.as<int32_t>(),
-                           g->rlists.as<uint64_t>(), g->rcounts.as<uint32_t>(), g->rcap, g->rK.as<double>(),
-                           g->off.as<int64_t>(), g->tablen.as<int32_t>(), g->Ukey.as<UEntry>());
-        if (n_recv > 0) {
-            int64_t blocks = std::min<int64_t>(ceil_div64(n_recv, 256), 16384);
-            hipLaunchKernelGGL(fill_recv_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, recv, n_recv, g->r0,
-                               g->off.as<int64_t>(), g->lenN.as<int32_t>(), g->cursor.as<int32_t>(), g->Ukey.as<UEntry>());
+        if (bins) {
+            GT_HIP(ctx, g->selfbuf.reserve(size_t(std::max<int64_t>(n_recv, 1)) * sizeof(Triplet)));
+            StageSpan span_bins(ctx, "symm_bins");
+            const size_t emit_lds = size_t(2 * nbins) * sizeof(int32_t);
+            hipLaunchKernelGGL(bin_emit_kernel, dim3((unsigned)ceil_div64(nloc, kEmitRows)), dim3(256), emit_lds, ctx->stream,
+                               nloc, k->MP, k->cand_d2.as<double>(), k->cand_j.as<uint32_t>(), g->rowsrc.as<int32_t>(),
+                               g->rlists.as<uint64_t>(), g->rcounts.as<uint32_t>(), g->rcap, g->rK.as<double>(),
+                               g->tablen.as<int32_t>(), perm, k->sh_invperm.as<int32_t>(), shift, nbins,
+                               g->binoff.as<int64_t>(), g->bincnt.as<int32_t>() + nbins, (Triplet*)g->selfbuf.p);
+            GT_HIP(ctx, hipGetLastError());
+            hipLaunchKernelGGL(bin_fill_kernel, dim3((unsigned)nbins), dim3(256), size_t(2) * (size_t(1) << shift) * sizeof(int32_t),
+                               ctx->stream, nloc, k->MP, k->cand_d2.as<double>(), k->cand_j.as<uint32_t>(),
+                               g->rowsrc.as<int32_t>(), g->rlists.as<uint64_t>(), g->rcounts.as<uint32_t>(), g->rcap,
+                               g->rK.as<double>(), g->tablen.as<int32_t>(), perm, shift, nbins, g->binoff.as<int64_t>(),
+                               (const Triplet*)g->selfbuf.p, g->cnt_sorted.as<int32_t>(), g->pos_sorted.as<int64_t>(),
+                               g->off.as<int64_t>(), g->Ukey.as<UEntry>());
+            GT_HIP(ctx, hipGetLastError());
+        } else {
+            hipLaunchKernelGGL(fill_rows_kernel, dim3((unsigned)ceil_div64(nloc, 4)), dim3(256), 0, ctx->stream, nloc, k->MP,
+                               k->cand_d2.as<double>(), k->cand_j.as<uint32_t>(), g->rowsrc.as<int32_t>(),
+                               g->rlists.as<uint64_t>(), g->rcounts.as<uint32_t>(), g->rcap, g->rK.as<double>(),
+                               g->off.as<int64_t>(), g->tablen.as<int32_t>(), g->Ukey.as<UEntry>());
+            if (n_recv > 0) {
+                int64_t blocks = std::min<int64_t>(ceil_div64(n_recv, 256), 16384);
+                hipLaunchKernelGGL(fill_recv_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, recv, n_recv, g->r0,
+                                   g->off.as<int64_t>(), g->lenN.as<int32_t>(), g->cursor.as<int32_t>(), g->Ukey.as<UEntry>());
+            }
         }
         hipLaunchKernelGGL(sort_merge_kernel, dim3((unsigned)ceil_div64(nloc, 4)), dim3(256), 0, ctx->stream, nloc,
                            g->off.as<int64_t>(), g->Ukey.as<UEntry>(), g->p.kernel_symm, g->p.theta,
@@ -1248,7 +1506,15 @@ extern "C" int gt_graph_finish(gt_ctx* ctx, const void* recv_buf_dev, int64_t n_
         }
         // ---- compact to CSR ----
         GT_HIP(ctx, g->indptr.reserve(size_t(nloc + 1) * sizeof(int64_t)));
-        rc = exclusive_scan(ctx, g->outlen.as<int32_t>(), nullptr, nloc, g->indptr.as<int64_t>(), g->scan_tmp);
+        const int32_t* outlen_rows = g->outlen.as<int32_t>();
+        if (bins) {
+            // merged lengths back in row order (lenT is free on this path)
+            hipLaunchKernelGGL(scatter_i32_kernel, dim3((unsigned)ceil_div64(nloc, 256)), dim3(256), 0, ctx->stream,
+                               g->outlen.as<int32_t>(), perm, nloc, g->lenT.as<int32_t>());
+            GT_HIP(ctx, hipGetLastError());
+            outlen_rows = g->lenT.as<int32_t>();
+        }
+        rc = exclusive_scan(ctx, outlen_rows, nullptr, nloc, g->indptr.as<int64_t>(), g->scan_tmp);
         int64_t nnz = 0;
         if (rc == GT_OK) {
             hipError_t e = hipMemcpyAsync(&nnz, g->indptr.as<int64_t>() + nloc, sizeof(int64_t), hipMemcpyDeviceToHost,
@@ -1268,7 +1534,7 @@ extern "C" int gt_graph_finish(gt_ctx* ctx, const void* recv_buf_dev, int64_t n_
         hipLaunchKernelGGL(compact_kernel, dim3((unsigned)ceil_div64(nloc, 4)), dim3(256), 0, ctx->stream, nloc, g->r0,
                            g->off.as<int64_t>(), g->outlen.as<int32_t>(), g->indptr.as<int64_t>(), g->Vkey.as<uint32_t>(),
                            g->Vval.as<double>(), g->indices.as<int32_t>(), g->Kdata.as<double>(), g->degree.as<double>(),
-                           g->flags.as<uint32_t>());
+                           g->flags.as<uint32_t>(), perm);
         GT_HIP(ctx, hipGetLastError());
     }
     g->finished = true;
@@ -1289,6 +1555,10 @@ extern "C" int gt_graph_finish(gt_ctx* ctx, const void* recv_buf_dev, int64_t n_
     if (out_nnz) *out_nnz = g->nnz;
     if (flags) *flags = fl;
     return GT_OK;
+}
+
+extern "C" int gt_graph_finish(gt_ctx* ctx, const void* recv_buf_dev, int64_t n_recv, int64_t* out_nnz, uint32_t* flags) {
+    return graph_finish_impl(ctx, recv_buf_dev, n_recv, false, out_nnz, flags);
 }
 
 static int finish_normalize(gt_ctx* ctx, GraphState* g, const double* degree_all_dev) {
@@ -1334,6 +1604,13 @@ extern "C" int gt_graph_build(gt_ctx* ctx, const gt_knn_params* params, int64_t*
     int64_t sendc[1] = {0};
     GT_TRY(gt_graph_begin(ctx, params, 1, 0, splits, sendc));
     GraphState* g = ctx->graph;
+    KnnWork* k = ctx->knn;
+    // every row is here: with the cell-sorted order of the points at hand the transpose is built through destination
+    // bins instead of the triplet exchange (option symmetrize_bins: -1 auto, 0 off, 1 on where possible)
+    const bool bins = ctx->symm_bins != 0 && sendc[0] > 0 && k->ordered && k->nq == g->nloc && g->r0 == 0 && !g->external &&
+                      g->nloc < (int64_t(1) << 31) && (ctx->symm_bins > 0 || g->nloc >= 65536);
+    g->bins_used = bins;
+    if (bins) return graph_finish_impl(ctx, nullptr, 0, true, out_nnz, flags);
     if (sendc[0] > 0) {
         GT_HIP(ctx, g->selfbuf.reserve(size_t(sendc[0]) * sizeof(Triplet)));
         GT_TRY(gt_graph_emit(ctx, g->selfbuf.p));

@@ -402,8 +402,9 @@ __global__ __launch_bounds__(256) void sym_radius_sum_kernel(const int64_t n, co
 //   * orphan_far x (rows launch A kept for it from the strided sample, not from the cells around it) >= need_m: its
 //     cell says little about where its neighbours are, D_K is loose;
 //   * a radius far beyond the typical one (cut x the mean over all rows) that is no longer small against the typical
-//     distance between two unrelated points (1/16 of it: the 16-feature partial distances of stage one are a quarter of
-//     the full ones on isotropic data): launch A found it SOME need_m rows nearby, none of its real neighbours.
+//     distance between two unrelated points (pair_frac of it: 1/16 when stage one sees 16 coordinates - a quarter of
+//     every distance on isotropic data -, 1/4 in the principal frame): launch A found it SOME need_m rows nearby, none
+//     of its real neighbours.
 // They collect nothing (+inf), keep the rows launch A found (sym_inject_orphans_kernel) and go to the repair pass, which
 // starts from those rows' exact distances.  acc = the statistics of sym_radius_sum_kernel over ALL rows.
 __global__ __launch_bounds__(256) void sym_orphan_cut_kernel(const int64_t n, const int32_t* __restrict__ perm,
@@ -411,7 +412,8 @@ __global__ __launch_bounds__(256) void sym_orphan_cut_kernel(const int64_t n, co
                                                              const float* __restrict__ farcnt,
                                                              const double* __restrict__ ymax2p, const ErrModel err,
                                                              const double* __restrict__ acc, const double cut,
-                                                             const int orphan_far, const int need_m) {
+                                                             const int orphan_far, const int need_m,
+                                                             const double pair_frac) {
     const int64_t p = int64_t(blockIdx.x) * 256 + threadIdx.x;
     if (p >= n) return;
     const float t = thr[p];
@@ -420,7 +422,7 @@ __global__ __launch_bounds__(256) void sym_orphan_cut_kernel(const int64_t n, co
     if (!orphan && cut > 0.0 && acc[1] > 0.0) {
         const double lb = sym_row_lb(t, xn[perm[p]], ymax2p[0], err);
         const double typical_pair = acc[3] > 0.0 ? acc[2] / acc[3] : 0.0;
-        orphan = lb > cut * (acc[0] / acc[1]) && lb > typical_pair / 16.0;
+        orphan = lb > cut * (acc[0] / acc[1]) && lb > typical_pair * pair_frac;
     }
     if (orphan) thr[p] = INFINITY;
 }
@@ -443,31 +445,89 @@ __global__ __launch_bounds__(256) void sym_inject_orphans_kernel(const int64_t n
         if (base + c < uint32_t(tcap)) tlists[size_t(p) * size_t(tcap) + base + c] = lists[size_t(p) * lstride + c];
 }
 
-// ---- two-stage scoring of launch B (partial distances) -----------------------------------------------------------
-// hh[p] = -1/2 sum_{k < HD} yc_k^2 over the first HD features of the sorted compact row p (float32, the float16 values
-// as they enter the MFMA): seeded with it, the first HD/16 k-steps of the chain give, for query row x,
-//     A = x_h.y_h - |y_h|^2/2 = |x_h|^2/2 - |x_h - y_h|^2/2        (x_h, y_h: the scaled float16 rows cut at HD)
-// i.e. the PARTIAL squared distance of the pair, which never exceeds the full one.
-__global__ __launch_bounds__(256) void sym_half_seeds_kernel(const _Float16* __restrict__ Ys, const int64_t n,
-                                                             const int64_t n_pad, const int DP, const int HD,
-                                                             float* __restrict__ hh) {
-    const int64_t p = int64_t(blockIdx.x) * 256 + threadIdx.x;
-    if (p >= n_pad) return;
-    if (p >= n) {
-        hh[p] = -INFINITY;
-        return;
-    }
-    typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-    const half8* r = reinterpret_cast<const half8*>(Ys + size_t(p) * DP);
-    float acc = 0.f;
-    for (int c = 0; c < HD / 8; ++c) {
-        const half8 v = r[c];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) acc = fmaf(float(v[e]), float(v[e]), acc);
-    }
-    hh[p] = -0.5f * acc;
+// ---- stage-one subspace of the two-stage collect -------------------------------------------------------------------
+// Partial distances work in ANY orthonormal frame: |P (x - y)| <= |x - y| for P with orthonormal rows.  The frame that
+// keeps the most of every distance is the one of the leading principal directions, so stage one scores a separate
+// 16-column copy Z = P x of the points (cell-sorted like the full copy), P = the 16 leading eigenvectors of the
+// covariance of a row sample.  (On data whose features all weigh the same - the benchmark mixture - this is no better
+// than any 16 features; on data with a spectrum - PCA-reduced input, manifolds - it is the difference between a filter
+// and none.)  The full scores of the cold pass, the thresholds and every exact stage keep the original coordinates.
+constexpr int kZ = 16;   // columns of the stage-one copy (one MFMA k-step)
+
+// column sums of the sampled rows (every `step`-th row) -> sums[d] (pre-zeroed)
+template <typename T>
+__global__ __launch_bounds__(256) void sample_colsum_kernel(const T* __restrict__ X, const int64_t n, const int d,
+                                                            const int64_t step, const int64_t ns, double* __restrict__ sums) {
+    const int c = threadIdx.x % 64, g = threadIdx.x / 64;
+    if (c >= d) return;
+    double acc = 0.0;
+    for (int64_t s = int64_t(blockIdx.x) * 4 + g; s < ns; s += int64_t(gridDim.x) * 4) acc += double(X[(s * step) * d + c]);
+    atomicAdd(sums + c, acc);
 }
 
+// covariance of the sampled rows about `mean`: C[a][b] += sum (x_a - m_a)(x_b - m_b)   (C pre-zeroed, d <= 64)
+template <typename T>
+__global__ __launch_bounds__(256) void sample_cov_kernel(const T* __restrict__ X, const int64_t n, const int d,
+                                                         const int64_t step, const int64_t ns,
+                                                         const double* __restrict__ sums, double* __restrict__ C) {
+    __shared__ float tile[64][65];
+    const int64_t s0 = int64_t(blockIdx.x) * 64;
+    for (int f = threadIdx.x; f < 64 * 64; f += 256) {
+        const int r = f / 64, c = f % 64;
+        const int64_t s = s0 + r;
+        tile[r][c] = (s < ns && c < d) ? float(double(X[(s * step) * d + c]) - sums[c] / double(ns)) : 0.f;
+    }
+    __syncthreads();
+    // thread t owns the 16 entries (a, b) with a = t / 4, b = 16 (t % 4) ... + 15
+    const int a = threadIdx.x / 4, b0 = 16 * (threadIdx.x % 4);
+    float acc[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    for (int r = 0; r < 64; ++r) {
+        const float xa = tile[r][a];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = fmaf(xa, tile[r][b0 + e], acc[e]);
+    }
+    if (a < d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+            if (b0 + e < d) atomicAdd(C + a * 64 + b0 + e, double(acc[e]));
+}
+
+// Z[p] = float16(scz * P x_perm[p]) (kZ columns), hh[p] = -|Z[p]|^2 / 2 in float32; pad rows: zeros / -inf.
+// 16 lanes per row: lane k forms column k; the row's features reach every lane through shuffles.
+template <typename T>
+__global__ __launch_bounds__(256) void sym_project_kernel(const T* __restrict__ X, const int32_t* __restrict__ perm,
+                                                          const int64_t n, const int64_t n_pad, const int d,
+                                                          const float* __restrict__ P, const float scz,
+                                                          _Float16* __restrict__ Z, float* __restrict__ hh) {
+    __shared__ float Ps[kZ * 64];
+    for (int f = threadIdx.x; f < kZ * 64; f += 256) Ps[f] = (f % 64) < d ? P[(f / 64) * 64 + (f % 64)] : 0.f;
+    __syncthreads();
+    const int k = threadIdx.x & 15;
+    const int64_t p = int64_t(blockIdx.x) * 16 + (threadIdx.x >> 4);
+    if (p >= n_pad) return;
+    float z = 0.f;
+    if (p < n) {
+        const T* x = X + int64_t(perm[p]) * d;
+        float xr[4];   // features k, k + 16, k + 32, k + 48 of the row
+#pragma unroll
+        for (int u = 0; u < 4; ++u) xr[u] = (k + 16 * u < d) ? float(x[k + 16 * u]) : 0.f;
+        float acc = 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            for (int src = 0; src < 16; ++src) acc = fmaf(Ps[k * 64 + 16 * u + src], __shfl(xr[u], src, 16), acc);
+        z = acc * scz;
+    }
+    const _Float16 zh = _Float16(z);
+    Z[size_t(p) * kZ + k] = zh;
+    float sq = float(zh) * float(zh);
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 16);
+    if (k == 0) hh[p] = p < n ? -0.5f * sq : -INFINITY;
+}
+
+// ---- two-stage scoring of launch B (partial distances) -----------------------------------------------------------
 // Thresholds of the partial test from the full thresholds thr[p] (sorted positions).  The re-rank will claim for row p
 // "every row closer than lb_p is in the list", lb_p = |x|^2 - 2 (thr_p / sc^2 + e) - 1e-9 (...) (rerank_sym_kernel,
 // bound_of_score) - so stage one must let through every pair with |x - y|^2 < lb_p, seen from either side.  Such a pair
@@ -482,8 +542,8 @@ __global__ __launch_bounds__(256) void sym_half_thresholds_kernel(const int64_t 
                                                                   const float* __restrict__ thr,
                                                                   const float* __restrict__ hh,
                                                                   const double* __restrict__ ymax2p, const ErrModel err,
-                                                                  const int HD, float* __restrict__ thrh,
-                                                                  float* __restrict__ gh) {
+                                                                  const int HD, const double scz, const double Lz,
+                                                                  float* __restrict__ thrh, float* __restrict__ gh) {
     const int64_t p = int64_t(blockIdx.x) * 256 + threadIdx.x;
     if (p >= n_pad) return;
     float th = INFINITY, g = INFINITY;
@@ -500,8 +560,9 @@ __global__ __launch_bounds__(256) void sym_half_thresholds_kernel(const int64_t 
             const double e = gt_err_bound(err, qs, y2);
             double lb = (qs - 2.0 * (double(t) * err.inv_sc2 + e)) - 1e-9 * (qs + y2);
             lb = (lb > 0.0 ? lb : 0.0) * (1.0 + 1e-6) + 1e-9 * (qs + y2);
-            const double sc = 1.0 / sqrt(err.inv_sc2);
-            const double Ls = sc * err.abs;                       // (err.abs = 1.001 x the largest residual norm)
+            // scz: scale of the stage-one copy (its rows are scz x an orthonormal projection of the points, up to 1e-6),
+            // Lz: largest rounding residual of one of its rows
+            const double sc = scz * (1.0 + 1e-6), Ls = Lz;
             const double X2 = (sc * sqrt(y2) + Ls) * (sc * sqrt(y2) + Ls);
             const double dmax = (2.0 * double(HD + 8) * 1.5 + 4.0) * u * X2;
             const double r = sc * sqrt(lb) + 2.0 * Ls;
@@ -720,10 +781,10 @@ int gt_sym_radius_sum(gt_ctx* ctx, const int32_t* perm, int64_t p_first, int64_t
 }
 
 int gt_sym_orphan_cut(gt_ctx* ctx, const int32_t* perm, float* thr, const float* farcnt, const ErrModel& err, const double* acc,
-                      int need_m) {
+                      int need_m, double pair_frac) {
     hipLaunchKernelGGL(sym_orphan_cut_kernel, dim3((unsigned)ceil_div64(ctx->n, 256)), dim3(256), 0, ctx->stream, ctx->n, perm,
                        ctx->xn.as<double>(), thr, farcnt, ctx->ymax.as<double>(), err, acc, ctx->sym_radius_cut,
-                       ctx->sym_orphan_far, need_m);
+                       ctx->sym_orphan_far, need_m, pair_frac);
     GT_HIP(ctx, hipGetLastError());
     return GT_OK;
 }
@@ -747,17 +808,43 @@ int gt_sym_g_from_thr(gt_ctx* ctx, int64_t n_pad_s, const float* thr, const floa
     return GT_OK;
 }
 
-int gt_sym_half_seeds(gt_ctx* ctx, const void* Ys, int64_t n_pad_s, int hd, float* hh) {
-    hipLaunchKernelGGL(sym_half_seeds_kernel, dim3((unsigned)ceil_div64(n_pad_s, 256)), dim3(256), 0, ctx->stream,
-                       reinterpret_cast<const _Float16*>(Ys), ctx->n, n_pad_s, ctx->DP, hd, hh);
+// Stage-one copy of the points (see "stage-one subspace" above): P_host [16][64] float (rows orthonormal), scale scz
+int gt_sym_project(gt_ctx* ctx, const int32_t* perm, int64_t n_pad_s, const float* P_dev, double scz, void* Z, float* hh) {
+    const dim3 grid((unsigned)ceil_div64(n_pad_s, 16));
+    if (ctx->dtype == GT_F32)
+        hipLaunchKernelGGL(sym_project_kernel<float>, grid, dim3(256), 0, ctx->stream, (const float*)ctx->X, perm, ctx->n, n_pad_s,
+                           ctx->d, P_dev, float(scz), reinterpret_cast<_Float16*>(Z), hh);
+    else
+        hipLaunchKernelGGL(sym_project_kernel<double>, grid, dim3(256), 0, ctx->stream, (const double*)ctx->X, perm, ctx->n,
+                           n_pad_s, ctx->d, P_dev, float(scz), reinterpret_cast<_Float16*>(Z), hh);
+    GT_HIP(ctx, hipGetLastError());
+    return GT_OK;
+}
+
+// covariance (about the sample mean) of every step-th row: C_dev [64][64] doubles, sums_dev [64] (both pre-zeroed here)
+int gt_sym_sample_cov(gt_ctx* ctx, int64_t step, int64_t ns, double* sums_dev, double* C_dev) {
+    if (ctx->d > 64) GT_FAIL(ctx, GT_E_ARG, "sample covariance: at most 64 features");
+    GT_HIP(ctx, hipMemsetAsync(sums_dev, 0, 64 * sizeof(double), ctx->stream));
+    GT_HIP(ctx, hipMemsetAsync(C_dev, 0, 64 * 64 * sizeof(double), ctx->stream));
+    if (ctx->dtype == GT_F32) {
+        hipLaunchKernelGGL(sample_colsum_kernel<float>, dim3(64), dim3(256), 0, ctx->stream, (const float*)ctx->X, ctx->n, ctx->d,
+                           step, ns, sums_dev);
+        hipLaunchKernelGGL(sample_cov_kernel<float>, dim3((unsigned)ceil_div64(ns, 64)), dim3(256), 0, ctx->stream,
+                           (const float*)ctx->X, ctx->n, ctx->d, step, ns, sums_dev, C_dev);
+    } else {
+        hipLaunchKernelGGL(sample_colsum_kernel<double>, dim3(64), dim3(256), 0, ctx->stream, (const double*)ctx->X, ctx->n,
+                           ctx->d, step, ns, sums_dev);
+        hipLaunchKernelGGL(sample_cov_kernel<double>, dim3((unsigned)ceil_div64(ns, 64)), dim3(256), 0, ctx->stream,
+                           (const double*)ctx->X, ctx->n, ctx->d, step, ns, sums_dev, C_dev);
+    }
     GT_HIP(ctx, hipGetLastError());
     return GT_OK;
 }
 
 int gt_sym_half_thresholds(gt_ctx* ctx, const int32_t* perm, int64_t n_pad_s, const float* thr, const float* hh,
-                           const ErrModel& err, int hd, float* thrh, float* gh, float* gminh) {
+                           const ErrModel& err, int hd, double scz, double Lz, float* thrh, float* gh, float* gminh) {
     hipLaunchKernelGGL(sym_half_thresholds_kernel, dim3((unsigned)ceil_div64(n_pad_s, 256)), dim3(256), 0, ctx->stream, ctx->n,
-                       n_pad_s, perm, ctx->xn.as<double>(), thr, hh, ctx->ymax.as<double>(), err, hd, thrh, gh);
+                       n_pad_s, perm, ctx->xn.as<double>(), thr, hh, ctx->ymax.as<double>(), err, hd, scz, Lz, thrh, gh);
     GT_HIP(ctx, hipGetLastError());
     hipLaunchKernelGGL(sym_gmin_kernel, dim3((unsigned)ceil_div64(n_pad_s, 256)), dim3(256), 0, ctx->stream, n_pad_s, gh, gminh);
     GT_HIP(ctx, hipGetLastError());
@@ -766,10 +853,10 @@ int gt_sym_half_thresholds(gt_ctx* ctx, const int32_t* perm, int64_t n_pad_s, co
 
 int gt_sym_two_probe(gt_ctx* ctx, const void* Ys, int hd, const float* hh, const float* thrh, const float* gh, int64_t samples,
                      uint32_t* flagged) {
-    if (ctx->n < 64 || hd > 32) GT_FAIL(ctx, GT_E_ARG, "sym probe: bad shape");
+    if (ctx->n < 64 || hd > kZ) GT_FAIL(ctx, GT_E_ARG, "sym probe: bad shape");   // Ys: the stage-one copy, kZ columns
     GT_HIP(ctx, hipMemsetAsync(flagged, 0, sizeof(uint32_t), ctx->stream));
     hipLaunchKernelGGL(sym_two_probe_kernel, dim3((unsigned)ceil_div64(samples, 4)), dim3(256), 0, ctx->stream,
-                       reinterpret_cast<const _Float16*>(Ys), ctx->n, ctx->DP, hd, hh, thrh, gh, samples, flagged);
+                       reinterpret_cast<const _Float16*>(Ys), ctx->n, kZ, hd, hh, thrh, gh, samples, flagged);
     GT_HIP(ctx, hipGetLastError());
     return GT_OK;
 }

@@ -1,0 +1,112 @@
+"""GPU: single-rank symmetrisation through destination bins (gt_sparse.hip bin_count / bin_emit / bin_fill) against the
+oracle and against the triplet-exchange path it replaces.  The bin path engages by itself from 65536 rows when the
+cell-sorted order of the points exists; here it is forced on small point sets (`symmetrize_bins=1`,
+`query_order_min_rows=1`).  Bar: K and P identical to the exchange path bit for bit, CSR structure identical to the
+oracle's, values within 1e-5 relative."""
+import numpy as np
+import pytest
+from scipy import sparse
+
+import oracle
+from conftest import make_gauss, make_manifold, make_mix
+
+pytestmark = pytest.mark.gpu
+
+
+def _build(X, bins, knn=15, decay=40.0, thresh=1e-4, bandwidth=None, symm="+", theta=None, aniso=0, opts=()):
+    from graphtools_amd import _hip
+
+    c = _hip.Context(0)
+    c.set_option("query_order_min_rows", "1")
+    c.set_option("symmetrize_bins", str(bins))
+    for k, v in opts:
+        c.set_option(k, str(v))
+    c.set_points(X)
+    p, keep = c.make_params(knn, decay, thresh, bandwidth, 1.0, None, symm, theta, aniso)
+    c.graph_build(p)
+    ran = c.stage_ms("symm_bins") >= 0
+    K = c.graph_fetch_csr(_hip.CSR_K)
+    P = c.graph_fetch_csr(_hip.CSR_P)[0]
+    st = c.graph_stats()
+    c.close()
+    return K, P, ran, st
+
+
+def _same(a, b):
+    (Kd, Ki, Kp), P = a[0], a[1]
+    (Ld, Li, Lp), Q = b[0], b[1]
+    assert np.array_equal(Kp, Lp) and np.array_equal(Ki, Li)
+    assert np.array_equal(Kd, Ld) and np.array_equal(P, Q)
+
+
+@pytest.mark.parametrize("n,d,maker,seed,kw", [
+    (5003, 64, make_mix, 0, {}),                                        # ragged last bin
+    (300, 10, make_gauss, 1, {"knn": 7}),                               # fewer rows than one bin
+    (512, 16, make_mix, 2, {"knn": 5, "decay": 10.0}),                  # exactly one bin
+    (4100, 33, make_mix, 3, {"symm": "*"}),
+    (4100, 33, make_mix, 3, {"symm": "mnn", "theta": 0.3}),
+    (3000, 20, make_manifold, 4, {"aniso": 1.0}),
+    (2600, 50, make_mix, 5, {"decay": None, "knn": 9}),                 # binary kernel
+])
+def test_bin_path_equals_the_exchange_path_and_the_oracle(n, d, maker, seed, kw):
+    X = maker(n, d, seed)
+    b = _build(X, 1, **kw)
+    e = _build(X, 0, **kw)
+    assert b[2] and not e[2]
+    _same(b, e)
+    Ko, Po = oracle.knn_graph(X, knn=kw.get("knn", 15), decay=kw.get("decay", 40.0), kernel_symm=kw.get("symm", "+"),
+                              theta=kw.get("theta"), anisotropy=kw.get("aniso", 0))
+    Ko = sparse.csr_matrix(Ko)
+    Ko.sort_indices()
+    if kw.get("symm") == "*":
+        Ko.eliminate_zeros()
+    (Kd, Ki, Kp) = b[0]
+    assert np.array_equal(Kp, Ko.indptr) and np.array_equal(Ki, Ko.indices)
+    np.testing.assert_allclose(Kd, Ko.data, rtol=2e-5 if kw.get("symm") == "*" else 1e-5, atol=0)
+
+
+def test_bin_path_with_rows_from_the_radius_pass_and_long_union_rows():
+    """wide kernel: every row comes from the radius lists, union rows of > 512 and > 2048 entries (register sorts of 16 /
+    32 keys per lane, global-memory sort)"""
+    X = make_gauss(3000, 12, 13)
+    kw = dict(knn=5, decay=2, bandwidth=2.5)
+    b = _build(X, 1, **kw)
+    e = _build(X, 0, **kw)
+    assert b[2] and not e[2]
+    assert b[3]["radius_rows"] == 3000
+    assert len(b[0][0]) / 3000 > 600
+    _same(b, e)
+
+
+def test_bin_path_with_a_hub_row():
+    """one point in the middle of everything: its union row receives a triplet from most rows (one bin holds a long run)"""
+    rng = np.random.default_rng(5)
+    X = rng.standard_normal((6000, 24)).astype(np.float32)
+    X /= np.linalg.norm(X, axis=1, keepdims=True)     # points on a sphere, the centre is everybody's neighbour
+    X[1234] = 0
+    b = _build(X, 1, knn=10, decay=20.0)
+    e = _build(X, 0, knn=10, decay=20.0)
+    assert b[2]
+    deg = np.diff(b[0][2])
+    assert deg[1234] > 3000
+    _same(b, e)
+
+
+@pytest.mark.parametrize("shift", [8, 11])
+def test_bin_path_with_other_bin_sizes(shift):
+    """256-row bins (one row per thread in the scan) and 2048-row bins (what point sets beyond 4 M rows get)"""
+    X = make_mix(5003, 40, 7)
+    b = _build(X, 1, opts=(("symmetrize_bin_shift", shift),))
+    e = _build(X, 0)
+    assert b[2]
+    _same(b, e)
+
+
+def test_bin_path_engages_by_itself_and_is_deterministic():
+    X = make_mix(150000, 64, 12)
+    a = _build(X, -1)
+    b = _build(X, -1)
+    e = _build(X, 0)
+    assert a[2] and b[2] and not e[2]
+    _same(a, b)
+    _same(a, e)

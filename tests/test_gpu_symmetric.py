@@ -181,10 +181,15 @@ def test_two_stage_forecast_declines_where_partial_distances_do_not_separate():
     _same_csr(auto, classic)
 
 
-def test_two_stage_queue_overflow_starts_over_with_the_one_stage_kernel():
+def test_two_stage_queue_spills_and_its_overflow_starts_over_with_the_one_stage_kernel():
+    """wave regions of two entries: nearly everything goes through the shared spill area; with that cut to 16 entries the
+    launch drops pairs, says so, and the one-stage kernel runs instead"""
     X = make_mix(70000, 64, 14)
-    small, st, _ = _build(X, {"select_sym_two_stage": 1, "select_sym_queue_cap": 2})
     ref, _, _ = _build(X, {"select_symmetric": 0})
+    spilled, st, _ = _build(X, {"select_sym_two_stage": 1, "select_sym_queue_cap": 2})
+    assert st["symmetric"] and st["sym_two_stage"] and st["sym_cold_pairs"] > 0
+    _same_csr(spilled, ref)
+    small, st, _ = _build(X, {"select_sym_two_stage": 1, "select_sym_queue_cap": 2, "select_sym_spill_cap": 16})
     assert st["symmetric"] and not st["sym_two_stage"]
     _same_csr(small, ref)
 
