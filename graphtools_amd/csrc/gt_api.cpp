@@ -293,6 +293,10 @@ int gt_set_option(gt_ctx* ctx, const char* name, const char* value) {
         ctx->symm_bins = v == "auto" ? -1 : std::atoi(value);
         return GT_OK;
     }
+    if (k == "symmetrize_key32") {
+        ctx->symm_key32 = std::atoi(value);
+        return GT_OK;
+    }
     if (k == "symmetrize_bin_shift") {
         const int sh = std::atoi(value);
         if (sh != 0 && (sh < 8 || sh > 12)) return GT_E_ARG;

@@ -152,6 +152,7 @@ struct gt_ctx {
     double sym_radius_cut = 4.0; //  rows whose completeness radius (squared) exceeds this many times the mean are repaired directly
     int32_t sym_two_stage = -1; //   launch B scores half the features first (partial distances): -1 auto, 0 off, 1 on
     int32_t symm_bins = -1;     // single-rank symmetrisation through destination bins (gt_sparse.hip): -1 auto, 0 off, 1 on
+    int32_t symm_key32 = 1;     //   per-row sorts of the symmetrisation on 32-bit keys where columns and positions fit (0: 64-bit keys)
     int32_t symm_bin_shift = 0; //   log2 of the rows per bin (0: 9, more from 2 M rows; development / tests: 8 ... 12)
     int32_t sym_pca = 1;        //   stage one scores the 16 leading principal directions (0: the first 16 features)
     int32_t sym_queue_cap = 0;  //   entries per wave region of the two-stage queue (0: sized from the problem; development / tests)

@@ -38,8 +38,9 @@ __device__ __forceinline__ uint64_t ld_agent_u64(const uint64_t* p) {
 }
 
 // ---- wave-level bitonic sort, descending, NT keys per lane; element e = t*64 + lane -----------
-template <int NT>
-__device__ __forceinline__ void wave_bitonic_desc(uint64_t (&key)[NT], const int lane) {
+// (32-bit keys: one shuffle, v_max_u32 / v_min_u32 and a select per step - half the work of a 64-bit key)
+template <int NT, typename K>
+__device__ __forceinline__ void wave_bitonic_desc(K (&key)[NT], const int lane) {
 #pragma unroll
     for (int k = 2; k <= 64 * NT; k <<= 1) {
 #pragma unroll
@@ -51,8 +52,8 @@ __device__ __forceinline__ void wave_bitonic_desc(uint64_t (&key)[NT], const int
                     if ((t & jj) == 0) {
                         const int u = t | jj;
                         const bool desc = (((t << 6) & k) == 0);
-                        const uint64_t a = key[t], b = key[u];
-                        const uint64_t mx = a > b ? a : b, mn = a > b ? b : a;
+                        const K a = key[t], b = key[u];
+                        const K mx = a > b ? a : b, mn = a > b ? b : a;
                         key[t] = desc ? mx : mn;
                         key[u] = desc ? mn : mx;
                     }
@@ -60,13 +61,15 @@ __device__ __forceinline__ void wave_bitonic_desc(uint64_t (&key)[NT], const int
             } else {
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
-                    const uint64_t a = key[t];
-                    const uint64_t o = __shfl_xor((unsigned long long)a, j);
+                    const K a = key[t];
+                    K o;
+                    if constexpr (sizeof(K) == 8) o = K(__shfl_xor((unsigned long long)a, j));
+                    else o = K(__shfl_xor((unsigned int)a, j));
                     const int e = (t << 6) | lane;
                     const bool desc = ((e & k) == 0);
                     const bool lower = ((lane & j) == 0);
                     const bool want_max = (lower == desc);
-                    const uint64_t mx = a > o ? a : o, mn = a > o ? o : a;
+                    const K mx = a > o ? a : o, mn = a > o ? o : a;
                     key[t] = want_max ? mx : mn;
                 }
             }

@@ -143,6 +143,7 @@ __global__ __launch_bounds__(256) void affinity_kernel(
     if (src < 0) {
         uint32_t n = cand_n[i];
         if (n > uint32_t(limit)) n = uint32_t(limit);
+        uint32_t last = 0;
         for (uint32_t e0 = 0; e0 < n; e0 += 64) {
             const uint32_t e = e0 + lane;
             bool keep = false;
@@ -155,7 +156,9 @@ __global__ __launch_bounds__(256) void affinity_kernel(
                 keep = binary || (kv >= thresh);
                 cand_d2[i * MP + e] = keep ? kv : -1.0;
             }
-            kept += __popcll(__ballot(keep));
+            const unsigned long long km = __ballot(keep);
+            kept += __popcll(km);
+            if (km != 0ull) last = e0 + 64u - uint32_t(__clzll((long long)km));
             if (count_owners) {
                 const int o = keep ? owner_of(sp, j) : -1;
                 for (int r = 0; r < sp.world; ++r) {
@@ -164,7 +167,9 @@ __global__ __launch_bounds__(256) void affinity_kernel(
                 }
             }
         }
-        if (lane == 0) tablen[i] = int32_t(n);   // the consumers stop here: slots beyond the eligible range are not theirs
+        // the consumers stop behind the last kept entry (the table is sorted by distance: the kept entries are a prefix,
+        // the passes over the rows read nothing else; slots beyond the eligible range are not theirs either way)
+        if (lane == 0) tablen[i] = int32_t(last);
     } else {
         const T* xrow = Qm + (qoff + i) * int64_t(d);
         for (int k = lane; k < d; k += 64) xs[k] = double(xrow[k]);
@@ -598,33 +603,34 @@ __device__ __forceinline__ double merge_values(double a, double b, int symm, dou
 }
 
 // merge a sorted key/value sequence held in registers (position p = t*64 + lane); returns the number of
-// merged entries written to (Vk, Vv).
+// merged entries written to (Vk, Vv).  Keys: (column << 1) | tag, kNoKey where there is no entry (columns are below
+// 2^31 - 1, so no key looks like it).
+constexpr uint32_t kNoKey = 0xFFFFFFFFu;
 template <int NT>
-__device__ __forceinline__ int merge_sorted_regs(const uint64_t (&hi)[NT], const uint64_t (&lo)[NT], const int lane,
+__device__ __forceinline__ int merge_sorted_regs(const uint32_t (&hi)[NT], const uint64_t (&lo)[NT], const int lane,
                                                  const int symm, const double theta, uint32_t* __restrict__ Vk,
                                                  double* __restrict__ Vv) {
-    constexpr uint64_t SENT = ~0ull;
     int count = 0;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        const uint64_t key = hi[t];
+        const uint32_t key = hi[t];
         const uint64_t val = lo[t];
-        uint64_t pk = __shfl_up((unsigned long long)key, 1);
-        const uint64_t pk_edge = (t > 0) ? __shfl((unsigned long long)hi[t > 0 ? t - 1 : 0], 63) : SENT;
+        uint32_t pk = __shfl_up(key, 1);
+        const uint32_t pk_edge = (t > 0) ? __shfl(hi[t > 0 ? t - 1 : 0], 63) : kNoKey;
         if (lane == 0) pk = pk_edge;
-        uint64_t nk = __shfl_down((unsigned long long)key, 1);
+        uint32_t nk = __shfl_down(key, 1);
         uint64_t nv = __shfl_down((unsigned long long)val, 1);
-        const uint64_t nk_edge = (t < NT - 1) ? __shfl((unsigned long long)hi[t < NT - 1 ? t + 1 : t], 0) : SENT;
+        const uint32_t nk_edge = (t < NT - 1) ? __shfl(hi[t < NT - 1 ? t + 1 : t], 0) : kNoKey;
         const uint64_t nv_edge = (t < NT - 1) ? __shfl((unsigned long long)lo[t < NT - 1 ? t + 1 : t], 0) : 0ull;
         if (lane == 63) {
             nk = nk_edge;
             nv = nv_edge;
         }
-        const bool valid = key != SENT;
-        const uint64_t col = key >> 1;
-        const bool first = valid && (pk == SENT || (pk >> 1) != col);
-        const bool pair = first && nk != SENT && (nk >> 1) == col;
-        const int tag = int(key & 1ull);
+        const bool valid = key != kNoKey;
+        const uint32_t col = key >> 1;
+        const bool first = valid && (pk == kNoKey || (pk >> 1) != col);
+        const bool pair = first && nk != kNoKey && (nk >> 1) == col;
+        const int tag = int(key & 1u);
         const double v = __longlong_as_double((long long)val);
         const double a = tag == 0 ? v : 0.0;
         const double b = tag == 1 ? v : (pair ? __longlong_as_double((long long)nv) : 0.0);
@@ -633,7 +639,7 @@ __device__ __forceinline__ int merge_sorted_regs(const uint64_t (&hi)[NT], const
         int total;
         const int p = wave_prefix_count(emit, lane, total);
         if (emit) {
-            Vk[count + p] = uint32_t(col);
+            Vk[count + p] = col;
             Vv[count + p] = m;
         }
         count += total;
@@ -642,29 +648,44 @@ __device__ __forceinline__ int merge_sorted_regs(const uint64_t (&hi)[NT], const
 }
 
 // One wave sorts a union row of L <= 64 NT entries by (column, tag) and merges the pairs.  Sort keys are packed into
-// one 64-bit word - (column, tag) above the entry's position in the row - so the bitonic network moves half the
-// registers of a key/value sort; the values are fetched by position afterwards (the row was read a moment ago).
+// one word - (column, tag) above the entry's position in the row - so the bitonic network moves one register per entry
+// instead of a key/value pair; the values are fetched by position afterwards (the row was read a moment ago).
+// K = uint32_t where key and position fit 32 bits together (sort_key_fits_u32: up to 4 M columns for rows of up to 512
+// entries), else uint64_t.
 template <int NT>
+struct SortPos {
+    static constexpr int bits = NT == 1 ? 6 : NT == 2 ? 7 : NT == 4 ? 8 : NT == 8 ? 9 : NT == 16 ? 10 : 11;
+    static_assert(NT == 1 || NT == 2 || NT == 4 || NT == 8 || NT == 16 || NT == 32, "rows of 64 ... 2048 entries");
+};
+// largest key of the build (2 ncols - 1) must stay below the all-ones pattern of its field
+static inline bool sort_key_fits_u32(int64_t ncols, int nt) {
+    int bits = 6;
+    while ((64 << (bits - 6)) < 64 * nt) ++bits;
+    return 2 * ncols - 1 < (int64_t(1) << (32 - bits)) - 1;
+}
+template <typename K, int NT>
 __device__ __forceinline__ int sort_merge_row(const UEntry* __restrict__ U, const int L, const int lane, const int symm,
                                               const double theta,
                                               uint32_t* __restrict__ Vk, double* __restrict__ Vv) {
-    uint64_t pk[NT];
+    constexpr int PB = SortPos<NT>::bits;
+    K pk[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int p = t * 64 + lane;
         // descending sort of the complement = ascending sort of the key; 0 (no entry) sorts last
-        pk[t] = (p < L) ? ~((uint64_t(U[p].key) << 16) | uint64_t(p)) : 0ull;
+        pk[t] = (p < L) ? K(~((K(U[p].key) << PB) | K(p))) : K(0);
     }
-    wave_bitonic_desc<NT>(pk, lane);
-    uint64_t hi[NT], lo[NT];
+    wave_bitonic_desc<NT, K>(pk, lane);
+    uint32_t hi[NT];
+    uint64_t lo[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        hi[t] = ~0ull;
+        hi[t] = kNoKey;
         lo[t] = 0ull;
-        if (pk[t] != 0ull) {
-            const uint64_t x = ~pk[t];
-            hi[t] = x >> 16;
-            lo[t] = (uint64_t)__double_as_longlong(U[x & 0xFFFFull].val);
+        if (pk[t] != K(0)) {
+            const K x = K(~pk[t]);
+            hi[t] = uint32_t(x >> PB);
+            lo[t] = (uint64_t)__double_as_longlong(U[uint32_t(x) & ((1u << PB) - 1u)].val);
         }
     }
     return merge_sorted_regs<NT>(hi, lo, lane, symm, theta, Vk, Vv);
@@ -677,7 +698,8 @@ __global__ __launch_bounds__(256) void sort_merge_kernel(const int64_t nloc, con
                                                          const UEntry* __restrict__ Uall,
                                                          const int symm, const double theta, uint32_t* __restrict__ Vkey,
                                                          double* __restrict__ Vval, int32_t* __restrict__ outlen,
-                                                         int32_t* __restrict__ bigrows, uint32_t* __restrict__ bigcount) {
+                                                         int32_t* __restrict__ bigrows, uint32_t* __restrict__ bigcount,
+                                                         const int key32) {
     const int lane = threadIdx.x & 63;
     const int w = threadIdx.x >> 6;
     const int64_t i = int64_t(blockIdx.x) * 4 + w;
@@ -696,14 +718,25 @@ __global__ __launch_bounds__(256) void sort_merge_kernel(const int64_t nloc, con
     uint32_t* Vk = Vkey + o0;
     double* Vv = Vval + o0;
     int c;
-    if (L <= 64)
-        c = sort_merge_row<1>(U, L, lane, symm, theta, Vk, Vv);
-    else if (L <= 128)
-        c = sort_merge_row<2>(U, L, lane, symm, theta, Vk, Vv);
-    else if (L <= 256)
-        c = sort_merge_row<4>(U, L, lane, symm, theta, Vk, Vv);
-    else
-        c = sort_merge_row<8>(U, L, lane, symm, theta, Vk, Vv);
+    if (key32) {   // (uniform over the launch)
+        if (L <= 64)
+            c = sort_merge_row<uint32_t, 1>(U, L, lane, symm, theta, Vk, Vv);
+        else if (L <= 128)
+            c = sort_merge_row<uint32_t, 2>(U, L, lane, symm, theta, Vk, Vv);
+        else if (L <= 256)
+            c = sort_merge_row<uint32_t, 4>(U, L, lane, symm, theta, Vk, Vv);
+        else
+            c = sort_merge_row<uint32_t, 8>(U, L, lane, symm, theta, Vk, Vv);
+    } else {
+        if (L <= 64)
+            c = sort_merge_row<uint64_t, 1>(U, L, lane, symm, theta, Vk, Vv);
+        else if (L <= 128)
+            c = sort_merge_row<uint64_t, 2>(U, L, lane, symm, theta, Vk, Vv);
+        else if (L <= 256)
+            c = sort_merge_row<uint64_t, 4>(U, L, lane, symm, theta, Vk, Vv);
+        else
+            c = sort_merge_row<uint64_t, 8>(U, L, lane, symm, theta, Vk, Vv);
+    }
     if (lane == 0) outlen[i] = c;
 }
 
@@ -728,8 +761,8 @@ __global__ __launch_bounds__(64) void sort_merge_long_kernel(const int64_t* __re
             continue;
         }
         const int L = int(L64);
-        const int c = (L <= 1024) ? sort_merge_row<16>(U + o0, L, lane, symm, theta, Vkey + o0, Vval + o0)
-                                  : sort_merge_row<32>(U + o0, L, lane, symm, theta, Vkey + o0, Vval + o0);
+        const int c = (L <= 1024) ? sort_merge_row<uint64_t, 16>(U + o0, L, lane, symm, theta, Vkey + o0, Vval + o0)
+                                  : sort_merge_row<uint64_t, 32>(U + o0, L, lane, symm, theta, Vkey + o0, Vval + o0);
         if (lane == 0) outlen[i] = c;
     }
 }
@@ -818,8 +851,10 @@ __global__ __launch_bounds__(256) void compact_kernel(const int64_t nloc, const 
                                                       const uint32_t* __restrict__ Vkey, const double* __restrict__ Vval,
                                                       int32_t* __restrict__ indices, double* __restrict__ Kdata,
                                                       double* __restrict__ degree, uint32_t* __restrict__ flags,
-                                                      const int32_t* __restrict__ perm) {
-    // perm: the merged rows are in sorted order (bin path: merged row p is row perm[p] of K); nullptr: in row order
+                                                      const int32_t* __restrict__ perm, double* __restrict__ Pdata) {
+    // perm: the merged rows are in sorted order (bin path: merged row p is row perm[p] of K); nullptr: in row order.
+    // Pdata: the row-normalised operator is written along (no anisotropy: K is final here) - normalize_kernel's
+    // arithmetic, same summation order
     const int lane = threadIdx.x & 63;
     const int w = threadIdx.x >> 6;
     const int64_t p = int64_t(blockIdx.x) * 4 + w;
@@ -828,7 +863,7 @@ __global__ __launch_bounds__(256) void compact_kernel(const int64_t nloc, const 
     const int64_t s = off[p];
     const int64_t dst = indptr[i];
     const int n = outlen[p];
-    double sum = 0.0;
+    double sum = 0.0, asum = 0.0;
     bool has_diag = false;
     for (int e = lane; e < n; e += 64) {
         const uint32_t c = Vkey[s + e];
@@ -836,6 +871,7 @@ __global__ __launch_bounds__(256) void compact_kernel(const int64_t nloc, const 
         indices[dst + e] = int32_t(c);
         Kdata[dst + e] = v;
         sum += v;
+        asum += fabs(v);
         has_diag |= (int64_t(c) == r0 + i) && (v != 0.0);
     }
     sum = wave_sum_f64(sum);
@@ -843,6 +879,13 @@ __global__ __launch_bounds__(256) void compact_kernel(const int64_t nloc, const 
     if (lane == 0) {
         degree[i] = sum;
         if (!any_diag) atomicOr(flags, GT_FLAG_ZERO_DIAGONAL);
+    }
+    if (Pdata) {
+        asum = wave_sum_f64(asum);
+        for (int e = lane; e < n; e += 64) {
+            const double v = Vval[s + e];
+            Pdata[dst + e] = (asum != 0.0) ? v / asum : v;
+        }
     }
 }
 
@@ -1449,7 +1492,7 @@ static int graph_finish_impl(gt_ctx* ctx, const void* recv_buf_dev, int64_t n_re
         hipLaunchKernelGGL(sort_merge_kernel, dim3((unsigned)ceil_div64(nloc, 4)), dim3(256), 0, ctx->stream, nloc,
                            g->off.as<int64_t>(), g->Ukey.as<UEntry>(), g->p.kernel_symm, g->p.theta,
                            g->Vkey.as<uint32_t>(), g->Vval.as<double>(), g->outlen.as<int32_t>(), g->bigrows.as<int32_t>(),
-                           g->bigcount.as<uint32_t>());
+                           g->bigcount.as<uint32_t>(), (ctx->symm_key32 != 0 && sort_key_fits_u32(g->n_total, 8)) ? 1 : 0);
         hipLaunchKernelGGL(sort_merge_long_kernel, dim3(4096), dim3(64), 0, ctx->stream, g->off.as<int64_t>(),
                            g->Ukey.as<UEntry>(), g->p.kernel_symm, g->p.theta, g->Vkey.as<uint32_t>(),
                            g->Vval.as<double>(), g->outlen.as<int32_t>(), g->bigrows.as<int32_t>(), g->bigcount.as<uint32_t>(),
@@ -1534,7 +1577,7 @@ static int graph_finish_impl(gt_ctx* ctx, const void* recv_buf_dev, int64_t n_re
         hipLaunchKernelGGL(compact_kernel, dim3((unsigned)ceil_div64(nloc, 4)), dim3(256), 0, ctx->stream, nloc, g->r0,
                            g->off.as<int64_t>(), g->outlen.as<int32_t>(), g->indptr.as<int64_t>(), g->Vkey.as<uint32_t>(),
                            g->Vval.as<double>(), g->indices.as<int32_t>(), g->Kdata.as<double>(), g->degree.as<double>(),
-                           g->flags.as<uint32_t>(), perm);
+                           g->flags.as<uint32_t>(), perm, g->p.anisotropy == 0.0 ? g->Pdata.as<double>() : nullptr);
         GT_HIP(ctx, hipGetLastError());
     }
     g->finished = true;
@@ -1542,9 +1585,7 @@ static int graph_finish_impl(gt_ctx* ctx, const void* recv_buf_dev, int64_t n_re
         // sharded build: the caller must all-gather the degrees and call gt_graph_anisotropy (K and every flag of the
         // build are final here, only the anisotropic rescaling and P are still to come)
         if (g->world == 1) GT_TRY(finish_normalize(ctx, g, g->degree.as<double>()));
-    } else {
-        GT_TRY(finish_normalize(ctx, g, nullptr));
-    }
+    }   // (no anisotropy: compact_kernel has written P next to K)
     uint32_t fl = 0, kfl = 0;
     GT_HIP(ctx, hipMemcpyAsync(&fl, g->flags.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     GT_HIP(ctx, hipMemcpyAsync(&kfl, k->gflags.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));

@@ -110,3 +110,13 @@ def test_bin_path_engages_by_itself_and_is_deterministic():
     assert a[2] and b[2] and not e[2]
     _same(a, b)
     _same(a, e)
+
+
+@pytest.mark.parametrize("bins", [0, 1])
+def test_row_sorts_on_32_bit_keys_equal_the_64_bit_ones(bins):
+    """the per-row sort packs (column, tag, position) into 32 bits where they fit (default); 64-bit keys otherwise"""
+    X = make_mix(6000, 30, 9)
+    a = _build(X, bins, knn=40, decay=15.0)                                   # union rows of 128 ... 512 entries
+    b = _build(X, bins, knn=40, decay=15.0, opts=(("symmetrize_key32", 0),))
+    assert np.diff(a[0][2]).max() > 128
+    _same(a, b)
