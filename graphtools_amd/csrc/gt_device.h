@@ -37,6 +37,87 @@ __device__ __forceinline__ uint64_t ld_agent_u64(const uint64_t* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// ---- canonical float64 dot product of the exact stages -----------------------------------------------------------
+// Every exact squared distance is (|x|^2 + (-2 x.y)) + |y|^2 with x.y and the norms summed in ONE fixed order, so that
+// the distance of a pair is the same bits wherever it is evaluated (either row's re-rank, the repairs, the radius rows)
+// and a row's distance to itself is exactly 0.  The order: 16 partial sums - element k goes to sum (k >> 2) & 15, in
+// increasing k, one fma each - combined by the tree (l, l + 8), (l, l + 4), (l, l + 2), (0, 1).  Sixteen independent
+// accumulators instead of one dependent fma chain per row; it is also the order a group of 16 lanes produces when lane l
+// takes the elements 4 l ... 4 l + 3 of every 64 (one 16-byte load per lane) and sums by rotations of 8, 4, 2, 1 lanes.
+__device__ __forceinline__ double gt_tree16(const double (&a)[16]) {
+    double b[8], c[4];
+#pragma unroll
+    for (int l = 0; l < 8; ++l) b[l] = a[l] + a[l + 8];
+#pragma unroll
+    for (int l = 0; l < 4; ++l) c[l] = b[l] + b[l + 4];
+    return (c[0] + c[2]) + (c[1] + c[3]);
+}
+template <typename TX, typename TY>
+__device__ __forceinline__ double gt_dot16(const TX* __restrict__ x, const TY* __restrict__ y, const int d) {
+    double a[16];
+#pragma unroll
+    for (int l = 0; l < 16; ++l) a[l] = 0.0;
+    int k0 = 0;
+    for (; k0 + 64 <= d; k0 += 64) {
+#pragma unroll
+        for (int e = 0; e < 64; ++e) a[e >> 2] = fma(double(x[k0 + e]), double(y[k0 + e]), a[e >> 2]);
+    }
+    if (k0 < d) {
+#pragma unroll
+        for (int e = 0; e < 64; ++e)
+            if (k0 + e < d) a[e >> 2] = fma(double(x[k0 + e]), double(y[k0 + e]), a[e >> 2]);
+    }
+    return gt_tree16(a);
+}
+// the same bits with a handful of live registers (one partial sum at a time, the tree folded as they come): for rare
+// paths inside kernels whose occupancy matters more
+template <typename TX, typename TY>
+__device__ __forceinline__ double gt_dot16_lean(const TX* __restrict__ x, const TY* __restrict__ y, const int d) {
+    auto part = [&](const int q) {
+        double s = 0.0;
+        for (int k = 4 * q; k < d; k += 64) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (k + e < d) s = fma(double(x[k + e]), double(y[k + e]), s);
+        }
+        return s;
+    };
+    auto c = [&](const int l) { return (part(l) + part(l + 8)) + (part(l + 4) + part(l + 12)); };
+    const double e0 = c(0) + c(2);
+    const double e1 = c(1) + c(3);
+    return e0 + e1;
+}
+// the same with 16-byte loads of a float32 row (d a multiple of 4, y 16-byte aligned)
+template <typename TX>
+__device__ __forceinline__ double gt_dot16_f4(const TX* __restrict__ x, const float* __restrict__ y, const int d) {
+    double a[16];
+#pragma unroll
+    for (int l = 0; l < 16; ++l) a[l] = 0.0;
+    const float4* y4 = reinterpret_cast<const float4*>(y);
+    int k0 = 0;
+    for (; k0 + 64 <= d; k0 += 64) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const float4 v = y4[(k0 >> 2) + q];
+            a[q] = fma(double(x[k0 + 4 * q + 0]), double(v.x), a[q]);
+            a[q] = fma(double(x[k0 + 4 * q + 1]), double(v.y), a[q]);
+            a[q] = fma(double(x[k0 + 4 * q + 2]), double(v.z), a[q]);
+            a[q] = fma(double(x[k0 + 4 * q + 3]), double(v.w), a[q]);
+        }
+    }
+    if (k0 < d) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+            if (k0 + 4 * q < d) {
+                const float4 v = y4[(k0 >> 2) + q];
+                a[q] = fma(double(x[k0 + 4 * q + 0]), double(v.x), a[q]);
+                a[q] = fma(double(x[k0 + 4 * q + 1]), double(v.y), a[q]);
+                a[q] = fma(double(x[k0 + 4 * q + 2]), double(v.z), a[q]);
+                a[q] = fma(double(x[k0 + 4 * q + 3]), double(v.w), a[q]);
+            }
+    }
+    return gt_tree16(a);
+}
 // ---- wave-level bitonic sort, descending, NT keys per lane; element e = t*64 + lane -----------
 // (32-bit keys: one shuffle, v_max_u32 / v_min_u32 and a select per step - half the work of a 64-bit key)
 template <int NT, typename K>
@@ -121,6 +202,64 @@ __device__ __forceinline__ void wave_bitonic_asc_pair(uint64_t (&hi)[NT], uint64
                 }
             }
         }
+    }
+}
+
+// The same result through ONE 64-bit key per entry: the low bits of hi (a float64 bit pattern) give way to the entry's
+// position, the network moves and compares one word instead of a 128-bit pair, and the pairs are fetched by position at
+// the end.  Two entries whose hi agree above those bits could come out in the wrong order: the sorted sequence is checked
+// for such neighbours and, when there is one (exact ties, distances within 2^-44 of each other), the pair network
+// runs instead - so the outcome is always the one of wave_bitonic_asc_pair.  Entries (kInf, 0xFFFFFFFF) mean "none" and
+// sort last; lo must fit 32 bits.
+template <int NT>
+__device__ __forceinline__ void wave_sort_asc_pair_fast(uint64_t (&hi)[NT], uint64_t (&lo)[NT], const int lane) {
+    static_assert(NT == 1 || NT == 2 || NT == 4 || NT == 8, "up to 512 entries");
+    constexpr int PB = NT == 1 ? 6 : NT == 2 ? 7 : NT == 4 ? 8 : 9;
+    constexpr uint64_t PM = (1ull << PB) - 1ull;
+    constexpr uint64_t kNoneHi = 0x7FF0000000000000ull;
+    uint64_t ck[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const bool none = hi[t] == kNoneHi && lo[t] == 0xFFFFFFFFull;
+        ck[t] = none ? 0ull : ~((hi[t] & ~PM) | uint64_t(t * 64 + lane));   // descending complement = ascending key
+    }
+    wave_bitonic_desc<NT>(ck, lane);
+    bool clash = false;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        uint64_t nx = __shfl_down((unsigned long long)ck[t], 1);
+        const uint64_t edge = (t < NT - 1) ? __shfl((unsigned long long)ck[t < NT - 1 ? t + 1 : t], 0) : 0ull;
+        if (lane == 63) nx = edge;
+        clash |= ck[t] != 0ull && nx != 0ull && ((~ck[t]) >> PB) == ((~nx) >> PB);
+    }
+    if (__ballot(clash) != 0ull) {   // wave-uniform, rare
+        wave_bitonic_asc_pair<NT>(hi, lo, lane);
+        return;
+    }
+    uint64_t nh[NT];
+    uint32_t nl[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const uint32_t p = uint32_t(~ck[t]) & uint32_t(PM);
+        const int sl = int(p & 63u), sr = int(p >> 6);
+        uint64_t h = kNoneHi;
+        uint32_t l = 0xFFFFFFFFu;
+#pragma unroll
+        for (int r = 0; r < NT; ++r) {
+            const uint64_t hr = __shfl((unsigned long long)hi[r], sl);
+            const uint32_t lr = __shfl(uint32_t(lo[r]), sl);
+            if (sr == r && ck[t] != 0ull) {
+                h = hr;
+                l = lr;
+            }
+        }
+        nh[t] = h;
+        nl[t] = l;
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        hi[t] = nh[t];
+        lo[t] = uint64_t(nl[t]);
     }
 }
 

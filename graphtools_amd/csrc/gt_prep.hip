@@ -116,13 +116,17 @@ __global__ __launch_bounds__(256) void row_norm_kernel(const T* __restrict__ X, 
                                                        double* __restrict__ xn_sel) {
     // xn: squared norm over all d columns (exact stages).  With `sel` the candidate pass sees only columns sel[0..dw):
     // its seeds, the norm bound and the residual bound come from the partial norm (xn_sel).
-    // One thread per row, columns accumulated in index order (the float64 stages depend on these exact sums); the
+    // One thread per row, columns accumulated in the canonical order of the exact stages (gt_dot16: a row's distance to
+    // itself must come out 0); the
     // block's 256 rows are staged through LDS in chunks of 32 columns so that the global reads are coalesced.
     constexpr int CH = 32;
     __shared__ T chunk[256][CH + 1];
     const int64_t r0 = int64_t(blockIdx.x) * 256;
     const int64_t r = r0 + threadIdx.x;
     double acc = 0.0, accs = 0.0, lo2 = 0.0;
+    double a16[16];   // the canonical partial sums (gt_device.h gt_dot16): column k goes to sum (k >> 2) & 15
+#pragma unroll
+    for (int l = 0; l < 16; ++l) a16[l] = 0.0;
     for (int c0 = 0; c0 < d; c0 += CH) {
         const int cw = d - c0 < CH ? d - c0 : CH;
         __syncthreads();
@@ -132,9 +136,23 @@ __global__ __launch_bounds__(256) void row_norm_kernel(const T* __restrict__ X, 
         }
         __syncthreads();
         if (r < n) {
+            if ((c0 & 32) == 0) {   // (uniform: columns 0 ... 31 of a group of 64 feed sums 0 ... 7, the others 8 ... 15)
+#pragma unroll
+                for (int k = 0; k < CH; ++k)
+                    if (k < cw) {
+                        const double v = double(chunk[threadIdx.x][k]);
+                        a16[k >> 2] = fma(v, v, a16[k >> 2]);
+                    }
+            } else {
+#pragma unroll
+                for (int k = 0; k < CH; ++k)
+                    if (k < cw) {
+                        const double v = double(chunk[threadIdx.x][k]);
+                        a16[8 + (k >> 2)] = fma(v, v, a16[8 + (k >> 2)]);
+                    }
+            }
             for (int k = 0; k < cw; ++k) {
                 const double v = double(chunk[threadIdx.x][k]);
-                acc = fma(v, v, acc);
                 if (lomax2_bits && !sel) {
                     // exact residual of the float16 rounding of the scaled value (what the hi-plane-only pass drops)
                     const double vs = v * sc;
@@ -144,6 +162,7 @@ __global__ __launch_bounds__(256) void row_norm_kernel(const T* __restrict__ X, 
             }
         }
     }
+    acc = gt_tree16(a16);
     if (r < n) {
         const T* src = X + r * int64_t(d);
         accs = acc;

@@ -21,28 +21,15 @@ namespace {
 
 constexpr unsigned long long kInfBits = 0x7FF0000000000000ull;
 
+// (the canonical summation order of the exact stages: gt_device.h gt_dot16)
 template <typename T>
 __device__ __forceinline__ double dot_row(const double* __restrict__ xs, const T* __restrict__ y, int d) {
-    double acc = 0.0;
-    for (int k = 0; k < d; ++k) acc = fma(xs[k], double(y[k]), acc);
-    return acc;
+    return gt_dot16(xs, y, d);
 }
 template <>
 __device__ __forceinline__ double dot_row<float>(const double* __restrict__ xs, const float* __restrict__ y, int d) {
-    double acc = 0.0;
-    if ((d & 3) == 0 && ((reinterpret_cast<uintptr_t>(y) & 15) == 0)) {
-        const float4* y4 = reinterpret_cast<const float4*>(y);
-        for (int k = 0; k < d / 4; ++k) {
-            const float4 v = y4[k];
-            acc = fma(xs[4 * k + 0], double(v.x), acc);
-            acc = fma(xs[4 * k + 1], double(v.y), acc);
-            acc = fma(xs[4 * k + 2], double(v.z), acc);
-            acc = fma(xs[4 * k + 3], double(v.w), acc);
-        }
-    } else {
-        for (int k = 0; k < d; ++k) acc = fma(xs[k], double(y[k]), acc);
-    }
-    return acc;
+    if ((d & 3) == 0 && ((reinterpret_cast<uintptr_t>(y) & 15) == 0)) return gt_dot16_f4(xs, y, d);
+    return gt_dot16(xs, y, d);
 }
 
 template <typename T, int NT2>
@@ -135,7 +122,7 @@ __global__ __launch_bounds__(256) void rerank_kernel(const T* __restrict__ X, co
         const uint64_t k129 = __shfl((unsigned long long)ks[2], 0);
         const double lb_rest = (k129 != 0ull) ? bound_of_score(cand_score(k129)) : INFINITY;
         uint64_t h2[2] = {hi[0], hi[1]}, l2[2] = {lo[0], lo[1]};
-        wave_bitonic_asc_pair<2>(h2, l2, lane);
+        wave_sort_asc_pair_fast<2>(h2, l2, lane);
         const uint64_t sel2 = (pos >> 6) == 0 ? h2[0] : h2[1];
         const double need2 = __longlong_as_double((long long)__shfl((unsigned long long)sel2, pos & 63));
         const double lbm = fmin(lb, lb_rest);
@@ -170,7 +157,10 @@ __global__ __launch_bounds__(256) void rerank_kernel(const T* __restrict__ X, co
             }
         }
     }
-    if (!settled) wave_bitonic_asc_pair<NT2>(hi, lo, lane);
+    if (!settled) {
+        if constexpr (NT2 <= 8) wave_sort_asc_pair_fast<NT2>(hi, lo, lane);
+        else wave_bitonic_asc_pair<NT2>(hi, lo, lane);
+    }
     // slots [0, max(n_tab, need_m)) are defined (+inf keys past the last candidate); nobody reads further
     const uint32_t n_def = n_tab > uint32_t(need_m) ? n_tab : uint32_t(need_m);
 #pragma unroll
@@ -198,6 +188,8 @@ __global__ __launch_bounds__(256) void rerank_kernel(const T* __restrict__ X, co
         if (n > 1 && second == 0ull) atomicOr(gflags, GT_FLAG_DUPLICATES);
     }
 }
+
+constexpr uint32_t kNoRow = 0xFFFFFFFFu;
 
 // ---- re-rank of the symmetric candidate pass (knn_select_kernel MODE 2) ---------------------------------------
 // List ql belongs to the row at cell-sorted position ql (row perm[ql]); it holds (score, sorted position) keys collected
@@ -258,10 +250,7 @@ __global__ __launch_bounds__(256) void rerank_sym_kernel(
         ks[u] = (c < n) ? tp[c] : 0ull;   // a valid key is never 0
     }
     if (n <= 128u) {   // wave-uniform
-        uint64_t k2[2] = {ks[0], ks[1]};
-        wave_bitonic_desc<2>(k2, lane);
-        ks[0] = k2[0];
-        ks[1] = k2[1];
+        // every candidate is in the first batch: their order does not matter (the keys sit in the first n slots as read)
     } else if (n <= 256u) {
         uint64_t k4[4] = {ks[0], ks[1], ks[2], ks[3]};
         wave_bitonic_desc<4>(k4, lane);
@@ -279,13 +268,22 @@ __global__ __launch_bounds__(256) void rerank_sym_kernel(
         hi[u] = kInfBits;
         lo[u] = 0xFFFFFFFFull;
     }
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        if (ks[u] != 0ull) {
-            const uint32_t j = uint32_t(perm[cand_index(ks[u])]);
-            const double dot = dot_row<T>(xs, X + int64_t(j) * d, d);
-            hi[u] = (uint64_t)__double_as_longlong(gt_pair_key(qnq, dot, xn[j], 0));
-            lo[u] = j;
+    {
+        const uint32_t j0 = ks[0] != 0ull ? uint32_t(perm[cand_index(ks[0])]) : kNoRow;
+        const uint32_t j1 = ks[1] != 0ull ? uint32_t(perm[cand_index(ks[1])]) : kNoRow;
+        double dot0, dot1;
+        // (one database row per lane.  Sixteen lanes per row with coalesced 16-byte loads and a rotation sum were tried:
+        //  8.1 ms against 5.8 - the kernel is bound by its sorting networks and the gathers hit the L2, the extra
+        //  registers of the batched loads cost more occupancy than the coalescing returns)
+        dot0 = j0 != kNoRow ? dot_row<T>(xs, X + int64_t(j0) * d, d) : 0.0;
+        dot1 = j1 != kNoRow ? dot_row<T>(xs, X + int64_t(j1) * d, d) : 0.0;
+        if (j0 != kNoRow) {
+            hi[0] = (uint64_t)__double_as_longlong(gt_pair_key(qnq, dot0, xn[j0], 0));
+            lo[0] = j0;
+        }
+        if (j1 != kNoRow) {
+            hi[1] = (uint64_t)__double_as_longlong(gt_pair_key(qnq, dot1, xn[j1], 0));
+            lo[1] = j1;
         }
     }
     const int pos = need_m - 1;
@@ -295,7 +293,7 @@ __global__ __launch_bounds__(256) void rerank_sym_kernel(
     const uint64_t k257 = __shfl((unsigned long long)ks[4], 0);
     const double lb_rest = (k129 != 0ull) ? bound_of_score(cand_score(k129)) : INFINITY;
     uint64_t h2[2] = {hi[0], hi[1]}, l2[2] = {lo[0], lo[1]};
-    wave_bitonic_asc_pair<2>(h2, l2, lane);
+    wave_sort_asc_pair_fast<2>(h2, l2, lane);
     const uint64_t sel2 = (pos >> 6) == 0 ? h2[0] : h2[1];
     const double need2 = __longlong_as_double((long long)__shfl((unsigned long long)sel2, pos & 63));
     const double lbm = fmin(lb, lb_rest);
@@ -306,17 +304,23 @@ __global__ __launch_bounds__(256) void rerank_sym_kernel(
         lb = lbm;
         n_tab = n_eval < 128u ? n_eval : 128u;
     } else {
-#pragma unroll
-        for (int u = 2; u < 4; ++u) {
-            if (ks[u] != 0ull) {
-                const uint32_t j = uint32_t(perm[cand_index(ks[u])]);
-                const double dot = dot_row<T>(xs, X + int64_t(j) * d, d);
-                hi[u] = (uint64_t)__double_as_longlong(gt_pair_key(qnq, dot, xn[j], 0));
-                lo[u] = j;
+        {
+            const uint32_t j2 = ks[2] != 0ull ? uint32_t(perm[cand_index(ks[2])]) : kNoRow;
+            const uint32_t j3 = ks[3] != 0ull ? uint32_t(perm[cand_index(ks[3])]) : kNoRow;
+            double dot2, dot3;
+            dot2 = j2 != kNoRow ? dot_row<T>(xs, X + int64_t(j2) * d, d) : 0.0;
+            dot3 = j3 != kNoRow ? dot_row<T>(xs, X + int64_t(j3) * d, d) : 0.0;
+            if (j2 != kNoRow) {
+                hi[2] = (uint64_t)__double_as_longlong(gt_pair_key(qnq, dot2, xn[j2], 0));
+                lo[2] = j2;
+            }
+            if (j3 != kNoRow) {
+                hi[3] = (uint64_t)__double_as_longlong(gt_pair_key(qnq, dot3, xn[j3], 0));
+                lo[3] = j3;
             }
         }
         if (k257 != 0ull) lb = fmin(lb, bound_of_score(cand_score(k257)));   // candidates beyond the table
-        wave_bitonic_asc_pair<4>(hi, lo, lane);
+        wave_sort_asc_pair_fast<4>(hi, lo, lane);
     }
     const uint32_t n_def = n_tab > uint32_t(need_m) ? n_tab : uint32_t(need_m);
 #pragma unroll
@@ -709,16 +713,14 @@ int gt_launch_rerank_sym(gt_ctx* ctx, const RerankArgs& a, const SymRerank& sr) 
     const int64_t blocks = ceil_div64(a.nq, 4);
     const size_t lds = size_t(4) * a.d * sizeof(double);
     if (a.MP != 256 || a.metric != 0) GT_FAIL(ctx, GT_E_ARG, "rerank_sym: table width 256, euclidean metric only");
-    if (a.dtype == GT_F32)
-        hipLaunchKernelGGL((rerank_sym_kernel<float>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, (const float*)a.X,
-                           a.d, a.xn, a.nq, sr.tlists, sr.tcap, sr.tcounts, a.thr_final, a.ymax2,
-                           a.err, a.need_m, sr.perm, a.cand_d2, a.cand_j, a.cand_n, a.d2_lb, a.fb_count, a.fb_rows, a.gflags,
-                           a.radius_key_factor, a.unproven, sr.stat, (ctx->dbg_select & 256) ? 1 : 0, sr.invperm, sr.own_rows, sr.own_r0);
-    else
-        hipLaunchKernelGGL((rerank_sym_kernel<double>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, (const double*)a.X,
-                           a.d, a.xn, a.nq, sr.tlists, sr.tcap, sr.tcounts, a.thr_final, a.ymax2,
-                           a.err, a.need_m, sr.perm, a.cand_d2, a.cand_j, a.cand_n, a.d2_lb, a.fb_count, a.fb_rows, a.gflags,
-                           a.radius_key_factor, a.unproven, sr.stat, (ctx->dbg_select & 256) ? 1 : 0, sr.invperm, sr.own_rows, sr.own_r0);
+#define GT_RERANK_SYM_LAUNCH(T_)                                                                                          \
+    hipLaunchKernelGGL((rerank_sym_kernel<T_>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, (const T_*)a.X, a.d,  \
+                       a.xn, a.nq, sr.tlists, sr.tcap, sr.tcounts, a.thr_final, a.ymax2, a.err, a.need_m, sr.perm,        \
+                       a.cand_d2, a.cand_j, a.cand_n, a.d2_lb, a.fb_count, a.fb_rows, a.gflags, a.radius_key_factor,      \
+                       a.unproven, sr.stat, (ctx->dbg_select & 256) ? 1 : 0, sr.invperm, sr.own_rows, sr.own_r0)
+    if (a.dtype == GT_F32) GT_RERANK_SYM_LAUNCH(float);
+    else GT_RERANK_SYM_LAUNCH(double);
+#undef GT_RERANK_SYM_LAUNCH
     GT_HIP(ctx, hipGetLastError());
     return GT_OK;
 }

@@ -122,9 +122,11 @@ __global__ __launch_bounds__(256) void stage_count_kernel(const int64_t nloc, co
 // ---- A1: affinities + counts ----------------------------------------------------------------------
 // One wave per local row.  Table rows: K overwrites cand_d2 in place (-1 marks a dropped slot).
 // Radius rows: exact float64 distance for every collected candidate, K into rK.
-template <typename T>
+// RADIUS: the launch covers the rows of the radius pass only (row_list, nloc of them) - their exact float64 distances
+// need registers the table rows of the main launch should not pay for with occupancy
+template <typename T, bool RADIUS>
 __global__ __launch_bounds__(256) void affinity_kernel(
-    const int64_t nloc, const int64_t r0, const T* __restrict__ X, const int d, const double* __restrict__ xn,
+    const int32_t* __restrict__ row_list, const int64_t nrows, const int64_t nloc, const int64_t r0, const T* __restrict__ X, const int d, const double* __restrict__ xn,
     const T* __restrict__ Qm, const double* __restrict__ qnorm, const int64_t qoff, const int dtype, const int metric, const int MP, const int limit, double* __restrict__ cand_d2, const uint32_t* __restrict__ cand_j,
     const uint32_t* __restrict__ cand_n, const int32_t* __restrict__ rowsrc, const uint64_t* __restrict__ rlists,
     const uint32_t* __restrict__ rcounts, const int32_t rcap, double* __restrict__ rK, const double* __restrict__ bw,
@@ -134,13 +136,15 @@ __global__ __launch_bounds__(256) void affinity_kernel(
     const int lane = threadIdx.x & 63;
     const int w = threadIdx.x >> 6;
     double* xs = reinterpret_cast<double*>(smem_raw) + size_t(w) * d;
-    const int64_t i = int64_t(blockIdx.x) * 4 + w;
-    if (i >= nloc) return;
+    const int64_t wi = int64_t(blockIdx.x) * 4 + w;
+    if (wi >= nrows) return;
+    const int64_t i = RADIUS ? int64_t(row_list[wi]) : wi;
     const int32_t src = rowsrc[i];
+    if (RADIUS != (src >= 0)) return;   // (the other launch's row)
     const double bwi = bw[i];
     int kept = 0;
     int owner_cnt = 0;   // lane o accumulates the count for owner o (world <= 64)
-    if (src < 0) {
+    if constexpr (!RADIUS) {
         uint32_t n = cand_n[i];
         if (n > uint32_t(limit)) n = uint32_t(limit);
         uint32_t last = 0;
@@ -187,8 +191,7 @@ __global__ __launch_bounds__(256) void affinity_kernel(
             if (e < n) {
                 j = cand_index(lp[e]);
                 const T* y = X + int64_t(j) * d;
-                double dot = 0.0;
-                for (int k = 0; k < d; ++k) dot = fma(xs[k], double(y[k]), dot);
+                const double dot = gt_dot16(xs, y, d);   // (the canonical order of the exact stages)
                 const double t = gt_pair_key(qn, dot, xn[j], metric);
                 const double kv = affinity(gt_key_to_dist(t, dtype, metric), bwi, decay);
                 keep = kv >= thresh;
@@ -968,15 +971,18 @@ Splits make_splits(const GraphState* g) {
 
 template <typename T>
 void launch_affinity(gt_ctx* ctx, GraphState* g, KnnWork* k, int binary, double decay, double thresh, int count_owners) {
-    const int64_t blocks = ceil_div64(g->nloc, 4);
     const size_t lds = size_t(4) * ctx->d * sizeof(double);
-    hipLaunchKernelGGL((affinity_kernel<T>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, g->nloc, g->r0,
-                       (const T*)ctx->X, ctx->d, ctx->xn.as<double>(), (const T*)g->Qmat, g->qnorm, g->qoff, ctx->dtype, ctx->metric,
-                       k->MP, g->limit, k->cand_d2.as<double>(),
-                       k->cand_j.as<uint32_t>(), k->cand_n.as<uint32_t>(), g->rowsrc.as<int32_t>(),
-                       g->rlists.as<uint64_t>(), g->rcounts.as<uint32_t>(), g->rcap, g->rK.as<double>(),
-                       g->bw.as<double>(), decay, binary, thresh, count_owners, make_splits(g), g->lenN.as<int32_t>(),
-                       g->ownercnt.as<int32_t>(), g->tablen.as<int32_t>());
+#define GT_AFFINITY_LAUNCH(RADIUS_, LIST_, NROWS_)                                                                          \
+    hipLaunchKernelGGL((affinity_kernel<T, RADIUS_>), dim3((unsigned)ceil_div64(NROWS_, 4)), dim3(256), lds, ctx->stream,   \
+                       LIST_, int64_t(NROWS_), g->nloc, g->r0, (const T*)ctx->X, ctx->d, ctx->xn.as<double>(),              \
+                       (const T*)g->Qmat, g->qnorm, g->qoff, ctx->dtype, ctx->metric, k->MP, g->limit,                     \
+                       k->cand_d2.as<double>(), k->cand_j.as<uint32_t>(), k->cand_n.as<uint32_t>(), g->rowsrc.as<int32_t>(), \
+                       g->rlists.as<uint64_t>(), g->rcounts.as<uint32_t>(), g->rcap, g->rK.as<double>(),                   \
+                       g->bw.as<double>(), decay, binary, thresh, count_owners, make_splits(g), g->lenN.as<int32_t>(),      \
+                       g->ownercnt.as<int32_t>(), g->tablen.as<int32_t>())
+    GT_AFFINITY_LAUNCH(false, (const int32_t*)nullptr, g->nloc);
+    if (g->n_over > 0) GT_AFFINITY_LAUNCH(true, g->over_rows.as<int32_t>(), g->n_over);
+#undef GT_AFFINITY_LAUNCH
 }
 
 }  // namespace
