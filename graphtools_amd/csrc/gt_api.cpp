@@ -65,6 +65,8 @@ int gt_ctx_create(int device, gt_ctx** out) {
     if (const char* v = std::getenv("GT_SYM_TWO_STAGE")) ctx->sym_two_stage = std::atoi(v);
     if (const char* v = std::getenv("GT_SYM_MIN_ROWS")) ctx->sym_min_rows = std::max(1, std::atoi(v));
     if (const char* v = std::getenv("GT_SYM_STRIDE")) ctx->sym_stride = std::max(0, std::atoi(v));
+    if (const char* v = std::getenv("GT_SYM_CELLS")) ctx->sym_cells = std::max(1, std::atoi(v));
+    if (const char* v = std::getenv("GT_ORDER_CELL_ROWS")) ctx->order_cell_rows = std::max(32, std::atoi(v));
     *out = ctx;
     return GT_OK;
 }
@@ -301,6 +303,14 @@ int gt_set_option(gt_ctx* ctx, const char* name, const char* value) {
         const int sh = std::atoi(value);
         if (sh != 0 && (sh < 8 || sh > 12)) return GT_E_ARG;
         ctx->symm_bin_shift = sh;
+        return GT_OK;
+    }
+    if (k == "select_sym_bounds") {
+        ctx->sym_bounds = v == "auto" ? -1 : std::atoi(value);
+        return GT_OK;
+    }
+    if (k == "select_sym_bound_cap") {
+        ctx->sym_bound_cap = std::max<long long>(0, std::atoll(value));
         return GT_OK;
     }
     if (k == "select_sym_pca") {

@@ -131,7 +131,8 @@ struct gt_ctx {
     int32_t query_order = 1;  // candidate pass: deal the query rows to workgroups grouped by nearest landmark (gt_order.hip)
     int32_t order_min_rows = 32768;  //   launches with fewer query rows (or fewer points) are not grouped
     int32_t thr0_mode = 1;           //   start the candidate lists from the threshold the assignment pass proves (0: from -inf)
-    int32_t order_cell_rows = 512;   //   rows per landmark cell (L = n / order_cell_rows landmarks, 64 ... 4096)
+    int32_t order_cell_rows = 244;   //   rows per landmark cell (L = n / order_cell_rows landmarks, 64 ... 4096; small cells: a cluster
+                                     //   without a landmark of its own swells the cells it lands in - see the bound pass, gt_sym.hip)
     DevBuf land_Y, land_h, order_cell, order_rows, order_tmp;
     int32_t samp_trig = 0;    //   level 0: entries per half-list that trigger a cut (0: samp_keep / 2 + 24)
     int32_t samp2_level = 3;  //   second cut of the lists once 2^samp2_level / samp_stride of the tiles are seen (0: none)
@@ -143,7 +144,7 @@ struct gt_ctx {
     int32_t sym_mode = -1;
     int64_t sym_min_rows = 65536;
     int32_t sym_stride = 96;    //   threshold-seeding launch: every sym_stride-th tile besides the row's own neighbourhood (0: none)
-    int32_t sym_cells = 8;     //   ... which is the rows of this many nearest cells (landmarks) of the block's own cells,
+    int32_t sym_cells = 12;    //   ... which is the rows of this many nearest cells (landmarks) of the block's own cells,
     int32_t sym_max_nb = 384;   //   at most this many tiles
     int32_t sym_tcap = 512;     //   capacity of a row's candidate list in launch B (<= 512)
     int32_t sym_ok = -1;        //   auto: 0 once the bound point set has overflowed the lists of launch B (reset by gt_set_points)
@@ -154,6 +155,8 @@ struct gt_ctx {
     int32_t symm_bins = -1;     // single-rank symmetrisation through destination bins (gt_sparse.hip): -1 auto, 0 off, 1 on
     int32_t symm_key32 = 1;     //   per-row sorts of the symmetrisation on 32-bit keys where columns and positions fit (0: 64-bit keys)
     int32_t symm_bin_shift = 0; //   log2 of the rows per bin (0: 9, more from 2 M rows; development / tests: 8 ... 12)
+    int32_t sym_bounds = -1;    //   bound pass in front of the two-stage collect (cell balls): -1 auto / 1 on, 0 off
+    int64_t sym_bound_cap = 0;  //   units the bound pass may leave before the collect launch runs instead (0: 4 M; tests)
     int32_t sym_pca = 1;        //   stage one scores the 16 leading principal directions (0: the first 16 features)
     int32_t sym_queue_cap = 0;  //   entries per wave region of the two-stage queue (0: sized from the problem; development / tests)
     int32_t sym_spill_cap = 0;  //   entries of the shared spill area behind the regions (0: 4 M; development / tests)

@@ -17,7 +17,7 @@ void gt_free_knn_work(gt_ctx* ctx) {
                       &k->d2_lb, &k->fb_rows, &k->fb_count, &k->fb_scratch, &k->gflags, &k->prof, &k->fb_qrows, &k->fb_thr, &k->fb_lists,
                       &k->fb_counts, &k->fb_max, &k->unproven, &k->qorder, &k->qthr0, &k->qlomax_dev, &k->Ycs, &k->hnegs,
                       &k->sym_g, &k->sym_gmin, &k->tlists, &k->tcounts, &k->sym_stat, &k->sym_work, &k->sym_tiles,
-                      &k->sym_tile_cnt, &k->sh_invperm, &k->sh_lists, &k->sh_counts, &k->sh_cnt, &k->sh_own, &k->sh_tmp, &k->sym_hh, &k->sym_thrh, &k->sym_gh, &k->sym_gminh, &k->sym_queue, &k->sym_qcount, &k->sym_qdense, &k->sym_qtot, &k->sym_racc, &k->sym_farcnt, &k->sym_z, &k->sym_p, &k->sym_cov, &k->sym_qspill})
+                      &k->sym_tile_cnt, &k->sh_invperm, &k->sh_lists, &k->sh_counts, &k->sh_cnt, &k->sh_own, &k->sh_tmp, &k->sym_hh, &k->sym_thrh, &k->sym_gh, &k->sym_gminh, &k->sym_queue, &k->sym_qcount, &k->sym_qdense, &k->sym_qtot, &k->sym_racc, &k->sym_farcnt, &k->sym_z, &k->sym_p, &k->sym_cov, &k->sym_qspill, &k->sym_rrow, &k->sym_bwork})
         b->release();
     delete k;
     ctx->knn = nullptr;
@@ -396,11 +396,43 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
                 }
                 GT_TRY(gt_sym_queue_prepare(ctx, n_pad_s, a));
             }
-            {
+            // Bound pass: on clustered points the cells of the sorted order rule out nearly every unit without looking at
+            // a row; what they leave goes straight to the cold launch and the collect launch does not run.  (More than
+            // 4 M units left: the unit loop is the better filter.)
+            bool bound_done = false;
+            k->sym_bound_used = false;
+            if (two_now && ctx->sym_bounds != 0 && n_pad_s % 1024 == 0 && ctx->order_L > 0) {
+                const int64_t bcap = ctx->sym_bound_cap > 0 ? ctx->sym_bound_cap : (int64_t(1) << 22);
+                GT_HIP(ctx, k->sym_qdense.reserve(size_t(bcap) * sizeof(uint2)));
+                GT_HIP(ctx, k->sym_qtot.reserve(4 * sizeof(uint32_t)));
+                uint32_t left = 0;
+                {
+                    StageSpan span(ctx, "sym_bound");
+                    GT_TRY(gt_sym_bound_queue(ctx, n_pad_s, k->Ycs.p, k->sym_rrow.as<float>(), k->sym_bwork,
+                                              k->sym_qdense.as<uint2>(), uint32_t(bcap), k->sym_qtot.as<uint32_t>()));
+                    GT_HIP(ctx, hipMemcpyAsync(&left, k->sym_qtot.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+                }
+                GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                if (ctx->dbg_select & 2048)
+                    fprintf(stderr, "[gt] bound pass: %u units left (capacity %lld)\n", left, (long long)bcap);
+                if (int64_t(left) <= bcap) {
+                    StageSpan span(ctx, "sym_cold");
+                    SelectArgs dq = a;
+                    dq.mode = 4;
+                    dq.sym.queue = k->sym_qdense.as<uint2>();
+                    dq.sym.qn = int32_t(left);
+                    GT_TRY(gt_launch_select(ctx, dq));
+                    k->sym_cold_entries = int64_t(left);
+                    k->sym_bound_used = true;
+                    bound_done = true;
+                    if (ctx->sym_two_ok < 0) ctx->sym_two_ok = 1;
+                }
+            }
+            if (!bound_done) {
                 StageSpan span(ctx, "knn_select");
                 GT_TRY(gt_sym_launch_collect(ctx, a));
             }
-            if (two_now) {
+            if (two_now && !bound_done) {
                 int ok = 0;
                 GT_TRY(gt_sym_queue_finish(ctx, a, &k->sym_cold_entries, &ok));
                 if (!ok) {
@@ -650,6 +682,7 @@ int gt_sym_two_stage_prepare(gt_ctx* ctx, const int32_t* perm, int64_t n_pad_s, 
     GT_HIP(ctx, k->sym_thrh.reserve(size_t(n_pad_s) * sizeof(float)));
     GT_HIP(ctx, k->sym_gh.reserve(size_t(n_pad_s) * sizeof(float)));
     GT_HIP(ctx, k->sym_gminh.reserve(size_t(n_pad_s / 32) * sizeof(float)));
+    GT_HIP(ctx, k->sym_rrow.reserve(size_t(n_pad_s) * sizeof(float)));
     GT_HIP(ctx, k->sym_qtot.reserve(4 * sizeof(uint32_t)));
     GT_HIP(ctx, k->sym_z.reserve(size_t(n_pad_s) * 16 * sizeof(_Float16)));
     GT_HIP(ctx, k->sym_p.reserve(16 * 64 * sizeof(float)));
@@ -681,7 +714,8 @@ int gt_sym_two_stage_prepare(gt_ctx* ctx, const int32_t* perm, int64_t n_pad_s, 
             GT_HIP(ctx, hipMemcpyAsync(k->sym_p.p, P_host, sizeof(P_host), hipMemcpyHostToDevice, ctx->stream));
             GT_TRY(gt_sym_project(ctx, perm, n_pad_s, k->sym_p.as<float>(), scz, k->sym_z.p, k->sym_hh.as<float>()));
             GT_TRY(gt_sym_half_thresholds(ctx, perm, n_pad_s, k->thr_final.as<float>(), k->sym_hh.as<float>(), em, hd, scz, Lz,
-                                          k->sym_thrh.as<float>(), k->sym_gh.as<float>(), k->sym_gminh.as<float>()));
+                                          k->sym_thrh.as<float>(), k->sym_gh.as<float>(), k->sym_gminh.as<float>(),
+                                          k->sym_rrow.as<float>()));
             if (ctx->sym_two_stage < 0)
                 GT_TRY(gt_sym_two_probe(ctx, k->sym_z.p, hd, k->sym_hh.as<float>(), k->sym_thrh.as<float>(),
                                         k->sym_gh.as<float>(), samples, k->sym_qtot.as<uint32_t>()));
@@ -714,7 +748,8 @@ int gt_sym_two_stage_prepare(gt_ctx* ctx, const int32_t* perm, int64_t n_pad_s, 
         GT_TRY(gt_sym_g_from_thr(ctx, n_pad_s, k->thr_final.as<float>(), k->hnegs.as<float>(), k->sym_g.as<float>(),
                                  k->sym_gmin.as<float>()));
         GT_TRY(gt_sym_half_thresholds(ctx, perm, n_pad_s, k->thr_final.as<float>(), k->sym_hh.as<float>(), em, hd, scz, Lz,
-                                      k->sym_thrh.as<float>(), k->sym_gh.as<float>(), k->sym_gminh.as<float>()));
+                                      k->sym_thrh.as<float>(), k->sym_gh.as<float>(), k->sym_gminh.as<float>(),
+                                      k->sym_rrow.as<float>()));
     }
     a.sym.half_steps = 1;
     a.sym.hh = k->sym_hh.as<float>();
@@ -855,6 +890,7 @@ extern "C" int gt_knn_stats(const gt_ctx* ctx, int64_t* out12) {
     if (k && k->sym_used) out12[6] = k->sym_nseg;   // work items per query block of launch B
     if (k && k->sym_used) out12[5] = k->sym_two_used ? k->sym_cold_entries : 0;   // pairs the cold launch scored in full
     if (k && k->sym_used) out12[7] = k->sym_two_used ? 1 : 0;                     // two-stage collect ran
+    if (k && k->sym_used) out12[4] = (k->sym_two_used && k->sym_bound_used) ? 1 : 0;   // units listed by cell bounds, no collect launch
     out12[10] = k ? k->sym_far : 0;                 // kept rows of launch A outside the neighbourhood cells (all points)
     return GT_OK;
 }

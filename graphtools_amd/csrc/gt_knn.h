@@ -34,6 +34,8 @@ struct KnnWork {
     DevBuf sym_hh, sym_thrh, sym_gh, sym_gminh;   // two-stage scoring (gt_sym.hip sym_half_*)
     DevBuf sym_z, sym_p, sym_cov;                 //   the stage-one copy Z = P x, its frame P, sample covariance scratch
     DevBuf sym_qspill;                            //   spill area of the queue (+ its counter)
+    DevBuf sym_rrow, sym_bwork;                   //   bound pass: radius of every row in the stage-one copy, cell scratch
+    bool sym_bound_used = false;                  //   the last symmetric pass listed its units by cell bounds (no collect launch)
     DevBuf sym_queue, sym_qcount, sym_qdense, sym_qtot;   //   and the queue of its deferred cold pass (wave regions,
                                                           //   their counts, the compacted queue, {total, overflow})
     int64_t sym_cold_entries = 0;
@@ -203,7 +205,11 @@ int gt_sym_two_stage_prepare(gt_ctx* ctx, const int32_t* perm, int64_t n_pad_s, 
 // overflowed (nothing was filed: the caller runs the one-stage kernel instead)
 int gt_sym_queue_finish(gt_ctx* ctx, const SelectArgs& a, int64_t* entries, int* ok);
 int gt_sym_half_thresholds(gt_ctx* ctx, const int32_t* perm, int64_t n_pad_s, const float* thr, const float* hh,
-                           const ErrModel& err, int hd, double scz, double Lz, float* thrh, float* gh, float* gminh);
+                           const ErrModel& err, int hd, double scz, double Lz, float* thrh, float* gh, float* gminh,
+                           float* rrow = nullptr);
+// bound pass of the two-stage collect (gt_sym.hip cell_ball_kernel): the units the cell bounds cannot rule out -> queue
+int gt_sym_bound_queue(gt_ctx* ctx, int64_t n_pad_s, const void* Ys, const float* rrow, DevBuf& work, uint2* queue,
+                       uint32_t cap, uint32_t* count_dev);
 // row-sharded symmetric pass (gt_knn_shard.cpp)
 #define GT_SYM_MAX_WORLD 64
 int gt_sym_g_from_thr(gt_ctx* ctx, int64_t n_pad_s, const float* thr, const float* hs, float* g, float* gmin);

@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void affinity_kernel(
     double* xs = reinterpret_cast<double*>(smem_raw) + size_t(w) * d;
     const int64_t wi = int64_t(blockIdx.x) * 4 + w;
     if (wi >= nrows) return;
-    const int64_t i = RADIUS ? int64_t(row_list[wi]) : wi;
+    const int64_t i = RADIUS ? int64_t(row_list[wi]) - qoff : wi;   // (the list holds rows of the query matrix: qoff + i)
     const int32_t src = rowsrc[i];
     if (RADIUS != (src >= 0)) return;   // (the other launch's row)
     const double bwi = bw[i];

@@ -26,6 +26,8 @@
 #include "gt_knn_select.h"
 
 #include <algorithm>
+#include <cstdio>
+#include <vector>
 
 namespace {
 
@@ -543,10 +545,14 @@ __global__ __launch_bounds__(256) void sym_half_thresholds_kernel(const int64_t 
                                                                   const float* __restrict__ hh,
                                                                   const double* __restrict__ ymax2p, const ErrModel err,
                                                                   const int HD, const double scz, const double Lz,
-                                                                  float* __restrict__ thrh, float* __restrict__ gh) {
+                                                                  float* __restrict__ thrh, float* __restrict__ gh,
+                                                                  float* __restrict__ rrow) {
     const int64_t p = int64_t(blockIdx.x) * 256 + threadIdx.x;
     if (p >= n_pad) return;
     float th = INFINITY, g = INFINITY;
+    // rrow: how far apart (rows of the full compact copy) a pair can be that row p needs listed, rounded up; -inf: the
+    // row needs nothing (orphan, pad row), +inf: everything
+    float rr = -INFINITY;
     if (p < n) {
         const float t = thr[p];
         if (t == INFINITY) {
@@ -554,6 +560,7 @@ __global__ __launch_bounds__(256) void sym_half_thresholds_kernel(const int64_t 
         } else if (!(t > -3.0e38f)) {
             th = -3.0e38f;   // no threshold was seeded for this row: everything passes, as in the full test
             g = -3.0e38f;
+            rr = INFINITY;
         } else {
             const double u = 5.9604644775390625e-08;
             const double qs = xn[perm[p]], y2 = ymax2p[0];
@@ -566,6 +573,14 @@ __global__ __launch_bounds__(256) void sym_half_thresholds_kernel(const int64_t 
             const double X2 = (sc * sqrt(y2) + Ls) * (sc * sqrt(y2) + Ls);
             const double dmax = (2.0 * double(HD + 8) * 1.5 + 4.0) * u * X2;
             const double r = sc * sqrt(lb) + 2.0 * Ls;
+            {
+                // the same radius among the rows of the FULL compact copy (scale 1 / sqrt(inv_sc2), residual norms up to
+                // err.abs before scaling): what the bound pass measures its cells in
+                const double scf = 1.0 / sqrt(err.inv_sc2), Lf = scf * err.abs;
+                const double rf = (scf * sqrt(lb) + 2.0 * Lf) * (1.0 + 1e-9);
+                rr = float(rf);
+                if (double(rr) <= rf) rr = nextafterf(rr, INFINITY);
+            }
             const double rho = 0.5 * r * r + dmax;
             const double a = -double(hh[p]) - rho, b = -rho;
             th = float(a);
@@ -578,6 +593,7 @@ __global__ __launch_bounds__(256) void sym_half_thresholds_kernel(const int64_t 
     }
     thrh[p] = th;
     gh[p] = g;
+    if (rrow) rrow[p] = rr;
 }
 
 // How many (64-query group, 32-row sub-tile) pairs would pass stage one?  One wave per pseudo-randomly drawn pair (lane =
@@ -730,6 +746,226 @@ __global__ __launch_bounds__(256) void shard_scatter_kernel(const uint4* __restr
     if (slot < uint32_t(tcap)) lists[size_t(r.x) * size_t(tcap) + slot] = (uint64_t(r.w) << 32) | uint64_t(r.z);
 }
 
+
+// ---- bound pass of the two-stage collect: whole cells instead of pairs of rows -----------------------------------------
+// The collect asks of every pair of rows whether they are closer than either row's radius rrow (what the thresholds
+// encode).  The points are sorted by landmark cell, and a cell is a compact set: with the centre c and radius R of a
+// cell's rows (in the float16 compact copy the candidate kernels score), no row of cell A is closer to a row of cell B
+// than |c_A - c_B| - R_A - R_B.  When that exceeds the largest radius of either cell, NO pair of the two cells can be one
+// either row needs - by the triangle inequality, for whatever centres were chosen - and the (64 queries, 32 rows) units
+// made of their rows need neither the unit loop nor the cold pass.  On clustered data that is nearly every unit: the
+// bound pass lists the units that are left straight into the queue of the cold launch and the collect launch does not
+// run.  (All DP columns: the 16 columns of stage one keep a quarter of the squared distance between two cluster centres
+// and a quarter of a cell's squared radius, but the rows' radii do not shrink - too many cell pairs stay undecided.
+// Centres are float32 means, distances and radii are evaluated in float64 from those stored values; radii are rounded
+// up, the comparison carries a relative margin.)
+__global__ __launch_bounds__(256) void cell_ball_kernel(const _Float16* __restrict__ Ys, const int DP,
+                                                        const float* __restrict__ rrow,
+                                                        const int32_t* __restrict__ start, const int32_t* __restrict__ endp,
+                                                        float* __restrict__ centre, float* __restrict__ radius,
+                                                        float* __restrict__ need) {
+    __shared__ float part[4][128];
+    __shared__ float cs[128];
+    __shared__ double red[4];
+    __shared__ float redn[4];
+    const int c = blockIdx.x;
+    const int s0 = start[c], s1 = endp[c];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (s0 < 0 || s1 <= s0) {   // empty cell: never looked up
+        for (int k = threadIdx.x; k < DP; k += 256) centre[size_t(c) * DP + k] = 0.f;
+        if (threadIdx.x == 0) {
+            radius[c] = 0.f;
+            need[c] = -INFINITY;
+        }
+        return;
+    }
+    // wave w takes the rows w, w + 4, ...; lane l the columns l and l + 64
+    float a0 = 0.f, a1 = 0.f;
+    for (int p = s0 + w; p < s1; p += 4) {
+        if (lane < DP) a0 += float(Ys[size_t(p) * DP + lane]);
+        if (lane + 64 < DP) a1 += float(Ys[size_t(p) * DP + lane + 64]);
+    }
+    part[w][lane] = a0;
+    part[w][lane + 64] = a1;
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const float t = (part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]) / float(s1 - s0);
+        cs[threadIdx.x] = t;
+        if (threadIdx.x < DP) centre[size_t(c) * DP + threadIdx.x] = t;
+    }
+    __syncthreads();
+    const double c0 = double(cs[lane]), c1 = double(cs[lane + 64]);
+    double rmax = 0.0;
+    float nmax = -INFINITY;
+    for (int p = s0 + w; p < s1; p += 4) {
+        const double d0 = lane < DP ? double(float(Ys[size_t(p) * DP + lane])) - c0 : 0.0;
+        const double d1 = lane + 64 < DP ? double(float(Ys[size_t(p) * DP + lane + 64])) - c1 : 0.0;
+        double d2 = fma(d0, d0, d1 * d1);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) d2 += __shfl_xor(d2, o);
+        rmax = fmax(rmax, sqrt(d2));
+        nmax = fmaxf(nmax, rrow[p]);
+    }
+    if (lane == 0) {
+        red[w] = rmax;
+        redn[w] = nmax;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double r = fmax(fmax(red[0], red[1]), fmax(red[2], red[3])) * (1.0 + 1e-9);
+        float rf = float(r);
+        if (double(rf) < r) rf = nextafterf(rf, INFINITY);
+        radius[c] = rf;
+        need[c] = fmaxf(fmaxf(redn[0], redn[1]), fmaxf(redn[2], redn[3]));
+    }
+}
+
+// bit b of word mask[a][b / 32]: no row of cell a and row of cell b can be a pair either of them needs.
+// Workgroup = 64 cells a x 256 cells b: thread t keeps the centre of cell b0 + t in registers, the centres of the a's come
+// from the LDS (broadcast reads).  Float32: a difference of two stored floats is rounded once, the squares are summed
+// without cancellation - relative error below (DP + 2) 2^-23 - and the comparison carries a margin of 1e-4.
+template <int DPC>
+__global__ __launch_bounds__(256) void cell_mask_kernel(const int L, const float* __restrict__ centre,
+                                                        const float* __restrict__ radius, const float* __restrict__ need,
+                                                        uint32_t* __restrict__ mask) {
+    __shared__ float ca[64][DPC];
+    const int words = (L + 31) / 32;
+    const int a0 = blockIdx.y * 64, b = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    for (int f = threadIdx.x; f < 64 * DPC; f += 256) {
+        const int a = a0 + f / DPC;
+        ca[f / DPC][f % DPC] = a < L ? centre[size_t(a) * DPC + f % DPC] : 0.f;
+    }
+    float cb[DPC];
+    const int bc = b < L ? b : L - 1;
+#pragma unroll
+    for (int q = 0; q < DPC; ++q) cb[q] = centre[size_t(bc) * DPC + q];
+    const float Rb = radius[bc], nb = need[bc];
+    __syncthreads();
+    for (int i = 0; i < 64; ++i) {
+        const int a = a0 + i;
+        if (a >= L) break;   // uniform
+        float d2 = 0.f;
+#pragma unroll
+        for (int q = 0; q < DPC; ++q) {
+            const float df = ca[i][q] - cb[q];
+            d2 = fmaf(df, df, d2);
+        }
+        const float nd = fmaxf(need[a], nb);
+        // (need = -inf on both sides: the cells need nothing at all; +inf: never prunable)
+        const bool pr = nd == -INFINITY ||
+                        double(sqrtf(d2)) * (1.0 - 1e-4) - (double(radius[a]) + double(Rb)) > double(nd) * (1.0 + 1e-6);
+        const unsigned long long m = __ballot(pr && b < L);
+        const int wd = (blockIdx.x * 256 + (threadIdx.x & ~63)) / 32;
+        if (lane == 0 && wd < words) mask[size_t(a) * words + wd] = uint32_t(m);
+        if (lane == 32 && wd + 1 < words) mask[size_t(a) * words + wd + 1] = uint32_t(m >> 32);
+    }
+}
+
+// first and last cell of the rows of every 32-row sub-tile of the sorted order (0xFFFF, 0: no real row)
+__global__ __launch_bounds__(256) void tile_cells_kernel(const uint32_t* __restrict__ cell_sorted, const int64_t n,
+                                                         const int64_t ntile32, uint32_t* __restrict__ tcell) {
+    const int64_t t = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (t >= ntile32) return;
+    const int64_t p0 = t * 32;
+    if (p0 >= n) {
+        tcell[t] = 0xFFFFu;
+        return;
+    }
+    const int64_t p1 = p0 + 31 < n ? p0 + 31 : n - 1;
+    tcell[t] = (cell_sorted[p0] & 0xFFFFu) | (cell_sorted[p1] << 16);
+}
+
+// The units (64 queries q64, 32 rows d32) of the collect launch's walks that the cell bounds cannot rule out -> queue.
+// One wave per q64.  For each cell a of its queries the lanes read the words of mask row a; every undecided cell b
+// (zero bit) contributes the sub-tiles its rows lie in - those that belong to the walk of q64's 1024-row block (own
+// block, H following blocks, the antipodal one when NB is even: knn_select_kernel<MODE 2> with two-stage scoring).  A
+// sub-tile (or the queries) can straddle cells: a unit is filed by the FIRST undecided pair (a, b) of its cell ranges.
+__global__ __launch_bounds__(64) void bound_queue_kernel(const int T, const int TPB, const int walk, const int L,
+                                                         const uint32_t* __restrict__ tcell,
+                                                         const int32_t* __restrict__ start, const int32_t* __restrict__ endp,
+                                                         const uint32_t* __restrict__ mask, const int words,
+                                                         uint2* __restrict__ queue, const uint32_t cap,
+                                                         uint32_t* __restrict__ count) {
+    const int lane = threadIdx.x;
+    const uint32_t q64 = blockIdx.x;
+    const int blk = int(q64) / (TPB * 2);   // (a 1024-row block = TPB 128-row tiles = 2 TPB groups of 64 queries)
+    const uint32_t qa = tcell[2 * q64], qb = tcell[2 * q64 + 1];
+    // cells of the 64 queries: [lo, hi] over the two sub-tiles that hold real rows
+    uint32_t qlo = 0xFFFFu, qhi = 0u;
+    if ((qa & 0xFFFFu) != 0xFFFFu) {
+        qlo = qa & 0xFFFFu;
+        qhi = qa >> 16;
+    }
+    if ((qb & 0xFFFFu) != 0xFFFFu) {
+        if ((qb & 0xFFFFu) < qlo) qlo = qb & 0xFFFFu;
+        if ((qb >> 16) > qhi) qhi = qb >> 16;
+    }
+    if (qlo == 0xFFFFu) return;   // pad queries only
+    auto open_pair = [&](const uint32_t a, const uint32_t b) {
+        return ((mask[size_t(a) * words + (b >> 5)] >> (b & 31u)) & 1u) == 0u;
+    };
+    // two rounds: count this wave's units, take their slots with ONE atomic (a device-scope counter serves ~90 returning
+    // atomics per microsecond: one per unit would cost more than the collect launch saves), then write them
+    uint32_t mine = 0u, slot = 0u;
+  for (int round = 0; round < 2; ++round) {
+    if (round == 1) {
+        uint32_t inc = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t up = uint32_t(__shfl_up(int(inc), o));
+            if (lane >= o) inc += up;
+        }
+        const uint32_t total = uint32_t(__shfl(int(inc), 63));
+        if (total == 0u) return;
+        uint32_t base = 0u;
+        if (lane == 0) base = atomicAdd(count, total);
+        base = uint32_t(__shfl(int(base), 0));
+        slot = base + inc - mine;
+    }
+    for (uint32_t a = qlo; a <= qhi; ++a) {
+        for (int w0 = 0; w0 < words; w0 += 64) {
+            const int wd = w0 + lane;
+            uint32_t zero = 0u;
+            if (wd < words) {
+                zero = ~mask[size_t(a) * words + wd];
+                if (wd * 32 + 32 > L) zero &= (L - wd * 32 >= 32) ? 0xFFFFFFFFu : ((1u << (L - wd * 32)) - 1u);
+            }
+            while (zero != 0u) {
+                const uint32_t b = uint32_t(wd) * 32u + uint32_t(__ffs(int(zero)) - 1);
+                zero &= zero - 1u;
+                const int sb0 = start[b], sb1 = endp[b];
+                if (sb0 < 0 || sb1 <= sb0) continue;   // empty cell
+                for (uint32_t d32 = uint32_t(sb0) / 32u; d32 <= uint32_t(sb1 - 1) / 32u; ++d32) {
+                    int rel = int(d32 / 4u) - blk * TPB;
+                    if (rel < 0) rel += T;
+                    if (rel >= walk) continue;   // not this block's unit (the other block's walk has it)
+                    // first undecided pair of (cells of the queries) x (cells of the sub-tile) files the unit
+                    const uint32_t dc = tcell[d32];
+                    const uint32_t dlo = dc & 0xFFFFu, dhi = dc >> 16;
+                    bool first = true;
+                    for (uint32_t a2 = qlo; a2 <= a && first; ++a2)
+                        for (uint32_t b2 = dlo; b2 <= dhi; ++b2) {
+                            if (a2 == a && b2 >= b) break;
+                            if (open_pair(a2, b2)) {
+                                first = false;
+                                break;
+                            }
+                        }
+                    if (!first) continue;
+                    if (round == 0) {
+                        ++mine;
+                    } else {
+                        if (slot < cap) queue[slot] = make_uint2(q64, d32);
+                        ++slot;
+                    }
+                }
+            }
+        }
+    }
+  }
+}
+
 }  // namespace
 
 int gt_sym_gather(gt_ctx* ctx, const int32_t* perm, int64_t n_pad_s, void* Ys, float* hs) {
@@ -842,9 +1078,10 @@ int gt_sym_sample_cov(gt_ctx* ctx, int64_t step, int64_t ns, double* sums_dev, d
 }
 
 int gt_sym_half_thresholds(gt_ctx* ctx, const int32_t* perm, int64_t n_pad_s, const float* thr, const float* hh,
-                           const ErrModel& err, int hd, double scz, double Lz, float* thrh, float* gh, float* gminh) {
+                           const ErrModel& err, int hd, double scz, double Lz, float* thrh, float* gh, float* gminh,
+                           float* rrow) {
     hipLaunchKernelGGL(sym_half_thresholds_kernel, dim3((unsigned)ceil_div64(n_pad_s, 256)), dim3(256), 0, ctx->stream, ctx->n,
-                       n_pad_s, perm, ctx->xn.as<double>(), thr, hh, ctx->ymax.as<double>(), err, hd, scz, Lz, thrh, gh);
+                       n_pad_s, perm, ctx->xn.as<double>(), thr, hh, ctx->ymax.as<double>(), err, hd, scz, Lz, thrh, gh, rrow);
     GT_HIP(ctx, hipGetLastError());
     hipLaunchKernelGGL(sym_gmin_kernel, dim3((unsigned)ceil_div64(n_pad_s, 256)), dim3(256), 0, ctx->stream, n_pad_s, gh, gminh);
     GT_HIP(ctx, hipGetLastError());
@@ -857,6 +1094,89 @@ int gt_sym_two_probe(gt_ctx* ctx, const void* Ys, int hd, const float* hh, const
     GT_HIP(ctx, hipMemsetAsync(flagged, 0, sizeof(uint32_t), ctx->stream));
     hipLaunchKernelGGL(sym_two_probe_kernel, dim3((unsigned)ceil_div64(samples, 4)), dim3(256), 0, ctx->stream,
                        reinterpret_cast<const _Float16*>(Ys), ctx->n, kZ, hd, hh, thrh, gh, samples, flagged);
+    GT_HIP(ctx, hipGetLastError());
+    return GT_OK;
+}
+
+// Bound pass (see cell_ball_kernel): fills `queue` (capacity cap entries) with the units of the two-stage collect's
+// walks (1024-row query blocks, 128-row tiles) that the cell bounds leave, *count = how many there are (beyond cap: the
+// caller runs the collect launch instead).  Ys: the sorted compact copy [n_pad][DP] float16, rrow: the rows' radii in
+// it; work: scratch.
+int gt_sym_bound_queue(gt_ctx* ctx, int64_t n_pad_s, const void* Ys, const float* rrow, DevBuf& work, uint2* queue,
+                       uint32_t cap, uint32_t* count_dev) {
+    const int L = ctx->order_L;
+    if (L <= 0 || L > 65535) GT_FAIL(ctx, GT_E_STATE, "bound pass: no landmark cells");
+    if (n_pad_s % 1024 != 0) GT_FAIL(ctx, GT_E_ARG, "bound pass: whole 1024-row query blocks");
+    const int words = (L + 31) / 32;
+    const int64_t nt32 = n_pad_s / 32;
+    const int DP = ctx->DP;
+    if (DP > 128) GT_FAIL(ctx, GT_E_ARG, "bound pass: at most 128 padded features");
+    // work: start [L] | end [L] | centre [L][DP] | radius [L] | need [L] | mask [L][words] | tcell [n_pad / 32]
+    const size_t bytes = (size_t(L) * (2 + DP + 2) + size_t(L) * words + size_t(nt32)) * 4;
+    GT_HIP(ctx, work.reserve(bytes));
+    int32_t* start = work.as<int32_t>();
+    int32_t* endp = start + L;
+    float* centre = reinterpret_cast<float*>(endp + L);
+    float* radius = centre + size_t(L) * DP;
+    float* need = radius + L;
+    uint32_t* mask = reinterpret_cast<uint32_t*>(need + L);
+    uint32_t* tcell = mask + size_t(L) * words;
+    const uint32_t* cell_sorted = ctx->order_cell.as<uint32_t>() + ctx->n;
+    GT_HIP(ctx, hipMemsetAsync(start, 0xFF, 2 * size_t(L) * sizeof(int32_t), ctx->stream));   // -1: empty cell
+    GT_HIP(ctx, hipMemsetAsync(count_dev, 0, sizeof(uint32_t), ctx->stream));
+    hipLaunchKernelGGL(cell_ranges_kernel, dim3((unsigned)ceil_div64(ctx->n, 256)), dim3(256), 0, ctx->stream, cell_sorted,
+                       ctx->n, start, endp);
+    hipLaunchKernelGGL(cell_ball_kernel, dim3((unsigned)L), dim3(256), 0, ctx->stream, reinterpret_cast<const _Float16*>(Ys),
+                       DP, rrow, start, endp, centre, radius, need);
+    {
+        const dim3 grid((unsigned)ceil_div64(L, 256), (unsigned)ceil_div64(L, 64));
+#define GT_MASK_CASE(DPC_)                                                                                               \
+    case DPC_:                                                                                                           \
+        hipLaunchKernelGGL(cell_mask_kernel<DPC_>, grid, dim3(256), 0, ctx->stream, L, centre, radius, need, mask);      \
+        break;
+        switch (DP) {
+            GT_MASK_CASE(16) GT_MASK_CASE(32) GT_MASK_CASE(48) GT_MASK_CASE(64) GT_MASK_CASE(80) GT_MASK_CASE(96)
+            GT_MASK_CASE(112) GT_MASK_CASE(128)
+            default: GT_FAIL(ctx, GT_E_ARG, "bound pass: unexpected padded feature count");
+        }
+#undef GT_MASK_CASE
+    }
+    hipLaunchKernelGGL(tile_cells_kernel, dim3((unsigned)ceil_div64(nt32, 256)), dim3(256), 0, ctx->stream, cell_sorted, ctx->n,
+                       nt32, tcell);
+    GT_HIP(ctx, hipGetLastError());
+    if (ctx->dbg_select & 2048) {   // development: what the cells look like
+        std::vector<float> rad(L), nd(L);
+        std::vector<uint32_t> mk(size_t(L) * words);
+        std::vector<int32_t> st(2 * size_t(L));
+        GT_HIP(ctx, hipMemcpyAsync(rad.data(), radius, L * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+        GT_HIP(ctx, hipMemcpyAsync(nd.data(), need, L * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+        GT_HIP(ctx, hipMemcpyAsync(mk.data(), mask, mk.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        GT_HIP(ctx, hipMemcpyAsync(st.data(), start, st.size() * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+        GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        std::vector<float> r2, n2;
+        int64_t open_pairs = 0, infn = 0, empty = 0;
+        for (int c = 0; c < L; ++c) {
+            if (st[c] < 0) {
+                ++empty;
+                continue;
+            }
+            r2.push_back(rad[c]);
+            if (nd[c] == INFINITY) ++infn;
+            else if (nd[c] > -INFINITY) n2.push_back(nd[c]);
+            for (int b = 0; b < L; ++b)
+                if (st[b] >= 0 && !((mk[size_t(c) * words + (b >> 5)] >> (b & 31)) & 1u)) ++open_pairs;
+        }
+        std::sort(r2.begin(), r2.end());
+        std::sort(n2.begin(), n2.end());
+        auto q = [](const std::vector<float>& v, double f) { return v.empty() ? 0.f : v[size_t(f * (v.size() - 1))]; };
+        fprintf(stderr, "[gt] bound pass cells: %d (%lld empty), radius min/median/90%%/max %.4g %.4g %.4g %.4g, need median/90%%/99%%/max %.4g %.4g %.4g %.4g (%lld cells need everything), undecided cell pairs %lld\n",
+                L, (long long)empty, q(r2, 0), q(r2, 0.5), q(r2, 0.9), q(r2, 1.0), q(n2, 0.5), q(n2, 0.9), q(n2, 0.99), q(n2, 1.0),
+                (long long)infn, (long long)open_pairs);
+    }
+    const int T = int(n_pad_s / 128), TPB = 8, NB = T / TPB, H = (NB - 1) / 2;
+    const int walk = TPB * (1 + H) + ((NB & 1) ? 0 : (NB > 1 ? TPB : 0));
+    hipLaunchKernelGGL(bound_queue_kernel, dim3((unsigned)(NB * 2 * TPB)), dim3(64), 0, ctx->stream, T, TPB, walk, L, tcell, start,
+                       endp, mask, words, queue, cap, count_dev);
     GT_HIP(ctx, hipGetLastError());
     return GT_OK;
 }

@@ -186,12 +186,46 @@ def test_two_stage_queue_spills_and_its_overflow_starts_over_with_the_one_stage_
     launch drops pairs, says so, and the one-stage kernel runs instead"""
     X = make_mix(70000, 64, 14)
     ref, _, _ = _build(X, {"select_symmetric": 0})
-    spilled, st, _ = _build(X, {"select_sym_two_stage": 1, "select_sym_queue_cap": 2})
-    assert st["symmetric"] and st["sym_two_stage"] and st["sym_cold_pairs"] > 0
+    spilled, st, _ = _build(X, {"select_sym_two_stage": 1, "select_sym_bounds": 0, "select_sym_queue_cap": 2})
+    assert st["symmetric"] and st["sym_two_stage"] and st["sym_cold_pairs"] > 0 and not st["sym_bound_pass"]
     _same_csr(spilled, ref)
-    small, st, _ = _build(X, {"select_sym_two_stage": 1, "select_sym_queue_cap": 2, "select_sym_spill_cap": 16})
+    small, st, _ = _build(X, {"select_sym_two_stage": 1, "select_sym_bounds": 0, "select_sym_queue_cap": 2,
+                              "select_sym_spill_cap": 16})
     assert st["symmetric"] and not st["sym_two_stage"]
     _same_csr(small, ref)
+
+
+def test_bound_pass_lists_the_units_of_the_cold_launch_without_a_collect_launch():
+    """clustered points: whole landmark cells rule out nearly every (64 queries, 32 rows) unit by the triangle inequality;
+    what is left goes straight to the cold launch.  Same graph as with the collect launch and as the classic pass."""
+    X = make_mix(150000, 64, 16)
+    bound, st, _ = _build(X, {"select_sym_two_stage": 1})
+    assert st["symmetric"] and st["sym_two_stage"] and st["sym_bound_pass"] and st["sym_cold_pairs"] > 0
+    n_bound = st["sym_cold_pairs"]
+    coll, st, _ = _build(X, {"select_sym_two_stage": 1, "select_sym_bounds": 0})
+    assert st["sym_two_stage"] and not st["sym_bound_pass"]
+    ref, _, _ = _build(X, {"select_symmetric": 0})
+    _same_csr(bound, coll)
+    _same_csr(bound, ref)
+    # the bounds are no tighter than stage one by much, and far from the 150000^2 / 4096 units there are
+    assert n_bound < 150000 ** 2 / 4096 / 20
+
+
+def test_bound_pass_gives_way_to_the_collect_launch_when_the_cells_decide_too_little():
+    X = make_mix(70000, 64, 17)
+    few, st, _ = _build(X, {"select_sym_two_stage": 1, "select_sym_bound_cap": 100})
+    assert st["symmetric"] and st["sym_two_stage"] and not st["sym_bound_pass"]
+    ref, _, _ = _build(X, {"select_symmetric": 0})
+    _same_csr(few, ref)
+
+
+@pytest.mark.parametrize("maker,d", [(make_gauss, 64), (make_manifold, 64), (make_mix, 40)])
+def test_bound_pass_on_small_forced_cases(sym_ctx, maker, d):
+    """unclustered / low-dimensional / 48 padded features, ragged last block: whatever the cells decide, the kNN are exact"""
+    sym_ctx.set_option("select_sym_two_stage", "1")
+    sym_ctx.set_option("select_sym_bounds", "1")
+    st = _knn(sym_ctx, maker(5003, d, 18), 15)
+    assert st["sym_two_stage"]
 
 
 def test_orphan_rows_are_repaired_from_their_seeds():

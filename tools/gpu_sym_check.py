@@ -14,7 +14,7 @@ sys.path.insert(0, ROOT)
 import oracle  # noqa: E402
 from graphtools_amd import _hip  # noqa: E402
 
-STAGES = ("prep", "query_order", "sym_prepare", "sym_seed", "knn_select", "sym_cold", "rerank", "fallback", "radius", "affinity",
+STAGES = ("prep", "query_order", "sym_prepare", "sym_seed", "sym_bound", "knn_select", "sym_cold", "rerank", "fallback", "radius", "affinity",
           "symmetrize", "normalize")
 
 
