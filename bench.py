@@ -55,8 +55,10 @@ def make_mix(n, d, seed, dtype=np.float32):
 
 
 SYM_KERNEL = "knn_select_kernel<64, 8, 2, 2>"   # symmetric collect (single float16 chain), one-stage
-SYM2_KERNEL = "knn_select_kernel<64, 8, 3, 2>"  # symmetric collect, two-stage: 16 features in the unit loop ...
+SYM2_KERNEL = "knn_select_kernel<16, 8, 3, 2>"  # symmetric collect, two-stage: 16 features in the unit loop ...
 SYM_COLD_KERNEL = "sym_cold_kernel<64>"         # ... survivors scored in full by the cold launch
+SYM_SEED_KERNEL = "knn_select_kernel<64, 8, 0, 2>"   # threshold-seeding launch of the symmetric pass
+BOUND_KERNELS = ("cell_ball_kernel", "cell_mask_kernel<64>", "bound_queue_kernel")   # bound pass (replaces the collect launch)
 
 
 def measured_traffic(n, d, precision, world, symmetric):
@@ -67,9 +69,14 @@ def measured_traffic(n, d, precision, world, symmetric):
         return None
     try:
         if symmetric:
+            # every launch of the candidate pass that the profiled run made: seeding, bound pass or collect, cold launch
             with open(os.path.join(ROOT, "profiles", "r2_pmc_fetch_write_per_kernel.json")) as f:
                 ks = json.load(f)["kernels"]
-                k = ks[SYM2_KERNEL] if SYM2_KERNEL in ks else ks[SYM_KERNEL]
+            tot = 0.0
+            for name, k in ks.items():
+                if name in (SYM_SEED_KERNEL, SYM2_KERNEL, SYM_KERNEL, SYM_COLD_KERNEL) or any(name.endswith(b) or b in name for b in BOUND_KERNELS):
+                    tot += (k["hbm_read_GB_per_launch_corrected_x2"] + k["hbm_write_GB_per_launch"]) * k.get("launches", 1)
+            return tot * 1e9
         else:
             name = {"f16x1": "f16x1", "f16": "f16split"}[precision]
             with open(os.path.join(ROOT, "profiles", "r1_pmc_fetch_write_per_kernel_%s.json" % name)) as f:
@@ -198,12 +205,13 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    select_ms, seed_ms, cold_ms = [], [], []
+    select_ms, seed_ms, cold_ms, bound_ms = [], [], [], []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         nnz, flags = step()
         # stage timers were recorded with hipEvents on the library's own stream during the step
-        select_ms.append(ctx.stage_ms("knn_select"))
+        select_ms.append(max(ctx.stage_ms("knn_select"), 0.0))   # (-1: the bound pass listed the units, no collect launch)
+        bound_ms.append(max(ctx.stage_ms("sym_bound"), 0.0))
         seed_ms.append(max(ctx.stage_ms("sym_seed"), 0.0))
         cold_ms.append(max(ctx.stage_ms("sym_cold"), 0.0))
     fence()
@@ -228,8 +236,10 @@ def main():
         symmetric = bool(kst["symmetric"])
         main_ms, seeding_ms, cold_launch_ms = float(np.mean(select_ms)), float(np.mean(seed_ms)), float(np.mean(cold_ms))
         two_stage = symmetric and bool(kst.get("sym_two_stage", False))
-        # the candidate pass = all of its launches (seeding + collect [+ cold launch of the two-stage collect])
-        avg_ms = main_ms + (seeding_ms if symmetric else 0.0) + (cold_launch_ms if two_stage else 0.0)
+        bound_pass = two_stage and bool(kst.get("sym_bound_pass", False))
+        bound_launch_ms = float(np.mean(bound_ms)) if two_stage else 0.0
+        # the candidate pass = all of its launches (seeding + [bound pass] + [collect] [+ cold launch of the two-stage collect])
+        avg_ms = main_ms + (seeding_ms if symmetric else 0.0) + (cold_launch_ms if two_stage else 0.0) + bound_launch_ms
         achieved = flops / (avg_ms * 1e-3) / 1e12
         if symmetric:
             # executed matrix work: every unordered pair of (padded) rows once, plus the tiles of the seeding launch
@@ -241,8 +251,15 @@ def main():
                 n_pad = -(-n // 1024) * 1024
                 nb = n_pad // 1024
                 walk_tiles = 8 * (1 + (nb - 1) // 2) + (0 if nb % 2 else 8)
-                collect_flop = 2.0 * 16 * 1024 * 128 * nb * walk_tiles + 2.0 * d * 64 * 32 * kst.get("sym_cold_pairs", 0) * world
-                kname = SYM2_KERNEL + " + " + SYM_COLD_KERNEL
+                cold_flop = 2.0 * d * 64 * 32 * kst.get("sym_cold_pairs", 0) * world
+                if bound_pass:
+                    # the cell bounds decide the units: no unit loop over the pairs, only the units left are scored
+                    # (the bound kernels themselves: L^2 cell pairs x d flop, not counted)
+                    collect_flop = cold_flop
+                    kname = "bound pass (cell_ball / cell_mask / bound_queue kernels, no collect launch) + " + SYM_COLD_KERNEL
+                else:
+                    collect_flop = 2.0 * 16 * 1024 * 128 * nb * walk_tiles + cold_flop
+                    kname = SYM2_KERNEL + " + " + SYM_COLD_KERNEL
             else:
                 n_pad = -(-n // 256) * 256
                 nb = n_pad // 256
@@ -251,7 +268,9 @@ def main():
                 kname = SYM_KERNEL
             executed = (collect_flop + seed_flop) / world
             kernel_name = "%s + the threshold-seeding launch knn_select_kernel<64, 8, 0, 2> (symmetric f16x1 MFMA candidate " \
-                          "pass, knn_precision=%s): every unordered pair of rows scored once" % (kname, args.knn_precision)
+                          "pass, knn_precision=%s): every unordered pair of rows %s" % (
+                              kname, args.knn_precision,
+                              "decided once - by its cells' bound or by its score" if bound_pass else "scored once")
         else:
             executed = flops * MFMA_CHAINS[main]
             kernel_name = "%s (%s MFMA candidate pass, knn_precision=%s)" % (SELECT_KERNEL[main], main, args.knn_precision)
@@ -273,18 +292,18 @@ def main():
                                    "kernel_symm='+', device-complete K and P" % (n, d, args.knn, args.decay),
                        "row_sharding": "%d rank(s) x %d rows" % (world, nloc), "nnz_K": nnz_total,
                        "radius_rows_rank0": stats["radius_rows"], "fallback_rows_rank0": stats["fallback_rows"],
-                       "symmetric_candidate_pass": symmetric, "two_stage_collect": two_stage},
+                       "symmetric_candidate_pass": symmetric, "two_stage_collect": two_stage, "bound_pass": bound_pass},
             "roofline": {"kernel": kernel_name,
                          "bound": "mfma",
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "traffic": measured_traffic(n, d, main, world, symmetric), "traffic_unit": "bytes/launch",
                          "avg_launch_ms": avg_ms, "main_launch_ms": main_ms, "seeding_launch_ms": seeding_ms if symmetric else 0.0,
-                         "cold_launch_ms": cold_launch_ms if two_stage else 0.0,
+                         "cold_launch_ms": cold_launch_ms if two_stage else 0.0, "bound_pass_ms": bound_launch_ms,
                          "algorithmic_flop_per_launch": flops,
                          "executed_mfma_flop_per_launch": executed,
                          "executed_mfma_frac": executed / (avg_ms * 1e-3) / 1e12 / peak},
             "stage_ms_last_step": {s: round(ctx.stage_ms(s), 3) for s in
-                                   ("prep", "query_order", "sym_prepare", "sym_seed", "knn_select", "sym_cold", "rerank", "fallback",
+                                   ("prep", "query_order", "sym_prepare", "sym_seed", "sym_bound", "knn_select", "sym_cold", "rerank", "fallback",
                                     "radius", "affinity", "symmetrize", "normalize")},
         }
         if world == 1 and not args.no_cpu_baseline:
