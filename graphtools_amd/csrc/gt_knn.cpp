@@ -376,10 +376,42 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
                 k->sym_nseg = a.sym.nseg;
             }
             a.thr_in = k->thr_final.as<float>();
-            if (two_stage) GT_TRY(gt_sym_two_stage_prepare(ctx, perm, n_pad_s, em, need_m, a));
-            const bool two_now = a.sym.half_steps > 0;
-            // (the orphans it declared start their lists with the rows launch A kept for them)
-            if (two_now)
+            // Bound pass first: on clustered points the cells of the sorted order rule out nearly every (64 queries, 32
+            // rows) unit without looking at a row; what they leave goes straight to the cold launch, and neither the
+            // stage-one copy nor the collect launch is needed.  (More than 4 M units left: the unit loop is the better
+            // filter - its preparation follows, with the orphans already cut.)
+            bool bound_done = false, bound_tried = false;
+            uint32_t bound_left = 0;
+            k->sym_bound_used = false;
+            if (two_stage && ctx->sym_bounds != 0 && n_pad_s % 1024 == 0 && ctx->order_L > 0 && ctx->sym_two_stage != 0 &&
+                (ctx->sym_two_stage > 0 || ctx->sym_two_ok != 0)) {
+                const int64_t bcap = ctx->sym_bound_cap > 0 ? ctx->sym_bound_cap : (int64_t(1) << 22);
+                GT_HIP(ctx, k->sym_qdense.reserve(size_t(bcap) * sizeof(uint2)));
+                GT_HIP(ctx, k->sym_qtot.reserve(4 * sizeof(uint32_t)));
+                GT_HIP(ctx, k->sym_rrow.reserve(size_t(n_pad_s) * sizeof(float)));
+                {
+                    StageSpan span(ctx, "sym_bound");
+                    // the orphans lose their thresholds (a handful of rows: their radii would keep whole cells undecided),
+                    // the forms derived from the thresholds are made again
+                    GT_TRY(gt_sym_orphan_cut(ctx, perm, k->thr_final.as<float>(), k->sym_farcnt.as<float>(), em,
+                                             k->sym_racc.as<double>(), need_m, 0.25));
+                    GT_TRY(gt_sym_g_from_thr(ctx, n_pad_s, k->thr_final.as<float>(), k->hnegs.as<float>(), k->sym_g.as<float>(),
+                                             k->sym_gmin.as<float>()));
+                    GT_TRY(gt_sym_row_radius(ctx, perm, n_pad_s, k->thr_final.as<float>(), em, k->sym_rrow.as<float>()));
+                    GT_TRY(gt_sym_bound_queue(ctx, n_pad_s, k->Ycs.p, k->sym_rrow.as<float>(), k->sym_bwork,
+                                              k->sym_qdense.as<uint2>(), uint32_t(bcap), k->sym_qtot.as<uint32_t>()));
+                    GT_HIP(ctx, hipMemcpyAsync(&bound_left, k->sym_qtot.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+                }
+                GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                bound_tried = true;
+                bound_done = int64_t(bound_left) <= bcap;
+                if (ctx->dbg_select & 2048)
+                    fprintf(stderr, "[gt] bound pass: %u units left (capacity %lld)\n", bound_left, (long long)bcap);
+            }
+            if (two_stage && !bound_done) GT_TRY(gt_sym_two_stage_prepare(ctx, perm, n_pad_s, em, need_m, a, bound_tried));
+            const bool two_now = bound_done || a.sym.half_steps > 0;
+            // (the orphans that were declared start their lists with the rows launch A kept for them)
+            if (two_now || bound_tried)
                 GT_TRY(gt_sym_inject_orphans(ctx, 0, n_pad_s, k->thr_final.as<float>(), k->lists.as<uint64_t>(), int(lcap),
                                              k->counts.as<uint32_t>(), k->tlists.as<uint64_t>(), tcap, k->tcounts.as<uint32_t>()));
             if (two_now) {
@@ -394,39 +426,18 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
                     }
                     a.sym.nseg = k->sym_nseg = best;
                 }
-                GT_TRY(gt_sym_queue_prepare(ctx, n_pad_s, a));
+                if (!bound_done) GT_TRY(gt_sym_queue_prepare(ctx, n_pad_s, a));
             }
-            // Bound pass: on clustered points the cells of the sorted order rule out nearly every unit without looking at
-            // a row; what they leave goes straight to the cold launch and the collect launch does not run.  (More than
-            // 4 M units left: the unit loop is the better filter.)
-            bool bound_done = false;
-            k->sym_bound_used = false;
-            if (two_now && ctx->sym_bounds != 0 && n_pad_s % 1024 == 0 && ctx->order_L > 0) {
-                const int64_t bcap = ctx->sym_bound_cap > 0 ? ctx->sym_bound_cap : (int64_t(1) << 22);
-                GT_HIP(ctx, k->sym_qdense.reserve(size_t(bcap) * sizeof(uint2)));
-                GT_HIP(ctx, k->sym_qtot.reserve(4 * sizeof(uint32_t)));
-                uint32_t left = 0;
-                {
-                    StageSpan span(ctx, "sym_bound");
-                    GT_TRY(gt_sym_bound_queue(ctx, n_pad_s, k->Ycs.p, k->sym_rrow.as<float>(), k->sym_bwork,
-                                              k->sym_qdense.as<uint2>(), uint32_t(bcap), k->sym_qtot.as<uint32_t>()));
-                    GT_HIP(ctx, hipMemcpyAsync(&left, k->sym_qtot.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-                }
-                GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-                if (ctx->dbg_select & 2048)
-                    fprintf(stderr, "[gt] bound pass: %u units left (capacity %lld)\n", left, (long long)bcap);
-                if (int64_t(left) <= bcap) {
-                    StageSpan span(ctx, "sym_cold");
-                    SelectArgs dq = a;
-                    dq.mode = 4;
-                    dq.sym.queue = k->sym_qdense.as<uint2>();
-                    dq.sym.qn = int32_t(left);
-                    GT_TRY(gt_launch_select(ctx, dq));
-                    k->sym_cold_entries = int64_t(left);
-                    k->sym_bound_used = true;
-                    bound_done = true;
-                    if (ctx->sym_two_ok < 0) ctx->sym_two_ok = 1;
-                }
+            if (bound_done) {
+                StageSpan span(ctx, "sym_cold");
+                SelectArgs dq = a;
+                dq.mode = 4;
+                dq.sym.queue = k->sym_qdense.as<uint2>();
+                dq.sym.qn = int32_t(bound_left);
+                GT_TRY(gt_launch_select(ctx, dq));
+                k->sym_cold_entries = int64_t(bound_left);
+                k->sym_bound_used = true;
+                if (ctx->sym_two_ok < 0) ctx->sym_two_ok = 1;
             }
             if (!bound_done) {
                 StageSpan span(ctx, "knn_select");

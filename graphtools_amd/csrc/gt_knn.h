@@ -207,6 +207,8 @@ int gt_sym_queue_finish(gt_ctx* ctx, const SelectArgs& a, int64_t* entries, int*
 int gt_sym_half_thresholds(gt_ctx* ctx, const int32_t* perm, int64_t n_pad_s, const float* thr, const float* hh,
                            const ErrModel& err, int hd, double scz, double Lz, float* thrh, float* gh, float* gminh,
                            float* rrow = nullptr);
+// radius of every sorted row in the full compact copy (what a pair it needs listed can be apart at most)
+int gt_sym_row_radius(gt_ctx* ctx, const int32_t* perm, int64_t n_pad_s, const float* thr, const ErrModel& err, float* rrow);
 // bound pass of the two-stage collect (gt_sym.hip cell_ball_kernel): the units the cell bounds cannot rule out -> queue
 int gt_sym_bound_queue(gt_ctx* ctx, int64_t n_pad_s, const void* Ys, const float* rrow, DevBuf& work, uint2* queue,
                        uint32_t cap, uint32_t* count_dev);

@@ -529,6 +529,35 @@ __global__ __launch_bounds__(256) void sym_project_kernel(const T* __restrict__ 
     if (k == 0) hh[p] = p < n ? -0.5f * sq : -INFINITY;
 }
 
+// Radius of row p among the rows of the full compact copy: a pair either row needs listed (true squared distance below
+// the bound lb_p the re-rank will claim, see sym_half_thresholds_kernel) has float16 rows at most this far apart.  -inf:
+// the row needs nothing (orphan, pad row); +inf: no threshold was seeded, it needs everything.  Rounded up.
+__global__ __launch_bounds__(256) void sym_row_radius_kernel(const int64_t n, const int64_t n_pad,
+                                                             const int32_t* __restrict__ perm, const double* __restrict__ xn,
+                                                             const float* __restrict__ thr, const double* __restrict__ ymax2p,
+                                                             const ErrModel err, float* __restrict__ rrow) {
+    const int64_t p = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (p >= n_pad) return;
+    float rr = -INFINITY;
+    if (p < n) {
+        const float t = thr[p];
+        if (t == INFINITY) {
+        } else if (!(t > -3.0e38f)) {
+            rr = INFINITY;
+        } else {
+            const double qs = xn[perm[p]], y2 = ymax2p[0];
+            const double e = gt_err_bound(err, qs, y2);
+            double lb = (qs - 2.0 * (double(t) * err.inv_sc2 + e)) - 1e-9 * (qs + y2);
+            lb = (lb > 0.0 ? lb : 0.0) * (1.0 + 1e-6) + 1e-9 * (qs + y2);
+            const double scf = 1.0 / sqrt(err.inv_sc2), Lf = scf * err.abs;
+            const double rf = (scf * sqrt(lb) + 2.0 * Lf) * (1.0 + 1e-9);
+            rr = float(rf);
+            if (double(rr) <= rf) rr = nextafterf(rr, INFINITY);
+        }
+    }
+    rrow[p] = rr;
+}
+
 // ---- two-stage scoring of launch B (partial distances) -----------------------------------------------------------
 // Thresholds of the partial test from the full thresholds thr[p] (sorted positions).  The re-rank will claim for row p
 // "every row closer than lb_p is in the list", lb_p = |x|^2 - 2 (thr_p / sc^2 + e) - 1e-9 (...) (rerank_sym_kernel,
@@ -1177,6 +1206,13 @@ int gt_sym_bound_queue(gt_ctx* ctx, int64_t n_pad_s, const void* Ys, const float
     const int walk = TPB * (1 + H) + ((NB & 1) ? 0 : (NB > 1 ? TPB : 0));
     hipLaunchKernelGGL(bound_queue_kernel, dim3((unsigned)(NB * 2 * TPB)), dim3(64), 0, ctx->stream, T, TPB, walk, L, tcell, start,
                        endp, mask, words, queue, cap, count_dev);
+    GT_HIP(ctx, hipGetLastError());
+    return GT_OK;
+}
+
+int gt_sym_row_radius(gt_ctx* ctx, const int32_t* perm, int64_t n_pad_s, const float* thr, const ErrModel& err, float* rrow) {
+    hipLaunchKernelGGL(sym_row_radius_kernel, dim3((unsigned)ceil_div64(n_pad_s, 256)), dim3(256), 0, ctx->stream, ctx->n, n_pad_s,
+                       perm, ctx->xn.as<double>(), thr, ctx->ymax.as<double>(), err, rrow);
     GT_HIP(ctx, hipGetLastError());
     return GT_OK;
 }

@@ -175,10 +175,14 @@ def test_two_stage_forecast_declines_where_partial_distances_do_not_separate():
     """a 5-dimensional manifold under a random projection: 16 of 64 features carry a quarter of every distance, a fifth of
     the sampled pairs would pass stage one - the one-stage kernel runs, no pass is wasted, the graph is the classic one"""
     X = make_manifold(100000, 64, 13)
-    auto, st, _ = _build(X, {"select_sym_min_rows": 1})
+    auto, st, _ = _build(X, {"select_sym_min_rows": 1, "select_sym_bounds": 0})
     classic, _, _ = _build(X, {"select_symmetric": 0})
     assert st["symmetric"] and not st["sym_two_stage"]
     _same_csr(auto, classic)
+    # with the bound pass in front (the default) the cells may or may not decide enough - the graph is the same
+    withb, st, _ = _build(X, {"select_sym_min_rows": 1})
+    assert st["symmetric"]
+    _same_csr(withb, classic)
 
 
 def test_two_stage_queue_spills_and_its_overflow_starts_over_with_the_one_stage_kernel():
