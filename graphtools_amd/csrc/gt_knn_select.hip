@@ -1236,6 +1236,9 @@ __global__ __launch_bounds__(256) void sym_queue_spill_kernel(const uint2* __res
 // against the 32 database rows [32 d32, 32 d32 + 32).  Operands come straight from the sorted compact copy; the block
 // is scored exactly as the collect kernel's own cold path scores it (same chain, same seeds), then tested and filed
 // by the same code (GT_ADMIT2P).
+#ifndef GT_SEL_COLD_EPW
+#define GT_SEL_COLD_EPW 16   // queue entries per wave of the cold launch (consecutive entries mostly share their queries)
+#endif
 template <int DP>
 __global__ __launch_bounds__(256, 3) void sym_cold_kernel(const float* __restrict__ Yp, const float* __restrict__ hneg,
                                                        const float* __restrict__ thr_in, const int32_t nq,
@@ -1243,45 +1246,55 @@ __global__ __launch_bounds__(256, 3) void sym_cold_kernel(const float* __restric
     using C = SelCfg<DP, 2>;
     constexpr int QT = 2;
     const int lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
-    const int64_t en_ = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
-    if (en_ >= int64_t(sy.qn)) return;
-    const uint2 ent = sy.queue[en_];
-    const int64_t qblock = int64_t(ent.x) * (QT * 32);
+    const int64_t en0 = (int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6)) * GT_SEL_COLD_EPW;
+    if (en0 >= int64_t(sy.qn)) return;
     const int w = 0;
-    const uint32_t tbase = ent.y * 32u;
-    // does the sub-tile's block take these queries as ITS candidates too?  (position of its tile in the walk of the
-    // queries' block, as in the collect kernel)
     constexpr int BQ = 128 * GT_SEL_TWO_QT, TPB = BQ / C::BN;   // query blocks of the collect launch
     const int T = ntiles, NB = T / TPB, H = (NB - 1) / 2;
-    int rel = int(ent.y / uint32_t(C::BN / 32)) - int(qblock / BQ) * TPB;
-    if (rel < 0) rel += T;
-    const bool tr_on = rel >= TPB && rel < TPB * (1 + H);
     Frag<DP, 2> bq[QT], ca;
     float thrF[QT], hnqF[QT], thr[QT];
+    uint32_t have_q = 0xFFFFFFFFu;
+    // a wave takes a few consecutive entries: the bound pass files the units of a group of 64 queries together (and the
+    // collect launch most of a wave's), so the query fragments, thresholds and seeds are loaded once per run
+    for (int ce_ = 0; ce_ < GT_SEL_COLD_EPW; ++ce_) {
+        const int64_t en_ = en0 + ce_;
+        if (en_ >= int64_t(sy.qn)) break;   // wave-uniform
+        const uint2 ent = sy.queue[en_];
+        const int64_t qblock = int64_t(ent.x) * (QT * 32);
+        const uint32_t tbase = ent.y * 32u;
+        // does the sub-tile's block take these queries as ITS candidates too?  (position of its tile in the walk of the
+        // queries' block, as in the collect kernel)
+        int rel = int(ent.y / uint32_t(C::BN / 32)) - int(qblock / BQ) * TPB;
+        if (rel < 0) rel += T;
+        const bool tr_on = rel >= TPB && rel < TPB * (1 + H);
+        if (ent.x != have_q) {   // wave-uniform
+            have_q = ent.x;
 #pragma unroll
-    for (int qt = 0; qt < QT; ++qt) {
-        const int64_t qg = qblock + qt * 32 + li;
-        const int64_t qc = qg < nq ? qg : int64_t(nq) - 1;
-        bq[qt].load(Yp + qc * C::RW, h);
-        thrF[qt] = qg < nq ? thr_in[qc] : INFINITY;
-        hnqF[qt] = qg < nq ? hneg[qc] : -INFINITY;
-        thr[qt] = thrF[qt];
-    }
-    ca.load(Yp + (size_t(tbase) + li) * C::RW, h);
-    f32x16 cs;
+            for (int qt = 0; qt < QT; ++qt) {
+                const int64_t qg = qblock + qt * 32 + li;
+                const int64_t qc = qg < nq ? qg : int64_t(nq) - 1;
+                bq[qt].load(Yp + qc * C::RW, h);
+                thrF[qt] = qg < nq ? thr_in[qc] : INFINITY;
+                hnqF[qt] = qg < nq ? hneg[qc] : -INFINITY;
+                thr[qt] = thrF[qt];
+            }
+        }
+        ca.load(Yp + (size_t(tbase) + li) * C::RW, h);
+        f32x16 cs;
 #pragma unroll
-    for (int g_ = 0; g_ < 4; ++g_) {
-        const float4 hv_ = *reinterpret_cast<const float4*>(hneg + size_t(tbase) + 8 * g_ + 4 * h);
-        cs[4 * g_ + 0] = hv_.x;
-        cs[4 * g_ + 1] = hv_.y;
-        cs[4 * g_ + 2] = hv_.z;
-        cs[4 * g_ + 3] = hv_.w;
+        for (int g_ = 0; g_ < 4; ++g_) {
+            const float4 hv_ = *reinterpret_cast<const float4*>(hneg + size_t(tbase) + 8 * g_ + 4 * h);
+            cs[4 * g_ + 0] = hv_.x;
+            cs[4 * g_ + 1] = hv_.y;
+            cs[4 * g_ + 2] = hv_.z;
+            cs[4 * g_ + 3] = hv_.w;
+        }
+        const float* gglob = sy.g + size_t(tbase);
+        f32x16 cacc = cs, cacc1 = cs;
+        mma_chain<DP>(ca, bq[0], cacc);
+        mma_chain<DP>(ca, bq[QT - 1], cacc1);
+        GT_ADMIT2P(cacc, cacc1, cs, 0);
     }
-    const float* gglob = sy.g + size_t(tbase);
-    f32x16 cacc = cs, cacc1 = cs;
-    mma_chain<DP>(ca, bq[0], cacc);
-    mma_chain<DP>(ca, bq[QT - 1], cacc1);
-    GT_ADMIT2P(cacc, cacc1, cs, 0);
     (void)thr;
 }
 
@@ -1305,7 +1318,7 @@ int launch_sym_cold(gt_ctx* ctx, const SelectArgs& a) {
     if (a.sym.qn <= 0) return GT_OK;
     if (!a.sym.queue || !a.sym.g || !a.sym.tlists || !a.sym.tcounts || a.sym.tcap <= 0)
         GT_FAIL(ctx, GT_E_ARG, "knn_select: the cold pass needs the queue and the lists of the collect launch");
-    hipLaunchKernelGGL(sym_cold_kernel<DP>, dim3((unsigned)ceil_div64(a.sym.qn, 4)), dim3(256), 0, ctx->stream, a.Yp, a.hneg,
+    hipLaunchKernelGGL(sym_cold_kernel<DP>, dim3((unsigned)ceil_div64(a.sym.qn, 4 * GT_SEL_COLD_EPW)), dim3(256), 0, ctx->stream, a.Yp, a.hneg,
                        a.thr_in, a.nq, int(a.n_pad / SelCfg<DP, 2>::BN), a.sym);
     GT_HIP(ctx, hipGetLastError());
     return GT_OK;

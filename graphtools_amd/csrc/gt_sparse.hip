@@ -147,22 +147,30 @@ __global__ __launch_bounds__(256) void affinity_kernel(
     if constexpr (!RADIUS) {
         uint32_t n = cand_n[i];
         if (n > uint32_t(limit)) n = uint32_t(limit);
-        uint32_t last = 0;
+        uint32_t* cand_j_w = const_cast<uint32_t*>(cand_j);
         for (uint32_t e0 = 0; e0 < n; e0 += 64) {
             const uint32_t e = e0 + lane;
             bool keep = false;
             uint32_t j = 0;
+            double kvv = -1.0;
             if (e < n) {
                 const double d2 = cand_d2[i * MP + e];
                 j = cand_j[i * MP + e];
                 double kv = 1.0;
                 if (!binary) kv = affinity(gt_key_to_dist(d2, dtype, metric), bwi, decay);
                 keep = binary || (kv >= thresh);
-                cand_d2[i * MP + e] = keep ? kv : -1.0;
+                kvv = kv;
             }
+            // the kept entries move to the front of the row, in order (in place: a chunk is read before it is written, and
+            // only at or below where it was read) - the table is sorted by distance, so they are a prefix anyway and nothing
+            // moves, but the passes over the rows rely on it
             const unsigned long long km = __ballot(keep);
+            if (keep) {
+                const uint32_t slot = uint32_t(kept) + uint32_t(__popcll(km & ((1ull << lane) - 1ull)));
+                cand_d2[i * MP + slot] = kvv;
+                if (slot != e) cand_j_w[i * MP + slot] = j;
+            }
             kept += __popcll(km);
-            if (km != 0ull) last = e0 + 64u - uint32_t(__clzll((long long)km));
             if (count_owners) {
                 const int o = keep ? owner_of(sp, j) : -1;
                 for (int r = 0; r < sp.world; ++r) {
@@ -171,9 +179,8 @@ __global__ __launch_bounds__(256) void affinity_kernel(
                 }
             }
         }
-        // the consumers stop behind the last kept entry (the table is sorted by distance: the kept entries are a prefix,
-        // the passes over the rows read nothing else; slots beyond the eligible range are not theirs either way)
-        if (lane == 0) tablen[i] = int32_t(last);
+        // the consumers read the kept prefix and nothing else
+        if (lane == 0) tablen[i] = int32_t(kept);
     } else {
         const T* xrow = Qm + (qoff + i) * int64_t(d);
         for (int k = lane; k < d; k += 64) xs[k] = double(xrow[k]);
@@ -182,22 +189,32 @@ __global__ __launch_bounds__(256) void affinity_kernel(
         const double qn = qnorm[qoff + i];
         uint32_t n = rcounts[src];
         if (n > uint32_t(rcap)) n = uint32_t(rcap);
-        const uint64_t* lp = rlists + size_t(src) * rcap;
+        uint64_t* lp = const_cast<uint64_t*>(rlists) + size_t(src) * rcap;
         double* kp = rK + size_t(src) * rcap;
         for (uint32_t e0 = 0; e0 < n; e0 += 64) {
             const uint32_t e = e0 + lane;
             bool keep = false;
             uint32_t j = 0;
+            uint64_t lkey = 0ull;
+            double kvv = -1.0;
             if (e < n) {
-                j = cand_index(lp[e]);
+                lkey = lp[e];
+                j = cand_index(lkey);
                 const T* y = X + int64_t(j) * d;
                 const double dot = gt_dot16(xs, y, d);   // (the canonical order of the exact stages)
                 const double t = gt_pair_key(qn, dot, xn[j], metric);
                 const double kv = affinity(gt_key_to_dist(t, dtype, metric), bwi, decay);
                 keep = kv >= thresh;
-                kp[e] = keep ? kv : -1.0;
+                kvv = kv;
             }
-            kept += __popcll(__ballot(keep));
+            // (kept entries to the front, as above; the list is in no particular order)
+            const unsigned long long km = __ballot(keep);
+            if (keep) {
+                const uint32_t slot = uint32_t(kept) + uint32_t(__popcll(km & ((1ull << lane) - 1ull)));
+                kp[slot] = kvv;
+                if (slot != e) lp[slot] = lkey;
+            }
+            kept += __popcll(km);
             if (count_owners) {
                 const int o = keep ? owner_of(sp, j) : -1;
                 for (int r = 0; r < sp.world; ++r) {
@@ -208,6 +225,9 @@ __global__ __launch_bounds__(256) void affinity_kernel(
         }
     }
     if (lane == 0) lenN[i] = kept;
+    if constexpr (RADIUS) {
+        if (lane == 0) const_cast<uint32_t*>(rcounts)[src] = uint32_t(kept);   // the list now ends behind its kept entries
+    }
     if (count_owners && lane < sp.world) ownercnt[int64_t(lane) * nloc + i] = owner_cnt;   // owner-major layout
 }
 
@@ -454,17 +474,29 @@ __global__ __launch_bounds__(256) void bin_count_kernel(const int64_t nloc, cons
                                                         const int32_t rcap, const double* __restrict__ rK,
                                                         const int32_t* __restrict__ tablen, const int32_t* __restrict__ perm,
                                                         const int32_t* __restrict__ pos, const int shift, const int nbins,
+                                                        const int64_t* __restrict__ sN, uint32_t* __restrict__ posj,
                                                         int32_t* __restrict__ bincnt) {
+    // posj: the sorted position of every kept entry's column, in the order of the kept entries of the sorted rows (row p
+    // at sN[p]) - the ONE pass that gathers pos[j] (a random 4-byte read per entry); bin_emit_kernel streams it
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     int32_t* hist = reinterpret_cast<int32_t*>(smem_raw);
     for (int b = threadIdx.x; b < nbins; b += 256) hist[b] = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    for (int64_t p = int64_t(blockIdx.x) * 4 + w; p < nloc; p += int64_t(gridDim.x) * 4)
+    for (int64_t p = int64_t(blockIdx.x) * 4 + w; p < nloc; p += int64_t(gridDim.x) * 4) {
+        int64_t at = sN[p];
         for_kept_entries(perm[p], lane, MP, cand_k, cand_j, rowsrc, rlists, rcounts, rcap, rK, tablen,
                          [&](bool keep, uint32_t j, double) {
-                             if (keep) atomicAdd(&hist[pos[j] >> shift], 1);
+                             int total;
+                             const int q = wave_prefix_count(keep, lane, total);
+                             if (keep) {
+                                 const uint32_t pj = uint32_t(pos[j]);
+                                 posj[at + q] = pj;
+                                 atomicAdd(&hist[pj >> shift], 1);
+                             }
+                             at += total;
                          });
+    }
     __syncthreads();
     for (int b = threadIdx.x; b < nbins; b += 256)
         if (hist[b] != 0) atomicAdd(&bincnt[b], hist[b]);
@@ -475,7 +507,8 @@ __global__ __launch_bounds__(256) void bin_emit_kernel(const int64_t nloc, const
                                                        const uint64_t* __restrict__ rlists, const uint32_t* __restrict__ rcounts,
                                                        const int32_t rcap, const double* __restrict__ rK,
                                                        const int32_t* __restrict__ tablen, const int32_t* __restrict__ perm,
-                                                       const int32_t* __restrict__ pos, const int shift, const int nbins,
+                                                       const int64_t* __restrict__ sN, const uint32_t* __restrict__ posj,
+                                                       const int shift, const int nbins,
                                                        const int64_t* __restrict__ binoff, int32_t* __restrict__ bincur,
                                                        Triplet* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -486,11 +519,8 @@ __global__ __launch_bounds__(256) void bin_emit_kernel(const int64_t nloc, const
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int64_t p0 = int64_t(blockIdx.x) * kEmitRows;
     const int64_t p1 = p0 + kEmitRows < nloc ? p0 + kEmitRows : nloc;
-    for (int64_t p = p0 + w; p < p1; p += 4)
-        for_kept_entries(perm[p], lane, MP, cand_k, cand_j, rowsrc, rlists, rcounts, rcap, rK, tablen,
-                         [&](bool keep, uint32_t j, double) {
-                             if (keep) atomicAdd(&hist[pos[j] >> shift], 1);
-                         });
+    // (the destinations of the workgroup's rows are one contiguous stretch of posj)
+    for (int64_t e = sN[p0] + threadIdx.x; e < sN[p1]; e += 256) atomicAdd(&hist[posj[e] >> shift], 1);
     __syncthreads();
     for (int b = threadIdx.x; b < nbins; b += 256)
         if (hist[b] != 0) {
@@ -500,10 +530,15 @@ __global__ __launch_bounds__(256) void bin_emit_kernel(const int64_t nloc, const
     __syncthreads();
     for (int64_t p = p0 + w; p < p1; p += 4) {
         const uint32_t i = uint32_t(perm[p]);
+        int64_t at = sN[p];
         for_kept_entries(int64_t(i), lane, MP, cand_k, cand_j, rowsrc, rlists, rcounts, rcap, rK, tablen,
-                         [&](bool keep, uint32_t j, double v) {
+                         [&](bool keep, uint32_t, double v) {
+                             int total;
+                             const int q = wave_prefix_count(keep, lane, total);
+                             const int64_t mine = at + q;
+                             at += total;
                              if (keep) {
-                                 const uint32_t pj = uint32_t(pos[j]);
+                                 const uint32_t pj = posj[mine];
                                  const int b = int(pj >> shift);
                                  const int slot = base[b] + atomicAdd(&hist[b], 1);
                                  Triplet t;
@@ -559,15 +594,37 @@ __global__ __launch_bounds__(256) void bin_fill_kernel(const int64_t nloc, const
     __syncthreads();
     int32_t run = inc - mine;
     for (int q = 0; q < w; ++q) run += wsum[q];
+    // off[]: start of the whole union row (own + received entries: where its merged form goes); the received halves
+    // alone are packed in U, row p's at off[p] - sN[p]
     const int64_t ubase = sN[p0] + t0;
+    int32_t lnrun = 0;   // own entries of the bin's rows before r_first
+    {
+        int32_t lmine = 0;
+        for (int u = 0; u < per; ++u) {
+            const int r = r_first + u;
+            if (r < nr) lmine += lenNs[p0 + r];
+        }
+        int32_t linc = lmine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int32_t up = __shfl_up(linc, o);
+            if (lane >= o) linc += up;
+        }
+        __syncthreads();   // (wsum is reused)
+        if (lane == 63) wsum[w] = linc;
+        __syncthreads();
+        lnrun = linc - lmine;
+        for (int q = 0; q < w; ++q) lnrun += wsum[q];
+    }
     for (int u = 0; u < per; ++u) {
         const int r = r_first + u;
         if (r < nr) {
             const int32_t ln = lenNs[p0 + r], lt = cnt[r];
             excl[r] = run;
-            cnt[r] = run + ln;
+            cnt[r] = run - lnrun;   // cursor of the row's received half inside the bin's stretch of U
             off[p0 + r] = ubase + run;
             run += ln + lt;
+            lnrun += ln;
         }
     }
     if (b == nbins - 1 && threadIdx.x == 255) off[nloc] = ubase + run;
@@ -575,17 +632,7 @@ __global__ __launch_bounds__(256) void bin_fill_kernel(const int64_t nloc, const
     for (int64_t t = t0 + threadIdx.x; t < t1; t += 256) {
         const Triplet tr = trip[t];
         const int slot = atomicAdd(&cnt[int64_t(tr.row) - p0], 1);
-        U[ubase + slot] = UEntry{(tr.col << 1) | 1u, 0u, tr.val};
-    }
-    for (int r = w; r < nr; r += 4) {
-        int64_t at = ubase + excl[r];
-        for_kept_entries(perm[p0 + r], lane, MP, cand_k, cand_j, rowsrc, rlists, rcounts, rcap, rK, tablen,
-                         [&](bool keep, uint32_t j, double v) {
-                             int total;
-                             const int q = wave_prefix_count(keep, lane, total);
-                             if (keep) U[at + q] = UEntry{j << 1, 0u, v};
-                             at += total;
-                         });
+        U[t0 + slot] = UEntry{(tr.col << 1) | 1u, 0u, tr.val};
     }
 }
 
@@ -666,8 +713,61 @@ static inline bool sort_key_fits_u32(int64_t ncols, int nt) {
     while ((64 << (bits - 6)) < 64 * nt) ++bits;
     return 2 * ncols - 1 < (int64_t(1) << (32 - bits)) - 1;
 }
+// Where the entries of a union row come from.  Exchange path: all L of them from U.  Bin path: the first ln are the row's
+// own kept entries, read where the affinity pass left them (the kept prefix of its table row or radius list), the
+// received ones behind them from U - the own half of a union row is never copied.
+struct RowSrc {
+    const UEntry* U;
+    int ln;
+    const double* kv;
+    const uint32_t* cj;
+    const uint64_t* rl;
+    __device__ __forceinline__ uint32_t key(const int p) const {
+        return p < ln ? ((cj ? cj[p] : cand_index(rl[p])) << 1) : U[p - ln].key;
+    }
+    __device__ __forceinline__ double val(const int p) const { return p < ln ? kv[p] : U[p - ln].val; }
+};
+struct UnionSrc {
+    const UEntry* U;
+    const int64_t* sN;        // nullptr: exchange path (U holds whole rows at off[])
+    const int32_t* lenNs;
+    const int32_t* perm;
+    const int32_t* rowsrc;
+    const double* cand_k;
+    const uint32_t* cand_j;
+    int MP;
+    const uint64_t* rlists;
+    const double* rK;
+    int32_t rcap;
+};
+__device__ __forceinline__ RowSrc make_row_src(const UnionSrc& us, const int64_t row, const int64_t o0) {
+    RowSrc r;
+    if (!us.sN) {
+        r.U = us.U + o0;
+        r.ln = 0;
+        r.kv = nullptr;
+        r.cj = nullptr;
+        r.rl = nullptr;
+        return r;
+    }
+    const int64_t i = us.perm[row];
+    r.ln = us.lenNs[row];
+    r.U = us.U + (o0 - us.sN[row]);
+    const int32_t src = us.rowsrc[i];
+    if (src < 0) {
+        r.kv = us.cand_k + i * us.MP;
+        r.cj = us.cand_j + i * us.MP;
+        r.rl = nullptr;
+    } else {
+        r.kv = us.rK + size_t(src) * us.rcap;
+        r.cj = nullptr;
+        r.rl = us.rlists + size_t(src) * us.rcap;
+    }
+    return r;
+}
+
 template <typename K, int NT>
-__device__ __forceinline__ int sort_merge_row(const UEntry* __restrict__ U, const int L, const int lane, const int symm,
+__device__ __forceinline__ int sort_merge_row(const RowSrc& U, const int L, const int lane, const int symm,
                                               const double theta,
                                               uint32_t* __restrict__ Vk, double* __restrict__ Vv) {
     constexpr int PB = SortPos<NT>::bits;
@@ -676,7 +776,7 @@ __device__ __forceinline__ int sort_merge_row(const UEntry* __restrict__ U, cons
     for (int t = 0; t < NT; ++t) {
         const int p = t * 64 + lane;
         // descending sort of the complement = ascending sort of the key; 0 (no entry) sorts last
-        pk[t] = (p < L) ? K(~((K(U[p].key) << PB) | K(p))) : K(0);
+        pk[t] = (p < L) ? K(~((K(U.key(p)) << PB) | K(p))) : K(0);
     }
     wave_bitonic_desc<NT, K>(pk, lane);
     uint32_t hi[NT];
@@ -688,7 +788,7 @@ __device__ __forceinline__ int sort_merge_row(const UEntry* __restrict__ U, cons
         if (pk[t] != K(0)) {
             const K x = K(~pk[t]);
             hi[t] = uint32_t(x >> PB);
-            lo[t] = (uint64_t)__double_as_longlong(U[uint32_t(x) & ((1u << PB) - 1u)].val);
+            lo[t] = (uint64_t)__double_as_longlong(U.val(int(uint32_t(x) & ((1u << PB) - 1u))));
         }
     }
     return merge_sorted_regs<NT>(hi, lo, lane, symm, theta, Vk, Vv);
@@ -698,7 +798,7 @@ constexpr int kBigRow = 512;    // longer rows go to sort_merge_long_kernel
 constexpr int kHugeRow = 2048;  // and beyond that to the global-memory sort (big_sort_kernel)
 
 __global__ __launch_bounds__(256) void sort_merge_kernel(const int64_t nloc, const int64_t* __restrict__ off,
-                                                         const UEntry* __restrict__ Uall,
+                                                         const UnionSrc us,
                                                          const int symm, const double theta, uint32_t* __restrict__ Vkey,
                                                          double* __restrict__ Vval, int32_t* __restrict__ outlen,
                                                          int32_t* __restrict__ bigrows, uint32_t* __restrict__ bigcount,
@@ -717,7 +817,7 @@ __global__ __launch_bounds__(256) void sort_merge_kernel(const int64_t nloc, con
         return;
     }
     const int L = int(L64);
-    const UEntry* U = Uall + o0;
+    const RowSrc U = make_row_src(us, i, o0);
     uint32_t* Vk = Vkey + o0;
     double* Vv = Vval + o0;
     int c;
@@ -746,7 +846,7 @@ __global__ __launch_bounds__(256) void sort_merge_kernel(const int64_t nloc, con
 // Rows of kBigRow < L <= kHugeRow entries (hub rows of the transpose): same register sort with 16 / 32 keys per lane in
 // a kernel of its own, so that its register budget does not cut the occupancy of the common case.  Persistent waves
 // walk the list sort_merge_kernel left in bigrows; what is longer still is compacted to the front of hugerows.
-__global__ __launch_bounds__(64) void sort_merge_long_kernel(const int64_t* __restrict__ off, const UEntry* __restrict__ U,
+__global__ __launch_bounds__(64) void sort_merge_long_kernel(const int64_t* __restrict__ off, const UnionSrc us,
                                                              const int symm,
                                                              const double theta, uint32_t* __restrict__ Vkey,
                                                              double* __restrict__ Vval, int32_t* __restrict__ outlen,
@@ -764,15 +864,16 @@ __global__ __launch_bounds__(64) void sort_merge_long_kernel(const int64_t* __re
             continue;
         }
         const int L = int(L64);
-        const int c = (L <= 1024) ? sort_merge_row<uint64_t, 16>(U + o0, L, lane, symm, theta, Vkey + o0, Vval + o0)
-                                  : sort_merge_row<uint64_t, 32>(U + o0, L, lane, symm, theta, Vkey + o0, Vval + o0);
+        const RowSrc U = make_row_src(us, i, o0);
+        const int c = (L <= 1024) ? sort_merge_row<uint64_t, 16>(U, L, lane, symm, theta, Vkey + o0, Vval + o0)
+                                  : sort_merge_row<uint64_t, 32>(U, L, lane, symm, theta, Vkey + o0, Vval + o0);
         if (lane == 0) outlen[i] = c;
     }
 }
 
 // huge rows: bitonic sort in global scratch (one workgroup per row), then a separate merge kernel
 __global__ __launch_bounds__(1024) void big_sort_kernel(const int32_t* __restrict__ bigrows, const int64_t* __restrict__ off,
-                                                        const UEntry* __restrict__ U,
+                                                        const UnionSrc us,
                                                         const int64_t* __restrict__ scratch_off,
                                                         uint32_t* __restrict__ Sk, double* __restrict__ Sv) {
     const int64_t i = bigrows[blockIdx.x];
@@ -782,9 +883,10 @@ __global__ __launch_bounds__(1024) void big_sort_kernel(const int32_t* __restric
     const int64_t P = scratch_off[blockIdx.x + 1] - s0;   // power of two >= L
     uint32_t* k = Sk + s0;
     double* v = Sv + s0;
+    const RowSrc U = make_row_src(us, i, o0);
     for (int64_t p = threadIdx.x; p < P; p += 1024) {
-        k[p] = p < L ? U[o0 + p].key : 0xFFFFFFFFu;
-        v[p] = p < L ? U[o0 + p].val : 0.0;
+        k[p] = p < L ? U.key(int(p)) : 0xFFFFFFFFu;
+        v[p] = p < L ? U.val(int(p)) : 0.0;
     }
     __syncthreads();
     for (int64_t kk = 2; kk <= P; kk <<= 1) {
@@ -1419,23 +1521,25 @@ static int graph_finish_impl(gt_ctx* ctx, const void* recv_buf_dev, int64_t n_re
             hipLaunchKernelGGL(gather_counts_kernel, dim3((unsigned)ceil_div64(nloc, 256)), dim3(256), 0, ctx->stream,
                                g->lenN.as<int32_t>(), perm, nloc, g->cnt_sorted.as<int32_t>());
             GT_TRY(exclusive_scan(ctx, g->cnt_sorted.as<int32_t>(), nullptr, nloc, g->pos_sorted.as<int64_t>(), g->scan_tmp));
-            hipLaunchKernelGGL(bin_count_kernel, dim3((unsigned)std::min<int64_t>(ceil_div64(nloc, 64), 2048)), dim3(256),
-                               size_t(nbins) * sizeof(int32_t), ctx->stream, nloc, k->MP, k->cand_d2.as<double>(),
-                               k->cand_j.as<uint32_t>(), g->rowsrc.as<int32_t>(), g->rlists.as<uint64_t>(),
-                               g->rcounts.as<uint32_t>(), g->rcap, g->rK.as<double>(), g->tablen.as<int32_t>(), perm,
-                               k->sh_invperm.as<int32_t>(), shift, nbins, g->bincnt.as<int32_t>());
-            GT_HIP(ctx, hipGetLastError());
-            rc = exclusive_scan(ctx, g->bincnt.as<int32_t>(), nullptr, nbins, g->binoff.as<int64_t>(), g->scan_tmp);
-            if (rc == GT_OK) {
-                hipError_t e = hipMemcpyAsync(&n_recv, g->binoff.as<int64_t>() + nbins, sizeof(int64_t), hipMemcpyDeviceToHost,
+            {
+                // every kept entry is sent once: the scan's total is the number of triplets
+                hipError_t e = hipMemcpyAsync(&n_recv, g->pos_sorted.as<int64_t>() + nloc, sizeof(int64_t), hipMemcpyDeviceToHost,
                                               ctx->stream);
                 if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
                 if (e != hipSuccess) {
                     ctx->set_error(std::string("scan: ") + hipGetErrorString(e));
-                    rc = GT_E_HIP;
+                    return GT_E_HIP;
                 }
             }
-            GT_TRY(rc);
+            GT_HIP(ctx, g->cursor.reserve(size_t(std::max<int64_t>(n_recv, 1)) * sizeof(uint32_t)));   // posj
+            hipLaunchKernelGGL(bin_count_kernel, dim3((unsigned)std::min<int64_t>(ceil_div64(nloc, 64), 2048)), dim3(256),
+                               size_t(nbins) * sizeof(int32_t), ctx->stream, nloc, k->MP, k->cand_d2.as<double>(),
+                               k->cand_j.as<uint32_t>(), g->rowsrc.as<int32_t>(), g->rlists.as<uint64_t>(),
+                               g->rcounts.as<uint32_t>(), g->rcap, g->rK.as<double>(), g->tablen.as<int32_t>(), perm,
+                               k->sh_invperm.as<int32_t>(), shift, nbins, g->pos_sorted.as<int64_t>(), g->cursor.as<uint32_t>(),
+                               g->bincnt.as<int32_t>());
+            GT_HIP(ctx, hipGetLastError());
+            GT_TRY(exclusive_scan(ctx, g->bincnt.as<int32_t>(), nullptr, nbins, g->binoff.as<int64_t>(), g->scan_tmp));
             total_u = 2 * n_recv;   // every kept entry once in its own row, once in its column's
         } else {
             GT_HIP(ctx, hipMemsetAsync(g->lenT.p, 0, size_t(nloc) * sizeof(int32_t), ctx->stream));
@@ -1459,7 +1563,8 @@ static int graph_finish_impl(gt_ctx* ctx, const void* recv_buf_dev, int64_t n_re
         }
         g->nnz0 = total_u - n_recv;
         HostTrace tr_u(ctx, "finish: fill + merge");
-        GT_HIP(ctx, g->Ukey.reserve(size_t(total_u) * sizeof(UEntry)));   // union rows
+        // union rows (bin path: their received halves only - the own halves are read from the tables)
+        GT_HIP(ctx, g->Ukey.reserve(size_t(bins ? std::max<int64_t>(n_recv, 1) : total_u) * sizeof(UEntry)));
         GT_HIP(ctx, g->Vkey.reserve(size_t(total_u) * sizeof(uint32_t)));
         GT_HIP(ctx, g->Vval.reserve(size_t(total_u) * sizeof(double)));
         GT_HIP(ctx, g->outlen.reserve(size_t(nloc) * sizeof(int32_t)));
@@ -1474,7 +1579,7 @@ static int graph_finish_impl(gt_ctx* ctx, const void* recv_buf_dev, int64_t n_re
             hipLaunchKernelGGL(bin_emit_kernel, dim3((unsigned)ceil_div64(nloc, kEmitRows)), dim3(256), emit_lds, ctx->stream,
                                nloc, k->MP, k->cand_d2.as<double>(), k->cand_j.as<uint32_t>(), g->rowsrc.as<int32_t>(),
                                g->rlists.as<uint64_t>(), g->rcounts.as<uint32_t>(), g->rcap, g->rK.as<double>(),
-                               g->tablen.as<int32_t>(), perm, k->sh_invperm.as<int32_t>(), shift, nbins,
+                               g->tablen.as<int32_t>(), perm, g->pos_sorted.as<int64_t>(), g->cursor.as<uint32_t>(), shift, nbins,
                                g->binoff.as<int64_t>(), g->bincnt.as<int32_t>() + nbins, (Triplet*)g->selfbuf.p);
             GT_HIP(ctx, hipGetLastError());
             hipLaunchKernelGGL(bin_fill_kernel, dim3((unsigned)nbins), dim3(256), size_t(2) * (size_t(1) << shift) * sizeof(int32_t),
@@ -1495,12 +1600,24 @@ static int graph_finish_impl(gt_ctx* ctx, const void* recv_buf_dev, int64_t n_re
                                    g->off.as<int64_t>(), g->lenN.as<int32_t>(), g->cursor.as<int32_t>(), g->Ukey.as<UEntry>());
             }
         }
+        UnionSrc us;
+        us.U = g->Ukey.as<UEntry>();
+        us.sN = bins ? g->pos_sorted.as<int64_t>() : nullptr;
+        us.lenNs = g->cnt_sorted.as<int32_t>();
+        us.perm = perm;
+        us.rowsrc = g->rowsrc.as<int32_t>();
+        us.cand_k = k->cand_d2.as<double>();
+        us.cand_j = k->cand_j.as<uint32_t>();
+        us.MP = k->MP;
+        us.rlists = g->rlists.as<uint64_t>();
+        us.rK = g->rK.as<double>();
+        us.rcap = g->rcap;
         hipLaunchKernelGGL(sort_merge_kernel, dim3((unsigned)ceil_div64(nloc, 4)), dim3(256), 0, ctx->stream, nloc,
-                           g->off.as<int64_t>(), g->Ukey.as<UEntry>(), g->p.kernel_symm, g->p.theta,
+                           g->off.as<int64_t>(), us, g->p.kernel_symm, g->p.theta,
                            g->Vkey.as<uint32_t>(), g->Vval.as<double>(), g->outlen.as<int32_t>(), g->bigrows.as<int32_t>(),
                            g->bigcount.as<uint32_t>(), (ctx->symm_key32 != 0 && sort_key_fits_u32(g->n_total, 8)) ? 1 : 0);
         hipLaunchKernelGGL(sort_merge_long_kernel, dim3(4096), dim3(64), 0, ctx->stream, g->off.as<int64_t>(),
-                           g->Ukey.as<UEntry>(), g->p.kernel_symm, g->p.theta, g->Vkey.as<uint32_t>(),
+                           us, g->p.kernel_symm, g->p.theta, g->Vkey.as<uint32_t>(),
                            g->Vval.as<double>(), g->outlen.as<int32_t>(), g->bigrows.as<int32_t>(), g->bigcount.as<uint32_t>(),
                            g->hugerows.as<int32_t>(), g->bigcount.as<uint32_t>() + 1);
         GT_HIP(ctx, hipGetLastError());
@@ -1540,7 +1657,7 @@ static int graph_finish_impl(gt_ctx* ctx, const void* recv_buf_dev, int64_t n_re
             GT_HIP(ctx, g->bigscratch_k.reserve(size_t(soff[nbig]) * sizeof(uint32_t)));
             GT_HIP(ctx, g->bigscratch_v.reserve(size_t(soff[nbig]) * sizeof(double)));
             hipLaunchKernelGGL(big_sort_kernel, dim3(nbig), dim3(1024), 0, ctx->stream, g->hugerows.as<int32_t>(),
-                               g->off.as<int64_t>(), g->Ukey.as<UEntry>(), soff_dev.as<int64_t>(),
+                               g->off.as<int64_t>(), us, soff_dev.as<int64_t>(),
                                g->bigscratch_k.as<uint32_t>(), g->bigscratch_v.as<double>());
             hipLaunchKernelGGL(big_merge_kernel, dim3(nbig), dim3(64), 0, ctx->stream, g->hugerows.as<int32_t>(),
                                g->off.as<int64_t>(), soff_dev.as<int64_t>(), g->bigscratch_k.as<uint32_t>(),
