@@ -210,8 +210,9 @@ int gt_sym_half_thresholds(gt_ctx* ctx, const int32_t* perm, int64_t n_pad_s, co
 // radius of every sorted row in the full compact copy (what a pair it needs listed can be apart at most)
 int gt_sym_row_radius(gt_ctx* ctx, const int32_t* perm, int64_t n_pad_s, const float* thr, const ErrModel& err, float* rrow);
 // bound pass of the two-stage collect (gt_sym.hip cell_ball_kernel): the units the cell bounds cannot rule out -> queue
+// (world / rank / group: a row-sharded build lists the units of its own pieces of the walks)
 int gt_sym_bound_queue(gt_ctx* ctx, int64_t n_pad_s, const void* Ys, const float* rrow, DevBuf& work, uint2* queue,
-                       uint32_t cap, uint32_t* count_dev);
+                       uint32_t cap, uint32_t* count_dev, int world = 1, int rank = 0, int group = 1);
 // row-sharded symmetric pass (gt_knn_shard.cpp)
 #define GT_SYM_MAX_WORLD 64
 int gt_sym_g_from_thr(gt_ctx* ctx, int64_t n_pad_s, const float* thr, const float* hs, float* g, float* gmin);

@@ -261,15 +261,48 @@ int gt_knn_shard_collect(gt_ctx* ctx, const float* thr_all, int64_t far_total, c
     a.sym.shard_world = k->sh_world;
     a.sym.shard_rank = k->sh_rank;
     a.sym.shard_group = std::max(1, ctx->sym_shard_group);
+    bool bound_done = false;
+    k->sym_bound_used = false;
     if (n_pad_s % 1024 == 0 && ctx->DP >= 32 && bq == 256 &&
         (ctx->sym_two_stage > 0 || (ctx->sym_two_stage < 0 && ctx->sym_two_ok != 0))) {
-        // two-stage scoring, as in the single-rank pass (gt_knn.cpp); the forecast runs on the same data on every rank
         ErrModel em = gt_err_model(ctx, 2);
         em.rel += 8.0 * 5.9604644775390625e-08;
-        GT_TRY(gt_sym_two_stage_prepare(ctx, k->qorder.as<int32_t>(), n_pad_s, em, k->sh_need, a, true));
+        if (ctx->sym_bounds != 0 && ctx->order_L > 0) {
+            // bound pass, as in the single-rank pass (gt_knn.cpp): the units of THIS rank's pieces of the walks that the
+            // cells of the sorted order cannot rule out go straight to the cold launch (the cell geometry is replicated
+            // work, 0.7 ms; every rank decides for its own share - the lists are complete either way)
+            const int64_t bcap = ctx->sym_bound_cap > 0 ? ctx->sym_bound_cap : (int64_t(1) << 22);
+            GT_HIP(ctx, k->sym_qdense.reserve(size_t(bcap) * sizeof(uint2)));
+            GT_HIP(ctx, k->sym_qtot.reserve(4 * sizeof(uint32_t)));
+            GT_HIP(ctx, k->sym_rrow.reserve(size_t(n_pad_s) * sizeof(float)));
+            uint32_t left = 0;
+            {
+                StageSpan span(ctx, "sym_bound");
+                GT_TRY(gt_sym_row_radius(ctx, k->qorder.as<int32_t>(), n_pad_s, k->thr_final.as<float>(), em, k->sym_rrow.as<float>()));
+                GT_TRY(gt_sym_bound_queue(ctx, n_pad_s, k->Ycs.p, k->sym_rrow.as<float>(), k->sym_bwork, k->sym_qdense.as<uint2>(),
+                                          uint32_t(bcap), k->sym_qtot.as<uint32_t>(), k->sh_world, k->sh_rank,
+                                          std::max(1, ctx->sym_shard_group)));
+                GT_HIP(ctx, hipMemcpyAsync(&left, k->sym_qtot.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+            }
+            GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (int64_t(left) <= bcap) {
+                StageSpan span(ctx, "sym_cold");
+                SelectArgs dq = a;
+                dq.mode = 4;
+                dq.sym.queue = k->sym_qdense.as<uint2>();
+                dq.sym.qn = int32_t(left);
+                GT_TRY(gt_launch_select(ctx, dq));
+                k->sym_cold_entries = int64_t(left);
+                bound_done = true;
+                k->sym_bound_used = true;
+                if (ctx->sym_two_ok < 0) ctx->sym_two_ok = 1;
+            }
+        }
+        // two-stage scoring, as in the single-rank pass (gt_knn.cpp); the forecast runs on the same data on every rank
+        if (!bound_done) GT_TRY(gt_sym_two_stage_prepare(ctx, k->qorder.as<int32_t>(), n_pad_s, em, k->sh_need, a, true));
     }
     const bool two_stage = a.sym.half_steps > 0;
-    k->sym_two_used = false;
+    k->sym_two_used = bound_done;
     {
         const int64_t slots = int64_t(ctx->n_cu) * 3, nb = n_pad_s / bq;
         int best = 1;
@@ -283,7 +316,7 @@ int gt_knn_shard_collect(gt_ctx* ctx, const float* thr_all, int64_t far_total, c
         k->sym_nseg = a.sym.nseg;
     }
     if (two_stage) GT_TRY(gt_sym_queue_prepare(ctx, n_pad_s, a));
-    for (int attempt = 0; attempt < 2; ++attempt) {
+    for (int attempt = 0; attempt < 2 && !bound_done; ++attempt) {
         {
             StageSpan span(ctx, "knn_select");
             GT_TRY(gt_sym_launch_collect(ctx, a));

@@ -911,6 +911,7 @@ __global__ __launch_bounds__(256) void tile_cells_kernel(const uint32_t* __restr
 // block, H following blocks, the antipodal one when NB is even: knn_select_kernel<MODE 2> with two-stage scoring).  A
 // sub-tile (or the queries) can straddle cells: a unit is filed by the FIRST undecided pair (a, b) of its cell ranges.
 __global__ __launch_bounds__(64) void bound_queue_kernel(const int T, const int TPB, const int walk, const int L,
+                                                         const int world, const int rank, const int group,
                                                          const uint32_t* __restrict__ tcell,
                                                          const int32_t* __restrict__ start, const int32_t* __restrict__ endp,
                                                          const uint32_t* __restrict__ mask, const int words,
@@ -931,6 +932,10 @@ __global__ __launch_bounds__(64) void bound_queue_kernel(const int T, const int 
         if ((qb >> 16) > qhi) qhi = qb >> 16;
     }
     if (qlo == 0xFFFFu) return;   // pad queries only
+    // row-sharded build: this rank's piece of the block's walk (the partition of knn_select_kernel<MODE 2>: piece
+    // (rank + block / group) mod world of `world` equal pieces)
+    const int piece = world > 1 ? (rank + blk / group) % world : 0;
+    const int rel_lo = int(int64_t(walk) * piece / world), rel_hi = int(int64_t(walk) * (piece + 1) / world);
     auto open_pair = [&](const uint32_t a, const uint32_t b) {
         return ((mask[size_t(a) * words + (b >> 5)] >> (b & 31u)) & 1u) == 0u;
     };
@@ -969,6 +974,7 @@ __global__ __launch_bounds__(64) void bound_queue_kernel(const int T, const int 
                     int rel = int(d32 / 4u) - blk * TPB;
                     if (rel < 0) rel += T;
                     if (rel >= walk) continue;   // not this block's unit (the other block's walk has it)
+                    if (rel < rel_lo || rel >= rel_hi) continue;   // another rank's piece
                     // first undecided pair of (cells of the queries) x (cells of the sub-tile) files the unit
                     const uint32_t dc = tcell[d32];
                     const uint32_t dlo = dc & 0xFFFFu, dhi = dc >> 16;
@@ -1132,7 +1138,7 @@ int gt_sym_two_probe(gt_ctx* ctx, const void* Ys, int hd, const float* hh, const
 // caller runs the collect launch instead).  Ys: the sorted compact copy [n_pad][DP] float16, rrow: the rows' radii in
 // it; work: scratch.
 int gt_sym_bound_queue(gt_ctx* ctx, int64_t n_pad_s, const void* Ys, const float* rrow, DevBuf& work, uint2* queue,
-                       uint32_t cap, uint32_t* count_dev) {
+                       uint32_t cap, uint32_t* count_dev, int world, int rank, int group) {
     const int L = ctx->order_L;
     if (L <= 0 || L > 65535) GT_FAIL(ctx, GT_E_STATE, "bound pass: no landmark cells");
     if (n_pad_s % 1024 != 0) GT_FAIL(ctx, GT_E_ARG, "bound pass: whole 1024-row query blocks");
@@ -1204,7 +1210,8 @@ int gt_sym_bound_queue(gt_ctx* ctx, int64_t n_pad_s, const void* Ys, const float
     }
     const int T = int(n_pad_s / 128), TPB = 8, NB = T / TPB, H = (NB - 1) / 2;
     const int walk = TPB * (1 + H) + ((NB & 1) ? 0 : (NB > 1 ? TPB : 0));
-    hipLaunchKernelGGL(bound_queue_kernel, dim3((unsigned)(NB * 2 * TPB)), dim3(64), 0, ctx->stream, T, TPB, walk, L, tcell, start,
+    hipLaunchKernelGGL(bound_queue_kernel, dim3((unsigned)(NB * 2 * TPB)), dim3(64), 0, ctx->stream, T, TPB, walk, L,
+                       std::max(world, 1), rank, std::max(group, 1), tcell, start,
                        endp, mask, words, queue, cap, count_dev);
     GT_HIP(ctx, hipGetLastError());
     return GT_OK;
