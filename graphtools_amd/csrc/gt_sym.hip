@@ -823,17 +823,28 @@ __global__ __launch_bounds__(256) void cell_ball_kernel(const _Float16* __restri
         if (threadIdx.x < DP) centre[size_t(c) * DP + threadIdx.x] = t;
     }
     __syncthreads();
-    const double c0 = double(cs[lane]), c1 = double(cs[lane + 64]);
+    // radius: one thread per row (16-byte loads of its 2 DP bytes, the centre from the LDS), float64 sums
     double rmax = 0.0;
     float nmax = -INFINITY;
-    for (int p = s0 + w; p < s1; p += 4) {
-        const double d0 = lane < DP ? double(float(Ys[size_t(p) * DP + lane])) - c0 : 0.0;
-        const double d1 = lane + 64 < DP ? double(float(Ys[size_t(p) * DP + lane + 64])) - c1 : 0.0;
-        double d2 = fma(d0, d0, d1 * d1);
+    typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+    for (int p = s0 + int(threadIdx.x); p < s1; p += 256) {
+        const half8* row = reinterpret_cast<const half8*>(Ys + size_t(p) * DP);
+        double d2 = 0.0;
+        for (int q8 = 0; q8 < DP / 8; ++q8) {
+            const half8 v = row[q8];
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) d2 += __shfl_xor(d2, o);
+            for (int e = 0; e < 8; ++e) {
+                const double df = double(float(v[e])) - double(cs[8 * q8 + e]);
+                d2 = fma(df, df, d2);
+            }
+        }
         rmax = fmax(rmax, sqrt(d2));
         nmax = fmaxf(nmax, rrow[p]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        rmax = fmax(rmax, __shfl_xor(rmax, o));
+        nmax = fmaxf(nmax, __shfl_xor(nmax, o));
     }
     if (lane == 0) {
         red[w] = rmax;
