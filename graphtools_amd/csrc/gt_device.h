@@ -150,8 +150,9 @@ __device__ __forceinline__ void wave_bitonic_desc(K (&key)[NT], const int lane) 
                     const bool desc = ((e & k) == 0);
                     const bool lower = ((lane & j) == 0);
                     const bool want_max = (lower == desc);
-                    const K mx = a > o ? a : o, mn = a > o ? o : a;
-                    key[t] = want_max ? mx : mn;
+                    // keep the own key when it is the one wanted: one compare, the lane-pattern mask folded in on the
+                    // scalar side, one select (instead of max, min and a select between them)
+                    key[t] = ((a > o) == want_max) ? a : o;
                 }
             }
         }

@@ -321,7 +321,7 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
             int keep = std::max(ctx->samp_keep > 0 ? ctx->samp_keep : 16, need_m);
             keep += keep & 1;
             a.samp_keep = keep;
-            a.samp_trig = ctx->samp_trig;
+            a.samp_trig = ctx->samp_trig > 0 ? ctx->samp_trig : 96;   // (lists of the neighbourhood tiles: compact at 96 keys, 7.5 -> 7.1 ms)
             a.samp_end = 0;
             a.samp2_level = 0;
             a.final_keep = need_m;
