@@ -63,9 +63,19 @@ __device__ __forceinline__ double gt_dot16(const TX* __restrict__ x, const TY* _
         for (int e = 0; e < 64; ++e) a[e >> 2] = fma(double(x[k0 + e]), double(y[k0 + e]), a[e >> 2]);
     }
     if (k0 < d) {
+        // the last, partial group of 64: whole quadruples without a test per element (d is uniform: so are the branches)
 #pragma unroll
-        for (int e = 0; e < 64; ++e)
-            if (k0 + e < d) a[e >> 2] = fma(double(x[k0 + e]), double(y[k0 + e]), a[e >> 2]);
+        for (int q = 0; q < 16; ++q) {
+            const int k = k0 + 4 * q;
+            if (k + 4 <= d) {
+                a[q] = fma(double(x[k + 0]), double(y[k + 0]), a[q]);
+                a[q] = fma(double(x[k + 1]), double(y[k + 1]), a[q]);
+                a[q] = fma(double(x[k + 2]), double(y[k + 2]), a[q]);
+                a[q] = fma(double(x[k + 3]), double(y[k + 3]), a[q]);
+            } else if (k < d) {
+                for (int e = 0; k + e < d; ++e) a[q] = fma(double(x[k + e]), double(y[k + e]), a[q]);
+            }
+        }
     }
     return gt_tree16(a);
 }
