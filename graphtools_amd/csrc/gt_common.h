@@ -131,7 +131,7 @@ struct gt_ctx {
     int32_t query_order = 1;  // candidate pass: deal the query rows to workgroups grouped by nearest landmark (gt_order.hip)
     int32_t order_min_rows = 32768;  //   launches with fewer query rows (or fewer points) are not grouped
     int32_t thr0_mode = 1;           //   start the candidate lists from the threshold the assignment pass proves (0: from -inf)
-    int32_t order_cell_rows = 244;   //   rows per landmark cell (L = n / order_cell_rows landmarks, 64 ... 4096; small cells: a cluster
+    int32_t order_cell_rows = 244;   //   rows per landmark cell (L = n / order_cell_rows landmarks, 64 ... 8192; small cells: a cluster
                                      //   without a landmark of its own swells the cells it lands in - see the bound pass, gt_sym.hip)
     DevBuf land_Y, land_h, order_cell, order_rows, order_tmp;
     int32_t samp_trig = 0;    //   level 0: entries per half-list that trigger a cut (0: samp_keep / 2 + 24)

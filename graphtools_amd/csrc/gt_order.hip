@@ -43,7 +43,9 @@ int gt_query_order(gt_ctx* ctx, const float* Qc, int64_t q0, int64_t nq, int nee
     if (!ctx->query_order || ctx->prec != 1 || ctx->fast_mode == 0 || !ctx->Yc.p || !Qc || nq < kMinRows || ctx->n < std::max<int64_t>(kMinRows, 64))
         return GT_OK;
     const int rw = ctx->DP / 2;   // dwords per row of the compact copy
-    int L = int(std::min<int64_t>(std::min<int64_t>(4096, ctx->n / 32 * 32), std::max<int64_t>(64, (ctx->n / std::max(ctx->order_cell_rows, 32)) / 32 * 32)));
+    // (up to 8192 cells: beyond a million rows the cells would otherwise grow, and with them the share of clusters that own
+    //  no landmark - see the bound pass, gt_sym.hip)
+    int L = int(std::min<int64_t>(std::min<int64_t>(8192, ctx->n / 32 * 32), std::max<int64_t>(64, (ctx->n / std::max(ctx->order_cell_rows, 32)) / 32 * 32)));
     const int64_t step = ctx->n / L;
     GT_HIP(ctx, ctx->land_Y.reserve(size_t(L) * rw * sizeof(uint32_t)));
     GT_HIP(ctx, ctx->land_h.reserve(size_t(L) * sizeof(float)));
