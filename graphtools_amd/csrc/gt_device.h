@@ -58,9 +58,18 @@ __device__ __forceinline__ double gt_dot16(const TX* __restrict__ x, const TY* _
 #pragma unroll
     for (int l = 0; l < 16; ++l) a[l] = 0.0;
     int k0 = 0;
+    // (general path - rows that are not 16-byte aligned float32: the scheduling barriers keep the compiler from hoisting
+    //  all 64 loads of a group in front of the arithmetic, which would cost the kernels around it their occupancy)
     for (; k0 + 64 <= d; k0 += 64) {
 #pragma unroll
-        for (int e = 0; e < 64; ++e) a[e >> 2] = fma(double(x[k0 + e]), double(y[k0 + e]), a[e >> 2]);
+        for (int q = 0; q < 16; ++q) {
+            const int k = k0 + 4 * q;
+            a[q] = fma(double(x[k + 0]), double(y[k + 0]), a[q]);
+            a[q] = fma(double(x[k + 1]), double(y[k + 1]), a[q]);
+            a[q] = fma(double(x[k + 2]), double(y[k + 2]), a[q]);
+            a[q] = fma(double(x[k + 3]), double(y[k + 3]), a[q]);
+            if ((q & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
     }
     if (k0 < d) {
         // the last, partial group of 64: whole quadruples without a test per element (d is uniform: so are the branches)
@@ -75,6 +84,7 @@ __device__ __forceinline__ double gt_dot16(const TX* __restrict__ x, const TY* _
             } else if (k < d) {
                 for (int e = 0; k + e < d; ++e) a[q] = fma(double(x[k + e]), double(y[k + e]), a[q]);
             }
+            if ((q & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
     }
     return gt_tree16(a);

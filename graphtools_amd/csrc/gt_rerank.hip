@@ -32,7 +32,15 @@ __device__ __forceinline__ double dot_row<float>(const double* __restrict__ xs, 
     return gt_dot16(xs, y, d);
 }
 
-template <typename T, int NT2>
+// F4 (host-decided: float32 rows, d a multiple of 4, 16-byte aligned): the 16-byte-load form alone is instantiated - the
+// general form next to it costs the re-rank kernels two thirds of their occupancy in registers
+template <typename T, bool F4>
+__device__ __forceinline__ double dot_row_sel(const double* __restrict__ xs, const T* __restrict__ y, int d) {
+    if constexpr (F4 && sizeof(T) == 4) return gt_dot16_f4(xs, reinterpret_cast<const float*>(y), d);
+    else return gt_dot16(xs, y, d);
+}
+
+template <typename T, int NT2, bool F4>
 __global__ __launch_bounds__(256) void rerank_kernel(const T* __restrict__ X, const int d, const double* __restrict__ xn,
                                                      const T* __restrict__ Q, const double* __restrict__ qn,
                                                      const double* __restrict__ qn_sel, const int64_t q0, const int64_t nq,
@@ -114,7 +122,7 @@ __global__ __launch_bounds__(256) void rerank_kernel(const T* __restrict__ X, co
         for (int u = 0; u < 2; ++u) {
             if (ks[u] != 0ull) {
                 const uint32_t j = cand_index(ks[u]);
-                const double dot = dot_row<T>(xs, X + int64_t(j) * d, d);
+                const double dot = dot_row_sel<T, F4>(xs, X + int64_t(j) * d, d);
                 hi[u] = (uint64_t)__double_as_longlong(gt_pair_key(qnq, dot, xn[j], metric));
                 lo[u] = j;
             }
@@ -137,7 +145,7 @@ __global__ __launch_bounds__(256) void rerank_kernel(const T* __restrict__ X, co
             for (int u = 2; u < 4; ++u) {
                 if (ks[u] != 0ull) {
                     const uint32_t j = cand_index(ks[u]);
-                    const double dot = dot_row<T>(xs, X + int64_t(j) * d, d);
+                    const double dot = dot_row_sel<T, F4>(xs, X + int64_t(j) * d, d);
                     hi[u] = (uint64_t)__double_as_longlong(gt_pair_key(qnq, dot, xn[j], metric));
                     lo[u] = j;
                 }
@@ -151,7 +159,7 @@ __global__ __launch_bounds__(256) void rerank_kernel(const T* __restrict__ X, co
             lo[u] = 0xFFFFFFFFull;
             if (c < n) {
                 const uint32_t j = cand_index(lp[c]);
-                const double dot = dot_row<T>(xs, X + int64_t(j) * d, d);
+                const double dot = dot_row_sel<T, F4>(xs, X + int64_t(j) * d, d);
                 hi[u] = (uint64_t)__double_as_longlong(gt_pair_key(qnq, dot, xn[j], metric));
                 lo[u] = j;
             }
@@ -197,8 +205,8 @@ constexpr uint32_t kNoRow = 0xFFFFFFFFu;
 // scored <= thr[ql].  The 256 best approximate scores are evaluated exactly in two batches of 128 like above (lists of up
 // to 128 / 256 keys take a shorter sorting network); a row whose list overflowed (more than tcap <= 512 keys) is handed
 // to the repair path (bound = -inf).
-template <typename T>
-__global__ __launch_bounds__(256) void rerank_sym_kernel(
+template <typename T, bool F4>
+__global__ __launch_bounds__(256, 5) void rerank_sym_kernel(
     const T* __restrict__ X, const int d, const double* __restrict__ xn, const int64_t nq,
     const uint64_t* __restrict__ tlists, const int tcap, const uint32_t* __restrict__ tcounts,
     const float* __restrict__ thr, const double* __restrict__ ymax2p, const ErrModel err, const int need_m,
@@ -275,8 +283,8 @@ __global__ __launch_bounds__(256) void rerank_sym_kernel(
         // (one database row per lane.  Sixteen lanes per row with coalesced 16-byte loads and a rotation sum were tried:
         //  8.1 ms against 5.8 - the kernel is bound by its sorting networks and the gathers hit the L2, the extra
         //  registers of the batched loads cost more occupancy than the coalescing returns)
-        dot0 = j0 != kNoRow ? dot_row<T>(xs, X + int64_t(j0) * d, d) : 0.0;
-        dot1 = j1 != kNoRow ? dot_row<T>(xs, X + int64_t(j1) * d, d) : 0.0;
+        dot0 = j0 != kNoRow ? dot_row_sel<T, F4>(xs, X + int64_t(j0) * d, d) : 0.0;
+        dot1 = j1 != kNoRow ? dot_row_sel<T, F4>(xs, X + int64_t(j1) * d, d) : 0.0;
         if (j0 != kNoRow) {
             hi[0] = (uint64_t)__double_as_longlong(gt_pair_key(qnq, dot0, xn[j0], 0));
             lo[0] = j0;
@@ -308,8 +316,8 @@ __global__ __launch_bounds__(256) void rerank_sym_kernel(
             const uint32_t j2 = ks[2] != 0ull ? uint32_t(perm[cand_index(ks[2])]) : kNoRow;
             const uint32_t j3 = ks[3] != 0ull ? uint32_t(perm[cand_index(ks[3])]) : kNoRow;
             double dot2, dot3;
-            dot2 = j2 != kNoRow ? dot_row<T>(xs, X + int64_t(j2) * d, d) : 0.0;
-            dot3 = j3 != kNoRow ? dot_row<T>(xs, X + int64_t(j3) * d, d) : 0.0;
+            dot2 = j2 != kNoRow ? dot_row_sel<T, F4>(xs, X + int64_t(j2) * d, d) : 0.0;
+            dot3 = j3 != kNoRow ? dot_row_sel<T, F4>(xs, X + int64_t(j3) * d, d) : 0.0;
             if (j2 != kNoRow) {
                 hi[2] = (uint64_t)__double_as_longlong(gt_pair_key(qnq, dot2, xn[j2], 0));
                 lo[2] = j2;
@@ -607,21 +615,31 @@ template <typename T>
 int rerank_t(gt_ctx* ctx, const RerankArgs& a) {
     const int64_t blocks = ceil_div64(a.nq, 4);
     const size_t lds = size_t(4) * a.d * sizeof(double);
+    const bool f4 = sizeof(T) == 4 && (a.d & 3) == 0 && (reinterpret_cast<uintptr_t>(a.X) & 15) == 0;
     if (a.MP == 128) {
-        hipLaunchKernelGGL((rerank_kernel<T, 2>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, (const T*)a.X,
+        if (f4) { hipLaunchKernelGGL((rerank_kernel<T, 2, true>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, (const T*)a.X,
                            a.d, a.xn, (const T*)a.Q, a.qn, a.qn_sel, a.q0, a.nq, a.lists, a.lstride, a.counts, a.thr_final, a.ymax2,
                            a.err, a.metric, a.need_m, a.cand_d2, a.cand_j, a.cand_n, a.d2_lb, a.fb_count, a.fb_rows,
-                           a.gflags, a.radius_key_factor, a.unproven, a.qrows);
+                           a.gflags, a.radius_key_factor, a.unproven, a.qrows); } else { hipLaunchKernelGGL((rerank_kernel<T, 2, false>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, (const T*)a.X,
+                           a.d, a.xn, (const T*)a.Q, a.qn, a.qn_sel, a.q0, a.nq, a.lists, a.lstride, a.counts, a.thr_final, a.ymax2,
+                           a.err, a.metric, a.need_m, a.cand_d2, a.cand_j, a.cand_n, a.d2_lb, a.fb_count, a.fb_rows,
+                           a.gflags, a.radius_key_factor, a.unproven, a.qrows); }
     } else if (a.MP == 256) {
-        hipLaunchKernelGGL((rerank_kernel<T, 4>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, (const T*)a.X,
+        if (f4) { hipLaunchKernelGGL((rerank_kernel<T, 4, true>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, (const T*)a.X,
                            a.d, a.xn, (const T*)a.Q, a.qn, a.qn_sel, a.q0, a.nq, a.lists, a.lstride, a.counts, a.thr_final, a.ymax2,
                            a.err, a.metric, a.need_m, a.cand_d2, a.cand_j, a.cand_n, a.d2_lb, a.fb_count, a.fb_rows,
-                           a.gflags, a.radius_key_factor, a.unproven, a.qrows);
+                           a.gflags, a.radius_key_factor, a.unproven, a.qrows); } else { hipLaunchKernelGGL((rerank_kernel<T, 4, false>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, (const T*)a.X,
+                           a.d, a.xn, (const T*)a.Q, a.qn, a.qn_sel, a.q0, a.nq, a.lists, a.lstride, a.counts, a.thr_final, a.ymax2,
+                           a.err, a.metric, a.need_m, a.cand_d2, a.cand_j, a.cand_n, a.d2_lb, a.fb_count, a.fb_rows,
+                           a.gflags, a.radius_key_factor, a.unproven, a.qrows); }
     } else if (a.MP == 512) {
-        hipLaunchKernelGGL((rerank_kernel<T, 8>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, (const T*)a.X,
+        if (f4) { hipLaunchKernelGGL((rerank_kernel<T, 8, true>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, (const T*)a.X,
                            a.d, a.xn, (const T*)a.Q, a.qn, a.qn_sel, a.q0, a.nq, a.lists, a.lstride, a.counts, a.thr_final, a.ymax2,
                            a.err, a.metric, a.need_m, a.cand_d2, a.cand_j, a.cand_n, a.d2_lb, a.fb_count, a.fb_rows,
-                           a.gflags, a.radius_key_factor, a.unproven, a.qrows);
+                           a.gflags, a.radius_key_factor, a.unproven, a.qrows); } else { hipLaunchKernelGGL((rerank_kernel<T, 8, false>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, (const T*)a.X,
+                           a.d, a.xn, (const T*)a.Q, a.qn, a.qn_sel, a.q0, a.nq, a.lists, a.lstride, a.counts, a.thr_final, a.ymax2,
+                           a.err, a.metric, a.need_m, a.cand_d2, a.cand_j, a.cand_n, a.d2_lb, a.fb_count, a.fb_rows,
+                           a.gflags, a.radius_key_factor, a.unproven, a.qrows); }
     } else {
         GT_FAIL(ctx, GT_E_ARG, "rerank: unsupported table width");
     }
@@ -713,13 +731,17 @@ int gt_launch_rerank_sym(gt_ctx* ctx, const RerankArgs& a, const SymRerank& sr) 
     const int64_t blocks = ceil_div64(a.nq, 4);
     const size_t lds = size_t(4) * a.d * sizeof(double);
     if (a.MP != 256 || a.metric != 0) GT_FAIL(ctx, GT_E_ARG, "rerank_sym: table width 256, euclidean metric only");
-#define GT_RERANK_SYM_LAUNCH(T_)                                                                                          \
-    hipLaunchKernelGGL((rerank_sym_kernel<T_>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, (const T_*)a.X, a.d,  \
+#define GT_RERANK_SYM_LAUNCH(T_, F4_)                                                                                     \
+    hipLaunchKernelGGL((rerank_sym_kernel<T_, F4_>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, (const T_*)a.X, a.d,  \
                        a.xn, a.nq, sr.tlists, sr.tcap, sr.tcounts, a.thr_final, a.ymax2, a.err, a.need_m, sr.perm,        \
                        a.cand_d2, a.cand_j, a.cand_n, a.d2_lb, a.fb_count, a.fb_rows, a.gflags, a.radius_key_factor,      \
                        a.unproven, sr.stat, (ctx->dbg_select & 256) ? 1 : 0, sr.invperm, sr.own_rows, sr.own_r0)
-    if (a.dtype == GT_F32) GT_RERANK_SYM_LAUNCH(float);
-    else GT_RERANK_SYM_LAUNCH(double);
+    if (a.dtype == GT_F32) {
+        if ((a.d & 3) == 0 && (reinterpret_cast<uintptr_t>(a.X) & 15) == 0) GT_RERANK_SYM_LAUNCH(float, true);
+        else GT_RERANK_SYM_LAUNCH(float, false);
+    } else {
+        GT_RERANK_SYM_LAUNCH(double, false);
+    }
 #undef GT_RERANK_SYM_LAUNCH
     GT_HIP(ctx, hipGetLastError());
     return GT_OK;

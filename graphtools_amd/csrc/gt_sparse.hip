@@ -574,7 +574,18 @@ __global__ __launch_bounds__(256) void bin_fill_kernel(const int64_t nloc, const
     for (int r = threadIdx.x; r < R; r += 256) cnt[r] = 0;
     __syncthreads();
     const int64_t t0 = binoff[b], t1 = binoff[b + 1];
-    for (int64_t t = t0 + threadIdx.x; t < t1; t += 256) atomicAdd(&cnt[int64_t(trip[t].row) - p0], 1);
+    {
+        // (four loads in flight per thread: the loop is bound by the latency of load -> LDS atomic otherwise)
+        int64_t t = t0 + threadIdx.x;
+        for (; t + 3 * 256 < t1; t += 4 * 256) {
+            const uint32_t r0 = trip[t].row, r1 = trip[t + 256].row, r2 = trip[t + 512].row, r3 = trip[t + 768].row;
+            atomicAdd(&cnt[int64_t(r0) - p0], 1);
+            atomicAdd(&cnt[int64_t(r1) - p0], 1);
+            atomicAdd(&cnt[int64_t(r2) - p0], 1);
+            atomicAdd(&cnt[int64_t(r3) - p0], 1);
+        }
+        for (; t < t1; t += 256) atomicAdd(&cnt[int64_t(trip[t].row) - p0], 1);
+    }
     __syncthreads();
     // exclusive scan of lenNs + cnt over the bin's rows: thread x owns the R / 256 consecutive rows from x R / 256
     const int per = R / 256;
@@ -629,10 +640,24 @@ __global__ __launch_bounds__(256) void bin_fill_kernel(const int64_t nloc, const
     }
     if (b == nbins - 1 && threadIdx.x == 255) off[nloc] = ubase + run;
     __syncthreads();
-    for (int64_t t = t0 + threadIdx.x; t < t1; t += 256) {
-        const Triplet tr = trip[t];
-        const int slot = atomicAdd(&cnt[int64_t(tr.row) - p0], 1);
-        U[t0 + slot] = UEntry{(tr.col << 1) | 1u, 0u, tr.val};
+    {
+        int64_t t = t0 + threadIdx.x;
+        for (; t + 3 * 256 < t1; t += 4 * 256) {
+            const Triplet a0 = trip[t], a1 = trip[t + 256], a2 = trip[t + 512], a3 = trip[t + 768];
+            const int s0 = atomicAdd(&cnt[int64_t(a0.row) - p0], 1);
+            const int s1 = atomicAdd(&cnt[int64_t(a1.row) - p0], 1);
+            const int s2 = atomicAdd(&cnt[int64_t(a2.row) - p0], 1);
+            const int s3 = atomicAdd(&cnt[int64_t(a3.row) - p0], 1);
+            U[t0 + s0] = UEntry{(a0.col << 1) | 1u, 0u, a0.val};
+            U[t0 + s1] = UEntry{(a1.col << 1) | 1u, 0u, a1.val};
+            U[t0 + s2] = UEntry{(a2.col << 1) | 1u, 0u, a2.val};
+            U[t0 + s3] = UEntry{(a3.col << 1) | 1u, 0u, a3.val};
+        }
+        for (; t < t1; t += 256) {
+            const Triplet tr = trip[t];
+            const int slot = atomicAdd(&cnt[int64_t(tr.row) - p0], 1);
+            U[t0 + slot] = UEntry{(tr.col << 1) | 1u, 0u, tr.val};
+        }
     }
 }
 
