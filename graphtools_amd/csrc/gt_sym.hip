@@ -110,16 +110,32 @@ __global__ __launch_bounds__(256) void sym_thresholds_kernel(const int64_t n, co
             int64_t jmine = 0;
             if (c0 + uint32_t(sub) < kept) jmine = perm[cand_index(lists[size_t(p) * lstride + c0 + sub])];
             const uint32_t lim = kept - c0 < 16u ? kept - c0 : 16u;
-            for (uint32_t c = 0; c < lim; ++c) {
-                const int64_t j = __shfl(jmine, int(c), 16);
-                const T* yj = X + j * int64_t(d);
-                double acc = 0.0;
+            // four candidate rows at a time: their loads are in flight together (one after the other the loop is a chain
+            // of shuffle -> address -> load -> reduce latencies)
+            for (uint32_t c = 0; c < lim; c += 4u) {
+                int64_t j4[4];
+                double acc4[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    j4[i] = __shfl(jmine, int((c + i) & 15u), 16);
+                    acc4[i] = 0.0;
+                }
 #pragma unroll
                 for (int u = 0; u < 8; ++u)
-                    if (sub + 16 * u < d) acc = fma(xr[u], double(yj[sub + 16 * u]), acc);
+                    if (sub + 16 * u < d) {
+                        T y4[4];
 #pragma unroll
-                for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 16);
-                dk = fmax(dk, gt_pair_key(qs, acc, xn[j], 0));
+                        for (int i = 0; i < 4; ++i) y4[i] = X[j4[i] * int64_t(d) + sub + 16 * u];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) acc4[i] = fma(xr[u], double(y4[i]), acc4[i]);
+                    }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    double acc = acc4[i];
+#pragma unroll
+                    for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 16);
+                    if (c + i < lim) dk = fmax(dk, gt_pair_key(qs, acc, xn[j4[i]], 0));
+                }
             }
         }
         dk *= 1.0 + 1e-12;
