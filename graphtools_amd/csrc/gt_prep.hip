@@ -70,6 +70,29 @@ __global__ __launch_bounds__(256) void max_abs_kernel(const T* __restrict__ X, c
     if (__ballot(nan) != 0ull && (threadIdx.x & 63) == 0) atomicOr(out_bits + 1, 1ull);
 }
 
+// (float32 data, 16-byte loads: four independent maxima per thread - the scalar form above runs at 1 TB/s)
+__global__ __launch_bounds__(256) void max_abs_f4_kernel(const float4* __restrict__ X4, const int64_t total4,
+                                                         unsigned long long* __restrict__ out_bits) {
+    float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f;
+    bool nan = false;
+    for (int64_t f = int64_t(blockIdx.x) * 256 + threadIdx.x; f < total4; f += int64_t(gridDim.x) * 256) {
+        const float4 v = X4[f];
+        const float a = fabsf(v.x), b = fabsf(v.y), c = fabsf(v.z), e = fabsf(v.w);
+        nan |= (a != a) | (b != b) | (c != c) | (e != e);
+        m0 = a > m0 ? a : m0;   // NaN never wins, infinity does
+        m1 = b > m1 ? b : m1;
+        m2 = c > m2 ? c : m2;
+        m3 = e > m3 ? e : m3;
+    }
+    m0 = m0 > m1 ? m0 : m1;
+    m2 = m2 > m3 ? m2 : m3;
+    double m = double(m0 > m2 ? m0 : m2);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(out_bits, (unsigned long long)__double_as_longlong(m));
+    if (__ballot(nan) != 0ull && (threadIdx.x & 63) == 0) atomicOr(out_bits + 1, 1ull);
+}
+
 // split-float16 working copy: row = hi plane (DP halves) | lo plane (DP halves), x*sc = hi + lo + O(2^-22 |x*sc|)
 template <typename T>
 __global__ __launch_bounds__(256) void pad_split_f16_kernel(const T* __restrict__ X, int64_t n, int d, int DP,
@@ -223,7 +246,10 @@ int gt_max_abs(gt_ctx* ctx, const void* Xdev, int64_t total, int dtype, double* 
     GT_HIP(ctx, tmp.reserve(64));
     GT_HIP(ctx, hipMemsetAsync(tmp.p, 0, 2 * sizeof(double), ctx->stream));
     int64_t blocks = std::min<int64_t>(ceil_div64(total, 256), 4096);
-    if (dtype == GT_F32)
+    if (dtype == GT_F32 && (total & 3) == 0 && (reinterpret_cast<uintptr_t>(Xdev) & 15) == 0)
+        hipLaunchKernelGGL(max_abs_f4_kernel, dim3((unsigned)std::min<int64_t>(ceil_div64(total / 4, 256), 4096)), dim3(256), 0,
+                           ctx->stream, (const float4*)Xdev, total / 4, (unsigned long long*)tmp.p);
+    else if (dtype == GT_F32)
         hipLaunchKernelGGL(max_abs_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (const float*)Xdev,
                            total, (unsigned long long*)tmp.p);
     else
