@@ -9,21 +9,30 @@ Workload (BASELINE.json configs[2], SURVEY.md 8d "C3"): synthetic `mix` data, N 
 float32, seed 1; graphtools.Graph(X, knn=15, decay=40, thresh=1e-4) -> kernel K and diff_op P.
 One step = one complete build of K and P (row norms / padded copy, kNN candidate pass, fp64 re-rank, radius
 pass, affinities, symmetrisation, row normalisation) with the points already resident in HBM; results stay on
-the device ("device-complete").  On one GPU the candidate pass is the symmetric one (graphtools_amd/csrc/gt_sym.hip):
-a threshold-seeding launch over every row's neighbourhood, then one launch that scores every unordered pair of rows
-once and tests the result for both rows.  With N > 1 GPUs the rows are sharded over the ranks: every step additionally
-contains the RCCL all-gather of the point slices and the all-to-all of the transposed triplets (strong
-scaling: the graph is the same size on any number of GPUs).
+the device ("device-complete").  With N > 1 GPUs the rows are sharded over the ranks: every step additionally
+contains the RCCL all-gather of the point slices and the exchanges of the sharded build (strong scaling: the graph
+is the same size on any number of GPUs).
 
-Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` (dominant kernel =
-knn_select, MFMA-bound, timed with HIP events on the library's stream; `achieved` = the algorithmic 2 N^2 d flop of the
-pairwise-distance problem over the time of BOTH candidate launches, the matrix work actually executed is reported next
-to it) and, at N = 1, `cpu_baseline`
-(the numpy/scipy/scikit-learn oracle port timed on this host on a bounded sample).
+Prints ONE JSON line on rank 0 (contract in the task description).  Besides the contract's keys:
+
+  roofline        the kernel with the largest average launch time of the step, priced on the work it EXECUTES
+                  (MFMA instructions issued x 32768 flop, or the algorithmic HBM bytes of SURVEY 8d for the streaming
+                  kernels) over its launch time (HIP events on the library's stream) against the chip peak: frac <= 1
+  kernels         the same figures for every timed launch group of the step
+  sparse_tail     affinity + symmetrise + P as one HBM-bound block: algorithmic bytes, counter bytes from
+                  the committed rocprofv3 PMC pass of this command (profiles/), waste ratio
+  pruning         2 N^2 d (the flops a dense distance contraction would need) against the flops executed - a ratio that
+                  says how much the cell bounds prune, NOT a roofline figure
+  incl_h2d        the same step with the 256 MB upload of X from pinned host memory inside the timed region
+  host_complete   SURVEY 8d's apples-to-apples wall time: host float32 X in -> scipy CSR K and P out
+  secondary       the other workloads of SURVEY 8d that fit one GPU (manifold / gauss inputs, decay=None, C2, C4, C5)
+  cpu_baseline    the oracle port on this host's cores, bounded sample (and cpu_baseline_full: the whole of C3 once,
+                  live with --cpu-full, else the recorded run under profiles/ when it was made on an identical host)
 """
 import argparse
 import json
 import os
+import platform
 import sys
 import time
 
@@ -32,13 +41,17 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# MI355X_MICROARCH.md dense matrix peaks (256 CUs @ 2.4 GHz)
+# MI355X_MICROARCH.md: dense matrix peaks (256 CUs @ 2.4 GHz) and HBM3E
 MFMA_PEAK_TFLOPS = {"f16x1": 2500.0,  # v_mfma_f32_32x32x16_f16, one chain per product (high float16 plane)
                     "f16": 2500.0,    # same instruction, split float16: 3 chains per product
                     "f32": 157.3}     # v_mfma_f32_32x32x2_f32
 MFMA_CHAINS = {"f16x1": 1.0, "f16": 3.0, "f32": 1.0}
-SELECT_KERNEL = {"f16x1": "knn_select_kernel<64, 8, 0, 2>", "f16": "knn_select_kernel<64, 8, 0, 1>",
-                 "f32": "knn_select_kernel<64, 8, 0, 0>"}
+HBM_PEAK_GBS = 8000.0
+PROFILE_TRAFFIC = os.path.join(ROOT, "profiles", "r3_pmc_fetch_write_per_kernel.json")
+PROFILE_CPU_FULL = os.path.join(ROOT, "profiles", "r3_cpu_baseline_full_c3.json")
+
+STAGES = ("prep", "query_order", "sym_prepare", "sym_seed", "sym_bound", "knn_select", "sym_cold", "rerank", "fallback",
+          "radius", "affinity", "symmetrize", "normalize")
 
 
 def make_mix(n, d, seed, dtype=np.float32):
@@ -54,55 +67,92 @@ def make_mix(n, d, seed, dtype=np.float32):
     return out
 
 
-SYM_KERNEL = "knn_select_kernel<64, 8, 2, 2>"   # symmetric collect (single float16 chain), one-stage
-SYM2_KERNEL = "knn_select_kernel<16, 8, 3, 2>"  # symmetric collect, two-stage: 16 features in the unit loop ...
-SYM_COLD_KERNEL = "sym_cold_kernel<64>"         # ... survivors scored in full by the cold launch
-SYM_SEED_KERNEL = "knn_select_kernel<64, 8, 0, 2>"   # threshold-seeding launch of the symmetric pass
-BOUND_KERNELS = ("cell_ball_kernel", "cell_mask_kernel<64>", "bound_queue_kernel")   # bound pass (replaces the collect launch)
+def make_manifold(n, d, seed):
+    rng = np.random.default_rng(seed)
+    a = rng.standard_normal((5, d))
+    out = np.empty((n, d), dtype=np.float32)
+    for s in range(0, n, 100000):
+        e = min(n, s + 100000)
+        out[s:e] = rng.standard_normal((e - s, 5)) @ a + 0.01 * rng.standard_normal((e - s, d))
+    return out
 
 
-def measured_traffic(n, d, precision, world, symmetric):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE doubled per
-    MI355X_MICROARCH.md + WRITE_SIZE, profiles/r*_pmc_fetch_write_per_kernel*.json).  PMC counters cannot be read
-    from inside this process, so the number is only reported for the exact workload that was profiled."""
-    if not (n == 1000000 and d == 64 and world == 1):
-        return None
+def make_gauss(n, d, seed):
+    rng = np.random.default_rng(seed)
+    out = np.empty((n, d), dtype=np.float32)
+    for s in range(0, n, 100000):
+        e = min(n, s + 100000)
+        out[s:e] = rng.standard_normal((e - s, d))
+    return out
+
+
+def host_info():
+    info = {"logical_cpus": os.cpu_count(), "machine": platform.machine()}
     try:
-        if symmetric:
-            # every launch of the candidate pass that the profiled run made: seeding, bound pass or collect, cold launch
-            with open(os.path.join(ROOT, "profiles", "r2_pmc_fetch_write_per_kernel.json")) as f:
-                ks = json.load(f)["kernels"]
-            tot = 0.0
-            for name, k in ks.items():
-                if name in (SYM_SEED_KERNEL, SYM2_KERNEL, SYM_KERNEL, SYM_COLD_KERNEL) or any(name.endswith(b) or b in name for b in BOUND_KERNELS):
-                    tot += (k["hbm_read_GB_per_launch_corrected_x2"] + k["hbm_write_GB_per_launch"]) * k.get("launches", 1)
-            return tot * 1e9
-        else:
-            name = {"f16x1": "f16x1", "f16": "f16split"}[precision]
-            with open(os.path.join(ROOT, "profiles", "r1_pmc_fetch_write_per_kernel_%s.json" % name)) as f:
-                k = json.load(f)["kernels"][SELECT_KERNEL[precision]]
-        return (k["hbm_read_GB_per_launch_corrected_x2"] + k["hbm_write_GB_per_launch"]) * 1e9
+        import psutil
+
+        info["physical_cores"] = psutil.cpu_count(logical=False)
+        info["ram_GB"] = round(psutil.virtual_memory().total / 2**30)
+    except Exception:
+        info["physical_cores"] = None
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    info["cpu_model"] = line.split(":", 1)[1].strip()
+                    break
+    except Exception:
+        pass
+    try:
+        from threadpoolctl import threadpool_info
+
+        info["threadpools"] = [{"api": i.get("user_api"), "lib": i.get("internal_api"), "threads": i.get("num_threads")}
+                               for i in threadpool_info()]
+    except Exception:
+        pass
+    vers = {"numpy": np.__version__}
+    for mod in ("scipy", "sklearn"):
+        try:
+            vers[mod] = __import__(mod).__version__
+        except Exception:
+            vers[mod] = None
+    info["versions"] = vers
+    return info
+
+
+def worker_threads(info):
+    th = [p.get("threads") or 1 for p in info.get("threadpools", [])]
+    return int(max(th + [1]))
+
+
+def profiled_traffic(kernel_names):
+    """HBM bytes per launch for the named kernels from the committed rocprofv3 PMC passes of this command (FETCH_SIZE with
+    the gfx950 correction of MI355X_MICROARCH.md + WRITE_SIZE, tools/pmc_traffic_summary.py).  PMC counters cannot be read
+    from inside the benchmarked process; None when the profile does not hold the kernel."""
+    try:
+        with open(PROFILE_TRAFFIC) as f:
+            ks = json.load(f)["kernels"]
     except Exception:
         return None
+    tot, found = 0.0, False
+    for name, k in ks.items():
+        if any(name.startswith(kn) or kn in name for kn in kernel_names):
+            tot += (k["hbm_read_GB_per_launch_corrected_x2"] + k["hbm_write_GB_per_launch"]) * k.get("launches", 1)
+            found = True
+    return tot * 1e9 if found else None
 
 
-def cpu_baseline(X, knn, decay, thresh, ctx, params_factory, budget_s=25.0):
-    """Oracle port (numpy/scipy + the reference's scikit-learn call sites) on this host's cores.
+def cpu_baseline_sample(X, knn, decay, thresh, K0, info, budget_s=25.0):
+    """Oracle port (numpy/scipy + the reference's scikit-learn call sites) on this host's cores, bounded sample.
 
     kNN search + radius fallback + CSR rows are timed on a block of query rows against the full database and
-    scaled by N / block (row-separable work); symmetrisation + diff_op are timed at full size on the real
-    unsymmetrised kernel."""
+    scaled by N / block (row-separable work); symmetrisation + diff_op are timed at full size on the unsymmetrised
+    kernel K0 (produced by the device, data only - not timed)."""
     import oracle
-    from scipy import sparse
 
     n = X.shape[0]
-    try:
-        import sklearn  # noqa: F401
-        engine = "sklearn"
-    except Exception:
-        engine = "numpy"
+    engine = "sklearn" if info["versions"].get("sklearn") else "numpy"
     m = min(1024, n)
-    t_rows = None
     while True:
         t0 = time.perf_counter()
         oracle.knn_kernel(X, knn=knn + 1, decay=decay, thresh=thresh, Y=X[:m], engine=engine)
@@ -111,31 +161,234 @@ def cpu_baseline(X, knn, decay, thresh, ctx, params_factory, budget_s=25.0):
             break
         m = min(n, m * (4 if t_rows < 0.1 * budget_s else 2))
     t_knn_full = t_rows * (n / m)
-    # sparse tail at full size on the unsymmetrised kernel produced by the device (data only, not timed)
-    p, keep = params_factory(None)
-    ctx.graph_build(p)
-    from graphtools_amd import _hip
-
-    d_, i_, p_ = ctx.graph_fetch_csr(_hip.CSR_K)
-    K0 = sparse.csr_matrix((d_, i_, p_), shape=(n, n))
     t0 = time.perf_counter()
     K = oracle.symmetrize_kernel(K0, "+")
+    from scipy import sparse
+
     oracle.kernel.diff_op_fast(sparse.csr_matrix(K))
     t_tail = time.perf_counter() - t0
-    threads = os.cpu_count()
-    try:
-        from threadpoolctl import threadpool_info
-
-        threads = max([i.get("num_threads", 1) for i in threadpool_info()] + [1])
-    except Exception:
-        pass
     total = t_knn_full + t_tail
     return {
-        "value": 1.0 / total, "unit": "graphs/s", "cores": int(threads), "kind": "port",
+        "value": 1.0 / total, "unit": "graphs/s", "cores": worker_threads(info), "physical_cores": info.get("physical_cores"),
+        "kind": "port",
         "sample": "oracle port (%s kNN engine): kNN+affinity rows timed on %d of %d query rows against the full database "
                   "(%.2f s, scaled x%.1f), symmetrise+diff_op timed at full size (%.2f s); estimated full build %.1f s"
                   % (engine, m, n, t_rows, n / m, t_tail, total),
+        "versions": info["versions"],
     }
+
+
+def cpu_baseline_full(X, knn, decay, thresh, info):
+    """The whole of C3 through the oracle port, once (SURVEY 8d "C3 timed in full"): minutes of host time."""
+    import oracle
+
+    engine = "sklearn" if info["versions"].get("sklearn") else "numpy"
+    t0 = time.perf_counter()
+    K0 = oracle.knn_kernel(X, knn=knn, decay=decay, thresh=thresh, engine=engine)
+    t1 = time.perf_counter()
+    K = oracle.symmetrize_kernel(K0, "+")
+    from scipy import sparse
+
+    K = sparse.csr_matrix(K)
+    P = oracle.kernel.diff_op_fast(K)
+    t2 = time.perf_counter()
+    return {"value": 1.0 / (t2 - t0), "unit": "graphs/s", "seconds": t2 - t0, "kernel_rows_s": t1 - t0, "symmetrise_P_s": t2 - t1,
+            "nnz_K": int(K.nnz), "nnz_P": int(P.nnz), "cores": worker_threads(info), "physical_cores": info.get("physical_cores"),
+            "kind": "port", "sample": "all %d rows, measured live (--cpu-full)" % X.shape[0], "host": info}
+
+
+def recorded_cpu_full(info):
+    """The committed full-size run, reported only when it was made on the same kind of host (cpu model, core count,
+    library versions) - otherwise it says nothing about this box."""
+    try:
+        with open(PROFILE_CPU_FULL) as f:
+            rec = json.load(f)
+    except Exception:
+        return None
+    h = rec.get("host", {})
+    same = (h.get("cpu_model") == info.get("cpu_model") and h.get("logical_cpus") == info.get("logical_cpus")
+            and h.get("versions") == info.get("versions"))
+    rec = dict(rec)
+    rec["sample"] = "all rows, recorded run (profiles/%s), host %s" % (os.path.basename(PROFILE_CPU_FULL),
+                                                                       "identical to this one" if same else "DIFFERENT from this one")
+    rec["host_matches"] = bool(same)
+    rec.pop("host", None)
+    return rec
+
+
+class StageTimes:
+    """per-step stage times of a context (HIP events on the library's stream), averaged over the timed steps"""
+
+    def __init__(self):
+        self.acc = {s: [] for s in STAGES}
+
+    def record(self, ctx):
+        for s in STAGES:
+            self.acc[s].append(max(ctx.stage_ms(s), 0.0))   # (-1: the stage did not run)
+
+    def mean(self, s):
+        return float(np.mean(self.acc[s])) if self.acc[s] else 0.0
+
+
+def kernel_table(ctx, st, n, nloc, d, world, nnz, nnz0, main):
+    """One entry per timed launch group: what it executes (flop / algorithmic bytes), its time, its roofline fraction."""
+    kst = ctx.knn_stats()
+    symmetric = bool(kst["symmetric"])
+    two_stage = symmetric and bool(kst.get("sym_two_stage", False))
+    bound_pass = two_stage and bool(kst.get("sym_bound_pass", False))
+    peak = MFMA_PEAK_TFLOPS[main]
+    rows = []
+
+    def mfma(name, kernel, ms, flop, note=""):
+        if ms <= 0:
+            return
+        ach = flop / (ms * 1e-3) / 1e12
+        rows.append({"stage": name, "kernel": kernel, "bound": "mfma", "avg_launch_ms": ms, "executed_flop": flop,
+                     "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "note": note})
+
+    def hbm(name, kernel, ms, nbytes, note=""):
+        if ms <= 0:
+            return
+        ach = nbytes / (ms * 1e-3) / 1e9
+        rows.append({"stage": name, "kernel": kernel, "bound": "hbm", "avg_launch_ms": ms, "algorithmic_bytes": nbytes,
+                     "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "note": note})
+
+    if symmetric:
+        seed_flop = float(kst.get("sym_seed_flop", 0)) or 2.0 * d * 256 * 128 * kst.get("sym_seed_tiles", 0)
+        mfma("sym_seed", kst.get("sym_seed_kernel", "knn_select_kernel<64, 8, 0, 2>"), st.mean("sym_seed"), seed_flop,
+             "threshold seeding: every row against its neighbourhood cells")
+        cold_flop = 2.0 * d * 64 * 32 * kst.get("sym_cold_pairs", 0)
+        if two_stage:
+            mfma("sym_cold", "sym_cold_kernel<%d>" % d, st.mean("sym_cold"), cold_flop,
+                 "(64 queries x 32 rows) units left by the cell bounds / stage one, scored in full")
+        if not bound_pass and st.mean("knn_select") > 0:
+            if two_stage:
+                n_pad = -(-n // 1024) * 1024
+                nb = n_pad // 1024
+                walk = 8 * (1 + (nb - 1) // 2) + (0 if nb % 2 else 8)
+                flop = 2.0 * 16 * 1024 * 128 * nb * walk / world
+                mfma("knn_select", "knn_select_kernel<16, 8, 3, 2>", st.mean("knn_select"), flop, "stage one of the two-stage collect")
+            else:
+                n_pad = -(-n // 256) * 256
+                nb = n_pad // 256
+                walk = 2 * (1 + (nb - 1) // 2) + (0 if nb % 2 else 2)
+                flop = 2.0 * d * 256 * 128 * nb * walk / world
+                mfma("knn_select", "knn_select_kernel<%d, 8, 2, 2>" % d, st.mean("knn_select"), flop, "one-stage symmetric collect")
+    else:
+        mfma("knn_select", "knn_select_kernel<%d, 8, 0, %d>" % (d, {"f32": 0, "f16": 1, "f16x1": 2}[main]), st.mean("knn_select"),
+             2.0 * nloc * n * d * MFMA_CHAINS[main], "classic candidate pass: every query row against every point")
+    # streaming kernels, algorithmic bytes per SURVEY 8d
+    tab = 128   # table entries the re-rank evaluates / the affinity pass reads per row (first batch)
+    hbm("rerank", "rerank_sym_kernel" if symmetric else "rerank_kernel", st.mean("rerank"),
+        nloc * tab * 8.0 + n * d * 4.0 + nloc * tab * 12.0,
+        "candidate lists in (8 B), X once, exact tables out (8 + 4 B); the row gathers come from L2/MALL")
+    hbm("affinity", "bandwidth_kernel + affinity_kernel", st.mean("affinity"), nloc * tab * 12.0 + nnz0 * 8.0,
+        "tables in (8 + 4 B per entry), kept values written in place")
+    hbm("symmetrize", "bin_count/bin_emit/bin_fill + sort_merge + compact (K, P)", st.mean("symmetrize"),
+        2.0 * nnz0 * 12.0 + nnz * 12.0 + nnz * 12.0 + nnz * 8.0,
+        "SURVEY 8d: read K0 and K0^T entries, write K; read K, write P")
+    return rows, {"symmetric": symmetric, "two_stage": two_stage, "bound_pass": bound_pass, "knn_stats": kst}
+
+
+def timed_builds(ctx, params, x_dev_ptr, n, d, steps, warmup, sync):
+    for _ in range(warmup):
+        ctx.set_points_device(x_dev_ptr, n, d, np.float32)
+        ctx.graph_build(params)
+    sync()
+    st = StageTimes()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ctx.set_points_device(x_dev_ptr, n, d, np.float32)
+        nnz, _ = ctx.graph_build(params)
+        st.record(ctx)
+    sync()
+    return (time.perf_counter() - t0) / steps * 1e3, nnz, st
+
+
+def secondary_knn(_hip, torch, device, name, X, knn=15, decay=40.0, steps=3):
+    """device-complete build of a secondary workload: {ms_per_graph, graphs_per_s, path, stage_ms}"""
+    ctx = _hip.Context(device.index or 0)
+    try:
+        n, d = X.shape
+        x_dev = torch.from_numpy(X).to(device)
+        params, keep = ctx.make_params(knn, decay, 1e-4, None, 1.0, None, "+", None, 0)
+
+        def sync():
+            torch.cuda.synchronize(device)
+            ctx.sync()
+
+        ms, nnz, st = timed_builds(ctx, params, x_dev.data_ptr(), n, d, steps, 2, sync)
+        kst = ctx.knn_stats()
+        path = "classic candidate pass (%s)" % ctx.last_knn_precision()
+        if kst["symmetric"]:
+            path = "symmetric pass: " + ("cell bounds + cold launch" if kst.get("sym_bound_pass") else
+                                         "two-stage collect" if kst.get("sym_two_stage") else "one-stage collect")
+        gs = ctx.graph_stats()
+        return {"workload": name, "ms_per_graph": ms, "graphs_per_s": 1e3 / ms, "nnz_K": int(nnz), "path": path,
+                "radius_rows": gs["radius_rows"], "repaired_rows": gs["fallback_rows"],
+                "stage_ms": {s: round(st.mean(s), 3) for s in STAGES if st.mean(s) > 0}}
+    finally:
+        ctx.close()
+
+
+def secondary_c4(_hip, torch, device, n=200000, d=100):
+    """BASELINE config 4: exact dense graph + diff_op from a device-resident float32 distance matrix (160 GB), in place."""
+    import ctypes
+
+    X = torch.from_numpy(make_mix(n, d, 2)).to(device)
+    D = torch.empty((n, n), dtype=torch.float32, device=device)
+    for r in range(0, n, 8192):
+        D[r: r + 8192] = torch.cdist(X[r: r + 8192], X)
+    D.fill_diagonal_(0.0)
+    torch.cuda.synchronize(device)
+    ctx = _hip.Context(device.index or 0)
+    try:
+        flags = ctypes.c_uint32(0)
+        t0 = time.perf_counter()
+        rc = ctx.lib.gt_dense_graph_build(ctx.h, ctypes.c_void_p(D.data_ptr()), n, 0, 0, 1, 1, 15, 40.0, 1e-4, None, 0, 1.0,
+                                          _hip.SYMM["+"], 1.0, 0.0, 1, None, None, 1, ctypes.byref(flags))
+        ctx._check(rc, "gt_dense_graph_build")
+        ctx.sync()
+        wall = time.perf_counter() - t0
+        st = {s: round(ctx.stage_ms(s), 2) for s in ("dense_bandwidth", "dense_kernel", "dense_normalize")}
+        nbytes = 20.0 * n * n   # SURVEY 8d: 4 N^2 x (D twice, K out, K in, P out)
+        return {"workload": "C4: mix N=%d d=%d seed=2, TraditionalGraph knn=15 decay=40 from a resident float32 distance matrix "
+                            "(precomputed='distance'), K in place + degrees (one build: the input is consumed)" % (n, d),
+                "ms_per_graph": wall * 1e3, "graphs_per_s": 1.0 / wall, "stage_ms": st,
+                "roofline": {"bound": "hbm", "algorithmic_bytes": nbytes, "achieved": nbytes / wall / 1e9, "peak": HBM_PEAK_GBS,
+                             "unit": "GB/s", "frac": nbytes / wall / 1e9 / HBM_PEAK_GBS}}
+    finally:
+        ctx.close()
+        del D, X
+        torch.cuda.empty_cache()
+        _hip.release_cached_memory()
+
+
+def secondary_c5(n=1000000, d=50):
+    """BASELINE config 5 on one GPU: kNN kernel + landmark operator (random landmarking), host arrays in and out."""
+    import warnings
+
+    import graphtools_amd
+
+    X = make_mix(n, d, 3)
+    best = None
+    for _ in range(2):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            t0 = time.perf_counter()
+            G = graphtools_amd.Graph(X, knn=15, decay=40, n_pca=None, n_landmark=2000, random_landmarking=True,
+                                     random_state=42, verbose=0)
+            t1 = time.perf_counter()
+            op = G.landmark_op
+            t2 = time.perf_counter()
+        cur = {"kernel_s": t1 - t0, "landmark_op_s": t2 - t1, "total_s": t2 - t0, "L": int(op.shape[0])}
+        if best is None or cur["total_s"] < best["total_s"]:
+            best = cur
+        del G, op
+    best["workload"] = "C5 on one GPU: mix N=%d d=%d seed=3, knn=15 decay=40, n_landmark=2000 random landmarking -> landmark_op; " \
+                       "host-complete (host X in, host operator out)" % (n, d)
+    best["graphs_per_s"] = 1.0 / best["total_s"]
+    return best
 
 
 def main():
@@ -148,6 +401,9 @@ def main():
     ap.add_argument("--knn", type=int, default=15)
     ap.add_argument("--decay", type=float, default=40.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-full", action="store_true", help="time the oracle port on ALL rows of the workload (minutes)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary workloads / host-complete legs")
+    ap.add_argument("--secondary-only", default="", help="comma list out of manifold,gauss,binary,c2,c4,c5")
     ap.add_argument("--knn-precision", choices=["auto", "f16x1", "f16", "f32"],
                     default=os.environ.get("GT_KNN_PRECISION", "auto"),
                     help="arithmetic of the candidate pass (results are identical; see DESIGN.md); auto = the library "
@@ -205,15 +461,11 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    select_ms, seed_ms, cold_ms, bound_ms = [], [], [], []
+    st = StageTimes()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         nnz, flags = step()
-        # stage timers were recorded with hipEvents on the library's own stream during the step
-        select_ms.append(max(ctx.stage_ms("knn_select"), 0.0))   # (-1: the bound pass listed the units, no collect launch)
-        bound_ms.append(max(ctx.stage_ms("sym_bound"), 0.0))
-        seed_ms.append(max(ctx.stage_ms("sym_seed"), 0.0))
-        cold_ms.append(max(ctx.stage_ms("sym_cold"), 0.0))
+        st.record(ctx)   # stage timers were recorded with hipEvents on the library's own stream during the step
     fence()
     elapsed = time.perf_counter() - t0
     if distributed:
@@ -225,56 +477,25 @@ def main():
         nnz_total = int(nz.item())
     else:
         nnz_total = int(nnz)
-    out = None
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         nloc = int(splits[1] - splits[0])
-        flops = 2.0 * nloc * n * d                      # algorithmic: 2*d flop per (query, database row) pair
-        main = ctx.last_knn_precision()                 # what the main candidate pass actually ran on
-        peak = MFMA_PEAK_TFLOPS[main]
-        kst = ctx.knn_stats()
-        symmetric = bool(kst["symmetric"])
-        main_ms, seeding_ms, cold_launch_ms = float(np.mean(select_ms)), float(np.mean(seed_ms)), float(np.mean(cold_ms))
-        two_stage = symmetric and bool(kst.get("sym_two_stage", False))
-        bound_pass = two_stage and bool(kst.get("sym_bound_pass", False))
-        bound_launch_ms = float(np.mean(bound_ms)) if two_stage else 0.0
-        # the candidate pass = all of its launches (seeding + [bound pass] + [collect] [+ cold launch of the two-stage collect])
-        avg_ms = main_ms + (seeding_ms if symmetric else 0.0) + (cold_launch_ms if two_stage else 0.0) + bound_launch_ms
-        achieved = flops / (avg_ms * 1e-3) / 1e12
-        if symmetric:
-            # executed matrix work: every unordered pair of (padded) rows once, plus the tiles of the seeding launch
-            # (256-row blocks x 128-row tiles, all d features).  One-stage collect: all d features of every pair;
-            # two-stage: 16 features of every pair (1024-row query blocks) + all d of the pairs the cold launch scores
-            # (64 queries x 32 rows each).  Row-sharded: every rank walks 1/world of the pieces, seeds 1/world of the blocks.
-            seed_flop = 2.0 * d * 256 * 128 * kst.get("sym_seed_tiles", 0)
-            if two_stage:
-                n_pad = -(-n // 1024) * 1024
-                nb = n_pad // 1024
-                walk_tiles = 8 * (1 + (nb - 1) // 2) + (0 if nb % 2 else 8)
-                cold_flop = 2.0 * d * 64 * 32 * kst.get("sym_cold_pairs", 0) * world
-                if bound_pass:
-                    # the cell bounds decide the units: no unit loop over the pairs, only the units left are scored
-                    # (the bound kernels themselves: L^2 cell pairs x d flop, not counted)
-                    collect_flop = cold_flop
-                    kname = "bound pass (cell_ball / cell_mask / bound_queue kernels, no collect launch) + " + SYM_COLD_KERNEL
-                else:
-                    collect_flop = 2.0 * 16 * 1024 * 128 * nb * walk_tiles + cold_flop
-                    kname = SYM2_KERNEL + " + " + SYM_COLD_KERNEL
-            else:
-                n_pad = -(-n // 256) * 256
-                nb = n_pad // 256
-                walk_tiles = 2 * (1 + (nb - 1) // 2) + (0 if nb % 2 else 2)
-                collect_flop = 2.0 * d * 256 * 128 * nb * walk_tiles
-                kname = SYM_KERNEL
-            executed = (collect_flop + seed_flop) / world
-            kernel_name = "%s + the threshold-seeding launch knn_select_kernel<64, 8, 0, 2> (symmetric f16x1 MFMA candidate " \
-                          "pass, knn_precision=%s): every unordered pair of rows %s" % (
-                              kname, args.knn_precision,
-                              "decided once - by its cells' bound or by its score" if bound_pass else "scored once")
-        else:
-            executed = flops * MFMA_CHAINS[main]
-            kernel_name = "%s (%s MFMA candidate pass, knn_precision=%s)" % (SELECT_KERNEL[main], main, args.knn_precision)
+        main_prec = ctx.last_knn_precision()                 # what the main candidate pass actually ran on
         stats = ctx.graph_stats()
+        nnz0 = int(stats["nnz_unsymmetrised"])
+        rows, flags_ = kernel_table(ctx, st, n, nloc, d, world, int(nnz), nnz0, main_prec)
+        dominant = max(rows, key=lambda r: r["avg_launch_ms"])
+        roof = {k: dominant[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_ms")}
+        roof["stage"] = dominant["stage"]
+        roof["share_of_step"] = dominant["avg_launch_ms"] / ms_per_step
+        roof["traffic"] = profiled_traffic([dominant["kernel"].split(" ")[0]]) if (n == 1000000 and d == 64 and world == 1) else None
+        roof["traffic_unit"] = "bytes/launch"
+        roof["work_per_launch"] = dominant.get("executed_flop", dominant.get("algorithmic_bytes"))
+        executed = sum(r.get("executed_flop", 0.0) for r in rows)
+        tail_ms = st.mean("affinity") + st.mean("symmetrize") + st.mean("normalize")
+        tail_bytes = sum(r["algorithmic_bytes"] for r in rows if r["stage"] in ("affinity", "symmetrize"))
+        tail_counter = profiled_traffic(["bandwidth_kernel", "affinity_kernel", "bin_", "sort_merge", "compact_kernel", "scan_",
+                                         "gather_counts", "scatter_", "sym_invperm", "symm_"]) if (n == 1000000 and d == 64 and world == 1) else None
         out = {
             "metric": "graphs/sec (kernel+diff_op) at N=1e6 d=64 k=15",
             "value": args.steps / elapsed,
@@ -285,35 +506,125 @@ def main():
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
             "scaling": "strong",
-            "vs_baseline": None,
-            "dtype": {"f16x1": "f16", "f16": "f16x2-split", "f32": "f32"}[main] + " MFMA candidates + f64 re-rank/affinities",
+            "vs_baseline": None,   # the reference publishes no number for this metric
+            "dtype": {"f16x1": "f16", "f16": "f16x2-split", "f32": "f32"}[main_prec] + " MFMA candidate filter (proven error bound) + f64 re-rank/affinities: every emitted value is float64 as in the reference",
             "data": "synthetic",
             "config": {"workload": "C3: mix N=%d d=%d float32 seed=1, kNNGraph knn=%d decay=%g thresh=1e-4, "
-                                   "kernel_symm='+', device-complete K and P" % (n, d, args.knn, args.decay),
-                       "row_sharding": "%d rank(s) x %d rows" % (world, nloc), "nnz_K": nnz_total,
+                                   "kernel_symm='+', points resident in HBM, device-complete K and P" % (n, d, args.knn, args.decay),
+                       "row_sharding": "%d rank(s) x %d rows" % (world, nloc), "nnz_K": nnz_total, "nnz_K0_rank0": nnz0,
                        "radius_rows_rank0": stats["radius_rows"], "fallback_rows_rank0": stats["fallback_rows"],
-                       "symmetric_candidate_pass": symmetric, "two_stage_collect": two_stage, "bound_pass": bound_pass},
-            "roofline": {"kernel": kernel_name,
-                         "bound": "mfma",
-                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "traffic": measured_traffic(n, d, main, world, symmetric), "traffic_unit": "bytes/launch",
-                         "avg_launch_ms": avg_ms, "main_launch_ms": main_ms, "seeding_launch_ms": seeding_ms if symmetric else 0.0,
-                         "cold_launch_ms": cold_launch_ms if two_stage else 0.0, "bound_pass_ms": bound_launch_ms,
-                         "algorithmic_flop_per_launch": flops,
-                         "executed_mfma_flop_per_launch": executed,
-                         "executed_mfma_frac": executed / (avg_ms * 1e-3) / 1e12 / peak},
-            "stage_ms_last_step": {s: round(ctx.stage_ms(s), 3) for s in
-                                   ("prep", "query_order", "sym_prepare", "sym_seed", "sym_bound", "knn_select", "sym_cold", "rerank", "fallback",
-                                    "radius", "affinity", "symmetrize", "normalize")},
+                       "symmetric_candidate_pass": flags_["symmetric"], "two_stage_collect": flags_["two_stage"],
+                       "bound_pass": flags_["bound_pass"]},
+            "roofline": roof,
+            "kernels": [{k: (round(v, 4) if isinstance(v, float) and k not in ("executed_flop", "algorithmic_bytes") else v)
+                         for k, v in r.items()} for r in rows],
+            "sparse_tail": {"stages": "affinity + symmetrise + P", "ms": tail_ms, "algorithmic_bytes": tail_bytes,
+                            "achieved_GBs": tail_bytes / (tail_ms * 1e-3) / 1e9 if tail_ms > 0 else None,
+                            "frac_of_hbm_peak": tail_bytes / (tail_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if tail_ms > 0 else None,
+                            "counter_bytes": tail_counter,
+                            "waste_ratio": (tail_counter / tail_bytes) if tail_counter else None},
+            "pruning": {"dense_contraction_flop_2N2d": 2.0 * nloc * n * d, "executed_mfma_flop": executed,
+                        "ratio": (2.0 * nloc * n * d / executed) if executed else None,
+                        "note": "how much of the N x d . d x N contraction the cell bounds and fixed thresholds prove "
+                                "unnecessary; a pruning ratio, not a roofline figure"},
+            "stage_ms": {s: round(st.mean(s), 3) for s in STAGES if st.mean(s) > 0},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(X, args.knn, args.decay, thresh, ctx, params_factory)
+        info = host_info()
+        single = world == 1 and not distributed
+        if single:
+            # ---- the same step with the upload of X inside the timed region (pinned host memory) ----
+            try:
+                x_pin = torch.from_numpy(X).pin_memory()
+                x_dev = torch.empty_like(x_local)
+                torch.cuda.synchronize(device)
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    x_dev.copy_(x_pin, non_blocking=True)
+                    torch.cuda.synchronize(device)
+                    ctx.set_points_device(x_dev.data_ptr(), n, d, np.float32)
+                    ctx.graph_build(params)
+                fence()
+                ms = (time.perf_counter() - t0) / args.steps * 1e3
+                out["incl_h2d"] = {"ms_per_graph": ms, "graphs_per_s": 1e3 / ms,
+                                   "note": "X (%.0f MB) copied from pinned host memory inside the timed region" % (X.nbytes / 1e6)}
+                del x_pin, x_dev
+            except Exception as e:   # pragma: no cover
+                out["incl_h2d"] = {"error": repr(e)}
+        K0 = None
+        if single and not args.no_cpu_baseline:
+            from scipy import sparse
+
+            p0, keep0 = params_factory(None)
+            ctx.graph_build(p0)
+            d_, i_, p_ = ctx.graph_fetch_csr(_hip.CSR_K)
+            K0 = sparse.csr_matrix((d_, i_, p_), shape=(n, n))
+            ctx.graph_build(params)
+        ctx.close()
+        ctx = None
+        del x_local
+        torch.cuda.empty_cache()
+        want = [w for w in args.secondary_only.split(",") if w] or ["manifold", "gauss", "binary", "c2", "c4", "c5"]
+        if single and not args.no_secondary:
+            # ---- host-complete: host X in -> scipy CSR K, P out (SURVEY 8d headline definition) ----
+            try:
+                import graphtools_amd
+
+                ts = []
+                for _ in range(3):
+                    t0 = time.perf_counter()
+                    G = graphtools_amd.Graph(X, knn=args.knn, decay=args.decay, n_pca=None, verbose=0)
+                    Kh, Ph = G.K, G.P
+                    ts.append(time.perf_counter() - t0)
+                    nnz_h = int(Kh.nnz)
+                    del G, Kh, Ph
+                out["host_complete"] = {"ms_per_graph": float(np.median(ts)) * 1e3, "graphs_per_s": 1.0 / float(np.median(ts)),
+                                        "runs_s": [round(t, 4) for t in ts], "nnz_K": nnz_h,
+                                        "note": "graphtools_amd.Graph(X, knn=15, decay=40).K/.P: pageable host X in, scipy CSR out "
+                                                "(H2D 256 MB, build, D2H of K values + indices + indptr and of P values)"}
+            except Exception as e:   # pragma: no cover
+                out["host_complete"] = {"error": repr(e)}
+            sec = {}
+            jobs = {
+                "manifold": lambda: secondary_knn(_hip, torch, device, "manifold N=1e6 d=64 seed=1 (5 dimensions embedded in 64), knn=15 decay=40",
+                                                  make_manifold(1000000, 64, 1)),
+                "gauss": lambda: secondary_knn(_hip, torch, device, "gauss N=1e6 d=64 seed=1 (isotropic: no structure to prune), knn=15 decay=40",
+                                               make_gauss(1000000, 64, 1), steps=2),
+                "binary": lambda: secondary_knn(_hip, torch, device, "C3 with decay=None (connectivity kernel): mix N=1e6 d=64 seed=1, knn=15",
+                                                X, decay=None),
+                "c2": lambda: secondary_knn(_hip, torch, device, "C2: mix N=1e5 d=50 seed=0, knn=15 decay=40", make_mix(100000, 50, 0), steps=5),
+                "c4": lambda: secondary_c4(_hip, torch, device),
+                "c5": lambda: secondary_c5(),
+            }
+            for name in want:
+                t0 = time.perf_counter()
+                try:
+                    sec[name] = jobs[name]()
+                except Exception as e:   # pragma: no cover
+                    sec[name] = {"error": repr(e)}
+                sec[name]["leg_wall_s"] = round(time.perf_counter() - t0, 1)
+                _hip.release_cached_memory()
+            out["secondary"] = sec
+        if single and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline_sample(X, args.knn, args.decay, thresh, K0, info)
+            full = cpu_baseline_full(X, args.knn, args.decay, thresh, info) if args.cpu_full else recorded_cpu_full(info)
+            if full and args.cpu_full:
+                # (copied to profiles/ by hand: the recorded run later invocations on an identical host report)
+                os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+                with open(os.path.join(ROOT, "gpurun_out", os.path.basename(PROFILE_CPU_FULL)), "w") as f:
+                    json.dump(full, f, indent=1)
+            if full:
+                full = {k: v for k, v in full.items() if k != "host"}
+                out["cpu_baseline_full"] = full
+                out["vs_cpu_baseline_full"] = out["value"] * full["seconds"] if "seconds" in full else None
+            out["vs_cpu_baseline_sampled"] = out["value"] / out["cpu_baseline"]["value"]
+        out["host"] = {k: info[k] for k in ("cpu_model", "logical_cpus", "physical_cores") if k in info}
         print(json.dumps(out))
         sys.stdout.flush()
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
-    ctx.close()
+    if ctx is not None:
+        ctx.close()
 
 
 if __name__ == "__main__":

@@ -46,6 +46,7 @@ def _units():
     for name in ("gt_prep.hip", "gt_rerank.hip", "gt_sparse.hip", "gt_dense.hip", "gt_landmark.hip", "gt_debug.hip", "gt_order.hip", "gt_sym.hip", "gt_pca.hip", "gt_thin.hip"):
         if os.path.exists(os.path.join(CSRC, name)):
             units.append((name, name.replace(".hip", ".o"), []))
+    units.append(("gt_seed.hip", "gt_seed.o", SELECT_FLAGS))
     for prec, dp in SELECT_UNITS:
         units.append(("gt_knn_select.hip", "gt_knn_select_p%d_dp%d.o" % (prec, dp),
                       ["-DGT_SEL_PREC=%d" % prec, "-DGT_SEL_DP=%d" % dp] + SELECT_FLAGS))

@@ -64,6 +64,7 @@ int gt_ctx_create(int device, gt_ctx** out) {
     if (const char* v = std::getenv("GT_SYMMETRIC")) ctx->sym_mode = std::atoi(v);
     if (const char* v = std::getenv("GT_SYM_TWO_STAGE")) ctx->sym_two_stage = std::atoi(v);
     if (const char* v = std::getenv("GT_SYM_MIN_ROWS")) ctx->sym_min_rows = std::max(1, std::atoi(v));
+    if (const char* v = std::getenv("GT_SYM_DENSE_SEED")) ctx->sym_dense_seed = std::atoi(v) != 0 ? 1 : 0;
     if (const char* v = std::getenv("GT_SYM_STRIDE")) ctx->sym_stride = std::max(0, std::atoi(v));
     if (const char* v = std::getenv("GT_SYM_CELLS")) ctx->sym_cells = std::max(1, std::atoi(v));
     if (const char* v = std::getenv("GT_ORDER_CELL_ROWS")) ctx->order_cell_rows = std::max(32, std::atoi(v));
@@ -273,6 +274,10 @@ int gt_set_option(gt_ctx* ctx, const char* name, const char* value) {
     }
     if (k == "select_symmetric") {
         ctx->sym_mode = v == "auto" ? -1 : std::atoi(value);
+        return GT_OK;
+    }
+    if (k == "select_sym_dense_seed") {
+        ctx->sym_dense_seed = std::atoi(value) != 0 ? 1 : 0;
         return GT_OK;
     }
     if (k == "select_sym_stride") {

@@ -144,6 +144,7 @@ struct gt_ctx {
     int32_t sym_mode = -1;
     int64_t sym_min_rows = 65536;
     int32_t sym_stride = 96;    //   threshold-seeding launch: every sym_stride-th tile besides the row's own neighbourhood (0: none)
+    int32_t sym_dense_seed = 1; //   threshold-seeding launch: 1 = dense cell blocks, keys in registers (gt_seed.hip), 0 = streaming lists
     int32_t sym_cells = 12;    //   ... which is the rows of this many nearest cells (landmarks) of the block's own cells,
     int32_t sym_max_nb = 384;   //   at most this many tiles
     int32_t sym_tcap = 512;     //   capacity of a row's candidate list in launch B (<= 512)

@@ -325,17 +325,26 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
             a.samp_end = 0;
             a.samp2_level = 0;
             a.final_keep = need_m;
+            // dense cell blocks with the keys in registers (gt_seed.hip), or the streaming lists of the candidate kernel
+            const bool dense_seed = ctx->sym_dense_seed != 0 && need_m <= 64 && tile_stride <= 1024 && n_pad_s % 128 == 0;
+            const int seed_lstride = dense_seed ? 64 : int(lcap);
             {
                 StageSpan span(ctx, "sym_seed");
-                GT_TRY(gt_launch_select(ctx, a));
+                if (dense_seed)
+                    GT_TRY(gt_sym_seed_dense(ctx, ctx->DP, k->Ycs.p, k->hnegs.as<float>(), nq, n_pad_s, k->sym_tiles.as<int32_t>(),
+                                             k->sym_tile_cnt.as<int32_t>(), tile_stride, bq_sym == 256 ? 1 : 0, 0, 0, need_m,
+                                             k->lists.as<uint64_t>(), seed_lstride, k->counts.as<uint32_t>()));
+                else
+                    GT_TRY(gt_launch_select(ctx, a));
             }
+            k->sym_seed_dense = dense_seed;
             if (ctx->dbg_select & 1024) return GT_OK;   // experiment: stop behind the seeding launch (tables are NOT valid)
             {
                 StageSpan span(ctx, "sym_prepare");
                 GT_HIP(ctx, k->sym_farcnt.reserve(size_t(n_pad_s) * sizeof(float)));
                 GT_HIP(ctx, k->sym_racc.reserve(4 * sizeof(double)));
                 GT_HIP(ctx, hipMemsetAsync(k->sym_racc.p, 0, 4 * sizeof(double), ctx->stream));
-                GT_TRY(gt_sym_thresholds(ctx, perm, n_pad_s, k->hnegs.as<float>(), k->lists.as<uint64_t>(), int(lcap),
+                GT_TRY(gt_sym_thresholds(ctx, perm, n_pad_s, k->hnegs.as<float>(), k->lists.as<uint64_t>(), seed_lstride,
                                          k->counts.as<uint32_t>(), need_m, em, rkf, k->thr_final.as<float>(),
                                          k->sym_g.as<float>(), k->sym_gmin.as<float>(), k->sym_work, ctx->sym_cells,
                                          k->sym_stat.as<unsigned long long>() + 2, k->sym_farcnt.as<float>()));
@@ -419,7 +428,7 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
             const bool two_now = bound_done || a.sym.half_steps > 0;
             // (the orphans that were declared start their lists with the rows launch A kept for them)
             if (two_now || bound_tried)
-                GT_TRY(gt_sym_inject_orphans(ctx, 0, n_pad_s, k->thr_final.as<float>(), k->lists.as<uint64_t>(), int(lcap),
+                GT_TRY(gt_sym_inject_orphans(ctx, 0, n_pad_s, k->thr_final.as<float>(), k->lists.as<uint64_t>(), seed_lstride,
                                              k->counts.as<uint32_t>(), k->tlists.as<uint64_t>(), tcap, k->tcounts.as<uint32_t>()));
             if (two_now) {
                 if (ctx->sym_nseg <= 0) {

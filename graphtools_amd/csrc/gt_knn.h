@@ -42,6 +42,7 @@ struct KnnWork {
     int sym_frame = 0;                            //   frame of stage one: 0 coordinate axes, 1 principal directions
     bool sym_two_used = false;                    //   the last symmetric pass ran the two-stage collect
     bool sym_used = false;
+    bool sym_seed_dense = false;                  //   the last seeding launch ran as dense cell blocks (gt_seed.hip)
     int64_t sym_overflow = 0;
     int sym_nseg = 1;
     int64_t sym_far = 0;
@@ -238,6 +239,10 @@ int gt_sym_shard_scatter(gt_ctx* ctx, const void* recs, int64_t n_recs, int64_t 
                          uint32_t* counts, uint32_t* bad);
 int gt_sym_schedule(gt_ctx* ctx, int64_t n_pad_s, int bq, int bn, int cells, int stride, int max_nb, int tile_stride,
                     DevBuf& work, int32_t* tile_list, int32_t* tile_cnt, unsigned long long* tiles_total = nullptr);
+// gt_seed.hip: the threshold-seeding launch as dense cell blocks (`need` distinct near rows per sorted position)
+int gt_sym_seed_dense(gt_ctx* ctx, int dp, const void* Ys, const float* hs, int64_t n, int64_t n_pad, const int32_t* tile_list,
+                      const int32_t* tile_cnt, int tile_stride, int list_shift, int64_t block0, int64_t nblk, int need,
+                      uint64_t* lists, int lstride, uint32_t* counts);
 int gt_launch_fallback(gt_ctx* ctx, const RerankArgs& a, int64_t n_rows, int64_t row_off, double* scratch);
 int gt_launch_fallback_thr(gt_ctx* ctx, const RerankArgs& a, int64_t n_rows, int64_t row_off, int32_t* qrows, float* thr);
 int gt_launch_collected_select(gt_ctx* ctx, const RerankArgs& a, int64_t n_rows, int64_t row_off, const uint64_t* clists,
