@@ -143,7 +143,7 @@ struct gt_ctx {
     // symmetric candidate pass for self queries over the whole point set (gt_sym.hip): -1 auto (large launches), 0 off, 1 on
     int32_t sym_mode = -1;
     int64_t sym_min_rows = 65536;
-    int32_t sym_stride = 96;    //   threshold-seeding launch: every sym_stride-th tile besides the row's own neighbourhood (0: none)
+    int32_t sym_stride = 384;   //   threshold-seeding launch: every sym_stride-th tile besides the row's own neighbourhood (0: none)
     int32_t sym_dense_seed = 1; //   threshold-seeding launch: 1 = dense cell blocks, keys in registers (gt_seed.hip), 0 = streaming lists
     int32_t sym_cells = 12;    //   ... which is the rows of this many nearest cells (landmarks) of the block's own cells,
     int32_t sym_max_nb = 384;   //   at most this many tiles

@@ -17,7 +17,7 @@ void gt_free_knn_work(gt_ctx* ctx) {
                       &k->d2_lb, &k->fb_rows, &k->fb_count, &k->fb_scratch, &k->gflags, &k->prof, &k->fb_qrows, &k->fb_thr, &k->fb_lists,
                       &k->fb_counts, &k->fb_max, &k->unproven, &k->qorder, &k->qthr0, &k->qlomax_dev, &k->Ycs, &k->hnegs,
                       &k->sym_g, &k->sym_gmin, &k->tlists, &k->tcounts, &k->sym_stat, &k->sym_work, &k->sym_tiles,
-                      &k->sym_tile_cnt, &k->sh_invperm, &k->sh_lists, &k->sh_counts, &k->sh_cnt, &k->sh_own, &k->sh_tmp, &k->sym_hh, &k->sym_thrh, &k->sym_gh, &k->sym_gminh, &k->sym_queue, &k->sym_qcount, &k->sym_qdense, &k->sym_qtot, &k->sym_racc, &k->sym_farcnt, &k->sym_z, &k->sym_p, &k->sym_cov, &k->sym_qspill, &k->sym_rrow, &k->sym_bwork})
+                      &k->sym_tile_cnt, &k->sh_invperm, &k->sh_lists, &k->sh_counts, &k->sh_cnt, &k->sh_own, &k->sh_tmp, &k->sym_hh, &k->sym_thrh, &k->sym_gh, &k->sym_gminh, &k->sym_queue, &k->sym_qcount, &k->sym_qdense, &k->sym_qtot, &k->sym_racc, &k->sym_farcnt, &k->sym_z, &k->sym_p, &k->sym_cov, &k->sym_qspill, &k->sym_rrow, &k->sym_bwork, &k->hnegs_fin})
         b->release();
     delete k;
     ctx->knn = nullptr;
@@ -291,7 +291,8 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
             GT_HIP(ctx, hipMemsetAsync(k->sym_stat.p, 0, 8 * sizeof(unsigned long long), ctx->stream));
             {
                 StageSpan span(ctx, "sym_prepare");
-                GT_TRY(gt_sym_gather(ctx, perm, n_pad_s, k->Ycs.p, k->hnegs.as<float>()));
+                GT_HIP(ctx, k->hnegs_fin.reserve(size_t(n_pad_s) * sizeof(float)));
+                GT_TRY(gt_sym_gather(ctx, perm, n_pad_s, k->Ycs.p, k->hnegs.as<float>(), k->hnegs_fin.as<float>()));
                 GT_TRY(gt_sym_schedule(ctx, n_pad_s, bq_sym, bn_sym, ctx->sym_cells, stride_a, ctx->sym_max_nb, tile_stride,
                                        k->sym_work, k->sym_tiles.as<int32_t>(), k->sym_tile_cnt.as<int32_t>(),
                                        k->sym_stat.as<unsigned long long>() + 5));
@@ -326,13 +327,13 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
             a.samp2_level = 0;
             a.final_keep = need_m;
             // dense cell blocks with the keys in registers (gt_seed.hip), or the streaming lists of the candidate kernel
-            const bool dense_seed = ctx->sym_dense_seed != 0 && need_m <= 64 && tile_stride <= 1024 && n_pad_s % 128 == 0;
+            const bool dense_seed = ctx->sym_dense_seed != 0 && need_m <= 64 && tile_stride <= 1024 && n_pad_s % 256 == 0;
             const int seed_lstride = dense_seed ? 64 : int(lcap);
             {
                 StageSpan span(ctx, "sym_seed");
                 if (dense_seed)
-                    GT_TRY(gt_sym_seed_dense(ctx, ctx->DP, k->Ycs.p, k->hnegs.as<float>(), nq, n_pad_s, k->sym_tiles.as<int32_t>(),
-                                             k->sym_tile_cnt.as<int32_t>(), tile_stride, bq_sym == 256 ? 1 : 0, 0, 0, need_m,
+                    GT_TRY(gt_sym_seed_dense(ctx, ctx->DP, k->Ycs.p, k->hnegs_fin.as<float>(), nq, n_pad_s, k->sym_tiles.as<int32_t>(),
+                                             k->sym_tile_cnt.as<int32_t>(), tile_stride, bq_sym, 0, 0, need_m,
                                              k->lists.as<uint64_t>(), seed_lstride, k->counts.as<uint32_t>()));
                 else
                     GT_TRY(gt_launch_select(ctx, a));

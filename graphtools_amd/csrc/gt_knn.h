@@ -28,6 +28,7 @@ struct KnnWork {
     DevBuf fb_qrows, fb_thr, fb_lists, fb_counts, fb_max;   // collected fallback
     // symmetric candidate pass (gt_sym.hip): cell-sorted compact copy + seeds, per-row thresholds in the transposed
     // form and their sub-tile minima, the candidate lists of launch B and their counters
+    DevBuf hnegs_fin;                             // seeds of the sorted rows, finite on the pad rows (dense seeding launch)
     DevBuf Ycs, hnegs, sym_g, sym_gmin, tlists, tcounts, sym_stat, sym_work, sym_tiles, sym_tile_cnt;
     DevBuf sym_racc, sym_farcnt;                     // radius / spread statistics of the orphan cut (4 doubles), far-kept
                                                   // seeds per sorted position
@@ -177,7 +178,8 @@ struct SymRerank {
 };
 int gt_launch_rerank_sym(gt_ctx* ctx, const RerankArgs& a, const SymRerank& sr);
 // gt_sym.hip
-int gt_sym_gather(gt_ctx* ctx, const int32_t* perm, int64_t n_pad_s, void* Ys, float* hs);
+// hs_fin (optional): the same seeds with -3e38 instead of -inf on the pad rows (gt_seed.hip)
+int gt_sym_gather(gt_ctx* ctx, const int32_t* perm, int64_t n_pad_s, void* Ys, float* hs, float* hs_fin = nullptr);
 // rows [p_first, p_last) of the sorted order only (p_last < 0: all); gmin = nullptr: sub-tile minima not formed
 int gt_sym_thresholds(gt_ctx* ctx, const int32_t* perm, int64_t n_pad_s, const float* hs, const uint64_t* lists, int lstride,
                       const uint32_t* counts, int need_m, const ErrModel& err, double rkf, float* thr, float* g, float* gmin,
@@ -241,7 +243,7 @@ int gt_sym_schedule(gt_ctx* ctx, int64_t n_pad_s, int bq, int bn, int cells, int
                     DevBuf& work, int32_t* tile_list, int32_t* tile_cnt, unsigned long long* tiles_total = nullptr);
 // gt_seed.hip: the threshold-seeding launch as dense cell blocks (`need` distinct near rows per sorted position)
 int gt_sym_seed_dense(gt_ctx* ctx, int dp, const void* Ys, const float* hs, int64_t n, int64_t n_pad, const int32_t* tile_list,
-                      const int32_t* tile_cnt, int tile_stride, int list_shift, int64_t block0, int64_t nblk, int need,
+                      const int32_t* tile_cnt, int tile_stride, int list_rows, int64_t block0, int64_t nblk, int need,
                       uint64_t* lists, int lstride, uint32_t* counts);
 int gt_launch_fallback(gt_ctx* ctx, const RerankArgs& a, int64_t n_rows, int64_t row_off, double* scratch);
 int gt_launch_fallback_thr(gt_ctx* ctx, const RerankArgs& a, int64_t n_rows, int64_t row_off, int32_t* qrows, float* thr);

@@ -36,7 +36,7 @@ namespace {
 __global__ __launch_bounds__(256) void gather_sorted_kernel(const uint4* __restrict__ Yc, const float* __restrict__ hneg,
                                                             const int32_t* __restrict__ perm, const int64_t n,
                                                             const int64_t n_pad, const int c16, uint4* __restrict__ Ys,
-                                                            float* __restrict__ hs) {
+                                                            float* __restrict__ hs, float* __restrict__ hs_fin) {
     const int64_t f = int64_t(blockIdx.x) * 256 + threadIdx.x;
     if (f >= n_pad * c16) return;
     const int64_t p = f / c16;
@@ -45,9 +45,14 @@ __global__ __launch_bounds__(256) void gather_sorted_kernel(const uint4* __restr
     if (p < n) {
         const int64_t r = perm[p];
         v = Yc[r * c16 + c];
-        if (c == 0) hs[p] = hneg[r];
+        if (c == 0) {
+            const float hv = hneg[r];
+            hs[p] = hv;
+            if (hs_fin) hs_fin[p] = hv;
+        }
     } else if (c == 0) {
         hs[p] = -INFINITY;
+        if (hs_fin) hs_fin[p] = -3.0e38f;   // (gt_seed.hip: pad rows with a finite seed)
     }
     Ys[f] = v;
 }
@@ -1030,11 +1035,11 @@ __global__ __launch_bounds__(64) void bound_queue_kernel(const int T, const int 
 
 }  // namespace
 
-int gt_sym_gather(gt_ctx* ctx, const int32_t* perm, int64_t n_pad_s, void* Ys, float* hs) {
+int gt_sym_gather(gt_ctx* ctx, const int32_t* perm, int64_t n_pad_s, void* Ys, float* hs, float* hs_fin) {
     const int c16 = ctx->DP / 8;   // 2*DP bytes per row
     const int64_t total = n_pad_s * c16;
     hipLaunchKernelGGL(gather_sorted_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, ctx->stream,
-                       ctx->Yc.as<uint4>(), ctx->hneg.as<float>(), perm, ctx->n, n_pad_s, c16, reinterpret_cast<uint4*>(Ys), hs);
+                       ctx->Yc.as<uint4>(), ctx->hneg.as<float>(), perm, ctx->n, n_pad_s, c16, reinterpret_cast<uint4*>(Ys), hs, hs_fin);
     GT_HIP(ctx, hipGetLastError());
     return GT_OK;
 }

@@ -15,14 +15,21 @@ if __name__ == "__main__":
     _build.build()
     out_dir = os.path.join(_build.HERE, "_variants")
     os.makedirs(out_dir, exist_ok=True)
-    prec, dp = [int(v) for v in os.environ.get("GT_VARIANT_UNIT", "1:64").split(":")]
+    unit = os.environ.get("GT_VARIANT_UNIT", "1:64")
     obj = os.path.join(out_dir, "sel_%s.o" % name)
-    cmd = [_build._hipcc()] + _build.COMMON_FLAGS + ["-DGT_SEL_PREC=%d" % prec, "-DGT_SEL_DP=%d" % dp] + _build.SELECT_FLAGS + flags + [
-        "-c", os.path.join(_build.CSRC, "gt_knn_select.hip"), "-o", obj]
+    if ":" in unit:
+        prec, dp = [int(v) for v in unit.split(":")]
+        replaced = "gt_knn_select_p%d_dp%d.o" % (prec, dp)
+        cmd = [_build._hipcc()] + _build.COMMON_FLAGS + ["-DGT_SEL_PREC=%d" % prec, "-DGT_SEL_DP=%d" % dp] + _build.SELECT_FLAGS + flags + [
+            "-c", os.path.join(_build.CSRC, "gt_knn_select.hip"), "-o", obj]
+    else:   # GT_VARIANT_UNIT=<source file>, e.g. gt_seed.hip: that translation unit with the extra flags
+        replaced = unit.replace(".hip", ".o").replace(".cpp", ".o")
+        extra = [e for s_, o_, e in _build._units() if o_ == replaced][0]
+        cmd = [_build._hipcc()] + _build.COMMON_FLAGS + extra + flags + ["-c", os.path.join(_build.CSRC, unit), "-o", obj]
     subprocess.run(cmd, check=True)
     objs = []
     for src, o, extra in _build._units():
-        objs.append(obj if o == "gt_knn_select_p%d_dp%d.o" % (prec, dp) else os.path.join(_build.OBJ, o))
+        objs.append(obj if o == replaced else os.path.join(_build.OBJ, o))
     lib = os.path.join(out_dir, "libgt_%s.so" % name)
     subprocess.run([_build._hipcc(), "--offload-arch=" + _build.ARCH, "-shared", "-fPIC", "-o", lib] + objs, check=True)
     print(lib)
