@@ -160,6 +160,7 @@ int gt_set_points(gt_ctx* ctx, const void* X, int64_t n, int32_t d, int32_t dtyp
     ctx->n = n;
     ctx->fast_ok = -1;
     ctx->sym_ok = -1;
+    ctx->symm_fused_ok = 1;
     ctx->sym_two_ok = -1;
     ctx->d = d;
     ctx->dtype = dtype;
@@ -274,6 +275,14 @@ int gt_set_option(gt_ctx* ctx, const char* name, const char* value) {
     }
     if (k == "select_symmetric") {
         ctx->sym_mode = v == "auto" ? -1 : std::atoi(value);
+        return GT_OK;
+    }
+    if (k == "symmetrize_fused") {
+        ctx->symm_fused = std::atoi(value) != 0 ? 1 : 0;
+        return GT_OK;
+    }
+    if (k == "rerank_lanes4") {
+        ctx->rerank_lanes4 = std::atoi(value) != 0 ? 1 : 0;
         return GT_OK;
     }
     if (k == "select_sym_dense_seed") {

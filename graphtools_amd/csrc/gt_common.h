@@ -144,6 +144,7 @@ struct gt_ctx {
     int32_t sym_mode = -1;
     int64_t sym_min_rows = 65536;
     int32_t sym_stride = 384;   //   threshold-seeding launch: every sym_stride-th tile besides the row's own neighbourhood (0: none)
+    int32_t rerank_lanes4 = 1;  //   re-rank of the symmetric pass: four lanes per candidate row (float32 rows, d % 4 == 0, d <= 128)
     int32_t sym_dense_seed = 1; //   threshold-seeding launch: 1 = dense cell blocks, keys in registers (gt_seed.hip), 0 = streaming lists
     int32_t sym_cells = 12;    //   ... which is the rows of this many nearest cells (landmarks) of the block's own cells,
     int32_t sym_max_nb = 384;   //   at most this many tiles
@@ -154,6 +155,9 @@ struct gt_ctx {
     double sym_radius_cut = 4.0; //  rows whose completeness radius (squared) exceeds this many times the mean are repaired directly
     int32_t sym_two_stage = -1; //   launch B scores half the features first (partial distances): -1 auto, 0 off, 1 on
     int32_t symm_bins = -1;     // single-rank symmetrisation through destination bins (gt_sparse.hip): -1 auto, 0 off, 1 on
+    int32_t symm_fused = 0;     //   single rank, '+', no anisotropy: merged lengths counted first, K and P written once, in row order (gt_sparse.hip
+                                //   pair_count_kernel).  Bit-identical, measured SLOWER than sort + compact (6.7 against 5.8 ms at N = 1e6): off
+    int32_t symm_fused_ok = 1;  //     0 once a union row of the bound points has outgrown the register sorts (reset by gt_set_points)
     int32_t symm_key32 = 1;     //   per-row sorts of the symmetrisation on 32-bit keys where columns and positions fit (0: 64-bit keys)
     int32_t symm_bin_shift = 0; //   log2 of the rows per bin (0: 9, more from 2 M rows; development / tests: 8 ... 12)
     int32_t sym_bounds = -1;    //   bound pass in front of the two-stage collect (cell balls): -1 auto / 1 on, 0 off

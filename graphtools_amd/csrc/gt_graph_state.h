@@ -54,7 +54,9 @@ struct GraphState {
     DevBuf Ukey, Uval, Vkey, Vval, bigrows, hugerows, bigcount, bigscratch_k, bigscratch_v, bigsoff, aniso_tmp, scan_own;
     DevBuf indices, Kdata, Pdata, flags;
     DevBuf bincnt, binoff;   // destination bins of the single-rank transpose: triplets per bin (+ the emit cursors), scan
+    DevBuf ucol, uval;       // fused tail: received entries in fixed slot rows [row][capT] (columns, values)
     bool bins_used = false;
+    bool fused_used = false;   // the last build wrote K and P through the fused tail (gt_sparse.hip bin_fill3_kernel)
     int64_t nnz0 = 0, nnz = 0;
 };
 

@@ -367,6 +367,201 @@ __global__ __launch_bounds__(256, 5) void rerank_sym_kernel(
     }
 }
 
+// ---- the same re-rank with FOUR LANES PER CANDIDATE ROW (float32 rows, d a multiple of 4, 16-byte aligned) ------------
+// rerank_sym_kernel gives every lane a database row of its own: a wave's load instruction touches 64 rows, 16 bytes of a
+// 64-byte sector each, and comes back to the sector three more times - 2048 sector requests per row of the graph at the
+// L1, which is what the kernel was bound by (5.3 ms at N = 1e6).  Here lane (r, c) = (lane / 4, lane % 4) reads quarter c
+// of EVERY 64-byte sector of candidate r's row: the four lanes of a group cover a whole sector in one instruction
+// (16 sectors per instruction, 512 requests per row of the graph), and the lane's share of the query - the same elements of
+// every candidate - stays in registers (no LDS at all).
+// The canonical summation order (gt_device.h gt_dot16: element k goes to partial sum (k >> 2) & 15, tree (l, l+8), (l, l+4),
+// (0, 2) + (1, 3)) falls into place: quad g = k >> 2 belongs to lane c = g & 3, the lane's four accumulators are the
+// partial sums c, c + 4, c + 8, c + 12, the first two tree levels are in-lane, the last two are one cross-lane add each
+// (additions commute: every lane of the group ends with the same bits).
+// DB = blocks of 64 features (d <= 64 DB).  Measured: 5.5 -> 5.2 ms at d = 64, 1.07 -> 0.90 ms at d = 36 (N = 3e5); with two
+// blocks (d = 100) the registers of the wider query share cost more than the coalescing returns (4.3 -> 6.1 ms): the
+// launcher keeps the lane-per-row kernel there.
+template <int DB>
+__global__ __launch_bounds__(256, 4) void rerank_sym4_kernel(
+    const float* __restrict__ X, const int d, const double* __restrict__ xn, const int64_t nq,
+    const uint64_t* __restrict__ tlists, const int tcap, const uint32_t* __restrict__ tcounts,
+    const float* __restrict__ thr, const double* __restrict__ ymax2p, const ErrModel err, const int need_m,
+    const int32_t* __restrict__ perm, double* __restrict__ cand_d2, uint32_t* __restrict__ cand_j,
+    uint32_t* __restrict__ cand_n, double* __restrict__ d2_lb, uint32_t* __restrict__ fb_count,
+    int32_t* __restrict__ fb_rows, uint32_t* __restrict__ gflags, const double radius_key_factor,
+    uint32_t* __restrict__ unproven, unsigned long long* __restrict__ stat, const int want_stats,
+    const int32_t* __restrict__ invperm, const int32_t* __restrict__ own_rows, const int64_t own_r0) {
+    constexpr int MP = 256;
+    constexpr int NI = 4 * DB;   // 64-byte sectors of a row this kernel can hold
+    const int lane = threadIdx.x & 63;
+    const int w = threadIdx.x >> 6;
+    const int c = lane & 3, r = lane >> 2;
+    const int64_t nb = gridDim.x, xcd = blockIdx.x & 7, base = nb >> 3, rem = nb & 7;
+    const int64_t bid = xcd * base + (xcd < rem ? xcd : rem) + (blockIdx.x >> 3);
+    const int64_t ql = bid * 4 + w;
+    if (ql >= nq) return;
+    const int64_t qo = invperm ? int64_t(own_rows[ql]) : int64_t(perm[ql]);   // row of the bound points
+    const int64_t q = invperm ? qo - own_r0 : qo;                             // row of the tables
+    const int64_t qt = invperm ? int64_t(invperm[qo]) : ql;                   // index of the threshold
+    const int64_t ls = invperm ? q : ql;                                      // index of the list
+    // this lane's share of the query row: elements 16 i + 4 c .. + 3 of every sector i
+    double xq[NI][4];
+    {
+        const float4* xrow4 = reinterpret_cast<const float4*>(X + qo * int64_t(d));
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const bool in = 16 * i + 4 * c < d;
+            const float4 v = in ? xrow4[4 * i + c] : make_float4(0.f, 0.f, 0.f, 0.f);
+            xq[i][0] = double(v.x);
+            xq[i][1] = double(v.y);
+            xq[i][2] = double(v.z);
+            xq[i][3] = double(v.w);
+        }
+    }
+    const double qnq = xn[qo];
+    const uint32_t ct_raw = tcounts[ls];
+    const uint32_t ct = ct_raw & 0x7FFFFFFFu;
+    const bool overflow = ct > uint32_t(tcap) || (ct_raw >> 31) != 0u;
+    const uint32_t n = ct < uint32_t(tcap) ? ct : uint32_t(tcap);
+    const uint64_t* tp = tlists + size_t(ls) * size_t(tcap);
+    const double y2 = ymax2p[0];
+    const double e = gt_err_bound(err, qnq, y2);
+    auto bound_of_score = [&](float score) {
+        const double sv = double(score) * err.inv_sc2;
+        return (qnq - 2.0 * (sv + e)) - 1e-9 * (qnq + y2);
+    };
+    double lb = overflow ? -INFINITY : bound_of_score(thr[qt]);
+
+    uint64_t ks[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const uint32_t cidx = uint32_t(u * 64 + lane);
+        ks[u] = (cidx < n) ? tp[cidx] : 0ull;   // a valid key is never 0
+    }
+    if (n <= 128u) {   // wave-uniform
+        // every candidate is in the first batch: their order does not matter
+    } else if (n <= 256u) {
+        uint64_t k4[4] = {ks[0], ks[1], ks[2], ks[3]};
+        wave_bitonic_desc<4>(k4, lane);
+        ks[0] = k4[0];
+        ks[1] = k4[1];
+        ks[2] = k4[2];
+        ks[3] = k4[3];
+    } else {
+        wave_bitonic_desc<8>(ks, lane);
+    }
+    const uint32_t n_eval = n < uint32_t(MP) ? n : uint32_t(MP);
+    // exact keys of the 128 candidates held as (jA: slot u, jB: slot u + 1), 16 candidates per pass: group r takes
+    // candidate 16 p + r of the batch, lane c of the group keeps the result of the passes p with p % 4 == c
+    auto eval128 = [&](const uint32_t jA, const uint32_t jB, uint64_t& hA, uint64_t& lA, uint64_t& hB, uint64_t& lB) {
+        hA = hB = kInfBits;
+        lA = lB = 0xFFFFFFFFull;
+#pragma unroll 2
+        for (int p = 0; p < 8; ++p) {
+            const uint32_t j = uint32_t(__shfl(int(p < 4 ? jA : jB), (p & 3) * 16 + r));
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;   // partial sums c, c + 4, c + 8, c + 12
+            double yn = 0.0;
+            if (j != kNoRow) {
+                const float4* y4 = reinterpret_cast<const float4*>(X + int64_t(j) * d);
+                float4 v[NI];
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
+                    if (16 * i < d) v[i] = (16 * i + 4 * c < d) ? y4[4 * i + c] : make_float4(0.f, 0.f, 0.f, 0.f);
+                yn = xn[j];
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
+                    if (16 * i < d) {   // (uniform; a quad past the end of the row contributes exact zeros, as in gt_dot16
+                                        //  where it is simply absent - x + 0 = x)
+                        double& acc = (i & 3) == 0 ? a0 : (i & 3) == 1 ? a1 : (i & 3) == 2 ? a2 : a3;
+                        if (16 * i + 4 * c < d) {
+                            acc = fma(xq[i][0], double(v[i].x), acc);
+                            acc = fma(xq[i][1], double(v[i].y), acc);
+                            acc = fma(xq[i][2], double(v[i].z), acc);
+                            acc = fma(xq[i][3], double(v[i].w), acc);
+                        }
+                    }
+            }
+            const double cc = (a0 + a2) + (a1 + a3);            // b[c] + b[c + 4]
+            const double w2 = cc + __shfl_xor(cc, 2);           // lanes 0, 2: c0 + c2; lanes 1, 3: c1 + c3
+            const double dot = w2 + __shfl_xor(w2, 1);          // (c0 + c2) + (c1 + c3)
+            if (j != kNoRow && c == (p & 3)) {
+                const uint64_t key = (uint64_t)__double_as_longlong(gt_pair_key(qnq, dot, yn, 0));
+                if (p < 4) {
+                    hA = key;
+                    lA = j;
+                } else {
+                    hB = key;
+                    lB = j;
+                }
+            }
+        }
+    };
+    uint64_t hi[4], lo[4];
+    {
+        const uint32_t j0 = ks[0] != 0ull ? uint32_t(perm[cand_index(ks[0])]) : kNoRow;
+        const uint32_t j1 = ks[1] != 0ull ? uint32_t(perm[cand_index(ks[1])]) : kNoRow;
+        eval128(j0, j1, hi[0], lo[0], hi[1], lo[1]);
+        hi[2] = hi[3] = kInfBits;
+        lo[2] = lo[3] = 0xFFFFFFFFull;
+    }
+    const int pos = need_m - 1;
+    const bool may_stop = radius_key_factor > 0.0;
+    const double rkf = fabs(radius_key_factor);
+    const uint64_t k129 = __shfl((unsigned long long)ks[2], 0);
+    const uint64_t k257 = __shfl((unsigned long long)ks[4], 0);
+    const double lb_rest = (k129 != 0ull) ? bound_of_score(cand_score(k129)) : INFINITY;
+    uint64_t h2[2] = {hi[0], hi[1]}, l2[2] = {lo[0], lo[1]};
+    wave_sort_asc_pair_fast<2>(h2, l2, lane);
+    const uint64_t sel2 = (pos >> 6) == 0 ? h2[0] : h2[1];
+    const double need2 = __longlong_as_double((long long)__shfl((unsigned long long)sel2, pos & 63));
+    const double lbm = fmin(lb, lb_rest);
+    uint32_t n_tab = n_eval;
+    if (may_stop && pos < 128 && need2 * rkf < lbm) {   // wave-uniform
+        hi[0] = h2[0]; hi[1] = h2[1];
+        lo[0] = l2[0]; lo[1] = l2[1];
+        lb = lbm;
+        n_tab = n_eval < 128u ? n_eval : 128u;
+    } else {
+        const uint32_t j2 = ks[2] != 0ull ? uint32_t(perm[cand_index(ks[2])]) : kNoRow;
+        const uint32_t j3 = ks[3] != 0ull ? uint32_t(perm[cand_index(ks[3])]) : kNoRow;
+        eval128(j2, j3, hi[2], lo[2], hi[3], lo[3]);
+        if (k257 != 0ull) lb = fmin(lb, bound_of_score(cand_score(k257)));   // candidates beyond the table
+        wave_sort_asc_pair_fast<4>(hi, lo, lane);
+    }
+    const uint32_t n_def = n_tab > uint32_t(need_m) ? n_tab : uint32_t(need_m);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        if (uint32_t(u * 64) < n_def) {   // wave-uniform
+            cand_d2[size_t(q) * MP + u * 64 + lane] = __longlong_as_double((long long)hi[u]);
+            cand_j[size_t(q) * MP + u * 64 + lane] = uint32_t(lo[u]);
+        }
+    }
+    uint64_t sel = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        if ((pos >> 6) == u) sel = hi[u];
+    const double d2_need = __longlong_as_double((long long)__shfl((unsigned long long)sel, pos & 63));
+    const uint64_t second = __shfl((unsigned long long)hi[0], 1);
+    if (lane == 0) {
+        cand_n[q] = n_tab;
+        d2_lb[q] = lb;
+        if (!(d2_need < lb)) {
+            const uint32_t slot = atomicAdd(fb_count, 1u);
+            fb_rows[slot] = int32_t(q);
+        }
+        if (unproven && !overflow && thr[qt] != INFINITY && !(d2_need * rkf < lb)) atomicAdd(unproven, 1u);
+        if (stat && overflow) atomicAdd(stat + 0, 1ull);
+        if (stat && want_stats) {
+            const unsigned long long tot = (unsigned long long)ct;
+            atomicAdd(stat + 1, tot);
+            atomicMax(stat + 3, tot);
+            if (tot > 256ull) atomicAdd(stat + 4, 1ull);
+            if (tot > 128ull) atomicAdd(stat + 7, 1ull);
+        }
+        if (n_tab > 1 && second == 0ull) atomicOr(gflags, GT_FLAG_DUPLICATES);
+    }
+}
+
 // ---- exhaustive exact fallback: one workgroup per flagged query ---------------------------------
 template <typename T, int NT2>
 __global__ __launch_bounds__(256) void fallback_kernel(const T* __restrict__ X, const int64_t n, const int d,
@@ -736,13 +931,21 @@ int gt_launch_rerank_sym(gt_ctx* ctx, const RerankArgs& a, const SymRerank& sr) 
                        a.xn, a.nq, sr.tlists, sr.tcap, sr.tcounts, a.thr_final, a.ymax2, a.err, a.need_m, sr.perm,        \
                        a.cand_d2, a.cand_j, a.cand_n, a.d2_lb, a.fb_count, a.fb_rows, a.gflags, a.radius_key_factor,      \
                        a.unproven, sr.stat, (ctx->dbg_select & 256) ? 1 : 0, sr.invperm, sr.own_rows, sr.own_r0)
+#define GT_RERANK_SYM4_LAUNCH(DB_)                                                                                        \
+    hipLaunchKernelGGL((rerank_sym4_kernel<DB_>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (const float*)a.X, a.d,    \
+                       a.xn, a.nq, sr.tlists, sr.tcap, sr.tcounts, a.thr_final, a.ymax2, a.err, a.need_m, sr.perm,        \
+                       a.cand_d2, a.cand_j, a.cand_n, a.d2_lb, a.fb_count, a.fb_rows, a.gflags, a.radius_key_factor,      \
+                       a.unproven, sr.stat, (ctx->dbg_select & 256) ? 1 : 0, sr.invperm, sr.own_rows, sr.own_r0)
     if (a.dtype == GT_F32) {
-        if ((a.d & 3) == 0 && (reinterpret_cast<uintptr_t>(a.X) & 15) == 0) GT_RERANK_SYM_LAUNCH(float, true);
+        const bool f4 = (a.d & 3) == 0 && (reinterpret_cast<uintptr_t>(a.X) & 15) == 0;
+        if (f4 && ctx->rerank_lanes4 != 0 && a.d <= 64) GT_RERANK_SYM4_LAUNCH(1);
+        else if (f4) GT_RERANK_SYM_LAUNCH(float, true);
         else GT_RERANK_SYM_LAUNCH(float, false);
     } else {
         GT_RERANK_SYM_LAUNCH(double, false);
     }
 #undef GT_RERANK_SYM_LAUNCH
+#undef GT_RERANK_SYM4_LAUNCH
     GT_HIP(ctx, hipGetLastError());
     return GT_OK;
 }

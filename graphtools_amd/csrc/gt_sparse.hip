@@ -22,7 +22,7 @@ void gt_free_graph_state(gt_ctx* ctx) {
     for (DevBuf* b : {&g->bw, &g->bw_user, &g->rowsrc, &g->hugerows, &g->tablen, &g->spmm_in, &g->spmm_out, &g->lenN, &g->lenT, &g->cursor, &g->off, &g->outlen, &g->indptr,
                       &g->degree, &g->over_rows, &g->over_count, &g->rthr, &g->rlists, &g->rcounts, &g->rK, &g->rmax,
                       &g->ownercnt, &g->ownerpos, &g->cnt_sorted, &g->pos_sorted, &g->scan_tmp, &g->selfbuf, &g->splits_dev, &g->Ukey, &g->Uval, &g->Vkey, &g->Vval,
-                      &g->bincnt, &g->binoff, &g->bigrows, &g->bigcount, &g->bigscratch_k, &g->bigscratch_v, &g->bigsoff, &g->aniso_tmp, &g->scan_own,
+                      &g->bincnt, &g->binoff, &g->ucol, &g->uval, &g->bigrows, &g->bigcount, &g->bigscratch_k, &g->bigscratch_v, &g->bigsoff, &g->aniso_tmp, &g->scan_own,
                       &g->indices, &g->Kdata, &g->Pdata, &g->flags})
         b->release();
     delete g;
@@ -568,7 +568,9 @@ __global__ __launch_bounds__(256) void bin_fill_kernel(const int64_t nloc, const
                                                        const int shift, const int nbins, const int64_t* __restrict__ binoff,
                                                        const Triplet* __restrict__ trip, const int32_t* __restrict__ lenNs,
                                                        const int64_t* __restrict__ sN, int64_t* __restrict__ off,
-                                                       UEntry* __restrict__ U) {
+                                                       UEntry* __restrict__ U, uint32_t* __restrict__ ucol,
+                                                       double* __restrict__ uval) {
+    // ucol / uval given (fused tail): the received entries go there as (column, value) in separate arrays instead of U
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int R = 1 << shift;
     int32_t* cnt = reinterpret_cast<int32_t*>(smem_raw);   // [R] received entries per row, then the cursor of its T part
@@ -655,15 +657,27 @@ __global__ __launch_bounds__(256) void bin_fill_kernel(const int64_t nloc, const
             const int s1 = atomicAdd(&cnt[int64_t(a1.row) - p0], 1);
             const int s2 = atomicAdd(&cnt[int64_t(a2.row) - p0], 1);
             const int s3 = atomicAdd(&cnt[int64_t(a3.row) - p0], 1);
-            U[t0 + s0] = UEntry{(a0.col << 1) | 1u, 0u, a0.val};
-            U[t0 + s1] = UEntry{(a1.col << 1) | 1u, 0u, a1.val};
-            U[t0 + s2] = UEntry{(a2.col << 1) | 1u, 0u, a2.val};
-            U[t0 + s3] = UEntry{(a3.col << 1) | 1u, 0u, a3.val};
+            if (ucol) {
+                ucol[t0 + s0] = a0.col; uval[t0 + s0] = a0.val;
+                ucol[t0 + s1] = a1.col; uval[t0 + s1] = a1.val;
+                ucol[t0 + s2] = a2.col; uval[t0 + s2] = a2.val;
+                ucol[t0 + s3] = a3.col; uval[t0 + s3] = a3.val;
+            } else {
+                U[t0 + s0] = UEntry{(a0.col << 1) | 1u, 0u, a0.val};
+                U[t0 + s1] = UEntry{(a1.col << 1) | 1u, 0u, a1.val};
+                U[t0 + s2] = UEntry{(a2.col << 1) | 1u, 0u, a2.val};
+                U[t0 + s3] = UEntry{(a3.col << 1) | 1u, 0u, a3.val};
+            }
         }
         for (; t < t1; t += 256) {
             const Triplet tr = trip[t];
             const int slot = atomicAdd(&cnt[int64_t(tr.row) - p0], 1);
-            U[t0 + slot] = UEntry{(tr.col << 1) | 1u, 0u, tr.val};
+            if (ucol) {
+                ucol[t0 + slot] = tr.col;
+                uval[t0 + slot] = tr.val;
+            } else {
+                U[t0 + slot] = UEntry{(tr.col << 1) | 1u, 0u, tr.val};
+            }
         }
     }
 }
@@ -1022,6 +1036,268 @@ __global__ __launch_bounds__(256) void compact_kernel(const int64_t nloc, const 
         for (int e = lane; e < n; e += 64) {
             const double v = Vval[s + e];
             Pdata[dst + e] = (asum != 0.0) ? v / asum : v;
+        }
+    }
+}
+
+// =====================================================================================================================
+// Count-first tail of the single-rank build (symmetrisation '+', no anisotropy; option symmetrize_fused, OFF by default):
+// the merged length of every row is counted before the merge, so that K, P and the degrees can be written ONCE, straight
+// into the final CSR, instead of parking the merged rows in global memory for a compaction pass.
+//   pair_count_kernel    one wave per row of K: merged length = own + received - pairs, the pairs (columns present in both
+//                        halves) found by comparing the received columns, one per lane, with the own ones (broadcast from
+//                        LDS); rows of more than 512 entries are listed for the long-row kernel
+//   (scan)               row pointers of the final CSR
+//   merge_final_kernel   one wave per row, in ROW order (the CSR is written front to back): register sort of the union by
+//                        (column, tag), merge, indices and K written at the row's place, the row sum accumulated in
+//                        compact_kernel's order (entry e in lane e % 64, increasing e, then the xor tree) through one LDS
+//                        permute per 64 sorted entries, P = K / sum written behind it
+//   merge_long_final_kernel  the rows of 513 ... 2048 entries (persistent waves, 16 / 32 keys per lane); longer rows are
+//                        flagged (the build takes the other path)
+// Results are bit-identical to sort_merge_kernel + compact_kernel (tests/test_gpu_symm_bins.py).  MEASURED AND REJECTED as
+// the default: 6.7 ms against 5.8 ms for symmetrise + P at N = 1e6 - the count pass (a second look at every column) and the
+// row-order merge (received halves fetched out of order, P held in registers) cost more than the compaction pass they
+// save.  A fixed-slot layout for the received halves (one read of the triplets instead of two in bin_fill_kernel) was
+// tried with it and dropped: the in-degrees of the unsymmetrised kernel are heavy-tailed (N = 1e6 mix: median 40, mean
+// 72, 99.9 % 749, maximum 1416; isotropic Gaussian N = 3e5: mean 134, maximum 15 685) - slots sized for the mean overflow
+// on 6 % of the rows, slots sized for the maximum do not fit.
+struct FusedSrc {
+    const int32_t* pos;       // row -> sorted position
+    const int32_t* lenN;      // own kept entries per row
+    const int64_t* off;       // [n + 1] start of the union row of every sorted position (own + received entries)
+    const int64_t* sN;        // [n + 1] scan of the own entries in sorted order: the received half of position p starts at
+                              //         off[p] - sN[p] in ucol / uval
+    const int32_t* rowsrc;
+    const double* cand_k;
+    const uint32_t* cand_j;
+    int MP;
+    const uint64_t* rlists;
+    const double* rK;
+    int32_t rcap;
+    const uint32_t* ucol;     // received entries, packed row by row in sorted order: columns ...
+    const double* uval;       // ... and values
+};
+struct RowSrc3 {
+    int ln;
+    const double* kv;
+    const uint32_t* cj;
+    const uint64_t* rl;
+    const uint32_t* uc;
+    const double* uv;
+    __device__ __forceinline__ uint32_t key(const int p) const {
+        return p < ln ? ((cj ? cj[p] : cand_index(rl[p])) << 1) : ((uc[p - ln] << 1) | 1u);
+    }
+    __device__ __forceinline__ double val(const int p) const { return p < ln ? kv[p] : uv[p - ln]; }
+};
+__device__ __forceinline__ RowSrc3 make_row_src3(const FusedSrc& fs, const int64_t i, const int64_t p, int& lt) {
+    RowSrc3 r;
+    r.ln = fs.lenN[i];
+    const int64_t o0 = fs.off[p];
+    lt = int(fs.off[p + 1] - o0) - r.ln;
+    const int32_t src = fs.rowsrc[i];
+    if (src < 0) {
+        r.kv = fs.cand_k + i * fs.MP;
+        r.cj = fs.cand_j + i * fs.MP;
+        r.rl = nullptr;
+    } else {
+        r.kv = fs.rK + size_t(src) * fs.rcap;
+        r.cj = nullptr;
+        r.rl = fs.rlists + size_t(src) * fs.rcap;
+    }
+    r.uc = fs.ucol + (o0 - fs.sN[p]);
+    r.uv = fs.uval + (o0 - fs.sN[p]);
+    return r;
+}
+
+constexpr uint32_t kFusedHugeRow = 2u;
+
+constexpr int kPairChunk = 512;   // own columns staged in LDS per round (per wave)
+__global__ __launch_bounds__(256) void pair_count_kernel(const int64_t nloc, const FusedSrc fs, int32_t* __restrict__ outlen,
+                                                         int32_t* __restrict__ biglist, uint32_t* __restrict__ bigcount,
+                                                         uint32_t* __restrict__ fflags) {
+    __shared__ uint32_t oc_s[4][kPairChunk];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t i = int64_t(blockIdx.x) * 4 + w;
+    if (i >= nloc) return;   // (wave-uniform)
+    const int64_t p = fs.pos[i];
+    int lt;
+    const RowSrc3 rs = make_row_src3(fs, i, p, lt);
+    const int ln = rs.ln;
+    uint32_t* oc = oc_s[w];
+    int pairs = 0;
+    // received columns: one per lane and round of 64; own columns: broadcast from LDS, kPairChunk at a time
+    for (int o0 = 0; o0 < ln; o0 += kPairChunk) {
+        const int on = ln - o0 < kPairChunk ? ln - o0 : kPairChunk;
+        __builtin_amdgcn_wave_barrier();
+        for (int e = lane; e < on; e += 64) oc[e] = rs.cj ? rs.cj[o0 + e] : cand_index(rs.rl[o0 + e]);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int r0 = 0; r0 < lt; r0 += 64) {
+            const uint32_t rc = (r0 + lane < lt) ? rs.uc[r0 + lane] : 0xFFFFFFFFu;   // (no column looks like it)
+            bool hit = false;
+            int e = 0;
+            for (; e + 4 <= on; e += 4) {
+                const uint4 o4 = *reinterpret_cast<const uint4*>(oc + e);
+                hit |= (o4.x == rc) | (o4.y == rc) | (o4.z == rc) | (o4.w == rc);
+            }
+            for (; e < on; ++e) hit |= oc[e] == rc;
+            pairs += __popcll(__ballot(hit));
+        }
+    }
+    const int L = ln + lt;
+    if (lane == 0) {
+        outlen[i] = L - pairs;
+        if (L > kBigRow) {
+            if (L > kHugeRow) atomicOr(fflags, kFusedHugeRow);
+            else biglist[atomicAdd(bigcount, 1u)] = int32_t(i);
+        }
+    }
+}
+
+// merge of a sorted (key, value) sequence held in registers straight into the final CSR row at dst; returns the row sum
+// in compact_kernel's order.  Keys: (column << 1) | tag, kNoKey where there is no entry.
+template <int NT>
+__device__ __forceinline__ double merge_sorted_final(const uint32_t (&hi)[NT], const uint64_t (&lo)[NT], const int lane,
+                                                     const int64_t row, int32_t* __restrict__ indices,
+                                                     double* __restrict__ Kdata, double* __restrict__ Pdata,
+                                                     const int64_t dst, bool& any_diag) {
+    int count = 0;
+    double msave[NT];
+    int esave[NT];   // final index of the lane's entry of chunk t, -1: none
+    double lsum = 0.0;   // this lane's partial sum: the entries e with e % 64 == lane, in increasing e
+    bool has_diag = false;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const uint32_t key = hi[t];
+        const uint64_t val = lo[t];
+        uint32_t pk = __shfl_up(key, 1);
+        const uint32_t pk_edge = (t > 0) ? __shfl(hi[t > 0 ? t - 1 : 0], 63) : kNoKey;
+        if (lane == 0) pk = pk_edge;
+        uint32_t nk = __shfl_down(key, 1);
+        uint64_t nv = __shfl_down((unsigned long long)val, 1);
+        const uint32_t nk_edge = (t < NT - 1) ? __shfl(hi[t < NT - 1 ? t + 1 : t], 0) : kNoKey;
+        const uint64_t nv_edge = (t < NT - 1) ? __shfl((unsigned long long)lo[t < NT - 1 ? t + 1 : t], 0) : 0ull;
+        if (lane == 63) {
+            nk = nk_edge;
+            nv = nv_edge;
+        }
+        const bool valid = key != kNoKey;
+        const uint32_t col = key >> 1;
+        const bool first = valid && (pk == kNoKey || (pk >> 1) != col);
+        const bool pair = first && nk != kNoKey && (nk >> 1) == col;
+        const int tag = int(key & 1u);
+        const double v = __longlong_as_double((long long)val);
+        const double a = tag == 0 ? v : 0.0;
+        const double b = tag == 1 ? v : (pair ? __longlong_as_double((long long)nv) : 0.0);
+        const double m = merge_values(a, b, GT_SYMM_ADD, 1.0);
+        const bool emit = first;   // ('+': a merged value is never 0 - both parts are >= thresh or absent)
+        int total;
+        const int pp = wave_prefix_count(emit, lane, total);
+        const int e = count + pp;
+        if (emit) {
+            indices[dst + e] = int32_t(col);
+            Kdata[dst + e] = m;
+            has_diag |= int64_t(col) == row && m != 0.0;
+        }
+        msave[t] = m;
+        esave[t] = emit ? e : -1;
+        // the value goes to lane e % 64 (emitters land on `total` consecutive lanes from count % 64, the others fill the
+        // rest: a permutation), which adds it to its partial sum - entries reach a lane in increasing e
+        const int dl = emit ? (e & 63) : ((count + total + (lane - pp)) & 63);
+        const unsigned long long mb = (unsigned long long)__double_as_longlong(m);
+        const int rlo = __builtin_amdgcn_ds_permute(dl << 2, int(uint32_t(mb)));
+        const int rhi = __builtin_amdgcn_ds_permute(dl << 2, int(uint32_t(mb >> 32)));
+        const double got = __longlong_as_double((long long)((uint64_t(uint32_t(rhi)) << 32) | uint64_t(uint32_t(rlo))));
+        if (((lane - count) & 63) < total) lsum += got;
+        count += total;
+    }
+    const double sum = wave_sum_f64(lsum);
+    any_diag = __ballot(has_diag) != 0ull;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+        if (esave[t] >= 0) Pdata[dst + esave[t]] = (sum != 0.0) ? msave[t] / sum : msave[t];
+    return sum;
+}
+
+template <typename K, int NT>
+__device__ __forceinline__ double sort_merge_final_row(const RowSrc3& U, const int L, const int lane, const int64_t row,
+                                                       int32_t* __restrict__ indices, double* __restrict__ Kdata,
+                                                       double* __restrict__ Pdata, const int64_t dst, bool& any_diag) {
+    constexpr int PB = SortPos<NT>::bits;
+    K pk[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int p = t * 64 + lane;
+        pk[t] = (p < L) ? K(~((K(U.key(p)) << PB) | K(p))) : K(0);
+    }
+    wave_bitonic_desc<NT, K>(pk, lane);
+    uint32_t hi[NT];
+    uint64_t lo[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        hi[t] = kNoKey;
+        lo[t] = 0ull;
+        if (pk[t] != K(0)) {
+            const K x = K(~pk[t]);
+            hi[t] = uint32_t(x >> PB);
+            lo[t] = (uint64_t)__double_as_longlong(U.val(int(uint32_t(x) & ((1u << PB) - 1u))));
+        }
+    }
+    return merge_sorted_final<NT>(hi, lo, lane, row, indices, Kdata, Pdata, dst, any_diag);
+}
+
+__global__ __launch_bounds__(256) void merge_final_kernel(const int64_t nloc, const FusedSrc fs, const int64_t* __restrict__ indptr,
+                                                          int32_t* __restrict__ indices, double* __restrict__ Kdata,
+                                                          double* __restrict__ Pdata, double* __restrict__ degree,
+                                                          uint32_t* __restrict__ flags, const int key32) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t i = int64_t(blockIdx.x) * 4 + w;
+    if (i >= nloc) return;
+    const int64_t p = fs.pos[i];
+    int lt;
+    const RowSrc3 U = make_row_src3(fs, i, p, lt);
+    const int L = U.ln + lt;
+    if (L > kBigRow) return;   // (merge_long_final_kernel)
+    const int64_t dst = indptr[i];
+    bool any_diag = false;
+    double sum;
+    if (key32) {   // (uniform over the launch)
+        if (L <= 64) sum = sort_merge_final_row<uint32_t, 1>(U, L, lane, i, indices, Kdata, Pdata, dst, any_diag);
+        else if (L <= 128) sum = sort_merge_final_row<uint32_t, 2>(U, L, lane, i, indices, Kdata, Pdata, dst, any_diag);
+        else if (L <= 256) sum = sort_merge_final_row<uint32_t, 4>(U, L, lane, i, indices, Kdata, Pdata, dst, any_diag);
+        else sum = sort_merge_final_row<uint32_t, 8>(U, L, lane, i, indices, Kdata, Pdata, dst, any_diag);
+    } else {
+        if (L <= 64) sum = sort_merge_final_row<uint64_t, 1>(U, L, lane, i, indices, Kdata, Pdata, dst, any_diag);
+        else if (L <= 128) sum = sort_merge_final_row<uint64_t, 2>(U, L, lane, i, indices, Kdata, Pdata, dst, any_diag);
+        else if (L <= 256) sum = sort_merge_final_row<uint64_t, 4>(U, L, lane, i, indices, Kdata, Pdata, dst, any_diag);
+        else sum = sort_merge_final_row<uint64_t, 8>(U, L, lane, i, indices, Kdata, Pdata, dst, any_diag);
+    }
+    if (lane == 0) {
+        degree[i] = sum;
+        if (!any_diag) atomicOr(flags, GT_FLAG_ZERO_DIAGONAL);
+    }
+}
+
+__global__ __launch_bounds__(64) void merge_long_final_kernel(const FusedSrc fs, const int64_t* __restrict__ indptr,
+                                                              int32_t* __restrict__ indices, double* __restrict__ Kdata,
+                                                              double* __restrict__ Pdata, double* __restrict__ degree,
+                                                              uint32_t* __restrict__ flags, const int32_t* __restrict__ biglist,
+                                                              const uint32_t* __restrict__ bigcount) {
+    const int lane = threadIdx.x;
+    const uint32_t nbig = *bigcount;
+    for (uint32_t bb = blockIdx.x; bb < nbig; bb += gridDim.x) {
+        const int64_t i = biglist[bb];
+        const int64_t p = fs.pos[i];
+        int lt;
+        const RowSrc3 U = make_row_src3(fs, i, p, lt);
+        const int L = U.ln + lt;
+        const int64_t dst = indptr[i];
+        bool any_diag = false;
+        const double sum = (L <= 1024) ? sort_merge_final_row<uint64_t, 16>(U, L, lane, i, indices, Kdata, Pdata, dst, any_diag)
+                                       : sort_merge_final_row<uint64_t, 32>(U, L, lane, i, indices, Kdata, Pdata, dst, any_diag);
+        if (lane == 0) {
+            degree[i] = sum;
+            if (!any_diag) atomicOr(flags, GT_FLAG_ZERO_DIAGONAL);
         }
     }
 }
@@ -1619,7 +1895,7 @@ static int graph_finish_impl(gt_ctx* ctx, const void* recv_buf_dev, int64_t n_re
                                g->rowsrc.as<int32_t>(), g->rlists.as<uint64_t>(), g->rcounts.as<uint32_t>(), g->rcap,
                                g->rK.as<double>(), g->tablen.as<int32_t>(), perm, shift, nbins, g->binoff.as<int64_t>(),
                                (const Triplet*)g->selfbuf.p, g->cnt_sorted.as<int32_t>(), g->pos_sorted.as<int64_t>(),
-                               g->off.as<int64_t>(), g->Ukey.as<UEntry>());
+                               g->off.as<int64_t>(), g->Ukey.as<UEntry>(), (uint32_t*)nullptr, (double*)nullptr);
             GT_HIP(ctx, hipGetLastError());
         } else {
             hipLaunchKernelGGL(fill_rows_kernel, dim3((unsigned)ceil_div64(nloc, 4)), dim3(256), 0, ctx->stream, nloc, k->MP,
@@ -1753,6 +2029,121 @@ static int graph_finish_impl(gt_ctx* ctx, const void* recv_buf_dev, int64_t n_re
     return GT_OK;
 }
 
+// Fused tail (see pair_count_kernel): single rank, every row local, cell-sorted order at hand, '+' symmetrisation, no
+// anisotropy, every kept value > 0.  Returns 1 when K, P and the degrees are final, 0 when the build has to take the
+// other path instead (a union row of more than 2048 entries), < 0 on error.
+static int graph_finish_fused(gt_ctx* ctx, int64_t* out_nnz, uint32_t* flags) {
+    GraphState* g = ctx->graph;
+    KnnWork* k = ctx->knn;
+    const int64_t nloc = g->nloc;
+    const int64_t n_recv = g->send_counts_host[0];   // every kept entry is sent once (graph_begin_impl)
+    if (n_recv <= 0) return 0;
+    StageSpan span(ctx, "symmetrize");
+    StageSpan span_f(ctx, "symm_fused");   // (nested: the sign that this path ran)
+    const int32_t* perm = k->qorder.as<int32_t>();
+    int shift = 9;
+    if (ctx->symm_bin_shift > 0) shift = ctx->symm_bin_shift;
+    while (ceil_div64(nloc, int64_t(1) << shift) > 4096) ++shift;
+    const int nbins = int(ceil_div64(nloc, int64_t(1) << shift));
+    GT_HIP(ctx, k->sh_invperm.reserve(size_t(nloc) * sizeof(int32_t)));
+    GT_TRY(gt_sym_invperm(ctx, perm, k->sh_invperm.as<int32_t>()));
+    GT_HIP(ctx, g->cnt_sorted.reserve(size_t(nloc) * sizeof(int32_t)));
+    GT_HIP(ctx, g->pos_sorted.reserve(size_t(nloc + 1) * sizeof(int64_t)));
+    GT_HIP(ctx, g->bincnt.reserve(size_t(2 * nbins) * sizeof(int32_t)));
+    GT_HIP(ctx, g->binoff.reserve(size_t(nbins + 1) * sizeof(int64_t)));
+    GT_HIP(ctx, g->cursor.reserve(size_t(n_recv) * sizeof(uint32_t)));   // posj
+    GT_HIP(ctx, g->selfbuf.reserve(size_t(n_recv) * sizeof(Triplet)));
+    GT_HIP(ctx, g->ucol.reserve(size_t(n_recv) * sizeof(uint32_t)));
+    GT_HIP(ctx, g->uval.reserve(size_t(n_recv) * sizeof(double)));
+    GT_HIP(ctx, g->off.reserve(size_t(nloc + 1) * sizeof(int64_t)));
+    GT_HIP(ctx, g->outlen.reserve(size_t(nloc) * sizeof(int32_t)));
+    GT_HIP(ctx, g->bigrows.reserve(size_t(nloc) * sizeof(int32_t)));
+    GT_HIP(ctx, g->bigcount.reserve(4 * sizeof(uint32_t)));   // [0] long rows, [2] fused-path flags
+    GT_HIP(ctx, g->indptr.reserve(size_t(nloc + 1) * sizeof(int64_t)));
+    const int64_t total_u = 2 * n_recv;   // upper bound of nnz(K)
+    GT_HIP(ctx, g->indices.reserve(size_t(total_u) * sizeof(int32_t)));
+    GT_HIP(ctx, g->Kdata.reserve(size_t(total_u) * sizeof(double)));
+    GT_HIP(ctx, g->Pdata.reserve(size_t(total_u) * sizeof(double)));
+    GT_HIP(ctx, g->degree.reserve(size_t(nloc) * sizeof(double)));
+    GT_HIP(ctx, hipMemsetAsync(g->bincnt.p, 0, size_t(2 * nbins) * sizeof(int32_t), ctx->stream));
+    GT_HIP(ctx, hipMemsetAsync(g->bigcount.p, 0, 4 * sizeof(uint32_t), ctx->stream));
+    uint32_t* fflags = g->bigcount.as<uint32_t>() + 2;
+    // own entries in sorted order and their scan; triplets per destination bin and their scan
+    hipLaunchKernelGGL(gather_counts_kernel, dim3((unsigned)ceil_div64(nloc, 256)), dim3(256), 0, ctx->stream,
+                       g->lenN.as<int32_t>(), perm, nloc, g->cnt_sorted.as<int32_t>());
+    GT_TRY(exclusive_scan(ctx, g->cnt_sorted.as<int32_t>(), nullptr, nloc, g->pos_sorted.as<int64_t>(), g->scan_tmp));
+    hipLaunchKernelGGL(bin_count_kernel, dim3((unsigned)std::min<int64_t>(ceil_div64(nloc, 64), 2048)), dim3(256),
+                       size_t(nbins) * sizeof(int32_t), ctx->stream, nloc, k->MP, k->cand_d2.as<double>(),
+                       k->cand_j.as<uint32_t>(), g->rowsrc.as<int32_t>(), g->rlists.as<uint64_t>(),
+                       g->rcounts.as<uint32_t>(), g->rcap, g->rK.as<double>(), g->tablen.as<int32_t>(), perm,
+                       k->sh_invperm.as<int32_t>(), shift, nbins, g->pos_sorted.as<int64_t>(), g->cursor.as<uint32_t>(),
+                       g->bincnt.as<int32_t>());
+    GT_TRY(exclusive_scan(ctx, g->bincnt.as<int32_t>(), nullptr, nbins, g->binoff.as<int64_t>(), g->scan_tmp));
+    hipLaunchKernelGGL(bin_emit_kernel, dim3((unsigned)ceil_div64(nloc, kEmitRows)), dim3(256), size_t(2 * nbins) * sizeof(int32_t),
+                       ctx->stream, nloc, k->MP, k->cand_d2.as<double>(), k->cand_j.as<uint32_t>(), g->rowsrc.as<int32_t>(),
+                       g->rlists.as<uint64_t>(), g->rcounts.as<uint32_t>(), g->rcap, g->rK.as<double>(),
+                       g->tablen.as<int32_t>(), perm, g->pos_sorted.as<int64_t>(), g->cursor.as<uint32_t>(), shift, nbins,
+                       g->binoff.as<int64_t>(), g->bincnt.as<int32_t>() + nbins, (Triplet*)g->selfbuf.p);
+    hipLaunchKernelGGL(bin_fill_kernel, dim3((unsigned)nbins), dim3(256), size_t(2) * (size_t(1) << shift) * sizeof(int32_t),
+                       ctx->stream, nloc, k->MP, k->cand_d2.as<double>(), k->cand_j.as<uint32_t>(), g->rowsrc.as<int32_t>(),
+                       g->rlists.as<uint64_t>(), g->rcounts.as<uint32_t>(), g->rcap, g->rK.as<double>(),
+                       g->tablen.as<int32_t>(), perm, shift, nbins, g->binoff.as<int64_t>(), (const Triplet*)g->selfbuf.p,
+                       g->cnt_sorted.as<int32_t>(), g->pos_sorted.as<int64_t>(), g->off.as<int64_t>(), (UEntry*)nullptr,
+                       g->ucol.as<uint32_t>(), g->uval.as<double>());
+    GT_HIP(ctx, hipGetLastError());
+    FusedSrc fs;
+    fs.pos = k->sh_invperm.as<int32_t>();
+    fs.lenN = g->lenN.as<int32_t>();
+    fs.off = g->off.as<int64_t>();
+    fs.sN = g->pos_sorted.as<int64_t>();
+    fs.rowsrc = g->rowsrc.as<int32_t>();
+    fs.cand_k = k->cand_d2.as<double>();
+    fs.cand_j = k->cand_j.as<uint32_t>();
+    fs.MP = k->MP;
+    fs.rlists = g->rlists.as<uint64_t>();
+    fs.rK = g->rK.as<double>();
+    fs.rcap = g->rcap;
+    fs.ucol = g->ucol.as<uint32_t>();
+    fs.uval = g->uval.as<double>();
+    hipLaunchKernelGGL(pair_count_kernel, dim3((unsigned)ceil_div64(nloc, 4)), dim3(256), 0, ctx->stream, nloc, fs,
+                       g->outlen.as<int32_t>(), g->bigrows.as<int32_t>(), g->bigcount.as<uint32_t>(), fflags);
+    GT_HIP(ctx, hipGetLastError());
+    GT_TRY(exclusive_scan(ctx, g->outlen.as<int32_t>(), nullptr, nloc, g->indptr.as<int64_t>(), g->scan_tmp));
+    hipLaunchKernelGGL(merge_final_kernel, dim3((unsigned)ceil_div64(nloc, 4)), dim3(256), 0, ctx->stream, nloc, fs,
+                       g->indptr.as<int64_t>(), g->indices.as<int32_t>(), g->Kdata.as<double>(), g->Pdata.as<double>(),
+                       g->degree.as<double>(), g->flags.as<uint32_t>(),
+                       (ctx->symm_key32 != 0 && sort_key_fits_u32(g->n_total, 8)) ? 1 : 0);
+    hipLaunchKernelGGL(merge_long_final_kernel, dim3(1024), dim3(64), 0, ctx->stream, fs, g->indptr.as<int64_t>(),
+                       g->indices.as<int32_t>(), g->Kdata.as<double>(), g->Pdata.as<double>(), g->degree.as<double>(),
+                       g->flags.as<uint32_t>(), g->bigrows.as<int32_t>(), g->bigcount.as<uint32_t>());
+    GT_HIP(ctx, hipGetLastError());
+    int64_t nnz = 0;
+    uint32_t ff = 0, fl = 0, kfl = 0;
+    GT_HIP(ctx, hipMemcpyAsync(&nnz, g->indptr.as<int64_t>() + nloc, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    GT_HIP(ctx, hipMemcpyAsync(&ff, fflags, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    GT_HIP(ctx, hipMemcpyAsync(&fl, g->flags.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    GT_HIP(ctx, hipMemcpyAsync(&kfl, k->gflags.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->dbg_select & 2048)
+        std::fprintf(stderr, "[gt] fused tail: flags %u, nnz %lld of at most %lld\n", ff, (long long)nnz, (long long)total_u);
+    if (ff != 0) {
+        // hub rows beyond the register sorts: this point set takes the other path, now and for its later builds; the
+        // zero-diagonal flag is set again by that path
+        ctx->symm_fused_ok = 0;
+        GT_HIP(ctx, hipMemsetAsync(g->flags.p, 0, sizeof(uint32_t), ctx->stream));
+        return 0;
+    }
+    g->nnz0 = n_recv;
+    g->nnz = nnz;
+    g->finished = true;
+    fl |= kfl;
+    if (k->n_fallback > 0) fl |= GT_FLAG_FALLBACK_ROWS;
+    if (g->n_over > 0) fl |= GT_FLAG_RADIUS_ROWS;
+    if (out_nnz) *out_nnz = g->nnz;
+    if (flags) *flags = fl;
+    return 1;
+}
+
 extern "C" int gt_graph_finish(gt_ctx* ctx, const void* recv_buf_dev, int64_t n_recv, int64_t* out_nnz, uint32_t* flags) {
     return graph_finish_impl(ctx, recv_buf_dev, n_recv, false, out_nnz, flags);
 }
@@ -1806,6 +2197,16 @@ extern "C" int gt_graph_build(gt_ctx* ctx, const gt_knn_params* params, int64_t*
     const bool bins = ctx->symm_bins != 0 && sendc[0] > 0 && k->ordered && k->nq == g->nloc && g->r0 == 0 && !g->external &&
                       g->nloc < (int64_t(1) << 31) && (ctx->symm_bins > 0 || g->nloc >= 65536);
     g->bins_used = bins;
+    g->fused_used = false;
+    if (bins && ctx->symm_fused != 0 && ctx->symm_fused_ok != 0 && g->p.kernel_symm == GT_SYMM_ADD && g->p.anisotropy == 0.0 &&
+        (std::isnan(g->p.decay) || g->p.thresh == 1.0 || g->p.thresh > 0.0)) {
+        const int rc = graph_finish_fused(ctx, out_nnz, flags);
+        if (rc < 0) return rc;
+        if (rc == 1) {
+            g->fused_used = true;
+            return GT_OK;
+        }
+    }
     if (bins) return graph_finish_impl(ctx, nullptr, 0, true, out_nnz, flags);
     if (sendc[0] > 0) {
         GT_HIP(ctx, g->selfbuf.reserve(size_t(sendc[0]) * sizeof(Triplet)));

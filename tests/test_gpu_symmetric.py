@@ -131,6 +131,50 @@ def test_symmetric_and_classic_pass_build_identical_kernels():
         assert np.array_equal(a, b)
 
 
+def _digest(ctx):
+    """sha1 of indptr | indices | K data | P data of the finished graph (whole matrix, host copies)"""
+    import hashlib
+
+    from graphtools_amd import _hip
+
+    kd, ki, kp = ctx.graph_fetch_csr(_hip.CSR_K)
+    pd, _, _ = ctx.graph_fetch_csr(_hip.CSR_P, structure=False)
+    return [hashlib.sha1(a.tobytes()).hexdigest() for a in (kp, ki, kd, pd)], int(kd.shape[0])
+
+
+@pytest.mark.parametrize("kind", ["mix", "manifold"])
+def test_headline_size_pruned_pass_equals_classic_pass_over_the_whole_matrix(kind):
+    """N = 1e6, d = 64, knn = 15, decay = 40 (BASELINE.json's headline shape): the default build - dense seeding launch,
+    cell bounds / two-stage collect, cold launch, four-lane re-rank - against the classic pass (every query row against
+    every point): indptr, indices, K and P of the WHOLE matrix bit for bit.  The symmetric pass proves completeness from
+    thresholds; a bound that wrongly ruled out a pair would drop a neighbour that only this comparison can see.
+    `manifold` (5 dimensions embedded in 64) is the input on which the cell bounds give way to the collect launch."""
+    from graphtools_amd import _hip
+
+    n = 1000000
+    if kind == "mix":
+        X = make_mix(n, 64, 1)
+    else:
+        rng = np.random.default_rng(1)
+        a = rng.standard_normal((5, 64))
+        X = np.empty((n, 64), dtype=np.float32)
+        for s0 in range(0, n, 100000):
+            X[s0:s0 + 100000] = rng.standard_normal((100000, 5)) @ a + 0.01 * rng.standard_normal((100000, 64))
+    out = {}
+    for mode in ("auto", "0"):
+        ctx = _hip.Context(0)
+        ctx.set_option("select_symmetric", mode)
+        ctx.set_points(X)
+        p, keep = ctx.make_params(15, 40.0, 1e-4, None, 1.0, None, "+", None, 0)
+        nnz, _ = ctx.graph_build(p)
+        assert ctx.knn_stats()["symmetric"] == (mode == "auto")
+        out[mode] = _digest(ctx)
+        assert out[mode][1] == nnz
+        ctx.close()
+        _hip.release_cached_memory()
+    assert out["auto"] == out["0"]
+
+
 # ---- two-stage collect (partial distances first, deferred cold pass) ---------------------------------------------------
 def _build(X, opts, knn=15, decay=40.0):
     from graphtools_amd import _hip
