@@ -82,12 +82,15 @@ _SIGNATURES = {
     "gt_host_place_block": (_c.c_int, [_c.c_int64] + [_c.c_void_p] * 9),
     "gt_graph_spmm": (_c.c_int, [_c.c_void_p, _c.c_int32, _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int32]),
     "gt_graph_fetch_vec": (_c.c_int, [_c.c_void_p, _c.c_int32, _c.c_void_p, _c.c_int32]),
+    "gt_graph_diff_aff": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int32]),
     "gt_graph_stats": (_c.c_int, [_c.c_void_p, _c.c_void_p]),
     "gt_knn_stats": (_c.c_int, [_c.c_void_p, _c.c_void_p]),
     "gt_dense_graph_build": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_int32,
                                         _c.c_int32, _c.c_int32, _c.c_double, _c.c_double, _c.c_void_p, _c.c_int64,
                                         _c.c_double, _c.c_int32, _c.c_double, _c.c_double, _c.c_int32, _c.c_void_p,
                                         _c.c_void_p, _c.c_int32, _c.POINTER(_c.c_uint32)]),
+    "gt_dense_extend": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_double, _c.c_double,
+                                   _c.c_void_p, _c.c_int64, _c.c_double, _c.c_void_p, _c.c_int32]),
     "gt_dense_fetch_vec": (_c.c_int, [_c.c_void_p, _c.c_int32, _c.c_void_p]),
     "gt_landmark_build": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int32, _c.c_void_p, _c.c_void_p, _c.c_int32,
                                      _c.POINTER(_c.c_int64)]),
@@ -426,6 +429,13 @@ class Context:
         self._check(self.lib.gt_graph_spmm(self.h, which, _ptr(X), X.shape[1], _ptr(out), 0), "gt_graph_spmm")
         return out[:, 0] if squeeze else out
 
+    def graph_diff_aff(self):
+        """values of D^-1/2 K D^-1/2 on the CSR structure of K (owned rows; single-rank builds)"""
+        _, _, nnz = self.graph_rows()
+        out = np.empty(nnz, dtype=np.float64)
+        self._check(self.lib.gt_graph_diff_aff(self.h, None, _ptr(out), 0), "gt_graph_diff_aff")
+        return out
+
     def graph_fetch_vec(self, which):
         r0, r1, _ = self.graph_rows()
         out = np.empty(r1 - r0, dtype=np.float64)
@@ -489,7 +499,10 @@ class Context:
     # ---- exact dense graph -------------------------------------------------------------------
     def dense_graph_build(self, data, precomputed, knn, decay, thresh, bandwidth, bandwidth_scale, kernel_symm, theta,
                           anisotropy, want_P=True):
-        """(K ndarray, P ndarray or None, flags).  Result dtype follows numpy's rules in the reference."""
+        """(K ndarray, P ndarray or None, flags).  Result dtype follows numpy's rules in the reference.
+        ``precomputed``: None / False (points), "distance" / True, "affinity", "adjacency"."""
+        mode = {None: 0, False: 0, True: 1, "distance": 1, "affinity": 2, "adjacency": 3}[precomputed]
+        precomputed = mode != 0
         data = np.ascontiguousarray(data)
         if data.dtype not in (np.float32, np.float64):
             data = data.astype(np.float64)
@@ -507,8 +520,9 @@ class Context:
         flags = ctypes.c_uint32(0)
         self._check(
             self.lib.gt_dense_graph_build(
-                self.h, _ptr(data), n, d, GT_F32 if data.dtype == np.float32 else GT_F64, 0, 1 if precomputed else 0,
-                int(knn) if knn is not None else 0, float(decay), float(thresh), _ptr(bw), bw_len, float(bandwidth_scale),
+                self.h, _ptr(data), n, d, GT_F32 if data.dtype == np.float32 else GT_F64, 0, mode,
+                int(knn) if knn is not None else 0, float("nan") if decay is None else float(decay), float(thresh), _ptr(bw),
+                bw_len, float(bandwidth_scale),
                 SYMM[kernel_symm], 1.0 if theta is None else float(theta), float(anisotropy), 0, _ptr(K), _ptr(P), 0,
                 ctypes.byref(flags)),
             "gt_dense_graph_build",
@@ -516,6 +530,21 @@ class Context:
         if not precomputed:
             self.n, self.d, self.dtype = n, data.shape[1], data.dtype
         return K, P, flags.value
+
+    def dense_extend(self, Y, knn, decay, thresh, bandwidth, bandwidth_scale):
+        """dense float64 kernel [m, n] from new points Y to the points of the last from-data dense build"""
+        Y = np.ascontiguousarray(Y, dtype=self.dtype)
+        m = Y.shape[0]
+        bw = None
+        bw_len = 0
+        if bandwidth is not None:
+            bw = np.ascontiguousarray(np.atleast_1d(np.asarray(bandwidth, dtype=np.float64)))
+            bw_len = bw.shape[0]
+        K = np.empty((m, self.n), dtype=np.float64)
+        self._check(self.lib.gt_dense_extend(self.h, _ptr(Y), m, 0, int(knn) if knn is not None else 0, float(decay),
+                                             float(thresh), _ptr(bw), bw_len, float(bandwidth_scale), _ptr(K), 0),
+                    "gt_dense_extend")
+        return K
 
     def dense_fetch_vec(self, which, n):
         out = np.empty(n, dtype=np.float64)

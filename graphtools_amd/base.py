@@ -149,9 +149,14 @@ class BaseGraph(object):
     def diff_aff(self):
         """Symmetric diffusion affinity D^-1/2 K D^-1/2 (reference: base.py:668-698).
 
-        A diagonal rescaling of the cached kernel by the cached degrees (both device results)."""
+        Sparse kernels that live on the device (kNN and MNN graphs): one pass over K's entries (``gt_graph_diff_aff``),
+        the result shares K's CSR structure.  Dense kernels (exact graphs, whose K was handed to the host when it was
+        built): the reference's two numpy divisions."""
         deg = self.kernel_degree
         if sparse.issparse(self.kernel):
+            fetch = getattr(self, "_fetch_diff_aff", None)
+            if fetch is not None:
+                return fetch()
             n = len(deg)
             dm = sparse.csr_matrix((1 / np.sqrt(deg.flatten()), np.arange(n), np.arange(n + 1)))
             return dm @ self.kernel @ dm

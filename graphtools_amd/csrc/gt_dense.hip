@@ -41,6 +41,14 @@ __device__ __forceinline__ T affinity_t(T dist, T bw, T decay, T xcut) {
     return (w != w) ? T(1) : w;
 }
 
+// unsymmetrised kernel entry of a precomputed matrix: 0 a distance (alpha-decay affinity), 1 an affinity (taken as is,
+// graphs.py:1532-1536), 2 an adjacency (diagonal set to 1, graphs.py:1537-1545)
+template <typename T>
+__device__ __forceinline__ T k0_t(T v, const double* __restrict__ bw, int64_t row, T decay, T xcut, int pass, bool on_diag) {
+    if (pass == 0) return affinity_t<T>(v, T(bw[row]), decay, xcut);
+    return (pass == 2 && on_diag) ? T(1) : v;
+}
+
 template <typename T>
 __device__ __forceinline__ T merge_t(T a, T b, int symm, T theta) {
     switch (symm) {
@@ -311,7 +319,7 @@ __global__ __launch_bounds__(256) void dense_kernel_tiles(const TD* __restrict__
                                                           const int64_t n, const int nb, const double* __restrict__ bw,
                                                           const double decay_d, const double thresh_d, const int symm,
                                                           const double theta_d, TC* __restrict__ Kout,
-                                                          uint32_t* __restrict__ flags, const double xcut_d) {
+                                                          uint32_t* __restrict__ flags, const double xcut_d, const int pass) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     TC* sA = reinterpret_cast<TC*>(smem_raw);      // [TS][TSP]  K0 of tile (I,J): sA[i][j]
     TC* sB = sA + TS * TSP;                        // [TS][TSP]  K0 of tile (J,I): sB[j][i]
@@ -391,11 +399,10 @@ __global__ __launch_bounds__(256) void dense_kernel_tiles(const TD* __restrict__
                     float ka[4] = {0.f, 0.f, 0.f, 0.f};
                     if (gi < n && gj0 < n) {
                         const float4 v = *reinterpret_cast<const float4*>(D + gi * n + gj0);
-                        const float bwi = float(bw[gi]);
-                        ka[0] = affinity_t<float>(v.x, bwi, decay, xcut);
-                        ka[1] = affinity_t<float>(v.y, bwi, decay, xcut);
-                        ka[2] = affinity_t<float>(v.z, bwi, decay, xcut);
-                        ka[3] = affinity_t<float>(v.w, bwi, decay, xcut);
+                        ka[0] = k0_t<float>(v.x, bw, gi, decay, xcut, pass, gi == gj0);
+                        ka[1] = k0_t<float>(v.y, bw, gi, decay, xcut, pass, gi == gj0 + 1);
+                        ka[2] = k0_t<float>(v.z, bw, gi, decay, xcut, pass, gi == gj0 + 2);
+                        ka[3] = k0_t<float>(v.w, bw, gi, decay, xcut, pass, gi == gj0 + 3);
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
                             if (ka[e] < thresh) ka[e] = 0.f;
@@ -408,11 +415,10 @@ __global__ __launch_bounds__(256) void dense_kernel_tiles(const TD* __restrict__
                     float kb[4] = {0.f, 0.f, 0.f, 0.f};
                     if (gj < n && gi0 < n) {
                         const float4 v = *reinterpret_cast<const float4*>(D + gj * n + gi0);
-                        const float bwj = float(bw[gj]);
-                        kb[0] = affinity_t<float>(v.x, bwj, decay, xcut);
-                        kb[1] = affinity_t<float>(v.y, bwj, decay, xcut);
-                        kb[2] = affinity_t<float>(v.z, bwj, decay, xcut);
-                        kb[3] = affinity_t<float>(v.w, bwj, decay, xcut);
+                        kb[0] = k0_t<float>(v.x, bw, gj, decay, xcut, pass, gj == gi0);
+                        kb[1] = k0_t<float>(v.y, bw, gj, decay, xcut, pass, gj == gi0 + 1);
+                        kb[2] = k0_t<float>(v.z, bw, gj, decay, xcut, pass, gj == gi0 + 2);
+                        kb[3] = k0_t<float>(v.w, bw, gj, decay, xcut, pass, gj == gi0 + 3);
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
                             if (kb[e] < thresh) kb[e] = 0.f;
@@ -462,7 +468,7 @@ __global__ __launch_bounds__(256) void dense_kernel_tiles(const TD* __restrict__
                 const int64_t gi = I0 + i, gj = J0 + tx;
                 TC ka = TC(0);
                 if (gi < n && gj < n) {
-                    ka = affinity_t<TC>(TC(D[gi * n + gj]), TC(bw[gi]), decay, xcut);
+                    ka = k0_t<TC>(TC(D[gi * n + gj]), bw, gi, decay, xcut, pass, gi == gj);
                     if (ka < thresh) ka = TC(0);
                 }
                 sA[i * TSP + tx] = ka;
@@ -471,7 +477,7 @@ __global__ __launch_bounds__(256) void dense_kernel_tiles(const TD* __restrict__
                 const int64_t gj = J0 + i, gi = I0 + tx;
                 TC kb = TC(0);
                 if (gi < n && gj < n) {
-                    kb = affinity_t<TC>(TC(D[gj * n + gi]), TC(bw[gj]), decay, xcut);
+                    kb = k0_t<TC>(TC(D[gj * n + gi]), bw, gj, decay, xcut, pass, gi == gj);
                     if (kb < thresh) kb = TC(0);
                 }
                 sB[i * TSP + tx] = kb;
@@ -595,7 +601,7 @@ static double dense_xcut(double decay, double thresh, bool f32) {
 
 template <typename TD, typename TC, typename TX, bool FROM_DATA>
 int launch_tiles(gt_ctx* ctx, const TD* D, const TX* X, int d, int64_t n, const double* bw, double decay, double thresh,
-                 int symm, double theta, TC* Kout, uint32_t* flags) {
+                 int symm, double theta, TC* Kout, uint32_t* flags, int pass = 0) {
     const int nb = int(ceil_div64(n, TS));
     const int64_t nbs = ceil_div64(nb, SG);
     const int64_t pairs = nbs * nbs * SG * SG;   // grid positions (super-tile order, lower triangle exits)
@@ -606,9 +612,77 @@ int launch_tiles(gt_ctx* ctx, const TD* D, const TX* X, int d, int64_t n, const 
     GT_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     int(lds)));
     hipLaunchKernelGGL(kern, dim3((unsigned)pairs), dim3(256), lds, ctx->stream, D, X, d, n, nb, bw, decay, thresh, symm,
-                       theta, Kout, flags, dense_xcut(decay, thresh, sizeof(TC) == 4));
+                       theta, Kout, flags, dense_xcut(decay, thresh, sizeof(TC) == 4), pass);
     GT_HIP(ctx, hipGetLastError());
     return GT_OK;
+}
+
+// ---- out-of-sample extension of an exact graph (TraditionalGraph.build_kernel_to_data, graphs.py:1612-1678) -----------
+// pdx = cdist(Y, X) (float64 difference form, sequential in k like scipy), bandwidth_y = the knn-th smallest of row y (or
+// the caller's) * scale, K_yj = exp(-(pdx_yj / bandwidth_y)^decay), NaN -> 1, < thresh -> 0.  One workgroup per
+// 64 x 64 tile; both row blocks are staged through LDS as float64.
+template <typename TX>
+__global__ __launch_bounds__(256) void dense_extend_tiles(const TX* __restrict__ Y, const int64_t m, const TX* __restrict__ X,
+                                                          const int64_t n, const int d, const double* __restrict__ bw,
+                                                          const double decay, const double thresh, const double xcut,
+                                                          double* __restrict__ Kout) {
+    constexpr int KC = 32, KCP = 33;
+    __shared__ double yI[TS * KCP], xJ[TS * KCP];
+    const int64_t I0 = int64_t(blockIdx.y) * TS, J0 = int64_t(blockIdx.x) * TS;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    double acc[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0;
+    for (int k0 = 0; k0 < d; k0 += KC) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < TS * KC; e += 256) {
+            const int r = e / KC, k = e % KC;
+            const int64_t gi = I0 + r, gj = J0 + r;
+            yI[r * KCP + k] = (gi < m && k0 + k < d) ? double(Y[gi * d + k0 + k]) : 0.0;
+            xJ[r * KCP + k] = (gj < n && k0 + k < d) ? double(X[gj * d + k0 + k]) : 0.0;
+        }
+        __syncthreads();
+        const int kc = (d - k0) < KC ? (d - k0) : KC;
+        for (int k = 0; k < kc; ++k) {
+            const double xj = xJ[tx * KCP + k];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const double diff = yI[(ty + 4 * r) * KCP + k] - xj;
+                acc[r] += diff * diff;
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int64_t gi = I0 + ty + 4 * r, gj = J0 + tx;
+        if (gi < m && gj < n) {
+            double kv = affinity_t<double>(sqrt(acc[r]), bw[gi], decay, xcut);
+            if (kv < thresh) kv = 0.0;
+            Kout[gi * n + gj] = kv;
+        }
+    }
+}
+
+// bandwidth of the extension rows from their exact nearest candidates (difference-form distances, like the build)
+template <typename T>
+__global__ __launch_bounds__(256) void dense_bandwidth_ext_kernel(const T* __restrict__ Y, const int64_t m, const T* __restrict__ X,
+                                                                  const int d, const uint32_t* __restrict__ cand_j, const int MP,
+                                                                  const int kth, const double scale, double* __restrict__ bw) {
+    const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= m) return;
+    const T* yi = Y + i * d;
+    double mx = 0.0;
+    for (int c = 0; c < kth; ++c) {
+        const T* xj = X + int64_t(cand_j[i * MP + c]) * d;
+        double s = 0.0;
+        for (int k = 0; k < d; ++k) {
+            const double diff = double(yi[k]) - double(xj[k]);
+            s += diff * diff;
+        }
+        const double dist = sqrt(s);
+        mx = dist > mx ? dist : mx;
+    }
+    bw[i] = mx * scale;
 }
 
 template <typename T>
@@ -645,10 +719,17 @@ extern "C" int gt_dense_graph_build(gt_ctx* ctx, const void* X_or_D, int64_t n, 
     ctx->reset_stages();
     if (!X_or_D || n <= 0) GT_FAIL(ctx, GT_E_ARG, "gt_dense_graph_build: empty input");
     if (dtype != GT_F32 && dtype != GT_F64) GT_FAIL(ctx, GT_E_ARG, "dtype must be GT_F32 or GT_F64");
+    if (precomputed < 0 || precomputed > GT_PRECOMPUTED_ADJACENCY) GT_FAIL(ctx, GT_E_ARG, "precomputed must be 0 ... 3");
+    // 2 / 3: the caller's matrix IS the unsymmetrised kernel (adjacency: with the diagonal set to 1) - no bandwidth, no decay
+    const int pass = precomputed >= GT_PRECOMPUTED_AFFINITY ? precomputed - 1 : 0;
+    if (pass) {
+        bandwidth_len = 0;
+        decay = 1.0;
+    }
     if (std::isnan(decay)) GT_FAIL(ctx, GT_E_ARG, "`decay` must be provided for a TraditionalGraph");
     if (bandwidth_len != 0 && bandwidth_len != 1 && bandwidth_len != n)
         GT_FAIL(ctx, GT_E_ARG, "bandwidth must have 1 or n entries");
-    if (bandwidth_len == 0 && (knn < 0 || int64_t(knn) + 1 > n)) GT_FAIL(ctx, GT_E_ARG, "knn + 1 exceeds n_samples");
+    if (!pass && bandwidth_len == 0 && (knn < 0 || int64_t(knn) + 1 > n)) GT_FAIL(ctx, GT_E_ARG, "knn + 1 exceeds n_samples");
     if (inplace && !(precomputed && on_device)) GT_FAIL(ctx, GT_E_ARG, "inplace needs a device-resident distance matrix");
     DenseState st;
     int rc = GT_OK;
@@ -680,6 +761,7 @@ extern "C" int gt_dense_graph_build(gt_ctx* ctx, const void* X_or_D, int64_t n, 
     } while (0)
 
     DENSE_HIP(st.bw.reserve(size_t(n) * sizeof(double)));
+    if (pass) DENSE_HIP(hipMemsetAsync(st.bw.p, 0, size_t(n) * sizeof(double), ctx->stream));
     DENSE_HIP(st.flags.reserve(sizeof(uint32_t)));
     DENSE_HIP(hipMemsetAsync(st.flags.p, 0, sizeof(uint32_t), ctx->stream));
     const void* in_dev = X_or_D;
@@ -693,7 +775,7 @@ extern "C" int gt_dense_graph_build(gt_ctx* ctx, const void* X_or_D, int64_t n, 
         in_dev = st.work_in.p;
     }
     // ---- bandwidth ----
-    {
+    if (!pass) {
         StageSpan span(ctx, "dense_bandwidth");
         if (bandwidth_len > 0) {
             DENSE_HIP(st.bw_user.reserve(size_t(bandwidth_len) * sizeof(double)));
@@ -768,13 +850,13 @@ extern "C" int gt_dense_graph_build(gt_ctx* ctx, const void* X_or_D, int64_t n, 
                                                                       thresh, kernel_symm, theta, (double*)K_dev, fl)));
         } else if (dtype == GT_F64) {
             DENSE_TRY((launch_tiles<double, double, double, false>(ctx, (const double*)in_dev, nullptr, 0, n, bw, decay,
-                                                                   thresh, kernel_symm, theta, (double*)K_dev, fl)));
+                                                                   thresh, kernel_symm, theta, (double*)K_dev, fl, pass)));
         } else if (out_f64) {
             DENSE_TRY((launch_tiles<float, double, double, false>(ctx, (const float*)in_dev, nullptr, 0, n, bw, decay,
-                                                                  thresh, kernel_symm, theta, (double*)K_dev, fl)));
+                                                                  thresh, kernel_symm, theta, (double*)K_dev, fl, pass)));
         } else {
             DENSE_TRY((launch_tiles<float, float, double, false>(ctx, (const float*)in_dev, nullptr, 0, n, bw, decay,
-                                                                 thresh, kernel_symm, theta, (float*)K_dev, fl)));
+                                                                 thresh, kernel_symm, theta, (float*)K_dev, fl, pass)));
         }
     }
     // ---- anisotropy + P ----
@@ -816,6 +898,99 @@ extern "C" int gt_dense_graph_build(gt_ctx* ctx, const void* X_or_D, int64_t n, 
     return GT_OK;
 #undef DENSE_TRY
 #undef DENSE_HIP
+}
+
+extern "C" int gt_dense_extend(gt_ctx* ctx, const void* Y, int64_t m, int32_t y_on_device, int32_t knn, double decay,
+                               double thresh, const double* bandwidth, int64_t bandwidth_len, double bandwidth_scale,
+                               double* out_K, int32_t out_on_device) {
+    if (!ctx || !Y || m <= 0 || !out_K) return GT_E_ARG;
+    GT_HIP(ctx, hipSetDevice(ctx->device));
+    ctx->reset_stages();
+    if (ctx->n <= 0 || !ctx->X) GT_FAIL(ctx, GT_E_STATE, "gt_dense_extend: no points bound (build the graph from data first)");
+    if (ctx->metric != 0) GT_FAIL(ctx, GT_E_LIMIT, "gt_dense_extend: euclidean metric only");
+    if (std::isnan(decay)) GT_FAIL(ctx, GT_E_ARG, "`decay` must be provided for a TraditionalGraph");
+    if (bandwidth_len != 0 && bandwidth_len != 1 && bandwidth_len != m)
+        GT_FAIL(ctx, GT_E_ARG, "bandwidth must have 1 or n_samples_y entries");
+    if (bandwidth_len == 0 && (knn < 1 || int64_t(knn) > ctx->n)) GT_FAIL(ctx, GT_E_ARG, "knn must be in [1, n_samples]");
+    const int64_t n = ctx->n;
+    const int d = ctx->d;
+    DevBuf bw, bw_user, kbuf;
+    int rc = GT_OK;
+    auto cleanup = [&]() {
+        bw.release();
+        bw_user.release();
+        kbuf.release();
+    };
+#define EXT_HIP(expr)                                                          \
+    do {                                                                       \
+        hipError_t _e = (expr);                                                \
+        if (_e != hipSuccess) {                                                \
+            ctx->set_error(std::string(#expr) + ": " + hipGetErrorString(_e)); \
+            cleanup();                                                         \
+            return GT_E_HIP;                                                   \
+        }                                                                      \
+    } while (0)
+#define EXT_TRY(expr)      \
+    do {                   \
+        rc = (expr);       \
+        if (rc != GT_OK) { \
+            cleanup();     \
+            return rc;     \
+        }                  \
+    } while (0)
+    // the query matrix on the device, in the points' dtype (also the working copy the candidate pass needs)
+    EXT_TRY(gt_prepare_queries(ctx, Y, m, y_on_device));
+    KnnWork* k = ctx->knn;
+    EXT_HIP(bw.reserve(size_t(m) * sizeof(double)));
+    {
+        StageSpan span(ctx, "dense_bandwidth");
+        if (bandwidth_len > 0) {
+            EXT_HIP(bw_user.reserve(size_t(bandwidth_len) * sizeof(double)));
+            EXT_HIP(hipMemcpyAsync(bw_user.p, bandwidth, size_t(bandwidth_len) * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+            hipLaunchKernelGGL(dense_user_bandwidth_kernel, dim3((unsigned)ceil_div64(m, 256)), dim3(256), 0, ctx->stream,
+                               bw_user.as<double>(), bandwidth_len, m, bandwidth_scale, bw.as<double>());
+        } else {
+            if (ctx->DP == 0) {
+                ctx->set_error("exact graph extension: this feature count is not supported on the HIP path (reduce with n_pca)");
+                cleanup();
+                return GT_E_LIMIT;
+            }
+            EXT_TRY(gt_knn_candidates(ctx, 0, m, true, knn));
+            k = ctx->knn;
+            if (ctx->dtype == GT_F32)
+                hipLaunchKernelGGL(dense_bandwidth_ext_kernel<float>, dim3((unsigned)ceil_div64(m, 256)), dim3(256), 0, ctx->stream,
+                                   (const float*)k->Qraw.p, m, (const float*)ctx->X, d, k->cand_j.as<uint32_t>(), k->MP, knn,
+                                   bandwidth_scale, bw.as<double>());
+            else
+                hipLaunchKernelGGL(dense_bandwidth_ext_kernel<double>, dim3((unsigned)ceil_div64(m, 256)), dim3(256), 0, ctx->stream,
+                                   (const double*)k->Qraw.p, m, (const double*)ctx->X, d, k->cand_j.as<uint32_t>(), k->MP, knn,
+                                   bandwidth_scale, bw.as<double>());
+        }
+        EXT_HIP(hipGetLastError());
+    }
+    double* K_dev = out_K;
+    if (!out_on_device) {
+        EXT_HIP(kbuf.reserve(size_t(m) * size_t(n) * sizeof(double)));
+        K_dev = kbuf.as<double>();
+    }
+    {
+        StageSpan span(ctx, "dense_kernel");
+        const dim3 grid((unsigned)ceil_div64(n, TS), (unsigned)ceil_div64(m, TS));
+        const double xcut = dense_xcut(decay, thresh, false);
+        if (ctx->dtype == GT_F32)
+            hipLaunchKernelGGL(dense_extend_tiles<float>, grid, dim3(256), 0, ctx->stream, (const float*)k->Qraw.p, m,
+                               (const float*)ctx->X, n, d, bw.as<double>(), decay, thresh, xcut, K_dev);
+        else
+            hipLaunchKernelGGL(dense_extend_tiles<double>, grid, dim3(256), 0, ctx->stream, (const double*)k->Qraw.p, m,
+                               (const double*)ctx->X, n, d, bw.as<double>(), decay, thresh, xcut, K_dev);
+        EXT_HIP(hipGetLastError());
+    }
+    if (!out_on_device) EXT_TRY(gt_copy_to_host(ctx, out_K, K_dev, size_t(m) * size_t(n) * sizeof(double)));
+    EXT_HIP(hipStreamSynchronize(ctx->stream));
+    cleanup();
+    return GT_OK;
+#undef EXT_HIP
+#undef EXT_TRY
 }
 
 extern "C" int gt_dense_fetch_vec(gt_ctx* ctx, int32_t which, double* out_host) {

@@ -1323,6 +1323,24 @@ __global__ __launch_bounds__(256) void anisotropy_kernel(const int64_t nloc, con
     if (lane == 0) degree_out[i] = sum;
 }
 
+// D^-1/2 K D^-1/2 (BaseGraph.diff_aff, base.py:668-698) on the structure of K: the reference forms it as two sparse
+// products with the diagonal matrix 1 / sqrt(degree) - (D K) D - i.e. every entry is rounded after each of the two
+// multiplications, left factor first
+__global__ __launch_bounds__(256) void diff_aff_kernel(const int64_t nloc, const int64_t r0, const int64_t* __restrict__ indptr,
+                                                       const int32_t* __restrict__ indices, const double* __restrict__ Kdata,
+                                                       const double* __restrict__ degree_all, double* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int w = threadIdx.x >> 6;
+    const int64_t i = int64_t(blockIdx.x) * 4 + w;
+    if (i >= nloc) return;
+    const int64_t s = indptr[i], e1 = indptr[i + 1];
+    const double di = 1.0 / sqrt(degree_all[r0 + i]);
+    for (int64_t e = s + lane; e < e1; e += 64) {
+        const double left = di * Kdata[e];
+        out[e] = left * (1.0 / sqrt(degree_all[indices[e]]));
+    }
+}
+
 __global__ __launch_bounds__(256) void normalize_kernel(const int64_t nloc, const int64_t* __restrict__ indptr,
                                                         const double* __restrict__ Kdata, double* __restrict__ Pdata) {
     const int lane = threadIdx.x & 63;
@@ -2183,6 +2201,38 @@ extern "C" int gt_graph_anisotropy(gt_ctx* ctx, const double* degree_all_dev) {
     GT_TRY(finish_normalize(ctx, g, degree_all_dev));
     GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return GT_OK;
+}
+
+extern "C" int gt_graph_diff_aff(gt_ctx* ctx, const double* degree_all_dev, double* out, int32_t on_device) {
+    if (!ctx || !out) return GT_E_ARG;
+    GT_HIP(ctx, hipSetDevice(ctx->device));
+    GraphState* g = ctx->graph;
+    if (!g || !g->finished) GT_FAIL(ctx, GT_E_STATE, "gt_graph_diff_aff: no finished graph");
+    if (!degree_all_dev && g->world != 1) GT_FAIL(ctx, GT_E_ARG, "gt_graph_diff_aff: a sharded build needs the degrees of all rows");
+    if (g->external) GT_FAIL(ctx, GT_E_STATE, "gt_graph_diff_aff: the device holds a rectangular kernel");
+    const double* deg = degree_all_dev ? degree_all_dev : g->degree.as<double>();
+    double* od = out;
+    DevBuf tmp;
+    if (!on_device) {
+        GT_HIP(ctx, tmp.reserve(size_t(std::max<int64_t>(g->nnz, 1)) * sizeof(double)));
+        od = tmp.as<double>();
+    }
+    hipLaunchKernelGGL(diff_aff_kernel, dim3((unsigned)ceil_div64(g->nloc, 4)), dim3(256), 0, ctx->stream, g->nloc,
+                       degree_all_dev ? g->r0 : int64_t(0), g->indptr.as<int64_t>(), g->indices.as<int32_t>(),
+                       g->Kdata.as<double>(), deg, od);
+    int rc = GT_OK;
+    if (hipGetLastError() != hipSuccess) {
+        ctx->set_error("gt_graph_diff_aff: launch failed");
+        rc = GT_E_HIP;
+    }
+    if (rc == GT_OK && !on_device) rc = gt_copy_to_host(ctx, out, od, size_t(g->nnz) * sizeof(double));
+    hipError_t es = hipStreamSynchronize(ctx->stream);
+    tmp.release();
+    if (rc == GT_OK && es != hipSuccess) {
+        ctx->set_error(std::string("gt_graph_diff_aff: ") + hipGetErrorString(es));
+        rc = GT_E_HIP;
+    }
+    return rc;
 }
 
 extern "C" int gt_graph_build(gt_ctx* ctx, const gt_knn_params* params, int64_t* out_nnz, uint32_t* flags) {

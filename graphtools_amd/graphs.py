@@ -57,6 +57,35 @@ class DataGraph(Data, BaseGraph):
         return Y
 
 
+    def extend_to_data(self, Y):
+        """Row-stochastic transitions from new points to the graph's data (reference: base.py:1166-1193): the kernel of
+        ``build_kernel_to_data`` with its rows l1-normalised.  (kNNGraph overrides this with the device's own P.)"""
+        Y = self._check_extension_shape(Y)
+        return _l1_rows(self.build_kernel_to_data(Y))
+
+    def interpolate(self, transform, transitions=None, Y=None):
+        """reference: base.py:1195-1229"""
+        if transitions is None:
+            if Y is None:
+                raise ValueError("Either `transitions` or `Y` must be provided.")
+            transitions = self.extend_to_data(Y)
+        return transitions.dot(transform)
+
+
+def _l1_rows(M):
+    # sklearn.preprocessing.normalize(M, "l1", axis=1): rows divided by the sum of their absolute values, zero rows kept
+    if sparse.issparse(M):
+        M = sparse.csr_matrix(M, dtype=np.float64, copy=True)
+        sums = np.asarray(abs(M).sum(axis=1)).ravel()
+        sums[sums == 0.0] = 1.0
+        M.data /= np.repeat(sums, np.diff(M.indptr))
+        return M
+    M = np.asarray(M, dtype=np.float64)
+    sums = np.abs(M).sum(axis=1)
+    sums[sums == 0.0] = 1.0
+    return M / sums[:, None]
+
+
 class _KnnTree(object):
     """Stand-in for the reference's ``knn_tree`` attribute (a fitted sklearn NearestNeighbors,
     graphs.py:748-769): ``kneighbors`` runs the brute-force search on the device."""
@@ -268,6 +297,13 @@ class kNNGraph(DataGraph):
         self._ensure_device_graph()
         return self.hip.graph_fetch_vec(_hip.VEC_DEGREE)
 
+    def _fetch_diff_aff(self):
+        self.K
+        self._ensure_device_graph()
+        vals = self.hip.graph_diff_aff()
+        K = self._kernel
+        return sparse.csr_matrix((vals, K.indices, K.indptr), shape=K.shape)
+
     def diff_op_torch(self):
         """The diffusion operator as a CUDA ``torch.sparse_csr_tensor`` (no host round trip): the hand-off to
         consumers that continue on the device, e.g. ``P @ X`` diffusion steps."""
@@ -317,7 +353,10 @@ class kNNGraph(DataGraph):
             knn = self.data_nu.shape[0]
         Y = self._check_extension_shape(Y)
         if bandwidth is not None and not isinstance(bandwidth, numbers.Number):
-            raise NotImplementedError("graphtools_amd: out-of-sample extension supports a scalar bandwidth only")
+            # one bandwidth per row of Y (graphs.py:893-897 broadcasts `bandwidth * bandwidth_scale` over the rows)
+            bandwidth = np.asarray(bandwidth, dtype=np.float64).ravel()
+            if bandwidth.shape[0] not in (1, np.asarray(Y).shape[0]):
+                raise ValueError("bandwidth must be a scalar or have one entry per row of Y")
         self._bind_points()
         params, keep = _hip.Context.make_params(knn, self.decay, self.thresh, bandwidth, bandwidth_scale, knn_max,
                                                 None, None, 0)
@@ -446,19 +485,7 @@ class LandmarkGraph(DataGraph):
             pnm = np.array([np.sum(kernel[:, inverse == i], axis=1).T for i in range(len(landmarks))]).transpose()
         return self._l1_rows(pnm)
 
-    @staticmethod
-    def _l1_rows(M):
-        # sklearn.preprocessing.normalize(M, "l1", axis=1): rows divided by the sum of their absolute values, zero rows kept
-        if sparse.issparse(M):
-            M = sparse.csr_matrix(M, dtype=np.float64, copy=True)
-            sums = np.asarray(abs(M).sum(axis=1)).ravel()
-            sums[sums == 0.0] = 1.0
-            M.data /= np.repeat(sums, np.diff(M.indptr))
-            return M
-        M = np.asarray(M, dtype=np.float64)
-        sums = np.abs(M).sum(axis=1)
-        sums[sums == 0.0] = 1.0
-        return M / sums[:, None]
+    _l1_rows = staticmethod(_l1_rows)
 
     def interpolate(self, transform, transitions=None, Y=None):
         """reference: graphs.py:1291-1317 - without ``transitions`` and ``Y`` the landmark transitions of the graph's own
@@ -564,10 +591,6 @@ class TraditionalGraph(DataGraph):
                 raise ValueError("Precomputed {} must be a square matrix. {} was given".format(precomputed, data.shape))
             elif (data < 0).sum() > 0:
                 raise ValueError("Precomputed {} should be non-negative".format(precomputed))
-        if distance != "euclidean" and precomputed is None:
-            raise NotImplementedError(
-                "graphtools_amd.TraditionalGraph: distance='{}' is not available on the HIP path yet".format(distance)
-            )
         self.knn = knn
         self.decay = decay
         self.bandwidth = bandwidth
@@ -604,47 +627,92 @@ class TraditionalGraph(DataGraph):
 
     def _build_kernel(self):
         data = self.data_nu
+        if self.precomputed in ("affinity", "adjacency"):
+            if sparse.issparse(self.data):
+                data = self.data   # (a sparse kernel stays sparse, as in the reference; data_nu is the dense copy)
+            # reference: graphs.py:1532-1545, 1596-1609 - the caller's matrix IS the unsymmetrised kernel (adjacency: with
+            # the diagonal set to 1), entries below thresh are zeroed; then the common tail on the device
+            if sparse.issparse(data):
+                K0 = sparse.csr_matrix(data, dtype=np.float64, copy=True)
+                if self.precomputed == "adjacency":
+                    K0 = K0.tolil()
+                    K0.setdiag(1)
+                    K0 = K0.tocsr()
+                K0.data[K0.data < self.thresh] = 0
+                K0.eliminate_zeros()
+                K0.sum_duplicates()
+                self._sparse_k0 = K0
+                nnz, flags = self.hip.csr_graph_build(K0, self.kernel_symm, self.theta, self.anisotropy, assume_unique=True)
+                self._device_state = (self.kernel_symm, self.theta, self.anisotropy)
+                kd, ki, kp = self.hip.graph_fetch_csr(_hip.CSR_K)
+                if nnz < 2**31:
+                    kp = kp.astype(np.int32)
+                K = sparse.csr_matrix((kd, ki, kp), shape=K0.shape)
+                pd_, _, _ = self.hip.graph_fetch_csr(_hip.CSR_P, structure=False)
+                self._diff_op = sparse.csr_matrix((pd_, K.indices, K.indptr), shape=K.shape)
+                self._kernel_degree = self.hip.graph_fetch_vec(_hip.VEC_DEGREE).reshape(-1, 1)
+                self._emit_build_warnings(flags, K)
+                return K
+            data = np.asarray(data)
+            K, P, flags = self.hip.dense_graph_build(
+                data, self.precomputed, None, None, self.thresh, None, 1.0, self.kernel_symm, self.theta,
+                self.anisotropy, want_P=True)
+            self._diff_op = P
+            self._kernel_degree = self.hip.dense_fetch_vec(_hip.VEC_DEGREE, K.shape[0]).reshape(-1, 1).astype(K.dtype)
+            self._emit_build_warnings(flags, K)
+            return K
         if sparse.issparse(data):
             data = data.toarray()
         data = np.asarray(data)
-        if self.precomputed in ("affinity", "adjacency"):
-            raise NotImplementedError(
-                "graphtools_amd: precomputed='{}' is a pass-through of the caller's matrix and is not routed "
-                "through the device".format(self.precomputed)
-            )
         bandwidth = self.bandwidth
+        host_pdx = None
+        if self.precomputed is None and (self.distance != "euclidean" or callable(bandwidth)):
+            # metrics other than the north star's euclidean, and bandwidth callables (which see the whole distance matrix,
+            # graphs.py:1588-1589): the distances are formed on the host with scipy exactly as the reference does
+            # (graphs.py:1552-1576), everything behind them runs on the device
+            from scipy.spatial.distance import pdist, squareform
+
+            host_pdx = squareform(pdist(data, metric=self.distance))
+            dup = np.argwhere(np.triu(host_pdx == 0, k=1))
+            if len(dup) > 0:
+                self._warn_duplicate_pairs([(int(i), int(j)) for i, j in dup] if len(dup) < 20 else None, len(dup))
         if callable(bandwidth):
-            if self.precomputed != "distance":
-                raise NotImplementedError(
-                    "graphtools_amd: a callable bandwidth needs the distance matrix on the host; pass "
-                    "precomputed='distance'"
-                )
-            bandwidth = np.asarray(bandwidth(data), dtype=np.float64)
+            bandwidth = np.asarray(bandwidth(host_pdx if host_pdx is not None else data), dtype=np.float64)
         K, P, flags = self.hip.dense_graph_build(
-            data, self.precomputed == "distance", self.knn, self.decay, self.thresh, bandwidth, self.bandwidth_scale,
-            self.kernel_symm, self.theta, self.anisotropy, want_P=True)
+            host_pdx if host_pdx is not None else data,
+            "distance" if (self.precomputed == "distance" or host_pdx is not None) else None, self.knn, self.decay,
+            self.thresh, bandwidth, self.bandwidth_scale, self.kernel_symm, self.theta, self.anisotropy, want_P=True)
         self._diff_op = P
         self._kernel_degree = self.hip.dense_fetch_vec(_hip.VEC_DEGREE, K.shape[0]).reshape(-1, 1).astype(K.dtype)
-        if flags & _hip.FLAG_DUPLICATES and self.precomputed is None:
+        if flags & _hip.FLAG_DUPLICATES and self.precomputed is None and host_pdx is None:
             # reference: graphs.py:1553-1574 - the pairs (i < j) at pdist distance 0, i.e. identical rows, named when
-            # there are fewer than 20 of them
-            _, inverse = np.unique(data, axis=0, return_inverse=True)
+            # there are fewer than 20 of them (counted first: a group of g identical rows holds g (g - 1) / 2 pairs)
+            _, inverse, counts = np.unique(data, axis=0, return_inverse=True, return_counts=True)
             inverse = np.asarray(inverse).ravel()
-            order = np.argsort(inverse, kind="stable")
-            groups = np.split(order, np.flatnonzero(np.diff(inverse[order])) + 1)
-            pairs = sorted((int(g[a]), int(g[b])) for g in groups if len(g) > 1
-                           for a in range(len(g)) for b in range(a + 1, len(g)))
-            if len(pairs) < 20:
-                warnings.warn(
-                    "Detected zero distance between samples {}. Consider removing duplicates to avoid errors in "
-                    "downstream processing.".format(", ".join("{} and {}".format(i, j) for i, j in pairs)),
-                    RuntimeWarning)
-            else:
-                warnings.warn(
-                    "Detected zero distance between {} pairs of samples. Consider removing duplicates to avoid errors "
-                    "in downstream processing.".format(len(pairs)), RuntimeWarning)
+            n_pairs = int(np.sum(counts.astype(np.int64) * (counts.astype(np.int64) - 1) // 2))
+            if 0 < n_pairs < 20:
+                order = np.argsort(inverse, kind="stable")
+                groups = np.split(order, np.flatnonzero(np.diff(inverse[order])) + 1)
+                pairs = sorted((int(g[a]), int(g[b])) for g in groups if len(g) > 1
+                               for a in range(len(g)) for b in range(a + 1, len(g)))
+                self._warn_duplicate_pairs(pairs, n_pairs)
+            elif n_pairs >= 20:
+                self._warn_duplicate_pairs(None, n_pairs)
+            # (n_pairs == 0 cannot happen: a float64 difference-form distance is 0 only between identical rows)
         self._emit_build_warnings(flags, K)
         return K
+
+    @staticmethod
+    def _warn_duplicate_pairs(pairs, n_pairs):
+        if pairs is not None and n_pairs < 20:
+            warnings.warn(
+                "Detected zero distance between samples {}. Consider removing duplicates to avoid errors in "
+                "downstream processing.".format(", ".join("{} and {}".format(i, j) for i, j in pairs)),
+                RuntimeWarning)
+        else:
+            warnings.warn(
+                "Detected zero distance between {} pairs of samples. Consider removing duplicates to avoid errors "
+                "in downstream processing.".format(n_pairs), RuntimeWarning)
 
     def _fetch_diff_op(self):
         return self._diff_op
@@ -653,7 +721,32 @@ class TraditionalGraph(DataGraph):
         return self._kernel_degree
 
     def build_kernel_to_data(self, Y, knn=None, bandwidth=None, bandwidth_scale=None):
-        raise NotImplementedError("graphtools_amd: out-of-sample extension is not on the HIP path yet")
+        """Dense kernel from new points ``Y`` to the graph's data (reference: graphs.py:1612-1678) on the device:
+        ``cdist`` in float64 difference form, bandwidth = the knn-th smallest distance of each row (or the caller's),
+        alpha-decay affinities, entries below ``thresh`` zeroed.  Returns a float64 array [n_samples_y, n_samples]."""
+        if knn is None:
+            knn = self.knn
+        if bandwidth is None:
+            bandwidth = self.bandwidth
+        if bandwidth_scale is None:
+            bandwidth_scale = self.bandwidth_scale
+        if self.precomputed is not None:
+            raise ValueError("Cannot extend kernel on precomputed graph")
+        Y = np.asarray(self._check_extension_shape(Y))
+        X = np.ascontiguousarray(self.data_nu.toarray() if sparse.issparse(self.data_nu) else self.data_nu)
+        if X.dtype not in (np.float32, np.float64):
+            X = X.astype(np.float64)
+        if self.distance != "euclidean":
+            raise NotImplementedError(
+                "graphtools_amd.TraditionalGraph.build_kernel_to_data: distance='{}' is not on the HIP path "
+                "(euclidean only)".format(self.distance))
+        if callable(bandwidth):
+            # the callable sees the whole distance matrix (graphs.py:1657-1658): formed on the host like the reference's
+            from scipy.spatial.distance import cdist
+
+            bandwidth = np.asarray(bandwidth(cdist(Y, X, metric=self.distance)), dtype=np.float64)
+        self.hip.set_points(X)
+        return self.hip.dense_extend(Y, knn, self.decay, self.thresh, bandwidth, bandwidth_scale)
 
 
 class MNNGraph(DataGraph):
@@ -812,6 +905,13 @@ class MNNGraph(DataGraph):
     def _fetch_degree(self):
         self._ensure_device_graph()
         return self.hip.graph_fetch_vec(_hip.VEC_DEGREE)
+
+    def _fetch_diff_aff(self):
+        self.K
+        self._ensure_device_graph()
+        vals = self.hip.graph_diff_aff()
+        K = self._kernel
+        return sparse.csr_matrix((vals, K.indices, K.indptr), shape=K.shape)
 
     def build_kernel_to_data(self, Y, theta=None):
         # reference: graphs.py:1948-1966

@@ -232,23 +232,45 @@ int gt_graph_fetch_vec(gt_ctx* ctx, int32_t which, double* out, int32_t on_devic
 int gt_graph_spmm(gt_ctx* ctx, int32_t which, const double* X, int64_t ncols, double* out, int32_t on_device);
 /* statistics of the last build: out[0]=rows that took the exact fallback, out[1]=rows that took the
  * radius pass, out[2]=nnz of the unsymmetrised kernel, out[3]=radius-pass capacity retries */
+/* Replaces BaseGraph.diff_aff (base.py:668-698): D^-1/2 K D^-1/2 with D = the row sums of K, as values on the CSR
+ * structure of K (gt_graph_fetch_csr).  degree_all_dev: device vector of the degrees of ALL rows (sharded builds, after
+ * the all-gather) or NULL on a single rank.  out: float64 [nnz of the owned rows], host or device. */
+int gt_graph_diff_aff(gt_ctx* ctx, const double* degree_all_dev, double* out, int32_t on_device);
+
 int gt_graph_stats(const gt_ctx* ctx, int64_t* out4);
 
 /* ---- exact dense graph (TraditionalGraph) -------------------------------------------------- */
 /* Replaces TraditionalGraph.build_kernel (graphs.py:1514-1610) + symmetrise + P for a dense n x n
- * problem on one GPU.
- *   from data       : X_or_D = n x d points (dtype F32/F64), precomputed = 0; distances are float64
- *                     difference form like scipy pdist; K, P are float64.
- *   from distances  : X_or_D = n x n matrix, precomputed = 1; dtype is preserved (float32 D -> float32 K, P).
+ * problem on one GPU.  `precomputed`:
+ *   GT_PRECOMPUTED_NONE      X_or_D = n x d points (dtype F32/F64); distances are float64 difference form like
+ *                            scipy pdist; K, P are float64.
+ *   GT_PRECOMPUTED_DISTANCE  X_or_D = n x n distances; dtype is preserved (float32 D -> float32 K, P).
+ *   GT_PRECOMPUTED_AFFINITY  X_or_D = n x n affinities: the unsymmetrised kernel IS the caller's matrix
+ *                            (graphs.py:1532-1536); entries below `thresh` are zeroed (:1596-1609), then the common tail
+ *                            (symmetrise, anisotropy, P); knn / decay / bandwidth are not used.
+ *   GT_PRECOMPUTED_ADJACENCY the same with the diagonal set to 1 first (graphs.py:1537-1545).
  * bandwidth: NULL -> (knn+1)-th smallest entry of each row (graphs.py:1583-1587), else 1 or n values.
  * Outputs (device or host per out_on_device, any may be NULL): K [n*n], P [n*n] in the result dtype.
- * When `inplace` != 0 and precomputed == 1 and X_or_D is a device pointer, K overwrites D (for
+ * When `inplace` != 0 and the input is a device-resident n x n matrix, K overwrites it (for
  * problems where D alone fills most of HBM) and out_K is ignored. */
+#define GT_PRECOMPUTED_NONE 0
+#define GT_PRECOMPUTED_DISTANCE 1
+#define GT_PRECOMPUTED_AFFINITY 2
+#define GT_PRECOMPUTED_ADJACENCY 3
 int gt_dense_graph_build(gt_ctx* ctx, const void* X_or_D, int64_t n, int32_t d, int32_t dtype, int32_t on_device,
                          int32_t precomputed, int32_t knn, double decay, double thresh,
                          const double* bandwidth, int64_t bandwidth_len, double bandwidth_scale,
                          int32_t kernel_symm, double theta, double anisotropy, int32_t inplace,
                          void* out_K, void* out_P, int32_t out_on_device, uint32_t* flags);
+
+/* Replaces TraditionalGraph.build_kernel_to_data (graphs.py:1612-1678): the dense kernel from m new points Y (same
+ * dtype and width as the points the last from-data gt_dense_graph_build bound) to those points.
+ *   pdx = cdist(Y, X) in float64 difference form; bandwidth NULL -> the knn-th smallest entry of each row of pdx
+ *   (:1654-1656), else 1 or m values; * bandwidth_scale; K = exp(-(pdx / bandwidth)^decay), NaN -> 1, < thresh -> 0.
+ * out_K: float64 [m * n], host or device. */
+int gt_dense_extend(gt_ctx* ctx, const void* Y, int64_t m, int32_t y_on_device, int32_t knn, double decay, double thresh,
+                    const double* bandwidth, int64_t bandwidth_len, double bandwidth_scale, double* out_K,
+                    int32_t out_on_device);
 
 /* degree (row sums of K, GT_VEC_DEGREE) or bandwidth (GT_VEC_BANDWIDTH) of the last dense build, n float64 to host */
 int gt_dense_fetch_vec(gt_ctx* ctx, int32_t which, double* out_host);

@@ -29,6 +29,12 @@ from .kernel import (  # noqa: F401
     knn_graph,
     symmetrize_kernel,
 )
-from .exact import exact_kernel, exact_graph, pairwise_distances_exact  # noqa: F401
+from .exact import (  # noqa: F401
+    cross_distances_exact,
+    exact_graph,
+    exact_kernel,
+    exact_kernel_to_data,
+    pairwise_distances_exact,
+)
 from .landmark import landmark_extend, landmark_operator, random_landmark_clusters  # noqa: F401
 from .mnn import mnn_graph, mnn_kernel  # noqa: F401

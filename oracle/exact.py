@@ -11,10 +11,11 @@ row (self's 0 counted, graphs.py:1583-1587), K = exp(-(D/bw)^decay) with NaN -> 
 (graphs.py:1593-1596), entries < thresh zeroed (graphs.py:1609).
 """
 import numpy as np
+from scipy import sparse
 
 from .kernel import apply_anisotropy, diff_op, symmetrize_kernel
 
-__all__ = ["pairwise_distances_exact", "exact_kernel", "exact_graph"]
+__all__ = ["pairwise_distances_exact", "cross_distances_exact", "exact_kernel", "exact_graph", "exact_kernel_to_data"]
 
 
 def pairwise_distances_exact(X):
@@ -33,11 +34,21 @@ def exact_kernel(
     data, knn=5, decay=40, thresh=1e-4, bandwidth=None, bandwidth_scale=1.0, precomputed=None
 ):
     """Unsymmetrised dense kernel (graphtools/graphs.py:1514-1610)."""
-    if precomputed == "affinity":
-        return np.asarray(data)
-    if precomputed == "adjacency":
+    if precomputed in ("affinity", "adjacency"):
+        # graphs.py:1532-1545: the caller's matrix is the kernel (adjacency: diagonal set to 1), truncated at thresh like
+        # every other kernel (:1596-1609); sparse input stays sparse
+        if sparse.issparse(data):
+            K = sparse.lil_matrix(data, dtype=np.float64, copy=True)
+            if precomputed == "adjacency":
+                K.setdiag(1)
+            K = K.tocsr()
+            K.data[K.data < thresh] = 0
+            K.eliminate_zeros()
+            return K
         K = np.array(data, copy=True)
-        np.fill_diagonal(K, 1)
+        if precomputed == "adjacency":
+            np.fill_diagonal(K, 1)
+        K[K < thresh] = 0
         return K
     if precomputed == "distance":
         pdx = np.asarray(data)
@@ -60,6 +71,33 @@ def exact_kernel(
     return K
 
 
+def cross_distances_exact(Y, X):
+    """float64 M x N euclidean distances, difference form, sequential in k (scipy cdist, graphs.py:1653)."""
+    Y64, X64 = np.asarray(Y, dtype=np.float64), np.asarray(X, dtype=np.float64)
+    acc = np.zeros((Y64.shape[0], X64.shape[0]), dtype=np.float64)
+    for k in range(X64.shape[1]):
+        diff = Y64[:, k][:, None] - X64[:, k][None, :]
+        acc += diff * diff
+    return np.sqrt(acc)
+
+
+def exact_kernel_to_data(data, Y, knn=5, decay=40, thresh=1e-4, bandwidth=None, bandwidth_scale=1.0):
+    """``TraditionalGraph.build_kernel_to_data`` (graphtools/graphs.py:1612-1678, non-numba branch): bandwidth = the
+    knn-th smallest distance of each row of cdist(Y, data) unless given."""
+    pdx = cross_distances_exact(Y, data)
+    if bandwidth is None:
+        knn_dist = np.partition(pdx, knn, axis=1)[:, :knn]
+        bandwidth = np.max(knn_dist, axis=1)
+    elif callable(bandwidth):
+        bandwidth = bandwidth(pdx)
+    bandwidth = bandwidth_scale * bandwidth
+    pdx = (pdx.T / bandwidth).T
+    K = np.exp(-1 * pdx**decay)
+    K = np.where(np.isnan(K), 1, K)
+    K[K < thresh] = 0
+    return K
+
+
 def exact_graph(
     data, knn=5, decay=40, thresh=1e-4, bandwidth=None, bandwidth_scale=1.0, precomputed=None,
     kernel_symm="+", theta=None, anisotropy=0,
@@ -68,4 +106,6 @@ def exact_graph(
     K0 = exact_kernel(data, knn, decay, thresh, bandwidth, bandwidth_scale, precomputed)
     K = symmetrize_kernel(K0, kernel_symm, theta)
     K = apply_anisotropy(K, anisotropy)
+    if sparse.issparse(K):
+        K = sparse.csr_matrix(K)
     return K, diff_op(K)

@@ -1,0 +1,126 @@
+"""GPU: the drop-in holes closed in round 3, against fixtures generated from the reference (tools/make_golden_r3.py):
+``diff_aff`` on the device, ``TraditionalGraph`` with ``precomputed="affinity"`` / ``"adjacency"`` (dense and sparse),
+``TraditionalGraph.build_kernel_to_data`` / ``extend_to_data``, the per-row bandwidth of ``kNNGraph.build_kernel_to_data``
+and exact graphs under a non-euclidean metric.  Bars: CSR structure identical; float64 values within 1e-9 relative (the
+device's exp / pow against numpy's), float32 within 1e-5."""
+import warnings
+
+import numpy as np
+import pytest
+from scipy import sparse
+
+import graphtools_amd
+from conftest import golden_csr, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _graph(*a, **kw):
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        return graphtools_amd.Graph(*a, n_pca=None, verbose=0, **kw)
+
+
+def _same_sparse(M, Mr, rtol):
+    M = sparse.csr_matrix(M)
+    M.sort_indices()
+    assert np.array_equal(M.indptr, Mr.indptr) and np.array_equal(M.indices, Mr.indices)
+    np.testing.assert_allclose(M.data, Mr.data, rtol=rtol, atol=0)
+
+
+def test_diff_aff_on_the_device_matches_reference():
+    z = load_golden("g10_diff_aff")
+    G = _graph(z["X"], knn=int(z["knn"]), decay=float(z["decay"]))
+    assert type(G).__name__ == "kNNGraph"
+    np.testing.assert_allclose(np.asarray(G.kernel_degree).ravel(), z["degree"], rtol=1e-13, atol=0)
+    A = G.diff_aff
+    assert sparse.issparse(A) and A.shape == G.K.shape
+    _same_sparse(A, golden_csr(z, "A"), 1e-12)
+    Ga = _graph(z["X"], knn=int(z["knn"]), decay=float(z["decay"]), anisotropy=0.5)
+    np.testing.assert_allclose(np.asarray(Ga.kernel_degree).ravel(), z["aniso_degree"], rtol=1e-12, atol=0)
+    _same_sparse(Ga.diff_aff, golden_csr(z, "aniso_A"), 1e-11)
+    Ge = _graph(z["exact_X"], knn=7, decay=10, graphtype="exact")
+    np.testing.assert_allclose(Ge.diff_aff, z["exact_A"], rtol=1e-9, atol=1e-300)
+
+
+@pytest.mark.parametrize("tag,src,kw,rtol", [
+    ("aff64", "A", dict(precomputed="affinity"), 1e-13),
+    ("aff64_mnn", "A", dict(precomputed="affinity", kernel_symm="mnn", theta=0.7), 1e-13),
+    ("aff64_aniso", "A", dict(precomputed="affinity", anisotropy=0.5), 1e-12),
+    ("aff32", "A32", dict(precomputed="affinity"), 1e-6),
+    ("adj64", "Adj", dict(precomputed="adjacency"), 1e-13),
+])
+def test_precomputed_affinity_and_adjacency_dense(tag, src, kw, rtol):
+    """graphs.py:1532-1545: the caller's matrix is the kernel (adjacency: diagonal 1); truncation, symmetrisation,
+    anisotropy and P on the device"""
+    z = load_golden("g11_exact_passthrough")
+    G = _graph(z[src].copy(), **kw)
+    assert type(G).__name__ == "TraditionalGraph"
+    Kr, Pr = z["K_" + tag], z["P_" + tag]
+    assert G.K.dtype == Kr.dtype and G.P.dtype == Pr.dtype
+    assert np.array_equal(G.K == 0, Kr == 0)
+    np.testing.assert_allclose(G.K, Kr, rtol=rtol, atol=0)
+    np.testing.assert_allclose(G.P, Pr, rtol=max(rtol, 1e-12) if Kr.dtype == np.float64 else 1e-5, atol=0)
+    np.testing.assert_allclose(np.asarray(G.kernel_degree).ravel(), Kr.sum(axis=1), rtol=1e-6)
+
+
+@pytest.mark.parametrize("tag,src,mode", [("adj_sparse", "Adj", "adjacency"), ("aff_sparse", "A", "affinity")])
+def test_precomputed_affinity_and_adjacency_sparse(tag, src, mode):
+    z = load_golden("g11_exact_passthrough")
+    G = _graph(sparse.csr_matrix(z[src]), precomputed=mode)
+    assert type(G).__name__ == "TraditionalGraph" and sparse.issparse(G.K) and sparse.issparse(G.P)
+    _same_sparse(G.K, golden_csr(z, "K_" + tag), 1e-14)
+    _same_sparse(G.P, golden_csr(z, "P_" + tag), 1e-13)
+
+
+@pytest.mark.parametrize("tag,kw", [
+    ("K_default", {}),
+    ("K_knn4", dict(knn=4)),
+    ("K_bw_scalar", dict(bandwidth=4.5)),
+    ("K_bw_vector", dict(bandwidth="vector", bandwidth_scale=1.25)),
+])
+def test_exact_graph_extension(tag, kw):
+    """TraditionalGraph.build_kernel_to_data (graphs.py:1612-1678): float64 difference-form cdist on the device"""
+    z = load_golden("g12_exact_extend")
+    kw = dict(kw)
+    if kw.get("bandwidth") == "vector":
+        kw["bandwidth"] = z["bw_vector"]
+    G = _graph(z["X"], knn=int(z["knn"]), decay=float(z["decay"]), graphtype="exact")
+    K = G.build_kernel_to_data(z["Y"], **kw)
+    Kr = z[tag]
+    assert K.shape == Kr.shape and K.dtype == np.float64
+    flip = (K == 0) != (Kr == 0)
+    assert flip.sum() <= 2 and np.all(np.maximum(K, Kr)[flip] < 1e-4 * (1 + 1e-6))
+    np.testing.assert_allclose(K[~flip], Kr[~flip], rtol=1e-9, atol=0)
+    if tag == "K_default":
+        T = G.extend_to_data(z["Y"])
+        np.testing.assert_allclose(T[~flip], z["T_default"][~flip], rtol=1e-9, atol=0)
+        G64 = _graph(z["X"].astype(np.float64), knn=int(z["knn"]), decay=float(z["decay"]), graphtype="exact")
+        K64 = G64.build_kernel_to_data(z["Y"].astype(np.float64))
+        m = (K64 == 0) == (z["K_f64"] == 0)
+        assert (~m).sum() <= 2
+        np.testing.assert_allclose(K64[m], z["K_f64"][m], rtol=1e-9, atol=0)
+    with pytest.raises(ValueError, match="Cannot extend kernel on precomputed graph"):
+        D = np.abs(np.random.default_rng(0).standard_normal((40, 40)))
+        _graph(D + D.T, precomputed="distance", knn=3, decay=5).build_kernel_to_data(z["Y"][:, :40])
+
+
+@pytest.mark.parametrize("tag,scale", [("K_bwvec", None), ("K_bwvec_scaled", 0.8)])
+def test_knn_extension_with_a_bandwidth_per_row(tag, scale):
+    """kNNGraph.build_kernel_to_data accepts one bandwidth per row of Y (graphs.py:819-982)"""
+    z = load_golden("g13_knn_extend_bwvec")
+    G = _graph(z["X"], knn=int(z["knn"]), decay=float(z["decay"]))
+    kw = {} if scale is None else {"bandwidth_scale": scale}
+    K = G.build_kernel_to_data(z["Y"], bandwidth=z["bw_vector"], **kw)
+    _same_sparse(K, golden_csr(z, tag), 1e-12)
+    with pytest.raises(ValueError):
+        G.build_kernel_to_data(z["Y"], bandwidth=z["bw_vector"][:7])
+
+
+def test_exact_graph_with_the_cosine_metric():
+    """metrics beyond euclidean: scipy pdist on the host as in the reference (graphs.py:1552), the rest on the device"""
+    z = load_golden("g14_exact_cosine")
+    G = _graph(z["X"], knn=int(z["knn"]), decay=float(z["decay"]), graphtype="exact", distance="cosine")
+    assert np.array_equal(G.K == 0, z["K"] == 0)
+    np.testing.assert_allclose(G.K, z["K"], rtol=1e-9, atol=0)
+    np.testing.assert_allclose(G.P, z["P"], rtol=1e-9, atol=0)

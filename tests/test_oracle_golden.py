@@ -183,3 +183,79 @@ def test_mnn_landmark_graph_matches_reference():
     op, tr = oracle.landmark_operator(K, clusters)
     np.testing.assert_allclose(op, z["landmark_op"], rtol=0, atol=1e-15)
     assert abs(sparse.csr_matrix(tr) - golden_csr(z, "transitions")).max() < 1e-15
+
+
+# ---- round 3: diff_aff, precomputed affinity / adjacency, exact-graph extension, per-row bandwidth of the kNN extension ----
+def test_diff_aff_matches_reference():
+    """BaseGraph.kernel_degree / diff_aff (base.py:648-698) on the reference's own K"""
+    z = load_golden("g10_diff_aff")
+    K = golden_csr(z, "K")
+    assert np.array_equal(oracle.kernel_degree(K).ravel(), z["degree"])
+    A = sparse.csr_matrix(oracle.diff_aff(K))
+    A.sort_indices()
+    Ar = golden_csr(z, "A")
+    assert np.array_equal(A.indptr, Ar.indptr) and np.array_equal(A.indices, Ar.indices)
+    assert np.array_equal(A.data, Ar.data)
+    assert np.array_equal(oracle.diff_aff(z["exact_K"]), z["exact_A"])
+
+
+@pytest.mark.parametrize("tag,src,kw", [
+    ("aff64", "A", dict(precomputed="affinity")),
+    ("aff64_mnn", "A", dict(precomputed="affinity", kernel_symm="mnn", theta=0.7)),
+    ("aff64_aniso", "A", dict(precomputed="affinity", anisotropy=0.5)),
+    ("aff32", "A32", dict(precomputed="affinity")),
+    ("adj64", "Adj", dict(precomputed="adjacency")),
+])
+def test_precomputed_affinity_and_adjacency_match_reference(tag, src, kw):
+    z = load_golden("g11_exact_passthrough")
+    K, P = oracle.exact_graph(z[src], knn=5, decay=40, **kw)
+    assert K.dtype == z["K_" + tag].dtype
+    assert np.array_equal(K, z["K_" + tag])
+    assert np.array_equal(P, z["P_" + tag])
+
+
+@pytest.mark.parametrize("tag,src,mode", [("adj_sparse", "Adj", "adjacency"), ("aff_sparse", "A", "affinity")])
+def test_sparse_precomputed_matches_reference(tag, src, mode):
+    z = load_golden("g11_exact_passthrough")
+    K, P = oracle.exact_graph(sparse.csr_matrix(z[src]), knn=5, decay=40, precomputed=mode)
+    K = sparse.csr_matrix(K)
+    K.sort_indices()
+    Kr, Pr = golden_csr(z, "K_" + tag), golden_csr(z, "P_" + tag)
+    assert np.array_equal(K.indptr, Kr.indptr) and np.array_equal(K.indices, Kr.indices) and np.array_equal(K.data, Kr.data)
+    P = sparse.csr_matrix(P)
+    P.sort_indices()
+    np.testing.assert_allclose(P.data, Pr.data, rtol=1e-15, atol=0)
+
+
+@pytest.mark.parametrize("tag,kw", [
+    ("K_default", {}),
+    ("K_knn4", dict(knn=4)),
+    ("K_bw_scalar", dict(bandwidth=4.5)),
+    ("K_bw_vector", dict(bandwidth="vector", bandwidth_scale=1.25)),
+])
+def test_exact_extension_matches_reference(tag, kw):
+    z = load_golden("g12_exact_extend")
+    kw = dict(kw)
+    if kw.get("bandwidth") == "vector":
+        kw["bandwidth"] = z["bw_vector"]
+    kw.setdefault("knn", int(z["knn"]))
+    K = oracle.exact_kernel_to_data(z["X"], z["Y"], decay=float(z["decay"]), **kw)
+    assert np.array_equal(K, z[tag])
+    if tag == "K_default":
+        T = K / np.abs(K).sum(axis=1, keepdims=True)
+        np.testing.assert_allclose(T, z["T_default"], rtol=1e-15, atol=0)
+        K64 = oracle.exact_kernel_to_data(z["X"].astype(np.float64), z["Y"].astype(np.float64), knn=int(z["knn"]),
+                                          decay=float(z["decay"]))
+        assert np.array_equal(K64, z["K_f64"])
+
+
+@pytest.mark.parametrize("tag,scale", [("K_bwvec", 1.0), ("K_bwvec_scaled", 0.8)])
+def test_knn_extension_with_vector_bandwidth_matches_reference(tag, scale):
+    z = load_golden("g13_knn_extend_bwvec")
+    K = oracle.knn_kernel(z["X"], knn=int(z["knn"]), decay=float(z["decay"]), Y=z["Y"], bandwidth=z["bw_vector"],
+                          bandwidth_scale=scale, engine="sklearn")
+    K = sparse.csr_matrix(K)
+    K.sort_indices()
+    Kr = golden_csr(z, tag)
+    assert np.array_equal(K.indptr, Kr.indptr) and np.array_equal(K.indices, Kr.indices)
+    assert np.array_equal(K.data, Kr.data)
