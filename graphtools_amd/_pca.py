@@ -35,6 +35,10 @@ def device_pca_applies(data, n_components, n_oversamples=10):
             and n_components + n_oversamples <= _MAX_THIN and n_components < data.shape[1])
 
 
+class DevicePCAUnsuitable(ValueError):
+    """the device solver would lose precision on this matrix (see DevicePCA.fit_transform); use scikit-learn"""
+
+
 class DevicePCA(object):
     """The attributes and methods of ``sklearn.decomposition.PCA`` the reference uses (``components_``, ``mean_``,
     ``singular_values_``, ``explained_variance_``, ``explained_variance_ratio_``, ``noise_variance_``, ``transform``,
@@ -87,6 +91,15 @@ class DevicePCA(object):
             mark("context")
             mean, ssq = ctx.pca_begin(X)
             mark("upload+moments")
+            # The products are formed on the uncentred float32 matrix and centred afterwards (Y = X Q - 1 mean^T Q): for
+            # data whose column means dwarf its spread (unnormalised counts with a large offset) the float32 products
+            # cancel digits scikit-learn keeps by centring first - about offset / spread x 2^-24 relative.  Beyond a
+            # ratio of 512 (3e-5) this solver steps aside and the caller takes scikit-learn's.
+            spread = float(np.sqrt(max(np.sum(ssq) / max((n - 1) * d, 1), 1e-300)))
+            if float(np.max(np.abs(mean))) > 512.0 * spread:
+                ctx.pca_end()
+                raise DevicePCAUnsuitable("column means up to %.3g against a spread of %.3g per feature"
+                                          % (float(np.max(np.abs(mean))), spread))
 
             def half_steps(Q):
                 ctx.pca_matmul(0, Q, mean @ Q, 1)                 # Y = (X - 1 mean^T) Q

@@ -234,8 +234,14 @@ class Data(object):
             backend = PCA_BACKEND
             if backend != "sklearn" and device_pca_applies(self.data, self.n_pca) and (
                     backend == "device" or self.data.size >= _PCA_DEVICE_MIN_ELEMENTS):
-                self.data_pca = DevicePCA(self.n_pca, random_state=self.random_state, device=getattr(self, "device", 0) or 0)
-                return self.data_pca.fit_transform(self.data)
+                from ._pca import DevicePCAUnsuitable
+
+                try:
+                    self.data_pca = DevicePCA(self.n_pca, random_state=self.random_state,
+                                              device=getattr(self, "device", 0) or 0)
+                    return self.data_pca.fit_transform(self.data)
+                except DevicePCAUnsuitable:
+                    pass   # (large offsets: scikit-learn centres before its products)
             self.data_pca = PCA(self.n_pca, svd_solver="randomized", random_state=self.random_state)
         self.data_pca.fit(self.data)
         return self.data_pca.transform(self.data)

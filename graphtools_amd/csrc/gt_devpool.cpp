@@ -14,21 +14,25 @@ struct Pool {
     std::mutex mu;
     std::multimap<size_t, void*> blocks[kMaxDevices];   // by size
     size_t cached[kMaxDevices] = {};
-    // bytes that may stay parked per device: GT_POOL_MAX_GB, else a quarter of the device's memory (at most 64 GB) -
-    // the rest of the process (torch, RCCL) cannot see what sits here
-    size_t limit() {
-        static const size_t v = [] {
+    // bytes that may stay parked per device: GT_POOL_MAX_GB, else an eighth of THAT device's memory (at most 32 GB) - the
+    // rest of the process (torch, RCCL) cannot see what sits here.  Queried per device, with the device current.
+    size_t lim[kMaxDevices] = {};
+    bool lim_known[kMaxDevices] = {};
+    size_t limit(int d) {   // (called with mu held and device d current)
+        if (!lim_known[d]) {
             const char* s = std::getenv("GT_POOL_MAX_GB");
+            size_t cap = size_t(32) << 30;
             if (s) {
                 const double gb = std::atof(s);
-                return gb <= 0 ? size_t(0) : size_t(gb * double(size_t(1) << 30));
+                cap = gb <= 0 ? size_t(0) : size_t(gb * double(size_t(1) << 30));
+            } else {
+                size_t free_b = 0, total_b = 0;
+                if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b > 0) cap = std::min(cap, total_b / 8);
             }
-            size_t free_b = 0, total_b = 0;
-            size_t cap = size_t(64) << 30;
-            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b > 0) cap = std::min(cap, total_b / 4);
-            return cap;
-        }();
-        return v;
+            lim[d] = cap;
+            lim_known[d] = true;
+        }
+        return lim[d];
     }
 };
 
@@ -89,7 +93,7 @@ void gt_pool_free(void* p, size_t bytes) {
         // grows or a context closes - never inside the steady state of a build.
         (void)hipDeviceSynchronize();
         std::lock_guard<std::mutex> lock(P.mu);
-        if (P.cached[d] + bytes <= P.limit()) {
+        if (P.cached[d] + bytes <= P.limit(d)) {
             P.blocks[d].emplace(bytes, p);
             P.cached[d] += bytes;
             return;

@@ -807,7 +807,10 @@ int gt_sym_queue_prepare(gt_ctx* ctx, int64_t n_pad_s, SelectArgs& a) {
     GT_HIP(ctx, k->sym_queue.reserve(size_t(nwaves) * size_t(rcap) * sizeof(uint2)));
     GT_HIP(ctx, k->sym_qcount.reserve(size_t(nwaves) * sizeof(uint32_t)));
     GT_HIP(ctx, hipMemsetAsync(k->sym_qcount.p, 0, size_t(nwaves) * sizeof(uint32_t), ctx->stream));
-    const int64_t spill_cap = ctx->sym_spill_cap > 0 ? ctx->sym_spill_cap : int64_t(1) << 22;
+    // (row-sharded builds: the spill area holds EVERY unit of the rank's pieces - an overflow on one rank alone would send
+    //  that rank to the one-stage kernel, whose pieces of the pair space are not the other ranks')
+    const int64_t spill_cap = a.sym.shard_world > 1 ? std::min<int64_t>(units + 1024, (int64_t(1) << 31) - 1024)
+                                                    : (ctx->sym_spill_cap > 0 ? ctx->sym_spill_cap : int64_t(1) << 22);
     GT_HIP(ctx, k->sym_qspill.reserve(size_t(spill_cap) * sizeof(uint2) + 16));
     a.sym.queue = k->sym_queue.as<uint2>();
     a.sym.qcount = k->sym_qcount.as<uint32_t>();
@@ -824,7 +827,8 @@ int gt_sym_queue_finish(gt_ctx* ctx, const SelectArgs& a, int64_t* entries, int*
     KnnWork* k = ctx->knn;
     *ok = 0;
     const int64_t nwaves = ceil_div64(a.n_pad, 128 * GT_SEL_TWO_QT) * a.sym.nseg * 4;
-    const int64_t dense_cap = std::min<int64_t>(nwaves * int64_t(a.sym.qcap) + a.sym.qspill_cap, int64_t(1) << 25);
+    const int64_t dense_cap = a.sym.shard_world > 1 ? nwaves * int64_t(a.sym.qcap) + a.sym.qspill_cap
+                                                    : std::min<int64_t>(nwaves * int64_t(a.sym.qcap) + a.sym.qspill_cap, int64_t(1) << 25);
     GT_HIP(ctx, k->sym_qdense.reserve(size_t(dense_cap) * sizeof(uint2)));
     GT_HIP(ctx, k->sym_qtot.reserve(4 * sizeof(uint32_t)));
     GT_HIP(ctx, hipMemsetAsync(k->sym_qtot.p, 0, 4 * sizeof(uint32_t), ctx->stream));

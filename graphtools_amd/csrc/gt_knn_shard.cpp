@@ -45,8 +45,10 @@ int gt_knn_shard_plan(gt_ctx* ctx, int world, int rank, const int64_t* splits, i
     k->sh_stage = 0;
     if (!shard_applicable(ctx, need_m) || splits[rank + 1] <= splits[rank]) return GT_OK;
     const int bq = gt_select_bq(ctx->DP);
-    // (the two-stage collect kernel works on query blocks of up to 1024 rows; the seeding shares stay 256-row blocks)
-    const bool two = ctx->DP >= 32 && bq == 256 && (ctx->sym_two_stage > 0 || (ctx->sym_two_stage < 0 && ctx->sym_two_ok != 0));
+    // (the two-stage collect kernel works on query blocks of up to 1024 rows; the seeding shares stay 256-row blocks.
+    //  The padding depends on the OPTIONS only, never on what earlier builds of this rank found out about the points:
+    //  every rank must arrive at the same n_pad_s and the same sorted splits)
+    const bool two = ctx->DP >= 32 && bq == 256 && ctx->sym_two_stage != 0;
     const int64_t pad_s = two ? 1024 : bq;
     const int64_t n_pad_s = ceil_div64(ctx->n, pad_s) * pad_s;
     const int64_t NB = n_pad_s / bq;
@@ -215,8 +217,9 @@ int gt_knn_shard_collect(gt_ctx* ctx, const float* thr_all, int64_t far_total, c
     // the statistics of ALL rows behind the orphan cut (every rank holds the same sums, applies the same cut)
     GT_HIP(ctx, hipMemcpyAsync(k->sym_racc.p, racc_total, 4 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     // The orphans (gt_sym.hip sym_orphan_cut_kernel) are declared on every rank alike wherever the two-stage collect is
-    // configured at all - whether a rank then runs it, or its forecast or its queue say no, is that rank's business, but
-    // which rows collect nothing must not differ between ranks (a row's list is the union of what the ranks collected)
+    // configured at all: which rows collect nothing must not differ between ranks (a row's list is the union of what the
+    // ranks collected).  The same holds for the kernel of launch B (below): every verdict behind it is taken on
+    // quantities all ranks hold alike.
     const bool cut = n_pad_s % 1024 == 0 && ctx->DP >= 32 && bq == 256 && ctx->sym_two_stage != 0;
     {
         StageSpan span(ctx, "sym_prepare");
@@ -275,7 +278,7 @@ int gt_knn_shard_collect(gt_ctx* ctx, const float* thr_all, int64_t far_total, c
             GT_HIP(ctx, k->sym_qdense.reserve(size_t(bcap) * sizeof(uint2)));
             GT_HIP(ctx, k->sym_qtot.reserve(4 * sizeof(uint32_t)));
             GT_HIP(ctx, k->sym_rrow.reserve(size_t(n_pad_s) * sizeof(float)));
-            uint32_t left = 0;
+            uint32_t left = 0, left_all = 0;
             {
                 StageSpan span(ctx, "sym_bound");
                 GT_TRY(gt_sym_row_radius(ctx, k->qorder.as<int32_t>(), n_pad_s, k->thr_final.as<float>(), em, k->sym_rrow.as<float>()));
@@ -283,9 +286,16 @@ int gt_knn_shard_collect(gt_ctx* ctx, const float* thr_all, int64_t far_total, c
                                           uint32_t(bcap), k->sym_qtot.as<uint32_t>(), k->sh_world, k->sh_rank,
                                           std::max(1, ctx->sym_shard_group)));
                 GT_HIP(ctx, hipMemcpyAsync(&left, k->sym_qtot.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+                GT_HIP(ctx, hipMemcpyAsync(&left_all, k->sym_qtot.as<uint32_t>() + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
             }
             GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            if (int64_t(left) <= bcap) {
+            // Which kernel runs launch B must be the SAME on every rank: the bound pass / two-stage collect and the
+            // one-stage kernel cut the pair space into different pieces (1024- against 256-row query blocks), a rank on
+            // its own would leave pairs unscored.  So the verdict is taken on the units of ALL ranks' pieces, a number
+            // every rank computes alike from the gathered thresholds - no collective needed; this rank's own units are
+            // at most that many and fit its queue.
+            if (k->sh_world == 1) left_all = left;
+            if (int64_t(left_all) <= bcap) {
                 StageSpan span(ctx, "sym_cold");
                 SelectArgs dq = a;
                 dq.mode = 4;

@@ -973,7 +973,7 @@ __global__ __launch_bounds__(64) void bound_queue_kernel(const int T, const int 
     };
     // two rounds: count this wave's units, take their slots with ONE atomic (a device-scope counter serves ~90 returning
     // atomics per microsecond: one per unit would cost more than the collect launch saves), then write them
-    uint32_t mine = 0u, slot = 0u;
+    uint32_t mine = 0u, slot = 0u, all_ranks = 0u;   // all_ranks: the units of EVERY rank's pieces (row-sharded builds)
   for (int round = 0; round < 2; ++round) {
     if (round == 1) {
         uint32_t inc = mine;
@@ -983,6 +983,14 @@ __global__ __launch_bounds__(64) void bound_queue_kernel(const int T, const int 
             if (lane >= o) inc += up;
         }
         const uint32_t total = uint32_t(__shfl(int(inc), 63));
+        if (world > 1) {
+            // the verdict "the cell bounds leave few enough units" has to be the same on every rank: it is taken on the
+            // count over ALL pieces, which every rank computes alike (count[1])
+            uint32_t ar = all_ranks;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) ar += uint32_t(__shfl_xor(int(ar), o));
+            if (lane == 0 && ar != 0u) atomicAdd(count + 1, ar);
+        }
         if (total == 0u) return;
         uint32_t base = 0u;
         if (lane == 0) base = atomicAdd(count, total);
@@ -1006,7 +1014,8 @@ __global__ __launch_bounds__(64) void bound_queue_kernel(const int T, const int 
                     int rel = int(d32 / 4u) - blk * TPB;
                     if (rel < 0) rel += T;
                     if (rel >= walk) continue;   // not this block's unit (the other block's walk has it)
-                    if (rel < rel_lo || rel >= rel_hi) continue;   // another rank's piece
+                    const bool own_piece = rel >= rel_lo && rel < rel_hi;
+                    if (!own_piece && (world == 1 || round == 1)) continue;   // another rank's piece (counted in round 0)
                     // first undecided pair of (cells of the queries) x (cells of the sub-tile) files the unit
                     const uint32_t dc = tcell[d32];
                     const uint32_t dlo = dc & 0xFFFFu, dhi = dc >> 16;
@@ -1021,7 +1030,8 @@ __global__ __launch_bounds__(64) void bound_queue_kernel(const int T, const int 
                         }
                     if (!first) continue;
                     if (round == 0) {
-                        ++mine;
+                        ++all_ranks;
+                        if (own_piece) ++mine;
                     } else {
                         if (slot < cap) queue[slot] = make_uint2(q64, d32);
                         ++slot;
@@ -1190,7 +1200,7 @@ int gt_sym_bound_queue(gt_ctx* ctx, int64_t n_pad_s, const void* Ys, const float
     uint32_t* tcell = mask + size_t(L) * words;
     const uint32_t* cell_sorted = ctx->order_cell.as<uint32_t>() + ctx->n;
     GT_HIP(ctx, hipMemsetAsync(start, 0xFF, 2 * size_t(L) * sizeof(int32_t), ctx->stream));   // -1: empty cell
-    GT_HIP(ctx, hipMemsetAsync(count_dev, 0, sizeof(uint32_t), ctx->stream));
+    GT_HIP(ctx, hipMemsetAsync(count_dev, 0, 2 * sizeof(uint32_t), ctx->stream));   // [0] this rank's units, [1] all ranks'
     hipLaunchKernelGGL(cell_ranges_kernel, dim3((unsigned)ceil_div64(ctx->n, 256)), dim3(256), 0, ctx->stream, cell_sorted,
                        ctx->n, start, endp);
     hipLaunchKernelGGL(cell_ball_kernel, dim3((unsigned)L), dim3(256), 0, ctx->stream, reinterpret_cast<const _Float16*>(Ys),

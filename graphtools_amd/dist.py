@@ -170,9 +170,13 @@ class ShardedKnnGraph(object):
         if not hasattr(ctx, "graph_sym_plan"):
             return False
         ok, n_pad, sorted_splits = ctx.graph_sym_plan(params, self.world, self.rank, self.splits)
-        flag = torch.tensor([1 if ok else 0], dtype=torch.int64, device=device)
+        # all-or-nothing, and only on ONE geometry: the ranks must agree on the padded row count and on the split of the
+        # sorted positions (MIN over {ok, n_pad, -n_pad, split hash, -split hash}: equal iff min(x) == -min(-x))
+        sig = int(np.asarray(sorted_splits, dtype=np.int64).sum() % (1 << 40)) if ok else 0
+        flag = torch.tensor([1 if ok else 0, n_pad, -n_pad, sig, -sig], dtype=torch.int64, device=device)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
-        if int(flag.item()) == 0:
+        f = [int(v) for v in flag.cpu().tolist()]
+        if f[0] == 0 or f[1] != -f[2] or f[3] != -f[4]:
             return False
         rows = int(sorted_splits[self.rank + 1] - sorted_splits[self.rank])
         thr_local = torch.empty((max(rows, 1), 2), dtype=torch.float32, device=device)   # {threshold, far-kept seeds}

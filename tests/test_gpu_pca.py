@@ -107,3 +107,26 @@ def test_graph_on_the_device_reduction_is_the_graph_on_sklearns_reduction(monkey
     assert common > 0.99 * max(A.nnz, B.nnz)
     both = A.multiply(B != 0), B.multiply(A != 0)
     assert np.max(np.abs(both[0].data - both[1].data)) < 0.05
+
+
+def test_large_offsets_take_the_sklearn_solver():
+    """column means far beyond the spread: the device solver (centring after its float32 products) steps aside"""
+    from graphtools_amd import _pca
+
+    rng = np.random.default_rng(5)
+    X = (rng.standard_normal((20000, 64)) + 5000.0).astype(np.float32)
+    with pytest.raises(_pca.DevicePCAUnsuitable):
+        _pca.DevicePCA(10, random_state=0).fit_transform(X)
+    import graphtools_amd.base as gb
+
+    old = gb.PCA_BACKEND
+    gb.PCA_BACKEND = "device"
+    try:
+        import graphtools_amd
+
+        G = graphtools_amd.Graph(X, n_pca=10, knn=5, decay=10, verbose=0, random_state=0)
+        from sklearn.decomposition import PCA
+
+        assert isinstance(G.data_pca, PCA)
+    finally:
+        gb.PCA_BACKEND = old

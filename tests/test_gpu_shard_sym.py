@@ -209,3 +209,25 @@ def test_stage_order_is_enforced():
     with pytest.raises(_hip.HipError):
         c.graph_sym_finish(0, 0)
     c.close()
+
+
+@pytest.mark.parametrize("opts,what", [
+    # the cell bounds leave more units than the cap: EVERY rank must move on to the collect launch - the verdict is taken on
+    # the units of all ranks' pieces (a rank deciding on its own share would run a kernel that cuts the pair space
+    # differently from its peers': pairs unscored, neighbours silently missing)
+    ({"select_sym_two_stage": 1, "select_sym_bound_cap": 50}, "bound pass over its cap on the global count"),
+    # queue regions of one entry per wave: everything goes through the spill area, which holds every unit of a rank's pieces
+    ({"select_sym_two_stage": 1, "select_sym_bounds": 0, "select_sym_queue_cap": 1}, "two-stage queue through the spill area"),
+    ({"select_sym_two_stage": 1, "select_sym_bounds": 0}, "two-stage collect"),
+    ({"select_sym_two_stage": 0}, "one-stage collect"),
+])
+def test_every_rank_runs_the_same_collect_kernel(opts, what):
+    n, world = 12000, 3
+    X = make_mix(n, 64, 11)
+    splits = np.array([0, 3100, 8000, n], dtype=np.int64)
+    pargs = (12, 30, 1e-4, None, 1.0, None, "+", None, 0)
+    got, ran, stats = sharded_build(X, splits, pargs, opts=opts)
+    assert ran, what
+    kinds = {(bool(s[0].get("sym_two_stage")), bool(s[0].get("sym_bound_pass"))) for s in stats}
+    assert len(kinds) == 1, (what, kinds)
+    _same(got, single_build(X, pargs, False))
