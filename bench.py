@@ -254,8 +254,11 @@ def kernel_table(ctx, st, n, nloc, d, world, nnz, nnz0, main):
                      "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "note": note})
 
     if symmetric:
-        seed_flop = float(kst.get("sym_seed_flop", 0)) or 2.0 * d * 256 * 128 * kst.get("sym_seed_tiles", 0)
-        mfma("sym_seed", kst.get("sym_seed_kernel", "knn_select_kernel<64, 8, 0, 2>"), st.mean("sym_seed"), seed_flop,
+        dp = 16 if d <= 16 else 32 if d <= 32 else 64 if d <= 64 else 128
+        bn = 128 if dp <= 64 else 64
+        seed_flop = 2.0 * dp * 256 * bn * kst.get("sym_seed_tiles", 0)   # (256-row query block) x (bn-row tile), padded depth
+        mfma("sym_seed", ("sym_seed_dense_kernel<%d>" if kst.get("sym_seed_dense") else "knn_select_kernel<%d, 8, 0, 2>") % dp,
+             st.mean("sym_seed"), seed_flop,
              "threshold seeding: every row against its neighbourhood cells")
         cold_flop = 2.0 * d * 64 * 32 * kst.get("sym_cold_pairs", 0)
         if two_stage:

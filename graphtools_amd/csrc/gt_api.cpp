@@ -281,6 +281,18 @@ int gt_set_option(gt_ctx* ctx, const char* name, const char* value) {
         ctx->symm_fused = std::atoi(value) != 0 ? 1 : 0;
         return GT_OK;
     }
+    if (k == "symmetrize_fill_threads") {
+        ctx->symm_fill_threads = std::atoi(value);
+        return GT_OK;
+    }
+    if (k == "select_sym_sorted_points") {
+        ctx->sym_sorted_points = std::atoi(value) != 0 ? 1 : 0;
+        return GT_OK;
+    }
+    if (k == "xcd_chunk") {
+        ctx->xcd_chunk = std::max(0, std::atoi(value));
+        return GT_OK;
+    }
     if (k == "rerank_lanes4") {
         ctx->rerank_lanes4 = std::atoi(value) != 0 ? 1 : 0;
         return GT_OK;

@@ -144,6 +144,8 @@ struct gt_ctx {
     int32_t sym_mode = -1;
     int64_t sym_min_rows = 65536;
     int32_t sym_stride = 384;   //   threshold-seeding launch: every sym_stride-th tile besides the row's own neighbourhood (0: none)
+    int32_t sym_sorted_points = 1;   //   symmetric pass: the exact stages read the points from a copy in cell-sorted order
+    int32_t xcd_chunk = 0;      //   row-walking kernels: work items per XCD chunk (gt_device.h gt_xcd_item), 0 = one contiguous eighth per XCD
     int32_t rerank_lanes4 = 1;  //   re-rank of the symmetric pass: four lanes per candidate row (float32 rows, d % 4 == 0, d <= 128)
     int32_t sym_dense_seed = 1; //   threshold-seeding launch: 1 = dense cell blocks, keys in registers (gt_seed.hip), 0 = streaming lists
     int32_t sym_cells = 12;    //   ... which is the rows of this many nearest cells (landmarks) of the block's own cells,
@@ -159,6 +161,7 @@ struct gt_ctx {
                                 //   pair_count_kernel).  Bit-identical, measured SLOWER than sort + compact (6.7 against 5.8 ms at N = 1e6): off
     int32_t symm_fused_ok = 1;  //     0 once a union row of the bound points has outgrown the register sorts (reset by gt_set_points)
     int32_t symm_key32 = 1;     //   per-row sorts of the symmetrisation on 32-bit keys where columns and positions fit (0: 64-bit keys)
+    int32_t symm_fill_threads = 256;   //   threads per workgroup of bin_fill_kernel (256 | 512 | 1024)
     int32_t symm_bin_shift = 0; //   log2 of the rows per bin (0: 9, more from 2 M rows; development / tests: 8 ... 12)
     int32_t sym_bounds = -1;    //   bound pass in front of the two-stage collect (cell balls): -1 auto / 1 on, 0 off
     int64_t sym_bound_cap = 0;  //   units the bound pass may leave before the collect launch runs instead (0: 4 M; tests)

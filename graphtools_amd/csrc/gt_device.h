@@ -138,8 +138,93 @@ __device__ __forceinline__ double gt_dot16_f4(const TX* __restrict__ x, const fl
     }
     return gt_tree16(a);
 }
+// ---- lane exchanges without the LDS -------------------------------------------------------------
+// value of lane (lane ^ J): DPP row operations inside a row of 16 lanes (quad_perm for 1 and 2, half-mirror + quad reversal
+// for 4, a rotation by 8 for 8), the gfx950 row / half swaps for 16 and 32.  ds_bpermute (what __shfl_xor compiles to) takes a
+// trip through the LDS pipeline with an s_waitcnt per step of a sorting network; these are VALU moves.
+template <int J>
+__device__ __forceinline__ uint32_t lane_xor_u32(const uint32_t v) {
+    static_assert(J == 1 || J == 2 || J == 4 || J == 8 || J == 16 || J == 32, "one lane bit");
+    if constexpr (J == 1) return uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0xB1, 0xF, 0xF, true));
+    else if constexpr (J == 2) return uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x4E, 0xF, 0xF, true));
+    else if constexpr (J == 4) {
+        const int t = __builtin_amdgcn_update_dpp(0, int(v), 0x141, 0xF, 0xF, true);   // lane ^ 7
+        return uint32_t(__builtin_amdgcn_update_dpp(0, t, 0x1B, 0xF, 0xF, true));        // ... ^ 3
+    } else if constexpr (J == 8) return uint32_t(__builtin_amdgcn_update_dpp(0, int(v), 0x128, 0xF, 0xF, true));
+    else if constexpr (J == 16) {
+        const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+        return (__lane_id() & 16) ? r[0] : r[1];
+    } else {
+        const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+        return (__lane_id() & 32) ? r[0] : r[1];
+    }
+}
+template <int J>
+__device__ __forceinline__ uint64_t lane_xor_u64(const uint64_t v) {
+    return uint64_t(lane_xor_u32<J>(uint32_t(v))) | (uint64_t(lane_xor_u32<J>(uint32_t(v >> 32))) << 32);
+}
+template <int J>
+__device__ __forceinline__ uint64_t lane_xor_any(const uint64_t v) { return lane_xor_u64<J>(v); }
+template <int J>
+__device__ __forceinline__ uint32_t lane_xor_any(const uint32_t v) { return lane_xor_u32<J>(v); }
+// J = 16 or 32: the pair of values the two partner lanes hold, the same in both - lo from the lane with bit J clear
+template <int J, typename K>
+__device__ __forceinline__ void lane_pair_values(const K v, K& lo, K& hi) {
+    static_assert(J == 16 || J == 32, "row / half swaps");
+    if constexpr (sizeof(K) == 8) {
+        const uint32_t v0 = uint32_t(uint64_t(v)), v1 = uint32_t(uint64_t(v) >> 32);
+        if constexpr (J == 16) {
+            const auto r0 = __builtin_amdgcn_permlane16_swap(v0, v0, false, false);
+            const auto r1 = __builtin_amdgcn_permlane16_swap(v1, v1, false, false);
+            lo = K(uint64_t(r0[0]) | (uint64_t(r1[0]) << 32));
+            hi = K(uint64_t(r0[1]) | (uint64_t(r1[1]) << 32));
+        } else {
+            const auto r0 = __builtin_amdgcn_permlane32_swap(v0, v0, false, false);
+            const auto r1 = __builtin_amdgcn_permlane32_swap(v1, v1, false, false);
+            lo = K(uint64_t(r0[0]) | (uint64_t(r1[0]) << 32));
+            hi = K(uint64_t(r0[1]) | (uint64_t(r1[1]) << 32));
+        }
+    } else {
+        if constexpr (J == 16) {
+            const auto r = __builtin_amdgcn_permlane16_swap(uint32_t(v), uint32_t(v), false, false);
+            lo = K(r[0]);
+            hi = K(r[1]);
+        } else {
+            const auto r = __builtin_amdgcn_permlane32_swap(uint32_t(v), uint32_t(v), false, false);
+            lo = K(r[0]);
+            hi = K(r[1]);
+        }
+    }
+}
+
 // ---- wave-level bitonic sort, descending, NT keys per lane; element e = t*64 + lane -----------
-// (32-bit keys: one shuffle, v_max_u32 / v_min_u32 and a select per step - half the work of a 64-bit key)
+// (32-bit keys: one exchange, one compare and a select per step - half the work of a 64-bit key)
+template <int J, int NT, typename K>
+__device__ __forceinline__ void wave_bitonic_desc_step(K (&key)[NT], const int lane, const int k) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const K a = key[t];
+        const int e = (t << 6) | lane;
+        const bool desc = ((e & k) == 0);
+        if constexpr (J >= 16) {
+            // both partners see the same (lo, hi): one compare decides for both.  The lower lane keeps the larger key when
+            // the run descends; equal keys are the same value either way
+            K lo, hi;
+            lane_pair_values<J>(a, lo, hi);
+            const bool upper = (lane & J) != 0;
+            key[t] = (((lo > hi) == desc) != upper) ? lo : hi;
+        } else {
+            K o;
+            if constexpr (sizeof(K) == 8) o = K(lane_xor_u64<J>(uint64_t(a)));
+            else o = K(lane_xor_u32<J>(uint32_t(a)));
+            const bool lower = ((lane & J) == 0);
+            const bool want_max = (lower == desc);
+            // keep the own key when it is the one wanted: one compare, the lane-pattern mask folded in on the scalar
+            // side, one select (instead of max, min and a select between them)
+            key[t] = ((a > o) == want_max) ? a : o;
+        }
+    }
+}
 template <int NT, typename K>
 __device__ __forceinline__ void wave_bitonic_desc(K (&key)[NT], const int lane) {
 #pragma unroll
@@ -160,19 +245,13 @@ __device__ __forceinline__ void wave_bitonic_desc(K (&key)[NT], const int lane) 
                     }
                 }
             } else {
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const K a = key[t];
-                    K o;
-                    if constexpr (sizeof(K) == 8) o = K(__shfl_xor((unsigned long long)a, j));
-                    else o = K(__shfl_xor((unsigned int)a, j));
-                    const int e = (t << 6) | lane;
-                    const bool desc = ((e & k) == 0);
-                    const bool lower = ((lane & j) == 0);
-                    const bool want_max = (lower == desc);
-                    // keep the own key when it is the one wanted: one compare, the lane-pattern mask folded in on the
-                    // scalar side, one select (instead of max, min and a select between them)
-                    key[t] = ((a > o) == want_max) ? a : o;
+                switch (j) {   // (constant after unrolling)
+                    case 32: wave_bitonic_desc_step<32>(key, lane, k); break;
+                    case 16: wave_bitonic_desc_step<16>(key, lane, k); break;
+                    case 8: wave_bitonic_desc_step<8>(key, lane, k); break;
+                    case 4: wave_bitonic_desc_step<4>(key, lane, k); break;
+                    case 2: wave_bitonic_desc_step<2>(key, lane, k); break;
+                    default: wave_bitonic_desc_step<1>(key, lane, k); break;
                 }
             }
         }
@@ -180,11 +259,12 @@ __device__ __forceinline__ void wave_bitonic_desc(K (&key)[NT], const int lane) 
 }
 
 // ---- wave-level bitonic sort, ascending on the 128-bit pair (hi, lo) ---------------------------
-__device__ __forceinline__ bool pair_gt(uint64_t ah, uint64_t al, uint64_t bh, uint64_t bl) {
+template <typename L>
+__device__ __forceinline__ bool pair_gt(uint64_t ah, L al, uint64_t bh, L bl) {
     return (ah > bh) || (ah == bh && al > bl);
 }
-template <int NT>
-__device__ __forceinline__ void wave_bitonic_asc_pair(uint64_t (&hi)[NT], uint64_t (&lo)[NT], const int lane) {
+template <int NT, typename L>   // L: uint64_t or uint32_t
+__device__ __forceinline__ void wave_bitonic_asc_pair(uint64_t (&hi)[NT], L (&lo)[NT], const int lane) {
 #pragma unroll
     for (int k = 2; k <= 64 * NT; k <<= 1) {
 #pragma unroll
@@ -196,7 +276,8 @@ __device__ __forceinline__ void wave_bitonic_asc_pair(uint64_t (&hi)[NT], uint64
                     if ((t & jj) == 0) {
                         const int u = t | jj;
                         const bool asc = (((t << 6) & k) == 0);
-                        const uint64_t ah = hi[t], al = lo[t], bh = hi[u], bl = lo[u];
+                        const uint64_t ah = hi[t], bh = hi[u];
+                        const L al = lo[t], bl = lo[u];
                         const bool a_gt = pair_gt(ah, al, bh, bl);
                         const bool swap = (a_gt == asc);
                         hi[t] = swap ? bh : ah;
@@ -208,9 +289,18 @@ __device__ __forceinline__ void wave_bitonic_asc_pair(uint64_t (&hi)[NT], uint64
             } else {
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
-                    const uint64_t ah = hi[t], al = lo[t];
-                    const uint64_t oh = __shfl_xor((unsigned long long)ah, j);
-                    const uint64_t ol = __shfl_xor((unsigned long long)al, j);
+                    const uint64_t ah = hi[t];
+                    const L al = lo[t];
+                    uint64_t oh;
+                    L ol;
+                    switch (j) {   // (constant after unrolling)
+                        case 32: oh = lane_xor_u64<32>(ah); ol = lane_xor_any<32>(al); break;
+                        case 16: oh = lane_xor_u64<16>(ah); ol = lane_xor_any<16>(al); break;
+                        case 8: oh = lane_xor_u64<8>(ah); ol = lane_xor_any<8>(al); break;
+                        case 4: oh = lane_xor_u64<4>(ah); ol = lane_xor_any<4>(al); break;
+                        case 2: oh = lane_xor_u64<2>(ah); ol = lane_xor_any<2>(al); break;
+                        default: oh = lane_xor_u64<1>(ah); ol = lane_xor_any<1>(al); break;
+                    }
                     const int e = (t << 6) | lane;
                     const bool asc = ((e & k) == 0);
                     const bool lower = ((lane & j) == 0);
@@ -232,8 +322,9 @@ __device__ __forceinline__ void wave_bitonic_asc_pair(uint64_t (&hi)[NT], uint64
 // for such neighbours and, when there is one (exact ties, distances within 2^-44 of each other), the pair network
 // runs instead - so the outcome is always the one of wave_bitonic_asc_pair.  Entries (kInf, 0xFFFFFFFF) mean "none" and
 // sort last; lo must fit 32 bits.
-template <int NT>
-__device__ __forceinline__ void wave_sort_asc_pair_fast(uint64_t (&hi)[NT], uint64_t (&lo)[NT], const int lane) {
+template <int NT, typename L>
+__device__ __forceinline__ void wave_sort_asc_pair_fast(uint64_t (&hi)[NT], L (&lo)[NT], const int lane,
+                                                        uint64_t* lds_hi = nullptr, uint32_t* lds_lo = nullptr) {
     static_assert(NT == 1 || NT == 2 || NT == 4 || NT == 8, "up to 512 entries");
     constexpr int PB = NT == 1 ? 6 : NT == 2 ? 7 : NT == 4 ? 8 : 9;
     constexpr uint64_t PM = (1ull << PB) - 1ull;
@@ -241,7 +332,7 @@ __device__ __forceinline__ void wave_sort_asc_pair_fast(uint64_t (&hi)[NT], uint
     uint64_t ck[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        const bool none = hi[t] == kNoneHi && lo[t] == 0xFFFFFFFFull;
+        const bool none = hi[t] == kNoneHi && lo[t] == L(0xFFFFFFFFu);
         ck[t] = none ? 0ull : ~((hi[t] & ~PM) | uint64_t(t * 64 + lane));   // descending complement = ascending key
     }
     wave_bitonic_desc<NT>(ck, lane);
@@ -259,45 +350,111 @@ __device__ __forceinline__ void wave_sort_asc_pair_fast(uint64_t (&hi)[NT], uint
     }
     uint64_t nh[NT];
     uint32_t nl[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const uint32_t p = uint32_t(~ck[t]) & uint32_t(PM);
-        const int sl = int(p & 63u), sr = int(p >> 6);
-        uint64_t h = kNoneHi;
-        uint32_t l = 0xFFFFFFFFu;
+    if (lds_hi) {
+        // the wave's own 64 NT (hi, lo) slots in the LDS: every entry is parked at its position, every sorted slot picks
+        // its entry up (2 NT writes and reads instead of 3 NT^2 lane permutes; LDS operations of one wave stay in order)
 #pragma unroll
         for (int r = 0; r < NT; ++r) {
-            const uint64_t hr = __shfl((unsigned long long)hi[r], sl);
-            const uint32_t lr = __shfl(uint32_t(lo[r]), sl);
-            if (sr == r && ck[t] != 0ull) {
-                h = hr;
-                l = lr;
-            }
+            lds_hi[r * 64 + lane] = hi[r];
+            lds_lo[r * 64 + lane] = uint32_t(lo[r]);
         }
-        nh[t] = h;
-        nl[t] = l;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const uint32_t p = uint32_t(~ck[t]) & uint32_t(PM);
+            const bool some = ck[t] != 0ull;
+            nh[t] = some ? lds_hi[p] : kNoneHi;
+            nl[t] = some ? lds_lo[p] : 0xFFFFFFFFu;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    } else {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const uint32_t p = uint32_t(~ck[t]) & uint32_t(PM);
+            const int sl = int(p & 63u), sr = int(p >> 6);
+            uint64_t h = kNoneHi;
+            uint32_t l = 0xFFFFFFFFu;
+#pragma unroll
+            for (int r = 0; r < NT; ++r) {
+                const uint64_t hr = __shfl((unsigned long long)hi[r], sl);
+                const uint32_t lr = __shfl(uint32_t(lo[r]), sl);
+                if (sr == r && ck[t] != 0ull) {
+                    h = hr;
+                    l = lr;
+                }
+            }
+            nh[t] = h;
+            nl[t] = l;
+        }
     }
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         hi[t] = nh[t];
-        lo[t] = uint64_t(nl[t]);
+        lo[t] = L(nl[t]);
     }
 }
 
+// ---- workgroup -> work mapping over the 8 XCDs -------------------------------------------------
+// Workgroups are dealt to the XCDs round robin (blockIdx & 7).  Work item b of `nb`, where neighbouring items touch the same
+// rows: XCD x takes chunk x of every run of 8 chunks of `chunk` consecutive items - the neighbours share an L2, and all XCDs
+// walk the same region of the (cell-sorted) point set at the same time, so that regions whose rows cost more (longer
+// candidate lists) are spread over the whole chip instead of landing on one XCD.  chunk <= 0: one contiguous eighth each.
+__device__ __forceinline__ int64_t gt_xcd_item(const int64_t bidx, const int64_t nb, const int chunk) {
+    int64_t start = 0, n = nb, b = bidx;
+    if (chunk > 0) {
+        const int64_t span = int64_t(8) * chunk, whole = nb / span * span;
+        if (bidx < whole) {
+            const int64_t g = bidx >> 3;
+            return (g / chunk) * span + (bidx & 7) * chunk + g % chunk;
+        }
+        start = whole;
+        n = nb - whole;
+        b = bidx - whole;
+    }
+    const int64_t xcd = b & 7, base = n >> 3, rem = n & 7;
+    return start + xcd * base + (xcd < rem ? xcd : rem) + (b >> 3);
+}
+
 // ---- wave reductions ------------------------------------------------------------------------
+__device__ __forceinline__ double lane_xor_f64(const double v, const int o) {   // o: a constant after unrolling
+    const uint64_t b = uint64_t(__double_as_longlong(v));
+    uint64_t r;
+    switch (o) {
+        case 32: r = lane_xor_u64<32>(b); break;
+        case 16: r = lane_xor_u64<16>(b); break;
+        case 8: r = lane_xor_u64<8>(b); break;
+        case 4: r = lane_xor_u64<4>(b); break;
+        case 2: r = lane_xor_u64<2>(b); break;
+        default: r = lane_xor_u64<1>(b); break;
+    }
+    return __longlong_as_double((long long)r);
+}
+__device__ __forceinline__ uint32_t lane_xor_b32(const uint32_t v, const int o) {
+    switch (o) {
+        case 32: return lane_xor_u32<32>(v);
+        case 16: return lane_xor_u32<16>(v);
+        case 8: return lane_xor_u32<8>(v);
+        case 4: return lane_xor_u32<4>(v);
+        case 2: return lane_xor_u32<2>(v);
+        default: return lane_xor_u32<1>(v);
+    }
+}
 __device__ __forceinline__ double wave_sum_f64(double v) {
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    for (int o = 32; o > 0; o >>= 1) v += lane_xor_f64(v, o);
     return v;
 }
 __device__ __forceinline__ float wave_max_f32(float v) {
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __uint_as_float(lane_xor_b32(__float_as_uint(v), o)));
     return v;
 }
 __device__ __forceinline__ int wave_sum_i32(int v) {
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    for (int o = 32; o > 0; o >>= 1) v += int(lane_xor_b32(uint32_t(v), o));
     return v;
 }
 // exclusive prefix count of a predicate within the wave + total

@@ -17,7 +17,7 @@ void gt_free_knn_work(gt_ctx* ctx) {
                       &k->d2_lb, &k->fb_rows, &k->fb_count, &k->fb_scratch, &k->gflags, &k->prof, &k->fb_qrows, &k->fb_thr, &k->fb_lists,
                       &k->fb_counts, &k->fb_max, &k->unproven, &k->qorder, &k->qthr0, &k->qlomax_dev, &k->Ycs, &k->hnegs,
                       &k->sym_g, &k->sym_gmin, &k->tlists, &k->tcounts, &k->sym_stat, &k->sym_work, &k->sym_tiles,
-                      &k->sym_tile_cnt, &k->sh_invperm, &k->sh_lists, &k->sh_counts, &k->sh_cnt, &k->sh_own, &k->sh_tmp, &k->sym_hh, &k->sym_thrh, &k->sym_gh, &k->sym_gminh, &k->sym_queue, &k->sym_qcount, &k->sym_qdense, &k->sym_qtot, &k->sym_racc, &k->sym_farcnt, &k->sym_z, &k->sym_p, &k->sym_cov, &k->sym_qspill, &k->sym_rrow, &k->sym_bwork, &k->hnegs_fin})
+                      &k->sym_tile_cnt, &k->sh_invperm, &k->sh_lists, &k->sh_counts, &k->sh_cnt, &k->sh_own, &k->sh_tmp, &k->sym_hh, &k->sym_thrh, &k->sym_gh, &k->sym_gminh, &k->sym_queue, &k->sym_qcount, &k->sym_qdense, &k->sym_qtot, &k->sym_racc, &k->sym_farcnt, &k->sym_z, &k->sym_p, &k->sym_cov, &k->sym_qspill, &k->sym_rrow, &k->sym_bwork, &k->hnegs_fin, &k->Xs, &k->xns})
         b->release();
     delete k;
     ctx->knn = nullptr;
@@ -193,6 +193,7 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
         int ordered = 0;
         const float* Qc = external ? k->Qc.as<float>() : ctx->Yc.as<float>();
         GT_HIP(ctx, k->qorder.reserve(size_t(nq) * sizeof(int32_t)));
+        k->xs_ready = false;   // (the sorted copy of the points follows the order)
         GT_HIP(ctx, k->qthr0.reserve(size_t(nq) * sizeof(float)));
         {
             StageSpan span(ctx, "query_order");
@@ -232,6 +233,10 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
             sr.invperm = k->sh_invperm.as<int32_t>();
             sr.own_rows = k->sh_own.as<int32_t>();
             sr.own_r0 = q0;
+            if (k->xs_ready) {
+                sr.Xs = k->Xs.p;
+                sr.xns = k->xns.as<double>();
+            }
             {
                 StageSpan span(ctx, "rerank");
                 GT_TRY(gt_launch_rerank_sym(ctx, ra, sr));
@@ -293,6 +298,7 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
                 StageSpan span(ctx, "sym_prepare");
                 GT_HIP(ctx, k->hnegs_fin.reserve(size_t(n_pad_s) * sizeof(float)));
                 GT_TRY(gt_sym_gather(ctx, perm, n_pad_s, k->Ycs.p, k->hnegs.as<float>(), k->hnegs_fin.as<float>()));
+                if (ctx->sym_sorted_points != 0) GT_TRY(gt_sym_gather_points(ctx, perm));
                 GT_TRY(gt_sym_schedule(ctx, n_pad_s, bq_sym, bn_sym, ctx->sym_cells, stride_a, ctx->sym_max_nb, tile_stride,
                                        k->sym_work, k->sym_tiles.as<int32_t>(), k->sym_tile_cnt.as<int32_t>(),
                                        k->sym_stat.as<unsigned long long>() + 5));
@@ -483,6 +489,10 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
             sr.tcap = tcap;
             sr.perm = perm;
             sr.stat = k->sym_stat.as<unsigned long long>();
+            if (k->xs_ready) {
+                sr.Xs = k->Xs.p;
+                sr.xns = k->xns.as<double>();
+            }
             {
                 StageSpan span(ctx, "rerank");
                 GT_TRY(gt_launch_rerank_sym(ctx, ra, sr));
@@ -921,7 +931,7 @@ extern "C" int gt_knn_stats(const gt_ctx* ctx, int64_t* out12) {
     for (int i = 0; i < 8; ++i) out12[4 + i] = (k && k->sym_used) ? int64_t(k->sym_stat_host[i]) : 0;
     if (k && k->sym_used) out12[6] = k->sym_nseg;   // work items per query block of launch B
     if (k && k->sym_used) out12[5] = k->sym_two_used ? k->sym_cold_entries : 0;   // pairs the cold launch scored in full
-    if (k && k->sym_used) out12[7] = k->sym_two_used ? 1 : 0;                     // two-stage collect ran
+    if (k && k->sym_used) out12[7] = (k->sym_two_used ? 1 : 0) | (k->sym_seed_dense ? 2 : 0);   // bit 0: two-stage collect ran, bit 1: dense seeding kernel
     if (k && k->sym_used) out12[4] = (k->sym_two_used && k->sym_bound_used) ? 1 : 0;   // units listed by cell bounds, no collect launch
     out12[10] = k ? k->sym_far : 0;                 // kept rows of launch A outside the neighbourhood cells (all points)
     return GT_OK;

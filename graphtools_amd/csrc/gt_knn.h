@@ -30,6 +30,8 @@ struct KnnWork {
     // form and their sub-tile minima, the candidate lists of launch B and their counters
     DevBuf hnegs_fin;                             // seeds of the sorted rows, finite on the pad rows (dense seeding launch)
     DevBuf Ycs, hnegs, sym_g, sym_gmin, tlists, tcounts, sym_stat, sym_work, sym_tiles, sym_tile_cnt;
+    DevBuf Xs, xns;                               //   the points and their squared norms in cell-sorted order (gt_sym_gather_points)
+    bool xs_ready = false;                        //   ... valid for the current order (reset whenever the order is rebuilt)
     DevBuf sym_racc, sym_farcnt;                     // radius / spread statistics of the orphan cut (4 doubles), far-kept
                                                   // seeds per sorted position
     DevBuf sym_hh, sym_thrh, sym_gh, sym_gminh;   // two-stage scoring (gt_sym.hip sym_half_*)
@@ -175,11 +177,16 @@ struct SymRerank {
     const int32_t* invperm = nullptr;
     const int32_t* own_rows = nullptr;   // the owned rows in the order of their sorted positions
     int64_t own_r0 = 0;
+    // the points / norms in sorted order (optional): candidate rows are then read by position
+    const void* Xs = nullptr;
+    const double* xns = nullptr;
 };
 int gt_launch_rerank_sym(gt_ctx* ctx, const RerankArgs& a, const SymRerank& sr);
 // gt_sym.hip
 // hs_fin (optional): the same seeds with -3e38 instead of -inf on the pad rows (gt_seed.hip)
 int gt_sym_gather(gt_ctx* ctx, const int32_t* perm, int64_t n_pad_s, void* Ys, float* hs, float* hs_fin = nullptr);
+// the caller's points (all ctx->n rows, their dtype) and norms in sorted order -> KnnWork::Xs / xns, xs_ready
+int gt_sym_gather_points(gt_ctx* ctx, const int32_t* perm);
 // rows [p_first, p_last) of the sorted order only (p_last < 0: all); gmin = nullptr: sub-tile minima not formed
 int gt_sym_thresholds(gt_ctx* ctx, const int32_t* perm, int64_t n_pad_s, const float* hs, const uint64_t* lists, int lstride,
                       const uint32_t* counts, int need_m, const ErrModel& err, double rkf, float* thr, float* g, float* gmin,

@@ -56,6 +56,7 @@ int gt_knn_shard_plan(gt_ctx* ctx, int world, int rank, const int64_t* splits, i
     // the cell-sorted order of ALL rows (position -> row in k->qorder)
     int ordered = 0;
     GT_HIP(ctx, k->qorder.reserve(size_t(ctx->n) * sizeof(int32_t)));
+    k->xs_ready = false;
     GT_HIP(ctx, k->qthr0.reserve(size_t(ctx->n) * sizeof(float)));
     {
         StageSpan span(ctx, "query_order");
@@ -114,6 +115,7 @@ int gt_knn_shard_seed(gt_ctx* ctx, float* thr_local, int64_t* far_local, double*
     {
         StageSpan span(ctx, "sym_prepare");
         GT_TRY(gt_sym_gather(ctx, perm, n_pad_s, k->Ycs.p, k->hnegs.as<float>()));
+        if (ctx->sym_sorted_points != 0) GT_TRY(gt_sym_gather_points(ctx, perm));
         GT_TRY(gt_sym_schedule(ctx, n_pad_s, bq, bn, ctx->sym_cells, stride_a, ctx->sym_max_nb, tile_stride, k->sym_work,
                                k->sym_tiles.as<int32_t>(), k->sym_tile_cnt.as<int32_t>(),
                                k->sym_stat.as<unsigned long long>() + 5));   // (tiles of ALL blocks; this rank walks 1/world)

@@ -214,14 +214,14 @@ __global__ __launch_bounds__(256, 5) void rerank_sym_kernel(
     uint32_t* __restrict__ cand_n, double* __restrict__ d2_lb, uint32_t* __restrict__ fb_count,
     int32_t* __restrict__ fb_rows, uint32_t* __restrict__ gflags, const double radius_key_factor,
     uint32_t* __restrict__ unproven, unsigned long long* __restrict__ stat, const int want_stats,
-    const int32_t* __restrict__ invperm, const int32_t* __restrict__ own_rows, const int64_t own_r0) {
+    const int32_t* __restrict__ invperm, const int32_t* __restrict__ own_rows, const int64_t own_r0,
+    const int xcd_chunk, const T* __restrict__ Xs, const double* __restrict__ xns) {
     constexpr int MP = 256;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int lane = threadIdx.x & 63;
     const int w = threadIdx.x >> 6;
     double* xs = reinterpret_cast<double*>(smem_raw) + size_t(w) * d;
-    const int64_t nb = gridDim.x, xcd = blockIdx.x & 7, base = nb >> 3, rem = nb & 7;
-    const int64_t bid = xcd * base + (xcd < rem ? xcd : rem) + (blockIdx.x >> 3);
+    const int64_t bid = gt_xcd_item(blockIdx.x, gridDim.x, xcd_chunk);
     const int64_t ql = bid * 4 + w;
     if (ql >= nq) return;
     // single rank: list ql = sorted position ql, tables indexed by the row perm[ql].  Row-sharded (invperm given): the
@@ -231,11 +231,12 @@ __global__ __launch_bounds__(256, 5) void rerank_sym_kernel(
     const int64_t q = invperm ? qo - own_r0 : qo;                             // row of the tables
     const int64_t qt = invperm ? int64_t(invperm[qo]) : ql;                   // index of the threshold
     const int64_t ls = invperm ? q : ql;                                      // index of the list
-    const T* xrow = X + qo * int64_t(d);
+    // (Xs / xns: the points and norms in sorted order - the candidates of neighbouring lists are neighbouring rows there)
+    const T* xrow = Xs ? Xs + qt * int64_t(d) : X + qo * int64_t(d);
     for (int k = lane; k < d; k += 64) xs[k] = double(xrow[k]);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    const double qnq = xn[qo];
+    const double qnq = xns ? xns[qt] : xn[qo];
     // (row-sharded builds: bit 31 = some rank's partial list of this row overflowed, gt_sym.hip shard_scatter_kernel)
     const uint32_t ct_raw = tcounts[ls];
     const uint32_t ct = ct_raw & 0x7FFFFFFFu;
@@ -251,82 +252,69 @@ __global__ __launch_bounds__(256, 5) void rerank_sym_kernel(
     };
     double lb = overflow ? -INFINITY : bound_of_score(thr[qt]);
 
-    uint64_t ks[8];
+    // up to 256 candidates: all of them are evaluated, their order does not matter.  (Sorting the approximate keys first so
+    // that the best 128 could settle the row was measured at N = 1e6: 29 % of the rows hold more than 128 candidates and only
+    // a third of those stopped after the first batch - the network over 256 keys cost more than the evaluations it saved.)
+    const bool both = n > 128u;   // wave-uniform
+    uint32_t pc[4];               // sorted positions of the candidates in slots u * 64 + lane
+    uint64_t k257 = 0ull;         // best key beyond the table
+    if (n <= 256u) {
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        const uint32_t c = uint32_t(u * 64 + lane);
-        ks[u] = (c < n) ? tp[c] : 0ull;   // a valid key is never 0
-    }
-    if (n <= 128u) {   // wave-uniform
-        // every candidate is in the first batch: their order does not matter (the keys sit in the first n slots as read)
-    } else if (n <= 256u) {
-        uint64_t k4[4] = {ks[0], ks[1], ks[2], ks[3]};
-        wave_bitonic_desc<4>(k4, lane);
-        ks[0] = k4[0];
-        ks[1] = k4[1];
-        ks[2] = k4[2];
-        ks[3] = k4[3];
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t c = uint32_t(u * 64 + lane);
+            pc[u] = (c < n) ? cand_index(tp[c]) : kNoRow;
+        }
     } else {
+        uint64_t ks[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const uint32_t c = uint32_t(u * 64 + lane);
+            ks[u] = (c < n) ? tp[c] : 0ull;   // a valid key is never 0
+        }
         wave_bitonic_desc<8>(ks, lane);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) pc[u] = ks[u] != 0ull ? cand_index(ks[u]) : kNoRow;
+        k257 = __shfl((unsigned long long)ks[4], 0);
     }
     const uint32_t n_eval = n < uint32_t(MP) ? n : uint32_t(MP);
-    uint64_t hi[4], lo[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        hi[u] = kInfBits;
-        lo[u] = 0xFFFFFFFFull;
-    }
-    {
-        const uint32_t j0 = ks[0] != 0ull ? uint32_t(perm[cand_index(ks[0])]) : kNoRow;
-        const uint32_t j1 = ks[1] != 0ull ? uint32_t(perm[cand_index(ks[1])]) : kNoRow;
-        double dot0, dot1;
-        // (one database row per lane.  Sixteen lanes per row with coalesced 16-byte loads and a rotation sum were tried:
-        //  8.1 ms against 5.8 - the kernel is bound by its sorting networks and the gathers hit the L2, the extra
-        //  registers of the batched loads cost more occupancy than the coalescing returns)
-        dot0 = j0 != kNoRow ? dot_row_sel<T, F4>(xs, X + int64_t(j0) * d, d) : 0.0;
-        dot1 = j1 != kNoRow ? dot_row_sel<T, F4>(xs, X + int64_t(j1) * d, d) : 0.0;
-        if (j0 != kNoRow) {
-            hi[0] = (uint64_t)__double_as_longlong(gt_pair_key(qnq, dot0, xn[j0], 0));
-            lo[0] = j0;
+    uint64_t hi[4];
+    uint32_t lo[4];
+    // (one database row per lane.  Sixteen lanes per row with coalesced 16-byte loads and a rotation sum were tried: 8.1 ms
+    //  against 5.8; four lanes per row is rerank_sym4_kernel below)
+    // two rows at a time, their loads in flight together (no branch between them)
+    auto eval2 = [&](const uint32_t pa, const uint32_t pb, uint64_t& ha, uint32_t& la, uint64_t& hb, uint32_t& lb_) {
+        const bool va = pa != kNoRow, vb = pb != kNoRow;
+        const uint32_t ja = va ? uint32_t(perm[pa]) : 0u, jb = vb ? uint32_t(perm[pb]) : 0u;   // the rows themselves: what the
+        const uint32_t ra = Xs ? (va ? pa : 0u) : ja, rb = Xs ? (vb ? pb : 0u) : jb;             // tables hold, what breaks ties
+        const T* base = Xs ? Xs : X;
+        const double* nrm = Xs ? xns : xn;
+        const double da = va ? dot_row_sel<T, F4>(xs, base + int64_t(ra) * d, d) : 0.0;
+        const double db = vb ? dot_row_sel<T, F4>(xs, base + int64_t(rb) * d, d) : 0.0;
+        ha = hb = kInfBits;
+        la = lb_ = 0xFFFFFFFFu;
+        if (va) {
+            ha = (uint64_t)__double_as_longlong(gt_pair_key(qnq, da, nrm[ra], 0));
+            la = ja;
         }
-        if (j1 != kNoRow) {
-            hi[1] = (uint64_t)__double_as_longlong(gt_pair_key(qnq, dot1, xn[j1], 0));
-            lo[1] = j1;
+        if (vb) {
+            hb = (uint64_t)__double_as_longlong(gt_pair_key(qnq, db, nrm[rb], 0));
+            lb_ = jb;
         }
-    }
+    };
+    eval2(pc[0], pc[1], hi[0], lo[0], hi[1], lo[1]);
+    hi[2] = hi[3] = kInfBits;
+    lo[2] = lo[3] = 0xFFFFFFFFu;
     const int pos = need_m - 1;
-    const bool may_stop = radius_key_factor > 0.0;
     const double rkf = fabs(radius_key_factor);
-    const uint64_t k129 = __shfl((unsigned long long)ks[2], 0);
-    const uint64_t k257 = __shfl((unsigned long long)ks[4], 0);
-    const double lb_rest = (k129 != 0ull) ? bound_of_score(cand_score(k129)) : INFINITY;
-    uint64_t h2[2] = {hi[0], hi[1]}, l2[2] = {lo[0], lo[1]};
-    wave_sort_asc_pair_fast<2>(h2, l2, lane);
-    const uint64_t sel2 = (pos >> 6) == 0 ? h2[0] : h2[1];
-    const double need2 = __longlong_as_double((long long)__shfl((unsigned long long)sel2, pos & 63));
-    const double lbm = fmin(lb, lb_rest);
-    uint32_t n_tab = n_eval;
-    if (may_stop && pos < 128 && need2 * rkf < lbm) {   // wave-uniform
+    const uint32_t n_tab = n_eval;
+    if (!both) {
+        uint64_t h2[2] = {hi[0], hi[1]};
+        uint32_t l2[2] = {lo[0], lo[1]};
+        wave_sort_asc_pair_fast<2>(h2, l2, lane);
         hi[0] = h2[0]; hi[1] = h2[1];
         lo[0] = l2[0]; lo[1] = l2[1];
-        lb = lbm;
-        n_tab = n_eval < 128u ? n_eval : 128u;
     } else {
-        {
-            const uint32_t j2 = ks[2] != 0ull ? uint32_t(perm[cand_index(ks[2])]) : kNoRow;
-            const uint32_t j3 = ks[3] != 0ull ? uint32_t(perm[cand_index(ks[3])]) : kNoRow;
-            double dot2, dot3;
-            dot2 = j2 != kNoRow ? dot_row_sel<T, F4>(xs, X + int64_t(j2) * d, d) : 0.0;
-            dot3 = j3 != kNoRow ? dot_row_sel<T, F4>(xs, X + int64_t(j3) * d, d) : 0.0;
-            if (j2 != kNoRow) {
-                hi[2] = (uint64_t)__double_as_longlong(gt_pair_key(qnq, dot2, xn[j2], 0));
-                lo[2] = j2;
-            }
-            if (j3 != kNoRow) {
-                hi[3] = (uint64_t)__double_as_longlong(gt_pair_key(qnq, dot3, xn[j3], 0));
-                lo[3] = j3;
-            }
-        }
+        eval2(pc[2], pc[3], hi[2], lo[2], hi[3], lo[3]);
         if (k257 != 0ull) lb = fmin(lb, bound_of_score(cand_score(k257)));   // candidates beyond the table
         wave_sort_asc_pair_fast<4>(hi, lo, lane);
     }
@@ -360,7 +348,7 @@ __global__ __launch_bounds__(256, 5) void rerank_sym_kernel(
             const unsigned long long tot = (unsigned long long)ct;
             atomicAdd(stat + 1, tot);
             atomicMax(stat + 3, tot);
-            if (tot > 256ull) atomicAdd(stat + 4, 1ull);
+            if (tot > 256ull || (tot > 128ull && n_tab <= 128u)) atomicAdd(stat + 4, 1ull);   // (experiment: long lists settled by the first batch)
             if (tot > 128ull) atomicAdd(stat + 7, 1ull);
         }
         if (n_tab > 1 && second == 0ull) atomicOr(gflags, GT_FLAG_DUPLICATES);
@@ -390,14 +378,18 @@ __global__ __launch_bounds__(256, 4) void rerank_sym4_kernel(
     uint32_t* __restrict__ cand_n, double* __restrict__ d2_lb, uint32_t* __restrict__ fb_count,
     int32_t* __restrict__ fb_rows, uint32_t* __restrict__ gflags, const double radius_key_factor,
     uint32_t* __restrict__ unproven, unsigned long long* __restrict__ stat, const int want_stats,
-    const int32_t* __restrict__ invperm, const int32_t* __restrict__ own_rows, const int64_t own_r0) {
+    const int32_t* __restrict__ invperm, const int32_t* __restrict__ own_rows, const int64_t own_r0,
+    const int xcd_chunk, const float* __restrict__ Xs, const double* __restrict__ xns) {
     constexpr int MP = 256;
     constexpr int NI = 4 * DB;   // 64-byte sectors of a row this kernel can hold
+    __shared__ uint64_t park_hi_all[4 * MP];   // (the sorted tables are picked up by position through the LDS)
+    __shared__ uint32_t park_lo_all[4 * MP];
     const int lane = threadIdx.x & 63;
     const int w = threadIdx.x >> 6;
     const int c = lane & 3, r = lane >> 2;
-    const int64_t nb = gridDim.x, xcd = blockIdx.x & 7, base = nb >> 3, rem = nb & 7;
-    const int64_t bid = xcd * base + (xcd < rem ? xcd : rem) + (blockIdx.x >> 3);
+    uint64_t* park_hi = park_hi_all + w * MP;
+    uint32_t* park_lo = park_lo_all + w * MP;
+    const int64_t bid = gt_xcd_item(blockIdx.x, gridDim.x, xcd_chunk);
     const int64_t ql = bid * 4 + w;
     if (ql >= nq) return;
     const int64_t qo = invperm ? int64_t(own_rows[ql]) : int64_t(perm[ql]);   // row of the bound points
@@ -407,7 +399,9 @@ __global__ __launch_bounds__(256, 4) void rerank_sym4_kernel(
     // this lane's share of the query row: elements 16 i + 4 c .. + 3 of every sector i
     double xq[NI][4];
     {
-        const float4* xrow4 = reinterpret_cast<const float4*>(X + qo * int64_t(d));
+        // (Xs / xns: the points and norms in sorted order, REQUIRED here - candidate rows are read by position, the row
+        //  numbers for the tables arrive on the side)
+        const float4* xrow4 = reinterpret_cast<const float4*>(Xs + qt * int64_t(d));
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const bool in = 16 * i + 4 * c < d;
@@ -418,7 +412,7 @@ __global__ __launch_bounds__(256, 4) void rerank_sym4_kernel(
             xq[i][3] = double(v.w);
         }
     }
-    const double qnq = xn[qo];
+    const double qnq = xns[qt];
     const uint32_t ct_raw = tcounts[ls];
     const uint32_t ct = ct_raw & 0x7FFFFFFFu;
     const bool overflow = ct > uint32_t(tcap) || (ct_raw >> 31) != 0u;
@@ -432,42 +426,50 @@ __global__ __launch_bounds__(256, 4) void rerank_sym4_kernel(
     };
     double lb = overflow ? -INFINITY : bound_of_score(thr[qt]);
 
-    uint64_t ks[8];
+    // up to 256 candidates: all of them are evaluated, their order does not matter.  (Sorting the approximate keys first so
+    // that the best 128 could settle the row was measured at N = 1e6: 29 % of the rows hold more than 128 candidates and only
+    // a third of those stopped after the first batch - the network over 256 keys cost more than the evaluations it saved.)
+    const bool both = n > 128u;   // wave-uniform
+    uint32_t pc[4];               // sorted positions of the candidates in slots u * 64 + lane
+    uint64_t k257 = 0ull;         // best key beyond the table
+    if (n <= 256u) {
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        const uint32_t cidx = uint32_t(u * 64 + lane);
-        ks[u] = (cidx < n) ? tp[cidx] : 0ull;   // a valid key is never 0
-    }
-    if (n <= 128u) {   // wave-uniform
-        // every candidate is in the first batch: their order does not matter
-    } else if (n <= 256u) {
-        uint64_t k4[4] = {ks[0], ks[1], ks[2], ks[3]};
-        wave_bitonic_desc<4>(k4, lane);
-        ks[0] = k4[0];
-        ks[1] = k4[1];
-        ks[2] = k4[2];
-        ks[3] = k4[3];
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t cidx = uint32_t(u * 64 + lane);
+            pc[u] = (cidx < n) ? cand_index(tp[cidx]) : kNoRow;
+        }
     } else {
+        uint64_t ks[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const uint32_t cidx = uint32_t(u * 64 + lane);
+            ks[u] = (cidx < n) ? tp[cidx] : 0ull;   // a valid key is never 0
+        }
         wave_bitonic_desc<8>(ks, lane);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) pc[u] = ks[u] != 0ull ? cand_index(ks[u]) : kNoRow;
+        k257 = __shfl((unsigned long long)ks[4], 0);
     }
     const uint32_t n_eval = n < uint32_t(MP) ? n : uint32_t(MP);
     // exact keys of the 128 candidates held as (jA: slot u, jB: slot u + 1), 16 candidates per pass: group r takes
     // candidate 16 p + r of the batch, lane c of the group keeps the result of the passes p with p % 4 == c
-    auto eval128 = [&](const uint32_t jA, const uint32_t jB, uint64_t& hA, uint64_t& lA, uint64_t& hB, uint64_t& lB) {
+    auto eval128 = [&](const uint32_t jA, const uint32_t jB, uint64_t& hA, uint32_t& lA, uint64_t& hB, uint32_t& lB) {
         hA = hB = kInfBits;
-        lA = lB = 0xFFFFFFFFull;
+        lA = lB = 0xFFFFFFFFu;
 #pragma unroll 2
         for (int p = 0; p < 8; ++p) {
-            const uint32_t j = uint32_t(__shfl(int(p < 4 ? jA : jB), (p & 3) * 16 + r));
+            const uint32_t pj = uint32_t(__shfl(int(p < 4 ? jA : jB), (p & 3) * 16 + r));   // position of the group's candidate
             double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;   // partial sums c, c + 4, c + 8, c + 12
             double yn = 0.0;
-            if (j != kNoRow) {
-                const float4* y4 = reinterpret_cast<const float4*>(X + int64_t(j) * d);
+            uint32_t j = kNoRow;
+            if (pj != kNoRow) {
+                j = uint32_t(perm[pj]);   // the row itself: what the tables hold and what breaks ties
+                const float4* y4 = reinterpret_cast<const float4*>(Xs + int64_t(pj) * d);   // (independent of j)
                 float4 v[NI];
 #pragma unroll
                 for (int i = 0; i < NI; ++i)
                     if (16 * i < d) v[i] = (16 * i + 4 * c < d) ? y4[4 * i + c] : make_float4(0.f, 0.f, 0.f, 0.f);
-                yn = xn[j];
+                yn = xns[pj];
 #pragma unroll
                 for (int i = 0; i < NI; ++i)
                     if (16 * i < d) {   // (uniform; a quad past the end of the row contributes exact zeros, as in gt_dot16
@@ -482,8 +484,8 @@ __global__ __launch_bounds__(256, 4) void rerank_sym4_kernel(
                     }
             }
             const double cc = (a0 + a2) + (a1 + a3);            // b[c] + b[c + 4]
-            const double w2 = cc + __shfl_xor(cc, 2);           // lanes 0, 2: c0 + c2; lanes 1, 3: c1 + c3
-            const double dot = w2 + __shfl_xor(w2, 1);          // (c0 + c2) + (c1 + c3)
+            const double w2 = cc + lane_xor_f64(cc, 2);         // lanes 0, 2: c0 + c2; lanes 1, 3: c1 + c3
+            const double dot = w2 + lane_xor_f64(w2, 1);        // (c0 + c2) + (c1 + c3)
             if (j != kNoRow && c == (p & 3)) {
                 const uint64_t key = (uint64_t)__double_as_longlong(gt_pair_key(qnq, dot, yn, 0));
                 if (p < 4) {
@@ -496,37 +498,25 @@ __global__ __launch_bounds__(256, 4) void rerank_sym4_kernel(
             }
         }
     };
-    uint64_t hi[4], lo[4];
+    uint64_t hi[4];
+    uint32_t lo[4];
     {
-        const uint32_t j0 = ks[0] != 0ull ? uint32_t(perm[cand_index(ks[0])]) : kNoRow;
-        const uint32_t j1 = ks[1] != 0ull ? uint32_t(perm[cand_index(ks[1])]) : kNoRow;
-        eval128(j0, j1, hi[0], lo[0], hi[1], lo[1]);
+        eval128(pc[0], pc[1], hi[0], lo[0], hi[1], lo[1]);
         hi[2] = hi[3] = kInfBits;
-        lo[2] = lo[3] = 0xFFFFFFFFull;
+        lo[2] = lo[3] = 0xFFFFFFFFu;
     }
     const int pos = need_m - 1;
-    const bool may_stop = radius_key_factor > 0.0;
-    const double rkf = fabs(radius_key_factor);
-    const uint64_t k129 = __shfl((unsigned long long)ks[2], 0);
-    const uint64_t k257 = __shfl((unsigned long long)ks[4], 0);
-    const double lb_rest = (k129 != 0ull) ? bound_of_score(cand_score(k129)) : INFINITY;
-    uint64_t h2[2] = {hi[0], hi[1]}, l2[2] = {lo[0], lo[1]};
-    wave_sort_asc_pair_fast<2>(h2, l2, lane);
-    const uint64_t sel2 = (pos >> 6) == 0 ? h2[0] : h2[1];
-    const double need2 = __longlong_as_double((long long)__shfl((unsigned long long)sel2, pos & 63));
-    const double lbm = fmin(lb, lb_rest);
-    uint32_t n_tab = n_eval;
-    if (may_stop && pos < 128 && need2 * rkf < lbm) {   // wave-uniform
+    const uint32_t n_tab = n_eval;
+    if (!both) {
+        uint64_t h2[2] = {hi[0], hi[1]};
+        uint32_t l2[2] = {lo[0], lo[1]};
+        wave_sort_asc_pair_fast<2>(h2, l2, lane, park_hi, park_lo);
         hi[0] = h2[0]; hi[1] = h2[1];
         lo[0] = l2[0]; lo[1] = l2[1];
-        lb = lbm;
-        n_tab = n_eval < 128u ? n_eval : 128u;
     } else {
-        const uint32_t j2 = ks[2] != 0ull ? uint32_t(perm[cand_index(ks[2])]) : kNoRow;
-        const uint32_t j3 = ks[3] != 0ull ? uint32_t(perm[cand_index(ks[3])]) : kNoRow;
-        eval128(j2, j3, hi[2], lo[2], hi[3], lo[3]);
+        eval128(pc[2], pc[3], hi[2], lo[2], hi[3], lo[3]);
         if (k257 != 0ull) lb = fmin(lb, bound_of_score(cand_score(k257)));   // candidates beyond the table
-        wave_sort_asc_pair_fast<4>(hi, lo, lane);
+        wave_sort_asc_pair_fast<4>(hi, lo, lane, park_hi, park_lo);
     }
     const uint32_t n_def = n_tab > uint32_t(need_m) ? n_tab : uint32_t(need_m);
 #pragma unroll
@@ -549,13 +539,13 @@ __global__ __launch_bounds__(256, 4) void rerank_sym4_kernel(
             const uint32_t slot = atomicAdd(fb_count, 1u);
             fb_rows[slot] = int32_t(q);
         }
-        if (unproven && !overflow && thr[qt] != INFINITY && !(d2_need * rkf < lb)) atomicAdd(unproven, 1u);
+        if (unproven && !overflow && thr[qt] != INFINITY && !(d2_need * fabs(radius_key_factor) < lb)) atomicAdd(unproven, 1u);
         if (stat && overflow) atomicAdd(stat + 0, 1ull);
         if (stat && want_stats) {
             const unsigned long long tot = (unsigned long long)ct;
             atomicAdd(stat + 1, tot);
             atomicMax(stat + 3, tot);
-            if (tot > 256ull) atomicAdd(stat + 4, 1ull);
+            if (tot > 256ull || (tot > 128ull && n_tab <= 128u)) atomicAdd(stat + 4, 1ull);   // (experiment: long lists settled by the first batch)
             if (tot > 128ull) atomicAdd(stat + 7, 1ull);
         }
         if (n_tab > 1 && second == 0ull) atomicOr(gflags, GT_FLAG_DUPLICATES);
@@ -930,15 +920,17 @@ int gt_launch_rerank_sym(gt_ctx* ctx, const RerankArgs& a, const SymRerank& sr) 
     hipLaunchKernelGGL((rerank_sym_kernel<T_, F4_>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, (const T_*)a.X, a.d,  \
                        a.xn, a.nq, sr.tlists, sr.tcap, sr.tcounts, a.thr_final, a.ymax2, a.err, a.need_m, sr.perm,        \
                        a.cand_d2, a.cand_j, a.cand_n, a.d2_lb, a.fb_count, a.fb_rows, a.gflags, a.radius_key_factor,      \
-                       a.unproven, sr.stat, (ctx->dbg_select & 256) ? 1 : 0, sr.invperm, sr.own_rows, sr.own_r0)
+                       a.unproven, sr.stat, (ctx->dbg_select & 256) ? 1 : 0, sr.invperm, sr.own_rows, sr.own_r0, ctx->xcd_chunk,      \
+                       (const T_*)sr.Xs, sr.xns)
 #define GT_RERANK_SYM4_LAUNCH(DB_)                                                                                        \
     hipLaunchKernelGGL((rerank_sym4_kernel<DB_>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (const float*)a.X, a.d,    \
                        a.xn, a.nq, sr.tlists, sr.tcap, sr.tcounts, a.thr_final, a.ymax2, a.err, a.need_m, sr.perm,        \
                        a.cand_d2, a.cand_j, a.cand_n, a.d2_lb, a.fb_count, a.fb_rows, a.gflags, a.radius_key_factor,      \
-                       a.unproven, sr.stat, (ctx->dbg_select & 256) ? 1 : 0, sr.invperm, sr.own_rows, sr.own_r0)
+                       a.unproven, sr.stat, (ctx->dbg_select & 256) ? 1 : 0, sr.invperm, sr.own_rows, sr.own_r0, ctx->xcd_chunk,      \
+                       (const float*)sr.Xs, sr.xns)
     if (a.dtype == GT_F32) {
         const bool f4 = (a.d & 3) == 0 && (reinterpret_cast<uintptr_t>(a.X) & 15) == 0;
-        if (f4 && ctx->rerank_lanes4 != 0 && a.d <= 64) GT_RERANK_SYM4_LAUNCH(1);
+        if (f4 && ctx->rerank_lanes4 != 0 && a.d <= 64 && sr.Xs != nullptr) GT_RERANK_SYM4_LAUNCH(1);
         else if (f4) GT_RERANK_SYM_LAUNCH(float, true);
         else GT_RERANK_SYM_LAUNCH(float, false);
     } else {

@@ -560,7 +560,8 @@ __global__ __launch_bounds__(256) void bin_emit_kernel(const int64_t nloc, const
 
 // One workgroup per bin.  sN: exclusive scan of the own-entry counts in sorted order (lenNs), binoff: of the bins'
 // triplet counts - the bin's union rows start at sN[first row] + binoff[bin].
-__global__ __launch_bounds__(256) void bin_fill_kernel(const int64_t nloc, const int MP, const double* __restrict__ cand_k,
+template <int NT>   // threads per workgroup (the kernel waits on load -> LDS atomic -> store chains: more of them in flight)
+__global__ __launch_bounds__(NT) void bin_fill_kernel(const int64_t nloc, const int MP, const double* __restrict__ cand_k,
                                                        const uint32_t* __restrict__ cand_j, const int32_t* __restrict__ rowsrc,
                                                        const uint64_t* __restrict__ rlists, const uint32_t* __restrict__ rcounts,
                                                        const int32_t rcap, const double* __restrict__ rK,
@@ -575,29 +576,30 @@ __global__ __launch_bounds__(256) void bin_fill_kernel(const int64_t nloc, const
     const int R = 1 << shift;
     int32_t* cnt = reinterpret_cast<int32_t*>(smem_raw);   // [R] received entries per row, then the cursor of its T part
     int32_t* excl = cnt + R;                               // [R] start of the row inside the bin's window
-    __shared__ int32_t wsum[4];
+    __shared__ int32_t wsum[NT / 64];
     const int b = blockIdx.x;
     const int64_t p0 = int64_t(b) << shift;
     const int nr = int(nloc - p0 < R ? nloc - p0 : R);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    for (int r = threadIdx.x; r < R; r += 256) cnt[r] = 0;
+    for (int r = threadIdx.x; r < R; r += NT) cnt[r] = 0;
     __syncthreads();
     const int64_t t0 = binoff[b], t1 = binoff[b + 1];
     {
         // (four loads in flight per thread: the loop is bound by the latency of load -> LDS atomic otherwise)
         int64_t t = t0 + threadIdx.x;
-        for (; t + 3 * 256 < t1; t += 4 * 256) {
-            const uint32_t r0 = trip[t].row, r1 = trip[t + 256].row, r2 = trip[t + 512].row, r3 = trip[t + 768].row;
+        for (; t + 3 * NT < t1; t += 4 * NT) {
+            const uint32_t r0 = trip[t].row, r1 = trip[t + NT].row, r2 = trip[t + 2 * NT].row, r3 = trip[t + 3 * NT].row;
             atomicAdd(&cnt[int64_t(r0) - p0], 1);
             atomicAdd(&cnt[int64_t(r1) - p0], 1);
             atomicAdd(&cnt[int64_t(r2) - p0], 1);
             atomicAdd(&cnt[int64_t(r3) - p0], 1);
         }
-        for (; t < t1; t += 256) atomicAdd(&cnt[int64_t(trip[t].row) - p0], 1);
+        for (; t < t1; t += NT) atomicAdd(&cnt[int64_t(trip[t].row) - p0], 1);
     }
     __syncthreads();
-    // exclusive scan of lenNs + cnt over the bin's rows: thread x owns the R / 256 consecutive rows from x R / 256
-    const int per = R / 256;
+    // exclusive scan of lenNs + cnt over the bin's rows: thread x owns the `per` consecutive rows from x per (R >= 256 is a
+    // power of two: with more threads than rows the first R threads own one row each)
+    const int per = R >= NT ? R / NT : 1;
     const int r_first = threadIdx.x * per;
     int32_t mine = 0;
     for (int u = 0; u < per; ++u) {
@@ -647,12 +649,12 @@ __global__ __launch_bounds__(256) void bin_fill_kernel(const int64_t nloc, const
             lnrun += ln;
         }
     }
-    if (b == nbins - 1 && threadIdx.x == 255) off[nloc] = ubase + run;
+    if (b == nbins - 1 && threadIdx.x == NT - 1) off[nloc] = ubase + run;
     __syncthreads();
     {
         int64_t t = t0 + threadIdx.x;
-        for (; t + 3 * 256 < t1; t += 4 * 256) {
-            const Triplet a0 = trip[t], a1 = trip[t + 256], a2 = trip[t + 512], a3 = trip[t + 768];
+        for (; t + 3 * NT < t1; t += 4 * NT) {
+            const Triplet a0 = trip[t], a1 = trip[t + NT], a2 = trip[t + 2 * NT], a3 = trip[t + 3 * NT];
             const int s0 = atomicAdd(&cnt[int64_t(a0.row) - p0], 1);
             const int s1 = atomicAdd(&cnt[int64_t(a1.row) - p0], 1);
             const int s2 = atomicAdd(&cnt[int64_t(a2.row) - p0], 1);
@@ -669,7 +671,7 @@ __global__ __launch_bounds__(256) void bin_fill_kernel(const int64_t nloc, const
                 U[t0 + s3] = UEntry{(a3.col << 1) | 1u, 0u, a3.val};
             }
         }
-        for (; t < t1; t += 256) {
+        for (; t < t1; t += NT) {
             const Triplet tr = trip[t];
             const int slot = atomicAdd(&cnt[int64_t(tr.row) - p0], 1);
             if (ucol) {
@@ -1908,12 +1910,17 @@ static int graph_finish_impl(gt_ctx* ctx, const void* recv_buf_dev, int64_t n_re
                                g->tablen.as<int32_t>(), perm, g->pos_sorted.as<int64_t>(), g->cursor.as<uint32_t>(), shift, nbins,
                                g->binoff.as<int64_t>(), g->bincnt.as<int32_t>() + nbins, (Triplet*)g->selfbuf.p);
             GT_HIP(ctx, hipGetLastError());
-            hipLaunchKernelGGL(bin_fill_kernel, dim3((unsigned)nbins), dim3(256), size_t(2) * (size_t(1) << shift) * sizeof(int32_t),
-                               ctx->stream, nloc, k->MP, k->cand_d2.as<double>(), k->cand_j.as<uint32_t>(),
-                               g->rowsrc.as<int32_t>(), g->rlists.as<uint64_t>(), g->rcounts.as<uint32_t>(), g->rcap,
-                               g->rK.as<double>(), g->tablen.as<int32_t>(), perm, shift, nbins, g->binoff.as<int64_t>(),
-                               (const Triplet*)g->selfbuf.p, g->cnt_sorted.as<int32_t>(), g->pos_sorted.as<int64_t>(),
-                               g->off.as<int64_t>(), g->Ukey.as<UEntry>(), (uint32_t*)nullptr, (double*)nullptr);
+#define GT_BIN_FILL(NT_)                                                                                                     \
+    hipLaunchKernelGGL(bin_fill_kernel<NT_>, dim3((unsigned)nbins), dim3(NT_), size_t(2) * (size_t(1) << shift) * sizeof(int32_t), \
+                       ctx->stream, nloc, k->MP, k->cand_d2.as<double>(), k->cand_j.as<uint32_t>(),                          \
+                       g->rowsrc.as<int32_t>(), g->rlists.as<uint64_t>(), g->rcounts.as<uint32_t>(), g->rcap,               \
+                       g->rK.as<double>(), g->tablen.as<int32_t>(), perm, shift, nbins, g->binoff.as<int64_t>(),            \
+                       (const Triplet*)g->selfbuf.p, g->cnt_sorted.as<int32_t>(), g->pos_sorted.as<int64_t>(),              \
+                       g->off.as<int64_t>(), g->Ukey.as<UEntry>(), (uint32_t*)nullptr, (double*)nullptr)
+            if (ctx->symm_fill_threads >= 1024) GT_BIN_FILL(1024);
+            else if (ctx->symm_fill_threads >= 512) GT_BIN_FILL(512);
+            else GT_BIN_FILL(256);
+#undef GT_BIN_FILL
             GT_HIP(ctx, hipGetLastError());
         } else {
             hipLaunchKernelGGL(fill_rows_kernel, dim3((unsigned)ceil_div64(nloc, 4)), dim3(256), 0, ctx->stream, nloc, k->MP,
@@ -2102,7 +2109,7 @@ static int graph_finish_fused(gt_ctx* ctx, int64_t* out_nnz, uint32_t* flags) {
                        g->rlists.as<uint64_t>(), g->rcounts.as<uint32_t>(), g->rcap, g->rK.as<double>(),
                        g->tablen.as<int32_t>(), perm, g->pos_sorted.as<int64_t>(), g->cursor.as<uint32_t>(), shift, nbins,
                        g->binoff.as<int64_t>(), g->bincnt.as<int32_t>() + nbins, (Triplet*)g->selfbuf.p);
-    hipLaunchKernelGGL(bin_fill_kernel, dim3((unsigned)nbins), dim3(256), size_t(2) * (size_t(1) << shift) * sizeof(int32_t),
+    hipLaunchKernelGGL(bin_fill_kernel<256>, dim3((unsigned)nbins), dim3(256), size_t(2) * (size_t(1) << shift) * sizeof(int32_t),
                        ctx->stream, nloc, k->MP, k->cand_d2.as<double>(), k->cand_j.as<uint32_t>(), g->rowsrc.as<int32_t>(),
                        g->rlists.as<uint64_t>(), g->rcounts.as<uint32_t>(), g->rcap, g->rK.as<double>(),
                        g->tablen.as<int32_t>(), perm, shift, nbins, g->binoff.as<int64_t>(), (const Triplet*)g->selfbuf.p,

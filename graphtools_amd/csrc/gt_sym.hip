@@ -57,6 +57,34 @@ __global__ __launch_bounds__(256) void gather_sorted_kernel(const uint4* __restr
     Ys[f] = v;
 }
 
+// The points themselves (and their squared norms) in cell-sorted order.  The exact stages - thresholds, re-rank - gather the
+// rows of a point's candidates: neighbours in space, i.e. rows of the same few cells, which sit next to each other in this
+// copy and are shared through the L2 by the neighbouring queries.  In the caller's row order every gather is a trip to
+// the HBM (PMC at N = 1e6, d = 64: the 16 M seed rows of sym_thresholds_kernel fetched 2.2 GB for 256 MB of points).
+template <typename T>
+__global__ __launch_bounds__(256) void gather_points_kernel(const T* __restrict__ X, const double* __restrict__ xn,
+                                                            const int32_t* __restrict__ perm, const int64_t n, const int d,
+                                                            T* __restrict__ Xs, double* __restrict__ xns) {
+    const int64_t f = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (f >= n * int64_t(d)) return;
+    const int64_t p = f / d;
+    const int c = int(f - p * d);
+    const int64_t r = perm[p];
+    Xs[f] = X[r * int64_t(d) + c];
+    if (c == 0) xns[p] = xn[r];
+}
+__global__ __launch_bounds__(256) void gather_points16_kernel(const uint4* __restrict__ X, const double* __restrict__ xn,
+                                                              const int32_t* __restrict__ perm, const int64_t n, const int c16,
+                                                              uint4* __restrict__ Xs, double* __restrict__ xns) {
+    const int64_t f = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (f >= n * int64_t(c16)) return;
+    const int64_t p = f / c16;
+    const int c = int(f - p * c16);
+    const int64_t r = perm[p];
+    Xs[f] = X[r * int64_t(c16) + c];
+    if (c == 0) xns[p] = xn[r];
+}
+
 // Fixed thresholds of launch B from the need_m rows launch A kept for sorted position p (list slots [0, kept)):
 //   D_K = the largest exact key (float64 squared distance, scikit-learn's association) among them: need_m distinct rows
 //   lie within D_K, so the need_m-th neighbour does.  The caller needs every row with d^2 <= rkf * d^2(need_m-th) <=
@@ -79,27 +107,37 @@ __global__ __launch_bounds__(256) void sym_thresholds_kernel(const int64_t n, co
                                                              float* __restrict__ g, const uint32_t* __restrict__ cell_sorted,
                                                              const int32_t* __restrict__ nbr, const int M,
                                                              unsigned long long* __restrict__ far_total,
-                                                             float* __restrict__ farcnt) {
-    const int sub = threadIdx.x & 15;
+                                                             float* __restrict__ farcnt, const int sorted) {
+    // sorted != 0: X / xn are the copies in cell-sorted order (gather_points_kernel): rows are addressed by position
+    const int sub = threadIdx.x & 15, lane64 = threadIdx.x & 63;
     const int64_t p = p_first + int64_t(blockIdx.x) * 16 + (threadIdx.x >> 4);
     if (p >= p_last) return;   // whole 16-lane group
     float t = INFINITY, gv = INFINITY;
     if (p < n) {
-        const int64_t q = perm[p];
+        const int64_t q = sorted ? p : int64_t(perm[p]);
         // how many of the kept rows lie outside the M cells around the row's own: when that is most of them the cells say
         // nothing about this point set (launch A found its neighbours in the strided sample) and the thresholds are loose
         uint32_t far = 0;
         if (far_total) {
+            // the M cells around the row's own sit in two registers per lane of the group (M <= 32); every kept row's cell is
+            // passed round the group and compared by all lanes at once.  (A loop of M dependent loads per kept row was the
+            // longest chain of this kernel.)
             const uint32_t kept0 = counts[p];
             const uint32_t cme = cell_sorted[p];
-            for (uint32_t c = uint32_t(sub); c < kept0; c += 16u) {
-                const uint32_t cc = cell_sorted[cand_index(lists[size_t(p) * lstride + c])];
-                bool near = false;
-                for (int m = 0; m < M; ++m) near = near || (uint32_t(nbr[size_t(cme) * M + m]) == cc);
-                far += near ? 0u : 1u;
-            }
+            const uint32_t nb0 = sub < M ? uint32_t(nbr[size_t(cme) * M + sub]) : 0xFFFFFFFFu;
+            const uint32_t nb1 = sub + 16 < M ? uint32_t(nbr[size_t(cme) * M + sub + 16]) : 0xFFFFFFFFu;
+            for (uint32_t c0 = 0; c0 < 64u; c0 += 16u) {   // (need_m <= 64; the trip count is the same for the whole wave)
+                if (__ballot(c0 < kept0) == 0ull) break;
+                const bool have = c0 + uint32_t(sub) < kept0;
+                const uint32_t ccm = have ? cell_sorted[cand_index(lists[size_t(p) * lstride + c0 + sub])] : 0xFFFFFFFEu;
 #pragma unroll
-            for (int o = 8; o > 0; o >>= 1) far += __shfl_xor(far, o, 16);
+                for (int c = 0; c < 16; ++c) {
+                    const uint32_t cc = uint32_t(__shfl(int(ccm), c, 16));
+                    const unsigned long long hit = __ballot(nb0 == cc || nb1 == cc);
+                    const bool near = ((hit >> (lane64 & 48)) & 0xFFFFull) != 0ull;
+                    far += (sub == 0 && cc != 0xFFFFFFFEu && !near) ? 1u : 0u;
+                }
+            }
             if (sub == 0 && far) atomicAdd(far_total, (unsigned long long)far);
         }
         const T* xq = X + q * int64_t(d);
@@ -113,7 +151,10 @@ __global__ __launch_bounds__(256) void sym_thresholds_kernel(const int64_t n, co
         double dk = 0.0;
         for (uint32_t c0 = 0; c0 < kept; c0 += 16u) {
             int64_t jmine = 0;
-            if (c0 + uint32_t(sub) < kept) jmine = perm[cand_index(lists[size_t(p) * lstride + c0 + sub])];
+            if (c0 + uint32_t(sub) < kept) {
+                const uint32_t pj = cand_index(lists[size_t(p) * lstride + c0 + sub]);
+                jmine = sorted ? int64_t(pj) : int64_t(perm[pj]);
+            }
             const uint32_t lim = kept - c0 < 16u ? kept - c0 : 16u;
             // four candidate rows at a time: their loads are in flight together (one after the other the loop is a chain
             // of shuffle -> address -> load -> reduce latencies)
@@ -1054,6 +1095,31 @@ int gt_sym_gather(gt_ctx* ctx, const int32_t* perm, int64_t n_pad_s, void* Ys, f
     return GT_OK;
 }
 
+int gt_sym_gather_points(gt_ctx* ctx, const int32_t* perm) {
+    KnnWork* k = ctx->knn;
+    const size_t esz = ctx->dtype == GT_F32 ? 4 : 8;
+    const int64_t n = ctx->n;
+    const int d = ctx->d;
+    k->xs_ready = false;
+    GT_HIP(ctx, k->Xs.reserve(size_t(n) * d * esz));
+    GT_HIP(ctx, k->xns.reserve(size_t(n) * sizeof(double)));
+    const size_t row_bytes = size_t(d) * esz;
+    if (row_bytes % 16 == 0 && (reinterpret_cast<uintptr_t>(ctx->X) & 15) == 0) {
+        const int c16 = int(row_bytes / 16);
+        hipLaunchKernelGGL(gather_points16_kernel, dim3((unsigned)ceil_div64(n * c16, 256)), dim3(256), 0, ctx->stream,
+                           (const uint4*)ctx->X, ctx->xn.as<double>(), perm, n, c16, k->Xs.as<uint4>(), k->xns.as<double>());
+    } else if (ctx->dtype == GT_F32) {
+        hipLaunchKernelGGL(gather_points_kernel<float>, dim3((unsigned)ceil_div64(n * d, 256)), dim3(256), 0, ctx->stream,
+                           (const float*)ctx->X, ctx->xn.as<double>(), perm, n, d, k->Xs.as<float>(), k->xns.as<double>());
+    } else {
+        hipLaunchKernelGGL(gather_points_kernel<double>, dim3((unsigned)ceil_div64(n * d, 256)), dim3(256), 0, ctx->stream,
+                           (const double*)ctx->X, ctx->xn.as<double>(), perm, n, d, k->Xs.as<double>(), k->xns.as<double>());
+    }
+    GT_HIP(ctx, hipGetLastError());
+    k->xs_ready = true;
+    return GT_OK;
+}
+
 int gt_sym_thresholds(gt_ctx* ctx, const int32_t* perm, int64_t n_pad_s, const float* hs, const uint64_t* lists, int lstride,
                       const uint32_t* counts, int need_m, const ErrModel& err, double rkf, float* thr, float* g, float* gmin,
                       const DevBuf& work, int cells, unsigned long long* far_total, float* farcnt, int64_t p_first,
@@ -1064,14 +1130,19 @@ int gt_sym_thresholds(gt_ctx* ctx, const int32_t* perm, int64_t n_pad_s, const f
     const int M = std::min(std::min(cells, 32), ctx->order_L);
     const int32_t* nbr = work.as<int32_t>();
     const uint32_t* cell_sorted = ctx->order_cell.as<uint32_t>() + ctx->n;
+    // the points in sorted order, when the caller has made the copy (gt_sym_gather_points)
+    const KnnWork* kw = ctx->knn;
+    const bool sorted = kw && kw->xs_ready;
+    const void* Xp = sorted ? kw->Xs.p : ctx->X;
+    const double* xnp = sorted ? kw->xns.as<double>() : ctx->xn.as<double>();
     if (ctx->dtype == GT_F32)
         hipLaunchKernelGGL(sym_thresholds_kernel<float>, grid, dim3(256), 0, ctx->stream, ctx->n, p_first, p_last, perm,
-                           (const float*)ctx->X, ctx->d, ctx->xn.as<double>(), hs, lists, lstride, counts, need_m,
-                           ctx->ymax.as<double>(), err, rkf, thr, g, cell_sorted, nbr, M, far_total, farcnt);
+                           (const float*)Xp, ctx->d, xnp, hs, lists, lstride, counts, need_m, ctx->ymax.as<double>(), err, rkf,
+                           thr, g, cell_sorted, nbr, M, far_total, farcnt, sorted ? 1 : 0);
     else
         hipLaunchKernelGGL(sym_thresholds_kernel<double>, grid, dim3(256), 0, ctx->stream, ctx->n, p_first, p_last, perm,
-                           (const double*)ctx->X, ctx->d, ctx->xn.as<double>(), hs, lists, lstride, counts, need_m,
-                           ctx->ymax.as<double>(), err, rkf, thr, g, cell_sorted, nbr, M, far_total, farcnt);
+                           (const double*)Xp, ctx->d, xnp, hs, lists, lstride, counts, need_m, ctx->ymax.as<double>(), err, rkf,
+                           thr, g, cell_sorted, nbr, M, far_total, farcnt, sorted ? 1 : 0);
     GT_HIP(ctx, hipGetLastError());
     if (gmin) {
         hipLaunchKernelGGL(sym_gmin_kernel, dim3((unsigned)ceil_div64(n_pad_s, 256)), dim3(256), 0, ctx->stream, n_pad_s, g, gmin);

@@ -116,7 +116,7 @@ int gt_set_option(gt_ctx* ctx, const char* name, const char* value);
 int gt_last_knn_precision(const gt_ctx* ctx);
 /* statistics of the most recent kNN candidate search: out[0] = 1 if the symmetric pass ran, out[1] = rows whose
  * symmetric lists overflowed (repaired), out[2] = rows repaired in all, out[3] = of those by the exhaustive kernel,
- * out[4..11] = counters of the symmetric pass: [6] work items per query block, [9] tiles visited by the seeding launch,
+ * out[4..11] = counters of the symmetric pass: [6] work items per query block, [7] bit 0 two-stage collect, bit 1 dense seeding kernel (gt_seed.hip), [9] tiles visited by the seeding launch,
  * the others list lengths (rerank_sym_kernel, only with dbg_select bit 256) */
 int gt_knn_stats(const gt_ctx* ctx, int64_t* out12);
 
