@@ -111,6 +111,7 @@ _SIGNATURES = {
     "gt_dev_upload": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_size_t]),
     "gt_dev_download": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_size_t]),
     "gt_dev_sync": (_c.c_int, [_c.c_void_p]),
+    "gt_stream_order": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int32]),
 }
 
 
@@ -627,3 +628,11 @@ class Context:
 
     def sync(self):
         self._check(self.lib.gt_dev_sync(self.h), "gt_dev_sync")
+
+    def wait_for_stream(self, stream_handle):
+        """the context's later work waits (on the device, not the host) for what ``stream_handle`` holds now"""
+        self._check(self.lib.gt_stream_order(self.h, ctypes.c_void_p(int(stream_handle)), 0), "gt_stream_order")
+
+    def stream_waits_for_me(self, stream_handle):
+        """``stream_handle`` waits for everything the context has queued so far"""
+        self._check(self.lib.gt_stream_order(self.h, ctypes.c_void_p(int(stream_handle)), 1), "gt_stream_order")

@@ -423,4 +423,20 @@ int gt_dev_sync(gt_ctx* ctx) {
     return GT_OK;
 }
 
+// Order the context's stream against a stream of the caller (a collective library's, torch's current stream) without
+// blocking the host: direction 0 = the context's later work waits for what the caller's stream holds now, 1 = the caller's
+// stream waits for what the context has queued so far.
+int gt_stream_order(gt_ctx* ctx, void* other_stream, int32_t direction) {
+    if (!ctx) return GT_E_ARG;
+    GT_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t other = static_cast<hipStream_t>(other_stream);   // (nullptr: the legacy default stream)
+    hipEvent_t ev;
+    GT_HIP(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    hipError_t e = hipEventRecord(ev, direction == 0 ? other : ctx->stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(direction == 0 ? ctx->stream : other, ev, 0);
+    (void)hipEventDestroy(ev);   // (released once the wait has been satisfied)
+    GT_HIP(ctx, e);
+    return GT_OK;
+}
+
 }  // extern "C"

@@ -45,6 +45,7 @@ struct KnnWork {
     int sym_frame = 0;                            //   frame of stage one: 0 coordinate axes, 1 principal directions
     bool sym_two_used = false;                    //   the last symmetric pass ran the two-stage collect
     bool sym_used = false;
+    int sh_lstride = 512;                         //   stride of the seeding lists of the sharded pass (64: dense kernel)
     bool sym_seed_dense = false;                  //   the last seeding launch ran as dense cell blocks (gt_seed.hip)
     int64_t sym_overflow = 0;
     int sym_nseg = 1;

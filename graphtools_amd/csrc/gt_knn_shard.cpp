@@ -114,7 +114,8 @@ int gt_knn_shard_seed(gt_ctx* ctx, float* thr_local, int64_t* far_local, double*
     GT_HIP(ctx, k->sym_tile_cnt.reserve(size_t(n_pad_s / bq) * sizeof(int32_t)));
     {
         StageSpan span(ctx, "sym_prepare");
-        GT_TRY(gt_sym_gather(ctx, perm, n_pad_s, k->Ycs.p, k->hnegs.as<float>()));
+        GT_HIP(ctx, k->hnegs_fin.reserve(size_t(n_pad_s) * sizeof(float)));
+        GT_TRY(gt_sym_gather(ctx, perm, n_pad_s, k->Ycs.p, k->hnegs.as<float>(), k->hnegs_fin.as<float>()));
         if (ctx->sym_sorted_points != 0) GT_TRY(gt_sym_gather_points(ctx, perm));
         GT_TRY(gt_sym_schedule(ctx, n_pad_s, bq, bn, ctx->sym_cells, stride_a, ctx->sym_max_nb, tile_stride, k->sym_work,
                                k->sym_tiles.as<int32_t>(), k->sym_tile_cnt.as<int32_t>(),
@@ -122,7 +123,13 @@ int gt_knn_shard_seed(gt_ctx* ctx, float* thr_local, int64_t* far_local, double*
     }
     // the lists of launch A are addressed by sorted position: a base pointer p0 rows before the buffer keeps the
     // kernels' indexing (only positions [p0, p1) are touched)
-    uint64_t* lists0 = k->lists.as<uint64_t>() - size_t(p0) * lcap;
+    // dense cell blocks with the keys in registers (gt_seed.hip) as in the single-rank pass, or the streaming lists; the dense
+    // kernel files exactly need_m keys per row at a stride of 64
+    const bool dense_seed = ctx->sym_dense_seed != 0 && need_m <= 64 && tile_stride <= 1024 && n_pad_s % 256 == 0 &&
+                            p0 % 128 == 0 && p1 % 128 == 0;
+    const size_t lstride = dense_seed ? size_t(64) : lcap;
+    k->sh_lstride = int(lstride);
+    uint64_t* lists0 = k->lists.as<uint64_t>() - size_t(p0) * lstride;
     ErrModel em = gt_err_model(ctx, 2);
     em.rel += 8.0 * 5.9604644775390625e-08;   // as in the single-rank pass (gt_knn.cpp)
     if (p1 > p0) {
@@ -167,10 +174,16 @@ int gt_knn_shard_seed(gt_ctx* ctx, float* thr_local, int64_t* far_local, double*
         a.final_keep = need_m;
         {
             StageSpan span(ctx, "sym_seed");
-            GT_TRY(gt_launch_select(ctx, a));
+            if (dense_seed)
+                GT_TRY(gt_sym_seed_dense(ctx, ctx->DP, k->Ycs.p, k->hnegs_fin.as<float>(), ctx->n, n_pad_s, k->sym_tiles.as<int32_t>(),
+                                         k->sym_tile_cnt.as<int32_t>(), tile_stride, bq, p0 / 128, (p1 - p0) / 128, need_m, lists0,
+                                         int(lstride), k->counts.as<uint32_t>()));
+            else
+                GT_TRY(gt_launch_select(ctx, a));
         }
+        k->sym_seed_dense = dense_seed;
         StageSpan span(ctx, "sym_prepare");
-        GT_TRY(gt_sym_thresholds(ctx, perm, n_pad_s, k->hnegs.as<float>(), lists0, int(lcap), k->counts.as<uint32_t>(), need_m,
+        GT_TRY(gt_sym_thresholds(ctx, perm, n_pad_s, k->hnegs.as<float>(), lists0, int(lstride), k->counts.as<uint32_t>(), need_m,
                                  em, std::max(1.0, std::fabs(k->sh_rkf)), k->thr_final.as<float>(), k->sym_g.as<float>(),
                                  nullptr, k->sym_work, ctx->sym_cells, k->sym_stat.as<unsigned long long>() + 2,
                                  k->sym_farcnt.as<float>(), p0, p1));
@@ -237,7 +250,7 @@ int gt_knn_shard_collect(gt_ctx* ctx, const float* thr_all, int64_t far_total, c
         if (cut) {
             // the orphans among the rows THIS rank seeded start their lists with the rows launch A kept for them; they
             // travel to the owners with the other records
-            const size_t lcap = size_t(64) * 8;
+            const size_t lcap = size_t(k->sh_lstride);
             GT_TRY(gt_sym_inject_orphans(ctx, k->sh_p0, k->sh_p1, k->thr_final.as<float>(),
                                          k->lists.as<uint64_t>() - size_t(k->sh_p0) * lcap, int(lcap), k->counts.as<uint32_t>(),
                                          k->tlists.as<uint64_t>(), tcap, k->tcounts.as<uint32_t>()));

@@ -128,6 +128,23 @@ def allgather_vector(v_local, splits, group=None):
     return allgather_rows(v_local.reshape(-1, 1), splits, group).reshape(-1)
 
 
+def _order_after_collectives(ctx, tensor):
+    """The library runs on its own stream: what a collective wrote into ``tensor`` (complete with respect to torch's
+    current stream) has to be ordered before the library's next launch - on the device, without stalling the host."""
+    if tensor.is_cuda and hasattr(ctx, "wait_for_stream"):
+        import torch
+
+        ctx.wait_for_stream(torch.cuda.current_stream(tensor.device).cuda_stream)
+
+
+def _order_before_collectives(ctx, tensor):
+    """... and the other way round: what the library has queued into ``tensor`` comes before the collective that sends it"""
+    if tensor.is_cuda and hasattr(ctx, "stream_waits_for_me"):
+        import torch
+
+        ctx.stream_waits_for_me(torch.cuda.current_stream(tensor.device).cuda_stream)
+
+
 class ShardedKnnGraph(object):
     """One rank's share of a row-sharded kNN graph build.
 
@@ -150,8 +167,7 @@ class ShardedKnnGraph(object):
         import torch
 
         full = allgather_rows(x_local, self.splits, self.group)
-        if full.is_cuda:
-            torch.cuda.synchronize(full.device)
+        _order_after_collectives(self.ctx, full)
         self._points = full
         self.ctx.set_points_device(full.data_ptr(), full.shape[0], full.shape[1],
                                    np.float32 if full.dtype == torch.float32 else np.float64)
@@ -181,20 +197,20 @@ class ShardedKnnGraph(object):
         rows = int(sorted_splits[self.rank + 1] - sorted_splits[self.rank])
         thr_local = torch.empty((max(rows, 1), 2), dtype=torch.float32, device=device)   # {threshold, far-kept seeds}
         stats = ctx.graph_sym_seed(thr_local.data_ptr())      # [far-kept rows, four sums behind the orphan cut]
+        _order_before_collectives(ctx, thr_local)
         thr_all = allgather_rows(thr_local[:rows], sorted_splits, self.group).contiguous()
         stats_t = torch.as_tensor(np.asarray(stats, dtype=np.float64), device=device)
         dist.all_reduce(stats_t, group=self.group)            # every rank receives the same sums
-        if thr_all.is_cuda:
-            torch.cuda.synchronize(device)
+        _order_after_collectives(ctx, thr_all)
         ok, send_counts = ctx.graph_sym_collect(thr_all.data_ptr(), stats_t.cpu().numpy(), self.world)
         if not ok:      # the predictor saw the summed count: the same verdict on every rank
             return False
         total = int(send_counts.sum())
         send = torch.empty(max(total, 1) * WORDS_PER_TRIPLET, dtype=torch.int64, device=device)
         ctx.graph_sym_emit(send.data_ptr() if total > 0 else 0)
+        _order_before_collectives(ctx, send)
         recv, recv_counts = exchange_triplets(send[: total * WORDS_PER_TRIPLET], send_counts, self.group)
-        if recv.is_cuda:
-            torch.cuda.synchronize(device)
+        _order_after_collectives(ctx, recv)
         n_recv = int(recv_counts.sum())
         ctx.graph_sym_finish(recv.data_ptr() if n_recv > 0 else 0, n_recv)
         return True
@@ -214,18 +230,18 @@ class ShardedKnnGraph(object):
         send = torch.empty(max(total, 1) * WORDS_PER_TRIPLET, dtype=torch.int64, device=device)
         if total > 0:
             ctx.graph_emit(send.data_ptr())
+        _order_before_collectives(ctx, send)
         recv, recv_counts = exchange_triplets(send[: total * WORDS_PER_TRIPLET], send_counts, self.group)
-        if recv.is_cuda:
-            torch.cuda.synchronize(device)
+        _order_after_collectives(ctx, recv)
         n_recv = int(recv_counts.sum())
         nnz, flags = ctx.graph_finish(recv.data_ptr() if n_recv > 0 else 0, n_recv)
         if params.anisotropy != 0.0 and self.world > 1:
             nloc = int(self.splits[self.rank + 1] - self.splits[self.rank])
             deg = torch.empty(nloc, dtype=torch.float64, device=device)
-            ctx._check(ctx.lib.gt_graph_fetch_vec(ctx.h, 1, deg.data_ptr(), 1), "gt_graph_fetch_vec")
+            ctx.graph_fetch_vec_device(1, deg.data_ptr())      # the owned rows' kernel degrees, device to device
+            _order_before_collectives(ctx, deg)
             deg_all = allgather_vector(deg, self.splits, self.group).contiguous()
-            if deg_all.is_cuda:
-                torch.cuda.synchronize(device)
+            _order_after_collectives(ctx, deg_all)
             ctx.graph_anisotropy(deg_all.data_ptr())
         self._keep = (send, recv)
         return nnz, flags
@@ -237,8 +253,10 @@ class ShardedKnnGraph(object):
         dist = _dist()
         M, R, tnnz = self.ctx.landmark_build(clusters, n_landmark)
         device = self._points.device
-        Mt = torch.as_tensor(M, device=device)
-        Rt = torch.as_tensor(R, device=device)
-        dist.all_reduce(Mt, group=self.group)
-        dist.all_reduce(Rt, group=self.group)
-        return self.ctx.landmark_scale(Mt.cpu().numpy(), Rt.cpu().numpy()), tnnz
+        L = int(n_landmark)
+        # ONE all-reduce: the L x L partial products with the L partial row sums appended
+        buf = torch.as_tensor(np.concatenate([np.asarray(M, dtype=np.float64).ravel(), np.asarray(R, dtype=np.float64)]),
+                              device=device)
+        dist.all_reduce(buf, group=self.group)
+        tot = buf.cpu().numpy()
+        return self.ctx.landmark_scale(tot[: L * L].reshape(L, L), tot[L * L:]), tnnz

@@ -334,6 +334,10 @@ int gt_dev_free(gt_ctx* ctx, void* p);
 int gt_dev_upload(gt_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
 int gt_dev_download(gt_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
 int gt_dev_sync(gt_ctx* ctx);
+/* order the context's stream against a stream of the caller without blocking the host (multi-GPU host code: the
+ * collectives of graphtools_amd/dist.py run on torch's streams): direction 0 = the context's later work waits for
+ * everything queued on `other_stream` so far, 1 = `other_stream` waits for everything the context has queued so far */
+int gt_stream_order(gt_ctx* ctx, void* other_stream, int32_t direction);
 
 #ifdef __cplusplus
 }

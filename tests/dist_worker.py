@@ -2,8 +2,9 @@
 
 The HIP library is replaced by ``FakeCtx`` - a numpy stand-in for gt_graph_begin/emit/finish built on the
 oracle (test infrastructure) - so that the HOST orchestration of the row-sharded build
-(graphtools_amd/dist.py: splits, point all-gather, triplet all-to-all, merge order) is exercised end to end
-without a GPU.  The device kernels themselves are covered by the -m gpu tests."""
+(graphtools_amd/dist.py: splits, point all-gather, threshold all-gather / record all-to-all of the symmetric pass,
+triplet all-to-all, merge order, degree all-gather of the anisotropic kernel, all-reduce of the landmark operator)
+is exercised end to end without a GPU.  The device kernels themselves are covered by the -m gpu tests."""
 import ctypes
 import os
 import sys
@@ -159,6 +160,37 @@ class FakeCtx(object):
         self.K.sort_indices()
         return self.K.nnz, 0
 
+    # ---- anisotropy: the degrees of ALL rows are needed (dist.py all-gathers the owned slices) ----
+    def graph_fetch_vec_device(self, which, ptr):
+        assert which == 1
+        self.calls = self.calls + ("fetch_degree",)
+        nloc = self.r1 - self.r0
+        out = np.frombuffer((ctypes.c_char * (nloc * 8)).from_address(ptr), dtype=np.float64)
+        out[:] = np.asarray(self.K.sum(axis=1)).ravel()
+
+    def graph_anisotropy(self, ptr):
+        self.calls = self.calls + ("anisotropy",)
+        n = self.X.shape[0]
+        d = np.frombuffer((ctypes.c_char * (n * 8)).from_address(ptr), dtype=np.float64).copy()
+        K = self.K.tocoo()
+        K.data = K.data / ((d[K.row + self.r0] * d[K.col]) ** self.p.anisotropy)
+        self.K = sparse.csr_matrix(K)
+        self.K.sort_indices()
+
+    # ---- landmark operator: partial L x L products of the owned rows (gt_landmark.hip) ----
+    def landmark_build(self, clusters, n_landmark):
+        self.calls = self.calls + ("landmark_build",)
+        n = self.X.shape[0]
+        S = sparse.csr_matrix((np.ones(n), (np.asarray(clusters), np.arange(n))), shape=(n_landmark, n))
+        T = np.asarray((self.K @ S.T).todense())            # [nloc, L]: row i of K summed per cluster
+        c = T.sum(axis=1)
+        M = T.T @ (T / c[:, None])
+        return M, T.sum(axis=0), int((T != 0).sum())
+
+    def landmark_scale(self, M, R):
+        self.calls = self.calls + ("landmark_scale",)
+        return np.asarray(M) / np.asarray(R)[:, None]
+
 
 def main():
     dist.init_process_group("gloo")
@@ -230,6 +262,30 @@ def main():
         K_full = sparse.csr_matrix(oracle.knn_graph(Xg, knn=10, decay=20, kernel_symm="+")[0])
         K_full.sort_indices()
         assert (c.K != K_full[g.splits[rank]:g.splits[rank + 1]]).nnz == 0
+    # 6. anisotropy: the owned degrees are all-gathered (fourth collective), then applied to the owned block
+    g = gdist.ShardedKnnGraph(FakeCtx(), Xg.shape[0])
+    g.gather_points(torch.from_numpy(Xg[g.splits[rank]:g.splits[rank + 1]].copy()))
+    g.build(FakeParams(10, 20, 1e-4, "+", anisotropy=0.5))
+    assert g.ctx.calls[-2:] == ("fetch_degree", "anisotropy"), g.ctx.calls
+    K_an = sparse.csr_matrix(oracle.knn_graph(Xg, knn=10, decay=20, kernel_symm="+", anisotropy=0.5)[0])
+    K_an.sort_indices()
+    blk = K_an[g.splits[rank]:g.splits[rank + 1]]
+    assert np.array_equal(blk.indptr, g.ctx.K.indptr) and np.array_equal(blk.indices, g.ctx.K.indices)
+    np.testing.assert_allclose(g.ctx.K.data, blk.data, rtol=1e-13, atol=0)
+
+    # 7. landmark operator: all-reduce (fifth collective) of the partial L x L products and row sums
+    g = gdist.ShardedKnnGraph(FakeCtx(), Xg.shape[0])
+    g.gather_points(torch.from_numpy(Xg[g.splits[rank]:g.splits[rank + 1]].copy()))
+    g.build(FakeParams(10, 20, 1e-4, "+"))
+    L = 12
+    clusters = np.random.default_rng(77).integers(0, L, size=Xg.shape[0])
+    clusters[:L] = np.arange(L)     # every label occurs
+    op, tnnz = g.landmark_operator(clusters, L)
+    assert g.ctx.calls[-2:] == ("landmark_build", "landmark_scale")
+    K_full = sparse.csr_matrix(oracle.knn_graph(Xg, knn=10, decay=20, kernel_symm="+")[0])
+    op_ref, _ = oracle.landmark_operator(K_full, clusters)
+    np.testing.assert_allclose(op, op_ref, rtol=1e-12, atol=1e-300)
+    np.testing.assert_allclose(op.sum(axis=1), 1.0, rtol=1e-12)
     dist.barrier()
     dist.destroy_process_group()
     print("rank %d ok" % rank)

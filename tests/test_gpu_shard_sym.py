@@ -231,3 +231,51 @@ def test_every_rank_runs_the_same_collect_kernel(opts, what):
     kinds = {(bool(s[0].get("sym_two_stage")), bool(s[0].get("sym_bound_pass"))) for s in stats}
     assert len(kinds) == 1, (what, kinds)
     _same(got, single_build(X, pargs, False))
+
+
+def test_host_flow_over_rccl_world_one():
+    """graphtools_amd/dist.py itself on the GPU: a one-rank RCCL group runs every collective of the sharded build (points
+    all-gather, threshold all-gather / record all-to-all of the staged symmetric pass, triplet all-to-all) on torch's
+    streams, ordered against the library's stream by gt_stream_order instead of host synchronisation.  The rows must equal
+    the direct single-rank build."""
+    import os
+    import socket
+
+    import torch
+    import torch.distributed as dist
+
+    from graphtools_amd import _hip
+    from graphtools_amd import dist as gdist
+
+    X = make_mix(60000, 24, 5)
+    pargs = (10, 20.0, 1e-4, None, 1.0, None, "+", None, 0)
+    ref = _ctx({})
+    ref.set_points(X)
+    p, keep = ref.make_params(*pargs)
+    ref.graph_build(p)
+    kd, ki, kp = ref.graph_fetch_csr(_hip.CSR_K)
+    pd, _, _ = ref.graph_fetch_csr(_hip.CSR_P, structure=False)
+    ref.close()
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ["GT_SHARD_SYM_FORCE"] = "1"      # the staged symmetric pass although there is one rank
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, world_size=1, rank=0)
+    try:
+        device = torch.device("cuda", 0)
+        ctx = _ctx({})
+        g = gdist.ShardedKnnGraph(ctx, X.shape[0])
+        g.gather_points(torch.from_numpy(X).to(device))
+        p2, keep2 = ctx.make_params(*pargs)
+        nnz, _ = g.build(p2)
+        assert g.symmetric_used
+        d2, i2, p2_ = ctx.graph_fetch_csr(_hip.CSR_K)
+        pd2, _, _ = ctx.graph_fetch_csr(_hip.CSR_P, structure=False)
+        assert np.array_equal(p2_, kp) and np.array_equal(i2, ki)
+        assert np.array_equal(d2, kd) and np.array_equal(pd2, pd)
+        ctx.close()
+    finally:
+        os.environ.pop("GT_SHARD_SYM_FORCE", None)
+        dist.destroy_process_group()
