@@ -198,27 +198,92 @@ class Data(object):
                 raise ValueError("Expected 2D array, got {}D array instead".format(data.ndim))
         if min(data.shape) == 0:
             raise ValueError("Found array with 0 sample(s) or feature(s): {}".format(data.shape))
-        if n_pca in (None, 0, False):
-            n_pca = None
-        elif n_pca is True or isinstance(n_pca, str):
-            raise NotImplementedError("n_pca='auto' (rank estimation) is not supported by graphtools_amd")
-        elif not isinstance(n_pca, numbers.Integral) or n_pca < 0:
-            raise ValueError("n_pca was not an instance of numbers.Number, could not be cast to False, and not None. "
-                             "Please supply an integer 0 <= n_pca < min(n_samples,n_features) or None")
-        elif n_pca >= min(data.shape):
-            warnings.warn(
-                "Cannot perform PCA to {} dimensions on data with min(n_samples, n_features) = {}".format(
-                    n_pca, min(data.shape)),
-                RuntimeWarning,
-            )
-            n_pca = None
+        n_pca, rank_threshold = self._resolve_n_pca(data.shape, n_pca, rank_threshold)
         self.data = data
         self.n_pca = n_pca
         self.rank_threshold = rank_threshold
         self.random_state = random_state
         self.data_nu = self._reduce_data()
 
+    @staticmethod
+    def _resolve_n_pca(shape, n_pca, rank_threshold):
+        """The accepted forms of ``n_pca`` / ``rank_threshold`` and their warnings (reference: base.py:137-213): an integer
+        (fractions are rounded, too large a value switches the reduction off), None / 0 / False (no reduction), True /
+        "auto" (rank estimate from the singular values, see ``_reduce_data``)."""
+        bad = ValueError("n_pca was not an instance of numbers.Number, could not be cast to False, and not None. "
+                         "Please supply an integer 0 <= n_pca < min(n_samples,n_features) or None")
+        if isinstance(n_pca, str):
+            if n_pca.lower() != "auto":
+                raise ValueError("n_pca must be an integer 0 <= n_pca < min(n_samples,n_features), "
+                                 "or in [None, False, True, 'auto'].")
+            n_pca = "auto"
+        elif n_pca is True:
+            n_pca = "auto"
+        elif n_pca is None or n_pca is False:
+            n_pca = None
+        elif isinstance(n_pca, numbers.Number):
+            if not float(n_pca).is_integer():
+                rounded = int(np.round(n_pca))
+                warnings.warn("Cannot perform PCA to fractional {} dimensions. Rounding to {}".format(n_pca, rounded),
+                              RuntimeWarning)
+                n_pca = rounded
+            n_pca = int(n_pca)
+            if n_pca < 0:
+                raise ValueError("n_pca cannot be negative. Please supply an integer "
+                                 "0 <= n_pca < min(n_samples,n_features) or None")
+            if n_pca >= min(shape):
+                warnings.warn("Cannot perform PCA to {} dimensions on data with min(n_samples, n_features) = {}".format(
+                    n_pca, min(shape)), RuntimeWarning)
+                n_pca = None
+            elif n_pca == 0:
+                n_pca = None
+        else:
+            raise bad
+        if n_pca != "auto":
+            if rank_threshold is not None:
+                warnings.warn("n_pca = {}, therefore rank_threshold of {} will not be used. To use rank thresholding, "
+                              "set n_pca = True".format(n_pca, rank_threshold), RuntimeWarning)
+            return n_pca, rank_threshold
+        if rank_threshold is None:
+            rank_threshold = "auto"
+        elif isinstance(rank_threshold, str):
+            rank_threshold = rank_threshold.lower()
+        ok = rank_threshold == "auto" or (isinstance(rank_threshold, numbers.Number) and rank_threshold > 0)
+        if not ok:
+            raise ValueError("rank_threshold must be positive float or 'auto'. ")
+        return n_pca, rank_threshold
+
+    def _reduce_auto(self):
+        """n_pca = "auto": all but one principal direction, then only those whose singular value reaches the threshold
+        (default: largest singular value x machine epsilon of the data's dtype x the larger dimension) are kept
+        (reference: base.py:243-283).  Solved by scikit-learn on the host, as in the reference - the rank estimate needs the
+        whole spectrum, which is not what the device solver (a few leading components of a tall matrix) is for."""
+        from sklearn.decomposition import PCA, TruncatedSVD
+
+        k = self.data.shape[1] - 1
+        if sparse.issparse(self.data):
+            if not isinstance(self.data, (sparse.csr_matrix, sparse.csc_matrix)):
+                self.data = self.data.tocsr()
+            op = TruncatedSVD(k, random_state=self.random_state)
+        else:
+            op = PCA(k, svd_solver="randomized", random_state=self.random_state)
+        op.fit(self.data)
+        sv = op.singular_values_
+        if self.rank_threshold == "auto":
+            self.rank_threshold = sv.max() * np.finfo(self.data.dtype).eps * max(self.data.shape)
+        keep = np.flatnonzero(sv >= self.rank_threshold)
+        if keep.size == 0:
+            raise ValueError("Supplied threshold {} was greater than maximum singular value {} for the data matrix".format(
+                self.rank_threshold, sv.max()))
+        self.n_pca = int(keep.size)
+        for name in ("components_", "explained_variance_", "explained_variance_ratio_", "singular_values_"):
+            setattr(op, name, getattr(op, name)[keep])
+        self.data_pca = op
+        return op.transform(self.data)
+
     def _reduce_data(self):
+        if self.n_pca == "auto":
+            return self._reduce_auto()
         if self.n_pca is None:
             d = self.data
             if sparse.issparse(d):

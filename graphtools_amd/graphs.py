@@ -547,19 +547,26 @@ class LandmarkGraph(DataGraph):
     def build_landmark_op(self):
         """Landmark operator and sample-to-landmark transitions (reference: graphs.py:1187-1246)."""
         self.K
-        if not sparse.issparse(self._kernel):
-            raise NotImplementedError(
-                "graphtools_amd: the landmark operator is accelerated for kNN (sparse) kernels only"
-            )
+        dense = not sparse.issparse(self._kernel)
         if not hasattr(self, "_clusters"):
             self._clusters = self._assign_clusters()
         landmarks, inverse = np.unique(self._clusters, return_inverse=True)
         L = len(landmarks)
-        self._ensure_device_graph()
+        if dense:
+            # an exact (dense) kernel: its non-zeros are handed to the device as they are (no symmetrisation, no anisotropy -
+            # K is final), the landmark products then run as for a kNN kernel; the reference returns dense transitions here
+            # (K is symmetric already: the "+" rule returns (a + a) / 2 = a exactly and tells the library so)
+            Ks = sparse.csr_matrix(np.asarray(self._kernel, dtype=np.float64))
+            self.hip.csr_graph_build(Ks, "+" if self.kernel_symm is not None else None, None, 0, assume_unique=True)
+            self._device_state = None   # (the context now holds this copy, not what _ensure_device_graph expects)
+        else:
+            self._ensure_device_graph()
         M, R, tnnz = self.hip.landmark_build(inverse.astype(np.int32), L)
         self._landmark_op = self.hip.landmark_scale(M, R)
         data, indices, indptr = self.hip.landmark_fetch_transitions(tnnz)
         self._transitions = sparse.csr_matrix((data, indices, indptr), shape=(self.data.shape[0], L))
+        if dense:
+            self._transitions = self._transitions.toarray()
 
 
 class TraditionalGraph(DataGraph):
@@ -624,6 +631,16 @@ class TraditionalGraph(DataGraph):
             raise ValueError("Cannot update bandwidth_scale. Please create a new graph")
         super().set_params(**params)
         return self
+
+    def _bind_points(self):
+        """the points on the device (random landmark assignment, graphs.py:1200-1213)"""
+        if self.precomputed is not None:
+            raise ValueError("random landmarking needs the points: the graph was built from a precomputed matrix")
+        X = self.data_nu.toarray() if sparse.issparse(self.data_nu) else np.ascontiguousarray(self.data_nu)
+        if X.dtype not in (np.float32, np.float64):
+            X = X.astype(np.float64)
+        self.hip.set_option("metric", "euclidean")
+        self.hip.set_points(X)
 
     def _build_kernel(self):
         data = self.data_nu

@@ -124,3 +124,16 @@ def test_exact_graph_with_the_cosine_metric():
     assert np.array_equal(G.K == 0, z["K"] == 0)
     np.testing.assert_allclose(G.K, z["K"], rtol=1e-9, atol=0)
     np.testing.assert_allclose(G.P, z["P"], rtol=1e-9, atol=0)
+
+
+def test_landmark_operator_of_an_exact_graph():
+    """TraditionalLandmarkGraph (reference graphs.py:1169-1246 on a dense kernel): the non-zeros of K go through the device's
+    landmark products; transitions come back dense like the reference's"""
+    z = load_golden("g15_exact_landmark")
+    G = _graph(z["X"], knn=int(z["knn"]), decay=float(z["decay"]), graphtype="exact", n_landmark=int(z["n_landmark"]),
+               random_landmarking=True, random_state=int(z["random_state"]))
+    assert type(G).__name__ == "TraditionalLandmarkGraph"
+    assert np.array_equal(G.clusters, z["clusters"])
+    np.testing.assert_allclose(G.landmark_op, z["landmark_op"], rtol=1e-9, atol=1e-15)
+    assert isinstance(G.transitions, np.ndarray) and G.transitions.shape == z["transitions"].shape
+    np.testing.assert_allclose(G.transitions, z["transitions"], rtol=1e-9, atol=1e-15)

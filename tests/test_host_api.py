@@ -145,3 +145,40 @@ def test_pca_backend_selection_is_host_logic():
     rng = np.random.default_rng(0)
     D = base.Data(rng.standard_normal((200, 30)).astype(np.float32), n_pca=5, random_state=0)
     assert type(D.data_pca).__name__ == "PCA" and D.data_nu.shape == (200, 5)
+
+
+def test_n_pca_rank_estimate():
+    """n_pca=True / "auto" (reference base.py:137-283): all but one direction, gated by the singular values"""
+    from graphtools_amd.base import Data
+
+    rng = np.random.default_rng(0)
+    A = rng.standard_normal((300, 6)) @ rng.standard_normal((6, 20))     # rank 6
+    for flag in (True, "auto", "AUTO"):
+        d = Data(A, n_pca=flag)
+        assert d.n_pca == 6 and d.data_nu.shape == (300, 6)
+        assert d.data_pca.components_.shape == (6, 20) and d.data_pca.singular_values_.shape == (6,)
+        # default threshold: largest singular value x eps of the dtype x the larger dimension
+        s0 = d.data_pca.singular_values_.max()
+        assert d.rank_threshold == pytest.approx(s0 * np.finfo(np.float64).eps * 300)
+    sv = Data(A, n_pca=True).data_pca.singular_values_
+    d = Data(A, n_pca="auto", rank_threshold=float(sv[2]) * 0.999)
+    assert d.n_pca == 3
+    with pytest.raises(ValueError, match="greater than maximum singular value"):
+        Data(A, n_pca=True, rank_threshold=float(sv[0]) * 10)
+    with pytest.raises(ValueError, match="rank_threshold must be positive float or 'auto'"):
+        Data(A, n_pca=True, rank_threshold=-1.0)
+    with pytest.raises(ValueError, match="rank_threshold must be positive float or 'auto'"):
+        Data(A, n_pca=True, rank_threshold="big")
+    with pytest.raises(ValueError, match="or in \\[None, False, True, 'auto'\\]"):
+        Data(A, n_pca="all")
+    with pytest.warns(RuntimeWarning, match="Rounding to 5"):
+        assert Data(A, n_pca=4.6).n_pca == 5
+    with pytest.warns(RuntimeWarning, match="rank_threshold of 0.5 will not be used"):
+        Data(A, n_pca=3, rank_threshold=0.5)
+    with pytest.raises(ValueError, match="n_pca cannot be negative"):
+        Data(A, n_pca=-2)
+    from scipy import sparse
+
+    S = sparse.random(200, 30, density=0.2, random_state=1, format="coo")
+    d = Data(S, n_pca=True)
+    assert d.data_nu.shape == (200, d.n_pca) and 1 <= d.n_pca <= 29
