@@ -44,8 +44,9 @@ __device__ __forceinline__ T affinity_t(T dist, T bw, T decay, T xcut) {
 // unsymmetrised kernel entry of a precomputed matrix: 0 a distance (alpha-decay affinity), 1 an affinity (taken as is,
 // graphs.py:1532-1536), 2 an adjacency (diagonal set to 1, graphs.py:1537-1545)
 template <typename T>
-__device__ __forceinline__ T k0_t(T v, const double* __restrict__ bw, int64_t row, T decay, T xcut, int pass, bool on_diag) {
-    if (pass == 0) return affinity_t<T>(v, T(bw[row]), decay, xcut);
+__device__ __forceinline__ T k0_t(T v, T bwv, T decay, T xcut, int pass, bool on_diag) {
+    // (pass is the same for the whole launch; bwv = the row's bandwidth, loaded once by the caller)
+    if (pass == 0) return affinity_t<T>(v, bwv, decay, xcut);
     return (pass == 2 && on_diag) ? T(1) : v;
 }
 
@@ -399,10 +400,11 @@ __global__ __launch_bounds__(256) void dense_kernel_tiles(const TD* __restrict__
                     float ka[4] = {0.f, 0.f, 0.f, 0.f};
                     if (gi < n && gj0 < n) {
                         const float4 v = *reinterpret_cast<const float4*>(D + gi * n + gj0);
-                        ka[0] = k0_t<float>(v.x, bw, gi, decay, xcut, pass, gi == gj0);
-                        ka[1] = k0_t<float>(v.y, bw, gi, decay, xcut, pass, gi == gj0 + 1);
-                        ka[2] = k0_t<float>(v.z, bw, gi, decay, xcut, pass, gi == gj0 + 2);
-                        ka[3] = k0_t<float>(v.w, bw, gi, decay, xcut, pass, gi == gj0 + 3);
+                        const float bwi = float(bw[gi]);
+                        ka[0] = k0_t<float>(v.x, bwi, decay, xcut, pass, gi == gj0);
+                        ka[1] = k0_t<float>(v.y, bwi, decay, xcut, pass, gi == gj0 + 1);
+                        ka[2] = k0_t<float>(v.z, bwi, decay, xcut, pass, gi == gj0 + 2);
+                        ka[3] = k0_t<float>(v.w, bwi, decay, xcut, pass, gi == gj0 + 3);
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
                             if (ka[e] < thresh) ka[e] = 0.f;
@@ -415,10 +417,11 @@ __global__ __launch_bounds__(256) void dense_kernel_tiles(const TD* __restrict__
                     float kb[4] = {0.f, 0.f, 0.f, 0.f};
                     if (gj < n && gi0 < n) {
                         const float4 v = *reinterpret_cast<const float4*>(D + gj * n + gi0);
-                        kb[0] = k0_t<float>(v.x, bw, gj, decay, xcut, pass, gj == gi0);
-                        kb[1] = k0_t<float>(v.y, bw, gj, decay, xcut, pass, gj == gi0 + 1);
-                        kb[2] = k0_t<float>(v.z, bw, gj, decay, xcut, pass, gj == gi0 + 2);
-                        kb[3] = k0_t<float>(v.w, bw, gj, decay, xcut, pass, gj == gi0 + 3);
+                        const float bwj = float(bw[gj]);
+                        kb[0] = k0_t<float>(v.x, bwj, decay, xcut, pass, gj == gi0);
+                        kb[1] = k0_t<float>(v.y, bwj, decay, xcut, pass, gj == gi0 + 1);
+                        kb[2] = k0_t<float>(v.z, bwj, decay, xcut, pass, gj == gi0 + 2);
+                        kb[3] = k0_t<float>(v.w, bwj, decay, xcut, pass, gj == gi0 + 3);
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
                             if (kb[e] < thresh) kb[e] = 0.f;
@@ -468,7 +471,7 @@ __global__ __launch_bounds__(256) void dense_kernel_tiles(const TD* __restrict__
                 const int64_t gi = I0 + i, gj = J0 + tx;
                 TC ka = TC(0);
                 if (gi < n && gj < n) {
-                    ka = k0_t<TC>(TC(D[gi * n + gj]), bw, gi, decay, xcut, pass, gi == gj);
+                    ka = k0_t<TC>(TC(D[gi * n + gj]), TC(bw[gi]), decay, xcut, pass, gi == gj);
                     if (ka < thresh) ka = TC(0);
                 }
                 sA[i * TSP + tx] = ka;
@@ -477,7 +480,7 @@ __global__ __launch_bounds__(256) void dense_kernel_tiles(const TD* __restrict__
                 const int64_t gj = J0 + i, gi = I0 + tx;
                 TC kb = TC(0);
                 if (gi < n && gj < n) {
-                    kb = k0_t<TC>(TC(D[gj * n + gi]), bw, gj, decay, xcut, pass, gi == gj);
+                    kb = k0_t<TC>(TC(D[gj * n + gi]), TC(bw[gj]), decay, xcut, pass, gi == gj);
                     if (kb < thresh) kb = TC(0);
                 }
                 sB[i * TSP + tx] = kb;
