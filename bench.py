@@ -51,7 +51,7 @@ PROFILE_TRAFFIC = os.path.join(ROOT, "profiles", "r3_pmc_fetch_write_per_kernel.
 PROFILE_CPU_FULL = os.path.join(ROOT, "profiles", "r3_cpu_baseline_full_c3.json")
 
 STAGES = ("prep", "query_order", "sym_prepare", "sym_seed", "sym_bound", "knn_select", "sym_cold", "rerank", "fallback",
-          "radius", "affinity", "symmetrize", "normalize")
+          "radius", "affinity", "symmetrize", "normalize", "symm_bins", "symm_merge", "symm_compact")
 
 
 def make_mix(n, d, seed, dtype=np.float32):
@@ -287,9 +287,19 @@ def kernel_table(ctx, st, n, nloc, d, world, nnz, nnz0, main):
         "candidate lists in (8 B), X once, exact tables out (8 + 4 B); the row gathers come from L2/MALL")
     hbm("affinity", "bandwidth_kernel + affinity_kernel", st.mean("affinity"), nloc * tab * 12.0 + nnz0 * 8.0,
         "tables in (8 + 4 B per entry), kept values written in place")
-    hbm("symmetrize", "bin_count/bin_emit/bin_fill + sort_merge + compact (K, P)", st.mean("symmetrize"),
-        2.0 * nnz0 * 12.0 + nnz * 12.0 + nnz * 12.0 + nnz * 8.0,
-        "SURVEY 8d: read K0 and K0^T entries, write K; read K, write P")
+    if st.mean("symm_merge") > 0 and st.mean("symm_compact") > 0:
+        # the three launch groups of the symmetrisation, each priced on what IT has to move (the stage as a whole is priced
+        # on SURVEY 8d's bytes in `sparse_tail`)
+        hbm("symm_bins", "bin_count_kernel + bin_emit_kernel + bin_fill_kernel", st.mean("symm_bins"), 2.0 * nnz0 * 12.0,
+            "transpose through destination bins: K0 entries in, K0^T entries out (12 B each)")
+        hbm("symm_merge", "sort_merge_kernel (+ sort_merge_long_kernel)", st.mean("symm_merge"), 2.0 * nnz0 * 12.0 + nnz * 12.0,
+            "both halves of every union row in, merged row out")
+        hbm("symm_compact", "compact_kernel", st.mean("symm_compact"), nnz * 12.0 + nnz * 20.0,
+            "merged rows in, CSR K (4 + 8 B) and P (8 B) out")
+    else:
+        hbm("symmetrize", "symmetrise + compact (K, P)", st.mean("symmetrize"),
+            2.0 * nnz0 * 12.0 + nnz * 12.0 + nnz * 12.0 + nnz * 8.0,
+            "SURVEY 8d: read K0 and K0^T entries, write K; read K, write P")
     return rows, {"symmetric": symmetric, "two_stage": two_stage, "bound_pass": bound_pass, "knn_stats": kst}
 
 
@@ -487,7 +497,9 @@ def main():
         stats = ctx.graph_stats()
         nnz0 = int(stats["nnz_unsymmetrised"])
         rows, flags_ = kernel_table(ctx, st, n, nloc, d, world, int(nnz), nnz0, main_prec)
-        dominant = max(rows, key=lambda r: r["avg_launch_ms"])
+        # the dominant KERNEL: rows that time a group of launches ("a + b") do not compete
+        singles = [r for r in rows if " + " not in r["kernel"]] or rows
+        dominant = max(singles, key=lambda r: r["avg_launch_ms"])
         roof = {k: dominant[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_ms")}
         roof["stage"] = dominant["stage"]
         roof["share_of_step"] = dominant["avg_launch_ms"] / ms_per_step
@@ -496,7 +508,9 @@ def main():
         roof["work_per_launch"] = dominant.get("executed_flop", dominant.get("algorithmic_bytes"))
         executed = sum(r.get("executed_flop", 0.0) for r in rows)
         tail_ms = st.mean("affinity") + st.mean("symmetrize") + st.mean("normalize")
-        tail_bytes = sum(r["algorithmic_bytes"] for r in rows if r["stage"] in ("affinity", "symmetrize"))
+        # tables in / kept values out (affinity); read K0 and K0^T entries, write K; read K, write P
+        tail_bytes = (sum(r["algorithmic_bytes"] for r in rows if r["stage"] == "affinity")
+                      + 2.0 * nnz0 * 12.0 + nnz * 12.0 + nnz * 12.0 + nnz * 8.0)
         tail_counter = profiled_traffic(["bandwidth_kernel", "affinity_kernel", "bin_", "sort_merge", "compact_kernel", "scan_",
                                          "gather_counts", "scatter_", "sym_invperm", "symm_"]) if (n == 1000000 and d == 64 and world == 1) else None
         out = {

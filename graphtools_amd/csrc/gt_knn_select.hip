@@ -1231,11 +1231,115 @@ __global__ __launch_bounds__(256) void sym_queue_spill_kernel(const uint2* __res
     if (threadIdx.x < c && base_s + threadIdx.x < dense_cap) dense[base_s + threadIdx.x] = spill[i0 + threadIdx.x];
 }
 
+// Admission of one (64 queries x 32 rows) unit of the cold launch: the tests GT_ADMIT2P makes, filed with fewer
+// instructions.  The compare results are used where they are born - as 64-bit lane masks in scalar registers: counts per
+// database row are scalar popcounts, a lane's slot inside a row's batch is its prefix count in the mask (v_mbcnt) - instead of
+// being packed into per-lane bit words and unpacked again.  One returning atomic instruction reserves the batches of all
+// 32 database rows (the count of row (e, h) sits in lane e + 16 h), one more per query tile the forward lists.
+// A0 / A1: scores of the wave's two query tiles (lane (li, h): query li of the tile, database rows 8 (e >> 2) + 4 h + (e & 3)),
+// SD: the rows' seeds (removed again from what is filed under the database rows).  List order differs from GT_ADMIT2P's;
+// the re-rank does not depend on it.
+template <typename SYM>
+__device__ __forceinline__ void cold_admit(const f32x16& A0, const f32x16& A1, const f32x16& SD, const float tq0, const float tq1,
+                                           const float hq0, const float hq1, const uint32_t qpos0, const uint32_t qpos1,
+                                           const uint32_t tbase, const float* __restrict__ gglob, const bool tr_on,
+                                           const int lane, const int li, const int h, const SYM& sy) {
+    const uint32_t tcap = uint32_t(sy.tcap);
+    // ---- forward: how many of the lane's 16 rows pass each query's threshold ----
+    uint32_t nf0 = 0u, nf1 = 0u;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        nf0 += (A0[e] > tq0) ? 1u : 0u;
+        nf1 += (A1[e] > tq1) ? 1u : 0u;
+    }
+    uint32_t k0 = 0u, k1 = 0u;
+    if (nf0) k0 = atomicAdd(&sy.tcounts[qpos0], nf0);
+    if (nf1) k1 = atomicAdd(&sy.tcounts[qpos1], nf1);
+    // ---- transposed: entries per database row, both query tiles together ----
+    uint32_t vcnt = 0u;
+    if (tr_on) {   // wave-uniform
+#pragma unroll
+        for (int g_ = 0; g_ < 4; ++g_) {
+            const float4 gv = *reinterpret_cast<const float4*>(gglob + 8 * g_ + 4 * h);
+            const float ge[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+            for (int c_ = 0; c_ < 4; ++c_) {
+                const int e = 4 * g_ + c_;
+                const unsigned long long c0 = __ballot((A0[e] + hq0) > ge[c_]), c1 = __ballot((A1[e] + hq1) > ge[c_]);
+                const uint32_t lo = uint32_t(__popcll(c0 & 0xFFFFFFFFull) + __popcll(c1 & 0xFFFFFFFFull));
+                const uint32_t hi = uint32_t(__popcll(c0 >> 32) + __popcll(c1 >> 32));
+                asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(vcnt) : "s"(lo), "n"(e));        // lane e      <- lo
+                asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(vcnt) : "s"(hi), "n"(e + 16));   // lane e + 16 <- hi
+            }
+        }
+    }
+    uint32_t vbase = 0u;
+    if (vcnt != 0u) {   // (lanes 0 ... 31 only: the others never received a count)
+        const uint32_t e = uint32_t(lane) & 15u, hh = uint32_t(lane) >> 4;
+        vbase = atomicAdd(&sy.tcounts[tbase + 8u * (e >> 2) + 4u * hh + (e & 3u)], vcnt);
+    }
+    // ---- forward stores ----
+    if (nf0) {
+        uint64_t* lp = sy.tlists + size_t(qpos0) * size_t(tcap);
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+            if (A0[e] > tq0) {
+                if (k0 < tcap) list_store(lp + k0, cand_pack(A0[e], tbase + uint32_t(8 * (e >> 2) + 4 * h + (e & 3))));
+                ++k0;
+            }
+    }
+    if (nf1) {
+        uint64_t* lp = sy.tlists + size_t(qpos1) * size_t(tcap);
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+            if (A1[e] > tq1) {
+                if (k1 < tcap) list_store(lp + k1, cand_pack(A1[e], tbase + uint32_t(8 * (e >> 2) + 4 * h + (e & 3))));
+                ++k1;
+            }
+    }
+    // ---- transposed stores: row (e, h)'s batch starts at the value its atomic returned; inside it the entries of query
+    //      tile 0 come first, each in the order of the lanes ----
+    if (tr_on && __ballot(vcnt != 0u) != 0ull) {
+#pragma unroll
+        for (int g_ = 0; g_ < 4; ++g_) {
+            const float4 gv = *reinterpret_cast<const float4*>(gglob + 8 * g_ + 4 * h);   // (again: not kept across the atomics)
+            const float ge[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+            for (int c_ = 0; c_ < 4; ++c_) {
+                const int e = 4 * g_ + c_;
+                const float s0 = A0[e] + hq0, s1 = A1[e] + hq1;
+                const bool p0 = s0 > ge[c_], p1 = s1 > ge[c_];
+                const unsigned long long c0 = __ballot(p0), c1 = __ballot(p1);
+                if ((c0 | c1) != 0ull) {   // wave-uniform
+                    const uint32_t bl = uint32_t(__builtin_amdgcn_readlane(int(vbase), e));
+                    const uint32_t bh = uint32_t(__builtin_amdgcn_readlane(int(vbase), e + 16));
+                    const uint32_t n0l = uint32_t(__popcll(c0 & 0xFFFFFFFFull)), n0h = uint32_t(__popcll(c0 >> 32));
+                    const uint32_t n1l = uint32_t(__popcll(c1 & 0xFFFFFFFFull));
+                    // prefix counts over the whole wave: the upper half sees the lower half's entries too - taken out of its
+                    // base
+                    const uint32_t pre0 = __builtin_amdgcn_mbcnt_hi(uint32_t(c0 >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(c0), 0u));
+                    const uint32_t pre1 = __builtin_amdgcn_mbcnt_hi(uint32_t(c1 >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(c1), 0u));
+                    const uint32_t b0 = h ? bh - n0l : bl;                       // tile 0 entries of my half's row
+                    const uint32_t b1 = h ? bh + n0h - n1l : bl + n0l;           // tile 1 entries behind them
+                    const uint32_t j = tbase + uint32_t(8 * (e >> 2) + (e & 3)) + 4u * uint32_t(h);
+                    uint64_t* lj = sy.tlists + size_t(j) * size_t(tcap);
+                    const uint32_t t0 = b0 + pre0, t1 = b1 + pre1;
+                    if (p0 && t0 < tcap) list_store(lj + t0, cand_pack(s0 - SD[e], qpos0));
+                    if (p1 && t1 < tcap) list_store(lj + t1, cand_pack(s1 - SD[e], qpos1));
+                }
+            }
+        }
+    }
+}
+
 // ---- deferred cold pass of the two-stage symmetric collect: one wave per queue entry -------------------------------
 // Entry {q64, d32}: the 64 queries [64 q64, 64 q64 + 64) (the two query tiles a wave of the collect launch owns)
 // against the 32 database rows [32 d32, 32 d32 + 32).  Operands come straight from the sorted compact copy; the block
 // is scored exactly as the collect kernel's own cold path scores it (same chain, same seeds), then tested and filed
 // by the same code (GT_ADMIT2P).
+#ifndef GT_SEL_COLD_ADMIT
+#define GT_SEL_COLD_ADMIT 1   // 1: cold_admit (scalar-mask filing), 0: the collect kernel's GT_ADMIT2P
+#endif
 #ifndef GT_SEL_COLD_EPW
 #define GT_SEL_COLD_EPW 16   // queue entries per wave of the cold launch (consecutive entries mostly share their queries)
 #endif
@@ -1293,9 +1397,15 @@ __global__ __launch_bounds__(256, 3) void sym_cold_kernel(const float* __restric
         f32x16 cacc = cs, cacc1 = cs;
         mma_chain<DP>(ca, bq[0], cacc);
         mma_chain<DP>(ca, bq[QT - 1], cacc1);
+#if GT_SEL_COLD_ADMIT
+        cold_admit(cacc, cacc1, cs, thrF[0], thrF[QT - 1], hnqF[0], hnqF[QT - 1], uint32_t(qblock + li),
+                   uint32_t(qblock + 32 + li), tbase, gglob, tr_on, lane, li, h, sy);
+#else
         GT_ADMIT2P(cacc, cacc1, cs, 0);
+#endif
     }
     (void)thr;
+    (void)w;
 }
 
 int launch_queue_compact(gt_ctx* ctx, const SelectArgs& a) {

@@ -1945,14 +1945,17 @@ static int graph_finish_impl(gt_ctx* ctx, const void* recv_buf_dev, int64_t n_re
         us.rlists = g->rlists.as<uint64_t>();
         us.rK = g->rK.as<double>();
         us.rcap = g->rcap;
-        hipLaunchKernelGGL(sort_merge_kernel, dim3((unsigned)ceil_div64(nloc, 4)), dim3(256), 0, ctx->stream, nloc,
-                           g->off.as<int64_t>(), us, g->p.kernel_symm, g->p.theta,
-                           g->Vkey.as<uint32_t>(), g->Vval.as<double>(), g->outlen.as<int32_t>(), g->bigrows.as<int32_t>(),
-                           g->bigcount.as<uint32_t>(), (ctx->symm_key32 != 0 && sort_key_fits_u32(g->n_total, 8)) ? 1 : 0);
-        hipLaunchKernelGGL(sort_merge_long_kernel, dim3(4096), dim3(64), 0, ctx->stream, g->off.as<int64_t>(),
-                           us, g->p.kernel_symm, g->p.theta, g->Vkey.as<uint32_t>(),
-                           g->Vval.as<double>(), g->outlen.as<int32_t>(), g->bigrows.as<int32_t>(), g->bigcount.as<uint32_t>(),
-                           g->hugerows.as<int32_t>(), g->bigcount.as<uint32_t>() + 1);
+        {
+            StageSpan span_m(ctx, "symm_merge");   // (nested in "symmetrize")
+            hipLaunchKernelGGL(sort_merge_kernel, dim3((unsigned)ceil_div64(nloc, 4)), dim3(256), 0, ctx->stream, nloc,
+                               g->off.as<int64_t>(), us, g->p.kernel_symm, g->p.theta,
+                               g->Vkey.as<uint32_t>(), g->Vval.as<double>(), g->outlen.as<int32_t>(), g->bigrows.as<int32_t>(),
+                               g->bigcount.as<uint32_t>(), (ctx->symm_key32 != 0 && sort_key_fits_u32(g->n_total, 8)) ? 1 : 0);
+            hipLaunchKernelGGL(sort_merge_long_kernel, dim3(4096), dim3(64), 0, ctx->stream, g->off.as<int64_t>(),
+                               us, g->p.kernel_symm, g->p.theta, g->Vkey.as<uint32_t>(),
+                               g->Vval.as<double>(), g->outlen.as<int32_t>(), g->bigrows.as<int32_t>(), g->bigcount.as<uint32_t>(),
+                               g->hugerows.as<int32_t>(), g->bigcount.as<uint32_t>() + 1);
+        }
         GT_HIP(ctx, hipGetLastError());
         uint32_t nbig = 0;   // rows beyond the register sorts
         GT_HIP(ctx, hipMemcpyAsync(&nbig, g->bigcount.as<uint32_t>() + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -2030,10 +2033,13 @@ static int graph_finish_impl(gt_ctx* ctx, const void* recv_buf_dev, int64_t n_re
         GT_HIP(ctx, g->Kdata.reserve(size_t(nnz) * sizeof(double)));
         GT_HIP(ctx, g->Pdata.reserve(size_t(nnz) * sizeof(double)));
         GT_HIP(ctx, g->degree.reserve(size_t(nloc) * sizeof(double)));
-        hipLaunchKernelGGL(compact_kernel, dim3((unsigned)ceil_div64(nloc, 4)), dim3(256), 0, ctx->stream, nloc, g->r0,
-                           g->off.as<int64_t>(), g->outlen.as<int32_t>(), g->indptr.as<int64_t>(), g->Vkey.as<uint32_t>(),
-                           g->Vval.as<double>(), g->indices.as<int32_t>(), g->Kdata.as<double>(), g->degree.as<double>(),
-                           g->flags.as<uint32_t>(), perm, g->p.anisotropy == 0.0 ? g->Pdata.as<double>() : nullptr);
+        {
+            StageSpan span_c(ctx, "symm_compact");   // (nested in "symmetrize")
+            hipLaunchKernelGGL(compact_kernel, dim3((unsigned)ceil_div64(nloc, 4)), dim3(256), 0, ctx->stream, nloc, g->r0,
+                               g->off.as<int64_t>(), g->outlen.as<int32_t>(), g->indptr.as<int64_t>(), g->Vkey.as<uint32_t>(),
+                               g->Vval.as<double>(), g->indices.as<int32_t>(), g->Kdata.as<double>(), g->degree.as<double>(),
+                               g->flags.as<uint32_t>(), perm, g->p.anisotropy == 0.0 ? g->Pdata.as<double>() : nullptr);
+        }
         GT_HIP(ctx, hipGetLastError());
     }
     g->finished = true;
