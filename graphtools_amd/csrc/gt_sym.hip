@@ -252,8 +252,8 @@ __global__ __launch_bounds__(64) void landmark_neighbours_kernel(const _Float16*
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
-            const float ov = __shfl_xor(best, o);
-            const int oi = __shfl_xor(bi, o);
+            const float ov = __uint_as_float(lane_xor_b32(__float_as_uint(best), o));
+            const int oi = int(lane_xor_b32(uint32_t(bi), o));
             if (ov < best || (ov == best && oi < bi)) {
                 best = ov;
                 bi = oi;
