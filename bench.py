@@ -282,7 +282,8 @@ def kernel_table(ctx, st, n, nloc, d, world, nnz, nnz0, main):
              2.0 * nloc * n * d * MFMA_CHAINS[main], "classic candidate pass: every query row against every point")
     # streaming kernels, algorithmic bytes per SURVEY 8d
     tab = 128   # table entries the re-rank evaluates / the affinity pass reads per row (first batch)
-    hbm("rerank", "rerank_sym_kernel" if symmetric else "rerank_kernel", st.mean("rerank"),
+    hbm("rerank", ("rerank_sym4_kernel<1>" if (d % 4 == 0 and d <= 64) else "rerank_sym_kernel") if symmetric else "rerank_kernel",
+        st.mean("rerank"),
         nloc * tab * 8.0 + n * d * 4.0 + nloc * tab * 12.0,
         "candidate lists in (8 B), X once, exact tables out (8 + 4 B); the row gathers come from L2/MALL")
     hbm("affinity", "bandwidth_kernel + affinity_kernel", st.mean("affinity"), nloc * tab * 12.0 + nnz0 * 8.0,

@@ -75,15 +75,24 @@ __global__ __launch_bounds__(256) void max_abs_f4_kernel(const float4* __restric
                                                          unsigned long long* __restrict__ out_bits) {
     float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f;
     bool nan = false;
-    for (int64_t f = int64_t(blockIdx.x) * 256 + threadIdx.x; f < total4; f += int64_t(gridDim.x) * 256) {
-        const float4 v = X4[f];
+    const int64_t stride = int64_t(gridDim.x) * 256;
+    auto take = [&](const float4 v) {
         const float a = fabsf(v.x), b = fabsf(v.y), c = fabsf(v.z), e = fabsf(v.w);
         nan |= (a != a) | (b != b) | (c != c) | (e != e);
         m0 = a > m0 ? a : m0;   // NaN never wins, infinity does
         m1 = b > m1 ? b : m1;
         m2 = c > m2 ? c : m2;
         m3 = e > m3 ? e : m3;
+    };
+    int64_t f = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    for (; f + 3 * stride < total4; f += 4 * stride) {   // four loads in flight per thread
+        const float4 v0 = X4[f], v1 = X4[f + stride], v2 = X4[f + 2 * stride], v3 = X4[f + 3 * stride];
+        take(v0);
+        take(v1);
+        take(v2);
+        take(v3);
     }
+    for (; f < total4; f += stride) take(X4[f]);
     m0 = m0 > m1 ? m0 : m1;
     m2 = m2 > m3 ? m2 : m3;
     double m = double(m0 > m2 ? m0 : m2);
@@ -91,6 +100,40 @@ __global__ __launch_bounds__(256) void max_abs_f4_kernel(const float4* __restric
     for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
     if ((threadIdx.x & 63) == 0) atomicMax(out_bits, (unsigned long long)__double_as_longlong(m));
     if (__ballot(nan) != 0ull && (threadIdx.x & 63) == 0) atomicOr(out_bits + 1, 1ull);
+}
+
+// the same for float32 rows that fill the padded width exactly (d == DP, a multiple of 8, no column selection, 16-byte
+// aligned): eight features per thread - two 16-byte loads, one 16-byte store per plane
+__global__ __launch_bounds__(256) void pad_split_f16_v8_kernel(const float4* __restrict__ X4, const int64_t n, const int DP,
+                                                               const int64_t n_pad, const float sc,
+                                                               uint4* __restrict__ Yh, uint4* __restrict__ Yc) {
+    typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+    const int c8 = DP / 8;
+    const int64_t total = n_pad * c8;
+    for (int64_t f = int64_t(blockIdx.x) * 256 + threadIdx.x; f < total; f += int64_t(gridDim.x) * 256) {
+        const int64_t r = f / c8;
+        const int c = int(f - r * c8);
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (r < n) {
+            const float4 a = X4[r * int64_t(2 * c8) + 2 * c], b = X4[r * int64_t(2 * c8) + 2 * c + 1];
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+            v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        }
+        half8 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float x = v[e] * sc;              // exact: sc is a power of two
+            const _Float16 h = _Float16(x);
+            hi[e] = h;
+            lo[e] = _Float16(x - float(h));         // (exact in float32: the residual of a float32 against its float16 rounding)
+        }
+        uint4 hb, lb;
+        __builtin_memcpy(&hb, &hi, 16);
+        __builtin_memcpy(&lb, &lo, 16);
+        Yh[r * int64_t(2 * c8) + c] = hb;           // row = hi plane | lo plane
+        Yh[r * int64_t(2 * c8) + c8 + c] = lb;
+        if (Yc) Yc[f] = hb;
+    }
 }
 
 // split-float16 working copy: row = hi plane (DP halves) | lo plane (DP halves), x*sc = hi + lo + O(2^-22 |x*sc|)
@@ -227,6 +270,76 @@ __global__ __launch_bounds__(256) void row_norm_kernel(const T* __restrict__ X, 
     }
 }
 
+// The same outputs for float32 rows with d a multiple of 4 and at most 64, all columns (no selection): FOUR LANES PER ROW,
+// lane c reads quad c of every 64-byte sector (one 16-byte load each, the row's 256 bytes in one instruction of the four
+// lanes) - no LDS staging, 16 rows per wave in flight.  The lane's four accumulators are the partial sums c, c + 4, c + 8,
+// c + 12 of gt_dot16, the lane tree is gt_tree16's: xn comes out bit for bit as above (a row's distance to itself must be 0).
+// The float16 residuals are summed per lane and then across the four lanes (an upper bound's rounding order is free).
+__global__ __launch_bounds__(256) void row_norm4_kernel(const float* __restrict__ X, const int64_t n, const int d,
+                                                        const int64_t n_pad, double* __restrict__ xn, float* __restrict__ hneg,
+                                                        const double sc2, unsigned long long* __restrict__ ymax2_bits,
+                                                        const double sc, unsigned long long* __restrict__ lomax2_bits) {
+    const int lane = threadIdx.x & 63, c = lane & 3;
+    double m = 0.0, l = 0.0;   // running maxima of this lane group (the atomics on ONE address are paid once per workgroup)
+    for (int64_t r = int64_t(blockIdx.x) * 64 + (threadIdx.x >> 2); r < n_pad; r += int64_t(gridDim.x) * 64) {
+        if (r < n) {
+            const float4* row = reinterpret_cast<const float4*>(X + r * int64_t(d));
+            float4 v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = (16 * i + 4 * c < d) ? row[4 * i + c] : make_float4(0.f, 0.f, 0.f, 0.f);
+            double a[4] = {0.0, 0.0, 0.0, 0.0};
+            double lo2 = 0.0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (16 * i + 4 * c < d) {
+                    const double e[4] = {double(v[i].x), double(v[i].y), double(v[i].z), double(v[i].w)};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        a[i] = fma(e[k], e[k], a[i]);
+                        if (lomax2_bits) {
+                            const double vs = e[k] * sc;
+                            const double res = vs - double(_Float16(vs));
+                            lo2 = fma(res, res, lo2);
+                        }
+                    }
+                }
+            const double cc = (a[0] + a[2]) + (a[1] + a[3]);   // b[c] + b[c + 4] of gt_tree16
+            const double w2 = cc + lane_xor_f64(cc, 2);
+            const double acc = w2 + lane_xor_f64(w2, 1);
+            lo2 += lane_xor_f64(lo2, 2);
+            lo2 += lane_xor_f64(lo2, 1);
+            if (c == 0) {
+                xn[r] = acc;
+                if (hneg) hneg[r] = float(-0.5 * acc * sc2);
+            }
+            m = fmax(m, acc);
+            l = fmax(l, lo2);
+        } else if (c == 0 && hneg) {
+            hneg[r] = -INFINITY;
+        }
+    }
+    __shared__ double red[2][4];
+#pragma unroll
+    for (int o = 32; o >= 4; o >>= 1) {
+        m = fmax(m, lane_xor_f64(m, o));
+        l = fmax(l, lane_xor_f64(l, o));
+    }
+    if (lane == 0) {
+        red[0][threadIdx.x >> 6] = m;
+        red[1][threadIdx.x >> 6] = l;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double mm = fmax(fmax(red[0][0], red[0][1]), fmax(red[0][2], red[0][3]));
+        const double ll = fmax(fmax(red[1][0], red[1][1]), fmax(red[1][2], red[1][3]));
+        if (ymax2_bits) {
+            atomicMax(ymax2_bits, (unsigned long long)__double_as_longlong(mm));
+            atomicMax(ymax2_bits + 1, (unsigned long long)__double_as_longlong(mm));
+        }
+        if (lomax2_bits) atomicMax(lomax2_bits, (unsigned long long)__double_as_longlong(ll));
+    }
+}
+
 }  // namespace
 
 int gt_normalize_rows(gt_ctx* ctx, const void* X, void* out, int64_t n, int d, int dtype) {
@@ -294,7 +407,11 @@ int gt_prep_matrix(gt_ctx* ctx, const void* Xdev, int64_t n, int d, int dtype, i
     if (Yp && prec == 1) {
         const int64_t total = n_pad * DP;
         int64_t blocks = std::min<int64_t>(ceil_div64(total, 256), 16384);
-        if (dtype == GT_F32)
+        if (dtype == GT_F32 && !sel && d == DP && (DP & 7) == 0 && (reinterpret_cast<uintptr_t>(Xdev) & 15) == 0 &&
+            sc <= 3.0e38 && sc >= 1.0e-38)
+            hipLaunchKernelGGL(pad_split_f16_v8_kernel, dim3((unsigned)std::min<int64_t>(ceil_div64(total / 8, 256), 16384)),
+                               dim3(256), 0, ctx->stream, (const float4*)Xdev, n, DP, n_pad, float(sc), (uint4*)Yp, (uint4*)Yc);
+        else if (dtype == GT_F32)
             hipLaunchKernelGGL(pad_split_f16_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream,
                                (const float*)Xdev, n, d, DP, n_pad, sc, (_Float16*)Yp, (_Float16*)Yc, sel, dw);
         else
@@ -315,6 +432,13 @@ int gt_prep_matrix(gt_ctx* ctx, const void* Xdev, int64_t n, int d, int dtype, i
     }
     const int64_t rows = hneg ? n_pad : n;
     const int64_t nb = ceil_div64(rows, 256);
+    if (dtype == GT_F32 && !sel && (d & 3) == 0 && d <= 64 && (reinterpret_cast<uintptr_t>(Xdev) & 15) == 0) {
+        hipLaunchKernelGGL(row_norm4_kernel, dim3((unsigned)std::min<int64_t>(ceil_div64(rows, 64), 4096)), dim3(256), 0, ctx->stream,
+                           (const float*)Xdev, n, d, rows, xn, hneg, sc * sc, (unsigned long long*)ymax2, sc,
+                           (unsigned long long*)lomax2);
+        GT_HIP(ctx, hipGetLastError());
+        return GT_OK;
+    }
     if (dtype == GT_F32)
         hipLaunchKernelGGL(row_norm_kernel<float>, dim3((unsigned)nb), dim3(256), 0, ctx->stream, (const float*)Xdev, n,
                            d, n_pad, xn, hneg, sc * sc, (unsigned long long*)ymax2, sc, (unsigned long long*)lomax2, sel, dw, xn_sel);
