@@ -44,9 +44,29 @@ __device__ __forceinline__ int owner_of(const Splits& sp, int64_t row) {
     return o;
 }
 
-__device__ __forceinline__ double affinity(double dist, double bw, double decay) {
-    double w = exp(-pow(dist / bw, decay));
+// idecay > 0: `decay` is that whole number (1 ... 128, the usual case: the default is 40) and the power is formed by
+// repeated squaring - a handful of multiplications instead of the library pow, which was most of the affinity kernel's
+// instructions (PMC: VALU busy 88 %).  The squarings' roundings add up to < 2^(bits of idecay) ulp of the power, i.e. a
+// relative 1e-14 of exp(-power) at the threshold: far inside the 1e-5 the values are held to, and the same function is
+// used wherever an affinity is formed, so every path agrees bit for bit.
+__device__ __forceinline__ double affinity(double dist, double bw, double decay, int idecay) {
+    const double x = dist / bw;
+    double p;
+    if (idecay > 0) {   // (uniform)
+        double b = x;
+        p = (idecay & 1) ? x : 1.0;
+        for (int n = idecay >> 1; n; n >>= 1) {
+            b *= b;
+            if (n & 1) p *= b;
+        }
+    } else {
+        p = pow(x, decay);
+    }
+    double w = exp(-p);
     return (w != w) ? 1.0 : w;   // NaN -> 1 (graphs.py:505-506)
+}
+__host__ __device__ inline int gt_whole_decay(double decay) {
+    return (decay >= 1.0 && decay <= 128.0 && decay == double(int(decay))) ? int(decay) : 0;
 }
 
 // ---- A0: bandwidth, radius, classification ------------------------------------------------------
@@ -138,6 +158,7 @@ __global__ __launch_bounds__(256) void affinity_kernel(
     double* xs = reinterpret_cast<double*>(smem_raw) + size_t(w) * d;
     const int64_t wi = int64_t(blockIdx.x) * 4 + w;
     if (wi >= nrows) return;
+    const int idecay = gt_whole_decay(decay);
     const int64_t i = RADIUS ? int64_t(row_list[wi]) - qoff : wi;   // (the list holds rows of the query matrix: qoff + i)
     const int32_t src = rowsrc[i];
     if (RADIUS != (src >= 0)) return;   // (the other launch's row)
@@ -157,7 +178,7 @@ __global__ __launch_bounds__(256) void affinity_kernel(
                 const double d2 = cand_d2[i * MP + e];
                 j = cand_j[i * MP + e];
                 double kv = 1.0;
-                if (!binary) kv = affinity(gt_key_to_dist(d2, dtype, metric), bwi, decay);
+                if (!binary) kv = affinity(gt_key_to_dist(d2, dtype, metric), bwi, decay, idecay);
                 keep = binary || (kv >= thresh);
                 kvv = kv;
             }
@@ -203,7 +224,7 @@ __global__ __launch_bounds__(256) void affinity_kernel(
                 const T* y = X + int64_t(j) * d;
                 const double dot = gt_dot16(xs, y, d);   // (the canonical order of the exact stages)
                 const double t = gt_pair_key(qn, dot, xn[j], metric);
-                const double kv = affinity(gt_key_to_dist(t, dtype, metric), bwi, decay);
+                const double kv = affinity(gt_key_to_dist(t, dtype, metric), bwi, decay, idecay);
                 keep = kv >= thresh;
                 kvv = kv;
             }
