@@ -2,7 +2,7 @@
 //
 // hipMemcpy into a FRESH host array (np.empty: no page touched yet) moves 15-25 GB/s on the MI355X host - the
 // runtime pins the destination page by page, single-threaded, taking the first-touch faults on the way - against
-// 56 GB/s into resident memory (tools/gpu_copy_probe.py).  The results of a graph build at N = 1e6 are 2.3 GB (CSR K
+// 56 GB/s into resident memory.  The results of a graph build at N = 1e6 are 2.3 GB (CSR K
 // and P), always copied into fresh arrays.  Here large device-to-host copies are cut into 8 MiB chunks and dealt to
 // kLanes host threads; every lane owns a HIP stream and two pinned slots and overlaps the DMA of its next chunk
 // with the memcpy of the current one from the slot into the caller's memory, where the page faults are then taken

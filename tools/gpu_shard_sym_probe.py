@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from graphtools_amd import _hip  # noqa: E402
-from tools.gpu_sym_check import make_mix  # noqa: E402
+from bench import make_mix  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
 d = int(sys.argv[2]) if len(sys.argv) > 2 else 64
