@@ -19,9 +19,9 @@ stays on the device in float64:
 * the embedding ``diff_op @ V`` is one more ``gt_graph_spmm`` (with P).
 
 The test matrix is drawn like sklearn's (same generator, same shape), the iteration count follows its rule.  The k-means
-that follows is scikit-learn's own MiniBatchKMeans on the host (RNG- and order-dependent by design), its final labelling
-pass - the nearest of the n_landmark centres for every point - runs on the device kNN path.  Parity with the reference is
-statistical: the subspace is the same up to the accuracy of the randomized method, the k-means trajectory is not.
+that follows is graphtools_amd/_kmeans.py: scikit-learn's MiniBatchKMeans algorithm with every nearest-centre search (the
+batches' and the final labelling) on the device kNN path.  Parity with the reference is statistical: the subspace is the
+same up to the accuracy of the randomized method, the k-means trajectory is RNG- and rounding-dependent by design.
 """
 import numpy as np
 
@@ -93,21 +93,11 @@ def spectral_embedding(ctx, n, n_svd, random_state, n_oversamples=10, n_iter="au
 
 
 def spectral_clusters(graph, ctx):
-    """The reference's default landmark assignment with the SVD, the embedding product and the labelling on the device"""
-    from sklearn.cluster import MiniBatchKMeans
-
-    from . import _hip
+    """The reference's default landmark assignment with the SVD, the embedding product and the k-means searches on the device"""
+    from ._kmeans import DeviceMiniBatchKMeans
 
     n = graph.data_nu.shape[0]
     E, _ = spectral_embedding(ctx, n, graph.n_svd, graph.random_state)
-    kmeans = MiniBatchKMeans(graph.n_landmark, init_size=3 * graph.n_landmark, n_init=1, batch_size=10000,
-                             random_state=graph.random_state, compute_labels=False)
-    kmeans.fit(E)
-    centres = np.ascontiguousarray(kmeans.cluster_centers_, dtype=np.float64)
-    lab_ctx = _hip.Context(getattr(graph, "device", 0) or 0)
-    try:
-        lab_ctx.set_points(centres)
-        _, idx, _ = lab_ctx.knn_search(1, Y=E)
-    finally:
-        lab_ctx.close()
-    return idx[:, 0].astype(np.int64)
+    kmeans = DeviceMiniBatchKMeans(graph.n_landmark, init_size=3 * graph.n_landmark, batch_size=10000,
+                                   random_state=graph.random_state, device=getattr(graph, "device", 0) or 0)
+    return kmeans.fit_predict(E).astype(np.int64)
