@@ -282,7 +282,7 @@ def test_cosine_metric_vs_oracle(dtype, rtol):
         # float32: scikit-learn's (and the oracle's) distances come from a float32 GEMM; values agree to float32
         # rounding amplified by the decay exponent, entries at the threshold may flip
         D = abs(sparse.csr_matrix(G.K) - sparse.csr_matrix(K0))
-        assert D.max() < 5e-3
+        assert D.max() < 2e-3     # (measured 1.9e-4 on 6000 rows: INTEGRATION.md, float32 cosine)
         assert abs(G.K.nnz - K0.nnz) <= 0.01 * K0.nnz
 
 
