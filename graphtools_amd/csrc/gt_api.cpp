@@ -161,6 +161,7 @@ int gt_set_points(gt_ctx* ctx, const void* X, int64_t n, int32_t d, int32_t dtyp
     ctx->fast_ok = -1;
     ctx->sym_ok = -1;
     ctx->symm_fused_ok = 1;
+    ctx->symm_pair_ok = 1;
     ctx->sym_two_ok = -1;
     ctx->d = d;
     ctx->dtype = dtype;
@@ -279,6 +280,10 @@ int gt_set_option(gt_ctx* ctx, const char* name, const char* value) {
     }
     if (k == "symmetrize_fused") {
         ctx->symm_fused = std::atoi(value) != 0 ? 1 : 0;
+        return GT_OK;
+    }
+    if (k == "symmetrize_pairs") {
+        ctx->symm_pairs = std::atoi(value) != 0 ? 1 : 0;
         return GT_OK;
     }
     if (k == "symmetrize_fill_threads") {

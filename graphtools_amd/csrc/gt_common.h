@@ -161,6 +161,9 @@ struct gt_ctx {
                                 //   pair_count_kernel).  Bit-identical, measured SLOWER than sort + compact (6.7 against 5.8 ms at N = 1e6): off
     int32_t symm_fused_ok = 1;  //     0 once a union row of the bound points has outgrown the register sorts (reset by gt_set_points)
     int32_t symm_key32 = 1;     //   per-row sorts of the symmetrisation on 32-bit keys where columns and positions fit (0: 64-bit keys)
+    int32_t in_graph_build = 0; //   (set by gt_graph_build around its gt_graph_begin: every row is here, the tail is its own)
+    int32_t symm_pairs = 1;     //   pair-resolved symmetrisation (gt_sparse.hip): every row settles its mutual pairs itself, only one-sided entries travel
+    int32_t symm_pair_ok = 1;   //   ... not refuted for the bound point set (a union row beyond the register sorts)
     int32_t symm_fill_threads = 256;   //   threads per workgroup of bin_fill_kernel (256 | 512 | 1024)
     int32_t symm_bin_shift = 0; //   log2 of the rows per bin (0: 9, more from 2 M rows; development / tests: 8 ... 12)
     int32_t sym_bounds = -1;    //   bound pass in front of the two-stage collect (cell balls): -1 auto / 1 on, 0 off

@@ -322,9 +322,11 @@ __device__ __forceinline__ void wave_bitonic_asc_pair(uint64_t (&hi)[NT], L (&lo
 // for such neighbours and, when there is one (exact ties, distances within 2^-44 of each other), the pair network
 // runs instead - so the outcome is always the one of wave_bitonic_asc_pair.  Entries (kInf, 0xFFFFFFFF) mean "none" and
 // sort last; lo must fit 32 bits.
+// x / lds_x (optional, with the LDS slots): a 64-bit payload per entry that follows its entry (NT values per lane).
 template <int NT, typename L>
 __device__ __forceinline__ void wave_sort_asc_pair_fast(uint64_t (&hi)[NT], L (&lo)[NT], const int lane,
-                                                        uint64_t* lds_hi = nullptr, uint32_t* lds_lo = nullptr) {
+                                                        uint64_t* lds_hi = nullptr, uint32_t* lds_lo = nullptr,
+                                                        uint64_t* x = nullptr, uint64_t* lds_x = nullptr) {
     static_assert(NT == 1 || NT == 2 || NT == 4 || NT == 8, "up to 512 entries");
     constexpr int PB = NT == 1 ? 6 : NT == 2 ? 7 : NT == 4 ? 8 : 9;
     constexpr uint64_t PM = (1ull << PB) - 1ull;
@@ -345,7 +347,32 @@ __device__ __forceinline__ void wave_sort_asc_pair_fast(uint64_t (&hi)[NT], L (&
         clash |= ck[t] != 0ull && nx != 0ull && ((~ck[t]) >> PB) == ((~nx) >> PB);
     }
     if (__ballot(clash) != 0ull) {   // wave-uniform, rare
+        if (x) {
+            // the payloads are parked by original position next to their entries' lo; after the pair network every slot
+            // looks its payload up by lo (unique within a row: a database row is a candidate once)
+#pragma unroll
+            for (int r = 0; r < NT; ++r) {
+                lds_lo[r * 64 + lane] = uint32_t(lo[r]);
+                lds_x[r * 64 + lane] = x[r];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
         wave_bitonic_asc_pair<NT>(hi, lo, lane);
+        if (x) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                uint64_t found = 0ull;
+                const uint32_t want = uint32_t(lo[t]);
+                if (want != 0xFFFFFFFFu)
+                    for (int q = 0; q < 64 * NT; ++q)
+                        if (lds_lo[q] == want) found = lds_x[q];
+                x[t] = found;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
         return;
     }
     uint64_t nh[NT];
@@ -357,6 +384,7 @@ __device__ __forceinline__ void wave_sort_asc_pair_fast(uint64_t (&hi)[NT], L (&
         for (int r = 0; r < NT; ++r) {
             lds_hi[r * 64 + lane] = hi[r];
             lds_lo[r * 64 + lane] = uint32_t(lo[r]);
+            if (x) lds_x[r * 64 + lane] = x[r];
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -367,6 +395,7 @@ __device__ __forceinline__ void wave_sort_asc_pair_fast(uint64_t (&hi)[NT], L (&
             const bool some = ck[t] != 0ull;
             nh[t] = some ? lds_hi[p] : kNoneHi;
             nl[t] = some ? lds_lo[p] : 0xFFFFFFFFu;
+            if (x) x[t] = some ? lds_x[p] : 0ull;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();

@@ -56,6 +56,7 @@ struct GraphState {
     DevBuf bincnt, binoff;   // destination bins of the single-rank transpose: triplets per bin (+ the emit cursors), scan
     DevBuf ucol, uval;       // fused tail: received entries in fixed slot rows [row][capT] (columns, values)
     bool bins_used = false;
+    bool pairs = false;        // this build's affinities settled the mutual pairs (negative = final values; graph_finish_pairs)
     bool fused_used = false;   // the last build wrote K and P through the fused tail (gt_sparse.hip bin_fill3_kernel)
     int64_t nnz0 = 0, nnz = 0;
 };

@@ -17,7 +17,7 @@ void gt_free_knn_work(gt_ctx* ctx) {
                       &k->d2_lb, &k->fb_rows, &k->fb_count, &k->fb_scratch, &k->gflags, &k->prof, &k->fb_qrows, &k->fb_thr, &k->fb_lists,
                       &k->fb_counts, &k->fb_max, &k->unproven, &k->qorder, &k->qthr0, &k->qlomax_dev, &k->Ycs, &k->hnegs,
                       &k->sym_g, &k->sym_gmin, &k->tlists, &k->tcounts, &k->sym_stat, &k->sym_work, &k->sym_tiles,
-                      &k->sym_tile_cnt, &k->sh_invperm, &k->sh_lists, &k->sh_counts, &k->sh_cnt, &k->sh_own, &k->sh_tmp, &k->sym_hh, &k->sym_thrh, &k->sym_gh, &k->sym_gminh, &k->sym_queue, &k->sym_qcount, &k->sym_qdense, &k->sym_qtot, &k->sym_racc, &k->sym_farcnt, &k->sym_z, &k->sym_p, &k->sym_cov, &k->sym_qspill, &k->sym_rrow, &k->sym_bwork, &k->hnegs_fin, &k->Xs, &k->xns})
+                      &k->sym_tile_cnt, &k->sh_invperm, &k->sh_lists, &k->sh_counts, &k->sh_cnt, &k->sh_own, &k->sh_tmp, &k->sym_hh, &k->sym_thrh, &k->sym_gh, &k->sym_gminh, &k->sym_queue, &k->sym_qcount, &k->sym_qdense, &k->sym_qtot, &k->sym_racc, &k->sym_farcnt, &k->sym_z, &k->sym_p, &k->sym_cov, &k->sym_qspill, &k->sym_rrow, &k->sym_bwork, &k->hnegs_fin, &k->Xs, &k->xns, &k->cand_d2t, &k->keyt_ok, &k->nokeyt_rows, &k->nokeyt_count})
         b->release();
     delete k;
     ctx->knn = nullptr;
@@ -92,6 +92,7 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
     if (!external) ctx->qlomax = 0.0;   // the residual bound of a previous external query matrix does not apply
     k->n_fallback = 0;
     k->n_fallback_exhaustive = 0;
+    k->keyt_valid = false;
     const size_t lcap = size_t(64) * nt;
     GT_HIP(ctx, k->lists.reserve(size_t(k->nq_pad) * lcap * sizeof(uint64_t)));
     GT_HIP(ctx, k->counts.reserve(size_t(k->nq_pad) * sizeof(uint32_t)));
@@ -493,10 +494,28 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
                 sr.Xs = k->Xs.p;
                 sr.xns = k->xns.as<double>();
             }
+            bool wrote_t = false;
+            if (ctx->symm_pairs != 0 && MP == 256) {
+                // the keys of the transposed pairs next to the tables (pair-resolved symmetrisation, gt_sparse.hip)
+                GT_HIP(ctx, k->cand_d2t.reserve(size_t(nq) * MP * sizeof(double)));
+                GT_HIP(ctx, k->keyt_ok.reserve(size_t(nq)));
+                GT_HIP(ctx, k->nokeyt_rows.reserve(size_t(nq) * sizeof(int32_t)));
+                GT_HIP(ctx, k->nokeyt_count.reserve(sizeof(uint32_t)));
+                GT_HIP(ctx, hipMemsetAsync(k->nokeyt_count.p, 0, sizeof(uint32_t), ctx->stream));
+                sr.cand_d2t = k->cand_d2t.as<double>();
+                sr.keyt_ok = k->keyt_ok.as<uint8_t>();
+                sr.nokeyt_rows = k->nokeyt_rows.as<int32_t>();
+                sr.nokeyt_count = k->nokeyt_count.as<uint32_t>();
+                sr.wrote_t = &wrote_t;
+            }
             {
                 StageSpan span(ctx, "rerank");
                 GT_TRY(gt_launch_rerank_sym(ctx, ra, sr));
             }
+            k->keyt_valid = wrote_t;
+            k->nokeyt_n = 0;
+            if (wrote_t)
+                GT_HIP(ctx, hipMemcpyAsync(&k->nokeyt_n, k->nokeyt_count.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
             uint32_t n_unproven = 0;
             GT_HIP(ctx, hipMemcpyAsync(&n_fb, k->fb_count.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
             GT_HIP(ctx, hipMemcpyAsync(&n_unproven, k->unproven.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -509,6 +528,7 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
                 ctx->sym_ok = 0;
                 sym_now = false;
                 k->sym_used = false;
+                k->keyt_valid = false;
                 GT_HIP(ctx, hipMemsetAsync(k->fb_count.p, 0, sizeof(uint32_t), ctx->stream));
                 GT_HIP(ctx, hipMemsetAsync(k->gflags.p, 0, sizeof(uint32_t), ctx->stream));
                 continue;
@@ -519,6 +539,7 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
                 if (!ok) {
                     main_prec = 1;
                     k->sym_used = false;
+                    k->keyt_valid = false;
                     GT_HIP(ctx, hipMemsetAsync(k->fb_count.p, 0, sizeof(uint32_t), ctx->stream));
                     GT_HIP(ctx, hipMemsetAsync(k->gflags.p, 0, sizeof(uint32_t), ctx->stream));
                     continue;

@@ -30,6 +30,10 @@ struct KnnWork {
     // form and their sub-tile minima, the candidate lists of launch B and their counters
     DevBuf hnegs_fin;                             // seeds of the sorted rows, finite on the pad rows (dense seeding launch)
     DevBuf Ycs, hnegs, sym_g, sym_gmin, tlists, tcounts, sym_stat, sym_work, sym_tiles, sym_tile_cnt;
+    DevBuf nokeyt_rows, nokeyt_count;             //   rows without them (handed to a repair pass), their number
+    uint32_t nokeyt_n = 0;
+    DevBuf cand_d2t, keyt_ok;                     //   keys of the transposed pairs next to cand_d2 (pair-resolved symmetrisation), row flags
+    bool keyt_valid = false;                      //   ... written by the last candidate search for every row it proved
     DevBuf Xs, xns;                               //   the points and their squared norms in cell-sorted order (gt_sym_gather_points)
     bool xs_ready = false;                        //   ... valid for the current order (reset whenever the order is rebuilt)
     DevBuf sym_racc, sym_farcnt;                     // radius / spread statistics of the orphan cut (4 doubles), far-kept
@@ -181,6 +185,12 @@ struct SymRerank {
     // the points / norms in sorted order (optional): candidate rows are then read by position
     const void* Xs = nullptr;
     const double* xns = nullptr;
+    // transposed keys next to the table's own (optional; rerank_sym4_kernel only): [nq][256] and one flag per row
+    double* cand_d2t = nullptr;
+    uint8_t* keyt_ok = nullptr;
+    int32_t* nokeyt_rows = nullptr;    // rows whose table will come from a repair pass (no transposed keys), and their number
+    uint32_t* nokeyt_count = nullptr;
+    bool* wrote_t = nullptr;   // out: the launch that ran fills them
 };
 int gt_launch_rerank_sym(gt_ctx* ctx, const RerankArgs& a, const SymRerank& sr);
 // gt_sym.hip

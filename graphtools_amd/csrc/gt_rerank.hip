@@ -369,8 +369,8 @@ __global__ __launch_bounds__(256, 5) void rerank_sym_kernel(
 // DB = blocks of 64 features (d <= 64 DB).  Measured: 5.5 -> 5.2 ms at d = 64, 1.07 -> 0.90 ms at d = 36 (N = 3e5); with two
 // blocks (d = 100) the registers of the wider query share cost more than the coalescing returns (4.3 -> 6.1 ms): the
 // launcher keeps the lane-per-row kernel there.
-template <int DB>
-__global__ __launch_bounds__(256, 4) void rerank_sym4_kernel(
+template <int DB, bool WT>   // WT: the transposed keys travel with the table (cand_d2t, keyt_ok)
+__global__ __launch_bounds__(256, WT ? 3 : 4) void rerank_sym4_kernel(
     const float* __restrict__ X, const int d, const double* __restrict__ xn, const int64_t nq,
     const uint64_t* __restrict__ tlists, const int tcap, const uint32_t* __restrict__ tcounts,
     const float* __restrict__ thr, const double* __restrict__ ymax2p, const ErrModel err, const int need_m,
@@ -379,16 +379,24 @@ __global__ __launch_bounds__(256, 4) void rerank_sym4_kernel(
     int32_t* __restrict__ fb_rows, uint32_t* __restrict__ gflags, const double radius_key_factor,
     uint32_t* __restrict__ unproven, unsigned long long* __restrict__ stat, const int want_stats,
     const int32_t* __restrict__ invperm, const int32_t* __restrict__ own_rows, const int64_t own_r0,
-    const int xcd_chunk, const float* __restrict__ Xs, const double* __restrict__ xns) {
+    const int xcd_chunk, const float* __restrict__ Xs, const double* __restrict__ xns, double* __restrict__ cand_d2t,
+    uint8_t* __restrict__ keyt_ok, int32_t* __restrict__ nokeyt_rows, uint32_t* __restrict__ nokeyt_count) {
+    // cand_d2t (optional): next to every key of the table, the key the OTHER row holds for the same pair - the same dot
+    // product in scikit-learn's association with the roles swapped, (|y|^2 - 2 x.y) + |x|^2 - so that the affinity pass can
+    // tell, bit for bit, what the transposed entry is worth (gt_sparse.hip, pair-resolved symmetrisation); keyt_ok[q] = 1
+    // when the row's table came from here with them
     constexpr int MP = 256;
     constexpr int NI = 4 * DB;   // 64-byte sectors of a row this kernel can hold
     __shared__ uint64_t park_hi_all[4 * MP];   // (the sorted tables are picked up by position through the LDS)
     __shared__ uint32_t park_lo_all[4 * MP];
+    __shared__ uint64_t park_x_all[4 * MP];
     const int lane = threadIdx.x & 63;
     const int w = threadIdx.x >> 6;
     const int c = lane & 3, r = lane >> 2;
     uint64_t* park_hi = park_hi_all + w * MP;
     uint32_t* park_lo = park_lo_all + w * MP;
+    uint64_t* park_x = park_x_all + w * MP;
+    constexpr bool want_t = WT;
     const int64_t bid = gt_xcd_item(blockIdx.x, gridDim.x, xcd_chunk);
     const int64_t ql = bid * 4 + w;
     if (ql >= nq) return;
@@ -453,9 +461,11 @@ __global__ __launch_bounds__(256, 4) void rerank_sym4_kernel(
     const uint32_t n_eval = n < uint32_t(MP) ? n : uint32_t(MP);
     // exact keys of the 128 candidates held as (jA: slot u, jB: slot u + 1), 16 candidates per pass: group r takes
     // candidate 16 p + r of the batch, lane c of the group keeps the result of the passes p with p % 4 == c
-    auto eval128 = [&](const uint32_t jA, const uint32_t jB, uint64_t& hA, uint32_t& lA, uint64_t& hB, uint32_t& lB) {
+    auto eval128 = [&](const uint32_t jA, const uint32_t jB, uint64_t& hA, uint32_t& lA, uint64_t& hB, uint32_t& lB,
+                       uint64_t& xA, uint64_t& xB) {
         hA = hB = kInfBits;
         lA = lB = 0xFFFFFFFFu;
+        xA = xB = 0ull;
 #pragma unroll 2
         for (int p = 0; p < 8; ++p) {
             const uint32_t pj = uint32_t(__shfl(int(p < 4 ? jA : jB), (p & 3) * 16 + r));   // position of the group's candidate
@@ -488,20 +498,24 @@ __global__ __launch_bounds__(256, 4) void rerank_sym4_kernel(
             const double dot = w2 + lane_xor_f64(w2, 1);        // (c0 + c2) + (c1 + c3)
             if (j != kNoRow && c == (p & 3)) {
                 const uint64_t key = (uint64_t)__double_as_longlong(gt_pair_key(qnq, dot, yn, 0));
+                const uint64_t keyt = want_t ? (uint64_t)__double_as_longlong(gt_pair_key(yn, dot, qnq, 0)) : 0ull;
                 if (p < 4) {
                     hA = key;
                     lA = j;
+                    xA = keyt;
                 } else {
                     hB = key;
                     lB = j;
+                    xB = keyt;
                 }
             }
         }
     };
     uint64_t hi[4];
     uint32_t lo[4];
+    uint64_t hx[4] = {0ull, 0ull, 0ull, 0ull};
     {
-        eval128(pc[0], pc[1], hi[0], lo[0], hi[1], lo[1]);
+        eval128(pc[0], pc[1], hi[0], lo[0], hi[1], lo[1], hx[0], hx[1]);
         hi[2] = hi[3] = kInfBits;
         lo[2] = lo[3] = 0xFFFFFFFFu;
     }
@@ -510,13 +524,15 @@ __global__ __launch_bounds__(256, 4) void rerank_sym4_kernel(
     if (!both) {
         uint64_t h2[2] = {hi[0], hi[1]};
         uint32_t l2[2] = {lo[0], lo[1]};
-        wave_sort_asc_pair_fast<2>(h2, l2, lane, park_hi, park_lo);
+        uint64_t x2[2] = {hx[0], hx[1]};
+        wave_sort_asc_pair_fast<2>(h2, l2, lane, park_hi, park_lo, want_t ? x2 : nullptr, park_x);
         hi[0] = h2[0]; hi[1] = h2[1];
         lo[0] = l2[0]; lo[1] = l2[1];
+        hx[0] = x2[0]; hx[1] = x2[1];
     } else {
-        eval128(pc[2], pc[3], hi[2], lo[2], hi[3], lo[3]);
+        eval128(pc[2], pc[3], hi[2], lo[2], hi[3], lo[3], hx[2], hx[3]);
         if (k257 != 0ull) lb = fmin(lb, bound_of_score(cand_score(k257)));   // candidates beyond the table
-        wave_sort_asc_pair_fast<4>(hi, lo, lane, park_hi, park_lo);
+        wave_sort_asc_pair_fast<4>(hi, lo, lane, park_hi, park_lo, want_t ? hx : nullptr, park_x);
     }
     const uint32_t n_def = n_tab > uint32_t(need_m) ? n_tab : uint32_t(need_m);
 #pragma unroll
@@ -524,6 +540,7 @@ __global__ __launch_bounds__(256, 4) void rerank_sym4_kernel(
         if (uint32_t(u * 64) < n_def) {   // wave-uniform
             cand_d2[size_t(q) * MP + u * 64 + lane] = __longlong_as_double((long long)hi[u]);
             cand_j[size_t(q) * MP + u * 64 + lane] = uint32_t(lo[u]);
+            if (want_t) cand_d2t[size_t(q) * MP + u * 64 + lane] = __longlong_as_double((long long)hx[u]);
         }
     }
     uint64_t sel = 0;
@@ -535,6 +552,10 @@ __global__ __launch_bounds__(256, 4) void rerank_sym4_kernel(
     if (lane == 0) {
         cand_n[q] = n_tab;
         d2_lb[q] = lb;
+        if (keyt_ok) {   // (a row handed to the repair pass gets a new table, without them: it is listed for the affinity pass)
+            keyt_ok[q] = (d2_need < lb) ? 1 : 0;
+            if (!(d2_need < lb)) nokeyt_rows[atomicAdd(nokeyt_count, 1u)] = int32_t(q);
+        }
         if (!(d2_need < lb)) {
             const uint32_t slot = atomicAdd(fb_count, 1u);
             fb_rows[slot] = int32_t(q);
@@ -922,15 +943,21 @@ int gt_launch_rerank_sym(gt_ctx* ctx, const RerankArgs& a, const SymRerank& sr) 
                        a.cand_d2, a.cand_j, a.cand_n, a.d2_lb, a.fb_count, a.fb_rows, a.gflags, a.radius_key_factor,      \
                        a.unproven, sr.stat, (ctx->dbg_select & 256) ? 1 : 0, sr.invperm, sr.own_rows, sr.own_r0, ctx->xcd_chunk,      \
                        (const T_*)sr.Xs, sr.xns)
-#define GT_RERANK_SYM4_LAUNCH(DB_)                                                                                        \
-    hipLaunchKernelGGL((rerank_sym4_kernel<DB_>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (const float*)a.X, a.d,    \
+#define GT_RERANK_SYM4_LAUNCH(DB_, WT_)                                                                                   \
+    hipLaunchKernelGGL((rerank_sym4_kernel<DB_, WT_>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (const float*)a.X, a.d, \
                        a.xn, a.nq, sr.tlists, sr.tcap, sr.tcounts, a.thr_final, a.ymax2, a.err, a.need_m, sr.perm,        \
                        a.cand_d2, a.cand_j, a.cand_n, a.d2_lb, a.fb_count, a.fb_rows, a.gflags, a.radius_key_factor,      \
                        a.unproven, sr.stat, (ctx->dbg_select & 256) ? 1 : 0, sr.invperm, sr.own_rows, sr.own_r0, ctx->xcd_chunk,      \
-                       (const float*)sr.Xs, sr.xns)
+                       (const float*)sr.Xs, sr.xns, sr.cand_d2t, sr.keyt_ok, sr.nokeyt_rows, sr.nokeyt_count)
+    if (sr.wrote_t) *sr.wrote_t = false;
     if (a.dtype == GT_F32) {
         const bool f4 = (a.d & 3) == 0 && (reinterpret_cast<uintptr_t>(a.X) & 15) == 0;
-        if (f4 && ctx->rerank_lanes4 != 0 && a.d <= 64 && sr.Xs != nullptr) GT_RERANK_SYM4_LAUNCH(1);
+        if (f4 && ctx->rerank_lanes4 != 0 && a.d <= 64 && sr.Xs != nullptr) {
+            const bool wt = sr.cand_d2t != nullptr && sr.keyt_ok != nullptr && sr.nokeyt_rows != nullptr && sr.nokeyt_count != nullptr;
+            if (wt) GT_RERANK_SYM4_LAUNCH(1, true);
+            else GT_RERANK_SYM4_LAUNCH(1, false);
+            if (sr.wrote_t) *sr.wrote_t = wt;
+        }
         else if (f4) GT_RERANK_SYM_LAUNCH(float, true);
         else GT_RERANK_SYM_LAUNCH(float, false);
     } else {

@@ -44,6 +44,16 @@ __device__ __forceinline__ int owner_of(const Splits& sp, int64_t row) {
     return o;
 }
 
+// the symmetrisation rule on one pair of values (base.py:557-577)
+__device__ __forceinline__ double merge_values(double a, double b, int symm, double theta) {
+    switch (symm) {
+        case GT_SYMM_ADD: return (a + b) / 2;
+        case GT_SYMM_MUL: return a * b;
+        case GT_SYMM_MNN: return theta * fmin(a, b) + (1 - theta) * fmax(a, b);
+        default: return a;
+    }
+}
+
 // idecay > 0: `decay` is that whole number (1 ... 128, the usual case: the default is 40) and the power is formed by
 // repeated squaring - a handful of multiplications instead of the library pow, which was most of the affinity kernel's
 // instructions (PMC: VALU busy 88 %).  The squarings' roundings add up to < 2^(bits of idecay) ulp of the power, i.e. a
@@ -144,14 +154,22 @@ __global__ __launch_bounds__(256) void stage_count_kernel(const int64_t nloc, co
 // Radius rows: exact float64 distance for every collected candidate, K into rK.
 // RADIUS: the launch covers the rows of the radius pass only (row_list, nloc of them) - their exact float64 distances
 // need registers the table rows of the main launch should not pay for with occupancy
-template <typename T, bool RADIUS>
+// PAIRS (table rows): 0 the plain kernel, 1 pair-resolved rows whose tables carry the transposed keys, 2 pair-resolved rows
+// whose tables came from a repair pass (the few: transposed keys from the dot products); a launch of 1 or 2 skips the other's rows
+template <typename T, bool RADIUS, int PAIRS>
 __global__ __launch_bounds__(256) void affinity_kernel(
     const int32_t* __restrict__ row_list, const int64_t nrows, const int64_t nloc, const int64_t r0, const T* __restrict__ X, const int d, const double* __restrict__ xn,
     const T* __restrict__ Qm, const double* __restrict__ qnorm, const int64_t qoff, const int dtype, const int metric, const int MP, const int limit, double* __restrict__ cand_d2, const uint32_t* __restrict__ cand_j,
     const uint32_t* __restrict__ cand_n, const int32_t* __restrict__ rowsrc, const uint64_t* __restrict__ rlists,
     const uint32_t* __restrict__ rcounts, const int32_t rcap, double* __restrict__ rK, const double* __restrict__ bw,
     const double decay, const int binary, const double thresh, const int count_owners, const Splits sp,
-    int32_t* __restrict__ lenN, int32_t* __restrict__ ownercnt, int32_t* __restrict__ tablen) {
+    int32_t* __restrict__ lenN, int32_t* __restrict__ ownercnt, int32_t* __restrict__ tablen,
+    const int pairs, const double* __restrict__ cand_d2t, const uint8_t* __restrict__ keyt_ok, const double rf_guard) {
+    // pairs (single-rank builds with the '+' rule, see graph_finish_pairs): the row settles its MUTUAL pairs itself.  For a
+    // kept entry (i, j) the value row j gives the same pair, K0(j, i), follows from the key row j holds for it - cand_d2t,
+    // or the dot product where the table came from a repair pass - and row j's bandwidth, through the very function row j
+    // uses: when it passes the threshold too the entry is stored as MINUS the merged value (final; nothing is sent), else
+    // as the plain value (the transposed half travels to row j as before).
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int lane = threadIdx.x & 63;
     const int w = threadIdx.x >> 6;
@@ -159,9 +177,10 @@ __global__ __launch_bounds__(256) void affinity_kernel(
     const int64_t wi = int64_t(blockIdx.x) * 4 + w;
     if (wi >= nrows) return;
     const int idecay = gt_whole_decay(decay);
-    const int64_t i = RADIUS ? int64_t(row_list[wi]) - qoff : wi;   // (the list holds rows of the query matrix: qoff + i)
+    const int64_t i = row_list ? int64_t(row_list[wi]) - qoff : wi;   // (a list holds rows of the query matrix: qoff + i)
     const int32_t src = rowsrc[i];
     if (RADIUS != (src >= 0)) return;   // (the other launch's row)
+    if (!RADIUS && PAIRS != 0 && (PAIRS == 1) != (keyt_ok[i] != 0)) return;   // (the other pair-resolving launch's row)
     const double bwi = bw[i];
     int kept = 0;
     int owner_cnt = 0;   // lane o accumulates the count for owner o (world <= 64)
@@ -169,6 +188,16 @@ __global__ __launch_bounds__(256) void affinity_kernel(
         uint32_t n = cand_n[i];
         if (n > uint32_t(limit)) n = uint32_t(limit);
         uint32_t* cand_j_w = const_cast<uint32_t*>(cand_j);
+        constexpr bool have_t = PAIRS == 1;
+        double qn_i = 0.0;
+        if constexpr (PAIRS == 2) {
+            // a table from a repair pass: the transposed keys are formed from the dot products (the query row in the LDS)
+            const T* xrow = Qm + (qoff + i) * int64_t(d);
+            for (int k = lane; k < d; k += 64) xs[k] = double(xrow[k]);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            qn_i = qnorm[qoff + i];
+        }
         for (uint32_t e0 = 0; e0 < n; e0 += 64) {
             const uint32_t e = e0 + lane;
             bool keep = false;
@@ -181,6 +210,25 @@ __global__ __launch_bounds__(256) void affinity_kernel(
                 if (!binary) kv = affinity(gt_key_to_dist(d2, dtype, metric), bwi, decay, idecay);
                 keep = binary || (kv >= thresh);
                 kvv = kv;
+                if constexpr (PAIRS != 0) {
+                    // (row j drops the pair when its distance exceeds bw_j x radius_factor: beyond that by a relative 1e-9 -
+                    //  six orders above the rounding of the affinity, which falls monotonically with the distance - the
+                    //  transposed value need not be formed to know that it is below the threshold)
+                    if (keep) {
+                        double d2t;
+                        if constexpr (have_t) {
+                            d2t = cand_d2t[i * MP + e];
+                        } else {
+                            const double dot = gt_dot16(xs, X + int64_t(j) * d, d);
+                            d2t = gt_pair_key(xn[j], dot, qn_i, metric);
+                        }
+                        const double dt = gt_key_to_dist(d2t, dtype, metric), bwj = bw[j];
+                        if (!(dt > bwj * rf_guard)) {
+                            const double kvt = affinity(dt, bwj, decay, idecay);
+                            if (kvt >= thresh) kvv = -merge_values(kv, kvt, GT_SYMM_ADD, 1.0);
+                        }
+                    }
+                }
             }
             // the kept entries move to the front of the row, in order (in place: a chunk is read before it is written, and
             // only at or below where it was read) - the table is sorted by distance, so they are a prefix anyway and nothing
@@ -227,6 +275,11 @@ __global__ __launch_bounds__(256) void affinity_kernel(
                 const double kv = affinity(gt_key_to_dist(t, dtype, metric), bwi, decay, idecay);
                 keep = kv >= thresh;
                 kvv = kv;
+                if (pairs && keep) {
+                    const double tt = gt_pair_key(xn[j], dot, qn, metric);
+                    const double kvt = affinity(gt_key_to_dist(tt, dtype, metric), bw[j], decay, idecay);
+                    if (kvt >= thresh) kvv = -merge_values(kv, kvt, GT_SYMM_ADD, 1.0);
+                }
             }
             // (kept entries to the front, as above; the list is in no particular order)
             const unsigned long long km = __ballot(keep);
@@ -490,10 +543,13 @@ __device__ __forceinline__ void for_kept_entries(const int64_t i, const int lane
             v = kv[e];
             j = (src < 0) ? cand_j[i * MP + e] : cand_index(rlists[size_t(src) * rcap + e]);
         }
-        f(v >= 0.0, j, v);
+        // (a kept value is positive; pair-resolved builds store a settled mutual pair as minus its final value: such an
+        //  entry stays in its row and nothing of it is sent - but it keeps its slot in the enumeration of the kept entries)
+        f(e < n, e < n && v >= 0.0, j, v);
     }
 }
 
+constexpr uint32_t kNoDest = 0xFFFFFFFFu;   // posj of a kept entry that is not sent
 constexpr int kEmitRows = 128;   // sorted rows per workgroup of bin_emit_kernel
 
 __global__ __launch_bounds__(256) void bin_count_kernel(const int64_t nloc, const int MP, const double* __restrict__ cand_k,
@@ -514,13 +570,15 @@ __global__ __launch_bounds__(256) void bin_count_kernel(const int64_t nloc, cons
     for (int64_t p = int64_t(blockIdx.x) * 4 + w; p < nloc; p += int64_t(gridDim.x) * 4) {
         int64_t at = sN[p];
         for_kept_entries(perm[p], lane, MP, cand_k, cand_j, rowsrc, rlists, rcounts, rcap, rK, tablen,
-                         [&](bool keep, uint32_t j, double) {
+                         [&](bool slot, bool send, uint32_t j, double) {
                              int total;
-                             const int q = wave_prefix_count(keep, lane, total);
-                             if (keep) {
+                             const int q = wave_prefix_count(slot, lane, total);
+                             if (send) {
                                  const uint32_t pj = uint32_t(pos[j]);
                                  posj[at + q] = pj;
                                  atomicAdd(&hist[pj >> shift], 1);
+                             } else if (slot) {
+                                 posj[at + q] = kNoDest;   // (a settled pair: nothing travels)
                              }
                              at += total;
                          });
@@ -548,7 +606,10 @@ __global__ __launch_bounds__(256) void bin_emit_kernel(const int64_t nloc, const
     const int64_t p0 = int64_t(blockIdx.x) * kEmitRows;
     const int64_t p1 = p0 + kEmitRows < nloc ? p0 + kEmitRows : nloc;
     // (the destinations of the workgroup's rows are one contiguous stretch of posj)
-    for (int64_t e = sN[p0] + threadIdx.x; e < sN[p1]; e += 256) atomicAdd(&hist[posj[e] >> shift], 1);
+    for (int64_t e = sN[p0] + threadIdx.x; e < sN[p1]; e += 256) {
+        const uint32_t pj = posj[e];
+        if (pj != kNoDest) atomicAdd(&hist[pj >> shift], 1);
+    }
     __syncthreads();
     for (int b = threadIdx.x; b < nbins; b += 256)
         if (hist[b] != 0) {
@@ -560,12 +621,12 @@ __global__ __launch_bounds__(256) void bin_emit_kernel(const int64_t nloc, const
         const uint32_t i = uint32_t(perm[p]);
         int64_t at = sN[p];
         for_kept_entries(int64_t(i), lane, MP, cand_k, cand_j, rowsrc, rlists, rcounts, rcap, rK, tablen,
-                         [&](bool keep, uint32_t, double v) {
+                         [&](bool slot, bool send, uint32_t, double v) {
                              int total;
-                             const int q = wave_prefix_count(keep, lane, total);
+                             const int q = wave_prefix_count(slot, lane, total);
                              const int64_t mine = at + q;
                              at += total;
-                             if (keep) {
+                             if (send) {
                                  const uint32_t pj = posj[mine];
                                  const int b = int(pj >> shift);
                                  const int slot = base[b] + atomicAdd(&hist[b], 1);
@@ -712,14 +773,6 @@ __global__ __launch_bounds__(256) void scatter_i32_kernel(const int32_t* __restr
 }
 
 // ---- S5: per-row sort by column + merge of (K0, K0^T) pairs ---------------------------------------
-__device__ __forceinline__ double merge_values(double a, double b, int symm, double theta) {
-    switch (symm) {
-        case GT_SYMM_ADD: return (a + b) / 2;
-        case GT_SYMM_MUL: return a * b;
-        case GT_SYMM_MNN: return theta * fmin(a, b) + (1 - theta) * fmax(a, b);
-        default: return a;
-    }
-}
 
 // merge a sorted key/value sequence held in registers (position p = t*64 + lane); returns the number of
 // merged entries written to (Vk, Vv).  Keys: (column << 1) | tag, kNoKey where there is no entry (columns are below
@@ -1212,7 +1265,8 @@ __device__ __forceinline__ double merge_sorted_final(const uint32_t (&hi)[NT], c
         const double v = __longlong_as_double((long long)val);
         const double a = tag == 0 ? v : 0.0;
         const double b = tag == 1 ? v : (pair ? __longlong_as_double((long long)nv) : 0.0);
-        const double m = merge_values(a, b, GT_SYMM_ADD, 1.0);
+        // (pair-resolved builds: an own entry stored negative is final already - minus the merged value of a mutual pair)
+        const double m = (tag == 0 && v < 0.0) ? -v : merge_values(a, b, GT_SYMM_ADD, 1.0);
         const bool emit = first;   // ('+': a merged value is never 0 - both parts are >= thresh or absent)
         int total;
         const int pp = wave_prefix_count(emit, lane, total);
@@ -1423,16 +1477,23 @@ Splits make_splits(const GraphState* g) {
 template <typename T>
 void launch_affinity(gt_ctx* ctx, GraphState* g, KnnWork* k, int binary, double decay, double thresh, int count_owners) {
     const size_t lds = size_t(4) * ctx->d * sizeof(double);
-#define GT_AFFINITY_LAUNCH(RADIUS_, LIST_, NROWS_)                                                                          \
-    hipLaunchKernelGGL((affinity_kernel<T, RADIUS_>), dim3((unsigned)ceil_div64(NROWS_, 4)), dim3(256), lds, ctx->stream,   \
+#define GT_AFFINITY_LAUNCH(RADIUS_, PAIRS_, LIST_, NROWS_)                                                                  \
+    hipLaunchKernelGGL((affinity_kernel<T, RADIUS_, PAIRS_>), dim3((unsigned)ceil_div64(NROWS_, 4)), dim3(256), lds, ctx->stream, \
                        LIST_, int64_t(NROWS_), g->nloc, g->r0, (const T*)ctx->X, ctx->d, ctx->xn.as<double>(),              \
                        (const T*)g->Qmat, g->qnorm, g->qoff, ctx->dtype, ctx->metric, k->MP, g->limit,                     \
                        k->cand_d2.as<double>(), k->cand_j.as<uint32_t>(), k->cand_n.as<uint32_t>(), g->rowsrc.as<int32_t>(), \
                        g->rlists.as<uint64_t>(), g->rcounts.as<uint32_t>(), g->rcap, g->rK.as<double>(),                   \
                        g->bw.as<double>(), decay, binary, thresh, count_owners, make_splits(g), g->lenN.as<int32_t>(),      \
-                       g->ownercnt.as<int32_t>(), g->tablen.as<int32_t>())
-    GT_AFFINITY_LAUNCH(false, (const int32_t*)nullptr, g->nloc);
-    if (g->n_over > 0) GT_AFFINITY_LAUNCH(true, g->over_rows.as<int32_t>(), g->n_over);
+                       g->ownercnt.as<int32_t>(), g->tablen.as<int32_t>(), g->pairs ? 1 : 0,                               \
+                       g->pairs ? k->cand_d2t.as<double>() : (const double*)nullptr,                                       \
+                       g->pairs ? k->keyt_ok.as<uint8_t>() : (const uint8_t*)nullptr, g->radius_factor * (1.0 + 1e-9))
+    if (g->pairs) {
+        GT_AFFINITY_LAUNCH(false, 1, (const int32_t*)nullptr, g->nloc);
+        if (k->nokeyt_n > 0) GT_AFFINITY_LAUNCH(false, 2, k->nokeyt_rows.as<int32_t>(), int64_t(k->nokeyt_n));   // (qoff = 0 here)
+    } else {
+        GT_AFFINITY_LAUNCH(false, 0, (const int32_t*)nullptr, g->nloc);
+    }
+    if (g->n_over > 0) GT_AFFINITY_LAUNCH(true, 0, g->over_rows.as<int32_t>(), g->n_over);
 #undef GT_AFFINITY_LAUNCH
 }
 
@@ -1744,6 +1805,17 @@ static int graph_begin_impl(gt_ctx* ctx, const gt_knn_params* params, int32_t wo
     }
     // ---- affinities + per-row / per-destination counts ----
     const int count_owners = (params->kernel_symm != GT_SYMM_NONE) ? 1 : 0;
+    // pair-resolved symmetrisation (graph_finish_pairs): a whole single-rank build (gt_graph_build) with the '+' rule whose
+    // tables carry the transposed keys and whose transpose will go through the destination bins
+    g->pairs = ctx->in_graph_build && ctx->symm_pairs != 0 && ctx->symm_pair_ok != 0 && ctx->symm_bins != 0 && world == 1 &&
+               !external && !binary && params->knn_max <= 0 && params->kernel_symm == GT_SYMM_ADD && params->anisotropy == 0.0 &&
+               ctx->metric == 0 && k->keyt_valid && k->ordered && k->nq == g->nloc && g->r0 == 0 &&
+               g->nloc < (int64_t(1) << 31) && (ctx->symm_bins > 0 || g->nloc >= 65536);
+    if (ctx->dbg_select & 2048)
+        std::fprintf(stderr, "[gt] pairs %d: in_build %d opt %d ok %d bins %d world %d ext %d bin %d kmax %lld symm %d aniso %g metric %d keyt %d ordered %d nq %lld nloc %lld r0 %lld\n",
+                     int(g->pairs), ctx->in_graph_build, ctx->symm_pairs, ctx->symm_pair_ok, ctx->symm_bins, world, int(external), int(binary),
+                     (long long)params->knn_max, params->kernel_symm, params->anisotropy, ctx->metric, int(k->keyt_valid), int(k->ordered),
+                     (long long)k->nq, (long long)g->nloc, (long long)g->r0);
     {
         StageSpan span(ctx, "affinity");
         if (ctx->dtype == GT_F32)
@@ -2084,6 +2156,152 @@ static int graph_finish_impl(gt_ctx* ctx, const void* recv_buf_dev, int64_t n_re
 // Fused tail (see pair_count_kernel): single rank, every row local, cell-sorted order at hand, '+' symmetrisation, no
 // anisotropy, every kept value > 0.  Returns 1 when K, P and the degrees are final, 0 when the build has to take the
 // other path instead (a union row of more than 2048 entries), < 0 on error.
+// ---- pair-resolved tail ('+' rule, single rank) ---------------------------------------------------------------------
+// affinity_kernel has settled every mutual pair in its own row (negative = final value), so only the one-sided entries
+// are transposed: 44 M instead of 72 M triplets at N = 1e6, no pair ever meets its partner in a union row - a row's
+// final length is its own kept entries plus what it receives, known once the bins are filled - and the merge sorts and
+// writes K and P straight into the CSR (merge_final_kernel of the count-first tail, without its counting pass).
+__global__ __launch_bounds__(256) void pairs_len_kernel(const int64_t nloc, const int32_t* __restrict__ pos,
+                                                        const int64_t* __restrict__ off, int32_t* __restrict__ outlen,
+                                                        int32_t* __restrict__ biglist, uint32_t* __restrict__ bigcount,
+                                                        uint32_t* __restrict__ fflags) {
+    const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= nloc) return;
+    const int64_t p = pos[i];
+    const int64_t L = off[p + 1] - off[p];
+    outlen[i] = int32_t(L);
+    if (L > kBigRow) {
+        if (L > kHugeRow) atomicOr(fflags, kFusedHugeRow);
+        else biglist[atomicAdd(bigcount, 1u)] = int32_t(i);
+    }
+}
+
+// returns 1: K and P are complete; 0: a union row beyond the register sorts - the caller rebuilds without this path
+static int graph_finish_pairs(gt_ctx* ctx, int64_t* out_nnz, uint32_t* flags) {
+    GraphState* g = ctx->graph;
+    KnnWork* k = ctx->knn;
+    const int64_t nloc = g->nloc;
+    const int64_t n_own = g->send_counts_host[0];   // kept entries of all rows (an upper bound of what is sent)
+    if (n_own <= 0) return 0;
+    StageSpan span(ctx, "symmetrize");
+    const int32_t* perm = k->qorder.as<int32_t>();
+    int shift = 9;
+    if (ctx->symm_bin_shift > 0) shift = ctx->symm_bin_shift;
+    while (ceil_div64(nloc, int64_t(1) << shift) > 4096) ++shift;
+    const int nbins = int(ceil_div64(nloc, int64_t(1) << shift));
+    GT_HIP(ctx, k->sh_invperm.reserve(size_t(nloc) * sizeof(int32_t)));
+    GT_HIP(ctx, g->cnt_sorted.reserve(size_t(nloc) * sizeof(int32_t)));
+    GT_HIP(ctx, g->pos_sorted.reserve(size_t(nloc + 1) * sizeof(int64_t)));
+    GT_HIP(ctx, g->bincnt.reserve(size_t(2 * nbins) * sizeof(int32_t)));
+    GT_HIP(ctx, g->binoff.reserve(size_t(nbins + 1) * sizeof(int64_t)));
+    GT_HIP(ctx, g->cursor.reserve(size_t(n_own) * sizeof(uint32_t)));   // posj
+    GT_HIP(ctx, g->selfbuf.reserve(size_t(n_own) * sizeof(Triplet)));
+    GT_HIP(ctx, g->ucol.reserve(size_t(n_own) * sizeof(uint32_t)));
+    GT_HIP(ctx, g->uval.reserve(size_t(n_own) * sizeof(double)));
+    GT_HIP(ctx, g->off.reserve(size_t(nloc + 1) * sizeof(int64_t)));
+    GT_HIP(ctx, g->outlen.reserve(size_t(nloc) * sizeof(int32_t)));
+    GT_HIP(ctx, g->bigrows.reserve(size_t(nloc) * sizeof(int32_t)));
+    GT_HIP(ctx, g->bigcount.reserve(4 * sizeof(uint32_t)));   // [0] long rows, [2] flags
+    GT_HIP(ctx, g->indptr.reserve(size_t(nloc + 1) * sizeof(int64_t)));
+    GT_HIP(ctx, g->degree.reserve(size_t(nloc) * sizeof(double)));
+    GT_HIP(ctx, hipMemsetAsync(g->bincnt.p, 0, size_t(2 * nbins) * sizeof(int32_t), ctx->stream));
+    GT_HIP(ctx, hipMemsetAsync(g->bigcount.p, 0, 4 * sizeof(uint32_t), ctx->stream));
+    uint32_t* fflags = g->bigcount.as<uint32_t>() + 2;
+    {
+        StageSpan span_bins(ctx, "symm_bins");
+        GT_TRY(gt_sym_invperm(ctx, perm, k->sh_invperm.as<int32_t>()));
+        hipLaunchKernelGGL(gather_counts_kernel, dim3((unsigned)ceil_div64(nloc, 256)), dim3(256), 0, ctx->stream,
+                           g->lenN.as<int32_t>(), perm, nloc, g->cnt_sorted.as<int32_t>());
+        GT_TRY(exclusive_scan(ctx, g->cnt_sorted.as<int32_t>(), nullptr, nloc, g->pos_sorted.as<int64_t>(), g->scan_tmp));
+        hipLaunchKernelGGL(bin_count_kernel, dim3((unsigned)std::min<int64_t>(ceil_div64(nloc, 64), 2048)), dim3(256),
+                           size_t(nbins) * sizeof(int32_t), ctx->stream, nloc, k->MP, k->cand_d2.as<double>(),
+                           k->cand_j.as<uint32_t>(), g->rowsrc.as<int32_t>(), g->rlists.as<uint64_t>(),
+                           g->rcounts.as<uint32_t>(), g->rcap, g->rK.as<double>(), g->tablen.as<int32_t>(), perm,
+                           k->sh_invperm.as<int32_t>(), shift, nbins, g->pos_sorted.as<int64_t>(), g->cursor.as<uint32_t>(),
+                           g->bincnt.as<int32_t>());
+        GT_TRY(exclusive_scan(ctx, g->bincnt.as<int32_t>(), nullptr, nbins, g->binoff.as<int64_t>(), g->scan_tmp));
+        hipLaunchKernelGGL(bin_emit_kernel, dim3((unsigned)ceil_div64(nloc, kEmitRows)), dim3(256), size_t(2 * nbins) * sizeof(int32_t),
+                           ctx->stream, nloc, k->MP, k->cand_d2.as<double>(), k->cand_j.as<uint32_t>(), g->rowsrc.as<int32_t>(),
+                           g->rlists.as<uint64_t>(), g->rcounts.as<uint32_t>(), g->rcap, g->rK.as<double>(),
+                           g->tablen.as<int32_t>(), perm, g->pos_sorted.as<int64_t>(), g->cursor.as<uint32_t>(), shift, nbins,
+                           g->binoff.as<int64_t>(), g->bincnt.as<int32_t>() + nbins, (Triplet*)g->selfbuf.p);
+        hipLaunchKernelGGL(bin_fill_kernel<256>, dim3((unsigned)nbins), dim3(256), size_t(2) * (size_t(1) << shift) * sizeof(int32_t),
+                           ctx->stream, nloc, k->MP, k->cand_d2.as<double>(), k->cand_j.as<uint32_t>(), g->rowsrc.as<int32_t>(),
+                           g->rlists.as<uint64_t>(), g->rcounts.as<uint32_t>(), g->rcap, g->rK.as<double>(),
+                           g->tablen.as<int32_t>(), perm, shift, nbins, g->binoff.as<int64_t>(), (const Triplet*)g->selfbuf.p,
+                           g->cnt_sorted.as<int32_t>(), g->pos_sorted.as<int64_t>(), g->off.as<int64_t>(), (UEntry*)nullptr,
+                           g->ucol.as<uint32_t>(), g->uval.as<double>());
+        GT_HIP(ctx, hipGetLastError());
+    }
+    // final row lengths (own + received: nothing merges), CSR offsets in row order
+    hipLaunchKernelGGL(pairs_len_kernel, dim3((unsigned)ceil_div64(nloc, 256)), dim3(256), 0, ctx->stream, nloc,
+                       k->sh_invperm.as<int32_t>(), g->off.as<int64_t>(), g->outlen.as<int32_t>(), g->bigrows.as<int32_t>(),
+                       g->bigcount.as<uint32_t>(), fflags);
+    GT_HIP(ctx, hipGetLastError());
+    GT_TRY(exclusive_scan(ctx, g->outlen.as<int32_t>(), nullptr, nloc, g->indptr.as<int64_t>(), g->scan_tmp));
+    int64_t nnz = 0;
+    uint32_t ff = 0;
+    GT_HIP(ctx, hipMemcpyAsync(&nnz, g->indptr.as<int64_t>() + nloc, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    GT_HIP(ctx, hipMemcpyAsync(&ff, fflags, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->dbg_select & 2048) {
+        std::vector<int32_t> ol(nloc);
+        std::vector<int64_t> oh(nloc + 1);
+        (void)hipMemcpy(ol.data(), g->outlen.p, size_t(nloc) * 4, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(oh.data(), g->off.p, size_t(nloc + 1) * 8, hipMemcpyDeviceToHost);
+        int64_t mx = 0, arg = 0, neg = 0, nonmono = 0;
+        for (int64_t i = 0; i < nloc; ++i) {
+            if (ol[i] > mx) mx = ol[i], arg = i;
+            if (ol[i] < 0) ++neg;
+            if (oh[i + 1] < oh[i]) ++nonmono;
+        }
+        std::fprintf(stderr, "[gt] pair-resolved tail: flags %u, nnz %lld, own entries %lld; longest row %lld (row %lld), negative %lld, off not monotone at %lld places, off[n] %lld\n",
+                     ff, (long long)nnz, (long long)n_own, (long long)mx, (long long)arg, (long long)neg, (long long)nonmono, (long long)oh[nloc]);
+    }
+    if (ff != 0) return 0;
+    GT_HIP(ctx, g->indices.reserve(size_t(nnz) * sizeof(int32_t)));
+    GT_HIP(ctx, g->Kdata.reserve(size_t(nnz) * sizeof(double)));
+    GT_HIP(ctx, g->Pdata.reserve(size_t(nnz) * sizeof(double)));
+    FusedSrc fs;
+    fs.pos = k->sh_invperm.as<int32_t>();
+    fs.lenN = g->lenN.as<int32_t>();
+    fs.off = g->off.as<int64_t>();
+    fs.sN = g->pos_sorted.as<int64_t>();
+    fs.rowsrc = g->rowsrc.as<int32_t>();
+    fs.cand_k = k->cand_d2.as<double>();
+    fs.cand_j = k->cand_j.as<uint32_t>();
+    fs.MP = k->MP;
+    fs.rlists = g->rlists.as<uint64_t>();
+    fs.rK = g->rK.as<double>();
+    fs.rcap = g->rcap;
+    fs.ucol = g->ucol.as<uint32_t>();
+    fs.uval = g->uval.as<double>();
+    {
+        StageSpan span_m(ctx, "symm_merge");
+        hipLaunchKernelGGL(merge_final_kernel, dim3((unsigned)ceil_div64(nloc, 4)), dim3(256), 0, ctx->stream, nloc, fs,
+                           g->indptr.as<int64_t>(), g->indices.as<int32_t>(), g->Kdata.as<double>(), g->Pdata.as<double>(),
+                           g->degree.as<double>(), g->flags.as<uint32_t>(),
+                           (ctx->symm_key32 != 0 && sort_key_fits_u32(g->n_total, 8)) ? 1 : 0);
+        hipLaunchKernelGGL(merge_long_final_kernel, dim3(1024), dim3(64), 0, ctx->stream, fs, g->indptr.as<int64_t>(),
+                           g->indices.as<int32_t>(), g->Kdata.as<double>(), g->Pdata.as<double>(), g->degree.as<double>(),
+                           g->flags.as<uint32_t>(), g->bigrows.as<int32_t>(), g->bigcount.as<uint32_t>());
+        GT_HIP(ctx, hipGetLastError());
+    }
+    uint32_t fl = 0, kfl = 0;
+    GT_HIP(ctx, hipMemcpyAsync(&fl, g->flags.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    GT_HIP(ctx, hipMemcpyAsync(&kfl, k->gflags.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    g->nnz0 = n_own;
+    g->nnz = nnz;
+    g->finished = true;
+    fl |= kfl;
+    if (k->n_fallback > 0) fl |= GT_FLAG_FALLBACK_ROWS;
+    if (g->n_over > 0) fl |= GT_FLAG_RADIUS_ROWS;
+    if (out_nnz) *out_nnz = g->nnz;
+    if (flags) *flags = fl;
+    return 1;
+}
+
 static int graph_finish_fused(gt_ctx* ctx, int64_t* out_nnz, uint32_t* flags) {
     GraphState* g = ctx->graph;
     KnnWork* k = ctx->knn;
@@ -2273,7 +2491,24 @@ extern "C" int gt_graph_build(gt_ctx* ctx, const gt_knn_params* params, int64_t*
     if (!ctx) return GT_E_ARG;
     int64_t splits[2] = {0, ctx->n};
     int64_t sendc[1] = {0};
-    GT_TRY(gt_graph_begin(ctx, params, 1, 0, splits, sendc));
+    for (int attempt = 0;; ++attempt) {
+        ctx->in_graph_build = 1;
+        const int rc_b = gt_graph_begin(ctx, params, 1, 0, splits, sendc);
+        ctx->in_graph_build = 0;
+        if (rc_b != GT_OK) return rc_b;
+        if (!ctx->graph->pairs) break;
+        const int rc = sendc[0] > 0 ? graph_finish_pairs(ctx, out_nnz, flags) : 0;
+        if (rc < 0) return rc;
+        if (rc == 1) {
+            ctx->graph->bins_used = true;
+            ctx->graph->fused_used = false;
+            return GT_OK;
+        }
+        // a union row beyond the register sorts (a hub of the transpose): the tables hold settled pairs the general tail
+        // cannot read - this point set is built again, now and from here on, the general way
+        ctx->symm_pair_ok = 0;
+        if (attempt > 0) GT_FAIL(ctx, GT_E_STATE, "gt_graph_build: the pair-resolved path was taken twice");
+    }
     GraphState* g = ctx->graph;
     KnnWork* k = ctx->knn;
     // every row is here: with the cell-sorted order of the points at hand the transpose is built through destination

@@ -138,3 +138,61 @@ def test_count_first_tail_equals_sort_and_compact(n, d, maker, seed, kw):
     b = _build(X, 1, **kw)
     assert f[2] is False or f[2] is True   # (either tail may have run: a declined attempt falls back)
     _same(f, b)
+
+
+def _build_pairs(X, pairs, knn=15, decay=40.0, bandwidth=None, opts=()):
+    """single-rank build with the symmetric candidate pass and the bin transpose forced on; returns the CSR parts, P and which
+    tail ran ("pairs": K and P written by the merge itself, no compaction pass)"""
+    from graphtools_amd import _hip
+
+    c = _hip.Context(0)
+    for k, v in (("query_order_min_rows", 1), ("symmetrize_bins", 1), ("select_symmetric", 1), ("select_sym_stride", 4),
+                 ("symmetrize_pairs", pairs)) + tuple(opts):
+        c.set_option(k, str(v))
+    c.set_points(X)
+    p, keep = c.make_params(knn, decay, 1e-4, bandwidth, 1.0, None, "+", None, 0)
+    out = []
+    for _ in range(2):      # (twice: a refuted pair path is remembered for the point set)
+        c.graph_build(p)
+        tail = "pairs" if (c.stage_ms("symm_merge") >= 0 and c.stage_ms("symm_compact") < 0) else "general"
+        out.append((c.graph_fetch_csr(_hip.CSR_K), c.graph_fetch_csr(_hip.CSR_P)[0], tail, c.graph_stats(), c.knn_stats()))
+    c.close()
+    return out
+
+
+@pytest.mark.parametrize("n,d,maker,seed,kw", [
+    (20000, 32, make_mix, 3, {}),
+    (30000, 24, make_manifold, 4, {"knn": 10, "decay": 20.0}),
+    (16000, 16, make_mix, 5, {"knn": 5, "decay": 8.0}),                  # wide kernel: radius rows, long union rows
+    (9000, 40, make_mix, 6, {"bandwidth": 6.0}),                          # caller's bandwidth
+])
+def test_pair_resolved_tail_equals_the_general_tail(n, d, maker, seed, kw):
+    """'+' rule, single rank: every row settles its mutual pairs itself from the transposed keys the re-rank left next to its
+    table (or from the dot products where the table came from a repair / radius pass), only one-sided entries travel, the merge
+    writes K and P at their final place.  Bar: K (structure and values) and P bit for bit those of the general tail."""
+    X = maker(n, d, seed)
+    a = _build_pairs(X, 1, **kw)
+    b = _build_pairs(X, 0, **kw)
+    assert b[0][2] == "general" and b[1][2] == "general"
+    assert a[0][4]["symmetric"], "the symmetric candidate pass did not run: nothing was tested"
+    for x, y in zip(a, b):
+        _same(x, y)
+    # the pair path ran, or was refuted by a union row beyond the register sorts - then it stays off for the point set
+    assert a[0][2] == "pairs" or a[1][2] == "general"
+    if a[0][2] == "pairs":
+        assert a[1][2] == "pairs"
+
+
+def test_pair_resolved_tail_gives_way_to_hub_rows():
+    """a point set with a hub (many rows keep one row that keeps few of them): its union row is longer than the register sorts
+    hold - the build is redone the general way and the verdict sticks"""
+    rng = np.random.default_rng(8)
+    X = make_mix(24000, 12, 8)
+    X[:4000] = X[4000] + 0.35 * rng.standard_normal((4000, 12)).astype(np.float32)    # a dense knot around one point
+    a = _build_pairs(X, 1, knn=4, decay=3.0)
+    b = _build_pairs(X, 0, knn=4, decay=3.0)
+    for x, y in zip(a, b):
+        _same(x, y)
+    lens = np.diff(a[0][0][2])
+    if lens.max() > 2048:
+        assert a[0][2] == "general" and a[1][2] == "general"
