@@ -297,6 +297,14 @@ def kernel_table(ctx, st, n, nloc, d, world, nnz, nnz0, main):
             "both halves of every union row in, merged row out")
         hbm("symm_compact", "compact_kernel", st.mean("symm_compact"), nnz * 12.0 + nnz * 20.0,
             "merged rows in, CSR K (4 + 8 B) and P (8 B) out")
+    elif st.mean("symm_merge") > 0:
+        # pair-resolved tail: mutual pairs were settled by the affinity pass, only one-sided entries (nnz - nnz0 of them)
+        # are transposed, the merge writes K and P at their final place
+        one_sided = float(nnz - nnz0)
+        hbm("symm_bins", "bin_count_kernel + bin_emit_kernel + bin_fill_kernel", st.mean("symm_bins"),
+            nnz0 * 12.0 + one_sided * 12.0, "kept entries in, one-sided entries out (12 B each)")
+        hbm("symm_merge", "merge_final_kernel (+ merge_long_final_kernel)", st.mean("symm_merge"),
+            nnz0 * 12.0 + one_sided * 12.0 + nnz * 20.0, "own and received entries in, CSR K (4 + 8 B) and P (8 B) out")
     else:
         hbm("symmetrize", "symmetrise + compact (K, P)", st.mean("symmetrize"),
             2.0 * nnz0 * 12.0 + nnz * 12.0 + nnz * 12.0 + nnz * 8.0,
