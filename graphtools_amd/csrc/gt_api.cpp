@@ -97,6 +97,8 @@ void gt_ctx_destroy(gt_ctx* ctx) {
     ctx->dense_bw.release();
     ctx->X_norm.release();
     for (DevBuf* b : {&ctx->land_Y, &ctx->land_h, &ctx->order_cell, &ctx->order_rows, &ctx->order_tmp}) b->release();
+    if (ctx->side_event) (void)hipEventDestroy(ctx->side_event);
+    if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

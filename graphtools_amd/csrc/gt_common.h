@@ -88,6 +88,8 @@ struct KnnWork;     // gt_knn.hip
 struct gt_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t side_stream = nullptr;   // created on first use: a launch that may overlap the main stream's (see side_launch_begin / end)
+    hipEvent_t side_event = nullptr;
     std::string err;
     std::map<std::string, StageAcc> stages;
     std::vector<hipEvent_t> event_pool;

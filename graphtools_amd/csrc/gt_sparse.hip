@@ -2278,14 +2278,24 @@ static int graph_finish_pairs(gt_ctx* ctx, int64_t* out_nnz, uint32_t* flags) {
     fs.uval = g->uval.as<double>();
     {
         StageSpan span_m(ctx, "symm_merge");
+        // the few long rows (one wave each, 270 registers: a thousand waves for half a millisecond) run on a side stream
+        // next to the merge of the others - the two launches write different rows; the main stream was drained by the
+        // read-back above, and takes the side stream's completion back before anything looks at the result
+        if (!ctx->side_stream) {
+            GT_HIP(ctx, hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
+            GT_HIP(ctx, hipEventCreateWithFlags(&ctx->side_event, hipEventDisableTiming));
+        }
+        hipLaunchKernelGGL(merge_long_final_kernel, dim3(1024), dim3(64), 0, ctx->side_stream, fs, g->indptr.as<int64_t>(),
+                           g->indices.as<int32_t>(), g->Kdata.as<double>(), g->Pdata.as<double>(), g->degree.as<double>(),
+                           g->flags.as<uint32_t>(), g->bigrows.as<int32_t>(), g->bigcount.as<uint32_t>());
+        GT_HIP(ctx, hipGetLastError());
+        GT_HIP(ctx, hipEventRecord(ctx->side_event, ctx->side_stream));
         hipLaunchKernelGGL(merge_final_kernel, dim3((unsigned)ceil_div64(nloc, 4)), dim3(256), 0, ctx->stream, nloc, fs,
                            g->indptr.as<int64_t>(), g->indices.as<int32_t>(), g->Kdata.as<double>(), g->Pdata.as<double>(),
                            g->degree.as<double>(), g->flags.as<uint32_t>(),
                            (ctx->symm_key32 != 0 && sort_key_fits_u32(g->n_total, 8)) ? 1 : 0);
-        hipLaunchKernelGGL(merge_long_final_kernel, dim3(1024), dim3(64), 0, ctx->stream, fs, g->indptr.as<int64_t>(),
-                           g->indices.as<int32_t>(), g->Kdata.as<double>(), g->Pdata.as<double>(), g->degree.as<double>(),
-                           g->flags.as<uint32_t>(), g->bigrows.as<int32_t>(), g->bigcount.as<uint32_t>());
         GT_HIP(ctx, hipGetLastError());
+        GT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->side_event, 0));
     }
     uint32_t fl = 0, kfl = 0;
     GT_HIP(ctx, hipMemcpyAsync(&fl, g->flags.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
