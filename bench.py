@@ -125,19 +125,25 @@ def worker_threads(info):
     return int(max(th + [1]))
 
 
-def profiled_traffic(kernel_names):
-    """HBM bytes per launch for the named kernels from the committed rocprofv3 PMC passes of this command (FETCH_SIZE with
-    the gfx950 correction of MI355X_MICROARCH.md + WRITE_SIZE, tools/pmc_traffic_summary.py).  PMC counters cannot be read
-    from inside the benchmarked process; None when the profile does not hold the kernel."""
+def profiled_traffic(kernel_names, per="launch"):
+    """HBM-side bytes of the named kernels from the committed rocprofv3 PMC passes of this command (FETCH_SIZE with the gfx950
+    correction of MI355X_MICROARCH.md + WRITE_SIZE, tools/pmc_traffic_summary.py): per launch of the (first) matching kernel, or
+    per graph (all launches of all matching kernels, divided by the number of builds the profiled command ran).  PMC counters
+    cannot be read from inside the benchmarked process; None when the profile does not hold the kernel."""
     try:
         with open(PROFILE_TRAFFIC) as f:
-            ks = json.load(f)["kernels"]
+            prof = json.load(f)
+        ks = prof["kernels"]
     except Exception:
         return None
+    builds = float(prof.get("builds_in_run", 2))   # (bench.py --steps 1 --warmup 0: the timed step and the H2D-inclusive step)
     tot, found = 0.0, False
     for name, k in ks.items():
-        if any(name.startswith(kn) or kn in name for kn in kernel_names):
-            tot += (k["hbm_read_GB_per_launch_corrected_x2"] + k["hbm_write_GB_per_launch"]) * k.get("launches", 1)
+        if any(name.split("<")[0] == kn.split("<")[0] or (kn.endswith("_") and name.startswith(kn)) for kn in kernel_names):
+            one = k["hbm_read_GB_per_launch_corrected_x2"] + k["hbm_write_GB_per_launch"]
+            if per == "launch":
+                return one * 1e9
+            tot += one * k.get("launches", 1) / builds
             found = True
     return tot * 1e9 if found else None
 
@@ -282,7 +288,7 @@ def kernel_table(ctx, st, n, nloc, d, world, nnz, nnz0, main):
              2.0 * nloc * n * d * MFMA_CHAINS[main], "classic candidate pass: every query row against every point")
     # streaming kernels, algorithmic bytes per SURVEY 8d
     tab = 128   # table entries the re-rank evaluates / the affinity pass reads per row (first batch)
-    hbm("rerank", ("rerank_sym4_kernel<1>" if (d % 4 == 0 and d <= 64) else "rerank_sym_kernel") if symmetric else "rerank_kernel",
+    hbm("rerank", ("rerank_sym4_kernel<1, WT>" if (d % 4 == 0 and d <= 64) else "rerank_sym_kernel") if symmetric else "rerank_kernel",
         st.mean("rerank"),
         nloc * tab * 8.0 + n * d * 4.0 + nloc * tab * 12.0,
         "candidate lists in (8 B), X once, exact tables out (8 + 4 B); the row gathers come from L2/MALL")
@@ -520,8 +526,9 @@ def main():
         # tables in / kept values out (affinity); read K0 and K0^T entries, write K; read K, write P
         tail_bytes = (sum(r["algorithmic_bytes"] for r in rows if r["stage"] == "affinity")
                       + 2.0 * nnz0 * 12.0 + nnz * 12.0 + nnz * 12.0 + nnz * 8.0)
-        tail_counter = profiled_traffic(["bandwidth_kernel", "affinity_kernel", "bin_", "sort_merge", "compact_kernel", "scan_",
-                                         "gather_counts", "scatter_", "sym_invperm", "symm_"]) if (n == 1000000 and d == 64 and world == 1) else None
+        tail_counter = profiled_traffic(["bandwidth_kernel", "affinity_kernel", "bin_", "sort_merge_kernel", "sort_merge_long_kernel",
+                                         "compact_kernel", "merge_final_kernel", "merge_long_final_kernel", "pairs_len_kernel", "scan_",
+                                         "gather_counts_kernel", "scatter_", "invperm_kernel"], per="graph") if (n == 1000000 and d == 64 and world == 1) else None
         out = {
             "metric": "graphs/sec (kernel+diff_op) at N=1e6 d=64 k=15",
             "value": args.steps / elapsed,
