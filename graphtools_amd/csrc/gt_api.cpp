@@ -292,6 +292,10 @@ int gt_set_option(gt_ctx* ctx, const char* name, const char* value) {
         ctx->symm_fill_threads = std::atoi(value);
         return GT_OK;
     }
+    if (k == "select_sym_cosine") {
+        ctx->sym_cosine = std::atoi(value) != 0 ? 1 : 0;
+        return GT_OK;
+    }
     if (k == "select_sym_sorted_points") {
         ctx->sym_sorted_points = std::atoi(value) != 0 ? 1 : 0;
         return GT_OK;

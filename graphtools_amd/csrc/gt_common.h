@@ -146,6 +146,7 @@ struct gt_ctx {
     int32_t sym_mode = -1;
     int64_t sym_min_rows = 65536;
     int32_t sym_stride = 384;   //   threshold-seeding launch: every sym_stride-th tile besides the row's own neighbourhood (0: none)
+    int32_t sym_cosine = 1;          //   the symmetric pass also serves the cosine metric (rows are normalised: the candidate stages are the euclidean ones)
     int32_t sym_sorted_points = 1;   //   symmetric pass: the exact stages read the points from a copy in cell-sorted order
     int32_t xcd_chunk = 0;      //   row-walking kernels: work items per XCD chunk (gt_device.h gt_xcd_item), 0 = one contiguous eighth per XCD
     int32_t rerank_lanes4 = 1;  //   re-rank of the symmetric pass: four lanes per candidate row (float32 rows, d % 4 == 0, d <= 128)

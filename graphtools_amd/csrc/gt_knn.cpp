@@ -209,7 +209,8 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
     // query order available (its permutation is the cell-sorted order both sides of the pass share)
     const int bq_sym = gt_select_bq(ctx->DP);
     const bool use_sym = ctx->sym_mode != 0 && !external && q0 == 0 && nq == ctx->n && sa.qrows != nullptr &&
-                         ctx->metric == 0 && !ctx->wide && nt == 8 && need_m <= 64 && ctx->Yc.p != nullptr &&
+                         (ctx->metric == 0 || (ctx->metric == 1 && ctx->sym_cosine != 0)) && !ctx->wide && nt == 8 && need_m <= 64 &&
+                         ctx->Yc.p != nullptr &&
                          (ctx->sym_mode > 0 || nq >= ctx->sym_min_rows) &&
                          ctx->order_L > 0 && nq >= int64_t(8) * bq_sym;
     k->sym_used = false;

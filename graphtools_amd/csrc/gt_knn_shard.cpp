@@ -27,7 +27,7 @@ namespace {
 bool shard_applicable(const gt_ctx* ctx, int need_m) {
     const int bq = gt_select_bq(ctx->DP);
     const bool fast = ctx->prec == 1 && (ctx->fast_mode == 2 || (ctx->fast_mode == 1 && ctx->fast_ok != 0));
-    return ctx->sym_mode != 0 && ctx->sym_ok != 0 && fast && ctx->metric == 0 && !ctx->wide && ctx->DP != 0 &&
+    return ctx->sym_mode != 0 && ctx->sym_ok != 0 && fast && (ctx->metric == 0 || (ctx->metric == 1 && ctx->sym_cosine != 0)) && !ctx->wide && ctx->DP != 0 &&
            need_m >= 1 && need_m <= ctx->nt8_max_need && need_m <= 64 && ctx->Yc.p != nullptr &&
            (ctx->sym_mode > 0 || ctx->n >= ctx->sym_min_rows) && ctx->n >= int64_t(8) * bq && ctx->n >= 4096;
 }

@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256, 5) void rerank_sym_kernel(
     int32_t* __restrict__ fb_rows, uint32_t* __restrict__ gflags, const double radius_key_factor,
     uint32_t* __restrict__ unproven, unsigned long long* __restrict__ stat, const int want_stats,
     const int32_t* __restrict__ invperm, const int32_t* __restrict__ own_rows, const int64_t own_r0,
-    const int xcd_chunk, const T* __restrict__ Xs, const double* __restrict__ xns) {
+    const int xcd_chunk, const T* __restrict__ Xs, const double* __restrict__ xns, const int metric) {
     constexpr int MP = 256;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int lane = threadIdx.x & 63;
@@ -246,9 +246,12 @@ __global__ __launch_bounds__(256, 5) void rerank_sym_kernel(
 
     const double y2 = ymax2p[0];
     const double e = gt_err_bound(err, qnq, y2);
+    // euclidean: d2 = |x|^2 - 2 s; cosine (rows normalised): D = 1 - x.y = 1 - s - |y|^2 / 2 >= 1 - s - ymax^2 / 2 - what the
+    // candidate stages guarantee is "every row scoring above thr is listed", whatever the score is turned into
     auto bound_of_score = [&](float score) {
         const double sv = double(score) * err.inv_sc2;
-        return (qnq - 2.0 * (sv + e)) - 1e-9 * (qnq + y2);
+        const double b = (metric == 1) ? (1.0 - (sv + e) - 0.5 * ymax2p[1]) : (qnq - 2.0 * (sv + e));
+        return b - 1e-9 * (qnq + y2);
     };
     double lb = overflow ? -INFINITY : bound_of_score(thr[qt]);
 
@@ -293,11 +296,11 @@ __global__ __launch_bounds__(256, 5) void rerank_sym_kernel(
         ha = hb = kInfBits;
         la = lb_ = 0xFFFFFFFFu;
         if (va) {
-            ha = (uint64_t)__double_as_longlong(gt_pair_key(qnq, da, nrm[ra], 0));
+            ha = (uint64_t)__double_as_longlong(gt_pair_key(qnq, da, nrm[ra], metric));
             la = ja;
         }
         if (vb) {
-            hb = (uint64_t)__double_as_longlong(gt_pair_key(qnq, db, nrm[rb], 0));
+            hb = (uint64_t)__double_as_longlong(gt_pair_key(qnq, db, nrm[rb], metric));
             lb_ = jb;
         }
     };
@@ -380,7 +383,7 @@ __global__ __launch_bounds__(256, WT ? 3 : 4) void rerank_sym4_kernel(
     uint32_t* __restrict__ unproven, unsigned long long* __restrict__ stat, const int want_stats,
     const int32_t* __restrict__ invperm, const int32_t* __restrict__ own_rows, const int64_t own_r0,
     const int xcd_chunk, const float* __restrict__ Xs, const double* __restrict__ xns, double* __restrict__ cand_d2t,
-    uint8_t* __restrict__ keyt_ok, int32_t* __restrict__ nokeyt_rows, uint32_t* __restrict__ nokeyt_count) {
+    uint8_t* __restrict__ keyt_ok, int32_t* __restrict__ nokeyt_rows, uint32_t* __restrict__ nokeyt_count, const int metric) {
     // cand_d2t (optional): next to every key of the table, the key the OTHER row holds for the same pair - the same dot
     // product in scikit-learn's association with the roles swapped, (|y|^2 - 2 x.y) + |x|^2 - so that the affinity pass can
     // tell, bit for bit, what the transposed entry is worth (gt_sparse.hip, pair-resolved symmetrisation); keyt_ok[q] = 1
@@ -428,9 +431,12 @@ __global__ __launch_bounds__(256, WT ? 3 : 4) void rerank_sym4_kernel(
     const uint64_t* tp = tlists + size_t(ls) * size_t(tcap);
     const double y2 = ymax2p[0];
     const double e = gt_err_bound(err, qnq, y2);
+    // euclidean: d2 = |x|^2 - 2 s; cosine (rows normalised): D = 1 - x.y = 1 - s - |y|^2 / 2 >= 1 - s - ymax^2 / 2 - what the
+    // candidate stages guarantee is "every row scoring above thr is listed", whatever the score is turned into
     auto bound_of_score = [&](float score) {
         const double sv = double(score) * err.inv_sc2;
-        return (qnq - 2.0 * (sv + e)) - 1e-9 * (qnq + y2);
+        const double b = (metric == 1) ? (1.0 - (sv + e) - 0.5 * ymax2p[1]) : (qnq - 2.0 * (sv + e));
+        return b - 1e-9 * (qnq + y2);
     };
     double lb = overflow ? -INFINITY : bound_of_score(thr[qt]);
 
@@ -497,8 +503,8 @@ __global__ __launch_bounds__(256, WT ? 3 : 4) void rerank_sym4_kernel(
             const double w2 = cc + lane_xor_f64(cc, 2);         // lanes 0, 2: c0 + c2; lanes 1, 3: c1 + c3
             const double dot = w2 + lane_xor_f64(w2, 1);        // (c0 + c2) + (c1 + c3)
             if (j != kNoRow && c == (p & 3)) {
-                const uint64_t key = (uint64_t)__double_as_longlong(gt_pair_key(qnq, dot, yn, 0));
-                const uint64_t keyt = want_t ? (uint64_t)__double_as_longlong(gt_pair_key(yn, dot, qnq, 0)) : 0ull;
+                const uint64_t key = (uint64_t)__double_as_longlong(gt_pair_key(qnq, dot, yn, metric));
+                const uint64_t keyt = want_t ? (uint64_t)__double_as_longlong(gt_pair_key(yn, dot, qnq, metric)) : 0ull;
                 if (p < 4) {
                     hA = key;
                     lA = j;
@@ -936,19 +942,19 @@ int gt_launch_collected_select(gt_ctx* ctx, const RerankArgs& a, int64_t n_rows,
 int gt_launch_rerank_sym(gt_ctx* ctx, const RerankArgs& a, const SymRerank& sr) {
     const int64_t blocks = ceil_div64(a.nq, 4);
     const size_t lds = size_t(4) * a.d * sizeof(double);
-    if (a.MP != 256 || a.metric != 0) GT_FAIL(ctx, GT_E_ARG, "rerank_sym: table width 256, euclidean metric only");
+    if (a.MP != 256) GT_FAIL(ctx, GT_E_ARG, "rerank_sym: table width 256");
 #define GT_RERANK_SYM_LAUNCH(T_, F4_)                                                                                     \
     hipLaunchKernelGGL((rerank_sym_kernel<T_, F4_>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, (const T_*)a.X, a.d,  \
                        a.xn, a.nq, sr.tlists, sr.tcap, sr.tcounts, a.thr_final, a.ymax2, a.err, a.need_m, sr.perm,        \
                        a.cand_d2, a.cand_j, a.cand_n, a.d2_lb, a.fb_count, a.fb_rows, a.gflags, a.radius_key_factor,      \
                        a.unproven, sr.stat, (ctx->dbg_select & 256) ? 1 : 0, sr.invperm, sr.own_rows, sr.own_r0, ctx->xcd_chunk,      \
-                       (const T_*)sr.Xs, sr.xns)
+                       (const T_*)sr.Xs, sr.xns, a.metric)
 #define GT_RERANK_SYM4_LAUNCH(DB_, WT_)                                                                                   \
     hipLaunchKernelGGL((rerank_sym4_kernel<DB_, WT_>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (const float*)a.X, a.d, \
                        a.xn, a.nq, sr.tlists, sr.tcap, sr.tcounts, a.thr_final, a.ymax2, a.err, a.need_m, sr.perm,        \
                        a.cand_d2, a.cand_j, a.cand_n, a.d2_lb, a.fb_count, a.fb_rows, a.gflags, a.radius_key_factor,      \
                        a.unproven, sr.stat, (ctx->dbg_select & 256) ? 1 : 0, sr.invperm, sr.own_rows, sr.own_r0, ctx->xcd_chunk,      \
-                       (const float*)sr.Xs, sr.xns, sr.cand_d2t, sr.keyt_ok, sr.nokeyt_rows, sr.nokeyt_count)
+                       (const float*)sr.Xs, sr.xns, sr.cand_d2t, sr.keyt_ok, sr.nokeyt_rows, sr.nokeyt_count, a.metric)
     if (sr.wrote_t) *sr.wrote_t = false;
     if (a.dtype == GT_F32) {
         const bool f4 = (a.d & 3) == 0 && (reinterpret_cast<uintptr_t>(a.X) & 15) == 0;

@@ -1809,7 +1809,7 @@ static int graph_begin_impl(gt_ctx* ctx, const gt_knn_params* params, int32_t wo
     // tables carry the transposed keys and whose transpose will go through the destination bins
     g->pairs = ctx->in_graph_build && ctx->symm_pairs != 0 && ctx->symm_pair_ok != 0 && ctx->symm_bins != 0 && world == 1 &&
                !external && !binary && params->knn_max <= 0 && params->kernel_symm == GT_SYMM_ADD && params->anisotropy == 0.0 &&
-               ctx->metric == 0 && k->keyt_valid && k->ordered && k->nq == g->nloc && g->r0 == 0 &&
+               k->keyt_valid && k->ordered && k->nq == g->nloc && g->r0 == 0 &&
                g->nloc < (int64_t(1) << 31) && (ctx->symm_bins > 0 || g->nloc >= 65536);
     if (ctx->dbg_select & 2048)
         std::fprintf(stderr, "[gt] pairs %d: in_build %d opt %d ok %d bins %d world %d ext %d bin %d kmax %lld symm %d aniso %g metric %d keyt %d ordered %d nq %lld nloc %lld r0 %lld\n",

@@ -107,7 +107,9 @@ __global__ __launch_bounds__(256) void sym_thresholds_kernel(const int64_t n, co
                                                              float* __restrict__ g, const uint32_t* __restrict__ cell_sorted,
                                                              const int32_t* __restrict__ nbr, const int M,
                                                              unsigned long long* __restrict__ far_total,
-                                                             float* __restrict__ farcnt, const int sorted) {
+                                                             float* __restrict__ farcnt, const int sorted, const int metric) {
+    // metric 1 (cosine, rows normalised): D_K is the largest key 1 - x.y among the kept rows; a row within rkf x that has
+    // x.y >= 1 - R2, i.e. true score x.y - |y|^2 / 2 >= 1 - R2 - ymax^2 / 2 - the rest (error bound, scale, rounding) as below.
     // sorted != 0: X / xn are the copies in cell-sorted order (gather_points_kernel): rows are addressed by position
     const int sub = threadIdx.x & 15, lane64 = threadIdx.x & 63;
     const int64_t p = p_first + int64_t(blockIdx.x) * 16 + (threadIdx.x >> 4);
@@ -180,7 +182,7 @@ __global__ __launch_bounds__(256) void sym_thresholds_kernel(const int64_t n, co
                     double acc = acc4[i];
 #pragma unroll
                     for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 16);
-                    if (c + i < lim) dk = fmax(dk, gt_pair_key(qs, acc, xn[j4[i]], 0));
+                    if (c + i < lim) dk = fmax(dk, gt_pair_key(qs, acc, xn[j4[i]], metric));
                 }
             }
         }
@@ -190,7 +192,7 @@ __global__ __launch_bounds__(256) void sym_thresholds_kernel(const int64_t n, co
         t = -3.0e38f;
         if (kept >= uint32_t(need_m)) {
             const double R2 = rkf * dk * (1.0 + 1e-5) + 1e-9 * (qs + y2);
-            const double smin = 0.5 * (qs - R2);
+            const double smin = (metric == 1) ? (1.0 - R2 - 0.5 * ymax2p[1]) : 0.5 * (qs - R2);
             const double x = (smin - e - 1e-9 * (qs + y2)) / err.inv_sc2;
             t = float(x);
             if (double(t) >= x) t = nextafterf(t, -INFINITY);
@@ -1164,11 +1166,11 @@ int gt_sym_thresholds(gt_ctx* ctx, const int32_t* perm, int64_t n_pad_s, const f
     if (ctx->dtype == GT_F32)
         hipLaunchKernelGGL(sym_thresholds_kernel<float>, grid, dim3(256), 0, ctx->stream, ctx->n, p_first, p_last, perm,
                            (const float*)Xp, ctx->d, xnp, hs, lists, lstride, counts, need_m, ctx->ymax.as<double>(), err, rkf,
-                           thr, g, cell_sorted, nbr, M, far_total, farcnt, sorted ? 1 : 0);
+                           thr, g, cell_sorted, nbr, M, far_total, farcnt, sorted ? 1 : 0, ctx->metric);
     else
         hipLaunchKernelGGL(sym_thresholds_kernel<double>, grid, dim3(256), 0, ctx->stream, ctx->n, p_first, p_last, perm,
                            (const double*)Xp, ctx->d, xnp, hs, lists, lstride, counts, need_m, ctx->ymax.as<double>(), err, rkf,
-                           thr, g, cell_sorted, nbr, M, far_total, farcnt, sorted ? 1 : 0);
+                           thr, g, cell_sorted, nbr, M, far_total, farcnt, sorted ? 1 : 0, ctx->metric);
     GT_HIP(ctx, hipGetLastError());
     if (gmin) {
         hipLaunchKernelGGL(sym_gmin_kernel, dim3((unsigned)ceil_div64(n_pad_s, 256)), dim3(256), 0, ctx->stream, n_pad_s, g, gmin);

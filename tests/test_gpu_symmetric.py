@@ -286,3 +286,61 @@ def test_orphan_rows_are_repaired_from_their_seeds():
     assert st["symmetric"] and st["sym_two_stage"]
     assert st["repaired_rows"] > 5
     _same_csr(orph, ref)
+
+
+@pytest.mark.parametrize("n,d,maker,seed,dtype,off", [
+    (6000, 48, make_mix, 21, np.float64, 3.0),       # off-centre: the angular structure is not trivial
+    (5003, 64, make_mix, 22, np.float32, 0.0),
+    (4500, 20, make_gauss, 23, np.float64, 1.0),     # unclustered
+    (8000, 33, make_manifold, 24, np.float32, 0.5),
+])
+def test_symmetric_pass_with_the_cosine_metric(n, d, maker, seed, dtype, off):
+    """cosine distance on the symmetric pass: the rows are normalised, so the candidate stages are the euclidean ones; the
+    thresholds come from the largest key 1 - x.y of the seeds, the re-rank's completeness bound is 1 - s - ymax^2 / 2.  Bar:
+    neighbour table and kernel identical to the classic pass bit for bit (which the cosine tests of test_gpu_graph.py hold
+    to the reference), float64 kernel within 1e-9 of the oracle."""
+    from graphtools_amd import _hip
+
+    X = (maker(n, d, seed, dtype) if maker is not make_manifold else maker(n, d, seed).astype(dtype)) + dtype(off)
+    out = {}
+    for mode in ("1", "0"):
+        ctx = _hip.Context(0)
+        for k, v in (("metric", "cosine"), ("query_order_min_rows", "1"), ("select_symmetric", mode), ("select_sym_stride", "4")):
+            ctx.set_option(k, v)
+        ctx.set_points(X)
+        dist, idx, _ = ctx.knn_search(13)
+        assert ctx.knn_stats()["symmetric"] == (mode == "1")
+        p, keep = ctx.make_params(12, 15.0, 1e-4, None, 1.0, None, "+", None, 0)
+        ctx.graph_build(p)
+        assert ctx.knn_stats()["symmetric"] == (mode == "1")
+        out[mode] = (dist, idx) + ctx.graph_fetch_csr(_hip.CSR_K) + ctx.graph_fetch_csr(_hip.CSR_P)[:1]
+        ctx.close()
+    for a, b in zip(out["1"], out["0"]):
+        assert np.array_equal(a, b)
+    if dtype == np.float64:
+        Ko, Po = oracle.knn_graph(X, knn=12, decay=15, distance="cosine")
+        Ko = sparse.csr_matrix(Ko)
+        Ko.sort_indices()
+        kd, ki, kp = out["1"][2], out["1"][3], out["1"][4]
+        assert np.array_equal(kp, Ko.indptr) and np.array_equal(ki, Ko.indices)
+        np.testing.assert_allclose(kd, Ko.data, rtol=1e-9, atol=0)
+
+
+def test_cosine_graph_at_the_size_where_the_pass_engages_by_itself():
+    """N = 150 000, cosine: the pruned symmetric pass equals the classic pass bit for bit"""
+    from graphtools_amd import _hip
+
+    X = make_mix(150000, 64, 31) + np.float32(1.0)
+    out = {}
+    for mode in ("auto", "0"):
+        ctx = _hip.Context(0)
+        ctx.set_option("metric", "cosine")
+        ctx.set_option("select_symmetric", mode)
+        ctx.set_points(X)
+        p, keep = ctx.make_params(15, 40.0, 1e-4, None, 1.0, None, "+", None, 0)
+        ctx.graph_build(p)
+        assert ctx.knn_stats()["symmetric"] == (mode == "auto")
+        out[mode] = ctx.graph_fetch_csr(_hip.CSR_K) + ctx.graph_fetch_csr(_hip.CSR_P)[:1]
+        ctx.close()
+    for a, b in zip(out["auto"], out["0"]):
+        assert np.array_equal(a, b)
