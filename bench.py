@@ -333,10 +333,12 @@ def timed_builds(ctx, params, x_dev_ptr, n, d, steps, warmup, sync):
     return (time.perf_counter() - t0) / steps * 1e3, nnz, st
 
 
-def secondary_knn(_hip, torch, device, name, X, knn=15, decay=40.0, steps=3):
+def secondary_knn(_hip, torch, device, name, X, knn=15, decay=40.0, steps=3, opts=()):
     """device-complete build of a secondary workload: {ms_per_graph, graphs_per_s, path, stage_ms}"""
     ctx = _hip.Context(device.index or 0)
     try:
+        for k, v in opts:
+            ctx.set_option(k, v)
         n, d = X.shape
         x_dev = torch.from_numpy(X).to(device)
         params, keep = ctx.make_params(knn, decay, 1e-4, None, 1.0, None, "+", None, 0)
@@ -431,7 +433,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-full", action="store_true", help="time the oracle port on ALL rows of the workload (minutes)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary workloads / host-complete legs")
-    ap.add_argument("--secondary-only", default="", help="comma list out of manifold,gauss,binary,c2,c4,c5")
+    ap.add_argument("--secondary-only", default="", help="comma list out of manifold,gauss,binary,cosine,c2,c4,c5")
     ap.add_argument("--knn-precision", choices=["auto", "f16x1", "f16", "f32"],
                     default=os.environ.get("GT_KNN_PRECISION", "auto"),
                     help="arithmetic of the candidate pass (results are identical; see DESIGN.md); auto = the library "
@@ -596,7 +598,7 @@ def main():
         ctx = None
         del x_local
         torch.cuda.empty_cache()
-        want = [w for w in args.secondary_only.split(",") if w] or ["manifold", "gauss", "binary", "c2", "c4", "c5"]
+        want = [w for w in args.secondary_only.split(",") if w] or ["manifold", "gauss", "binary", "cosine", "c2", "c4", "c5"]
         if single and not args.no_secondary:
             # ---- host-complete: host X in -> scipy CSR K, P out (SURVEY 8d headline definition) ----
             try:
@@ -624,6 +626,8 @@ def main():
                                                make_gauss(1000000, 64, 1), steps=2),
                 "binary": lambda: secondary_knn(_hip, torch, device, "C3 with decay=None (connectivity kernel): mix N=1e6 d=64 seed=1, knn=15",
                                                 X, decay=None),
+                "cosine": lambda: secondary_knn(_hip, torch, device, "C3 with distance='cosine': mix N=1e6 d=64 seed=1, knn=15 decay=40",
+                                                X, opts=(("metric", "cosine"),)),
                 "c2": lambda: secondary_knn(_hip, torch, device, "C2: mix N=1e5 d=50 seed=0, knn=15 decay=40", make_mix(100000, 50, 0), steps=5),
                 "c4": lambda: secondary_c4(_hip, torch, device),
                 "c5": lambda: secondary_c5(),
