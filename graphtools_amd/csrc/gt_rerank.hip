@@ -199,6 +199,37 @@ __global__ __launch_bounds__(256) void rerank_kernel(const T* __restrict__ X, co
 
 constexpr uint32_t kNoRow = 0xFFFFFFFFu;
 
+// The caller will need the rows within radius_key_factor x key(need_m-th neighbour) (a build's affinity radius; 1: a plain
+// k-nearest table): what lies beyond that - a third of the candidates, the margin of the float16 filter - need not enter the
+// table.  Returns the number of leading entries kept (>= need_m; the table is sorted) and lowers `lb`, the table's own
+// completeness bound, to the first key dropped.  No cut for a non-positive factor (the extent is not tied to that neighbour).
+__device__ __forceinline__ uint32_t sym_table_cut(const uint64_t (&hi)[4], const uint32_t n_tab, const int need_m, const int lane,
+                                                  const double radius_key_factor, double& lb) {
+    if (!(radius_key_factor > 0.0) || n_tab <= uint32_t(need_m)) return n_tab;
+    const int pos = need_m - 1;
+    uint64_t sel = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        if ((pos >> 6) == u) sel = hi[u];
+    const double d2_need = __longlong_as_double((long long)__shfl((unsigned long long)sel, pos & 63));
+    const double cut = d2_need * radius_key_factor * (1.0 + 1e-5);
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const bool in = uint32_t(u * 64 + lane) < n_tab && __longlong_as_double((long long)hi[u]) <= cut;
+        cnt += uint32_t(__popcll(__ballot(in)));
+    }
+    if (cnt < uint32_t(need_m)) cnt = uint32_t(need_m);
+    if (cnt >= n_tab) return n_tab;
+    uint64_t fd = 0;   // the first key left out (sorted position cnt)
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        if ((cnt >> 6) == uint32_t(u)) fd = hi[u];
+    const double first_drop = __longlong_as_double((long long)__shfl((unsigned long long)fd, int(cnt & 63u)));
+    lb = fmin(lb, first_drop);
+    return cnt;
+}
+
 // ---- re-rank of the symmetric candidate pass (knn_select_kernel MODE 2) ---------------------------------------
 // List ql belongs to the row at cell-sorted position ql (row perm[ql]); it holds (score, sorted position) keys collected
 // against the FIXED threshold thr[ql] by every workgroup that scored a pair with that row: every row that is not in it
@@ -321,7 +352,10 @@ __global__ __launch_bounds__(256, 5) void rerank_sym_kernel(
         if (k257 != 0ull) lb = fmin(lb, bound_of_score(cand_score(k257)));   // candidates beyond the table
         wave_sort_asc_pair_fast<4>(hi, lo, lane);
     }
-    const uint32_t n_def = n_tab > uint32_t(need_m) ? n_tab : uint32_t(need_m);
+    const double lb_cand = lb;   // (what the candidate stages proved; the table may be cut shorter below)
+    const uint32_t n_all = n_tab;
+    const uint32_t n_cut = sym_table_cut(hi, n_tab, need_m, lane, radius_key_factor, lb);
+    const uint32_t n_def = n_cut > uint32_t(need_m) ? n_cut : uint32_t(need_m);
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         if (uint32_t(u * 64) < n_def) {   // wave-uniform
@@ -336,25 +370,25 @@ __global__ __launch_bounds__(256, 5) void rerank_sym_kernel(
     const double d2_need = __longlong_as_double((long long)__shfl((unsigned long long)sel, pos & 63));
     const uint64_t second = __shfl((unsigned long long)hi[0], 1);
     if (lane == 0) {
-        cand_n[q] = n_tab;
+        cand_n[q] = n_cut;
         d2_lb[q] = lb;
-        if (!(d2_need < lb)) {
+        if (!(d2_need < lb_cand)) {
             const uint32_t slot = atomicAdd(fb_count, 1u);
             fb_rows[slot] = int32_t(q);
         }
         // (an overflowing row is short of room, an orphan - threshold +inf - of seeds, neither of precision: they do not
         //  count against the arithmetic)
-        if (unproven && !overflow && thr[qt] != INFINITY && !(d2_need * rkf < lb)) atomicAdd(unproven, 1u);
+        if (unproven && !overflow && thr[qt] != INFINITY && !(d2_need * rkf < lb_cand)) atomicAdd(unproven, 1u);
         if (stat && overflow) atomicAdd(stat + 0, 1ull);
         if (stat && want_stats) {
             // [1] sum of the list lengths [3] longest list [4] rows with more than 256 keys [7] rows with more than 128 keys
             const unsigned long long tot = (unsigned long long)ct;
             atomicAdd(stat + 1, tot);
             atomicMax(stat + 3, tot);
-            if (tot > 256ull || (tot > 128ull && n_tab <= 128u)) atomicAdd(stat + 4, 1ull);   // (experiment: long lists settled by the first batch)
+            if (tot > 256ull) atomicAdd(stat + 4, 1ull);
             if (tot > 128ull) atomicAdd(stat + 7, 1ull);
         }
-        if (n_tab > 1 && second == 0ull) atomicOr(gflags, GT_FLAG_DUPLICATES);
+        if (n_all > 1 && second == 0ull) atomicOr(gflags, GT_FLAG_DUPLICATES);
     }
 }
 
@@ -540,7 +574,10 @@ __global__ __launch_bounds__(256, WT ? 3 : 4) void rerank_sym4_kernel(
         if (k257 != 0ull) lb = fmin(lb, bound_of_score(cand_score(k257)));   // candidates beyond the table
         wave_sort_asc_pair_fast<4>(hi, lo, lane, park_hi, park_lo, want_t ? hx : nullptr, park_x);
     }
-    const uint32_t n_def = n_tab > uint32_t(need_m) ? n_tab : uint32_t(need_m);
+    const double lb_cand = lb;   // (what the candidate stages proved; the table may be cut shorter below)
+    const uint32_t n_all = n_tab;
+    const uint32_t n_cut = sym_table_cut(hi, n_tab, need_m, lane, radius_key_factor, lb);
+    const uint32_t n_def = n_cut > uint32_t(need_m) ? n_cut : uint32_t(need_m);
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         if (uint32_t(u * 64) < n_def) {   // wave-uniform
@@ -556,26 +593,26 @@ __global__ __launch_bounds__(256, WT ? 3 : 4) void rerank_sym4_kernel(
     const double d2_need = __longlong_as_double((long long)__shfl((unsigned long long)sel, pos & 63));
     const uint64_t second = __shfl((unsigned long long)hi[0], 1);
     if (lane == 0) {
-        cand_n[q] = n_tab;
+        cand_n[q] = n_cut;
         d2_lb[q] = lb;
         if (keyt_ok) {   // (a row handed to the repair pass gets a new table, without them: it is listed for the affinity pass)
-            keyt_ok[q] = (d2_need < lb) ? 1 : 0;
-            if (!(d2_need < lb)) nokeyt_rows[atomicAdd(nokeyt_count, 1u)] = int32_t(q);
+            keyt_ok[q] = (d2_need < lb_cand) ? 1 : 0;
+            if (!(d2_need < lb_cand)) nokeyt_rows[atomicAdd(nokeyt_count, 1u)] = int32_t(q);
         }
-        if (!(d2_need < lb)) {
+        if (!(d2_need < lb_cand)) {
             const uint32_t slot = atomicAdd(fb_count, 1u);
             fb_rows[slot] = int32_t(q);
         }
-        if (unproven && !overflow && thr[qt] != INFINITY && !(d2_need * fabs(radius_key_factor) < lb)) atomicAdd(unproven, 1u);
+        if (unproven && !overflow && thr[qt] != INFINITY && !(d2_need * fabs(radius_key_factor) < lb_cand)) atomicAdd(unproven, 1u);
         if (stat && overflow) atomicAdd(stat + 0, 1ull);
         if (stat && want_stats) {
             const unsigned long long tot = (unsigned long long)ct;
             atomicAdd(stat + 1, tot);
             atomicMax(stat + 3, tot);
-            if (tot > 256ull || (tot > 128ull && n_tab <= 128u)) atomicAdd(stat + 4, 1ull);   // (experiment: long lists settled by the first batch)
+            if (tot > 256ull) atomicAdd(stat + 4, 1ull);
             if (tot > 128ull) atomicAdd(stat + 7, 1ull);
         }
-        if (n_tab > 1 && second == 0ull) atomicOr(gflags, GT_FLAG_DUPLICATES);
+        if (n_all > 1 && second == 0ull) atomicOr(gflags, GT_FLAG_DUPLICATES);
     }
 }
 
