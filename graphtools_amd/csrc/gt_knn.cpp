@@ -435,6 +435,15 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
             }
             if (two_stage && !bound_done) GT_TRY(gt_sym_two_stage_prepare(ctx, perm, n_pad_s, em, need_m, a, bound_tried));
             const bool two_now = bound_done || a.sym.half_steps > 0;
+            if (!two_now && ctx->sym_mode < 0 && double(k->sym_far) >= 0.5 * double(nq)) {
+                // neither the cell bounds nor the partial distances prune this point set, and every second row found a seed
+                // outside the cells around it: no cluster structure at the cells' scale.  The one-stage collect would score
+                // every pair once with admissions all along - measured slower than the classic pass on such data (isotropic
+                // Gaussian, d = 24, N = 3e5: 33 ms against 16) - so the classic pass runs, now and from here on
+                ctx->sym_ok = 0;
+                sym_now = false;
+                continue;
+            }
             // (the orphans that were declared start their lists with the rows launch A kept for them)
             if (two_now || bound_tried)
                 GT_TRY(gt_sym_inject_orphans(ctx, 0, n_pad_s, k->thr_final.as<float>(), k->lists.as<uint64_t>(), seed_lstride,
