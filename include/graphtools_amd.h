@@ -110,7 +110,12 @@ int gt_stage_launches(const gt_ctx* ctx, const char* stage);
  * "select_samp_end", "select_samp2_level", "select_samp2_keep", "select_samp_trig", "select_thr0", "select_narrow",
  * "query_order_cell_rows", "query_order_min_rows"; "select_symmetric" ("auto" | 0 | 1: self queries over the whole point set score every
  * unordered pair of rows once and test the result for both rows - gt_sym.hip), "select_sym_stride",
- * "select_sym_min_rows", "select_sym_tcap", "select_sym_cells", "select_sym_max_nb", "select_sym_nseg", "select_sym_shard_group", "select_sym_two_stage", "select_sym_radius_cut", "select_sym_orphan_far", "select_sym_queue_cap", "select_sym_two_steps"; "dbg_select" switches invalidate the results. */
+ * "select_sym_min_rows", "select_sym_tcap", "select_sym_cells", "select_sym_max_nb", "select_sym_nseg", "select_sym_shard_group", "select_sym_two_stage", "select_sym_radius_cut", "select_sym_orphan_far", "select_sym_queue_cap", "select_sym_two_steps",
+ * "select_sym_dense_seed" (dense cell-block seeding kernel, gt_seed.hip), "select_sym_sorted_points" (the exact stages read a
+ * cell-sorted copy of the points), "select_sym_cosine" (the symmetric pass serves the cosine metric too), "rerank_lanes4",
+ * "symmetrize_bins", "symmetrize_bin_shift", "symmetrize_fill_threads", "symmetrize_fused", "symmetrize_pairs" (pair-resolved
+ * symmetrisation of single-rank '+' builds: every row settles its mutual pairs itself, only one-sided entries are transposed),
+ * "xcd_chunk"; "dbg_select" switches invalidate the results. */
 int gt_set_option(gt_ctx* ctx, const char* name, const char* value);
 /* arithmetic the most recent main candidate pass ran on: 0 float32, 1 split float16 (3 chains), 2 single float16 chain */
 int gt_last_knn_precision(const gt_ctx* ctx);
