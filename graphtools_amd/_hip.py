@@ -71,6 +71,9 @@ _SIGNATURES = {
     "gt_graph_sym_finish": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64]),
     "gt_graph_finish": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64, _c.POINTER(_c.c_int64), _c.POINTER(_c.c_uint32)]),
     "gt_graph_anisotropy": (_c.c_int, [_c.c_void_p, _c.c_void_p]),
+    "gt_graph_stage_counts": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int32, _c.c_int32, _c.c_void_p, _c.c_void_p,
+                                         _c.POINTER(_c.c_int32)]),
+    "gt_graph_set_stage_totals": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int32]),
     "gt_graph_build": (_c.c_int, [_c.c_void_p, _c.POINTER(KnnParams), _c.POINTER(_c.c_int64), _c.POINTER(_c.c_uint32)]),
     "gt_graph_extend": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int32, _c.POINTER(KnnParams),
                                    _c.POINTER(_c.c_int64), _c.POINTER(_c.c_uint32)]),
@@ -305,6 +308,22 @@ class Context:
                                                 float(anisotropy), ctypes.byref(nnz), ctypes.byref(flags)),
                     "gt_csr_graph_build")
         return nnz.value, flags.value
+
+    def graph_stage_counts(self, params, world, rank, row_splits):
+        """row-sharded builds with knn_max: this rank's counts for the reference's search-expansion loop (int64 array, possibly
+        empty: nothing to exchange)"""
+        splits = np.ascontiguousarray(row_splits, dtype=np.int64)
+        counts = np.zeros(4, dtype=np.int64)
+        n = ctypes.c_int32(0)
+        self._check(self.lib.gt_graph_stage_counts(self.h, ctypes.byref(params), world, rank, _ptr(splits), _ptr(counts),
+                                                   ctypes.byref(n)), "gt_graph_stage_counts")
+        return counts[: n.value].copy()
+
+    def graph_set_stage_totals(self, totals):
+        totals = np.ascontiguousarray(totals, dtype=np.int64)
+        buf = np.zeros(4, dtype=np.int64)
+        buf[: len(totals)] = totals
+        self._check(self.lib.gt_graph_set_stage_totals(self.h, _ptr(buf), int(len(totals))), "gt_graph_set_stage_totals")
 
     def graph_begin(self, params, world, rank, row_splits):
         splits = np.ascontiguousarray(row_splits, dtype=np.int64)

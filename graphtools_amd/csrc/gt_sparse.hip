@@ -1639,9 +1639,11 @@ static int graph_begin_impl(gt_ctx* ctx, const gt_knn_params* params, int32_t wo
         }
         need = int(km);
         if (km > kMaxTable || world > 1) {
-            // (sharded builds cannot replay the loop - it needs the row counts of every rank - and always cap)
+            // sharded builds replay the loop on the row counts of ALL ranks: the host sums the ranks' counts
+            // (gt_graph_stage_counts) and hands the totals back (gt_graph_set_stage_totals); without that exchange a sharded
+            // build caps every row, as it always used to
             if (world > 1 && km <= kMaxTable) {
-                n_kst = 0;
+                if (!ctx->stage_counts_only && !ctx->stage_totals_valid) n_kst = 0;
             } else {
                 need = 0;
                 for (int t = 0; t < n_kst; ++t)
@@ -1722,12 +1724,25 @@ static int graph_begin_impl(gt_ctx* ctx, const gt_knn_params* params, int32_t wo
         uint32_t un[4] = {0, 0, 0, 0};
         GT_HIP(ctx, hipMemcpyAsync(un, g->rmax.p, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
         GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        int64_t rows_total = g->nloc;
+        if (ctx->stage_counts_only) {
+            // gt_graph_stage_counts: this rank's counts are all the caller wants of this pass
+            ctx->stage_n = n_avail;
+            for (int t = 0; t < 4; ++t) ctx->stage_local[t] = t < n_avail ? int64_t(un[t]) : 0;
+            for (int r = 0; r < world; ++r) send_counts[r] = 0;
+            return GT_OK;
+        }
+        if (world > 1) {
+            // the counts over the rows of every rank (the reference's loop looks at the whole point set)
+            for (int t = 0; t < 4; ++t) un[t] = uint32_t(std::min<int64_t>(ctx->stage_totals[t], 0xFFFFFFFFll));
+            rows_total = ctx->n;
+        }
         // replay of the loop: t = step the remaining rows were last searched with, `next` = the table size tried next
         int t = 0;
         int64_t next = std::min<int64_t>(int64_t(kst[0]) * 6, km);
         uint32_t remaining = un[0];
         bool blind = n_avail < 1;
-        while (!blind && int64_t(remaining) > g->nloc / 10 && double(next) < double(ctx->n) / 2.0 && next < km) {
+        while (!blind && int64_t(remaining) > rows_total / 10 && double(next) < double(ctx->n) / 2.0 && next < km) {
             ++t;
             if (t >= n_avail) {
                 blind = true;
@@ -1863,7 +1878,40 @@ extern "C" int gt_graph_begin(gt_ctx* ctx, const gt_knn_params* params, int32_t 
     if (!ctx) return GT_E_ARG;
     // (the stages of a sharded symmetric pass that is about to be consumed belong to this build)
     if (!(ctx->knn && ctx->knn->sh_stage == 5)) ctx->reset_stages();
-    return graph_begin_impl(ctx, params, world, rank, row_splits, send_counts, false, 0);
+    const int rc = graph_begin_impl(ctx, params, world, rank, row_splits, send_counts, false, 0);
+    ctx->stage_totals_valid = 0;   // (the totals belong to one build)
+    return rc;
+}
+
+// Row-sharded builds with knn_max (graphs.py:916-976: the search-expansion loop escalates while more than a tenth of ALL rows
+// still have their whole table inside their radius): this rank's counts for the loop's steps.  The caller sums them over the
+// ranks and hands the sums to gt_graph_set_stage_totals before gt_graph_begin; n_counts = 0: nothing to exchange (no knn_max,
+// one rank, or a table depth the kernels cannot hold).  Runs the candidate search of the owned rows (gt_graph_begin runs it
+// again: the price of following the reference's branches in this rare configuration).
+extern "C" int gt_graph_stage_counts(gt_ctx* ctx, const gt_knn_params* params, int32_t world, int32_t rank,
+                                     const int64_t* row_splits, int64_t* counts4, int32_t* n_counts) {
+    if (!ctx || !params || !counts4 || !n_counts) return GT_E_ARG;
+    *n_counts = 0;
+    for (int t = 0; t < 4; ++t) counts4[t] = 0;
+    if (world <= 1 || params->knn_max <= 0 || std::isnan(params->decay)) return GT_OK;
+    std::vector<int64_t> sendc(size_t(world), 0);
+    ctx->reset_stages();
+    ctx->stage_counts_only = 1;
+    ctx->stage_n = 0;
+    const int rc = graph_begin_impl(ctx, params, world, rank, row_splits, sendc.data(), false, 0);
+    ctx->stage_counts_only = 0;
+    if (ctx->graph) ctx->graph->begun = false;
+    if (rc != GT_OK) return rc;
+    *n_counts = ctx->stage_n;
+    for (int t = 0; t < ctx->stage_n && t < 4; ++t) counts4[t] = ctx->stage_local[t];
+    return GT_OK;
+}
+
+extern "C" int gt_graph_set_stage_totals(gt_ctx* ctx, const int64_t* totals4, int32_t n_counts) {
+    if (!ctx || !totals4 || n_counts < 0 || n_counts > 4) return GT_E_ARG;
+    for (int t = 0; t < 4; ++t) ctx->stage_totals[t] = t < n_counts ? totals4[t] : 0;
+    ctx->stage_totals_valid = n_counts > 0 ? 1 : 0;
+    return GT_OK;
 }
 
 extern "C" int gt_graph_extend(gt_ctx* ctx, const void* Y, int64_t m, int32_t y_on_device, const gt_knn_params* params,

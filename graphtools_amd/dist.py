@@ -225,6 +225,17 @@ class ShardedKnnGraph(object):
         # (a single rank has the whole pass in gt_graph_begin; GT_SHARD_SYM_FORCE=1 runs the staged form anyway - development)
         staged = self.world > 1 or os.environ.get("GT_SHARD_SYM_FORCE") == "1"
         self.symmetric_used = bool(symmetric) and staged and self.symmetric_candidates(params)
+        if self.world > 1 and getattr(params, "knn_max", -1) > 0 and hasattr(ctx, "graph_stage_counts"):
+            # knn_max: the reference's search-expansion loop looks at the rows of the whole point set - the ranks' counts
+            # for its steps are summed (one small all-reduce) and handed back before the build
+            local = np.zeros(4, dtype=np.int64)
+            got = np.asarray(ctx.graph_stage_counts(params, self.world, self.rank, self.splits), dtype=np.int64)
+            local[: len(got)] = got
+            tot = torch.as_tensor(np.concatenate([local, [len(got)]]), device=device)
+            dist.all_reduce(tot, group=self.group)
+            tot = tot.cpu().numpy()
+            if int(tot[4]) == self.world * len(got) and len(got) > 0:     # (every rank reported the same number of steps)
+                ctx.graph_set_stage_totals(tot[: len(got)])
         send_counts = ctx.graph_begin(params, self.world, self.rank, self.splits)
         total = int(send_counts.sum())
         send = torch.empty(max(total, 1) * WORDS_PER_TRIPLET, dtype=torch.int64, device=device)

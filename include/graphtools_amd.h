@@ -144,6 +144,14 @@ int gt_knn_search(gt_ctx* ctx, int64_t row0, int64_t row1, const void* Y, int64_
                   int32_t k, int64_t* out_idx, double* out_dist, int32_t out_on_device, uint32_t* flags);
 
 /* ---- kNN graph: kernel + diffusion operator ------------------------------------------------ */
+/* Row-sharded builds with knn_max (graphs.py:916-976): the reference's search-expansion loop escalates while more than a tenth
+ * of ALL rows still have their whole table inside their radius, so the ranks must agree on those counts.  Before
+ * gt_graph_begin: every rank calls gt_graph_stage_counts (its counts for the loop's up to 4 steps; n_counts = 0: nothing to
+ * exchange), the host sums them (all-reduce) and hands the sums to gt_graph_set_stage_totals.  Without the exchange a sharded
+ * build with knn_max caps every row at knn_max. */
+int gt_graph_stage_counts(gt_ctx* ctx, const gt_knn_params* params, int32_t world, int32_t rank, const int64_t* row_splits,
+                          int64_t* counts4, int32_t* n_counts);
+int gt_graph_set_stage_totals(gt_ctx* ctx, const int64_t* totals4, int32_t n_counts);
 /* The three calls replace, for rows [row0,row1) of the graph,
  *   kNNGraph.build_kernel            graphs.py:771-785, 819-982 (+ _build_csr_from_neighbors :450-559)
  *   BaseGraph.symmetrize_kernel      base.py:557-577

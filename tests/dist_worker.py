@@ -30,9 +30,9 @@ def _view(ptr, count):
 
 
 class FakeParams(object):
-    def __init__(self, knn, decay, thresh, kernel_symm, anisotropy=0.0, theta=1.0):
+    def __init__(self, knn, decay, thresh, kernel_symm, anisotropy=0.0, theta=1.0, knn_max=-1):
         self.knn, self.decay, self.thresh, self.kernel_symm = knn, decay, thresh, kernel_symm
-        self.anisotropy, self.theta = anisotropy, theta
+        self.anisotropy, self.theta, self.knn_max = anisotropy, theta, knn_max
 
 
 class FakeCtx(object):
@@ -160,6 +160,17 @@ class FakeCtx(object):
         self.K.sort_indices()
         return self.K.nnz, 0
 
+    # ---- knn_max: the counts of the search-expansion loop are summed over the ranks before the build ----
+    stage_totals = None
+
+    def graph_stage_counts(self, params, world, rank, splits):
+        self.calls = self.calls + ("stage_counts",)
+        return np.array([100 + rank, 7 * (rank + 1)], dtype=np.int64)
+
+    def graph_set_stage_totals(self, totals):
+        self.calls = self.calls + ("stage_totals",)
+        self.stage_totals = np.asarray(totals, dtype=np.int64).copy()
+
     # ---- anisotropy: the degrees of ALL rows are needed (dist.py all-gathers the owned slices) ----
     def graph_fetch_vec_device(self, which, ptr):
         assert which == 1
@@ -262,6 +273,14 @@ def main():
         K_full = sparse.csr_matrix(oracle.knn_graph(Xg, knn=10, decay=20, kernel_symm="+")[0])
         K_full.sort_indices()
         assert (c.K != K_full[g.splits[rank]:g.splits[rank + 1]]).nnz == 0
+    # 5b. knn_max: one all-reduce of the ranks' loop counts in front of the build (sixth collective)
+    c = FakeCtx()
+    g = gdist.ShardedKnnGraph(c, Xg.shape[0])
+    g.gather_points(torch.from_numpy(Xg[g.splits[rank]:g.splits[rank + 1]].copy()))
+    g.build(FakeParams(10, 20, 1e-4, "+", knn_max=60), symmetric=False)
+    assert c.calls[:2] == ("stage_counts", "stage_totals"), c.calls
+    assert np.array_equal(c.stage_totals, [sum(100 + r for r in range(world)), sum(7 * (r + 1) for r in range(world))])
+
     # 6. anisotropy: the owned degrees are all-gathered (fourth collective), then applied to the owned block
     g = gdist.ShardedKnnGraph(FakeCtx(), Xg.shape[0])
     g.gather_points(torch.from_numpy(Xg[g.splits[rank]:g.splits[rank + 1]].copy()))

@@ -527,3 +527,64 @@ def test_device_memory_cache_is_reused_and_released():
     del G
     graphtools_amd.release_cached_memory()
     assert base - free_bytes() < (64 << 20)
+
+
+@pytest.mark.parametrize("n,d,maker,seed,knn,decay,knn_max", [
+    (3000, 20, make_mix, 21, 5, 40.0, 300),     # radius branch, no cap
+    (2500, 8, make_gauss, 22, 5, 3.0, 250),     # wide kernel: escalation
+    (2000, 16, make_mix, 23, 4, 10.0, 40),      # capped branch
+])
+def test_two_rank_sharding_with_knn_max_follows_the_reference_branches(n, d, maker, seed, knn, decay, knn_max):
+    """row-sharded builds with knn_max: the ranks' counts for the search-expansion loop are summed by the host
+    (gt_graph_stage_counts / gt_graph_set_stage_totals), so the sharded build takes the branch the single-rank build - and the
+    reference - takes; without the exchange it caps every row.  Two contexts on one GPU, exchanges by hand."""
+    X = maker(n, d, seed)
+    splits = np.array([0, n // 2 - 37, n], dtype=np.int64)
+    ref = _hip.Context(0)
+    ref.set_points(X)
+    p, keep = ref.make_params(knn, decay, 1e-4, None, 1.0, knn_max, "+", None, 0.0)
+    ref.graph_build(p)
+    Kd, Ki, Kp = ref.graph_fetch_csr(_hip.CSR_K)
+    ref.close()
+    ctxs = [_hip.Context(0), _hip.Context(0)]
+    trip = np.dtype([("row", np.uint32), ("col", np.uint32), ("val", np.float64)])
+    local = []
+    for r, c in enumerate(ctxs):
+        c.set_points(X)
+        local.append(c.graph_stage_counts(p, 2, r, splits))
+    assert len(local[0]) == len(local[1]) and len(local[0]) > 0
+    totals = local[0] + local[1]
+    sends, counts = [], []
+    for r, c in enumerate(ctxs):
+        c.graph_set_stage_totals(totals)
+        cnt = c.graph_begin(p, 2, r, splits)
+        total = int(cnt.sum())
+        host = np.zeros(total, dtype=trip)
+        if total:
+            buf = c.dev_alloc(total * 16)
+            c.graph_emit(buf)
+            c.dev_download(host, buf)
+            c.dev_free(buf)
+        sends.append(host)
+        counts.append(cnt)
+    datas, inds, ptrs = [], [], []
+    base = 0
+    for r, c in enumerate(ctxs):
+        parts = []
+        for s_ in range(2):
+            off = int(counts[s_][:r].sum())
+            parts.append(sends[s_][off: off + int(counts[s_][r])])
+        recv = np.concatenate(parts)
+        buf = c.dev_alloc(max(len(recv), 1) * 16)
+        if len(recv):
+            c.dev_upload(buf, recv)
+        c.graph_finish(buf if len(recv) else 0, len(recv))
+        c.dev_free(buf)
+        d_, i_, p_ = c.graph_fetch_csr(_hip.CSR_K)
+        datas.append(d_); inds.append(i_)
+        ptrs.append(p_[:-1] + base)
+        base += p_[-1]
+        c.close()
+    assert np.array_equal(np.concatenate(ptrs + [[base]]), Kp)
+    assert np.array_equal(np.concatenate(inds), Ki)
+    assert np.array_equal(np.concatenate(datas), Kd)
