@@ -394,6 +394,43 @@ def secondary_c4(_hip, torch, device, n=200000, d=100):
         _hip.release_cached_memory()
 
 
+def secondary_c4_points(_hip, torch, device, n=200000, d=100, steps=2):
+    """Config 4's graph built FROM THE POINTS (graphs.py:1546-1609 without forming all pairs): radius search of the kNN path with
+    float64 distances, then K and P written out densely (float32, device-resident, one N x N buffer reused for both)."""
+    X = torch.from_numpy(make_mix(n, d, 2)).to(device)
+    out = torch.empty((n, n), dtype=torch.float32, device=device)
+    ctx = _hip.Context(device.index or 0)
+    try:
+        ctx.set_option("distance_dtype", "float64")
+        params, keep = ctx.make_params(15, 40.0, 1e-4, None, 1.0, None, "+", None, 0)
+        best = None
+        for it in range(steps + 1):
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            ctx.set_points_device(X.data_ptr(), n, d, np.float32)
+            nnz, _ = ctx.graph_build(params)
+            ctx.sync()
+            t1 = time.perf_counter()
+            ctx.graph_to_dense(_hip.CSR_K, n, np.float32, out_device=out)
+            ctx.graph_to_dense(_hip.CSR_P, n, np.float32, out_device=out)
+            ctx.sync()
+            t2 = time.perf_counter()
+            cur = {"build_ms": (t1 - t0) * 1e3, "dense_out_ms": (t2 - t1) * 1e3, "ms_per_graph": (t2 - t0) * 1e3}
+            if it > 0 and (best is None or cur["ms_per_graph"] < best["ms_per_graph"]):
+                best = cur
+        nbytes = 8.0 * n * n   # two float32 N x N matrices written once
+        best.update({"workload": "C4 from points: mix N=%d d=%d seed=2 float32, TraditionalGraph knn=15 decay=40 thresh=1e-4, "
+                                 "radius search + dense float32 K and P on the device" % (n, d),
+                     "graphs_per_s": 1e3 / best["ms_per_graph"], "nnz_K": int(nnz),
+                     "dense_out_GBs": nbytes / best["dense_out_ms"] / 1e6})
+        return best
+    finally:
+        ctx.close()
+        del out, X
+        torch.cuda.empty_cache()
+        _hip.release_cached_memory()
+
+
 def secondary_c5(n=1000000, d=50):
     """BASELINE config 5 on one GPU: kNN kernel + landmark operator (random landmarking), host arrays in and out."""
     import warnings
@@ -433,7 +470,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-full", action="store_true", help="time the oracle port on ALL rows of the workload (minutes)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary workloads / host-complete legs")
-    ap.add_argument("--secondary-only", default="", help="comma list out of manifold,gauss,binary,cosine,c2,c4,c5")
+    ap.add_argument("--secondary-only", default="", help="comma list out of manifold,gauss,binary,cosine,c2,c4,c4points,c5")
     ap.add_argument("--knn-precision", choices=["auto", "f16x1", "f16", "f32"],
                     default=os.environ.get("GT_KNN_PRECISION", "auto"),
                     help="arithmetic of the candidate pass (results are identical; see DESIGN.md); auto = the library "
@@ -598,7 +635,7 @@ def main():
         ctx = None
         del x_local
         torch.cuda.empty_cache()
-        want = [w for w in args.secondary_only.split(",") if w] or ["manifold", "gauss", "binary", "cosine", "c2", "c4", "c5"]
+        want = [w for w in args.secondary_only.split(",") if w] or ["manifold", "gauss", "binary", "cosine", "c2", "c4", "c4points", "c5"]
         if single and not args.no_secondary:
             # ---- host-complete: host X in -> scipy CSR K, P out (SURVEY 8d headline definition) ----
             try:
@@ -630,6 +667,7 @@ def main():
                                                 X, opts=(("metric", "cosine"),)),
                 "c2": lambda: secondary_knn(_hip, torch, device, "C2: mix N=1e5 d=50 seed=0, knn=15 decay=40", make_mix(100000, 50, 0), steps=5),
                 "c4": lambda: secondary_c4(_hip, torch, device),
+                "c4points": lambda: secondary_c4_points(_hip, torch, device),
                 "c5": lambda: secondary_c5(),
             }
             for name in want:

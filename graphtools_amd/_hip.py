@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get("GRAPHTOOLS_AMD_LIB") or os.path.join(_HERE, "libgraph
 GT_F32, GT_F64 = 0, 1
 GT_E_NONFINITE = -6  # include/graphtools_amd.h
 SYMM = {None: 0, "none": 0, "+": 1, "*": 2, "mnn": 3}
+MAX_KNN = 447   # deepest neighbour count of the candidate tables (gt_knn.cpp)
 FLAG_DUPLICATES, FLAG_ZERO_DIAGONAL, FLAG_FALLBACK_ROWS, FLAG_RADIUS_ROWS = 1, 2, 4, 8
 CSR_K, CSR_P = 0, 1
 VEC_BANDWIDTH, VEC_DEGREE = 0, 1
@@ -81,6 +82,7 @@ _SIGNATURES = {
                                       _c.c_double, _c.c_double, _c.POINTER(_c.c_int64), _c.POINTER(_c.c_uint32)]),
     "gt_graph_rows": (_c.c_int, [_c.c_void_p, _c.POINTER(_c.c_int64), _c.POINTER(_c.c_int64), _c.POINTER(_c.c_int64)]),
     "gt_graph_fetch_csr": (_c.c_int, [_c.c_void_p, _c.c_int32, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int32]),
+    "gt_graph_to_dense": (_c.c_int, [_c.c_void_p, _c.c_int32, _c.c_void_p, _c.c_int32, _c.c_int32]),
     "gt_release_cached_memory": (_c.c_int, []),
     "gt_host_place_block": (_c.c_int, [_c.c_int64] + [_c.c_void_p] * 9),
     "gt_graph_spmm": (_c.c_int, [_c.c_void_p, _c.c_int32, _c.c_void_p, _c.c_int64, _c.c_void_p, _c.c_int32]),
@@ -405,6 +407,19 @@ class Context:
         self._check(self.lib.gt_graph_fetch_csr(self.h, which, _ptr(data), _ptr(indices) if structure else None,
                                                 _ptr(indptr) if structure else None, 0), "gt_graph_fetch_csr")
         return data, indices, indptr
+
+    def graph_to_dense(self, which, n, dtype=np.float64, out_device=None):
+        """dense copy [owned rows, n] of K or P (n = columns of the graph): a host ndarray, or (``out_device``: a CUDA torch
+        tensor of that shape and dtype) written in place on the device"""
+        r0, r1, _ = self.graph_rows()
+        code = GT_F32 if np.dtype(dtype) == np.float32 else GT_F64
+        if out_device is not None:
+            self._check(self.lib.gt_graph_to_dense(self.h, which, ctypes.c_void_p(out_device.data_ptr()), code, 1),
+                        "gt_graph_to_dense")
+            return out_device
+        out = np.empty((r1 - r0, n), dtype=dtype)
+        self._check(self.lib.gt_graph_to_dense(self.h, which, _ptr(out), code, 0), "gt_graph_to_dense")
+        return out
 
     def graph_csr_torch(self, which):
         """Device-resident hand-off: the owned rows of K or P as a ``torch.sparse_csr_tensor`` on this context's GPU

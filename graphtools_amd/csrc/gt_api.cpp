@@ -284,6 +284,12 @@ int gt_set_option(gt_ctx* ctx, const char* name, const char* value) {
         ctx->symm_fused = std::atoi(value) != 0 ? 1 : 0;
         return GT_OK;
     }
+    if (k == "distance_dtype") {
+        const std::string v = value;
+        if (v != "data" && v != "float64") GT_FAIL(ctx, GT_E_ARG, "distance_dtype must be 'data' or 'float64'");
+        ctx->dist_f64 = v == "float64" ? 1 : 0;
+        return GT_OK;
+    }
     if (k == "symmetrize_pairs") {
         ctx->symm_pairs = std::atoi(value) != 0 ? 1 : 0;
         return GT_OK;

@@ -167,6 +167,7 @@ struct gt_ctx {
     // row-sharded builds with knn_max: the counts of the reference's search-expansion loop travel through the host
     int32_t stage_counts_only = 0, stage_totals_valid = 0, stage_n = 0;
     int64_t stage_local[4] = {0, 0, 0, 0}, stage_totals[4] = {0, 0, 0, 0};
+    int32_t dist_f64 = 0;       //   distances from the float64 keys in float64 whatever the points' dtype (option "distance_dtype")
     int32_t in_graph_build = 0; //   (set by gt_graph_build around its gt_graph_begin: every row is here, the tail is its own)
     int32_t symm_pairs = 1;     //   pair-resolved symmetrisation (gt_sparse.hip): every row settles its mutual pairs itself, only one-sided entries travel
     int32_t symm_pair_ok = 1;   //   ... not refuted for the bound point set (a union row beyond the register sorts)

@@ -44,6 +44,11 @@ __device__ __forceinline__ int owner_of(const Splits& sp, int64_t row) {
     return o;
 }
 
+// dtype the distances are formed in from the float64 keys: the points' own (scikit-learn rounds a float32 set's distances to
+// float32, graphs.py:883), or float64 whatever the points are ("distance_dtype" = "float64": scipy pdist / cdist semantics,
+// what the exact graph built through this path needs - graphs.py:1552)
+static inline int gt_dist_dtype(const gt_ctx* ctx) { return ctx->dist_f64 ? GT_F64 : ctx->dtype; }
+
 // the symmetrisation rule on one pair of values (base.py:557-577)
 __device__ __forceinline__ double merge_values(double a, double b, int symm, double theta) {
     switch (symm) {
@@ -1480,7 +1485,7 @@ void launch_affinity(gt_ctx* ctx, GraphState* g, KnnWork* k, int binary, double 
 #define GT_AFFINITY_LAUNCH(RADIUS_, PAIRS_, LIST_, NROWS_)                                                                  \
     hipLaunchKernelGGL((affinity_kernel<T, RADIUS_, PAIRS_>), dim3((unsigned)ceil_div64(NROWS_, 4)), dim3(256), lds, ctx->stream, \
                        LIST_, int64_t(NROWS_), g->nloc, g->r0, (const T*)ctx->X, ctx->d, ctx->xn.as<double>(),              \
-                       (const T*)g->Qmat, g->qnorm, g->qoff, ctx->dtype, ctx->metric, k->MP, g->limit,                     \
+                       (const T*)g->Qmat, g->qnorm, g->qoff, gt_dist_dtype(ctx), ctx->metric, k->MP, g->limit,            \
                        k->cand_d2.as<double>(), k->cand_j.as<uint32_t>(), k->cand_n.as<uint32_t>(), g->rowsrc.as<int32_t>(), \
                        g->rlists.as<uint64_t>(), g->rcounts.as<uint32_t>(), g->rcap, g->rK.as<double>(),                   \
                        g->bw.as<double>(), decay, binary, thresh, count_owners, make_splits(g), g->lenN.as<int32_t>(),      \
@@ -1700,7 +1705,7 @@ static int graph_begin_impl(gt_ctx* ctx, const gt_knn_params* params, int32_t wo
     {
         StageSpan span(ctx, "affinity");
         hipLaunchKernelGGL(bandwidth_kernel, dim3((unsigned)ceil_div64(g->nloc, 256)), dim3(256), 0, ctx->stream, g->nloc,
-                           g->r0, k->MP, kprime, ctx->dtype, ctx->metric, k->cand_d2.as<double>(), k->d2_lb.as<double>(),
+                           g->r0, k->MP, kprime, gt_dist_dtype(ctx), ctx->metric, k->cand_d2.as<double>(), k->d2_lb.as<double>(),
                            qn_bound, g->qnorm, g->qoff, ctx->ymax.as<double>(), err_model, g->bw_user.as<double>(),
                            params->bandwidth_len, params->bandwidth_scale, use_radius ? 1 : 0, g->radius_factor,
                            g->bw.as<double>(), g->rowsrc.as<int32_t>(), g->over_rows.as<int32_t>(),
@@ -1718,7 +1723,7 @@ static int graph_begin_impl(gt_ctx* ctx, const gt_knn_params* params, int32_t wo
         GT_HIP(ctx, g->rmax.reserve(4 * sizeof(uint32_t)));
         GT_HIP(ctx, hipMemsetAsync(g->rmax.p, 0, 4 * sizeof(uint32_t), ctx->stream));
         hipLaunchKernelGGL(stage_count_kernel, dim3((unsigned)ceil_div64(g->nloc, 256)), dim3(256), 0, ctx->stream, g->nloc,
-                           k->MP, ctx->dtype, ctx->metric, k->cand_d2.as<double>(), g->bw.as<double>(), g->radius_factor,
+                           k->MP, gt_dist_dtype(ctx), ctx->metric, k->cand_d2.as<double>(), g->bw.as<double>(), g->radius_factor,
                            make_int4(kst[0], kst[1], kst[2], kst[3]), n_avail, g->rmax.as<uint32_t>());
         GT_HIP(ctx, hipGetLastError());
         uint32_t un[4] = {0, 0, 0, 0};
@@ -1761,7 +1766,7 @@ static int graph_begin_impl(gt_ctx* ctx, const gt_knn_params* params, int32_t wo
             GT_HIP(ctx, hipMemsetAsync(g->over_count.p, 0, sizeof(uint32_t), ctx->stream));
             StageSpan span(ctx, "affinity");
             hipLaunchKernelGGL(bandwidth_kernel, dim3((unsigned)ceil_div64(g->nloc, 256)), dim3(256), 0, ctx->stream, g->nloc,
-                               g->r0, k->MP, kprime, ctx->dtype, ctx->metric, k->cand_d2.as<double>(), k->d2_lb.as<double>(),
+                               g->r0, k->MP, kprime, gt_dist_dtype(ctx), ctx->metric, k->cand_d2.as<double>(), k->d2_lb.as<double>(),
                                qn_bound, g->qnorm, g->qoff, ctx->ymax.as<double>(), err_model, g->bw_user.as<double>(),
                                params->bandwidth_len, params->bandwidth_scale, 1, g->radius_factor,
                                g->bw.as<double>(), g->rowsrc.as<int32_t>(), g->over_rows.as<int32_t>(),
@@ -2807,4 +2812,69 @@ extern "C" int gt_graph_stats(const gt_ctx* ctx, int64_t* out4) {
     out4[2] = ctx->graph->nnz0;
     out4[3] = ctx->graph->radius_retries;
     return GT_OK;
+}
+
+// ---- dense copy of the owned rows of K or P (the exact graph built through the sparse path: TraditionalGraph from data) ----
+template <typename TO>
+__global__ __launch_bounds__(256) void csr_to_dense_kernel(const int64_t nloc, const int64_t ncols, const int64_t* __restrict__ indptr,
+                                                           const int32_t* __restrict__ indices, const double* __restrict__ data,
+                                                           TO* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    if (i >= nloc) return;
+    TO* row = out + i * ncols;
+    constexpr int V = 16 / int(sizeof(TO));   // elements per 16-byte store
+    if ((ncols % V) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+        u32x4* row4 = reinterpret_cast<u32x4*>(row);
+        const int64_t n4 = ncols / V;
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        int64_t c = lane;
+        for (; c + 192 < n4; c += 256) {
+            __builtin_nontemporal_store(z, row4 + c);
+            __builtin_nontemporal_store(z, row4 + c + 64);
+            __builtin_nontemporal_store(z, row4 + c + 128);
+            __builtin_nontemporal_store(z, row4 + c + 192);
+        }
+        for (; c < n4; c += 64) __builtin_nontemporal_store(z, row4 + c);
+    } else {
+        for (int64_t c = lane; c < ncols; c += 64) row[c] = TO(0);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // the zeros of this row have landed before its entries are written
+    for (int64_t e = indptr[i] + lane; e < indptr[i + 1]; e += 64) row[indices[e]] = TO(data[e]);
+}
+
+extern "C" int gt_graph_to_dense(gt_ctx* ctx, int32_t which, void* out, int32_t out_dtype, int32_t out_on_device) {
+    if (!ctx || !out) return GT_E_ARG;
+    GT_HIP(ctx, hipSetDevice(ctx->device));
+    GraphState* g = ctx->graph;
+    if (!g || !g->finished) GT_FAIL(ctx, GT_E_STATE, "gt_graph_to_dense: no finished graph");
+    if (which != GT_CSR_K && which != GT_CSR_P) GT_FAIL(ctx, GT_E_ARG, "which must be GT_CSR_K or GT_CSR_P");
+    if (out_dtype != GT_F32 && out_dtype != GT_F64) GT_FAIL(ctx, GT_E_ARG, "out_dtype must be GT_F32 or GT_F64");
+    const int64_t nloc = g->nloc, ncols = g->n_total;
+    const size_t esz = out_dtype == GT_F32 ? 4 : 8;
+    const size_t bytes = size_t(nloc) * size_t(ncols) * esz;
+    DevBuf tmp;
+    void* dst = out;
+    if (!out_on_device) {
+        GT_HIP(ctx, tmp.reserve(bytes));
+        dst = tmp.p;
+    }
+    const double* data = which == GT_CSR_K ? g->Kdata.as<double>() : g->Pdata.as<double>();
+    if (out_dtype == GT_F32)
+        hipLaunchKernelGGL(csr_to_dense_kernel<float>, dim3((unsigned)ceil_div64(nloc, 4)), dim3(256), 0, ctx->stream, nloc, ncols,
+                           g->indptr.as<int64_t>(), g->indices.as<int32_t>(), data, (float*)dst);
+    else
+        hipLaunchKernelGGL(csr_to_dense_kernel<double>, dim3((unsigned)ceil_div64(nloc, 4)), dim3(256), 0, ctx->stream, nloc, ncols,
+                           g->indptr.as<int64_t>(), g->indices.as<int32_t>(), data, (double*)dst);
+    hipError_t e = hipGetLastError();
+    int rc = GT_OK;
+    if (e == hipSuccess && !out_on_device) rc = gt_copy_to_host(ctx, out, dst, bytes);
+    if (e == hipSuccess && rc == GT_OK) e = hipStreamSynchronize(ctx->stream);
+    tmp.release();
+    if (e != hipSuccess) {
+        ctx->set_error(std::string("gt_graph_to_dense: ") + hipGetErrorString(e));
+        return GT_E_HIP;
+    }
+    return rc;
 }

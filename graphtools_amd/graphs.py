@@ -642,6 +642,45 @@ class TraditionalGraph(DataGraph):
         self.hip.set_option("metric", "euclidean")
         self.hip.set_points(X)
 
+    # smallest point set sent through the neighbour search: below it the all-pairs tile kernel is as fast
+    _NEIGHBOUR_ROUTE_MIN = 4096
+
+    def _build_kernel_through_neighbours(self, data, bandwidth):
+        """The exact graph from points without forming all pairs (reference: graphs.py:1546-1609).
+
+        ``K[K < thresh] = 0`` makes every entry beyond ``bandwidth_i * (-log thresh)^(1/decay)`` of row i exactly zero, so
+        the kept entries are a radius search: the kNN path's build (candidate distances on the matrix cores, float64
+        refinement inside the radius only) with the same ``knn`` (the bandwidth is the distance to the knn-th OTHER point in
+        both: graphs.py:1584-1588 here, graphs.py:776 ``knn + 1`` with the point itself there), then written out densely
+        on the device.  Distances are float64 (pdist converts to double); the points are centred first, which pdist's
+        differences do not see and which keeps the expanded form |x|^2 - 2 x.y + |y|^2 of the search well conditioned.
+        Returns None when this route does not apply (small sets, thresh = 0, duplicate points - their warnings and the
+        0 / 0 bandwidth rule live in the all-pairs path)."""
+        n = data.shape[0]
+        if (n < self._NEIGHBOUR_ROUTE_MIN or not self.thresh or self.thresh <= 0 or self.decay is None
+                or (self.knn is not None and self.knn + 1 > _hip.MAX_KNN)):   # (+ 1: the point itself)
+            return None
+        X = np.asarray(data, dtype=np.float64)
+        X = np.ascontiguousarray(X - X.mean(axis=0, keepdims=True))
+        self.hip.set_option("metric", "euclidean")
+        self.hip.set_points(X)
+        bw = bandwidth
+        if bw is not None and not isinstance(bw, numbers.Number):
+            bw = np.asarray(bw, dtype=np.float64)
+            if bw.shape != (n,):
+                return None
+        params, keep = _hip.Context.make_params(self.knn if self.knn is not None else 1, self.decay, self.thresh, bw,
+                                                self.bandwidth_scale, None, self.kernel_symm, self.theta, self.anisotropy)
+        nnz, flags = self.hip.graph_build(params)
+        del keep
+        if flags & _hip.FLAG_DUPLICATES:
+            return None
+        K = self.hip.graph_to_dense(_hip.CSR_K, n)
+        self._diff_op = self.hip.graph_to_dense(_hip.CSR_P, n)
+        self._kernel_degree = self.hip.graph_fetch_vec(_hip.VEC_DEGREE).reshape(-1, 1)
+        self._emit_build_warnings(flags, K)
+        return K
+
     def _build_kernel(self):
         data = self.data_nu
         if self.precomputed in ("affinity", "adjacency"):
@@ -695,6 +734,10 @@ class TraditionalGraph(DataGraph):
                 self._warn_duplicate_pairs([(int(i), int(j)) for i, j in dup] if len(dup) < 20 else None, len(dup))
         if callable(bandwidth):
             bandwidth = np.asarray(bandwidth(host_pdx if host_pdx is not None else data), dtype=np.float64)
+        if host_pdx is None and self.precomputed is None:
+            K = self._build_kernel_through_neighbours(data, bandwidth)
+            if K is not None:
+                return K
         K, P, flags = self.hip.dense_graph_build(
             host_pdx if host_pdx is not None else data,
             "distance" if (self.precomputed == "distance" or host_pdx is not None) else None, self.knn, self.decay,

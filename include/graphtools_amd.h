@@ -237,6 +237,14 @@ int gt_graph_extend(gt_ctx* ctx, const void* Y, int64_t m, int32_t y_on_device, 
 int gt_graph_rows(const gt_ctx* ctx, int64_t* row0, int64_t* row1, int64_t* nnz);
 int gt_graph_fetch_csr(gt_ctx* ctx, int32_t which, double* data, int32_t* indices, int64_t* indptr,
                        int32_t on_device);
+
+/* Dense copy of the owned rows of K or P: out[nloc][n_total], zeros where the sparse form has no entry.  out_dtype GT_F32 or
+ * GT_F64.  Serves the exact graph built FROM POINTS (TraditionalGraph, graphtools/graphs.py:1546-1609: pdist -> bandwidth ->
+ * exp(-(d/bw)^decay) -> entries below thresh zeroed): everything outside the thresh radius is exactly 0 there, so the build is
+ * the kNN path's (candidate distances on the matrix cores, float64 refinement inside the radius only) and this call writes
+ * the dense form the reference returns.  Option "distance_dtype" = "float64" makes a float32 point set's distances float64
+ * (scipy's pdist converts to double) instead of scikit-learn's float32. */
+int gt_graph_to_dense(gt_ctx* ctx, int32_t which, void* out, int32_t out_dtype, int32_t out_on_device);
 int gt_graph_fetch_vec(gt_ctx* ctx, int32_t which, double* out, int32_t on_device);
 /* out[owned rows][ncols] = (K or P)[owned rows, :] @ X[n][ncols]  (float64, row-major) with the operator left on the
  * device: the building block of the diffusion steps P^t X that consume `diff_op` downstream of the reference

@@ -156,3 +156,78 @@ def test_exact_graph_names_the_duplicate_pairs():
     X[41] = X[5]
     with pytest.warns(RuntimeWarning, match="Detected zero distance between samples 5 and 40, 5 and 41, 17 and 250, 40 and 41. Consider"):
         graphtools_amd.Graph(X, knn=5, decay=10, graphtype="exact", n_pca=None, verbose=0).K
+
+
+def _compare_dense_to_oracle(G, K0, P0, thresh, rtol):
+    assert G.K.shape == K0.shape and G.K.dtype == np.float64 and not sparse.issparse(G.K)
+    flip = (G.K == 0) != (K0 == 0)
+    assert np.all(np.abs(np.where(flip, np.maximum(G.K, K0), thresh) - thresh) <= 1e-6 * thresh)
+    assert flip.sum() <= 4
+    m = ~flip
+    np.testing.assert_allclose(G.K[m], K0[m], rtol=rtol, atol=1e-300)
+    np.testing.assert_allclose(G.P[m], P0[m], rtol=max(rtol, 1e-7), atol=1e-300)
+    np.testing.assert_allclose(G.kernel_degree.ravel(), K0.sum(axis=1), rtol=1e-7)
+
+
+@pytest.mark.parametrize("kw", [
+    dict(), dict(kernel_symm="mnn", theta=0.3), dict(anisotropy=1.0), dict(bandwidth=7.5, bandwidth_scale=0.9),
+    dict(knn=4, decay=2, thresh=1e-3), dict(dtype=np.float32),
+])
+def test_exact_graph_from_points_through_the_neighbour_search(kw, monkeypatch):
+    """above _NEIGHBOUR_ROUTE_MIN points the exact graph is built by the kNN path's radius search and written out densely
+    (graphs.py:1546-1609: everything below thresh is exactly 0); tolerance 1e-9 relative on K like the all-pairs path (measured:
+    2e-12 - the search forms |x|^2 - 2 x.y + |y|^2 in float64 on centred points where pdist sums squared differences)"""
+    kw = dict(kw)
+    dtype = kw.pop("dtype", np.float64)
+    X = (make_mix(4500, 24, 33) + 40.0).astype(dtype)    # (far from the origin: the route centres the points)
+    args = dict(knn=6, decay=20, thresh=1e-4)
+    args.update(kw)
+    calls = []
+    from graphtools_amd import _hip
+    real = _hip.Context.graph_to_dense
+    monkeypatch.setattr(_hip.Context, "graph_to_dense", lambda self, *a, **k: (calls.append(a[0]), real(self, *a, **k))[1])
+    G = graphtools_amd.Graph(X, n_pca=None, graphtype="exact", **args)
+    G.K
+    assert calls == [_hip.CSR_K, _hip.CSR_P]
+    K0, P0 = oracle.exact_graph(X.astype(np.float64), **args)
+    _compare_dense_to_oracle(G, K0, P0, args["thresh"], 1e-9)
+    np.testing.assert_allclose(G.diff_op, G.P)
+
+
+def test_exact_graph_from_points_keeps_the_all_pairs_path_for_duplicates_and_small_sets(monkeypatch):
+    from graphtools_amd import _hip
+    calls = []
+    real = _hip.Context.graph_to_dense
+    monkeypatch.setattr(_hip.Context, "graph_to_dense", lambda self, *a, **k: (calls.append(a[0]), real(self, *a, **k))[1])
+    X = make_mix(4400, 12, 5)
+    X[17] = X[4100]
+    with pytest.warns(RuntimeWarning, match="Detected zero distance between samples 17 and 4100"):
+        G = graphtools_amd.Graph(X, n_pca=None, graphtype="exact", knn=5, decay=10)
+        G.K
+    assert calls == []
+    K0, P0 = oracle.exact_graph(X, knn=5, decay=10)
+    np.testing.assert_allclose(G.K, K0, rtol=1e-9, atol=1e-300)
+    G2 = graphtools_amd.Graph(X[:500], n_pca=None, graphtype="exact", knn=5, decay=10, thresh=0)
+    G2.K
+    assert calls == []
+
+
+def test_distance_dtype_option_gives_float32_points_float64_distances():
+    """'distance_dtype' = 'float64': a float32 point set's distances come out of the float64 keys unrounded (scipy's pdist
+    semantics) - the same graph as the float64 copy of the points gives"""
+    from graphtools_amd import _hip
+    X32 = make_mix(6000, 16, 3).astype(np.float32)
+    out = []
+    for X, opt in ((X32, "float64"), (X32.astype(np.float64), "data"), (X32, "data")):
+        ctx = _hip.Context(0)
+        ctx.set_option("distance_dtype", opt)
+        ctx.set_points(X)
+        params, keep = _hip.Context.make_params(8, 30, 1e-4, None, 1.0, None, "+", None, 0)
+        ctx.graph_build(params)
+        d, i, p = ctx.graph_fetch_csr(_hip.CSR_K)
+        out.append(sparse.csr_matrix((d, i, p), shape=(6000, 6000)))
+        ctx.close()
+    a, b, c = out
+    assert np.array_equal(a.indptr, b.indptr) and np.array_equal(a.indices, b.indices)
+    np.testing.assert_allclose(a.data, b.data, rtol=1e-11)
+    assert abs(a - c).max() > 1e-9       # (the float32 rounding of the distances is visible without the option)
