@@ -199,7 +199,12 @@ struct gt_ctx {
     void* landmark = nullptr;   // LandmarkState (gt_landmark.hip)
     void* pca = nullptr;        // PcaState (gt_pca.hip)
 
-    void set_error(const std::string& m) { err = m; }
+    // (every failure is reported through here: HIP's per-thread last-error slot is emptied with it, or the error would
+    //  resurface in the launch check - hipGetLastError() - of the next, unrelated call on this thread)
+    void set_error(const std::string& m) {
+        err = m;
+        (void)hipGetLastError();
+    }
 
     hipEvent_t get_event() {
         if (!event_pool.empty()) {

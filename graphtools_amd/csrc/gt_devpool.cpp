@@ -79,6 +79,7 @@ hipError_t gt_pool_alloc(void** p, size_t bytes, size_t* got) {
         }
         e = hipMalloc(p, bytes);
     }
+    if (e != hipSuccess) (void)hipGetLastError();   // handed to the caller as a return value: leave no stale error behind
     *got = bytes;
     return e;
 }

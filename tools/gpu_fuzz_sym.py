@@ -1,0 +1,114 @@
+#!/usr/bin/env python
+"""Randomised A/B sweep of the symmetric candidate pass and the pair-resolved tail: the same graph built with the pass forced on
+and with the classic pass (and the general symmetrisation tail) must be identical bit for bit - K (indptr, indices, data), P.
+usage: gpu_fuzz_sym.py [n_cases] [seed]      writes gpurun_out/gpu_fuzz_sym_failures.json"""
+import hashlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from graphtools_amd import _hip  # noqa: E402
+
+
+def make_data(rng, kind, n, d, dtype):
+    if kind == "mix":
+        c = max(n // int(rng.choice([200, 1000, 5000])), 1)
+        centres = rng.uniform(-10, 10, (c, d))
+        X = centres[rng.integers(c, size=n)] + rng.standard_normal((n, d)) * rng.uniform(0.3, 2.0, (n, 1))
+    elif kind == "manifold":
+        z = rng.standard_normal((n, min(5, d)))
+        X = np.tanh(z @ rng.standard_normal((min(5, d), d))) + 0.01 * rng.standard_normal((n, d))
+    elif kind == "gauss":
+        X = rng.standard_normal((n, d))
+    elif kind == "shifted":
+        X = rng.standard_normal((n, d)) * 0.3 + 25.0
+    elif kind == "hubs":     # a dense core that many sparse rows point into: long union rows
+        X = rng.standard_normal((n, d)) * np.where(rng.random((n, 1)) < 0.02, 0.02, 1.0)
+    else:   # lattice: many exact ties
+        X = rng.integers(0, 5, size=(n, d)).astype(np.float64)
+    return np.ascontiguousarray(X.astype(dtype))
+
+
+def build(X, opts, params):
+    ctx = _hip.Context(0)
+    try:
+        for k, v in opts:
+            ctx.set_option(k, v)
+        ctx.set_points(X)
+        p, keep = ctx.make_params(*params)
+        nnz, flags = ctx.graph_build(p)
+        kd, ki, kp = ctx.graph_fetch_csr(_hip.CSR_K)
+        pd, _, _ = ctx.graph_fetch_csr(_hip.CSR_P, structure=False)
+        sig = [hashlib.sha1(a.tobytes()).hexdigest()[:16] for a in (kp, ki, kd, pd)]
+        st = ctx.knn_stats()
+        return sig, int(nnz), int(flags), st
+    finally:
+        ctx.close()
+
+
+def main():
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    rng = np.random.default_rng(seed)
+    fails, engaged = [], 0
+    t0 = time.time()
+    for case in range(n_cases):
+        kind = str(rng.choice(["mix", "manifold", "gauss", "shifted", "hubs", "lattice"], p=[0.35, 0.2, 0.1, 0.1, 0.15, 0.1]))
+        n = int(rng.choice([int(rng.integers(4096, 12000)), int(rng.integers(12000, 60000)), int(rng.integers(65536, 140000))]))
+        d = int(rng.choice([4, 8, 16, 20, 33, 50, 64, 100, 128]))
+        dtype = rng.choice([np.float32, np.float32, np.float64])
+        knn = int(rng.integers(2, 40))
+        decay = rng.choice([None, 2.0, 10.0, 40.0, 40.0])
+        decay = None if decay is None else float(decay)
+        thresh = float(rng.choice([1e-4, 1e-3, 1e-2]))
+        symm = str(rng.choice(["+", "+", "*", "mnn", "none"]))
+        symm = None if symm == "none" else symm
+        theta = float(rng.uniform(0, 1)) if symm == "mnn" else None
+        aniso = float(rng.choice([0.0, 0.0, 0.5, 1.0]))
+        metric = str(rng.choice(["euclidean", "euclidean", "cosine"]))
+        if kind == "lattice" and metric == "cosine":
+            metric = "euclidean"
+        bw = None
+        if decay is not None and rng.random() < 0.25:
+            bw = float(rng.uniform(0.5, 3.0)) if rng.random() < 0.5 else rng.uniform(0.5, 3.0, n)
+        X = make_data(rng, kind, n, d, dtype)
+        params = (knn, decay, thresh, bw, float(rng.choice([1.0, 1.0, 0.7, 1.5])), None, symm, theta, aniso)
+        forced = [("metric", metric), ("query_order_min_rows", "1"), ("select_symmetric", "1"),
+                  ("select_sym_stride", str(int(rng.choice([2, 4, 16, 384]))))]
+        if rng.random() < 0.3:
+            forced.append(("select_sym_bounds", str(int(rng.choice([0, 1])))))
+        if rng.random() < 0.3:
+            forced.append(("select_sym_two_stage", str(int(rng.choice([0, 1])))))
+        if rng.random() < 0.2:
+            forced.append(("select_sym_dense_seed", "0"))
+        classic = [("metric", metric), ("select_symmetric", "0"), ("symmetrize_pairs", "0")]
+        desc = dict(case=case, kind=kind, n=n, d=d, dtype=np.dtype(dtype).name, knn=knn, decay=decay, thresh=thresh, symm=symm,
+                    theta=theta, aniso=aniso, metric=metric, bw=("vector" if isinstance(bw, np.ndarray) else bw),
+                    bandwidth_scale=params[4], forced=forced[3:])
+        try:
+            a, nnz_a, fl_a, st_a = build(X, forced, params)
+            b, nnz_b, fl_b, st_b = build(X, classic, params)
+            engaged += bool(st_a["symmetric"])
+            ok = a == b and nnz_a == nnz_b
+            desc.update(symmetric=bool(st_a["symmetric"]), nnz=nnz_a, flags=(fl_a, fl_b))
+            if not ok:
+                desc["sig"] = (a, b, nnz_a, nnz_b)
+                fails.append(desc)
+            print(("ok   " if ok else "FAIL ") + json.dumps(desc), flush=True)
+        except Exception as e:   # a build error is a finding too
+            desc["error"] = repr(e)
+            fails.append(desc)
+            print("ERR  " + json.dumps(desc), flush=True)
+    print("cases %d, symmetric pass engaged in %d, failures %d, %.0f s" % (n_cases, engaged, len(fails), time.time() - t0))
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    json.dump(fails, open(os.path.join(ROOT, "gpurun_out", "gpu_fuzz_sym_failures.json"), "w"), indent=1)
+    sys.exit(1 if fails else 0)
+
+
+if __name__ == "__main__":
+    main()
