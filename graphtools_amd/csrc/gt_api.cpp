@@ -284,6 +284,18 @@ int gt_set_option(gt_ctx* ctx, const char* name, const char* value) {
         ctx->symm_fused = std::atoi(value) != 0 ? 1 : 0;
         return GT_OK;
     }
+    if (k == "rerank_waves_per_block") {
+        const int v = std::atoi(value);
+        if (v != 1 && v != 4) GT_FAIL(ctx, GT_E_ARG, "rerank_waves_per_block must be 1 or 4");
+        ctx->rerank_wpb = v;
+        return GT_OK;
+    }
+    if (k == "row_waves_per_block") {
+        const int v = std::atoi(value);
+        if (v != 1 && v != 4) GT_FAIL(ctx, GT_E_ARG, "row_waves_per_block must be 1 or 4");
+        ctx->row_wpb = v;
+        return GT_OK;
+    }
     if (k == "distance_dtype") {
         const std::string v = value;
         if (v != "data" && v != "float64") GT_FAIL(ctx, GT_E_ARG, "distance_dtype must be 'data' or 'float64'");

@@ -167,6 +167,8 @@ struct gt_ctx {
     // row-sharded builds with knn_max: the counts of the reference's search-expansion loop travel through the host
     int32_t stage_counts_only = 0, stage_totals_valid = 0, stage_n = 0;
     int64_t stage_local[4] = {0, 0, 0, 0}, stage_totals[4] = {0, 0, 0, 0};
+    int32_t rerank_wpb = 1;     //   rows (waves) per workgroup of the four-lanes-per-candidate re-rank (1 or 4; option "rerank_waves_per_block")
+    int32_t row_wpb = 1;        //   rows (waves) per workgroup of the wave-per-row kernels of the tail (affinities, final merge; option "row_waves_per_block")
     int32_t dist_f64 = 0;       //   distances from the float64 keys in float64 whatever the points' dtype (option "distance_dtype")
     int32_t in_graph_build = 0; //   (set by gt_graph_build around its gt_graph_begin: every row is here, the tail is its own)
     int32_t symm_pairs = 1;     //   pair-resolved symmetrisation (gt_sparse.hip): every row settles its mutual pairs itself, only one-sided entries travel

@@ -406,8 +406,8 @@ __global__ __launch_bounds__(256, 5) void rerank_sym_kernel(
 // DB = blocks of 64 features (d <= 64 DB).  Measured: 5.5 -> 5.2 ms at d = 64, 1.07 -> 0.90 ms at d = 36 (N = 3e5); with two
 // blocks (d = 100) the registers of the wider query share cost more than the coalescing returns (4.3 -> 6.1 ms): the
 // launcher keeps the lane-per-row kernel there.
-template <int DB, bool WT>   // WT: the transposed keys travel with the table (cand_d2t, keyt_ok)
-__global__ __launch_bounds__(256, WT ? 3 : 4) void rerank_sym4_kernel(
+template <int DB, bool WT, int WPB>   // WT: the transposed keys travel with the table (cand_d2t, keyt_ok); WPB: waves (rows) per workgroup
+__global__ __launch_bounds__(64 * WPB, WT ? 3 : 4) void rerank_sym4_kernel(
     const float* __restrict__ X, const int d, const double* __restrict__ xn, const int64_t nq,
     const uint64_t* __restrict__ tlists, const int tcap, const uint32_t* __restrict__ tcounts,
     const float* __restrict__ thr, const double* __restrict__ ymax2p, const ErrModel err, const int need_m,
@@ -424,9 +424,9 @@ __global__ __launch_bounds__(256, WT ? 3 : 4) void rerank_sym4_kernel(
     // when the row's table came from here with them
     constexpr int MP = 256;
     constexpr int NI = 4 * DB;   // 64-byte sectors of a row this kernel can hold
-    __shared__ uint64_t park_hi_all[4 * MP];   // (the sorted tables are picked up by position through the LDS)
-    __shared__ uint32_t park_lo_all[4 * MP];
-    __shared__ uint64_t park_x_all[4 * MP];
+    __shared__ uint64_t park_hi_all[WPB * MP];   // (the sorted tables are picked up by position through the LDS)
+    __shared__ uint32_t park_lo_all[WPB * MP];
+    __shared__ uint64_t park_x_all[WT ? WPB * MP : 1];
     const int lane = threadIdx.x & 63;
     const int w = threadIdx.x >> 6;
     const int c = lane & 3, r = lane >> 2;
@@ -434,8 +434,8 @@ __global__ __launch_bounds__(256, WT ? 3 : 4) void rerank_sym4_kernel(
     uint32_t* park_lo = park_lo_all + w * MP;
     uint64_t* park_x = park_x_all + w * MP;
     constexpr bool want_t = WT;
-    const int64_t bid = gt_xcd_item(blockIdx.x, gridDim.x, xcd_chunk);
-    const int64_t ql = bid * 4 + w;
+    const int64_t bid = gt_xcd_item(blockIdx.x, gridDim.x, xcd_chunk * (4 / WPB));
+    const int64_t ql = bid * WPB + w;
     if (ql >= nq) return;
     const int64_t qo = invperm ? int64_t(own_rows[ql]) : int64_t(perm[ql]);   // row of the bound points
     const int64_t q = invperm ? qo - own_r0 : qo;                             // row of the tables
@@ -986,8 +986,8 @@ int gt_launch_rerank_sym(gt_ctx* ctx, const RerankArgs& a, const SymRerank& sr) 
                        a.cand_d2, a.cand_j, a.cand_n, a.d2_lb, a.fb_count, a.fb_rows, a.gflags, a.radius_key_factor,      \
                        a.unproven, sr.stat, (ctx->dbg_select & 256) ? 1 : 0, sr.invperm, sr.own_rows, sr.own_r0, ctx->xcd_chunk,      \
                        (const T_*)sr.Xs, sr.xns, a.metric)
-#define GT_RERANK_SYM4_LAUNCH(DB_, WT_)                                                                                   \
-    hipLaunchKernelGGL((rerank_sym4_kernel<DB_, WT_>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (const float*)a.X, a.d, \
+#define GT_RERANK_SYM4_LAUNCH(DB_, WT_, WPB_)                                                                             \
+    hipLaunchKernelGGL((rerank_sym4_kernel<DB_, WT_, WPB_>), dim3((unsigned)ceil_div64(a.nq, WPB_)), dim3(64 * WPB_), 0, ctx->stream, (const float*)a.X, a.d, \
                        a.xn, a.nq, sr.tlists, sr.tcap, sr.tcounts, a.thr_final, a.ymax2, a.err, a.need_m, sr.perm,        \
                        a.cand_d2, a.cand_j, a.cand_n, a.d2_lb, a.fb_count, a.fb_rows, a.gflags, a.radius_key_factor,      \
                        a.unproven, sr.stat, (ctx->dbg_select & 256) ? 1 : 0, sr.invperm, sr.own_rows, sr.own_r0, ctx->xcd_chunk,      \
@@ -997,8 +997,13 @@ int gt_launch_rerank_sym(gt_ctx* ctx, const RerankArgs& a, const SymRerank& sr) 
         const bool f4 = (a.d & 3) == 0 && (reinterpret_cast<uintptr_t>(a.X) & 15) == 0;
         if (f4 && ctx->rerank_lanes4 != 0 && a.d <= 64 && sr.Xs != nullptr) {
             const bool wt = sr.cand_d2t != nullptr && sr.keyt_ok != nullptr && sr.nokeyt_rows != nullptr && sr.nokeyt_count != nullptr;
-            if (wt) GT_RERANK_SYM4_LAUNCH(1, true);
-            else GT_RERANK_SYM4_LAUNCH(1, false);
+            // one wave per workgroup: a row with more than 128 candidates costs twice a short one, and a workgroup's slots
+            // are only handed on when its last wave is done (option "rerank_waves_per_block" = 4: the old grouping)
+            const bool one = ctx->rerank_wpb != 4;
+            if (wt && one) GT_RERANK_SYM4_LAUNCH(1, true, 1);
+            else if (wt) GT_RERANK_SYM4_LAUNCH(1, true, 4);
+            else if (one) GT_RERANK_SYM4_LAUNCH(1, false, 1);
+            else GT_RERANK_SYM4_LAUNCH(1, false, 4);
             if (sr.wrote_t) *sr.wrote_t = wt;
         }
         else if (f4) GT_RERANK_SYM_LAUNCH(float, true);

@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void affinity_kernel(
     const int lane = threadIdx.x & 63;
     const int w = threadIdx.x >> 6;
     double* xs = reinterpret_cast<double*>(smem_raw) + size_t(w) * d;
-    const int64_t wi = int64_t(blockIdx.x) * 4 + w;
+    const int64_t wi = int64_t(blockIdx.x) * (blockDim.x >> 6) + w;
     if (wi >= nrows) return;
     const int idecay = gt_whole_decay(decay);
     const int64_t i = row_list ? int64_t(row_list[wi]) - qoff : wi;   // (a list holds rows of the query matrix: qoff + i)
@@ -1333,7 +1333,7 @@ __global__ __launch_bounds__(256) void merge_final_kernel(const int64_t nloc, co
                                                           double* __restrict__ Pdata, double* __restrict__ degree,
                                                           uint32_t* __restrict__ flags, const int key32) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int64_t i = int64_t(blockIdx.x) * 4 + w;
+    const int64_t i = int64_t(blockIdx.x) * (blockDim.x >> 6) + w;
     if (i >= nloc) return;
     const int64_t p = fs.pos[i];
     int lt;
@@ -1481,9 +1481,11 @@ Splits make_splits(const GraphState* g) {
 
 template <typename T>
 void launch_affinity(gt_ctx* ctx, GraphState* g, KnnWork* k, int binary, double decay, double thresh, int count_owners) {
-    const size_t lds = size_t(4) * ctx->d * sizeof(double);
+    // (rows per workgroup: a workgroup's wave slots are handed on when its LAST wave is done, and the rows' costs differ)
+    const int wpb = ctx->row_wpb == 4 ? 4 : 1;
+    const size_t lds = size_t(wpb) * ctx->d * sizeof(double);
 #define GT_AFFINITY_LAUNCH(RADIUS_, PAIRS_, LIST_, NROWS_)                                                                  \
-    hipLaunchKernelGGL((affinity_kernel<T, RADIUS_, PAIRS_>), dim3((unsigned)ceil_div64(NROWS_, 4)), dim3(256), lds, ctx->stream, \
+    hipLaunchKernelGGL((affinity_kernel<T, RADIUS_, PAIRS_>), dim3((unsigned)ceil_div64(NROWS_, wpb)), dim3(64 * wpb), lds, ctx->stream, \
                        LIST_, int64_t(NROWS_), g->nloc, g->r0, (const T*)ctx->X, ctx->d, ctx->xn.as<double>(),              \
                        (const T*)g->Qmat, g->qnorm, g->qoff, gt_dist_dtype(ctx), ctx->metric, k->MP, g->limit,            \
                        k->cand_d2.as<double>(), k->cand_j.as<uint32_t>(), k->cand_n.as<uint32_t>(), g->rowsrc.as<int32_t>(), \
@@ -2343,7 +2345,7 @@ static int graph_finish_pairs(gt_ctx* ctx, int64_t* out_nnz, uint32_t* flags) {
                            g->flags.as<uint32_t>(), g->bigrows.as<int32_t>(), g->bigcount.as<uint32_t>());
         GT_HIP(ctx, hipGetLastError());
         GT_HIP(ctx, hipEventRecord(ctx->side_event, ctx->side_stream));
-        hipLaunchKernelGGL(merge_final_kernel, dim3((unsigned)ceil_div64(nloc, 4)), dim3(256), 0, ctx->stream, nloc, fs,
+        hipLaunchKernelGGL(merge_final_kernel, dim3((unsigned)ceil_div64(nloc, ctx->row_wpb == 4 ? 4 : 1)), dim3(ctx->row_wpb == 4 ? 256 : 64), 0, ctx->stream, nloc, fs,
                            g->indptr.as<int64_t>(), g->indices.as<int32_t>(), g->Kdata.as<double>(), g->Pdata.as<double>(),
                            g->degree.as<double>(), g->flags.as<uint32_t>(),
                            (ctx->symm_key32 != 0 && sort_key_fits_u32(g->n_total, 8)) ? 1 : 0);
@@ -2442,7 +2444,7 @@ static int graph_finish_fused(gt_ctx* ctx, int64_t* out_nnz, uint32_t* flags) {
                        g->outlen.as<int32_t>(), g->bigrows.as<int32_t>(), g->bigcount.as<uint32_t>(), fflags);
     GT_HIP(ctx, hipGetLastError());
     GT_TRY(exclusive_scan(ctx, g->outlen.as<int32_t>(), nullptr, nloc, g->indptr.as<int64_t>(), g->scan_tmp));
-    hipLaunchKernelGGL(merge_final_kernel, dim3((unsigned)ceil_div64(nloc, 4)), dim3(256), 0, ctx->stream, nloc, fs,
+    hipLaunchKernelGGL(merge_final_kernel, dim3((unsigned)ceil_div64(nloc, ctx->row_wpb == 4 ? 4 : 1)), dim3(ctx->row_wpb == 4 ? 256 : 64), 0, ctx->stream, nloc, fs,
                        g->indptr.as<int64_t>(), g->indices.as<int32_t>(), g->Kdata.as<double>(), g->Pdata.as<double>(),
                        g->degree.as<double>(), g->flags.as<uint32_t>(),
                        (ctx->symm_key32 != 0 && sort_key_fits_u32(g->n_total, 8)) ? 1 : 0);
