@@ -1350,7 +1350,7 @@ __global__ __launch_bounds__(256, 3) void sym_cold_kernel(const float* __restric
     using C = SelCfg<DP, 2>;
     constexpr int QT = 2;
     const int lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
-    const int64_t en0 = (int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6)) * GT_SEL_COLD_EPW;
+    const int64_t en0 = (int64_t(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6)) * GT_SEL_COLD_EPW;
     if (en0 >= int64_t(sy.qn)) return;
     const int w = 0;
     constexpr int BQ = 128 * GT_SEL_TWO_QT, TPB = BQ / C::BN;   // query blocks of the collect launch
@@ -1428,7 +1428,9 @@ int launch_sym_cold(gt_ctx* ctx, const SelectArgs& a) {
     if (a.sym.qn <= 0) return GT_OK;
     if (!a.sym.queue || !a.sym.g || !a.sym.tlists || !a.sym.tcounts || a.sym.tcap <= 0)
         GT_FAIL(ctx, GT_E_ARG, "knn_select: the cold pass needs the queue and the lists of the collect launch");
-    hipLaunchKernelGGL(sym_cold_kernel<DP>, dim3((unsigned)ceil_div64(a.sym.qn, 4 * GT_SEL_COLD_EPW)), dim3(256), 0, ctx->stream, a.Yp, a.hneg,
+    // (independent waves: one per workgroup, so that a wave with much to file does not hold three idle slots)
+    const int wpb = ctx->row_wpb == 4 ? 4 : 1;
+    hipLaunchKernelGGL(sym_cold_kernel<DP>, dim3((unsigned)ceil_div64(a.sym.qn, wpb * GT_SEL_COLD_EPW)), dim3(64 * wpb), 0, ctx->stream, a.Yp, a.hneg,
                        a.thr_in, a.nq, int(a.n_pad / SelCfg<DP, 2>::BN), a.sym);
     GT_HIP(ctx, hipGetLastError());
     return GT_OK;

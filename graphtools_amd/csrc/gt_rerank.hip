@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void rerank_kernel(const T* __restrict__ X, co
     // those rows in its own L2.
     const int64_t nb = gridDim.x, xcd = blockIdx.x & 7, base = nb >> 3, rem = nb & 7;
     const int64_t bid = xcd * base + (xcd < rem ? xcd : rem) + (blockIdx.x >> 3);
-    const int64_t ql = bid * 4 + w;   // list index: the order the candidate pass dealt the queries in
+    const int64_t ql = bid * (blockDim.x >> 6) + w;   // list index: the order the candidate pass dealt the queries in
     if (ql >= nq) return;   // whole wave exits together (ql is wave-uniform); no block-level sync below
     const int64_t q = qrows ? int64_t(qrows[ql]) - q0 : ql;   // row of the tables (rows [q0, q0 + nq) in their own order)
 
@@ -252,8 +252,8 @@ __global__ __launch_bounds__(256, 5) void rerank_sym_kernel(
     const int lane = threadIdx.x & 63;
     const int w = threadIdx.x >> 6;
     double* xs = reinterpret_cast<double*>(smem_raw) + size_t(w) * d;
-    const int64_t bid = gt_xcd_item(blockIdx.x, gridDim.x, xcd_chunk);
-    const int64_t ql = bid * 4 + w;
+    const int64_t bid = gt_xcd_item(blockIdx.x, gridDim.x, xcd_chunk * (4 / int(blockDim.x >> 6)));
+    const int64_t ql = bid * (blockDim.x >> 6) + w;
     if (ql >= nq) return;
     // single rank: list ql = sorted position ql, tables indexed by the row perm[ql].  Row-sharded (invperm given): the
     // ql-th owned row in the sorted order is own_rows[ql] (neighbouring waves then evaluate overlapping candidate rows),
@@ -862,30 +862,31 @@ __global__ __launch_bounds__(256) void emit_knn_kernel(const double* __restrict_
 
 template <typename T>
 int rerank_t(gt_ctx* ctx, const RerankArgs& a) {
-    const int64_t blocks = ceil_div64(a.nq, 4);
-    const size_t lds = size_t(4) * a.d * sizeof(double);
+    const int wpb = ctx->rerank_wpb != 4 ? 1 : 4;   // rows (waves) per workgroup: see gt_launch_rerank_sym
+    const int64_t blocks = ceil_div64(a.nq, wpb);
+    const size_t lds = size_t(wpb) * a.d * sizeof(double);
     const bool f4 = sizeof(T) == 4 && (a.d & 3) == 0 && (reinterpret_cast<uintptr_t>(a.X) & 15) == 0;
     if (a.MP == 128) {
-        if (f4) { hipLaunchKernelGGL((rerank_kernel<T, 2, true>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, (const T*)a.X,
+        if (f4) { hipLaunchKernelGGL((rerank_kernel<T, 2, true>), dim3((unsigned)blocks), dim3(64 * wpb), lds, ctx->stream, (const T*)a.X,
                            a.d, a.xn, (const T*)a.Q, a.qn, a.qn_sel, a.q0, a.nq, a.lists, a.lstride, a.counts, a.thr_final, a.ymax2,
                            a.err, a.metric, a.need_m, a.cand_d2, a.cand_j, a.cand_n, a.d2_lb, a.fb_count, a.fb_rows,
-                           a.gflags, a.radius_key_factor, a.unproven, a.qrows); } else { hipLaunchKernelGGL((rerank_kernel<T, 2, false>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, (const T*)a.X,
+                           a.gflags, a.radius_key_factor, a.unproven, a.qrows); } else { hipLaunchKernelGGL((rerank_kernel<T, 2, false>), dim3((unsigned)blocks), dim3(64 * wpb), lds, ctx->stream, (const T*)a.X,
                            a.d, a.xn, (const T*)a.Q, a.qn, a.qn_sel, a.q0, a.nq, a.lists, a.lstride, a.counts, a.thr_final, a.ymax2,
                            a.err, a.metric, a.need_m, a.cand_d2, a.cand_j, a.cand_n, a.d2_lb, a.fb_count, a.fb_rows,
                            a.gflags, a.radius_key_factor, a.unproven, a.qrows); }
     } else if (a.MP == 256) {
-        if (f4) { hipLaunchKernelGGL((rerank_kernel<T, 4, true>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, (const T*)a.X,
+        if (f4) { hipLaunchKernelGGL((rerank_kernel<T, 4, true>), dim3((unsigned)blocks), dim3(64 * wpb), lds, ctx->stream, (const T*)a.X,
                            a.d, a.xn, (const T*)a.Q, a.qn, a.qn_sel, a.q0, a.nq, a.lists, a.lstride, a.counts, a.thr_final, a.ymax2,
                            a.err, a.metric, a.need_m, a.cand_d2, a.cand_j, a.cand_n, a.d2_lb, a.fb_count, a.fb_rows,
-                           a.gflags, a.radius_key_factor, a.unproven, a.qrows); } else { hipLaunchKernelGGL((rerank_kernel<T, 4, false>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, (const T*)a.X,
+                           a.gflags, a.radius_key_factor, a.unproven, a.qrows); } else { hipLaunchKernelGGL((rerank_kernel<T, 4, false>), dim3((unsigned)blocks), dim3(64 * wpb), lds, ctx->stream, (const T*)a.X,
                            a.d, a.xn, (const T*)a.Q, a.qn, a.qn_sel, a.q0, a.nq, a.lists, a.lstride, a.counts, a.thr_final, a.ymax2,
                            a.err, a.metric, a.need_m, a.cand_d2, a.cand_j, a.cand_n, a.d2_lb, a.fb_count, a.fb_rows,
                            a.gflags, a.radius_key_factor, a.unproven, a.qrows); }
     } else if (a.MP == 512) {
-        if (f4) { hipLaunchKernelGGL((rerank_kernel<T, 8, true>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, (const T*)a.X,
+        if (f4) { hipLaunchKernelGGL((rerank_kernel<T, 8, true>), dim3((unsigned)blocks), dim3(64 * wpb), lds, ctx->stream, (const T*)a.X,
                            a.d, a.xn, (const T*)a.Q, a.qn, a.qn_sel, a.q0, a.nq, a.lists, a.lstride, a.counts, a.thr_final, a.ymax2,
                            a.err, a.metric, a.need_m, a.cand_d2, a.cand_j, a.cand_n, a.d2_lb, a.fb_count, a.fb_rows,
-                           a.gflags, a.radius_key_factor, a.unproven, a.qrows); } else { hipLaunchKernelGGL((rerank_kernel<T, 8, false>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, (const T*)a.X,
+                           a.gflags, a.radius_key_factor, a.unproven, a.qrows); } else { hipLaunchKernelGGL((rerank_kernel<T, 8, false>), dim3((unsigned)blocks), dim3(64 * wpb), lds, ctx->stream, (const T*)a.X,
                            a.d, a.xn, (const T*)a.Q, a.qn, a.qn_sel, a.q0, a.nq, a.lists, a.lstride, a.counts, a.thr_final, a.ymax2,
                            a.err, a.metric, a.need_m, a.cand_d2, a.cand_j, a.cand_n, a.d2_lb, a.fb_count, a.fb_rows,
                            a.gflags, a.radius_key_factor, a.unproven, a.qrows); }
@@ -977,11 +978,12 @@ int gt_launch_collected_select(gt_ctx* ctx, const RerankArgs& a, int64_t n_rows,
 }
 
 int gt_launch_rerank_sym(gt_ctx* ctx, const RerankArgs& a, const SymRerank& sr) {
-    const int64_t blocks = ceil_div64(a.nq, 4);
-    const size_t lds = size_t(4) * a.d * sizeof(double);
+    const int wpb = 4;   // (the lane-per-row kernel: measured 3.56 ms with four rows per workgroup, 3.79 with one - N = 3e5, d = 100)
+    const int64_t blocks = ceil_div64(a.nq, wpb);
+    const size_t lds = size_t(wpb) * a.d * sizeof(double);
     if (a.MP != 256) GT_FAIL(ctx, GT_E_ARG, "rerank_sym: table width 256");
 #define GT_RERANK_SYM_LAUNCH(T_, F4_)                                                                                     \
-    hipLaunchKernelGGL((rerank_sym_kernel<T_, F4_>), dim3((unsigned)blocks), dim3(256), lds, ctx->stream, (const T_*)a.X, a.d,  \
+    hipLaunchKernelGGL((rerank_sym_kernel<T_, F4_>), dim3((unsigned)blocks), dim3(64 * wpb), lds, ctx->stream, (const T_*)a.X, a.d,  \
                        a.xn, a.nq, sr.tlists, sr.tcap, sr.tcounts, a.thr_final, a.ymax2, a.err, a.need_m, sr.perm,        \
                        a.cand_d2, a.cand_j, a.cand_n, a.d2_lb, a.fb_count, a.fb_rows, a.gflags, a.radius_key_factor,      \
                        a.unproven, sr.stat, (ctx->dbg_select & 256) ? 1 : 0, sr.invperm, sr.own_rows, sr.own_r0, ctx->xcd_chunk,      \
