@@ -932,7 +932,7 @@ __global__ __launch_bounds__(256) void sort_merge_kernel(const int64_t nloc, con
                                                          const int key32) {
     const int lane = threadIdx.x & 63;
     const int w = threadIdx.x >> 6;
-    const int64_t i = int64_t(blockIdx.x) * 4 + w;
+    const int64_t i = int64_t(blockIdx.x) * (blockDim.x >> 6) + w;
     if (i >= nloc) return;
     const int64_t o0 = off[i];
     const int64_t L64 = off[i + 1] - o0;
@@ -1089,7 +1089,7 @@ __global__ __launch_bounds__(256) void compact_kernel(const int64_t nloc, const 
     // arithmetic, same summation order
     const int lane = threadIdx.x & 63;
     const int w = threadIdx.x >> 6;
-    const int64_t p = int64_t(blockIdx.x) * 4 + w;
+    const int64_t p = int64_t(blockIdx.x) * (blockDim.x >> 6) + w;
     if (p >= nloc) return;
     const int64_t i = perm ? int64_t(perm[p]) : p;
     const int64_t s = off[p];
@@ -1198,7 +1198,7 @@ __global__ __launch_bounds__(256) void pair_count_kernel(const int64_t nloc, con
                                                          uint32_t* __restrict__ fflags) {
     __shared__ uint32_t oc_s[4][kPairChunk];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int64_t i = int64_t(blockIdx.x) * 4 + w;
+    const int64_t i = int64_t(blockIdx.x) * (blockDim.x >> 6) + w;
     if (i >= nloc) return;   // (wave-uniform)
     const int64_t p = fs.pos[i];
     int lt;
@@ -2095,7 +2095,7 @@ static int graph_finish_impl(gt_ctx* ctx, const void* recv_buf_dev, int64_t n_re
         us.rcap = g->rcap;
         {
             StageSpan span_m(ctx, "symm_merge");   // (nested in "symmetrize")
-            hipLaunchKernelGGL(sort_merge_kernel, dim3((unsigned)ceil_div64(nloc, 4)), dim3(256), 0, ctx->stream, nloc,
+            hipLaunchKernelGGL(sort_merge_kernel, dim3((unsigned)ceil_div64(nloc, ctx->row_wpb == 4 ? 4 : 1)), dim3(ctx->row_wpb == 4 ? 256 : 64), 0, ctx->stream, nloc,
                                g->off.as<int64_t>(), us, g->p.kernel_symm, g->p.theta,
                                g->Vkey.as<uint32_t>(), g->Vval.as<double>(), g->outlen.as<int32_t>(), g->bigrows.as<int32_t>(),
                                g->bigcount.as<uint32_t>(), (ctx->symm_key32 != 0 && sort_key_fits_u32(g->n_total, 8)) ? 1 : 0);
@@ -2183,7 +2183,7 @@ static int graph_finish_impl(gt_ctx* ctx, const void* recv_buf_dev, int64_t n_re
         GT_HIP(ctx, g->degree.reserve(size_t(nloc) * sizeof(double)));
         {
             StageSpan span_c(ctx, "symm_compact");   // (nested in "symmetrize")
-            hipLaunchKernelGGL(compact_kernel, dim3((unsigned)ceil_div64(nloc, 4)), dim3(256), 0, ctx->stream, nloc, g->r0,
+            hipLaunchKernelGGL(compact_kernel, dim3((unsigned)ceil_div64(nloc, ctx->row_wpb == 4 ? 4 : 1)), dim3(ctx->row_wpb == 4 ? 256 : 64), 0, ctx->stream, nloc, g->r0,
                                g->off.as<int64_t>(), g->outlen.as<int32_t>(), g->indptr.as<int64_t>(), g->Vkey.as<uint32_t>(),
                                g->Vval.as<double>(), g->indices.as<int32_t>(), g->Kdata.as<double>(), g->degree.as<double>(),
                                g->flags.as<uint32_t>(), perm, g->p.anisotropy == 0.0 ? g->Pdata.as<double>() : nullptr);
@@ -2440,7 +2440,7 @@ static int graph_finish_fused(gt_ctx* ctx, int64_t* out_nnz, uint32_t* flags) {
     fs.rcap = g->rcap;
     fs.ucol = g->ucol.as<uint32_t>();
     fs.uval = g->uval.as<double>();
-    hipLaunchKernelGGL(pair_count_kernel, dim3((unsigned)ceil_div64(nloc, 4)), dim3(256), 0, ctx->stream, nloc, fs,
+    hipLaunchKernelGGL(pair_count_kernel, dim3((unsigned)ceil_div64(nloc, ctx->row_wpb == 4 ? 4 : 1)), dim3(ctx->row_wpb == 4 ? 256 : 64), 0, ctx->stream, nloc, fs,
                        g->outlen.as<int32_t>(), g->bigrows.as<int32_t>(), g->bigcount.as<uint32_t>(), fflags);
     GT_HIP(ctx, hipGetLastError());
     GT_TRY(exclusive_scan(ctx, g->outlen.as<int32_t>(), nullptr, nloc, g->indptr.as<int64_t>(), g->scan_tmp));
