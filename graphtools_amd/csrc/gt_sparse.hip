@@ -2310,8 +2310,14 @@ static int graph_finish_pairs(gt_ctx* ctx, int64_t* out_nnz, uint32_t* flags) {
             if (ol[i] < 0) ++neg;
             if (oh[i + 1] < oh[i]) ++nonmono;
         }
-        std::fprintf(stderr, "[gt] pair-resolved tail: flags %u, nnz %lld, own entries %lld; longest row %lld (row %lld), negative %lld, off not monotone at %lld places, off[n] %lld\n",
-                     ff, (long long)nnz, (long long)n_own, (long long)mx, (long long)arg, (long long)neg, (long long)nonmono, (long long)oh[nloc]);
+        uint32_t nbig = 0;
+        (void)hipMemcpy(&nbig, g->bigcount.p, sizeof(uint32_t), hipMemcpyDeviceToHost);
+        int64_t hist[6] = {0, 0, 0, 0, 0, 0};   // rows of up to 64, 128, 256, 512, 1024, more entries
+        for (int64_t i = 0; i < nloc; ++i) ++hist[ol[i] <= 64 ? 0 : ol[i] <= 128 ? 1 : ol[i] <= 256 ? 2 : ol[i] <= 512 ? 3 : ol[i] <= 1024 ? 4 : 5];
+        std::fprintf(stderr, "[gt] pair-resolved tail: flags %u, nnz %lld, own entries %lld; longest row %lld (row %lld), negative %lld, off not monotone at %lld places, off[n] %lld; "
+                     "%u rows for the long-row kernel; rows by length <=64 %lld, <=128 %lld, <=256 %lld, <=512 %lld, <=1024 %lld, more %lld\n",
+                     ff, (long long)nnz, (long long)n_own, (long long)mx, (long long)arg, (long long)neg, (long long)nonmono, (long long)oh[nloc], nbig,
+                     (long long)hist[0], (long long)hist[1], (long long)hist[2], (long long)hist[3], (long long)hist[4], (long long)hist[5]);
     }
     if (ff != 0) return 0;
     GT_HIP(ctx, g->indices.reserve(size_t(nnz) * sizeof(int32_t)));
