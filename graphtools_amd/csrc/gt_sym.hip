@@ -857,10 +857,12 @@ __global__ __launch_bounds__(256) void cell_ball_kernel(const _Float16* __restri
                                                         const int32_t* __restrict__ start, const int32_t* __restrict__ endp,
                                                         float* __restrict__ centre, float* __restrict__ radius,
                                                         float* __restrict__ need) {
-    __shared__ float part[4][128];
+    // DP / 8 threads per row, each with one 16-byte load of its eight columns (DP <= 128: at least 16 rows per step)
+    __shared__ __attribute__((aligned(16))) float part[32][129];   // per row slot: partial column sums, then partial squared distances
     __shared__ float cs[128];
     __shared__ double red[4];
     __shared__ float redn[4];
+    typedef _Float16 half8 __attribute__((ext_vector_type(8)));
     const int c = blockIdx.x;
     const int s0 = start[c], s1 = endp[c];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -872,38 +874,70 @@ __global__ __launch_bounds__(256) void cell_ball_kernel(const _Float16* __restri
         }
         return;
     }
-    // wave w takes the rows w, w + 4, ...; lane l the columns l and l + 64
-    float a0 = 0.f, a1 = 0.f;
-    for (int p = s0 + w; p < s1; p += 4) {
-        if (lane < DP) a0 += float(Ys[size_t(p) * DP + lane]);
-        if (lane + 64 < DP) a1 += float(Ys[size_t(p) * DP + lane + 64]);
+    const int tpr = DP / 8;                 // threads per row
+    const int rps = 256 / tpr < 32 ? 256 / tpr : 32;   // rows per step
+    const int slot = int(threadIdx.x) / tpr, t = int(threadIdx.x) % tpr;
+    const bool on = slot < rps;
+    // centre: column sums, slot by slot, then across the slots
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (on)
+        for (int p = s0 + slot; p < s1; p += rps) {
+            const half8 v = *reinterpret_cast<const half8*>(Ys + size_t(p) * DP + 8 * t);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a[e] += float(v[e]);
+        }
+    if (on) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) part[slot][8 * t + e] = a[e];
     }
-    part[w][lane] = a0;
-    part[w][lane + 64] = a1;
     __syncthreads();
-    if (threadIdx.x < 128) {
-        const float t = (part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]) / float(s1 - s0);
-        cs[threadIdx.x] = t;
-        if (threadIdx.x < DP) centre[size_t(c) * DP + threadIdx.x] = t;
+    if (int(threadIdx.x) < DP) {
+        float sum = 0.f;
+        for (int q = 0; q < rps; ++q) sum += part[q][threadIdx.x];
+        const float m = sum / float(s1 - s0);
+        cs[threadIdx.x] = m;
+        centre[size_t(c) * DP + threadIdx.x] = m;
     }
     __syncthreads();
-    // radius: one thread per row (16-byte loads of its 2 DP bytes, the centre from the LDS), float64 sums
+    // radius: float64 squared distance of every row to the stored centre (thread t of the row's group: its eight columns)
     double rmax = 0.0;
     float nmax = -INFINITY;
-    typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-    for (int p = s0 + int(threadIdx.x); p < s1; p += 256) {
-        const half8* row = reinterpret_cast<const half8*>(Ys + size_t(p) * DP);
+    double cd[8];
+    if (on) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) cd[e] = double(cs[8 * t + e]);
+    }
+    for (int p0 = s0; p0 < s1; p0 += rps) {   // (uniform trip count: the group's partial sums meet in the LDS)
+        const int p = p0 + slot;
         double d2 = 0.0;
-        for (int q8 = 0; q8 < DP / 8; ++q8) {
-            const half8 v = row[q8];
+        if (on && p < s1) {
+            const half8 v = *reinterpret_cast<const half8*>(Ys + size_t(p) * DP + 8 * t);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const double df = double(float(v[e])) - double(cs[8 * q8 + e]);
+                const double df = double(float(v[e])) - cd[e];
                 d2 = fma(df, df, d2);
             }
         }
-        rmax = fmax(rmax, sqrt(d2));
-        nmax = fmaxf(nmax, rrow[p]);
+        // the tpr partial sums of a row sit in consecutive lanes of one wave (tpr divides 64 for DP = 32, 64, 128) or are
+        // summed through the LDS otherwise
+        if ((64 % tpr) == 0) {
+            for (int o = 1; o < tpr; o <<= 1) d2 += __shfl_xor(d2, o);
+            if (on && p < s1 && t == 0) {
+                rmax = fmax(rmax, sqrt(d2));
+                nmax = fmaxf(nmax, rrow[p]);
+            }
+        } else {
+            __syncthreads();
+            double* pd = reinterpret_cast<double*>(&part[0][0]);   // [rps][tpr] doubles: 32 x 16 x 8 B <= the array
+            if (on) pd[slot * tpr + t] = d2;
+            __syncthreads();
+            if (on && p < s1 && t == 0) {
+                double tot = 0.0;
+                for (int q = 0; q < tpr; ++q) tot += pd[slot * tpr + q];
+                rmax = fmax(rmax, sqrt(tot));
+                nmax = fmaxf(nmax, rrow[p]);
+            }
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
