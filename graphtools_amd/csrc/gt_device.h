@@ -1,6 +1,7 @@
 // Device-side helpers for gfx950 (wave64): order-preserving float keys, wave-level
 // bitonic sorting networks held in registers, wave reductions.
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -323,7 +324,12 @@ __device__ __forceinline__ void wave_bitonic_asc_pair(uint64_t (&hi)[NT], L (&lo
 // runs instead - so the outcome is always the one of wave_bitonic_asc_pair.  Entries (kInf, 0xFFFFFFFF) mean "none" and
 // sort last; lo must fit 32 bits.
 // x / lds_x (optional, with the LDS slots): a 64-bit payload per entry that follows its entry (NT values per lane).
-template <int NT, typename L>
+__device__ __forceinline__ float wave_max_f32(float v);
+// Q32: the composite keys of the network are 32 bits - the key as a 23 / 24-bit fixed-point fraction of the row's own key range
+// (float32 minimum and maximum of the wave, widened) above the position bits - instead of the key's own upper bits in 64: half
+// the instructions per exchange.  The mapping is monotone, so only entries that fall into the same step of the range (and
+// true ties) can come out in the wrong order: they are detected below and the row takes the exact pair network.
+template <int NT, typename L, bool Q32 = false>
 __device__ __forceinline__ void wave_sort_asc_pair_fast(uint64_t (&hi)[NT], L (&lo)[NT], const int lane,
                                                         uint64_t* lds_hi = nullptr, uint32_t* lds_lo = nullptr,
                                                         uint64_t* x = nullptr, uint64_t* lds_x = nullptr) {
@@ -331,20 +337,53 @@ __device__ __forceinline__ void wave_sort_asc_pair_fast(uint64_t (&hi)[NT], L (&
     constexpr int PB = NT == 1 ? 6 : NT == 2 ? 7 : NT == 4 ? 8 : 9;
     constexpr uint64_t PM = (1ull << PB) - 1ull;
     constexpr uint64_t kNoneHi = 0x7FF0000000000000ull;
-    uint64_t ck[NT];
+    using CK = typename std::conditional<Q32, uint32_t, uint64_t>::type;
+    CK ck[NT];
+    if constexpr (Q32) {
+        constexpr int QB = 32 - PB;   // bits of the fraction
+        float fmin_ = INFINITY, fmax_ = 0.f;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const bool none = hi[t] == kNoneHi && lo[t] == L(0xFFFFFFFFu);
-        ck[t] = none ? 0ull : ~((hi[t] & ~PM) | uint64_t(t * 64 + lane));   // descending complement = ascending key
+        for (int t = 0; t < NT; ++t) {
+            const bool none = hi[t] == kNoneHi && lo[t] == L(0xFFFFFFFFu);
+            const float f = float(__longlong_as_double((long long)hi[t]));   // (keys are non-negative)
+            if (!none) {
+                fmin_ = fminf(fmin_, f);
+                fmax_ = fmaxf(fmax_, f);
+            }
+        }
+        fmin_ = -wave_max_f32(-fmin_);
+        fmax_ = wave_max_f32(fmax_);
+        const double base = double(fmin_) * (1.0 - 0x1p-20);
+        const double top = double(fmax_) * (1.0 + 0x1p-20);
+        const double span = top - base;
+        const double scale = (span > 0.0 && span < INFINITY) ? double(1u << QB) / span : 0.0;
+        constexpr uint32_t qmax = (1u << QB) - 2u;   // (all ones with the last position is the complement of the "no entry" key)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const bool none = hi[t] == kNoneHi && lo[t] == L(0xFFFFFFFFu);
+            const double rel = (__longlong_as_double((long long)hi[t]) - base) * scale;
+            uint32_t q = rel > 0.0 ? (rel < double(qmax) ? uint32_t(rel) : qmax) : 0u;
+            ck[t] = none ? 0u : ~((q << PB) | uint32_t(t * 64 + lane));   // descending complement = ascending key
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const bool none = hi[t] == kNoneHi && lo[t] == L(0xFFFFFFFFu);
+            ck[t] = none ? 0ull : ~((hi[t] & ~PM) | uint64_t(t * 64 + lane));   // descending complement = ascending key
+        }
     }
     wave_bitonic_desc<NT>(ck, lane);
     bool clash = false;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        uint64_t nx = __shfl_down((unsigned long long)ck[t], 1);
-        const uint64_t edge = (t < NT - 1) ? __shfl((unsigned long long)ck[t < NT - 1 ? t + 1 : t], 0) : 0ull;
+        CK nx;
+        if constexpr (Q32) nx = __shfl_down(ck[t], 1);
+        else nx = __shfl_down((unsigned long long)ck[t], 1);
+        CK edge = 0;
+        if constexpr (Q32) edge = (t < NT - 1) ? __shfl(ck[t < NT - 1 ? t + 1 : t], 0) : 0u;
+        else edge = (t < NT - 1) ? __shfl((unsigned long long)ck[t < NT - 1 ? t + 1 : t], 0) : 0ull;
         if (lane == 63) nx = edge;
-        clash |= ck[t] != 0ull && nx != 0ull && ((~ck[t]) >> PB) == ((~nx) >> PB);
+        clash |= ck[t] != 0 && nx != 0 && (CK(~ck[t]) >> PB) == (CK(~nx) >> PB);
     }
     if (__ballot(clash) != 0ull) {   // wave-uniform, rare
         if (x) {
@@ -392,7 +431,7 @@ __device__ __forceinline__ void wave_sort_asc_pair_fast(uint64_t (&hi)[NT], L (&
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const uint32_t p = uint32_t(~ck[t]) & uint32_t(PM);
-            const bool some = ck[t] != 0ull;
+            const bool some = ck[t] != 0;
             nh[t] = some ? lds_hi[p] : kNoneHi;
             nl[t] = some ? lds_lo[p] : 0xFFFFFFFFu;
             if (x) x[t] = some ? lds_x[p] : 0ull;
@@ -410,7 +449,7 @@ __device__ __forceinline__ void wave_sort_asc_pair_fast(uint64_t (&hi)[NT], L (&
             for (int r = 0; r < NT; ++r) {
                 const uint64_t hr = __shfl((unsigned long long)hi[r], sl);
                 const uint32_t lr = __shfl(uint32_t(lo[r]), sl);
-                if (sr == r && ck[t] != 0ull) {
+                if (sr == r && ck[t] != 0) {
                     h = hr;
                     l = lr;
                 }

@@ -406,6 +406,12 @@ __global__ __launch_bounds__(256, 5) void rerank_sym_kernel(
 // DB = blocks of 64 features (d <= 64 DB).  Measured: 5.5 -> 5.2 ms at d = 64, 1.07 -> 0.90 ms at d = 36 (N = 3e5); with two
 // blocks (d = 100) the registers of the wider query share cost more than the coalescing returns (4.3 -> 6.1 ms): the
 // launcher keeps the lane-per-row kernel there.
+#ifndef GT_RERANK_EXP
+#define GT_RERANK_EXP 0   // development: 1 = tables left unsorted, 2 = one evaluation pass per batch (timing only, wrong results), 3 = tables sorted twice (same results: the sort's share of the time)
+#endif
+#ifndef GT_RERANK_Q32
+#define GT_RERANK_Q32 true   // 32-bit composite keys in the table sort (gt_device.h wave_sort_asc_pair_fast)
+#endif
 template <int DB, bool WT, int WPB>   // WT: the transposed keys travel with the table (cand_d2t, keyt_ok); WPB: waves (rows) per workgroup
 __global__ __launch_bounds__(64 * WPB, WT ? 3 : 4) void rerank_sym4_kernel(
     const float* __restrict__ X, const int d, const double* __restrict__ xn, const int64_t nq,
@@ -507,7 +513,7 @@ __global__ __launch_bounds__(64 * WPB, WT ? 3 : 4) void rerank_sym4_kernel(
         lA = lB = 0xFFFFFFFFu;
         xA = xB = 0ull;
 #pragma unroll 2
-        for (int p = 0; p < 8; ++p) {
+        for (int p = 0; p < (GT_RERANK_EXP == 2 ? 1 : 8); ++p) {
             const uint32_t pj = uint32_t(__shfl(int(p < 4 ? jA : jB), (p & 3) * 16 + r));   // position of the group's candidate
             double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;   // partial sums c, c + 4, c + 8, c + 12
             double yn = 0.0;
@@ -565,14 +571,24 @@ __global__ __launch_bounds__(64 * WPB, WT ? 3 : 4) void rerank_sym4_kernel(
         uint64_t h2[2] = {hi[0], hi[1]};
         uint32_t l2[2] = {lo[0], lo[1]};
         uint64_t x2[2] = {hx[0], hx[1]};
-        wave_sort_asc_pair_fast<2>(h2, l2, lane, park_hi, park_lo, want_t ? x2 : nullptr, park_x);
+#if GT_RERANK_EXP != 1
+        wave_sort_asc_pair_fast<2, uint32_t, GT_RERANK_Q32>(h2, l2, lane, park_hi, park_lo, want_t ? x2 : nullptr, park_x);
+#endif
+#if GT_RERANK_EXP == 3
+        wave_sort_asc_pair_fast<2, uint32_t, GT_RERANK_Q32>(h2, l2, lane, park_hi, park_lo, want_t ? x2 : nullptr, park_x);
+#endif
         hi[0] = h2[0]; hi[1] = h2[1];
         lo[0] = l2[0]; lo[1] = l2[1];
         hx[0] = x2[0]; hx[1] = x2[1];
     } else {
         eval128(pc[2], pc[3], hi[2], lo[2], hi[3], lo[3], hx[2], hx[3]);
         if (k257 != 0ull) lb = fmin(lb, bound_of_score(cand_score(k257)));   // candidates beyond the table
-        wave_sort_asc_pair_fast<4>(hi, lo, lane, park_hi, park_lo, want_t ? hx : nullptr, park_x);
+#if GT_RERANK_EXP != 1
+        wave_sort_asc_pair_fast<4, uint32_t, GT_RERANK_Q32>(hi, lo, lane, park_hi, park_lo, want_t ? hx : nullptr, park_x);
+#endif
+#if GT_RERANK_EXP == 3
+        wave_sort_asc_pair_fast<4, uint32_t, GT_RERANK_Q32>(hi, lo, lane, park_hi, park_lo, want_t ? hx : nullptr, park_x);
+#endif
     }
     const double lb_cand = lb;   // (what the candidate stages proved; the table may be cut shorter below)
     const uint32_t n_all = n_tab;
