@@ -409,6 +409,9 @@ __global__ __launch_bounds__(256, 5) void rerank_sym_kernel(
 #ifndef GT_RERANK_EXP
 #define GT_RERANK_EXP 0   // development: 1 = tables left unsorted, 2 = one evaluation pass per batch (timing only, wrong results), 3 = tables sorted twice (same results: the sort's share of the time)
 #endif
+#ifndef GT_RERANK_UNROLL
+#define GT_RERANK_UNROLL 2   // evaluation passes whose loads are issued together
+#endif
 #ifndef GT_RERANK_Q32
 #define GT_RERANK_Q32 true   // 32-bit composite keys in the table sort (gt_device.h wave_sort_asc_pair_fast)
 #endif
@@ -512,7 +515,7 @@ __global__ __launch_bounds__(64 * WPB, WT ? 3 : 4) void rerank_sym4_kernel(
         hA = hB = kInfBits;
         lA = lB = 0xFFFFFFFFu;
         xA = xB = 0ull;
-#pragma unroll 2
+#pragma unroll GT_RERANK_UNROLL
         for (int p = 0; p < (GT_RERANK_EXP == 2 ? 1 : 8); ++p) {
             const uint32_t pj = uint32_t(__shfl(int(p < 4 ? jA : jB), (p & 3) * 16 + r));   // position of the group's candidate
             double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;   // partial sums c, c + 4, c + 8, c + 12
