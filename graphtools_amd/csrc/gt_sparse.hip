@@ -2343,7 +2343,10 @@ static int graph_finish_pairs(gt_ctx* ctx, int64_t* out_nnz, uint32_t* flags) {
         // next to the merge of the others - the two launches write different rows; the main stream was drained by the
         // read-back above, and takes the side stream's completion back before anything looks at the result
         if (!ctx->side_stream) {
-            GT_HIP(ctx, hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
+            // (highest priority: the thousand long-row waves are the shorter job and must not queue behind the million short rows)
+            int prio_lo = 0, prio_hi = 0;
+            GT_HIP(ctx, hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+            GT_HIP(ctx, hipStreamCreateWithPriority(&ctx->side_stream, hipStreamNonBlocking, prio_hi));
             GT_HIP(ctx, hipEventCreateWithFlags(&ctx->side_event, hipEventDisableTiming));
         }
         hipLaunchKernelGGL(merge_long_final_kernel, dim3(1024), dim3(64), 0, ctx->side_stream, fs, g->indptr.as<int64_t>(),
