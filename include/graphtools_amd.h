@@ -115,7 +115,11 @@ int gt_stage_launches(const gt_ctx* ctx, const char* stage);
  * cell-sorted copy of the points), "select_sym_cosine" (the symmetric pass serves the cosine metric too), "rerank_lanes4",
  * "symmetrize_bins", "symmetrize_bin_shift", "symmetrize_fill_threads", "symmetrize_fused", "symmetrize_pairs" (pair-resolved
  * symmetrisation of single-rank '+' builds: every row settles its mutual pairs itself, only one-sided entries are transposed),
- * "xcd_chunk"; "dbg_select" switches invalidate the results. */
+ * "xcd_chunk", "rerank_waves_per_block" / "row_waves_per_block" (1 | 4: rows per workgroup of the wave-per-row kernels; 1 = a long
+ * row holds no idle wave slots); "dbg_select" switches invalidate the results.
+ * "distance_dtype" ("data" | "float64") DOES change results, by design: "float64" takes the distances of a float32 point set from
+ * the float64 keys unrounded (scipy pdist semantics, the exact graph built through this path - gt_graph_to_dense) instead of
+ * rounding them to float32 as scikit-learn's kneighbors does (graphs.py:883). */
 int gt_set_option(gt_ctx* ctx, const char* name, const char* value);
 /* arithmetic the most recent main candidate pass ran on: 0 float32, 1 split float16 (3 chains), 2 single float16 chain */
 int gt_last_knn_precision(const gt_ctx* ctx);

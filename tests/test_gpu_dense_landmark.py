@@ -231,3 +231,28 @@ def test_distance_dtype_option_gives_float32_points_float64_distances():
     assert np.array_equal(a.indptr, b.indptr) and np.array_equal(a.indices, b.indices)
     np.testing.assert_allclose(a.data, b.data, rtol=1e-11)
     assert abs(a - c).max() > 1e-9       # (the float32 rounding of the distances is visible without the option)
+
+
+def test_dense_copy_on_the_device_in_float32():
+    """gt_graph_to_dense into a caller's device buffer (float32): the sparse K of the same build, densified"""
+    import torch
+    from graphtools_amd import _hip
+
+    torch.cuda.init()
+    X = make_mix(5000, 16, 9).astype(np.float32)
+    ctx = _hip.Context(0)
+    try:
+        ctx.set_points(X)
+        params, keep = _hip.Context.make_params(7, 30, 1e-4, None, 1.0, None, "+", None, 0)
+        ctx.graph_build(params)
+        d, i, p = ctx.graph_fetch_csr(_hip.CSR_K)
+        K = sparse.csr_matrix((d, i, p), shape=(5000, 5000))
+        out = torch.full((5000, 5000), -1.0, dtype=torch.float32, device="cuda:0")
+        ctx.graph_to_dense(_hip.CSR_K, 5000, np.float32, out_device=out)
+        assert np.array_equal(out.cpu().numpy(), K.toarray().astype(np.float32))
+        pd_, _, _ = ctx.graph_fetch_csr(_hip.CSR_P, structure=False)
+        ctx.graph_to_dense(_hip.CSR_P, 5000, np.float32, out_device=out)       # (the same buffer: rows are zero-filled first)
+        P = sparse.csr_matrix((pd_, i, p), shape=(5000, 5000))
+        assert np.array_equal(out.cpu().numpy(), P.toarray().astype(np.float32))
+    finally:
+        ctx.close()
