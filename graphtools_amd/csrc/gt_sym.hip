@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void sym_thresholds_kernel(const int64_t n, co
                 for (int i = 0; i < 4; ++i) {
                     double acc = acc4[i];
 #pragma unroll
-                    for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 16);
+                    for (int o = 8; o > 0; o >>= 1) acc += lane_xor_f64(acc, o);   // (row operations: no LDS round trip)
                     if (c + i < lim) dk = fmax(dk, gt_pair_key(qs, acc, xn[j4[i]], metric));
                 }
             }
