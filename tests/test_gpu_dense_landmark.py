@@ -171,7 +171,7 @@ def _compare_dense_to_oracle(G, K0, P0, thresh, rtol):
 
 @pytest.mark.parametrize("kw", [
     dict(), dict(kernel_symm="mnn", theta=0.3), dict(anisotropy=1.0), dict(bandwidth=7.5, bandwidth_scale=0.9),
-    dict(knn=4, decay=2, thresh=1e-3), dict(dtype=np.float32),
+    dict(knn=4, decay=2, thresh=1e-3), dict(dtype=np.float32), dict(kernel_symm="*"), dict(kernel_symm=None, anisotropy=0.5),
 ])
 def test_exact_graph_from_points_through_the_neighbour_search(kw, monkeypatch):
     """above _NEIGHBOUR_ROUTE_MIN points the exact graph is built by the kNN path's radius search and written out densely
