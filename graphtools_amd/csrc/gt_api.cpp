@@ -360,6 +360,10 @@ int gt_set_option(gt_ctx* ctx, const char* name, const char* value) {
         ctx->symm_bin_shift = sh;
         return GT_OK;
     }
+    if (k == "select_sym_cold_split") {
+        ctx->sym_cold_split = std::atoi(value) != 0 ? 1 : 0;
+        return GT_OK;
+    }
     if (k == "select_sym_bounds") {
         ctx->sym_bounds = v == "auto" ? -1 : std::atoi(value);
         return GT_OK;

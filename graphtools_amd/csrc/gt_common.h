@@ -175,6 +175,8 @@ struct gt_ctx {
     int32_t symm_pair_ok = 1;   //   ... not refuted for the bound point set (a union row beyond the register sorts)
     int32_t symm_fill_threads = 256;   //   threads per workgroup of bin_fill_kernel (256 | 512 | 1024)
     int32_t symm_bin_shift = 0; //   log2 of the rows per bin (0: 9, more from 2 M rows; development / tests: 8 ... 12)
+    int32_t sym_cold_split = 0; //   the cold launch behind the bound pass scores with the three split chains (tight error bound: a third fewer
+                                //   candidates - measured at C3: re-rank 3.96 -> 3.25 ms, cold launch 2.51 -> 3.25 ms: no net gain, off by default)
     int32_t sym_bounds = -1;    //   bound pass in front of the two-stage collect (cell balls): -1 auto / 1 on, 0 off
     int64_t sym_bound_cap = 0;  //   units the bound pass may leave before the collect launch runs instead (0: 4 M; tests)
     int32_t sym_pca = 1;        //   stage one scores the 16 leading principal directions (0: the first 16 features)

@@ -1343,11 +1343,12 @@ __device__ __forceinline__ void cold_admit(const f32x16& A0, const f32x16& A1, c
 #ifndef GT_SEL_COLD_EPW
 #define GT_SEL_COLD_EPW 16   // queue entries per wave of the cold launch (consecutive entries mostly share their queries)
 #endif
-template <int DP>
-__global__ __launch_bounds__(256, 3) void sym_cold_kernel(const float* __restrict__ Yp, const float* __restrict__ hneg,
+template <int DP, int CP>   // CP: arithmetic of the scores - 2 the hi planes alone (one chain), 1 hi and lo planes (three chains)
+__global__ __launch_bounds__(256, CP == 1 ? 2 : 3) void sym_cold_kernel(const float* __restrict__ Yp, const float* __restrict__ hneg,
                                                        const float* __restrict__ thr_in, const int32_t nq,
                                                        const int32_t ntiles, const SymDev sy) {
     using C = SelCfg<DP, 2>;
+    constexpr int RWC = SelCfg<DP, CP>::RW;   // row width of the copy this launch reads
     constexpr int QT = 2;
     const int lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
     const int64_t en0 = (int64_t(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6)) * GT_SEL_COLD_EPW;
@@ -1355,7 +1356,7 @@ __global__ __launch_bounds__(256, 3) void sym_cold_kernel(const float* __restric
     const int w = 0;
     constexpr int BQ = 128 * GT_SEL_TWO_QT, TPB = BQ / C::BN;   // query blocks of the collect launch
     const int T = ntiles, NB = T / TPB, H = (NB - 1) / 2;
-    Frag<DP, 2> bq[QT], ca;
+    Frag<DP, CP> bq[QT], ca;
     float thrF[QT], hnqF[QT], thr[QT];
     uint32_t have_q = 0xFFFFFFFFu;
     // a wave takes a few consecutive entries: the bound pass files the units of a group of 64 queries together (and the
@@ -1377,13 +1378,13 @@ __global__ __launch_bounds__(256, 3) void sym_cold_kernel(const float* __restric
             for (int qt = 0; qt < QT; ++qt) {
                 const int64_t qg = qblock + qt * 32 + li;
                 const int64_t qc = qg < nq ? qg : int64_t(nq) - 1;
-                bq[qt].load(Yp + qc * C::RW, h);
+                bq[qt].load(Yp + qc * RWC, h);
                 thrF[qt] = qg < nq ? thr_in[qc] : INFINITY;
                 hnqF[qt] = qg < nq ? hneg[qc] : -INFINITY;
                 thr[qt] = thrF[qt];
             }
         }
-        ca.load(Yp + (size_t(tbase) + li) * C::RW, h);
+        ca.load(Yp + (size_t(tbase) + li) * RWC, h);
         f32x16 cs;
 #pragma unroll
         for (int g_ = 0; g_ < 4; ++g_) {
@@ -1430,8 +1431,12 @@ int launch_sym_cold(gt_ctx* ctx, const SelectArgs& a) {
         GT_FAIL(ctx, GT_E_ARG, "knn_select: the cold pass needs the queue and the lists of the collect launch");
     // (independent waves: one per workgroup, so that a wave with much to file does not hold three idle slots)
     const int wpb = ctx->row_wpb == 4 ? 4 : 1;
-    hipLaunchKernelGGL(sym_cold_kernel<DP>, dim3((unsigned)ceil_div64(a.sym.qn, wpb * GT_SEL_COLD_EPW)), dim3(64 * wpb), 0, ctx->stream, a.Yp, a.hneg,
-                       a.thr_in, a.nq, int(a.n_pad / SelCfg<DP, 2>::BN), a.sym);
+    if (a.cold_split)
+        hipLaunchKernelGGL((sym_cold_kernel<DP, 1>), dim3((unsigned)ceil_div64(a.sym.qn, wpb * GT_SEL_COLD_EPW)), dim3(64 * wpb), 0, ctx->stream, a.Yp, a.hneg,
+                           a.thr_in, a.nq, int(a.n_pad / SelCfg<DP, 2>::BN), a.sym);
+    else
+        hipLaunchKernelGGL((sym_cold_kernel<DP, 2>), dim3((unsigned)ceil_div64(a.sym.qn, wpb * GT_SEL_COLD_EPW)), dim3(64 * wpb), 0, ctx->stream, a.Yp, a.hneg,
+                           a.thr_in, a.nq, int(a.n_pad / SelCfg<DP, 2>::BN), a.sym);
     GT_HIP(ctx, hipGetLastError());
     return GT_OK;
 }

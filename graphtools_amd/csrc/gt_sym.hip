@@ -599,7 +599,8 @@ __global__ __launch_bounds__(256) void sym_project_kernel(const T* __restrict__ 
 __global__ __launch_bounds__(256) void sym_row_radius_kernel(const int64_t n, const int64_t n_pad,
                                                              const int32_t* __restrict__ perm, const double* __restrict__ xn,
                                                              const float* __restrict__ thr, const double* __restrict__ ymax2p,
-                                                             const ErrModel err, float* __restrict__ rrow) {
+                                                             const ErrModel err, float* __restrict__ rrow, const double lres) {
+    // lres >= 0: largest rounding residual of a row (true units) when err is not the single-chain model, whose `abs` is it
     const int64_t p = int64_t(blockIdx.x) * 256 + threadIdx.x;
     if (p >= n_pad) return;
     float rr = -INFINITY;
@@ -613,7 +614,7 @@ __global__ __launch_bounds__(256) void sym_row_radius_kernel(const int64_t n, co
             const double e = gt_err_bound(err, qs, y2);
             double lb = (qs - 2.0 * (double(t) * err.inv_sc2 + e)) - 1e-9 * (qs + y2);
             lb = (lb > 0.0 ? lb : 0.0) * (1.0 + 1e-6) + 1e-9 * (qs + y2);
-            const double scf = 1.0 / sqrt(err.inv_sc2), Lf = scf * err.abs;
+            const double scf = 1.0 / sqrt(err.inv_sc2), Lf = scf * (lres >= 0.0 ? lres : err.abs);
             const double rf = (scf * sqrt(lb) + 2.0 * Lf) * (1.0 + 1e-9);
             rr = float(rf);
             if (double(rr) <= rf) rr = nextafterf(rr, INFINITY);
@@ -1402,9 +1403,44 @@ int gt_sym_bound_queue(gt_ctx* ctx, int64_t n_pad_s, const void* Ys, const float
     return GT_OK;
 }
 
-int gt_sym_row_radius(gt_ctx* ctx, const int32_t* perm, int64_t n_pad_s, const float* thr, const ErrModel& err, float* rrow) {
+int gt_sym_row_radius(gt_ctx* ctx, const int32_t* perm, int64_t n_pad_s, const float* thr, const ErrModel& err, float* rrow,
+                      double lres) {
     hipLaunchKernelGGL(sym_row_radius_kernel, dim3((unsigned)ceil_div64(n_pad_s, 256)), dim3(256), 0, ctx->stream, ctx->n, n_pad_s,
-                       perm, ctx->xn.as<double>(), thr, ctx->ymax.as<double>(), err, rrow);
+                       perm, ctx->xn.as<double>(), thr, ctx->ymax.as<double>(), err, rrow, lres);
+    GT_HIP(ctx, hipGetLastError());
+    return GT_OK;
+}
+
+// thresholds fixed for one arithmetic restated for another (sym_thresholds_kernel: x = (smin - e - c) / inv_sc2, rounded down):
+// x' = x + (e_from - e_to) / inv_sc2 >= thr + ..., rounded down again.  xns: squared norms in sorted order.
+__global__ __launch_bounds__(256) void sym_thr_retarget_kernel(const int64_t n, const double* __restrict__ xns,
+                                                               float* __restrict__ thr, const double* __restrict__ ymax2p,
+                                                               const ErrModel from, const ErrModel to) {
+    const int64_t p = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (p >= n) return;
+    const float t = thr[p];
+    if (t == INFINITY || !(t > -3.0e38f)) return;   // orphan / no threshold seeded
+    const double qs = xns[p], y2 = ymax2p[0];
+    const double x = double(t) + (gt_err_bound(from, qs, y2) - gt_err_bound(to, qs, y2)) / from.inv_sc2;
+    float t2 = float(x);
+    if (double(t2) >= x) t2 = nextafterf(t2, -INFINITY);
+    if (t2 > t) thr[p] = t2;
+}
+
+int gt_sym_thr_retarget(gt_ctx* ctx, const double* xns, float* thr, const ErrModel& from, const ErrModel& to) {
+    hipLaunchKernelGGL(sym_thr_retarget_kernel, dim3((unsigned)ceil_div64(ctx->n, 256)), dim3(256), 0, ctx->stream, ctx->n, xns, thr,
+                       ctx->ymax.as<double>(), from, to);
+    GT_HIP(ctx, hipGetLastError());
+    return GT_OK;
+}
+
+// the split working copy (hi | lo planes, 4 DP bytes per row) in cell-sorted order
+int gt_sym_gather_split(gt_ctx* ctx, const int32_t* perm, int64_t n_pad_s, void* Yps, float* hs) {
+    const int c16 = ctx->DP / 4;
+    const int64_t total = n_pad_s * c16;
+    hipLaunchKernelGGL(gather_sorted_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, ctx->stream,
+                       ctx->Yp.as<uint4>(), ctx->hneg.as<float>(), perm, ctx->n, n_pad_s, c16, reinterpret_cast<uint4*>(Yps), hs,
+                       (float*)nullptr);
     GT_HIP(ctx, hipGetLastError());
     return GT_OK;
 }
