@@ -1340,11 +1340,14 @@ __device__ __forceinline__ void cold_admit(const f32x16& A0, const f32x16& A1, c
 #ifndef GT_SEL_COLD_ADMIT
 #define GT_SEL_COLD_ADMIT 1   // 1: cold_admit (scalar-mask filing), 0: the collect kernel's GT_ADMIT2P
 #endif
+#ifndef GT_SEL_COLD_WAVES
+#define GT_SEL_COLD_WAVES 3   // waves per SIMD the cold kernel's registers are cut for (it fits 4 at 122 VGPRs)
+#endif
 #ifndef GT_SEL_COLD_EPW
 #define GT_SEL_COLD_EPW 16   // queue entries per wave of the cold launch (consecutive entries mostly share their queries)
 #endif
 template <int DP, int CP>   // CP: arithmetic of the scores - 2 the hi planes alone (one chain), 1 hi and lo planes (three chains)
-__global__ __launch_bounds__(256, CP == 1 ? 2 : 3) void sym_cold_kernel(const float* __restrict__ Yp, const float* __restrict__ hneg,
+__global__ __launch_bounds__(256, CP == 1 ? 2 : GT_SEL_COLD_WAVES) void sym_cold_kernel(const float* __restrict__ Yp, const float* __restrict__ hneg,
                                                        const float* __restrict__ thr_in, const int32_t nq,
                                                        const int32_t ntiles, const SymDev sy) {
     using C = SelCfg<DP, 2>;

@@ -115,6 +115,8 @@ int gt_stage_launches(const gt_ctx* ctx, const char* stage);
  * cell-sorted copy of the points), "select_sym_cosine" (the symmetric pass serves the cosine metric too), "rerank_lanes4",
  * "symmetrize_bins", "symmetrize_bin_shift", "symmetrize_fill_threads", "symmetrize_fused", "symmetrize_pairs" (pair-resolved
  * symmetrisation of single-rank '+' builds: every row settles its mutual pairs itself, only one-sided entries are transposed),
+ * "select_sym_cold_split" (0 | 1: the cold launch behind the bound pass scores with the three split chains - tighter thresholds,
+ * a third fewer candidates for the re-rank; no net gain measured, default 0),
  * "xcd_chunk", "rerank_waves_per_block" / "row_waves_per_block" (1 | 4: rows per workgroup of the wave-per-row kernels; 1 = a long
  * row holds no idle wave slots); "dbg_select" switches invalidate the results.
  * "distance_dtype" ("data" | "float64") DOES change results, by design: "float64" takes the distances of a float32 point set from
