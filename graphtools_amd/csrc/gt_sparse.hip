@@ -2826,6 +2826,26 @@ extern "C" int gt_graph_stats(const gt_ctx* ctx, int64_t* out4) {
 }
 
 // ---- dense copy of the owned rows of K or P (the exact graph built through the sparse path: TraditionalGraph from data) ----
+// zero fill of the whole output as ONE linear stream (16-byte non-temporal stores, consecutive workgroups on consecutive 4 KB
+// pieces: a wave per row - 800 KB rows at N = 2e5 - keeps thousands of distant streams open and reached 3.5 TB/s), then the
+// entries of every row scattered over it
+__global__ __launch_bounds__(256) void dense_zero_kernel(void* __restrict__ out, const size_t bytes) {
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    u32x4* o = reinterpret_cast<u32x4*>(out);
+    const size_t n16 = bytes / 16;
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    const size_t stride = size_t(gridDim.x) * 256;
+    size_t f = size_t(blockIdx.x) * 256 + threadIdx.x;
+    for (; f + 3 * stride < n16; f += 4 * stride) {
+        __builtin_nontemporal_store(z, o + f);
+        __builtin_nontemporal_store(z, o + f + stride);
+        __builtin_nontemporal_store(z, o + f + 2 * stride);
+        __builtin_nontemporal_store(z, o + f + 3 * stride);
+    }
+    for (; f < n16; f += stride) __builtin_nontemporal_store(z, o + f);
+    if (blockIdx.x == 0 && threadIdx.x < (bytes & 15)) reinterpret_cast<unsigned char*>(out)[n16 * 16 + threadIdx.x] = 0;
+}
+
 template <typename TO>
 __global__ __launch_bounds__(256) void csr_to_dense_kernel(const int64_t nloc, const int64_t ncols, const int64_t* __restrict__ indptr,
                                                            const int32_t* __restrict__ indices, const double* __restrict__ data,
@@ -2834,24 +2854,6 @@ __global__ __launch_bounds__(256) void csr_to_dense_kernel(const int64_t nloc, c
     const int64_t i = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
     if (i >= nloc) return;
     TO* row = out + i * ncols;
-    constexpr int V = 16 / int(sizeof(TO));   // elements per 16-byte store
-    if ((ncols % V) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
-        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-        u32x4* row4 = reinterpret_cast<u32x4*>(row);
-        const int64_t n4 = ncols / V;
-        const u32x4 z = {0u, 0u, 0u, 0u};
-        int64_t c = lane;
-        for (; c + 192 < n4; c += 256) {
-            __builtin_nontemporal_store(z, row4 + c);
-            __builtin_nontemporal_store(z, row4 + c + 64);
-            __builtin_nontemporal_store(z, row4 + c + 128);
-            __builtin_nontemporal_store(z, row4 + c + 192);
-        }
-        for (; c < n4; c += 64) __builtin_nontemporal_store(z, row4 + c);
-    } else {
-        for (int64_t c = lane; c < ncols; c += 64) row[c] = TO(0);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // the zeros of this row have landed before its entries are written
     for (int64_t e = indptr[i] + lane; e < indptr[i + 1]; e += 64) row[indices[e]] = TO(data[e]);
 }
 
@@ -2872,6 +2874,11 @@ extern "C" int gt_graph_to_dense(gt_ctx* ctx, int32_t which, void* out, int32_t 
         dst = tmp.p;
     }
     const double* data = which == GT_CSR_K ? g->Kdata.as<double>() : g->Pdata.as<double>();
+    if ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)
+        hipLaunchKernelGGL(dense_zero_kernel, dim3((unsigned)std::min<size_t>(ceil_div64(int64_t(bytes / 16) + 1, 256), size_t(1) << 20)),
+                           dim3(256), 0, ctx->stream, dst, bytes);
+    else
+        GT_HIP(ctx, hipMemsetAsync(dst, 0, bytes, ctx->stream));
     if (out_dtype == GT_F32)
         hipLaunchKernelGGL(csr_to_dense_kernel<float>, dim3((unsigned)ceil_div64(nloc, 4)), dim3(256), 0, ctx->stream, nloc, ncols,
                            g->indptr.as<int64_t>(), g->indices.as<int32_t>(), data, (float*)dst);
