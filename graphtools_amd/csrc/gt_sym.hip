@@ -423,25 +423,37 @@ __global__ __launch_bounds__(256) void sym_radius_sum_kernel(const int64_t n, co
                                                              double* __restrict__ acc) {
     double s = 0.0, c = 0.0, ps = 0.0, pc = 0.0;
     const int64_t hi = p_last < n ? p_last : n;
-    for (int64_t p = p_first + int64_t(blockIdx.x) * 256 + threadIdx.x; p < hi; p += int64_t(gridDim.x) * 256) {
-        const float t = thr[p];
-        const int64_t row = perm[p];
-        if (t != INFINITY && t > -3.0e38f) {
+    // (the trip count is the wave's: the whole wave takes part in the partner distances below)
+    for (int64_t pb = p_first + int64_t(blockIdx.x) * 256 + (threadIdx.x & ~63u); pb < hi; pb += int64_t(gridDim.x) * 256) {
+        const int64_t p = pb + (threadIdx.x & 63);
+        const bool in = p < hi;
+        const float t = in ? thr[p] : INFINITY;
+        const int64_t row = in ? int64_t(perm[p]) : 0;
+        if (in && t != INFINITY && t > -3.0e38f) {
             const double lb = sym_row_lb(t, xn[row], ymax2p[0], err);
             s += lb > 0.0 ? lb : 0.0;
             c += 1.0;
         }
-        if ((p & 63) == 0) {
-            const int64_t other = int64_t((uint64_t(p) * 0x9E3779B97F4A7C15ull >> 20) % uint64_t(n));
-            const T* a = X + row * int64_t(d);
+        // every 64th row against a pseudo-random partner: the WAVE forms the distance (lane k the features k, k + 64, ...; one
+        // lane walking the whole row serially was most of this kernel's 0.19 ms)
+        const unsigned long long lead = __ballot(in && (p & 63) == 0);
+        if (lead != 0ull) {   // wave-uniform
+            const int src = __ffsll((long long)lead) - 1;
+            const int64_t prow = __shfl(row, src);
+            const int64_t pp = __shfl(p, src);
+            const int64_t other = int64_t((uint64_t(pp) * 0x9E3779B97F4A7C15ull >> 20) % uint64_t(n));
+            const T* a = X + prow * int64_t(d);
             const T* b = X + other * int64_t(d);
             double dd = 0.0;
-            for (int k = 0; k < d; ++k) {
+            for (int k = int(threadIdx.x & 63); k < d; k += 64) {
                 const double df = double(a[k]) - double(b[k]);
                 dd = fma(df, df, dd);
             }
-            ps += dd;
-            pc += 1.0;
+            dd = wave_sum_f64(dd);
+            if (int(threadIdx.x & 63) == src) {
+                ps += dd;
+                pc += 1.0;
+            }
         }
     }
 #pragma unroll
