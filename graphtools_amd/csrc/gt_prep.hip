@@ -70,9 +70,10 @@ __global__ __launch_bounds__(256) void max_abs_kernel(const T* __restrict__ X, c
     __shared__ double wm[4];
     __shared__ int wn[4];
     const int w = threadIdx.x >> 6;
+    const bool wave_nan = __ballot(nan) != 0ull;   // (all lanes vote: outside the branch)
     if ((threadIdx.x & 63) == 0) {
         wm[w] = m;
-        wn[w] = __ballot(nan) != 0ull ? 1 : 0;
+        wn[w] = wave_nan ? 1 : 0;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -112,9 +113,10 @@ __global__ __launch_bounds__(256) void max_abs_f4_kernel(const float4* __restric
     __shared__ float wm[4];
     __shared__ int wn[4];
     const int w = threadIdx.x >> 6;
+    const bool wave_nan = __ballot(nan) != 0ull;   // (all lanes vote: outside the branch)
     if ((threadIdx.x & 63) == 0) {
         wm[w] = mf;
-        wn[w] = __ballot(nan) != 0ull ? 1 : 0;
+        wn[w] = wave_nan ? 1 : 0;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
