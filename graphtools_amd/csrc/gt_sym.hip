@@ -1054,21 +1054,25 @@ __global__ __launch_bounds__(64) void bound_estimate_kernel(const int L, const i
 // (zero bit) contributes the sub-tiles its rows lie in - those that belong to the walk of q64's 1024-row block (own
 // block, H following blocks, the antipodal one when NB is even: knn_select_kernel<MODE 2> with two-stage scoring).  A
 // sub-tile (or the queries) can straddle cells: a unit is filed by the FIRST undecided pair (a, b) of its cell ranges.
-__global__ __launch_bounds__(64) void bound_queue_kernel(const int T, const int TPB, const int walk, const int L,
+__global__ __launch_bounds__(256) void bound_queue_kernel(const int nq64, const int T, const int TPB, const int walk, const int L,
                                                          const int world, const int rank, const int group,
                                                          const uint32_t* __restrict__ tcell,
                                                          const int32_t* __restrict__ start, const int32_t* __restrict__ endp,
                                                          const uint32_t* __restrict__ mask, const int words,
                                                          uint2* __restrict__ queue, const uint32_t cap,
                                                          uint32_t* __restrict__ count, const double* __restrict__ forecast) {
-    const int lane = threadIdx.x;
-    const uint32_t q64 = blockIdx.x;
+    // four groups of 64 queries per workgroup: their slots come from ONE returning atomic (15 600 of them, one per group, were
+    // half of this kernel's time)
+    __shared__ uint32_t wtot[4], wbase;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint32_t q64 = blockIdx.x * 4u + uint32_t(w);
     if (forecast && *forecast > 4.0 * double(cap)) {   // (bound_estimate_kernel: far too many units - report "too many", list none)
         if (q64 == 0u && lane == 0) count[0] = count[1] = 0xFFFFFFFFu;
-        return;
+        return;   // (every wave of the launch alike)
     }
+    bool active = int(q64) < nq64;
     const int blk = int(q64) / (TPB * 2);   // (a 1024-row block = TPB 128-row tiles = 2 TPB groups of 64 queries)
-    const uint32_t qa = tcell[2 * q64], qb = tcell[2 * q64 + 1];
+    const uint32_t qa = active ? tcell[2 * q64] : 0xFFFFFFFFu, qb = active ? tcell[2 * q64 + 1] : 0xFFFFFFFFu;
     // cells of the 64 queries: [lo, hi] over the two sub-tiles that hold real rows
     uint32_t qlo = 0xFFFFu, qhi = 0u;
     if ((qa & 0xFFFFu) != 0xFFFFu) {
@@ -1079,7 +1083,7 @@ __global__ __launch_bounds__(64) void bound_queue_kernel(const int T, const int 
         if ((qb & 0xFFFFu) < qlo) qlo = qb & 0xFFFFu;
         if ((qb >> 16) > qhi) qhi = qb >> 16;
     }
-    if (qlo == 0xFFFFu) return;   // pad queries only
+    if (qlo == 0xFFFFu) active = false;   // pad queries only (the wave still meets the others at the reservation)
     // row-sharded build: this rank's piece of the block's walk (the partition of knn_select_kernel<MODE 2>: piece
     // (rank + block / group) mod world of `world` equal pieces)
     const int piece = world > 1 ? (rank + blk / group) % world : 0;
@@ -1107,12 +1111,19 @@ __global__ __launch_bounds__(64) void bound_queue_kernel(const int T, const int 
             for (int o = 32; o > 0; o >>= 1) ar += uint32_t(__shfl_xor(int(ar), o));
             if (lane == 0 && ar != 0u) atomicAdd(count + 1, ar);
         }
+        if (lane == 0) wtot[w] = total;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint32_t sum = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+            wbase = sum != 0u ? atomicAdd(count, sum) : 0u;
+        }
+        __syncthreads();
         if (total == 0u) return;
-        uint32_t base = 0u;
-        if (lane == 0) base = atomicAdd(count, total);
-        base = uint32_t(__shfl(int(base), 0));
+        uint32_t base = wbase;
+        for (int v = 0; v < w; ++v) base += wtot[v];
         slot = base + inc - mine;
     }
+    if (active)
     for (uint32_t a = qlo; a <= qhi; ++a) {
         for (int w0 = 0; w0 < words; w0 += 64) {
             const int wd = w0 + lane;
@@ -1408,7 +1419,7 @@ int gt_sym_bound_queue(gt_ctx* ctx, int64_t n_pad_s, const void* Ys, const float
     }
     const int T = int(n_pad_s / 128), TPB = 8, NB = T / TPB, H = (NB - 1) / 2;
     const int walk = TPB * (1 + H) + ((NB & 1) ? 0 : (NB > 1 ? TPB : 0));
-    hipLaunchKernelGGL(bound_queue_kernel, dim3((unsigned)(NB * 2 * TPB)), dim3(64), 0, ctx->stream, T, TPB, walk, L,
+    hipLaunchKernelGGL(bound_queue_kernel, dim3((unsigned)((NB * 2 * TPB + 3) / 4)), dim3(256), 0, ctx->stream, NB * 2 * TPB, T, TPB, walk, L,
                        std::max(world, 1), rank, std::max(group, 1), tcell, start,
                        endp, mask, words, queue, cap, count_dev, est_ptr);
     GT_HIP(ctx, hipGetLastError());
