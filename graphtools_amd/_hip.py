@@ -70,6 +70,11 @@ _SIGNATURES = {
     "gt_graph_sym_collect": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_void_p, _c.POINTER(_c.c_int32), _c.c_void_p]),
     "gt_graph_sym_emit": (_c.c_int, [_c.c_void_p, _c.c_void_p]),
     "gt_graph_sym_finish": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64]),
+    "gt_points_cell_sort": (_c.c_int, [_c.c_void_p, _c.POINTER(_c.c_int32)]),
+    "gt_points_shard_splits": (_c.c_int, [_c.c_void_p, _c.c_int32, _c.c_void_p]),
+    "gt_points_row_ids": (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_int64, _c.c_void_p, _c.c_int32]),
+    "gt_graph_shard_local": (_c.c_int, [_c.c_void_p, _c.POINTER(KnnParams), _c.c_int32, _c.c_int32, _c.c_void_p,
+                                        _c.POINTER(_c.c_int32)]),
     "gt_graph_finish": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64, _c.POINTER(_c.c_int64), _c.POINTER(_c.c_uint32)]),
     "gt_graph_anisotropy": (_c.c_int, [_c.c_void_p, _c.c_void_p]),
     "gt_graph_stage_counts": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int32, _c.c_int32, _c.c_void_p, _c.c_void_p,
@@ -375,6 +380,32 @@ class Context:
     def graph_sym_finish(self, recv_ptr, n_recv):
         self._check(self.lib.gt_graph_sym_finish(self.h, ctypes.c_void_p(int(recv_ptr)) if recv_ptr else None, int(n_recv)),
                     "gt_graph_sym_finish")
+
+    # ---- cell-sorted renumbering: the row-sharded build without candidate exchange (gt_knn_shard.cpp) ----
+    def points_cell_sort(self):
+        """renumber the bound points in cell-sorted order; -> True when applied (False: too few / too wide points)"""
+        applied = ctypes.c_int32(0)
+        self._check(self.lib.gt_points_cell_sort(self.h, ctypes.byref(applied)), "gt_points_cell_sort")
+        return bool(applied.value)
+
+    def points_shard_splits(self, world):
+        splits = np.zeros(world + 1, dtype=np.int64)
+        self._check(self.lib.gt_points_shard_splits(self.h, int(world), _ptr(splits)), "gt_points_shard_splits")
+        return splits
+
+    def points_row_ids(self, row0, row1):
+        """the caller's row numbers of the context's rows [row0, row1) (numpy int32)"""
+        out = np.zeros(max(int(row1 - row0), 0), dtype=np.int32)
+        if len(out):
+            self._check(self.lib.gt_points_row_ids(self.h, int(row0), int(row1), _ptr(out), 0), "gt_points_row_ids")
+        return out
+
+    def graph_shard_local(self, params, world, rank, row_splits):
+        splits = np.ascontiguousarray(row_splits, dtype=np.int64)
+        applies = ctypes.c_int32(0)
+        self._check(self.lib.gt_graph_shard_local(self.h, ctypes.byref(params), int(world), int(rank), _ptr(splits),
+                                                  ctypes.byref(applies)), "gt_graph_shard_local")
+        return bool(applies.value)
 
     def graph_emit(self, send_ptr):
         self._check(self.lib.gt_graph_emit(self.h, ctypes.c_void_p(int(send_ptr)) if send_ptr else None), "gt_graph_emit")

@@ -96,7 +96,7 @@ void gt_ctx_destroy(gt_ctx* ctx) {
     ctx->dense_degree.release();
     ctx->dense_bw.release();
     ctx->X_norm.release();
-    for (DevBuf* b : {&ctx->land_Y, &ctx->land_h, &ctx->order_cell, &ctx->order_rows, &ctx->order_tmp}) b->release();
+    for (DevBuf* b : {&ctx->land_Y, &ctx->land_h, &ctx->order_cell, &ctx->order_rows, &ctx->order_tmp, &ctx->vperm, &ctx->vcell}) b->release();
     if (ctx->side_event) (void)hipEventDestroy(ctx->side_event);
     if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
     (void)hipStreamDestroy(ctx->stream);
@@ -135,6 +135,7 @@ int gt_set_points(gt_ctx* ctx, const void* X, int64_t n, int32_t d, int32_t dtyp
     if (n >= (int64_t(1) << 31) - 1) GT_FAIL(ctx, GT_E_LIMIT, "gt_set_points: n must be < 2^31 - 1");
     GT_HIP(ctx, hipSetDevice(ctx->device));
     ctx->reset_stages();
+    ctx->presorted = 0;   // (a renumbering belongs to the points it was made for)
     const size_t esz = dtype == GT_F32 ? 4 : 8;
     if (on_device) {
         ctx->X = X;

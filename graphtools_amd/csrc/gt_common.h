@@ -186,6 +186,14 @@ struct gt_ctx {
     int32_t sym_two_ok = -1;    //   verdict of the last launch for the bound point set (cold-path share), -1 unknown
     int32_t sym_shard_group = 32;   //   row-sharded launch B: query blocks per rotation step of the walk pieces
     int32_t order_L = 0;        // landmark cells of the last query order (gt_order.hip)
+    // Cell-sorted renumbering (gt_points_cell_sort, gt_knn_shard.cpp): the bound points ARE the caller's points in the
+    // cell-sorted order - row v of the context is the caller's row vperm[v], a landmark cell is a run of consecutive rows,
+    // and gt_query_order answers with the identity.  Row-sharded builds own contiguous runs of cells that way (a rank's
+    // neighbourhoods are its own rows); the tail writes the caller's column numbers (relabelled at the final sort).
+    int32_t presorted = 0;
+    int32_t presorted_L = 0;    //   cells of the renumbering
+    int32_t order_has_thr0 = 0; //   the last query order left starting thresholds in its out_thr0 (not in the presorted case)
+    DevBuf vperm, vcell;        //   int32 [n] row of the caller for every row of the context; uint32 [n] its cell (non-decreasing)
     int64_t n_pad = 0;   // rows of the working copy (multiple of the db tile)
     DevBuf Yp;           // working copy: [n_pad] rows of 4*DP bytes (float32, or float16 hi plane | lo plane)
     DevBuf Yc;           // prec 1 with fast_mode: compact copy of the hi plane, [n_pad] rows of 2*DP bytes

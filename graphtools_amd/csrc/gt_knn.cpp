@@ -184,8 +184,10 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
     ra.unproven = k->unproven.as<uint32_t>();
     bool have_thr0 = false;
     // row-sharded symmetric pass (gt_knn_shard.cpp): the candidate lists of exactly these rows are waiting
-    bool sh_ready = k->sh_stage == 5 && !external && q0 == k->sh_r0 && nq == k->sh_nloc && need_m == k->sh_need &&
-                    radius_key_factor == k->sh_rkf && MP == 256;
+    // (stage 6: collected by the rank itself on renumbered points, gt_knn_shard_local - lists by sorted position = row)
+    const bool sh_local = k->sh_stage == 6;
+    bool sh_ready = (k->sh_stage == 5 || k->sh_stage == 6) && !external && q0 == k->sh_r0 && nq == k->sh_nloc &&
+                    need_m == k->sh_need && radius_key_factor == k->sh_rkf && MP == 256;
     k->sh_stage = 0;
     if (sh_ready) {
         k->ordered = false;   // k->qorder holds the sorted order of ALL rows (candidate ids are positions in it)
@@ -204,7 +206,7 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
         }
         if (ordered) sa.qrows = ra.qrows = k->qorder.as<int32_t>();
         k->ordered = ordered != 0 && !external && q0 == 0 && nq == ctx->n;
-        have_thr0 = ordered != 0 && need_m <= 32 && ctx->thr0_mode != 0;
+        have_thr0 = ordered != 0 && need_m <= 32 && ctx->thr0_mode != 0 && ctx->order_has_thr0 != 0;
     }
     // Symmetric pass (gt_sym.hip): self queries over the whole point set, euclidean, single-chain arithmetic, grouped
     // query order available (its permutation is the cell-sorted order both sides of the pass share)
@@ -228,17 +230,26 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
             GT_HIP(ctx, hipMemsetAsync(k->sym_stat.p, 0, 2 * sizeof(unsigned long long), ctx->stream));
             GT_HIP(ctx, hipMemsetAsync(k->unproven.p, 0, sizeof(uint32_t), ctx->stream));
             SymRerank sr;
-            sr.tlists = k->sh_lists.as<uint64_t>();
-            sr.tcounts = k->sh_counts.as<uint32_t>();
             sr.tcap = ctx->sym_tcap;
             sr.perm = k->qorder.as<int32_t>();
             sr.stat = k->sym_stat.as<unsigned long long>();
-            sr.invperm = k->sh_invperm.as<int32_t>();
-            sr.own_rows = k->sh_own.as<int32_t>();
             sr.own_r0 = q0;
-            if (k->xs_ready) {
-                sr.Xs = k->Xs.p;
-                sr.xns = k->xns.as<double>();
+            if (sh_local) {
+                // lists, thresholds and rows by sorted position, which IS the row of the renumbered points
+                sr.tlists = k->tlists.as<uint64_t>();
+                sr.tcounts = k->tcounts.as<uint32_t>();
+                sr.pos0 = q0;
+                sr.Xs = ctx->X;
+                sr.xns = ctx->xn.as<double>();
+            } else {
+                sr.tlists = k->sh_lists.as<uint64_t>();
+                sr.tcounts = k->sh_counts.as<uint32_t>();
+                sr.invperm = k->sh_invperm.as<int32_t>();
+                sr.own_rows = k->sh_own.as<int32_t>();
+                if (k->xs_ready) {
+                    sr.Xs = k->Xs.p;
+                    sr.xns = k->xns.as<double>();
+                }
             }
             {
                 StageSpan span(ctx, "rerank");

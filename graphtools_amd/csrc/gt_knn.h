@@ -184,6 +184,8 @@ struct SymRerank {
     const int32_t* invperm = nullptr;
     const int32_t* own_rows = nullptr;   // the owned rows in the order of their sorted positions
     int64_t own_r0 = 0;
+    // lists of a RANGE of sorted positions (no invperm): list / threshold ql + pos0, table row perm[ql + pos0] - own_r0
+    int64_t pos0 = 0;
     // the points / norms in sorted order (optional): candidate rows are then read by position
     const void* Xs = nullptr;
     const double* xns = nullptr;
@@ -237,8 +239,11 @@ int gt_sym_thr_retarget(gt_ctx* ctx, const double* xns, float* thr, const ErrMod
 int gt_sym_gather_split(gt_ctx* ctx, const int32_t* perm, int64_t n_pad_s, void* Yps, float* hs);
 // bound pass of the two-stage collect (gt_sym.hip cell_ball_kernel): the units the cell bounds cannot rule out -> queue
 // (world / rank / group: a row-sharded build lists the units of its own pieces of the walks)
+// own_p1 > own_p0: the query groups of the sorted positions [own_p0, own_p1) against EVERY sub-tile (no walks; own_p0 a
+// multiple of 64) - the queue of a cold launch that files under the queries only (SymDev::own_only)
 int gt_sym_bound_queue(gt_ctx* ctx, int64_t n_pad_s, const void* Ys, const float* rrow, DevBuf& work, uint2* queue,
-                       uint32_t cap, uint32_t* count_dev, int world = 1, int rank = 0, int group = 1);
+                       uint32_t cap, uint32_t* count_dev, int world = 1, int rank = 0, int group = 1, int64_t own_p0 = 0,
+                       int64_t own_p1 = 0);
 // row-sharded symmetric pass (gt_knn_shard.cpp)
 #define GT_SYM_MAX_WORLD 64
 int gt_sym_g_from_thr(gt_ctx* ctx, int64_t n_pad_s, const float* thr, const float* hs, float* g, float* gmin);

@@ -1374,7 +1374,7 @@ __global__ __launch_bounds__(256, CP == 1 ? 2 : GT_SEL_COLD_WAVES) void sym_cold
         // queries' block, as in the collect kernel)
         int rel = int(ent.y / uint32_t(C::BN / 32)) - int(qblock / BQ) * TPB;
         if (rel < 0) rel += T;
-        const bool tr_on = rel >= TPB && rel < TPB * (1 + H);
+        const bool tr_on = sy.own_only == 0 && rel >= TPB && rel < TPB * (1 + H);
         if (ent.x != have_q) {   // wave-uniform
             have_q = ent.x;
 #pragma unroll

@@ -21,6 +21,9 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <utility>
+#include <vector>
 
 namespace {
 
@@ -33,6 +36,249 @@ bool shard_applicable(const gt_ctx* ctx, int need_m) {
 }
 
 }  // namespace
+
+// ---- cell-sorted renumbering of the bound points ---------------------------------------------------------------------
+// Row-sharded builds (dist.py) give every rank a run of consecutive rows.  In the caller's row order a rank's rows lie
+// all over the point set: its candidate pairs are everybody's, and the symmetric pass had to ship every candidate it
+// found to the row's owner (14 M records per rank at N = 1e6, world 8).  Renumbered in the cell-sorted order a rank's
+// rows are whole landmark cells: the pairs a row needs are scored by the rank that owns the row, nothing is shipped
+// before the transposed triplets of the symmetrisation.  The renumbering is a property of the CONTEXT (every stage works
+// on the renumbered points and never learns about it); the caller's numbers come back in the last sort of the tail
+// (gt_sparse.hip: RowSrc::relabel) and through gt_points_row_ids.
+//   applied = 0: the points are too few (or too wide) for a cell order - nothing changed.
+extern "C" int gt_points_cell_sort(gt_ctx* ctx, int32_t* applied) {
+    if (!ctx || !applied) return GT_E_ARG;
+    *applied = 0;
+    GT_HIP(ctx, hipSetDevice(ctx->device));
+    if (ctx->n <= 0 || !ctx->X) GT_FAIL(ctx, GT_E_STATE, "gt_points_cell_sort: no points bound (call gt_set_points first)");
+    if (ctx->presorted) {
+        *applied = 1;
+        return GT_OK;
+    }
+    if (ctx->DP == 0 || ctx->wide || ctx->prec != 1 || ctx->fast_mode == 0 || !ctx->Yc.p) return GT_OK;
+    if (!ctx->knn) ctx->knn = new KnnWork();
+    KnnWork* k = ctx->knn;
+    const int64_t n = ctx->n;
+    int ordered = 0;
+    GT_HIP(ctx, k->qorder.reserve(size_t(n) * sizeof(int32_t)));
+    GT_HIP(ctx, k->qthr0.reserve(size_t(n) * sizeof(float)));
+    {
+        StageSpan span(ctx, "query_order");
+        GT_TRY(gt_query_order(ctx, ctx->Yc.as<float>(), 0, n, 1, k->qorder.as<int32_t>(), k->qthr0.as<float>(), &ordered));
+    }
+    k->ordered = false;
+    k->xs_ready = false;
+    k->yps_ready = false;
+    k->sh_stage = 0;
+    if (!ordered || ctx->order_L <= 0) return GT_OK;
+    StageSpan span(ctx, "renumber");
+    // the points in the new order (the caller's buffer is not referenced any more), their row numbers and cells
+    GT_TRY(gt_sym_gather_points(ctx, k->qorder.as<int32_t>()));
+    std::swap(ctx->X_own, k->Xs);
+    ctx->X = ctx->X_own.p;
+    k->xs_ready = false;
+    GT_HIP(ctx, ctx->vperm.reserve(size_t(n) * sizeof(int32_t)));
+    GT_HIP(ctx, ctx->vcell.reserve(size_t(n) * sizeof(uint32_t)));
+    GT_HIP(ctx, hipMemcpyAsync(ctx->vperm.p, k->qorder.p, size_t(n) * sizeof(int32_t), hipMemcpyDeviceToDevice, ctx->stream));
+    GT_HIP(ctx, hipMemcpyAsync(ctx->vcell.p, ctx->order_cell.as<uint32_t>() + n, size_t(n) * sizeof(uint32_t),
+                               hipMemcpyDeviceToDevice, ctx->stream));
+    // norms and working copies of the renumbered rows (the same rows: the same norms, the same float16 scale; the landmark
+    // rows gt_query_order picked keep describing the cells)
+    GT_TRY(gt_prep_points(ctx));
+    ctx->presorted = 1;
+    ctx->presorted_L = ctx->order_L;
+    GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *applied = 1;
+    return GT_OK;
+}
+
+// the caller's row number of the context's rows [v0, v1) (identity when the points were not renumbered)
+extern "C" int gt_points_row_ids(gt_ctx* ctx, int64_t v0, int64_t v1, int32_t* out, int32_t out_on_device) {
+    if (!ctx || !out) return GT_E_ARG;
+    GT_HIP(ctx, hipSetDevice(ctx->device));
+    if (v0 < 0 || v1 > ctx->n || v1 < v0) GT_FAIL(ctx, GT_E_ARG, "gt_points_row_ids: bad row range");
+    if (v1 == v0) return GT_OK;
+    if (ctx->presorted) {
+        GT_HIP(ctx, hipMemcpyAsync(out, ctx->vperm.as<int32_t>() + v0, size_t(v1 - v0) * sizeof(int32_t),
+                                   out_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
+        GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return GT_OK;
+    }
+    std::vector<int32_t> ids(size_t(v1 - v0));
+    for (int64_t v = v0; v < v1; ++v) ids[size_t(v - v0)] = int32_t(v);
+    GT_HIP(ctx, hipMemcpyAsync(out, ids.data(), ids.size() * sizeof(int32_t),
+                               out_on_device ? hipMemcpyHostToDevice : hipMemcpyHostToHost, ctx->stream));
+    GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return GT_OK;
+}
+
+// ---- row-sharded symmetric pass on renumbered points: no exchange at all --------------------------------------------
+// The bound points are in cell-sorted order (gt_points_cell_sort) and the rank owns the rows [r0, r1) = whole 1024-row
+// blocks of that order (gt_points_shard_splits).  Everything launch A and launch B need of OTHER rows is their
+// coordinates, which every rank holds: the rank seeds its own rows, fixes their thresholds, lists the (64 own queries,
+// 32 rows) units its own rows' radii cannot rule out - against EVERY sub-tile, other ranks' included - and files each
+// survivor under the query only.  A pair of rows of two ranks is scored twice, once by each owner (2 / world of the pair
+// scores per rank instead of 1 / world), and in exchange nothing is shipped: no thresholds, no candidate records.  The
+// lists equal the single-rank lists of the same rows (same thresholds, same scores), gt_knn_candidates() re-ranks them.
+//   applies = 0: not on this point set / these parameters, or the cell bounds leave too many units - the caller's
+//   gt_graph_begin then runs the classic pass for the rank's rows (any rank may, on its own: nothing is shared).
+int gt_knn_shard_local(gt_ctx* ctx, int64_t r0, int64_t r1, int need_m, double rkf, int32_t* applies) {
+    *applies = 0;
+    if (ctx->n <= 0 || !ctx->X) GT_FAIL(ctx, GT_E_STATE, "no points bound (call gt_set_points first)");
+    if (r0 < 0 || r1 > ctx->n || r1 <= r0) GT_FAIL(ctx, GT_E_ARG, "sym shard: bad row range");
+    if (!ctx->knn) ctx->knn = new KnnWork();
+    KnnWork* k = ctx->knn;
+    k->sh_stage = 0;
+    const int bq = gt_select_bq(ctx->DP), bn = gt_select_bn(ctx->DP);
+    if (!ctx->presorted || !shard_applicable(ctx, need_m) || ctx->DP < 32 || bq != 256 || ctx->sym_two_stage == 0 ||
+        ctx->sym_bounds == 0 || ctx->sym_dense_seed == 0 || need_m > 64)
+        return GT_OK;
+    if (r0 % 1024 != 0 || (r1 % 1024 != 0 && r1 != ctx->n)) return GT_OK;   // whole blocks (gt_points_shard_splits)
+    const int64_t n_pad_s = ceil_div64(ctx->n, 1024) * 1024;
+    const int64_t p0 = r0, p1 = ceil_div64(r1, 1024) * 1024;   // (the last rank's run ends with the pad rows)
+    const int tcap = ctx->sym_tcap;
+    // identity order (the points are sorted), cells from the renumbering
+    int ordered = 0;
+    GT_HIP(ctx, k->qorder.reserve(size_t(ctx->n) * sizeof(int32_t)));
+    GT_HIP(ctx, k->qthr0.reserve(size_t(ctx->n) * sizeof(float)));
+    GT_TRY(gt_query_order(ctx, ctx->Yc.as<float>(), 0, ctx->n, need_m, k->qorder.as<int32_t>(), k->qthr0.as<float>(), &ordered));
+    k->ordered = false;
+    k->xs_ready = false;
+    if (!ordered || ctx->order_L <= 0) return GT_OK;
+    const int32_t* perm = k->qorder.as<int32_t>();
+    GT_HIP(ctx, k->Ycs.reserve(size_t(n_pad_s) * ctx->DP * sizeof(_Float16)));
+    GT_HIP(ctx, k->hnegs.reserve(size_t(n_pad_s) * sizeof(float)));
+    GT_HIP(ctx, k->hnegs_fin.reserve(size_t(n_pad_s) * sizeof(float)));
+    GT_HIP(ctx, k->tlists.reserve(size_t(n_pad_s) * size_t(tcap) * sizeof(uint64_t)));
+    GT_HIP(ctx, k->tcounts.reserve(size_t(n_pad_s) * sizeof(uint32_t)));
+    GT_HIP(ctx, k->sym_stat.reserve(8 * sizeof(unsigned long long)));
+    GT_HIP(ctx, k->lists.reserve(size_t(p1 - p0) * 64 * sizeof(uint64_t)));   // the dense seeding kernel's keys: own blocks only
+    GT_HIP(ctx, k->counts.reserve(size_t(n_pad_s) * sizeof(uint32_t)));
+    GT_HIP(ctx, k->thr_final.reserve(size_t(n_pad_s) * sizeof(float)));
+    GT_HIP(ctx, k->sym_g.reserve(size_t(n_pad_s) * sizeof(float)));
+    GT_HIP(ctx, k->sym_farcnt.reserve(size_t(n_pad_s) * sizeof(float)));
+    GT_HIP(ctx, k->sym_racc.reserve(4 * sizeof(double)));
+    GT_HIP(ctx, k->sym_rrow.reserve(size_t(n_pad_s) * sizeof(float)));
+    GT_HIP(ctx, k->sym_qtot.reserve(4 * sizeof(uint32_t)));
+    const int64_t bcap = ctx->sym_bound_cap > 0 ? ctx->sym_bound_cap : (int64_t(1) << 22);
+    GT_HIP(ctx, k->sym_qdense.reserve(size_t(bcap) * sizeof(uint2)));
+    GT_HIP(ctx, hipMemsetAsync(k->sym_farcnt.p, 0, size_t(n_pad_s) * sizeof(float), ctx->stream));
+    GT_HIP(ctx, hipMemsetAsync(k->sym_stat.p, 0, 8 * sizeof(unsigned long long), ctx->stream));
+    GT_HIP(ctx, hipMemsetAsync(k->sym_racc.p, 0, 4 * sizeof(double), ctx->stream));
+    const int n_tiles_s = int(n_pad_s / bn);
+    const int stride_a = ctx->sym_stride > 0 && n_tiles_s >= 8 * ctx->sym_stride ? ctx->sym_stride : 0;
+    const int tile_stride = ((stride_a ? n_tiles_s / stride_a + 1 : 0) + ctx->sym_max_nb + bq / bn + 63) / 64 * 64;
+    if (tile_stride > 1024) return GT_OK;
+    GT_HIP(ctx, k->sym_tiles.reserve(size_t(n_pad_s / bq) * tile_stride * sizeof(int32_t)));
+    GT_HIP(ctx, k->sym_tile_cnt.reserve(size_t(n_pad_s / bq) * sizeof(int32_t)));
+    ErrModel em = gt_err_model(ctx, 2);
+    em.rel += 8.0 * 5.9604644775390625e-08;   // as in the single-rank pass (gt_knn.cpp)
+    {
+        StageSpan span(ctx, "sym_prepare");
+        // the compact copy padded to whole 1024-row blocks (the order is the identity: a copy with pad rows)
+        GT_TRY(gt_sym_gather(ctx, perm, n_pad_s, k->Ycs.p, k->hnegs.as<float>(), k->hnegs_fin.as<float>()));
+        GT_TRY(gt_sym_schedule(ctx, n_pad_s, bq, bn, ctx->sym_cells, stride_a, ctx->sym_max_nb, tile_stride, k->sym_work,
+                               k->sym_tiles.as<int32_t>(), k->sym_tile_cnt.as<int32_t>(),
+                               k->sym_stat.as<unsigned long long>() + 5));
+        // every row that is not the rank's: no threshold (+inf: asks for nothing, admits nothing, has no radius)
+        GT_HIP(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(k->thr_final.p), 0x7F800000, size_t(n_pad_s), ctx->stream));
+    }
+    uint64_t* lists0 = k->lists.as<uint64_t>() - size_t(p0) * 64;   // (addressed by sorted position: only [p0, p1) is touched)
+    {
+        StageSpan span(ctx, "sym_seed");
+        GT_TRY(gt_sym_seed_dense(ctx, ctx->DP, k->Ycs.p, k->hnegs_fin.as<float>(), ctx->n, n_pad_s, k->sym_tiles.as<int32_t>(),
+                                 k->sym_tile_cnt.as<int32_t>(), tile_stride, bq, p0 / 128, (p1 - p0) / 128, need_m, lists0, 64,
+                                 k->counts.as<uint32_t>()));
+    }
+    k->sym_seed_dense = true;
+    k->sh_lstride = 64;
+    unsigned long long far = 0;
+    {
+        StageSpan span(ctx, "sym_prepare");
+        // (the exact stages read the points themselves: they ARE in sorted order)
+        GT_TRY(gt_sym_thresholds(ctx, perm, n_pad_s, k->hnegs.as<float>(), lists0, 64, k->counts.as<uint32_t>(), need_m, em,
+                                 std::max(1.0, std::fabs(rkf)), k->thr_final.as<float>(), k->sym_g.as<float>(), nullptr,
+                                 k->sym_work, ctx->sym_cells, k->sym_stat.as<unsigned long long>() + 2,
+                                 k->sym_farcnt.as<float>(), p0, p1));
+        GT_TRY(gt_sym_radius_sum(ctx, perm, p0, std::min<int64_t>(p1, ctx->n), k->thr_final.as<float>(), em, k->sym_racc.as<double>()));
+        GT_HIP(ctx, hipMemsetAsync(k->tcounts.p, 0, size_t(n_pad_s) * sizeof(uint32_t), ctx->stream));
+        GT_HIP(ctx, hipMemcpyAsync(&far, k->sym_stat.as<unsigned long long>() + 2, sizeof(far), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    k->sym_far = int64_t(far);
+    if (ctx->sym_mode < 0) {
+        // the predictor of the single-rank pass (gt_knn.cpp) on this rank's rows
+        const double est = double(need_m) + double(std::max(stride_a, 1)) * double(far) / double(r1 - r0);
+        if (stride_a > 0 && est > double(tcap) / 8.0) return GT_OK;
+    }
+    uint32_t left = 0;
+    {
+        StageSpan span(ctx, "sym_bound");
+        // orphans (statistics of the rank's own rows), radii, then the units the cells cannot rule out
+        GT_TRY(gt_sym_orphan_cut(ctx, perm, k->thr_final.as<float>(), k->sym_farcnt.as<float>(), em, k->sym_racc.as<double>(),
+                                 need_m, 0.25));
+        GT_TRY(gt_sym_row_radius(ctx, perm, n_pad_s, k->thr_final.as<float>(), em, k->sym_rrow.as<float>()));
+        GT_TRY(gt_sym_bound_queue(ctx, n_pad_s, k->Ycs.p, k->sym_rrow.as<float>(), k->sym_bwork, k->sym_qdense.as<uint2>(),
+                                  uint32_t(bcap), k->sym_qtot.as<uint32_t>(), 1, 0, 1, p0, p1));
+        GT_HIP(ctx, hipMemcpyAsync(&left, k->sym_qtot.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->dbg_select & 2048)
+        fprintf(stderr, "[gt] local shard rows [%lld, %lld): bound pass leaves %u units (capacity %lld), far-kept %llu\n",
+                (long long)r0, (long long)r1, left, (long long)bcap, far);
+    if (int64_t(left) > bcap) return GT_OK;   // no cluster structure at the cells' scale: the classic pass for these rows
+    GT_TRY(gt_sym_inject_orphans(ctx, p0, std::min<int64_t>(p1, ctx->n), k->thr_final.as<float>(), lists0, 64,
+                                 k->counts.as<uint32_t>(), k->tlists.as<uint64_t>(), tcap, k->tcounts.as<uint32_t>()));
+    {
+        StageSpan span(ctx, "sym_cold");
+        SelectArgs dq;
+        dq.dp = ctx->DP;
+        dq.prec = 2;
+        dq.mode = 4;
+        dq.nt = 8;
+        dq.Yp = dq.Qp = k->Ycs.as<float>();
+        dq.hneg = k->hnegs.as<float>();
+        dq.n_pad = n_pad_s;
+        dq.q0 = 0;
+        dq.nq = int32_t(ctx->n);
+        dq.thr_in = k->thr_final.as<float>();
+        dq.sym.g = k->sym_g.as<float>();   // (not read: own_only)
+        dq.sym.tlists = k->tlists.as<uint64_t>();
+        dq.sym.tcounts = k->tcounts.as<uint32_t>();
+        dq.sym.tcap = tcap;
+        dq.sym.queue = k->sym_qdense.as<uint2>();
+        dq.sym.qn = int32_t(left);
+        dq.sym.own_only = 1;
+        GT_TRY(gt_launch_select(ctx, dq));
+    }
+    k->sym_cold_entries = int64_t(left);
+    k->sym_bound_used = true;
+    k->sym_two_used = true;
+    k->sym_nseg = 1;
+    ctx->last_main_prec = 2;
+    k->sh_world = 1;
+    k->sh_rank = 0;
+    k->sh_r0 = r0;
+    k->sh_nloc = r1 - r0;
+    k->sh_n_pad_s = n_pad_s;
+    k->sh_p0 = p0;
+    k->sh_p1 = p1;
+    k->sh_need = need_m;
+    k->sh_rkf = rkf;
+    k->sh_stage = 6;   // the lists of the sorted positions [r0, r1) wait in tlists (gt_knn_candidates)
+    *applies = 1;
+    return GT_OK;
+}
+
+// row splits of a sharded build on renumbered points: runs of whole 1024-row blocks, as even as they come
+extern "C" int gt_points_shard_splits(gt_ctx* ctx, int32_t world, int64_t* out_splits) {
+    if (!ctx || !out_splits || world < 1) return GT_E_ARG;
+    if (ctx->n <= 0) GT_FAIL(ctx, GT_E_STATE, "gt_points_shard_splits: no points bound");
+    const int64_t nb = ceil_div64(ctx->n, 1024);
+    for (int r = 0; r <= world; ++r) out_splits[r] = std::min<int64_t>(ctx->n, (nb * r / world) * 1024);
+    out_splits[world] = ctx->n;
+    return GT_OK;
+}
 
 int gt_knn_shard_plan(gt_ctx* ctx, int world, int rank, const int64_t* splits, int need_m, double rkf, int32_t* applies,
                       int64_t* n_pad_sorted, int64_t* sorted_splits) {

@@ -39,6 +39,21 @@ int gt_query_order(gt_ctx* ctx, const float* Qc, int64_t q0, int64_t nq, int nee
                    int* active) {
     *active = 0;
     ctx->order_L = 0;
+    ctx->order_has_thr0 = 0;
+    if (ctx->presorted && Qc == ctx->Yc.as<float>() && ctx->vcell.p && q0 >= 0 && q0 + nq <= ctx->n && nq >= 1) {
+        // the bound points were renumbered in cell-sorted order (gt_points_cell_sort): rows [q0, q0 + nq) are grouped already
+        GT_HIP(ctx, ctx->order_cell.reserve(size_t(nq) * sizeof(uint32_t) * 2));
+        uint32_t* cell = ctx->order_cell.as<uint32_t>();
+        GT_HIP(ctx, hipMemcpyAsync(cell, ctx->vcell.as<uint32_t>() + q0, size_t(nq) * sizeof(uint32_t), hipMemcpyDeviceToDevice,
+                                   ctx->stream));
+        GT_HIP(ctx, hipMemcpyAsync(cell + nq, ctx->vcell.as<uint32_t>() + q0, size_t(nq) * sizeof(uint32_t),
+                                   hipMemcpyDeviceToDevice, ctx->stream));
+        hipLaunchKernelGGL(iota_rows_kernel, dim3((unsigned)ceil_div64(nq, 256)), dim3(256), 0, ctx->stream, q0, nq, out_rows);
+        GT_HIP(ctx, hipGetLastError());
+        ctx->order_L = ctx->presorted_L;
+        *active = 1;
+        return GT_OK;
+    }
     const int64_t kMinRows = ctx->order_min_rows;   // below this the whole launch is a few workgroup rounds
     if (!ctx->query_order || ctx->prec != 1 || ctx->fast_mode == 0 || !ctx->Yc.p || !Qc || nq < kMinRows || ctx->n < std::max<int64_t>(kMinRows, 64))
         return GT_OK;
@@ -71,6 +86,7 @@ int gt_query_order(gt_ctx* ctx, const float* Qc, int64_t q0, int64_t nq, int nee
     GT_HIP(ctx, rocprim::radix_sort_pairs(ctx->order_tmp.p, tmp_bytes, cell, cell_sorted, ctx->order_rows.as<int32_t>(),
                                           out_rows, size_t(nq), 0u, unsigned(bits), ctx->stream));
     ctx->order_L = L;   // cells of the order just built (cell ids of the sorted rows: order_cell + nq)
+    ctx->order_has_thr0 = 1;
     *active = 1;
     return GT_OK;
 }

@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256, 5) void rerank_sym_kernel(
     int32_t* __restrict__ fb_rows, uint32_t* __restrict__ gflags, const double radius_key_factor,
     uint32_t* __restrict__ unproven, unsigned long long* __restrict__ stat, const int want_stats,
     const int32_t* __restrict__ invperm, const int32_t* __restrict__ own_rows, const int64_t own_r0,
-    const int xcd_chunk, const T* __restrict__ Xs, const double* __restrict__ xns, const int metric) {
+    const int xcd_chunk, const T* __restrict__ Xs, const double* __restrict__ xns, const int metric, const int64_t pos0) {
     constexpr int MP = 256;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int lane = threadIdx.x & 63;
@@ -258,10 +258,11 @@ __global__ __launch_bounds__(256, 5) void rerank_sym_kernel(
     // single rank: list ql = sorted position ql, tables indexed by the row perm[ql].  Row-sharded (invperm given): the
     // ql-th owned row in the sorted order is own_rows[ql] (neighbouring waves then evaluate overlapping candidate rows),
     // its list and table sit at its local index, its threshold at its sorted position
-    const int64_t qo = invperm ? int64_t(own_rows[ql]) : int64_t(perm[ql]);   // row of the bound points
-    const int64_t q = invperm ? qo - own_r0 : qo;                             // row of the tables
-    const int64_t qt = invperm ? int64_t(invperm[qo]) : ql;                   // index of the threshold
-    const int64_t ls = invperm ? q : ql;                                      // index of the list
+    // (pos0: the launch covers the sorted positions [pos0, pos0 + nq) - a rank's run of a renumbered point set)
+    const int64_t qo = invperm ? int64_t(own_rows[ql]) : int64_t(perm[ql + pos0]);   // row of the bound points
+    const int64_t q = qo - own_r0;                                                   // row of the tables (own_r0 = 0 on one rank)
+    const int64_t qt = invperm ? int64_t(invperm[qo]) : ql + pos0;                   // index of the threshold
+    const int64_t ls = invperm ? q : ql + pos0;                                      // index of the list
     // (Xs / xns: the points and norms in sorted order - the candidates of neighbouring lists are neighbouring rows there)
     const T* xrow = Xs ? Xs + qt * int64_t(d) : X + qo * int64_t(d);
     for (int k = lane; k < d; k += 64) xs[k] = double(xrow[k]);
@@ -426,7 +427,8 @@ __global__ __launch_bounds__(64 * WPB, WT ? 3 : 4) void rerank_sym4_kernel(
     uint32_t* __restrict__ unproven, unsigned long long* __restrict__ stat, const int want_stats,
     const int32_t* __restrict__ invperm, const int32_t* __restrict__ own_rows, const int64_t own_r0,
     const int xcd_chunk, const float* __restrict__ Xs, const double* __restrict__ xns, double* __restrict__ cand_d2t,
-    uint8_t* __restrict__ keyt_ok, int32_t* __restrict__ nokeyt_rows, uint32_t* __restrict__ nokeyt_count, const int metric) {
+    uint8_t* __restrict__ keyt_ok, int32_t* __restrict__ nokeyt_rows, uint32_t* __restrict__ nokeyt_count, const int metric,
+    const int64_t pos0) {
     // cand_d2t (optional): next to every key of the table, the key the OTHER row holds for the same pair - the same dot
     // product in scikit-learn's association with the roles swapped, (|y|^2 - 2 x.y) + |x|^2 - so that the affinity pass can
     // tell, bit for bit, what the transposed entry is worth (gt_sparse.hip, pair-resolved symmetrisation); keyt_ok[q] = 1
@@ -446,10 +448,11 @@ __global__ __launch_bounds__(64 * WPB, WT ? 3 : 4) void rerank_sym4_kernel(
     const int64_t bid = gt_xcd_item(blockIdx.x, gridDim.x, xcd_chunk * (4 / WPB));
     const int64_t ql = bid * WPB + w;
     if (ql >= nq) return;
-    const int64_t qo = invperm ? int64_t(own_rows[ql]) : int64_t(perm[ql]);   // row of the bound points
-    const int64_t q = invperm ? qo - own_r0 : qo;                             // row of the tables
-    const int64_t qt = invperm ? int64_t(invperm[qo]) : ql;                   // index of the threshold
-    const int64_t ls = invperm ? q : ql;                                      // index of the list
+    // (pos0: the launch covers the sorted positions [pos0, pos0 + nq) - a rank's run of a renumbered point set)
+    const int64_t qo = invperm ? int64_t(own_rows[ql]) : int64_t(perm[ql + pos0]);   // row of the bound points
+    const int64_t q = qo - own_r0;                                                   // row of the tables (own_r0 = 0 on one rank)
+    const int64_t qt = invperm ? int64_t(invperm[qo]) : ql + pos0;                   // index of the threshold
+    const int64_t ls = invperm ? q : ql + pos0;                                      // index of the list
     // this lane's share of the query row: elements 16 i + 4 c .. + 3 of every sector i
     double xq[NI][4];
     {
@@ -1006,13 +1009,13 @@ int gt_launch_rerank_sym(gt_ctx* ctx, const RerankArgs& a, const SymRerank& sr) 
                        a.xn, a.nq, sr.tlists, sr.tcap, sr.tcounts, a.thr_final, a.ymax2, a.err, a.need_m, sr.perm,        \
                        a.cand_d2, a.cand_j, a.cand_n, a.d2_lb, a.fb_count, a.fb_rows, a.gflags, a.radius_key_factor,      \
                        a.unproven, sr.stat, (ctx->dbg_select & 256) ? 1 : 0, sr.invperm, sr.own_rows, sr.own_r0, ctx->xcd_chunk,      \
-                       (const T_*)sr.Xs, sr.xns, a.metric)
+                       (const T_*)sr.Xs, sr.xns, a.metric, sr.pos0)
 #define GT_RERANK_SYM4_LAUNCH(DB_, WT_, WPB_)                                                                             \
     hipLaunchKernelGGL((rerank_sym4_kernel<DB_, WT_, WPB_>), dim3((unsigned)ceil_div64(a.nq, WPB_)), dim3(64 * WPB_), 0, ctx->stream, (const float*)a.X, a.d, \
                        a.xn, a.nq, sr.tlists, sr.tcap, sr.tcounts, a.thr_final, a.ymax2, a.err, a.need_m, sr.perm,        \
                        a.cand_d2, a.cand_j, a.cand_n, a.d2_lb, a.fb_count, a.fb_rows, a.gflags, a.radius_key_factor,      \
                        a.unproven, sr.stat, (ctx->dbg_select & 256) ? 1 : 0, sr.invperm, sr.own_rows, sr.own_r0, ctx->xcd_chunk,      \
-                       (const float*)sr.Xs, sr.xns, sr.cand_d2t, sr.keyt_ok, sr.nokeyt_rows, sr.nokeyt_count, a.metric)
+                       (const float*)sr.Xs, sr.xns, sr.cand_d2t, sr.keyt_ok, sr.nokeyt_rows, sr.nokeyt_count, a.metric, sr.pos0)
     if (sr.wrote_t) *sr.wrote_t = false;
     if (a.dtype == GT_F32) {
         const bool f4 = (a.d & 3) == 0 && (reinterpret_cast<uintptr_t>(a.X) & 15) == 0;

@@ -23,7 +23,7 @@ void gt_free_graph_state(gt_ctx* ctx) {
                       &g->degree, &g->over_rows, &g->over_count, &g->rthr, &g->rlists, &g->rcounts, &g->rK, &g->rmax,
                       &g->ownercnt, &g->ownerpos, &g->cnt_sorted, &g->pos_sorted, &g->scan_tmp, &g->selfbuf, &g->splits_dev, &g->Ukey, &g->Uval, &g->Vkey, &g->Vval,
                       &g->bincnt, &g->binoff, &g->ucol, &g->uval, &g->bigrows, &g->bigcount, &g->bigscratch_k, &g->bigscratch_v, &g->bigsoff, &g->aniso_tmp, &g->scan_own,
-                      &g->indices, &g->Kdata, &g->Pdata, &g->flags})
+                      &g->indices, &g->Kdata, &g->Pdata, &g->flags, &g->deg_caller})
         b->release();
     delete g;
     ctx->graph = nullptr;
@@ -460,7 +460,9 @@ __global__ __launch_bounds__(256) void fill_rows_kernel(
     const int64_t nloc, const int MP, const double* __restrict__ cand_k, const uint32_t* __restrict__ cand_j,
     const int32_t* __restrict__ rowsrc, const uint64_t* __restrict__ rlists, const uint32_t* __restrict__ rcounts,
     const int32_t rcap, const double* __restrict__ rK, const int64_t* __restrict__ off,
-    const int32_t* __restrict__ tablen, UEntry* __restrict__ U) {
+    const int32_t* __restrict__ tablen, UEntry* __restrict__ U, const int32_t* __restrict__ relabel) {
+    // relabel (optional): the context's rows are a renumbering of the caller's (gt_points_cell_sort) - the union rows get
+    // the caller's column numbers, so that the sort by column, the row sums and the CSR are the caller's
     const int lane = threadIdx.x & 63;
     const int w = threadIdx.x >> 6;
     const int64_t i = int64_t(blockIdx.x) * 4 + w;
@@ -488,7 +490,7 @@ __global__ __launch_bounds__(256) void fill_rows_kernel(
         const bool keep = v >= 0.0;
         int total;
         const int p = wave_prefix_count(keep, lane, total);
-        if (keep) U[pos + p] = UEntry{j << 1, 0u, v};
+        if (keep) U[pos + p] = UEntry{(relabel ? uint32_t(relabel[j]) : j) << 1, 0u, v};
         pos += total;
     }
 }
@@ -498,12 +500,12 @@ __global__ __launch_bounds__(256) void fill_recv_kernel(const Triplet* __restric
                                                         const int64_t r0, const int64_t* __restrict__ off,
                                                         const int32_t* __restrict__ lenN,
                                                         const int32_t* __restrict__ slot,
-                                                        UEntry* __restrict__ U) {
+                                                        UEntry* __restrict__ U, const int32_t* __restrict__ relabel) {
     for (int64_t t = int64_t(blockIdx.x) * 256 + threadIdx.x; t < n_recv; t += int64_t(gridDim.x) * 256) {
         const Triplet tr = recv[t];
         const int64_t il = int64_t(tr.row) - r0;
         const int64_t pos = off[il] + lenN[il] + slot[t];
-        U[pos] = UEntry{(tr.col << 1) | 1u, 0u, tr.val};
+        U[pos] = UEntry{((relabel ? uint32_t(relabel[tr.col]) : tr.col) << 1) | 1u, 0u, tr.val};
     }
 }
 
@@ -1083,7 +1085,8 @@ __global__ __launch_bounds__(256) void compact_kernel(const int64_t nloc, const 
                                                       const uint32_t* __restrict__ Vkey, const double* __restrict__ Vval,
                                                       int32_t* __restrict__ indices, double* __restrict__ Kdata,
                                                       double* __restrict__ degree, uint32_t* __restrict__ flags,
-                                                      const int32_t* __restrict__ perm, double* __restrict__ Pdata) {
+                                                      const int32_t* __restrict__ perm, double* __restrict__ Pdata,
+                                                      const int32_t* __restrict__ relabel = nullptr) {
     // perm: the merged rows are in sorted order (bin path: merged row p is row perm[p] of K); nullptr: in row order.
     // Pdata: the row-normalised operator is written along (no anisotropy: K is final here) - normalize_kernel's
     // arithmetic, same summation order
@@ -1097,6 +1100,7 @@ __global__ __launch_bounds__(256) void compact_kernel(const int64_t nloc, const 
     const int n = outlen[p];
     double sum = 0.0, asum = 0.0;
     bool has_diag = false;
+    const int64_t self = relabel ? int64_t(relabel[r0 + i]) : r0 + i;   // the row's own column (the caller's numbering)
     for (int e = lane; e < n; e += 64) {
         const uint32_t c = Vkey[s + e];
         const double v = Vval[s + e];
@@ -1104,7 +1108,7 @@ __global__ __launch_bounds__(256) void compact_kernel(const int64_t nloc, const 
         Kdata[dst + e] = v;
         sum += v;
         asum += fabs(v);
-        has_diag |= (int64_t(c) == r0 + i) && (v != 0.0);
+        has_diag |= (int64_t(c) == self) && (v != 0.0);
     }
     sum = wave_sum_f64(sum);
     const bool any_diag = __ballot(has_diag) != 0ull;
@@ -1388,13 +1392,14 @@ __global__ __launch_bounds__(256) void anisotropy_kernel(const int64_t nloc, con
                                                          const int64_t* __restrict__ indptr,
                                                          const int32_t* __restrict__ indices, double* __restrict__ Kdata,
                                                          const double* __restrict__ degree_all, const double alpha,
-                                                         double* __restrict__ degree_out) {
+                                                         double* __restrict__ degree_out,
+                                                         const int32_t* __restrict__ rowid) {
     const int lane = threadIdx.x & 63;
     const int w = threadIdx.x >> 6;
     const int64_t i = int64_t(blockIdx.x) * 4 + w;
     if (i >= nloc) return;
     const int64_t s = indptr[i], e1 = indptr[i + 1];
-    const double qi = degree_all[r0 + i];
+    const double qi = degree_all[rowid ? int64_t(rowid[r0 + i]) : r0 + i];   // (rowid: renumbered points, degree_all in the caller's numbering)
     double sum = 0.0;
     for (int64_t e = s + lane; e < e1; e += 64) {
         const double v = Kdata[e] / pow(qi * degree_all[indices[e]], alpha);
@@ -1410,13 +1415,14 @@ __global__ __launch_bounds__(256) void anisotropy_kernel(const int64_t nloc, con
 // multiplications, left factor first
 __global__ __launch_bounds__(256) void diff_aff_kernel(const int64_t nloc, const int64_t r0, const int64_t* __restrict__ indptr,
                                                        const int32_t* __restrict__ indices, const double* __restrict__ Kdata,
-                                                       const double* __restrict__ degree_all, double* __restrict__ out) {
+                                                       const double* __restrict__ degree_all, double* __restrict__ out,
+                                                       const int32_t* __restrict__ rowid) {
     const int lane = threadIdx.x & 63;
     const int w = threadIdx.x >> 6;
     const int64_t i = int64_t(blockIdx.x) * 4 + w;
     if (i >= nloc) return;
     const int64_t s = indptr[i], e1 = indptr[i + 1];
-    const double di = 1.0 / sqrt(degree_all[r0 + i]);
+    const double di = 1.0 / sqrt(degree_all[rowid ? int64_t(rowid[r0 + i]) : r0 + i]);
     for (int64_t e = s + lane; e < e1; e += 64) {
         const double left = di * Kdata[e];
         out[e] = left * (1.0 / sqrt(degree_all[indices[e]]));
@@ -1435,6 +1441,13 @@ __global__ __launch_bounds__(256) void normalize_kernel(const int64_t nloc, cons
     sum = wave_sum_f64(sum);
     // sklearn inplace_csr_row_normalize_l1: rows with zero sum are left untouched
     for (int64_t e = s + lane; e < e1; e += 64) Pdata[e] = (sum != 0.0) ? Kdata[e] / sum : Kdata[e];
+}
+
+// out[idx[i]] = in[i] (the degrees of a renumbered point set in the caller's numbering)
+__global__ __launch_bounds__(256) void scatter_f64_kernel(const double* __restrict__ in, const int32_t* __restrict__ idx,
+                                                          const int64_t n, double* __restrict__ out) {
+    const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i < n) out[idx[i]] = in[i];
 }
 
 int exclusive_scan(gt_ctx* ctx, const int32_t* a, const int32_t* b, int64_t n, int64_t* out, DevBuf& tmp) {
@@ -1588,6 +1601,36 @@ extern "C" int gt_graph_sym_finish(gt_ctx* ctx, const void* recv, int64_t n_recv
     return gt_knn_shard_finish(ctx, recv, n_recv);
 }
 
+// Row-sharded build on renumbered points (gt_points_cell_sort; row_splits from gt_points_shard_splits): the candidate lists
+// of the rank's own rows, collected by the rank alone (gt_knn_shard.cpp gt_knn_shard_local) - no exchange.  applies = 0:
+// gt_graph_begin will run the classic candidate pass for these rows instead (every rank decides for itself).
+int gt_knn_shard_local(gt_ctx* ctx, int64_t r0, int64_t r1, int need_m, double rkf, int32_t* applies);
+extern "C" int gt_graph_shard_local(gt_ctx* ctx, const gt_knn_params* params, int32_t world, int32_t rank,
+                                    const int64_t* row_splits, int32_t* applies) {
+    if (!ctx || !params || !applies || !row_splits) return GT_E_ARG;
+    GT_HIP(ctx, hipSetDevice(ctx->device));
+    ctx->reset_stages();
+    *applies = 0;
+    if (world < 1 || world > kMaxWorld || rank < 0 || rank >= world) GT_FAIL(ctx, GT_E_ARG, "gt_graph_shard_local: bad world/rank");
+    if (row_splits[0] != 0 || row_splits[world] != ctx->n) GT_FAIL(ctx, GT_E_ARG, "row_splits must cover [0, n]");
+    if (row_splits[rank + 1] <= row_splits[rank]) return GT_OK;
+    if (params->knn < 1 || params->knn_max > 0 || int64_t(params->knn) + 1 > ctx->n) return GT_OK;
+    const bool binary = std::isnan(params->decay) || params->thresh == 1.0;
+    double thresh = params->thresh;
+    if (!binary) {
+        if (thresh <= 0) return GT_OK;
+        if (thresh < DBL_EPSILON) thresh = DBL_EPSILON;
+    }
+    const double hint = candidate_hint(ctx, params, thresh, !binary);
+    return gt_knn_shard_local(ctx, row_splits[rank], row_splits[rank + 1], params->knn + 1, hint, applies);
+}
+
+__global__ __launch_bounds__(256) void gather_f64_kernel(const double* __restrict__ in, const int32_t* __restrict__ idx,
+                                                         const int64_t n, double* __restrict__ out) {
+    const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i < n) out[i] = in[idx[i]];
+}
+
 static int graph_begin_impl(gt_ctx* ctx, const gt_knn_params* params, int32_t world, int32_t rank,
                             const int64_t* row_splits, int64_t* send_counts, bool external, int64_t m_ext) {
     if (!ctx || !params) return GT_E_ARG;
@@ -1698,6 +1741,15 @@ static int graph_begin_impl(gt_ctx* ctx, const gt_knn_params* params, int32_t wo
         GT_HIP(ctx, g->bw_user.reserve(size_t(params->bandwidth_len) * sizeof(double)));
         GT_HIP(ctx, hipMemcpyAsync(g->bw_user.p, params->bandwidth, size_t(params->bandwidth_len) * sizeof(double),
                                    hipMemcpyHostToDevice, ctx->stream));
+        if (ctx->presorted && !external && params->bandwidth_len == ctx->n) {
+            // one bandwidth per row of the CALLER's numbering: into the context's
+            GT_HIP(ctx, g->deg_caller.reserve(size_t(ctx->n) * sizeof(double)));
+            GT_HIP(ctx, hipMemcpyAsync(g->deg_caller.p, g->bw_user.p, size_t(ctx->n) * sizeof(double), hipMemcpyDeviceToDevice,
+                                       ctx->stream));
+            hipLaunchKernelGGL(gather_f64_kernel, dim3((unsigned)ceil_div64(ctx->n, 256)), dim3(256), 0, ctx->stream,
+                               g->deg_caller.as<double>(), ctx->vperm.as<int32_t>(), ctx->n, g->bw_user.as<double>());
+            GT_HIP(ctx, hipGetLastError());
+        }
     }
     g->radius_factor = binary ? 0.0 : std::pow(-1.0 * std::log(thresh), 1.0 / params->decay);   // graphs.py:902-904
     // repairs (radius pass) run on the accurate arithmetic of the working copy, whatever the main pass used
@@ -1831,7 +1883,7 @@ static int graph_begin_impl(gt_ctx* ctx, const gt_knn_params* params, int32_t wo
     // tables carry the transposed keys and whose transpose will go through the destination bins
     g->pairs = ctx->in_graph_build && ctx->symm_pairs != 0 && ctx->symm_pair_ok != 0 && ctx->symm_bins != 0 && world == 1 &&
                !external && !binary && params->knn_max <= 0 && params->kernel_symm == GT_SYMM_ADD && params->anisotropy == 0.0 &&
-               k->keyt_valid && k->ordered && k->nq == g->nloc && g->r0 == 0 &&
+               k->keyt_valid && k->ordered && k->nq == g->nloc && g->r0 == 0 && !ctx->presorted &&
                g->nloc < (int64_t(1) << 31) && (ctx->symm_bins > 0 || g->nloc >= 65536);
     if (ctx->dbg_select & 2048)
         std::fprintf(stderr, "[gt] pairs %d: in_build %d opt %d ok %d bins %d world %d ext %d bin %d kmax %lld symm %d aniso %g metric %d keyt %d ordered %d nq %lld nloc %lld r0 %lld\n",
@@ -1884,7 +1936,7 @@ extern "C" int gt_graph_begin(gt_ctx* ctx, const gt_knn_params* params, int32_t 
                               const int64_t* row_splits, int64_t* send_counts) {
     if (!ctx) return GT_E_ARG;
     // (the stages of a sharded symmetric pass that is about to be consumed belong to this build)
-    if (!(ctx->knn && ctx->knn->sh_stage == 5)) ctx->reset_stages();
+    if (!(ctx->knn && (ctx->knn->sh_stage == 5 || ctx->knn->sh_stage == 6))) ctx->reset_stages();
     const int rc = graph_begin_impl(ctx, params, world, rank, row_splits, send_counts, false, 0);
     ctx->stage_totals_valid = 0;   // (the totals belong to one build)
     return rc;
@@ -1972,6 +2024,9 @@ static int graph_finish_impl(gt_ctx* ctx, const void* recv_buf_dev, int64_t n_re
     KnnWork* k = ctx->knn;
     const Triplet* recv = (const Triplet*)recv_buf_dev;
     const int64_t nloc = g->nloc;
+    // renumbered points (gt_points_cell_sort): rows and triplets are the context's, the CSR gets the caller's columns
+    const int32_t* relabel = (ctx->presorted && !g->external && !bins) ? ctx->vperm.as<int32_t>() : nullptr;
+    g->relabelled = relabel != nullptr;
     {
         StageSpan span(ctx, "symmetrize");
         HostTrace tr_all(ctx, "finish: symmetrize");
@@ -2074,11 +2129,12 @@ static int graph_finish_impl(gt_ctx* ctx, const void* recv_buf_dev, int64_t n_re
             hipLaunchKernelGGL(fill_rows_kernel, dim3((unsigned)ceil_div64(nloc, 4)), dim3(256), 0, ctx->stream, nloc, k->MP,
                                k->cand_d2.as<double>(), k->cand_j.as<uint32_t>(), g->rowsrc.as<int32_t>(),
                                g->rlists.as<uint64_t>(), g->rcounts.as<uint32_t>(), g->rcap, g->rK.as<double>(),
-                               g->off.as<int64_t>(), g->tablen.as<int32_t>(), g->Ukey.as<UEntry>());
+                               g->off.as<int64_t>(), g->tablen.as<int32_t>(), g->Ukey.as<UEntry>(), relabel);
             if (n_recv > 0) {
                 int64_t blocks = std::min<int64_t>(ceil_div64(n_recv, 256), 16384);
                 hipLaunchKernelGGL(fill_recv_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, recv, n_recv, g->r0,
-                                   g->off.as<int64_t>(), g->lenN.as<int32_t>(), g->cursor.as<int32_t>(), g->Ukey.as<UEntry>());
+                                   g->off.as<int64_t>(), g->lenN.as<int32_t>(), g->cursor.as<int32_t>(), g->Ukey.as<UEntry>(),
+                                   relabel);
             }
         }
         UnionSrc us;
@@ -2186,7 +2242,7 @@ static int graph_finish_impl(gt_ctx* ctx, const void* recv_buf_dev, int64_t n_re
             hipLaunchKernelGGL(compact_kernel, dim3((unsigned)ceil_div64(nloc, ctx->row_wpb == 4 ? 4 : 1)), dim3(ctx->row_wpb == 4 ? 256 : 64), 0, ctx->stream, nloc, g->r0,
                                g->off.as<int64_t>(), g->outlen.as<int32_t>(), g->indptr.as<int64_t>(), g->Vkey.as<uint32_t>(),
                                g->Vval.as<double>(), g->indices.as<int32_t>(), g->Kdata.as<double>(), g->degree.as<double>(),
-                               g->flags.as<uint32_t>(), perm, g->p.anisotropy == 0.0 ? g->Pdata.as<double>() : nullptr);
+                               g->flags.as<uint32_t>(), perm, g->p.anisotropy == 0.0 ? g->Pdata.as<double>() : nullptr, relabel);
         }
         GT_HIP(ctx, hipGetLastError());
     }
@@ -2500,9 +2556,18 @@ static int finish_normalize(gt_ctx* ctx, GraphState* g, const double* degree_all
         // degree_all_dev is indexed by GLOBAL row; for world == 1 the local degree vector is global
         DevBuf& tmp = g->aniso_tmp;
         GT_HIP(ctx, tmp.reserve(size_t(nloc) * sizeof(double)));
+        // renumbered points: the CSR holds the caller's column numbers, degree_all_dev is indexed by them (a sharded caller
+        // hands it over that way; the local vector of a single-rank build is scattered here)
+        const int32_t* rowid = g->relabelled ? ctx->vperm.as<int32_t>() : nullptr;
+        if (rowid && degree_all_dev == g->degree.as<double>()) {
+            GT_HIP(ctx, g->deg_caller.reserve(size_t(g->n_total) * sizeof(double)));
+            hipLaunchKernelGGL(scatter_f64_kernel, dim3((unsigned)ceil_div64(nloc, 256)), dim3(256), 0, ctx->stream,
+                               g->degree.as<double>(), rowid + g->r0, nloc, g->deg_caller.as<double>());
+            degree_all_dev = g->deg_caller.as<double>();
+        }
         hipLaunchKernelGGL(anisotropy_kernel, dim3((unsigned)ceil_div64(nloc, 4)), dim3(256), 0, ctx->stream, nloc, g->r0,
                            g->indptr.as<int64_t>(), g->indices.as<int32_t>(), g->Kdata.as<double>(), degree_all_dev,
-                           g->p.anisotropy, tmp.as<double>());
+                           g->p.anisotropy, tmp.as<double>(), rowid);
         hipError_t e = hipMemcpyAsync(g->degree.p, tmp.p, size_t(nloc) * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) {
@@ -2537,6 +2602,13 @@ extern "C" int gt_graph_diff_aff(gt_ctx* ctx, const double* degree_all_dev, doub
     if (!degree_all_dev && g->world != 1) GT_FAIL(ctx, GT_E_ARG, "gt_graph_diff_aff: a sharded build needs the degrees of all rows");
     if (g->external) GT_FAIL(ctx, GT_E_STATE, "gt_graph_diff_aff: the device holds a rectangular kernel");
     const double* deg = degree_all_dev ? degree_all_dev : g->degree.as<double>();
+    const int32_t* rowid = g->relabelled ? ctx->vperm.as<int32_t>() : nullptr;
+    if (rowid && !degree_all_dev) {   // (one rank, renumbered points: the degrees in the caller's numbering)
+        GT_HIP(ctx, g->deg_caller.reserve(size_t(g->n_total) * sizeof(double)));
+        hipLaunchKernelGGL(scatter_f64_kernel, dim3((unsigned)ceil_div64(g->nloc, 256)), dim3(256), 0, ctx->stream,
+                           g->degree.as<double>(), rowid + g->r0, g->nloc, g->deg_caller.as<double>());
+        deg = g->deg_caller.as<double>();
+    }
     double* od = out;
     DevBuf tmp;
     if (!on_device) {
@@ -2544,8 +2616,8 @@ extern "C" int gt_graph_diff_aff(gt_ctx* ctx, const double* degree_all_dev, doub
         od = tmp.as<double>();
     }
     hipLaunchKernelGGL(diff_aff_kernel, dim3((unsigned)ceil_div64(g->nloc, 4)), dim3(256), 0, ctx->stream, g->nloc,
-                       degree_all_dev ? g->r0 : int64_t(0), g->indptr.as<int64_t>(), g->indices.as<int32_t>(),
-                       g->Kdata.as<double>(), deg, od);
+                       (degree_all_dev || rowid) ? g->r0 : int64_t(0), g->indptr.as<int64_t>(), g->indices.as<int32_t>(),
+                       g->Kdata.as<double>(), deg, od, rowid);
     int rc = GT_OK;
     if (hipGetLastError() != hipSuccess) {
         ctx->set_error("gt_graph_diff_aff: launch failed");
@@ -2587,7 +2659,7 @@ extern "C" int gt_graph_build(gt_ctx* ctx, const gt_knn_params* params, int64_t*
     KnnWork* k = ctx->knn;
     // every row is here: with the cell-sorted order of the points at hand the transpose is built through destination
     // bins instead of the triplet exchange (option symmetrize_bins: -1 auto, 0 off, 1 on where possible)
-    const bool bins = ctx->symm_bins != 0 && sendc[0] > 0 && k->ordered && k->nq == g->nloc && g->r0 == 0 && !g->external &&
+    const bool bins = ctx->symm_bins != 0 && sendc[0] > 0 && k->ordered && k->nq == g->nloc && g->r0 == 0 && !g->external && !ctx->presorted &&
                       g->nloc < (int64_t(1) << 31) && (ctx->symm_bins > 0 || g->nloc >= 65536);
     g->bins_used = bins;
     g->fused_used = false;

@@ -1056,6 +1056,7 @@ __global__ __launch_bounds__(64) void bound_estimate_kernel(const int L, const i
 // sub-tile (or the queries) can straddle cells: a unit is filed by the FIRST undecided pair (a, b) of its cell ranges.
 __global__ __launch_bounds__(256) void bound_queue_kernel(const int nq64, const int T, const int TPB, const int walk, const int L,
                                                          const int world, const int rank, const int group,
+                                                         const int own_q0, const int own_full,
                                                          const uint32_t* __restrict__ tcell,
                                                          const int32_t* __restrict__ start, const int32_t* __restrict__ endp,
                                                          const uint32_t* __restrict__ mask, const int words,
@@ -1065,8 +1066,10 @@ __global__ __launch_bounds__(256) void bound_queue_kernel(const int nq64, const 
     // half of this kernel's time)
     __shared__ uint32_t wtot[4], wbase;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const uint32_t q64 = blockIdx.x * 4u + uint32_t(w);
-    if (forecast && *forecast > 4.0 * double(cap)) {   // (bound_estimate_kernel: far too many units - report "too many", list none)
+    // own_full: the groups [own_q0, nq64) against EVERY sub-tile (no walks: a row-sharded build on renumbered points files
+    // each pair under the query's side only, the launch covers the rank's own groups)
+    const uint32_t q64 = uint32_t(own_q0) + blockIdx.x * 4u + uint32_t(w);
+    if (forecast && !own_full && *forecast > 4.0 * double(cap)) {   // (bound_estimate_kernel: far too many units - report "too many", list none)
         if (q64 == 0u && lane == 0) count[0] = count[1] = 0xFFFFFFFFu;
         return;   // (every wave of the launch alike)
     }
@@ -1140,8 +1143,8 @@ __global__ __launch_bounds__(256) void bound_queue_kernel(const int nq64, const 
                 for (uint32_t d32 = uint32_t(sb0) / 32u; d32 <= uint32_t(sb1 - 1) / 32u; ++d32) {
                     int rel = int(d32 / 4u) - blk * TPB;
                     if (rel < 0) rel += T;
-                    if (rel >= walk) continue;   // not this block's unit (the other block's walk has it)
-                    const bool own_piece = rel >= rel_lo && rel < rel_hi;
+                    if (!own_full && rel >= walk) continue;   // not this block's unit (the other block's walk has it)
+                    const bool own_piece = own_full || (rel >= rel_lo && rel < rel_hi);
                     if (!own_piece && (world == 1 || round == 1)) continue;   // another rank's piece (counted in round 0)
                     // first undecided pair of (cells of the queries) x (cells of the sub-tile) files the unit
                     const uint32_t dc = tcell[d32];
@@ -1337,7 +1340,7 @@ int gt_sym_two_probe(gt_ctx* ctx, const void* Ys, int hd, const float* hh, const
 // caller runs the collect launch instead).  Ys: the sorted compact copy [n_pad][DP] float16, rrow: the rows' radii in
 // it; work: scratch.
 int gt_sym_bound_queue(gt_ctx* ctx, int64_t n_pad_s, const void* Ys, const float* rrow, DevBuf& work, uint2* queue,
-                       uint32_t cap, uint32_t* count_dev, int world, int rank, int group) {
+                       uint32_t cap, uint32_t* count_dev, int world, int rank, int group, int64_t own_p0, int64_t own_p1) {
     const int L = ctx->order_L;
     if (L <= 0 || L > 65535) GT_FAIL(ctx, GT_E_STATE, "bound pass: no landmark cells");
     if (n_pad_s % 1024 != 0) GT_FAIL(ctx, GT_E_ARG, "bound pass: whole 1024-row query blocks");
@@ -1419,8 +1422,16 @@ int gt_sym_bound_queue(gt_ctx* ctx, int64_t n_pad_s, const void* Ys, const float
     }
     const int T = int(n_pad_s / 128), TPB = 8, NB = T / TPB, H = (NB - 1) / 2;
     const int walk = TPB * (1 + H) + ((NB & 1) ? 0 : (NB > 1 ? TPB : 0));
+    if (own_p1 > own_p0) {
+        // the rank's own query groups [own_p0 / 64, own_p1 / 64) against every sub-tile (own_p0 a multiple of 64)
+        const int q_lo = int(own_p0 / 64), q_hi = int((own_p1 + 63) / 64);
+        hipLaunchKernelGGL(bound_queue_kernel, dim3((unsigned)((q_hi - q_lo + 3) / 4)), dim3(256), 0, ctx->stream, q_hi, T, TPB, walk, L,
+                           1, 0, 1, q_lo, 1, tcell, start, endp, mask, words, queue, cap, count_dev, est_ptr);
+        GT_HIP(ctx, hipGetLastError());
+        return GT_OK;
+    }
     hipLaunchKernelGGL(bound_queue_kernel, dim3((unsigned)((NB * 2 * TPB + 3) / 4)), dim3(256), 0, ctx->stream, NB * 2 * TPB, T, TPB, walk, L,
-                       std::max(world, 1), rank, std::max(group, 1), tcell, start,
+                       std::max(world, 1), rank, std::max(group, 1), 0, 0, tcell, start,
                        endp, mask, words, queue, cap, count_dev, est_ptr);
     GT_HIP(ctx, hipGetLastError());
     return GT_OK;

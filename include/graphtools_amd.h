@@ -211,6 +211,28 @@ int gt_graph_sym_collect(gt_ctx* ctx, const void* thr_all_dev, int64_t far_total
                          int64_t* send_counts);
 int gt_graph_sym_emit(gt_ctx* ctx, void* send_buf_dev);
 int gt_graph_sym_finish(gt_ctx* ctx, const void* recv_buf_dev, int64_t n_recv);
+/* Row-sharded builds, the default since round 4: CELL-SORTED RENUMBERING.  The reference's n_jobs = -1 (api.py:35,
+ * graphs.py:763-768) spends every core on one kneighbors call; the multi-GPU counterpart splits the rows of K over the
+ * ranks.  In the caller's row order a rank's rows lie all over the point set and every candidate pair is everybody's;
+ * renumbered by landmark cell (the order the single-GPU pass sorts by anyway) a rank owns whole cells, its rows' candidate
+ * pairs are found by the rank itself, and NOTHING is exchanged before the transposed triplets of the symmetrisation:
+ *   gt_set_points          every rank binds ALL points (RCCL all-gather of the row slices first)
+ *   gt_points_cell_sort    renumbers the bound points in cell-sorted order (deterministic: every rank arrives at the
+ *                          same numbering); applied = 0: too few / too wide points - nothing changed, the caller's
+ *                          numbering stays (the flow below still works, gt_graph_shard_local then declines)
+ *   gt_points_shard_splits row_splits [world + 1] in the NEW numbering: runs of whole 1024-row blocks
+ *   gt_graph_shard_local   candidate lists of the rank's own rows, no communication; applies = 0: gt_graph_begin runs
+ *                          the classic candidate pass for the rank's rows instead (each rank decides for itself)
+ *   gt_graph_begin / gt_graph_emit / all-to-all of the triplets / gt_graph_finish as above, in the new numbering
+ *   gt_points_row_ids      the caller's row number of every row of the context (the rank's rows: [row0, row1) of
+ *                          gt_graph_rows); the CSR's COLUMN indices are the caller's numbers already (relabelled in the
+ *                          final per-row sort, so K, P and the degrees equal the single-GPU build's bit for bit)
+ * Degree vectors handed to gt_graph_anisotropy / gt_graph_diff_aff are indexed by the caller's row numbers. */
+int gt_points_cell_sort(gt_ctx* ctx, int32_t* applied);
+int gt_points_shard_splits(gt_ctx* ctx, int32_t world, int64_t* out_splits);
+int gt_points_row_ids(gt_ctx* ctx, int64_t row0, int64_t row1, int32_t* out, int32_t out_on_device);
+int gt_graph_shard_local(gt_ctx* ctx, const gt_knn_params* params, int32_t world, int32_t rank, const int64_t* row_splits,
+                         int32_t* applies);
 /* single-GPU convenience: begin + emit + finish with an internal buffer */
 int gt_graph_build(gt_ctx* ctx, const gt_knn_params* params, int64_t* out_nnz, uint32_t* flags);
 

@@ -1,0 +1,260 @@
+"""GPU: the row-sharded build on renumbered points (gt_points_cell_sort / gt_graph_shard_local, gt_knn_shard.cpp).
+
+Every rank binds all points and renumbers them by landmark cell; a rank owns a run of whole cells, collects the
+candidate lists of its own rows by itself (no candidate exchange), and only the transposed triplets of the
+symmetrisation travel.  The ranks are played by one context each on one GPU, the all-to-all is done by hand.  The rows of
+every rank, put back at the caller's row numbers (gt_points_row_ids), must equal the single-rank build bit for bit -
+structure, K, P - which the other tests pin to the oracle and to the reference's fixtures."""
+import numpy as np
+import pytest
+from scipy import sparse
+
+from conftest import make_gauss, make_manifold, make_mix
+
+pytestmark = pytest.mark.gpu
+
+TRIP = np.dtype([("row", np.uint32), ("col", np.uint32), ("val", np.float64)])
+
+
+def _ctx(opts):
+    from graphtools_amd import _hip
+
+    c = _hip.Context(0)
+    c.set_option("query_order_min_rows", "1")
+    c.set_option("select_symmetric", "1")
+    c.set_option("select_sym_stride", "4")
+    for k, v in opts.items():
+        c.set_option(k, str(v))
+    return c
+
+
+def _exchange(sends, counts, world):
+    out = []
+    for r in range(world):
+        parts = []
+        for s in range(world):
+            off = int(counts[s][:r].sum())
+            parts.append(sends[s][off: off + int(counts[s][r])])
+        out.append(np.concatenate(parts))
+    return out
+
+
+def sharded_local_build(X, world, pargs, opts=None, want_local=True):
+    """-> (K csr, P csr in the caller's numbering, per-rank flags 'the local lists were used', stats)"""
+    from graphtools_amd import _hip
+
+    n = X.shape[0]
+    # (opts: one dict for every rank, or a list with one dict per rank)
+    ctxs = [_ctx((opts[r] if isinstance(opts, list) else opts) or {}) for r in range(world)]
+    for c in ctxs:
+        c.set_points(X)
+        assert c.points_cell_sort(), "renumbering declined"
+    p, keep = ctxs[0].make_params(*pargs)
+    splits = ctxs[0].points_shard_splits(world)
+    assert splits[0] == 0 and splits[-1] == n and np.all(np.diff(splits) >= 0)
+    for c in ctxs[1:]:
+        assert np.array_equal(c.points_shard_splits(world), splits)
+    used = [c.graph_shard_local(p, world, r, splits) for r, c in enumerate(ctxs)]
+    sends, counts = [], []
+    for r, c in enumerate(ctxs):
+        cnt = c.graph_begin(p, world, r, splits)
+        assert bool(c.knn_stats()["symmetric"]) == used[r], (r, used[r], c.knn_stats())
+        total = int(cnt.sum())
+        host = np.zeros(total, dtype=TRIP)
+        if total:
+            buf = c.dev_alloc(total * 16)
+            c.graph_emit(buf)
+            c.dev_download(host, buf)
+            c.dev_free(buf)
+        sends.append(host)
+        counts.append(cnt)
+    rows_all, blocks_K, blocks_P, stats = [], [], [], []
+    for r, (c, recv) in enumerate(zip(ctxs, _exchange(sends, counts, world))):
+        assert np.all((recv["row"] >= splits[r]) & (recv["row"] < splits[r + 1]))
+        buf = c.dev_alloc(max(len(recv), 1) * 16)
+        if len(recv):
+            c.dev_upload(buf, recv)
+        c.graph_finish(buf if len(recv) else 0, len(recv))
+        c.dev_free(buf)
+        r0, r1, nnz = c.graph_rows()
+        assert (r0, r1) == (splits[r], splits[r + 1])
+        d_, i_, p_ = c.graph_fetch_csr(_hip.CSR_K)
+        pd_, _, _ = c.graph_fetch_csr(_hip.CSR_P)
+        rows_all.append(c.points_row_ids(r0, r1))
+        blocks_K.append(sparse.csr_matrix((d_, i_, p_), shape=(r1 - r0, n)))
+        blocks_P.append(sparse.csr_matrix((pd_, i_, p_), shape=(r1 - r0, n)))
+        stats.append((c.knn_stats(), c.graph_stats()))
+    rows = np.concatenate(rows_all)
+    assert np.array_equal(np.sort(rows), np.arange(n)), "the ranks' rows are not a partition of the caller's rows"
+    # every rank arrives at the same numbering
+    full = ctxs[0].points_row_ids(0, n)
+    assert np.array_equal(full, rows)
+    for c in ctxs:
+        c.close()
+    inv = np.empty(n, dtype=np.int64)
+    inv[rows] = np.arange(n)
+    K = sparse.vstack(blocks_K).tocsr()[inv]
+    P = sparse.vstack(blocks_P).tocsr()[inv]
+    return K, P, used, stats
+
+
+def single_build(X, pargs):
+    from graphtools_amd import _hip
+
+    c = _hip.Context(0)
+    c.set_points(X)
+    p, keep = c.make_params(*pargs)
+    c.graph_build(p)
+    Kd, Ki, Kp = c.graph_fetch_csr(_hip.CSR_K)
+    Pd, _, _ = c.graph_fetch_csr(_hip.CSR_P)
+    n = X.shape[0]
+    c.close()
+    return sparse.csr_matrix((Kd, Ki, Kp), shape=(n, n)), sparse.csr_matrix((Pd, Ki, Kp), shape=(n, n))
+
+
+def _same(A, B):
+    assert A.has_sorted_indices or True
+    A.sort_indices()
+    B.sort_indices()
+    assert np.array_equal(A.indptr, B.indptr)
+    assert np.array_equal(A.indices, B.indices)
+    assert np.array_equal(A.data, B.data)
+
+
+@pytest.mark.parametrize("n,d,world,symm,seed,thresh", [
+    (20000, 64, 2, "+", 0, 1e-4),
+    (33001, 32, 3, "*", 1, 1e-4),      # ragged last block
+    (40000, 48, 4, None, 2, 1e-4),
+    (24000, 64, 8, "mnn", 3, 1e-3),    # three blocks per rank
+])
+def test_renumbered_sharded_build_equals_the_single_rank_build(n, d, world, symm, seed, thresh):
+    X = make_mix(n, d, seed)
+    pargs = (12, 30, thresh, None, 1.0, None, symm, 0.7 if symm == "mnn" else None, 0)
+    K, P, used, stats = sharded_local_build(X, world, pargs)
+    assert all(used), "the local candidate pass did not apply on every rank: %r" % (used,)
+    K1, P1 = single_build(X, pargs)
+    _same(K, K1)
+    _same(P, P1)
+
+
+def test_one_rank_build_on_renumbered_points_returns_the_callers_columns():
+    """gt_graph_build on a renumbered context: rows in the new order, the caller's column numbers, same bits"""
+    from graphtools_amd import _hip
+
+    X = make_mix(30000, 64, 4)
+    pargs = (15, 40, 1e-4, None, 1.0, None, "+", None, 0)
+    c = _ctx({})
+    c.set_points(X)
+    assert c.points_cell_sort()
+    p, keep = c.make_params(*pargs)
+    nnz, flags = c.graph_build(p)
+    d_, i_, p_ = c.graph_fetch_csr(_hip.CSR_K)
+    pd_, _, _ = c.graph_fetch_csr(_hip.CSR_P)
+    rows = c.points_row_ids(0, X.shape[0])
+    deg = c.graph_fetch_vec(1)
+    c.close()
+    inv = np.empty(len(rows), dtype=np.int64)
+    inv[rows] = np.arange(len(rows))
+    n = X.shape[0]
+    K = sparse.csr_matrix((d_, i_, p_), shape=(n, n))[inv]
+    P = sparse.csr_matrix((pd_, i_, p_), shape=(n, n))[inv]
+    K1, P1 = single_build(X, pargs)
+    _same(K, K1)
+    _same(P, P1)
+    assert np.array_equal(np.asarray(K1.sum(axis=1)).ravel()[rows], deg) or np.allclose(np.asarray(K1.sum(axis=1)).ravel()[rows], deg, rtol=1e-14)
+
+
+def test_anisotropy_and_vector_bandwidth_follow_the_renumbering():
+    """per-row inputs (a bandwidth per row) and per-column ones (the degrees behind the anisotropy) are the CALLER's"""
+    X = make_mix(20000, 32, 6)
+    bw = np.random.default_rng(6).uniform(5.5, 7.5, size=X.shape[0])
+    pargs = (10, 20, 1e-4, bw, 1.0, None, "+", None, 0.5)
+    # two ranks: the degrees of all rows in the caller's numbering, as dist.py hands them over
+    from graphtools_amd import _hip
+
+    world, n = 2, X.shape[0]
+    ctxs = [_ctx({}) for _ in range(world)]
+    for c in ctxs:
+        c.set_points(X)
+        assert c.points_cell_sort()
+    p, keep = ctxs[0].make_params(*pargs)
+    splits = ctxs[0].points_shard_splits(world)
+    sends, counts = [], []
+    for r, c in enumerate(ctxs):
+        c.graph_shard_local(p, world, r, splits)
+        cnt = c.graph_begin(p, world, r, splits)
+        host = np.zeros(int(cnt.sum()), dtype=TRIP)
+        buf = c.dev_alloc(max(len(host), 1) * 16)
+        c.graph_emit(buf)
+        if len(host):
+            c.dev_download(host, buf)
+        c.dev_free(buf)
+        sends.append(host)
+        counts.append(cnt)
+    deg_caller = np.zeros(n)
+    for r, (c, recv) in enumerate(zip(ctxs, _exchange(sends, counts, world))):
+        buf = c.dev_alloc(max(len(recv), 1) * 16)
+        c.dev_upload(buf, recv)
+        c.graph_finish(buf, len(recv))
+        c.dev_free(buf)
+        deg_caller[c.points_row_ids(splits[r], splits[r + 1])] = c.graph_fetch_vec(1)
+    blocks_K, blocks_P, rows_all = [], [], []
+    for r, c in enumerate(ctxs):
+        dbuf = c.dev_alloc(n * 8)
+        c.dev_upload(dbuf, deg_caller)
+        c.graph_anisotropy(dbuf)
+        c.dev_free(dbuf)
+        d_, i_, p_ = c.graph_fetch_csr(_hip.CSR_K)
+        pd_, _, _ = c.graph_fetch_csr(_hip.CSR_P)
+        rows_all.append(c.points_row_ids(splits[r], splits[r + 1]))
+        blocks_K.append(sparse.csr_matrix((d_, i_, p_), shape=(splits[r + 1] - splits[r], n)))
+        blocks_P.append(sparse.csr_matrix((pd_, i_, p_), shape=(splits[r + 1] - splits[r], n)))
+        c.close()
+    rows = np.concatenate(rows_all)
+    inv = np.empty(n, dtype=np.int64)
+    inv[rows] = np.arange(n)
+    K = sparse.vstack(blocks_K).tocsr()[inv]
+    P = sparse.vstack(blocks_P).tocsr()[inv]
+    K1, P1 = single_build(X, pargs)
+    _same(K, K1)
+    _same(P, P1)
+
+
+def test_a_rank_may_take_the_classic_pass_on_its_own():
+    """nothing is shared before the triplets: a rank whose cell bounds leave too many units (here: a cap of 50) builds its
+    rows with the classic candidate pass while its peers use their local lists - the graph is the same; isotropic points
+    (whatever each rank decides) likewise"""
+    X = make_mix(24000, 64, 7)
+    pargs = (12, 30, 1e-4, None, 1.0, None, "+", None, 0)
+    K1, P1 = single_build(X, pargs)
+    K, P, used, stats = sharded_local_build(X, 3, pargs, opts=[{}, {"select_sym_bound_cap": 50}, {}])
+    assert used == [True, False, True]
+    _same(K, K1)
+    _same(P, P1)
+    K, P, used, stats = sharded_local_build(X, 2, pargs, opts={"select_sym_bound_cap": 50})
+    assert not any(used)
+    _same(K, K1)
+    _same(P, P1)
+    X = make_gauss(20000, 24, 7)
+    pargs = (8, 30, 1e-4, None, 1.0, None, "+", None, 0)
+    K, P, used, stats = sharded_local_build(X, 2, pargs, opts={"select_symmetric": "auto", "select_sym_min_rows": 1})
+    K1, P1 = single_build(X, pargs)
+    _same(K, K1)
+    _same(P, P1)
+
+
+def test_manifold_rows_and_small_lists():
+    """overflowing lists (repairs on the owner) and a curled manifold (the bound pass leaves more units: still the same graph)"""
+    X = make_manifold(30000, 64, 8)
+    pargs = (15, 40, 1e-4, None, 1.0, None, "+", None, 0)
+    K, P, used, stats = sharded_local_build(X, 3, pargs)
+    K1, P1 = single_build(X, pargs)
+    _same(K, K1)
+    _same(P, P1)
+    X = make_mix(20000, 32, 9)
+    K, P, used, stats = sharded_local_build(X, 2, pargs, opts={"select_sym_tcap": 64})
+    assert all(used)
+    assert sum(s[0]["sym_overflow_rows"] for s in stats) > 100
+    K1, P1 = single_build(X, pargs)
+    _same(K, K1)
+    _same(P, P1)

@@ -1,0 +1,136 @@
+#!/usr/bin/env python
+"""Per-rank critical path of the row-sharded build on renumbered points (gt_points_cell_sort / gt_graph_shard_local),
+simulated on ONE GPU: a context plays every rank in turn (set_points on the gathered points, renumbering, local candidate
+lists, affinities, triplet emit); the all-to-all is done by hand through the host; then rank `who` runs its whole sequence
+back to back, timed - everything a rank computes between the points all-gather and its finished rows of K and P.  What is
+NOT in the number: the two collectives themselves (sizes are reported).
+
+usage: gpu_shard_local_probe.py [n] [d] [world] [kind] [out.json]      (GT_WHO = rank to time, GT_OPTS = k=v,k=v)"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from graphtools_amd import _hip  # noqa: E402
+from bench import make_gauss, make_manifold, make_mix  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
+d = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+world = int(sys.argv[3]) if len(sys.argv) > 3 else 8
+kind = sys.argv[4] if len(sys.argv) > 4 else "mix"
+out_path = sys.argv[5] if len(sys.argv) > 5 else None
+who = int(os.environ.get("GT_WHO", "0"))
+X = {"mix": make_mix, "gauss": make_gauss, "manifold": make_manifold}[kind](n, d, 1)
+TRIP = np.dtype([("row", np.uint32), ("col", np.uint32), ("val", np.float64)])
+STAGES = ["prep", "query_order", "renumber", "sym_prepare", "sym_seed", "sym_bound", "sym_cold", "knn_select", "rerank", "fallback",
+          "radius", "affinity", "symmetrize", "symm_merge", "symm_compact", "normalize"]
+
+ctx = _hip.Context(0)
+for o in [o for o in os.environ.get("GT_OPTS", "").split(",") if o]:
+    k, v = o.split("=")
+    ctx.set_option(k, v)
+p, keep = ctx.make_params(15, 40.0, 1e-4, None, 1.0, None, "+", None, 0)
+
+# the single-rank build of the same graph on this GPU (device-complete, points resident): the 1-GPU time of the scaling ratio
+xb = ctx.dev_alloc(X.nbytes)
+ctx.dev_upload(xb, X)
+single = []
+for _ in range(3):
+    ctx.sync()
+    t = time.perf_counter()
+    ctx.set_points_device(xb, n, d, np.float32)
+    nnz1, _ = ctx.graph_build(p)
+    ctx.sync()
+    single.append((time.perf_counter() - t) * 1e3)
+single_ms = min(single)
+single_stage = {s: round(ctx.stage_ms(s), 3) for s in STAGES if ctx.stage_ms(s) > 0}
+
+
+def rank_until_emit(r, timed=False):
+    """set_points .. emit for rank r; -> (send_counts, device buffer of the triplets, wall ms by phase, stage ms, used)"""
+    ctx.sync()
+    t0 = time.perf_counter()
+    ctx.set_points_device(xb, n, d, np.float32)
+    applied = ctx.points_cell_sort()
+    ctx.sync()
+    t1 = time.perf_counter()
+    st0 = {s: ctx.stage_ms(s) for s in ("prep", "query_order", "renumber")}
+    splits = ctx.points_shard_splits(world)
+    used = ctx.graph_shard_local(p, world, r, splits)
+    ctx.sync()
+    t2 = time.perf_counter()
+    sc = ctx.graph_begin(p, world, r, splits)
+    ctx.sync()
+    t3 = time.perf_counter()
+    buf = ctx.dev_alloc(max(int(sc.sum()), 1) * 16)
+    ctx.graph_emit(buf)
+    ctx.sync()
+    t4 = time.perf_counter()
+    wall = {"set_points+renumber": (t1 - t0) * 1e3, "local_lists": (t2 - t1) * 1e3, "begin(rerank+affinity)": (t3 - t2) * 1e3,
+            "emit": (t4 - t3) * 1e3}
+    st = {s: max(ctx.stage_ms(s), 0.0) for s in STAGES}
+    for s, v in st0.items():
+        st[s] = max(v, 0.0)
+    return sc, buf, wall, st, used, applied, splits
+
+
+# every rank once: what rank `who` will receive
+recv_parts, send_totals, used_all = [], [], []
+for r in range(world):
+    sc, buf, wall, st, used, applied, splits = rank_until_emit(r)
+    off = int(sc[:who].sum())
+    host = np.zeros(int(sc[who]), dtype=TRIP)
+    if len(host):
+        ctx.dev_download(host, buf + off * 16)
+    ctx.dev_free(buf)
+    recv_parts.append(host)
+    send_totals.append(int(sc.sum()))
+    used_all.append(bool(used))
+recv = np.concatenate(recv_parts)
+rb = ctx.dev_alloc(max(len(recv), 1) * 16)
+if len(recv):
+    ctx.dev_upload(rb, recv)
+
+runs = []
+for rep in range(int(os.environ.get("GT_REPS", "4"))):
+    sc, buf, wall, st, used, applied, splits = rank_until_emit(who)
+    t0 = time.perf_counter()
+    nnz, flags = ctx.graph_finish(rb, len(recv))
+    ctx.sync()
+    wall["finish(merge+P)"] = (time.perf_counter() - t0) * 1e3
+    for s in ("symmetrize", "symm_merge", "symm_compact", "normalize"):
+        st[s] = max(ctx.stage_ms(s), 0.0)
+    ctx.dev_free(buf)
+    wall["total"] = sum(wall.values())
+    runs.append({"wall_ms": {k: round(v, 3) for k, v in wall.items()}, "stage_ms": {k: round(v, 3) for k, v in st.items() if v > 0},
+                 "nnz_rows_of_rank": int(nnz)})
+best = min(runs[1:] or runs, key=lambda r: r["wall_ms"]["total"])
+rows_who = int(splits[who + 1] - splits[who])
+out = {
+    "what": "row-sharded build on renumbered points, per-rank critical path simulated on one MI355X (one context plays every "
+            "rank in turn; the collectives are NOT in the time, their sizes are below)",
+    "workload": "%s N=%d d=%d float32 seed=1, knn=15 decay=40 thresh=1e-4, world %d, rank %d (%d rows)" % (kind, n, d, world, who, rows_who),
+    "renumbering_applied": bool(applied), "local_lists_used_by_rank": used_all,
+    "single_rank_ms": round(single_ms, 3), "single_rank_stage_ms": single_stage, "nnz_single": int(nnz1),
+    "per_rank": best, "per_rank_all_runs_total_ms": [r["wall_ms"]["total"] for r in runs],
+    "speedup_before_collectives": round(single_ms / best["wall_ms"]["total"], 2),
+    "collectives": {
+        "all_gather_points_bytes_total": int(X.nbytes),
+        "all_to_all_counts_bytes": 8 * world,
+        "all_to_all_triplets_bytes_sent_by_rank": int(send_totals[who]) * 16,
+        "all_to_all_triplets_bytes_received_by_rank": int(len(recv)) * 16,
+        "candidate_record_exchange_bytes": 0,
+        "threshold_all_gather_bytes": 0,
+        "number_of_collectives": 3,
+    },
+    "triplets_sent_by_every_rank": send_totals,
+}
+print(json.dumps(out), flush=True)
+if out_path:
+    os.makedirs(os.path.dirname(os.path.abspath(out_path)), exist_ok=True)
+    with open(out_path, "w") as f:
+        json.dump(out, f, indent=1)

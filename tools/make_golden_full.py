@@ -1,0 +1,103 @@
+#!/usr/bin/env python
+"""Pin the BASELINE sizes to the REAL reference: build C2 (mix N=1e5, d=50, seed 0) and C3 (mix N=1e6, d=64, seed 1)
+with the reference imported from /root/reference (tools/ref_import.py) and keep compact fixtures of the results:
+
+  row_len      uint16[N]   entries per row of K (= of P); indptr is its running sum
+  row_hash     uint32[N]   per-row checksum of the sorted column indices: sum_j (col_j + 1) * 2654435761 mod 2^32
+  sha256       bytes       sha-256 of K.indices as little-endian int32 (whole-matrix structure hash)
+  degree       float64[N]  kernel_degree = row sums of K (graphs base.py:648-660)
+  sample_{i,j,K,P}         10^5 stored entries drawn uniformly (default_rng(12345)) with their K and P values
+  nnz, time_s, versions
+
+Only inputs' recipe (seeded generator) and outputs are written; no reference text travels.  Runs only in the build
+container: `python tools/make_golden_full.py c2` (about 15 s) / `c3` (about 20 minutes, 8 cores, ~25 GB of RAM).
+"""
+import hashlib
+import os
+import sys
+import time
+import warnings
+
+import numpy as np
+from scipy import sparse
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+
+from ref_import import import_reference  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+CONFIGS = {"c2": dict(n=100000, d=50, seed=0), "c3": dict(n=1000000, d=64, seed=1)}
+
+
+def make_mix(n, d, seed, dtype=np.float32):
+    # bench.py's generator (chunked; the same stream of draws as tests/conftest.make_mix)
+    rng = np.random.default_rng(seed)
+    c = max(n // 2000, 1)
+    centres = rng.uniform(-10, 10, (c, d))
+    labels = rng.integers(c, size=n)
+    out = np.empty((n, d), dtype=dtype)
+    step = 100000
+    for s in range(0, n, step):
+        e = min(n, s + step)
+        out[s:e] = centres[labels[s:e]] + rng.standard_normal((e - s, d))
+    return out
+
+
+def row_hash(indices, indptr):
+    h = ((indices.astype(np.uint64) + np.uint64(1)) * np.uint64(2654435761)) & np.uint64(0xFFFFFFFF)
+    cs = np.zeros(len(h) + 1, dtype=np.uint64)
+    np.cumsum(h, dtype=np.uint64, out=cs[1:])            # (wraps modulo 2^64: differences stay exact modulo 2^32)
+    return ((cs[indptr[1:]] - cs[indptr[:-1]]) & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+
+
+def build(tag):
+    cfg = CONFIGS[tag]
+    gt = import_reference()
+    X = make_mix(cfg["n"], cfg["d"], cfg["seed"])
+    t0 = time.perf_counter()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        G = gt.Graph(X, knn=15, decay=40, n_pca=None, verbose=0, random_state=42)
+        K = sparse.csr_matrix(G.K)
+        t1 = time.perf_counter()
+        P = sparse.csr_matrix(G.P)
+    t2 = time.perf_counter()
+    assert type(G).__name__ == "kNNGraph"
+    K.sort_indices()
+    P.sort_indices()
+    assert np.array_equal(K.indices, P.indices) and np.array_equal(K.indptr, P.indptr)
+    n = K.shape[0]
+    row_len = np.diff(K.indptr)
+    assert row_len.max() < 65536
+    degree = np.asarray(K.sum(axis=1)).ravel()   # base.py:659 kernel_degree (matrix row sums)
+    rng = np.random.default_rng(12345)
+    pos = np.sort(rng.choice(K.nnz, size=100000, replace=False))
+    rows = np.searchsorted(K.indptr, pos, side="right") - 1
+    import scipy
+    import sklearn
+
+    out = {
+        "n": np.int64(n), "d": np.int64(cfg["d"]), "seed": np.int64(cfg["seed"]), "knn": np.int64(15), "decay": np.float64(40),
+        "thresh": np.float64(1e-4), "nnz": np.int64(K.nnz),
+        "row_len": row_len.astype(np.uint16), "row_hash": row_hash(K.indices, K.indptr),
+        "sha256_indices": np.frombuffer(hashlib.sha256(K.indices.astype("<i4").tobytes()).digest(), dtype=np.uint8),
+        "degree": degree.astype(np.float64),
+        "sample_i": rows.astype(np.int32), "sample_j": K.indices[pos].astype(np.int32),
+        "sample_K": K.data[pos].astype(np.float64), "sample_P": P.data[pos].astype(np.float64),
+        "time_kernel_s": np.float64(t1 - t0), "time_total_s": np.float64(t2 - t0), "cores": np.int64(os.cpu_count()),
+        "versions": np.array("graphtools %s numpy %s scipy %s sklearn %s" % (gt.__version__, np.__version__, scipy.__version__,
+                                                                             sklearn.__version__)),
+    }
+    path = os.path.join(OUT, "full_%s_reference.npz" % tag)
+    np.savez_compressed(path, **out)
+    print("%s: N=%d nnz=%d  reference wall %.1f s (kernel %.1f s)  fixture %.2f MB" % (
+        tag, n, K.nnz, t2 - t0, t1 - t0, os.path.getsize(path) / 1e6), flush=True)
+
+
+if __name__ == "__main__":
+    for tag in sys.argv[1:] or ["c2"]:
+        build(tag)
