@@ -467,6 +467,10 @@ def main():
     ap.add_argument("--dim", type=int, default=64)
     ap.add_argument("--knn", type=int, default=15)
     ap.add_argument("--decay", type=float, default=40.0)
+    ap.add_argument("--workload", choices=["c3", "gauss", "c5"], default="c3",
+                    help="c3 (default): the headline.  gauss: the same build on isotropic points (nothing to prune: the dense "
+                         "contraction runs, sharded by row blocks).  c5: BASELINE config 5, mix N=1e6 d=50 + landmark operator "
+                         "(n_landmark=2000, random landmarking).  Both exist for the N > 1 legs: --gpus N --workload gauss|c5")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-full", action="store_true", help="time the oracle port on ALL rows of the workload (minutes)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary workloads / host-complete legs")
@@ -498,7 +502,14 @@ def main():
         dist.init_process_group("nccl")
     n, d = args.npoints, args.dim
     thresh = 1e-4
-    X = make_mix(n, d, 1)
+    if args.workload == "c5":
+        d = 50
+        X = make_mix(n, d, 3)
+    elif args.workload == "gauss":
+        X = make_gauss(n, d, 1)
+    else:
+        X = make_mix(n, d, 1)
+    n_landmark = 2000
     ctx = _hip.Context(local_rank)
     ctx.set_option("knn_precision", args.knn_precision)
 
@@ -511,12 +522,36 @@ def main():
     sharded = gdist.ShardedKnnGraph(ctx, n) if distributed else None
     torch.cuda.synchronize(device)
 
+    landmark_out = {}
+
     def step():
         if distributed:
             sharded.gather_points(x_local)
-            return sharded.build(params)
+            res = sharded.build(params)
+            if args.workload == "c5":
+                # random landmarking (graphs.py:1200-1213) + the landmark operator (graphs.py:1169-1246) over the ranks:
+                # an all-gather of the cluster labels, an all-reduce of the L x L partial products
+                clusters = sharded.random_landmark_clusters(n_landmark, 42)
+                landmark_out["op"], landmark_out["tnnz"] = sharded.landmark_operator(clusters, n_landmark)
+            return res
         ctx.set_points_device(x_local.data_ptr(), n, d, np.float32)
-        return ctx.graph_build(params)
+        res = ctx.graph_build(params)
+        if args.workload == "c5":
+            # random landmarking as graphtools_amd.graphs.LandmarkGraph does it on one GPU: 1-NN of every row against the
+            # L landmark rows on the MFMA path (sklearn's euclidean_distances arithmetic, graphs.py:1210)
+            landmarks = np.random.default_rng(42).choice(n, n_landmark, replace=False)
+            lm_rows = x_local[torch.as_tensor(landmarks, device=device)].contiguous()
+            torch.cuda.synchronize(device)
+            lm_ctx = _hip.Context(local_rank)
+            try:
+                lm_ctx.set_points_device(lm_rows.data_ptr(), n_landmark, d, np.float32)
+                d_, idx, _ = lm_ctx.knn_search_device(4, x_local.data_ptr(), n)
+            finally:
+                lm_ctx.close()
+            clusters = np.where(d_ == d_[:, :1], idx, np.iinfo(np.int64).max).min(axis=1).astype(np.int32)
+            M, R, landmark_out["tnnz"] = ctx.landmark_build(clusters, n_landmark)
+            landmark_out["op"] = ctx.landmark_scale(M, R)
+        return res
 
     def fence():
         torch.cuda.synchronize(device)
@@ -557,7 +592,7 @@ def main():
         roof = {k: dominant[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_ms")}
         roof["stage"] = dominant["stage"]
         roof["share_of_step"] = dominant["avg_launch_ms"] / ms_per_step
-        roof["traffic"] = profiled_traffic([dominant["kernel"].split(" ")[0]]) if (n == 1000000 and d == 64 and world == 1) else None
+        roof["traffic"] = profiled_traffic([dominant["kernel"].split(" ")[0]]) if (n == 1000000 and d == 64 and world == 1 and args.workload == "c3") else None
         roof["traffic_unit"] = "bytes/launch"
         roof["work_per_launch"] = dominant.get("executed_flop", dominant.get("algorithmic_bytes"))
         executed = sum(r.get("executed_flop", 0.0) for r in rows)
@@ -567,9 +602,19 @@ def main():
                       + 2.0 * nnz0 * 12.0 + nnz * 12.0 + nnz * 12.0 + nnz * 8.0)
         tail_counter = profiled_traffic(["bandwidth_kernel", "affinity_kernel", "bin_", "sort_merge_kernel", "sort_merge_long_kernel",
                                          "compact_kernel", "merge_final_kernel", "merge_long_final_kernel", "pairs_len_kernel", "scan_",
-                                         "gather_counts_kernel", "scatter_", "invperm_kernel"], per="graph") if (n == 1000000 and d == 64 and world == 1) else None
+                                         "gather_counts_kernel", "scatter_", "invperm_kernel"], per="graph") if (n == 1000000 and d == 64 and world == 1 and args.workload == "c3") else None
+        wl_name = {"c3": "C3: mix N=%d d=%d float32 seed=1, kNNGraph knn=%d decay=%g thresh=1e-4, kernel_symm='+', points resident "
+                         "in HBM, device-complete K and P" % (n, d, args.knn, args.decay),
+                   "gauss": "gauss: isotropic N=%d d=%d float32 seed=1 (no structure to prune: the classic candidate pass scores "
+                            "every query row of a rank against every point), kNNGraph knn=%d decay=%g thresh=1e-4, device-complete "
+                            "K and P" % (n, d, args.knn, args.decay),
+                   "c5": "C5: mix N=%d d=%d float32 seed=3, kNNGraph knn=%d decay=%g + LandmarkGraph n_landmark=%d random "
+                         "landmarking (random_state=42): K, P on the device, landmark_op (L x L) on the host"
+                         % (n, d, args.knn, args.decay, n_landmark)}[args.workload]
         out = {
-            "metric": "graphs/sec (kernel+diff_op) at N=1e6 d=64 k=15",
+            "metric": {"c3": "graphs/sec (kernel+diff_op) at N=1e6 d=64 k=15",
+                       "gauss": "graphs/sec (kernel+diff_op) at N=1e6 d=64 k=15, isotropic input",
+                       "c5": "graphs/sec (kernel+diff_op+landmark_op) at N=1e6 d=50 k=15 n_landmark=2000"}[args.workload],
             "value": args.steps / elapsed,
             "unit": "graphs/s",
             "n_gpus": world,
@@ -581,9 +626,12 @@ def main():
             "vs_baseline": None,   # the reference publishes no number for this metric
             "dtype": {"f16x1": "f16", "f16": "f16x2-split", "f32": "f32"}[main_prec] + " MFMA candidate filter (proven error bound) + f64 re-rank/affinities: every emitted value is float64 as in the reference",
             "data": "synthetic",
-            "config": {"workload": "C3: mix N=%d d=%d float32 seed=1, kNNGraph knn=%d decay=%g thresh=1e-4, "
-                                   "kernel_symm='+', points resident in HBM, device-complete K and P" % (n, d, args.knn, args.decay),
-                       "row_sharding": "%d rank(s) x %d rows" % (world, nloc), "nnz_K": nnz_total, "nnz_K0_rank0": nnz0,
+            "config": {"workload": wl_name,
+                       "row_sharding": ("%d rank(s) x ~%d rows" % (world, nloc)) + (
+                           "; rows renumbered by landmark cell, candidate lists collected by the owner (no candidate exchange); "
+                           "collectives per graph: points all-gather, triplet counts, triplet all-to-all"
+                           if (distributed and sharded.renumbered) else ""),
+                       "nnz_K": nnz_total, "nnz_K0_rank0": nnz0,
                        "radius_rows_rank0": stats["radius_rows"], "fallback_rows_rank0": stats["fallback_rows"],
                        "symmetric_candidate_pass": flags_["symmetric"], "two_stage_collect": flags_["two_stage"],
                        "bound_pass": flags_["bound_pass"]},
@@ -601,8 +649,12 @@ def main():
                                 "unnecessary; a pruning ratio, not a roofline figure"},
             "stage_ms": {s: round(st.mean(s), 3) for s in STAGES if st.mean(s) > 0},
         }
+        if args.workload == "c5" and "op" in landmark_out:
+            op = np.asarray(landmark_out["op"])
+            out["config"]["landmark_op"] = {"shape": list(op.shape), "row_sums_max_abs_dev_from_1": float(np.abs(op.sum(axis=1) - 1.0).max()),
+                                            "transitions_nnz_rank0": int(landmark_out.get("tnnz", 0))}
         info = host_info()
-        single = world == 1 and not distributed
+        single = world == 1 and not distributed and args.workload == "c3"
         if single:
             # ---- the same step with the upload of X inside the timed region (pinned host memory) ----
             try:

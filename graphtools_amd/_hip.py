@@ -73,6 +73,8 @@ _SIGNATURES = {
     "gt_points_cell_sort": (_c.c_int, [_c.c_void_p, _c.POINTER(_c.c_int32)]),
     "gt_points_shard_splits": (_c.c_int, [_c.c_void_p, _c.c_int32, _c.c_void_p]),
     "gt_points_row_ids": (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_int64, _c.c_void_p, _c.c_int32]),
+    "gt_points_device": (_c.c_int, [_c.c_void_p, _c.c_int64, _c.POINTER(_c.c_void_p), _c.POINTER(_c.c_int32),
+                                    _c.POINTER(_c.c_int32)]),
     "gt_graph_shard_local": (_c.c_int, [_c.c_void_p, _c.POINTER(KnnParams), _c.c_int32, _c.c_int32, _c.c_void_p,
                                         _c.POINTER(_c.c_int32)]),
     "gt_graph_finish": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64, _c.POINTER(_c.c_int64), _c.POINTER(_c.c_uint32)]),
@@ -238,6 +240,21 @@ class Context:
         )
 
     # ---- kNN --------------------------------------------------------------------------------
+    def points_device(self, row0=0):
+        """device address of row `row0` of the bound points as the context holds them"""
+        p = ctypes.c_void_p()
+        self._check(self.lib.gt_points_device(self.h, int(row0), ctypes.byref(p), None, None), "gt_points_device")
+        return p.value
+
+    def knn_search_device(self, k, y_dev_ptr, m):
+        """gt_knn_search with a device-resident query matrix (m rows of the bound points' dtype and width)"""
+        idx = np.empty((m, k), dtype=np.int64)
+        dist = np.empty((m, k), dtype=np.float64)
+        flags = ctypes.c_uint32(0)
+        self._check(self.lib.gt_knn_search(self.h, 0, 0, ctypes.c_void_p(int(y_dev_ptr)), int(m), 1, int(k), _ptr(idx), _ptr(dist), 0,
+                                           ctypes.byref(flags)), "gt_knn_search")
+        return dist, idx, flags.value
+
     def knn_search(self, k, rows=None, Y=None):
         """(distances float64 [m,k], indices int64 [m,k], flags)"""
         if Y is not None:

@@ -275,8 +275,26 @@ extern "C" int gt_points_shard_splits(gt_ctx* ctx, int32_t world, int64_t* out_s
     if (!ctx || !out_splits || world < 1) return GT_E_ARG;
     if (ctx->n <= 0) GT_FAIL(ctx, GT_E_STATE, "gt_points_shard_splits: no points bound");
     const int64_t nb = ceil_div64(ctx->n, 1024);
-    for (int r = 0; r <= world; ++r) out_splits[r] = std::min<int64_t>(ctx->n, (nb * r / world) * 1024);
+    if (nb >= int64_t(2) * world) {
+        for (int r = 0; r <= world; ++r) out_splits[r] = std::min<int64_t>(ctx->n, (nb * r / world) * 1024);
+    } else {
+        // a handful of blocks: even runs of rows (gt_graph_shard_local declines, the classic pass serves such sets)
+        for (int r = 0; r <= world; ++r) out_splits[r] = ctx->n * r / world;
+    }
     out_splits[world] = ctx->n;
+    return GT_OK;
+}
+
+// device address of row `row0` of the bound points as the context holds them (its own numbering, the caller's dtype;
+// cosine: the normalised rows) - for device-to-device hand-offs (e.g. a rank's rows as the query matrix of another context)
+extern "C" int gt_points_device(gt_ctx* ctx, int64_t row0, void** out, int32_t* out_dtype, int32_t* out_d) {
+    if (!ctx || !out) return GT_E_ARG;
+    if (ctx->n <= 0 || !ctx->X) GT_FAIL(ctx, GT_E_STATE, "gt_points_device: no points bound");
+    if (row0 < 0 || row0 >= ctx->n) GT_FAIL(ctx, GT_E_ARG, "gt_points_device: row out of range");
+    const size_t esz = ctx->dtype == GT_F32 ? 4 : 8;
+    *out = const_cast<char*>(static_cast<const char*>(ctx->X)) + size_t(row0) * size_t(ctx->d) * esz;
+    if (out_dtype) *out_dtype = ctx->dtype;
+    if (out_d) *out_d = ctx->d;
     return GT_OK;
 }
 

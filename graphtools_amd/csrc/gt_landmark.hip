@@ -16,6 +16,8 @@
 #include "gt_device.h"
 #include "gt_graph_state.h"
 
+#include <vector>
+
 struct LandmarkState {
     int32_t L = 0;
     int64_t nloc = 0, tnnz = 0;
@@ -483,6 +485,18 @@ extern "C" int gt_nearest_landmark(gt_ctx* ctx, int64_t row0, int64_t row1, cons
     DevBuf lmk, out;
     GT_HIP(ctx, lmk.reserve(size_t(n_landmark) * sizeof(int64_t)));
     GT_HIP(ctx, out.reserve(size_t(nrows) * sizeof(int32_t)));
+    std::vector<int64_t> lm_ctx;
+    if (ctx->presorted) {
+        // renumbered points (gt_points_cell_sort): [row0, row1) are rows of the context, the landmarks are the CALLER's row
+        // numbers - looked up through the inverse of the renumbering
+        std::vector<int32_t> vperm(size_t(ctx->n)), inv(size_t(ctx->n));
+        GT_HIP(ctx, hipMemcpyAsync(vperm.data(), ctx->vperm.p, size_t(ctx->n) * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+        GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (int64_t v = 0; v < ctx->n; ++v) inv[size_t(vperm[size_t(v)])] = int32_t(v);
+        lm_ctx.resize(size_t(n_landmark));
+        for (int j = 0; j < n_landmark; ++j) lm_ctx[size_t(j)] = inv[size_t(landmarks[j])];
+        landmarks = lm_ctx.data();
+    }
     GT_HIP(ctx, hipMemcpyAsync(lmk.p, landmarks, size_t(n_landmark) * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
     const size_t lds = (size_t(32) * ctx->d + 32) * sizeof(double);
     {

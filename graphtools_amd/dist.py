@@ -1,17 +1,24 @@
 """Row-sharded multi-GPU build: one process per GPU, ``torch.distributed`` over RCCL/xGMI.
 
-The N x N affinity build shards by row blocks: rank g owns rows
-``[splits[g], splits[g+1])`` and every rank needs all N points as the database side.
+The N x N affinity build shards by row blocks; every rank needs all N points as the database side.
 
-  1. all-gather of the points        (each rank contributes its row slice; RCCL all-gather)
-  1b. symmetric candidate pass       gt_graph_sym_*: every unordered row pair scored once, 1/world of them per rank;
-                                      all-gather of per-row thresholds (4 B per row), all-to-all of candidate records
-                                      (skipped, on all ranks alike, where the pass does not apply)
-  2. local work                      gt_graph_begin: kNN -> bandwidth -> radius pass -> affinities
-  3. all-to-all of transposed triplets {row, col, value} (16 B each) bucketed by the owner of ``row``
-                                      gt_graph_emit fills the send buffer, RCCL all-to-all moves it
-  4. local merge + normalisation     gt_graph_finish  (anisotropy: + one all-gather of the degrees)
+  1. all-gather of the points        (each rank contributes its row slice; RCCL all-gather) - collective 1
+  2. renumbering                     gt_points_cell_sort: every rank renumbers the gathered points by landmark cell (the
+                                      same deterministic numbering everywhere, no communication) and owns a run of whole
+                                      cells: rows ``[splits[g], splits[g+1])`` of the NEW numbering (``row_ids()`` gives
+                                      the caller's row numbers; the CSR's columns are the caller's numbers already)
+  3. local work                      gt_graph_shard_local: the candidate lists of the rank's own rows, collected by the
+                                      rank itself - no thresholds or candidate records travel (a rank may decline and run
+                                      the classic pass for its rows: nothing is shared); gt_graph_begin: re-rank ->
+                                      bandwidth -> radius pass -> affinities
+  4. all-to-all of transposed triplets {row, col, value} (16 B each) bucketed by the owner of ``row`` - collectives 2
+                                      (counts, 8 B per peer) and 3 (the triplets)
+  5. local merge + normalisation     gt_graph_finish  (anisotropy: + one all-gather of the degrees)
   landmark operator: all-reduce(sum) of the L x L partial products and the L partial row sums.
+
+Where the renumbering does not apply (a few thousand points, more than 128 features, ``renumber=False``) the rows keep the
+caller's numbering and the staged symmetric pass of rounds 2-3 runs instead (gt_graph_sym_*: 1/world of the pair scores per
+rank, an all-gather of thresholds and an all-to-all of candidate records in front of step 3).
 
 torch is used for device buffers and collectives only; all numerics are in libgraphtools_amd.so.
 The communication helpers work on CPU tensors with the gloo backend too (tests/test_dist_cpu.py).
@@ -153,25 +160,57 @@ class ShardedKnnGraph(object):
     of K and P is resident on the device (``ctx.graph_fetch_csr`` copies it to the host).
     """
 
-    def __init__(self, ctx, n_total, group=None):
+    def __init__(self, ctx, n_total, group=None, renumber=True):
         dist = _dist()
         self.ctx = ctx
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.n = int(n_total)
-        self.splits = even_row_splits(self.n, self.world)
+        self.renumber = bool(renumber)
+        self.renumbered = False
+        # the split of the caller's rows (who contributes which slice to the all-gather; also the ownership when the points
+        # keep the caller's numbering)
+        self.input_splits = even_row_splits(self.n, self.world)
+        self.splits = self.input_splits
+        self._row_ids_all = None
 
     def gather_points(self, x_local):
-        """RCCL all-gather of the row slices; binds the full matrix (kept alive on self) to the context."""
+        """RCCL all-gather of the row slices; binds the full matrix to the context and renumbers it by landmark cell
+        (``self.renumbered``; ``self.splits`` then are rows of the new numbering, ``row_ids()`` maps them back)."""
         import torch
 
-        full = allgather_rows(x_local, self.splits, self.group)
+        full = allgather_rows(x_local, self.input_splits, self.group)
         _order_after_collectives(self.ctx, full)
         self._points = full
+        self._device = full.device
         self.ctx.set_points_device(full.data_ptr(), full.shape[0], full.shape[1],
                                    np.float32 if full.dtype == torch.float32 else np.float64)
+        self.renumbered = False
+        self.splits = self.input_splits
+        self._row_ids_all = None
+        if self.renumber and hasattr(self.ctx, "points_cell_sort"):
+            # deterministic: the same points and the same kernels give every rank the same numbering (no collective)
+            self.renumbered = bool(self.ctx.points_cell_sort())
+        if self.renumbered:
+            # (the context holds its own, renumbered copy; the gathered matrix stays for row look-ups by the caller's numbers)
+            self.splits = np.asarray(self.ctx.points_shard_splits(self.world), dtype=np.int64)
         return full
+
+    def row_ids(self):
+        """the caller's row numbers of this rank's rows of K and P, in the order of the rows (numpy int64)"""
+        r0, r1 = int(self.splits[self.rank]), int(self.splits[self.rank + 1])
+        if not self.renumbered:
+            return np.arange(r0, r1, dtype=np.int64)
+        return np.asarray(self.ctx.points_row_ids(r0, r1), dtype=np.int64)
+
+    def _all_row_ids(self):
+        import torch
+
+        if self._row_ids_all is None:
+            ids = np.asarray(self.ctx.points_row_ids(0, self.n), dtype=np.int64) if self.renumbered else np.arange(self.n)
+            self._row_ids_all = torch.as_tensor(ids, device=self._device)
+        return self._row_ids_all
 
     def symmetric_candidates(self, params):
         """The symmetric candidate pass split over the ranks (gt_knn_shard.cpp): each rank scores 1/world of the
@@ -182,7 +221,7 @@ class ShardedKnnGraph(object):
 
         dist = _dist()
         ctx = self.ctx
-        device = self._points.device
+        device = self._device
         if not hasattr(ctx, "graph_sym_plan"):
             return False
         ok, n_pad, sorted_splits = ctx.graph_sym_plan(params, self.world, self.rank, self.splits)
@@ -221,21 +260,31 @@ class ShardedKnnGraph(object):
 
         dist = _dist()
         ctx = self.ctx
-        device = self._points.device
+        device = self._device
         # (a single rank has the whole pass in gt_graph_begin; GT_SHARD_SYM_FORCE=1 runs the staged form anyway - development)
         staged = self.world > 1 or os.environ.get("GT_SHARD_SYM_FORCE") == "1"
-        self.symmetric_used = bool(symmetric) and staged and self.symmetric_candidates(params)
+        if self.renumbered:
+            # the rank's own rows' candidate lists, no communication (a rank that declines runs the classic pass on its own)
+            self.symmetric_used = bool(symmetric) and staged and bool(ctx.graph_shard_local(params, self.world, self.rank,
+                                                                                            self.splits))
+        else:
+            self.symmetric_used = bool(symmetric) and staged and self.symmetric_candidates(params)
         if self.world > 1 and getattr(params, "knn_max", -1) > 0 and hasattr(ctx, "graph_stage_counts"):
             # knn_max: the reference's search-expansion loop looks at the rows of the whole point set - the ranks' counts
             # for its steps are summed (one small all-reduce) and handed back before the build
             local = np.zeros(4, dtype=np.int64)
             got = np.asarray(ctx.graph_stage_counts(params, self.world, self.rank, self.splits), dtype=np.int64)
             local[: len(got)] = got
-            tot = torch.as_tensor(np.concatenate([local, [len(got)]]), device=device)
+            # {counts, number of steps, -number of steps}: the sums of the counts, and MIN over the ranks of the last two -
+            # every rank reported the same number of steps iff min(len) == -min(-len) (decided alike on every rank)
+            tot = torch.as_tensor(local, device=device)
             dist.all_reduce(tot, group=self.group)
+            steps = torch.as_tensor(np.array([len(got), -len(got)], dtype=np.int64), device=device)
+            dist.all_reduce(steps, op=dist.ReduceOp.MIN, group=self.group)
             tot = tot.cpu().numpy()
-            if int(tot[4]) == self.world * len(got) and len(got) > 0:     # (every rank reported the same number of steps)
-                ctx.graph_set_stage_totals(tot[: len(got)])
+            steps = steps.cpu().numpy()
+            if int(steps[0]) == -int(steps[1]) and int(steps[0]) > 0:
+                ctx.graph_set_stage_totals(tot[: int(steps[0])])
         send_counts = ctx.graph_begin(params, self.world, self.rank, self.splits)
         total = int(send_counts.sum())
         send = torch.empty(max(total, 1) * WORDS_PER_TRIPLET, dtype=torch.int64, device=device)
@@ -252,18 +301,62 @@ class ShardedKnnGraph(object):
             ctx.graph_fetch_vec_device(1, deg.data_ptr())      # the owned rows' kernel degrees, device to device
             _order_before_collectives(ctx, deg)
             deg_all = allgather_vector(deg, self.splits, self.group).contiguous()
+            if self.renumbered:
+                # the library wants the degrees by the CALLER's row numbers (the columns of its CSR)
+                by_caller = torch.empty_like(deg_all)
+                by_caller[self._all_row_ids()] = deg_all
+                deg_all = by_caller
             _order_after_collectives(ctx, deg_all)
             ctx.graph_anisotropy(deg_all.data_ptr())
         self._keep = (send, recv)
         return nnz, flags
+
+    def random_landmark_clusters(self, n_landmark, random_state):
+        """LandmarkGraph's random landmarking (graphs.py:1200-1213) over the ranks: the landmark rows are drawn on every rank
+        alike (``default_rng(random_state).choice(N, L, replace=False)``, the caller's row numbers), every rank assigns
+        its own rows to their nearest landmark (gt_nearest_landmark), one all-gather of the labels (4 B per row).
+        Returns the cluster label of every row, by the caller's row numbers (numpy int32)."""
+        import torch
+
+        rng = np.random.default_rng(random_state)
+        landmarks = rng.choice(self.n, int(n_landmark), replace=False)
+        r0, r1 = int(self.splits[self.rank]), int(self.splits[self.rank + 1])
+        if self.n > 5000 and hasattr(self.ctx, "points_device") and self._points.is_cuda:
+            # sklearn's euclidean_distances arithmetic (graphs.py:1210): the rank's rows as queries of a 1-NN search against the
+            # L landmark rows on the MFMA path, argmin's first-index rule among the nearest that tie after the float32
+            # rounding (as graphtools_amd.graphs.LandmarkGraph does on one GPU)
+            from . import _hip
+
+            lm_rows = self._points[torch.as_tensor(landmarks, device=self._device)].contiguous()
+            torch.cuda.current_stream(self._device).synchronize()
+            lm_ctx = _hip.Context(self._device.index or 0)
+            try:
+                lm_ctx.set_points_device(lm_rows.data_ptr(), lm_rows.shape[0], lm_rows.shape[1],
+                                         np.float32 if lm_rows.dtype == torch.float32 else np.float64)
+                k = int(min(4, n_landmark))
+                d_, idx, _ = lm_ctx.knn_search_device(k, self.ctx.points_device(r0), r1 - r0)
+            finally:
+                lm_ctx.close()
+            tie = d_ == d_[:, :1]
+            own = np.where(tie, idx, np.iinfo(np.int64).max).min(axis=1).astype(np.int32)
+        else:
+            # small sets: scipy cdist arithmetic (mode 0); larger ones on the exact float64 kernel (mode 1)
+            own = np.asarray(self.ctx.nearest_landmark(landmarks, 1 if self.n > 5000 else 0, rows=(r0, r1)), dtype=np.int32)
+        labels = allgather_vector(torch.as_tensor(own, device=self._device), self.splits, self.group)
+        labels = labels.cpu().numpy()
+        if not self.renumbered:
+            return labels
+        by_caller = np.empty(self.n, dtype=np.int32)
+        by_caller[self._all_row_ids().cpu().numpy()] = labels
+        return by_caller
 
     def landmark_operator(self, clusters, n_landmark):
         """all-reduce of the partial L x L products; returns the finished landmark operator (host array)."""
         import torch
 
         dist = _dist()
-        M, R, tnnz = self.ctx.landmark_build(clusters, n_landmark)
-        device = self._points.device
+        M, R, tnnz = self.ctx.landmark_build(clusters, n_landmark)   # (clusters: by the caller's row numbers = the CSR's columns)
+        device = self._device
         L = int(n_landmark)
         # ONE all-reduce: the L x L partial products with the L partial row sums appended
         buf = torch.as_tensor(np.concatenate([np.asarray(M, dtype=np.float64).ravel(), np.asarray(R, dtype=np.float64)]),

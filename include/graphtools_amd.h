@@ -233,6 +233,10 @@ int gt_points_shard_splits(gt_ctx* ctx, int32_t world, int64_t* out_splits);
 int gt_points_row_ids(gt_ctx* ctx, int64_t row0, int64_t row1, int32_t* out, int32_t out_on_device);
 int gt_graph_shard_local(gt_ctx* ctx, const gt_knn_params* params, int32_t world, int32_t rank, const int64_t* row_splits,
                          int32_t* applies);
+/* device address of row `row0` of the bound points as the context holds them (its numbering; out_dtype / out_d optional) -
+ * a rank's own rows as the device-resident query matrix of gt_knn_search on another context (random landmarking over
+ * the ranks, graphs.py:1200-1213: dist.ShardedKnnGraph.random_landmark_clusters) */
+int gt_points_device(gt_ctx* ctx, int64_t row0, void** out, int32_t* out_dtype, int32_t* out_d);
 /* single-GPU convenience: begin + emit + finish with an internal buffer */
 int gt_graph_build(gt_ctx* ctx, const gt_knn_params* params, int64_t* out_nnz, uint32_t* flags);
 

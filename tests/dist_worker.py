@@ -116,6 +116,38 @@ class FakeCtx(object):
         assert np.array_equal(want[np.lexsort(want.T[::-1])], have[np.lexsort(have.T[::-1])]), "records lost or duplicated"
         self.sym_ready = True
 
+    # ---- cell-sorted renumbering (gt_points_cell_sort / gt_points_shard_splits / gt_points_row_ids /
+    # gt_graph_shard_local): a miniature with the library's contracts - the bound points become a deterministic
+    # permutation of the caller's, rows and triplets are in the new numbering, the finished rows carry the caller's columns
+    renumber_applies = True
+    local_applies = True
+    perm = None
+
+    def points_cell_sort(self):
+        self.calls = self.calls + ("cell_sort",)
+        if not self.renumber_applies:
+            return False
+        key = np.floor(self.X[:, 0].astype(np.float64) * 2.0)   # "cells": coarse bins of the first coordinate
+        self.perm = np.argsort(key, kind="stable")
+        self.X = self.X[self.perm]
+        return True
+
+    def points_shard_splits(self, world):
+        n = self.X.shape[0]
+        nb = -(-n // 8)
+        s = np.array([min(n, (nb * r // world) * 8) for r in range(world + 1)], dtype=np.int64)
+        s[-1] = n
+        return s
+
+    def points_row_ids(self, r0, r1):
+        return (self.perm[r0:r1] if self.perm is not None else np.arange(r0, r1)).astype(np.int32)
+
+    def graph_shard_local(self, params, world, rank, splits):
+        self.calls = self.calls + ("shard_local",)
+        assert self.perm is not None and np.array_equal(splits, self.points_shard_splits(world))
+        self.sym_ready = self.local_applies
+        return self.local_applies
+
     def graph_begin(self, params, world, rank, splits):
         self.sym_consumed, self.sym_ready = self.sym_ready, False
         self.p, self.world, self.rank, self.splits = params, world, rank, np.asarray(splits)
@@ -156,6 +188,9 @@ class FakeCtx(object):
             K = A
         else:
             raise NotImplementedError(s)
+        if self.perm is not None:   # the caller's column numbers (relabelled in the final sort of the tail)
+            K = sparse.coo_matrix(K)
+            K = sparse.csr_matrix((K.data, (K.row, self.perm[K.col])), shape=K.shape)
         self.K = sparse.csr_matrix(K)
         self.K.sort_indices()
         return self.K.nnz, 0
@@ -184,7 +219,8 @@ class FakeCtx(object):
         n = self.X.shape[0]
         d = np.frombuffer((ctypes.c_char * (n * 8)).from_address(ptr), dtype=np.float64).copy()
         K = self.K.tocoo()
-        K.data = K.data / ((d[K.row + self.r0] * d[K.col]) ** self.p.anisotropy)
+        own = self.perm[K.row + self.r0] if self.perm is not None else K.row + self.r0   # (d: by the caller's row numbers)
+        K.data = K.data / ((d[own] * d[K.col]) ** self.p.anisotropy)
         self.K = sparse.csr_matrix(K)
         self.K.sort_indices()
 
@@ -247,7 +283,7 @@ def main():
 
     Xg = make_mix(900, 20, 5)
     for symm in ("+", "*", None):
-        g = gdist.ShardedKnnGraph(FakeCtx(), Xg.shape[0])
+        g = gdist.ShardedKnnGraph(FakeCtx(), Xg.shape[0], renumber=False)   # (the staged pass of the caller's numbering)
         local = torch.from_numpy(Xg[g.splits[rank]:g.splits[rank + 1]].copy())
         g.gather_points(local)
         nnz, _ = g.build(FakeParams(10, 20, 1e-4, symm))
@@ -265,7 +301,7 @@ def main():
         c = FakeCtx()
         c.sym_applies = not (scenario == "plan" and rank == 1)
         c.sym_refuse_at_collect = scenario == "collect"
-        g = gdist.ShardedKnnGraph(c, Xg.shape[0])
+        g = gdist.ShardedKnnGraph(c, Xg.shape[0], renumber=False)
         g.gather_points(torch.from_numpy(Xg[g.splits[rank]:g.splits[rank + 1]].copy()))
         g.build(FakeParams(10, 20, 1e-4, "+"), symmetric=False if scenario == "off" else "auto")
         assert not g.symmetric_used and not c.sym_consumed
@@ -275,26 +311,54 @@ def main():
         assert (c.K != K_full[g.splits[rank]:g.splits[rank + 1]]).nnz == 0
     # 5b. knn_max: one all-reduce of the ranks' loop counts in front of the build (sixth collective)
     c = FakeCtx()
-    g = gdist.ShardedKnnGraph(c, Xg.shape[0])
+    g = gdist.ShardedKnnGraph(c, Xg.shape[0], renumber=False)
     g.gather_points(torch.from_numpy(Xg[g.splits[rank]:g.splits[rank + 1]].copy()))
     g.build(FakeParams(10, 20, 1e-4, "+", knn_max=60), symmetric=False)
     assert c.calls[:2] == ("stage_counts", "stage_totals"), c.calls
     assert np.array_equal(c.stage_totals, [sum(100 + r for r in range(world)), sum(7 * (r + 1) for r in range(world))])
 
+    # 5c. the DEFAULT flow: cell-sorted renumbering - three collectives (points all-gather, triplet counts, triplets), the
+    #     rank's rows are rows of the new numbering, row_ids() gives the caller's; a rank may decline the local pass alone
+    for symm in ("+", "*", None):
+        for scenario in ("local", "rank1 declines", "renumbering declines"):
+            c = FakeCtx()
+            c.local_applies = not (scenario == "rank1 declines" and rank == 1)
+            c.renumber_applies = scenario != "renumbering declines"
+            g = gdist.ShardedKnnGraph(c, Xg.shape[0])
+            ins = g.input_splits
+            g.gather_points(torch.from_numpy(Xg[ins[rank]:ins[rank + 1]].copy()))
+            assert g.renumbered == c.renumber_applies
+            g.build(FakeParams(10, 20, 1e-4, symm))
+            K_full = sparse.csr_matrix(oracle.knn_graph(Xg, knn=10, decay=20, kernel_symm=symm)[0])
+            K_full.sort_indices()
+            ids = g.row_ids()
+            assert len(ids) == g.splits[rank + 1] - g.splits[rank]
+            assert (c.K != K_full[ids]).nnz == 0, "rows of the renumbered build differ from the single-process oracle (%s, %s)" % (symm, scenario)
+            if c.renumber_applies:
+                assert c.calls == ("cell_sort", "shard_local"), c.calls
+                assert g.symmetric_used == c.local_applies and c.sym_consumed == c.local_applies
+                # the ranks' row sets partition the caller's rows
+                mine = torch.zeros(Xg.shape[0], dtype=torch.int64)
+                mine[torch.from_numpy(ids)] = 1
+                dist.all_reduce(mine)
+                assert bool((mine == 1).all())
+            else:
+                assert c.calls == ("cell_sort", "plan", "seed", "collect", "emit", "finish"), c.calls
+
     # 6. anisotropy: the owned degrees are all-gathered (fourth collective), then applied to the owned block
     g = gdist.ShardedKnnGraph(FakeCtx(), Xg.shape[0])
-    g.gather_points(torch.from_numpy(Xg[g.splits[rank]:g.splits[rank + 1]].copy()))
+    g.gather_points(torch.from_numpy(Xg[g.input_splits[rank]:g.input_splits[rank + 1]].copy()))
     g.build(FakeParams(10, 20, 1e-4, "+", anisotropy=0.5))
     assert g.ctx.calls[-2:] == ("fetch_degree", "anisotropy"), g.ctx.calls
     K_an = sparse.csr_matrix(oracle.knn_graph(Xg, knn=10, decay=20, kernel_symm="+", anisotropy=0.5)[0])
     K_an.sort_indices()
-    blk = K_an[g.splits[rank]:g.splits[rank + 1]]
+    blk = K_an[g.row_ids()]
     assert np.array_equal(blk.indptr, g.ctx.K.indptr) and np.array_equal(blk.indices, g.ctx.K.indices)
     np.testing.assert_allclose(g.ctx.K.data, blk.data, rtol=1e-13, atol=0)
 
     # 7. landmark operator: all-reduce (fifth collective) of the partial L x L products and row sums
     g = gdist.ShardedKnnGraph(FakeCtx(), Xg.shape[0])
-    g.gather_points(torch.from_numpy(Xg[g.splits[rank]:g.splits[rank + 1]].copy()))
+    g.gather_points(torch.from_numpy(Xg[g.input_splits[rank]:g.input_splits[rank + 1]].copy()))
     g.build(FakeParams(10, 20, 1e-4, "+"))
     L = 12
     clusters = np.random.default_rng(77).integers(0, L, size=Xg.shape[0])

@@ -258,3 +258,92 @@ def test_manifold_rows_and_small_lists():
     K1, P1 = single_build(X, pargs)
     _same(K, K1)
     _same(P, P1)
+
+
+def test_landmark_operator_of_row_blocks_on_renumbered_points():
+    """gt_landmark_build on the row blocks of a sharded build (graphs.py:1169-1246 split over ranks): the stacked partial
+    products M and row sums R of the ranks equal the single-rank ones - and the operator equals the reference's fixture
+    g7 (tests/golden, written by the imported reference) - whatever the numbering of the rows; gt_nearest_landmark on a
+    rank's row range assigns the caller's rows (graphs.py:1200-1213)"""
+    from conftest import load_golden
+    from graphtools_amd import _hip
+
+    z = load_golden("g7_landmark")
+    X = z["X"]
+    n = X.shape[0]
+    L = int(z["n_landmark"])
+    clusters = z["clusters"].astype(np.int32)
+    pargs = (15, 40, 1e-4, None, 1.0, None, "+", None, 0)
+    # single rank
+    c1 = _hip.Context(0)
+    c1.set_points(X)
+    p, keep = c1.make_params(*pargs)
+    c1.graph_build(p)
+    M1, R1, t1 = c1.landmark_build(clusters, L)
+    op1 = c1.landmark_scale(M1, R1)
+    c1.close()
+    np.testing.assert_allclose(op1, z["landmark_op"], rtol=1e-9, atol=1e-300)
+    # two ranks on row blocks; small point sets keep the caller's numbering (the renumbering needs cells), larger ones do not
+    for Xs, cl, Lx in ((X, clusters, L), (None, None, 64)):
+        if Xs is None:
+            Xs = make_mix(20000, 32, 12)
+            cl = np.random.default_rng(12).integers(0, Lx, size=Xs.shape[0]).astype(np.int32)
+            cl[:Lx] = np.arange(Lx)
+            c1 = _hip.Context(0)
+            c1.set_points(Xs)
+            p, keep = c1.make_params(*pargs)
+            c1.graph_build(p)
+            M1, R1, t1 = c1.landmark_build(cl, Lx)
+            op1 = c1.landmark_scale(M1, R1)
+            # random landmarking on the caller's rows (graphs.py:1200-1213)
+            lm = np.sort(np.random.default_rng(5).choice(Xs.shape[0], Lx, replace=False)).astype(np.int64)
+            near1 = c1.nearest_landmark(lm, 0)
+            c1.close()
+        world, nn = 2, Xs.shape[0]
+        ctxs = [_ctx({}) for _ in range(world)]
+        renum = []
+        for c in ctxs:
+            c.set_points(Xs)
+            renum.append(c.points_cell_sort())
+        assert len(set(renum)) == 1
+        if renum[0]:
+            splits = ctxs[0].points_shard_splits(world)
+        else:
+            splits = np.array([0, nn // 2, nn], dtype=np.int64)
+        p, keep = ctxs[0].make_params(*pargs)
+        sends, counts = [], []
+        for r, c in enumerate(ctxs):
+            if renum[0]:
+                c.graph_shard_local(p, world, r, splits)
+            cnt = c.graph_begin(p, world, r, splits)
+            host = np.zeros(int(cnt.sum()), dtype=TRIP)
+            buf = c.dev_alloc(max(len(host), 1) * 16)
+            c.graph_emit(buf)
+            if len(host):
+                c.dev_download(host, buf)
+            c.dev_free(buf)
+            sends.append(host)
+            counts.append(cnt)
+        M, R = np.zeros((Lx, Lx)), np.zeros(Lx)
+        near = np.full(nn, -1, dtype=np.int64)
+        for r, (c, recv) in enumerate(zip(ctxs, _exchange(sends, counts, world))):
+            buf = c.dev_alloc(max(len(recv), 1) * 16)
+            if len(recv):
+                c.dev_upload(buf, recv)
+            c.graph_finish(buf if len(recv) else 0, len(recv))
+            c.dev_free(buf)
+            Mr, Rr, tr = c.landmark_build(cl, Lx)     # (cluster labels by the caller's row numbers = the CSR's columns)
+            M += np.asarray(Mr)
+            R += np.asarray(Rr)
+            if Xs is not X:
+                ids = c.points_row_ids(splits[r], splits[r + 1])
+                near[ids] = c.nearest_landmark(lm, 0, rows=(int(splits[r]), int(splits[r + 1])))
+        op = ctxs[0].landmark_scale(M, R)
+        for c in ctxs:
+            c.close()
+        np.testing.assert_allclose(op, op1, rtol=1e-12, atol=1e-300)
+        if Xs is X:
+            np.testing.assert_allclose(op, z["landmark_op"], rtol=1e-9, atol=1e-300)
+        else:
+            assert renum[0], "20 000 points should have been renumbered"
+            assert np.array_equal(near, near1)

@@ -261,21 +261,42 @@ def test_host_flow_over_rccl_world_one():
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    os.environ["GT_SHARD_SYM_FORCE"] = "1"      # the staged symmetric pass although there is one rank
+    os.environ["GT_SHARD_SYM_FORCE"] = "1"      # the staged / local symmetric pass although there is one rank
     dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, world_size=1, rank=0)
     try:
+        from scipy import sparse
+
         device = torch.device("cuda", 0)
-        ctx = _ctx({})
-        g = gdist.ShardedKnnGraph(ctx, X.shape[0])
-        g.gather_points(torch.from_numpy(X).to(device))
-        p2, keep2 = ctx.make_params(*pargs)
-        nnz, _ = g.build(p2)
-        assert g.symmetric_used
-        d2, i2, p2_ = ctx.graph_fetch_csr(_hip.CSR_K)
-        pd2, _, _ = ctx.graph_fetch_csr(_hip.CSR_P, structure=False)
-        assert np.array_equal(p2_, kp) and np.array_equal(i2, ki)
-        assert np.array_equal(d2, kd) and np.array_equal(pd2, pd)
-        ctx.close()
+        n = X.shape[0]
+        K_ref = sparse.csr_matrix((kd, ki, kp), shape=(n, n))
+        clusters = np.random.default_rng(3).integers(0, 40, size=n).astype(np.int32)
+        clusters[:40] = np.arange(40)
+        op_ref = None
+        for renumber in (True, False):     # the default flow (cell-sorted renumbering) and the staged pass of rounds 2-3
+            ctx = _ctx({})
+            g = gdist.ShardedKnnGraph(ctx, n, renumber=renumber)
+            g.gather_points(torch.from_numpy(X).to(device))
+            assert g.renumbered == renumber
+            p2, keep2 = ctx.make_params(*pargs)
+            nnz, _ = g.build(p2)
+            assert g.symmetric_used
+            d2, i2, p2_ = ctx.graph_fetch_csr(_hip.CSR_K)
+            pd2, _, _ = ctx.graph_fetch_csr(_hip.CSR_P, structure=False)
+            ids = g.row_ids()
+            assert np.array_equal(np.sort(ids), np.arange(n))
+            want = K_ref[ids]                                   # the caller's rows in the rank's order, the caller's columns
+            assert np.array_equal(p2_, want.indptr) and np.array_equal(i2, want.indices)
+            assert np.array_equal(d2, want.data)
+            want_p = sparse.csr_matrix((pd, ki, kp), shape=(n, n))[ids]
+            assert np.array_equal(pd2, want_p.data)
+            # landmark operator over the same group (one all-reduce of the L x L partials): independent of the numbering
+            op, tnnz = g.landmark_operator(clusters, 40)
+            np.testing.assert_allclose(op.sum(axis=1), 1.0, rtol=1e-12)
+            if op_ref is None:
+                op_ref = op
+            else:
+                np.testing.assert_allclose(op, op_ref, rtol=1e-12, atol=1e-300)
+            ctx.close()
     finally:
         os.environ.pop("GT_SHARD_SYM_FORCE", None)
         dist.destroy_process_group()

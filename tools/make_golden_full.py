@@ -3,9 +3,10 @@
 with the reference imported from /root/reference (tools/ref_import.py) and keep compact fixtures of the results:
 
   row_len      uint16[N]   entries per row of K (= of P); indptr is its running sum
-  row_hash     uint32[N]   per-row checksum of the sorted column indices: sum_j (col_j + 1) * 2654435761 mod 2^32
+  row_hash     uint16[N]   per-row checksum of the sorted column indices: upper half of sum_j (col_j + 1) * 2654435761 mod 2^32
   sha256       bytes       sha-256 of K.indices as little-endian int32 (whole-matrix structure hash)
-  degree       float64[N]  kernel_degree = row sums of K (graphs base.py:648-660)
+  degree4      float64[ceil(N/4)]  kernel_degree (row sums of K, base.py:648-660) of the rows 0, 4, 8, ...
+  degree_blocks float64[ceil(N/1024)]  sums of kernel_degree over blocks of 1024 rows (every row counts)
   sample_{i,j,K,P}         10^5 stored entries drawn uniformly (default_rng(12345)) with their K and P values
   nnz, time_s, versions
 
@@ -83,9 +84,10 @@ def build(tag):
     out = {
         "n": np.int64(n), "d": np.int64(cfg["d"]), "seed": np.int64(cfg["seed"]), "knn": np.int64(15), "decay": np.float64(40),
         "thresh": np.float64(1e-4), "nnz": np.int64(K.nnz),
-        "row_len": row_len.astype(np.uint16), "row_hash": row_hash(K.indices, K.indptr),
+        "row_len": row_len.astype(np.uint16), "row_hash": (row_hash(K.indices, K.indptr) >> np.uint32(16)).astype(np.uint16),
         "sha256_indices": np.frombuffer(hashlib.sha256(K.indices.astype("<i4").tobytes()).digest(), dtype=np.uint8),
-        "degree": degree.astype(np.float64),
+        "degree4": degree[::4].astype(np.float64),
+        "degree_blocks": np.add.reduceat(degree.astype(np.float64), np.arange(0, n, 1024)),
         "sample_i": rows.astype(np.int32), "sample_j": K.indices[pos].astype(np.int32),
         "sample_K": K.data[pos].astype(np.float64), "sample_P": P.data[pos].astype(np.float64),
         "time_kernel_s": np.float64(t1 - t0), "time_total_s": np.float64(t2 - t0), "cores": np.int64(os.cpu_count()),
