@@ -71,6 +71,9 @@ _SIGNATURES = {
     "gt_graph_sym_emit": (_c.c_int, [_c.c_void_p, _c.c_void_p]),
     "gt_graph_sym_finish": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64]),
     "gt_points_cell_sort": (_c.c_int, [_c.c_void_p, _c.POINTER(_c.c_int32)]),
+    "gt_points_cells_begin": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_int64, _c.c_int64,
+                                         _c.c_void_p, _c.POINTER(_c.c_int32)]),
+    "gt_points_cells_finish": (_c.c_int, [_c.c_void_p, _c.c_void_p]),
     "gt_points_shard_splits": (_c.c_int, [_c.c_void_p, _c.c_int32, _c.c_void_p]),
     "gt_points_row_ids": (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_int64, _c.c_void_p, _c.c_int32]),
     "gt_points_device": (_c.c_int, [_c.c_void_p, _c.c_int64, _c.POINTER(_c.c_void_p), _c.POINTER(_c.c_int32),
@@ -404,6 +407,20 @@ class Context:
         applied = ctypes.c_int32(0)
         self._check(self.lib.gt_points_cell_sort(self.h, ctypes.byref(applied)), "gt_points_cell_sort")
         return bool(applied.value)
+
+    def points_cells_begin(self, dev_ptr, n, d, dtype, row0, row1, cells_out_ptr):
+        """bind device-resident points and assign the rows [row0, row1) to their landmark cells (uint32 per row at
+        cells_out_ptr, device); -> True when a cell order applies (then all-gather the cells and call points_cells_finish)"""
+        self.n, self.d, self.dtype = int(n), int(d), np.dtype(dtype)
+        applied = ctypes.c_int32(0)
+        self._check(self.lib.gt_points_cells_begin(self.h, ctypes.c_void_p(int(dev_ptr)), self.n, self.d,
+                                                   GT_F32 if self.dtype == np.float32 else GT_F64, int(row0), int(row1),
+                                                   ctypes.c_void_p(int(cells_out_ptr)) if cells_out_ptr else None,
+                                                   ctypes.byref(applied)), "gt_points_cells_begin")
+        return bool(applied.value)
+
+    def points_cells_finish(self, cells_all_ptr):
+        self._check(self.lib.gt_points_cells_finish(self.h, ctypes.c_void_p(int(cells_all_ptr))), "gt_points_cells_finish")
 
     def points_shard_splits(self, world):
         splits = np.zeros(world + 1, dtype=np.int64)

@@ -96,7 +96,7 @@ void gt_ctx_destroy(gt_ctx* ctx) {
     ctx->dense_degree.release();
     ctx->dense_bw.release();
     ctx->X_norm.release();
-    for (DevBuf* b : {&ctx->land_Y, &ctx->land_h, &ctx->order_cell, &ctx->order_rows, &ctx->order_tmp, &ctx->vperm, &ctx->vcell}) b->release();
+    for (DevBuf* b : {&ctx->land_Y, &ctx->land_h, &ctx->order_cell, &ctx->order_rows, &ctx->order_tmp, &ctx->vperm, &ctx->vcell, &ctx->land_X, &ctx->land_Yp, &ctx->land_xn}) b->release();
     if (ctx->side_event) (void)hipEventDestroy(ctx->side_event);
     if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
     (void)hipStreamDestroy(ctx->stream);
@@ -128,7 +128,11 @@ int gt_stage_launches(const gt_ctx* ctx, const char* stage) {
     return it->second.launches;
 }
 
-int gt_set_points(gt_ctx* ctx, const void* X, int64_t n, int32_t d, int32_t dtype, int32_t on_device) {
+}  // extern "C"
+
+// Everything gt_set_points does before the working copies are made: the caller's matrix bound (uploaded when it is host
+// memory), finiteness check + max |x|, cosine normalisation, the padded feature count / wide-data column choice.
+int gt_bind_points(gt_ctx* ctx, const void* X, int64_t n, int32_t d, int32_t dtype, int32_t on_device) {
     if (!ctx) return GT_E_ARG;
     if (!X || n <= 0 || d <= 0) GT_FAIL(ctx, GT_E_ARG, "gt_set_points: empty input");
     if (dtype != GT_F32 && dtype != GT_F64) GT_FAIL(ctx, GT_E_ARG, "gt_set_points: dtype must be GT_F32 or GT_F64");
@@ -136,6 +140,7 @@ int gt_set_points(gt_ctx* ctx, const void* X, int64_t n, int32_t d, int32_t dtyp
     GT_HIP(ctx, hipSetDevice(ctx->device));
     ctx->reset_stages();
     ctx->presorted = 0;   // (a renumbering belongs to the points it was made for)
+    ctx->cells_pending = 0;
     const size_t esz = dtype == GT_F32 ? 4 : 8;
     if (on_device) {
         ctx->X = X;
@@ -177,18 +182,30 @@ int gt_set_points(gt_ctx* ctx, const void* X, int64_t n, int32_t d, int32_t dtyp
         ctx->DP = 128;
         GT_TRY(gt_select_columns(ctx, 128));
     }
+    return GT_OK;
+}
+
+// ... and the working copies (norms, float16 planes, seeds) of the bound points
+int gt_prep_bound_points(gt_ctx* ctx) {
     if (ctx->DP == 0) {
         // more than 2048 features: the exact dense path and landmark assignment still work on the raw points
         ctx->n_pad = 0;
-        GT_HIP(ctx, ctx->xn.reserve(size_t(n) * sizeof(double)));
+        GT_HIP(ctx, ctx->xn.reserve(size_t(ctx->n) * sizeof(double)));
         GT_HIP(ctx, ctx->ymax.reserve(sizeof(double)));
-        GT_TRY(gt_prep_matrix(ctx, ctx->X, n, d, dtype, 0, 0, nullptr, ctx->xn.as<double>(), nullptr,
+        GT_TRY(gt_prep_matrix(ctx, ctx->X, ctx->n, ctx->d, ctx->dtype, 0, 0, nullptr, ctx->xn.as<double>(), nullptr,
                               ctx->ymax.as<double>(), 0, 1.0));
     } else {
         GT_TRY(gt_prep_points(ctx));
     }
     GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return GT_OK;
+}
+
+extern "C" {
+
+int gt_set_points(gt_ctx* ctx, const void* X, int64_t n, int32_t d, int32_t dtype, int32_t on_device) {
+    GT_TRY(gt_bind_points(ctx, X, n, d, dtype, on_device));
+    return gt_prep_bound_points(ctx);
 }
 
 int gt_last_knn_precision(const gt_ctx* ctx) { return ctx ? ctx->last_main_prec : GT_E_ARG; }

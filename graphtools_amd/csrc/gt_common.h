@@ -194,6 +194,9 @@ struct gt_ctx {
     int32_t presorted_L = 0;    //   cells of the renumbering
     int32_t order_has_thr0 = 0; //   the last query order left starting thresholds in its out_thr0 (not in the presorted case)
     DevBuf vperm, vcell;        //   int32 [n] row of the caller for every row of the context; uint32 [n] its cell (non-decreasing)
+    int32_t cells_pending = 0;  //   gt_points_cells_begin has bound the points and assigned a share of them: gt_points_cells_finish is due
+    int32_t cells_L = 0;        //     landmark cells of that assignment
+    DevBuf land_X, land_Yp, land_xn;   //   landmark rows of the sharded assignment: raw rows, their working copy, norms
     int64_t n_pad = 0;   // rows of the working copy (multiple of the db tile)
     DevBuf Yp;           // working copy: [n_pad] rows of 4*DP bytes (float32, or float16 hi plane | lo plane)
     DevBuf Yc;           // prec 1 with fast_mode: compact copy of the hi plane, [n_pad] rows of 2*DP bytes
@@ -284,5 +287,8 @@ struct HostTrace {
 
 // gt_prep.hip
 int gt_prep_points(gt_ctx* ctx);
+// gt_api.cpp: the two halves of gt_set_points
+int gt_bind_points(gt_ctx* ctx, const void* X, int64_t n, int32_t d, int32_t dtype, int32_t on_device);
+int gt_prep_bound_points(gt_ctx* ctx);
 // choose the padded feature count for d (0 if unsupported)
 int gt_choose_dp(int d);

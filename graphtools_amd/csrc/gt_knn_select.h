@@ -109,3 +109,7 @@ int gt_query_order(gt_ctx* ctx, const float* Qc, int64_t q0, int64_t nq, int nee
 int gt_choose_dp_prec(int d, int prec);  // padded feature count for a precision (0 if unsupported)
 int gt_select_bq(int dp);  // query rows per workgroup
 int gt_select_bn(int dp);  // database rows per tile
+// the cell order of all bound rows in two halves (row-sharded builds: a rank assigns 1 / world of the rows, the cells are
+// all-gathered, every rank sorts) - gt_order.hip
+int gt_order_cells_partial(gt_ctx* ctx, int64_t row0, int64_t row1, uint32_t* cells_out, int* active);
+int gt_order_sort_cells(gt_ctx* ctx, const uint32_t* cells_all, int32_t* out_rows);

@@ -46,6 +46,31 @@ bool shard_applicable(const gt_ctx* ctx, int need_m) {
 // on the renumbered points and never learns about it); the caller's numbers come back in the last sort of the tail
 // (gt_sparse.hip: RowSrc::relabel) and through gt_points_row_ids.
 //   applied = 0: the points are too few (or too wide) for a cell order - nothing changed.
+// perm (device int32 [n], with the sorted cells in order_cell + n): the bound points become rows perm[0], perm[1], ...
+static int renumber_by(gt_ctx* ctx, const int32_t* perm) {
+    KnnWork* k = ctx->knn;
+    const int64_t n = ctx->n;
+    StageSpan span(ctx, "renumber");
+    // the points in the new order (the caller's buffer is not referenced any more), their row numbers and cells
+    GT_HIP(ctx, ctx->xn.reserve(size_t(n) * sizeof(double)));   // (gathered along; recomputed below)
+    GT_TRY(gt_sym_gather_points(ctx, perm));
+    std::swap(ctx->X_own, k->Xs);
+    ctx->X = ctx->X_own.p;
+    k->xs_ready = false;
+    GT_HIP(ctx, ctx->vperm.reserve(size_t(n) * sizeof(int32_t)));
+    GT_HIP(ctx, ctx->vcell.reserve(size_t(n) * sizeof(uint32_t)));
+    GT_HIP(ctx, hipMemcpyAsync(ctx->vperm.p, perm, size_t(n) * sizeof(int32_t), hipMemcpyDeviceToDevice, ctx->stream));
+    GT_HIP(ctx, hipMemcpyAsync(ctx->vcell.p, ctx->order_cell.as<uint32_t>() + n, size_t(n) * sizeof(uint32_t),
+                               hipMemcpyDeviceToDevice, ctx->stream));
+    // norms and working copies of the renumbered rows (the same rows: the same norms, the same float16 scale; the landmark
+    // rows the order was made with keep describing the cells)
+    GT_TRY(gt_prep_points(ctx));
+    ctx->presorted = 1;
+    ctx->presorted_L = ctx->order_L;
+    GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return GT_OK;
+}
+
 extern "C" int gt_points_cell_sort(gt_ctx* ctx, int32_t* applied) {
     if (!ctx || !applied) return GT_E_ARG;
     *applied = 0;
@@ -71,25 +96,59 @@ extern "C" int gt_points_cell_sort(gt_ctx* ctx, int32_t* applied) {
     k->yps_ready = false;
     k->sh_stage = 0;
     if (!ordered || ctx->order_L <= 0) return GT_OK;
-    StageSpan span(ctx, "renumber");
-    // the points in the new order (the caller's buffer is not referenced any more), their row numbers and cells
-    GT_TRY(gt_sym_gather_points(ctx, k->qorder.as<int32_t>()));
-    std::swap(ctx->X_own, k->Xs);
-    ctx->X = ctx->X_own.p;
-    k->xs_ready = false;
-    GT_HIP(ctx, ctx->vperm.reserve(size_t(n) * sizeof(int32_t)));
-    GT_HIP(ctx, ctx->vcell.reserve(size_t(n) * sizeof(uint32_t)));
-    GT_HIP(ctx, hipMemcpyAsync(ctx->vperm.p, k->qorder.p, size_t(n) * sizeof(int32_t), hipMemcpyDeviceToDevice, ctx->stream));
-    GT_HIP(ctx, hipMemcpyAsync(ctx->vcell.p, ctx->order_cell.as<uint32_t>() + n, size_t(n) * sizeof(uint32_t),
-                               hipMemcpyDeviceToDevice, ctx->stream));
-    // norms and working copies of the renumbered rows (the same rows: the same norms, the same float16 scale; the landmark
-    // rows gt_query_order picked keep describing the cells)
-    GT_TRY(gt_prep_points(ctx));
-    ctx->presorted = 1;
-    ctx->presorted_L = ctx->order_L;
+    GT_TRY(renumber_by(ctx, k->qorder.as<int32_t>()));
+    *applied = 1;
+    return GT_OK;
+}
+
+// The same renumbering with the cell assignment SPLIT over the ranks of a sharded build (assign_cells_kernel is 0.77 ms
+// of replicated work at N = 1e6 when every rank assigns every row, and the full working copy it reads another 0.26 ms):
+//   gt_points_cells_begin   binds the gathered points (device memory) WITHOUT making the working copies, prepares the
+//                           landmark rows and the rows [row0, row1) only, assigns those rows to their cells
+//                           -> cells_out (device uint32 [row1 - row0]); the host all-gathers the ranks' cells (4 B per row)
+//   gt_points_cells_finish  cells of all rows (device uint32 [n]) -> stable sort, renumbering, working copies
+// applied = 0 from _begin: no cell order for these points (too few / too wide) - they are bound as gt_set_points binds them,
+// nothing to gather, _finish must not be called.
+extern "C" int gt_points_cells_begin(gt_ctx* ctx, const void* X_dev, int64_t n, int32_t d, int32_t dtype, int64_t row0,
+                                     int64_t row1, void* cells_out_dev, int32_t* applied) {
+    if (!ctx || !applied) return GT_E_ARG;
+    *applied = 0;
+    GT_TRY(gt_bind_points(ctx, X_dev, n, d, dtype, 1));
+    if (row0 < 0 || row1 > n || row1 < row0 || (row1 > row0 && !cells_out_dev)) GT_FAIL(ctx, GT_E_ARG, "gt_points_cells_begin: bad row range");
+    int active = 0;
+    if (ctx->DP != 0 && !ctx->wide && ctx->prec == 1 && ctx->fast_mode != 0) {
+        ctx->sc = gt_f16_scale(ctx->maxabs);
+        if (ctx->metric == 1) {   // (the normalised rows: their own max |x|, as gt_prep_points measures it)
+            GT_TRY(gt_max_abs(ctx, ctx->X, ctx->n * int64_t(ctx->d), ctx->dtype, &ctx->maxabs, nullptr));
+            ctx->sc = gt_f16_scale(ctx->maxabs);
+        }
+        StageSpan span(ctx, "query_order");
+        GT_TRY(gt_order_cells_partial(ctx, row0, row1, static_cast<uint32_t*>(cells_out_dev), &active));
+    }
+    if (!active) return gt_prep_bound_points(ctx);   // no cell order: plain gt_set_points
+    ctx->cells_pending = 1;
     GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     *applied = 1;
     return GT_OK;
+}
+
+extern "C" int gt_points_cells_finish(gt_ctx* ctx, const void* cells_all_dev) {
+    if (!ctx || !cells_all_dev) return GT_E_ARG;
+    GT_HIP(ctx, hipSetDevice(ctx->device));
+    if (!ctx->cells_pending || ctx->n <= 0 || !ctx->X) GT_FAIL(ctx, GT_E_STATE, "gt_points_cells_finish: call gt_points_cells_begin first");
+    ctx->cells_pending = 0;
+    if (!ctx->knn) ctx->knn = new KnnWork();
+    KnnWork* k = ctx->knn;
+    GT_HIP(ctx, k->qorder.reserve(size_t(ctx->n) * sizeof(int32_t)));
+    {
+        StageSpan span(ctx, "query_order");
+        GT_TRY(gt_order_sort_cells(ctx, static_cast<const uint32_t*>(cells_all_dev), k->qorder.as<int32_t>()));
+    }
+    k->ordered = false;
+    k->xs_ready = false;
+    k->yps_ready = false;
+    k->sh_stage = 0;
+    return renumber_by(ctx, k->qorder.as<int32_t>());
 }
 
 // the caller's row number of the context's rows [v0, v1) (identity when the points were not renumbered)

@@ -11,8 +11,9 @@ The N x N affinity build shards by row blocks; every rank
                                       rank itself - no thresholds or candidate records travel (a rank may decline and run
                                       the classic pass for its rows: nothing is shared); gt_graph_begin: re-rank ->
                                       bandwidth -> radius pass -> affinities
-  4. all-to-all of transposed triplets {row, col, value} (16 B each) bucketed by the owner of ``row`` - collectives 2
-                                      (counts, 8 B per peer) and 3 (the triplets)
+  4. all-to-all of transposed triplets {row, col, value} (16 B each) bucketed by the owner of ``row`` - collectives 3
+                                      (counts, 8 B per peer) and 4 (the triplets); collective 2 is the all-gather of the
+                                      cell numbers inside step 2 (4 B per row: each rank assigns 1 / world of the rows)
   5. local merge + normalisation     gt_graph_finish  (anisotropy: + one all-gather of the degrees)
   landmark operator: all-reduce(sum) of the L x L partial products and the L partial row sums.
 
@@ -184,14 +185,25 @@ class ShardedKnnGraph(object):
         _order_after_collectives(self.ctx, full)
         self._points = full
         self._device = full.device
-        self.ctx.set_points_device(full.data_ptr(), full.shape[0], full.shape[1],
-                                   np.float32 if full.dtype == torch.float32 else np.float64)
+        np_dtype = np.float32 if full.dtype == torch.float32 else np.float64
         self.renumbered = False
         self.splits = self.input_splits
         self._row_ids_all = None
-        if self.renumber and hasattr(self.ctx, "points_cell_sort"):
-            # deterministic: the same points and the same kernels give every rank the same numbering (no collective)
-            self.renumbered = bool(self.ctx.points_cell_sort())
+        if self.renumber and hasattr(self.ctx, "points_cells_begin") and full.is_cuda:
+            # the cell assignment behind the renumbering, 1 / world of it per rank: every rank assigns its slice of the
+            # gathered rows, one all-gather of the cells (4 B per row), every rank sorts (deterministic: one numbering)
+            r0, r1 = int(self.input_splits[self.rank]), int(self.input_splits[self.rank + 1])
+            cells = torch.empty(max(r1 - r0, 1), dtype=torch.int32, device=full.device)
+            if self.ctx.points_cells_begin(full.data_ptr(), full.shape[0], full.shape[1], np_dtype, r0, r1, cells.data_ptr()):
+                cells_all = allgather_vector(cells[: r1 - r0], self.input_splits, self.group).contiguous()
+                _order_after_collectives(self.ctx, cells_all)
+                self.ctx.points_cells_finish(cells_all.data_ptr())
+                self.renumbered = True
+        else:
+            self.ctx.set_points_device(full.data_ptr(), full.shape[0], full.shape[1], np_dtype)
+            if self.renumber and hasattr(self.ctx, "points_cell_sort"):
+                # (every rank assigns every row: deterministic, the same numbering everywhere without a collective)
+                self.renumbered = bool(self.ctx.points_cell_sort())
         if self.renumbered:
             # (the context holds its own, renumbered copy; the gathered matrix stays for row look-ups by the caller's numbers)
             self.splits = np.asarray(self.ctx.points_shard_splits(self.world), dtype=np.int64)

@@ -229,6 +229,16 @@ int gt_graph_sym_finish(gt_ctx* ctx, const void* recv_buf_dev, int64_t n_recv);
  *                          final per-row sort, so K, P and the degrees equal the single-GPU build's bit for bit)
  * Degree vectors handed to gt_graph_anisotropy / gt_graph_diff_aff are indexed by the caller's row numbers. */
 int gt_points_cell_sort(gt_ctx* ctx, int32_t* applied);
+/* ... with the cell assignment itself split over the ranks (it is 1 ms of replicated work at N = 1e6 otherwise):
+ *   gt_points_cells_begin   instead of gt_set_points: binds the gathered points (device memory), assigns the rows
+ *                           [row0, row1) - the rank's share, any split of [0, n) - to their landmark cells
+ *                           -> cells_out_dev (uint32 [row1 - row0]); applied = 0: no cell order for these points, they are
+ *                           bound as gt_set_points binds them and gt_points_cells_finish must not follow
+ *                           -> the host all-gathers the ranks' cells (4 bytes per row)
+ *   gt_points_cells_finish  cells of ALL rows (device uint32 [n]) -> the renumbering of gt_points_cell_sort */
+int gt_points_cells_begin(gt_ctx* ctx, const void* X_dev, int64_t n, int32_t d, int32_t dtype, int64_t row0, int64_t row1,
+                          void* cells_out_dev, int32_t* applied);
+int gt_points_cells_finish(gt_ctx* ctx, const void* cells_all_dev);
 int gt_points_shard_splits(gt_ctx* ctx, int32_t world, int64_t* out_splits);
 int gt_points_row_ids(gt_ctx* ctx, int64_t row0, int64_t row1, int32_t* out, int32_t out_on_device);
 int gt_graph_shard_local(gt_ctx* ctx, const gt_knn_params* params, int32_t world, int32_t rank, const int64_t* row_splits,

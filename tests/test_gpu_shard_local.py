@@ -347,3 +347,51 @@ def test_landmark_operator_of_row_blocks_on_renumbered_points():
         else:
             assert renum[0], "20 000 points should have been renumbered"
             assert np.array_equal(near, near1)
+
+
+def test_split_cell_assignment_gives_the_same_numbering():
+    """gt_points_cells_begin / _finish (every rank assigns 1 / world of the rows, the cells are all-gathered) arrive at the
+    numbering gt_points_cell_sort finds alone - and the build on it is the same graph"""
+    from graphtools_amd import _hip
+
+    X = make_mix(30000, 64, 13)
+    n, d = X.shape
+    a = _ctx({})
+    a.set_points(X)
+    assert a.points_cell_sort()
+    ids_a = a.points_row_ids(0, n)
+    a.close()
+    b = _ctx({})
+    xb = b.dev_alloc(X.nbytes)
+    b.dev_upload(xb, X)
+    cells = b.dev_alloc(n * 4)
+    cuts = [0, 7000, 7001, 22000, n]          # uneven shares, one of a single row
+    for r in range(len(cuts) - 1):
+        assert b.points_cells_begin(xb, n, d, np.float32, cuts[r], cuts[r + 1], cells + cuts[r] * 4)
+    b.points_cells_finish(cells)
+    ids_b = b.points_row_ids(0, n)
+    assert np.array_equal(ids_a, ids_b)
+    pargs = (15, 40, 1e-4, None, 1.0, None, "+", None, 0)
+    p, keep = b.make_params(*pargs)
+    b.graph_build(p)
+    d_, i_, p_ = b.graph_fetch_csr(_hip.CSR_K)
+    b.dev_free(cells)
+    b.dev_free(xb)
+    b.close()
+    inv = np.empty(n, dtype=np.int64)
+    inv[ids_b] = np.arange(n)
+    K = sparse.csr_matrix((d_, i_, p_), shape=(n, n))[inv]
+    K1, P1 = single_build(X, pargs)
+    _same(K, K1)
+    # too few points for a cell order: bound as gt_set_points binds them, nothing to finish
+    c = _hip.Context(0)
+    small = make_mix(3000, 16, 1)
+    xs = c.dev_alloc(small.nbytes)
+    c.dev_upload(xs, small)
+    assert not c.points_cells_begin(xs, 3000, 16, np.float32, 0, 1500, c.dev_alloc(1500 * 4))
+    with pytest.raises(_hip.HipError):
+        c.points_cells_finish(xs)
+    p, keep = c.make_params(5, 20, 1e-4, None, 1.0, None, "+", None, 0)
+    nnz, _ = c.graph_build(p)
+    assert nnz > 0
+    c.close()

@@ -50,15 +50,35 @@ single_ms = min(single)
 single_stage = {s: round(ctx.stage_ms(s), 3) for s in STAGES if ctx.stage_ms(s) > 0}
 
 
+in_splits = np.linspace(0, n, world + 1).astype(np.int64)   # the slices of the caller's rows the ranks contribute
+split_assign = os.environ.get("GT_SPLIT_ASSIGN", "1") != "0"
+cells_all_dev = None
+if split_assign:
+    # every rank's share of the cell assignment (what the cells all-gather delivers)
+    cells_all_dev = ctx.dev_alloc(n * 4)
+    for r in range(world):
+        ok = ctx.points_cells_begin(xb, n, d, np.float32, in_splits[r], in_splits[r + 1], cells_all_dev + int(in_splits[r]) * 4)
+        assert ok, "no cell order for these points"
+
+
 def rank_until_emit(r, timed=False):
     """set_points .. emit for rank r; -> (send_counts, device buffer of the triplets, wall ms by phase, stage ms, used)"""
     ctx.sync()
     t0 = time.perf_counter()
-    ctx.set_points_device(xb, n, d, np.float32)
-    applied = ctx.points_cell_sort()
+    if split_assign:
+        own = ctx.dev_alloc(int(in_splits[r + 1] - in_splits[r]) * 4)
+        applied = ctx.points_cells_begin(xb, n, d, np.float32, in_splits[r], in_splits[r + 1], own)
+        st_a = {s: ctx.stage_ms(s) for s in ("prep", "query_order")}
+        ctx.points_cells_finish(cells_all_dev)
+        ctx.dev_free(own)
+    else:
+        ctx.set_points_device(xb, n, d, np.float32)
+        applied = ctx.points_cell_sort()
     ctx.sync()
     t1 = time.perf_counter()
     st0 = {s: ctx.stage_ms(s) for s in ("prep", "query_order", "renumber")}
+    if split_assign:   # (the stage timers are reset by the bind inside _begin only: both halves are in them)
+        pass
     splits = ctx.points_shard_splits(world)
     used = ctx.graph_shard_local(p, world, r, splits)
     ctx.sync()
@@ -120,12 +140,13 @@ out = {
     "speedup_before_collectives": round(single_ms / best["wall_ms"]["total"], 2),
     "collectives": {
         "all_gather_points_bytes_total": int(X.nbytes),
+        "all_gather_cells_bytes_total": int(4 * n) if split_assign else 0,
         "all_to_all_counts_bytes": 8 * world,
         "all_to_all_triplets_bytes_sent_by_rank": int(send_totals[who]) * 16,
         "all_to_all_triplets_bytes_received_by_rank": int(len(recv)) * 16,
         "candidate_record_exchange_bytes": 0,
         "threshold_all_gather_bytes": 0,
-        "number_of_collectives": 3,
+        "number_of_collectives": 4 if split_assign else 3,
     },
     "triplets_sent_by_every_rank": send_totals,
 }
