@@ -15,6 +15,19 @@ from scipy import sparse
 from . import _hip
 
 
+def log_task(verbose, name, seconds):
+    """The reference reports its phases through ``tasklogger`` ("Calculating KNN search..." / "Calculated KNN search in
+    1.23 seconds.", graphs.py:873-885, 1197, base.py:242).  Here the phases run on the device back to back and their times
+    come from the library's stage timers afterwards: one completed-task line per phase, in tasklogger's wording, when the
+    graph was made with a truthy ``verbose``."""
+    if verbose:
+        print("Calculated {} in {:.2f} seconds.".format(name, seconds), flush=True)
+
+
+# attributes that hold device state (a ctypes handle, what the context currently holds): never pickled, rebuilt lazily
+_DEVICE_ATTRS = ("_hip_ctx", "_points_bound", "_device_state", "_knn_tree")
+
+
 class BaseGraph(object):
     """Parent graph class (reference: graphtools/base.py:427-724).
 
@@ -76,6 +89,25 @@ class BaseGraph(object):
         if "kernel_symm" in params and params["kernel_symm"] != self.kernel_symm:
             raise ValueError("Cannot update kernel_symm. Please create a new graph")
         return self
+
+    # ---- pickling (reference: base.py:887-902 to_pickle; graphs are plain picklable objects there) ----------
+    def __getstate__(self):
+        """Everything but the device context: the host-side results that were already fetched (K, P, ...) travel, what lives
+        on the GPU is rebuilt on first use after loading (``_bind_points`` / ``_ensure_device_graph``)."""
+        state = dict(self.__dict__)
+        for key in _DEVICE_ATTRS:
+            state.pop(key, None)
+        return state
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+
+    def to_pickle(self, path):
+        """Save the current Graph to a pickle (reference: base.py:887-902)."""
+        import pickle
+
+        with open(path, "wb") as f:
+            pickle.dump(self, f, protocol=pickle.HIGHEST_PROTOCOL)
 
     # ---- device plumbing --------------------------------------------------------------------
     @property

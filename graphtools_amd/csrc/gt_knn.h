@@ -267,8 +267,10 @@ int gt_sym_shard_emit(gt_ctx* ctx, const int32_t* perm, const uint64_t* tlists, 
                       const int64_t* splits, unsigned long long* cursor, void* out);
 int gt_sym_shard_scatter(gt_ctx* ctx, const void* recs, int64_t n_recs, int64_t nloc, int tcap, uint64_t* lists,
                          uint32_t* counts, uint32_t* bad);
+// p_last > p_first: the tile lists of the query blocks of the sorted positions [p_first, p_last) only (a rank's own rows)
 int gt_sym_schedule(gt_ctx* ctx, int64_t n_pad_s, int bq, int bn, int cells, int stride, int max_nb, int tile_stride,
-                    DevBuf& work, int32_t* tile_list, int32_t* tile_cnt, unsigned long long* tiles_total = nullptr);
+                    DevBuf& work, int32_t* tile_list, int32_t* tile_cnt, unsigned long long* tiles_total = nullptr,
+                    int64_t p_first = 0, int64_t p_last = 0);
 // gt_seed.hip: the threshold-seeding launch as dense cell blocks (`need` distinct near rows per sorted position)
 int gt_sym_seed_dense(gt_ctx* ctx, int dp, const void* Ys, const float* hs, int64_t n, int64_t n_pad, const int32_t* tile_list,
                       const int32_t* tile_cnt, int tile_stride, int list_rows, int64_t block0, int64_t nblk, int need,

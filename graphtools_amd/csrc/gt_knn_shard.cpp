@@ -238,7 +238,7 @@ int gt_knn_shard_local(gt_ctx* ctx, int64_t r0, int64_t r1, int need_m, double r
         GT_TRY(gt_sym_gather(ctx, perm, n_pad_s, k->Ycs.p, k->hnegs.as<float>(), k->hnegs_fin.as<float>()));
         GT_TRY(gt_sym_schedule(ctx, n_pad_s, bq, bn, ctx->sym_cells, stride_a, ctx->sym_max_nb, tile_stride, k->sym_work,
                                k->sym_tiles.as<int32_t>(), k->sym_tile_cnt.as<int32_t>(),
-                               k->sym_stat.as<unsigned long long>() + 5));
+                               k->sym_stat.as<unsigned long long>() + 5, p0, p1));
         // every row that is not the rank's: no threshold (+inf: asks for nothing, admits nothing, has no radius)
         GT_HIP(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(k->thr_final.p), 0x7F800000, size_t(n_pad_s), ctx->stream));
     }

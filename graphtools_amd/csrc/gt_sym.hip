@@ -221,9 +221,14 @@ __global__ __launch_bounds__(256) void sym_gmin_kernel(const int64_t n_pad, cons
 // M nearest landmarks of every landmark (itself first): one wave per landmark, float32 squared differences of the
 // float16 landmark rows (approximate by design: any tile list is correct)
 __global__ __launch_bounds__(64) void landmark_neighbours_kernel(const _Float16* __restrict__ Yl, const int L, const int DP,
-                                                                 const int M, int32_t* __restrict__ nbr) {
+                                                                 const int M, int32_t* __restrict__ nbr,
+                                                                 const uint32_t* __restrict__ cell_lo,
+                                                                 const uint32_t* __restrict__ cell_hi) {
     extern __shared__ float dist[];   // [L]
     const int a = blockIdx.x, lane = threadIdx.x;
+    // (cell_lo / cell_hi, optional: addresses of the first and last cell whose neighbours anybody will ask for - the cells
+    //  of a rank's own rows in a row-sharded build)
+    if (cell_lo && (uint32_t(a) < *cell_lo || uint32_t(a) > *cell_hi)) return;
     // rows are DP halves = DP/8 16-byte chunks (DP is a multiple of 16): one vector load per 8 features
     typedef _Float16 half8 __attribute__((ext_vector_type(8)));
     const half8* ra = reinterpret_cast<const half8*>(Yl + size_t(a) * DP);
@@ -288,9 +293,10 @@ __global__ __launch_bounds__(64) void sym_schedule_kernel(const uint32_t* __rest
                                                           const int32_t* __restrict__ nbr, const int M, const int NB,
                                                           const int BQ, const int BN, const int T, const int stride,
                                                           const int max_nb, const int tile_stride,
-                                                          int32_t* __restrict__ tile_list, int32_t* __restrict__ tile_cnt) {
+                                                          int32_t* __restrict__ tile_list, int32_t* __restrict__ tile_cnt,
+                                                          const int block0) {
     extern __shared__ uint32_t bm[];   // [ceil(T / 32)]
-    const int I = blockIdx.x, lane = threadIdx.x;
+    const int I = block0 + blockIdx.x, lane = threadIdx.x;
     const int nw = (T + 31) / 32;
     for (int w = lane; w < nw; w += 64) bm[w] = 0u;
     __syncthreads();
@@ -978,10 +984,13 @@ __global__ __launch_bounds__(256) void cell_ball_kernel(const _Float16* __restri
 template <int DPC>
 __global__ __launch_bounds__(256) void cell_mask_kernel(const int L, const float* __restrict__ centre,
                                                         const float* __restrict__ radius, const float* __restrict__ need,
-                                                        uint32_t* __restrict__ mask) {
+                                                        uint32_t* __restrict__ mask, const uint32_t* __restrict__ cell_lo,
+                                                        const uint32_t* __restrict__ cell_hi) {
     __shared__ float ca[64][DPC];
     const int words = (L + 31) / 32;
     const int a0 = blockIdx.y * 64, b = blockIdx.x * 256 + threadIdx.x;
+    // (optional: only the mask rows of the cells [*cell_lo, *cell_hi] will be read - a rank's own queries)
+    if (cell_lo && (uint32_t(a0 + 63) < *cell_lo || uint32_t(a0) > *cell_hi)) return;
     const int lane = threadIdx.x & 63;
     for (int f = threadIdx.x; f < 64 * DPC; f += 256) {
         const int a = a0 + f / DPC;
@@ -1361,6 +1370,8 @@ int gt_sym_bound_queue(gt_ctx* ctx, int64_t n_pad_s, const void* Ys, const float
     const uint32_t* cell_sorted = ctx->order_cell.as<uint32_t>() + ctx->n;
     GT_HIP(ctx, hipMemsetAsync(start, 0xFF, 2 * size_t(L) * sizeof(int32_t), ctx->stream));   // -1: empty cell
     GT_HIP(ctx, hipMemsetAsync(count_dev, 0, 2 * sizeof(uint32_t), ctx->stream));   // [0] this rank's units, [1] all ranks'
+    const bool own = own_p1 > own_p0;
+    const int64_t own_pl = own ? std::min<int64_t>(own_p1, ctx->n) : 0;
     hipLaunchKernelGGL(cell_ranges_kernel, dim3((unsigned)ceil_div64(ctx->n, 256)), dim3(256), 0, ctx->stream, cell_sorted,
                        ctx->n, start, endp);
     hipLaunchKernelGGL(cell_ball_kernel, dim3((unsigned)L), dim3(256), 0, ctx->stream, reinterpret_cast<const _Float16*>(Ys),
@@ -1369,7 +1380,8 @@ int gt_sym_bound_queue(gt_ctx* ctx, int64_t n_pad_s, const void* Ys, const float
         const dim3 grid((unsigned)ceil_div64(L, 256), (unsigned)ceil_div64(L, 64));
 #define GT_MASK_CASE(DPC_)                                                                                               \
     case DPC_:                                                                                                           \
-        hipLaunchKernelGGL(cell_mask_kernel<DPC_>, grid, dim3(256), 0, ctx->stream, L, centre, radius, need, mask);      \
+        hipLaunchKernelGGL(cell_mask_kernel<DPC_>, grid, dim3(256), 0, ctx->stream, L, centre, radius, need, mask,       \
+                           own ? cell_sorted + own_p0 : nullptr, own ? cell_sorted + (own_pl - 1) : nullptr);            \
         break;
         switch (DP) {
             GT_MASK_CASE(16) GT_MASK_CASE(32) GT_MASK_CASE(48) GT_MASK_CASE(64) GT_MASK_CASE(80) GT_MASK_CASE(96)
@@ -1411,7 +1423,7 @@ int gt_sym_bound_queue(gt_ctx* ctx, int64_t n_pad_s, const void* Ys, const float
                 (long long)infn, (long long)open_pairs);
     }
     const double* est_ptr = nullptr;
-    {
+    if (!own) {
         // forecast: far more undecided units than the queue holds -> the caller falls through to the collect launch without
         // paying for their enumeration (the same verdict on every rank: the cells are the same everywhere)
         double* est_dev = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(tcell + nt32) + 7) & ~uintptr_t(7));
@@ -1533,7 +1545,8 @@ int gt_sym_shard_scatter(gt_ctx* ctx, const void* recs, int64_t n_recs, int64_t 
 // Tile lists of launch A for the NB query blocks of the sorted order (tile_list [NB][tile_stride], tile_cnt [NB]).
 // Uses the landmark rows and the sorted cell ids the query ordering left in the context (gt_order.hip).
 int gt_sym_schedule(gt_ctx* ctx, int64_t n_pad_s, int bq, int bn, int cells, int stride, int max_nb, int tile_stride,
-                    DevBuf& work, int32_t* tile_list, int32_t* tile_cnt, unsigned long long* tiles_total) {
+                    DevBuf& work, int32_t* tile_list, int32_t* tile_cnt, unsigned long long* tiles_total, int64_t p_first,
+                    int64_t p_last) {
     const int L = ctx->order_L;
     if (L <= 0 || !ctx->land_Y.p) GT_FAIL(ctx, GT_E_STATE, "sym schedule: no landmark cells");
     const int M = std::min(std::min(cells, 32), L);
@@ -1543,18 +1556,24 @@ int gt_sym_schedule(gt_ctx* ctx, int64_t n_pad_s, int bq, int bn, int cells, int
     int32_t* start = nbr + size_t(L) * M;
     int32_t* endp = start + L;
     GT_HIP(ctx, hipMemsetAsync(start, 0xFF, 2 * size_t(L) * sizeof(int32_t), ctx->stream));   // -1: empty cell
-    hipLaunchKernelGGL(landmark_neighbours_kernel, dim3((unsigned)L), dim3(64), size_t(L) * sizeof(float), ctx->stream,
-                       ctx->land_Y.as<_Float16>(), L, ctx->DP, M, nbr);
-    GT_HIP(ctx, hipGetLastError());
     const uint32_t* cell_sorted = ctx->order_cell.as<uint32_t>() + ctx->n;
+    // p_last > p_first: tile lists (and landmark neighbourhoods) for the query blocks of the sorted positions [p_first, p_last)
+    // only - a rank's own rows; the cells of those rows are a run of cell numbers (the order is sorted by cell)
+    const bool part = p_last > p_first;
+    const int64_t pl = part ? std::min<int64_t>(p_last, ctx->n) : 0;
+    hipLaunchKernelGGL(landmark_neighbours_kernel, dim3((unsigned)L), dim3(64), size_t(L) * sizeof(float), ctx->stream,
+                       ctx->land_Y.as<_Float16>(), L, ctx->DP, M, nbr, part ? cell_sorted + p_first : nullptr,
+                       part ? cell_sorted + (pl - 1) : nullptr);
+    GT_HIP(ctx, hipGetLastError());
     hipLaunchKernelGGL(cell_ranges_kernel, dim3((unsigned)ceil_div64(ctx->n, 256)), dim3(256), 0, ctx->stream, cell_sorted,
                        ctx->n, start, endp);
     GT_HIP(ctx, hipGetLastError());
     const int NB = int(n_pad_s / bq), T = int(n_pad_s / bn);
-    hipLaunchKernelGGL(sym_schedule_kernel, dim3((unsigned)NB), dim3(64), size_t((T + 31) / 32) * sizeof(uint32_t), ctx->stream,
-                       cell_sorted, ctx->n, start, endp, nbr, M, NB, bq, bn, T, stride, max_nb, tile_stride, tile_list, tile_cnt);
+    const int b0 = part ? int(p_first / bq) : 0, nblk = part ? int(ceil_div64(p_last, bq)) - b0 : NB;
+    hipLaunchKernelGGL(sym_schedule_kernel, dim3((unsigned)nblk), dim3(64), size_t((T + 31) / 32) * sizeof(uint32_t), ctx->stream,
+                       cell_sorted, ctx->n, start, endp, nbr, M, NB, bq, bn, T, stride, max_nb, tile_stride, tile_list, tile_cnt, b0);
     GT_HIP(ctx, hipGetLastError());
-    if (tiles_total) {   // statistics: tiles launch A visits in all (device counter, pre-zeroed by the caller)
+    if (tiles_total && !part) {   // statistics: tiles launch A visits in all (device counter, pre-zeroed by the caller)
         hipLaunchKernelGGL(sum_i32_kernel, dim3(16), dim3(256), 0, ctx->stream, tile_cnt, int64_t(NB), tiles_total);
         GT_HIP(ctx, hipGetLastError());
     }

@@ -15,6 +15,7 @@ import numpy as np
 from scipy import sparse
 
 from . import _hip
+from . import base as _base
 from .base import BaseGraph, Data
 
 
@@ -265,8 +266,20 @@ class kNNGraph(DataGraph):
         if getattr(self, "_device_state", None) != want:
             self._device_build(*want)
 
+    # stage timers of the library behind the reference's two phases (graphs.py:873-885)
+    _KNN_STAGES = ("prep", "query_order", "sym_prepare", "sym_seed", "sym_bound", "sym_cold", "knn_select", "rerank", "fallback",
+                   "radius")
+    _AFFINITY_STAGES = ("affinity", "symmetrize", "normalize")
+
+    def _log_phases(self):
+        if self.verbose:
+            ms = lambda names: sum(max(self.hip.stage_ms(s), 0.0) for s in names)   # noqa: E731
+            _base.log_task(self.verbose, "KNN search", ms(self._KNN_STAGES) * 1e-3)
+            _base.log_task(self.verbose, "affinities", ms(self._AFFINITY_STAGES) * 1e-3)
+
     def _build_kernel(self):
         nnz, flags = self._device_build(self.kernel_symm, self.theta, self.anisotropy)
+        self._log_phases()
         self._build_flags = flags
         data, indices, indptr = self.hip.graph_fetch_csr(_hip.CSR_K)
         n = self.data_nu.shape[0]
@@ -657,27 +670,37 @@ class TraditionalGraph(DataGraph):
         Returns None when this route does not apply (small sets, thresh = 0, duplicate points - their warnings and the
         0 / 0 bandwidth rule live in the all-pairs path)."""
         n = data.shape[0]
-        if (n < self._NEIGHBOUR_ROUTE_MIN or not self.thresh or self.thresh <= 0 or self.decay is None
+        # (thresh below float64's eps: the kNN build clamps it to eps - graphs.py:628-629 is a kNNGraph rule, the reference's
+        #  TraditionalGraph keeps entries in [thresh, eps) - so such a threshold belongs to the all-pairs path)
+        if (n < self._NEIGHBOUR_ROUTE_MIN or not self.thresh or self.thresh < np.finfo(float).eps or self.decay is None
                 or (self.knn is not None and self.knn + 1 > _hip.MAX_KNN)):   # (+ 1: the point itself)
             return None
-        X = np.asarray(data, dtype=np.float64)
-        X = np.ascontiguousarray(X - X.mean(axis=0, keepdims=True))
-        self.hip.set_option("metric", "euclidean")
-        self.hip.set_points(X)
         bw = bandwidth
         if bw is not None and not isinstance(bw, numbers.Number):
             bw = np.asarray(bw, dtype=np.float64)
             if bw.shape != (n,):
                 return None
-        params, keep = _hip.Context.make_params(self.knn if self.knn is not None else 1, self.decay, self.thresh, bw,
-                                                self.bandwidth_scale, None, self.kernel_symm, self.theta, self.anisotropy)
-        nnz, flags = self.hip.graph_build(params)
-        del keep
-        if flags & _hip.FLAG_DUPLICATES:
+        X = np.asarray(data, dtype=np.float64)
+        X = np.ascontiguousarray(X - X.mean(axis=0, keepdims=True))
+        try:
+            # anything this route cannot hold (more than 2048 features, a radius list or the n x n device copy beyond the
+            # memory at hand) is the all-pairs path's to build, as it was before this route existed
+            self.hip.set_option("metric", "euclidean")
+            self.hip.set_points(X)
+            params, keep = _hip.Context.make_params(self.knn if self.knn is not None else 1, self.decay, self.thresh, bw,
+                                                    self.bandwidth_scale, None, self.kernel_symm, self.theta, self.anisotropy)
+            nnz, flags = self.hip.graph_build(params)
+            del keep
+            if flags & _hip.FLAG_DUPLICATES:
+                return None
+            K = self.hip.graph_to_dense(_hip.CSR_K, n)
+            self._diff_op = self.hip.graph_to_dense(_hip.CSR_P, n)
+            self._kernel_degree = self.hip.graph_fetch_vec(_hip.VEC_DEGREE).reshape(-1, 1)
+        except _hip.HipError:
+            self._diff_op = None
+            if hasattr(self, "_kernel_degree"):
+                del self._kernel_degree
             return None
-        K = self.hip.graph_to_dense(_hip.CSR_K, n)
-        self._diff_op = self.hip.graph_to_dense(_hip.CSR_P, n)
-        self._kernel_degree = self.hip.graph_fetch_vec(_hip.VEC_DEGREE).reshape(-1, 1)
         self._emit_build_warnings(flags, K)
         return K
 

@@ -212,6 +212,33 @@ def test_exact_graph_from_points_keeps_the_all_pairs_path_for_duplicates_and_sma
     assert calls == []
 
 
+def test_exact_graph_from_points_hands_what_the_search_cannot_hold_to_the_all_pairs_path(monkeypatch):
+    """(round-3 advisor finding) a threshold below float64's eps is NOT clamped by TraditionalGraph (graphs.py:628-629 is a
+    kNNGraph rule): entries in [thresh, eps) stay; and inputs the search refuses (more than 2048 features with a caller-given
+    bandwidth: GT_E_LIMIT) are built by the all-pairs kernel instead of raising"""
+    from graphtools_amd import _hip
+    calls = []
+    real = _hip.Context.graph_to_dense
+    monkeypatch.setattr(_hip.Context, "graph_to_dense", lambda self, *a, **k: (calls.append(a[0]), real(self, *a, **k))[1])
+    X = make_mix(4200, 16, 21).astype(np.float64)
+    G = graphtools_amd.Graph(X, n_pca=None, graphtype="exact", knn=5, decay=10, thresh=1e-20)
+    G.K
+    assert calls == []                       # the all-pairs path
+    K0, P0 = oracle.exact_graph(X, knn=5, decay=10, thresh=1e-20)
+    tiny = (K0 > 0) & (K0 < np.finfo(float).eps)
+    assert tiny.sum() > 0, "the case should hold entries between thresh and eps"
+    np.testing.assert_allclose(G.K, K0, rtol=1e-9, atol=1e-300)
+    np.testing.assert_allclose(G.P, P0, rtol=1e-7, atol=1e-300)
+    # wide data + explicit bandwidth: the neighbour search refuses, the build still succeeds
+    rng = np.random.default_rng(3)
+    Xw = (rng.standard_normal((4100, 5)) @ rng.standard_normal((5, 2100))).astype(np.float64)
+    Gw = graphtools_amd.Graph(Xw, n_pca=None, graphtype="exact", knn=5, decay=10, bandwidth=60.0)
+    Kw0, Pw0 = oracle.exact_graph(Xw, knn=5, decay=10, bandwidth=60.0)
+    flip = (Gw.K == 0) != (Kw0 == 0)
+    assert flip.sum() <= 4
+    np.testing.assert_allclose(Gw.K[~flip], Kw0[~flip], rtol=1e-9, atol=1e-300)
+
+
 def test_distance_dtype_option_gives_float32_points_float64_distances():
     """'distance_dtype' = 'float64': a float32 point set's distances come out of the float64 keys unrounded (scipy's pdist
     semantics) - the same graph as the float64 copy of the points gives"""

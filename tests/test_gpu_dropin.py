@@ -137,3 +137,37 @@ def test_landmark_operator_of_an_exact_graph():
     np.testing.assert_allclose(G.landmark_op, z["landmark_op"], rtol=1e-9, atol=1e-15)
     assert isinstance(G.transitions, np.ndarray) and G.transitions.shape == z["transitions"].shape
     np.testing.assert_allclose(G.transitions, z["transitions"], rtol=1e-9, atol=1e-15)
+
+
+def test_pickle_round_trip_drops_the_device_context_and_rebuilds_lazily(tmp_path, capsys):
+    """reference graphs are plain picklable objects (base.py:887-902 to_pickle); here the device context is left behind and
+    rebuilt on first use: fetched results travel, device-side calls (extend_to_data) work again after loading"""
+    import pickle
+
+    from conftest import make_mix
+
+    X = make_mix(3000, 20, 3)
+    G = graphtools_amd.Graph(X, knn=8, decay=20, n_pca=None, verbose=True)
+    out = capsys.readouterr().out
+    assert "Calculated KNN search in" in out and "Calculated affinities in" in out     # the reference's task names (graphs.py:873-885)
+    K, P = G.K.copy(), G.P.copy()
+    blob = pickle.dumps(G)
+    G2 = pickle.loads(blob)
+    assert not hasattr(G2, "_hip_ctx")
+    assert (G2.K != K).nnz == 0 and (G2.P != P).nnz == 0           # host results travelled
+    Y = X[:50] + 0.01
+    T1 = G.extend_to_data(Y)
+    T2 = G2.extend_to_data(Y)                                         # rebinds the points, rebuilds on the device
+    assert (T1 != T2).nnz == 0
+    np.testing.assert_array_equal(np.asarray(G2.kernel_degree), np.asarray(G.kernel_degree))
+    path = tmp_path / "g.pkl"
+    G.to_pickle(str(path))
+    with open(path, "rb") as f:
+        G3 = pickle.load(f)
+    assert (G3.K != K).nnz == 0
+    # a graph that was never initialised pickles too and builds after loading
+    G4 = pickle.loads(pickle.dumps(graphtools_amd.Graph(X, knn=8, decay=20, n_pca=None, initialize=False)))
+    assert not hasattr(G4, "_kernel")
+    assert (G4.K != K).nnz == 0
+    quiet = graphtools_amd.Graph(X, knn=8, decay=20, n_pca=None, verbose=0)
+    assert "Calculated" not in capsys.readouterr().out
