@@ -92,6 +92,7 @@ _SIGNATURES = {
                                       _c.c_double, _c.c_double, _c.POINTER(_c.c_int64), _c.POINTER(_c.c_uint32)]),
     "gt_graph_rows": (_c.c_int, [_c.c_void_p, _c.POINTER(_c.c_int64), _c.POINTER(_c.c_int64), _c.POINTER(_c.c_int64)]),
     "gt_graph_fetch_csr": (_c.c_int, [_c.c_void_p, _c.c_int32, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int32]),
+    "gt_graph_fetch_kp": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p]),
     "gt_graph_to_dense": (_c.c_int, [_c.c_void_p, _c.c_int32, _c.c_void_p, _c.c_int32, _c.c_int32]),
     "gt_release_cached_memory": (_c.c_int, []),
     "gt_host_place_block": (_c.c_int, [_c.c_int64] + [_c.c_void_p] * 9),
@@ -472,6 +473,17 @@ class Context:
         self._check(self.lib.gt_graph_fetch_csr(self.h, which, _ptr(data), _ptr(indices) if structure else None,
                                                 _ptr(indptr) if structure else None, 0), "gt_graph_fetch_csr")
         return data, indices, indptr
+
+    def graph_fetch_kp(self):
+        """host copies of K and P in one pass over the link: (K data, indices int32, indptr int64, P data); the P values are
+        derived on the host from K and the degrees while K is still arriving (bit-identical to the device's P)"""
+        r0, r1, nnz = self.graph_rows()
+        kd = np.empty(nnz, dtype=np.float64)
+        pd = np.empty(nnz, dtype=np.float64)
+        indices = np.empty(nnz, dtype=np.int32)
+        indptr = np.empty(r1 - r0 + 1, dtype=np.int64)
+        self._check(self.lib.gt_graph_fetch_kp(self.h, _ptr(kd), _ptr(indices), _ptr(indptr), _ptr(pd)), "gt_graph_fetch_kp")
+        return kd, indices, indptr, pd
 
     def graph_to_dense(self, which, n, dtype=np.float64, out_device=None):
         """dense copy [owned rows, n] of K or P (n = columns of the graph): a host ndarray, or (``out_device``: a CUDA torch

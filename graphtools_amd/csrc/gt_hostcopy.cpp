@@ -12,6 +12,7 @@
 // runtime may already be gone when static destructors run.
 #include <algorithm>
 #include <atomic>
+#include <functional>
 #include <mutex>
 #include <system_error>
 #include <thread>
@@ -69,7 +70,12 @@ hipError_t pipe_for(int device, Pipe** out) {
 }
 
 // chunk c of the copy covers bytes [c * kSlotBytes, min(bytes, (c+1) * kSlotBytes)); lane l takes c = l, l + kLanes, ...
-void lane_d2h(int device, Lane* ln, int lane, char* dst, const char* src, size_t bytes, std::atomic<int>* err) {
+// post (optional): called by the lane's thread for every chunk once it sits in the caller's memory (byte offset, length) -
+// host work that rides along with the transfer (gt_fetch_kp_host: P = K / degree while the next chunks are on the link)
+typedef std::function<void(size_t, size_t)> ChunkFn;
+
+void lane_d2h(int device, Lane* ln, int lane, char* dst, const char* src, size_t bytes, std::atomic<int>* err,
+              const ChunkFn* post) {
     hipError_t e = hipSetDevice(device);
     const size_t nchunks = (bytes + kSlotBytes - 1) / kSlotBytes;
     auto issue = [&](size_t c, int s) {
@@ -86,6 +92,7 @@ void lane_d2h(int device, Lane* ln, int lane, char* dst, const char* src, size_t
         if (e != hipSuccess) break;
         const size_t off = c * kSlotBytes, len = std::min(kSlotBytes, bytes - off);
         std::memcpy(dst + off, ln->slot[s], len);
+        if (post) (*post)(off, len);
     }
     if (e != hipSuccess) {
         (void)hipStreamSynchronize(ln->stream);
@@ -93,7 +100,7 @@ void lane_d2h(int device, Lane* ln, int lane, char* dst, const char* src, size_t
     }
 }
 
-int pipelined_d2h(gt_ctx* ctx, void* dst, const void* src, size_t bytes) {
+int pipelined_d2h(gt_ctx* ctx, void* dst, const void* src, size_t bytes, const ChunkFn* post = nullptr) {
     Pipe* p = nullptr;
     GT_HIP(ctx, pipe_for(ctx->device, &p));
     std::lock_guard<std::mutex> lock(p->busy);
@@ -104,11 +111,11 @@ int pipelined_d2h(gt_ctx* ctx, void* dst, const void* src, size_t bytes) {
     try {
         for (; started < nl; ++started)
             th[started] = std::thread(lane_d2h, ctx->device, &p->lanes[started], started, static_cast<char*>(dst),
-                                      static_cast<const char*>(src), bytes, &err);
+                                      static_cast<const char*>(src), bytes, &err, post);
     } catch (const std::system_error&) {
         // the process cannot start another thread: this thread takes over the lanes that did not get one
         for (int l = started; l < nl; ++l)
-            lane_d2h(ctx->device, &p->lanes[l], l, static_cast<char*>(dst), static_cast<const char*>(src), bytes, &err);
+            lane_d2h(ctx->device, &p->lanes[l], l, static_cast<char*>(dst), static_cast<const char*>(src), bytes, &err, post);
     }
     for (int l = 0; l < started; ++l) th[l].join();
     if (err.load() != 0) {
@@ -129,6 +136,51 @@ int gt_copy_to_host(gt_ctx* ctx, void* dst_host, const void* src_dev, size_t byt
     }
     GT_HIP(ctx, hipStreamSynchronize(ctx->stream));   // the producer kernels of src_dev
     return pipelined_d2h(ctx, dst_host, src_dev, bytes);
+}
+
+// K (values) to the host with P derived on the way: P[e] = K[e] / degree[row of e] - the division the device made when it
+// wrote its own P (compact_kernel / merge_final_kernel: v / asum, asum = the row sum in the degrees' summation order; IEEE
+// division on both sides: the same bits, tests/test_gpu_dropin.py) - computed by the copy lanes on every chunk of K as it
+// lands, while later chunks are still on the link.  The 0.93 GB of P values of a C3 graph then never cross PCIe (a third of
+// the host-complete build's transfer).  indptr / degree: host arrays already fetched; *negative: set when a value < 0 was
+// seen (|v| sums differ from the degrees then: the caller fetches P itself).
+int gt_fetch_kp_host(gt_ctx* ctx, double* K_host, double* P_host, const double* K_dev, long long nnz_, const long long* indptr_,
+                     const double* degree, long long nrows_, int* negative) {
+    const int64_t nnz = nnz_, nrows = nrows_;
+    const int64_t* indptr = reinterpret_cast<const int64_t*>(indptr_);
+    *negative = 0;
+    if (nnz <= 0) return GT_OK;
+    std::atomic<int> neg(0);
+    const ChunkFn post = [&](size_t off, size_t len) {
+        const int64_t e0 = int64_t(off / sizeof(double)), e1 = e0 + int64_t(len / sizeof(double));
+        int64_t row = int64_t(std::upper_bound(indptr, indptr + nrows + 1, e0) - indptr) - 1;   // indptr[row] <= e0 < indptr[row + 1]
+        bool bad = false;
+        for (int64_t e = e0; e < e1;) {
+            while (row + 1 <= nrows && indptr[row + 1] <= e) ++row;
+            const int64_t end = std::min<int64_t>(e1, indptr[row + 1]);
+            const double s = degree[row];
+            if (s != 0.0) {
+                for (; e < end; ++e) {
+                    const double v = K_host[e];
+                    bad |= v < 0.0;
+                    P_host[e] = v / s;
+                }
+            } else {
+                for (; e < end; ++e) P_host[e] = K_host[e];
+            }
+        }
+        if (bad) neg.store(1);
+    };
+    const size_t bytes = size_t(nnz) * sizeof(double);
+    GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (bytes < kMinPipelined || kLanes == 0) {
+        GT_HIP(ctx, hipMemcpy(K_host, K_dev, bytes, hipMemcpyDeviceToHost));
+        post(0, bytes);
+    } else {
+        GT_TRY(pipelined_d2h(ctx, K_host, K_dev, bytes, &post));
+    }
+    *negative = neg.load();
+    return GT_OK;
 }
 
 int gt_copy_from_host(gt_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes) {

@@ -249,6 +249,7 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
                 if (k->xs_ready) {
                     sr.Xs = k->Xs.p;
                     sr.xns = k->xns.as<double>();
+                    sr.xs_d = k->xs_d;
                 }
             }
             {
@@ -312,7 +313,7 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
                 StageSpan span(ctx, "sym_prepare");
                 GT_HIP(ctx, k->hnegs_fin.reserve(size_t(n_pad_s) * sizeof(float)));
                 GT_TRY(gt_sym_gather(ctx, perm, n_pad_s, k->Ycs.p, k->hnegs.as<float>(), k->hnegs_fin.as<float>()));
-                if (ctx->sym_sorted_points != 0) GT_TRY(gt_sym_gather_points(ctx, perm));
+                if (ctx->sym_sorted_points != 0) GT_TRY(gt_sym_gather_points(ctx, perm, true));
                 GT_TRY(gt_sym_schedule(ctx, n_pad_s, bq_sym, bn_sym, ctx->sym_cells, stride_a, ctx->sym_max_nb, tile_stride,
                                        k->sym_work, k->sym_tiles.as<int32_t>(), k->sym_tile_cnt.as<int32_t>(),
                                        k->sym_stat.as<unsigned long long>() + 5));
@@ -547,6 +548,7 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
             if (k->xs_ready) {
                 sr.Xs = k->Xs.p;
                 sr.xns = k->xns.as<double>();
+                sr.xs_d = k->xs_d;
             }
             bool wrote_t = false;
             if (ctx->symm_pairs != 0 && MP == 256) {

@@ -38,6 +38,8 @@ struct KnnWork {
     bool keyt_valid = false;                      //   ... written by the last candidate search for every row it proved
     DevBuf Xs, xns;                               //   the points and their squared norms in cell-sorted order (gt_sym_gather_points)
     bool xs_ready = false;                        //   ... valid for the current order (reset whenever the order is rebuilt)
+    int xs_d = 0;                                 //   row stride of Xs in elements: d, or d rounded up to a multiple of 4 (float32
+                                                  //   rows, zero padded: the four-lanes-per-row re-rank reads 16-byte quarters)
     DevBuf sym_racc, sym_farcnt;                     // radius / spread statistics of the orphan cut (4 doubles), far-kept
                                                   // seeds per sorted position
     DevBuf sym_hh, sym_thrh, sym_gh, sym_gminh;   // two-stage scoring (gt_sym.hip sym_half_*)
@@ -189,6 +191,7 @@ struct SymRerank {
     // the points / norms in sorted order (optional): candidate rows are then read by position
     const void* Xs = nullptr;
     const double* xns = nullptr;
+    int xs_d = 0;              // row stride of Xs in elements (0: the points' own d)
     // transposed keys next to the table's own (optional; rerank_sym4_kernel only): [nq][256] and one flag per row
     double* cand_d2t = nullptr;
     uint8_t* keyt_ok = nullptr;
@@ -201,7 +204,9 @@ int gt_launch_rerank_sym(gt_ctx* ctx, const RerankArgs& a, const SymRerank& sr);
 // hs_fin (optional): the same seeds with -3e38 instead of -inf on the pad rows (gt_seed.hip)
 int gt_sym_gather(gt_ctx* ctx, const int32_t* perm, int64_t n_pad_s, void* Ys, float* hs, float* hs_fin = nullptr);
 // the caller's points (all ctx->n rows, their dtype) and norms in sorted order -> KnnWork::Xs / xns, xs_ready
-int gt_sym_gather_points(gt_ctx* ctx, const int32_t* perm);
+// pad4: float32 rows whose length is no multiple of 4 are zero padded to one (KnnWork::xs_d) - the zeros add nothing to any
+// dot product, and the copy serves the 16-byte loads of rerank_sym4_kernel (d = 50: C2, C5)
+int gt_sym_gather_points(gt_ctx* ctx, const int32_t* perm, bool pad4 = false);
 // rows [p_first, p_last) of the sorted order only (p_last < 0: all); gmin = nullptr: sub-tile minima not formed
 int gt_sym_thresholds(gt_ctx* ctx, const int32_t* perm, int64_t n_pad_s, const float* hs, const uint64_t* lists, int lstride,
                       const uint32_t* counts, int need_m, const ErrModel& err, double rkf, float* thr, float* g, float* gmin,

@@ -1011,15 +1011,20 @@ int gt_launch_rerank_sym(gt_ctx* ctx, const RerankArgs& a, const SymRerank& sr) 
                        a.unproven, sr.stat, (ctx->dbg_select & 256) ? 1 : 0, sr.invperm, sr.own_rows, sr.own_r0, ctx->xcd_chunk,      \
                        (const T_*)sr.Xs, sr.xns, a.metric, sr.pos0)
 #define GT_RERANK_SYM4_LAUNCH(DB_, WT_, WPB_)                                                                             \
-    hipLaunchKernelGGL((rerank_sym4_kernel<DB_, WT_, WPB_>), dim3((unsigned)ceil_div64(a.nq, WPB_)), dim3(64 * WPB_), 0, ctx->stream, (const float*)a.X, a.d, \
+    hipLaunchKernelGGL((rerank_sym4_kernel<DB_, WT_, WPB_>), dim3((unsigned)ceil_div64(a.nq, WPB_)), dim3(64 * WPB_), 0, ctx->stream, (const float*)a.X, dx, \
                        a.xn, a.nq, sr.tlists, sr.tcap, sr.tcounts, a.thr_final, a.ymax2, a.err, a.need_m, sr.perm,        \
                        a.cand_d2, a.cand_j, a.cand_n, a.d2_lb, a.fb_count, a.fb_rows, a.gflags, a.radius_key_factor,      \
                        a.unproven, sr.stat, (ctx->dbg_select & 256) ? 1 : 0, sr.invperm, sr.own_rows, sr.own_r0, ctx->xcd_chunk,      \
                        (const float*)sr.Xs, sr.xns, sr.cand_d2t, sr.keyt_ok, sr.nokeyt_rows, sr.nokeyt_count, a.metric, sr.pos0)
     if (sr.wrote_t) *sr.wrote_t = false;
+    // (dx: row length = stride of the sorted copy - the points' d, or d zero padded to a multiple of 4)
+    const int dx = (sr.Xs && sr.xs_d > 0) ? sr.xs_d : a.d;
+    if (dx != a.d && !(a.dtype == GT_F32 && (dx & 3) == 0 && dx <= 64 && ctx->rerank_lanes4 != 0))
+        GT_FAIL(ctx, GT_E_STATE, "rerank_sym: a padded sorted copy needs the four-lanes-per-row kernel");
     if (a.dtype == GT_F32) {
         const bool f4 = (a.d & 3) == 0 && (reinterpret_cast<uintptr_t>(a.X) & 15) == 0;
-        if (f4 && ctx->rerank_lanes4 != 0 && a.d <= 64 && sr.Xs != nullptr) {
+        const bool f4x = sr.Xs != nullptr && (dx & 3) == 0 && (reinterpret_cast<uintptr_t>(sr.Xs) & 15) == 0;
+        if (f4x && ctx->rerank_lanes4 != 0 && dx <= 64) {
             const bool wt = sr.cand_d2t != nullptr && sr.keyt_ok != nullptr && sr.nokeyt_rows != nullptr && sr.nokeyt_count != nullptr;
             // one wave per workgroup: a row with more than 128 candidates costs twice a short one, and a workgroup's slots
             // are only handed on when its last wave is done (option "rerank_waves_per_block" = 4: the old grouping)

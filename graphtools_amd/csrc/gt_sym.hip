@@ -73,6 +73,18 @@ __global__ __launch_bounds__(256) void gather_points_kernel(const T* __restrict_
     Xs[f] = X[r * int64_t(d) + c];
     if (c == 0) xns[p] = xn[r];
 }
+// float32 rows of d values -> rows of dp >= d values, zero padded
+__global__ __launch_bounds__(256) void gather_points_pad_kernel(const float* __restrict__ X, const double* __restrict__ xn,
+                                                                const int32_t* __restrict__ perm, const int64_t n, const int d,
+                                                                const int dp, float* __restrict__ Xs, double* __restrict__ xns) {
+    const int64_t f = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (f >= n * int64_t(dp)) return;
+    const int64_t p = f / dp;
+    const int c = int(f - p * dp);
+    const int64_t r = perm[p];
+    Xs[f] = c < d ? X[r * int64_t(d) + c] : 0.f;
+    if (c == 0) xns[p] = xn[r];
+}
 __global__ __launch_bounds__(256) void gather_points16_kernel(const uint4* __restrict__ X, const double* __restrict__ xn,
                                                               const int32_t* __restrict__ perm, const int64_t n, const int c16,
                                                               uint4* __restrict__ Xs, double* __restrict__ xns) {
@@ -1193,14 +1205,25 @@ int gt_sym_gather(gt_ctx* ctx, const int32_t* perm, int64_t n_pad_s, void* Ys, f
     return GT_OK;
 }
 
-int gt_sym_gather_points(gt_ctx* ctx, const int32_t* perm) {
+int gt_sym_gather_points(gt_ctx* ctx, const int32_t* perm, bool pad4) {
     KnnWork* k = ctx->knn;
     const size_t esz = ctx->dtype == GT_F32 ? 4 : 8;
     const int64_t n = ctx->n;
     const int d = ctx->d;
     k->xs_ready = false;
-    GT_HIP(ctx, k->Xs.reserve(size_t(n) * d * esz));
+    k->xs_d = d;
     GT_HIP(ctx, k->xns.reserve(size_t(n) * sizeof(double)));
+    if (pad4 && ctx->dtype == GT_F32 && (d & 3) != 0 && d <= 64 && ctx->rerank_lanes4 != 0) {
+        const int dp = (d + 3) & ~3;
+        GT_HIP(ctx, k->Xs.reserve(size_t(n) * dp * esz));
+        hipLaunchKernelGGL(gather_points_pad_kernel, dim3((unsigned)ceil_div64(n * dp, 256)), dim3(256), 0, ctx->stream,
+                           (const float*)ctx->X, ctx->xn.as<double>(), perm, n, d, dp, k->Xs.as<float>(), k->xns.as<double>());
+        GT_HIP(ctx, hipGetLastError());
+        k->xs_d = dp;
+        k->xs_ready = true;
+        return GT_OK;
+    }
+    GT_HIP(ctx, k->Xs.reserve(size_t(n) * d * esz));
     const size_t row_bytes = size_t(d) * esz;
     if (row_bytes % 16 == 0 && (reinterpret_cast<uintptr_t>(ctx->X) & 15) == 0) {
         const int c16 = int(row_bytes / 16);
@@ -1233,9 +1256,10 @@ int gt_sym_thresholds(gt_ctx* ctx, const int32_t* perm, int64_t n_pad_s, const f
     const bool sorted = kw && kw->xs_ready;
     const void* Xp = sorted ? kw->Xs.p : ctx->X;
     const double* xnp = sorted ? kw->xns.as<double>() : ctx->xn.as<double>();
+    const int dx = sorted ? kw->xs_d : ctx->d;   // (row stride = row length: a zero-padded copy adds exact zeros)
     if (ctx->dtype == GT_F32)
         hipLaunchKernelGGL(sym_thresholds_kernel<float>, grid, dim3(256), 0, ctx->stream, ctx->n, p_first, p_last, perm,
-                           (const float*)Xp, ctx->d, xnp, hs, lists, lstride, counts, need_m, ctx->ymax.as<double>(), err, rkf,
+                           (const float*)Xp, dx, xnp, hs, lists, lstride, counts, need_m, ctx->ymax.as<double>(), err, rkf,
                            thr, g, cell_sorted, nbr, M, far_total, farcnt, sorted ? 1 : 0, ctx->metric);
     else
         hipLaunchKernelGGL(sym_thresholds_kernel<double>, grid, dim3(256), 0, ctx->stream, ctx->n, p_first, p_last, perm,

@@ -281,11 +281,15 @@ class kNNGraph(DataGraph):
         nnz, flags = self._device_build(self.kernel_symm, self.theta, self.anisotropy)
         self._log_phases()
         self._build_flags = flags
-        data, indices, indptr = self.hip.graph_fetch_csr(_hip.CSR_K)
+        # K and P in one pass over the link (SURVEY 8d host-complete: scipy CSR K and P out): the P values are derived on the
+        # host from K and the degrees by the copy threads while K is still arriving - the division the device made for its
+        # own P, same bits - so they never cross PCIe (gt_graph_fetch_kp)
+        data, indices, indptr, pdata = self.hip.graph_fetch_kp()
         n = self.data_nu.shape[0]
         if nnz < 2**31:
             indptr = indptr.astype(np.int32)
         K = sparse.csr_matrix((data, indices, indptr), shape=(n, n))
+        self._diff_op = sparse.csr_matrix((pdata, K.indices, K.indptr), shape=(n, n))
         if flags & _hip.FLAG_DUPLICATES:
             self._check_duplicates()
         self._emit_build_warnings(flags, K)

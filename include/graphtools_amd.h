@@ -279,6 +279,11 @@ int gt_graph_extend(gt_ctx* ctx, const void* Y, int64_t m, int32_t y_on_device, 
 int gt_graph_rows(const gt_ctx* ctx, int64_t* row0, int64_t* row1, int64_t* nnz);
 int gt_graph_fetch_csr(gt_ctx* ctx, int32_t which, double* data, int32_t* indices, int64_t* indptr,
                        int32_t on_device);
+/* K and P of the owned rows to the host in one pass over the link (the host-complete build, SURVEY 8d: scipy CSR K and P
+ * out): structure and K values are copied; the P values are derived from them on the host by the copy threads while later
+ * chunks are on the link - P[e] = K[e] / degree[row], the division the device made for its own P (base.py:645 normalize l1;
+ * bit-identical) - so the P values never cross PCIe.  All outputs are host arrays of the caller. */
+int gt_graph_fetch_kp(gt_ctx* ctx, double* K_data, int32_t* indices, int64_t* indptr, double* P_data);
 
 /* Dense copy of the owned rows of K or P: out[nloc][n_total], zeros where the sparse form has no entry.  out_dtype GT_F32 or
  * GT_F64.  Serves the exact graph built FROM POINTS (TraditionalGraph, graphtools/graphs.py:1546-1609: pdist -> bandwidth ->

@@ -171,3 +171,25 @@ def test_pickle_round_trip_drops_the_device_context_and_rebuilds_lazily(tmp_path
     assert (G4.K != K).nnz == 0
     quiet = graphtools_amd.Graph(X, knn=8, decay=20, n_pca=None, verbose=0)
     assert "Calculated" not in capsys.readouterr().out
+
+
+def test_host_copy_of_P_derived_on_the_way_equals_the_device_P():
+    """gt_graph_fetch_kp: K and the structure cross the link, P = K / degree is formed by the copy threads on the host -
+    it must equal the P the device wrote (base.py:645) bit for bit, with and without anisotropy, on a graph large enough
+    for the pipelined copy (> 32 MB of values)"""
+    from conftest import make_mix
+    from graphtools_amd import _hip
+
+    X = make_mix(60000, 32, 17)
+    for aniso in (0.0, 0.5):
+        c = _hip.Context(0)
+        c.set_points(X)
+        p, keep = c.make_params(15, 10, 1e-4, None, 1.0, None, "+", None, aniso)
+        nnz, _ = c.graph_build(p)
+        assert nnz * 8 > (32 << 20)
+        kd, ki, kp, pd = c.graph_fetch_kp()
+        kd2, ki2, kp2 = c.graph_fetch_csr(_hip.CSR_K)
+        pd2, _, _ = c.graph_fetch_csr(_hip.CSR_P, structure=False)
+        c.close()
+        assert np.array_equal(kd, kd2) and np.array_equal(ki, ki2) and np.array_equal(kp, kp2)
+        assert np.array_equal(pd, pd2), "host-derived P differs from the device's (anisotropy %g)" % aniso
