@@ -375,18 +375,27 @@ def secondary_c4(_hip, torch, device, n=200000, d=100):
     try:
         flags = ctypes.c_uint32(0)
         t0 = time.perf_counter()
+        # in place: D -> K -> P = diff_op in the same 160 GB buffer (K and P together would be 320 GB: more than the HBM);
+        # what stays is P, the degrees (K = P * degree row by row) and the bandwidths
         rc = ctx.lib.gt_dense_graph_build(ctx.h, ctypes.c_void_p(D.data_ptr()), n, 0, 0, 1, 1, 15, 40.0, 1e-4, None, 0, 1.0,
-                                          _hip.SYMM["+"], 1.0, 0.0, 1, None, None, 1, ctypes.byref(flags))
+                                          _hip.SYMM["+"], 1.0, 0.0, 1, None, ctypes.c_void_p(D.data_ptr()), 1, ctypes.byref(flags))
         ctx._check(rc, "gt_dense_graph_build")
         ctx.sync()
         wall = time.perf_counter() - t0
         st = {s: round(ctx.stage_ms(s), 2) for s in ("dense_bandwidth", "dense_kernel", "dense_normalize")}
-        nbytes = 20.0 * n * n   # 4 N^2 x (D twice, K out, K in, P out)
+        row_sums = float(D[:4096].double().sum(dim=1).sub(1.0).abs().max().item())   # diff_op rows sum to 1 (float32 entries)
+        # bytes this run needs (round-3 verdict: price what runs): D read once for the bandwidths (4 N^2), D read + K written by
+        # the tile-pair kernel with the row sums accumulated on the way (8 N^2), K read + P written (8 N^2)
+        nbytes = 20.0 * n * n
         return {"workload": "C4: mix N=%d d=%d seed=2, TraditionalGraph knn=15 decay=40 from a resident float32 distance matrix "
-                            "(precomputed='distance'), K in place + degrees (one build: the input is consumed)" % (n, d),
+                            "(precomputed='distance'): bandwidths, K, diff_op materialised IN PLACE (the buffer ends as P; K = P x "
+                            "degree), degrees (one build: the input is consumed)" % (n, d),
                 "ms_per_graph": wall * 1e3, "graphs_per_s": 1.0 / wall, "stage_ms": st,
+                "diff_op_row_sum_max_dev_first_4096_rows": row_sums,
                 "roofline": {"bound": "hbm", "algorithmic_bytes": nbytes, "achieved": nbytes / wall / 1e9, "peak": HBM_PEAK_GBS,
-                             "unit": "GB/s", "frac": nbytes / wall / 1e9 / HBM_PEAK_GBS}}
+                             "unit": "GB/s", "frac": nbytes / wall / 1e9 / HBM_PEAK_GBS,
+                             "note": "20 N^2 bytes as run: 4 N^2 bandwidth pass (one read), 8 N^2 tile-pair kernel (row sums fused), "
+                                     "8 N^2 normalisation"}}
     finally:
         ctx.close()
         del D, X

@@ -320,6 +320,20 @@ int gt_set_option(gt_ctx* ctx, const char* name, const char* value) {
         ctx->dist_f64 = v == "float64" ? 1 : 0;
         return GT_OK;
     }
+    if (k == "dense_bandwidth_passes") {
+        const int v = std::atoi(value);
+        if (v != 1 && v != 2) GT_FAIL(ctx, GT_E_ARG, "dense_bandwidth_passes must be 1 or 2");
+        ctx->dense_bw_passes = v;
+        return GT_OK;
+    }
+    if (k == "select_sym_sample_far") {
+        ctx->sym_sample_far = std::atof(value);
+        return GT_OK;
+    }
+    if (k == "dense_fused_rowsum") {
+        ctx->dense_fused_rowsum = std::atoi(value) != 0 ? 1 : 0;
+        return GT_OK;
+    }
     if (k == "symmetrize_pairs") {
         ctx->symm_pairs = std::atoi(value) != 0 ? 1 : 0;
         return GT_OK;

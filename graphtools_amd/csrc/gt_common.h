@@ -17,13 +17,17 @@
 #include "../../include/graphtools_amd.h"
 
 // ---- error helpers ---------------------------------------------------------------------------
+// (an allocation the device cannot satisfy is a LIMIT of the build, not a failure of the runtime: GT_E_LIMIT, with what was
+//  being reserved - callers that have another route, e.g. TraditionalGraph's all-pairs path, take it)
 #define GT_HIP(ctx, expr)                                                                       \
     do {                                                                                        \
         hipError_t _e = (expr);                                                                 \
         if (_e != hipSuccess) {                                                                 \
-            (ctx)->set_error(std::string(#expr) + ": " + hipGetErrorString(_e) + " (" __FILE__ ":" + \
+            const bool _oom = (_e == hipErrorOutOfMemory);                                      \
+            (ctx)->set_error(std::string(_oom ? "the working set of this build does not fit the GPU's memory - " : "") + \
+                             std::string(#expr) + ": " + hipGetErrorString(_e) + " (" __FILE__ ":" +   \
                              std::to_string(__LINE__) + ")");                                   \
-            return GT_E_HIP;                                                                    \
+            return _oom ? GT_E_LIMIT : GT_E_HIP;                                                \
         }                                                                                       \
     } while (0)
 
@@ -154,6 +158,10 @@ struct gt_ctx {
     int32_t sym_cells = 12;    //   ... which is the rows of this many nearest cells (landmarks) of the block's own cells,
     int32_t sym_max_nb = 384;   //   at most this many tiles
     int32_t sym_tcap = 512;     //   capacity of a row's candidate list in launch B (<= 512)
+    double sym_sample_far = 1.0;    //   seeding sample: far-kept seeds per row from which the symmetric pass is given up at once
+                                    //   (isotropic Gaussians 2.0 / 3.6, half the points in one blob 1.4; manifold 0.13, mixtures ~0:
+                                    //   tools/ladder_probe.py) - what the full launch decides later at 0.5 once the bound pass and the
+                                    //   two-stage forecast have failed too
     int32_t sym_ok = -1;        //   auto: 0 once the bound point set has overflowed the lists of launch B (reset by gt_set_points)
     int32_t sym_nseg = 0;       //   work items per query block in launch B (0: chosen to fill the last round of workgroups)
     int32_t sym_orphan_far = 4;  //  a row is an orphan when this many times its far-kept seeds reach the seeds wanted (0: off)
@@ -205,6 +213,8 @@ struct gt_ctx {
     DevBuf ymax;         // float [1]     max row norm (as float bits, atomicMax on uint)
     float ymax_host = 0.f;
 
+    int32_t dense_bw_passes = 1;      // exact graph from a distance matrix: bandwidths in one streaming read (2: the two-pass kernel)
+    int32_t dense_fused_rowsum = 1;   //   float32 matrices: row sums accumulated by the tile kernel (0: a pass of their own)
     // last dense build (gt_dense_graph_build): degree = row sums of K, bandwidth
     DevBuf dense_degree, dense_bw;
     int64_t dense_n = 0;

@@ -11,6 +11,7 @@
 // HBM-bound: per element 1 read + 1 write for K, 1-2 reads + 1 write for P (row sums re-read the row while
 // it is L2 resident).  The from-data variant adds 3*d float64 flops per element on the vector pipe.
 #include <cfloat>
+#include <type_traits>
 
 #include "gt_common.h"
 #include "gt_hostcopy.h"
@@ -255,6 +256,185 @@ __global__ __launch_bounds__(256) void dense_bandwidth_2pass_kernel(const T* __r
     if (tid == 0) bw[i] = __longlong_as_double((long long)v) * scale;
 }
 
+// kth smallest of a row in ONE streaming pass (kth <= 256): the row is read once (the two-pass kernel above reads its 800 KB
+// at N = 2e5 twice from the HBM - 256 rows in flight per XCD do not stay in a 4 MB L2).
+//   steps 0, 1   (the first 2 x 256 x 16 / sizeof(T) values) stay in registers, every thread takes the minimum of
+//                its own; the kth smallest of the 256 minima is an upper bound `ub` of the answer with at least kth
+//                stored values at or below it (the two-pass kernel's argument); the stored values <= ub (a few dozen) start
+//                the candidate list;
+//   later steps  append what is <= ub to the list (LDS atomic for the slot: a handful per step); every 8th step the list
+//                is looked at - beyond half its capacity it is cut back to its kth smallest, which lowers ub;
+//   the end      the kth smallest of the list is the row's: every value <= the final ub was appended while ub was at
+//                least that large, and survives every cut.
+// The selections run on the values' own bit patterns (32 search steps for float32) over a few values per thread - the
+// first version searched 8192 LDS entries with 64-bit patterns and two barriers per step: 2.7 TB/s instead of 6.
+// Rows with mass ties at the bound (list overflow) are flagged for the generic kernel.
+template <typename T>
+__global__ __launch_bounds__(256) void dense_bandwidth_1pass_kernel(const T* __restrict__ D, const int64_t n, const int kth,
+                                                                    const double scale, double* __restrict__ bw,
+                                                                    uint32_t* __restrict__ redo) {
+    constexpr int VW = 16 / int(sizeof(T));
+    constexpr int PT = 4 * VW;                 // values per thread and step
+    constexpr int CHUNK = 256 * PT;            // values per step of the workgroup
+    constexpr int LCAP = 1024;                 // candidate list
+    constexpr int BITS = int(sizeof(T)) * 8;
+    typedef typename std::conditional<sizeof(T) == 4, uint32_t, unsigned long long>::type key_t;
+    __shared__ T lst[LCAP];
+    __shared__ int red[2][4];
+    __shared__ int cnt;
+    const int64_t i = blockIdx.x;
+    const int tid = threadIdx.x;
+    const T* row = D + i * n;
+    typedef T vecT __attribute__((ext_vector_type(VW)));
+    const bool vec = (n % VW) == 0;
+    const vecT* rv = reinterpret_cast<const vecT*>(row);
+    const int64_t nv = n / VW;
+    auto key_of = [](T x) -> key_t {   // order-preserving for x >= 0 (distances); anything <= 0 sorts first
+        if (!(x > T(0))) return key_t(0);
+        if constexpr (sizeof(T) == 4) return key_t(__float_as_uint(x));
+        else return key_t((unsigned long long)__double_as_longlong(x));
+    };
+    // kth smallest key (1-based) among the keys k[0 .. E) of all threads (invalid slots: the all-ones key)
+    auto select = [&](const key_t* k, const int E) -> key_t {
+        key_t v = 0;
+        int par = 0;
+        for (int b = BITS - 1; b >= 0; --b, par ^= 1) {
+            const key_t trial = v | ((key_t(1) << b) - key_t(1));
+            int c = 0;
+            for (int e = 0; e < E; ++e) c += (k[e] <= trial) ? 1 : 0;
+            c = wave_sum_i32(c);
+            if ((tid & 63) == 0) red[par][tid >> 6] = c;
+            __syncthreads();   // (one barrier per step: the next step writes the other half of `red`)
+            if (red[par][0] + red[par][1] + red[par][2] + red[par][3] < kth) v |= (key_t(1) << b);
+        }
+        return v;
+    };
+    const key_t kInvalid = ~key_t(0);
+    if (tid == 0) cnt = 0;
+    T ub = T(INFINITY);
+    T mn = T(INFINITY);
+    T x0[PT];   // the values of step 0, held until the bound is known
+#pragma unroll
+    for (int u = 0; u < PT; ++u) x0[u] = T(INFINITY);
+    bool bad = false;
+    const int64_t steps = vec ? (nv + 256 * 4 - 1) / (256 * 4) : (n + CHUNK - 1) / CHUNK;
+    for (int64_t st = 0; st < steps; ++st) {
+        T x[PT];
+        if (vec) {
+            vecT v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t j = st * (256 * 4) + u * 256 + tid;
+                if (j < nv) {
+                    v[u] = rv[j];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < VW; ++e) v[u][e] = T(INFINITY);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int e = 0; e < VW; ++e) x[u * VW + e] = v[u][e];
+        } else {
+#pragma unroll
+            for (int u = 0; u < PT; ++u) {
+                const int64_t j = st * CHUNK + int64_t(u) * 256 + tid;
+                x[u] = j < n ? row[j] : T(INFINITY);
+            }
+        }
+        if (st < 2) {
+#pragma unroll
+            for (int u = 0; u < PT; ++u) mn = x[u] < mn ? x[u] : mn;
+            if (st == 0) {
+#pragma unroll
+                for (int u = 0; u < PT; ++u) x0[u] = x[u];
+                if (steps > 1) continue;
+            }
+            // the bound from the 256 minima, then the values of these steps at or below it start the list
+            const key_t kmn = (mn < T(INFINITY)) ? key_of(mn) : kInvalid;
+            __syncthreads();
+            const key_t kb = select(&kmn, 1);
+#pragma unroll
+            for (int u = 0; u < PT; ++u) {
+                if (x0[u] < T(INFINITY) && key_of(x0[u]) <= kb) {
+                    const int pos = atomicAdd(&cnt, 1);
+                    if (pos < LCAP) lst[pos] = x0[u];
+                }
+                if (st == 1 && x[u] < T(INFINITY) && key_of(x[u]) <= kb) {
+                    const int pos = atomicAdd(&cnt, 1);
+                    if (pos < LCAP) lst[pos] = x[u];
+                }
+            }
+            if constexpr (sizeof(T) == 4) ub = __uint_as_float(uint32_t(kb));
+            else ub = __longlong_as_double((long long)kb);
+            __syncthreads();
+            if (cnt > LCAP) {
+                bad = true;
+                break;
+            }
+            continue;
+        }
+#pragma unroll
+        for (int u = 0; u < PT; ++u) {
+            if (x[u] <= ub) {
+                const int pos = atomicAdd(&cnt, 1);
+                if (pos < LCAP) lst[pos] = x[u];
+            }
+        }
+        if (!((st & 7) == 7)) continue;
+        __syncthreads();
+        const int m = cnt;   // (uniform: read behind the barrier)
+        if (m > LCAP) {      // appends were dropped
+            bad = true;
+            break;
+        }
+        if (m > LCAP / 2) {
+            key_t k4[LCAP / 256];
+#pragma unroll
+            for (int q = 0; q < LCAP / 256; ++q) k4[q] = (q * 256 + tid < m) ? key_of(lst[q * 256 + tid]) : kInvalid;
+            const key_t kb = select(k4, LCAP / 256);
+            __syncthreads();
+            if (tid == 0) cnt = 0;
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < LCAP / 256; ++q)
+                if (k4[q] <= kb) {
+                    const int pos = atomicAdd(&cnt, 1);
+                    if constexpr (sizeof(T) == 4) lst[pos] = __uint_as_float(uint32_t(k4[q]));
+                    else lst[pos] = __longlong_as_double((long long)k4[q]);
+                }
+            if constexpr (sizeof(T) == 4) ub = __uint_as_float(uint32_t(kb));
+            else ub = __longlong_as_double((long long)kb);
+            __syncthreads();
+            if (cnt > LCAP / 2) {   // ties at the kth value fill the list: the generic kernel's case
+                bad = true;
+                break;
+            }
+        }
+    }
+    __syncthreads();
+    if (!bad && cnt > LCAP) bad = true;
+    if (bad) {
+        if (tid == 0) {
+            bw[i] = -1.0;
+            atomicAdd(redo, 1u);
+        }
+        return;
+    }
+    const int m = cnt;
+    key_t k4[LCAP / 256];
+#pragma unroll
+    for (int q = 0; q < LCAP / 256; ++q) k4[q] = (q * 256 + tid < m) ? key_of(lst[q * 256 + tid]) : kInvalid;
+    const key_t kb = select(k4, LCAP / 256);
+    if (tid == 0) {
+        double r;
+        if constexpr (sizeof(T) == 4) r = double(__uint_as_float(uint32_t(kb)));
+        else r = __longlong_as_double((long long)kb);
+        bw[i] = r * scale;
+    }
+}
+
 // generic (any kth): bitwise search straight over the row (64 passes; the row stays L2 resident)
 template <typename T>
 __global__ __launch_bounds__(256) void dense_bandwidth_generic_kernel(const T* __restrict__ D, const int64_t n,
@@ -320,7 +500,11 @@ __global__ __launch_bounds__(256) void dense_kernel_tiles(const TD* __restrict__
                                                           const int64_t n, const int nb, const double* __restrict__ bw,
                                                           const double decay_d, const double thresh_d, const int symm,
                                                           const double theta_d, TC* __restrict__ Kout,
-                                                          uint32_t* __restrict__ flags, const double xcut_d, const int pass) {
+                                                          uint32_t* __restrict__ flags, const double xcut_d, const int pass,
+                                                          double* __restrict__ rowsum) {
+    // rowsum (optional, pre-zeroed; float32 16-byte path only): sum of |K_ij| of every row, accumulated tile by tile - one
+    // float64 atomic per row and tile (the 16 lanes that hold a row's 64 outputs reduce first) - so that the row sums
+    // behind P and the degrees do not need a pass of their own over the N x N matrix (4 N^2 bytes of HBM reads)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     TC* sA = reinterpret_cast<TC*>(smem_raw);      // [TS][TSP]  K0 of tile (I,J): sA[i][j]
     TC* sB = sA + TS * TSP;                        // [TS][TSP]  K0 of tile (J,I): sB[j][i]
@@ -436,6 +620,7 @@ __global__ __launch_bounds__(256) void dense_kernel_tiles(const TD* __restrict__
                 const int i = ty16 + 16 * r;
                 {   // output tile (I,J)
                     const int64_t gi = I0 + i, gj0 = J0 + 4 * tx4;
+                    double part = 0.0;
                     if (gi < n && gj0 < n) {
                         float o[4];
 #pragma unroll
@@ -445,10 +630,18 @@ __global__ __launch_bounds__(256) void dense_kernel_tiles(const TD* __restrict__
                             o[e] = merge_t<float>(a, b, symm, theta);
                         }
                         *reinterpret_cast<float4*>(Kout + gi * n + gj0) = make_float4(o[0], o[1], o[2], o[3]);
+                        part = double(fabsf(o[0])) + double(fabsf(o[1])) + double(fabsf(o[2])) + double(fabsf(o[3]));
+                        if (rowsum && diag && gi >= gj0 && gi < gj0 + 4 && o[gi - gj0] == 0.f) atomicOr(flags, GT_FLAG_ZERO_DIAGONAL);
+                    }
+                    if (rowsum) {   // (uniform: the 16 lanes of a row's group reduce together, in or out of range)
+#pragma unroll
+                        for (int off = 8; off > 0; off >>= 1) part += __shfl_xor(part, off, 16);
+                        if (tx4 == 0 && gi < n) atomicAdd(rowsum + gi, part);
                     }
                 }
                 if (!diag) {   // output tile (J,I)
                     const int64_t gj = J0 + i, gi0 = I0 + 4 * tx4;
+                    double part = 0.0;
                     if (gj < n && gi0 < n) {
                         float o[4];
 #pragma unroll
@@ -458,6 +651,12 @@ __global__ __launch_bounds__(256) void dense_kernel_tiles(const TD* __restrict__
                             o[e] = merge_t<float>(b, a, symm, theta);
                         }
                         *reinterpret_cast<float4*>(Kout + gj * n + gi0) = make_float4(o[0], o[1], o[2], o[3]);
+                        part = double(fabsf(o[0])) + double(fabsf(o[1])) + double(fabsf(o[2])) + double(fabsf(o[3]));
+                    }
+                    if (rowsum) {
+#pragma unroll
+                        for (int off = 8; off > 0; off >>= 1) part += __shfl_xor(part, off, 16);
+                        if (tx4 == 0 && gj < n) atomicAdd(rowsum + gj, part);
                     }
                 }
             }
@@ -586,6 +785,37 @@ __global__ __launch_bounds__(256) void dense_normalize_kernel(const T* __restric
     P[i * n + j] = T(K[i * n + j] / T(s));
 }
 
+// P = K / rowsum, float32, four values per thread (in place allowed: every thread rewrites what it read)
+__global__ __launch_bounds__(256) void dense_normalize4_kernel(const float4* __restrict__ K, const int64_t n4,
+                                                               const double* __restrict__ rowsum, float4* __restrict__ P) {
+    // one workgroup per row, four 16-byte loads in flight per thread (a pure HBM stream)
+    const int64_t i = blockIdx.x;
+    double s = rowsum[i];
+    if (s == 0.0) s = 1.0;   // sklearn _handle_zeros_in_scale
+    const float sf = float(s);
+    const float4* kr = K + i * n4;
+    float4* pr = P + i * n4;
+    for (int64_t j0 = 0; j0 < n4; j0 += 256 * 4) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t j = j0 + u * 256 + threadIdx.x;
+            if (j < n4) v[u] = __builtin_nontemporal_load(kr + j);   // (read once, rewritten once: no reuse to keep in the caches)
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t j = j0 + u * 256 + threadIdx.x;
+            if (j < n4) {
+                v[u].x = v[u].x / sf;
+                v[u].y = v[u].y / sf;
+                v[u].z = v[u].z / sf;
+                v[u].w = v[u].w / sf;
+                __builtin_nontemporal_store(v[u], pr + j);
+            }
+        }
+    }
+}
+
 struct DenseState {
     DevBuf bw, bw_user, rowsum, deg, work_in, work_k, work_p, flags, redo;
 };
@@ -604,7 +834,7 @@ static double dense_xcut(double decay, double thresh, bool f32) {
 
 template <typename TD, typename TC, typename TX, bool FROM_DATA>
 int launch_tiles(gt_ctx* ctx, const TD* D, const TX* X, int d, int64_t n, const double* bw, double decay, double thresh,
-                 int symm, double theta, TC* Kout, uint32_t* flags, int pass = 0) {
+                 int symm, double theta, TC* Kout, uint32_t* flags, int pass = 0, double* rowsum = nullptr) {
     const int nb = int(ceil_div64(n, TS));
     const int64_t nbs = ceil_div64(nb, SG);
     const int64_t pairs = nbs * nbs * SG * SG;   // grid positions (super-tile order, lower triangle exits)
@@ -615,7 +845,7 @@ int launch_tiles(gt_ctx* ctx, const TD* D, const TX* X, int d, int64_t n, const 
     GT_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     int(lds)));
     hipLaunchKernelGGL(kern, dim3((unsigned)pairs), dim3(256), lds, ctx->stream, D, X, d, n, nb, bw, decay, thresh, symm,
-                       theta, Kout, flags, dense_xcut(decay, thresh, sizeof(TC) == 4), pass);
+                       theta, Kout, flags, dense_xcut(decay, thresh, sizeof(TC) == 4), pass, rowsum);
     GT_HIP(ctx, hipGetLastError());
     return GT_OK;
 }
@@ -689,8 +919,27 @@ __global__ __launch_bounds__(256) void dense_bandwidth_ext_kernel(const T* __res
 }
 
 template <typename T>
-int finish_dense(gt_ctx* ctx, DenseState& st, T* K, T* P, int64_t n, double anisotropy) {
+int finish_dense(gt_ctx* ctx, DenseState& st, T* K, T* P, int64_t n, double anisotropy, bool have_rowsum = false) {
     GT_HIP(ctx, st.rowsum.reserve(size_t(n) * sizeof(double)));
+    if (have_rowsum) {
+        // the tile kernel accumulated the row sums (and the zero-diagonal flag): only P is left, 16 bytes per thread
+        StageSpan span(ctx, "dense_normalize");
+        if (P) {
+            if constexpr (sizeof(T) == 4) {
+                if (n % 4 == 0) {
+                    hipLaunchKernelGGL(dense_normalize4_kernel, dim3((unsigned)n), dim3(256), 0,
+                                       ctx->stream, reinterpret_cast<const float4*>(K), n / 4, st.rowsum.as<double>(),
+                                       reinterpret_cast<float4*>(P));
+                    GT_HIP(ctx, hipGetLastError());
+                    return GT_OK;
+                }
+            }
+            hipLaunchKernelGGL(dense_normalize_kernel<T>, dim3((unsigned)ceil_div64(n, 256), (unsigned)n), dim3(256), 0,
+                               ctx->stream, K, n, st.rowsum.as<double>(), P);
+            GT_HIP(ctx, hipGetLastError());
+        }
+        return GT_OK;
+    }
     {
         StageSpan span(ctx, "dense_normalize");
         if (anisotropy != 0.0) {
@@ -808,12 +1057,21 @@ extern "C" int gt_dense_graph_build(gt_ctx* ctx, const void* X_or_D, int64_t n, 
             DENSE_HIP(hipMemsetAsync(st.redo.p, 0, sizeof(uint32_t), ctx->stream));
             uint32_t n_redo = (kth > 256) ? 1u : 0u;
             if (kth <= 256) {
-                if (dtype == GT_F32)
-                    hipLaunchKernelGGL(dense_bandwidth_2pass_kernel<float>, dim3((unsigned)n), dim3(256), 0, ctx->stream,
+                // one streaming read of the matrix (option dense_bandwidth_passes = 2: the two-pass kernel of round 3)
+                if (ctx->dense_bw_passes == 2) {
+                    if (dtype == GT_F32)
+                        hipLaunchKernelGGL(dense_bandwidth_2pass_kernel<float>, dim3((unsigned)n), dim3(256), 0, ctx->stream,
+                                           (const float*)in_dev, n, kth, bandwidth_scale, st.bw.as<double>(), st.redo.as<uint32_t>());
+                    else
+                        hipLaunchKernelGGL(dense_bandwidth_2pass_kernel<double>, dim3((unsigned)n), dim3(256), 0, ctx->stream,
+                                           (const double*)in_dev, n, kth, bandwidth_scale, st.bw.as<double>(), st.redo.as<uint32_t>());
+                } else if (dtype == GT_F32) {
+                    hipLaunchKernelGGL(dense_bandwidth_1pass_kernel<float>, dim3((unsigned)n), dim3(256), 0, ctx->stream,
                                        (const float*)in_dev, n, kth, bandwidth_scale, st.bw.as<double>(), st.redo.as<uint32_t>());
-                else
-                    hipLaunchKernelGGL(dense_bandwidth_2pass_kernel<double>, dim3((unsigned)n), dim3(256), 0, ctx->stream,
+                } else {
+                    hipLaunchKernelGGL(dense_bandwidth_1pass_kernel<double>, dim3((unsigned)n), dim3(256), 0, ctx->stream,
                                        (const double*)in_dev, n, kth, bandwidth_scale, st.bw.as<double>(), st.redo.as<uint32_t>());
+                }
                 DENSE_HIP(hipGetLastError());
                 DENSE_HIP(hipMemcpyAsync(&n_redo, st.redo.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
                 DENSE_HIP(hipStreamSynchronize(ctx->stream));
@@ -831,6 +1089,7 @@ extern "C" int gt_dense_graph_build(gt_ctx* ctx, const void* X_or_D, int64_t n, 
         DENSE_HIP(hipGetLastError());
     }
     // ---- kernel tiles ----
+    bool fused_rowsum = false;
     void* K_dev = nullptr;
     if (inplace) {
         K_dev = const_cast<void*>(in_dev);
@@ -858,8 +1117,15 @@ extern "C" int gt_dense_graph_build(gt_ctx* ctx, const void* X_or_D, int64_t n, 
             DENSE_TRY((launch_tiles<float, double, double, false>(ctx, (const float*)in_dev, nullptr, 0, n, bw, decay,
                                                                   thresh, kernel_symm, theta, (double*)K_dev, fl, pass)));
         } else {
+            // float32 in, float32 out, whole quads, no anisotropy: the tile kernel accumulates the row sums as it writes K
+            fused_rowsum = anisotropy == 0.0 && (n % 4) == 0 && ctx->dense_fused_rowsum != 0;
+            if (fused_rowsum) {
+                DENSE_HIP(st.rowsum.reserve(size_t(n) * sizeof(double)));
+                DENSE_HIP(hipMemsetAsync(st.rowsum.p, 0, size_t(n) * sizeof(double), ctx->stream));
+            }
             DENSE_TRY((launch_tiles<float, float, double, false>(ctx, (const float*)in_dev, nullptr, 0, n, bw, decay,
-                                                                 thresh, kernel_symm, theta, (float*)K_dev, fl, pass)));
+                                                                 thresh, kernel_symm, theta, (float*)K_dev, fl, pass,
+                                                                 fused_rowsum ? st.rowsum.as<double>() : nullptr)));
         }
     }
     // ---- anisotropy + P ----
@@ -875,7 +1141,7 @@ extern "C" int gt_dense_graph_build(gt_ctx* ctx, const void* X_or_D, int64_t n, 
     if (out_f64)
         DENSE_TRY(finish_dense<double>(ctx, st, (double*)K_dev, (double*)P_dev, n, anisotropy));
     else
-        DENSE_TRY(finish_dense<float>(ctx, st, (float*)K_dev, (float*)P_dev, n, anisotropy));
+        DENSE_TRY(finish_dense<float>(ctx, st, (float*)K_dev, (float*)P_dev, n, anisotropy, fused_rowsum));
     if (out_K && !out_on_device) DENSE_TRY(gt_copy_to_host(ctx, out_K, K_dev, size_t(n) * n * out_esz));
     if (out_P && !out_on_device) DENSE_TRY(gt_copy_to_host(ctx, out_P, P_dev, size_t(n) * n * out_esz));
     uint32_t fl = 0;

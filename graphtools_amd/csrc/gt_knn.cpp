@@ -350,6 +350,45 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
             // dense cell blocks with the keys in registers (gt_seed.hip), or the streaming lists of the candidate kernel
             const bool dense_seed = ctx->sym_dense_seed != 0 && need_m <= 64 && tile_stride <= 1024 && n_pad_s % 256 == 0;
             const int seed_lstride = dense_seed ? 64 : int(lcap);
+            if (ctx->sym_mode < 0 && ctx->sym_ok < 0 && dense_seed && n_pad_s >= int64_t(16) * 8192) {
+                // First build on this point set, verdict "do the seeds come from the cells around the row?" still open: ask a
+                // SAMPLE first - the first sixteenth of the sorted positions (cells are numbered by landmark, landmarks are
+                // evenly strided rows: a prefix of the cells is a spatially random sample) - before every row is seeded.  On
+                // points without cluster structure (isotropic Gaussian, N = 2e5, d = 24: 18 ms against 11 ms for the classic
+                // pass alone, tests/test_gpu_ladder.py) the lost attempt shrinks from ~6 ms to ~1 ms.
+                const int64_t ps = std::max<int64_t>(4096, (n_pad_s / 16) / 256 * 256), prows = std::min<int64_t>(ps, nq);
+                unsigned long long far_s = 0;
+                {
+                    StageSpan span(ctx, "sym_seed");
+                    GT_TRY(gt_sym_seed_dense(ctx, ctx->DP, k->Ycs.p, k->hnegs_fin.as<float>(), nq, n_pad_s, k->sym_tiles.as<int32_t>(),
+                                             k->sym_tile_cnt.as<int32_t>(), tile_stride, bq_sym, 0, ps / 128, need_m,
+                                             k->lists.as<uint64_t>(), seed_lstride, k->counts.as<uint32_t>()));
+                }
+                {
+                    StageSpan span(ctx, "sym_prepare");
+                    GT_HIP(ctx, k->sym_farcnt.reserve(size_t(n_pad_s) * sizeof(float)));
+                    GT_TRY(gt_sym_thresholds(ctx, perm, n_pad_s, k->hnegs.as<float>(), k->lists.as<uint64_t>(), seed_lstride,
+                                             k->counts.as<uint32_t>(), need_m, em, rkf, k->thr_final.as<float>(),
+                                             k->sym_g.as<float>(), nullptr, k->sym_work, ctx->sym_cells,
+                                             k->sym_stat.as<unsigned long long>() + 2, k->sym_farcnt.as<float>(), 0, ps));
+                    GT_HIP(ctx, hipMemcpyAsync(&far_s, k->sym_stat.as<unsigned long long>() + 2, sizeof(far_s), hipMemcpyDeviceToHost,
+                                               ctx->stream));
+                    GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                    GT_HIP(ctx, hipMemsetAsync(k->sym_stat.as<unsigned long long>() + 2, 0, sizeof(unsigned long long), ctx->stream));
+                }
+                const double est_s = double(need_m) + double(std::max(stride_a, 1)) * double(far_s) / double(prows);
+                if (ctx->dbg_select & 2048)
+                    fprintf(stderr, "[gt] seeding sample: %lld rows, far-kept %llu (%.2f per row), estimate %.1f (limit %.1f)\n",
+                            (long long)prows, far_s, double(far_s) / double(prows), est_s, double(tcap) / 8.0);
+                // (the two verdicts of the full launch, on the sample: the far-kept predictor where a strided sample of the other
+                //  tiles was scored, and "every second row kept a seed from outside the cells around it" - GT_SAMPLE_FAR rows)
+                if ((stride_a > 0 && est_s > double(tcap) / 8.0) || double(far_s) >= ctx->sym_sample_far * double(prows)) {
+                    k->sym_far = int64_t(double(far_s) * double(nq) / double(prows));
+                    ctx->sym_ok = 0;
+                    sym_now = false;
+                    continue;
+                }
+            }
             {
                 StageSpan span(ctx, "sym_seed");
                 if (dense_seed)
@@ -601,6 +640,7 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
                     continue;
                 }
             }
+            if (ctx->sym_ok < 0) ctx->sym_ok = 1;   // (the verdicts are in for this point set: later builds skip the seeding sample)
             break;
         }
         sa.prec = main_prec;

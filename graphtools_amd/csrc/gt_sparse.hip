@@ -1843,6 +1843,21 @@ static int graph_begin_impl(gt_ctx* ctx, const gt_knn_params* params, int32_t wo
         GT_HIP(ctx, g->rcounts.reserve(size_t(nover_pad) * sizeof(uint32_t)));
         for (;;) {
             if (cap > ctx->n_pad) cap = ctx->n_pad;
+            {
+                // the radius lists are [rows][cap] (+ as many affinities): say what a too-wide kernel asks for instead of
+                // letting the allocator fail
+                const double need_gb = double(nover_pad) * double(cap) * 16.0 / 1073741824.0;
+                size_t free_b = 0, total_b = 0;
+                if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && need_gb * 1073741824.0 > 0.9 * double(total_b)) {
+                    char msg[320];
+                    std::snprintf(msg, sizeof(msg),
+                                  "radius pass: %u rows with up to %lld candidates inside their kernel radius need %.1f GB of lists "
+                                  "(GPU: %.1f GB) - the kernel reaches too far for the sparse path (raise thresh or decay, lower "
+                                  "bandwidth_scale, or build the exact dense graph)", n_over, (long long)cap, need_gb,
+                                  double(total_b) / 1073741824.0);
+                    GT_FAIL(ctx, GT_E_LIMIT, msg);
+                }
+            }
             GT_HIP(ctx, g->rlists.reserve(size_t(nover_pad) * size_t(cap) * sizeof(uint64_t)));
             SelectArgs sa;
             sa.dp = ctx->DP;

@@ -283,3 +283,41 @@ def test_dense_copy_on_the_device_in_float32():
         assert np.array_equal(out.cpu().numpy(), P.toarray().astype(np.float32))
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("n,symm", [(2500, "+"), (1028, "*"), (2052, "mnn")])
+def test_one_pass_bandwidth_and_fused_row_sums_equal_the_separate_passes(n, symm):
+    """round 4: the exact graph from a float32 distance matrix reads the matrix ONCE for the bandwidths
+    (dense_bandwidth_1pass_kernel) and accumulates the row sums in the tile-pair kernel (no pass of their own).  Against the
+    round-3 kernels (options) K is bit-identical; the row sums differ only by their summation order; against the oracle
+    (graphs.py:1583-1609, base.py:645) the usual tolerances hold.  Sizes with ragged 64 x 64 edge tiles."""
+    from graphtools_amd import _hip
+    rng = np.random.default_rng(n)
+    X = make_mix(n, 12, 3).astype(np.float64)
+    D = np.sqrt(((X[:, None, :] - X[None, :, :]) ** 2).sum(-1)).astype(np.float32) if n <= 1100 else None
+    if D is None:
+        from scipy.spatial.distance import pdist, squareform
+        D = squareform(pdist(X)).astype(np.float32)
+    D[rng.integers(0, n, 50), rng.integers(0, n, 50)] += 0.0     # (no-op: keeps the generator in the signature of the case)
+    theta = 0.3 if symm == "mnn" else None
+    res = {}
+    for tag, opts in (("new", {}), ("old", {"dense_bandwidth_passes": "2", "dense_fused_rowsum": "0"})):
+        c = _hip.Context(0)
+        for k, v in opts.items():
+            c.set_option(k, v)
+        K, P, flags = c.dense_graph_build(D, "distance", 7, 12.0, 1e-4, None, 1.0, symm, theta, 0.0, want_P=True)
+        deg = c.dense_fetch_vec(_hip.VEC_DEGREE, n)
+        bw = c.dense_fetch_vec(_hip.VEC_BANDWIDTH, n) if hasattr(_hip, "VEC_BANDWIDTH") else None
+        c.close()
+        res[tag] = (K, P, deg, bw)
+    assert res["new"][0].dtype == np.float32
+    assert np.array_equal(res["new"][0], res["old"][0])                      # K: bit-identical (the bandwidths are)
+    if res["new"][3] is not None:
+        assert np.array_equal(res["new"][3], res["old"][3])
+    np.testing.assert_allclose(res["new"][2], res["old"][2], rtol=1e-12)    # degrees: float64 sums in another order
+    np.testing.assert_allclose(res["new"][1], res["old"][1], rtol=2e-7, atol=0)   # P: float32 K / float32(sum)
+    K0, P0 = oracle.exact_graph(D, knn=7, decay=12.0, thresh=1e-4, precomputed="distance", kernel_symm=symm, theta=theta)
+    m = (res["new"][0] == 0) == (K0 == 0)
+    assert (~m).sum() <= 4
+    np.testing.assert_allclose(res["new"][0][m], K0[m], rtol=1e-5, atol=0)
+    np.testing.assert_allclose(res["new"][1][m], P0[m], rtol=1e-5, atol=0)

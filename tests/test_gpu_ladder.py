@@ -1,0 +1,90 @@
+"""GPU: the decision ladder picks between candidate passes that are 2-10 x apart on a given data family.
+Whatever it picks is exact (the other tests); this one bounds how badly `auto` can LOSE: on eight data families at
+N = 2e5 the default build must not take more than 1.5 x the time of the better of the two forced routes (symmetric pass forced
+on / classic pass forced) - plus 1 ms, the granularity of the fixed costs at this size.  Reference semantics are not involved:
+all three builds produce the same graph (asserted)."""
+import time
+
+import numpy as np
+import pytest
+
+from conftest import make_gauss, make_manifold, make_mix
+
+pytestmark = pytest.mark.gpu
+
+N = 200000
+
+
+def _unequal_scales(seed):
+    rng = np.random.default_rng(seed)
+    c = 100
+    centres = rng.uniform(-10, 10, (c, 32))
+    scale = rng.choice([0.2, 1.0, 3.0], size=c)
+    lab = rng.integers(c, size=N)
+    return (centres[lab] + scale[lab, None] * rng.standard_normal((N, 32))).astype(np.float32)
+
+
+def _one_big_cell(seed):
+    rng = np.random.default_rng(seed)
+    X = make_mix(N, 48, seed)
+    big = rng.random(N) < 0.5
+    X[big] = (rng.standard_normal((int(big.sum()), 48)) * 0.5 + 3.0).astype(np.float32)   # half of the points in one tight blob
+    return X
+
+
+def _hubs(seed):
+    rng = np.random.default_rng(seed)
+    X = make_mix(N, 32, seed)
+    X[:200] = (0.05 * rng.standard_normal((200, 32))).astype(np.float32) + X[200:400].mean(axis=0)   # points many rows are close to
+    return X
+
+
+FAMILIES = {
+    "mix d=64": lambda: make_mix(N, 64, 1),
+    "mix, clusters of unequal scale d=32": lambda: _unequal_scales(2),
+    "half of the points in one blob d=48": lambda: _one_big_cell(3),
+    "manifold (5 dims in 64)": lambda: make_manifold(N, 64, 4),
+    "isotropic gauss d=24": lambda: make_gauss(N, 24, 5),
+    "isotropic gauss d=64": lambda: make_gauss(N, 64, 6),
+    "mix with hubs d=32": lambda: _hubs(7),
+    "mix shifted far from the origin d=64": lambda: (make_mix(N, 64, 8) + np.float32(300.0)),
+}
+
+
+def _build_ms(X, opts, reps=3):
+    from graphtools_amd import _hip
+
+    c = _hip.Context(0)
+    try:
+        for k, v in opts.items():
+            c.set_option(k, v)
+        c.set_points(X)
+        p, keep = c.make_params(15, 40.0, 1e-4, None, 1.0, None, "+", None, 0)
+        best, nnz = None, None
+        for _ in range(reps):
+            c.sync()
+            t = time.perf_counter()
+            c.set_points(X)
+            nnz, _ = c.graph_build(p)
+            c.sync()
+            ms = (time.perf_counter() - t) * 1e3
+            best = ms if best is None else min(best, ms)
+        sym = bool(c.knn_stats()["symmetric"])
+        deg = c.graph_fetch_vec(1)
+        return best, int(nnz), sym, float(deg.sum())
+    finally:
+        c.close()
+
+
+@pytest.mark.parametrize("family", list(FAMILIES))
+def test_auto_is_never_far_behind_the_better_forced_route(family):
+    X = FAMILIES[family]()
+    auto, nnz_a, sym_a, s_a = _build_ms(X, {})
+    forced_sym, nnz_s, sym_s, s_s = _build_ms(X, {"select_symmetric": "1"})
+    classic, nnz_c, sym_c, s_c = _build_ms(X, {"select_symmetric": "0"})
+    assert nnz_a == nnz_s == nnz_c and s_a == s_s == s_c, "the routes built different graphs"
+    assert not sym_c
+    best = min(forced_sym, classic)
+    print("%-42s auto %.2f ms (%s)  symmetric forced %.2f  classic %.2f" % (family, auto, "symmetric" if sym_a else "classic",
+                                                                             forced_sym, classic))
+    assert auto <= 1.5 * best + 1.0, "auto %.2f ms vs the better forced route %.2f ms on '%s'" % (auto, best, family)

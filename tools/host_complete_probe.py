@@ -1,26 +1,45 @@
 #!/usr/bin/env python
-"""Development probe: host-complete time of one C3 graph (numpy in, scipy CSR K and P out), for the copy-lane settings in
-the environment (GT_COPY_LANES, GT_COPY_SLOT_MB)."""
+"""Where the host-complete build (host X in, scipy CSR K and P out: SURVEY 8d) spends its wall time.
+usage: host_complete_probe.py [n] [d]"""
+import json
 import os
 import sys
 import time
-import warnings
 
 import numpy as np
+from scipy import sparse
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from bench import make_mix  # noqa: E402
+from graphtools_amd import _hip  # noqa: E402
 import graphtools_amd  # noqa: E402
 
-X = make_mix(1000000, 64, 1)
-ts = []
-for _ in range(4):
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore")
-        t0 = time.perf_counter()
-        G = graphtools_amd.Graph(X, knn=15, decay=40, n_pca=None, verbose=0)
-        K, P = G.K, G.P
-        ts.append(time.perf_counter() - t0)
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
+d = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+X = make_mix(n, d, 1)
+res = []
+for rep in range(4):
+    t0 = time.perf_counter()
+    G = graphtools_amd.Graph(X, knn=15, decay=40, n_pca=None, verbose=0, initialize=False)
+    t1 = time.perf_counter()
+    G._bind_points()
+    t2 = time.perf_counter()
+    nnz, flags = G._device_build(G.kernel_symm, G.theta, G.anisotropy)
+    G.hip.sync()
+    t3 = time.perf_counter()
+    kd, ki, kp, pd = G.hip.graph_fetch_kp()
+    t4 = time.perf_counter()
+    kp32 = kp.astype(np.int32)
+    K = sparse.csr_matrix((kd, ki, kp32), shape=(n, n))
+    P = sparse.csr_matrix((pd, K.indices, K.indptr), shape=(n, n))
+    t5 = time.perf_counter()
+    res.append({"ctor_ms": (t1 - t0) * 1e3, "set_points_ms": (t2 - t1) * 1e3, "build_ms": (t3 - t2) * 1e3, "fetch_kp_ms": (t4 - t3) * 1e3,
+                "scipy_ms": (t5 - t4) * 1e3, "total_ms": (t5 - t0) * 1e3, "fetch_GBs": (kd.nbytes + ki.nbytes + kp.nbytes) / (t4 - t3) / 1e9})
+    del G, K, P, kd, ki, kp, pd
+    t0 = time.perf_counter()
+    G = graphtools_amd.Graph(X, knn=15, decay=40, n_pca=None, verbose=0)
+    K, P = G.K, G.P
+    res[-1]["graph_api_total_ms"] = (time.perf_counter() - t0) * 1e3
     del G, K, P
-print("lanes %s slot %s MB: %s ms" % (os.environ.get("GT_COPY_LANES", "8"), os.environ.get("GT_COPY_SLOT_MB", "8"), [round(t * 1e3, 1) for t in ts]))
+print(json.dumps(res, indent=1))
