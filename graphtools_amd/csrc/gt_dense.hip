@@ -789,6 +789,7 @@ __global__ __launch_bounds__(256) void dense_normalize_kernel(const T* __restric
 __global__ __launch_bounds__(256) void dense_normalize4_kernel(const float4* __restrict__ K, const int64_t n4,
                                                                const double* __restrict__ rowsum, float4* __restrict__ P) {
     // one workgroup per row, four 16-byte loads in flight per thread (a pure HBM stream)
+    typedef float f4v __attribute__((ext_vector_type(4)));
     const int64_t i = blockIdx.x;
     double s = rowsum[i];
     if (s == 0.0) s = 1.0;   // sklearn _handle_zeros_in_scale
@@ -800,7 +801,10 @@ __global__ __launch_bounds__(256) void dense_normalize4_kernel(const float4* __r
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int64_t j = j0 + u * 256 + threadIdx.x;
-            if (j < n4) v[u] = __builtin_nontemporal_load(kr + j);   // (read once, rewritten once: no reuse to keep in the caches)
+            if (j < n4) {   // (read once, rewritten once: no reuse to keep in the caches)
+                const f4v t = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(kr + j));
+                v[u] = make_float4(t[0], t[1], t[2], t[3]);
+            }
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -810,7 +814,9 @@ __global__ __launch_bounds__(256) void dense_normalize4_kernel(const float4* __r
                 v[u].y = v[u].y / sf;
                 v[u].z = v[u].z / sf;
                 v[u].w = v[u].w / sf;
-                __builtin_nontemporal_store(v[u], pr + j);
+                f4v t;
+                t[0] = v[u].x; t[1] = v[u].y; t[2] = v[u].z; t[3] = v[u].w;
+                __builtin_nontemporal_store(t, reinterpret_cast<f4v*>(pr + j));
             }
         }
     }
