@@ -350,6 +350,7 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
             // dense cell blocks with the keys in registers (gt_seed.hip), or the streaming lists of the candidate kernel
             const bool dense_seed = ctx->sym_dense_seed != 0 && need_m <= 64 && tile_stride <= 1024 && n_pad_s % 256 == 0;
             const int seed_lstride = dense_seed ? 64 : int(lcap);
+            int64_t seeded_to = 0;   // sorted positions [0, seeded_to) were seeded (and got their thresholds) by the sample below
             if (ctx->sym_mode < 0 && ctx->sym_ok < 0 && dense_seed && n_pad_s >= int64_t(16) * 8192) {
                 // First build on this point set, verdict "do the seeds come from the cells around the row?" still open: ask a
                 // SAMPLE first - the first sixteenth of the sorted positions (cells are numbered by landmark, landmarks are
@@ -374,7 +375,6 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
                     GT_HIP(ctx, hipMemcpyAsync(&far_s, k->sym_stat.as<unsigned long long>() + 2, sizeof(far_s), hipMemcpyDeviceToHost,
                                                ctx->stream));
                     GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-                    GT_HIP(ctx, hipMemsetAsync(k->sym_stat.as<unsigned long long>() + 2, 0, sizeof(unsigned long long), ctx->stream));
                 }
                 const double est_s = double(need_m) + double(std::max(stride_a, 1)) * double(far_s) / double(prows);
                 if (ctx->dbg_select & 2048)
@@ -388,12 +388,14 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
                     sym_now = false;
                     continue;
                 }
+                seeded_to = ps;   // (accepted: the sample's rows are done, the launches below take the rest)
             }
             {
                 StageSpan span(ctx, "sym_seed");
                 if (dense_seed)
                     GT_TRY(gt_sym_seed_dense(ctx, ctx->DP, k->Ycs.p, k->hnegs_fin.as<float>(), nq, n_pad_s, k->sym_tiles.as<int32_t>(),
-                                             k->sym_tile_cnt.as<int32_t>(), tile_stride, bq_sym, 0, 0, need_m,
+                                             k->sym_tile_cnt.as<int32_t>(), tile_stride, bq_sym, seeded_to / 128,
+                                             seeded_to > 0 ? (n_pad_s - seeded_to) / 128 : 0, need_m,
                                              k->lists.as<uint64_t>(), seed_lstride, k->counts.as<uint32_t>()));
                 else
                     GT_TRY(gt_launch_select(ctx, a));
@@ -408,7 +410,7 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
                 GT_TRY(gt_sym_thresholds(ctx, perm, n_pad_s, k->hnegs.as<float>(), k->lists.as<uint64_t>(), seed_lstride,
                                          k->counts.as<uint32_t>(), need_m, em, rkf, k->thr_final.as<float>(),
                                          k->sym_g.as<float>(), k->sym_gmin.as<float>(), k->sym_work, ctx->sym_cells,
-                                         k->sym_stat.as<unsigned long long>() + 2, k->sym_farcnt.as<float>()));
+                                         k->sym_stat.as<unsigned long long>() + 2, k->sym_farcnt.as<float>(), seeded_to, -1));
                 // statistics for the orphan cut of the two-stage collect (gt_sym_two_stage_prepare)
                 GT_TRY(gt_sym_radius_sum(ctx, perm, 0, n_pad_s, k->thr_final.as<float>(), em, k->sym_racc.as<double>()));
                 GT_HIP(ctx, hipMemsetAsync(k->tcounts.p, 0, size_t(n_pad_s) * sizeof(uint32_t), ctx->stream));
