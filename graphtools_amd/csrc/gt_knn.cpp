@@ -647,10 +647,12 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
         }
         sa.prec = main_prec;
         // Few query rows (a shard of a multi-GPU build): 128-row workgroups double the number of workgroups, which fills
-        // the machine better than it costs in shared-operand reuse (measured: -6 % at 125 k rows, -8 % at 250 k, +6 %
-        // at 1 M rows on 256 CUs x 3 workgroups).
+        // the machine better than it costs in shared-operand reuse - as long as the 256-row workgroups would leave CUs
+        // without one.  Round 4, isotropic N = 1e6, d = 64 sharded (tools/gpu_shard_local_probe.py): 31 k rows 13.1 against
+        // 19.2 ms, 62 k rows 15.0 against 19.4; from 125 k rows (488 workgroups of 256 rows on 256 CUs) the wide kernel wins:
+        // 23.4 against 30.0 ms, 250 k rows 45.4 against 49.7.
         sa.narrow = (main_prec == 2 && ctx->DP <= 64 &&
-                     (ctx->narrow_mode < 0 ? nq <= int64_t(ctx->n_cu) * 3 * 256 * 3 / 2 : ctx->narrow_mode == 1)) ? 1 : 0;
+                     (ctx->narrow_mode < 0 ? nq <= int64_t(ctx->n_cu) * 256 * 3 / 2 : ctx->narrow_mode == 1)) ? 1 : 0;
         // the single chain streams the compact hi-plane copies (rows of 2*DP bytes), the others the full working copy
         sa.Yp = main_prec == 2 ? ctx->Yc.as<float>() : ctx->Yp.as<float>();
         sa.Qp = main_prec == 2 ? (external ? k->Qc.as<float>() : ctx->Yc.as<float>())
