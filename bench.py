@@ -47,7 +47,7 @@ MFMA_PEAK_TFLOPS = {"f16x1": 2500.0,  # v_mfma_f32_32x32x16_f16, one chain per p
                     "f32": 157.3}     # v_mfma_f32_32x32x2_f32
 MFMA_CHAINS = {"f16x1": 1.0, "f16": 3.0, "f32": 1.0}
 HBM_PEAK_GBS = 8000.0
-PROFILE_TRAFFIC = os.path.join(ROOT, "profiles", "r3_pmc_fetch_write_per_kernel.json")
+PROFILE_TRAFFIC = os.path.join(ROOT, "profiles", "r4_pmc_fetch_write_per_kernel.json")
 PROFILE_CPU_FULL = os.path.join(ROOT, "profiles", "r3_cpu_baseline_full_c3.json")
 
 STAGES = ("prep", "query_order", "sym_prepare", "sym_seed", "sym_bound", "knn_select", "sym_cold", "rerank", "fallback",
@@ -603,6 +603,9 @@ def main():
         roof["share_of_step"] = dominant["avg_launch_ms"] / ms_per_step
         roof["traffic"] = profiled_traffic([dominant["kernel"].split(" ")[0]]) if (n == 1000000 and d == 64 and world == 1 and args.workload == "c3") else None
         roof["traffic_unit"] = "bytes/launch"
+        roof["traffic_source"] = ("committed rocprofv3 PMC passes of this command (profiles/%s: FETCH_SIZE x 2 per MI355X_MICROARCH.md + "
+                                  "WRITE_SIZE), an earlier process - counters cannot be read from inside the benchmarked one"
+                                  % os.path.basename(PROFILE_TRAFFIC))
         roof["work_per_launch"] = dominant.get("executed_flop", dominant.get("algorithmic_bytes"))
         executed = sum(r.get("executed_flop", 0.0) for r in rows)
         tail_ms = st.mean("affinity") + st.mean("symmetrize") + st.mean("normalize")

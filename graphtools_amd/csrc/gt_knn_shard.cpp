@@ -243,11 +243,41 @@ int gt_knn_shard_local(gt_ctx* ctx, int64_t r0, int64_t r1, int need_m, double r
         GT_HIP(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(k->thr_final.p), 0x7F800000, size_t(n_pad_s), ctx->stream));
     }
     uint64_t* lists0 = k->lists.as<uint64_t>() - size_t(p0) * 64;   // (addressed by sorted position: only [p0, p1) is touched)
-    {
+    int64_t seeded_to = p0;
+    if (ctx->sym_mode < 0 && ctx->sym_ok < 0 && p1 - p0 >= int64_t(16) * 2048) {
+        // first build on these points: a sixteenth of the rank's rows is seeded first and asked the questions the whole
+        // launch would be asked (gt_knn.cpp) - a rank whose rows have no cluster structure (isotropic data) gives up after
+        // 0.4 ms instead of 1.7 and runs the classic pass
+        const int64_t ps = std::max<int64_t>(2048, ((p1 - p0) / 16) / 256 * 256), prows = std::min<int64_t>(p0 + ps, ctx->n) - p0;
+        unsigned long long far_s = 0;
+        {
+            StageSpan span(ctx, "sym_seed");
+            GT_TRY(gt_sym_seed_dense(ctx, ctx->DP, k->Ycs.p, k->hnegs_fin.as<float>(), ctx->n, n_pad_s, k->sym_tiles.as<int32_t>(),
+                                     k->sym_tile_cnt.as<int32_t>(), tile_stride, bq, p0 / 128, ps / 128, need_m, lists0, 64,
+                                     k->counts.as<uint32_t>()));
+        }
+        {
+            StageSpan span(ctx, "sym_prepare");
+            GT_TRY(gt_sym_thresholds(ctx, perm, n_pad_s, k->hnegs.as<float>(), lists0, 64, k->counts.as<uint32_t>(), need_m, em,
+                                     std::max(1.0, std::fabs(rkf)), k->thr_final.as<float>(), k->sym_g.as<float>(), nullptr,
+                                     k->sym_work, ctx->sym_cells, k->sym_stat.as<unsigned long long>() + 2,
+                                     k->sym_farcnt.as<float>(), p0, p0 + ps));
+            GT_HIP(ctx, hipMemcpyAsync(&far_s, k->sym_stat.as<unsigned long long>() + 2, sizeof(far_s), hipMemcpyDeviceToHost, ctx->stream));
+            GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        }
+        const double est_s = double(need_m) + double(std::max(stride_a, 1)) * double(far_s) / double(std::max<int64_t>(prows, 1));
+        if ((stride_a > 0 && est_s > double(tcap) / 8.0) || double(far_s) >= ctx->sym_sample_far * double(prows)) {
+            k->sym_far = int64_t(double(far_s) * double(r1 - r0) / double(std::max<int64_t>(prows, 1)));
+            ctx->sym_ok = 0;
+            return GT_OK;
+        }
+        seeded_to = p0 + ps;
+    }
+    if (seeded_to < p1) {
         StageSpan span(ctx, "sym_seed");
         GT_TRY(gt_sym_seed_dense(ctx, ctx->DP, k->Ycs.p, k->hnegs_fin.as<float>(), ctx->n, n_pad_s, k->sym_tiles.as<int32_t>(),
-                                 k->sym_tile_cnt.as<int32_t>(), tile_stride, bq, p0 / 128, (p1 - p0) / 128, need_m, lists0, 64,
-                                 k->counts.as<uint32_t>()));
+                                 k->sym_tile_cnt.as<int32_t>(), tile_stride, bq, seeded_to / 128, (p1 - seeded_to) / 128, need_m,
+                                 lists0, 64, k->counts.as<uint32_t>()));
     }
     k->sym_seed_dense = true;
     k->sh_lstride = 64;
@@ -255,10 +285,11 @@ int gt_knn_shard_local(gt_ctx* ctx, int64_t r0, int64_t r1, int need_m, double r
     {
         StageSpan span(ctx, "sym_prepare");
         // (the exact stages read the points themselves: they ARE in sorted order)
-        GT_TRY(gt_sym_thresholds(ctx, perm, n_pad_s, k->hnegs.as<float>(), lists0, 64, k->counts.as<uint32_t>(), need_m, em,
-                                 std::max(1.0, std::fabs(rkf)), k->thr_final.as<float>(), k->sym_g.as<float>(), nullptr,
-                                 k->sym_work, ctx->sym_cells, k->sym_stat.as<unsigned long long>() + 2,
-                                 k->sym_farcnt.as<float>(), p0, p1));
+        if (seeded_to < p1)
+            GT_TRY(gt_sym_thresholds(ctx, perm, n_pad_s, k->hnegs.as<float>(), lists0, 64, k->counts.as<uint32_t>(), need_m, em,
+                                     std::max(1.0, std::fabs(rkf)), k->thr_final.as<float>(), k->sym_g.as<float>(), nullptr,
+                                     k->sym_work, ctx->sym_cells, k->sym_stat.as<unsigned long long>() + 2,
+                                     k->sym_farcnt.as<float>(), seeded_to, p1));
         GT_TRY(gt_sym_radius_sum(ctx, perm, p0, std::min<int64_t>(p1, ctx->n), k->thr_final.as<float>(), em, k->sym_racc.as<double>()));
         GT_HIP(ctx, hipMemsetAsync(k->tcounts.p, 0, size_t(n_pad_s) * sizeof(uint32_t), ctx->stream));
         GT_HIP(ctx, hipMemcpyAsync(&far, k->sym_stat.as<unsigned long long>() + 2, sizeof(far), hipMemcpyDeviceToHost, ctx->stream));
@@ -324,6 +355,7 @@ int gt_knn_shard_local(gt_ctx* ctx, int64_t r0, int64_t r1, int need_m, double r
     k->sh_p1 = p1;
     k->sh_need = need_m;
     k->sh_rkf = rkf;
+    if (ctx->sym_ok < 0) ctx->sym_ok = 1;
     k->sh_stage = 6;   // the lists of the sorted positions [r0, r1) wait in tlists (gt_knn_candidates)
     *applies = 1;
     return GT_OK;
