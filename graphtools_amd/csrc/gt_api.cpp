@@ -330,6 +330,10 @@ int gt_set_option(gt_ctx* ctx, const char* name, const char* value) {
         ctx->sym_sample_far = std::atof(value);
         return GT_OK;
     }
+    if (k == "dense_p_only") {
+        ctx->dense_p_only = std::atoi(value) != 0 ? 1 : 0;
+        return GT_OK;
+    }
     if (k == "dense_fused_rowsum") {
         ctx->dense_fused_rowsum = std::atoi(value) != 0 ? 1 : 0;
         return GT_OK;

@@ -215,6 +215,7 @@ struct gt_ctx {
 
     int32_t dense_bw_passes = 1;      // exact graph from a distance matrix: bandwidths in one streaming read (2: the two-pass kernel)
     int32_t dense_fused_rowsum = 1;   //   float32 matrices: row sums accumulated by the tile kernel (0: a pass of their own)
+    int32_t dense_p_only = 1;         //   the operator alone in place: two tile passes, K never stored (0: K, then the normalisation pass)
     // last dense build (gt_dense_graph_build): degree = row sums of K, bandwidth
     DevBuf dense_degree, dense_bw;
     int64_t dense_n = 0;

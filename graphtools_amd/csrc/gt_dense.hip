@@ -501,7 +501,12 @@ __global__ __launch_bounds__(256) void dense_kernel_tiles(const TD* __restrict__
                                                           const double decay_d, const double thresh_d, const int symm,
                                                           const double theta_d, TC* __restrict__ Kout,
                                                           uint32_t* __restrict__ flags, const double xcut_d, const int pass,
-                                                          double* __restrict__ rowsum) {
+                                                          double* __restrict__ rowsum, const int rs_mode) {
+    // rs_mode (float32 16-byte path, rowsum given): 0 K is written and the row sums accumulated on the way; 1 NOTHING is written,
+    // only the row sums (and the zero-diagonal flag) are formed; 2 the row sums are final: the tiles are computed again and
+    // P = K / rowsum is written instead of K.  1 + 2 = the operator in place without ever storing K: 4 N^2 + 8 N^2 bytes instead
+    // of 8 N^2 (K) + 8 N^2 (normalisation pass) - the distance tiles are read twice, the affinities computed twice (cheap: the
+    // transcendental work is skipped beyond the cut).
     // rowsum (optional, pre-zeroed; float32 16-byte path only): sum of |K_ij| of every row, accumulated tile by tile - one
     // float64 atomic per row and tile (the 16 lanes that hold a row's 64 outputs reduce first) - so that the row sums
     // behind P and the degrees do not need a pass of their own over the N x N matrix (4 N^2 bytes of HBM reads)
@@ -629,11 +634,19 @@ __global__ __launch_bounds__(256) void dense_kernel_tiles(const TD* __restrict__
                             const float b = diag ? sA[(4 * tx4 + e) * TSP + i] : sB[(4 * tx4 + e) * TSP + i];
                             o[e] = merge_t<float>(a, b, symm, theta);
                         }
-                        *reinterpret_cast<float4*>(Kout + gi * n + gj0) = make_float4(o[0], o[1], o[2], o[3]);
+                        if (rs_mode == 2) {
+                            double sd = rowsum[gi];
+                            if (sd == 0.0) sd = 1.0;   // sklearn _handle_zeros_in_scale
+                            const float sf = float(sd);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[e] = o[e] / sf;
+                        }
+                        if (rs_mode != 1) *reinterpret_cast<float4*>(Kout + gi * n + gj0) = make_float4(o[0], o[1], o[2], o[3]);
                         part = double(fabsf(o[0])) + double(fabsf(o[1])) + double(fabsf(o[2])) + double(fabsf(o[3]));
-                        if (rowsum && diag && gi >= gj0 && gi < gj0 + 4 && o[gi - gj0] == 0.f) atomicOr(flags, GT_FLAG_ZERO_DIAGONAL);
+                        if (rowsum && rs_mode != 2 && diag && gi >= gj0 && gi < gj0 + 4 && o[gi - gj0] == 0.f)
+                            atomicOr(flags, GT_FLAG_ZERO_DIAGONAL);
                     }
-                    if (rowsum) {   // (uniform: the 16 lanes of a row's group reduce together, in or out of range)
+                    if (rowsum && rs_mode != 2) {   // (uniform: the 16 lanes of a row's group reduce together, in or out of range)
 #pragma unroll
                         for (int off = 8; off > 0; off >>= 1) part += __shfl_xor(part, off, 16);
                         if (tx4 == 0 && gi < n) atomicAdd(rowsum + gi, part);
@@ -650,10 +663,17 @@ __global__ __launch_bounds__(256) void dense_kernel_tiles(const TD* __restrict__
                             const float a = sA[(4 * tx4 + e) * TSP + i];
                             o[e] = merge_t<float>(b, a, symm, theta);
                         }
-                        *reinterpret_cast<float4*>(Kout + gj * n + gi0) = make_float4(o[0], o[1], o[2], o[3]);
+                        if (rs_mode == 2) {
+                            double sd = rowsum[gj];
+                            if (sd == 0.0) sd = 1.0;
+                            const float sf = float(sd);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[e] = o[e] / sf;
+                        }
+                        if (rs_mode != 1) *reinterpret_cast<float4*>(Kout + gj * n + gi0) = make_float4(o[0], o[1], o[2], o[3]);
                         part = double(fabsf(o[0])) + double(fabsf(o[1])) + double(fabsf(o[2])) + double(fabsf(o[3]));
                     }
-                    if (rowsum) {
+                    if (rowsum && rs_mode != 2) {
 #pragma unroll
                         for (int off = 8; off > 0; off >>= 1) part += __shfl_xor(part, off, 16);
                         if (tx4 == 0 && gj < n) atomicAdd(rowsum + gj, part);
@@ -840,7 +860,7 @@ static double dense_xcut(double decay, double thresh, bool f32) {
 
 template <typename TD, typename TC, typename TX, bool FROM_DATA>
 int launch_tiles(gt_ctx* ctx, const TD* D, const TX* X, int d, int64_t n, const double* bw, double decay, double thresh,
-                 int symm, double theta, TC* Kout, uint32_t* flags, int pass = 0, double* rowsum = nullptr) {
+                 int symm, double theta, TC* Kout, uint32_t* flags, int pass = 0, double* rowsum = nullptr, int rs_mode = 0) {
     const int nb = int(ceil_div64(n, TS));
     const int64_t nbs = ceil_div64(nb, SG);
     const int64_t pairs = nbs * nbs * SG * SG;   // grid positions (super-tile order, lower triangle exits)
@@ -851,7 +871,7 @@ int launch_tiles(gt_ctx* ctx, const TD* D, const TX* X, int d, int64_t n, const 
     GT_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     int(lds)));
     hipLaunchKernelGGL(kern, dim3((unsigned)pairs), dim3(256), lds, ctx->stream, D, X, d, n, nb, bw, decay, thresh, symm,
-                       theta, Kout, flags, dense_xcut(decay, thresh, sizeof(TC) == 4), pass, rowsum);
+                       theta, Kout, flags, dense_xcut(decay, thresh, sizeof(TC) == 4), pass, rowsum, rs_mode);
     GT_HIP(ctx, hipGetLastError());
     return GT_OK;
 }
@@ -1095,7 +1115,7 @@ extern "C" int gt_dense_graph_build(gt_ctx* ctx, const void* X_or_D, int64_t n, 
         DENSE_HIP(hipGetLastError());
     }
     // ---- kernel tiles ----
-    bool fused_rowsum = false;
+    bool fused_rowsum = false, p_only = false;
     void* K_dev = nullptr;
     if (inplace) {
         K_dev = const_cast<void*>(in_dev);
@@ -1129,9 +1149,21 @@ extern "C" int gt_dense_graph_build(gt_ctx* ctx, const void* X_or_D, int64_t n, 
                 DENSE_HIP(st.rowsum.reserve(size_t(n) * sizeof(double)));
                 DENSE_HIP(hipMemsetAsync(st.rowsum.p, 0, size_t(n) * sizeof(double), ctx->stream));
             }
-            DENSE_TRY((launch_tiles<float, float, double, false>(ctx, (const float*)in_dev, nullptr, 0, n, bw, decay,
-                                                                 thresh, kernel_symm, theta, (float*)K_dev, fl, pass,
-                                                                 fused_rowsum ? st.rowsum.as<double>() : nullptr)));
+            // The operator alone, in place (inplace, out_P = the matrix itself, no out_K): K is never stored - one tile pass forms
+            // the row sums, a second one writes P = K / rowsum over the distances (12 N^2 bytes instead of 16 N^2)
+            p_only = fused_rowsum && inplace && out_P == K_dev && !out_K && out_on_device && ctx->dense_p_only != 0;
+            if (p_only) {
+                DENSE_TRY((launch_tiles<float, float, double, false>(ctx, (const float*)in_dev, nullptr, 0, n, bw, decay, thresh,
+                                                                     kernel_symm, theta, (float*)K_dev, fl, pass,
+                                                                     st.rowsum.as<double>(), 1)));
+                DENSE_TRY((launch_tiles<float, float, double, false>(ctx, (const float*)in_dev, nullptr, 0, n, bw, decay, thresh,
+                                                                     kernel_symm, theta, (float*)K_dev, fl, pass,
+                                                                     st.rowsum.as<double>(), 2)));
+            } else {
+                DENSE_TRY((launch_tiles<float, float, double, false>(ctx, (const float*)in_dev, nullptr, 0, n, bw, decay,
+                                                                     thresh, kernel_symm, theta, (float*)K_dev, fl, pass,
+                                                                     fused_rowsum ? st.rowsum.as<double>() : nullptr)));
+            }
         }
     }
     // ---- anisotropy + P ----
@@ -1146,7 +1178,7 @@ extern "C" int gt_dense_graph_build(gt_ctx* ctx, const void* X_or_D, int64_t n, 
     }
     if (out_f64)
         DENSE_TRY(finish_dense<double>(ctx, st, (double*)K_dev, (double*)P_dev, n, anisotropy));
-    else
+    else if (!p_only)   // (p_only: the second tile pass has written P already)
         DENSE_TRY(finish_dense<float>(ctx, st, (float*)K_dev, (float*)P_dev, n, anisotropy, fused_rowsum));
     if (out_K && !out_on_device) DENSE_TRY(gt_copy_to_host(ctx, out_K, K_dev, size_t(n) * n * out_esz));
     if (out_P && !out_on_device) DENSE_TRY(gt_copy_to_host(ctx, out_P, P_dev, size_t(n) * n * out_esz));

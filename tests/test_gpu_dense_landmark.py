@@ -321,3 +321,39 @@ def test_one_pass_bandwidth_and_fused_row_sums_equal_the_separate_passes(n, symm
     assert (~m).sum() <= 4
     np.testing.assert_allclose(res["new"][0][m], K0[m], rtol=1e-5, atol=0)
     np.testing.assert_allclose(res["new"][1][m], P0[m], rtol=1e-5, atol=0)
+
+
+def test_operator_alone_in_place_never_stores_K():
+    """BASELINE config 4 as bench.py runs it: a device-resident float32 distance matrix becomes diff_op IN PLACE (K and P together
+    would not fit the HBM at N = 2e5): one tile pass forms the row sums, a second writes P = K / rowsum over the distances
+    (graphs.py:1583-1609 + base.py:645).  Equals the P of the ordinary build; the degrees are K's row sums."""
+    import ctypes
+
+    import torch
+
+    from graphtools_amd import _hip
+
+    n = 2116                      # ragged edge tiles, a multiple of 4
+    X = make_mix(n, 10, 8).astype(np.float64)
+    from scipy.spatial.distance import pdist, squareform
+    D = squareform(pdist(X)).astype(np.float32)
+    c = _hip.Context(0)
+    K, P, flags = c.dense_graph_build(D, "distance", 6, 15.0, 1e-4, None, 1.0, "+", None, 0.0, want_P=True)
+    deg = c.dense_fetch_vec(_hip.VEC_DEGREE, n)
+    c.close()
+    for opt in ("1", "0"):
+        Dd = torch.from_numpy(D).cuda()
+        c = _hip.Context(0)
+        c.set_option("dense_p_only", opt)
+        fl = ctypes.c_uint32(0)
+        rc = c.lib.gt_dense_graph_build(c.h, ctypes.c_void_p(Dd.data_ptr()), n, 0, 0, 1, 1, 6, 15.0, 1e-4, None, 0, 1.0, _hip.SYMM["+"],
+                                        1.0, 0.0, 1, None, ctypes.c_void_p(Dd.data_ptr()), 1, ctypes.byref(fl))
+        c._check(rc, "gt_dense_graph_build")
+        c.sync()
+        P2 = Dd.cpu().numpy()
+        deg2 = c.dense_fetch_vec(_hip.VEC_DEGREE, n)
+        c.close()
+        assert np.array_equal(P2 == 0, P == 0)
+        np.testing.assert_allclose(P2, P, rtol=3e-7, atol=0)
+        np.testing.assert_allclose(deg2, deg, rtol=1e-12)
+        np.testing.assert_allclose(P2.astype(np.float64).sum(axis=1), 1.0, rtol=1e-5)
