@@ -215,7 +215,9 @@ struct gt_ctx {
 
     int32_t dense_bw_passes = 1;      // exact graph from a distance matrix: bandwidths in one streaming read (2: the two-pass kernel)
     int32_t dense_fused_rowsum = 1;   //   float32 matrices: row sums accumulated by the tile kernel (0: a pass of their own)
-    int32_t dense_p_only = 1;         //   the operator alone in place: two tile passes, K never stored (0: K, then the normalisation pass)
+    int32_t dense_p_only = 0;         //   the operator alone in place as two tile passes, K never stored (12 N^2 instead of 16 N^2 bytes behind the
+                                      //   bandwidths).  Measured SLOWER at N = 2e5: 152 ms for the two passes against 71 + 60 ms - the tile-pair
+                                      //   kernel is not bound by its bytes (a pass that writes nothing takes as long as one that writes K): off
     // last dense build (gt_dense_graph_build): degree = row sums of K, bandwidth
     DevBuf dense_degree, dense_bw;
     int64_t dense_n = 0;

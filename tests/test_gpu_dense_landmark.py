@@ -325,8 +325,9 @@ def test_one_pass_bandwidth_and_fused_row_sums_equal_the_separate_passes(n, symm
 
 def test_operator_alone_in_place_never_stores_K():
     """BASELINE config 4 as bench.py runs it: a device-resident float32 distance matrix becomes diff_op IN PLACE (K and P together
-    would not fit the HBM at N = 2e5): one tile pass forms the row sums, a second writes P = K / rowsum over the distances
-    (graphs.py:1583-1609 + base.py:645).  Equals the P of the ordinary build; the degrees are K's row sums."""
+    would not fit the HBM at N = 2e5; graphs.py:1583-1609 + base.py:645) - by K in place + an in-place normalisation (default), or
+    (option dense_p_only: measured slower, kept) by one tile pass for the row sums and a second that writes P = K / rowsum over the
+    distances.  Both equal the P of the ordinary build; the degrees are K's row sums."""
     import ctypes
 
     import torch
