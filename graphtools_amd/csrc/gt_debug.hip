@@ -56,7 +56,57 @@ __global__ void dbg_mfma_kernel(const float* a, const float* bt, int K, float* c
     }
 }
 
+// every lane exchange of gt_device.h against ds_bpermute (__shfl_xor): mismatches per form -> bad[0 .. 9]
+__global__ void dbg_lane_ops_kernel(const uint32_t seed, uint32_t* bad) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t v = (uint32_t(blockIdx.x) * 64u + uint32_t(lane) + 1u) * 2654435761u ^ seed;
+    const uint64_t v64 = (uint64_t(v) << 32) | uint64_t(~v * 40503u);
+    auto chk = [&](int slot, bool ok) {
+        if (!ok) atomicAdd(bad + slot, 1u);
+    };
+    chk(0, lane_xor_u32<1>(v) == uint32_t(__shfl_xor(int(v), 1)));
+    chk(1, lane_xor_u32<2>(v) == uint32_t(__shfl_xor(int(v), 2)));
+    chk(2, lane_xor_u32<4>(v) == uint32_t(__shfl_xor(int(v), 4)));
+    chk(3, lane_xor_u32<8>(v) == uint32_t(__shfl_xor(int(v), 8)));
+    chk(4, lane_xor_u32<16>(v) == uint32_t(__shfl_xor(int(v), 16)));
+    chk(5, lane_xor_u32<32>(v) == uint32_t(__shfl_xor(int(v), 32)));
+    chk(6, lane_xor_u64<16>(v64) == uint64_t(__shfl_xor((unsigned long long)v64, 16)) &&
+               lane_xor_u64<4>(v64) == uint64_t(__shfl_xor((unsigned long long)v64, 4)));
+    // reductions: against the same tree built from __shfl_xor (bitwise: same order of additions)
+    const double x = double(int(v >> 8)) * 1e-3;
+    double r = x;
+    for (int o = 32; o > 0; o >>= 1) r += __shfl_xor(r, o);
+    chk(7, wave_sum_f64(x) == r);
+    float m = float(int(v >> 9));
+    const float m0 = m;
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    chk(8, wave_max_f32(m0) == m);
+    int si = int(v >> 12);
+    const int si0 = si;
+    for (int o = 32; o > 0; o >>= 1) si += __shfl_xor(si, o);
+    chk(9, wave_sum_i32(si0) == si);
+}
+
 }  // namespace
+
+// self-test of the DPP / permlane lane exchanges and the reductions built on them (full waves, as their precondition demands)
+extern "C" int gt_dbg_lane_ops(gt_ctx* ctx, uint32_t seed, uint32_t* bad10_host) {
+    if (!ctx || !bad10_host) return GT_E_ARG;
+    GT_HIP(ctx, hipSetDevice(ctx->device));
+    DevBuf b;
+    GT_HIP(ctx, b.reserve(10 * sizeof(uint32_t)));
+    GT_HIP(ctx, hipMemsetAsync(b.p, 0, 10 * sizeof(uint32_t), ctx->stream));
+    hipLaunchKernelGGL(dbg_lane_ops_kernel, dim3(64), dim3(256), 0, ctx->stream, seed, b.as<uint32_t>());
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(bad10_host, b.p, 10 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    b.release();
+    if (e != hipSuccess) {
+        ctx->set_error(std::string("gt_dbg_lane_ops: ") + hipGetErrorString(e));
+        return GT_E_HIP;
+    }
+    return GT_OK;
+}
 
 extern "C" int gt_dbg_sort_desc(gt_ctx* ctx, const uint64_t* keys_host, int n, int nt, uint64_t* out_host) {
     if (!ctx) return GT_E_ARG;

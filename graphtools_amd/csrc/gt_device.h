@@ -510,6 +510,11 @@ __device__ __forceinline__ uint32_t lane_xor_b32(const uint32_t v, const int o) 
         default: return lane_xor_u32<1>(v);
     }
 }
+// PRECONDITION of every helper built on lane_xor_* (these reductions, the bitonic networks): the whole wave executes the call
+// CONVERGED - all 64 lanes active.  The DPP forms zero-fill what an inactive partner lane would have delivered (bound_ctrl) and
+// the permlane swaps leave an inactive lane's value in place, so a reduction inside a divergent branch silently drops addends.
+// Kernels therefore take their early exits per WAVE (`if (row >= n) return;` with one row per wave) or mask inside the call
+// (zero addends), never per lane around it.  gt_dbg_lane_ops (gt_debug.hip) checks every form against __shfl_xor on the GPU.
 __device__ __forceinline__ double wave_sum_f64(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += lane_xor_f64(v, o);

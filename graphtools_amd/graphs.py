@@ -832,6 +832,11 @@ class TraditionalGraph(DataGraph):
             from scipy.spatial.distance import cdist
 
             bandwidth = np.asarray(bandwidth(cdist(Y, X, metric=self.distance)), dtype=np.float64)
+        # scipy's cdist(Y, X) promotes both sides to float64 and keeps Y's precision (graphs.py:1653): a float64 Y on a float32
+        # graph (e.g. the output of data_pca.transform) must not be rounded to the points' dtype first
+        Ya = np.asarray(Y)
+        if Ya.dtype == np.float64 and X.dtype == np.float32:
+            X = X.astype(np.float64)
         self.hip.set_points(X)
         return self.hip.dense_extend(Y, knn, self.decay, self.thresh, bandwidth, bandwidth_scale)
 

@@ -313,3 +313,18 @@ def test_query_order_for_external_queries_and_deeper_tables():
         assert np.array_equal(i0, i1) and np.array_equal(d0, d1)
     d_or, i_or = oracle.kneighbors(X, Y[:200], 30)
     assert np.array_equal(res["auto"][1][1][:200], i_or)
+
+
+def test_lane_exchanges_and_wave_reductions_match_ds_bpermute(hip_ctx):
+    """gt_device.h exchanges lanes through DPP row operations and the gfx950 row / half swaps instead of ds_bpermute; every form
+    (lane ^ 1 ... ^ 32, 32- and 64-bit) and the reductions built on them (wave_sum_f64 / wave_max_f32 / wave_sum_i32) must give
+    what the __shfl_xor tree gives, bit for bit, with all 64 lanes active (their stated precondition)"""
+    import ctypes
+
+    lib = hip_ctx.lib
+    lib.gt_dbg_lane_ops.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]
+    lib.gt_dbg_lane_ops.restype = ctypes.c_int
+    for seed in (0, 12345, 0xFFFFFFFF):
+        bad = np.ones(10, dtype=np.uint32)
+        assert lib.gt_dbg_lane_ops(hip_ctx.h, seed, bad.ctypes.data) == 0
+        assert not bad.any(), bad

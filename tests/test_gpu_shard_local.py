@@ -137,6 +137,29 @@ def test_renumbered_sharded_build_equals_the_single_rank_build(n, d, world, symm
     _same(P, P1)
 
 
+@pytest.mark.parametrize("dtype,metric,d", [(np.float64, "euclidean", 40), (np.float32, "cosine", 64), (np.float64, "cosine", 30),
+                                             (np.float32, "euclidean", 50)])
+def test_renumbered_sharded_build_other_dtypes_and_metrics(dtype, metric, d):
+    """float64 points (lane-per-row re-rank on the renumbered points), the cosine metric (the context's points are the
+    normalised rows: they are what gets renumbered), a feature count that is no multiple of 4"""
+    X = make_mix(26000, d, 21).astype(dtype)
+    pargs = (10, 20, 1e-4, None, 1.0, None, "+", None, 0)
+    K, P, used, stats = sharded_local_build(X, 3, pargs, opts={"metric": metric})
+    assert all(used)
+    from graphtools_amd import _hip
+    c = _hip.Context(0)
+    c.set_option("metric", metric)
+    c.set_points(X)
+    p, keep = c.make_params(*pargs)
+    c.graph_build(p)
+    Kd, Ki, Kp = c.graph_fetch_csr(_hip.CSR_K)
+    Pd, _, _ = c.graph_fetch_csr(_hip.CSR_P)
+    c.close()
+    n = X.shape[0]
+    _same(K, sparse.csr_matrix((Kd, Ki, Kp), shape=(n, n)))
+    _same(P, sparse.csr_matrix((Pd, Ki, Kp), shape=(n, n)))
+
+
 def test_one_rank_build_on_renumbered_points_returns_the_callers_columns():
     """gt_graph_build on a renumbered context: rows in the new order, the caller's column numbers, same bits"""
     from graphtools_amd import _hip
