@@ -872,7 +872,7 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
                     frag_load_part<DP, NS1>(afr[(sb + 1) & 1], tb + ((sb + 1) * 32 + li) * LDP, h, aswz);
                 if constexpr (SEEDREG) {
                     mma_chain_seeded_part<DP, NS1>(afr[sb & 1], bq[qt], seedr, accp[u % NACC]);
-                    if (qt == QT - 1 && sb + 1 < NSUB) GT_SEEDR(sb + 1);   // behind the last reader of this sub-tile's seeds
+                    if (!(GT_EXP & 1) && qt == QT - 1 && sb + 1 < NSUB) GT_SEEDR(sb + 1);   // behind the last reader of this sub-tile's seeds
                 } else {
                     if (u + 1 < NU) GT_SEED(u + 1);
                     mma_chain<DP>(afr[(GT_EXP & 2) ? 0 : (sb & 1)], bq[qt], accp[u % 3]);
