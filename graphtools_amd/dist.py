@@ -136,6 +136,48 @@ def allgather_vector(v_local, splits, group=None):
     return allgather_rows(v_local.reshape(-1, 1), splits, group).reshape(-1)
 
 
+def allgather_csr_blocks(indptr, indices, values, row_ids, shape, device, group=None):
+    """Every rank holds a CSR row block - ``row_ids`` say which rows of the full matrix, in the block's order; the blocks of
+    all ranks partition the rows - and every rank receives the full matrices with their rows in natural order.
+
+    indptr, indices : the block's structure;  values : list of value arrays on that structure (K's and P's data share one)
+    returns (indptr_full, indices_full, [values_full ...]) as numpy arrays (int64 / indices' dtype / float64)
+    Four + len(values) all-gathers (sizes, row numbers, row lengths, column indices, each value array)."""
+    import torch
+
+    dist = _dist()
+    world = dist.get_world_size(group)
+    lens = np.diff(np.asarray(indptr, dtype=np.int64))
+    sizes = torch.as_tensor(np.array([len(lens), int(lens.sum())], dtype=np.int64), device=device)
+    all_sizes = torch.empty(2 * world, dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(all_sizes, sizes, group=group)
+    all_sizes = all_sizes.cpu().numpy().reshape(world, 2)
+    row_splits = np.concatenate([[0], np.cumsum(all_sizes[:, 0])]).astype(np.int64)
+    nnz_splits = np.concatenate([[0], np.cumsum(all_sizes[:, 1])]).astype(np.int64)
+    if int(row_splits[-1]) != int(shape[0]):
+        raise RuntimeError("allgather_csr_blocks: the ranks' blocks hold %d rows of %d" % (int(row_splits[-1]), int(shape[0])))
+
+    def gather(a, splits, dtype):
+        t = torch.as_tensor(np.ascontiguousarray(a, dtype=dtype), device=device)
+        return allgather_vector(t, splits, group).cpu().numpy()
+
+    ids = gather(row_ids, row_splits, np.int64)
+    lens_all = gather(lens, row_splits, np.int64)
+    idx_dtype = np.asarray(indices).dtype
+    cols = gather(indices, nnz_splits, idx_dtype)
+    vals = [gather(v, nnz_splits, np.float64) for v in values]
+    # rows into natural order: entry k of output row r comes from position start_of(block row holding r) + k
+    where = np.empty(int(shape[0]), dtype=np.int64)
+    where[ids] = np.arange(len(ids), dtype=np.int64)
+    if len(np.unique(ids)) != len(ids):
+        raise RuntimeError("allgather_csr_blocks: a row is held by more than one rank")
+    src_ptr = np.concatenate([[0], np.cumsum(lens_all)]).astype(np.int64)
+    out_lens = lens_all[where]
+    out_ptr = np.concatenate([[0], np.cumsum(out_lens)]).astype(np.int64)
+    take = np.arange(int(out_ptr[-1]), dtype=np.int64) - np.repeat(out_ptr[:-1] - src_ptr[where], out_lens)
+    return out_ptr, cols[take], [v[take] for v in vals]
+
+
 def _order_after_collectives(ctx, tensor):
     """The library runs on its own stream: what a collective wrote into ``tensor`` (complete with respect to torch's
     current stream) has to be ordered before the library's next launch - on the device, without stalling the host."""

@@ -23,9 +23,22 @@ class DataGraph(Data, BaseGraph):
     """Graphs built from a data matrix (reference: graphtools/base.py:1046-1254)."""
 
     def __init__(self, data, n_pca=None, rank_threshold=None, random_state=None, verbose=True, n_jobs=1,
-                 device=None, **kwargs):
+                 device=None, distributed=False, group=None, **kwargs):
         self.n_jobs = n_jobs
         self.verbose = verbose
+        # Where the reference spends all cores of one process (``n_jobs=-1``, api.py:35 / graphs.py:763-768) this package spends
+        # all GPUs of one ``torch.distributed`` job: with ``distributed=True`` (or "auto": when a process group with more than
+        # one rank is initialised) EVERY rank makes the same call with the same data, the build is row-sharded over the ranks
+        # (graphtools_amd.dist, one process per GPU, RCCL) and every rank ends with the full ``K`` / ``P`` on its host, like a
+        # single-process build; ``K_local`` / ``P_local`` / ``local_rows`` are the rank's own rows without the gather.
+        if distributed not in (False, True, "auto", None):
+            raise ValueError("distributed must be True, False or 'auto'. Got {}".format(distributed))
+        self.distributed = distributed or False
+        self.group = group
+        if device is None and self.distributed:
+            import os
+
+            device = int(os.environ.get("LOCAL_RANK", "0"))   # (torchrun's convention: one process per GPU of the node)
         self.device = device
         Data.__init__(self, data, n_pca=n_pca, rank_threshold=rank_threshold, random_state=random_state)
         BaseGraph.__init__(self, **kwargs)
@@ -43,6 +56,38 @@ class DataGraph(Data, BaseGraph):
         Data.set_params(self, **params)
         BaseGraph.set_params(self, **params)
         return self
+
+    # ---- row-sharded builds over torch.distributed ------------------------------------------------
+    def _dist_ranks(self):
+        """(group, world, rank) when this graph is built row-sharded over ``torch.distributed``, else None."""
+        mode = getattr(self, "distributed", False)
+        if not mode:
+            return None
+        import torch.distributed as tdist
+
+        if not (tdist.is_available() and tdist.is_initialized()):
+            if mode == "auto":
+                return None
+            raise RuntimeError("distributed=True needs an initialised torch.distributed process group (one process per GPU)")
+        group = getattr(self, "group", None)
+        world = tdist.get_world_size(group)
+        if world == 1 and mode == "auto":
+            return None
+        return group, world, tdist.get_rank(group)
+
+    def _dist_device(self):
+        """the torch device the collectives run on: this rank's GPU under RCCL, the host under gloo (CPU tests)"""
+        import torch
+        import torch.distributed as tdist
+
+        if "nccl" in str(tdist.get_backend(getattr(self, "group", None))):
+            return torch.device("cuda", int(getattr(self, "device", 0) or 0))
+        return torch.device("cpu")
+
+    def _no_sharded(self, what):
+        if self._dist_ranks() is not None:
+            raise NotImplementedError("graphtools_amd: {} is not available on a row-sharded (distributed=True) graph - build "
+                                      "it with distributed=False on one GPU".format(what))
 
     def _check_extension_shape(self, Y):
         Y = np.asarray(Y)
@@ -277,7 +322,61 @@ class kNNGraph(DataGraph):
             _base.log_task(self.verbose, "KNN search", ms(self._KNN_STAGES) * 1e-3)
             _base.log_task(self.verbose, "affinities", ms(self._AFFINITY_STAGES) * 1e-3)
 
+    def _build_kernel_sharded(self):
+        """The build of ``_build_kernel`` row-sharded over the ranks of a torch.distributed job (graphtools_amd.dist: points
+        all-gather, renumbering by cell, local candidate lists, triplet all-to-all, local merge), then the ranks' row blocks
+        of K and P all-gathered so that every rank returns what a single-process build returns."""
+        import torch
+
+        from . import dist as gdist
+
+        group, world, rank = self._dist_ranks()
+        X = np.ascontiguousarray(self.data_nu)
+        if X.dtype not in (np.float32, np.float64):
+            X = X.astype(np.float64)
+        n = X.shape[0]
+        device = self._dist_device()
+        self.hip.set_option("metric", self.distance)
+        sk = gdist.ShardedKnnGraph(self.hip, n, group=group)
+        r0, r1 = int(sk.input_splits[rank]), int(sk.input_splits[rank + 1])
+        sk.gather_points(torch.from_numpy(X[r0:r1]).to(device))   # (only the rank's slice crosses its PCIe link)
+        params, keep = self._params_struct()
+        nnz_local, flags = sk.build(params)
+        del keep
+        self._points_bound = False    # (the context holds the renumbered points of the sharded build)
+        self._device_state = None
+        self._sharded = sk
+        self._log_phases()
+        data, indices, indptr = self.hip.graph_fetch_csr(_hip.CSR_K)
+        pdata, _, _ = self.hip.graph_fetch_csr(_hip.CSR_P, structure=False)
+        rows = sk.row_ids()
+        self.local_rows = rows
+        self.K_local = sparse.csr_matrix((data, indices, indptr), shape=(len(rows), n))
+        self.P_local = sparse.csr_matrix((pdata, indices, indptr), shape=(len(rows), n))
+        deg_local = np.asarray(self.hip.graph_fetch_vec(_hip.VEC_DEGREE), dtype=np.float64)
+        # the full matrices on every rank (what `G.K`, `G.P` mean in the reference); flags: OR over the ranks
+        fl = torch.as_tensor(np.array([(flags >> b) & 1 for b in range(8)], dtype=np.int64), device=device)
+        torch.distributed.all_reduce(fl, op=torch.distributed.ReduceOp.MAX, group=group)
+        flags = int(sum(int(v) << b for b, v in enumerate(fl.cpu().tolist())))
+        self._build_flags = flags
+        ptr, cols, (kv, pv) = gdist.allgather_csr_blocks(indptr, indices, [data, pdata], rows, (n, n), device, group)
+        deg = np.empty(n, dtype=np.float64)
+        ids_t = gdist.allgather_vector(torch.as_tensor(rows, device=device), sk.splits, group).cpu().numpy()
+        deg[ids_t] = gdist.allgather_vector(torch.as_tensor(deg_local, device=device), sk.splits, group).cpu().numpy()
+        self._kernel_degree = deg.reshape(-1, 1)
+        if int(ptr[-1]) < 2**31:
+            ptr = ptr.astype(np.int32)
+        K = sparse.csr_matrix((kv, cols, ptr), shape=(n, n))
+        self._diff_op = sparse.csr_matrix((pv, K.indices, K.indptr), shape=(n, n))
+        if flags & _hip.FLAG_DUPLICATES:
+            warnings.warn("Detected zero distance between samples. Consider removing duplicates to avoid errors in "
+                          "downstream processing.", RuntimeWarning)
+        self._emit_build_warnings(flags, K)
+        return K
+
     def _build_kernel(self):
+        if self._dist_ranks() is not None:
+            return self._build_kernel_sharded()
         nnz, flags = self._device_build(self.kernel_symm, self.theta, self.anisotropy)
         self._log_phases()
         self._build_flags = flags
@@ -297,6 +396,7 @@ class kNNGraph(DataGraph):
 
     def build_kernel(self):
         """The unsymmetrised kernel K0 (reference: graphs.py:771-785), as a scipy CSR matrix."""
+        self._no_sharded("build_kernel() (the unsymmetrised kernel)")
         nnz, flags = self._device_build(None, None, 0)
         data, indices, indptr = self.hip.graph_fetch_csr(_hip.CSR_K)
         n = self.data_nu.shape[0]
@@ -316,6 +416,11 @@ class kNNGraph(DataGraph):
 
     def _fetch_diff_aff(self):
         self.K
+        if self._dist_ranks() is not None:
+            # (a sharded graph's device holds the rank's rows only: base.py:683-698 on the gathered host copy)
+            d = np.asarray(self.kernel_degree, dtype=np.float64).ravel()
+            dm = sparse.csr_matrix((1 / np.sqrt(d), np.arange(len(d)), np.arange(len(d) + 1)))
+            return dm @ self._kernel @ dm
         self._ensure_device_graph()
         vals = self.hip.graph_diff_aff()
         K = self._kernel
@@ -324,6 +429,7 @@ class kNNGraph(DataGraph):
     def diff_op_torch(self):
         """The diffusion operator as a CUDA ``torch.sparse_csr_tensor`` (no host round trip): the hand-off to
         consumers that continue on the device, e.g. ``P @ X`` diffusion steps."""
+        self._no_sharded("diff_op_torch()")
         self.K
         self._ensure_device_graph()
         return self.hip.graph_csr_torch(_hip.CSR_P)
@@ -331,6 +437,7 @@ class kNNGraph(DataGraph):
     def diffuse(self, X, t=1):
         """``P^t X`` with the diffusion operator left on the device (``gt_graph_spmm``; the reference's consumers do
         ``graph.diff_op.dot(X)`` on the host CSR).  X: [n_samples] or [n_samples, c]."""
+        self._no_sharded("diffuse()")
         self.K
         self._ensure_device_graph()
         X = np.asarray(X)
@@ -342,6 +449,7 @@ class kNNGraph(DataGraph):
 
     def kernel_torch(self):
         """The kernel matrix K as a CUDA ``torch.sparse_csr_tensor``."""
+        self._no_sharded("kernel_torch()")
         self.K
         self._ensure_device_graph()
         return self.hip.graph_csr_torch(_hip.CSR_K)
@@ -356,6 +464,7 @@ class kNNGraph(DataGraph):
         return st
 
     def _extend_on_device(self, Y, knn=None, knn_max=None, bandwidth=None, bandwidth_scale=None):
+        self._no_sharded("the out-of-sample extension")
         if knn is None:
             knn = self.knn
         if bandwidth is None:
@@ -519,6 +628,10 @@ class LandmarkGraph(DataGraph):
             # reference: graphs.py:1200-1213
             if self.distance != "euclidean":
                 raise NotImplementedError("graphtools_amd: random landmarking supports the euclidean metric only")
+            if self._dist_ranks() is not None:
+                # every rank assigns its own rows, one all-gather of the labels (graphtools_amd.dist)
+                self.K
+                return np.asarray(self._sharded.random_landmark_clusters(self.n_landmark, self.random_state), dtype=np.int64)
             rng = np.random.default_rng(self.random_state)
             landmark_indices = rng.choice(n_samples, self.n_landmark, replace=False)
             if n_samples > 5000:
@@ -545,6 +658,7 @@ class LandmarkGraph(DataGraph):
         # diff_aff, the embedding product and the labelling pass on the device (graphtools_amd/_spectral.py; statistical
         # parity - the k-means in the middle is scikit-learn's own and RNG-dependent); otherwise host scikit-learn as in
         # the reference.
+        self._no_sharded("spectral landmarking (use random_landmarking=True)")
         from . import base as _base
         if (_base.SPECTRAL_BACKEND != "sklearn" and isinstance(self, kNNGraph) and self.n_svd + 10 <= 128
                 and (_base.SPECTRAL_BACKEND == "device" or n_samples >= _base._SPECTRAL_DEVICE_MIN_ROWS)):
@@ -569,6 +683,19 @@ class LandmarkGraph(DataGraph):
             self._clusters = self._assign_clusters()
         landmarks, inverse = np.unique(self._clusters, return_inverse=True)
         L = len(landmarks)
+        if self._dist_ranks() is not None:
+            # partial L x L products of the rank's rows, ONE all-reduce (dist.landmark_operator); the rank's rows of the
+            # transitions all-gathered like K's
+            from . import dist as gdist
+
+            group, world, rank = self._dist_ranks()
+            sk = self._sharded
+            self._landmark_op, tnnz = sk.landmark_operator(inverse.astype(np.int32), L)
+            data, indices, indptr = self.hip.landmark_fetch_transitions(tnnz)
+            n = self.data.shape[0]
+            ptr, cols, (tv,) = gdist.allgather_csr_blocks(indptr, indices, [data], sk.row_ids(), (n, L), self._dist_device(), group)
+            self._transitions = sparse.csr_matrix((tv, cols, ptr.astype(np.int32)), shape=(n, L))
+            return
         if dense:
             # an exact (dense) kernel: its non-zeros are handed to the device as they are (no symmetrisation, no anisotropy -
             # K is final), the landmark products then run as for a kNN kernel; the reference returns dense transitions here
@@ -709,6 +836,7 @@ class TraditionalGraph(DataGraph):
         return K
 
     def _build_kernel(self):
+        self._no_sharded("an exact (TraditionalGraph) build")
         data = self.data_nu
         if self.precomputed in ("affinity", "adjacency"):
             if sparse.issparse(self.data):
@@ -978,6 +1106,7 @@ class MNNGraph(DataGraph):
         kNNGraph._bind_points(self)
 
     def _build_kernel(self):
+        self._no_sharded("an MNN build")
         K0 = self._kernel0 = self._assemble_kernel0()
         nnz, flags = self._device_build_from_k0()
         data, indices, indptr = self.hip.graph_fetch_csr(_hip.CSR_K)

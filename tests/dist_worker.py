@@ -35,12 +35,53 @@ class FakeParams(object):
         self.anisotropy, self.theta, self.knn_max = anisotropy, theta, knn_max
 
 
+def _plain_params(p):
+    """the ctypes parameter block the product hands to the library, in the stand-in's terms"""
+    if isinstance(p, FakeParams):
+        return p
+    symm = {0: None, 1: "+", 2: "*"}[int(p.kernel_symm)]
+    decay = None if p.decay != p.decay else float(p.decay)
+    return FakeParams(int(p.knn), decay, float(p.thresh), symm, anisotropy=float(p.anisotropy), theta=float(p.theta),
+                      knn_max=int(p.knn_max))
+
+
 class FakeCtx(object):
     """numpy/oracle stand-in with the call sequence of graphtools_amd._hip.Context"""
+
+    # ---- what graphtools_amd.graphs asks of a context around a sharded build ----
+    def set_option(self, name, value):
+        pass
+
+    def stage_ms(self, stage):
+        return 0.0
+
+    def graph_fetch_csr(self, which, structure=True):
+        M = self.K
+        if which == 1:   # P: rows of K over their sums
+            M = sparse.csr_matrix(sparse.diags(1.0 / np.asarray(self.K.sum(axis=1)).ravel()) @ self.K)
+            M.sort_indices()
+        return M.data.copy(), M.indices.astype(np.int32), M.indptr.astype(np.int64)
+
+    def graph_fetch_vec(self, which):
+        assert which == 1
+        return np.asarray(self.K.sum(axis=1)).ravel()
+
+    def nearest_landmark(self, landmarks, mode, rows=None):
+        from scipy.spatial.distance import cdist
+
+        r0, r1 = rows
+        X0 = self.X0 if self.perm is None else self.X0   # landmark rows are the caller's row numbers
+        return np.argmin(cdist(self.X[r0:r1], X0[np.asarray(landmarks)]), axis=1).astype(np.int32)
+
+    def landmark_fetch_transitions(self, tnnz):
+        T = sparse.csr_matrix(self._T / self._T.sum(axis=1)[:, None])
+        T.sort_indices()
+        return T.data.copy(), T.indices.astype(np.int32), T.indptr.astype(np.int64)
 
     def set_points_device(self, ptr, n, d, dtype):
         self.X = np.frombuffer((ctypes.c_char * (n * d * np.dtype(dtype).itemsize)).from_address(ptr),
                                dtype=dtype).reshape(n, d).copy()
+        self.X0 = self.X   # by the caller's row numbers
 
     # ---- the sharded symmetric candidate pass (gt_graph_sym_*): a miniature with the same call sequence and buffer
     # contracts - thresholds are position numbers, every rank contributes a known set of records per row - so that the
@@ -143,12 +184,14 @@ class FakeCtx(object):
         return (self.perm[r0:r1] if self.perm is not None else np.arange(r0, r1)).astype(np.int32)
 
     def graph_shard_local(self, params, world, rank, splits):
+        params = _plain_params(params)
         self.calls = self.calls + ("shard_local",)
         assert self.perm is not None and np.array_equal(splits, self.points_shard_splits(world))
         self.sym_ready = self.local_applies
         return self.local_applies
 
     def graph_begin(self, params, world, rank, splits):
+        params = _plain_params(params)
         self.sym_consumed, self.sym_ready = self.sym_ready, False
         self.p, self.world, self.rank, self.splits = params, world, rank, np.asarray(splits)
         r0, r1 = int(splits[rank]), int(splits[rank + 1])
@@ -230,6 +273,7 @@ class FakeCtx(object):
         n = self.X.shape[0]
         S = sparse.csr_matrix((np.ones(n), (np.asarray(clusters), np.arange(n))), shape=(n_landmark, n))
         T = np.asarray((self.K @ S.T).todense())            # [nloc, L]: row i of K summed per cluster
+        self._T = T
         c = T.sum(axis=1)
         M = T.T @ (T / c[:, None])
         return M, T.sum(axis=0), int((T != 0).sum())
@@ -369,6 +413,64 @@ def main():
     op_ref, _ = oracle.landmark_operator(K_full, clusters)
     np.testing.assert_allclose(op, op_ref, rtol=1e-12, atol=1e-300)
     np.testing.assert_allclose(op.sum(axis=1), 1.0, rtol=1e-12)
+    # 8. the same through the package's own boundary: every rank calls graphtools_amd.Graph(X, ..., distributed=True) with the
+    #    same data and gets the FULL K / P of a single-process build (blocks all-gathered, rows back in the caller's order),
+    #    its own rows as K_local / local_rows, the gathered degrees, and - landmark graphs - the operator and transitions
+    import graphtools_amd
+    from graphtools_amd import graphs as ggraphs
+
+    for symm, aniso in (("+", 0), ("*", 0), ("+", 0.5)):
+        G = graphtools_amd.Graph(Xg, knn=10, decay=20, kernel_symm=symm, anisotropy=aniso, distributed=True, initialize=False,
+                                 n_pca=None, verbose=False)
+        assert isinstance(G, ggraphs.kNNGraph)
+        G._hip_ctx = FakeCtx()
+        K_ref = sparse.csr_matrix(oracle.knn_graph(Xg, knn=10, decay=20, kernel_symm=symm, anisotropy=aniso)[0])
+        K_ref.sort_indices()
+        K = G.K
+        assert K.shape == K_ref.shape and np.array_equal(K.indptr, K_ref.indptr) and np.array_equal(K.indices, K_ref.indices)
+        np.testing.assert_allclose(K.data, K_ref.data, rtol=1e-13, atol=0)
+        P_ref = sparse.csr_matrix(sparse.diags(1.0 / np.asarray(K_ref.sum(axis=1)).ravel()) @ K_ref)
+        P_ref.sort_indices()
+        np.testing.assert_allclose(G.P.data, P_ref.data, rtol=1e-12, atol=0)
+        assert np.array_equal(G.diff_op.indices, K_ref.indices)
+        np.testing.assert_allclose(G.kernel_degree.ravel(), np.asarray(K_ref.sum(axis=1)).ravel(), rtol=1e-12)
+        assert (G.K_local != K[G.local_rows]).nnz == 0 and G.K_local.shape == (len(G.local_rows), Xg.shape[0])
+        mine = torch.zeros(Xg.shape[0], dtype=torch.int64)
+        mine[torch.from_numpy(np.asarray(G.local_rows))] = 1
+        dist.all_reduce(mine)
+        assert bool((mine == 1).all()), "the ranks' rows do not partition the data"
+        da = G.diff_aff
+        d = np.asarray(K_ref.sum(axis=1)).ravel()
+        Kc = K_ref.tocoo()
+        np.testing.assert_allclose(sparse.csr_matrix(da).data, sparse.csr_matrix((Kc.data / np.sqrt(d[Kc.row] * d[Kc.col]), (Kc.row, Kc.col)), shape=K_ref.shape).data, rtol=1e-12)
+        for call in (G.build_kernel, G.diff_op_torch, lambda: G.extend_to_data(Xg[:5])):
+            try:
+                call()
+            except NotImplementedError:
+                pass
+            else:
+                raise AssertionError("a sharded graph answered a single-device request")
+    Gl = graphtools_amd.Graph(Xg, knn=10, decay=20, n_landmark=12, random_landmarking=True, random_state=3, distributed=True,
+                              initialize=False, n_pca=None, verbose=False)
+    Gl._hip_ctx = FakeCtx()
+    K_full = sparse.csr_matrix(oracle.knn_graph(Xg, knn=10, decay=20, kernel_symm="+")[0])
+    lm = np.random.default_rng(3).choice(Xg.shape[0], 12, replace=False)
+    from scipy.spatial.distance import cdist
+
+    want_clusters = np.argmin(cdist(Xg, Xg[lm]), axis=1)
+    assert np.array_equal(np.asarray(Gl.clusters), want_clusters)
+    op_ref, _ = oracle.landmark_operator(K_full, want_clusters)
+    np.testing.assert_allclose(Gl.landmark_op, op_ref, rtol=1e-12, atol=1e-300)
+    S = sparse.csr_matrix((np.ones(Xg.shape[0]), (np.arange(Xg.shape[0]), want_clusters)), shape=(Xg.shape[0], 12))
+    T_ref = np.asarray((K_full @ S).todense())
+    T_ref = T_ref / T_ref.sum(axis=1)[:, None]
+    np.testing.assert_allclose(np.asarray(Gl.transitions.todense()), T_ref, rtol=1e-12, atol=1e-300)
+    try:
+        graphtools_amd.Graph(Xg, knn=10, decay=20, n_landmark=12, distributed=True, initialize=False, n_pca=None)._assign_clusters()
+    except NotImplementedError:
+        pass
+    else:
+        raise AssertionError("spectral landmarking answered on a sharded graph")
     dist.barrier()
     dist.destroy_process_group()
     print("rank %d ok" % rank)

@@ -297,6 +297,30 @@ def test_host_flow_over_rccl_world_one():
             else:
                 np.testing.assert_allclose(op, op_ref, rtol=1e-12, atol=1e-300)
             ctx.close()
+        # the package's own boundary over the same group: Graph(X, ..., distributed=True) == Graph(X, ...) - full K and P, degrees,
+        # and (landmark graphs) clusters, operator and transitions
+        import graphtools_amd
+
+        G1 = graphtools_amd.Graph(X, knn=10, decay=20, n_pca=None, verbose=False, n_landmark=40, random_landmarking=True,
+                                  random_state=7)
+        Gd = graphtools_amd.Graph(X, knn=10, decay=20, n_pca=None, verbose=False, n_landmark=40, random_landmarking=True,
+                                  random_state=7, distributed=True)
+        assert Gd._dist_ranks() is not None and Gd._sharded.renumbered
+        for a, b in ((G1.K, Gd.K), (G1.P, Gd.P)):
+            assert np.array_equal(a.indptr, b.indptr) and np.array_equal(a.indices, b.indices) and np.array_equal(a.data, b.data)
+        assert np.array_equal(G1.K.data, kd)
+        assert np.array_equal(G1.kernel_degree, Gd.kernel_degree)
+        assert (Gd.K_local != Gd.K[Gd.local_rows]).nnz == 0
+        assert np.array_equal(np.asarray(G1.clusters), np.asarray(Gd.clusters))
+        np.testing.assert_allclose(Gd.landmark_op, G1.landmark_op, rtol=1e-12, atol=1e-300)
+        assert np.array_equal(G1.transitions.indices, Gd.transitions.indices)
+        np.testing.assert_allclose(Gd.transitions.data, G1.transitions.data, rtol=1e-13)
+        np.testing.assert_allclose(sparse.csr_matrix(Gd.diff_aff).data, sparse.csr_matrix(G1.diff_aff).data, rtol=1e-13)
+        with pytest.raises(NotImplementedError):
+            Gd.extend_to_data(X[:5])
+        # "auto" with a single rank stays on the single-GPU path
+        Ga = graphtools_amd.Graph(X[:5000], knn=10, decay=20, n_pca=None, verbose=False, distributed="auto")
+        assert Ga._dist_ranks() is None and not hasattr(Ga, "_sharded")
     finally:
         os.environ.pop("GT_SHARD_SYM_FORCE", None)
         dist.destroy_process_group()
