@@ -373,6 +373,8 @@ def secondary_c4(_hip, torch, device, n=200000, d=100):
     torch.cuda.synchronize(device)
     ctx = _hip.Context(device.index or 0)
     try:
+        for o in [o for o in os.environ.get("GT_C4_OPTS", "").split(",") if o]:   # development: library options for this leg
+            ctx.set_option(*o.split("="))
         flags = ctypes.c_uint32(0)
         t0 = time.perf_counter()
         # in place: D -> K -> P = diff_op in the same 160 GB buffer (K and P together would be 320 GB: more than the HBM);
@@ -382,11 +384,16 @@ def secondary_c4(_hip, torch, device, n=200000, d=100):
         ctx._check(rc, "gt_dense_graph_build")
         ctx.sync()
         wall = time.perf_counter() - t0
-        st = {s: round(ctx.stage_ms(s), 2) for s in ("dense_bandwidth", "dense_kernel", "dense_normalize")}
+        st = {s: round(ctx.stage_ms(s), 2) for s in ("dense_bandwidth", "dense_rows_scan", "dense_kernel", "dense_normalize")}
         row_sums = float(D[:4096].double().sum(dim=1).sub(1.0).abs().max().item())   # diff_op rows sum to 1 (float32 entries)
-        # bytes this run needs (round-3 verdict: price what runs): D read once for the bandwidths (4 N^2), D read + K written by
-        # the tile-pair kernel with the row sums accumulated on the way (8 N^2), K read + P written (8 N^2)
-        nbytes = 20.0 * n * n
+        # bytes this run needs (round-3 verdict: price what runs).  Row-streaming form (round 4, what runs by default): D read once
+        # for the bandwidths (4 N^2), once for the row sums and the list of kept affinities (4 N^2), once more while P is written
+        # over it (8 N^2).  Tile-pair form: bandwidths 4 N^2, K with fused row sums 8 N^2, normalisation 8 N^2.
+        rows_form = st["dense_rows_scan"] > 0
+        nbytes = (16.0 if rows_form else 20.0) * n * n
+        note = ("16 N^2 bytes as run (row-streaming form): 4 N^2 bandwidth pass, 4 N^2 scan (row sums + the kept affinities as a "
+                "list), 8 N^2 write pass (P over the distances; the transposed half arrives as the list)") if rows_form else (
+                "20 N^2 bytes as run: 4 N^2 bandwidth pass (one read), 8 N^2 tile-pair kernel (row sums fused), 8 N^2 normalisation")
         return {"workload": "C4: mix N=%d d=%d seed=2, TraditionalGraph knn=15 decay=40 from a resident float32 distance matrix "
                             "(precomputed='distance'): bandwidths, K, diff_op materialised IN PLACE (the buffer ends as P; K = P x "
                             "degree), degrees (one build: the input is consumed)" % (n, d),
@@ -394,8 +401,7 @@ def secondary_c4(_hip, torch, device, n=200000, d=100):
                 "diff_op_row_sum_max_dev_first_4096_rows": row_sums,
                 "roofline": {"bound": "hbm", "algorithmic_bytes": nbytes, "achieved": nbytes / wall / 1e9, "peak": HBM_PEAK_GBS,
                              "unit": "GB/s", "frac": nbytes / wall / 1e9 / HBM_PEAK_GBS,
-                             "note": "20 N^2 bytes as run: 4 N^2 bandwidth pass (one read), 8 N^2 tile-pair kernel (row sums fused), "
-                                     "8 N^2 normalisation"}}
+                             "note": note}}
     finally:
         ctx.close()
         del D, X

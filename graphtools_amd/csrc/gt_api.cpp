@@ -330,6 +330,14 @@ int gt_set_option(gt_ctx* ctx, const char* name, const char* value) {
         ctx->sym_sample_far = std::atof(value);
         return GT_OK;
     }
+    if (k == "dense_rows") {
+        ctx->dense_rows = v == "auto" ? -1 : std::atoi(value);
+        return GT_OK;
+    }
+    if (k == "dense_rows_cap") {
+        ctx->dense_rows_cap = std::atoll(value);
+        return GT_OK;
+    }
     if (k == "dense_p_only") {
         ctx->dense_p_only = std::atoi(value) != 0 ? 1 : 0;
         return GT_OK;

@@ -11,6 +11,7 @@
 // HBM-bound: per element 1 read + 1 write for K, 1-2 reads + 1 write for P (row sums re-read the row while
 // it is L2 resident).  The from-data variant adds 3*d float64 flops per element on the vector pipe.
 #include <cfloat>
+#include <memory>
 #include <type_traits>
 
 #include "gt_common.h"
@@ -730,6 +731,262 @@ __global__ __launch_bounds__(256) void dense_kernel_tiles(const TD* __restrict__
     }
 }
 
+
+// ---- row-streaming form of the '+' rule on a float32 distance matrix ------------------------------------------------------
+// K = (K0 + K0^T) / 2 needs K0_ji next to K0_ij.  The tile-pair kernel reads both tiles - 256-byte row segments of 64 rows each,
+// which the HBM serves at 4.3 TB/s whatever the kernel does with them (a read-only tile pass takes as long).  But K0 is SPARSE
+// after the threshold (decay 40, thresh 1e-4: ~170 of 200 000 entries per row): the transposed half can travel as a list.
+//   S1  dense_rows_scan_kernel    one workgroup per row streams the row (16-byte loads): own row sum, non-zeros {i, j, K0_ij}
+//                                 collected in LDS and appended to a flat list (one reservation per row)
+//   T   tri_count / scan / tri_scatter   the list transposed: for every row i the entries {j, K0_ji} ("incoming")
+//   S3  dense_rows_write_kernel   one workgroup per row: row sum = (own + incoming) / 2; the incoming entries are merged with
+//                                 the row's own values first (their distances are still there: the row is written by this
+//                                 workgroup only) and parked; the row is streamed once more - (K0_ij + 0) / 2, or / row sum
+//                                 when P is what is wanted - and written; the parked values then overwrite their places.
+// Every element sees the operations of the tile-pair kernel in the same order ((a + b) / 2, then / float(row sum)): same bits
+// up to the summation order of the float64 row sums.  Bytes: 4 N^2 (S1) + 8 N^2 (S3) instead of 8 N^2 + 8 N^2 (normalisation
+// pass), all of it as whole rows.
+constexpr int ROWS_LDS_CAP = 1024;   // non-zeros of a row parked in LDS before the row's one reservation (beyond: direct appends)
+
+struct TriList {
+    uint32_t* i;
+    uint32_t* j;
+    float* a;
+    unsigned long long* cursor;   // entries appended so far (may run past cap: the host checks)
+    unsigned long long cap;
+};
+
+__global__ __launch_bounds__(256) void dense_rows_scan_kernel(const float* __restrict__ D, const int64_t n,
+                                                              const double* __restrict__ bw, const double decay_d,
+                                                              const double thresh_d, const double xcut_d,
+                                                              double* __restrict__ own_sum, const TriList tl,
+                                                              uint32_t* __restrict__ flags) {
+    __shared__ uint32_t lcol[ROWS_LDS_CAP];
+    __shared__ float lval[ROWS_LDS_CAP];
+    __shared__ uint32_t lcount, lbase_lo, lbase_hi;
+    __shared__ double red[4];
+    const int64_t i = blockIdx.x;
+    const float decay = float(decay_d), thresh = float(thresh_d), xcut = float(xcut_d);
+    const float bwi = float(bw[i]);
+    if (threadIdx.x == 0) lcount = 0u;
+    __syncthreads();
+    const float4* rv = reinterpret_cast<const float4*>(D + i * n);
+    const int64_t nv = n / 4;
+    double s = 0.0;
+    for (int64_t j0 = 0; j0 < nv; j0 += 256 * 4) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t j = j0 + u * 256 + threadIdx.x;
+            v[u] = (j < nv) ? rv[j] : make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t j = j0 + u * 256 + threadIdx.x;
+            float a[4];
+            a[0] = affinity_t<float>(v[u].x, bwi, decay, xcut);
+            a[1] = affinity_t<float>(v[u].y, bwi, decay, xcut);
+            a[2] = affinity_t<float>(v[u].z, bwi, decay, xcut);
+            a[3] = affinity_t<float>(v[u].w, bwi, decay, xcut);
+            int nh = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (a[e] < thresh) a[e] = 0.f;
+                nh += a[e] != 0.f ? 1 : 0;
+            }
+            if (j < nv && nh) {   // (rare: a handful of the row's entries survive the threshold)
+                s += (double(a[0]) + double(a[1])) + (double(a[2]) + double(a[3]));
+                const uint32_t slot = atomicAdd(&lcount, uint32_t(nh));
+                if (slot + uint32_t(nh) <= uint32_t(ROWS_LDS_CAP)) {
+                    uint32_t k = slot;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (a[e] != 0.f) {
+                            lcol[k] = uint32_t(4 * j + e);
+                            lval[k] = a[e];
+                            ++k;
+                        }
+                } else {
+                    // a row with more non-zeros than the LDS list holds: appended directly (correct, slow)
+                    unsigned long long g = atomicAdd(tl.cursor, (unsigned long long)nh);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (a[e] != 0.f) {
+                            if (g < tl.cap) {
+                                tl.i[g] = uint32_t(i);
+                                tl.j[g] = uint32_t(4 * j + e);
+                                tl.a[g] = a[e];
+                            }
+                            ++g;
+                        }
+                    // (its slots of the LDS list stay unused: marked below)
+                    for (uint32_t k = slot; k < slot + uint32_t(nh) && k < uint32_t(ROWS_LDS_CAP); ++k) lcol[k] = 0xFFFFFFFFu;
+                }
+            }
+        }
+    }
+    s = wave_sum_f64(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    const uint32_t nl = lcount < uint32_t(ROWS_LDS_CAP) ? lcount : uint32_t(ROWS_LDS_CAP);
+    if (threadIdx.x == 0) {
+        own_sum[i] = (red[0] + red[1]) + (red[2] + red[3]);
+        const unsigned long long g = nl ? atomicAdd(tl.cursor, (unsigned long long)nl) : 0ull;   // the row's ONE reservation
+        lbase_lo = uint32_t(g);
+        lbase_hi = uint32_t(g >> 32);
+    }
+    __syncthreads();
+    const unsigned long long base = (unsigned long long)lbase_lo | ((unsigned long long)lbase_hi << 32);
+    bool diag_seen = false;
+    for (uint32_t k = threadIdx.x; k < nl; k += 256) {
+        const uint32_t c = lcol[k];
+        const unsigned long long g = base + k;
+        if (g < tl.cap) {   // (unused slots travel as zeros to column 0xFFFFFFFF: skipped by the consumers)
+            tl.i[g] = uint32_t(i);
+            tl.j[g] = c;
+            tl.a[g] = c == 0xFFFFFFFFu ? 0.f : lval[k];
+        }
+        diag_seen |= c == uint32_t(i);
+    }
+    // K_ii = K0_ii: zero when the row's own diagonal entry did not survive (base.py:553 warns)
+    if (lcount <= uint32_t(ROWS_LDS_CAP)) {
+        if (!__syncthreads_or(diag_seen ? 1 : 0) && threadIdx.x == 0) atomicOr(flags, GT_FLAG_ZERO_DIAGONAL);
+    } else if (threadIdx.x == 0) {
+        const float aii = affinity_t<float>(D[i * n + i], bwi, decay, xcut);
+        if (aii < thresh) atomicOr(flags, GT_FLAG_ZERO_DIAGONAL);
+    }
+}
+
+__global__ __launch_bounds__(256) void tri_count_kernel(const uint32_t* __restrict__ tj, const int64_t total,
+                                                        uint32_t* __restrict__ incount) {
+    const int64_t t = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (t < total && tj[t] != 0xFFFFFFFFu) atomicAdd(&incount[tj[t]], 1u);
+}
+
+// exclusive scan of n counts by ONE workgroup (n is a row count: at most a few million)
+__global__ __launch_bounds__(1024) void rows_scan_counts_kernel(const uint32_t* __restrict__ cnt, const int64_t n,
+                                                                unsigned long long* __restrict__ ptr) {
+    __shared__ unsigned long long part[1024];
+    const int64_t per = (n + 1023) / 1024;
+    const int64_t a = int64_t(threadIdx.x) * per, b = a + per < n ? a + per : n;
+    unsigned long long s = 0ull;
+    for (int64_t k = a; k < b; ++k) s += cnt[k];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long run = 0ull;
+        for (int t = 0; t < 1024; ++t) {
+            const unsigned long long v = part[t];
+            part[t] = run;
+            run += v;
+        }
+        ptr[n] = run;
+    }
+    __syncthreads();
+    unsigned long long run = part[threadIdx.x];
+    for (int64_t k = a; k < b; ++k) {
+        ptr[k] = run;
+        run += cnt[k];
+    }
+}
+
+__global__ __launch_bounds__(256) void tri_scatter_kernel(const uint32_t* __restrict__ ti, const uint32_t* __restrict__ tj,
+                                                          const float* __restrict__ ta, const int64_t total,
+                                                          const unsigned long long* __restrict__ inptr,
+                                                          uint32_t* __restrict__ cursor, uint32_t* __restrict__ in_col,
+                                                          float* __restrict__ in_val) {
+    const int64_t t = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (t >= total) return;
+    const uint32_t j = tj[t];
+    if (j == 0xFFFFFFFFu) return;
+    const unsigned long long k = inptr[j] + atomicAdd(&cursor[j], 1u);
+    in_col[k] = ti[t];
+    in_val[k] = ta[t];
+}
+
+template <bool DIVIDE>   // DIVIDE: P = K / row sum is written instead of K
+__global__ __launch_bounds__(256) void dense_rows_write_kernel(const float* __restrict__ D, const int64_t n,
+                                                               const double* __restrict__ bw, const double decay_d,
+                                                               const double thresh_d, const double xcut_d,
+                                                               const double* __restrict__ own_sum,
+                                                               const unsigned long long* __restrict__ inptr,
+                                                               const uint32_t* __restrict__ in_col, float* __restrict__ in_val,
+                                                               double* __restrict__ rowsum, float* __restrict__ out) {
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    __shared__ double red[4];
+    __shared__ float sf_s;
+    const int64_t i = blockIdx.x;
+    const float decay = float(decay_d), thresh = float(thresh_d), xcut = float(xcut_d);
+    const float bwi = float(bw[i]);
+    const unsigned long long p0 = inptr[i], p1 = inptr[i + 1];
+    // the entries that have a transposed partner: merged now, while the row's distances are still in place.  Row sum of K (what
+    // numpy sums is the float32 K): every entry contributes (K0_ij + 0) / 2 = own / 2 unless it has a partner - those contribute
+    // their merged, float32-rounded value instead.  Float64 sums of exactly the values the tile-pair kernel sums.
+    const float* drow = D + i * n;
+    double corr = 0.0;
+    for (unsigned long long k = p0 + threadIdx.x; k < p1; k += 256) {
+        const uint32_t j = in_col[k];
+        float a = affinity_t<float>(drow[j], bwi, decay, xcut);
+        if (a < thresh) a = 0.f;
+        const float o = merge_t<float>(a, in_val[k], GT_SYMM_ADD, 1.f);
+        in_val[k] = o;
+        corr += double(o) - double(merge_t<float>(a, 0.f, GT_SYMM_ADD, 1.f));
+    }
+    corr = wave_sum_f64(corr);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = corr;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double rs = own_sum[i] / 2.0 + ((red[0] + red[1]) + (red[2] + red[3]));
+        rowsum[i] = rs;
+        sf_s = float(rs == 0.0 ? 1.0 : rs);   // sklearn _handle_zeros_in_scale
+    }
+    __syncthreads();
+    const float sf = sf_s;
+    if (DIVIDE)
+        for (unsigned long long k = p0 + threadIdx.x; k < p1; k += 256) in_val[k] = in_val[k] / sf;
+    __syncthreads();   // (in place: every read of the row's distances above comes before the first write below)
+    const float4* rv = reinterpret_cast<const float4*>(drow);
+    float4* ov = reinterpret_cast<float4*>(out + i * n);
+    const int64_t nv = n / 4;
+    for (int64_t j0 = 0; j0 < nv; j0 += 256 * 4) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t j = j0 + u * 256 + threadIdx.x;
+            if (j < nv) {
+                const f4v t = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(rv + j));
+                v[u] = make_float4(t[0], t[1], t[2], t[3]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t j = j0 + u * 256 + threadIdx.x;
+            if (j < nv) {
+                float a[4];
+                a[0] = affinity_t<float>(v[u].x, bwi, decay, xcut);
+                a[1] = affinity_t<float>(v[u].y, bwi, decay, xcut);
+                a[2] = affinity_t<float>(v[u].z, bwi, decay, xcut);
+                a[3] = affinity_t<float>(v[u].w, bwi, decay, xcut);
+                f4v t;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (a[e] < thresh) a[e] = 0.f;
+                    float o = merge_t<float>(a[e], 0.f, GT_SYMM_ADD, 1.f);
+                    if (DIVIDE) o = o / sf;
+                    t[e] = o;
+                }
+                __builtin_nontemporal_store(t, reinterpret_cast<f4v*>(ov + j));
+            }
+        }
+    }
+    // the streamed row is complete before the merged entries go over it: both writes of an address come from this workgroup
+    // (one CU, one path to the address's L2 channel), the barrier's workgroup-scope release waits for the first to be
+    // acknowledged.  (NOT __threadfence(): a device-scope release writes the XCD's L2 back - once per row, 1.9 x the time)
+    __syncthreads();
+    float* orow = out + i * n;
+    for (unsigned long long k = p0 + threadIdx.x; k < p1; k += 256) orow[in_col[k]] = in_val[k];
+}
+
 // ---- row sums / anisotropy / normalisation ---------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void dense_rowsum_kernel(const T* __restrict__ K, const int64_t n, const int use_abs,
@@ -844,6 +1101,7 @@ __global__ __launch_bounds__(256) void dense_normalize4_kernel(const float4* __r
 
 struct DenseState {
     DevBuf bw, bw_user, rowsum, deg, work_in, work_k, work_p, flags, redo;
+    DevBuf own_sum, tri_i, tri_j, tri_a, tri_cursor, incount, inptr, in_col, in_val;   // row-streaming form
 };
 
 // Scaled distance beyond which exp(-x^decay) is exactly 0 in the reference: it falls below `thresh` (zeroed,
@@ -1017,7 +1275,8 @@ extern "C" int gt_dense_graph_build(gt_ctx* ctx, const void* X_or_D, int64_t n, 
     const size_t out_esz = out_f64 ? 8 : 4;
     const size_t in_esz = dtype == GT_F64 ? 8 : 4;
     auto cleanup = [&]() {
-        for (DevBuf* b : {&st.bw, &st.bw_user, &st.rowsum, &st.deg, &st.work_in, &st.work_k, &st.work_p, &st.flags, &st.redo})
+        for (DevBuf* b : {&st.bw, &st.bw_user, &st.rowsum, &st.deg, &st.work_in, &st.work_k, &st.work_p, &st.flags, &st.redo,
+                          &st.own_sum, &st.tri_i, &st.tri_j, &st.tri_a, &st.tri_cursor, &st.incount, &st.inptr, &st.in_col, &st.in_val})
             b->release();
     };
 #define DENSE_TRY(expr)            \
@@ -1117,7 +1376,97 @@ extern "C" int gt_dense_graph_build(gt_ctx* ctx, const void* X_or_D, int64_t n, 
     // ---- kernel tiles ----
     bool fused_rowsum = false, p_only = false;
     void* K_dev = nullptr;
-    if (inplace) {
+    // Row-streaming form (float32 distances, the '+' rule, no anisotropy, whole quads): the transposed half of the sparse
+    // thresholded kernel travels as a list, every pass over the matrix reads and writes whole rows.  P alone wanted: K is never
+    // stored (4 N^2 + 8 N^2 bytes); K wanted: the normalisation pass follows as before.
+    const bool rows_ok = precomputed && !pass && dtype == GT_F32 && !out_f64 && kernel_symm == GT_SYMM_ADD && anisotropy == 0.0 &&
+                         (n % 4) == 0 && n < (int64_t(1) << 32) &&
+                         (ctx->dense_rows > 0 || (ctx->dense_rows < 0 && n >= 16384));
+    bool rows_done = false, rows_wrote_p = false;
+    if (rows_ok) {
+        const bool direct_p = out_P && !out_K;   // the operator alone
+        void* target = nullptr;
+        if (direct_p) {
+            if (out_on_device) {
+                target = out_P;
+            } else {
+                DENSE_HIP(st.work_p.reserve(size_t(n) * n * out_esz));
+                target = st.work_p.p;
+            }
+        } else if (inplace) {
+            target = const_cast<void*>(in_dev);
+        } else if (out_K && out_on_device) {
+            target = out_K;
+        } else {
+            DENSE_HIP(st.work_k.reserve(size_t(n) * n * out_esz));
+            target = st.work_k.p;
+        }
+        std::unique_ptr<StageSpan> span(new StageSpan(ctx, "dense_rows_scan"));
+        const unsigned long long cap = ctx->dense_rows_cap > 0 ? (unsigned long long)ctx->dense_rows_cap
+            : (unsigned long long)std::min<double>(double(n) * double(n), std::max<double>(double(n) * 1024.0, double(1 << 24)));
+        DENSE_HIP(st.own_sum.reserve(size_t(n) * sizeof(double)));
+        DENSE_HIP(st.tri_i.reserve(size_t(cap) * sizeof(uint32_t)));
+        DENSE_HIP(st.tri_j.reserve(size_t(cap) * sizeof(uint32_t)));
+        DENSE_HIP(st.tri_a.reserve(size_t(cap) * sizeof(float)));
+        DENSE_HIP(st.tri_cursor.reserve(sizeof(unsigned long long)));
+        DENSE_HIP(hipMemsetAsync(st.tri_cursor.p, 0, sizeof(unsigned long long), ctx->stream));
+        DENSE_HIP(st.incount.reserve(size_t(n) * 2 * sizeof(uint32_t)));   // counts, then the scatter's cursors
+        DENSE_HIP(hipMemsetAsync(st.incount.p, 0, size_t(n) * 2 * sizeof(uint32_t), ctx->stream));
+        DENSE_HIP(st.inptr.reserve(size_t(n + 1) * sizeof(unsigned long long)));
+        DENSE_HIP(st.rowsum.reserve(size_t(n) * sizeof(double)));
+        TriList tl;
+        tl.i = st.tri_i.as<uint32_t>();
+        tl.j = st.tri_j.as<uint32_t>();
+        tl.a = st.tri_a.as<float>();
+        tl.cursor = st.tri_cursor.as<unsigned long long>();
+        tl.cap = cap;
+        const double xc = dense_xcut(decay, thresh, true);
+        hipLaunchKernelGGL(dense_rows_scan_kernel, dim3((unsigned)n), dim3(256), 0, ctx->stream, (const float*)in_dev, n,
+                           st.bw.as<double>(), decay, thresh, xc, st.own_sum.as<double>(), tl, st.flags.as<uint32_t>());
+        DENSE_HIP(hipGetLastError());
+        unsigned long long total = 0;
+        DENSE_HIP(hipMemcpyAsync(&total, st.tri_cursor.p, sizeof(total), hipMemcpyDeviceToHost, ctx->stream));
+        DENSE_HIP(hipStreamSynchronize(ctx->stream));
+        span.reset();
+        if (total <= cap) {
+            StageSpan span2(ctx, "dense_kernel");
+            DENSE_HIP(st.in_col.reserve(size_t(std::max<unsigned long long>(total, 1)) * sizeof(uint32_t)));
+            DENSE_HIP(st.in_val.reserve(size_t(std::max<unsigned long long>(total, 1)) * sizeof(float)));
+            uint32_t* incount = st.incount.as<uint32_t>();
+            if (total > 0)
+                hipLaunchKernelGGL(tri_count_kernel, dim3((unsigned)ceil_div64(int64_t(total), 256)), dim3(256), 0, ctx->stream,
+                                   tl.j, int64_t(total), incount);
+            hipLaunchKernelGGL(rows_scan_counts_kernel, dim3(1), dim3(1024), 0, ctx->stream, incount, n,
+                               st.inptr.as<unsigned long long>());
+            if (total > 0)
+                hipLaunchKernelGGL(tri_scatter_kernel, dim3((unsigned)ceil_div64(int64_t(total), 256)), dim3(256), 0, ctx->stream,
+                                   tl.i, tl.j, tl.a, int64_t(total), st.inptr.as<unsigned long long>(), incount + n,
+                                   st.in_col.as<uint32_t>(), st.in_val.as<float>());
+            if (direct_p)
+                hipLaunchKernelGGL(dense_rows_write_kernel<true>, dim3((unsigned)n), dim3(256), 0, ctx->stream, (const float*)in_dev, n,
+                                   st.bw.as<double>(), decay, thresh, xc, st.own_sum.as<double>(),
+                                   st.inptr.as<unsigned long long>(), st.in_col.as<uint32_t>(), st.in_val.as<float>(),
+                                   st.rowsum.as<double>(), (float*)target);
+            else
+                hipLaunchKernelGGL(dense_rows_write_kernel<false>, dim3((unsigned)n), dim3(256), 0, ctx->stream, (const float*)in_dev, n,
+                                   st.bw.as<double>(), decay, thresh, xc, st.own_sum.as<double>(),
+                                   st.inptr.as<unsigned long long>(), st.in_col.as<uint32_t>(), st.in_val.as<float>(),
+                                   st.rowsum.as<double>(), (float*)target);
+            DENSE_HIP(hipGetLastError());
+            rows_done = true;
+            rows_wrote_p = direct_p;
+            fused_rowsum = true;   // (the row sums are final)
+            K_dev = direct_p ? nullptr : target;
+        } else {
+            // more kept entries than the list was sized for (a kernel that is not sparse): the tile-pair form below; the matrix
+            // is untouched so far.  (the zero-diagonal flag may have been raised by rows the scan saw: recomputed there)
+            DENSE_HIP(hipMemsetAsync(st.flags.p, 0, sizeof(uint32_t), ctx->stream));
+        }
+        for (DevBuf* b : {&st.tri_i, &st.tri_j, &st.tri_a}) b->release();
+    }
+    if (rows_done) {
+        // (nothing left for the tile kernels)
+    } else if (inplace) {
         K_dev = const_cast<void*>(in_dev);
     } else if (out_K && out_on_device) {
         K_dev = out_K;
@@ -1125,7 +1474,7 @@ extern "C" int gt_dense_graph_build(gt_ctx* ctx, const void* X_or_D, int64_t n, 
         DENSE_HIP(st.work_k.reserve(size_t(n) * n * out_esz));
         K_dev = st.work_k.p;
     }
-    {
+    if (!rows_done) {
         StageSpan span(ctx, "dense_kernel");
         uint32_t* fl = st.flags.as<uint32_t>();
         const double* bw = st.bw.as<double>();
@@ -1178,7 +1527,7 @@ extern "C" int gt_dense_graph_build(gt_ctx* ctx, const void* X_or_D, int64_t n, 
     }
     if (out_f64)
         DENSE_TRY(finish_dense<double>(ctx, st, (double*)K_dev, (double*)P_dev, n, anisotropy));
-    else if (!p_only)   // (p_only: the second tile pass has written P already)
+    else if (!p_only && !rows_wrote_p)   // (p_only / the row-streaming form for P alone: P is written already)
         DENSE_TRY(finish_dense<float>(ctx, st, (float*)K_dev, (float*)P_dev, n, anisotropy, fused_rowsum));
     if (out_K && !out_on_device) DENSE_TRY(gt_copy_to_host(ctx, out_K, K_dev, size_t(n) * n * out_esz));
     if (out_P && !out_on_device) DENSE_TRY(gt_copy_to_host(ctx, out_P, P_dev, size_t(n) * n * out_esz));

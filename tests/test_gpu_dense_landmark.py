@@ -358,3 +358,71 @@ def test_operator_alone_in_place_never_stores_K():
         np.testing.assert_allclose(P2, P, rtol=3e-7, atol=0)
         np.testing.assert_allclose(deg2, deg, rtol=1e-12)
         np.testing.assert_allclose(P2.astype(np.float64).sum(axis=1), 1.0, rtol=1e-5)
+
+
+@pytest.mark.parametrize("case", ["sparse", "asymmetric", "heavy rows", "not sparse", "zero diagonal"])
+def test_row_streaming_form_equals_the_tile_pairs(case):
+    """round 4: float32 distances under the '+' rule (graphs.py:1583-1609, base.py:557-561, 645): the matrix is read and written
+    as whole rows, the transposed half of the thresholded kernel travels as a list (dense_rows_scan / dense_rows_write; default
+    from 16384 rows, forced here).  Against the tile-pair kernels: K bit-identical - also for a matrix that is NOT symmetric,
+    for rows with more non-zeros than the LDS list holds (appended directly) and for a kernel that is not sparse at all (the list
+    overflows: the tile-pair form takes over) -, degrees to the summation order, P = K / float32(sum).  In place, P alone: equal
+    to the P of the ordinary build; the matrix is consumed."""
+    import ctypes
+
+    import torch
+
+    from graphtools_amd import _hip
+    from scipy.spatial.distance import pdist, squareform
+
+    n, decay, knn = 2116, 15.0, 6
+    X = make_mix(n, 10, 8).astype(np.float64)
+    if case == "heavy rows":
+        knn = 1200      # every row keeps what lies within its 1200-th neighbour's distance: more than the LDS list holds
+    D = squareform(pdist(X)).astype(np.float32)
+    if case == "asymmetric":
+        D = (D * (1.0 + 0.05 * np.random.default_rng(2).random((n, n)))).astype(np.float32)
+        np.fill_diagonal(D, 0.0)
+    if case == "zero diagonal":
+        D[5, 5] = 1e3        # a "distance" of a point to itself beyond every radius: K_55 = 0 (base.py:553 warns)
+    if case == "not sparse":
+        decay, knn = 1.0, 200    # exp(-d / bw) with a wide bandwidth: nearly every entry survives 1e-4
+    res = {}
+    cap = {"dense_rows_cap": "100000"} if case == "not sparse" else {}      # (the list overflows: the tile pairs take over)
+    for tag, opts in (("rows", dict(dense_rows="1", **cap)), ("tiles", {"dense_rows": "0"})):
+        c = _hip.Context(0)
+        for k, v in opts.items():
+            c.set_option(k, v)
+        K, P, flags = c.dense_graph_build(D, "distance", knn, decay, 1e-4, None, 1.0, "+", None, 0.0, want_P=True)
+        deg = c.dense_fetch_vec(_hip.VEC_DEGREE, n)
+        st = (c.stage_launches("dense_rows_scan"), c.stage_launches("dense_kernel"))
+        c.close()
+        res[tag] = (K, P, deg, flags, st)
+    assert res["rows"][4][0] == 1 and res["tiles"][4][0] <= 0                # (the scan of the row-streaming form ran / did not)
+    if case == "not sparse":
+        assert (res["rows"][0] != 0).sum() > 100000 and res["rows"][4][1] == 1
+    assert np.array_equal(res["rows"][0], res["tiles"][0]), "K differs"
+    assert res["rows"][3] == res["tiles"][3], "flags differ"
+    assert bool(res["rows"][3] & _hip.FLAG_ZERO_DIAGONAL) == (case == "zero diagonal")
+    np.testing.assert_allclose(res["rows"][2], res["tiles"][2], rtol=1e-12)
+    np.testing.assert_allclose(res["rows"][1], res["tiles"][1], rtol=2e-7, atol=0)
+    if case == "heavy rows":
+        assert (res["rows"][0] != 0).sum(axis=1).min() > 1024
+    # in place, the operator alone (BASELINE config 4 as bench.py runs it)
+    Dd = torch.from_numpy(D).cuda()
+    c = _hip.Context(0)
+    c.set_option("dense_rows", "1")
+    for k, v in cap.items():
+        c.set_option(k, v)
+    fl = ctypes.c_uint32(0)
+    rc = c.lib.gt_dense_graph_build(c.h, ctypes.c_void_p(Dd.data_ptr()), n, 0, 0, 1, 1, knn, decay, 1e-4, None, 0, 1.0, _hip.SYMM["+"],
+                                    1.0, 0.0, 1, None, ctypes.c_void_p(Dd.data_ptr()), 1, ctypes.byref(fl))
+    c._check(rc, "gt_dense_graph_build")
+    c.sync()
+    P2 = Dd.cpu().numpy()
+    deg2 = c.dense_fetch_vec(_hip.VEC_DEGREE, n)
+    c.close()
+    assert np.array_equal(P2 == 0, res["tiles"][1] == 0)
+    np.testing.assert_allclose(P2, res["tiles"][1], rtol=3e-7, atol=0)
+    np.testing.assert_allclose(deg2, res["tiles"][2], rtol=1e-12)
+    assert fl.value == res["tiles"][3]
