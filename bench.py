@@ -390,8 +390,11 @@ def secondary_c4(_hip, torch, device, n=200000, d=100):
         # for the bandwidths (4 N^2), once for the row sums and the list of kept affinities (4 N^2), once more while P is written
         # over it (8 N^2).  Tile-pair form: bandwidths 4 N^2, K with fused row sums 8 N^2, normalisation 8 N^2.
         rows_form = st["dense_rows_scan"] > 0
-        nbytes = (16.0 if rows_form else 20.0) * n * n
-        note = ("16 N^2 bytes as run (row-streaming form): 4 N^2 bandwidth pass, 4 N^2 scan (row sums + the kept affinities as a "
+        listed = ctx.stage_launches("dense_rows_listed") > 0    # the bandwidth pass listed the kept affinities: no scan of its own
+        nbytes = ((12.0 if listed else 16.0) if rows_form else 20.0) * n * n
+        note = ("12 N^2 bytes as run (row-streaming form): 4 N^2 bandwidth pass, which also lists the rows' kept affinities, 8 N^2 write "
+                "pass (P over the distances; the transposed half arrives as the list)") if rows_form and listed else (
+                "16 N^2 bytes as run (row-streaming form): 4 N^2 bandwidth pass, 4 N^2 scan (row sums + the kept affinities as a "
                 "list), 8 N^2 write pass (P over the distances; the transposed half arrives as the list)") if rows_form else (
                 "20 N^2 bytes as run: 4 N^2 bandwidth pass (one read), 8 N^2 tile-pair kernel (row sums fused), 8 N^2 normalisation")
         return {"workload": "C4: mix N=%d d=%d seed=2, TraditionalGraph knn=15 decay=40 from a resident float32 distance matrix "

@@ -62,6 +62,17 @@ __device__ __forceinline__ T merge_t(T a, T b, int symm, T theta) {
     }
 }
 
+// (row-streaming form of the '+' rule, below: the kept affinities of all rows as one flat list)
+constexpr int ROWS_LDS_CAP = 1024;   // non-zeros of a row parked in LDS before the row's one reservation (beyond: direct appends)
+
+struct TriList {
+    uint32_t* i;
+    uint32_t* j;
+    float* a;
+    unsigned long long* cursor;   // entries appended so far (may run past cap: the host checks)
+    unsigned long long cap;
+};
+
 // ---- bandwidth from a precomputed distance matrix: (knn+1)-th smallest of every row --------------
 template <typename T, int KL>
 __global__ __launch_bounds__(256) void dense_bandwidth_kernel(const T* __restrict__ D, const int64_t n, const int kth,
@@ -270,19 +281,40 @@ __global__ __launch_bounds__(256) void dense_bandwidth_2pass_kernel(const T* __r
 // The selections run on the values' own bit patterns (32 search steps for float32) over a few values per thread - the
 // first version searched 8192 LDS entries with 64-bit patterns and two barriers per step: 2.7 TB/s instead of 6.
 // Rows with mass ties at the bound (list overflow) are flagged for the generic kernel.
-template <typename T>
-__global__ __launch_bounds__(256) void dense_bandwidth_1pass_kernel(const T* __restrict__ D, const int64_t n, const int kth,
+#ifndef GT_DENSE_EMIT_WAVES
+#define GT_DENSE_EMIT_WAVES 6   // waves per SIMD the listing variant of the one-pass bandwidth kernel is cut for (80 VGPRs; 128 uncut)
+#endif
+struct EmitArgs {
+    float rfac, decay, thresh, xcut;
+    double* own_sum;
+    TriList tl;
+    uint32_t* flags;
+    uint32_t* scan_rows;     // rows that need dense_rows_scan_kernel (their list overflowed here)
+    uint32_t* scan_count;
+};
+
+template <typename T, bool EMIT>
+__global__ __launch_bounds__(256, EMIT ? GT_DENSE_EMIT_WAVES : 1) void dense_bandwidth_1pass_kernel(const T* __restrict__ D, const int64_t n, const int kth,
                                                                     const double scale, double* __restrict__ bw,
-                                                                    uint32_t* __restrict__ redo) {
+                                                                    uint32_t* __restrict__ redo, const EmitArgs em) {
+    // EMIT (row-streaming form of the '+' rule, float32): the list keeps, WITH their columns, every value within rfac x the
+    // running bound - rfac = bandwidth scale x the scaled distance beyond which an affinity is zero (+ rounding room) - so that
+    // when the row's bandwidth is known the row's kept affinities are all in the list: they are evaluated, summed (own half of
+    // the row sum) and appended to the flat list the transposition reads - the matrix is not read a second time for them.
+    // A row whose list overflows is redone by the generic bandwidth kernel and scanned on its own (em.scan_rows).
     constexpr int VW = 16 / int(sizeof(T));
     constexpr int PT = 4 * VW;                 // values per thread and step
     constexpr int CHUNK = 256 * PT;            // values per step of the workgroup
-    constexpr int LCAP = 1024;                 // candidate list
+    constexpr int LCAP = EMIT ? 2048 : 1024;   // candidate list
     constexpr int BITS = int(sizeof(T)) * 8;
     typedef typename std::conditional<sizeof(T) == 4, uint32_t, unsigned long long>::type key_t;
     __shared__ T lst[LCAP];
+    __shared__ uint32_t lcolv[EMIT ? LCAP : 1];
     __shared__ int red[2][4];
     __shared__ int cnt;
+    const T rfac = EMIT ? T(em.rfac) : T(1);
+#define GT_BW_COL(ST_, U_) (vec ? uint32_t(((ST_) * (256 * 4) + ((U_) / VW) * 256 + tid) * VW + (U_) % VW) \
+                                : uint32_t((ST_) * CHUNK + int64_t(U_) * 256 + tid))
     const int64_t i = blockIdx.x;
     const int tid = threadIdx.x;
     const T* row = D + i * n;
@@ -312,6 +344,7 @@ __global__ __launch_bounds__(256) void dense_bandwidth_1pass_kernel(const T* __r
     };
     const key_t kInvalid = ~key_t(0);
     if (tid == 0) cnt = 0;
+    bool nan_seen = false;   // EMIT: a NaN distance is an affinity of 1 in the reference (graphs.py:1593) - such a row is scanned on its own
     T ub = T(INFINITY);
     T mn = T(INFINITY);
     T x0[PT];   // the values of step 0, held until the bound is known
@@ -344,6 +377,10 @@ __global__ __launch_bounds__(256) void dense_bandwidth_1pass_kernel(const T* __r
                 x[u] = j < n ? row[j] : T(INFINITY);
             }
         }
+        if (EMIT) {
+#pragma unroll
+            for (int u = 0; u < PT; ++u) nan_seen |= x[u] != x[u];
+        }
         if (st < 2) {
 #pragma unroll
             for (int u = 0; u < PT; ++u) mn = x[u] < mn ? x[u] : mn;
@@ -356,19 +393,25 @@ __global__ __launch_bounds__(256) void dense_bandwidth_1pass_kernel(const T* __r
             const key_t kmn = (mn < T(INFINITY)) ? key_of(mn) : kInvalid;
             __syncthreads();
             const key_t kb = select(&kmn, 1);
-#pragma unroll
-            for (int u = 0; u < PT; ++u) {
-                if (x0[u] < T(INFINITY) && key_of(x0[u]) <= kb) {
-                    const int pos = atomicAdd(&cnt, 1);
-                    if (pos < LCAP) lst[pos] = x0[u];
-                }
-                if (st == 1 && x[u] < T(INFINITY) && key_of(x[u]) <= kb) {
-                    const int pos = atomicAdd(&cnt, 1);
-                    if (pos < LCAP) lst[pos] = x[u];
-                }
-            }
             if constexpr (sizeof(T) == 4) ub = __uint_as_float(uint32_t(kb));
             else ub = __longlong_as_double((long long)kb);
+#pragma unroll
+            for (int u = 0; u < PT; ++u) {
+                if (x0[u] < T(INFINITY) && (EMIT ? x0[u] <= ub * rfac : key_of(x0[u]) <= kb)) {
+                    const int pos = atomicAdd(&cnt, 1);
+                    if (pos < LCAP) {
+                        lst[pos] = x0[u];
+                        if (EMIT) lcolv[pos] = GT_BW_COL(int64_t(0), u);
+                    }
+                }
+                if (st == 1 && x[u] < T(INFINITY) && (EMIT ? x[u] <= ub * rfac : key_of(x[u]) <= kb)) {
+                    const int pos = atomicAdd(&cnt, 1);
+                    if (pos < LCAP) {
+                        lst[pos] = x[u];
+                        if (EMIT) lcolv[pos] = GT_BW_COL(int64_t(1), u);
+                    }
+                }
+            }
             __syncthreads();
             if (cnt > LCAP) {
                 bad = true;
@@ -376,11 +419,17 @@ __global__ __launch_bounds__(256) void dense_bandwidth_1pass_kernel(const T* __r
             }
             continue;
         }
+        {
+            const T rb = EMIT ? ub * rfac : ub;
 #pragma unroll
-        for (int u = 0; u < PT; ++u) {
-            if (x[u] <= ub) {
-                const int pos = atomicAdd(&cnt, 1);
-                if (pos < LCAP) lst[pos] = x[u];
+            for (int u = 0; u < PT; ++u) {
+                if (x[u] <= rb) {
+                    const int pos = atomicAdd(&cnt, 1);
+                    if (pos < LCAP) {
+                        lst[pos] = x[u];
+                        if (EMIT) lcolv[pos] = GT_BW_COL(st, u);
+                    }
+                }
             }
         }
         if (!((st & 7) == 7)) continue;
@@ -391,22 +440,44 @@ __global__ __launch_bounds__(256) void dense_bandwidth_1pass_kernel(const T* __r
             break;
         }
         if (m > LCAP / 2) {
-            key_t k4[LCAP / 256];
+            key_t kb;
+            {
+                key_t k4[LCAP / 256];
 #pragma unroll
-            for (int q = 0; q < LCAP / 256; ++q) k4[q] = (q * 256 + tid < m) ? key_of(lst[q * 256 + tid]) : kInvalid;
-            const key_t kb = select(k4, LCAP / 256);
+                for (int q = 0; q < LCAP / 256; ++q) k4[q] = (q * 256 + tid < m) ? key_of(lst[q * 256 + tid]) : kInvalid;
+                kb = select(k4, LCAP / 256);
+            }
+            if constexpr (sizeof(T) == 4) ub = __uint_as_float(uint32_t(kb));
+            else ub = __longlong_as_double((long long)kb);
+            // the entries are read again (not held across the selection: registers), then the list is rebuilt
+            T xv[LCAP / 256];
+            uint32_t cv[LCAP / 256];
+#pragma unroll
+            for (int q = 0; q < LCAP / 256; ++q) {
+                const bool in = q * 256 + tid < m;
+                xv[q] = in ? lst[q * 256 + tid] : T(INFINITY);
+                cv[q] = (EMIT && in) ? lcolv[q * 256 + tid] : 0xFFFFFFFFu;
+            }
             __syncthreads();
             if (tid == 0) cnt = 0;
             __syncthreads();
 #pragma unroll
-            for (int q = 0; q < LCAP / 256; ++q)
-                if (k4[q] <= kb) {
+            for (int q = 0; q < LCAP / 256; ++q) {
+                const bool in = q * 256 + tid < m;
+                // (the plain list holds keys' values: anything <= 0 is stored as the key says; the emitting list keeps the
+                //  value itself - its affinity is evaluated from it)
+                if (in && (EMIT ? xv[q] <= ub * rfac : key_of(xv[q]) <= kb)) {
                     const int pos = atomicAdd(&cnt, 1);
-                    if constexpr (sizeof(T) == 4) lst[pos] = __uint_as_float(uint32_t(k4[q]));
-                    else lst[pos] = __longlong_as_double((long long)k4[q]);
+                    if (EMIT) {
+                        lst[pos] = xv[q];
+                        lcolv[pos] = cv[q];
+                    } else if constexpr (sizeof(T) == 4) {
+                        lst[pos] = __uint_as_float(uint32_t(key_of(xv[q])));
+                    } else {
+                        lst[pos] = __longlong_as_double((long long)key_of(xv[q]));
+                    }
                 }
-            if constexpr (sizeof(T) == 4) ub = __uint_as_float(uint32_t(kb));
-            else ub = __longlong_as_double((long long)kb);
+            }
             __syncthreads();
             if (cnt > LCAP / 2) {   // ties at the kth value fill the list: the generic kernel's case
                 bad = true;
@@ -416,10 +487,14 @@ __global__ __launch_bounds__(256) void dense_bandwidth_1pass_kernel(const T* __r
     }
     __syncthreads();
     if (!bad && cnt > LCAP) bad = true;
+    if (EMIT) {
+        if (__syncthreads_or(nan_seen ? 1 : 0)) bad = true;
+    }
     if (bad) {
         if (tid == 0) {
             bw[i] = -1.0;
             atomicAdd(redo, 1u);
+            if (EMIT) em.scan_rows[atomicAdd(em.scan_count, 1u)] = uint32_t(i);
         }
         return;
     }
@@ -428,12 +503,58 @@ __global__ __launch_bounds__(256) void dense_bandwidth_1pass_kernel(const T* __r
 #pragma unroll
     for (int q = 0; q < LCAP / 256; ++q) k4[q] = (q * 256 + tid < m) ? key_of(lst[q * 256 + tid]) : kInvalid;
     const key_t kb = select(k4, LCAP / 256);
-    if (tid == 0) {
-        double r;
-        if constexpr (sizeof(T) == 4) r = double(__uint_as_float(uint32_t(kb)));
-        else r = __longlong_as_double((long long)kb);
-        bw[i] = r * scale;
+    double r;
+    if constexpr (sizeof(T) == 4) r = double(__uint_as_float(uint32_t(kb)));
+    else r = __longlong_as_double((long long)kb);
+    if (tid == 0) bw[i] = r * scale;
+    if constexpr (EMIT && sizeof(T) == 4) {
+        // the row's kept affinities, from the list (dense_rows_scan_kernel's arithmetic and outputs)
+        __shared__ double reds[4];
+        __shared__ uint32_t nzc, base_lo, base_hi;
+        const float bwi = float(r * scale);
+        float av[LCAP / 256];
+        double sown = 0.0;
+        uint32_t nh = 0;
+        bool diag_seen = false;
+        if (tid == 0) nzc = 0u;
+#pragma unroll
+        for (int q = 0; q < LCAP / 256; ++q) {
+            av[q] = 0.f;
+            if (q * 256 + tid < m) {
+                float a = affinity_t<float>(lst[q * 256 + tid], bwi, em.decay, em.xcut);
+                if (a < em.thresh) a = 0.f;
+                av[q] = a;
+                sown += double(a);
+                nh += a != 0.f ? 1u : 0u;
+                diag_seen |= a != 0.f && lcolv[q * 256 + tid] == uint32_t(i);
+            }
+        }
+        sown = wave_sum_f64(sown);
+        if ((tid & 63) == 0) reds[tid >> 6] = sown;
+        __syncthreads();
+        const uint32_t slot = nh ? atomicAdd(&nzc, nh) : 0u;
+        __syncthreads();
+        if (tid == 0) {
+            em.own_sum[i] = (reds[0] + reds[1]) + (reds[2] + reds[3]);
+            const unsigned long long g = nzc ? atomicAdd(em.tl.cursor, (unsigned long long)nzc) : 0ull;   // the row's ONE reservation
+            base_lo = uint32_t(g);
+            base_hi = uint32_t(g >> 32);
+        }
+        __syncthreads();
+        unsigned long long g = ((unsigned long long)base_lo | ((unsigned long long)base_hi << 32)) + slot;
+#pragma unroll
+        for (int q = 0; q < LCAP / 256; ++q)
+            if (av[q] != 0.f) {
+                if (g < em.tl.cap) {
+                    em.tl.i[g] = uint32_t(i);
+                    em.tl.j[g] = lcolv[q * 256 + tid];
+                    em.tl.a[g] = av[q];
+                }
+                ++g;
+            }
+        if (!__syncthreads_or(diag_seen ? 1 : 0) && tid == 0) atomicOr(em.flags, GT_FLAG_ZERO_DIAGONAL);
     }
+#undef GT_BW_COL
 }
 
 // generic (any kth): bitwise search straight over the row (64 passes; the row stays L2 resident)
@@ -746,26 +867,17 @@ __global__ __launch_bounds__(256) void dense_kernel_tiles(const TD* __restrict__
 // Every element sees the operations of the tile-pair kernel in the same order ((a + b) / 2, then / float(row sum)): same bits
 // up to the summation order of the float64 row sums.  Bytes: 4 N^2 (S1) + 8 N^2 (S3) instead of 8 N^2 + 8 N^2 (normalisation
 // pass), all of it as whole rows.
-constexpr int ROWS_LDS_CAP = 1024;   // non-zeros of a row parked in LDS before the row's one reservation (beyond: direct appends)
-
-struct TriList {
-    uint32_t* i;
-    uint32_t* j;
-    float* a;
-    unsigned long long* cursor;   // entries appended so far (may run past cap: the host checks)
-    unsigned long long cap;
-};
 
 __global__ __launch_bounds__(256) void dense_rows_scan_kernel(const float* __restrict__ D, const int64_t n,
                                                               const double* __restrict__ bw, const double decay_d,
                                                               const double thresh_d, const double xcut_d,
                                                               double* __restrict__ own_sum, const TriList tl,
-                                                              uint32_t* __restrict__ flags) {
+                                                              uint32_t* __restrict__ flags, const uint32_t* __restrict__ row_list) {
     __shared__ uint32_t lcol[ROWS_LDS_CAP];
     __shared__ float lval[ROWS_LDS_CAP];
     __shared__ uint32_t lcount, lbase_lo, lbase_hi;
     __shared__ double red[4];
-    const int64_t i = blockIdx.x;
+    const int64_t i = row_list ? int64_t(row_list[blockIdx.x]) : int64_t(blockIdx.x);
     const float decay = float(decay_d), thresh = float(thresh_d), xcut = float(xcut_d);
     const float bwi = float(bw[i]);
     if (threadIdx.x == 0) lcount = 0u;
@@ -1101,7 +1213,7 @@ __global__ __launch_bounds__(256) void dense_normalize4_kernel(const float4* __r
 
 struct DenseState {
     DevBuf bw, bw_user, rowsum, deg, work_in, work_k, work_p, flags, redo;
-    DevBuf own_sum, tri_i, tri_j, tri_a, tri_cursor, incount, inptr, in_col, in_val;   // row-streaming form
+    DevBuf own_sum, tri_i, tri_j, tri_a, tri_cursor, incount, inptr, in_col, in_val, scan_rows;   // row-streaming form
 };
 
 // Scaled distance beyond which exp(-x^decay) is exactly 0 in the reference: it falls below `thresh` (zeroed,
@@ -1276,7 +1388,8 @@ extern "C" int gt_dense_graph_build(gt_ctx* ctx, const void* X_or_D, int64_t n, 
     const size_t in_esz = dtype == GT_F64 ? 8 : 4;
     auto cleanup = [&]() {
         for (DevBuf* b : {&st.bw, &st.bw_user, &st.rowsum, &st.deg, &st.work_in, &st.work_k, &st.work_p, &st.flags, &st.redo,
-                          &st.own_sum, &st.tri_i, &st.tri_j, &st.tri_a, &st.tri_cursor, &st.incount, &st.inptr, &st.in_col, &st.in_val})
+                          &st.own_sum, &st.tri_i, &st.tri_j, &st.tri_a, &st.tri_cursor, &st.incount, &st.inptr, &st.in_col, &st.in_val,
+                          &st.scan_rows})
             b->release();
     };
 #define DENSE_TRY(expr)            \
@@ -1311,6 +1424,37 @@ extern "C" int gt_dense_graph_build(gt_ctx* ctx, const void* X_or_D, int64_t n, 
         DENSE_TRY(gt_copy_from_host(ctx, st.work_in.p, X_or_D, size_t(n) * n * in_esz));
         in_dev = st.work_in.p;
     }
+    // Row-streaming form (float32 distances, the '+' rule, no anisotropy, whole quads): the transposed half of the sparse
+    // thresholded kernel travels as a list, every pass over the matrix reads and writes whole rows.  P alone wanted: K is never
+    // stored; K wanted: the normalisation pass follows as before.
+    const bool rows_ok = precomputed && !pass && dtype == GT_F32 && !out_f64 && kernel_symm == GT_SYMM_ADD && anisotropy == 0.0 &&
+                         (n % 4) == 0 && n < (int64_t(1) << 32) &&
+                         (ctx->dense_rows > 0 || (ctx->dense_rows < 0 && n >= 16384));
+    bool rows_listed = false;   // the bandwidth pass has listed the kept affinities already
+    TriList tl;
+    tl.i = tl.j = nullptr;
+    tl.a = nullptr;
+    tl.cursor = nullptr;
+    tl.cap = 0;
+    auto rows_alloc = [&]() -> int {
+        if (tl.i) return GT_OK;
+        const unsigned long long cap = ctx->dense_rows_cap > 0 ? (unsigned long long)ctx->dense_rows_cap
+            : (unsigned long long)std::min<double>(double(n) * double(n), std::max<double>(double(n) * 1024.0, double(1 << 24)));
+        GT_HIP(ctx, st.own_sum.reserve(size_t(n) * sizeof(double)));
+        GT_HIP(ctx, st.tri_i.reserve(size_t(cap) * sizeof(uint32_t)));
+        GT_HIP(ctx, st.tri_j.reserve(size_t(cap) * sizeof(uint32_t)));
+        GT_HIP(ctx, st.tri_a.reserve(size_t(cap) * sizeof(float)));
+        GT_HIP(ctx, st.tri_cursor.reserve(sizeof(unsigned long long)));
+        GT_HIP(ctx, hipMemsetAsync(st.tri_cursor.p, 0, sizeof(unsigned long long), ctx->stream));
+        GT_HIP(ctx, st.scan_rows.reserve(size_t(n + 1) * sizeof(uint32_t)));
+        GT_HIP(ctx, hipMemsetAsync(st.scan_rows.as<uint32_t>() + n, 0, sizeof(uint32_t), ctx->stream));
+        tl.i = st.tri_i.as<uint32_t>();
+        tl.j = st.tri_j.as<uint32_t>();
+        tl.a = st.tri_a.as<float>();
+        tl.cursor = st.tri_cursor.as<unsigned long long>();
+        tl.cap = cap;
+        return GT_OK;
+    };
     // ---- bandwidth ----
     if (!pass) {
         StageSpan span(ctx, "dense_bandwidth");
@@ -1350,12 +1494,29 @@ extern "C" int gt_dense_graph_build(gt_ctx* ctx, const void* X_or_D, int64_t n, 
                     else
                         hipLaunchKernelGGL(dense_bandwidth_2pass_kernel<double>, dim3((unsigned)n), dim3(256), 0, ctx->stream,
                                            (const double*)in_dev, n, kth, bandwidth_scale, st.bw.as<double>(), st.redo.as<uint32_t>());
+                } else if (dtype == GT_F32 && rows_ok && ctx->dense_rows_fused != 0) {
+                    // the row-streaming form follows: this pass also lists the rows' kept affinities (no second read for them)
+                    DENSE_TRY(rows_alloc());
+                    EmitArgs em;
+                    const double xc = dense_xcut(decay, thresh, true);
+                    em.rfac = float(bandwidth_scale * xc * 1.0001);
+                    em.decay = float(decay);
+                    em.thresh = float(thresh);
+                    em.xcut = float(xc);
+                    em.own_sum = st.own_sum.as<double>();
+                    em.tl = tl;
+                    em.flags = st.flags.as<uint32_t>();
+                    em.scan_rows = st.scan_rows.as<uint32_t>();
+                    em.scan_count = st.scan_rows.as<uint32_t>() + n;
+                    hipLaunchKernelGGL((dense_bandwidth_1pass_kernel<float, true>), dim3((unsigned)n), dim3(256), 0, ctx->stream,
+                                       (const float*)in_dev, n, kth, bandwidth_scale, st.bw.as<double>(), st.redo.as<uint32_t>(), em);
+                    rows_listed = true;
                 } else if (dtype == GT_F32) {
-                    hipLaunchKernelGGL(dense_bandwidth_1pass_kernel<float>, dim3((unsigned)n), dim3(256), 0, ctx->stream,
-                                       (const float*)in_dev, n, kth, bandwidth_scale, st.bw.as<double>(), st.redo.as<uint32_t>());
+                    hipLaunchKernelGGL((dense_bandwidth_1pass_kernel<float, false>), dim3((unsigned)n), dim3(256), 0, ctx->stream,
+                                       (const float*)in_dev, n, kth, bandwidth_scale, st.bw.as<double>(), st.redo.as<uint32_t>(), EmitArgs());
                 } else {
-                    hipLaunchKernelGGL(dense_bandwidth_1pass_kernel<double>, dim3((unsigned)n), dim3(256), 0, ctx->stream,
-                                       (const double*)in_dev, n, kth, bandwidth_scale, st.bw.as<double>(), st.redo.as<uint32_t>());
+                    hipLaunchKernelGGL((dense_bandwidth_1pass_kernel<double, false>), dim3((unsigned)n), dim3(256), 0, ctx->stream,
+                                       (const double*)in_dev, n, kth, bandwidth_scale, st.bw.as<double>(), st.redo.as<uint32_t>(), EmitArgs());
                 }
                 DENSE_HIP(hipGetLastError());
                 DENSE_HIP(hipMemcpyAsync(&n_redo, st.redo.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -1376,12 +1537,6 @@ extern "C" int gt_dense_graph_build(gt_ctx* ctx, const void* X_or_D, int64_t n, 
     // ---- kernel tiles ----
     bool fused_rowsum = false, p_only = false;
     void* K_dev = nullptr;
-    // Row-streaming form (float32 distances, the '+' rule, no anisotropy, whole quads): the transposed half of the sparse
-    // thresholded kernel travels as a list, every pass over the matrix reads and writes whole rows.  P alone wanted: K is never
-    // stored (4 N^2 + 8 N^2 bytes); K wanted: the normalisation pass follows as before.
-    const bool rows_ok = precomputed && !pass && dtype == GT_F32 && !out_f64 && kernel_symm == GT_SYMM_ADD && anisotropy == 0.0 &&
-                         (n % 4) == 0 && n < (int64_t(1) << 32) &&
-                         (ctx->dense_rows > 0 || (ctx->dense_rows < 0 && n >= 16384));
     bool rows_done = false, rows_wrote_p = false;
     if (rows_ok) {
         const bool direct_p = out_P && !out_K;   // the operator alone
@@ -1402,27 +1557,28 @@ extern "C" int gt_dense_graph_build(gt_ctx* ctx, const void* X_or_D, int64_t n, 
             target = st.work_k.p;
         }
         std::unique_ptr<StageSpan> span(new StageSpan(ctx, "dense_rows_scan"));
-        const unsigned long long cap = ctx->dense_rows_cap > 0 ? (unsigned long long)ctx->dense_rows_cap
-            : (unsigned long long)std::min<double>(double(n) * double(n), std::max<double>(double(n) * 1024.0, double(1 << 24)));
-        DENSE_HIP(st.own_sum.reserve(size_t(n) * sizeof(double)));
-        DENSE_HIP(st.tri_i.reserve(size_t(cap) * sizeof(uint32_t)));
-        DENSE_HIP(st.tri_j.reserve(size_t(cap) * sizeof(uint32_t)));
-        DENSE_HIP(st.tri_a.reserve(size_t(cap) * sizeof(float)));
-        DENSE_HIP(st.tri_cursor.reserve(sizeof(unsigned long long)));
-        DENSE_HIP(hipMemsetAsync(st.tri_cursor.p, 0, sizeof(unsigned long long), ctx->stream));
+        if (rows_listed) StageSpan mark(ctx, "dense_rows_listed");   // (the bandwidth pass listed the kept affinities: no pass over the matrix here)
+        DENSE_TRY(rows_alloc());
+        const unsigned long long cap = tl.cap;
         DENSE_HIP(st.incount.reserve(size_t(n) * 2 * sizeof(uint32_t)));   // counts, then the scatter's cursors
         DENSE_HIP(hipMemsetAsync(st.incount.p, 0, size_t(n) * 2 * sizeof(uint32_t), ctx->stream));
         DENSE_HIP(st.inptr.reserve(size_t(n + 1) * sizeof(unsigned long long)));
         DENSE_HIP(st.rowsum.reserve(size_t(n) * sizeof(double)));
-        TriList tl;
-        tl.i = st.tri_i.as<uint32_t>();
-        tl.j = st.tri_j.as<uint32_t>();
-        tl.a = st.tri_a.as<float>();
-        tl.cursor = st.tri_cursor.as<unsigned long long>();
-        tl.cap = cap;
         const double xc = dense_xcut(decay, thresh, true);
-        hipLaunchKernelGGL(dense_rows_scan_kernel, dim3((unsigned)n), dim3(256), 0, ctx->stream, (const float*)in_dev, n,
-                           st.bw.as<double>(), decay, thresh, xc, st.own_sum.as<double>(), tl, st.flags.as<uint32_t>());
+        if (!rows_listed) {
+            hipLaunchKernelGGL(dense_rows_scan_kernel, dim3((unsigned)n), dim3(256), 0, ctx->stream, (const float*)in_dev, n,
+                               st.bw.as<double>(), decay, thresh, xc, st.own_sum.as<double>(), tl, st.flags.as<uint32_t>(),
+                               (const uint32_t*)nullptr);
+        } else {
+            // (listed by the bandwidth pass; the rows it gave up on - bandwidths from the generic kernel by now - are scanned here)
+            uint32_t n_scan = 0;
+            DENSE_HIP(hipMemcpyAsync(&n_scan, st.scan_rows.as<uint32_t>() + n, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+            DENSE_HIP(hipStreamSynchronize(ctx->stream));
+            if (n_scan > 0)
+                hipLaunchKernelGGL(dense_rows_scan_kernel, dim3(n_scan), dim3(256), 0, ctx->stream, (const float*)in_dev, n,
+                                   st.bw.as<double>(), decay, thresh, xc, st.own_sum.as<double>(), tl, st.flags.as<uint32_t>(),
+                                   st.scan_rows.as<uint32_t>());
+        }
         DENSE_HIP(hipGetLastError());
         unsigned long long total = 0;
         DENSE_HIP(hipMemcpyAsync(&total, st.tri_cursor.p, sizeof(total), hipMemcpyDeviceToHost, ctx->stream));

@@ -389,16 +389,22 @@ def test_row_streaming_form_equals_the_tile_pairs(case):
         decay, knn = 1.0, 200    # exp(-d / bw) with a wide bandwidth: nearly every entry survives 1e-4
     res = {}
     cap = {"dense_rows_cap": "100000"} if case == "not sparse" else {}      # (the list overflows: the tile pairs take over)
-    for tag, opts in (("rows", dict(dense_rows="1", **cap)), ("tiles", {"dense_rows": "0"})):
+    for tag, opts in (("rows", dict(dense_rows="1", **cap)), ("rows, scan of its own", dict(dense_rows="1", dense_rows_fused="0", **cap)),
+                      ("tiles", {"dense_rows": "0"})):
         c = _hip.Context(0)
         for k, v in opts.items():
             c.set_option(k, v)
         K, P, flags = c.dense_graph_build(D, "distance", knn, decay, 1e-4, None, 1.0, "+", None, 0.0, want_P=True)
         deg = c.dense_fetch_vec(_hip.VEC_DEGREE, n)
-        st = (c.stage_launches("dense_rows_scan"), c.stage_launches("dense_kernel"))
+        st = (c.stage_launches("dense_rows_scan"), c.stage_launches("dense_kernel"), c.stage_launches("dense_rows_listed"))
         c.close()
         res[tag] = (K, P, deg, flags, st)
-    assert res["rows"][4][0] == 1 and res["tiles"][4][0] <= 0                # (the scan of the row-streaming form ran / did not)
+    assert res["rows"][4][0] == 1 and res["tiles"][4][0] <= 0                # (the row-streaming form ran / did not)
+    # (its list came out of the one-pass bandwidth kernel - which serves knn + 1 <= 256 - / a scan of its own)
+    assert (res["rows"][4][2] == 1) == (knn + 1 <= 256) and res["rows, scan of its own"][4][2] <= 0
+    assert np.array_equal(res["rows, scan of its own"][0], res["rows"][0]) and np.array_equal(res["rows, scan of its own"][1], res["rows"][1])
+    assert res["rows, scan of its own"][3] == res["rows"][3]
+    np.testing.assert_allclose(res["rows, scan of its own"][2], res["rows"][2], rtol=1e-12)
     if case == "not sparse":
         assert (res["rows"][0] != 0).sum() > 100000 and res["rows"][4][1] == 1
     assert np.array_equal(res["rows"][0], res["tiles"][0]), "K differs"
