@@ -43,7 +43,8 @@ int gt_ctx_create(int device, gt_ctx** out) {
     }
     gt_ctx* ctx = new gt_ctx();
     ctx->device = device;
-    e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    ctx->stream = gt_handle_take_stream(device, false);
+    e = ctx->stream ? hipSuccess : hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         g_create_error = std::string("hipStreamCreate: ") + hipGetErrorString(e);
         delete ctx;
@@ -76,12 +77,13 @@ void gt_ctx_destroy(gt_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    gt_pool_quiesced_begin();   // (one device synchronisation for the ~100 buffers let go below)
     gt_free_knn_work(ctx);
     gt_free_graph_state(ctx);
     gt_free_landmark_state(ctx);
     gt_free_pca_state(ctx);
     ctx->reset_stages();
-    for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
+    gt_handle_park_events(ctx->device, ctx->event_pool);
     ctx->X_own.release();
     ctx->Yp.release();
     ctx->Yc.release();
@@ -98,8 +100,12 @@ void gt_ctx_destroy(gt_ctx* ctx) {
     ctx->X_norm.release();
     for (DevBuf* b : {&ctx->land_Y, &ctx->land_h, &ctx->order_cell, &ctx->order_rows, &ctx->order_tmp, &ctx->vperm, &ctx->vcell, &ctx->land_X, &ctx->land_Yp, &ctx->land_xn}) b->release();
     if (ctx->side_event) (void)hipEventDestroy(ctx->side_event);
-    if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
-    (void)hipStreamDestroy(ctx->stream);
+    if (ctx->side_stream) {
+        (void)hipStreamSynchronize(ctx->side_stream);
+        gt_handle_park_stream(ctx->device, true, ctx->side_stream);
+    }
+    gt_handle_park_stream(ctx->device, false, ctx->stream);
+    gt_pool_quiesced_end();
     delete ctx;
 }
 

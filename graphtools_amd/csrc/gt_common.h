@@ -45,11 +45,19 @@
 
 // Device memory of the library goes through a small process-wide cache (gt_devpool.cpp): a graph build holds ~15 GB
 // of workspace at N = 1e6, and handing that back to the driver with hipFree only to hipMalloc it again for the next
-// graph of the process costs hundreds of milliseconds.  Blocks of at least 1 MiB are parked per device when a
+// graph of the process costs hundreds of milliseconds.  Blocks of every size are parked per device when a
 // context lets go of them (up to GT_POOL_MAX_GB, default 64) and reused for requests they fit within a factor of two;
 // gt_release_cached_memory() / an allocation failure empties the cache.
 hipError_t gt_pool_alloc(void** p, size_t bytes, size_t* got);
 void gt_pool_free(void* p, size_t bytes);
+// a batch of releases behind ONE device synchronisation (a context closing): gt_pool_free skips its own between the two calls
+void gt_pool_quiesced_begin();
+void gt_pool_quiesced_end();
+// streams and events of closed contexts, parked per device and taken over by the next context (gt_devpool.cpp)
+hipStream_t gt_handle_take_stream(int device, bool side);        // nullptr: none parked
+void gt_handle_park_stream(int device, bool side, hipStream_t s);
+hipEvent_t gt_handle_take_event(int device);                      // parked, or a new one
+void gt_handle_park_events(int device, std::vector<hipEvent_t>& ev);
 
 // grow-only device buffer
 struct DevBuf {
@@ -243,9 +251,7 @@ struct gt_ctx {
             event_pool.pop_back();
             return e;
         }
-        hipEvent_t e;
-        (void)hipEventCreate(&e);
-        return e;
+        return gt_handle_take_event(device);
     }
     void reset_stages() {
         for (auto& kv : stages) {

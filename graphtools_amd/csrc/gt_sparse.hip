@@ -2416,8 +2416,11 @@ static int graph_finish_pairs(gt_ctx* ctx, int64_t* out_nnz, uint32_t* flags) {
         if (!ctx->side_stream) {
             // (highest priority: the thousand long-row waves are the shorter job and must not queue behind the million short rows)
             int prio_lo = 0, prio_hi = 0;
-            GT_HIP(ctx, hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-            GT_HIP(ctx, hipStreamCreateWithPriority(&ctx->side_stream, hipStreamNonBlocking, prio_hi));
+            ctx->side_stream = gt_handle_take_stream(ctx->device, true);   // (parked by a closed context, gt_devpool.cpp)
+            if (!ctx->side_stream) {
+                GT_HIP(ctx, hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+                GT_HIP(ctx, hipStreamCreateWithPriority(&ctx->side_stream, hipStreamNonBlocking, prio_hi));
+            }
             GT_HIP(ctx, hipEventCreateWithFlags(&ctx->side_event, hipEventDisableTiming));
         }
         hipLaunchKernelGGL(merge_long_final_kernel, dim3(1024), dim3(64), 0, ctx->side_stream, fs, g->indptr.as<int64_t>(),

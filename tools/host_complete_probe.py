@@ -28,6 +28,8 @@ for rep in range(4):
     nnz, flags = G._device_build(G.kernel_symm, G.theta, G.anisotropy)
     G.hip.sync()
     t3 = time.perf_counter()
+    stages = {s_: round(G.hip.stage_ms(s_), 3) for s_ in ("prep", "query_order", "sym_prepare", "sym_seed", "sym_bound", "sym_cold", "knn_select",
+                                                          "rerank", "fallback", "radius", "affinity", "symmetrize", "normalize") if G.hip.stage_ms(s_) > 0}
     kd, ki, kp, pd = G.hip.graph_fetch_kp()
     t4 = time.perf_counter()
     kp32 = kp.astype(np.int32)
@@ -35,7 +37,7 @@ for rep in range(4):
     P = sparse.csr_matrix((pd, K.indices, K.indptr), shape=(n, n))
     t5 = time.perf_counter()
     res.append({"ctor_ms": (t1 - t0) * 1e3, "set_points_ms": (t2 - t1) * 1e3, "build_ms": (t3 - t2) * 1e3, "fetch_kp_ms": (t4 - t3) * 1e3,
-                "scipy_ms": (t5 - t4) * 1e3, "total_ms": (t5 - t0) * 1e3, "fetch_GBs": (kd.nbytes + ki.nbytes + kp.nbytes) / (t4 - t3) / 1e9})
+                "scipy_ms": (t5 - t4) * 1e3, "stage_sum_ms": round(sum(stages.values()), 3), "stages": stages, "total_ms": (t5 - t0) * 1e3, "fetch_GBs": (kd.nbytes + ki.nbytes + kp.nbytes) / (t4 - t3) / 1e9})
     del G, K, P, kd, ki, kp, pd
     t0 = time.perf_counter()
     G = graphtools_amd.Graph(X, knn=15, decay=40, n_pca=None, verbose=0)
