@@ -191,6 +191,7 @@ struct gt_ctx {
     int32_t dist_f64 = 0;       //   distances from the float64 keys in float64 whatever the points' dtype (option "distance_dtype")
     int32_t in_graph_build = 0; //   (set by gt_graph_build around its gt_graph_begin: every row is here, the tail is its own)
     int32_t symm_pairs = 1;     //   pair-resolved symmetrisation (gt_sparse.hip): every row settles its mutual pairs itself, only one-sided entries travel
+    int32_t keep_stages = 0;    //   (gt_graph_build's second attempt after a refutation: the stage timers are not reset)
     int32_t symm_pair_ok = 1;   //   ... not refuted for the bound point set (a union row beyond the register sorts)
     int32_t symm_fill_threads = 256;   //   threads per workgroup of bin_fill_kernel (256 | 512 | 1024)
     int32_t symm_bin_shift = 0; //   log2 of the rows per bin (0: 9, more from 2 M rows; development / tests: 8 ... 12)

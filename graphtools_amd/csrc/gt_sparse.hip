@@ -1951,7 +1951,9 @@ extern "C" int gt_graph_begin(gt_ctx* ctx, const gt_knn_params* params, int32_t 
                               const int64_t* row_splits, int64_t* send_counts) {
     if (!ctx) return GT_E_ARG;
     // (the stages of a sharded symmetric pass that is about to be consumed belong to this build)
-    if (!(ctx->knn && (ctx->knn->sh_stage == 5 || ctx->knn->sh_stage == 6))) ctx->reset_stages();
+    // (... and so do those of a first attempt that the pair-resolved tail refuted: gt_graph_build keeps them, the stage times
+    //  then say what the build cost)
+    if (!(ctx->knn && (ctx->knn->sh_stage == 5 || ctx->knn->sh_stage == 6)) && !ctx->keep_stages) ctx->reset_stages();
     const int rc = graph_begin_impl(ctx, params, world, rank, row_splits, send_counts, false, 0);
     ctx->stage_totals_valid = 0;   // (the totals belong to one build)
     return rc;
@@ -2659,9 +2661,11 @@ extern "C" int gt_graph_build(gt_ctx* ctx, const gt_knn_params* params, int64_t*
         ctx->in_graph_build = 1;
         const int rc_b = gt_graph_begin(ctx, params, 1, 0, splits, sendc);
         ctx->in_graph_build = 0;
+        ctx->keep_stages = 0;
         if (rc_b != GT_OK) return rc_b;
         if (!ctx->graph->pairs) break;
-        const int rc = sendc[0] > 0 ? graph_finish_pairs(ctx, out_nnz, flags) : 0;
+        if (sendc[0] == 0) break;   // (no kept entry at all: nothing is settled in the tables, the general tail returns the empty graph)
+        const int rc = graph_finish_pairs(ctx, out_nnz, flags);
         if (rc < 0) return rc;
         if (rc == 1) {
             ctx->graph->bins_used = true;
@@ -2671,6 +2675,7 @@ extern "C" int gt_graph_build(gt_ctx* ctx, const gt_knn_params* params, int64_t*
         // a union row beyond the register sorts (a hub of the transpose): the tables hold settled pairs the general tail
         // cannot read - this point set is built again, now and from here on, the general way
         ctx->symm_pair_ok = 0;
+        ctx->keep_stages = 1;   // (the second attempt's stage times are added to the first's)
         if (attempt > 0) GT_FAIL(ctx, GT_E_STATE, "gt_graph_build: the pair-resolved path was taken twice");
     }
     GraphState* g = ctx->graph;

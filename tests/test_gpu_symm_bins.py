@@ -155,7 +155,8 @@ def _build_pairs(X, pairs, knn=15, decay=40.0, bandwidth=None, opts=()):
     for _ in range(2):      # (twice: a refuted pair path is remembered for the point set)
         c.graph_build(p)
         tail = "pairs" if (c.stage_ms("symm_merge") >= 0 and c.stage_ms("symm_compact") < 0) else "general"
-        out.append((c.graph_fetch_csr(_hip.CSR_K), c.graph_fetch_csr(_hip.CSR_P)[0], tail, c.graph_stats(), c.knn_stats()))
+        out.append((c.graph_fetch_csr(_hip.CSR_K), c.graph_fetch_csr(_hip.CSR_P)[0], tail, c.graph_stats(), c.knn_stats(),
+                    c.stage_launches("affinity")))
     c.close()
     return out
 
@@ -196,3 +197,6 @@ def test_pair_resolved_tail_gives_way_to_hub_rows():
     lens = np.diff(a[0][0][2])
     if lens.max() > 2048:
         assert a[0][2] == "general" and a[1][2] == "general"
+        # the refuted first attempt stays in the stage timers (its launches are counted next to the second attempt's); once the
+        # verdict is in, a build is one attempt
+        assert a[0][5] == 2 * a[1][5] and a[1][5] == b[0][5]

@@ -15,6 +15,11 @@ from bench import make_mix  # noqa: E402
 from graphtools_amd import _hip  # noqa: E402
 import graphtools_amd  # noqa: E402
 
+if os.environ.get("GT_PROBE_TORCH") == "1":   # the same with torch's HIP state in the process (bench.py has it)
+    import torch
+
+    torch.zeros(1000, device="cuda:0")
+    torch.cuda.synchronize()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
 d = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 X = make_mix(n, d, 1)
