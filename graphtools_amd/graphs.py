@@ -646,7 +646,12 @@ class LandmarkGraph(DataGraph):
                 try:
                     lm_ctx.set_points(X[landmark_indices])
                     k = int(min(4, self.n_landmark))
-                    dist, idx, _ = lm_ctx.knn_search(k, Y=X)
+                    if getattr(self, "_points_bound", False) and self.hip.n == X.shape[0] and self.hip.dtype == X.dtype:
+                        # (the graph's own context holds these rows on the device already: queried where they are)
+                        self.hip.sync()
+                        dist, idx, _ = lm_ctx.knn_search_device(k, self.hip.points_device(0), X.shape[0])
+                    else:
+                        dist, idx, _ = lm_ctx.knn_search(k, Y=X)
                 finally:
                     lm_ctx.close()
                 tie = dist == dist[:, :1]
@@ -681,7 +686,13 @@ class LandmarkGraph(DataGraph):
         dense = not sparse.issparse(self._kernel)
         if not hasattr(self, "_clusters"):
             self._clusters = self._assign_clusters()
-        landmarks, inverse = np.unique(self._clusters, return_inverse=True)
+        cl = np.asarray(self._clusters)
+        if (cl.ndim == 1 and cl.dtype.kind in "iu" and cl.size and int(cl.min()) == 0 and int(cl.max()) < 4 * self.n_landmark
+                and np.all(np.bincount(cl, minlength=int(cl.max()) + 1) > 0)):
+            # labels 0 .. L-1, every one in use (random landmarking: a landmark is its own nearest): np.unique's answer without its sort
+            landmarks, inverse = np.arange(int(cl.max()) + 1), cl
+        else:
+            landmarks, inverse = np.unique(cl, return_inverse=True)
         L = len(landmarks)
         if self._dist_ranks() is not None:
             # partial L x L products of the rank's rows, ONE all-reduce (dist.landmark_operator); the rank's rows of the
