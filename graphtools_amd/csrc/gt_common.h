@@ -160,13 +160,13 @@ struct gt_ctx {
     // symmetric candidate pass for self queries over the whole point set (gt_sym.hip): -1 auto (large launches), 0 off, 1 on
     int32_t sym_mode = -1;
     int64_t sym_min_rows = 65536;
-    int32_t sym_stride = 384;   //   threshold-seeding launch: every sym_stride-th tile besides the row's own neighbourhood (0: none)
+    int32_t sym_stride = 768;   //   threshold-seeding launch: every sym_stride-th tile besides the row's own neighbourhood (0: none; 384 until round 4's sweep, tools/seed_sweep.py)
     int32_t sym_cosine = 1;          //   the symmetric pass also serves the cosine metric (rows are normalised: the candidate stages are the euclidean ones)
     int32_t sym_sorted_points = 1;   //   symmetric pass: the exact stages read the points from a copy in cell-sorted order
     int32_t xcd_chunk = 0;      //   row-walking kernels: work items per XCD chunk (gt_device.h gt_xcd_item), 0 = one contiguous eighth per XCD
     int32_t rerank_lanes4 = 1;  //   re-rank of the symmetric pass: four lanes per candidate row (float32 rows, d % 4 == 0, d <= 128)
     int32_t sym_dense_seed = 1; //   threshold-seeding launch: 1 = dense cell blocks, keys in registers (gt_seed.hip), 0 = streaming lists
-    int32_t sym_cells = 12;    //   ... which is the rows of this many nearest cells (landmarks) of the block's own cells,
+    int32_t sym_cells = 8;     //   ... which is the rows of this many nearest cells (landmarks) of the block's own cells (12 until round 4's sweep),
     int32_t sym_max_nb = 384;   //   at most this many tiles
     int32_t sym_tcap = 512;     //   capacity of a row's candidate list in launch B (<= 512)
     double sym_sample_far = 1.0;    //   seeding sample: far-kept seeds per row from which the symmetric pass is given up at once
