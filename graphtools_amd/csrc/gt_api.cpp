@@ -280,6 +280,18 @@ int gt_set_option(gt_ctx* ctx, const char* name, const char* value) {
         ctx->narrow_mode = v == "auto" ? -1 : std::atoi(value);
         return GT_OK;
     }
+    if (k == "select_sym_outlier_orphans") {
+        ctx->sym_outlier_orphans = std::atoi(value) != 0 ? 1 : 0;
+        return GT_OK;
+    }
+    if (k == "symmetrize_pairs_huge") {
+        ctx->symm_pair_huge = std::atoi(value) != 0 ? 1 : 0;
+        return GT_OK;
+    }
+    if (k == "query_order_outliers") {
+        ctx->order_outliers = std::atoi(value) != 0 ? 1 : 0;
+        return GT_OK;
+    }
     if (k == "query_order_cell_rows") {
         ctx->order_cell_rows = std::atoi(value);
         return GT_OK;

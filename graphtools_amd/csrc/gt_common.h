@@ -145,6 +145,7 @@ struct gt_ctx {
     int32_t query_order = 1;  // candidate pass: deal the query rows to workgroups grouped by nearest landmark (gt_order.hip)
     int32_t order_min_rows = 32768;  //   launches with fewer query rows (or fewer points) are not grouped
     int32_t thr0_mode = 1;           //   start the candidate lists from the threshold the assignment pass proves (0: from -inf)
+    int32_t order_outliers = 1;      //   rows far from every landmark get a cell of their own (gt_order.hip; 0: off)
     int32_t order_cell_rows = 244;   //   rows per landmark cell (L = n / order_cell_rows landmarks, 64 ... 8192; small cells: a cluster
                                      //   without a landmark of its own swells the cells it lands in - see the bound pass, gt_sym.hip)
     DevBuf land_Y, land_h, order_cell, order_rows, order_tmp;
@@ -191,6 +192,7 @@ struct gt_ctx {
     int32_t dist_f64 = 0;       //   distances from the float64 keys in float64 whatever the points' dtype (option "distance_dtype")
     int32_t in_graph_build = 0; //   (set by gt_graph_build around its gt_graph_begin: every row is here, the tail is its own)
     int32_t symm_pairs = 1;     //   pair-resolved symmetrisation (gt_sparse.hip): every row settles its mutual pairs itself, only one-sided entries travel
+    int32_t symm_pair_huge = 1; //   ... union rows beyond the register sorts are finished by a segmented sort (0: they refute the path: the general tail)
     int32_t keep_stages = 0;    //   (gt_graph_build's second attempt after a refutation: the stage timers are not reset)
     int32_t symm_pair_ok = 1;   //   ... not refuted for the bound point set (a union row beyond the register sorts)
     int32_t symm_fill_threads = 256;   //   threads per workgroup of bin_fill_kernel (256 | 512 | 1024)
@@ -205,6 +207,8 @@ struct gt_ctx {
     int32_t sym_two_steps = 0;  //   k-steps of stage one (0: half of them; development, must match the kernel build)
     int32_t sym_two_ok = -1;    //   verdict of the last launch for the bound point set (cold-path share), -1 unknown
     int32_t sym_shard_group = 32;   //   row-sharded launch B: query blocks per rotation step of the walk pieces
+    int32_t sym_outlier_orphans = 0;   // the rows of the outlier cell are orphans of the symmetric pass (collect nothing, repaired exactly)
+    int32_t order_outlier_cell = -1;   // id of the outlier cell of the last query order (its rows are orphans of the symmetric pass), -1: none
     int32_t order_L = 0;        // landmark cells of the last query order (gt_order.hip)
     // Cell-sorted renumbering (gt_points_cell_sort, gt_knn_shard.cpp): the bound points ARE the caller's points in the
     // cell-sorted order - row v of the context is the caller's row vperm[v], a landmark cell is a run of consecutive rows,

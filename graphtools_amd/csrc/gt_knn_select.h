@@ -97,7 +97,7 @@ struct SelectArgs {
 int gt_launch_select(gt_ctx* ctx, const SelectArgs& a);
 // nearest of the L landmark rows Yl (compact hi-plane rows, seeds hl) for the rows [q0, q0 + nq) of Yc (approximate)
 int gt_launch_assign_cells(gt_ctx* ctx, int dp, const float* Yc, const float* Yl, const float* hl, int64_t q0, int32_t nq,
-                           int32_t L, int32_t need, uint32_t* cell, float* thr0);
+                           int32_t L, int32_t need, uint32_t* cell, float* thr0, float* best = nullptr);
 // gt_order.hip: the rows [q0, q0 + nq) grouped by nearest landmark -> out_rows (device, int32 [nq]); *active = 0 when
 // the launch is too small to bother or the compact copy is not available (out_rows untouched)
 // out_thr0 (device, float [nq], indexed by row - q0): a score at least `need` (<= 32) database rows reach in the

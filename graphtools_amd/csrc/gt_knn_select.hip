@@ -1113,7 +1113,10 @@ template <int DP>
 __global__ __launch_bounds__(256) void assign_cells_kernel(const float* __restrict__ Yc, const float* __restrict__ Yl,
                                                            const float* __restrict__ hl, const int64_t q0,
                                                            const int32_t nq, const int32_t L, const int32_t need,
-                                                           uint32_t* __restrict__ cell, float* __restrict__ thr0) {
+                                                           uint32_t* __restrict__ cell, float* __restrict__ thr0,
+                                                           float* __restrict__ best_out) {
+    // best_out (optional): the score of the row's nearest landmark (how far the row is from every cell: gt_order.hip's
+    // outlier cell)
     constexpr int RW = DP / 2;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, li = lane & 31, h = lane >> 5;
     const int64_t q = int64_t(blockIdx.x) * 128 + w * 32 + li;
@@ -1188,6 +1191,7 @@ __global__ __launch_bounds__(256) void assign_cells_kernel(const float* __restri
     if (h == 0 && q < nq) {
         cell[q] = bidx;
         thr0[q] = gmin;
+        if (best_out) best_out[q] = fmaxf(best, ob);
     }
 }
 
@@ -1530,9 +1534,9 @@ int launch_dp(gt_ctx* ctx, const SelectArgs& a) {
 #if GT_SEL_PREC == 2 && !GT_SEL_QT1
 int GT_CAT3(gt_launch_assign_cells_p, GT_SEL_PREC, _dp, GT_SEL_DP)(gt_ctx* ctx, const float* Yc, const float* Yl,
                                                                   const float* hl, int64_t q0, int32_t nq, int32_t L,
-                                                                  int32_t need, uint32_t* cell, float* thr0) {
+                                                                  int32_t need, uint32_t* cell, float* thr0, float* best) {
     hipLaunchKernelGGL(assign_cells_kernel<GT_SEL_DP>, dim3((unsigned)ceil_div64(nq, 128)), dim3(256), 0, ctx->stream, Yc,
-                       Yl, hl, q0, nq, L, need, cell, thr0);
+                       Yl, hl, q0, nq, L, need, cell, thr0, best);
     GT_HIP(ctx, hipGetLastError());
     return GT_OK;
 }

@@ -9,7 +9,7 @@
 #define GT_DECL(PR_, DP_) int gt_launch_select_p##PR_##_dp##DP_(gt_ctx*, const SelectArgs&);
 #define GT_DECL_NARROW(PR_, DP_) int gt_launch_select_narrow_p##PR_##_dp##DP_(gt_ctx*, const SelectArgs&);
 #define GT_DECL_ASSIGN(PR_, DP_) \
-    int gt_launch_assign_cells_p##PR_##_dp##DP_(gt_ctx*, const float*, const float*, const float*, int64_t, int32_t, int32_t, int32_t, uint32_t*, float*);
+    int gt_launch_assign_cells_p##PR_##_dp##DP_(gt_ctx*, const float*, const float*, const float*, int64_t, int32_t, int32_t, int32_t, uint32_t*, float*, float*);
 GT_SEL_P2_LIST(GT_DECL_ASSIGN)
 GT_SEL_NARROW_LIST(GT_DECL_NARROW)
 GT_SEL_P0_LIST(GT_DECL)
@@ -44,8 +44,8 @@ int gt_launch_select(gt_ctx* ctx, const SelectArgs& a) {
 }
 
 int gt_launch_assign_cells(gt_ctx* ctx, int dp, const float* Yc, const float* Yl, const float* hl, int64_t q0, int32_t nq,
-                           int32_t L, int32_t need, uint32_t* cell, float* thr0) {
-#define GT_CASE_ASSIGN(PR_, DP_) if (dp == DP_) return gt_launch_assign_cells_p##PR_##_dp##DP_(ctx, Yc, Yl, hl, q0, nq, L, need, cell, thr0);
+                           int32_t L, int32_t need, uint32_t* cell, float* thr0, float* best) {
+#define GT_CASE_ASSIGN(PR_, DP_) if (dp == DP_) return gt_launch_assign_cells_p##PR_##_dp##DP_(ctx, Yc, Yl, hl, q0, nq, L, need, cell, thr0, best);
     GT_SEL_P2_LIST(GT_CASE_ASSIGN)
     GT_FAIL(ctx, GT_E_LIMIT, "assign_cells: unsupported feature count");
 }

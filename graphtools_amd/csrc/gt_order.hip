@@ -13,6 +13,7 @@
 #include <rocprim/device/device_radix_sort.hpp>
 
 #include "gt_common.h"
+#include "gt_device.h"
 #include "gt_knn.h"
 #include "gt_knn_select.h"
 
@@ -40,6 +41,76 @@ __global__ __launch_bounds__(256) void gather_strided_rows_kernel(const uint32_t
     const int64_t f = int64_t(blockIdx.x) * 256 + threadIdx.x;
     if (f >= int64_t(L) * rw) return;
     out[f] = X[(f / rw) * step * rw + f % rw];
+}
+
+// ---- the outlier cell ---------------------------------------------------------------------------------------------------
+// A cell is what the bound pass reasons about: centre, radius (its farthest member), the largest collection radius of its
+// rows.  ONE row far from every landmark - an isolated point, a point half way between two clusters - inflates the ball of the
+// cell it lands in, the fat ball stays undecided against thousands of cells, and twenty such rows in a million (real data has
+// them) were enough to push the bound pass over its queue and the build from 18 to 84 ms.  Rows whose squared distance to their
+// nearest landmark exceeds tau x the mean of all rows are therefore given a cell of their own, the last one: its ball is huge,
+// every pair with one of its rows is scored - as it has to be - and the other cells keep the balls of their bulk.  tau: the
+// smallest of 4, 8, 16, 32, 64 that leaves the cell at most `cap` rows, most of which are still beyond 4 tau (none fits: no
+// outlier cell - the tail is the data's nature, not an exception).  o = -(hneg + best) = |x - landmark|^2 / 2 in the units of the scores.
+constexpr int kOutlierTaus = 5;
+
+__global__ __launch_bounds__(256) void outlier_sum_kernel(const int64_t nq, const int64_t q0, const float* __restrict__ hneg,
+                                                          const float* __restrict__ best, double* __restrict__ acc) {
+    double s = 0.0;
+    for (int64_t q = int64_t(blockIdx.x) * 256 + threadIdx.x; q < nq; q += int64_t(gridDim.x) * 256) {
+        const float o = -(hneg[q0 + q] + best[q]);
+        s += o > 0.f ? double(o) : 0.0;
+    }
+    // (one atomic per workgroup: a thousand waves adding to one address took 0.1 ms)
+    __shared__ double red[4];
+    s = wave_sum_f64(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(acc, (red[0] + red[1]) + (red[2] + red[3]));
+}
+
+__global__ __launch_bounds__(256) void outlier_count_kernel(const int64_t nq, const int64_t q0, const float* __restrict__ hneg,
+                                                            const float* __restrict__ best, const double* __restrict__ acc,
+                                                            uint32_t* __restrict__ counts) {
+    const float mean = float(acc[0] / double(nq));
+    uint32_t c[kOutlierTaus] = {0u, 0u, 0u, 0u, 0u};
+    for (int64_t q = int64_t(blockIdx.x) * 256 + threadIdx.x; q < nq; q += int64_t(gridDim.x) * 256) {
+        const float o = -(hneg[q0 + q] + best[q]);
+#pragma unroll
+        for (int t = 0; t < kOutlierTaus; ++t) c[t] += o > float(4 << t) * mean ? 1u : 0u;
+    }
+    __shared__ int redc[4][kOutlierTaus];
+#pragma unroll
+    for (int t = 0; t < kOutlierTaus; ++t) {
+        const int tot = wave_sum_i32(int(c[t]));
+        if ((threadIdx.x & 63) == 0) redc[threadIdx.x >> 6][t] = tot;
+    }
+    __syncthreads();
+    if (threadIdx.x < kOutlierTaus) {
+        const int tot = redc[0][threadIdx.x] + redc[1][threadIdx.x] + redc[2][threadIdx.x] + redc[3][threadIdx.x];
+        if (tot) atomicAdd(&counts[threadIdx.x], uint32_t(tot));
+    }
+}
+
+__global__ __launch_bounds__(256) void outlier_relabel_kernel(const int64_t nq, const int64_t q0, const float* __restrict__ hneg,
+                                                              const float* __restrict__ best, const double* __restrict__ acc,
+                                                              const uint32_t* __restrict__ counts, const uint32_t cap,
+                                                              const uint32_t outlier_cell, uint32_t* __restrict__ cell) {
+    const int64_t q = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (q >= nq) return;
+    // the smallest factor whose tail fits AND is flat - most of its rows are still beyond four times the factor: rows that
+    // belong to nothing, not the upper end of a distribution that simply has one (a curled manifold: two thousand rows beyond
+    // 4 x the mean, a few dozen beyond 16 x - packing those into a cell of their own costs them their neighbourhood, their
+    // seeds, and the build 11 ms of repairs); the two largest factors have nothing to be compared with: a handful of rows
+    int pick = -1;
+#pragma unroll
+    for (int t = kOutlierTaus - 1; t >= 0; --t) {
+        const bool flat = (t + 2 < kOutlierTaus) ? counts[t] <= 2u * counts[t + 2] + 16u : counts[t] <= 64u;
+        if (counts[t] <= cap && flat) pick = t;
+    }
+    if (pick < 0) return;
+    const float mean = float(acc[0] / double(nq));
+    if (-(hneg[q0 + q] + best[q]) > float(4 << pick) * mean) cell[q] = outlier_cell;
 }
 
 }  // namespace
@@ -117,6 +188,7 @@ int gt_order_sort_cells(gt_ctx* ctx, const uint32_t* cells_all, int32_t* out_row
                                           size_t(n), 0u, unsigned(bits), ctx->stream));
     ctx->order_L = L;
     ctx->order_has_thr0 = 0;
+    ctx->order_outlier_cell = -1;
     return GT_OK;
 }
 
@@ -125,6 +197,7 @@ int gt_query_order(gt_ctx* ctx, const float* Qc, int64_t q0, int64_t nq, int nee
     *active = 0;
     ctx->order_L = 0;
     ctx->order_has_thr0 = 0;
+    ctx->order_outlier_cell = -1;
     if (ctx->presorted && Qc == ctx->Yc.as<float>() && ctx->vcell.p && q0 >= 0 && q0 + nq <= ctx->n && nq >= 1) {
         // the bound points were renumbered in cell-sorted order (gt_points_cell_sort): rows [q0, q0 + nq) are grouped already
         GT_HIP(ctx, ctx->order_cell.reserve(size_t(nq) * sizeof(uint32_t) * 2));
@@ -147,8 +220,12 @@ int gt_query_order(gt_ctx* ctx, const float* Qc, int64_t q0, int64_t nq, int nee
     //  no landmark - see the bound pass, gt_sym.hip)
     int L = order_cells_of(ctx, ctx->n);
     const int64_t step = ctx->n / L;
-    GT_HIP(ctx, ctx->land_Y.reserve(size_t(L) * rw * sizeof(uint32_t)));
-    GT_HIP(ctx, ctx->land_h.reserve(size_t(L) * sizeof(float)));
+    // (one row more than there are landmarks: the outlier cell's stand-in - zeros, the origin - for whoever indexes the
+    //  landmark rows by cell; neighbourhoods are approximate by design)
+    GT_HIP(ctx, ctx->land_Y.reserve(size_t(L + 1) * rw * sizeof(uint32_t)));
+    GT_HIP(ctx, ctx->land_h.reserve(size_t(L + 1) * sizeof(float)));
+    GT_HIP(ctx, hipMemsetAsync(ctx->land_Y.as<uint32_t>() + size_t(L) * rw, 0, size_t(rw) * sizeof(uint32_t), ctx->stream));
+    GT_HIP(ctx, hipMemsetAsync(ctx->land_h.as<float>() + L, 0, sizeof(float), ctx->stream));
     GT_HIP(ctx, ctx->order_cell.reserve(size_t(nq) * sizeof(uint32_t) * 2));
     GT_HIP(ctx, ctx->order_rows.reserve(size_t(nq) * sizeof(int32_t)));
     hipLaunchKernelGGL(gather_landmarks_kernel, dim3((unsigned)ceil_div64(int64_t(L) * rw, 256)), dim3(256), 0, ctx->stream,
@@ -157,20 +234,43 @@ int gt_query_order(gt_ctx* ctx, const float* Qc, int64_t q0, int64_t nq, int nee
     GT_HIP(ctx, hipGetLastError());
     uint32_t* cell = ctx->order_cell.as<uint32_t>();
     uint32_t* cell_sorted = cell + nq;
+    // the outlier cell (above): for the rows of the bound point set (their seeds -|x|^2 / 2 are at hand)
+    const bool outliers = ctx->order_outliers != 0 && Qc == ctx->Yc.as<float>() && ctx->hneg.p != nullptr;
+    float* best = nullptr;
+    if (outliers) {
+        GT_HIP(ctx, ctx->order_tmp.reserve(size_t(nq) * sizeof(float) + 64));
+        best = ctx->order_tmp.as<float>();
+    }
     GT_TRY(gt_launch_assign_cells(ctx, ctx->DP, Qc, ctx->land_Y.as<float>(), ctx->land_h.as<float>(), q0,
-                                  int32_t(nq), L, need, cell, out_thr0));
+                                  int32_t(nq), L, need, cell, out_thr0, best));
+    int n_cells = L;
+    if (outliers) {
+        // acc: sum of the scores (double) | five counts, behind the scores in the same buffer
+        double* acc = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(best + nq) + 7) & ~uintptr_t(7));
+        uint32_t* counts = reinterpret_cast<uint32_t*>(acc + 1);
+        GT_HIP(ctx, hipMemsetAsync(acc, 0, sizeof(double) + kOutlierTaus * sizeof(uint32_t), ctx->stream));
+        const unsigned grid = (unsigned)std::min<int64_t>(ceil_div64(nq, 256), int64_t(ctx->n_cu) * 2);
+        hipLaunchKernelGGL(outlier_sum_kernel, dim3(grid), dim3(256), 0, ctx->stream, nq, q0, ctx->hneg.as<float>(), best, acc);
+        hipLaunchKernelGGL(outlier_count_kernel, dim3(grid), dim3(256), 0, ctx->stream, nq, q0, ctx->hneg.as<float>(), best, acc, counts);
+        const uint32_t cap = uint32_t(std::max<int64_t>(64, nq / 512));
+        hipLaunchKernelGGL(outlier_relabel_kernel, dim3((unsigned)ceil_div64(nq, 256)), dim3(256), 0, ctx->stream, nq, q0,
+                           ctx->hneg.as<float>(), best, acc, counts, cap, uint32_t(L), cell);
+        GT_HIP(ctx, hipGetLastError());
+        n_cells = L + 1;
+    }
     hipLaunchKernelGGL(iota_rows_kernel, dim3((unsigned)ceil_div64(nq, 256)), dim3(256), 0, ctx->stream, q0, nq,
                        ctx->order_rows.as<int32_t>());
     GT_HIP(ctx, hipGetLastError());
     int bits = 1;
-    while ((1 << bits) < L) ++bits;
+    while ((1 << bits) < n_cells) ++bits;
     size_t tmp_bytes = 0;
     GT_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tmp_bytes, cell, cell_sorted, ctx->order_rows.as<int32_t>(), out_rows,
                                           size_t(nq), 0u, unsigned(bits), ctx->stream));
     GT_HIP(ctx, ctx->order_tmp.reserve(tmp_bytes));
     GT_HIP(ctx, rocprim::radix_sort_pairs(ctx->order_tmp.p, tmp_bytes, cell, cell_sorted, ctx->order_rows.as<int32_t>(),
                                           out_rows, size_t(nq), 0u, unsigned(bits), ctx->stream));
-    ctx->order_L = L;   // cells of the order just built (cell ids of the sorted rows: order_cell + nq)
+    ctx->order_outlier_cell = (outliers && q0 == 0 && nq == ctx->n) ? L : -1;
+    ctx->order_L = n_cells;   // cells of the order just built (cell ids of the sorted rows: order_cell + nq)
     ctx->order_has_thr0 = 1;
     *active = 1;
     return GT_OK;

@@ -9,6 +9,8 @@
 //   K     = sym(K0);  K_ij /= (q_i q_j)^alpha;  P = diag(1/sum_j|K_ij|) K;  degree = K 1
 #include <cfloat>
 
+#include <rocprim/device/device_segmented_radix_sort.hpp>
+
 #include "gt_common.h"
 #include "gt_hostcopy.h"
 #include "gt_device.h"
@@ -1388,6 +1390,78 @@ __global__ __launch_bounds__(64) void merge_long_final_kernel(const FusedSrc fs,
     }
 }
 
+// ---- union rows beyond the register sorts, pair-resolved tail -----------------------------------------------------------
+// A row of more than kHugeRow entries - a hub of the transpose, or an isolated point whose radius takes in thousands of rows -
+// used to refute the pair-resolved tail for the point set: the whole build was done again the general way (twenty isolated
+// points in a million: 2 x the time).  Such rows are now finished behind the others: gathered (column, final value) into a
+// scratch segment each, sorted by column by rocPRIM's segmented radix sort, written to their place in the CSR with the row
+// sum in the order every other path uses (lane l adds the entries l, l + 64, ... in turn, then the wave's tree).
+__global__ __launch_bounds__(64) void huge_gather_kernel(const FusedSrc fs, const int32_t* __restrict__ hugelist, const uint32_t nhuge,
+                                                         unsigned long long* __restrict__ cursor, uint32_t* __restrict__ seg_begin,
+                                                         uint32_t* __restrict__ seg_end, uint32_t* __restrict__ keys,
+                                                         double* __restrict__ vals) {
+    const int lane = threadIdx.x;
+    const uint32_t b = blockIdx.x;
+    if (b >= nhuge) return;
+    const int64_t i = hugelist[-int64_t(b)];   // (the list grows downwards from its last slot)
+    const int64_t p = fs.pos[i];
+    int lt;
+    const RowSrc3 U = make_row_src3(fs, i, p, lt);
+    const int L = U.ln + lt;
+    unsigned long long base = 0ull;
+    if (lane == 0) base = atomicAdd(cursor, (unsigned long long)L);
+    base = __shfl((unsigned long long)base, 0);
+    if (lane == 0) {
+        seg_begin[b] = uint32_t(base);
+        seg_end[b] = uint32_t(base) + uint32_t(L);
+    }
+    for (int q = lane; q < L; q += 64) {
+        const uint32_t key = U.key(q);
+        const double v = U.val(q);
+        const int tag = int(key & 1u);
+        // (no column occurs twice in a pair-resolved union row: an own entry stored negative is the settled value of a mutual
+        //  pair, every other entry is one side of a pair whose other side is absent)
+        const double m = (tag == 0 && v < 0.0) ? -v : merge_values(tag == 0 ? v : 0.0, tag == 1 ? v : 0.0, GT_SYMM_ADD, 1.0);
+        keys[base + q] = key >> 1;
+        vals[base + q] = m;
+    }
+}
+
+__global__ __launch_bounds__(64) void huge_finalize_kernel(const int32_t* __restrict__ hugelist, const uint32_t nhuge,
+                                                           const uint32_t* __restrict__ seg_begin, const uint32_t* __restrict__ seg_end,
+                                                           const uint32_t* __restrict__ keys, const double* __restrict__ vals,
+                                                           const int64_t* __restrict__ indptr, int32_t* __restrict__ indices,
+                                                           double* __restrict__ Kdata, double* __restrict__ Pdata,
+                                                           double* __restrict__ degree, uint32_t* __restrict__ flags) {
+    const int lane = threadIdx.x;
+    const uint32_t b = blockIdx.x;
+    if (b >= nhuge) return;
+    const int64_t i = hugelist[-int64_t(b)];
+    const uint32_t s0 = seg_begin[b];
+    const int L = int(seg_end[b] - s0);
+    const int64_t dst = indptr[i];
+    double lsum = 0.0;
+    bool has_diag = false;
+    for (int e = lane; e < L; e += 64) {
+        const uint32_t col = keys[s0 + e];
+        const double m = vals[s0 + e];
+        indices[dst + e] = int32_t(col);
+        Kdata[dst + e] = m;
+        has_diag |= int64_t(col) == i && m != 0.0;
+        lsum += m;
+    }
+    const double sum = wave_sum_f64(lsum);
+    const bool any_diag = __ballot(has_diag) != 0ull;
+    for (int e = lane; e < L; e += 64) {
+        const double m = vals[s0 + e];
+        Pdata[dst + e] = (sum != 0.0) ? m / sum : m;
+    }
+    if (lane == 0) {
+        degree[i] = sum;
+        if (!any_diag) atomicOr(flags, GT_FLAG_ZERO_DIAGONAL);
+    }
+}
+
 __global__ __launch_bounds__(256) void anisotropy_kernel(const int64_t nloc, const int64_t r0,
                                                          const int64_t* __restrict__ indptr,
                                                          const int32_t* __restrict__ indices, double* __restrict__ Kdata,
@@ -2293,14 +2367,21 @@ __global__ __launch_bounds__(256) void pairs_len_kernel(const int64_t nloc, cons
                                                         const int64_t* __restrict__ off, int32_t* __restrict__ outlen,
                                                         int32_t* __restrict__ biglist, uint32_t* __restrict__ bigcount,
                                                         uint32_t* __restrict__ fflags) {
+    // bigcount: [0] rows for merge_long_final_kernel (listed from biglist[0] upwards), [2] = fflags, [4] rows beyond the
+    // register sorts (listed from biglist[nloc - 1] downwards), [6..7] their entries in all (64 bit)
     const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
     if (i >= nloc) return;
     const int64_t p = pos[i];
     const int64_t L = off[p + 1] - off[p];
     outlen[i] = int32_t(L);
     if (L > kBigRow) {
-        if (L > kHugeRow) atomicOr(fflags, kFusedHugeRow);
-        else biglist[atomicAdd(bigcount, 1u)] = int32_t(i);
+        if (L > kHugeRow) {
+            atomicOr(fflags, kFusedHugeRow);
+            biglist[nloc - 1 - int64_t(atomicAdd(bigcount + 4, 1u))] = int32_t(i);
+            atomicAdd(reinterpret_cast<unsigned long long*>(bigcount + 6), (unsigned long long)L);
+        } else {
+            biglist[atomicAdd(bigcount, 1u)] = int32_t(i);
+        }
     }
 }
 
@@ -2329,11 +2410,11 @@ static int graph_finish_pairs(gt_ctx* ctx, int64_t* out_nnz, uint32_t* flags) {
     GT_HIP(ctx, g->off.reserve(size_t(nloc + 1) * sizeof(int64_t)));
     GT_HIP(ctx, g->outlen.reserve(size_t(nloc) * sizeof(int32_t)));
     GT_HIP(ctx, g->bigrows.reserve(size_t(nloc) * sizeof(int32_t)));
-    GT_HIP(ctx, g->bigcount.reserve(4 * sizeof(uint32_t)));   // [0] long rows, [2] flags
+    GT_HIP(ctx, g->bigcount.reserve(8 * sizeof(uint32_t)));   // [0] long rows, [2] flags, [4] huge rows, [6..7] their entries (pairs_len_kernel)
     GT_HIP(ctx, g->indptr.reserve(size_t(nloc + 1) * sizeof(int64_t)));
     GT_HIP(ctx, g->degree.reserve(size_t(nloc) * sizeof(double)));
     GT_HIP(ctx, hipMemsetAsync(g->bincnt.p, 0, size_t(2 * nbins) * sizeof(int32_t), ctx->stream));
-    GT_HIP(ctx, hipMemsetAsync(g->bigcount.p, 0, 4 * sizeof(uint32_t), ctx->stream));
+    GT_HIP(ctx, hipMemsetAsync(g->bigcount.p, 0, 8 * sizeof(uint32_t), ctx->stream));
     uint32_t* fflags = g->bigcount.as<uint32_t>() + 2;
     {
         StageSpan span_bins(ctx, "symm_bins");
@@ -2369,9 +2450,13 @@ static int graph_finish_pairs(gt_ctx* ctx, int64_t* out_nnz, uint32_t* flags) {
     GT_TRY(exclusive_scan(ctx, g->outlen.as<int32_t>(), nullptr, nloc, g->indptr.as<int64_t>(), g->scan_tmp));
     int64_t nnz = 0;
     uint32_t ff = 0;
+    uint32_t huge_host[4] = {0, 0, 0, 0};   // [0] rows beyond the register sorts, [2..3] their entries
     GT_HIP(ctx, hipMemcpyAsync(&nnz, g->indptr.as<int64_t>() + nloc, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
     GT_HIP(ctx, hipMemcpyAsync(&ff, fflags, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    GT_HIP(ctx, hipMemcpyAsync(huge_host, g->bigcount.as<uint32_t>() + 4, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const uint32_t n_huge = huge_host[0];
+    const unsigned long long huge_total = (unsigned long long)huge_host[2] | ((unsigned long long)huge_host[3] << 32);
     if (ctx->dbg_select & 2048) {
         std::vector<int32_t> ol(nloc);
         std::vector<int64_t> oh(nloc + 1);
@@ -2392,7 +2477,9 @@ static int graph_finish_pairs(gt_ctx* ctx, int64_t* out_nnz, uint32_t* flags) {
                      ff, (long long)nnz, (long long)n_own, (long long)mx, (long long)arg, (long long)neg, (long long)nonmono, (long long)oh[nloc], nbig,
                      (long long)hist[0], (long long)hist[1], (long long)hist[2], (long long)hist[3], (long long)hist[4], (long long)hist[5]);
     }
-    if (ff != 0) return 0;
+    // (huge rows: finished behind the others, below - unless they are beyond a 32-bit scratch or the option says no, then
+    //  the caller builds the general way as it used to)
+    if ((ff & ~kFusedHugeRow) != 0 || ((ff & kFusedHugeRow) && (ctx->symm_pair_huge == 0 || huge_total >= (1ull << 31)))) return 0;
     GT_HIP(ctx, g->indices.reserve(size_t(nnz) * sizeof(int32_t)));
     GT_HIP(ctx, g->Kdata.reserve(size_t(nnz) * sizeof(double)));
     GT_HIP(ctx, g->Pdata.reserve(size_t(nnz) * sizeof(double)));
@@ -2436,6 +2523,38 @@ static int graph_finish_pairs(gt_ctx* ctx, int64_t* out_nnz, uint32_t* flags) {
                            (ctx->symm_key32 != 0 && sort_key_fits_u32(g->n_total, 8)) ? 1 : 0);
         GT_HIP(ctx, hipGetLastError());
         GT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->side_event, 0));
+        if (n_huge > 0) {
+            // the rows beyond the register sorts: gather -> segmented sort by column -> their place in the CSR
+            StageSpan span_h(ctx, "symm_huge");
+            const size_t H = size_t(huge_total);
+            GT_HIP(ctx, g->bigscratch_k.reserve(2 * H * sizeof(uint32_t)));
+            GT_HIP(ctx, g->bigscratch_v.reserve(2 * H * sizeof(double)));
+            GT_HIP(ctx, g->bigsoff.reserve((2 * size_t(n_huge) + 2) * sizeof(uint32_t) + sizeof(unsigned long long)));
+            uint32_t* kin = g->bigscratch_k.as<uint32_t>();
+            uint32_t* kout = kin + H;
+            double* vin = g->bigscratch_v.as<double>();
+            double* vout = vin + H;
+            unsigned long long* cursor = g->bigsoff.as<unsigned long long>();
+            uint32_t* seg_begin = reinterpret_cast<uint32_t*>(cursor + 1);
+            uint32_t* seg_end = seg_begin + n_huge;
+            GT_HIP(ctx, hipMemsetAsync(cursor, 0, sizeof(unsigned long long), ctx->stream));
+            const int32_t* hugelist = g->bigrows.as<int32_t>() + (nloc - 1);
+            hipLaunchKernelGGL(huge_gather_kernel, dim3(n_huge), dim3(64), 0, ctx->stream, fs, hugelist, n_huge, cursor, seg_begin,
+                               seg_end, kin, vin);
+            GT_HIP(ctx, hipGetLastError());
+            int bits = 1;
+            while (bits < 32 && (int64_t(1) << bits) < g->n_total) ++bits;
+            size_t tmp_bytes = 0;
+            GT_HIP(ctx, rocprim::segmented_radix_sort_pairs(nullptr, tmp_bytes, kin, kout, vin, vout, unsigned(H), n_huge, seg_begin,
+                                                            seg_end, 0u, unsigned(bits), ctx->stream));
+            GT_HIP(ctx, g->hugerows.reserve(tmp_bytes));
+            GT_HIP(ctx, rocprim::segmented_radix_sort_pairs(g->hugerows.p, tmp_bytes, kin, kout, vin, vout, unsigned(H), n_huge,
+                                                            seg_begin, seg_end, 0u, unsigned(bits), ctx->stream));
+            hipLaunchKernelGGL(huge_finalize_kernel, dim3(n_huge), dim3(64), 0, ctx->stream, hugelist, n_huge, seg_begin, seg_end, kout,
+                               vout, g->indptr.as<int64_t>(), g->indices.as<int32_t>(), g->Kdata.as<double>(),
+                               g->Pdata.as<double>(), g->degree.as<double>(), g->flags.as<uint32_t>());
+            GT_HIP(ctx, hipGetLastError());
+        }
     }
     uint32_t fl = 0, kfl = 0;
     GT_HIP(ctx, hipMemcpyAsync(&fl, g->flags.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));

@@ -509,12 +509,19 @@ __global__ __launch_bounds__(256) void sym_orphan_cut_kernel(const int64_t n, co
                                                              const double* __restrict__ ymax2p, const ErrModel err,
                                                              const double* __restrict__ acc, const double cut,
                                                              const int orphan_far, const int need_m,
-                                                             const double pair_frac) {
+                                                             const double pair_frac, const uint32_t* __restrict__ cell_sorted,
+                                                             const uint32_t outlier_cell) {
     const int64_t p = int64_t(blockIdx.x) * 256 + threadIdx.x;
     if (p >= n) return;
     const float t = thr[p];
     if (t == INFINITY || !(t > -3.0e38f)) return;
     bool orphan = orphan_far > 0 && farcnt && farcnt[p] * float(orphan_far) >= float(need_m);
+    // the rows of the outlier cell (gt_order.hip: far from every landmark): as queries they would be undecided against every
+    // tile - one query group walking the whole point set while the launch waits for it - and their lists would overflow anyway
+    // (option select_sym_outlier_orphans; off by default: on manifold-like data the cell holds the natural tail of the
+    //  distribution - two thousand rows whose repairs cost 11 ms - and the walk it was meant to shorten is not the bound
+    //  pass's problem)
+    if (cell_sorted && cell_sorted[p] == outlier_cell) orphan = true;
     if (!orphan && cut > 0.0 && acc[1] > 0.0) {
         const double lb = sym_row_lb(t, xn[perm[p]], ymax2p[0], err);
         const double typical_pair = acc[3] > 0.0 ? acc[2] / acc[3] : 0.0;
@@ -1290,7 +1297,9 @@ int gt_sym_orphan_cut(gt_ctx* ctx, const int32_t* perm, float* thr, const float*
                       int need_m, double pair_frac) {
     hipLaunchKernelGGL(sym_orphan_cut_kernel, dim3((unsigned)ceil_div64(ctx->n, 256)), dim3(256), 0, ctx->stream, ctx->n, perm,
                        ctx->xn.as<double>(), thr, farcnt, ctx->ymax.as<double>(), err, acc, ctx->sym_radius_cut,
-                       ctx->sym_orphan_far, need_m, pair_frac);
+                       ctx->sym_orphan_far, need_m, pair_frac,
+                       (ctx->sym_outlier_orphans != 0 && ctx->order_outlier_cell >= 0 && ctx->order_cell.p) ? ctx->order_cell.as<uint32_t>() + ctx->n : (const uint32_t*)nullptr,
+                       uint32_t(ctx->order_outlier_cell >= 0 ? ctx->order_outlier_cell : 0));
     GT_HIP(ctx, hipGetLastError());
     return GT_OK;
 }

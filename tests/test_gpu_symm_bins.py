@@ -186,7 +186,7 @@ def test_pair_resolved_tail_equals_the_general_tail(n, d, maker, seed, kw):
 
 def test_pair_resolved_tail_gives_way_to_hub_rows():
     """a point set with a hub (many rows keep one row that keeps few of them): its union row is longer than the register sorts
-    hold - the build is redone the general way and the verdict sticks"""
+    hold - that row is sorted by rocPRIM's segmented sort behind the others (same bits as the general tail)"""
     rng = np.random.default_rng(8)
     X = make_mix(24000, 12, 8)
     X[:4000] = X[4000] + 0.35 * rng.standard_normal((4000, 12)).astype(np.float32)    # a dense knot around one point
@@ -195,8 +195,14 @@ def test_pair_resolved_tail_gives_way_to_hub_rows():
     for x, y in zip(a, b):
         _same(x, y)
     lens = np.diff(a[0][0][2])
-    if lens.max() > 2048:
-        assert a[0][2] == "general" and a[1][2] == "general"
-        # the refuted first attempt stays in the stage timers (its launches are counted next to the second attempt's); once the
-        # verdict is in, a build is one attempt
-        assert a[0][5] == 2 * a[1][5] and a[1][5] == b[0][5]
+    assert lens.max() > 2048, "the case holds no row beyond the register sorts"
+    # round 4: such rows are finished by a segmented sort behind the others - the pair-resolved tail stays, one attempt
+    assert a[0][2] == "pairs" and a[1][2] == "pairs" and a[0][5] == b[0][5]
+    # ... and where the option says so they refute the path as they used to: the build is redone the general way, the refuted
+    # first attempt stays in the stage timers (its launches are counted next to the second attempt's); once the verdict is in,
+    # a build is one attempt
+    c = _build_pairs(X, 1, knn=4, decay=3.0, opts=(("symmetrize_pairs_huge", 0),))
+    for x, y in zip(c, b):
+        _same(x, y)
+    assert c[0][2] == "general" and c[1][2] == "general"
+    assert c[0][5] == 2 * c[1][5] and c[1][5] == b[0][5]

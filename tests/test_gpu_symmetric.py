@@ -344,3 +344,48 @@ def test_cosine_graph_at_the_size_where_the_pass_engages_by_itself():
         ctx.close()
     for a, b in zip(out["auto"], out["0"]):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("kind", ["isolated points", "points between clusters", "both, float64"])
+def test_rows_that_belong_to_no_cluster_do_not_change_the_graph(kind):
+    """Real data holds rows far from everything.  They used to inflate the ball of the landmark cell they fell into (the bound
+    pass then left millions of units and gave up) and, as hubs of the transpose, to refute the pair-resolved tail (the build
+    was done twice).  Round 4: such rows get a cell of their own (gt_order.hip), union rows beyond the register sorts are
+    finished by a segmented sort (gt_sparse.hip).  The graph must be what the classic pass over the whole matrix with the
+    general tail builds - K (structure, values) and P bit for bit (graphs.py:771-982, base.py:557-646)."""
+    from graphtools_amd import _hip
+
+    n, d = 200000, 32
+    rng = np.random.default_rng(11)
+    X = make_mix(n, d, 7)
+    if kind != "points between clusters":
+        idx = rng.choice(n, 12, replace=False)
+        X[idx] = rng.uniform(-12, 12, (12, d)).astype(np.float32)
+    if kind != "isolated points":
+        idx = rng.choice(n, 300, replace=False)
+        X[idx] = (0.5 * (X[idx] + X[rng.choice(n, 300)])).astype(np.float32)
+    if kind == "both, float64":
+        X = X.astype(np.float64)
+    res = {}
+    for tag, opts in (("default", {}), ("classic", {"select_symmetric": "0", "symmetrize_pairs": "0"}),
+                      ("no outlier cell", {"query_order_outliers": "0"})):
+        c = _hip.Context(0)
+        for k, v in opts.items():
+            c.set_option(k, v)
+        c.set_points(X)
+        p, keep = c.make_params(15, 40.0, 1e-4, None, 1.0, None, "+", None, 0)
+        nnz, flags = c.graph_build(p)
+        K = c.graph_fetch_csr(_hip.CSR_K)
+        P = c.graph_fetch_csr(_hip.CSR_P, structure=False)[0]
+        st = c.knn_stats()
+        res[tag] = (K, P, nnz, bool(st["symmetric"]), c.stage_launches("symm_huge"))
+        c.close()
+    assert res["default"][3] and not res["classic"][3]
+    for tag in ("default", "no outlier cell"):
+        for a, b in zip(res[tag][0], res["classic"][0]):
+            assert np.array_equal(a, b), tag
+        assert np.array_equal(res[tag][1], res["classic"][1]), tag
+    # (a union row beyond the register sorts - the isolated points' rows usually are - took the segmented sort)
+    assert (res["default"][4] == 1) == (np.diff(res["default"][0][2]).max() > 2048)
+    if kind == "isolated points":
+        assert res["default"][4] == 1
