@@ -505,8 +505,23 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
                     GT_TRY(gt_sym_g_from_thr(ctx, n_pad_s, k->thr_final.as<float>(), k->hnegs.as<float>(), k->sym_g.as<float>(),
                                              k->sym_gmin.as<float>()));
                 }
-                if (ctx->dbg_select & 2048)
+                if (ctx->dbg_select & 2048) {
                     fprintf(stderr, "[gt] bound pass: %u units left (capacity %lld)\n", bound_left, (long long)bcap);
+                    if (int64_t(bound_left) <= bcap && bound_left > 0) {   // development: how the units spread over the query groups
+                        std::vector<uint2> q(bound_left);
+                        (void)hipMemcpy(q.data(), k->sym_qdense.p, size_t(bound_left) * sizeof(uint2), hipMemcpyDeviceToHost);
+                        std::vector<uint32_t> per(size_t(n_pad_s / 64), 0u);
+                        for (auto& u : q) per[u.x] += 1u;
+                        uint32_t mx = 0, arg = 0;
+                        uint64_t over1k = 0;
+                        for (size_t g = 0; g < per.size(); ++g) {
+                            if (per[g] > mx) mx = per[g], arg = uint32_t(g);
+                            if (per[g] > 1000u) ++over1k;
+                        }
+                        fprintf(stderr, "[gt] bound pass: most units in one query group %u (group %u of %zu), groups with more than 1000 units %llu\n",
+                                mx, arg, per.size(), (unsigned long long)over1k);
+                    }
+                }
             }
             if (two_stage && !bound_done) GT_TRY(gt_sym_two_stage_prepare(ctx, perm, n_pad_s, em, need_m, a, bound_tried));
             const bool two_now = bound_done || a.sym.half_steps > 0;

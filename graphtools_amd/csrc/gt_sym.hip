@@ -1089,7 +1089,8 @@ __global__ __launch_bounds__(256) void bound_queue_kernel(const int nq64, const 
                                                          const int32_t* __restrict__ start, const int32_t* __restrict__ endp,
                                                          const uint32_t* __restrict__ mask, const int words,
                                                          uint2* __restrict__ queue, const uint32_t cap,
-                                                         uint32_t* __restrict__ count, const double* __restrict__ forecast) {
+                                                         uint32_t* __restrict__ count, const double* __restrict__ forecast,
+                                                         const int64_t n_rows) {
     // four groups of 64 queries per workgroup: their slots come from ONE returning atomic (15 600 of them, one per group, were
     // half of this kernel's time)
     __shared__ uint32_t wtot[4], wbase;
@@ -1125,6 +1126,23 @@ __global__ __launch_bounds__(256) void bound_queue_kernel(const int nq64, const 
     // two rounds: count this wave's units, take their slots with ONE atomic (a device-scope counter serves ~90 returning
     // atomics per microsecond: one per unit would cost more than the collect launch saves), then write them
     uint32_t mine = 0u, slot = 0u, all_ranks = 0u;   // all_ranks: the units of EVERY rank's pieces (row-sharded builds)
+    // A group that holds rows of a cell undecided against EVERY cell (the outlier cell of gt_order.hip: a ball as wide as the
+    // point set) needs every tile of its walk, whatever its other cells say: the tiles are counted and filed by arithmetic,
+    // 64 lanes side by side - not cell by cell through the mask (one lane per 32 cells, three dependent loads per tile: 1.5 ms
+    // for the one group that holds the cell while the whole launch waits for it)
+    bool all_open = false;
+    if (active)
+        for (uint32_t a = qlo; a <= qhi && !all_open; ++a) {
+            bool row_open = true;
+            for (int w0 = 0; w0 < words; w0 += 64) {
+                const int wd = w0 + lane;
+                if (wd < words) {
+                    const uint32_t full = (wd * 32 + 32 <= L) ? 0xFFFFFFFFu : ((1u << (L - wd * 32)) - 1u);
+                    row_open &= (~mask[size_t(a) * words + wd] & full) == full;
+                }
+            }
+            all_open = __all(row_open) != 0;
+        }
   for (int round = 0; round < 2; ++round) {
     if (round == 1) {
         uint32_t inc = mine;
@@ -1154,7 +1172,23 @@ __global__ __launch_bounds__(256) void bound_queue_kernel(const int nq64, const 
         for (int v = 0; v < w; ++v) base += wtot[v];
         slot = base + inc - mine;
     }
-    if (active)
+    if (active && all_open) {
+        const uint32_t nt_real = uint32_t((n_rows + 31) / 32);
+        for (uint32_t d32 = uint32_t(lane); d32 < nt_real; d32 += 64u) {
+            int rel = int(d32 / 4u) - blk * TPB;
+            if (rel < 0) rel += T;
+            if (!own_full && rel >= walk) continue;
+            const bool own_piece = own_full || (rel >= rel_lo && rel < rel_hi);
+            if (!own_piece && (world == 1 || round == 1)) continue;
+            if (round == 0) {
+                ++all_ranks;
+                if (own_piece) ++mine;
+            } else {
+                if (slot < cap) queue[slot] = make_uint2(q64, d32);
+                ++slot;
+            }
+        }
+    } else if (active)
     for (uint32_t a = qlo; a <= qhi; ++a) {
         for (int w0 = 0; w0 < words; w0 += 64) {
             const int wd = w0 + lane;
@@ -1471,13 +1505,13 @@ int gt_sym_bound_queue(gt_ctx* ctx, int64_t n_pad_s, const void* Ys, const float
         // the rank's own query groups [own_p0 / 64, own_p1 / 64) against every sub-tile (own_p0 a multiple of 64)
         const int q_lo = int(own_p0 / 64), q_hi = int((own_p1 + 63) / 64);
         hipLaunchKernelGGL(bound_queue_kernel, dim3((unsigned)((q_hi - q_lo + 3) / 4)), dim3(256), 0, ctx->stream, q_hi, T, TPB, walk, L,
-                           1, 0, 1, q_lo, 1, tcell, start, endp, mask, words, queue, cap, count_dev, est_ptr);
+                           1, 0, 1, q_lo, 1, tcell, start, endp, mask, words, queue, cap, count_dev, est_ptr, ctx->n);
         GT_HIP(ctx, hipGetLastError());
         return GT_OK;
     }
     hipLaunchKernelGGL(bound_queue_kernel, dim3((unsigned)((NB * 2 * TPB + 3) / 4)), dim3(256), 0, ctx->stream, NB * 2 * TPB, T, TPB, walk, L,
                        std::max(world, 1), rank, std::max(group, 1), 0, 0, tcell, start,
-                       endp, mask, words, queue, cap, count_dev, est_ptr);
+                       endp, mask, words, queue, cap, count_dev, est_ptr, ctx->n);
     GT_HIP(ctx, hipGetLastError());
     return GT_OK;
 }
