@@ -1,5 +1,5 @@
 """GPU: the decision ladder picks between candidate passes that are 2-10 x apart on a given data family.
-Whatever it picks is exact (the other tests); this one bounds how badly `auto` can LOSE: on eight data families at
+Whatever it picks is exact (the other tests); this one bounds how badly `auto` can LOSE: on nine data families at
 N = 2e5 the default build must not take more than 1.5 x the time of the better of the two forced routes (symmetric pass forced
 on / classic pass forced) - plus 1 ms, the granularity of the fixed costs at this size.  Reference semantics are not involved:
 all three builds produce the same graph (asserted)."""
@@ -39,6 +39,14 @@ def _hubs(seed):
     return X
 
 
+def _isolated(seed):
+    rng = np.random.default_rng(seed)
+    X = make_mix(N, 48, seed)
+    idx = rng.choice(N, 15, replace=False)
+    X[idx] = rng.uniform(-12, 12, (15, 48)).astype(np.float32)   # rows that belong to no cluster (round 4: 4.7 x the build time then)
+    return X
+
+
 FAMILIES = {
     "mix d=64": lambda: make_mix(N, 64, 1),
     "mix, clusters of unequal scale d=32": lambda: _unequal_scales(2),
@@ -48,6 +56,7 @@ FAMILIES = {
     "isotropic gauss d=64": lambda: make_gauss(N, 64, 6),
     "mix with hubs d=32": lambda: _hubs(7),
     "mix shifted far from the origin d=64": lambda: (make_mix(N, 64, 8) + np.float32(300.0)),
+    "mix with 15 isolated points d=48": lambda: _isolated(9),
 }
 
 
