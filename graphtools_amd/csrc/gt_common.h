@@ -167,6 +167,7 @@ struct gt_ctx {
     int32_t xcd_chunk = 0;      //   row-walking kernels: work items per XCD chunk (gt_device.h gt_xcd_item), 0 = one contiguous eighth per XCD
     int32_t rerank_lanes4 = 1;  //   re-rank of the symmetric pass: four lanes per candidate row (float32 rows, d % 4 == 0, d <= 128)
     int32_t sym_dense_seed = 1; //   threshold-seeding launch: 1 = dense cell blocks, keys in registers (gt_seed.hip), 0 = streaming lists
+    int32_t sym_cells_shard = 12;   //   ... at least this many in the row-sharded passes (gt_knn_shard.cpp)
     int32_t sym_cells = 8;     //   ... which is the rows of this many nearest cells (landmarks) of the block's own cells (12 until round 4's sweep),
     int32_t sym_max_nb = 384;   //   at most this many tiles
     int32_t sym_tcap = 512;     //   capacity of a row's candidate list in launch B (<= 512)

@@ -19,6 +19,11 @@
 #include "gt_knn.h"
 #include "gt_knn_select.h"
 
+// cells whose rows seed a row's thresholds in the row-sharded passes: a rank pays the fixed cost of the repair pass (launches,
+// read-backs: 0.4 ms) as soon as ONE of its rows needs it, so the neighbourhood stays wider than the single-GPU default
+// (8 since round 4's sweep: rank 0 of 8 on C3 repairs nothing with 12 cells, a handful of rows with 8 - 4.89 against 5.20 ms)
+static inline int shard_cells(const gt_ctx* ctx) { return std::max(ctx->sym_cells, ctx->sym_cells_shard); }
+
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -236,7 +241,7 @@ int gt_knn_shard_local(gt_ctx* ctx, int64_t r0, int64_t r1, int need_m, double r
         StageSpan span(ctx, "sym_prepare");
         // the compact copy padded to whole 1024-row blocks (the order is the identity: a copy with pad rows)
         GT_TRY(gt_sym_gather(ctx, perm, n_pad_s, k->Ycs.p, k->hnegs.as<float>(), k->hnegs_fin.as<float>()));
-        GT_TRY(gt_sym_schedule(ctx, n_pad_s, bq, bn, ctx->sym_cells, stride_a, ctx->sym_max_nb, tile_stride, k->sym_work,
+        GT_TRY(gt_sym_schedule(ctx, n_pad_s, bq, bn, shard_cells(ctx), stride_a, ctx->sym_max_nb, tile_stride, k->sym_work,
                                k->sym_tiles.as<int32_t>(), k->sym_tile_cnt.as<int32_t>(),
                                k->sym_stat.as<unsigned long long>() + 5, p0, p1));
         // every row that is not the rank's: no threshold (+inf: asks for nothing, admits nothing, has no radius)
@@ -260,7 +265,7 @@ int gt_knn_shard_local(gt_ctx* ctx, int64_t r0, int64_t r1, int need_m, double r
             StageSpan span(ctx, "sym_prepare");
             GT_TRY(gt_sym_thresholds(ctx, perm, n_pad_s, k->hnegs.as<float>(), lists0, 64, k->counts.as<uint32_t>(), need_m, em,
                                      std::max(1.0, std::fabs(rkf)), k->thr_final.as<float>(), k->sym_g.as<float>(), nullptr,
-                                     k->sym_work, ctx->sym_cells, k->sym_stat.as<unsigned long long>() + 2,
+                                     k->sym_work, shard_cells(ctx), k->sym_stat.as<unsigned long long>() + 2,
                                      k->sym_farcnt.as<float>(), p0, p0 + ps));
             GT_HIP(ctx, hipMemcpyAsync(&far_s, k->sym_stat.as<unsigned long long>() + 2, sizeof(far_s), hipMemcpyDeviceToHost, ctx->stream));
             GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -288,7 +293,7 @@ int gt_knn_shard_local(gt_ctx* ctx, int64_t r0, int64_t r1, int need_m, double r
         if (seeded_to < p1)
             GT_TRY(gt_sym_thresholds(ctx, perm, n_pad_s, k->hnegs.as<float>(), lists0, 64, k->counts.as<uint32_t>(), need_m, em,
                                      std::max(1.0, std::fabs(rkf)), k->thr_final.as<float>(), k->sym_g.as<float>(), nullptr,
-                                     k->sym_work, ctx->sym_cells, k->sym_stat.as<unsigned long long>() + 2,
+                                     k->sym_work, shard_cells(ctx), k->sym_stat.as<unsigned long long>() + 2,
                                      k->sym_farcnt.as<float>(), seeded_to, p1));
         GT_TRY(gt_sym_radius_sum(ctx, perm, p0, std::min<int64_t>(p1, ctx->n), k->thr_final.as<float>(), em, k->sym_racc.as<double>()));
         GT_HIP(ctx, hipMemsetAsync(k->tcounts.p, 0, size_t(n_pad_s) * sizeof(uint32_t), ctx->stream));
@@ -472,7 +477,7 @@ int gt_knn_shard_seed(gt_ctx* ctx, float* thr_local, int64_t* far_local, double*
         GT_HIP(ctx, k->hnegs_fin.reserve(size_t(n_pad_s) * sizeof(float)));
         GT_TRY(gt_sym_gather(ctx, perm, n_pad_s, k->Ycs.p, k->hnegs.as<float>(), k->hnegs_fin.as<float>()));
         if (ctx->sym_sorted_points != 0) GT_TRY(gt_sym_gather_points(ctx, perm));
-        GT_TRY(gt_sym_schedule(ctx, n_pad_s, bq, bn, ctx->sym_cells, stride_a, ctx->sym_max_nb, tile_stride, k->sym_work,
+        GT_TRY(gt_sym_schedule(ctx, n_pad_s, bq, bn, shard_cells(ctx), stride_a, ctx->sym_max_nb, tile_stride, k->sym_work,
                                k->sym_tiles.as<int32_t>(), k->sym_tile_cnt.as<int32_t>(),
                                k->sym_stat.as<unsigned long long>() + 5));   // (tiles of ALL blocks; this rank walks 1/world)
     }
@@ -540,7 +545,7 @@ int gt_knn_shard_seed(gt_ctx* ctx, float* thr_local, int64_t* far_local, double*
         StageSpan span(ctx, "sym_prepare");
         GT_TRY(gt_sym_thresholds(ctx, perm, n_pad_s, k->hnegs.as<float>(), lists0, int(lstride), k->counts.as<uint32_t>(), need_m,
                                  em, std::max(1.0, std::fabs(k->sh_rkf)), k->thr_final.as<float>(), k->sym_g.as<float>(),
-                                 nullptr, k->sym_work, ctx->sym_cells, k->sym_stat.as<unsigned long long>() + 2,
+                                 nullptr, k->sym_work, shard_cells(ctx), k->sym_stat.as<unsigned long long>() + 2,
                                  k->sym_farcnt.as<float>(), p0, p1));
         // {threshold, far-kept seeds} of every position of the share, interleaved, to the caller
         GT_HIP(ctx, hipMemcpy2DAsync(thr_local, 2 * sizeof(float), k->thr_final.as<float>() + p0, sizeof(float), sizeof(float),

@@ -138,8 +138,11 @@ int gt_order_cells_partial(gt_ctx* ctx, int64_t row0, int64_t row1, uint32_t* ce
     GT_HIP(ctx, ctx->land_X.reserve(size_t(L) * ctx->d * esz));
     GT_HIP(ctx, ctx->land_Yp.reserve(size_t(L) * ctx->DP * sizeof(float)));
     GT_HIP(ctx, ctx->land_xn.reserve(size_t(L) * sizeof(double)));
-    GT_HIP(ctx, ctx->land_Y.reserve(size_t(L) * rw * sizeof(uint32_t)));
-    GT_HIP(ctx, ctx->land_h.reserve(size_t(L) * sizeof(float)));
+    // (one row more: the stand-in of the outlier cell, as in gt_query_order)
+    GT_HIP(ctx, ctx->land_Y.reserve(size_t(L + 1) * rw * sizeof(uint32_t)));
+    GT_HIP(ctx, ctx->land_h.reserve(size_t(L + 1) * sizeof(float)));
+    GT_HIP(ctx, hipMemsetAsync(ctx->land_Y.as<uint32_t>() + size_t(L) * rw, 0, size_t(rw) * sizeof(uint32_t), ctx->stream));
+    GT_HIP(ctx, hipMemsetAsync(ctx->land_h.as<float>() + L, 0, sizeof(float), ctx->stream));
     hipLaunchKernelGGL(gather_strided_rows_kernel, dim3((unsigned)ceil_div64(int64_t(L) * rw_raw, 256)), dim3(256), 0, ctx->stream,
                        static_cast<const uint32_t*>(ctx->X), step, L, rw_raw, ctx->land_X.as<uint32_t>());
     GT_HIP(ctx, hipGetLastError());
@@ -157,10 +160,31 @@ int gt_order_cells_partial(gt_ctx* ctx, int64_t row0, int64_t row1, uint32_t* ce
         const char* Xs = static_cast<const char*>(ctx->X) + size_t(row0) * ctx->d * esz;
         GT_TRY(gt_prep_matrix(ctx, Xs, nloc, ctx->d, ctx->dtype, ctx->DP, nloc, ctx->Yp.as<float>(), ctx->xn.as<double>(),
                               ctx->hneg.as<float>(), nullptr, 1, ctx->sc, nullptr, ctx->Yc.p));
+        // the outlier cell (see above): decided for the share from the share's own statistics - the shares are slices of the
+        // caller's rows, the cells of all rows are gathered afterwards: one numbering everywhere, whatever each rank decided
+        const bool outliers = ctx->order_outliers != 0;
+        float* best = nullptr;
+        if (outliers) {
+            GT_HIP(ctx, ctx->order_tmp.reserve(size_t(nloc) * sizeof(float) + 64));
+            best = ctx->order_tmp.as<float>();
+        }
         GT_TRY(gt_launch_assign_cells(ctx, ctx->DP, ctx->Yc.as<float>(), ctx->land_Y.as<float>(), ctx->land_h.as<float>(), 0,
-                                      int32_t(nloc), L, 1, cells_out, ctx->order_rows.as<float>()));
+                                      int32_t(nloc), L, 1, cells_out, ctx->order_rows.as<float>(), best));
+        if (outliers) {
+            double* acc = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(best + nloc) + 7) & ~uintptr_t(7));
+            uint32_t* counts = reinterpret_cast<uint32_t*>(acc + 1);
+            GT_HIP(ctx, hipMemsetAsync(acc, 0, sizeof(double) + kOutlierTaus * sizeof(uint32_t), ctx->stream));
+            const unsigned grid = (unsigned)std::min<int64_t>(ceil_div64(nloc, 256), int64_t(ctx->n_cu) * 2);
+            hipLaunchKernelGGL(outlier_sum_kernel, dim3(grid), dim3(256), 0, ctx->stream, nloc, int64_t(0), ctx->hneg.as<float>(), best, acc);
+            hipLaunchKernelGGL(outlier_count_kernel, dim3(grid), dim3(256), 0, ctx->stream, nloc, int64_t(0), ctx->hneg.as<float>(), best, acc,
+                               counts);
+            const uint32_t cap = uint32_t(std::max<int64_t>(8, nloc / 512));
+            hipLaunchKernelGGL(outlier_relabel_kernel, dim3((unsigned)ceil_div64(nloc, 256)), dim3(256), 0, ctx->stream, nloc, int64_t(0),
+                               ctx->hneg.as<float>(), best, acc, counts, cap, uint32_t(L), cells_out);
+            GT_HIP(ctx, hipGetLastError());
+        }
     }
-    ctx->cells_L = L;
+    ctx->cells_L = L + (ctx->order_outliers != 0 ? 1 : 0);
     *active = 1;
     return GT_OK;
 }
@@ -188,7 +212,7 @@ int gt_order_sort_cells(gt_ctx* ctx, const uint32_t* cells_all, int32_t* out_row
                                           size_t(n), 0u, unsigned(bits), ctx->stream));
     ctx->order_L = L;
     ctx->order_has_thr0 = 0;
-    ctx->order_outlier_cell = -1;
+    ctx->order_outlier_cell = ctx->order_outliers != 0 ? L - 1 : -1;
     return GT_OK;
 }
 
