@@ -1090,7 +1090,8 @@ __global__ __launch_bounds__(256) void bound_queue_kernel(const int nq64, const 
                                                          const uint32_t* __restrict__ mask, const int words,
                                                          uint2* __restrict__ queue, const uint32_t cap,
                                                          uint32_t* __restrict__ count, const double* __restrict__ forecast,
-                                                         const int64_t n_rows) {
+                                                         const int64_t n_rows, unsigned long long* __restrict__ dbg_cyc) {
+    const unsigned long long t_begin = dbg_cyc ? __builtin_readcyclecounter() : 0ull;
     // four groups of 64 queries per workgroup: their slots come from ONE returning atomic (15 600 of them, one per group, were
     // half of this kernel's time)
     __shared__ uint32_t wtot[4], wbase;
@@ -1137,7 +1138,8 @@ __global__ __launch_bounds__(256) void bound_queue_kernel(const int nq64, const 
             for (int w0 = 0; w0 < words; w0 += 64) {
                 const int wd = w0 + lane;
                 if (wd < words) {
-                    const uint32_t full = (wd * 32 + 32 <= L) ? 0xFFFFFFFFu : ((1u << (L - wd * 32)) - 1u);
+                    uint32_t full = (wd * 32 + 32 <= L) ? 0xFFFFFFFFu : ((1u << (L - wd * 32)) - 1u);
+                    if (int(a >> 5) == wd) full &= ~(1u << (a & 31u));   // (a cell against itself is whatever cell_mask_kernel says: not asked)
                     row_open &= (~mask[size_t(a) * words + wd] & full) == full;
                 }
             }
@@ -1167,7 +1169,10 @@ __global__ __launch_bounds__(256) void bound_queue_kernel(const int nq64, const 
             wbase = sum != 0u ? atomicAdd(count, sum) : 0u;
         }
         __syncthreads();
-        if (total == 0u) return;
+        if (total == 0u) {
+            if (dbg_cyc && lane == 0) dbg_cyc[q64] = __builtin_readcyclecounter() - t_begin;
+            return;
+        }
         uint32_t base = wbase;
         for (int v = 0; v < w; ++v) base += wtot[v];
         slot = base + inc - mine;
@@ -1233,6 +1238,7 @@ __global__ __launch_bounds__(256) void bound_queue_kernel(const int nq64, const 
         }
     }
   }
+    if (dbg_cyc && lane == 0) dbg_cyc[q64] = __builtin_readcyclecounter() - t_begin;
 }
 
 }  // namespace
@@ -1499,20 +1505,45 @@ int gt_sym_bound_queue(gt_ctx* ctx, int64_t n_pad_s, const void* Ys, const float
         GT_HIP(ctx, hipGetLastError());
         est_ptr = est_dev;   // (read by the enumeration itself: no trip to the host)
     }
+    unsigned long long* dbg_cyc = nullptr;
+    DevBuf dbg_buf;
+    if (ctx->dbg_select & 4096) {   // development: cycles per query group of the enumeration
+        GT_HIP(ctx, dbg_buf.reserve(size_t(n_pad_s / 64 + 8) * sizeof(unsigned long long)));
+        GT_HIP(ctx, hipMemsetAsync(dbg_buf.p, 0, size_t(n_pad_s / 64 + 8) * sizeof(unsigned long long), ctx->stream));
+        dbg_cyc = dbg_buf.as<unsigned long long>();
+    }
     const int T = int(n_pad_s / 128), TPB = 8, NB = T / TPB, H = (NB - 1) / 2;
     const int walk = TPB * (1 + H) + ((NB & 1) ? 0 : (NB > 1 ? TPB : 0));
     if (own_p1 > own_p0) {
         // the rank's own query groups [own_p0 / 64, own_p1 / 64) against every sub-tile (own_p0 a multiple of 64)
         const int q_lo = int(own_p0 / 64), q_hi = int((own_p1 + 63) / 64);
         hipLaunchKernelGGL(bound_queue_kernel, dim3((unsigned)((q_hi - q_lo + 3) / 4)), dim3(256), 0, ctx->stream, q_hi, T, TPB, walk, L,
-                           1, 0, 1, q_lo, 1, tcell, start, endp, mask, words, queue, cap, count_dev, est_ptr, ctx->n);
+                           1, 0, 1, q_lo, 1, tcell, start, endp, mask, words, queue, cap, count_dev, est_ptr, ctx->n, dbg_cyc);
         GT_HIP(ctx, hipGetLastError());
         return GT_OK;
     }
     hipLaunchKernelGGL(bound_queue_kernel, dim3((unsigned)((NB * 2 * TPB + 3) / 4)), dim3(256), 0, ctx->stream, NB * 2 * TPB, T, TPB, walk, L,
                        std::max(world, 1), rank, std::max(group, 1), 0, 0, tcell, start,
-                       endp, mask, words, queue, cap, count_dev, est_ptr, ctx->n);
+                       endp, mask, words, queue, cap, count_dev, est_ptr, ctx->n, dbg_cyc);
     GT_HIP(ctx, hipGetLastError());
+    if (dbg_cyc) {
+        std::vector<unsigned long long> cyc(size_t(n_pad_s / 64));
+        GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        (void)hipMemcpy(cyc.data(), dbg_cyc, cyc.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        std::vector<std::pair<unsigned long long, size_t>> top;
+        for (size_t g = 0; g < cyc.size(); ++g) top.emplace_back(cyc[g], g);
+        std::sort(top.rbegin(), top.rend());
+        const uint32_t* cs = ctx->order_cell.as<uint32_t>() + ctx->n;
+        for (int t = 0; t < 6 && t < int(top.size()); ++t) {
+            uint32_t c0 = 0, c1 = 0;
+            (void)hipMemcpy(&c0, cs + std::min<size_t>(top[t].second * 64, size_t(ctx->n - 1)), 4, hipMemcpyDeviceToHost);
+            (void)hipMemcpy(&c1, cs + std::min<size_t>(top[t].second * 64 + 63, size_t(ctx->n - 1)), 4, hipMemcpyDeviceToHost);
+            fprintf(stderr, "[gt] bound queue: group %zu took %llu cycles (cells %u .. %u)\n", top[t].second, top[t].first, c0, c1);
+        }
+        unsigned long long med = top[top.size() / 2].first;
+        fprintf(stderr, "[gt] bound queue: median group %llu cycles\n", med);
+        dbg_buf.release();
+    }
     return GT_OK;
 }
 
