@@ -177,7 +177,7 @@ struct gt_ctx {
                                     //   two-stage forecast have failed too
     int32_t sym_ok = -1;        //   auto: 0 once the bound point set has overflowed the lists of launch B (reset by gt_set_points)
     int32_t sym_nseg = 0;       //   work items per query block in launch B (0: chosen to fill the last round of workgroups)
-    int32_t sym_orphan_far = 4;  //  a row is an orphan when this many times its far-kept seeds reach the seeds wanted (0: off)
+    int32_t sym_orphan_far = 0;  //  a row is an orphan when this many times its far-kept seeds reach the seeds wanted (0: off - the default since the end of round 4: the rule sent ~150 rows of C3 to the repair pass that the lists hold without it; 4 until then)
     double sym_radius_cut = 4.0; //  rows whose completeness radius (squared) exceeds this many times the mean are repaired directly
     int32_t sym_two_stage = -1; //   launch B scores half the features first (partial distances): -1 auto, 0 off, 1 on
     int32_t symm_bins = -1;     // single-rank symmetrisation through destination bins (gt_sparse.hip): -1 auto, 0 off, 1 on
