@@ -384,15 +384,21 @@ def secondary_c4(_hip, torch, device, n=200000, d=100):
         ctx._check(rc, "gt_dense_graph_build")
         ctx.sync()
         wall = time.perf_counter() - t0
-        st = {s: round(ctx.stage_ms(s), 2) for s in ("dense_bandwidth", "dense_rows_scan", "dense_kernel", "dense_normalize")}
+        st = {s: round(ctx.stage_ms(s), 2) for s in ("dense_bandwidth", "dense_rows_scan", "dense_kernel", "dense_rows_transpose",
+                                                     "dense_normalize")}
         row_sums = float(D[:4096].double().sum(dim=1).sub(1.0).abs().max().item())   # diff_op rows sum to 1 (float32 entries)
         # bytes this run needs (round-3 verdict: price what runs).  Row-streaming form (round 4, what runs by default): D read once
-        # for the bandwidths (4 N^2), once for the row sums and the list of kept affinities (4 N^2), once more while P is written
-        # over it (8 N^2).  Tile-pair form: bandwidths 4 N^2, K with fused row sums 8 N^2, normalisation 8 N^2.
+        # for the bandwidths (4 N^2), which also gives the row sums and the list of kept affinities (else: a scan of its own,
+        # 4 N^2); P written over it (4 N^2: zeros streamed, the listed entries placed - or 8 N^2 when the rows are read again).
+        # Tile-pair form: bandwidths 4 N^2, K with fused row sums 8 N^2, normalisation 8 N^2.
         rows_form = st["dense_rows_scan"] > 0
         listed = ctx.stage_launches("dense_rows_listed") > 0    # the bandwidth pass listed the kept affinities: no scan of its own
-        nbytes = ((12.0 if listed else 16.0) if rows_form else 20.0) * n * n
-        note = ("12 N^2 bytes as run (row-streaming form): 4 N^2 bandwidth pass, which also lists the rows' kept affinities, 8 N^2 write "
+        placed = ctx.stage_launches("dense_rows_placed") > 0    # the write pass read no row
+        nbytes = (((8.0 if placed else 12.0) if listed else 16.0) if rows_form else 20.0) * n * n
+        note = ("8 N^2 bytes as run (row-streaming form): 4 N^2 read by the bandwidth pass, which also lists the rows' kept affinities, "
+                "4 N^2 written by the write pass (zeros streamed over the distances, the listed entries and their transposed partners "
+                "placed: the matrix is read ONCE)") if rows_form and listed and placed else (
+                "12 N^2 bytes as run (row-streaming form): 4 N^2 bandwidth pass, which also lists the rows' kept affinities, 8 N^2 write "
                 "pass (P over the distances; the transposed half arrives as the list)") if rows_form and listed else (
                 "16 N^2 bytes as run (row-streaming form): 4 N^2 bandwidth pass, 4 N^2 scan (row sums + the kept affinities as a "
                 "list), 8 N^2 write pass (P over the distances; the transposed half arrives as the list)") if rows_form else (

@@ -352,6 +352,10 @@ int gt_set_option(gt_ctx* ctx, const char* name, const char* value) {
         ctx->dense_rows = v == "auto" ? -1 : std::atoi(value);
         return GT_OK;
     }
+    if (k == "dense_rows_reread") {
+        ctx->dense_rows_reread = std::atoi(value) != 0 ? 1 : 0;
+        return GT_OK;
+    }
     if (k == "dense_rows_fused") {
         ctx->dense_rows_fused = std::atoi(value) != 0 ? 1 : 0;
         return GT_OK;

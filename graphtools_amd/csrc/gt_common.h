@@ -154,6 +154,7 @@ struct gt_ctx {
     int32_t samp2_keep = 64;  //   to this many entries (at least 3 * samp_keep)
     int32_t nt8_max_need = 88;  // tables of up to this many neighbours use the 128-entry list budget (else 512)
     int32_t dense_rows = -1;  // exact graph from float32 distances, '+' rule: row-streaming form with the transposed half as a list (-1: from 16384 rows, 0 never, 1 always)
+    int32_t dense_rows_reread = 0; //   its write pass reads every row again and recomputes the affinities (0: zeros streamed, the listed entries placed: three launches)
     int32_t dense_rows_fused = 1; //   its list of kept affinities comes out of the bandwidth pass (0: from a pass of its own)
     int64_t dense_rows_cap = 0;   //   entries its list of kept affinities may hold (0: 1024 per row, at least 2^24; beyond: the tile-pair form)
     int32_t narrow_mode = -1; // 128-row-workgroup candidate kernels: -1 auto (few query rows), 0 never, 1 whenever available

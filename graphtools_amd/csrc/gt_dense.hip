@@ -71,7 +71,12 @@ struct TriList {
     float* a;
     unsigned long long* cursor;   // entries appended so far (may run past cap: the host checks)
     unsigned long long cap;
+    // where a row's own entries sit (its one reservation): the write pass places them from here instead of reading the row again;
+    // own_cnt = kNoOwnList: the row's entries are not in one piece (more of them than the LDS list holds)
+    unsigned long long* own_base;
+    uint32_t* own_cnt;
 };
+constexpr uint32_t kNoOwnList = 0xFFFFFFFFu;
 
 // ---- bandwidth from a precomputed distance matrix: (knn+1)-th smallest of every row --------------
 template <typename T, int KL>
@@ -537,6 +542,8 @@ __global__ __launch_bounds__(256, EMIT ? GT_DENSE_EMIT_WAVES : 1) void dense_ban
         if (tid == 0) {
             em.own_sum[i] = (reds[0] + reds[1]) + (reds[2] + reds[3]);
             const unsigned long long g = nzc ? atomicAdd(em.tl.cursor, (unsigned long long)nzc) : 0ull;   // the row's ONE reservation
+            em.tl.own_base[i] = g;
+            em.tl.own_cnt[i] = nzc;
             base_lo = uint32_t(g);
             base_hi = uint32_t(g >> 32);
         }
@@ -862,11 +869,15 @@ __global__ __launch_bounds__(256) void dense_kernel_tiles(const TD* __restrict__
 //   T   tri_count / scan / tri_scatter   the list transposed: for every row i the entries {j, K0_ji} ("incoming")
 //   S3  dense_rows_write_kernel   one workgroup per row: row sum = (own + incoming) / 2; the incoming entries are merged with
 //                                 the row's own values first (their distances are still there: the row is written by this
-//                                 workgroup only) and parked; the row is streamed once more - (K0_ij + 0) / 2, or / row sum
-//                                 when P is what is wanted - and written; the parked values then overwrite their places.
+//                                 workgroup only) and parked.  Then nothing of the matrix is needed any more: zeros are
+//                                 streamed over it (dense_zero_rows_kernel), every row's own entries - they are in the list -
+//                                 are placed as (K0_ij + 0) / 2, or / row sum when P is what is wanted, and the parked values
+//                                 overwrite their places.  (The first form of this pass streamed every row once more and
+//                                 recomputed its affinities: option dense_rows_reread, and what a row does whose entries are
+//                                 not in one piece of the list.)
 // Every element sees the operations of the tile-pair kernel in the same order ((a + b) / 2, then / float(row sum)): same bits
-// up to the summation order of the float64 row sums.  Bytes: 4 N^2 (S1) + 8 N^2 (S3) instead of 8 N^2 + 8 N^2 (normalisation
-// pass), all of it as whole rows.
+// up to the summation order of the float64 row sums.  Bytes: 4 N^2 read (S1, inside the bandwidth pass) + 4 N^2 written (S3)
+// instead of 4 N^2 + 8 N^2 + 8 N^2 (bandwidths, tile pairs, normalisation pass): the matrix is read ONCE and written once.
 
 __global__ __launch_bounds__(256) void dense_rows_scan_kernel(const float* __restrict__ D, const int64_t n,
                                                               const double* __restrict__ bw, const double decay_d,
@@ -944,6 +955,8 @@ __global__ __launch_bounds__(256) void dense_rows_scan_kernel(const float* __res
     if (threadIdx.x == 0) {
         own_sum[i] = (red[0] + red[1]) + (red[2] + red[3]);
         const unsigned long long g = nl ? atomicAdd(tl.cursor, (unsigned long long)nl) : 0ull;   // the row's ONE reservation
+        tl.own_base[i] = g;
+        tl.own_cnt[i] = lcount <= uint32_t(ROWS_LDS_CAP) ? nl : kNoOwnList;
         lbase_lo = uint32_t(g);
         lbase_hi = uint32_t(g >> 32);
     }
@@ -1016,14 +1029,40 @@ __global__ __launch_bounds__(256) void tri_scatter_kernel(const uint32_t* __rest
     in_val[k] = ta[t];
 }
 
-template <bool DIVIDE>   // DIVIDE: P = K / row sum is written instead of K
+// zeros streamed over the rows whose entries the placement launch will write (the others were written whole by the merge launch)
+__global__ __launch_bounds__(256) void dense_zero_rows_kernel(float* __restrict__ out, const int64_t n,
+                                                              const uint32_t* __restrict__ own_cnt) {
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    f4v z;
+    z[0] = z[1] = z[2] = z[3] = 0.f;
+    const int64_t nv = n / 4;
+    for (int64_t i = blockIdx.x; i < n; i += gridDim.x) {
+        if (own_cnt[i] == kNoOwnList) continue;   // (workgroup-uniform)
+        f4v* ov = reinterpret_cast<f4v*>(out + i * n);
+        for (int64_t j0 = threadIdx.x; j0 < nv; j0 += 256 * 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (j0 + u * 256 < nv) __builtin_nontemporal_store(z, ov + j0 + u * 256);
+        }
+    }
+}
+
+// The write pass.  PART 0: one launch - every row is read again, its affinities recomputed and written, the merged entries placed
+// over them (the first form of this pass: 8 N^2 bytes).  PART 1, dense_zero_rows_kernel, PART 2 - three launches, 4 N^2 bytes: the
+// rows' kept affinities are known (the list the transposition read), so the matrix is not read again - (1) the incoming entries
+// are merged with the row's own values and the row sums formed while the distances are still there, (2) zeros are streamed over
+// the matrix (a pure store stream: 7 TB/s), (3) every row's own entries take their places, (K0_ij + 0) / 2 like the streamed
+// form computes them, then the merged ones.  A row whose own entries are not in one piece of the list (own_cnt = kNoOwnList)
+// is written whole by launch 1, PART 0's way, and left alone by the other two.
+template <bool DIVIDE, int PART>   // DIVIDE: P = K / row sum is written instead of K
 __global__ __launch_bounds__(256) void dense_rows_write_kernel(const float* __restrict__ D, const int64_t n,
                                                                const double* __restrict__ bw, const double decay_d,
                                                                const double thresh_d, const double xcut_d,
                                                                const double* __restrict__ own_sum,
                                                                const unsigned long long* __restrict__ inptr,
                                                                const uint32_t* __restrict__ in_col, float* __restrict__ in_val,
-                                                               double* __restrict__ rowsum, float* __restrict__ out) {
+                                                               double* __restrict__ rowsum, float* __restrict__ out,
+                                                               const TriList own) {
     typedef float f4v __attribute__((ext_vector_type(4)));
     __shared__ double red[4];
     __shared__ float sf_s;
@@ -1035,6 +1074,21 @@ __global__ __launch_bounds__(256) void dense_rows_write_kernel(const float* __re
     // numpy sums is the float32 K): every entry contributes (K0_ij + 0) / 2 = own / 2 unless it has a partner - those contribute
     // their merged, float32-rounded value instead.  Float64 sums of exactly the values the tile-pair kernel sums.
     const float* drow = D + i * n;
+    float* orow = out + i * n;
+    if constexpr (PART == 2) {
+        const uint32_t n_own2 = own.own_cnt[i];
+        if (n_own2 == kNoOwnList) return;   // (workgroup-uniform)
+        const float sf2 = float(rowsum[i] == 0.0 ? 1.0 : rowsum[i]);
+        const unsigned long long b2 = own.own_base[i];
+        for (uint32_t k = threadIdx.x; k < n_own2; k += 256) {
+            float o = merge_t<float>(own.a[b2 + k], 0.f, GT_SYMM_ADD, 1.f);
+            if (DIVIDE) o = o / sf2;
+            orow[own.j[b2 + k]] = o;
+        }
+        __syncthreads();   // (a partnered entry is written twice: the merged value last)
+        for (unsigned long long k = p0 + threadIdx.x; k < p1; k += 256) orow[in_col[k]] = in_val[k];
+        return;
+    }
     double corr = 0.0;
     for (unsigned long long k = p0 + threadIdx.x; k < p1; k += 256) {
         const uint32_t j = in_col[k];
@@ -1056,6 +1110,7 @@ __global__ __launch_bounds__(256) void dense_rows_write_kernel(const float* __re
     const float sf = sf_s;
     if (DIVIDE)
         for (unsigned long long k = p0 + threadIdx.x; k < p1; k += 256) in_val[k] = in_val[k] / sf;
+    if (PART == 1 && own.own_cnt[i] != kNoOwnList) return;   // (workgroup-uniform)
     __syncthreads();   // (in place: every read of the row's distances above comes before the first write below)
     const float4* rv = reinterpret_cast<const float4*>(drow);
     float4* ov = reinterpret_cast<float4*>(out + i * n);
@@ -1095,7 +1150,6 @@ __global__ __launch_bounds__(256) void dense_rows_write_kernel(const float* __re
     // (one CU, one path to the address's L2 channel), the barrier's workgroup-scope release waits for the first to be
     // acknowledged.  (NOT __threadfence(): a device-scope release writes the XCD's L2 back - once per row, 1.9 x the time)
     __syncthreads();
-    float* orow = out + i * n;
     for (unsigned long long k = p0 + threadIdx.x; k < p1; k += 256) orow[in_col[k]] = in_val[k];
 }
 
@@ -1213,7 +1267,7 @@ __global__ __launch_bounds__(256) void dense_normalize4_kernel(const float4* __r
 
 struct DenseState {
     DevBuf bw, bw_user, rowsum, deg, work_in, work_k, work_p, flags, redo;
-    DevBuf own_sum, tri_i, tri_j, tri_a, tri_cursor, incount, inptr, in_col, in_val, scan_rows;   // row-streaming form
+    DevBuf own_sum, tri_i, tri_j, tri_a, tri_cursor, incount, inptr, in_col, in_val, scan_rows, own_base, own_cnt;   // row-streaming form
 };
 
 // Scaled distance beyond which exp(-x^decay) is exactly 0 in the reference: it falls below `thresh` (zeroed,
@@ -1388,7 +1442,7 @@ extern "C" int gt_dense_graph_build(gt_ctx* ctx, const void* X_or_D, int64_t n, 
     const size_t in_esz = dtype == GT_F64 ? 8 : 4;
     auto cleanup = [&]() {
         for (DevBuf* b : {&st.bw, &st.bw_user, &st.rowsum, &st.deg, &st.work_in, &st.work_k, &st.work_p, &st.flags, &st.redo,
-                          &st.own_sum, &st.tri_i, &st.tri_j, &st.tri_a, &st.tri_cursor, &st.incount, &st.inptr, &st.in_col, &st.in_val,
+                          &st.own_sum, &st.tri_i, &st.tri_j, &st.tri_a, &st.tri_cursor, &st.incount, &st.inptr, &st.in_col, &st.in_val, &st.own_base, &st.own_cnt,
                           &st.scan_rows})
             b->release();
     };
@@ -1436,6 +1490,8 @@ extern "C" int gt_dense_graph_build(gt_ctx* ctx, const void* X_or_D, int64_t n, 
     tl.a = nullptr;
     tl.cursor = nullptr;
     tl.cap = 0;
+    tl.own_base = nullptr;
+    tl.own_cnt = nullptr;
     auto rows_alloc = [&]() -> int {
         if (tl.i) return GT_OK;
         const unsigned long long cap = ctx->dense_rows_cap > 0 ? (unsigned long long)ctx->dense_rows_cap
@@ -1453,6 +1509,10 @@ extern "C" int gt_dense_graph_build(gt_ctx* ctx, const void* X_or_D, int64_t n, 
         tl.a = st.tri_a.as<float>();
         tl.cursor = st.tri_cursor.as<unsigned long long>();
         tl.cap = cap;
+        GT_HIP(ctx, st.own_base.reserve(size_t(n) * sizeof(unsigned long long)));
+        GT_HIP(ctx, st.own_cnt.reserve(size_t(n) * sizeof(uint32_t)));
+        tl.own_base = st.own_base.as<unsigned long long>();
+        tl.own_cnt = st.own_cnt.as<uint32_t>();
         return GT_OK;
     };
     // ---- bandwidth ----
@@ -1589,6 +1649,7 @@ extern "C" int gt_dense_graph_build(gt_ctx* ctx, const void* X_or_D, int64_t n, 
             DENSE_HIP(st.in_col.reserve(size_t(std::max<unsigned long long>(total, 1)) * sizeof(uint32_t)));
             DENSE_HIP(st.in_val.reserve(size_t(std::max<unsigned long long>(total, 1)) * sizeof(float)));
             uint32_t* incount = st.incount.as<uint32_t>();
+            std::unique_ptr<StageSpan> tspan(new StageSpan(ctx, "dense_rows_transpose"));
             if (total > 0)
                 hipLaunchKernelGGL(tri_count_kernel, dim3((unsigned)ceil_div64(int64_t(total), 256)), dim3(256), 0, ctx->stream,
                                    tl.j, int64_t(total), incount);
@@ -1598,16 +1659,22 @@ extern "C" int gt_dense_graph_build(gt_ctx* ctx, const void* X_or_D, int64_t n, 
                 hipLaunchKernelGGL(tri_scatter_kernel, dim3((unsigned)ceil_div64(int64_t(total), 256)), dim3(256), 0, ctx->stream,
                                    tl.i, tl.j, tl.a, int64_t(total), st.inptr.as<unsigned long long>(), incount + n,
                                    st.in_col.as<uint32_t>(), st.in_val.as<float>());
-            if (direct_p)
-                hipLaunchKernelGGL(dense_rows_write_kernel<true>, dim3((unsigned)n), dim3(256), 0, ctx->stream, (const float*)in_dev, n,
-                                   st.bw.as<double>(), decay, thresh, xc, st.own_sum.as<double>(),
-                                   st.inptr.as<unsigned long long>(), st.in_col.as<uint32_t>(), st.in_val.as<float>(),
-                                   st.rowsum.as<double>(), (float*)target);
-            else
-                hipLaunchKernelGGL(dense_rows_write_kernel<false>, dim3((unsigned)n), dim3(256), 0, ctx->stream, (const float*)in_dev, n,
-                                   st.bw.as<double>(), decay, thresh, xc, st.own_sum.as<double>(),
-                                   st.inptr.as<unsigned long long>(), st.in_col.as<uint32_t>(), st.in_val.as<float>(),
-                                   st.rowsum.as<double>(), (float*)target);
+            tspan.reset();
+            // (option dense_rows_reread = 1: one launch, every row is read again and its affinities recomputed - the first form)
+#define GT_ROWS_PART(DIV_, PART_)                                                                                              \
+    hipLaunchKernelGGL((dense_rows_write_kernel<DIV_, PART_>), dim3((unsigned)n), dim3(256), 0, ctx->stream, (const float*)in_dev, n, \
+                       st.bw.as<double>(), decay, thresh, xc, st.own_sum.as<double>(), st.inptr.as<unsigned long long>(),     \
+                       st.in_col.as<uint32_t>(), st.in_val.as<float>(), st.rowsum.as<double>(), (float*)target, tl)
+            if (ctx->dense_rows_reread != 0) {
+                if (direct_p) GT_ROWS_PART(true, 0); else GT_ROWS_PART(false, 0);
+            } else {
+                StageSpan mark(ctx, "dense_rows_placed");   // (marker: the write pass reads no row - 4 N^2 bytes, not 8)
+                if (direct_p) GT_ROWS_PART(true, 1); else GT_ROWS_PART(false, 1);
+                hipLaunchKernelGGL(dense_zero_rows_kernel, dim3((unsigned)std::min<int64_t>(n, int64_t(ctx->n_cu) * 16)), dim3(256), 0,
+                                   ctx->stream, (float*)target, n, tl.own_cnt);
+                if (direct_p) GT_ROWS_PART(true, 2); else GT_ROWS_PART(false, 2);
+            }
+#undef GT_ROWS_PART
             DENSE_HIP(hipGetLastError());
             rows_done = true;
             rows_wrote_p = direct_p;

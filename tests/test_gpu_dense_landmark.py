@@ -360,11 +360,11 @@ def test_operator_alone_in_place_never_stores_K():
         np.testing.assert_allclose(P2.astype(np.float64).sum(axis=1), 1.0, rtol=1e-5)
 
 
-@pytest.mark.parametrize("case", ["sparse", "asymmetric", "heavy rows", "not sparse", "zero diagonal"])
+@pytest.mark.parametrize("case", ["sparse", "asymmetric", "heavy rows", "some heavy rows", "not sparse", "zero diagonal"])
 def test_row_streaming_form_equals_the_tile_pairs(case):
     """round 4: float32 distances under the '+' rule (graphs.py:1583-1609, base.py:557-561, 645): the matrix is read and written
     as whole rows, the transposed half of the thresholded kernel travels as a list (dense_rows_scan / dense_rows_write; default
-    from 16384 rows, forced here).  Against the tile-pair kernels: K bit-identical - also for a matrix that is NOT symmetric,
+    from 16384 rows, forced here); the write pass does not read the matrix: zeros are streamed, the listed entries placed.  Against the tile-pair kernels: K bit-identical - also for a matrix that is NOT symmetric,
     for rows with more non-zeros than the LDS list holds (appended directly) and for a kernel that is not sparse at all (the list
     overflows: the tile-pair form takes over) -, degrees to the summation order, P = K / float32(sum).  In place, P alone: equal
     to the P of the ordinary build; the matrix is consumed."""
@@ -379,6 +379,8 @@ def test_row_streaming_form_equals_the_tile_pairs(case):
     X = make_mix(n, 10, 8).astype(np.float64)
     if case == "heavy rows":
         knn = 1200      # every row keeps what lies within its 1200-th neighbour's distance: more than the LDS list holds
+    if case == "some heavy rows":
+        X[:1100] = X[0]     # 1100 copies of one point: their rows keep 1100 entries (more than the LDS list holds), the others a few
     D = squareform(pdist(X)).astype(np.float32)
     if case == "asymmetric":
         D = (D * (1.0 + 0.05 * np.random.default_rng(2).random((n, n)))).astype(np.float32)
@@ -390,13 +392,14 @@ def test_row_streaming_form_equals_the_tile_pairs(case):
     res = {}
     cap = {"dense_rows_cap": "100000"} if case == "not sparse" else {}      # (the list overflows: the tile pairs take over)
     for tag, opts in (("rows", dict(dense_rows="1", **cap)), ("rows, scan of its own", dict(dense_rows="1", dense_rows_fused="0", **cap)),
-                      ("tiles", {"dense_rows": "0"})):
+                      ("rows, read again", dict(dense_rows="1", dense_rows_reread="1", **cap)), ("tiles", {"dense_rows": "0"})):
         c = _hip.Context(0)
         for k, v in opts.items():
             c.set_option(k, v)
         K, P, flags = c.dense_graph_build(D, "distance", knn, decay, 1e-4, None, 1.0, "+", None, 0.0, want_P=True)
         deg = c.dense_fetch_vec(_hip.VEC_DEGREE, n)
-        st = (c.stage_launches("dense_rows_scan"), c.stage_launches("dense_kernel"), c.stage_launches("dense_rows_listed"))
+        st = (c.stage_launches("dense_rows_scan"), c.stage_launches("dense_kernel"), c.stage_launches("dense_rows_listed"),
+              c.stage_launches("dense_rows_placed"))
         c.close()
         res[tag] = (K, P, deg, flags, st)
     assert res["rows"][4][0] == 1 and res["tiles"][4][0] <= 0                # (the row-streaming form ran / did not)
@@ -405,6 +408,11 @@ def test_row_streaming_form_equals_the_tile_pairs(case):
     assert np.array_equal(res["rows, scan of its own"][0], res["rows"][0]) and np.array_equal(res["rows, scan of its own"][1], res["rows"][1])
     assert res["rows, scan of its own"][3] == res["rows"][3]
     np.testing.assert_allclose(res["rows, scan of its own"][2], res["rows"][2], rtol=1e-12)
+    # the write pass places the listed entries over streamed zeros (rows whose entries are not in one piece - "heavy rows" - are
+    # read again, one by one) / reads every row again (option): the same bits
+    assert (res["rows"][4][3] == 1) == (case != "not sparse") and res["rows, read again"][4][3] <= 0
+    assert np.array_equal(res["rows, read again"][0], res["rows"][0]) and np.array_equal(res["rows, read again"][1], res["rows"][1])
+    assert np.array_equal(res["rows, read again"][2], res["rows"][2]) and res["rows, read again"][3] == res["rows"][3]
     if case == "not sparse":
         assert (res["rows"][0] != 0).sum() > 100000 and res["rows"][4][1] == 1
     assert np.array_equal(res["rows"][0], res["tiles"][0]), "K differs"
@@ -414,6 +422,9 @@ def test_row_streaming_form_equals_the_tile_pairs(case):
     np.testing.assert_allclose(res["rows"][1], res["tiles"][1], rtol=2e-7, atol=0)
     if case == "heavy rows":
         assert (res["rows"][0] != 0).sum(axis=1).min() > 1024
+    if case == "some heavy rows":
+        nzr = (res["rows"][0] != 0).sum(axis=1)
+        assert nzr[:1100].min() > 1024 and np.median(nzr[1100:]) < 200      # (K is symmetric: the copies' neighbours receive 1100 entries)
     # in place, the operator alone (BASELINE config 4 as bench.py runs it)
     Dd = torch.from_numpy(D).cuda()
     c = _hip.Context(0)
