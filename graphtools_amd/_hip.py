@@ -113,6 +113,7 @@ _SIGNATURES = {
     "gt_landmark_scale": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int32, _c.c_int32]),
     "gt_landmark_fetch_transitions": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_void_p, _c.c_int32]),
     "gt_nearest_landmark": (_c.c_int, [_c.c_void_p, _c.c_int64, _c.c_int64, _c.c_void_p, _c.c_int32, _c.c_int32, _c.c_void_p]),
+    "gt_knn_first_nearest": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_void_p, _c.c_void_p]),
     "gt_pca_begin": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int32, _c.c_int32, _c.c_void_p, _c.c_void_p]),
     "gt_pca_matmul": (_c.c_int, [_c.c_void_p, _c.c_int32, _c.c_void_p, _c.c_int32, _c.c_int32, _c.c_void_p, _c.c_int32]),
     "gt_pca_tmatmul": (_c.c_int, [_c.c_void_p, _c.c_int32, _c.c_int32, _c.c_void_p, _c.c_void_p]),
@@ -258,6 +259,20 @@ class Context:
         self._check(self.lib.gt_knn_search(self.h, 0, 0, ctypes.c_void_p(int(y_dev_ptr)), int(m), 1, int(k), _ptr(idx), _ptr(dist), 0,
                                            ctypes.byref(flags)), "gt_knn_search")
         return dist, idx, flags.value
+
+    def knn_first_nearest(self, k, Y=None, y_dev_ptr=None, m=None):
+        """gt_knn_first_nearest: for every query row the lowest index among its nearest bound points that tie (int64 [m]);
+        Y: host matrix, or y_dev_ptr / m: a device-resident one of the bound points' dtype and width"""
+        if Y is not None:
+            Y = np.ascontiguousarray(Y, dtype=self.dtype)
+            m, ptr, on_dev = Y.shape[0], _ptr(Y), 0
+        else:
+            ptr, on_dev = ctypes.c_void_p(int(y_dev_ptr)), 1
+        out = np.empty(int(m), dtype=np.int64)
+        flags = ctypes.c_uint32(0)
+        self._check(self.lib.gt_knn_first_nearest(self.h, ptr, int(m), on_dev, int(k), _ptr(out), ctypes.byref(flags)),
+                    "gt_knn_first_nearest")
+        return out
 
     def knn_search(self, k, rows=None, Y=None):
         """(distances float64 [m,k], indices int64 [m,k], flags)"""

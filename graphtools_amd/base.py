@@ -58,7 +58,16 @@ class BaseGraph(object):
             # reference: Base.__init__ is object.__init__ -> unexpected keyword TypeError (test_api.py:161-165)
             raise TypeError("__init__() got an unexpected keyword argument '{}'".format(sorted(kwargs)[0]))
         if initialize:
-            self.K
+            self._initialize()
+
+    def _ensure_built(self):
+        """The kernel exists where the device operations read it (default: the host copy is made too)."""
+        self.K
+
+    def _initialize(self):
+        """``initialize=True`` (reference: base.py:77-83 builds ``self.K``).  A graph whose kernel lives on the device may build it there
+        and leave the host copy to the first access of ``K`` / ``P`` (kNNGraph)."""
+        self.K
 
     def _check_symmetrization(self, kernel_symm, theta):
         # reference: base.py:508-532
@@ -94,6 +103,8 @@ class BaseGraph(object):
     def __getstate__(self):
         """Everything but the device context: the host-side results that were already fetched (K, P, ...) travel, what lives
         on the GPU is rebuilt on first use after loading (``_bind_points`` / ``_ensure_device_graph``)."""
+        if not hasattr(self, "_kernel") and getattr(self, "_device_state", None) is not None:
+            self.K   # (built on the device, never fetched: the pickle holds what the reference's holds)
         state = dict(self.__dict__)
         for key in _DEVICE_ATTRS:
             state.pop(key, None)

@@ -472,6 +472,48 @@ extern "C" int gt_landmark_fetch_transitions(gt_ctx* ctx, double* data, int32_t*
     return GT_OK;
 }
 
+// first index among the nearest that tie: labels[i] = min { idx[i][c] : dist[i][c] == dist[i][0] } (tables sorted by distance)
+__global__ __launch_bounds__(256) void first_nearest_kernel(const int64_t* __restrict__ idx, const double* __restrict__ dist,
+                                                            const int64_t m, const int k, int64_t* __restrict__ out) {
+    const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= m) return;
+    const double d0 = dist[i * k];
+    int64_t best = idx[i * k];
+    for (int c = 1; c < k; ++c)
+        if (dist[i * k + c] == d0 && idx[i * k + c] < best) best = idx[i * k + c];
+    out[i] = best;
+}
+
+extern "C" int gt_knn_first_nearest(gt_ctx* ctx, const void* Y, int64_t m, int32_t y_on_device, int32_t k, int64_t* out_labels,
+                                    uint32_t* flags) {
+    if (!ctx) return GT_E_ARG;
+    if (!Y || m <= 0 || k < 1 || !out_labels) GT_FAIL(ctx, GT_E_ARG, "gt_knn_first_nearest: bad arguments");
+    GT_HIP(ctx, hipSetDevice(ctx->device));
+    DevBuf d_idx, d_dist, d_out;
+    GT_HIP(ctx, d_idx.reserve(size_t(m) * k * sizeof(int64_t)));
+    GT_HIP(ctx, d_dist.reserve(size_t(m) * k * sizeof(double)));
+    GT_HIP(ctx, d_out.reserve(size_t(m) * sizeof(int64_t)));
+    int rc = gt_knn_search(ctx, 0, 0, Y, m, y_on_device, k, d_idx.as<int64_t>(), d_dist.as<double>(), 1, flags);
+    if (rc == GT_OK) {
+        hipLaunchKernelGGL(first_nearest_kernel, dim3((unsigned)ceil_div64(m, 256)), dim3(256), 0, ctx->stream, d_idx.as<int64_t>(),
+                           d_dist.as<double>(), m, int(k), d_out.as<int64_t>());
+        if (hipGetLastError() != hipSuccess) {
+            ctx->set_error("gt_knn_first_nearest: launch failed");
+            rc = GT_E_HIP;
+        }
+    }
+    if (rc == GT_OK) rc = gt_copy_to_host(ctx, out_labels, d_out.p, size_t(m) * sizeof(int64_t));
+    const hipError_t es = hipStreamSynchronize(ctx->stream);
+    d_idx.release();
+    d_dist.release();
+    d_out.release();
+    if (rc == GT_OK && es != hipSuccess) {
+        ctx->set_error(std::string("gt_knn_first_nearest: ") + hipGetErrorString(es));
+        rc = GT_E_HIP;
+    }
+    return rc;
+}
+
 extern "C" int gt_nearest_landmark(gt_ctx* ctx, int64_t row0, int64_t row1, const int64_t* landmarks, int32_t n_landmark,
                                    int32_t mode, int32_t* out_clusters) {
     if (!ctx) return GT_E_ARG;

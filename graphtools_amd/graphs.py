@@ -374,12 +374,37 @@ class kNNGraph(DataGraph):
         self._emit_build_warnings(flags, K)
         return K
 
+    def _build_on_device(self):
+        """Kernel and diffusion operator built and left on the device, with the warnings of the build (reference: base.py:551-554,
+        graphs.py:887-914); nothing crosses PCIe.  Idempotent while the device holds this graph's kernel."""
+        want = (self.kernel_symm, self.theta, self.anisotropy)
+        if getattr(self, "_device_state", None) == want and hasattr(self, "_build_nnz"):
+            return self._build_nnz, self._build_flags
+        nnz, flags = self._device_build(*want)
+        self._log_phases()
+        self._build_nnz, self._build_flags = nnz, flags
+        if flags & _hip.FLAG_DUPLICATES:
+            self._check_duplicates()
+        if self.kernel_symm is not None:
+            self._emit_build_warnings(flags)
+        return nnz, flags
+
+    def _ensure_built(self):
+        if self._dist_ranks() is not None or self.kernel_symm is None:
+            self.K
+        else:
+            self._build_on_device()
+
+    def _initialize(self):
+        # the landmark operator, the spectral clustering, diffuse() and the torch hand-offs read the kernel where it is: the host
+        # copy (1.4 GB over PCIe at N = 1e6: 30 ms, twice the build) is made when K or P are first asked for.  Without a
+        # symmetrisation the reference's symmetry warning needs the matrix itself: fetched right away.
+        self._ensure_built()
+
     def _build_kernel(self):
         if self._dist_ranks() is not None:
             return self._build_kernel_sharded()
-        nnz, flags = self._device_build(self.kernel_symm, self.theta, self.anisotropy)
-        self._log_phases()
-        self._build_flags = flags
+        nnz, flags = self._build_on_device()
         # K and P in one pass over the link (SURVEY 8d host-complete: scipy CSR K and P out): the P values are derived on the
         # host from K and the degrees by the copy threads while K is still arriving - the division the device made for its
         # own P, same bits - so they never cross PCIe (gt_graph_fetch_kp)
@@ -389,9 +414,8 @@ class kNNGraph(DataGraph):
             indptr = indptr.astype(np.int32)
         K = sparse.csr_matrix((data, indices, indptr), shape=(n, n))
         self._diff_op = sparse.csr_matrix((pdata, K.indices, K.indptr), shape=(n, n))
-        if flags & _hip.FLAG_DUPLICATES:
-            self._check_duplicates()
-        self._emit_build_warnings(flags, K)
+        if self.kernel_symm is None:
+            self._emit_build_warnings(flags, K)
         return K
 
     def build_kernel(self):
@@ -430,7 +454,7 @@ class kNNGraph(DataGraph):
         """The diffusion operator as a CUDA ``torch.sparse_csr_tensor`` (no host round trip): the hand-off to
         consumers that continue on the device, e.g. ``P @ X`` diffusion steps."""
         self._no_sharded("diff_op_torch()")
-        self.K
+        self._ensure_built()
         self._ensure_device_graph()
         return self.hip.graph_csr_torch(_hip.CSR_P)
 
@@ -438,7 +462,7 @@ class kNNGraph(DataGraph):
         """``P^t X`` with the diffusion operator left on the device (``gt_graph_spmm``; the reference's consumers do
         ``graph.diff_op.dot(X)`` on the host CSR).  X: [n_samples] or [n_samples, c]."""
         self._no_sharded("diffuse()")
-        self.K
+        self._ensure_built()
         self._ensure_device_graph()
         X = np.asarray(X)
         if X.shape[0] != self.data_nu.shape[0]:
@@ -450,14 +474,14 @@ class kNNGraph(DataGraph):
     def kernel_torch(self):
         """The kernel matrix K as a CUDA ``torch.sparse_csr_tensor``."""
         self._no_sharded("kernel_torch()")
-        self.K
+        self._ensure_built()
         self._ensure_device_graph()
         return self.hip.graph_csr_torch(_hip.CSR_K)
 
     @property
     def build_stats(self):
         """Device-side statistics of the last build (fallback / radius rows, stage timings in ms)."""
-        self.K
+        self._ensure_built()
         st = self.hip.graph_stats()
         st["stage_ms"] = {s: self.hip.stage_ms(s) for s in
                           ("knn_select", "rerank", "fallback", "radius", "affinity", "symmetrize", "normalize")}
@@ -649,14 +673,10 @@ class LandmarkGraph(DataGraph):
                     if getattr(self, "_points_bound", False) and self.hip.n == X.shape[0] and self.hip.dtype == X.dtype:
                         # (the graph's own context holds these rows on the device already: queried where they are)
                         self.hip.sync()
-                        dist, idx, _ = lm_ctx.knn_search_device(k, self.hip.points_device(0), X.shape[0])
-                    else:
-                        dist, idx, _ = lm_ctx.knn_search(k, Y=X)
+                        return lm_ctx.knn_first_nearest(k, y_dev_ptr=self.hip.points_device(0), m=X.shape[0])
+                    return lm_ctx.knn_first_nearest(k, Y=X)
                 finally:
                     lm_ctx.close()
-                tie = dist == dist[:, :1]
-                cand = np.where(tie, idx, np.iinfo(np.int64).max)
-                return cand.min(axis=1).astype(np.int64)
             self._bind_points()
             return self.hip.nearest_landmark(landmark_indices, 0).astype(np.int64)
         # spectral front end (graphs.py:1215-1230).  Sparse kNN kernels that live on the device: randomized SVD of
@@ -669,7 +689,7 @@ class LandmarkGraph(DataGraph):
                 and (_base.SPECTRAL_BACKEND == "device" or n_samples >= _base._SPECTRAL_DEVICE_MIN_ROWS)):
             from ._spectral import spectral_clusters
 
-            self.K
+            self._ensure_built()
             self._ensure_device_graph()
             return spectral_clusters(self, self.hip)
         from sklearn.cluster import MiniBatchKMeans
@@ -682,8 +702,8 @@ class LandmarkGraph(DataGraph):
 
     def build_landmark_op(self):
         """Landmark operator and sample-to-landmark transitions (reference: graphs.py:1187-1246)."""
-        self.K
-        dense = not sparse.issparse(self._kernel)
+        self._ensure_built()
+        dense = hasattr(self, "_kernel") and not sparse.issparse(self._kernel)   # (a kNN kernel may exist on the device only)
         if not hasattr(self, "_clusters"):
             self._clusters = self._assign_clusters()
         cl = np.asarray(self._clusters)

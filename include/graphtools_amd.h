@@ -396,6 +396,13 @@ int gt_pca_end(gt_ctx* ctx);
 int gt_nearest_landmark(gt_ctx* ctx, int64_t row0, int64_t row1, const int64_t* landmarks, int32_t n_landmark,
                         int32_t mode, int32_t* out_clusters);
 
+/* The same assignment when the landmarks are the BOUND points and the rows to assign are the queries (graphs.py:1200-1213 at
+ * scale: sklearn euclidean_distances arithmetic, argmin's first-index rule): gt_knn_search of Y [m rows, host or device] for
+ * the k nearest bound points, then out_labels[i] = the lowest index among those at exactly the nearest's distance - formed on
+ * the device, so m labels cross PCIe instead of 2 m k table entries.  out_labels: int64 [m] (host). */
+int gt_knn_first_nearest(gt_ctx* ctx, const void* Y, int64_t m, int32_t y_on_device, int32_t k, int64_t* out_labels,
+                         uint32_t* flags);
+
 /* ---- device memory helpers (so a host language without a HIP binding can keep data resident) -- */
 int gt_dev_alloc(gt_ctx* ctx, size_t bytes, void** out);
 int gt_dev_free(gt_ctx* ctx, void* p);

@@ -100,6 +100,41 @@ def test_random_landmark_assignment_large_n_path():
     np.testing.assert_allclose(G.landmark_op, op, rtol=1e-9, atol=1e-15)
 
 
+@pytest.mark.parametrize("where", ["host rows", "device rows"])
+def test_first_nearest_on_the_device_follows_argmin(where):
+    """gt_knn_first_nearest (random landmarking at scale, graphs.py:1200-1213): the label formed on the device is numpy's
+    argmin over the distances gt_knn_search returns - the FIRST index among the nearest that tie (landmark rows that are copies
+    of each other tie for every row; their own rows tie at distance 0)."""
+    from graphtools_amd import _hip
+
+    rng = np.random.default_rng(11)
+    X = make_mix(40000, 24, 4)      # (from 32768 query rows against fewer points the bound points seed the queries' thresholds)
+    lm = rng.choice(X.shape[0], 300, replace=False)
+    L = X[lm].copy()
+    L[250:] = L[:50]       # fifty landmarks twice: rows near one of them see a tie of the two nearest
+    c = _hip.Context(0)
+    c.set_points(L)
+    c.set_option("query_order", "0")
+    dist, idx, _ = c.knn_search(4, Y=X)
+    c.set_option("query_order", "1")
+    unseeded_ms = c.stage_ms("query_order")
+    want = np.where(dist == dist[:, :1], idx, np.iinfo(np.int64).max).min(axis=1)
+    if where == "host rows":
+        got = c.knn_first_nearest(4, Y=X)
+    else:
+        g = _hip.Context(0)
+        g.set_points(X)
+        got = c.knn_first_nearest(4, y_dev_ptr=g.points_device(0), m=X.shape[0])
+        g.close()
+    assert c.stage_ms("query_order") > 10 * unseeded_ms      # (the seeded search ran: the stage is not an empty span)
+    d2, i2, _ = c.knn_search(4, Y=X)
+    assert np.array_equal(d2, dist) and np.array_equal(i2, idx)      # ... and returns the tables of the unseeded one
+    c.close()
+    assert got.dtype == np.int64 and np.array_equal(got, want)
+    assert (dist[:, 0] == dist[:, 1]).sum() > 500 and got.max() < 250     # (ties happened; the copies never win)
+    assert np.array_equal(got[lm[:250]], np.arange(250))                   # a landmark is its own nearest
+
+
 @pytest.mark.parametrize("n", [1022, 1024, 257])
 @pytest.mark.parametrize("kw", [dict(kernel_symm="+"), dict(kernel_symm="*"), dict(kernel_symm="mnn", theta=0.3),
                                 dict(kernel_symm="+", thresh=0)])
