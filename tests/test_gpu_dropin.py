@@ -173,6 +173,34 @@ def test_pickle_round_trip_drops_the_device_context_and_rebuilds_lazily(tmp_path
     assert "Calculated" not in capsys.readouterr().out
 
 
+def test_a_knn_kernel_is_built_on_construction_and_copied_to_the_host_when_asked_for():
+    """initialize=True builds the kernel (base.py:77-83) - on the device; the host copy of a kNN kernel is made on the first access
+    of K / P.  The warnings of the build come at construction as in the reference, the consumers that read the kernel where it is
+    (landmark operator, diffuse) do not fetch it, a pickle made before any access holds K like the reference's."""
+    import pickle
+    import warnings
+
+    from conftest import make_mix
+
+    X = make_mix(4000, 16, 5)
+    X[7] = X[3]         # a duplicate: the reference warns while it builds (graphs.py:887-914)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        G = graphtools_amd.Graph(X, knn=6, decay=15, n_pca=None, n_landmark=50, random_landmarking=True, random_state=3)
+    assert any("zero distance between samples 3 and 7" in str(x.message) for x in w)
+    assert not hasattr(G, "_kernel") and G.build_stats["stage_ms"]["rerank"] > 0        # built, not fetched
+    op = G.landmark_op
+    Z = G.diffuse(X[:, :3])
+    assert not hasattr(G, "_kernel")
+    G2 = pickle.loads(pickle.dumps(G))
+    assert hasattr(G2, "_kernel") and hasattr(G, "_kernel")                              # (pickling fetched it)
+    eager = graphtools_amd.Graph(X, knn=6, decay=15, n_pca=None, n_landmark=50, random_landmarking=True, random_state=3, verbose=0)
+    K = eager.K
+    assert (G.K != K).nnz == 0 and (G2.K != K).nnz == 0 and (G.P != eager.P).nnz == 0
+    np.testing.assert_allclose(op, eager.landmark_op, rtol=1e-12, atol=1e-300)      # (float64 atomics: the summation order varies)
+    np.testing.assert_array_equal(Z, eager.P.dot(X[:, :3]))
+
+
 def test_host_copy_of_P_derived_on_the_way_equals_the_device_P():
     """gt_graph_fetch_kp: K and the structure cross the link, P = K / degree is formed by the copy threads on the host -
     it must equal the P the device wrote (base.py:645) bit for bit, with and without anisotropy, on a graph large enough
