@@ -48,7 +48,7 @@ struct GraphState {
     int32_t rcap = 0;
     int64_t radius_retries = 0;
     // exchange
-    DevBuf ownercnt, ownerpos, cnt_sorted, pos_sorted, scan_tmp, selfbuf, splits_dev;
+    DevBuf ownercnt, ownerpos, cnt_sorted, pos_sorted, scan_tmp, selfbuf, splits_dev, edges;
     std::vector<int64_t> send_counts_host;
     // merge
     DevBuf Ukey, Uval, Vkey, Vval, bigrows, hugerows, bigcount, bigscratch_k, bigscratch_v, bigsoff, aniso_tmp, scan_own;
