@@ -394,12 +394,14 @@ def secondary_c4(_hip, torch, device, n=200000, d=100):
         rows_form = st["dense_rows_scan"] > 0
         listed = ctx.stage_launches("dense_rows_listed") > 0    # the bandwidth pass listed the kept affinities: no scan of its own
         placed = ctx.stage_launches("dense_rows_placed") > 0    # the write pass read no row
-        nbytes = (((8.0 if placed else 12.0) if listed else 16.0) if rows_form else 20.0) * n * n
+        nbytes = (((8.0 if placed else 12.0) if listed else (12.0 if placed else 16.0)) if rows_form else 20.0) * n * n
         note = ("8 N^2 bytes as run (row-streaming form): 4 N^2 read by the bandwidth pass, which also lists the rows' kept affinities, "
                 "4 N^2 written by the write pass (zeros streamed over the distances, the listed entries and their transposed partners "
                 "placed: the matrix is read ONCE)") if rows_form and listed and placed else (
                 "12 N^2 bytes as run (row-streaming form): 4 N^2 bandwidth pass, which also lists the rows' kept affinities, 8 N^2 write "
                 "pass (P over the distances; the transposed half arrives as the list)") if rows_form and listed else (
+                "12 N^2 bytes as run (row-streaming form): 4 N^2 bandwidth pass, 4 N^2 scan (row sums + the kept affinities as a "
+                "list), 4 N^2 written by the write pass (zeros streamed, the listed entries placed)") if rows_form and placed else (
                 "16 N^2 bytes as run (row-streaming form): 4 N^2 bandwidth pass, 4 N^2 scan (row sums + the kept affinities as a "
                 "list), 8 N^2 write pass (P over the distances; the transposed half arrives as the list)") if rows_form else (
                 "20 N^2 bytes as run: 4 N^2 bandwidth pass (one read), 8 N^2 tile-pair kernel (row sums fused), 8 N^2 normalisation")
