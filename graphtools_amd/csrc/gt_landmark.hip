@@ -40,6 +40,7 @@ int gt_exclusive_scan_i32(gt_ctx* ctx, const int32_t* a, int64_t n, int64_t* out
 namespace {
 
 constexpr int kRowCap = 512;   // rows up to this many entries are aggregated by one wave in registers/LDS
+constexpr int kBigStage = 512; // entries of a longer row staged in LDS at a time (aggregate_big_rows_kernel)
 
 // sort one row by (cluster, column) and emit (cluster, sum) pairs; returns the number of pairs
 template <int NT>
@@ -142,13 +143,29 @@ __global__ __launch_bounds__(256) void aggregate_big_rows_kernel(const int32_t* 
     double* acc = reinterpret_cast<double*>(smem_raw);   // [L]
     __shared__ int wtot[4];
     __shared__ int base_sh;
+    __shared__ int32_t st_c[kBigStage];
+    __shared__ double st_v[kBigStage];
     const int64_t i = bigrows[blockIdx.x];
     const int64_t s = indptr[i], e = indptr[i + 1];
     for (int c = threadIdx.x; c < L; c += 256) acc[c] = 0.0;
     if (threadIdx.x == 0) base_sh = 0;
     __syncthreads();
-    for (int64_t p = s + threadIdx.x; p < e; p += 256) atomicAdd(&acc[clusters[indices[p]]], Kdata[p]);
-    __syncthreads();
+    // a cluster's sum belongs to ONE thread (cluster % 256), which meets the row's entries in column order: the sums of the
+    // wave-per-row path, bit for bit, whatever the scheduling (LDS atomics summed in arrival order: the last bit varied from
+    // run to run).  The entries are staged by all threads, then every thread walks the stage (broadcast reads).
+    for (int64_t p0 = s; p0 < e; p0 += kBigStage) {
+        const int m = int(e - p0 < int64_t(kBigStage) ? e - p0 : int64_t(kBigStage));
+        for (int q = threadIdx.x; q < m; q += 256) {
+            st_c[q] = clusters[indices[p0 + q]];
+            st_v[q] = Kdata[p0 + q];
+        }
+        __syncthreads();
+        for (int q = 0; q < m; ++q) {
+            const int c = st_c[q];
+            if ((c & 255) == int(threadIdx.x)) acc[c] += st_v[q];
+        }
+        __syncthreads();
+    }
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     for (int c0 = 0; c0 < L; c0 += 256) {
         const int c = c0 + threadIdx.x;

@@ -100,6 +100,37 @@ def test_random_landmark_assignment_large_n_path():
     np.testing.assert_allclose(G.landmark_op, op, rtol=1e-9, atol=1e-15)
 
 
+def test_transitions_of_long_rows_are_reproducible_and_ordered():
+    """Kernel rows of more than 512 entries are aggregated by a workgroup over a dense accumulator (gt_landmark.hip
+    aggregate_big_rows_kernel): every cluster's sum is formed by one thread in column order - what scipy's `K @ onehot` does
+    (graphs.py:1232-1236) - so two builds give the same bits (LDS atomics, the first form, did not) and the sums equal the
+    host's column-ordered sums exactly."""
+    X = make_mix(3000, 12, 6)
+    args = dict(knn=400, decay=None, n_pca=None, n_landmark=60, random_landmarking=True, random_state=5, verbose=0)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        G1 = graphtools_amd.Graph(X, **args)
+        G2 = graphtools_amd.Graph(X, **args)
+        T1, T2 = sparse.csr_matrix(G1.transitions), sparse.csr_matrix(G2.transitions)
+    K = sparse.csr_matrix(G1.K)
+    assert np.diff(K.indptr).max() > 512
+    assert (T1 != T2).nnz == 0
+    # column-ordered sums on the host: row by row, cluster by cluster, in the order of the CSR columns
+    cl = np.asarray(G1.clusters)
+    _, inv = np.unique(cl, return_inverse=True)
+    rows = np.flatnonzero(np.diff(K.indptr) > 512)[:20]
+    for i in rows:
+        cols, vals = K.indices[K.indptr[i]:K.indptr[i + 1]], K.data[K.indptr[i]:K.indptr[i + 1]]
+        assert np.all(np.diff(cols) > 0)
+        acc = np.zeros(int(inv.max()) + 1)
+        for j, v in zip(cols, vals):
+            acc[inv[j]] += v
+        want = acc / acc.sum()
+        got = np.asarray(T1[i].todense()).ravel()
+        np.testing.assert_allclose(got, want, rtol=4e-16, atol=0)      # (the normalising sum is formed in another order: an ulp)
+        assert np.array_equal(got != 0, want != 0)
+
+
 @pytest.mark.parametrize("where", ["host rows", "device rows"])
 def test_first_nearest_on_the_device_follows_argmin(where):
     """gt_knn_first_nearest (random landmarking at scale, graphs.py:1200-1213): the label formed on the device is numpy's
