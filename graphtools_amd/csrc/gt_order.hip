@@ -240,7 +240,7 @@ int gt_query_order(gt_ctx* ctx, const float* Qc, int64_t q0, int64_t nq, int nee
     // Many query rows against FEW points (a random-landmark assignment: 1e6 rows, 2000 landmarks): nearly every point is a
     // landmark of the order - what the queries gain is the threshold (the need-th best of the scores seen here bounds the need-th
     // best of all from below): the candidate pass then admits a handful of rows per query instead of filling its lists from an
-    // open threshold (N = 1e6 against 2000: candidate pass 10.9 -> 1.5 ms, re-rank 8.0 -> 1.3 ms).
+    // open threshold (N = 1e6 against 2000: candidate pass 10.9 -> 1.3 ms, re-rank 8.0 -> 4.6 ms).
     const bool few_points = ctx->n < kMinRows && ctx->n >= 64 && Qc != ctx->Yc.as<float>();
     if (!ctx->query_order || ctx->prec != 1 || ctx->fast_mode == 0 || !ctx->Yc.p || !Qc || nq < kMinRows ||
         (ctx->n < std::max<int64_t>(kMinRows, 64) && !few_points))
