@@ -28,6 +28,10 @@ SELECT_NARROW_UNITS = [(2, dp) for dp in (16, 32, 48, 64)]
 # admission test needs no canonicalising moves
 SELECT_FLAGS = ["-fno-honor-nans"]
 
+# GT_BUILD_DEBUG_HOOKS=0 leaves gt_debug.hip (the gt_dbg_* hooks the GPU unit tests of the device primitives call) out of the
+# library; the default build - the one the tests run against - has them
+DEBUG_HOOKS = os.environ.get("GT_BUILD_DEBUG_HOOKS", "1") != "0"
+
 COMMON_FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
                 "-ffp-contract=off"]
 
@@ -44,6 +48,8 @@ def _units():
     for name in ("gt_api.cpp", "gt_knn.cpp", "gt_knn_shard.cpp", "gt_knn_select_dispatch.cpp", "gt_hostcopy.cpp", "gt_devpool.cpp"):
         units.append((name, name.replace(".cpp", ".o"), ["-x", "hip"]))
     for name in ("gt_prep.hip", "gt_rerank.hip", "gt_sparse.hip", "gt_dense.hip", "gt_landmark.hip", "gt_debug.hip", "gt_order.hip", "gt_sym.hip", "gt_pca.hip", "gt_thin.hip"):
+        if name == "gt_debug.hip" and not DEBUG_HOOKS:
+            continue   # (the gt_dbg_* development / unit-test entry points: not part of the ABI of include/graphtools_amd.h)
         if os.path.exists(os.path.join(CSRC, name)):
             units.append((name, name.replace(".hip", ".o"), []))
     units.append(("gt_seed.hip", "gt_seed.o", SELECT_FLAGS))
@@ -93,11 +99,15 @@ def build(verbose=False, jobs=None):
             rebuilt |= did
             if verbose and log.strip():
                 print(log, file=sys.stderr)
-    if rebuilt or not os.path.exists(LIB):
+    link_stamp = os.path.join(OBJ, "link.stamp")
+    linked = " ".join(sorted(os.path.basename(o) for o in objs))
+    if rebuilt or not os.path.exists(LIB) or not os.path.exists(link_stamp) or open(link_stamp).read() != linked:
         cmd = [_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
         res = subprocess.run(cmd, capture_output=True, text=True)
         if res.returncode != 0:
             raise RuntimeError("link failed:\n%s\n%s" % (" ".join(cmd), res.stderr[-8000:]))
+        with open(link_stamp, "w") as f:
+            f.write(linked)
     return LIB
 
 

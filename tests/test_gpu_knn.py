@@ -114,6 +114,8 @@ def test_forced_exact_fallback(hip_ctx):
 def test_device_primitives(hip_ctx):
     """wave-level sorting networks and the MFMA result layout, in isolation"""
     lib = hip_ctx.lib
+    if not hasattr(lib, "gt_dbg_mfma"):
+        pytest.skip("library built without the gt_dbg_* hooks (GT_BUILD_DEBUG_HOOKS=0)")
     rng = np.random.default_rng(0)
     a = rng.standard_normal((32, 8)).astype(np.float32)
     bt = rng.standard_normal((32, 8)).astype(np.float32)   # asymmetric on purpose (transpose-detecting)
@@ -322,6 +324,8 @@ def test_lane_exchanges_and_wave_reductions_match_ds_bpermute(hip_ctx):
     import ctypes
 
     lib = hip_ctx.lib
+    if not hasattr(lib, "gt_dbg_lane_ops"):
+        pytest.skip("library built without the gt_dbg_* hooks (GT_BUILD_DEBUG_HOOKS=0)")
     lib.gt_dbg_lane_ops.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]
     lib.gt_dbg_lane_ops.restype = ctypes.c_int
     for seed in (0, 12345, 0xFFFFFFFF):
