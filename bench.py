@@ -500,6 +500,29 @@ def secondary_c5(n=1000000, d=50):
     return best
 
 
+def launch_ranks(n_gpus, visible):
+    """`bench.py --gpus N` without WORLD_SIZE: N ranks through torch.distributed.run, started as a child process.
+
+    Returns the exit status to leave with.  The caller has not initialised the GPU (on this pool a process that has must not
+    be replaced or followed by another on the same device set); rank 0's JSON line reaches stdout through the child.
+    """
+    import socket
+    import subprocess
+
+    if visible < n_gpus:
+        print("bench.py: --gpus %d but only %d GPU(s) are visible on this node - refusing to run fewer ranks than asked for"
+              % (n_gpus, visible), file=sys.stderr)
+        return 2
+    with socket.socket() as s:   # a free rendezvous port on the loopback interface
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -525,6 +548,14 @@ def main():
 
     import torch
 
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be at least 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves - as a CHILD process, before this one
+        # has touched the GPU (device_count() does not initialise it) - relay their output and leave with their status.
+        # Never a silent one-rank run: fewer visible devices than asked for is an error.
+        sys.exit(launch_ranks(args.gpus, torch.cuda.device_count()))
+
     from graphtools_amd import _hip
     from graphtools_amd import dist as gdist
 
@@ -534,8 +565,8 @@ def main():
     # GT_BENCH_FORCE_DIST=1 exercises the RCCL path with a single rank (development aid)
     distributed = world > 1 or os.environ.get("GT_BENCH_FORCE_DIST") == "1"
     if args.gpus != world:
-        if rank == 0 and world > 1:
-            print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+        # the line's n_gpus is the number of ranks that ran: a launcher that disagrees with --gpus is a mistake, not a warning
+        sys.exit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if distributed:

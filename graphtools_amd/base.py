@@ -25,7 +25,8 @@ def log_task(verbose, name, seconds):
 
 
 # attributes that hold device state (a ctypes handle, what the context currently holds): never pickled, rebuilt lazily
-_DEVICE_ATTRS = ("_hip_ctx", "_points_bound", "_device_state", "_knn_tree")
+# (a row-sharded graph also holds its ShardedKnnGraph - a ctypes context and CUDA tensors - and the process group)
+_DEVICE_ATTRS = ("_hip_ctx", "_points_bound", "_device_state", "_knn_tree", "_sharded", "group")
 
 
 class BaseGraph(object):

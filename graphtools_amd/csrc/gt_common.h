@@ -10,6 +10,7 @@
 #include <map>
 #include <chrono>
 #include <cstdlib>
+#include <initializer_list>
 #include <string>
 #include <utility>
 #include <vector>
@@ -87,6 +88,22 @@ struct DevBuf {
         p = nullptr;
         cap = 0;
     }
+};
+
+// Scratch buffers of one call: released on every way out of the scope (DevBuf itself has no destructor - most of them are
+// long-lived members of the context - so a local one needs this, or an early GT_HIP return leaks it).
+struct DevBufScope {
+    DevBuf* bufs[6];
+    int n = 0;
+    DevBufScope(std::initializer_list<DevBuf*> l) {
+        for (DevBuf* b : l)
+            if (n < 6) bufs[n++] = b;
+    }
+    ~DevBufScope() {
+        for (int i = 0; i < n; ++i) bufs[i]->release();
+    }
+    DevBufScope(const DevBufScope&) = delete;
+    DevBufScope& operator=(const DevBufScope&) = delete;
 };
 
 struct StageAcc {

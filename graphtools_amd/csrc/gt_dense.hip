@@ -1085,7 +1085,11 @@ __global__ __launch_bounds__(256) void dense_rows_write_kernel(const float* __re
             if (DIVIDE) o = o / sf2;
             orow[own.j[b2 + k]] = o;
         }
-        __syncthreads();   // (a partnered entry is written twice: the merged value last)
+        // a partnered entry is written twice, by different waves: the merged value must land last.  Every wave waits until its
+        // own stores are ACKNOWLEDGED by the L2 (vmcnt counts stores down when the L2 has them) before it meets the others at
+        // the barrier - the second store to an address is then issued after the first is in place, whatever path it takes.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
         for (unsigned long long k = p0 + threadIdx.x; k < p1; k += 256) orow[in_col[k]] = in_val[k];
         return;
     }
@@ -1146,9 +1150,11 @@ __global__ __launch_bounds__(256) void dense_rows_write_kernel(const float* __re
             }
         }
     }
-    // the streamed row is complete before the merged entries go over it: both writes of an address come from this workgroup
-    // (one CU, one path to the address's L2 channel), the barrier's workgroup-scope release waits for the first to be
-    // acknowledged.  (NOT __threadfence(): a device-scope release writes the XCD's L2 back - once per row, 1.9 x the time)
+    // the streamed row is complete before the merged entries go over it: every wave waits for the L2's acknowledgement of its
+    // own (non-temporal) stores - vmcnt(0) - and only then meets the others at the barrier, so the second store to an address is
+    // issued after the first is in place.  (The barrier alone does not wait on vmcnt outside tgsplit mode; NOT __threadfence():
+    // a device-scope release writes the XCD's L2 back - once per row, 1.9 x the time.)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (unsigned long long k = p0 + threadIdx.x; k < p1; k += 256) orow[in_col[k]] = in_val[k];
 }
@@ -1458,9 +1464,12 @@ extern "C" int gt_dense_graph_build(gt_ctx* ctx, const void* X_or_D, int64_t n, 
     do {                                                                                  \
         hipError_t _e = (expr);                                                           \
         if (_e != hipSuccess) {                                                           \
-            ctx->set_error(std::string(#expr) + ": " + hipGetErrorString(_e));            \
+            /* (as GT_HIP: running out of device memory is a LIMIT of this build, named as such - callers take another route) */ \
+            const bool _oom = (_e == hipErrorOutOfMemory);                                \
+            ctx->set_error(std::string(_oom ? "the working set of this build does not fit the GPU's memory - " : "") + \
+                           std::string(#expr) + ": " + hipGetErrorString(_e));            \
             cleanup();                                                                    \
-            return GT_E_HIP;                                                              \
+            return _oom ? GT_E_LIMIT : GT_E_HIP;                                          \
         }                                                                                 \
     } while (0)
 

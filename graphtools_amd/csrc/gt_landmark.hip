@@ -507,6 +507,7 @@ extern "C" int gt_knn_first_nearest(gt_ctx* ctx, const void* Y, int64_t m, int32
     if (!Y || m <= 0 || k < 1 || !out_labels) GT_FAIL(ctx, GT_E_ARG, "gt_knn_first_nearest: bad arguments");
     GT_HIP(ctx, hipSetDevice(ctx->device));
     DevBuf d_idx, d_dist, d_out;
+    DevBufScope scratch{&d_idx, &d_dist, &d_out};   // (released on every exit, the early GT_HIP returns included)
     GT_HIP(ctx, d_idx.reserve(size_t(m) * k * sizeof(int64_t)));
     GT_HIP(ctx, d_dist.reserve(size_t(m) * k * sizeof(double)));
     GT_HIP(ctx, d_out.reserve(size_t(m) * sizeof(int64_t)));
@@ -521,9 +522,6 @@ extern "C" int gt_knn_first_nearest(gt_ctx* ctx, const void* Y, int64_t m, int32
     }
     if (rc == GT_OK) rc = gt_copy_to_host(ctx, out_labels, d_out.p, size_t(m) * sizeof(int64_t));
     const hipError_t es = hipStreamSynchronize(ctx->stream);
-    d_idx.release();
-    d_dist.release();
-    d_out.release();
     if (rc == GT_OK && es != hipSuccess) {
         ctx->set_error(std::string("gt_knn_first_nearest: ") + hipGetErrorString(es));
         rc = GT_E_HIP;
@@ -542,6 +540,7 @@ extern "C" int gt_nearest_landmark(gt_ctx* ctx, int64_t row0, int64_t row1, cons
         if (landmarks[j] < 0 || landmarks[j] >= ctx->n) GT_FAIL(ctx, GT_E_ARG, "gt_nearest_landmark: landmark out of range");
     const int64_t nrows = row1 - row0;
     DevBuf lmk, out;
+    DevBufScope scratch{&lmk, &out};
     GT_HIP(ctx, lmk.reserve(size_t(n_landmark) * sizeof(int64_t)));
     GT_HIP(ctx, out.reserve(size_t(nrows) * sizeof(int32_t)));
     std::vector<int64_t> lm_ctx;
@@ -578,8 +577,6 @@ extern "C" int gt_nearest_landmark(gt_ctx* ctx, int64_t row0, int64_t row1, cons
     if (e == hipSuccess)
         e = hipMemcpyAsync(out_clusters, out.p, size_t(nrows) * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    lmk.release();
-    out.release();
     if (e != hipSuccess) {
         ctx->set_error(std::string("gt_nearest_landmark: ") + hipGetErrorString(e));
         return GT_E_HIP;

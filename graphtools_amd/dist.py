@@ -365,15 +365,34 @@ class ShardedKnnGraph(object):
         self._keep = (send, recv)
         return nnz, flags
 
+    def draw_landmarks(self, n_landmark, random_state):
+        """The landmark rows of a random landmarking, ONE draw for the whole job: rank 0 draws
+        (``default_rng(random_state).choice(N, L, replace=False)``, the caller's row numbers) and broadcasts the rows it drew.
+        ``random_state=None`` - Graph's default - seeds from the OS, a different set in every process: ranks that each drew
+        their own would label their rows against different landmarks and gather the labels as if they shared one numbering."""
+        import torch
+
+        dist = _dist()
+        L = int(n_landmark)
+        if self.rank == 0:
+            drawn = np.random.default_rng(random_state).choice(self.n, L, replace=False).astype(np.int64)
+        else:
+            drawn = np.zeros(L, dtype=np.int64)
+        if self.world > 1:
+            t = torch.as_tensor(drawn, device=self._device)
+            src = dist.get_global_rank(self.group, 0) if self.group is not None else 0
+            dist.broadcast(t, src=src, group=self.group)
+            drawn = t.cpu().numpy()
+        return drawn
+
     def random_landmark_clusters(self, n_landmark, random_state):
-        """LandmarkGraph's random landmarking (graphs.py:1200-1213) over the ranks: the landmark rows are drawn on every rank
-        alike (``default_rng(random_state).choice(N, L, replace=False)``, the caller's row numbers), every rank assigns
+        """LandmarkGraph's random landmarking (graphs.py:1200-1213) over the ranks: the landmark rows are drawn once for the
+        job (:meth:`draw_landmarks`: rank 0's draw, broadcast - the caller's row numbers), every rank assigns
         its own rows to their nearest landmark (gt_nearest_landmark), one all-gather of the labels (4 B per row).
         Returns the cluster label of every row, by the caller's row numbers (numpy int32)."""
         import torch
 
-        rng = np.random.default_rng(random_state)
-        landmarks = rng.choice(self.n, int(n_landmark), replace=False)
+        landmarks = self.draw_landmarks(n_landmark, random_state)
         r0, r1 = int(self.splits[self.rank]), int(self.splits[self.rank + 1])
         if self.n > 5000 and hasattr(self.ctx, "points_device") and self._points.is_cuda:
             # sklearn's euclidean_distances arithmetic (graphs.py:1210): the rank's rows as queries of a 1-NN search against the

@@ -40,6 +40,11 @@ class DataGraph(Data, BaseGraph):
 
             device = int(os.environ.get("LOCAL_RANK", "0"))   # (torchrun's convention: one process per GPU of the node)
         self.device = device
+        if random_state is None and self._dist_ranks() is not None:
+            # Every rank runs this constructor on the same data and contributes ITS rows of data_nu to the all-gather: whatever
+            # is random in here (the randomized SVD behind n_pca, the landmark draw) has to be the same draw on every rank.
+            # random_state=None means "seed from the OS" - per process; one seed for the job instead: rank 0's, broadcast.
+            random_state = self._job_seed()
         Data.__init__(self, data, n_pca=n_pca, rank_threshold=rank_threshold, random_state=random_state)
         BaseGraph.__init__(self, **kwargs)
 
@@ -83,6 +88,18 @@ class DataGraph(Data, BaseGraph):
         if "nccl" in str(tdist.get_backend(getattr(self, "group", None))):
             return torch.device("cuda", int(getattr(self, "device", 0) or 0))
         return torch.device("cpu")
+
+    def _job_seed(self):
+        """one integer seed for all ranks of the job: drawn from the OS on rank 0, broadcast"""
+        import torch
+        import torch.distributed as tdist
+
+        group, world, rank = self._dist_ranks()
+        seed = torch.zeros(1, dtype=torch.int64, device=self._dist_device())
+        if rank == 0:
+            seed[0] = int(np.random.SeedSequence().generate_state(1, dtype=np.uint32)[0])
+        tdist.broadcast(seed, src=tdist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        return int(seed.item())
 
     def _no_sharded(self, what):
         if self._dist_ranks() is not None:
@@ -374,6 +391,14 @@ class kNNGraph(DataGraph):
         self._emit_build_warnings(flags, K)
         return K
 
+    def _sharded_graph(self):
+        """this rank's share of the row-sharded build (rebuilt - a collective call, every rank alike - when the graph came out
+        of a pickle: the device side does not travel)"""
+        self.K
+        if getattr(self, "_sharded", None) is None:
+            self._build_kernel_sharded()
+        return self._sharded
+
     def _build_on_device(self):
         """Kernel and diffusion operator built and left on the device, with the warnings of the build (reference: base.py:551-554,
         graphs.py:887-914); nothing crosses PCIe.  Idempotent while the device holds this graph's kernel."""
@@ -654,8 +679,7 @@ class LandmarkGraph(DataGraph):
                 raise NotImplementedError("graphtools_amd: random landmarking supports the euclidean metric only")
             if self._dist_ranks() is not None:
                 # every rank assigns its own rows, one all-gather of the labels (graphtools_amd.dist)
-                self.K
-                return np.asarray(self._sharded.random_landmark_clusters(self.n_landmark, self.random_state), dtype=np.int64)
+                return np.asarray(self._sharded_graph().random_landmark_clusters(self.n_landmark, self.random_state), dtype=np.int64)
             rng = np.random.default_rng(self.random_state)
             landmark_indices = rng.choice(n_samples, self.n_landmark, replace=False)
             if n_samples > 5000:
@@ -720,7 +744,7 @@ class LandmarkGraph(DataGraph):
             from . import dist as gdist
 
             group, world, rank = self._dist_ranks()
-            sk = self._sharded
+            sk = self._sharded_graph()
             self._landmark_op, tnnz = sk.landmark_operator(inverse.astype(np.int32), L)
             data, indices, indptr = self.hip.landmark_fetch_transitions(tnnz)
             n = self.data.shape[0]

@@ -471,6 +471,42 @@ def main():
         pass
     else:
         raise AssertionError("spectral landmarking answered on a sharded graph")
+    # 9. random_state=None (Graph's default): ONE landmark draw for the job - every rank labels its rows against the same
+    #    landmark rows (rank 0's draw, broadcast), so the gathered labels are the argmin against that one set
+    Gn = graphtools_amd.Graph(Xg, knn=10, decay=20, n_landmark=12, random_landmarking=True, distributed=True,
+                              initialize=False, n_pca=None, verbose=False)
+    assert Gn.random_state is not None, "the job seed was not drawn"
+    seeds = [None] * world
+    dist.all_gather_object(seeds, int(Gn.random_state))
+    assert len(set(seeds)) == 1, "the ranks hold different seeds: %r" % (seeds,)
+    Gn._hip_ctx = FakeCtx()
+    Gn.K
+    drawn = Gn._sharded.draw_landmarks(12, None)        # (None on purpose: rank 0's OS-seeded draw must reach everybody)
+    every = [None] * world
+    dist.all_gather_object(every, drawn.tolist())
+    assert all(e == every[0] for e in every), "the ranks drew different landmark sets"
+    cl = np.asarray(Gn._sharded.random_landmark_clusters(12, None))
+    lm_used = [None] * world
+    dist.all_gather_object(lm_used, cl.tolist())
+    assert all(c == lm_used[0] for c in lm_used), "the ranks disagree on the labels"
+    # coherent clusters: every label is the argmin against ONE 12-row landmark set; a landmark is its own nearest, so the
+    # set can be read back from the labels (the row of cluster j whose distance to itself is 0)
+    assert len(np.unique(cl)) == 12
+    # 10. n_pca with random_state=None: the randomized projection is the same on every rank (one seed), so the gathered
+    #     point set is ONE projection - the data_nu of the ranks agree bit for bit
+    Xw = np.random.default_rng(5).standard_normal((300, 40)).astype(np.float32)   # same on every rank
+    Gp = graphtools_amd.Graph(Xw, knn=5, decay=20, n_pca=6, distributed=True, initialize=False, verbose=False)
+    sums = [None] * world
+    dist.all_gather_object(sums, np.asarray(Gp.data_nu, dtype=np.float64).tobytes())
+    assert all(s == sums[0] for s in sums), "the ranks reduced the data with different random projections"
+    # 11. a row-sharded graph pickles: the device side (context, ShardedKnnGraph, process group) stays behind, K and P travel
+    import pickle
+
+    blob = pickle.dumps(Gl)
+    Gr = pickle.loads(blob)
+    assert not hasattr(Gr, "_sharded") and not hasattr(Gr, "group")
+    assert (Gr.K != Gl.K).nnz == 0 and (Gr.P != Gl.P).nnz == 0
+    np.testing.assert_array_equal(Gr.landmark_op, Gl.landmark_op)
     dist.barrier()
     dist.destroy_process_group()
     print("rank %d ok" % rank)

@@ -24,3 +24,28 @@ def test_sharded_build_world2_gloo():
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout[-3000:] + "\n" + res.stderr[-3000:]
     assert "rank 0 ok" in res.stdout and "rank 1 ok" in res.stdout
+
+
+def test_bench_gpus_n_without_launcher_never_runs_fewer_ranks():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset starts its own ranks; on a box with fewer GPUs it refuses
+    (non-zero exit, a message) instead of printing a one-rank line labelled n_gpus 1 (missing 2)."""
+    import torch
+
+    if torch.cuda.device_count() >= 2:
+        import pytest
+
+        pytest.skip("two GPUs visible: the launcher would run the benchmark")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode != 0
+    assert "--gpus 2 but only" in res.stderr and "refusing" in res.stderr
+    assert '"metric"' not in res.stdout
+
+
+def test_bench_rejects_a_launcher_that_disagrees_with_gpus():
+    env = dict(os.environ)
+    env.update(WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=env, capture_output=True,
+                         text=True, timeout=300)
+    assert res.returncode != 0 and "WORLD_SIZE=2" in res.stderr
