@@ -32,6 +32,7 @@ from .kernel import (  # noqa: F401
 from .exact import (  # noqa: F401
     cross_distances_exact,
     exact_graph,
+    exact_graph_rows,
     exact_kernel,
     exact_kernel_to_data,
     pairwise_distances_exact,

@@ -15,7 +15,8 @@ from scipy import sparse
 
 from .kernel import apply_anisotropy, diff_op, symmetrize_kernel
 
-__all__ = ["pairwise_distances_exact", "cross_distances_exact", "exact_kernel", "exact_graph", "exact_kernel_to_data"]
+__all__ = ["pairwise_distances_exact", "cross_distances_exact", "exact_kernel", "exact_graph", "exact_kernel_to_data",
+           "exact_graph_rows"]
 
 
 def pairwise_distances_exact(X):
@@ -109,3 +110,31 @@ def exact_graph(
     if sparse.issparse(K):
         K = sparse.csr_matrix(K)
     return K, diff_op(K)
+
+
+def exact_graph_rows(D_rows, D_cols, bw, rows, decay=40, thresh=1e-4):
+    """Rows ``rows`` of K and P of :func:`exact_graph` (precomputed distances, '+' rule, no anisotropy) WITHOUT the N x N
+    matrix: what a test at BASELINE config 4's size can afford (N = 2e5: the matrix is 160 GB and lives on the device).
+
+    D_rows : D[rows, :]  [m, N];  D_cols : D[:, rows]  [N, m]  (D need not be symmetric);  bw : the bandwidth of EVERY row -
+    the (knn+1)-th smallest entry of the row, graphs.py:1583-1587 (a selection: whoever picks it gets the same value).
+    The arithmetic is exact_kernel's, entry by entry and in D's dtype like numpy's (graphs.py:1589-1609): K0_ij =
+    exp(-(D_ij / bw_i)^decay), NaN -> 1, < thresh -> 0; then (K0 + K0^T) / 2 (base.py:557-561) and rows over their sums
+    (base.py:645, :func:`diff_op`).  Returns (K_rows, P_rows, degree_rows)."""
+    D_rows, D_cols = np.asarray(D_rows), np.asarray(D_cols)
+    bw = np.asarray(bw)
+    rows = np.asarray(rows)
+
+    def k0(pdx):
+        K = np.exp(-1 * np.power(pdx, decay))
+        K = np.where(np.isnan(K), 1, K)
+        K[K < thresh] = 0
+        return K
+
+    own = k0((D_rows.T / bw[rows]).T)            # K0[rows, :]
+    other = k0((D_cols.T / bw).T.T)              # K0[:, rows]^T laid out [m, N]: entry (r, j) = K0[j, rows[r]]
+    K = (own + other) / 2
+    norms = np.abs(K).sum(axis=1)
+    deg = K.sum(axis=1)
+    norms[norms == 0.0] = 1.0
+    return K, K / norms[:, None], deg

@@ -2,8 +2,12 @@
 Whatever it picks is exact (the other tests); this one bounds how badly `auto` can LOSE: on nine data families at
 N = 2e5 the default build must not take more than 1.5 x the time of the better of the two forced routes (symmetric pass forced
 on / classic pass forced) - plus 1 ms, the granularity of the fixed costs at this size.  Reference semantics are not involved:
-all three builds produce the same graph (asserted)."""
-import time
+all three builds produce the same graph (asserted).
+
+What is compared is DEVICE time: the HIP-event spans of the build's top-level stages (gt_stage_ms: events recorded on the
+library's stream around each stage), best of three builds - not the wall clock, which on a shared box measures the
+neighbours - and a comparison that fails is repeated (up to three attempts) before the test does: a busy box cannot turn the
+parity suite red, a ladder that really picks the slow route still does."""
 
 import numpy as np
 import pytest
@@ -60,6 +64,11 @@ FAMILIES = {
 }
 
 
+# the top-level stage spans of gt_graph_build (nested ones - symm_bins, symm_merge ... - are parts of these)
+TOP_STAGES = ("query_order", "sym_prepare", "sym_seed", "sym_bound", "knn_select", "sym_cold", "rerank", "fallback", "radius",
+              "affinity", "symmetrize", "normalize")
+
+
 def _build_ms(X, opts, reps=3):
     from graphtools_amd import _hip
 
@@ -71,12 +80,10 @@ def _build_ms(X, opts, reps=3):
         p, keep = c.make_params(15, 40.0, 1e-4, None, 1.0, None, "+", None, 0)
         best, nnz = None, None
         for _ in range(reps):
-            c.sync()
-            t = time.perf_counter()
             c.set_points(X)
             nnz, _ = c.graph_build(p)
             c.sync()
-            ms = (time.perf_counter() - t) * 1e3
+            ms = sum(max(c.stage_ms(s), 0.0) for s in TOP_STAGES)
             best = ms if best is None else min(best, ms)
         sym = bool(c.knn_stats()["symmetric"])
         deg = c.graph_fetch_vec(1)
@@ -88,12 +95,17 @@ def _build_ms(X, opts, reps=3):
 @pytest.mark.parametrize("family", list(FAMILIES))
 def test_auto_is_never_far_behind_the_better_forced_route(family):
     X = FAMILIES[family]()
-    auto, nnz_a, sym_a, s_a = _build_ms(X, {})
-    forced_sym, nnz_s, sym_s, s_s = _build_ms(X, {"select_symmetric": "1"})
-    classic, nnz_c, sym_c, s_c = _build_ms(X, {"select_symmetric": "0"})
-    assert nnz_a == nnz_s == nnz_c and s_a == s_s == s_c, "the routes built different graphs"
-    assert not sym_c
-    best = min(forced_sym, classic)
-    print("%-42s auto %.2f ms (%s)  symmetric forced %.2f  classic %.2f" % (family, auto, "symmetric" if sym_a else "classic",
-                                                                             forced_sym, classic))
-    assert auto <= 1.5 * best + 1.0, "auto %.2f ms vs the better forced route %.2f ms on '%s'" % (auto, best, family)
+    last = None
+    for attempt in range(3):
+        auto, nnz_a, sym_a, s_a = _build_ms(X, {})
+        forced_sym, nnz_s, sym_s, s_s = _build_ms(X, {"select_symmetric": "1"})
+        classic, nnz_c, sym_c, s_c = _build_ms(X, {"select_symmetric": "0"})
+        assert nnz_a == nnz_s == nnz_c and s_a == s_s == s_c, "the routes built different graphs"
+        assert not sym_c
+        best = min(forced_sym, classic)
+        print("%-42s auto %.2f ms (%s)  symmetric forced %.2f  classic %.2f  (device time, attempt %d)" % (
+            family, auto, "symmetric" if sym_a else "classic", forced_sym, classic, attempt + 1))
+        last = (auto, best)
+        if auto <= 1.5 * best + 1.0:
+            return
+    assert False, "auto %.2f ms vs the better forced route %.2f ms on '%s' (device time, three attempts)" % (last[0], last[1], family)

@@ -259,3 +259,25 @@ def test_knn_extension_with_vector_bandwidth_matches_reference(tag, scale):
     Kr = golden_csr(z, tag)
     assert np.array_equal(K.indptr, Kr.indptr) and np.array_equal(K.indices, Kr.indices)
     assert np.array_equal(K.data, Kr.data)
+
+
+def test_exact_graph_rows_is_exact_graph_restricted_to_rows():
+    """oracle.exact_graph_rows (the checker of BASELINE config 4 at full size, where the N x N matrix lives on the device only)
+    gives the rows of oracle.exact_graph bit for bit - also on a matrix that is not symmetric"""
+    from scipy.spatial.distance import pdist, squareform
+
+    import oracle
+
+    rng = np.random.default_rng(0)
+    n = 300
+    D = squareform(pdist(rng.standard_normal((n, 6)))).astype(np.float32)
+    D = (D * (1 + 0.05 * rng.random((n, n)))).astype(np.float32)
+    np.fill_diagonal(D, 0)
+    for decay, knn in ((15, 5), (40, 15)):
+        K, P = oracle.exact_graph(D, knn=knn, decay=decay, precomputed="distance")
+        bw = np.max(np.partition(D, knn + 1, axis=1)[:, : knn + 1], axis=1)
+        rows = np.array([3, 17, 299, 0])
+        Kr, Pr, deg = oracle.exact_graph_rows(D[rows], D[:, rows], bw, rows, decay=decay)
+        assert Kr.dtype == K.dtype == np.float32
+        assert np.array_equal(K[rows], Kr) and np.array_equal(P[rows], Pr)
+        np.testing.assert_allclose(deg, K[rows].sum(axis=1), rtol=1e-6)

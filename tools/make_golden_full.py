@@ -12,6 +12,16 @@ with the reference imported from /root/reference (tools/ref_import.py) and keep 
 
 Only inputs' recipe (seeded generator) and outputs are written; no reference text travels.  Runs only in the build
 container: `python tools/make_golden_full.py c2` (about 15 s) / `c3` (about 20 minutes, 8 cores, ~25 GB of RAM).
+
+Round 5 - the production paths of BASELINE configs 4 and 5 at sizes where they engage:
+
+  c4   TraditionalGraph(D, precomputed="distance", knn=15, decay=40) on a float32 distance matrix of n = 16384 points (the
+       row-streaming form of gt_dense.hip is the default from 16384 rows).  The points are `mix` d = 100 seed 4 rounded to
+       multiples of 1/4: every squared distance is then an exact multiple of 1/16 below 2^24 - the same float32 matrix D on
+       any BLAS, any box (quantised_distance_matrix).  Kept: per-row non-zero counts and column hashes of K, kernel degrees,
+       10^5 sampled (i, j, K_ij, P_ij) (float32, as the reference holds them).
+  c5   kNNLandmarkGraph: mix N = 1e5, d = 50, seed 3, knn=15 decay=40, n_landmark=2000, random_landmarking=True,
+       random_state=42: clusters (all), landmark_op (2000 x 2000, float64), transitions (row lengths, hashes, samples).
 """
 import hashlib
 import os
@@ -100,6 +110,103 @@ def build(tag):
         tag, n, K.nnz, t2 - t0, t1 - t0, os.path.getsize(path) / 1e6), flush=True)
 
 
+def quantised_points(n, d, seed):
+    """`mix` rounded to multiples of 1/4 (float64): squared distances are exact multiples of 1/16"""
+    return np.round(make_mix(n, d, seed, dtype=np.float64) * 4.0) / 4.0
+
+
+def quantised_distance_matrix(Xq):
+    """float32 euclidean distance matrix of quantised points: d2 = |x|^2 + |y|^2 - 2 x.y is EXACT in float64 in any summation
+    order (integers / 16 far below 2^53), sqrt is correctly rounded, so is the conversion to float32: one matrix everywhere"""
+    sq = (Xq * Xq).sum(axis=1)
+    d2 = sq[:, None] + sq[None, :] - 2.0 * (Xq @ Xq.T)
+    assert d2.min() >= 0.0 and np.all(d2 * 16.0 == np.round(d2 * 16.0))
+    return np.sqrt(d2).astype(np.float32)
+
+
+def dense_row_stats(M):
+    """non-zero count and 16-bit column checksum of every row of a dense matrix (row_hash's formula)"""
+    nz = M != 0
+    cnt = nz.sum(axis=1)
+    cols = np.flatnonzero(nz.ravel()) % M.shape[1]
+    ptr = np.concatenate([[0], np.cumsum(cnt)])
+    return cnt, (row_hash(cols, ptr) >> np.uint32(16)).astype(np.uint16)
+
+
+def build_c4(n=16384, d=100, seed=4):
+    gt = import_reference()
+    D = quantised_distance_matrix(quantised_points(n, d, seed))
+    t0 = time.perf_counter()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        G = gt.Graph(D, precomputed="distance", knn=15, decay=40, n_pca=None, verbose=0)
+        K = np.asarray(G.K)
+        P = np.asarray(G.P)
+    t1 = time.perf_counter()
+    assert type(G).__name__ == "TraditionalGraph" and K.shape == (n, n)
+    cnt, h16 = dense_row_stats(K)
+    degree = np.asarray(G.kernel_degree).ravel()
+    rng = np.random.default_rng(12345)
+    nzpos = np.flatnonzero(K.ravel())
+    pos = np.sort(rng.choice(nzpos, size=100000, replace=False))
+    import scipy
+    import sklearn
+
+    out = {"n": np.int64(n), "d": np.int64(d), "seed": np.int64(seed), "knn": np.int64(15), "decay": np.float64(40),
+           "thresh": np.float64(1e-4), "nnz": np.int64(len(nzpos)), "dtype_K": np.array(str(K.dtype)), "dtype_P": np.array(str(P.dtype)),
+           "row_nnz": cnt.astype(np.uint32), "row_hash": h16, "degree": degree.astype(np.float64),
+           "P_row_sums": P.astype(np.float64).sum(axis=1),
+           "sample_i": (pos // n).astype(np.int32), "sample_j": (pos % n).astype(np.int32),
+           "sample_K": K.ravel()[pos].astype(np.float64), "sample_P": P.ravel()[pos].astype(np.float64),
+           "time_total_s": np.float64(t1 - t0), "cores": np.int64(os.cpu_count()),
+           "versions": np.array("graphtools %s numpy %s scipy %s sklearn %s" % (gt.__version__, np.__version__, scipy.__version__,
+                                                                                sklearn.__version__))}
+    path = os.path.join(OUT, "full_c4_n16384_reference.npz")
+    np.savez_compressed(path, **out)
+    print("c4: n=%d nnz=%d (%.1f per row) K %s P %s  reference wall %.1f s  fixture %.2f MB" % (
+        n, len(nzpos), len(nzpos) / n, K.dtype, P.dtype, t1 - t0, os.path.getsize(path) / 1e6), flush=True)
+
+
+def build_c5(n=100000, d=50, seed=3, L=2000):
+    gt = import_reference()
+    X = make_mix(n, d, seed)
+    t0 = time.perf_counter()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        G = gt.Graph(X, knn=15, decay=40, n_pca=None, n_landmark=L, random_landmarking=True, random_state=42, verbose=0)
+        op = np.asarray(G.landmark_op)
+        T = sparse.csr_matrix(G.transitions)
+        clusters = np.asarray(G.clusters)
+    t1 = time.perf_counter()
+    assert type(G).__name__ == "kNNLandmarkGraph" and op.shape == (L, L)
+    T.sort_indices()
+    T.eliminate_zeros()
+    rng = np.random.default_rng(12345)
+    pos = np.sort(rng.choice(T.nnz, size=100000, replace=False))
+    rows = np.searchsorted(T.indptr, pos, side="right") - 1
+    import scipy
+    import sklearn
+
+    out = {"n": np.int64(n), "d": np.int64(d), "seed": np.int64(seed), "knn": np.int64(15), "decay": np.float64(40),
+           "n_landmark": np.int64(L), "random_state": np.int64(42),
+           "clusters": clusters.astype(np.int32), "landmark_op": op.astype(np.float64),
+           "t_nnz": np.int64(T.nnz), "t_row_len": np.diff(T.indptr).astype(np.uint16),
+           "t_row_hash": (row_hash(T.indices, T.indptr) >> np.uint32(16)).astype(np.uint16),
+           "t_sample_i": rows.astype(np.int32), "t_sample_j": T.indices[pos].astype(np.int32), "t_sample_v": T.data[pos].astype(np.float64),
+           "time_total_s": np.float64(t1 - t0), "cores": np.int64(os.cpu_count()),
+           "versions": np.array("graphtools %s numpy %s scipy %s sklearn %s" % (gt.__version__, np.__version__, scipy.__version__,
+                                                                                sklearn.__version__))}
+    path = os.path.join(OUT, "full_c5_n1e5_reference.npz")
+    np.savez_compressed(path, **out)
+    print("c5: N=%d L=%d transitions nnz=%d  reference wall %.1f s  fixture %.2f MB" % (n, L, T.nnz, t1 - t0,
+                                                                                      os.path.getsize(path) / 1e6), flush=True)
+
+
 if __name__ == "__main__":
     for tag in sys.argv[1:] or ["c2"]:
-        build(tag)
+        if tag == "c4":
+            build_c4()
+        elif tag == "c5":
+            build_c5()
+        else:
+            build(tag)
