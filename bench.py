@@ -203,6 +203,75 @@ def cpu_baseline_full(X, knn, decay, thresh, info):
             "kind": "port", "sample": "all %d rows, measured live (--cpu-full)" % X.shape[0], "host": info}
 
 
+def cpu_baseline_c2(info, n=100000, d=50):
+    """BASELINE config 2 through the oracle port, IN FULL (N = 1e5: seconds on the box's cores) - SURVEY 8d asks for the CPU
+    reference beside every config."""
+    import oracle
+    from scipy import sparse
+
+    engine = "sklearn" if info["versions"].get("sklearn") else "numpy"
+    X = make_mix(n, d, 0)
+    t0 = time.perf_counter()
+    K0 = oracle.knn_kernel(X, knn=15, decay=40.0, thresh=1e-4, engine=engine)
+    t1 = time.perf_counter()
+    K = sparse.csr_matrix(oracle.symmetrize_kernel(K0, "+"))
+    P = oracle.kernel.diff_op_fast(K)
+    t2 = time.perf_counter()
+    return {"value": 1.0 / (t2 - t0), "unit": "graphs/s", "seconds": t2 - t0, "kernel_rows_s": t1 - t0, "symmetrise_P_s": t2 - t1,
+            "nnz_K": int(K.nnz), "nnz_P": int(P.nnz), "cores": worker_threads(info), "physical_cores": info.get("physical_cores"),
+            "kind": "port", "sample": "oracle port (%s kNN engine), all %d rows, measured live" % (engine, n),
+            "versions": info["versions"]}
+
+
+def cpu_baseline_c4(info, sizes=(5000, 10000, 20000), n_full=200000, d=100):
+    """BASELINE config 4 through the oracle port (oracle.exact_graph on a float32 distance matrix: bandwidths by partition,
+    exp(-(D / bw)^decay), threshold, (K + K^T) / 2, rows over their sums - graphs.py:1583-1609, base.py:557-561, 645) at three
+    sizes the host can hold, fitted t = a N^2 (every step is a pass over the N x N matrix) and EXTRAPOLATED to N = 2e5:
+    the full size needs ~1 TB of host arrays in numpy's formulation and is not run."""
+    import oracle
+
+    pts = []
+    for n in sizes:
+        X = make_mix(n, d, 2).astype(np.float64)
+        sq = (X * X).sum(axis=1)
+        D = np.sqrt(np.maximum(sq[:, None] + sq[None, :] - 2.0 * (X @ X.T), 0.0)).astype(np.float32)   # (the config's INPUT: not timed)
+        np.fill_diagonal(D, 0.0)
+        t0 = time.perf_counter()
+        K, P = oracle.exact_graph(D, knn=15, decay=40, thresh=1e-4, precomputed="distance")
+        pts.append((n, time.perf_counter() - t0))
+        del D, K, P
+    a = sum(t * n * n for n, t in pts) / sum(float(n) ** 4 for n, _ in pts)     # least squares through the origin in N^2
+    est = a * float(n_full) ** 2
+    return {"value": 1.0 / est, "unit": "graphs/s", "seconds": est, "extrapolated": True,
+            "measured": [{"n": int(n), "seconds": round(t, 3)} for n, t in pts], "fit": "t = %.3e x N^2 s" % a,
+            "cores": worker_threads(info), "physical_cores": info.get("physical_cores"), "kind": "port",
+            "sample": "oracle.exact_graph timed at N = %s, fitted to N^2 and extrapolated to N = %d (flag `extrapolated`)"
+                      % ("/".join(str(n) for n, _ in pts), n_full),
+            "versions": info["versions"]}
+
+
+def cpu_baseline_c5(info, X, K0, K, n_landmark=2000, budget_s=12.0):
+    """BASELINE config 5 on the host's cores: the kernel part as cpu_baseline_sample times it (kNN + affinity rows on a block of
+    query rows scaled to N, symmetrise + diff_op at full size), then - in full - the random landmark assignment
+    (graphs.py:1200-1213) and the landmark operator (graphs.py:1169-1246) on the finished kernel K (host CSR from the device
+    build: data for the timed algebra, its production is not timed)."""
+    import oracle
+
+    ker = cpu_baseline_sample(X, 15, 40.0, 1e-4, K0, info, budget_s=budget_s)
+    t0 = time.perf_counter()
+    clusters, _ = oracle.random_landmark_clusters(X, n_landmark, 42)
+    t1 = time.perf_counter()
+    op, _ = oracle.landmark_operator(K, clusters)
+    t2 = time.perf_counter()
+    total = 1.0 / ker["value"] + (t2 - t0)
+    return {"value": 1.0 / total, "unit": "graphs/s", "seconds_estimated": total, "kernel": ker["sample"],
+            "landmark_assignment_s": t1 - t0, "landmark_operator_s": t2 - t1, "cores": worker_threads(info),
+            "physical_cores": info.get("physical_cores"), "kind": "port",
+            "sample": "kernel: sampled query rows scaled to N (see `kernel`); random landmarking + landmark_op (L = %d): all rows, live"
+                      % n_landmark,
+            "versions": info["versions"]}
+
+
 def recorded_cpu_full(info):
     """The committed full-size run, reported only when it was made on the same kind of host (cpu model, core count,
     library versions) - otherwise it says nothing about this box."""
@@ -473,7 +542,7 @@ def secondary_c4_points(_hip, torch, device, n=200000, d=100, steps=2):
         _hip.release_cached_memory()
 
 
-def secondary_c5(n=1000000, d=50):
+def secondary_c5(n=1000000, d=50, cpu_info=None):
     """BASELINE config 5 on one GPU: kNN kernel + landmark operator (random landmarking), host arrays in and out."""
     import warnings
 
@@ -497,6 +566,18 @@ def secondary_c5(n=1000000, d=50):
     best["workload"] = "C5 on one GPU: mix N=%d d=%d seed=3, knn=15 decay=40, n_landmark=2000 random landmarking -> landmark_op; " \
                        "host-complete (host X in, host operator out)" % (n, d)
     best["graphs_per_s"] = 1.0 / best["total_s"]
+    if cpu_info is not None:
+        try:
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                G = graphtools_amd.Graph(X, knn=15, decay=40, n_pca=None, verbose=0)
+                K0 = G.build_kernel()      # the unsymmetrised kernel (graphs.py:771-982): input of the timed symmetrisation
+                K = G.K
+            best["cpu_baseline"] = cpu_baseline_c5(cpu_info, X, K0, K)
+            best["vs_cpu_baseline"] = best["graphs_per_s"] / best["cpu_baseline"]["value"]
+            del G, K0, K
+        except Exception as e:   # pragma: no cover
+            best["cpu_baseline"] = {"error": repr(e)}
     return best
 
 
@@ -800,7 +881,7 @@ def main():
                 "c2": lambda: secondary_knn(_hip, torch, device, "C2: mix N=1e5 d=50 seed=0, knn=15 decay=40", make_mix(100000, 50, 0), steps=5),
                 "c4": lambda: secondary_c4(_hip, torch, device),
                 "c4points": lambda: secondary_c4_points(_hip, torch, device),
-                "c5": lambda: secondary_c5(),
+                "c5": lambda: secondary_c5(cpu_info=None if args.no_cpu_baseline else info),
             }
             for name in want:
                 t0 = time.perf_counter()
@@ -810,6 +891,18 @@ def main():
                     sec[name] = {"error": repr(e)}
                 sec[name]["leg_wall_s"] = round(time.perf_counter() - t0, 1)
                 _hip.release_cached_memory()
+                # the CPU reference beside the config, on the box's cores: C2 in full, C4 fitted and extrapolated
+                if not args.no_cpu_baseline and name in ("c2", "c4") and "error" not in sec[name]:
+                    try:
+                        cb = cpu_baseline_c2(info) if name == "c2" else cpu_baseline_c4(info)
+                        sec[name]["cpu_baseline"] = cb
+                        gps = sec[name].get("graphs_per_s")
+                        if gps:
+                            sec[name]["vs_cpu_baseline"] = gps / cb["value"]
+                            sec[name]["vs_cpu_baseline_note"] = "device-resident GPU build against the host-to-host CPU port" + (
+                                "; the CPU figure is extrapolated" if cb.get("extrapolated") else "")
+                    except Exception as e:   # pragma: no cover
+                        sec[name]["cpu_baseline"] = {"error": repr(e)}
             out["secondary"] = sec
         if single and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_sample(X, args.knn, args.decay, thresh, K0, info)

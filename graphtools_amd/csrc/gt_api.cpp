@@ -430,6 +430,14 @@ int gt_set_option(gt_ctx* ctx, const char* name, const char* value) {
         ctx->symm_bin_shift = sh;
         return GT_OK;
     }
+    if (k == "rerank_rows_per_wave") {
+        ctx->rerank_rows_per_wave = std::min(64, std::max(1, std::atoi(value)));
+        return GT_OK;
+    }
+    if (k == "select_sym_cold_local") {
+        ctx->sym_cold_local = std::atoi(value) != 0 ? 1 : 0;
+        return GT_OK;
+    }
     if (k == "select_sym_cold_split") {
         ctx->sym_cold_split = std::atoi(value) != 0 ? 1 : 0;
         return GT_OK;

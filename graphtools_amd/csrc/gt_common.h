@@ -216,6 +216,10 @@ struct gt_ctx {
     int32_t symm_pair_ok = 1;   //   ... not refuted for the bound point set (a union row beyond the register sorts)
     int32_t symm_fill_threads = 256;   //   threads per workgroup of bin_fill_kernel (256 | 512 | 1024)
     int32_t symm_bin_shift = 0; //   log2 of the rows per bin (0: 9, more from 2 M rows; development / tests: 8 ... 12)
+    int32_t rerank_rows_per_wave = 8;   // rerank_sym4_kernel: consecutive sorted positions one wave re-ranks, the next row's list prefetched
+    int32_t sym_cold_local = 1; //   the cold launch scores its units in the frame of their queries (gt_knn_select.hip sym_cold_local_kernel:
+                                //   float16 roundings of (x - o) sc from the sorted float32 points) - the margin of the float16 chain shrinks
+                                //   from |x||y| 2^-10 to cell size; 0: the compact copy in the global frame (rounds 2-4)
     int32_t sym_cold_split = 0; //   the cold launch behind the bound pass scores with the three split chains (tight error bound: a third fewer
                                 //   candidates - measured at C3: re-rank 3.96 -> 3.25 ms, cold launch 2.51 -> 3.25 ms: no net gain, off by default)
     int32_t sym_bounds = -1;    //   bound pass in front of the two-stage collect (cell balls): -1 auto / 1 on, 0 off

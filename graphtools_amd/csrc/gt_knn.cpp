@@ -17,7 +17,7 @@ void gt_free_knn_work(gt_ctx* ctx) {
                       &k->d2_lb, &k->fb_rows, &k->fb_count, &k->fb_scratch, &k->gflags, &k->prof, &k->fb_qrows, &k->fb_thr, &k->fb_lists,
                       &k->fb_counts, &k->fb_max, &k->unproven, &k->qorder, &k->qthr0, &k->qlomax_dev, &k->Ycs, &k->hnegs,
                       &k->sym_g, &k->sym_gmin, &k->tlists, &k->tcounts, &k->sym_stat, &k->sym_work, &k->sym_tiles,
-                      &k->sym_tile_cnt, &k->sh_invperm, &k->sh_lists, &k->sh_counts, &k->sh_cnt, &k->sh_own, &k->sh_tmp, &k->sym_hh, &k->sym_thrh, &k->sym_gh, &k->sym_gminh, &k->sym_queue, &k->sym_qcount, &k->sym_qdense, &k->sym_qtot, &k->sym_racc, &k->sym_farcnt, &k->sym_z, &k->sym_p, &k->sym_cov, &k->sym_qspill, &k->sym_rrow, &k->sym_bwork, &k->hnegs_fin, &k->Xs, &k->xns, &k->cand_d2t, &k->keyt_ok, &k->nokeyt_rows, &k->nokeyt_count})
+                      &k->sym_tile_cnt, &k->sh_invperm, &k->sh_lists, &k->sh_counts, &k->sh_cnt, &k->sh_own, &k->sh_tmp, &k->sym_hh, &k->sym_thrh, &k->sym_gh, &k->sym_gminh, &k->sym_queue, &k->sym_qcount, &k->sym_qdense, &k->sym_qtot, &k->sym_racc, &k->sym_farcnt, &k->sym_z, &k->sym_p, &k->sym_cov, &k->sym_qspill, &k->sym_rrow, &k->sym_bwork, &k->sym_rloc, &k->sym_gcen, &k->hnegs_fin, &k->Xs, &k->xns, &k->cand_d2t, &k->keyt_ok, &k->nokeyt_rows, &k->nokeyt_count})
         b->release();
     delete k;
     ctx->knn = nullptr;
@@ -525,6 +525,26 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
             }
             if (two_stage && !bound_done) GT_TRY(gt_sym_two_stage_prepare(ctx, perm, n_pad_s, em, need_m, a, bound_tried));
             const bool two_now = bound_done || a.sym.half_steps > 0;
+            k->sym_cold_local_used = false;
+            // (behind the bound pass only: the units stage one of the two-stage collect lets through - 7.6 M on the manifold
+            //  set - are mostly far pairs that file nothing; there the launch is all operand traffic and the frame costs
+            //  14.0 -> 20.9 ms for 0.4 ms of re-rank)
+            if (bound_done && ctx->sym_cold_local != 0 && !split_cold && k->xs_ready && ctx->dtype == GT_F32 && (k->xs_d & 3) == 0 &&
+                k->xs_d <= ctx->DP && ctx->DP >= 32 && ctx->DP <= 64) {
+                // the cold launch (behind the bound pass, or behind stage one) in the frame of its queries: what every row needs
+                // listed, as a radius (the one the re-rank will claim: lb of thr - the thresholds are final here), and room for
+                // the query groups' centres
+                GT_HIP(ctx, k->sym_rloc.reserve(size_t(n_pad_s) * sizeof(float)));
+                GT_HIP(ctx, k->sym_gcen.reserve(size_t(n_pad_s / 64) * ctx->DP * sizeof(float)));
+                GT_TRY(gt_sym_row_radius(ctx, perm, n_pad_s, k->thr_final.as<float>(), em, k->sym_rloc.as<float>(), 0.0));
+                a.sym.xs = k->Xs.as<float>();
+                a.sym.xs_d = k->xs_d;
+                a.sym.xs_n = int32_t(ctx->n);
+                a.sym.gcen = k->sym_gcen.as<float>();
+                a.sym.rloc = k->sym_rloc.as<float>();
+                a.sym.sc = float(ctx->sc);
+                k->sym_cold_local_used = true;
+            }
             if (!two_now && ctx->sym_mode < 0 && double(k->sym_far) >= 0.5 * double(nq)) {
                 // neither the cell bounds nor the partial distances prune this point set, and every second row found a seed
                 // outside the cells around it: no cluster structure at the cells' scale.  The one-stage collect would score
@@ -1067,7 +1087,7 @@ extern "C" int gt_knn_stats(const gt_ctx* ctx, int64_t* out12) {
     for (int i = 0; i < 8; ++i) out12[4 + i] = (k && k->sym_used) ? int64_t(k->sym_stat_host[i]) : 0;
     if (k && k->sym_used) out12[6] = k->sym_nseg;   // work items per query block of launch B
     if (k && k->sym_used) out12[5] = k->sym_two_used ? k->sym_cold_entries : 0;   // pairs the cold launch scored in full
-    if (k && k->sym_used) out12[7] = (k->sym_two_used ? 1 : 0) | (k->sym_seed_dense ? 2 : 0);   // bit 0: two-stage collect ran, bit 1: dense seeding kernel
+    if (k && k->sym_used) out12[7] = (k->sym_two_used ? 1 : 0) | (k->sym_seed_dense ? 2 : 0) | (k->sym_cold_local_used ? 4 : 0);   // bit 0: two-stage collect ran, bit 1: dense seeding kernel
     if (k && k->sym_used) out12[4] = (k->sym_two_used && k->sym_bound_used) ? 1 : 0;   // units listed by cell bounds, no collect launch
     out12[10] = k ? k->sym_far : 0;                 // kept rows of launch A outside the neighbourhood cells (all points)
     return GT_OK;

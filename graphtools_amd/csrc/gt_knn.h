@@ -46,6 +46,9 @@ struct KnnWork {
     DevBuf sym_z, sym_p, sym_cov;                 //   the stage-one copy Z = P x, its frame P, sample covariance scratch
     DevBuf sym_qspill;                            //   spill area of the queue (+ its counter)
     DevBuf sym_rrow, sym_bwork;                   //   bound pass: radius of every row in the stage-one copy, cell scratch
+    DevBuf sym_rloc, sym_gcen;                    //   local-frame cold launch: the radius every row needs listed (scaled), the centres of
+                                                  //   the 64-row query groups
+    bool sym_cold_local_used = false;
     bool sym_bound_used = false;                  //   the last symmetric pass listed its units by cell bounds (no collect launch)
     DevBuf sym_queue, sym_qcount, sym_qdense, sym_qtot;   //   and the queue of its deferred cold pass (wave regions,
                                                           //   their counts, the compacted queue, {total, overflow})

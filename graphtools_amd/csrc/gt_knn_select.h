@@ -56,6 +56,19 @@ struct SymDev {
                                // rows' side belongs to whoever owns the rows)
     int32_t list_shift = 0;    // sched 1: the tile list of query block b is list b >> list_shift (narrow 128-row
                                // workgroups on lists made for 256-row blocks)
+    // mode 4 in a LOCAL FRAME (sym_cold_local_kernel): the units are scored on float16 roundings of (x - o) sc, o = the centre
+    // of the unit's 64 queries - the rounding error scales with the size of a cell, not with the distance from the origin.
+    // xs: the float32 points in sorted order (row stride xs_d floats, a multiple of 4, xs_n rows), gcen [n_pad / 64][dp]:
+    // the groups' centres (scaled by sc), rloc [n_pad]: the radius every row needs listed, scaled (-inf: nothing, +inf:
+    // everything).  nullptr: the launch scores the compact copy as before.
+    const float* xs = nullptr;
+    int32_t xs_d = 0;
+    int32_t xs_n = 0;
+    const float* gcen = nullptr;
+    const float* rloc = nullptr;
+    float sc = 0.f;
+    int32_t gc_first = 0;      // the centres of the groups [gc_first, gc_first + gc_count) are formed (gc_count = 0: all)
+    int32_t gc_count = 0;
 };
 
 struct SelectArgs {

@@ -1416,6 +1416,266 @@ __global__ __launch_bounds__(256, CP == 1 ? 2 : GT_SEL_COLD_WAVES) void sym_cold
     (void)w;
 }
 
+// ---- the cold pass in a LOCAL FRAME -----------------------------------------------------------------------------------
+// The single float16 chain rounds every coordinate of x sc to 11 bits: the score of a pair is off by up to ~2^-10 |x||y|, an
+// error that grows with the distance of the points from the ORIGIN, while the quantity the pass decides on - is this pair closer
+// than either row's radius? - lives at the scale of a cell.  On C3 (|x| ~ 46, neighbours ~ 11 apart) the margin the thresholds
+// have to leave for it lets a third of the collected candidates through for nothing (35 % of 117 M: DESIGN 4.4), and the
+// re-rank, the largest kernel of the build, evaluates them all.
+// Here a unit is scored in the frame of its QUERIES: o = the centre of the 64 query rows (gt_sym_group_centres), both
+// operands are float16 roundings of (x - o) sc formed on the fly from the float32 points in sorted order.  Everything is then
+// EXACT arithmetic on perturbed points x' = o + u / sc, |x' - x| <= eps |x - o| (eps = 2^-11: the float16 rounding):
+//     -|x' - y'|^2 / 2 = u.w - |w|^2 / 2 - |u|^2 / 2           (u, w: the rounded operands; norms of the ROUNDED rows, float32)
+// and |x' - y'| differs from |x - y| by at most delta = eps (|u| + |w|) (triangle inequality).  A pair row q needs listed
+// (|x - y| <= r_q, rloc) has |x' - y'| <= r_q + delta: the test  s > T_q := -(r_q + delta)^2 / 2 - E  never loses it (E: the
+// float32 accumulation, (DP + 16) 2^-24 (|u| + |w|)^2); the same s against T_j decides for the database row.  delta and E
+// are formed per unit from the largest operand norms (a few DPP steps).  With |u|, |w| ~ a cell radius the margin in d^2 is
+// ~ 2 r delta ~ 0.3 on C3 where the global frame's 2 e was ~ 3.5.
+// What is FILED is an upper bound of the true score in the global frame's terms, (|x|^2 - (|x' - y'| - delta)^2) / 2 scaled -
+// so that the re-rank's bound on what lies beyond a full table (bound_of_score of the 257th key) holds as it stands.
+template <typename SYM>
+__device__ __forceinline__ void cold_admit_local(const f32x16& A0, const f32x16& A1, const float tq0, const float tq1,
+                                                 const float hq0, const float hq1, const float fq0, const float fq1,
+                                                 const uint32_t qpos0, const uint32_t qpos1, const uint32_t tbase,
+                                                 const float* __restrict__ Tl, const float* __restrict__ Bl, const bool tr_on,
+                                                 const int lane, const int li, const int h, const SYM& sy) {
+    // tq: forward thresholds on the accumulator (T_q - hu_q); hq: -|u_q|^2 / 2; fq: what turns an accumulator into the filed
+    // forward score; Tl / Bl (LDS, by row of the sub-tile): the rows' thresholds T_j and their filing terms
+    const uint32_t tcap = uint32_t(sy.tcap);
+    uint32_t nf0 = 0u, nf1 = 0u;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        nf0 += (A0[e] > tq0) ? 1u : 0u;
+        nf1 += (A1[e] > tq1) ? 1u : 0u;
+    }
+    uint32_t k0 = 0u, k1 = 0u;
+    if (nf0) k0 = atomicAdd(&sy.tcounts[qpos0], nf0);
+    if (nf1) k1 = atomicAdd(&sy.tcounts[qpos1], nf1);
+    uint32_t vcnt = 0u;
+    if (tr_on) {   // wave-uniform
+#pragma unroll
+        for (int g_ = 0; g_ < 4; ++g_) {
+            const float4 gv = *reinterpret_cast<const float4*>(Tl + 8 * g_ + 4 * h);
+            const float ge[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+            for (int c_ = 0; c_ < 4; ++c_) {
+                const int e = 4 * g_ + c_;
+                const unsigned long long c0 = __ballot((A0[e] + hq0) > ge[c_]), c1 = __ballot((A1[e] + hq1) > ge[c_]);
+                const uint32_t lo = uint32_t(__popcll(c0 & 0xFFFFFFFFull) + __popcll(c1 & 0xFFFFFFFFull));
+                const uint32_t hi = uint32_t(__popcll(c0 >> 32) + __popcll(c1 >> 32));
+                asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(vcnt) : "s"(lo), "n"(e));
+                asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(vcnt) : "s"(hi), "n"(e + 16));
+            }
+        }
+    }
+    uint32_t vbase = 0u;
+    if (vcnt != 0u) {
+        const uint32_t e = uint32_t(lane) & 15u, hh = uint32_t(lane) >> 4;
+        vbase = atomicAdd(&sy.tcounts[tbase + 8u * (e >> 2) + 4u * hh + (e & 3u)], vcnt);
+    }
+    if (nf0) {
+        uint64_t* lp = sy.tlists + size_t(qpos0) * size_t(tcap);
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+            if (A0[e] > tq0) {
+                if (k0 < tcap) list_store(lp + k0, cand_pack(A0[e] + fq0, tbase + uint32_t(8 * (e >> 2) + 4 * h + (e & 3))));
+                ++k0;
+            }
+    }
+    if (nf1) {
+        uint64_t* lp = sy.tlists + size_t(qpos1) * size_t(tcap);
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+            if (A1[e] > tq1) {
+                if (k1 < tcap) list_store(lp + k1, cand_pack(A1[e] + fq1, tbase + uint32_t(8 * (e >> 2) + 4 * h + (e & 3))));
+                ++k1;
+            }
+    }
+    if (tr_on && __ballot(vcnt != 0u) != 0ull) {
+#pragma unroll
+        for (int g_ = 0; g_ < 4; ++g_) {
+            const float4 gv = *reinterpret_cast<const float4*>(Tl + 8 * g_ + 4 * h);
+            const float4 bv = *reinterpret_cast<const float4*>(Bl + 8 * g_ + 4 * h);
+            const float ge[4] = {gv.x, gv.y, gv.z, gv.w};
+            const float be[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+            for (int c_ = 0; c_ < 4; ++c_) {
+                const int e = 4 * g_ + c_;
+                const float s0 = A0[e] + hq0, s1 = A1[e] + hq1;
+                const bool p0 = s0 > ge[c_], p1 = s1 > ge[c_];
+                const unsigned long long c0 = __ballot(p0), c1 = __ballot(p1);
+                if ((c0 | c1) != 0ull) {   // wave-uniform
+                    const uint32_t bl = uint32_t(__builtin_amdgcn_readlane(int(vbase), e));
+                    const uint32_t bh = uint32_t(__builtin_amdgcn_readlane(int(vbase), e + 16));
+                    const uint32_t n0l = uint32_t(__popcll(c0 & 0xFFFFFFFFull)), n0h = uint32_t(__popcll(c0 >> 32));
+                    const uint32_t n1l = uint32_t(__popcll(c1 & 0xFFFFFFFFull));
+                    const uint32_t pre0 = __builtin_amdgcn_mbcnt_hi(uint32_t(c0 >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(c0), 0u));
+                    const uint32_t pre1 = __builtin_amdgcn_mbcnt_hi(uint32_t(c1 >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(c1), 0u));
+                    const uint32_t b0 = h ? bh - n0l : bl;
+                    const uint32_t b1 = h ? bh + n0h - n1l : bl + n0l;
+                    const uint32_t j = tbase + uint32_t(8 * (e >> 2) + (e & 3)) + 4u * uint32_t(h);
+                    uint64_t* lj = sy.tlists + size_t(j) * size_t(tcap);
+                    const uint32_t t0 = b0 + pre0, t1 = b1 + pre1;
+                    if (p0 && t0 < tcap) list_store(lj + t0, cand_pack(s0 + be[c_], qpos0));
+                    if (p1 && t1 < tcap) list_store(lj + t1, cand_pack(s1 + be[c_], qpos1));
+                }
+            }
+        }
+    }
+}
+
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+// one row of the sorted float32 points -> the lane's share of the MFMA operand in the frame o (osc = o sc, LDS): features
+// [16 s + 8 h, 16 s + 8 h + 8) of every k-step s as float16 (u = fl16(fl32(x sc - o sc))); returns the lane's share of |u|^2
+template <int DP>
+__device__ __forceinline__ float frag_load_local(Frag<DP, 2>& f, const float* __restrict__ row, const int xs_d,
+                                                 const float* __restrict__ osc, const float sc, const int h) {
+    float part = 0.f;
+#pragma unroll
+    for (int s = 0; s < DP / 16; ++s) {
+        const int f0 = 16 * s + 8 * h;
+        float4 xa = make_float4(0.f, 0.f, 0.f, 0.f), xb = xa;
+        if (f0 < xs_d) xa = *reinterpret_cast<const float4*>(row + f0);          // (xs_d is a multiple of 4; columns beyond
+        if (f0 + 4 < xs_d) xb = *reinterpret_cast<const float4*>(row + f0 + 4);  //  it are zeros in the points AND the centre)
+        const float4 oa = *reinterpret_cast<const float4*>(osc + f0), ob = *reinterpret_cast<const float4*>(osc + f0 + 4);
+        const float u[8] = {fmaf(xa.x, sc, -oa.x), fmaf(xa.y, sc, -oa.y), fmaf(xa.z, sc, -oa.z), fmaf(xa.w, sc, -oa.w),
+                            fmaf(xb.x, sc, -ob.x), fmaf(xb.y, sc, -ob.y), fmaf(xb.z, sc, -ob.z), fmaf(xb.w, sc, -ob.w)};
+        f16x8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = _Float16(u[e]);
+        f.hi[s] = v;
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+            f16x2 p;
+            p[0] = v[e];
+            p[1] = v[e + 1];
+            part = __builtin_amdgcn_fdot2(p, p, part, false);
+        }
+    }
+    return part;
+}
+
+#ifndef GT_SEL_COLD_LOCAL_WAVES
+#define GT_SEL_COLD_LOCAL_WAVES 4
+#endif
+template <int DP>
+__global__ __launch_bounds__(256, GT_SEL_COLD_LOCAL_WAVES) void sym_cold_local_kernel(const float* __restrict__ hneg, const int32_t nq,
+                                                                               const int32_t ntiles, const SymDev sy) {
+    using C = SelCfg<DP, 2>;
+    constexpr int QT = 2;
+    __shared__ __attribute__((aligned(16))) float lds_all[4][DP + 96];
+    const int lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5, wv = threadIdx.x >> 6;
+    float* osc = lds_all[wv];   // [DP]  centre of the wave's queries, scaled
+    float* hwl = osc + DP;      // [32]  -|w_j|^2 / 2 of the sub-tile's rows
+    float* Tl = hwl + 32;       // [32]  their thresholds T_j
+    float* Bl = Tl + 32;        // [32]  their filing terms
+    const int64_t en0 = (int64_t(blockIdx.x) * (blockDim.x >> 6) + wv) * GT_SEL_COLD_EPW;
+    if (en0 >= int64_t(sy.qn)) return;
+    constexpr int BQ = 128 * GT_SEL_TWO_QT, TPB = BQ / C::BN;
+    const int T = ntiles, NB = T / TPB, H = (NB - 1) / 2;
+    const float sc = sy.sc;
+    const int xs_d = sy.xs_d;
+    const float EPS = 4.90189e-4f;                     // 2^-11 (1 + 2^-8): float16 rounding of an operand, with head-room
+    const float C1 = float(DP + 16) * 5.9604645e-8f;   // float32 accumulation of a score, per (|u| + |w|)^2
+    Frag<DP, 2> bq[QT], ca;
+    float hu[QT], rq[QT], hgq[QT];
+    float umax = 0.f;
+    uint32_t have_q = 0xFFFFFFFFu;
+    for (int ce_ = 0; ce_ < GT_SEL_COLD_EPW; ++ce_) {
+        const int64_t en_ = en0 + ce_;
+        if (en_ >= int64_t(sy.qn)) break;   // wave-uniform
+        const uint2 ent = sy.queue[en_];
+        const int64_t qblock = int64_t(ent.x) * (QT * 32);
+        const uint32_t tbase = ent.y * 32u;
+        int rel = int(ent.y / uint32_t(C::BN / 32)) - int(qblock / BQ) * TPB;
+        if (rel < 0) rel += T;
+        const bool tr_on = sy.own_only == 0 && rel >= TPB && rel < TPB * (1 + H);
+        if (ent.x != have_q) {   // wave-uniform
+            have_q = ent.x;
+            __builtin_amdgcn_wave_barrier();
+            if (lane < DP) osc[lane] = sy.gcen[size_t(ent.x) * DP + lane];
+            if (DP > 64 && lane + 64 < DP) osc[lane + 64] = sy.gcen[size_t(ent.x) * DP + lane + 64];
+            __builtin_amdgcn_wave_barrier();
+            float um = 0.f;
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) {
+                const int64_t qg = qblock + qt * 32 + li;
+                const bool real = qg < nq;
+                const int64_t qc = real ? qg : int64_t(nq) - 1;
+                float part = frag_load_local<DP>(bq[qt], sy.xs + qc * int64_t(xs_d), xs_d, osc, sc, h);
+                part += __uint_as_float(lane_xor_b32(__float_as_uint(part), 32));
+                hu[qt] = real ? -0.5f * part : -INFINITY;
+                rq[qt] = real ? sy.rloc[qc] : -INFINITY;
+                hgq[qt] = real ? hneg[qc] : 0.f;
+                um = fmaxf(um, real ? part : 0.f);
+            }
+            umax = sqrtf(wave_max_f32(um));
+        }
+        // the sub-tile's rows in the same frame
+        const int64_t jg = int64_t(tbase) + li;
+        const bool jreal = jg < int64_t(sy.xs_n);
+        const int64_t jc = jreal ? jg : int64_t(sy.xs_n) - 1;
+        float nw = frag_load_local<DP>(ca, sy.xs + jc * int64_t(xs_d), xs_d, osc, sc, h);
+        nw += __uint_as_float(lane_xor_b32(__float_as_uint(nw), 32));
+        const float rj = jreal ? sy.rloc[jc] : -INFINITY;
+        const float hgj = jreal ? hneg[jc] : 0.f;
+        __builtin_amdgcn_wave_barrier();
+        if (h == 0) hwl[li] = jreal ? -0.5f * nw : -INFINITY;
+        __builtin_amdgcn_wave_barrier();
+        f32x16 cs;
+#pragma unroll
+        for (int g_ = 0; g_ < 4; ++g_) {
+            const float4 hv_ = *reinterpret_cast<const float4*>(hwl + 8 * g_ + 4 * h);
+            cs[4 * g_ + 0] = hv_.x;
+            cs[4 * g_ + 1] = hv_.y;
+            cs[4 * g_ + 2] = hv_.z;
+            cs[4 * g_ + 3] = hv_.w;
+        }
+        f32x16 cacc = cs, cacc1 = cs;
+        mma_chain<DP>(ca, bq[0], cacc);
+        mma_chain<DP>(ca, bq[QT - 1], cacc1);
+        // margins of this unit
+        const float wmax = sqrtf(wave_max_f32(jreal ? nw : 0.f));
+        const float span = umax + wmax;
+        const float delta = EPS * span + 1e-6f;
+        const float Es = 1.0625f * C1 * span * span + 1e-30f;
+        auto thr_of = [&](const float r) {   // T = -(r + delta)^2 / 2 - E, rounded down; a row that needs nothing: +inf
+            const float rd = r + delta;
+            return r >= 0.f ? -0.5000005f * rd * rd - Es : INFINITY;
+        };
+        auto file_of = [&](const float r, const float hg) {   // what turns -|x' - y'|^2 / 2 into the filed score
+            return r >= 0.f ? (r + delta) * delta + Es - hg : 0.f;
+        };
+        if (h == 0) {
+            Tl[li] = thr_of(rj);
+            Bl[li] = file_of(rj, hgj);
+        }
+        __builtin_amdgcn_wave_barrier();
+        const float T0 = thr_of(rq[0]), T1 = thr_of(rq[QT - 1]);
+        cold_admit_local(cacc, cacc1, T0 - hu[0], T1 - hu[QT - 1], hu[0], hu[QT - 1], hu[0] + file_of(rq[0], hgq[0]),
+                         hu[QT - 1] + file_of(rq[QT - 1], hgq[QT - 1]), uint32_t(qblock + li), uint32_t(qblock + 32 + li), tbase,
+                         Tl, Bl, tr_on, lane, li, h, sy);
+    }
+}
+
+// centres of the groups of 64 consecutive sorted rows, scaled: gcen[g][c] = sc x mean of column c over the group's real rows
+// (columns beyond the row length: 0).  One wave per group, lane = column.
+__global__ __launch_bounds__(256) void sym_group_centres_kernel(const float* __restrict__ xs, const int xs_d, const int64_t n,
+                                                                const int64_t g_first, const int64_t g_end, const int dp,
+                                                                const float sc, float* __restrict__ gcen) {
+    const int lane = threadIdx.x & 63;
+    const int64_t g = g_first + int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    if (g >= g_end) return;
+    const int64_t p0 = g * 64, p1 = p0 + 64 < n ? p0 + 64 : n;
+    for (int c = lane; c < dp; c += 64) {
+        float acc = 0.f;
+        if (c < xs_d)
+            for (int64_t p = p0; p < p1; ++p) acc += xs[p * xs_d + c];
+        gcen[g * dp + c] = p1 > p0 ? (acc / float(p1 - p0)) * sc : 0.f;
+    }
+}
+
 int launch_queue_compact(gt_ctx* ctx, const SelectArgs& a) {
     // a.lists: the dense queue (capacity a.cap entries); a.counts: [0] total, [1] fullest region, [2] spill overflow
     // flag (all pre-zeroed);
@@ -1438,6 +1698,19 @@ int launch_sym_cold(gt_ctx* ctx, const SelectArgs& a) {
         GT_FAIL(ctx, GT_E_ARG, "knn_select: the cold pass needs the queue and the lists of the collect launch");
     // (independent waves: one per workgroup, so that a wave with much to file does not hold three idle slots)
     const int wpb = ctx->row_wpb == 4 ? 4 : 1;
+    if (a.sym.xs != nullptr && !a.cold_split) {
+        // local frame (sym_cold_local_kernel): the centres of the query groups first
+        if (!a.sym.gcen || !a.sym.rloc || a.sym.xs_d <= 0 || (a.sym.xs_d & 3) != 0 || a.sym.xs_d > DP || a.sym.xs_n <= 0 || !(a.sym.sc > 0.f))
+            GT_FAIL(ctx, GT_E_ARG, "knn_select: the local-frame cold pass needs the sorted float32 points, the group centres and the rows' radii");
+        const int64_t g_first = a.sym.gc_count > 0 ? a.sym.gc_first : 0;
+        const int64_t g_end = a.sym.gc_count > 0 ? g_first + a.sym.gc_count : a.n_pad / 64;
+        hipLaunchKernelGGL(sym_group_centres_kernel, dim3((unsigned)ceil_div64(g_end - g_first, 4)), dim3(256), 0, ctx->stream, a.sym.xs,
+                           a.sym.xs_d, int64_t(a.sym.xs_n), g_first, g_end, DP, a.sym.sc, const_cast<float*>(a.sym.gcen));
+        hipLaunchKernelGGL((sym_cold_local_kernel<DP>), dim3((unsigned)ceil_div64(a.sym.qn, wpb * GT_SEL_COLD_EPW)), dim3(64 * wpb), 0,
+                           ctx->stream, a.hneg, a.nq, int(a.n_pad / SelCfg<DP, 2>::BN), a.sym);
+        GT_HIP(ctx, hipGetLastError());
+        return GT_OK;
+    }
     if (a.cold_split)
         hipLaunchKernelGGL((sym_cold_kernel<DP, 1>), dim3((unsigned)ceil_div64(a.sym.qn, wpb * GT_SEL_COLD_EPW)), dim3(64 * wpb), 0, ctx->stream, a.Yp, a.hneg,
                            a.thr_in, a.nq, int(a.n_pad / SelCfg<DP, 2>::BN), a.sym);

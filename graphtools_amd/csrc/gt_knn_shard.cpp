@@ -344,6 +344,23 @@ int gt_knn_shard_local(gt_ctx* ctx, int64_t r0, int64_t r1, int need_m, double r
         dq.sym.queue = k->sym_qdense.as<uint2>();
         dq.sym.qn = int32_t(left);
         dq.sym.own_only = 1;
+        k->sym_cold_local_used = false;
+        if (ctx->sym_cold_local != 0 && ctx->dtype == GT_F32 && (ctx->d & 3) == 0 && ctx->d <= ctx->DP && ctx->DP <= 64) {
+            // the units in the frame of their queries (gt_knn_select.hip sym_cold_local_kernel), as on one GPU: the renumbered
+            // points ARE the sorted float32 copy; centres for the rank's own query groups only
+            GT_HIP(ctx, k->sym_rloc.reserve(size_t(n_pad_s) * sizeof(float)));
+            GT_HIP(ctx, k->sym_gcen.reserve(size_t(n_pad_s / 64) * ctx->DP * sizeof(float)));
+            GT_TRY(gt_sym_row_radius(ctx, perm, n_pad_s, k->thr_final.as<float>(), em, k->sym_rloc.as<float>(), 0.0));
+            dq.sym.xs = reinterpret_cast<const float*>(ctx->X);
+            dq.sym.xs_d = ctx->d;
+            dq.sym.xs_n = int32_t(ctx->n);
+            dq.sym.gcen = k->sym_gcen.as<float>();
+            dq.sym.rloc = k->sym_rloc.as<float>();
+            dq.sym.sc = float(ctx->sc);
+            dq.sym.gc_first = int32_t(p0 / 64);
+            dq.sym.gc_count = int32_t((p1 - p0) / 64);
+            k->sym_cold_local_used = true;
+        }
         GT_TRY(gt_launch_select(ctx, dq));
     }
     k->sym_cold_entries = int64_t(left);

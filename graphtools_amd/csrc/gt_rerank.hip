@@ -379,7 +379,7 @@ __global__ __launch_bounds__(256, 5) void rerank_sym_kernel(
         }
         // (an overflowing row is short of room, an orphan - threshold +inf - of seeds, neither of precision: they do not
         //  count against the arithmetic)
-        if (unproven && !overflow && thr[qt] != INFINITY && !(d2_need * rkf < lb_cand)) atomicAdd(unproven, 1u);
+        if (unproven && !overflow && k257 == 0ull && thr[qt] != INFINITY && !(d2_need * rkf < lb_cand)) atomicAdd(unproven, 1u);
         if (stat && overflow) atomicAdd(stat + 0, 1ull);
         if (stat && want_stats) {
             // [1] sum of the list lengths [3] longest list [4] rows with more than 256 keys [7] rows with more than 128 keys
@@ -413,11 +413,17 @@ __global__ __launch_bounds__(256, 5) void rerank_sym_kernel(
 #ifndef GT_RERANK_UNROLL
 #define GT_RERANK_UNROLL 2   // evaluation passes whose loads are issued together
 #endif
+#ifndef GT_RERANK_RPW
+#define GT_RERANK_RPW 1   // rows per wave of rerank_sym4_kernel, fixed at compile time (0: the run-time option rerank_rows_per_wave)
+#endif
+#ifndef GT_RERANK_WAVES
+#define GT_RERANK_WAVES 4   // waves per SIMD the registers are cut for
+#endif
 #ifndef GT_RERANK_Q32
 #define GT_RERANK_Q32 true   // 32-bit composite keys in the table sort (gt_device.h wave_sort_asc_pair_fast)
 #endif
 template <int DB, bool WT, int WPB>   // WT: the transposed keys travel with the table (cand_d2t, keyt_ok); WPB: waves (rows) per workgroup
-__global__ __launch_bounds__(64 * WPB, WT ? 3 : 4) void rerank_sym4_kernel(
+__global__ __launch_bounds__(64 * WPB, GT_RERANK_WAVES) void rerank_sym4_kernel(
     const float* __restrict__ X, const int d, const double* __restrict__ xn, const int64_t nq,
     const uint64_t* __restrict__ tlists, const int tcap, const uint32_t* __restrict__ tcounts,
     const float* __restrict__ thr, const double* __restrict__ ymax2p, const ErrModel err, const int need_m,
@@ -428,7 +434,7 @@ __global__ __launch_bounds__(64 * WPB, WT ? 3 : 4) void rerank_sym4_kernel(
     const int32_t* __restrict__ invperm, const int32_t* __restrict__ own_rows, const int64_t own_r0,
     const int xcd_chunk, const float* __restrict__ Xs, const double* __restrict__ xns, double* __restrict__ cand_d2t,
     uint8_t* __restrict__ keyt_ok, int32_t* __restrict__ nokeyt_rows, uint32_t* __restrict__ nokeyt_count, const int metric,
-    const int64_t pos0) {
+    const int64_t pos0, const int rows_per_wave) {
     // cand_d2t (optional): next to every key of the table, the key the OTHER row holds for the same pair - the same dot
     // product in scikit-learn's association with the roles swapped, (|y|^2 - 2 x.y) + |x|^2 - so that the affinity pass can
     // tell, bit for bit, what the transposed entry is worth (gt_sparse.hip, pair-resolved symmetrisation); keyt_ok[q] = 1
@@ -445,15 +451,41 @@ __global__ __launch_bounds__(64 * WPB, WT ? 3 : 4) void rerank_sym4_kernel(
     uint32_t* park_lo = park_lo_all + w * MP;
     uint64_t* park_x = park_x_all + w * MP;
     constexpr bool want_t = WT;
+    // A wave can take several CONSECUTIVE sorted positions, one after the other, with the next row's counter and first 128 keys
+    // loaded (unconditionally: slots beyond the count are masked later) at the top of the current row - the chain counter ->
+    // keys (two trips to the HBM: the lists span 4 GB) -> gathers leaves the critical path of all but a wave's first row.
+    // Measured in round 5 (C3): 3.67 -> 3.48 ms from one to four rows per wave in a build that could afford the loop's
+    // registers, but the loop-carried state costs ~20 VGPRs (168 unconstrained, 108 B of scratch at four waves per SIMD) and four
+    // waves per SIMD are worth more (3.16 ms with one row per wave against 3.72 with three waves): GT_RERANK_RPW = 1 compiles
+    // the loop and the prefetch away.
     const int64_t bid = gt_xcd_item(blockIdx.x, gridDim.x, xcd_chunk * (4 / WPB));
-    const int64_t ql = bid * WPB + w;
-    if (ql >= nq) return;
+    const int rpw_ = GT_RERANK_RPW > 0 ? GT_RERANK_RPW : rows_per_wave;
+    const int64_t row0 = (bid * WPB + w) * int64_t(rpw_);
+    if (row0 >= nq) return;
+    uint32_t pf_ct = 0u;
+    uint64_t pf_k0 = 0ull, pf_k1 = 0ull;
+    auto prefetch = [&](const int64_t qn_) {
+        if (!invperm && qn_ < nq) {   // (wave-uniform)
+            const int64_t lsn = qn_ + pos0;
+            pf_ct = tcounts[lsn];
+            const uint64_t* tpn = tlists + size_t(lsn) * size_t(tcap);
+            pf_k0 = lane < tcap ? tpn[lane] : 0ull;
+            pf_k1 = lane + 64 < tcap ? tpn[64 + lane] : 0ull;
+        }
+    };
+    constexpr bool kPrefetch = GT_RERANK_RPW != 1;   // (one row per wave: the list is read where it is needed, as in rounds 3-4)
+    if (kPrefetch) prefetch(row0);
+  for (int rr_ = 0; rr_ < rpw_; ++rr_) {
+    const int64_t ql = row0 + rr_;
+    if (ql >= nq) break;
     // (pos0: the launch covers the sorted positions [pos0, pos0 + nq) - a rank's run of a renumbered point set)
     const int64_t qo = invperm ? int64_t(own_rows[ql]) : int64_t(perm[ql + pos0]);   // row of the bound points
     const int64_t q = qo - own_r0;                                                   // row of the tables (own_r0 = 0 on one rank)
     const int64_t qt = invperm ? int64_t(invperm[qo]) : ql + pos0;                   // index of the threshold
     const int64_t ls = invperm ? q : ql + pos0;                                      // index of the list
-    // this lane's share of the query row: elements 16 i + 4 c .. + 3 of every sector i
+    // this lane's share of the query row: elements 16 i + 4 c .. + 3 of every sector i (float64: 32 VGPRs.  Kept in the LDS
+    // instead and read back in every pass - tried in round 5 to make room for a fifth wave per SIMD - the kernel took 3.5 ms
+    // against 3.2: the reads and the extra spills cost more than they freed)
     double xq[NI][4];
     {
         // (Xs / xns: the points and norms in sorted order, REQUIRED here - candidate rows are read by position, the row
@@ -470,11 +502,18 @@ __global__ __launch_bounds__(64 * WPB, WT ? 3 : 4) void rerank_sym4_kernel(
         }
     }
     const double qnq = xns[qt];
-    const uint32_t ct_raw = tcounts[ls];
+    const bool direct = invperm != nullptr || !kPrefetch;
+    const uint32_t ct_raw = direct ? tcounts[ls] : pf_ct;
     const uint32_t ct = ct_raw & 0x7FFFFFFFu;
     const bool overflow = ct > uint32_t(tcap) || (ct_raw >> 31) != 0u;
     const uint32_t n = ct < uint32_t(tcap) ? ct : uint32_t(tcap);
     const uint64_t* tp = tlists + size_t(ls) * size_t(tcap);
+    uint64_t key0 = 0ull, key1 = 0ull;
+    if constexpr (kPrefetch) {
+        key0 = direct ? (uint32_t(lane) < n ? tp[lane] : 0ull) : pf_k0;
+        key1 = direct ? (uint32_t(lane) + 64u < n ? tp[64 + lane] : 0ull) : pf_k1;
+        if (rr_ + 1 < rpw_) prefetch(ql + 1);
+    }   // (the next row's list travels while this one is evaluated)
     const double y2 = ymax2p[0];
     const double e = gt_err_bound(err, qnq, y2);
     // euclidean: d2 = |x|^2 - 2 s; cosine (rows normalised): D = 1 - x.y = 1 - s - |y|^2 / 2 >= 1 - s - ymax^2 / 2 - what the
@@ -493,10 +532,20 @@ __global__ __launch_bounds__(64 * WPB, WT ? 3 : 4) void rerank_sym4_kernel(
     uint32_t pc[4];               // sorted positions of the candidates in slots u * 64 + lane
     uint64_t k257 = 0ull;         // best key beyond the table
     if (n <= 256u) {
+        if constexpr (kPrefetch) {
+            pc[0] = uint32_t(lane) < n ? cand_index(key0) : kNoRow;
+            pc[1] = uint32_t(lane) + 64u < n ? cand_index(key1) : kNoRow;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const uint32_t cidx = uint32_t(u * 64 + lane);
-            pc[u] = (cidx < n) ? cand_index(tp[cidx]) : kNoRow;
+            for (int u = 2; u < 4; ++u) {
+                const uint32_t cidx = uint32_t(u * 64 + lane);
+                pc[u] = (cidx < n) ? cand_index(tp[cidx]) : kNoRow;
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t cidx = uint32_t(u * 64 + lane);
+                pc[u] = (cidx < n) ? cand_index(tp[cidx]) : kNoRow;
+            }
         }
     } else {
         uint64_t ks[8];
@@ -513,53 +562,76 @@ __global__ __launch_bounds__(64 * WPB, WT ? 3 : 4) void rerank_sym4_kernel(
     const uint32_t n_eval = n < uint32_t(MP) ? n : uint32_t(MP);
     // exact keys of the 128 candidates held as (jA: slot u, jB: slot u + 1), 16 candidates per pass: group r takes
     // candidate 16 p + r of the batch, lane c of the group keeps the result of the passes p with p % 4 == c
+    // npass: passes of 16 candidates that hold any (wave-uniform).  The passes are software-pipelined: the gather of pass p + 1
+    // (row number, norm, the lane's four quarters of the candidate row) is issued BEFORE the arithmetic of pass p, into a second
+    // set of registers - a pass's loads are always in flight behind the previous pass's multiply-adds.  (Round 4 issued two
+    // passes' loads together and then waited for both: with ~5 passes per row the wave sat through three full L2 round trips.)
+    struct CandLoad {
+        float4 v[NI];
+        double yn;
+        uint32_t j;
+    };
+    auto issue = [&](const int p, const uint32_t jA, const uint32_t jB, CandLoad& L) {
+        const uint32_t pj = uint32_t(__shfl(int(p < 4 ? jA : jB), (p & 3) * 16 + r));   // position of the group's candidate
+        L.j = kNoRow;
+        L.yn = 0.0;
+        if (pj != kNoRow) {
+            L.j = uint32_t(perm[pj]);   // the row itself: what the tables hold and what breaks ties
+            const float4* y4 = reinterpret_cast<const float4*>(Xs + int64_t(pj) * d);   // (independent of j)
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+                if (16 * i < d) L.v[i] = (16 * i + 4 * c < d) ? y4[4 * i + c] : make_float4(0.f, 0.f, 0.f, 0.f);
+            L.yn = xns[pj];
+        }
+    };
+    auto finish = [&](const int p, const CandLoad& L, uint64_t& hA, uint32_t& lA, uint64_t& hB, uint32_t& lB, uint64_t& xA,
+                      uint64_t& xB) {
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;   // partial sums c, c + 4, c + 8, c + 12
+        if (L.j != kNoRow) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+                if (16 * i < d) {   // (uniform; a quad past the end of the row contributes exact zeros, as in gt_dot16
+                                    //  where it is simply absent - x + 0 = x)
+                    double& acc = (i & 3) == 0 ? a0 : (i & 3) == 1 ? a1 : (i & 3) == 2 ? a2 : a3;
+                    if (16 * i + 4 * c < d) {
+                        acc = fma(xq[i][0], double(L.v[i].x), acc);
+                        acc = fma(xq[i][1], double(L.v[i].y), acc);
+                        acc = fma(xq[i][2], double(L.v[i].z), acc);
+                        acc = fma(xq[i][3], double(L.v[i].w), acc);
+                    }
+                }
+        }
+        const double cc = (a0 + a2) + (a1 + a3);            // b[c] + b[c + 4]
+        const double w2 = cc + lane_xor_f64(cc, 2);         // lanes 0, 2: c0 + c2; lanes 1, 3: c1 + c3
+        const double dot = w2 + lane_xor_f64(w2, 1);        // (c0 + c2) + (c1 + c3)
+        if (L.j != kNoRow && c == (p & 3)) {
+            const uint64_t key = (uint64_t)__double_as_longlong(gt_pair_key(qnq, dot, L.yn, metric));
+            const uint64_t keyt = want_t ? (uint64_t)__double_as_longlong(gt_pair_key(L.yn, dot, qnq, metric)) : 0ull;
+            if (p < 4) {
+                hA = key;
+                lA = L.j;
+                xA = keyt;
+            } else {
+                hB = key;
+                lB = L.j;
+                xB = keyt;
+            }
+        }
+    };
     auto eval128 = [&](const uint32_t jA, const uint32_t jB, uint64_t& hA, uint32_t& lA, uint64_t& hB, uint32_t& lB,
-                       uint64_t& xA, uint64_t& xB) {
+                       uint64_t& xA, uint64_t& xB, const int npass_) {
         hA = hB = kInfBits;
         lA = lB = 0xFFFFFFFFu;
         xA = xB = 0ull;
-#pragma unroll GT_RERANK_UNROLL
-        for (int p = 0; p < (GT_RERANK_EXP == 2 ? 1 : 8); ++p) {
-            const uint32_t pj = uint32_t(__shfl(int(p < 4 ? jA : jB), (p & 3) * 16 + r));   // position of the group's candidate
-            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;   // partial sums c, c + 4, c + 8, c + 12
-            double yn = 0.0;
-            uint32_t j = kNoRow;
-            if (pj != kNoRow) {
-                j = uint32_t(perm[pj]);   // the row itself: what the tables hold and what breaks ties
-                const float4* y4 = reinterpret_cast<const float4*>(Xs + int64_t(pj) * d);   // (independent of j)
-                float4 v[NI];
-#pragma unroll
-                for (int i = 0; i < NI; ++i)
-                    if (16 * i < d) v[i] = (16 * i + 4 * c < d) ? y4[4 * i + c] : make_float4(0.f, 0.f, 0.f, 0.f);
-                yn = xns[pj];
-#pragma unroll
-                for (int i = 0; i < NI; ++i)
-                    if (16 * i < d) {   // (uniform; a quad past the end of the row contributes exact zeros, as in gt_dot16
-                                        //  where it is simply absent - x + 0 = x)
-                        double& acc = (i & 3) == 0 ? a0 : (i & 3) == 1 ? a1 : (i & 3) == 2 ? a2 : a3;
-                        if (16 * i + 4 * c < d) {
-                            acc = fma(xq[i][0], double(v[i].x), acc);
-                            acc = fma(xq[i][1], double(v[i].y), acc);
-                            acc = fma(xq[i][2], double(v[i].z), acc);
-                            acc = fma(xq[i][3], double(v[i].w), acc);
-                        }
-                    }
-            }
-            const double cc = (a0 + a2) + (a1 + a3);            // b[c] + b[c + 4]
-            const double w2 = cc + lane_xor_f64(cc, 2);         // lanes 0, 2: c0 + c2; lanes 1, 3: c1 + c3
-            const double dot = w2 + lane_xor_f64(w2, 1);        // (c0 + c2) + (c1 + c3)
-            if (j != kNoRow && c == (p & 3)) {
-                const uint64_t key = (uint64_t)__double_as_longlong(gt_pair_key(qnq, dot, yn, metric));
-                const uint64_t keyt = want_t ? (uint64_t)__double_as_longlong(gt_pair_key(yn, dot, qnq, metric)) : 0ull;
-                if (p < 4) {
-                    hA = key;
-                    lA = j;
-                    xA = keyt;
-                } else {
-                    hB = key;
-                    lB = j;
-                    xB = keyt;
-                }
+        const int npass = GT_RERANK_EXP == 2 ? 1 : npass_;
+        CandLoad L0, L1;
+        issue(0, jA, jB, L0);
+        for (int p = 0; p < npass; p += 2) {
+            if (p + 1 < npass) issue(p + 1, jA, jB, L1);
+            finish(p, L0, hA, lA, hB, lB, xA, xB);
+            if (p + 1 < npass) {
+                if (p + 2 < npass) issue(p + 2, jA, jB, L0);
+                finish(p + 1, L1, hA, lA, hB, lB, xA, xB);
             }
         }
     };
@@ -567,13 +639,24 @@ __global__ __launch_bounds__(64 * WPB, WT ? 3 : 4) void rerank_sym4_kernel(
     uint32_t lo[4];
     uint64_t hx[4] = {0ull, 0ull, 0ull, 0ull};
     {
-        eval128(pc[0], pc[1], hi[0], lo[0], hi[1], lo[1], hx[0], hx[1]);
+        const uint32_t n1 = n_eval < 128u ? n_eval : 128u;
+        eval128(pc[0], pc[1], hi[0], lo[0], hi[1], lo[1], hx[0], hx[1], int((n1 + 15u) >> 4));
         hi[2] = hi[3] = kInfBits;
         lo[2] = lo[3] = 0xFFFFFFFFu;
     }
     const int pos = need_m - 1;
     const uint32_t n_tab = n_eval;
-    if (!both) {
+    if (n_eval <= 64u) {   // wave-uniform: one key per lane, the network of 64
+        uint64_t h1[1] = {hi[0]};
+        uint32_t l1[1] = {lo[0]};
+        uint64_t x1[1] = {hx[0]};
+#if GT_RERANK_EXP != 1
+        wave_sort_asc_pair_fast<1, uint32_t, GT_RERANK_Q32>(h1, l1, lane, park_hi, park_lo, want_t ? x1 : nullptr, park_x);
+#endif
+        hi[0] = h1[0];
+        lo[0] = l1[0];
+        hx[0] = x1[0];
+    } else if (!both) {
         uint64_t h2[2] = {hi[0], hi[1]};
         uint32_t l2[2] = {lo[0], lo[1]};
         uint64_t x2[2] = {hx[0], hx[1]};
@@ -587,7 +670,7 @@ __global__ __launch_bounds__(64 * WPB, WT ? 3 : 4) void rerank_sym4_kernel(
         lo[0] = l2[0]; lo[1] = l2[1];
         hx[0] = x2[0]; hx[1] = x2[1];
     } else {
-        eval128(pc[2], pc[3], hi[2], lo[2], hi[3], lo[3], hx[2], hx[3]);
+        eval128(pc[2], pc[3], hi[2], lo[2], hi[3], lo[3], hx[2], hx[3], int((n_eval - 128u + 15u) >> 4));
         if (k257 != 0ull) lb = fmin(lb, bound_of_score(cand_score(k257)));   // candidates beyond the table
 #if GT_RERANK_EXP != 1
         wave_sort_asc_pair_fast<4, uint32_t, GT_RERANK_Q32>(hi, lo, lane, park_hi, park_lo, want_t ? hx : nullptr, park_x);
@@ -625,7 +708,9 @@ __global__ __launch_bounds__(64 * WPB, WT ? 3 : 4) void rerank_sym4_kernel(
             const uint32_t slot = atomicAdd(fb_count, 1u);
             fb_rows[slot] = int32_t(q);
         }
-        if (unproven && !overflow && thr[qt] != INFINITY && !(d2_need * fabs(radius_key_factor) < lb_cand)) atomicAdd(unproven, 1u);
+        // ("unproven" judges the ARITHMETIC of the candidate pass: a row with more candidates than the table holds - k257 - is
+        //  short of room, like an overflowing one; with the margin of the local frame such rows are no longer all overflows)
+        if (unproven && !overflow && k257 == 0ull && thr[qt] != INFINITY && !(d2_need * fabs(radius_key_factor) < lb_cand)) atomicAdd(unproven, 1u);
         if (stat && overflow) atomicAdd(stat + 0, 1ull);
         if (stat && want_stats) {
             const unsigned long long tot = (unsigned long long)ct;
@@ -636,6 +721,7 @@ __global__ __launch_bounds__(64 * WPB, WT ? 3 : 4) void rerank_sym4_kernel(
         }
         if (n_all > 1 && second == 0ull) atomicOr(gflags, GT_FLAG_DUPLICATES);
     }
+  }   // rows of the wave
 }
 
 // ---- exhaustive exact fallback: one workgroup per flagged query ---------------------------------
@@ -1011,12 +1097,15 @@ int gt_launch_rerank_sym(gt_ctx* ctx, const RerankArgs& a, const SymRerank& sr) 
                        a.unproven, sr.stat, (ctx->dbg_select & 256) ? 1 : 0, sr.invperm, sr.own_rows, sr.own_r0, ctx->xcd_chunk,      \
                        (const T_*)sr.Xs, sr.xns, a.metric, sr.pos0)
 #define GT_RERANK_SYM4_LAUNCH(DB_, WT_, WPB_)                                                                             \
-    hipLaunchKernelGGL((rerank_sym4_kernel<DB_, WT_, WPB_>), dim3((unsigned)ceil_div64(a.nq, WPB_)), dim3(64 * WPB_), 0, ctx->stream, (const float*)a.X, dx, \
+    hipLaunchKernelGGL((rerank_sym4_kernel<DB_, WT_, WPB_>), dim3((unsigned)ceil_div64(a.nq, int64_t(WPB_) * rpw)), dim3(64 * WPB_), 0, ctx->stream, (const float*)a.X, dx, \
                        a.xn, a.nq, sr.tlists, sr.tcap, sr.tcounts, a.thr_final, a.ymax2, a.err, a.need_m, sr.perm,        \
                        a.cand_d2, a.cand_j, a.cand_n, a.d2_lb, a.fb_count, a.fb_rows, a.gflags, a.radius_key_factor,      \
                        a.unproven, sr.stat, (ctx->dbg_select & 256) ? 1 : 0, sr.invperm, sr.own_rows, sr.own_r0, ctx->xcd_chunk,      \
-                       (const float*)sr.Xs, sr.xns, sr.cand_d2t, sr.keyt_ok, sr.nokeyt_rows, sr.nokeyt_count, a.metric, sr.pos0)
+                       (const float*)sr.Xs, sr.xns, sr.cand_d2t, sr.keyt_ok, sr.nokeyt_rows, sr.nokeyt_count, a.metric, sr.pos0, rpw)
     if (sr.wrote_t) *sr.wrote_t = false;
+    // rows per wave of rerank_sym4_kernel (consecutive sorted positions, the next row's list prefetched): enough waves to fill
+    // the chip a few times over must remain
+    const int rpw = GT_RERANK_RPW > 0 ? GT_RERANK_RPW : std::max(1, std::min(ctx->rerank_rows_per_wave, int(a.nq / (int64_t(ctx->n_cu) * 64) + 1)));
     // (dx: row length = stride of the sorted copy - the points' d, or d zero padded to a multiple of 4)
     const int dx = (sr.Xs && sr.xs_d > 0) ? sr.xs_d : a.d;
     if (dx != a.d && !(a.dtype == GT_F32 && (dx & 3) == 0 && dx <= 64 && ctx->rerank_lanes4 != 0))
