@@ -697,6 +697,22 @@ class Context:
                     "gt_landmark_build")
         return M, R, tnnz.value
 
+    def landmark_build_device(self, clusters, n_landmark, buf_ptr):
+        """the same partial products left ON THE DEVICE: ``buf_ptr`` addresses L*L + L float64 (M row-major, then R) - the buffer
+        a row-sharded build all-reduces over the ranks before :meth:`landmark_scale_device`.  Returns the transitions' nnz."""
+        cl = np.ascontiguousarray(clusters, dtype=np.int32)
+        L = int(n_landmark)
+        tnnz = ctypes.c_int64(0)
+        self._check(self.lib.gt_landmark_build(self.h, _ptr(cl), L, ctypes.c_void_p(int(buf_ptr)),
+                                               ctypes.c_void_p(int(buf_ptr) + 8 * L * L), 1, ctypes.byref(tnnz)), "gt_landmark_build")
+        return tnnz.value
+
+    def landmark_scale_device(self, buf_ptr, n_landmark):
+        """landmark_op = M / R in place on the device buffer of :meth:`landmark_build_device` (after the ranks' sum)"""
+        L = int(n_landmark)
+        self._check(self.lib.gt_landmark_scale(self.h, ctypes.c_void_p(int(buf_ptr)), ctypes.c_void_p(int(buf_ptr) + 8 * L * L), L, 1),
+                    "gt_landmark_scale")
+
     def landmark_scale(self, M, R):
         M = np.ascontiguousarray(M, dtype=np.float64)
         R = np.ascontiguousarray(R, dtype=np.float64)

@@ -174,7 +174,6 @@ int gt_bind_points(gt_ctx* ctx, const void* X, int64_t n, int32_t d, int32_t dty
     ctx->n = n;
     ctx->fast_ok = -1;
     ctx->sym_ok = -1;
-    ctx->symm_fused_ok = 1;
     ctx->symm_pair_ok = 1;
     ctx->sym_two_ok = -1;
     ctx->d = d;
@@ -268,20 +267,12 @@ int gt_set_option(gt_ctx* ctx, const char* name, const char* value) {
         ctx->samp_trig = std::atoi(value);
         return GT_OK;
     }
-    if (k == "select_thr0") {
-        ctx->thr0_mode = std::atoi(value);
-        return GT_OK;
-    }
     if (k == "select_nt8_max_need") {
         ctx->nt8_max_need = std::min(112, std::max(1, std::atoi(value)));
         return GT_OK;
     }
     if (k == "select_narrow") {
         ctx->narrow_mode = v == "auto" ? -1 : std::atoi(value);
-        return GT_OK;
-    }
-    if (k == "select_sym_outlier_orphans") {
-        ctx->sym_outlier_orphans = std::atoi(value) != 0 ? 1 : 0;
         return GT_OK;
     }
     if (k == "symmetrize_pairs_huge") {
@@ -316,32 +307,10 @@ int gt_set_option(gt_ctx* ctx, const char* name, const char* value) {
         ctx->sym_mode = v == "auto" ? -1 : std::atoi(value);
         return GT_OK;
     }
-    if (k == "symmetrize_fused") {
-        ctx->symm_fused = std::atoi(value) != 0 ? 1 : 0;
-        return GT_OK;
-    }
-    if (k == "rerank_waves_per_block") {
-        const int v = std::atoi(value);
-        if (v != 1 && v != 4) GT_FAIL(ctx, GT_E_ARG, "rerank_waves_per_block must be 1 or 4");
-        ctx->rerank_wpb = v;
-        return GT_OK;
-    }
-    if (k == "row_waves_per_block") {
-        const int v = std::atoi(value);
-        if (v != 1 && v != 4) GT_FAIL(ctx, GT_E_ARG, "row_waves_per_block must be 1 or 4");
-        ctx->row_wpb = v;
-        return GT_OK;
-    }
     if (k == "distance_dtype") {
         const std::string v = value;
         if (v != "data" && v != "float64") GT_FAIL(ctx, GT_E_ARG, "distance_dtype must be 'data' or 'float64'");
         ctx->dist_f64 = v == "float64" ? 1 : 0;
-        return GT_OK;
-    }
-    if (k == "dense_bandwidth_passes") {
-        const int v = std::atoi(value);
-        if (v != 1 && v != 2) GT_FAIL(ctx, GT_E_ARG, "dense_bandwidth_passes must be 1 or 2");
-        ctx->dense_bw_passes = v;
         return GT_OK;
     }
     if (k == "select_sym_sample_far") {
@@ -352,20 +321,12 @@ int gt_set_option(gt_ctx* ctx, const char* name, const char* value) {
         ctx->dense_rows = v == "auto" ? -1 : std::atoi(value);
         return GT_OK;
     }
-    if (k == "dense_rows_reread") {
-        ctx->dense_rows_reread = std::atoi(value) != 0 ? 1 : 0;
-        return GT_OK;
-    }
     if (k == "dense_rows_fused") {
         ctx->dense_rows_fused = std::atoi(value) != 0 ? 1 : 0;
         return GT_OK;
     }
     if (k == "dense_rows_cap") {
         ctx->dense_rows_cap = std::atoll(value);
-        return GT_OK;
-    }
-    if (k == "dense_p_only") {
-        ctx->dense_p_only = std::atoi(value) != 0 ? 1 : 0;
         return GT_OK;
     }
     if (k == "dense_fused_rowsum") {
@@ -376,20 +337,12 @@ int gt_set_option(gt_ctx* ctx, const char* name, const char* value) {
         ctx->symm_pairs = std::atoi(value) != 0 ? 1 : 0;
         return GT_OK;
     }
-    if (k == "symmetrize_fill_threads") {
-        ctx->symm_fill_threads = std::atoi(value);
-        return GT_OK;
-    }
     if (k == "select_sym_cosine") {
         ctx->sym_cosine = std::atoi(value) != 0 ? 1 : 0;
         return GT_OK;
     }
     if (k == "select_sym_sorted_points") {
         ctx->sym_sorted_points = std::atoi(value) != 0 ? 1 : 0;
-        return GT_OK;
-    }
-    if (k == "xcd_chunk") {
-        ctx->xcd_chunk = std::max(0, std::atoi(value));
         return GT_OK;
     }
     if (k == "rerank_lanes4") {
@@ -430,16 +383,8 @@ int gt_set_option(gt_ctx* ctx, const char* name, const char* value) {
         ctx->symm_bin_shift = sh;
         return GT_OK;
     }
-    if (k == "rerank_rows_per_wave") {
-        ctx->rerank_rows_per_wave = std::min(64, std::max(1, std::atoi(value)));
-        return GT_OK;
-    }
     if (k == "select_sym_cold_local") {
         ctx->sym_cold_local = std::atoi(value) != 0 ? 1 : 0;
-        return GT_OK;
-    }
-    if (k == "select_sym_cold_split") {
-        ctx->sym_cold_split = std::atoi(value) != 0 ? 1 : 0;
         return GT_OK;
     }
     if (k == "select_sym_bounds") {
@@ -460,10 +405,6 @@ int gt_set_option(gt_ctx* ctx, const char* name, const char* value) {
     }
     if (k == "select_sym_queue_cap") {
         ctx->sym_queue_cap = std::max(0, std::atoi(value));
-        return GT_OK;
-    }
-    if (k == "select_sym_two_steps") {
-        ctx->sym_two_steps = std::max(0, std::atoi(value));
         return GT_OK;
     }
     if (k == "select_sym_shard_group") {

@@ -161,7 +161,6 @@ struct gt_ctx {
     int32_t samp_end = -1;    //   list budget at the end of that phase (0: none, -1: same as samp_keep)
     int32_t query_order = 1;  // candidate pass: deal the query rows to workgroups grouped by nearest landmark (gt_order.hip)
     int32_t order_min_rows = 32768;  //   launches with fewer query rows (or fewer points) are not grouped
-    int32_t thr0_mode = 1;           //   start the candidate lists from the threshold the assignment pass proves (0: from -inf)
     int32_t order_outliers = 1;      //   rows far from every landmark get a cell of their own (gt_order.hip; 0: off)
     int32_t order_cell_rows = 244;   //   rows per landmark cell (L = n / order_cell_rows landmarks, 64 ... 8192; small cells: a cluster
                                      //   without a landmark of its own swells the cells it lands in - see the bound pass, gt_sym.hip)
@@ -171,7 +170,6 @@ struct gt_ctx {
     int32_t samp2_keep = 64;  //   to this many entries (at least 3 * samp_keep)
     int32_t nt8_max_need = 88;  // tables of up to this many neighbours use the 128-entry list budget (else 512)
     int32_t dense_rows = -1;  // exact graph from float32 distances, '+' rule: row-streaming form with the transposed half as a list (-1: from 16384 rows, 0 never, 1 always)
-    int32_t dense_rows_reread = 0; //   its write pass reads every row again and recomputes the affinities (0: zeros streamed, the listed entries placed: three launches)
     int32_t dense_rows_fused = 1; //   its list of kept affinities comes out of the bandwidth pass (0: from a pass of its own)
     int64_t dense_rows_cap = 0;   //   entries its list of kept affinities may hold (0: 1024 per row, at least 2^24; beyond: the tile-pair form)
     int32_t narrow_mode = -1; // 128-row-workgroup candidate kernels: -1 auto (few query rows), 0 never, 1 whenever available
@@ -182,7 +180,6 @@ struct gt_ctx {
     int32_t sym_stride = 768;   //   threshold-seeding launch: every sym_stride-th tile besides the row's own neighbourhood (0: none; 384 until round 4's sweep, tools/seed_sweep.py)
     int32_t sym_cosine = 1;          //   the symmetric pass also serves the cosine metric (rows are normalised: the candidate stages are the euclidean ones)
     int32_t sym_sorted_points = 1;   //   symmetric pass: the exact stages read the points from a copy in cell-sorted order
-    int32_t xcd_chunk = 0;      //   row-walking kernels: work items per XCD chunk (gt_device.h gt_xcd_item), 0 = one contiguous eighth per XCD
     int32_t rerank_lanes4 = 1;  //   re-rank of the symmetric pass: four lanes per candidate row (float32 rows, d % 4 == 0, d <= 128)
     int32_t sym_dense_seed = 1; //   threshold-seeding launch: 1 = dense cell blocks, keys in registers (gt_seed.hip), 0 = streaming lists
     int32_t sym_cells_shard = 12;   //   ... at least this many in the row-sharded passes (gt_knn_shard.cpp)
@@ -199,38 +196,27 @@ struct gt_ctx {
     double sym_radius_cut = 4.0; //  rows whose completeness radius (squared) exceeds this many times the mean are repaired directly
     int32_t sym_two_stage = -1; //   launch B scores half the features first (partial distances): -1 auto, 0 off, 1 on
     int32_t symm_bins = -1;     // single-rank symmetrisation through destination bins (gt_sparse.hip): -1 auto, 0 off, 1 on
-    int32_t symm_fused = 0;     //   single rank, '+', no anisotropy: merged lengths counted first, K and P written once, in row order (gt_sparse.hip
-                                //   pair_count_kernel).  Bit-identical, measured SLOWER than sort + compact (6.7 against 5.8 ms at N = 1e6): off
-    int32_t symm_fused_ok = 1;  //     0 once a union row of the bound points has outgrown the register sorts (reset by gt_set_points)
     int32_t symm_key32 = 1;     //   per-row sorts of the symmetrisation on 32-bit keys where columns and positions fit (0: 64-bit keys)
     // row-sharded builds with knn_max: the counts of the reference's search-expansion loop travel through the host
     int32_t stage_counts_only = 0, stage_totals_valid = 0, stage_n = 0;
     int64_t stage_local[4] = {0, 0, 0, 0}, stage_totals[4] = {0, 0, 0, 0};
-    int32_t rerank_wpb = 1;     //   rows (waves) per workgroup of the four-lanes-per-candidate re-rank (1 or 4; option "rerank_waves_per_block")
-    int32_t row_wpb = 1;        //   rows (waves) per workgroup of the wave-per-row kernels of the tail (affinities, final merge; option "row_waves_per_block")
     int32_t dist_f64 = 0;       //   distances from the float64 keys in float64 whatever the points' dtype (option "distance_dtype")
     int32_t in_graph_build = 0; //   (set by gt_graph_build around its gt_graph_begin: every row is here, the tail is its own)
     int32_t symm_pairs = 1;     //   pair-resolved symmetrisation (gt_sparse.hip): every row settles its mutual pairs itself, only one-sided entries travel
     int32_t symm_pair_huge = 1; //   ... union rows beyond the register sorts are finished by a segmented sort (0: they refute the path: the general tail)
     int32_t keep_stages = 0;    //   (gt_graph_build's second attempt after a refutation: the stage timers are not reset)
     int32_t symm_pair_ok = 1;   //   ... not refuted for the bound point set (a union row beyond the register sorts)
-    int32_t symm_fill_threads = 256;   //   threads per workgroup of bin_fill_kernel (256 | 512 | 1024)
     int32_t symm_bin_shift = 0; //   log2 of the rows per bin (0: 9, more from 2 M rows; development / tests: 8 ... 12)
-    int32_t rerank_rows_per_wave = 8;   // rerank_sym4_kernel: consecutive sorted positions one wave re-ranks, the next row's list prefetched
     int32_t sym_cold_local = 1; //   the cold launch scores its units in the frame of their queries (gt_knn_select.hip sym_cold_local_kernel:
                                 //   float16 roundings of (x - o) sc from the sorted float32 points) - the margin of the float16 chain shrinks
                                 //   from |x||y| 2^-10 to cell size; 0: the compact copy in the global frame (rounds 2-4)
-    int32_t sym_cold_split = 0; //   the cold launch behind the bound pass scores with the three split chains (tight error bound: a third fewer
-                                //   candidates - measured at C3: re-rank 3.96 -> 3.25 ms, cold launch 2.51 -> 3.25 ms: no net gain, off by default)
     int32_t sym_bounds = -1;    //   bound pass in front of the two-stage collect (cell balls): -1 auto / 1 on, 0 off
     int64_t sym_bound_cap = 0;  //   units the bound pass may leave before the collect launch runs instead (0: 4 M; tests)
     int32_t sym_pca = 1;        //   stage one scores the 16 leading principal directions (0: the first 16 features)
     int32_t sym_queue_cap = 0;  //   entries per wave region of the two-stage queue (0: sized from the problem; development / tests)
     int32_t sym_spill_cap = 0;  //   entries of the shared spill area behind the regions (0: 4 M; development / tests)
-    int32_t sym_two_steps = 0;  //   k-steps of stage one (0: half of them; development, must match the kernel build)
     int32_t sym_two_ok = -1;    //   verdict of the last launch for the bound point set (cold-path share), -1 unknown
     int32_t sym_shard_group = 32;   //   row-sharded launch B: query blocks per rotation step of the walk pieces
-    int32_t sym_outlier_orphans = 0;   // the rows of the outlier cell are orphans of the symmetric pass (collect nothing, repaired exactly)
     int32_t order_outlier_cell = -1;   // id of the outlier cell of the last query order (its rows are orphans of the symmetric pass), -1: none
     int32_t order_L = 0;        // landmark cells of the last query order (gt_order.hip)
     // Cell-sorted renumbering (gt_points_cell_sort, gt_knn_shard.cpp): the bound points ARE the caller's points in the
@@ -252,12 +238,7 @@ struct gt_ctx {
     DevBuf ymax;         // float [1]     max row norm (as float bits, atomicMax on uint)
     float ymax_host = 0.f;
 
-    int32_t dense_bw_passes = 1;      // exact graph from a distance matrix: bandwidths in one streaming read (2: the two-pass kernel)
     int32_t dense_fused_rowsum = 1;   //   float32 matrices: row sums accumulated by the tile kernel (0: a pass of their own)
-    int32_t dense_p_only = 0;         //   the operator alone in place as two tile passes, K never stored (12 N^2 instead of 16 N^2 bytes behind the
-                                      //   bandwidths).  Measured SLOWER at N = 2e5: 152 ms for the two passes against 71 + 60 ms - the tile-pair
-                                      //   kernel is not bound by its bytes (a pass that writes nothing takes as long as one that writes K): off
-    // last dense build (gt_dense_graph_build): degree = row sums of K, bandwidth
     DevBuf dense_degree, dense_bw;
     int64_t dense_n = 0;
 

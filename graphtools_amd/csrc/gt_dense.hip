@@ -156,124 +156,7 @@ __global__ __launch_bounds__(256) void dense_bandwidth_kernel(const T* __restric
     if (tid == 0) bw[i] = __longlong_as_double((long long)v) * scale;
 }
 
-// kth smallest of a row in two streaming passes (kth <= 256): the kth smallest of the 256 per-thread minima is an
-// upper bound of the answer with at least kth entries at or below it; the second pass collects everything at or
-// below that bound (a few dozen values) and the answer is selected among them.  Per element: one convert and one
-// min / compare - the kernel runs at the speed of the two HBM reads instead of maintaining per-thread sorted lists.
-// Returns through bw[i]; rows that collect more than CAP values are redone by the generic kernel (flagged in `redo`).
-template <typename T>
-__global__ __launch_bounds__(256) void dense_bandwidth_2pass_kernel(const T* __restrict__ D, const int64_t n, const int kth,
-                                                                    const double scale, double* __restrict__ bw,
-                                                                    uint32_t* __restrict__ redo) {
-    constexpr int CAP = 1024;
-    __shared__ double vals[CAP];
-    __shared__ int red[4];
-    __shared__ int cnt;
-    const int64_t i = blockIdx.x;
-    const int tid = threadIdx.x;
-    const T* row = D + i * n;
-    constexpr int VW = 16 / int(sizeof(T));
-    typedef T vecT __attribute__((ext_vector_type(VW)));
-    const bool vec = (n % VW) == 0;
-    const vecT* rv = reinterpret_cast<const vecT*>(row);
-    const int64_t nv = n / VW;
-    // ---- pass 1: per-thread minimum ----
-    double mn = INFINITY;
-    if (vec) {
-        for (int64_t j0 = 0; j0 < nv; j0 += 256 * 4) {
-            vecT v[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int64_t j = j0 + u * 256 + tid;
-                if (j < nv) {
-                    v[u] = rv[j];
-                } else {
-#pragma unroll
-                    for (int e = 0; e < VW; ++e) v[u][e] = T(INFINITY);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int e = 0; e < VW; ++e) mn = fmin(mn, double(v[u][e]));
-        }
-    } else {
-        for (int64_t j = tid; j < n; j += 256) mn = fmin(mn, double(row[j]));
-    }
-    // ---- kth smallest of the 256 minima (bitwise search on the float64 pattern; values >= 0) ----
-    const unsigned long long mykey = (mn > 0.0) ? (unsigned long long)__double_as_longlong(mn) : 0ull;
-    unsigned long long bound = 0ull;
-    for (int b = 63; b >= 0; --b) {
-        const unsigned long long trial = bound | ((1ull << b) - 1ull);
-        int c = wave_sum_i32((mykey <= trial) ? 1 : 0);
-        __syncthreads();
-        if ((tid & 63) == 0) red[tid >> 6] = c;
-        __syncthreads();
-        if (red[0] + red[1] + red[2] + red[3] < kth) bound |= (1ull << b);
-    }
-    const double ub = __longlong_as_double((long long)bound);
-    if (tid == 0) cnt = 0;
-    __syncthreads();
-    // ---- pass 2: collect everything <= ub ----
-#define GT_BW_TAKE(V_)                                             \
-    {                                                              \
-        const double v_ = double(V_);                              \
-        if (v_ <= ub) {                                            \
-            const int pos = atomicAdd(&cnt, 1);                    \
-            if (pos < CAP) vals[pos] = v_;                         \
-        }                                                          \
-    }
-    if (vec) {
-        for (int64_t j0 = 0; j0 < nv; j0 += 256 * 4) {
-            vecT v[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int64_t j = j0 + u * 256 + tid;
-                if (j < nv) {
-                    v[u] = rv[j];
-                } else {
-#pragma unroll
-                    for (int e = 0; e < VW; ++e) v[u][e] = T(INFINITY);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int e = 0; e < VW; ++e) GT_BW_TAKE(v[u][e]);
-        }
-    } else {
-        for (int64_t j = tid; j < n; j += 256) GT_BW_TAKE(row[j]);
-    }
-#undef GT_BW_TAKE
-    __syncthreads();
-    const int m = cnt;
-    if (m > CAP) {   // pathological row (mass ties at the bound): leave it to the generic kernel
-        if (tid == 0) {
-            bw[i] = -1.0;
-            atomicAdd(redo, 1u);
-        }
-        return;
-    }
-    // ---- kth smallest of the m collected values ----
-    unsigned long long v = 0ull;
-    for (int b = 63; b >= 0; --b) {
-        const unsigned long long trial = v | ((1ull << b) - 1ull);
-        int c = 0;
-        for (int e = tid; e < m; e += 256) {
-            const double x = vals[e];
-            const unsigned long long key = (x > 0.0) ? (unsigned long long)__double_as_longlong(x) : 0ull;
-            c += (key <= trial) ? 1 : 0;
-        }
-        c = wave_sum_i32(c);
-        __syncthreads();
-        if ((tid & 63) == 0) red[tid >> 6] = c;
-        __syncthreads();
-        if (red[0] + red[1] + red[2] + red[3] < kth) v |= (1ull << b);
-    }
-    if (tid == 0) bw[i] = __longlong_as_double((long long)v) * scale;
-}
-
-// kth smallest of a row in ONE streaming pass (kth <= 256): the row is read once (the two-pass kernel above reads its 800 KB
+// kth smallest of a row in ONE streaming pass (kth <= 256): the row is read once (the two-pass kernel of round 3 read its 800 KB
 // at N = 2e5 twice from the HBM - 256 rows in flight per XCD do not stay in a 4 MB L2).
 //   steps 0, 1   (the first 2 x 256 x 16 / sizeof(T) values) stay in registers, every thread takes the minimum of
 //                its own; the kth smallest of the 256 minima is an upper bound `ub` of the answer with at least kth
@@ -1555,15 +1438,8 @@ extern "C" int gt_dense_graph_build(gt_ctx* ctx, const void* X_or_D, int64_t n, 
             DENSE_HIP(hipMemsetAsync(st.redo.p, 0, sizeof(uint32_t), ctx->stream));
             uint32_t n_redo = (kth > 256) ? 1u : 0u;
             if (kth <= 256) {
-                // one streaming read of the matrix (option dense_bandwidth_passes = 2: the two-pass kernel of round 3)
-                if (ctx->dense_bw_passes == 2) {
-                    if (dtype == GT_F32)
-                        hipLaunchKernelGGL(dense_bandwidth_2pass_kernel<float>, dim3((unsigned)n), dim3(256), 0, ctx->stream,
-                                           (const float*)in_dev, n, kth, bandwidth_scale, st.bw.as<double>(), st.redo.as<uint32_t>());
-                    else
-                        hipLaunchKernelGGL(dense_bandwidth_2pass_kernel<double>, dim3((unsigned)n), dim3(256), 0, ctx->stream,
-                                           (const double*)in_dev, n, kth, bandwidth_scale, st.bw.as<double>(), st.redo.as<uint32_t>());
-                } else if (dtype == GT_F32 && rows_ok && ctx->dense_rows_fused != 0) {
+                // one streaming read of the matrix
+                if (dtype == GT_F32 && rows_ok && ctx->dense_rows_fused != 0) {
                     // the row-streaming form follows: this pass also lists the rows' kept affinities (no second read for them)
                     DENSE_TRY(rows_alloc());
                     EmitArgs em;
@@ -1604,7 +1480,7 @@ extern "C" int gt_dense_graph_build(gt_ctx* ctx, const void* X_or_D, int64_t n, 
         DENSE_HIP(hipGetLastError());
     }
     // ---- kernel tiles ----
-    bool fused_rowsum = false, p_only = false;
+    bool fused_rowsum = false;
     void* K_dev = nullptr;
     bool rows_done = false, rows_wrote_p = false;
     if (rows_ok) {
@@ -1669,14 +1545,11 @@ extern "C" int gt_dense_graph_build(gt_ctx* ctx, const void* X_or_D, int64_t n, 
                                    tl.i, tl.j, tl.a, int64_t(total), st.inptr.as<unsigned long long>(), incount + n,
                                    st.in_col.as<uint32_t>(), st.in_val.as<float>());
             tspan.reset();
-            // (option dense_rows_reread = 1: one launch, every row is read again and its affinities recomputed - the first form)
 #define GT_ROWS_PART(DIV_, PART_)                                                                                              \
     hipLaunchKernelGGL((dense_rows_write_kernel<DIV_, PART_>), dim3((unsigned)n), dim3(256), 0, ctx->stream, (const float*)in_dev, n, \
                        st.bw.as<double>(), decay, thresh, xc, st.own_sum.as<double>(), st.inptr.as<unsigned long long>(),     \
                        st.in_col.as<uint32_t>(), st.in_val.as<float>(), st.rowsum.as<double>(), (float*)target, tl)
-            if (ctx->dense_rows_reread != 0) {
-                if (direct_p) GT_ROWS_PART(true, 0); else GT_ROWS_PART(false, 0);
-            } else {
+            {
                 StageSpan mark(ctx, "dense_rows_placed");   // (marker: the write pass reads no row - 4 N^2 bytes, not 8)
                 if (direct_p) GT_ROWS_PART(true, 1); else GT_ROWS_PART(false, 1);
                 hipLaunchKernelGGL(dense_zero_rows_kernel, dim3((unsigned)std::min<int64_t>(n, int64_t(ctx->n_cu) * 16)), dim3(256), 0,
@@ -1730,21 +1603,9 @@ extern "C" int gt_dense_graph_build(gt_ctx* ctx, const void* X_or_D, int64_t n, 
                 DENSE_HIP(st.rowsum.reserve(size_t(n) * sizeof(double)));
                 DENSE_HIP(hipMemsetAsync(st.rowsum.p, 0, size_t(n) * sizeof(double), ctx->stream));
             }
-            // The operator alone, in place (inplace, out_P = the matrix itself, no out_K): K is never stored - one tile pass forms
-            // the row sums, a second one writes P = K / rowsum over the distances (12 N^2 bytes instead of 16 N^2)
-            p_only = fused_rowsum && inplace && out_P == K_dev && !out_K && out_on_device && ctx->dense_p_only != 0;
-            if (p_only) {
-                DENSE_TRY((launch_tiles<float, float, double, false>(ctx, (const float*)in_dev, nullptr, 0, n, bw, decay, thresh,
-                                                                     kernel_symm, theta, (float*)K_dev, fl, pass,
-                                                                     st.rowsum.as<double>(), 1)));
-                DENSE_TRY((launch_tiles<float, float, double, false>(ctx, (const float*)in_dev, nullptr, 0, n, bw, decay, thresh,
-                                                                     kernel_symm, theta, (float*)K_dev, fl, pass,
-                                                                     st.rowsum.as<double>(), 2)));
-            } else {
-                DENSE_TRY((launch_tiles<float, float, double, false>(ctx, (const float*)in_dev, nullptr, 0, n, bw, decay,
-                                                                     thresh, kernel_symm, theta, (float*)K_dev, fl, pass,
-                                                                     fused_rowsum ? st.rowsum.as<double>() : nullptr)));
-            }
+            DENSE_TRY((launch_tiles<float, float, double, false>(ctx, (const float*)in_dev, nullptr, 0, n, bw, decay,
+                                                                 thresh, kernel_symm, theta, (float*)K_dev, fl, pass,
+                                                                 fused_rowsum ? st.rowsum.as<double>() : nullptr)));
         }
     }
     // ---- anisotropy + P ----
@@ -1759,7 +1620,7 @@ extern "C" int gt_dense_graph_build(gt_ctx* ctx, const void* X_or_D, int64_t n, 
     }
     if (out_f64)
         DENSE_TRY(finish_dense<double>(ctx, st, (double*)K_dev, (double*)P_dev, n, anisotropy));
-    else if (!p_only && !rows_wrote_p)   // (p_only / the row-streaming form for P alone: P is written already)
+    else if (!rows_wrote_p)   // (the row-streaming form for P alone: P is written already)
         DENSE_TRY(finish_dense<float>(ctx, st, (float*)K_dev, (float*)P_dev, n, anisotropy, fused_rowsum));
     if (out_K && !out_on_device) DENSE_TRY(gt_copy_to_host(ctx, out_K, K_dev, size_t(n) * n * out_esz));
     if (out_P && !out_on_device) DENSE_TRY(gt_copy_to_host(ctx, out_P, P_dev, size_t(n) * n * out_esz));

@@ -58,7 +58,6 @@ struct GraphState {
     DevBuf ucol, uval;       // fused tail: received entries in fixed slot rows [row][capT] (columns, values)
     bool bins_used = false;
     bool pairs = false;        // this build's affinities settled the mutual pairs (negative = final values; graph_finish_pairs)
-    bool fused_used = false;   // the last build wrote K and P through the fused tail (gt_sparse.hip bin_fill3_kernel)
     bool relabelled = false;   // the CSR's columns are the caller's row numbers of a renumbered point set (rows: gt_points_row_ids)
     int64_t nnz0 = 0, nnz = 0;
 };

@@ -197,7 +197,6 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
         const float* Qc = external ? k->Qc.as<float>() : ctx->Yc.as<float>();
         GT_HIP(ctx, k->qorder.reserve(size_t(nq) * sizeof(int32_t)));
         k->xs_ready = false;   // (the sorted copy of the points follows the order)
-        k->yps_ready = false;
         GT_HIP(ctx, k->qthr0.reserve(size_t(nq) * sizeof(float)));
         {
             StageSpan span(ctx, "query_order");
@@ -206,7 +205,7 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
         }
         if (ordered) sa.qrows = ra.qrows = k->qorder.as<int32_t>();
         k->ordered = ordered != 0 && !external && q0 == 0 && nq == ctx->n;
-        have_thr0 = ordered != 0 && need_m <= 32 && ctx->thr0_mode != 0 && ctx->order_has_thr0 != 0;
+        have_thr0 = ordered != 0 && need_m <= 32 && ctx->order_has_thr0 != 0;
     }
     // Symmetric pass (gt_sym.hip): self queries over the whole point set, euclidean, single-chain arithmetic, grouped
     // query order available (its permutation is the cell-sorted order both sides of the pass share)
@@ -462,11 +461,6 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
             bool bound_done = false, bound_tried = false;
             uint32_t bound_left = 0;
             k->sym_bound_used = false;
-            k->sym_cold_split = false;
-            // (the split copy and the sorted norms must be there; float32 / float64 points alike - the planes are float16)
-            const bool split_cold = ctx->sym_cold_split != 0 && ctx->prec == 1 && k->xs_ready && ctx->DP <= 64 && ctx->Yp.p != nullptr;
-            ErrModel em_split = gt_err_model(ctx, 1);
-            em_split.rel += 8.0 * 5.9604644775390625e-08;   // (the transposed test's two roundings, as in em)
             if (two_stage && ctx->sym_bounds != 0 && n_pad_s % 1024 == 0 && ctx->order_L > 0 && ctx->sym_two_stage != 0 &&
                 (ctx->sym_two_stage > 0 || ctx->sym_two_ok != 0)) {
                 const int64_t bcap = ctx->sym_bound_cap > 0 ? ctx->sym_bound_cap : (int64_t(1) << 22);
@@ -479,18 +473,9 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
                     // the forms derived from the thresholds are made again
                     GT_TRY(gt_sym_orphan_cut(ctx, perm, k->thr_final.as<float>(), k->sym_farcnt.as<float>(), em,
                                              k->sym_racc.as<double>(), need_m, 0.25));
-                    if (split_cold) {
-                        // the cold launch will score with the three split chains: the thresholds lose the margin of the single
-                        // chain's error bound (the single-chain ones are kept aside in case the bound pass gives up)
-                        GT_HIP(ctx, k->thr_keep.reserve(size_t(ctx->n) * sizeof(float)));   // (pad rows are not touched)
-                        GT_HIP(ctx, hipMemcpyAsync(k->thr_keep.p, k->thr_final.p, size_t(ctx->n) * sizeof(float),
-                                                   hipMemcpyDeviceToDevice, ctx->stream));
-                        GT_TRY(gt_sym_thr_retarget(ctx, k->xns.as<double>(), k->thr_final.as<float>(), em, em_split));
-                    }
                     GT_TRY(gt_sym_g_from_thr(ctx, n_pad_s, k->thr_final.as<float>(), k->hnegs.as<float>(), k->sym_g.as<float>(),
                                              k->sym_gmin.as<float>()));
-                    GT_TRY(gt_sym_row_radius(ctx, perm, n_pad_s, k->thr_final.as<float>(), split_cold ? em_split : em,
-                                             k->sym_rrow.as<float>(), split_cold ? em.abs : -1.0));
+                    GT_TRY(gt_sym_row_radius(ctx, perm, n_pad_s, k->thr_final.as<float>(), em, k->sym_rrow.as<float>()));
                     GT_TRY(gt_sym_bound_queue(ctx, n_pad_s, k->Ycs.p, k->sym_rrow.as<float>(), k->sym_bwork,
                                               k->sym_qdense.as<uint2>(), uint32_t(bcap), k->sym_qtot.as<uint32_t>()));
                     GT_HIP(ctx, hipMemcpyAsync(&bound_left, k->sym_qtot.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -498,13 +483,6 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
                 GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
                 bound_tried = true;
                 bound_done = int64_t(bound_left) <= bcap;
-                if (split_cold && !bound_done) {
-                    // the unit loop scores the single chain: back to its thresholds
-                    GT_HIP(ctx, hipMemcpyAsync(k->thr_final.p, k->thr_keep.p, size_t(ctx->n) * sizeof(float), hipMemcpyDeviceToDevice,
-                                               ctx->stream));
-                    GT_TRY(gt_sym_g_from_thr(ctx, n_pad_s, k->thr_final.as<float>(), k->hnegs.as<float>(), k->sym_g.as<float>(),
-                                             k->sym_gmin.as<float>()));
-                }
                 if (ctx->dbg_select & 2048) {
                     fprintf(stderr, "[gt] bound pass: %u units left (capacity %lld)\n", bound_left, (long long)bcap);
                     if (int64_t(bound_left) <= bcap && bound_left > 0) {   // development: how the units spread over the query groups
@@ -529,7 +507,7 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
             // (behind the bound pass only: the units stage one of the two-stage collect lets through - 7.6 M on the manifold
             //  set - are mostly far pairs that file nothing; there the launch is all operand traffic and the frame costs
             //  14.0 -> 20.9 ms for 0.4 ms of re-rank)
-            if (bound_done && ctx->sym_cold_local != 0 && !split_cold && k->xs_ready && ctx->dtype == GT_F32 && (k->xs_d & 3) == 0 &&
+            if (bound_done && ctx->sym_cold_local != 0 && k->xs_ready && ctx->dtype == GT_F32 && (k->xs_d & 3) == 0 &&
                 k->xs_d <= ctx->DP && ctx->DP >= 32 && ctx->DP <= 64) {
                 // the cold launch (behind the bound pass, or behind stage one) in the frame of its queries: what every row needs
                 // listed, as a radius (the one the re-rank will claim: lb of thr - the thresholds are final here), and room for
@@ -578,17 +556,6 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
                 dq.mode = 4;
                 dq.sym.queue = k->sym_qdense.as<uint2>();
                 dq.sym.qn = int32_t(bound_left);
-                if (split_cold) {
-                    if (!k->yps_ready) {
-                        GT_HIP(ctx, k->Yps.reserve(size_t(n_pad_s) * ctx->DP * sizeof(float)));
-                        GT_TRY(gt_sym_gather_split(ctx, perm, n_pad_s, k->Yps.p, k->hnegs.as<float>()));
-                        k->yps_ready = true;
-                    }
-                    dq.Yp = dq.Qp = k->Yps.as<float>();
-                    dq.cold_split = 1;
-                    k->sym_cold_split = true;
-                    ra.err = em_split;   // what the re-rank may claim about the rows that were not collected
-                }
                 GT_TRY(gt_launch_select(ctx, dq));
                 k->sym_cold_entries = int64_t(bound_left);
                 k->sym_bound_used = true;

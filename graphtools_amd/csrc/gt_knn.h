@@ -30,8 +30,6 @@ struct KnnWork {
     // form and their sub-tile minima, the candidate lists of launch B and their counters
     DevBuf hnegs_fin;                             // seeds of the sorted rows, finite on the pad rows (dense seeding launch)
     DevBuf Ycs, hnegs, sym_g, sym_gmin, tlists, tcounts, sym_stat, sym_work, sym_tiles, sym_tile_cnt;
-    DevBuf Yps, thr_keep;   // split-precision cold launch: the split copy in sorted order; the single-chain thresholds kept aside
-    bool yps_ready = false, sym_cold_split = false;
     DevBuf nokeyt_rows, nokeyt_count;             //   rows without them (handed to a repair pass), their number
     uint32_t nokeyt_n = 0;
     DevBuf cand_d2t, keyt_ok;                     //   keys of the transposed pairs next to cand_d2 (pair-resolved symmetrisation), row flags
@@ -243,8 +241,6 @@ int gt_sym_half_thresholds(gt_ctx* ctx, const int32_t* perm, int64_t n_pad_s, co
 // radius of every sorted row in the full compact copy (what a pair it needs listed can be apart at most)
 int gt_sym_row_radius(gt_ctx* ctx, const int32_t* perm, int64_t n_pad_s, const float* thr, const ErrModel& err, float* rrow,
                       double lres = -1.0);
-int gt_sym_thr_retarget(gt_ctx* ctx, const double* xns, float* thr, const ErrModel& from, const ErrModel& to);
-int gt_sym_gather_split(gt_ctx* ctx, const int32_t* perm, int64_t n_pad_s, void* Yps, float* hs);
 // bound pass of the two-stage collect (gt_sym.hip cell_ball_kernel): the units the cell bounds cannot rule out -> queue
 // (world / rank / group: a row-sharded build lists the units of its own pieces of the walks)
 // own_p1 > own_p0: the query groups of the sorted positions [own_p0, own_p1) against EVERY sub-tile (no walks; own_p0 a

@@ -103,8 +103,6 @@ struct SelectArgs {
     int32_t narrow = 0;             // selection, prec 2, dp <= 64: 128-row workgroups (launches with few query rows)
     int32_t final_keep = 0;         // selection: entries kept per query at the end (0: M' = 16*nt; at most 64*nt)
     int32_t dbg = 0;                // experiment switches (bit 0: no survivors, bit 1: no compaction sort)
-    int32_t cold_split = 0;         // mode 4: Yp is the SPLIT copy (hi | lo planes, rows of 4*dp bytes) and the units are scored with the three
-                                    //   chains (error bound of prec 1) - thresholds, seeds and bounds must belong to that arithmetic
 };
 
 int gt_launch_select(gt_ctx* ctx, const SelectArgs& a);

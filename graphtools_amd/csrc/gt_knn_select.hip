@@ -1350,12 +1350,12 @@ __device__ __forceinline__ void cold_admit(const f32x16& A0, const f32x16& A1, c
 #ifndef GT_SEL_COLD_EPW
 #define GT_SEL_COLD_EPW 16   // queue entries per wave of the cold launch (consecutive entries mostly share their queries)
 #endif
-template <int DP, int CP>   // CP: arithmetic of the scores - 2 the hi planes alone (one chain), 1 hi and lo planes (three chains)
-__global__ __launch_bounds__(256, CP == 1 ? 2 : GT_SEL_COLD_WAVES) void sym_cold_kernel(const float* __restrict__ Yp, const float* __restrict__ hneg,
+template <int DP>
+__global__ __launch_bounds__(256, GT_SEL_COLD_WAVES) void sym_cold_kernel(const float* __restrict__ Yp, const float* __restrict__ hneg,
                                                        const float* __restrict__ thr_in, const int32_t nq,
                                                        const int32_t ntiles, const SymDev sy) {
     using C = SelCfg<DP, 2>;
-    constexpr int RWC = SelCfg<DP, CP>::RW;   // row width of the copy this launch reads
+    constexpr int RWC = C::RW;   // row width of the compact copy
     constexpr int QT = 2;
     const int lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
     const int64_t en0 = (int64_t(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6)) * GT_SEL_COLD_EPW;
@@ -1363,7 +1363,7 @@ __global__ __launch_bounds__(256, CP == 1 ? 2 : GT_SEL_COLD_WAVES) void sym_cold
     const int w = 0;
     constexpr int BQ = 128 * GT_SEL_TWO_QT, TPB = BQ / C::BN;   // query blocks of the collect launch
     const int T = ntiles, NB = T / TPB, H = (NB - 1) / 2;
-    Frag<DP, CP> bq[QT], ca;
+    Frag<DP, 2> bq[QT], ca;
     float thrF[QT], hnqF[QT], thr[QT];
     uint32_t have_q = 0xFFFFFFFFu;
     // a wave takes a few consecutive entries: the bound pass files the units of a group of 64 queries together (and the
@@ -1697,8 +1697,8 @@ int launch_sym_cold(gt_ctx* ctx, const SelectArgs& a) {
     if (!a.sym.queue || !a.sym.g || !a.sym.tlists || !a.sym.tcounts || a.sym.tcap <= 0)
         GT_FAIL(ctx, GT_E_ARG, "knn_select: the cold pass needs the queue and the lists of the collect launch");
     // (independent waves: one per workgroup, so that a wave with much to file does not hold three idle slots)
-    const int wpb = ctx->row_wpb == 4 ? 4 : 1;
-    if (a.sym.xs != nullptr && !a.cold_split) {
+    const int wpb = 1;
+    if (a.sym.xs != nullptr) {
         // local frame (sym_cold_local_kernel): the centres of the query groups first
         if (!a.sym.gcen || !a.sym.rloc || a.sym.xs_d <= 0 || (a.sym.xs_d & 3) != 0 || a.sym.xs_d > DP || a.sym.xs_n <= 0 || !(a.sym.sc > 0.f))
             GT_FAIL(ctx, GT_E_ARG, "knn_select: the local-frame cold pass needs the sorted float32 points, the group centres and the rows' radii");
@@ -1711,12 +1711,8 @@ int launch_sym_cold(gt_ctx* ctx, const SelectArgs& a) {
         GT_HIP(ctx, hipGetLastError());
         return GT_OK;
     }
-    if (a.cold_split)
-        hipLaunchKernelGGL((sym_cold_kernel<DP, 1>), dim3((unsigned)ceil_div64(a.sym.qn, wpb * GT_SEL_COLD_EPW)), dim3(64 * wpb), 0, ctx->stream, a.Yp, a.hneg,
-                           a.thr_in, a.nq, int(a.n_pad / SelCfg<DP, 2>::BN), a.sym);
-    else
-        hipLaunchKernelGGL((sym_cold_kernel<DP, 2>), dim3((unsigned)ceil_div64(a.sym.qn, wpb * GT_SEL_COLD_EPW)), dim3(64 * wpb), 0, ctx->stream, a.Yp, a.hneg,
-                           a.thr_in, a.nq, int(a.n_pad / SelCfg<DP, 2>::BN), a.sym);
+    hipLaunchKernelGGL((sym_cold_kernel<DP>), dim3((unsigned)ceil_div64(a.sym.qn, wpb * GT_SEL_COLD_EPW)), dim3(64 * wpb), 0, ctx->stream, a.Yp, a.hneg,
+                       a.thr_in, a.nq, int(a.n_pad / SelCfg<DP, 2>::BN), a.sym);
     GT_HIP(ctx, hipGetLastError());
     return GT_OK;
 }

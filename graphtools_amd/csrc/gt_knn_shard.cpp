@@ -98,7 +98,6 @@ extern "C" int gt_points_cell_sort(gt_ctx* ctx, int32_t* applied) {
     }
     k->ordered = false;
     k->xs_ready = false;
-    k->yps_ready = false;
     k->sh_stage = 0;
     if (!ordered || ctx->order_L <= 0) return GT_OK;
     GT_TRY(renumber_by(ctx, k->qorder.as<int32_t>()));
@@ -151,7 +150,6 @@ extern "C" int gt_points_cells_finish(gt_ctx* ctx, const void* cells_all_dev) {
     }
     k->ordered = false;
     k->xs_ready = false;
-    k->yps_ready = false;
     k->sh_stage = 0;
     return renumber_by(ctx, k->qorder.as<int32_t>());
 }

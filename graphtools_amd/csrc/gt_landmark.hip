@@ -443,6 +443,7 @@ extern "C" int gt_landmark_scale(gt_ctx* ctx, double* M_inout, const double* R, 
     GT_HIP(ctx, hipSetDevice(ctx->device));
     const int L = n_landmark;
     DevBuf dm, dr;
+    DevBufScope scratch{&dm, &dr};
     double* Md = M_inout;
     const double* Rd = R;
     if (!on_device) {
@@ -459,8 +460,6 @@ extern "C" int gt_landmark_scale(gt_ctx* ctx, double* M_inout, const double* R, 
     if (e == hipSuccess && !on_device)
         e = hipMemcpyAsync(M_inout, Md, size_t(L) * L * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    dm.release();
-    dr.release();
     if (e != hipSuccess) {
         ctx->set_error(std::string("gt_landmark_scale: ") + hipGetErrorString(e));
         return GT_E_HIP;

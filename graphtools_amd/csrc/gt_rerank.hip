@@ -414,7 +414,7 @@ __global__ __launch_bounds__(256, 5) void rerank_sym_kernel(
 #define GT_RERANK_UNROLL 2   // evaluation passes whose loads are issued together
 #endif
 #ifndef GT_RERANK_RPW
-#define GT_RERANK_RPW 1   // rows per wave of rerank_sym4_kernel, fixed at compile time (0: the run-time option rerank_rows_per_wave)
+#define GT_RERANK_RPW 1   // rows per wave of rerank_sym4_kernel, fixed at compile time (0: eight)
 #endif
 #ifndef GT_RERANK_WAVES
 #define GT_RERANK_WAVES 4   // waves per SIMD the registers are cut for
@@ -970,7 +970,7 @@ __global__ __launch_bounds__(256) void emit_knn_kernel(const double* __restrict_
 
 template <typename T>
 int rerank_t(gt_ctx* ctx, const RerankArgs& a) {
-    const int wpb = ctx->rerank_wpb != 4 ? 1 : 4;   // rows (waves) per workgroup: see gt_launch_rerank_sym
+    const int wpb = 1;   // rows (waves) per workgroup: see gt_launch_rerank_sym
     const int64_t blocks = ceil_div64(a.nq, wpb);
     const size_t lds = size_t(wpb) * a.d * sizeof(double);
     const bool f4 = sizeof(T) == 4 && (a.d & 3) == 0 && (reinterpret_cast<uintptr_t>(a.X) & 15) == 0;
@@ -1094,18 +1094,18 @@ int gt_launch_rerank_sym(gt_ctx* ctx, const RerankArgs& a, const SymRerank& sr) 
     hipLaunchKernelGGL((rerank_sym_kernel<T_, F4_>), dim3((unsigned)blocks), dim3(64 * wpb), lds, ctx->stream, (const T_*)a.X, a.d,  \
                        a.xn, a.nq, sr.tlists, sr.tcap, sr.tcounts, a.thr_final, a.ymax2, a.err, a.need_m, sr.perm,        \
                        a.cand_d2, a.cand_j, a.cand_n, a.d2_lb, a.fb_count, a.fb_rows, a.gflags, a.radius_key_factor,      \
-                       a.unproven, sr.stat, (ctx->dbg_select & 256) ? 1 : 0, sr.invperm, sr.own_rows, sr.own_r0, ctx->xcd_chunk,      \
+                       a.unproven, sr.stat, (ctx->dbg_select & 256) ? 1 : 0, sr.invperm, sr.own_rows, sr.own_r0, 0,      \
                        (const T_*)sr.Xs, sr.xns, a.metric, sr.pos0)
 #define GT_RERANK_SYM4_LAUNCH(DB_, WT_, WPB_)                                                                             \
     hipLaunchKernelGGL((rerank_sym4_kernel<DB_, WT_, WPB_>), dim3((unsigned)ceil_div64(a.nq, int64_t(WPB_) * rpw)), dim3(64 * WPB_), 0, ctx->stream, (const float*)a.X, dx, \
                        a.xn, a.nq, sr.tlists, sr.tcap, sr.tcounts, a.thr_final, a.ymax2, a.err, a.need_m, sr.perm,        \
                        a.cand_d2, a.cand_j, a.cand_n, a.d2_lb, a.fb_count, a.fb_rows, a.gflags, a.radius_key_factor,      \
-                       a.unproven, sr.stat, (ctx->dbg_select & 256) ? 1 : 0, sr.invperm, sr.own_rows, sr.own_r0, ctx->xcd_chunk,      \
+                       a.unproven, sr.stat, (ctx->dbg_select & 256) ? 1 : 0, sr.invperm, sr.own_rows, sr.own_r0, 0,      \
                        (const float*)sr.Xs, sr.xns, sr.cand_d2t, sr.keyt_ok, sr.nokeyt_rows, sr.nokeyt_count, a.metric, sr.pos0, rpw)
     if (sr.wrote_t) *sr.wrote_t = false;
     // rows per wave of rerank_sym4_kernel (consecutive sorted positions, the next row's list prefetched): enough waves to fill
     // the chip a few times over must remain
-    const int rpw = GT_RERANK_RPW > 0 ? GT_RERANK_RPW : std::max(1, std::min(ctx->rerank_rows_per_wave, int(a.nq / (int64_t(ctx->n_cu) * 64) + 1)));
+    const int rpw = GT_RERANK_RPW > 0 ? GT_RERANK_RPW : 8;
     // (dx: row length = stride of the sorted copy - the points' d, or d zero padded to a multiple of 4)
     const int dx = (sr.Xs && sr.xs_d > 0) ? sr.xs_d : a.d;
     if (dx != a.d && !(a.dtype == GT_F32 && (dx & 3) == 0 && dx <= 64 && ctx->rerank_lanes4 != 0))
@@ -1115,13 +1115,10 @@ int gt_launch_rerank_sym(gt_ctx* ctx, const RerankArgs& a, const SymRerank& sr) 
         const bool f4x = sr.Xs != nullptr && (dx & 3) == 0 && (reinterpret_cast<uintptr_t>(sr.Xs) & 15) == 0;
         if (f4x && ctx->rerank_lanes4 != 0 && dx <= 64) {
             const bool wt = sr.cand_d2t != nullptr && sr.keyt_ok != nullptr && sr.nokeyt_rows != nullptr && sr.nokeyt_count != nullptr;
-            // one wave per workgroup: a row with more than 128 candidates costs twice a short one, and a workgroup's slots
-            // are only handed on when its last wave is done (option "rerank_waves_per_block" = 4: the old grouping)
-            const bool one = ctx->rerank_wpb != 4;
-            if (wt && one) GT_RERANK_SYM4_LAUNCH(1, true, 1);
-            else if (wt) GT_RERANK_SYM4_LAUNCH(1, true, 4);
-            else if (one) GT_RERANK_SYM4_LAUNCH(1, false, 1);
-            else GT_RERANK_SYM4_LAUNCH(1, false, 4);
+            // one wave per workgroup: rows differ in cost, and a workgroup's slots are only handed on when its last wave is
+            // done (four rows per workgroup measured 4.28 against 4.02 ms in round 3; the variant was removed in round 5)
+            if (wt) GT_RERANK_SYM4_LAUNCH(1, true, 1);
+            else GT_RERANK_SYM4_LAUNCH(1, false, 1);
             if (sr.wrote_t) *sr.wrote_t = wt;
         }
         else if (f4) GT_RERANK_SYM_LAUNCH(float, true);

@@ -977,6 +977,9 @@ __global__ __launch_bounds__(256) void sort_merge_kernel(const int64_t nloc, con
 // Rows of kBigRow < L <= kHugeRow entries (hub rows of the transpose): same register sort with 16 / 32 keys per lane in
 // a kernel of its own, so that its register budget does not cut the occupancy of the common case.  Persistent waves
 // walk the list sort_merge_kernel left in bigrows; what is longer still is compacted to the front of hugerows.
+// (NT = 16: the rows of up to 1024 entries - and the listing of the huge ones -, NT = 32: those of 1025 ... 2048: two launches,
+//  so that the common range is not compiled against the 32-key network's 260 registers and its 272 B of scratch)
+template <int NT>
 __global__ __launch_bounds__(64) void sort_merge_long_kernel(const int64_t* __restrict__ off, const UnionSrc us,
                                                              const int symm,
                                                              const double theta, uint32_t* __restrict__ Vkey,
@@ -991,13 +994,13 @@ __global__ __launch_bounds__(64) void sort_merge_long_kernel(const int64_t* __re
         const int64_t o0 = off[i];
         const int64_t L64 = off[i + 1] - o0;
         if (L64 > kHugeRow) {
-            if (lane == 0) hugerows[atomicAdd(hugecount, 1u)] = int32_t(i);
+            if (NT == 16 && lane == 0) hugerows[atomicAdd(hugecount, 1u)] = int32_t(i);
             continue;
         }
         const int L = int(L64);
+        if ((L <= 1024) != (NT == 16)) continue;   // (the other launch's row; wave-uniform)
         const RowSrc U = make_row_src(us, i, o0);
-        const int c = (L <= 1024) ? sort_merge_row<uint64_t, 16>(U, L, lane, symm, theta, Vkey + o0, Vval + o0)
-                                  : sort_merge_row<uint64_t, 32>(U, L, lane, symm, theta, Vkey + o0, Vval + o0);
+        const int c = sort_merge_row<uint64_t, NT>(U, L, lane, symm, theta, Vkey + o0, Vval + o0);
         if (lane == 0) outlen[i] = c;
     }
 }
@@ -1128,26 +1131,18 @@ __global__ __launch_bounds__(256) void compact_kernel(const int64_t nloc, const 
 }
 
 // =====================================================================================================================
-// Count-first tail of the single-rank build (symmetrisation '+', no anisotropy; option symmetrize_fused, OFF by default):
-// the merged length of every row is counted before the merge, so that K, P and the degrees can be written ONCE, straight
-// into the final CSR, instead of parking the merged rows in global memory for a compaction pass.
-//   pair_count_kernel    one wave per row of K: merged length = own + received - pairs, the pairs (columns present in both
-//                        halves) found by comparing the received columns, one per lane, with the own ones (broadcast from
-//                        LDS); rows of more than 512 entries are listed for the long-row kernel
-//   (scan)               row pointers of the final CSR
+// Final-CSR merge kernels of the pair-resolved tail (below; symmetrisation '+', single rank): K, P and the degrees are written
+// ONCE, straight into the final CSR - the row pointers are scanned before the merge.
 //   merge_final_kernel   one wave per row, in ROW order (the CSR is written front to back): register sort of the union by
 //                        (column, tag), merge, indices and K written at the row's place, the row sum accumulated in
 //                        compact_kernel's order (entry e in lane e % 64, increasing e, then the xor tree) through one LDS
 //                        permute per 64 sorted entries, P = K / sum written behind it
-//   merge_long_final_kernel  the rows of 513 ... 2048 entries (persistent waves, 16 / 32 keys per lane); longer rows are
-//                        flagged (the build takes the other path)
-// Results are bit-identical to sort_merge_kernel + compact_kernel (tests/test_gpu_symm_bins.py).  MEASURED AND REJECTED as
-// the default: 6.7 ms against 5.8 ms for symmetrise + P at N = 1e6 - the count pass (a second look at every column) and the
-// row-order merge (received halves fetched out of order, P held in registers) cost more than the compaction pass they
-// save.  A fixed-slot layout for the received halves (one read of the triplets instead of two in bin_fill_kernel) was
-// tried with it and dropped: the in-degrees of the unsymmetrised kernel are heavy-tailed (N = 1e6 mix: median 40, mean
-// 72, 99.9 % 749, maximum 1416; isotropic Gaussian N = 3e5: mean 134, maximum 15 685) - slots sized for the mean overflow
-// on 6 % of the rows, slots sized for the maximum do not fit.
+//   merge_long_final_kernel  the rows of 513 ... 2048 entries (persistent waves, 16 / 32 keys per lane); longer rows go to
+//                        the segmented sort (symm_huge)
+// Results are bit-identical to sort_merge_kernel + compact_kernel (tests/test_gpu_symm_bins.py).  (A count-first variant for
+// kernels WITHOUT settled pairs - a counting pass over every column in front of the same merge - was measured at 6.7 ms
+// against 5.8 ms for sort + compact at N = 1e6 and removed in round 5; so was a fixed-slot layout for the received halves:
+// the in-degrees of the unsymmetrised kernel are heavy-tailed - N = 1e6 mix: median 40, mean 72, 99.9 % 749, maximum 1416.)
 struct FusedSrc {
     const int32_t* pos;       // row -> sorted position
     const int32_t* lenN;      // own kept entries per row
@@ -1197,49 +1192,6 @@ __device__ __forceinline__ RowSrc3 make_row_src3(const FusedSrc& fs, const int64
 }
 
 constexpr uint32_t kFusedHugeRow = 2u;
-
-constexpr int kPairChunk = 512;   // own columns staged in LDS per round (per wave)
-__global__ __launch_bounds__(256) void pair_count_kernel(const int64_t nloc, const FusedSrc fs, int32_t* __restrict__ outlen,
-                                                         int32_t* __restrict__ biglist, uint32_t* __restrict__ bigcount,
-                                                         uint32_t* __restrict__ fflags) {
-    __shared__ uint32_t oc_s[4][kPairChunk];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int64_t i = int64_t(blockIdx.x) * (blockDim.x >> 6) + w;
-    if (i >= nloc) return;   // (wave-uniform)
-    const int64_t p = fs.pos[i];
-    int lt;
-    const RowSrc3 rs = make_row_src3(fs, i, p, lt);
-    const int ln = rs.ln;
-    uint32_t* oc = oc_s[w];
-    int pairs = 0;
-    // received columns: one per lane and round of 64; own columns: broadcast from LDS, kPairChunk at a time
-    for (int o0 = 0; o0 < ln; o0 += kPairChunk) {
-        const int on = ln - o0 < kPairChunk ? ln - o0 : kPairChunk;
-        __builtin_amdgcn_wave_barrier();
-        for (int e = lane; e < on; e += 64) oc[e] = rs.cj ? rs.cj[o0 + e] : cand_index(rs.rl[o0 + e]);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        for (int r0 = 0; r0 < lt; r0 += 64) {
-            const uint32_t rc = (r0 + lane < lt) ? rs.uc[r0 + lane] : 0xFFFFFFFFu;   // (no column looks like it)
-            bool hit = false;
-            int e = 0;
-            for (; e + 4 <= on; e += 4) {
-                const uint4 o4 = *reinterpret_cast<const uint4*>(oc + e);
-                hit |= (o4.x == rc) | (o4.y == rc) | (o4.z == rc) | (o4.w == rc);
-            }
-            for (; e < on; ++e) hit |= oc[e] == rc;
-            pairs += __popcll(__ballot(hit));
-        }
-    }
-    const int L = ln + lt;
-    if (lane == 0) {
-        outlen[i] = L - pairs;
-        if (L > kBigRow) {
-            if (L > kHugeRow) atomicOr(fflags, kFusedHugeRow);
-            else biglist[atomicAdd(bigcount, 1u)] = int32_t(i);
-        }
-    }
-}
 
 // merge of a sorted (key, value) sequence held in registers straight into the final CSR row at dst; returns the row sum
 // in compact_kernel's order.  Keys: (column << 1) | tag, kNoKey where there is no entry.
@@ -1366,6 +1318,9 @@ __global__ __launch_bounds__(256) void merge_final_kernel(const int64_t nloc, co
     }
 }
 
+// NT = 16: the rows of 513 ... 1024 entries, NT = 32: those of 1025 ... 2048 - two launches over the same list.  (One kernel
+// holding both networks needed 265 VGPRs and 272 B of scratch: one wave per SIMD for rows that are mostly in the lower range.)
+template <int NT>
 __global__ __launch_bounds__(64) void merge_long_final_kernel(const FusedSrc fs, const int64_t* __restrict__ indptr,
                                                               int32_t* __restrict__ indices, double* __restrict__ Kdata,
                                                               double* __restrict__ Pdata, double* __restrict__ degree,
@@ -1379,10 +1334,10 @@ __global__ __launch_bounds__(64) void merge_long_final_kernel(const FusedSrc fs,
         int lt;
         const RowSrc3 U = make_row_src3(fs, i, p, lt);
         const int L = U.ln + lt;
+        if ((L <= 1024) != (NT == 16)) continue;   // (the other launch's row; wave-uniform)
         const int64_t dst = indptr[i];
         bool any_diag = false;
-        const double sum = (L <= 1024) ? sort_merge_final_row<uint64_t, 16>(U, L, lane, i, indices, Kdata, Pdata, dst, any_diag)
-                                       : sort_merge_final_row<uint64_t, 32>(U, L, lane, i, indices, Kdata, Pdata, dst, any_diag);
+        const double sum = sort_merge_final_row<uint64_t, NT>(U, L, lane, i, indices, Kdata, Pdata, dst, any_diag);
         if (lane == 0) {
             degree[i] = sum;
             if (!any_diag) atomicOr(flags, GT_FLAG_ZERO_DIAGONAL);
@@ -1575,7 +1530,7 @@ Splits make_splits(const GraphState* g) {
 template <typename T>
 void launch_affinity(gt_ctx* ctx, GraphState* g, KnnWork* k, int binary, double decay, double thresh, int count_owners) {
     // (rows per workgroup: a workgroup's wave slots are handed on when its LAST wave is done, and the rows' costs differ)
-    const int wpb = ctx->row_wpb == 4 ? 4 : 1;
+    const int wpb = 1;
     const size_t lds = size_t(wpb) * ctx->d * sizeof(double);
 #define GT_AFFINITY_LAUNCH(RADIUS_, PAIRS_, LIST_, NROWS_)                                                                  \
     hipLaunchKernelGGL((affinity_kernel<T, RADIUS_, PAIRS_>), dim3((unsigned)ceil_div64(NROWS_, wpb)), dim3(64 * wpb), lds, ctx->stream, \
@@ -2226,9 +2181,7 @@ static int graph_finish_impl(gt_ctx* ctx, const void* recv_buf_dev, int64_t n_re
                        g->rK.as<double>(), g->tablen.as<int32_t>(), perm, shift, nbins, g->binoff.as<int64_t>(),            \
                        (const Triplet*)g->selfbuf.p, g->cnt_sorted.as<int32_t>(), g->pos_sorted.as<int64_t>(),              \
                        g->off.as<int64_t>(), g->Ukey.as<UEntry>(), (uint32_t*)nullptr, (double*)nullptr)
-            if (ctx->symm_fill_threads >= 1024) GT_BIN_FILL(1024);
-            else if (ctx->symm_fill_threads >= 512) GT_BIN_FILL(512);
-            else GT_BIN_FILL(256);
+            GT_BIN_FILL(256);
 #undef GT_BIN_FILL
             GT_HIP(ctx, hipGetLastError());
         } else {
@@ -2257,11 +2210,15 @@ static int graph_finish_impl(gt_ctx* ctx, const void* recv_buf_dev, int64_t n_re
         us.rcap = g->rcap;
         {
             StageSpan span_m(ctx, "symm_merge");   // (nested in "symmetrize")
-            hipLaunchKernelGGL(sort_merge_kernel, dim3((unsigned)ceil_div64(nloc, ctx->row_wpb == 4 ? 4 : 1)), dim3(ctx->row_wpb == 4 ? 256 : 64), 0, ctx->stream, nloc,
+            hipLaunchKernelGGL(sort_merge_kernel, dim3((unsigned)ceil_div64(nloc, 1)), dim3(64), 0, ctx->stream, nloc,
                                g->off.as<int64_t>(), us, g->p.kernel_symm, g->p.theta,
                                g->Vkey.as<uint32_t>(), g->Vval.as<double>(), g->outlen.as<int32_t>(), g->bigrows.as<int32_t>(),
                                g->bigcount.as<uint32_t>(), (ctx->symm_key32 != 0 && sort_key_fits_u32(g->n_total, 8)) ? 1 : 0);
-            hipLaunchKernelGGL(sort_merge_long_kernel, dim3(4096), dim3(64), 0, ctx->stream, g->off.as<int64_t>(),
+            hipLaunchKernelGGL(sort_merge_long_kernel<16>, dim3(4096), dim3(64), 0, ctx->stream, g->off.as<int64_t>(),
+                               us, g->p.kernel_symm, g->p.theta, g->Vkey.as<uint32_t>(),
+                               g->Vval.as<double>(), g->outlen.as<int32_t>(), g->bigrows.as<int32_t>(), g->bigcount.as<uint32_t>(),
+                               g->hugerows.as<int32_t>(), g->bigcount.as<uint32_t>() + 1);
+            hipLaunchKernelGGL(sort_merge_long_kernel<32>, dim3(2048), dim3(64), 0, ctx->stream, g->off.as<int64_t>(),
                                us, g->p.kernel_symm, g->p.theta, g->Vkey.as<uint32_t>(),
                                g->Vval.as<double>(), g->outlen.as<int32_t>(), g->bigrows.as<int32_t>(), g->bigcount.as<uint32_t>(),
                                g->hugerows.as<int32_t>(), g->bigcount.as<uint32_t>() + 1);
@@ -2345,7 +2302,7 @@ static int graph_finish_impl(gt_ctx* ctx, const void* recv_buf_dev, int64_t n_re
         GT_HIP(ctx, g->degree.reserve(size_t(nloc) * sizeof(double)));
         {
             StageSpan span_c(ctx, "symm_compact");   // (nested in "symmetrize")
-            hipLaunchKernelGGL(compact_kernel, dim3((unsigned)ceil_div64(nloc, ctx->row_wpb == 4 ? 4 : 1)), dim3(ctx->row_wpb == 4 ? 256 : 64), 0, ctx->stream, nloc, g->r0,
+            hipLaunchKernelGGL(compact_kernel, dim3((unsigned)ceil_div64(nloc, 1)), dim3(64), 0, ctx->stream, nloc, g->r0,
                                g->off.as<int64_t>(), g->outlen.as<int32_t>(), g->indptr.as<int64_t>(), g->Vkey.as<uint32_t>(),
                                g->Vval.as<double>(), g->indices.as<int32_t>(), g->Kdata.as<double>(), g->degree.as<double>(),
                                g->flags.as<uint32_t>(), perm, g->p.anisotropy == 0.0 ? g->Pdata.as<double>() : nullptr, relabel);
@@ -2370,14 +2327,11 @@ static int graph_finish_impl(gt_ctx* ctx, const void* recv_buf_dev, int64_t n_re
     return GT_OK;
 }
 
-// Fused tail (see pair_count_kernel): single rank, every row local, cell-sorted order at hand, '+' symmetrisation, no
-// anisotropy, every kept value > 0.  Returns 1 when K, P and the degrees are final, 0 when the build has to take the
-// other path instead (a union row of more than 2048 entries), < 0 on error.
 // ---- pair-resolved tail ('+' rule, single rank) ---------------------------------------------------------------------
 // affinity_kernel has settled every mutual pair in its own row (negative = final value), so only the one-sided entries
 // are transposed: 44 M instead of 72 M triplets at N = 1e6, no pair ever meets its partner in a union row - a row's
 // final length is its own kept entries plus what it receives, known once the bins are filled - and the merge sorts and
-// writes K and P straight into the CSR (merge_final_kernel of the count-first tail, without its counting pass).
+// writes K and P straight into the CSR (merge_final_kernel).
 __global__ __launch_bounds__(256) void pairs_len_kernel(const int64_t nloc, const int32_t* __restrict__ pos,
                                                         const int64_t* __restrict__ off, int32_t* __restrict__ outlen,
                                                         int32_t* __restrict__ biglist, uint32_t* __restrict__ bigcount,
@@ -2527,12 +2481,15 @@ static int graph_finish_pairs(gt_ctx* ctx, int64_t* out_nnz, uint32_t* flags) {
             }
             GT_HIP(ctx, hipEventCreateWithFlags(&ctx->side_event, hipEventDisableTiming));
         }
-        hipLaunchKernelGGL(merge_long_final_kernel, dim3(1024), dim3(64), 0, ctx->side_stream, fs, g->indptr.as<int64_t>(),
+        hipLaunchKernelGGL(merge_long_final_kernel<16>, dim3(2048), dim3(64), 0, ctx->side_stream, fs, g->indptr.as<int64_t>(),
+                           g->indices.as<int32_t>(), g->Kdata.as<double>(), g->Pdata.as<double>(), g->degree.as<double>(),
+                           g->flags.as<uint32_t>(), g->bigrows.as<int32_t>(), g->bigcount.as<uint32_t>());
+        hipLaunchKernelGGL(merge_long_final_kernel<32>, dim3(1024), dim3(64), 0, ctx->side_stream, fs, g->indptr.as<int64_t>(),
                            g->indices.as<int32_t>(), g->Kdata.as<double>(), g->Pdata.as<double>(), g->degree.as<double>(),
                            g->flags.as<uint32_t>(), g->bigrows.as<int32_t>(), g->bigcount.as<uint32_t>());
         GT_HIP(ctx, hipGetLastError());
         GT_HIP(ctx, hipEventRecord(ctx->side_event, ctx->side_stream));
-        hipLaunchKernelGGL(merge_final_kernel, dim3((unsigned)ceil_div64(nloc, ctx->row_wpb == 4 ? 4 : 1)), dim3(ctx->row_wpb == 4 ? 256 : 64), 0, ctx->stream, nloc, fs,
+        hipLaunchKernelGGL(merge_final_kernel, dim3((unsigned)ceil_div64(nloc, 1)), dim3(64), 0, ctx->stream, nloc, fs,
                            g->indptr.as<int64_t>(), g->indices.as<int32_t>(), g->Kdata.as<double>(), g->Pdata.as<double>(),
                            g->degree.as<double>(), g->flags.as<uint32_t>(),
                            (ctx->symm_key32 != 0 && sort_key_fits_u32(g->n_total, 8)) ? 1 : 0);
@@ -2576,118 +2533,6 @@ static int graph_finish_pairs(gt_ctx* ctx, int64_t* out_nnz, uint32_t* flags) {
     GT_HIP(ctx, hipMemcpyAsync(&kfl, k->gflags.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     g->nnz0 = n_own;
-    g->nnz = nnz;
-    g->finished = true;
-    fl |= kfl;
-    if (k->n_fallback > 0) fl |= GT_FLAG_FALLBACK_ROWS;
-    if (g->n_over > 0) fl |= GT_FLAG_RADIUS_ROWS;
-    if (out_nnz) *out_nnz = g->nnz;
-    if (flags) *flags = fl;
-    return 1;
-}
-
-static int graph_finish_fused(gt_ctx* ctx, int64_t* out_nnz, uint32_t* flags) {
-    GraphState* g = ctx->graph;
-    KnnWork* k = ctx->knn;
-    const int64_t nloc = g->nloc;
-    const int64_t n_recv = g->send_counts_host[0];   // every kept entry is sent once (graph_begin_impl)
-    if (n_recv <= 0) return 0;
-    StageSpan span(ctx, "symmetrize");
-    StageSpan span_f(ctx, "symm_fused");   // (nested: the sign that this path ran)
-    const int32_t* perm = k->qorder.as<int32_t>();
-    int shift = 9;
-    if (ctx->symm_bin_shift > 0) shift = ctx->symm_bin_shift;
-    while (ceil_div64(nloc, int64_t(1) << shift) > 4096) ++shift;
-    const int nbins = int(ceil_div64(nloc, int64_t(1) << shift));
-    GT_HIP(ctx, k->sh_invperm.reserve(size_t(nloc) * sizeof(int32_t)));
-    GT_TRY(gt_sym_invperm(ctx, perm, k->sh_invperm.as<int32_t>()));
-    GT_HIP(ctx, g->cnt_sorted.reserve(size_t(nloc) * sizeof(int32_t)));
-    GT_HIP(ctx, g->pos_sorted.reserve(size_t(nloc + 1) * sizeof(int64_t)));
-    GT_HIP(ctx, g->bincnt.reserve(size_t(2 * nbins) * sizeof(int32_t)));
-    GT_HIP(ctx, g->binoff.reserve(size_t(nbins + 1) * sizeof(int64_t)));
-    GT_HIP(ctx, g->cursor.reserve(size_t(n_recv) * sizeof(uint32_t)));   // posj
-    GT_HIP(ctx, g->selfbuf.reserve(size_t(n_recv) * sizeof(Triplet)));
-    GT_HIP(ctx, g->ucol.reserve(size_t(n_recv) * sizeof(uint32_t)));
-    GT_HIP(ctx, g->uval.reserve(size_t(n_recv) * sizeof(double)));
-    GT_HIP(ctx, g->off.reserve(size_t(nloc + 1) * sizeof(int64_t)));
-    GT_HIP(ctx, g->outlen.reserve(size_t(nloc) * sizeof(int32_t)));
-    GT_HIP(ctx, g->bigrows.reserve(size_t(nloc) * sizeof(int32_t)));
-    GT_HIP(ctx, g->bigcount.reserve(4 * sizeof(uint32_t)));   // [0] long rows, [2] fused-path flags
-    GT_HIP(ctx, g->indptr.reserve(size_t(nloc + 1) * sizeof(int64_t)));
-    const int64_t total_u = 2 * n_recv;   // upper bound of nnz(K)
-    GT_HIP(ctx, g->indices.reserve(size_t(total_u) * sizeof(int32_t)));
-    GT_HIP(ctx, g->Kdata.reserve(size_t(total_u) * sizeof(double)));
-    GT_HIP(ctx, g->Pdata.reserve(size_t(total_u) * sizeof(double)));
-    GT_HIP(ctx, g->degree.reserve(size_t(nloc) * sizeof(double)));
-    GT_HIP(ctx, hipMemsetAsync(g->bincnt.p, 0, size_t(2 * nbins) * sizeof(int32_t), ctx->stream));
-    GT_HIP(ctx, hipMemsetAsync(g->bigcount.p, 0, 4 * sizeof(uint32_t), ctx->stream));
-    uint32_t* fflags = g->bigcount.as<uint32_t>() + 2;
-    // own entries in sorted order and their scan; triplets per destination bin and their scan
-    hipLaunchKernelGGL(gather_counts_kernel, dim3((unsigned)ceil_div64(nloc, 256)), dim3(256), 0, ctx->stream,
-                       g->lenN.as<int32_t>(), perm, nloc, g->cnt_sorted.as<int32_t>());
-    GT_TRY(exclusive_scan(ctx, g->cnt_sorted.as<int32_t>(), nullptr, nloc, g->pos_sorted.as<int64_t>(), g->scan_tmp));
-    hipLaunchKernelGGL(bin_count_kernel, dim3((unsigned)std::min<int64_t>(ceil_div64(nloc, 64), 2048)), dim3(256),
-                       size_t(nbins) * sizeof(int32_t), ctx->stream, nloc, k->MP, k->cand_d2.as<double>(),
-                       k->cand_j.as<uint32_t>(), g->rowsrc.as<int32_t>(), g->rlists.as<uint64_t>(),
-                       g->rcounts.as<uint32_t>(), g->rcap, g->rK.as<double>(), g->tablen.as<int32_t>(), perm,
-                       k->sh_invperm.as<int32_t>(), shift, nbins, g->pos_sorted.as<int64_t>(), g->cursor.as<uint32_t>(),
-                       g->bincnt.as<int32_t>());
-    GT_TRY(exclusive_scan(ctx, g->bincnt.as<int32_t>(), nullptr, nbins, g->binoff.as<int64_t>(), g->scan_tmp));
-    hipLaunchKernelGGL(bin_emit_kernel, dim3((unsigned)ceil_div64(nloc, kEmitRows)), dim3(256), size_t(2 * nbins) * sizeof(int32_t),
-                       ctx->stream, nloc, k->MP, k->cand_d2.as<double>(), k->cand_j.as<uint32_t>(), g->rowsrc.as<int32_t>(),
-                       g->rlists.as<uint64_t>(), g->rcounts.as<uint32_t>(), g->rcap, g->rK.as<double>(),
-                       g->tablen.as<int32_t>(), perm, g->pos_sorted.as<int64_t>(), g->cursor.as<uint32_t>(), shift, nbins,
-                       g->binoff.as<int64_t>(), g->bincnt.as<int32_t>() + nbins, (Triplet*)g->selfbuf.p);
-    hipLaunchKernelGGL(bin_fill_kernel<256>, dim3((unsigned)nbins), dim3(256), size_t(2) * (size_t(1) << shift) * sizeof(int32_t),
-                       ctx->stream, nloc, k->MP, k->cand_d2.as<double>(), k->cand_j.as<uint32_t>(), g->rowsrc.as<int32_t>(),
-                       g->rlists.as<uint64_t>(), g->rcounts.as<uint32_t>(), g->rcap, g->rK.as<double>(),
-                       g->tablen.as<int32_t>(), perm, shift, nbins, g->binoff.as<int64_t>(), (const Triplet*)g->selfbuf.p,
-                       g->cnt_sorted.as<int32_t>(), g->pos_sorted.as<int64_t>(), g->off.as<int64_t>(), (UEntry*)nullptr,
-                       g->ucol.as<uint32_t>(), g->uval.as<double>());
-    GT_HIP(ctx, hipGetLastError());
-    FusedSrc fs;
-    fs.pos = k->sh_invperm.as<int32_t>();
-    fs.lenN = g->lenN.as<int32_t>();
-    fs.off = g->off.as<int64_t>();
-    fs.sN = g->pos_sorted.as<int64_t>();
-    fs.rowsrc = g->rowsrc.as<int32_t>();
-    fs.cand_k = k->cand_d2.as<double>();
-    fs.cand_j = k->cand_j.as<uint32_t>();
-    fs.MP = k->MP;
-    fs.rlists = g->rlists.as<uint64_t>();
-    fs.rK = g->rK.as<double>();
-    fs.rcap = g->rcap;
-    fs.ucol = g->ucol.as<uint32_t>();
-    fs.uval = g->uval.as<double>();
-    hipLaunchKernelGGL(pair_count_kernel, dim3((unsigned)ceil_div64(nloc, ctx->row_wpb == 4 ? 4 : 1)), dim3(ctx->row_wpb == 4 ? 256 : 64), 0, ctx->stream, nloc, fs,
-                       g->outlen.as<int32_t>(), g->bigrows.as<int32_t>(), g->bigcount.as<uint32_t>(), fflags);
-    GT_HIP(ctx, hipGetLastError());
-    GT_TRY(exclusive_scan(ctx, g->outlen.as<int32_t>(), nullptr, nloc, g->indptr.as<int64_t>(), g->scan_tmp));
-    hipLaunchKernelGGL(merge_final_kernel, dim3((unsigned)ceil_div64(nloc, ctx->row_wpb == 4 ? 4 : 1)), dim3(ctx->row_wpb == 4 ? 256 : 64), 0, ctx->stream, nloc, fs,
-                       g->indptr.as<int64_t>(), g->indices.as<int32_t>(), g->Kdata.as<double>(), g->Pdata.as<double>(),
-                       g->degree.as<double>(), g->flags.as<uint32_t>(),
-                       (ctx->symm_key32 != 0 && sort_key_fits_u32(g->n_total, 8)) ? 1 : 0);
-    hipLaunchKernelGGL(merge_long_final_kernel, dim3(1024), dim3(64), 0, ctx->stream, fs, g->indptr.as<int64_t>(),
-                       g->indices.as<int32_t>(), g->Kdata.as<double>(), g->Pdata.as<double>(), g->degree.as<double>(),
-                       g->flags.as<uint32_t>(), g->bigrows.as<int32_t>(), g->bigcount.as<uint32_t>());
-    GT_HIP(ctx, hipGetLastError());
-    int64_t nnz = 0;
-    uint32_t ff = 0, fl = 0, kfl = 0;
-    GT_HIP(ctx, hipMemcpyAsync(&nnz, g->indptr.as<int64_t>() + nloc, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
-    GT_HIP(ctx, hipMemcpyAsync(&ff, fflags, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-    GT_HIP(ctx, hipMemcpyAsync(&fl, g->flags.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-    GT_HIP(ctx, hipMemcpyAsync(&kfl, k->gflags.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-    GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (ctx->dbg_select & 2048)
-        std::fprintf(stderr, "[gt] fused tail: flags %u, nnz %lld of at most %lld\n", ff, (long long)nnz, (long long)total_u);
-    if (ff != 0) {
-        // hub rows beyond the register sorts: this point set takes the other path, now and for its later builds; the
-        // zero-diagonal flag is set again by that path
-        ctx->symm_fused_ok = 0;
-        GT_HIP(ctx, hipMemsetAsync(g->flags.p, 0, sizeof(uint32_t), ctx->stream));
-        return 0;
-    }
-    g->nnz0 = n_recv;
     g->nnz = nnz;
     g->finished = true;
     fl |= kfl;
@@ -2803,7 +2648,6 @@ extern "C" int gt_graph_build(gt_ctx* ctx, const gt_knn_params* params, int64_t*
         if (rc < 0) return rc;
         if (rc == 1) {
             ctx->graph->bins_used = true;
-            ctx->graph->fused_used = false;
             return GT_OK;
         }
         // a union row beyond the register sorts (a hub of the transpose): the tables hold settled pairs the general tail
@@ -2819,16 +2663,6 @@ extern "C" int gt_graph_build(gt_ctx* ctx, const gt_knn_params* params, int64_t*
     const bool bins = ctx->symm_bins != 0 && sendc[0] > 0 && k->ordered && k->nq == g->nloc && g->r0 == 0 && !g->external && !ctx->presorted &&
                       g->nloc < (int64_t(1) << 31) && (ctx->symm_bins > 0 || g->nloc >= 65536);
     g->bins_used = bins;
-    g->fused_used = false;
-    if (bins && ctx->symm_fused != 0 && ctx->symm_fused_ok != 0 && g->p.kernel_symm == GT_SYMM_ADD && g->p.anisotropy == 0.0 &&
-        (std::isnan(g->p.decay) || g->p.thresh == 1.0 || g->p.thresh > 0.0)) {
-        const int rc = graph_finish_fused(ctx, out_nnz, flags);
-        if (rc < 0) return rc;
-        if (rc == 1) {
-            g->fused_used = true;
-            return GT_OK;
-        }
-    }
     if (bins) return graph_finish_impl(ctx, nullptr, 0, true, out_nnz, flags);
     if (sendc[0] > 0) {
         GT_HIP(ctx, g->selfbuf.reserve(size_t(sendc[0]) * sizeof(Triplet)));

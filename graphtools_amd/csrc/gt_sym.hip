@@ -509,19 +509,14 @@ __global__ __launch_bounds__(256) void sym_orphan_cut_kernel(const int64_t n, co
                                                              const double* __restrict__ ymax2p, const ErrModel err,
                                                              const double* __restrict__ acc, const double cut,
                                                              const int orphan_far, const int need_m,
-                                                             const double pair_frac, const uint32_t* __restrict__ cell_sorted,
-                                                             const uint32_t outlier_cell) {
+                                                             const double pair_frac) {
     const int64_t p = int64_t(blockIdx.x) * 256 + threadIdx.x;
     if (p >= n) return;
     const float t = thr[p];
     if (t == INFINITY || !(t > -3.0e38f)) return;
     bool orphan = orphan_far > 0 && farcnt && farcnt[p] * float(orphan_far) >= float(need_m);
-    // the rows of the outlier cell (gt_order.hip: far from every landmark): as queries they would be undecided against every
-    // tile - one query group walking the whole point set while the launch waits for it - and their lists would overflow anyway
-    // (option select_sym_outlier_orphans; off by default: on manifold-like data the cell holds the natural tail of the
-    //  distribution - two thousand rows whose repairs cost 11 ms - and the walk it was meant to shorten is not the bound
-    //  pass's problem)
-    if (cell_sorted && cell_sorted[p] == outlier_cell) orphan = true;
+    // (the rows of the outlier cell - gt_order.hip - are NOT declared orphans: tried in round 4, on manifold-like data the cell
+    //  holds the natural tail of the distribution, two thousand rows whose repairs cost 11 ms)
     if (!orphan && cut > 0.0 && acc[1] > 0.0) {
         const double lb = sym_row_lb(t, xn[perm[p]], ymax2p[0], err);
         const double typical_pair = acc[3] > 0.0 ? acc[2] / acc[3] : 0.0;
@@ -1337,9 +1332,7 @@ int gt_sym_orphan_cut(gt_ctx* ctx, const int32_t* perm, float* thr, const float*
                       int need_m, double pair_frac) {
     hipLaunchKernelGGL(sym_orphan_cut_kernel, dim3((unsigned)ceil_div64(ctx->n, 256)), dim3(256), 0, ctx->stream, ctx->n, perm,
                        ctx->xn.as<double>(), thr, farcnt, ctx->ymax.as<double>(), err, acc, ctx->sym_radius_cut,
-                       ctx->sym_orphan_far, need_m, pair_frac,
-                       (ctx->sym_outlier_orphans != 0 && ctx->order_outlier_cell >= 0 && ctx->order_cell.p) ? ctx->order_cell.as<uint32_t>() + ctx->n : (const uint32_t*)nullptr,
-                       uint32_t(ctx->order_outlier_cell >= 0 ? ctx->order_outlier_cell : 0));
+                       ctx->sym_orphan_far, need_m, pair_frac);
     GT_HIP(ctx, hipGetLastError());
     return GT_OK;
 }
@@ -1551,40 +1544,6 @@ int gt_sym_row_radius(gt_ctx* ctx, const int32_t* perm, int64_t n_pad_s, const f
                       double lres) {
     hipLaunchKernelGGL(sym_row_radius_kernel, dim3((unsigned)ceil_div64(n_pad_s, 256)), dim3(256), 0, ctx->stream, ctx->n, n_pad_s,
                        perm, ctx->xn.as<double>(), thr, ctx->ymax.as<double>(), err, rrow, lres);
-    GT_HIP(ctx, hipGetLastError());
-    return GT_OK;
-}
-
-// thresholds fixed for one arithmetic restated for another (sym_thresholds_kernel: x = (smin - e - c) / inv_sc2, rounded down):
-// x' = x + (e_from - e_to) / inv_sc2 >= thr + ..., rounded down again.  xns: squared norms in sorted order.
-__global__ __launch_bounds__(256) void sym_thr_retarget_kernel(const int64_t n, const double* __restrict__ xns,
-                                                               float* __restrict__ thr, const double* __restrict__ ymax2p,
-                                                               const ErrModel from, const ErrModel to) {
-    const int64_t p = int64_t(blockIdx.x) * 256 + threadIdx.x;
-    if (p >= n) return;
-    const float t = thr[p];
-    if (t == INFINITY || !(t > -3.0e38f)) return;   // orphan / no threshold seeded
-    const double qs = xns[p], y2 = ymax2p[0];
-    const double x = double(t) + (gt_err_bound(from, qs, y2) - gt_err_bound(to, qs, y2)) / from.inv_sc2;
-    float t2 = float(x);
-    if (double(t2) >= x) t2 = nextafterf(t2, -INFINITY);
-    if (t2 > t) thr[p] = t2;
-}
-
-int gt_sym_thr_retarget(gt_ctx* ctx, const double* xns, float* thr, const ErrModel& from, const ErrModel& to) {
-    hipLaunchKernelGGL(sym_thr_retarget_kernel, dim3((unsigned)ceil_div64(ctx->n, 256)), dim3(256), 0, ctx->stream, ctx->n, xns, thr,
-                       ctx->ymax.as<double>(), from, to);
-    GT_HIP(ctx, hipGetLastError());
-    return GT_OK;
-}
-
-// the split working copy (hi | lo planes, 4 DP bytes per row) in cell-sorted order
-int gt_sym_gather_split(gt_ctx* ctx, const int32_t* perm, int64_t n_pad_s, void* Yps, float* hs) {
-    const int c16 = ctx->DP / 4;
-    const int64_t total = n_pad_s * c16;
-    hipLaunchKernelGGL(gather_sorted_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, ctx->stream,
-                       ctx->Yp.as<uint4>(), ctx->hneg.as<float>(), perm, ctx->n, n_pad_s, c16, reinterpret_cast<uint4*>(Yps), hs,
-                       (float*)nullptr);
     GT_HIP(ctx, hipGetLastError());
     return GT_OK;
 }

@@ -424,14 +424,28 @@ class ShardedKnnGraph(object):
         return by_caller
 
     def landmark_operator(self, clusters, n_landmark):
-        """all-reduce of the partial L x L products; returns the finished landmark operator (host array)."""
+        """all-reduce of the partial L x L products; returns the finished landmark operator (host array).
+
+        On the GPU the partial products never leave the device: gt_landmark_build writes M and R into ONE device buffer, RCCL
+        sums it over the ranks in place, gt_landmark_scale divides in place, and the finished operator crosses PCIe once
+        (round 4 fetched M and R to the host, uploaded them for the all-reduce and fetched the sum again: three trips of
+        32 MB at L = 2000)."""
         import torch
 
         dist = _dist()
-        M, R, tnnz = self.ctx.landmark_build(clusters, n_landmark)   # (clusters: by the caller's row numbers = the CSR's columns)
         device = self._device
         L = int(n_landmark)
-        # ONE all-reduce: the L x L partial products with the L partial row sums appended
+        if device.type == "cuda" and hasattr(self.ctx, "landmark_build_device"):
+            buf = torch.empty(L * L + L, dtype=torch.float64, device=device)
+            torch.cuda.current_stream(device).synchronize()     # (the allocation is visible to the library's stream)
+            tnnz = self.ctx.landmark_build_device(clusters, L, buf.data_ptr())   # (clusters: by the caller's row numbers)
+            _order_before_collectives(self.ctx, buf)
+            dist.all_reduce(buf, group=self.group)               # ONE all-reduce: M with the L partial row sums appended
+            _order_after_collectives(self.ctx, buf)
+            self.ctx.landmark_scale_device(buf.data_ptr(), L)
+            self.ctx.sync()
+            return buf[: L * L].reshape(L, L).cpu().numpy(), tnnz
+        M, R, tnnz = self.ctx.landmark_build(clusters, n_landmark)   # (CPU stand-ins, gloo: host arrays)
         buf = torch.as_tensor(np.concatenate([np.asarray(M, dtype=np.float64).ravel(), np.asarray(R, dtype=np.float64)]),
                               device=device)
         dist.all_reduce(buf, group=self.group)

@@ -137,6 +137,29 @@ def test_renumbered_sharded_build_equals_the_single_rank_build(n, d, world, symm
     _same(P, P1)
 
 
+def test_rows_that_belong_to_no_cluster_on_a_sharded_build():
+    """isolated points ("next" 3b): the renumbering gives rows far from every landmark a cell of their own, the
+    last one (gt_order.hip outlier cell, in the split assignment of gt_points_cells_begin as in gt_points_cell_sort), so the rank
+    that receives them keeps its bound pass inside its queue instead of falling to the classic pass for all its rows; the graph is
+    the single-rank build's bit for bit - with and without the outlier cell"""
+    n, world = 64000, 4
+    rng = np.random.default_rng(21)
+    X = make_mix(n, 48, 9)
+    idx = rng.choice(n, 15, replace=False)
+    X[idx] = rng.uniform(-12, 12, (15, 48)).astype(np.float32)
+    pargs = (15, 40, 1e-4, None, 1.0, None, "+", None, 0)
+    K1, P1 = single_build(X, pargs)
+    K, P, used, stats = sharded_local_build(X, world, pargs)
+    assert all(used), "a rank fell to the classic pass: %r" % (used,)
+    _same(K, K1)
+    _same(P, P1)
+    K0, P0, used0, _ = sharded_local_build(X, world, pargs, opts={"query_order_outliers": 0})
+    _same(K0, K1)
+    _same(P0, P1)
+    # the isolated rows are hubs of nothing: their rows hold little more than themselves and their own neighbours
+    assert np.diff(K1.indptr)[idx].max() < 4096
+
+
 @pytest.mark.parametrize("dtype,metric,d", [(np.float64, "euclidean", 40), (np.float32, "cosine", 64), (np.float64, "cosine", 30),
                                              (np.float32, "euclidean", 50)])
 def test_renumbered_sharded_build_other_dtypes_and_metrics(dtype, metric, d):

@@ -122,24 +122,6 @@ def test_row_sorts_on_32_bit_keys_equal_the_64_bit_ones(bins):
     _same(a, b)
 
 
-@pytest.mark.parametrize("n,d,maker,seed,kw", [
-    (5003, 64, make_mix, 0, {}),
-    (300, 10, make_gauss, 1, {"knn": 7}),
-    (2600, 50, make_mix, 5, {"decay": None, "knn": 9}),                 # binary kernel
-    (6000, 8, make_gauss, 6, {"knn": 30, "decay": 2.0}),                # long union rows (wide kernel, low dimension)
-    (120000, 64, make_mix, 7, {}),                                      # several bins, hub rows of more than 512 entries
-])
-def test_count_first_tail_equals_sort_and_compact(n, d, maker, seed, kw):
-    """option symmetrize_fused (off by default - measured slower): merged lengths counted first, K and P written once in row
-    order.  Same bits as sort_merge_kernel + compact_kernel; a union row beyond the register sorts sends the build down
-    the default path (same result)."""
-    X = maker(n, d, seed)
-    f = _build(X, 1, opts=(("symmetrize_fused", 1),), **kw)
-    b = _build(X, 1, **kw)
-    assert f[2] is False or f[2] is True   # (either tail may have run: a declined attempt falls back)
-    _same(f, b)
-
-
 def _build_pairs(X, pairs, knn=15, decay=40.0, bandwidth=None, opts=()):
     """single-rank build with the symmetric candidate pass and the bin transpose forced on; returns the CSR parts, P and which
     tail ran ("pairs": K and P written by the merge itself, no compaction pass)"""

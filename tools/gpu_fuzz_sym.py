@@ -87,7 +87,7 @@ def main():
         if rng.random() < 0.2:
             forced.append(("select_sym_dense_seed", "0"))
         if rng.random() < 0.5:
-            forced.append(("select_sym_cold_split", "1"))
+            forced.append(("select_sym_cold_local", "0"))     # (the global-frame cold launch of rounds 2-4 against the default)
         classic = [("metric", metric), ("select_symmetric", "0"), ("symmetrize_pairs", "0")]
         desc = dict(case=case, kind=kind, n=n, d=d, dtype=np.dtype(dtype).name, knn=knn, decay=decay, thresh=thresh, symm=symm,
                     theta=theta, aniso=aniso, metric=metric, bw=("vector" if isinstance(bw, np.ndarray) else bw),
