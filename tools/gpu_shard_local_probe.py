@@ -24,7 +24,9 @@ world = int(sys.argv[3]) if len(sys.argv) > 3 else 8
 kind = sys.argv[4] if len(sys.argv) > 4 else "mix"
 out_path = sys.argv[5] if len(sys.argv) > 5 else None
 who = int(os.environ.get("GT_WHO", "0"))
-X = {"mix": make_mix, "gauss": make_gauss, "manifold": make_manifold}[kind](n, d, 1)
+# c5: BASELINE config 5 - mix d = 50 seed 3 + the landmark operator (GT_LANDMARKS, default 2000; random landmarking, seed 42)
+X = make_mix(n, d, 3) if kind == "c5" else {"mix": make_mix, "gauss": make_gauss, "manifold": make_manifold}[kind](n, d, 1)
+n_landmark = int(os.environ.get("GT_LANDMARKS", "2000"))
 TRIP = np.dtype([("row", np.uint32), ("col", np.uint32), ("val", np.float64)])
 STAGES = ["prep", "query_order", "renumber", "sym_prepare", "sym_seed", "sym_bound", "sym_cold", "knn_select", "rerank", "fallback",
           "radius", "affinity", "symmetrize", "symm_merge", "symm_compact", "normalize"]
@@ -115,6 +117,16 @@ rb = ctx.dev_alloc(max(len(recv), 1) * 16)
 if len(recv):
     ctx.dev_upload(rb, recv)
 
+labels_all = None
+if kind == "c5":
+    # what the labels all-gather delivers: the nearest landmark of EVERY row, by the caller's row numbers (not timed here: every
+    # rank labels its own rows - timed below - and receives the others')
+    landmarks = np.random.default_rng(42).choice(n, n_landmark, replace=False)
+    lm = _hip.Context(0)
+    lm.set_points(X[landmarks])
+    labels_all = np.asarray(lm.knn_first_nearest(int(min(4, n_landmark)), Y=X), dtype=np.int32)
+    lm.close()
+
 runs = []
 for rep in range(int(os.environ.get("GT_REPS", "4"))):
     sc, buf, wall, st, used, applied, splits = rank_until_emit(who)
@@ -125,6 +137,30 @@ for rep in range(int(os.environ.get("GT_REPS", "4"))):
     for s in ("symmetrize", "symm_merge", "symm_compact", "normalize"):
         st[s] = max(ctx.stage_ms(s), 0.0)
     ctx.dev_free(buf)
+    if kind == "c5":
+        # the rank's share of the landmark stage: labels of its own rows (1-NN against the L landmark rows on the MFMA path,
+        # argmin's first-index rule on the device), partial L x L products of its rows (left on the device for the all-reduce),
+        # the scaling of the summed operator
+        r0_, r1_ = int(splits[who]), int(splits[who + 1])
+        ctx.sync()
+        t0 = time.perf_counter()
+        lm = _hip.Context(0)
+        lm.set_points(X[landmarks])
+        own_labels = lm.knn_first_nearest(int(min(4, n_landmark)), y_dev_ptr=ctx.points_device(r0_), m=r1_ - r0_)
+        lm.close()
+        t1 = time.perf_counter()
+        lbuf = ctx.dev_alloc((n_landmark * n_landmark + n_landmark) * 8)
+        tnnz = ctx.landmark_build_device(labels_all, n_landmark, lbuf)
+        ctx.sync()
+        t2 = time.perf_counter()
+        ctx.landmark_scale_device(lbuf, n_landmark)
+        ctx.sync()
+        t3 = time.perf_counter()
+        ctx.dev_free(lbuf)
+        assert np.array_equal(np.asarray(own_labels, dtype=np.int32), labels_all[ctx.points_row_ids(r0_, r1_)])
+        wall["landmark_labels_own_rows"] = (t1 - t0) * 1e3
+        wall["landmark_build_partial"] = (t2 - t1) * 1e3
+        wall["landmark_scale"] = (t3 - t2) * 1e3
     wall["total"] = sum(wall.values())
     runs.append({"wall_ms": {k: round(v, 3) for k, v in wall.items()}, "stage_ms": {k: round(v, 3) for k, v in st.items() if v > 0},
                  "nnz_rows_of_rank": int(nnz)})
@@ -146,7 +182,9 @@ out = {
         "all_to_all_triplets_bytes_received_by_rank": int(len(recv)) * 16,
         "candidate_record_exchange_bytes": 0,
         "threshold_all_gather_bytes": 0,
-        "number_of_collectives": 4 if split_assign else 3,
+        "number_of_collectives": (4 if split_assign else 3) + (2 if kind == "c5" else 0),
+        "all_gather_labels_bytes_total": int(4 * n) if kind == "c5" else 0,
+        "all_reduce_landmark_bytes": int(8 * (n_landmark * n_landmark + n_landmark)) if kind == "c5" else 0,
     },
     "triplets_sent_by_every_rank": send_totals,
 }
