@@ -1192,6 +1192,10 @@ __device__ __forceinline__ RowSrc3 make_row_src3(const FusedSrc& fs, const int64
 }
 
 constexpr uint32_t kFusedHugeRow = 2u;
+// pair-resolved tail: union rows beyond this go to the segmented sort (symm_huge).  1024, not kHugeRow: the 32-keys-per-lane
+// register network that served 1025 ... 2048 entries needs 260 VGPRs and 272 B of scratch - ONE such row took ~1 ms (a hundred
+// thousand unrolled instructions at one wave per SIMD), longer than the merge of the million short rows it ran beside.
+constexpr int kPairHugeRow = 1024;
 
 // merge of a sorted (key, value) sequence held in registers straight into the final CSR row at dst; returns the row sum
 // in compact_kernel's order.  Keys: (column << 1) | tag, kNoKey where there is no entry.
@@ -1318,8 +1322,8 @@ __global__ __launch_bounds__(256) void merge_final_kernel(const int64_t nloc, co
     }
 }
 
-// NT = 16: the rows of 513 ... 1024 entries, NT = 32: those of 1025 ... 2048 - two launches over the same list.  (One kernel
-// holding both networks needed 265 VGPRs and 272 B of scratch: one wave per SIMD for rows that are mostly in the lower range.)
+// NT = 16: the rows of 513 ... 1024 entries (135 VGPRs, no scratch).  Longer rows take the segmented sort (kPairHugeRow): the
+// kernel that also held the 32-keys-per-lane network needed 265 VGPRs and 272 B of scratch.
 template <int NT>
 __global__ __launch_bounds__(64) void merge_long_final_kernel(const FusedSrc fs, const int64_t* __restrict__ indptr,
                                                               int32_t* __restrict__ indices, double* __restrict__ Kdata,
@@ -1334,7 +1338,6 @@ __global__ __launch_bounds__(64) void merge_long_final_kernel(const FusedSrc fs,
         int lt;
         const RowSrc3 U = make_row_src3(fs, i, p, lt);
         const int L = U.ln + lt;
-        if ((L <= 1024) != (NT == 16)) continue;   // (the other launch's row; wave-uniform)
         const int64_t dst = indptr[i];
         bool any_diag = false;
         const double sum = sort_merge_final_row<uint64_t, NT>(U, L, lane, i, indices, Kdata, Pdata, dst, any_diag);
@@ -2344,7 +2347,7 @@ __global__ __launch_bounds__(256) void pairs_len_kernel(const int64_t nloc, cons
     const int64_t L = off[p + 1] - off[p];
     outlen[i] = int32_t(L);
     if (L > kBigRow) {
-        if (L > kHugeRow) {
+        if (L > kPairHugeRow) {
             atomicOr(fflags, kFusedHugeRow);
             biglist[nloc - 1 - int64_t(atomicAdd(bigcount + 4, 1u))] = int32_t(i);
             atomicAdd(reinterpret_cast<unsigned long long*>(bigcount + 6), (unsigned long long)L);
@@ -2484,19 +2487,10 @@ static int graph_finish_pairs(gt_ctx* ctx, int64_t* out_nnz, uint32_t* flags) {
         hipLaunchKernelGGL(merge_long_final_kernel<16>, dim3(2048), dim3(64), 0, ctx->side_stream, fs, g->indptr.as<int64_t>(),
                            g->indices.as<int32_t>(), g->Kdata.as<double>(), g->Pdata.as<double>(), g->degree.as<double>(),
                            g->flags.as<uint32_t>(), g->bigrows.as<int32_t>(), g->bigcount.as<uint32_t>());
-        hipLaunchKernelGGL(merge_long_final_kernel<32>, dim3(1024), dim3(64), 0, ctx->side_stream, fs, g->indptr.as<int64_t>(),
-                           g->indices.as<int32_t>(), g->Kdata.as<double>(), g->Pdata.as<double>(), g->degree.as<double>(),
-                           g->flags.as<uint32_t>(), g->bigrows.as<int32_t>(), g->bigcount.as<uint32_t>());
         GT_HIP(ctx, hipGetLastError());
-        GT_HIP(ctx, hipEventRecord(ctx->side_event, ctx->side_stream));
-        hipLaunchKernelGGL(merge_final_kernel, dim3((unsigned)ceil_div64(nloc, 1)), dim3(64), 0, ctx->stream, nloc, fs,
-                           g->indptr.as<int64_t>(), g->indices.as<int32_t>(), g->Kdata.as<double>(), g->Pdata.as<double>(),
-                           g->degree.as<double>(), g->flags.as<uint32_t>(),
-                           (ctx->symm_key32 != 0 && sort_key_fits_u32(g->n_total, 8)) ? 1 : 0);
-        GT_HIP(ctx, hipGetLastError());
-        GT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->side_event, 0));
         if (n_huge > 0) {
-            // the rows beyond the register sorts: gather -> segmented sort by column -> their place in the CSR
+            // the rows beyond the register sorts: gather -> segmented sort by column -> their place in the CSR, on the side
+            // stream as well (they write their own rows of the CSR: nothing the merge of the others reads or writes)
             StageSpan span_h(ctx, "symm_huge");
             const size_t H = size_t(huge_total);
             GT_HIP(ctx, g->bigscratch_k.reserve(2 * H * sizeof(uint32_t)));
@@ -2509,24 +2503,31 @@ static int graph_finish_pairs(gt_ctx* ctx, int64_t* out_nnz, uint32_t* flags) {
             unsigned long long* cursor = g->bigsoff.as<unsigned long long>();
             uint32_t* seg_begin = reinterpret_cast<uint32_t*>(cursor + 1);
             uint32_t* seg_end = seg_begin + n_huge;
-            GT_HIP(ctx, hipMemsetAsync(cursor, 0, sizeof(unsigned long long), ctx->stream));
+            GT_HIP(ctx, hipMemsetAsync(cursor, 0, sizeof(unsigned long long), ctx->side_stream));
             const int32_t* hugelist = g->bigrows.as<int32_t>() + (nloc - 1);
-            hipLaunchKernelGGL(huge_gather_kernel, dim3(n_huge), dim3(64), 0, ctx->stream, fs, hugelist, n_huge, cursor, seg_begin,
+            hipLaunchKernelGGL(huge_gather_kernel, dim3(n_huge), dim3(64), 0, ctx->side_stream, fs, hugelist, n_huge, cursor, seg_begin,
                                seg_end, kin, vin);
             GT_HIP(ctx, hipGetLastError());
             int bits = 1;
             while (bits < 32 && (int64_t(1) << bits) < g->n_total) ++bits;
             size_t tmp_bytes = 0;
             GT_HIP(ctx, rocprim::segmented_radix_sort_pairs(nullptr, tmp_bytes, kin, kout, vin, vout, unsigned(H), n_huge, seg_begin,
-                                                            seg_end, 0u, unsigned(bits), ctx->stream));
+                                                            seg_end, 0u, unsigned(bits), ctx->side_stream));
             GT_HIP(ctx, g->hugerows.reserve(tmp_bytes));
             GT_HIP(ctx, rocprim::segmented_radix_sort_pairs(g->hugerows.p, tmp_bytes, kin, kout, vin, vout, unsigned(H), n_huge,
-                                                            seg_begin, seg_end, 0u, unsigned(bits), ctx->stream));
-            hipLaunchKernelGGL(huge_finalize_kernel, dim3(n_huge), dim3(64), 0, ctx->stream, hugelist, n_huge, seg_begin, seg_end, kout,
+                                                            seg_begin, seg_end, 0u, unsigned(bits), ctx->side_stream));
+            hipLaunchKernelGGL(huge_finalize_kernel, dim3(n_huge), dim3(64), 0, ctx->side_stream, hugelist, n_huge, seg_begin, seg_end, kout,
                                vout, g->indptr.as<int64_t>(), g->indices.as<int32_t>(), g->Kdata.as<double>(),
                                g->Pdata.as<double>(), g->degree.as<double>(), g->flags.as<uint32_t>());
             GT_HIP(ctx, hipGetLastError());
         }
+        GT_HIP(ctx, hipEventRecord(ctx->side_event, ctx->side_stream));
+        hipLaunchKernelGGL(merge_final_kernel, dim3((unsigned)ceil_div64(nloc, 1)), dim3(64), 0, ctx->stream, nloc, fs,
+                           g->indptr.as<int64_t>(), g->indices.as<int32_t>(), g->Kdata.as<double>(), g->Pdata.as<double>(),
+                           g->degree.as<double>(), g->flags.as<uint32_t>(),
+                           (ctx->symm_key32 != 0 && sort_key_fits_u32(g->n_total, 8)) ? 1 : 0);
+        GT_HIP(ctx, hipGetLastError());
+        GT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->side_event, 0));
     }
     uint32_t fl = 0, kfl = 0;
     GT_HIP(ctx, hipMemcpyAsync(&fl, g->flags.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));

@@ -386,6 +386,8 @@ def test_rows_that_belong_to_no_cluster_do_not_change_the_graph(kind):
             assert np.array_equal(a, b), tag
         assert np.array_equal(res[tag][1], res["classic"][1]), tag
     # (a union row beyond the register sorts - the isolated points' rows usually are - took the segmented sort)
-    assert (res["default"][4] == 1) == (np.diff(res["default"][0][2]).max() > 2048)
+    # (float64 points take the general tail: no pair-resolved merge, no symm_huge stage - its register sorts reach 2048 entries)
+    if kind != "both, float64":
+        assert (res["default"][4] == 1) == (np.diff(res["default"][0][2]).max() > 1024)   # (kPairHugeRow, gt_sparse.hip)
     if kind == "isolated points":
         assert res["default"][4] == 1
