@@ -337,8 +337,10 @@ def kernel_table(ctx, st, n, nloc, d, world, nnz, nnz0, main):
              "threshold seeding: every row against its neighbourhood cells")
         cold_flop = 2.0 * d * 64 * 32 * kst.get("sym_cold_pairs", 0)
         if two_stage:
-            mfma("sym_cold", "sym_cold_kernel<%d>" % d, st.mean("sym_cold"), cold_flop,
-                 "(64 queries x 32 rows) units left by the cell bounds / stage one, scored in full")
+            mfma("sym_cold", ("sym_cold_local_kernel<%d>" if kst.get("sym_cold_local") else "sym_cold_kernel<%d>") % dp, st.mean("sym_cold"), cold_flop,
+                 "(64 queries x 32 rows) units left by the cell bounds / stage one, scored in full" +
+                 (" in the frame of their queries (float16 of (x - o) sc formed on the fly); the stage also forms the group centres"
+                  if kst.get("sym_cold_local") else ""))
         if not bound_pass and st.mean("knn_select") > 0:
             if two_stage:
                 n_pad = -(-n // 1024) * 1024
