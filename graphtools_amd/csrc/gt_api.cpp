@@ -334,7 +334,7 @@ int gt_set_option(gt_ctx* ctx, const char* name, const char* value) {
         return GT_OK;
     }
     if (k == "symmetrize_pairs") {
-        ctx->symm_pairs = std::atoi(value) != 0 ? 1 : 0;
+        ctx->symm_pairs = std::min(2, std::max(0, std::atoi(value)));   // 2 (default): with the tables by sorted position
         return GT_OK;
     }
     if (k == "select_sym_cosine") {

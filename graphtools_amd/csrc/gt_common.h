@@ -202,7 +202,8 @@ struct gt_ctx {
     int64_t stage_local[4] = {0, 0, 0, 0}, stage_totals[4] = {0, 0, 0, 0};
     int32_t dist_f64 = 0;       //   distances from the float64 keys in float64 whatever the points' dtype (option "distance_dtype")
     int32_t in_graph_build = 0; //   (set by gt_graph_build around its gt_graph_begin: every row is here, the tail is its own)
-    int32_t symm_pairs = 1;     //   pair-resolved symmetrisation (gt_sparse.hip): every row settles its mutual pairs itself, only one-sided entries travel
+    int32_t symm_pairs = 2;     //   pair-resolved symmetrisation (gt_sparse.hip): every row settles its mutual pairs itself, only one-sided entries travel
+                                //   (2: and the re-rank lays the tables out by sorted position for it - KnnWork::tab_sorted; 1: tables by row)
     int32_t symm_pair_huge = 1; //   ... union rows beyond the register sorts are finished by a segmented sort (0: they refute the path: the general tail)
     int32_t keep_stages = 0;    //   (gt_graph_build's second attempt after a refutation: the stage timers are not reset)
     int32_t symm_pair_ok = 1;   //   ... not refuted for the bound point set (a union row beyond the register sorts)
@@ -278,7 +279,16 @@ struct StageSpan {
     gt_ctx* ctx;
     StageAcc* acc;
     hipEvent_t e0, e1;
-    StageSpan(gt_ctx* c, const char* name, int launches = 1) : ctx(c) {
+    const char* nm;
+    static bool trace_on() {   // GT_STAGE_TRACE=1: every stage is announced and waited for (development: which stage faults)
+        static const bool on = std::getenv("GT_STAGE_TRACE") != nullptr;
+        return on;
+    }
+    StageSpan(gt_ctx* c, const char* name, int launches = 1) : ctx(c), nm(name) {
+        if (trace_on()) {
+            (void)hipStreamSynchronize(c->stream);
+            std::fprintf(stderr, "[gt_stage] > %s\n", name);
+        }
         acc = &c->stages[name];
         e0 = c->get_event();
         e1 = c->get_event();
@@ -286,6 +296,10 @@ struct StageSpan {
         (void)hipEventRecord(e0, c->stream);
     }
     ~StageSpan() {
+        if (trace_on()) {
+            const hipError_t e = hipStreamSynchronize(ctx->stream);
+            std::fprintf(stderr, "[gt_stage] < %s (%s)\n", nm, hipGetErrorString(e));
+        }
         (void)hipEventRecord(e1, ctx->stream);
         acc->spans.emplace_back(e0, e1);
     }

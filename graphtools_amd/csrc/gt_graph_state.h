@@ -42,6 +42,8 @@ struct GraphState {
     DevBuf bw, bw_user, rowsrc, lenN, lenT, cursor, off, outlen, indptr, degree;
     DevBuf spmm_in, spmm_out;   // staging of gt_graph_spmm for host operands
     DevBuf tablen;   // int32 [nloc]: entries of the candidate-table row the affinity pass looked at
+    DevBuf bw_s;     // float64 [nloc]: the bandwidths by sorted position (tables by sorted position only, KnnWork::tab_sorted)
+    DevBuf rowsrc_s; // int32 [nloc]: rowsrc by sorted position (same)
     // radius pass
     DevBuf over_rows, over_count, rthr, rlists, rcounts, rK, rmax;
     int64_t n_over = 0;

@@ -154,6 +154,7 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
         sa.prof = k->prof.as<unsigned long long>();
     }
     GT_HIP(ctx, k->unproven.reserve(sizeof(uint32_t)));
+    k->tab_sorted = false;
     RerankArgs ra;
     ra.X = ctx->X;
     ra.dtype = ctx->dtype;
@@ -606,12 +607,21 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
                 sr.nokeyt_rows = k->nokeyt_rows.as<int32_t>();
                 sr.nokeyt_count = k->nokeyt_count.as<uint32_t>();
                 sr.wrote_t = &wrote_t;
+                sr.tab_sorted = k->want_tab_sorted && q0 == 0 && nq == ctx->n;
             }
             {
                 StageSpan span(ctx, "rerank");
                 GT_TRY(gt_launch_rerank_sym(ctx, ra, sr));
             }
             k->keyt_valid = wrote_t;
+            k->tab_sorted = wrote_t && sr.tab_sorted;
+            if (k->tab_sorted) {
+                // tables by sorted position: whoever comes by row (the repairs below, the listed rows of the affinity pass) asks
+                // the inverse permutation for the slot
+                GT_HIP(ctx, k->sh_invperm.reserve(size_t(nq) * sizeof(int32_t)));
+                GT_TRY(gt_sym_invperm(ctx, perm, k->sh_invperm.as<int32_t>()));
+                ra.trow = k->sh_invperm.as<int32_t>();
+            }
             k->nokeyt_n = 0;
             if (wrote_t)
                 GT_HIP(ctx, hipMemcpyAsync(&k->nokeyt_n, k->nokeyt_count.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -628,6 +638,8 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
                 sym_now = false;
                 k->sym_used = false;
                 k->keyt_valid = false;
+                k->tab_sorted = false;
+                ra.trow = nullptr;
                 GT_HIP(ctx, hipMemsetAsync(k->fb_count.p, 0, sizeof(uint32_t), ctx->stream));
                 GT_HIP(ctx, hipMemsetAsync(k->gflags.p, 0, sizeof(uint32_t), ctx->stream));
                 continue;
@@ -639,6 +651,8 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
                     main_prec = 1;
                     k->sym_used = false;
                     k->keyt_valid = false;
+                    k->tab_sorted = false;
+                    ra.trow = nullptr;
                     GT_HIP(ctx, hipMemsetAsync(k->fb_count.p, 0, sizeof(uint32_t), ctx->stream));
                     GT_HIP(ctx, hipMemsetAsync(k->gflags.p, 0, sizeof(uint32_t), ctx->stream));
                     continue;

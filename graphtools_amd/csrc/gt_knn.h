@@ -44,6 +44,12 @@ struct KnnWork {
     DevBuf sym_z, sym_p, sym_cov;                 //   the stage-one copy Z = P x, its frame P, sample covariance scratch
     DevBuf sym_qspill;                            //   spill area of the queue (+ its counter)
     DevBuf sym_rrow, sym_bwork;                   //   bound pass: radius of every row in the stage-one copy, cell scratch
+    // Tables laid out by SORTED POSITION (round 5): a whole single-rank '+' build that will take the pair-resolved tail asks for it
+    // (want_tab_sorted, gt_sparse.hip); the symmetric re-rank then writes row perm[t]'s table - cand_d2 / cand_j / cand_d2t and
+    // the per-table scalars cand_n / d2_lb / keyt_ok - at slot t, and tab_of_row (the inverse permutation) tells everybody who
+    // comes by row where it is.  The affinity pass, the destination bins and the final merge walk the rows in sorted order anyway:
+    // their table reads become streams, and the partners' bandwidths they gather are a shared, cache-resident set.
+    bool want_tab_sorted = false, tab_sorted = false;
     DevBuf sym_rloc, sym_gcen;                    //   local-frame cold launch: the radius every row needs listed (scaled), the centres of
                                                   //   the 64-row query groups
     bool sym_cold_local_used = false;
@@ -173,6 +179,7 @@ struct RerankArgs {
     double radius_key_factor = 1.0;   // see gt_knn_candidates
     uint32_t* unproven = nullptr;     // optional counter: rows with key(need_m-th) * radius_key_factor >= bound
     const int32_t* qrows = nullptr;   // list i of the candidate pass belongs to row qrows[i] (else q0 + i)
+    const int32_t* trow = nullptr;    // row -> slot of its table (KnnWork::tab_sorted: the repairs write where the re-rank did), else the row
 };
 int gt_launch_rerank(gt_ctx* ctx, const RerankArgs& a);
 // symmetric candidate pass (gt_sym.hip): segments of list ql = cell-sorted position ql, row perm[ql]
@@ -199,6 +206,7 @@ struct SymRerank {
     int32_t* nokeyt_rows = nullptr;    // rows whose table will come from a repair pass (no transposed keys), and their number
     uint32_t* nokeyt_count = nullptr;
     bool* wrote_t = nullptr;   // out: the launch that ran fills them
+    bool tab_sorted = false;   // rerank_sym4_kernel with the transposed keys only: the table of list ql goes to slot ql (not to its row's)
 };
 int gt_launch_rerank_sym(gt_ctx* ctx, const RerankArgs& a, const SymRerank& sr);
 // gt_sym.hip

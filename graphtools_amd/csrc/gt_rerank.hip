@@ -434,7 +434,7 @@ __global__ __launch_bounds__(64 * WPB, GT_RERANK_WAVES) void rerank_sym4_kernel(
     const int32_t* __restrict__ invperm, const int32_t* __restrict__ own_rows, const int64_t own_r0,
     const int xcd_chunk, const float* __restrict__ Xs, const double* __restrict__ xns, double* __restrict__ cand_d2t,
     uint8_t* __restrict__ keyt_ok, int32_t* __restrict__ nokeyt_rows, uint32_t* __restrict__ nokeyt_count, const int metric,
-    const int64_t pos0, const int rows_per_wave) {
+    const int64_t pos0, const int rows_per_wave, const int tab_sorted) {
     // cand_d2t (optional): next to every key of the table, the key the OTHER row holds for the same pair - the same dot
     // product in scikit-learn's association with the roles swapped, (|y|^2 - 2 x.y) + |x|^2 - so that the affinity pass can
     // tell, bit for bit, what the transposed entry is worth (gt_sparse.hip, pair-resolved symmetrisation); keyt_ok[q] = 1
@@ -483,6 +483,7 @@ __global__ __launch_bounds__(64 * WPB, GT_RERANK_WAVES) void rerank_sym4_kernel(
     const int64_t q = qo - own_r0;                                                   // row of the tables (own_r0 = 0 on one rank)
     const int64_t qt = invperm ? int64_t(invperm[qo]) : ql + pos0;                   // index of the threshold
     const int64_t ls = invperm ? q : ql + pos0;                                      // index of the list
+    const int64_t tq = tab_sorted ? ql + pos0 : q;                                   // slot of the table (KnnWork::tab_sorted: the sorted position)
     // this lane's share of the query row: elements 16 i + 4 c .. + 3 of every sector i (float64: 32 VGPRs.  Kept in the LDS
     // instead and read back in every pass - tried in round 5 to make room for a fifth wave per SIMD - the kernel took 3.5 ms
     // against 3.2: the reads and the extra spills cost more than they freed)
@@ -686,9 +687,9 @@ __global__ __launch_bounds__(64 * WPB, GT_RERANK_WAVES) void rerank_sym4_kernel(
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         if (uint32_t(u * 64) < n_def) {   // wave-uniform
-            cand_d2[size_t(q) * MP + u * 64 + lane] = __longlong_as_double((long long)hi[u]);
-            cand_j[size_t(q) * MP + u * 64 + lane] = uint32_t(lo[u]);
-            if (want_t) cand_d2t[size_t(q) * MP + u * 64 + lane] = __longlong_as_double((long long)hx[u]);
+            cand_d2[size_t(tq) * MP + u * 64 + lane] = __longlong_as_double((long long)hi[u]);
+            cand_j[size_t(tq) * MP + u * 64 + lane] = uint32_t(lo[u]);
+            if (want_t) cand_d2t[size_t(tq) * MP + u * 64 + lane] = __longlong_as_double((long long)hx[u]);
         }
     }
     uint64_t sel = 0;
@@ -698,10 +699,10 @@ __global__ __launch_bounds__(64 * WPB, GT_RERANK_WAVES) void rerank_sym4_kernel(
     const double d2_need = __longlong_as_double((long long)__shfl((unsigned long long)sel, pos & 63));
     const uint64_t second = __shfl((unsigned long long)hi[0], 1);
     if (lane == 0) {
-        cand_n[q] = n_cut;
-        d2_lb[q] = lb;
+        cand_n[tq] = n_cut;
+        d2_lb[tq] = lb;
         if (keyt_ok) {   // (a row handed to the repair pass gets a new table, without them: it is listed for the affinity pass)
-            keyt_ok[q] = (d2_need < lb_cand) ? 1 : 0;
+            keyt_ok[tq] = (d2_need < lb_cand) ? 1 : 0;
             if (!(d2_need < lb_cand)) nokeyt_rows[atomicAdd(nokeyt_count, 1u)] = int32_t(q);
         }
         if (!(d2_need < lb_cand)) {
@@ -732,7 +733,8 @@ __global__ __launch_bounds__(256) void fallback_kernel(const T* __restrict__ X, 
                                                        const int32_t* __restrict__ fb_rows, const int64_t row_off,
                                                        const int metric, const int need_m, double* __restrict__ scratch,
                                                        double* __restrict__ cand_d2, uint32_t* __restrict__ cand_j,
-                                                       uint32_t* __restrict__ cand_n, double* __restrict__ d2_lb) {
+                                                       uint32_t* __restrict__ cand_n, double* __restrict__ d2_lb,
+                                                       const int32_t* __restrict__ trow) {
     constexpr int MP = NT2 * 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     double* xs = reinterpret_cast<double*>(smem_raw);                         // [d]
@@ -809,14 +811,15 @@ __global__ __launch_bounds__(256) void fallback_kernel(const T* __restrict__ X, 
             lo[u] = out_lo[u * 64 + lane];
         }
         wave_bitonic_asc_pair<NT2>(hi, lo, lane);
+        const int64_t tq = trow ? int64_t(trow[q]) : int64_t(q);   // (KnnWork::tab_sorted: the slot the re-rank wrote this row's table to)
 #pragma unroll
         for (int u = 0; u < NT2; ++u) {
-            cand_d2[size_t(q) * MP + u * 64 + lane] = __longlong_as_double((long long)hi[u]);
-            cand_j[size_t(q) * MP + u * 64 + lane] = uint32_t(lo[u]);
+            cand_d2[size_t(tq) * MP + u * 64 + lane] = __longlong_as_double((long long)hi[u]);
+            cand_j[size_t(tq) * MP + u * 64 + lane] = uint32_t(lo[u]);
         }
         if (lane == 0) {
-            cand_n[q] = uint32_t(need_m);
-            d2_lb[q] = __longlong_as_double((long long)v);   // everything strictly closer is in the table
+            cand_n[tq] = uint32_t(need_m);
+            d2_lb[tq] = __longlong_as_double((long long)v);   // everything strictly closer is in the table
         }
     }
 }
@@ -835,11 +838,12 @@ __global__ __launch_bounds__(256) void fallback_thr_kernel(const int32_t* __rest
                                                            const double* __restrict__ qn,
                                                            const double* __restrict__ qn_full,
                                                            const double* __restrict__ ymax2p, const ErrModel err,
-                                                           int32_t* __restrict__ qrows, float* __restrict__ thr) {
+                                                           int32_t* __restrict__ qrows, float* __restrict__ thr,
+                                                           const int32_t* __restrict__ trow) {
     const int64_t f = int64_t(blockIdx.x) * 256 + threadIdx.x;
     if (f >= n_rows) return;
     const int64_t q = fb_rows[row_off + f];
-    const double key = cand_d2[q * MP + (need_m - 1)] * (1.0 + 1e-12);
+    const double key = cand_d2[(trow ? int64_t(trow[q]) : q) * MP + (need_m - 1)] * (1.0 + 1e-12);
     const double qnq = qn[q0 + q];   // norm over the scored columns
     const double y2 = ymax2p[0];
     const double e = gt_err_bound(err, qnq, y2);
@@ -858,7 +862,7 @@ __global__ __launch_bounds__(256) void collected_select_kernel(
     const double* __restrict__ qn, const int64_t q0, const int32_t* __restrict__ fb_rows, const int64_t row_off,
     const int metric, const int need_m, const uint64_t* __restrict__ clists, const uint32_t* __restrict__ ccounts,
     const int cap, double* __restrict__ scratch, double* __restrict__ cand_d2, uint32_t* __restrict__ cand_j,
-    uint32_t* __restrict__ cand_n, double* __restrict__ d2_lb, uint32_t* __restrict__ fail) {
+    uint32_t* __restrict__ cand_n, double* __restrict__ d2_lb, uint32_t* __restrict__ fail, const int32_t* __restrict__ trow) {
     constexpr int MP = NT2 * 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     double* xs = reinterpret_cast<double*>(smem_raw);                             // [d]
@@ -941,14 +945,15 @@ __global__ __launch_bounds__(256) void collected_select_kernel(
             lo[u] = out_lo[u * 64 + lane];
         }
         wave_bitonic_asc_pair<NT2>(hi, lo, lane);
+        const int64_t tq = trow ? int64_t(trow[q]) : int64_t(q);   // (KnnWork::tab_sorted: the slot the re-rank wrote this row's table to)
 #pragma unroll
         for (int u = 0; u < NT2; ++u) {
-            cand_d2[size_t(q) * MP + u * 64 + lane] = __longlong_as_double((long long)hi[u]);
-            cand_j[size_t(q) * MP + u * 64 + lane] = uint32_t(lo[u]);
+            cand_d2[size_t(tq) * MP + u * 64 + lane] = __longlong_as_double((long long)hi[u]);
+            cand_j[size_t(tq) * MP + u * 64 + lane] = uint32_t(lo[u]);
         }
         if (lane == 0) {
-            cand_n[q] = uint32_t(need_m);
-            d2_lb[q] = __longlong_as_double((long long)v);   // everything strictly closer is in the table
+            cand_n[tq] = uint32_t(need_m);
+            d2_lb[tq] = __longlong_as_double((long long)v);   // everything strictly closer is in the table
         }
     }
 }
@@ -1011,17 +1016,17 @@ int fallback_t(gt_ctx* ctx, const RerankArgs& a, int64_t n_rows, int64_t row_off
         const size_t lds = size_t(a.d) * 8 + size_t(128) * 12 + 16;
         hipLaunchKernelGGL((fallback_kernel<T, 2>), dim3((unsigned)n_rows), dim3(256), lds, ctx->stream, (const T*)a.X,
                            a.n, a.d, a.xn, (const T*)a.Q, a.qn, a.q0, a.fb_rows, row_off, a.metric, a.need_m, scratch, a.cand_d2,
-                           a.cand_j, a.cand_n, a.d2_lb);
+                           a.cand_j, a.cand_n, a.d2_lb, a.trow);
     } else if (a.MP == 256) {
         const size_t lds = size_t(a.d) * 8 + size_t(256) * 12 + 16;
         hipLaunchKernelGGL((fallback_kernel<T, 4>), dim3((unsigned)n_rows), dim3(256), lds, ctx->stream, (const T*)a.X,
                            a.n, a.d, a.xn, (const T*)a.Q, a.qn, a.q0, a.fb_rows, row_off, a.metric, a.need_m, scratch, a.cand_d2,
-                           a.cand_j, a.cand_n, a.d2_lb);
+                           a.cand_j, a.cand_n, a.d2_lb, a.trow);
     } else if (a.MP == 512) {
         const size_t lds = size_t(a.d) * 8 + size_t(512) * 12 + 16;
         hipLaunchKernelGGL((fallback_kernel<T, 8>), dim3((unsigned)n_rows), dim3(256), lds, ctx->stream, (const T*)a.X,
                            a.n, a.d, a.xn, (const T*)a.Q, a.qn, a.q0, a.fb_rows, row_off, a.metric, a.need_m, scratch, a.cand_d2,
-                           a.cand_j, a.cand_n, a.d2_lb);
+                           a.cand_j, a.cand_n, a.d2_lb, a.trow);
     } else {
         GT_FAIL(ctx, GT_E_ARG, "fallback: unsupported table width");
     }
@@ -1054,7 +1059,7 @@ int gt_launch_emit_knn(gt_ctx* ctx, const double* cand_d2, const uint32_t* cand_
 
 int gt_launch_fallback_thr(gt_ctx* ctx, const RerankArgs& a, int64_t n_rows, int64_t row_off, int32_t* qrows, float* thr) {
     hipLaunchKernelGGL(fallback_thr_kernel, dim3((unsigned)ceil_div64(n_rows, 256)), dim3(256), 0, ctx->stream, a.fb_rows,
-                       n_rows, row_off, a.q0, a.MP, a.need_m, a.metric, a.cand_d2, a.qn_sel, a.qn, a.ymax2, a.err, qrows, thr);
+                       n_rows, row_off, a.q0, a.MP, a.need_m, a.metric, a.cand_d2, a.qn_sel, a.qn, a.ymax2, a.err, qrows, thr, a.trow);
     GT_HIP(ctx, hipGetLastError());
     return GT_OK;
 }
@@ -1066,15 +1071,15 @@ static int collected_t(gt_ctx* ctx, const RerankArgs& a, int64_t n_rows, int64_t
     if (a.MP == 128)
         hipLaunchKernelGGL((collected_select_kernel<T, 2>), dim3((unsigned)n_rows), dim3(256), lds, ctx->stream, (const T*)a.X,
                            a.d, a.xn, (const T*)a.Q, a.qn, a.q0, a.fb_rows, row_off, a.metric, a.need_m, clists, ccounts, cap,
-                           scratch, a.cand_d2, a.cand_j, a.cand_n, a.d2_lb, fail);
+                           scratch, a.cand_d2, a.cand_j, a.cand_n, a.d2_lb, fail, a.trow);
     else if (a.MP == 256)
         hipLaunchKernelGGL((collected_select_kernel<T, 4>), dim3((unsigned)n_rows), dim3(256), lds, ctx->stream, (const T*)a.X,
                            a.d, a.xn, (const T*)a.Q, a.qn, a.q0, a.fb_rows, row_off, a.metric, a.need_m, clists, ccounts, cap,
-                           scratch, a.cand_d2, a.cand_j, a.cand_n, a.d2_lb, fail);
+                           scratch, a.cand_d2, a.cand_j, a.cand_n, a.d2_lb, fail, a.trow);
     else
         hipLaunchKernelGGL((collected_select_kernel<T, 8>), dim3((unsigned)n_rows), dim3(256), lds, ctx->stream, (const T*)a.X,
                            a.d, a.xn, (const T*)a.Q, a.qn, a.q0, a.fb_rows, row_off, a.metric, a.need_m, clists, ccounts, cap,
-                           scratch, a.cand_d2, a.cand_j, a.cand_n, a.d2_lb, fail);
+                           scratch, a.cand_d2, a.cand_j, a.cand_n, a.d2_lb, fail, a.trow);
     GT_HIP(ctx, hipGetLastError());
     return GT_OK;
 }
@@ -1101,8 +1106,10 @@ int gt_launch_rerank_sym(gt_ctx* ctx, const RerankArgs& a, const SymRerank& sr) 
                        a.xn, a.nq, sr.tlists, sr.tcap, sr.tcounts, a.thr_final, a.ymax2, a.err, a.need_m, sr.perm,        \
                        a.cand_d2, a.cand_j, a.cand_n, a.d2_lb, a.fb_count, a.fb_rows, a.gflags, a.radius_key_factor,      \
                        a.unproven, sr.stat, (ctx->dbg_select & 256) ? 1 : 0, sr.invperm, sr.own_rows, sr.own_r0, 0,      \
-                       (const float*)sr.Xs, sr.xns, sr.cand_d2t, sr.keyt_ok, sr.nokeyt_rows, sr.nokeyt_count, a.metric, sr.pos0, rpw)
+                       (const float*)sr.Xs, sr.xns, sr.cand_d2t, sr.keyt_ok, sr.nokeyt_rows, sr.nokeyt_count, a.metric, sr.pos0, rpw, tabs)
     if (sr.wrote_t) *sr.wrote_t = false;
+    // (tables by sorted position: only the kernel that also writes the transposed keys does that - the caller looks at wrote_t)
+    const int tabs = (sr.tab_sorted && sr.cand_d2t != nullptr && sr.keyt_ok != nullptr && !sr.invperm) ? 1 : 0;
     // rows per wave of rerank_sym4_kernel (consecutive sorted positions, the next row's list prefetched): enough waves to fill
     // the chip a few times over must remain
     const int rpw = GT_RERANK_RPW > 0 ? GT_RERANK_RPW : 8;
@@ -1117,8 +1124,12 @@ int gt_launch_rerank_sym(gt_ctx* ctx, const RerankArgs& a, const SymRerank& sr) 
             const bool wt = sr.cand_d2t != nullptr && sr.keyt_ok != nullptr && sr.nokeyt_rows != nullptr && sr.nokeyt_count != nullptr;
             // one wave per workgroup: rows differ in cost, and a workgroup's slots are only handed on when its last wave is
             // done (four rows per workgroup measured 4.28 against 4.02 ms in round 3; the variant was removed in round 5)
-            if (wt) GT_RERANK_SYM4_LAUNCH(1, true, 1);
-            else GT_RERANK_SYM4_LAUNCH(1, false, 1);
+            if (wt) {
+                GT_RERANK_SYM4_LAUNCH(1, true, 1);
+            } else {
+                if (tabs) GT_FAIL(ctx, GT_E_STATE, "rerank_sym: tables by sorted position need the transposed keys");
+                GT_RERANK_SYM4_LAUNCH(1, false, 1);
+            }
             if (sr.wrote_t) *sr.wrote_t = wt;
         }
         else if (f4) GT_RERANK_SYM_LAUNCH(float, true);

@@ -21,7 +21,7 @@
 void gt_free_graph_state(gt_ctx* ctx) {
     if (!ctx->graph) return;
     GraphState* g = ctx->graph;
-    for (DevBuf* b : {&g->bw, &g->bw_user, &g->rowsrc, &g->hugerows, &g->tablen, &g->spmm_in, &g->spmm_out, &g->lenN, &g->lenT, &g->cursor, &g->off, &g->outlen, &g->indptr,
+    for (DevBuf* b : {&g->bw, &g->bw_s, &g->rowsrc_s, &g->bw_user, &g->rowsrc, &g->hugerows, &g->tablen, &g->spmm_in, &g->spmm_out, &g->lenN, &g->lenT, &g->cursor, &g->off, &g->outlen, &g->indptr,
                       &g->degree, &g->over_rows, &g->over_count, &g->rthr, &g->rlists, &g->rcounts, &g->rK, &g->rmax,
                       &g->ownercnt, &g->ownerpos, &g->cnt_sorted, &g->pos_sorted, &g->scan_tmp, &g->selfbuf, &g->splits_dev, &g->edges, &g->Ukey, &g->Uval, &g->Vkey, &g->Vval,
                       &g->bincnt, &g->binoff, &g->ucol, &g->uval, &g->bigrows, &g->bigcount, &g->bigscratch_k, &g->bigscratch_v, &g->bigsoff, &g->aniso_tmp, &g->scan_own,
@@ -94,21 +94,24 @@ __global__ __launch_bounds__(256) void bandwidth_kernel(
     const int64_t qoff, const double* __restrict__ ymax2p,
     const ErrModel err, const double* __restrict__ bw_user, const int64_t bw_len, const double bw_scale,
     const int use_radius, const double radius_factor, double* __restrict__ bw_out, int32_t* __restrict__ rowsrc,
-    int32_t* __restrict__ over_rows, uint32_t* __restrict__ over_count, float* __restrict__ rthr) {
+    int32_t* __restrict__ over_rows, uint32_t* __restrict__ over_count, float* __restrict__ rthr,
+    const int32_t* __restrict__ trow, double* __restrict__ bw_s, int32_t* __restrict__ rowsrc_s) {
     const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
     if (i >= nloc) return;
+    const int64_t ti = trow ? int64_t(trow[i]) : i;   // (KnnWork::tab_sorted: the row's table is at its sorted position)
     double bw;
     if (bw_len == 0)
-        bw = gt_key_to_dist(cand_d2[i * MP + (kprime - 1)], dtype, metric) * bw_scale;
+        bw = gt_key_to_dist(cand_d2[ti * MP + (kprime - 1)], dtype, metric) * bw_scale;
     else
         bw = (bw_len == 1 ? bw_user[0] : bw_user[r0 + i]) * bw_scale;
     bw = fmax(bw, DBL_EPSILON);
     bw_out[i] = bw;
+    if (bw_s) bw_s[ti] = bw;   // (by sorted position too: what the affinity pass looks the partners' up by)
     int32_t src = -1;
     if (use_radius) {
         const double r = bw * radius_factor * (1.0 + 1e-6);
         const double r2 = (metric == 1) ? r : r * r;   // key space: squared distance / cosine distance
-        if (!(r2 < d2_lb[i])) {
+        if (!(r2 < d2_lb[ti])) {
             const uint32_t slot = atomicAdd(over_count, 1u);
             over_rows[slot] = int32_t(qoff + i);
             src = int32_t(slot);
@@ -126,6 +129,7 @@ __global__ __launch_bounds__(256) void bandwidth_kernel(
         }
     }
     rowsrc[i] = src;
+    if (rowsrc_s) rowsrc_s[ti] = src;
 }
 
 __global__ void max_u32_kernel(const uint32_t* __restrict__ v, const int64_t n, uint32_t* __restrict__ out) {
@@ -171,7 +175,11 @@ __global__ __launch_bounds__(256) void affinity_kernel(
     const uint32_t* __restrict__ rcounts, const int32_t rcap, double* __restrict__ rK, const double* __restrict__ bw,
     const double decay, const int binary, const double thresh, const int count_owners, const Splits sp,
     int32_t* __restrict__ lenN, int32_t* __restrict__ ownercnt, int32_t* __restrict__ tablen,
-    const int pairs, const double* __restrict__ cand_d2t, const uint8_t* __restrict__ keyt_ok, const double rf_guard) {
+    const int pairs, const double* __restrict__ cand_d2t, const uint8_t* __restrict__ keyt_ok, const double rf_guard,
+    const int32_t* __restrict__ tperm, const int32_t* __restrict__ trow) {
+    // tperm / trow (KnnWork::tab_sorted): the tables lie by sorted position - tperm: slot -> row, for the launch over all the
+    // rows (wave wi takes slot wi: the tables stream, and the partners whose bandwidths a stretch of slots gathers are a
+    // cache-resident neighbourhood); trow: row -> slot, for the listed rows
     // pairs (single-rank builds with the '+' rule, see graph_finish_pairs): the row settles its MUTUAL pairs itself.  For a
     // kept entry (i, j) the value row j gives the same pair, K0(j, i), follows from the key row j holds for it - cand_d2t,
     // or the dot product where the table came from a repair pass - and row j's bandwidth, through the very function row j
@@ -181,18 +189,19 @@ __global__ __launch_bounds__(256) void affinity_kernel(
     const int lane = threadIdx.x & 63;
     const int w = threadIdx.x >> 6;
     double* xs = reinterpret_cast<double*>(smem_raw) + size_t(w) * d;
+    const int idecay = gt_whole_decay(decay);
     const int64_t wi = int64_t(blockIdx.x) * (blockDim.x >> 6) + w;
     if (wi >= nrows) return;
-    const int idecay = gt_whole_decay(decay);
-    const int64_t i = row_list ? int64_t(row_list[wi]) - qoff : wi;   // (a list holds rows of the query matrix: qoff + i)
+    const int64_t i = row_list ? int64_t(row_list[wi]) - qoff : (tperm ? int64_t(tperm[wi]) : wi);   // (a list holds rows of the query matrix: qoff + i)
+    const int64_t ti = row_list ? (trow ? int64_t(trow[i]) : i) : (tperm ? wi : i);                  // where the row's table is
     const int32_t src = rowsrc[i];
     if (RADIUS != (src >= 0)) return;   // (the other launch's row)
-    if (!RADIUS && PAIRS != 0 && (PAIRS == 1) != (keyt_ok[i] != 0)) return;   // (the other pair-resolving launch's row)
+    if (!RADIUS && PAIRS != 0 && (PAIRS == 1) != (keyt_ok[ti] != 0)) return;   // (the other pair-resolving launch's row)
     const double bwi = bw[i];
     int kept = 0;
     int owner_cnt = 0;   // lane o accumulates the count for owner o (world <= 64)
     if constexpr (!RADIUS) {
-        uint32_t n = cand_n[i];
+        uint32_t n = cand_n[ti];
         if (n > uint32_t(limit)) n = uint32_t(limit);
         uint32_t* cand_j_w = const_cast<uint32_t*>(cand_j);
         constexpr bool have_t = PAIRS == 1;
@@ -205,14 +214,12 @@ __global__ __launch_bounds__(256) void affinity_kernel(
             __builtin_amdgcn_wave_barrier();
             qn_i = qnorm[qoff + i];
         }
-        for (uint32_t e0 = 0; e0 < n; e0 += 64) {
-            const uint32_t e = e0 + lane;
+        // one chunk of 64 entries, its loads done: e = entry of this lane, (d2, j) its key and column, d2t / bwj the transposed
+        // key and the partner's bandwidth where the caller fetched them ahead (PAIRS == 1)
+        auto chunk = [&](const uint32_t e, const double d2, const uint32_t j, double d2t, double bwj) {
             bool keep = false;
-            uint32_t j = 0;
             double kvv = -1.0;
             if (e < n) {
-                const double d2 = cand_d2[i * MP + e];
-                j = cand_j[i * MP + e];
                 double kv = 1.0;
                 if (!binary) kv = affinity(gt_key_to_dist(d2, dtype, metric), bwi, decay, idecay);
                 keep = binary || (kv >= thresh);
@@ -222,14 +229,12 @@ __global__ __launch_bounds__(256) void affinity_kernel(
                     //  six orders above the rounding of the affinity, which falls monotonically with the distance - the
                     //  transposed value need not be formed to know that it is below the threshold)
                     if (keep) {
-                        double d2t;
-                        if constexpr (have_t) {
-                            d2t = cand_d2t[i * MP + e];
-                        } else {
+                        if constexpr (!have_t) {
                             const double dot = gt_dot16(xs, X + int64_t(j) * d, d);
                             d2t = gt_pair_key(xn[j], dot, qn_i, metric);
+                            bwj = bw[j];
                         }
-                        const double dt = gt_key_to_dist(d2t, dtype, metric), bwj = bw[j];
+                        const double dt = gt_key_to_dist(d2t, dtype, metric);
                         if (!(dt > bwj * rf_guard)) {
                             const double kvt = affinity(dt, bwj, decay, idecay);
                             if (kvt >= thresh) kvv = -merge_values(kv, kvt, GT_SYMM_ADD, 1.0);
@@ -243,8 +248,8 @@ __global__ __launch_bounds__(256) void affinity_kernel(
             const unsigned long long km = __ballot(keep);
             if (keep) {
                 const uint32_t slot = uint32_t(kept) + uint32_t(__popcll(km & ((1ull << lane) - 1ull)));
-                cand_d2[i * MP + slot] = kvv;
-                if (slot != e) cand_j_w[i * MP + slot] = j;
+                cand_d2[ti * MP + slot] = kvv;
+                if (slot != e) cand_j_w[ti * MP + slot] = j;
             }
             kept += __popcll(km);
             if (count_owners) {
@@ -253,6 +258,41 @@ __global__ __launch_bounds__(256) void affinity_kernel(
                     const int c = __popcll(__ballot(o == r));
                     if (lane == r) owner_cnt += c;
                 }
+            }
+        };
+        if constexpr (have_t) {
+            // The row is a chain of dependent reads (entry -> column -> the partner's bandwidth) and a million rows hide each
+            // other's latency only eight to a SIMD: two chunks' keys, columns and transposed keys are fetched at once and the
+            // partners' bandwidths right behind them - for every entry, kept or not (nine in ten are) - before any arithmetic.
+            for (uint32_t e0 = 0; e0 < n; e0 += 128) {
+                const uint32_t ea = e0 + lane, eb = ea + 64;
+                double d2a = 0.0, d2b = 0.0, ta = 0.0, tb = 0.0, bja = 1.0, bjb = 1.0;
+                uint32_t ja = 0, jb = 0;
+                if (ea < n) {
+                    d2a = cand_d2[ti * MP + ea];
+                    ja = cand_j[ti * MP + ea];
+                    ta = cand_d2t[ti * MP + ea];
+                }
+                if (eb < n) {
+                    d2b = cand_d2[ti * MP + eb];
+                    jb = cand_j[ti * MP + eb];
+                    tb = cand_d2t[ti * MP + eb];
+                }
+                if (ea < n) bja = bw[ja];
+                if (eb < n) bjb = bw[jb];
+                chunk(ea, d2a, ja, ta, bja);
+                if (e0 + 64 < n) chunk(eb, d2b, jb, tb, bjb);   // (uniform)
+            }
+        } else {
+            for (uint32_t e0 = 0; e0 < n; e0 += 64) {
+                const uint32_t e = e0 + lane;
+                double d2 = 0.0;
+                uint32_t j = 0;
+                if (e < n) {
+                    d2 = cand_d2[ti * MP + e];
+                    j = cand_j[ti * MP + e];
+                }
+                chunk(e, d2, j, 0.0, 1.0);
             }
         }
         // the consumers read the kept prefix and nothing else
@@ -310,6 +350,126 @@ __global__ __launch_bounds__(256) void affinity_kernel(
         if (lane == 0) const_cast<uint32_t*>(rcounts)[src] = uint32_t(kept);   // the list now ends behind its kept entries
     }
     if (count_owners && lane < sp.world) ownercnt[int64_t(lane) * nloc + i] = owner_cnt;   // owner-major layout
+}
+
+// ---- A1s: the affinity pass over tables that lie by sorted position (KnnWork::tab_sorted) -----------------------------
+// Same arithmetic, same in-place result as affinity_kernel<T, false, 1> (the pair-resolving launch over the rows whose tables
+// carry the transposed keys) - but a row there is a chain of dependent reads (row number -> its header -> its table -> the
+// partners' bandwidths) that eight waves per SIMD cannot hide (SQ counters, round 5: waves parked 66 % of their cycles, VALU
+// busy 14 %).  Here a wave walks `rpw` consecutive slots: everything a row needs before its table - row number, count, flags,
+// bandwidth - lies BY SLOT and is fetched two rows ahead, the first 128 entries of the next row's table (addresses known from
+// the slot alone) while the current row's partners' bandwidths are on their way: one exposed round trip per row instead of four.
+struct SlotHdr {
+    int32_t i;        // the row
+    uint32_t n;       // entries of its table
+    int32_t src;      // >= 0: a row of the radius pass (not this launch's)
+    uint32_t kok;     // its table carries the transposed keys (else: the listed launch's)
+    double bwi;
+};
+struct SlotTab {
+    double d2a, d2b, ta, tb;
+    uint32_t ja, jb;
+};
+__global__ __launch_bounds__(256) void affinity_slots_kernel(
+    const int64_t nslots, const int rpw, const int32_t* __restrict__ tperm, const uint32_t* __restrict__ cand_n,
+    const uint8_t* __restrict__ keyt_ok, const int32_t* __restrict__ rowsrc_s, const double* __restrict__ bw_s,
+    const double* __restrict__ bw, const int dtype, const int metric, const int MP, const int limit, double* __restrict__ cand_d2,
+    uint32_t* __restrict__ cand_j, const double* __restrict__ cand_d2t, const double decay, const int binary, const double thresh,
+    const double rf_guard, const int count_owners, int32_t* __restrict__ lenN, int32_t* __restrict__ ownercnt,
+    int32_t* __restrict__ tablen) {
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6));
+    const int idecay = gt_whole_decay(decay);
+    const int64_t t0 = (int64_t(blockIdx.x) * 4 + w) * rpw;
+    const int64_t t1 = t0 + rpw < nslots ? t0 + rpw : nslots;
+    auto load_hdr = [&](const int64_t t, SlotHdr& h) {
+        if (t < t1) {   // (uniform)
+            h.i = tperm[t];
+            h.n = cand_n[t];
+            h.src = rowsrc_s[t];
+            h.kok = keyt_ok[t];
+            h.bwi = bw_s[t];
+        }
+    };
+    auto load_tab = [&](const int64_t t, SlotTab& x) {
+        if (t < t1) {   // (all 128 slots, whatever the count: inside the row's stride, masked where they are used)
+            const size_t o = size_t(t) * MP + lane;
+            x.d2a = cand_d2[o];
+            x.ja = cand_j[o];
+            x.ta = cand_d2t[o];
+            x.d2b = cand_d2[o + 64];
+            x.jb = cand_j[o + 64];
+            x.tb = cand_d2t[o + 64];
+        }
+    };
+    SlotHdr h0 = {0, 0u, 0, 0u, 1.0}, h1 = h0, h2 = h0;
+    SlotTab x0 = {0.0, 0.0, 0.0, 0.0, 0u, 0u}, x1 = x0;
+    load_hdr(t0, h0);
+    load_tab(t0, x0);
+    load_hdr(t0 + 1, h1);
+    for (int64_t t = t0; t < t1; ++t) {
+        load_tab(t + 1, x1);
+        load_hdr(t + 2, h2);
+        if (h0.src < 0 && h0.kok != 0u) {   // (else: the radius launch's / the listed launch's row)
+            const int64_t i = h0.i;
+            const double bwi = h0.bwi;
+            uint32_t n = h0.n;
+            if (n > uint32_t(limit)) n = uint32_t(limit);
+            int kept = 0;
+            auto chunk = [&](const uint32_t e, const double d2, const uint32_t j, const double d2t, const double bwj) {
+                bool keep = false;
+                double kvv = -1.0;
+                if (e < n) {
+                    double kv = 1.0;
+                    if (!binary) kv = affinity(gt_key_to_dist(d2, dtype, metric), bwi, decay, idecay);
+                    keep = binary || (kv >= thresh);
+                    kvv = kv;
+                    if (keep) {   // (see affinity_kernel: the pair is settled here when row j keeps it too)
+                        const double dt = gt_key_to_dist(d2t, dtype, metric);
+                        if (!(dt > bwj * rf_guard)) {
+                            const double kvt = affinity(dt, bwj, decay, idecay);
+                            if (kvt >= thresh) kvv = -merge_values(kv, kvt, GT_SYMM_ADD, 1.0);
+                        }
+                    }
+                }
+                const unsigned long long km = __ballot(keep);
+                if (keep) {
+                    const uint32_t slot = uint32_t(kept) + uint32_t(__popcll(km & ((1ull << lane) - 1ull)));
+                    cand_d2[size_t(t) * MP + slot] = kvv;
+                    if (slot != e) cand_j[size_t(t) * MP + slot] = j;
+                }
+                kept += __popcll(km);
+            };
+            {
+                const uint32_t ea = uint32_t(lane), eb = ea + 64u;
+                double bja = 1.0, bjb = 1.0;
+                if (ea < n) bja = bw[x0.ja];
+                if (eb < n) bjb = bw[x0.jb];
+                chunk(ea, x0.d2a, x0.ja, x0.ta, bja);
+                if (n > 64u) chunk(eb, x0.d2b, x0.jb, x0.tb, bjb);   // (uniform)
+            }
+            for (uint32_t e0 = 128u; e0 < n; e0 += 64u) {   // (the few rows beyond 128 entries: as they come)
+                const uint32_t e = e0 + lane;
+                double d2 = 0.0, d2t = 0.0, bwj = 1.0;
+                uint32_t j = 0;
+                if (e < n) {
+                    d2 = cand_d2[size_t(t) * MP + e];
+                    j = cand_j[size_t(t) * MP + e];
+                    d2t = cand_d2t[size_t(t) * MP + e];
+                    bwj = bw[j];
+                }
+                chunk(e, d2, j, d2t, bwj);
+            }
+            if (lane == 0) {
+                tablen[i] = int32_t(kept);
+                lenN[i] = kept;
+                if (count_owners) ownercnt[i] = kept;   // (one rank: every kept entry is its own)
+            }
+        }
+        h0 = h1;
+        h1 = h2;
+        x0 = x1;
+    }
 }
 
 // ---- A2t: transposed triplets, bucketed by destination rank --------------------------------------
@@ -528,7 +688,7 @@ __global__ __launch_bounds__(256) void fill_recv_kernel(const Triplet* __restric
 // Entry order inside a union row depends on the atomics' arrival order; the per-row sort keys (column, tag) are unique,
 // so K does not.
 template <typename F>
-__device__ __forceinline__ void for_kept_entries(const int64_t i, const int lane, const int MP, const double* __restrict__ cand_k,
+__device__ __forceinline__ void for_kept_entries(const int64_t i, const int64_t ti, const int lane, const int MP, const double* __restrict__ cand_k,
                                                  const uint32_t* __restrict__ cand_j, const int32_t* __restrict__ rowsrc,
                                                  const uint64_t* __restrict__ rlists, const uint32_t* __restrict__ rcounts,
                                                  const int32_t rcap, const double* __restrict__ rK,
@@ -538,7 +698,7 @@ __device__ __forceinline__ void for_kept_entries(const int64_t i, const int lane
     const double* kv;
     if (src < 0) {
         n = uint32_t(tablen[i]);
-        kv = cand_k + i * MP;
+        kv = cand_k + ti * MP;   // (ti: where the row's table is - the row, or its sorted position: KnnWork::tab_sorted)
     } else {
         n = rcounts[src];
         if (n > uint32_t(rcap)) n = uint32_t(rcap);
@@ -550,7 +710,7 @@ __device__ __forceinline__ void for_kept_entries(const int64_t i, const int lane
         uint32_t j = 0;
         if (e < n) {
             v = kv[e];
-            j = (src < 0) ? cand_j[i * MP + e] : cand_index(rlists[size_t(src) * rcap + e]);
+            j = (src < 0) ? cand_j[ti * MP + e] : cand_index(rlists[size_t(src) * rcap + e]);
         }
         // (a kept value is positive; pair-resolved builds store a settled mutual pair as minus its final value: such an
         //  entry stays in its row and nothing of it is sent - but it keeps its slot in the enumeration of the kept entries)
@@ -568,7 +728,7 @@ __global__ __launch_bounds__(256) void bin_count_kernel(const int64_t nloc, cons
                                                         const int32_t* __restrict__ tablen, const int32_t* __restrict__ perm,
                                                         const int32_t* __restrict__ pos, const int shift, const int nbins,
                                                         const int64_t* __restrict__ sN, uint32_t* __restrict__ posj,
-                                                        int32_t* __restrict__ bincnt) {
+                                                        int32_t* __restrict__ bincnt, const int tab_sorted) {
     // posj: the sorted position of every kept entry's column, in the order of the kept entries of the sorted rows (row p
     // at sN[p]) - the ONE pass that gathers pos[j] (a random 4-byte read per entry); bin_emit_kernel streams it
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -578,7 +738,8 @@ __global__ __launch_bounds__(256) void bin_count_kernel(const int64_t nloc, cons
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     for (int64_t p = int64_t(blockIdx.x) * 4 + w; p < nloc; p += int64_t(gridDim.x) * 4) {
         int64_t at = sN[p];
-        for_kept_entries(perm[p], lane, MP, cand_k, cand_j, rowsrc, rlists, rcounts, rcap, rK, tablen,
+        const int64_t i = perm[p];
+        for_kept_entries(i, tab_sorted ? p : i, lane, MP, cand_k, cand_j, rowsrc, rlists, rcounts, rcap, rK, tablen,
                          [&](bool slot, bool send, uint32_t j, double) {
                              int total;
                              const int q = wave_prefix_count(slot, lane, total);
@@ -605,7 +766,7 @@ __global__ __launch_bounds__(256) void bin_emit_kernel(const int64_t nloc, const
                                                        const int64_t* __restrict__ sN, const uint32_t* __restrict__ posj,
                                                        const int shift, const int nbins,
                                                        const int64_t* __restrict__ binoff, int32_t* __restrict__ bincur,
-                                                       Triplet* __restrict__ out) {
+                                                       Triplet* __restrict__ out, const int tab_sorted) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     int32_t* hist = reinterpret_cast<int32_t*>(smem_raw);   // entries of this workgroup per bin, then its cursor there
     int32_t* base = hist + nbins;                           // first slot of this workgroup's run inside the bin
@@ -629,7 +790,7 @@ __global__ __launch_bounds__(256) void bin_emit_kernel(const int64_t nloc, const
     for (int64_t p = p0 + w; p < p1; p += 4) {
         const uint32_t i = uint32_t(perm[p]);
         int64_t at = sN[p];
-        for_kept_entries(int64_t(i), lane, MP, cand_k, cand_j, rowsrc, rlists, rcounts, rcap, rK, tablen,
+        for_kept_entries(int64_t(i), tab_sorted ? p : int64_t(i), lane, MP, cand_k, cand_j, rowsrc, rlists, rcounts, rcap, rK, tablen,
                          [&](bool slot, bool send, uint32_t, double v) {
                              int total;
                              const int q = wave_prefix_count(slot, lane, total);
@@ -1158,6 +1319,7 @@ struct FusedSrc {
     int32_t rcap;
     const uint32_t* ucol;     // received entries, packed row by row in sorted order: columns ...
     const double* uval;       // ... and values
+    int tab_sorted;           // the tables lie by sorted position (KnnWork::tab_sorted), else by row
 };
 struct RowSrc3 {
     int ln;
@@ -1178,8 +1340,9 @@ __device__ __forceinline__ RowSrc3 make_row_src3(const FusedSrc& fs, const int64
     lt = int(fs.off[p + 1] - o0) - r.ln;
     const int32_t src = fs.rowsrc[i];
     if (src < 0) {
-        r.kv = fs.cand_k + i * fs.MP;
-        r.cj = fs.cand_j + i * fs.MP;
+        const int64_t ti = fs.tab_sorted ? p : i;
+        r.kv = fs.cand_k + ti * fs.MP;
+        r.cj = fs.cand_j + ti * fs.MP;
         r.rl = nullptr;
     } else {
         r.kv = fs.rK + size_t(src) * fs.rcap;
@@ -1544,8 +1707,20 @@ void launch_affinity(gt_ctx* ctx, GraphState* g, KnnWork* k, int binary, double 
                        g->bw.as<double>(), decay, binary, thresh, count_owners, make_splits(g), g->lenN.as<int32_t>(),      \
                        g->ownercnt.as<int32_t>(), g->tablen.as<int32_t>(), g->pairs ? 1 : 0,                               \
                        g->pairs ? k->cand_d2t.as<double>() : (const double*)nullptr,                                       \
-                       g->pairs ? k->keyt_ok.as<uint8_t>() : (const uint8_t*)nullptr, g->radius_factor * (1.0 + 1e-9))
-    if (g->pairs) {
+                       g->pairs ? k->keyt_ok.as<uint8_t>() : (const uint8_t*)nullptr, g->radius_factor * (1.0 + 1e-9),      \
+                       tperm, trow)
+    const int32_t* tperm = k->tab_sorted ? k->qorder.as<int32_t>() : (const int32_t*)nullptr;
+    const int32_t* trow = k->tab_sorted ? k->sh_invperm.as<int32_t>() : (const int32_t*)nullptr;
+    if (g->pairs && k->tab_sorted) {
+        const int rpw = std::getenv("GT_AFF_RPW") ? std::max(1, std::atoi(std::getenv("GT_AFF_RPW"))) : 8;   // EXPERIMENT
+        hipLaunchKernelGGL(affinity_slots_kernel, dim3((unsigned)ceil_div64(g->nloc, int64_t(4) * rpw)), dim3(256), 0, ctx->stream,
+                           g->nloc, rpw, tperm, k->cand_n.as<uint32_t>(), k->keyt_ok.as<uint8_t>(), g->rowsrc_s.as<int32_t>(),
+                           g->bw_s.as<double>(), g->bw.as<double>(), gt_dist_dtype(ctx), ctx->metric, k->MP, g->limit,
+                           k->cand_d2.as<double>(), k->cand_j.as<uint32_t>(), k->cand_d2t.as<double>(), decay, binary, thresh,
+                           g->radius_factor * (1.0 + 1e-9), count_owners, g->lenN.as<int32_t>(), g->ownercnt.as<int32_t>(),
+                           g->tablen.as<int32_t>());
+        if (k->nokeyt_n > 0) GT_AFFINITY_LAUNCH(false, 2, k->nokeyt_rows.as<int32_t>(), int64_t(k->nokeyt_n));   // (qoff = 0 here)
+    } else if (g->pairs) {
         GT_AFFINITY_LAUNCH(false, 1, (const int32_t*)nullptr, g->nloc);
         if (k->nokeyt_n > 0) GT_AFFINITY_LAUNCH(false, 2, k->nokeyt_rows.as<int32_t>(), int64_t(k->nokeyt_n));   // (qoff = 0 here)
     } else {
@@ -1753,7 +1928,18 @@ static int graph_begin_impl(gt_ctx* ctx, const gt_knn_params* params, int32_t wo
         // (it also lets the re-rank stop after its first batch of candidates); a caller-given bandwidth is not tied to
         // the k-th neighbour: no hint, every candidate is evaluated
         const double hint = candidate_hint(ctx, params, thresh, use_radius);
-        GT_TRY(gt_knn_candidates(ctx, g->r0, g->nloc, external, need, hint));
+        // A build that will take the pair-resolved tail (the static half of g->pairs below; the other half - the symmetric
+        // pass wrote the transposed keys - is what makes the re-rank honour the request) asks for its tables by sorted
+        // position: every pass of the tail walks the rows in that order.
+        if (!ctx->knn) ctx->knn = new KnnWork();
+        ctx->knn->want_tab_sorted = ctx->in_graph_build && ctx->symm_pairs == 2 && ctx->symm_pair_ok != 0 && ctx->symm_bins != 0 &&
+                                    world == 1 && !external && !binary && params->knn_max <= 0 &&
+                                    params->kernel_symm == GT_SYMM_ADD && params->anisotropy == 0.0 && g->r0 == 0 &&
+                                    g->nloc == ctx->n && !ctx->presorted && g->nloc < (int64_t(1) << 31) &&
+                                    (ctx->symm_bins > 0 || g->nloc >= 65536);
+        const int rc_knn = gt_knn_candidates(ctx, g->r0, g->nloc, external, need, hint);
+        ctx->knn->want_tab_sorted = false;
+        if (rc_knn != GT_OK) return rc_knn;
     }
     KnnWork* k = ctx->knn;
     g->Qmat = external ? k->Qraw.p : ctx->X;
@@ -1762,6 +1948,10 @@ static int graph_begin_impl(gt_ctx* ctx, const gt_knn_params* params, int32_t wo
     g->limit = binary ? kprime : (params->knn_max > 0 ? need : k->MP);
 
     GT_HIP(ctx, g->bw.reserve(size_t(g->nloc) * sizeof(double)));
+    if (k->tab_sorted) {
+        GT_HIP(ctx, g->bw_s.reserve(size_t(g->nloc) * sizeof(double)));
+        GT_HIP(ctx, g->rowsrc_s.reserve(size_t(g->nloc) * sizeof(int32_t)));
+    }
     GT_HIP(ctx, g->rowsrc.reserve(size_t(g->nloc) * sizeof(int32_t)));
     GT_HIP(ctx, g->lenN.reserve(size_t(g->nloc) * sizeof(int32_t)));
     GT_HIP(ctx, g->tablen.reserve(size_t(g->nloc) * sizeof(int32_t)));
@@ -1794,6 +1984,8 @@ static int graph_begin_impl(gt_ctx* ctx, const gt_knn_params* params, int32_t wo
     const ErrModel err_model = gt_err_model(ctx, ctx->prec);
     // norms the candidate pass saw (partial norms for wide data): they bound the scores of everything inside a radius
     const double* qn_bound = !ctx->wide ? g->qnorm : (external ? k->qn_sel.as<double>() : ctx->xn_sel.as<double>());
+    // tables by sorted position (KnnWork::tab_sorted, asked for above): row -> slot
+    const int32_t* trow = k->tab_sorted ? k->sh_invperm.as<int32_t>() : (const int32_t*)nullptr;
     {
         StageSpan span(ctx, "affinity");
         hipLaunchKernelGGL(bandwidth_kernel, dim3((unsigned)ceil_div64(g->nloc, 256)), dim3(256), 0, ctx->stream, g->nloc,
@@ -1801,7 +1993,8 @@ static int graph_begin_impl(gt_ctx* ctx, const gt_knn_params* params, int32_t wo
                            qn_bound, g->qnorm, g->qoff, ctx->ymax.as<double>(), err_model, g->bw_user.as<double>(),
                            params->bandwidth_len, params->bandwidth_scale, use_radius ? 1 : 0, g->radius_factor,
                            g->bw.as<double>(), g->rowsrc.as<int32_t>(), g->over_rows.as<int32_t>(),
-                           g->over_count.as<uint32_t>(), g->rthr.as<float>());
+                           g->over_count.as<uint32_t>(), g->rthr.as<float>(), trow, trow ? g->bw_s.as<double>() : (double*)nullptr,
+                           trow ? g->rowsrc_s.as<int32_t>() : (int32_t*)nullptr);
         GT_HIP(ctx, hipGetLastError());
     }
     if (n_kst > 0) {
@@ -1862,7 +2055,8 @@ static int graph_begin_impl(gt_ctx* ctx, const gt_knn_params* params, int32_t wo
                                qn_bound, g->qnorm, g->qoff, ctx->ymax.as<double>(), err_model, g->bw_user.as<double>(),
                                params->bandwidth_len, params->bandwidth_scale, 1, g->radius_factor,
                                g->bw.as<double>(), g->rowsrc.as<int32_t>(), g->over_rows.as<int32_t>(),
-                               g->over_count.as<uint32_t>(), g->rthr.as<float>());
+                               g->over_count.as<uint32_t>(), g->rthr.as<float>(), trow, trow ? g->bw_s.as<double>() : (double*)nullptr,
+                           trow ? g->rowsrc_s.as<int32_t>() : (int32_t*)nullptr);
             GT_HIP(ctx, hipGetLastError());
         } else if (need != km) {
             // every row finished inside the tables: nothing is capped, nothing is missing
@@ -1938,6 +2132,7 @@ static int graph_begin_impl(gt_ctx* ctx, const gt_knn_params* params, int32_t wo
                !external && !binary && params->knn_max <= 0 && params->kernel_symm == GT_SYMM_ADD && params->anisotropy == 0.0 &&
                k->keyt_valid && k->ordered && k->nq == g->nloc && g->r0 == 0 && !ctx->presorted &&
                g->nloc < (int64_t(1) << 31) && (ctx->symm_bins > 0 || g->nloc >= 65536);
+    if (k->tab_sorted && !g->pairs) GT_FAIL(ctx, GT_E_STATE, "graph build: tables by sorted position without the pair-resolved tail");
     if (ctx->dbg_select & 2048)
         std::fprintf(stderr, "[gt] pairs %d: in_build %d opt %d ok %d bins %d world %d ext %d bin %d kmax %lld symm %d aniso %g metric %d keyt %d ordered %d nq %lld nloc %lld r0 %lld\n",
                      int(g->pairs), ctx->in_graph_build, ctx->symm_pairs, ctx->symm_pair_ok, ctx->symm_bins, world, int(external), int(binary),
@@ -2132,7 +2327,7 @@ static int graph_finish_impl(gt_ctx* ctx, const void* recv_buf_dev, int64_t n_re
                                k->cand_j.as<uint32_t>(), g->rowsrc.as<int32_t>(), g->rlists.as<uint64_t>(),
                                g->rcounts.as<uint32_t>(), g->rcap, g->rK.as<double>(), g->tablen.as<int32_t>(), perm,
                                k->sh_invperm.as<int32_t>(), shift, nbins, g->pos_sorted.as<int64_t>(), g->cursor.as<uint32_t>(),
-                               g->bincnt.as<int32_t>());
+                               g->bincnt.as<int32_t>(), 0);
             GT_HIP(ctx, hipGetLastError());
             GT_TRY(exclusive_scan(ctx, g->bincnt.as<int32_t>(), nullptr, nbins, g->binoff.as<int64_t>(), g->scan_tmp));
             total_u = 2 * n_recv;   // every kept entry once in its own row, once in its column's
@@ -2175,7 +2370,7 @@ static int graph_finish_impl(gt_ctx* ctx, const void* recv_buf_dev, int64_t n_re
                                nloc, k->MP, k->cand_d2.as<double>(), k->cand_j.as<uint32_t>(), g->rowsrc.as<int32_t>(),
                                g->rlists.as<uint64_t>(), g->rcounts.as<uint32_t>(), g->rcap, g->rK.as<double>(),
                                g->tablen.as<int32_t>(), perm, g->pos_sorted.as<int64_t>(), g->cursor.as<uint32_t>(), shift, nbins,
-                               g->binoff.as<int64_t>(), g->bincnt.as<int32_t>() + nbins, (Triplet*)g->selfbuf.p);
+                               g->binoff.as<int64_t>(), g->bincnt.as<int32_t>() + nbins, (Triplet*)g->selfbuf.p, 0);
             GT_HIP(ctx, hipGetLastError());
 #define GT_BIN_FILL(NT_)                                                                                                     \
     hipLaunchKernelGGL(bin_fill_kernel<NT_>, dim3((unsigned)nbins), dim3(NT_), size_t(2) * (size_t(1) << shift) * sizeof(int32_t), \
@@ -2366,6 +2561,7 @@ static int graph_finish_pairs(gt_ctx* ctx, int64_t* out_nnz, uint32_t* flags) {
     if (n_own <= 0) return 0;
     StageSpan span(ctx, "symmetrize");
     const int32_t* perm = k->qorder.as<int32_t>();
+    const int tabs = k->tab_sorted ? 1 : 0;   // the tables lie by sorted position (and k->sh_invperm is there already)
     int shift = 9;
     if (ctx->symm_bin_shift > 0) shift = ctx->symm_bin_shift;
     while (ceil_div64(nloc, int64_t(1) << shift) > 4096) ++shift;
@@ -2390,7 +2586,7 @@ static int graph_finish_pairs(gt_ctx* ctx, int64_t* out_nnz, uint32_t* flags) {
     uint32_t* fflags = g->bigcount.as<uint32_t>() + 2;
     {
         StageSpan span_bins(ctx, "symm_bins");
-        GT_TRY(gt_sym_invperm(ctx, perm, k->sh_invperm.as<int32_t>()));
+        if (!tabs) GT_TRY(gt_sym_invperm(ctx, perm, k->sh_invperm.as<int32_t>()));
         hipLaunchKernelGGL(gather_counts_kernel, dim3((unsigned)ceil_div64(nloc, 256)), dim3(256), 0, ctx->stream,
                            g->lenN.as<int32_t>(), perm, nloc, g->cnt_sorted.as<int32_t>());
         GT_TRY(exclusive_scan(ctx, g->cnt_sorted.as<int32_t>(), nullptr, nloc, g->pos_sorted.as<int64_t>(), g->scan_tmp));
@@ -2399,13 +2595,13 @@ static int graph_finish_pairs(gt_ctx* ctx, int64_t* out_nnz, uint32_t* flags) {
                            k->cand_j.as<uint32_t>(), g->rowsrc.as<int32_t>(), g->rlists.as<uint64_t>(),
                            g->rcounts.as<uint32_t>(), g->rcap, g->rK.as<double>(), g->tablen.as<int32_t>(), perm,
                            k->sh_invperm.as<int32_t>(), shift, nbins, g->pos_sorted.as<int64_t>(), g->cursor.as<uint32_t>(),
-                           g->bincnt.as<int32_t>());
+                           g->bincnt.as<int32_t>(), tabs);
         GT_TRY(exclusive_scan(ctx, g->bincnt.as<int32_t>(), nullptr, nbins, g->binoff.as<int64_t>(), g->scan_tmp));
         hipLaunchKernelGGL(bin_emit_kernel, dim3((unsigned)ceil_div64(nloc, kEmitRows)), dim3(256), size_t(2 * nbins) * sizeof(int32_t),
                            ctx->stream, nloc, k->MP, k->cand_d2.as<double>(), k->cand_j.as<uint32_t>(), g->rowsrc.as<int32_t>(),
                            g->rlists.as<uint64_t>(), g->rcounts.as<uint32_t>(), g->rcap, g->rK.as<double>(),
                            g->tablen.as<int32_t>(), perm, g->pos_sorted.as<int64_t>(), g->cursor.as<uint32_t>(), shift, nbins,
-                           g->binoff.as<int64_t>(), g->bincnt.as<int32_t>() + nbins, (Triplet*)g->selfbuf.p);
+                           g->binoff.as<int64_t>(), g->bincnt.as<int32_t>() + nbins, (Triplet*)g->selfbuf.p, tabs);
         hipLaunchKernelGGL(bin_fill_kernel<256>, dim3((unsigned)nbins), dim3(256), size_t(2) * (size_t(1) << shift) * sizeof(int32_t),
                            ctx->stream, nloc, k->MP, k->cand_d2.as<double>(), k->cand_j.as<uint32_t>(), g->rowsrc.as<int32_t>(),
                            g->rlists.as<uint64_t>(), g->rcounts.as<uint32_t>(), g->rcap, g->rK.as<double>(),
@@ -2469,6 +2665,7 @@ static int graph_finish_pairs(gt_ctx* ctx, int64_t* out_nnz, uint32_t* flags) {
     fs.rcap = g->rcap;
     fs.ucol = g->ucol.as<uint32_t>();
     fs.uval = g->uval.as<double>();
+    fs.tab_sorted = tabs;
     {
         StageSpan span_m(ctx, "symm_merge");
         // the few long rows (one wave each, 270 registers: a thousand waves for half a millisecond) run on a side stream
