@@ -42,8 +42,9 @@ struct GraphState {
     DevBuf bw, bw_user, rowsrc, lenN, lenT, cursor, off, outlen, indptr, degree;
     DevBuf spmm_in, spmm_out;   // staging of gt_graph_spmm for host operands
     DevBuf tablen;   // int32 [nloc]: entries of the candidate-table row the affinity pass looked at
-    DevBuf bw_s;     // float64 [nloc]: the bandwidths by sorted position (tables by sorted position only, KnnWork::tab_sorted)
-    DevBuf rowsrc_s; // int32 [nloc]: rowsrc by sorted position (same)
+    DevBuf rec_s;    // SlotRec [nloc]: row, table length, bandwidth by sorted position (tables by sorted position only, KnnWork::tab_sorted)
+    DevBuf bwpos;    // BwPos [nloc]: bandwidth and sorted position by row (same)
+    DevBuf sC;       // int64 [nloc + 1]: scan of the tables' lengths by sorted position (fused destination count: posj lies by it)
     // radius pass
     DevBuf over_rows, over_count, rthr, rlists, rcounts, rK, rmax;
     int64_t n_over = 0;
@@ -60,6 +61,10 @@ struct GraphState {
     DevBuf ucol, uval;       // fused tail: received entries in fixed slot rows [row][capT] (columns, values)
     bool bins_used = false;
     bool pairs = false;        // this build's affinities settled the mutual pairs (negative = final values; graph_finish_pairs)
+    bool pairs_fused = false;  // ... and counted the destinations of the one-sided entries on the way (tables by sorted position, no
+                               //     row of the radius pass): posj (cursor) lies by sC, bincnt is filled - bin_count_kernel is skipped
+    int32_t bin_shift = 9, bin_count = 0;   // rows per destination bin (log2), bins
+    int64_t sc_total = 0;                   // entries of posj when it lies by sC
     bool relabelled = false;   // the CSR's columns are the caller's row numbers of a renumbered point set (rows: gt_points_row_ids)
     int64_t nnz0 = 0, nnz = 0;
 };

@@ -21,7 +21,7 @@
 void gt_free_graph_state(gt_ctx* ctx) {
     if (!ctx->graph) return;
     GraphState* g = ctx->graph;
-    for (DevBuf* b : {&g->bw, &g->bw_s, &g->rowsrc_s, &g->bw_user, &g->rowsrc, &g->hugerows, &g->tablen, &g->spmm_in, &g->spmm_out, &g->lenN, &g->lenT, &g->cursor, &g->off, &g->outlen, &g->indptr,
+    for (DevBuf* b : {&g->bw, &g->rec_s, &g->bwpos, &g->sC, &g->bw_user, &g->rowsrc, &g->hugerows, &g->tablen, &g->spmm_in, &g->spmm_out, &g->lenN, &g->lenT, &g->cursor, &g->off, &g->outlen, &g->indptr,
                       &g->degree, &g->over_rows, &g->over_count, &g->rthr, &g->rlists, &g->rcounts, &g->rK, &g->rmax,
                       &g->ownercnt, &g->ownerpos, &g->cnt_sorted, &g->pos_sorted, &g->scan_tmp, &g->selfbuf, &g->splits_dev, &g->edges, &g->Ukey, &g->Uval, &g->Vkey, &g->Vval,
                       &g->bincnt, &g->binoff, &g->ucol, &g->uval, &g->bigrows, &g->bigcount, &g->bigscratch_k, &g->bigscratch_v, &g->bigsoff, &g->aniso_tmp, &g->scan_own,
@@ -86,6 +86,19 @@ __host__ __device__ inline int gt_whole_decay(double decay) {
     return (decay >= 1.0 && decay <= 128.0 && decay == double(int(decay))) ? int(decay) : 0;
 }
 
+constexpr uint32_t kNoDest = 0xFFFFFFFFu;   // posj of a kept entry that is not sent (destination bins, below)
+
+// Tables by sorted position (KnnWork::tab_sorted): what affinity_slots_kernel reads per slot and per partner, one record each
+struct SlotRec {      // by slot
+    int32_t i;        // the row
+    uint32_t n;       // entries of its table - 0: not that launch's row (a row of the radius pass, a table from a repair pass)
+    double bwi;       // its bandwidth
+};
+struct BwPos {        // by row: ONE gather per table entry fetches the partner's bandwidth and its sorted position
+    double bw;
+    uint32_t pos, pad;
+};
+
 // ---- A0: bandwidth, radius, classification ------------------------------------------------------
 __global__ __launch_bounds__(256) void bandwidth_kernel(
     const int64_t nloc, const int64_t r0, const int MP, const int kprime, const int dtype, const int metric,
@@ -95,7 +108,8 @@ __global__ __launch_bounds__(256) void bandwidth_kernel(
     const ErrModel err, const double* __restrict__ bw_user, const int64_t bw_len, const double bw_scale,
     const int use_radius, const double radius_factor, double* __restrict__ bw_out, int32_t* __restrict__ rowsrc,
     int32_t* __restrict__ over_rows, uint32_t* __restrict__ over_count, float* __restrict__ rthr,
-    const int32_t* __restrict__ trow, double* __restrict__ bw_s, int32_t* __restrict__ rowsrc_s) {
+    const int32_t* __restrict__ trow, SlotRec* __restrict__ rec_s, BwPos* __restrict__ bwpos,
+    const uint32_t* __restrict__ cand_n, const uint8_t* __restrict__ keyt_ok) {
     const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
     if (i >= nloc) return;
     const int64_t ti = trow ? int64_t(trow[i]) : i;   // (KnnWork::tab_sorted: the row's table is at its sorted position)
@@ -106,7 +120,6 @@ __global__ __launch_bounds__(256) void bandwidth_kernel(
         bw = (bw_len == 1 ? bw_user[0] : bw_user[r0 + i]) * bw_scale;
     bw = fmax(bw, DBL_EPSILON);
     bw_out[i] = bw;
-    if (bw_s) bw_s[ti] = bw;   // (by sorted position too: what the affinity pass looks the partners' up by)
     int32_t src = -1;
     if (use_radius) {
         const double r = bw * radius_factor * (1.0 + 1e-6);
@@ -129,7 +142,18 @@ __global__ __launch_bounds__(256) void bandwidth_kernel(
         }
     }
     rowsrc[i] = src;
-    if (rowsrc_s) rowsrc_s[ti] = src;
+    if (rec_s) {
+        SlotRec r;
+        r.i = int32_t(i);
+        r.n = (src < 0 && keyt_ok[ti] != 0) ? cand_n[ti] : 0u;
+        r.bwi = bw;
+        rec_s[ti] = r;
+        BwPos b;
+        b.bw = bw;
+        b.pos = uint32_t(ti);
+        b.pad = 0u;
+        bwpos[i] = b;
+    }
 }
 
 __global__ void max_u32_kernel(const uint32_t* __restrict__ v, const int64_t n, uint32_t* __restrict__ out) {
@@ -176,7 +200,10 @@ __global__ __launch_bounds__(256) void affinity_kernel(
     const double decay, const int binary, const double thresh, const int count_owners, const Splits sp,
     int32_t* __restrict__ lenN, int32_t* __restrict__ ownercnt, int32_t* __restrict__ tablen,
     const int pairs, const double* __restrict__ cand_d2t, const uint8_t* __restrict__ keyt_ok, const double rf_guard,
-    const int32_t* __restrict__ tperm, const int32_t* __restrict__ trow) {
+    const int32_t* __restrict__ tperm, const int32_t* __restrict__ trow, uint32_t* __restrict__ posj,
+    const int64_t* __restrict__ sC) {
+    // posj / sC (with trow, table rows): the destinations of the pair-resolved tail are looked up here (see
+    // affinity_slots_kernel: this launch serves the few rows whose tables came from a repair pass)
     // tperm / trow (KnnWork::tab_sorted): the tables lie by sorted position - tperm: slot -> row, for the launch over all the
     // rows (wave wi takes slot wi: the tables stream, and the partners whose bandwidths a stretch of slots gathers are a
     // cache-resident neighbourhood); trow: row -> slot, for the listed rows
@@ -250,6 +277,10 @@ __global__ __launch_bounds__(256) void affinity_kernel(
                 const uint32_t slot = uint32_t(kept) + uint32_t(__popcll(km & ((1ull << lane) - 1ull)));
                 cand_d2[ti * MP + slot] = kvv;
                 if (slot != e) cand_j_w[ti * MP + slot] = j;
+                if (posj) {
+                    const uint32_t pj = uint32_t(trow[j]);
+                    posj[sC[ti] + slot] = kvv >= 0.0 ? pj : kNoDest;
+                }
             }
             kept += __popcll(km);
             if (count_owners) {
@@ -295,6 +326,8 @@ __global__ __launch_bounds__(256) void affinity_kernel(
                 chunk(e, d2, j, 0.0, 1.0);
             }
         }
+        if (posj)   // (the row's stretch of posj is as long as its table: nothing travels from the slots behind the kept ones)
+            for (int64_t e = sC[ti] + kept + lane; e < sC[ti + 1]; e += 64) posj[e] = kNoDest;
         // the consumers read the kept prefix and nothing else
         if (lane == 0) tablen[i] = int32_t(kept);
     } else {
@@ -359,36 +392,35 @@ __global__ __launch_bounds__(256) void affinity_kernel(
 // busy 14 %).  Here a wave walks `rpw` consecutive slots: everything a row needs before its table - row number, count, flags,
 // bandwidth - lies BY SLOT and is fetched two rows ahead, the first 128 entries of the next row's table (addresses known from
 // the slot alone) while the current row's partners' bandwidths are on their way: one exposed round trip per row instead of four.
-struct SlotHdr {
-    int32_t i;        // the row
-    uint32_t n;       // entries of its table
-    int32_t src;      // >= 0: a row of the radius pass (not this launch's)
-    uint32_t kok;     // its table carries the transposed keys (else: the listed launch's)
-    double bwi;
-};
 struct SlotTab {
     double d2a, d2b, ta, tb;
     uint32_t ja, jb;
 };
 __global__ __launch_bounds__(256) void affinity_slots_kernel(
-    const int64_t nslots, const int rpw, const int32_t* __restrict__ tperm, const uint32_t* __restrict__ cand_n,
-    const uint8_t* __restrict__ keyt_ok, const int32_t* __restrict__ rowsrc_s, const double* __restrict__ bw_s,
-    const double* __restrict__ bw, const int dtype, const int metric, const int MP, const int limit, double* __restrict__ cand_d2,
-    uint32_t* __restrict__ cand_j, const double* __restrict__ cand_d2t, const double decay, const int binary, const double thresh,
-    const double rf_guard, const int count_owners, int32_t* __restrict__ lenN, int32_t* __restrict__ ownercnt,
-    int32_t* __restrict__ tablen) {
+    const int64_t nslots, const int rpw, const SlotRec* __restrict__ rec_s, const BwPos* __restrict__ bwpos, const int dtype,
+    const int metric, const int MP, const int limit, double* __restrict__ cand_d2, uint32_t* __restrict__ cand_j,
+    const double* __restrict__ cand_d2t, const double decay, const int binary, const double thresh, const double rf_guard,
+    const int count_owners, int32_t* __restrict__ lenN, int32_t* __restrict__ ownercnt, int32_t* __restrict__ tablen,
+    uint32_t* __restrict__ posj, const int64_t* __restrict__ sC) {
+    // posj / sC (optional, together): the destination lookup of the pair-resolved tail (bin_count_kernel) is done HERE - the
+    // partner's sorted position arrives with its bandwidth, every kept entry's destination goes to posj[sC[slot] + its place in
+    // the row] (sC: scan of the TABLE lengths, known before this pass; kNoDest for a settled pair and for the slots behind the
+    // kept ones); posj_hist_kernel counts the bins from the packed array.  (Counting them here, in an LDS histogram per
+    // workgroup, cost the pass what bin_count_kernel had taken; a separate gather of the positions +0.45 ms: C3, round 5.)
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6));
     const int idecay = gt_whole_decay(decay);
     const int64_t t0 = (int64_t(blockIdx.x) * 4 + w) * rpw;
     const int64_t t1 = t0 + rpw < nslots ? t0 + rpw : nslots;
-    auto load_hdr = [&](const int64_t t, SlotHdr& h) {
+    struct Hdr {
+        SlotRec r;
+        int64_t c0;   // start of the row's stretch of posj
+    };
+    auto load_hdr = [&](const int64_t t, Hdr& h) {
         if (t < t1) {   // (uniform)
-            h.i = tperm[t];
-            h.n = cand_n[t];
-            h.src = rowsrc_s[t];
-            h.kok = keyt_ok[t];
-            h.bwi = bw_s[t];
+            h.r = rec_s[t];
+            if (h.r.n > uint32_t(limit)) h.r.n = uint32_t(limit);
+            if (posj) h.c0 = sC[t];
         }
     };
     auto load_tab = [&](const int64_t t, SlotTab& x) {
@@ -402,21 +434,39 @@ __global__ __launch_bounds__(256) void affinity_slots_kernel(
             x.tb = cand_d2t[o + 64];
         }
     };
-    SlotHdr h0 = {0, 0u, 0, 0u, 1.0}, h1 = h0, h2 = h0;
-    SlotTab x0 = {0.0, 0.0, 0.0, 0.0, 0u, 0u}, x1 = x0;
+    // three rows in flight: the table of row t + 2 and the header of row t + 3 are requested, then the partners' records of
+    // row t + 1 (its columns arrived while row t - 1 was worked on), then row t - everything it needs is in registers - is done
+    struct SlotBw {
+        BwPos a, b;
+    };
+    auto load_bw = [&](const int64_t t, const Hdr& h, const SlotTab& x, SlotBw& g) {
+        g.a.bw = g.b.bw = 1.0;
+        g.a.pos = g.b.pos = 0u;
+        if (t < t1) {
+            if (uint32_t(lane) < h.r.n) g.a = bwpos[x.ja];
+            if (uint32_t(lane) + 64u < h.r.n) g.b = bwpos[x.jb];
+        }
+    };
+    Hdr h0 = {{0, 0u, 1.0}, 0}, h1 = h0, h2 = h0, h3 = h0;
+    SlotTab x0 = {0.0, 0.0, 0.0, 0.0, 0u, 0u}, x1 = x0, x2 = x0;
+    SlotBw g0 = {{1.0, 0u, 0u}, {1.0, 0u, 0u}}, g1 = g0;
     load_hdr(t0, h0);
     load_tab(t0, x0);
     load_hdr(t0 + 1, h1);
+    load_tab(t0 + 1, x1);
+    load_hdr(t0 + 2, h2);
+    load_bw(t0, h0, x0, g0);
     for (int64_t t = t0; t < t1; ++t) {
-        load_tab(t + 1, x1);
-        load_hdr(t + 2, h2);
-        if (h0.src < 0 && h0.kok != 0u) {   // (else: the radius launch's / the listed launch's row)
-            const int64_t i = h0.i;
-            const double bwi = h0.bwi;
-            uint32_t n = h0.n;
-            if (n > uint32_t(limit)) n = uint32_t(limit);
+        load_tab(t + 2, x2);
+        load_hdr(t + 3, h3);
+        load_bw(t + 1, h1, x1, g1);
+        const uint32_t n = h0.r.n;
+        if (n != 0u) {   // (else: the radius launch's / the listed launch's row)
+            const int64_t i = h0.r.i;
+            const double bwi = h0.r.bwi;
             int kept = 0;
-            auto chunk = [&](const uint32_t e, const double d2, const uint32_t j, const double d2t, const double bwj) {
+            auto chunk = [&](const uint32_t e, const double d2, const uint32_t j, const double d2t, const double bwj,
+                             const uint32_t pj) {
                 bool keep = false;
                 double kvv = -1.0;
                 if (e < n) {
@@ -437,29 +487,27 @@ __global__ __launch_bounds__(256) void affinity_slots_kernel(
                     const uint32_t slot = uint32_t(kept) + uint32_t(__popcll(km & ((1ull << lane) - 1ull)));
                     cand_d2[size_t(t) * MP + slot] = kvv;
                     if (slot != e) cand_j[size_t(t) * MP + slot] = j;
+                    if (posj) posj[h0.c0 + slot] = kvv >= 0.0 ? pj : kNoDest;
                 }
                 kept += __popcll(km);
             };
-            {
-                const uint32_t ea = uint32_t(lane), eb = ea + 64u;
-                double bja = 1.0, bjb = 1.0;
-                if (ea < n) bja = bw[x0.ja];
-                if (eb < n) bjb = bw[x0.jb];
-                chunk(ea, x0.d2a, x0.ja, x0.ta, bja);
-                if (n > 64u) chunk(eb, x0.d2b, x0.jb, x0.tb, bjb);   // (uniform)
-            }
+            chunk(uint32_t(lane), x0.d2a, x0.ja, x0.ta, g0.a.bw, g0.a.pos);
+            if (n > 64u) chunk(uint32_t(lane) + 64u, x0.d2b, x0.jb, x0.tb, g0.b.bw, g0.b.pos);   // (uniform)
             for (uint32_t e0 = 128u; e0 < n; e0 += 64u) {   // (the few rows beyond 128 entries: as they come)
                 const uint32_t e = e0 + lane;
-                double d2 = 0.0, d2t = 0.0, bwj = 1.0;
+                double d2 = 0.0, d2t = 0.0;
                 uint32_t j = 0;
+                BwPos bp = {1.0, 0u, 0u};
                 if (e < n) {
                     d2 = cand_d2[size_t(t) * MP + e];
                     j = cand_j[size_t(t) * MP + e];
                     d2t = cand_d2t[size_t(t) * MP + e];
-                    bwj = bw[j];
+                    bp = bwpos[j];
                 }
-                chunk(e, d2, j, d2t, bwj);
+                chunk(e, d2, j, d2t, bp.bw, bp.pos);
             }
+            if (posj)   // (the row's stretch is as long as its table)
+                for (uint32_t e = uint32_t(kept) + lane; e < n; e += 64u) posj[h0.c0 + e] = kNoDest;
             if (lane == 0) {
                 tablen[i] = int32_t(kept);
                 lenN[i] = kept;
@@ -468,8 +516,38 @@ __global__ __launch_bounds__(256) void affinity_slots_kernel(
         }
         h0 = h1;
         h1 = h2;
+        h2 = h3;
         x0 = x1;
+        x1 = x2;
+        g0 = g1;
     }
+}
+
+// destinations per bin from the packed posj (fused destination lookup): a workgroup counts a contiguous stretch in the LDS
+__global__ __launch_bounds__(256) void posj_hist_kernel(const uint32_t* __restrict__ posj, const int64_t total, const int shift,
+                                                        const int nbins, int32_t* __restrict__ bincnt) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    int32_t* hist = reinterpret_cast<int32_t*>(smem_raw);
+    for (int b = threadIdx.x; b < nbins; b += 256) hist[b] = 0;
+    __syncthreads();
+    const int64_t per = (((total + gridDim.x - 1) / gridDim.x) + 3) & ~int64_t(3);
+    const int64_t e0 = int64_t(blockIdx.x) * per, e1 = e0 + per < total ? e0 + per : total;
+    const uint4* p4 = reinterpret_cast<const uint4*>(posj + e0);   // (per is a multiple of 4: 16-byte aligned)
+    const int64_t n4 = e1 > e0 ? (e1 - e0) / 4 : 0;
+    for (int64_t q = threadIdx.x; q < n4; q += 256) {
+        const uint4 v = p4[q];
+        if (v.x != kNoDest) atomicAdd(&hist[v.x >> shift], 1);
+        if (v.y != kNoDest) atomicAdd(&hist[v.y >> shift], 1);
+        if (v.z != kNoDest) atomicAdd(&hist[v.z >> shift], 1);
+        if (v.w != kNoDest) atomicAdd(&hist[v.w >> shift], 1);
+    }
+    for (int64_t e = e0 + n4 * 4 + threadIdx.x; e < e1; e += 256) {
+        const uint32_t v = posj[e];
+        if (v != kNoDest) atomicAdd(&hist[v >> shift], 1);
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < nbins; b += 256)
+        if (hist[b] != 0) atomicAdd(&bincnt[b], hist[b]);
 }
 
 // ---- A2t: transposed triplets, bucketed by destination rank --------------------------------------
@@ -718,7 +796,6 @@ __device__ __forceinline__ void for_kept_entries(const int64_t i, const int64_t 
     }
 }
 
-constexpr uint32_t kNoDest = 0xFFFFFFFFu;   // posj of a kept entry that is not sent
 constexpr int kEmitRows = 128;   // sorted rows per workgroup of bin_emit_kernel
 
 __global__ __launch_bounds__(256) void bin_count_kernel(const int64_t nloc, const int MP, const double* __restrict__ cand_k,
@@ -1698,7 +1775,7 @@ void launch_affinity(gt_ctx* ctx, GraphState* g, KnnWork* k, int binary, double 
     // (rows per workgroup: a workgroup's wave slots are handed on when its LAST wave is done, and the rows' costs differ)
     const int wpb = 1;
     const size_t lds = size_t(wpb) * ctx->d * sizeof(double);
-#define GT_AFFINITY_LAUNCH(RADIUS_, PAIRS_, LIST_, NROWS_)                                                                  \
+#define GT_AFFINITY_LAUNCH(RADIUS_, PAIRS_, LIST_, NROWS_, POSJ_)                                                                  \
     hipLaunchKernelGGL((affinity_kernel<T, RADIUS_, PAIRS_>), dim3((unsigned)ceil_div64(NROWS_, wpb)), dim3(64 * wpb), lds, ctx->stream, \
                        LIST_, int64_t(NROWS_), g->nloc, g->r0, (const T*)ctx->X, ctx->d, ctx->xn.as<double>(),              \
                        (const T*)g->Qmat, g->qnorm, g->qoff, gt_dist_dtype(ctx), ctx->metric, k->MP, g->limit,            \
@@ -1708,25 +1785,31 @@ void launch_affinity(gt_ctx* ctx, GraphState* g, KnnWork* k, int binary, double 
                        g->ownercnt.as<int32_t>(), g->tablen.as<int32_t>(), g->pairs ? 1 : 0,                               \
                        g->pairs ? k->cand_d2t.as<double>() : (const double*)nullptr,                                       \
                        g->pairs ? k->keyt_ok.as<uint8_t>() : (const uint8_t*)nullptr, g->radius_factor * (1.0 + 1e-9),      \
-                       tperm, trow)
+                       tperm, trow, POSJ_, g->sC.as<int64_t>())
     const int32_t* tperm = k->tab_sorted ? k->qorder.as<int32_t>() : (const int32_t*)nullptr;
     const int32_t* trow = k->tab_sorted ? k->sh_invperm.as<int32_t>() : (const int32_t*)nullptr;
     if (g->pairs && k->tab_sorted) {
-        const int rpw = std::getenv("GT_AFF_RPW") ? std::max(1, std::atoi(std::getenv("GT_AFF_RPW"))) : 8;   // EXPERIMENT
+        // (eight consecutive slots per wave: 2 ... 8 measured alike on C3, 16 slower - the longer run of a wave's last rows)
+        const int rpw = 8;
+        const bool fz = g->pairs_fused;
         hipLaunchKernelGGL(affinity_slots_kernel, dim3((unsigned)ceil_div64(g->nloc, int64_t(4) * rpw)), dim3(256), 0, ctx->stream,
-                           g->nloc, rpw, tperm, k->cand_n.as<uint32_t>(), k->keyt_ok.as<uint8_t>(), g->rowsrc_s.as<int32_t>(),
-                           g->bw_s.as<double>(), g->bw.as<double>(), gt_dist_dtype(ctx), ctx->metric, k->MP, g->limit,
-                           k->cand_d2.as<double>(), k->cand_j.as<uint32_t>(), k->cand_d2t.as<double>(), decay, binary, thresh,
-                           g->radius_factor * (1.0 + 1e-9), count_owners, g->lenN.as<int32_t>(), g->ownercnt.as<int32_t>(),
-                           g->tablen.as<int32_t>());
-        if (k->nokeyt_n > 0) GT_AFFINITY_LAUNCH(false, 2, k->nokeyt_rows.as<int32_t>(), int64_t(k->nokeyt_n));   // (qoff = 0 here)
+                           g->nloc, rpw, (const SlotRec*)g->rec_s.p, (const BwPos*)g->bwpos.p, gt_dist_dtype(ctx), ctx->metric, k->MP,
+                           g->limit, k->cand_d2.as<double>(), k->cand_j.as<uint32_t>(), k->cand_d2t.as<double>(), decay, binary,
+                           thresh, g->radius_factor * (1.0 + 1e-9), count_owners, g->lenN.as<int32_t>(), g->ownercnt.as<int32_t>(),
+                           g->tablen.as<int32_t>(), fz ? g->cursor.as<uint32_t>() : (uint32_t*)nullptr, g->sC.as<int64_t>());
+        if (k->nokeyt_n > 0)
+            GT_AFFINITY_LAUNCH(false, 2, k->nokeyt_rows.as<int32_t>(), int64_t(k->nokeyt_n),   // (qoff = 0 here)
+                               fz ? g->cursor.as<uint32_t>() : (uint32_t*)nullptr);
+        if (fz)
+            hipLaunchKernelGGL(posj_hist_kernel, dim3(2048), dim3(256), size_t(g->bin_count) * sizeof(int32_t), ctx->stream,
+                               g->cursor.as<uint32_t>(), g->sc_total, g->bin_shift, g->bin_count, g->bincnt.as<int32_t>());
     } else if (g->pairs) {
-        GT_AFFINITY_LAUNCH(false, 1, (const int32_t*)nullptr, g->nloc);
-        if (k->nokeyt_n > 0) GT_AFFINITY_LAUNCH(false, 2, k->nokeyt_rows.as<int32_t>(), int64_t(k->nokeyt_n));   // (qoff = 0 here)
+        GT_AFFINITY_LAUNCH(false, 1, (const int32_t*)nullptr, g->nloc, (uint32_t*)nullptr);
+        if (k->nokeyt_n > 0) GT_AFFINITY_LAUNCH(false, 2, k->nokeyt_rows.as<int32_t>(), int64_t(k->nokeyt_n), (uint32_t*)nullptr);   // (qoff = 0 here)
     } else {
-        GT_AFFINITY_LAUNCH(false, 0, (const int32_t*)nullptr, g->nloc);
+        GT_AFFINITY_LAUNCH(false, 0, (const int32_t*)nullptr, g->nloc, (uint32_t*)nullptr);
     }
-    if (g->n_over > 0) GT_AFFINITY_LAUNCH(true, 0, g->over_rows.as<int32_t>(), g->n_over);
+    if (g->n_over > 0) GT_AFFINITY_LAUNCH(true, 0, g->over_rows.as<int32_t>(), g->n_over, (uint32_t*)nullptr);
 #undef GT_AFFINITY_LAUNCH
 }
 
@@ -1949,8 +2032,8 @@ static int graph_begin_impl(gt_ctx* ctx, const gt_knn_params* params, int32_t wo
 
     GT_HIP(ctx, g->bw.reserve(size_t(g->nloc) * sizeof(double)));
     if (k->tab_sorted) {
-        GT_HIP(ctx, g->bw_s.reserve(size_t(g->nloc) * sizeof(double)));
-        GT_HIP(ctx, g->rowsrc_s.reserve(size_t(g->nloc) * sizeof(int32_t)));
+        GT_HIP(ctx, g->rec_s.reserve(size_t(g->nloc) * sizeof(SlotRec)));
+        GT_HIP(ctx, g->bwpos.reserve(size_t(g->nloc) * sizeof(BwPos)));
     }
     GT_HIP(ctx, g->rowsrc.reserve(size_t(g->nloc) * sizeof(int32_t)));
     GT_HIP(ctx, g->lenN.reserve(size_t(g->nloc) * sizeof(int32_t)));
@@ -1993,8 +2076,8 @@ static int graph_begin_impl(gt_ctx* ctx, const gt_knn_params* params, int32_t wo
                            qn_bound, g->qnorm, g->qoff, ctx->ymax.as<double>(), err_model, g->bw_user.as<double>(),
                            params->bandwidth_len, params->bandwidth_scale, use_radius ? 1 : 0, g->radius_factor,
                            g->bw.as<double>(), g->rowsrc.as<int32_t>(), g->over_rows.as<int32_t>(),
-                           g->over_count.as<uint32_t>(), g->rthr.as<float>(), trow, trow ? g->bw_s.as<double>() : (double*)nullptr,
-                           trow ? g->rowsrc_s.as<int32_t>() : (int32_t*)nullptr);
+                           g->over_count.as<uint32_t>(), g->rthr.as<float>(), trow, trow ? (SlotRec*)g->rec_s.p : (SlotRec*)nullptr,
+                           trow ? (BwPos*)g->bwpos.p : (BwPos*)nullptr, k->cand_n.as<uint32_t>(), k->keyt_ok.as<uint8_t>());
         GT_HIP(ctx, hipGetLastError());
     }
     if (n_kst > 0) {
@@ -2055,8 +2138,8 @@ static int graph_begin_impl(gt_ctx* ctx, const gt_knn_params* params, int32_t wo
                                qn_bound, g->qnorm, g->qoff, ctx->ymax.as<double>(), err_model, g->bw_user.as<double>(),
                                params->bandwidth_len, params->bandwidth_scale, 1, g->radius_factor,
                                g->bw.as<double>(), g->rowsrc.as<int32_t>(), g->over_rows.as<int32_t>(),
-                               g->over_count.as<uint32_t>(), g->rthr.as<float>(), trow, trow ? g->bw_s.as<double>() : (double*)nullptr,
-                           trow ? g->rowsrc_s.as<int32_t>() : (int32_t*)nullptr);
+                               g->over_count.as<uint32_t>(), g->rthr.as<float>(), trow, trow ? (SlotRec*)g->rec_s.p : (SlotRec*)nullptr,
+                           trow ? (BwPos*)g->bwpos.p : (BwPos*)nullptr, k->cand_n.as<uint32_t>(), k->keyt_ok.as<uint8_t>());
             GT_HIP(ctx, hipGetLastError());
         } else if (need != km) {
             // every row finished inside the tables: nothing is capped, nothing is missing
@@ -2064,6 +2147,15 @@ static int graph_begin_impl(gt_ctx* ctx, const gt_knn_params* params, int32_t wo
         }
     }
     uint32_t n_over = 0;
+    int64_t sc_total = 0;
+    if (k->tab_sorted) {
+        // (tables by sorted position: the scan of their lengths - where the fused destination count of the affinity pass puts a
+        //  row's destinations; the total comes back with the count of the radius rows)
+        GT_HIP(ctx, g->sC.reserve(size_t(g->nloc + 1) * sizeof(int64_t)));
+        GT_TRY(exclusive_scan(ctx, reinterpret_cast<const int32_t*>(k->cand_n.as<uint32_t>()), nullptr, g->nloc, g->sC.as<int64_t>(),
+                              g->scan_tmp));
+        GT_HIP(ctx, hipMemcpyAsync(&sc_total, g->sC.as<int64_t>() + g->nloc, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    }
     GT_HIP(ctx, hipMemcpyAsync(&n_over, g->over_count.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     g->n_over = n_over;
@@ -2133,6 +2225,21 @@ static int graph_begin_impl(gt_ctx* ctx, const gt_knn_params* params, int32_t wo
                k->keyt_valid && k->ordered && k->nq == g->nloc && g->r0 == 0 && !ctx->presorted &&
                g->nloc < (int64_t(1) << 31) && (ctx->symm_bins > 0 || g->nloc >= 65536);
     if (k->tab_sorted && !g->pairs) GT_FAIL(ctx, GT_E_STATE, "graph build: tables by sorted position without the pair-resolved tail");
+    g->pairs_fused = false;
+    if (g->pairs) {
+        // the destination bins of the tail (graph_finish_pairs): rows per bin, bins; their counters start at zero
+        int shift = 9;
+        if (ctx->symm_bin_shift > 0) shift = ctx->symm_bin_shift;
+        while (ceil_div64(g->nloc, int64_t(1) << shift) > 4096) ++shift;
+        g->bin_shift = shift;
+        g->bin_count = int32_t(ceil_div64(g->nloc, int64_t(1) << shift));
+        GT_HIP(ctx, g->bincnt.reserve(size_t(2 * g->bin_count) * sizeof(int32_t)));
+        GT_HIP(ctx, hipMemsetAsync(g->bincnt.p, 0, size_t(2 * g->bin_count) * sizeof(int32_t), ctx->stream));
+        // with the tables by sorted position and no row of the radius pass, the affinity pass counts the destinations itself
+        g->pairs_fused = k->tab_sorted && n_over == 0 && sc_total > 0 && sc_total < (int64_t(1) << 31);
+        if (g->pairs_fused) GT_HIP(ctx, g->cursor.reserve(size_t(sc_total) * sizeof(uint32_t)));   // posj, by sC
+        g->sc_total = sc_total;
+    }
     if (ctx->dbg_select & 2048)
         std::fprintf(stderr, "[gt] pairs %d: in_build %d opt %d ok %d bins %d world %d ext %d bin %d kmax %lld symm %d aniso %g metric %d keyt %d ordered %d nq %lld nloc %lld r0 %lld\n",
                      int(g->pairs), ctx->in_graph_build, ctx->symm_pairs, ctx->symm_pair_ok, ctx->symm_bins, world, int(external), int(binary),
@@ -2562,16 +2669,13 @@ static int graph_finish_pairs(gt_ctx* ctx, int64_t* out_nnz, uint32_t* flags) {
     StageSpan span(ctx, "symmetrize");
     const int32_t* perm = k->qorder.as<int32_t>();
     const int tabs = k->tab_sorted ? 1 : 0;   // the tables lie by sorted position (and k->sh_invperm is there already)
-    int shift = 9;
-    if (ctx->symm_bin_shift > 0) shift = ctx->symm_bin_shift;
-    while (ceil_div64(nloc, int64_t(1) << shift) > 4096) ++shift;
-    const int nbins = int(ceil_div64(nloc, int64_t(1) << shift));
+    const bool fused = g->pairs_fused;        // ... and the affinity pass has counted the destinations (posj by g->sC, bincnt)
+    const int shift = g->bin_shift, nbins = g->bin_count;   // (set, and the counters cleared, where g->pairs was decided)
     GT_HIP(ctx, k->sh_invperm.reserve(size_t(nloc) * sizeof(int32_t)));
     GT_HIP(ctx, g->cnt_sorted.reserve(size_t(nloc) * sizeof(int32_t)));
     GT_HIP(ctx, g->pos_sorted.reserve(size_t(nloc + 1) * sizeof(int64_t)));
-    GT_HIP(ctx, g->bincnt.reserve(size_t(2 * nbins) * sizeof(int32_t)));
     GT_HIP(ctx, g->binoff.reserve(size_t(nbins + 1) * sizeof(int64_t)));
-    GT_HIP(ctx, g->cursor.reserve(size_t(n_own) * sizeof(uint32_t)));   // posj
+    if (!fused) GT_HIP(ctx, g->cursor.reserve(size_t(n_own) * sizeof(uint32_t)));   // posj
     GT_HIP(ctx, g->selfbuf.reserve(size_t(n_own) * sizeof(Triplet)));
     GT_HIP(ctx, g->ucol.reserve(size_t(n_own) * sizeof(uint32_t)));
     GT_HIP(ctx, g->uval.reserve(size_t(n_own) * sizeof(double)));
@@ -2581,26 +2685,28 @@ static int graph_finish_pairs(gt_ctx* ctx, int64_t* out_nnz, uint32_t* flags) {
     GT_HIP(ctx, g->bigcount.reserve(8 * sizeof(uint32_t)));   // [0] long rows, [2] flags, [4] huge rows, [6..7] their entries (pairs_len_kernel)
     GT_HIP(ctx, g->indptr.reserve(size_t(nloc + 1) * sizeof(int64_t)));
     GT_HIP(ctx, g->degree.reserve(size_t(nloc) * sizeof(double)));
-    GT_HIP(ctx, hipMemsetAsync(g->bincnt.p, 0, size_t(2 * nbins) * sizeof(int32_t), ctx->stream));
     GT_HIP(ctx, hipMemsetAsync(g->bigcount.p, 0, 8 * sizeof(uint32_t), ctx->stream));
     uint32_t* fflags = g->bigcount.as<uint32_t>() + 2;
+    // posj: by the scan of the own entries - or, counted by the affinity pass, by the scan of the tables' lengths
+    const int64_t* sP = fused ? g->sC.as<int64_t>() : g->pos_sorted.as<int64_t>();
     {
         StageSpan span_bins(ctx, "symm_bins");
         if (!tabs) GT_TRY(gt_sym_invperm(ctx, perm, k->sh_invperm.as<int32_t>()));
         hipLaunchKernelGGL(gather_counts_kernel, dim3((unsigned)ceil_div64(nloc, 256)), dim3(256), 0, ctx->stream,
                            g->lenN.as<int32_t>(), perm, nloc, g->cnt_sorted.as<int32_t>());
         GT_TRY(exclusive_scan(ctx, g->cnt_sorted.as<int32_t>(), nullptr, nloc, g->pos_sorted.as<int64_t>(), g->scan_tmp));
-        hipLaunchKernelGGL(bin_count_kernel, dim3((unsigned)std::min<int64_t>(ceil_div64(nloc, 64), 2048)), dim3(256),
-                           size_t(nbins) * sizeof(int32_t), ctx->stream, nloc, k->MP, k->cand_d2.as<double>(),
-                           k->cand_j.as<uint32_t>(), g->rowsrc.as<int32_t>(), g->rlists.as<uint64_t>(),
-                           g->rcounts.as<uint32_t>(), g->rcap, g->rK.as<double>(), g->tablen.as<int32_t>(), perm,
-                           k->sh_invperm.as<int32_t>(), shift, nbins, g->pos_sorted.as<int64_t>(), g->cursor.as<uint32_t>(),
-                           g->bincnt.as<int32_t>(), tabs);
+        if (!fused)
+            hipLaunchKernelGGL(bin_count_kernel, dim3((unsigned)std::min<int64_t>(ceil_div64(nloc, 64), 2048)), dim3(256),
+                               size_t(nbins) * sizeof(int32_t), ctx->stream, nloc, k->MP, k->cand_d2.as<double>(),
+                               k->cand_j.as<uint32_t>(), g->rowsrc.as<int32_t>(), g->rlists.as<uint64_t>(),
+                               g->rcounts.as<uint32_t>(), g->rcap, g->rK.as<double>(), g->tablen.as<int32_t>(), perm,
+                               k->sh_invperm.as<int32_t>(), shift, nbins, g->pos_sorted.as<int64_t>(), g->cursor.as<uint32_t>(),
+                               g->bincnt.as<int32_t>(), tabs);
         GT_TRY(exclusive_scan(ctx, g->bincnt.as<int32_t>(), nullptr, nbins, g->binoff.as<int64_t>(), g->scan_tmp));
         hipLaunchKernelGGL(bin_emit_kernel, dim3((unsigned)ceil_div64(nloc, kEmitRows)), dim3(256), size_t(2 * nbins) * sizeof(int32_t),
                            ctx->stream, nloc, k->MP, k->cand_d2.as<double>(), k->cand_j.as<uint32_t>(), g->rowsrc.as<int32_t>(),
                            g->rlists.as<uint64_t>(), g->rcounts.as<uint32_t>(), g->rcap, g->rK.as<double>(),
-                           g->tablen.as<int32_t>(), perm, g->pos_sorted.as<int64_t>(), g->cursor.as<uint32_t>(), shift, nbins,
+                           g->tablen.as<int32_t>(), perm, sP, g->cursor.as<uint32_t>(), shift, nbins,
                            g->binoff.as<int64_t>(), g->bincnt.as<int32_t>() + nbins, (Triplet*)g->selfbuf.p, tabs);
         hipLaunchKernelGGL(bin_fill_kernel<256>, dim3((unsigned)nbins), dim3(256), size_t(2) * (size_t(1) << shift) * sizeof(int32_t),
                            ctx->stream, nloc, k->MP, k->cand_d2.as<double>(), k->cand_j.as<uint32_t>(), g->rowsrc.as<int32_t>(),
