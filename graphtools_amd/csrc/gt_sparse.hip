@@ -90,8 +90,8 @@ constexpr uint32_t kNoDest = 0xFFFFFFFFu;   // posj of a kept entry that is not 
 
 // Tables by sorted position (KnnWork::tab_sorted): what affinity_slots_kernel reads per slot and per partner, one record each
 struct SlotRec {      // by slot
-    int32_t i;        // the row
-    uint32_t n;       // entries of its table - 0: not that launch's row (a row of the radius pass, a table from a repair pass)
+    int32_t i;        // the row; -1: not that launch's row (a row of the radius pass, a table from a repair pass)
+    uint32_t n;       // entries of its table
     double bwi;       // its bandwidth
 };
 struct BwPos {        // by row: ONE gather per table entry fetches the partner's bandwidth and its sorted position
@@ -144,8 +144,8 @@ __global__ __launch_bounds__(256) void bandwidth_kernel(
     rowsrc[i] = src;
     if (rec_s) {
         SlotRec r;
-        r.i = int32_t(i);
-        r.n = (src < 0 && keyt_ok[ti] != 0) ? cand_n[ti] : 0u;
+        r.i = (src < 0 && keyt_ok[ti] != 0) ? int32_t(i) : -1;
+        r.n = cand_n[ti];
         r.bwi = bw;
         rec_s[ti] = r;
         BwPos b;
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256) void affinity_kernel(
     int32_t* __restrict__ lenN, int32_t* __restrict__ ownercnt, int32_t* __restrict__ tablen,
     const int pairs, const double* __restrict__ cand_d2t, const uint8_t* __restrict__ keyt_ok, const double rf_guard,
     const int32_t* __restrict__ tperm, const int32_t* __restrict__ trow, uint32_t* __restrict__ posj,
-    const int64_t* __restrict__ sC) {
+    const int64_t* __restrict__ sC, int32_t* __restrict__ lenN_s) {
     // posj / sC (with trow, table rows): the destinations of the pair-resolved tail are looked up here (see
     // affinity_slots_kernel: this launch serves the few rows whose tables came from a repair pass)
     // tperm / trow (KnnWork::tab_sorted): the tables lie by sorted position - tperm: slot -> row, for the launch over all the
@@ -379,6 +379,7 @@ __global__ __launch_bounds__(256) void affinity_kernel(
         }
     }
     if (lane == 0) lenN[i] = kept;
+    if (lane == 0 && trow && lenN_s) lenN_s[trow[i]] = kept;   // (tables by sorted position: by slot too - every launch writes it)
     if constexpr (RADIUS) {
         if (lane == 0) const_cast<uint32_t*>(rcounts)[src] = uint32_t(kept);   // the list now ends behind its kept entries
     }
@@ -401,7 +402,7 @@ __global__ __launch_bounds__(256) void affinity_slots_kernel(
     const int metric, const int MP, const int limit, double* __restrict__ cand_d2, uint32_t* __restrict__ cand_j,
     const double* __restrict__ cand_d2t, const double decay, const int binary, const double thresh, const double rf_guard,
     const int count_owners, int32_t* __restrict__ lenN, int32_t* __restrict__ ownercnt, int32_t* __restrict__ tablen,
-    uint32_t* __restrict__ posj, const int64_t* __restrict__ sC) {
+    uint32_t* __restrict__ posj, const int64_t* __restrict__ sC, int32_t* __restrict__ lenN_s) {
     // posj / sC (optional, together): the destination lookup of the pair-resolved tail (bin_count_kernel) is done HERE - the
     // partner's sorted position arrives with its bandwidth, every kept entry's destination goes to posj[sC[slot] + its place in
     // the row] (sC: scan of the TABLE lengths, known before this pass; kNoDest for a settled pair and for the slots behind the
@@ -420,6 +421,7 @@ __global__ __launch_bounds__(256) void affinity_slots_kernel(
         if (t < t1) {   // (uniform)
             h.r = rec_s[t];
             if (h.r.n > uint32_t(limit)) h.r.n = uint32_t(limit);
+            if (h.r.i < 0) h.r.n = 0u;
             if (posj) h.c0 = sC[t];
         }
     };
@@ -461,7 +463,7 @@ __global__ __launch_bounds__(256) void affinity_slots_kernel(
         load_hdr(t + 3, h3);
         load_bw(t + 1, h1, x1, g1);
         const uint32_t n = h0.r.n;
-        if (n != 0u) {   // (else: the radius launch's / the listed launch's row)
+        if (h0.r.i >= 0) {   // (else: the radius launch's / the listed launch's row)
             const int64_t i = h0.r.i;
             const double bwi = h0.r.bwi;
             int kept = 0;
@@ -511,6 +513,7 @@ __global__ __launch_bounds__(256) void affinity_slots_kernel(
             if (lane == 0) {
                 tablen[i] = int32_t(kept);
                 lenN[i] = kept;
+                lenN_s[t] = kept;   // (by slot too: what the passes over the sorted rows read)
                 if (count_owners) ownercnt[i] = kept;   // (one rank: every kept entry is its own)
             }
         }
@@ -887,6 +890,93 @@ __global__ __launch_bounds__(256) void bin_emit_kernel(const int64_t nloc, const
     }
 }
 
+// bin_emit_kernel for builds whose affinity pass looked the destinations up (GraphState::pairs_fused: every row is a table row,
+// tables / counts / posj by slot).  The same triplets; a row here is table -> LDS cursor -> store: the header (row, count, start
+// of its stretch of posj) is fetched two rows ahead, values and destinations one row ahead, and the bin's offset - a dependent
+// global read per entry there - is folded into the run's base when the run is reserved.
+__global__ __launch_bounds__(256) void bin_emit_slots_kernel(const int64_t nloc, const int MP, const double* __restrict__ cand_k,
+                                                             const int32_t* __restrict__ lenN_s, const int32_t* __restrict__ perm,
+                                                             const int64_t* __restrict__ sC, const uint32_t* __restrict__ posj,
+                                                             const int shift, const int nbins, const int64_t* __restrict__ binoff,
+                                                             int32_t* __restrict__ bincur, Triplet* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    int32_t* hist = reinterpret_cast<int32_t*>(smem_raw);          // entries of this workgroup per bin, then its cursor there
+    uint32_t* base = reinterpret_cast<uint32_t*>(hist + nbins);    // first slot of this workgroup's run: binoff[b] + its start inside the bin
+    for (int b = threadIdx.x; b < nbins; b += 256) hist[b] = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6));
+    const int64_t p0 = int64_t(blockIdx.x) * kEmitRows;
+    const int64_t p1 = p0 + kEmitRows < nloc ? p0 + kEmitRows : nloc;
+    for (int64_t e = sC[p0] + threadIdx.x; e < sC[p1]; e += 256) {
+        const uint32_t pj = posj[e];
+        if (pj != kNoDest) atomicAdd(&hist[pj >> shift], 1);
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < nbins; b += 256)
+        if (hist[b] != 0) {
+            base[b] = uint32_t(binoff[b]) + uint32_t(atomicAdd(&bincur[b], hist[b]));
+            hist[b] = 0;
+        }
+    __syncthreads();
+    struct Hdr {
+        int64_t c0;
+        int32_t i, n;
+    };
+    struct Dat {
+        double va, vb;
+        uint32_t pa, pb;
+    };
+    auto load_hdr = [&](const int64_t p, Hdr& h) {
+        if (p < p1) {
+            h.c0 = sC[p];
+            h.i = perm[p];
+            h.n = lenN_s[p];
+        }
+    };
+    auto load_dat = [&](const int64_t p, const Hdr& h, Dat& x) {
+        x.va = x.vb = -1.0;
+        x.pa = x.pb = kNoDest;
+        if (p < p1) {
+            if (lane < h.n) {
+                x.va = cand_k[size_t(p) * MP + lane];
+                x.pa = posj[h.c0 + lane];
+            }
+            if (lane + 64 < h.n) {
+                x.vb = cand_k[size_t(p) * MP + 64 + lane];
+                x.pb = posj[h.c0 + 64 + lane];
+            }
+        }
+    };
+    auto send = [&](const uint32_t i, const double v, const uint32_t pj) {
+        if (v >= 0.0 && pj != kNoDest) {   // (a settled pair is stored negative: nothing of it travels)
+            const int b = int(pj >> shift);
+            const uint32_t slot = base[b] + uint32_t(atomicAdd(&hist[b], 1));
+            Triplet t;
+            t.row = pj;   // destination: the SORTED POSITION of point j
+            t.col = i;    // column: the point itself
+            t.val = v;
+            out[slot] = t;
+        }
+    };
+    Hdr h0 = {0, 0, 0}, h1 = h0, h2 = h0;
+    Dat x0 = {-1.0, -1.0, kNoDest, kNoDest}, x1 = x0;
+    const int64_t pw = p0 + w;
+    load_hdr(pw, h0);
+    load_hdr(pw + 4, h1);
+    load_dat(pw, h0, x0);
+    for (int64_t p = pw; p < p1; p += 4) {
+        load_hdr(p + 8, h2);
+        load_dat(p + 4, h1, x1);
+        send(uint32_t(h0.i), x0.va, x0.pa);
+        send(uint32_t(h0.i), x0.vb, x0.pb);
+        for (int e = 128 + lane; e < h0.n; e += 64) send(uint32_t(h0.i), cand_k[size_t(p) * MP + e], posj[h0.c0 + e]);
+        h0 = h1;
+        h1 = h2;
+        x0 = x1;
+    }
+}
+
 // One workgroup per bin.  sN: exclusive scan of the own-entry counts in sorted order (lenNs), binoff: of the bins'
 // triplet counts - the bin's union rows start at sN[first row] + binoff[bin].
 template <int NT>   // threads per workgroup (the kernel waits on load -> LDS atomic -> store chains: more of them in flight)
@@ -914,8 +1004,15 @@ __global__ __launch_bounds__(NT) void bin_fill_kernel(const int64_t nloc, const 
     __syncthreads();
     const int64_t t0 = binoff[b], t1 = binoff[b + 1];
     {
-        // (four loads in flight per thread: the loop is bound by the latency of load -> LDS atomic otherwise)
+        // (eight, then four loads in flight per thread: the loop is bound by the latency of load -> LDS atomic otherwise)
         int64_t t = t0 + threadIdx.x;
+        for (; t + 7 * NT < t1; t += 8 * NT) {
+            uint32_t r[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) r[u] = trip[t + u * NT].row;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) atomicAdd(&cnt[int64_t(r[u]) - p0], 1);
+        }
         for (; t + 3 * NT < t1; t += 4 * NT) {
             const uint32_t r0 = trip[t].row, r1 = trip[t + NT].row, r2 = trip[t + 2 * NT].row, r3 = trip[t + 3 * NT].row;
             atomicAdd(&cnt[int64_t(r0) - p0], 1);
@@ -982,6 +1079,21 @@ __global__ __launch_bounds__(NT) void bin_fill_kernel(const int64_t nloc, const 
     __syncthreads();
     {
         int64_t t = t0 + threadIdx.x;
+        if (ucol) {
+            for (; t + 7 * NT < t1; t += 8 * NT) {
+                Triplet a[8];
+                int sl[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) a[u] = trip[t + u * NT];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) sl[u] = atomicAdd(&cnt[int64_t(a[u].row) - p0], 1);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    ucol[t0 + sl[u]] = a[u].col;
+                    uval[t0 + sl[u]] = a[u].val;
+                }
+            }
+        }
         for (; t + 3 * NT < t1; t += 4 * NT) {
             const Triplet a0 = trip[t], a1 = trip[t + NT], a2 = trip[t + 2 * NT], a3 = trip[t + 3 * NT];
             const int s0 = atomicAdd(&cnt[int64_t(a0.row) - p0], 1);
@@ -1785,7 +1897,7 @@ void launch_affinity(gt_ctx* ctx, GraphState* g, KnnWork* k, int binary, double 
                        g->ownercnt.as<int32_t>(), g->tablen.as<int32_t>(), g->pairs ? 1 : 0,                               \
                        g->pairs ? k->cand_d2t.as<double>() : (const double*)nullptr,                                       \
                        g->pairs ? k->keyt_ok.as<uint8_t>() : (const uint8_t*)nullptr, g->radius_factor * (1.0 + 1e-9),      \
-                       tperm, trow, POSJ_, g->sC.as<int64_t>())
+                       tperm, trow, POSJ_, g->sC.as<int64_t>(), k->tab_sorted ? g->cnt_sorted.as<int32_t>() : (int32_t*)nullptr)
     const int32_t* tperm = k->tab_sorted ? k->qorder.as<int32_t>() : (const int32_t*)nullptr;
     const int32_t* trow = k->tab_sorted ? k->sh_invperm.as<int32_t>() : (const int32_t*)nullptr;
     if (g->pairs && k->tab_sorted) {
@@ -1796,7 +1908,8 @@ void launch_affinity(gt_ctx* ctx, GraphState* g, KnnWork* k, int binary, double 
                            g->nloc, rpw, (const SlotRec*)g->rec_s.p, (const BwPos*)g->bwpos.p, gt_dist_dtype(ctx), ctx->metric, k->MP,
                            g->limit, k->cand_d2.as<double>(), k->cand_j.as<uint32_t>(), k->cand_d2t.as<double>(), decay, binary,
                            thresh, g->radius_factor * (1.0 + 1e-9), count_owners, g->lenN.as<int32_t>(), g->ownercnt.as<int32_t>(),
-                           g->tablen.as<int32_t>(), fz ? g->cursor.as<uint32_t>() : (uint32_t*)nullptr, g->sC.as<int64_t>());
+                           g->tablen.as<int32_t>(), fz ? g->cursor.as<uint32_t>() : (uint32_t*)nullptr, g->sC.as<int64_t>(),
+                           g->cnt_sorted.as<int32_t>());
         if (k->nokeyt_n > 0)
             GT_AFFINITY_LAUNCH(false, 2, k->nokeyt_rows.as<int32_t>(), int64_t(k->nokeyt_n),   // (qoff = 0 here)
                                fz ? g->cursor.as<uint32_t>() : (uint32_t*)nullptr);
@@ -2032,6 +2145,7 @@ static int graph_begin_impl(gt_ctx* ctx, const gt_knn_params* params, int32_t wo
 
     GT_HIP(ctx, g->bw.reserve(size_t(g->nloc) * sizeof(double)));
     if (k->tab_sorted) {
+        GT_HIP(ctx, g->cnt_sorted.reserve(size_t(g->nloc) * sizeof(int32_t)));   // (lenN by slot, written by the affinity launches)
         GT_HIP(ctx, g->rec_s.reserve(size_t(g->nloc) * sizeof(SlotRec)));
         GT_HIP(ctx, g->bwpos.reserve(size_t(g->nloc) * sizeof(BwPos)));
     }
@@ -2692,8 +2806,9 @@ static int graph_finish_pairs(gt_ctx* ctx, int64_t* out_nnz, uint32_t* flags) {
     {
         StageSpan span_bins(ctx, "symm_bins");
         if (!tabs) GT_TRY(gt_sym_invperm(ctx, perm, k->sh_invperm.as<int32_t>()));
-        hipLaunchKernelGGL(gather_counts_kernel, dim3((unsigned)ceil_div64(nloc, 256)), dim3(256), 0, ctx->stream,
-                           g->lenN.as<int32_t>(), perm, nloc, g->cnt_sorted.as<int32_t>());
+        if (!tabs)   // (tables by sorted position: the affinity launches wrote the counts by slot)
+            hipLaunchKernelGGL(gather_counts_kernel, dim3((unsigned)ceil_div64(nloc, 256)), dim3(256), 0, ctx->stream,
+                               g->lenN.as<int32_t>(), perm, nloc, g->cnt_sorted.as<int32_t>());
         GT_TRY(exclusive_scan(ctx, g->cnt_sorted.as<int32_t>(), nullptr, nloc, g->pos_sorted.as<int64_t>(), g->scan_tmp));
         if (!fused)
             hipLaunchKernelGGL(bin_count_kernel, dim3((unsigned)std::min<int64_t>(ceil_div64(nloc, 64), 2048)), dim3(256),
@@ -2703,6 +2818,12 @@ static int graph_finish_pairs(gt_ctx* ctx, int64_t* out_nnz, uint32_t* flags) {
                                k->sh_invperm.as<int32_t>(), shift, nbins, g->pos_sorted.as<int64_t>(), g->cursor.as<uint32_t>(),
                                g->bincnt.as<int32_t>(), tabs);
         GT_TRY(exclusive_scan(ctx, g->bincnt.as<int32_t>(), nullptr, nbins, g->binoff.as<int64_t>(), g->scan_tmp));
+        if (fused && n_own < (int64_t(1) << 32))
+            hipLaunchKernelGGL(bin_emit_slots_kernel, dim3((unsigned)ceil_div64(nloc, kEmitRows)), dim3(256),
+                               size_t(2 * nbins) * sizeof(int32_t), ctx->stream, nloc, k->MP, k->cand_d2.as<double>(),
+                               g->cnt_sorted.as<int32_t>(), perm, sP, g->cursor.as<uint32_t>(), shift, nbins, g->binoff.as<int64_t>(),
+                               g->bincnt.as<int32_t>() + nbins, (Triplet*)g->selfbuf.p);
+        else
         hipLaunchKernelGGL(bin_emit_kernel, dim3((unsigned)ceil_div64(nloc, kEmitRows)), dim3(256), size_t(2 * nbins) * sizeof(int32_t),
                            ctx->stream, nloc, k->MP, k->cand_d2.as<double>(), k->cand_j.as<uint32_t>(), g->rowsrc.as<int32_t>(),
                            g->rlists.as<uint64_t>(), g->rcounts.as<uint32_t>(), g->rcap, g->rK.as<double>(),
