@@ -44,6 +44,7 @@ struct GraphState {
     DevBuf tablen;   // int32 [nloc]: entries of the candidate-table row the affinity pass looked at
     DevBuf rec_s;    // SlotRec [nloc]: row, table length, bandwidth by sorted position (tables by sorted position only, KnnWork::tab_sorted)
     DevBuf bwpos;    // BwPos [nloc]: bandwidth and sorted position by row (same)
+    DevBuf midrows;  // int32 [nloc]: rows of 129 ... kBigRow union entries (fused-destination builds: merge_final_kernel over a list)
     DevBuf sC;       // int64 [nloc + 1]: scan of the tables' lengths by sorted position (fused destination count: posj lies by it)
     // radius pass
     DevBuf over_rows, over_count, rthr, rlists, rcounts, rK, rmax;

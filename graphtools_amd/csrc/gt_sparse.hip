@@ -21,7 +21,7 @@
 void gt_free_graph_state(gt_ctx* ctx) {
     if (!ctx->graph) return;
     GraphState* g = ctx->graph;
-    for (DevBuf* b : {&g->bw, &g->rec_s, &g->bwpos, &g->sC, &g->bw_user, &g->rowsrc, &g->hugerows, &g->tablen, &g->spmm_in, &g->spmm_out, &g->lenN, &g->lenT, &g->cursor, &g->off, &g->outlen, &g->indptr,
+    for (DevBuf* b : {&g->bw, &g->rec_s, &g->bwpos, &g->sC, &g->midrows, &g->bw_user, &g->rowsrc, &g->hugerows, &g->tablen, &g->spmm_in, &g->spmm_out, &g->lenN, &g->lenT, &g->cursor, &g->off, &g->outlen, &g->indptr,
                       &g->degree, &g->over_rows, &g->over_count, &g->rthr, &g->rlists, &g->rcounts, &g->rK, &g->rmax,
                       &g->ownercnt, &g->ownerpos, &g->cnt_sorted, &g->pos_sorted, &g->scan_tmp, &g->selfbuf, &g->splits_dev, &g->edges, &g->Ukey, &g->Uval, &g->Vkey, &g->Vval,
                       &g->bincnt, &g->binoff, &g->ucol, &g->uval, &g->bigrows, &g->bigcount, &g->bigscratch_k, &g->bigscratch_v, &g->bigsoff, &g->aniso_tmp, &g->scan_own,
@@ -1645,10 +1645,14 @@ __device__ __forceinline__ double sort_merge_final_row(const RowSrc3& U, const i
 __global__ __launch_bounds__(256) void merge_final_kernel(const int64_t nloc, const FusedSrc fs, const int64_t* __restrict__ indptr,
                                                           int32_t* __restrict__ indices, double* __restrict__ Kdata,
                                                           double* __restrict__ Pdata, double* __restrict__ degree,
-                                                          uint32_t* __restrict__ flags, const int key32) {
+                                                          uint32_t* __restrict__ flags, const int key32,
+                                                          const int32_t* __restrict__ list) {
+    // list (optional): the launch covers these rows (nloc of them) - the rows of 129 ... kBigRow entries that
+    // merge_pairs_slots_kernel leaves out
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int64_t i = int64_t(blockIdx.x) * (blockDim.x >> 6) + w;
-    if (i >= nloc) return;
+    const int64_t wi = int64_t(blockIdx.x) * (blockDim.x >> 6) + w;
+    if (wi >= nloc) return;
+    const int64_t i = list ? int64_t(list[wi]) : wi;
     const int64_t p = fs.pos[i];
     int lt;
     const RowSrc3 U = make_row_src3(fs, i, p, lt);
@@ -1671,6 +1675,134 @@ __global__ __launch_bounds__(256) void merge_final_kernel(const int64_t nloc, co
     if (lane == 0) {
         degree[i] = sum;
         if (!any_diag) atomicOr(flags, GT_FLAG_ZERO_DIAGONAL);
+    }
+}
+
+// merge_final_kernel for builds whose affinity pass looked the destinations up (GraphState::pairs_fused: every row is a table
+// row; tables, counts, union rows by slot).  A wave walks `rpw` consecutive slots with the next rows' headers and the first
+// 128 (key, value) pairs of the next row in flight.  A union row of a pair-resolved build holds no column twice (see
+// huge_gather_kernel), so rows of up to 128 entries take a short path: sort the composite keys, pick the values up by position
+// through the LDS, store - entry e of the sorted row IS entry e of the CSR row, and lane l's share of the row sum is its own
+// entries in turn: the sum and every value come out as merge_sorted_final forms them.  Longer rows are left to
+// merge_final_kernel (pairs_len_kernel lists them) and merge_long_final_kernel: their register networks in this loop would
+// cost every row its occupancy.
+template <typename K>
+__global__ __launch_bounds__(256) void merge_pairs_slots_kernel(const int64_t nloc, const int rpw, const FusedSrc fs,
+                                                                const int32_t* __restrict__ lenN_s, const int32_t* __restrict__ perm,
+                                                                const int64_t* __restrict__ indptr, int32_t* __restrict__ indices,
+                                                                double* __restrict__ Kdata, double* __restrict__ Pdata,
+                                                                double* __restrict__ degree, uint32_t* __restrict__ flags) {
+    __shared__ double park_all[4][128];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6));
+    double* park = park_all[w];
+    const int64_t t0 = (int64_t(blockIdx.x) * 4 + w) * rpw;
+    const int64_t t1 = t0 + rpw < nloc ? t0 + rpw : nloc;
+    struct Hdr {
+        int64_t o0, sn, dst;
+        int32_t i, ln, L;
+    };
+    struct Dat {
+        double va, vb;
+        uint32_t ka, kb;
+    };
+    auto load_hdr = [&](const int64_t p, Hdr& h) {
+        if (p < t1) {
+            h.i = perm[p];
+            h.ln = lenN_s[p];
+            h.o0 = fs.off[p];
+            h.L = int32_t(fs.off[p + 1] - h.o0);
+            h.sn = fs.sN[p];
+        }
+    };
+    auto load_dst = [&](const int64_t p, Hdr& h) {
+        if (p < t1) h.dst = indptr[h.i];
+    };
+    auto load_one = [&](const int64_t p, const Hdr& h, const int q, uint32_t& key, double& val) {
+        key = kNoKey;
+        val = 0.0;
+        if (q < h.L) {
+            if (q < h.ln) {
+                key = fs.cand_j[size_t(p) * fs.MP + q] << 1;
+                val = fs.cand_k[size_t(p) * fs.MP + q];
+            } else {
+                const int64_t r = (h.o0 - h.sn) + (q - h.ln);
+                key = (fs.ucol[r] << 1) | 1u;
+                val = fs.uval[r];
+            }
+        }
+    };
+    auto load_dat = [&](const int64_t p, const Hdr& h, Dat& x) {
+        x.ka = x.kb = kNoKey;
+        x.va = x.vb = 0.0;
+        if (p < t1 && h.L <= 128) {   // (a longer row reads itself where it is sorted)
+            load_one(p, h, lane, x.ka, x.va);
+            load_one(p, h, lane + 64, x.kb, x.vb);
+        }
+    };
+    Hdr h0 = {0, 0, 0, 0, 0, 0}, h1 = h0, h2 = h0;
+    Dat x0 = {0.0, 0.0, kNoKey, kNoKey}, x1 = x0;
+    load_hdr(t0, h0);
+    load_hdr(t0 + 1, h1);
+    load_dst(t0, h0);
+    load_dat(t0, h0, x0);
+    for (int64_t p = t0; p < t1; ++p) {
+        load_hdr(p + 2, h2);
+        load_dst(p + 1, h1);
+        load_dat(p + 1, h1, x1);
+        const int L = h0.L;
+        const int64_t row = h0.i, dst = h0.dst;
+        if (L <= 128) {
+            K pk[2];
+            pk[0] = (lane < L) ? K(~((K(x0.ka) << 7) | K(lane))) : K(0);
+            pk[1] = (lane + 64 < L) ? K(~((K(x0.kb) << 7) | K(lane + 64))) : K(0);
+            park[lane] = x0.va;
+            park[lane + 64] = x0.vb;
+            if (L <= 64) {   // (uniform)
+                K p1[1] = {pk[0]};
+                wave_bitonic_desc<1, K>(p1, lane);
+                pk[0] = p1[0];
+            } else {
+                wave_bitonic_desc<2, K>(pk, lane);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            double m[2];
+            bool has_diag = false;
+            double lsum = 0.0;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                m[t] = 0.0;
+                if (pk[t] != K(0)) {   // (the entries come out in front: slot e of the sorted row is entry e of the CSR row)
+                    const K x = K(~pk[t]);
+                    const uint32_t key = uint32_t(x >> 7);
+                    const double v = park[int(uint32_t(x) & 127u)];
+                    const int tag = int(key & 1u);
+                    const uint32_t col = key >> 1;
+                    m[t] = (tag == 0 && v < 0.0) ? -v : merge_values(tag == 0 ? v : 0.0, tag == 1 ? v : 0.0, GT_SYMM_ADD, 1.0);
+                    const int e = t * 64 + lane;
+                    indices[dst + e] = int32_t(col);
+                    Kdata[dst + e] = m[t];
+                    has_diag |= int64_t(col) == row && m[t] != 0.0;
+                    lsum += m[t];
+                }
+            }
+            const double sum = wave_sum_f64(lsum);
+            const bool any_diag = __ballot(has_diag) != 0ull;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+                if (pk[t] != K(0)) Pdata[dst + t * 64 + lane] = (sum != 0.0) ? m[t] / sum : m[t];
+            if (lane == 0) {
+                degree[row] = sum;
+                if (!any_diag) atomicOr(flags, GT_FLAG_ZERO_DIAGONAL);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();   // (the next row parks into the same slots)
+        }   // (longer rows: merge_final_kernel over the listed rows, merge_long_final_kernel)
+        h0 = h1;
+        h1 = h2;
+        x0 = x1;
     }
 }
 
@@ -2754,14 +2886,29 @@ static int graph_finish_impl(gt_ctx* ctx, const void* recv_buf_dev, int64_t n_re
 __global__ __launch_bounds__(256) void pairs_len_kernel(const int64_t nloc, const int32_t* __restrict__ pos,
                                                         const int64_t* __restrict__ off, int32_t* __restrict__ outlen,
                                                         int32_t* __restrict__ biglist, uint32_t* __restrict__ bigcount,
-                                                        uint32_t* __restrict__ fflags) {
+                                                        uint32_t* __restrict__ fflags, int32_t* __restrict__ midlist) {
+    // midlist (optional): the rows of 129 ... kBigRow entries, counted in bigcount[1] (one atomic per wave)
     // bigcount: [0] rows for merge_long_final_kernel (listed from biglist[0] upwards), [2] = fflags, [4] rows beyond the
     // register sorts (listed from biglist[nloc - 1] downwards), [6..7] their entries in all (64 bit)
     const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    int64_t L = 0;
+    if (i < nloc) {
+        const int64_t p = pos[i];
+        L = off[p + 1] - off[p];
+        outlen[i] = int32_t(L);
+    }
+    if (midlist) {   // (uniform)
+        const bool mid = L > 128 && L <= kBigRow;
+        const unsigned long long mm = __ballot(mid);
+        if (mm != 0ull) {
+            const int lane = threadIdx.x & 63;
+            uint32_t base = 0u;
+            if (lane == 0) base = atomicAdd(bigcount + 1, uint32_t(__popcll(mm)));
+            base = uint32_t(__shfl(int(base), 0));
+            if (mid) midlist[base + uint32_t(__popcll(mm & ((1ull << lane) - 1ull)))] = int32_t(i);
+        }
+    }
     if (i >= nloc) return;
-    const int64_t p = pos[i];
-    const int64_t L = off[p + 1] - off[p];
-    outlen[i] = int32_t(L);
     if (L > kBigRow) {
         if (L > kPairHugeRow) {
             atomicOr(fflags, kFusedHugeRow);
@@ -2796,7 +2943,8 @@ static int graph_finish_pairs(gt_ctx* ctx, int64_t* out_nnz, uint32_t* flags) {
     GT_HIP(ctx, g->off.reserve(size_t(nloc + 1) * sizeof(int64_t)));
     GT_HIP(ctx, g->outlen.reserve(size_t(nloc) * sizeof(int32_t)));
     GT_HIP(ctx, g->bigrows.reserve(size_t(nloc) * sizeof(int32_t)));
-    GT_HIP(ctx, g->bigcount.reserve(8 * sizeof(uint32_t)));   // [0] long rows, [2] flags, [4] huge rows, [6..7] their entries (pairs_len_kernel)
+    GT_HIP(ctx, g->bigcount.reserve(8 * sizeof(uint32_t)));   // [0] long rows, [1] rows of 129 ... kBigRow entries, [2] flags, [4] huge rows, [6..7] their entries (pairs_len_kernel)
+    if (fused) GT_HIP(ctx, g->midrows.reserve(size_t(nloc) * sizeof(int32_t)));
     GT_HIP(ctx, g->indptr.reserve(size_t(nloc + 1) * sizeof(int64_t)));
     GT_HIP(ctx, g->degree.reserve(size_t(nloc) * sizeof(double)));
     GT_HIP(ctx, hipMemsetAsync(g->bigcount.p, 0, 8 * sizeof(uint32_t), ctx->stream));
@@ -2840,11 +2988,12 @@ static int graph_finish_pairs(gt_ctx* ctx, int64_t* out_nnz, uint32_t* flags) {
     // final row lengths (own + received: nothing merges), CSR offsets in row order
     hipLaunchKernelGGL(pairs_len_kernel, dim3((unsigned)ceil_div64(nloc, 256)), dim3(256), 0, ctx->stream, nloc,
                        k->sh_invperm.as<int32_t>(), g->off.as<int64_t>(), g->outlen.as<int32_t>(), g->bigrows.as<int32_t>(),
-                       g->bigcount.as<uint32_t>(), fflags);
+                       g->bigcount.as<uint32_t>(), fflags, fused ? g->midrows.as<int32_t>() : (int32_t*)nullptr);
     GT_HIP(ctx, hipGetLastError());
     GT_TRY(exclusive_scan(ctx, g->outlen.as<int32_t>(), nullptr, nloc, g->indptr.as<int64_t>(), g->scan_tmp));
     int64_t nnz = 0;
-    uint32_t ff = 0;
+    uint32_t ff = 0, n_mid = 0;
+    GT_HIP(ctx, hipMemcpyAsync(&n_mid, g->bigcount.as<uint32_t>() + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     uint32_t huge_host[4] = {0, 0, 0, 0};   // [0] rows beyond the register sorts, [2..3] their entries
     GT_HIP(ctx, hipMemcpyAsync(&nnz, g->indptr.as<int64_t>() + nloc, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
     GT_HIP(ctx, hipMemcpyAsync(&ff, fflags, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -2946,10 +3095,28 @@ static int graph_finish_pairs(gt_ctx* ctx, int64_t* out_nnz, uint32_t* flags) {
             GT_HIP(ctx, hipGetLastError());
         }
         GT_HIP(ctx, hipEventRecord(ctx->side_event, ctx->side_stream));
+        const int key32 = (ctx->symm_key32 != 0 && sort_key_fits_u32(g->n_total, 8)) ? 1 : 0;
+        if (fused) {
+            const int rpw = 8;
+            // (the short path's composite keys: column, tag and 7 position bits)
+            if (ctx->symm_key32 != 0 && sort_key_fits_u32(g->n_total, 2))
+                hipLaunchKernelGGL(merge_pairs_slots_kernel<uint32_t>, dim3((unsigned)ceil_div64(nloc, int64_t(4) * rpw)), dim3(256), 0,
+                                   ctx->stream, nloc, rpw, fs, g->cnt_sorted.as<int32_t>(), perm, g->indptr.as<int64_t>(),
+                                   g->indices.as<int32_t>(), g->Kdata.as<double>(), g->Pdata.as<double>(), g->degree.as<double>(),
+                                   g->flags.as<uint32_t>());
+            else
+                hipLaunchKernelGGL(merge_pairs_slots_kernel<uint64_t>, dim3((unsigned)ceil_div64(nloc, int64_t(4) * rpw)), dim3(256), 0,
+                                   ctx->stream, nloc, rpw, fs, g->cnt_sorted.as<int32_t>(), perm, g->indptr.as<int64_t>(),
+                                   g->indices.as<int32_t>(), g->Kdata.as<double>(), g->Pdata.as<double>(), g->degree.as<double>(),
+                                   g->flags.as<uint32_t>());
+            if (n_mid > 0)
+                hipLaunchKernelGGL(merge_final_kernel, dim3(n_mid), dim3(64), 0, ctx->stream, int64_t(n_mid), fs, g->indptr.as<int64_t>(),
+                                   g->indices.as<int32_t>(), g->Kdata.as<double>(), g->Pdata.as<double>(), g->degree.as<double>(),
+                                   g->flags.as<uint32_t>(), key32, g->midrows.as<int32_t>());
+        } else
         hipLaunchKernelGGL(merge_final_kernel, dim3((unsigned)ceil_div64(nloc, 1)), dim3(64), 0, ctx->stream, nloc, fs,
                            g->indptr.as<int64_t>(), g->indices.as<int32_t>(), g->Kdata.as<double>(), g->Pdata.as<double>(),
-                           g->degree.as<double>(), g->flags.as<uint32_t>(),
-                           (ctx->symm_key32 != 0 && sort_key_fits_u32(g->n_total, 8)) ? 1 : 0);
+                           g->degree.as<double>(), g->flags.as<uint32_t>(), key32, (const int32_t*)nullptr);
         GT_HIP(ctx, hipGetLastError());
         GT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->side_event, 0));
     }
