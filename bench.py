@@ -363,8 +363,10 @@ def kernel_table(ctx, st, n, nloc, d, world, nnz, nnz0, main):
         st.mean("rerank"),
         nloc * tab * 8.0 + n * d * 4.0 + nloc * tab * 12.0,
         "candidate lists in (8 B), X once, exact tables out (8 + 4 B); the row gathers come from L2/MALL")
-    hbm("affinity", "bandwidth_kernel + affinity_kernel", st.mean("affinity"), nloc * tab * 12.0 + nnz0 * 8.0,
-        "tables in (8 + 4 B per entry), kept values written in place")
+    # (tables by sorted position + no row of the radius pass: the pipelined slot kernels of round 5 - st.mean("symm_bins") of such
+    #  a build holds no bin_count_kernel; which ones ran shows in the kernel names of the committed rocprofv3 summary)
+    hbm("affinity", "bandwidth_kernel + affinity_slots_kernel (+ posj_hist_kernel) | affinity_kernel", st.mean("affinity"),
+        nloc * tab * 12.0 + nnz0 * 8.0, "tables in (8 + 4 B per entry), kept values written in place")
     if st.mean("symm_merge") > 0 and st.mean("symm_compact") > 0:
         # the three launch groups of the symmetrisation, each priced on what IT has to move (the stage as a whole is priced
         # on SURVEY 8d's bytes in `sparse_tail`)
@@ -378,9 +380,9 @@ def kernel_table(ctx, st, n, nloc, d, world, nnz, nnz0, main):
         # pair-resolved tail: mutual pairs were settled by the affinity pass, only one-sided entries (nnz - nnz0 of them)
         # are transposed, the merge writes K and P at their final place
         one_sided = float(nnz - nnz0)
-        hbm("symm_bins", "bin_count_kernel + bin_emit_kernel + bin_fill_kernel", st.mean("symm_bins"),
-            nnz0 * 12.0 + one_sided * 12.0, "kept entries in, one-sided entries out (12 B each)")
-        hbm("symm_merge", "merge_final_kernel (+ merge_long_final_kernel)", st.mean("symm_merge"),
+        hbm("symm_bins", "bin_emit_slots_kernel + bin_fill_kernel | bin_count_kernel + bin_emit_kernel + bin_fill_kernel",
+            st.mean("symm_bins"), nnz0 * 12.0 + one_sided * 12.0, "kept entries in, one-sided entries out (12 B each)")
+        hbm("symm_merge", "merge_pairs_slots_kernel + merge_final_kernel (+ merge_long_final_kernel)", st.mean("symm_merge"),
             nnz0 * 12.0 + one_sided * 12.0 + nnz * 20.0, "own and received entries in, CSR K (4 + 8 B) and P (8 B) out")
     else:
         hbm("symmetrize", "symmetrise + compact (K, P)", st.mean("symmetrize"),
@@ -759,8 +761,9 @@ def main():
         # tables in / kept values out (affinity); read K0 and K0^T entries, write K; read K, write P
         tail_bytes = (sum(r["algorithmic_bytes"] for r in rows if r["stage"] == "affinity")
                       + 2.0 * nnz0 * 12.0 + nnz * 12.0 + nnz * 12.0 + nnz * 8.0)
-        tail_counter = profiled_traffic(["bandwidth_kernel", "affinity_kernel", "bin_", "sort_merge_kernel", "sort_merge_long_kernel",
-                                         "compact_kernel", "merge_final_kernel", "merge_long_final_kernel", "pairs_len_kernel", "scan_",
+        tail_counter = profiled_traffic(["bandwidth_kernel", "affinity_kernel", "affinity_slots_kernel", "posj_hist_kernel", "bin_",
+                                         "sort_merge_kernel", "sort_merge_long_kernel", "compact_kernel", "merge_final_kernel",
+                                         "merge_pairs_slots_kernel", "merge_long_final_kernel", "pairs_len_kernel", "scan_",
                                          "gather_counts_kernel", "scatter_", "invperm_kernel"], per="graph") if (n == 1000000 and d == 64 and world == 1 and args.workload == "c3") else None
         wl_name = {"c3": "C3: mix N=%d d=%d float32 seed=1, kNNGraph knn=%d decay=%g thresh=1e-4, kernel_symm='+', points resident "
                          "in HBM, device-complete K and P" % (n, d, args.knn, args.decay),

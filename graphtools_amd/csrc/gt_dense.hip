@@ -1627,7 +1627,7 @@ extern "C" int gt_dense_graph_build(gt_ctx* ctx, const void* X_or_D, int64_t n, 
     uint32_t fl = 0;
     DENSE_HIP(hipMemcpyAsync(&fl, st.flags.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     DENSE_HIP(hipStreamSynchronize(ctx->stream));
-    if (!precomputed && ctx->knn) {
+    if (!precomputed && ctx->knn && ctx->knn->gflags.p) {   // (a search that was refused before its first launch leaves no flags)
         uint32_t kfl = 0;
         DENSE_HIP(hipMemcpy(&kfl, ctx->knn->gflags.p, sizeof(uint32_t), hipMemcpyDeviceToHost));
         fl |= (kfl & GT_FLAG_DUPLICATES);

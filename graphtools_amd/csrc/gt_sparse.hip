@@ -3019,6 +3019,16 @@ static int graph_finish_pairs(gt_ctx* ctx, int64_t* out_nnz, uint32_t* flags) {
         }
         uint32_t nbig = 0;
         (void)hipMemcpy(&nbig, g->bigcount.p, sizeof(uint32_t), hipMemcpyDeviceToHost);
+        {
+            std::vector<int64_t> bo(nbins + 1);
+            (void)hipMemcpy(bo.data(), g->binoff.p, size_t(nbins + 1) * 8, hipMemcpyDeviceToHost);
+            std::vector<int64_t> bs(nbins);
+            for (int b = 0; b < nbins; ++b) bs[b] = bo[b + 1] - bo[b];
+            std::sort(bs.begin(), bs.end());
+            std::fprintf(stderr, "[gt] destination bins: %d of %d rows, triplets per bin min %lld median %lld mean %.0f p90 %lld p99 %lld max %lld\n", nbins,
+                         1 << shift, (long long)bs[0], (long long)bs[nbins / 2], double(bo[nbins]) / nbins, (long long)bs[nbins * 9 / 10],
+                         (long long)bs[nbins * 99 / 100], (long long)bs[nbins - 1]);
+        }
         int64_t hist[6] = {0, 0, 0, 0, 0, 0};   // rows of up to 64, 128, 256, 512, 1024, more entries
         for (int64_t i = 0; i < nloc; ++i) ++hist[ol[i] <= 64 ? 0 : ol[i] <= 128 ? 1 : ol[i] <= 256 ? 2 : ol[i] <= 512 ? 3 : ol[i] <= 1024 ? 4 : 5];
         std::fprintf(stderr, "[gt] pair-resolved tail: flags %u, nnz %lld, own entries %lld; longest row %lld (row %lld), negative %lld, off not monotone at %lld places, off[n] %lld; "

@@ -143,18 +143,22 @@ def _build_pairs(X, pairs, knn=15, decay=40.0, bandwidth=None, opts=()):
     return out
 
 
+@pytest.mark.parametrize("pairs", [1, 2])
 @pytest.mark.parametrize("n,d,maker,seed,kw", [
     (20000, 32, make_mix, 3, {}),
     (30000, 24, make_manifold, 4, {"knn": 10, "decay": 20.0}),
     (16000, 16, make_mix, 5, {"knn": 5, "decay": 8.0}),                  # wide kernel: radius rows, long union rows
     (9000, 40, make_mix, 6, {"bandwidth": 6.0}),                          # caller's bandwidth
 ])
-def test_pair_resolved_tail_equals_the_general_tail(n, d, maker, seed, kw):
+def test_pair_resolved_tail_equals_the_general_tail(n, d, maker, seed, kw, pairs):
     """'+' rule, single rank: every row settles its mutual pairs itself from the transposed keys the re-rank left next to its
     table (or from the dot products where the table came from a repair / radius pass), only one-sided entries travel, the merge
-    writes K and P at their final place.  Bar: K (structure and values) and P bit for bit those of the general tail."""
+    writes K and P at their final place.  Bar: K (structure and values) and P bit for bit those of the general tail.
+    pairs = 2 (the default since round 5): the tables lie by sorted position and - where no row took the radius pass - the
+    affinity pass looks the destinations up itself, the emit and the merge walk the slots (affinity_slots_kernel,
+    bin_emit_slots_kernel, merge_pairs_slots_kernel); with rows of the radius pass the kernels of pairs = 1 read those tables."""
     X = maker(n, d, seed)
-    a = _build_pairs(X, 1, **kw)
+    a = _build_pairs(X, pairs, **kw)
     b = _build_pairs(X, 0, **kw)
     assert b[0][2] == "general" and b[1][2] == "general"
     assert a[0][4]["symmetric"], "the symmetric candidate pass did not run: nothing was tested"
@@ -166,13 +170,14 @@ def test_pair_resolved_tail_equals_the_general_tail(n, d, maker, seed, kw):
         assert a[1][2] == "pairs"
 
 
-def test_pair_resolved_tail_gives_way_to_hub_rows():
+@pytest.mark.parametrize("pairs", [1, 2])
+def test_pair_resolved_tail_gives_way_to_hub_rows(pairs):
     """a point set with a hub (many rows keep one row that keeps few of them): its union row is longer than the register sorts
     hold - that row is sorted by rocPRIM's segmented sort behind the others (same bits as the general tail)"""
     rng = np.random.default_rng(8)
     X = make_mix(24000, 12, 8)
     X[:4000] = X[4000] + 0.35 * rng.standard_normal((4000, 12)).astype(np.float32)    # a dense knot around one point
-    a = _build_pairs(X, 1, knn=4, decay=3.0)
+    a = _build_pairs(X, pairs, knn=4, decay=3.0)
     b = _build_pairs(X, 0, knn=4, decay=3.0)
     for x, y in zip(a, b):
         _same(x, y)
@@ -183,7 +188,7 @@ def test_pair_resolved_tail_gives_way_to_hub_rows():
     # ... and where the option says so they refute the path as they used to: the build is redone the general way, the refuted
     # first attempt stays in the stage timers (its launches are counted next to the second attempt's); once the verdict is in,
     # a build is one attempt
-    c = _build_pairs(X, 1, knn=4, decay=3.0, opts=(("symmetrize_pairs_huge", 0),))
+    c = _build_pairs(X, pairs, knn=4, decay=3.0, opts=(("symmetrize_pairs_huge", 0),))
     for x, y in zip(c, b):
         _same(x, y)
     assert c[0][2] == "general" and c[1][2] == "general"

@@ -88,6 +88,10 @@ def main():
             forced.append(("select_sym_dense_seed", "0"))
         if rng.random() < 0.5:
             forced.append(("select_sym_cold_local", "0"))     # (the global-frame cold launch of rounds 2-4 against the default)
+        if rng.random() < 0.5:
+            forced.append(("symmetrize_bins", "1"))           # (the bin transpose - and with it the pair-resolved tail - below 65536 rows too)
+        if rng.random() < 0.3:
+            forced.append(("symmetrize_pairs", "1"))          # (tables by row, round 4, against the default: by sorted position)
         classic = [("metric", metric), ("select_symmetric", "0"), ("symmetrize_pairs", "0")]
         desc = dict(case=case, kind=kind, n=n, d=d, dtype=np.dtype(dtype).name, knn=knn, decay=decay, thresh=thresh, symm=symm,
                     theta=theta, aniso=aniso, metric=metric, bw=("vector" if isinstance(bw, np.ndarray) else bw),
