@@ -1195,6 +1195,109 @@ __global__ __launch_bounds__(256) void assign_cells_kernel(const float* __restri
     }
 }
 
+// The same assignment with two query tiles per wave and 64 landmarks per barrier (launches of many rows: C3).  assign_cells_kernel
+// reads every landmark fragment from the LDS once per 32 queries and meets at a barrier every 32 landmarks - at L = n / 512
+// landmarks the launch ran at 13 % of the float16 peak, waiting on both.  Here a fragment serves 64 queries and a barrier 64
+// landmarks.  Scores, ties and therefore cells / thr0 / best are those of assign_cells_kernel bit for bit (the same chain per
+// (query, landmark) pair, the same first-wins rule per accumulator slot in the same landmark order).
+template <int DP>
+__global__ __launch_bounds__(256) void assign_cells2_kernel(const float* __restrict__ Yc, const float* __restrict__ Yl,
+                                                            const float* __restrict__ hl, const int64_t q0,
+                                                            const int32_t nq, const int32_t L, const int32_t need,
+                                                            uint32_t* __restrict__ cell, float* __restrict__ thr0,
+                                                            float* __restrict__ best_out) {
+    constexpr int RW = DP / 2;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, li = lane & 31, h = lane >> 5;
+    const int64_t qa = int64_t(blockIdx.x) * 256 + w * 64 + li;   // this lane's queries: qa and qa + 32
+    Frag<DP, 2> bq[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int64_t q = qa + 32 * t;
+        const int64_t qc = q < nq ? q : int64_t(nq) - 1;
+        bq[t].load(Yc + (q0 + qc) * RW, h);
+    }
+    float gm[2][16];
+    int gl[2][16];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            gm[t][e] = -INFINITY;
+            gl[t][e] = 0;
+        }
+    constexpr int LDPA = RW + 4;
+    __shared__ __attribute__((aligned(16))) float lmk[2][64 * LDPA];
+    __shared__ __attribute__((aligned(16))) float lsd[2][64];
+    auto stage = [&](int l0, int buf) {
+        const int rows = L - l0 < 64 ? L - l0 : 64;   // (L is a multiple of 32)
+        for (int f = threadIdx.x; f < rows * (RW / 4); f += 256) {
+            const int r = f / (RW / 4), c4 = f % (RW / 4);
+            *reinterpret_cast<float4*>(&lmk[buf][r * LDPA + 4 * c4]) =
+                *reinterpret_cast<const float4*>(Yl + size_t(l0 + r) * RW + 4 * c4);
+        }
+        if (threadIdx.x < rows) lsd[buf][threadIdx.x] = hl[l0 + threadIdx.x];
+    };
+    stage(0, 0);
+    __syncthreads();
+    for (int l0 = 0, buf = 0; l0 < L; l0 += 64, buf ^= 1) {
+        if (l0 + 64 < L) stage(l0 + 64, buf ^ 1);   // the other buffer was released by the barrier that ended the last step
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            if (l0 + 32 * s < L) {   // (uniform)
+                Frag<DP, 2> a;
+                a.load(&lmk[buf][(32 * s + li) * LDPA], h);
+                f32x16 seed;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 hv = *reinterpret_cast<const float4*>(&lsd[buf][32 * s + 8 * g + 4 * h]);
+                    seed[4 * g + 0] = hv.x;
+                    seed[4 * g + 1] = hv.y;
+                    seed[4 * g + 2] = hv.z;
+                    seed[4 * g + 3] = hv.w;
+                }
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    f32x16 acc = seed;
+                    mma_chain<DP>(a, bq[t], acc);
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const bool better = acc[e] > gm[t][e];
+                        gm[t][e] = better ? acc[e] : gm[t][e];
+                        gl[t][e] = better ? l0 + 32 * s : gl[t][e];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int64_t q = qa + 32 * t;
+        float best = gm[t][0];
+        uint32_t bidx = uint32_t(gl[t][0] + 4 * h);
+#pragma unroll
+        for (int e = 1; e < 16; ++e) {
+            const uint32_t idx = uint32_t(gl[t][e] + 8 * (e >> 2) + 4 * h + (e & 3));
+            const bool better = gm[t][e] > best || (gm[t][e] == best && idx < bidx);
+            best = better ? gm[t][e] : best;
+            bidx = better ? idx : bidx;
+        }
+        float gmin = gm[t][0];
+#pragma unroll
+        for (int e = 1; e < 16; ++e) gmin = fminf(gmin, gm[t][e]);
+        const float gother = __shfl_xor(gmin, 32);
+        gmin = need <= 16 ? fmaxf(gmin, gother) : fminf(gmin, gother);
+        const float ob = __shfl_xor(best, 32);
+        const uint32_t oi = __shfl_xor(bidx, 32);
+        if (ob > best || (ob == best && oi < bidx)) bidx = oi;
+        if (h == 0 && q < nq) {
+            cell[q] = bidx;
+            thr0[q] = gmin;
+            if (best_out) best_out[q] = fmaxf(best, ob);
+        }
+    }
+}
+
 // The wave regions of the collect launch -> one dense queue (order does not matter): one wave per region, its slots in
 // the dense queue from one atomic.  total (pre-zeroed): entries copied; flag (pre-zeroed): the largest region count.
 __global__ __launch_bounds__(256) void sym_queue_compact_kernel(const uint2* __restrict__ regions,
@@ -1804,8 +1907,13 @@ int launch_dp(gt_ctx* ctx, const SelectArgs& a) {
 int GT_CAT3(gt_launch_assign_cells_p, GT_SEL_PREC, _dp, GT_SEL_DP)(gt_ctx* ctx, const float* Yc, const float* Yl,
                                                                   const float* hl, int64_t q0, int32_t nq, int32_t L,
                                                                   int32_t need, uint32_t* cell, float* thr0, float* best) {
-    hipLaunchKernelGGL(assign_cells_kernel<GT_SEL_DP>, dim3((unsigned)ceil_div64(nq, 128)), dim3(256), 0, ctx->stream, Yc,
-                       Yl, hl, q0, nq, L, need, cell, thr0, best);
+    // (two query tiles per wave from 2^17 rows: below that the 128-row workgroups fill the machine better)
+    if (nq >= (1 << 17) && !(ctx->dbg_select & 16384))
+        hipLaunchKernelGGL(assign_cells2_kernel<GT_SEL_DP>, dim3((unsigned)ceil_div64(nq, 256)), dim3(256), 0, ctx->stream, Yc,
+                           Yl, hl, q0, nq, L, need, cell, thr0, best);
+    else
+        hipLaunchKernelGGL(assign_cells_kernel<GT_SEL_DP>, dim3((unsigned)ceil_div64(nq, 128)), dim3(256), 0, ctx->stream, Yc,
+                           Yl, hl, q0, nq, L, need, cell, thr0, best);
     GT_HIP(ctx, hipGetLastError());
     return GT_OK;
 }
