@@ -99,6 +99,7 @@ void gt_ctx_destroy(gt_ctx* ctx) {
     ctx->dense_bw.release();
     ctx->X_norm.release();
     for (DevBuf* b : {&ctx->land_Y, &ctx->land_h, &ctx->order_cell, &ctx->order_rows, &ctx->order_tmp, &ctx->vperm, &ctx->vcell, &ctx->land_X, &ctx->land_Yp, &ctx->land_xn}) b->release();
+    if (ctx->mail) (void)hipHostFree(ctx->mail);
     if (ctx->side_event) (void)hipEventDestroy(ctx->side_event);
     if (ctx->side_stream) {
         (void)hipStreamSynchronize(ctx->side_stream);

@@ -119,6 +119,19 @@ struct gt_ctx {
     hipStream_t stream = nullptr;
     hipStream_t side_stream = nullptr;   // created on first use: a launch that may overlap the main stream's (see side_launch_begin / end)
     hipEvent_t side_event = nullptr;
+    // Small read-backs (counters, flags, totals) land in a pinned mailbox: copies into pageable memory are staged one host round
+    // trip each (~17 us of idle stream per copy on the C3 timeline, three or four in a row at the read-back points of a build);
+    // into pinned memory they queue behind each other and the one synchronisation that follows takes them all.
+    unsigned char* mail = nullptr;   // 1 KB, hipHostMalloc on first use
+    size_t mail_used = 0;
+    void* mail_slot(size_t bytes) {
+        if (!mail && hipHostMalloc(reinterpret_cast<void**>(&mail), 1024, hipHostMallocDefault) != hipSuccess) mail = nullptr;
+        bytes = (bytes + 7) & ~size_t(7);
+        if (!mail || mail_used + bytes > 1024) return nullptr;
+        void* r = mail + mail_used;
+        mail_used += bytes;
+        return r;
+    }
     std::string err;
     std::map<std::string, StageAcc> stages;
     std::vector<hipEvent_t> event_pool;
@@ -306,6 +319,34 @@ struct StageSpan {
 };
 
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// A group of small device -> host read-backs with ONE synchronisation: add() queues a copy into the context's pinned mailbox
+// (straight into `dst` when the mailbox is full or missing), sync() waits for the stream and hands the values out.  The group
+// lives on the stack of the function whose locals receive the values.
+struct ReadBack {
+    gt_ctx* ctx;
+    struct Item {
+        void* dst;
+        const void* slot;
+        size_t bytes;
+    };
+    Item items[8];
+    int n = 0;
+    explicit ReadBack(gt_ctx* c) : ctx(c) { c->mail_used = 0; }
+    hipError_t add(void* dst, const void* dev, size_t bytes) {
+        void* slot = n < 8 ? ctx->mail_slot(bytes) : nullptr;
+        if (!slot) return hipMemcpyAsync(dst, dev, bytes, hipMemcpyDeviceToHost, ctx->stream);
+        items[n++] = Item{dst, slot, bytes};
+        return hipMemcpyAsync(slot, dev, bytes, hipMemcpyDeviceToHost, ctx->stream);
+    }
+    hipError_t sync() {
+        const hipError_t e = hipStreamSynchronize(ctx->stream);
+        if (e == hipSuccess)
+            for (int i = 0; i < n; ++i) std::memcpy(items[i].dst, items[i].slot, items[i].bytes);
+        n = 0;
+        return e;
+    }
+};
 
 // GT_TRACE=1: host wall-clock trace of the coarse steps of a call (development aid; synchronises the stream)
 struct HostTrace {

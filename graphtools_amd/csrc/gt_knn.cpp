@@ -623,13 +623,15 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
                 ra.trow = k->sh_invperm.as<int32_t>();
             }
             k->nokeyt_n = 0;
-            if (wrote_t)
-                GT_HIP(ctx, hipMemcpyAsync(&k->nokeyt_n, k->nokeyt_count.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
             uint32_t n_unproven = 0;
-            GT_HIP(ctx, hipMemcpyAsync(&n_fb, k->fb_count.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-            GT_HIP(ctx, hipMemcpyAsync(&n_unproven, k->unproven.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-            GT_HIP(ctx, hipMemcpyAsync(k->sym_stat_host, k->sym_stat.p, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
-            GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            {
+                ReadBack rb(ctx);
+                if (wrote_t) GT_HIP(ctx, rb.add(&k->nokeyt_n, k->nokeyt_count.p, sizeof(uint32_t)));
+                GT_HIP(ctx, rb.add(&n_fb, k->fb_count.p, sizeof(uint32_t)));
+                GT_HIP(ctx, rb.add(&n_unproven, k->unproven.p, sizeof(uint32_t)));
+                GT_HIP(ctx, rb.add(k->sym_stat_host, k->sym_stat.p, 8 * sizeof(unsigned long long)));
+                GT_HIP(ctx, rb.sync());
+            }
             k->sym_overflow = int64_t(k->sym_stat_host[0]);
             if (ctx->sym_mode < 0 && double(k->sym_overflow) > 0.10 * double(nq)) {
                 // neighbourhoods too large for the fixed lists (every overflowing row costs a repair): this point set

@@ -2400,10 +2400,13 @@ static int graph_begin_impl(gt_ctx* ctx, const gt_knn_params* params, int32_t wo
         GT_HIP(ctx, g->sC.reserve(size_t(g->nloc + 1) * sizeof(int64_t)));
         GT_TRY(exclusive_scan(ctx, reinterpret_cast<const int32_t*>(k->cand_n.as<uint32_t>()), nullptr, g->nloc, g->sC.as<int64_t>(),
                               g->scan_tmp));
-        GT_HIP(ctx, hipMemcpyAsync(&sc_total, g->sC.as<int64_t>() + g->nloc, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
     }
-    GT_HIP(ctx, hipMemcpyAsync(&n_over, g->over_count.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-    GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    {
+        ReadBack rb(ctx);
+        if (k->tab_sorted) GT_HIP(ctx, rb.add(&sc_total, g->sC.as<int64_t>() + g->nloc, sizeof(int64_t)));
+        GT_HIP(ctx, rb.add(&n_over, g->over_count.p, sizeof(uint32_t)));
+        GT_HIP(ctx, rb.sync());
+    }
     g->n_over = n_over;
     if (n_over > 0) {
         // ---- radius pass over the rows whose table is not provably complete out to their radius ----
@@ -2998,12 +3001,17 @@ static int graph_finish_pairs(gt_ctx* ctx, int64_t* out_nnz, uint32_t* flags) {
     GT_TRY(exclusive_scan(ctx, g->outlen.as<int32_t>(), nullptr, nloc, g->indptr.as<int64_t>(), g->scan_tmp));
     int64_t nnz = 0;
     uint32_t ff = 0, n_mid = 0;
-    GT_HIP(ctx, hipMemcpyAsync(&n_mid, g->bigcount.as<uint32_t>() + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     uint32_t huge_host[4] = {0, 0, 0, 0};   // [0] rows beyond the register sorts, [2..3] their entries
-    GT_HIP(ctx, hipMemcpyAsync(&nnz, g->indptr.as<int64_t>() + nloc, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
-    GT_HIP(ctx, hipMemcpyAsync(&ff, fflags, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-    GT_HIP(ctx, hipMemcpyAsync(huge_host, g->bigcount.as<uint32_t>() + 4, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-    GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    {
+        uint32_t bc[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // (pairs_len_kernel's counters, one copy)
+        ReadBack rb(ctx);
+        GT_HIP(ctx, rb.add(&nnz, g->indptr.as<int64_t>() + nloc, sizeof(int64_t)));
+        GT_HIP(ctx, rb.add(bc, g->bigcount.p, 8 * sizeof(uint32_t)));
+        GT_HIP(ctx, rb.sync());
+        n_mid = bc[1];
+        ff = bc[2];
+        for (int q = 0; q < 4; ++q) huge_host[q] = bc[4 + q];
+    }
     const uint32_t n_huge = huge_host[0];
     const unsigned long long huge_total = (unsigned long long)huge_host[2] | ((unsigned long long)huge_host[3] << 32);
     if (ctx->dbg_select & 2048) {
@@ -3137,9 +3145,12 @@ static int graph_finish_pairs(gt_ctx* ctx, int64_t* out_nnz, uint32_t* flags) {
         GT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->side_event, 0));
     }
     uint32_t fl = 0, kfl = 0;
-    GT_HIP(ctx, hipMemcpyAsync(&fl, g->flags.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-    GT_HIP(ctx, hipMemcpyAsync(&kfl, k->gflags.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-    GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    {
+        ReadBack rb(ctx);
+        GT_HIP(ctx, rb.add(&fl, g->flags.p, sizeof(uint32_t)));
+        GT_HIP(ctx, rb.add(&kfl, k->gflags.p, sizeof(uint32_t)));
+        GT_HIP(ctx, rb.sync());
+    }
     g->nnz0 = n_own;
     g->nnz = nnz;
     g->finished = true;
