@@ -152,8 +152,74 @@ def load_library():
 
 
 def release_cached_memory():
-    """Hand the device memory parked by closed contexts (see gt_release_cached_memory) back to the driver."""
+    """Hand the device memory parked by closed contexts (see gt_release_cached_memory) back to the driver, and drop the host
+    blocks kept for result arrays (``_HostPool``)."""
     load_library().gt_release_cached_memory()
+    _host_pool.clear()
+
+
+class _HostPool:
+    """Host memory for the big result arrays (the CSR of a graph: 2.3 GB at N = 1e6), RE-USED once nobody refers to an earlier
+    result any more.  A fresh ``np.empty`` costs the copy threads a page fault per 4 KB they write - at 2.3 GB that is a third of
+    the device -> host time of a graph (31 ms against 25 for resident memory, more with torch's allocator in the process).  A block
+    is an array OF THE REQUESTED DTYPE the pool keeps a reference to (scipy's CSR constructor copies a float64 view of a byte
+    block, it keeps a slice of a float64 array); callers get the head of it, whose ``base`` is the block: the block's
+    reference count tells whether any array of an earlier result is still alive, and only a block nobody else refers to is
+    handed out again (``np.empty`` semantics: the content is whatever was there).  At most ``GRAPHTOOLS_AMD_HOST_POOL_GB``
+    (default 8, 0 = off) stay cached; ``release_cached_memory()`` drops them."""
+
+    MIN_BYTES = 32 << 20
+    ROUND = 16 << 20
+
+    def __init__(self):
+        import threading
+
+        self.blocks = []   # least recently used first
+        self.lock = threading.Lock()
+        try:
+            self.cap = int(float(os.environ.get("GRAPHTOOLS_AMD_HOST_POOL_GB", "8")) * (1 << 30))
+        except ValueError:
+            self.cap = 8 << 30
+
+    def clear(self):
+        with self.lock:
+            self.blocks = []
+
+    def empty(self, count, dtype):
+        import sys
+
+        dtype = np.dtype(dtype)
+        nbytes = int(count) * dtype.itemsize
+        if self.cap <= 0 or nbytes < self.MIN_BYTES:
+            return np.empty(count, dtype=dtype)
+        with self.lock:
+            best = -1
+            for idx in range(len(self.blocks)):
+                # references to a free block: the list's, and getrefcount's own argument
+                if (nbytes <= self.blocks[idx].nbytes <= nbytes + nbytes // 4 + 4 * self.ROUND
+                        and self.blocks[idx].dtype == dtype and sys.getrefcount(self.blocks[idx]) == 2
+                        and (best < 0 or self.blocks[idx].nbytes < self.blocks[best].nbytes)):
+                    best = idx
+            if best >= 0:
+                block = self.blocks.pop(best)
+            else:
+                size = (nbytes + self.ROUND - 1) // self.ROUND * self.ROUND
+                total = sum(b.nbytes for b in self.blocks)
+                idx = 0
+                while total + size > self.cap and idx < len(self.blocks):   # make room: free blocks go first, oldest first
+                    if sys.getrefcount(self.blocks[idx]) == 2:
+                        total -= self.blocks[idx].nbytes
+                        self.blocks.pop(idx)
+                    else:
+                        idx += 1
+                if total + size > self.cap:
+                    return np.empty(count, dtype=dtype)   # (the cap is held by live results: this one is not cached)
+                block = np.empty(size // dtype.itemsize, dtype=dtype)
+            self.blocks.append(block)
+            return block[:int(count)]
+
+
+_host_pool = _HostPool()
 
 
 def host_place_block(M, rows_global, cols_global, scale, cursor, out_indices, out_data):
@@ -482,8 +548,8 @@ class Context:
         """host copies: (data float64, indices int32, indptr int64) for the owned rows; ``structure=False`` copies
         the values only (K and P share indices / indptr) and returns (data, None, None)"""
         r0, r1, nnz = self.graph_rows()
-        data = np.empty(nnz, dtype=np.float64)
-        indices = np.empty(nnz, dtype=np.int32) if structure else None
+        data = _host_pool.empty(nnz, np.float64)
+        indices = _host_pool.empty(nnz, np.int32) if structure else None
         indptr = np.empty(r1 - r0 + 1, dtype=np.int64) if structure else None
         self._check(self.lib.gt_graph_fetch_csr(self.h, which, _ptr(data), _ptr(indices) if structure else None,
                                                 _ptr(indptr) if structure else None, 0), "gt_graph_fetch_csr")
@@ -493,9 +559,9 @@ class Context:
         """host copies of K and P in one pass over the link: (K data, indices int32, indptr int64, P data); the P values are
         derived on the host from K and the degrees while K is still arriving (bit-identical to the device's P)"""
         r0, r1, nnz = self.graph_rows()
-        kd = np.empty(nnz, dtype=np.float64)
-        pd = np.empty(nnz, dtype=np.float64)
-        indices = np.empty(nnz, dtype=np.int32)
+        kd = _host_pool.empty(nnz, np.float64)
+        pd = _host_pool.empty(nnz, np.float64)
+        indices = _host_pool.empty(nnz, np.int32)
         indptr = np.empty(r1 - r0 + 1, dtype=np.int64)
         self._check(self.lib.gt_graph_fetch_kp(self.h, _ptr(kd), _ptr(indices), _ptr(indptr), _ptr(pd)), "gt_graph_fetch_kp")
         return kd, indices, indptr, pd

@@ -12,10 +12,14 @@
 // runtime may already be gone when static destructors run.
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
 #include <functional>
 #include <mutex>
 #include <system_error>
 #include <thread>
+
+#include <sys/mman.h>
+#include <unistd.h>
 
 #include "gt_common.h"
 #include "gt_hostcopy.h"
@@ -125,10 +129,93 @@ int pipelined_d2h(gt_ctx* ctx, void* dst, const void* src, size_t bytes, const C
     return GT_OK;
 }
 
+// RESIDENT destinations (round 5).  The lanes exist because the runtime's copy into untouched pages is slow; into pages that
+// are already resident a plain hipMemcpy runs at the link's rate (measured on the MI355X host: 56.0 GB/s into a resident
+// malloc'd gigabyte, 57.1 into registered or hipHostMalloc'd memory, 53 in 8 MiB pieces - the lanes, with their staging memcpy,
+// reach 46).  The Python binding recycles the big result arrays (graphtools_amd/_hip.py `_HostPool`), so from the second
+// graph of a process on the destinations ARE resident: the copy then goes direct, in 64 MiB pieces when host work rides along
+// (worker threads take the pieces as they land).  Residency is sampled with mincore() - one page every 2 MiB and the last.
+bool dst_resident(const void* p, size_t bytes) {
+    static const bool off = std::getenv("GT_COPY_DIRECT") != nullptr && std::atoi(std::getenv("GT_COPY_DIRECT")) == 0;
+    if (off || bytes == 0) return false;
+    const size_t page = size_t(sysconf(_SC_PAGESIZE));
+    const uintptr_t a0 = reinterpret_cast<uintptr_t>(p) & ~(uintptr_t(page) - 1);
+    const uintptr_t a1 = (reinterpret_cast<uintptr_t>(p) + bytes - 1) & ~(uintptr_t(page) - 1);
+    unsigned char v = 0;
+    for (uintptr_t a = a0; a <= a1; a += (size_t(2) << 20)) {
+        if (mincore(reinterpret_cast<void*>(a), page, &v) != 0 || !(v & 1)) return false;
+    }
+    if (mincore(reinterpret_cast<void*>(a1), page, &v) != 0 || !(v & 1)) return false;
+    return true;
+}
+
+int direct_d2h(gt_ctx* ctx, void* dst, const void* src, size_t bytes, const ChunkFn* post) {
+    if (std::getenv("GT_TRACE")) std::fprintf(stderr, "[gt_trace] direct device -> host copy of %.1f MB%s\n", double(bytes) / 1e6, post ? " (host work rides along)" : "");
+    if (!post) {
+        GT_HIP(ctx, hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+        return GT_OK;
+    }
+    // copies of 64 MiB; the host work is dealt in 4 MiB items (whoever is free takes the next one that has landed): behind the
+    // last copy there is a sixteenth of a piece left per worker, not a whole piece for one of them
+    static const size_t piece = size_t(env_int("GT_COPY_PIECE_MB", 64, 8, 4096)) << 20;
+    const size_t item = size_t(4) << 20;
+    const size_t npieces = (bytes + piece - 1) / piece, nitems = (bytes + item - 1) / item;
+    std::mutex m;
+    std::condition_variable cv;
+    size_t landed = 0;     // bytes that have landed
+    bool failed = false;
+    std::atomic<size_t> next(0);
+    // (six workers: P = K / degree over a C3 graph behind the copy took 17.8 ms with 4 or 8 of them, 18.5-19.6 with 16, 19.0 with
+    //  32 - the copy alone is 16.6 ms at the link's rate, and threads beyond what the arithmetic needs only get in its way)
+    static const int kWorkers = env_int("GT_COPY_WORKERS", 6, 1, kMaxLanes);
+    const int nw = int(std::min<size_t>(size_t(kWorkers), nitems));
+    std::thread th[kMaxLanes];
+    auto worker = [&]() {
+        for (;;) {
+            const size_t it = next.fetch_add(1);
+            if (it >= nitems) return;
+            const size_t off = it * item, len = std::min(item, bytes - off);
+            {
+                std::unique_lock<std::mutex> lock(m);
+                cv.wait(lock, [&] { return landed >= off + len || failed; });
+                if (failed) return;
+            }
+            (*post)(off, len);
+        }
+    };
+    int started = 0;
+    try {
+        for (; started < nw; ++started) th[started] = std::thread(worker);
+    } catch (const std::system_error&) {
+    }
+    hipError_t e = hipSuccess;
+    for (size_t c = 0; c < npieces && e == hipSuccess; ++c) {
+        const size_t off = c * piece, len = std::min(piece, bytes - off);
+        e = hipMemcpy(static_cast<char*>(dst) + off, static_cast<const char*>(src) + off, len, hipMemcpyDeviceToHost);
+        {
+            std::lock_guard<std::mutex> lock(m);
+            if (e == hipSuccess) landed = off + len;
+            else failed = true;
+        }
+        cv.notify_all();
+    }
+    if (e == hipSuccess) worker();   // (this thread helps with what is left - all of it when no worker could be started)
+    for (int l = 0; l < started; ++l) th[l].join();
+    if (e != hipSuccess) {
+        ctx->set_error(std::string("direct host copy: ") + hipGetErrorString(e));
+        return GT_E_HIP;
+    }
+    return GT_OK;
+}
+
 }  // namespace
 
 int gt_copy_to_host(gt_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes) {
     if (bytes == 0) return GT_OK;
+    if (bytes >= kMinPipelined && dst_resident(dst_host, bytes)) {
+        GT_HIP(ctx, hipStreamSynchronize(ctx->stream));   // the producer kernels of src_dev
+        return direct_d2h(ctx, dst_host, src_dev, bytes, nullptr);
+    }
     if (bytes < kMinPipelined || kLanes == 0) {
         GT_HIP(ctx, hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
         GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -173,7 +260,9 @@ int gt_fetch_kp_host(gt_ctx* ctx, double* K_host, double* P_host, const double* 
     };
     const size_t bytes = size_t(nnz) * sizeof(double);
     GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (bytes < kMinPipelined || kLanes == 0) {
+    if (bytes >= kMinPipelined && dst_resident(K_host, bytes) && dst_resident(P_host, bytes)) {
+        GT_TRY(direct_d2h(ctx, K_host, K_dev, bytes, &post));
+    } else if (bytes < kMinPipelined || kLanes == 0) {
         GT_HIP(ctx, hipMemcpy(K_host, K_dev, bytes, hipMemcpyDeviceToHost));
         post(0, bytes);
     } else {

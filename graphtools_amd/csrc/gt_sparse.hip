@@ -3438,13 +3438,22 @@ extern "C" int gt_graph_fetch_kp(gt_ctx* ctx, double* K_data, int32_t* indices, 
     GraphState* g = ctx->graph;
     if (!g || !g->finished) GT_FAIL(ctx, GT_E_STATE, "gt_graph_fetch_kp: no finished graph");
     if (g->p.anisotropy != 0.0 && !g->aniso_applied) GT_FAIL(ctx, GT_E_STATE, "gt_graph_fetch_kp: the anisotropy of this build is still to be applied");
-    GT_TRY(gt_copy_to_host(ctx, indptr, g->indptr.p, size_t(g->nloc + 1) * sizeof(int64_t)));
     std::vector<double> deg(size_t(g->nloc));
-    GT_TRY(gt_copy_to_host(ctx, deg.data(), g->degree.p, size_t(g->nloc) * sizeof(double)));
-    GT_TRY(gt_copy_to_host(ctx, indices, g->indices.p, size_t(g->nnz) * sizeof(int32_t)));
+    {
+        HostTrace t(ctx, "fetch_kp: indptr + degrees");
+        GT_TRY(gt_copy_to_host(ctx, indptr, g->indptr.p, size_t(g->nloc + 1) * sizeof(int64_t)));
+        GT_TRY(gt_copy_to_host(ctx, deg.data(), g->degree.p, size_t(g->nloc) * sizeof(double)));
+    }
+    {
+        HostTrace t(ctx, "fetch_kp: indices");
+        GT_TRY(gt_copy_to_host(ctx, indices, g->indices.p, size_t(g->nnz) * sizeof(int32_t)));
+    }
     int negative = 0;
-    GT_TRY(gt_fetch_kp_host(ctx, K_data, P_data, g->Kdata.as<double>(), g->nnz, reinterpret_cast<const long long*>(indptr),
-                            deg.data(), g->nloc, &negative));
+    {
+        HostTrace t(ctx, "fetch_kp: K with P derived");
+        GT_TRY(gt_fetch_kp_host(ctx, K_data, P_data, g->Kdata.as<double>(), g->nnz, reinterpret_cast<const long long*>(indptr),
+                                deg.data(), g->nloc, &negative));
+    }
     if (negative) GT_TRY(gt_copy_to_host(ctx, P_data, g->Pdata.p, size_t(g->nnz) * sizeof(double)));
     return GT_OK;
 }

@@ -182,3 +182,53 @@ def test_n_pca_rank_estimate():
     S = sparse.random(200, 30, density=0.2, random_state=1, format="coo")
     d = Data(S, n_pca=True)
     assert d.data_nu.shape == (200, d.n_pca) and 1 <= d.n_pca <= 29
+
+
+def test_result_arrays_are_recycled_only_when_nobody_refers_to_them():
+    """graphtools_amd._hip._HostPool: the big result arrays (CSR values / indices of a graph) come from host blocks that are
+    handed out again once every array of an earlier result is gone - a view, a slice or a scipy matrix built on one keeps its
+    block out of circulation (scipy shares the memory: the blocks are of the requested dtype), small arrays are plain
+    np.empty, release_cached_memory() empties the pool."""
+    import gc
+
+    from scipy import sparse
+
+    from graphtools_amd import _hip
+
+    pool = _hip._HostPool()
+    n = pool.MIN_BYTES // 8 + 1000
+
+    def addr(a):
+        return a.__array_interface__["data"][0]
+
+    a = pool.empty(n, np.float64)
+    assert a.dtype == np.float64 and a.shape == (n,) and a.base is not None
+    pa = addr(a)
+    b = pool.empty(n, np.float64)
+    assert addr(b) != pa, "a live array's block was handed out again"
+    v = a[5:100]
+    del a
+    c = pool.empty(n, np.float64)
+    assert addr(c) != pa, "a view still refers to the block"
+    del v
+    d = pool.empty(n - 10, np.float64)
+    assert addr(d) == pa, "a released block of the right size should be re-used"
+    assert addr(pool.empty(n, np.int32)) not in (pa, addr(b), addr(c)), "blocks are per dtype"
+    # scipy keeps the arrays it is given (no copy): the matrix holds the block
+    x = pool.empty(n, np.float64)
+    x[:] = 1.0
+    idx = np.zeros(n, dtype=np.int32)
+    ptr = np.array([0, n], dtype=np.int32)
+    M = sparse.csr_matrix((x, idx, ptr), shape=(1, 1))
+    assert np.shares_memory(M.data, x)
+    px = addr(x)
+    del x
+    assert addr(pool.empty(n, np.float64)) != px
+    del M
+    gc.collect()
+    assert addr(pool.empty(n, np.float64)) == px
+    assert pool.empty(100, np.float64).base is None
+    pool.cap = 0
+    assert pool.empty(n, np.float64).base is None
+    pool.clear()
+    assert pool.blocks == []
