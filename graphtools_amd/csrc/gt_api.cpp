@@ -264,10 +264,6 @@ int gt_set_option(gt_ctx* ctx, const char* name, const char* value) {
             GT_FAIL(ctx, GT_E_ARG, "query_order must be 'auto' or 'off'");
         return GT_OK;
     }
-    if (k == "select_samp_trig") {
-        ctx->samp_trig = std::atoi(value);
-        return GT_OK;
-    }
     if (k == "select_nt8_max_need") {
         ctx->nt8_max_need = std::min(112, std::max(1, std::atoi(value)));
         return GT_OK;
@@ -288,14 +284,6 @@ int gt_set_option(gt_ctx* ctx, const char* name, const char* value) {
         ctx->order_cell_rows = std::atoi(value);
         return GT_OK;
     }
-    if (k == "select_samp2_level") {
-        ctx->samp2_level = std::atoi(value);
-        return GT_OK;
-    }
-    if (k == "select_samp2_keep") {
-        ctx->samp2_keep = std::atoi(value);
-        return GT_OK;
-    }
     if (k == "select_samp_keep") {
         ctx->samp_keep = std::atoi(value);
         return GT_OK;
@@ -312,10 +300,6 @@ int gt_set_option(gt_ctx* ctx, const char* name, const char* value) {
         const std::string v = value;
         if (v != "data" && v != "float64") GT_FAIL(ctx, GT_E_ARG, "distance_dtype must be 'data' or 'float64'");
         ctx->dist_f64 = v == "float64" ? 1 : 0;
-        return GT_OK;
-    }
-    if (k == "select_sym_sample_far") {
-        ctx->sym_sample_far = std::atof(value);
         return GT_OK;
     }
     if (k == "dense_rows") {
@@ -356,10 +340,6 @@ int gt_set_option(gt_ctx* ctx, const char* name, const char* value) {
     }
     if (k == "select_sym_stride") {
         ctx->sym_stride = std::max(0, std::atoi(value));
-        return GT_OK;
-    }
-    if (k == "select_sym_radius_cut") {
-        ctx->sym_radius_cut = std::atof(value);
         return GT_OK;
     }
     if (k == "select_sym_orphan_far") {
@@ -418,10 +398,6 @@ int gt_set_option(gt_ctx* ctx, const char* name, const char* value) {
     }
     if (k == "select_sym_cells") {
         ctx->sym_cells = std::min(32, std::max(1, std::atoi(value)));
-        return GT_OK;
-    }
-    if (k == "select_sym_max_nb") {
-        ctx->sym_max_nb = std::max(8, std::atoi(value));
         return GT_OK;
     }
     if (k == "select_sym_min_rows") {
