@@ -1006,6 +1006,13 @@ __global__ __launch_bounds__(NT) void bin_fill_kernel(const int64_t nloc, const 
     {
         // (eight, then four loads in flight per thread: the loop is bound by the latency of load -> LDS atomic otherwise)
         int64_t t = t0 + threadIdx.x;
+        for (; t + 15 * NT < t1; t += 16 * NT) {
+            uint32_t r[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) r[u] = trip[t + u * NT].row;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) atomicAdd(&cnt[int64_t(r[u]) - p0], 1);
+        }
         for (; t + 7 * NT < t1; t += 8 * NT) {
             uint32_t r[8];
 #pragma unroll
@@ -1080,6 +1087,19 @@ __global__ __launch_bounds__(NT) void bin_fill_kernel(const int64_t nloc, const 
     {
         int64_t t = t0 + threadIdx.x;
         if (ucol) {
+            for (; t + 15 * NT < t1; t += 16 * NT) {
+                Triplet a[16];
+                int sl[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) a[u] = trip[t + u * NT];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) sl[u] = atomicAdd(&cnt[int64_t(a[u].row) - p0], 1);
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    ucol[t0 + sl[u]] = a[u].col;
+                    uval[t0 + sl[u]] = a[u].val;
+                }
+            }
             for (; t + 7 * NT < t1; t += 8 * NT) {
                 Triplet a[8];
                 int sl[8];
