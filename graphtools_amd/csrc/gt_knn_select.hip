@@ -1685,10 +1685,15 @@ __global__ __launch_bounds__(256, GT_SEL_COLD_LOCAL_WAVES) void sym_cold_local_k
     float hu[QT], rq[QT], hgq[QT];
     float umax = 0.f;
     uint32_t have_q = 0xFFFFFFFFu;
+    // the wave's entries in one load (lane l holds entry en0 + l): the loop reads them from there - one round trip less per unit
+    static_assert(GT_SEL_COLD_EPW <= 64, "one queue entry per lane");
+    uint2 ent_mine = make_uint2(0u, 0u);
+    if (lane < GT_SEL_COLD_EPW && en0 + lane < int64_t(sy.qn)) ent_mine = sy.queue[en0 + lane];
     for (int ce_ = 0; ce_ < GT_SEL_COLD_EPW; ++ce_) {
         const int64_t en_ = en0 + ce_;
         if (en_ >= int64_t(sy.qn)) break;   // wave-uniform
-        const uint2 ent = sy.queue[en_];
+        const uint2 ent = make_uint2(uint32_t(__builtin_amdgcn_readlane(int(ent_mine.x), ce_)),
+                                     uint32_t(__builtin_amdgcn_readlane(int(ent_mine.y), ce_)));
         const int64_t qblock = int64_t(ent.x) * (QT * 32);
         const uint32_t tbase = ent.y * 32u;
         int rel = int(ent.y / uint32_t(C::BN / 32)) - int(qblock / BQ) * TPB;

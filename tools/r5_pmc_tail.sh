@@ -19,8 +19,10 @@ done
 python3 - "$O" <<'PY'
 import csv, glob, os, sys
 root = sys.argv[1]
-want = ("affinity_kernel<float, false, 1>", "bin_count_kernel", "bin_emit_kernel", "bin_fill_kernel<256>", "merge_final_kernel",
-        "rerank_sym4_kernel<1, true, 1>", "sym_cold_local_kernel<64>")
+want = ("affinity_kernel<float, false, 1>", "affinity_slots_kernel", "bin_count_kernel", "bin_emit_kernel", "bin_emit_slots_kernel",
+        "bin_fill_kernel<256>", "merge_final_kernel", "merge_pairs_slots_kernel<unsigned int>", "rerank_sym4_kernel<1, true, 1>",
+        "sym_cold_local_kernel<64>", "sym_thresholds_kernel<float>", "sym_seed_dense_kernel<64>", "assign_cells2_kernel<64>",
+        "bound_queue_kernel", "landmark_neighbours_kernel", "_ZN12_GLOBAL__N_126landmark_neighbours_kernelEPKDF16_iiiPiPKjS4_")
 for d in sorted(x for x in glob.glob(os.path.join(root, "*")) if os.path.isdir(x)):
     acc = {}
     for fn in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
