@@ -180,6 +180,26 @@ class _HostPool:
             self.cap = int(float(os.environ.get("GRAPHTOOLS_AMD_HOST_POOL_GB", "8")) * (1 << 30))
         except ValueError:
             self.cap = 8 << 30
+        if not self._refcounts_behave():
+            self.cap = 0   # (an interpreter whose reference counts do not say "nobody else holds this": never recycle)
+
+    @staticmethod
+    def _refcounts_behave():
+        """the pool's one assumption, checked once: a block held by a list alone counts 2 (the list, getrefcount's argument),
+        and every view of it - however derived - adds one until it dies"""
+        import sys
+
+        try:
+            held = [np.empty(64, dtype=np.float64)]
+            if sys.getrefcount(held[0]) != 2:
+                return False
+            v = held[0][:8]
+            w = v[2:4].view(np.int64)
+            ok = sys.getrefcount(held[0]) == 4 and w.base is held[0]
+            del v, w
+            return ok and sys.getrefcount(held[0]) == 2
+        except Exception:
+            return False
 
     def clear(self):
         with self.lock:
