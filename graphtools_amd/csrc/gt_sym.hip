@@ -129,44 +129,44 @@ __global__ __launch_bounds__(256) void sym_thresholds_kernel(const int64_t n, co
     float t = INFINITY, gv = INFINITY;
     if (p < n) {
         const int64_t q = sorted ? p : int64_t(perm[p]);
-        // how many of the kept rows lie outside the M cells around the row's own: when that is most of them the cells say
-        // nothing about this point set (launch A found its neighbours in the strided sample) and the thresholds are loose
-        uint32_t far = 0;
-        if (far_total) {
-            // the M cells around the row's own sit in two registers per lane of the group (M <= 32); every kept row's cell is
-            // passed round the group and compared by all lanes at once.  (A loop of M dependent loads per kept row was the
-            // longest chain of this kernel.)
-            const uint32_t kept0 = counts[p];
-            const uint32_t cme = cell_sorted[p];
-            const uint32_t nb0 = sub < M ? uint32_t(nbr[size_t(cme) * M + sub]) : 0xFFFFFFFFu;
-            const uint32_t nb1 = sub + 16 < M ? uint32_t(nbr[size_t(cme) * M + sub + 16]) : 0xFFFFFFFFu;
-            for (uint32_t c0 = 0; c0 < 64u; c0 += 16u) {   // (need_m <= 64; the trip count is the same for the whole wave)
-                if (__ballot(c0 < kept0) == 0ull) break;
-                const bool have = c0 + uint32_t(sub) < kept0;
-                const uint32_t ccm = have ? cell_sorted[cand_index(lists[size_t(p) * lstride + c0 + sub])] : 0xFFFFFFFEu;
-#pragma unroll
-                for (int c = 0; c < 16; ++c) {
-                    const uint32_t cc = uint32_t(__shfl(int(ccm), c, 16));
-                    const unsigned long long hit = __ballot(nb0 == cc || nb1 == cc);
-                    const bool near = ((hit >> (lane64 & 48)) & 0xFFFFull) != 0ull;
-                    far += (sub == 0 && cc != 0xFFFFFFFEu && !near) ? 1u : 0u;
-                }
-            }
-            if (sub == 0 && far) atomicAdd(far_total, (unsigned long long)far);
-        }
+        // Everything the row needs that can be asked for NOW is (round 5: the far count in front of the distances cost the kernel
+        // three dependent round trips before the first candidate row was on its way): the first sixteen list entries serve the
+        // distances and the far count, the far count's reads (the cells around the row's own, the kept rows' cells) travel
+        // while the distances are formed and are looked at behind them.
+        const uint32_t kept = counts[p];
+        const uint64_t l0 = uint32_t(sub) < kept ? lists[size_t(p) * lstride + sub] : 0ull;
+        const uint32_t cme = far_total ? cell_sorted[p] : 0u;
         const T* xq = X + q * int64_t(d);
         const double qs = xn[q];
-        const uint32_t kept = counts[p];
-        // this lane's slice of the query row (features sub, sub + 16, ...), up to 8 values in registers (d <= 128)
+        // this lane's slice of the query row, up to 8 values in registers (d <= 128): features sub, sub + 16, ... - or, float32 rows
+        // of a multiple of four features (vec4: D_K is an upper bound, any summation order serves), features 4 sub ... 4 sub + 3
+        // of every 64: a candidate row is then ONE 16-byte load per lane and 64 features instead of four 4-byte ones
+        constexpr bool kF32 = sizeof(T) == 4;
+        const bool vec4 = kF32 && (d & 3) == 0;
         double xr[8];
+        if (vec4) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) xr[u] = (sub + 16 * u < d) ? double(xq[sub + 16 * u]) : 0.0;
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int k2 = 0; k2 < 4; ++k2) xr[4 * u + k2] = (64 * u + 4 * sub + k2 < d) ? double(xq[64 * u + 4 * sub + k2]) : 0.0;
+        } else {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) xr[u] = (sub + 16 * u < d) ? double(xq[sub + 16 * u]) : 0.0;
+        }
+        uint32_t nb0 = 0xFFFFFFFFu, nb1 = 0xFFFFFFFFu, ccm0 = 0xFFFFFFFEu;
+        if (far_total) {
+            // the M cells around the row's own sit in two registers per lane of the group (M <= 32); every kept row's cell is
+            // passed round the group and compared by all lanes at once
+            if (sub < M) nb0 = uint32_t(nbr[size_t(cme) * M + sub]);
+            if (sub + 16 < M) nb1 = uint32_t(nbr[size_t(cme) * M + sub + 16]);
+            if (uint32_t(sub) < kept) ccm0 = cell_sorted[cand_index(l0)];
+        }
         // candidate ids: lane c of the group fetches entry c (need_m <= 64: four rounds at most)
         double dk = 0.0;
         for (uint32_t c0 = 0; c0 < kept; c0 += 16u) {
             int64_t jmine = 0;
             if (c0 + uint32_t(sub) < kept) {
-                const uint32_t pj = cand_index(lists[size_t(p) * lstride + c0 + sub]);
+                const uint32_t pj = cand_index(c0 == 0u ? l0 : lists[size_t(p) * lstride + c0 + sub]);
                 jmine = sorted ? int64_t(pj) : int64_t(perm[pj]);
             }
             const uint32_t lim = kept - c0 < 16u ? kept - c0 : 16u;
@@ -181,15 +181,35 @@ __global__ __launch_bounds__(256) void sym_thresholds_kernel(const int64_t n, co
                     j4[i] = __shfl(jmine, int((c + i) & 15u), 16);
                     acc4[i] = 0.0;
                 }
+                if (vec4) {
+                    if constexpr (kF32) {
 #pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    if (sub + 16 * u < d) {
-                        T y4[CB];
+                        for (int u = 0; u < 2; ++u)
+                            if (64 * u + 4 * sub < d) {
+                                float4 y4[CB];
 #pragma unroll
-                        for (int i = 0; i < CB; ++i) y4[i] = X[j4[i] * int64_t(d) + sub + 16 * u];
+                                for (int i = 0; i < CB; ++i)
+                                    y4[i] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(X) + j4[i] * int64_t(d) + 64 * u + 4 * sub);
 #pragma unroll
-                        for (int i = 0; i < CB; ++i) acc4[i] = fma(xr[u], double(y4[i]), acc4[i]);
+                                for (int i = 0; i < CB; ++i) {
+                                    acc4[i] = fma(xr[4 * u + 0], double(y4[i].x), acc4[i]);
+                                    acc4[i] = fma(xr[4 * u + 1], double(y4[i].y), acc4[i]);
+                                    acc4[i] = fma(xr[4 * u + 2], double(y4[i].z), acc4[i]);
+                                    acc4[i] = fma(xr[4 * u + 3], double(y4[i].w), acc4[i]);
+                                }
+                            }
                     }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (sub + 16 * u < d) {
+                            T y4[CB];
+#pragma unroll
+                            for (int i = 0; i < CB; ++i) y4[i] = X[j4[i] * int64_t(d) + sub + 16 * u];
+#pragma unroll
+                            for (int i = 0; i < CB; ++i) acc4[i] = fma(xr[u], double(y4[i]), acc4[i]);
+                        }
+                }
 #pragma unroll
                 for (int i = 0; i < CB; ++i) {
                     double acc = acc4[i];
@@ -198,6 +218,25 @@ __global__ __launch_bounds__(256) void sym_thresholds_kernel(const int64_t n, co
                     if (c + i < lim) dk = fmax(dk, gt_pair_key(qs, acc, xn[j4[i]], metric));
                 }
             }
+        }
+        // how many of the kept rows lie outside the M cells around the row's own: when that is most of them the cells say
+        // nothing about this point set (launch A found its neighbours in the strided sample) and the thresholds are loose
+        uint32_t far = 0;
+        if (far_total) {
+            for (uint32_t c0 = 0; c0 < 64u; c0 += 16u) {   // (need_m <= 64; the trip count is the same for the whole wave)
+                if (__ballot(c0 < kept) == 0ull) break;
+                const bool have = c0 + uint32_t(sub) < kept;
+                const uint32_t ccm = c0 == 0u ? ccm0
+                                              : (have ? cell_sorted[cand_index(lists[size_t(p) * lstride + c0 + sub])] : 0xFFFFFFFEu);
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    const uint32_t cc = uint32_t(__shfl(int(ccm), c, 16));
+                    const unsigned long long hit = __ballot(nb0 == cc || nb1 == cc);
+                    const bool near = ((hit >> (lane64 & 48)) & 0xFFFFull) != 0ull;
+                    far += (sub == 0 && cc != 0xFFFFFFFEu && !near) ? 1u : 0u;
+                }
+            }
+            if (sub == 0 && far) atomicAdd(far_total, (unsigned long long)far);
         }
         dk *= 1.0 + 1e-12;
         const double y2 = ymax2p[0];
