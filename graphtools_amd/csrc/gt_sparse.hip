@@ -959,21 +959,25 @@ __global__ __launch_bounds__(256) void bin_emit_slots_kernel(const int64_t nloc,
             out[slot] = t;
         }
     };
-    Hdr h0 = {0, 0, 0}, h1 = h0, h2 = h0;
-    Dat x0 = {-1.0, -1.0, kNoDest, kNoDest}, x1 = x0;
+    Hdr h0 = {0, 0, 0}, h1 = h0, h2 = h0, h3 = h0;
+    Dat x0 = {-1.0, -1.0, kNoDest, kNoDest}, x1 = x0, x2 = x0;
     const int64_t pw = p0 + w;
     load_hdr(pw, h0);
     load_hdr(pw + 4, h1);
+    load_hdr(pw + 8, h2);
     load_dat(pw, h0, x0);
+    load_dat(pw + 4, h1, x1);
     for (int64_t p = pw; p < p1; p += 4) {
-        load_hdr(p + 8, h2);
-        load_dat(p + 4, h1, x1);
+        load_hdr(p + 12, h3);
+        load_dat(p + 8, h2, x2);
         send(uint32_t(h0.i), x0.va, x0.pa);
         send(uint32_t(h0.i), x0.vb, x0.pb);
         for (int e = 128 + lane; e < h0.n; e += 64) send(uint32_t(h0.i), cand_k[size_t(p) * MP + e], posj[h0.c0 + e]);
         h0 = h1;
         h1 = h2;
+        h2 = h3;
         x0 = x1;
+        x1 = x2;
     }
 }
 
@@ -1760,16 +1764,20 @@ __global__ __launch_bounds__(256) void merge_pairs_slots_kernel(const int64_t nl
             load_one(p, h, lane + 64, x.kb, x.vb);
         }
     };
-    Hdr h0 = {0, 0, 0, 0, 0, 0}, h1 = h0, h2 = h0;
-    Dat x0 = {0.0, 0.0, kNoKey, kNoKey}, x1 = x0;
+    // (headers three rows ahead, offsets and entries two: one row of sorting does not cover a round trip)
+    Hdr h0 = {0, 0, 0, 0, 0, 0}, h1 = h0, h2 = h0, h3 = h0;
+    Dat x0 = {0.0, 0.0, kNoKey, kNoKey}, x1 = x0, x2 = x0;
     load_hdr(t0, h0);
     load_hdr(t0 + 1, h1);
+    load_hdr(t0 + 2, h2);
     load_dst(t0, h0);
+    load_dst(t0 + 1, h1);
     load_dat(t0, h0, x0);
+    load_dat(t0 + 1, h1, x1);
     for (int64_t p = t0; p < t1; ++p) {
-        load_hdr(p + 2, h2);
-        load_dst(p + 1, h1);
-        load_dat(p + 1, h1, x1);
+        load_hdr(p + 3, h3);
+        load_dst(p + 2, h2);
+        load_dat(p + 2, h2, x2);
         const int L = h0.L;
         const int64_t row = h0.i, dst = h0.dst;
         if (L <= 128) {
@@ -1822,7 +1830,9 @@ __global__ __launch_bounds__(256) void merge_pairs_slots_kernel(const int64_t nl
         }   // (longer rows: merge_final_kernel over the listed rows, merge_long_final_kernel)
         h0 = h1;
         h1 = h2;
+        h2 = h3;
         x0 = x1;
+        x1 = x2;
     }
 }
 
