@@ -1,6 +1,7 @@
 // Host orchestration of the kNN search: candidate pass (MFMA) -> exact re-rank (fp64) -> exhaustive
 // fallback for the rows whose candidate table could not be proven complete.
 #include "gt_knn.h"
+#include "gt_graph_state.h"
 #include "gt_hostcopy.h"
 #include "gt_knn_select.h"
 
@@ -1070,7 +1071,8 @@ extern "C" int gt_knn_stats(const gt_ctx* ctx, int64_t* out12) {
     for (int i = 0; i < 8; ++i) out12[4 + i] = (k && k->sym_used) ? int64_t(k->sym_stat_host[i]) : 0;
     if (k && k->sym_used) out12[6] = k->sym_nseg;   // work items per query block of launch B
     if (k && k->sym_used) out12[5] = k->sym_two_used ? k->sym_cold_entries : 0;   // pairs the cold launch scored in full
-    if (k && k->sym_used) out12[7] = (k->sym_two_used ? 1 : 0) | (k->sym_seed_dense ? 2 : 0) | (k->sym_cold_local_used ? 4 : 0);   // bit 0: two-stage collect ran, bit 1: dense seeding kernel
+    if (k && k->sym_used) out12[7] = (k->sym_two_used ? 1 : 0) | (k->sym_seed_dense ? 2 : 0) | (k->sym_cold_local_used ? 4 : 0) | (k->tab_sorted ? 8 : 0) |
+                                      ((k->tab_sorted && ctx->graph && ctx->graph->pairs_fused) ? 16 : 0);   // bit 0: two-stage collect ran, bit 1: dense seeding kernel, bit 2: cold launch in the local frame, bit 3: tables by sorted position, bit 4: the affinity pass looked the destinations up
     if (k && k->sym_used) out12[4] = (k->sym_two_used && k->sym_bound_used) ? 1 : 0;   // units listed by cell bounds, no collect launch
     out12[10] = k ? k->sym_far : 0;                 // kept rows of launch A outside the neighbourhood cells (all points)
     return GT_OK;

@@ -193,3 +193,29 @@ def test_pair_resolved_tail_gives_way_to_hub_rows(pairs):
         _same(x, y)
     assert c[0][2] == "general" and c[1][2] == "general"
     assert c[0][5] == 2 * c[1][5] and c[1][5] == b[0][5]
+
+
+def test_default_build_of_a_large_point_set_takes_the_slot_kernels():
+    """a whole single-rank '+' build of 65536+ rows with default options: the tables lie by sorted position and the affinity pass
+    looks the destinations up itself (no bin_count launch) - a silent fall-back to the round-4 kernels would cost 1.2 ms per C3 graph
+    without any test noticing; same K and P as the general tail"""
+    from graphtools_amd import _hip
+
+    X = make_mix(70000, 24, 11)
+    out = []
+    for opts in ((), (("symmetrize_pairs", "0"),)):
+        c = _hip.Context(0)
+        for k, v in opts:
+            c.set_option(k, v)
+        c.set_points(X)
+        p, keep = c.make_params(10, 20.0, 1e-4, None, 1.0, None, "+", None, 0)
+        c.graph_build(p)
+        out.append((c.graph_fetch_csr(_hip.CSR_K), c.graph_fetch_csr(_hip.CSR_P)[0], c.knn_stats(), c.graph_stats()))
+        c.close()
+    st = out[0][2]
+    assert st["symmetric"] and st["tables_by_slot"], st
+    assert st["destinations_fused"] == (out[0][3]["radius_rows"] == 0), (st, out[0][3])
+    assert not out[1][2]["tables_by_slot"]
+    for a, b in zip(out[0][0], out[1][0]):
+        assert np.array_equal(a, b)
+    assert np.array_equal(out[0][1], out[1][1])
