@@ -796,7 +796,9 @@ def main():
                        "nnz_K": nnz_total, "nnz_K0_rank0": nnz0,
                        "radius_rows_rank0": stats["radius_rows"], "fallback_rows_rank0": stats["fallback_rows"],
                        "symmetric_candidate_pass": flags_["symmetric"], "two_stage_collect": flags_["two_stage"],
-                       "bound_pass": flags_["bound_pass"]},
+                       "bound_pass": flags_["bound_pass"],
+                       "tail_tables_by_slot": bool(flags_["knn_stats"].get("tables_by_slot", False)),
+                       "tail_destinations_fused": bool(flags_["knn_stats"].get("destinations_fused", False))},
             "roofline": roof,
             "kernels": [{k: (round(v, 4) if isinstance(v, float) and k not in ("executed_flop", "algorithmic_bytes") else v)
                          for k, v in r.items()} for r in rows],
