@@ -3468,7 +3468,9 @@ extern "C" int gt_graph_fetch_kp(gt_ctx* ctx, double* K_data, int32_t* indices, 
     GraphState* g = ctx->graph;
     if (!g || !g->finished) GT_FAIL(ctx, GT_E_STATE, "gt_graph_fetch_kp: no finished graph");
     if (g->p.anisotropy != 0.0 && !g->aniso_applied) GT_FAIL(ctx, GT_E_STATE, "gt_graph_fetch_kp: the anisotropy of this build is still to be applied");
-    std::vector<double> deg(size_t(g->nloc));
+    // (kept per thread: a fresh 8 MB vector is zeroed and faulted in on every call - a millisecond of the host-complete graph)
+    static thread_local std::vector<double> deg;
+    if (deg.size() < size_t(g->nloc)) deg.resize(size_t(g->nloc));
     {
         HostTrace t(ctx, "fetch_kp: indptr + degrees");
         GT_TRY(gt_copy_to_host(ctx, indptr, g->indptr.p, size_t(g->nloc + 1) * sizeof(int64_t)));

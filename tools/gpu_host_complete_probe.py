@@ -32,7 +32,7 @@ def wrap(name):
 
 for nm in [m for m in dir(_hip.Context) if not m.startswith("_") and callable(getattr(_hip.Context, m))]:
     wrap(nm)
-for rep in range(4):
+for rep in range(int(os.environ.get("GT_REPS", "4"))):
     acc.clear()
     t0 = time.perf_counter()
     G = graphtools_amd.Graph(X, knn=15, decay=40, n_pca=None, verbose=0)
@@ -45,6 +45,9 @@ for rep in range(4):
     inner = sum(sum(v) for v in acc.values())
     print("run %d: total %.1f ms = Graph() %.1f + .K %.1f + .P %.1f; binding calls %.1f ms, Python around them %.1f ms" % (
         rep, tot * 1e3, (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, inner * 1e3, (tot - inner) * 1e3))
+    print("      pool: %d blocks, %.2f GB; K.data at %#x (block of %s)" % (
+        len(_hip._host_pool.blocks), sum(b.nbytes for b in _hip._host_pool.blocks) / 2**30, K.data.__array_interface__["data"][0],
+        "the pool" if K.data.base is not None else "np.empty"))
     for k, v in sorted(acc.items(), key=lambda kv: -sum(kv[1])):
         if sum(v) > 2e-4:
             print("      %-28s x%-2d %.2f ms" % (k, len(v), sum(v) * 1e3))
