@@ -2069,7 +2069,7 @@ void launch_affinity(gt_ctx* ctx, GraphState* g, KnnWork* k, int binary, double 
         hipLaunchKernelGGL(affinity_slots_kernel, dim3((unsigned)ceil_div64(g->nloc, int64_t(4) * rpw)), dim3(256), 0, ctx->stream,
                            g->nloc, rpw, (const SlotRec*)g->rec_s.p, (const BwPos*)g->bwpos.p, gt_dist_dtype(ctx), ctx->metric, k->MP,
                            g->limit, k->cand_d2.as<double>(), k->cand_j.as<uint32_t>(), k->cand_d2t.as<double>(), decay, binary,
-                           thresh, g->radius_factor * (1.0 + 1e-9), count_owners, g->lenN.as<int32_t>(), g->ownercnt.as<int32_t>(),
+                           thresh, g->radius_factor * (1.0 + 1e-9), fz ? 0 : count_owners, g->lenN.as<int32_t>(), g->ownercnt.as<int32_t>(),
                            g->tablen.as<int32_t>(), fz ? g->cursor.as<uint32_t>() : (uint32_t*)nullptr, g->sC.as<int64_t>(),
                            g->cnt_sorted.as<int32_t>());
         if (k->nokeyt_n > 0)
@@ -2533,7 +2533,11 @@ static int graph_begin_impl(gt_ctx* ctx, const gt_knn_params* params, int32_t wo
         GT_HIP(ctx, hipGetLastError());
     }
     g->send_counts_host.assign(world, 0);
-    if (count_owners) {
+    if (count_owners && g->pairs_fused) {
+        // the pair-resolved tail that follows sizes its buffers by this: the entries of all tables bound the kept ones, which the
+        // tail counts itself (the scan of the counts by slot) - no gather / scan / scatter / read-back of the owners' counts here
+        g->send_counts_host[0] = g->sc_total;
+    } else if (count_owners) {
         // exclusive scan of the owner-major counts: slot of every (row, owner) pair inside the bucketed send buffer
         GT_HIP(ctx, g->ownerpos.reserve(size_t(int64_t(world) * g->nloc + 1) * sizeof(int64_t)));
         const bool sorted_buf = world == 1 && !external && k->ordered && k->nq == g->nloc && g->r0 == 0;
@@ -3032,9 +3036,11 @@ static int graph_finish_pairs(gt_ctx* ctx, int64_t* out_nnz, uint32_t* flags) {
     int64_t nnz = 0;
     uint32_t ff = 0, n_mid = 0;
     uint32_t huge_host[4] = {0, 0, 0, 0};   // [0] rows beyond the register sorts, [2..3] their entries
+    int64_t n_kept = n_own;   // (fused builds: n_own is the bound the buffers were sized by, the kept entries are counted here)
     {
         uint32_t bc[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // (pairs_len_kernel's counters, one copy)
         ReadBack rb(ctx);
+        if (fused) GT_HIP(ctx, rb.add(&n_kept, g->pos_sorted.as<int64_t>() + nloc, sizeof(int64_t)));
         GT_HIP(ctx, rb.add(&nnz, g->indptr.as<int64_t>() + nloc, sizeof(int64_t)));
         GT_HIP(ctx, rb.add(bc, g->bigcount.p, 8 * sizeof(uint32_t)));
         GT_HIP(ctx, rb.sync());
@@ -3181,7 +3187,7 @@ static int graph_finish_pairs(gt_ctx* ctx, int64_t* out_nnz, uint32_t* flags) {
         GT_HIP(ctx, rb.add(&kfl, k->gflags.p, sizeof(uint32_t)));
         GT_HIP(ctx, rb.sync());
     }
-    g->nnz0 = n_own;
+    g->nnz0 = n_kept;
     g->nnz = nnz;
     g->finished = true;
     fl |= kfl;
