@@ -588,3 +588,35 @@ def test_two_rank_sharding_with_knn_max_follows_the_reference_branches(n, d, mak
     assert np.array_equal(np.concatenate(ptrs + [[base]]), Kp)
     assert np.array_equal(np.concatenate(inds), Ki)
     assert np.array_equal(np.concatenate(datas), Kd)
+
+
+def test_recycled_result_arrays_take_the_direct_copy_and_hold_the_same_bits():
+    """the big result arrays of a dropped graph are handed out again (graphtools_amd._hip._HostPool) and a copy into such resident
+    memory goes direct, in 64 MiB pieces with host threads deriving P behind it (gt_hostcopy.cpp) - the first fetch of a process
+    goes through the staging lanes into fresh memory: K and P of both must be the same bits, and P the device's own"""
+    import gc
+
+    X = make_mix(300000, 32, 5)
+    _hip._host_pool.clear()
+    ref = None
+    addr = []
+    for rep in range(3):
+        c = _hip.Context(0)
+        c.set_points(X)
+        p, keep = c.make_params(15, 40.0, 1e-4, None, 1.0, None, "+", None, 0)
+        c.graph_build(p)
+        kd, ind, ptr, pd = c.graph_fetch_kp()
+        assert kd.nbytes >= _hip._HostPool.MIN_BYTES, "the case should be large enough for the pool"
+        addr.append(kd.__array_interface__["data"][0])
+        pdev = c.graph_fetch_csr(_hip.CSR_P, structure=False)[0]
+        assert np.array_equal(pd, pdev), "P derived on the host differs from the device's P"
+        cur = (kd.copy(), ind.copy(), ptr.copy(), pd.copy())
+        if ref is None:
+            ref = cur
+        else:
+            for a, b in zip(ref, cur):
+                assert np.array_equal(a, b)
+        c.close()
+        del kd, ind, ptr, pd, pdev
+        gc.collect()
+    assert addr[1] == addr[0] or addr[2] in addr[:2], "the result arrays were never recycled"
