@@ -285,18 +285,44 @@ __global__ __launch_bounds__(64) void landmark_neighbours_kernel(const _Float16*
     typedef _Float16 half8 __attribute__((ext_vector_type(8)));
     const half8* ra = reinterpret_cast<const half8*>(Yl + size_t(a) * DP);
     const int c8 = DP / 8;
-    for (int b = lane; b < L; b += 64) {
-        const half8* rb = reinterpret_cast<const half8*>(Yl + size_t(b) * DP);
-        float acc = 0.f;
-        for (int c = 0; c < c8; ++c) {
-            const half8 va = ra[c], vb = rb[c];
+    if (DP == 64) {
+        // (the usual width: the landmark's own row is widened once, not once per other landmark - a quarter of the loop's
+        //  instructions; same operations on the same values in the same order: same distances)
+        float fa[64];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float df = float(va[e]) - float(vb[e]);
-                acc = fmaf(df, df, acc);
-            }
+        for (int c = 0; c < 8; ++c) {
+            const half8 va = ra[c];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) fa[8 * c + e] = float(va[e]);
         }
-        dist[b] = acc;
+        for (int b = lane; b < L; b += 64) {
+            const half8* rb = reinterpret_cast<const half8*>(Yl + size_t(b) * DP);
+            float acc = 0.f;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const half8 vb = rb[c];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float df = fa[8 * c + e] - float(vb[e]);
+                    acc = fmaf(df, df, acc);
+                }
+            }
+            dist[b] = acc;
+        }
+    } else {
+        for (int b = lane; b < L; b += 64) {
+            const half8* rb = reinterpret_cast<const half8*>(Yl + size_t(b) * DP);
+            float acc = 0.f;
+            for (int c = 0; c < c8; ++c) {
+                const half8 va = ra[c], vb = rb[c];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float df = float(va[e]) - float(vb[e]);
+                    acc = fmaf(df, df, acc);
+                }
+            }
+            dist[b] = acc;
+        }
     }
     __syncthreads();
     for (int m = 0; m < M; ++m) {
