@@ -325,16 +325,46 @@ __global__ __launch_bounds__(64) void landmark_neighbours_kernel(const _Float16*
         }
     }
     __syncthreads();
-    for (int m = 0; m < M; ++m) {
-        float best = INFINITY;
-        int bi = 0x7fffffff;
+    // The M nearest, in turn (distance, then index).  Every lane keeps the four best of ITS landmarks (b = lane, lane + 64, ...)
+    // in order; a round is the wave's arg-min over the lanes' heads, and the lane that won moves its queue up.  A lane whose
+    // queue runs dry while it may still hold candidates - more than four of the M nearest in one residue class: rare - scans its
+    // landmarks again (the taken ones are marked in the LDS).  (Until round 5 every round scanned all L distances: 32 x 64
+    // reads and compares per lane instead of 64 + 32 x a handful.)
+    float cv[4] = {INFINITY, INFINITY, INFINITY, INFINITY};
+    int ci[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
+    auto refill = [&]() {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            cv[q] = INFINITY;
+            ci[q] = 0x7fffffff;
+        }
         for (int b = lane; b < L; b += 64) {
-            const float v = dist[b];
-            if (v < best) {
-                best = v;
-                bi = b;
+            float v = dist[b];
+            int vi = b;
+            if (v < INFINITY) {   // (insertion into the sorted four; equal values keep the smaller index in front: b ascends)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const bool lt = v < cv[q];
+                    const float tv = lt ? cv[q] : v;
+                    const int ti = lt ? ci[q] : vi;
+                    cv[q] = lt ? v : cv[q];
+                    ci[q] = lt ? vi : ci[q];
+                    v = tv;
+                    vi = ti;
+                }
             }
         }
+    };
+    refill();
+    bool dry = false;   // the queue has been emptied by wins: the lane may hold more (a fifth candidate was never recorded)
+    for (int m = 0; m < M; ++m) {
+        if (__ballot(dry && cv[0] == INFINITY) != 0ull) {   // (wave-uniform; all lanes rebuild - their queues come out the same)
+            __syncthreads();
+            refill();
+            dry = false;
+        }
+        float best = cv[0];
+        int bi = ci[0];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             const float ov = __uint_as_float(lane_xor_b32(__float_as_uint(best), o));
@@ -344,11 +374,15 @@ __global__ __launch_bounds__(64) void landmark_neighbours_kernel(const _Float16*
                 bi = oi;
             }
         }
-        if (lane == 0) {
-            nbr[size_t(a) * M + m] = (bi < L) ? bi : a;
-            if (bi < L) dist[bi] = INFINITY;
+        if (bi < L && (bi & 63) == lane) {   // this lane's head was taken
+            dist[bi] = INFINITY;
+            cv[0] = cv[1]; ci[0] = ci[1];
+            cv[1] = cv[2]; ci[1] = ci[2];
+            cv[2] = cv[3]; ci[2] = ci[3];
+            cv[3] = INFINITY; ci[3] = 0x7fffffff;
+            dry = true;
         }
-        __syncthreads();
+        if (lane == 0) nbr[size_t(a) * M + m] = (bi < L) ? bi : a;
     }
 }
 
