@@ -981,6 +981,18 @@ __global__ __launch_bounds__(256) void bin_emit_slots_kernel(const int64_t nloc,
     }
 }
 
+constexpr int kBigRow = 512;    // longer rows go to sort_merge_long_kernel
+constexpr uint32_t kFusedHugeRow = 2u;
+constexpr int kPairHugeRow = 1024;   // pair-resolved tail: union rows beyond this go to the segmented sort (see merge_long_final_kernel)
+// What pairs_len_kernel hands the final merge, written by bin_fill_kernel itself where it is given (fused-destination builds: the
+// kernel knows every union row's length the moment it has placed the row - a separate pass over the rows cost 0.11 ms)
+struct PairsOut {
+    int32_t* outlen;       // [row] final length of the row (null: not wanted)
+    int32_t* biglist;      // rows for merge_long_final_kernel from [0] upwards, rows beyond the register sorts from [nloc - 1] downwards
+    uint32_t* bigcount;    // [0] long rows, [1] rows of 129 ... kBigRow entries, [2] flags, [4] huge rows, [6..7] their entries
+    int32_t* midlist;      // rows of 129 ... kBigRow entries
+};
+
 // One workgroup per bin.  sN: exclusive scan of the own-entry counts in sorted order (lenNs), binoff: of the bins'
 // triplet counts - the bin's union rows start at sN[first row] + binoff[bin].
 template <int NT>   // threads per workgroup (the kernel waits on load -> LDS atomic -> store chains: more of them in flight)
@@ -993,8 +1005,11 @@ __global__ __launch_bounds__(NT) void bin_fill_kernel(const int64_t nloc, const 
                                                        const Triplet* __restrict__ trip, const int32_t* __restrict__ lenNs,
                                                        const int64_t* __restrict__ sN, int64_t* __restrict__ off,
                                                        UEntry* __restrict__ U, uint32_t* __restrict__ ucol,
-                                                       double* __restrict__ uval) {
+                                                       double* __restrict__ uval, const PairsOut po) {
     // ucol / uval given (fused tail): the received entries go there as (column, value) in separate arrays instead of U
+    __shared__ uint32_t mid_n, mid_base;
+    __shared__ int32_t mid_rows[1024];   // (R <= 4096 rows per bin in principle; lists beyond 1024 medium rows of one bin go out one by one)
+    if (po.outlen && threadIdx.x == 0) mid_n = 0u;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int R = 1 << shift;
     int32_t* cnt = reinterpret_cast<int32_t*>(smem_raw);   // [R] received entries per row, then the cursor of its T part
@@ -1084,7 +1099,30 @@ __global__ __launch_bounds__(NT) void bin_fill_kernel(const int64_t nloc, const 
             off[p0 + r] = ubase + run;
             run += ln + lt;
             lnrun += ln;
+            if (po.outlen) {   // (what pairs_len_kernel did in a pass of its own)
+                const int32_t L = ln + lt;
+                const int32_t row = perm[p0 + r];
+                po.outlen[row] = L;
+                if (L > kPairHugeRow) {
+                    atomicOr(po.bigcount + 2, kFusedHugeRow);
+                    po.biglist[nloc - 1 - int64_t(atomicAdd(po.bigcount + 4, 1u))] = row;
+                    atomicAdd(reinterpret_cast<unsigned long long*>(po.bigcount + 6), (unsigned long long)L);
+                } else if (L > kBigRow) {
+                    po.biglist[atomicAdd(po.bigcount, 1u)] = row;
+                } else if (L > 128) {
+                    const uint32_t q = atomicAdd(&mid_n, 1u);
+                    if (q < 1024u) mid_rows[q] = row;
+                    else po.midlist[atomicAdd(po.bigcount + 1, 1u)] = row;
+                }
+            }
         }
+    }
+    if (po.outlen) {   // the bin's medium rows: one atomic for all of them
+        __syncthreads();
+        const uint32_t nm = mid_n < 1024u ? mid_n : 1024u;
+        if (threadIdx.x == 0) mid_base = nm ? atomicAdd(po.bigcount + 1, nm) : 0u;
+        __syncthreads();
+        for (uint32_t q = threadIdx.x; q < nm; q += NT) po.midlist[mid_base + q] = mid_rows[q];
     }
     if (b == nbins - 1 && threadIdx.x == NT - 1) off[nloc] = ubase + run;
     __syncthreads();
@@ -1299,7 +1337,7 @@ __device__ __forceinline__ int sort_merge_row(const RowSrc& U, const int L, cons
     return merge_sorted_regs<NT>(hi, lo, lane, symm, theta, Vk, Vv);
 }
 
-constexpr int kBigRow = 512;    // longer rows go to sort_merge_long_kernel
+// (kBigRow: defined in front of bin_fill_kernel)
 constexpr int kHugeRow = 2048;  // and beyond that to the global-memory sort (big_sort_kernel)
 
 __global__ __launch_bounds__(256) void sort_merge_kernel(const int64_t nloc, const int64_t* __restrict__ off,
@@ -1567,11 +1605,10 @@ __device__ __forceinline__ RowSrc3 make_row_src3(const FusedSrc& fs, const int64
     return r;
 }
 
-constexpr uint32_t kFusedHugeRow = 2u;
+// (kFusedHugeRow, kPairHugeRow: defined in front of bin_fill_kernel)
 // pair-resolved tail: union rows beyond this go to the segmented sort (symm_huge).  1024, not kHugeRow: the 32-keys-per-lane
 // register network that served 1025 ... 2048 entries needs 260 VGPRs and 272 B of scratch - ONE such row took ~1 ms (a hundred
 // thousand unrolled instructions at one wave per SIMD), longer than the merge of the million short rows it ran beside.
-constexpr int kPairHugeRow = 1024;
 
 // merge of a sorted (key, value) sequence held in registers straight into the final CSR row at dst; returns the row sum
 // in compact_kernel's order.  Keys: (column << 1) | tag, kNoKey where there is no entry.
@@ -2768,7 +2805,8 @@ static int graph_finish_impl(gt_ctx* ctx, const void* recv_buf_dev, int64_t n_re
                        g->rowsrc.as<int32_t>(), g->rlists.as<uint64_t>(), g->rcounts.as<uint32_t>(), g->rcap,               \
                        g->rK.as<double>(), g->tablen.as<int32_t>(), perm, shift, nbins, g->binoff.as<int64_t>(),            \
                        (const Triplet*)g->selfbuf.p, g->cnt_sorted.as<int32_t>(), g->pos_sorted.as<int64_t>(),              \
-                       g->off.as<int64_t>(), g->Ukey.as<UEntry>(), (uint32_t*)nullptr, (double*)nullptr)
+                       g->off.as<int64_t>(), g->Ukey.as<UEntry>(), (uint32_t*)nullptr, (double*)nullptr,                        \
+                       PairsOut{nullptr, nullptr, nullptr, nullptr})
             GT_BIN_FILL(256);
 #undef GT_BIN_FILL
             GT_HIP(ctx, hipGetLastError());
@@ -3024,10 +3062,13 @@ static int graph_finish_pairs(gt_ctx* ctx, int64_t* out_nnz, uint32_t* flags) {
                            g->rlists.as<uint64_t>(), g->rcounts.as<uint32_t>(), g->rcap, g->rK.as<double>(),
                            g->tablen.as<int32_t>(), perm, shift, nbins, g->binoff.as<int64_t>(), (const Triplet*)g->selfbuf.p,
                            g->cnt_sorted.as<int32_t>(), g->pos_sorted.as<int64_t>(), g->off.as<int64_t>(), (UEntry*)nullptr,
-                           g->ucol.as<uint32_t>(), g->uval.as<double>());
+                           g->ucol.as<uint32_t>(), g->uval.as<double>(),
+                           fused ? PairsOut{g->outlen.as<int32_t>(), g->bigrows.as<int32_t>(), g->bigcount.as<uint32_t>(), g->midrows.as<int32_t>()}
+                                 : PairsOut{nullptr, nullptr, nullptr, nullptr});
         GT_HIP(ctx, hipGetLastError());
     }
-    // final row lengths (own + received: nothing merges), CSR offsets in row order
+    // final row lengths (own + received: nothing merges), CSR offsets in row order (fused builds: bin_fill_kernel wrote them)
+    if (!fused)
     hipLaunchKernelGGL(pairs_len_kernel, dim3((unsigned)ceil_div64(nloc, 256)), dim3(256), 0, ctx->stream, nloc,
                        k->sh_invperm.as<int32_t>(), g->off.as<int64_t>(), g->outlen.as<int32_t>(), g->bigrows.as<int32_t>(),
                        g->bigcount.as<uint32_t>(), fflags, fused ? g->midrows.as<int32_t>() : (int32_t*)nullptr);
