@@ -686,7 +686,8 @@ __global__ __launch_bounds__(64 * WPB, GT_RERANK_WAVES) void rerank_sym4_kernel(
     const uint32_t n_def = n_cut > uint32_t(need_m) ? n_cut : uint32_t(need_m);
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-        if (uint32_t(u * 64) < n_def) {   // wave-uniform
+        // (only the defined slots travel: a row's 80 entries of the 128 its two chunks hold - a gigabyte of the launch's stores)
+        if (uint32_t(u * 64 + lane) < n_def) {
             cand_d2[size_t(tq) * MP + u * 64 + lane] = __longlong_as_double((long long)hi[u]);
             cand_j[size_t(tq) * MP + u * 64 + lane] = uint32_t(lo[u]);
             if (want_t) cand_d2t[size_t(tq) * MP + u * 64 + lane] = __longlong_as_double((long long)hx[u]);
