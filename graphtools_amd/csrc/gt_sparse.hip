@@ -425,15 +425,19 @@ __global__ __launch_bounds__(256) void affinity_slots_kernel(
             if (posj) h.c0 = sC[t];
         }
     };
-    auto load_tab = [&](const int64_t t, SlotTab& x) {
-        if (t < t1) {   // (all 128 slots, whatever the count: inside the row's stride, masked where they are used)
+    auto load_tab = [&](const int64_t t, const Hdr& h, SlotTab& x) {
+        if (t < t1) {   // (the row's defined slots: its header arrived a row earlier)
             const size_t o = size_t(t) * MP + lane;
-            x.d2a = cand_d2[o];
-            x.ja = cand_j[o];
-            x.ta = cand_d2t[o];
-            x.d2b = cand_d2[o + 64];
-            x.jb = cand_j[o + 64];
-            x.tb = cand_d2t[o + 64];
+            if (uint32_t(lane) < h.r.n) {
+                x.d2a = cand_d2[o];
+                x.ja = cand_j[o];
+                x.ta = cand_d2t[o];
+            }
+            if (uint32_t(lane) + 64u < h.r.n) {
+                x.d2b = cand_d2[o + 64];
+                x.jb = cand_j[o + 64];
+                x.tb = cand_d2t[o + 64];
+            }
         }
     };
     // three rows in flight: the table of row t + 2 and the header of row t + 3 are requested, then the partners' records of
@@ -453,13 +457,13 @@ __global__ __launch_bounds__(256) void affinity_slots_kernel(
     SlotTab x0 = {0.0, 0.0, 0.0, 0.0, 0u, 0u}, x1 = x0, x2 = x0;
     SlotBw g0 = {{1.0, 0u, 0u}, {1.0, 0u, 0u}}, g1 = g0;
     load_hdr(t0, h0);
-    load_tab(t0, x0);
     load_hdr(t0 + 1, h1);
-    load_tab(t0 + 1, x1);
     load_hdr(t0 + 2, h2);
+    load_tab(t0, h0, x0);
+    load_tab(t0 + 1, h1, x1);
     load_bw(t0, h0, x0, g0);
     for (int64_t t = t0; t < t1; ++t) {
-        load_tab(t + 2, x2);
+        load_tab(t + 2, h2, x2);
         load_hdr(t + 3, h3);
         load_bw(t + 1, h1, x1, g1);
         const uint32_t n = h0.r.n;
