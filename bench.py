@@ -858,7 +858,7 @@ def main():
                 import graphtools_amd
 
                 ts = []
-                for _ in range(5):   # (five: the first call of a process allocates the result arrays, later ones recycle them)
+                for _ in range(7):   # (seven: the first call of a process allocates the result arrays, the second is the first to recycle them)
                     t0 = time.perf_counter()
                     G = graphtools_amd.Graph(X, knn=args.knn, decay=args.decay, n_pca=None, verbose=0)
                     Kh, Ph = G.K, G.P
@@ -870,7 +870,7 @@ def main():
                                         "note": "graphtools_amd.Graph(X, knn=15, decay=40).K/.P: pageable host X in, scipy CSR out "
                                                 "(H2D 256 MB, build, D2H of K values + indices + indptr; the P values are derived "
                                                 "from K and the degrees by host threads while K arrives - bit-identical to "
-                                                "the device's P, which stays on the device for device consumers); median of five "
+                                                "the device's P, which stays on the device for device consumers); median of seven "
                                                 "calls in one process: the result arrays of a dropped graph are recycled "
                                                 "(graphtools_amd._hip._HostPool) and a copy into resident memory runs at the "
                                                 "link's rate - the first call of a process, into fresh arrays, is the slowest of "
