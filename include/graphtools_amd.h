@@ -91,37 +91,72 @@ int gt_device_count(void);
  * the parked blocks back to the driver. */
 int gt_release_cached_memory(void);
 /* per-stage GPU time (ms, hipEvent on the ctx stream) of the most recent call that ran `stage`;
- * stages: "prep" "knn_select" "rerank" "fallback" "radius" "affinity" "symmetrize" "normalize"
- *         "dense_bandwidth" "dense_kernel" "dense_normalize" "landmark".  Returns <0 if never run. */
+ * stages: "prep" "query_order" "sym_prepare" "sym_seed" "sym_bound" "sym_cold" "knn_select" "rerank" "fallback" "radius"
+ *         "affinity" "symmetrize" (with its parts "symm_bins" "symm_merge" "symm_huge" "symm_compact") "normalize" "renumber"
+ *         "sym_exchange" "dense_bandwidth" "dense_kernel" "dense_normalize" "dense_rows_listed" "dense_rows_placed"
+ *         "landmark" "landmark_assign" "pca_gram" "pca_matmul" "pca_tmatmul" "spmm".  Returns <0 if never run. */
 double gt_stage_ms(const gt_ctx* ctx, const char* stage);
 /* number of launches accumulated for `stage` in the most recent call (for roofline: ms / launches) */
 int gt_stage_launches(const gt_ctx* ctx, const char* stage);
 
-/* Options (call before gt_set_points).  "knn_precision": arithmetic of the candidate pass -
- *   "auto"  (default) float16 MFMA: one chain on the high float16 plane of every value when the bound data tolerate
- *           its wider score error bound (judged after the first pass: at most 20 % of the rows left to the repair passes), otherwise
- *   "f16"   three chains on two float16 planes per value (2^-22), "f16x1" forces the single chain,
- *   "f32"   float32 MFMA.
- * Results never depend on it - exact ordering and values always come from the float64 stage, rows whose candidate
- * table cannot be proven complete are repaired on the accurate arithmetic - only speed does.  The environment
- * variable GT_KNN_PRECISION sets the default.  Also: "metric" ("euclidean" | "cosine"); "query_order" ("auto" | "off":
- * deal the query rows of large launches to workgroups grouped by nearest landmark - speed only).  Tuning switches of
- * the candidate pass (development; results never depend on them): "select_samp_stride", "select_samp_keep",
- * "select_samp_end", "select_samp2_level", "select_samp2_keep", "select_samp_trig", "select_thr0", "select_narrow",
- * "query_order_cell_rows", "query_order_min_rows"; "select_symmetric" ("auto" | 0 | 1: self queries over the whole point set score every
- * unordered pair of rows once and test the result for both rows - gt_sym.hip), "select_sym_stride",
- * "select_sym_min_rows", "select_sym_tcap", "select_sym_cells", "select_sym_max_nb", "select_sym_nseg", "select_sym_shard_group", "select_sym_two_stage", "select_sym_radius_cut", "select_sym_orphan_far", "select_sym_queue_cap", "select_sym_two_steps",
- * "select_sym_dense_seed" (dense cell-block seeding kernel, gt_seed.hip), "select_sym_sorted_points" (the exact stages read a
- * cell-sorted copy of the points), "select_sym_cosine" (the symmetric pass serves the cosine metric too), "rerank_lanes4",
- * "symmetrize_bins", "symmetrize_bin_shift", "symmetrize_fill_threads", "symmetrize_fused", "symmetrize_pairs" (pair-resolved
- * symmetrisation of single-rank '+' builds: every row settles its mutual pairs itself, only one-sided entries are transposed),
- * "select_sym_cold_split" (0 | 1: the cold launch behind the bound pass scores with the three split chains - tighter thresholds,
- * a third fewer candidates for the re-rank; no net gain measured, default 0),
- * "xcd_chunk", "rerank_waves_per_block" / "row_waves_per_block" (1 | 4: rows per workgroup of the wave-per-row kernels; 1 = a long
- * row holds no idle wave slots); "dbg_select" switches invalidate the results.
- * "distance_dtype" ("data" | "float64") DOES change results, by design: "float64" takes the distances of a float32 point set from
- * the float64 keys unrounded (scipy pdist semantics, the exact graph built through this path - gt_graph_to_dense) instead of
- * rounding them to float32 as scikit-learn's kneighbors does (graphs.py:883). */
+/* Options (call before gt_set_points).  Every name gt_set_option accepts is listed between the OPTIONS markers below, one
+ * per line (tests/test_abi.py checks the list against the parser in csrc/gt_api.cpp in both directions, tests/test_gpu_dropin.py
+ * sets each of them on the device); anything else returns GT_E_ARG "unknown option".  Results never depend on an option unless
+ * its line says so: exact ordering and values always come from the float64 stages, rows whose candidate table cannot be proven
+ * complete are repaired - the tuning switches only move time.  Values are decimal integers unless stated; "auto" where listed.
+ * OPTIONS-BEGIN
+ *   knn_precision            "auto" | "f16x1" | "f16" | "f32": arithmetic of the candidate pass.  auto (default): one float16 MFMA
+ *                            chain on the high plane of every value when the bound data tolerate its wider score error bound
+ *                            (judged after the first pass: at most 20 % of the rows left to the repair passes), else "f16" = three
+ *                            chains on two float16 planes (2^-22); "f16x1" forces the single chain; "f32" float32 MFMA.
+ *                            Environment variable GT_KNN_PRECISION sets the default.  Points must be bound again afterwards.
+ *   metric                   "euclidean" | "cosine" (graphs.py:763-768 hands the metric to scikit-learn).  CHANGES RESULTS, by
+ *                            definition.  Points must be bound again afterwards.
+ *   distance_dtype           "data" | "float64".  CHANGES RESULTS, by design: "float64" takes the distances of a float32 point set
+ *                            from the float64 keys unrounded (scipy pdist semantics, the exact graph built through this path)
+ *                            instead of rounding them to float32 as scikit-learn's kneighbors does (graphs.py:883).
+ *   query_order              "auto" | "off": deal the query rows of large launches to workgroups grouped by nearest landmark.
+ *   query_order_min_rows     launches with fewer query rows are not grouped (32768).
+ *   query_order_cell_rows    rows per landmark cell (244).
+ *   query_order_outliers     0 | 1: rows far from every landmark get a cell of their own (1).
+ *   select_samp_stride       classic pass: threshold-seeding phase over every n-th tile (32; <= 1: off).
+ *   select_samp_keep         list budget of that phase (0: the neighbours wanted, at least 16).
+ *   select_samp_end          list budget at the end of that phase (-1: same as select_samp_keep, 0: none).
+ *   select_nt8_max_need      tables of up to this many neighbours use the 512-slot lists (88), larger ones the 2048-slot lists.
+ *   select_narrow            "auto" | 0 | 1: 128-row-workgroup candidate kernels (auto: launches with few query rows).
+ *   select_symmetric         "auto" | 0 | 1: self queries over the whole point set score every unordered pair of rows once and
+ *                            test the result for both rows (gt_sym.hip); 0 forces the classic pass (every query against every row).
+ *   select_sym_min_rows      auto runs the symmetric pass from this many rows (65536).
+ *   select_sym_stride        threshold-seeding launch: every n-th tile besides the row's own neighbourhood (768; 0: none).
+ *   select_sym_cells         ... whose size is the rows of this many nearest cells (8; 1 ... 32).
+ *   select_sym_dense_seed    0 | 1: dense cell-block seeding kernel with the keys in registers (gt_seed.hip) (1).
+ *   select_sym_tcap          capacity of a row's candidate list (512; 64 ... 512).
+ *   select_sym_nseg          work items per query block of the collect launch (0: chosen to fill the last round; <= 8).
+ *   select_sym_shard_group   row-sharded collect: query blocks per rotation step of the walk pieces (32).
+ *   select_sym_two_stage     "auto" | 0 | 1: the collect scores 16 leading directions first (partial distances).
+ *   select_sym_pca           0 | 1: ... the 16 leading principal directions (1) or the first 16 features (0).
+ *   select_sym_bounds        "auto" | 0 | 1: bound pass (cell balls) in front of the collect.
+ *   select_sym_bound_cap     units the bound pass may leave before the two-stage collect runs instead (0: 4 M).
+ *   select_sym_queue_cap     entries per wave region of the two-stage queue (0: sized from the problem).
+ *   select_sym_spill_cap     entries of the shared spill area behind the regions (0: 4 M).
+ *   select_sym_cold_local    0 | 1: the cold launch scores its units in the frame of their queries (1).
+ *   select_sym_orphan_far    a row whose far-kept seeds reach n times the seeds wanted is repaired (0: off).
+ *   select_sym_cosine        0 | 1: the symmetric pass also serves the cosine metric (1).
+ *   select_sym_sorted_points 0 | 1: the exact stages read a cell-sorted copy of the points (1).
+ *   rerank_lanes4            0 | 1: re-rank of the symmetric pass with four lanes per candidate row (1).
+ *   symmetrize_bins          "auto" | 0 | 1: single-rank symmetrisation through destination bins (gt_sparse.hip).
+ *   symmetrize_bin_shift     log2 of the rows per bin (0: 9, more from 2 M rows; else 8 ... 12).
+ *   symmetrize_key32         0 | 1: per-row sorts of the symmetrisation on 32-bit keys where columns and positions fit (1).
+ *   symmetrize_pairs         0 | 1 | 2: pair-resolved symmetrisation of '+' builds - every row settles its mutual pairs itself,
+ *                            only one-sided entries are transposed; 2 (default): with the tables by sorted position.
+ *   symmetrize_pairs_huge    0 | 1: union rows beyond the register sorts are finished by a segmented sort (1) or refute the path.
+ *   dense_rows               "auto" | 0 | 1: exact graph from float32 distances, '+' rule, in the row-streaming form (auto: from
+ *                            16384 rows).
+ *   dense_rows_fused         0 | 1: its list of kept affinities comes out of the bandwidth pass (1).
+ *   dense_rows_cap           entries that list may hold (0: 1024 per row, at least 2^24; beyond it: the tile-pair form).
+ *   dense_fused_rowsum       0 | 1: float32 matrices: row sums accumulated by the tile kernel (1).
+ *   dbg_select               development switches (bit mask); INVALIDATES RESULTS for some bits.
+ * OPTIONS-END */
 int gt_set_option(gt_ctx* ctx, const char* name, const char* value);
 /* arithmetic the most recent main candidate pass ran on: 0 float32, 1 split float16 (3 chains), 2 single float16 chain */
 int gt_last_knn_precision(const gt_ctx* ctx);

@@ -27,6 +27,29 @@ def test_library_exports_every_declared_symbol():
     assert not missing, missing
 
 
+def header_options():
+    """the option names include/graphtools_amd.h documents (between its OPTIONS-BEGIN / OPTIONS-END markers, one per line)"""
+    text = open(HEADER).read()
+    block = text[text.index("OPTIONS-BEGIN"):text.index("OPTIONS-END")]
+    return re.findall(r"^ \*   ([a-z][a-z0-9_]*) ", block, flags=re.M)
+
+
+def test_header_documents_exactly_the_options_the_parser_accepts():
+    """the public header is the boundary's documentation: every option it names is one gt_set_option parses
+    (csrc/gt_api.cpp) and the other way round (the device-side check that each is ACCEPTED: test_gpu_dropin.py)"""
+    src = open(os.path.join(ROOT, "graphtools_amd", "csrc", "gt_api.cpp")).read()
+    body = src[src.index("int gt_set_option("):src.index('"unknown option"')]
+    parsed = re.findall(r'k == "([a-z0-9_]+)"', body)
+    named = header_options()
+    assert len(named) == len(set(named)) and len(parsed) == len(set(parsed))
+    assert sorted(named) == sorted(parsed), (sorted(set(named) - set(parsed)), sorted(set(parsed) - set(named)))
+    # ... and no option name appears in the header's prose that is not in the list (stale documentation)
+    text = open(HEADER).read()
+    prose = text[:text.index("OPTIONS-BEGIN")] + text[text.index("OPTIONS-END"):]
+    quoted = set(re.findall(r'"((?:select|symmetrize|query_order|rerank|xcd|row)_[a-z0-9_]+)"', prose))
+    assert quoted <= set(named), sorted(quoted - set(named))
+
+
 def test_python_binding_covers_header():
     assert set(_declared_functions()) == set(_hip._SIGNATURES)
 

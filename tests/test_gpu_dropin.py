@@ -221,3 +221,21 @@ def test_host_copy_of_P_derived_on_the_way_equals_the_device_P():
         c.close()
         assert np.array_equal(kd, kd2) and np.array_equal(ki, ki2) and np.array_equal(kp, kp2)
         assert np.array_equal(pd, pd2), "host-derived P differs from the device's (anisotropy %g)" % aniso
+
+
+def test_every_option_the_header_documents_is_accepted_and_nothing_else():
+    """include/graphtools_amd.h OPTIONS list <-> gt_set_option on the device (the CPU half: test_abi.py)"""
+    from graphtools_amd import _hip
+    from test_abi import header_options
+
+    values = {"knn_precision": "auto", "metric": "euclidean", "distance_dtype": "data", "query_order": "auto"}
+    c = _hip.Context(0)
+    try:
+        for name in header_options():
+            c.set_option(name, values.get(name, "0" if name == "dbg_select" else "1"))
+        for stale in ("select_thr0", "symmetrize_fused", "select_sym_cold_split", "xcd_chunk", "rerank_waves_per_block",
+                      "row_waves_per_block", "select_samp2_level", "select_samp_trig", "no_such_option"):
+            with pytest.raises(Exception, match="unknown option"):
+                c.set_option(stale, "1")
+    finally:
+        c.close()
