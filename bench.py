@@ -305,6 +305,23 @@ class StageTimes:
         return float(np.mean(self.acc[s])) if self.acc[s] else 0.0
 
 
+def candidate_counts(ctx, nloc):
+    """(candidates in the lists of the symmetric pass, table entries the re-rank kept) of the most recent build, read back
+    through the library's development fetch (gt_dbg_fetch_sym: list lengths, table lengths); (None, None) if unavailable"""
+    import ctypes
+    try:
+        fn = ctx.lib.gt_dbg_fetch_sym
+        fn.restype = ctypes.c_int
+        fn.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p]
+        lens = np.zeros(nloc, dtype=np.uint32)
+        tabs = np.zeros(nloc, dtype=np.uint32)
+        if fn(ctx.h, 3, nloc, lens.ctypes.data) != 0 or fn(ctx.h, 13, nloc, tabs.ctypes.data) != 0:
+            return None, None
+        return float(np.minimum(lens, 512).sum(dtype=np.int64)), float(tabs.sum(dtype=np.int64))
+    except Exception:
+        return None, None
+
+
 def kernel_table(ctx, st, n, nloc, d, world, nnz, nnz0, main):
     """One entry per timed launch group: what it executes (flop / algorithmic bytes), its time, its roofline fraction."""
     kst = ctx.knn_stats()
@@ -342,7 +359,10 @@ def kernel_table(ctx, st, n, nloc, d, world, nnz, nnz0, main):
                  (" in the frame of their queries (float16 of (x - o) sc formed on the fly); the stage also forms the group centres"
                   if kst.get("sym_cold_local") else ""))
         if not bound_pass and st.mean("knn_select") > 0:
-            if two_stage:
+            if kst.get("sym_listed"):
+                mfma("knn_select", "knn_select_kernel<%d, 8, 2, 2>" % dp, st.mean("knn_select"), cold_flop,
+                     "one-stage symmetric collect over listed walks: the (256 x 128) tiles the cell bounds leave, scored and filed in one launch")
+            elif two_stage:
                 n_pad = -(-n // 1024) * 1024
                 nb = n_pad // 1024
                 walk = 8 * (1 + (nb - 1) // 2) + (0 if nb % 2 else 8)
@@ -358,11 +378,17 @@ def kernel_table(ctx, st, n, nloc, d, world, nnz, nnz0, main):
         mfma("knn_select", "knn_select_kernel<%d, 8, 0, %d>" % (d, {"f32": 0, "f16": 1, "f16x1": 2}[main]), st.mean("knn_select"),
              2.0 * nloc * n * d * MFMA_CHAINS[main], "classic candidate pass: every query row against every point")
     # streaming kernels, algorithmic bytes per SURVEY 8d
-    tab = 128   # table entries the re-rank evaluates / the affinity pass reads per row (first batch)
+    tab = 128   # table entries the affinity pass reads per row (first batch)
+    # the re-rank is priced on what it actually sees (round 6; the 128-slot capacity flattered it by 10-15 %): the candidates
+    # the lists hold (8-byte keys in) and the table entries it keeps (8 + 4 B out), counted on the device after the timed region
+    cand_in, tab_out = candidate_counts(ctx, nloc) if symmetric else (None, None)
+    if cand_in is None:
+        cand_in = tab_out = float(nloc) * tab
     hbm("rerank", ("rerank_sym4_kernel<1, WT>" if (d % 4 == 0 and d <= 64) else "rerank_sym_kernel") if symmetric else "rerank_kernel",
         st.mean("rerank"),
-        nloc * tab * 8.0 + n * d * 4.0 + nloc * tab * 12.0,
-        "candidate lists in (8 B), X once, exact tables out (8 + 4 B); the row gathers come from L2/MALL")
+        cand_in * 8.0 + n * d * 4.0 + tab_out * 12.0,
+        "candidate lists in (8 B x %d candidates = %.1f per row), X once, exact tables out ((8 + 4) B x %d entries kept); "
+        "the row gathers come from L2/MALL" % (int(cand_in), cand_in / max(nloc, 1), int(tab_out)))
     # (tables by sorted position + no row of the radius pass: the pipelined slot kernels of round 5 - st.mean("symm_bins") of such
     #  a build holds no bin_count_kernel; which ones ran shows in the kernel names of the committed rocprofv3 summary)
     hbm("affinity", "bandwidth_kernel + affinity_slots_kernel (+ posj_hist_kernel) | affinity_kernel", st.mean("affinity"),

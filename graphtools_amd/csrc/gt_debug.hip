@@ -206,7 +206,7 @@ extern "C" int gt_dbg_fetch_prof(gt_ctx* ctx, int64_t nwaves, unsigned long long
 }
 
 // development: raw buffers of the symmetric candidate pass (gt_sym.hip) of the most recent kNN call
-//   which: 0 thr (float [n]) 1 perm (int32 [n]) 3 list lengths (uint32 [n])
+//   which: 0 thr (float [n]) 1 perm (int32 [n]) 3 list lengths (uint32 [n]; may exceed the capacity) 13 table lengths (uint32 [n])
 //          4 tile counts of launch A (int32 [blocks]) 5 sorted cell ids (uint32 [n])
 extern "C" int gt_dbg_fetch_sym(gt_ctx* ctx, int32_t which, int64_t count, void* out_host) {
     if (!ctx || !ctx->knn) return GT_E_STATE;
@@ -226,6 +226,7 @@ extern "C" int gt_dbg_fetch_sym(gt_ctx* ctx, int32_t which, int64_t count, void*
         case 10: src = k->sym_thrh.p; break;   // two-stage collect: partial-distance thresholds, half seeds, row radii term
         case 11: src = k->sym_hh.p; break;
         case 12: src = k->sym_gh.p; break;
+        case 13: src = k->cand_n.p; break;     // entries of every exact table (by slot in builds with the tables by sorted position)
         case 7: src = k->sym_work.p; break;    // nbr [L][M] | start [L] | end [L]   // [blocks][tile_stride] tile lists of launch A (count = entries)
         default: return GT_E_ARG;
     }

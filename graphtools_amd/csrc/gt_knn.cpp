@@ -503,7 +503,45 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
                     }
                 }
             }
-            if (two_stage && !bound_done) GT_TRY(gt_sym_two_stage_prepare(ctx, perm, n_pad_s, em, need_m, a, bound_tried));
+            // Too many units for the queue - but the cell masks are there, and they may still rule out most TILES (points near a
+            // low-dimensional sheet: the cells around a row are a few per cent of all cells, while a 244-row cell is compact
+            // only down to its own radius - millions of small units).  Then the one-stage collect streams only the listed
+            // tiles of every query block's walk (gt_sym.hip collect_lists_kernel), scoring and filing in one launch: neither
+            // the stage-one copy (a PCA on the host, two projections) nor the 16-column stream over ALL pairs nor a cold
+            // launch of one round trip per unit.  Taken when the lists hold at most a quarter of the walks (a listed tile
+            // costs ~5 x an unlisted tile of the 16-column stream, plus what the cold launch would have cost).
+            k->sym_listed = false;
+            k->sym_listed_tiles = 0;
+            if (two_stage && bound_tried && !bound_done && ctx->sym_listed != 0 && bq_sym == 256 && bn_sym == 128) {
+                const int64_t nb = n_pad_s / bq_sym;
+                const int wcap = 2048;   // entries per block (a block whose list is longer walks everything)
+                GT_HIP(ctx, k->sym_wlist.reserve(size_t(nb) * wcap * sizeof(int32_t)));
+                GT_HIP(ctx, k->sym_wcnt.reserve(size_t(nb) * sizeof(int32_t) + 16));
+                unsigned long long* tot_dev = reinterpret_cast<unsigned long long*>(
+                    (reinterpret_cast<uintptr_t>(k->sym_wcnt.as<int32_t>() + nb) + 7) & ~uintptr_t(7));
+                int walk = 0;
+                unsigned long long listed = 0;
+                {
+                    StageSpan span(ctx, "sym_bound");
+                    GT_TRY(gt_sym_collect_lists(ctx, n_pad_s, k->sym_bwork, wcap, wcap, k->sym_wlist.as<int32_t>(),
+                                                k->sym_wcnt.as<int32_t>(), tot_dev, &walk));
+                    GT_HIP(ctx, hipMemcpyAsync(&listed, tot_dev, sizeof(listed), hipMemcpyDeviceToHost, ctx->stream));
+                    GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                }
+                const double frac = double(listed) / std::max(1.0, double(nb) * double(walk));
+                if (ctx->dbg_select & 2048)
+                    fprintf(stderr, "[gt] listed walks: %llu tiles of %lld (%.2f %%), walk %d\n", listed, (long long)(nb * walk),
+                            100.0 * frac, walk);
+                if (ctx->sym_listed > 0 || frac <= 0.25) {
+                    a.sym.walk_list = k->sym_wlist.as<int32_t>();
+                    a.sym.walk_cnt = k->sym_wcnt.as<int32_t>();
+                    a.sym.walk_stride = wcap;
+                    k->sym_listed = true;
+                    k->sym_listed_tiles = int64_t(listed);
+                }
+            }
+            if (two_stage && !bound_done && !k->sym_listed)
+                GT_TRY(gt_sym_two_stage_prepare(ctx, perm, n_pad_s, em, need_m, a, bound_tried));
             const bool two_now = bound_done || a.sym.half_steps > 0;
             k->sym_cold_local_used = false;
             // (behind the bound pass only: the units stage one of the two-stage collect lets through - 7.6 M on the manifold
@@ -525,7 +563,7 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
                 a.sym.sc = float(ctx->sc);
                 k->sym_cold_local_used = true;
             }
-            if (!two_now && ctx->sym_mode < 0 && double(k->sym_far) >= 0.5 * double(nq)) {
+            if (!two_now && !k->sym_listed && ctx->sym_mode < 0 && double(k->sym_far) >= 0.5 * double(nq)) {
                 // neither the cell bounds nor the partial distances prune this point set, and every second row found a seed
                 // outside the cells around it: no cluster structure at the cells' scale.  The one-stage collect would score
                 // every pair once with admissions all along - measured slower than the classic pass on such data (isotropic
@@ -1071,8 +1109,10 @@ extern "C" int gt_knn_stats(const gt_ctx* ctx, int64_t* out12) {
     for (int i = 0; i < 8; ++i) out12[4 + i] = (k && k->sym_used) ? int64_t(k->sym_stat_host[i]) : 0;
     if (k && k->sym_used) out12[6] = k->sym_nseg;   // work items per query block of launch B
     if (k && k->sym_used) out12[5] = k->sym_two_used ? k->sym_cold_entries : 0;   // pairs the cold launch scored in full
+    // (one-stage collect over listed walks: the (64 x 32) units its tiles hold - 16 per (256 x 128) tile)
+    if (k && k->sym_used && k->sym_listed && !k->sym_two_used) out12[5] = k->sym_listed_tiles * 16;
     if (k && k->sym_used) out12[7] = (k->sym_two_used ? 1 : 0) | (k->sym_seed_dense ? 2 : 0) | (k->sym_cold_local_used ? 4 : 0) | (k->tab_sorted ? 8 : 0) |
-                                      ((k->tab_sorted && ctx->graph && ctx->graph->pairs_fused) ? 16 : 0);   // bit 0: two-stage collect ran, bit 1: dense seeding kernel, bit 2: cold launch in the local frame, bit 3: tables by sorted position, bit 4: the affinity pass looked the destinations up
+                                      ((k->tab_sorted && ctx->graph && ctx->graph->pairs_fused) ? 16 : 0) | ((k->sym_listed && !k->sym_two_used) ? 32 : 0);   // bit 0: two-stage collect ran, bit 1: dense seeding kernel, bit 2: cold launch in the local frame, bit 3: tables by sorted position, bit 4: the affinity pass looked the destinations up
     if (k && k->sym_used) out12[4] = (k->sym_two_used && k->sym_bound_used) ? 1 : 0;   // units listed by cell bounds, no collect launch
     out12[10] = k ? k->sym_far : 0;                 // kept rows of launch A outside the neighbourhood cells (all points)
     return GT_OK;

@@ -44,6 +44,9 @@ struct KnnWork {
     DevBuf sym_z, sym_p, sym_cov;                 //   the stage-one copy Z = P x, its frame P, sample covariance scratch
     DevBuf sym_qspill;                            //   spill area of the queue (+ its counter)
     DevBuf sym_rrow, sym_bwork;                   //   bound pass: radius of every row in the stage-one copy, cell scratch
+    DevBuf sym_wlist, sym_wcnt;                   //   listed walks of the one-stage collect (gt_sym_collect_lists) + their total
+    bool sym_listed = false;                      //   the last symmetric pass ran the one-stage collect over listed walks
+    int64_t sym_listed_tiles = 0;                 //   ... (256 query rows x 128 rows) tiles it scored
     // Tables laid out by SORTED POSITION (round 5): a whole single-rank '+' build that will take the pair-resolved tail asks for it
     // (want_tab_sorted, gt_sparse.hip); the symmetric re-rank then writes row perm[t]'s table - cand_d2 / cand_j / cand_d2t and
     // the per-table scalars cand_n / d2_lb / keyt_ok - at slot t, and tab_of_row (the inverse permutation) tells everybody who
@@ -256,6 +259,9 @@ int gt_sym_row_radius(gt_ctx* ctx, const int32_t* perm, int64_t n_pad_s, const f
 int gt_sym_bound_queue(gt_ctx* ctx, int64_t n_pad_s, const void* Ys, const float* rrow, DevBuf& work, uint2* queue,
                        uint32_t cap, uint32_t* count_dev, int world = 1, int rank = 0, int group = 1, int64_t own_p0 = 0,
                        int64_t own_p1 = 0);
+// listed walks of the one-stage collect (gt_sym.hip collect_lists_kernel) from the cell masks gt_sym_bound_queue left in `work`
+int gt_sym_collect_lists(gt_ctx* ctx, int64_t n_pad_s, DevBuf& work, int cap, int stride, int32_t* tile_list, int32_t* tile_cnt,
+                         unsigned long long* total_dev, int* walk_out);
 // row-sharded symmetric pass (gt_knn_shard.cpp)
 #define GT_SYM_MAX_WORLD 64
 int gt_sym_g_from_thr(gt_ctx* ctx, int64_t n_pad_s, const float* thr, const float* hs, float* g, float* gmin);

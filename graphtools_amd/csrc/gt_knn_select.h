@@ -67,6 +67,13 @@ struct SymDev {
     const float* gcen = nullptr;
     const float* rloc = nullptr;
     float sc = 0.f;
+    // MODE 2 (one-stage collect) over LISTED walks (gt_sym.hip collect_lists_kernel): query block b visits only the positions
+    // walk_list[b * walk_stride + 0 .. walk_cnt[b]) of its walk (ascending; a position rel is the tile (b TPB + rel) mod T) -
+    // the tiles whose cells the cell bounds of the bound pass could not rule out against the block's own cells; the nseg work
+    // items of a block share its list.  walk_cnt[b] < 0: the list did not fit, the block walks everything.  nullptr: off.
+    const int32_t* walk_list = nullptr;
+    const int32_t* walk_cnt = nullptr;
+    int32_t walk_stride = 0;
     int32_t gc_first = 0;      // the centres of the groups [gc_first, gc_first + gc_count) are formed (gc_count = 0: all)
     int32_t gc_count = 0;
 };

@@ -413,13 +413,22 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
     int n_tr_end = 0;
     const int32_t* tl_base = nullptr;
     int32_t tl_cache = 0;
+    // MODE 2, listed walk (SymDev::walk_list): `it` runs over the entries of the block's list, an entry is a walk position
+    const int32_t* wl_base = nullptr;
     if (own_sched) {
         const int T = ntiles, NB = T / TPB;
         t_begin = 0;
         if (MODE == 2) {
             const int H = (NB - 1) / 2;
             n_tr_end = TPB * (1 + H);
-            const int walk = n_tr_end + ((NB & 1) ? 0 : (NB > 1 ? TPB : 0));
+            int walk = n_tr_end + ((NB & 1) ? 0 : (NB > 1 ? TPB : 0));
+            if (!TWO && sy.walk_list != nullptr) {
+                const int wc_ = sy.walk_cnt[bidx];
+                if (wc_ >= 0) {   // (< 0: the list did not fit - the whole walk)
+                    walk = wc_;
+                    wl_base = sy.walk_list + size_t(bidx) * size_t(sy.walk_stride);
+                }
+            }
             const int nseg = (sy.nseg > 0 ? sy.nseg : 1) * (sy.shard_world > 1 ? sy.shard_world : 1);
             t_begin = int(int64_t(walk) * seg / nseg);          // this item's part of the block's walk
             t_end = int(int64_t(walk) * (seg + 1) / nseg);
@@ -530,15 +539,40 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
     // admissions.
     const int n_a = (MODE == 0 && samp_stride > 1 && !own_sched) ? (ntiles + samp_stride - 1) / samp_stride : 0;
     int t = t_begin, t_step = n_a ? samp_stride : 1, level = 0;
+    // MODE 2: walk positions of the tiles at `it`, it + 1, it + 2 (the position itself, or the entries of the block's list - a
+    // scalar load each, issued an iteration before the value is used), and the tile a position stands for
+    const int tbase_blk = (MODE == 2) ? int((int64_t(bidx) * TPB) % ntiles) : 0;
+    // (list entries come 64 at a time into one register, lane l <- entry wl_c0 + l, and out of it with a readlane: one
+    //  compiler-tracked vector load - and the drain of the memory queue it implies - per ~60 tiles)
+    int32_t wl_cache = 0;
+    int wl_c0 = -(1 << 30);
+    auto walk_rel = [&](const int i_) -> int {
+        if (wl_base == nullptr || i_ >= t_end) return i_;   // wave-uniform
+        if (i_ >= wl_c0 + 64) {
+            wl_c0 = i_;
+            wl_cache = wl_base[i_ + lane < t_end ? i_ + lane : t_end - 1];
+        }
+        return __builtin_amdgcn_readlane(wl_cache, i_ - wl_c0);
+    };
+    auto walk_tile = [&](const int rel_) -> int {
+        const int t_ = tbase_blk + rel_;
+        return t_ >= ntiles ? t_ - ntiles : t_;
+    };
+    int rel_c = 0, rel_n1 = 0, rel_n2 = 0, rel_n3 = 0;
     if (own_sched) {
-        t = int((int64_t(bidx) * TPB + t_begin) % ntiles);                // MODE 2: the own block first (segment 0)
+        if (MODE == 2) {
+            rel_c = walk_rel(t_begin);
+            rel_n1 = walk_rel(t_begin + 1);
+            rel_n2 = walk_rel(t_begin + 2);
+            t = walk_tile(rel_c);                                          // MODE 2: the own block first (segment 0)
+        }
         if (MODE == 0) t = __builtin_amdgcn_readlane(tl_cache, 0);         // sched 1: first entry of the list
     }
     if constexpr (C::GLDS) {
         GT_GLDS_ISSUE(t, 0);
         if constexpr (NBUF == 3) {
             if (t_begin + 1 < t_end) {
-                const int t1_ = (t + 1 >= ntiles) ? t + 1 - ntiles : t + 1;
+                const int t1_ = (MODE == 2) ? walk_tile(rel_n1) : ((t + 1 >= ntiles) ? t + 1 - ntiles : t + 1);
                 GT_GLDS_ISSUE(t1_, 1);
             }
         }
@@ -589,8 +623,7 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
         int t_next = t + t_step, level_next = level, t_step_next = t_step;
         if (own_sched) {
             if (MODE == 2) {
-                t_next = t + 1;
-                if (t_next >= ntiles) t_next -= ntiles;
+                t_next = walk_tile(rel_n1);
             } else if (it + 1 < t_end) {
                 // the list is read 64 entries at a time (one per lane), entries come out with a readlane
                 const int nx = it + 1;
@@ -611,8 +644,10 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
             if (it + 2 < t_end) {
                 int t2_ = t_next + 1;
                 if (t2_ >= ntiles) t2_ -= ntiles;
+                if (MODE == 2) t2_ = walk_tile(rel_n2);
                 GT_GLDS_ISSUE(t2_, (it + 2 - t_begin) % 3);
             }
+            if (MODE == 2) rel_n3 = walk_rel(it + 3);   // (used from the next iteration on)
         } else if (!(GT_EXP & (4 | 32)) && it + 1 < t_end) {
             if constexpr (C::GLDS) {
                 GT_GLDS_ISSUE(t_next, buf ^ 1);   // every wave left buf^1 at the barrier that ended the previous tile
@@ -624,7 +659,7 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
         const float* hb = hn + buf * BN;
         const uint32_t tbase = uint32_t(t) * BN;
         // MODE 2: does this tile's block also take the results as ITS queries?  (wave-uniform; +inf switches the test off)
-        const bool tr_on = MODE == 2 && it >= TPB && it < n_tr_end;
+        const bool tr_on = MODE == 2 && rel_c >= TPB && rel_c < n_tr_end;
         const float* gglob = (MODE == 2) ? sy.g + size_t(tbase) : nullptr;   // row thresholds of this tile (cold path only)
         float gms[BN / 32];
 #pragma unroll
@@ -1070,6 +1105,12 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
         t = t_next;
         t_step = t_step_next;
         level = level_next;
+        if (MODE == 2) {
+            if (NBUF != 3) rel_n3 = walk_rel(it + 3);
+            rel_c = rel_n1;
+            rel_n1 = rel_n2;
+            rel_n2 = rel_n3;
+        }
     }
     if (prof && lane == 0) {
         unsigned long long* o = prof + (size_t(blockIdx.x) * 4 + w) * 8;

@@ -1336,6 +1336,81 @@ __global__ __launch_bounds__(256) void bound_queue_kernel(const int nq64, const 
     if (dbg_cyc && lane == 0) dbg_cyc[q64] = __builtin_readcyclecounter() - t_begin;
 }
 
+
+// ---- listed walks of the one-stage collect (knn_select_kernel<MODE 2>, SymDev::walk_list) --------------------------------
+// When the cell bounds leave too many (64 x 32) units for the queue of the cold launch, they may still rule out most TILES:
+// on points that lie near a low-dimensional sheet the cells around a row are a few per cent of all cells, yet a cell of 244
+// rows is compact only down to its own radius - millions of small units, each with a hit or two, none worth a unit of the
+// cold launch (one memory round trip per unit) but cheap as 128-row tiles streamed through the LDS.  One workgroup per
+// 256-row query block b: `closed` = the AND of the mask rows of the block's cells (bit c: no row of cell c and row of the block
+// can be a pair either needs); position rel of the block's walk (tile (b TPB + rel) mod T) is listed when a cell of the
+// tile's rows is not closed.  The list is ascending, so the walk keeps its order (own block first).  A list that does not
+// fit its `cap` slots is given up (cnt = -1: the block walks everything).  total += tiles listed (the whole walk for a
+// block without a list).
+__global__ __launch_bounds__(256) void collect_lists_kernel(const int NB, const int T, const int TPB, const int walk, const int L,
+                                                            const int words, const uint32_t* __restrict__ tcell,
+                                                            const uint32_t* __restrict__ mask, const int cap, const int stride,
+                                                            int32_t* __restrict__ tile_list, int32_t* __restrict__ tile_cnt,
+                                                            unsigned long long* __restrict__ total) {
+    extern __shared__ uint32_t closed[];   // [words]
+    __shared__ int wsum[4];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int spb = TPB * 4;   // 32-row sub-tiles per query block
+    uint32_t qlo = 0xFFFFu, qhi = 0u;
+    for (int s_ = 0; s_ < spb; ++s_) {
+        const uint32_t c = tcell[size_t(b) * spb + s_];
+        if ((c & 0xFFFFu) != 0xFFFFu) {
+            qlo = (c & 0xFFFFu) < qlo ? (c & 0xFFFFu) : qlo;
+            qhi = (c >> 16) > qhi ? (c >> 16) : qhi;
+        }
+    }
+    if (qlo == 0xFFFFu) {   // pad rows only
+        if (tid == 0) tile_cnt[b] = 0;
+        return;
+    }
+    for (int wd = tid; wd < words; wd += 256) {
+        uint32_t m = 0xFFFFFFFFu;
+        for (uint32_t a = qlo; a <= qhi; ++a) m &= mask[size_t(a) * words + wd];
+        closed[wd] = m;
+    }
+    __syncthreads();
+    int count = 0;
+    int32_t* out = tile_list + size_t(b) * size_t(stride);
+    for (int rel0 = 0; rel0 < walk; rel0 += 256) {
+        const int rel = rel0 + tid;
+        bool need = false;
+        if (rel < walk) {
+            int t = b * TPB + rel;
+            if (t >= T) t -= T;
+            uint32_t dlo = 0xFFFFu, dhi = 0u;
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_) {
+                const uint32_t c = tcell[size_t(t) * 4 + s_];
+                if ((c & 0xFFFFu) != 0xFFFFu) {
+                    dlo = (c & 0xFFFFu) < dlo ? (c & 0xFFFFu) : dlo;
+                    dhi = (c >> 16) > dhi ? (c >> 16) : dhi;
+                }
+            }
+            if (dlo != 0xFFFFu)
+                for (uint32_t c = dlo; c <= dhi && !need; ++c) need = ((closed[c >> 5] >> (c & 31u)) & 1u) == 0u;
+        }
+        const unsigned long long bm = __ballot(need);
+        if (lane == 0) wsum[w] = __popcll(bm);
+        __syncthreads();
+        int off = count;
+        for (int v = 0; v < w; ++v) off += wsum[v];
+        off += __popcll(bm & ((1ull << lane) - 1ull));
+        if (need && off < cap) out[off] = rel;
+        count += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const bool fits = count <= cap;
+        tile_cnt[b] = fits ? count : -1;
+        atomicAdd(total, (unsigned long long)(fits ? count : walk));
+    }
+}
+
 }  // namespace
 
 int gt_sym_gather(gt_ctx* ctx, const int32_t* perm, int64_t n_pad_s, void* Ys, float* hs, float* hs_fin) {
@@ -1637,6 +1712,35 @@ int gt_sym_bound_queue(gt_ctx* ctx, int64_t n_pad_s, const void* Ys, const float
         fprintf(stderr, "[gt] bound queue: median group %llu cycles\n", med);
         dbg_buf.release();
     }
+    return GT_OK;
+}
+
+
+// Listed walks for the one-stage collect from the cell masks the bound pass left in `work` (gt_sym_bound_queue ran on this
+// point set and order): tile_list [NB][stride], tile_cnt [NB] for the NB = n_pad_s / 256 query blocks, *total_dev (pre-zeroed
+// here) = tiles listed in all.  Returns the length of a whole walk in *walk_out.
+int gt_sym_collect_lists(gt_ctx* ctx, int64_t n_pad_s, DevBuf& work, int cap, int stride, int32_t* tile_list, int32_t* tile_cnt,
+                         unsigned long long* total_dev, int* walk_out) {
+    const int L = ctx->order_L;
+    if (L <= 0 || L > 65535 || !work.p) GT_FAIL(ctx, GT_E_STATE, "collect lists: no cell masks");
+    if (n_pad_s % 256 != 0 || ctx->DP > 64) GT_FAIL(ctx, GT_E_ARG, "collect lists: whole 256-row query blocks of 128-row tiles");
+    const int words = (L + 31) / 32;
+    const int DP = ctx->DP;
+    // (the layout of gt_sym_bound_queue's scratch)
+    int32_t* start = work.as<int32_t>();
+    int32_t* endp = start + L;
+    float* centre = reinterpret_cast<float*>(endp + L);
+    float* radius = centre + size_t(L) * DP;
+    float* need = radius + L;
+    const uint32_t* mask = reinterpret_cast<const uint32_t*>(need + L);
+    const uint32_t* tcell = mask + size_t(L) * words;
+    const int T = int(n_pad_s / 128), TPB = 2, NB = T / TPB, H = (NB - 1) / 2;
+    const int walk = TPB * (1 + H) + ((NB & 1) ? 0 : (NB > 1 ? TPB : 0));
+    GT_HIP(ctx, hipMemsetAsync(total_dev, 0, sizeof(unsigned long long), ctx->stream));
+    hipLaunchKernelGGL(collect_lists_kernel, dim3((unsigned)NB), dim3(256), size_t(words) * sizeof(uint32_t), ctx->stream, NB, T, TPB,
+                       walk, L, words, tcell, mask, cap, stride, tile_list, tile_cnt, total_dev);
+    GT_HIP(ctx, hipGetLastError());
+    if (walk_out) *walk_out = walk;
     return GT_OK;
 }
 

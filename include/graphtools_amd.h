@@ -136,6 +136,9 @@ int gt_stage_launches(const gt_ctx* ctx, const char* stage);
  *   select_sym_two_stage     "auto" | 0 | 1: the collect scores 16 leading directions first (partial distances).
  *   select_sym_pca           0 | 1: ... the 16 leading principal directions (1) or the first 16 features (0).
  *   select_sym_bounds        "auto" | 0 | 1: bound pass (cell balls) in front of the collect.
+ *   select_sym_listed        "auto" | 0 | 1: when the bound pass leaves more units than its queue holds but its cell masks rule
+ *                            out most tiles (auto: the listed tiles are at most a quarter of the walks), the one-stage collect
+ *                            streams the listed tiles only - no stage-one copy, no cold launch.
  *   select_sym_bound_cap     units the bound pass may leave before the two-stage collect runs instead (0: 4 M).
  *   select_sym_queue_cap     entries per wave region of the two-stage queue (0: sized from the problem).
  *   select_sym_spill_cap     entries of the shared spill area behind the regions (0: 4 M).
@@ -162,7 +165,7 @@ int gt_set_option(gt_ctx* ctx, const char* name, const char* value);
 int gt_last_knn_precision(const gt_ctx* ctx);
 /* statistics of the most recent kNN candidate search: out[0] = 1 if the symmetric pass ran, out[1] = rows whose
  * symmetric lists overflowed (repaired), out[2] = rows repaired in all, out[3] = of those by the exhaustive kernel,
- * out[4..11] = counters of the symmetric pass: [6] work items per query block, [7] bit 0 two-stage collect, bit 1 dense seeding kernel (gt_seed.hip), [9] tiles visited by the seeding launch,
+ * out[4..11] = counters of the symmetric pass: [6] work items per query block, [5] (64 x 32) units scored in full (cold launch / listed one-stage collect), [7] bit 0 two-stage collect, bit 1 dense seeding kernel (gt_seed.hip), bit 2 cold launch in the local frame, bit 3 tables by sorted position, bit 4 destinations looked up by the affinity pass, bit 5 one-stage collect over listed walks, [9] tiles visited by the seeding launch,
  * the others list lengths (rerank_sym_kernel, only with dbg_select bit 256) */
 int gt_knn_stats(const gt_ctx* ctx, int64_t* out12);
 

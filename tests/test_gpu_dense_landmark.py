@@ -296,9 +296,34 @@ def test_exact_graph_from_points_hands_what_the_search_cannot_hold_to_the_all_pa
     np.testing.assert_allclose(G.K, K0, rtol=1e-9, atol=1e-300)
     np.testing.assert_allclose(G.P, P0, rtol=1e-7, atol=1e-300)
     # wide data + explicit bandwidth: the neighbour search refuses, the build still succeeds
+    # (1300 rows with the route's minimum lowered for the test: the oracle's pdist over 2100 columns took 80 s at 4100 rows -
+    #  a sixth of the suite - and what is under test is the refusal, which does not depend on the row count)
+    from graphtools_amd.graphs import TraditionalGraph
+    monkeypatch.setattr(TraditionalGraph, "_NEIGHBOUR_ROUTE_MIN", 1024)
+    refused = []
+    real_build = _hip.Context.graph_build
+
+    def build_spy(self, *a, **k):
+        try:
+            return real_build(self, *a, **k)
+        except _hip.HipError as e:
+            refused.append(str(e))
+            raise
+    real_points = _hip.Context.set_points
+
+    def points_spy(self, *a, **k):
+        try:
+            return real_points(self, *a, **k)
+        except _hip.HipError as e:
+            refused.append(str(e))
+            raise
+    monkeypatch.setattr(_hip.Context, "graph_build", build_spy)
+    monkeypatch.setattr(_hip.Context, "set_points", points_spy)
     rng = np.random.default_rng(3)
-    Xw = (rng.standard_normal((4100, 5)) @ rng.standard_normal((5, 2100))).astype(np.float64)
+    Xw = (rng.standard_normal((1300, 5)) @ rng.standard_normal((5, 2100))).astype(np.float64)
     Gw = graphtools_amd.Graph(Xw, n_pca=None, graphtype="exact", knn=5, decay=10, bandwidth=60.0)
+    Gw.K
+    assert refused, "the neighbour route should have been tried and refused (more than 2048 features)"
     Kw0, Pw0 = oracle.exact_graph(Xw, knn=5, decay=10, bandwidth=60.0)
     flip = (Gw.K == 0) != (Kw0 == 0)
     assert flip.sum() <= 4

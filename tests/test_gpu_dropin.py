@@ -228,7 +228,8 @@ def test_every_option_the_header_documents_is_accepted_and_nothing_else():
     from graphtools_amd import _hip
     from test_abi import header_options
 
-    values = {"knn_precision": "auto", "metric": "euclidean", "distance_dtype": "data", "query_order": "auto"}
+    values = {"knn_precision": "auto", "metric": "euclidean", "distance_dtype": "data", "query_order": "auto",
+              "symmetrize_bin_shift": "9"}
     c = _hip.Context(0)
     try:
         for name in header_options():

@@ -5,9 +5,12 @@ on / classic pass forced) - plus 1 ms, the granularity of the fixed costs at thi
 all three builds produce the same graph (asserted).
 
 What is compared is DEVICE time: the HIP-event spans of the build's top-level stages (gt_stage_ms: events recorded on the
-library's stream around each stage), best of three builds - not the wall clock, which on a shared box measures the
-neighbours - and a comparison that fails is repeated (up to three attempts) before the test does: a busy box cannot turn the
-parity suite red, a ladder that really picks the slow route still does."""
+library's stream around each stage), best of three builds - and, more loosely (2 x + 2 ms), the WALL clock of the same builds,
+which also sees what the spans do not: the synchronisations and read-backs of a refuted attempt, the host gaps between stages.
+The majority of up to three attempts decides: a busy box cannot turn the parity suite red with one slow attempt, and a ladder
+that really picks the slow route cannot pass with one lucky one."""
+
+import time
 
 import numpy as np
 import pytest
@@ -78,16 +81,20 @@ def _build_ms(X, opts, reps=3):
             c.set_option(k, v)
         c.set_points(X)
         p, keep = c.make_params(15, 40.0, 1e-4, None, 1.0, None, "+", None, 0)
-        best, nnz = None, None
+        best, wall, nnz = None, None, None
         for _ in range(reps):
             c.set_points(X)
+            c.sync()
+            t0 = time.perf_counter()
             nnz, _ = c.graph_build(p)
             c.sync()
+            w = (time.perf_counter() - t0) * 1e3
             ms = sum(max(c.stage_ms(s), 0.0) for s in TOP_STAGES)
             best = ms if best is None else min(best, ms)
+            wall = w if wall is None else min(wall, w)
         sym = bool(c.knn_stats()["symmetric"])
         deg = c.graph_fetch_vec(1)
-        return best, int(nnz), sym, float(deg.sum())
+        return best, int(nnz), sym, float(deg.sum()), wall
     finally:
         c.close()
 
@@ -95,17 +102,23 @@ def _build_ms(X, opts, reps=3):
 @pytest.mark.parametrize("family", list(FAMILIES))
 def test_auto_is_never_far_behind_the_better_forced_route(family):
     X = FAMILIES[family]()
-    last = None
+    passed, failed, last = 0, 0, None
     for attempt in range(3):
-        auto, nnz_a, sym_a, s_a = _build_ms(X, {})
-        forced_sym, nnz_s, sym_s, s_s = _build_ms(X, {"select_symmetric": "1"})
-        classic, nnz_c, sym_c, s_c = _build_ms(X, {"select_symmetric": "0"})
+        auto, nnz_a, sym_a, s_a, wall_a = _build_ms(X, {})
+        forced_sym, nnz_s, sym_s, s_s, wall_s = _build_ms(X, {"select_symmetric": "1"})
+        classic, nnz_c, sym_c, s_c, wall_c = _build_ms(X, {"select_symmetric": "0"})
         assert nnz_a == nnz_s == nnz_c and s_a == s_s == s_c, "the routes built different graphs"
         assert not sym_c
-        best = min(forced_sym, classic)
-        print("%-42s auto %.2f ms (%s)  symmetric forced %.2f  classic %.2f  (device time, attempt %d)" % (
-            family, auto, "symmetric" if sym_a else "classic", forced_sym, classic, attempt + 1))
-        last = (auto, best)
-        if auto <= 1.5 * best + 1.0:
-            return
-    assert False, "auto %.2f ms vs the better forced route %.2f ms on '%s' (device time, three attempts)" % (last[0], last[1], family)
+        best, best_wall = min(forced_sym, classic), min(wall_s, wall_c)
+        print("%-42s auto %.2f ms (%s)  symmetric forced %.2f  classic %.2f  (device time; wall %.2f / %.2f / %.2f; attempt %d)" % (
+            family, auto, "symmetric" if sym_a else "classic", forced_sym, classic, wall_a, wall_s, wall_c, attempt + 1))
+        last = (auto, best, wall_a, best_wall)
+        # device time: the tight bound; wall clock (best of three builds, host gaps, read-backs and refuted attempts of a wrong
+        # rung included): a looser one - round-5 advisor: a ladder that loses on the HOST side must not pass on device spans
+        ok = auto <= 1.5 * best + 1.0 and wall_a <= 2.0 * best_wall + 2.0
+        passed += ok
+        failed += not ok
+        if passed >= 2 or failed >= 2:   # the majority of three attempts decides (a single lucky attempt does not)
+            break
+    assert passed >= 2, "auto %.2f ms vs the better forced route %.2f ms (device), wall %.2f vs %.2f, on '%s' (%d of %d attempts passed)" % (
+        last[0], last[1], last[2], last[3], family, passed, passed + failed)

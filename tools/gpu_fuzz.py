@@ -125,7 +125,7 @@ def main():
             fails.append(rec)
     print(json.dumps({"cases": n_cases, "failures": len(fails), "seconds": round(time.time() - t_start, 1)}))
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    json.dump(fails, open(os.path.join(ROOT, "gpurun_out", "gpu_fuzz_failures.json"), "w"), indent=1)
+    json.dump(fails, open(os.environ.get("GT_FUZZ_FAILURES") or os.path.join(ROOT, "gpurun_out", "gpu_fuzz_failures.json"), "w"), indent=1)
     sys.exit(1 if fails else 0)
 
 
