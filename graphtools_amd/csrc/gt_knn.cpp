@@ -825,39 +825,48 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
     return GT_OK;
 }
 
-// Symmetric eigenproblem of a small matrix (cyclic Jacobi, float64): A [m][m] row-major is destroyed, V gets the
-// eigenvectors in its COLUMNS, the eigenvalues end on A's diagonal.
-static void jacobi_eigen(std::vector<double>& A, std::vector<double>& V, int m) {
-    V.assign(size_t(m) * m, 0.0);
-    for (int i = 0; i < m; ++i) V[size_t(i) * m + i] = 1.0;
-    for (int sweep = 0; sweep < 30; ++sweep) {
-        double off = 0.0, diag = 0.0;
-        for (int i = 0; i < m; ++i)
-            for (int j = 0; j < m; ++j) (i == j ? diag : off) += A[size_t(i) * m + j] * A[size_t(i) * m + j];
-        if (off <= 1e-28 * diag) break;
-        for (int p = 0; p < m - 1; ++p)
-            for (int q = p + 1; q < m; ++q) {
-                const double apq = A[size_t(p) * m + q];
-                if (std::fabs(apq) < 1e-300) continue;
-                const double theta = (A[size_t(q) * m + q] - A[size_t(p) * m + p]) / (2.0 * apq);
-                const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
-                const double c = 1.0 / std::sqrt(t * t + 1.0), sn = t * c;
-                for (int r = 0; r < m; ++r) {   // columns p, q
-                    const double arp = A[size_t(r) * m + p], arq = A[size_t(r) * m + q];
-                    A[size_t(r) * m + p] = c * arp - sn * arq;
-                    A[size_t(r) * m + q] = sn * arp + c * arq;
+// An orthonormal basis of (approximately) the k leading principal directions of the symmetric m x m matrix C (row-major):
+// orthogonal iteration Q <- orth(C Q), a few steps from the k coordinate axes of largest variance.  Stage one only needs an
+// ORTHONORMAL frame that keeps most of the variance - any such frame gives valid partial distances, the results never depend
+// on it - so the directions need not be converged eigenvectors: 8 steps of 64 x 64 x 16 cost ~0.1 ms on the host where the
+// cyclic Jacobi sweeps over the full 64 x 64 problem took 2 ms (round 5's timeline of the manifold set: a 2.0 ms hole in the
+// stream behind sample_cov_kernel).  Q: [m][k] row-major, columns orthonormal (modified Gram-Schmidt, twice).
+static void leading_subspace(const std::vector<double>& C, int m, int k, std::vector<double>& Q) {
+    std::vector<int> order(m);
+    for (int i = 0; i < m; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return C[size_t(x) * m + x] > C[size_t(y) * m + y]; });
+    Q.assign(size_t(m) * k, 0.0);
+    for (int c = 0; c < k; ++c) Q[size_t(order[c]) * k + c] = 1.0;
+    std::vector<double> Z(size_t(m) * k);
+    auto orthonormalise = [&](std::vector<double>& A) {
+        for (int pass = 0; pass < 2; ++pass)
+            for (int c = 0; c < k; ++c) {
+                for (int p = 0; p < c; ++p) {
+                    double dot = 0.0;
+                    for (int r = 0; r < m; ++r) dot += A[size_t(r) * k + p] * A[size_t(r) * k + c];
+                    for (int r = 0; r < m; ++r) A[size_t(r) * k + c] -= dot * A[size_t(r) * k + p];
                 }
-                for (int r = 0; r < m; ++r) {   // rows p, q
-                    const double apr = A[size_t(p) * m + r], aqr = A[size_t(q) * m + r];
-                    A[size_t(p) * m + r] = c * apr - sn * aqr;
-                    A[size_t(q) * m + r] = sn * apr + c * aqr;
+                double nn = 0.0;
+                for (int r = 0; r < m; ++r) nn += A[size_t(r) * k + c] * A[size_t(r) * k + c];
+                if (!(nn > 1e-300)) {   // (a direction without variance: any unit vector orthogonal to the others will do)
+                    for (int r = 0; r < m; ++r) A[size_t(r) * k + c] = 0.0;
+                    A[size_t(order[c]) * k + c] = 1.0;
+                    nn = 1.0;
+                    if (pass == 0) continue;   // (the second pass orthogonalises it)
                 }
-                for (int r = 0; r < m; ++r) {
-                    const double vrp = V[size_t(r) * m + p], vrq = V[size_t(r) * m + q];
-                    V[size_t(r) * m + p] = c * vrp - sn * vrq;
-                    V[size_t(r) * m + q] = sn * vrp + c * vrq;
-                }
+                const double inv = 1.0 / std::sqrt(nn);
+                for (int r = 0; r < m; ++r) A[size_t(r) * k + c] *= inv;
             }
+    };
+    for (int it = 0; it < 8; ++it) {
+        for (int r = 0; r < m; ++r)
+            for (int c = 0; c < k; ++c) {
+                double acc = 0.0;
+                for (int j = 0; j < m; ++j) acc += C[size_t(r) * m + j] * Q[size_t(j) * k + c];
+                Z[size_t(r) * k + c] = acc;
+            }
+        orthonormalise(Z);
+        Q.swap(Z);
     }
 }
 
@@ -881,12 +890,21 @@ static int stage_one_frame(gt_ctx* ctx, float* P_host, bool principal) {
     std::vector<double> A(size_t(d) * d), V;
     for (int i = 0; i < d; ++i)
         for (int j = 0; j < d; ++j) A[size_t(i) * d + j] = 0.5 * (C64[i * 64 + j] + C64[j * 64 + i]);
-    jacobi_eigen(A, V, d);
-    std::vector<int> order(d);
-    for (int i = 0; i < d; ++i) order[i] = i;
-    std::sort(order.begin(), order.end(), [&](int x, int y) { return A[size_t(x) * d + x] > A[size_t(y) * d + y]; });
+    leading_subspace(A, d, 16, V);
+    // (what the partial distances rely on is the frame's orthonormality, nothing else: checked, the coordinate axes otherwise)
+    double worst = 0.0;
+    for (int a = 0; a < 16; ++a)
+        for (int b = a; b < 16; ++b) {
+            double dot = 0.0;
+            for (int m = 0; m < d; ++m) dot += V[size_t(m) * 16 + a] * V[size_t(m) * 16 + b];
+            worst = std::max(worst, std::fabs(dot - (a == b ? 1.0 : 0.0)));
+        }
+    if (!(worst <= 1e-9)) {
+        for (int c = 0; c < 16 && c < d; ++c) P_host[c * 64 + c] = 1.f;
+        return GT_OK;
+    }
     for (int c = 0; c < 16; ++c)
-        for (int m = 0; m < d; ++m) P_host[c * 64 + m] = float(V[size_t(m) * d + order[c]]);
+        for (int m = 0; m < d; ++m) P_host[c * 64 + m] = float(V[size_t(m) * 16 + c]);
     return GT_OK;
 }
 
@@ -915,10 +933,12 @@ int gt_sym_two_stage_prepare(gt_ctx* ctx, const int32_t* perm, int64_t n_pad_s, 
     // (a covariance pass and a 64 x 64 eigenproblem on the host: only when the axes do not separate).  The forecast
     // decides; with the two-stage collect forced on, the first frame offered is taken (select_sym_pca = 2: the
     // principal one).
+    // (round 6: the principal frame FIRST wherever it exists - it keeps at least the variance the coordinate frame keeps, so a
+    //  coordinate frame that would pass is a principal frame that passes, and the projection + forecast of a coordinate frame
+    //  that fails - 0.8 ms on the manifold set - is not paid in front of it; the frame itself is a 0.3 ms matter now)
     const bool can_pca = ctx->sym_pca != 0 && ctx->d > 16 && ctx->d <= 64;
     bool accepted = false;
-    for (int frame = (ctx->sym_pca == 2 && can_pca) ? 1 : 0; frame < 2 && !accepted; ++frame) {
-        if (frame == 1 && !can_pca) break;
+    for (int frame = can_pca ? 1 : 0; frame < (can_pca ? 2 : 1) && !accepted; ++frame) {
         float P_host[16 * 64];
         {
             StageSpan span(ctx, "sym_prepare");

@@ -1339,25 +1339,50 @@ __global__ __launch_bounds__(256) void assign_cells2_kernel(const float* __restr
     }
 }
 
-// The wave regions of the collect launch -> one dense queue (order does not matter): one wave per region, its slots in
-// the dense queue from one atomic.  total (pre-zeroed): entries copied; flag (pre-zeroed): the largest region count.
+// The wave regions of the collect launch -> one dense queue (order does not matter): a workgroup takes 16 regions, their slots
+// in the dense queue come from ONE atomic (round 6: one per region - 27 000 returning atomics on one address, ~90 per
+// microsecond - was half of the launch's 0.63 ms on the manifold set).  total (pre-zeroed): entries copied; flag
+// (pre-zeroed): the largest region count.
 __global__ __launch_bounds__(256) void sym_queue_compact_kernel(const uint2* __restrict__ regions,
                                                                 const uint32_t* __restrict__ cnts, const int64_t nwaves,
                                                                 const int rcap, uint2* __restrict__ dense,
                                                                 const uint32_t dense_cap, uint32_t* __restrict__ total,
                                                                 uint32_t* __restrict__ flag) {
-    const int lane = threadIdx.x & 63;
-    const int64_t r = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
-    if (r >= nwaves) return;
-    uint32_t c = cnts[r];
-    if (c == 0u) return;
-    if (lane == 0) atomicMax(flag, c);   // the fullest region (statistics)
-    uint32_t base = 0u;
-    if (lane == 0) base = atomicAdd(total, c);
-    base = __shfl(base, 0);
-    const uint2* src = regions + size_t(r) * size_t(rcap);
-    for (uint32_t i = uint32_t(lane); i < c; i += 64u)
-        if (base + i < dense_cap) dense[base + i] = src[i];
+    __shared__ uint32_t off_s[17];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t r0 = int64_t(blockIdx.x) * 16;
+    if (threadIdx.x < 64) {   // wave 0: the 16 counts, their exclusive scan, the reservation
+        const uint32_t c = (lane < 16 && r0 + lane < nwaves) ? cnts[r0 + lane] : 0u;
+        uint32_t inc = c;
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+            const uint32_t up = uint32_t(__shfl_up(int(inc), o));
+            if (lane >= o) inc += up;
+        }
+        const uint32_t sum = uint32_t(__shfl(int(inc), 15));
+        uint32_t mx = c;
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) mx = max(mx, uint32_t(__shfl_xor(int(mx), o)));
+        uint32_t base = 0u;
+        if (lane == 0 && sum != 0u) {
+            base = atomicAdd(total, sum);
+            atomicMax(flag, mx);   // the fullest region (statistics)
+        }
+        base = uint32_t(__shfl(int(base), 0));
+        if (lane < 16) off_s[lane] = base + inc - c;
+        if (lane == 0) off_s[16] = sum;
+    }
+    __syncthreads();
+    if (off_s[16] == 0u) return;
+    for (int i = 0; i < 4; ++i) {
+        const int64_t r = r0 + w * 4 + i;
+        if (r >= nwaves) break;
+        const uint32_t c = cnts[r];
+        const uint32_t base = off_s[w * 4 + i];
+        const uint2* src = regions + size_t(r) * size_t(rcap);
+        for (uint32_t e = uint32_t(lane); e < c; e += 64u)
+            if (base + e < dense_cap) dense[base + e] = src[e];
+    }
 }
 
 // ... and the spill area behind them (spill_n entries, already dense): appended with one atomic per workgroup
@@ -1829,7 +1854,7 @@ int launch_queue_compact(gt_ctx* ctx, const SelectArgs& a) {
     // a.lists: the dense queue (capacity a.cap entries); a.counts: [0] total, [1] fullest region, [2] spill overflow
     // flag (all pre-zeroed);
     // a.sym.queue / qcount / qcap: the regions; a.nq: number of wave regions
-    hipLaunchKernelGGL(sym_queue_compact_kernel, dim3((unsigned)ceil_div64(a.nq, 4)), dim3(256), 0, ctx->stream, a.sym.queue,
+    hipLaunchKernelGGL(sym_queue_compact_kernel, dim3((unsigned)ceil_div64(a.nq, 16)), dim3(256), 0, ctx->stream, a.sym.queue,
                        a.sym.qcount, int64_t(a.nq), a.sym.qcap, reinterpret_cast<uint2*>(a.lists), uint32_t(a.cap), a.counts,
                        a.counts + 1);
     GT_HIP(ctx, hipGetLastError());

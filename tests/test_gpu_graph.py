@@ -319,9 +319,15 @@ def test_float32_cosine_agrees_with_scikit_learn_up_to_its_float32_noise(name):
     bw = np.maximum(d_dev[:, knn], 1e-12)                       # the rows' bandwidths: distance to the knn-th neighbour
     u = -np.log(np.clip(kr, 1e-300, 1.0))
     bound = 1e-5 + kr * u * decay * (2 * eps / bw[r] + 2 * eps / bw[c])
-    worst = (np.abs(k - kr) / bound).max()
-    print("   max |dK| %.3g, at most %.2f of the first-order bound" % (np.abs(k - kr).max(), worst))
+    dk = np.abs(k - kr)
+    # (K = (a_ij + a_ji) / 2 with a cut at thresh: where one side's affinity lies within that noise of thresh it is kept by one
+    #  arithmetic and cut by the other - the entry moves by thresh / 2; such entries are counted, not excused wholesale)
+    flip = (dk > bound) & (np.abs(dk - 0.5e-4) <= bound)
+    worst = (dk[~flip] / bound[~flip]).max()
+    print("   max |dK| %.3g, at most %.2f of the first-order bound; %d of %d entries moved by thresh / 2 (one side at the cut)" % (
+        dk.max(), worst, int(flip.sum()), len(dk)))
     assert worst <= 1.0
+    assert flip.sum() <= 1e-4 * len(dk) + 4
 
 
 @pytest.mark.parametrize("d,concentrated", [(200, True), (300, False)])

@@ -1,0 +1,263 @@
+"""GPU: the row-sharded build at the BASELINE sizes, pinned to the REAL reference.
+
+BASELINE config 3 IS "row-sharded across 8"; until round 6 every sharded test stopped at 40 000 rows and the world-8 figures at
+N = 10^6 (tools/gpu_shard_local_probe.py) were timings of a result nobody compared.  Here one context plays the eight ranks of
+the build on renumbered points in turn (gt_points_cells_begin / _finish, gt_graph_shard_local, gt_graph_begin / emit / finish -
+exactly the calls graphtools_amd/dist.py makes on every rank), the triplet all-to-all is done by hand through the host, and the
+rows every rank finishes - put back at the caller's row numbers - are checked against the fixtures tools/make_golden_full.py
+wrote from the imported reference (graphs.py:771-982, base.py:534-646, graphs.py:1169-1246):
+
+* C3, N = 10^6, d = 64, world 8: row lengths, the 16-bit checksum of every row's columns, the sha-256 of all 116 M column
+  indices, kernel degrees, 10^5 sampled K and P entries of `full_c3_reference.npz` (same tolerances as the single-rank test,
+  tests/test_gpu_full_reference.py);
+* C5, N = 10^5, d = 50, L = 2000, world 8: the ranks' partial landmark products summed as the all-reduce would, the operator
+  against `full_c5_n1e5_reference.npz` (1e-9), the transitions' row lengths / column checksums / sampled values.
+
+Every rank runs twice (once to produce what the others receive, once more - its state was overwritten by the ranks played
+after it - to finish its own rows): ~40 builds of ~6 ms and the host traffic of one full graph."""
+import hashlib
+import os
+import warnings
+
+import numpy as np
+import pytest
+from scipy import sparse
+
+from conftest import GOLDEN, make_mix
+
+pytestmark = pytest.mark.gpu
+
+TRIP = np.dtype([("row", np.uint32), ("col", np.uint32), ("val", np.float64)])
+
+
+def _row_hash16(indices, indptr):
+    h = ((indices.astype(np.uint64) + np.uint64(1)) * np.uint64(2654435761)) & np.uint64(0xFFFFFFFF)
+    cs = np.zeros(len(h) + 1, dtype=np.uint64)
+    np.cumsum(h, dtype=np.uint64, out=cs[1:])
+    full = (cs[indptr[1:]] - cs[indptr[:-1]]) & np.uint64(0xFFFFFFFF)
+    return (full >> np.uint64(16)).astype(np.uint16)
+
+
+class SimulatedRanks:
+    """one context, `world` ranks of the build on renumbered points played in turn"""
+
+    def __init__(self, X, world, pargs):
+        from graphtools_amd import _hip
+
+        self.hip = _hip
+        self.X, self.world = X, world
+        self.n, self.d = X.shape
+        self.ctx = _hip.Context(0)
+        self.params, self._keep = self.ctx.make_params(*pargs)
+        self.xb = self.ctx.dev_alloc(X.nbytes)
+        self.ctx.dev_upload(self.xb, X)
+        # every rank's share of the cell assignment: what the cells all-gather delivers
+        self.in_splits = np.linspace(0, self.n, world + 1).astype(np.int64)
+        self.cells_all = self.ctx.dev_alloc(self.n * 4)
+        for r in range(world):
+            ok = self.ctx.points_cells_begin(self.xb, self.n, self.d, np.float32, self.in_splits[r], self.in_splits[r + 1],
+                                             self.cells_all + int(self.in_splits[r]) * 4)
+            assert ok, "no cell order for these points"
+        self.splits = None
+        self.used = []
+
+    def until_emit(self, r):
+        """bind + renumber + local candidate lists + affinities + triplet emit of rank r -> (send counts, host triplets)"""
+        c = self.ctx
+        own = c.dev_alloc(int(self.in_splits[r + 1] - self.in_splits[r]) * 4)
+        assert c.points_cells_begin(self.xb, self.n, self.d, np.float32, self.in_splits[r], self.in_splits[r + 1], own)
+        c.points_cells_finish(self.cells_all)
+        c.dev_free(own)
+        splits = c.points_shard_splits(self.world)
+        if self.splits is None:
+            self.splits = splits
+        assert np.array_equal(splits, self.splits), "the ranks disagree on the row blocks"
+        used = c.graph_shard_local(self.params, self.world, r, splits)
+        sc = c.graph_begin(self.params, self.world, r, splits)
+        total = int(sc.sum())
+        host = np.zeros(total, dtype=TRIP)
+        if total:
+            buf = c.dev_alloc(total * 16)
+            c.graph_emit(buf)
+            c.dev_download(host, buf)
+            c.dev_free(buf)
+        return sc, host, bool(used)
+
+    def exchange(self):
+        """every rank once -> what each rank receives (the all-to-all, by hand)"""
+        sends, counts = [], []
+        for r in range(self.world):
+            sc, host, used = self.until_emit(r)
+            sends.append(host)
+            counts.append(sc)
+            self.used.append(used)
+        recv = []
+        for r in range(self.world):
+            parts = []
+            for s in range(self.world):
+                off = int(counts[s][:r].sum())
+                parts.append(sends[s][off: off + int(counts[s][r])])
+            recv.append(np.concatenate(parts))
+        return recv
+
+    def finish(self, r, recv):
+        """rank r again up to its emit, then its finish with what it received -> its context, rows finished"""
+        c = self.ctx
+        self.until_emit(r)
+        assert np.all((recv["row"] >= self.splits[r]) & (recv["row"] < self.splits[r + 1]))
+        rb = c.dev_alloc(max(len(recv), 1) * 16)
+        if len(recv):
+            c.dev_upload(rb, recv)
+        nnz, flags = c.graph_finish(rb if len(recv) else 0, len(recv))
+        c.dev_free(rb)
+        r0, r1, nnz_rows = c.graph_rows()
+        assert (r0, r1) == (self.splits[r], self.splits[r + 1])
+        return c, int(nnz)
+
+    def close(self):
+        self.ctx.dev_free(self.cells_all)
+        self.ctx.dev_free(self.xb)
+        self.ctx.close()
+
+
+def _assemble(n, parts):
+    """parts: per rank (caller rows of its block, indptr, indices, [value arrays]) -> CSR arrays in the caller's row order"""
+    row_len = np.zeros(n, dtype=np.int64)
+    for rows, ip, _, _ in parts:
+        row_len[rows] = np.diff(ip)
+    indptr = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(row_len, out=indptr[1:])
+    nnz = int(indptr[-1])
+    indices = np.empty(nnz, dtype=np.int32)
+    nval = len(parts[0][3])
+    values = [np.empty(nnz, dtype=np.float64) for _ in range(nval)]
+    for rows, ip, ii, vals in parts:
+        lens = np.diff(ip)
+        dest = np.repeat(indptr[rows] - ip[:-1], lens) + np.arange(len(ii), dtype=np.int64)
+        indices[dest] = ii
+        for dst, src in zip(values, vals):
+            dst[dest] = src
+    return indptr, indices, values
+
+
+def test_c3_sharded_over_eight_ranks_reproduces_the_reference_at_full_size():
+    path = os.path.join(GOLDEN, "full_c3_reference.npz")
+    if not os.path.exists(path):
+        pytest.skip("fixture not generated (tools/make_golden_full.py c3)")
+    z = np.load(path, allow_pickle=False)
+    n, d, seed, world = int(z["n"]), int(z["d"]), int(z["seed"]), 8
+    X = make_mix(n, d, seed)
+    sim = SimulatedRanks(X, world, (int(z["knn"]), float(z["decay"]), float(z["thresh"]), None, 1.0, None, "+", None, 0))
+    try:
+        recv = sim.exchange()
+        assert all(sim.used), "the local candidate pass did not apply on every rank: %r" % (sim.used,)
+        parts, deg = [], np.empty(n)
+        for r in range(world):
+            c, nnz_r = sim.finish(r, recv[r])
+            Kd, Ki, Kp = c.graph_fetch_csr(sim.hip.CSR_K)
+            Pd, _, _ = c.graph_fetch_csr(sim.hip.CSR_P, structure=False)
+            rows = c.points_row_ids(int(sim.splits[r]), int(sim.splits[r + 1]))
+            assert len(Ki) == nnz_r and Kp[0] == 0 and Kp[-1] == nnz_r
+            parts.append((rows, Kp.astype(np.int64), Ki.copy(), (Kd.copy(), Pd.copy())))
+            deg[rows] = c.graph_fetch_vec(1)
+        all_rows = np.concatenate([p[0] for p in parts])
+        assert np.array_equal(np.sort(all_rows), np.arange(n)), "the ranks' rows are not a partition of the caller's rows"
+    finally:
+        sim.close()
+    Kp, Ki, (Kd, Pd) = _assemble(n, parts)
+    del parts
+    # ---- structure: every row of every rank ----
+    bad_len = np.flatnonzero(np.diff(Kp) != z["row_len"].astype(np.int64))
+    bad_hash = np.flatnonzero(_row_hash16(Ki, Kp) != z["row_hash"])
+    bad = np.union1d(bad_len, bad_hash)
+    assert len(bad) <= 4, "%d rows differ in structure from the reference (first: %s)" % (len(bad), bad[:10])
+    if len(bad) == 0:
+        assert int(Kp[-1]) == int(z["nnz"])
+        assert hashlib.sha256(Ki.astype("<i4").tobytes()).digest() == z["sha256_indices"].tobytes()
+    ok = np.ones(n, dtype=bool)
+    ok[bad] = False
+
+    def close_but_for_a_few(got, want, what):
+        rel = np.abs(got - want) / np.abs(want)
+        loose = int((rel > 1e-9).sum())
+        assert loose <= max(1, len(want) // 10000), "%s: %d of %d beyond 1e-9" % (what, loose, len(want))
+        assert rel.max() <= 1e-4, "%s: %.2e" % (what, rel.max())
+        return loose, float(rel.max()), float(np.median(rel))
+
+    ld, dmax, dmed = close_but_for_a_few(deg[::4][ok[::4]], z["degree4"][ok[::4]], "kernel_degree")
+    np.testing.assert_allclose(np.add.reduceat(deg, np.arange(0, n, 1024)), z["degree_blocks"], rtol=1e-7 if len(bad) == 0 else 1e-5)
+    si, sj = z["sample_i"].astype(np.int64), z["sample_j"].astype(np.int64)
+    got_K, got_P = np.full(len(si), np.nan), np.full(len(si), np.nan)
+    for t in range(len(si)):
+        a, b = Kp[si[t]], Kp[si[t] + 1]
+        pos = a + np.searchsorted(Ki[a:b], sj[t])
+        if pos < b and Ki[pos] == sj[t]:
+            got_K[t], got_P[t] = Kd[pos], Pd[pos]
+    missing = np.isnan(got_K)
+    assert missing.sum() <= 4 and np.all(np.isin(si[missing], bad)), "sampled entries of the reference are missing"
+    lk, kmax, kmed = close_but_for_a_few(got_K[~missing], z["sample_K"][~missing], "sampled K")
+    lp, pmax, pmed = close_but_for_a_few(got_P[~missing], z["sample_P"][~missing], "sampled P")
+    print("C3 over 8 simulated ranks: structure rows differing %d of %d; beyond 1e-9: degrees %d (max %.1e), sampled K %d, P %d "
+          "(max %.1e, %.1e); medians %.1e %.1e %.1e" % (len(bad), n, ld, dmax, lk, lp, kmax, pmax, dmed, kmed, pmed))
+    assert max(dmed, kmed, pmed) < 1e-12
+
+
+def test_c5_sharded_over_eight_ranks_reproduces_the_reference_fixture():
+    path = os.path.join(GOLDEN, "full_c5_n1e5_reference.npz")
+    if not os.path.exists(path):
+        pytest.skip("fixture not generated (tools/make_golden_full.py c5)")
+    z = np.load(path, allow_pickle=False)
+    n, d, seed, L, world = int(z["n"]), int(z["d"]), int(z["seed"]), int(z["n_landmark"]), 8
+    X = make_mix(n, d, seed)
+    landmarks = np.random.default_rng(int(z["random_state"])).choice(n, L, replace=False)
+    sim = SimulatedRanks(X, world, (int(z["knn"]), float(z["decay"]), 1e-4, None, 1.0, None, "+", None, 0))
+    try:
+        recv = sim.exchange()
+        total = np.zeros(L * L + L)
+        labels = np.full(n, -1, dtype=np.int32)
+        keep = []
+        # ---- the labels of every rank's OWN rows (graphs.py:1200-1213 over the ranks: dist.random_landmark_clusters) ----
+        for r in range(world):
+            c, _ = sim.finish(r, recv[r])
+            r0, r1 = int(sim.splits[r]), int(sim.splits[r + 1])
+            lm = sim.hip.Context(0)
+            try:
+                lm.set_points(X[landmarks])
+                own = lm.knn_first_nearest(int(min(4, L)), y_dev_ptr=c.points_device(r0), m=r1 - r0)
+            finally:
+                lm.close()
+            labels[c.points_row_ids(r0, r1)] = np.asarray(own, dtype=np.int32)     # (the labels all-gather)
+        assert np.array_equal(labels, z["clusters"]), "%d labels differ from the reference's" % int((labels != z["clusters"]).sum())
+        # ---- every rank's partial products, summed as the all-reduce does; its rows of the transitions ----
+        for r in range(world):
+            c, _ = sim.finish(r, recv[r])
+            buf = c.dev_alloc((L * L + L) * 8)
+            tnnz = c.landmark_build_device(labels, L, buf)
+            part = np.empty(L * L + L)
+            c.dev_download(part, buf)
+            total += part
+            c.dev_free(buf)
+            td, ti, tp = c.landmark_fetch_transitions(tnnz)
+            keep.append((c.points_row_ids(int(sim.splits[r]), int(sim.splits[r + 1])), tp.astype(np.int64), ti.copy(), (td.copy(),)))
+        c = sim.ctx
+        buf = c.dev_alloc((L * L + L) * 8)
+        c.dev_upload(buf, total)
+        c.landmark_scale_device(buf, L)
+        c.sync()
+        op = np.empty(L * L + L)
+        c.dev_download(op, buf)
+        c.dev_free(buf)
+        op = op[: L * L].reshape(L, L)
+    finally:
+        sim.close()
+    np.testing.assert_allclose(op, z["landmark_op"], rtol=1e-9, atol=1e-15)
+    np.testing.assert_allclose(op.sum(axis=1), 1.0, rtol=0, atol=1e-12)
+    Tp, Ti, (Td,) = _assemble(n, keep)
+    T = sparse.csr_matrix((Td, Ti, Tp), shape=(n, L))
+    T.sort_indices()
+    T.eliminate_zeros()
+    assert T.nnz == int(z["t_nnz"])
+    assert np.array_equal(np.diff(T.indptr), z["t_row_len"].astype(np.int64))
+    assert np.array_equal(_row_hash16(T.indices, T.indptr), z["t_row_hash"])
+    got = np.asarray(T[z["t_sample_i"].astype(np.int64), z["t_sample_j"].astype(np.int64)]).ravel()
+    np.testing.assert_allclose(got, z["t_sample_v"], rtol=1e-9, atol=0)

@@ -260,11 +260,29 @@ def test_bound_pass_lists_the_units_of_the_cold_launch_without_a_collect_launch(
 
 
 def test_bound_pass_gives_way_to_the_collect_launch_when_the_cells_decide_too_little():
+    """more units than the queue of the cold launch holds (here: a queue of 100).  The cell masks still rule out most TILES of
+    a mixture, so the one-stage collect over listed walks takes over (round 6, gt_sym.hip collect_lists_kernel); with that
+    switched off, the two-stage collect does, as it does when the lists would hold most of the walks.  Same graph either way."""
     X = make_mix(70000, 64, 17)
-    few, st, _ = _build(X, {"select_sym_two_stage": 1, "select_sym_bound_cap": 100})
-    assert st["symmetric"] and st["sym_two_stage"] and not st["sym_bound_pass"]
     ref, _, _ = _build(X, {"select_symmetric": 0})
+    listed, st, _ = _build(X, {"select_sym_two_stage": 1, "select_sym_bound_cap": 100})
+    assert st["symmetric"] and st["sym_listed"] and not st["sym_two_stage"] and not st["sym_bound_pass"]
+    assert 0 < st["sym_cold_pairs"] < (70000 / 64) * (70000 / 32) / 2 / 4      # units scored: under a quarter of all pairs
+    _same_csr(listed, ref)
+    few, st, _ = _build(X, {"select_sym_two_stage": 1, "select_sym_bound_cap": 100, "select_sym_listed": 0})
+    assert st["symmetric"] and st["sym_two_stage"] and not st["sym_listed"] and not st["sym_bound_pass"]
     _same_csr(few, ref)
+
+
+@pytest.mark.parametrize("maker,d,n", [(make_manifold, 64, 70000), (make_gauss, 32, 66000), (make_mix, 48, 65536 + 777)])
+def test_one_stage_collect_over_listed_walks_whatever_the_lists_hold(maker, d, n):
+    """select_sym_listed = 1: the listed walks are used however long they are (a sheet in 64 dimensions: nearly every tile;
+    isotropic points: every tile; a mixture with a ragged last block: a few) - graph equal to the classic pass's bit for bit"""
+    X = maker(n, d, 29)
+    ref, _, _ = _build(X, {"select_symmetric": 0})
+    got, st, _ = _build(X, {"select_symmetric": 1, "select_sym_two_stage": 1, "select_sym_bound_cap": 1, "select_sym_listed": 1})
+    assert st["symmetric"] and st["sym_listed"] and not st["sym_two_stage"]
+    _same_csr(got, ref)
 
 
 @pytest.mark.parametrize("maker,d", [(make_gauss, 64), (make_manifold, 64), (make_mix, 40)])
