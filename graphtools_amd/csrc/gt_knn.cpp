@@ -1007,8 +1007,11 @@ int gt_sym_queue_prepare(gt_ctx* ctx, int64_t n_pad_s, SelectArgs& a) {
     KnnWork* k = ctx->knn;
     // one region per wave of the collect launch, sized so that all of them together hold about one pair in 8 - beyond
     // that stage one is not doing its job; a wave whose region is full spills into a shared area (4 M pairs)
-    const int64_t nwaves = ceil_div64(n_pad_s, 128 * GT_SEL_TWO_QT) * a.sym.nseg * 4;
-    const int64_t units = (n_pad_s / 64) * (n_pad_s / 32) / 2 / std::max(1, a.sym.shard_world);
+    // (own-only collect of a rank: nblk query blocks against every tile)
+    const bool own = a.sym.own_only != 0 && a.sym.nblk > 0;
+    const int64_t nwaves = (own ? int64_t(a.sym.nblk) : ceil_div64(n_pad_s, 128 * GT_SEL_TWO_QT)) * a.sym.nseg * 4;
+    const int64_t units = own ? int64_t(a.sym.nblk) * (128 * GT_SEL_TWO_QT / 64) * (n_pad_s / 32)
+                              : (n_pad_s / 64) * (n_pad_s / 32) / 2 / std::max(1, a.sym.shard_world);
     int64_t rcap = 1024;   // (a wave next to the diagonal of a clustered set notes several hundred pairs)
     while (rcap < 8192 && rcap * nwaves < units / 8) rcap *= 2;
     if (ctx->sym_queue_cap > 0) rcap = ctx->sym_queue_cap;
@@ -1034,7 +1037,8 @@ int gt_sym_queue_prepare(gt_ctx* ctx, int64_t n_pad_s, SelectArgs& a) {
 int gt_sym_queue_finish(gt_ctx* ctx, const SelectArgs& a, int64_t* entries, int* ok) {
     KnnWork* k = ctx->knn;
     *ok = 0;
-    const int64_t nwaves = ceil_div64(a.n_pad, 128 * GT_SEL_TWO_QT) * a.sym.nseg * 4;
+    const int64_t nwaves = ((a.sym.own_only != 0 && a.sym.nblk > 0) ? int64_t(a.sym.nblk) : ceil_div64(a.n_pad, 128 * GT_SEL_TWO_QT)) *
+                           a.sym.nseg * 4;
     const int64_t dense_cap = a.sym.shard_world > 1 ? nwaves * int64_t(a.sym.qcap) + a.sym.qspill_cap
                                                     : std::min<int64_t>(nwaves * int64_t(a.sym.qcap) + a.sym.qspill_cap, int64_t(1) << 25);
     GT_HIP(ctx, k->sym_qdense.reserve(size_t(dense_cap) * sizeof(uint2)));

@@ -51,7 +51,9 @@ struct SymDev {
     uint32_t* qspill_count = nullptr;
     int32_t qspill_cap = 0;
     int32_t qn = 0;                 // mode 4: entries to process
-    int32_t own_only = 0;      // mode 4: every unit files under its QUERIES only (row-sharded builds on renumbered points: the
+    int32_t own_only = 0;      // mode 2 (two-stage collect): the query blocks [block0, block0 + nblk) of 1024 rows against EVERY
+                               // tile, forward test only (a rank's own rows, gt_knn_shard_local);
+                               // mode 4: every unit files under its QUERIES only (row-sharded builds on renumbered points: the
                                // queue pairs the rank's own query groups with every sub-tile the cell bounds leave - the
                                // rows' side belongs to whoever owns the rows)
     int32_t list_shift = 0;    // sched 1: the tile list of query block b is list b >> list_shift (narrow 128-row

@@ -391,6 +391,9 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
             seg = int(bidx % nseg);
             bidx /= nseg;
             if (sy.shard_world > 1) seg += int((int64_t(sy.shard_rank) + bidx / sy.shard_group) % sy.shard_world) * nseg;
+            // own-only collect (a rank's own query blocks against EVERY tile, forward test only): the launch covers the
+            // blocks [block0, block0 + nblk)
+            if (sy.own_only != 0) bidx += sy.block0;
         } else {
             bidx += sy.block0;
         }
@@ -422,6 +425,10 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
             const int H = (NB - 1) / 2;
             n_tr_end = TPB * (1 + H);
             int walk = n_tr_end + ((NB & 1) ? 0 : (NB > 1 ? TPB : 0));
+            if (sy.own_only != 0) {   // every tile once, starting with the own block; no tile takes the results as its queries
+                walk = T;
+                n_tr_end = 0;
+            }
             if (!TWO && sy.walk_list != nullptr) {
                 const int wc_ = sy.walk_cnt[bidx];
                 if (wc_ >= 0) {   // (< 0: the list did not fit - the whole walk)
@@ -1922,9 +1929,14 @@ int launch_one(gt_ctx* ctx, const SelectArgs& a) {
         GT_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         int(lds_bytes)));
     }
-    if (a.sym.nblk > 0 && (MODE != 0 || a.sym.sched != 1 || a.sym.block0 < 0 || int64_t(a.sym.block0) + a.sym.nblk > a.n_pad / C::BQ))
+    const bool own_collect = MODE == 2 && a.sym.own_only != 0;   // a rank's own query blocks against every tile (gt_knn_shard.cpp)
+    if (own_collect && (a.sym.nblk <= 0 || a.sym.block0 < 0 || int64_t(a.sym.block0) + a.sym.nblk > a.n_pad / BQL || a.sym.shard_world > 1 ||
+                        a.sym.walk_list != nullptr))
+        GT_FAIL(ctx, GT_E_ARG, "knn_select: the own-only collect needs a block range and whole walks");
+    if (!own_collect && a.sym.nblk > 0 &&
+        (MODE != 0 || a.sym.sched != 1 || a.sym.block0 < 0 || int64_t(a.sym.block0) + a.sym.nblk > a.n_pad / C::BQ))
         GT_FAIL(ctx, GT_E_ARG, "knn_select: a block range needs the own-neighbourhood schedule");
-    const int64_t grid_x = MODE == 2 ? nblocks * a.sym.nseg : (a.sym.nblk > 0 ? a.sym.nblk : nblocks);
+    const int64_t grid_x = MODE == 2 ? (own_collect ? int64_t(a.sym.nblk) : nblocks) * a.sym.nseg : (a.sym.nblk > 0 ? a.sym.nblk : nblocks);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid_x, (unsigned)nsplit), dim3(256), lds_bytes, ctx->stream, a.Yp,
                        a.hneg, a.Qp, a.qrows, a.q0, a.nq, ntiles, a.lists, a.counts, a.thr_in, a.thr_out, a.cap, a.dbg, a.prof,
                        a.samp_stride, a.samp_keep, a.samp_end, a.samp2_level, a.samp2_keep,

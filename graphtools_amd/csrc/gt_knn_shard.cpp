@@ -319,10 +319,63 @@ int gt_knn_shard_local(gt_ctx* ctx, int64_t r0, int64_t r1, int need_m, double r
     if (ctx->dbg_select & 2048)
         fprintf(stderr, "[gt] local shard rows [%lld, %lld): bound pass leaves %u units (capacity %lld), far-kept %llu\n",
                 (long long)r0, (long long)r1, left, (long long)bcap, far);
-    if (int64_t(left) > bcap) return GT_OK;   // no cluster structure at the cells' scale: the classic pass for these rows
+    const bool bound_done = int64_t(left) <= bcap;
+    SelectArgs ta;   // the two-stage collect of the rank's own blocks, where the cell bounds leave too many units
+    if (!bound_done) {
+        // Round 6: points near a low-dimensional sheet (the manifold set: 41 % of the cell pairs undecided) used to send the
+        // rank to the classic pass here - 27 ms per rank at world 8 where the single-rank build takes 43.  Now the rank's own
+        // 1024-row query blocks stream EVERY tile through stage one of the two-stage collect (16 principal directions,
+        // forward test only: 2 / world of the single rank's stage-one work), the units that pass go to the cold launch, filed
+        // under the queries only - the same lists.  The frame and its forecast are formed from the same rows on every rank.
+        if (n_pad_s % 1024 != 0 || !(ctx->sym_two_stage > 0 || ctx->sym_two_ok != 0)) return GT_OK;
+        ta.dp = ctx->DP;
+        ta.prec = 2;
+        ta.mode = 2;
+        ta.nt = 8;
+        ta.Yp = ta.Qp = k->Ycs.as<float>();
+        ta.hneg = k->hnegs.as<float>();
+        ta.n_pad = n_pad_s;
+        ta.q0 = 0;
+        ta.nq = int32_t(ctx->n);
+        ta.counts = k->counts.as<uint32_t>();
+        ta.thr_in = k->thr_final.as<float>();
+        ta.sym.g = k->sym_g.as<float>();
+        ta.sym.gmin = nullptr;
+        ta.sym.tlists = k->tlists.as<uint64_t>();
+        ta.sym.tcounts = k->tcounts.as<uint32_t>();
+        ta.sym.tcap = tcap;
+        ta.sym.own_only = 1;
+        ta.sym.block0 = int32_t(p0 / 1024);
+        ta.sym.nblk = int32_t((p1 - p0) / 1024);
+        GT_HIP(ctx, k->sym_gmin.reserve(size_t(n_pad_s / 32) * sizeof(float)));
+        GT_TRY(gt_sym_two_stage_prepare(ctx, perm, n_pad_s, em, need_m, ta, true));
+        if (ta.sym.half_steps <= 0) return GT_OK;   // stage one is no filter on these points: the classic pass
+        const int64_t slots = int64_t(ctx->n_cu) * 3;
+        int best = 1;
+        double best_cost = 1e30;
+        for (int sgm = 1; sgm <= 8; ++sgm) {
+            const double cost = double(ceil_div64(int64_t(ta.sym.nblk) * sgm, slots)) / sgm + 0.01 * sgm;
+            if (cost < best_cost - 1e-9) best_cost = cost, best = sgm;
+        }
+        ta.sym.nseg = ctx->sym_nseg > 0 ? std::min(ctx->sym_nseg, 8) : best;
+    }
     GT_TRY(gt_sym_inject_orphans(ctx, p0, std::min<int64_t>(p1, ctx->n), k->thr_final.as<float>(), lists0, 64,
                                  k->counts.as<uint32_t>(), k->tlists.as<uint64_t>(), tcap, k->tcounts.as<uint32_t>()));
-    {
+    if (!bound_done) {
+        GT_TRY(gt_sym_queue_prepare(ctx, n_pad_s, ta));
+        {
+            StageSpan span(ctx, "knn_select");
+            GT_TRY(gt_sym_launch_collect(ctx, ta));
+        }
+        int ok = 0;
+        GT_TRY(gt_sym_queue_finish(ctx, ta, &k->sym_cold_entries, &ok));
+        if (!ok) {   // the queue overflowed: the lists are incomplete - the classic pass for these rows
+            ctx->sym_two_ok = 0;
+            return GT_OK;
+        }
+        if (ctx->sym_two_ok < 0) ctx->sym_two_ok = 1;
+        k->sym_cold_local_used = false;
+    } else {
         StageSpan span(ctx, "sym_cold");
         SelectArgs dq;
         dq.dp = ctx->DP;
@@ -360,11 +413,11 @@ int gt_knn_shard_local(gt_ctx* ctx, int64_t r0, int64_t r1, int need_m, double r
             k->sym_cold_local_used = true;
         }
         GT_TRY(gt_launch_select(ctx, dq));
+        k->sym_cold_entries = int64_t(left);
     }
-    k->sym_cold_entries = int64_t(left);
-    k->sym_bound_used = true;
+    k->sym_bound_used = bound_done;
     k->sym_two_used = true;
-    k->sym_nseg = 1;
+    k->sym_nseg = bound_done ? 1 : ta.sym.nseg;
     ctx->last_main_prec = 2;
     k->sh_world = 1;
     k->sh_rank = 0;

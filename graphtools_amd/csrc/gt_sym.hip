@@ -1155,9 +1155,14 @@ __global__ __launch_bounds__(256) void tile_cells_kernel(const uint32_t* __restr
 // enumeration below where it would only establish that there are far too many (unclustered data: 97 M units, 3.5 ms).
 __global__ __launch_bounds__(64) void bound_estimate_kernel(const int L, const int32_t* __restrict__ start,
                                                             const int32_t* __restrict__ endp, const uint32_t* __restrict__ mask,
-                                                            const int words, double* __restrict__ est) {
+                                                            const int words, double* __restrict__ est,
+                                                            const uint32_t* __restrict__ cell_lo,
+                                                            const uint32_t* __restrict__ cell_hi) {
+    // (cell_lo / cell_hi: only the cells [*cell_lo, *cell_hi] ask - a rank's own query groups against every sub-tile, each
+    //  unit counted once: no halving.  Boundary cells count whole: the forecast is compared with 4 x the capacity.)
     const int a = blockIdx.x, lane = threadIdx.x;
     if (start[a] < 0) return;
+    if (cell_lo && (uint32_t(a) < *cell_lo || uint32_t(a) > *cell_hi)) return;
     const double ra = double(endp[a] - start[a]) / 64.0;
     double acc = 0.0;
     for (int wd = lane; wd < words; wd += 64) {
@@ -1169,7 +1174,7 @@ __global__ __launch_bounds__(64) void bound_estimate_kernel(const int L, const i
         }
     }
     acc = wave_sum_f64(acc);
-    if (lane == 0 && acc > 0.0) atomicAdd(est, 0.5 * ra * acc);
+    if (lane == 0 && acc > 0.0) atomicAdd(est, (cell_lo ? 1.0 : 0.5) * ra * acc);
 }
 
 // The units (64 queries q64, 32 rows d32) of the collect launch's walks that the cell bounds cannot rule out -> queue.
@@ -1194,8 +1199,8 @@ __global__ __launch_bounds__(256) void bound_queue_kernel(const int nq64, const 
     // own_full: the groups [own_q0, nq64) against EVERY sub-tile (no walks: a row-sharded build on renumbered points files
     // each pair under the query's side only, the launch covers the rank's own groups)
     const uint32_t q64 = uint32_t(own_q0) + blockIdx.x * 4u + uint32_t(w);
-    if (forecast && !own_full && *forecast > 4.0 * double(cap)) {   // (bound_estimate_kernel: far too many units - report "too many", list none)
-        if (q64 == 0u && lane == 0) count[0] = count[1] = 0xFFFFFFFFu;
+    if (forecast && *forecast > 4.0 * double(cap)) {   // (bound_estimate_kernel: far too many units - report "too many", list none)
+        if (blockIdx.x == 0 && threadIdx.x == 0) count[0] = count[1] = 0xFFFFFFFFu;   // (own_full launches start at own_q0)
         return;   // (every wave of the launch alike)
     }
     bool active = int(q64) < nq64;
@@ -1664,12 +1669,15 @@ int gt_sym_bound_queue(gt_ctx* ctx, int64_t n_pad_s, const void* Ys, const float
                 (long long)infn, (long long)open_pairs);
     }
     const double* est_ptr = nullptr;
-    if (!own) {
+    {
         // forecast: far more undecided units than the queue holds -> the caller falls through to the collect launch without
-        // paying for their enumeration (the same verdict on every rank: the cells are the same everywhere)
+        // paying for their enumeration (the same verdict on every rank: the cells are the same everywhere; a rank's own
+        // groups against every sub-tile - round 6: the enumeration of 25 M units it would only count cost the manifold set 1.7 ms
+        // per rank - ask for their own cells)
         double* est_dev = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(tcell + nt32) + 7) & ~uintptr_t(7));
         GT_HIP(ctx, hipMemsetAsync(est_dev, 0, sizeof(double), ctx->stream));
-        hipLaunchKernelGGL(bound_estimate_kernel, dim3((unsigned)L), dim3(64), 0, ctx->stream, L, start, endp, mask, words, est_dev);
+        hipLaunchKernelGGL(bound_estimate_kernel, dim3((unsigned)L), dim3(64), 0, ctx->stream, L, start, endp, mask, words, est_dev,
+                           own ? cell_sorted + own_p0 : nullptr, own ? cell_sorted + (own_pl - 1) : nullptr);
         GT_HIP(ctx, hipGetLastError());
         est_ptr = est_dev;   // (read by the enumeration itself: no trip to the host)
     }

@@ -261,3 +261,45 @@ def test_c5_sharded_over_eight_ranks_reproduces_the_reference_fixture():
     assert np.array_equal(_row_hash16(T.indices, T.indptr), z["t_row_hash"])
     got = np.asarray(T[z["t_sample_i"].astype(np.int64), z["t_sample_j"].astype(np.int64)]).ravel()
     np.testing.assert_allclose(got, z["t_sample_v"], rtol=1e-9, atol=0)
+
+
+def test_manifold_sharded_over_eight_ranks_equals_the_single_rank_build_at_full_size():
+    """points near a 5-dimensional sheet in 64 dimensions (bench.py's `manifold` leg, the shape of single-cell data): the cell
+    bounds leave every rank far more units than its queue holds, so each runs the two-stage collect of its OWN query blocks
+    against every tile (round 6, gt_knn_shard_local - until then such ranks fell back to the classic pass).  No reference
+    fixture exists at this size for this set; the single-rank build of the same points - itself pinned to the classic pass bit
+    for bit (test_gpu_symmetric.py) - is the yardstick: K structure, K and P values of all 10^6 rows, bit for bit."""
+    from bench import make_manifold
+
+    n, d, world = 1000000, 64, 8
+    X = make_manifold(n, d, 1)
+    pargs = (15, 40.0, 1e-4, None, 1.0, None, "+", None, 0)
+    sim = SimulatedRanks(X, world, pargs)
+    try:
+        recv = sim.exchange()
+        assert all(sim.used), "the local candidate pass did not apply on every rank: %r" % (sim.used,)
+        parts = []
+        for r in range(world):
+            c, nnz_r = sim.finish(r, recv[r])
+            st = c.knn_stats()
+            assert st["symmetric"] and st["sym_two_stage"] and not st["sym_bound_pass"], st
+            Kd, Ki, Kp = c.graph_fetch_csr(sim.hip.CSR_K)
+            Pd, _, _ = c.graph_fetch_csr(sim.hip.CSR_P, structure=False)
+            rows = c.points_row_ids(int(sim.splits[r]), int(sim.splits[r + 1]))
+            parts.append((rows, Kp.astype(np.int64), Ki.copy(), (Kd.copy(), Pd.copy())))
+        # the single-rank build on the same context's GPU
+        c = sim.hip.Context(0)
+        try:
+            c.set_points(X)
+            p1, keep = c.make_params(*pargs)
+            c.graph_build(p1)
+            Kd1, Ki1, Kp1 = c.graph_fetch_csr(sim.hip.CSR_K)
+            Pd1, _, _ = c.graph_fetch_csr(sim.hip.CSR_P, structure=False)
+            Kd1, Ki1, Kp1, Pd1 = Kd1.copy(), Ki1.copy(), Kp1.copy(), Pd1.copy()
+        finally:
+            c.close()
+    finally:
+        sim.close()
+    Kp, Ki, (Kd, Pd) = _assemble(n, parts)
+    assert np.array_equal(Kp, Kp1) and np.array_equal(Ki, Ki1), "structure differs from the single-rank build"
+    assert np.array_equal(Kd, Kd1) and np.array_equal(Pd, Pd1), "values differ from the single-rank build"

@@ -267,17 +267,17 @@ def test_anisotropy_and_vector_bandwidth_follow_the_renumbering():
 
 
 def test_a_rank_may_take_the_classic_pass_on_its_own():
-    """nothing is shared before the triplets: a rank whose cell bounds leave too many units (here: a cap of 50) builds its
-    rows with the classic candidate pass while its peers use their local lists - the graph is the same; isotropic points
-    (whatever each rank decides) likewise"""
+    """nothing is shared before the triplets: a rank that declines the local pass (here: by option) builds its rows with the
+    classic candidate pass while its peers use their local lists - the graph is the same; isotropic points (whatever each rank
+    decides) likewise"""
     X = make_mix(24000, 64, 7)
     pargs = (12, 30, 1e-4, None, 1.0, None, "+", None, 0)
     K1, P1 = single_build(X, pargs)
-    K, P, used, stats = sharded_local_build(X, 3, pargs, opts=[{}, {"select_sym_bound_cap": 50}, {}])
+    K, P, used, stats = sharded_local_build(X, 3, pargs, opts=[{}, {"select_sym_two_stage": 0}, {}])
     assert used == [True, False, True]
     _same(K, K1)
     _same(P, P1)
-    K, P, used, stats = sharded_local_build(X, 2, pargs, opts={"select_sym_bound_cap": 50})
+    K, P, used, stats = sharded_local_build(X, 2, pargs, opts={"select_sym_two_stage": 0})
     assert not any(used)
     _same(K, K1)
     _same(P, P1)
@@ -285,6 +285,27 @@ def test_a_rank_may_take_the_classic_pass_on_its_own():
     pargs = (8, 30, 1e-4, None, 1.0, None, "+", None, 0)
     K, P, used, stats = sharded_local_build(X, 2, pargs, opts={"select_symmetric": "auto", "select_sym_min_rows": 1})
     K1, P1 = single_build(X, pargs)
+    _same(K, K1)
+    _same(P, P1)
+
+
+@pytest.mark.parametrize("maker,n,d,world", [(make_mix, 70000, 64, 3), (make_mix, 90000, 32, 4), (make_mix, 66001, 48, 2)])
+def test_cell_bounds_that_decide_too_little_send_a_rank_to_its_own_two_stage_collect(maker, n, d, world):
+    """round 6: a rank whose cell bounds leave more units than the queue of the cold launch holds (here: a queue of 50) no
+    longer falls back to the classic pass - its own 1024-row query blocks stream every tile through stage one of the two-stage
+    collect (forward test only), the survivors go to the cold launch, filed under the queries.  Same graph; one rank of the
+    first case alone (its peers within the bounds), every rank of the others; a ragged last block in the third.  (Sizes with a
+    few dozen clusters: with a dozen, one random pair in twelve passes stage one and its forecast rightly declines.  The data
+    the path is FOR - a sheet in 64 dimensions - passes the forecast from ~10^6 rows only: tests/test_gpu_shard_full.py.)"""
+    X = maker(n, d, 7)
+    pargs = (12, 30, 1e-4, None, 1.0, None, "+", None, 0)
+    K1, P1 = single_build(X, pargs)
+    opts = [{}, {"select_sym_bound_cap": 50}, {}] if world == 3 else {"select_sym_bound_cap": 50}
+    K, P, used, stats = sharded_local_build(X, world, pargs, opts=opts)
+    assert all(used)
+    for r, (ks, gs) in enumerate(stats):
+        capped = world != 3 or r == 1
+        assert ks["sym_two_stage"] and ks["sym_bound_pass"] == (not capped), (r, ks)
     _same(K, K1)
     _same(P, P1)
 
