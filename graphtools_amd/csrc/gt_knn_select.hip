@@ -1419,8 +1419,10 @@ __global__ __launch_bounds__(256) void sym_queue_spill_kernel(const uint2* __res
 // A0 / A1: scores of the wave's two query tiles (lane (li, h): query li of the tile, database rows 8 (e >> 2) + 4 h + (e & 3)),
 // SD: the rows' seeds (removed again from what is filed under the database rows).  List order differs from GT_ADMIT2P's;
 // the re-rank does not depend on it.
+// Returns (wave-uniform) whether the unit issued - and waited for - a returning atomic: every memory operation of the wave older
+// than it (loads and LDS-DMA copies return in order with returning atomics) has then completed too.
 template <typename SYM>
-__device__ __forceinline__ void cold_admit(const f32x16& A0, const f32x16& A1, const f32x16& SD, const float tq0, const float tq1,
+__device__ __forceinline__ bool cold_admit(const f32x16& A0, const f32x16& A1, const f32x16& SD, const float tq0, const float tq1,
                                            const float hq0, const float hq1, const uint32_t qpos0, const uint32_t qpos1,
                                            const uint32_t tbase, const float* __restrict__ gglob, const bool tr_on,
                                            const int lane, const int li, const int h, const SYM& sy) {
@@ -1458,6 +1460,10 @@ __device__ __forceinline__ void cold_admit(const f32x16& A0, const f32x16& A1, c
         const uint32_t e = uint32_t(lane) & 15u, hh = uint32_t(lane) >> 4;
         vbase = atomicAdd(&sy.tcounts[tbase + 8u * (e >> 2) + 4u * hh + (e & 3u)], vcnt);
     }
+    // All three reservations are waited for HERE, in front of the first list store: the compiler then knows of no memory
+    // operation in flight behind this point (the list stores are inline asm it does not track), and inserts no wait of its own
+    // further down - at the top of the caller's next unit it would be a `vmcnt(0)` that also sits out the stores just issued.
+    asm volatile("" ::"v"(k0), "v"(k1), "v"(vbase));
     // ---- forward stores ----
     if (nf0) {
         uint64_t* lp = sy.tlists + size_t(qpos0) * size_t(tcap);
@@ -1510,6 +1516,7 @@ __device__ __forceinline__ void cold_admit(const f32x16& A0, const f32x16& A1, c
             }
         }
     }
+    return __ballot((nf0 | nf1 | vcnt) != 0u) != 0ull;
 }
 
 // ---- deferred cold pass of the two-stage symmetric collect: one wave per queue entry -------------------------------
@@ -1525,6 +1532,19 @@ __device__ __forceinline__ void cold_admit(const f32x16& A0, const f32x16& A1, c
 #endif
 #ifndef GT_SEL_COLD_EPW
 #define GT_SEL_COLD_EPW 16   // queue entries per wave of the cold launch (consecutive entries mostly share their queries)
+#endif
+// Round 6: the operands of unit i + 1 travel while unit i is scored and filed.  A unit used to be a chain of three dependent
+// round trips - its queue entry, its operand rows (32 rows of the compact copy + their seeds and thresholds), the returning
+// atomics that reserve its list slots - at four waves per SIMD: 1.8 ns per unit on the chip, ~14 000 cycles per unit and wave,
+// all of it latency (13.6 of the manifold set's 43 ms for 7.6 M units).  Now the wave's 16 entries arrive in ONE load, and the
+// rows, seeds and thresholds of the NEXT unit are copied global -> LDS (LDS-DMA: no registers - the version that prefetched into
+// a second set of fragment registers lost more to occupancy than the round trip it hid, round 5) right after this unit's
+// fragments have been read out of the same buffer: the copy is in flight behind the matrix instructions and the atomics.  The
+// copies are inline asm (hipcc would fence every LDS read behind every copy it knows of); they are older than the unit's
+// atomics, so a unit that filed anything has waited for them by the time its atomics returned (cold_admit's return value) and
+// the list stores behind - which nobody waits for - stay out of the wait; a unit that filed nothing waits for the copies alone.
+#ifndef GT_SEL_COLD_LDS
+#define GT_SEL_COLD_LDS 1
 #endif
 template <int DP>
 __global__ __launch_bounds__(256, GT_SEL_COLD_WAVES) void sym_cold_kernel(const float* __restrict__ Yp, const float* __restrict__ hneg,
@@ -1542,12 +1562,44 @@ __global__ __launch_bounds__(256, GT_SEL_COLD_WAVES) void sym_cold_kernel(const 
     Frag<DP, 2> bq[QT], ca;
     float thrF[QT], hnqF[QT], thr[QT];
     uint32_t have_q = 0xFFFFFFFFu;
+#if GT_SEL_COLD_LDS
+    // (one wave per workgroup: launch_sym_cold) 32 rows of the compact copy | 2 x {32 seeds | 32 row thresholds}
+    constexpr int TILE_B = 32 * C::RB;
+    static_assert(TILE_B % 1024 == 0, "whole 1 KiB pieces");
+    __shared__ __attribute__((aligned(16))) unsigned char cold_lds[TILE_B + 2 * 256];
+    typedef __attribute__((address_space(3))) void lds_void_;
+    const uint32_t lds_tile = uint32_t(size_t((lds_void_*)cold_lds)), lds_sg = lds_tile + uint32_t(TILE_B);
+    const float* tileA = reinterpret_cast<const float*>(cold_lds);
+    const float* sgbuf = reinterpret_cast<const float*>(cold_lds + TILE_B);
+    static_assert(GT_SEL_COLD_EPW <= 64, "one queue entry per lane");
+    uint2 ent_mine = make_uint2(0u, 0u);
+    if (lane < GT_SEL_COLD_EPW && en0 + lane < int64_t(sy.qn)) ent_mine = sy.queue[en0 + lane];
+    const int n_ent = int(int64_t(sy.qn) - en0 < int64_t(GT_SEL_COLD_EPW) ? int64_t(sy.qn) - en0 : int64_t(GT_SEL_COLD_EPW));
+    const bool with_g = sy.own_only == 0;   // (own-only launches read no row thresholds: sy.g may be null)
+    auto issue = [&](const int i_) {
+        const uint32_t tb_ = uint32_t(__builtin_amdgcn_readlane(int(ent_mine.y), i_)) * 32u;
+        const char* src_ = reinterpret_cast<const char*>(Yp) + size_t(tb_) * size_t(C::RB) + size_t(lane) * 16;
+#pragma unroll
+        for (int k_ = 0; k_ < TILE_B / 1024; ++k_)
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src_ + k_ * 1024), "s"(lds_tile + uint32_t(k_ * 1024)) : "memory");
+        // lanes 0 .. 31: the rows' seeds; lanes 32 .. 63: their thresholds (g) - one 256-byte piece, double buffered (the
+        // thresholds are read again behind the atomics, when the next unit's copy is already under way)
+        const float* sp_ = lane < 32 ? hneg + size_t(tb_) + lane : (with_g ? sy.g + size_t(tb_) + (lane - 32) : hneg + size_t(tb_) + (lane - 32));
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(sp_), "s"(lds_sg + uint32_t((i_ & 1) * 256)) : "memory");
+    };
+    issue(0);
+    bool had = false;
+    for (int ce_ = 0; ce_ < n_ent; ++ce_) {
+        const uint2 ent = make_uint2(uint32_t(__builtin_amdgcn_readlane(int(ent_mine.x), ce_)),
+                                     uint32_t(__builtin_amdgcn_readlane(int(ent_mine.y), ce_)));
+#else
     // a wave takes a few consecutive entries: the bound pass files the units of a group of 64 queries together (and the
     // collect launch most of a wave's), so the query fragments, thresholds and seeds are loaded once per run
     for (int ce_ = 0; ce_ < GT_SEL_COLD_EPW; ++ce_) {
         const int64_t en_ = en0 + ce_;
         if (en_ >= int64_t(sy.qn)) break;   // wave-uniform
         const uint2 ent = sy.queue[en_];
+#endif
         const int64_t qblock = int64_t(ent.x) * (QT * 32);
         const uint32_t tbase = ent.y * 32u;
         // does the sub-tile's block take these queries as ITS candidates too?  (position of its tile in the walk of the
@@ -1566,9 +1618,37 @@ __global__ __launch_bounds__(256, GT_SEL_COLD_WAVES) void sym_cold_kernel(const 
                 hnqF[qt] = qg < nq ? hneg[qc] : -INFINITY;
                 thr[qt] = thrF[qt];
             }
+#if GT_SEL_COLD_LDS
+            // (the queries' loads are waited for here, once per group: a compiler-inserted wait for them further down would be a
+            //  `vmcnt(0)` behind the next unit's copy - the very round trip the copy is meant to hide)
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) {
+#pragma unroll
+                for (int s_ = 0; s_ < DP / 16; ++s_) asm volatile("" ::"v"(bq[qt].hi[s_]));
+                asm volatile("" ::"v"(thrF[qt]), "v"(hnqF[qt]));
+            }
+#endif
         }
-        ca.load(Yp + (size_t(tbase) + li) * RWC, h);
         f32x16 cs;
+#if GT_SEL_COLD_LDS
+        // the unit's operands have landed: a unit that filed something waited for its atomics, which are younger than the copy
+        if (ce_ == 0 || !had) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ca.load(tileA + li * RWC, h);
+        const float* sg_ = sgbuf + (ce_ & 1) * 64;
+#pragma unroll
+        for (int g_ = 0; g_ < 4; ++g_) {
+            const float4 hv_ = *reinterpret_cast<const float4*>(sg_ + 8 * g_ + 4 * h);
+            cs[4 * g_ + 0] = hv_.x;
+            cs[4 * g_ + 1] = hv_.y;
+            cs[4 * g_ + 2] = hv_.z;
+            cs[4 * g_ + 3] = hv_.w;
+        }
+        // fragments and seeds are in registers: the tile and the other {seeds | thresholds} buffer may be overwritten
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (ce_ + 1 < n_ent) issue(ce_ + 1);
+        const float* gglob = sg_ + 32;
+#else
+        ca.load(Yp + (size_t(tbase) + li) * RWC, h);
 #pragma unroll
         for (int g_ = 0; g_ < 4; ++g_) {
             const float4 hv_ = *reinterpret_cast<const float4*>(hneg + size_t(tbase) + 8 * g_ + 4 * h);
@@ -1578,12 +1658,18 @@ __global__ __launch_bounds__(256, GT_SEL_COLD_WAVES) void sym_cold_kernel(const 
             cs[4 * g_ + 3] = hv_.w;
         }
         const float* gglob = sy.g + size_t(tbase);
+#endif
         f32x16 cacc = cs, cacc1 = cs;
         mma_chain<DP>(ca, bq[0], cacc);
         mma_chain<DP>(ca, bq[QT - 1], cacc1);
-#if GT_SEL_COLD_ADMIT
-        cold_admit(cacc, cacc1, cs, thrF[0], thrF[QT - 1], hnqF[0], hnqF[QT - 1], uint32_t(qblock + li),
-                   uint32_t(qblock + 32 + li), tbase, gglob, tr_on, lane, li, h, sy);
+#if GT_SEL_COLD_ADMIT || GT_SEL_COLD_LDS
+        const bool had_ = cold_admit(cacc, cacc1, cs, thrF[0], thrF[QT - 1], hnqF[0], hnqF[QT - 1], uint32_t(qblock + li),
+                                     uint32_t(qblock + 32 + li), tbase, gglob, tr_on, lane, li, h, sy);
+#if GT_SEL_COLD_LDS
+        had = had_;
+#else
+        (void)had_;
+#endif
 #else
         GT_ADMIT2P(cacc, cacc1, cs, 0);
 #endif
