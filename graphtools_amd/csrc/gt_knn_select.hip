@@ -1696,7 +1696,7 @@ __global__ __launch_bounds__(256, GT_SEL_COLD_WAVES) void sym_cold_kernel(const 
 // What is FILED is an upper bound of the true score in the global frame's terms, (|x|^2 - (|x' - y'| - delta)^2) / 2 scaled -
 // so that the re-rank's bound on what lies beyond a full table (bound_of_score of the 257th key) holds as it stands.
 template <typename SYM>
-__device__ __forceinline__ void cold_admit_local(const f32x16& A0, const f32x16& A1, const float tq0, const float tq1,
+__device__ __forceinline__ bool cold_admit_local(const f32x16& A0, const f32x16& A1, const float tq0, const float tq1,
                                                  const float hq0, const float hq1, const float fq0, const float fq1,
                                                  const uint32_t qpos0, const uint32_t qpos1, const uint32_t tbase,
                                                  const float* __restrict__ Tl, const float* __restrict__ Bl, const bool tr_on,
@@ -1735,6 +1735,7 @@ __device__ __forceinline__ void cold_admit_local(const f32x16& A0, const f32x16&
         const uint32_t e = uint32_t(lane) & 15u, hh = uint32_t(lane) >> 4;
         vbase = atomicAdd(&sy.tcounts[tbase + 8u * (e >> 2) + 4u * hh + (e & 3u)], vcnt);
     }
+    asm volatile("" ::"v"(k0), "v"(k1), "v"(vbase));   // (all three waited for here, in front of the first list store: cold_admit)
     if (nf0) {
         uint64_t* lp = sy.tlists + size_t(qpos0) * size_t(tcap);
 #pragma unroll
@@ -1784,6 +1785,7 @@ __device__ __forceinline__ void cold_admit_local(const f32x16& A0, const f32x16&
             }
         }
     }
+    return __ballot((nf0 | nf1 | vcnt) != 0u) != 0ull;
 }
 
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
@@ -1826,18 +1828,54 @@ __global__ __launch_bounds__(256, GT_SEL_COLD_LOCAL_WAVES) void sym_cold_local_k
                                                                                const int32_t ntiles, const SymDev sy) {
     using C = SelCfg<DP, 2>;
     constexpr int QT = 2;
-    __shared__ __attribute__((aligned(16))) float lds_all[4][DP + 96];
-    const int lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5, wv = threadIdx.x >> 6;
+    // (one wave per workgroup: launch_sym_cold)
+    __shared__ __attribute__((aligned(16))) float lds_all[1][DP + 96];
+    const int lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5, wv = 0;
     float* osc = lds_all[wv];   // [DP]  centre of the wave's queries, scaled
     float* hwl = osc + DP;      // [32]  -|w_j|^2 / 2 of the sub-tile's rows
     float* Tl = hwl + 32;       // [32]  their thresholds T_j
     float* Bl = Tl + 32;        // [32]  their filing terms
-    const int64_t en0 = (int64_t(blockIdx.x) * (blockDim.x >> 6) + wv) * GT_SEL_COLD_EPW;
+    const int64_t en0 = int64_t(blockIdx.x) * GT_SEL_COLD_EPW;
     if (en0 >= int64_t(sy.qn)) return;
     constexpr int BQ = 128 * GT_SEL_TWO_QT, TPB = BQ / C::BN;
     const int T = ntiles, NB = T / TPB, H = (NB - 1) / 2;
     const float sc = sy.sc;
     const int xs_d = sy.xs_d;
+#if GT_SEL_COLD_LDS
+    // Round 6, as in sym_cold_kernel: the 32 float32 rows of the NEXT unit (xs_d floats each: up to 8 KiB) and their {radius,
+    // seed} pairs are copied global -> LDS while this unit is scored and filed; the fragments of this unit were converted out of
+    // the same buffer before the copy was issued.
+    __shared__ __attribute__((aligned(16))) unsigned char rows_lds[32 * DP * 4 + 256];
+    typedef __attribute__((address_space(3))) void lds_void_;
+    const uint32_t lds_rows = uint32_t(size_t((lds_void_*)rows_lds)), lds_rh = lds_rows + uint32_t(32 * DP * 4);
+    const float* rowsL = reinterpret_cast<const float*>(rows_lds);
+    const float* rhL = reinterpret_cast<const float*>(rows_lds + 32 * DP * 4);   // [32] radii | [32] seeds
+    const int tile_bytes = 32 * xs_d * 4;
+    auto issue = [&](const uint32_t d32_) {
+        // (uniform base in scalar registers, the lane's offset in ONE transient register: per-lane 64-bit addresses held across
+        //  the loop pushed the kernel over its 128 registers - and a reload from scratch is a `vmcnt(0)` behind the copy)
+        const char* base_ = reinterpret_cast<const char*>(sy.xs) + int64_t(d32_) * tile_bytes;
+        const int64_t left_ = (int64_t(sy.xs_n) - int64_t(d32_) * 32) * xs_d * 4;   // bytes of the point set from this row on
+        const int valid_ = int(left_ < int64_t(tile_bytes) ? left_ : int64_t(tile_bytes));   // (rows beyond it: not copied, masked below)
+#pragma unroll
+        for (int k_ = 0; k_ < DP / 8; ++k_) {   // 1 KiB pieces of at most 32 x DP x 4 bytes
+            if (k_ * 1024 < tile_bytes) {       // (uniform)
+                const uint32_t lo_ = uint32_t(lane) * 16u + uint32_t((k_ >> 2) * 4096);
+                if (int(lo_) + (k_ & 3) * 1024 + 16 <= valid_)
+                    // (the instruction's offset moves BOTH addresses: global base + lane offset + offset -> M0 + 16 lane + offset)
+                    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3" ::"v"(lo_), "s"(base_),
+                                 "s"(lds_rows + uint32_t((k_ >> 2) * 4096)), "n"((k_ & 3) * 1024) : "memory");
+            }
+        }
+        // lanes 0 .. 31: the rows' radii, lanes 32 .. 63: their seeds - one copy per half, each from a scalar base (a lane's
+        // LDS slot is its place in the wave, whatever the execution mask)
+        const uint32_t j_ = d32_ * 32u + uint32_t(li);
+        const uint32_t jo_ = (j_ < uint32_t(sy.xs_n) ? j_ : uint32_t(sy.xs_n) - 1u) * 4u;
+        if (h == 0) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(jo_), "s"(sy.rloc), "s"(lds_rh) : "memory");
+        else asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(jo_), "s"(hneg), "s"(lds_rh) : "memory");
+    };
+    bool had = false;
+#endif
     const float EPS = 4.90189e-4f;                     // 2^-11 (1 + 2^-8): float16 rounding of an operand, with head-room
     const float C1 = float(DP + 16) * 5.9604645e-8f;   // float32 accumulation of a score, per (|u| + |w|)^2
     Frag<DP, 2> bq[QT], ca;
@@ -1848,6 +1886,9 @@ __global__ __launch_bounds__(256, GT_SEL_COLD_LOCAL_WAVES) void sym_cold_local_k
     static_assert(GT_SEL_COLD_EPW <= 64, "one queue entry per lane");
     uint2 ent_mine = make_uint2(0u, 0u);
     if (lane < GT_SEL_COLD_EPW && en0 + lane < int64_t(sy.qn)) ent_mine = sy.queue[en0 + lane];
+#if GT_SEL_COLD_LDS
+    issue(uint32_t(__builtin_amdgcn_readlane(int(ent_mine.y), 0)));
+#endif
     for (int ce_ = 0; ce_ < GT_SEL_COLD_EPW; ++ce_) {
         const int64_t en_ = en0 + ce_;
         if (en_ >= int64_t(sy.qn)) break;   // wave-uniform
@@ -1878,15 +1919,34 @@ __global__ __launch_bounds__(256, GT_SEL_COLD_LOCAL_WAVES) void sym_cold_local_k
                 um = fmaxf(um, real ? part : 0.f);
             }
             umax = sqrtf(wave_max_f32(um));
+#if GT_SEL_COLD_LDS
+            // (nothing of the queries' loads stays in flight behind this block: sym_cold_kernel)
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) asm volatile("" ::"v"(rq[qt]), "v"(hgq[qt]), "v"(hu[qt]));
+#endif
         }
         // the sub-tile's rows in the same frame
         const int64_t jg = int64_t(tbase) + li;
         const bool jreal = jg < int64_t(sy.xs_n);
         const int64_t jc = jreal ? jg : int64_t(sy.xs_n) - 1;
+#if GT_SEL_COLD_LDS
+        // the unit's rows have landed: a unit that filed something waited for its atomics, which are younger than the copy
+        if (ce_ == 0 || !had) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        float nw = frag_load_local<DP>(ca, rowsL + li * xs_d, xs_d, osc, sc, h);
+        const float rj_l = rhL[li], hgj_l = rhL[32 + li];
+        // rows, radii and seeds are in registers: the buffer takes the next unit's
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (ce_ + 1 < GT_SEL_COLD_EPW && en_ + 1 < int64_t(sy.qn)) issue(uint32_t(__builtin_amdgcn_readlane(int(ent_mine.y), ce_ + 1)));
+        nw += __uint_as_float(lane_xor_b32(__float_as_uint(nw), 32));
+        const float rj = jreal ? rj_l : -INFINITY;
+        const float hgj = jreal ? hgj_l : 0.f;
+        (void)jc;
+#else
         float nw = frag_load_local<DP>(ca, sy.xs + jc * int64_t(xs_d), xs_d, osc, sc, h);
         nw += __uint_as_float(lane_xor_b32(__float_as_uint(nw), 32));
         const float rj = jreal ? sy.rloc[jc] : -INFINITY;
         const float hgj = jreal ? hneg[jc] : 0.f;
+#endif
         __builtin_amdgcn_wave_barrier();
         if (h == 0) hwl[li] = jreal ? -0.5f * nw : -INFINITY;
         __builtin_amdgcn_wave_barrier();
@@ -1920,9 +1980,14 @@ __global__ __launch_bounds__(256, GT_SEL_COLD_LOCAL_WAVES) void sym_cold_local_k
         }
         __builtin_amdgcn_wave_barrier();
         const float T0 = thr_of(rq[0]), T1 = thr_of(rq[QT - 1]);
-        cold_admit_local(cacc, cacc1, T0 - hu[0], T1 - hu[QT - 1], hu[0], hu[QT - 1], hu[0] + file_of(rq[0], hgq[0]),
-                         hu[QT - 1] + file_of(rq[QT - 1], hgq[QT - 1]), uint32_t(qblock + li), uint32_t(qblock + 32 + li), tbase,
-                         Tl, Bl, tr_on, lane, li, h, sy);
+        const bool had_ = cold_admit_local(cacc, cacc1, T0 - hu[0], T1 - hu[QT - 1], hu[0], hu[QT - 1], hu[0] + file_of(rq[0], hgq[0]),
+                                           hu[QT - 1] + file_of(rq[QT - 1], hgq[QT - 1]), uint32_t(qblock + li),
+                                           uint32_t(qblock + 32 + li), tbase, Tl, Bl, tr_on, lane, li, h, sy);
+#if GT_SEL_COLD_LDS
+        had = had_;
+#else
+        (void)had_;
+#endif
     }
 }
 
