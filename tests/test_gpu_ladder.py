@@ -92,6 +92,8 @@ def _build_ms(X, opts, reps=3):
             ms = sum(max(c.stage_ms(s), 0.0) for s in TOP_STAGES)
             best = ms if best is None else min(best, ms)
             wall = w if wall is None else min(wall, w)
+            if w > 1000.0:   # a route that takes seconds where the others take a fraction (the symmetric pass FORCED on points
+                break        # shifted 300 units from the origin: 8.8 s per build) is not timed three times
         sym = bool(c.knn_stats()["symmetric"])
         deg = c.graph_fetch_vec(1)
         return best, int(nnz), sym, float(deg.sum()), wall
