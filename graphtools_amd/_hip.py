@@ -166,7 +166,14 @@ class _HostPool:
     block, it keeps a slice of a float64 array); callers get the head of it, whose ``base`` is the block: the block's
     reference count tells whether any array of an earlier result is still alive, and only a block nobody else refers to is
     handed out again (``np.empty`` semantics: the content is whatever was there).  At most ``GRAPHTOOLS_AMD_HOST_POOL_GB``
-    (default 8, 0 = off) stay cached; ``release_cached_memory()`` drops them."""
+    (default 5 - two graphs of 10^6 rows: the one a caller still holds and the one being copied out -, 0 = off) stay cached
+    after the graphs that used them are dropped; ``release_cached_memory()`` drops them.
+
+    What the recycling rests on is CPython's reference count of the block (checked by a self-test at start-up; an interpreter
+    where it fails, or a free-threaded build - whose counts are not a safe "nobody else holds this" -, never recycles).  A
+    consumer that keeps a RAW POINTER into a result array without holding the array (ctypes, a C extension that does not take
+    a buffer) is not seen by it: such a consumer must keep a reference to the array for as long as it uses the memory - as it
+    must for any numpy array - or switch the pool off."""
 
     MIN_BYTES = 32 << 20
     ROUND = 16 << 20
@@ -177,11 +184,25 @@ class _HostPool:
         self.blocks = []   # least recently used first
         self.lock = threading.Lock()
         try:
-            self.cap = int(float(os.environ.get("GRAPHTOOLS_AMD_HOST_POOL_GB", "8")) * (1 << 30))
+            self.cap = int(float(os.environ.get("GRAPHTOOLS_AMD_HOST_POOL_GB", "5")) * (1 << 30))
         except ValueError:
-            self.cap = 8 << 30
-        if not self._refcounts_behave():
+            self.cap = 5 << 30
+        if not self._refcounts_behave() or self._free_threaded():
             self.cap = 0   # (an interpreter whose reference counts do not say "nobody else holds this": never recycle)
+
+    @staticmethod
+    def _free_threaded():
+        """a build without the GIL: reference counts are biased / deferred there, and two threads may race the check"""
+        import sys
+        import sysconfig
+
+        try:
+            if sysconfig.get_config_var("Py_GIL_DISABLED"):
+                return True
+            gil = getattr(sys, "_is_gil_enabled", None)
+            return gil is not None and not gil()
+        except Exception:
+            return True
 
     @staticmethod
     def _refcounts_behave():

@@ -124,6 +124,7 @@ struct gt_ctx {
     // into pinned memory they queue behind each other and the one synchronisation that follows takes them all.
     unsigned char* mail = nullptr;   // 1 KB, hipHostMalloc on first use
     size_t mail_used = 0;
+    bool mail_busy = false;          // a ReadBack group holds the mailbox
     void* mail_slot(size_t bytes) {
         if (!mail && hipHostMalloc(reinterpret_cast<void**>(&mail), 1024, hipHostMallocDefault) != hipSuccess) mail = nullptr;
         bytes = (bytes + 7) & ~size_t(7);
@@ -334,18 +335,39 @@ struct ReadBack {
     };
     Item items[8];
     int n = 0;
-    explicit ReadBack(gt_ctx* c) : ctx(c) { c->mail_used = 0; }
+    bool owner = false;     // this group holds the mailbox (one at a time: a second group alive at once copies straight into `dst`)
+    bool pending = false;   // copies were queued and not yet waited for
+    explicit ReadBack(gt_ctx* c) : ctx(c) {
+        // (round-5 advisor: the constructor used to reset the shared mailbox unconditionally - a helper opening its own group
+        //  between another group's add() and sync() would have handed out the same slots)
+        if (!c->mail_busy) {
+            c->mail_busy = true;
+            c->mail_used = 0;
+            owner = true;
+        }
+    }
+    ~ReadBack() {
+        // an early return between add() and sync() (GT_HIP on a failed launch) must not leave copies in flight into the caller's
+        // stack frame (the direct path) or into slots the next group will hand out again
+        if (pending) (void)hipStreamSynchronize(ctx->stream);
+        if (owner) ctx->mail_busy = false;
+    }
+    ReadBack(const ReadBack&) = delete;
+    ReadBack& operator=(const ReadBack&) = delete;
     hipError_t add(void* dst, const void* dev, size_t bytes) {
-        void* slot = n < 8 ? ctx->mail_slot(bytes) : nullptr;
+        pending = true;
+        void* slot = (owner && n < 8) ? ctx->mail_slot(bytes) : nullptr;
         if (!slot) return hipMemcpyAsync(dst, dev, bytes, hipMemcpyDeviceToHost, ctx->stream);
         items[n++] = Item{dst, slot, bytes};
         return hipMemcpyAsync(slot, dev, bytes, hipMemcpyDeviceToHost, ctx->stream);
     }
     hipError_t sync() {
         const hipError_t e = hipStreamSynchronize(ctx->stream);
+        pending = false;
         if (e == hipSuccess)
             for (int i = 0; i < n; ++i) std::memcpy(items[i].dst, items[i].slot, items[i].bytes);
         n = 0;
+        if (owner) ctx->mail_used = 0;
         return e;
     }
 };

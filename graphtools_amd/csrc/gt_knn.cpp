@@ -229,6 +229,7 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
             ra.err = em;
             // (the counters of the seeding stage - far-kept rows [2], tiles [5] - stay; only the re-rank's own start at 0)
             GT_HIP(ctx, hipMemsetAsync(k->sym_stat.p, 0, 2 * sizeof(unsigned long long), ctx->stream));
+            GT_HIP(ctx, hipMemsetAsync(k->sym_stat.as<unsigned long long>() + 6, 0, sizeof(unsigned long long), ctx->stream));
             GT_HIP(ctx, hipMemsetAsync(k->unproven.p, 0, sizeof(uint32_t), ctx->stream));
             SymRerank sr;
             sr.tcap = ctx->sym_tcap;
@@ -270,7 +271,8 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
             if (ctx->dbg_select & 2048)
                 fprintf(stderr, "[gt] shard rerank: rows %lld unproven %u repairs %u overflow %lld\n", (long long)nq, n_unproven,
                         n_fb, (long long)k->sym_overflow);
-            const bool too_many = ctx->sym_mode < 0 && double(k->sym_overflow) > 0.10 * double(nq);
+            // (rows whose table is full and still cannot prove its radius count like overflows: sym_stat[6], gt_rerank.hip)
+            const bool too_many = ctx->sym_mode < 0 && double(k->sym_overflow + int64_t(k->sym_stat_host[6])) > 0.10 * double(nq);
             const bool unproved = fast_auto && double(n_unproven) > kFastFailFrac * double(nq);
             if (too_many || unproved) {
                 if (too_many) ctx->sym_ok = 0;
@@ -672,7 +674,7 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
                 GT_HIP(ctx, rb.sync());
             }
             k->sym_overflow = int64_t(k->sym_stat_host[0]);
-            if (ctx->sym_mode < 0 && double(k->sym_overflow) > 0.10 * double(nq)) {
+            if (ctx->sym_mode < 0 && double(k->sym_overflow + int64_t(k->sym_stat_host[6])) > 0.10 * double(nq)) {
                 // neighbourhoods too large for the fixed lists (every overflowing row costs a repair): this point set
                 // goes through the classic pass, now and from here on
                 ctx->sym_ok = 0;

@@ -380,6 +380,10 @@ __global__ __launch_bounds__(256, 5) void rerank_sym_kernel(
         // (an overflowing row is short of room, an orphan - threshold +inf - of seeds, neither of precision: they do not
         //  count against the arithmetic)
         if (unproven && !overflow && k257 == 0ull && thr[qt] != INFINITY && !(d2_need * rkf < lb_cand)) atomicAdd(unproven, 1u);
+        // (round-5 advisor: a row with 257 .. tcap candidates whose table cannot prove its radius is neither "unproven" - that
+        //  verdict judges the arithmetic - nor an overflow, yet it costs a repair like one: counted on its own, and the ladder
+        //  holds overflows + these against its 10 % give-up threshold)
+        if (stat && !overflow && k257 != 0ull && thr[qt] != INFINITY && !(d2_need * rkf < lb_cand)) atomicAdd(stat + 6, 1ull);
         if (stat && overflow) atomicAdd(stat + 0, 1ull);
         if (stat && want_stats) {
             // [1] sum of the list lengths [3] longest list [4] rows with more than 256 keys [7] rows with more than 128 keys
@@ -713,6 +717,10 @@ __global__ __launch_bounds__(64 * WPB, GT_RERANK_WAVES) void rerank_sym4_kernel(
         // ("unproven" judges the ARITHMETIC of the candidate pass: a row with more candidates than the table holds - k257 - is
         //  short of room, like an overflowing one; with the margin of the local frame such rows are no longer all overflows)
         if (unproven && !overflow && k257 == 0ull && thr[qt] != INFINITY && !(d2_need * fabs(radius_key_factor) < lb_cand)) atomicAdd(unproven, 1u);
+        // (round-5 advisor: a row with 257 .. tcap candidates whose table cannot prove its radius is neither "unproven" - that
+        //  verdict judges the arithmetic - nor an overflow, yet it costs a repair like one: counted on its own, and the ladder
+        //  holds overflows + these against its 10 % give-up threshold)
+        if (stat && !overflow && k257 != 0ull && thr[qt] != INFINITY && !(d2_need * fabs(radius_key_factor) < lb_cand)) atomicAdd(stat + 6, 1ull);
         if (stat && overflow) atomicAdd(stat + 0, 1ull);
         if (stat && want_stats) {
             const unsigned long long tot = (unsigned long long)ct;

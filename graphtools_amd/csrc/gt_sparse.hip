@@ -31,6 +31,9 @@ void gt_free_graph_state(gt_ctx* ctx) {
     ctx->graph = nullptr;
 }
 
+// internal bit of GraphState::flags (never handed to the caller): merge_pairs_slots_kernel saw the same column twice in a union row
+static constexpr uint32_t kFlagPairDupColumn = 0x40000000u;
+
 namespace {
 
 constexpr int kMaxWorld = 64;
@@ -1840,6 +1843,7 @@ __global__ __launch_bounds__(256) void merge_pairs_slots_kernel(const int64_t nl
             double m[2];
             bool has_diag = false;
             double lsum = 0.0;
+            uint32_t colv[2] = {0u, 0u};
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 m[t] = 0.0;
@@ -1849,6 +1853,7 @@ __global__ __launch_bounds__(256) void merge_pairs_slots_kernel(const int64_t nl
                     const double v = park[int(uint32_t(x) & 127u)];
                     const int tag = int(key & 1u);
                     const uint32_t col = key >> 1;
+                    colv[t] = col;
                     m[t] = (tag == 0 && v < 0.0) ? -v : merge_values(tag == 0 ? v : 0.0, tag == 1 ? v : 0.0, GT_SYMM_ADD, 1.0);
                     const int e = t * 64 + lane;
                     indices[dst + e] = int32_t(col);
@@ -1862,6 +1867,18 @@ __global__ __launch_bounds__(256) void merge_pairs_slots_kernel(const int64_t nl
 #pragma unroll
             for (int t = 0; t < 2; ++t)
                 if (pk[t] != K(0)) Pdata[dst + t * 64 + lane] = (sum != 0.0) ? m[t] / sum : m[t];
+            // "a union row of a pair-resolved build holds no column twice" is what this path rests on: rows i and j must agree
+            // on whether their pair is mutual.  Should they ever not (round-5 advisor: a repaired row next to a partner that was
+            // not), the same column sits in two neighbouring entries of the sorted row - seen here with one shuffle per half, and
+            // the build is done again the general way (graph_finish_pairs returns 0) instead of emitting a duplicate column.
+            {
+                uint32_t n0 = uint32_t(__shfl_down(int(colv[0]), 1));
+                const uint32_t first1 = uint32_t(__shfl(int(colv[1]), 0));
+                if (lane == 63) n0 = first1;
+                const uint32_t n1 = uint32_t(__shfl_down(int(colv[1]), 1));
+                const bool dup = (lane + 1 < L && colv[0] == n0) || (lane < 63 && 64 + lane + 1 < L && colv[1] == n1);
+                if (__ballot(dup) != 0ull && lane == 0) atomicOr(flags, kFlagPairDupColumn);
+            }
             if (lane == 0) {
                 degree[row] = sum;
                 if (!any_diag) atomicOr(flags, GT_FLAG_ZERO_DIAGONAL);
@@ -3231,6 +3248,11 @@ static int graph_finish_pairs(gt_ctx* ctx, int64_t* out_nnz, uint32_t* flags) {
         GT_HIP(ctx, rb.add(&fl, g->flags.p, sizeof(uint32_t)));
         GT_HIP(ctx, rb.add(&kfl, k->gflags.p, sizeof(uint32_t)));
         GT_HIP(ctx, rb.sync());
+    }
+    if (fl & kFlagPairDupColumn) {
+        // (never seen: two rows disagreed on whether their pair is mutual - the general tail builds the graph)
+        if (ctx->dbg_select & 2048) std::fprintf(stderr, "[gt] pair-resolved tail: a union row holds a column twice - rebuilt the general way\n");
+        return 0;
     }
     g->nnz0 = n_kept;
     g->nnz = nnz;
