@@ -368,6 +368,10 @@ int gt_set_option(gt_ctx* ctx, const char* name, const char* value) {
         ctx->sym_cold_local = std::atoi(value) != 0 ? 1 : 0;
         return GT_OK;
     }
+    if (k == "select_sym_two_skip") {
+        ctx->sym_two_skip = std::atoi(value) != 0 ? 1 : 0;
+        return GT_OK;
+    }
     if (k == "select_sym_listed") {
         ctx->sym_listed = v == "auto" ? -1 : std::atoi(value);
         return GT_OK;

@@ -225,6 +225,7 @@ struct gt_ctx {
     int32_t sym_cold_local = 1; //   the cold launch scores its units in the frame of their queries (gt_knn_select.hip sym_cold_local_kernel:
                                 //   float16 roundings of (x - o) sc from the sorted float32 points) - the margin of the float16 chain shrinks
                                 //   from |x||y| 2^-10 to cell size; 0: the compact copy in the global frame (rounds 2-4)
+    int32_t sym_two_skip = 1;   //   two-stage collect: units whose balls in the stage-one space are too far apart are not scored (0: off)
     int32_t sym_listed = -1;    //   one-stage collect over listed walks when the bound pass leaves too many units but few tiles (gt_sym.hip
                                 //   collect_lists_kernel): -1 auto (lists <= a quarter of the walks), 0 off, 1 whenever the lists exist
     int32_t sym_bounds = -1;    //   bound pass in front of the two-stage collect (cell balls): -1 auto / 1 on, 0 off

@@ -994,6 +994,19 @@ int gt_sym_two_stage_prepare(gt_ctx* ctx, const int32_t* perm, int64_t n_pad_s, 
     a.sym.thrh = k->sym_thrh.as<float>();
     a.sym.gminh = k->sym_gminh.as<float>();
     a.sym.zrows = k->sym_z.as<float>();
+    if (ctx->sym_two_skip != 0) {
+        // unit skipping (round 6): balls of the groups of 32 sorted rows in the stage-one space, from the FINAL thresholds
+        StageSpan span(ctx, "sym_prepare");
+        const double u = 5.9604644775390625e-08;
+        const double sc = scz * (1.0 + 1e-6);
+        const double X2 = (sc * ymax + Lz) * (sc * ymax + Lz);
+        const double dmax = (2.0 * double(hd + 8) * 1.5 + 4.0) * u * X2;   // (sym_half_thresholds_kernel's)
+        GT_HIP(ctx, k->sym_zc.reserve(size_t(n_pad_s / 32) * 16 * sizeof(float)));
+        GT_HIP(ctx, k->sym_zrn.reserve(size_t(n_pad_s / 32) * 2 * sizeof(float)));
+        GT_TRY(gt_sym_z_balls(ctx, n_pad_s, k->sym_z.p, k->sym_gh.as<float>(), 4.0 * dmax, k->sym_zc.as<float>(), k->sym_zrn.as<float>()));
+        a.sym.zc = k->sym_zc.as<float>();
+        a.sym.zrn = k->sym_zrn.as<float>();
+    }
     return GT_OK;
 }
 

@@ -44,6 +44,7 @@ struct KnnWork {
     DevBuf sym_z, sym_p, sym_cov;                 //   the stage-one copy Z = P x, its frame P, sample covariance scratch
     DevBuf sym_qspill;                            //   spill area of the queue (+ its counter)
     DevBuf sym_rrow, sym_bwork;                   //   bound pass: radius of every row in the stage-one copy, cell scratch
+    DevBuf sym_zc, sym_zrn;                       //   balls of the groups of 32 rows in the stage-one space (unit skipping)
     DevBuf sym_wlist, sym_wcnt;                   //   listed walks of the one-stage collect (gt_sym_collect_lists) + their total
     bool sym_listed = false;                      //   the last symmetric pass ran the one-stage collect over listed walks
     int64_t sym_listed_tiles = 0;                 //   ... (256 query rows x 128 rows) tiles it scored
@@ -259,6 +260,8 @@ int gt_sym_row_radius(gt_ctx* ctx, const int32_t* perm, int64_t n_pad_s, const f
 int gt_sym_bound_queue(gt_ctx* ctx, int64_t n_pad_s, const void* Ys, const float* rrow, DevBuf& work, uint2* queue,
                        uint32_t cap, uint32_t* count_dev, int world = 1, int rank = 0, int group = 1, int64_t own_p0 = 0,
                        int64_t own_p1 = 0);
+// balls of the groups of 32 sorted rows in the stage-one space: the unit skipping of the two-stage collect (gt_sym.hip)
+int gt_sym_z_balls(gt_ctx* ctx, int64_t n_pad_s, const void* Z, const float* gh, double dmargin, float* zc, float* zrn);
 // listed walks of the one-stage collect (gt_sym.hip collect_lists_kernel) from the cell masks gt_sym_bound_queue left in `work`
 int gt_sym_collect_lists(gt_ctx* ctx, int64_t n_pad_s, DevBuf& work, int cap, int stride, int32_t* tile_list, int32_t* tile_cnt,
                          unsigned long long* total_dev, int* walk_out);

@@ -69,6 +69,12 @@ struct SymDev {
     const float* gcen = nullptr;
     const float* rloc = nullptr;
     float sc = 0.f;
+    // two-stage collect, unit skipping by balls in the stage-one space (gt_sym.hip z_balls_kernel): for every group of 32
+    // consecutive sorted rows the centre zc [n_pad / 32][16] of its stage-one rows, and zrn [n_pad / 32][2] = {radius of the rows
+    // around it, largest stage-one radius a row of the group asks for}.  A (32 queries x 32 rows) unit whose balls are farther
+    // apart than either group's need cannot hold a pair that passes stage one: its MFMA and its tests are skipped.  nullptr: off.
+    const float* zc = nullptr;
+    const float* zrn = nullptr;
     // MODE 2 (one-stage collect) over LISTED walks (gt_sym.hip collect_lists_kernel): query block b visits only the positions
     // walk_list[b * walk_stride + 0 .. walk_cnt[b]) of its walk (ascending; a position rel is the tile (b TPB + rel) mod T) -
     // the tiles whose cells the cell bounds of the bound pass could not rule out against the block's own cells; the nseg work

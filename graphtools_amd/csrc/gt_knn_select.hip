@@ -118,8 +118,11 @@ struct SelCfg {
     // by the bytes in flight, cdna_hip_programming.md "latency x bandwidth") and also stages the per-sub-tile minima
     // of the row thresholds [NBUF][8]
     static constexpr int NBUF_SYM = (GLDS && GT_SEL_NBUF3) ? 3 : 2;
+    // (+ the balls of the unit skipping of the two-stage collect: per buffer 4 sub-tile centres [16] and {radius, need} pairs,
+    //  per wave the same for its GT_SEL_TWO_QT query tiles)
     static constexpr size_t LDS_BYTES_SYM =
-        size_t(NBUF_SYM) * TILE_FLOATS * 4 + size_t(NBUF_SYM) * BN * 4 + size_t(NBUF_SYM) * 8 * 4;
+        size_t(NBUF_SYM) * TILE_FLOATS * 4 + size_t(NBUF_SYM) * BN * 4 + size_t(NBUF_SYM) * 8 * 4 +
+        size_t(NBUF_SYM) * (64 + 8) * 4 + size_t(4) * GT_SEL_TWO_QT * 18 * 4;
     static constexpr int TPB = BQ / BN;                 // database tiles per query block
     // swizzle geometry (GLDS)
     static constexpr int CPR = RB / 16;                 // 16-byte chunks per row
@@ -370,6 +373,11 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
     float* tile = reinterpret_cast<float*>(smem_raw);                    // [NBUF][BN][LDP]
     float* hn = tile + NBUF * C::TILE_FLOATS;                            // [NBUF][BN]
     float* gm = hn + NBUF * BN;                                          // MODE 2: [NBUF][8] sub-tile minima of the row thresholds
+    // two-stage collect, unit skipping (SymDev::zc): balls of the tile's sub-tiles per buffer, of the wave's query tiles
+    float* tcz = gm + NBUF * 8;                                          // [NBUF][4][16] centres
+    float* trn = tcz + NBUF * 64;                                        // [NBUF][4][2]  {radius, need}
+    float* qcz = trn + NBUF * 8;                                         // [4 waves][QT][16]
+    float* qrn = qcz + 4 * GT_SEL_TWO_QT * 16;                           // [4 waves][QT][2]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -534,6 +542,11 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
         if (MODE == 2 && wu == 3 && lv_ < BN / 32)                                                         \
             __builtin_amdgcn_global_load_lds((glb_void*)((TWO ? sy.gminh : sy.gmin) + size_t(T_) * (BN / 32) + lv_), \
                                              (lds_void*)(gm + (BUF_) * 8), 4, 0, 0);                       \
+        /* two-stage collect: the balls of the tile's four sub-tiles (64 centre floats by wave 2, 8 {radius, need} by wave 3) */ \
+        if (TWO && sy.zc != nullptr && wu == 2)                                                            \
+            __builtin_amdgcn_global_load_lds((glb_void*)(sy.zc + size_t(T_) * 64 + lv_), (lds_void*)(tcz + (BUF_) * 64), 4, 0, 0); \
+        if (TWO && sy.zc != nullptr && wu == 3 && lv_ < 8)                                                 \
+            __builtin_amdgcn_global_load_lds((glb_void*)(sy.zrn + size_t(T_) * 8 + lv_), (lds_void*)(trn + (BUF_) * 8), 4, 0, 0); \
     }
 
     // Tile order (MODE 0 with samp_stride = S > 1, a power of two): level 0 visits the tiles 0, S, 2S, ... with a small
@@ -574,6 +587,15 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
             t = walk_tile(rel_c);                                          // MODE 2: the own block first (segment 0)
         }
         if (MODE == 0) t = __builtin_amdgcn_readlane(tl_cache, 0);         // sched 1: first entry of the list
+    }
+    // two-stage collect, unit skipping: the balls of this wave's query tiles (groups of 32 sorted rows), once
+    const bool skip_on = TWO && sy.zc != nullptr;
+    if constexpr (TWO) {
+        if (skip_on) {
+            const int64_t g0_ = qblock / 32 + w * QT;
+            for (int f_ = lane; f_ < QT * 16; f_ += 64) qcz[w * QT * 16 + f_] = sy.zc[g0_ * 16 + f_];
+            if (lane < QT * 2) qrn[w * QT * 2 + lane] = sy.zrn[g0_ * 2 + lane];
+        }
     }
     if constexpr (C::GLDS) {
         GT_GLDS_ISSUE(t, 0);
@@ -672,6 +694,35 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
 #pragma unroll
         for (int sb_ = 0; sb_ < BN / 32; ++sb_)
             gms[sb_] = tr_on ? __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(gm[buf * 8 + sb_]))) : INFINITY;
+        // two-stage collect: which of the tile's (sub-tile, query tile) units can hold a pair that passes stage one at all?
+        // Lane l < NU judges unit l (sub-tile l / QT, query tile l % QT) by the balls of the two groups of 32 rows in the
+        // stage-one space: every pair is at least |c_q - c_t| - R_q - R_t apart, and passes only below the larger of the two
+        // groups' needs (z_balls_kernel; float32 here, radii and needs rounded up there, a relative margin of 1e-4 on the
+        // distance of the centres).  ~50 vector instructions per tile for up to 32 MFMAs and their tests.
+        uint32_t act = 0xFFFFFFFFu;
+        if constexpr (TWO) {
+            if (skip_on) {   // (wave-uniform)
+                const int ul_ = lane < (BN / 32) * QT ? lane : 0;
+                const int sbl_ = ul_ / QT, qtl_ = ul_ % QT;
+                const float* cq_ = qcz + (w * QT + qtl_) * 16;
+                const float* ct_ = tcz + buf * 64 + sbl_ * 16;
+                float d2_ = 0.f;
+#pragma unroll
+                for (int k_ = 0; k_ < 4; ++k_) {
+                    const float4 a_ = *reinterpret_cast<const float4*>(cq_ + 4 * k_);
+                    const float4 b_ = *reinterpret_cast<const float4*>(ct_ + 4 * k_);
+                    d2_ = fmaf(a_.x - b_.x, a_.x - b_.x, d2_);
+                    d2_ = fmaf(a_.y - b_.y, a_.y - b_.y, d2_);
+                    d2_ = fmaf(a_.z - b_.z, a_.z - b_.z, d2_);
+                    d2_ = fmaf(a_.w - b_.w, a_.w - b_.w, d2_);
+                }
+                const float rsum_ = qrn[(w * QT + qtl_) * 2] + trn[buf * 8 + sbl_ * 2];
+                const float need_ = fmaxf(qrn[(w * QT + qtl_) * 2 + 1], trn[buf * 8 + sbl_ * 2 + 1]);
+                const bool far_ = sqrtf(d2_) * (1.f - 1e-4f) - rsum_ * (1.f + 1e-6f) > need_ * (1.f + 1e-6f);
+                act = uint32_t(__ballot(!far_ && lane < (BN / 32) * QT));
+                if (GT_EXP & 512) act = 0xFFFFFFFFu;   // (development: the mask is formed, nothing is skipped)
+            }
+        }
 
         // Software pipeline over the NU = (BN/32)*QT units (sub-tile, query tile) of this tile, fully unrolled:
         //   unit u:  [ MFMA chain of u   ||   admission predicates of u-1 (VALU/SALU in the MFMA issue gaps) ]
@@ -900,6 +951,47 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
         } else {
             GT_SEED(0);
         }
+        if constexpr (TWO) {
+            // ---- the unit loop of the two-stage collect (round 6) ----
+            // The SQ counters of the generic loop on this kernel (manifold set, profiles/r6_pmc_sq_two_stage.txt): 26 scalar
+            // instructions and 6 branches per MFMA - the compare masks of every unit were OR-ed, tested and folded into the
+            // wave's hit mask on the scalar unit, ONE per compute unit, which the twelve waves of a CU kept ~80 % busy while
+            // the matrix pipes ran at 18 %.  Here a unit is one guarded block - skipped as a whole when its balls are too far
+            // apart (`act`) - and what it finds stays in vector registers: bit u of `hitv` in the lanes whose test fired.  The
+            // scalar side looks at `hitv` once per tile, and at its bits only when there is one (3 % of the units pass).
+            // The MFMA's latency is no longer covered by the previous unit's tests of the same wave - at a fifth of the
+            // matrix peak the other waves of the SIMD cover it.
+            uint32_t hitv = 0u;   // (afr[0]: the first sub-tile's fragment, loaded above)
+#pragma unroll
+            for (int sb = 0; sb < NSUB; ++sb) {
+                if (sb + 1 < NSUB) frag_load_part<DP, NS1>(afr[(sb + 1) & 1], tb + ((sb + 1) * 32 + li) * LDP, h, aswz);
+                if (((act >> (sb * QT)) & ((1u << QT) - 1u)) != 0u) {   // (wave-uniform: some unit of the sub-tile is scored)
+                    GT_SEEDR(sb);
+#pragma unroll
+                    for (int qt = 0; qt < QT; ++qt) {
+                        if ((act >> (sb * QT + qt)) & 1u) {
+                            f32x16 pa;
+                            mma_chain_seeded_part<DP, NS1>(afr[sb & 1], bq[qt], seedr, pa);
+#pragma unroll
+                            for (int t3 = 0; t3 < 5; ++t3) mx[t3] = fmaxf(fmaxf(pa[3 * t3], pa[3 * t3 + 1]), pa[3 * t3 + 2]);
+                            const float m5 = fmaxf(fmaxf(mx[0], mx[1]), mx[2]);
+                            const float m6 = fmaxf(fmaxf(mx[3], mx[4]), pa[15]);
+                            const float m16 = fmaxf(m5, m6);
+                            // (the same two tests as the generic loop: the lane's query, or some row of the sub-tile)
+                            const bool fired = (m16 > thr[qt]) || (m16 + hnq[qt] > gms[sb]);
+                            hitv |= fired ? (1u << (sb * QT + qt)) : 0u;
+                        }
+                    }
+                }
+            }
+            if (__ballot(hitv != 0u) != 0ull) {   // (rare)
+#pragma unroll
+                for (int u = 0; u < NU; ++u)
+                    if (__ballot((hitv >> u) & 1u) != 0ull) hitmask |= 1u << u;
+            }
+            (void)any_hit;
+            (void)hit_now;
+        } else {
 #pragma unroll
         for (int u = 0; u <= NU; ++u) {
             const int sb = u / QT, qt = u % QT;              // the unit whose chain is issued now (u < NU)
@@ -913,14 +1005,16 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
                 if (!(GT_EXP & 2) && qt == 0 && sb + 1 < NSUB)
                     frag_load_part<DP, NS1>(afr[(sb + 1) & 1], tb + ((sb + 1) * 32 + li) * LDP, h, aswz);
                 if constexpr (SEEDREG) {
-                    mma_chain_seeded_part<DP, NS1>(afr[sb & 1], bq[qt], seedr, accp[u % NACC]);
+                    if (!TWO || ((act >> u) & 1u))   // (two-stage collect: a unit whose balls are too far apart is not scored)
+                        mma_chain_seeded_part<DP, NS1>(afr[sb & 1], bq[qt], seedr, accp[u % NACC]);
                     if (!(GT_EXP & 1) && qt == QT - 1 && sb + 1 < NSUB) GT_SEEDR(sb + 1);   // behind the last reader of this sub-tile's seeds
                 } else {
                     if (u + 1 < NU) GT_SEED(u + 1);
                     mma_chain<DP>(afr[(GT_EXP & 2) ? 0 : (sb & 1)], bq[qt], accp[u % 3]);
                 }
             }
-            if (u > 0) {
+            hit_now = false;
+            if (u > 0 && (!TWO || ((act >> (u - 1)) & 1u))) {
                 // one predicate per lane: the largest of its 16 scores against the query's threshold (a v_max3 tree
                 // and one compare in the MFMA issue gaps; the per-element compares are redone on the cold admission path)
                 const float tq = (GT_EXP & 8) ? INFINITY : thr[pqt];
@@ -966,6 +1060,7 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
                     GT_ADMIT(accp[(u - 1) % NACC], any_hit, mx, psb, pqt);
                 }
             }
+        }
         }
         if constexpr (TWO) {
             // two-stage scoring: the pairs that passed stage one go to the queue of the cold launch (sym_cold_kernel)

@@ -1342,6 +1342,83 @@ __global__ __launch_bounds__(256) void bound_queue_kernel(const int nq64, const 
 }
 
 
+// ---- unit skipping of the two-stage collect: balls of the groups of 32 sorted rows in the stage-one space -----------------
+// Stage one passes a pair (q, j) when its partial score beats q's threshold or (transposed) j's: in exact arithmetic on the
+// stored float16 rows, |z_q - z_j|^2 < 2 rho_p + (a few dmax) for p = q or p = j (sym_half_thresholds_kernel: gh[p] = -rho_p -
+// dmax, rounded down; dmax bounds the float32 accumulation and the roundings of the seeds).  So with need_p :=
+// sqrt(-2 gh[p] + 4 dmax) (rounded up; -inf for a row that asks for nothing, +inf for one that asks for everything), a pair
+// more than max(need_q, need_j) apart in the stage-one space cannot pass.  Per group of 32 consecutive sorted rows (the query
+// tiles and the sub-tiles of knn_select_kernel alike): the centre c of its real rows (float32 mean), R = the largest
+// distance of a row from the STORED centre (float64, rounded up) and need = the largest need of its rows.  Two groups whose
+// centres are farther apart than R_a + R_b + max(need_a, need_b) hold no pair that passes: the collect kernel skips the unit.
+// One wave per group: lane = (row l >> 1, eight columns l & 1).
+__global__ __launch_bounds__(256) void z_balls_kernel(const _Float16* __restrict__ Z, const float* __restrict__ gh, const int64_t n,
+                                                      const int64_t ngroups, const double dmargin, float* __restrict__ zc,
+                                                      float* __restrict__ zrn) {
+    typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+    const int lane = threadIdx.x & 63;
+    const int64_t g = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    if (g >= ngroups) return;
+    const int r = lane >> 1, hf = lane & 1;
+    const int64_t p = g * 32 + r;
+    const bool real = p < n;
+    float x[8];
+    {
+        half8 v = {};
+        if (real) v = *reinterpret_cast<const half8*>(Z + size_t(p) * kZ + 8 * hf);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = real ? float(v[e]) : 0.f;
+    }
+    float cnt = real ? 1.f : 0.f;
+    float c[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) c[e] = x[e];
+#pragma unroll
+    for (int o = 2; o < 64; o <<= 1) {   // over the rows (lanes of the same column half)
+        cnt += __shfl_xor(cnt, o);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) c[e] += __shfl_xor(c[e], o);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) c[e] = cnt > 0.f ? c[e] / cnt : 0.f;
+    if (r == 0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) zc[size_t(g) * 16 + 8 * hf + e] = c[e];
+    }
+    double d2 = 0.0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const double df = double(x[e]) - double(c[e]);
+        d2 = fma(df, df, d2);
+    }
+    d2 += __shfl_xor(d2, 1);
+    double rmax = real ? d2 : 0.0;
+    float need = -INFINITY;
+    if (real) {
+        const float gv = gh[p];
+        if (gv == INFINITY) need = -INFINITY;             // an orphan: collects nothing
+        else if (!(gv > -1.0e38f)) need = INFINITY;       // no threshold: everything passes
+        else {
+            const double n2 = -2.0 * double(gv) + dmargin;
+            const double nd = sqrt(n2 > 0.0 ? n2 : 0.0) * (1.0 + 1e-9);
+            need = float(nd);
+            if (double(need) <= nd) need = nextafterf(need, INFINITY);
+        }
+    }
+#pragma unroll
+    for (int o = 2; o < 64; o <<= 1) {
+        rmax = fmax(rmax, __shfl_xor(rmax, o));
+        need = fmaxf(need, __shfl_xor(need, o));
+    }
+    if (lane == 0) {
+        const double rr = sqrt(rmax) * (1.0 + 1e-9);
+        float rf = float(rr);
+        if (double(rf) <= rr) rf = nextafterf(rf, INFINITY);
+        zrn[size_t(g) * 2 + 0] = rf;
+        zrn[size_t(g) * 2 + 1] = need;
+    }
+}
+
 // ---- listed walks of the one-stage collect (knn_select_kernel<MODE 2>, SymDev::walk_list) --------------------------------
 // When the cell bounds leave too many (64 x 32) units for the queue of the cold launch, they may still rule out most TILES:
 // on points that lie near a low-dimensional sheet the cells around a row are a few per cent of all cells, yet a cell of 244
@@ -1723,6 +1800,15 @@ int gt_sym_bound_queue(gt_ctx* ctx, int64_t n_pad_s, const void* Ys, const float
     return GT_OK;
 }
 
+
+// balls of the groups of 32 sorted rows in the stage-one space (z_balls_kernel): zc [n_pad_s / 32][16], zrn [n_pad_s / 32][2]
+int gt_sym_z_balls(gt_ctx* ctx, int64_t n_pad_s, const void* Z, const float* gh, double dmargin, float* zc, float* zrn) {
+    const int64_t ng = n_pad_s / 32;
+    hipLaunchKernelGGL(z_balls_kernel, dim3((unsigned)ceil_div64(ng, 4)), dim3(256), 0, ctx->stream,
+                       reinterpret_cast<const _Float16*>(Z), gh, ctx->n, ng, dmargin, zc, zrn);
+    GT_HIP(ctx, hipGetLastError());
+    return GT_OK;
+}
 
 // Listed walks for the one-stage collect from the cell masks the bound pass left in `work` (gt_sym_bound_queue ran on this
 // point set and order): tile_list [NB][stride], tile_cnt [NB] for the NB = n_pad_s / 256 query blocks, *total_dev (pre-zeroed

@@ -136,6 +136,8 @@ int gt_stage_launches(const gt_ctx* ctx, const char* stage);
  *   select_sym_two_stage     "auto" | 0 | 1: the collect scores 16 leading directions first (partial distances).
  *   select_sym_pca           0 | 1: ... the 16 leading principal directions (1) or the first 16 features (0).
  *   select_sym_bounds        "auto" | 0 | 1: bound pass (cell balls) in front of the collect.
+ *   select_sym_two_skip      0 | 1: two-stage collect: a (32 queries x 32 rows) unit whose two groups' balls in the stage-one space
+ *                            are farther apart than either group asks for is not scored (1).
  *   select_sym_listed        "auto" | 0 | 1: when the bound pass leaves more units than its queue holds but its cell masks rule
  *                            out most tiles (auto: the listed tiles are at most a quarter of the walks), the one-stage collect
  *                            streams the listed tiles only - no stage-one copy, no cold launch.
