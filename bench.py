@@ -367,7 +367,12 @@ def kernel_table(ctx, st, n, nloc, d, world, nnz, nnz0, main):
                 nb = n_pad // 1024
                 walk = 8 * (1 + (nb - 1) // 2) + (0 if nb % 2 else 8)
                 flop = 2.0 * 16 * 1024 * 128 * nb * walk / world
-                mfma("knn_select", "knn_select_kernel<16, 8, 3, 2>", st.mean("knn_select"), flop, "stage one of the two-stage collect")
+                scored = kst.get("sym_stage_one_units", 0)
+                if scored > 0:   # (round 6: units whose balls in the stage-one space are too far apart issue no MFMA)
+                    flop = 2.0 * 16 * 32 * 32 * scored
+                mfma("knn_select", "knn_select_kernel<16, 8, 3, 2>", st.mean("knn_select"), flop,
+                     "stage one of the two-stage collect" + ("" if scored <= 0 else
+                      ": %d of %d (32 x 32) units scored, the others skipped by their balls" % (scored, int(nb * walk * 256 / world))))
             else:
                 n_pad = -(-n // 256) * 256
                 nb = n_pad // 256

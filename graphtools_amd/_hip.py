@@ -721,7 +721,8 @@ class Context:
         out["sym_bound_pass"] = bool(st[0]) and bool(st[4])
         if st[0]:
             out.update(sym_nseg=int(st[6]), sym_seed_tiles=int(st[9]), sym_cold_pairs=int(st[5]), sym_two_stage=bool(st[7] & 1), sym_seed_dense=bool(st[7] & 2), sym_cold_local=bool(st[7] & 4), tables_by_slot=bool(st[7] & 8), destinations_fused=bool(st[7] & 16), sym_listed=bool(st[7] & 32),
-                       sym_rows_over_256=int(st[8]),
+                       sym_rows_over_256=int(st[8]),   # (without dbg_select bit 256, after a two-stage collect: the units stage one scored)
+                       sym_stage_one_units=int(st[8]) if (st[7] & 1) and not st[4] else 0,
                        sym_rows_over_128=int(st[11]))   # list-length counters: only with dbg_select bit 256
         return out
 

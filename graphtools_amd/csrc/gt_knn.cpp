@@ -1045,7 +1045,7 @@ int gt_sym_queue_prepare(gt_ctx* ctx, int64_t n_pad_s, SelectArgs& a) {
     a.sym.qspill = k->sym_qspill.as<uint2>();
     a.sym.qspill_count = reinterpret_cast<uint32_t*>(k->sym_qspill.as<uint2>() + spill_cap);
     a.sym.qspill_cap = int32_t(spill_cap);
-    GT_HIP(ctx, hipMemsetAsync(a.sym.qspill_count, 0, sizeof(uint32_t), ctx->stream));
+    GT_HIP(ctx, hipMemsetAsync(a.sym.qspill_count, 0, 2 * sizeof(uint32_t), ctx->stream));   // (+ the count of scored units)
     return GT_OK;
 }
 
@@ -1068,8 +1068,11 @@ int gt_sym_queue_finish(gt_ctx* ctx, const SelectArgs& a, int64_t* entries, int*
     c.counts = k->sym_qtot.as<uint32_t>();
     GT_TRY(gt_launch_select(ctx, c));
     uint32_t tot[3] = {0, 0, 0};   // entries, fullest region, spill overflow
+    uint32_t scored = 0;
     GT_HIP(ctx, hipMemcpyAsync(tot, k->sym_qtot.p, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    GT_HIP(ctx, hipMemcpyAsync(&scored, a.sym.qspill_count + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    k->sym_units_scored = int64_t(scored);
     *entries = int64_t(tot[0]);
     if (ctx->dbg_select & 2048)
         fprintf(stderr, "[gt] two-stage queue: %u entries, fullest region %u, %lld regions of %d, dense capacity %lld\n", tot[0], tot[1],
@@ -1147,6 +1150,9 @@ extern "C" int gt_knn_stats(const gt_ctx* ctx, int64_t* out12) {
     out12[3] = k ? k->n_fallback_exhaustive : 0;
     for (int i = 0; i < 8; ++i) out12[4 + i] = (k && k->sym_used) ? int64_t(k->sym_stat_host[i]) : 0;
     if (k && k->sym_used) out12[6] = k->sym_nseg;   // work items per query block of launch B
+    // ((32 x 32) units stage one of the two-stage collect scored - the others were skipped by their balls - unless the list
+    //  statistics of dbg_select bit 256 are on, whose slot this is)
+    if (k && k->sym_used && k->sym_two_used && !k->sym_bound_used && !(ctx->dbg_select & 256)) out12[8] = k->sym_units_scored;
     if (k && k->sym_used) out12[5] = k->sym_two_used ? k->sym_cold_entries : 0;   // pairs the cold launch scored in full
     // (one-stage collect over listed walks: the (64 x 32) units its tiles hold - 16 per (256 x 128) tile)
     if (k && k->sym_used && k->sym_listed && !k->sym_two_used) out12[5] = k->sym_listed_tiles * 16;

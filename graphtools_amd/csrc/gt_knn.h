@@ -61,6 +61,7 @@ struct KnnWork {
     DevBuf sym_queue, sym_qcount, sym_qdense, sym_qtot;   //   and the queue of its deferred cold pass (wave regions,
                                                           //   their counts, the compacted queue, {total, overflow})
     int64_t sym_cold_entries = 0;
+    int64_t sym_units_scored = 0;                 //   (32 x 32) units stage one of the last two-stage collect scored (not skipped)
     int sym_frame = 0;                            //   frame of stage one: 0 coordinate axes, 1 principal directions
     bool sym_two_used = false;                    //   the last symmetric pass ran the two-stage collect
     bool sym_used = false;

@@ -614,6 +614,7 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
     }
     __syncthreads();
     const int aswz = C::GLDS ? swz_of_row(li, C::RDIV, C::SMASK) : 0;   // sub-tiles start at multiples of 32 rows
+    uint32_t n_scored = 0u;                                               // two-stage collect: units this wave scored (not skipped)
     uint32_t qfill = 0u;                                                  // two-stage collect: entries this wave has queued
     uint32_t pend_pm = 0u, pend_t = 0u;                                   //   pairs of the previous tile not yet written
 // The wave owns its region of the queue: the slots come from a register, the entries leave as stores nobody waits for.
@@ -722,6 +723,7 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
                 act = uint32_t(__ballot(!far_ && lane < (BN / 32) * QT));
                 if (GT_EXP & 512) act = 0xFFFFFFFFu;   // (development: the mask is formed, nothing is skipped)
             }
+            n_scored += uint32_t(__builtin_popcount(act));
         }
 
         // Software pipeline over the NU = (BN/32)*QT units (sub-tile, query tile) of this tile, fully unrolled:
@@ -1222,6 +1224,7 @@ __global__ __launch_bounds__(256, (PREC == 2 && NT == 8) ? GT_SEL_P2_WAVES : 2) 
 
     GT_QUEUE_FLUSH();
     if (TWO && lane == 0) sy.qcount[size_t(blockIdx.x) * 4 + w] = qfill;
+    if (TWO && lane == 0 && n_scored != 0u) atomicAdd(sy.qspill_count + 1, n_scored);   // (statistics: units scored by stage one)
     // ---- finalisation: gather every list into slots [0, count), publish count and the last admission threshold ----
     if (MODE == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
