@@ -47,7 +47,7 @@ MFMA_PEAK_TFLOPS = {"f16x1": 2500.0,  # v_mfma_f32_32x32x16_f16, one chain per p
                     "f32": 157.3}     # v_mfma_f32_32x32x2_f32
 MFMA_CHAINS = {"f16x1": 1.0, "f16": 3.0, "f32": 1.0}
 HBM_PEAK_GBS = 8000.0
-PROFILE_TRAFFIC = os.path.join(ROOT, "profiles", "r5_pmc_fetch_write_per_kernel.json")
+PROFILE_TRAFFIC = os.path.join(ROOT, "profiles", "r6_pmc_fetch_write_per_kernel.json")
 PROFILE_CPU_FULL = os.path.join(ROOT, "profiles", "r3_cpu_baseline_full_c3.json")
 
 STAGES = ("prep", "query_order", "sym_prepare", "sym_seed", "sym_bound", "knn_select", "sym_cold", "rerank", "fallback",
