@@ -169,6 +169,9 @@ __global__ __launch_bounds__(256) void dense_bandwidth_kernel(const T* __restric
 // The selections run on the values' own bit patterns (32 search steps for float32) over a few values per thread - the
 // first version searched 8192 LDS entries with 64-bit patterns and two barriers per step: 2.7 TB/s instead of 6.
 // Rows with mass ties at the bound (list overflow) are flagged for the generic kernel.
+#ifndef GT_DENSE_PREFETCH
+#define GT_DENSE_PREFETCH 0
+#endif
 #ifndef GT_DENSE_EMIT_WAVES
 #define GT_DENSE_EMIT_WAVES 6   // waves per SIMD the listing variant of the one-pass bandwidth kernel is cut for (80 VGPRs; 128 uncut)
 #endif
@@ -240,19 +243,32 @@ __global__ __launch_bounds__(256, EMIT ? GT_DENSE_EMIT_WAVES : 1) void dense_ban
     for (int u = 0; u < PT; ++u) x0[u] = T(INFINITY);
     bool bad = false;
     const int64_t steps = vec ? (nv + 256 * 4 - 1) / (256 * 4) : (n + CHUNK - 1) / CHUNK;
+    // (GT_DENSE_PREFETCH: the loads of step st + 1 are issued before step st is looked at - a second set of 16 registers; the
+    //  workgroup's 16 KB per step then overlap its own list work instead of leaving that to the other workgroups of the CU)
+    auto load_step = [&](const int64_t st_, vecT* v_) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t j = st_ * (256 * 4) + u * 256 + tid;
+            if (j < nv) {
+                v_[u] = rv[j];
+            } else {
+#pragma unroll
+                for (int e = 0; e < VW; ++e) v_[u][e] = T(INFINITY);
+            }
+        }
+    };
+    vecT vpre[4];
+    if (GT_DENSE_PREFETCH && vec) load_step(0, vpre);
     for (int64_t st = 0; st < steps; ++st) {
         T x[PT];
         if (vec) {
             vecT v[4];
+            if (GT_DENSE_PREFETCH) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int64_t j = st * (256 * 4) + u * 256 + tid;
-                if (j < nv) {
-                    v[u] = rv[j];
-                } else {
-#pragma unroll
-                    for (int e = 0; e < VW; ++e) v[u][e] = T(INFINITY);
-                }
+                for (int u = 0; u < 4; ++u) v[u] = vpre[u];
+                if (st + 1 < steps) load_step(st + 1, vpre);
+            } else {
+                load_step(st, v);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u)
