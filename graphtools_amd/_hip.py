@@ -85,6 +85,9 @@ _SIGNATURES = {
     "gt_graph_stage_counts": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int32, _c.c_int32, _c.c_void_p, _c.c_void_p,
                                          _c.POINTER(_c.c_int32)]),
     "gt_graph_set_stage_totals": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int32]),
+    "gt_graph_bandwidth_local": (_c.c_int, [_c.c_void_p, _c.POINTER(KnnParams), _c.c_int32, _c.c_int32, _c.c_void_p, _c.c_void_p,
+                                            _c.POINTER(_c.c_int32)]),
+    "gt_graph_set_bandwidths": (_c.c_int, [_c.c_void_p, _c.c_void_p]),
     "gt_graph_build": (_c.c_int, [_c.c_void_p, _c.POINTER(KnnParams), _c.POINTER(_c.c_int64), _c.POINTER(_c.c_uint32)]),
     "gt_graph_extend": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int64, _c.c_int32, _c.POINTER(KnnParams),
                                    _c.POINTER(_c.c_int64), _c.POINTER(_c.c_uint32)]),
@@ -563,6 +566,21 @@ class Context:
         self._check(self.lib.gt_graph_shard_local(self.h, ctypes.byref(params), int(world), int(rank), _ptr(splits),
                                                   ctypes.byref(applies)), "gt_graph_shard_local")
         return bool(applies.value)
+
+    def graph_bandwidth_local(self, params, world, rank, row_splits, bw_local_ptr):
+        """Row-sharded pair-resolved tail: the first half of graph_begin for the rank's rows, its bandwidths (float64, device,
+        on the library's stream) into ``bw_local_ptr``.  False: not this tail's parameters - nothing was done, the same answer
+        on every rank; ``graph_begin`` runs the whole build."""
+        splits = np.ascontiguousarray(row_splits, dtype=np.int64)
+        applies = ctypes.c_int32(0)
+        self._check(self.lib.gt_graph_bandwidth_local(self.h, ctypes.byref(params), int(world), int(rank), _ptr(splits),
+                                                      ctypes.c_void_p(int(bw_local_ptr)) if bw_local_ptr else None,
+                                                      ctypes.byref(applies)), "gt_graph_bandwidth_local")
+        return bool(applies.value)
+
+    def graph_set_bandwidths(self, bw_all_ptr):
+        """... the bandwidths of all rows (float64 [n], device, rank slices in rank order; alive until graph_begin returned)"""
+        self._check(self.lib.gt_graph_set_bandwidths(self.h, ctypes.c_void_p(int(bw_all_ptr))), "gt_graph_set_bandwidths")
 
     def graph_emit(self, send_ptr):
         self._check(self.lib.gt_graph_emit(self.h, ctypes.c_void_p(int(send_ptr)) if send_ptr else None), "gt_graph_emit")

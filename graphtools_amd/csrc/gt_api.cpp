@@ -272,6 +272,10 @@ int gt_set_option(gt_ctx* ctx, const char* name, const char* value) {
         ctx->narrow_mode = v == "auto" ? -1 : std::atoi(value);
         return GT_OK;
     }
+    if (k == "symmetrize_pairs_shard") {
+        ctx->symm_pairs_shard = std::atoi(value) != 0 ? 1 : 0;
+        return GT_OK;
+    }
     if (k == "symmetrize_pairs_huge") {
         ctx->symm_pair_huge = std::atoi(value) != 0 ? 1 : 0;
         return GT_OK;

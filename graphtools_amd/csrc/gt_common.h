@@ -218,6 +218,7 @@ struct gt_ctx {
     int32_t in_graph_build = 0; //   (set by gt_graph_build around its gt_graph_begin: every row is here, the tail is its own)
     int32_t symm_pairs = 2;     //   pair-resolved symmetrisation (gt_sparse.hip): every row settles its mutual pairs itself, only one-sided entries travel
                                 //   (2: and the re-rank lays the tables out by sorted position for it - KnnWork::tab_sorted; 1: tables by row)
+    int32_t symm_pairs_shard = 1;  //   ... also on the ranks of a row-sharded build, given the bandwidths of all rows (gt_graph_bandwidth_local / gt_graph_set_bandwidths)
     int32_t symm_pair_huge = 1; //   ... union rows beyond the register sorts are finished by a segmented sort (0: they refute the path: the general tail)
     int32_t keep_stages = 0;    //   (gt_graph_build's second attempt after a refutation: the stage timers are not reset)
     int32_t symm_pair_ok = 1;   //   ... not refuted for the bound point set (a union row beyond the register sorts)

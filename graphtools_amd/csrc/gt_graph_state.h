@@ -66,6 +66,13 @@ struct GraphState {
                                //     row of the radius pass): posj (cursor) lies by sC, bincnt is filled - bin_count_kernel is skipped
     int32_t bin_shift = 9, bin_count = 0;   // rows per destination bin (log2), bins
     int64_t sc_total = 0;                   // entries of posj when it lies by sC
+    // row-sharded pair-resolved tail (gt_graph_bandwidth_local -> gt_graph_set_bandwidths -> gt_graph_begin -> ... -> gt_graph_finish)
+    bool half_begun = false;     // gt_graph_bandwidth_local ran the first half of gt_graph_begin for half_params / world / rank / splits
+    gt_knn_params half_params{};
+    DevBuf bw_all;               // float64 [n_total]: the bandwidths of all rows, gathered by the caller
+    bool bw_all_valid = false;   // ... handed over for the build that is half begun
+    bool pairs_shard = false;    // this rank settles its mutual pairs with bw_all; only one-sided entries travel (graph_finish_pairs_shard)
+    DevBuf ident;                // int32 [nloc]: 0 ... nloc - 1 (a shard's rows are their own positions: FusedSrc::pos)
     bool relabelled = false;   // the CSR's columns are the caller's row numbers of a renumbered point set (rows: gt_points_row_ids)
     int64_t nnz0 = 0, nnz = 0;
 };

@@ -254,11 +254,29 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
                     sr.xs_d = k->xs_d;
                 }
             }
+            bool wrote_t = false;
+            if (k->want_keyt_shard && ctx->symm_pairs != 0 && MP == 256) {
+                // the pair-resolved tail on a rank of a sharded build (gt_graph_bandwidth_local): the keys of the transposed pairs
+                // next to the tables, as in the single-rank pass below (the tables stay by row)
+                GT_HIP(ctx, k->cand_d2t.reserve(size_t(nq) * MP * sizeof(double)));
+                GT_HIP(ctx, k->keyt_ok.reserve(size_t(nq)));
+                GT_HIP(ctx, k->nokeyt_rows.reserve(size_t(nq) * sizeof(int32_t)));
+                GT_HIP(ctx, k->nokeyt_count.reserve(sizeof(uint32_t)));
+                GT_HIP(ctx, hipMemsetAsync(k->nokeyt_count.p, 0, sizeof(uint32_t), ctx->stream));
+                sr.cand_d2t = k->cand_d2t.as<double>();
+                sr.keyt_ok = k->keyt_ok.as<uint8_t>();
+                sr.nokeyt_rows = k->nokeyt_rows.as<int32_t>();
+                sr.nokeyt_count = k->nokeyt_count.as<uint32_t>();
+                sr.wrote_t = &wrote_t;
+            }
             {
                 StageSpan span(ctx, "rerank");
                 GT_TRY(gt_launch_rerank_sym(ctx, ra, sr));
             }
+            k->keyt_valid = wrote_t;
+            k->nokeyt_n = 0;
             uint32_t n_unproven = 0;
+            if (wrote_t) GT_HIP(ctx, hipMemcpyAsync(&k->nokeyt_n, k->nokeyt_count.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
             GT_HIP(ctx, hipMemcpyAsync(&n_fb, k->fb_count.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
             GT_HIP(ctx, hipMemcpyAsync(&n_unproven, k->unproven.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
             GT_HIP(ctx, hipMemcpyAsync(k->sym_stat_host, k->sym_stat.p, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
@@ -278,6 +296,8 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
                 if (too_many) ctx->sym_ok = 0;
                 if (unproved) ctx->fast_ok = 0, main_prec = 1;
                 k->sym_used = false;
+                k->keyt_valid = false;
+                k->nokeyt_n = 0;
                 n_fb = 0;
                 GT_HIP(ctx, hipMemsetAsync(k->fb_count.p, 0, sizeof(uint32_t), ctx->stream));
                 GT_HIP(ctx, hipMemsetAsync(k->gflags.p, 0, sizeof(uint32_t), ctx->stream));

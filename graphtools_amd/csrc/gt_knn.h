@@ -54,6 +54,7 @@ struct KnnWork {
     // comes by row where it is.  The affinity pass, the destination bins and the final merge walk the rows in sorted order anyway:
     // their table reads become streams, and the partners' bandwidths they gather are a shared, cache-resident set.
     bool want_tab_sorted = false, tab_sorted = false;
+    bool want_keyt_shard = false;   // the re-rank of a sharded rank's lists (sh_stage 5 / 6) writes the transposed keys too (gt_graph_bandwidth_local)
     DevBuf sym_rloc, sym_gcen;                    //   local-frame cold launch: the radius every row needs listed (scaled), the centres of
                                                   //   the 64-row query groups
     bool sym_cold_local_used = false;

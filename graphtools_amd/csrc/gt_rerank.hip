@@ -708,7 +708,9 @@ __global__ __launch_bounds__(64 * WPB, GT_RERANK_WAVES) void rerank_sym4_kernel(
         d2_lb[tq] = lb;
         if (keyt_ok) {   // (a row handed to the repair pass gets a new table, without them: it is listed for the affinity pass)
             keyt_ok[tq] = (d2_need < lb_cand) ? 1 : 0;
-            if (!(d2_need < lb_cand)) nokeyt_rows[atomicAdd(nokeyt_count, 1u)] = int32_t(q);
+            // (listed as rows of the query matrix - own_r0 + q, like the rows of the radius pass: the affinity launch over the list
+            //  subtracts the offset of its rows)
+            if (!(d2_need < lb_cand)) nokeyt_rows[atomicAdd(nokeyt_count, 1u)] = int32_t(qo);
         }
         if (!(d2_need < lb_cand)) {
             const uint32_t slot = atomicAdd(fb_count, 1u);

@@ -204,7 +204,10 @@ __global__ __launch_bounds__(256) void affinity_kernel(
     int32_t* __restrict__ lenN, int32_t* __restrict__ ownercnt, int32_t* __restrict__ tablen,
     const int pairs, const double* __restrict__ cand_d2t, const uint8_t* __restrict__ keyt_ok, const double rf_guard,
     const int32_t* __restrict__ tperm, const int32_t* __restrict__ trow, uint32_t* __restrict__ posj,
-    const int64_t* __restrict__ sC, int32_t* __restrict__ lenN_s) {
+    const int64_t* __restrict__ sC, int32_t* __restrict__ lenN_s, const int64_t bw_i0) {
+    // bw_i0: where this launch's row 0 sits in bw (0: bw holds the launch's rows - one rank; r0: bw holds the bandwidths of ALL
+    // rows, gathered over the ranks - the pair-resolved tail of a row-sharded build, `pairs` = 2: partners j are global rows, and
+    // only the entries that TRAVEL - the one-sided ones, stored non-negative - are counted per owner)
     // posj / sC (with trow, table rows): the destinations of the pair-resolved tail are looked up here (see
     // affinity_slots_kernel: this launch serves the few rows whose tables came from a repair pass)
     // tperm / trow (KnnWork::tab_sorted): the tables lie by sorted position - tperm: slot -> row, for the launch over all the
@@ -227,7 +230,7 @@ __global__ __launch_bounds__(256) void affinity_kernel(
     const int32_t src = rowsrc[i];
     if (RADIUS != (src >= 0)) return;   // (the other launch's row)
     if (!RADIUS && PAIRS != 0 && (PAIRS == 1) != (keyt_ok[ti] != 0)) return;   // (the other pair-resolving launch's row)
-    const double bwi = bw[i];
+    const double bwi = bw[bw_i0 + i];
     int kept = 0;
     int owner_cnt = 0;   // lane o accumulates the count for owner o (world <= 64)
     if constexpr (!RADIUS) {
@@ -287,7 +290,7 @@ __global__ __launch_bounds__(256) void affinity_kernel(
             }
             kept += __popcll(km);
             if (count_owners) {
-                const int o = keep ? owner_of(sp, j) : -1;
+                const int o = (keep && (pairs != 2 || kvv >= 0.0)) ? owner_of(sp, j) : -1;
                 for (int r = 0; r < sp.world; ++r) {
                     const int c = __popcll(__ballot(o == r));
                     if (lane == r) owner_cnt += c;
@@ -373,7 +376,7 @@ __global__ __launch_bounds__(256) void affinity_kernel(
             }
             kept += __popcll(km);
             if (count_owners) {
-                const int o = keep ? owner_of(sp, j) : -1;
+                const int o = (keep && (pairs != 2 || kvv >= 0.0)) ? owner_of(sp, j) : -1;
                 for (int r = 0; r < sp.world; ++r) {
                     const int c = __popcll(__ballot(o == r));
                     if (lane == r) owner_cnt += c;
@@ -1578,6 +1581,11 @@ struct FusedSrc {
     const uint32_t* ucol;     // received entries, packed row by row in sorted order: columns ...
     const double* uval;       // ... and values
     int tab_sorted;           // the tables lie by sorted position (KnnWork::tab_sorted), else by row
+    // a rank of a row-sharded build on renumbered points (graph_finish_pairs_shard): the tables hold the context's row numbers,
+    // the CSR gets the caller's - cmap: context row -> caller's row (nullptr: the same), row0: context row of local row 0
+    const int32_t* cmap;
+    int64_t row0;
+    __device__ __forceinline__ int64_t caller_row(const int64_t i) const { return cmap ? int64_t(cmap[row0 + i]) : i; }
 };
 struct RowSrc3 {
     int ln;
@@ -1586,14 +1594,18 @@ struct RowSrc3 {
     const uint64_t* rl;
     const uint32_t* uc;
     const double* uv;
+    const int32_t* cmap;   // (FusedSrc::cmap; the received entries carry the caller's columns already)
     __device__ __forceinline__ uint32_t key(const int p) const {
-        return p < ln ? ((cj ? cj[p] : cand_index(rl[p])) << 1) : ((uc[p - ln] << 1) | 1u);
+        if (p >= ln) return (uc[p - ln] << 1) | 1u;
+        const uint32_t c = cj ? cj[p] : cand_index(rl[p]);
+        return (cmap ? uint32_t(cmap[c]) : c) << 1;
     }
     __device__ __forceinline__ double val(const int p) const { return p < ln ? kv[p] : uv[p - ln]; }
 };
 __device__ __forceinline__ RowSrc3 make_row_src3(const FusedSrc& fs, const int64_t i, const int64_t p, int& lt) {
     RowSrc3 r;
     r.ln = fs.lenN[i];
+    r.cmap = fs.cmap;
     const int64_t o0 = fs.off[p];
     lt = int(fs.off[p + 1] - o0) - r.ln;
     const int32_t src = fs.rowsrc[i];
@@ -1729,16 +1741,17 @@ __global__ __launch_bounds__(256) void merge_final_kernel(const int64_t nloc, co
     const int64_t dst = indptr[i];
     bool any_diag = false;
     double sum;
+    const int64_t ic = fs.caller_row(i);   // (the diagonal is where the column is the row's own number - the caller's)
     if (key32) {   // (uniform over the launch)
-        if (L <= 64) sum = sort_merge_final_row<uint32_t, 1>(U, L, lane, i, indices, Kdata, Pdata, dst, any_diag);
-        else if (L <= 128) sum = sort_merge_final_row<uint32_t, 2>(U, L, lane, i, indices, Kdata, Pdata, dst, any_diag);
-        else if (L <= 256) sum = sort_merge_final_row<uint32_t, 4>(U, L, lane, i, indices, Kdata, Pdata, dst, any_diag);
-        else sum = sort_merge_final_row<uint32_t, 8>(U, L, lane, i, indices, Kdata, Pdata, dst, any_diag);
+        if (L <= 64) sum = sort_merge_final_row<uint32_t, 1>(U, L, lane, ic, indices, Kdata, Pdata, dst, any_diag);
+        else if (L <= 128) sum = sort_merge_final_row<uint32_t, 2>(U, L, lane, ic, indices, Kdata, Pdata, dst, any_diag);
+        else if (L <= 256) sum = sort_merge_final_row<uint32_t, 4>(U, L, lane, ic, indices, Kdata, Pdata, dst, any_diag);
+        else sum = sort_merge_final_row<uint32_t, 8>(U, L, lane, ic, indices, Kdata, Pdata, dst, any_diag);
     } else {
-        if (L <= 64) sum = sort_merge_final_row<uint64_t, 1>(U, L, lane, i, indices, Kdata, Pdata, dst, any_diag);
-        else if (L <= 128) sum = sort_merge_final_row<uint64_t, 2>(U, L, lane, i, indices, Kdata, Pdata, dst, any_diag);
-        else if (L <= 256) sum = sort_merge_final_row<uint64_t, 4>(U, L, lane, i, indices, Kdata, Pdata, dst, any_diag);
-        else sum = sort_merge_final_row<uint64_t, 8>(U, L, lane, i, indices, Kdata, Pdata, dst, any_diag);
+        if (L <= 64) sum = sort_merge_final_row<uint64_t, 1>(U, L, lane, ic, indices, Kdata, Pdata, dst, any_diag);
+        else if (L <= 128) sum = sort_merge_final_row<uint64_t, 2>(U, L, lane, ic, indices, Kdata, Pdata, dst, any_diag);
+        else if (L <= 256) sum = sort_merge_final_row<uint64_t, 4>(U, L, lane, ic, indices, Kdata, Pdata, dst, any_diag);
+        else sum = sort_merge_final_row<uint64_t, 8>(U, L, lane, ic, indices, Kdata, Pdata, dst, any_diag);
     }
     if (lane == 0) {
         degree[i] = sum;
@@ -1791,7 +1804,8 @@ __global__ __launch_bounds__(256) void merge_pairs_slots_kernel(const int64_t nl
         val = 0.0;
         if (q < h.L) {
             if (q < h.ln) {
-                key = fs.cand_j[size_t(p) * fs.MP + q] << 1;
+                const uint32_t c = fs.cand_j[size_t(p) * fs.MP + q];
+                key = (fs.cmap ? uint32_t(fs.cmap[c]) : c) << 1;
                 val = fs.cand_k[size_t(p) * fs.MP + q];
             } else {
                 const int64_t r = (h.o0 - h.sn) + (q - h.ln);
@@ -1824,6 +1838,7 @@ __global__ __launch_bounds__(256) void merge_pairs_slots_kernel(const int64_t nl
         load_dat(p + 2, h2, x2);
         const int L = h0.L;
         const int64_t row = h0.i, dst = h0.dst;
+        const int64_t rowc = fs.caller_row(row);
         if (L <= 128) {
             K pk[2];
             pk[0] = (lane < L) ? K(~((K(x0.ka) << 7) | K(lane))) : K(0);
@@ -1858,7 +1873,7 @@ __global__ __launch_bounds__(256) void merge_pairs_slots_kernel(const int64_t nl
                     const int e = t * 64 + lane;
                     indices[dst + e] = int32_t(col);
                     Kdata[dst + e] = m[t];
-                    has_diag |= int64_t(col) == row && m[t] != 0.0;
+                    has_diag |= int64_t(col) == rowc && m[t] != 0.0;
                     lsum += m[t];
                 }
             }
@@ -1912,7 +1927,7 @@ __global__ __launch_bounds__(64) void merge_long_final_kernel(const FusedSrc fs,
         const int L = U.ln + lt;
         const int64_t dst = indptr[i];
         bool any_diag = false;
-        const double sum = sort_merge_final_row<uint64_t, NT>(U, L, lane, i, indices, Kdata, Pdata, dst, any_diag);
+        const double sum = sort_merge_final_row<uint64_t, NT>(U, L, lane, fs.caller_row(i), indices, Kdata, Pdata, dst, any_diag);
         if (lane == 0) {
             degree[i] = sum;
             if (!any_diag) atomicOr(flags, GT_FLAG_ZERO_DIAGONAL);
@@ -1962,11 +1977,13 @@ __global__ __launch_bounds__(64) void huge_finalize_kernel(const int32_t* __rest
                                                            const uint32_t* __restrict__ keys, const double* __restrict__ vals,
                                                            const int64_t* __restrict__ indptr, int32_t* __restrict__ indices,
                                                            double* __restrict__ Kdata, double* __restrict__ Pdata,
-                                                           double* __restrict__ degree, uint32_t* __restrict__ flags) {
+                                                           double* __restrict__ degree, uint32_t* __restrict__ flags,
+                                                           const int32_t* __restrict__ cmap, const int64_t row0) {
     const int lane = threadIdx.x;
     const uint32_t b = blockIdx.x;
     if (b >= nhuge) return;
     const int64_t i = hugelist[-int64_t(b)];
+    const int64_t ic = cmap ? int64_t(cmap[row0 + i]) : i;   // (FusedSrc::caller_row)
     const uint32_t s0 = seg_begin[b];
     const int L = int(seg_end[b] - s0);
     const int64_t dst = indptr[i];
@@ -1977,7 +1994,7 @@ __global__ __launch_bounds__(64) void huge_finalize_kernel(const int32_t* __rest
         const double m = vals[s0 + e];
         indices[dst + e] = int32_t(col);
         Kdata[dst + e] = m;
-        has_diag |= int64_t(col) == i && m != 0.0;
+        has_diag |= int64_t(col) == ic && m != 0.0;
         lsum += m;
     }
     const double sum = wave_sum_f64(lsum);
@@ -2113,11 +2130,15 @@ void launch_affinity(gt_ctx* ctx, GraphState* g, KnnWork* k, int binary, double 
                        (const T*)g->Qmat, g->qnorm, g->qoff, gt_dist_dtype(ctx), ctx->metric, k->MP, g->limit,            \
                        k->cand_d2.as<double>(), k->cand_j.as<uint32_t>(), k->cand_n.as<uint32_t>(), g->rowsrc.as<int32_t>(), \
                        g->rlists.as<uint64_t>(), g->rcounts.as<uint32_t>(), g->rcap, g->rK.as<double>(),                   \
-                       g->bw.as<double>(), decay, binary, thresh, count_owners, make_splits(g), g->lenN.as<int32_t>(),      \
-                       g->ownercnt.as<int32_t>(), g->tablen.as<int32_t>(), g->pairs ? 1 : 0,                               \
+                       bwp, decay, binary, thresh, count_owners, make_splits(g), g->lenN.as<int32_t>(),                      \
+                       g->ownercnt.as<int32_t>(), g->tablen.as<int32_t>(), g->pairs ? (g->pairs_shard ? 2 : 1) : 0,            \
                        g->pairs ? k->cand_d2t.as<double>() : (const double*)nullptr,                                       \
                        g->pairs ? k->keyt_ok.as<uint8_t>() : (const uint8_t*)nullptr, g->radius_factor * (1.0 + 1e-9),      \
-                       tperm, trow, POSJ_, g->sC.as<int64_t>(), k->tab_sorted ? g->cnt_sorted.as<int32_t>() : (int32_t*)nullptr)
+                       tperm, trow, POSJ_, g->sC.as<int64_t>(), k->tab_sorted ? g->cnt_sorted.as<int32_t>() : (int32_t*)nullptr, \
+                       bw_i0)
+    // (row-sharded pair-resolved build: the bandwidths of ALL rows, this rank's from row r0 on - gt_graph_set_bandwidths)
+    const double* bwp = g->pairs_shard ? g->bw_all.as<double>() : g->bw.as<double>();
+    const int64_t bw_i0 = g->pairs_shard ? g->r0 : 0;
     const int32_t* tperm = k->tab_sorted ? k->qorder.as<int32_t>() : (const int32_t*)nullptr;
     const int32_t* trow = k->tab_sorted ? k->sh_invperm.as<int32_t>() : (const int32_t*)nullptr;
     if (g->pairs && k->tab_sorted) {
@@ -2136,9 +2157,14 @@ void launch_affinity(gt_ctx* ctx, GraphState* g, KnnWork* k, int binary, double 
         if (fz)
             hipLaunchKernelGGL(posj_hist_kernel, dim3(2048), dim3(256), size_t(g->bin_count) * sizeof(int32_t), ctx->stream,
                                g->cursor.as<uint32_t>(), g->sc_total, g->bin_shift, g->bin_count, g->bincnt.as<int32_t>());
+    } else if (g->pairs && g->pairs_shard && !k->keyt_valid) {
+        // (a rank whose rows went through the classic pass: no table carries transposed keys - every kept entry's comes from its
+        //  dot product; keyt_ok is all zeros, graph_begin_b)
+        GT_AFFINITY_LAUNCH(false, 2, (const int32_t*)nullptr, g->nloc, (uint32_t*)nullptr);
     } else if (g->pairs) {
         GT_AFFINITY_LAUNCH(false, 1, (const int32_t*)nullptr, g->nloc, (uint32_t*)nullptr);
-        if (k->nokeyt_n > 0) GT_AFFINITY_LAUNCH(false, 2, k->nokeyt_rows.as<int32_t>(), int64_t(k->nokeyt_n), (uint32_t*)nullptr);   // (qoff = 0 here)
+        // (the list holds rows of the query matrix, qoff + i: qoff = 0 on one rank, r0 on a rank of a sharded build)
+        if (k->nokeyt_n > 0) GT_AFFINITY_LAUNCH(false, 2, k->nokeyt_rows.as<int32_t>(), int64_t(k->nokeyt_n), (uint32_t*)nullptr);
     } else {
         GT_AFFINITY_LAUNCH(false, 0, (const int32_t*)nullptr, g->nloc, (uint32_t*)nullptr);
     }
@@ -2260,8 +2286,20 @@ __global__ __launch_bounds__(256) void gather_f64_kernel(const double* __restric
     if (i < n) out[i] = in[idx[i]];
 }
 
-static int graph_begin_impl(gt_ctx* ctx, const gt_knn_params* params, int32_t world, int32_t rank,
-                            const int64_t* row_splits, int64_t* send_counts, bool external, int64_t m_ext) {
+// gt_graph_begin in two halves.  graph_begin_a: the candidate tables of the owned rows and their bandwidths (+ the replay of the
+// reference's knn_max loop); graph_begin_b: radius pass, affinities, the counts of what travels.  One call runs both; a rank of a
+// row-sharded build may stop between them (gt_graph_bandwidth_local) so that the caller can gather the bandwidths of ALL rows -
+// what the pair-resolved tail needs to know of a partner - and hand them back (gt_graph_set_bandwidths) before the second half.
+// *done (graph_begin_a): the call has ended (gt_graph_stage_counts wanted the counts only).
+static bool shard_pairs_static(const gt_ctx* ctx, const gt_knn_params* params, int64_t nloc) {
+    // what every rank of a build decides alike: the '+' rule over a decaying kernel, nothing the tail does not serve
+    const bool binary = std::isnan(params->decay) || params->thresh == 1.0;
+    return ctx->symm_pairs != 0 && ctx->symm_pairs_shard != 0 && !binary && params->knn_max <= 0 &&
+           params->kernel_symm == GT_SYMM_ADD && params->anisotropy == 0.0 && ctx->n < (int64_t(1) << 31) && nloc < (int64_t(1) << 31);
+}
+static int graph_begin_a(gt_ctx* ctx, const gt_knn_params* params, int32_t world, int32_t rank,
+                         const int64_t* row_splits, int64_t* send_counts, bool external, int64_t m_ext, bool want_keyt, bool* done) {
+    *done = false;
     if (!ctx || !params) return GT_E_ARG;
     GT_HIP(ctx, hipSetDevice(ctx->device));
     if (ctx->n <= 0) GT_FAIL(ctx, GT_E_STATE, "gt_graph_begin: no points bound");
@@ -2353,8 +2391,11 @@ static int graph_begin_impl(gt_ctx* ctx, const gt_knn_params* params, int32_t wo
                                     params->kernel_symm == GT_SYMM_ADD && params->anisotropy == 0.0 && g->r0 == 0 &&
                                     g->nloc == ctx->n && !ctx->presorted && g->nloc < (int64_t(1) << 31) &&
                                     (ctx->symm_bins > 0 || g->nloc >= 65536);
+        // (a rank of a row-sharded build that will take the pair-resolved tail: its re-rank writes the transposed keys too)
+        ctx->knn->want_keyt_shard = want_keyt;
         const int rc_knn = gt_knn_candidates(ctx, g->r0, g->nloc, external, need, hint);
         ctx->knn->want_tab_sorted = false;
+        ctx->knn->want_keyt_shard = false;
         if (rc_knn != GT_OK) return rc_knn;
     }
     KnnWork* k = ctx->knn;
@@ -2437,6 +2478,7 @@ static int graph_begin_impl(gt_ctx* ctx, const gt_knn_params* params, int32_t wo
             ctx->stage_n = n_avail;
             for (int t = 0; t < 4; ++t) ctx->stage_local[t] = t < n_avail ? int64_t(un[t]) : 0;
             for (int r = 0; r < world; ++r) send_counts[r] = 0;
+            *done = true;
             return GT_OK;
         }
         if (world > 1) {
@@ -2480,6 +2522,14 @@ static int graph_begin_impl(gt_ctx* ctx, const gt_knn_params* params, int32_t wo
             g->limit = need;
         }
     }
+    return GT_OK;
+}
+
+static int graph_begin_b(gt_ctx* ctx, const gt_knn_params* params, int32_t world, int64_t* send_counts, bool external) {
+    GraphState* g = ctx->graph;
+    KnnWork* k = ctx->knn;
+    const bool binary = std::isnan(params->decay) || params->thresh == 1.0;
+    const double thresh = g->p.thresh;   // (clamped by the first half)
     uint32_t n_over = 0;
     int64_t sc_total = 0;
     if (k->tab_sorted) {
@@ -2563,7 +2613,21 @@ static int graph_begin_impl(gt_ctx* ctx, const gt_knn_params* params, int32_t wo
                g->nloc < (int64_t(1) << 31) && (ctx->symm_bins > 0 || g->nloc >= 65536);
     if (k->tab_sorted && !g->pairs) GT_FAIL(ctx, GT_E_STATE, "graph build: tables by sorted position without the pair-resolved tail");
     g->pairs_fused = false;
-    if (g->pairs) {
+    // ... or a rank of a row-sharded build that was handed the bandwidths of all rows (gt_graph_set_bandwidths): it settles its
+    // mutual pairs itself - whichever rank the partner lives on - and only the one-sided entries travel (graph_finish_pairs_shard).
+    // Every rank takes this branch or none: the conditions are the call's parameters, and a rank whose tables carry no
+    // transposed keys (classic pass, repaired rows) forms them from the dot products.
+    g->pairs_shard = g->bw_all_valid && !external && shard_pairs_static(ctx, params, g->nloc);
+    g->bw_all_valid = false;   // (the bandwidths belong to one build)
+    if (g->pairs_shard) {
+        g->pairs = true;
+        if (!k->keyt_valid) {
+            GT_HIP(ctx, k->keyt_ok.reserve(size_t(g->nloc)));
+            GT_HIP(ctx, hipMemsetAsync(k->keyt_ok.p, 0, size_t(g->nloc), ctx->stream));
+            k->nokeyt_n = 0;
+        }
+    }
+    if (g->pairs && !g->pairs_shard) {
         // the destination bins of the tail (graph_finish_pairs): rows per bin, bins; their counters start at zero
         int shift = 9;
         if (ctx->symm_bin_shift > 0) shift = ctx->symm_bin_shift;
@@ -2637,9 +2701,41 @@ static int graph_begin_impl(gt_ctx* ctx, const gt_knn_params* params, int32_t wo
     return GT_OK;
 }
 
+static int graph_begin_impl(gt_ctx* ctx, const gt_knn_params* params, int32_t world, int32_t rank,
+                            const int64_t* row_splits, int64_t* send_counts, bool external, int64_t m_ext) {
+    bool done = false;
+    if (ctx && ctx->graph) ctx->graph->half_begun = false, ctx->graph->bw_all_valid = false;   // (a build from its start)
+    GT_TRY(graph_begin_a(ctx, params, world, rank, row_splits, send_counts, external, m_ext, false, &done));
+    if (done) return GT_OK;
+    return graph_begin_b(ctx, params, world, send_counts, external);
+}
+
+static bool same_build(const GraphState* g, const gt_knn_params* p, int32_t world, int32_t rank, const int64_t* row_splits) {
+    if (g->world != world || g->rank != rank) return false;
+    for (int r = 0; r <= world; ++r)
+        if (g->splits[r] != row_splits[r]) return false;
+    const gt_knn_params& q = g->half_params;
+    const bool decay_same = (std::isnan(p->decay) && std::isnan(q.decay)) || p->decay == q.decay;
+    return p->knn == q.knn && decay_same && p->thresh == q.thresh && p->knn_max == q.knn_max && p->kernel_symm == q.kernel_symm &&
+           p->theta == q.theta && p->anisotropy == q.anisotropy && p->bandwidth_len == q.bandwidth_len &&
+           p->bandwidth_scale == q.bandwidth_scale && p->bandwidth == q.bandwidth;
+}
+
 extern "C" int gt_graph_begin(gt_ctx* ctx, const gt_knn_params* params, int32_t world, int32_t rank,
                               const int64_t* row_splits, int64_t* send_counts) {
     if (!ctx) return GT_E_ARG;
+    if (ctx->graph && ctx->graph->half_begun) {
+        // the second half of a build whose first half gt_graph_bandwidth_local ran (its stages belong to this build)
+        GraphState* g = ctx->graph;
+        g->half_begun = false;
+        if (!params || !row_splits || !send_counts) return GT_E_ARG;
+        GT_HIP(ctx, hipSetDevice(ctx->device));
+        if (!same_build(g, params, world, rank, row_splits))
+            GT_FAIL(ctx, GT_E_STATE, "gt_graph_begin: not the build gt_graph_bandwidth_local started (parameters, world, rank or row_splits differ)");
+        const int rc = graph_begin_b(ctx, params, world, send_counts, false);
+        ctx->stage_totals_valid = 0;
+        return rc;
+    }
     // (the stages of a sharded symmetric pass that is about to be consumed belong to this build)
     // (... and so do those of a first attempt that the pair-resolved tail refuted: gt_graph_build keeps them, the stage times
     //  then say what the build cost)
@@ -2647,6 +2743,45 @@ extern "C" int gt_graph_begin(gt_ctx* ctx, const gt_knn_params* params, int32_t 
     const int rc = graph_begin_impl(ctx, params, world, rank, row_splits, send_counts, false, 0);
     ctx->stage_totals_valid = 0;   // (the totals belong to one build)
     return rc;
+}
+
+// Row-sharded build, pair-resolved tail (include/graphtools_amd.h): the first half of gt_graph_begin for this rank's rows - candidate
+// tables, re-rank (with the transposed keys), bandwidths - and the rank's bandwidths into bw_local_dev (device, float64
+// [row_splits[rank + 1] - row_splits[rank]], on the library's stream).  applies = 0: nothing was done (the build's parameters
+// are not the pair-resolved tail's: every rank gets the same answer) - gt_graph_begin runs the whole build as it always did.
+extern "C" int gt_graph_bandwidth_local(gt_ctx* ctx, const gt_knn_params* params, int32_t world, int32_t rank,
+                                        const int64_t* row_splits, double* bw_local_dev, int32_t* applies) {
+    if (!ctx || !params || !row_splits || !applies) return GT_E_ARG;
+    *applies = 0;
+    GT_HIP(ctx, hipSetDevice(ctx->device));
+    if (world < 1 || world > kMaxWorld || rank < 0 || rank >= world) GT_FAIL(ctx, GT_E_ARG, "gt_graph_bandwidth_local: bad world/rank");
+    if (ctx->graph) ctx->graph->half_begun = false, ctx->graph->bw_all_valid = false;
+    const int64_t nloc = row_splits[rank + 1] - row_splits[rank];
+    if (nloc <= 0 || params->knn < 1 || !shard_pairs_static(ctx, params, nloc)) return GT_OK;
+    if (!bw_local_dev) GT_FAIL(ctx, GT_E_ARG, "gt_graph_bandwidth_local: bw_local_dev is NULL");
+    if (!(ctx->knn && (ctx->knn->sh_stage == 5 || ctx->knn->sh_stage == 6)) && !ctx->keep_stages) ctx->reset_stages();
+    std::vector<int64_t> sendc(size_t(world), 0);
+    bool done = false;
+    GT_TRY(graph_begin_a(ctx, params, world, rank, row_splits, sendc.data(), false, 0, true, &done));
+    GraphState* g = ctx->graph;
+    GT_HIP(ctx, hipMemcpyAsync(bw_local_dev, g->bw.p, size_t(g->nloc) * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    g->half_begun = true;
+    g->half_params = *params;
+    *applies = 1;
+    return GT_OK;
+}
+
+// ... and the bandwidths of ALL rows (device, float64 [n], in the order of the context's rows: the ranks' slices in rank order),
+// copied on the library's stream: the caller keeps bw_all_dev alive until gt_graph_begin has returned.
+extern "C" int gt_graph_set_bandwidths(gt_ctx* ctx, const double* bw_all_dev) {
+    if (!ctx || !bw_all_dev) return GT_E_ARG;
+    GT_HIP(ctx, hipSetDevice(ctx->device));
+    GraphState* g = ctx->graph;
+    if (!g || !g->half_begun) GT_FAIL(ctx, GT_E_STATE, "gt_graph_set_bandwidths: call gt_graph_bandwidth_local first");
+    GT_HIP(ctx, g->bw_all.reserve(size_t(ctx->n) * sizeof(double)));
+    GT_HIP(ctx, hipMemcpyAsync(g->bw_all.p, bw_all_dev, size_t(ctx->n) * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    g->bw_all_valid = true;
+    return GT_OK;
 }
 
 // Row-sharded builds with knn_max (graphs.py:916-976: the search-expansion loop escalates while more than a tenth of ALL rows
@@ -3021,6 +3156,94 @@ __global__ __launch_bounds__(256) void pairs_len_kernel(const int64_t nloc, cons
     }
 }
 
+// the merge launches of the pair-resolved tails (graph_finish_pairs, graph_finish_pairs_shard): union rows -> K, P, degrees in the
+// CSR.  slots: every row is a table row and the rows are walked by slot (merge_pairs_slots_kernel; perm_slots: slot -> row,
+// lenN_slots: own entries by slot; the rows of 129 ... kBigRow entries are listed in g->midrows, n_mid of them)
+static int launch_pair_merges(gt_ctx* ctx, GraphState* g, const FusedSrc& fs, const int64_t nloc, const bool fused, const uint32_t n_mid,
+                              const uint32_t n_huge, const unsigned long long huge_total, const int32_t* perm_slots,
+                              const int32_t* lenN_slots) {
+    {
+        StageSpan span_m(ctx, "symm_merge");
+        // the few long rows (one wave each, 270 registers: a thousand waves for half a millisecond) run on a side stream
+        // next to the merge of the others - the two launches write different rows; the main stream was drained by the
+        // read-back above, and takes the side stream's completion back before anything looks at the result
+        if (!ctx->side_stream) {
+            // (highest priority: the thousand long-row waves are the shorter job and must not queue behind the million short rows)
+            int prio_lo = 0, prio_hi = 0;
+            ctx->side_stream = gt_handle_take_stream(ctx->device, true);   // (parked by a closed context, gt_devpool.cpp)
+            if (!ctx->side_stream) {
+                GT_HIP(ctx, hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+                GT_HIP(ctx, hipStreamCreateWithPriority(&ctx->side_stream, hipStreamNonBlocking, prio_hi));
+            }
+            GT_HIP(ctx, hipEventCreateWithFlags(&ctx->side_event, hipEventDisableTiming));
+        }
+        hipLaunchKernelGGL(merge_long_final_kernel<16>, dim3(2048), dim3(64), 0, ctx->side_stream, fs, g->indptr.as<int64_t>(),
+                           g->indices.as<int32_t>(), g->Kdata.as<double>(), g->Pdata.as<double>(), g->degree.as<double>(),
+                           g->flags.as<uint32_t>(), g->bigrows.as<int32_t>(), g->bigcount.as<uint32_t>());
+        GT_HIP(ctx, hipGetLastError());
+        if (n_huge > 0) {
+            // the rows beyond the register sorts: gather -> segmented sort by column -> their place in the CSR, on the side
+            // stream as well (they write their own rows of the CSR: nothing the merge of the others reads or writes)
+            StageSpan span_h(ctx, "symm_huge");
+            const size_t H = size_t(huge_total);
+            GT_HIP(ctx, g->bigscratch_k.reserve(2 * H * sizeof(uint32_t)));
+            GT_HIP(ctx, g->bigscratch_v.reserve(2 * H * sizeof(double)));
+            GT_HIP(ctx, g->bigsoff.reserve((2 * size_t(n_huge) + 2) * sizeof(uint32_t) + sizeof(unsigned long long)));
+            uint32_t* kin = g->bigscratch_k.as<uint32_t>();
+            uint32_t* kout = kin + H;
+            double* vin = g->bigscratch_v.as<double>();
+            double* vout = vin + H;
+            unsigned long long* cursor = g->bigsoff.as<unsigned long long>();
+            uint32_t* seg_begin = reinterpret_cast<uint32_t*>(cursor + 1);
+            uint32_t* seg_end = seg_begin + n_huge;
+            GT_HIP(ctx, hipMemsetAsync(cursor, 0, sizeof(unsigned long long), ctx->side_stream));
+            const int32_t* hugelist = g->bigrows.as<int32_t>() + (nloc - 1);
+            hipLaunchKernelGGL(huge_gather_kernel, dim3(n_huge), dim3(64), 0, ctx->side_stream, fs, hugelist, n_huge, cursor, seg_begin,
+                               seg_end, kin, vin);
+            GT_HIP(ctx, hipGetLastError());
+            int bits = 1;
+            while (bits < 32 && (int64_t(1) << bits) < g->n_total) ++bits;
+            size_t tmp_bytes = 0;
+            GT_HIP(ctx, rocprim::segmented_radix_sort_pairs(nullptr, tmp_bytes, kin, kout, vin, vout, unsigned(H), n_huge, seg_begin,
+                                                            seg_end, 0u, unsigned(bits), ctx->side_stream));
+            GT_HIP(ctx, g->hugerows.reserve(tmp_bytes));
+            GT_HIP(ctx, rocprim::segmented_radix_sort_pairs(g->hugerows.p, tmp_bytes, kin, kout, vin, vout, unsigned(H), n_huge,
+                                                            seg_begin, seg_end, 0u, unsigned(bits), ctx->side_stream));
+            hipLaunchKernelGGL(huge_finalize_kernel, dim3(n_huge), dim3(64), 0, ctx->side_stream, hugelist, n_huge, seg_begin, seg_end, kout,
+                               vout, g->indptr.as<int64_t>(), g->indices.as<int32_t>(), g->Kdata.as<double>(),
+                               g->Pdata.as<double>(), g->degree.as<double>(), g->flags.as<uint32_t>(), fs.cmap, fs.row0);
+            GT_HIP(ctx, hipGetLastError());
+        }
+        if (fused && n_mid > 0)   // (the rows of 129 ... kBigRow entries: next to the short rows' kernel on the main stream)
+            hipLaunchKernelGGL(merge_final_kernel, dim3(n_mid), dim3(64), 0, ctx->side_stream, int64_t(n_mid), fs, g->indptr.as<int64_t>(),
+                               g->indices.as<int32_t>(), g->Kdata.as<double>(), g->Pdata.as<double>(), g->degree.as<double>(),
+                               g->flags.as<uint32_t>(),
+                               (ctx->symm_key32 != 0 && sort_key_fits_u32(g->n_total, 8)) ? 1 : 0, g->midrows.as<int32_t>());
+        GT_HIP(ctx, hipEventRecord(ctx->side_event, ctx->side_stream));
+        const int key32 = (ctx->symm_key32 != 0 && sort_key_fits_u32(g->n_total, 8)) ? 1 : 0;
+        if (fused) {
+            const int rpw = 8;
+            // (the short path's composite keys: column, tag and 7 position bits)
+            if (ctx->symm_key32 != 0 && sort_key_fits_u32(g->n_total, 2))
+                hipLaunchKernelGGL(merge_pairs_slots_kernel<uint32_t>, dim3((unsigned)ceil_div64(nloc, int64_t(4) * rpw)), dim3(256), 0,
+                                   ctx->stream, nloc, rpw, fs, lenN_slots, perm_slots, g->indptr.as<int64_t>(),
+                                   g->indices.as<int32_t>(), g->Kdata.as<double>(), g->Pdata.as<double>(), g->degree.as<double>(),
+                                   g->flags.as<uint32_t>());
+            else
+                hipLaunchKernelGGL(merge_pairs_slots_kernel<uint64_t>, dim3((unsigned)ceil_div64(nloc, int64_t(4) * rpw)), dim3(256), 0,
+                                   ctx->stream, nloc, rpw, fs, lenN_slots, perm_slots, g->indptr.as<int64_t>(),
+                                   g->indices.as<int32_t>(), g->Kdata.as<double>(), g->Pdata.as<double>(), g->degree.as<double>(),
+                                   g->flags.as<uint32_t>());
+        } else
+        hipLaunchKernelGGL(merge_final_kernel, dim3((unsigned)ceil_div64(nloc, 1)), dim3(64), 0, ctx->stream, nloc, fs,
+                           g->indptr.as<int64_t>(), g->indices.as<int32_t>(), g->Kdata.as<double>(), g->Pdata.as<double>(),
+                           g->degree.as<double>(), g->flags.as<uint32_t>(), key32, (const int32_t*)nullptr);
+        GT_HIP(ctx, hipGetLastError());
+        GT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->side_event, 0));
+    }
+    return GT_OK;
+}
+
 // returns 1: K and P are complete; 0: a union row beyond the register sorts - the caller rebuilds without this path
 static int graph_finish_pairs(gt_ctx* ctx, int64_t* out_nnz, uint32_t* flags) {
     GraphState* g = ctx->graph;
@@ -3163,85 +3386,9 @@ static int graph_finish_pairs(gt_ctx* ctx, int64_t* out_nnz, uint32_t* flags) {
     fs.ucol = g->ucol.as<uint32_t>();
     fs.uval = g->uval.as<double>();
     fs.tab_sorted = tabs;
-    {
-        StageSpan span_m(ctx, "symm_merge");
-        // the few long rows (one wave each, 270 registers: a thousand waves for half a millisecond) run on a side stream
-        // next to the merge of the others - the two launches write different rows; the main stream was drained by the
-        // read-back above, and takes the side stream's completion back before anything looks at the result
-        if (!ctx->side_stream) {
-            // (highest priority: the thousand long-row waves are the shorter job and must not queue behind the million short rows)
-            int prio_lo = 0, prio_hi = 0;
-            ctx->side_stream = gt_handle_take_stream(ctx->device, true);   // (parked by a closed context, gt_devpool.cpp)
-            if (!ctx->side_stream) {
-                GT_HIP(ctx, hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-                GT_HIP(ctx, hipStreamCreateWithPriority(&ctx->side_stream, hipStreamNonBlocking, prio_hi));
-            }
-            GT_HIP(ctx, hipEventCreateWithFlags(&ctx->side_event, hipEventDisableTiming));
-        }
-        hipLaunchKernelGGL(merge_long_final_kernel<16>, dim3(2048), dim3(64), 0, ctx->side_stream, fs, g->indptr.as<int64_t>(),
-                           g->indices.as<int32_t>(), g->Kdata.as<double>(), g->Pdata.as<double>(), g->degree.as<double>(),
-                           g->flags.as<uint32_t>(), g->bigrows.as<int32_t>(), g->bigcount.as<uint32_t>());
-        GT_HIP(ctx, hipGetLastError());
-        if (n_huge > 0) {
-            // the rows beyond the register sorts: gather -> segmented sort by column -> their place in the CSR, on the side
-            // stream as well (they write their own rows of the CSR: nothing the merge of the others reads or writes)
-            StageSpan span_h(ctx, "symm_huge");
-            const size_t H = size_t(huge_total);
-            GT_HIP(ctx, g->bigscratch_k.reserve(2 * H * sizeof(uint32_t)));
-            GT_HIP(ctx, g->bigscratch_v.reserve(2 * H * sizeof(double)));
-            GT_HIP(ctx, g->bigsoff.reserve((2 * size_t(n_huge) + 2) * sizeof(uint32_t) + sizeof(unsigned long long)));
-            uint32_t* kin = g->bigscratch_k.as<uint32_t>();
-            uint32_t* kout = kin + H;
-            double* vin = g->bigscratch_v.as<double>();
-            double* vout = vin + H;
-            unsigned long long* cursor = g->bigsoff.as<unsigned long long>();
-            uint32_t* seg_begin = reinterpret_cast<uint32_t*>(cursor + 1);
-            uint32_t* seg_end = seg_begin + n_huge;
-            GT_HIP(ctx, hipMemsetAsync(cursor, 0, sizeof(unsigned long long), ctx->side_stream));
-            const int32_t* hugelist = g->bigrows.as<int32_t>() + (nloc - 1);
-            hipLaunchKernelGGL(huge_gather_kernel, dim3(n_huge), dim3(64), 0, ctx->side_stream, fs, hugelist, n_huge, cursor, seg_begin,
-                               seg_end, kin, vin);
-            GT_HIP(ctx, hipGetLastError());
-            int bits = 1;
-            while (bits < 32 && (int64_t(1) << bits) < g->n_total) ++bits;
-            size_t tmp_bytes = 0;
-            GT_HIP(ctx, rocprim::segmented_radix_sort_pairs(nullptr, tmp_bytes, kin, kout, vin, vout, unsigned(H), n_huge, seg_begin,
-                                                            seg_end, 0u, unsigned(bits), ctx->side_stream));
-            GT_HIP(ctx, g->hugerows.reserve(tmp_bytes));
-            GT_HIP(ctx, rocprim::segmented_radix_sort_pairs(g->hugerows.p, tmp_bytes, kin, kout, vin, vout, unsigned(H), n_huge,
-                                                            seg_begin, seg_end, 0u, unsigned(bits), ctx->side_stream));
-            hipLaunchKernelGGL(huge_finalize_kernel, dim3(n_huge), dim3(64), 0, ctx->side_stream, hugelist, n_huge, seg_begin, seg_end, kout,
-                               vout, g->indptr.as<int64_t>(), g->indices.as<int32_t>(), g->Kdata.as<double>(),
-                               g->Pdata.as<double>(), g->degree.as<double>(), g->flags.as<uint32_t>());
-            GT_HIP(ctx, hipGetLastError());
-        }
-        if (fused && n_mid > 0)   // (the rows of 129 ... kBigRow entries: next to the short rows' kernel on the main stream)
-            hipLaunchKernelGGL(merge_final_kernel, dim3(n_mid), dim3(64), 0, ctx->side_stream, int64_t(n_mid), fs, g->indptr.as<int64_t>(),
-                               g->indices.as<int32_t>(), g->Kdata.as<double>(), g->Pdata.as<double>(), g->degree.as<double>(),
-                               g->flags.as<uint32_t>(),
-                               (ctx->symm_key32 != 0 && sort_key_fits_u32(g->n_total, 8)) ? 1 : 0, g->midrows.as<int32_t>());
-        GT_HIP(ctx, hipEventRecord(ctx->side_event, ctx->side_stream));
-        const int key32 = (ctx->symm_key32 != 0 && sort_key_fits_u32(g->n_total, 8)) ? 1 : 0;
-        if (fused) {
-            const int rpw = 8;
-            // (the short path's composite keys: column, tag and 7 position bits)
-            if (ctx->symm_key32 != 0 && sort_key_fits_u32(g->n_total, 2))
-                hipLaunchKernelGGL(merge_pairs_slots_kernel<uint32_t>, dim3((unsigned)ceil_div64(nloc, int64_t(4) * rpw)), dim3(256), 0,
-                                   ctx->stream, nloc, rpw, fs, g->cnt_sorted.as<int32_t>(), perm, g->indptr.as<int64_t>(),
-                                   g->indices.as<int32_t>(), g->Kdata.as<double>(), g->Pdata.as<double>(), g->degree.as<double>(),
-                                   g->flags.as<uint32_t>());
-            else
-                hipLaunchKernelGGL(merge_pairs_slots_kernel<uint64_t>, dim3((unsigned)ceil_div64(nloc, int64_t(4) * rpw)), dim3(256), 0,
-                                   ctx->stream, nloc, rpw, fs, g->cnt_sorted.as<int32_t>(), perm, g->indptr.as<int64_t>(),
-                                   g->indices.as<int32_t>(), g->Kdata.as<double>(), g->Pdata.as<double>(), g->degree.as<double>(),
-                                   g->flags.as<uint32_t>());
-        } else
-        hipLaunchKernelGGL(merge_final_kernel, dim3((unsigned)ceil_div64(nloc, 1)), dim3(64), 0, ctx->stream, nloc, fs,
-                           g->indptr.as<int64_t>(), g->indices.as<int32_t>(), g->Kdata.as<double>(), g->Pdata.as<double>(),
-                           g->degree.as<double>(), g->flags.as<uint32_t>(), key32, (const int32_t*)nullptr);
-        GT_HIP(ctx, hipGetLastError());
-        GT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->side_event, 0));
-    }
+    fs.cmap = nullptr;
+    fs.row0 = 0;
+    GT_TRY(launch_pair_merges(ctx, g, fs, nloc, fused, n_mid, n_huge, huge_total, perm, g->cnt_sorted.as<int32_t>()));
     uint32_t fl = 0, kfl = 0;
     {
         ReadBack rb(ctx);
@@ -3265,7 +3412,138 @@ static int graph_finish_pairs(gt_ctx* ctx, int64_t* out_nnz, uint32_t* flags) {
     return 1;
 }
 
+// ---- pair-resolved tail of a rank of a row-sharded build ------------------------------------------------------------------
+// The rank's affinity pass (graph_begin_b, pairs_shard) has settled every mutual pair in its own row - minus the merged value - with
+// the partner's bandwidth from the all-gather, wherever the partner lives; what arrived here are the one-sided entries of other
+// rows (and of this rank's own: they went through the exchange like everybody's) whose transposed half belongs to a local row.
+// No pair meets its partner in a union row: a row's final length is its kept entries plus what it received, the CSR offsets are
+// one scan away, and the merge kernels of the single-rank tail sort each union row by the CALLER's column numbers and write
+// K, P and the degree straight into the CSR - no union buffer of all entries, no merge of duplicates, no compaction pass.
+__global__ __launch_bounds__(256) void iota_i32_kernel(const int64_t n, int32_t* __restrict__ out) {
+    const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i < n) out[i] = int32_t(i);
+}
+__global__ __launch_bounds__(256) void fill_recv_pairs_kernel(const Triplet* __restrict__ recv, const int64_t n_recv, const int64_t r0,
+                                                              const int64_t* __restrict__ off, const int64_t* __restrict__ sN,
+                                                              const int32_t* __restrict__ slot, uint32_t* __restrict__ ucol,
+                                                              double* __restrict__ uval, const int32_t* __restrict__ relabel) {
+    // (the received half of local row il starts at off[il] - sN[il] of ucol / uval: FusedSrc)
+    for (int64_t t = int64_t(blockIdx.x) * 256 + threadIdx.x; t < n_recv; t += int64_t(gridDim.x) * 256) {
+        const Triplet tr = recv[t];
+        const int64_t il = int64_t(tr.row) - r0;
+        const int64_t pos = (off[il] - sN[il]) + slot[t];
+        ucol[pos] = relabel ? uint32_t(relabel[tr.col]) : tr.col;
+        uval[pos] = tr.val;
+    }
+}
+
+static int graph_finish_pairs_shard(gt_ctx* ctx, const void* recv_buf_dev, int64_t n_recv, int64_t* out_nnz, uint32_t* flags) {
+    GT_HIP(ctx, hipSetDevice(ctx->device));
+    GraphState* g = ctx->graph;
+    KnnWork* k = ctx->knn;
+    if (n_recv < 0 || (n_recv > 0 && !recv_buf_dev)) GT_FAIL(ctx, GT_E_ARG, "gt_graph_finish: bad receive buffer");
+    const Triplet* recv = (const Triplet*)recv_buf_dev;
+    const int64_t nloc = g->nloc;
+    const int32_t* relabel = ctx->presorted ? ctx->vperm.as<int32_t>() : nullptr;
+    g->relabelled = relabel != nullptr;
+    const bool slots = g->n_over == 0;   // every row is a table row: the short rows take merge_pairs_slots_kernel
+    StageSpan span(ctx, "symmetrize");
+    GT_HIP(ctx, g->ident.reserve(size_t(nloc) * sizeof(int32_t)));
+    GT_HIP(ctx, g->cursor.reserve(size_t(std::max<int64_t>(n_recv, 1)) * sizeof(int32_t)));   // slot of every received triplet
+    GT_HIP(ctx, g->off.reserve(size_t(nloc + 1) * sizeof(int64_t)));
+    GT_HIP(ctx, g->pos_sorted.reserve(size_t(nloc + 1) * sizeof(int64_t)));
+    GT_HIP(ctx, g->outlen.reserve(size_t(nloc) * sizeof(int32_t)));
+    GT_HIP(ctx, g->bigrows.reserve(size_t(nloc) * sizeof(int32_t)));
+    GT_HIP(ctx, g->midrows.reserve(size_t(nloc) * sizeof(int32_t)));
+    GT_HIP(ctx, g->bigcount.reserve(8 * sizeof(uint32_t)));
+    GT_HIP(ctx, g->indptr.reserve(size_t(nloc + 1) * sizeof(int64_t)));
+    GT_HIP(ctx, g->degree.reserve(size_t(nloc) * sizeof(double)));
+    GT_HIP(ctx, g->ucol.reserve(size_t(std::max<int64_t>(n_recv, 1)) * sizeof(uint32_t)));
+    GT_HIP(ctx, g->uval.reserve(size_t(std::max<int64_t>(n_recv, 1)) * sizeof(double)));
+    GT_HIP(ctx, hipMemsetAsync(g->bigcount.p, 0, 8 * sizeof(uint32_t), ctx->stream));
+    GT_HIP(ctx, hipMemsetAsync(g->lenT.p, 0, size_t(nloc) * sizeof(int32_t), ctx->stream));
+    uint32_t* fflags = g->bigcount.as<uint32_t>() + 2;
+    hipLaunchKernelGGL(iota_i32_kernel, dim3((unsigned)ceil_div64(nloc, 256)), dim3(256), 0, ctx->stream, nloc, g->ident.as<int32_t>());
+    if (n_recv > 0) {
+        const int64_t blocks = std::min<int64_t>(ceil_div64(n_recv, 256), 16384);
+        hipLaunchKernelGGL(count_recv_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, recv, n_recv, g->r0,
+                           g->lenT.as<int32_t>(), g->cursor.as<int32_t>());
+    }
+    GT_HIP(ctx, hipGetLastError());
+    // union rows (own + received) and own entries, scanned in row order: off, sN
+    GT_TRY(exclusive_scan(ctx, g->lenN.as<int32_t>(), g->lenT.as<int32_t>(), nloc, g->off.as<int64_t>(), g->scan_tmp));
+    GT_TRY(exclusive_scan(ctx, g->lenN.as<int32_t>(), nullptr, nloc, g->pos_sorted.as<int64_t>(), g->scan_tmp));
+    hipLaunchKernelGGL(pairs_len_kernel, dim3((unsigned)ceil_div64(nloc, 256)), dim3(256), 0, ctx->stream, nloc, g->ident.as<int32_t>(),
+                       g->off.as<int64_t>(), g->outlen.as<int32_t>(), g->bigrows.as<int32_t>(), g->bigcount.as<uint32_t>(), fflags,
+                       slots ? g->midrows.as<int32_t>() : (int32_t*)nullptr);
+    GT_HIP(ctx, hipGetLastError());
+    // (the rows of the CSR are the local rows in their order: its offsets are the union rows')
+    GT_HIP(ctx, hipMemcpyAsync(g->indptr.p, g->off.p, size_t(nloc + 1) * sizeof(int64_t), hipMemcpyDeviceToDevice, ctx->stream));
+    if (n_recv > 0) {
+        const int64_t blocks = std::min<int64_t>(ceil_div64(n_recv, 256), 16384);
+        hipLaunchKernelGGL(fill_recv_pairs_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, recv, n_recv, g->r0,
+                           g->off.as<int64_t>(), g->pos_sorted.as<int64_t>(), g->cursor.as<int32_t>(), g->ucol.as<uint32_t>(),
+                           g->uval.as<double>(), relabel);
+        GT_HIP(ctx, hipGetLastError());
+    }
+    int64_t nnz = 0, n_kept = 0;
+    uint32_t bc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    {
+        ReadBack rb(ctx);
+        GT_HIP(ctx, rb.add(&nnz, g->off.as<int64_t>() + nloc, sizeof(int64_t)));
+        GT_HIP(ctx, rb.add(&n_kept, g->pos_sorted.as<int64_t>() + nloc, sizeof(int64_t)));
+        GT_HIP(ctx, rb.add(bc, g->bigcount.p, 8 * sizeof(uint32_t)));
+        GT_HIP(ctx, rb.sync());
+    }
+    if (nnz != n_kept + n_recv) GT_FAIL(ctx, GT_E_STATE, "gt_graph_finish: received triplets for rows this rank does not own");
+    const uint32_t n_mid = bc[1], ff = bc[2], n_huge = bc[4];
+    const unsigned long long huge_total = (unsigned long long)bc[6] | ((unsigned long long)bc[7] << 32);
+    if ((ff & ~kFusedHugeRow) != 0 || ((ff & kFusedHugeRow) && huge_total >= (1ull << 31)))
+        GT_FAIL(ctx, GT_E_LIMIT, "gt_graph_finish: a union row beyond what the pair-resolved tail of a sharded build holds (set symmetrize_pairs_shard=0)");
+    GT_HIP(ctx, g->indices.reserve(size_t(std::max<int64_t>(nnz, 1)) * sizeof(int32_t)));
+    GT_HIP(ctx, g->Kdata.reserve(size_t(std::max<int64_t>(nnz, 1)) * sizeof(double)));
+    GT_HIP(ctx, g->Pdata.reserve(size_t(std::max<int64_t>(nnz, 1)) * sizeof(double)));
+    FusedSrc fs;
+    fs.pos = g->ident.as<int32_t>();
+    fs.lenN = g->lenN.as<int32_t>();
+    fs.off = g->off.as<int64_t>();
+    fs.sN = g->pos_sorted.as<int64_t>();
+    fs.rowsrc = g->rowsrc.as<int32_t>();
+    fs.cand_k = k->cand_d2.as<double>();
+    fs.cand_j = k->cand_j.as<uint32_t>();
+    fs.MP = k->MP;
+    fs.rlists = g->rlists.as<uint64_t>();
+    fs.rK = g->rK.as<double>();
+    fs.rcap = g->rcap;
+    fs.ucol = g->ucol.as<uint32_t>();
+    fs.uval = g->uval.as<double>();
+    fs.tab_sorted = 0;
+    fs.cmap = relabel;
+    fs.row0 = g->r0;
+    GT_TRY(launch_pair_merges(ctx, g, fs, nloc, slots, n_mid, n_huge, huge_total, g->ident.as<int32_t>(), g->lenN.as<int32_t>()));
+    uint32_t fl = 0, kfl = 0;
+    {
+        ReadBack rb(ctx);
+        GT_HIP(ctx, rb.add(&fl, g->flags.p, sizeof(uint32_t)));
+        GT_HIP(ctx, rb.add(&kfl, k->gflags.p, sizeof(uint32_t)));
+        GT_HIP(ctx, rb.sync());
+    }
+    if (fl & kFlagPairDupColumn)
+        GT_FAIL(ctx, GT_E_STATE, "gt_graph_finish: two ranks disagreed on a mutual pair (a column twice in a union row; set symmetrize_pairs_shard=0)");
+    g->nnz0 = n_kept;
+    g->nnz = nnz;
+    g->finished = true;
+    fl |= kfl;
+    if (k->n_fallback > 0) fl |= GT_FLAG_FALLBACK_ROWS;
+    if (g->n_over > 0) fl |= GT_FLAG_RADIUS_ROWS;
+    if (out_nnz) *out_nnz = g->nnz;
+    if (flags) *flags = fl;
+    return GT_OK;
+}
+
 extern "C" int gt_graph_finish(gt_ctx* ctx, const void* recv_buf_dev, int64_t n_recv, int64_t* out_nnz, uint32_t* flags) {
+    if (ctx && ctx->graph && ctx->graph->begun && ctx->graph->pairs_shard)
+        return graph_finish_pairs_shard(ctx, recv_buf_dev, n_recv, out_nnz, flags);
     return graph_finish_impl(ctx, recv_buf_dev, n_recv, false, out_nnz, flags);
 }
 

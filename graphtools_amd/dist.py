@@ -11,6 +11,9 @@ The N x N affinity build shards by row blocks; every rank
                                       rank itself - no thresholds or candidate records travel (a rank may decline and run
                                       the classic pass for its rows: nothing is shared); gt_graph_begin: re-rank ->
                                       bandwidth -> radius pass -> affinities
+  3b. '+' rule: all-gather of the bandwidths (8 B per row) between the two halves of gt_graph_begin
+                                      (gt_graph_bandwidth_local / gt_graph_set_bandwidths): every rank settles its mutual
+                                      pairs itself, only the one-sided entries travel in step 4
   4. all-to-all of transposed triplets {row, col, value} (16 B each) bucketed by the owner of ``row`` - collectives 3
                                       (counts, 8 B per peer) and 4 (the triplets); collective 2 is the all-gather of the
                                       cell numbers inside step 2 (4 B per row: each rank assigns 1 / world of the rows)
@@ -339,6 +342,20 @@ class ShardedKnnGraph(object):
             steps = steps.cpu().numpy()
             if int(steps[0]) == -int(steps[1]) and int(steps[0]) > 0:
                 ctx.graph_set_stage_totals(tot[: int(steps[0])])
+        bw_all = None
+        self.pairs_used = False
+        if self.world > 1 and hasattr(ctx, "graph_bandwidth_local"):
+            # the pair-resolved tail on every rank ('+' rule): the ranks' bandwidths are gathered (collective: 8 B per row)
+            # between the two halves of graph_begin - a rank then settles its mutual pairs itself, only one-sided entries
+            # travel.  Whether it applies follows from the parameters alone: the same answer on every rank, no vote.
+            nloc = int(self.splits[self.rank + 1] - self.splits[self.rank])
+            bw = torch.empty(max(nloc, 1), dtype=torch.float64, device=device)
+            if ctx.graph_bandwidth_local(params, self.world, self.rank, self.splits, bw.data_ptr()):
+                _order_before_collectives(ctx, bw)
+                bw_all = allgather_vector(bw[:nloc], self.splits, self.group).contiguous()
+                _order_after_collectives(ctx, bw_all)
+                ctx.graph_set_bandwidths(bw_all.data_ptr())
+                self.pairs_used = True
         send_counts = ctx.graph_begin(params, self.world, self.rank, self.splits)
         total = int(send_counts.sum())
         send = torch.empty(max(total, 1) * WORDS_PER_TRIPLET, dtype=torch.int64, device=device)
@@ -362,7 +379,7 @@ class ShardedKnnGraph(object):
                 deg_all = by_caller
             _order_after_collectives(ctx, deg_all)
             ctx.graph_anisotropy(deg_all.data_ptr())
-        self._keep = (send, recv)
+        self._keep = (send, recv, bw_all)
         return nnz, flags
 
     def draw_landmarks(self, n_landmark, random_state):

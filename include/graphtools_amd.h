@@ -154,6 +154,8 @@ int gt_stage_launches(const gt_ctx* ctx, const char* stage);
  *   symmetrize_key32         0 | 1: per-row sorts of the symmetrisation on 32-bit keys where columns and positions fit (1).
  *   symmetrize_pairs         0 | 1 | 2: pair-resolved symmetrisation of '+' builds - every row settles its mutual pairs itself,
  *                            only one-sided entries are transposed; 2 (default): with the tables by sorted position.
+ *   symmetrize_pairs_shard   0 | 1: ... also on the ranks of a row-sharded build whose caller gathers the bandwidths
+ *                            (gt_graph_bandwidth_local / gt_graph_set_bandwidths) (1; 0: gt_graph_bandwidth_local answers "no").
  *   symmetrize_pairs_huge    0 | 1: union rows beyond the register sorts are finished by a segmented sort (1) or refute the path.
  *   dense_rows               "auto" | 0 | 1: exact graph from float32 distances, '+' rule, in the row-streaming form (auto: from
  *                            16384 rows).
@@ -225,6 +227,28 @@ int gt_graph_finish(gt_ctx* ctx, const void* recv_buf_dev, int64_t n_recv, int64
  * degrees; the caller all-gathers the degree vectors (GT_VEC_DEGREE) into one n-vector on the device and
  * calls gt_graph_anisotropy, which rescales K (base.py:579-592) and then forms P. */
 int gt_graph_anisotropy(gt_ctx* ctx, const double* degree_all_dev);
+/* Row-sharded builds with the '+' rule, optional: the PAIR-RESOLVED TAIL on every rank.  BaseGraph.symmetrize_kernel
+ * (base.py:557-577) forms (K + K.T) / 2; an entry K[i, j] whose transposed partner K[j, i] is kept too is a MUTUAL pair, and
+ * whether it is follows from row j's bandwidth alone (the key row j holds for the pair is the same dot product in scikit-learn's
+ * association with the roles swapped, written next to the table by the re-rank).  A rank that knows the bandwidths of ALL rows
+ * therefore settles its mutual pairs itself, whichever rank the partner lives on; only the one-sided entries travel (44 M of
+ * 116 M at BASELINE config 3), no pair ever meets its partner in a union row, and gt_graph_finish sorts each row once and
+ * writes K, P and the degrees straight into the CSR.  Between gt_graph_shard_local and gt_graph_begin every rank calls
+ *   gt_graph_bandwidth_local  the first half of gt_graph_begin (candidate tables, re-rank, bandwidths) for the rank's rows;
+ *                             bw_local_dev (device, float64 [rows of the rank], out, on the library's stream).  applies (out)
+ *                             = 0: the parameters are not this tail's ('*' / mnn rule, knn_max, anisotropy, a binary kernel,
+ *                             symmetrize_pairs / symmetrize_pairs_shard = 0) - the same answer on every rank, nothing was done,
+ *                             gt_graph_begin runs the whole build the general way
+ *   -> the host all-gathers the slices into float64 [n] in the order of the context's rows (collective: 8 B per row)
+ *   gt_graph_set_bandwidths   bw_all_dev (device; kept alive by the caller until gt_graph_begin has returned)
+ * and then gt_graph_begin (same params / world / rank / row_splits: the second half) / gt_graph_emit / all-to-all /
+ * gt_graph_finish as above.  gt_graph_begin without gt_graph_set_bandwidths finishes the build the general way.  A rank
+ * whose tables carry no transposed keys (classic candidate pass, repaired rows) forms them from the dot products: every
+ * rank can always follow, which is what lets the ranks decide without a vote.  K, P and the degrees equal the general
+ * tail's bit for bit (x / 2 + y / 2 == (x + y) / 2 in binary floating point). */
+int gt_graph_bandwidth_local(gt_ctx* ctx, const gt_knn_params* params, int32_t world, int32_t rank, const int64_t* row_splits,
+                             double* bw_local_dev, int32_t* applies);
+int gt_graph_set_bandwidths(gt_ctx* ctx, const double* bw_all_dev);
 /* Row-sharded builds, optional first phase: the symmetric candidate pass (every unordered pair of rows scored once,
  * DESIGN.md 3.6) split over the ranks - each rank scores 1/world of the pairs instead of its rows against everything.
  * Every rank holds all points and calls, in order (a rank may stop after any call whose `applies` comes back 0, as long

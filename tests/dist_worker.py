@@ -190,6 +190,32 @@ class FakeCtx(object):
         self.sym_ready = self.local_applies
         return self.local_applies
 
+    # ---- the pair-resolved tail of a sharded build (gt_graph_bandwidth_local / gt_graph_set_bandwidths): the rank's
+    # bandwidths go out, the bandwidths of ALL rows come back in the order of the context's rows; the rank then settles its
+    # mutual pairs itself and sends the one-sided entries only.  The stand-in checks what dist.py delivered against the
+    # bandwidths of a whole-set build and looks the partners' entries up in that build's kernel.
+    pairs_enabled = True      # (the library's option symmetrize_pairs_shard)
+    pairs_calls = ()
+    bw_all = None
+
+    def graph_bandwidth_local(self, params, world, rank, splits, ptr):
+        p = _plain_params(params)
+        self.pairs_calls = self.pairs_calls + ("bandwidth_local",)
+        self.bw_all = None
+        if not self.pairs_enabled or p.kernel_symm != "+" or p.decay is None or p.anisotropy != 0 or p.knn_max > 0:
+            return False      # (the parameters alone decide: the same answer on every rank)
+        r0, r1 = int(splits[rank]), int(splits[rank + 1])
+        _, info = oracle.knn_kernel(self.X, knn=p.knn + 1, decay=p.decay, thresh=p.thresh, Y=self.X[r0:r1], return_search=True)
+        out = np.frombuffer((ctypes.c_char * ((r1 - r0) * 8)).from_address(ptr), dtype=np.float64)
+        out[:] = info["bandwidth"]
+        self._half = (p.knn, p.decay, p.thresh, world, rank, tuple(int(v) for v in splits))
+        return True
+
+    def graph_set_bandwidths(self, ptr):
+        self.pairs_calls = self.pairs_calls + ("set_bandwidths",)
+        n = self.X.shape[0]
+        self.bw_all = np.frombuffer((ctypes.c_char * (n * 8)).from_address(ptr), dtype=np.float64).copy()
+
     def graph_begin(self, params, world, rank, splits):
         params = _plain_params(params)
         self.sym_consumed, self.sym_ready = self.sym_ready, False
@@ -198,6 +224,21 @@ class FakeCtx(object):
         self.r0, self.r1 = r0, r1
         K0 = oracle.knn_kernel(self.X, knn=params.knn + 1, decay=params.decay, thresh=params.thresh, Y=self.X[r0:r1])
         self.K0 = sparse.coo_matrix(K0)
+        self.pairs = self.bw_all is not None
+        if self.pairs:
+            assert self._half == (params.knn, params.decay, params.thresh, world, rank, tuple(int(v) for v in splits)), \
+                "graph_begin is not the build graph_bandwidth_local started"
+            full, info = oracle.knn_kernel(self.X, knn=params.knn, decay=params.decay, thresh=params.thresh, return_search=True)
+            assert np.array_equal(self.bw_all, info["bandwidth"]), "the gathered bandwidths are not those of the context's rows, in order"
+            self.bw_all = None
+            full = sparse.csr_matrix(full)
+            partner = np.asarray(full[self.K0.col, self.K0.row + r0]).ravel()   # K0[j, i] of every own entry (i, j)
+            mutual = partner != 0
+            # settled here: (K[i, j] + K[j, i]) / 2, never sent; the one-sided entries travel (own rows' too)
+            self.settled = sparse.csr_matrix(((self.K0.data[mutual] + partner[mutual]) / 2,
+                                              (self.K0.row[mutual], self.K0.col[mutual])), shape=(r1 - r0, self.X.shape[0]))
+            self.K0 = sparse.coo_matrix((self.K0.data[~mutual], (self.K0.row[~mutual], self.K0.col[~mutual])),
+                                        shape=self.K0.shape)
         owner = np.searchsorted(self.splits, self.K0.col, side="right") - 1
         self.owner = owner
         if params.kernel_symm is None:
@@ -223,7 +264,12 @@ class FakeCtx(object):
         else:
             B = sparse.csr_matrix((nloc, n))
         s = self.p.kernel_symm
-        if s == "+":
+        if s == "+" and self.pairs:
+            # no pair meets its partner in a union row: own one-sided, received and settled entries are disjoint
+            assert A.multiply(B).nnz == 0 and A.multiply(self.settled).nnz == 0 and B.multiply(self.settled).nnz == 0, \
+                "a pair met its partner in a union row"
+            K = self.settled + (A + B) / 2
+        elif s == "+":
             K = (A + B) / 2
         elif s == "*":
             K = A.multiply(B)
@@ -363,9 +409,10 @@ def main():
 
     # 5c. the DEFAULT flow: cell-sorted renumbering - three collectives (points all-gather, triplet counts, triplets), the
     #     rank's rows are rows of the new numbering, row_ids() gives the caller's; a rank may decline the local pass alone
-    for symm in ("+", "*", None):
+    for symm, pairs_on in (("+", True), ("+", False), ("*", True), (None, True)):
         for scenario in ("local", "rank1 declines", "renumbering declines"):
             c = FakeCtx()
+            c.pairs_enabled = pairs_on
             c.local_applies = not (scenario == "rank1 declines" and rank == 1)
             c.renumber_applies = scenario != "renumbering declines"
             g = gdist.ShardedKnnGraph(c, Xg.shape[0])
@@ -378,6 +425,11 @@ def main():
             ids = g.row_ids()
             assert len(ids) == g.splits[rank + 1] - g.splits[rank]
             assert (c.K != K_full[ids]).nnz == 0, "rows of the renumbered build differ from the single-process oracle (%s, %s)" % (symm, scenario)
+            # the pair-resolved tail: one more collective (the bandwidths) for the '+' rule, whatever the candidate pass was;
+            # any other rule (or the option off) answers "no" on every rank and the build runs the general way
+            want_pairs = symm == "+" and pairs_on
+            assert c.pairs_calls == (("bandwidth_local", "set_bandwidths") if want_pairs else ("bandwidth_local",)), c.pairs_calls
+            assert g.pairs_used == want_pairs and c.pairs == want_pairs
             if c.renumber_applies:
                 assert c.calls == ("cell_sort", "shard_local"), c.calls
                 assert g.symmetric_used == c.local_applies and c.sym_consumed == c.local_applies

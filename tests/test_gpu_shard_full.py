@@ -41,7 +41,9 @@ def _row_hash16(indices, indptr):
 class SimulatedRanks:
     """one context, `world` ranks of the build on renumbered points played in turn"""
 
-    def __init__(self, X, world, pargs):
+    def __init__(self, X, world, pargs, pairs=True):
+        """pairs: the ranks take the pair-resolved tail where the library offers it (gt_graph_bandwidth_local - the all-gather
+        of the bandwidths is played by hand like the other collectives); False: the general tail, as until round 6"""
         from graphtools_amd import _hip
 
         self.hip = _hip
@@ -60,9 +62,12 @@ class SimulatedRanks:
             assert ok, "no cell order for these points"
         self.splits = None
         self.used = []
+        self.want_pairs = bool(pairs)
+        self.pairs = False
+        self.bw_all = None      # host: the bandwidths of all rows once every rank has reported its own
 
-    def until_emit(self, r):
-        """bind + renumber + local candidate lists + affinities + triplet emit of rank r -> (send counts, host triplets)"""
+    def until_tables(self, r):
+        """bind + renumber + local candidate lists of rank r -> (row blocks, whether the local pass applied)"""
         c = self.ctx
         own = c.dev_alloc(int(self.in_splits[r + 1] - self.in_splits[r]) * 4)
         assert c.points_cells_begin(self.xb, self.n, self.d, np.float32, self.in_splits[r], self.in_splits[r + 1], own)
@@ -72,8 +77,45 @@ class SimulatedRanks:
         if self.splits is None:
             self.splits = splits
         assert np.array_equal(splits, self.splits), "the ranks disagree on the row blocks"
-        used = c.graph_shard_local(self.params, self.world, r, splits)
+        return splits, c.graph_shard_local(self.params, self.world, r, splits)
+
+    def _bandwidth_half(self, r, splits):
+        """first half of rank r's graph_begin -> its bandwidths (host), or None where the tail does not apply"""
+        c = self.ctx
+        nloc = int(splits[r + 1] - splits[r])
+        buf = c.dev_alloc(nloc * 8)
+        ok = c.graph_bandwidth_local(self.params, self.world, r, splits, buf)
+        bw = None
+        if ok:
+            bw = np.empty(nloc, dtype=np.float64)
+            c.sync()
+            c.dev_download(bw, buf)
+        c.dev_free(buf)
+        return bw
+
+    def gather_bandwidths(self):
+        """every rank once up to its bandwidths: what the all-gather between the halves of graph_begin delivers"""
+        parts = []
+        for r in range(self.world):
+            splits, _ = self.until_tables(r)
+            parts.append(self._bandwidth_half(r, splits))
+        answers = [p is not None for p in parts]
+        assert all(answers) or not any(answers), "the ranks disagree on the pair-resolved tail: %r" % (answers,)
+        self.pairs = all(answers)
+        self.bw_all = np.concatenate(parts) if self.pairs else None
+
+    def until_emit(self, r):
+        """... + affinities + triplet emit of rank r -> (send counts, host triplets)"""
+        c = self.ctx
+        splits, used = self.until_tables(r)
+        if self.pairs:
+            assert self._bandwidth_half(r, splits) is not None
+            bwb = c.dev_alloc(self.n * 8)
+            c.dev_upload(bwb, self.bw_all)
+            c.graph_set_bandwidths(bwb)
         sc = c.graph_begin(self.params, self.world, r, splits)
+        if self.pairs:
+            c.dev_free(bwb)
         total = int(sc.sum())
         host = np.zeros(total, dtype=TRIP)
         if total:
@@ -85,6 +127,8 @@ class SimulatedRanks:
 
     def exchange(self):
         """every rank once -> what each rank receives (the all-to-all, by hand)"""
+        if self.want_pairs and self.bw_all is None and hasattr(self.ctx, "graph_bandwidth_local"):
+            self.gather_bandwidths()
         sends, counts = [], []
         for r in range(self.world):
             sc, host, used = self.until_emit(r)
@@ -151,6 +195,7 @@ def test_c3_sharded_over_eight_ranks_reproduces_the_reference_at_full_size():
     try:
         recv = sim.exchange()
         assert all(sim.used), "the local candidate pass did not apply on every rank: %r" % (sim.used,)
+        assert sim.pairs, "the ranks did not take the pair-resolved tail"
         parts, deg = [], np.empty(n)
         for r in range(world):
             c, nnz_r = sim.finish(r, recv[r])

@@ -39,8 +39,10 @@ def _exchange(sends, counts, world):
     return out
 
 
-def sharded_local_build(X, world, pargs, opts=None, want_local=True):
-    """-> (K csr, P csr in the caller's numbering, per-rank flags 'the local lists were used', stats)"""
+def sharded_local_build(X, world, pargs, opts=None, want_local=True, pairs=True):
+    """-> (K csr, P csr in the caller's numbering, per-rank flags 'the local lists were used', stats)
+    pairs: the ranks take the pair-resolved tail where the library offers it (the all-gather of the bandwidths between the
+    halves of gt_graph_begin is played by hand); sharded_local_build.pairs_used says whether they did"""
     from graphtools_amd import _hip
 
     n = X.shape[0]
@@ -55,6 +57,31 @@ def sharded_local_build(X, world, pargs, opts=None, want_local=True):
     for c in ctxs[1:]:
         assert np.array_equal(c.points_shard_splits(world), splits)
     used = [c.graph_shard_local(p, world, r, splits) for r, c in enumerate(ctxs)]
+    sharded_local_build.pairs_used = False
+    bw_bufs = []
+    if pairs:
+        parts = []
+        for r, c in enumerate(ctxs):
+            nloc = int(splits[r + 1] - splits[r])
+            buf = c.dev_alloc(max(nloc, 1) * 8)
+            ok = c.graph_bandwidth_local(p, world, r, splits, buf)
+            bw = np.empty(nloc, dtype=np.float64)
+            if ok:
+                c.sync()
+                c.dev_download(bw, buf)
+            c.dev_free(buf)
+            parts.append(bw if ok else None)
+        answers = [q is not None for q in parts]
+        assert all(answers) or not any(answers), "the ranks disagree on the pair-resolved tail: %r" % (answers,)
+        if all(answers):
+            bw_all = np.concatenate(parts)
+            assert len(bw_all) == n and np.all(bw_all > 0)
+            for c in ctxs:
+                b = c.dev_alloc(n * 8)
+                c.dev_upload(b, bw_all)
+                c.graph_set_bandwidths(b)
+                bw_bufs.append((c, b))
+            sharded_local_build.pairs_used = True
     sends, counts = [], []
     for r, c in enumerate(ctxs):
         cnt = c.graph_begin(p, world, r, splits)
@@ -68,6 +95,9 @@ def sharded_local_build(X, world, pargs, opts=None, want_local=True):
             c.dev_free(buf)
         sends.append(host)
         counts.append(cnt)
+    for c, b in bw_bufs:
+        c.dev_free(b)
+    sharded_local_build.triplets = int(sum(int(cnt.sum()) for cnt in counts))
     rows_all, blocks_K, blocks_P, stats = [], [], [], []
     for r, (c, recv) in enumerate(zip(ctxs, _exchange(sends, counts, world))):
         assert np.all((recv["row"] >= splits[r]) & (recv["row"] < splits[r + 1]))
@@ -461,4 +491,86 @@ def test_split_cell_assignment_gives_the_same_numbering():
     p, keep = c.make_params(5, 20, 1e-4, None, 1.0, None, "+", None, 0)
     nnz, _ = c.graph_build(p)
     assert nnz > 0
+    c.close()
+
+
+# ---- the pair-resolved tail on the ranks of a sharded build (round 6: gt_graph_bandwidth_local / gt_graph_set_bandwidths) --------
+
+
+@pytest.mark.parametrize("maker,n,d,world,knn,decay,thresh", [
+    (make_mix, 30000, 64, 3, 12, 30, 1e-4),      # tables with transposed keys on every rank
+    (make_mix, 20000, 8, 2, 10, 4, 1e-4),        # radii that reach past the tables: rows of the radius pass, long union rows
+    (make_gauss, 20000, 24, 2, 8, 30, 1e-4),     # isotropic: the ranks fall to the classic pass - keys from the dot products
+    (make_manifold, 40000, 32, 4, 15, 40, 1e-4),
+])
+def test_pair_resolved_tail_on_sharded_ranks_equals_the_general_tail_and_the_single_rank_build(maker, n, d, world, knn, decay, thresh):
+    """'+' rule: every rank settles its mutual pairs itself with the gathered bandwidths, only one-sided entries travel, the
+    union rows are sorted once and written straight into the CSR.  K and P equal the general tail's (every kept entry travels,
+    union rows merged) and the single-rank build's bit for bit; fewer triplets cross."""
+    X = maker(n, d, 11)
+    pargs = (knn, decay, thresh, None, 1.0, None, "+", None, 0)
+    K1, P1 = single_build(X, pargs)
+    K, P, used, stats = sharded_local_build(X, world, pargs)
+    assert sharded_local_build.pairs_used, "the ranks did not take the pair-resolved tail"
+    sent = sharded_local_build.triplets
+    _same(K, K1)
+    _same(P, P1)
+    Kg, Pg, _, stats_g = sharded_local_build(X, world, pargs, pairs=False)
+    assert not sharded_local_build.pairs_used
+    _same(Kg, K1)
+    _same(Pg, P1)
+    # the general tail sends every kept entry (nnz of the unsymmetrised kernel), this one the one-sided entries only:
+    # K's entries = mutual pairs counted once per side + one-sided entries counted on both sides
+    sent_g = sharded_local_build.triplets
+    assert sent < sent_g and K1.nnz == sent_g + sent, (sent, sent_g, K1.nnz)
+    print("triplets: %d one-sided of %d kept (%.0f %%)" % (sent, sent_g, 100.0 * sent / sent_g))
+
+
+def test_pair_resolved_tail_is_an_option_and_only_serves_the_plus_rule():
+    X = make_mix(20000, 32, 12)
+    for symm, opts, want in (("+", {}, True), ("+", {"symmetrize_pairs_shard": 0}, False), ("+", {"symmetrize_pairs": 0}, False),
+                             ("*", {}, False), (None, {}, False)):
+        pargs = (10, 20, 1e-4, None, 1.0, None, symm, None, 0)
+        K, P, used, _ = sharded_local_build(X, 2, pargs, opts=opts)
+        assert sharded_local_build.pairs_used == want, (symm, opts)
+        K1, P1 = single_build(X, pargs)
+        _same(K, K1)
+        _same(P, P1)
+
+
+def test_pair_resolved_tail_with_a_bandwidth_per_row_and_a_rank_that_declines_its_local_pass():
+    """the caller's bandwidths (by the caller's row numbers) reach the partners through the gather like the derived ones; a
+    rank whose tables came from the classic pass forms the transposed keys from the dot products while its peers read theirs"""
+    X = make_mix(24000, 64, 7)
+    bw = np.random.default_rng(8).uniform(5.5, 7.5, size=X.shape[0])
+    pargs = (12, 30, 1e-4, bw, 1.0, None, "+", None, 0)
+    K1, P1 = single_build(X, pargs)
+    K, P, used, _ = sharded_local_build(X, 3, pargs, opts=[{}, {"select_sym_two_stage": 0}, {}])
+    assert sharded_local_build.pairs_used and used == [True, False, True]
+    _same(K, K1)
+    _same(P, P1)
+
+
+def test_begin_after_a_bandwidth_half_must_be_the_same_build():
+    from graphtools_amd import _hip
+
+    X = make_mix(16000, 32, 3)
+    c = _ctx({})
+    c.set_points(X)
+    assert c.points_cell_sort()
+    p, keep = c.make_params(10, 20, 1e-4, None, 1.0, None, "+", None, 0)
+    q, keep_q = c.make_params(11, 20, 1e-4, None, 1.0, None, "+", None, 0)
+    splits = c.points_shard_splits(2)
+    nloc = int(splits[1] - splits[0])
+    buf = c.dev_alloc(nloc * 8)
+    with pytest.raises(_hip.HipError):
+        c.graph_set_bandwidths(buf)                      # nothing is half begun
+    c.graph_shard_local(p, 2, 0, splits)
+    assert c.graph_bandwidth_local(p, 2, 0, splits, buf)
+    with pytest.raises(_hip.HipError):
+        c.graph_begin(q, 2, 0, splits)                   # other parameters
+    # (the refused call ended the half-begun build: a begin from the start is what follows, the general way)
+    cnt = c.graph_begin(p, 2, 0, splits)
+    assert int(cnt.sum()) > 0
+    c.dev_free(buf)
     c.close()

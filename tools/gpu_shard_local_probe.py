@@ -63,8 +63,13 @@ if split_assign:
         assert ok, "no cell order for these points"
 
 
-def rank_until_emit(r, timed=False):
-    """set_points .. emit for rank r; -> (send_counts, device buffer of the triplets, wall ms by phase, stage ms, used)"""
+want_pairs = os.environ.get("GT_PAIRS", "1") != "0"   # the pair-resolved tail on the ranks (gt_graph_bandwidth_local), where it applies
+bw_all_dev = None                                      # the bandwidths of all rows: what the all-gather between the halves delivers
+
+
+def rank_until_emit(r, timed=False, only_bandwidths=False):
+    """set_points .. emit for rank r; -> (send_counts, device buffer of the triplets, wall ms by phase, stage ms, used)
+    only_bandwidths: stop after the first half of graph_begin -> the rank's bandwidths (host), None where the tail does not apply"""
     ctx.sync()
     t0 = time.perf_counter()
     if split_assign:
@@ -85,9 +90,25 @@ def rank_until_emit(r, timed=False):
     used = ctx.graph_shard_local(p, world, r, splits)
     ctx.sync()
     t2 = time.perf_counter()
+    if only_bandwidths or bw_all_dev is not None:
+        nloc = int(splits[r + 1] - splits[r])
+        bwb = ctx.dev_alloc(max(nloc, 1) * 8)
+        ok = ctx.graph_bandwidth_local(p, world, r, splits, bwb)
+        if only_bandwidths:
+            bw = None
+            if ok:
+                bw = np.empty(nloc, dtype=np.float64)
+                ctx.sync()
+                ctx.dev_download(bw, bwb)
+            ctx.dev_free(bwb)
+            return bw
+        assert ok
+        ctx.graph_set_bandwidths(bw_all_dev)   # (the all-gather itself is not in the time: 8 B per row, listed below)
     sc = ctx.graph_begin(p, world, r, splits)
     ctx.sync()
     t3 = time.perf_counter()
+    if bw_all_dev is not None:
+        ctx.dev_free(bwb)
     buf = ctx.dev_alloc(max(int(sc.sum()), 1) * 16)
     ctx.graph_emit(buf)
     ctx.sync()
@@ -99,6 +120,15 @@ def rank_until_emit(r, timed=False):
         st[s] = max(v, 0.0)
     return sc, buf, wall, st, used, applied, splits
 
+
+if want_pairs and hasattr(ctx, "graph_bandwidth_local"):
+    parts = [rank_until_emit(r, only_bandwidths=True) for r in range(world)]
+    if all(q is not None for q in parts):
+        bw_host = np.concatenate(parts)
+        bw_all_dev = ctx.dev_alloc(n * 8)
+        ctx.dev_upload(bw_all_dev, bw_host)
+    else:
+        assert not any(q is not None for q in parts), "the ranks disagree on the pair-resolved tail"
 
 # every rank once: what rank `who` will receive
 recv_parts, send_totals, used_all = [], [], []
@@ -171,6 +201,7 @@ out = {
             "rank in turn; the collectives are NOT in the time, their sizes are below)",
     "workload": "%s N=%d d=%d float32 seed=1, knn=15 decay=40 thresh=1e-4, world %d, rank %d (%d rows)" % (kind, n, d, world, who, rows_who),
     "renumbering_applied": bool(applied), "local_lists_used_by_rank": used_all,
+    "pair_resolved_tail": bw_all_dev is not None,
     "single_rank_ms": round(single_ms, 3), "single_rank_stage_ms": single_stage, "nnz_single": int(nnz1),
     "per_rank": best, "per_rank_all_runs_total_ms": [r["wall_ms"]["total"] for r in runs],
     "speedup_before_collectives": round(single_ms / best["wall_ms"]["total"], 2),
@@ -182,7 +213,8 @@ out = {
         "all_to_all_triplets_bytes_received_by_rank": int(len(recv)) * 16,
         "candidate_record_exchange_bytes": 0,
         "threshold_all_gather_bytes": 0,
-        "number_of_collectives": (4 if split_assign else 3) + (2 if kind == "c5" else 0),
+        "all_gather_bandwidths_bytes_total": int(8 * n) if bw_all_dev is not None else 0,
+        "number_of_collectives": (4 if split_assign else 3) + (2 if kind == "c5" else 0) + (1 if bw_all_dev is not None else 0),
         "all_gather_labels_bytes_total": int(4 * n) if kind == "c5" else 0,
         "all_reduce_landmark_bytes": int(8 * (n_landmark * n_landmark + n_landmark)) if kind == "c5" else 0,
     },
