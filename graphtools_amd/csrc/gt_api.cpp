@@ -98,7 +98,7 @@ void gt_ctx_destroy(gt_ctx* ctx) {
     ctx->dense_degree.release();
     ctx->dense_bw.release();
     ctx->X_norm.release();
-    for (DevBuf* b : {&ctx->land_Y, &ctx->land_h, &ctx->order_cell, &ctx->order_rows, &ctx->order_tmp, &ctx->vperm, &ctx->vcell, &ctx->land_X, &ctx->land_Yp, &ctx->land_xn}) b->release();
+    for (DevBuf* b : {&ctx->land_Y, &ctx->land_h, &ctx->order_cell, &ctx->order_rows, &ctx->order_tmp, &ctx->vperm, &ctx->vcell, &ctx->land_X, &ctx->land_Yp, &ctx->land_xn, &ctx->land_ord}) b->release();
     if (ctx->mail) (void)hipHostFree(ctx->mail);
     if (ctx->side_event) (void)hipEventDestroy(ctx->side_event);
     if (ctx->side_stream) {
@@ -278,6 +278,10 @@ int gt_set_option(gt_ctx* ctx, const char* name, const char* value) {
     }
     if (k == "symmetrize_pairs_huge") {
         ctx->symm_pair_huge = std::atoi(value) != 0 ? 1 : 0;
+        return GT_OK;
+    }
+    if (k == "query_order_coherent") {
+        ctx->order_coherent = std::atoi(value) != 0 ? 1 : 0;
         return GT_OK;
     }
     if (k == "query_order_outliers") {

@@ -229,6 +229,7 @@ extern "C" int gt_dbg_fetch_sym(gt_ctx* ctx, int32_t which, int64_t count, void*
         case 14: src = k->sym_zc.p; break;     // unit skipping of the two-stage collect: centres [n_pad / 32][16] (float)
         case 15: src = k->sym_zrn.p; break;    //   {radius, need} [n_pad / 32][2] (float)
         case 13: src = k->cand_n.p; break;     // entries of every exact table (by slot in builds with the tables by sorted position)
+        case 16: src = k->lists.p; esz = 8; break;   // rows launch A kept: uint64 keys [n_pad][64] (cand_index = sorted position)
         case 7: src = k->sym_work.p; break;    // nbr [L][M] | start [L] | end [L]   // [blocks][tile_stride] tile lists of launch A (count = entries)
         default: return GT_E_ARG;
     }

@@ -72,6 +72,9 @@ struct GraphState {
     DevBuf bw_all;               // float64 [n_total]: the bandwidths of all rows, gathered by the caller
     bool bw_all_valid = false;   // ... handed over for the build that is half begun
     bool pairs_shard = false;    // this rank settles its mutual pairs with bw_all; only one-sided entries travel (graph_finish_pairs_shard)
+    bool pairs_shard_bins = false;   // ... and its local one-sided entries go through its own destination bins (every row a table row):
+                                     //     posj (cursor) by sC, bincnt filled; only entries for OTHER ranks' rows are emitted
+    DevBuf colid;                // int32 [nloc]: the caller's number of every local row (the column it is in its partners' rows)
     DevBuf ident;                // int32 [nloc]: 0 ... nloc - 1 (a shard's rows are their own positions: FusedSrc::pos)
     bool relabelled = false;   // the CSR's columns are the caller's row numbers of a renumbered point set (rows: gt_points_row_ids)
     int64_t nnz0 = 0, nnz = 0;

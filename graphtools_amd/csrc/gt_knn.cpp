@@ -276,11 +276,15 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
             k->keyt_valid = wrote_t;
             k->nokeyt_n = 0;
             uint32_t n_unproven = 0;
-            if (wrote_t) GT_HIP(ctx, hipMemcpyAsync(&k->nokeyt_n, k->nokeyt_count.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-            GT_HIP(ctx, hipMemcpyAsync(&n_fb, k->fb_count.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-            GT_HIP(ctx, hipMemcpyAsync(&n_unproven, k->unproven.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-            GT_HIP(ctx, hipMemcpyAsync(k->sym_stat_host, k->sym_stat.p, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
-            GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            {
+                // (one group through the pinned mailbox: four copies into pageable memory were four staged round trips, ~18 us each)
+                ReadBack rb(ctx);
+                if (wrote_t) GT_HIP(ctx, rb.add(&k->nokeyt_n, k->nokeyt_count.p, sizeof(uint32_t)));
+                GT_HIP(ctx, rb.add(&n_fb, k->fb_count.p, sizeof(uint32_t)));
+                GT_HIP(ctx, rb.add(&n_unproven, k->unproven.p, sizeof(uint32_t)));
+                GT_HIP(ctx, rb.add(k->sym_stat_host, k->sym_stat.p, 8 * sizeof(unsigned long long)));
+                GT_HIP(ctx, rb.sync());
+            }
             k->sym_overflow = int64_t(k->sym_stat_host[0]);
             k->sym_used = true;
             ctx->last_main_prec = 2;
@@ -394,7 +398,7 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
                     GT_TRY(gt_sym_thresholds(ctx, perm, n_pad_s, k->hnegs.as<float>(), k->lists.as<uint64_t>(), seed_lstride,
                                              k->counts.as<uint32_t>(), need_m, em, rkf, k->thr_final.as<float>(),
                                              k->sym_g.as<float>(), nullptr, k->sym_work, ctx->sym_cells,
-                                             k->sym_stat.as<unsigned long long>() + 2, k->sym_farcnt.as<float>(), 0, ps));
+                                             k->sym_stat.as<unsigned long long>() + 2, k->sym_farcnt.as<float>(), 0, ps, true));
                     GT_HIP(ctx, hipMemcpyAsync(&far_s, k->sym_stat.as<unsigned long long>() + 2, sizeof(far_s), hipMemcpyDeviceToHost,
                                                ctx->stream));
                     GT_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -226,7 +226,7 @@ int gt_sym_gather_points(gt_ctx* ctx, const int32_t* perm, bool pad4 = false);
 int gt_sym_thresholds(gt_ctx* ctx, const int32_t* perm, int64_t n_pad_s, const float* hs, const uint64_t* lists, int lstride,
                       const uint32_t* counts, int need_m, const ErrModel& err, double rkf, float* thr, float* g, float* gmin,
                       const DevBuf& work, int cells, unsigned long long* far_total, float* farcnt = nullptr,
-                      int64_t p_first = 0, int64_t p_last = -1);
+                      int64_t p_first = 0, int64_t p_last = -1, bool sample = false);
 // two-stage scoring of launch B: half seeds of the sorted rows, partial-distance thresholds from the full ones
 // stage-one copy of the two-stage collect: Z [n_pad][16] float16 = scz x P x (P_dev [16][64], orthonormal rows) in sorted
 // order, hh = its half seeds; sample covariance for the principal frame

@@ -264,7 +264,7 @@ int gt_knn_shard_local(gt_ctx* ctx, int64_t r0, int64_t r1, int need_m, double r
             GT_TRY(gt_sym_thresholds(ctx, perm, n_pad_s, k->hnegs.as<float>(), lists0, 64, k->counts.as<uint32_t>(), need_m, em,
                                      std::max(1.0, std::fabs(rkf)), k->thr_final.as<float>(), k->sym_g.as<float>(), nullptr,
                                      k->sym_work, shard_cells(ctx), k->sym_stat.as<unsigned long long>() + 2,
-                                     k->sym_farcnt.as<float>(), p0, p0 + ps));
+                                     k->sym_farcnt.as<float>(), p0, p0 + ps, true));
             GT_HIP(ctx, hipMemcpyAsync(&far_s, k->sym_stat.as<unsigned long long>() + 2, sizeof(far_s), hipMemcpyDeviceToHost, ctx->stream));
             GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
         }

@@ -43,6 +43,26 @@ __global__ __launch_bounds__(256) void gather_strided_rows_kernel(const uint32_t
     out[f] = X[(f / rw) * step * rw + f % rw];
 }
 
+// rows lidx[l] * step of the compact copy (and their seeds) as landmark l
+__global__ __launch_bounds__(256) void gather_landmarks_idx_kernel(const uint32_t* __restrict__ Yc, const float* __restrict__ hneg,
+                                                                   const int32_t* __restrict__ lidx, const int64_t step, const int L,
+                                                                   const int rw, uint32_t* __restrict__ Yl, float* __restrict__ hl) {
+    const int64_t f = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (f >= int64_t(L) * rw) return;
+    const int64_t l = f / rw;
+    const int c = int(f % rw);
+    const int64_t row = int64_t(lidx[l]) * step;
+    Yl[f] = Yc[row * rw + c];
+    if (c == 0) hl[l] = hneg[row];
+}
+__global__ __launch_bounds__(256) void gather_strided_rows_idx_kernel(const uint32_t* __restrict__ X, const int32_t* __restrict__ lidx,
+                                                                      const int64_t step, const int L, const int rw,
+                                                                      uint32_t* __restrict__ out) {
+    const int64_t f = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (f >= int64_t(L) * rw) return;
+    out[f] = X[int64_t(lidx[f / rw]) * step * rw + f % rw];
+}
+
 // ---- the outlier cell ---------------------------------------------------------------------------------------------------
 // A cell is what the bound pass reasons about: centre, radius (its farthest member), the largest collection radius of its
 // rows.  ONE row far from every landmark - an isolated point, a point half way between two clusters - inflates the ball of the
@@ -115,6 +135,59 @@ __global__ __launch_bounds__(256) void outlier_relabel_kernel(const int64_t nq, 
 
 }  // namespace
 
+// ---- a COHERENT order of the cells -----------------------------------------------------------------------------------------
+// The landmarks are evenly strided rows: in the caller's row order, i.e. in no order at all - cell c and cell c + 1 of the sorted
+// points have nothing to do with each other, and the eight or so cells that share a cluster (or a patch of a manifold) lie
+// anywhere in the order.  Every pass that walks the sorted rows pays for that: the exact stages gather a row's candidates from
+// eight places (each new cell of a walk brings a new half megabyte into the L2 instead of finding its cluster's there), and a rank
+// of a row-sharded build - a run of whole cells - owns an eighth of EVERY cluster: six in ten of its one-sided entries pointed
+// at other ranks' rows (C3, world 8).  So the landmarks themselves are put in an order in which neighbours in space are
+// neighbours in number: every S-th landmark is a "super" landmark (S = L / 8: a super cell is about a cluster's worth), every
+// landmark goes to its nearest super (the assignment kernel, L rows against S), and the landmarks are sorted by super, stably.
+// lidx_out[l']: the strided landmark that becomes landmark l'.  Cheap (L <= 8192 rows), deterministic (every rank of a sharded
+// build computes the same order from the same rows), and any order is correct: cells only group.
+static int coherent_landmark_order(gt_ctx* ctx, const int L, const int rw, const uint32_t* Yl, const float* hl, int32_t** lidx_out) {
+    *lidx_out = nullptr;
+    if (ctx->order_coherent == 0 || L < 256) return GT_OK;
+    // Only where launch A of the symmetric pass scores a strided sample of the far tiles (gt_knn.cpp stride_a: from 8 x sym_stride
+    // tiles, ~8e5 rows).  Below that the one early sign of a point set whose cells say nothing (half the points in one blob: any
+    // cell of the blob serves a row as well as the cells around it) is that a query block's OTHER cells - strangers, in the
+    // landmarks' own order - contribute as many seeds as the row's own neighbourhood; numbered coherently the block's other
+    // cells are neighbours, the sign is gone, and the pass was abandoned only after its lists had overflowed (tests/
+    // test_gpu_ladder.py, N = 2e5: 44 ms against 34).  The sets the order is for - a million rows and more - have the sample.
+    if (ctx->sym_stride <= 0 || ctx->n / gt_select_bn(ctx->DP) < int64_t(8) * ctx->sym_stride) return GT_OK;
+    const int S = std::max(32, (L / 8) / 32 * 32);
+    const int sstep = L / S;
+    int bits = 1;
+    while ((1 << bits) < S) ++bits;
+    size_t sort_bytes = 0;
+    GT_HIP(ctx, rocprim::radix_sort_pairs(nullptr, sort_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr,
+                                          size_t(L), 0u, unsigned(bits), ctx->stream));
+    // one buffer: super rows | super seeds | super of every landmark (in, sorted) | thresholds (unused) | iota | order | sort scratch
+    const size_t o_sy = 0, o_sh = o_sy + size_t(S) * rw * 4, o_k0 = o_sh + size_t(S) * 4, o_k1 = o_k0 + size_t(L) * 4,
+                 o_thr = o_k1 + size_t(L) * 4, o_io = o_thr + size_t(L) * 4, o_ix = o_io + size_t(L) * 4,
+                 o_tmp = (o_ix + size_t(L) * 4 + 255) & ~size_t(255);
+    GT_HIP(ctx, ctx->land_ord.reserve(o_tmp + sort_bytes + 256));
+    char* base = static_cast<char*>(ctx->land_ord.p);
+    uint32_t* sup_Y = reinterpret_cast<uint32_t*>(base + o_sy);
+    float* sup_h = reinterpret_cast<float*>(base + o_sh);
+    uint32_t* k0 = reinterpret_cast<uint32_t*>(base + o_k0);
+    uint32_t* k1 = reinterpret_cast<uint32_t*>(base + o_k1);
+    float* thr = reinterpret_cast<float*>(base + o_thr);
+    int32_t* io = reinterpret_cast<int32_t*>(base + o_io);
+    int32_t* ix = reinterpret_cast<int32_t*>(base + o_ix);
+    hipLaunchKernelGGL(gather_landmarks_kernel, dim3((unsigned)ceil_div64(int64_t(S) * rw, 256)), dim3(256), 0, ctx->stream, Yl, hl,
+                       int64_t(sstep), S, rw, sup_Y, sup_h);
+    GT_HIP(ctx, hipGetLastError());
+    GT_TRY(gt_launch_assign_cells(ctx, ctx->DP, reinterpret_cast<const float*>(Yl), reinterpret_cast<const float*>(sup_Y), sup_h, 0,
+                                  int32_t(L), S, 1, k0, thr, nullptr));
+    hipLaunchKernelGGL(iota_rows_kernel, dim3((unsigned)ceil_div64(L, 256)), dim3(256), 0, ctx->stream, int64_t(0), int64_t(L), io);
+    GT_HIP(ctx, hipGetLastError());
+    GT_HIP(ctx, rocprim::radix_sort_pairs(base + o_tmp, sort_bytes, k0, k1, io, ix, size_t(L), 0u, unsigned(bits), ctx->stream));
+    *lidx_out = ix;
+    return GT_OK;
+}
+
 // number of landmark cells of a point set of n rows (0: too few rows for a cell order)
 static int order_cells_of(const gt_ctx* ctx, int64_t n) {
     return int(std::min<int64_t>(std::min<int64_t>(8192, n / 32 * 32), std::max<int64_t>(64, (n / std::max(ctx->order_cell_rows, 32)) / 32 * 32)));
@@ -148,6 +221,18 @@ int gt_order_cells_partial(gt_ctx* ctx, int64_t row0, int64_t row1, uint32_t* ce
     GT_HIP(ctx, hipGetLastError());
     GT_TRY(gt_prep_matrix(ctx, ctx->land_X.p, L, ctx->d, ctx->dtype, ctx->DP, L, ctx->land_Yp.as<float>(), ctx->land_xn.as<double>(),
                           ctx->land_h.as<float>(), nullptr, 1, ctx->sc, nullptr, ctx->land_Y.p));
+    {
+        // the landmarks in a coherent order (above): the same rows, renumbered - gathered and prepared again in that order
+        int32_t* lidx = nullptr;
+        GT_TRY(coherent_landmark_order(ctx, L, rw, ctx->land_Y.as<uint32_t>(), ctx->land_h.as<float>(), &lidx));
+        if (lidx) {
+            hipLaunchKernelGGL(gather_strided_rows_idx_kernel, dim3((unsigned)ceil_div64(int64_t(L) * rw_raw, 256)), dim3(256), 0,
+                               ctx->stream, static_cast<const uint32_t*>(ctx->X), lidx, step, L, rw_raw, ctx->land_X.as<uint32_t>());
+            GT_HIP(ctx, hipGetLastError());
+            GT_TRY(gt_prep_matrix(ctx, ctx->land_X.p, L, ctx->d, ctx->dtype, ctx->DP, L, ctx->land_Yp.as<float>(),
+                                  ctx->land_xn.as<double>(), ctx->land_h.as<float>(), nullptr, 1, ctx->sc, nullptr, ctx->land_Y.p));
+        }
+    }
     if (nloc > 0) {
         // working copy of the share, at the head of the context's own buffers (the full copy overwrites it later)
         const int bn = ctx->DP <= 64 ? 128 : 64;
@@ -262,6 +347,17 @@ int gt_query_order(gt_ctx* ctx, const float* Qc, int64_t q0, int64_t nq, int nee
                        ctx->Yc.as<uint32_t>(), ctx->hneg.as<float>(), step, L, rw, ctx->land_Y.as<uint32_t>(),
                        ctx->land_h.as<float>());
     GT_HIP(ctx, hipGetLastError());
+    if (!few_points) {
+        // ... in a coherent order (coherent_landmark_order): the same rows, renumbered
+        int32_t* lidx = nullptr;
+        GT_TRY(coherent_landmark_order(ctx, L, rw, ctx->land_Y.as<uint32_t>(), ctx->land_h.as<float>(), &lidx));
+        if (lidx) {
+            hipLaunchKernelGGL(gather_landmarks_idx_kernel, dim3((unsigned)ceil_div64(int64_t(L) * rw, 256)), dim3(256), 0, ctx->stream,
+                               ctx->Yc.as<uint32_t>(), ctx->hneg.as<float>(), lidx, step, L, rw, ctx->land_Y.as<uint32_t>(),
+                               ctx->land_h.as<float>());
+            GT_HIP(ctx, hipGetLastError());
+        }
+    }
     uint32_t* cell = ctx->order_cell.as<uint32_t>();
     uint32_t* cell_sorted = cell + nq;
     // the outlier cell (above): for the rows of the bound point set (their seeds -|x|^2 / 2 are at hand)

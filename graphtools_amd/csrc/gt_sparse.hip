@@ -204,10 +204,12 @@ __global__ __launch_bounds__(256) void affinity_kernel(
     int32_t* __restrict__ lenN, int32_t* __restrict__ ownercnt, int32_t* __restrict__ tablen,
     const int pairs, const double* __restrict__ cand_d2t, const uint8_t* __restrict__ keyt_ok, const double rf_guard,
     const int32_t* __restrict__ tperm, const int32_t* __restrict__ trow, uint32_t* __restrict__ posj,
-    const int64_t* __restrict__ sC, int32_t* __restrict__ lenN_s, const int64_t bw_i0) {
+    const int64_t* __restrict__ sC, int32_t* __restrict__ lenN_s, const int64_t bw_i0, const int self_rank) {
     // bw_i0: where this launch's row 0 sits in bw (0: bw holds the launch's rows - one rank; r0: bw holds the bandwidths of ALL
     // rows, gathered over the ranks - the pair-resolved tail of a row-sharded build, `pairs` = 2: partners j are global rows, and
-    // only the entries that TRAVEL - the one-sided ones, stored non-negative - are counted per owner)
+    // only the entries that TRAVEL - the one-sided ones, stored non-negative - are counted per owner; `pairs` = 3: ... and of those
+    // only the ones whose partner lives on ANOTHER rank (self_rank: this one) - the local ones go through the rank's own
+    // destination bins, their destination - the partner's local row - noted in posj like the single-rank build's)
     // posj / sC (with trow, table rows): the destinations of the pair-resolved tail are looked up here (see
     // affinity_slots_kernel: this launch serves the few rows whose tables came from a repair pass)
     // tperm / trow (KnnWork::tab_sorted): the tables lie by sorted position - tperm: slot -> row, for the launch over all the
@@ -284,13 +286,16 @@ __global__ __launch_bounds__(256) void affinity_kernel(
                 cand_d2[ti * MP + slot] = kvv;
                 if (slot != e) cand_j_w[ti * MP + slot] = j;
                 if (posj) {
-                    const uint32_t pj = uint32_t(trow[j]);
+                    // (tables by sorted position: the partner's; a rank of a sharded build: the partner's local row, if it has one)
+                    const int64_t jl = int64_t(j) - r0;
+                    const uint32_t pj = trow ? uint32_t(trow[j]) : ((jl >= 0 && jl < nloc) ? uint32_t(jl) : kNoDest);
                     posj[sC[ti] + slot] = kvv >= 0.0 ? pj : kNoDest;
                 }
             }
             kept += __popcll(km);
             if (count_owners) {
-                const int o = (keep && (pairs != 2 || kvv >= 0.0)) ? owner_of(sp, j) : -1;
+                int o = (keep && (pairs < 2 || kvv >= 0.0)) ? owner_of(sp, j) : -1;
+                if (pairs == 3 && o == self_rank) o = -1;
                 for (int r = 0; r < sp.world; ++r) {
                     const int c = __popcll(__ballot(o == r));
                     if (lane == r) owner_cnt += c;
@@ -376,7 +381,8 @@ __global__ __launch_bounds__(256) void affinity_kernel(
             }
             kept += __popcll(km);
             if (count_owners) {
-                const int o = (keep && (pairs != 2 || kvv >= 0.0)) ? owner_of(sp, j) : -1;
+                int o = (keep && (pairs < 2 || kvv >= 0.0)) ? owner_of(sp, j) : -1;
+                if (pairs == 3 && o == self_rank) o = -1;
                 for (int r = 0; r < sp.world; ++r) {
                     const int c = __popcll(__ballot(o == r));
                     if (lane == r) owner_cnt += c;
@@ -568,7 +574,9 @@ __global__ __launch_bounds__(256) void emit_triplets_kernel(
     const int64_t nloc, const int64_t r0, const int MP, const double* __restrict__ cand_k,
     const uint32_t* __restrict__ cand_j, const int32_t* __restrict__ rowsrc, const uint64_t* __restrict__ rlists,
     const uint32_t* __restrict__ rcounts, const int32_t rcap, const double* __restrict__ rK, const Splits sp,
-    const int64_t* __restrict__ ownerpos, const int32_t* __restrict__ tablen, Triplet* __restrict__ out) {
+    const int64_t* __restrict__ ownerpos, const int32_t* __restrict__ tablen, Triplet* __restrict__ out, const int skip_owner) {
+    // skip_owner (-1: none): entries for that rank - this one - do not travel (the pair-resolved tail of a sharded build takes its
+    // local one-sided entries through the rank's own destination bins; the affinity pass counted accordingly)
     const int lane = threadIdx.x & 63;
     const int w = threadIdx.x >> 6;
     const int64_t i = int64_t(blockIdx.x) * 4 + w;
@@ -596,7 +604,8 @@ __global__ __launch_bounds__(256) void emit_triplets_kernel(
             j = (src < 0) ? cand_j[i * MP + e] : cand_index(rlists[size_t(src) * rcap + e]);
         }
         const bool keep = v >= 0.0;
-        const int o = keep ? owner_of(sp, j) : -1;
+        int o = keep ? owner_of(sp, j) : -1;
+        if (o == skip_owner) o = -1;
         for (int r = 0; r < sp.world; ++r) {
             const unsigned long long m = __ballot(o == r);
             if (m == 0ull) continue;
@@ -2131,14 +2140,16 @@ void launch_affinity(gt_ctx* ctx, GraphState* g, KnnWork* k, int binary, double 
                        k->cand_d2.as<double>(), k->cand_j.as<uint32_t>(), k->cand_n.as<uint32_t>(), g->rowsrc.as<int32_t>(), \
                        g->rlists.as<uint64_t>(), g->rcounts.as<uint32_t>(), g->rcap, g->rK.as<double>(),                   \
                        bwp, decay, binary, thresh, count_owners, make_splits(g), g->lenN.as<int32_t>(),                      \
-                       g->ownercnt.as<int32_t>(), g->tablen.as<int32_t>(), g->pairs ? (g->pairs_shard ? 2 : 1) : 0,            \
+                       g->ownercnt.as<int32_t>(), g->tablen.as<int32_t>(), g->pairs ? (g->pairs_shard ? (g->pairs_shard_bins ? 3 : 2) : 1) : 0, \
                        g->pairs ? k->cand_d2t.as<double>() : (const double*)nullptr,                                       \
                        g->pairs ? k->keyt_ok.as<uint8_t>() : (const uint8_t*)nullptr, g->radius_factor * (1.0 + 1e-9),      \
                        tperm, trow, POSJ_, g->sC.as<int64_t>(), k->tab_sorted ? g->cnt_sorted.as<int32_t>() : (int32_t*)nullptr, \
-                       bw_i0)
+                       bw_i0, g->rank)
     // (row-sharded pair-resolved build: the bandwidths of ALL rows, this rank's from row r0 on - gt_graph_set_bandwidths)
     const double* bwp = g->pairs_shard ? g->bw_all.as<double>() : g->bw.as<double>();
     const int64_t bw_i0 = g->pairs_shard ? g->r0 : 0;
+    // (... whose local one-sided entries go through the rank's own destination bins: their destinations by the scan of the tables)
+    uint32_t* shard_posj = g->pairs_shard_bins ? g->cursor.as<uint32_t>() : (uint32_t*)nullptr;
     const int32_t* tperm = k->tab_sorted ? k->qorder.as<int32_t>() : (const int32_t*)nullptr;
     const int32_t* trow = k->tab_sorted ? k->sh_invperm.as<int32_t>() : (const int32_t*)nullptr;
     if (g->pairs && k->tab_sorted) {
@@ -2160,15 +2171,18 @@ void launch_affinity(gt_ctx* ctx, GraphState* g, KnnWork* k, int binary, double 
     } else if (g->pairs && g->pairs_shard && !k->keyt_valid) {
         // (a rank whose rows went through the classic pass: no table carries transposed keys - every kept entry's comes from its
         //  dot product; keyt_ok is all zeros, graph_begin_b)
-        GT_AFFINITY_LAUNCH(false, 2, (const int32_t*)nullptr, g->nloc, (uint32_t*)nullptr);
+        GT_AFFINITY_LAUNCH(false, 2, (const int32_t*)nullptr, g->nloc, shard_posj);
     } else if (g->pairs) {
-        GT_AFFINITY_LAUNCH(false, 1, (const int32_t*)nullptr, g->nloc, (uint32_t*)nullptr);
+        GT_AFFINITY_LAUNCH(false, 1, (const int32_t*)nullptr, g->nloc, shard_posj);
         // (the list holds rows of the query matrix, qoff + i: qoff = 0 on one rank, r0 on a rank of a sharded build)
-        if (k->nokeyt_n > 0) GT_AFFINITY_LAUNCH(false, 2, k->nokeyt_rows.as<int32_t>(), int64_t(k->nokeyt_n), (uint32_t*)nullptr);
+        if (k->nokeyt_n > 0) GT_AFFINITY_LAUNCH(false, 2, k->nokeyt_rows.as<int32_t>(), int64_t(k->nokeyt_n), shard_posj);
     } else {
         GT_AFFINITY_LAUNCH(false, 0, (const int32_t*)nullptr, g->nloc, (uint32_t*)nullptr);
     }
     if (g->n_over > 0) GT_AFFINITY_LAUNCH(true, 0, g->over_rows.as<int32_t>(), g->n_over, (uint32_t*)nullptr);
+    if (g->pairs_shard_bins)
+        hipLaunchKernelGGL(posj_hist_kernel, dim3(2048), dim3(256), size_t(g->bin_count) * sizeof(int32_t), ctx->stream,
+                           g->cursor.as<uint32_t>(), g->sc_total, g->bin_shift, g->bin_count, g->bincnt.as<int32_t>());
 #undef GT_AFFINITY_LAUNCH
 }
 
@@ -2532,7 +2546,11 @@ static int graph_begin_b(gt_ctx* ctx, const gt_knn_params* params, int32_t world
     const double thresh = g->p.thresh;   // (clamped by the first half)
     uint32_t n_over = 0;
     int64_t sc_total = 0;
-    if (k->tab_sorted) {
+    // (a rank of a sharded build about to take the pair-resolved tail: the same scan - its local one-sided entries go through
+    //  destination bins of its own, graph_finish_pairs_shard)
+    const bool shard_pairs_next = g->bw_all_valid && !external && ctx->symm_bins != 0 && shard_pairs_static(ctx, params, g->nloc);
+    const bool scan_tables = k->tab_sorted || shard_pairs_next;
+    if (scan_tables) {
         // (tables by sorted position: the scan of their lengths - where the fused destination count of the affinity pass puts a
         //  row's destinations; the total comes back with the count of the radius rows)
         GT_HIP(ctx, g->sC.reserve(size_t(g->nloc + 1) * sizeof(int64_t)));
@@ -2541,7 +2559,7 @@ static int graph_begin_b(gt_ctx* ctx, const gt_knn_params* params, int32_t world
     }
     {
         ReadBack rb(ctx);
-        if (k->tab_sorted) GT_HIP(ctx, rb.add(&sc_total, g->sC.as<int64_t>() + g->nloc, sizeof(int64_t)));
+        if (scan_tables) GT_HIP(ctx, rb.add(&sc_total, g->sC.as<int64_t>() + g->nloc, sizeof(int64_t)));
         GT_HIP(ctx, rb.add(&n_over, g->over_count.p, sizeof(uint32_t)));
         GT_HIP(ctx, rb.sync());
     }
@@ -2619,12 +2637,31 @@ static int graph_begin_b(gt_ctx* ctx, const gt_knn_params* params, int32_t world
     // transposed keys (classic pass, repaired rows) forms them from the dot products.
     g->pairs_shard = g->bw_all_valid && !external && shard_pairs_static(ctx, params, g->nloc);
     g->bw_all_valid = false;   // (the bandwidths belong to one build)
+    g->pairs_shard_bins = false;
     if (g->pairs_shard) {
         g->pairs = true;
         if (!k->keyt_valid) {
             GT_HIP(ctx, k->keyt_ok.reserve(size_t(g->nloc)));
             GT_HIP(ctx, hipMemsetAsync(k->keyt_ok.p, 0, size_t(g->nloc), ctx->stream));
             k->nokeyt_n = 0;
+        }
+        // Most one-sided entries of a rank point at rows of the SAME rank (it owns whole cells): those stay out of the exchange
+        // and go through destination bins of the rank's own, as on one GPU - the affinity pass notes each one's local
+        // destination row (posj, by the scan of the tables) and counts per owner only what leaves.  Needs every row to be a
+        // table row (no row of the radius pass); else every one-sided entry travels and is placed by atomics.
+        g->pairs_shard_bins = shard_pairs_next && n_over == 0 && sc_total > 0 && sc_total < (int64_t(1) << 31);
+        if (g->pairs_shard_bins) {
+            int shift = 9;
+            if (ctx->symm_bin_shift > 0) shift = ctx->symm_bin_shift;
+            while (ceil_div64(g->nloc, int64_t(1) << shift) > 4096) ++shift;
+            // (a rank's share of the rows is small: bins of 128 rows still give the fill pass, one workgroup per bin, its thousand)
+            while (ctx->symm_bin_shift <= 0 && shift > 7 && ceil_div64(g->nloc, int64_t(1) << shift) < 1024) --shift;
+            g->bin_shift = shift;
+            g->bin_count = int32_t(ceil_div64(g->nloc, int64_t(1) << shift));
+            GT_HIP(ctx, g->bincnt.reserve(size_t(2 * g->bin_count) * sizeof(int32_t)));
+            GT_HIP(ctx, hipMemsetAsync(g->bincnt.p, 0, size_t(2 * g->bin_count) * sizeof(int32_t), ctx->stream));
+            GT_HIP(ctx, g->cursor.reserve(size_t(sc_total) * sizeof(uint32_t)));   // posj, by sC
+            g->sc_total = sc_total;
         }
     }
     if (g->pairs && !g->pairs_shard) {
@@ -2847,7 +2884,8 @@ extern "C" int gt_graph_emit(gt_ctx* ctx, void* send_buf_dev) {
     hipLaunchKernelGGL(emit_triplets_kernel, dim3((unsigned)ceil_div64(g->nloc, 4)), dim3(256), 0, ctx->stream, g->nloc,
                        g->r0, k->MP, k->cand_d2.as<double>(), k->cand_j.as<uint32_t>(), g->rowsrc.as<int32_t>(),
                        g->rlists.as<uint64_t>(), g->rcounts.as<uint32_t>(), g->rcap, g->rK.as<double>(), make_splits(g),
-                       g->ownerpos.as<int64_t>(), g->tablen.as<int32_t>(), (Triplet*)send_buf_dev);
+                       g->ownerpos.as<int64_t>(), g->tablen.as<int32_t>(), (Triplet*)send_buf_dev,
+                       g->pairs_shard_bins ? g->rank : -1);
     GT_HIP(ctx, hipGetLastError());
     GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return GT_OK;
@@ -3437,6 +3475,58 @@ __global__ __launch_bounds__(256) void fill_recv_pairs_kernel(const Triplet* __r
     }
 }
 
+// ... with destination bins of the rank's own (GraphState::pairs_shard_bins): what arrives are the few entries of OTHER ranks' rows -
+// counted per bin, placed behind the local ones by the bins' cursors
+__global__ __launch_bounds__(256) void recv_hist_kernel(const Triplet* __restrict__ recv, const int64_t n_recv, const int64_t r0,
+                                                        const int shift, const int nbins, int32_t* __restrict__ bincnt) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    int32_t* hist = reinterpret_cast<int32_t*>(smem_raw);
+    for (int b = threadIdx.x; b < nbins; b += 256) hist[b] = 0;
+    __syncthreads();
+    for (int64_t t = int64_t(blockIdx.x) * 256 + threadIdx.x; t < n_recv; t += int64_t(gridDim.x) * 256)
+        atomicAdd(&hist[(int64_t(recv[t].row) - r0) >> shift], 1);
+    __syncthreads();
+    for (int b = threadIdx.x; b < nbins; b += 256)
+        if (hist[b] != 0) atomicAdd(&bincnt[b], hist[b]);
+}
+constexpr int kRecvEmitChunk = 8192;   // received triplets per workgroup of recv_bin_emit_kernel
+__global__ __launch_bounds__(256) void recv_bin_emit_kernel(const Triplet* __restrict__ recv, const int64_t n_recv, const int64_t r0,
+                                                            const int shift, const int nbins, const int64_t* __restrict__ binoff,
+                                                            int32_t* __restrict__ bincur, Triplet* __restrict__ out,
+                                                            const int32_t* __restrict__ relabel) {
+    // (as bin_emit_kernel: the workgroup counts its chunk per bin in the LDS, reserves its run inside each bin it touches with
+    //  ONE returning atomic, places through LDS cursors - a global atomic per triplet on a thousand cursors took a millisecond)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    int32_t* hist = reinterpret_cast<int32_t*>(smem_raw);
+    int32_t* base = hist + nbins;
+    for (int b = threadIdx.x; b < nbins; b += 256) hist[b] = 0;
+    __syncthreads();
+    const int64_t t0 = int64_t(blockIdx.x) * kRecvEmitChunk;
+    const int64_t t1 = t0 + kRecvEmitChunk < n_recv ? t0 + kRecvEmitChunk : n_recv;
+    for (int64_t t = t0 + threadIdx.x; t < t1; t += 256) atomicAdd(&hist[(int64_t(recv[t].row) - r0) >> shift], 1);
+    __syncthreads();
+    for (int b = threadIdx.x; b < nbins; b += 256)
+        if (hist[b] != 0) {
+            base[b] = atomicAdd(&bincur[b], hist[b]);
+            hist[b] = 0;
+        }
+    __syncthreads();
+    for (int64_t t = t0 + threadIdx.x; t < t1; t += 256) {
+        Triplet tr = recv[t];
+        const int64_t pl = int64_t(tr.row) - r0;
+        const int b = int(pl >> shift);
+        const int slot = base[b] + atomicAdd(&hist[b], 1);
+        tr.row = uint32_t(pl);                                    // destination: the local row
+        if (relabel) tr.col = uint32_t(relabel[tr.col]);          // column: the caller's number of the sender's row
+        out[binoff[b] + slot] = tr;
+    }
+}
+__global__ __launch_bounds__(256) void caller_rows_kernel(const int64_t nloc, const int64_t r0, const int32_t* __restrict__ relabel,
+                                                          int32_t* __restrict__ out) {
+    const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i < nloc) out[i] = relabel ? relabel[r0 + i] : int32_t(r0 + i);
+}
+
 static int graph_finish_pairs_shard(gt_ctx* ctx, const void* recv_buf_dev, int64_t n_recv, int64_t* out_nnz, uint32_t* flags) {
     GT_HIP(ctx, hipSetDevice(ctx->device));
     GraphState* g = ctx->graph;
@@ -3447,9 +3537,10 @@ static int graph_finish_pairs_shard(gt_ctx* ctx, const void* recv_buf_dev, int64
     const int32_t* relabel = ctx->presorted ? ctx->vperm.as<int32_t>() : nullptr;
     g->relabelled = relabel != nullptr;
     const bool slots = g->n_over == 0;   // every row is a table row: the short rows take merge_pairs_slots_kernel
+    const bool bins = g->pairs_shard_bins;
+    const int64_t recv_cap = std::max<int64_t>(n_recv + (bins ? g->sc_total : 0), 1);   // entries the received halves can hold
     StageSpan span(ctx, "symmetrize");
     GT_HIP(ctx, g->ident.reserve(size_t(nloc) * sizeof(int32_t)));
-    GT_HIP(ctx, g->cursor.reserve(size_t(std::max<int64_t>(n_recv, 1)) * sizeof(int32_t)));   // slot of every received triplet
     GT_HIP(ctx, g->off.reserve(size_t(nloc + 1) * sizeof(int64_t)));
     GT_HIP(ctx, g->pos_sorted.reserve(size_t(nloc + 1) * sizeof(int64_t)));
     GT_HIP(ctx, g->outlen.reserve(size_t(nloc) * sizeof(int32_t)));
@@ -3458,34 +3549,71 @@ static int graph_finish_pairs_shard(gt_ctx* ctx, const void* recv_buf_dev, int64
     GT_HIP(ctx, g->bigcount.reserve(8 * sizeof(uint32_t)));
     GT_HIP(ctx, g->indptr.reserve(size_t(nloc + 1) * sizeof(int64_t)));
     GT_HIP(ctx, g->degree.reserve(size_t(nloc) * sizeof(double)));
-    GT_HIP(ctx, g->ucol.reserve(size_t(std::max<int64_t>(n_recv, 1)) * sizeof(uint32_t)));
-    GT_HIP(ctx, g->uval.reserve(size_t(std::max<int64_t>(n_recv, 1)) * sizeof(double)));
+    GT_HIP(ctx, g->ucol.reserve(size_t(recv_cap) * sizeof(uint32_t)));
+    GT_HIP(ctx, g->uval.reserve(size_t(recv_cap) * sizeof(double)));
     GT_HIP(ctx, hipMemsetAsync(g->bigcount.p, 0, 8 * sizeof(uint32_t), ctx->stream));
-    GT_HIP(ctx, hipMemsetAsync(g->lenT.p, 0, size_t(nloc) * sizeof(int32_t), ctx->stream));
     uint32_t* fflags = g->bigcount.as<uint32_t>() + 2;
     hipLaunchKernelGGL(iota_i32_kernel, dim3((unsigned)ceil_div64(nloc, 256)), dim3(256), 0, ctx->stream, nloc, g->ident.as<int32_t>());
-    if (n_recv > 0) {
-        const int64_t blocks = std::min<int64_t>(ceil_div64(n_recv, 256), 16384);
-        hipLaunchKernelGGL(count_recv_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, recv, n_recv, g->r0,
-                           g->lenT.as<int32_t>(), g->cursor.as<int32_t>());
-    }
-    GT_HIP(ctx, hipGetLastError());
-    // union rows (own + received) and own entries, scanned in row order: off, sN
-    GT_TRY(exclusive_scan(ctx, g->lenN.as<int32_t>(), g->lenT.as<int32_t>(), nloc, g->off.as<int64_t>(), g->scan_tmp));
+    // own entries, scanned in row order: sN (the received half of row p starts at off[p] - sN[p] of ucol / uval)
     GT_TRY(exclusive_scan(ctx, g->lenN.as<int32_t>(), nullptr, nloc, g->pos_sorted.as<int64_t>(), g->scan_tmp));
-    hipLaunchKernelGGL(pairs_len_kernel, dim3((unsigned)ceil_div64(nloc, 256)), dim3(256), 0, ctx->stream, nloc, g->ident.as<int32_t>(),
-                       g->off.as<int64_t>(), g->outlen.as<int32_t>(), g->bigrows.as<int32_t>(), g->bigcount.as<uint32_t>(), fflags,
-                       slots ? g->midrows.as<int32_t>() : (int32_t*)nullptr);
-    GT_HIP(ctx, hipGetLastError());
+    int64_t n_placed = n_recv;   // entries of the received halves
+    if (bins) {
+        StageSpan span_bins(ctx, "symm_bins");
+        const int shift = g->bin_shift, nbins = g->bin_count;
+        GT_HIP(ctx, g->binoff.reserve(size_t(nbins + 1) * sizeof(int64_t)));
+        GT_HIP(ctx, g->selfbuf.reserve(size_t(recv_cap) * sizeof(Triplet)));
+        GT_HIP(ctx, g->colid.reserve(size_t(nloc) * sizeof(int32_t)));
+        hipLaunchKernelGGL(caller_rows_kernel, dim3((unsigned)ceil_div64(nloc, 256)), dim3(256), 0, ctx->stream, nloc, g->r0, relabel,
+                           g->colid.as<int32_t>());
+        if (n_recv > 0) {
+            const int64_t blocks = std::min<int64_t>(ceil_div64(n_recv, 1024), 1024);
+            hipLaunchKernelGGL(recv_hist_kernel, dim3((unsigned)blocks), dim3(256), size_t(nbins) * sizeof(int32_t), ctx->stream, recv,
+                               n_recv, g->r0, shift, nbins, g->bincnt.as<int32_t>());
+        }
+        GT_HIP(ctx, hipGetLastError());
+        GT_TRY(exclusive_scan(ctx, g->bincnt.as<int32_t>(), nullptr, nbins, g->binoff.as<int64_t>(), g->scan_tmp));
+        hipLaunchKernelGGL(bin_emit_slots_kernel, dim3((unsigned)ceil_div64(nloc, kEmitRows)), dim3(256),
+                           size_t(2 * nbins) * sizeof(int32_t), ctx->stream, nloc, k->MP, k->cand_d2.as<double>(),
+                           g->lenN.as<int32_t>(), g->colid.as<int32_t>(), g->sC.as<int64_t>(), g->cursor.as<uint32_t>(), shift, nbins,
+                           g->binoff.as<int64_t>(), g->bincnt.as<int32_t>() + nbins, (Triplet*)g->selfbuf.p);
+        if (n_recv > 0) {
+            hipLaunchKernelGGL(recv_bin_emit_kernel, dim3((unsigned)ceil_div64(n_recv, kRecvEmitChunk)), dim3(256),
+                               size_t(2 * nbins) * sizeof(int32_t), ctx->stream, recv, n_recv, g->r0, shift, nbins,
+                               g->binoff.as<int64_t>(), g->bincnt.as<int32_t>() + nbins, (Triplet*)g->selfbuf.p, relabel);
+        }
+        hipLaunchKernelGGL(bin_fill_kernel<256>, dim3((unsigned)nbins), dim3(256), size_t(2) * (size_t(1) << shift) * sizeof(int32_t),
+                           ctx->stream, nloc, k->MP, k->cand_d2.as<double>(), k->cand_j.as<uint32_t>(), g->rowsrc.as<int32_t>(),
+                           g->rlists.as<uint64_t>(), g->rcounts.as<uint32_t>(), g->rcap, g->rK.as<double>(),
+                           g->tablen.as<int32_t>(), g->ident.as<int32_t>(), shift, nbins, g->binoff.as<int64_t>(),
+                           (const Triplet*)g->selfbuf.p, g->lenN.as<int32_t>(), g->pos_sorted.as<int64_t>(), g->off.as<int64_t>(),
+                           (UEntry*)nullptr, g->ucol.as<uint32_t>(), g->uval.as<double>(),
+                           PairsOut{g->outlen.as<int32_t>(), g->bigrows.as<int32_t>(), g->bigcount.as<uint32_t>(), g->midrows.as<int32_t>()});
+        GT_HIP(ctx, hipGetLastError());
+    } else {
+        GT_HIP(ctx, g->cursor.reserve(size_t(std::max<int64_t>(n_recv, 1)) * sizeof(int32_t)));   // slot of every received triplet
+        GT_HIP(ctx, hipMemsetAsync(g->lenT.p, 0, size_t(nloc) * sizeof(int32_t), ctx->stream));
+        if (n_recv > 0) {
+            const int64_t blocks = std::min<int64_t>(ceil_div64(n_recv, 256), 16384);
+            hipLaunchKernelGGL(count_recv_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, recv, n_recv, g->r0,
+                               g->lenT.as<int32_t>(), g->cursor.as<int32_t>());
+        }
+        GT_HIP(ctx, hipGetLastError());
+        // union rows (own + received), scanned in row order: off
+        GT_TRY(exclusive_scan(ctx, g->lenN.as<int32_t>(), g->lenT.as<int32_t>(), nloc, g->off.as<int64_t>(), g->scan_tmp));
+        hipLaunchKernelGGL(pairs_len_kernel, dim3((unsigned)ceil_div64(nloc, 256)), dim3(256), 0, ctx->stream, nloc, g->ident.as<int32_t>(),
+                           g->off.as<int64_t>(), g->outlen.as<int32_t>(), g->bigrows.as<int32_t>(), g->bigcount.as<uint32_t>(), fflags,
+                           slots ? g->midrows.as<int32_t>() : (int32_t*)nullptr);
+        GT_HIP(ctx, hipGetLastError());
+        if (n_recv > 0) {
+            const int64_t blocks = std::min<int64_t>(ceil_div64(n_recv, 256), 16384);
+            hipLaunchKernelGGL(fill_recv_pairs_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, recv, n_recv, g->r0,
+                               g->off.as<int64_t>(), g->pos_sorted.as<int64_t>(), g->cursor.as<int32_t>(), g->ucol.as<uint32_t>(),
+                               g->uval.as<double>(), relabel);
+            GT_HIP(ctx, hipGetLastError());
+        }
+    }
     // (the rows of the CSR are the local rows in their order: its offsets are the union rows')
     GT_HIP(ctx, hipMemcpyAsync(g->indptr.p, g->off.p, size_t(nloc + 1) * sizeof(int64_t), hipMemcpyDeviceToDevice, ctx->stream));
-    if (n_recv > 0) {
-        const int64_t blocks = std::min<int64_t>(ceil_div64(n_recv, 256), 16384);
-        hipLaunchKernelGGL(fill_recv_pairs_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, recv, n_recv, g->r0,
-                           g->off.as<int64_t>(), g->pos_sorted.as<int64_t>(), g->cursor.as<int32_t>(), g->ucol.as<uint32_t>(),
-                           g->uval.as<double>(), relabel);
-        GT_HIP(ctx, hipGetLastError());
-    }
     int64_t nnz = 0, n_kept = 0;
     uint32_t bc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     {
@@ -3493,9 +3621,10 @@ static int graph_finish_pairs_shard(gt_ctx* ctx, const void* recv_buf_dev, int64
         GT_HIP(ctx, rb.add(&nnz, g->off.as<int64_t>() + nloc, sizeof(int64_t)));
         GT_HIP(ctx, rb.add(&n_kept, g->pos_sorted.as<int64_t>() + nloc, sizeof(int64_t)));
         GT_HIP(ctx, rb.add(bc, g->bigcount.p, 8 * sizeof(uint32_t)));
+        if (bins) GT_HIP(ctx, rb.add(&n_placed, g->binoff.as<int64_t>() + g->bin_count, sizeof(int64_t)));
         GT_HIP(ctx, rb.sync());
     }
-    if (nnz != n_kept + n_recv) GT_FAIL(ctx, GT_E_STATE, "gt_graph_finish: received triplets for rows this rank does not own");
+    if (nnz != n_kept + n_placed) GT_FAIL(ctx, GT_E_STATE, "gt_graph_finish: received triplets for rows this rank does not own");
     const uint32_t n_mid = bc[1], ff = bc[2], n_huge = bc[4];
     const unsigned long long huge_total = (unsigned long long)bc[6] | ((unsigned long long)bc[7] << 32);
     if ((ff & ~kFusedHugeRow) != 0 || ((ff & kFusedHugeRow) && huge_total >= (1ull << 31)))

@@ -119,7 +119,21 @@ __global__ __launch_bounds__(256) void sym_thresholds_kernel(const int64_t n, co
                                                              float* __restrict__ g, const uint32_t* __restrict__ cell_sorted,
                                                              const int32_t* __restrict__ nbr, const int M,
                                                              unsigned long long* __restrict__ far_total,
-                                                             float* __restrict__ farcnt, const int sorted, const int metric) {
+                                                             float* __restrict__ farcnt, const int sorted, const int metric,
+                                                             const int32_t* __restrict__ cstart, const int32_t* __restrict__ cend,
+                                                             const int bn, const int skip_t0, const int skip_t1, const int stride) {
+    // stride (> 0: launch A scored every stride-th tile besides the neighbourhoods): only kept rows of THOSE tiles can be far -
+    // what the count is extrapolated from.  (A query block takes the tiles around ALL its cells; with coherent cell numbers the
+    // block's other cells are cells of the same cluster, and what a row finds around them is no strided find either.)
+    // skip_t0 / skip_t1: kept rows of the tiles [skip_t0, skip_t1) are not counted far - the SAMPLE launches (the first rows of
+    // the order, asked before every row is seeded) pass their own range: with coherent cell numbers the sample is a compact region,
+    // the strided tile that happens to lie inside it is a neighbour of a sixteenth of the sample's rows rather than of a
+    // five-hundredth, and extrapolated by the stride it refuted the pass on the very data it is for
+    // cstart / cend / bn: first and one-past-last sorted position of every cell, rows per tile - a kept row counts as NEAR (not
+    // "far": found by the strided sample) when its cell is one of the M around the row's own OR its tile is one that those cells'
+    // rows reach into.  The second half matters since the cells are numbered coherently (gt_order.hip): the tiles at the ends of
+    // a neighbourhood cell's run spill into the next cell in number, which is now a cell of the same cluster - rows launch A
+    // rightly found there are neighbourhood finds, not strided ones (counted far they refuted the pass: 0.34 per row on C3).
     // metric 1 (cosine, rows normalised): D_K is the largest key 1 - x.y among the kept rows; a row within rkf x that has
     // x.y >= 1 - R2, i.e. true score x.y - |y|^2 / 2 >= 1 - R2 - ymax^2 / 2 - the rest (error bound, scale, rounding) as below.
     // sorted != 0: X / xn are the copies in cell-sorted order (gather_points_kernel): rows are addressed by position
@@ -154,12 +168,23 @@ __global__ __launch_bounds__(256) void sym_thresholds_kernel(const int64_t n, co
             for (int u = 0; u < 8; ++u) xr[u] = (sub + 16 * u < d) ? double(xq[sub + 16 * u]) : 0.0;
         }
         uint32_t nb0 = 0xFFFFFFFFu, nb1 = 0xFFFFFFFFu, ccm0 = 0xFFFFFFFEu;
+        int lo0 = 1, hi0 = 0, lo1 = 1, hi1 = 0;   // tiles the lane's neighbourhood cells reach into (empty: lo > hi)
         if (far_total) {
             // the M cells around the row's own sit in two registers per lane of the group (M <= 32); every kept row's cell is
             // passed round the group and compared by all lanes at once
             if (sub < M) nb0 = uint32_t(nbr[size_t(cme) * M + sub]);
             if (sub + 16 < M) nb1 = uint32_t(nbr[size_t(cme) * M + sub + 16]);
             if (uint32_t(sub) < kept) ccm0 = cell_sorted[cand_index(l0)];
+            if (cstart) {
+                if (nb0 != 0xFFFFFFFFu) {
+                    const int s0 = cstart[nb0], e0 = cend[nb0];
+                    if (s0 >= 0 && e0 > s0) lo0 = s0 / bn, hi0 = (e0 - 1) / bn;
+                }
+                if (nb1 != 0xFFFFFFFFu) {
+                    const int s1 = cstart[nb1], e1 = cend[nb1];
+                    if (s1 >= 0 && e1 > s1) lo1 = s1 / bn, hi1 = (e1 - 1) / bn;
+                }
+            }
         }
         // candidate ids: lane c of the group fetches entry c (need_m <= 64: four rounds at most)
         double dk = 0.0;
@@ -226,14 +251,17 @@ __global__ __launch_bounds__(256) void sym_thresholds_kernel(const int64_t n, co
             for (uint32_t c0 = 0; c0 < 64u; c0 += 16u) {   // (need_m <= 64; the trip count is the same for the whole wave)
                 if (__ballot(c0 < kept) == 0ull) break;
                 const bool have = c0 + uint32_t(sub) < kept;
-                const uint32_t ccm = c0 == 0u ? ccm0
-                                              : (have ? cell_sorted[cand_index(lists[size_t(p) * lstride + c0 + sub])] : 0xFFFFFFFEu);
+                const uint32_t pjm = have ? cand_index(c0 == 0u ? l0 : lists[size_t(p) * lstride + c0 + sub]) : 0u;
+                const uint32_t ccm = c0 == 0u ? ccm0 : (have ? cell_sorted[pjm] : 0xFFFFFFFEu);
+                const int tjm = have ? int(pjm / uint32_t(bn)) : -1;
 #pragma unroll
                 for (int c = 0; c < 16; ++c) {
                     const uint32_t cc = uint32_t(__shfl(int(ccm), c, 16));
-                    const unsigned long long hit = __ballot(nb0 == cc || nb1 == cc);
+                    const int tj = __shfl(tjm, c, 16);
+                    const unsigned long long hit = __ballot(nb0 == cc || nb1 == cc || (tj >= lo0 && tj <= hi0) || (tj >= lo1 && tj <= hi1));
                     const bool near = ((hit >> (lane64 & 48)) & 0xFFFFull) != 0ull;
-                    far += (sub == 0 && cc != 0xFFFFFFFEu && !near) ? 1u : 0u;
+                    far += (sub == 0 && cc != 0xFFFFFFFEu && !near && !(tj >= skip_t0 && tj < skip_t1) &&
+                            (stride <= 0 || tj % stride == 0)) ? 1u : 0u;
                 }
             }
             if (sub == 0 && far) atomicAdd(far_total, (unsigned long long)far);
@@ -1195,6 +1223,7 @@ __global__ __launch_bounds__(256) void bound_queue_kernel(const int nq64, const 
     // four groups of 64 queries per workgroup: their slots come from ONE returning atomic (15 600 of them, one per group, were
     // half of this kernel's time)
     __shared__ uint32_t wtot[4], wbase;
+    __shared__ uint16_t blist[4][2048];   // per wave: the undecided cells of one stretch (64 words) of a mask row
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     // own_full: the groups [own_q0, nq64) against EVERY sub-tile (no walks: a row-sharded build on renumbered points files
     // each pair under the query's side only, the launch covers the rank's own groups)
@@ -1302,9 +1331,32 @@ __global__ __launch_bounds__(256) void bound_queue_kernel(const int nq64, const 
                 zero = ~mask[size_t(a) * words + wd];
                 if (wd * 32 + 32 > L) zero &= (L - wd * 32 >= 32) ? 0xFFFFFFFFu : ((1u << (L - wd * 32)) - 1u);
             }
-            while (zero != 0u) {
-                const uint32_t b = uint32_t(wd) * 32u + uint32_t(__ffs(int(zero)) - 1);
-                zero &= zero - 1u;
+            // The undecided cells of this stretch of the mask row are dealt to the lanes ONE BY ONE (compacted through the LDS),
+            // not word by word: with coherent cell numbers (gt_order.hip) the dozen cells a cell is undecided against are
+            // neighbours in number - one or two words, i.e. one or two lanes did the whole row while 62 watched (C3: 0.68 -> 1.01
+            // ms when the numbering became coherent).  The order of the queue does not matter; both rounds deal alike.
+            uint32_t nb;
+            {
+                const uint32_t c = uint32_t(__popc(zero));
+                uint32_t inc = c;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const uint32_t up = uint32_t(__shfl_up(int(inc), o));
+                    if (lane >= o) inc += up;
+                }
+                nb = uint32_t(__shfl(int(inc), 63));
+                uint32_t at = inc - c;
+                uint32_t z = zero;
+                while (z != 0u) {
+                    blist[w][at++] = uint16_t(uint32_t(wd) * 32u + uint32_t(__ffs(int(z)) - 1));
+                    z &= z - 1u;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (uint32_t it = uint32_t(lane); it < nb; it += 64u) {
+                const uint32_t b = blist[w][it];
                 const int sb0 = start[b], sb1 = endp[b];
                 if (sb0 < 0 || sb1 <= sb0) continue;   // empty cell
                 for (uint32_t d32 = uint32_t(sb0) / 32u; d32 <= uint32_t(sb1 - 1) / 32u; ++d32) {
@@ -1335,6 +1387,8 @@ __global__ __launch_bounds__(256) void bound_queue_kernel(const int nq64, const 
                     }
                 }
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();   // (the next stretch reuses the list)
         }
     }
   }
@@ -1543,12 +1597,22 @@ int gt_sym_gather_points(gt_ctx* ctx, const int32_t* perm, bool pad4) {
 int gt_sym_thresholds(gt_ctx* ctx, const int32_t* perm, int64_t n_pad_s, const float* hs, const uint64_t* lists, int lstride,
                       const uint32_t* counts, int need_m, const ErrModel& err, double rkf, float* thr, float* g, float* gmin,
                       const DevBuf& work, int cells, unsigned long long* far_total, float* farcnt, int64_t p_first,
-                      int64_t p_last) {
+                      int64_t p_last, bool sample) {
     if (p_last < 0) p_last = n_pad_s;
     const dim3 grid((unsigned)ceil_div64(p_last - p_first, 16));
     // landmark adjacency the schedule of launch A was built from (gt_sym_schedule: nbr [L][M] at the head of `work`)
     const int M = std::min(std::min(cells, 32), ctx->order_L);
     const int32_t* nbr = work.as<int32_t>();
+    // (... and the cells' runs behind it: start [L] | end [L])
+    const int32_t* cstart = nbr + size_t(ctx->order_L) * M;
+    const int32_t* cend = cstart + ctx->order_L;
+    const int bn = gt_select_bn(ctx->DP);
+    // (the strided sample of launch A, as every caller of gt_sym_schedule derives it)
+    const int64_t n_tiles_s = n_pad_s / bn;
+    const int stride = ctx->sym_stride > 0 && n_tiles_s >= int64_t(8) * ctx->sym_stride ? ctx->sym_stride : 0;
+    // (a sample launch does not count the strided tiles inside its own range; without a strided sample there is nothing to skip)
+    const bool skip = sample && stride > 0;
+    const int skip_t0 = skip ? int(p_first / bn) : 0, skip_t1 = skip ? int((p_last + bn - 1) / bn) : 0;
     const uint32_t* cell_sorted = ctx->order_cell.as<uint32_t>() + ctx->n;
     // the points in sorted order, when the caller has made the copy (gt_sym_gather_points)
     const KnnWork* kw = ctx->knn;
@@ -1559,11 +1623,11 @@ int gt_sym_thresholds(gt_ctx* ctx, const int32_t* perm, int64_t n_pad_s, const f
     if (ctx->dtype == GT_F32)
         hipLaunchKernelGGL(sym_thresholds_kernel<float>, grid, dim3(256), 0, ctx->stream, ctx->n, p_first, p_last, perm,
                            (const float*)Xp, dx, xnp, hs, lists, lstride, counts, need_m, ctx->ymax.as<double>(), err, rkf,
-                           thr, g, cell_sorted, nbr, M, far_total, farcnt, sorted ? 1 : 0, ctx->metric);
+                           thr, g, cell_sorted, nbr, M, far_total, farcnt, sorted ? 1 : 0, ctx->metric, cstart, cend, bn, skip_t0, skip_t1, stride);
     else
         hipLaunchKernelGGL(sym_thresholds_kernel<double>, grid, dim3(256), 0, ctx->stream, ctx->n, p_first, p_last, perm,
                            (const double*)Xp, ctx->d, xnp, hs, lists, lstride, counts, need_m, ctx->ymax.as<double>(), err, rkf,
-                           thr, g, cell_sorted, nbr, M, far_total, farcnt, sorted ? 1 : 0, ctx->metric);
+                           thr, g, cell_sorted, nbr, M, far_total, farcnt, sorted ? 1 : 0, ctx->metric, cstart, cend, bn, skip_t0, skip_t1, stride);
     GT_HIP(ctx, hipGetLastError());
     if (gmin) {
         hipLaunchKernelGGL(sym_gmin_kernel, dim3((unsigned)ceil_div64(n_pad_s, 256)), dim3(256), 0, ctx->stream, n_pad_s, g, gmin);

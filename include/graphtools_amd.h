@@ -119,6 +119,8 @@ int gt_stage_launches(const gt_ctx* ctx, const char* stage);
  *   query_order_min_rows     launches with fewer query rows are not grouped (32768).
  *   query_order_cell_rows    rows per landmark cell (244).
  *   query_order_outliers     0 | 1: rows far from every landmark get a cell of their own (1).
+ *   query_order_coherent     0 | 1: the landmark cells are numbered so that neighbours in space are neighbours in number - the
+ *                            sorted rows of a cluster lie together, a rank of a row-sharded build owns whole clusters (1).
  *   select_samp_stride       classic pass: threshold-seeding phase over every n-th tile (32; <= 1: off).
  *   select_samp_keep         list budget of that phase (0: the neighbours wanted, at least 16).
  *   select_samp_end          list budget at the end of that phase (-1: same as select_samp_keep, 0: none).

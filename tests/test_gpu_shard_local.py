@@ -512,9 +512,16 @@ def test_pair_resolved_tail_on_sharded_ranks_equals_the_general_tail_and_the_sin
     K1, P1 = single_build(X, pargs)
     K, P, used, stats = sharded_local_build(X, world, pargs)
     assert sharded_local_build.pairs_used, "the ranks did not take the pair-resolved tail"
-    sent = sharded_local_build.triplets
+    sent_bins = sharded_local_build.triplets
     _same(K, K1)
     _same(P, P1)
+    # ... without destination bins of the rank's own: every one-sided entry goes through the exchange, a rank's own too
+    Kn, Pn, _, _ = sharded_local_build(X, world, pargs, opts={"symmetrize_bins": 0})
+    assert sharded_local_build.pairs_used
+    sent = sharded_local_build.triplets
+    assert sent_bins <= sent
+    _same(Kn, K1)
+    _same(Pn, P1)
     Kg, Pg, _, stats_g = sharded_local_build(X, world, pargs, pairs=False)
     assert not sharded_local_build.pairs_used
     _same(Kg, K1)
@@ -523,7 +530,7 @@ def test_pair_resolved_tail_on_sharded_ranks_equals_the_general_tail_and_the_sin
     # K's entries = mutual pairs counted once per side + one-sided entries counted on both sides
     sent_g = sharded_local_build.triplets
     assert sent < sent_g and K1.nnz == sent_g + sent, (sent, sent_g, K1.nnz)
-    print("triplets: %d one-sided of %d kept (%.0f %%)" % (sent, sent_g, 100.0 * sent / sent_g))
+    print("triplets: %d one-sided of %d kept (%.0f %%), %d of them for other ranks' rows" % (sent, sent_g, 100.0 * sent / sent_g, sent_bins))
 
 
 def test_pair_resolved_tail_is_an_option_and_only_serves_the_plus_rule():

@@ -67,17 +67,32 @@ want_pairs = os.environ.get("GT_PAIRS", "1") != "0"   # the pair-resolved tail o
 bw_all_dev = None                                      # the bandwidths of all rows: what the all-gather between the halves delivers
 
 
+# Scratch the HARNESS hands the library (the cells of a rank's share, its bandwidths, its send buffer): allocated once, outside
+# the timed sequence - dist.py takes them from torch's caching allocator, a hipMalloc / hipFree per call (50-100 us each, and a
+# device synchronisation) is not part of a rank's critical path.  (Until round 6 the probe allocated inside: ~0.25 ms per rank.)
+_scratch = {}
+
+
+def scratch(name, nbytes):
+    cur = _scratch.get(name)
+    if cur is None or cur[1] < nbytes:
+        if cur is not None:
+            ctx.dev_free(cur[0])
+        cur = (ctx.dev_alloc(int(nbytes * 1.25) + 256), int(nbytes * 1.25) + 256)
+        _scratch[name] = cur
+    return cur[0]
+
+
 def rank_until_emit(r, timed=False, only_bandwidths=False):
     """set_points .. emit for rank r; -> (send_counts, device buffer of the triplets, wall ms by phase, stage ms, used)
     only_bandwidths: stop after the first half of graph_begin -> the rank's bandwidths (host), None where the tail does not apply"""
     ctx.sync()
     t0 = time.perf_counter()
     if split_assign:
-        own = ctx.dev_alloc(int(in_splits[r + 1] - in_splits[r]) * 4)
+        own = scratch("cells", int(in_splits[r + 1] - in_splits[r]) * 4)
         applied = ctx.points_cells_begin(xb, n, d, np.float32, in_splits[r], in_splits[r + 1], own)
         st_a = {s: ctx.stage_ms(s) for s in ("prep", "query_order")}
         ctx.points_cells_finish(cells_all_dev)
-        ctx.dev_free(own)
     else:
         ctx.set_points_device(xb, n, d, np.float32)
         applied = ctx.points_cell_sort()
@@ -92,7 +107,7 @@ def rank_until_emit(r, timed=False, only_bandwidths=False):
     t2 = time.perf_counter()
     if only_bandwidths or bw_all_dev is not None:
         nloc = int(splits[r + 1] - splits[r])
-        bwb = ctx.dev_alloc(max(nloc, 1) * 8)
+        bwb = scratch("bw", max(nloc, 1) * 8)
         ok = ctx.graph_bandwidth_local(p, world, r, splits, bwb)
         if only_bandwidths:
             bw = None
@@ -100,16 +115,13 @@ def rank_until_emit(r, timed=False, only_bandwidths=False):
                 bw = np.empty(nloc, dtype=np.float64)
                 ctx.sync()
                 ctx.dev_download(bw, bwb)
-            ctx.dev_free(bwb)
             return bw
         assert ok
         ctx.graph_set_bandwidths(bw_all_dev)   # (the all-gather itself is not in the time: 8 B per row, listed below)
     sc = ctx.graph_begin(p, world, r, splits)
     ctx.sync()
     t3 = time.perf_counter()
-    if bw_all_dev is not None:
-        ctx.dev_free(bwb)
-    buf = ctx.dev_alloc(max(int(sc.sum()), 1) * 16)
+    buf = scratch("send", max(int(sc.sum()), 1) * 16)
     ctx.graph_emit(buf)
     ctx.sync()
     t4 = time.perf_counter()
@@ -138,7 +150,6 @@ for r in range(world):
     host = np.zeros(int(sc[who]), dtype=TRIP)
     if len(host):
         ctx.dev_download(host, buf + off * 16)
-    ctx.dev_free(buf)
     recv_parts.append(host)
     send_totals.append(int(sc.sum()))
     used_all.append(bool(used))
@@ -166,7 +177,6 @@ for rep in range(int(os.environ.get("GT_REPS", "4"))):
     wall["finish(merge+P)"] = (time.perf_counter() - t0) * 1e3
     for s in ("symmetrize", "symm_merge", "symm_compact", "normalize"):
         st[s] = max(ctx.stage_ms(s), 0.0)
-    ctx.dev_free(buf)
     if kind == "c5":
         # the rank's share of the landmark stage: labels of its own rows (1-NN against the L landmark rows on the MFMA path,
         # argmin's first-index rule on the device), partial L x L products of its rows (left on the device for the all-reduce),
