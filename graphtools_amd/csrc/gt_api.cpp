@@ -147,6 +147,7 @@ int gt_bind_points(gt_ctx* ctx, const void* X, int64_t n, int32_t d, int32_t dty
     GT_HIP(ctx, hipSetDevice(ctx->device));
     ctx->reset_stages();
     ctx->presorted = 0;   // (a renumbering belongs to the points it was made for)
+    ctx->order_coherent_active = 0;
     ctx->cells_pending = 0;
     const size_t esz = dtype == GT_F32 ? 4 : 8;
     if (on_device) {

@@ -249,6 +249,7 @@ struct gt_ctx {
     int32_t cells_pending = 0;  //   gt_points_cells_begin has bound the points and assigned a share of them: gt_points_cells_finish is due
     int32_t cells_L = 0;        //     landmark cells of that assignment
     int32_t order_coherent = 1;      //   the landmarks are numbered so that neighbours in space are neighbours in number (gt_order.hip coherent_landmark_order)
+    int32_t order_coherent_active = 0;   //   ... and the cell order in force was made that way
     DevBuf land_ord;                 //   its scratch
     DevBuf land_X, land_Yp, land_xn;   //   landmark rows of the sharded assignment: raw rows, their working copy, norms
     int64_t n_pad = 0;   // rows of the working copy (multiple of the db tile)

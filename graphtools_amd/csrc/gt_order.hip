@@ -160,6 +160,7 @@ __global__ __launch_bounds__(256) void compose_group_keys_kernel(const int L, co
 
 static int coherent_landmark_order(gt_ctx* ctx, const int L, const int rw, const uint32_t* Yl, const float* hl, int32_t** lidx_out) {
     *lidx_out = nullptr;
+    ctx->order_coherent_active = 0;
     if (ctx->order_coherent == 0 || L < 256) return GT_OK;
     // Only where launch A of the symmetric pass scores a strided sample of the far tiles (gt_knn.cpp stride_a: from 8 x sym_stride
     // tiles, ~8e5 rows).  Below that the one early sign of a point set whose cells say nothing (half the points in one blob: any
@@ -228,6 +229,7 @@ static int coherent_landmark_order(gt_ctx* ctx, const int L, const int rw, const
     GT_HIP(ctx, hipGetLastError());
     GT_HIP(ctx, rocprim::radix_sort_pairs(base + o_tmp, sort_bytes, k0, k1, io, ix, size_t(L), 0u, unsigned(kb), ctx->stream));
     *lidx_out = ix;
+    ctx->order_coherent_active = 1;
     return GT_OK;
 }
 
@@ -364,6 +366,7 @@ int gt_query_order(gt_ctx* ctx, const float* Qc, int64_t q0, int64_t nq, int nee
         *active = 1;
         return GT_OK;
     }
+    ctx->order_coherent_active = 0;   // (an order made here is made anew)
     const int64_t kMinRows = ctx->order_min_rows;   // below this the whole launch is a few workgroup rounds
     // Many query rows against FEW points (a random-landmark assignment: 1e6 rows, 2000 landmarks): nearly every point is a
     // landmark of the order - what the queries gain is the threshold (the need-th best of the scores seen here bounds the need-th

@@ -1609,9 +1609,11 @@ int gt_sym_thresholds(gt_ctx* ctx, const int32_t* perm, int64_t n_pad_s, const f
     const int bn = gt_select_bn(ctx->DP);
     // (the strided sample of launch A, as every caller of gt_sym_schedule derives it)
     const int64_t n_tiles_s = n_pad_s / bn;
-    const int stride = ctx->sym_stride > 0 && n_tiles_s >= int64_t(8) * ctx->sym_stride ? ctx->sym_stride : 0;
-    // (a sample launch does not count the strided tiles inside its own range; without a strided sample there is nothing to skip)
+    // (... all of which belongs to the COHERENT numbering of the cells, gt_order.hip - it is made only where there is a strided
+    //  sample.  In the landmarks' own order "far" is what it always was: a kept row outside the M cells around the row's own.)
+    const int stride = (ctx->order_coherent_active != 0 && ctx->sym_stride > 0 && n_tiles_s >= int64_t(8) * ctx->sym_stride) ? ctx->sym_stride : 0;
     const bool skip = sample && stride > 0;
+    if (stride <= 0) cstart = cend = nullptr;
     const int skip_t0 = skip ? int(p_first / bn) : 0, skip_t1 = skip ? int((p_last + bn - 1) / bn) : 0;
     const uint32_t* cell_sorted = ctx->order_cell.as<uint32_t>() + ctx->n;
     // the points in sorted order, when the caller has made the copy (gt_sym_gather_points)
