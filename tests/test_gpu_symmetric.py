@@ -409,3 +409,59 @@ def test_rows_that_belong_to_no_cluster_do_not_change_the_graph(kind):
         assert (res["default"][4] == 1) == (np.diff(res["default"][0][2]).max() > 1024)   # (kPairHugeRow, gt_sparse.hip)
     if kind == "isolated points":
         assert res["default"][4] == 1
+
+
+def _cell_order_stats(X, coherent, stride=4):
+    """-> (K csr, per cell: the largest distance IN NUMBER to one of its 8 nearest cells, rows per cell) of a build whose
+    symmetric pass ran, with the cells numbered coherently or in the landmarks' own order"""
+    import ctypes
+
+    from graphtools_amd import _hip
+
+    c = _hip.Context(0)
+    c.set_option("select_symmetric", "1")
+    c.set_option("select_sym_stride", str(stride))
+    c.set_option("query_order_coherent", str(coherent))
+    c.set_points(X)
+    p, keep = c.make_params(15, 40.0, 1e-4, None, 1.0, None, "+", None, 0)
+    c.graph_build(p)
+    assert c.knn_stats()["symmetric"]
+    Kd, Ki, Kp = c.graph_fetch_csr(_hip.CSR_K)
+    n = X.shape[0]
+    c.lib.gt_dbg_fetch_sym.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p]
+
+    def fetch(which, count, dtype):
+        out = np.empty(count, dtype=dtype)
+        assert c.lib.gt_dbg_fetch_sym(c.h, which, count, out.ctypes.data_as(ctypes.c_void_p)) == 0
+        return out
+
+    cells = fetch(5, n, np.uint32).astype(np.int64)           # cell of every sorted position
+    assert np.all(np.diff(cells) >= 0)
+    L = int(cells.max()) + 1
+    sizes = np.bincount(cells, minlength=L)
+    M = 8
+    nbr = fetch(7, L * M, np.int32).reshape(L, M).astype(np.int64)
+    gap = np.abs(nbr - np.arange(L)[:, None]).max(axis=1)[: L - 1]   # (the last cell may be the outlier cell: not a landmark's)
+    c.close()
+    return (Kd, Ki, Kp), gap, sizes
+
+
+def test_coherent_cell_order_groups_neighbouring_cells_and_changes_no_bit():
+    """gt_order.hip coherent_landmark_order: the landmark cells numbered so that neighbours in space are neighbours in number
+    (three levels of groups, one composite-key sort).  Any order is correct - the graph is the same bit for bit - and the
+    order does what it is for: the eight cells around a cell lie within a few dozen numbers of it instead of anywhere."""
+    X = make_mix(100000, 32, 17)
+    on, gap_on, sizes_on = _cell_order_stats(X, 1)
+    off, gap_off, sizes_off = _cell_order_stats(X, 0)
+    _same_csr(on, off)
+    # the same cells, renumbered
+    assert np.array_equal(np.sort(sizes_on), np.sort(sizes_off))
+    L = len(gap_off)
+    assert L >= 256, "too few cells for a coherent order: %d" % L
+    med_on, med_off = float(np.median(gap_on)), float(np.median(gap_off))
+    print("cells %d: largest distance in number to one of the 8 nearest cells, median: coherent %.0f, landmark order %.0f" % (L, med_on, med_off))
+    assert med_off > L / 4          # the landmarks' own order: anywhere
+    assert med_on < med_off / 3     # coherent: close by (416 cells here, two levels of groups: 53 against 243)
+    # below the size the strided sample of launch A exists at, the order is left alone (gt_order.hip explains)
+    _, gap_small, _ = _cell_order_stats(X, 1, stride=768)
+    assert np.array_equal(gap_small, gap_off)
