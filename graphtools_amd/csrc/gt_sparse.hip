@@ -414,7 +414,10 @@ __global__ __launch_bounds__(256) void affinity_slots_kernel(
     const int metric, const int MP, const int limit, double* __restrict__ cand_d2, uint32_t* __restrict__ cand_j,
     const double* __restrict__ cand_d2t, const double decay, const int binary, const double thresh, const double rf_guard,
     const int count_owners, int32_t* __restrict__ lenN, int32_t* __restrict__ ownercnt, int32_t* __restrict__ tablen,
-    uint32_t* __restrict__ posj, const int64_t* __restrict__ sC, int32_t* __restrict__ lenN_s) {
+    uint32_t* __restrict__ posj, const int64_t* __restrict__ sC, int32_t* __restrict__ lenN_s, const Splits sp, const int self_rank) {
+    // count_owners = 2 (a rank of a row-sharded build, GraphState::pairs_shard_bins: slots are the rank's rows, the partner records
+    // lie by the row numbers of ALL rows, a partner on another rank has no position - kNoDest): per owner the one-sided entries
+    // whose partner lives on ANOTHER rank (ownercnt owner-major [world][nslots], what emit_triplets_kernel sends)
     // posj / sC (optional, together): the destination lookup of the pair-resolved tail (bin_count_kernel) is done HERE - the
     // partner's sorted position arrives with its bandwidth, every kept entry's destination goes to posj[sC[slot] + its place in
     // the row] (sC: scan of the TABLE lengths, known before this pass; kNoDest for a settled pair and for the slots behind the
@@ -483,6 +486,7 @@ __global__ __launch_bounds__(256) void affinity_slots_kernel(
             const int64_t i = h0.r.i;
             const double bwi = h0.r.bwi;
             int kept = 0;
+            int owner_cnt = 0;   // (count_owners = 2: lane o counts what leaves for rank o)
             auto chunk = [&](const uint32_t e, const double d2, const uint32_t j, const double d2t, const double bwj,
                              const uint32_t pj) {
                 bool keep = false;
@@ -508,6 +512,17 @@ __global__ __launch_bounds__(256) void affinity_slots_kernel(
                     if (posj) posj[h0.c0 + slot] = kvv >= 0.0 ? pj : kNoDest;
                 }
                 kept += __popcll(km);
+                if (count_owners == 2) {
+                    // (the few entries whose partner lives elsewhere: most chunks hold none)
+                    const bool leaves = keep && kvv >= 0.0 && pj == kNoDest;
+                    if (__ballot(leaves) != 0ull) {
+                        const int o = leaves ? owner_of(sp, j) : -1;
+                        for (int r = 0; r < sp.world; ++r) {
+                            const int cnt_r = __popcll(__ballot(o == r && r != self_rank));
+                            if (lane == r) owner_cnt += cnt_r;
+                        }
+                    }
+                }
             };
             chunk(uint32_t(lane), x0.d2a, x0.ja, x0.ta, g0.a.bw, g0.a.pos);
             if (n > 64u) chunk(uint32_t(lane) + 64u, x0.d2b, x0.jb, x0.tb, g0.b.bw, g0.b.pos);   // (uniform)
@@ -530,8 +545,9 @@ __global__ __launch_bounds__(256) void affinity_slots_kernel(
                 tablen[i] = int32_t(kept);
                 lenN[i] = kept;
                 lenN_s[t] = kept;   // (by slot too: what the passes over the sorted rows read)
-                if (count_owners) ownercnt[i] = kept;   // (one rank: every kept entry is its own)
+                if (count_owners == 1) ownercnt[i] = kept;   // (one rank: every kept entry is its own)
             }
+            if (count_owners == 2 && lane < sp.world) ownercnt[int64_t(lane) * nslots + i] = owner_cnt;
         }
         h0 = h1;
         h1 = h2;
@@ -539,6 +555,29 @@ __global__ __launch_bounds__(256) void affinity_slots_kernel(
         x0 = x1;
         x1 = x2;
         g0 = g1;
+    }
+}
+
+// the records affinity_slots_kernel reads, for a rank of a row-sharded build (slot = local row): rec_s by local row, bwpos by
+// the row numbers of ALL rows - a partner's bandwidth from the all-gather and its local row, kNoDest where another rank owns it
+__global__ __launch_bounds__(256) void shard_slot_records_kernel(const int64_t nloc, const int64_t r0, const int64_t n_total,
+                                                                 const double* __restrict__ bw_all, const uint32_t* __restrict__ cand_n,
+                                                                 const uint8_t* __restrict__ keyt_ok, const int32_t* __restrict__ rowsrc,
+                                                                 SlotRec* __restrict__ rec_s, BwPos* __restrict__ bwpos) {
+    const int64_t j = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (j < n_total) {
+        BwPos b;
+        b.bw = bw_all[j];
+        b.pos = (j >= r0 && j < r0 + nloc) ? uint32_t(j - r0) : kNoDest;
+        b.pad = 0u;
+        bwpos[j] = b;
+    }
+    if (j < nloc) {
+        SlotRec r;
+        r.i = (rowsrc[j] < 0 && keyt_ok[j] != 0) ? int32_t(j) : -1;   // (-1: the row of another launch - radius pass, repaired table)
+        r.n = cand_n[j];
+        r.bwi = bw_all[r0 + j];
+        rec_s[j] = r;
     }
 }
 
@@ -2161,13 +2200,23 @@ void launch_affinity(gt_ctx* ctx, GraphState* g, KnnWork* k, int binary, double 
                            g->limit, k->cand_d2.as<double>(), k->cand_j.as<uint32_t>(), k->cand_d2t.as<double>(), decay, binary,
                            thresh, g->radius_factor * (1.0 + 1e-9), fz ? 0 : count_owners, g->lenN.as<int32_t>(), g->ownercnt.as<int32_t>(),
                            g->tablen.as<int32_t>(), fz ? g->cursor.as<uint32_t>() : (uint32_t*)nullptr, g->sC.as<int64_t>(),
-                           g->cnt_sorted.as<int32_t>());
+                           g->cnt_sorted.as<int32_t>(), make_splits(g), g->rank);
         if (k->nokeyt_n > 0)
             GT_AFFINITY_LAUNCH(false, 2, k->nokeyt_rows.as<int32_t>(), int64_t(k->nokeyt_n),   // (qoff = 0 here)
                                fz ? g->cursor.as<uint32_t>() : (uint32_t*)nullptr);
         if (fz)
             hipLaunchKernelGGL(posj_hist_kernel, dim3(2048), dim3(256), size_t(g->bin_count) * sizeof(int32_t), ctx->stream,
                                g->cursor.as<uint32_t>(), g->sc_total, g->bin_shift, g->bin_count, g->bincnt.as<int32_t>());
+    } else if (g->pairs_shard_bins && k->keyt_valid) {
+        // a rank of a sharded build whose tables carry the transposed keys and whose local one-sided entries go through its own
+        // bins: the slot kernel (slot = local row; the records graph_begin_b prepared: shard_slot_records_kernel)
+        const int rpw = 8;
+        hipLaunchKernelGGL(affinity_slots_kernel, dim3((unsigned)ceil_div64(g->nloc, int64_t(4) * rpw)), dim3(256), 0, ctx->stream,
+                           g->nloc, rpw, (const SlotRec*)g->rec_s.p, (const BwPos*)g->bwpos.p, gt_dist_dtype(ctx), ctx->metric, k->MP,
+                           g->limit, k->cand_d2.as<double>(), k->cand_j.as<uint32_t>(), k->cand_d2t.as<double>(), decay, binary,
+                           thresh, g->radius_factor * (1.0 + 1e-9), count_owners ? 2 : 0, g->lenN.as<int32_t>(), g->ownercnt.as<int32_t>(),
+                           g->tablen.as<int32_t>(), shard_posj, g->sC.as<int64_t>(), g->lenN.as<int32_t>(), make_splits(g), g->rank);
+        if (k->nokeyt_n > 0) GT_AFFINITY_LAUNCH(false, 2, k->nokeyt_rows.as<int32_t>(), int64_t(k->nokeyt_n), shard_posj);
     } else if (g->pairs && g->pairs_shard && !k->keyt_valid) {
         // (a rank whose rows went through the classic pass: no table carries transposed keys - every kept entry's comes from its
         //  dot product; keyt_ok is all zeros, graph_begin_b)
@@ -2662,6 +2711,14 @@ static int graph_begin_b(gt_ctx* ctx, const gt_knn_params* params, int32_t world
             GT_HIP(ctx, hipMemsetAsync(g->bincnt.p, 0, size_t(2 * g->bin_count) * sizeof(int32_t), ctx->stream));
             GT_HIP(ctx, g->cursor.reserve(size_t(sc_total) * sizeof(uint32_t)));   // posj, by sC
             g->sc_total = sc_total;
+            if (k->keyt_valid) {   // (the affinity pass will run as affinity_slots_kernel: its records)
+                GT_HIP(ctx, g->rec_s.reserve(size_t(g->nloc) * sizeof(SlotRec)));
+                GT_HIP(ctx, g->bwpos.reserve(size_t(ctx->n) * sizeof(BwPos)));
+                hipLaunchKernelGGL(shard_slot_records_kernel, dim3((unsigned)ceil_div64(ctx->n, 256)), dim3(256), 0, ctx->stream, g->nloc,
+                                   g->r0, ctx->n, g->bw_all.as<double>(), k->cand_n.as<uint32_t>(), k->keyt_ok.as<uint8_t>(),
+                                   g->rowsrc.as<int32_t>(), (SlotRec*)g->rec_s.p, (BwPos*)g->bwpos.p);
+                GT_HIP(ctx, hipGetLastError());
+            }
         }
     }
     if (g->pairs && !g->pairs_shard) {
