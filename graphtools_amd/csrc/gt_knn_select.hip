@@ -1923,7 +1923,7 @@ __device__ __forceinline__ float frag_load_local(Frag<DP, 2>& f, const float* __
 #endif
 template <int DP>
 __global__ __launch_bounds__(256, GT_SEL_COLD_LOCAL_WAVES) void sym_cold_local_kernel(const float* __restrict__ hneg, const int32_t nq,
-                                                                               const int32_t ntiles, const SymDev sy) {
+                                                                               const int32_t ntiles, const SymDev sy, const int xcd_chunk) {
     using C = SelCfg<DP, 2>;
     constexpr int QT = 2;
     // (one wave per workgroup: launch_sym_cold)
@@ -1933,7 +1933,9 @@ __global__ __launch_bounds__(256, GT_SEL_COLD_LOCAL_WAVES) void sym_cold_local_k
     float* hwl = osc + DP;      // [32]  -|w_j|^2 / 2 of the sub-tile's rows
     float* Tl = hwl + 32;       // [32]  their thresholds T_j
     float* Bl = Tl + 32;        // [32]  their filing terms
-    const int64_t en0 = int64_t(blockIdx.x) * GT_SEL_COLD_EPW;
+    // (xcd_chunk >= 0: the waves are dealt to the XCDs in runs of that many - gt_xcd_item: the queue is in the order of the query
+    //  groups, the units of a cluster's groups walk the same few hundred sub-tiles, and an L2 should fetch them once)
+    const int64_t en0 = (xcd_chunk >= 0 ? gt_xcd_item(blockIdx.x, gridDim.x, xcd_chunk) : int64_t(blockIdx.x)) * GT_SEL_COLD_EPW;
     if (en0 >= int64_t(sy.qn)) return;
     constexpr int BQ = 128 * GT_SEL_TWO_QT, TPB = BQ / C::BN;
     const int T = ntiles, NB = T / TPB, H = (NB - 1) / 2;
@@ -2137,7 +2139,8 @@ int launch_sym_cold(gt_ctx* ctx, const SelectArgs& a) {
         hipLaunchKernelGGL(sym_group_centres_kernel, dim3((unsigned)ceil_div64(g_end - g_first, 4)), dim3(256), 0, ctx->stream, a.sym.xs,
                            a.sym.xs_d, int64_t(a.sym.xs_n), g_first, g_end, DP, a.sym.sc, const_cast<float*>(a.sym.gcen));
         hipLaunchKernelGGL((sym_cold_local_kernel<DP>), dim3((unsigned)ceil_div64(a.sym.qn, wpb * GT_SEL_COLD_EPW)), dim3(64 * wpb), 0,
-                           ctx->stream, a.hneg, a.nq, int(a.n_pad / SelCfg<DP, 2>::BN), a.sym);
+                           ctx->stream, a.hneg, a.nq, int(a.n_pad / SelCfg<DP, 2>::BN), a.sym,
+                           64);   // (runs of 64 waves ~ a cluster's query groups per XCD: 1.86 -> 1.80 ms on C3, nothing on the manifold set)
         GT_HIP(ctx, hipGetLastError());
         return GT_OK;
     }

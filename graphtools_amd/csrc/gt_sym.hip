@@ -314,28 +314,39 @@ __global__ __launch_bounds__(64) void landmark_neighbours_kernel(const _Float16*
     const half8* ra = reinterpret_cast<const half8*>(Yl + size_t(a) * DP);
     const int c8 = DP / 8;
     if (DP == 64) {
-        // (the usual width: the landmark's own row is widened once, not once per other landmark - a quarter of the loop's
-        //  instructions; same operations on the same values in the same order: same distances)
-        float fa[64];
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
+        // The usual width.  EIGHT LANES PER ROW: lane (r, c) = (lane / 8, lane % 8) reads chunk c - eight features, 16 bytes - of
+        // row b0 + r, a load instruction covers eight whole 128-byte rows, and the eight partial sums meet in three exchanges.
+        // (One row per lane - 64 rows, 64 cache lines per load instruction, eight instructions per row - kept the texture
+        // addresser busy for 0.31 ms at L = 4096 with the arithmetic idle; round 6.)  Any summation order serves: the lists are
+        // approximate by design, and every rank of a sharded build runs this same kernel.
+        const int r = lane >> 3, c = lane & 7;
+        float fa[8];
+        {
             const half8 va = ra[c];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) fa[8 * c + e] = float(va[e]);
+            for (int e = 0; e < 8; ++e) fa[e] = float(va[e]);
         }
-        for (int b = lane; b < L; b += 64) {
-            const half8* rb = reinterpret_cast<const half8*>(Yl + size_t(b) * DP);
-            float acc = 0.f;
+        for (int b0 = 0; b0 < L; b0 += 64) {   // (eight loads in flight: the loop is otherwise one L2 round trip per 8 rows)
+            half8 vb[8];
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const half8 vb = rb[c];
+            for (int u = 0; u < 8; ++u) {
+                const int b = b0 + 8 * u + r;
+                vb[u] = reinterpret_cast<const half8*>(Yl + size_t(b < L ? b : 0) * DP)[c];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int b = b0 + 8 * u + r;
+                float acc = 0.f;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const float df = fa[8 * c + e] - float(vb[e]);
+                    const float df = fa[e] - float(vb[u][e]);
                     acc = fmaf(df, df, acc);
                 }
+                acc += __uint_as_float(lane_xor_b32(__float_as_uint(acc), 1));
+                acc += __uint_as_float(lane_xor_b32(__float_as_uint(acc), 2));
+                acc += __uint_as_float(lane_xor_b32(__float_as_uint(acc), 4));
+                if (c == 0 && b < L) dist[b] = acc;
             }
-            dist[b] = acc;
         }
     } else {
         for (int b = lane; b < L; b += 64) {
