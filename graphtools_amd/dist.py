@@ -344,7 +344,7 @@ class ShardedKnnGraph(object):
                 ctx.graph_set_stage_totals(tot[: int(steps[0])])
         bw_all = None
         self.pairs_used = False
-        if self.world > 1 and hasattr(ctx, "graph_bandwidth_local"):
+        if staged and hasattr(ctx, "graph_bandwidth_local"):
             # the pair-resolved tail on every rank ('+' rule): the ranks' bandwidths are gathered (collective: 8 B per row)
             # between the two halves of graph_begin - a rank then settles its mutual pairs itself, only one-sided entries
             # travel.  Whether it applies follows from the parameters alone: the same answer on every rank, no vote.

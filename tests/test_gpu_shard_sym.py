@@ -280,6 +280,7 @@ def test_host_flow_over_rccl_world_one():
             p2, keep2 = ctx.make_params(*pargs)
             nnz, _ = g.build(p2)
             assert g.symmetric_used
+            assert g.pairs_used, "the pair-resolved tail (bandwidth all-gather between the halves of graph_begin) did not run"
             d2, i2, p2_ = ctx.graph_fetch_csr(_hip.CSR_K)
             pd2, _, _ = ctx.graph_fetch_csr(_hip.CSR_P, structure=False)
             ids = g.row_ids()
