@@ -821,9 +821,13 @@ def main():
             "data": "synthetic",
             "config": {"workload": wl_name,
                        "row_sharding": ("%d rank(s) x ~%d rows" % (world, nloc)) + (
-                           "; rows renumbered by landmark cell, candidate lists collected by the owner (no candidate exchange); "
-                           "collectives per graph: points all-gather, triplet counts, triplet all-to-all"
+                           "; rows renumbered by landmark cell (coherent cell numbers: a rank owns whole clusters), candidate lists "
+                           "collected by the owner (no candidate exchange); collectives per graph: points all-gather, cell numbers "
+                           "all-gather (4 B per row)" + (", bandwidths all-gather (8 B per row: every rank settles its mutual pairs itself, "
+                           "only one-sided entries for other ranks' rows travel)" if getattr(sharded, "pairs_used", False) else "") +
+                           ", triplet counts, triplet all-to-all"
                            if (distributed and sharded.renumbered) else ""),
+                       "pair_resolved_tail_on_ranks": bool(getattr(sharded, "pairs_used", False)) if distributed else None,
                        "nnz_K": nnz_total, "nnz_K0_rank0": nnz0,
                        "radius_rows_rank0": stats["radius_rows"], "fallback_rows_rank0": stats["fallback_rows"],
                        "symmetric_candidate_pass": flags_["symmetric"], "two_stage_collect": flags_["two_stage"],
