@@ -581,3 +581,39 @@ def test_begin_after_a_bandwidth_half_must_be_the_same_build():
     assert int(cnt.sum()) > 0
     c.dev_free(buf)
     c.close()
+
+
+def _fuzz_cases(count, seed):
+    rng = np.random.default_rng(seed)
+    cases = []
+    for _ in range(count):
+        maker = [make_mix, make_mix, make_manifold, make_gauss][int(rng.integers(4))]
+        n = int(rng.integers(4200, 30000))
+        d = int(rng.choice([8, 16, 24, 33, 48, 64, 100]))
+        world = int(rng.integers(2, 7))
+        knn = int(rng.integers(3, 40))
+        decay = float(rng.choice([2, 4, 10, 20, 40, 2.5]))
+        thresh = float(rng.choice([1e-2, 1e-3, 1e-4, 1e-6]))
+        scale = float(rng.choice([0.5, 1.0, 1.0, 2.0]))
+        dtype = np.float64 if rng.random() < 0.2 else np.float32
+        cases.append((maker, n, d, world, knn, decay, thresh, scale, dtype, int(rng.integers(1 << 30))))
+    return cases
+
+
+@pytest.mark.parametrize("case", _fuzz_cases(14, 20261004), ids=lambda c: "%s-n%d-d%d-w%d-k%d-a%g-t%g-s%g-%s" % (
+    c[0].__name__[5:], c[1], c[2], c[3], c[4], c[5], c[6], c[7], np.dtype(c[8]).name))
+def test_pair_resolved_tail_on_random_sharded_configurations(case):
+    """random sizes, widths (also no multiple of 4, also beyond 64 features), rank counts, neighbour counts, decays (small ones:
+    radii that reach far past the tables - rows of the radius pass, union rows of every length class), thresholds, bandwidth
+    scales, float64 points: the ranks' pair-resolved tail gives the single-rank build's K and P bit for bit"""
+    maker, n, d, world, knn, decay, thresh, scale, dtype, seed = case
+    X = maker(n, d, seed % 1000, dtype)
+    pargs = (knn, decay, thresh, None, scale, None, "+", None, 0)
+    try:
+        K1, P1 = single_build(X, pargs)
+    except Exception as ex:     # (a kernel that reaches every point is declined with GT_E_LIMIT: not this test's subject)
+        pytest.skip("single-rank build declined: %s" % str(ex)[:80])
+    K, P, used, _ = sharded_local_build(X, world, pargs)
+    assert sharded_local_build.pairs_used
+    _same(K, K1)
+    _same(P, P1)
