@@ -750,14 +750,35 @@ int gt_knn_candidates(gt_ctx* ctx, int64_t q0, int64_t nq, bool external, int ne
         ctx->last_main_prec = main_prec;
         if (ctx->dbg_select & 4) return GT_OK;   // experiment: candidate pass only (tables are NOT valid)
         GT_HIP(ctx, hipMemsetAsync(k->unproven.p, 0, sizeof(uint32_t), ctx->stream));
+        bool wrote_t = false;
+        if ((k->want_keyt_classic || k->want_keyt_shard) && ctx->symm_pairs != 0 && MP == 256 && !external) {
+            // a '+' build that can take the pair-resolved tail (gt_sparse.hip): the keys of the transposed pairs next to the tables,
+            // as the symmetric re-rank writes them (rerank_kernel<., ., ., true>)
+            GT_HIP(ctx, k->cand_d2t.reserve(size_t(nq) * MP * sizeof(double)));
+            GT_HIP(ctx, k->keyt_ok.reserve(size_t(nq)));
+            GT_HIP(ctx, k->nokeyt_rows.reserve(size_t(nq) * sizeof(int32_t)));
+            GT_HIP(ctx, k->nokeyt_count.reserve(sizeof(uint32_t)));
+            GT_HIP(ctx, hipMemsetAsync(k->nokeyt_count.p, 0, sizeof(uint32_t), ctx->stream));
+            ra.cand_d2t = k->cand_d2t.as<double>();
+            ra.keyt_ok = k->keyt_ok.as<uint8_t>();
+            ra.nokeyt_rows = k->nokeyt_rows.as<int32_t>();
+            ra.nokeyt_count = k->nokeyt_count.as<uint32_t>();
+            ra.wrote_t = &wrote_t;
+        }
         {
             StageSpan span(ctx, "rerank");
             GT_TRY(gt_launch_rerank(ctx, ra));
         }
+        k->keyt_valid = wrote_t;
+        k->nokeyt_n = 0;
         uint32_t n_unproven = 0;
-        GT_HIP(ctx, hipMemcpyAsync(&n_fb, k->fb_count.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-        GT_HIP(ctx, hipMemcpyAsync(&n_unproven, k->unproven.p, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-        GT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        {
+            ReadBack rb(ctx);
+            if (wrote_t) GT_HIP(ctx, rb.add(&k->nokeyt_n, k->nokeyt_count.p, sizeof(uint32_t)));
+            GT_HIP(ctx, rb.add(&n_fb, k->fb_count.p, sizeof(uint32_t)));
+            GT_HIP(ctx, rb.add(&n_unproven, k->unproven.p, sizeof(uint32_t)));
+            GT_HIP(ctx, rb.sync());
+        }
         if (main_prec == 2 && fast_auto) {
             // verdict for this point set: the wide error bound of the single chain must leave (almost) every row
             // provably complete, otherwise the repairs would cost more than the split chains

@@ -54,6 +54,7 @@ struct KnnWork {
     // comes by row where it is.  The affinity pass, the destination bins and the final merge walk the rows in sorted order anyway:
     // their table reads become streams, and the partners' bandwidths they gather are a shared, cache-resident set.
     bool want_tab_sorted = false, tab_sorted = false;
+    bool want_keyt_classic = false; // the re-rank of the classic pass writes the transposed keys too (a '+' build that can take the pair-resolved tail)
     bool want_keyt_shard = false;   // the re-rank of a sharded rank's lists (sh_stage 5 / 6) writes the transposed keys too (gt_graph_bandwidth_local)
     DevBuf sym_rloc, sym_gcen;                    //   local-frame cold launch: the radius every row needs listed (scaled), the centres of
                                                   //   the 64-row query groups
@@ -186,6 +187,12 @@ struct RerankArgs {
     uint32_t* unproven = nullptr;     // optional counter: rows with key(need_m-th) * radius_key_factor >= bound
     const int32_t* qrows = nullptr;   // list i of the candidate pass belongs to row qrows[i] (else q0 + i)
     const int32_t* trow = nullptr;    // row -> slot of its table (KnnWork::tab_sorted: the repairs write where the re-rank did), else the row
+    // optional, together (tables of 256 slots): the transposed keys next to the tables, as the symmetric re-rank writes them
+    double* cand_d2t = nullptr;
+    uint8_t* keyt_ok = nullptr;
+    int32_t* nokeyt_rows = nullptr;
+    uint32_t* nokeyt_count = nullptr;
+    bool* wrote_t = nullptr;          // (out) the launch wrote them
 };
 int gt_launch_rerank(gt_ctx* ctx, const RerankArgs& a);
 // symmetric candidate pass (gt_sym.hip): segments of list ql = cell-sorted position ql, row perm[ql]

@@ -40,7 +40,11 @@ __device__ __forceinline__ double dot_row_sel(const double* __restrict__ xs, con
     else return gt_dot16(xs, y, d);
 }
 
-template <typename T, int NT2, bool F4>
+// WT (tables of 256 slots): next to every key the key the OTHER row holds for the same pair (cand_d2t: the same dot product with
+// the roles swapped, as in rerank_sym4_kernel), keyt_ok / nokeyt_rows: which rows' tables carry them - so that builds whose
+// candidates came from the classic pass (isotropic data) take the pair-resolved tail too (round 6; the verdicts' "transposed keys
+// through the classic re-rank").  The keys travel through the sorts as a payload parked in the LDS (wave_sort_asc_pair_fast).
+template <typename T, int NT2, bool F4, bool WT = false>
 __global__ __launch_bounds__(256) void rerank_kernel(const T* __restrict__ X, const int d, const double* __restrict__ xn,
                                                      const T* __restrict__ Q, const double* __restrict__ qn,
                                                      const double* __restrict__ qn_sel, const int64_t q0, const int64_t nq,
@@ -53,12 +57,29 @@ __global__ __launch_bounds__(256) void rerank_kernel(const T* __restrict__ X, co
                                                      double* __restrict__ d2_lb, uint32_t* __restrict__ fb_count,
                                                      int32_t* __restrict__ fb_rows, uint32_t* __restrict__ gflags,
                                                      const double radius_key_factor, uint32_t* __restrict__ unproven,
-                                                     const int32_t* __restrict__ qrows) {
+                                                     const int32_t* __restrict__ qrows, double* __restrict__ cand_d2t = nullptr,
+                                                     uint8_t* __restrict__ keyt_ok = nullptr, int32_t* __restrict__ nokeyt_rows = nullptr,
+                                                     uint32_t* __restrict__ nokeyt_count = nullptr) {
     constexpr int MP = NT2 * 64;
+    static_assert(!WT || NT2 <= 8, "the payload rides through wave_sort_asc_pair_fast");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int lane = threadIdx.x & 63;
     const int w = threadIdx.x >> 6;
     double* xs = reinterpret_cast<double*>(smem_raw) + size_t(w) * d;
+    // (WT: behind the waves' query rows, per wave MP parked keys | MP transposed keys | MP row numbers)
+    uint64_t* park_hi = nullptr;
+    uint64_t* park_x = nullptr;
+    uint32_t* park_lo = nullptr;
+    if constexpr (WT) {
+        const int nw = int(blockDim.x >> 6);
+        uint64_t* pb = reinterpret_cast<uint64_t*>(smem_raw) + size_t(nw) * d;
+        park_hi = pb + size_t(w) * MP;
+        park_x = pb + size_t(nw) * MP + size_t(w) * MP;
+        park_lo = reinterpret_cast<uint32_t*>(pb + size_t(2) * nw * MP) + size_t(w) * MP;
+    }
+    uint64_t hx[NT2];
+#pragma unroll
+    for (int u = 0; u < NT2; ++u) hx[u] = 0ull;
     // Workgroups are dealt to the 8 XCDs round robin; consecutive lists belong to neighbouring queries (same landmark
     // cell) and re-rank largely the same database rows, so each XCD takes one contiguous eighth of the lists and finds
     // those rows in its own L2.
@@ -123,20 +144,24 @@ __global__ __launch_bounds__(256) void rerank_kernel(const T* __restrict__ X, co
             if (ks[u] != 0ull) {
                 const uint32_t j = cand_index(ks[u]);
                 const double dot = dot_row_sel<T, F4>(xs, X + int64_t(j) * d, d);
-                hi[u] = (uint64_t)__double_as_longlong(gt_pair_key(qnq, dot, xn[j], metric));
+                const double xnj = xn[j];
+                hi[u] = (uint64_t)__double_as_longlong(gt_pair_key(qnq, dot, xnj, metric));
                 lo[u] = j;
+                if constexpr (WT) hx[u] = (uint64_t)__double_as_longlong(gt_pair_key(xnj, dot, qnq, metric));
             }
         }
         const uint64_t k129 = __shfl((unsigned long long)ks[2], 0);
         const double lb_rest = (k129 != 0ull) ? bound_of_score(cand_score(k129)) : INFINITY;
         uint64_t h2[2] = {hi[0], hi[1]}, l2[2] = {lo[0], lo[1]};
-        wave_sort_asc_pair_fast<2>(h2, l2, lane);
+        uint64_t x2[2] = {hx[0], hx[1]};
+        wave_sort_asc_pair_fast<2>(h2, l2, lane, park_hi, park_lo, WT ? x2 : nullptr, park_x);
         const uint64_t sel2 = (pos >> 6) == 0 ? h2[0] : h2[1];
         const double need2 = __longlong_as_double((long long)__shfl((unsigned long long)sel2, pos & 63));
         const double lbm = fmin(lb, lb_rest);
         if (may_stop && pos < 128 && need2 * rkf < lbm) {   // wave-uniform
             hi[0] = h2[0]; hi[1] = h2[1];
             lo[0] = l2[0]; lo[1] = l2[1];
+            hx[0] = x2[0]; hx[1] = x2[1];
             lb = lbm;
             n_tab = n < 128u ? n : 128u;
             settled = true;
@@ -146,8 +171,10 @@ __global__ __launch_bounds__(256) void rerank_kernel(const T* __restrict__ X, co
                 if (ks[u] != 0ull) {
                     const uint32_t j = cand_index(ks[u]);
                     const double dot = dot_row_sel<T, F4>(xs, X + int64_t(j) * d, d);
-                    hi[u] = (uint64_t)__double_as_longlong(gt_pair_key(qnq, dot, xn[j], metric));
+                    const double xnj = xn[j];
+                    hi[u] = (uint64_t)__double_as_longlong(gt_pair_key(qnq, dot, xnj, metric));
                     lo[u] = j;
+                    if constexpr (WT) hx[u] = (uint64_t)__double_as_longlong(gt_pair_key(xnj, dot, qnq, metric));
                 }
             }
         }
@@ -160,13 +187,15 @@ __global__ __launch_bounds__(256) void rerank_kernel(const T* __restrict__ X, co
             if (c < n) {
                 const uint32_t j = cand_index(lp[c]);
                 const double dot = dot_row_sel<T, F4>(xs, X + int64_t(j) * d, d);
-                hi[u] = (uint64_t)__double_as_longlong(gt_pair_key(qnq, dot, xn[j], metric));
+                const double xnj = xn[j];
+                hi[u] = (uint64_t)__double_as_longlong(gt_pair_key(qnq, dot, xnj, metric));
                 lo[u] = j;
+                if constexpr (WT) hx[u] = (uint64_t)__double_as_longlong(gt_pair_key(xnj, dot, qnq, metric));
             }
         }
     }
     if (!settled) {
-        if constexpr (NT2 <= 8) wave_sort_asc_pair_fast<NT2>(hi, lo, lane);
+        if constexpr (NT2 <= 8) wave_sort_asc_pair_fast<NT2>(hi, lo, lane, park_hi, park_lo, WT ? hx : nullptr, park_x);
         else wave_bitonic_asc_pair<NT2>(hi, lo, lane);
     }
     // slots [0, max(n_tab, need_m)) are defined (+inf keys past the last candidate); nobody reads further
@@ -176,6 +205,7 @@ __global__ __launch_bounds__(256) void rerank_kernel(const T* __restrict__ X, co
         if (uint32_t(u * 64) < n_def) {   // wave-uniform
             cand_d2[size_t(q) * MP + u * 64 + lane] = __longlong_as_double((long long)hi[u]);
             cand_j[size_t(q) * MP + u * 64 + lane] = uint32_t(lo[u]);
+            if constexpr (WT) cand_d2t[size_t(q) * MP + u * 64 + lane] = __longlong_as_double((long long)hx[u]);
         }
     }
     // d2 of the need_m-th neighbour (position need_m - 1)
@@ -191,6 +221,10 @@ __global__ __launch_bounds__(256) void rerank_kernel(const T* __restrict__ X, co
         if (!(d2_need < lb)) {
             const uint32_t slot = atomicAdd(fb_count, 1u);
             fb_rows[slot] = int32_t(q);
+        }
+        if constexpr (WT) {   // (a row handed to the repair pass gets a new table, without the transposed keys: it is listed)
+            keyt_ok[q] = (d2_need < lb) ? 1 : 0;
+            if (!(d2_need < lb)) nokeyt_rows[atomicAdd(nokeyt_count, 1u)] = int32_t(q0 + q);
         }
         if (unproven && !(d2_need * rkf < lb)) atomicAdd(unproven, 1u);
         if (n > 1 && second == 0ull) atomicOr(gflags, GT_FLAG_DUPLICATES);
@@ -986,6 +1020,7 @@ __global__ __launch_bounds__(256) void emit_knn_kernel(const double* __restrict_
 
 template <typename T>
 int rerank_t(gt_ctx* ctx, const RerankArgs& a) {
+    if (a.wrote_t) *a.wrote_t = false;
     const int wpb = 1;   // rows (waves) per workgroup: see gt_launch_rerank_sym
     const int64_t blocks = ceil_div64(a.nq, wpb);
     const size_t lds = size_t(wpb) * a.d * sizeof(double);
@@ -998,6 +1033,17 @@ int rerank_t(gt_ctx* ctx, const RerankArgs& a) {
                            a.d, a.xn, (const T*)a.Q, a.qn, a.qn_sel, a.q0, a.nq, a.lists, a.lstride, a.counts, a.thr_final, a.ymax2,
                            a.err, a.metric, a.need_m, a.cand_d2, a.cand_j, a.cand_n, a.d2_lb, a.fb_count, a.fb_rows,
                            a.gflags, a.radius_key_factor, a.unproven, a.qrows); }
+    } else if (a.MP == 256 && a.cand_d2t && a.keyt_ok && a.nokeyt_rows && a.nokeyt_count) {
+        // (with the transposed keys: + MP x 20 bytes of LDS per wave for the sorts' parked payload)
+        const size_t lds_t = lds + size_t(wpb) * 256 * 20;
+        if (f4) { hipLaunchKernelGGL((rerank_kernel<T, 4, true, true>), dim3((unsigned)blocks), dim3(64 * wpb), lds_t, ctx->stream, (const T*)a.X,
+                           a.d, a.xn, (const T*)a.Q, a.qn, a.qn_sel, a.q0, a.nq, a.lists, a.lstride, a.counts, a.thr_final, a.ymax2,
+                           a.err, a.metric, a.need_m, a.cand_d2, a.cand_j, a.cand_n, a.d2_lb, a.fb_count, a.fb_rows,
+                           a.gflags, a.radius_key_factor, a.unproven, a.qrows, a.cand_d2t, a.keyt_ok, a.nokeyt_rows, a.nokeyt_count); } else { hipLaunchKernelGGL((rerank_kernel<T, 4, false, true>), dim3((unsigned)blocks), dim3(64 * wpb), lds_t, ctx->stream, (const T*)a.X,
+                           a.d, a.xn, (const T*)a.Q, a.qn, a.qn_sel, a.q0, a.nq, a.lists, a.lstride, a.counts, a.thr_final, a.ymax2,
+                           a.err, a.metric, a.need_m, a.cand_d2, a.cand_j, a.cand_n, a.d2_lb, a.fb_count, a.fb_rows,
+                           a.gflags, a.radius_key_factor, a.unproven, a.qrows, a.cand_d2t, a.keyt_ok, a.nokeyt_rows, a.nokeyt_count); }
+        if (a.wrote_t) *a.wrote_t = true;
     } else if (a.MP == 256) {
         if (f4) { hipLaunchKernelGGL((rerank_kernel<T, 4, true>), dim3((unsigned)blocks), dim3(64 * wpb), lds, ctx->stream, (const T*)a.X,
                            a.d, a.xn, (const T*)a.Q, a.qn, a.qn_sel, a.q0, a.nq, a.lists, a.lstride, a.counts, a.thr_final, a.ymax2,

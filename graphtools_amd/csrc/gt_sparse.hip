@@ -2456,9 +2456,17 @@ static int graph_begin_a(gt_ctx* ctx, const gt_knn_params* params, int32_t world
                                     (ctx->symm_bins > 0 || g->nloc >= 65536);
         // (a rank of a row-sharded build that will take the pair-resolved tail: its re-rank writes the transposed keys too)
         ctx->knn->want_keyt_shard = want_keyt;
+        // (... and so does the re-rank of the classic pass in a single-rank build whose parameters are the tail's - isotropic data
+        //  never reach the symmetric pass, their tail was the general one until round 6)
+        ctx->knn->want_keyt_classic = ctx->in_graph_build && ctx->symm_pairs != 0 && ctx->symm_pair_ok != 0 && ctx->symm_bins != 0 &&
+                                      world == 1 && !external && !binary && params->knn_max <= 0 &&
+                                      params->kernel_symm == GT_SYMM_ADD && params->anisotropy == 0.0 && g->r0 == 0 &&
+                                      g->nloc == ctx->n && !ctx->presorted && g->nloc < (int64_t(1) << 31) &&
+                                      (ctx->symm_bins > 0 || g->nloc >= 65536);
         const int rc_knn = gt_knn_candidates(ctx, g->r0, g->nloc, external, need, hint);
         ctx->knn->want_tab_sorted = false;
         ctx->knn->want_keyt_shard = false;
+        ctx->knn->want_keyt_classic = false;
         if (rc_knn != GT_OK) return rc_knn;
     }
     KnnWork* k = ctx->knn;
