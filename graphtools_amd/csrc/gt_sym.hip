@@ -300,12 +300,14 @@ __global__ __launch_bounds__(256) void sym_gmin_kernel(const int64_t n_pad, cons
 // ---- neighbourhood schedule of launch A -------------------------------------------------------------------------
 // M nearest landmarks of every landmark (itself first): one wave per landmark, float32 squared differences of the
 // float16 landmark rows (approximate by design: any tile list is correct)
-__global__ __launch_bounds__(64) void landmark_neighbours_kernel(const _Float16* __restrict__ Yl, const int L, const int DP,
-                                                                 const int M, int32_t* __restrict__ nbr,
-                                                                 const uint32_t* __restrict__ cell_lo,
-                                                                 const uint32_t* __restrict__ cell_hi) {
+__global__ __launch_bounds__(256) void landmark_neighbours_kernel(const _Float16* __restrict__ Yl, const int L, const int DP,
+                                                                  const int M, int32_t* __restrict__ nbr,
+                                                                  const uint32_t* __restrict__ cell_lo,
+                                                                  const uint32_t* __restrict__ cell_hi) {
+    // FOUR waves per landmark for the distances (each a quarter of the rows: the loop is a chain of L2 round trips, a quarter as
+    // long this way - round 6: 0.25 -> ... ms at L = 4096), wave 0 alone for the selection
     extern __shared__ float dist[];   // [L]
-    const int a = blockIdx.x, lane = threadIdx.x;
+    const int a = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = int(blockDim.x >> 6);
     // (cell_lo / cell_hi, optional: addresses of the first and last cell whose neighbours anybody will ask for - the cells
     //  of a rank's own rows in a row-sharded build)
     if (cell_lo && (uint32_t(a) < *cell_lo || uint32_t(a) > *cell_hi)) return;
@@ -326,7 +328,7 @@ __global__ __launch_bounds__(64) void landmark_neighbours_kernel(const _Float16*
 #pragma unroll
             for (int e = 0; e < 8; ++e) fa[e] = float(va[e]);
         }
-        for (int b0 = 0; b0 < L; b0 += 64) {   // (eight loads in flight: the loop is otherwise one L2 round trip per 8 rows)
+        for (int b0 = wv * 64; b0 < L; b0 += 64 * nwv) {   // (eight loads in flight: the loop is otherwise one L2 round trip per 8 rows)
             half8 vb[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -349,7 +351,7 @@ __global__ __launch_bounds__(64) void landmark_neighbours_kernel(const _Float16*
             }
         }
     } else {
-        for (int b = lane; b < L; b += 64) {
+        for (int b = wv * 64 + lane; b < L; b += 64 * nwv) {
             const half8* rb = reinterpret_cast<const half8*>(Yl + size_t(b) * DP);
             float acc = 0.f;
             for (int c = 0; c < c8; ++c) {
@@ -364,6 +366,7 @@ __global__ __launch_bounds__(64) void landmark_neighbours_kernel(const _Float16*
         }
     }
     __syncthreads();
+    if (wv != 0) return;   // (no workgroup barrier below: the selection is wave 0's)
     // The M nearest, in turn (distance, then index).  Every lane keeps the four best of ITS landmarks (b = lane, lane + 64, ...)
     // in order; a round is the wave's arg-min over the lanes' heads, and the lane that won moves its queue up.  A lane whose
     // queue runs dry while it may still hold candidates - more than four of the M nearest in one residue class: rare - scans its
@@ -398,7 +401,9 @@ __global__ __launch_bounds__(64) void landmark_neighbours_kernel(const _Float16*
     bool dry = false;   // the queue has been emptied by wins: the lane may hold more (a fifth candidate was never recorded)
     for (int m = 0; m < M; ++m) {
         if (__ballot(dry && cv[0] == INFINITY) != 0ull) {   // (wave-uniform; all lanes rebuild - their queues come out the same)
-            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             refill();
             dry = false;
         }
@@ -1993,7 +1998,7 @@ int gt_sym_schedule(gt_ctx* ctx, int64_t n_pad_s, int bq, int bn, int cells, int
     // only - a rank's own rows; the cells of those rows are a run of cell numbers (the order is sorted by cell)
     const bool part = p_last > p_first;
     const int64_t pl = part ? std::min<int64_t>(p_last, ctx->n) : 0;
-    hipLaunchKernelGGL(landmark_neighbours_kernel, dim3((unsigned)L), dim3(64), size_t(L) * sizeof(float), ctx->stream,
+    hipLaunchKernelGGL(landmark_neighbours_kernel, dim3((unsigned)L), dim3(256), size_t(L) * sizeof(float), ctx->stream,
                        ctx->land_Y.as<_Float16>(), L, ctx->DP, M, nbr, part ? cell_sorted + p_first : nullptr,
                        part ? cell_sorted + (pl - 1) : nullptr);
     GT_HIP(ctx, hipGetLastError());
