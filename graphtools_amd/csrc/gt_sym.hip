@@ -195,9 +195,14 @@ __global__ __launch_bounds__(256) void sym_thresholds_kernel(const int64_t n, co
                 jmine = sorted ? int64_t(pj) : int64_t(perm[pj]);
             }
             const uint32_t lim = kept - c0 < 16u ? kept - c0 : 16u;
-            // four candidate rows at a time: their loads are in flight together (one after the other the loop is a chain
-            // of shuffle -> address -> load -> reduce latencies; eight at a time, tried in round 5, cost occupancy: +0.22 ms)
-            constexpr int CB = 4;
+            // TWO candidate rows at a time: their loads are in flight together (one after the other the loop is a chain of
+            // shuffle -> address -> load -> reduce latencies: 1.26 ms of sym_prepare on C3; two: 1.18; four - the choice of rounds 4-5,
+            // in the landmarks' own order - 1.40; eight 1.58: the registers of the rows in flight cost occupancy, and with the
+            // cells numbered coherently the rows come out of the L2, not from further away; round 6)
+#ifndef GT_THR_CB
+#define GT_THR_CB 2
+#endif
+            constexpr int CB = GT_THR_CB;
             for (uint32_t c = 0; c < lim; c += uint32_t(CB)) {
                 int64_t j4[CB];
                 double acc4[CB];
