@@ -310,7 +310,7 @@ __global__ __launch_bounds__(256) void landmark_neighbours_kernel(const _Float16
                                                                   const uint32_t* __restrict__ cell_lo,
                                                                   const uint32_t* __restrict__ cell_hi) {
     // FOUR waves per landmark for the distances (each a quarter of the rows: the loop is a chain of L2 round trips, a quarter as
-    // long this way - round 6: 0.25 -> ... ms at L = 4096), wave 0 alone for the selection
+    // long this way - round 6: 0.25 -> 0.155 ms at L = 4096), wave 0 alone for the selection
     extern __shared__ float dist[];   // [L]
     const int a = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = int(blockDim.x >> 6);
     // (cell_lo / cell_hi, optional: addresses of the first and last cell whose neighbours anybody will ask for - the cells
