@@ -455,7 +455,12 @@ __global__ __launch_bounds__(64) void sym_schedule_kernel(const uint32_t* __rest
                                                           const int BQ, const int BN, const int T, const int stride,
                                                           const int max_nb, const int tile_stride,
                                                           int32_t* __restrict__ tile_list, int32_t* __restrict__ tile_cnt,
-                                                          const int block0) {
+                                                          const int block0, const int outlier_cell) {
+    // outlier_cell (-1: none): a block that holds rows of the outlier cell (gt_order.hip: rows that belong to no cluster) takes
+    // EIGHT times the strided sample.  Such rows have no neighbourhood; what launch A finds for them decides how far their repair
+    // has to look.  In the landmarks' own order the block's other cells were strangers from all over the point set and their
+    // neighbourhoods a sample of it; numbered coherently they are one region, the isolated rows' sixteenth-best seed lay four
+    // times as far and their repair collected 114 000 rows each instead of 25 000 (15 isolated points in 10^6: 26 ms against 20).
     extern __shared__ uint32_t bm[];   // [ceil(T / 32)]
     const int I = block0 + blockIdx.x, lane = threadIdx.x;
     const int nw = (T + 31) / 32;
@@ -548,8 +553,11 @@ __global__ __launch_bounds__(64) void sym_schedule_kernel(const uint32_t* __rest
         cnt += __shfl(incl, 63);
     }
     if (stride > 0) {
-        for (int k0 = 0; k0 * stride < T; k0 += 64) {
-            const int t = (k0 + lane) * stride;
+        bool has_outlier = false;
+        for (int k = 0; k < nu; ++k) has_outlier |= outlier_cell >= 0 && int(blk_cells[k]) == outlier_cell;
+        const int stride_b = has_outlier ? (stride >= 8 ? stride / 8 : 1) : stride;
+        for (int k0 = 0; k0 * stride_b < T; k0 += 64) {
+            const int t = (k0 + lane) * stride_b;
             const bool want = t < T && !((bm[t >> 5] >> (t & 31)) & 1u) && (t < own_a || t > own_b);
             const unsigned long long wm = __ballot(want);
             const int pos = cnt + __popcll(wm & ((1ull << lane) - 1ull));
@@ -2013,7 +2021,8 @@ int gt_sym_schedule(gt_ctx* ctx, int64_t n_pad_s, int bq, int bn, int cells, int
     const int NB = int(n_pad_s / bq), T = int(n_pad_s / bn);
     const int b0 = part ? int(p_first / bq) : 0, nblk = part ? int(ceil_div64(p_last, bq)) - b0 : NB;
     hipLaunchKernelGGL(sym_schedule_kernel, dim3((unsigned)nblk), dim3(64), size_t((T + 31) / 32) * sizeof(uint32_t), ctx->stream,
-                       cell_sorted, ctx->n, start, endp, nbr, M, NB, bq, bn, T, stride, max_nb, tile_stride, tile_list, tile_cnt, b0);
+                       cell_sorted, ctx->n, start, endp, nbr, M, NB, bq, bn, T, stride, max_nb, tile_stride, tile_list, tile_cnt, b0,
+                       ctx->order_coherent_active != 0 ? ctx->order_outlier_cell : -1);
     GT_HIP(ctx, hipGetLastError());
     if (tiles_total && !part) {   // statistics: tiles launch A visits in all (device counter, pre-zeroed by the caller)
         hipLaunchKernelGGL(sum_i32_kernel, dim3(16), dim3(256), 0, ctx->stream, tile_cnt, int64_t(NB), tiles_total);
